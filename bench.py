@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""bench.py — TPC-H SF10 Q6 stage 1 (scan→filter→project→partial sum) on HBM-resident Arrow columns.
+
+One "step" = one execution of the plan over the rank's lineitem shard through the C ABI
+(createPlan → executePlan → releasePlan, exactly what one Spark task does).  Q6 shards by contiguous row
+ranges with no data-path collective: each rank owns SF10 rows (weak scaling), rank 0
+prints one JSON line.  roofline.achieved uses SURVEY §8(d)'s algorithmic bytes (52 B/row) over the
+kernel time measured with HIP events on the plan's stream; cpu_baseline times the oracle's
+operator-at-a-time restatement of the reference pipeline on one host core over a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SF10_ROWS = 59_986_052
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=SF10_ROWS, help="lineitem rows per GPU (default: SF10)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=20_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    from datafusion_comet_amd import native, serde as S, tpch
+
+    plan = tpch.q6_plan()
+    plan_bytes = plan.encode()
+    table = tpch.lineitem_q6(args.rows, seed=6 + rank)
+    dtab = native.DeviceTable.from_arrow(table, dev)
+    n = args.rows
+
+    def step():
+        it = native.CometExecIterator([native.DeviceInput(dtab, device_id=local_rank)], tpch.Q6_NUM_OUTPUT_COLS, plan_bytes,
+                                      device_id=local_rank)
+        out = list(it_batches(it))
+        stats = it.kernel_stats()
+        it.close()
+        return out, stats
+
+    def it_batches(it):
+        while True:
+            b = native.Native.executePlan(it.handle, it.num_output_cols)
+            if b is None:
+                return
+            yield b
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    result = None
+    for _ in range(args.warmup):
+        result, _ = step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, launches = 0.0, 0
+    for _ in range(args.steps):
+        result, st = step()
+        kernel_ms += st[0]
+        launches += st[1]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        rows_per_s = n * world * args.steps / elapsed
+        avg_kernel_ms = kernel_ms / max(launches, 1)
+        algo_bytes = n * tpch.Q6_BYTES_PER_ROW            # per launch: one launch processes the rank's n rows
+        achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "rows/sec, TPC-H Q6 scan->filter->agg (HBM-resident Arrow columns)",
+            "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i128 (Decimal128) / i32 (Date32)", "data": "synthetic",
+            "config": {"workload": "TPC-H SF10 Q6 stage 1 (Filter 5 conjuncts -> Project -> partial SumDecimal) per GPU",
+                       "rows_per_gpu": n, "bytes_per_row_algorithmic": tpch.Q6_BYTES_PER_ROW, "parallelism": f"row-range shards x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_agg",
+                         "kernel_ms": avg_kernel_ms, "algorithmic_bytes": algo_bytes},
+            "result_check": str(result[0].column(0)[0]) if result else None,
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            m = min(args.cpu_sample_rows, n)
+            sample = table.slice(0, m)
+            O.q6_reference_pipeline(sample.slice(0, 100_000), tpch.days(1994, 1, 1), tpch.days(1995, 1, 1), 5, 7, 2400)
+            c0 = time.perf_counter()
+            O.q6_reference_pipeline(sample, tpch.days(1994, 1, 1), tpch.days(1995, 1, 1), 5, 7, 2400)
+            cdt = time.perf_counter() - c0
+            line["cpu_baseline"] = {"value": m / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
+                                    "sample": f"first {m} rows of the same lineitem shard, operator-at-a-time C restatement "
+                                              f"(oracle/comet_oracle.c o_q6_reference_pipeline, 8192-row batches), {cdt:.2f} s"}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+// extern "C" boundary (include/comet_amd.h).  Every entry catches all C++ exceptions: the reference
+// wraps each JNI entry in try_unwrap_or_throw (native/jni-bridge/src/errors.rs:832-850).
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "../../include/comet_amd.h"
+#include "exec.hpp"
+
+using namespace comet;
+
+// kernels_static.hip
+extern "C" int comet_launch_murmur3(int type_id, int precision, const void* values, const uint8_t* validity,
+                                    const void* aux, int64_t n, uint32_t* hashes, void* stream);
+extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out, void* stream);
+
+namespace {
+
+std::mutex g_mu;
+std::map<int64_t, std::shared_ptr<ExecutionContext>> g_ctx;
+int64_t g_next = 1;
+thread_local std::string t_last_error;
+thread_local int t_last_kind = 0;
+
+std::shared_ptr<ExecutionContext> lookup(int64_t h) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_ctx.find(h);
+  return it == g_ctx.end() ? nullptr : it->second;
+}
+
+template <class F>
+auto guarded(ExecutionContext* ctx, decltype(std::declval<F>()()) err_value, F f) -> decltype(f()) {
+  try {
+    return f();
+  } catch (const CometError& e) {
+    if (ctx) { ctx->last_error = e.what(); ctx->last_error_kind = e.kind; }
+    t_last_error = e.what();
+    t_last_kind = e.kind;
+  } catch (const std::exception& e) {
+    if (ctx) { ctx->last_error = e.what(); ctx->last_error_kind = 0; }
+    t_last_error = e.what();
+    t_last_kind = 0;
+  } catch (...) {
+    if (ctx) { ctx->last_error = "unknown native error"; ctx->last_error_kind = 0; }
+    t_last_error = "unknown native error";
+    t_last_kind = 0;
+  }
+  return err_value;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* config, size_t config_len, void** inputs,
+                          const int32_t* input_kinds, int32_t n_inputs, int32_t partition_count, int32_t batch_size,
+                          int32_t device_id) {
+  (void)partition_count;
+  return guarded(nullptr, (int64_t)0, [&]() -> int64_t {
+    if (!plan || plan_len == 0) throw CometError("empty plan");
+    OperatorP op = decode_operator(plan, plan_len);
+    auto cfg = (config && config_len) ? decode_config_map(config, config_len) : std::vector<std::pair<std::string, std::string>>();
+    std::vector<InputSource> ins;
+    for (int i = 0; i < n_inputs; i++) {
+      InputSource s;
+      s.kind = input_kinds ? input_kinds[i] : 0;
+      if (s.kind == COMET_INPUT_HOST_STREAM) s.host = (ArrowArrayStream*)inputs[i];
+      else if (s.kind == COMET_INPUT_DEVICE_STREAM) s.dev = (ArrowDeviceArrayStream*)inputs[i];
+      else throw CometError("unknown input kind " + std::to_string(s.kind));
+      ins.push_back(s);
+    }
+    std::shared_ptr<ExecutionContext> ctx;
+    try {
+      ctx = std::make_shared<ExecutionContext>(op, cfg, ins, batch_size, device_id);
+    } catch (...) {
+      // ownership of the streams was transferred to us: release them even when planning fails
+      for (auto& s : ins) {
+        if (s.host && s.host->release) s.host->release(s.host);
+        if (s.dev && s.dev->release) s.dev->release(s.dev);
+      }
+      throw;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    int64_t h = g_next++;
+    g_ctx[h] = ctx;
+    return h;
+  });
+}
+
+int64_t comet_execute_plan(int64_t handle, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas, int32_t n_out) {
+  auto ctx = lookup(handle);
+  if (!ctx) {
+    t_last_error = "invalid plan handle";
+    return -2;
+  }
+  return guarded(ctx.get(), (int64_t)-2, [&]() -> int64_t { return ctx->execute(out_arrays, out_schemas, n_out); });
+}
+
+void comet_release_plan(int64_t handle) {
+  std::shared_ptr<ExecutionContext> ctx;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(handle);
+    if (it == g_ctx.end()) return;
+    ctx = it->second;
+    g_ctx.erase(it);
+  }
+  guarded(nullptr, 0, [&]() -> int { ctx.reset(); return 0; });
+}
+
+const char* comet_last_error(int64_t handle) {
+  if (handle == 0) return t_last_error.c_str();
+  auto ctx = lookup(handle);
+  if (!ctx) return t_last_error.c_str();
+  // keep the string alive in thread-local storage: the context may be released concurrently
+  t_last_error = ctx->last_error;
+  return t_last_error.c_str();
+}
+
+int32_t comet_last_error_kind(int64_t handle) {
+  if (handle == 0) return t_last_kind;
+  auto ctx = lookup(handle);
+  return ctx ? ctx->last_error_kind : t_last_kind;
+}
+
+int64_t comet_plan_metrics(int64_t handle, uint8_t* buf, size_t cap) {
+  auto ctx = lookup(handle);
+  if (!ctx) return -2;
+  return guarded(ctx.get(), (int64_t)-2, [&]() -> int64_t {
+    std::string s = ctx->metrics_proto();
+    if (buf && cap) memcpy(buf, s.data(), std::min(cap, s.size()));
+    return (int64_t)s.size();
+  });
+}
+
+const char* comet_explain(int64_t handle) {
+  auto ctx = lookup(handle);
+  if (!ctx) return "";
+  static thread_local std::string s;
+  s = ctx->explain();
+  return s.c_str();
+}
+
+void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launches, int64_t* input_rows) {
+  auto ctx = lookup(handle);
+  if (!ctx) return;
+  if (kernel_ms) *kernel_ms = ctx->last_kernel_ms;
+  if (launches) *launches = ctx->last_kernel_launches;
+  if (input_rows) *input_rows = ctx->input_rows;
+}
+
+int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    OperatorP op = decode_operator(plan, plan_len);
+    std::string ex = ExecutionContext::compile_only(*op);
+    if (out && cap) {
+      size_t n = std::min(cap - 1, ex.size());
+      memcpy(out, ex.data(), n);
+      out[n] = 0;
+    }
+    return 0;
+  });
+}
+
+int32_t comet_murmur3_column(int32_t type_id, int32_t precision, const void* values, const uint8_t* validity,
+                             const void* aux_bytes, int64_t n, uint32_t* hashes, void* hip_stream) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    int rc = comet_launch_murmur3(type_id, precision, values, validity, aux_bytes, n, hashes, hip_stream);
+    if (rc != 0) throw CometError("murmur3: unsupported column type " + std::to_string(type_id));
+    return 0;
+  });
+}
+
+int32_t comet_pmod_partition(const uint32_t* hashes, int64_t n, int32_t num_partitions, int32_t* partition_ids, void* hip_stream) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    if (num_partitions <= 0) throw CometError("pmod: num_partitions must be positive");
+    if (comet_launch_pmod(hashes, n, num_partitions, partition_ids, hip_stream) != 0) throw CometError("pmod launch failed");
+    return 0;
+  });
+}
+
+const char* comet_version(void) { return "comet-mi355x 0.1.0 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,1308 @@
+// Planner + HIP code generator.
+//
+// A chain  Scan → (Filter | Projection)* → [HashAggregate]  collapses into ONE fused pipeline:
+// projections are substituted into later expressions, filter predicates are split into conjuncts,
+// and the per-row code is emitted in STAGES (one per conjunct) so a column is only loaded for rows
+// (lanes) that survived the earlier conjuncts.  The kernel structure is hand-written
+// (device/comet_device.hpp); this file only emits the functor P those templates call.
+//
+// Semantics followed (reference file:line):
+//   operator arms        native/core/src/execution/planner.rs:1230-1384
+//   binary arithmetic    planner.rs:976-1132 (wide-decimal path selection :1000-1008)
+//   CheckOverflow        planner.rs:600-649, spark-expr/src/math_funcs/internal/checkoverflow.rs:103-160
+//   aggregates           planner.rs:2558-2700, spark-expr/src/agg_funcs/*.rs (state schemas)
+#include "codegen.hpp"
+#include "kparams.h"
+
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <sstream>
+
+namespace comet {
+namespace {
+
+const u128 kUnbounded = ~(u128)0;
+
+u128 pow10_u128(int e) {
+  u128 r = 1;
+  for (int i = 0; i < e; i++) r *= 10;
+  return r;
+}
+u128 sat_mul(u128 a, u128 b) {
+  if (a == 0 || b == 0) return 0;
+  if (a == kUnbounded || b == kUnbounded) return kUnbounded;
+  u128 r;
+  if (__builtin_mul_overflow(a, b, &r)) return kUnbounded;
+  return r;
+}
+u128 sat_add(u128 a, u128 b) {
+  if (a == kUnbounded || b == kUnbounded) return kUnbounded;
+  u128 r;
+  if (__builtin_add_overflow(a, b, &r)) return kUnbounded;
+  return r;
+}
+
+enum class Rep { B, I32, I64, I128, F32, F64 };
+
+const char* rep_ctype(Rep r) {
+  switch (r) {
+    case Rep::B: return "bool";
+    case Rep::I32: return "i32";
+    case Rep::I64: return "i64";
+    case Rep::I128: return "i128";
+    case Rep::F32: return "float";
+    case Rep::F64: return "double";
+  }
+  return "?";
+}
+
+std::string hex64(uint64_t v) {
+  char b[32];
+  snprintf(b, sizeof b, "0x%016llxull", (unsigned long long)v);
+  return b;
+}
+std::string lit_i128(i128 v) {
+  return "comet::mk128(" + hex64((uint64_t)((u128)v >> 64)) + ", " + hex64((uint64_t)(u128)v) + ")";
+}
+std::string lit_u128(u128 v) { return "(u128)" + lit_i128((i128)v); }
+std::string lit_i64(int64_t v) { return "(i64)" + hex64((uint64_t)v); }
+
+struct Val {
+  std::string v;    // C expression (per-row vars carry the [r] suffix already)
+  std::string ok;   // validity expression, empty = never null
+  DType t;
+  Rep rep = Rep::I64;
+  u128 maxabs = kUnbounded;  // static bound on |value| for ints/decimals
+  bool is_null_lit = false;
+  bool wide_decimal = false;  // produced by the wide-decimal path (CheckOverflow elision rule)
+  bool is_cast_dec = false;   // Cast(decimal→decimal) not yet checked (fusion with CheckOverflow)
+  std::string cast_child_v, cast_child_ok;  // for the fused DecimalRescaleCheckOverflow
+  DType cast_child_t;
+  Rep cast_child_rep = Rep::I64;
+  u128 cast_child_max = kUnbounded;
+};
+
+Rep rep_for_type(const DType& t) {
+  switch (t.id) {
+    case TypeId::Bool: return Rep::B;
+    case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Date: return Rep::I32;
+    case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: return Rep::I64;
+    case TypeId::Float: return Rep::F32;
+    case TypeId::Double: return Rep::F64;
+    case TypeId::Decimal: return t.precision <= 18 ? Rep::I64 : Rep::I128;
+    default: throw CometError("Unsupported data type in native GPU pipeline: " + t.str());
+  }
+}
+u128 type_maxabs(const DType& t) {
+  switch (t.id) {
+    case TypeId::Int8: return 128;
+    case TypeId::Int16: return 32768;
+    case TypeId::Int32: case TypeId::Date: return (u128)1 << 31;
+    case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: return (u128)1 << 63;
+    case TypeId::Decimal: return pow10_u128(t.precision) - 1;
+    default: return kUnbounded;
+  }
+}
+Rep rep_for_bound(u128 maxabs) { return maxabs < ((u128)1 << 63) ? Rep::I64 : Rep::I128; }
+
+int type_width(const DType& t) {
+  switch (t.id) {
+    case TypeId::Bool: case TypeId::Int8: return 1;
+    case TypeId::Int16: return 2;
+    case TypeId::Int32: case TypeId::Date: case TypeId::Float: return 4;
+    case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: case TypeId::Double: return 8;
+    case TypeId::Decimal: return 16;
+    default: throw CometError("Unsupported output type: " + t.str());
+  }
+}
+const char* store_ctype(const DType& t) {
+  switch (t.id) {
+    case TypeId::Bool: return "u8";
+    case TypeId::Int8: return "i8";
+    case TypeId::Int16: return "i16";
+    case TypeId::Int32: case TypeId::Date: return "i32";
+    case TypeId::Float: return "float";
+    case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: return "i64";
+    case TypeId::Double: return "double";
+    case TypeId::Decimal: return "i128";
+    default: throw CometError("Unsupported output type: " + t.str());
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Expression substitution (Projection folding) and conjunct splitting.
+// ---------------------------------------------------------------------------------------------
+ExprP substitute(const ExprP& e, const std::vector<ExprP>& cols, std::map<const Expr*, ExprP>& memo) {
+  auto it = memo.find(e.get());
+  if (it != memo.end()) return it->second;
+  ExprP out;
+  if (e->kind == ExprKind::Bound) {
+    if (e->bound_index < 0 || (size_t)e->bound_index >= cols.size())
+      throw CometError("Column index " + std::to_string(e->bound_index) + " is out of bound. Schema has " +
+                       std::to_string(cols.size()) + " fields");
+    out = cols[e->bound_index];
+  } else if (e->children.empty()) {
+    out = e;
+  } else {
+    auto n = std::make_shared<Expr>(*e);
+    bool changed = false;
+    for (auto& c : n->children) {
+      ExprP s = substitute(c, cols, memo);
+      if (s != c) changed = true;
+      c = s;
+    }
+    out = changed ? n : e;
+  }
+  memo[e.get()] = out;
+  return out;
+}
+
+void split_conjuncts(const ExprP& e, std::vector<ExprP>& out) {
+  if (e->kind == ExprKind::And && e->children.size() == 2) {
+    split_conjuncts(e->children[0], out);
+    split_conjuncts(e->children[1], out);
+  } else {
+    out.push_back(e);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Emitter
+// ---------------------------------------------------------------------------------------------
+struct Gen {
+  const std::vector<DType>& in_types;
+  const std::vector<bool>& in_valid;
+  std::vector<bool> in_used;
+  int nvar = 0;
+  std::string decls;
+  struct Stage { std::string loads, body; };
+  std::vector<Stage> stages;
+  std::map<std::string, Val> cse;
+  std::map<const Expr*, std::string> keymemo;
+  std::map<int, Val> col_cache;
+  bool uses_err = false;
+
+  Gen(const std::vector<DType>& t, const std::vector<bool>& v) : in_types(t), in_valid(v), in_used(t.size(), false) {
+    stages.emplace_back();
+  }
+
+  std::string newvar(const char* ctype) {
+    std::string n = "x" + std::to_string(nvar++);
+    decls += std::string("    ") + ctype + " " + n + "[R];\n";
+    return n + "[r]";
+  }
+  void stmt(const std::string& s) { stages.back().body += "      " + s + "\n"; }
+  void load(const std::string& s) { stages.back().loads += "      " + s + "\n"; }
+  void next_stage() { stages.emplace_back(); }
+
+  // materialise an expression string into a variable (so later uses do not recompute it)
+  Val named(Val x) {
+    if (!x.v.empty() && x.v[0] == 'x' && x.v.find_first_of(" (") == std::string::npos) return x;
+    std::string n = newvar(rep_ctype(x.rep));
+    stmt(n + " = " + x.v + ";");
+    x.v = n;
+    if (!x.ok.empty() && !(x.ok[0] == 'x' && x.ok.find_first_of(" (") == std::string::npos)) {
+      std::string o = newvar("bool");
+      stmt(o + " = " + x.ok + ";");
+      x.ok = o;
+    }
+    return x;
+  }
+
+  std::string key_of(const ExprP& e) {
+    auto it = keymemo.find(e.get());
+    if (it != keymemo.end()) return it->second;
+    std::ostringstream k;
+    k << (int)e->kind << ":" << (int)e->dtype.id << "," << e->dtype.precision << "," << e->dtype.scale << ":"
+      << (int)e->eval_mode << e->fail_on_error << e->negated;
+    if (e->kind == ExprKind::Bound) k << "#" << e->bound_index;
+    if (e->kind == ExprKind::Literal) {
+      k << "L" << e->lit_case << e->lit_null << e->lit_bool << ":" << e->lit_i64 << ":";
+      uint64_t fb;
+      memcpy(&fb, &e->lit_f64, 8);
+      k << fb << ":" << (uint64_t)((u128)e->lit_dec >> 64) << "_" << (uint64_t)(u128)e->lit_dec << ":" << e->lit_bytes;
+    }
+    k << "(";
+    for (auto& c : e->children) k << key_of(c) << ";";
+    k << ")";
+    keymemo[e.get()] = k.str();
+    return k.str();
+  }
+
+  Val column(int idx) {
+    auto it = col_cache.find(idx);
+    if (it != col_cache.end()) return it->second;
+    if (idx < 0 || (size_t)idx >= in_types.size()) throw CometError("Column index " + std::to_string(idx) + " is out of bound");
+    const DType& t = in_types[idx];
+    in_used[idx] = true;
+    Val x;
+    x.t = t;
+    x.rep = rep_for_type(t);
+    x.maxabs = type_maxabs(t);
+    std::string c = "prm.in[" + std::to_string(idx) + "]";
+    std::string n = newvar(rep_ctype(x.rep));
+    std::string ldx;
+    switch (t.id) {
+      case TypeId::Bool: ldx = "comet::ld_bool(" + c + ", idx[r])"; break;
+      case TypeId::Int8: ldx = "(i32)comet::ld<i8>(" + c + ", idx[r])"; break;
+      case TypeId::Int16: ldx = "(i32)comet::ld<i16>(" + c + ", idx[r])"; break;
+      case TypeId::Int32: case TypeId::Date: ldx = "comet::ld<i32>(" + c + ", idx[r])"; break;
+      case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: ldx = "comet::ld<i64>(" + c + ", idx[r])"; break;
+      case TypeId::Float: ldx = "comet::ld<float>(" + c + ", idx[r])"; break;
+      case TypeId::Double: ldx = "comet::ld<double>(" + c + ", idx[r])"; break;
+      case TypeId::Decimal:
+        ldx = t.precision <= 18 ? "comet::ld_dec_lo(" + c + ", idx[r])" : "comet::ld<i128>(" + c + ", idx[r])";
+        break;
+      default: throw CometError("Unsupported scan column type: " + t.str());
+    }
+    load(n + " = " + ldx + ";");
+    x.v = n;
+    if (in_valid[idx]) {
+      std::string o = newvar("bool");
+      load(o + " = comet::ld_valid(" + c + ", idx[r]);");
+      x.ok = o;
+    }
+    col_cache[idx] = x;
+    return x;
+  }
+
+  static std::string and_ok(const std::string& a, const std::string& b) {
+    if (a.empty()) return b;
+    if (b.empty()) return a;
+    return "(" + a + " && " + b + ")";
+  }
+
+  Val literal(const Expr& e) {
+    Val x;
+    x.t = e.dtype;
+    if (e.dtype.id == TypeId::Null) throw CometError("NullType literal is not supported in GPU pipeline");
+    x.rep = rep_for_type(e.dtype);
+    if (e.lit_null) {
+      x.is_null_lit = true;
+      x.ok = "false";
+      x.maxabs = 0;
+      switch (x.rep) {
+        case Rep::B: x.v = "false"; break;
+        case Rep::F32: x.v = "0.0f"; break;
+        case Rep::F64: x.v = "0.0"; break;
+        case Rep::I128: x.v = "(i128)0"; break;
+        default: x.v = std::string("(") + rep_ctype(x.rep) + ")0";
+      }
+      return x;
+    }
+    switch (e.dtype.id) {
+      case TypeId::Bool: x.v = e.lit_bool ? "true" : "false"; break;
+      case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Date:
+        x.v = "(i32)" + std::to_string((int32_t)e.lit_i64);
+        x.maxabs = (u128)(e.lit_i64 < 0 ? -(i128)e.lit_i64 : (i128)e.lit_i64);
+        break;
+      case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz:
+        x.v = lit_i64(e.lit_i64);
+        x.maxabs = (u128)(e.lit_i64 < 0 ? -(i128)e.lit_i64 : (i128)e.lit_i64);
+        break;
+      case TypeId::Float: {
+        float f = (float)e.lit_f64;
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        x.v = "__int_as_float((int)" + std::to_string((int32_t)u) + ")";
+        break;
+      }
+      case TypeId::Double: {
+        uint64_t u;
+        memcpy(&u, &e.lit_f64, 8);
+        x.v = "__longlong_as_double(" + lit_i64((int64_t)u) + ")";
+        break;
+      }
+      case TypeId::Decimal: {
+        i128 v = e.lit_dec;
+        x.maxabs = (u128)(v < 0 ? -v : v);
+        if (x.rep == Rep::I64) x.v = lit_i64((int64_t)v);
+        else x.v = lit_i128(v);
+        break;
+      }
+      default: throw CometError("Unsupported literal type: " + e.dtype.str());
+    }
+    return x;
+  }
+
+  std::string as128(const Val& x) { return x.rep == Rep::I128 ? x.v : "(i128)(" + x.v + ")"; }
+  std::string as64(const Val& x) {
+    if (x.rep == Rep::I64) return x.v;
+    return "(i64)(" + x.v + ")";
+  }
+
+  // total-order key for floats (arrow-ord compares floats with IEEE totalOrder)
+  std::string fkey(const Val& x) {
+    if (x.rep == Rep::F64) return "comet::f64_total_key(" + x.v + ")";
+    return "comet::f32_total_key(" + x.v + ")";
+  }
+
+  Val compare(ExprKind k, Val a, Val b) {
+    Val r;
+    r.t = DType::of(TypeId::Bool);
+    r.rep = Rep::B;
+    std::string op;
+    switch (k) {
+      case ExprKind::Eq: case ExprKind::EqNullSafe: op = "=="; break;
+      case ExprKind::Neq: case ExprKind::NeqNullSafe: op = "!="; break;
+      case ExprKind::Gt: op = ">"; break;
+      case ExprKind::GtEq: op = ">="; break;
+      case ExprKind::Lt: op = "<"; break;
+      case ExprKind::LtEq: op = "<="; break;
+      default: throw CometError("bad comparison");
+    }
+    if (a.t.id == TypeId::Decimal && b.t.id == TypeId::Decimal && a.t.scale != b.t.scale)
+      throw CometError("Decimal comparison requires equal scales: " + a.t.str() + " vs " + b.t.str());
+    bool af = a.rep == Rep::F32 || a.rep == Rep::F64, bf = b.rep == Rep::F32 || b.rep == Rep::F64;
+    if (af != bf || (af && a.rep != b.rep)) throw CometError("Comparison of mismatched types: " + a.t.str() + " vs " + b.t.str());
+    if ((a.rep == Rep::B) != (b.rep == Rep::B)) throw CometError("Comparison of mismatched types: " + a.t.str() + " vs " + b.t.str());
+    std::string l, rr;
+    if (af) { l = fkey(a); rr = fkey(b); }
+    else if (a.rep == Rep::B) { l = "(int)" + a.v; rr = "(int)" + b.v; }
+    else if (a.rep == Rep::I128 || b.rep == Rep::I128) { l = as128(a); rr = as128(b); }
+    else if (a.rep == Rep::I64 || b.rep == Rep::I64) { l = "(i64)" + a.v; rr = "(i64)" + b.v; }
+    else { l = a.v; rr = b.v; }
+    std::string cmp = "(" + l + " " + op + " " + rr + ")";
+    if (k == ExprKind::EqNullSafe || k == ExprKind::NeqNullSafe) {
+      std::string aok = a.ok.empty() ? "true" : a.ok, bok = b.ok.empty() ? "true" : b.ok;
+      std::string eq = "((" + aok + " && " + bok + " && (" + l + " == " + rr + ")) || (!" + aok + " && !" + bok + "))";
+      r.v = (k == ExprKind::EqNullSafe) ? eq : "(!" + eq + ")";
+      return r;
+    }
+    r.v = cmp;
+    r.ok = and_ok(a.ok, b.ok);
+    return r;
+  }
+
+  Val logic(ExprKind k, Val a, Val b) {
+    Val r;
+    r.t = DType::of(TypeId::Bool);
+    r.rep = Rep::B;
+    if (a.rep != Rep::B || b.rep != Rep::B) throw CometError("AND/OR expects boolean operands");
+    a = named(a);
+    b = named(b);
+    if (a.ok.empty() && b.ok.empty()) {
+      r.v = "(" + a.v + (k == ExprKind::And ? " && " : " || ") + b.v + ")";
+      return r;
+    }
+    std::string aok = a.ok.empty() ? "true" : a.ok, bok = b.ok.empty() ? "true" : b.ok;
+    if (k == ExprKind::And) {
+      // Kleene: FALSE dominates NULL
+      r.v = "(" + aok + " && " + a.v + " && " + bok + " && " + b.v + ")";
+      r.ok = "((" + aok + " && !" + a.v + ") || (" + bok + " && !" + b.v + ") || (" + aok + " && " + bok + "))";
+    } else {
+      r.v = "((" + aok + " && " + a.v + ") || (" + bok + " && " + b.v + "))";
+      r.ok = "((" + aok + " && " + a.v + ") || (" + bok + " && " + b.v + ") || (" + aok + " && " + bok + "))";
+    }
+    return r;
+  }
+
+  // raise a Spark error for the rows where `cond` holds (ANSI mode)
+  void raise_if(const std::string& cond, int code) {
+    uses_err = true;
+    stmt("if (" + cond + ") atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], " + std::to_string(1u << code) + "u);");
+  }
+
+  // CheckOverflow / bound check shared tail: value `v` (rep), ok expr, bound 10^p-1
+  Val bound_check(Val x, int p, bool fail_on_error, int err_code) {
+    u128 bound = pow10_u128(p) - 1;
+    if (x.maxabs <= bound) return x;  // statically in range: nothing to emit
+    x = named(x);
+    std::string fits = x.rep == Rep::I128 ? "comet::dec_fits(" + x.v + ", " + lit_u128(bound) + ")"
+                                          : "comet::dec_fits64(" + x.v + ", " + hex64((uint64_t)bound) + ")";
+    if (x.rep != Rep::I128 && bound >= ((u128)1 << 63)) return x;  // i64 value cannot exceed a ≥2^63 bound
+    if (fail_on_error) {
+      raise_if(and_ok(x.ok, "!" + fits), err_code);
+    } else {
+      std::string o = newvar("bool");
+      stmt(o + " = " + and_ok(x.ok, fits) + ";");
+      x.ok = o;
+    }
+    x.maxabs = bound;
+    return x;
+  }
+
+  Val decimal_binary(const Expr& e, Val a, Val b) {
+    const int p1 = a.t.precision, s1 = a.t.scale, p2 = b.t.precision, s2 = b.t.scale;
+    const bool mul = e.kind == ExprKind::Multiply;
+    const bool addsub = e.kind == ExprKind::Add || e.kind == ExprKind::Subtract;
+    if (!mul && !addsub) throw CometError(std::string("Decimal ") + expr_name(e.proto_tag) + " is not supported in the GPU pipeline yet");
+    const int smax = std::max(s1, s2);
+    // planner.rs:1000-1008
+    const bool wide = (addsub && smax + std::max(p1 - s1, p2 - s2) >= 38) || (mul && p1 + p2 >= 38);
+    Val r;
+    r.rep = Rep::I128;
+    r.ok = and_ok(a.ok, b.ok);
+    if (wide) {
+      if (!e.has_dtype || e.dtype.id != TypeId::Decimal) throw CometError("Expected Decimal128 return type");
+      const int p_out = e.dtype.precision, s_out = e.dtype.scale;
+      const u128 bound = pow10_u128(p_out) - 1;
+      r.t = e.dtype;
+      r.wide_decimal = true;
+      a = named(a);
+      b = named(b);
+      std::string raw = newvar("comet::i256");
+      int scale_diff;
+      if (mul) {
+        scale_diff = s1 + s2 - s_out;
+        stmt(raw + " = comet::i128_mul_i128(" + as128(a) + ", " + as128(b) + ");");
+      } else {
+        scale_diff = smax - s_out;
+        std::string l = "comet::i128_mul_i128(" + as128(a) + ", " + lit_i128((i128)pow10_u128(smax - s1)) + ")";
+        std::string rr = "comet::i128_mul_i128(" + as128(b) + ", " + lit_i128((i128)pow10_u128(smax - s2)) + ")";
+        stmt(raw + " = comet::" + (e.kind == ExprKind::Add ? "i256_add(" : "i256_sub(") + l + ", " + rr + ");");
+      }
+      if (scale_diff > 0) {
+        if (scale_diff > 38) throw CometError("wide decimal rescale by more than 10^38 is not supported");
+        stmt(raw + " = comet::i256_div_pow10_half_up(" + raw + ", " + lit_u128(pow10_u128(scale_diff)) + ");");
+      } else if (scale_diff < 0) {
+        if (-scale_diff > 38) throw CometError("wide decimal rescale by more than 10^38 is not supported");
+        // raw.wrapping_mul(10^k): two's-complement wrapping multiply equals the unsigned one
+        stmt(raw + " = comet::u256_mul_u128_wrapping(" + raw + ", " + lit_u128(pow10_u128(-scale_diff)) + ");");
+      }
+      std::string val = newvar("i128");
+      std::string fit = newvar("bool");
+      stmt(fit + " = comet::i256_fits_bound(" + raw + ", " + lit_u128(bound) + ", " + val + ");");
+      if (e.eval_mode == EvalMode::Ansi) {
+        raise_if(and_ok(r.ok, "!" + fit), 0);
+      } else {
+        std::string o = newvar("bool");
+        stmt(o + " = " + and_ok(r.ok, fit) + ";");
+        r.ok = o;
+      }
+      r.v = val;
+      r.maxabs = bound;
+      return r;
+    }
+    // narrow path: exact i128 arithmetic, result typed like arrow-arith's decimal kernels
+    if (mul) {
+      r.t = DType::decimal(std::min(38, p1 + p2 + 1), s1 + s2);
+      r.maxabs = sat_mul(a.maxabs, b.maxabs);
+      r.rep = rep_for_bound(r.maxabs);
+      if (r.rep == Rep::I64) r.v = "(" + as64(a) + " * " + as64(b) + ")";
+      else if (a.rep != Rep::I128 && b.rep != Rep::I128) r.v = "((i128)" + as64(a) + " * (i128)" + as64(b) + ")";
+      else r.v = "(" + as128(a) + " * " + as128(b) + ")";
+    } else {
+      r.t = DType::decimal(std::min(38, std::max(p1 - s1, p2 - s2) + smax + 1), smax);
+      u128 fa = pow10_u128(smax - s1), fb = pow10_u128(smax - s2);
+      r.maxabs = sat_add(sat_mul(a.maxabs, fa), sat_mul(b.maxabs, fb));
+      r.rep = rep_for_bound(r.maxabs);
+      const char* op = e.kind == ExprKind::Add ? " + " : " - ";
+      if (r.rep == Rep::I64) {
+        std::string l = fa == 1 ? as64(a) : "(" + as64(a) + " * " + lit_i64((int64_t)fa) + ")";
+        std::string rr = fb == 1 ? as64(b) : "(" + as64(b) + " * " + lit_i64((int64_t)fb) + ")";
+        r.v = "(" + l + op + rr + ")";
+      } else {
+        std::string l = fa == 1 ? as128(a) : "(" + as128(a) + " * " + lit_i128((i128)fa) + ")";
+        std::string rr = fb == 1 ? as128(b) : "(" + as128(b) + " * " + lit_i128((i128)fb) + ")";
+        r.v = "(" + l + op + rr + ")";
+      }
+    }
+    if (r.maxabs == kUnbounded) throw CometError("internal: narrow decimal path with unbounded operand");
+    return r;
+  }
+
+  Val arithmetic(const Expr& e, Val a, Val b) {
+    if (a.t.id == TypeId::Decimal && b.t.id == TypeId::Decimal) return decimal_binary(e, a, b);
+    if (!e.has_dtype) throw CometError("arithmetic expression without return_type");
+    const DType& rt = e.dtype;
+    Val r;
+    r.t = rt;
+    r.rep = rep_for_type(rt);
+    r.ok = and_ok(a.ok, b.ok);
+    const bool checked = (e.eval_mode == EvalMode::Ansi || e.eval_mode == EvalMode::Try);
+    if (rt.is_integer()) {
+      if (!(a.t.is_integer() && b.t.is_integer())) throw CometError("integer arithmetic on non-integer operands");
+      const char* ct = r.rep == Rep::I64 ? "i64" : "i32";
+      const char* ut = r.rep == Rep::I64 ? "u64" : "u32";
+      std::string op;
+      const char* builtin = nullptr;
+      switch (e.kind) {
+        case ExprKind::Add: op = "+"; builtin = "__builtin_add_overflow"; break;
+        case ExprKind::Subtract: op = "-"; builtin = "__builtin_sub_overflow"; break;
+        case ExprKind::Multiply: op = "*"; builtin = "__builtin_mul_overflow"; break;
+        default: throw CometError(std::string("Integer ") + expr_name(e.proto_tag) + " is not supported in the GPU pipeline yet");
+      }
+      if (!checked) {
+        // LEGACY: wrapping (DataFusion BinaryExpr add_wrapping, planner.rs:1128)
+        std::string w = std::string("(") + ct + ")((" + ut + ")(" + ct + ")" + a.v + " " + op + " (" + ut + ")(" + ct + ")" + b.v + ")";
+        if (rt.id == TypeId::Int8) w = "(i32)(i8)" + w;
+        if (rt.id == TypeId::Int16) w = "(i32)(i16)" + w;
+        r.v = w;
+      } else {
+        // checked_arithmetic.rs:54-124: ANSI → error, TRY → NULL (value slot zeroed)
+        a = named(a);
+        b = named(b);
+        std::string out = newvar(ct), ovf = newvar("bool");
+        std::string narrow;
+        stmt("{ " + std::string(ct) + " t_; " + ovf + " = " + builtin + "((" + ct + ")" + a.v + ", (" + ct + ")" + b.v + ", &t_); " + out + " = t_; }");
+        if (rt.id == TypeId::Int8) stmt(ovf + " = " + ovf + " || " + out + " != (i32)(i8)" + out + ";");
+        if (rt.id == TypeId::Int16) stmt(ovf + " = " + ovf + " || " + out + " != (i32)(i16)" + out + ";");
+        if (e.eval_mode == EvalMode::Ansi) {
+          raise_if(and_ok(r.ok, ovf), 1);
+          r.v = out;
+        } else {
+          std::string o = newvar("bool");
+          stmt(o + " = " + and_ok(r.ok, "!" + ovf) + ";");
+          r.ok = o;
+          r.v = "(" + o + " ? " + out + " : (" + ct + ")0)";
+        }
+      }
+      return r;
+    }
+    if (rt.is_float()) {
+      const char* ct = r.rep == Rep::F64 ? "double" : "float";
+      std::string op;
+      switch (e.kind) {
+        case ExprKind::Add: op = "+"; break;
+        case ExprKind::Subtract: op = "-"; break;
+        case ExprKind::Multiply: op = "*"; break;
+        case ExprKind::Divide: op = "/"; break;
+        default: throw CometError(std::string("Float ") + expr_name(e.proto_tag) + " is not supported in the GPU pipeline yet");
+      }
+      if (e.kind == ExprKind::Divide && checked) throw CometError("ANSI/TRY float division is not supported in the GPU pipeline yet");
+      // contraction off: a*b+c must round twice like the CPU path
+      r.v = std::string("comet::fp_") + (e.kind == ExprKind::Add ? "add" : e.kind == ExprKind::Subtract ? "sub" : e.kind == ExprKind::Multiply ? "mul" : "div") +
+            "((" + ct + ")" + a.v + ", (" + ct + ")" + b.v + ")";
+      return r;
+    }
+    throw CometError("Arithmetic on " + rt.str() + " is not supported in the GPU pipeline");
+  }
+
+  Val cast(const Expr& e, Val c) {
+    const DType& to = e.dtype;
+    const DType& from = c.t;
+    if (from == to) return c;
+    Val r;
+    r.t = to;
+    r.rep = rep_for_type(to);
+    r.ok = c.ok;
+    auto is_intlike = [](const DType& t) { return t.is_integer(); };
+    if (is_intlike(from) && is_intlike(to)) {
+      // LEGACY: wrap on narrowing (conversion_funcs/numeric.rs); ANSI narrowing overflow → error
+      if (type_width(to) >= type_width(from)) {
+        r.v = std::string("(") + rep_ctype(r.rep) + ")" + c.v;
+        r.maxabs = c.maxabs;
+        return r;
+      }
+      const char* nt = to.id == TypeId::Int8 ? "i8" : to.id == TypeId::Int16 ? "i16" : "i32";
+      c = named(c);
+      r.v = std::string("(") + rep_ctype(r.rep) + ")(" + nt + ")" + c.v;
+      if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(c.ok, std::string("(i64)(") + nt + ")" + c.v + " != (i64)" + c.v), 2);
+      r.maxabs = type_maxabs(to);
+      return r;
+    }
+    if ((is_intlike(from) || from.id == TypeId::Float) && to.id == TypeId::Double) {
+      r.v = "(double)" + c.v;
+      return r;
+    }
+    if (is_intlike(from) && to.id == TypeId::Float) {
+      r.v = "(float)" + c.v;
+      return r;
+    }
+    if (is_intlike(from) && to.id == TypeId::Decimal) {
+      // cast_int_to_decimal128 (conversion_funcs/numeric.rs): v * 10^s, overflow → NULL (legacy) / error (ANSI)
+      u128 f = pow10_u128(to.scale);
+      Val m;
+      m.t = to;
+      m.ok = c.ok;
+      m.maxabs = sat_mul(c.maxabs, f);
+      m.rep = rep_for_bound(m.maxabs);
+      m.v = m.rep == Rep::I64 ? "((i64)" + c.v + " * " + lit_i64((int64_t)f) + ")" : "((i128)" + c.v + " * " + lit_i128((i128)f) + ")";
+      return bound_check(m, to.precision, e.eval_mode == EvalMode::Ansi, 3);
+    }
+    if (from.id == TypeId::Decimal && to.id == TypeId::Decimal) {
+      // Deferred: CheckOverflow(Cast(dec→dec)) fuses into DecimalRescaleCheckOverflow (planner.rs:615-633).
+      Val x = rescale(c, from.scale, to.precision, to.scale, e.eval_mode == EvalMode::Ansi);
+      x.is_cast_dec = true;
+      x.cast_child_v = c.v;
+      x.cast_child_ok = c.ok;
+      x.cast_child_t = c.t;
+      x.cast_child_rep = c.rep;
+      x.cast_child_max = c.maxabs;
+      return x;
+    }
+    if (from.id == TypeId::Date && to.id == TypeId::Date) return c;
+    throw CometError("Cast from " + from.str() + " to " + to.str() + " is not supported in the GPU pipeline yet");
+  }
+
+  // rescale_and_check (decimal_rescale_check.rs:108-150)
+  Val rescale(Val c, int s_in, int p_out, int s_out, bool fail_on_error) {
+    Val r;
+    r.t = DType::decimal(p_out, s_out);
+    r.ok = c.ok;
+    const int delta = s_out - s_in;
+    const u128 bound = pow10_u128(p_out) - 1;
+    if (delta == 0) {
+      r.v = c.v;
+      r.rep = c.rep;
+      r.maxabs = c.maxabs;
+      return bound_check(r, p_out, fail_on_error, 3);
+    }
+    if (std::abs(delta) > 38) throw CometError("DecimalRescaleCheckOverflow: scale delta " + std::to_string(delta) + " exceeds maximum supported range");
+    u128 f = pow10_u128(std::abs(delta));
+    if (delta > 0) {
+      r.maxabs = sat_mul(c.maxabs, f);
+      if (r.maxabs != kUnbounded && r.maxabs < ((u128)1 << 126)) {
+        r.rep = rep_for_bound(r.maxabs);
+        r.v = r.rep == Rep::I64 ? "(" + as64(c) + " * " + lit_i64((int64_t)f) + ")" : "(" + as128(c) + " * " + lit_i128((i128)f) + ")";
+        return bound_check(r, p_out, fail_on_error, 3);
+      }
+      c = named(c);
+      std::string out = newvar("i128"), fit = newvar("bool");
+      stmt(fit + " = comet::dec_rescale_up(" + as128(c) + ", " + lit_i128((i128)f) + ", " + lit_u128(bound) + ", " + out + ");");
+      r.rep = Rep::I128;
+      r.v = out;
+      r.maxabs = bound;
+      if (fail_on_error) raise_if(and_ok(c.ok, "!" + fit), 3);
+      else {
+        std::string o = newvar("bool");
+        stmt(o + " = " + and_ok(c.ok, fit) + ";");
+        r.ok = o;
+      }
+      return r;
+    }
+    // scale down, HALF_UP
+    c = named(c);
+    std::string out = newvar("i128"), fit = newvar("bool");
+    stmt(fit + " = comet::dec_rescale_down(" + as128(c) + ", " + lit_i128((i128)f) + ", " + lit_u128(bound) + ", " + out + ");");
+    r.rep = Rep::I128;
+    r.v = out;
+    u128 m = c.maxabs == kUnbounded ? kUnbounded : c.maxabs / f + 1;
+    r.maxabs = m;
+    if (m <= bound) return r;  // cannot overflow: `fit` is always true
+    r.maxabs = bound;
+    if (fail_on_error) raise_if(and_ok(c.ok, "!" + fit), 3);
+    else {
+      std::string o = newvar("bool");
+      stmt(o + " = " + and_ok(c.ok, fit) + ";");
+      r.ok = o;
+    }
+    return r;
+  }
+
+  Val gen(const ExprP& ep) {
+    const Expr& e = *ep;
+    std::string key = key_of(ep);
+    auto it = cse.find(key);
+    if (it != cse.end()) return it->second;
+    Val out = gen_uncached(e);
+    // keep cheap leaf expressions inline, name everything else once
+    if (e.kind != ExprKind::Literal && e.kind != ExprKind::Bound) out = named(out);
+    cse[key] = out;
+    return out;
+  }
+
+  Val gen_uncached(const Expr& e) {
+    switch (e.kind) {
+      case ExprKind::Bound: return column(e.bound_index);
+      case ExprKind::Literal: return literal(e);
+      case ExprKind::Add: case ExprKind::Subtract: case ExprKind::Multiply: case ExprKind::Divide: case ExprKind::Remainder: {
+        if (e.children.size() != 2) throw CometError("binary expression needs two children");
+        Val a = gen(e.children[0]), b = gen(e.children[1]);
+        return arithmetic(e, a, b);
+      }
+      case ExprKind::Eq: case ExprKind::Neq: case ExprKind::Gt: case ExprKind::GtEq: case ExprKind::Lt: case ExprKind::LtEq:
+      case ExprKind::EqNullSafe: case ExprKind::NeqNullSafe: {
+        if (e.children.size() != 2) throw CometError("comparison needs two children");
+        Val a = gen(e.children[0]), b = gen(e.children[1]);
+        return compare(e.kind, a, b);
+      }
+      case ExprKind::And: case ExprKind::Or: {
+        if (e.children.size() != 2) throw CometError("AND/OR needs two children");
+        Val a = gen(e.children[0]), b = gen(e.children[1]);
+        return logic(e.kind, a, b);
+      }
+      case ExprKind::Not: {
+        Val a = gen(e.children.at(0));
+        if (a.rep != Rep::B) throw CometError("NOT expects a boolean operand");
+        Val r = a;
+        r.v = "(!" + a.v + ")";
+        return r;
+      }
+      case ExprKind::IsNull: case ExprKind::IsNotNull: {
+        Val a = gen(e.children.at(0));
+        Val r;
+        r.t = DType::of(TypeId::Bool);
+        r.rep = Rep::B;
+        std::string ok = a.ok.empty() ? "true" : a.ok;
+        r.v = e.kind == ExprKind::IsNull ? "(!" + ok + ")" : ok;
+        return r;
+      }
+      case ExprKind::CheckOverflow: {
+        Val c = gen(e.children.at(0));
+        if (c.t.id != TypeId::Decimal || e.dtype.id != TypeId::Decimal)
+          throw CometError("CheckOverflow expects only Decimal128, but got " + c.t.str());
+        // planner.rs:606-613: WideDecimalBinaryExpr already checked, same type → child itself
+        if (c.wide_decimal && c.t == e.dtype) return c;
+        // planner.rs:615-633: Cast(dec→dec)+CheckOverflow with equal target → fused rescale+check
+        if (c.is_cast_dec && c.t == e.dtype) {
+          Val child;
+          child.v = c.cast_child_v; child.ok = c.cast_child_ok; child.t = c.cast_child_t; child.rep = c.cast_child_rep;
+          child.maxabs = c.cast_child_max;
+          Val x = rescale(child, child.t.scale, e.dtype.precision, e.dtype.scale, e.fail_on_error);
+          x.is_cast_dec = false;
+          return x;
+        }
+        if (c.t.scale != e.dtype.scale)
+          throw CometError("CheckOverflow cannot change scale (" + c.t.str() + " → " + e.dtype.str() + ")");
+        Val x = c;
+        x.t = e.dtype;
+        x.wide_decimal = false;
+        x.is_cast_dec = false;
+        return bound_check(x, e.dtype.precision, e.fail_on_error, 3);
+      }
+      case ExprKind::Cast: return cast(e, gen(e.children.at(0)));
+      case ExprKind::UnaryMinus: {
+        Val a = gen(e.children.at(0));
+        Val r = a;
+        switch (a.rep) {
+          case Rep::I32: r.v = "(i32)(0u - (u32)" + a.v + ")"; break;
+          case Rep::I64: r.v = "(i64)(0ull - (u64)" + a.v + ")"; break;
+          case Rep::I128: r.v = "(i128)((u128)0 - (u128)" + a.v + ")"; break;
+          case Rep::F32: case Rep::F64: r.v = "(-" + a.v + ")"; break;
+          default: throw CometError("unary minus on boolean");
+        }
+        if (e.fail_on_error && a.t.is_integer()) {
+          a = named(a);
+          std::string mn = a.t.id == TypeId::Int64 ? "(i64)0x8000000000000000ull" : a.t.id == TypeId::Int32 ? "(i32)0x80000000" : a.t.id == TypeId::Int16 ? "-32768" : "-128";
+          raise_if(and_ok(a.ok, a.v + " == " + mn), 1);
+        }
+        return r;
+      }
+      case ExprKind::If: {
+        if (e.children.size() != 3) throw CometError("If needs three children");
+        Val c = named(gen(e.children[0])), t = named(gen(e.children[1])), f = named(gen(e.children[2]));
+        if (t.rep != f.rep) throw CometError("If branches have different types");
+        std::string cond = "(" + and_ok(c.ok, c.v) + ")";
+        Val r = t;
+        r.maxabs = std::max(t.maxabs, f.maxabs);
+        r.v = "(" + cond + " ? " + t.v + " : " + f.v + ")";
+        if (!t.ok.empty() || !f.ok.empty())
+          r.ok = "(" + cond + " ? " + (t.ok.empty() ? "true" : t.ok) + " : " + (f.ok.empty() ? "true" : f.ok) + ")";
+        else r.ok = "";
+        r.wide_decimal = false;
+        return r;
+      }
+      case ExprKind::In: {
+        Val v = named(gen(e.children.at(0)));
+        std::string any = "false", anynull = "false";
+        for (size_t i = 1; i < e.children.size(); i++) {
+          Val li = gen(e.children[i]);
+          Val c = compare(ExprKind::Eq, v, li);
+          std::string lok = li.ok.empty() ? "true" : li.ok;
+          any = "(" + any + " || (" + lok + " && " + c.v + "))";
+          if (!li.ok.empty()) anynull = "(" + anynull + " || !" + li.ok + ")";
+        }
+        Val r;
+        r.t = DType::of(TypeId::Bool);
+        r.rep = Rep::B;
+        std::string hit = newvar("bool");
+        stmt(hit + " = " + any + ";");
+        r.v = e.negated ? "(!" + hit + ")" : hit;
+        std::string ok = v.ok;
+        if (anynull != "false") ok = and_ok(ok, "(" + hit + " || !" + anynull + ")");
+        r.ok = ok;
+        return r;
+      }
+      case ExprKind::NormalizeNaNAndZero: {
+        Val a = gen(e.children.at(0));
+        Val r = a;
+        if (a.rep == Rep::F64) r.v = "comet::normalize_nan_zero_f64(" + a.v + ")";
+        else if (a.rep == Rep::F32) r.v = "comet::normalize_nan_zero_f32(" + a.v + ")";
+        return r;
+      }
+      default:
+        throw CometError(std::string("Expression ") + expr_name(e.proto_tag) + " (tag " + std::to_string(e.proto_tag) +
+                         ") is not supported by the MI355X native engine");
+    }
+  }
+
+  // Filter conjunct: rows survive only where the predicate is TRUE and valid
+  void add_predicate(const ExprP& p) {
+    Val v = gen(p);
+    if (v.rep != Rep::B) throw CometError("Filter predicate must be boolean, got " + v.t.str());
+    stmt("k[r] = " + and_ok(v.ok, v.v) + ";");
+    next_stage();
+  }
+
+  // assemble the staged body: every stage is a load loop followed by a compute loop over the R rows
+  std::string body(const std::string& indent_unused = "") const {
+    (void)indent_unused;
+    std::string s;
+    for (auto& st : stages) {
+      if (!st.loads.empty()) {
+        s += "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) if (k[r]) {\n" + st.loads + "    }\n";
+      }
+      if (!st.body.empty()) {
+        s += "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) if (k[r]) {\n" + st.body + "    }\n";
+      }
+    }
+    return s;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Aggregate lowering
+// ---------------------------------------------------------------------------------------------
+enum class Prim { Cnt, Sum128, Sum192, SumI64, SumF64, AMax, SignFlags, MinI64, MaxI64, MinI128, MaxI128, MinF64, MaxF64, RowCnt };
+
+struct PrimSlot {
+  Prim prim;
+  int word;      // first accumulator word
+  int nwords;
+};
+
+int prim_words(Prim p) {
+  switch (p) {
+    case Prim::Sum128: case Prim::AMax: case Prim::MinI128: case Prim::MaxI128: return 2;
+    case Prim::Sum192: return 3;
+    default: return 1;
+  }
+}
+
+struct AggLowering {
+  Gen& g;
+  int nw = 0;
+  std::map<std::string, PrimSlot> slots;   // key: prim|valuekey|filterkey
+  std::string init_code, combine_code, feed_code;
+  std::vector<int> word_ops;               // per word: AccOp for the grouped atomic path
+
+  explicit AggLowering(Gen& gen) : g(gen) {}
+
+  PrimSlot get(Prim p, const std::string& vkey, const std::string& fkey, const std::function<std::string(int)>& feed_stmt) {
+    std::string key = std::to_string((int)p) + "|" + vkey + "|" + fkey;
+    if (p == Prim::Cnt) {
+      // a count whose condition is empty counts every row reaching the aggregate: share the row counter
+      std::string probe = feed_stmt(0);
+      if (probe.rfind("if (", 0) != 0) key = std::to_string((int)Prim::RowCnt) + "|*|";
+    }
+    auto it = slots.find(key);
+    if (it != slots.end()) return it->second;
+    PrimSlot s{p, nw, prim_words(p)};
+    nw += s.nwords;
+    slots[key] = s;
+    std::string w = std::to_string(s.word);
+    switch (p) {
+      case Prim::Cnt: case Prim::RowCnt: case Prim::SumI64:
+        init_code += "    a[" + w + "] = 0;\n";
+        combine_code += "    comet::acc_add64(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::SumF64:
+        init_code += "    a[" + w + "] = 0;\n";
+        combine_code += "    comet::acc_fadd64(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::Sum128:
+        init_code += "    a[" + w + "] = 0; a[" + w + " + 1] = 0;\n";
+        combine_code += "    comet::acc_add128(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::Sum192:
+        init_code += "    a[" + w + "] = 0; a[" + w + " + 1] = 0; a[" + w + " + 2] = 0;\n";
+        combine_code += "    comet::acc_add192(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::AMax:
+        init_code += "    a[" + w + "] = 0; a[" + w + " + 1] = 0;\n";
+        combine_code += "    comet::acc_umax128(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::SignFlags:
+        init_code += "    a[" + w + "] = 0;\n";
+        combine_code += "    comet::acc_or64(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::MinI64:
+        init_code += "    a[" + w + "] = 0x7fffffffffffffffull;\n";
+        combine_code += "    comet::acc_imin64(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::MaxI64:
+        init_code += "    a[" + w + "] = 0x8000000000000000ull;\n";
+        combine_code += "    comet::acc_imax64(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::MinI128:
+        init_code += "    a[" + w + "] = ~0ull; a[" + w + " + 1] = 0x7fffffffffffffffull;\n";
+        combine_code += "    comet::acc_imin128(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::MaxI128:
+        init_code += "    a[" + w + "] = 0; a[" + w + " + 1] = 0x8000000000000000ull;\n";
+        combine_code += "    comet::acc_imax128(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::MinF64:
+        init_code += "    a[" + w + "] = 0x7ff0000000000000ull;\n";  // +inf
+        combine_code += "    comet::acc_fmin64(a + " + w + ", b + " + w + ");\n";
+        break;
+      case Prim::MaxF64:
+        init_code += "    a[" + w + "] = 0xfff0000000000000ull;\n";  // -inf
+        combine_code += "    comet::acc_fmax64(a + " + w + ", b + " + w + ");\n";
+        break;
+    }
+    g.stmt(feed_stmt(s.word));
+    return s;
+  }
+};
+
+std::string explain_expr(const ExprP& e) {
+  std::string s = expr_name(e->proto_tag);
+  if (e->kind == ExprKind::Bound) return "col" + std::to_string(e->bound_index);
+  if (e->kind == ExprKind::Literal) return "lit:" + e->dtype.str();
+  s += "(";
+  for (size_t i = 0; i < e->children.size(); i++) s += (i ? ", " : "") + explain_expr(e->children[i]);
+  return s + ")";
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// generate_pipeline
+// ---------------------------------------------------------------------------------------------
+PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity) {
+  // 1. walk root → leaf collecting the chain
+  std::vector<const Operator*> chain;
+  const Operator* cur = &root;
+  while (true) {
+    chain.push_back(cur);
+    if (cur->kind == OpKind::Scan) break;
+    if (cur->kind == OpKind::Unsupported)
+      throw CometError(std::string("Operator ") + op_name(cur->proto_tag) + " is not supported by the MI355X native engine");
+    if (cur->kind != OpKind::Filter && cur->kind != OpKind::Projection && cur->kind != OpKind::HashAgg)
+      throw CometError(std::string("Operator ") + op_name(cur->proto_tag) + " is not supported in a fused GPU pipeline yet");
+    if (cur->children.size() != 1) throw CometError(std::string(op_name(cur->proto_tag)) + " expects exactly one child");
+    cur = cur->children[0].get();
+  }
+  const Operator& scan = *chain.back();
+  PipelineDesc d;
+  d.in_types = scan.scan_fields;
+  for (auto* op : chain) d.op_names.push_back(op_name(op->proto_tag));
+  if (in_has_validity.size() != d.in_types.size()) throw CometError("internal: validity mask arity mismatch");
+  if (d.in_types.size() > COMET_MAX_IN) throw CometError("too many scan columns for one GPU pipeline");
+
+  // 2. fold leaf → root
+  std::vector<ExprP> cols;
+  for (size_t i = 0; i < d.in_types.size(); i++) {
+    auto b = std::make_shared<Expr>();
+    b->kind = ExprKind::Bound;
+    b->proto_tag = 3;
+    b->bound_index = (int)i;
+    b->dtype = d.in_types[i];
+    b->has_dtype = true;
+    cols.push_back(b);
+  }
+  std::vector<ExprP> preds;
+  const Operator* agg = nullptr;
+  std::vector<ExprP> group_exprs;
+  struct AggIn { const AggExpr* a; std::vector<ExprP> children; ExprP filter; };
+  std::vector<AggIn> agg_ins;
+  for (int i = (int)chain.size() - 2; i >= 0; i--) {
+    const Operator& op = *chain[i];
+    std::map<const Expr*, ExprP> memo;
+    if (agg) throw CometError("Operators above a HashAggregate in the same native plan are not supported yet");
+    if (op.kind == OpKind::Filter) {
+      if (!op.predicate) throw CometError("Filter without predicate");
+      split_conjuncts(substitute(op.predicate, cols, memo), preds);
+      d.has_filter = true;
+    } else if (op.kind == OpKind::Projection) {
+      std::vector<ExprP> nc;
+      for (auto& e : op.project_list) nc.push_back(substitute(e, cols, memo));
+      cols = nc;
+    } else if (op.kind == OpKind::HashAgg) {
+      agg = &op;
+      for (auto& e : op.grouping_exprs) group_exprs.push_back(substitute(e, cols, memo));
+      for (auto& a : op.agg_exprs) {
+        AggIn in;
+        in.a = &a;
+        if (op.agg_mode == AggMode::Partial) {
+          for (auto& c : a.children) in.children.push_back(substitute(c, cols, memo));
+          if (a.filter) in.filter = substitute(a.filter, cols, memo);
+        }
+        agg_ins.push_back(in);
+      }
+    }
+  }
+
+  Gen g(d.in_types, in_has_validity);
+  for (auto& p : preds) g.add_predicate(p);
+
+  std::ostringstream src;
+  src << "// generated by datafusion-comet_amd codegen — fused pipeline: ";
+  for (auto& n : d.op_names) src << n << " <- ";
+  src << "input\n";
+  src << "#include \"comet_device.hpp\"\nusing namespace comet;\n";
+
+  std::ostringstream ex;
+  for (auto& p : preds) ex << "  filter: " << explain_expr(p) << "\n";
+
+  if (!agg) {
+    // ---------------- Output sink ----------------
+    d.sink = SinkKind::Output;
+    std::vector<Val> outs;
+    // outputs are evaluated in the emit kernel (per surviving row); predicates in the mask kernel.
+    Gen ge(d.in_types, in_has_validity);
+    for (auto& c : cols) {
+      Val v = ge.named(ge.gen(c));
+      outs.push_back(v);
+      OutCol oc;
+      oc.type = v.t;
+      oc.nullable = !v.ok.empty();
+      d.out_cols.push_back(oc);
+      ex << "  output: " << explain_expr(c) << " : " << v.t.str() << "\n";
+    }
+    if (d.out_cols.size() * 2 + kOutFirstCol > COMET_MAX_OUT) throw CometError("too many output columns for one GPU pipeline");
+    for (size_t j = 0; j < outs.size(); j++) {
+      const Val& v = outs[j];
+      std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * j) + "]";
+      std::string ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * j + 1) + "]";
+      const char* st = store_ctype(v.t);
+      std::string val = v.v;
+      if (v.t.id == TypeId::Decimal) val = v.rep == Rep::I128 ? v.v : "(i128)" + v.v;
+      else if (v.t.id == TypeId::Bool) val = "(u8)(" + v.v + " ? 1 : 0)";
+      else val = std::string("(") + st + ")" + v.v;
+      // NULL slots are written as zero like arrow builders do (deterministic bytes)
+      if (!v.ok.empty()) {
+        ge.stmt("((" + std::string(st) + "*)" + vb + ")[pos[r]] = " + v.ok + " ? " + val + " : (" + st + ")0;");
+        ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");
+      } else {
+        ge.stmt("((" + std::string(st) + "*)" + vb + ")[pos[r]] = " + val + ";");
+      }
+    }
+    for (size_t i = 0; i < d.in_types.size(); i++) d.in_used.push_back(g.in_used[i] || ge.in_used[i]);
+    src << "struct P {\n  static constexpr int R = 1;\n";
+    // keep(): single row, stages degenerate to nested ifs via k[0]
+    src << "  static __device__ __forceinline__ bool keep(const CometKParams& prm, i64 i) {\n"
+        << "    bool k[R] = {true}; i64 idx[R] = {i};\n"
+        << g.decls << g.body() << "    return k[0];\n  }\n";
+    src << "  static __device__ __forceinline__ void emit(const CometKParams& prm, i64 i, i64 p) {\n"
+        << "    bool k[R] = {true}; i64 idx[R] = {i}; i64 pos[R] = {p};\n"
+        << ge.decls << ge.body() << "  }\n};\n";
+    if (d.has_filter) {
+      src << "extern \"C\" __global__ __launch_bounds__(256) void k_mask(const CometKParams prm) { comet::filter_mask_body<P>(prm); }\n";
+      src << "extern \"C\" __global__ __launch_bounds__(256) void k_scan(const CometKParams prm) { comet::tile_scan_body((u64*)prm.out[1], prm.iarg[0]); }\n";
+      src << "extern \"C\" __global__ __launch_bounds__(256) void k_emit(const CometKParams prm) { comet::filter_emit_body<P>(prm); }\n";
+      d.kernels = {"k_mask", "k_scan", "k_emit"};
+    } else {
+      src << "extern \"C\" __global__ __launch_bounds__(256) void k_emit(const CometKParams prm) { comet::project_body<P>(prm); }\n";
+      d.kernels = {"k_emit"};
+    }
+    src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
+    d.kernels.push_back("k_pack");
+    d.R = 1;
+    d.source = src.str();
+    d.explain = ex.str();
+    return d;
+  }
+
+  // ---------------- Aggregate sinks ----------------
+  if (agg->agg_mode != AggMode::Partial)
+    throw CometError("HashAggregate mode Final/PartialMerge is handled by the merge pipeline (not fused)");
+  if (!group_exprs.empty()) throw CometError("grouped aggregate: see grouped pipeline generator");
+  d.sink = SinkKind::AggNoGroup;
+  AggLowering al(g);
+  std::string fin;  // finalize body
+  int out_j = 0;
+  auto out_val = [&](int j) { return "prm.out[" + std::to_string(kOutFirstCol + 2 * j) + "]"; };
+  auto out_ok = [&](int j) { return "prm.out[" + std::to_string(kOutFirstCol + 2 * j + 1) + "]"; };
+  // rows that reach the aggregate
+  std::string rowcnt_word;
+  {
+    PrimSlot rc = al.get(Prim::RowCnt, "*", "", [&](int w) { return "acc[" + std::to_string(w) + "] += 1;"; });
+    rowcnt_word = std::to_string(rc.word);
+  }
+  long long max_rows_exact = 0;
+  for (auto& in : agg_ins) {
+    const AggExpr& a = *in.a;
+    std::string fkey;
+    std::string guard;
+    if (in.filter) {
+      // FILTER (WHERE …): row contributes only if the filter is TRUE and valid (sum_decimal.rs:452-458)
+      Val f = g.named(g.gen(in.filter));
+      fkey = g.key_of(in.filter);
+      guard = Gen::and_ok(f.ok, f.v);
+    }
+    auto guarded = [&](const std::string& ok) { return Gen::and_ok(guard, ok); };
+    auto cond_stmt = [&](const std::string& cond, const std::string& body) {
+      return cond.empty() ? body : "if (" + cond + ") { " + body + " }";
+    };
+    switch (a.kind) {
+      case AggKind::Count: {
+        if (in.children.empty()) throw CometError("count() without children");
+        std::string ok, vkey;
+        for (auto& c : in.children) {
+          Val v = g.gen(c);
+          ok = Gen::and_ok(ok, v.ok);
+          vkey += g.key_of(c) + ",";
+        }
+        if (ok.empty()) vkey = "*";  // count of non-nullable args = row count
+        PrimSlot s = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(ok), "acc[" + std::to_string(w) + "] += 1;"); });
+        OutCol oc; oc.type = DType::of(TypeId::Int64); oc.nullable = false;
+        d.out_cols.push_back(oc);
+        fin += "    ((i64*)" + out_val(out_j) + ")[0] = (i64)acc[" + std::to_string(s.word) + "];\n";
+        out_j++;
+        ex << "  agg: count -> Int64\n";
+        break;
+      }
+      case AggKind::Sum: case AggKind::Avg: {
+        if (in.children.size() != 1) throw CometError("sum/avg expects one child");
+        Val v = g.named(g.gen(in.children[0]));
+        std::string vkey = g.key_of(in.children[0]);
+        const bool is_avg = a.kind == AggKind::Avg;
+        const DType& rt = a.dtype;
+        if (rt.id == TypeId::Decimal) {
+          if (v.t.id != TypeId::Decimal) throw CometError("decimal sum/avg over non-decimal input " + v.t.str());
+          const DType st = is_avg ? a.sum_dtype : rt;   // accumulation type
+          if (st.id != TypeId::Decimal) throw CometError("Invalid data type for SumDecimal");
+          if (st.scale != v.t.scale) throw CometError("decimal sum/avg: input scale differs from sum scale");
+          const u128 bound = pow10_u128(st.precision) - 1;
+          // Appendix C.1: no prefix can overflow while rows × max|v| ≤ 10^p − 1
+          u128 vmax = v.maxabs == 0 ? 1 : v.maxabs;
+          u128 safe_rows = vmax == kUnbounded ? 0 : bound / vmax;
+          const bool dynamic = safe_rows < ((u128)1 << 34);
+          if (!dynamic) {
+            long long sr = safe_rows > (u128)0x7fffffffffffffffll ? 0x7fffffffffffffffll : (long long)safe_rows;
+            if (max_rows_exact == 0 || sr < max_rows_exact) max_rows_exact = sr;
+          }
+          std::string val128 = v.rep == Rep::I128 ? v.v : "(i128)" + v.v;
+          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += 1;"); });
+          PrimSlot sum, amax{}, sflags{};
+          if (!dynamic) {
+            sum = al.get(Prim::Sum128, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "comet::acc_feed_i128(acc + " + std::to_string(w) + ", " + val128 + ");"); });
+          } else {
+            sum = al.get(Prim::Sum192, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "comet::acc_feed_i192(acc + " + std::to_string(w) + ", " + val128 + ");"); });
+            amax = al.get(Prim::AMax, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "comet::acc_feed_amax(acc + " + std::to_string(w) + ", " + val128 + ");"); });
+            sflags = al.get(Prim::SignFlags, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] |= (" + val128 + " < 0) ? 2ull : ((" + val128 + " > 0) ? 1ull : 0ull);"); });
+          }
+          std::string W = std::to_string(sum.word), C = std::to_string(cnt.word);
+          // overflow decision → `ovf` (sticky NULL in the reference), `inexact` → host error
+          fin += "    {\n      i128 total = comet::mk128(acc[" + W + " + 1], acc[" + W + "]);\n      bool ovf = false;\n";
+          if (dynamic) {
+            std::string A = std::to_string(amax.word), F = std::to_string(sflags.word);
+            fin += "      comet::sum_overflow_decide(acc + " + W + ", acc + " + A + ", acc[" + F + "], acc[" + C + "], " + lit_u128(bound) +
+                   ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
+            g.uses_err = true;
+          }
+          if (!is_avg) {
+            // SumDecimalAccumulator::state (sum_decimal.rs:281-295): (sum | NULL if overflowed, is_empty)
+            fin += "      bool empty = acc[" + C + "] == 0;\n";
+            fin += "      ((i128*)" + out_val(out_j) + ")[0] = ovf ? (i128)0 : total;\n";
+            fin += "      ((u8*)" + out_ok(out_j) + ")[0] = ovf ? 0 : 1;\n";
+            fin += "      ((u8*)" + out_val(out_j + 1) + ")[0] = empty ? 1 : 0;\n    }\n";
+            OutCol s0; s0.type = st; s0.nullable = true;
+            OutCol s1; s1.type = DType::of(TypeId::Bool); s1.nullable = false;
+            d.out_cols.push_back(s0);
+            d.out_cols.push_back(s1);
+            out_j += 2;
+            ex << "  agg: sum_decimal -> (" << st.str() << ", is_empty)\n";
+          } else {
+            // AvgDecimalAccumulator::state (avg_decimal.rs:283-288): sum = None until the first value
+            fin += "      bool none = acc[" + C + "] == 0 || ovf;\n";
+            fin += "      ((i128*)" + out_val(out_j) + ")[0] = none ? (i128)0 : total;\n";
+            fin += "      ((u8*)" + out_ok(out_j) + ")[0] = none ? 0 : 1;\n";
+            fin += "      ((i64*)" + out_val(out_j + 1) + ")[0] = (i64)acc[" + C + "];\n";
+            fin += "      ((u8*)" + out_ok(out_j + 1) + ")[0] = 1;\n    }\n";
+            OutCol s0; s0.type = st; s0.nullable = true;
+            OutCol s1; s1.type = DType::of(TypeId::Int64); s1.nullable = true;
+            d.out_cols.push_back(s0);
+            d.out_cols.push_back(s1);
+            out_j += 2;
+            ex << "  agg: avg_decimal -> (" << st.str() << ", count)\n";
+          }
+        } else if (!is_avg && rt.is_integer()) {
+          // SumInteger LEGACY (sum_int.rs:117-160): wrapping i64, NULL until a non-null value arrives
+          if (!v.t.is_integer()) throw CometError("integer sum over " + v.t.str());
+          if (a.eval_mode != EvalMode::Legacy) throw CometError("ANSI/TRY integer sum is not supported in the GPU pipeline yet");
+          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += 1;"); });
+          PrimSlot sum = al.get(Prim::SumI64, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += (u64)(i64)" + v.v + ";"); });
+          fin += "    ((i64*)" + out_val(out_j) + ")[0] = acc[" + std::to_string(cnt.word) + "] ? (i64)acc[" + std::to_string(sum.word) + "] : 0;\n";
+          fin += "    ((u8*)" + out_ok(out_j) + ")[0] = acc[" + std::to_string(cnt.word) + "] ? 1 : 0;\n";
+          OutCol s0; s0.type = DType::of(TypeId::Int64); s0.nullable = true;
+          d.out_cols.push_back(s0);
+          out_j++;
+          ex << "  agg: sum_int -> Int64\n";
+        } else {
+          // float sum (DataFusion sum_udaf over Float64, planner.rs:2628-2634) / Avg (avg.rs): child cast to Float64
+          std::string dv;
+          if (v.rep == Rep::F64) dv = v.v;
+          else if (v.rep == Rep::F32 || v.rep == Rep::I32 || v.rep == Rep::I64) dv = "(double)" + v.v;
+          else throw CometError("float sum/avg over " + v.t.str() + " is not supported in the GPU pipeline yet");
+          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += 1;"); });
+          PrimSlot sum = al.get(Prim::SumF64, "f64:" + vkey, fkey, [&](int w) {
+            return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] = (u64)__double_as_longlong(comet::fp_add(__longlong_as_double((i64)acc[" + std::to_string(w) + "]), " + dv + "));");
+          });
+          std::string S = std::to_string(sum.word), C = std::to_string(cnt.word);
+          if (is_avg) {
+            // AvgAccumulator::state (avg.rs:139-144): sum is Some(0.0) once any batch arrived
+            fin += "    ((double*)" + out_val(out_j) + ")[0] = __longlong_as_double((i64)acc[" + S + "]);\n";
+            fin += "    ((u8*)" + out_ok(out_j) + ")[0] = acc[" + rowcnt_word + "] ? 1 : 0;\n";
+            fin += "    ((i64*)" + out_val(out_j + 1) + ")[0] = (i64)acc[" + C + "];\n";
+            fin += "    ((u8*)" + out_ok(out_j + 1) + ")[0] = 1;\n";
+            OutCol s0; s0.type = DType::of(TypeId::Double); s0.nullable = true;
+            OutCol s1; s1.type = DType::of(TypeId::Int64); s1.nullable = true;
+            d.out_cols.push_back(s0);
+            d.out_cols.push_back(s1);
+            out_j += 2;
+            ex << "  agg: avg_f64 -> (Float64, count)\n";
+          } else {
+            fin += "    ((double*)" + out_val(out_j) + ")[0] = __longlong_as_double((i64)acc[" + S + "]);\n";
+            fin += "    ((u8*)" + out_ok(out_j) + ")[0] = acc[" + C + "] ? 1 : 0;\n";
+            OutCol s0; s0.type = DType::of(TypeId::Double); s0.nullable = true;
+            d.out_cols.push_back(s0);
+            out_j++;
+            ex << "  agg: sum_f64 -> Float64\n";
+          }
+        }
+        break;
+      }
+      case AggKind::Min: case AggKind::Max: {
+        if (in.children.size() != 1) throw CometError("min/max expects one child");
+        Val v = g.named(g.gen(in.children[0]));
+        std::string vkey = g.key_of(in.children[0]);
+        const bool mn = a.kind == AggKind::Min;
+        if (!(v.t == a.dtype)) throw CometError("min/max with cast is not supported in the GPU pipeline yet");
+        PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += 1;"); });
+        PrimSlot s;
+        std::string rd;
+        const char* st = store_ctype(v.t);
+        if (v.rep == Rep::I32 || v.rep == Rep::I64) {
+          s = al.get(mn ? Prim::MinI64 : Prim::MaxI64, vkey, fkey, [&](int w) {
+            return cond_stmt(guarded(v.ok), "{ u64 t_ = (u64)(i64)" + v.v + "; comet::acc_" + (mn ? "imin64" : "imax64") + "(acc + " + std::to_string(w) + ", &t_); }");
+          });
+          rd = v.t.id == TypeId::Decimal ? "(i128)(i64)acc[" + std::to_string(s.word) + "]" : std::string("(") + st + ")(i64)acc[" + std::to_string(s.word) + "]";
+        } else if (v.rep == Rep::I128) {
+          s = al.get(mn ? Prim::MinI128 : Prim::MaxI128, vkey, fkey, [&](int w) {
+            return cond_stmt(guarded(v.ok), "{ u64 t_[2] = {comet::lo64(" + v.v + "), comet::hi64(" + v.v + ")}; comet::acc_" + (mn ? "imin128" : "imax128") + "(acc + " + std::to_string(w) + ", t_); }");
+          });
+          rd = "comet::mk128(acc[" + std::to_string(s.word) + " + 1], acc[" + std::to_string(s.word) + "])";
+        } else {
+          throw CometError("min/max over " + v.t.str() + " is not supported in the GPU pipeline yet");
+        }
+        std::string C = std::to_string(cnt.word);
+        fin += "    ((" + std::string(st) + "*)" + out_val(out_j) + ")[0] = acc[" + C + "] ? " + rd + " : (" + st + ")0;\n";
+        fin += "    ((u8*)" + out_ok(out_j) + ")[0] = acc[" + C + "] ? 1 : 0;\n";
+        OutCol s0; s0.type = v.t; s0.nullable = true;
+        d.out_cols.push_back(s0);
+        out_j++;
+        ex << "  agg: " << (mn ? "min" : "max") << " -> " << v.t.str() << "\n";
+        break;
+      }
+      default:
+        throw CometError("Aggregate function (tag " + std::to_string(a.proto_tag) + ") is not supported by the MI355X native engine");
+    }
+  }
+  if (d.out_cols.size() * 2 + kOutFirstCol > COMET_MAX_OUT) throw CometError("too many aggregate state columns for one GPU pipeline");
+  d.NW = al.nw;
+  d.R = 4;
+  d.max_rows_exact = max_rows_exact;
+  d.in_used = g.in_used;
+  src << "struct P {\n  static constexpr int R = " << d.R << ";\n  static constexpr int NW = " << d.NW << ";\n";
+  src << "  static __device__ __forceinline__ void init(u64* a) {\n" << al.init_code << "  }\n";
+  src << "  static __device__ __forceinline__ void combine(u64* a, const u64* b) {\n" << al.combine_code << "  }\n";
+  src << "  static __device__ __forceinline__ void tile(const CometKParams& prm, i64 base, i64 n, u64* acc) {\n"
+      << "    bool k[R]; i64 idx[R];\n"
+      << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n"
+      << g.decls << g.body() << "  }\n";
+  src << "  static __device__ __forceinline__ void finalize(const CometKParams& prm, const u64* acc) {\n" << fin << "  }\n};\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg(const CometKParams prm) { comet::agg_nogroup_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg_final(const CometKParams prm) { comet::agg_nogroup_final_body<P>(prm); }\n";
+  d.kernels = {"k_agg", "k_agg_final"};
+  d.source = src.str();
+  d.explain = ex.str();
+  return d;
+}
+
+}  // namespace comet

@@ -1,0 +1,51 @@
+// Planner + code generator: proto plan IR → fused pipeline description + HIP source whose only
+// plan-specific part is the per-row expression functor; the kernels themselves are the hand-written
+// templates of device/comet_device.hpp.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "plan.hpp"
+
+namespace comet {
+
+enum class SinkKind { Output, AggNoGroup, AggGrouped };
+
+struct OutCol {
+  DType type;
+  bool nullable = true;
+  // AggGrouped string keys come back packed (≤7 bytes + length) in a u64; host expands to Utf8.
+  bool packed_string = false;
+};
+
+// How the host must treat each group-key word / accumulator word of a grouped aggregate.
+struct PipelineDesc {
+  SinkKind sink = SinkKind::Output;
+  bool has_filter = false;
+  int R = 4;                       // rows per thread per tile
+  int NW = 0;                      // accumulator words (aggregates)
+  int NK = 0;                      // key words (grouped)
+  int lds_cap = 0;
+  std::vector<DType> in_types;     // Scan fields
+  std::vector<bool> in_used;       // columns the kernels actually read
+  std::vector<OutCol> out_cols;    // output schema in order
+  std::string source;              // full HIP translation unit
+  std::vector<std::string> kernels;  // extern "C" kernel names present in `source`
+  // static row bound under which decimal sums cannot overflow (Appendix C.1 rule); 0 = no limit
+  long long max_rows_exact = 0;
+  std::string explain;             // human-readable fused plan
+  std::vector<std::string> op_names;  // operator names root→leaf (metrics tree / tracing label)
+};
+
+// `in_has_validity[i]` tells whether input column i arrives with a validity bitmap in this batch
+// chunk; kernels are specialised on it.  Throws CometError for unsupported plans.
+PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity);
+
+// index of out[] slots used by the generated kernels (must match exec.cpp)
+constexpr int kOutPartials = 0;      // AggNoGroup: partials;  Output: mask words
+constexpr int kOutCounts = 1;        // Output: tile counts / offsets
+constexpr int kOutErr = 2;           // u32[4] error flags (ANSI overflow etc.)
+constexpr int kOutFirstCol = 4;      // out[4+2j] = values of col j, out[5+2j] = validity bytes of col j
+
+}  // namespace comet

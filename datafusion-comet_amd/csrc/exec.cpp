@@ -1,0 +1,664 @@
+#include "exec.hpp"
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+namespace comet {
+
+// ---------------------------------------------------------------------------------------------
+// buffers
+// ---------------------------------------------------------------------------------------------
+void DevBuf::ensure(size_t n) {
+  if (n <= cap) return;
+  release();
+  size_t want = n < 256 ? 256 : n;
+  HIP_CHECK(hipMalloc(&p, want));
+  cap = want;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+void PinnedBuf::ensure(size_t n) {
+  if (n <= cap) return;
+  release();
+  size_t want = n < 256 ? 256 : n;
+  HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+  cap = want;
+}
+void PinnedBuf::release() {
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+namespace {
+
+int fixed_width(const DType& t) {
+  switch (t.id) {
+    case TypeId::Int8: return 1;
+    case TypeId::Int16: return 2;
+    case TypeId::Int32: case TypeId::Date: case TypeId::Float: return 4;
+    case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: case TypeId::Double: return 8;
+    case TypeId::Decimal: return 16;
+    case TypeId::Bool: return 0;  // bit-packed
+    default: throw CometError("Unsupported column type in GPU scan: " + t.str());
+  }
+}
+
+// append n bits from src (starting at bit src_off) to dst at bit dst_off
+void bit_append(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t src_off, int64_t n) {
+  if (n <= 0) return;
+  if ((dst_off & 7) == 0 && (src_off & 7) == 0) {
+    int64_t full = n >> 3;
+    memcpy(dst + (dst_off >> 3), src + (src_off >> 3), (size_t)full);
+    int64_t rem = n & 7;
+    if (rem) {
+      uint8_t m = (uint8_t)((1u << rem) - 1);
+      uint8_t& d = dst[(dst_off >> 3) + full];
+      d = (uint8_t)((d & ~m) | (src[(src_off >> 3) + full] & m));
+    }
+    return;
+  }
+  for (int64_t i = 0; i < n; i++) {
+    int64_t s = src_off + i, d = dst_off + i;
+    uint8_t bit = (src[s >> 3] >> (s & 7)) & 1;
+    if (bit) dst[d >> 3] |= (uint8_t)(1u << (d & 7));
+    else dst[d >> 3] &= (uint8_t)~(1u << (d & 7));
+  }
+}
+void bit_fill_ones(uint8_t* dst, int64_t dst_off, int64_t n) {
+  for (int64_t i = 0; i < n;) {
+    int64_t d = dst_off + i;
+    if ((d & 7) == 0 && n - i >= 8) {
+      int64_t full = (n - i) >> 3;
+      memset(dst + (d >> 3), 0xff, (size_t)full);
+      i += full * 8;
+    } else {
+      dst[d >> 3] |= (uint8_t)(1u << (d & 7));
+      i++;
+    }
+  }
+}
+
+std::string expected_format(const DType& t) {
+  switch (t.id) {
+    case TypeId::Bool: return "b";
+    case TypeId::Int8: return "c";
+    case TypeId::Int16: return "s";
+    case TypeId::Int32: return "i";
+    case TypeId::Int64: return "l";
+    case TypeId::Float: return "f";
+    case TypeId::Double: return "g";
+    case TypeId::Date: return "tdD";
+    case TypeId::Timestamp: return "tsu:UTC";
+    case TypeId::TimestampNtz: return "tsu:";
+    case TypeId::String: return "u";
+    case TypeId::Bytes: return "z";
+    case TypeId::Decimal: return "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale);
+    default: return "?";
+  }
+}
+
+bool format_matches(const char* fmt, const DType& t) {
+  if (!fmt) return false;
+  std::string f = fmt;
+  if (t.id == TypeId::Timestamp) return f.rfind("tsu:", 0) == 0 && f.size() > 4;
+  if (t.id == TypeId::Decimal) {
+    std::string e = expected_format(t);
+    return f == e || f == e + ",128";
+  }
+  return f == expected_format(t);
+}
+
+const Operator* find_scan(const Operator* op) {
+  while (op && op->kind != OpKind::Scan) {
+    if (op->children.empty()) return nullptr;
+    op = op->children[0].get();
+  }
+  return op;
+}
+
+std::string validity_key(const std::vector<bool>& v) {
+  std::string k;
+  for (bool b : v) k.push_back(b ? '1' : '0');
+  return k;
+}
+
+struct Timer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ns() const { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+ExecutionContext::ExecutionContext(OperatorP plan, std::vector<std::pair<std::string, std::string>> config,
+                                   std::vector<InputSource> inputs, int batch_size, int device_id)
+    : plan_(std::move(plan)), config_(std::move(config)), inputs_(std::move(inputs)), batch_size_(batch_size), device_id_(device_id) {
+  chunk_rows_ = 4 << 20;
+  for (auto& kv : config_) {
+    if (kv.first == "spark.comet.gpu.chunkRows") chunk_rows_ = std::max<long long>(1024, atoll(kv.second.c_str()));
+  }
+  if (const char* e = getenv("COMET_GPU_CHUNK_ROWS")) chunk_rows_ = std::max<long long>(1024, atoll(e));
+  const Operator* scan = find_scan(plan_.get());
+  if (!scan) throw CometError("Plan has no Scan leaf: only Scan-rooted pipelines are supported by the MI355X native engine");
+  in_types_ = scan->scan_fields;
+  if (inputs_.size() != 1) throw CometError("Expected exactly one input stream for a single-Scan plan, got " + std::to_string(inputs_.size()));
+  // Validate the plan shape eagerly (all-valid variant is generated, not compiled) so that
+  // unsupported operators fail at createPlan like the reference's planner would on first execute.
+  std::vector<bool> none(in_types_.size(), false);
+  PipelineDesc d = generate_pipeline(*plan_, none);
+  explain_ = d.explain;
+  sink_ = d.sink;
+}
+
+ExecutionContext::~ExecutionContext() {
+  // Dropping the context releases the input streams back to their producer (scan.rs:41-44).
+  for (auto& in : inputs_) {
+    if (in.host && in.host->release) in.host->release(in.host);
+    if (in.dev && in.dev->release) in.dev->release(in.dev);
+  }
+  if (ev_start_) (void)hipEventDestroy(ev_start_);
+  if (ev_stop_) (void)hipEventDestroy(ev_stop_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+const std::string& ExecutionContext::explain() { return explain_; }
+
+std::string ExecutionContext::compile_only(const Operator& plan) {
+  const Operator* scan = find_scan(&plan);
+  if (!scan) throw CometError("Plan has no Scan leaf");
+  std::vector<bool> none(scan->scan_fields.size(), false);
+  PipelineDesc d = generate_pipeline(plan, none);
+  jit_compile(d.source);
+  return d.explain;
+}
+
+Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid) {
+  std::string key = validity_key(has_valid);
+  auto it = variants_.find(key);
+  if (it != variants_.end()) return it->second;
+  Variant v;
+  v.desc = generate_pipeline(*plan_, has_valid);
+  auto co = jit_compile(v.desc.source);
+  v.mod = jit_load(co);
+  auto res = variants_.emplace(key, std::move(v));
+  return res.first->second;
+}
+
+void ExecutionContext::launch(Variant& v, const char* kernel, int grid, CometKParams& prm) {
+  hipFunction_t fn = v.mod->fn(kernel);
+  void* args[] = {&prm};
+  HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream_, args, nullptr));
+}
+
+// one chunk of input rows resident in HBM → run the fused pipeline on it
+void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n) {
+  if (n == 0) return;
+  Variant& v = variant_for(has_valid);
+  const PipelineDesc& d = v.desc;
+  if (d.max_rows_exact && input_rows + n > d.max_rows_exact)
+    throw CometError("decimal sum over more rows than the exactness bound allows (" + std::to_string(d.max_rows_exact) + ")");
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  prm.n = n;
+  for (size_t i = 0; i < cols.size(); i++) {
+    prm.in[i].data = cols[i].data;
+    prm.in[i].valid = has_valid[i] ? cols[i].valid : nullptr;
+    prm.in[i].aux = cols[i].aux;
+    prm.in[i].offset = cols[i].offset;
+  }
+  err_flags_.ensure(16);
+  prm.out[kOutErr] = err_flags_.p;
+  input_rows += n;
+
+  if (d.sink == SinkKind::AggNoGroup) {
+    if (agg_variant_ && agg_variant_->desc.NW != d.NW) throw CometError("internal: accumulator layout differs between variants");
+    agg_variant_ = &v;
+    const int64_t tile = (int64_t)d.R * 256;
+    int grid = (int)std::min<int64_t>((n + tile - 1) / tile, 256 * 8);
+    size_t need = (size_t)(n_partials_ + grid) * d.NW * 8;
+    if (need > partials_.cap) {
+      DevBuf bigger;
+      bigger.ensure(std::max(need * 2, (size_t)(4096 * d.NW * 8)));
+      if (n_partials_) HIP_CHECK(hipMemcpyAsync(bigger.p, partials_.p, (size_t)n_partials_ * d.NW * 8, hipMemcpyDeviceToDevice, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      std::swap(partials_.p, bigger.p);
+      std::swap(partials_.cap, bigger.cap);
+    }
+    prm.out[kOutPartials] = (char*)partials_.p + (size_t)n_partials_ * d.NW * 8;
+    HIP_CHECK(hipEventRecord(ev_start_, stream_));
+    launch(v, "k_agg", grid, prm);
+    HIP_CHECK(hipEventRecord(ev_stop_, stream_));
+    HIP_CHECK(hipEventSynchronize(ev_stop_));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev_start_, ev_stop_));
+    last_kernel_ms += ms;
+    last_kernel_launches++;
+    n_partials_ += grid;
+    return;
+  }
+
+  if (d.sink == SinkKind::Output) {
+    const size_t ncol = d.out_cols.size();
+    const int64_t ntiles = (n + 1023) / 1024;
+    int64_t out_rows = n;
+    if (out_vals_.size() < ncol) {
+      out_vals_.resize(ncol);
+      out_valid_.resize(ncol);
+      for (size_t j = 0; j < ncol; j++) {
+        if (!out_vals_[j]) out_vals_[j].reset(new DevBuf());
+        if (!out_valid_[j]) out_valid_[j].reset(new DevBuf());
+      }
+    }
+    auto bind_outputs = [&](int64_t rows_cap) {
+      for (size_t j = 0; j < ncol; j++) {
+        int w = d.out_cols[j].type.id == TypeId::Bool ? 1 : fixed_width(d.out_cols[j].type);
+        out_vals_[j]->ensure((size_t)rows_cap * w + 16);
+        prm.out[kOutFirstCol + 2 * j] = out_vals_[j]->p;
+        if (d.out_cols[j].nullable) {
+          out_valid_[j]->ensure((size_t)rows_cap + 16);
+          prm.out[kOutFirstCol + 2 * j + 1] = out_valid_[j]->p;
+        }
+      }
+    };
+    HIP_CHECK(hipEventRecord(ev_start_, stream_));
+    if (d.has_filter) {
+      scratch_mask_.ensure((size_t)((n + 63) / 64) * 8 + 64);
+      scratch_counts_.ensure((size_t)(ntiles + 1) * 8);
+      prm.out[0] = scratch_mask_.p;
+      prm.out[1] = scratch_counts_.p;
+      int grid = (int)std::min<int64_t>(ntiles, 256 * 8);
+      launch(v, "k_mask", grid, prm);
+      prm.iarg[0] = ntiles;
+      launch(v, "k_scan", 1, prm);
+      uint64_t total = 0;
+      HIP_CHECK(hipMemcpyAsync(&total, (char*)scratch_counts_.p + (size_t)ntiles * 8, 8, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      out_rows = (int64_t)total;
+      if (out_rows > 0) {
+        bind_outputs(out_rows);
+        launch(v, "k_emit", grid, prm);
+      }
+    } else {
+      bind_outputs(n);
+      int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+      launch(v, "k_emit", grid, prm);
+    }
+    HIP_CHECK(hipEventRecord(ev_stop_, stream_));
+    HIP_CHECK(hipEventSynchronize(ev_stop_));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev_start_, ev_stop_));
+    last_kernel_ms += ms;
+    last_kernel_launches++;
+    check_device_errors();
+    if (out_rows == 0) return;
+    // device → host, then cut into batches of at most batch_size rows (FilterExec coalesces toward
+    // the configured batch size; planner.rs:4688-4689)
+    std::vector<std::vector<uint8_t>> hv(ncol), hk(ncol);
+    for (size_t j = 0; j < ncol; j++) {
+      int w = d.out_cols[j].type.id == TypeId::Bool ? 1 : fixed_width(d.out_cols[j].type);
+      hv[j].resize((size_t)out_rows * w);
+      HIP_CHECK(hipMemcpyAsync(hv[j].data(), out_vals_[j]->p, hv[j].size(), hipMemcpyDeviceToHost, stream_));
+      if (d.out_cols[j].nullable) {
+        hk[j].resize((size_t)out_rows);
+        HIP_CHECK(hipMemcpyAsync(hk[j].data(), out_valid_[j]->p, hk[j].size(), hipMemcpyDeviceToHost, stream_));
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    const int64_t bs = batch_size_ > 0 ? batch_size_ : out_rows;
+    for (int64_t off = 0; off < out_rows; off += bs) {
+      int64_t len = std::min(bs, out_rows - off);
+      HostBatch b;
+      b.rows = len;
+      for (size_t j = 0; j < ncol; j++) {
+        HostColumn c;
+        c.type = d.out_cols[j].type;
+        c.length = len;
+        if (c.type.id == TypeId::Bool) {
+          c.values.assign((size_t)((len + 7) / 8), 0);
+          for (int64_t i = 0; i < len; i++)
+            if (hv[j][(size_t)(off + i)]) c.values[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+        } else {
+          int w = fixed_width(c.type);
+          c.values.assign(hv[j].begin() + (size_t)off * w, hv[j].begin() + (size_t)(off + len) * w);
+        }
+        if (d.out_cols[j].nullable) {
+          int64_t nulls = 0;
+          std::vector<uint8_t> bm((size_t)((len + 7) / 8), 0);
+          for (int64_t i = 0; i < len; i++) {
+            if (hk[j][(size_t)(off + i)]) bm[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+            else nulls++;
+          }
+          c.null_count = nulls;
+          if (nulls) c.validity = std::move(bm);
+        }
+        b.cols.push_back(std::move(c));
+      }
+      ready_.push_back(std::move(b));
+    }
+    return;
+  }
+  throw CometError("internal: unsupported sink");
+}
+
+void ExecutionContext::check_device_errors() {
+  if (!err_flags_.p) return;
+  uint32_t flags[4] = {0, 0, 0, 0};
+  HIP_CHECK(hipMemcpyAsync(flags, err_flags_.p, 16, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  uint32_t f = flags[0];
+  if (!f) return;
+  // Spark error JSON as thrown through CometQueryExecutionException (native/common/src/error.rs:806-831)
+  if (f & 1u) throw CometError("{\"errorType\":\"ArithmeticOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"fromType\":\"decimal\"}}", 1);
+  if (f & 2u) throw CometError("{\"errorType\":\"ArithmeticOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"fromType\":\"integer\"}}", 1);
+  if (f & 4u) throw CometError("{\"errorType\":\"CastOverFlow\",\"errorClass\":\"CAST_OVERFLOW\",\"params\":{}}", 1);
+  if (f & 8u) throw CometError("{\"errorType\":\"NumericValueOutOfRange\",\"errorClass\":\"NUMERIC_VALUE_OUT_OF_RANGE\",\"params\":{}}", 1);
+  if (f & 16u)
+    throw CometError("decimal sum overflow cannot be decided order-independently for this input (mixed signs beyond the precision bound); "
+                     "exact sequential evaluation is not implemented");
+  throw CometError("device error flags " + std::to_string(f));
+}
+
+void ExecutionContext::finish_aggregate() {
+  // AggregateExec emits one state row even for empty input
+  std::vector<bool> none(in_types_.size(), false);
+  Variant& v = agg_variant_ ? *agg_variant_ : variant_for(none);
+  const PipelineDesc& d = v.desc;
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  partials_.ensure(64);
+  err_flags_.ensure(16);
+  prm.out[kOutPartials] = partials_.p;
+  prm.out[kOutErr] = err_flags_.p;
+  prm.iarg[0] = n_partials_;
+  const size_t ncol = d.out_cols.size();
+  out_vals_.resize(ncol);
+  out_valid_.resize(ncol);
+  for (size_t j = 0; j < ncol; j++) {
+    if (!out_vals_[j]) out_vals_[j].reset(new DevBuf());
+    if (!out_valid_[j]) out_valid_[j].reset(new DevBuf());
+    out_vals_[j]->ensure(64);
+    out_valid_[j]->ensure(64);
+    HIP_CHECK(hipMemsetAsync(out_valid_[j]->p, 1, 8, stream_));
+    prm.out[kOutFirstCol + 2 * j] = out_vals_[j]->p;
+    prm.out[kOutFirstCol + 2 * j + 1] = out_valid_[j]->p;
+  }
+  launch(v, "k_agg_final", 1, prm);
+  HostBatch b;
+  b.rows = 1;
+  std::vector<std::vector<uint8_t>> hv(ncol), hk(ncol);
+  for (size_t j = 0; j < ncol; j++) {
+    hv[j].resize(16);
+    hk[j].resize(8);
+    HIP_CHECK(hipMemcpyAsync(hv[j].data(), out_vals_[j]->p, 16, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(hk[j].data(), out_valid_[j]->p, 8, hipMemcpyDeviceToHost, stream_));
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  for (size_t j = 0; j < ncol; j++) {
+    HostColumn c;
+    c.type = d.out_cols[j].type;
+    c.length = 1;
+    if (c.type.id == TypeId::Bool) {
+      c.values.assign(1, hv[j][0] ? 1 : 0);
+    } else {
+      int w = fixed_width(c.type);
+      c.values.assign(hv[j].begin(), hv[j].begin() + w);
+    }
+    if (d.out_cols[j].nullable && hk[j][0] == 0) {
+      c.null_count = 1;
+      c.validity.assign(1, 0);
+    }
+    b.cols.push_back(std::move(c));
+  }
+  ready_.push_back(std::move(b));
+}
+
+// Pull host batches from the JVM stream until a chunk is full; copy through pinned staging to HBM.
+bool ExecutionContext::pull_host_chunk() {
+  InputSource& in = inputs_[0];
+  if (in.exhausted) return false;
+  const size_t nc = in_types_.size();
+  if (stage_vals_.size() != nc) {
+    stage_vals_.resize(nc);
+    stage_valid_.resize(nc);
+    dev_vals_.resize(nc);
+    dev_valid_.resize(nc);
+    for (size_t c = 0; c < nc; c++) {
+      stage_vals_[c].reset(new PinnedBuf());
+      stage_valid_[c].reset(new PinnedBuf());
+      dev_vals_[c].reset(new DevBuf());
+      dev_valid_[c].reset(new DevBuf());
+    }
+  }
+  int64_t rows = 0;
+  std::vector<bool> has_valid(nc, false);
+  std::vector<ArrowArray> held;
+  // gather batches first so that staging buffers can be sized once
+  while (rows < chunk_rows_) {
+    ArrowArray arr;
+    memset(&arr, 0, sizeof arr);
+    int rc = in.host->get_next(in.host, &arr);
+    if (rc != 0) {
+      const char* m = in.host->get_last_error ? in.host->get_last_error(in.host) : nullptr;
+      for (auto& a : held) if (a.release) a.release(&a);
+      throw CometError(std::string("input ArrowArrayStream.get_next failed: ") + (m ? m : "unknown error"));
+    }
+    if (!arr.release) {  // end of stream
+      in.exhausted = true;
+      break;
+    }
+    if ((size_t)arr.n_children != nc) {
+      std::string msg = "input batch has " + std::to_string(arr.n_children) + " columns, Scan declares " + std::to_string(nc);
+      arr.release(&arr);
+      for (auto& a : held) if (a.release) a.release(&a);
+      throw CometError(msg);
+    }
+    rows += arr.length;
+    held.push_back(arr);
+  }
+  if (rows == 0) {
+    for (auto& a : held) if (a.release) a.release(&a);
+    return !in.exhausted;
+  }
+  for (auto& a : held)
+    for (size_t c = 0; c < nc; c++)
+      if (a.children[c]->null_count != 0 && a.children[c]->buffers[0]) has_valid[c] = true;
+  for (size_t c = 0; c < nc; c++) {
+    const DType& t = in_types_[c];
+    const int w = fixed_width(t);
+    size_t vbytes = w ? (size_t)rows * w : (size_t)((rows + 7) / 8);
+    stage_vals_[c]->ensure(vbytes + 16);
+    if (has_valid[c]) stage_valid_[c]->ensure((size_t)((rows + 7) / 8) + 16);
+    int64_t at = 0;
+    for (auto& a : held) {
+      const ArrowArray* col = a.children[c];
+      if (col->dictionary) throw CometError("dictionary-encoded input columns are not unpacked on the GPU path yet");
+      const int64_t len = col->length, off = col->offset;
+      if (len != a.length) throw CometError("ragged input batch");
+      if (w) {
+        // Decimal128 buffers from the JVM may be only 8-byte aligned (aligned_stream_reader.rs:95-107);
+        // the staging copy realigns them.
+        memcpy((char*)stage_vals_[c]->p + (size_t)at * w, (const char*)col->buffers[1] + (size_t)off * w, (size_t)len * w);
+      } else {
+        bit_append((uint8_t*)stage_vals_[c]->p, at, (const uint8_t*)col->buffers[1], off, len);
+      }
+      if (has_valid[c]) {
+        if (col->null_count != 0 && col->buffers[0]) bit_append((uint8_t*)stage_valid_[c]->p, at, (const uint8_t*)col->buffers[0], off, len);
+        else bit_fill_ones((uint8_t*)stage_valid_[c]->p, at, len);
+      }
+      at += len;
+    }
+    dev_vals_[c]->ensure(vbytes + 16);
+    HIP_CHECK(hipMemcpyAsync(dev_vals_[c]->p, stage_vals_[c]->p, vbytes, hipMemcpyHostToDevice, stream_));
+    if (has_valid[c]) {
+      size_t kb = (size_t)((rows + 7) / 8);
+      dev_valid_[c]->ensure(kb + 16);
+      HIP_CHECK(hipMemcpyAsync(dev_valid_[c]->p, stage_valid_[c]->p, kb, hipMemcpyHostToDevice, stream_));
+    }
+  }
+  for (auto& a : held) if (a.release) a.release(&a);
+  std::vector<DeviceColumnView> views(nc);
+  for (size_t c = 0; c < nc; c++) {
+    views[c].data = dev_vals_[c]->p;
+    views[c].valid = has_valid[c] ? (const uint8_t*)dev_valid_[c]->p : nullptr;
+  }
+  process_chunk(views, has_valid, rows);
+  return !in.exhausted;
+}
+
+// HBM-resident input (Arrow C Device stream, ARROW_DEVICE_ROCM): zero copy.
+bool ExecutionContext::pull_device_batch() {
+  InputSource& in = inputs_[0];
+  if (in.exhausted) return false;
+  ArrowDeviceArray da;
+  memset(&da, 0, sizeof da);
+  int rc = in.dev->get_next(in.dev, &da);
+  if (rc != 0) {
+    const char* m = in.dev->get_last_error ? in.dev->get_last_error(in.dev) : nullptr;
+    throw CometError(std::string("input ArrowDeviceArrayStream.get_next failed: ") + (m ? m : "unknown error"));
+  }
+  if (!da.array.release) {
+    in.exhausted = true;
+    return false;
+  }
+  struct Guard {
+    ArrowArray* a;
+    ~Guard() { if (a->release) a->release(a); }
+  } guard{&da.array};
+  if (da.device_type != ARROW_DEVICE_ROCM && da.device_type != ARROW_DEVICE_ROCM_HOST)
+    throw CometError("device input stream must carry ARROW_DEVICE_ROCM memory");
+  if (da.sync_event) HIP_CHECK(hipStreamWaitEvent(stream_, *(hipEvent_t*)da.sync_event, 0));
+  const size_t nc = in_types_.size();
+  if ((size_t)da.array.n_children != nc) throw CometError("device batch column count does not match Scan fields");
+  std::vector<DeviceColumnView> views(nc);
+  std::vector<bool> has_valid(nc, false);
+  for (size_t c = 0; c < nc; c++) {
+    const ArrowArray* col = da.array.children[c];
+    if (col->dictionary) throw CometError("dictionary-encoded device columns are not supported yet");
+    views[c].data = col->buffers[1];
+    views[c].offset = col->offset;
+    if (in_types_[c].id == TypeId::Decimal && (((uintptr_t)col->buffers[1]) & 15))
+      throw CometError("device Decimal128 buffers must be 16-byte aligned");
+    if (col->null_count != 0 && col->buffers[0]) {
+      has_valid[c] = true;
+      views[c].valid = (const uint8_t*)col->buffers[0];
+    }
+  }
+  process_chunk(views, has_valid, da.array.length);
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  return true;
+}
+
+void ExecutionContext::run_to_completion() {
+  // ungrouped / grouped aggregates are pipeline breakers: drain the input completely
+  while (true) {
+    bool more = inputs_[0].kind == 0 ? pull_host_chunk() : pull_device_batch();
+    if (!more) break;
+  }
+}
+
+int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
+  Timer t;
+  if (!started_) {
+    // Lazy start like the reference (jni_api.rs:795-872): nothing touches the input before the first executePlan.
+    HIP_CHECK(hipSetDevice(device_id_));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreate(&ev_start_));
+    HIP_CHECK(hipEventCreate(&ev_stop_));
+    err_flags_.ensure(16);
+    HIP_CHECK(hipMemsetAsync(err_flags_.p, 0, 16, stream_));
+    started_ = true;
+  } else {
+    HIP_CHECK(hipSetDevice(device_id_));
+  }
+  const bool is_agg = sink_ != SinkKind::Output;
+  if (!finished_) {
+    if (is_agg) {
+      run_to_completion();
+      finish_aggregate();
+      finished_ = true;
+    } else {
+      while (ready_.empty() && !finished_) {
+        bool more = inputs_[0].kind == 0 ? pull_host_chunk() : pull_device_batch();
+        if (!more) finished_ = true;
+      }
+    }
+  }
+  elapsed_compute_ns_ += t.ns();
+  if (ready_.empty()) return -1;
+  HostBatch b = std::move(ready_.front());
+  ready_.pop_front();
+  export_batch(b, out_arrays, out_schemas, n_out);
+  output_rows_ += b.rows;
+  return b.rows;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Arrow C Data export (prepare_output, jni_api.rs:674-742): one moved ArrowArray + ArrowSchema per
+// output column, offset 0, buffers owned by the array until the consumer calls release.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ExportedColumn {
+  HostColumn col;
+  const void* buffers[3];
+  std::string format;
+};
+void release_array(ArrowArray* a) {
+  delete (ExportedColumn*)a->private_data;
+  a->release = nullptr;
+}
+void release_schema(ArrowSchema* s) {
+  delete (std::string*)s->private_data;
+  s->release = nullptr;
+}
+}  // namespace
+
+void ExecutionContext::export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
+  if ((size_t)n_out != b.cols.size())
+    throw CometError("Output column count mismatch: expected " + std::to_string(n_out) + ", got " + std::to_string(b.cols.size()));
+  for (int j = 0; j < n_out; j++) {
+    auto* ec = new ExportedColumn();
+    ec->col = std::move(b.cols[j]);
+    ec->format = expected_format(ec->col.type);
+    ArrowArray* a = out_arrays[j];
+    memset(a, 0, sizeof *a);
+    a->length = ec->col.length;
+    a->null_count = ec->col.null_count;
+    a->offset = 0;
+    a->n_buffers = 2;
+    ec->buffers[0] = ec->col.null_count ? ec->col.validity.data() : nullptr;
+    ec->buffers[1] = ec->col.values.data();
+    a->buffers = ec->buffers;
+    a->private_data = ec;
+    a->release = release_array;
+    ArrowSchema* s = out_schemas[j];
+    memset(s, 0, sizeof *s);
+    auto* fmt = new std::string(ec->format);
+    s->format = fmt->c_str();
+    s->name = "";
+    s->flags = ARROW_FLAG_NULLABLE;
+    s->private_data = fmt;
+    s->release = release_schema;
+  }
+}
+
+std::string ExecutionContext::metrics_proto() {
+  // tree mirrors the Operator tree (metrics/utils.rs:30-45); per-node attribution of a fused pipeline:
+  // the root carries the measured values, fused children report zero time and their row counts unknown (0).
+  std::function<MetricNode(const Operator&, bool)> build = [&](const Operator& op, bool root) {
+    MetricNode n;
+    n.metrics.emplace_back("output_rows", root ? output_rows_ : 0);
+    n.metrics.emplace_back("elapsed_compute", root ? (int64_t)elapsed_compute_ns_ : 0);
+    for (auto& c : op.children) n.children.push_back(build(*c, false));
+    return n;
+  };
+  return encode_metric_node(build(*plan_, true));
+}
+
+}  // namespace comet

@@ -1,0 +1,137 @@
+// Execution context: the MI355X counterpart of the reference's ExecutionContext
+// (native/core/src/execution/jni_api.rs:306-365) — one per Spark task / plan handle.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "arrow_abi.hpp"
+#include "codegen.hpp"
+#include "jit.hpp"
+#include "kparams.h"
+#include "plan.hpp"
+
+namespace comet {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n);
+  void release();
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n);
+  void release();
+  ~PinnedBuf() { release(); }
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+};
+
+// one host-side result batch, buffers malloc'ed, exported through the Arrow C Data interface
+struct HostColumn {
+  DType type;
+  int64_t length = 0;
+  int64_t null_count = 0;
+  std::vector<uint8_t> validity;  // bitmap, empty if null_count == 0
+  std::vector<uint8_t> values;    // fixed width values / bit-packed booleans / int32 offsets (Utf8)
+  std::vector<uint8_t> data;      // Utf8 bytes
+};
+struct HostBatch {
+  int64_t rows = 0;
+  std::vector<HostColumn> cols;
+};
+
+struct InputSource {
+  int kind = 0;  // 0 = ArrowArrayStream (host memory), 1 = ArrowDeviceArrayStream (HBM resident)
+  ArrowArrayStream* host = nullptr;
+  ArrowDeviceArrayStream* dev = nullptr;
+  bool exhausted = false;
+};
+
+struct DeviceColumnView {
+  const void* data = nullptr;
+  const uint8_t* valid = nullptr;
+  const void* aux = nullptr;
+  int64_t offset = 0;
+};
+
+struct Variant {  // one JIT specialisation of the pipeline (per input-validity pattern)
+  PipelineDesc desc;
+  std::shared_ptr<LoadedModule> mod;
+};
+
+class ExecutionContext {
+ public:
+  ExecutionContext(OperatorP plan, std::vector<std::pair<std::string, std::string>> config,
+                   std::vector<InputSource> inputs, int batch_size, int device_id);
+  ~ExecutionContext();
+
+  // returns rows of the exported batch, or -1 at end of stream
+  int64_t execute(ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
+  std::string metrics_proto();
+  const std::string& explain();
+  // CPU-only: plan + generate + hiprtc-compile the all-valid variant (used by build()/tests w/o GPU)
+  static std::string compile_only(const Operator& plan);
+
+  std::string last_error;
+  int last_error_kind = 0;
+
+  // timing of the last run (for bench.py): device time of the main kernels measured with HIP events
+  double last_kernel_ms = 0;
+  int64_t last_kernel_launches = 0;
+  int64_t input_rows = 0;
+
+ private:
+  void run_to_completion();
+  Variant& variant_for(const std::vector<bool>& has_valid);
+  void process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n);
+  void finish_aggregate();
+  bool pull_host_chunk();
+  bool pull_device_batch();
+  void export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
+  void check_device_errors();
+  void launch(Variant& v, const char* kernel, int grid, CometKParams& prm);
+
+  OperatorP plan_;
+  std::vector<std::pair<std::string, std::string>> config_;
+  std::vector<InputSource> inputs_;
+  int batch_size_;
+  int device_id_;
+  int64_t chunk_rows_;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
+  bool started_ = false, finished_ = false;
+  std::vector<DType> in_types_;
+  std::map<std::string, Variant> variants_;
+  Variant* agg_variant_ = nullptr;   // variant whose accumulator layout the partials follow
+  std::string explain_;
+  SinkKind sink_ = SinkKind::Output;
+
+  // host→device staging (one chunk at a time)
+  std::vector<std::unique_ptr<PinnedBuf>> stage_vals_, stage_valid_;
+  std::vector<std::unique_ptr<DevBuf>> dev_vals_, dev_valid_;
+
+  // aggregate state
+  DevBuf partials_;
+  int64_t n_partials_ = 0;
+  DevBuf err_flags_;
+  DevBuf scratch_mask_, scratch_counts_;
+  std::vector<std::unique_ptr<DevBuf>> out_vals_, out_valid_;
+
+  std::deque<HostBatch> ready_;
+  int64_t output_rows_ = 0;
+  double elapsed_compute_ns_ = 0;
+};
+
+}  // namespace comet

@@ -1,0 +1,156 @@
+#include "jit.hpp"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+
+#include "plan.hpp"
+
+namespace comet {
+
+// device/comet_device.hpp and kparams.h embedded at build time (see Makefile: embedded_headers.inc)
+extern const char* const kEmbeddedDeviceHeader;
+extern const char* const kEmbeddedKParamsHeader;
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) {
+    throw CometError(std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") in " + what);
+  }
+}
+
+namespace {
+
+uint64_t fnv1a(const std::string& s, uint64_t h = 0xcbf29ce484222325ull) {
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 0x100000001b3ull;
+  }
+  return h;
+}
+
+std::string cache_dir() {
+  if (const char* e = getenv("COMET_JIT_CACHE_DIR")) return e;
+  // default: next to libcomet.so so that a cache warmed at build time travels with the library
+  Dl_info info;
+  if (dladdr((void*)&hip_check, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    size_t k = p.rfind('/');
+    if (k != std::string::npos) return p.substr(0, k) + "/jit_cache";
+  }
+  return "/tmp/comet_jit_cache";
+}
+
+std::mutex g_mu;
+std::map<std::string, std::shared_ptr<CodeObject>> g_mem_cache;
+
+}  // namespace
+
+std::shared_ptr<CodeObject> jit_compile(const std::string& source) {
+  // the key covers the generated source AND the hand-written headers it instantiates
+  uint64_t h1 = fnv1a(source), h2 = fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader));
+  char keybuf[64];
+  snprintf(keybuf, sizeof keybuf, "%016llx_%016llx", (unsigned long long)h1, (unsigned long long)h2);
+  std::string key = keybuf;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_mem_cache.find(key);
+    if (it != g_mem_cache.end()) return it->second;
+  }
+  if (const char* dd = getenv("COMET_JIT_DUMP_DIR")) {
+    mkdir(dd, 0755);
+    std::ofstream f(std::string(dd) + "/" + key + ".hip");
+    f << source;
+  }
+  const bool disk = !(getenv("COMET_JIT_NO_DISK_CACHE"));
+  std::string dir = cache_dir(), path = dir + "/" + key + ".hsaco";
+  if (disk) {
+    std::ifstream f(path, std::ios::binary);
+    if (f) {
+      auto co = std::make_shared<CodeObject>();
+      co->bytes.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      if (!co->bytes.empty()) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_mem_cache[key] = co;
+        return co;
+      }
+    }
+  }
+  hiprtcProgram prog;
+  const char* headers[] = {kEmbeddedDeviceHeader, kEmbeddedKParamsHeader};
+  const char* names[] = {"comet_device.hpp", "kparams.h"};
+  if (hiprtcCreateProgram(&prog, source.c_str(), "comet_pipeline.hip", 2, headers, names) != HIPRTC_SUCCESS)
+    throw CometError("hiprtcCreateProgram failed");
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"};
+  hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+  auto co = std::make_shared<CodeObject>();
+  size_t logsz = 0;
+  hiprtcGetProgramLogSize(prog, &logsz);
+  if (logsz > 1) {
+    co->log.resize(logsz);
+    hiprtcGetProgramLog(prog, &co->log[0]);
+  }
+  if (rc != HIPRTC_SUCCESS) {
+    hiprtcDestroyProgram(&prog);
+    if (getenv("COMET_JIT_DUMP")) fprintf(stderr, "---- failing source ----\n%s\n", source.c_str());
+    throw CometError(std::string("hiprtc compilation failed: ") + hiprtcGetErrorString(rc) + "\n" + co->log);
+  }
+  size_t sz = 0;
+  hiprtcGetCodeSize(prog, &sz);
+  co->bytes.resize(sz);
+  hiprtcGetCode(prog, co->bytes.data());
+  hiprtcDestroyProgram(&prog);
+  if (disk) {
+    mkdir(dir.c_str(), 0755);
+    std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    std::ofstream f(tmp, std::ios::binary);
+    if (f) {
+      f.write(co->bytes.data(), (std::streamsize)co->bytes.size());
+      f.close();
+      rename(tmp.c_str(), path.c_str());
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_mem_cache[key] = co;
+  return co;
+}
+
+hipFunction_t LoadedModule::fn(const std::string& name) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = fns.find(name);
+  if (it != fns.end()) return it->second;
+  hipFunction_t f;
+  hip_check(hipModuleGetFunction(&f, mod, name.c_str()), ("hipModuleGetFunction(" + name + ")").c_str());
+  fns[name] = f;
+  return f;
+}
+
+LoadedModule::~LoadedModule() {
+  if (mod) (void)hipModuleUnload(mod);
+}
+
+std::shared_ptr<LoadedModule> jit_load(const std::shared_ptr<CodeObject>& co) {
+  // one loaded module per (device, code object), shared by every plan handle of the process: Spark runs
+  // the same stage plan once per task, only the first task on a device pays hipModuleLoadData.
+  static std::mutex mu;
+  static std::map<std::pair<int, const CodeObject*>, std::shared_ptr<LoadedModule>> loaded;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto key = std::make_pair(dev, co.get());
+  auto it = loaded.find(key);
+  if (it != loaded.end()) return it->second;
+  auto m = std::make_shared<LoadedModule>();
+  HIP_CHECK(hipModuleLoadData(&m->mod, co->bytes.data()));
+  m->keepalive = co;
+  loaded[key] = m;
+  return m;
+}
+
+}  // namespace comet

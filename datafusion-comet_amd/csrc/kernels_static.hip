@@ -1,0 +1,134 @@
+// Ahead-of-time kernels (hipcc --offload-arch=gfx950): the pieces of the hot path that do not depend on
+// the plan — Spark murmur3 row hashing + pmod partitioning for the exchange step — and a
+// hand-written instantiation of the fused aggregate template for TPC-H Q6, which keeps the templates of
+// comet_device.hpp under the ahead-of-time compiler as well as hiprtc.
+#include <hip/hip_runtime.h>
+
+#include "device/comet_device.hpp"
+
+using namespace comet;
+
+// ---------------------------------------------------------------------------------------------
+// murmur3: one lane per row, hashes[] chained across key columns (create_hashes_internal!,
+// native/spark-expr/src/hash_funcs/utils.rs:573-760): NULL rows leave the running hash untouched.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void mm3_kernel(const void* values, const u8* validity, i64 n, u32* hashes, F f) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    if (validity && !((validity[i >> 3] >> (i & 7)) & 1)) continue;
+    hashes[i] = f(values, i, hashes[i]);
+  }
+}
+
+struct HashBool { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_i32((((const u8*)v)[i >> 3] >> (i & 7)) & 1, s); } };
+struct HashI8 { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_i32((i32)((const i8*)v)[i], s); } };
+struct HashI16 { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_i32((i32)((const i16*)v)[i], s); } };
+struct HashI32 { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_i32(((const i32*)v)[i], s); } };
+struct HashI64 { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_i64(((const i64*)v)[i], s); } };
+struct HashF32 { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_f32(((const float*)v)[i], s); } };
+struct HashF64 { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_f64(((const double*)v)[i], s); } };
+// decimal(p ≤ 18) hashes as i64, wider as the 16 little-endian bytes (hash_funcs/utils.rs:154-158)
+struct HashDecSmall { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_i64(((const i64*)v)[2 * i], s); } };
+struct HashDecWide { __device__ u32 operator()(const void* v, i64 i, u32 s) const { return mm3_hash_i128(((const i128*)v)[i], s); } };
+struct HashUtf8 {
+  const u8* bytes;
+  __device__ u32 operator()(const void* v, i64 i, u32 s) const {
+    const i32* off = (const i32*)v;
+    return mm3_hash_bytes(bytes + off[i], off[i + 1] - off[i], s);
+  }
+};
+
+__global__ __launch_bounds__(256) void pmod_kernel(const u32* hashes, i64 n, i32 np, i32* out) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = pmod(hashes[i], np);
+}
+
+static int grid_for(i64 n) {
+  i64 g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 256 * 8 ? 256 * 8 : g));
+}
+
+extern "C" int comet_launch_murmur3(int type_id, int precision, const void* values, const uint8_t* validity, const void* aux,
+                                    int64_t n, uint32_t* hashes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0) return 0;
+  int g = grid_for(n);
+  switch (type_id) {
+    case 0: hipLaunchKernelGGL(mm3_kernel<HashBool>, g, 256, 0, st, values, validity, (i64)n, hashes, HashBool()); break;
+    case 1: hipLaunchKernelGGL(mm3_kernel<HashI8>, g, 256, 0, st, values, validity, (i64)n, hashes, HashI8()); break;
+    case 2: hipLaunchKernelGGL(mm3_kernel<HashI16>, g, 256, 0, st, values, validity, (i64)n, hashes, HashI16()); break;
+    case 3: case 12: hipLaunchKernelGGL(mm3_kernel<HashI32>, g, 256, 0, st, values, validity, (i64)n, hashes, HashI32()); break;
+    case 4: case 9: case 11: hipLaunchKernelGGL(mm3_kernel<HashI64>, g, 256, 0, st, values, validity, (i64)n, hashes, HashI64()); break;
+    case 5: hipLaunchKernelGGL(mm3_kernel<HashF32>, g, 256, 0, st, values, validity, (i64)n, hashes, HashF32()); break;
+    case 6: hipLaunchKernelGGL(mm3_kernel<HashF64>, g, 256, 0, st, values, validity, (i64)n, hashes, HashF64()); break;
+    case 7: case 8: {
+      HashUtf8 h;
+      h.bytes = (const u8*)aux;
+      hipLaunchKernelGGL(mm3_kernel<HashUtf8>, g, 256, 0, st, values, validity, (i64)n, hashes, h);
+      break;
+    }
+    case 10:
+      if (precision <= 18) hipLaunchKernelGGL(mm3_kernel<HashDecSmall>, g, 256, 0, st, values, validity, (i64)n, hashes, HashDecSmall());
+      else hipLaunchKernelGGL(mm3_kernel<HashDecWide>, g, 256, 0, st, values, validity, (i64)n, hashes, HashDecWide());
+      break;
+    default: return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pmod_kernel, grid_for(n), 256, 0, (hipStream_t)stream, hashes, (i64)n, np, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hand-written TPC-H Q6 functor (what codegen emits for the plan, written out by hand):
+//   in[0] l_quantity dec(12,2)  in[1] l_extendedprice dec(12,2)  in[2] l_discount dec(12,2)  in[3] l_shipdate date32
+//   WHERE shipdate >= d0 AND shipdate < d1 AND discount BETWEEN lo AND hi AND quantity < q
+//   SUM(extendedprice * discount) : Decimal(35,4) state (sum, is_empty)
+//   iarg[1]=d0 iarg[2]=d1 iarg[3]=disc_lo iarg[4]=disc_hi iarg[5]=qty_lt
+// ---------------------------------------------------------------------------------------------
+struct Q6Static {
+  static constexpr int R = 4;
+  static constexpr int NW = 3;  // [0] rows, [1..2] sum128
+  static __device__ __forceinline__ void init(u64* a) { a[0] = a[1] = a[2] = 0; }
+  static __device__ __forceinline__ void combine(u64* a, const u64* b) {
+    acc_add64(a, b);
+    acc_add128(a + 1, b + 1);
+  }
+  static __device__ __forceinline__ void tile(const CometKParams& prm, i64 base, i64 n, u64* acc) {
+    bool k[R];
+    i64 idx[R];
+    i32 sd[R];
+    i64 disc[R], qty[R], price[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * kBlock + threadIdx.x; k[r] = idx[r] < n; }
+#pragma unroll
+    for (int r = 0; r < R; r++) if (k[r]) sd[r] = ld<i32>(prm.in[3], idx[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) if (k[r]) k[r] = sd[r] >= (i32)prm.iarg[1] && sd[r] < (i32)prm.iarg[2];
+#pragma unroll
+    for (int r = 0; r < R; r++) if (k[r]) disc[r] = ld_dec_lo(prm.in[2], idx[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) if (k[r]) k[r] = disc[r] >= prm.iarg[3] && disc[r] <= prm.iarg[4];
+#pragma unroll
+    for (int r = 0; r < R; r++) if (k[r]) qty[r] = ld_dec_lo(prm.in[0], idx[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) if (k[r]) k[r] = qty[r] < prm.iarg[5];
+#pragma unroll
+    for (int r = 0; r < R; r++) if (k[r]) price[r] = ld_dec_lo(prm.in[1], idx[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) if (k[r]) {
+      acc[0] += 1;
+      acc_feed_i128(acc + 1, (i128)price[r] * (i128)disc[r]);
+    }
+  }
+  static __device__ __forceinline__ void finalize(const CometKParams& prm, const u64* acc) {
+    ((i128*)prm.out[4])[0] = mk128(acc[2], acc[1]);
+    ((u8*)prm.out[5])[0] = 1;
+    ((u8*)prm.out[6])[0] = acc[0] == 0 ? 1 : 0;
+  }
+};
+
+extern "C" __global__ __launch_bounds__(256) void comet_q6_static_agg(const CometKParams prm) { agg_nogroup_body<Q6Static>(prm); }
+extern "C" __global__ __launch_bounds__(256) void comet_q6_static_final(const CometKParams prm) { agg_nogroup_final_body<Q6Static>(prm); }

@@ -1,0 +1,165 @@
+// Plan IR decoded from Comet's protobuf plan (native/proto/src/proto/{operator,expr,types,literal}.proto).
+// The IR mirrors the proto messages this engine executes; anything else decodes to Kind::Unsupported
+// and is rejected at planning time with the operator/expression name, like the reference's planner
+// does for unknown arms (native/core/src/execution/planner.rs:446, :1211).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace comet {
+
+struct CometError : std::runtime_error {
+  // kind: 0 = CometNativeException, 1 = CometQueryExecutionException (json payload)
+  int kind;
+  explicit CometError(const std::string& m, int k = 0) : std::runtime_error(m), kind(k) {}
+};
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+// spark.spark_expression.DataType.DataTypeId (types.proto:43-66)
+enum class TypeId : int {
+  Bool = 0, Int8 = 1, Int16 = 2, Int32 = 3, Int64 = 4, Float = 5, Double = 6, String = 7, Bytes = 8,
+  Timestamp = 9, Decimal = 10, TimestampNtz = 11, Date = 12, Null = 13, List = 14, Map = 15, Struct = 16,
+  Time = 17, Unknown = 99
+};
+
+struct DType {
+  TypeId id = TypeId::Unknown;
+  int precision = 0, scale = 0;  // Decimal only
+  bool operator==(const DType& o) const { return id == o.id && precision == o.precision && scale == o.scale; }
+  bool operator!=(const DType& o) const { return !(*this == o); }
+  bool is_decimal() const { return id == TypeId::Decimal; }
+  bool is_integer() const { return id == TypeId::Int8 || id == TypeId::Int16 || id == TypeId::Int32 || id == TypeId::Int64; }
+  bool is_float() const { return id == TypeId::Float || id == TypeId::Double; }
+  std::string str() const;
+  static DType of(TypeId t) { DType d; d.id = t; return d; }
+  static DType decimal(int p, int s) { DType d; d.id = TypeId::Decimal; d.precision = p; d.scale = s; return d; }
+};
+
+enum class EvalMode : int { Legacy = 0, Try = 1, Ansi = 2 };
+
+// Expr.expr_struct oneof tags (expr.proto:30-107) for the arms on the hot path.
+enum class ExprKind : int {
+  Literal = 2, Bound = 3, Add = 4, Subtract = 5, Multiply = 6, Divide = 7, Cast = 8,
+  Eq = 9, Neq = 10, Gt = 11, GtEq = 12, Lt = 13, LtEq = 14, IsNull = 15, IsNotNull = 16, And = 17, Or = 18,
+  CheckOverflow = 25, EqNullSafe = 32, NeqNullSafe = 33, Remainder = 37, CaseWhen = 38, In = 39, Not = 40,
+  UnaryMinus = 41, If = 44, NormalizeNaNAndZero = 45, Unbound = 51,
+  Unsupported = -1
+};
+
+struct Expr;
+typedef std::shared_ptr<Expr> ExprP;
+
+struct Expr {
+  ExprKind kind = ExprKind::Unsupported;
+  int proto_tag = 0;              // raw oneof tag (for error messages)
+  std::vector<ExprP> children;    // operands in proto field order
+  DType dtype;                    // declared type (Literal.datatype, Bound.datatype, Cast.datatype,
+                                  // CheckOverflow.datatype, MathExpr.return_type)
+  bool has_dtype = false;
+  EvalMode eval_mode = EvalMode::Legacy;
+  bool fail_on_error = false;     // CheckOverflow / UnaryMinus
+  bool negated = false;           // In
+  int bound_index = -1;           // Bound
+  // Literal payload
+  bool lit_null = false;
+  bool lit_bool = false;
+  int64_t lit_i64 = 0;            // byte/short/int/long/date/timestamp
+  double lit_f64 = 0;             // float/double
+  i128 lit_dec = 0;               // decimal unscaled value (literal.proto:38, BE two's complement)
+  std::string lit_bytes;          // string/bytes
+  int lit_case = 0;               // which Literal.value arm was present (1..11), 0 = none
+  uint64_t expr_id = 0;
+};
+
+// AggExpr.expr_struct oneof tags (expr.proto:143-176)
+enum class AggKind : int { Count = 2, Sum = 3, Min = 4, Max = 5, Avg = 6, First = 7, Last = 8, Unsupported = -1 };
+
+struct AggExpr {
+  AggKind kind = AggKind::Unsupported;
+  int proto_tag = 0;
+  std::vector<ExprP> children;    // Count.children or the single child
+  DType dtype;                    // Sum/Min/Max/Avg.datatype (result type)
+  DType sum_dtype;                // Avg.sum_datatype
+  EvalMode eval_mode = EvalMode::Legacy;
+  ExprP filter;                   // AggExpr.filter = 89
+  uint64_t expr_id = 0;
+};
+
+// Operator.op_struct oneof tags (operator.proto:32-79)
+enum class OpKind : int {
+  Scan = 100, Projection = 101, Filter = 102, Sort = 103, HashAgg = 104, Limit = 105, HashJoin = 109,
+  NativeScan = 111, Unsupported = -1
+};
+
+enum class AggMode : int { Partial = 0, Final = 1, PartialMerge = 2 };
+enum class JoinType : int { Inner = 0, LeftOuter = 1, RightOuter = 2, FullOuter = 3, LeftSemi = 4, LeftAnti = 5 };
+enum class BuildSide : int { Left = 0, Right = 1 };
+
+struct StructField {  // SparkStructField (operator.proto:117-124)
+  std::string name;
+  DType dtype;
+  bool nullable = true;
+};
+
+struct PartitionedFile {  // SparkPartitionedFile (operator.proto:103-109)
+  std::string file_path;
+  int64_t start = 0, length = 0, file_size = 0;
+  std::vector<ExprP> partition_values;
+};
+
+struct Operator;
+typedef std::shared_ptr<Operator> OperatorP;
+
+struct Operator {
+  OpKind kind = OpKind::Unsupported;
+  int proto_tag = 0;
+  uint32_t plan_id = 0;
+  std::vector<OperatorP> children;
+  // Scan
+  std::vector<DType> scan_fields;
+  std::string scan_source;
+  // Projection
+  std::vector<ExprP> project_list;
+  // Filter
+  ExprP predicate;
+  // HashAggregate
+  std::vector<ExprP> grouping_exprs;
+  std::vector<AggExpr> agg_exprs;
+  AggMode agg_mode = AggMode::Partial;
+  std::vector<int> expr_modes;
+  int initial_input_buffer_offset = 0;
+  // HashJoin
+  std::vector<ExprP> left_keys, right_keys;
+  JoinType join_type = JoinType::Inner;
+  ExprP join_condition;
+  BuildSide build_side = BuildSide::Left;
+  bool null_aware_anti = false;
+  // Limit
+  int limit = -1, offset = 0;
+  // NativeScan
+  std::vector<StructField> required_schema, data_schema, partition_schema;
+  std::vector<ExprP> data_filters;
+  std::vector<int64_t> projection_vector;
+  std::vector<PartitionedFile> files;
+  std::string session_timezone;
+};
+
+// proto.cpp
+OperatorP decode_operator(const uint8_t* data, size_t len);
+std::vector<std::pair<std::string, std::string>> decode_config_map(const uint8_t* data, size_t len);
+// NativeMetricNode encoder (metric.proto:26-29)
+struct MetricNode {
+  std::vector<std::pair<std::string, int64_t>> metrics;
+  std::vector<MetricNode> children;
+};
+std::string encode_metric_node(const MetricNode& n);
+
+const char* op_name(int proto_tag);
+const char* expr_name(int proto_tag);
+
+}  // namespace comet

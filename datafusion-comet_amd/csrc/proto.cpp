@@ -1,0 +1,489 @@
+// Hand-written proto3 wire decoder for Comet's plan messages (no protoc / libprotobuf in this image).
+// Field numbers follow native/proto/src/proto/{operator,expr,types,literal,config,metric}.proto; the
+// reference decodes the same bytes with prost in native/core/src/execution/serde.rs:45-58.
+#include <cstring>
+
+#include "plan.hpp"
+
+namespace comet {
+
+namespace {
+
+struct Reader {
+  const uint8_t* p;
+  const uint8_t* end;
+  Reader(const uint8_t* d, size_t n) : p(d), end(d + n) {}
+  bool done() const { return p >= end; }
+  uint64_t varint() {
+    uint64_t v = 0;
+    int shift = 0;
+    while (true) {
+      if (p >= end) throw CometError("protobuf: truncated varint");
+      uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) break;
+      shift += 7;
+      if (shift > 63) throw CometError("protobuf: varint too long");
+    }
+    return v;
+  }
+  // returns field number, sets wire type
+  int tag(int& wt) {
+    uint64_t t = varint();
+    wt = (int)(t & 7);
+    return (int)(t >> 3);
+  }
+  Reader sub() {
+    uint64_t n = varint();
+    if ((uint64_t)(end - p) < n) throw CometError("protobuf: truncated length-delimited field");
+    Reader r(p, (size_t)n);
+    p += n;
+    return r;
+  }
+  std::string bytes() {
+    Reader r = sub();
+    return std::string((const char*)r.p, (size_t)(r.end - r.p));
+  }
+  uint32_t fixed32() {
+    if (end - p < 4) throw CometError("protobuf: truncated fixed32");
+    uint32_t v;
+    memcpy(&v, p, 4);
+    p += 4;
+    return v;
+  }
+  uint64_t fixed64() {
+    if (end - p < 8) throw CometError("protobuf: truncated fixed64");
+    uint64_t v;
+    memcpy(&v, p, 8);
+    p += 8;
+    return v;
+  }
+  void skip(int wt) {
+    switch (wt) {
+      case 0: varint(); break;
+      case 1: fixed64(); break;
+      case 2: sub(); break;
+      case 5: fixed32(); break;
+      default: throw CometError("protobuf: unsupported wire type " + std::to_string(wt));
+    }
+  }
+  // repeated scalar: packed (wt 2) or unpacked (wt 0)
+  template <class F>
+  void repeated_varint(int wt, F f) {
+    if (wt == 2) {
+      Reader r = sub();
+      while (!r.done()) f(r.varint());
+    } else {
+      f(varint());
+    }
+  }
+};
+
+DType decode_datatype(Reader r) {
+  DType d;
+  d.id = TypeId::Bool;  // proto3 default enum value 0
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    if (f == 1 && wt == 0) {
+      int id = (int)r.varint();
+      d.id = (id >= 0 && id <= 17) ? (TypeId)id : TypeId::Unknown;
+    } else if (f == 2 && wt == 2) {  // DataTypeInfo
+      Reader info = r.sub();
+      while (!info.done()) {
+        int wt2, f2 = info.tag(wt2);
+        if (f2 == 2 && wt2 == 2) {  // DecimalInfo
+          Reader dec = info.sub();
+          while (!dec.done()) {
+            int wt3, f3 = dec.tag(wt3);
+            if (f3 == 1 && wt3 == 0) d.precision = (int)(int32_t)dec.varint();
+            else if (f3 == 2 && wt3 == 0) d.scale = (int)(int32_t)dec.varint();
+            else dec.skip(wt3);
+          }
+        } else {
+          info.skip(wt2);
+        }
+      }
+    } else {
+      r.skip(wt);
+    }
+  }
+  return d;
+}
+
+ExprP decode_expr(Reader r);
+
+// BigInteger.toByteArray: big-endian two's complement (spark/.../serde/literals.scala:92-95;
+// decoded by the reference at planner.rs:544-562).
+i128 decode_be_twos_complement(const std::string& b) {
+  if (b.empty()) return 0;
+  if (b.size() > 16) {
+    // allowed only if the extra leading bytes are pure sign extension
+    uint8_t ext = (b[b.size() - 16] & 0x80) ? 0xff : 0x00;
+    for (size_t i = 0; i + 16 < b.size(); i++)
+      if ((uint8_t)b[i] != ext) throw CometError("Cannot parse decimal literal as i128");
+  }
+  u128 v = ((uint8_t)b[0] & 0x80) ? ~(u128)0 : 0;
+  for (size_t i = 0; i < b.size(); i++) v = (v << 8) | (uint8_t)b[i];
+  return (i128)v;
+}
+
+void decode_literal(Reader r, Expr& e) {
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    switch (f) {
+      case 1: e.lit_bool = r.varint() != 0; e.lit_case = 1; break;
+      case 2: case 3: case 4: e.lit_i64 = (int64_t)(int32_t)r.varint(); e.lit_case = f; break;
+      case 5: e.lit_i64 = (int64_t)r.varint(); e.lit_case = 5; break;
+      case 6: { uint32_t u = r.fixed32(); float fl; memcpy(&fl, &u, 4); e.lit_f64 = fl; e.lit_case = 6; break; }
+      case 7: { uint64_t u = r.fixed64(); memcpy(&e.lit_f64, &u, 8); e.lit_case = 7; break; }
+      case 8: case 9: e.lit_bytes = r.bytes(); e.lit_case = f; break;
+      case 10: e.lit_dec = decode_be_twos_complement(r.bytes()); e.lit_case = 10; break;
+      case 12: e.dtype = decode_datatype(r.sub()); e.has_dtype = true; break;
+      case 13: e.lit_null = r.varint() != 0; break;
+      default: r.skip(wt);
+    }
+  }
+}
+
+// MathExpr / BinaryExpr / UnaryExpr / Cast / CheckOverflow / BoundReference / In / If / CaseWhen share
+// the shape "child exprs at low field numbers + a few scalars"; one generic walker with a per-kind
+// field map keeps the decoder small.
+void decode_expr_body(Reader r, Expr& e) {
+  const ExprKind k = e.kind;
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    bool handled = false;
+    switch (k) {
+      case ExprKind::Unbound:
+        if (f == 2 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
+        break;
+      case ExprKind::Bound:
+        if (f == 1 && wt == 0) { e.bound_index = (int)(int32_t)r.varint(); handled = true; }
+        else if (f == 2 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
+        break;
+      case ExprKind::Add: case ExprKind::Subtract: case ExprKind::Multiply: case ExprKind::Divide:
+      case ExprKind::Remainder:
+        if ((f == 1 || f == 2) && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 4 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
+        else if (f == 5 && wt == 0) { e.eval_mode = (EvalMode)r.varint(); handled = true; }
+        break;
+      case ExprKind::Cast:
+        if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 2 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
+        else if (f == 4 && wt == 0) { e.eval_mode = (EvalMode)r.varint(); handled = true; }
+        break;
+      case ExprKind::CheckOverflow:
+        if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 2 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
+        else if (f == 3 && wt == 0) { e.fail_on_error = r.varint() != 0; handled = true; }
+        break;
+      case ExprKind::NormalizeNaNAndZero:
+        if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 2 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
+        break;
+      case ExprKind::UnaryMinus:
+        if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 2 && wt == 0) { e.fail_on_error = r.varint() != 0; handled = true; }
+        break;
+      case ExprKind::In:
+        // children[0] = in_value, children[1..] = lists
+        if ((f == 1 || f == 2) && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 3 && wt == 0) { e.negated = r.varint() != 0; handled = true; }
+        break;
+      case ExprKind::If:
+        if (f >= 1 && f <= 3 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        break;
+      default:
+        // BinaryExpr{left=1,right=2} and UnaryExpr{child=1}
+        if ((f == 1 || f == 2) && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        break;
+    }
+    if (!handled) r.skip(wt);
+  }
+}
+
+ExprP decode_expr(Reader r) {
+  auto e = std::make_shared<Expr>();
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    if (f == 91 && wt == 0) { e->expr_id = r.varint(); continue; }
+    if (f == 90) { r.skip(wt); continue; }  // QueryContext: error decoration only
+    if (wt != 2) { r.skip(wt); continue; }
+    e->proto_tag = f;
+    switch (f) {
+      case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
+      case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
+      case 15: case 16: case 17: case 18: case 25: case 32: case 33: case 37: case 39: case 40: case 41:
+      case 44: case 45: case 51:
+        e->kind = (ExprKind)f;
+        if (e->kind == ExprKind::Bound) e->bound_index = 0;  // proto3 omits zero-valued scalars
+        decode_expr_body(r.sub(), *e);
+        break;
+      default:
+        e->kind = ExprKind::Unsupported;
+        r.skip(wt);
+    }
+  }
+  return e;
+}
+
+AggExpr decode_agg_expr(Reader r) {
+  AggExpr a;
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    if (f == 89 && wt == 2) { a.filter = decode_expr(r.sub()); continue; }
+    if (f == 91 && wt == 0) { a.expr_id = r.varint(); continue; }
+    if (f == 90 || wt != 2) { r.skip(wt); continue; }
+    a.proto_tag = f;
+    Reader b = r.sub();
+    if (f >= 2 && f <= 8) a.kind = (AggKind)f;
+    else { a.kind = AggKind::Unsupported; continue; }
+    while (!b.done()) {
+      int wt2, f2 = b.tag(wt2);
+      if (f2 == 1 && wt2 == 2) a.children.push_back(decode_expr(b.sub()));
+      else if (f2 == 2 && wt2 == 2) a.dtype = decode_datatype(b.sub());
+      else if (f2 == 3 && wt2 == 2 && a.kind == AggKind::Avg) a.sum_dtype = decode_datatype(b.sub());
+      else if (f2 == 3 && wt2 == 0 && a.kind == AggKind::Sum) a.eval_mode = (EvalMode)b.varint();
+      else if (f2 == 4 && wt2 == 0 && a.kind == AggKind::Avg) a.eval_mode = (EvalMode)b.varint();
+      else b.skip(wt2);
+    }
+  }
+  return a;
+}
+
+StructField decode_struct_field(Reader r) {
+  StructField s;
+  s.nullable = false;
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    if (f == 1 && wt == 2) s.name = r.bytes();
+    else if (f == 2 && wt == 2) s.dtype = decode_datatype(r.sub());
+    else if (f == 3 && wt == 0) s.nullable = r.varint() != 0;
+    else r.skip(wt);
+  }
+  return s;
+}
+
+void decode_native_scan(Reader r, Operator& op) {
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    if (f == 1 && wt == 2) {  // NativeScanCommon
+      Reader c = r.sub();
+      while (!c.done()) {
+        int wt2, f2 = c.tag(wt2);
+        if (f2 == 1 && wt2 == 2) op.required_schema.push_back(decode_struct_field(c.sub()));
+        else if (f2 == 2 && wt2 == 2) op.data_schema.push_back(decode_struct_field(c.sub()));
+        else if (f2 == 3 && wt2 == 2) op.partition_schema.push_back(decode_struct_field(c.sub()));
+        else if (f2 == 4 && wt2 == 2) op.data_filters.push_back(decode_expr(c.sub()));
+        else if (f2 == 5) c.repeated_varint(wt2, [&](uint64_t v) { op.projection_vector.push_back((int64_t)v); });
+        else if (f2 == 6 && wt2 == 2) op.session_timezone = c.bytes();
+        else if (f2 == 12 && wt2 == 2) op.scan_source = c.bytes();
+        else if (f2 == 13 && wt2 == 2) op.scan_fields.push_back(decode_datatype(c.sub()));
+        else c.skip(wt2);
+      }
+    } else if (f == 2 && wt == 2) {  // SparkFilePartition
+      Reader fp = r.sub();
+      while (!fp.done()) {
+        int wt2, f2 = fp.tag(wt2);
+        if (f2 == 1 && wt2 == 2) {
+          Reader pf = fp.sub();
+          PartitionedFile file;
+          while (!pf.done()) {
+            int wt3, f3 = pf.tag(wt3);
+            if (f3 == 1 && wt3 == 2) file.file_path = pf.bytes();
+            else if (f3 == 2 && wt3 == 0) file.start = (int64_t)pf.varint();
+            else if (f3 == 3 && wt3 == 0) file.length = (int64_t)pf.varint();
+            else if (f3 == 4 && wt3 == 0) file.file_size = (int64_t)pf.varint();
+            else if (f3 == 5 && wt3 == 2) file.partition_values.push_back(decode_expr(pf.sub()));
+            else pf.skip(wt3);
+          }
+          op.files.push_back(std::move(file));
+        } else {
+          fp.skip(wt2);
+        }
+      }
+    } else {
+      r.skip(wt);
+    }
+  }
+}
+
+OperatorP decode_operator_r(Reader r) {
+  auto op = std::make_shared<Operator>();
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    if (f == 1 && wt == 2) { op->children.push_back(decode_operator_r(r.sub())); continue; }
+    if (f == 2 && wt == 0) { op->plan_id = (uint32_t)r.varint(); continue; }
+    if (f < 100 || wt != 2) { r.skip(wt); continue; }
+    op->proto_tag = f;
+    Reader b = r.sub();
+    switch (f) {
+      case 100:
+        op->kind = OpKind::Scan;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) op->scan_fields.push_back(decode_datatype(b.sub()));
+          else if (f2 == 2 && wt2 == 2) op->scan_source = b.bytes();
+          else b.skip(wt2);
+        }
+        break;
+      case 101:
+        op->kind = OpKind::Projection;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) op->project_list.push_back(decode_expr(b.sub()));
+          else b.skip(wt2);
+        }
+        break;
+      case 102:
+        op->kind = OpKind::Filter;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) op->predicate = decode_expr(b.sub());
+          else b.skip(wt2);
+        }
+        break;
+      case 104:
+        op->kind = OpKind::HashAgg;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) op->grouping_exprs.push_back(decode_expr(b.sub()));
+          else if (f2 == 2 && wt2 == 2) op->agg_exprs.push_back(decode_agg_expr(b.sub()));
+          else if (f2 == 5 && wt2 == 0) op->agg_mode = (AggMode)b.varint();
+          else if (f2 == 6) b.repeated_varint(wt2, [&](uint64_t v) { op->expr_modes.push_back((int)v); });
+          else if (f2 == 7 && wt2 == 0) op->initial_input_buffer_offset = (int)(int32_t)b.varint();
+          else b.skip(wt2);
+        }
+        break;
+      case 105:
+        op->kind = OpKind::Limit;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 0) op->limit = (int)(int32_t)b.varint();
+          else if (f2 == 2 && wt2 == 0) op->offset = (int)(int32_t)b.varint();
+          else b.skip(wt2);
+        }
+        break;
+      case 109:
+        op->kind = OpKind::HashJoin;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) op->left_keys.push_back(decode_expr(b.sub()));
+          else if (f2 == 2 && wt2 == 2) op->right_keys.push_back(decode_expr(b.sub()));
+          else if (f2 == 3 && wt2 == 0) op->join_type = (JoinType)b.varint();
+          else if (f2 == 4 && wt2 == 2) op->join_condition = decode_expr(b.sub());
+          else if (f2 == 5 && wt2 == 0) op->build_side = (BuildSide)b.varint();
+          else if (f2 == 6 && wt2 == 0) op->null_aware_anti = b.varint() != 0;
+          else b.skip(wt2);
+        }
+        break;
+      case 111:
+        op->kind = OpKind::NativeScan;
+        decode_native_scan(b, *op);
+        break;
+      default:
+        op->kind = OpKind::Unsupported;
+    }
+  }
+  return op;
+}
+
+void put_varint(std::string& s, uint64_t v) {
+  while (v >= 0x80) { s.push_back((char)(v | 0x80)); v >>= 7; }
+  s.push_back((char)v);
+}
+
+}  // namespace
+
+OperatorP decode_operator(const uint8_t* data, size_t len) { return decode_operator_r(Reader(data, len)); }
+
+std::vector<std::pair<std::string, std::string>> decode_config_map(const uint8_t* data, size_t len) {
+  std::vector<std::pair<std::string, std::string>> out;
+  Reader r(data, len);
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    if (f == 1 && wt == 2) {  // map entry {key=1, value=2}
+      Reader e = r.sub();
+      std::string k, v;
+      while (!e.done()) {
+        int wt2, f2 = e.tag(wt2);
+        if (f2 == 1 && wt2 == 2) k = e.bytes();
+        else if (f2 == 2 && wt2 == 2) v = e.bytes();
+        else e.skip(wt2);
+      }
+      out.emplace_back(std::move(k), std::move(v));
+    } else {
+      r.skip(wt);
+    }
+  }
+  return out;
+}
+
+std::string encode_metric_node(const MetricNode& n) {
+  std::string s;
+  for (auto& kv : n.metrics) {
+    std::string e;
+    e.push_back((char)((1 << 3) | 2));
+    put_varint(e, kv.first.size());
+    e += kv.first;
+    e.push_back((char)((2 << 3) | 0));
+    put_varint(e, (uint64_t)kv.second);
+    s.push_back((char)((1 << 3) | 2));
+    put_varint(s, e.size());
+    s += e;
+  }
+  for (auto& c : n.children) {
+    std::string e = encode_metric_node(c);
+    s.push_back((char)((2 << 3) | 2));
+    put_varint(s, e.size());
+    s += e;
+  }
+  return s;
+}
+
+std::string DType::str() const {
+  switch (id) {
+    case TypeId::Bool: return "Boolean";
+    case TypeId::Int8: return "Int8";
+    case TypeId::Int16: return "Int16";
+    case TypeId::Int32: return "Int32";
+    case TypeId::Int64: return "Int64";
+    case TypeId::Float: return "Float32";
+    case TypeId::Double: return "Float64";
+    case TypeId::String: return "Utf8";
+    case TypeId::Bytes: return "Binary";
+    case TypeId::Timestamp: return "Timestamp(us, UTC)";
+    case TypeId::TimestampNtz: return "Timestamp(us)";
+    case TypeId::Date: return "Date32";
+    case TypeId::Null: return "Null";
+    case TypeId::Decimal: return "Decimal128(" + std::to_string(precision) + ", " + std::to_string(scale) + ")";
+    default: return "Unsupported(" + std::to_string((int)id) + ")";
+  }
+}
+
+const char* op_name(int t) {
+  switch (t) {
+    case 100: return "Scan"; case 101: return "Projection"; case 102: return "Filter"; case 103: return "Sort";
+    case 104: return "HashAggregate"; case 105: return "Limit"; case 106: return "ShuffleWriter";
+    case 107: return "Expand"; case 108: return "SortMergeJoin"; case 109: return "HashJoin";
+    case 110: return "Window"; case 111: return "NativeScan"; case 112: return "IcebergScan";
+    case 113: return "ParquetWriter"; case 114: return "Explode"; case 115: return "CsvScan";
+    case 116: return "ShuffleScan"; case 117: return "BroadcastNestedLoopJoin"; case 118: return "Sample";
+    case 200: return "ContribScan"; default: return "Unknown";
+  }
+}
+
+const char* expr_name(int t) {
+  switch (t) {
+    case 2: return "Literal"; case 3: return "BoundReference"; case 4: return "Add"; case 5: return "Subtract";
+    case 6: return "Multiply"; case 7: return "Divide"; case 8: return "Cast"; case 9: return "Eq";
+    case 10: return "Neq"; case 11: return "Gt"; case 12: return "GtEq"; case 13: return "Lt"; case 14: return "LtEq";
+    case 15: return "IsNull"; case 16: return "IsNotNull"; case 17: return "And"; case 18: return "Or";
+    case 19: return "SortOrder"; case 25: return "CheckOverflow"; case 26: return "Like"; case 31: return "ScalarFunc";
+    case 32: return "EqNullSafe"; case 33: return "NeqNullSafe"; case 37: return "Remainder"; case 38: return "CaseWhen";
+    case 39: return "In"; case 40: return "Not"; case 41: return "UnaryMinus"; case 44: return "If";
+    case 45: return "NormalizeNaNAndZero"; default: return "Expr";
+  }
+}
+
+}  // namespace comet

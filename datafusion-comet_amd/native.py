@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference's JVM boundary, over the C ABI of libcomet.so.
+
+``Native`` has the three calls of ``org.apache.comet.Native`` (spark/src/main/scala/org/apache/comet/
+Native.scala:60-111) and ``CometExecIterator`` mirrors the Scala class of the same name
+(spark/src/main/scala/org/apache/comet/CometExecIterator.scala:64-256): createPlan once, executePlan per
+output batch until -1, releasePlan on close.  Inputs are exported through the Arrow C Stream interface
+(host memory, what the JVM does) or the Arrow C Device Stream interface (buffers already in HBM).
+
+There is no CPU fallback here: if libcomet.so is missing or fails to load, import raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Iterator, List, Optional, Sequence
+
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcomet.so")
+
+
+class CometNativeException(RuntimeError):
+    """org.apache.comet.CometNativeException"""
+
+
+class CometQueryExecutionException(RuntimeError):
+    """org.apache.comet.exceptions.CometQueryExecutionException (message is the Spark error JSON)"""
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the native engine)")
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    lib.comet_create_plan.restype = c.c_int64
+    lib.comet_create_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_void_p),
+                                      c.POINTER(c.c_int32), c.c_int32, c.c_int32, c.c_int32, c.c_int32]
+    lib.comet_execute_plan.restype = c.c_int64
+    lib.comet_execute_plan.argtypes = [c.c_int64, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p), c.c_int32]
+    lib.comet_release_plan.restype = None
+    lib.comet_release_plan.argtypes = [c.c_int64]
+    lib.comet_last_error.restype = c.c_char_p
+    lib.comet_last_error.argtypes = [c.c_int64]
+    lib.comet_last_error_kind.restype = c.c_int32
+    lib.comet_last_error_kind.argtypes = [c.c_int64]
+    lib.comet_plan_metrics.restype = c.c_int64
+    lib.comet_plan_metrics.argtypes = [c.c_int64, c.c_void_p, c.c_size_t]
+    lib.comet_explain.restype = c.c_char_p
+    lib.comet_explain.argtypes = [c.c_int64]
+    lib.comet_plan_kernel_stats.restype = None
+    lib.comet_plan_kernel_stats.argtypes = [c.c_int64, c.POINTER(c.c_double), c.POINTER(c.c_int64), c.POINTER(c.c_int64)]
+    lib.comet_compile_plan.restype = c.c_int32
+    lib.comet_compile_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_char_p, c.c_size_t]
+    lib.comet_murmur3_column.restype = c.c_int32
+    lib.comet_murmur3_column.argtypes = [c.c_int32, c.c_int32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    lib.comet_pmod_partition.restype = c.c_int32
+    lib.comet_pmod_partition.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p]
+    lib.comet_version.restype = c.c_char_p
+    return lib
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+# --------------------------------------------------------------------------- Arrow C structs
+
+
+class ArrowSchemaC(ctypes.Structure):
+    pass
+
+
+class ArrowArrayC(ctypes.Structure):
+    pass
+
+
+ArrowSchemaC._fields_ = [("format", ctypes.c_char_p), ("name", ctypes.c_char_p), ("metadata", ctypes.c_char_p),
+                         ("flags", ctypes.c_int64), ("n_children", ctypes.c_int64),
+                         ("children", ctypes.POINTER(ctypes.POINTER(ArrowSchemaC))),
+                         ("dictionary", ctypes.POINTER(ArrowSchemaC)), ("release", ctypes.c_void_p),
+                         ("private_data", ctypes.c_void_p)]
+ArrowArrayC._fields_ = [("length", ctypes.c_int64), ("null_count", ctypes.c_int64), ("offset", ctypes.c_int64),
+                        ("n_buffers", ctypes.c_int64), ("n_children", ctypes.c_int64),
+                        ("buffers", ctypes.POINTER(ctypes.c_void_p)),
+                        ("children", ctypes.POINTER(ctypes.POINTER(ArrowArrayC))),
+                        ("dictionary", ctypes.POINTER(ArrowArrayC)), ("release", ctypes.c_void_p),
+                        ("private_data", ctypes.c_void_p)]
+
+
+class ArrowArrayStreamC(ctypes.Structure):
+    _fields_ = [("get_schema", ctypes.c_void_p), ("get_next", ctypes.c_void_p), ("get_last_error", ctypes.c_void_p),
+                ("release", ctypes.c_void_p), ("private_data", ctypes.c_void_p)]
+
+
+class ArrowDeviceArrayC(ctypes.Structure):
+    _fields_ = [("array", ArrowArrayC), ("device_id", ctypes.c_int64), ("device_type", ctypes.c_int32),
+                ("sync_event", ctypes.c_void_p), ("reserved", ctypes.c_int64 * 3)]
+
+
+class ArrowDeviceArrayStreamC(ctypes.Structure):
+    _fields_ = [("device_type", ctypes.c_int32), ("get_schema", ctypes.c_void_p), ("get_next", ctypes.c_void_p),
+                ("get_last_error", ctypes.c_void_p), ("release", ctypes.c_void_p), ("private_data", ctypes.c_void_p)]
+
+
+ARROW_DEVICE_ROCM = 10
+
+_GET_SCHEMA_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+_GET_NEXT_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+_LAST_ERR_T = ctypes.CFUNCTYPE(ctypes.c_char_p, ctypes.c_void_p)
+_RELEASE_T = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+
+class HostInput:
+    """An input handed over as struct ArrowArrayStream* (what CometNativeArrowSource exports)."""
+
+    kind = 0
+
+    def __init__(self, reader: pa.RecordBatchReader):
+        self._c = ArrowArrayStreamC()
+        reader._export_to_c(ctypes.addressof(self._c))
+
+    @staticmethod
+    def from_table(table: pa.Table, batch_rows: int = 8192) -> "HostInput":
+        batches = table.to_batches(max_chunksize=batch_rows)
+        return HostInput(pa.RecordBatchReader.from_batches(table.schema, batches))
+
+    @property
+    def address(self) -> int:
+        return ctypes.addressof(self._c)
+
+
+_FIXED_WIDTH = {pa.int8(): 1, pa.int16(): 2, pa.int32(): 4, pa.int64(): 8, pa.float32(): 4, pa.float64(): 8,
+                pa.date32(): 4}
+
+
+class DeviceTable:
+    """Arrow-layout columns resident in HBM (torch tensors own the memory)."""
+
+    def __init__(self, schema: pa.Schema, num_rows: int, values, validity, device):
+        self.schema, self.num_rows, self.values, self.validity, self.device = schema, num_rows, values, validity, device
+
+    @staticmethod
+    def from_arrow(table: pa.Table, device="cuda:0") -> "DeviceTable":
+        import numpy as np
+        import torch
+        table = table.combine_chunks()
+        vals, valid = [], []
+        for name in table.schema.names:
+            arr = table.column(name).chunk(0) if table.num_rows else pa.array([], type=table.schema.field(name).type)
+            if arr.offset != 0:
+                arr = pa.concat_arrays([arr])
+            bufs = arr.buffers()
+            data = bufs[1]
+            host = np.frombuffer(data, dtype=np.uint8) if data is not None and data.size else np.zeros(0, np.uint8)
+            # torch allocations are 256 B aligned → Decimal128 loads are 16 B aligned
+            vals.append(torch.from_numpy(host.copy()).to(device))
+            if arr.null_count and bufs[0] is not None:
+                valid.append(torch.from_numpy(np.frombuffer(bufs[0], dtype=np.uint8).copy()).to(device))
+            else:
+                valid.append(None)
+        return DeviceTable(table.schema, table.num_rows, vals, valid, device)
+
+    def nbytes(self) -> int:
+        return sum(v.numel() for v in self.values) + sum(v.numel() for v in self.validity if v is not None)
+
+
+class DeviceInput:
+    """An input handed over as struct ArrowDeviceArrayStream* with ARROW_DEVICE_ROCM buffers.
+
+    The stream yields the table as ONE batch per ``get_next`` (optionally split into ``splits`` row ranges);
+    it can be rewound with ``rewind()`` so a bench loop can re-run the plan on the same resident data.
+    """
+
+    kind = 1
+
+    def __init__(self, table: DeviceTable, device_id: int = 0):
+        self.table = table
+        self.device_id = device_id
+        self._emitted = False
+        self._keep = []  # ctypes objects referenced from C structs
+        self._c = ArrowDeviceArrayStreamC()
+        self._cb_schema = _GET_SCHEMA_T(self._get_schema)
+        self._cb_next = _GET_NEXT_T(self._get_next)
+        self._cb_err = _LAST_ERR_T(lambda _s: b"")
+        self._cb_release = _RELEASE_T(self._release)
+        self._cb_arr_release = _RELEASE_T(self._array_release)
+        self._c.device_type = ARROW_DEVICE_ROCM
+        self._c.get_schema = ctypes.cast(self._cb_schema, ctypes.c_void_p)
+        self._c.get_next = ctypes.cast(self._cb_next, ctypes.c_void_p)
+        self._c.get_last_error = ctypes.cast(self._cb_err, ctypes.c_void_p)
+        self._c.release = ctypes.cast(self._cb_release, ctypes.c_void_p)
+        self.released = False
+
+    @property
+    def address(self) -> int:
+        return ctypes.addressof(self._c)
+
+    def _get_schema(self, _self, out) -> int:
+        self.table.schema._export_to_c(out)
+        return 0
+
+    def _array_release(self, arr_ptr):
+        a = ctypes.cast(arr_ptr, ctypes.POINTER(ArrowArrayC)).contents
+        a.release = None
+
+    def _get_next(self, _self, out) -> int:
+        dev = ctypes.cast(out, ctypes.POINTER(ArrowDeviceArrayC)).contents
+        ctypes.memset(out, 0, ctypes.sizeof(ArrowDeviceArrayC))
+        if self._emitted:
+            return 0  # release == NULL → end of stream
+        self._emitted = True
+        t = self.table
+        n = len(t.values)
+        kids = (ctypes.POINTER(ArrowArrayC) * n)()
+        release = ctypes.cast(self._cb_arr_release, ctypes.c_void_p)
+        for i in range(n):
+            child = ArrowArrayC()
+            bufs = (ctypes.c_void_p * 2)()
+            bufs[0] = t.validity[i].data_ptr() if t.validity[i] is not None else None
+            bufs[1] = t.values[i].data_ptr() if t.values[i].numel() else None
+            child.length = t.num_rows
+            child.null_count = -1 if t.validity[i] is not None else 0
+            child.offset = 0
+            child.n_buffers = 2
+            child.n_children = 0
+            child.buffers = bufs
+            child.release = release
+            kids[i] = ctypes.pointer(child)
+            self._keep += [child, bufs]
+        top_bufs = (ctypes.c_void_p * 1)()
+        top_bufs[0] = None
+        dev.array.length = t.num_rows
+        dev.array.null_count = 0
+        dev.array.offset = 0
+        dev.array.n_buffers = 1
+        dev.array.n_children = n
+        dev.array.buffers = top_bufs
+        dev.array.children = kids
+        dev.array.release = release
+        dev.device_id = self.device_id
+        dev.device_type = ARROW_DEVICE_ROCM
+        self._keep += [kids, top_bufs]
+        return 0
+
+    def _release(self, _self):
+        self.released = True
+        self._c.release = None
+
+
+# --------------------------------------------------------------------------- Native (Native.scala)
+
+
+def _raise_last(handle: int):
+    l = lib()
+    msg = (l.comet_last_error(handle) or b"").decode(errors="replace")
+    kind = l.comet_last_error_kind(handle)
+    if kind == 1:
+        raise CometQueryExecutionException(msg)
+    raise CometNativeException(msg)
+
+
+class Native:
+    """The three calls of org.apache.comet.Native (Native.scala:60-111)."""
+
+    @staticmethod
+    def createPlan(inputs: Sequence, plan: bytes, config: bytes = b"", partition_count: int = 1, batch_size: int = 8192,
+                   device_id: int = 0) -> int:
+        l = lib()
+        n = len(inputs)
+        addrs = (ctypes.c_void_p * max(n, 1))(*[i.address for i in inputs])
+        kinds = (ctypes.c_int32 * max(n, 1))(*[i.kind for i in inputs])
+        h = l.comet_create_plan(plan, len(plan), config if config else None, len(config), addrs, kinds, n, partition_count,
+                                batch_size, device_id)
+        if h == 0:
+            _raise_last(0)
+        return h
+
+    @staticmethod
+    def executePlan(handle: int, num_output_cols: int) -> Optional[pa.RecordBatch]:
+        """Returns the next output batch, or None at end of stream (executePlan == -1)."""
+        l = lib()
+        arrays = [ArrowArrayC() for _ in range(num_output_cols)]
+        schemas = [ArrowSchemaC() for _ in range(num_output_cols)]
+        aaddr = (ctypes.c_void_p * max(num_output_cols, 1))(*[ctypes.addressof(a) for a in arrays])
+        saddr = (ctypes.c_void_p * max(num_output_cols, 1))(*[ctypes.addressof(s) for s in schemas])
+        rows = l.comet_execute_plan(handle, aaddr, saddr, num_output_cols)
+        if rows == -1:
+            return None
+        if rows < 0:
+            _raise_last(handle)
+        cols = [pa.Array._import_from_c(ctypes.addressof(a), ctypes.addressof(s)) for a, s in zip(arrays, schemas)]
+        if not cols:
+            return pa.RecordBatch.from_arrays([], names=[])
+        return pa.RecordBatch.from_arrays(cols, names=[f"col_{i}" for i in range(len(cols))])
+
+    @staticmethod
+    def releasePlan(handle: int) -> None:
+        lib().comet_release_plan(handle)
+
+
+class CometExecIterator:
+    """Per-task driver: createPlan → executePlan* → releasePlan (CometExecIterator.scala:109,158,236)."""
+
+    def __init__(self, inputs: Sequence, num_output_cols: int, plan: bytes, config: bytes = b"", batch_size: int = 8192,
+                 device_id: int = 0):
+        self._inputs = list(inputs)  # keep the exported streams alive
+        self.num_output_cols = num_output_cols
+        self.handle = Native.createPlan(self._inputs, plan, config, 1, batch_size, device_id)
+        self._closed = False
+
+    def __iter__(self) -> Iterator[pa.RecordBatch]:
+        return self
+
+    def __next__(self) -> pa.RecordBatch:
+        if self._closed:
+            raise StopIteration
+        b = Native.executePlan(self.handle, self.num_output_cols)
+        if b is None:
+            self.close()
+            raise StopIteration
+        return b
+
+    def kernel_stats(self):
+        ms, launches, rows = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+        lib().comet_plan_kernel_stats(self.handle, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows))
+        return ms.value, launches.value, rows.value
+
+    def metrics(self) -> bytes:
+        n = lib().comet_plan_metrics(self.handle, None, 0)
+        buf = ctypes.create_string_buffer(max(int(n), 1))
+        lib().comet_plan_metrics(self.handle, buf, n)
+        return buf.raw[:n]
+
+    def explain(self) -> str:
+        return (lib().comet_explain(self.handle) or b"").decode()
+
+    def close(self):
+        if not self._closed:
+            self._closed = True
+            Native.releasePlan(self.handle)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def execute_to_table(inputs: Sequence, num_output_cols: int, plan: bytes, **kw) -> List[pa.RecordBatch]:
+    it = CometExecIterator(inputs, num_output_cols, plan, **kw)
+    try:
+        return list(it)
+    finally:
+        it.close()
+
+
+def compile_plan(plan: bytes) -> str:
+    """Decode, plan, generate and hiprtc-compile for gfx950 without a GPU; returns the fused-pipeline text."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    rc = lib().comet_compile_plan(plan, len(plan), buf, len(buf))
+    if rc != 0:
+        _raise_last(0)
+    return buf.value.decode()

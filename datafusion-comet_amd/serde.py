@@ -1,0 +1,399 @@
+"""Plan-bytes builder: produces the protobuf bytes the JVM side would send for a plan.
+
+This is the Python stand-in for Spark's ``QueryPlanSerde`` (spark/src/main/scala/org/apache/comet/serde/
+QueryPlanSerde.scala, ``arithmetic.scala``, ``aggregates.scala``, ``literals.scala``) used by tests and
+bench.py: it emits wire-format bytes for ``spark.spark_operator.Operator`` exactly as protoc-generated
+code would (field numbers from native/proto/src/proto/{operator,expr,types,literal}.proto), without
+needing protoc.  The same Python plan objects are interpreted by ``oracle/`` so that the product (which
+only ever sees the bytes) and the oracle are driven from one description.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+# --------------------------------------------------------------------------- wire format
+
+
+def _varint(v: int) -> bytes:
+    if v < 0:
+        v += 1 << 64
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _tag(field_no: int, wt: int) -> bytes:
+    return _varint((field_no << 3) | wt)
+
+
+def _f_varint(field_no: int, v: int) -> bytes:
+    return _tag(field_no, 0) + _varint(v)
+
+
+def _f_bytes(field_no: int, b: bytes) -> bytes:
+    return _tag(field_no, 2) + _varint(len(b)) + b
+
+
+def _f_msg(field_no: int, b: bytes) -> bytes:
+    return _f_bytes(field_no, b)
+
+
+# --------------------------------------------------------------------------- types (types.proto:43-114)
+
+BOOL, INT8, INT16, INT32, INT64, FLOAT, DOUBLE, STRING, BYTES, TIMESTAMP, DECIMAL, TIMESTAMP_NTZ, DATE, NULL = range(14)
+
+
+@dataclass(frozen=True)
+class DataType:
+    type_id: int
+    precision: int = 0
+    scale: int = 0
+
+    def encode(self) -> bytes:
+        out = b""
+        if self.type_id != 0:
+            out += _f_varint(1, self.type_id)
+        if self.type_id == DECIMAL:
+            dec = _f_varint(1, self.precision) + (_f_varint(2, self.scale) if self.scale else b"")
+            out += _f_msg(2, _f_msg(2, dec))
+        return out
+
+    def __repr__(self):
+        names = ["bool", "int8", "int16", "int32", "int64", "float", "double", "string", "bytes", "timestamp",
+                 "decimal", "timestamp_ntz", "date", "null"]
+        if self.type_id == DECIMAL:
+            return f"decimal({self.precision},{self.scale})"
+        return names[self.type_id]
+
+
+def decimal(p: int, s: int) -> DataType:
+    return DataType(DECIMAL, p, s)
+
+
+T_BOOL, T_INT8, T_INT16, T_INT32, T_INT64 = (DataType(t) for t in (BOOL, INT8, INT16, INT32, INT64))
+T_FLOAT, T_DOUBLE, T_STRING, T_DATE, T_TIMESTAMP = (DataType(t) for t in (FLOAT, DOUBLE, STRING, DATE, TIMESTAMP))
+
+LEGACY, TRY, ANSI = 0, 1, 2
+
+# --------------------------------------------------------------------------- expressions (expr.proto)
+
+
+@dataclass
+class Expr:
+    kind: str                       # 'literal', 'bound', 'add', ...
+    children: List["Expr"] = field(default_factory=list)
+    dtype: Optional[DataType] = None  # literal/bound/cast/check_overflow datatype, math return_type
+    value: object = None            # literal python value (None = NULL)
+    index: int = -1                 # bound
+    eval_mode: int = LEGACY
+    fail_on_error: bool = False
+    negated: bool = False
+
+    # field numbers of Expr.expr_struct (expr.proto:30-107)
+    TAGS = dict(literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
+                lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, eq_null_safe=32,
+                neq_null_safe=33, remainder=37, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
+                unbound=51)
+
+    def encode(self) -> bytes:
+        k = self.kind
+        tag = self.TAGS[k]
+        if k == "literal":
+            body = self._encode_literal()
+        elif k == "bound":
+            body = (_f_varint(1, self.index) if self.index else b"") + _f_msg(2, self.dtype.encode())
+        elif k == "unbound":
+            body = _f_bytes(1, b"col") + _f_msg(2, self.dtype.encode())
+        elif k in ("add", "subtract", "multiply", "divide", "remainder"):
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.children[1].encode())
+            body += _f_msg(4, self.dtype.encode())
+            if self.eval_mode:
+                body += _f_varint(5, self.eval_mode)
+        elif k == "cast":
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_bytes(3, b"UTC")
+            if self.eval_mode:
+                body += _f_varint(4, self.eval_mode)
+        elif k == "check_overflow":
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode())
+            if self.fail_on_error:
+                body += _f_varint(3, 1)
+        elif k == "normalize_nan_and_zero":
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode())
+        elif k == "unary_minus":
+            body = _f_msg(1, self.children[0].encode()) + (_f_varint(2, 1) if self.fail_on_error else b"")
+        elif k == "in_":
+            body = _f_msg(1, self.children[0].encode())
+            for c in self.children[1:]:
+                body += _f_msg(2, c.encode())
+            if self.negated:
+                body += _f_varint(3, 1)
+        elif k == "if_":
+            body = b"".join(_f_msg(i + 1, c.encode()) for i, c in enumerate(self.children))
+        else:  # BinaryExpr / UnaryExpr
+            body = b"".join(_f_msg(i + 1, c.encode()) for i, c in enumerate(self.children))
+        return _f_msg(tag, body)
+
+    def _encode_literal(self) -> bytes:
+        t = self.dtype
+        out = b""
+        v = self.value
+        if v is not None:
+            tid = t.type_id
+            if tid == BOOL:
+                out += _f_varint(1, 1 if v else 0)
+            elif tid == INT8:
+                out += _f_varint(2, int(v))
+            elif tid == INT16:
+                out += _f_varint(3, int(v))
+            elif tid in (INT32, DATE):
+                out += _f_varint(4, int(v))
+            elif tid in (INT64, TIMESTAMP, TIMESTAMP_NTZ):
+                out += _f_varint(5, int(v))
+            elif tid == FLOAT:
+                out += _tag(6, 5) + struct.pack("<f", float(v))
+            elif tid == DOUBLE:
+                out += _tag(7, 1) + struct.pack("<d", float(v))
+            elif tid == STRING:
+                out += _f_bytes(8, v.encode() if isinstance(v, str) else bytes(v))
+            elif tid == BYTES:
+                out += _f_bytes(9, bytes(v))
+            elif tid == DECIMAL:
+                # BigInteger.toByteArray: minimal big-endian two's complement (literals.scala:92-95)
+                iv = int(v)
+                n = max(1, (iv.bit_length() + 8) // 8)
+                out += _f_bytes(10, iv.to_bytes(n, "big", signed=True))
+            else:
+                raise ValueError(f"literal of {t}")
+        out += _f_msg(12, t.encode())
+        if v is None:
+            out += _f_varint(13, 1)
+        return out
+
+
+def lit(value, dtype: DataType) -> Expr:
+    return Expr("literal", dtype=dtype, value=value)
+
+
+def col(index: int, dtype: DataType) -> Expr:
+    return Expr("bound", dtype=dtype, index=index)
+
+
+def _bin(kind):
+    def f(a: Expr, b: Expr) -> Expr:
+        return Expr(kind, [a, b])
+    return f
+
+
+eq, neq, gt, gt_eq, lt, lt_eq = (_bin(k) for k in ("eq", "neq", "gt", "gt_eq", "lt", "lt_eq"))
+and_, or_ = _bin("and_"), _bin("or_")
+eq_null_safe = _bin("eq_null_safe")
+
+
+def not_(a: Expr) -> Expr:
+    return Expr("not_", [a])
+
+
+def is_null(a: Expr) -> Expr:
+    return Expr("is_null", [a])
+
+
+def is_not_null(a: Expr) -> Expr:
+    return Expr("is_not_null", [a])
+
+
+def math(kind: str, a: Expr, b: Expr, return_type: DataType, eval_mode: int = LEGACY) -> Expr:
+    return Expr(kind, [a, b], dtype=return_type, eval_mode=eval_mode)
+
+
+def check_overflow(child: Expr, dtype: DataType, fail_on_error: bool = False) -> Expr:
+    return Expr("check_overflow", [child], dtype=dtype, fail_on_error=fail_on_error)
+
+
+def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY) -> Expr:
+    return Expr("cast", [child], dtype=dtype, eval_mode=eval_mode)
+
+
+def if_(c: Expr, t: Expr, f: Expr) -> Expr:
+    return Expr("if_", [c, t, f])
+
+
+def in_(value: Expr, items: Sequence[Expr], negated: bool = False) -> Expr:
+    return Expr("in_", [value, *items], negated=negated)
+
+
+# --------------------------------------------------------------------------- aggregates (expr.proto:143-260)
+
+
+@dataclass
+class AggExpr:
+    kind: str                       # count | sum | min | max | avg
+    children: List[Expr]
+    dtype: Optional[DataType] = None      # result type
+    sum_dtype: Optional[DataType] = None  # avg
+    eval_mode: int = LEGACY
+    filter: Optional[Expr] = None
+
+    TAGS = dict(count=2, sum=3, min=4, max=5, avg=6)
+
+    def encode(self) -> bytes:
+        if self.kind == "count":
+            body = b"".join(_f_msg(1, c.encode()) for c in self.children)
+        elif self.kind == "sum":
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode())
+            if self.eval_mode:
+                body += _f_varint(3, self.eval_mode)
+        elif self.kind in ("min", "max"):
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode())
+        elif self.kind == "avg":
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_msg(3, self.sum_dtype.encode())
+            if self.eval_mode:
+                body += _f_varint(4, self.eval_mode)
+        else:
+            raise ValueError(self.kind)
+        out = _f_msg(self.TAGS[self.kind], body)
+        if self.filter is not None:
+            out += _f_msg(89, self.filter.encode())
+        return out
+
+
+def count(*children: Expr) -> AggExpr:
+    return AggExpr("count", list(children))
+
+
+def sum_(child: Expr, dtype: DataType, eval_mode: int = LEGACY, filter: Optional[Expr] = None) -> AggExpr:
+    return AggExpr("sum", [child], dtype=dtype, eval_mode=eval_mode, filter=filter)
+
+
+def avg(child: Expr, dtype: DataType, sum_dtype: DataType, eval_mode: int = LEGACY) -> AggExpr:
+    return AggExpr("avg", [child], dtype=dtype, sum_dtype=sum_dtype, eval_mode=eval_mode)
+
+
+def min_(child: Expr, dtype: DataType) -> AggExpr:
+    return AggExpr("min", [child], dtype=dtype)
+
+
+def max_(child: Expr, dtype: DataType) -> AggExpr:
+    return AggExpr("max", [child], dtype=dtype)
+
+
+# --------------------------------------------------------------------------- operators (operator.proto)
+
+PARTIAL, FINAL, PARTIAL_MERGE = 0, 1, 2
+
+
+@dataclass
+class Operator:
+    kind: str                                   # scan | projection | filter | hash_agg | raw
+    children: List["Operator"] = field(default_factory=list)
+    fields: List[DataType] = field(default_factory=list)      # scan
+    exprs: List[Expr] = field(default_factory=list)           # projection list / grouping exprs
+    predicate: Optional[Expr] = None
+    aggs: List[AggExpr] = field(default_factory=list)
+    mode: int = PARTIAL
+    plan_id: int = 0
+    raw_tag: int = 0                            # 'raw': arbitrary op_struct tag with empty body (negative tests)
+
+    TAGS = dict(scan=100, projection=101, filter=102, hash_agg=104)
+
+    def encode(self) -> bytes:
+        out = b"".join(_f_msg(1, c.encode()) for c in self.children)
+        if self.plan_id:
+            out += _f_varint(2, self.plan_id)
+        if self.kind == "scan":
+            body = b"".join(_f_msg(1, f.encode()) for f in self.fields) + _f_bytes(2, b"test_scan")
+        elif self.kind == "projection":
+            body = b"".join(_f_msg(1, e.encode()) for e in self.exprs)
+        elif self.kind == "filter":
+            body = _f_msg(1, self.predicate.encode())
+        elif self.kind == "hash_agg":
+            body = b"".join(_f_msg(1, e.encode()) for e in self.exprs)
+            body += b"".join(_f_msg(2, a.encode()) for a in self.aggs)
+            if self.mode:
+                body += _f_varint(5, self.mode)
+        elif self.kind == "raw":
+            return out + _f_msg(self.raw_tag, b"")
+        else:
+            raise ValueError(self.kind)
+        return out + _f_msg(self.TAGS[self.kind], body)
+
+
+def scan(fields: Sequence[DataType]) -> Operator:
+    return Operator("scan", fields=list(fields))
+
+
+def filter_(child: Operator, predicate: Expr) -> Operator:
+    return Operator("filter", [child], predicate=predicate)
+
+
+def project(child: Operator, exprs: Sequence[Expr]) -> Operator:
+    return Operator("projection", [child], exprs=list(exprs))
+
+
+def hash_agg(child: Operator, grouping: Sequence[Expr], aggs: Sequence[AggExpr], mode: int = PARTIAL) -> Operator:
+    return Operator("hash_agg", [child], exprs=list(grouping), aggs=list(aggs), mode=mode)
+
+
+def config_map(entries: dict) -> bytes:
+    """spark.spark_config.ConfigMap (config.proto:24)."""
+    out = b""
+    for k, v in entries.items():
+        out += _f_msg(1, _f_bytes(1, k.encode()) + _f_bytes(2, str(v).encode()))
+    return out
+
+
+def decode_metric_node(b: bytes):
+    """spark.spark_metric.NativeMetricNode → (dict, [children]) — what CometMetricNode.set_all_from_bytes parses."""
+    pos = 0
+    metrics, children = {}, []
+
+    def rv():
+        nonlocal pos
+        v, shift = 0, 0
+        while True:
+            c = b[pos]
+            pos += 1
+            v |= (c & 0x7F) << shift
+            if not c & 0x80:
+                return v
+            shift += 7
+
+    while pos < len(b):
+        t = rv()
+        fno, wt = t >> 3, t & 7
+        assert wt == 2
+        n = rv()
+        sub = b[pos:pos + n]
+        pos += n
+        if fno == 1:
+            p2 = 0
+            key, val = None, 0
+            while p2 < len(sub):
+                t2 = sub[p2]
+                p2 += 1
+                if t2 == 0x0A:
+                    ln = sub[p2]
+                    p2 += 1
+                    key = sub[p2:p2 + ln].decode()
+                    p2 += ln
+                elif t2 == 0x10:
+                    v, shift = 0, 0
+                    while True:
+                        c = sub[p2]
+                        p2 += 1
+                        v |= (c & 0x7F) << shift
+                        if not c & 0x80:
+                            break
+                        shift += 7
+                    val = v if v < (1 << 63) else v - (1 << 64)
+            metrics[key] = val
+        elif fno == 2:
+            children.append(decode_metric_node(sub))
+    return metrics, children

@@ -1,0 +1,106 @@
+"""TPC-H plan shapes (as Comet serialises them) and seeded synthetic lineitem data.
+
+Plans follow the reference's native stage-1 shapes: Q6 SURVEY §3.3, Q1 SURVEY §3.4; decimal result types
+are Spark's (Appendix B; golden schema spark/src/test/resources/tpch-query-results/q1.sql.out:3-4).
+"""
+from __future__ import annotations
+
+import datetime
+
+import numpy as np
+import pyarrow as pa
+
+from . import serde as S
+
+DEC = S.decimal(12, 2)
+EPOCH = datetime.date(1970, 1, 1)
+
+
+def days(y, m, d) -> int:
+    return (datetime.date(y, m, d) - EPOCH).days
+
+
+# ------------------------------------------------------------------ data
+
+def _dec128_array(int64_values: np.ndarray, p: int, s: int) -> pa.Array:
+    """int64 unscaled values → Decimal128(p, s) Arrow array (16 B little-endian two's complement)."""
+    n = len(int64_values)
+    buf = np.empty((n, 2), dtype=np.int64)
+    buf[:, 0] = int64_values
+    buf[:, 1] = int64_values >> 63
+    return pa.Array.from_buffers(pa.decimal128(p, s), n, [None, pa.py_buffer(buf.tobytes())])
+
+
+def lineitem_q6(n: int, seed: int = 6, null_frac: float = 0.0) -> pa.Table:
+    """Columns in scan order: l_quantity, l_extendedprice, l_discount (decimal(12,2)), l_shipdate (date32)."""
+    rng = np.random.default_rng(seed)
+    qty = rng.integers(1, 51, n, dtype=np.int64)
+    price = qty * rng.integers(90000, 210001, n, dtype=np.int64)      # qty × U[900.00, 2100.00]
+    disc = rng.integers(0, 11, n, dtype=np.int64)                      # 0.00 .. 0.10
+    ship = rng.integers(days(1992, 1, 2), days(1998, 12, 1) + 1, n, dtype=np.int64).astype(np.int32)
+    cols = [_dec128_array(qty * 100, 12, 2), _dec128_array(price, 12, 2), _dec128_array(disc, 12, 2),
+            pa.array(ship, type=pa.int32()).cast(pa.date32())]
+    if null_frac > 0:
+        out = []
+        for i, c in enumerate(cols):
+            mask = rng.random(n) < null_frac
+            out.append(pa.Array.from_buffers(c.type, n, [pa.py_buffer(np.packbits(~mask, bitorder="little").tobytes()),
+                                                        c.buffers()[1]], null_count=int(mask.sum())))
+        cols = out
+    return pa.table(cols, names=["l_quantity", "l_extendedprice", "l_discount", "l_shipdate"])
+
+
+def lineitem_q1(n: int, seed: int = 1) -> pa.Table:
+    """l_quantity, l_extendedprice, l_discount, l_tax (decimal(12,2)), l_returnflag, l_linestatus (utf8), l_shipdate."""
+    rng = np.random.default_rng(seed)
+    qty = rng.integers(1, 51, n, dtype=np.int64)
+    price = qty * rng.integers(90000, 210001, n, dtype=np.int64)
+    disc = rng.integers(0, 11, n, dtype=np.int64)
+    tax = rng.integers(0, 9, n, dtype=np.int64)
+    ship = rng.integers(days(1992, 1, 2), days(1998, 12, 1) + 1, n, dtype=np.int64).astype(np.int32)
+    # dbgen correlation: shipped after 1995-06-17 → 'N'/'O'; earlier → 'R' or 'A' / 'F'
+    cutoff = days(1995, 6, 17)
+    late = ship > cutoff
+    rf = np.where(late, ord("N"), np.where(rng.random(n) < 0.5, ord("R"), ord("A"))).astype(np.uint8)
+    ls = np.where(late, ord("O"), ord("F")).astype(np.uint8)
+    # a sliver of 'N','F' like the real data (orders straddling the cutoff)
+    straddle = (~late) & (ship > cutoff - 60) & (rng.random(n) < 0.3)
+    rf = np.where(straddle, ord("N"), rf).astype(np.uint8)
+    offs = np.arange(n + 1, dtype=np.int32)
+
+    def utf8(bytes_arr):
+        return pa.Array.from_buffers(pa.utf8(), n, [None, pa.py_buffer(offs.tobytes()), pa.py_buffer(bytes_arr.tobytes())])
+
+    return pa.table([_dec128_array(qty * 100, 12, 2), _dec128_array(price, 12, 2), _dec128_array(disc, 12, 2),
+                     _dec128_array(tax, 12, 2), utf8(rf), utf8(ls), pa.array(ship, type=pa.int32()).cast(pa.date32())],
+                    names=["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"])
+
+
+# ------------------------------------------------------------------ plans
+
+def q6_plan(mode: int = S.PARTIAL) -> S.Operator:
+    """TPC-H Q6 stage 1:
+    HashAgg(Partial, sum(CheckOverflow(price*disc → dec(25,4))) : dec(35,4))
+      ← Project[price, disc] ← Filter(shipdate >= 1994-01-01 AND shipdate < 1995-01-01 AND
+                                       disc >= 0.05 AND disc <= 0.07 AND qty < 24.00) ← Scan."""
+    fields = [DEC, DEC, DEC, S.T_DATE]
+    qty, price, disc, ship = (S.col(i, t) for i, t in enumerate(fields))
+    pred = S.and_(S.and_(S.and_(S.and_(
+        S.gt_eq(ship, S.lit(days(1994, 1, 1), S.T_DATE)),
+        S.lt(ship, S.lit(days(1995, 1, 1), S.T_DATE))),
+        S.gt_eq(disc, S.lit(5, DEC))),
+        S.lt_eq(disc, S.lit(7, DEC))),
+        S.lt(qty, S.lit(2400, DEC)))
+    f = S.filter_(S.scan(fields), pred)
+    p = S.project(f, [price, disc])
+    revenue = S.check_overflow(S.math("multiply", S.col(0, DEC), S.col(1, DEC), S.decimal(25, 4)), S.decimal(25, 4))
+    return S.hash_agg(p, [], [S.sum_(revenue, S.decimal(35, 4))], mode)
+
+
+Q6_NUM_OUTPUT_COLS = 2  # (sum dec(35,4), is_empty bool)
+Q6_BYTES_PER_ROW = 4 + 16 + 16 + 16  # Arrow layout of the four referenced columns
+
+
+def warm_plans():
+    """Plans whose fused kernels build() pre-compiles into the code-object cache."""
+    return [q6_plan()]

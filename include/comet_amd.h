@@ -1,0 +1,96 @@
+/* comet_amd.h — C ABI of libcomet.so, the MI355X-native drop-in for Comet's native library on the
+ * hot path  Scan → Filter/Project → HashAggregate (→ HashJoin probe).
+ *
+ * Each entry point names the reference interface it replaces.  The JNI symbols that Spark's
+ * `Native.scala` binds (Java_org_apache_comet_Native_*) are thin shims over these functions
+ * (datafusion-comet_amd/csrc/jni_shim.cpp); tests and bench.py drive the same functions through
+ * ctypes + the Arrow C Data / C Stream / C Device interfaces, the JVM-free path that mirrors the
+ * reference's TEST_EXEC_CONTEXT_ID planner tests (native/core/src/execution/planner.rs:245,4637-4936).
+ *
+ * Conventions: plain pointers and sizes only; no C++ exception ever crosses this boundary.  A failed
+ * call returns the documented error value and leaves a message retrievable with comet_last_error().
+ */
+#ifndef COMET_AMD_H
+#define COMET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct ArrowArray;
+struct ArrowSchema;
+
+/* how input i is handed over */
+#define COMET_INPUT_HOST_STREAM 0   /* struct ArrowArrayStream*       — JVM path (CometNativeArrowSource.scala:67) */
+#define COMET_INPUT_DEVICE_STREAM 1 /* struct ArrowDeviceArrayStream* — ARROW_DEVICE_ROCM buffers already in HBM */
+
+/* error kinds → Java exception class (native/jni-bridge/src/errors.rs:473-560) */
+#define COMET_ERR_NATIVE 0          /* org/apache/comet/CometNativeException(msg) */
+#define COMET_ERR_QUERY_EXECUTION 1 /* org/apache/comet/exceptions/CometQueryExecutionException(json) */
+
+/* Replaces Java_org_apache_comet_Native_createPlan (native/core/src/execution/jni_api.rs:371-562;
+ * Scala declaration spark/src/main/scala/org/apache/comet/Native.scala:60-79).
+ *   plan/plan_len       protobuf bytes of spark.spark_operator.Operator (native/proto/src/proto/operator.proto:32)
+ *   config/config_len   protobuf bytes of spark.spark_config.ConfigMap (may be NULL/0)
+ *   inputs/input_kinds  one entry per Scan leaf in depth-first order (planner.rs:1726); the library takes
+ *                       ownership of each stream and releases it when the plan is released (scan.rs:41-44)
+ *   batch_size          spark.comet.batchSize: upper bound on rows per output batch (0 = unbounded)
+ *   device_id           HIP device ordinal this plan runs on (one plan = one Spark partition = one GPU)
+ * Nothing is pulled from the inputs before the first comet_execute_plan (jni_api.rs:795-797).
+ * Returns a handle > 0, or 0 on error (message via comet_last_error(0)). */
+int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* config, size_t config_len,
+                          void** inputs, const int32_t* input_kinds, int32_t n_inputs, int32_t partition_count,
+                          int32_t batch_size, int32_t device_id);
+
+/* Replaces Java_org_apache_comet_Native_executePlan (jni_api.rs:767-957; Native.scala:98-103).
+ * Writes one MOVED ArrowArray + ArrowSchema per output column into the caller-allocated structs
+ * (prepare_output, jni_api.rs:674-742; array offset is 0; buffers live until the consumer calls release).
+ * Returns the number of rows, -1 at end of stream, -2 on error. */
+int64_t comet_execute_plan(int64_t handle, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas,
+                           int32_t n_out);
+
+/* Replaces Java_org_apache_comet_Native_releasePlan (jni_api.rs:961-990). Safe mid-stream. */
+void comet_release_plan(int64_t handle);
+
+/* Error text / kind of the last failed call on this handle (handle 0: last failed comet_create_plan on
+ * the calling thread).  The JNI shim turns it into the Java exception (errors.rs:832-850). */
+const char* comet_last_error(int64_t handle);
+int32_t comet_last_error_kind(int64_t handle);
+
+/* Serialized spark.spark_metric.NativeMetricNode for the plan (what the reference pushes through
+ * CometMetricNode.set_all_from_bytes, native/core/src/execution/metrics/utils.rs:30-45).
+ * Returns the byte length; copies at most cap bytes into buf. */
+int64_t comet_plan_metrics(int64_t handle, uint8_t* buf, size_t cap);
+
+/* Fused-pipeline description (the counterpart of spark.comet.explain.native.enabled, jni_api.rs:816-820). */
+const char* comet_explain(int64_t handle);
+
+/* Kernel timing of the work done so far by this plan, measured with HIP events on the plan's own
+ * stream: total milliseconds, number of timed launches, input rows.  Used by bench.py's roofline. */
+void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launches, int64_t* input_rows);
+
+/* Decode + plan + generate + compile (hiprtc, gfx950) without touching a GPU.  Returns 0 on success and
+ * writes a description into out (NUL terminated, truncated to cap), -2 on error (comet_last_error(0)). */
+int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap);
+
+/* Spark-compatible murmur3 (seed chaining) + pmod partition ids for the exchange step — replaces
+ * create_murmur3_hashes (native/spark-expr/src/hash_funcs/murmur3.rs:185-198) and pmod
+ * (native/shuffle/src/comet_partitioning.rs:51-57).  All pointers are DEVICE pointers.
+ *   type_id: spark DataTypeId (types.proto:43-66) of the column; precision for DECIMAL
+ *   hashes:  in/out uint32 per row (initialise to 42 for the first column)
+ * Returns 0, or -2 on error. */
+int32_t comet_murmur3_column(int32_t type_id, int32_t precision, const void* values, const uint8_t* validity,
+                             const void* aux_bytes, int64_t n, uint32_t* hashes, void* hip_stream);
+int32_t comet_pmod_partition(const uint32_t* hashes, int64_t n, int32_t num_partitions, int32_t* partition_ids,
+                             void* hip_stream);
+
+/* Library identity (NativeBase.java:82-106 loads "comet"). */
+const char* comet_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,410 @@
+/* comet_oracle.c — CPU restatement of the reference's arithmetic for the scan→filter→aggregate hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under datafusion-comet_amd/ may include, link or call this file;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker
+ * (or as the timed CPU baseline), never as the product.
+ *
+ * The reference is Rust (apache/datafusion-comet) and cannot be built in this image (no rustc/cargo, no
+ * vendored crates), so each function below restates one reference function in plain C and cites it.
+ * Where the arithmetic lives in a third-party crate that is not under /root/reference (arrow-arith /
+ * arrow-ord 58.4.0, datafusion 54.1.0 — pinned in native/Cargo.toml:38-44), the published Arrow
+ * semantics are restated and anchored on the reference's own call sites.
+ * Pinned by tests/test_oracle_kat.py against every known-answer vector the reference's tests hold for
+ * this path: murmur3/pmod KATs, wide-decimal cases, SumDecimal/AvgDecimal cases.
+ *
+ * Layout conventions: Decimal128 columns are arrays of __int128 (Arrow's 16-byte little-endian layout),
+ * validity is one byte per row (1 = valid) to keep the checker trivial to audit.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------------------------------------
+ * Spark murmur3_x86_32 — native/spark-expr/src/hash_funcs/murmur3.rs:73-142
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+static inline uint32_t mix_k1(uint32_t k1) { k1 *= 0xcc9e2d51u; k1 = rotl32(k1, 15); k1 *= 0x1b873593u; return k1; }
+static inline uint32_t mix_h1(uint32_t h1, uint32_t k1) { h1 ^= k1; h1 = rotl32(h1, 13); return h1 * 5u + 0xe6546b64u; }
+static inline uint32_t fmix(uint32_t h1, uint32_t len) {
+  h1 ^= len; h1 ^= h1 >> 16; h1 *= 0x85ebca6bu; h1 ^= h1 >> 13; h1 *= 0xc2b2ae35u; h1 ^= h1 >> 16; return h1;
+}
+uint32_t o_murmur3_bytes(const uint8_t* data, int32_t len, uint32_t seed) {
+  uint32_t h1 = seed;
+  int32_t aligned = len - len % 4;
+  for (int32_t i = 0; i < aligned; i += 4) {       /* hash_bytes_by_int, murmur3.rs:103-116 */
+    uint32_t w;
+    memcpy(&w, data + i, 4);
+    h1 = mix_h1(h1, mix_k1(w));
+  }
+  for (int32_t i = aligned; i < len; i++) {        /* tail bytes sign-extended one at a time, :135-138 */
+    int32_t half = (int32_t)(int8_t)data[i];
+    h1 = mix_h1(h1, mix_k1((uint32_t)half));
+  }
+  return fmix(h1, (uint32_t)len);
+}
+/* create_hashes_internal! type dispatch — native/spark-expr/src/hash_funcs/utils.rs:573-760:
+ * bool/int8/int16/int32/date32 hash as 4-byte i32; int64/timestamp/decimal(p≤18) as 8-byte i64;
+ * floats with -0.0 → 0; decimal(p>18) as 16 LE bytes; NULL rows leave the running hash untouched. */
+void o_murmur3_i32(const int32_t* v, const uint8_t* valid, int64_t n, uint32_t* hashes) {
+  for (int64_t i = 0; i < n; i++) if (!valid || valid[i]) hashes[i] = o_murmur3_bytes((const uint8_t*)&v[i], 4, hashes[i]);
+}
+void o_murmur3_i64(const int64_t* v, const uint8_t* valid, int64_t n, uint32_t* hashes) {
+  for (int64_t i = 0; i < n; i++) if (!valid || valid[i]) hashes[i] = o_murmur3_bytes((const uint8_t*)&v[i], 8, hashes[i]);
+}
+void o_murmur3_f32(const float* v, const uint8_t* valid, int64_t n, uint32_t* hashes) {
+  for (int64_t i = 0; i < n; i++) if (!valid || valid[i]) {
+    float f = v[i];
+    int32_t bits;
+    if (f == 0.0f) bits = 0; else memcpy(&bits, &f, 4);   /* hash_array_primitive_float: -0.0 → 0 */
+    hashes[i] = o_murmur3_bytes((const uint8_t*)&bits, 4, hashes[i]);
+  }
+}
+void o_murmur3_f64(const double* v, const uint8_t* valid, int64_t n, uint32_t* hashes) {
+  for (int64_t i = 0; i < n; i++) if (!valid || valid[i]) {
+    double d = v[i];
+    int64_t bits;
+    if (d == 0.0) bits = 0; else memcpy(&bits, &d, 8);
+    hashes[i] = o_murmur3_bytes((const uint8_t*)&bits, 8, hashes[i]);
+  }
+}
+void o_murmur3_decimal(const i128* v, int precision, const uint8_t* valid, int64_t n, uint32_t* hashes) {
+  for (int64_t i = 0; i < n; i++) if (!valid || valid[i]) {
+    if (precision <= 18) { int64_t x = (int64_t)v[i]; hashes[i] = o_murmur3_bytes((const uint8_t*)&x, 8, hashes[i]); }
+    else hashes[i] = o_murmur3_bytes((const uint8_t*)&v[i], 16, hashes[i]);
+  }
+}
+void o_murmur3_utf8(const int32_t* offsets, const uint8_t* bytes, const uint8_t* valid, int64_t n, uint32_t* hashes) {
+  for (int64_t i = 0; i < n; i++) if (!valid || valid[i])
+    hashes[i] = o_murmur3_bytes(bytes + offsets[i], offsets[i + 1] - offsets[i], hashes[i]);
+}
+/* pmod — native/shuffle/src/comet_partitioning.rs:51-57 */
+int32_t o_pmod(uint32_t hash, int32_t n) {
+  int32_t h = (int32_t)hash;
+  int32_t r = h % n;
+  return r < 0 ? (r + n) % n : r;
+}
+void o_pmod_array(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out) {
+  for (int64_t i = 0; i < n; i++) out[i] = o_pmod(hashes[i], np);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * i256 (arrow_buffer::i256 semantics: two's complement, wrapping ops) — four little-endian u64 limbs
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t w[4]; } i256;
+static i256 i256_from_i128(i128 v) {
+  i256 r; r.w[0] = (uint64_t)(u128)v; r.w[1] = (uint64_t)((u128)v >> 64);
+  r.w[2] = r.w[3] = v < 0 ? ~0ull : 0ull; return r;
+}
+static int i256_is_neg(i256 a) { return (int)(a.w[3] >> 63); }
+static i256 i256_add(i256 a, i256 b) {
+  i256 r; u128 c = 0;
+  for (int k = 0; k < 4; k++) { c += (u128)a.w[k] + b.w[k]; r.w[k] = (uint64_t)c; c >>= 64; }
+  return r;
+}
+static i256 i256_negate(i256 a) {
+  i256 r; u128 c = 1;
+  for (int k = 0; k < 4; k++) { c += (u128)(~a.w[k]); r.w[k] = (uint64_t)c; c >>= 64; }
+  return r;
+}
+static i256 i256_sub(i256 a, i256 b) { return i256_add(a, i256_negate(b)); }
+static i256 i256_mul_wrapping(i256 a, i256 b) {   /* schoolbook, low 256 bits */
+  uint64_t r[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 carry = 0;
+    for (int j = 0; i + j < 4; j++) {
+      u128 t = (u128)a.w[i] * b.w[j] + r[i + j] + carry;
+      r[i + j] = (uint64_t)t; carry = t >> 64;
+    }
+  }
+  i256 o; memcpy(o.w, r, 32); return o;
+}
+static int i256_cmp(i256 a, i256 b) {             /* signed compare */
+  int na = i256_is_neg(a), nb = i256_is_neg(b);
+  if (na != nb) return na ? -1 : 1;
+  for (int k = 3; k >= 0; k--) if (a.w[k] != b.w[k]) return a.w[k] < b.w[k] ? -1 : 1;
+  return 0;
+}
+static int u256_bit(i256 a, int bit) { return (int)((a.w[bit >> 6] >> (bit & 63)) & 1); }
+/* truncating signed division, quotient and remainder like Rust `/` and `%` on i256 */
+static void i256_divrem(i256 n, i256 d, i256* q, i256* r) {
+  int nn = i256_is_neg(n), dn = i256_is_neg(d);
+  i256 an = nn ? i256_negate(n) : n, ad = dn ? i256_negate(d) : d;
+  i256 quo = {{0, 0, 0, 0}}, rem = {{0, 0, 0, 0}};
+  for (int bit = 255; bit >= 0; bit--) {
+    /* rem = rem << 1 | bit */
+    for (int k = 3; k > 0; k--) rem.w[k] = (rem.w[k] << 1) | (rem.w[k - 1] >> 63);
+    rem.w[0] = (rem.w[0] << 1) | (uint64_t)u256_bit(an, bit);
+    /* unsigned compare rem >= ad */
+    int ge = 1;
+    for (int k = 3; k >= 0; k--) if (rem.w[k] != ad.w[k]) { ge = rem.w[k] > ad.w[k]; break; }
+    if (ge) { rem = i256_sub(rem, ad); quo.w[bit >> 6] |= 1ull << (bit & 63); }
+  }
+  *q = (nn != dn) ? i256_negate(quo) : quo;
+  *r = nn ? i256_negate(rem) : rem;
+}
+static i256 i256_pow10(int e) {                   /* wide_decimal_binary_expr.rs:150-158 */
+  i256 r = i256_from_i128(1), ten = i256_from_i128(10);
+  for (int i = 0; i < e; i++) r = i256_mul_wrapping(r, ten);
+  return r;
+}
+/* div_round_half_up — wide_decimal_binary_expr.rs:121-144 */
+static i256 div_round_half_up(i256 value, i256 divisor) {
+  i256 quot, rem, zero = {{0, 0, 0, 0}}, one = i256_from_i128(1), two = i256_from_i128(2);
+  i256_divrem(value, divisor, &quot, &rem);
+  i256 abs_rem_x2 = i256_mul_wrapping(i256_cmp(rem, zero) < 0 ? i256_negate(rem) : rem, two);
+  i256 abs_div = i256_cmp(divisor, zero) < 0 ? i256_negate(divisor) : divisor;
+  if (i256_cmp(abs_rem_x2, abs_div) >= 0) {
+    if ((i256_cmp(value, zero) < 0) != (i256_cmp(divisor, zero) < 0)) return i256_sub(quot, one);
+    return i256_add(quot, one);
+  }
+  return quot;
+}
+
+static i128 pow10_i128(int e) { i128 r = 1; for (int i = 0; i < e; i++) r *= 10; return r; }
+
+/* WideDecimalBinaryExpr::evaluate — wide_decimal_binary_expr.rs:179-300 (+ check_overflow_and_convert :335-350).
+ * op: 0 add, 1 subtract, 2 multiply.  ok[i] = 0 where the result overflowed p_out (LEGACY/TRY → NULL);
+ * returns the number of overflowed rows (ANSI callers turn >0 into an error). Input validity is the caller's. */
+int64_t o_wide_decimal(int op, const i128* l, int s1, const i128* r, int s2, int p_out, int s_out,
+                       i128* out, uint8_t* ok, int64_t n) {
+  i256 bound = i256_sub(i256_pow10(p_out), i256_from_i128(1));
+  i256 neg_bound = i256_negate(bound);
+  int64_t overflowed = 0;
+  int max_scale = s1 > s2 ? s1 : s2;
+  int scale_diff = (op == 2) ? (s1 + s2 - s_out) : (max_scale - s_out);
+  i256 l_up = i256_pow10(op == 2 ? 0 : max_scale - s1), r_up = i256_pow10(op == 2 ? 0 : max_scale - s2);
+  i256 rescale = i256_pow10(scale_diff > 0 ? scale_diff : -scale_diff);
+  for (int64_t i = 0; i < n; i++) {
+    i256 raw;
+    if (op == 2) raw = i256_mul_wrapping(i256_from_i128(l[i]), i256_from_i128(r[i]));
+    else {
+      i256 a = i256_mul_wrapping(i256_from_i128(l[i]), l_up), b = i256_mul_wrapping(i256_from_i128(r[i]), r_up);
+      raw = op == 0 ? i256_add(a, b) : i256_sub(a, b);
+    }
+    i256 res = scale_diff > 0 ? div_round_half_up(raw, rescale) : (scale_diff < 0 ? i256_mul_wrapping(raw, rescale) : raw);
+    if (i256_cmp(res, bound) > 0 || i256_cmp(res, neg_bound) < 0) { ok[i] = 0; out[i] = 0; overflowed++; }
+    else { ok[i] = 1; out[i] = (i128)(((u128)res.w[1] << 64) | res.w[0]); }
+  }
+  return overflowed;
+}
+
+/* Decimal128Type::is_valid_decimal_precision as used by CheckOverflow — checkoverflow.rs:128-160:
+ * never rescales, only |v| <= 10^p - 1. */
+int o_dec_fits(i128 v, int p) { i128 b = pow10_i128(p) - 1; return v <= b && v >= -b; }
+void o_check_overflow(const i128* v, int p, uint8_t* ok, int64_t n) { for (int64_t i = 0; i < n; i++) ok[i] = (uint8_t)o_dec_fits(v[i], p); }
+
+/* rescale_and_check — decimal_rescale_check.rs:108-150 */
+void o_rescale_check(const i128* v, int s_in, int p_out, int s_out, i128* out, uint8_t* ok, int64_t n) {
+  int delta = s_out - s_in;
+  i128 f = pow10_i128(delta < 0 ? -delta : delta), bound = pow10_i128(p_out) - 1;
+  for (int64_t i = 0; i < n; i++) {
+    i128 x = v[i], r;
+    if (delta > 0) { if (__builtin_mul_overflow(x, f, &r)) { ok[i] = 0; out[i] = 0; continue; } }
+    else if (delta < 0) { i128 half = f / 2, sign = (x > 0) - (x < 0); r = (x + sign * half) / f; }
+    else r = x;
+    if (r > bound || r < -bound) { ok[i] = 0; out[i] = 0; } else { ok[i] = 1; out[i] = r; }
+  }
+}
+
+/* Narrow decimal arithmetic: DataFusion BinaryExpr → arrow-arith decimal kernels (third-party; call site
+ * planner.rs:1128).  mul: product of the unscaled values, scale s1+s2; add/sub: operands scaled to
+ * max(s1,s2) first.  Exact in i128 because the planner only takes this path when the result precision
+ * stays below 38 (planner.rs:1000-1008). */
+void o_dec_mul(const i128* a, const i128* b, i128* out, int64_t n) { for (int64_t i = 0; i < n; i++) out[i] = a[i] * b[i]; }
+void o_dec_addsub(const i128* a, int s1, const i128* b, int s2, int sub, i128* out, int64_t n) {
+  int m = s1 > s2 ? s1 : s2;
+  i128 fa = pow10_i128(m - s1), fb = pow10_i128(m - s2);
+  for (int64_t i = 0; i < n; i++) out[i] = sub ? a[i] * fa - b[i] * fb : a[i] * fa + b[i] * fb;
+}
+/* comparison kernels (arrow-ord, third-party; call sites expressions/comparison.rs:34-50): op 0 eq 1 neq 2 lt 3 lteq 4 gt 5 gteq */
+void o_cmp_i128(int op, const i128* a, const i128* b, uint8_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    i128 x = a[i], y = b[i];
+    out[i] = (uint8_t)(op == 0 ? x == y : op == 1 ? x != y : op == 2 ? x < y : op == 3 ? x <= y : op == 4 ? x > y : x >= y);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * SumDecimal — native/spark-expr/src/agg_funcs/sum_decimal.rs
+ * state: sum (Option<i128>), is_empty.  "overflowed" is sum==None && !is_empty.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { i128 sum; int32_t has_sum; int32_t is_empty; } SumDecState;
+
+void o_sumdec_init(SumDecState* s) { s->sum = 0; s->has_sum = 1; s->is_empty = 1; }   /* SumDecimalAccumulator::new, :185-197; resize_helper :400-404 */
+/* update_single — sum_decimal.rs:201-224 (ungrouped) and :417-438 (grouped): identical arithmetic */
+static int sumdec_update_single(SumDecState* s, i128 v, int precision, int ansi) {
+  if (!s->is_empty && !s->has_sum) return 0;
+  i128 running = s->has_sum ? s->sum : 0, ns;
+  int ovf = __builtin_add_overflow(running, v, &ns);
+  if (ovf || !o_dec_fits(ns, precision)) {
+    if (ansi) return 1;
+    s->has_sum = 0; s->is_empty = 0;
+    return 0;
+  }
+  s->sum = ns; s->has_sum = 1; s->is_empty = 0;
+  return 0;
+}
+/* SumDecimalAccumulator::update_batch — :231-262 (ungrouped; valid==NULL means no nulls). returns 1 on ANSI error */
+int o_sumdec_update_batch(SumDecState* s, const i128* v, const uint8_t* valid, int64_t n, int precision, int ansi) {
+  if (!s->is_empty && !s->has_sum) return 0;
+  int64_t nulls = 0;
+  if (valid) for (int64_t i = 0; i < n; i++) nulls += !valid[i];
+  s->is_empty = s->is_empty && (n == nulls);
+  if (s->is_empty) return 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (valid && !valid[i]) continue;
+    if (sumdec_update_single(s, v[i], precision, ansi)) return 1;
+  }
+  return 0;
+}
+/* SumDecimalGroupsAccumulator::update_batch — :441-475; filter (opt_filter) rows are applied by the caller
+ * by passing valid=0 for excluded rows (a NULL or false filter excludes the row, :452-458) */
+int o_sumdec_update_groups(SumDecState* states, const i128* v, const uint8_t* valid, const int64_t* group, int64_t n,
+                           int precision, int ansi) {
+  for (int64_t i = 0; i < n; i++) {
+    if (valid && !valid[i]) continue;
+    if (sumdec_update_single(&states[group[i]], v[i], precision, ansi)) return 1;
+  }
+  return 0;
+}
+/* merge_batch — :309-368 (ungrouped) / :540-609 (grouped): one partial-state row into `s` */
+int o_sumdec_merge(SumDecState* s, const i128* that_sum_p, int that_has_sum, int that_is_empty, int precision, int ansi) {
+  i128 that_sum = *that_sum_p;
+  int that_overflowed = !that_is_empty && !that_has_sum;
+  int this_overflowed = !s->is_empty && !s->has_sum;
+  if (that_overflowed || this_overflowed) { s->has_sum = 0; s->is_empty = 0; return 0; }
+  if (that_is_empty) return 0;
+  if (s->is_empty) { s->sum = that_sum; s->has_sum = 1; s->is_empty = 0; return 0; }
+  i128 ns;
+  int ovf = __builtin_add_overflow(s->sum, that_sum, &ns);
+  if (ovf || !o_dec_fits(ns, precision)) {
+    if (ansi) return 1;
+    s->has_sum = 0; s->is_empty = 0;
+  } else s->sum = ns;
+  return 0;
+}
+/* evaluate — :264-279 / :477-495: NULL if empty or overflowed or out of precision. returns 1 if value present */
+int o_sumdec_evaluate(const SumDecState* s, int precision, i128* out) {
+  if (s->is_empty || !s->has_sum || !o_dec_fits(s->sum, precision)) return 0;
+  *out = s->sum;
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * AvgDecimal — native/spark-expr/src/agg_funcs/avg_decimal.rs (grouped accumulator :483-494, merge
+ * :542-595, evaluate :597-636, avg() :670-689)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { i128 sum; int64_t count; int32_t is_not_null; int32_t pad; } AvgDecState;
+void o_avgdec_init(AvgDecState* s) { s->sum = 0; s->count = 0; s->is_not_null = 1; s->pad = 0; }
+void o_avgdec_update_groups(AvgDecState* states, const i128* v, const uint8_t* valid, const int64_t* group, int64_t n, int sum_precision) {
+  for (int64_t i = 0; i < n; i++) {
+    if (valid && !valid[i]) continue;
+    AvgDecState* s = &states[group ? group[i] : 0];
+    i128 ns;
+    int ovf = __builtin_add_overflow(s->sum, v[i], &ns);
+    if (ovf) ns = (i128)((u128)s->sum + (u128)v[i]);   /* overflowing_add keeps the wrapped value */
+    s->count += 1;
+    s->sum = ns;
+    if (ovf || !o_dec_fits(ns, sum_precision)) s->is_not_null = 0;
+  }
+}
+int o_avgdec_merge(AvgDecState* s, const i128* psum_p, int psum_valid, int64_t pcount, int pcount_valid, int sum_precision, int ansi) {
+  i128 psum = *psum_p;
+  s->count += pcount;
+  if (!psum_valid) { s->is_not_null = 0; }
+  else {
+    i128 ns;
+    int ovf = __builtin_add_overflow(s->sum, psum, &ns);
+    if (ovf || !o_dec_fits(ns, sum_precision)) { if (ansi) return 1; s->is_not_null = 0; }
+    else s->sum = ns;
+  }
+  if (!pcount_valid) s->is_not_null = 0;
+  return 0;
+}
+/* avg() — avg_decimal.rs:670-689: sum*scaler / count ROUND_HALF_UP, bound check. returns 1 if value present */
+int o_avgdec_avg(i128 sum, int64_t count, int target_precision, int target_scale, int sum_scale, i128* out) {
+  int up = target_scale - sum_scale; if (up < 0) up = 0;         /* saturating_sub */
+  i128 scaler = pow10_i128(up), value;
+  if (__builtin_mul_overflow(sum, scaler, &value)) return 0;
+  i128 c = (i128)count, div = value / c, rem = value % c;
+  i128 half = (c + 1) / 2;  /* div_ceil(count, 2), count > 0 */
+  i128 nv = div;
+  if (value >= 0) { if (rem >= half) nv = div + 1; }
+  else { if (rem <= -half) nv = div - 1; }
+  i128 b = pow10_i128(target_precision) - 1;
+  if (nv < -b || nv > b) return 0;
+  *out = nv;
+  return 1;
+}
+int o_avgdec_evaluate(const AvgDecState* s, int target_precision, int target_scale, int sum_scale, i128* out) {
+  if (!s->is_not_null || s->count == 0) return 0;               /* :613-616 */
+  return o_avgdec_avg(s->sum, s->count, target_precision, target_scale, sum_scale, out);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Avg (Float64) — agg_funcs/avg.rs:239-280 (grouped: sequential sum += v in row order), evaluate :311-327
+ * SumInteger LEGACY — agg_funcs/sum_int.rs:403-475 (wrapping i64, NULL until a non-null value)
+ * ---------------------------------------------------------------------------------------------- */
+void o_avgf64_update_groups(double* sums, int64_t* counts, const double* v, const uint8_t* valid, const int64_t* group, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    if (valid && !valid[i]) continue;
+    int64_t g = group ? group[i] : 0;
+    sums[g] = sums[g] + v[i];
+    counts[g] += 1;
+  }
+}
+void o_sumint_update_groups(int64_t* sums, uint8_t* has, const int64_t* v, const uint8_t* valid, const int64_t* group, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    if (valid && !valid[i]) continue;
+    int64_t g = group ? group[i] : 0;
+    sums[g] = (int64_t)((uint64_t)(has[g] ? sums[g] : 0) + (uint64_t)v[i]);
+    has[g] = 1;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CPU baseline: TPC-H Q6 stage 1 executed the way the reference executes it — operator at a time over
+ * batches of `batch` rows (spark.comet.batchSize = 8192): FilterExec evaluates each comparison into a
+ * boolean array, ANDs them, filter_record_batch compacts the projected columns, ProjectionExec
+ * materialises price*disc and CheckOverflow, SumDecimal::update_batch accumulates
+ * (call stack SURVEY.md §3.3; planner.rs:1230-1384).  Single thread.
+ *   cols: l_quantity, l_extendedprice, l_discount as Decimal128 (i128), l_shipdate as int32 days.
+ * ---------------------------------------------------------------------------------------------- */
+void o_q6_reference_pipeline(const i128* qty, const i128* price, const i128* disc, const int32_t* ship, int64_t n,
+                             int32_t d0, int32_t d1, const i128* lits /* disc_lo, disc_hi, qty_lt */, int64_t batch,
+                             i128* out_sum, int32_t* out_has_sum, int32_t* out_is_empty) {
+  const i128 disc_lo = lits[0], disc_hi = lits[1], qty_lt = lits[2];
+  SumDecState st;
+  o_sumdec_init(&st);
+  uint8_t* m0 = (uint8_t*)malloc((size_t)batch);
+  uint8_t* m1 = (uint8_t*)malloc((size_t)batch);
+  i128* fprice = (i128*)malloc((size_t)batch * 16);
+  i128* fdisc = (i128*)malloc((size_t)batch * 16);
+  i128* prod = (i128*)malloc((size_t)batch * 16);
+  uint8_t* ok = (uint8_t*)malloc((size_t)batch);
+  for (int64_t base = 0; base < n; base += batch) {
+    int64_t len = n - base < batch ? n - base : batch;
+    /* FilterExec: one pass per comparison node, then AND (BinaryExpr tree, no fusion) */
+    for (int64_t i = 0; i < len; i++) m0[i] = ship[base + i] >= d0;
+    for (int64_t i = 0; i < len; i++) m1[i] = ship[base + i] < d1;
+    for (int64_t i = 0; i < len; i++) m0[i] &= m1[i];
+    for (int64_t i = 0; i < len; i++) m1[i] = disc[base + i] >= disc_lo;
+    for (int64_t i = 0; i < len; i++) m0[i] &= m1[i];
+    for (int64_t i = 0; i < len; i++) m1[i] = disc[base + i] <= disc_hi;
+    for (int64_t i = 0; i < len; i++) m0[i] &= m1[i];
+    for (int64_t i = 0; i < len; i++) m1[i] = qty[base + i] < qty_lt;
+    for (int64_t i = 0; i < len; i++) m0[i] &= m1[i];
+    /* filter_record_batch on the columns the projection needs */
+    int64_t k = 0;
+    for (int64_t i = 0; i < len; i++) if (m0[i]) { fprice[k] = price[base + i]; fdisc[k] = disc[base + i]; k++; }
+    if (k == 0) continue;
+    o_dec_mul(fprice, fdisc, prod, k);          /* ProjectionExec: Multiply */
+    o_check_overflow(prod, 25, ok, k);          /* CheckOverflow → Decimal128(25,4) */
+    o_sumdec_update_batch(&st, prod, ok, k, 35, 0);  /* SumDecimal(35,4) */
+  }
+  *out_sum = st.sum; *out_has_sum = st.has_sum; *out_is_empty = st.is_empty;
+  free(m0); free(m1); free(fprice); free(fdisc); free(prod); free(ok);
+}

@@ -1,0 +1,660 @@
+"""CPU oracle: evaluates a Comet plan (the ``serde`` Python objects the plan bytes were made from) over
+pyarrow tables, operator at a time, the way the reference's DataFusion plan does.
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product (datafusion-comet_amd/) never imports this module.
+
+Heavy per-row arithmetic is in ``comet_oracle.c`` (plain C restatement, each function citing the
+reference); this file restates the operator semantics:
+  FilterExec        keep rows whose predicate is TRUE and valid     (planner.rs:1230-1247)
+  ProjectionExec    one materialised array per expression           (operators/projection.rs:37-74)
+  AggregateExec     Partial → state columns, Final → values         (planner.rs:1248-1384, agg_funcs/*.rs)
+  expressions       planner.rs:976-1132 (decimal path selection), :600-649 (CheckOverflow fusion)
+Exact Python ``int`` versions of the decimal rules live in ``pyint.py`` and cross-check the C code.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libcomet_oracle.so")
+
+DEC128 = np.dtype([("lo", "<u8"), ("hi", "<i8")])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _lib():
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "comet_oracle.c")):
+        build()
+    return ctypes.CDLL(_SO)
+
+
+C = _lib()
+_vp = ctypes.c_void_p
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+class SumDecState(ctypes.Structure):
+    _fields_ = [("sum", ctypes.c_uint64 * 2), ("has_sum", ctypes.c_int32), ("is_empty", ctypes.c_int32)]
+
+
+class AvgDecState(ctypes.Structure):
+    _fields_ = [("sum", ctypes.c_uint64 * 2), ("count", ctypes.c_int64), ("is_not_null", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+def dec_to_int(a: np.ndarray, i: int) -> int:
+    return (int(a["hi"][i]) << 64) | int(a["lo"][i])
+
+
+def ints_to_dec(vals) -> np.ndarray:
+    out = np.zeros(len(vals), dtype=DEC128)
+    for i, v in enumerate(vals):
+        v = int(v)
+        out["lo"][i] = v & 0xFFFFFFFFFFFFFFFF
+        out["hi"][i] = v >> 64
+    return out
+
+
+def i64_to_dec(v: np.ndarray) -> np.ndarray:
+    out = np.zeros(len(v), dtype=DEC128)
+    out["lo"] = v.astype(np.int64).view(np.uint64)
+    out["hi"] = v.astype(np.int64) >> 63
+    return out
+
+
+def _limbs_to_int(limbs) -> int:
+    v = (int(limbs[1]) << 64) | int(limbs[0])
+    return v - (1 << 128) if v >> 127 else v
+
+
+# --------------------------------------------------------------------------- columns
+
+
+@dataclass
+class Col:
+    dtype: object                 # serde.DataType
+    values: np.ndarray
+    valid: Optional[np.ndarray]   # bool array, None = all valid
+
+    def __len__(self):
+        return len(self.values)
+
+    def ok(self) -> np.ndarray:
+        return np.ones(len(self.values), bool) if self.valid is None else self.valid
+
+
+def _np_dtype(S, t):
+    return {S.BOOL: np.bool_, S.INT8: np.int8, S.INT16: np.int16, S.INT32: np.int32, S.INT64: np.int64, S.FLOAT: np.float32,
+            S.DOUBLE: np.float64, S.DATE: np.int32, S.TIMESTAMP: np.int64}.get(t.type_id)
+
+
+def col_from_arrow(S, arr: pa.Array, t) -> Col:
+    if isinstance(arr, pa.ChunkedArray):
+        arr = arr.combine_chunks()
+    n = len(arr)
+    valid = None
+    if arr.null_count:
+        valid = np.array(arr.is_valid().to_numpy(zero_copy_only=False), dtype=bool)
+    if t.type_id == S.DECIMAL:
+        buf = arr.buffers()[1]
+        vals = np.frombuffer(buf, dtype=DEC128)[arr.offset:arr.offset + n].copy()
+    elif t.type_id == S.BOOL:
+        vals = np.array(arr.fill_null(False).to_numpy(zero_copy_only=False), dtype=bool)
+    elif t.type_id == S.STRING:
+        vals = np.array(arr.to_pylist(), dtype=object)
+    else:
+        nt = _np_dtype(S, t)
+        buf = arr.buffers()[1]
+        vals = np.frombuffer(buf, dtype=nt)[arr.offset:arr.offset + n].copy()
+    return Col(t, vals, valid)
+
+
+def col_to_arrow(S, c: Col) -> pa.Array:
+    n = len(c)
+    t = c.dtype
+    mask = None if c.valid is None or c.valid.all() else ~c.valid
+    if t.type_id == S.DECIMAL:
+        vals = c.values.copy()
+        if mask is not None:
+            vals[mask] = np.zeros(1, DEC128)[0]
+        vb = None
+        nulls = 0
+        if mask is not None:
+            vb = pa.py_buffer(np.packbits(~mask, bitorder="little").tobytes())
+            nulls = int(mask.sum())
+        return pa.Array.from_buffers(pa.decimal128(t.precision, t.scale), n, [vb, pa.py_buffer(vals.tobytes())], null_count=nulls)
+    pt = {S.BOOL: pa.bool_(), S.INT8: pa.int8(), S.INT16: pa.int16(), S.INT32: pa.int32(), S.INT64: pa.int64(),
+          S.FLOAT: pa.float32(), S.DOUBLE: pa.float64(), S.DATE: pa.date32(), S.STRING: pa.utf8()}[t.type_id]
+    if t.type_id == S.DATE:
+        return pa.array(c.values.astype(np.int32), type=pa.int32(), mask=mask).cast(pa.date32())
+    if t.type_id == S.STRING:
+        return pa.array([None if (mask is not None and mask[i]) else c.values[i] for i in range(n)], type=pa.utf8())
+    return pa.array(c.values, type=pt, mask=mask)
+
+
+# --------------------------------------------------------------------------- expression evaluation
+
+
+class OracleError(Exception):
+    """A Spark-semantic error the reference would raise (ANSI overflow, …)."""
+
+
+class Evaluator:
+    def __init__(self, S):
+        self.S = S
+
+    # ---- helpers
+    def _and_valid(self, a, b):
+        if a is None:
+            return b
+        if b is None:
+            return a
+        return a & b
+
+    def _as_dec(self, c: Col) -> np.ndarray:
+        return c.values
+
+    def eval(self, e, cols: List[Col], n: int) -> Col:
+        S = self.S
+        k = e.kind
+        if k == "bound":
+            return cols[e.index]
+        if k == "literal":
+            return self._literal(e, n)
+        if k in ("eq", "neq", "lt", "lt_eq", "gt", "gt_eq"):
+            a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            return Col(S.T_BOOL, self._compare(k, a, b), self._and_valid(a.valid, b.valid))
+        if k == "eq_null_safe":
+            a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            eq = self._compare("eq", a, b)
+            return Col(S.T_BOOL, (a.ok() & b.ok() & eq) | (~a.ok() & ~b.ok()), None)
+        if k in ("and_", "or_"):
+            a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            av, bv, ao, bo = a.values.astype(bool), b.values.astype(bool), a.ok(), b.ok()
+            if k == "and_":   # Kleene: FALSE dominates NULL
+                val = ao & av & bo & bv
+                ok = (ao & ~av) | (bo & ~bv) | (ao & bo)
+            else:
+                val = (ao & av) | (bo & bv)
+                ok = (ao & av) | (bo & bv) | (ao & bo)
+            return Col(S.T_BOOL, val, None if ok.all() else ok)
+        if k == "not_":
+            a = self.eval(e.children[0], cols, n)
+            return Col(S.T_BOOL, ~a.values.astype(bool), a.valid)
+        if k == "is_null":
+            a = self.eval(e.children[0], cols, n)
+            return Col(S.T_BOOL, ~a.ok(), None)
+        if k == "is_not_null":
+            a = self.eval(e.children[0], cols, n)
+            return Col(S.T_BOOL, a.ok().copy(), None)
+        if k in ("add", "subtract", "multiply", "divide"):
+            a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            return self._arith(e, a, b)
+        if k == "check_overflow":
+            return self._check_overflow(e, cols, n)
+        if k == "cast":
+            return self._cast(e, self.eval(e.children[0], cols, n))
+        if k == "if_":
+            c, t, f = (self.eval(x, cols, n) for x in e.children)
+            sel = c.ok() & c.values.astype(bool)
+            vals = np.where(sel, t.values, f.values) if t.dtype.type_id != S.DECIMAL else np.where(sel, t.values, f.values)
+            ok = np.where(sel, t.ok(), f.ok())
+            return Col(t.dtype, vals, None if ok.all() else ok)
+        if k == "in_":
+            v = self.eval(e.children[0], cols, n)
+            hit = np.zeros(n, bool)
+            anynull = np.zeros(n, bool)
+            for item in e.children[1:]:
+                li = self.eval(item, cols, n)
+                hit |= li.ok() & self._compare("eq", v, li)
+                anynull |= ~li.ok()
+            ok = v.ok() & (hit | ~anynull)
+            return Col(S.T_BOOL, ~hit if e.negated else hit, None if ok.all() else ok)
+        raise NotImplementedError(f"oracle: expression {k}")
+
+    def _literal(self, e, n) -> Col:
+        S = self.S
+        t = e.dtype
+        valid = None if e.value is not None else np.zeros(n, bool)
+        if t.type_id == S.DECIMAL:
+            vals = ints_to_dec([e.value or 0]).repeat(n)
+        elif t.type_id == S.STRING:
+            vals = np.array([e.value] * n, dtype=object)
+        else:
+            vals = np.full(n, e.value if e.value is not None else 0, dtype=_np_dtype(S, t))
+        return Col(t, vals, valid)
+
+    def _compare(self, k, a: Col, b: Col) -> np.ndarray:
+        S = self.S
+        if a.dtype.type_id == S.DECIMAL:
+            assert a.dtype.scale == b.dtype.scale, "decimal comparison needs equal scales"
+            op = {"eq": 0, "neq": 1, "lt": 2, "lt_eq": 3, "gt": 4, "gt_eq": 5}[k]
+            out = np.zeros(len(a), np.uint8)
+            C.o_cmp_i128(op, _p(np.ascontiguousarray(a.values)), _p(np.ascontiguousarray(b.values)), _p(out), ctypes.c_int64(len(a)))
+            return out.astype(bool)
+        x, y = a.values, b.values
+        if a.dtype.type_id in (S.FLOAT, S.DOUBLE):
+            # arrow-ord compares floats with IEEE totalOrder
+            it = np.int64 if a.dtype.type_id == S.DOUBLE else np.int32
+            bits = 63 if it is np.int64 else 31
+
+            def key(v):
+                b_ = v.view(it)
+                return b_ ^ ((b_ >> bits).astype(it).view(np.uint64 if it is np.int64 else np.uint32) >> 1).view(it)
+            x, y = key(np.ascontiguousarray(x)), key(np.ascontiguousarray(y))
+        return {"eq": x == y, "neq": x != y, "lt": x < y, "lt_eq": x <= y, "gt": x > y, "gt_eq": x >= y}[k]
+
+    def _arith(self, e, a: Col, b: Col) -> Col:
+        S = self.S
+        n = len(a)
+        valid = self._and_valid(a.valid, b.valid)
+        if a.dtype.type_id == S.DECIMAL and b.dtype.type_id == S.DECIMAL:
+            p1, s1, p2, s2 = a.dtype.precision, a.dtype.scale, b.dtype.precision, b.dtype.scale
+            mul = e.kind == "multiply"
+            addsub = e.kind in ("add", "subtract")
+            assert mul or addsub, "decimal divide not in oracle yet"
+            wide = (addsub and max(s1, s2) + max(p1 - s1, p2 - s2) >= 38) or (mul and p1 + p2 >= 38)  # planner.rs:1000-1008
+            av, bv = np.ascontiguousarray(a.values), np.ascontiguousarray(b.values)
+            out = np.zeros(n, DEC128)
+            if wide:
+                ok = np.zeros(n, np.uint8)
+                op = {"add": 0, "subtract": 1, "multiply": 2}[e.kind]
+                C.o_wide_decimal(op, _p(av), s1, _p(bv), s2, e.dtype.precision, e.dtype.scale, _p(out), _p(ok), ctypes.c_int64(n))
+                okb = ok.astype(bool)
+                if e.eval_mode == S.ANSI and (~okb & (np.ones(n, bool) if valid is None else valid)).any():
+                    raise OracleError("ARITHMETIC_OVERFLOW")
+                valid2 = okb if valid is None else (valid & okb)
+                c = Col(e.dtype, out, None if valid2.all() else valid2)
+                c.wide = True
+                return c
+            if mul:
+                C.o_dec_mul(_p(av), _p(bv), _p(out), ctypes.c_int64(n))
+                return Col(S.decimal(min(38, p1 + p2 + 1), s1 + s2), out, valid)
+            C.o_dec_addsub(_p(av), s1, _p(bv), s2, 1 if e.kind == "subtract" else 0, _p(out), ctypes.c_int64(n))
+            sm = max(s1, s2)
+            return Col(S.decimal(min(38, max(p1 - s1, p2 - s2) + sm + 1), sm), out, valid)
+        rt = e.dtype
+        if rt.type_id in (S.INT8, S.INT16, S.INT32, S.INT64):
+            nt = _np_dtype(S, rt)
+            x, y = a.values.astype(np.int64), b.values.astype(np.int64)
+            with np.errstate(over="ignore"):
+                if rt.type_id == S.INT64:
+                    ux, uy = x.view(np.uint64), y.view(np.uint64)
+                    r = {"add": ux + uy, "subtract": ux - uy, "multiply": ux * uy}[e.kind].view(np.int64)
+                    if e.eval_mode != S.LEGACY:
+                        big = {"add": x.astype(object) + y.astype(object), "subtract": x.astype(object) - y.astype(object),
+                               "multiply": x.astype(object) * y.astype(object)}[e.kind]
+                        ovf = np.array([not (-2**63 <= int(v) < 2**63) for v in big], bool)
+                    else:
+                        ovf = None
+                else:
+                    full = {"add": x + y, "subtract": x - y, "multiply": x * y}[e.kind]
+                    r = full.astype(nt)
+                    ovf = (r.astype(np.int64) != full) if e.eval_mode != S.LEGACY else None
+            if ovf is not None:
+                live = ovf & (np.ones(n, bool) if valid is None else valid)
+                if e.eval_mode == S.ANSI and live.any():
+                    raise OracleError("ARITHMETIC_OVERFLOW integer")
+                if e.eval_mode == S.TRY:
+                    v2 = ~ovf if valid is None else (valid & ~ovf)
+                    r = np.where(v2, r, 0).astype(nt)   # checked_arithmetic.rs:54-124 zeroes NULL slots
+                    return Col(rt, r, None if v2.all() else v2)
+            return Col(rt, r.astype(nt), valid)
+        if rt.type_id in (S.FLOAT, S.DOUBLE):
+            nt = _np_dtype(S, rt)
+            x, y = a.values.astype(nt), b.values.astype(nt)
+            with np.errstate(all="ignore"):
+                r = {"add": x + y, "subtract": x - y, "multiply": x * y, "divide": x / y}[e.kind]
+            return Col(rt, r.astype(nt), valid)
+        raise NotImplementedError(f"oracle arithmetic on {rt}")
+
+    def _check_overflow(self, e, cols, n) -> Col:
+        S = self.S
+        child_e = e.children[0]
+        # planner.rs:615-633: Cast(dec→dec) + CheckOverflow with the same target type → fused rescale+check
+        if child_e.kind == "cast" and child_e.dtype == e.dtype:
+            inner = self.eval(child_e.children[0], cols, n)
+            if inner.dtype.type_id == S.DECIMAL:
+                return self._rescale(inner, e.dtype, e.fail_on_error)
+        c = self.eval(child_e, cols, n)
+        assert c.dtype.type_id == S.DECIMAL
+        if getattr(c, "wide", False) and c.dtype == e.dtype:   # planner.rs:606-613
+            return c
+        assert c.dtype.scale == e.dtype.scale, "CheckOverflow never rescales (checkoverflow.rs:36-39)"
+        ok = np.zeros(n, np.uint8)
+        C.o_check_overflow(_p(np.ascontiguousarray(c.values)), e.dtype.precision, _p(ok), ctypes.c_int64(n))
+        okb = ok.astype(bool)
+        if e.fail_on_error and (~okb & c.ok()).any():
+            raise OracleError("NUMERIC_VALUE_OUT_OF_RANGE")
+        v2 = okb if c.valid is None else (c.valid & okb)
+        return Col(e.dtype, c.values, None if v2.all() else v2)
+
+    def _rescale(self, c: Col, to, fail_on_error) -> Col:
+        n = len(c)
+        out = np.zeros(n, DEC128)
+        ok = np.zeros(n, np.uint8)
+        C.o_rescale_check(_p(np.ascontiguousarray(c.values)), c.dtype.scale, to.precision, to.scale, _p(out), _p(ok), ctypes.c_int64(n))
+        okb = ok.astype(bool)
+        if fail_on_error and (~okb & c.ok()).any():
+            raise OracleError("NUMERIC_VALUE_OUT_OF_RANGE")
+        v2 = okb if c.valid is None else (c.valid & okb)
+        return Col(to, out, None if v2.all() else v2)
+
+    def _cast(self, e, c: Col) -> Col:
+        S = self.S
+        to, frm = e.dtype, c.dtype
+        if to == frm:
+            return c
+        ints = (S.INT8, S.INT16, S.INT32, S.INT64)
+        if frm.type_id in ints and to.type_id in ints:
+            r = c.values.astype(np.int64).astype(_np_dtype(S, to))   # LEGACY wraps
+            if e.eval_mode == S.ANSI and ((r.astype(np.int64) != c.values.astype(np.int64)) & c.ok()).any():
+                raise OracleError("CAST_OVERFLOW")
+            return Col(to, r, c.valid)
+        if frm.type_id in ints + (S.FLOAT,) and to.type_id == S.DOUBLE:
+            return Col(to, c.values.astype(np.float64), c.valid)
+        if frm.type_id in ints and to.type_id == S.FLOAT:
+            return Col(to, c.values.astype(np.float32), c.valid)
+        if frm.type_id in ints and to.type_id == S.DECIMAL:
+            vals = [int(v) * 10 ** to.scale for v in c.values]
+            bound = 10 ** to.precision - 1
+            ok = np.array([abs(v) <= bound for v in vals], bool)
+            if e.eval_mode == S.ANSI and (~ok & c.ok()).any():
+                raise OracleError("NUMERIC_VALUE_OUT_OF_RANGE")
+            v2 = ok if c.valid is None else (c.valid & ok)
+            return Col(to, ints_to_dec([v if o else 0 for v, o in zip(vals, ok)]), None if v2.all() else v2)
+        if frm.type_id == S.DECIMAL and to.type_id == S.DECIMAL:
+            return self._rescale(c, to, e.eval_mode == S.ANSI)
+        raise NotImplementedError(f"oracle cast {frm} → {to}")
+
+
+# --------------------------------------------------------------------------- operators
+
+
+def _take(c: Col, idx: np.ndarray) -> Col:
+    return Col(c.dtype, c.values[idx], None if c.valid is None else c.valid[idx])
+
+
+def run_plan(S, op, table: pa.Table) -> List[Col]:
+    """Evaluate the operator tree over `table` (the single Scan input). Returns the output columns."""
+    ev = Evaluator(S)
+    k = op.kind
+    if k == "scan":
+        assert table.num_columns == len(op.fields)
+        return [col_from_arrow(S, table.column(i), t) for i, t in enumerate(op.fields)]
+    child = run_plan(S, op.children[0], table)
+    n = len(child[0]) if child else 0
+    if k == "filter":
+        p = ev.eval(op.predicate, child, n)
+        keep = p.ok() & p.values.astype(bool)      # only TRUE and valid survives
+        idx = np.nonzero(keep)[0]
+        return [_take(c, idx) for c in child]
+    if k == "projection":
+        return [ev.eval(e, child, n) for e in op.exprs]
+    if k == "hash_agg":
+        return _hash_agg(S, ev, op, child, n)
+    raise NotImplementedError(k)
+
+
+def _group_ids(S, keys: List[Col], n: int):
+    """Row → group index in first-seen order (DataFusion GroupValues; output order is unspecified in the
+    reference, tests compare as multisets)."""
+    if not keys:
+        return np.zeros(n, np.int64), 1, []
+    tuples = []
+    for i in range(n):
+        t = []
+        for kcol in keys:
+            if kcol.valid is not None and not kcol.valid[i]:
+                t.append(None)
+            elif kcol.dtype.type_id == S.DECIMAL:
+                t.append(dec_to_int(kcol.values, i))
+            else:
+                v = kcol.values[i]
+                t.append(v.item() if hasattr(v, "item") else v)
+        tuples.append(tuple(t))
+    index = {}
+    gid = np.zeros(n, np.int64)
+    for i, t in enumerate(tuples):
+        g = index.get(t)
+        if g is None:
+            g = len(index)
+            index[t] = g
+        gid[i] = g
+    return gid, len(index), list(index.keys())
+
+
+def _hash_agg(S, ev: Evaluator, op, child: List[Col], n: int) -> List[Col]:
+    grouped = len(op.exprs) > 0
+    keys = [ev.eval(e, child, n) for e in op.exprs]
+    if op.mode == S.PARTIAL:
+        gid, ng, key_vals = _group_ids(S, keys, n)
+    else:
+        gid, ng, key_vals = _group_ids(S, child[:len(op.exprs)], n) if grouped else (np.zeros(n, np.int64), 1, [])
+    out: List[Col] = []
+    for ki, kc in enumerate(op.exprs):
+        src = keys[ki] if op.mode == S.PARTIAL else child[ki]
+        # first row of each group carries the key
+        first = np.full(ng, -1, np.int64)
+        for i in range(n - 1, -1, -1):
+            first[gid[i]] = i
+        out.append(_take(src, first))
+    state_col = len(op.exprs)
+    for a in op.aggs:
+        if op.mode == S.PARTIAL:
+            out += _agg_partial(S, ev, a, child, n, gid, ng, grouped)
+        else:
+            cols, used = _agg_final(S, a, child, state_col, n, gid, ng, grouped)
+            state_col += used
+            out += cols
+    return out
+
+
+def _filter_valid(S, ev, a, child, n, base_valid):
+    if a.filter is None:
+        return base_valid
+    f = ev.eval(a.filter, child, n)
+    keep = f.ok() & f.values.astype(bool)
+    return keep if base_valid is None else (base_valid & keep)
+
+
+def _agg_partial(S, ev, a, child, n, gid, ng, grouped) -> List[Col]:
+    gidc = np.ascontiguousarray(gid)
+    if a.kind == "count":
+        ok = np.ones(n, bool)
+        for ce in a.children:
+            ok &= ev.eval(ce, child, n).ok()
+        ok = _filter_valid(S, ev, a, child, n, ok)
+        cnt = np.bincount(gid[ok], minlength=ng).astype(np.int64) if n else np.zeros(ng, np.int64)
+        return [Col(S.T_INT64, cnt, None)]
+    v = ev.eval(a.children[0], child, n)
+    valid = _filter_valid(S, ev, a, child, n, v.valid)
+    vb = None if valid is None else np.ascontiguousarray(valid.astype(np.uint8))
+    if a.kind in ("sum", "avg") and a.dtype.type_id == S.DECIMAL:
+        st = a.dtype if a.kind == "sum" else a.sum_dtype
+        vals = np.ascontiguousarray(v.values)
+        if a.kind == "sum":
+            states = (SumDecState * ng)()
+            for g in range(ng):
+                C.o_sumdec_init(ctypes.byref(states[g]))
+            if grouped:
+                rc = C.o_sumdec_update_groups(states, _p(vals), _p(vb), _p(gidc), ctypes.c_int64(n), st.precision, int(a.eval_mode == S.ANSI))
+            else:
+                # ungrouped accumulator sees the input batch by batch; is_empty logic is per batch (sum_decimal.rs:246-251)
+                rc = 0
+                for base in range(0, max(n, 1), 8192):
+                    ln = min(8192, n - base)
+                    if ln <= 0:
+                        break
+                    sl = vals[base:base + ln]
+                    vbs = None if vb is None else vb[base:base + ln]
+                    rc |= C.o_sumdec_update_batch(ctypes.byref(states[0]), _p(np.ascontiguousarray(sl)),
+                                                  _p(None if vbs is None else np.ascontiguousarray(vbs)), ctypes.c_int64(ln),
+                                                  st.precision, int(a.eval_mode == S.ANSI))
+            if rc:
+                raise OracleError("ARITHMETIC_OVERFLOW sum")
+            sums = ints_to_dec([_limbs_to_int(s.sum) if s.has_sum else 0 for s in states])
+            has = np.array([bool(s.has_sum) for s in states], bool)
+            empty = np.array([bool(s.is_empty) for s in states], bool)
+            return [Col(st, sums, None if has.all() else has), Col(S.T_BOOL, empty, None)]
+        states = (AvgDecState * ng)()
+        for g in range(ng):
+            C.o_avgdec_init(ctypes.byref(states[g]))
+        C.o_avgdec_update_groups(states, _p(vals), _p(vb), _p(gidc) if grouped else None, ctypes.c_int64(n), st.precision)
+        if grouped:
+            nn = np.array([bool(s.is_not_null) for s in states], bool)
+            sums = ints_to_dec([_limbs_to_int(s.sum) for s in states])
+            cnts = np.array([s.count for s in states], np.int64)
+            vv = None if nn.all() else nn
+            return [Col(st, sums, vv), Col(S.T_INT64, cnts, vv)]   # both arrays share the null mask (avg_decimal.rs:638-653)
+        s = states[0]
+        has = s.count > 0 and bool(s.is_not_null)   # ungrouped: sum is None until the first value (avg_decimal.rs:225)
+        return [Col(st, ints_to_dec([_limbs_to_int(s.sum) if has else 0]), None if has else np.array([False])),
+                Col(S.T_INT64, np.array([s.count], np.int64), None)]
+    if a.kind == "sum" and a.dtype.type_id in (S.INT8, S.INT16, S.INT32, S.INT64):
+        sums = np.zeros(ng, np.int64)
+        has = np.zeros(ng, np.uint8)
+        C.o_sumint_update_groups(_p(sums), _p(has), _p(np.ascontiguousarray(v.values.astype(np.int64))), _p(vb), _p(gidc), ctypes.c_int64(n))
+        hb = has.astype(bool)
+        return [Col(S.T_INT64, np.where(hb, sums, 0), None if hb.all() else hb)]
+    if a.kind in ("sum", "avg"):   # float
+        sums = np.zeros(ng, np.float64)
+        cnts = np.zeros(ng, np.int64)
+        C.o_avgf64_update_groups(_p(sums), _p(cnts), _p(np.ascontiguousarray(v.values.astype(np.float64))), _p(vb), _p(gidc), ctypes.c_int64(n))
+        if a.kind == "avg":
+            if grouped:
+                return [Col(S.T_DOUBLE, sums, None), Col(S.T_INT64, cnts, None)]
+            some = n > 0
+            return [Col(S.T_DOUBLE, sums, None if some else np.array([False])), Col(S.T_INT64, cnts, None)]
+        hb = cnts > 0
+        return [Col(S.T_DOUBLE, sums, None if hb.all() else hb)]
+    if a.kind in ("min", "max"):
+        ok = np.ones(n, bool) if valid is None else valid
+        res, has = [], []
+        for g in range(ng):
+            sel = np.nonzero((gid == g) & ok)[0]
+            if len(sel) == 0:
+                res.append(0)
+                has.append(False)
+                continue
+            if v.dtype.type_id == S.DECIMAL:
+                xs = [dec_to_int(v.values, i) for i in sel]
+            else:
+                xs = [v.values[i].item() for i in sel]
+            res.append(min(xs) if a.kind == "min" else max(xs))
+            has.append(True)
+        hb = np.array(has, bool)
+        vals = ints_to_dec(res) if v.dtype.type_id == S.DECIMAL else np.array(res, dtype=_np_dtype(S, v.dtype))
+        return [Col(v.dtype, vals, None if hb.all() else hb)]
+    raise NotImplementedError(f"oracle aggregate {a.kind}")
+
+
+def _agg_final(S, a, child, state_col, n, gid, ng, grouped):
+    if a.kind == "count":
+        c = child[state_col]
+        out = np.zeros(ng, np.int64)
+        np.add.at(out, gid, c.values.astype(np.int64))
+        return [Col(S.T_INT64, out, None)], 1
+    if a.kind == "sum" and a.dtype.type_id == S.DECIMAL:
+        sc, ec = child[state_col], child[state_col + 1]
+        states = (SumDecState * ng)()
+        for g in range(ng):
+            C.o_sumdec_init(ctypes.byref(states[g]))
+        for i in range(n):
+            rc = C.o_sumdec_merge(ctypes.byref(states[gid[i]]), ctypes.byref(_i128(dec_to_int(sc.values, i))), int(sc.ok()[i]), int(bool(ec.values[i])),
+                                  a.dtype.precision, int(a.eval_mode == S.ANSI))
+            if rc:
+                raise OracleError("ARITHMETIC_OVERFLOW sum")
+        vals, ok = [], []
+        for s in states:
+            out = (ctypes.c_uint64 * 2)()
+            has = C.o_sumdec_evaluate(ctypes.byref(s), a.dtype.precision, out)
+            vals.append(_limbs_to_int(out) if has else 0)
+            ok.append(bool(has))
+        okb = np.array(ok, bool)
+        return [Col(a.dtype, ints_to_dec(vals), None if okb.all() else okb)], 2
+    if a.kind == "avg" and a.dtype.type_id == S.DECIMAL:
+        sc, cc = child[state_col], child[state_col + 1]
+        states = (AvgDecState * ng)()
+        for g in range(ng):
+            C.o_avgdec_init(ctypes.byref(states[g]))
+        for i in range(n):
+            rc = C.o_avgdec_merge(ctypes.byref(states[gid[i]]), ctypes.byref(_i128(dec_to_int(sc.values, i))), int(sc.ok()[i]), ctypes.c_int64(int(cc.values[i])),
+                                  int(cc.ok()[i]), a.sum_dtype.precision, int(a.eval_mode == S.ANSI))
+            if rc:
+                raise OracleError("ARITHMETIC_OVERFLOW avg")
+        vals, ok = [], []
+        for s in states:
+            out = (ctypes.c_uint64 * 2)()
+            has = C.o_avgdec_evaluate(ctypes.byref(s), a.dtype.precision, a.dtype.scale, a.sum_dtype.scale, out)
+            vals.append(_limbs_to_int(out) if has else 0)
+            ok.append(bool(has))
+        okb = np.array(ok, bool)
+        return [Col(a.dtype, ints_to_dec(vals), None if okb.all() else okb)], 2
+    if a.kind == "sum" and a.dtype.type_id in (S.INT8, S.INT16, S.INT32, S.INT64):
+        c = child[state_col]
+        sums = np.zeros(ng, np.int64)
+        has = np.zeros(ng, np.uint8)
+        C.o_sumint_update_groups(_p(sums), _p(has), _p(np.ascontiguousarray(c.values.astype(np.int64))),
+                                 _p(None if c.valid is None else np.ascontiguousarray(c.valid.astype(np.uint8))),
+                                 _p(np.ascontiguousarray(gid)), ctypes.c_int64(n))
+        hb = has.astype(bool)
+        return [Col(S.T_INT64, np.where(hb, sums, 0), None if hb.all() else hb)], 1
+    if a.kind == "avg":
+        sc, cc = child[state_col], child[state_col + 1]
+        sums = np.zeros(ng, np.float64)
+        cnts = np.zeros(ng, np.int64)
+        for i in range(n):
+            if sc.ok()[i]:
+                sums[gid[i]] += sc.values[i]
+            cnts[gid[i]] += int(cc.values[i])
+        hb = cnts > 0
+        with np.errstate(all="ignore"):
+            res = np.where(hb, sums / np.where(hb, cnts, 1), 0.0)
+        return [Col(S.T_DOUBLE, res, None if hb.all() else hb)], 2
+    raise NotImplementedError(f"oracle final aggregate {a.kind}")
+
+
+class _I128(ctypes.Structure):
+    _fields_ = [("lo", ctypes.c_uint64), ("hi", ctypes.c_uint64)]
+
+
+def _i128(v: int) -> _I128:
+    v &= (1 << 128) - 1
+    return _I128(v & 0xFFFFFFFFFFFFFFFF, v >> 64)
+
+
+def run_plan_to_arrow(S, op, table: pa.Table) -> pa.Table:
+    cols = run_plan(S, op, table)
+    return pa.table([col_to_arrow(S, c) for c in cols], names=[f"col_{i}" for i in range(len(cols))])
+
+
+# --------------------------------------------------------------------------- CPU baseline (bench.py)
+
+
+def q6_reference_pipeline(table: pa.Table, d0: int, d1: int, disc_lo: int, disc_hi: int, qty_lt: int, batch: int = 8192):
+    """Times nothing itself: runs the operator-at-a-time Q6 stage-1 pipeline of comet_oracle.c over the table."""
+    n = table.num_rows
+    cols = [table.column(i).combine_chunks() for i in range(4)]
+    qty, price, disc = (np.frombuffer(c.buffers()[1], dtype=DEC128)[c.offset:c.offset + n] for c in cols[:3])
+    ship = np.frombuffer(cols[3].buffers()[1], dtype=np.int32)[cols[3].offset:cols[3].offset + n]
+    out = (ctypes.c_uint64 * 2)()
+    has, empty = ctypes.c_int32(), ctypes.c_int32()
+    lits = (_I128 * 3)(_i128(disc_lo), _i128(disc_hi), _i128(qty_lt))
+    C.o_q6_reference_pipeline(_p(np.ascontiguousarray(qty)), _p(np.ascontiguousarray(price)), _p(np.ascontiguousarray(disc)),
+                              _p(np.ascontiguousarray(ship)), ctypes.c_int64(n), ctypes.c_int32(d0), ctypes.c_int32(d1),
+                              lits, ctypes.c_int64(batch), out, ctypes.byref(has), ctypes.byref(empty))
+    return _limbs_to_int(out), bool(has.value), bool(empty.value)
