@@ -32,6 +32,14 @@ def _load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the native engine)")
+    # The harness keeps device buffers in torch tensors; torch bundles its own copy of libamdhip64.so.7.
+    # Import it first so that libcomet.so (NEEDED libamdhip64.so.7) binds to the SAME runtime instance —
+    # two HIP runtimes in one process do not share a device context.  (Under the JVM there is no torch and
+    # the system ROCm runtime is used.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     c = ctypes
     lib.comet_create_plan.restype = c.c_int64

@@ -84,6 +84,21 @@ def test_column_count_mismatch_is_an_error(built):
 
 
 def test_metrics_tree_mirrors_operator_tree(built):
+    # NativeMetricNode tree has one node per Operator (metrics/utils.rs:30-45): agg <- project <- filter <- scan
     table = tpch.lineitem_q6(10_000)
     it = native.CometExecIterator([native.HostInput.from_table(table)], 2, tpch.q6_plan().encode())
-    list(iter(it.__next__, None)) if False else [b for b in it]
+    batches = []
+    while True:
+        b = native.Native.executePlan(it.handle, 2)
+        if b is None:
+            break
+        batches.append(b)
+    metrics, children = S.decode_metric_node(it.metrics())
+    it.close()
+    assert metrics["output_rows"] == 1 and metrics["elapsed_compute"] > 0
+    depth = 0
+    while children:
+        assert len(children) == 1
+        _, children = children[0]
+        depth += 1
+    assert depth == 3
