@@ -844,9 +844,12 @@ struct Gen {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Aggregate lowering
+// Aggregate lowering: every aggregate function decomposes into commutative accumulator primitives
+// (words of u64); identical primitives over the same (value, filter) are shared (sum(x) and avg(x)
+// use one sum and one count).  The same lowering feeds the ungrouped template (registers) and the
+// grouped template (per-group slots, atomics).
 // ---------------------------------------------------------------------------------------------
-enum class Prim { Cnt, Sum128, Sum192, SumI64, SumF64, AMax, SignFlags, MinI64, MaxI64, MinI128, MaxI128, MinF64, MaxF64, RowCnt };
+enum class Prim { Cnt, RowCnt, Sum128, Sum192, SumI64, SumF64, AMaxHi, SignFlags, MinI64, MaxI64, MinI128, MaxI128, MinF64, MaxF64 };
 
 struct PrimSlot {
   Prim prim;
@@ -856,7 +859,7 @@ struct PrimSlot {
 
 int prim_words(Prim p) {
   switch (p) {
-    case Prim::Sum128: case Prim::AMax: case Prim::MinI128: case Prim::MaxI128: return 2;
+    case Prim::Sum128: case Prim::MinI128: case Prim::MaxI128: return 2;
     case Prim::Sum192: return 3;
     default: return 1;
   }
@@ -864,80 +867,118 @@ int prim_words(Prim p) {
 
 struct AggLowering {
   Gen& g;
+  bool grouped;
   int nw = 0;
   std::map<std::string, PrimSlot> slots;   // key: prim|valuekey|filterkey
-  std::string init_code, combine_code, feed_code;
-  std::vector<int> word_ops;               // per word: AccOp for the grouped atomic path
+  std::string init_code, combine_code;
+  std::vector<std::string> gops, gident;   // grouped: per-word GOp name and identity literal
+  std::string val_code;                    // grouped: per-row contribution assignments (val[w] = …)
 
-  explicit AggLowering(Gen& gen) : g(gen) {}
+  AggLowering(Gen& gen, bool grp) : g(gen), grouped(grp) {}
 
-  PrimSlot get(Prim p, const std::string& vkey, const std::string& fkey, const std::function<std::string(int)>& feed_stmt) {
+  // cond: row contributes iff cond (empty = always); x: value expression typed for the primitive
+  PrimSlot get(Prim p, const std::string& vkey, const std::string& fkey, const std::string& cond, const std::string& x) {
     std::string key = std::to_string((int)p) + "|" + vkey + "|" + fkey;
-    if (p == Prim::Cnt) {
-      // a count whose condition is empty counts every row reaching the aggregate: share the row counter
-      std::string probe = feed_stmt(0);
-      if (probe.rfind("if (", 0) != 0) key = std::to_string((int)Prim::RowCnt) + "|*|";
-    }
+    if (p == Prim::Cnt && cond.empty()) key = std::to_string((int)Prim::RowCnt) + "|*|";  // counts every row: share
     auto it = slots.find(key);
     if (it != slots.end()) return it->second;
     PrimSlot s{p, nw, prim_words(p)};
     nw += s.nwords;
     slots[key] = s;
-    std::string w = std::to_string(s.word);
+    const std::string w = std::to_string(s.word), w1 = std::to_string(s.word + 1), w2 = std::to_string(s.word + 2);
+    const std::string c = cond.empty() ? "true" : cond;
+    auto ops = [&](std::initializer_list<const char*> o, std::initializer_list<const char*> id) {
+      for (auto* q : o) gops.push_back(q);
+      for (auto* q : id) gident.push_back(q);
+    };
+    auto feed = [&](const std::string& body) { g.stmt(cond.empty() ? body : "if (" + cond + ") { " + body + " }"); };
     switch (p) {
-      case Prim::Cnt: case Prim::RowCnt: case Prim::SumI64:
+      case Prim::Cnt: case Prim::RowCnt:
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    comet::acc_add64(a + " + w + ", b + " + w + ");\n";
+        ops({"G_ADD64"}, {"0ull"});
+        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? 1ull : 0ull;\n";
+        else feed("acc[" + w + "] += 1;");
+        break;
+      case Prim::SumI64:
+        init_code += "    a[" + w + "] = 0;\n";
+        combine_code += "    comet::acc_add64(a + " + w + ", b + " + w + ");\n";
+        ops({"G_ADD64"}, {"0ull"});
+        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (u64)(i64)(" + x + ") : 0ull;\n";
+        else feed("acc[" + w + "] += (u64)(i64)(" + x + ");");
         break;
       case Prim::SumF64:
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    comet::acc_fadd64(a + " + w + ", b + " + w + ");\n";
+        ops({"G_FADD64"}, {"0ull"});
+        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (u64)__double_as_longlong((double)(" + x + ")) : 0ull;\n";
+        else feed("acc[" + w + "] = (u64)__double_as_longlong(comet::fp_add(__longlong_as_double((i64)acc[" + w + "]), (double)(" + x + ")));");
         break;
       case Prim::Sum128:
-        init_code += "    a[" + w + "] = 0; a[" + w + " + 1] = 0;\n";
+        init_code += "    a[" + w + "] = 0; a[" + w1 + "] = 0;\n";
         combine_code += "    comet::acc_add128(a + " + w + ", b + " + w + ");\n";
+        ops({"G_ADD128", "G_CONT"}, {"0ull", "0ull"});
+        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? comet::lo64(" + x + ") : 0ull; val[" + w1 + "] = (" + c + ") ? comet::hi64(" + x + ") : 0ull;\n";
+        else feed("comet::acc_feed_i128(acc + " + w + ", " + x + ");");
         break;
       case Prim::Sum192:
-        init_code += "    a[" + w + "] = 0; a[" + w + " + 1] = 0; a[" + w + " + 2] = 0;\n";
+        init_code += "    a[" + w + "] = 0; a[" + w1 + "] = 0; a[" + w2 + "] = 0;\n";
         combine_code += "    comet::acc_add192(a + " + w + ", b + " + w + ");\n";
+        ops({"G_ADD192", "G_CONT", "G_CONT"}, {"0ull", "0ull", "0ull"});
+        if (grouped)
+          val_code += "        val[" + w + "] = (" + c + ") ? comet::lo64(" + x + ") : 0ull; val[" + w1 + "] = (" + c + ") ? comet::hi64(" + x +
+                      ") : 0ull; val[" + w2 + "] = ((" + c + ") && (" + x + ") < 0) ? ~0ull : 0ull;\n";
+        else feed("comet::acc_feed_i192(acc + " + w + ", " + x + ");");
         break;
-      case Prim::AMax:
-        init_code += "    a[" + w + "] = 0; a[" + w + " + 1] = 0;\n";
-        combine_code += "    comet::acc_umax128(a + " + w + ", b + " + w + ");\n";
+      case Prim::AMaxHi:
+        // hi64(|v|) + 1 (0 = no value yet): max|v| < word · 2^64
+        init_code += "    a[" + w + "] = 0;\n";
+        combine_code += "    if (b[" + w + "] > a[" + w + "]) a[" + w + "] = b[" + w + "];\n";
+        ops({"G_UMAX64"}, {"0ull"});
+        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (comet::hi64((i128)comet::uabs128(" + x + ")) + 1ull) : 0ull;\n";
+        else feed("{ u64 t_ = comet::hi64((i128)comet::uabs128(" + x + ")) + 1ull; if (t_ > acc[" + w + "]) acc[" + w + "] = t_; }");
         break;
       case Prim::SignFlags:
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    comet::acc_or64(a + " + w + ", b + " + w + ");\n";
+        ops({"G_OR64"}, {"0ull"});
+        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (((" + x + ") < 0) ? 2ull : (((" + x + ") > 0) ? 1ull : 0ull)) : 0ull;\n";
+        else feed("acc[" + w + "] |= ((" + x + ") < 0) ? 2ull : (((" + x + ") > 0) ? 1ull : 0ull);");
         break;
-      case Prim::MinI64:
-        init_code += "    a[" + w + "] = 0x7fffffffffffffffull;\n";
-        combine_code += "    comet::acc_imin64(a + " + w + ", b + " + w + ");\n";
+      case Prim::MinI64: case Prim::MaxI64: {
+        const bool mn = p == Prim::MinI64;
+        const char* id = mn ? "0x7fffffffffffffffull" : "0x8000000000000000ull";
+        init_code += "    a[" + w + "] = " + id + ";\n";
+        combine_code += std::string("    comet::acc_") + (mn ? "imin64" : "imax64") + "(a + " + w + ", b + " + w + ");\n";
+        ops({mn ? "G_IMIN64" : "G_IMAX64"}, {id});
+        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (u64)(i64)(" + x + ") : " + id + ";\n";
+        else feed(std::string("{ u64 t_ = (u64)(i64)(") + x + "); comet::acc_" + (mn ? "imin64" : "imax64") + "(acc + " + w + ", &t_); }");
         break;
-      case Prim::MaxI64:
-        init_code += "    a[" + w + "] = 0x8000000000000000ull;\n";
-        combine_code += "    comet::acc_imax64(a + " + w + ", b + " + w + ");\n";
+      }
+      case Prim::MinF64: case Prim::MaxF64: {
+        const bool mn = p == Prim::MinF64;
+        const char* id = mn ? "0x7fffffffffffffffull" : "0xffffffffffffffffull";  // extremes of the IEEE total order
+        init_code += "    a[" + w + "] = " + id + ";\n";
+        combine_code += std::string("    comet::acc_") + (mn ? "fmin64" : "fmax64") + "(a + " + w + ", b + " + w + ");\n";
+        ops({mn ? "G_FMIN64" : "G_FMAX64"}, {id});
+        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (u64)__double_as_longlong((double)(" + x + ")) : " + id + ";\n";
+        else feed(std::string("{ u64 t_ = (u64)__double_as_longlong((double)(") + x + ")); comet::acc_" + (mn ? "fmin64" : "fmax64") + "(acc + " + w + ", &t_); }");
         break;
-      case Prim::MinI128:
-        init_code += "    a[" + w + "] = ~0ull; a[" + w + " + 1] = 0x7fffffffffffffffull;\n";
-        combine_code += "    comet::acc_imin128(a + " + w + ", b + " + w + ");\n";
+      }
+      case Prim::MinI128: case Prim::MaxI128: {
+        const bool mn = p == Prim::MinI128;
+        if (grouped) throw CometError("min/max of a decimal wider than 18 digits is not supported in a grouped GPU aggregate yet");
+        init_code += mn ? "    a[" + w + "] = ~0ull; a[" + w1 + "] = 0x7fffffffffffffffull;\n" : "    a[" + w + "] = 0; a[" + w1 + "] = 0x8000000000000000ull;\n";
+        combine_code += std::string("    comet::acc_") + (mn ? "imin128" : "imax128") + "(a + " + w + ", b + " + w + ");\n";
+        ops({"G_CONT", "G_CONT"}, {"0ull", "0ull"});
+        feed("{ u64 t_[2] = {comet::lo64(" + x + "), comet::hi64(" + x + ")}; comet::acc_" + std::string(mn ? "imin128" : "imax128") + "(acc + " + w + ", t_); }");
         break;
-      case Prim::MaxI128:
-        init_code += "    a[" + w + "] = 0; a[" + w + " + 1] = 0x8000000000000000ull;\n";
-        combine_code += "    comet::acc_imax128(a + " + w + ", b + " + w + ");\n";
-        break;
-      case Prim::MinF64:
-        init_code += "    a[" + w + "] = 0x7ff0000000000000ull;\n";  // +inf
-        combine_code += "    comet::acc_fmin64(a + " + w + ", b + " + w + ");\n";
-        break;
-      case Prim::MaxF64:
-        init_code += "    a[" + w + "] = 0xfff0000000000000ull;\n";  // -inf
-        combine_code += "    comet::acc_fmax64(a + " + w + ", b + " + w + ");\n";
-        break;
+      }
     }
-    g.stmt(feed_stmt(s.word));
     return s;
   }
 };
+
 
 std::string explain_expr(const ExprP& e) {
   std::string s = expr_name(e->proto_tag);
@@ -1090,25 +1131,95 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
 
   // ---------------- Aggregate sinks ----------------
   if (agg->agg_mode != AggMode::Partial)
-    throw CometError("HashAggregate mode Final/PartialMerge is handled by the merge pipeline (not fused)");
-  if (!group_exprs.empty()) throw CometError("grouped aggregate: see grouped pipeline generator");
-  d.sink = SinkKind::AggNoGroup;
-  AggLowering al(g);
-  std::string fin;  // finalize body
+    throw CometError("HashAggregate mode Final/PartialMerge is not supported by the fused GPU pipeline yet");
+  const bool grouped = !group_exprs.empty();
+  d.sink = grouped ? SinkKind::AggGrouped : SinkKind::AggNoGroup;
+  AggLowering al(g, grouped);
+  std::string fin;  // finalize body; ROW is "[0]" (ungrouped) or "[pos]" (grouped emit)
+  const std::string ROW = grouped ? "[pos]" : "[0]";
   int out_j = 0;
   auto out_val = [&](int j) { return "prm.out[" + std::to_string(kOutFirstCol + 2 * j) + "]"; };
   auto out_ok = [&](int j) { return "prm.out[" + std::to_string(kOutFirstCol + 2 * j + 1) + "]"; };
-  // rows that reach the aggregate
-  std::string rowcnt_word;
-  {
-    PrimSlot rc = al.get(Prim::RowCnt, "*", "", [&](int w) { return "acc[" + std::to_string(w) + "] += 1;"; });
-    rowcnt_word = std::to_string(rc.word);
+
+  // ---- group keys → packed key words (word 0 = NULL bitmask of the keys)
+  std::string key_code, key_emit;
+  int nk = 0;
+  if (grouped) {
+    nk = 1;
+    key_code += "        key[0] = 0;\n";
+    int kj = 0;
+    for (auto& ge : group_exprs) {
+      OutCol oc;
+      std::string ok_expr;
+      const std::string vb = out_val(out_j), ob = out_ok(out_j);
+      const std::string nullbit = std::to_string(1ull << kj) + "ull";
+      if (ge->kind == ExprKind::Bound && d.in_types[ge->bound_index].id == TypeId::String) {
+        // Utf8 key: ≤15 bytes packed into two words (ld_str16); emitted packed, the host expands to Utf8
+        const int ci = ge->bound_index;
+        g.in_used[ci] = true;
+        const std::string c = "prm.in[" + std::to_string(ci) + "]";
+        std::string sv = g.newvar("comet::str16");
+        g.stmt("{ bool tl_ = false; " + sv + " = comet::ld_str16(" + c + ", idx[r], tl_); if (tl_) atomicOr((unsigned int*)prm.out[" +
+               std::to_string(kOutErr) + "], 64u); }");
+        g.uses_err = true;
+        if (in_has_validity[ci]) {
+          std::string o = g.newvar("bool");
+          g.stmt(o + " = comet::ld_valid(" + c + ", idx[r]);");
+          ok_expr = o;
+        }
+        const std::string k0 = std::to_string(nk), k1 = std::to_string(nk + 1);
+        const std::string okc = ok_expr.empty() ? "true" : ok_expr;
+        key_code += "        key[" + k0 + "] = (" + okc + ") ? " + sv + ".a : 0ull; key[" + k1 + "] = (" + okc + ") ? " + sv + ".b : 0ull;\n";
+        key_emit += "    ((u64*)" + vb + ")[2 * pos] = key[" + k0 + "]; ((u64*)" + vb + ")[2 * pos + 1] = key[" + k1 + "];\n";
+        nk += 2;
+        oc.type = DType::of(TypeId::String);
+        oc.packed_string = true;
+      } else {
+        Val v = g.named(g.gen(ge));
+        ok_expr = v.ok;
+        const std::string okc = ok_expr.empty() ? "true" : ok_expr;
+        const char* st = store_ctype(v.t);
+        if (v.rep == Rep::I128) {
+          const std::string k0 = std::to_string(nk), k1 = std::to_string(nk + 1);
+          key_code += "        key[" + k0 + "] = (" + okc + ") ? comet::lo64(" + v.v + ") : 0ull; key[" + k1 + "] = (" + okc + ") ? comet::hi64(" + v.v + ") : 0ull;\n";
+          key_emit += "    ((i128*)" + vb + ")[pos] = comet::mk128(key[" + k1 + "], key[" + k0 + "]);\n";
+          nk += 2;
+        } else {
+          const std::string k0 = std::to_string(nk);
+          std::string enc, dec;
+          switch (v.rep) {
+            case Rep::B: enc = "(u64)(" + v.v + " ? 1 : 0)"; dec = "(u8)key[" + k0 + "]"; break;
+            case Rep::I32: case Rep::I64: enc = "(u64)(i64)" + v.v; dec = std::string("(") + st + ")(i64)key[" + k0 + "]"; break;
+            // group keys reach the aggregate through NormalizeNaNAndZero (planner.rs:725-729): bit equality is value equality
+            case Rep::F64: enc = "(u64)__double_as_longlong(" + v.v + ")"; dec = "__longlong_as_double((i64)key[" + k0 + "])"; break;
+            case Rep::F32: enc = "(u64)(u32)__float_as_int(" + v.v + ")"; dec = "__int_as_float((int)(u32)key[" + k0 + "])"; break;
+            default: throw CometError("unsupported group key type " + v.t.str());
+          }
+          if (v.t.id == TypeId::Decimal) dec = "(i128)(i64)key[" + k0 + "]";
+          key_code += "        key[" + k0 + "] = (" + okc + ") ? " + enc + " : 0ull;\n";
+          key_emit += "    ((" + std::string(st) + "*)" + vb + ")[pos] = " + dec + ";\n";
+          nk += 1;
+        }
+        oc.type = v.t;
+      }
+      if (!ok_expr.empty()) key_code += "        if (!(" + ok_expr + ")) key[0] |= " + nullbit + ";\n";
+      key_emit += "    ((u8*)" + ob + ")[pos] = (key[0] & " + nullbit + ") ? 0 : 1;\n";
+      oc.nullable = true;
+      d.out_cols.push_back(oc);
+      ex << "  group key: " << explain_expr(ge) << " : " << oc.type.str() << "\n";
+      out_j++;
+      kj++;
+      if (kj > 60) throw CometError("too many group keys");
+    }
   }
+
+  // rows that reach the aggregate
+  PrimSlot rowcnt = al.get(Prim::RowCnt, "*", "", "", "");
+  const std::string rowcnt_word = std::to_string(rowcnt.word);
   long long max_rows_exact = 0;
   for (auto& in : agg_ins) {
     const AggExpr& a = *in.a;
-    std::string fkey;
-    std::string guard;
+    std::string fkey, guard;
     if (in.filter) {
       // FILTER (WHERE …): row contributes only if the filter is TRUE and valid (sum_decimal.rs:452-458)
       Val f = g.named(g.gen(in.filter));
@@ -1116,9 +1227,6 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       guard = Gen::and_ok(f.ok, f.v);
     }
     auto guarded = [&](const std::string& ok) { return Gen::and_ok(guard, ok); };
-    auto cond_stmt = [&](const std::string& cond, const std::string& body) {
-      return cond.empty() ? body : "if (" + cond + ") { " + body + " }";
-    };
     switch (a.kind) {
       case AggKind::Count: {
         if (in.children.empty()) throw CometError("count() without children");
@@ -1128,11 +1236,10 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
           ok = Gen::and_ok(ok, v.ok);
           vkey += g.key_of(c) + ",";
         }
-        if (ok.empty()) vkey = "*";  // count of non-nullable args = row count
-        PrimSlot s = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(ok), "acc[" + std::to_string(w) + "] += 1;"); });
+        PrimSlot s = al.get(Prim::Cnt, vkey, fkey, guarded(ok), "");
         OutCol oc; oc.type = DType::of(TypeId::Int64); oc.nullable = false;
         d.out_cols.push_back(oc);
-        fin += "    ((i64*)" + out_val(out_j) + ")[0] = (i64)acc[" + std::to_string(s.word) + "];\n";
+        fin += "    ((i64*)" + out_val(out_j) + ")" + ROW + " = (i64)acc[" + std::to_string(s.word) + "];\n";
         out_j++;
         ex << "  agg: count -> Int64\n";
         break;
@@ -1143,6 +1250,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         std::string vkey = g.key_of(in.children[0]);
         const bool is_avg = a.kind == AggKind::Avg;
         const DType& rt = a.dtype;
+        const std::string cond = guarded(v.ok);
         if (rt.id == TypeId::Decimal) {
           if (v.t.id != TypeId::Decimal) throw CometError("decimal sum/avg over non-decimal input " + v.t.str());
           const DType st = is_avg ? a.sum_dtype : rt;   // accumulation type
@@ -1158,30 +1266,28 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             if (max_rows_exact == 0 || sr < max_rows_exact) max_rows_exact = sr;
           }
           std::string val128 = v.rep == Rep::I128 ? v.v : "(i128)" + v.v;
-          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += 1;"); });
+          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, cond, "");
           PrimSlot sum, amax{}, sflags{};
           if (!dynamic) {
-            sum = al.get(Prim::Sum128, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "comet::acc_feed_i128(acc + " + std::to_string(w) + ", " + val128 + ");"); });
+            sum = al.get(Prim::Sum128, vkey, fkey, cond, val128);
           } else {
-            sum = al.get(Prim::Sum192, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "comet::acc_feed_i192(acc + " + std::to_string(w) + ", " + val128 + ");"); });
-            amax = al.get(Prim::AMax, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "comet::acc_feed_amax(acc + " + std::to_string(w) + ", " + val128 + ");"); });
-            sflags = al.get(Prim::SignFlags, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] |= (" + val128 + " < 0) ? 2ull : ((" + val128 + " > 0) ? 1ull : 0ull);"); });
+            sum = al.get(Prim::Sum192, vkey, fkey, cond, val128);
+            amax = al.get(Prim::AMaxHi, vkey, fkey, cond, val128);
+            sflags = al.get(Prim::SignFlags, vkey, fkey, cond, val128);
           }
-          std::string W = std::to_string(sum.word), C = std::to_string(cnt.word);
-          // overflow decision → `ovf` (sticky NULL in the reference), `inexact` → host error
-          fin += "    {\n      i128 total = comet::mk128(acc[" + W + " + 1], acc[" + W + "]);\n      bool ovf = false;\n";
+          std::string W = std::to_string(sum.word), W1 = std::to_string(sum.word + 1), C = std::to_string(cnt.word);
+          fin += "    {\n      i128 total = comet::mk128(acc[" + W1 + "], acc[" + W + "]);\n      bool ovf = false;\n";
           if (dynamic) {
-            std::string A = std::to_string(amax.word), F = std::to_string(sflags.word);
-            fin += "      comet::sum_overflow_decide(acc + " + W + ", acc + " + A + ", acc[" + F + "], acc[" + C + "], " + lit_u128(bound) +
-                   ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
+            fin += "      comet::sum_overflow_decide(acc + " + W + ", acc[" + std::to_string(amax.word) + "], acc[" + std::to_string(sflags.word) +
+                   "], acc[" + C + "], " + lit_u128(bound) + ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
             g.uses_err = true;
           }
           if (!is_avg) {
-            // SumDecimalAccumulator::state (sum_decimal.rs:281-295): (sum | NULL if overflowed, is_empty)
+            // SumDecimal state (sum_decimal.rs:281-295, :526-538): (sum | NULL if overflowed, is_empty)
             fin += "      bool empty = acc[" + C + "] == 0;\n";
-            fin += "      ((i128*)" + out_val(out_j) + ")[0] = ovf ? (i128)0 : total;\n";
-            fin += "      ((u8*)" + out_ok(out_j) + ")[0] = ovf ? 0 : 1;\n";
-            fin += "      ((u8*)" + out_val(out_j + 1) + ")[0] = empty ? 1 : 0;\n    }\n";
+            fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = ovf ? (i128)0 : total;\n";
+            fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = ovf ? 0 : 1;\n";
+            fin += "      ((u8*)" + out_val(out_j + 1) + ")" + ROW + " = empty ? 1 : 0;\n    }\n";
             OutCol s0; s0.type = st; s0.nullable = true;
             OutCol s1; s1.type = DType::of(TypeId::Bool); s1.nullable = false;
             d.out_cols.push_back(s0);
@@ -1189,12 +1295,20 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             out_j += 2;
             ex << "  agg: sum_decimal -> (" << st.str() << ", is_empty)\n";
           } else {
-            // AvgDecimalAccumulator::state (avg_decimal.rs:283-288): sum = None until the first value
-            fin += "      bool none = acc[" + C + "] == 0 || ovf;\n";
-            fin += "      ((i128*)" + out_val(out_j) + ")[0] = none ? (i128)0 : total;\n";
-            fin += "      ((u8*)" + out_ok(out_j) + ")[0] = none ? 0 : 1;\n";
-            fin += "      ((i64*)" + out_val(out_j + 1) + ")[0] = (i64)acc[" + C + "];\n";
-            fin += "      ((u8*)" + out_ok(out_j + 1) + ")[0] = 1;\n    }\n";
+            if (grouped) {
+              // AvgDecimalGroupsAccumulator::state (avg_decimal.rs:638-653): sum and count share the is_not_null mask
+              fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = ovf ? (i128)0 : total;\n";
+              fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = ovf ? 0 : 1;\n";
+              fin += "      ((i64*)" + out_val(out_j + 1) + ")" + ROW + " = ovf ? 0 : (i64)acc[" + C + "];\n";
+              fin += "      ((u8*)" + out_ok(out_j + 1) + ")" + ROW + " = ovf ? 0 : 1;\n    }\n";
+            } else {
+              // AvgDecimalAccumulator::state (avg_decimal.rs:283-288): sum = None until the first value
+              fin += "      bool none = acc[" + C + "] == 0 || ovf;\n";
+              fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = none ? (i128)0 : total;\n";
+              fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = none ? 0 : 1;\n";
+              fin += "      ((i64*)" + out_val(out_j + 1) + ")" + ROW + " = (i64)acc[" + C + "];\n";
+              fin += "      ((u8*)" + out_ok(out_j + 1) + ")" + ROW + " = 1;\n    }\n";
+            }
             OutCol s0; s0.type = st; s0.nullable = true;
             OutCol s1; s1.type = DType::of(TypeId::Int64); s1.nullable = true;
             d.out_cols.push_back(s0);
@@ -1203,34 +1317,30 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             ex << "  agg: avg_decimal -> (" << st.str() << ", count)\n";
           }
         } else if (!is_avg && rt.is_integer()) {
-          // SumInteger LEGACY (sum_int.rs:117-160): wrapping i64, NULL until a non-null value arrives
+          // SumInteger LEGACY (sum_int.rs:117-160, :403-475): wrapping i64, NULL until a non-null value arrives
           if (!v.t.is_integer()) throw CometError("integer sum over " + v.t.str());
           if (a.eval_mode != EvalMode::Legacy) throw CometError("ANSI/TRY integer sum is not supported in the GPU pipeline yet");
-          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += 1;"); });
-          PrimSlot sum = al.get(Prim::SumI64, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += (u64)(i64)" + v.v + ";"); });
-          fin += "    ((i64*)" + out_val(out_j) + ")[0] = acc[" + std::to_string(cnt.word) + "] ? (i64)acc[" + std::to_string(sum.word) + "] : 0;\n";
-          fin += "    ((u8*)" + out_ok(out_j) + ")[0] = acc[" + std::to_string(cnt.word) + "] ? 1 : 0;\n";
+          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, cond, "");
+          PrimSlot sum = al.get(Prim::SumI64, vkey, fkey, cond, v.v);
+          fin += "    ((i64*)" + out_val(out_j) + ")" + ROW + " = acc[" + std::to_string(cnt.word) + "] ? (i64)acc[" + std::to_string(sum.word) + "] : 0;\n";
+          fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + std::to_string(cnt.word) + "] ? 1 : 0;\n";
           OutCol s0; s0.type = DType::of(TypeId::Int64); s0.nullable = true;
           d.out_cols.push_back(s0);
           out_j++;
           ex << "  agg: sum_int -> Int64\n";
         } else {
           // float sum (DataFusion sum_udaf over Float64, planner.rs:2628-2634) / Avg (avg.rs): child cast to Float64
-          std::string dv;
-          if (v.rep == Rep::F64) dv = v.v;
-          else if (v.rep == Rep::F32 || v.rep == Rep::I32 || v.rep == Rep::I64) dv = "(double)" + v.v;
-          else throw CometError("float sum/avg over " + v.t.str() + " is not supported in the GPU pipeline yet");
-          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += 1;"); });
-          PrimSlot sum = al.get(Prim::SumF64, "f64:" + vkey, fkey, [&](int w) {
-            return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] = (u64)__double_as_longlong(comet::fp_add(__longlong_as_double((i64)acc[" + std::to_string(w) + "]), " + dv + "));");
-          });
+          if (!(v.rep == Rep::F64 || v.rep == Rep::F32 || v.rep == Rep::I32 || v.rep == Rep::I64))
+            throw CometError("float sum/avg over " + v.t.str() + " is not supported in the GPU pipeline yet");
+          PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, cond, "");
+          PrimSlot sum = al.get(Prim::SumF64, "f64:" + vkey, fkey, cond, v.v);
           std::string S = std::to_string(sum.word), C = std::to_string(cnt.word);
           if (is_avg) {
-            // AvgAccumulator::state (avg.rs:139-144): sum is Some(0.0) once any batch arrived
-            fin += "    ((double*)" + out_val(out_j) + ")[0] = __longlong_as_double((i64)acc[" + S + "]);\n";
-            fin += "    ((u8*)" + out_ok(out_j) + ")[0] = acc[" + rowcnt_word + "] ? 1 : 0;\n";
-            fin += "    ((i64*)" + out_val(out_j + 1) + ")[0] = (i64)acc[" + C + "];\n";
-            fin += "    ((u8*)" + out_ok(out_j + 1) + ")[0] = 1;\n";
+            // AvgAccumulator::state (avg.rs:139-144): ungrouped sum is Some once any batch arrived; grouped never NULL
+            fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = __longlong_as_double((i64)acc[" + S + "]);\n";
+            fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = " + (grouped ? std::string("1") : "acc[" + rowcnt_word + "] ? 1 : 0") + ";\n";
+            fin += "    ((i64*)" + out_val(out_j + 1) + ")" + ROW + " = (i64)acc[" + C + "];\n";
+            fin += "    ((u8*)" + out_ok(out_j + 1) + ")" + ROW + " = 1;\n";
             OutCol s0; s0.type = DType::of(TypeId::Double); s0.nullable = true;
             OutCol s1; s1.type = DType::of(TypeId::Int64); s1.nullable = true;
             d.out_cols.push_back(s0);
@@ -1238,8 +1348,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             out_j += 2;
             ex << "  agg: avg_f64 -> (Float64, count)\n";
           } else {
-            fin += "    ((double*)" + out_val(out_j) + ")[0] = __longlong_as_double((i64)acc[" + S + "]);\n";
-            fin += "    ((u8*)" + out_ok(out_j) + ")[0] = acc[" + C + "] ? 1 : 0;\n";
+            fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = __longlong_as_double((i64)acc[" + S + "]);\n";
+            fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + C + "] ? 1 : 0;\n";
             OutCol s0; s0.type = DType::of(TypeId::Double); s0.nullable = true;
             d.out_cols.push_back(s0);
             out_j++;
@@ -1254,26 +1364,26 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         std::string vkey = g.key_of(in.children[0]);
         const bool mn = a.kind == AggKind::Min;
         if (!(v.t == a.dtype)) throw CometError("min/max with cast is not supported in the GPU pipeline yet");
-        PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, [&](int w) { return cond_stmt(guarded(v.ok), "acc[" + std::to_string(w) + "] += 1;"); });
+        const std::string cond = guarded(v.ok);
+        PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, cond, "");
         PrimSlot s;
         std::string rd;
         const char* st = store_ctype(v.t);
         if (v.rep == Rep::I32 || v.rep == Rep::I64) {
-          s = al.get(mn ? Prim::MinI64 : Prim::MaxI64, vkey, fkey, [&](int w) {
-            return cond_stmt(guarded(v.ok), "{ u64 t_ = (u64)(i64)" + v.v + "; comet::acc_" + (mn ? "imin64" : "imax64") + "(acc + " + std::to_string(w) + ", &t_); }");
-          });
+          s = al.get(mn ? Prim::MinI64 : Prim::MaxI64, vkey, fkey, cond, v.v);
           rd = v.t.id == TypeId::Decimal ? "(i128)(i64)acc[" + std::to_string(s.word) + "]" : std::string("(") + st + ")(i64)acc[" + std::to_string(s.word) + "]";
         } else if (v.rep == Rep::I128) {
-          s = al.get(mn ? Prim::MinI128 : Prim::MaxI128, vkey, fkey, [&](int w) {
-            return cond_stmt(guarded(v.ok), "{ u64 t_[2] = {comet::lo64(" + v.v + "), comet::hi64(" + v.v + ")}; comet::acc_" + (mn ? "imin128" : "imax128") + "(acc + " + std::to_string(w) + ", t_); }");
-          });
-          rd = "comet::mk128(acc[" + std::to_string(s.word) + " + 1], acc[" + std::to_string(s.word) + "])";
+          s = al.get(mn ? Prim::MinI128 : Prim::MaxI128, vkey, fkey, cond, v.v);
+          rd = "comet::mk128(acc[" + std::to_string(s.word + 1) + "], acc[" + std::to_string(s.word) + "])";
+        } else if (v.rep == Rep::F64 || v.rep == Rep::F32) {
+          s = al.get(mn ? Prim::MinF64 : Prim::MaxF64, vkey, fkey, cond, v.v);
+          rd = std::string("(") + st + ")__longlong_as_double((i64)acc[" + std::to_string(s.word) + "])";
         } else {
           throw CometError("min/max over " + v.t.str() + " is not supported in the GPU pipeline yet");
         }
         std::string C = std::to_string(cnt.word);
-        fin += "    ((" + std::string(st) + "*)" + out_val(out_j) + ")[0] = acc[" + C + "] ? " + rd + " : (" + st + ")0;\n";
-        fin += "    ((u8*)" + out_ok(out_j) + ")[0] = acc[" + C + "] ? 1 : 0;\n";
+        fin += "    ((" + std::string(st) + "*)" + out_val(out_j) + ")" + ROW + " = acc[" + C + "] ? " + rd + " : (" + st + ")0;\n";
+        fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + C + "] ? 1 : 0;\n";
         OutCol s0; s0.type = v.t; s0.nullable = true;
         d.out_cols.push_back(s0);
         out_j++;
@@ -1286,20 +1396,48 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
   if (d.out_cols.size() * 2 + kOutFirstCol > COMET_MAX_OUT) throw CometError("too many aggregate state columns for one GPU pipeline");
   d.NW = al.nw;
-  d.R = 4;
+  d.NK = nk;
+  d.R = grouped ? 2 : 4;
   d.max_rows_exact = max_rows_exact;
   d.in_used = g.in_used;
   src << "struct P {\n  static constexpr int R = " << d.R << ";\n  static constexpr int NW = " << d.NW << ";\n";
   src << "  static __device__ __forceinline__ void init(u64* a) {\n" << al.init_code << "  }\n";
   src << "  static __device__ __forceinline__ void combine(u64* a, const u64* b) {\n" << al.combine_code << "  }\n";
-  src << "  static __device__ __forceinline__ void tile(const CometKParams& prm, i64 base, i64 n, u64* acc) {\n"
-      << "    bool k[R]; i64 idx[R];\n"
-      << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n"
-      << g.decls << g.body() << "  }\n";
-  src << "  static __device__ __forceinline__ void finalize(const CometKParams& prm, const u64* acc) {\n" << fin << "  }\n};\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg(const CometKParams prm) { comet::agg_nogroup_body<P>(prm); }\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg_final(const CometKParams prm) { comet::agg_nogroup_final_body<P>(prm); }\n";
-  d.kernels = {"k_agg", "k_agg_final"};
+  if (!grouped) {
+    src << "  static __device__ __forceinline__ void tile(const CometKParams& prm, i64 base, i64 n, u64* acc) {\n"
+        << "    bool k[R]; i64 idx[R];\n"
+        << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n"
+        << g.decls << g.body() << "  }\n";
+    src << "  static __device__ __forceinline__ void finalize(const CometKParams& prm, const u64* acc) {\n" << fin << "  }\n};\n";
+    src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg(const CometKParams prm) { comet::agg_nogroup_body<P>(prm); }\n";
+    src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg_final(const CometKParams prm) { comet::agg_nogroup_final_body<P>(prm); }\n";
+    d.kernels = {"k_agg", "k_agg_final"};
+  } else {
+    // LDS table: as many slots as fit in 32 KiB (power of two, ≤ 1024)
+    const int slot_bytes = 8 + 8 * (d.NK + d.NW);
+    int cap = 1024;
+    while (cap > 16 && cap * slot_bytes > 32 * 1024) cap >>= 1;
+    d.lds_cap = cap;
+    src << "  static constexpr int NK = " << d.NK << ";\n  static constexpr int LDS_CAP = " << cap << ";\n";
+    src << "  static __device__ __forceinline__ constexpr int op(int k) {\n    switch (k) {\n";
+    for (size_t k = 0; k < al.gops.size(); k++) src << "      case " << k << ": return comet::" << al.gops[k] << ";\n";
+    src << "      default: return comet::G_CONT;\n    }\n  }\n";
+    src << "  static __device__ __forceinline__ constexpr u64 identity(int k) {\n    switch (k) {\n";
+    for (size_t k = 0; k < al.gident.size(); k++) src << "      case " << k << ": return " << al.gident[k] << ";\n";
+    src << "      default: return 0ull;\n    }\n  }\n";
+    src << "  static __device__ __forceinline__ void tile_grouped(const CometKParams& prm, i64 base, i64 n, const comet::GroupCtx<P>& grp) {\n"
+        << "    bool k[R]; i64 idx[R];\n"
+        << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n"
+        << g.decls << g.body()
+        << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) {\n      u64 key[NK]; u64 val[NW];\n      if (k[r]) {\n"
+        << key_code << al.val_code << "      }\n      comet::group_update<P>(grp, k[r], key, val);\n    }\n  }\n";
+    src << "  static __device__ __forceinline__ void emit_group(const CometKParams& prm, const u64* key, const u64* acc, i64 pos) {\n"
+        << key_emit << fin << "  }\n};\n";
+    src << "extern \"C\" __global__ __launch_bounds__(256) void k_gagg(const CometKParams prm) { comet::agg_grouped_body<P>(prm); }\n";
+    src << "extern \"C\" __global__ __launch_bounds__(256) void k_gemit(const CometKParams prm) { comet::agg_grouped_emit_body<P>(prm); }\n";
+    src << "extern \"C\" __global__ __launch_bounds__(256) void k_grehash(const CometKParams prm) { comet::agg_grouped_rehash_body<P>(prm); }\n";
+    d.kernels = {"k_gagg", "k_gemit", "k_grehash"};
+  }
   d.source = src.str();
   d.explain = ex.str();
   return d;

@@ -57,6 +57,30 @@ CDEV bool ld_bool(const CometCol& c, i64 i) {
 // Decimal128 whose precision ≤ 18: the upper limb is sign extension, read only the lower one.
 CDEV i64 ld_dec_lo(const CometCol& c, i64 i) { return ((const i64*)c.data)[2 * (c.offset + i)]; }
 
+// Utf8 values of ≤ 15 bytes packed into two words (bytes 0-7 in a, bytes 8-14 in the low 56 bits of b,
+// length in the top byte of b): injective, so equality and grouping on the packed form are exact.
+// Longer strings set `toolong` (the host turns it into an explicit "not supported yet" error).
+struct str16 {
+  u64 a, b;
+};
+CDEV str16 ld_str16(const CometCol& c, i64 i, bool& toolong) {
+  const i32* off = (const i32*)c.data;
+  i64 j = c.offset + i;
+  i32 lo = off[j], len = off[j + 1] - lo;
+  const u8* p = (const u8*)c.aux + lo;
+  str16 r;
+  r.a = 0;
+  r.b = 0;
+  if (len > 15) { toolong = true; len = 15; }
+  for (i32 k = 0; k < len; k++) {
+    u64 byte = p[k];
+    if (k < 8) r.a |= byte << (8 * k);
+    else r.b |= byte << (8 * (k - 8));
+  }
+  r.b |= (u64)len << 56;
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 256-bit two's-complement integer (four little-endian u64 limbs) for the wide-decimal path.
 // ---------------------------------------------------------------------------------------------
@@ -377,14 +401,15 @@ CDEV void acc_fmax64(u64* a, const u64* b) {
 // sum leaves the precision it stays NULL).  A parallel reduction only sees totals, so decide exactness
 // from order-independent facts:
 //   1. cnt · max|v| ≤ bound            → no prefix can overflow, the total is the answer
+//      (max|v| is tracked coarsely as hi64(|v|)+1, one word, so the grouped path can use atomicMax)
 //   2. all values share one sign       → prefixes are monotone, overflow ⇔ |total| > bound (192-bit total)
 //   3. otherwise                       → cannot be decided without the row order: flag err bit 4
-CDEV void sum_overflow_decide(const u64* sum192, const u64* amax, u64 signflags, u64 cnt, u128 bound, bool& ovf,
+CDEV void sum_overflow_decide(const u64* sum192, u64 amax_hi_plus1, u64 signflags, u64 cnt, u128 bound, bool& ovf,
                               unsigned int* err) {
   ovf = false;
-  u128 m = ((u128)amax[1] << 64) | amax[0];
-  if (cnt == 0 || m == 0) return;
-  if (m <= bound / (u128)cnt) return;  // case 1 (floor division is exact enough: m·cnt ≤ bound)
+  if (cnt == 0 || amax_hi_plus1 == 0) return;
+  // case 1: max|v| < amax_hi_plus1·2^64, so cnt·max|v| < cnt·amax_hi_plus1·2^64 ≤ bound
+  if ((u128)amax_hi_plus1 * (u128)cnt <= (bound >> 64)) return;
   // |total| from the three limbs
   bool neg = (sum192[2] >> 63) != 0;
   u64 l0 = sum192[0], l1 = sum192[1], l2 = sum192[2];
@@ -639,9 +664,10 @@ struct Slot {
 // find-or-insert in a table living in LDS or global memory.  No lane ever waits for another lane
 // while holding a claim, so lanes of one wave probing the same slot cannot deadlock.
 template <int NK, int NW, class InitFn>
-CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* key, InitFn init) {
+CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* key, InitFn init, u64 max_probes,
+                                        unsigned long long* insert_counter = nullptr) {
   u64 h = hash_key<NK>(key) & (cap - 1);
-  for (u64 probes = 0; probes < cap;) {
+  for (u64 probes = 0; probes < max_probes;) {
     Slot<NK, NW>* s = &tbl[h];
     u32 st = __hip_atomic_load(&s->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     if (st == kSlotEmpty) {
@@ -652,6 +678,7 @@ CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* k
         for (int k = 0; k < NK; k++) s->key[k] = key[k];
         init(s->acc);
         __hip_atomic_store(&s->state, kSlotReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (insert_counter) atomicAdd(insert_counter, 1ull);
         return s;
       }
       continue;  // lost the race: re-read this slot
@@ -667,35 +694,204 @@ CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* k
   return nullptr;
 }
 
-CDEV void atomic_word(u64* dst, u64 v, int op) {
-  switch (op) {
-    case OP_ADD: atomicAdd((unsigned long long*)dst, v); break;
-    case OP_UMAX: atomicMax((unsigned long long*)dst, v); break;
-    case OP_OR: atomicOr((unsigned long long*)dst, v); break;
-    case OP_IMIN: atomicMin((long long*)dst, (long long)v); break;
-    case OP_IMAX: atomicMax((long long*)dst, (long long)v); break;
-    case OP_FADD: atomicAdd((double*)dst, __longlong_as_double((i64)v)); break;
-    default: break;
-  }
-}
-// multi-limb wrapping add with explicit carries: each limb add returns the old value, the carry out
-// of THIS add is exact, and carries commute — the final limbs equal the true sum mod 2^(64·L).
+// per-word atomic combine.  Multi-limb wrapping adds use explicit carries: each limb add returns the
+// old value, so the carry out of THIS add is exact, and carries commute — after all updates the limbs
+// equal the true sum mod 2^(64·L) regardless of interleaving.
 CDEV void atomic_add_limbs(u64* dst, const u64* v, int limbs) {
   u64 carry = 0;
   for (int k = 0; k < limbs; k++) {
     u64 add = v[k] + carry;
-    u64 c1 = add < carry ? 1 : 0;  // v[k] + carry overflowed
-    if (add != 0 || k == 0) {
-      u64 old = atomicAdd((unsigned long long*)&dst[k], add);
-      carry = c1 + ((old + add) < old ? 1 : 0);
-    } else {
-      carry = c1;
+    u64 c = (add < carry) ? 1 : 0;  // v[k] + carry wrapped (only when v[k] = 2^64-1 and carry = 1)
+    if (add != 0) {
+      u64 old = atomicAdd((unsigned long long*)&dst[k], (unsigned long long)add);
+      if (old + add < old) c = 1;
     }
-    if (carry == 0 && k + 1 < limbs) {
-      // nothing more to propagate unless the remaining addend limbs are non-zero
-      bool rest = false;
-      for (int j = k + 1; j < limbs; j++) rest |= v[j] != 0;
-      if (!rest) return;
+    carry = c;
+  }
+}
+CDEV void atomic_cas_combine_f64(u64* dst, u64 v, int op) {
+  u64 old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) {
+    u64 nv = old;
+    if (op == OP_FADD) nv = (u64)__double_as_longlong(fp_add(__longlong_as_double((i64)old), __longlong_as_double((i64)v)));
+    else { u64 t[1] = {old}; u64 w[1] = {v}; if (op == OP_IMIN) acc_fmin64(t, w); else acc_fmax64(t, w); nv = t[0]; }
+    if (nv == old) return;
+    if (__hip_atomic_compare_exchange_strong(dst, &old, nv, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  }
+}
+
+// accumulator word kinds of the grouped path (P::op(k))
+enum GOp : int { G_ADD64 = 0, G_ADD128 = 1, G_ADD192 = 2, G_UMAX64 = 3, G_OR64 = 4, G_FADD64 = 5, G_IMIN64 = 6, G_IMAX64 = 7, G_FMIN64 = 8, G_FMAX64 = 9, G_CONT = 10 };
+
+// apply one contribution (NW words) to a slot's accumulators
+template <class P>
+CDEV void slot_apply(u64* acc, const u64* val) {
+#pragma unroll
+  for (int k = 0; k < P::NW; k++) {
+    switch (P::op(k)) {
+      case G_ADD64: if (val[k]) atomicAdd((unsigned long long*)&acc[k], (unsigned long long)val[k]); break;
+      case G_ADD128: atomic_add_limbs(acc + k, val + k, 2); break;
+      case G_ADD192: atomic_add_limbs(acc + k, val + k, 3); break;
+      case G_UMAX64: if (val[k]) atomicMax((unsigned long long*)&acc[k], (unsigned long long)val[k]); break;
+      case G_OR64: if (val[k]) atomicOr((unsigned long long*)&acc[k], (unsigned long long)val[k]); break;
+      case G_IMIN64: atomicMin((long long*)&acc[k], (long long)val[k]); break;
+      case G_IMAX64: atomicMax((long long*)&acc[k], (long long)val[k]); break;
+      case G_FADD64: atomic_cas_combine_f64(acc + k, val[k], OP_FADD); break;
+      case G_FMIN64: atomic_cas_combine_f64(acc + k, val[k], OP_IMIN); break;
+      case G_FMAX64: atomic_cas_combine_f64(acc + k, val[k], OP_IMAX); break;
+      default: break;  // G_CONT: continuation limb of a multi-limb add
+    }
+  }
+}
+
+// butterfly reduction of a contribution across the wave (every lane ends with the total); lanes that do
+// not belong to the group being reduced contribute P::identity
+template <class P>
+CDEV void wave_reduce_contrib(u64* val) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    u64 o[P::NW];
+#pragma unroll
+    for (int k = 0; k < P::NW; k++) o[k] = shfl_xor_u64(val[k], m);
+#pragma unroll
+    for (int k = 0; k < P::NW; k++) {
+      switch (P::op(k)) {
+        case G_ADD64: val[k] += o[k]; break;
+        case G_ADD128: acc_add128(val + k, o + k); break;
+        case G_ADD192: acc_add192(val + k, o + k); break;
+        case G_UMAX64: if (o[k] > val[k]) val[k] = o[k]; break;
+        case G_OR64: val[k] |= o[k]; break;
+        case G_IMIN64: acc_imin64(val + k, o + k); break;
+        case G_IMAX64: acc_imax64(val + k, o + k); break;
+        case G_FADD64: acc_fadd64(val + k, o + k); break;
+        case G_FMIN64: acc_fmin64(val + k, o + k); break;
+        case G_FMAX64: acc_fmax64(val + k, o + k); break;
+        default: break;
+      }
+    }
+  }
+}
+
+template <class P>
+struct GroupCtx {
+  Slot<P::NK, P::NW>* lds;
+  Slot<P::NK, P::NW>* glb;
+  u64 glb_cap;
+  unsigned int* err;            // err[0] flags; ((u64*)err)[1] = number of groups in the global table
+  CDEV unsigned long long* counter() const { return (unsigned long long*)err + 1; }
+};
+constexpr u64 kMaxGlobalProbes = 1024;  // beyond this the table counts as full (host grows it and re-runs)
+
+template <class P>
+struct SlotInit {
+  CDEV void operator()(u64* acc) const { P::init(acc); }
+};
+
+// One row per lane.  Must be called convergently by the whole wave (inactive lanes pass active=false).
+template <class P>
+CDEV void group_update(const GroupCtx<P>& g, bool active, const u64* key, u64* val) {
+  typedef Slot<P::NK, P::NW> S;
+  S* s = nullptr;
+  if (active) {
+    if (P::LDS_CAP > 0) s = table_find_or_insert<P::NK, P::NW>(g.lds, (u64)P::LDS_CAP, key, SlotInit<P>(), 16);
+    if (!s) {
+      s = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
+      if (!s) atomicOr(g.err, 32u);
+    }
+  }
+  const bool live = active && s != nullptr;
+  u64 todo = __ballot(live);
+  int rounds = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const u64 sp = shfl_u64((u64)s, leader);
+    const bool mine = live && (u64)s == sp;
+    const u64 same = __ballot(mine);
+    if (__popcll(same) >= 4 && rounds < 6) {
+      // low cardinality: fold the wave's rows of this group in registers, ONE atomic set per wave
+      u64 red[P::NW];
+#pragma unroll
+      for (int k = 0; k < P::NW; k++) red[k] = mine ? val[k] : P::identity(k);
+      wave_reduce_contrib<P>(red);
+      if (lane_id() == leader) slot_apply<P>(((S*)sp)->acc, red);
+    } else {
+      if (mine) slot_apply<P>(s->acc, val);
+    }
+    todo &= ~same;
+    rounds++;
+  }
+}
+
+// Kernel template C body.  prm.out[0] = global table, prm.iarg[0] = its capacity, prm.out[2] = err flags.
+template <class P>
+CDEV void agg_grouped_body(const CometKParams& prm) {
+  typedef Slot<P::NK, P::NW> S;
+  __shared__ S s_tbl[P::LDS_CAP > 0 ? P::LDS_CAP : 1];
+  if (P::LDS_CAP > 0) {
+    for (int i = threadIdx.x; i < P::LDS_CAP; i += kBlock) s_tbl[i].state = kSlotEmpty;
+    __syncthreads();
+  }
+  GroupCtx<P> g;
+  g.lds = s_tbl;
+  g.glb = (S*)prm.out[0];
+  g.glb_cap = (u64)prm.iarg[0];
+  g.err = (unsigned int*)prm.out[2];
+  const i64 n = prm.n;
+  const i64 tile = (i64)P::R * kBlock;
+  for (i64 base = (i64)blockIdx.x * tile; base < n; base += (i64)gridDim.x * tile) P::tile_grouped(prm, base, n, g);
+  if (P::LDS_CAP > 0) {
+    __syncthreads();
+    // merge this block's LDS table into the global table
+    for (int i = threadIdx.x; i < P::LDS_CAP; i += kBlock) {
+      S* ls = &s_tbl[i];
+      if (ls->state == kSlotReady) {
+        u64 key[P::NK], val[P::NW];
+#pragma unroll
+        for (int k = 0; k < P::NK; k++) key[k] = ls->key[k];
+#pragma unroll
+        for (int k = 0; k < P::NW; k++) val[k] = ls->acc[k];
+        S* gs = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
+        if (gs) slot_apply<P>(gs->acc, val);
+        else atomicOr(g.err, 32u);
+      }
+    }
+  }
+}
+
+// Emit one output row per occupied slot (order unspecified, like the reference's hash aggregate).
+//   prm.out[0] table, iarg[0] capacity, prm.out[1] = u64 row counter
+template <class P>
+CDEV void agg_grouped_emit_body(const CometKParams& prm) {
+  typedef Slot<P::NK, P::NW> S;
+  const S* tbl = (const S*)prm.out[0];
+  const i64 cap = prm.iarg[0];
+  for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < cap; i += (i64)gridDim.x * kBlock) {
+    if (tbl[i].state == kSlotReady) {
+      i64 pos = (i64)atomicAdd((unsigned long long*)prm.out[1], 1ull);
+      P::emit_group(prm, tbl[i].key, tbl[i].acc, pos);
+    }
+  }
+}
+
+// Move every group of an old table into a larger one (growth between chunks).
+//   prm.out[0] new table, iarg[0] new capacity, prm.out[3] old table, iarg[1] old capacity
+template <class P>
+CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
+  typedef Slot<P::NK, P::NW> S;
+  const S* old = (const S*)prm.out[3];
+  S* nt = (S*)prm.out[0];
+  for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < prm.iarg[1]; i += (i64)gridDim.x * kBlock) {
+    if (old[i].state == kSlotReady) {
+      u64 key[P::NK];
+#pragma unroll
+      for (int k = 0; k < P::NK; k++) key[k] = old[i].key[k];
+      S* gs = table_find_or_insert<P::NK, P::NW>(nt, (u64)prm.iarg[0], key, SlotInit<P>(), (u64)prm.iarg[0], (unsigned long long*)prm.out[2] + 1);
+      if (gs) {
+#pragma unroll
+        for (int k = 0; k < P::NW; k++) gs->acc[k] = old[i].acc[k];  // unique key per old slot: plain copy
+      } else {
+        atomicOr((unsigned int*)prm.out[2], 32u);
+      }
     }
   }
 }

@@ -243,6 +243,71 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     return;
   }
 
+  if (d.sink == SinkKind::AggGrouped) {
+    if (agg_variant_ && (agg_variant_->desc.NW != d.NW || agg_variant_->desc.NK != d.NK))
+      throw CometError("internal: group slot layout differs between variants");
+    agg_variant_ = &v;
+    const size_t slot_bytes = 8 + 8 * (size_t)(d.NK + d.NW);
+    auto alloc_table = [&](DevBuf& buf, int64_t cap) {
+      buf.ensure((size_t)cap * slot_bytes);
+      HIP_CHECK(hipMemsetAsync(buf.p, 0, (size_t)cap * slot_bytes, stream_));
+    };
+    if (group_cap_ == 0) {
+      // start small: low-cardinality group-bys (TPC-H Q1: 4 groups) must not pay for a table sized by the row count
+      int64_t want = 1 << 16;
+      group_cap_ = want;
+      alloc_table(group_table_, group_cap_);
+      HIP_CHECK(hipMemsetAsync((char*)err_flags_.p + 8, 0, 8, stream_));
+    }
+    const int64_t tile = (int64_t)d.R * 256;
+    int grid = (int)std::min<int64_t>((n + tile - 1) / tile, 256 * 4);
+    while (true) {
+      // checkpoint: if the table fills up mid-chunk some rows are dropped, so the chunk is re-run from the checkpoint
+      group_backup_.ensure((size_t)group_cap_ * slot_bytes);
+      HIP_CHECK(hipMemcpyAsync(group_backup_.p, group_table_.p, (size_t)group_cap_ * slot_bytes, hipMemcpyDeviceToDevice, stream_));
+      uint64_t groups_before = 0;
+      HIP_CHECK(hipMemcpyAsync(&groups_before, (char*)err_flags_.p + 8, 8, hipMemcpyDeviceToHost, stream_));
+      prm.out[0] = group_table_.p;
+      prm.iarg[0] = group_cap_;
+      HIP_CHECK(hipEventRecord(ev_start_, stream_));
+      launch(v, "k_gagg", grid, prm);
+      HIP_CHECK(hipEventRecord(ev_stop_, stream_));
+      uint32_t flags[4];
+      HIP_CHECK(hipMemcpyAsync(flags, err_flags_.p, 16, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, ev_start_, ev_stop_));
+      last_kernel_ms += ms;
+      last_kernel_launches++;
+      uint64_t groups_now;
+      memcpy(&groups_now, &flags[2], 8);
+      const bool full = (flags[0] & 32u) != 0;
+      if (!full && (int64_t)groups_now * 2 <= group_cap_) break;
+      // grow ×8 and rehash; after a "full" event restart this chunk from the checkpoint
+      int64_t new_cap = group_cap_ * 8;
+      if (new_cap > ((int64_t)1 << 28)) throw CometError("group table would exceed 2^28 slots");
+      DevBuf bigger;
+      alloc_table(bigger, new_cap);
+      uint32_t zero4[4] = {flags[0] & ~32u, flags[1], 0, 0};
+      HIP_CHECK(hipMemcpyAsync(err_flags_.p, zero4, 16, hipMemcpyHostToDevice, stream_));
+      CometKParams rp;
+      memset(&rp, 0, sizeof rp);
+      rp.out[0] = bigger.p;
+      rp.iarg[0] = new_cap;
+      rp.out[2] = err_flags_.p;
+      rp.out[3] = full ? group_backup_.p : group_table_.p;
+      rp.iarg[1] = group_cap_;
+      launch(v, "k_grehash", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), rp);
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      std::swap(group_table_.p, bigger.p);
+      std::swap(group_table_.cap, bigger.cap);
+      group_cap_ = new_cap;
+      (void)groups_before;
+      if (!full) break;
+    }
+    return;
+  }
+
   if (d.sink == SinkKind::Output) {
     const size_t ncol = d.out_cols.size();
     const int64_t ntiles = (n + 1023) / 1024;
@@ -358,6 +423,7 @@ void ExecutionContext::check_device_errors() {
   if (f & 2u) throw CometError("{\"errorType\":\"ArithmeticOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"fromType\":\"integer\"}}", 1);
   if (f & 4u) throw CometError("{\"errorType\":\"CastOverFlow\",\"errorClass\":\"CAST_OVERFLOW\",\"params\":{}}", 1);
   if (f & 8u) throw CometError("{\"errorType\":\"NumericValueOutOfRange\",\"errorClass\":\"NUMERIC_VALUE_OUT_OF_RANGE\",\"params\":{}}", 1);
+  if (f & 64u) throw CometError("Utf8 group keys longer than 15 bytes are not supported by the GPU hash aggregate yet");
   if (f & 16u)
     throw CometError("decimal sum overflow cannot be decided order-independently for this input (mixed signs beyond the precision bound); "
                      "exact sequential evaluation is not implemented");
@@ -419,6 +485,95 @@ void ExecutionContext::finish_aggregate() {
   ready_.push_back(std::move(b));
 }
 
+void ExecutionContext::finish_grouped() {
+  if (!agg_variant_) return;  // no input rows → no groups → no output batch
+  Variant& v = *agg_variant_;
+  const PipelineDesc& d = v.desc;
+  uint64_t ngroups = 0;
+  HIP_CHECK(hipMemcpyAsync(&ngroups, (char*)err_flags_.p + 8, 8, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  if (ngroups == 0) return;
+  const size_t ncol = d.out_cols.size();
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  prm.out[0] = group_table_.p;
+  prm.iarg[0] = group_cap_;
+  scratch_counts_.ensure(64);
+  HIP_CHECK(hipMemsetAsync(scratch_counts_.p, 0, 8, stream_));
+  prm.out[1] = scratch_counts_.p;
+  prm.out[kOutErr] = err_flags_.p;
+  out_vals_.resize(ncol);
+  out_valid_.resize(ncol);
+  std::vector<int> widths(ncol);
+  for (size_t j = 0; j < ncol; j++) {
+    if (!out_vals_[j]) out_vals_[j].reset(new DevBuf());
+    if (!out_valid_[j]) out_valid_[j].reset(new DevBuf());
+    const OutCol& oc = d.out_cols[j];
+    widths[j] = oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type));
+    out_vals_[j]->ensure((size_t)ngroups * widths[j] + 16);
+    out_valid_[j]->ensure((size_t)ngroups + 16);
+    HIP_CHECK(hipMemsetAsync(out_valid_[j]->p, 1, (size_t)ngroups, stream_));
+    prm.out[kOutFirstCol + 2 * j] = out_vals_[j]->p;
+    prm.out[kOutFirstCol + 2 * j + 1] = out_valid_[j]->p;
+  }
+  launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
+  std::vector<std::vector<uint8_t>> hv(ncol), hk(ncol);
+  for (size_t j = 0; j < ncol; j++) {
+    hv[j].resize((size_t)ngroups * widths[j]);
+    hk[j].resize((size_t)ngroups);
+    HIP_CHECK(hipMemcpyAsync(hv[j].data(), out_vals_[j]->p, hv[j].size(), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(hk[j].data(), out_valid_[j]->p, hk[j].size(), hipMemcpyDeviceToHost, stream_));
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  const int64_t total = (int64_t)ngroups;
+  const int64_t bs = batch_size_ > 0 ? batch_size_ : total;
+  for (int64_t off = 0; off < total; off += bs) {
+    const int64_t len = std::min(bs, total - off);
+    HostBatch b;
+    b.rows = len;
+    for (size_t j = 0; j < ncol; j++) {
+      const OutCol& oc = d.out_cols[j];
+      HostColumn c;
+      c.type = oc.type;
+      c.length = len;
+      if (oc.packed_string) {
+        // expand str16 (bytes 0-7 | bytes 8-14 + length byte) into Arrow Utf8 offsets + data
+        c.values.resize((size_t)(len + 1) * 4);
+        int32_t* offs = (int32_t*)c.values.data();
+        offs[0] = 0;
+        for (int64_t i = 0; i < len; i++) {
+          uint64_t w[2];
+          memcpy(w, hv[j].data() + (size_t)(off + i) * 16, 16);
+          int slen = hk[j][(size_t)(off + i)] ? (int)(w[1] >> 56) : 0;
+          for (int k = 0; k < slen; k++) c.data.push_back((uint8_t)(k < 8 ? (w[0] >> (8 * k)) : (w[1] >> (8 * (k - 8)))));
+          offs[i + 1] = (int32_t)c.data.size();
+        }
+      } else if (c.type.id == TypeId::Bool) {
+        c.values.assign((size_t)((len + 7) / 8), 0);
+        for (int64_t i = 0; i < len; i++)
+          if (hv[j][(size_t)(off + i)]) c.values[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+      } else {
+        int w = widths[j];
+        c.values.assign(hv[j].begin() + (size_t)off * w, hv[j].begin() + (size_t)(off + len) * w);
+      }
+      if (oc.nullable) {
+        int64_t nulls = 0;
+        std::vector<uint8_t> bm((size_t)((len + 7) / 8), 0);
+        for (int64_t i = 0; i < len; i++) {
+          if (hk[j][(size_t)(off + i)]) bm[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+          else nulls++;
+        }
+        c.null_count = nulls;
+        if (nulls) c.validity = std::move(bm);
+      }
+      b.cols.push_back(std::move(c));
+    }
+    ready_.push_back(std::move(b));
+  }
+}
+
 // Pull host batches from the JVM stream until a chunk is full; copy through pinned staging to HBM.
 bool ExecutionContext::pull_host_chunk() {
   InputSource& in = inputs_[0];
@@ -427,13 +582,17 @@ bool ExecutionContext::pull_host_chunk() {
   if (stage_vals_.size() != nc) {
     stage_vals_.resize(nc);
     stage_valid_.resize(nc);
+    stage_aux_.resize(nc);
     dev_vals_.resize(nc);
     dev_valid_.resize(nc);
+    dev_aux_.resize(nc);
     for (size_t c = 0; c < nc; c++) {
       stage_vals_[c].reset(new PinnedBuf());
       stage_valid_[c].reset(new PinnedBuf());
+      stage_aux_[c].reset(new PinnedBuf());
       dev_vals_[c].reset(new DevBuf());
       dev_valid_[c].reset(new DevBuf());
+      dev_aux_[c].reset(new DevBuf());
     }
   }
   int64_t rows = 0;
@@ -469,8 +628,52 @@ bool ExecutionContext::pull_host_chunk() {
   for (auto& a : held)
     for (size_t c = 0; c < nc; c++)
       if (a.children[c]->null_count != 0 && a.children[c]->buffers[0]) has_valid[c] = true;
+  std::vector<size_t> aux_bytes(nc, 0);
   for (size_t c = 0; c < nc; c++) {
     const DType& t = in_types_[c];
+    if (t.id == TypeId::String || t.id == TypeId::Bytes) {
+      // Utf8: int32 offsets rebased to the chunk + concatenated bytes
+      size_t total_bytes = 0;
+      for (auto& a : held) {
+        const ArrowArray* col = a.children[c];
+        const int32_t* off = (const int32_t*)col->buffers[1];
+        total_bytes += (size_t)(off[col->offset + col->length] - off[col->offset]);
+      }
+      if (total_bytes > 0x7fffffffull) throw CometError("Utf8 chunk exceeds 2 GiB of string bytes; lower spark.comet.gpu.chunkRows");
+      stage_vals_[c]->ensure((size_t)(rows + 1) * 4 + 16);
+      stage_aux_[c]->ensure(total_bytes + 16);
+      if (has_valid[c]) stage_valid_[c]->ensure((size_t)((rows + 7) / 8) + 16);
+      int32_t* so = (int32_t*)stage_vals_[c]->p;
+      int64_t at = 0;
+      int32_t pos = 0;
+      for (auto& a : held) {
+        const ArrowArray* col = a.children[c];
+        if (col->dictionary) throw CometError("dictionary-encoded input columns are not unpacked on the GPU path yet");
+        const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
+        const int32_t base = off[0];
+        for (int64_t i = 0; i < col->length; i++) so[at + i] = pos + (off[i] - base);
+        size_t nb = (size_t)(off[col->length] - base);
+        if (nb) memcpy((char*)stage_aux_[c]->p + pos, (const char*)col->buffers[2] + base, nb);
+        if (has_valid[c]) {
+          if (col->null_count != 0 && col->buffers[0]) bit_append((uint8_t*)stage_valid_[c]->p, at, (const uint8_t*)col->buffers[0], col->offset, col->length);
+          else bit_fill_ones((uint8_t*)stage_valid_[c]->p, at, col->length);
+        }
+        pos += (int32_t)nb;
+        at += col->length;
+      }
+      so[rows] = pos;
+      dev_vals_[c]->ensure((size_t)(rows + 1) * 4 + 16);
+      dev_aux_[c]->ensure(total_bytes + 16);
+      HIP_CHECK(hipMemcpyAsync(dev_vals_[c]->p, stage_vals_[c]->p, (size_t)(rows + 1) * 4, hipMemcpyHostToDevice, stream_));
+      if (total_bytes) HIP_CHECK(hipMemcpyAsync(dev_aux_[c]->p, stage_aux_[c]->p, total_bytes, hipMemcpyHostToDevice, stream_));
+      if (has_valid[c]) {
+        size_t kb = (size_t)((rows + 7) / 8);
+        dev_valid_[c]->ensure(kb + 16);
+        HIP_CHECK(hipMemcpyAsync(dev_valid_[c]->p, stage_valid_[c]->p, kb, hipMemcpyHostToDevice, stream_));
+      }
+      aux_bytes[c] = total_bytes;
+      continue;
+    }
     const int w = fixed_width(t);
     size_t vbytes = w ? (size_t)rows * w : (size_t)((rows + 7) / 8);
     stage_vals_[c]->ensure(vbytes + 16);
@@ -507,8 +710,10 @@ bool ExecutionContext::pull_host_chunk() {
   for (size_t c = 0; c < nc; c++) {
     views[c].data = dev_vals_[c]->p;
     views[c].valid = has_valid[c] ? (const uint8_t*)dev_valid_[c]->p : nullptr;
+    views[c].aux = dev_aux_[c]->p;
   }
   process_chunk(views, has_valid, rows);
+  HIP_CHECK(hipStreamSynchronize(stream_));  // staging buffers are reused by the next chunk
   return !in.exhausted;
 }
 
@@ -543,6 +748,7 @@ bool ExecutionContext::pull_device_batch() {
     if (col->dictionary) throw CometError("dictionary-encoded device columns are not supported yet");
     views[c].data = col->buffers[1];
     views[c].offset = col->offset;
+    if (in_types_[c].id == TypeId::String || in_types_[c].id == TypeId::Bytes) views[c].aux = col->buffers[2];
     if (in_types_[c].id == TypeId::Decimal && (((uintptr_t)col->buffers[1]) & 15))
       throw CometError("device Decimal128 buffers must be 16-byte aligned");
     if (col->null_count != 0 && col->buffers[0]) {
@@ -581,7 +787,8 @@ int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_sch
   if (!finished_) {
     if (is_agg) {
       run_to_completion();
-      finish_aggregate();
+      if (sink_ == SinkKind::AggGrouped) finish_grouped();
+      else finish_aggregate();
       finished_ = true;
     } else {
       while (ready_.empty() && !finished_) {
@@ -631,9 +838,12 @@ void ExecutionContext::export_batch(HostBatch& b, ArrowArray** out_arrays, Arrow
     a->length = ec->col.length;
     a->null_count = ec->col.null_count;
     a->offset = 0;
-    a->n_buffers = 2;
+    const bool is_str = ec->col.type.id == TypeId::String || ec->col.type.id == TypeId::Bytes;
+    a->n_buffers = is_str ? 3 : 2;
     ec->buffers[0] = ec->col.null_count ? ec->col.validity.data() : nullptr;
     ec->buffers[1] = ec->col.values.data();
+    static const uint8_t kEmpty[1] = {0};
+    ec->buffers[2] = is_str ? (ec->col.data.empty() ? (const void*)kEmpty : (const void*)ec->col.data.data()) : nullptr;
     a->buffers = ec->buffers;
     a->private_data = ec;
     a->release = release_array;

@@ -97,6 +97,7 @@ class ExecutionContext {
   Variant& variant_for(const std::vector<bool>& has_valid);
   void process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n);
   void finish_aggregate();
+  void finish_grouped();
   bool pull_host_chunk();
   bool pull_device_batch();
   void export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
@@ -119,13 +120,15 @@ class ExecutionContext {
   SinkKind sink_ = SinkKind::Output;
 
   // host→device staging (one chunk at a time)
-  std::vector<std::unique_ptr<PinnedBuf>> stage_vals_, stage_valid_;
-  std::vector<std::unique_ptr<DevBuf>> dev_vals_, dev_valid_;
+  std::vector<std::unique_ptr<PinnedBuf>> stage_vals_, stage_valid_, stage_aux_;
+  std::vector<std::unique_ptr<DevBuf>> dev_vals_, dev_valid_, dev_aux_;
 
   // aggregate state
   DevBuf partials_;
   int64_t n_partials_ = 0;
   DevBuf err_flags_;
+  DevBuf group_table_, group_backup_;
+  int64_t group_cap_ = 0;
   DevBuf scratch_mask_, scratch_counts_;
   std::vector<std::unique_ptr<DevBuf>> out_vals_, out_valid_;
 

@@ -152,15 +152,16 @@ _FIXED_WIDTH = {pa.int8(): 1, pa.int16(): 2, pa.int32(): 4, pa.int64(): 8, pa.fl
 class DeviceTable:
     """Arrow-layout columns resident in HBM (torch tensors own the memory)."""
 
-    def __init__(self, schema: pa.Schema, num_rows: int, values, validity, device):
+    def __init__(self, schema: pa.Schema, num_rows: int, values, validity, device, aux=None):
         self.schema, self.num_rows, self.values, self.validity, self.device = schema, num_rows, values, validity, device
+        self.aux = aux if aux is not None else [None] * len(values)   # Utf8: data bytes (values = int32 offsets)
 
     @staticmethod
     def from_arrow(table: pa.Table, device="cuda:0") -> "DeviceTable":
         import numpy as np
         import torch
         table = table.combine_chunks()
-        vals, valid = [], []
+        vals, valid, aux = [], [], []
         for name in table.schema.names:
             arr = table.column(name).chunk(0) if table.num_rows else pa.array([], type=table.schema.field(name).type)
             if arr.offset != 0:
@@ -174,10 +175,17 @@ class DeviceTable:
                 valid.append(torch.from_numpy(np.frombuffer(bufs[0], dtype=np.uint8).copy()).to(device))
             else:
                 valid.append(None)
-        return DeviceTable(table.schema, table.num_rows, vals, valid, device)
+            if pa.types.is_string(arr.type) or pa.types.is_binary(arr.type):
+                d = bufs[2]
+                hd = np.frombuffer(d, dtype=np.uint8) if d is not None and d.size else np.zeros(1, np.uint8)
+                aux.append(torch.from_numpy(hd.copy()).to(device))
+            else:
+                aux.append(None)
+        return DeviceTable(table.schema, table.num_rows, vals, valid, device, aux)
 
     def nbytes(self) -> int:
-        return sum(v.numel() for v in self.values) + sum(v.numel() for v in self.validity if v is not None)
+        return (sum(v.numel() for v in self.values) + sum(v.numel() for v in self.validity if v is not None)
+                + sum(v.numel() for v in self.aux if v is not None))
 
 
 class DeviceInput:
@@ -231,13 +239,16 @@ class DeviceInput:
         release = ctypes.cast(self._cb_arr_release, ctypes.c_void_p)
         for i in range(n):
             child = ArrowArrayC()
-            bufs = (ctypes.c_void_p * 2)()
+            nb = 3 if t.aux[i] is not None else 2
+            bufs = (ctypes.c_void_p * nb)()
             bufs[0] = t.validity[i].data_ptr() if t.validity[i] is not None else None
             bufs[1] = t.values[i].data_ptr() if t.values[i].numel() else None
+            if nb == 3:
+                bufs[2] = t.aux[i].data_ptr()
             child.length = t.num_rows
             child.null_count = -1 if t.validity[i] is not None else 0
             child.offset = 0
-            child.n_buffers = 2
+            child.n_buffers = nb
             child.n_children = 0
             child.buffers = bufs
             child.release = release

@@ -101,6 +101,37 @@ Q6_NUM_OUTPUT_COLS = 2  # (sum dec(35,4), is_empty bool)
 Q6_BYTES_PER_ROW = 4 + 16 + 16 + 16  # Arrow layout of the four referenced columns
 
 
+def q1_plan(mode: int = S.PARTIAL) -> S.Operator:
+    """TPC-H Q1 stage 1.  Scan order: qty, price, disc, tax, returnflag, linestatus, shipdate.
+    HashAgg(Partial, keys=[returnflag, linestatus],
+            [sum(qty) d(22,2), sum(price) d(22,2), sum(disc_price) d(36,4), sum(charge) d(38,6),
+             avg(qty), avg(price), avg(disc) → d(16,6) with sum type d(22,2), count(1)])
+      ← Project[returnflag, linestatus, qty, price, disc,
+                disc_price = CheckOverflow(price * CheckOverflow(1 - disc → d(13,2)) → d(26,4)),
+                charge     = wide (disc_price d(26,4)) * CheckOverflow(1 + tax → d(13,2)) → d(38,6)]
+      ← Filter(shipdate <= 1998-09-02) ← Scan."""
+    fields = [DEC, DEC, DEC, DEC, S.T_STRING, S.T_STRING, S.T_DATE]
+    qty, price, disc, tax, rf, ls, ship = (S.col(i, t) for i, t in enumerate(fields))
+    f = S.filter_(S.scan(fields), S.lt_eq(ship, S.lit(days(1998, 9, 2), S.T_DATE)))
+    one = S.lit(100, S.decimal(12, 2))   # Spark promotes the literal 1 to decimal(12,2)? it sends Decimal(1,0) cast; keep (12,2)
+    one_minus = S.check_overflow(S.math("subtract", one, disc, S.decimal(13, 2)), S.decimal(13, 2))
+    one_plus = S.check_overflow(S.math("add", one, tax, S.decimal(13, 2)), S.decimal(13, 2))
+    disc_price = S.check_overflow(S.math("multiply", price, one_minus, S.decimal(26, 4)), S.decimal(26, 4))
+    charge = S.check_overflow(S.math("multiply", disc_price, one_plus, S.decimal(38, 6)), S.decimal(38, 6))
+    p = S.project(f, [rf, ls, qty, price, disc, disc_price, charge])
+    D22, D16 = S.decimal(22, 2), S.decimal(16, 6)
+    c = lambda i, t: S.col(i, t)
+    aggs = [S.sum_(c(2, DEC), D22), S.sum_(c(3, DEC), D22), S.sum_(c(5, S.decimal(26, 4)), S.decimal(36, 4)),
+            S.sum_(c(6, S.decimal(38, 6)), S.decimal(38, 6)),
+            S.avg(c(2, DEC), D16, D22), S.avg(c(3, DEC), D16, D22), S.avg(c(4, DEC), D16, D22),
+            S.count(S.lit(1, S.T_INT32))]
+    return S.hash_agg(p, [c(0, S.T_STRING), c(1, S.T_STRING)], aggs, mode)
+
+
+Q1_NUM_OUTPUT_COLS = 2 + 4 * 2 + 3 * 2 + 1  # keys + (sum,is_empty)×4 + (sum,count)×3 + count
+Q1_BYTES_PER_ROW = 4 + 4 * 16 + 2 * (4 + 1)  # SURVEY §8(d)
+
+
 def warm_plans():
     """Plans whose fused kernels build() pre-compiles into the code-object cache."""
-    return [q6_plan()]
+    return [q6_plan(), q1_plan()]

@@ -408,3 +408,7 @@ void o_q6_reference_pipeline(const i128* qty, const i128* price, const i128* dis
   *out_sum = st.sum; *out_has_sum = st.has_sum; *out_is_empty = st.is_empty;
   free(m0); free(m1); free(fprice); free(fdisc); free(prod); free(ok);
 }
+
+/* layout self-check used by the Python binding */
+int o_sizeof_sumdec_state(void) { return (int)sizeof(SumDecState); }
+int o_sizeof_avgdec_state(void) { return (int)sizeof(AvgDecState); }

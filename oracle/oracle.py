@@ -48,7 +48,8 @@ def _p(a: Optional[np.ndarray]):
 
 
 class SumDecState(ctypes.Structure):
-    _fields_ = [("sum", ctypes.c_uint64 * 2), ("has_sum", ctypes.c_int32), ("is_empty", ctypes.c_int32)]
+    # C: struct { __int128 sum; int32_t has_sum; int32_t is_empty; } → 16-byte aligned, sizeof == 32
+    _fields_ = [("sum", ctypes.c_uint64 * 2), ("has_sum", ctypes.c_int32), ("is_empty", ctypes.c_int32), ("_pad", ctypes.c_uint64)]
 
 
 class AvgDecState(ctypes.Structure):
