@@ -15,6 +15,7 @@
 #include "kparams.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <sstream>
@@ -182,6 +183,7 @@ struct Gen {
   std::map<const Expr*, std::string> keymemo;
   std::map<int, Val> col_cache;
   bool uses_err = false;
+  bool eager_loads = false;   // hoist every column load into the first stage (no lazy loading after predicates)
 
   Gen(const std::vector<DType>& t, const std::vector<bool>& v) : in_types(t), in_valid(v), in_used(t.size(), false) {
     stages.emplace_back();
@@ -193,7 +195,7 @@ struct Gen {
     return n + "[r]";
   }
   void stmt(const std::string& s) { stages.back().body += "      " + s + "\n"; }
-  void load(const std::string& s) { stages.back().loads += "      " + s + "\n"; }
+  void load(const std::string& s) { (eager_loads ? stages.front() : stages.back()).loads += "      " + s + "\n"; }
   void next_stage() { stages.emplace_back(); }
 
   // materialise an expression string into a variable (so later uses do not recompute it)
@@ -853,8 +855,9 @@ enum class Prim { Cnt, RowCnt, Sum128, Sum192, SumI64, SumF64, AMaxHi, SignFlags
 
 struct PrimSlot {
   Prim prim;
-  int word;      // first accumulator word
+  int word;      // first canonical accumulator word (or kernel-level word index when kernel_level)
   int nwords;
+  bool kernel_level = false;
 };
 
 int prim_words(Prim p) {
@@ -865,69 +868,125 @@ int prim_words(Prim p) {
   }
 }
 
+int bit_length_u128(u128 v) {
+  int b = 0;
+  while (v) { b++; v >>= 1; }
+  return b;
+}
+
+constexpr int kLimbBitsHost = 43;  // must equal comet::kLimbBits
+
 struct AggLowering {
   Gen& g;
   bool grouped;
-  int nw = 0;
+  int nw = 0;    // canonical words
+  int npw = 0;   // grouped: private (limb-form) words per group
+  int nkw = 0;   // grouped: kernel-level words
   std::map<std::string, PrimSlot> slots;   // key: prim|valuekey|filterkey
   std::string init_code, combine_code;
-  std::vector<std::string> gops, gident;   // grouped: per-word GOp name and identity literal
-  std::string val_code;                    // grouped: per-row contribution assignments (val[w] = …)
+  std::vector<std::string> gops, gident;   // canonical: per-word GOp name and identity literal (global-table atomics)
+  std::vector<std::string> pops, pident;   // grouped: private words
+  std::vector<std::string> kops;           // grouped: kernel-level words
+  std::string pv_code;                     // grouped: per-row limb contributions (pv[j] = …)
+  std::string fold_code;                   // grouped: limb words pw[] → canonical contribution val[]
+  std::string kfeed_code;                  // grouped: per-row kernel-level updates
 
   AggLowering(Gen& gen, bool grp) : g(gen), grouped(grp) {}
 
-  // cond: row contributes iff cond (empty = always); x: value expression typed for the primitive
-  PrimSlot get(Prim p, const std::string& vkey, const std::string& fkey, const std::string& cond, const std::string& x) {
+  int pword(const char* op, const char* ident) {
+    pops.push_back(op);
+    pident.push_back(ident);
+    return npw++;
+  }
+
+  // cond: row contributes iff cond (empty = always); x: value expression typed for the primitive;
+  // maxabs: static bound on |x| (integer sums), used to size the limb split
+  PrimSlot get(Prim p, const std::string& vkey, const std::string& fkey, const std::string& cond, const std::string& x,
+               u128 maxabs = kUnbounded) {
     std::string key = std::to_string((int)p) + "|" + vkey + "|" + fkey;
     if (p == Prim::Cnt && cond.empty()) key = std::to_string((int)Prim::RowCnt) + "|*|";  // counts every row: share
     auto it = slots.find(key);
     if (it != slots.end()) return it->second;
+    const std::string c = cond.empty() ? "true" : cond;
+    auto feed = [&](const std::string& body) { g.stmt(cond.empty() ? body : "if (" + cond + ") { " + body + " }"); };
+    if (grouped && (p == Prim::AMaxHi || p == Prim::SignFlags)) {
+      // value bounds for the overflow proof are tracked per KERNEL, not per group (a bound for all groups is a
+      // bound for each): two registers per thread instead of two LDS atomics per row
+      PrimSlot s{p, nkw, 1, true};
+      slots[key] = s;
+      const std::string kk = std::to_string(nkw++);
+      if (p == Prim::AMaxHi) {
+        kops.push_back("G_UMAX64");
+        kfeed_code += "        if (" + c + ") { u64 t_ = comet::hi64((i128)comet::uabs128(" + x + ")) + 1ull; if (t_ > kacc[" + kk + "]) kacc[" + kk + "] = t_; }\n";
+      } else {
+        kops.push_back("G_OR64");
+        kfeed_code += "        if (" + c + ") kacc[" + kk + "] |= ((" + x + ") < 0) ? 2ull : (((" + x + ") > 0) ? 1ull : 0ull);\n";
+      }
+      return s;
+    }
     PrimSlot s{p, nw, prim_words(p)};
     nw += s.nwords;
     slots[key] = s;
     const std::string w = std::to_string(s.word), w1 = std::to_string(s.word + 1), w2 = std::to_string(s.word + 2);
-    const std::string c = cond.empty() ? "true" : cond;
     auto ops = [&](std::initializer_list<const char*> o, std::initializer_list<const char*> id) {
       for (auto* q : o) gops.push_back(q);
       for (auto* q : id) gident.push_back(q);
     };
-    auto feed = [&](const std::string& body) { g.stmt(cond.empty() ? body : "if (" + cond + ") { " + body + " }"); };
+    // grouped integer sum: split into limbs, fold back into `nlimb_words` canonical words
+    auto grouped_int_sum = [&](const std::string& x128, u128 bound, int canon_words) {
+      int bits = (bound == kUnbounded ? 127 : bit_length_u128(bound)) + 1;
+      int nl = (bits + kLimbBitsHost - 1) / kLimbBitsHost;
+      if (nl < 1) nl = 1;
+      int j0 = -1;
+      for (int t = 0; t < nl; t++) {
+        int j = pword("G_ADD64", "0ull");
+        if (t == 0) j0 = j;
+        pv_code += "        pv[" + std::to_string(j) + "] = (" + c + ") ? comet::limb_of(" + x128 + ", " + std::to_string(t) + ", " + std::to_string(nl) + ") : 0ull;\n";
+      }
+      fold_code += "    { u64 t3_[3]; comet::limbs_to_i192(pw + " + std::to_string(j0) + ", " + std::to_string(nl) + ", t3_);";
+      for (int k = 0; k < canon_words; k++) fold_code += " val[" + std::to_string(s.word + k) + "] = t3_[" + std::to_string(k) + "];";
+      fold_code += " }\n";
+    };
     switch (p) {
       case Prim::Cnt: case Prim::RowCnt:
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    comet::acc_add64(a + " + w + ", b + " + w + ");\n";
         ops({"G_ADD64"}, {"0ull"});
-        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? 1ull : 0ull;\n";
-        else feed("acc[" + w + "] += 1;");
+        if (grouped) {
+          int j = pword("G_ADD64", "0ull");
+          pv_code += "        pv[" + std::to_string(j) + "] = (" + c + ") ? 1ull : 0ull;\n";
+          fold_code += "    val[" + w + "] = pw[" + std::to_string(j) + "];\n";
+        } else feed("acc[" + w + "] += 1;");
         break;
       case Prim::SumI64:
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    comet::acc_add64(a + " + w + ", b + " + w + ");\n";
         ops({"G_ADD64"}, {"0ull"});
-        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (u64)(i64)(" + x + ") : 0ull;\n";
+        if (grouped) grouped_int_sum("(i128)(i64)(" + x + ")", maxabs == kUnbounded ? ((u128)1 << 63) : maxabs, 1);  // wraps mod 2^64 like add_wrapping
         else feed("acc[" + w + "] += (u64)(i64)(" + x + ");");
         break;
       case Prim::SumF64:
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    comet::acc_fadd64(a + " + w + ", b + " + w + ");\n";
         ops({"G_FADD64"}, {"0ull"});
-        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (u64)__double_as_longlong((double)(" + x + ")) : 0ull;\n";
-        else feed("acc[" + w + "] = (u64)__double_as_longlong(comet::fp_add(__longlong_as_double((i64)acc[" + w + "]), (double)(" + x + ")));");
+        if (grouped) {
+          int j = pword("G_FADD64", "0ull");
+          pv_code += "        pv[" + std::to_string(j) + "] = (" + c + ") ? (u64)__double_as_longlong((double)(" + x + ")) : 0ull;\n";
+          fold_code += "    val[" + w + "] = pw[" + std::to_string(j) + "];\n";
+        } else feed("acc[" + w + "] = (u64)__double_as_longlong(comet::fp_add(__longlong_as_double((i64)acc[" + w + "]), (double)(" + x + ")));");
         break;
       case Prim::Sum128:
         init_code += "    a[" + w + "] = 0; a[" + w1 + "] = 0;\n";
         combine_code += "    comet::acc_add128(a + " + w + ", b + " + w + ");\n";
         ops({"G_ADD128", "G_CONT"}, {"0ull", "0ull"});
-        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? comet::lo64(" + x + ") : 0ull; val[" + w1 + "] = (" + c + ") ? comet::hi64(" + x + ") : 0ull;\n";
+        if (grouped) grouped_int_sum(x, maxabs, 2);
         else feed("comet::acc_feed_i128(acc + " + w + ", " + x + ");");
         break;
       case Prim::Sum192:
         init_code += "    a[" + w + "] = 0; a[" + w1 + "] = 0; a[" + w2 + "] = 0;\n";
         combine_code += "    comet::acc_add192(a + " + w + ", b + " + w + ");\n";
         ops({"G_ADD192", "G_CONT", "G_CONT"}, {"0ull", "0ull", "0ull"});
-        if (grouped)
-          val_code += "        val[" + w + "] = (" + c + ") ? comet::lo64(" + x + ") : 0ull; val[" + w1 + "] = (" + c + ") ? comet::hi64(" + x +
-                      ") : 0ull; val[" + w2 + "] = ((" + c + ") && (" + x + ") < 0) ? ~0ull : 0ull;\n";
+        if (grouped) grouped_int_sum(x, maxabs, 3);
         else feed("comet::acc_feed_i192(acc + " + w + ", " + x + ");");
         break;
       case Prim::AMaxHi:
@@ -935,15 +994,13 @@ struct AggLowering {
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    if (b[" + w + "] > a[" + w + "]) a[" + w + "] = b[" + w + "];\n";
         ops({"G_UMAX64"}, {"0ull"});
-        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (comet::hi64((i128)comet::uabs128(" + x + ")) + 1ull) : 0ull;\n";
-        else feed("{ u64 t_ = comet::hi64((i128)comet::uabs128(" + x + ")) + 1ull; if (t_ > acc[" + w + "]) acc[" + w + "] = t_; }");
+        feed("{ u64 t_ = comet::hi64((i128)comet::uabs128(" + x + ")) + 1ull; if (t_ > acc[" + w + "]) acc[" + w + "] = t_; }");
         break;
       case Prim::SignFlags:
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    comet::acc_or64(a + " + w + ", b + " + w + ");\n";
         ops({"G_OR64"}, {"0ull"});
-        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (((" + x + ") < 0) ? 2ull : (((" + x + ") > 0) ? 1ull : 0ull)) : 0ull;\n";
-        else feed("acc[" + w + "] |= ((" + x + ") < 0) ? 2ull : (((" + x + ") > 0) ? 1ull : 0ull);");
+        feed("acc[" + w + "] |= ((" + x + ") < 0) ? 2ull : (((" + x + ") > 0) ? 1ull : 0ull);");
         break;
       case Prim::MinI64: case Prim::MaxI64: {
         const bool mn = p == Prim::MinI64;
@@ -951,18 +1008,26 @@ struct AggLowering {
         init_code += "    a[" + w + "] = " + id + ";\n";
         combine_code += std::string("    comet::acc_") + (mn ? "imin64" : "imax64") + "(a + " + w + ", b + " + w + ");\n";
         ops({mn ? "G_IMIN64" : "G_IMAX64"}, {id});
-        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (u64)(i64)(" + x + ") : " + id + ";\n";
-        else feed(std::string("{ u64 t_ = (u64)(i64)(") + x + "); comet::acc_" + (mn ? "imin64" : "imax64") + "(acc + " + w + ", &t_); }");
+        if (grouped) {
+          int j = pword(mn ? "G_IMIN64" : "G_IMAX64", id);
+          pv_code += "        pv[" + std::to_string(j) + "] = (" + c + ") ? (u64)(i64)(" + x + ") : " + id + ";\n";
+          fold_code += "    val[" + w + "] = pw[" + std::to_string(j) + "];\n";
+        } else feed(std::string("{ u64 t_ = (u64)(i64)(") + x + "); comet::acc_" + (mn ? "imin64" : "imax64") + "(acc + " + w + ", &t_); }");
         break;
       }
       case Prim::MinF64: case Prim::MaxF64: {
         const bool mn = p == Prim::MinF64;
-        const char* id = mn ? "0x7fffffffffffffffull" : "0xffffffffffffffffull";  // extremes of the IEEE total order
+        const char* id = mn ? "0x7fffffffffffffffull" : "0xffffffffffffffffull";  // extremes of the IEEE total order (as bits)
         init_code += "    a[" + w + "] = " + id + ";\n";
         combine_code += std::string("    comet::acc_") + (mn ? "fmin64" : "fmax64") + "(a + " + w + ", b + " + w + ");\n";
         ops({mn ? "G_FMIN64" : "G_FMAX64"}, {id});
-        if (grouped) val_code += "        val[" + w + "] = (" + c + ") ? (u64)__double_as_longlong((double)(" + x + ")) : " + id + ";\n";
-        else feed(std::string("{ u64 t_ = (u64)__double_as_longlong((double)(") + x + ")); comet::acc_" + (mn ? "fmin64" : "fmax64") + "(acc + " + w + ", &t_); }");
+        if (grouped) {
+          // in LDS: integer min/max on the total-order key (an involution of the bit pattern)
+          const char* kid = mn ? "0x7fffffffffffffffull" : "0x8000000000000000ull";
+          int j = pword(mn ? "G_IMIN64" : "G_IMAX64", kid);
+          pv_code += "        pv[" + std::to_string(j) + "] = (" + c + ") ? (u64)comet::f64_total_key((double)(" + x + ")) : " + kid + ";\n";
+          fold_code += "    val[" + w + "] = (u64)comet::f64_total_key(__longlong_as_double((i64)pw[" + std::to_string(j) + "]));\n";
+        } else feed(std::string("{ u64 t_ = (u64)__double_as_longlong((double)(") + x + ")); comet::acc_" + (mn ? "fmin64" : "fmax64") + "(acc + " + w + ", &t_); }");
         break;
       }
       case Prim::MinI128: case Prim::MaxI128: {
@@ -978,7 +1043,6 @@ struct AggLowering {
     return s;
   }
 };
-
 
 std::string explain_expr(const ExprP& e) {
   std::string s = expr_name(e->proto_tag);
@@ -1059,12 +1123,14 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
 
   Gen g(d.in_types, in_has_validity);
+  if (const char* e = getenv("COMET_GEN_EAGER")) g.eager_loads = atoi(e) != 0;
   for (auto& p : preds) g.add_predicate(p);
 
   std::ostringstream src;
   src << "// generated by datafusion-comet_amd codegen — fused pipeline: ";
   for (auto& n : d.op_names) src << n << " <- ";
   src << "input\n";
+  if (const char* e = getenv("COMET_EXPERIMENT")) src << "#define COMET_EXPERIMENT " << atoi(e) << "\n";
   src << "#include \"comet_device.hpp\"\nusing namespace comet;\n";
 
   std::ostringstream ex;
@@ -1260,7 +1326,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
           // Appendix C.1: no prefix can overflow while rows × max|v| ≤ 10^p − 1
           u128 vmax = v.maxabs == 0 ? 1 : v.maxabs;
           u128 safe_rows = vmax == kUnbounded ? 0 : bound / vmax;
-          const bool dynamic = safe_rows < ((u128)1 << 34);
+          const bool dynamic = safe_rows < ((u128)1 << 33);  // Spark sizes sum types for 10^10 rows (p+10)
           if (!dynamic) {
             long long sr = safe_rows > (u128)0x7fffffffffffffffll ? 0x7fffffffffffffffll : (long long)safe_rows;
             if (max_rows_exact == 0 || sr < max_rows_exact) max_rows_exact = sr;
@@ -1269,17 +1335,21 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
           PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, cond, "");
           PrimSlot sum, amax{}, sflags{};
           if (!dynamic) {
-            sum = al.get(Prim::Sum128, vkey, fkey, cond, val128);
+            sum = al.get(Prim::Sum128, vkey, fkey, cond, val128, v.maxabs);
           } else {
-            sum = al.get(Prim::Sum192, vkey, fkey, cond, val128);
+            sum = al.get(Prim::Sum192, vkey, fkey, cond, val128, v.maxabs);
             amax = al.get(Prim::AMaxHi, vkey, fkey, cond, val128);
             sflags = al.get(Prim::SignFlags, vkey, fkey, cond, val128);
           }
           std::string W = std::to_string(sum.word), W1 = std::to_string(sum.word + 1), C = std::to_string(cnt.word);
           fin += "    {\n      i128 total = comet::mk128(acc[" + W1 + "], acc[" + W + "]);\n      bool ovf = false;\n";
           if (dynamic) {
-            fin += "      comet::sum_overflow_decide(acc + " + W + ", acc[" + std::to_string(amax.word) + "], acc[" + std::to_string(sflags.word) +
-                   "], acc[" + C + "], " + lit_u128(bound) + ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
+            auto kw = [&](const PrimSlot& ps) {
+              return ps.kernel_level ? "((const u64*)prm.out[" + std::to_string(kOutErr) + "])[2 + " + std::to_string(ps.word) + "]"
+                                     : "acc[" + std::to_string(ps.word) + "]";
+            };
+            fin += "      comet::sum_overflow_decide(acc + " + W + ", " + kw(amax) + ", " + kw(sflags) + ", acc[" + C + "], " + lit_u128(bound) +
+                   ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
             g.uses_err = true;
           }
           if (!is_avg) {
@@ -1321,7 +1391,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
           if (!v.t.is_integer()) throw CometError("integer sum over " + v.t.str());
           if (a.eval_mode != EvalMode::Legacy) throw CometError("ANSI/TRY integer sum is not supported in the GPU pipeline yet");
           PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, cond, "");
-          PrimSlot sum = al.get(Prim::SumI64, vkey, fkey, cond, v.v);
+          PrimSlot sum = al.get(Prim::SumI64, vkey, fkey, cond, v.v, v.maxabs);
           fin += "    ((i64*)" + out_val(out_j) + ")" + ROW + " = acc[" + std::to_string(cnt.word) + "] ? (i64)acc[" + std::to_string(sum.word) + "] : 0;\n";
           fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + std::to_string(cnt.word) + "] ? 1 : 0;\n";
           OutCol s0; s0.type = DType::of(TypeId::Int64); s0.nullable = true;
@@ -1398,6 +1468,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   d.NW = al.nw;
   d.NK = nk;
   d.R = grouped ? 2 : 4;
+  if (const char* e = getenv("COMET_GEN_R")) d.R = std::max(1, std::min(8, atoi(e)));
   d.max_rows_exact = max_rows_exact;
   d.in_used = g.in_used;
   src << "struct P {\n  static constexpr int R = " << d.R << ";\n  static constexpr int NW = " << d.NW << ";\n";
@@ -1413,24 +1484,37 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg_final(const CometKParams prm) { comet::agg_nogroup_final_body<P>(prm); }\n";
     d.kernels = {"k_agg", "k_agg_final"};
   } else {
-    // LDS table: as many slots as fit in 32 KiB (power of two, ≤ 1024)
-    const int slot_bytes = 8 + 8 * (d.NK + d.NW);
+    // LDS budget: private copies [GC][NPW][COPIES] + table slots, ≤ 48 KiB per block (≥ 3 blocks per CU)
+    d.NPW = al.npw;
+    const int copies = 32;
+    int gc = 8;
+    while (gc > 1 && gc * al.npw * copies * 8 > 24 * 1024) gc >>= 1;
+    if (const char* e = getenv("COMET_GEN_GC")) gc = std::max(1, std::min(16, atoi(e)));
+    const int slot_bytes = 8 + 8 * (d.NK + al.npw + 1);
     int cap = 1024;
-    while (cap > 16 && cap * slot_bytes > 32 * 1024) cap >>= 1;
+    while (cap > 16 && cap * slot_bytes > 24 * 1024) cap >>= 1;
     d.lds_cap = cap;
-    src << "  static constexpr int NK = " << d.NK << ";\n  static constexpr int LDS_CAP = " << cap << ";\n";
-    src << "  static __device__ __forceinline__ constexpr int op(int k) {\n    switch (k) {\n";
-    for (size_t k = 0; k < al.gops.size(); k++) src << "      case " << k << ": return comet::" << al.gops[k] << ";\n";
-    src << "      default: return comet::G_CONT;\n    }\n  }\n";
-    src << "  static __device__ __forceinline__ constexpr u64 identity(int k) {\n    switch (k) {\n";
-    for (size_t k = 0; k < al.gident.size(); k++) src << "      case " << k << ": return " << al.gident[k] << ";\n";
-    src << "      default: return 0ull;\n    }\n  }\n";
-    src << "  static __device__ __forceinline__ void tile_grouped(const CometKParams& prm, i64 base, i64 n, const comet::GroupCtx<P>& grp) {\n"
+    if (al.nkw > 12) throw CometError("too many overflow-tracked sums in one aggregate");
+    src << "  static constexpr int NK = " << d.NK << ";\n  static constexpr int NPW = " << al.npw << ";\n  static constexpr int NKW = " << al.nkw
+        << ";\n  static constexpr int LDS_CAP = " << cap << ";\n  static constexpr int GC = " << gc << ";\n  static constexpr int COPIES = " << copies << ";\n";
+    auto emit_switch = [&](const char* sig, const std::vector<std::string>& v, const char* prefix, const char* dflt) {
+      src << "  static __device__ __forceinline__ constexpr " << sig << " {\n    switch (k) {\n";
+      for (size_t k = 0; k < v.size(); k++) src << "      case " << k << ": return " << prefix << v[k] << ";\n";
+      src << "      default: return " << dflt << ";\n    }\n  }\n";
+    };
+    emit_switch("int op(int k)", al.gops, "comet::", "comet::G_CONT");
+    emit_switch("u64 identity(int k)", al.gident, "", "0ull");
+    emit_switch("int pop(int k)", al.pops, "comet::", "comet::G_CONT");
+    emit_switch("u64 pidentity(int k)", al.pident, "", "0ull");
+    emit_switch("int kop(int k)", al.kops, "comet::", "comet::G_OR64");
+    src << "  static __device__ __forceinline__ void kinit(u64* kacc) { for (int k = 0; k < (NKW > 0 ? NKW : 1); k++) kacc[k] = 0; }\n";
+    src << "  static __device__ __forceinline__ void fold(const u64* pw, u64* val) {\n" << al.fold_code << "  }\n";
+    src << "  static __device__ __forceinline__ void tile_grouped(const CometKParams& prm, i64 base, i64 n, const comet::GroupCtx<P>& grp, u64* kacc) {\n"
         << "    bool k[R]; i64 idx[R];\n"
         << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n"
         << g.decls << g.body()
-        << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) {\n      u64 key[NK]; u64 val[NW];\n      if (k[r]) {\n"
-        << key_code << al.val_code << "      }\n      comet::group_update<P>(grp, k[r], key, val);\n    }\n  }\n";
+        << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) {\n      if (k[r]) {\n        u64 key[NK]; u64 pv[NPW];\n"
+        << key_code << al.pv_code << al.kfeed_code << "        comet::group_update<P>(grp, true, key, pv);\n      }\n    }\n  }\n";
     src << "  static __device__ __forceinline__ void emit_group(const CometKParams& prm, const u64* key, const u64* acc, i64 pos) {\n"
         << key_emit << fin << "  }\n};\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_gagg(const CometKParams prm) { comet::agg_grouped_body<P>(prm); }\n";

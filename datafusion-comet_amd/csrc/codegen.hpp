@@ -26,6 +26,7 @@ struct PipelineDesc {
   int R = 4;                       // rows per thread per tile
   int NW = 0;                      // accumulator words (aggregates)
   int NK = 0;                      // key words (grouped)
+  int NPW = 0;                     // private limb-form words per group (grouped)
   int lds_cap = 0;
   std::vector<DType> in_types;     // Scan fields
   std::vector<bool> in_used;       // columns the kernels actually read

@@ -694,165 +694,310 @@ CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* k
   return nullptr;
 }
 
-// per-word atomic combine.  Multi-limb wrapping adds use explicit carries: each limb add returns the
-// old value, so the carry out of THIS add is exact, and carries commute — after all updates the limbs
-// equal the true sum mod 2^(64·L) regardless of interleaving.
-CDEV void atomic_add_limbs(u64* dst, const u64* v, int limbs) {
+// ---- atomics that work on both global (agent scope) and LDS (address_space(3), workgroup scope) words.
+// Going through address_space(3) pointers matters: a generic pointer makes the compiler emit FLAT
+// instructions for the LDS table, and a FLAT access has to wait for every outstanding global load
+// (vmcnt AND lgkmcnt), which serialises the table probe behind the column loads.
+#define COMET_LDS __attribute__((address_space(3)))
+
+template <int SCOPE, class WordPtr>
+CDEV void atomic_add_limbs(WordPtr dst, const u64* v, int limbs) {
+  // multi-limb wrapping add with explicit carries: each limb add returns the old value, so the carry out of
+  // THIS add is exact, and carries commute — after all updates the limbs equal the true sum mod 2^(64·L).
   u64 carry = 0;
   for (int k = 0; k < limbs; k++) {
     u64 add = v[k] + carry;
     u64 c = (add < carry) ? 1 : 0;  // v[k] + carry wrapped (only when v[k] = 2^64-1 and carry = 1)
     if (add != 0) {
-      u64 old = atomicAdd((unsigned long long*)&dst[k], (unsigned long long)add);
+      u64 old = __hip_atomic_fetch_add(dst + k, add, __ATOMIC_RELAXED, SCOPE);
       if (old + add < old) c = 1;
     }
     carry = c;
   }
 }
-CDEV void atomic_cas_combine_f64(u64* dst, u64 v, int op) {
-  u64 old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <int SCOPE, class WordPtr>
+CDEV void atomic_cas_combine_f64(WordPtr dst, u64 v, int op) {
+  u64 old = __hip_atomic_load(dst, __ATOMIC_RELAXED, SCOPE);
   while (true) {
     u64 nv = old;
     if (op == OP_FADD) nv = (u64)__double_as_longlong(fp_add(__longlong_as_double((i64)old), __longlong_as_double((i64)v)));
     else { u64 t[1] = {old}; u64 w[1] = {v}; if (op == OP_IMIN) acc_fmin64(t, w); else acc_fmax64(t, w); nv = t[0]; }
     if (nv == old) return;
-    if (__hip_atomic_compare_exchange_strong(dst, &old, nv, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (__hip_atomic_compare_exchange_strong(dst, &old, nv, __ATOMIC_RELAXED, __ATOMIC_RELAXED, SCOPE)) return;
   }
 }
 
 // accumulator word kinds of the grouped path (P::op(k))
 enum GOp : int { G_ADD64 = 0, G_ADD128 = 1, G_ADD192 = 2, G_UMAX64 = 3, G_OR64 = 4, G_FADD64 = 5, G_IMIN64 = 6, G_IMAX64 = 7, G_FMIN64 = 8, G_FMAX64 = 9, G_CONT = 10 };
 
+template <class T> struct as_i64;
+template <> struct as_i64<u64*> { typedef i64* type; };
+template <> struct as_i64<COMET_LDS u64*> { typedef COMET_LDS i64* type; };
+
 // apply one contribution (NW words) to a slot's accumulators
-template <class P>
-CDEV void slot_apply(u64* acc, const u64* val) {
+template <class P, int SCOPE, class WordPtr>
+CDEV void slot_apply(WordPtr acc, const u64* val) {
 #pragma unroll
   for (int k = 0; k < P::NW; k++) {
     switch (P::op(k)) {
-      case G_ADD64: if (val[k]) atomicAdd((unsigned long long*)&acc[k], (unsigned long long)val[k]); break;
-      case G_ADD128: atomic_add_limbs(acc + k, val + k, 2); break;
-      case G_ADD192: atomic_add_limbs(acc + k, val + k, 3); break;
-      case G_UMAX64: if (val[k]) atomicMax((unsigned long long*)&acc[k], (unsigned long long)val[k]); break;
-      case G_OR64: if (val[k]) atomicOr((unsigned long long*)&acc[k], (unsigned long long)val[k]); break;
-      case G_IMIN64: atomicMin((long long*)&acc[k], (long long)val[k]); break;
-      case G_IMAX64: atomicMax((long long*)&acc[k], (long long)val[k]); break;
-      case G_FADD64: atomic_cas_combine_f64(acc + k, val[k], OP_FADD); break;
-      case G_FMIN64: atomic_cas_combine_f64(acc + k, val[k], OP_IMIN); break;
-      case G_FMAX64: atomic_cas_combine_f64(acc + k, val[k], OP_IMAX); break;
+      case G_ADD64: if (val[k]) __hip_atomic_fetch_add(acc + k, val[k], __ATOMIC_RELAXED, SCOPE); break;
+      case G_ADD128: atomic_add_limbs<SCOPE>(acc + k, val + k, 2); break;
+      case G_ADD192: atomic_add_limbs<SCOPE>(acc + k, val + k, 3); break;
+      case G_UMAX64: if (val[k]) __hip_atomic_fetch_max(acc + k, val[k], __ATOMIC_RELAXED, SCOPE); break;
+      case G_OR64: if (val[k]) __hip_atomic_fetch_or(acc + k, val[k], __ATOMIC_RELAXED, SCOPE); break;
+      case G_IMIN64: __hip_atomic_fetch_min((typename as_i64<WordPtr>::type)(acc + k), (i64)val[k], __ATOMIC_RELAXED, SCOPE); break;
+      case G_IMAX64: __hip_atomic_fetch_max((typename as_i64<WordPtr>::type)(acc + k), (i64)val[k], __ATOMIC_RELAXED, SCOPE); break;
+      case G_FADD64: atomic_cas_combine_f64<SCOPE>(acc + k, val[k], OP_FADD); break;
+      case G_FMIN64: atomic_cas_combine_f64<SCOPE>(acc + k, val[k], OP_IMIN); break;
+      case G_FMAX64: atomic_cas_combine_f64<SCOPE>(acc + k, val[k], OP_IMAX); break;
       default: break;  // G_CONT: continuation limb of a multi-limb add
     }
   }
 }
 
-// butterfly reduction of a contribution across the wave (every lane ends with the total); lanes that do
-// not belong to the group being reduced contribute P::identity
-template <class P>
-CDEV void wave_reduce_contrib(u64* val) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    u64 o[P::NW];
-#pragma unroll
-    for (int k = 0; k < P::NW; k++) o[k] = shfl_xor_u64(val[k], m);
-#pragma unroll
-    for (int k = 0; k < P::NW; k++) {
-      switch (P::op(k)) {
-        case G_ADD64: val[k] += o[k]; break;
-        case G_ADD128: acc_add128(val + k, o + k); break;
-        case G_ADD192: acc_add192(val + k, o + k); break;
-        case G_UMAX64: if (o[k] > val[k]) val[k] = o[k]; break;
-        case G_OR64: val[k] |= o[k]; break;
-        case G_IMIN64: acc_imin64(val + k, o + k); break;
-        case G_IMAX64: acc_imax64(val + k, o + k); break;
-        case G_FADD64: acc_fadd64(val + k, o + k); break;
-        case G_FMIN64: acc_fmin64(val + k, o + k); break;
-        case G_FMAX64: acc_fmax64(val + k, o + k); break;
-        default: break;
-      }
+// ---------------------------------------------------------------------------------------------
+// Block-level accumulation in LDS, "carry-save" form.
+// A per-row 128-bit add into a shared accumulator would need a returning atomic per limb (carry) and, for a
+// low-cardinality GROUP BY, 64 lanes hammering the same address.  Instead every integer sum is split into
+// LIMBS of kLimbBits bits, each limb accumulated in its own 64-bit LDS word by a NON-returning ds_add_u64:
+// no carries, no dependent LDS round trips.  A block adds at most kMaxRowsPerBlock rows, so a word cannot
+// overflow; the limbs are recombined (P::fold) once per block.  The first P::GC groups a block meets get
+// P::COPIES private copies of their accumulator words (copy = lane % COPIES, layout [group][word][copy] so a
+// wave's lanes hit consecutive banks) which removes the same-address serialisation; other groups use the
+// single copy in their LDS table slot; groups that do not fit the LDS table go to the global table.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLimbBits = 43;
+constexpr i64 kMaxRowsPerBlock = (i64)1 << 19;  // 2^19 rows · 2^43 per limb < 2^63
+
+// limb j (of nl) of a signed value: lower limbs unsigned kLimbBits bits, top limb signed
+CDEV u64 limb_of(i128 v, int j, int nl) {
+  if (j == nl - 1) return (u64)(i64)(v >> (kLimbBits * j));
+  return (u64)(v >> (kLimbBits * j)) & ((1ull << kLimbBits) - 1);
+}
+// Σ_j sext(w[j]) · 2^(43·j) as a 192-bit two's-complement number
+CDEV void limbs_to_i192(const u64* w, int nl, u64* out3) {
+  out3[0] = out3[1] = out3[2] = 0;
+  for (int j = 0; j < nl; j++) {
+    i64 sw = (i64)w[j];
+    u64 t[3] = {(u64)sw, sw < 0 ? ~0ull : 0ull, sw < 0 ? ~0ull : 0ull};
+    int sh = kLimbBits * j;
+    // 192-bit left shift by sh (< 192)
+    u64 r[3] = {0, 0, 0};
+    int ws = sh >> 6, bs = sh & 63;
+    for (int k = 2; k >= 0; k--) {
+      int src = k - ws;
+      if (src < 0) continue;
+      u64 v = t[src] << bs;
+      if (bs && src > 0) v |= t[src - 1] >> (64 - bs);
+      r[k] = v;
     }
+    acc_add192(out3, r);
   }
 }
 
+// LDS slot (level 1): limb-form accumulators; padded to an ODD number of 8-byte words so consecutive slots
+// start on different banks.
+template <int NK, int NPW>
+struct LSlot {
+  u32 state;
+  u32 ord;
+  u64 key[NK];
+  u64 acc[NPW];
+  u64 pad[((1 + NK + NPW) % 2 == 0) ? 1 : 0];
+};
+
 template <class P>
 struct GroupCtx {
-  Slot<P::NK, P::NW>* lds;
+  COMET_LDS LSlot<P::NK, P::NPW>* lds;  // per-block table (LDS)
+  COMET_LDS u32* lds_count;             // number of groups inserted into the LDS table (dense ordinals)
+  COMET_LDS u32* ord_slot;              // ordinal (< P::GC) → LDS slot index
+  COMET_LDS u64* priv;                  // [GC][NPW][COPIES] private accumulator copies
   Slot<P::NK, P::NW>* glb;
   u64 glb_cap;
-  unsigned int* err;            // err[0] flags; ((u64*)err)[1] = number of groups in the global table
+  unsigned int* err;                    // err[0] flags; ((u64*)err)[1] = number of groups in the global table
   CDEV unsigned long long* counter() const { return (unsigned long long*)err + 1; }
 };
 constexpr u64 kMaxGlobalProbes = 1024;  // beyond this the table counts as full (host grows it and re-runs)
+constexpr u32 kNoOrdinal = 0xffffffffu;
 
 template <class P>
 struct SlotInit {
   CDEV void operator()(u64* acc) const { P::init(acc); }
 };
 
-// One row per lane.  Must be called convergently by the whole wave (inactive lanes pass active=false).
+// one private word ← one contribution (non-returning LDS atomic)
 template <class P>
-CDEV void group_update(const GroupCtx<P>& g, bool active, const u64* key, u64* val) {
-  typedef Slot<P::NK, P::NW> S;
-  S* s = nullptr;
-  if (active) {
-    if (P::LDS_CAP > 0) s = table_find_or_insert<P::NK, P::NW>(g.lds, (u64)P::LDS_CAP, key, SlotInit<P>(), 16);
-    if (!s) {
-      s = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
-      if (!s) atomicOr(g.err, 32u);
-    }
+CDEV void lds_word_apply(COMET_LDS u64* w, int k, u64 v) {
+  switch (P::pop(k)) {
+    case G_ADD64: if (v) __hip_atomic_fetch_add(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+    case G_UMAX64: if (v) __hip_atomic_fetch_max(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+    case G_OR64: if (v) __hip_atomic_fetch_or(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+    case G_IMIN64: __hip_atomic_fetch_min((COMET_LDS i64*)w, (i64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+    case G_IMAX64: __hip_atomic_fetch_max((COMET_LDS i64*)w, (i64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+    case G_FADD64: __hip_atomic_fetch_add((COMET_LDS double*)w, __longlong_as_double((i64)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+    default: break;
   }
-  const bool live = active && s != nullptr;
-  u64 todo = __ballot(live);
-  int rounds = 0;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const u64 sp = shfl_u64((u64)s, leader);
-    const bool mine = live && (u64)s == sp;
-    const u64 same = __ballot(mine);
-    if (__popcll(same) >= 4 && rounds < 6) {
-      // low cardinality: fold the wave's rows of this group in registers, ONE atomic set per wave
-      u64 red[P::NW];
-#pragma unroll
-      for (int k = 0; k < P::NW; k++) red[k] = mine ? val[k] : P::identity(k);
-      wave_reduce_contrib<P>(red);
-      if (lane_id() == leader) slot_apply<P>(((S*)sp)->acc, red);
-    } else {
-      if (mine) slot_apply<P>(s->acc, val);
-    }
-    todo &= ~same;
-    rounds++;
+}
+// plain (non-atomic) combine of two private words of kind P::pop(k)
+template <class P>
+CDEV u64 pword_combine(int k, u64 a, u64 b) {
+  switch (P::pop(k)) {
+    case G_ADD64: return a + b;
+    case G_UMAX64: return a > b ? a : b;
+    case G_OR64: return a | b;
+    case G_IMIN64: return (i64)b < (i64)a ? b : a;
+    case G_IMAX64: return (i64)b > (i64)a ? b : a;
+    case G_FADD64: return (u64)__double_as_longlong(fp_add(__longlong_as_double((i64)a), __longlong_as_double((i64)b)));
+    default: return a;
   }
 }
 
-// Kernel template C body.  prm.out[0] = global table, prm.iarg[0] = its capacity, prm.out[2] = err flags.
+// LDS-table lookup: workgroup scope, relaxed — the table lives and dies inside one block, so no
+// agent-scope acquire/release (= L1/L2 invalidate + write-back per row) is needed here.
+// Returns the slot and its dense ordinal (order of first insertion within the block).
+template <class P>
+CDEV COMET_LDS LSlot<P::NK, P::NPW>* lds_find_or_insert(const GroupCtx<P>& g, const u64* key, u32& ordinal) {
+  typedef COMET_LDS LSlot<P::NK, P::NPW> S;
+  u32 h = (u32)hash_key<P::NK>(key) & (u32)(P::LDS_CAP - 1);
+  for (int probes = 0; probes < 16;) {
+    S* s = g.lds + h;
+    u32 st = __hip_atomic_load(&s->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (st == kSlotEmpty) {
+      u32 expected = kSlotEmpty;
+      if (__hip_atomic_compare_exchange_strong(&s->state, &expected, kSlotBusy, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP)) {
+#pragma unroll
+        for (int k = 0; k < P::NK; k++) s->key[k] = key[k];
+#pragma unroll
+        for (int k = 0; k < P::NPW; k++) s->acc[k] = P::pidentity(k);
+        u32 ord = __hip_atomic_fetch_add(g.lds_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        s->ord = ord;
+        if (ord < (u32)P::GC) g.ord_slot[ord] = h;
+        __hip_atomic_store(&s->state, kSlotReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ordinal = ord;
+        return s;
+      }
+      continue;  // lost the race: re-read this slot
+    }
+    if (st == kSlotBusy) continue;  // owner is publishing; it never waits on us
+    bool eq = true;
+#pragma unroll
+    for (int k = 0; k < P::NK; k++) eq &= (s->key[k] == key[k]);
+    if (eq) {
+      ordinal = s->ord;
+      return s;
+    }
+    h = (h + 1) & (u32)(P::LDS_CAP - 1);
+    probes++;
+  }
+  ordinal = kNoOrdinal;
+  return nullptr;
+}
+
+// One row per lane: key words + limb-form contribution pv[NPW].
+template <class P>
+CDEV void group_update(const GroupCtx<P>& g, bool active, const u64* key, const u64* pv) {
+  if (!active) return;
+#if defined(COMET_EXPERIMENT) && COMET_EXPERIMENT == 1
+  {  // floor measurement: keep key/pv alive, no probe, no update
+    u64 x = 0;
+    for (int k = 0; k < P::NK; k++) x ^= key[k];
+    for (int k = 0; k < P::NPW; k++) x += pv[k];
+    if (x == 0x123456789abcdefull) atomicOr(g.err, 128u);
+    return;
+  }
+#endif
+  u32 ord = kNoOrdinal;
+  COMET_LDS LSlot<P::NK, P::NPW>* ls = nullptr;
+  if (P::LDS_CAP > 0) ls = lds_find_or_insert<P>(g, key, ord);
+  if (ord < (u32)P::GC) {
+    COMET_LDS u64* base = g.priv + (u32)(ord * P::NPW) * P::COPIES + (threadIdx.x & (P::COPIES - 1));
+#pragma unroll
+    for (int k = 0; k < P::NPW; k++) lds_word_apply<P>(base + k * P::COPIES, k, pv[k]);
+    return;
+  }
+  if (ls) {
+#pragma unroll
+    for (int k = 0; k < P::NPW; k++) lds_word_apply<P>(&ls->acc[k], k, pv[k]);
+    return;
+  }
+  Slot<P::NK, P::NW>* s = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
+  if (!s) { atomicOr(g.err, 32u); return; }
+  u64 val[P::NW];
+  P::fold(pv, val);
+  slot_apply<P, __HIP_MEMORY_SCOPE_AGENT>(&s->acc[0], val);
+}
+
+// Kernel template C body.  prm.out[0] = global table, prm.iarg[0] = its capacity, prm.out[2] = err/aux words.
 template <class P>
 CDEV void agg_grouped_body(const CometKParams& prm) {
   typedef Slot<P::NK, P::NW> S;
-  __shared__ S s_tbl[P::LDS_CAP > 0 ? P::LDS_CAP : 1];
+  typedef LSlot<P::NK, P::NPW> LS;
+  __shared__ LS s_tbl[P::LDS_CAP > 0 ? P::LDS_CAP : 1];
+  __shared__ u64 s_priv[P::GC * P::NPW * P::COPIES];
+  __shared__ u32 s_count;
+  __shared__ u32 s_ord_slot[P::GC];
   if (P::LDS_CAP > 0) {
     for (int i = threadIdx.x; i < P::LDS_CAP; i += kBlock) s_tbl[i].state = kSlotEmpty;
-    __syncthreads();
   }
+  for (int i = threadIdx.x; i < P::GC * P::NPW * P::COPIES; i += kBlock) s_priv[i] = P::pidentity((i / P::COPIES) % P::NPW);
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
   GroupCtx<P> g;
-  g.lds = s_tbl;
+  g.lds = (COMET_LDS LS*)s_tbl;
+  g.lds_count = (COMET_LDS u32*)&s_count;
+  g.ord_slot = (COMET_LDS u32*)s_ord_slot;
+  g.priv = (COMET_LDS u64*)s_priv;
   g.glb = (S*)prm.out[0];
   g.glb_cap = (u64)prm.iarg[0];
   g.err = (unsigned int*)prm.out[2];
+  u64 kacc[P::NKW > 0 ? P::NKW : 1];  // kernel-level (not per-group) accumulators: value bounds for the overflow proof
+  P::kinit(kacc);
   const i64 n = prm.n;
   const i64 tile = (i64)P::R * kBlock;
-  for (i64 base = (i64)blockIdx.x * tile; base < n; base += (i64)gridDim.x * tile) P::tile_grouped(prm, base, n, g);
-  if (P::LDS_CAP > 0) {
-    __syncthreads();
-    // merge this block's LDS table into the global table
-    for (int i = threadIdx.x; i < P::LDS_CAP; i += kBlock) {
-      S* ls = &s_tbl[i];
-      if (ls->state == kSlotReady) {
-        u64 key[P::NK], val[P::NW];
+  for (i64 base = (i64)blockIdx.x * tile; base < n; base += (i64)gridDim.x * tile) P::tile_grouped(prm, base, n, g, kacc);
+  __syncthreads();
+  // level 0 → level 1: sum the private copies into the group's LDS slot (one thread per (group, word))
+  const u32 ngrp = s_count < (u32)P::GC ? s_count : (u32)P::GC;
+  for (u32 t = threadIdx.x; t < ngrp * P::NPW; t += kBlock) {
+    const u32 gi = t / P::NPW, k = t % P::NPW;
+    u64 a = P::pidentity(k);
+    for (int c = 0; c < P::COPIES; c++) a = pword_combine<P>(k, a, s_priv[(gi * P::NPW + k) * P::COPIES + c]);
+    LS* ls = &s_tbl[s_ord_slot[gi]];
+    ls->acc[k] = pword_combine<P>(k, ls->acc[k], a);
+  }
+  __syncthreads();
+  // level 1 → level 2: fold limbs to canonical words and merge into the global table
+  for (int i = threadIdx.x; i < P::LDS_CAP; i += kBlock) {
+    LS* ls = &s_tbl[i];
+    if (ls->state == kSlotReady) {
+      u64 key[P::NK], pw[P::NPW], val[P::NW];
 #pragma unroll
-        for (int k = 0; k < P::NK; k++) key[k] = ls->key[k];
+      for (int k = 0; k < P::NK; k++) key[k] = ls->key[k];
 #pragma unroll
-        for (int k = 0; k < P::NW; k++) val[k] = ls->acc[k];
-        S* gs = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
-        if (gs) slot_apply<P>(gs->acc, val);
-        else atomicOr(g.err, 32u);
+      for (int k = 0; k < P::NPW; k++) pw[k] = ls->acc[k];
+      P::fold(pw, val);
+      S* gs = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
+      if (gs) slot_apply<P, __HIP_MEMORY_SCOPE_AGENT>(&gs->acc[0], val);
+      else atomicOr(g.err, 32u);
+    }
+  }
+  // kernel-level accumulators: wave reduce, one global atomic per wave
+  if (P::NKW > 0) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+      for (int k = 0; k < P::NKW; k++) {
+        u64 o = shfl_xor_u64(kacc[k], m);
+        kacc[k] = P::kop(k) == G_UMAX64 ? (o > kacc[k] ? o : kacc[k]) : (kacc[k] | o);
+      }
+    }
+    if (lane_id() == 0) {
+      unsigned long long* aux = (unsigned long long*)prm.out[2] + 2;
+#pragma unroll
+      for (int k = 0; k < P::NKW; k++) {
+        if (P::kop(k) == G_UMAX64) atomicMax(aux + k, (unsigned long long)kacc[k]);
+        else atomicOr(aux + k, (unsigned long long)kacc[k]);
       }
     }
   }

@@ -212,7 +212,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     prm.in[i].aux = cols[i].aux;
     prm.in[i].offset = cols[i].offset;
   }
-  err_flags_.ensure(16);
+  err_flags_.ensure(128);
   prm.out[kOutErr] = err_flags_.p;
   input_rows += n;
 
@@ -261,6 +261,9 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     }
     const int64_t tile = (int64_t)d.R * 256;
     int grid = (int)std::min<int64_t>((n + tile - 1) / tile, 256 * 4);
+    // carry-save LDS accumulation bounds the rows one block may add (comet::kMaxRowsPerBlock = 2^19)
+    const int64_t per_block_cap = ((int64_t)1 << 19) - 2 * tile;
+    grid = (int)std::max<int64_t>(grid, (n + per_block_cap - 1) / per_block_cap);
     while (true) {
       // checkpoint: if the table fills up mid-chunk some rows are dropped, so the chunk is re-run from the checkpoint
       group_backup_.ensure((size_t)group_cap_ * slot_bytes);
@@ -438,7 +441,7 @@ void ExecutionContext::finish_aggregate() {
   CometKParams prm;
   memset(&prm, 0, sizeof prm);
   partials_.ensure(64);
-  err_flags_.ensure(16);
+  err_flags_.ensure(128);
   prm.out[kOutPartials] = partials_.p;
   prm.out[kOutErr] = err_flags_.p;
   prm.iarg[0] = n_partials_;
@@ -777,8 +780,8 @@ int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_sch
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreate(&ev_start_));
     HIP_CHECK(hipEventCreate(&ev_stop_));
-    err_flags_.ensure(16);
-    HIP_CHECK(hipMemsetAsync(err_flags_.p, 0, 16, stream_));
+    err_flags_.ensure(128);
+    HIP_CHECK(hipMemsetAsync(err_flags_.p, 0, 128, stream_));
     started_ = true;
   } else {
     HIP_CHECK(hipSetDevice(device_id_));
