@@ -1,1 +1,196 @@
-// placeholder until the JNI shim lands (see jni_shim.cpp in a later commit)
+// JNI entry points of libcomet.so — the symbols org.apache.comet.Native / NativeBase bind
+// (spark/src/main/scala/org/apache/comet/Native.scala:60-111, spark/src/main/java/org/apache/comet/NativeBase.java).
+// Each export is a thin shim over the JVM-free C ABI (include/comet_amd.h): unpack Java arrays/objects,
+// call comet_*, map failures to the Java exception classes the reference throws
+// (native/jni-bridge/src/errors.rs:473-560) and return the type's zero value (errors.rs:390-470).
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/comet_amd.h"
+#include "third_party/jni_min.h"
+
+namespace {
+
+JavaVM* g_vm = nullptr;
+
+struct JavaSide {                 // global refs held for the lifetime of a plan (jni_api.rs:423-436,517-527)
+  std::vector<jobject> iterators;
+  jobject metrics_node = nullptr;
+};
+std::mutex g_mu;
+std::map<jlong, JavaSide> g_java;
+
+void throw_java(JNIEnv* env, int kind, const char* msg) {
+  if (jni_ExceptionCheck(env)) return;  // a pending Java throwable is re-thrown as is (errors.rs:481-506)
+  const char* cls = kind == COMET_ERR_QUERY_EXECUTION ? "org/apache/comet/exceptions/CometQueryExecutionException"
+                                                       : "org/apache/comet/CometNativeException";
+  jclass c = jni_FindClass(env, cls);
+  if (c) jni_ThrowNew(env, c, msg ? msg : "native error");
+}
+
+std::vector<uint8_t> byte_array(JNIEnv* env, jbyteArray a) {
+  std::vector<uint8_t> v;
+  if (!a) return v;
+  jsize n = jni_GetArrayLength(env, a);
+  v.resize((size_t)n);
+  if (n) jni_GetByteArrayRegion(env, a, 0, n, (jbyte*)v.data());
+  return v;
+}
+
+int pick_device(jlong task_attempt_id) {
+  // COMET_GPU_DEVICES="0,1,2,3": tasks are spread round-robin over the listed HIP devices
+  // (one native plan = one Spark partition = one GPU).
+  const char* e = getenv("COMET_GPU_DEVICES");
+  std::vector<int> devs;
+  if (e && *e) {
+    const char* p = e;
+    while (*p) {
+      devs.push_back(atoi(p));
+      while (*p && *p != ',') p++;
+      if (*p == ',') p++;
+    }
+  }
+  if (devs.empty()) devs.push_back(0);
+  return devs[(size_t)((uint64_t)task_attempt_id % devs.size())];
+}
+
+void push_metrics(JNIEnv* env, jlong handle, jobject node) {
+  // CometMetricNode.set_all_from_bytes([B)V (native/jni-bridge/src/comet_metric_node.rs:62, metrics/utils.rs:30-45)
+  if (!node) return;
+  int64_t n = comet_plan_metrics(handle, nullptr, 0);
+  if (n <= 0) return;
+  std::vector<uint8_t> buf((size_t)n);
+  comet_plan_metrics(handle, buf.data(), buf.size());
+  jclass cls = jni_GetObjectClass(env, node);
+  if (!cls) return;
+  jmethodID mid = jni_GetMethodID(env, cls, "set_all_from_bytes", "([B)V");
+  if (!mid) return;
+  jbyteArray arr = jni_NewByteArray(env, (jsize)n);
+  if (!arr) return;
+  jni_SetByteArrayRegion(env, arr, 0, (jsize)n, (const jbyte*)buf.data());
+  jni_CallVoidMethod1(env, node, mid, arr);
+  jni_DeleteLocalRef(env, arr);
+}
+
+}  // namespace
+
+extern "C" {
+
+JNIEXPORT void JNICALL Java_org_apache_comet_NativeBase_init(JNIEnv* env, jclass, jstring /*logConfPath*/, jstring /*logLevel*/) {
+  // native/core/src/lib.rs:91-126: remember the JavaVM for worker-thread attachment; logging goes to stderr
+  jni_GetJavaVM(env, &g_vm);
+}
+JNIEXPORT void JNICALL Java_org_apache_comet_NativeBase_release(JNIEnv*, jclass) {}
+JNIEXPORT jboolean JNICALL Java_org_apache_comet_NativeBase_isFeatureEnabled(JNIEnv*, jclass, jstring) { return 0; }
+JNIEXPORT jboolean JNICALL Java_org_apache_comet_NativeBase_isObjectStoreSchemeSupported(JNIEnv* env, jclass, jstring url) {
+  if (!url) return 0;
+  const char* s = jni_GetStringUTFChars(env, url);
+  jboolean ok = s && (strncmp(s, "file:", 5) == 0 || s[0] == '/');
+  if (s) jni_ReleaseStringUTFChars(env, url, s);
+  return ok;
+}
+
+// Native.createPlan (jni_api.rs:371-562)
+JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
+    JNIEnv* env, jclass, jlong /*id*/, jobjectArray iterators, jbyteArray plan, jbyteArray configMap, jint partitionCount,
+    jobject metricsNode, jlong /*metricsUpdateInterval*/, jobject /*taskMemoryManager*/, jobjectArray /*localDirs*/, jint batchSize,
+    jboolean /*offHeapMode*/, jstring /*memoryPoolType*/, jlong /*memoryLimit*/, jlong /*memoryLimitPerTask*/, jlong taskAttemptId,
+    jlong /*taskCPUs*/, jobject /*keyUnwrapper*/, jobject /*taskContext*/, jobject /*classLoader*/) {
+  std::vector<uint8_t> plan_b = byte_array(env, plan), cfg_b = byte_array(env, configMap);
+  JavaSide js;
+  std::vector<void*> inputs;
+  std::vector<int32_t> kinds;
+  const jsize n_it = iterators ? jni_GetArrayLength(env, iterators) : 0;
+  for (jsize i = 0; i < n_it; i++) {
+    jobject it = jni_GetObjectArrayElement(env, iterators, i);
+    if (!it) { throw_java(env, COMET_ERR_NATIVE, "null input iterator"); return 0; }
+    // org.apache.arrow.c.ArrowArrayStream.memoryAddress()J (native/jni-bridge/src/arrow_array_stream.rs:45); the
+    // native side takes ownership of the C struct at that address (scan.rs:98-106)
+    jclass cls = jni_GetObjectClass(env, it);
+    jmethodID mid = cls ? jni_GetMethodID(env, cls, "memoryAddress", "()J") : nullptr;
+    if (!mid || jni_ExceptionCheck(env)) {
+      throw_java(env, COMET_ERR_NATIVE, "input iterator is not an org.apache.arrow.c.ArrowArrayStream (CometShuffleBlockIterator inputs are not supported by the MI355X engine yet)");
+      return 0;
+    }
+    jlong addr = jni_CallLongMethod0(env, it, mid);
+    if (jni_ExceptionCheck(env)) return 0;
+    inputs.push_back((void*)(intptr_t)addr);
+    kinds.push_back(COMET_INPUT_HOST_STREAM);
+    js.iterators.push_back(jni_NewGlobalRef(env, it));
+    jni_DeleteLocalRef(env, it);
+  }
+  int64_t h = comet_create_plan(plan_b.data(), plan_b.size(), cfg_b.empty() ? nullptr : cfg_b.data(), cfg_b.size(), inputs.data(),
+                                kinds.data(), (int32_t)inputs.size(), partitionCount, batchSize, pick_device(taskAttemptId));
+  if (h == 0) {
+    for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
+    throw_java(env, comet_last_error_kind(0), comet_last_error(0));
+    return 0;
+  }
+  if (metricsNode) js.metrics_node = jni_NewGlobalRef(env, metricsNode);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_java[h] = js;
+  return (jlong)h;
+}
+
+// Native.executePlan (jni_api.rs:767-957): returns rows, or -1 at end of stream
+JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_executePlan(JNIEnv* env, jclass, jint /*stage*/, jint /*partition*/, jlong handle,
+                                                                 jlongArray arrayAddrs, jlongArray schemaAddrs) {
+  const jsize n = arrayAddrs ? jni_GetArrayLength(env, arrayAddrs) : 0;
+  const jsize ns = schemaAddrs ? jni_GetArrayLength(env, schemaAddrs) : 0;
+  if (n != ns) { throw_java(env, COMET_ERR_NATIVE, "arrayAddrs and schemaAddrs differ in length"); return 0; }
+  std::vector<jlong> aa((size_t)n), sa((size_t)n);
+  if (n) {
+    jni_GetLongArrayRegion(env, arrayAddrs, 0, n, aa.data());
+    jni_GetLongArrayRegion(env, schemaAddrs, 0, n, sa.data());
+  }
+  std::vector<struct ArrowArray*> arrays((size_t)n);
+  std::vector<struct ArrowSchema*> schemas((size_t)n);
+  for (jsize i = 0; i < n; i++) {
+    arrays[(size_t)i] = (struct ArrowArray*)(intptr_t)aa[(size_t)i];
+    schemas[(size_t)i] = (struct ArrowSchema*)(intptr_t)sa[(size_t)i];
+  }
+  int64_t rows = comet_execute_plan(handle, arrays.data(), schemas.data(), (int32_t)n);
+  if (rows == -2) {
+    throw_java(env, comet_last_error_kind(handle), comet_last_error(handle));
+    return 0;
+  }
+  if (rows == -1) {
+    jobject node = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      auto it = g_java.find(handle);
+      if (it != g_java.end()) node = it->second.metrics_node;
+    }
+    push_metrics(env, handle, node);
+  }
+  return (jlong)rows;
+}
+
+// Native.releasePlan (jni_api.rs:961-990): final metrics push, then drop (fires ArrowArrayStream.release)
+JNIEXPORT void JNICALL Java_org_apache_comet_Native_releasePlan(JNIEnv* env, jclass, jlong handle) {
+  JavaSide js;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_java.find(handle);
+    if (it != g_java.end()) {
+      js = it->second;
+      g_java.erase(it);
+    }
+  }
+  push_metrics(env, handle, js.metrics_node);
+  comet_release_plan(handle);
+  for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
+  if (js.metrics_node) jni_DeleteGlobalRef(env, js.metrics_node);
+}
+
+// tracing / misc entry points the JVM may call on any plan (jni_api.rs:1186-1232): accepted, no-ops here
+JNIEXPORT void JNICALL Java_org_apache_comet_Native_traceBegin(JNIEnv*, jclass, jstring) {}
+JNIEXPORT void JNICALL Java_org_apache_comet_Native_traceEnd(JNIEnv*, jclass, jstring) {}
+JNIEXPORT void JNICALL Java_org_apache_comet_Native_logMemoryUsage(JNIEnv*, jclass, jstring, jlong) {}
+JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_getRustThreadId(JNIEnv*, jclass) { return 0; }
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""ctypes driver for the JVM-less JNIEnv mock (tests/jni_mock/jni_mock.c) — calls libcomet's
+Java_org_apache_comet_Native_* exports exactly as a JVM would."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libjnimock.so")
+
+
+def load():
+    src = os.path.join(_HERE, "jni_mock.c")
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)
+        subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-Wall", "-o", _SO, src])
+    m = ctypes.CDLL(_SO)
+    vp = ctypes.c_void_p
+    m.mock_env.restype = vp
+    for f in ("mock_bytes", "mock_longs", "mock_objs", "mock_stream", "mock_plain_object", "mock_metrics_node", "mock_string"):
+        getattr(m, f).restype = vp
+    m.mock_bytes.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    m.mock_longs.argtypes = [vp, ctypes.c_int64]
+    m.mock_objs.argtypes = [vp, ctypes.c_int64]
+    m.mock_stream.argtypes = [ctypes.c_int64]
+    m.mock_string.argtypes = [ctypes.c_char_p]
+    m.mock_metrics_len.restype = ctypes.c_int64
+    m.mock_metrics_len.argtypes = [vp]
+    m.mock_metrics_bytes.restype = vp
+    m.mock_metrics_bytes.argtypes = [vp]
+    m.mock_exception_class.restype = ctypes.c_char_p
+    m.mock_exception_msg.restype = ctypes.c_char_p
+    return m
+
+
+class Jvm:
+    """Calls the JNI exports with the exact argument lists of Native.scala:60-111."""
+
+    def __init__(self, libcomet: ctypes.CDLL):
+        self.m = load()
+        self.lib = libcomet
+        self.env = self.m.mock_env()
+        vp, i64, i32, u8 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint8
+        f = libcomet.Java_org_apache_comet_Native_createPlan
+        f.restype = i64
+        f.argtypes = [vp, vp, i64, vp, vp, vp, i32, vp, i64, vp, vp, i32, u8, vp, i64, i64, i64, i64, vp, vp, vp]
+        g = libcomet.Java_org_apache_comet_Native_executePlan
+        g.restype = i64
+        g.argtypes = [vp, vp, i32, i32, i64, vp, vp]
+        r = libcomet.Java_org_apache_comet_Native_releasePlan
+        r.restype = None
+        r.argtypes = [vp, vp, i64]
+
+    def create_plan(self, stream_addrs, plan: bytes, config: bytes = b"", batch_size=8192, metrics_node=None, task_attempt_id=0,
+                    iterator_objects=None):
+        objs = iterator_objects if iterator_objects is not None else [self.m.mock_stream(a) for a in stream_addrs]
+        arr = (ctypes.c_void_p * max(len(objs), 1))(*objs)
+        its = self.m.mock_objs(arr, len(objs))
+        return self.lib.Java_org_apache_comet_Native_createPlan(
+            self.env, None, 1, its, self.m.mock_bytes(plan, len(plan)), self.m.mock_bytes(config, len(config)) if config else None, 1,
+            metrics_node, 1000, None, None, batch_size, 1, None, 0, 0, task_attempt_id, 1, None, None, None)
+
+    def execute_plan(self, handle, array_addrs, schema_addrs):
+        a = (ctypes.c_int64 * max(len(array_addrs), 1))(*array_addrs)
+        s = (ctypes.c_int64 * max(len(schema_addrs), 1))(*schema_addrs)
+        return self.lib.Java_org_apache_comet_Native_executePlan(self.env, None, 0, 0, handle, self.m.mock_longs(a, len(array_addrs)),
+                                                                 self.m.mock_longs(s, len(schema_addrs)))
+
+    def release_plan(self, handle):
+        self.lib.Java_org_apache_comet_Native_releasePlan(self.env, None, handle)
+
+    def exception(self):
+        if not self.m.mock_exception_pending():
+            return None
+        e = (self.m.mock_exception_class().decode(), self.m.mock_exception_msg().decode())
+        self.m.mock_exception_clear()
+        return e

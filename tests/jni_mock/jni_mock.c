@@ -1,0 +1,100 @@
+/* A JVM-less JNIEnv for exercising libcomet's JNI shim from ctypes (TEST INFRASTRUCTURE).
+ * Implements exactly the JNI functions jni_shim.cpp calls, at their specified function-table indices, over
+ * tiny C "objects".  It proves the shim's marshalling, ownership and exception mapping without a JVM. */
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../datafusion-comet_amd/csrc/third_party/jni_min.h"
+
+enum { K_BYTES = 1, K_LONGS, K_OBJS, K_STREAM, K_METRICS, K_STRING, K_CLASS };
+typedef struct MObj {
+  int kind;
+  int64_t len;
+  void* data;          /* bytes / longs / MObj** / char* */
+  int64_t addr;        /* K_STREAM: ArrowArrayStream address */
+  int global_refs;
+  const char* cname;   /* K_CLASS */
+} MObj;
+
+static struct JNINativeInterface_min g_tab;
+static const struct JNINativeInterface_min* g_env = &g_tab;
+static struct JNIInvokeInterface_min g_vmtab;
+static const struct JNIInvokeInterface_min* g_vm = &g_vmtab;
+static char g_exc_class[256], g_exc_msg[8192];
+static int g_exc_pending;
+static int g_live_global_refs;
+static MObj g_cls_stream = {K_CLASS, 0, 0, 0, 0, "org/apache/arrow/c/ArrowArrayStream"};
+static MObj g_cls_metrics = {K_CLASS, 0, 0, 0, 0, "org/apache/spark/sql/comet/CometMetricNode"};
+static MObj g_cls_other = {K_CLASS, 0, 0, 0, 0, "java/lang/Object"};
+static int g_mid_memaddr, g_mid_setall;
+
+static jclass f_FindClass(JNIEnv* e, const char* n) { (void)e; MObj* c = calloc(1, sizeof *c); c->kind = K_CLASS; c->cname = strdup(n); return c; }
+static jint f_ThrowNew(JNIEnv* e, jclass c, const char* m) {
+  (void)e; g_exc_pending = 1;
+  strncpy(g_exc_class, ((MObj*)c)->cname, sizeof g_exc_class - 1);
+  strncpy(g_exc_msg, m ? m : "", sizeof g_exc_msg - 1);
+  return 0;
+}
+static jboolean f_ExceptionCheck(JNIEnv* e) { (void)e; return (jboolean)g_exc_pending; }
+static jobject f_NewGlobalRef(JNIEnv* e, jobject o) { (void)e; if (o) { ((MObj*)o)->global_refs++; g_live_global_refs++; } return o; }
+static void f_DeleteGlobalRef(JNIEnv* e, jobject o) { (void)e; if (o) { ((MObj*)o)->global_refs--; g_live_global_refs--; } }
+static void f_DeleteLocalRef(JNIEnv* e, jobject o) { (void)e; (void)o; }
+static jclass f_GetObjectClass(JNIEnv* e, jobject o) {
+  (void)e; MObj* m = o;
+  return m->kind == K_STREAM ? (jclass)&g_cls_stream : m->kind == K_METRICS ? (jclass)&g_cls_metrics : (jclass)&g_cls_other;
+}
+static jmethodID f_GetMethodID(JNIEnv* e, jclass c, const char* n, const char* sig) {
+  (void)e;
+  if (c == &g_cls_stream && !strcmp(n, "memoryAddress") && !strcmp(sig, "()J")) return &g_mid_memaddr;
+  if (c == &g_cls_metrics && !strcmp(n, "set_all_from_bytes") && !strcmp(sig, "([B)V")) return &g_mid_setall;
+  return NULL;   /* a real JVM would also raise NoSuchMethodError */
+}
+static jlong f_CallLongMethod(JNIEnv* e, jobject o, jmethodID m, ...) { (void)e; return m == &g_mid_memaddr ? ((MObj*)o)->addr : 0; }
+static void f_CallVoidMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
+  (void)e;
+  if (m != &g_mid_setall) return;
+  va_list ap; va_start(ap, m); MObj* arr = va_arg(ap, MObj*); va_end(ap);
+  MObj* node = o;
+  free(node->data);
+  node->data = malloc((size_t)arr->len ? (size_t)arr->len : 1);
+  memcpy(node->data, arr->data, (size_t)arr->len);
+  node->len = arr->len;
+}
+static const char* f_GetStringUTFChars(JNIEnv* e, jstring s, jboolean* c) { (void)e; if (c) *c = 0; return ((MObj*)s)->data; }
+static void f_ReleaseStringUTFChars(JNIEnv* e, jstring s, const char* c) { (void)e; (void)s; (void)c; }
+static jsize f_GetArrayLength(JNIEnv* e, jarray a) { (void)e; return (jsize)((MObj*)a)->len; }
+static jobject f_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { (void)e; return ((MObj**)((MObj*)a)->data)[i]; }
+static jbyteArray f_NewByteArray(JNIEnv* e, jsize n) { (void)e; MObj* o = calloc(1, sizeof *o); o->kind = K_BYTES; o->len = n; o->data = calloc(1, (size_t)n + 1); return o; }
+static void f_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, jbyte* b) { (void)e; memcpy(b, (char*)((MObj*)a)->data + s, (size_t)l); }
+static void f_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, const jbyte* b) { (void)e; memcpy((char*)((MObj*)a)->data + s, b, (size_t)l); }
+static void f_GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, jlong* b) { (void)e; memcpy(b, (jlong*)((MObj*)a)->data + s, (size_t)l * 8); }
+static jint f_GetJavaVM(JNIEnv* e, JavaVM** vm) { (void)e; *vm = (JavaVM*)&g_vm; return 0; }
+
+JNIEnv* mock_env(void) {
+  g_tab.fn[JNI_FindClass] = (void*)f_FindClass; g_tab.fn[JNI_ThrowNew] = (void*)f_ThrowNew; g_tab.fn[JNI_ExceptionCheck] = (void*)f_ExceptionCheck;
+  g_tab.fn[JNI_NewGlobalRef] = (void*)f_NewGlobalRef; g_tab.fn[JNI_DeleteGlobalRef] = (void*)f_DeleteGlobalRef;
+  g_tab.fn[JNI_DeleteLocalRef] = (void*)f_DeleteLocalRef; g_tab.fn[JNI_GetObjectClass] = (void*)f_GetObjectClass;
+  g_tab.fn[JNI_GetMethodID] = (void*)f_GetMethodID; g_tab.fn[JNI_CallLongMethod] = (void*)f_CallLongMethod;
+  g_tab.fn[JNI_CallVoidMethod] = (void*)f_CallVoidMethod; g_tab.fn[JNI_GetStringUTFChars] = (void*)f_GetStringUTFChars;
+  g_tab.fn[JNI_ReleaseStringUTFChars] = (void*)f_ReleaseStringUTFChars; g_tab.fn[JNI_GetArrayLength] = (void*)f_GetArrayLength;
+  g_tab.fn[JNI_GetObjectArrayElement] = (void*)f_GetObjectArrayElement; g_tab.fn[JNI_NewByteArray] = (void*)f_NewByteArray;
+  g_tab.fn[JNI_GetByteArrayRegion] = (void*)f_GetByteArrayRegion; g_tab.fn[JNI_SetByteArrayRegion] = (void*)f_SetByteArrayRegion;
+  g_tab.fn[JNI_GetLongArrayRegion] = (void*)f_GetLongArrayRegion; g_tab.fn[JNI_GetJavaVM] = (void*)f_GetJavaVM;
+  return (JNIEnv*)&g_env;
+}
+void* mock_bytes(const void* p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_BYTES; o->len = n; o->data = malloc((size_t)n + 1); memcpy(o->data, p, (size_t)n); return o; }
+void* mock_longs(const int64_t* p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_LONGS; o->len = n; o->data = malloc((size_t)n * 8 + 8); memcpy(o->data, p, (size_t)n * 8); return o; }
+void* mock_objs(void** p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_OBJS; o->len = n; o->data = malloc((size_t)n * 8 + 8); memcpy(o->data, p, (size_t)n * 8); return o; }
+void* mock_stream(int64_t addr) { MObj* o = calloc(1, sizeof *o); o->kind = K_STREAM; o->addr = addr; return o; }
+void* mock_plain_object(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_OBJS; return o; }
+void* mock_metrics_node(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_METRICS; return o; }
+void* mock_string(const char* s) { MObj* o = calloc(1, sizeof *o); o->kind = K_STRING; o->data = strdup(s); return o; }
+int64_t mock_metrics_len(void* n) { return ((MObj*)n)->len; }
+const void* mock_metrics_bytes(void* n) { return ((MObj*)n)->data; }
+int mock_exception_pending(void) { return g_exc_pending; }
+const char* mock_exception_class(void) { return g_exc_class; }
+const char* mock_exception_msg(void) { return g_exc_msg; }
+void mock_exception_clear(void) { g_exc_pending = 0; g_exc_class[0] = 0; g_exc_msg[0] = 0; }
+int mock_live_global_refs(void) { return g_live_global_refs; }

@@ -1,0 +1,74 @@
+"""The JNI exports (what Spark's Native.scala binds) driven through a JVM-less JNIEnv: argument marshalling,
+stream ownership, global-ref balance and the Java exception classes thrown on failure
+(native/jni-bridge/src/errors.rs:473-560).  No GPU work happens here: plans fail at planning time."""
+import ctypes
+
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native, serde as S, tpch
+from tests.jni_mock import Jvm
+
+
+@pytest.fixture()
+def jvm(built):
+    return Jvm(ctypes.CDLL(native.LIB_PATH))
+
+
+def test_jni_symbols_exported(built):
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for n in ("NativeBase_init", "NativeBase_isFeatureEnabled", "Native_createPlan", "Native_executePlan", "Native_releasePlan",
+              "Native_traceBegin", "Native_traceEnd", "Native_logMemoryUsage", "Native_getRustThreadId"):
+        assert hasattr(lib, "Java_org_apache_comet_" + n)
+
+
+def test_create_release_balances_global_refs_and_releases_stream(jvm):
+    t = tpch.lineitem_q6(100)
+    inp = native.HostInput.from_table(t)
+    node = jvm.m.mock_metrics_node()
+    h = jvm.create_plan([inp.address], tpch.q6_plan().encode(), metrics_node=node)
+    assert h > 0 and jvm.exception() is None
+    assert jvm.m.mock_live_global_refs() == 2          # iterator + metrics node
+    assert inp._c.release                              # not touched before the first executePlan (jni_api.rs:795-797)
+    jvm.release_plan(h)
+    assert jvm.m.mock_live_global_refs() == 0
+    assert not inp._c.release                          # dropped plan released the ArrowArrayStream (scan.rs:41-44)
+    assert jvm.m.mock_metrics_len(node) > 0            # final metrics push (jni_api.rs:961-990)
+    raw = ctypes.string_at(jvm.m.mock_metrics_bytes(node), jvm.m.mock_metrics_len(node))
+    metrics, children = S.decode_metric_node(raw)
+    assert "output_rows" in metrics and len(children) == 1
+
+
+def test_unsupported_plan_throws_comet_native_exception(jvm):
+    t = pa.table({"a": pa.array([1], pa.int32())})
+    inp = native.HostInput.from_table(t)
+    plan = S.Operator("raw", [S.scan([S.T_INT32])], raw_tag=110)   # Window
+    h = jvm.create_plan([inp.address], plan.encode())
+    assert h == 0                                       # JNIDefault zero value (errors.rs:390-450)
+    cls, msg = jvm.exception()
+    assert cls == "org/apache/comet/CometNativeException" and "Window" in msg
+    assert jvm.m.mock_live_global_refs() == 0
+    assert not inp._c.release
+
+
+def test_non_stream_iterator_is_rejected(jvm):
+    h = jvm.create_plan([], tpch.q6_plan().encode(), iterator_objects=[jvm.m.mock_plain_object()])
+    assert h == 0
+    cls, msg = jvm.exception()
+    assert cls == "org/apache/comet/CometNativeException" and "ArrowArrayStream" in msg
+
+
+def test_execute_with_mismatched_address_arrays(jvm):
+    t = tpch.lineitem_q6(10)
+    inp = native.HostInput.from_table(t)
+    h = jvm.create_plan([inp.address], tpch.q6_plan().encode())
+    rows = jvm.execute_plan(h, [1, 2], [1])
+    assert rows == 0
+    cls, _ = jvm.exception()
+    assert cls == "org/apache/comet/CometNativeException"
+    jvm.release_plan(h)
+
+
+def test_invalid_handle(jvm):
+    rows = jvm.execute_plan(987654, [], [])
+    assert rows == 0 and jvm.exception()[0] == "org/apache/comet/CometNativeException"
