@@ -71,7 +71,10 @@ int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* c
     }
     std::shared_ptr<ExecutionContext> ctx;
     try {
-      ctx = std::make_shared<ExecutionContext>(op, cfg, ins, batch_size, device_id);
+      uint64_t ph = 0xcbf29ce484222325ull;
+      for (size_t i = 0; i < plan_len; i++) { ph ^= plan[i]; ph *= 0x100000001b3ull; }
+      ph ^= (uint64_t)plan_len << 48;
+      ctx = std::make_shared<ExecutionContext>(op, ph, cfg, ins, batch_size, device_id);
     } catch (...) {
       // ownership of the streams was transferred to us: release them even when planning fails
       for (auto& s : ins) {

@@ -4,35 +4,120 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 
 namespace comet {
 
 // ---------------------------------------------------------------------------------------------
 // buffers
 // ---------------------------------------------------------------------------------------------
+// Per-process pools.  A Spark executor runs thousands of short tasks with the same plan: hipMalloc/hipFree
+// (device-synchronising), hipHostMalloc and stream/event creation per task would dominate a 0.2 ms kernel.
+// Blocks are recycled by power-of-two size class and keyed by device.
+namespace {
+struct Pools {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void*>> dev_free;   // (device, class bytes) → blocks
+  std::map<size_t, std::vector<void*>> pinned_free;
+  std::map<int, std::vector<hipStream_t>> streams;
+  std::map<int, std::vector<hipEvent_t>> events;
+};
+Pools& pools() {
+  static Pools* p = new Pools();  // intentionally leaked: HIP may already be torn down at process exit
+  return *p;
+}
+size_t size_class(size_t n) {
+  size_t c = 256;
+  while (c < n) c <<= 1;
+  return c;
+}
+int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d;
+}
+}  // namespace
+
 void DevBuf::ensure(size_t n) {
   if (n <= cap) return;
   release();
-  size_t want = n < 256 ? 256 : n;
-  HIP_CHECK(hipMalloc(&p, want));
-  cap = want;
+  const size_t cls = size_class(n);
+  dev = current_device();
+  {
+    std::lock_guard<std::mutex> lk(pools().mu);
+    auto& fl = pools().dev_free[{dev, cls}];
+    if (!fl.empty()) {
+      p = fl.back();
+      fl.pop_back();
+      cap = cls;
+      return;
+    }
+  }
+  HIP_CHECK(hipMalloc(&p, cls));
+  cap = cls;
 }
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p) {
+    std::lock_guard<std::mutex> lk(pools().mu);
+    pools().dev_free[{dev, cap}].push_back(p);
+  }
   p = nullptr;
   cap = 0;
 }
 void PinnedBuf::ensure(size_t n) {
   if (n <= cap) return;
   release();
-  size_t want = n < 256 ? 256 : n;
-  HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
-  cap = want;
+  const size_t cls = size_class(n);
+  {
+    std::lock_guard<std::mutex> lk(pools().mu);
+    auto& fl = pools().pinned_free[cls];
+    if (!fl.empty()) {
+      p = fl.back();
+      fl.pop_back();
+      cap = cls;
+      return;
+    }
+  }
+  HIP_CHECK(hipHostMalloc(&p, cls, hipHostMallocDefault));
+  cap = cls;
 }
 void PinnedBuf::release() {
-  if (p) (void)hipHostFree(p);
+  if (p) {
+    std::lock_guard<std::mutex> lk(pools().mu);
+    pools().pinned_free[cap].push_back(p);
+  }
   p = nullptr;
   cap = 0;
+}
+
+static hipStream_t pool_get_stream(int dev) {
+  {
+    std::lock_guard<std::mutex> lk(pools().mu);
+    auto& v = pools().streams[dev];
+    if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+  }
+  hipStream_t s;
+  HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+static void pool_put_stream(int dev, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(pools().mu);
+  pools().streams[dev].push_back(s);
+}
+static hipEvent_t pool_get_event(int dev) {
+  {
+    std::lock_guard<std::mutex> lk(pools().mu);
+    auto& v = pools().events[dev];
+    if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
+  }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+static void pool_put_event(int dev, hipEvent_t e) {
+  std::lock_guard<std::mutex> lk(pools().mu);
+  pools().events[dev].push_back(e);
 }
 
 namespace {
@@ -135,10 +220,46 @@ struct Timer {
 
 }  // namespace
 
+// Planned pipelines are shared by every task that runs the same plan bytes (a Spark stage = thousands of
+// identical createPlan calls): (plan hash, validity pattern) → generated source + compiled code object.
+namespace {
+struct PlannedVariant {
+  PipelineDesc desc;
+  std::shared_ptr<CodeObject> code;
+};
+std::mutex g_plan_mu;
+std::map<std::string, std::shared_ptr<PlannedVariant>> g_plan_cache;
+}  // namespace
+
+static std::shared_ptr<PlannedVariant> planned_variant(const Operator& plan, uint64_t plan_hash, const std::vector<bool>& has_valid,
+                                                       bool compile) {
+  std::string key = std::to_string(plan_hash) + ":" + validity_key(has_valid);
+  std::shared_ptr<PlannedVariant> pv;
+  {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    if (it != g_plan_cache.end()) pv = it->second;
+  }
+  if (!pv) {
+    pv = std::make_shared<PlannedVariant>();
+    pv->desc = generate_pipeline(plan, has_valid);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto res = g_plan_cache.emplace(key, pv);
+    pv = res.first->second;
+  }
+  if (compile && !pv->code) {
+    auto co = jit_compile(pv->desc.source);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (!pv->code) pv->code = co;
+  }
+  return pv;
+}
+
 // ---------------------------------------------------------------------------------------------
-ExecutionContext::ExecutionContext(OperatorP plan, std::vector<std::pair<std::string, std::string>> config,
+ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vector<std::pair<std::string, std::string>> config,
                                    std::vector<InputSource> inputs, int batch_size, int device_id)
-    : plan_(std::move(plan)), config_(std::move(config)), inputs_(std::move(inputs)), batch_size_(batch_size), device_id_(device_id) {
+    : plan_(std::move(plan)), plan_hash_(plan_hash), config_(std::move(config)), inputs_(std::move(inputs)), batch_size_(batch_size),
+      device_id_(device_id) {
   chunk_rows_ = 4 << 20;
   for (auto& kv : config_) {
     if (kv.first == "spark.comet.gpu.chunkRows") chunk_rows_ = std::max<long long>(1024, atoll(kv.second.c_str()));
@@ -151,9 +272,9 @@ ExecutionContext::ExecutionContext(OperatorP plan, std::vector<std::pair<std::st
   // Validate the plan shape eagerly (all-valid variant is generated, not compiled) so that
   // unsupported operators fail at createPlan like the reference's planner would on first execute.
   std::vector<bool> none(in_types_.size(), false);
-  PipelineDesc d = generate_pipeline(*plan_, none);
-  explain_ = d.explain;
-  sink_ = d.sink;
+  auto pv = planned_variant(*plan_, plan_hash_, none, false);
+  explain_ = pv->desc.explain;
+  sink_ = pv->desc.sink;
 }
 
 ExecutionContext::~ExecutionContext() {
@@ -162,9 +283,11 @@ ExecutionContext::~ExecutionContext() {
     if (in.host && in.host->release) in.host->release(in.host);
     if (in.dev && in.dev->release) in.dev->release(in.dev);
   }
-  if (ev_start_) (void)hipEventDestroy(ev_start_);
-  if (ev_stop_) (void)hipEventDestroy(ev_stop_);
-  if (stream_) (void)hipStreamDestroy(stream_);
+  if (stream_) {
+    (void)hipStreamSynchronize(stream_);  // pooled buffers go back only once the stream is idle
+    for (auto& pr : timed_) { pool_put_event(device_id_, pr.first); pool_put_event(device_id_, pr.second); }
+    pool_put_stream(device_id_, stream_);
+  }
 }
 
 const std::string& ExecutionContext::explain() { return explain_; }
@@ -182,10 +305,10 @@ Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid) {
   std::string key = validity_key(has_valid);
   auto it = variants_.find(key);
   if (it != variants_.end()) return it->second;
+  auto pv = planned_variant(*plan_, plan_hash_, has_valid, true);
   Variant v;
-  v.desc = generate_pipeline(*plan_, has_valid);
-  auto co = jit_compile(v.desc.source);
-  v.mod = jit_load(co);
+  v.desc = pv->desc;
+  v.mod = jit_load(pv->code);
   auto res = variants_.emplace(key, std::move(v));
   return res.first->second;
 }
@@ -231,14 +354,9 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       std::swap(partials_.cap, bigger.cap);
     }
     prm.out[kOutPartials] = (char*)partials_.p + (size_t)n_partials_ * d.NW * 8;
-    HIP_CHECK(hipEventRecord(ev_start_, stream_));
+    timed_begin();
     launch(v, "k_agg", grid, prm);
-    HIP_CHECK(hipEventRecord(ev_stop_, stream_));
-    HIP_CHECK(hipEventSynchronize(ev_stop_));
-    float ms = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms, ev_start_, ev_stop_));
-    last_kernel_ms += ms;
-    last_kernel_launches++;
+    timed_end();
     n_partials_ += grid;
     return;
   }
@@ -272,16 +390,12 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       HIP_CHECK(hipMemcpyAsync(&groups_before, (char*)err_flags_.p + 8, 8, hipMemcpyDeviceToHost, stream_));
       prm.out[0] = group_table_.p;
       prm.iarg[0] = group_cap_;
-      HIP_CHECK(hipEventRecord(ev_start_, stream_));
+      timed_begin();
       launch(v, "k_gagg", grid, prm);
-      HIP_CHECK(hipEventRecord(ev_stop_, stream_));
+      timed_end();
       uint32_t flags[4];
       HIP_CHECK(hipMemcpyAsync(flags, err_flags_.p, 16, hipMemcpyDeviceToHost, stream_));
       HIP_CHECK(hipStreamSynchronize(stream_));
-      float ms = 0;
-      HIP_CHECK(hipEventElapsedTime(&ms, ev_start_, ev_stop_));
-      last_kernel_ms += ms;
-      last_kernel_launches++;
       uint64_t groups_now;
       memcpy(&groups_now, &flags[2], 8);
       const bool full = (flags[0] & 32u) != 0;
@@ -334,7 +448,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
         }
       }
     };
-    HIP_CHECK(hipEventRecord(ev_start_, stream_));
+    timed_begin();
     if (d.has_filter) {
       scratch_mask_.ensure((size_t)((n + 63) / 64) * 8 + 64);
       scratch_counts_.ensure((size_t)(ntiles + 1) * 8);
@@ -357,12 +471,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
       launch(v, "k_emit", grid, prm);
     }
-    HIP_CHECK(hipEventRecord(ev_stop_, stream_));
-    HIP_CHECK(hipEventSynchronize(ev_stop_));
-    float ms = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms, ev_start_, ev_stop_));
-    last_kernel_ms += ms;
-    last_kernel_launches++;
+    timed_end();
     check_device_errors();
     if (out_rows == 0) return;
     // device → host, then cut into batches of at most batch_size rows (FilterExec coalesces toward
@@ -414,12 +523,33 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
   throw CometError("internal: unsupported sink");
 }
 
+void ExecutionContext::timed_begin() {
+  hipEvent_t a = pool_get_event(device_id_), b = pool_get_event(device_id_);
+  timed_.emplace_back(a, b);
+  HIP_CHECK(hipEventRecord(a, stream_));
+}
+void ExecutionContext::timed_end() { HIP_CHECK(hipEventRecord(timed_.back().second, stream_)); }
+// resolve the recorded event pairs (the stream must be idle)
+void ExecutionContext::collect_timings() {
+  for (; timed_done_ < timed_.size(); timed_done_++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, timed_[timed_done_].first, timed_[timed_done_].second) == hipSuccess) {
+      last_kernel_ms += ms;
+      last_kernel_launches++;
+    }
+  }
+}
+
 void ExecutionContext::check_device_errors() {
   if (!err_flags_.p) return;
   uint32_t flags[4] = {0, 0, 0, 0};
   HIP_CHECK(hipMemcpyAsync(flags, err_flags_.p, 16, hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipStreamSynchronize(stream_));
-  uint32_t f = flags[0];
+  collect_timings();
+  raise_device_errors(flags[0]);
+}
+
+void ExecutionContext::raise_device_errors(uint32_t f) {
   if (!f) return;
   // Spark error JSON as thrown through CometQueryExecutionException (native/common/src/error.rs:806-831)
   if (f & 1u) throw CometError("{\"errorType\":\"ArithmeticOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"fromType\":\"decimal\"}}", 1);
@@ -441,45 +571,47 @@ void ExecutionContext::finish_aggregate() {
   CometKParams prm;
   memset(&prm, 0, sizeof prm);
   partials_.ensure(64);
-  err_flags_.ensure(128);
+  const size_t ncol = d.out_cols.size();
+  // one result block: [128 B error/aux words][32 B per output column: 16 B value, 1 B validity] → ONE D2H copy
+  const size_t block_bytes = 128 + ncol * 32;
+  if (err_flags_.cap < block_bytes) {
+    DevBuf bigger;
+    bigger.ensure(block_bytes);
+    HIP_CHECK(hipMemcpyAsync(bigger.p, err_flags_.p, 128, hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    std::swap(err_flags_.p, bigger.p);
+    std::swap(err_flags_.cap, bigger.cap);
+  }
   prm.out[kOutPartials] = partials_.p;
   prm.out[kOutErr] = err_flags_.p;
   prm.iarg[0] = n_partials_;
-  const size_t ncol = d.out_cols.size();
-  out_vals_.resize(ncol);
-  out_valid_.resize(ncol);
+  char* base = (char*)err_flags_.p + 128;
+  HIP_CHECK(hipMemsetAsync(base, 1, ncol * 32, stream_));  // validity defaults to 1
   for (size_t j = 0; j < ncol; j++) {
-    if (!out_vals_[j]) out_vals_[j].reset(new DevBuf());
-    if (!out_valid_[j]) out_valid_[j].reset(new DevBuf());
-    out_vals_[j]->ensure(64);
-    out_valid_[j]->ensure(64);
-    HIP_CHECK(hipMemsetAsync(out_valid_[j]->p, 1, 8, stream_));
-    prm.out[kOutFirstCol + 2 * j] = out_vals_[j]->p;
-    prm.out[kOutFirstCol + 2 * j + 1] = out_valid_[j]->p;
+    prm.out[kOutFirstCol + 2 * j] = base + j * 32;
+    prm.out[kOutFirstCol + 2 * j + 1] = base + j * 32 + 16;
   }
   launch(v, "k_agg_final", 1, prm);
+  result_host_.ensure(block_bytes);
+  HIP_CHECK(hipMemcpyAsync(result_host_.p, err_flags_.p, block_bytes, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  collect_timings();
+  raise_device_errors(((const uint32_t*)result_host_.p)[0]);
+  const uint8_t* hb = (const uint8_t*)result_host_.p + 128;
   HostBatch b;
   b.rows = 1;
-  std::vector<std::vector<uint8_t>> hv(ncol), hk(ncol);
-  for (size_t j = 0; j < ncol; j++) {
-    hv[j].resize(16);
-    hk[j].resize(8);
-    HIP_CHECK(hipMemcpyAsync(hv[j].data(), out_vals_[j]->p, 16, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipMemcpyAsync(hk[j].data(), out_valid_[j]->p, 8, hipMemcpyDeviceToHost, stream_));
-  }
-  HIP_CHECK(hipStreamSynchronize(stream_));
-  check_device_errors();
   for (size_t j = 0; j < ncol; j++) {
     HostColumn c;
     c.type = d.out_cols[j].type;
     c.length = 1;
+    const uint8_t* val = hb + j * 32;
     if (c.type.id == TypeId::Bool) {
-      c.values.assign(1, hv[j][0] ? 1 : 0);
+      c.values.assign(1, val[0] ? 1 : 0);
     } else {
       int w = fixed_width(c.type);
-      c.values.assign(hv[j].begin(), hv[j].begin() + w);
+      c.values.assign(val, val + w);
     }
-    if (d.out_cols[j].nullable && hk[j][0] == 0) {
+    if (d.out_cols[j].nullable && val[16] == 0) {
       c.null_count = 1;
       c.validity.assign(1, 0);
     }
@@ -777,9 +909,7 @@ int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_sch
   if (!started_) {
     // Lazy start like the reference (jni_api.rs:795-872): nothing touches the input before the first executePlan.
     HIP_CHECK(hipSetDevice(device_id_));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreate(&ev_start_));
-    HIP_CHECK(hipEventCreate(&ev_stop_));
+    stream_ = pool_get_stream(device_id_);
     err_flags_.ensure(128);
     HIP_CHECK(hipMemsetAsync(err_flags_.p, 0, 128, stream_));
     started_ = true;

@@ -20,6 +20,7 @@ namespace comet {
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  int dev = 0;
   void ensure(size_t n);
   void release();
   ~DevBuf() { release(); }
@@ -73,7 +74,7 @@ struct Variant {  // one JIT specialisation of the pipeline (per input-validity 
 
 class ExecutionContext {
  public:
-  ExecutionContext(OperatorP plan, std::vector<std::pair<std::string, std::string>> config,
+  ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vector<std::pair<std::string, std::string>> config,
                    std::vector<InputSource> inputs, int batch_size, int device_id);
   ~ExecutionContext();
 
@@ -102,16 +103,22 @@ class ExecutionContext {
   bool pull_device_batch();
   void export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
   void check_device_errors();
+  void raise_device_errors(uint32_t flags);
+  void timed_begin();
+  void timed_end();
+  void collect_timings();
   void launch(Variant& v, const char* kernel, int grid, CometKParams& prm);
 
   OperatorP plan_;
+  uint64_t plan_hash_ = 0;
   std::vector<std::pair<std::string, std::string>> config_;
   std::vector<InputSource> inputs_;
   int batch_size_;
   int device_id_;
   int64_t chunk_rows_;
   hipStream_t stream_ = nullptr;
-  hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_;   // (start, stop) around each main-kernel launch
+  size_t timed_done_ = 0;
   bool started_ = false, finished_ = false;
   std::vector<DType> in_types_;
   std::map<std::string, Variant> variants_;
@@ -127,6 +134,7 @@ class ExecutionContext {
   DevBuf partials_;
   int64_t n_partials_ = 0;
   DevBuf err_flags_;
+  PinnedBuf result_host_;
   DevBuf group_table_, group_backup_;
   int64_t group_cap_ = 0;
   DevBuf scratch_mask_, scratch_counts_;

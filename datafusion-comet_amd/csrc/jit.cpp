@@ -54,7 +54,8 @@ std::map<std::string, std::shared_ptr<CodeObject>> g_mem_cache;
 
 std::shared_ptr<CodeObject> jit_compile(const std::string& source) {
   // the key covers the generated source AND the hand-written headers it instantiates
-  uint64_t h1 = fnv1a(source), h2 = fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader));
+  static const uint64_t h2 = fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader));
+  uint64_t h1 = fnv1a(source);
   char keybuf[64];
   snprintf(keybuf, sizeof keybuf, "%016llx_%016llx", (unsigned long long)h1, (unsigned long long)h2);
   std::string key = keybuf;

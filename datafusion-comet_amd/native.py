@@ -273,6 +273,14 @@ class DeviceInput:
         self.released = True
         self._c.release = None
 
+    def rearm(self) -> "DeviceInput":
+        """Make the (released) stream usable for another plan over the same resident table (bench loops)."""
+        self._emitted = False
+        self._keep = []
+        self.released = False
+        self._c.release = ctypes.cast(self._cb_release, ctypes.c_void_p)
+        return self
+
 
 # --------------------------------------------------------------------------- Native (Native.scala)
 
