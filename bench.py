@@ -91,6 +91,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # outside the timed region: gather the per-rank Partial states on rank 0 and run the Final stage there
+    # (the only cross-rank step of a Q6/Q1-shaped plan) — proves the N-GPU answer is the merged one
+    import pyarrow as pa
+    from datafusion_comet_amd import parallel
+    states = parallel.gather_partial_states(pa.Table.from_batches(result) if result else None, 0)
+    final_value = None
+    if rank == 0 and states is not None:
+        fplan = S.hash_agg(S.scan([S.decimal(35, 4), S.T_BOOL]), [], plan.aggs, S.FINAL)
+        fin = native.execute_to_table([native.HostInput.from_table(states)], 1, fplan.encode(), device_id=local_rank)
+        final_value = str(fin[0].column(0)[0])
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rows_per_s = n * world * args.steps / elapsed
@@ -116,7 +127,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_agg",
                          "kernel_ms": avg_kernel_ms, "algorithmic_bytes": algo_bytes},
-            "result_check": str(result[0].column(0)[0]) if result else None,
+            "result_check": {"rank0_partial_sum": str(result[0].column(0)[0]) if result else None, "final_revenue_all_ranks": final_value},
         }
         if not args.no_cpu_baseline:
             from oracle import oracle as O

@@ -1095,6 +1095,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   std::vector<ExprP> group_exprs;
   struct AggIn { const AggExpr* a; std::vector<ExprP> children; ExprP filter; };
   std::vector<AggIn> agg_ins;
+  size_t final_state_pos = 0;
   for (int i = (int)chain.size() - 2; i >= 0; i--) {
     const Operator& op = *chain[i];
     std::map<const Expr*, ExprP> memo;
@@ -1116,6 +1117,17 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         if (op.agg_mode == AggMode::Partial) {
           for (auto& c : a.children) in.children.push_back(substitute(c, cols, memo));
           if (a.filter) in.filter = substitute(a.filter, cols, memo);
+        } else if (op.agg_mode == AggMode::Final) {
+          // Final: the aggregate's inputs are the Partial state columns that follow the group columns, in order
+          // (AggregateExec Final mode; the serialized children are unbound, operators.scala:1786-1792)
+          int arity = 1;
+          if (a.kind == AggKind::Avg) arity = 2;
+          if (a.kind == AggKind::Sum && a.dtype.id == TypeId::Decimal) arity = 2;
+          for (int k = 0; k < arity; k++) {
+            size_t idx = op.grouping_exprs.size() + final_state_pos++;
+            if (idx >= cols.size()) throw CometError("Final aggregate: state column " + std::to_string(idx) + " is out of bound");
+            in.children.push_back(cols[idx]);
+          }
         }
         agg_ins.push_back(in);
       }
@@ -1196,8 +1208,9 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
 
   // ---------------- Aggregate sinks ----------------
-  if (agg->agg_mode != AggMode::Partial)
-    throw CometError("HashAggregate mode Final/PartialMerge is not supported by the fused GPU pipeline yet");
+  if (agg->agg_mode == AggMode::PartialMerge)
+    throw CometError("HashAggregate mode PartialMerge is not supported by the fused GPU pipeline yet");
+  const bool final_mode = agg->agg_mode == AggMode::Final;
   const bool grouped = !group_exprs.empty();
   d.sink = grouped ? SinkKind::AggGrouped : SinkKind::AggNoGroup;
   AggLowering al(g, grouped);
@@ -1293,6 +1306,160 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       guard = Gen::and_ok(f.ok, f.v);
     }
     auto guarded = [&](const std::string& ok) { return Gen::and_ok(guard, ok); };
+    if (final_mode) {
+      // ---- Final mode: merge Partial states (merge_batch + evaluate of each accumulator) ----
+      auto okx = [](const Val& v) { return v.ok.empty() ? std::string("true") : v.ok; };
+      switch (a.kind) {
+        case AggKind::Count: {
+          // count state: Int64, summed (DataFusion count_udaf merge)
+          Val c = g.named(g.gen(in.children.at(0)));
+          if (!c.t.is_integer()) throw CometError("Final count expects an Int64 state column");
+          PrimSlot s = al.get(Prim::SumI64, "fin:" + g.key_of(in.children[0]), "", c.ok, c.v, (u128)1 << 63);
+          OutCol oc; oc.type = DType::of(TypeId::Int64); oc.nullable = false;
+          d.out_cols.push_back(oc);
+          fin += "    ((i64*)" + out_val(out_j) + ")" + ROW + " = (i64)acc[" + std::to_string(s.word) + "];\n";
+          out_j++;
+          ex << "  agg(final): count -> Int64\n";
+          break;
+        }
+        case AggKind::Sum: case AggKind::Avg: {
+          const bool is_avg = a.kind == AggKind::Avg;
+          if (a.dtype.id == TypeId::Decimal) {
+            Val sv = g.named(g.gen(in.children.at(0)));
+            Val s2 = g.named(g.gen(in.children.at(1)));
+            const DType st = is_avg ? a.sum_dtype : a.dtype;
+            if (!(sv.t == st)) throw CometError("Final decimal aggregate: state type " + sv.t.str() + " differs from " + st.str());
+            const u128 bound = pow10_u128(st.precision) - 1;
+            const std::string vk = "fin:" + g.key_of(in.children[0]);
+            std::string val128 = sv.rep == Rep::I128 ? sv.v : "(i128)" + sv.v;
+            if (!is_avg) {
+              // SumDecimal merge_batch (sum_decimal.rs:309-368 / :540-609): state = (sum nullable, is_empty)
+              if (s2.rep != Rep::B) throw CometError("Final SumDecimal expects (sum, is_empty) state columns");
+              const std::string empty = "(" + s2.v + ")";                       // is_empty is non-null
+              const std::string that_ovf = "(!" + empty + " && !" + okx(sv) + ")";  // overflowed partial: sticky
+              const std::string contrib = "(!" + empty + " && " + okx(sv) + ")";
+              PrimSlot cnt = al.get(Prim::Cnt, vk, "ne", contrib, "");
+              PrimSlot any_ovf = al.get(Prim::Cnt, vk, "ovf", that_ovf, "");
+              PrimSlot sum = al.get(Prim::Sum192, vk, "", contrib, val128, bound);
+              PrimSlot amax = al.get(Prim::AMaxHi, vk, "", contrib, val128);
+              PrimSlot sflags = al.get(Prim::SignFlags, vk, "", contrib, val128);
+              auto kw = [&](const PrimSlot& ps) {
+                return ps.kernel_level ? "((const u64*)prm.out[" + std::to_string(kOutErr) + "])[2 + " + std::to_string(ps.word) + "]"
+                                       : "acc[" + std::to_string(ps.word) + "]";
+              };
+              const std::string W = std::to_string(sum.word), W1 = std::to_string(sum.word + 1);
+              fin += "    {\n      i128 total = comet::mk128(acc[" + W1 + "], acc[" + W + "]);\n      bool ovf = false;\n";
+              fin += "      comet::sum_overflow_decide(acc + " + W + ", " + kw(amax) + ", " + kw(sflags) + ", acc[" + std::to_string(cnt.word) + "], " +
+                     lit_u128(bound) + ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
+              g.uses_err = true;
+              // evaluate (sum_decimal.rs:264-279): NULL if empty, overflowed, or out of precision
+              fin += "      bool isnull = acc[" + std::to_string(cnt.word) + "] == 0 || acc[" + std::to_string(any_ovf.word) + "] != 0 || ovf || !comet::dec_fits(total, " + lit_u128(bound) + ");\n";
+              fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = isnull ? (i128)0 : total;\n";
+              fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = isnull ? 0 : 1;\n    }\n";
+              OutCol oc; oc.type = st; oc.nullable = true;
+              d.out_cols.push_back(oc);
+              out_j++;
+              ex << "  agg(final): sum_decimal -> " << st.str() << "\n";
+            } else {
+              // AvgDecimal merge (avg_decimal.rs:542-595) + evaluate (:597-636, avg() :670-689): state = (sum nullable, count)
+              if (!s2.t.is_integer()) throw CometError("Final AvgDecimal expects (sum, count) state columns");
+              PrimSlot cnt = al.get(Prim::SumI64, vk + "#cnt", "", s2.ok, s2.v, (u128)1 << 63);
+              PrimSlot bad = al.get(Prim::Cnt, vk, "nullstate", "(!" + okx(sv) + " || !" + okx(s2) + ")", "");
+              PrimSlot nsum = al.get(Prim::Cnt, vk, "nsum", sv.ok, "");
+              PrimSlot sum = al.get(Prim::Sum192, vk, "", sv.ok, val128, bound);
+              PrimSlot amax = al.get(Prim::AMaxHi, vk, "", sv.ok, val128);
+              PrimSlot sflags = al.get(Prim::SignFlags, vk, "", sv.ok, val128);
+              auto kw = [&](const PrimSlot& ps) {
+                return ps.kernel_level ? "((const u64*)prm.out[" + std::to_string(kOutErr) + "])[2 + " + std::to_string(ps.word) + "]"
+                                       : "acc[" + std::to_string(ps.word) + "]";
+              };
+              const std::string W = std::to_string(sum.word), W1 = std::to_string(sum.word + 1);
+              const u128 tbound = pow10_u128(a.dtype.precision) - 1;
+              const int up = std::max(0, a.dtype.scale - st.scale);
+              fin += "    {\n      i128 total = comet::mk128(acc[" + W1 + "], acc[" + W + "]);\n      bool ovf = false;\n";
+              fin += "      comet::sum_overflow_decide(acc + " + W + ", " + kw(amax) + ", " + kw(sflags) + ", acc[" + std::to_string(nsum.word) + "], " +
+                     lit_u128(bound) + ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
+              g.uses_err = true;
+              fin += "      i64 count = (i64)acc[" + std::to_string(cnt.word) + "];\n";
+              fin += "      i128 avgv = 0;\n";
+              fin += "      bool has = acc[" + std::to_string(bad.word) + "] == 0 && !ovf && count != 0 && comet::dec_avg(total, count, " +
+                     lit_i128((i128)pow10_u128(up)) + ", " + lit_u128(tbound) + ", avgv);\n";
+              fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = has ? avgv : (i128)0;\n";
+              fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = has ? 1 : 0;\n    }\n";
+              OutCol oc; oc.type = a.dtype; oc.nullable = true;
+              d.out_cols.push_back(oc);
+              out_j++;
+              ex << "  agg(final): avg_decimal -> " << a.dtype.str() << "\n";
+            }
+          } else if (!is_avg && a.dtype.is_integer()) {
+            // SumInteger merge (sum_int.rs:494-530): wrapping sum of the non-null partial sums, NULL if none
+            Val sv = g.named(g.gen(in.children.at(0)));
+            const std::string vk = "fin:" + g.key_of(in.children[0]);
+            PrimSlot cnt = al.get(Prim::Cnt, vk, "", sv.ok, "");
+            PrimSlot sum = al.get(Prim::SumI64, vk, "", sv.ok, sv.v, (u128)1 << 63);
+            fin += "    ((i64*)" + out_val(out_j) + ")" + ROW + " = acc[" + std::to_string(cnt.word) + "] ? (i64)acc[" + std::to_string(sum.word) + "] : 0;\n";
+            fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + std::to_string(cnt.word) + "] ? 1 : 0;\n";
+            OutCol oc; oc.type = DType::of(TypeId::Int64); oc.nullable = true;
+            d.out_cols.push_back(oc);
+            out_j++;
+            ex << "  agg(final): sum_int -> Int64\n";
+          } else {
+            // float: Avg merge/evaluate (avg.rs:146-176, :283-327) / DataFusion sum merge
+            Val sv = g.named(g.gen(in.children.at(0)));
+            if (sv.rep != Rep::F64) throw CometError("Final float aggregate expects a Float64 state column");
+            const std::string vk = "fin:" + g.key_of(in.children[0]);
+            PrimSlot nsum = al.get(Prim::Cnt, vk, "", sv.ok, "");
+            PrimSlot sum = al.get(Prim::SumF64, vk, "", sv.ok, sv.v);
+            const std::string S = std::to_string(sum.word);
+            if (is_avg) {
+              Val s2 = g.named(g.gen(in.children.at(1)));
+              PrimSlot cnt = al.get(Prim::SumI64, vk + "#cnt", "", s2.ok, s2.v, (u128)1 << 63);
+              fin += "    { i64 count = (i64)acc[" + std::to_string(cnt.word) + "];\n";
+              fin += "      ((double*)" + out_val(out_j) + ")" + ROW + " = count ? comet::fp_div(__longlong_as_double((i64)acc[" + S + "]), (double)count) : 0.0;\n";
+              fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = count ? 1 : 0; }\n";
+            } else {
+              fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = __longlong_as_double((i64)acc[" + S + "]);\n";
+              fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + std::to_string(nsum.word) + "] ? 1 : 0;\n";
+            }
+            OutCol oc; oc.type = DType::of(TypeId::Double); oc.nullable = true;
+            d.out_cols.push_back(oc);
+            out_j++;
+            ex << "  agg(final): " << (is_avg ? "avg" : "sum") << "_f64 -> Float64\n";
+          }
+          break;
+        }
+        case AggKind::Min: case AggKind::Max: {
+          Val v = g.named(g.gen(in.children.at(0)));
+          const bool mn = a.kind == AggKind::Min;
+          const std::string vk = "fin:" + g.key_of(in.children[0]);
+          PrimSlot cnt = al.get(Prim::Cnt, vk, "", v.ok, "");
+          PrimSlot s;
+          std::string rd;
+          const char* stc = store_ctype(v.t);
+          if (v.rep == Rep::I32 || v.rep == Rep::I64) {
+            s = al.get(mn ? Prim::MinI64 : Prim::MaxI64, vk, "", v.ok, v.v);
+            rd = v.t.id == TypeId::Decimal ? "(i128)(i64)acc[" + std::to_string(s.word) + "]" : std::string("(") + stc + ")(i64)acc[" + std::to_string(s.word) + "]";
+          } else if (v.rep == Rep::I128) {
+            s = al.get(mn ? Prim::MinI128 : Prim::MaxI128, vk, "", v.ok, v.v);
+            rd = "comet::mk128(acc[" + std::to_string(s.word + 1) + "], acc[" + std::to_string(s.word) + "])";
+          } else if (v.rep == Rep::F64 || v.rep == Rep::F32) {
+            s = al.get(mn ? Prim::MinF64 : Prim::MaxF64, vk, "", v.ok, v.v);
+            rd = std::string("(") + stc + ")__longlong_as_double((i64)acc[" + std::to_string(s.word) + "])";
+          } else throw CometError("min/max over " + v.t.str() + " is not supported in the GPU pipeline yet");
+          const std::string C = std::to_string(cnt.word);
+          fin += "    ((" + std::string(stc) + "*)" + out_val(out_j) + ")" + ROW + " = acc[" + C + "] ? " + rd + " : (" + stc + ")0;\n";
+          fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + C + "] ? 1 : 0;\n";
+          OutCol oc; oc.type = v.t; oc.nullable = true;
+          d.out_cols.push_back(oc);
+          out_j++;
+          ex << "  agg(final): " << (mn ? "min" : "max") << " -> " << v.t.str() << "\n";
+          break;
+        }
+        default:
+          throw CometError("Final mode of aggregate (tag " + std::to_string(a.proto_tag) + ") is not supported by the MI355X native engine");
+      }
+      continue;
+    }
     switch (a.kind) {
       case AggKind::Count: {
         if (in.children.empty()) throw CometError("count() without children");
@@ -1494,7 +1661,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     int cap = 1024;
     while (cap > 16 && cap * slot_bytes > 24 * 1024) cap >>= 1;
     d.lds_cap = cap;
-    if (al.nkw > 12) throw CometError("too many overflow-tracked sums in one aggregate");
+    if (al.nkw > (kErrBytes - 16) / 8) throw CometError("too many overflow-tracked sums in one aggregate");
     src << "  static constexpr int NK = " << d.NK << ";\n  static constexpr int NPW = " << al.npw << ";\n  static constexpr int NKW = " << al.nkw
         << ";\n  static constexpr int LDS_CAP = " << cap << ";\n  static constexpr int GC = " << gc << ";\n  static constexpr int COPIES = " << copies << ";\n";
     auto emit_switch = [&](const char* sig, const std::vector<std::string>& v, const char* prefix, const char* dflt) {

@@ -47,6 +47,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
 constexpr int kOutPartials = 0;      // AggNoGroup: partials;  Output: mask words
 constexpr int kOutCounts = 1;        // Output: tile counts / offsets
 constexpr int kOutErr = 2;           // u32[4] error flags (ANSI overflow etc.)
+constexpr int kErrBytes = 256;       // error/aux block: u32 flags[4] (u64 group counter at +8), then u64 aux words from +16
 constexpr int kOutFirstCol = 4;      // out[4+2j] = values of col j, out[5+2j] = validity bytes of col j
 
 }  // namespace comet

@@ -335,7 +335,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     prm.in[i].aux = cols[i].aux;
     prm.in[i].offset = cols[i].offset;
   }
-  err_flags_.ensure(128);
+  err_flags_.ensure(kErrBytes);
   prm.out[kOutErr] = err_flags_.p;
   input_rows += n;
 
@@ -572,12 +572,12 @@ void ExecutionContext::finish_aggregate() {
   memset(&prm, 0, sizeof prm);
   partials_.ensure(64);
   const size_t ncol = d.out_cols.size();
-  // one result block: [128 B error/aux words][32 B per output column: 16 B value, 1 B validity] → ONE D2H copy
-  const size_t block_bytes = 128 + ncol * 32;
+  // one result block: [kErrBytes error/aux words][32 B per output column: 16 B value, 1 B validity] → ONE D2H copy
+  const size_t block_bytes = kErrBytes + ncol * 32;
   if (err_flags_.cap < block_bytes) {
     DevBuf bigger;
     bigger.ensure(block_bytes);
-    HIP_CHECK(hipMemcpyAsync(bigger.p, err_flags_.p, 128, hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(bigger.p, err_flags_.p, kErrBytes, hipMemcpyDeviceToDevice, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::swap(err_flags_.p, bigger.p);
     std::swap(err_flags_.cap, bigger.cap);
@@ -585,7 +585,7 @@ void ExecutionContext::finish_aggregate() {
   prm.out[kOutPartials] = partials_.p;
   prm.out[kOutErr] = err_flags_.p;
   prm.iarg[0] = n_partials_;
-  char* base = (char*)err_flags_.p + 128;
+  char* base = (char*)err_flags_.p + kErrBytes;
   HIP_CHECK(hipMemsetAsync(base, 1, ncol * 32, stream_));  // validity defaults to 1
   for (size_t j = 0; j < ncol; j++) {
     prm.out[kOutFirstCol + 2 * j] = base + j * 32;
@@ -597,7 +597,7 @@ void ExecutionContext::finish_aggregate() {
   HIP_CHECK(hipStreamSynchronize(stream_));
   collect_timings();
   raise_device_errors(((const uint32_t*)result_host_.p)[0]);
-  const uint8_t* hb = (const uint8_t*)result_host_.p + 128;
+  const uint8_t* hb = (const uint8_t*)result_host_.p + kErrBytes;
   HostBatch b;
   b.rows = 1;
   for (size_t j = 0; j < ncol; j++) {
@@ -910,8 +910,8 @@ int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_sch
     // Lazy start like the reference (jni_api.rs:795-872): nothing touches the input before the first executePlan.
     HIP_CHECK(hipSetDevice(device_id_));
     stream_ = pool_get_stream(device_id_);
-    err_flags_.ensure(128);
-    HIP_CHECK(hipMemsetAsync(err_flags_.p, 0, 128, stream_));
+    err_flags_.ensure(kErrBytes);
+    HIP_CHECK(hipMemsetAsync(err_flags_.p, 0, kErrBytes, stream_));
     started_ = true;
   } else {
     HIP_CHECK(hipSetDevice(device_id_));

@@ -626,6 +626,21 @@ def _agg_final(S, a, child, state_col, n, gid, ng, grouped):
         with np.errstate(all="ignore"):
             res = np.where(hb, sums / np.where(hb, cnts, 1), 0.0)
         return [Col(S.T_DOUBLE, res, None if hb.all() else hb)], 2
+    if a.kind in ("min", "max"):
+        c = child[state_col]
+        res, has = [], []
+        for g in range(ng):
+            sel = np.nonzero((gid == g) & c.ok())[0]
+            if len(sel) == 0:
+                res.append(0)
+                has.append(False)
+                continue
+            xs = [dec_to_int(c.values, i) for i in sel] if c.dtype.type_id == S.DECIMAL else [c.values[i].item() for i in sel]
+            res.append(min(xs) if a.kind == "min" else max(xs))
+            has.append(True)
+        hb = np.array(has, bool)
+        vals = ints_to_dec(res) if c.dtype.type_id == S.DECIMAL else np.array(res, dtype=_np_dtype(S, c.dtype))
+        return [Col(c.dtype, vals, None if hb.all() else hb)], 1
     raise NotImplementedError(f"oracle final aggregate {a.kind}")
 
 
