@@ -155,7 +155,7 @@ void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launche
 int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     OperatorP op = decode_operator(plan, plan_len);
-    std::string ex = ExecutionContext::compile_only(*op);
+    std::string ex = ExecutionContext::compile_only(op);
     if (out && cap) {
       size_t n = std::min(cap - 1, ex.size());
       memcpy(out, ex.data(), n);

@@ -44,7 +44,7 @@ u128 sat_add(u128 a, u128 b) {
   return r;
 }
 
-enum class Rep { B, I32, I64, I128, F32, F64 };
+enum class Rep { B, I32, I64, I128, F32, F64, STR };  // STR: Utf8 of ≤15 bytes packed in comet::str16
 
 const char* rep_ctype(Rep r) {
   switch (r) {
@@ -54,6 +54,7 @@ const char* rep_ctype(Rep r) {
     case Rep::I128: return "i128";
     case Rep::F32: return "float";
     case Rep::F64: return "double";
+    case Rep::STR: return "comet::str16";
   }
   return "?";
 }
@@ -92,6 +93,7 @@ Rep rep_for_type(const DType& t) {
     case TypeId::Float: return Rep::F32;
     case TypeId::Double: return Rep::F64;
     case TypeId::Decimal: return t.precision <= 18 ? Rep::I64 : Rep::I128;
+    case TypeId::String: return Rep::STR;
     default: throw CometError("Unsupported data type in native GPU pipeline: " + t.str());
   }
 }
@@ -184,6 +186,8 @@ struct Gen {
   std::map<int, Val> col_cache;
   bool uses_err = false;
   bool eager_loads = false;   // hoist every column load into the first stage (no lazy loading after predicates)
+  // where column `idx` lives: kernel-argument slot and row expression (joins read two tables with different rows)
+  std::function<std::pair<int, std::string>(int)> locate = [](int idx) { return std::make_pair(idx, std::string("idx[r]")); };
 
   Gen(const std::vector<DType>& t, const std::vector<bool>& v) : in_types(t), in_valid(v), in_used(t.size(), false) {
     stages.emplace_back();
@@ -242,27 +246,36 @@ struct Gen {
     x.t = t;
     x.rep = rep_for_type(t);
     x.maxabs = type_maxabs(t);
-    std::string c = "prm.in[" + std::to_string(idx) + "]";
+    auto loc = locate(idx);
+    std::string c = "prm.in[" + std::to_string(loc.first) + "]";
+    const std::string row = loc.second;
     std::string n = newvar(rep_ctype(x.rep));
     std::string ldx;
     switch (t.id) {
-      case TypeId::Bool: ldx = "comet::ld_bool(" + c + ", idx[r])"; break;
-      case TypeId::Int8: ldx = "(i32)comet::ld<i8>(" + c + ", idx[r])"; break;
-      case TypeId::Int16: ldx = "(i32)comet::ld<i16>(" + c + ", idx[r])"; break;
-      case TypeId::Int32: case TypeId::Date: ldx = "comet::ld<i32>(" + c + ", idx[r])"; break;
-      case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: ldx = "comet::ld<i64>(" + c + ", idx[r])"; break;
-      case TypeId::Float: ldx = "comet::ld<float>(" + c + ", idx[r])"; break;
-      case TypeId::Double: ldx = "comet::ld<double>(" + c + ", idx[r])"; break;
+      case TypeId::Bool: ldx = "comet::ld_bool(" + c + ", " + row + ")"; break;
+      case TypeId::Int8: ldx = "(i32)comet::ld<i8>(" + c + ", " + row + ")"; break;
+      case TypeId::Int16: ldx = "(i32)comet::ld<i16>(" + c + ", " + row + ")"; break;
+      case TypeId::Int32: case TypeId::Date: ldx = "comet::ld<i32>(" + c + ", " + row + ")"; break;
+      case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: ldx = "comet::ld<i64>(" + c + ", " + row + ")"; break;
+      case TypeId::Float: ldx = "comet::ld<float>(" + c + ", " + row + ")"; break;
+      case TypeId::Double: ldx = "comet::ld<double>(" + c + ", " + row + ")"; break;
       case TypeId::Decimal:
-        ldx = t.precision <= 18 ? "comet::ld_dec_lo(" + c + ", idx[r])" : "comet::ld<i128>(" + c + ", idx[r])";
+        ldx = t.precision <= 18 ? "comet::ld_dec_lo(" + c + ", " + row + ")" : "comet::ld<i128>(" + c + ", " + row + ")";
+        break;
+      case TypeId::String:
+        // ≤15-byte strings travel packed (str16); a longer value raises error bit 64 → explicit "not supported yet"
+        uses_err = true;
+        ldx = "";
+        load("{ bool tl_ = false; " + n + " = comet::ld_str16(" + c + ", " + row + ", tl_); if (tl_) atomicOr((unsigned int*)prm.out[" +
+             std::to_string(kOutErr) + "], 64u); }");
         break;
       default: throw CometError("Unsupported scan column type: " + t.str());
     }
-    load(n + " = " + ldx + ";");
+    if (!ldx.empty()) load(n + " = " + ldx + ";");
     x.v = n;
     if (in_valid[idx]) {
       std::string o = newvar("bool");
-      load(o + " = comet::ld_valid(" + c + ", idx[r]);");
+      load(o + " = comet::ld_valid(" + c + ", " + row + ");");
       x.ok = o;
     }
     col_cache[idx] = x;
@@ -285,6 +298,7 @@ struct Gen {
       x.ok = "false";
       x.maxabs = 0;
       switch (x.rep) {
+        case Rep::STR: x.v = "comet::str16{0ull, 0ull}"; break;
         case Rep::B: x.v = "false"; break;
         case Rep::F32: x.v = "0.0f"; break;
         case Rep::F64: x.v = "0.0"; break;
@@ -323,6 +337,18 @@ struct Gen {
         else x.v = lit_i128(v);
         break;
       }
+      case TypeId::String: {
+        if (e.lit_bytes.size() > 15) throw CometError("string literals longer than 15 bytes are not supported in the GPU pipeline yet");
+        uint64_t a = 0, b = 0;
+        for (size_t k = 0; k < e.lit_bytes.size(); k++) {
+          uint64_t byte = (uint8_t)e.lit_bytes[k];
+          if (k < 8) a |= byte << (8 * k);
+          else b |= byte << (8 * (k - 8));
+        }
+        b |= (uint64_t)e.lit_bytes.size() << 56;
+        x.v = "comet::str16{" + hex64(a) + ", " + hex64(b) + "}";
+        break;
+      }
       default: throw CometError("Unsupported literal type: " + e.dtype.str());
     }
     return x;
@@ -359,6 +385,23 @@ struct Gen {
     bool af = a.rep == Rep::F32 || a.rep == Rep::F64, bf = b.rep == Rep::F32 || b.rep == Rep::F64;
     if (af != bf || (af && a.rep != b.rep)) throw CometError("Comparison of mismatched types: " + a.t.str() + " vs " + b.t.str());
     if ((a.rep == Rep::B) != (b.rep == Rep::B)) throw CometError("Comparison of mismatched types: " + a.t.str() + " vs " + b.t.str());
+    if (a.rep == Rep::STR || b.rep == Rep::STR) {
+      if (a.rep != b.rep) throw CometError("Comparison of mismatched types: " + a.t.str() + " vs " + b.t.str());
+      if (!(k == ExprKind::Eq || k == ExprKind::Neq || k == ExprKind::EqNullSafe || k == ExprKind::NeqNullSafe))
+        throw CometError("ordering comparisons on Utf8 are not supported in the GPU pipeline yet");
+      a = named(a);
+      b = named(b);
+      std::string eq = "(" + a.v + ".a == " + b.v + ".a && " + a.v + ".b == " + b.v + ".b)";
+      if (k == ExprKind::EqNullSafe || k == ExprKind::NeqNullSafe) {
+        std::string aok = a.ok.empty() ? "true" : a.ok, bok = b.ok.empty() ? "true" : b.ok;
+        std::string e2 = "((" + aok + " && " + bok + " && " + eq + ") || (!" + aok + " && !" + bok + "))";
+        r.v = (k == ExprKind::EqNullSafe) ? e2 : "(!" + e2 + ")";
+        return r;
+      }
+      r.v = (k == ExprKind::Eq) ? eq : "(!" + eq + ")";
+      r.ok = and_ok(a.ok, b.ok);
+      return r;
+    }
     std::string l, rr;
     if (af) { l = fkey(a); rr = fkey(b); }
     else if (a.rep == Rep::B) { l = "(int)" + a.v; rr = "(int)" + b.v; }
@@ -1058,13 +1101,17 @@ std::string explain_expr(const ExprP& e) {
 // ---------------------------------------------------------------------------------------------
 // generate_pipeline
 // ---------------------------------------------------------------------------------------------
-PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity) {
-  // 1. walk root → leaf collecting the chain
+PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity, const std::vector<DType>* source_types) {
+  // 1. walk root → leaf collecting the chain; the chain ends at a Scan or at a materialised source (a join's output)
   std::vector<const Operator*> chain;
   const Operator* cur = &root;
   while (true) {
     chain.push_back(cur);
     if (cur->kind == OpKind::Scan) break;
+    if (cur->kind == OpKind::HashJoin) {
+      if (!source_types) throw CometError("internal: join source without a schema");
+      break;
+    }
     if (cur->kind == OpKind::Unsupported)
       throw CometError(std::string("Operator ") + op_name(cur->proto_tag) + " is not supported by the MI355X native engine");
     if (cur->kind != OpKind::Filter && cur->kind != OpKind::Projection && cur->kind != OpKind::HashAgg)
@@ -1074,7 +1121,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
   const Operator& scan = *chain.back();
   PipelineDesc d;
-  d.in_types = scan.scan_fields;
+  d.in_types = source_types ? *source_types : scan.scan_fields;
   for (auto* op : chain) d.op_names.push_back(op_name(op->proto_tag));
   if (in_has_validity.size() != d.in_types.size()) throw CometError("internal: validity mask arity mismatch");
   if (d.in_types.size() > COMET_MAX_IN) throw CometError("too many scan columns for one GPU pipeline");
@@ -1232,38 +1279,26 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       std::string ok_expr;
       const std::string vb = out_val(out_j), ob = out_ok(out_j);
       const std::string nullbit = std::to_string(1ull << kj) + "ull";
-      if (ge->kind == ExprKind::Bound && d.in_types[ge->bound_index].id == TypeId::String) {
-        // Utf8 key: ≤15 bytes packed into two words (ld_str16); emitted packed, the host expands to Utf8
-        const int ci = ge->bound_index;
-        g.in_used[ci] = true;
-        const std::string c = "prm.in[" + std::to_string(ci) + "]";
-        std::string sv = g.newvar("comet::str16");
-        g.stmt("{ bool tl_ = false; " + sv + " = comet::ld_str16(" + c + ", idx[r], tl_); if (tl_) atomicOr((unsigned int*)prm.out[" +
-               std::to_string(kOutErr) + "], 64u); }");
-        g.uses_err = true;
-        if (in_has_validity[ci]) {
-          std::string o = g.newvar("bool");
-          g.stmt(o + " = comet::ld_valid(" + c + ", idx[r]);");
-          ok_expr = o;
-        }
-        const std::string k0 = std::to_string(nk), k1 = std::to_string(nk + 1);
-        const std::string okc = ok_expr.empty() ? "true" : ok_expr;
-        key_code += "        key[" + k0 + "] = (" + okc + ") ? " + sv + ".a : 0ull; key[" + k1 + "] = (" + okc + ") ? " + sv + ".b : 0ull;\n";
-        key_emit += "    ((u64*)" + vb + ")[2 * pos] = key[" + k0 + "]; ((u64*)" + vb + ")[2 * pos + 1] = key[" + k1 + "];\n";
-        nk += 2;
-        oc.type = DType::of(TypeId::String);
-        oc.packed_string = true;
+      if (false) {
       } else {
         Val v = g.named(g.gen(ge));
         ok_expr = v.ok;
         const std::string okc = ok_expr.empty() ? "true" : ok_expr;
-        const char* st = store_ctype(v.t);
-        if (v.rep == Rep::I128) {
+        if (v.rep == Rep::STR) {
+          // Utf8 key: two packed words; emitted packed, the host expands to Utf8
+          const std::string k0 = std::to_string(nk), k1 = std::to_string(nk + 1);
+          key_code += "        key[" + k0 + "] = (" + okc + ") ? " + v.v + ".a : 0ull; key[" + k1 + "] = (" + okc + ") ? " + v.v + ".b : 0ull;\n";
+          key_emit += "    ((u64*)" + vb + ")[2 * pos] = key[" + k0 + "]; ((u64*)" + vb + ")[2 * pos + 1] = key[" + k1 + "];\n";
+          nk += 2;
+          oc.type = DType::of(TypeId::String);
+          oc.packed_string = true;
+        } else if (v.rep == Rep::I128) {
           const std::string k0 = std::to_string(nk), k1 = std::to_string(nk + 1);
           key_code += "        key[" + k0 + "] = (" + okc + ") ? comet::lo64(" + v.v + ") : 0ull; key[" + k1 + "] = (" + okc + ") ? comet::hi64(" + v.v + ") : 0ull;\n";
           key_emit += "    ((i128*)" + vb + ")[pos] = comet::mk128(key[" + k1 + "], key[" + k0 + "]);\n";
           nk += 2;
         } else {
+          const char* st = store_ctype(v.t);
           const std::string k0 = std::to_string(nk);
           std::string enc, dec;
           switch (v.rep) {
@@ -1279,7 +1314,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
           key_emit += "    ((" + std::string(st) + "*)" + vb + ")[pos] = " + dec + ";\n";
           nk += 1;
         }
-        oc.type = v.t;
+        if (v.rep != Rep::STR) oc.type = v.t;
       }
       if (!ok_expr.empty()) key_code += "        if (!(" + ok_expr + ")) key[0] |= " + nullbit + ";\n";
       key_emit += "    ((u8*)" + ob + ")[pos] = (key[0] & " + nullbit + ") ? 0 : 1;\n";
@@ -1651,15 +1686,15 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg_final(const CometKParams prm) { comet::agg_nogroup_final_body<P>(prm); }\n";
     d.kernels = {"k_agg", "k_agg_final"};
   } else {
-    // LDS budget: private copies [GC][NPW][COPIES] + table slots, ≤ 48 KiB per block (≥ 3 blocks per CU)
+    // LDS budget: private copies [GC][NPW][COPIES] + table slots ≈ 20 KiB per block (8 blocks = 32 waves per CU)
     d.NPW = al.npw;
     const int copies = 32;
     int gc = 8;
-    while (gc > 1 && gc * al.npw * copies * 8 > 24 * 1024) gc >>= 1;
+    while (gc > 1 && gc * al.npw * copies * 8 > 10 * 1024) gc >>= 1;
     if (const char* e = getenv("COMET_GEN_GC")) gc = std::max(1, std::min(16, atoi(e)));
     const int slot_bytes = 8 + 8 * (d.NK + al.npw + 1);
     int cap = 1024;
-    while (cap > 16 && cap * slot_bytes > 24 * 1024) cap >>= 1;
+    while (cap > 16 && cap * slot_bytes > 10 * 1024) cap >>= 1;
     d.lds_cap = cap;
     if (al.nkw > (kErrBytes - 16) / 8) throw CometError("too many overflow-tracked sums in one aggregate");
     src << "  static constexpr int NK = " << d.NK << ";\n  static constexpr int NPW = " << al.npw << ";\n  static constexpr int NKW = " << al.nkw
@@ -1694,4 +1729,176 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   return d;
 }
 
+// ---------------------------------------------------------------------------------------------
+// generate_join: key hashing / equality / residual condition / output gather functor for the hash-join templates
+// (join_build_body, join_count_body, join_emit_body).  Reference: planner.rs:2192-2266, :2415-2555.
+// ---------------------------------------------------------------------------------------------
+PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, const std::vector<DType>& rt, const std::vector<bool>& lvalid,
+                           const std::vector<bool>& rvalid) {
+  if (j.kind != OpKind::HashJoin) throw CometError("internal: generate_join on a non-join");
+  if (j.left_keys.size() != j.right_keys.size() || j.left_keys.empty()) throw CometError("HashJoin needs matching, non-empty key lists");
+  int mode;
+  switch (j.join_type) {
+    case JoinType::Inner: mode = 0; break;
+    case JoinType::LeftSemi: mode = 1; break;
+    case JoinType::LeftAnti: mode = 2; break;
+    default: throw CometError("HashJoin type " + std::to_string((int)j.join_type) + " (outer joins) is not supported by the MI355X native engine yet");
+  }
+  if (j.null_aware_anti) throw CometError("null-aware anti join is not supported by the MI355X native engine yet");
+  const bool build_left = j.build_side == BuildSide::Left;
+  if (mode != 0 && build_left) throw CometError("LeftSemi/LeftAnti with BuildLeft is not supported by the MI355X native engine yet");
+  const std::vector<DType>& bt = build_left ? lt : rt;
+  const std::vector<DType>& pt = build_left ? rt : lt;
+  const std::vector<bool>& bv = build_left ? lvalid : rvalid;
+  const std::vector<bool>& pv = build_left ? rvalid : lvalid;
+  const int nb = (int)bt.size(), np = (int)pt.size(), nl = (int)lt.size(), nr = (int)rt.size();
+  if (nb + np > COMET_MAX_IN) throw CometError("too many columns for one GPU hash join");
+  const std::vector<ExprP>& bkeys = build_left ? j.left_keys : j.right_keys;
+  const std::vector<ExprP>& pkeys = build_left ? j.right_keys : j.left_keys;
+
+  PipelineDesc d;
+  d.sink = SinkKind::Output;
+  d.R = 1;
+  d.op_names.push_back("HashJoin");
+  std::ostringstream src, ex;
+  src << "// generated by datafusion-comet_amd codegen — hash join\n#include \"comet_device.hpp\"\nusing namespace comet;\n";
+  src << "struct P {\n  static constexpr int R = 1;\n  static constexpr int MODE = " << mode << ";\n";
+
+  // key words of one side
+  auto key_fn = [&](const char* name, const char* rowvar, const std::vector<DType>& types, const std::vector<bool>& valid, int base,
+                    const std::vector<ExprP>& keys, bool want_hash) {
+    Gen g(types, valid);
+    g.locate = [base, rowvar](int idx) { return std::make_pair(base + idx, std::string(rowvar)); };
+    std::string okall;
+    std::vector<std::string> words;
+    for (auto& ke : keys) {
+      Val v = g.named(g.gen(ke));
+      okall = Gen::and_ok(okall, v.ok);
+      switch (v.rep) {
+        case Rep::B: words.push_back("(u64)(" + v.v + " ? 1 : 0)"); break;
+        case Rep::I32: case Rep::I64: words.push_back("(u64)(i64)" + v.v); break;
+        case Rep::I128: words.push_back("comet::lo64(" + v.v + ")"); words.push_back("comet::hi64(" + v.v + ")"); break;
+        case Rep::F64: words.push_back("(u64)__double_as_longlong(comet::normalize_nan_zero_f64(" + v.v + "))"); break;
+        case Rep::F32: words.push_back("(u64)(u32)__float_as_int(comet::normalize_nan_zero_f32(" + v.v + "))"); break;
+        case Rep::STR: words.push_back(v.v + ".a"); words.push_back(v.v + ".b"); break;
+      }
+    }
+    src << "  static __device__ __forceinline__ " << (want_hash ? "u64 " : "bool ") << name << "(const CometKParams& prm, i64 " << rowvar << ") {\n"
+        << "    bool k[R] = {true};\n" << g.decls << g.body();
+    if (want_hash) {
+      src << "    u64 kw[" << words.size() << "];\n";
+      for (size_t w = 0; w < words.size(); w++) {
+        std::string e = words[w];
+        for (size_t p0 = e.find("[r]"); p0 != std::string::npos; p0 = e.find("[r]")) e.replace(p0, 3, "[0]");
+        src << "    kw[" << w << "] = " << e << ";\n";
+      }
+      src << "    return comet::hash_key<" << words.size() << ">(kw);\n  }\n";
+    } else {
+      std::string e = okall.empty() ? "true" : okall;
+      for (size_t p0 = e.find("[r]"); p0 != std::string::npos; p0 = e.find("[r]")) e.replace(p0, 3, "[0]");
+      src << "    return " << e << ";\n  }\n";
+    }
+    return (int)words.size();
+  };
+  key_fn("bvalid", "i", bt, bv, 0, bkeys, false);
+  int nwb = key_fn("bhash", "i", bt, bv, 0, bkeys, true);
+  key_fn("pvalid", "j", pt, pv, nb, pkeys, false);
+  int nwp = key_fn("phash", "j", pt, pv, nb, pkeys, true);
+  if (nwb != nwp) throw CometError("HashJoin key types differ between the two sides");
+
+  // combined schema left ++ right: where does combined column c live?
+  std::vector<DType> ct(lt);
+  ct.insert(ct.end(), rt.begin(), rt.end());
+  std::vector<bool> cv(lvalid);
+  cv.insert(cv.end(), rvalid.begin(), rvalid.end());
+  auto locate_combined = [=](int c) {
+    const bool is_left = c < nl;
+    const int local = is_left ? c : c - nl;
+    const bool in_build = (is_left == build_left);
+    return std::make_pair(in_build ? local : nb + local, std::string(in_build ? "i" : "j"));
+  };
+  {
+    // match(i, j): every key pair equal (NULL never equals) and the residual condition TRUE
+    Gen g(ct, cv);
+    g.locate = locate_combined;
+    std::string cond;
+    for (size_t k = 0; k < j.left_keys.size(); k++) {
+      std::map<const Expr*, ExprP> memo;
+      // right keys are bound to the right child's schema: shift their column indices by nl
+      std::function<ExprP(const ExprP&)> shift = [&](const ExprP& e) -> ExprP {
+        if (e->kind == ExprKind::Bound) {
+          auto n = std::make_shared<Expr>(*e);
+          n->bound_index = e->bound_index + nl;
+          return n;
+        }
+        if (e->children.empty()) return e;
+        auto n = std::make_shared<Expr>(*e);
+        for (auto& c : n->children) c = shift(c);
+        return n;
+      };
+      Val a = g.gen(j.left_keys[k]);
+      Val b = g.gen(shift(j.right_keys[k]));
+      Val c = g.compare(ExprKind::Eq, a, b);
+      cond = Gen::and_ok(cond, Gen::and_ok(c.ok, c.v));
+    }
+    if (j.join_condition) {
+      Val c = g.gen(j.join_condition);
+      if (c.rep != Rep::B) throw CometError("join condition must be boolean");
+      cond = Gen::and_ok(cond, Gen::and_ok(c.ok, c.v));
+      ex << "  condition: " << explain_expr(j.join_condition) << "\n";
+    }
+    Val r;
+    r.rep = Rep::B;
+    r.v = cond;
+    r = g.named(r);
+    std::string e = r.v;
+    for (size_t p0 = e.find("[r]"); p0 != std::string::npos; p0 = e.find("[r]")) e.replace(p0, 3, "[0]");
+    src << "  static __device__ __forceinline__ bool match(const CometKParams& prm, i64 i, i64 j) {\n    bool k[R] = {true};\n"
+        << g.decls << g.body() << "    return " << e << ";\n  }\n";
+  }
+  {
+    // emit(i, j, pos): output = left columns then right columns (Inner); left columns only (Semi/Anti)
+    Gen g(ct, cv);
+    g.locate = locate_combined;
+    const int nout = mode == 0 ? nl + nr : nl;
+    if (nout * 2 + kOutFirstCol > 44) throw CometError("too many output columns for one GPU hash join");
+    for (int c = 0; c < nout; c++) {
+      if (ct[c].id == TypeId::String || ct[c].id == TypeId::Bytes) throw CometError("Utf8 payload columns are not supported in a GPU hash join yet");
+      Val v = g.column(c);
+      OutCol oc;
+      oc.type = ct[c];
+      oc.nullable = !v.ok.empty();
+      d.out_cols.push_back(oc);
+      const char* st = store_ctype(v.t);
+      std::string val = v.v;
+      if (v.t.id == TypeId::Decimal) val = v.rep == Rep::I128 ? v.v : "(i128)" + v.v;
+      else if (v.t.id == TypeId::Bool) val = "(u8)(" + v.v + " ? 1 : 0)";
+      else val = std::string("(") + st + ")" + v.v;
+      std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * c) + "]", ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * c + 1) + "]";
+      if (!v.ok.empty()) {
+        g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = " + v.ok + " ? " + val + " : (" + st + ")0;");
+        g.stmt("((u8*)" + ob + ")[pos] = " + v.ok + " ? 1 : 0;");
+      } else {
+        g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = " + val + ";");
+      }
+    }
+    src << "  static __device__ __forceinline__ void emit(const CometKParams& prm, i64 i, i64 j, i64 pos) {\n    bool k[R] = {true};\n"
+        << g.decls << g.body() << "  }\n";
+  }
+  src << "};\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbuild(const CometKParams prm) { comet::join_build_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jcount(const CometKParams prm) { comet::join_count_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jscan(const CometKParams prm) { comet::tile_scan_body((u64*)prm.out[comet::kJoinTileCounts], prm.iarg[2]); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jemit(const CometKParams prm) { comet::join_emit_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
+  d.kernels = {"k_jbuild", "k_jcount", "k_jscan", "k_jemit", "k_pack"};
+  ex << "  hash join: " << (mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti") << ", build " << (build_left ? "left" : "right") << ", "
+     << j.left_keys.size() << " key(s)\n";
+  d.in_types = ct;
+  d.source = src.str();
+  d.explain = ex.str();
+  return d;
+}
+
 }  // namespace comet
+

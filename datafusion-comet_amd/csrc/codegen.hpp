@@ -41,7 +41,12 @@ struct PipelineDesc {
 
 // `in_has_validity[i]` tells whether input column i arrives with a validity bitmap in this batch
 // chunk; kernels are specialised on it.  Throws CometError for unsupported plans.
-PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity);
+PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity,
+                               const std::vector<DType>* source_types = nullptr);
+
+// Hash join of two materialised tables (left/right = the join's children in plan order).
+PipelineDesc generate_join(const Operator& join, const std::vector<DType>& left_types, const std::vector<DType>& right_types,
+                           const std::vector<bool>& left_has_validity, const std::vector<bool>& right_has_validity);
 
 // index of out[] slots used by the generated kernels (must match exec.cpp)
 constexpr int kOutPartials = 0;      // AggNoGroup: partials;  Output: mask words

@@ -43,19 +43,23 @@ CDEV u128 uabs128(i128 v) { return v < 0 ? (u128)0 - (u128)v : (u128)v; }
 // Column access.  Lane l of a wave reads row base+l: every load instruction is one contiguous
 // 64×sizeof(T) segment (1 KiB for Decimal128).
 // ---------------------------------------------------------------------------------------------
+// Column buffers are always global memory: say so (address_space(1)), otherwise the `const void*` in the
+// kernel-argument struct makes the compiler emit FLAT loads, which bump lgkmcnt as well as vmcnt and thereby
+// couple every LDS wait to the outstanding HBM loads.
+#define COMET_GLOBAL __attribute__((address_space(1)))
 template <class T>
-CDEV T ld(const CometCol& c, i64 i) { return ((const T*)c.data)[c.offset + i]; }
+CDEV T ld(const CometCol& c, i64 i) { return ((const COMET_GLOBAL T*)c.data)[c.offset + i]; }
 CDEV bool ld_valid(const CometCol& c, i64 i) {
   i64 j = c.offset + i;
-  return (c.valid[j >> 3] >> (j & 7)) & 1;
+  return (((const COMET_GLOBAL u8*)c.valid)[j >> 3] >> (j & 7)) & 1;
 }
 // Boolean values are bit-packed in Arrow.
 CDEV bool ld_bool(const CometCol& c, i64 i) {
   i64 j = c.offset + i;
-  return (((const u8*)c.data)[j >> 3] >> (j & 7)) & 1;
+  return (((const COMET_GLOBAL u8*)c.data)[j >> 3] >> (j & 7)) & 1;
 }
 // Decimal128 whose precision ≤ 18: the upper limb is sign extension, read only the lower one.
-CDEV i64 ld_dec_lo(const CometCol& c, i64 i) { return ((const i64*)c.data)[2 * (c.offset + i)]; }
+CDEV i64 ld_dec_lo(const CometCol& c, i64 i) { return ((const COMET_GLOBAL i64*)c.data)[2 * (c.offset + i)]; }
 
 // Utf8 values of ≤ 15 bytes packed into two words (bytes 0-7 in a, bytes 8-14 in the low 56 bits of b,
 // length in the top byte of b): injective, so equality and grouping on the packed form are exact.
@@ -64,10 +68,10 @@ struct str16 {
   u64 a, b;
 };
 CDEV str16 ld_str16(const CometCol& c, i64 i, bool& toolong) {
-  const i32* off = (const i32*)c.data;
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
   i64 j = c.offset + i;
   i32 lo = off[j], len = off[j + 1] - lo;
-  const u8* p = (const u8*)c.aux + lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
   str16 r;
   r.a = 0;
   r.b = 0;
@@ -1041,4 +1045,128 @@ CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel template D — hash join (reference: planner.rs:2192-2266 → DataFusion HashJoinExec; NULL keys never
+// match, planner.rs:2225-2227).  Build side: bucket-chained table over the build rows,
+//   head[cap] (i32, -1 = empty) and next[n_build]; insertion is one atomicExch per row, duplicates chain.
+// Probe side, two passes so the output is sized exactly: join_count (matches per probe row + per-tile sums),
+// tile scan, join_emit (block prefix inside the tile, then one output row per match).
+//   P::bvalid(prm,i) / P::pvalid(prm,j)   all key columns non-NULL
+//   P::bhash(prm,i)  / P::phash(prm,j)    64-bit hash of the key words
+//   P::match(prm,i,j)                     keys equal (and residual join condition TRUE)
+//   P::emit(prm,i,j,pos)                  write output row pos from build row i / probe row j (i = -1: no build row)
+//   P::MODE                               0 inner, 1 semi (probe row kept if it matches), 2 anti (kept if it does not)
+// prm.in[0 .. NB) = build columns, prm.in[NB ..) = probe columns; prm.iarg[0] = table capacity (power of two),
+// iarg[1] = build rows, prm.n = probe rows; out[0] = head, out[1] = next, out[2] = err, out[3] = per-row counts (u32),
+// out[kJoinTileCounts] = tile counts/offsets.
+// ---------------------------------------------------------------------------------------------
+constexpr int kJoinTileCounts = 44;
+
+template <class P>
+CDEV void join_build_body(const CometKParams& prm) {
+  i32* head = (i32*)prm.out[0];
+  i32* next = (i32*)prm.out[1];
+  const u64 mask = (u64)prm.iarg[0] - 1;
+  const i64 nb = prm.iarg[1];
+  for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < nb; i += (i64)gridDim.x * kBlock) {
+    if (!P::bvalid(prm, i)) continue;
+    u64 h = P::bhash(prm, i) & mask;
+    next[i] = atomicExch(&head[h], (i32)i);
+  }
+}
+
+template <class P>
+CDEV u32 join_row_matches(const CometKParams& prm, i64 j) {
+  const i32* head = (const i32*)prm.out[0];
+  const i32* next = (const i32*)prm.out[1];
+  u32 c = 0;
+  if (P::pvalid(prm, j)) {
+    u64 h = P::phash(prm, j) & ((u64)prm.iarg[0] - 1);
+    for (i32 i = head[h]; i >= 0; i = next[i]) {
+      if (P::match(prm, (i64)i, j)) {
+        c++;
+        if (P::MODE != 0) break;  // semi / anti only need existence
+      }
+    }
+  }
+  if (P::MODE == 2) c = c ? 0u : 1u;
+  return c;
+}
+
+template <class P>
+CDEV void join_count_body(const CometKParams& prm) {
+  const i64 n = prm.n;
+  u32* counts = (u32*)prm.out[3];
+  u64* tile_counts = (u64*)prm.out[kJoinTileCounts];
+  const i64 ntiles = (n + kMaskTileRows - 1) / kMaskTileRows;
+  __shared__ u32 s_cnt;
+  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    u32 local = 0;
+#pragma unroll
+    for (int r = 0; r < kMaskTileRows / kBlock; r++) {
+      i64 j = t * kMaskTileRows + r * kBlock + threadIdx.x;
+      if (j < n) {
+        u32 c = join_row_matches<P>(prm, j);
+        counts[j] = c;
+        local += c;
+      }
+    }
+    // wave reduce then one LDS atomic per wave
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) local += __shfl_xor(local, m, kWave);
+    if (lane_id() == 0) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[t] = s_cnt;
+    __syncthreads();
+  }
+}
+
+template <class P>
+CDEV void join_emit_body(const CometKParams& prm) {
+  const i64 n = prm.n;
+  const u32* counts = (const u32*)prm.out[3];
+  const u64* tile_off = (const u64*)prm.out[kJoinTileCounts];
+  const i32* head = (const i32*)prm.out[0];
+  const i32* next = (const i32*)prm.out[1];
+  const i64 ntiles = (n + kMaskTileRows - 1) / kMaskTileRows;
+  __shared__ u32 s_wave[kBlock / kWave];
+  __shared__ u32 s_run;
+  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int r = 0; r < kMaskTileRows / kBlock; r++) {
+      i64 j = t * kMaskTileRows + r * kBlock + threadIdx.x;
+      u32 c = j < n ? counts[j] : 0;
+      u32 x = c;  // inclusive scan across the wave
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        u32 y = __shfl_up(x, d, kWave);
+        if (lane_id() >= d) x += y;
+      }
+      if (lane_id() == kWave - 1) s_wave[wave_id()] = x;
+      __syncthreads();
+      u32 woff = 0;
+      for (int w = 0; w < wave_id(); w++) woff += s_wave[w];
+      const u32 run = s_run;
+      i64 pos = (i64)tile_off[t] + run + woff + (x - c);
+      if (c) {
+        if (P::MODE != 0) {
+          P::emit(prm, -1, j, pos);
+        } else {
+          u64 h = P::phash(prm, j) & ((u64)prm.iarg[0] - 1);
+          for (i32 i = head[h]; i >= 0; i = next[i]) {
+            if (P::match(prm, (i64)i, j)) P::emit(prm, (i64)i, j, pos++);
+          }
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == kBlock - 1) s_run = run + woff + x;
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace comet
+

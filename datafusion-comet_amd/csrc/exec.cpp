@@ -232,8 +232,12 @@ std::map<std::string, std::shared_ptr<PlannedVariant>> g_plan_cache;
 }  // namespace
 
 static std::shared_ptr<PlannedVariant> planned_variant(const Operator& plan, uint64_t plan_hash, const std::vector<bool>& has_valid,
-                                                       bool compile) {
+                                                       bool compile, const std::vector<DType>* source_types = nullptr) {
   std::string key = std::to_string(plan_hash) + ":" + validity_key(has_valid);
+  if (source_types) {
+    key += ":";
+    for (auto& t : *source_types) key += t.str() + ",";
+  }
   std::shared_ptr<PlannedVariant> pv;
   {
     std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -242,7 +246,7 @@ static std::shared_ptr<PlannedVariant> planned_variant(const Operator& plan, uin
   }
   if (!pv) {
     pv = std::make_shared<PlannedVariant>();
-    pv->desc = generate_pipeline(plan, has_valid);
+    pv->desc = generate_pipeline(plan, has_valid, source_types);
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto res = g_plan_cache.emplace(key, pv);
     pv = res.first->second;
@@ -265,16 +269,74 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     if (kv.first == "spark.comet.gpu.chunkRows") chunk_rows_ = std::max<long long>(1024, atoll(kv.second.c_str()));
   }
   if (const char* e = getenv("COMET_GPU_CHUNK_ROWS")) chunk_rows_ = std::max<long long>(1024, atoll(e));
-  const Operator* scan = find_scan(plan_.get());
-  if (!scan) throw CometError("Plan has no Scan leaf: only Scan-rooted pipelines are supported by the MI355X native engine");
-  in_types_ = scan->scan_fields;
-  if (inputs_.size() != 1) throw CometError("Expected exactly one input stream for a single-Scan plan, got " + std::to_string(inputs_.size()));
-  // Validate the plan shape eagerly (all-valid variant is generated, not compiled) so that
-  // unsupported operators fail at createPlan like the reference's planner would on first execute.
-  std::vector<bool> none(in_types_.size(), false);
-  auto pv = planned_variant(*plan_, plan_hash_, none, false);
-  explain_ = pv->desc.explain;
-  sink_ = pv->desc.sink;
+  // Scan leaves in depth-first, left-before-right order map to the input streams (planner.rs:1726, :2391)
+  std::function<void(const Operator&)> walk = [&](const Operator& op) {
+    node_id_[&op] = (int)node_id_.size();
+    if (op.kind == OpKind::Scan) scan_input_[&op] = scan_input_.size();
+    if (op.kind == OpKind::HashJoin) has_join_ = true;
+    if (op.kind == OpKind::Unsupported)
+      throw CometError(std::string("Operator ") + op_name(op.proto_tag) + " is not supported by the MI355X native engine");
+    for (auto& c : op.children) walk(*c);
+  };
+  walk(*plan_);
+  if (scan_input_.empty()) throw CometError("Plan has no Scan leaf: only Scan-rooted pipelines are supported by the MI355X native engine");
+  if (inputs_.size() != scan_input_.size())
+    throw CometError("Plan has " + std::to_string(scan_input_.size()) + " Scan leaves but " + std::to_string(inputs_.size()) + " input streams were given");
+  // the root chain ends at a Scan or at the first join below it
+  root_source_ = plan_.get();
+  while (root_source_->kind != OpKind::Scan && root_source_->kind != OpKind::HashJoin) {
+    if (root_source_->children.size() != 1) throw CometError(std::string(op_name(root_source_->proto_tag)) + " expects exactly one child");
+    root_source_ = root_source_->children[0].get();
+  }
+  // Validate the plan shape eagerly (generated, not compiled) so that unsupported operators fail at createPlan
+  // like the reference's planner would on first execute.
+  if (!has_join_) {
+    in_types_ = root_source_->scan_fields;
+    std::vector<bool> none(in_types_.size(), false);
+    auto pv = planned_variant(*plan_, plan_hash_, none, false);
+    explain_ = pv->desc.explain;
+    sink_ = pv->desc.sink;
+  } else {
+    in_types_ = infer_schema(*root_source_);
+    if (plan_.get() != root_source_) {
+      std::vector<bool> none(in_types_.size(), false);
+      auto pv = planned_variant(*plan_, plan_hash_, none, false, &in_types_);
+      explain_ = explain_ + pv->desc.explain;
+      sink_ = pv->desc.sink;
+    } else {
+      sink_ = SinkKind::Output;
+    }
+  }
+}
+
+// Output schema of a sub-plan (no data needed): Scan fields, chain outputs, join = left ++ right (semi/anti: left)
+std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
+  if (op.kind == OpKind::Scan) return op.scan_fields;
+  if (op.kind == OpKind::HashJoin) {
+    if (op.children.size() != 2) throw CometError("HashJoin expects two children");
+    std::vector<DType> l = infer_schema(*op.children[0]), r = infer_schema(*op.children[1]);
+    std::vector<bool> lv(l.size(), false), rv(r.size(), false);
+    PipelineDesc d = generate_join(op, l, r, lv, rv);   // validates keys / join type
+    if (compile_in_infer_) jit_compile(d.source);
+    explain_ += d.explain;
+    std::vector<DType> out;
+    for (auto& c : d.out_cols) out.push_back(c.type);
+    return out;
+  }
+  const Operator* src = &op;
+  while (src->kind != OpKind::Scan && src->kind != OpKind::HashJoin) {
+    if (src->children.size() != 1) throw CometError(std::string(op_name(src->proto_tag)) + " expects exactly one child");
+    src = src->children[0].get();
+  }
+  std::vector<DType> st = infer_schema(*src);
+  std::vector<bool> none(st.size(), false);
+  PipelineDesc d = generate_pipeline(op, none, &st);
+  if (d.sink != SinkKind::Output) throw CometError("an aggregate below a join in the same native plan is not supported yet");
+  if (compile_in_infer_) jit_compile(d.source);
+  explain_ += d.explain;
+  std::vector<DType> out;
+  for (auto& c : d.out_cols) out.push_back(c.type);
+  return out;
 }
 
 ExecutionContext::~ExecutionContext() {
@@ -292,20 +354,36 @@ ExecutionContext::~ExecutionContext() {
 
 const std::string& ExecutionContext::explain() { return explain_; }
 
-std::string ExecutionContext::compile_only(const Operator& plan) {
-  const Operator* scan = find_scan(&plan);
-  if (!scan) throw CometError("Plan has no Scan leaf");
-  std::vector<bool> none(scan->scan_fields.size(), false);
-  PipelineDesc d = generate_pipeline(plan, none);
-  jit_compile(d.source);
-  return d.explain;
+std::string ExecutionContext::compile_only(OperatorP plan) {
+  // count Scan leaves to fabricate the (never used) input list
+  size_t nscan = 0;
+  std::function<void(const Operator&)> cnt = [&](const Operator& op) {
+    if (op.kind == OpKind::Scan) nscan++;
+    for (auto& c : op.children) cnt(*c);
+  };
+  cnt(*plan);
+  std::vector<InputSource> ins(nscan);
+  ExecutionContext ctx(plan, 0x5eed, {}, ins, 8192, 0);
+  std::vector<bool> none(ctx.in_types_.size(), false);
+  if (ctx.has_join_) {
+    ctx.compile_in_infer_ = true;
+    ctx.explain_.clear();
+    ctx.infer_schema(*ctx.root_source_);
+    if (ctx.plan_.get() != ctx.root_source_) {
+      auto pv = planned_variant(*ctx.plan_, ctx.plan_hash_, none, true, &ctx.in_types_);
+      ctx.explain_ += pv->desc.explain;
+    }
+  } else {
+    planned_variant(*ctx.plan_, ctx.plan_hash_, none, true);
+  }
+  return ctx.explain_;
 }
 
 Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid) {
   std::string key = validity_key(has_valid);
   auto it = variants_.find(key);
   if (it != variants_.end()) return it->second;
-  auto pv = planned_variant(*plan_, plan_hash_, has_valid, true);
+  auto pv = planned_variant(*plan_, plan_hash_, has_valid, true, has_join_ ? &in_types_ : nullptr);
   Variant v;
   v.desc = pv->desc;
   v.mod = jit_load(pv->code);
@@ -337,7 +415,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
   }
   err_flags_.ensure(kErrBytes);
   prm.out[kOutErr] = err_flags_.p;
-  input_rows += n;
+  if (!has_join_) input_rows += n;
 
   if (d.sink == SinkKind::AggNoGroup) {
     if (agg_variant_ && agg_variant_->desc.NW != d.NW) throw CometError("internal: accumulator layout differs between variants");
@@ -378,7 +456,9 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       HIP_CHECK(hipMemsetAsync((char*)err_flags_.p + 8, 0, 8, stream_));
     }
     const int64_t tile = (int64_t)d.R * 256;
-    int grid = (int)std::min<int64_t>((n + tile - 1) / tile, 256 * 4);
+    int grid_mult = 4;
+    if (const char* e = getenv("COMET_GROUPED_GRID_MULT")) grid_mult = std::max(1, atoi(e));
+    int grid = (int)std::min<int64_t>((n + tile - 1) / tile, 256 * grid_mult);
     // carry-save LDS accumulation bounds the rows one block may add (comet::kMaxRowsPerBlock = 2^19)
     const int64_t per_block_cap = ((int64_t)1 << 19) - 2 * tile;
     grid = (int)std::max<int64_t>(grid, (n + per_block_cap - 1) / per_block_cap);
@@ -710,9 +790,21 @@ void ExecutionContext::finish_grouped() {
 }
 
 // Pull host batches from the JVM stream until a chunk is full; copy through pinned staging to HBM.
-bool ExecutionContext::pull_host_chunk() {
-  InputSource& in = inputs_[0];
+// Gather host batches of input `input` (up to max_rows rows) into one chunk resident in HBM.
+// Returns false when nothing was read (stream exhausted); `rows` may be 0 with more to come only for empty batches.
+bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& in_types_, int64_t max_rows,
+                                       std::vector<DeviceColumnView>& views, std::vector<bool>& has_valid, int64_t& rows_out) {
+  InputSource& in = inputs_[input];
+  rows_out = 0;
   if (in.exhausted) return false;
+  if (staging_.size() <= input) staging_.resize(input + 1);
+  if (!staging_[input]) staging_[input].reset(new Staging());
+  auto& stage_vals_ = staging_[input]->stage_vals;
+  auto& stage_valid_ = staging_[input]->stage_valid;
+  auto& stage_aux_ = staging_[input]->stage_aux;
+  auto& dev_vals_ = staging_[input]->dev_vals;
+  auto& dev_valid_ = staging_[input]->dev_valid;
+  auto& dev_aux_ = staging_[input]->dev_aux;
   const size_t nc = in_types_.size();
   if (stage_vals_.size() != nc) {
     stage_vals_.resize(nc);
@@ -731,10 +823,10 @@ bool ExecutionContext::pull_host_chunk() {
     }
   }
   int64_t rows = 0;
-  std::vector<bool> has_valid(nc, false);
+  has_valid.assign(nc, false);
   std::vector<ArrowArray> held;
   // gather batches first so that staging buffers can be sized once
-  while (rows < chunk_rows_) {
+  while (rows < max_rows) {
     ArrowArray arr;
     memset(&arr, 0, sizeof arr);
     int rc = in.host->get_next(in.host, &arr);
@@ -841,62 +933,403 @@ bool ExecutionContext::pull_host_chunk() {
     }
   }
   for (auto& a : held) if (a.release) a.release(&a);
-  std::vector<DeviceColumnView> views(nc);
+  views.assign(nc, DeviceColumnView());
   for (size_t c = 0; c < nc; c++) {
     views[c].data = dev_vals_[c]->p;
     views[c].valid = has_valid[c] ? (const uint8_t*)dev_valid_[c]->p : nullptr;
     views[c].aux = dev_aux_[c]->p;
   }
-  process_chunk(views, has_valid, rows);
-  HIP_CHECK(hipStreamSynchronize(stream_));  // staging buffers are reused by the next chunk
-  return !in.exhausted;
+  rows_out = rows;
+  return true;
 }
 
-// HBM-resident input (Arrow C Device stream, ARROW_DEVICE_ROCM): zero copy.
-bool ExecutionContext::pull_device_batch() {
-  InputSource& in = inputs_[0];
+bool ExecutionContext::pull_host_chunk() {
+  std::vector<DeviceColumnView> views;
+  std::vector<bool> has_valid;
+  int64_t rows = 0;
+  if (!pull_host_table(0, in_types_, chunk_rows_, views, has_valid, rows)) return false;
+  if (rows > 0) {
+    process_chunk(views, has_valid, rows);
+    HIP_CHECK(hipStreamSynchronize(stream_));  // staging buffers are reused by the next chunk
+  }
+  return !inputs_[0].exhausted;
+}
+
+bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>& types, std::vector<DeviceColumnView>& views,
+                                         std::vector<bool>& has_valid, int64_t& rows, std::shared_ptr<void>& keepalive) {
+  InputSource& in = inputs_[input];
+  rows = 0;
   if (in.exhausted) return false;
-  ArrowDeviceArray da;
-  memset(&da, 0, sizeof da);
-  int rc = in.dev->get_next(in.dev, &da);
+  auto da = std::make_shared<ArrowDeviceArray>();
+  memset(da.get(), 0, sizeof(ArrowDeviceArray));
+  int rc = in.dev->get_next(in.dev, da.get());
   if (rc != 0) {
     const char* m = in.dev->get_last_error ? in.dev->get_last_error(in.dev) : nullptr;
     throw CometError(std::string("input ArrowDeviceArrayStream.get_next failed: ") + (m ? m : "unknown error"));
   }
-  if (!da.array.release) {
+  if (!da->array.release) {
     in.exhausted = true;
     return false;
   }
-  struct Guard {
-    ArrowArray* a;
-    ~Guard() { if (a->release) a->release(a); }
-  } guard{&da.array};
-  if (da.device_type != ARROW_DEVICE_ROCM && da.device_type != ARROW_DEVICE_ROCM_HOST)
+  // the producer's buffers stay alive until the keepalive is dropped
+  keepalive = std::shared_ptr<void>(da.get(), [da](void*) mutable {
+    if (da->array.release) da->array.release(&da->array);
+  });
+  if (da->device_type != ARROW_DEVICE_ROCM && da->device_type != ARROW_DEVICE_ROCM_HOST)
     throw CometError("device input stream must carry ARROW_DEVICE_ROCM memory");
-  if (da.sync_event) HIP_CHECK(hipStreamWaitEvent(stream_, *(hipEvent_t*)da.sync_event, 0));
-  const size_t nc = in_types_.size();
-  if ((size_t)da.array.n_children != nc) throw CometError("device batch column count does not match Scan fields");
-  std::vector<DeviceColumnView> views(nc);
-  std::vector<bool> has_valid(nc, false);
+  if (da->sync_event) HIP_CHECK(hipStreamWaitEvent(stream_, *(hipEvent_t*)da->sync_event, 0));
+  const size_t nc = types.size();
+  if ((size_t)da->array.n_children != nc) throw CometError("device batch column count does not match Scan fields");
+  views.assign(nc, DeviceColumnView());
+  has_valid.assign(nc, false);
   for (size_t c = 0; c < nc; c++) {
-    const ArrowArray* col = da.array.children[c];
+    const ArrowArray* col = da->array.children[c];
     if (col->dictionary) throw CometError("dictionary-encoded device columns are not supported yet");
     views[c].data = col->buffers[1];
     views[c].offset = col->offset;
-    if (in_types_[c].id == TypeId::String || in_types_[c].id == TypeId::Bytes) views[c].aux = col->buffers[2];
-    if (in_types_[c].id == TypeId::Decimal && (((uintptr_t)col->buffers[1]) & 15))
+    if (types[c].id == TypeId::String || types[c].id == TypeId::Bytes) views[c].aux = col->buffers[2];
+    if (types[c].id == TypeId::Decimal && (((uintptr_t)col->buffers[1]) & 15))
       throw CometError("device Decimal128 buffers must be 16-byte aligned");
     if (col->null_count != 0 && col->buffers[0]) {
       has_valid[c] = true;
       views[c].valid = (const uint8_t*)col->buffers[0];
     }
   }
-  process_chunk(views, has_valid, da.array.length);
+  rows = da->array.length;
+  return true;
+}
+
+// HBM-resident input (Arrow C Device stream, ARROW_DEVICE_ROCM): zero copy.
+bool ExecutionContext::pull_device_batch() {
+  std::vector<DeviceColumnView> views;
+  std::vector<bool> has_valid;
+  int64_t rows = 0;
+  std::shared_ptr<void> keep;
+  if (!pull_device_table(0, in_types_, views, has_valid, rows, keep)) return false;
+  process_chunk(views, has_valid, rows);
   HIP_CHECK(hipStreamSynchronize(stream_));
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Plans with joins: every join input is materialised in HBM (chains are fused pipelines, joins are the
+// materialisation points), then the root chain streams over the top join's output.
+// ---------------------------------------------------------------------------------------------
+namespace {
+int out_width(const OutCol& oc) { return oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
+}  // namespace
+
+// dense outputs written by an emit kernel (values + validity BYTES) → Arrow-layout device table (validity bitmaps)
+DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals,
+                                            const std::vector<std::shared_ptr<DevBuf>>& valid_bytes, int64_t rows) {
+  const PipelineDesc& d = v.desc;
+  DevTable t;
+  t.rows = rows;
+  for (size_t j = 0; j < d.out_cols.size(); j++) {
+    const OutCol& oc = d.out_cols[j];
+    if (oc.packed_string) throw CometError("Utf8 columns cannot cross a GPU join/pipeline boundary yet");
+    DeviceColumnView cv;
+    cv.data = vals[j]->p;
+    t.owners.push_back(vals[j]);
+    bool hv = false;
+    if (oc.type.id == TypeId::Bool) {
+      // kernels store booleans as bytes; Arrow wants bits
+      auto bits = std::make_shared<DevBuf>();
+      bits->ensure((size_t)((rows + 7) / 8) + 16);
+      CometKParams pk;
+      memset(&pk, 0, sizeof pk);
+      pk.n = rows;
+      pk.out[0] = vals[j]->p;
+      pk.out[1] = bits->p;
+      if (rows) launch(v, "k_pack", (int)std::min<int64_t>((rows + 255) / 256, 2048), pk);
+      cv.data = bits->p;
+      t.owners.push_back(bits);
+    }
+    if (oc.nullable && rows) {
+      auto bm = std::make_shared<DevBuf>();
+      bm->ensure((size_t)((rows + 7) / 8) + 16);
+      CometKParams pk;
+      memset(&pk, 0, sizeof pk);
+      pk.n = rows;
+      pk.out[0] = valid_bytes[j]->p;
+      pk.out[1] = bm->p;
+      launch(v, "k_pack", (int)std::min<int64_t>((rows + 255) / 256, 2048), pk);
+      cv.valid = (const uint8_t*)bm->p;
+      t.owners.push_back(bm);
+      t.owners.push_back(valid_bytes[j]);
+      hv = true;
+    }
+    t.types.push_back(oc.type);
+    t.cols.push_back(cv);
+    t.has_valid.push_back(hv);
+  }
+  return t;
+}
+
+// Filter/Project chain `top` over the resident table `in` → resident table
+DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTable& in) {
+  auto pv = planned_variant(top, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&top] + 1)), in.has_valid, true, &in.types);
+  if (pv->desc.sink != SinkKind::Output) throw CometError("an aggregate below a join in the same native plan is not supported yet");
+  Variant v;
+  v.desc = pv->desc;
+  v.mod = jit_load(pv->code);
+  const PipelineDesc& d = v.desc;
+  const int64_t n = in.rows;
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  prm.n = n;
+  for (size_t i = 0; i < in.cols.size(); i++) {
+    prm.in[i].data = in.cols[i].data;
+    prm.in[i].valid = in.has_valid[i] ? in.cols[i].valid : nullptr;
+    prm.in[i].aux = in.cols[i].aux;
+    prm.in[i].offset = in.cols[i].offset;
+  }
+  prm.out[kOutErr] = err_flags_.p;
+  const size_t ncol = d.out_cols.size();
+  std::vector<std::shared_ptr<DevBuf>> vals(ncol), vbytes(ncol);
+  auto bind = [&](int64_t cap) {
+    for (size_t j = 0; j < ncol; j++) {
+      vals[j] = std::make_shared<DevBuf>();
+      vals[j]->ensure((size_t)cap * out_width(d.out_cols[j]) + 16);
+      prm.out[kOutFirstCol + 2 * j] = vals[j]->p;
+      vbytes[j] = std::make_shared<DevBuf>();
+      if (d.out_cols[j].nullable) {
+        vbytes[j]->ensure((size_t)cap + 16);
+        prm.out[kOutFirstCol + 2 * j + 1] = vbytes[j]->p;
+      }
+    }
+  };
+  int64_t out_rows = n;
+  timed_begin();
+  if (n == 0) {
+    bind(1);
+    out_rows = 0;
+  } else if (d.has_filter) {
+    const int64_t ntiles = (n + 1023) / 1024;
+    scratch_mask_.ensure((size_t)((n + 63) / 64) * 8 + 64);
+    scratch_counts_.ensure((size_t)(ntiles + 1) * 8);
+    prm.out[0] = scratch_mask_.p;
+    prm.out[1] = scratch_counts_.p;
+    int grid = (int)std::min<int64_t>(ntiles, 256 * 8);
+    launch(v, "k_mask", grid, prm);
+    prm.iarg[0] = ntiles;
+    launch(v, "k_scan", 1, prm);
+    uint64_t total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, (char*)scratch_counts_.p + (size_t)ntiles * 8, 8, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    out_rows = (int64_t)total;
+    bind(std::max<int64_t>(out_rows, 1));
+    if (out_rows > 0) launch(v, "k_emit", grid, prm);
+  } else {
+    bind(n);
+    launch(v, "k_emit", (int)std::min<int64_t>((n + 255) / 256, 256 * 8), prm);
+  }
+  timed_end();
+  DevTable out = outputs_to_table(v, vals, vbytes, out_rows);
+  out.owners.push_back(v.mod);
+  return out;
+}
+
+DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const DevTable& R) {
+  // planned once per (join node, validity patterns)
+  std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&j] + 1))) + ":J:" + validity_key(L.has_valid) + "|" +
+                    validity_key(R.has_valid);
+  std::shared_ptr<PlannedVariant> pv;
+  {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    if (it != g_plan_cache.end()) pv = it->second;
+  }
+  if (!pv) {
+    pv = std::make_shared<PlannedVariant>();
+    pv->desc = generate_join(j, L.types, R.types, L.has_valid, R.has_valid);
+    pv->code = jit_compile(pv->desc.source);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plan_cache[key] = pv;
+  }
+  Variant v;
+  v.desc = pv->desc;
+  v.mod = jit_load(pv->code);
+  const PipelineDesc& d = v.desc;
+  const bool build_left = j.build_side == BuildSide::Left;
+  const DevTable& B = build_left ? L : R;
+  const DevTable& P = build_left ? R : L;
+  if (B.rows >= ((int64_t)1 << 31)) throw CometError("hash join build side exceeds 2^31 rows");
+  const size_t nb = B.cols.size(), np = P.cols.size();
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  for (size_t i = 0; i < nb; i++) {
+    prm.in[i].data = B.cols[i].data;
+    prm.in[i].valid = B.has_valid[i] ? B.cols[i].valid : nullptr;
+    prm.in[i].aux = B.cols[i].aux;
+    prm.in[i].offset = B.cols[i].offset;
+  }
+  for (size_t i = 0; i < np; i++) {
+    prm.in[nb + i].data = P.cols[i].data;
+    prm.in[nb + i].valid = P.has_valid[i] ? P.cols[i].valid : nullptr;
+    prm.in[nb + i].aux = P.cols[i].aux;
+    prm.in[nb + i].offset = P.cols[i].offset;
+  }
+  int64_t cap = 1024;
+  while (cap < 2 * B.rows) cap <<= 1;
+  const int64_t n = P.rows;
+  const int64_t ntiles = (n + 1023) / 1024;
+  DevBuf head, next, counts, tiles;
+  head.ensure((size_t)cap * 4);
+  next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4);
+  counts.ensure((size_t)std::max<int64_t>(n, 1) * 4);
+  tiles.ensure((size_t)(ntiles + 1) * 8);
+  HIP_CHECK(hipMemsetAsync(head.p, 0xff, (size_t)cap * 4, stream_));
+  prm.n = n;
+  prm.iarg[0] = cap;
+  prm.iarg[1] = B.rows;
+  prm.iarg[2] = ntiles;
+  prm.out[0] = head.p;
+  prm.out[1] = next.p;
+  prm.out[kOutErr] = err_flags_.p;
+  prm.out[3] = counts.p;
+  prm.out[44] = tiles.p;
+  timed_begin();
+  if (B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+  int64_t out_rows = 0;
+  const size_t ncol = d.out_cols.size();
+  std::vector<std::shared_ptr<DevBuf>> vals(ncol), vbytes(ncol);
+  if (n > 0) {
+    int grid = (int)std::min<int64_t>(ntiles, 256 * 8);
+    launch(v, "k_jcount", grid, prm);
+    launch(v, "k_jscan", 1, prm);
+    uint64_t total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, (char*)tiles.p + (size_t)ntiles * 8, 8, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    out_rows = (int64_t)total;
+  }
+  for (size_t c = 0; c < ncol; c++) {
+    vals[c] = std::make_shared<DevBuf>();
+    vals[c]->ensure((size_t)std::max<int64_t>(out_rows, 1) * out_width(d.out_cols[c]) + 16);
+    prm.out[kOutFirstCol + 2 * c] = vals[c]->p;
+    vbytes[c] = std::make_shared<DevBuf>();
+    if (d.out_cols[c].nullable) {
+      vbytes[c]->ensure((size_t)std::max<int64_t>(out_rows, 1) + 16);
+      prm.out[kOutFirstCol + 2 * c + 1] = vbytes[c]->p;
+    }
+  }
+  if (out_rows > 0) launch(v, "k_jemit", (int)std::min<int64_t>(ntiles, 256 * 8), prm);
+  timed_end();
+  DevTable out = outputs_to_table(v, vals, vbytes, out_rows);
+  HIP_CHECK(hipStreamSynchronize(stream_));  // head/next/counts go back to the pool when this frame ends
+  out.owners.push_back(v.mod);
+  join_build_rows_ += B.rows;
+  join_probe_rows_ += P.rows;
+  return out;
+}
+
+DevTable ExecutionContext::materialize(const Operator& op) {
+  if (op.kind == OpKind::Scan) {
+    const size_t input = scan_input_.at(&op);
+    DevTable t;
+    t.types = op.scan_fields;
+    if (inputs_[input].kind == 0) {
+      // host stream: the whole input becomes one resident chunk (joins need their inputs complete)
+      int64_t rows = 0;
+      if (pull_host_table(input, op.scan_fields, INT64_MAX, t.cols, t.has_valid, rows)) t.rows = rows;
+      if (t.cols.empty()) {
+        t.cols.assign(op.scan_fields.size(), DeviceColumnView());
+        t.has_valid.assign(op.scan_fields.size(), false);
+      }
+      HIP_CHECK(hipStreamSynchronize(stream_));
+    } else {
+      std::shared_ptr<void> keep;
+      int64_t rows = 0;
+      if (pull_device_table(input, op.scan_fields, t.cols, t.has_valid, rows, keep)) {
+        t.rows = rows;
+        t.owners.push_back(keep);
+        std::vector<DeviceColumnView> c2;
+        std::vector<bool> v2;
+        std::shared_ptr<void> k2;
+        int64_t r2 = 0;
+        if (pull_device_table(input, op.scan_fields, c2, v2, r2, k2) && r2 > 0)
+          throw CometError("a device input stream feeding a join must deliver a single batch");
+      } else {
+        t.cols.assign(op.scan_fields.size(), DeviceColumnView());
+        t.has_valid.assign(op.scan_fields.size(), false);
+      }
+    }
+    input_rows += t.rows;
+    return t;
+  }
+  if (op.kind == OpKind::HashJoin) {
+    DevTable l = materialize(*op.children[0]);
+    DevTable r = materialize(*op.children[1]);
+    return hash_join(op, l, r);
+  }
+  // Filter / Projection chain: fused over its source
+  const Operator* src = &op;
+  while (src->kind != OpKind::Scan && src->kind != OpKind::HashJoin) src = src->children[0].get();
+  DevTable in = materialize(*src);
+  DevTable out = run_chain_to_device(op, in);
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  return out;
+}
+
+// resident table → host batches of ≤ batch_size rows (root of a plan that ends in a join)
+void ExecutionContext::table_to_host_batches(const DevTable& t) {
+  if (t.rows == 0) return;
+  const size_t ncol = t.cols.size();
+  std::vector<std::vector<uint8_t>> hv(ncol), hb(ncol);
+  for (size_t j = 0; j < ncol; j++) {
+    const DType& ty = t.types[j];
+    size_t bytes = ty.id == TypeId::Bool ? (size_t)((t.rows + 7) / 8) : (size_t)t.rows * fixed_width(ty);
+    hv[j].resize(bytes);
+    HIP_CHECK(hipMemcpyAsync(hv[j].data(), t.cols[j].data, bytes, hipMemcpyDeviceToHost, stream_));
+    if (t.has_valid[j]) {
+      hb[j].resize((size_t)((t.rows + 7) / 8));
+      HIP_CHECK(hipMemcpyAsync(hb[j].data(), t.cols[j].valid, hb[j].size(), hipMemcpyDeviceToHost, stream_));
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  const int64_t bs = batch_size_ > 0 ? batch_size_ : t.rows;
+  auto getbit = [](const std::vector<uint8_t>& b, int64_t i) { return (b[(size_t)(i >> 3)] >> (i & 7)) & 1; };
+  for (int64_t off = 0; off < t.rows; off += bs) {
+    const int64_t len = std::min(bs, t.rows - off);
+    HostBatch b;
+    b.rows = len;
+    for (size_t j = 0; j < ncol; j++) {
+      HostColumn c;
+      c.type = t.types[j];
+      c.length = len;
+      if (c.type.id == TypeId::Bool) {
+        c.values.assign((size_t)((len + 7) / 8), 0);
+        for (int64_t i = 0; i < len; i++)
+          if (getbit(hv[j], off + i)) c.values[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+      } else {
+        int w = fixed_width(c.type);
+        c.values.assign(hv[j].begin() + (size_t)off * w, hv[j].begin() + (size_t)(off + len) * w);
+      }
+      if (t.has_valid[j]) {
+        int64_t nulls = 0;
+        std::vector<uint8_t> bm((size_t)((len + 7) / 8), 0);
+        for (int64_t i = 0; i < len; i++) {
+          if (getbit(hb[j], off + i)) bm[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+          else nulls++;
+        }
+        c.null_count = nulls;
+        if (nulls) c.validity = std::move(bm);
+      }
+      b.cols.push_back(std::move(c));
+    }
+    ready_.push_back(std::move(b));
+  }
+}
+
 void ExecutionContext::run_to_completion() {
+  if (has_join_) {
+    DevTable src = materialize(*root_source_);
+    if (plan_.get() == root_source_) throw CometError("internal: bare join root");
+    process_chunk(src.cols, src.has_valid, src.rows);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    return;
+  }
   // ungrouped / grouped aggregates are pipeline breakers: drain the input completely
   while (true) {
     bool more = inputs_[0].kind == 0 ? pull_host_chunk() : pull_device_batch();
@@ -924,6 +1357,16 @@ int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_sch
       else finish_aggregate();
       finished_ = true;
     } else {
+      if (has_join_) {
+        if (plan_.get() == root_source_) {
+          // the join itself is the plan root: export its materialised output
+          DevTable t = materialize(*root_source_);
+          table_to_host_batches(t);
+        } else {
+          run_to_completion();
+        }
+        finished_ = true;
+      }
       while (ready_.empty() && !finished_) {
         bool more = inputs_[0].kind == 0 ? pull_host_chunk() : pull_device_batch();
         if (!more) finished_ = true;

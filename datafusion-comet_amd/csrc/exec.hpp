@@ -67,6 +67,20 @@ struct DeviceColumnView {
   int64_t offset = 0;
 };
 
+// a table resident in HBM (Arrow layout); owners keep pooled buffers / producer arrays alive
+struct DevTable {
+  int64_t rows = 0;
+  std::vector<DType> types;
+  std::vector<DeviceColumnView> cols;
+  std::vector<bool> has_valid;
+  std::vector<std::shared_ptr<void>> owners;
+};
+
+struct Staging {  // host→device staging of one input stream (one chunk at a time)
+  std::vector<std::unique_ptr<PinnedBuf>> stage_vals, stage_valid, stage_aux;
+  std::vector<std::unique_ptr<DevBuf>> dev_vals, dev_valid, dev_aux;
+};
+
 struct Variant {  // one JIT specialisation of the pipeline (per input-validity pattern)
   PipelineDesc desc;
   std::shared_ptr<LoadedModule> mod;
@@ -83,7 +97,7 @@ class ExecutionContext {
   std::string metrics_proto();
   const std::string& explain();
   // CPU-only: plan + generate + hiprtc-compile the all-valid variant (used by build()/tests w/o GPU)
-  static std::string compile_only(const Operator& plan);
+  static std::string compile_only(OperatorP plan);
 
   std::string last_error;
   int last_error_kind = 0;
@@ -99,8 +113,19 @@ class ExecutionContext {
   void process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n);
   void finish_aggregate();
   void finish_grouped();
+  std::vector<DType> infer_schema(const Operator& op);
+  DevTable materialize(const Operator& op);
+  DevTable run_chain_to_device(const Operator& top, const DevTable& in);
+  DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
+  DevTable outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals, const std::vector<std::shared_ptr<DevBuf>>& valid_bytes,
+                            int64_t rows);
+  void table_to_host_batches(const DevTable& t);
   bool pull_host_chunk();
   bool pull_device_batch();
+  bool pull_host_table(size_t input, const std::vector<DType>& types, int64_t max_rows, std::vector<DeviceColumnView>& views,
+                       std::vector<bool>& has_valid, int64_t& rows);
+  bool pull_device_table(size_t input, const std::vector<DType>& types, std::vector<DeviceColumnView>& views, std::vector<bool>& has_valid,
+                         int64_t& rows, std::shared_ptr<void>& keepalive);
   void export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
   void check_device_errors();
   void raise_device_errors(uint32_t flags);
@@ -125,10 +150,14 @@ class ExecutionContext {
   Variant* agg_variant_ = nullptr;   // variant whose accumulator layout the partials follow
   std::string explain_;
   SinkKind sink_ = SinkKind::Output;
+  bool has_join_ = false;
+  bool compile_in_infer_ = false;
+  const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from
+  std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)
+  std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index
+  int64_t join_build_rows_ = 0, join_probe_rows_ = 0;
 
-  // host→device staging (one chunk at a time)
-  std::vector<std::unique_ptr<PinnedBuf>> stage_vals_, stage_valid_, stage_aux_;
-  std::vector<std::unique_ptr<DevBuf>> dev_vals_, dev_valid_, dev_aux_;
+  std::vector<std::unique_ptr<Staging>> staging_;   // per input stream
 
   // aggregate state
   DevBuf partials_;

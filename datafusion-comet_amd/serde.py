@@ -300,8 +300,13 @@ class Operator:
     mode: int = PARTIAL
     plan_id: int = 0
     raw_tag: int = 0                            # 'raw': arbitrary op_struct tag with empty body (negative tests)
+    left_keys: List[Expr] = field(default_factory=list)       # hash_join
+    right_keys: List[Expr] = field(default_factory=list)
+    join_type: int = 0
+    build_side: int = 0
+    condition: Optional[Expr] = None
 
-    TAGS = dict(scan=100, projection=101, filter=102, hash_agg=104)
+    TAGS = dict(scan=100, projection=101, filter=102, hash_agg=104, hash_join=109)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -318,6 +323,15 @@ class Operator:
             body += b"".join(_f_msg(2, a.encode()) for a in self.aggs)
             if self.mode:
                 body += _f_varint(5, self.mode)
+        elif self.kind == "hash_join":
+            # HashJoin{left_join_keys=1,right_join_keys=2,join_type=3,condition=4,build_side=5} (operator.proto:754-763)
+            body = b"".join(_f_msg(1, e.encode()) for e in self.left_keys) + b"".join(_f_msg(2, e.encode()) for e in self.right_keys)
+            if self.join_type:
+                body += _f_varint(3, self.join_type)
+            if self.condition is not None:
+                body += _f_msg(4, self.condition.encode())
+            if self.build_side:
+                body += _f_varint(5, self.build_side)
         elif self.kind == "raw":
             return out + _f_msg(self.raw_tag, b"")
         else:
@@ -339,6 +353,17 @@ def project(child: Operator, exprs: Sequence[Expr]) -> Operator:
 
 def hash_agg(child: Operator, grouping: Sequence[Expr], aggs: Sequence[AggExpr], mode: int = PARTIAL) -> Operator:
     return Operator("hash_agg", [child], exprs=list(grouping), aggs=list(aggs), mode=mode)
+
+
+INNER, LEFT_OUTER, RIGHT_OUTER, FULL_OUTER, LEFT_SEMI, LEFT_ANTI = range(6)
+BUILD_LEFT, BUILD_RIGHT = 0, 1
+
+
+def hash_join(left: Operator, right: Operator, left_keys: Sequence[Expr], right_keys: Sequence[Expr], join_type: int = INNER,
+              build_side: int = BUILD_LEFT, condition: Optional[Expr] = None) -> Operator:
+    """Keys are bound to each side's own schema; `condition` to the concatenated left ++ right schema."""
+    return Operator("hash_join", [left, right], left_keys=list(left_keys), right_keys=list(right_keys), join_type=join_type,
+                    build_side=build_side, condition=condition)
 
 
 def config_map(entries: dict) -> bytes:

@@ -135,3 +135,64 @@ Q1_BYTES_PER_ROW = 4 + 4 * 16 + 2 * (4 + 1)
 def warm_plans():
     """Plans whose fused kernels build() pre-compiles into the code-object cache."""
     return [q6_plan(), q1_plan()]
+
+
+# ------------------------------------------------------------------ Q3 (SURVEY §3.5, §8d config 4)
+
+SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]
+
+
+def q3_tables(n_orders: int, seed: int = 3):
+    """customer (n_orders/10 rows), orders (n_orders), lineitem (~4 per order) shaped like dbgen:
+    customer[c_custkey int64, c_mktsegment utf8], orders[o_orderkey, o_custkey int64, o_orderdate date32,
+    o_shippriority int32], lineitem[l_orderkey int64, l_extendedprice, l_discount dec(12,2), l_shipdate date32]."""
+    rng = np.random.default_rng(seed)
+    n_c = max(1, n_orders // 10)
+    ckey = np.arange(1, n_c + 1, dtype=np.int64)
+    seg = rng.integers(0, 5, n_c)
+    lens = np.array([len(s) for s in SEGMENTS], np.int32)
+    offs = np.zeros(n_c + 1, np.int32)
+    offs[1:] = np.cumsum(lens[seg])
+    data = b"".join(SEGMENTS[i] for i in seg)
+    customer = pa.table([pa.array(ckey), pa.Array.from_buffers(pa.utf8(), n_c, [None, pa.py_buffer(offs.tobytes()), pa.py_buffer(data)])],
+                        names=["c_custkey", "c_mktsegment"])
+    okey = (np.arange(n_orders, dtype=np.int64) // 8) * 32 + (np.arange(n_orders, dtype=np.int64) % 8) + 1   # dbgen's sparse order keys
+    ocust = rng.integers(1, n_c + 1, n_orders, dtype=np.int64)
+    odate = rng.integers(days(1992, 1, 1), days(1998, 8, 2) + 1, n_orders, dtype=np.int64).astype(np.int32)
+    orders = pa.table([pa.array(okey), pa.array(ocust), pa.array(odate, pa.int32()).cast(pa.date32()), pa.array(np.zeros(n_orders, np.int32))],
+                      names=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    per = rng.integers(1, 8, n_orders)
+    lo = np.repeat(np.arange(n_orders), per)
+    n_l = len(lo)
+    lkey = okey[lo]
+    qty = rng.integers(1, 51, n_l, dtype=np.int64)
+    price = qty * rng.integers(90000, 210001, n_l, dtype=np.int64)
+    disc = rng.integers(0, 11, n_l, dtype=np.int64)
+    ship = (odate[lo].astype(np.int64) + rng.integers(1, 122, n_l)).astype(np.int32)
+    lineitem = pa.table([pa.array(lkey), _dec128_array(price, 12, 2), _dec128_array(disc, 12, 2), pa.array(ship, pa.int32()).cast(pa.date32())],
+                        names=["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
+    return customer, orders, lineitem
+
+
+def q3_plan() -> S.Operator:
+    """TPC-H Q3 as one native stage: customer ⋈ orders ⋈ lineitem (Inner, build = left), project, partial aggregate.
+    Scan leaves in depth-first order: customer, orders, lineitem."""
+    cutoff = days(1995, 3, 15)
+    cust = S.project(S.filter_(S.scan([S.T_INT64, S.T_STRING]), S.eq(S.col(1, S.T_STRING), S.lit("BUILDING", S.T_STRING))), [S.col(0, S.T_INT64)])
+    ofields = [S.T_INT64, S.T_INT64, S.T_DATE, S.T_INT32]
+    orders = S.filter_(S.scan(ofields), S.lt(S.col(2, S.T_DATE), S.lit(cutoff, S.T_DATE)))
+    j1 = S.hash_join(cust, orders, [S.col(0, S.T_INT64)], [S.col(1, S.T_INT64)], S.INNER, S.BUILD_LEFT)
+    # j1 output: c_custkey, o_orderkey, o_custkey, o_orderdate, o_shippriority
+    j1p = S.project(j1, [S.col(1, S.T_INT64), S.col(3, S.T_DATE), S.col(4, S.T_INT32)])
+    lfields = [S.T_INT64, DEC, DEC, S.T_DATE]
+    li = S.project(S.filter_(S.scan(lfields), S.gt(S.col(3, S.T_DATE), S.lit(cutoff, S.T_DATE))),
+                   [S.col(0, S.T_INT64), S.col(1, DEC), S.col(2, DEC)])
+    j2 = S.hash_join(j1p, li, [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.INNER, S.BUILD_LEFT)
+    # j2 output: o_orderkey, o_orderdate, o_shippriority, l_orderkey, l_extendedprice, l_discount
+    one_minus = S.check_overflow(S.math("subtract", S.lit(100, DEC), S.col(5, DEC), S.decimal(13, 2)), S.decimal(13, 2))
+    rev = S.check_overflow(S.math("multiply", S.col(4, DEC), one_minus, S.decimal(26, 4)), S.decimal(26, 4))
+    p = S.project(j2, [S.col(3, S.T_INT64), S.col(1, S.T_DATE), S.col(2, S.T_INT32), rev])
+    return S.hash_agg(p, [S.col(0, S.T_INT64), S.col(1, S.T_DATE), S.col(2, S.T_INT32)], [S.sum_(S.col(3, S.decimal(26, 4)), S.decimal(36, 4))])
+
+
+Q3_NUM_OUTPUT_COLS = 3 + 2

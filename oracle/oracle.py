@@ -389,13 +389,23 @@ def _take(c: Col, idx: np.ndarray) -> Col:
     return Col(c.dtype, c.values[idx], None if c.valid is None else c.valid[idx])
 
 
-def run_plan(S, op, table: pa.Table) -> List[Col]:
-    """Evaluate the operator tree over `table` (the single Scan input). Returns the output columns."""
+def run_plan(S, op, table) -> List[Col]:
+    """Evaluate the operator tree.  `table` is the Scan input, or a list of tables consumed by the Scan leaves in
+    depth-first, left-before-right order (planner.rs:1726).  Returns the output columns."""
+    if isinstance(table, pa.Table):
+        table = [table]
+    if not isinstance(table, _ScanQueue):
+        table = _ScanQueue(list(table))
     ev = Evaluator(S)
     k = op.kind
     if k == "scan":
-        assert table.num_columns == len(op.fields)
-        return [col_from_arrow(S, table.column(i), t) for i, t in enumerate(op.fields)]
+        t = table.pop()
+        assert t.num_columns == len(op.fields)
+        return [col_from_arrow(S, t.column(i), ty) for i, ty in enumerate(op.fields)]
+    if k == "hash_join":
+        left = run_plan(S, op.children[0], table)
+        right = run_plan(S, op.children[1], table)
+        return _hash_join(S, ev, op, left, right)
     child = run_plan(S, op.children[0], table)
     n = len(child[0]) if child else 0
     if k == "filter":
@@ -408,6 +418,63 @@ def run_plan(S, op, table: pa.Table) -> List[Col]:
     if k == "hash_agg":
         return _hash_agg(S, ev, op, child, n)
     raise NotImplementedError(k)
+
+
+class _ScanQueue:
+    def __init__(self, tables):
+        self.tables = tables
+
+    def pop(self):
+        return self.tables.pop(0)
+
+
+def _key_tuple(S, cols: List[Col], i: int):
+    t = []
+    for c in cols:
+        if c.valid is not None and not c.valid[i]:
+            return None                         # NULL never matches (NullEqualsNothing, planner.rs:2225-2227)
+        if c.dtype.type_id == S.DECIMAL:
+            t.append(dec_to_int(c.values, i))
+        else:
+            v = c.values[i]
+            v = v.item() if hasattr(v, "item") else v
+            if isinstance(v, float) and v == 0.0:
+                v = 0.0                          # -0.0 == 0.0 for join keys (NormalizeNaNAndZero)
+            t.append(v)
+    return tuple(t)
+
+
+def _hash_join(S, ev: "Evaluator", op, left: List[Col], right: List[Col]) -> List[Col]:
+    """HashJoinExec restated (planner.rs:2192-2266): Inner / LeftSemi / LeftAnti, optional residual condition over
+    left ++ right.  Output order is unspecified in the reference; here probe order (tests compare multisets)."""
+    nl = len(left[0]) if left else 0
+    nr = len(right[0]) if right else 0
+    lk = [ev.eval(e, left, nl) for e in op.left_keys]
+    rk = [ev.eval(e, right, nr) for e in op.right_keys]
+    index = {}
+    for i in range(nr):
+        k = _key_tuple(S, rk, i)
+        if k is not None:
+            index.setdefault(k, []).append(i)
+    li, ri = [], []
+    for i in range(nl):
+        k = _key_tuple(S, lk, i)
+        for j in (index.get(k, []) if k is not None else []):
+            li.append(i)
+            ri.append(j)
+    li, ri = np.array(li, np.int64), np.array(ri, np.int64)
+    pairs = [_take(c, li) for c in left] + [_take(c, ri) for c in right]
+    if op.condition is not None and len(li):
+        c = ev.eval(op.condition, pairs, len(li))
+        keep = c.ok() & c.values.astype(bool)
+        li, ri = li[keep], ri[keep]
+        pairs = [_take(c2, np.nonzero(keep)[0]) for c2 in pairs]
+    if op.join_type == S.INNER:
+        return pairs
+    matched = np.zeros(nl, bool)
+    matched[li] = True
+    sel = np.nonzero(matched if op.join_type == S.LEFT_SEMI else ~matched)[0]
+    return [_take(c, sel) for c in left]
 
 
 def _group_ids(S, keys: List[Col], n: int):
@@ -653,7 +720,7 @@ def _i128(v: int) -> _I128:
     return _I128(v & 0xFFFFFFFFFFFFFFFF, v >> 64)
 
 
-def run_plan_to_arrow(S, op, table: pa.Table) -> pa.Table:
+def run_plan_to_arrow(S, op, table) -> pa.Table:
     cols = run_plan(S, op, table)
     return pa.table([col_to_arrow(S, c) for c in cols], names=[f"col_{i}" for i in range(len(cols))])
 
