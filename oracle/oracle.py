@@ -482,6 +482,15 @@ def _group_ids(S, keys: List[Col], n: int):
     reference, tests compare as multisets)."""
     if not keys:
         return np.zeros(n, np.int64), 1, []
+    if n and all(k.values.dtype.kind in "iub" for k in keys):
+        # fast path (integer-like keys): np.unique over (is_null, value) pairs; group order is irrelevant
+        mat = np.zeros((n, 2 * len(keys)), np.int64)
+        for j, k in enumerate(keys):
+            ok = k.ok()
+            mat[:, 2 * j] = ~ok
+            mat[:, 2 * j + 1] = np.where(ok, k.values.astype(np.int64), 0)
+        _, first, inv = np.unique(mat, axis=0, return_index=True, return_inverse=True)
+        return inv.reshape(-1).astype(np.int64), len(first), None
     tuples = []
     for i in range(n):
         t = []
@@ -516,9 +525,8 @@ def _hash_agg(S, ev: Evaluator, op, child: List[Col], n: int) -> List[Col]:
     for ki, kc in enumerate(op.exprs):
         src = keys[ki] if op.mode == S.PARTIAL else child[ki]
         # first row of each group carries the key
-        first = np.full(ng, -1, np.int64)
-        for i in range(n - 1, -1, -1):
-            first[gid[i]] = i
+        first = np.full(ng, n, np.int64)
+        np.minimum.at(first, gid, np.arange(n, dtype=np.int64))
         out.append(_take(src, first))
     state_col = len(op.exprs)
     for a in op.aggs:
@@ -609,6 +617,15 @@ def _agg_partial(S, ev, a, child, n, gid, ng, grouped) -> List[Col]:
             return [Col(S.T_DOUBLE, sums, None if some else np.array([False])), Col(S.T_INT64, cnts, None)]
         hb = cnts > 0
         return [Col(S.T_DOUBLE, sums, None if hb.all() else hb)]
+    if a.kind in ("min", "max") and v.values.dtype.kind in "iuf":
+        ok = np.ones(n, bool) if valid is None else valid
+        is_f = v.values.dtype.kind == "f"
+        init = (np.inf if a.kind == "min" else -np.inf) if is_f else (np.iinfo(np.int64).max if a.kind == "min" else np.iinfo(np.int64).min)
+        acc = np.full(ng, init, np.float64 if is_f else np.int64)
+        vals_ok = v.values[ok].astype(acc.dtype)
+        (np.minimum if a.kind == "min" else np.maximum).at(acc, gid[ok], vals_ok)
+        hb = np.bincount(gid[ok], minlength=ng) > 0
+        return [Col(v.dtype, np.where(hb, acc, 0).astype(_np_dtype(S, v.dtype)), None if hb.all() else hb)]
     if a.kind in ("min", "max"):
         ok = np.ones(n, bool) if valid is None else valid
         res, has = [], []
