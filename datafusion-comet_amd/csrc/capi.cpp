@@ -185,3 +185,34 @@ int32_t comet_pmod_partition(const uint32_t* hashes, int64_t n, int32_t num_part
 const char* comet_version(void) { return "comet-mi355x 0.1.0 (gfx950)"; }
 
 }  // extern "C"
+
+// ---- Parquet footer description (host-only; used by tests to pin the Thrift/footer parser against pyarrow) ----
+#include <fstream>
+#include <iterator>
+
+#include "parquet_meta.hpp"
+extern "C" int32_t comet_parquet_describe(const char* path, char* out, size_t cap) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw CometError(std::string("cannot open ") + path);
+    std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    comet::pq::FileMeta fm = comet::pq::parse_footer(data.data(), data.size());
+    std::string s = "rows=" + std::to_string(fm.num_rows) + ";row_groups=" + std::to_string(fm.row_groups.size()) + ";schema=";
+    for (size_t i = 1; i < fm.schema.size(); i++)
+      s += fm.schema[i].name + ":" + std::to_string(fm.schema[i].type) + ":" + std::to_string(fm.schema[i].repetition) + ":" +
+           std::to_string(fm.schema[i].type_length) + ":" + std::to_string(fm.schema[i].precision) + ":" + std::to_string(fm.schema[i].scale) + ",";
+    for (auto& rg : fm.row_groups) {
+      s += ";rg=" + std::to_string(rg.num_rows) + "[";
+      for (auto& c : rg.columns)
+        s += std::to_string(c.codec) + ":" + std::to_string(c.num_values) + ":" + std::to_string(c.data_page_offset) + ":" +
+             std::to_string(c.dictionary_page_offset) + ":" + std::to_string(c.total_compressed) + ":" + std::to_string(c.total_uncompressed) + ",";
+      s += "]";
+    }
+    if (out && cap) {
+      size_t n = std::min(cap - 1, s.size());
+      memcpy(out, s.data(), n);
+      out[n] = 0;
+    }
+    return 0;
+  });
+}

@@ -1108,8 +1108,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   while (true) {
     chain.push_back(cur);
     if (cur->kind == OpKind::Scan) break;
-    if (cur->kind == OpKind::HashJoin) {
-      if (!source_types) throw CometError("internal: join source without a schema");
+    if (cur->kind == OpKind::HashJoin || cur->kind == OpKind::NativeScan) {
+      if (!source_types) throw CometError("internal: materialised source without a schema");
       break;
     }
     if (cur->kind == OpKind::Unsupported)

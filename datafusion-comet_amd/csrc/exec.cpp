@@ -273,18 +273,18 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
   std::function<void(const Operator&)> walk = [&](const Operator& op) {
     node_id_[&op] = (int)node_id_.size();
     if (op.kind == OpKind::Scan) scan_input_[&op] = scan_input_.size();
-    if (op.kind == OpKind::HashJoin) has_join_ = true;
+    if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan) has_join_ = true;   // sources materialised in HBM
     if (op.kind == OpKind::Unsupported)
       throw CometError(std::string("Operator ") + op_name(op.proto_tag) + " is not supported by the MI355X native engine");
     for (auto& c : op.children) walk(*c);
   };
   walk(*plan_);
-  if (scan_input_.empty()) throw CometError("Plan has no Scan leaf: only Scan-rooted pipelines are supported by the MI355X native engine");
+  if (scan_input_.empty() && !has_join_) throw CometError("Plan has no Scan leaf: only Scan-rooted pipelines are supported by the MI355X native engine");
   if (inputs_.size() != scan_input_.size())
     throw CometError("Plan has " + std::to_string(scan_input_.size()) + " Scan leaves but " + std::to_string(inputs_.size()) + " input streams were given");
   // the root chain ends at a Scan or at the first join below it
   root_source_ = plan_.get();
-  while (root_source_->kind != OpKind::Scan && root_source_->kind != OpKind::HashJoin) {
+  while (root_source_->kind != OpKind::Scan && root_source_->kind != OpKind::HashJoin && root_source_->kind != OpKind::NativeScan) {
     if (root_source_->children.size() != 1) throw CometError(std::string(op_name(root_source_->proto_tag)) + " expects exactly one child");
     root_source_ = root_source_->children[0].get();
   }
@@ -312,6 +312,13 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
 // Output schema of a sub-plan (no data needed): Scan fields, chain outputs, join = left ++ right (semi/anti: left)
 std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
   if (op.kind == OpKind::Scan) return op.scan_fields;
+  if (op.kind == OpKind::NativeScan) {
+    if (!op.partition_schema.empty()) throw CometError("Hive-partition columns are not supported by the GPU Parquet scan yet");
+    std::vector<DType> out;
+    for (auto& f : op.required_schema) out.push_back(f.dtype);
+    explain_ += "  parquet scan: " + std::to_string(op.files.size()) + " file(s), " + std::to_string(out.size()) + " column(s)\n";
+    return out;
+  }
   if (op.kind == OpKind::HashJoin) {
     if (op.children.size() != 2) throw CometError("HashJoin expects two children");
     std::vector<DType> l = infer_schema(*op.children[0]), r = infer_schema(*op.children[1]);
@@ -324,7 +331,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     return out;
   }
   const Operator* src = &op;
-  while (src->kind != OpKind::Scan && src->kind != OpKind::HashJoin) {
+  while (src->kind != OpKind::Scan && src->kind != OpKind::HashJoin && src->kind != OpKind::NativeScan) {
     if (src->children.size() != 1) throw CometError(std::string(op_name(src->proto_tag)) + " expects exactly one child");
     src = src->children[0].get();
   }
@@ -1257,6 +1264,11 @@ DevTable ExecutionContext::materialize(const Operator& op) {
     input_rows += t.rows;
     return t;
   }
+  if (op.kind == OpKind::NativeScan) {
+    DevTable t = scan_parquet(op);
+    input_rows += t.rows;
+    return t;
+  }
   if (op.kind == OpKind::HashJoin) {
     DevTable l = materialize(*op.children[0]);
     DevTable r = materialize(*op.children[1]);
@@ -1264,7 +1276,7 @@ DevTable ExecutionContext::materialize(const Operator& op) {
   }
   // Filter / Projection chain: fused over its source
   const Operator* src = &op;
-  while (src->kind != OpKind::Scan && src->kind != OpKind::HashJoin) src = src->children[0].get();
+  while (src->kind != OpKind::Scan && src->kind != OpKind::HashJoin && src->kind != OpKind::NativeScan) src = src->children[0].get();
   DevTable in = materialize(*src);
   DevTable out = run_chain_to_device(op, in);
   HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1276,14 +1288,24 @@ void ExecutionContext::table_to_host_batches(const DevTable& t) {
   if (t.rows == 0) return;
   const size_t ncol = t.cols.size();
   std::vector<std::vector<uint8_t>> hv(ncol), hb(ncol);
+  std::vector<std::vector<uint8_t>> hd(ncol);
   for (size_t j = 0; j < ncol; j++) {
     const DType& ty = t.types[j];
-    size_t bytes = ty.id == TypeId::Bool ? (size_t)((t.rows + 7) / 8) : (size_t)t.rows * fixed_width(ty);
+    const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
+    size_t bytes = is_str ? (size_t)(t.rows + 1) * 4 : ty.id == TypeId::Bool ? (size_t)((t.rows + 7) / 8) : (size_t)t.rows * fixed_width(ty);
     hv[j].resize(bytes);
     HIP_CHECK(hipMemcpyAsync(hv[j].data(), t.cols[j].data, bytes, hipMemcpyDeviceToHost, stream_));
     if (t.has_valid[j]) {
       hb[j].resize((size_t)((t.rows + 7) / 8));
       HIP_CHECK(hipMemcpyAsync(hb[j].data(), t.cols[j].valid, hb[j].size(), hipMemcpyDeviceToHost, stream_));
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  for (size_t j = 0; j < ncol; j++) {
+    if (t.types[j].id == TypeId::String || t.types[j].id == TypeId::Bytes) {
+      const int32_t* offs = (const int32_t*)hv[j].data();
+      hd[j].resize((size_t)offs[t.rows]);
+      if (!hd[j].empty()) HIP_CHECK(hipMemcpyAsync(hd[j].data(), t.cols[j].aux, hd[j].size(), hipMemcpyDeviceToHost, stream_));
     }
   }
   HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1298,7 +1320,13 @@ void ExecutionContext::table_to_host_batches(const DevTable& t) {
       HostColumn c;
       c.type = t.types[j];
       c.length = len;
-      if (c.type.id == TypeId::Bool) {
+      if (c.type.id == TypeId::String || c.type.id == TypeId::Bytes) {
+        const int32_t* offs = (const int32_t*)hv[j].data();
+        c.values.resize((size_t)(len + 1) * 4);
+        int32_t* o = (int32_t*)c.values.data();
+        for (int64_t i = 0; i <= len; i++) o[i] = offs[off + i] - offs[off];
+        c.data.assign(hd[j].begin() + offs[off], hd[j].begin() + offs[off + len]);
+      } else if (c.type.id == TypeId::Bool) {
         c.values.assign((size_t)((len + 7) / 8), 0);
         for (int64_t i = 0; i < len; i++)
           if (getbit(hv[j], off + i)) c.values[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
@@ -1441,6 +1469,7 @@ std::string ExecutionContext::metrics_proto() {
     MetricNode n;
     n.metrics.emplace_back("output_rows", root ? output_rows_ : 0);
     n.metrics.emplace_back("elapsed_compute", root ? (int64_t)elapsed_compute_ns_ : 0);
+    if (op.kind == OpKind::NativeScan) n.metrics.emplace_back("bytes_scanned", bytes_scanned_);
     for (auto& c : op.children) n.children.push_back(build(*c, false));
     return n;
   };

@@ -115,6 +115,7 @@ class ExecutionContext {
   void finish_grouped();
   std::vector<DType> infer_schema(const Operator& op);
   DevTable materialize(const Operator& op);
+  DevTable scan_parquet(const Operator& native_scan);
   DevTable run_chain_to_device(const Operator& top, const DevTable& in);
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
   DevTable outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals, const std::vector<std::shared_ptr<DevBuf>>& valid_bytes,
@@ -156,6 +157,7 @@ class ExecutionContext {
   std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)
   std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index
   int64_t join_build_rows_ = 0, join_probe_rows_ = 0;
+  int64_t bytes_scanned_ = 0;
 
   std::vector<std::unique_ptr<Staging>> staging_;   // per input stream
 

@@ -1,0 +1,52 @@
+/* Tables handed to the Parquet decode kernels (host builds them from page/run HEADERS only; every value is
+ * decoded on the device). */
+#ifndef COMET_PARQUET_DEV_H
+#define COMET_PARQUET_DEV_H
+#include <stdint.h>
+
+typedef struct PqPage {        /* one data page of a column chunk */
+  int64_t row_start;           /* first row of the page within the column chunk (flat columns: values == rows) */
+  int64_t values_off;          /* staged-byte offset of the PLAIN values, or of the hybrid-encoded dictionary indices */
+  int64_t str_first;           /* PLAIN BYTE_ARRAY pages: index of the page's first value in the string offset table */
+  int32_t num_values;
+  int32_t encoding;            /* 0 PLAIN, 1 dictionary indices (RLE/bit-packed hybrid) */
+  int32_t bit_width;           /* dictionary index width */
+  int32_t def_run_first, def_run_count;   /* definition-level runs (count 0: every value valid) */
+  int32_t idx_run_first, idx_run_count;   /* dictionary-index runs */
+  int32_t pad;
+} PqPage;
+
+typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section */
+  int64_t byte_off;            /* bit-packed: staged-byte offset of the run's first group */
+  int32_t value_start;         /* index of the run's first value within its page section */
+  int32_t count;
+  int32_t is_rle;
+  uint32_t rle_value;
+} PqRun;
+
+/* output conversions */
+enum { PQ_COPY4 = 0, PQ_COPY8 = 1, PQ_I32_TO_I64 = 2, PQ_I32_TO_DEC = 3, PQ_I64_TO_DEC = 4, PQ_FLBA_TO_DEC = 5, PQ_BOOL = 6,
+       PQ_I32_TO_I16 = 7, PQ_I32_TO_I8 = 8 };
+
+typedef struct PqDecodeArgs {
+  const PqPage* pages;
+  int32_t npages;
+  int32_t max_def;             /* 0 = required column */
+  const PqRun* def_runs;
+  const PqRun* idx_runs;
+  const uint8_t* bytes;        /* staged, decompressed page bodies of the column chunk */
+  const uint8_t* dict;         /* PLAIN dictionary values (fixed width) or dictionary string bytes */
+  const int32_t* dict_offs;    /* strings: dictionary offsets (n_dict + 1) */
+  const int64_t* plain_str_offs; /* PLAIN BYTE_ARRAY data pages: staged-byte offset of each value's bytes (+1 sentinel per page) */
+  int64_t n_rows;              /* rows of this column chunk */
+  int32_t kind;                /* PQ_* conversion */
+  int32_t width;               /* source value width in bytes (FLBA length, 4, 8) */
+  uint8_t* valid_out;          /* per-row validity bytes (at the chunk's row offset) */
+  uint32_t* vidx;              /* per-row exclusive count of non-null rows before it (scratch) */
+  void* values_out;            /* typed output at the chunk's row offset */
+  uint32_t* lengths_out;       /* strings: per-row byte length */
+  const int32_t* str_offsets;  /* strings (copy phase): output offsets at the chunk's row offset */
+  uint8_t* str_bytes_out;      /* strings (copy phase): output data buffer */
+} PqDecodeArgs;
+
+#endif

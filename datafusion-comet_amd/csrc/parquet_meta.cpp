@@ -1,0 +1,347 @@
+#include "parquet_meta.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "plan.hpp"
+
+namespace comet {
+namespace pq {
+
+namespace {
+
+// ---- Thrift compact protocol reader -------------------------------------------------------------
+struct TReader {
+  const uint8_t* p;
+  const uint8_t* end;
+  TReader(const uint8_t* d, size_t n) : p(d), end(d + n) {}
+  uint8_t byte() {
+    if (p >= end) throw CometError("parquet: truncated thrift data");
+    return *p++;
+  }
+  uint64_t varint() {
+    uint64_t v = 0;
+    int sh = 0;
+    while (true) {
+      uint8_t b = byte();
+      v |= (uint64_t)(b & 0x7f) << sh;
+      if (!(b & 0x80)) return v;
+      sh += 7;
+      if (sh > 63) throw CometError("parquet: bad varint");
+    }
+  }
+  int64_t zigzag() {
+    uint64_t u = varint();
+    return (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
+  }
+  std::string binary() {
+    uint64_t n = varint();
+    if ((uint64_t)(end - p) < n) throw CometError("parquet: truncated thrift binary");
+    std::string s((const char*)p, (size_t)n);
+    p += n;
+    return s;
+  }
+  // returns field type (0 = STOP); updates field id
+  int field(int16_t& fid) {
+    uint8_t h = byte();
+    if (h == 0) return 0;
+    int type = h & 0x0f;
+    int delta = h >> 4;
+    if (delta == 0) fid = (int16_t)zigzag();
+    else fid = (int16_t)(fid + delta);
+    return type;
+  }
+  void list_header(int& elem_type, uint32_t& size) {
+    uint8_t h = byte();
+    elem_type = h & 0x0f;
+    size = h >> 4;
+    if (size == 15) size = (uint32_t)varint();
+  }
+  void skip(int type) {
+    switch (type) {
+      case 1: case 2: break;                 // bool encoded in the field header
+      case 3: byte(); break;
+      case 4: case 5: case 6: zigzag(); break;
+      case 7: if (end - p < 8) throw CometError("parquet: truncated double"); p += 8; break;
+      case 8: binary(); break;
+      case 9: case 10: {
+        int et;
+        uint32_t n;
+        list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) {
+          if (et == 1 || et == 2) byte();     // bools in lists take a byte each
+          else skip(et);
+        }
+        break;
+      }
+      case 11: {
+        uint64_t n = varint();
+        if (n) {
+          uint8_t kv = byte();
+          for (uint64_t i = 0; i < n; i++) { skip(kv >> 4); skip(kv & 0x0f); }
+        }
+        break;
+      }
+      case 12: {
+        int16_t fid = 0;
+        while (int t = field(fid)) skip(t);
+        break;
+      }
+      default: throw CometError("parquet: unknown thrift type " + std::to_string(type));
+    }
+  }
+};
+
+SchemaElement read_schema_element(TReader& r) {
+  SchemaElement e;
+  int16_t fid = 0;
+  while (int t = r.field(fid)) {
+    switch (fid) {
+      case 1: e.type = (int)r.zigzag(); break;
+      case 2: e.type_length = (int)r.zigzag(); break;
+      case 3: e.repetition = (int)r.zigzag(); break;
+      case 4: e.name = r.binary(); break;
+      case 5: e.num_children = (int)r.zigzag(); break;
+      case 6: e.converted_type = (int)r.zigzag(); break;
+      case 7: e.scale = (int)r.zigzag(); break;
+      case 8: e.precision = (int)r.zigzag(); break;
+      default: r.skip(t);
+    }
+  }
+  return e;
+}
+
+ColumnMeta read_column_meta(TReader& r) {
+  ColumnMeta m;
+  int16_t fid = 0;
+  while (int t = r.field(fid)) {
+    switch (fid) {
+      case 1: m.type = (int)r.zigzag(); break;
+      case 3: {
+        int et;
+        uint32_t n;
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) m.path.push_back(r.binary());
+        break;
+      }
+      case 4: m.codec = (int)r.zigzag(); break;
+      case 5: m.num_values = r.zigzag(); break;
+      case 6: m.total_uncompressed = r.zigzag(); break;
+      case 7: m.total_compressed = r.zigzag(); break;
+      case 9: m.data_page_offset = r.zigzag(); break;
+      case 11: m.dictionary_page_offset = r.zigzag(); break;
+      default: r.skip(t);
+    }
+  }
+  return m;
+}
+
+RowGroup read_row_group(TReader& r) {
+  RowGroup g;
+  int16_t fid = 0;
+  while (int t = r.field(fid)) {
+    switch (fid) {
+      case 1: {
+        int et;
+        uint32_t n;
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) {
+          // ColumnChunk { 1 file_path, 2 file_offset, 3 meta_data }
+          int16_t f2 = 0;
+          ColumnMeta cm;
+          while (int t2 = r.field(f2)) {
+            if (f2 == 3 && t2 == 12) cm = read_column_meta(r);
+            else r.skip(t2);
+          }
+          g.columns.push_back(std::move(cm));
+        }
+        break;
+      }
+      case 2: g.total_byte_size = r.zigzag(); break;
+      case 3: g.num_rows = r.zigzag(); break;
+      case 6: g.total_compressed = r.zigzag(); break;
+      default: r.skip(t);
+    }
+  }
+  return g;
+}
+
+// ---- snappy (raw format) — https://github.com/google/snappy/blob/main/format_description.txt -------
+void snappy_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_len) {
+  size_t i = 0;
+  uint64_t ulen = 0;
+  int sh = 0;
+  while (true) {
+    if (i >= n) throw CometError("snappy: truncated preamble");
+    uint8_t b = src[i++];
+    ulen |= (uint64_t)(b & 0x7f) << sh;
+    if (!(b & 0x80)) break;
+    sh += 7;
+  }
+  if (ulen != dst_len) throw CometError("snappy: uncompressed length mismatch");
+  size_t o = 0;
+  while (i < n) {
+    uint8_t tag = src[i++];
+    uint32_t len, off;
+    switch (tag & 3) {
+      case 0: {
+        len = (tag >> 2) + 1;
+        if (len > 60) {
+          uint32_t nb = len - 60;
+          if (i + nb > n) throw CometError("snappy: truncated literal length");
+          len = 0;
+          for (uint32_t k = 0; k < nb; k++) len |= (uint32_t)src[i + k] << (8 * k);
+          len += 1;
+          i += nb;
+        }
+        if (i + len > n || o + len > dst_len) throw CometError("snappy: literal overruns buffer");
+        memcpy(dst + o, src + i, len);
+        i += len;
+        o += len;
+        continue;
+      }
+      case 1:
+        len = ((tag >> 2) & 7) + 4;
+        if (i >= n) throw CometError("snappy: truncated copy");
+        off = ((uint32_t)(tag >> 5) << 8) | src[i++];
+        break;
+      case 2:
+        len = (tag >> 2) + 1;
+        if (i + 2 > n) throw CometError("snappy: truncated copy");
+        off = src[i] | ((uint32_t)src[i + 1] << 8);
+        i += 2;
+        break;
+      default:
+        len = (tag >> 2) + 1;
+        if (i + 4 > n) throw CometError("snappy: truncated copy");
+        off = src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16) | ((uint32_t)src[i + 3] << 24);
+        i += 4;
+    }
+    if (off == 0 || off > o || o + len > dst_len) throw CometError("snappy: bad copy");
+    for (uint32_t k = 0; k < len; k++) dst[o + k] = dst[o + k - off];  // may overlap: byte by byte
+    o += len;
+  }
+  if (o != dst_len) throw CometError("snappy: short output");
+}
+
+typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
+typedef unsigned (*zstd_iserror_fn)(size_t);
+
+}  // namespace
+
+FileMeta parse_footer(const uint8_t* file, size_t size) {
+  if (size < 12 || memcmp(file + size - 4, "PAR1", 4) != 0 || memcmp(file, "PAR1", 4) != 0)
+    throw CometError("not a Parquet file (missing PAR1 magic; encrypted footers are not supported)");
+  uint32_t mlen;
+  memcpy(&mlen, file + size - 8, 4);
+  if ((size_t)mlen + 8 > size) throw CometError("parquet: bad footer length");
+  TReader r(file + size - 8 - mlen, mlen);
+  FileMeta fm;
+  int16_t fid = 0;
+  while (int t = r.field(fid)) {
+    switch (fid) {
+      case 2: {
+        int et;
+        uint32_t n;
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) fm.schema.push_back(read_schema_element(r));
+        break;
+      }
+      case 3: fm.num_rows = r.zigzag(); break;
+      case 4: {
+        int et;
+        uint32_t n;
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) fm.row_groups.push_back(read_row_group(r));
+        break;
+      }
+      default: r.skip(t);
+    }
+  }
+  return fm;
+}
+
+PageHeader parse_page_header(const uint8_t* p, size_t avail) {
+  TReader r(p, avail);
+  PageHeader h;
+  int16_t fid = 0;
+  while (int t = r.field(fid)) {
+    switch (fid) {
+      case 1: h.type = (int)r.zigzag(); break;
+      case 2: h.uncompressed_size = (int32_t)r.zigzag(); break;
+      case 3: h.compressed_size = (int32_t)r.zigzag(); break;
+      case 5: {  // DataPageHeader
+        int16_t f2 = 0;
+        while (int t2 = r.field(f2)) {
+          switch (f2) {
+            case 1: h.num_values = (int32_t)r.zigzag(); break;
+            case 2: h.encoding = (int)r.zigzag(); break;
+            case 3: h.def_encoding = (int)r.zigzag(); break;
+            case 4: h.rep_encoding = (int)r.zigzag(); break;
+            default: r.skip(t2);
+          }
+        }
+        break;
+      }
+      case 7: {  // DictionaryPageHeader
+        int16_t f2 = 0;
+        while (int t2 = r.field(f2)) {
+          switch (f2) {
+            case 1: h.num_values = (int32_t)r.zigzag(); break;
+            case 2: h.encoding = (int)r.zigzag(); break;
+            default: r.skip(t2);
+          }
+        }
+        break;
+      }
+      case 8: {  // DataPageHeaderV2
+        int16_t f2 = 0;
+        while (int t2 = r.field(f2)) {
+          switch (f2) {
+            case 1: h.num_values = (int32_t)r.zigzag(); break;
+            case 2: h.num_nulls = (int32_t)r.zigzag(); break;
+            case 3: h.num_rows = (int32_t)r.zigzag(); break;
+            case 4: h.encoding = (int)r.zigzag(); break;
+            case 5: h.def_bytes = (int32_t)r.zigzag(); break;
+            case 6: h.rep_bytes = (int32_t)r.zigzag(); break;
+            case 7: h.v2_compressed = (t2 == 1); break;
+            default: r.skip(t2);
+          }
+        }
+        break;
+      }
+      default: r.skip(t);
+    }
+  }
+  h.header_len = (size_t)(r.p - p);
+  return h;
+}
+
+void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) {
+  switch (codec) {
+    case UNCOMPRESSED:
+      if (src_len != dst_len) throw CometError("parquet: uncompressed page size mismatch");
+      memcpy(dst, src, dst_len);
+      return;
+    case SNAPPY: snappy_decompress(src, src_len, dst, dst_len); return;
+    case ZSTD: {
+      static zstd_decompress_fn fn = nullptr;
+      static zstd_iserror_fn iserr = nullptr;
+      if (!fn) {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) throw CometError("parquet: zstd pages need libzstd.so.1, which could not be loaded");
+        fn = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
+        iserr = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+        if (!fn || !iserr) throw CometError("parquet: libzstd.so.1 lacks ZSTD_decompress");
+      }
+      size_t rc = fn(dst, dst_len, src, src_len);
+      if (iserr(rc) || rc != dst_len) throw CometError("parquet: zstd decompression failed");
+      return;
+    }
+    default: throw CometError("parquet: compression codec " + std::to_string(codec) + " is not supported yet (UNCOMPRESSED, SNAPPY, ZSTD are)");
+  }
+}
+
+}  // namespace pq
+}  // namespace comet

@@ -1,0 +1,67 @@
+// Parquet footer / page-header parsing (Thrift compact protocol, hand-written: no thrift or parquet library in
+// this image) and host-side page preparation for the device decoder.
+// The reference delegates this to the `parquet` 58.4.0 crate through DataFusion's ParquetSource
+// (native/core/src/parquet/parquet_exec.rs:60-211); the format itself is the public Apache Parquet spec.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace comet {
+namespace pq {
+
+enum PhysType : int { BOOLEAN = 0, INT32 = 1, INT64 = 2, INT96 = 3, FLOAT = 4, DOUBLE = 5, BYTE_ARRAY = 6, FLBA = 7 };
+enum Encoding : int { PLAIN = 0, PLAIN_DICTIONARY = 2, RLE = 3, BIT_PACKED = 4, RLE_DICTIONARY = 8 };
+enum Codec : int { UNCOMPRESSED = 0, SNAPPY = 1, GZIP = 2, LZO = 3, BROTLI = 4, LZ4 = 5, ZSTD = 6, LZ4_RAW = 7 };
+enum PageType : int { DATA_PAGE = 0, INDEX_PAGE = 1, DICTIONARY_PAGE = 2, DATA_PAGE_V2 = 3 };
+
+struct SchemaElement {
+  int type = -1;          // PhysType, -1 for groups
+  int type_length = 0;
+  int repetition = 0;     // 0 required, 1 optional, 2 repeated
+  std::string name;
+  int num_children = 0;
+  int converted_type = -1;
+  int scale = 0, precision = 0;
+};
+
+struct ColumnMeta {
+  int type = 0;
+  std::vector<std::string> path;
+  int codec = 0;
+  int64_t num_values = 0;
+  int64_t total_uncompressed = 0, total_compressed = 0;
+  int64_t data_page_offset = 0, dictionary_page_offset = 0;
+};
+
+struct RowGroup {
+  std::vector<ColumnMeta> columns;
+  int64_t total_byte_size = 0, num_rows = 0, total_compressed = 0;
+};
+
+struct FileMeta {
+  std::vector<SchemaElement> schema;   // depth-first, element 0 = root
+  int64_t num_rows = 0;
+  std::vector<RowGroup> row_groups;
+};
+
+struct PageHeader {
+  int type = -1;
+  int32_t uncompressed_size = 0, compressed_size = 0;
+  int32_t num_values = 0;
+  int encoding = 0;
+  int def_encoding = 0, rep_encoding = 0;
+  // v2
+  int32_t num_nulls = 0, num_rows = 0, def_bytes = 0, rep_bytes = 0;
+  bool v2_compressed = true;
+  size_t header_len = 0;   // bytes consumed by the thrift header
+};
+
+FileMeta parse_footer(const uint8_t* file, size_t size);
+PageHeader parse_page_header(const uint8_t* p, size_t avail);
+
+// decompress one page body; throws CometError for unsupported codecs
+void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len);
+
+}  // namespace pq
+}  // namespace comet

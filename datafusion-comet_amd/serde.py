@@ -306,7 +306,11 @@ class Operator:
     build_side: int = 0
     condition: Optional[Expr] = None
 
-    TAGS = dict(scan=100, projection=101, filter=102, hash_agg=104, hash_join=109)
+    # native_scan
+    field_names: List[str] = field(default_factory=list)
+    files: List[tuple] = field(default_factory=list)          # (path, start, length, file_size)
+
+    TAGS = dict(scan=100, projection=101, filter=102, hash_agg=104, hash_join=109, native_scan=111)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -323,6 +327,22 @@ class Operator:
             body += b"".join(_f_msg(2, a.encode()) for a in self.aggs)
             if self.mode:
                 body += _f_varint(5, self.mode)
+        elif self.kind == "native_scan":
+            # NativeScan{common=1 NativeScanCommon{required_schema=1,data_schema=2,projection_vector=5,session_timezone=6,
+            # case_sensitive=9,source=12,fields=13}, file_partition=2 SparkFilePartition{partitioned_file=1}} (operator.proto:103-190)
+            sf = lambda n, t: _f_bytes(1, n.encode()) + _f_msg(2, t.encode()) + _f_varint(3, 1)
+            common = b"".join(_f_msg(1, sf(n, t)) for n, t in zip(self.field_names, self.fields))
+            common += b"".join(_f_msg(2, sf(n, t)) for n, t in zip(self.field_names, self.fields))
+            common += b"".join(_f_varint(5, i) for i in range(len(self.fields)))
+            common += _f_bytes(6, b"UTC") + _f_varint(9, 1) + _f_bytes(12, b"parquet") + b"".join(_f_msg(13, t.encode()) for t in self.fields)
+            part = b""
+            for path, start, length, size in self.files:
+                pf = _f_bytes(1, ("file://" + path).encode())
+                if start:
+                    pf += _f_varint(2, start)
+                pf += _f_varint(3, length) + _f_varint(4, size)
+                part += _f_msg(1, pf)
+            body = _f_msg(1, common) + _f_msg(2, part)
         elif self.kind == "hash_join":
             # HashJoin{left_join_keys=1,right_join_keys=2,join_type=3,condition=4,build_side=5} (operator.proto:754-763)
             body = b"".join(_f_msg(1, e.encode()) for e in self.left_keys) + b"".join(_f_msg(2, e.encode()) for e in self.right_keys)
@@ -353,6 +373,19 @@ def project(child: Operator, exprs: Sequence[Expr]) -> Operator:
 
 def hash_agg(child: Operator, grouping: Sequence[Expr], aggs: Sequence[AggExpr], mode: int = PARTIAL) -> Operator:
     return Operator("hash_agg", [child], exprs=list(grouping), aggs=list(aggs), mode=mode)
+
+
+def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType]) -> Operator:
+    """Parquet scan of `files` (paths, or (path, start, length, size) byte-range splits) producing columns `names`."""
+    import os
+    fl = []
+    for f in files:
+        if isinstance(f, str):
+            sz = os.path.getsize(f)
+            fl.append((f, 0, sz, sz))
+        else:
+            fl.append(tuple(f))
+    return Operator("native_scan", fields=list(types), field_names=list(names), files=fl)
 
 
 INNER, LEFT_OUTER, RIGHT_OUTER, FULL_OUTER, LEFT_SEMI, LEFT_ANTI = range(6)

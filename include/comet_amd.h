@@ -87,6 +87,11 @@ int32_t comet_murmur3_column(int32_t type_id, int32_t precision, const void* val
 int32_t comet_pmod_partition(const uint32_t* hashes, int64_t n, int32_t num_partitions, int32_t* partition_ids,
                              void* hip_stream);
 
+/* Host-only description of a Parquet footer as parsed by the library's own Thrift reader (rows, row groups, schema
+ * elements, per-chunk codec/offsets) — the metadata the NativeScan path (native/core/src/parquet/parquet_exec.rs:60-211)
+ * plans from.  Returns 0, or -2 on error. */
+int32_t comet_parquet_describe(const char* path, char* out, size_t cap);
+
 /* Library identity (NativeBase.java:82-106 loads "comet"). */
 const char* comet_version(void);
 

@@ -392,6 +392,8 @@ def _take(c: Col, idx: np.ndarray) -> Col:
 def run_plan(S, op, table) -> List[Col]:
     """Evaluate the operator tree.  `table` is the Scan input, or a list of tables consumed by the Scan leaves in
     depth-first, left-before-right order (planner.rs:1726).  Returns the output columns."""
+    if table is None:
+        table = []
     if isinstance(table, pa.Table):
         table = [table]
     if not isinstance(table, _ScanQueue):
@@ -401,6 +403,24 @@ def run_plan(S, op, table) -> List[Col]:
     if k == "scan":
         t = table.pop()
         assert t.num_columns == len(op.fields)
+        return [col_from_arrow(S, t.column(i), ty) for i, ty in enumerate(op.fields)]
+    if k == "native_scan":
+        # independent decoder: Arrow C++ / parquet-cpp through pyarrow (parity for K18 is pinned on it)
+        import pyarrow.parquet as papq
+        parts = []
+        for path, start, length, size in op.files:
+            pf = papq.ParquetFile(path)
+            md = pf.metadata
+            for g in range(md.num_row_groups):
+                rg = md.row_group(g)
+                c0 = rg.column(0)
+                first = c0.dictionary_page_offset if (c0.has_dictionary_page and c0.dictionary_page_offset < c0.data_page_offset) else c0.data_page_offset
+                comp = sum(rg.column(i).total_compressed_size for i in range(rg.num_columns))
+                mid = first + comp // 2
+                if start <= mid < start + length:
+                    parts.append(pf.read_row_group(g, columns=list(op.field_names)))
+        t = pa.concat_tables(parts) if parts else pa.table({n: pa.array([], type=pa.null()) for n in op.field_names})
+        t = t.select(list(op.field_names))
         return [col_from_arrow(S, t.column(i), ty) for i, ty in enumerate(op.fields)]
     if k == "hash_join":
         left = run_plan(S, op.children[0], table)
