@@ -185,6 +185,7 @@ struct Gen {
   std::map<const Expr*, std::string> keymemo;
   std::map<int, Val> col_cache;
   bool uses_err = false;
+  std::vector<int> str_fixed_len;   // per input column: uniform Utf8 length verified by the executor, -1 = variable
   bool eager_loads = false;   // hoist every column load into the first stage (no lazy loading after predicates)
   // where column `idx` lives: kernel-argument slot and row expression (joins read two tables with different rows)
   std::function<std::pair<int, std::string>(int)> locate = [](int idx) { return std::make_pair(idx, std::string("idx[r]")); };
@@ -196,6 +197,18 @@ struct Gen {
   std::string newvar(const char* ctype) {
     std::string n = "x" + std::to_string(nvar++);
     decls += std::string("    ") + ctype + " " + n + "[R];\n";
+    return n + "[r]";
+  }
+  // Software pipelining: variables loaded in the FIRST stage live in a struct `L` that the kernel template fills for
+  // tile t+1 before it computes tile t (loads stay in flight across the whole compute phase).
+  bool pipelined = false;
+  std::string ldecls, laliases;
+  bool load_targets_front() const { return eager_loads || stages.size() == 1; }
+  std::string newloadvar(const char* ctype) {
+    if (!pipelined || !load_targets_front()) return newvar(ctype);
+    std::string n = "x" + std::to_string(nvar++);
+    ldecls += std::string("    ") + ctype + " " + n + "[R];\n";
+    laliases += "    auto& " + n + " = ld." + n + ";\n";
     return n + "[r]";
   }
   void stmt(const std::string& s) { stages.back().body += "      " + s + "\n"; }
@@ -249,7 +262,7 @@ struct Gen {
     auto loc = locate(idx);
     std::string c = "prm.in[" + std::to_string(loc.first) + "]";
     const std::string row = loc.second;
-    std::string n = newvar(rep_ctype(x.rep));
+    std::string n = newloadvar(rep_ctype(x.rep));
     std::string ldx;
     switch (t.id) {
       case TypeId::Bool: ldx = "comet::ld_bool(" + c + ", " + row + ")"; break;
@@ -263,6 +276,10 @@ struct Gen {
         ldx = t.precision <= 18 ? "comet::ld_dec_lo(" + c + ", " + row + ")" : "comet::ld<i128>(" + c + ", " + row + ")";
         break;
       case TypeId::String:
+        if ((size_t)idx < str_fixed_len.size() && str_fixed_len[idx] >= 0 && str_fixed_len[idx] <= 15) {
+          ldx = "comet::ld_str_fixed<" + std::to_string(str_fixed_len[idx]) + ">(" + c + ", " + row + ")";
+          break;
+        }
         // ≤15-byte strings travel packed (str16); a longer value raises error bit 64 → explicit "not supported yet"
         uses_err = true;
         ldx = "";
@@ -274,7 +291,7 @@ struct Gen {
     if (!ldx.empty()) load(n + " = " + ldx + ";");
     x.v = n;
     if (in_valid[idx]) {
-      std::string o = newvar("bool");
+      std::string o = newloadvar("bool");
       load(o + " = comet::ld_valid(" + c + ", " + row + ");");
       x.ok = o;
     }
@@ -487,6 +504,22 @@ struct Gen {
       r.wide_decimal = true;
       a = named(a);
       b = named(b);
+      if (mul && s1 + s2 == s_out && (a.rep != Rep::I128 || b.rep != Rep::I128)) {
+        // one factor fits in 64 bits and no rescale: 128×64 product with the bound check fused
+        const Val& w = a.rep == Rep::I128 ? a : b;
+        const Val& n64 = a.rep == Rep::I128 ? b : a;
+        std::string val = newvar("i128"), fit = newvar("bool");
+        stmt(fit + " = comet::i128_mul_i64_fits(" + as128(w) + ", (i64)" + n64.v + ", " + lit_u128(bound) + ", " + val + ");");
+        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, "!" + fit), 0);
+        else {
+          std::string o = newvar("bool");
+          stmt(o + " = " + and_ok(r.ok, fit) + ";");
+          r.ok = o;
+        }
+        r.v = val;
+        r.maxabs = bound;
+        return r;
+      }
       std::string raw = newvar("comet::i256");
       int scale_diff;
       if (mul) {
@@ -873,11 +906,34 @@ struct Gen {
   }
 
   // assemble the staged body: every stage is a load loop followed by a compute loop over the R rows
-  std::string body(const std::string& indent_unused = "") const {
+  // the stage-0 load loop alone (writes ld.xN), for the prefetch half of a pipelined tile
+  std::string prefetch_body() const {
+    std::string l = stages.front().loads, out;
+    // "xN[r] = …" → "ld.xN[r] = …" (only at statement starts / inside the string-load block)
+    size_t pos = 0;
+    while (pos < l.size()) {
+      size_t e = l.find('\n', pos);
+      std::string line = l.substr(pos, e == std::string::npos ? std::string::npos : e - pos + 1);
+      size_t a = line.find_first_not_of(' ');
+      if (a != std::string::npos && line[a] == 'x') line.insert(a, "ld.");
+      else {
+        size_t b = line.find("; x");   // "{ bool tl_ = false; xN[r] = comet::ld_str16(…"
+        if (b != std::string::npos) line.insert(b + 2, "ld.");
+      }
+      out += line;
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+    return "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) if (k[r]) {\n" + out + "    }\n";
+  }
+  std::string body(const std::string& indent_unused = "", bool skip_front_loads = false) const {
     (void)indent_unused;
     std::string s;
+    bool first = true;
     for (auto& st : stages) {
-      if (!st.loads.empty()) {
+      const bool skip = skip_front_loads && first;
+      first = false;
+      if (!st.loads.empty() && !skip) {
         s += "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) if (k[r]) {\n" + st.loads + "    }\n";
       }
       if (!st.body.empty()) {
@@ -1101,7 +1157,8 @@ std::string explain_expr(const ExprP& e) {
 // ---------------------------------------------------------------------------------------------
 // generate_pipeline
 // ---------------------------------------------------------------------------------------------
-PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity, const std::vector<DType>* source_types) {
+PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity, const std::vector<DType>* source_types,
+                               const std::vector<int>* str_fixed_len) {
   // 1. walk root → leaf collecting the chain; the chain ends at a Scan or at a materialised source (a join's output)
   std::vector<const Operator*> chain;
   const Operator* cur = &root;
@@ -1182,7 +1239,10 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
 
   Gen g(d.in_types, in_has_validity);
+  if (str_fixed_len) g.str_fixed_len = *str_fixed_len;
   if (const char* e = getenv("COMET_GEN_EAGER")) g.eager_loads = atoi(e) != 0;
+  g.pipelined = agg != nullptr;   // aggregate sinks prefetch tile t+1's first-stage columns while computing tile t
+  if (const char* e = getenv("COMET_GEN_PIPELINE")) g.pipelined = g.pipelined && atoi(e) != 0;
   for (auto& p : preds) g.add_predicate(p);
 
   std::ostringstream src;
@@ -1201,6 +1261,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     std::vector<Val> outs;
     // outputs are evaluated in the emit kernel (per surviving row); predicates in the mask kernel.
     Gen ge(d.in_types, in_has_validity);
+    if (str_fixed_len) ge.str_fixed_len = *str_fixed_len;
     for (auto& c : cols) {
       Val v = ge.named(ge.gen(c));
       outs.push_back(v);
@@ -1677,10 +1738,16 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   src << "  static __device__ __forceinline__ void init(u64* a) {\n" << al.init_code << "  }\n";
   src << "  static __device__ __forceinline__ void combine(u64* a, const u64* b) {\n" << al.combine_code << "  }\n";
   if (!grouped) {
-    src << "  static __device__ __forceinline__ void tile(const CometKParams& prm, i64 base, i64 n, u64* acc) {\n"
-        << "    bool k[R]; i64 idx[R];\n"
-        << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n"
-        << g.decls << g.body() << "  }\n";
+    const std::string rowinit = "    bool k[R]; i64 idx[R];\n    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n";
+    src << "  static constexpr bool PIPELINED = " << (g.pipelined ? "true" : "false") << ";\n";
+    if (g.pipelined) {
+      src << "  struct L {\n" << g.ldecls << "  };\n";
+      src << "  static __device__ __forceinline__ void tile_load(const CometKParams& prm, i64 base, i64 n, L& ld) {\n" << rowinit << g.prefetch_body() << "  }\n";
+      src << "  static __device__ __forceinline__ void tile(const CometKParams& prm, i64 base, i64 n, L& ld, u64* acc) {\n" << rowinit << g.laliases
+          << g.decls << g.body("", true) << "  }\n";
+    } else {
+      src << "  static __device__ __forceinline__ void tile(const CometKParams& prm, i64 base, i64 n, u64* acc) {\n" << rowinit << g.decls << g.body() << "  }\n";
+    }
     src << "  static __device__ __forceinline__ void finalize(const CometKParams& prm, const u64* acc) {\n" << fin << "  }\n};\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg(const CometKParams prm) { comet::agg_nogroup_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg_final(const CometKParams prm) { comet::agg_nogroup_final_body<P>(prm); }\n";
@@ -1711,12 +1778,19 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     emit_switch("int kop(int k)", al.kops, "comet::", "comet::G_OR64");
     src << "  static __device__ __forceinline__ void kinit(u64* kacc) { for (int k = 0; k < (NKW > 0 ? NKW : 1); k++) kacc[k] = 0; }\n";
     src << "  static __device__ __forceinline__ void fold(const u64* pw, u64* val) {\n" << al.fold_code << "  }\n";
-    src << "  static __device__ __forceinline__ void tile_grouped(const CometKParams& prm, i64 base, i64 n, const comet::GroupCtx<P>& grp, u64* kacc) {\n"
-        << "    bool k[R]; i64 idx[R];\n"
-        << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n"
-        << g.decls << g.body()
-        << "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) {\n      if (k[r]) {\n        u64 key[NK]; u64 pv[NPW];\n"
-        << key_code << al.pv_code << al.kfeed_code << "        comet::group_update<P>(grp, true, key, pv);\n      }\n    }\n  }\n";
+    const std::string rowinit = "    bool k[R]; i64 idx[R];\n    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n";
+    const std::string update = "    _Pragma(\"unroll\") for (int r = 0; r < R; r++) {\n      if (k[r]) {\n        u64 key[NK]; u64 pv[NPW];\n" + key_code + al.pv_code +
+                               al.kfeed_code + "        comet::group_update<P>(grp, true, key, pv);\n      }\n    }\n  }\n";
+    src << "  static constexpr bool PIPELINED = " << (g.pipelined ? "true" : "false") << ";\n";
+    if (g.pipelined) {
+      src << "  struct L {\n" << g.ldecls << "  };\n";
+      src << "  static __device__ __forceinline__ void tile_load(const CometKParams& prm, i64 base, i64 n, L& ld) {\n" << rowinit << g.prefetch_body() << "  }\n";
+      src << "  static __device__ __forceinline__ void tile_grouped(const CometKParams& prm, i64 base, i64 n, L& ld, const comet::GroupCtx<P>& grp, u64* kacc) {\n"
+          << rowinit << g.laliases << g.decls << g.body("", true) << update;
+    } else {
+      src << "  static __device__ __forceinline__ void tile_grouped(const CometKParams& prm, i64 base, i64 n, const comet::GroupCtx<P>& grp, u64* kacc) {\n"
+          << rowinit << g.decls << g.body() << update;
+    }
     src << "  static __device__ __forceinline__ void emit_group(const CometKParams& prm, const u64* key, const u64* acc, i64 pos) {\n"
         << key_emit << fin << "  }\n};\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_gagg(const CometKParams prm) { comet::agg_grouped_body<P>(prm); }\n";

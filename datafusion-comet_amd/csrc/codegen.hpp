@@ -42,7 +42,7 @@ struct PipelineDesc {
 // `in_has_validity[i]` tells whether input column i arrives with a validity bitmap in this batch
 // chunk; kernels are specialised on it.  Throws CometError for unsupported plans.
 PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity,
-                               const std::vector<DType>* source_types = nullptr);
+                               const std::vector<DType>* source_types = nullptr, const std::vector<int>* str_fixed_len = nullptr);
 
 // Hash join of two materialised tables (left/right = the join's children in plan order).
 PipelineDesc generate_join(const Operator& join, const std::vector<DType>& left_types, const std::vector<DType>& right_types,

@@ -85,6 +85,25 @@ CDEV str16 ld_str16(const CometCol& c, i64 i, bool& toolong) {
   return r;
 }
 
+// Utf8 column whose values all have the same length LEN (≤ 15; verified by the executor before this variant is
+// chosen): the bytes of row i sit at aux + (offset + i)·LEN, so neither the int32 offsets nor a dependent load is
+// needed (TPC-H flag/status columns: LEN = 1).
+template <int LEN>
+CDEV str16 ld_str_fixed(const CometCol& c, i64 i) {
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + (c.offset + i) * LEN;
+  str16 r;
+  r.a = 0;
+  r.b = 0;
+#pragma unroll
+  for (int k = 0; k < LEN; k++) {
+    u64 byte = p[k];
+    if (k < 8) r.a |= byte << (8 * k);
+    else r.b |= byte << (8 * (k - 8));
+  }
+  r.b |= (u64)LEN << 56;
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 256-bit two's-complement integer (four little-endian u64 limbs) for the wide-decimal path.
 // ---------------------------------------------------------------------------------------------
@@ -151,6 +170,19 @@ CDEV i256 u128_mul_u128(u128 a, u128 b) {
 CDEV i256 i128_mul_i128(i128 a, i128 b) {
   i256 m = u128_mul_u128(uabs128(a), uabs128(b));
   return ((a < 0) != (b < 0)) ? i256_negate(m) : m;
+}
+// |a| < 2^127, |b| < 2^63: exact product and the 10^p-1 bound check without forming all 256 bits
+// (same result as i128_mul_i128 + i256_fits_bound; TPC-H Q1's charge = disc_price(26,4) × (1+tax)(13,2))
+CDEV bool i128_mul_i64_fits(i128 a, i64 b, u128 bound, i128& out) {
+  const u128 ua = uabs128(a);
+  const u64 ub = (u64)(b < 0 ? -(u64)b : (u64)b);
+  const u128 lo = (u128)(u64)ua * ub;           // a0·b
+  const u128 hi = (u128)(u64)(ua >> 64) * ub;   // a1·b (to be shifted by 64)
+  const u128 mid = hi + (lo >> 64);
+  const bool fits = (mid >> 64) == 0;
+  const u128 mag = (mid << 64) | (u64)lo;
+  out = ((a < 0) != (b < 0)) ? (i128)((u128)0 - mag) : (i128)mag;
+  return fits && mag <= bound;
 }
 // u256 × u128 keeping the low 256 bits (wrapping_mul by a power of ten)
 CDEV i256 u256_mul_u128_wrapping(const i256& a, u128 b) {
@@ -466,7 +498,20 @@ CDEV void agg_nogroup_body(const CometKParams& prm) {
   P::init(acc);
   const i64 n = prm.n;
   const i64 tile = (i64)P::R * kBlock;
-  for (i64 base = (i64)blockIdx.x * tile; base < n; base += (i64)gridDim.x * tile) P::tile(prm, base, n, acc);
+  const i64 stride = (i64)gridDim.x * tile;
+  if constexpr (P::PIPELINED) {
+    // software pipeline: tile t+1's first-stage loads are issued before tile t is computed
+    typename P::L cur, nxt;
+    i64 base = (i64)blockIdx.x * tile;
+    if (base < n) P::tile_load(prm, base, n, cur);
+    for (; base < n; base += stride) {
+      if (base + stride < n) P::tile_load(prm, base + stride, n, nxt);
+      P::tile(prm, base, n, cur, acc);
+      cur = nxt;
+    }
+  } else {
+    for (i64 base = (i64)blockIdx.x * tile; base < n; base += stride) P::tile(prm, base, n, acc);
+  }
   block_reduce_acc<P>(acc);
   if (threadIdx.x == 0) {
     u64* dst = (u64*)prm.out[0] + (i64)blockIdx.x * P::NW;
@@ -959,7 +1004,19 @@ CDEV void agg_grouped_body(const CometKParams& prm) {
   P::kinit(kacc);
   const i64 n = prm.n;
   const i64 tile = (i64)P::R * kBlock;
-  for (i64 base = (i64)blockIdx.x * tile; base < n; base += (i64)gridDim.x * tile) P::tile_grouped(prm, base, n, g, kacc);
+  const i64 stride = (i64)gridDim.x * tile;
+  if constexpr (P::PIPELINED) {
+    typename P::L cur, nxt;
+    i64 base = (i64)blockIdx.x * tile;
+    if (base < n) P::tile_load(prm, base, n, cur);
+    for (; base < n; base += stride) {
+      if (base + stride < n) P::tile_load(prm, base + stride, n, nxt);
+      P::tile_grouped(prm, base, n, cur, g, kacc);
+      cur = nxt;
+    }
+  } else {
+    for (i64 base = (i64)blockIdx.x * tile; base < n; base += stride) P::tile_grouped(prm, base, n, g, kacc);
+  }
   __syncthreads();
   // level 0 → level 1: sum the private copies into the group's LDS slot (one thread per (group, word))
   const u32 ngrp = s_count < (u32)P::GC ? s_count : (u32)P::GC;

@@ -120,6 +120,8 @@ static void pool_put_event(int dev, hipEvent_t e) {
   pools().events[dev].push_back(e);
 }
 
+extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream);
+
 namespace {
 
 int fixed_width(const DType& t) {
@@ -232,8 +234,13 @@ std::map<std::string, std::shared_ptr<PlannedVariant>> g_plan_cache;
 }  // namespace
 
 static std::shared_ptr<PlannedVariant> planned_variant(const Operator& plan, uint64_t plan_hash, const std::vector<bool>& has_valid,
-                                                       bool compile, const std::vector<DType>* source_types = nullptr) {
+                                                       bool compile, const std::vector<DType>* source_types = nullptr,
+                                                       const std::vector<int>* str_fixed_len = nullptr) {
   std::string key = std::to_string(plan_hash) + ":" + validity_key(has_valid);
+  if (str_fixed_len) {
+    key += ":L";
+    for (int l : *str_fixed_len) key += std::to_string(l) + ",";
+  }
   if (source_types) {
     key += ":";
     for (auto& t : *source_types) key += t.str() + ",";
@@ -246,7 +253,7 @@ static std::shared_ptr<PlannedVariant> planned_variant(const Operator& plan, uin
   }
   if (!pv) {
     pv = std::make_shared<PlannedVariant>();
-    pv->desc = generate_pipeline(plan, has_valid, source_types);
+    pv->desc = generate_pipeline(plan, has_valid, source_types, str_fixed_len);
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto res = g_plan_cache.emplace(key, pv);
     pv = res.first->second;
@@ -386,11 +393,13 @@ std::string ExecutionContext::compile_only(OperatorP plan) {
   return ctx.explain_;
 }
 
-Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid) {
-  std::string key = validity_key(has_valid);
+Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid, const std::vector<int>& str_fixed_len) {
+  std::string key = validity_key(has_valid) + ":";
+  bool any_fixed = false;
+  for (int l : str_fixed_len) { key += std::to_string(l) + ","; any_fixed |= l >= 0; }
   auto it = variants_.find(key);
   if (it != variants_.end()) return it->second;
-  auto pv = planned_variant(*plan_, plan_hash_, has_valid, true, has_join_ ? &in_types_ : nullptr);
+  auto pv = planned_variant(*plan_, plan_hash_, has_valid, true, has_join_ ? &in_types_ : nullptr, any_fixed ? &str_fixed_len : nullptr);
   Variant v;
   v.desc = pv->desc;
   v.mod = jit_load(pv->code);
@@ -407,7 +416,9 @@ void ExecutionContext::launch(Variant& v, const char* kernel, int grid, CometKPa
 // one chunk of input rows resident in HBM → run the fused pipeline on it
 void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n) {
   if (n == 0) return;
-  Variant& v = variant_for(has_valid);
+  std::vector<int> fixed_lens(cols.size(), -1);
+  for (size_t i = 0; i < cols.size(); i++) fixed_lens[i] = cols[i].fixed_len;
+  Variant& v = variant_for(has_valid, fixed_lens);
   const PipelineDesc& d = v.desc;
   if (d.max_rows_exact && input_rows + n > d.max_rows_exact)
     throw CometError("decimal sum over more rows than the exactness bound allows (" + std::to_string(d.max_rows_exact) + ")");
@@ -653,7 +664,7 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
 void ExecutionContext::finish_aggregate() {
   // AggregateExec emits one state row even for empty input
   std::vector<bool> none(in_types_.size(), false);
-  Variant& v = agg_variant_ ? *agg_variant_ : variant_for(none);
+  Variant& v = agg_variant_ ? *agg_variant_ : variant_for(none, std::vector<int>(in_types_.size(), -1));
   const PipelineDesc& d = v.desc;
   CometKParams prm;
   memset(&prm, 0, sizeof prm);
@@ -863,6 +874,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
     for (size_t c = 0; c < nc; c++)
       if (a.children[c]->null_count != 0 && a.children[c]->buffers[0]) has_valid[c] = true;
   std::vector<size_t> aux_bytes(nc, 0);
+  std::vector<int> str_uniform_(nc, -1);
   for (size_t c = 0; c < nc; c++) {
     const DType& t = in_types_[c];
     if (t.id == TypeId::String || t.id == TypeId::Bytes) {
@@ -880,12 +892,18 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
       int32_t* so = (int32_t*)stage_vals_[c]->p;
       int64_t at = 0;
       int32_t pos = 0;
+      int uniform = -2;   // -2 no value seen yet, -1 lengths differ, else the common length
       for (auto& a : held) {
         const ArrowArray* col = a.children[c];
         if (col->dictionary) throw CometError("dictionary-encoded input columns are not unpacked on the GPU path yet");
         const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
         const int32_t base = off[0];
-        for (int64_t i = 0; i < col->length; i++) so[at + i] = pos + (off[i] - base);
+        for (int64_t i = 0; i < col->length; i++) {
+          so[at + i] = pos + (off[i] - base);
+          const int len = off[i + 1] - off[i];
+          if (uniform == -2) uniform = len;
+          else if (uniform != len) uniform = -1;
+        }
         size_t nb = (size_t)(off[col->length] - base);
         if (nb) memcpy((char*)stage_aux_[c]->p + pos, (const char*)col->buffers[2] + base, nb);
         if (has_valid[c]) {
@@ -906,6 +924,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
         HIP_CHECK(hipMemcpyAsync(dev_valid_[c]->p, stage_valid_[c]->p, kb, hipMemcpyHostToDevice, stream_));
       }
       aux_bytes[c] = total_bytes;
+      str_uniform_[c] = (uniform >= 0 && uniform <= 15) ? uniform : -1;
       continue;
     }
     const int w = fixed_width(t);
@@ -945,6 +964,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
     views[c].data = dev_vals_[c]->p;
     views[c].valid = has_valid[c] ? (const uint8_t*)dev_valid_[c]->p : nullptr;
     views[c].aux = dev_aux_[c]->p;
+    views[c].fixed_len = str_uniform_[c];   // staged bytes are contiguous from 0, offsets rebased
   }
   rows_out = rows;
   return true;
@@ -1003,6 +1023,31 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
     }
   }
   rows = da->array.length;
+  // Utf8 columns: check on the device whether all values share one length (one pass over the offsets, 4 B/row);
+  // if so the fused kernels skip the offsets and the dependent byte load altogether
+  for (size_t c = 0; c < nc && rows > 0; c++) {
+    if (types[c].id != TypeId::String) continue;
+    const ArrowArray* col = da->array.children[c];
+    const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
+    int32_t ends[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(&ends[0], off, 4, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(&ends[1], off + rows, 4, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    const int64_t total = (int64_t)ends[1] - ends[0];
+    if (total % rows != 0 || total / rows > 15) continue;
+    const int32_t L = (int32_t)(total / rows);
+    uint32_t* flag = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 1);   // last word of the error/aux block: scratch
+    HIP_CHECK(hipMemsetAsync(flag, 0, 4, stream_));
+    if (comet_launch_utf8_uniform(off, rows, L, flag, stream_) != 0) continue;
+    uint32_t f = 1;
+    HIP_CHECK(hipMemcpyAsync(&f, flag, 4, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    HIP_CHECK(hipMemsetAsync(flag, 0, 4, stream_));
+    if (f == 0) {
+      views[c].fixed_len = L;
+      views[c].aux = (const char*)col->buffers[2] + ends[0] - (int64_t)col->offset * L;
+    }
+  }
   return true;
 }
 

@@ -65,6 +65,7 @@ struct DeviceColumnView {
   const uint8_t* valid = nullptr;
   const void* aux = nullptr;
   int64_t offset = 0;
+  int fixed_len = -1;   // Utf8: every value has this byte length (aux then addresses the bytes directly); -1 = variable
 };
 
 // a table resident in HBM (Arrow layout); owners keep pooled buffers / producer arrays alive
@@ -109,7 +110,7 @@ class ExecutionContext {
 
  private:
   void run_to_completion();
-  Variant& variant_for(const std::vector<bool>& has_valid);
+  Variant& variant_for(const std::vector<bool>& has_valid, const std::vector<int>& str_fixed_len);
   void process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n);
   void finish_aggregate();
   void finish_grouped();

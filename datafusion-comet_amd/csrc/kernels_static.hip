@@ -42,6 +42,12 @@ __global__ __launch_bounds__(256) void pmod_kernel(const u32* hashes, i64 n, i32
   for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = pmod(hashes[i], np);
 }
 
+// Are all n Utf8 values exactly L bytes long?  (lets the fused kernels address the bytes directly, see ld_str_fixed)
+__global__ __launch_bounds__(256) void utf8_uniform_kernel(const i32* off, i64 n, i32 L, u32* flag) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256)
+    if (off[i + 1] - off[i] != L) *flag = 1;
+}
+
 static int grid_for(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 8 ? 256 * 8 : g));
@@ -75,6 +81,12 @@ extern "C" int comet_launch_murmur3(int type_id, int precision, const void* valu
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(utf8_uniform_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offsets, (i64)n, L, flag);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(pmod_kernel, grid_for(n), 256, 0, (hipStream_t)stream, hashes, (i64)n, np, out);
@@ -91,6 +103,7 @@ extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, 
 struct Q6Static {
   static constexpr int R = 4;
   static constexpr int NW = 3;  // [0] rows, [1..2] sum128
+  static constexpr bool PIPELINED = false;
   static __device__ __forceinline__ void init(u64* a) { a[0] = a[1] = a[2] = 0; }
   static __device__ __forceinline__ void combine(u64* a, const u64* b) {
     acc_add64(a, b);
