@@ -120,6 +120,14 @@ static void pool_put_event(int dev, hipEvent_t e) {
   pools().events[dev].push_back(e);
 }
 
+extern "C" int comet_launch_dict_gather_fixed(const void* idx, int iw, const uint8_t* idx_valid, const uint8_t* dict, const uint8_t* dict_valid,
+                                              int width, int64_t n, uint8_t* out, uint8_t* out_valid_bytes, void* stream);
+extern "C" int comet_launch_dict_gather_str_len(const void* idx, int iw, const uint8_t* idx_valid, const int32_t* dict_offs, const uint8_t* dict_valid,
+                                                int64_t n, uint32_t* lengths, uint8_t* out_valid_bytes, void* stream);
+extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const uint8_t* valid_bytes, const int32_t* dict_offs, const uint8_t* dict_bytes,
+                                                 int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
+extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
+extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
 extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream);
 
 namespace {
@@ -875,7 +883,120 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
       if (a.children[c]->null_count != 0 && a.children[c]->buffers[0]) has_valid[c] = true;
   std::vector<size_t> aux_bytes(nc, 0);
   std::vector<int> str_uniform_(nc, -1);
+  // index width of dictionary-encoded columns comes from the stream schema (fetched once per input)
+  if (staging_[input]->dict_index_width.empty()) {
+    staging_[input]->dict_index_width.assign(nc, 0);
+    bool any_dict = false;
+    for (auto& a : held)
+      for (size_t c = 0; c < nc; c++) any_dict |= a.children[c]->dictionary != nullptr;
+    if (any_dict) {
+      ArrowSchema sch;
+      memset(&sch, 0, sizeof sch);
+      if (in.host->get_schema(in.host, &sch) != 0 || !sch.release) throw CometError("input stream: get_schema failed");
+      for (size_t c = 0; c < nc && c < (size_t)sch.n_children; c++) {
+        const ArrowSchema* f = sch.children[c];
+        if (f->dictionary && f->format) {
+          int w = f->format[0] == 'c' || f->format[0] == 'C' ? 1 : f->format[0] == 's' || f->format[0] == 'S' ? 2 : f->format[0] == 'i' || f->format[0] == 'I' ? 4 : 8;
+          staging_[input]->dict_index_width[c] = w;
+        }
+      }
+      sch.release(&sch);
+    }
+  }
+  std::vector<std::shared_ptr<DevBuf>> dict_keep;
+  std::vector<bool> dict_done(nc, false);
   for (size_t c = 0; c < nc; c++) {
+    bool is_dict = false;
+    for (auto& a : held) is_dict |= a.children[c]->dictionary != nullptr;
+    if (!is_dict) continue;
+    // ---- dictionary unpack on the device (K1): indices + dictionary go up, a gather kernel writes the plain column
+    const DType& t = in_types_[c];
+    const int iw = staging_[input]->dict_index_width[c];
+    if (!iw) throw CometError("dictionary-encoded column without an index type in the stream schema");
+    const bool is_str = t.id == TypeId::String || t.id == TypeId::Bytes;
+    const int w = is_str ? 0 : (t.id == TypeId::Bool ? -1 : fixed_width(t));
+    if (w < 0) throw CometError("dictionary-encoded boolean columns are not supported yet");
+    auto vbytes = std::make_shared<DevBuf>();
+    vbytes->ensure((size_t)rows + 16);
+    dict_keep.push_back(vbytes);
+    auto upload = [&](const void* src, size_t n) {
+      auto d = std::make_shared<DevBuf>();
+      d->ensure(n + 16);
+      if (n) HIP_CHECK(hipMemcpy(d->p, src, n, hipMemcpyHostToDevice));
+      dict_keep.push_back(d);
+      return d;
+    };
+    struct Part { std::shared_ptr<DevBuf> idx, doffs, dbytes; int64_t at, len; };
+    std::vector<Part> parts;
+    auto lengths = std::make_shared<DevBuf>();
+    if (is_str) lengths->ensure((size_t)rows * 4 + 16);
+    else dev_vals_[c]->ensure((size_t)rows * w + 16);
+    int64_t at = 0;
+    bool any_null = false;
+    for (auto& a : held) {
+      const ArrowArray* col = a.children[c];
+      const ArrowArray* dict = col->dictionary;
+      if (!dict) throw CometError("a column mixes dictionary-encoded and plain batches");
+      const int64_t len = col->length;
+      auto d_idx = upload((const char*)col->buffers[1] + (size_t)col->offset * iw, (size_t)len * iw);
+      std::shared_ptr<DevBuf> d_iv, d_dv;
+      if (col->null_count != 0 && col->buffers[0]) {
+        std::vector<uint8_t> bm((size_t)((len + 7) / 8) + 1, 0);
+        bit_append(bm.data(), 0, (const uint8_t*)col->buffers[0], col->offset, len);
+        d_iv = upload(bm.data(), bm.size());
+        any_null = true;
+      }
+      if (dict->null_count != 0 && dict->buffers[0]) {
+        std::vector<uint8_t> bm((size_t)((dict->length + 7) / 8) + 1, 0);
+        bit_append(bm.data(), 0, (const uint8_t*)dict->buffers[0], dict->offset, dict->length);
+        d_dv = upload(bm.data(), bm.size());
+        any_null = true;
+      }
+      if (!is_str) {
+        auto d_vals = upload((const char*)dict->buffers[1] + (size_t)dict->offset * w, (size_t)dict->length * w);
+        comet_launch_dict_gather_fixed(d_idx->p, iw, d_iv ? (const uint8_t*)d_iv->p : nullptr, (const uint8_t*)d_vals->p,
+                                       d_dv ? (const uint8_t*)d_dv->p : nullptr, w, len, (uint8_t*)dev_vals_[c]->p + (size_t)at * w,
+                                       (uint8_t*)vbytes->p + at, stream_);
+      } else {
+        const int32_t* off = (const int32_t*)dict->buffers[1] + dict->offset;
+        std::vector<int32_t> ro((size_t)dict->length + 1);
+        for (int64_t k = 0; k <= dict->length; k++) ro[(size_t)k] = off[k] - off[0];
+        auto d_off = upload(ro.data(), ro.size() * 4);
+        auto d_bytes = upload((const char*)dict->buffers[2] + off[0], (size_t)ro[(size_t)dict->length]);
+        comet_launch_dict_gather_str_len(d_idx->p, iw, d_iv ? (const uint8_t*)d_iv->p : nullptr, (const int32_t*)d_off->p,
+                                         d_dv ? (const uint8_t*)d_dv->p : nullptr, len, (uint32_t*)lengths->p + at, (uint8_t*)vbytes->p + at, stream_);
+        parts.push_back({d_idx, d_off, d_bytes, at, len});
+      }
+      at += len;
+    }
+    if (is_str) {
+      auto tiles = std::make_shared<DevBuf>();
+      tiles->ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+      dict_keep.push_back(tiles);
+      dict_keep.push_back(lengths);
+      dev_vals_[c]->ensure((size_t)(rows + 1) * 4 + 16);
+      pq_launch_u32_scan((const uint32_t*)lengths->p, rows, (uint64_t*)tiles->p, (int32_t*)dev_vals_[c]->p, stream_);
+      int32_t total = 0;
+      HIP_CHECK(hipMemcpyAsync(&total, (char*)dev_vals_[c]->p + (size_t)rows * 4, 4, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      dev_aux_[c]->ensure((size_t)std::max(total, 1) + 16);
+      for (auto& pt : parts)
+        comet_launch_dict_gather_str_copy(pt.idx->p, iw, (const uint8_t*)vbytes->p + pt.at, (const int32_t*)pt.doffs->p, (const uint8_t*)pt.dbytes->p, pt.len,
+                                          (const int32_t*)dev_vals_[c]->p + pt.at, (uint8_t*)dev_aux_[c]->p, stream_);
+    }
+    if (any_null) {
+      has_valid[c] = true;
+      dev_valid_[c]->ensure((size_t)((rows + 7) / 8) + 16);
+      pq_launch_pack((const uint8_t*)vbytes->p, (uint8_t*)dev_valid_[c]->p, rows, stream_);
+    } else {
+      has_valid[c] = false;
+    }
+    dict_done[c] = true;
+  }
+  if (!dict_keep.empty()) HIP_CHECK(hipStreamSynchronize(stream_));   // uploaded indices/dictionaries are released below
+  dict_keep.clear();
+  for (size_t c = 0; c < nc; c++) {
+    if (dict_done[c]) continue;
     const DType& t = in_types_[c];
     if (t.id == TypeId::String || t.id == TypeId::Bytes) {
       // Utf8: int32 offsets rebased to the chunk + concatenated bytes

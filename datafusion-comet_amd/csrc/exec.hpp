@@ -80,6 +80,7 @@ struct DevTable {
 struct Staging {  // host→device staging of one input stream (one chunk at a time)
   std::vector<std::unique_ptr<PinnedBuf>> stage_vals, stage_valid, stage_aux;
   std::vector<std::unique_ptr<DevBuf>> dev_vals, dev_valid, dev_aux;
+  std::vector<int> dict_index_width;   // per column: byte width of dictionary indices (0 = not dictionary-encoded)
 };
 
 struct Variant {  // one JIT specialisation of the pipeline (per input-validity pattern)

@@ -48,6 +48,50 @@ __global__ __launch_bounds__(256) void utf8_uniform_kernel(const i32* off, i64 n
     if (off[i + 1] - off[i] != L) *flag = 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dictionary unpack (ScanExec always hands plain arrays downstream: operators/scan.rs:98-106, copy.rs:69-93):
+// out[i] = dict[idx[i]], validity = index validity AND dictionary-value validity.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ i64 dict_index(const void* idx, int iw, i64 i) {
+  switch (iw) {
+    case 1: return ((const i8*)idx)[i];
+    case 2: return ((const i16*)idx)[i];
+    case 4: return ((const i32*)idx)[i];
+    default: return ((const i64*)idx)[i];
+  }
+}
+__global__ __launch_bounds__(256) void dict_gather_fixed_kernel(const void* idx, int iw, const u8* idx_valid, const u8* dict, const u8* dict_valid,
+                                                                int width, i64 n, u8* out, u8* out_valid_bytes) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    bool ok = !idx_valid || ((idx_valid[i >> 3] >> (i & 7)) & 1);
+    i64 k = ok ? dict_index(idx, iw, i) : 0;
+    if (ok && dict_valid) ok = (dict_valid[k >> 3] >> (k & 7)) & 1;
+    for (int b = 0; b < width; b++) out[i * width + b] = ok ? dict[k * width + b] : 0;
+    out_valid_bytes[i] = ok ? 1 : 0;
+  }
+}
+__global__ __launch_bounds__(256) void dict_gather_str_len_kernel(const void* idx, int iw, const u8* idx_valid, const i32* dict_offs, const u8* dict_valid,
+                                                                  i64 n, u32* lengths, u8* out_valid_bytes) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    bool ok = !idx_valid || ((idx_valid[i >> 3] >> (i & 7)) & 1);
+    i64 k = ok ? dict_index(idx, iw, i) : 0;
+    if (ok && dict_valid) ok = (dict_valid[k >> 3] >> (k & 7)) & 1;
+    lengths[i] = ok ? (u32)(dict_offs[k + 1] - dict_offs[k]) : 0;
+    out_valid_bytes[i] = ok ? 1 : 0;
+  }
+}
+__global__ __launch_bounds__(256) void dict_gather_str_copy_kernel(const void* idx, int iw, const u8* valid_bytes, const i32* dict_offs, const u8* dict_bytes,
+                                                                   i64 n, const i32* out_offs, u8* out_bytes) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    if (!valid_bytes[i]) continue;
+    i64 k = dict_index(idx, iw, i);
+    const u8* src = dict_bytes + dict_offs[k];
+    i32 len = dict_offs[k + 1] - dict_offs[k];
+    u8* dst = out_bytes + out_offs[i];
+    for (i32 b = 0; b < len; b++) dst[b] = src[b];
+  }
+}
+
 static int grid_for(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 8 ? 256 * 8 : g));
@@ -84,6 +128,25 @@ extern "C" int comet_launch_murmur3(int type_id, int precision, const void* valu
 extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(utf8_uniform_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offsets, (i64)n, L, flag);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int comet_launch_dict_gather_fixed(const void* idx, int iw, const uint8_t* idx_valid, const uint8_t* dict, const uint8_t* dict_valid,
+                                              int width, int64_t n, uint8_t* out, uint8_t* out_valid_bytes, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dict_gather_fixed_kernel, grid_for(n), 256, 0, (hipStream_t)stream, idx, iw, idx_valid, dict, dict_valid, width, (i64)n, out, out_valid_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int comet_launch_dict_gather_str_len(const void* idx, int iw, const uint8_t* idx_valid, const int32_t* dict_offs, const uint8_t* dict_valid,
+                                                int64_t n, uint32_t* lengths, uint8_t* out_valid_bytes, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dict_gather_str_len_kernel, grid_for(n), 256, 0, (hipStream_t)stream, idx, iw, idx_valid, dict_offs, dict_valid, (i64)n, lengths, out_valid_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const uint8_t* valid_bytes, const int32_t* dict_offs, const uint8_t* dict_bytes,
+                                                 int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dict_gather_str_copy_kernel, grid_for(n), 256, 0, (hipStream_t)stream, idx, iw, valid_bytes, dict_offs, dict_bytes, (i64)n, out_offs, out_bytes);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -196,3 +196,35 @@ def q3_plan() -> S.Operator:
 
 
 Q3_NUM_OUTPUT_COLS = 3 + 2
+
+
+def lineitem_q1_device(n: int, device="cuda:0", seed: int = 1):
+    """The Q1 lineitem columns generated directly in HBM with torch (SF100 = 600 M rows = 46.8 GB does not have to pass
+    through host memory).  Same distributions as lineitem_q1; returns a native.DeviceTable."""
+    import torch
+    from .native import DeviceTable
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def dec(v):  # int64 unscaled (non-negative here) → Decimal128 little-endian limbs
+        buf = torch.zeros((n, 2), dtype=torch.int64, device=device)
+        buf[:, 0] = v
+        return buf.view(torch.uint8).reshape(-1)
+
+    qty = torch.randint(1, 51, (n,), generator=g, device=device, dtype=torch.int64)
+    price = qty * torch.randint(90000, 210001, (n,), generator=g, device=device, dtype=torch.int64)
+    disc = torch.randint(0, 11, (n,), generator=g, device=device, dtype=torch.int64)
+    tax = torch.randint(0, 9, (n,), generator=g, device=device, dtype=torch.int64)
+    ship = torch.randint(days(1992, 1, 2), days(1998, 12, 1) + 1, (n,), generator=g, device=device, dtype=torch.int32)
+    late = ship > days(1995, 6, 17)
+    coin = torch.rand((n,), generator=g, device=device) < 0.5
+    rf = torch.where(late, torch.tensor(ord("N"), device=device, dtype=torch.uint8),
+                     torch.where(coin, torch.tensor(ord("R"), device=device, dtype=torch.uint8), torch.tensor(ord("A"), device=device, dtype=torch.uint8)))
+    ls = torch.where(late, torch.tensor(ord("O"), device=device, dtype=torch.uint8), torch.tensor(ord("F"), device=device, dtype=torch.uint8))
+    offs = torch.arange(n + 1, device=device, dtype=torch.int32).view(torch.uint8).reshape(-1)
+    schema = pa.schema([("l_quantity", pa.decimal128(12, 2)), ("l_extendedprice", pa.decimal128(12, 2)), ("l_discount", pa.decimal128(12, 2)),
+                        ("l_tax", pa.decimal128(12, 2)), ("l_returnflag", pa.utf8()), ("l_linestatus", pa.utf8()), ("l_shipdate", pa.date32())])
+    values = [dec(qty * 100), dec(price), dec(disc), dec(tax), offs, offs.clone(), ship.view(torch.uint8).reshape(-1)]
+    aux = [None, None, None, None, rf, ls, None]
+    checks = {"qty": qty, "price": price, "ship": ship, "rf": rf, "ls": ls}
+    return DeviceTable(schema, n, values, [None] * 7, device, aux), checks
