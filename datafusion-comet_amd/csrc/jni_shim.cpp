@@ -193,4 +193,30 @@ JNIEXPORT void JNICALL Java_org_apache_comet_Native_traceEnd(JNIEnv*, jclass, js
 JNIEXPORT void JNICALL Java_org_apache_comet_Native_logMemoryUsage(JNIEnv*, jclass, jstring, jlong) {}
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_getRustThreadId(JNIEnv*, jclass) { return 0; }
 
+// Shuffle-writer and columnar-to-row entry points (jni_api.rs:1047,1130,1163,1253,1275,1363): outside the hot path
+// (SURVEY §8b "must exist").  They resolve, throw CometNativeException and return the type's zero value, so a Spark plan that
+// reaches them fails with a clear message instead of an UnsatisfiedLinkError.
+#define COMET_UNSUPPORTED(env, what) throw_java(env, COMET_ERR_NATIVE, what " is not implemented by the MI355X engine (libcomet.so, hot path only)")
+JNIEXPORT jlongArray JNICALL Java_org_apache_comet_Native_writeSortedFileNative(JNIEnv* env, jclass, jlongArray, jintArray, jobjectArray, jstring,
+                                                                                jdouble, jint, jboolean, jint, jlong, jstring, jint, jboolean) {
+  COMET_UNSUPPORTED(env, "Native.writeSortedFileNative");
+  return nullptr;
+}
+JNIEXPORT void JNICALL Java_org_apache_comet_Native_sortRowPartitionsNative(JNIEnv* env, jclass, jlong, jlong, jboolean) {
+  COMET_UNSUPPORTED(env, "Native.sortRowPartitionsNative");
+}
+JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_decodeShuffleBlock(JNIEnv* env, jclass, jobject, jint, jlongArray, jlongArray, jboolean) {
+  COMET_UNSUPPORTED(env, "Native.decodeShuffleBlock");
+  return 0;
+}
+JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_columnarToRowInit(JNIEnv* env, jclass, jobjectArray, jint) {
+  COMET_UNSUPPORTED(env, "Native.columnarToRowInit");
+  return 0;
+}
+JNIEXPORT jobject JNICALL Java_org_apache_comet_Native_columnarToRowConvert(JNIEnv* env, jclass, jlong, jlongArray, jlongArray, jint) {
+  COMET_UNSUPPORTED(env, "Native.columnarToRowConvert");
+  return nullptr;
+}
+JNIEXPORT void JNICALL Java_org_apache_comet_Native_columnarToRowClose(JNIEnv*, jclass, jlong) {}
+
 }  // extern "C"

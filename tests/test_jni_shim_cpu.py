@@ -18,8 +18,19 @@ def jvm(built):
 def test_jni_symbols_exported(built):
     lib = ctypes.CDLL(native.LIB_PATH)
     for n in ("NativeBase_init", "NativeBase_isFeatureEnabled", "Native_createPlan", "Native_executePlan", "Native_releasePlan",
-              "Native_traceBegin", "Native_traceEnd", "Native_logMemoryUsage", "Native_getRustThreadId"):
+              "Native_traceBegin", "Native_traceEnd", "Native_logMemoryUsage", "Native_getRustThreadId",
+              "Native_writeSortedFileNative", "Native_sortRowPartitionsNative", "Native_decodeShuffleBlock",
+              "Native_columnarToRowInit", "Native_columnarToRowConvert", "Native_columnarToRowClose"):
         assert hasattr(lib, "Java_org_apache_comet_" + n)
+
+
+def test_out_of_scope_entry_points_throw_instead_of_unsatisfied_link(jvm):
+    f = jvm.lib.Java_org_apache_comet_Native_columnarToRowInit
+    f.restype = ctypes.c_int64
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+    assert f(jvm.env, None, None, 8192) == 0
+    cls, msg = jvm.exception()
+    assert cls == "org/apache/comet/CometNativeException" and "columnarToRowInit" in msg
 
 
 def test_create_release_balances_global_refs_and_releases_stream(jvm):
