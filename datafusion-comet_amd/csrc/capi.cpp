@@ -14,6 +14,12 @@ extern "C" int comet_launch_murmur3(int type_id, int precision, const void* valu
                                     const void* aux, int64_t n, uint32_t* hashes, void* stream);
 extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out, void* stream);
 
+// exchange_kernels.hip
+extern "C" int64_t comet_partition_tiles(int64_t n);
+extern "C" int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
+                                              uint32_t* row_indices, void* stream);
+extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream);
+
 namespace {
 
 std::mutex g_mu;
@@ -21,6 +27,12 @@ std::map<int64_t, std::shared_ptr<ExecutionContext>> g_ctx;
 int64_t g_next = 1;
 thread_local std::string t_last_error;
 thread_local int t_last_kind = 0;
+
+uint64_t plan_bytes_hash(const uint8_t* plan, size_t plan_len) {   // FNV-1a: key of the process-wide plan cache
+  uint64_t ph = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < plan_len; i++) { ph ^= plan[i]; ph *= 0x100000001b3ull; }
+  return ph ^ ((uint64_t)plan_len << 48);
+}
 
 std::shared_ptr<ExecutionContext> lookup(int64_t h) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -71,10 +83,7 @@ int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* c
     }
     std::shared_ptr<ExecutionContext> ctx;
     try {
-      uint64_t ph = 0xcbf29ce484222325ull;
-      for (size_t i = 0; i < plan_len; i++) { ph ^= plan[i]; ph *= 0x100000001b3ull; }
-      ph ^= (uint64_t)plan_len << 48;
-      ctx = std::make_shared<ExecutionContext>(op, ph, cfg, ins, batch_size, device_id);
+      ctx = std::make_shared<ExecutionContext>(op, plan_bytes_hash(plan, plan_len), cfg, ins, batch_size, device_id);
     } catch (...) {
       // ownership of the streams was transferred to us: release them even when planning fails
       for (auto& s : ins) {
@@ -97,6 +106,15 @@ int64_t comet_execute_plan(int64_t handle, struct ArrowArray** out_arrays, struc
     return -2;
   }
   return guarded(ctx.get(), (int64_t)-2, [&]() -> int64_t { return ctx->execute(out_arrays, out_schemas, n_out); });
+}
+
+int64_t comet_execute_plan_device(int64_t handle, struct ArrowDeviceArray** out_arrays, struct ArrowSchema** out_schemas, int32_t n_out) {
+  auto ctx = lookup(handle);
+  if (!ctx) {
+    t_last_error = "invalid plan handle";
+    return -2;
+  }
+  return guarded(ctx.get(), (int64_t)-2, [&]() -> int64_t { return ctx->execute_device(out_arrays, out_schemas, n_out); });
 }
 
 void comet_release_plan(int64_t handle) {
@@ -155,7 +173,7 @@ void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launche
 int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     OperatorP op = decode_operator(plan, plan_len);
-    std::string ex = ExecutionContext::compile_only(op);
+    std::string ex = ExecutionContext::compile_only(op, plan_bytes_hash(plan, plan_len));
     if (out && cap) {
       size_t n = std::min(cap - 1, ex.size());
       memcpy(out, ex.data(), n);
@@ -178,6 +196,36 @@ int32_t comet_pmod_partition(const uint32_t* hashes, int64_t n, int32_t num_part
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     if (num_partitions <= 0) throw CometError("pmod: num_partitions must be positive");
     if (comet_launch_pmod(hashes, n, num_partitions, partition_ids, hip_stream) != 0) throw CometError("pmod launch failed");
+    return 0;
+  });
+}
+
+int32_t comet_partition_indices(const int32_t* partition_ids, int64_t n, int32_t num_partitions, int64_t* partition_starts,
+                                uint32_t* partition_row_indices, void* hip_stream) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    if (num_partitions <= 0 || num_partitions > 4096) throw CometError("partition_indices: num_partitions must be in 1..4096");
+    if (n < 0 || n >= (int64_t)1 << 32) throw CometError("partition_indices: row count must fit 32 bits (multi_partition.rs uses u32 row indices)");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int64_t W = comet_partition_tiles(n);
+    DevBuf scratch;   // histogram + one flag word; returned to the pool once the stream is idle
+    const size_t hist_bytes = ((size_t)num_partitions * (size_t)W + 1) * 8;
+    scratch.ensure(hist_bytes + 8);
+    uint32_t* bad = (uint32_t*)((char*)scratch.p + hist_bytes);
+    if (hipMemsetAsync(bad, 0, 4, st) != hipSuccess) throw CometError("partition_indices: memset failed");
+    if (comet_launch_partition_indices(partition_ids, n, num_partitions, (uint64_t*)scratch.p, bad, partition_starts, partition_row_indices, st) != 0)
+      throw CometError("partition_indices: launch failed");
+    uint32_t flag = 0;
+    if (hipMemcpyAsync(&flag, bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      throw CometError(std::string("partition_indices: ") + hipGetErrorString(hipGetLastError()));
+    if (flag) throw CometError("partition_indices: a partition id is outside [0, num_partitions)");
+    return 0;
+  });
+}
+
+int32_t comet_take_column(int32_t width_bytes, const void* src, const uint32_t* row_indices, int64_t n, void* dst, void* hip_stream) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    if (comet_launch_take(width_bytes, src, row_indices, n, dst, hip_stream) != 0)
+      throw CometError("take_column: unsupported value width " + std::to_string(width_bytes));
     return 0;
   });
 }

@@ -1,0 +1,163 @@
+// Exchange (shuffle) step on device: partition ids → partition_starts + partition_row_indices → per-column take.
+// This is the GPU form of the reference's hash repartitioner scratch computation
+// (native/shuffle/src/partitioners/multi_partition.rs:54-103: count per partition, prefix sum, row indices grouped by
+// partition in ascending row order) followed by the per-partition `take` that builds the outgoing batches
+// (multi_partition.rs:457-520).  Partition ids come from comet_murmur3_column + comet_pmod_partition.
+//
+// Layout of the work: one wave owns a tile of kPartTile consecutive rows.  Pass 1 counts rows per partition per tile
+// into hist[p * W + tile]; an exclusive scan over that partition-major array yields, for every (partition, tile), the
+// first output slot; pass 2 replays the tile in row order and writes row i to its slot, so rows keep their input
+// order inside each partition (same result as the reference's reverse fill).
+#include <hip/hip_runtime.h>
+
+#include "device/comet_device.hpp"
+
+using namespace comet;
+
+namespace {
+
+constexpr int kPartTile = 8192;  // rows per wave tile
+
+// Visit the groups of equal partition id among the active lanes of this wave, in lane order of their first member.
+// f(leader_lane, pid_of_group, member_mask) is called uniformly by the whole wave.
+template <class F>
+__device__ __forceinline__ void for_each_group(i32 pid, bool active, F f) {
+  u64 remaining = __ballot(active);
+  while (remaining) {
+    const int l = __ffsll((unsigned long long)remaining) - 1;
+    const i32 lp = __shfl(pid, l, kWave);
+    const u64 m = __ballot(active && pid == lp);
+    f(l, lp, m);
+    remaining &= ~m;
+  }
+}
+
+__global__ __launch_bounds__(256) void part_hist_kernel(const i32* pids, i64 n, i32 P, i64 W, u64* hist, u32* bad) {
+  extern __shared__ u32 s_cnt[];  // [4][P]
+  u32* mine = s_cnt + wave_id() * P;
+  const i64 block_tiles = (W + 3) / 4;
+  for (i64 bt = blockIdx.x; bt < block_tiles; bt += gridDim.x) {
+    const i64 g = bt * 4 + wave_id();
+    for (int p = lane_id(); p < P; p += kWave) mine[p] = 0;
+    __syncthreads();
+    if (g < W) {
+      const i64 lo = g * kPartTile, hi = lo + kPartTile < n ? lo + kPartTile : n;
+      for (i64 base = lo; base < hi; base += kWave) {
+        const i64 i = base + lane_id();
+        const bool active = i < hi;
+        i32 pid = active ? pids[i] : 0;
+        if (active && (pid < 0 || pid >= P)) { *bad = 1; pid = 0; }
+        for_each_group(pid, active, [&](int l, i32 lp, u64 m) {
+          if (lane_id() == l) atomicAdd(&mine[lp], (u32)__popcll(m));
+        });
+      }
+    }
+    __syncthreads();
+    if (g < W)
+      for (int p = lane_id(); p < P; p += kWave) hist[(i64)p * W + g] = mine[p];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void part_scan_kernel(u64* hist, i64 len) { tile_scan_body(hist, len); }
+
+__global__ __launch_bounds__(256) void part_starts_kernel(const u64* scanned, i32 P, i64 W, i64 n, i64* starts) {
+  for (int p = threadIdx.x; p <= P; p += 256) starts[p] = p == P ? n : (i64)scanned[(i64)p * W];
+}
+
+__global__ __launch_bounds__(256) void part_index_kernel(const i32* pids, i64 n, i32 P, i64 W, const u64* scanned, u32* row_indices) {
+  extern __shared__ u32 s_cnt[];
+  u32* run = s_cnt + wave_id() * P;
+  const i64 block_tiles = (W + 3) / 4;
+  const u64 lt = (1ull << lane_id()) - 1;
+  for (i64 bt = blockIdx.x; bt < block_tiles; bt += gridDim.x) {
+    const i64 g = bt * 4 + wave_id();
+    if (g < W)
+      for (int p = lane_id(); p < P; p += kWave) run[p] = (u32)scanned[(i64)p * W + g];
+    __syncthreads();
+    if (g < W) {
+      const i64 lo = g * kPartTile, hi = lo + kPartTile < n ? lo + kPartTile : n;
+      for (i64 base = lo; base < hi; base += kWave) {
+        const i64 i = base + lane_id();
+        const bool active = i < hi;
+        i32 pid = active ? pids[i] : 0;
+        if (pid < 0 || pid >= P) pid = 0;
+        u32 slot = 0;
+        for_each_group(pid, active, [&](int l, i32 lp, u64 m) {
+          u32 b = 0;
+          if (lane_id() == l) b = atomicAdd(&run[lp], (u32)__popcll(m));
+          b = __shfl(b, l, kWave);
+          if (active && pid == lp) slot = b + (u32)__popcll(m & lt);
+        });
+        if (active) row_indices[slot] = (u32)i;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// take: dst[k] = src[idx[k]]
+template <class T>
+__global__ __launch_bounds__(256) void take_kernel(const T* src, const u32* idx, i64 n, T* dst) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) dst[k] = src[idx[k]];
+}
+// bit-packed source (validity bitmaps, Boolean values): one output byte (8 rows) per lane
+__global__ __launch_bounds__(256) void take_bits_kernel(const u8* src, const u32* idx, i64 n, u8* dst) {
+  const i64 nbytes = (n + 7) / 8;
+  for (i64 b = (i64)blockIdx.x * 256 + threadIdx.x; b < nbytes; b += (i64)gridDim.x * 256) {
+    u32 v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const i64 k = b * 8 + j;
+      if (k < n) {
+        const u32 r = idx[k];
+        v |= (u32)((src[r >> 3] >> (r & 7)) & 1) << j;
+      }
+    }
+    dst[b] = (u8)v;
+  }
+}
+
+int grid_for(i64 n) {
+  i64 g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t comet_partition_tiles(int64_t n) { return n <= 0 ? 1 : (n + kPartTile - 1) / kPartTile; }
+
+// hist: (P*W + 1) u64 scratch; bad: one zeroed u32; starts: P+1 i64; row_indices: n u32
+int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
+                                   uint32_t* row_indices, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const i64 W = comet_partition_tiles(n);
+  const i64 block_tiles = (W + 3) / 4;
+  const int grid = (int)(block_tiles > 256 * 8 ? 256 * 8 : block_tiles);
+  const size_t lds = (size_t)4 * (size_t)P * sizeof(u32);
+  hipLaunchKernelGGL(part_hist_kernel, grid, 256, lds, st, pids, (i64)n, P, W, (u64*)hist, bad);
+  hipLaunchKernelGGL(part_scan_kernel, 1, 256, 0, st, (u64*)hist, (i64)P * W);
+  hipLaunchKernelGGL(part_starts_kernel, 1, 256, 0, st, (const u64*)hist, P, W, (i64)n, (i64*)starts);
+  if (n > 0) hipLaunchKernelGGL(part_index_kernel, grid, 256, lds, st, pids, (i64)n, P, W, (const u64*)hist, row_indices);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// width: bytes per value (1, 2, 4, 8, 16) or 0 for bit-packed data
+int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0) return 0;
+  switch (width) {
+    case 0: hipLaunchKernelGGL(take_bits_kernel, grid_for((n + 7) / 8), 256, 0, st, (const u8*)src, idx, (i64)n, (u8*)dst); break;
+    case 1: hipLaunchKernelGGL(take_kernel<u8>, grid_for(n), 256, 0, st, (const u8*)src, idx, (i64)n, (u8*)dst); break;
+    case 2: hipLaunchKernelGGL(take_kernel<unsigned short>, grid_for(n), 256, 0, st, (const unsigned short*)src, idx, (i64)n, (unsigned short*)dst); break;
+    case 4: hipLaunchKernelGGL(take_kernel<u32>, grid_for(n), 256, 0, st, (const u32*)src, idx, (i64)n, (u32*)dst); break;
+    case 8: hipLaunchKernelGGL(take_kernel<u64>, grid_for(n), 256, 0, st, (const u64*)src, idx, (i64)n, (u64*)dst); break;
+    case 16: hipLaunchKernelGGL(take_kernel<i128>, grid_for(n), 256, 0, st, (const i128*)src, idx, (i64)n, (i128*)dst); break;
+    default: return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // extern "C"

@@ -376,7 +376,7 @@ ExecutionContext::~ExecutionContext() {
 
 const std::string& ExecutionContext::explain() { return explain_; }
 
-std::string ExecutionContext::compile_only(OperatorP plan) {
+std::string ExecutionContext::compile_only(OperatorP plan, uint64_t plan_hash) {
   // count Scan leaves to fabricate the (never used) input list
   size_t nscan = 0;
   std::function<void(const Operator&)> cnt = [&](const Operator& op) {
@@ -385,7 +385,7 @@ std::string ExecutionContext::compile_only(OperatorP plan) {
   };
   cnt(*plan);
   std::vector<InputSource> ins(nscan);
-  ExecutionContext ctx(plan, 0x5eed, {}, ins, 8192, 0);
+  ExecutionContext ctx(plan, plan_hash, {}, ins, 8192, 0);
   std::vector<bool> none(ctx.in_types_.size(), false);
   if (ctx.has_join_) {
     ctx.compile_in_infer_ = true;
@@ -1531,8 +1531,7 @@ void ExecutionContext::run_to_completion() {
   }
 }
 
-int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
-  Timer t;
+void ExecutionContext::start() {
   if (!started_) {
     // Lazy start like the reference (jni_api.rs:795-872): nothing touches the input before the first executePlan.
     HIP_CHECK(hipSetDevice(device_id_));
@@ -1543,6 +1542,75 @@ int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_sch
   } else {
     HIP_CHECK(hipSetDevice(device_id_));
   }
+}
+
+namespace {
+struct ExportedDeviceColumn {
+  std::vector<std::shared_ptr<void>> owners;   // pooled buffers / producer arrays the pointers live in
+  const void* buffers[3];
+};
+void release_device_array(ArrowArray* a) {
+  delete (ExportedDeviceColumn*)a->private_data;
+  a->release = nullptr;
+}
+void release_fmt_schema(ArrowSchema* s) {
+  delete (std::string*)s->private_data;
+  s->release = nullptr;
+}
+}  // namespace
+
+// The stage boundary for multi-GPU plans: a Filter/Project/HashJoin plan's output stays resident so that the
+// exchange (murmur3 → pmod → partition scatter → RCCL all-to-all) never touches the host.  One batch = the whole result.
+int64_t ExecutionContext::execute_device(ArrowDeviceArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
+  Timer t;
+  start();
+  if (sink_ != SinkKind::Output)
+    throw CometError("comet_execute_plan_device: aggregate results are small and are exported through comet_execute_plan");
+  if (finished_) return -1;
+  DevTable tab = materialize(*plan_);
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  collect_timings();
+  finished_ = true;
+  if ((size_t)n_out != tab.cols.size())
+    throw CometError("Output column count mismatch: expected " + std::to_string(n_out) + ", got " + std::to_string(tab.cols.size()));
+  for (int j = 0; j < n_out; j++) {
+    const DType& ty = tab.types[(size_t)j];
+    const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
+    if (tab.cols[(size_t)j].offset != 0) throw CometError("comet_execute_plan_device: input column with a non-zero Arrow offset passed through");
+    auto* ec = new ExportedDeviceColumn();
+    ec->owners = tab.owners;
+    ec->buffers[0] = tab.has_valid[(size_t)j] ? tab.cols[(size_t)j].valid : nullptr;
+    ec->buffers[1] = tab.cols[(size_t)j].data;
+    ec->buffers[2] = is_str ? tab.cols[(size_t)j].aux : nullptr;
+    ArrowDeviceArray* d = out_arrays[j];
+    memset(d, 0, sizeof *d);
+    d->array.length = tab.rows;
+    d->array.null_count = tab.has_valid[(size_t)j] ? -1 : 0;
+    d->array.n_buffers = is_str ? 3 : 2;
+    d->array.buffers = ec->buffers;
+    d->array.private_data = ec;
+    d->array.release = release_device_array;
+    d->device_id = device_id_;
+    d->device_type = ARROW_DEVICE_ROCM;
+    d->sync_event = nullptr;   // the plan's stream was synchronised above
+    ArrowSchema* s = out_schemas[j];
+    memset(s, 0, sizeof *s);
+    auto* fmt = new std::string(expected_format(ty));
+    s->format = fmt->c_str();
+    s->name = "";
+    s->flags = ARROW_FLAG_NULLABLE;
+    s->private_data = fmt;
+    s->release = release_fmt_schema;
+  }
+  output_rows_ += tab.rows;
+  elapsed_compute_ns_ += t.ns();
+  return tab.rows;
+}
+
+int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
+  Timer t;
+  start();
   const bool is_agg = sink_ != SinkKind::Output;
   if (!finished_) {
     if (is_agg) {

@@ -96,10 +96,12 @@ class ExecutionContext {
 
   // returns rows of the exported batch, or -1 at end of stream
   int64_t execute(ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
+  // same, but the (single) result batch stays in HBM and is exported as ARROW_DEVICE_ROCM arrays
+  int64_t execute_device(ArrowDeviceArray** out_arrays, ArrowSchema** out_schemas, int n_out);
   std::string metrics_proto();
   const std::string& explain();
   // CPU-only: plan + generate + hiprtc-compile the all-valid variant (used by build()/tests w/o GPU)
-  static std::string compile_only(OperatorP plan);
+  static std::string compile_only(OperatorP plan, uint64_t plan_hash);
 
   std::string last_error;
   int last_error_kind = 0;
@@ -111,6 +113,7 @@ class ExecutionContext {
 
  private:
   void run_to_completion();
+  void start();
   Variant& variant_for(const std::vector<bool>& has_valid, const std::vector<int>& str_fixed_len);
   void process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n);
   void finish_aggregate();

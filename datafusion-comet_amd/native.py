@@ -66,6 +66,12 @@ def _load() -> ctypes.CDLL:
     lib.comet_pmod_partition.restype = c.c_int32
     lib.comet_pmod_partition.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p]
     lib.comet_version.restype = c.c_char_p
+    lib.comet_execute_plan_device.restype = c.c_int64
+    lib.comet_execute_plan_device.argtypes = [c.c_int64, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p), c.c_int32]
+    lib.comet_partition_indices.restype = c.c_int32
+    lib.comet_partition_indices.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.comet_take_column.restype = c.c_int32
+    lib.comet_take_column.argtypes = [c.c_int32, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
     return lib
 
 
@@ -186,6 +192,54 @@ class DeviceTable:
     def nbytes(self) -> int:
         return (sum(v.numel() for v in self.values) + sum(v.numel() for v in self.validity if v is not None)
                 + sum(v.numel() for v in self.aux if v is not None))
+
+    def to_arrow(self) -> pa.Table:
+        """Copy back to host memory as a pyarrow Table (tests / small results only)."""
+        import numpy as np
+        cols = []
+        for i, f in enumerate(self.schema):
+            host = lambda t: pa.py_buffer(t.detach().cpu().numpy().tobytes()) if t is not None else None
+            bufs = [host(self.validity[i]), host(self.values[i])]
+            if pa.types.is_string(f.type) or pa.types.is_binary(f.type):
+                bufs.append(host(self.aux[i]))
+            cols.append(pa.Array.from_buffers(f.type, self.num_rows, bufs, null_count=-1 if self.validity[i] is not None else 0))
+        return pa.Table.from_arrays(cols, schema=self.schema)
+
+
+def value_width(t: pa.DataType) -> int:
+    """Bytes per value of the values buffer (0 = bit-packed Boolean); Utf8 is not fixed width."""
+    if pa.types.is_boolean(t):
+        return 0
+    if pa.types.is_decimal(t):
+        return 16
+    if t in _FIXED_WIDTH:
+        return _FIXED_WIDTH[t]
+    if pa.types.is_timestamp(t):
+        return 8
+    raise CometNativeException(f"no fixed value width for {t}")
+
+
+class _ExportedBatch:
+    """Owns the ArrowDeviceArrays a plan exported (comet_execute_plan_device); releases them when collected."""
+
+    def __init__(self, arrays):
+        self.arrays = arrays
+
+    def __del__(self):
+        for a in self.arrays:
+            try:
+                if a.array.release:
+                    _RELEASE_T(a.array.release)(ctypes.addressof(a.array))
+            except Exception:
+                pass
+
+
+class _DeviceBuffer:
+    """One exported HBM buffer, visible to torch through __cuda_array_interface__ (zero copy; keeps its batch alive)."""
+
+    def __init__(self, owner, ptr: int, nbytes: int):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
 
 
 class DeviceInput:
@@ -329,6 +383,47 @@ class Native:
         return pa.RecordBatch.from_arrays(cols, names=[f"col_{i}" for i in range(len(cols))])
 
     @staticmethod
+    def executePlanDevice(handle: int, num_output_cols: int) -> Optional["DeviceTable"]:
+        """comet_execute_plan_device: the whole result as ONE batch that stays in HBM (None at end of stream).  The returned
+        DeviceTable's tensors alias the library's buffers (zero copy) and keep them alive."""
+        import torch
+        l = lib()
+        arrays = [ArrowDeviceArrayC() for _ in range(num_output_cols)]
+        schemas = [ArrowSchemaC() for _ in range(num_output_cols)]
+        aaddr = (ctypes.c_void_p * max(num_output_cols, 1))(*[ctypes.addressof(a) for a in arrays])
+        saddr = (ctypes.c_void_p * max(num_output_cols, 1))(*[ctypes.addressof(s) for s in schemas])
+        rows = l.comet_execute_plan_device(handle, aaddr, saddr, num_output_cols)
+        if rows == -1:
+            return None
+        if rows < 0:
+            _raise_last(handle)
+        owner = _ExportedBatch(arrays)
+        fields = [pa.Field._import_from_c(ctypes.addressof(s)).with_name(f"col_{i}") for i, s in enumerate(schemas)]
+        device = f"cuda:{arrays[0].device_id}" if arrays else "cuda:0"
+
+        def wrap(ptr, nbytes):
+            if not ptr or nbytes == 0:
+                return torch.empty(0, dtype=torch.uint8, device=device)
+            return torch.as_tensor(_DeviceBuffer(owner, ptr, nbytes), device=device)
+
+        vals, valid, aux = [], [], []
+        for a, f in zip(arrays, fields):
+            if a.device_type != ARROW_DEVICE_ROCM:
+                raise CometNativeException(f"unexpected device type {a.device_type}")
+            b = a.array.buffers
+            if pa.types.is_string(f.type) or pa.types.is_binary(f.type):
+                offs = wrap(b[1], (rows + 1) * 4)
+                total = int(offs.view(torch.int32)[-1].item()) if rows else 0
+                vals.append(offs)
+                aux.append(wrap(b[2], max(total, 1)))
+            else:
+                w = value_width(f.type)
+                vals.append(wrap(b[1], (rows + 7) // 8 if w == 0 else rows * w))
+                aux.append(None)
+            valid.append(wrap(b[0], (rows + 7) // 8) if b[0] else None)
+        return DeviceTable(pa.schema(fields), rows, vals, valid, device, aux)
+
+    @staticmethod
     def releasePlan(handle: int) -> None:
         lib().comet_release_plan(handle)
 
@@ -387,6 +482,78 @@ def execute_to_table(inputs: Sequence, num_output_cols: int, plan: bytes, **kw) 
         return list(it)
     finally:
         it.close()
+
+
+def execute_to_device(inputs: Sequence, num_output_cols: int, plan: bytes, device_id: int = 0, config: bytes = b"") -> DeviceTable:
+    """createPlan → executePlanDevice → releasePlan; the result keeps its buffers alive after the plan is released."""
+    keep = list(inputs)
+    h = Native.createPlan(keep, plan, config, 1, 0, device_id)
+    try:
+        t = Native.executePlanDevice(h, num_output_cols)
+        if t is None:
+            raise CometNativeException("plan produced no device batch")
+        return t
+    finally:
+        Native.releasePlan(h)
+
+
+def _stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def partition_ids(table: DeviceTable, key_cols: Sequence[int], num_partitions: int):
+    """Spark hash partitioning on device: murmur3 (seed 42, chained over key_cols) then pmod (comet_murmur3_column,
+    comet_pmod_partition).  Returns an int32 torch tensor of table.num_rows partition ids."""
+    import torch
+    from . import serde as S
+    n = table.num_rows
+    hashes = torch.full((max(n, 1),), 42, dtype=torch.int32, device=table.device)   # same bits as u32 42
+    st = _stream_ptr()
+    for c in key_cols:
+        t = table.schema.field(c).type
+        tid, prec = S.arrow_type_id(t)
+        rc = lib().comet_murmur3_column(tid, prec, table.values[c].data_ptr() if table.values[c].numel() else None,
+                                        table.validity[c].data_ptr() if table.validity[c] is not None else None,
+                                        table.aux[c].data_ptr() if table.aux[c] is not None else None, n, hashes.data_ptr(), st)
+        if rc != 0:
+            _raise_last(0)
+    pids = torch.empty((max(n, 1),), dtype=torch.int32, device=table.device)
+    if lib().comet_pmod_partition(hashes.data_ptr(), n, num_partitions, pids.data_ptr(), st) != 0:
+        _raise_last(0)
+    return pids[:n]
+
+
+def partition_table(table: DeviceTable, pids, num_partitions: int):
+    """Group the rows of `table` by partition id (comet_partition_indices + comet_take_column per buffer).
+    Returns (DeviceTable with rows grouped by partition, partition_starts as a Python list of P+1 ints)."""
+    import torch
+    n = table.num_rows
+    dev = table.device
+    st = _stream_ptr()
+    starts = torch.empty((num_partitions + 1,), dtype=torch.int64, device=dev)
+    idx = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    if lib().comet_partition_indices(pids.data_ptr() if n else None, n, num_partitions, starts.data_ptr(), idx.data_ptr(), st) != 0:
+        _raise_last(0)
+    vals, valid, aux = [], [], []
+    for i, f in enumerate(table.schema):
+        if pa.types.is_string(f.type) or pa.types.is_binary(f.type):
+            raise CometNativeException("Utf8 columns cannot cross the GPU exchange yet")
+        w = value_width(f.type)
+        out = torch.empty(((n + 7) // 8 if w == 0 else n * w,), dtype=torch.uint8, device=dev)
+        if n and lib().comet_take_column(w, table.values[i].data_ptr(), idx.data_ptr(), n, out.data_ptr(), st) != 0:
+            _raise_last(0)
+        vals.append(out)
+        aux.append(None)
+        if table.validity[i] is not None:
+            vb = torch.empty(((n + 7) // 8,), dtype=torch.uint8, device=dev)
+            if n and lib().comet_take_column(0, table.validity[i].data_ptr(), idx.data_ptr(), n, vb.data_ptr(), st) != 0:
+                _raise_last(0)
+            valid.append(vb)
+        else:
+            valid.append(None)
+    torch.cuda.current_stream().synchronize()
+    return DeviceTable(table.schema, n, vals, valid, dev, aux), [int(x) for x in starts.cpu().tolist()]
 
 
 def compile_plan(plan: bytes) -> str:

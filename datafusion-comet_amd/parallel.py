@@ -63,3 +63,173 @@ def run_sharded_aggregate(table_rows: int, load_shard: Callable[[int, int], pa.T
     if rank != 0 or gathered is None:
         return None
     return run_final(gathered)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Exchange between stages (hash-partitioned plans: joins, high-cardinality aggregates) — SURVEY §8e / config 4.
+#
+# A stage's output stays in HBM (comet_execute_plan_device); rows are assigned to partitions exactly like Spark's
+# HashPartitioning (murmur3 seed 42 chained over the key columns, pmod num_partitions — the reference's shuffle writer,
+# native/shuffle/src/partitioners/multi_partition.rs:280-330), grouped by partition on device (comet_partition_indices +
+# comet_take_column) and moved with ONE all-to-all per buffer over RCCL (torch.distributed backend "nccl"; xGMI is
+# point-to-point, so the all-to-all maps 1:1 onto the links).  partition p of the exchange lives on rank p.
+# ------------------------------------------------------------------------------------------------------------------
+
+
+class HipPartitioner:
+    """The product partitioner: every step is a HIP kernel of libcomet.so on the table's GPU."""
+
+    def __call__(self, table, key_cols, num_partitions):
+        from . import native
+        pids = native.partition_ids(table, key_cols, num_partitions)
+        return native.partition_table(table, pids, num_partitions)
+
+
+def _unpack_bits(bits, n):
+    import torch
+    sh = torch.arange(8, device=bits.device, dtype=torch.uint8)
+    return ((bits[:, None] >> sh) & 1).reshape(-1)[:n].contiguous()
+
+
+def _pack_bits(bytes_):
+    import torch
+    n = bytes_.numel()
+    pad = (-n) % 8
+    if pad:
+        bytes_ = torch.cat([bytes_, torch.zeros(pad, dtype=torch.uint8, device=bytes_.device)])
+    sh = torch.arange(8, device=bytes_.device, dtype=torch.uint8)
+    return (bytes_.reshape(-1, 8) << sh).sum(dim=1, dtype=torch.int32).to(torch.uint8)
+
+
+def exchange(table, key_cols, partitioner, group=None):
+    """Hash-repartition `table` (a native.DeviceTable; this rank's part of a distributed table) on `key_cols` across the
+    ranks of `group`.  Returns the rows whose partition id equals this rank, as a DeviceTable.  Rows from one sender keep
+    their order; senders are concatenated in rank order."""
+    import pyarrow as pa
+    import torch
+    import torch.distributed as dist
+    from .native import DeviceTable, value_width
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    part, starts = partitioner(table, key_cols, world)
+    if world == 1:
+        return part
+    dev = part.values[0].device if part.values else torch.device(table.device)
+    send = [starts[i + 1] - starts[i] for i in range(world)]
+    t_send = torch.tensor(send, dtype=torch.int64, device=dev)
+    t_recv = torch.empty_like(t_send)
+    dist.all_to_all_single(t_recv, t_send, group=group)
+    recv = [int(x) for x in t_recv.tolist()]
+    n_in, n_out = part.num_rows, sum(recv)
+    # a column carries validity after the exchange iff it does on any rank
+    flags = torch.tensor([1 if v is not None else 0 for v in part.validity], dtype=torch.int32, device=dev)
+    if flags.numel():
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    any_valid = [bool(x) for x in flags.tolist()]
+
+    def a2a(rows):   # rows: [n_in, w] uint8
+        out = torch.empty((n_out, rows.shape[1]), dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv, input_split_sizes=send, group=group)
+        return out
+
+    vals, valid = [], []
+    for i, f in enumerate(part.schema):
+        if pa.types.is_string(f.type) or pa.types.is_binary(f.type):
+            raise NotImplementedError("Utf8 columns cannot cross the exchange yet")
+        w = value_width(f.type)
+        if w == 0:   # Boolean values travel one byte per row (partition boundaries are not byte aligned)
+            vals.append(_pack_bits(a2a(_unpack_bits(part.values[i], n_in).reshape(n_in, 1)).reshape(-1)))
+        else:
+            vals.append(a2a(part.values[i].reshape(n_in, w)).reshape(-1))
+        if any_valid[i]:
+            vb = _unpack_bits(part.validity[i], n_in) if part.validity[i] is not None else torch.ones(n_in, dtype=torch.uint8, device=dev)
+            valid.append(_pack_bits(a2a(vb.reshape(n_in, 1)).reshape(-1)))
+        else:
+            valid.append(None)
+    return DeviceTable(part.schema, n_out, vals, valid, table.device, [None] * len(vals))
+
+
+class GpuEngine:
+    """Runs one stage plan on this rank's GPU through the C ABI (device-resident inputs and outputs)."""
+
+    def __init__(self, device_id: int = 0):
+        self.device_id = device_id
+        self.kernel_ms = 0.0
+
+    def _inputs(self, tables):
+        from . import native
+        return [native.DeviceInput(t, self.device_id) if isinstance(t, native.DeviceTable) else native.HostInput.from_table(t) for t in tables]
+
+    def run_device(self, plan, tables, ncols):
+        from . import native
+        return native.execute_to_device(self._inputs(tables), ncols, plan.encode(), device_id=self.device_id)
+
+    def run_host(self, plan, tables, ncols):
+        from . import native
+        out = native.execute_to_table(self._inputs(tables), ncols, plan.encode(), batch_size=0, device_id=self.device_id)
+        return pa.Table.from_batches(out) if out else None
+
+
+def q3_top10(final: Optional[pa.Table]) -> list:
+    """ORDER BY revenue DESC, o_orderdate LIMIT 10 over (l_orderkey, o_orderdate, o_shippriority, revenue) rows — Spark's
+    TakeOrderedAndProject, which stays on the JVM side (outside the native hot path)."""
+    if final is None or final.num_rows == 0:
+        return []
+    rows = list(zip(*[final.column(i).to_pylist() for i in range(final.num_columns)]))
+    rows.sort(key=lambda r: (-r[3], r[1], r[0]))
+    return rows[:10]
+
+
+def run_q3_distributed(engine, partitioner, customer, orders, lineitem, group=None, timings: Optional[dict] = None):
+    """TPC-H Q3 over the ranks of `group`: each rank holds an arbitrary shard of the three tables.  Stages follow
+    tpch.q3_stage_plans(); three exchanges on the join keys; aggregation is partition-local because l_orderkey is both the
+    last exchange key and a group key.  Returns (top-10 rows on rank 0 else None, number of result groups on this rank)."""
+    import time
+    import torch.distributed as dist
+    from . import serde as S, tpch
+    st = tpch.q3_stage_plans()
+
+    def clock():
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        return time.perf_counter()
+
+    def stage(name, inputs):
+        plan, ncols, key = st[name]
+        t0 = clock()
+        out = engine.run_device(plan, inputs, ncols)
+        t1 = clock()
+        res = exchange(out, [key], partitioner, group)
+        t2 = clock()
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + (t1 - t0)
+            timings["exchange"] = timings.get("exchange", 0.0) + (t2 - t1)
+            timings["exchange_rows"] = timings.get("exchange_rows", 0) + out.num_rows
+            timings["exchange_bytes"] = timings.get("exchange_bytes", 0) + out.nbytes()
+        return res
+
+    c = stage("customer", [customer])
+    o = stage("orders", [orders])
+    j1 = stage("join1", [c, o])
+    l = stage("lineitem", [lineitem])
+    plan, ncols, _ = st["join2agg"]
+    t0 = clock()
+    partial = engine.run_host(plan, [j1, l], ncols)
+    final = engine.run_host(S.final_of(plan, partial.schema), [partial], 4) if partial is not None and partial.num_rows else None
+    if timings is not None:
+        timings["join2agg"] = timings.get("join2agg", 0.0) + (clock() - t0)
+    local = q3_top10(final)
+    groups = final.num_rows if final is not None else 0
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local, groups
+    rank = dist.get_rank(group)
+    out = [None] * dist.get_world_size(group) if rank == 0 else None
+    dist.gather_object(local, out, dst=0, group=group)
+    if rank != 0:
+        return None, groups
+    merged = [r for part in out for r in part]
+    merged.sort(key=lambda r: (-r[3], r[1], r[0]))
+    return merged[:10], groups

@@ -83,6 +83,26 @@ T_FLOAT, T_DOUBLE, T_STRING, T_DATE, T_TIMESTAMP = (DataType(t) for t in (FLOAT,
 
 LEGACY, TRY, ANSI = 0, 1, 2
 
+
+def from_arrow_type(t) -> DataType:
+    """pyarrow DataType → spark.spark_expression.DataType (inverse of to_arrow_datatype, execution/serde.rs:71-200)."""
+    import pyarrow as pa
+    if pa.types.is_decimal(t):
+        return decimal(t.precision, t.scale)
+    if pa.types.is_timestamp(t):
+        return T_TIMESTAMP if t.tz else DataType(TIMESTAMP_NTZ)
+    m = {pa.bool_(): T_BOOL, pa.int8(): T_INT8, pa.int16(): T_INT16, pa.int32(): T_INT32, pa.int64(): T_INT64, pa.float32(): T_FLOAT,
+         pa.float64(): T_DOUBLE, pa.utf8(): T_STRING, pa.binary(): DataType(BYTES), pa.date32(): T_DATE}
+    if t not in m:
+        raise ValueError(f"no Spark type for Arrow {t}")
+    return m[t]
+
+
+def arrow_type_id(t):
+    """(DataTypeId, precision) as comet_murmur3_column expects them."""
+    d = from_arrow_type(t)
+    return d.type_id, d.precision
+
 # --------------------------------------------------------------------------- expressions (expr.proto)
 
 
@@ -373,6 +393,14 @@ def project(child: Operator, exprs: Sequence[Expr]) -> Operator:
 
 def hash_agg(child: Operator, grouping: Sequence[Expr], aggs: Sequence[AggExpr], mode: int = PARTIAL) -> Operator:
     return Operator("hash_agg", [child], exprs=list(grouping), aggs=list(aggs), mode=mode)
+
+
+def final_of(partial_plan: "Operator", state_schema) -> "Operator":
+    """HashAggregate(Final) over a Scan of a Partial plan's output (group columns, then each aggregate's state columns) —
+    the stage Spark plans after the exchange (planner.rs:1248-1384 with AggregateMode::Final)."""
+    fields = [from_arrow_type(f.type) for f in state_schema]
+    ng = len(partial_plan.exprs)
+    return hash_agg(scan(fields), [col(i, fields[i]) for i in range(ng)], partial_plan.aggs, FINAL)
 
 
 def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType]) -> Operator:

@@ -134,7 +134,7 @@ Q1_BYTES_PER_ROW = 4 + 4 * 16 + 2 * (4 + 1)
 
 def warm_plans():
     """Plans whose fused kernels build() pre-compiles into the code-object cache."""
-    return [q6_plan(), q1_plan()]
+    return [q6_plan(), q1_plan()] + [pl for pl, _, _ in q3_stage_plans().values()]
 
 
 # ------------------------------------------------------------------ Q3 (SURVEY §3.5, §8d config 4)
@@ -198,6 +198,34 @@ def q3_plan() -> S.Operator:
 Q3_NUM_OUTPUT_COLS = 3 + 2
 
 
+def q3_stage_plans() -> dict:
+    """TPC-H Q3 cut at its exchanges, the way Spark plans it for a partitioned run: every stage is one native
+    plan per partition; `exchange` names the hash-partitioning key column of the stage's output (None = no exchange).
+
+      customer:  Scan → Filter(c_mktsegment = 'BUILDING') → Project(c_custkey)                       ⇒ hash(c_custkey)
+      orders:    Scan → Filter(o_orderdate < 1995-03-15)                                             ⇒ hash(o_custkey)
+      join1:     customer' ⋈ orders' on custkey → Project(o_orderkey, o_orderdate, o_shippriority)   ⇒ hash(o_orderkey)
+      lineitem:  Scan → Filter(l_shipdate > 1995-03-15) → Project(l_orderkey, price, discount)       ⇒ hash(l_orderkey)
+      join2agg:  join1' ⋈ lineitem' on orderkey → Project → HashAggregate(Partial)   (groups are partition-local)
+    """
+    cutoff = days(1995, 3, 15)
+    I64, DATE, I32 = S.T_INT64, S.T_DATE, S.T_INT32
+    customer = S.project(S.filter_(S.scan([I64, S.T_STRING]), S.eq(S.col(1, S.T_STRING), S.lit("BUILDING", S.T_STRING))), [S.col(0, I64)])
+    ofields = [I64, I64, DATE, I32]
+    orders = S.project(S.filter_(S.scan(ofields), S.lt(S.col(2, DATE), S.lit(cutoff, DATE))), [S.col(i, t) for i, t in enumerate(ofields)])
+    j1 = S.hash_join(S.scan([I64]), S.scan(ofields), [S.col(0, I64)], [S.col(1, I64)], S.INNER, S.BUILD_LEFT)
+    join1 = S.project(j1, [S.col(1, I64), S.col(3, DATE), S.col(4, I32)])
+    lineitem = S.project(S.filter_(S.scan([I64, DEC, DEC, DATE]), S.gt(S.col(3, DATE), S.lit(cutoff, DATE))),
+                         [S.col(0, I64), S.col(1, DEC), S.col(2, DEC)])
+    j2 = S.hash_join(S.scan([I64, DATE, I32]), S.scan([I64, DEC, DEC]), [S.col(0, I64)], [S.col(0, I64)], S.INNER, S.BUILD_LEFT)
+    one_minus = S.check_overflow(S.math("subtract", S.lit(100, DEC), S.col(5, DEC), S.decimal(13, 2)), S.decimal(13, 2))
+    rev = S.check_overflow(S.math("multiply", S.col(4, DEC), one_minus, S.decimal(26, 4)), S.decimal(26, 4))
+    p = S.project(j2, [S.col(3, I64), S.col(1, DATE), S.col(2, I32), rev])
+    join2agg = S.hash_agg(p, [S.col(0, I64), S.col(1, DATE), S.col(2, I32)], [S.sum_(S.col(3, S.decimal(26, 4)), S.decimal(36, 4))])
+    return {"customer": (customer, 1, 0), "orders": (orders, 4, 1), "join1": (join1, 3, 0), "lineitem": (lineitem, 3, 0),
+            "join2agg": (join2agg, Q3_NUM_OUTPUT_COLS, None)}   # name → (plan, output columns, exchange key column)
+
+
 def lineitem_q1_device(n: int, device="cuda:0", seed: int = 1):
     """The Q1 lineitem columns generated directly in HBM with torch (SF100 = 600 M rows = 46.8 GB does not have to pass
     through host memory).  Same distributions as lineitem_q1; returns a native.DeviceTable."""
@@ -228,3 +256,102 @@ def lineitem_q1_device(n: int, device="cuda:0", seed: int = 1):
     aux = [None, None, None, None, rf, ls, None]
     checks = {"qty": qty, "price": price, "ship": ship, "rf": rf, "ls": ls}
     return DeviceTable(schema, n, values, [None] * 7, device, aux), checks
+
+
+def q3_tables_device(n_orders: int, world: int = 1, rank: int = 0, device="cuda:0", seed: int = 3):
+    """This rank's shard of the Q3 tables generated directly in HBM (same shapes as q3_tables; SF100 = 150 M orders):
+    orders rows shard_range(n_orders), their lineitems (1..7 each), customers shard_range(n_orders/10).  Deterministic in
+    (seed, world, rank).  Returns (customer, orders, lineitem DeviceTables, raw) where raw holds the generating tensors
+    for an independent torch cross-check."""
+    import torch
+    from .native import DeviceTable
+    from .parallel import shard_range
+    g = torch.Generator(device=device)
+    g.manual_seed(seed * 1000 + rank)
+    n_c_total = max(1, n_orders // 10)
+    c0, nc = shard_range(n_c_total, world, rank)
+    o0, no = shard_range(n_orders, world, rank)
+    u8 = lambda t: t.contiguous().view(torch.uint8).reshape(-1)
+
+    def dec(v):
+        buf = torch.zeros((v.numel(), 2), dtype=torch.int64, device=device)
+        buf[:, 0] = v
+        return buf.view(torch.uint8).reshape(-1)
+
+    # customer
+    ckey = torch.arange(c0 + 1, c0 + nc + 1, device=device, dtype=torch.int64)
+    seg = torch.randint(0, 5, (nc,), generator=g, device=device)
+    width = max(len(s) for s in SEGMENTS)
+    tab = torch.zeros((5, width), dtype=torch.uint8)
+    lens = torch.zeros(5, dtype=torch.int32)
+    for i, s in enumerate(SEGMENTS):
+        tab[i, :len(s)] = torch.tensor(list(s), dtype=torch.uint8)
+        lens[i] = len(s)
+    tab, lens = tab.to(device), lens.to(device)
+    offs = torch.zeros(nc + 1, dtype=torch.int32, device=device)
+    offs[1:] = torch.cumsum(lens[seg], 0, dtype=torch.int32)
+    mask = torch.arange(width, device=device)[None, :] < lens[seg][:, None]
+    cbytes = tab[seg][mask]
+    if cbytes.numel() == 0:
+        cbytes = torch.zeros(1, dtype=torch.uint8, device=device)
+    customer = DeviceTable(pa.schema([("c_custkey", pa.int64()), ("c_mktsegment", pa.utf8())]), nc, [u8(ckey), u8(offs)], [None, None], device,
+                           [None, cbytes])
+    # orders
+    oi = torch.arange(o0, o0 + no, device=device, dtype=torch.int64)
+    okey = (oi // 8) * 32 + (oi % 8) + 1
+    ocust = torch.randint(1, n_c_total + 1, (no,), generator=g, device=device, dtype=torch.int64)
+    odate = torch.randint(days(1992, 1, 1), days(1998, 8, 2) + 1, (no,), generator=g, device=device, dtype=torch.int32)
+    oprio = torch.zeros(no, dtype=torch.int32, device=device)
+    orders = DeviceTable(pa.schema([("o_orderkey", pa.int64()), ("o_custkey", pa.int64()), ("o_orderdate", pa.date32()), ("o_shippriority", pa.int32())]),
+                         no, [u8(okey), u8(ocust), u8(odate), u8(oprio)], [None] * 4, device)
+    # lineitem
+    per = torch.randint(1, 8, (no,), generator=g, device=device)
+    lo = torch.repeat_interleave(torch.arange(no, device=device), per)
+    nl = lo.numel()
+    lkey = okey[lo]
+    qty = torch.randint(1, 51, (nl,), generator=g, device=device, dtype=torch.int64)
+    price = qty * torch.randint(90000, 210001, (nl,), generator=g, device=device, dtype=torch.int64)
+    disc = torch.randint(0, 11, (nl,), generator=g, device=device, dtype=torch.int64)
+    ship = (odate[lo] + torch.randint(1, 122, (nl,), generator=g, device=device, dtype=torch.int32)).to(torch.int32)
+    lineitem = DeviceTable(pa.schema([("l_orderkey", pa.int64()), ("l_extendedprice", pa.decimal128(12, 2)), ("l_discount", pa.decimal128(12, 2)),
+                                      ("l_shipdate", pa.date32())]), nl, [u8(lkey), dec(price), dec(disc), u8(ship)], [None] * 4, device)
+    raw = {"c0": c0, "seg": seg, "o0": o0, "ocust": ocust, "odate": odate, "lo": lo, "price": price, "disc": disc, "ship": ship}
+    return customer, orders, lineitem, raw
+
+
+def q3_torch_reference(n_orders: int, world: int, device="cuda:0", seed: int = 3, top: int = 10):
+    """Independent answer for the tables q3_tables_device generates (all ranks' shards regenerated one after the other):
+    dense lookups instead of hash joins, exact int64 arithmetic.  Returns (top rows as (orderkey, orderdate days,
+    shippriority, unscaled revenue at scale 4), number of result groups)."""
+    import torch
+    cutoff = days(1995, 3, 15)
+    n_c_total = max(1, n_orders // 10)
+    building = torch.zeros(n_c_total + 1, dtype=torch.bool, device=device)
+    shards = []
+    for r in range(world):
+        _, _, _, raw = q3_tables_device(n_orders, world, r, device, seed)
+        nc = raw["seg"].numel()
+        building[raw["c0"] + 1: raw["c0"] + nc + 1] = raw["seg"] == SEGMENTS.index(b"BUILDING")
+        shards.append(raw)
+    revenue = torch.zeros(n_orders, dtype=torch.int64, device=device)
+    hit = torch.zeros(n_orders, dtype=torch.bool, device=device)
+    odate_all = torch.zeros(n_orders, dtype=torch.int32, device=device)
+    for raw in shards:
+        no = raw["ocust"].numel()
+        ok_order = building[raw["ocust"]] & (raw["odate"] < cutoff)
+        odate_all[raw["o0"]: raw["o0"] + no] = raw["odate"]
+        keep = ok_order[raw["lo"]] & (raw["ship"] > cutoff)
+        idx = raw["lo"][keep] + raw["o0"]
+        revenue.index_add_(0, idx, raw["price"][keep] * (100 - raw["disc"][keep]))
+        hit[idx] = True
+    groups = int(hit.sum().item())
+    cand = torch.nonzero(hit).reshape(-1)
+    rev = revenue[cand]
+    k = min(top * 50, cand.numel())
+    _, pos = torch.topk(rev, k)
+    rows = []
+    for p in pos.tolist():
+        oi = int(cand[p].item())
+        rows.append(((oi // 8) * 32 + (oi % 8) + 1, int(odate_all[oi].item()), 0, int(rev[p].item())))
+    rows.sort(key=lambda r: (-r[3], r[1], r[0]))
+    return rows[:top], groups

@@ -22,6 +22,7 @@ extern "C" {
 
 struct ArrowArray;
 struct ArrowSchema;
+struct ArrowDeviceArray;
 
 /* how input i is handed over */
 #define COMET_INPUT_HOST_STREAM 0   /* struct ArrowArrayStream*       — JVM path (CometNativeArrowSource.scala:67) */
@@ -51,6 +52,15 @@ int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* c
  * Returns the number of rows, -1 at end of stream, -2 on error. */
 int64_t comet_execute_plan(int64_t handle, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas,
                            int32_t n_out);
+
+/* Device-resident variant of comet_execute_plan for plans that end in Filter / Projection / HashJoin (not aggregates):
+ * the whole result is ONE batch that stays in HBM; out_arrays[i] is filled as an ArrowDeviceArray with
+ * device_type = ARROW_DEVICE_ROCM, device_id = the plan's device, sync_event = NULL (the plan's stream has been
+ * synchronised) and null_count = -1 where a validity bitmap is present.  This is the stage boundary of a multi-GPU
+ * plan: what the reference hands to its shuffle writer (ShuffleWriterExec input, native/shuffle/src/shuffle_writer.rs)
+ * stays on the GPU for the RCCL exchange.  Returns rows, -1 at end of stream (second call), -2 on error. */
+int64_t comet_execute_plan_device(int64_t handle, struct ArrowDeviceArray** out_arrays, struct ArrowSchema** out_schemas,
+                                  int32_t n_out);
 
 /* Replaces Java_org_apache_comet_Native_releasePlan (jni_api.rs:961-990). Safe mid-stream. */
 void comet_release_plan(int64_t handle);
@@ -86,6 +96,21 @@ int32_t comet_murmur3_column(int32_t type_id, int32_t precision, const void* val
                              const void* aux_bytes, int64_t n, uint32_t* hashes, void* hip_stream);
 int32_t comet_pmod_partition(const uint32_t* hashes, int64_t n, int32_t num_partitions, int32_t* partition_ids,
                              void* hip_stream);
+
+/* Exchange bookkeeping on device — replaces ScratchSpace::map_partition_ids_to_starts_and_indices
+ * (native/shuffle/src/partitioners/multi_partition.rs:54-103): from one partition id per row compute
+ *   partition_starts[num_partitions + 1]  (int64, device)  — slice k = [starts[k], starts[k+1])
+ *   partition_row_indices[n]              (uint32, device) — row numbers grouped by partition, ascending inside each
+ * e.g. ids [3,1,1,1,2,2,0] → indices [6,1,2,3,4,5,0], starts [0,1,4,6,7] (the reference's own example, :78-84).
+ * Synchronises hip_stream before returning.  n < 2^32, num_partitions ≤ 4096.  Returns 0, or -2 on error. */
+int32_t comet_partition_indices(const int32_t* partition_ids, int64_t n, int32_t num_partitions, int64_t* partition_starts,
+                                uint32_t* partition_row_indices, void* hip_stream);
+
+/* dst[k] = src[row_indices[k]] for one buffer of a column — the per-partition `take` that builds the outgoing
+ * batches (multi_partition.rs:457-520, partitioned_batch_iterator.rs).  width_bytes ∈ {1,2,4,8,16}, or 0 for
+ * bit-packed buffers (validity bitmaps, Boolean values).  Asynchronous on hip_stream.  Returns 0, or -2 on error. */
+int32_t comet_take_column(int32_t width_bytes, const void* src, const uint32_t* row_indices, int64_t n, void* dst,
+                          void* hip_stream);
 
 /* Host-only description of a Parquet footer as parsed by the library's own Thrift reader (rows, row groups, schema
  * elements, per-chunk codec/offsets) — the metadata the NativeScan path (native/core/src/parquet/parquet_exec.rs:60-211)

@@ -90,6 +90,22 @@ void o_pmod_array(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out) {
   for (int64_t i = 0; i < n; i++) out[i] = o_pmod(hashes[i], np);
 }
 
+/* ScratchSpace::map_partition_ids_to_starts_and_indices — native/shuffle/src/partitioners/multi_partition.rs:54-103:
+ * count per partition, running sum into partition ends, then fill the row indices from the LAST row backwards so
+ * that each partition's slice lists its rows in ascending order; the ends have become the starts afterwards.
+ * partition_starts has np + 1 entries (the extra last one is the row count). */
+void o_partition_starts_and_indices(const int32_t* partition_ids, int64_t n, int32_t np, uint32_t* partition_starts,
+                                    uint32_t* partition_row_indices) {
+  for (int32_t p = 0; p <= np; p++) partition_starts[p] = 0;
+  for (int64_t i = 0; i < n; i++) partition_starts[partition_ids[i]] += 1;                  /* :65-67 */
+  uint32_t accum = 0;
+  for (int32_t p = 0; p <= np; p++) { partition_starts[p] += accum; accum = partition_starts[p]; }  /* :71-76 */
+  for (int64_t i = n - 1; i >= 0; i--) {                                                       /* :93-97 */
+    uint32_t end = --partition_starts[partition_ids[i]];
+    partition_row_indices[end] = (uint32_t)i;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * i256 (arrow_buffer::i256 semantics: two's complement, wrapping ops) — four little-endian u64 limbs
  * ---------------------------------------------------------------------------------------------- */

@@ -757,6 +757,43 @@ def _i128(v: int) -> _I128:
     return _I128(v & 0xFFFFFFFFFFFFFFFF, v >> 64)
 
 
+def partition_starts_and_indices(pids: np.ndarray, num_partitions: int):
+    """multi_partition.rs:54-103 → (partition_starts[P+1] uint32, partition_row_indices[n] uint32)."""
+    pids = np.ascontiguousarray(pids, dtype=np.int32)
+    starts = np.zeros(num_partitions + 1, np.uint32)
+    idx = np.zeros(max(len(pids), 1), np.uint32)
+    _lib().o_partition_starts_and_indices(_p(pids), ctypes.c_int64(len(pids)), ctypes.c_int32(num_partitions), _p(starts), _p(idx))
+    return starts, idx[:len(pids)]
+
+
+def hash_partition_ids(S, table: pa.Table, key_cols, num_partitions: int) -> np.ndarray:
+    """Spark HashPartitioning ids: murmur3 seed 42 chained over the key columns (hash_funcs/utils.rs:573-760), pmod
+    (comet_partitioning.rs:51-57) — the shuffle writer's computation at multi_partition.rs:296-312."""
+    C = _lib()
+    n = table.num_rows
+    h = np.full(max(n, 1), 42, np.uint32)
+    for c in key_cols:
+        arr = table.column(c).combine_chunks() if isinstance(table.column(c), pa.ChunkedArray) else table.column(c)
+        t = arr.type
+        vb = None
+        if arr.null_count:
+            vb = np.asarray(arr.is_valid()).astype(np.uint8)
+        if pa.types.is_decimal(t):
+            col = col_from_arrow(S, arr, S.from_arrow_type(t))
+            C.o_murmur3_decimal(_p(np.ascontiguousarray(col.values)), ctypes.c_int32(t.precision), _p(vb), ctypes.c_int64(n), _p(h))
+        elif t in (pa.int64(),) or pa.types.is_timestamp(t):
+            a = np.ascontiguousarray(np.asarray(arr.cast(pa.int64()).fill_null(0)), dtype=np.int64)
+            C.o_murmur3_i64(_p(a), _p(vb), ctypes.c_int64(n), _p(h))
+        elif t in (pa.int32(), pa.date32(), pa.int16(), pa.int8()):
+            a = np.ascontiguousarray(np.asarray(arr.cast(pa.int32()).fill_null(0)), dtype=np.int32)
+            C.o_murmur3_i32(_p(a), _p(vb), ctypes.c_int64(n), _p(h))
+        else:
+            raise OracleError(f"hash partitioning on {t} is not restated")
+    out = np.zeros(max(n, 1), np.int32)
+    C.o_pmod_array(_p(h), ctypes.c_int64(n), ctypes.c_int32(num_partitions), _p(out))
+    return out[:n]
+
+
 def run_plan_to_arrow(S, op, table) -> pa.Table:
     cols = run_plan(S, op, table)
     return pa.table([col_to_arrow(S, c) for c in cols], names=[f"col_{i}" for i in range(len(cols))])

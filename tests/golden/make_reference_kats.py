@@ -81,6 +81,9 @@ K["avg_decimal_golden_q1"] = [
     {"sum": "56568041380.90", "count": 1478870, "avg": "38250.854626"},
 ]
 # native/core/src/execution/planner.rs:4637-4699: `col = 3` over n % 4, 100 rows → 25 rows
+# native/shuffle/src/partitioners/multi_partition.rs:78-84 (the worked example in map_partition_ids_to_starts_and_indices)
+K["partition_indices"] = {"partition_ids": [3, 1, 1, 1, 2, 2, 0], "num_partitions": 4,
+                          "partition_row_indices": [6, 1, 2, 3, 4, 5, 0], "partition_starts": [0, 1, 4, 6, 7]}
 K["planner_filter_case"] = {"rows": 100, "modulus": 4, "equals": 3, "expected_rows": 25}
 
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")

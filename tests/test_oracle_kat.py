@@ -224,3 +224,17 @@ def test_oracle_q6_agrees_with_pyarrow_compute():
                         pc.less(t["l_quantity"], d("24.00"))))
     f = t.filter(m)
     assert out.column(0)[0].as_py() == pc.sum(pc.multiply(f["l_extendedprice"], f["l_discount"])).as_py()
+
+
+def test_partition_starts_and_indices_reference_example():
+    # multi_partition.rs:78-84
+    k = K["partition_indices"]
+    starts, idx = O.partition_starts_and_indices(np.array(k["partition_ids"]), k["num_partitions"])
+    assert starts.tolist() == k["partition_starts"]
+    assert idx.tolist() == k["partition_row_indices"]
+    # ≡ a stable sort by partition id
+    rng = np.random.default_rng(5)
+    pids = rng.integers(0, 13, 10_000)
+    starts, idx = O.partition_starts_and_indices(pids, 13)
+    assert np.array_equal(idx, np.argsort(pids, kind="stable"))
+    assert np.array_equal(starts, np.concatenate([[0], np.cumsum(np.bincount(pids, minlength=13))]))

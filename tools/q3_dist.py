@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""TPC-H Q3 over N GPUs of one node: one process per GPU (torch.distributed, backend nccl = RCCL),
+tables generated in HBM, three hash exchanges (murmur3/pmod → partition → all-to-all over xGMI), partition-local join +
+aggregate.  Strong scaling: the total size (--orders) is fixed, every rank holds 1/N of it.
+
+  single GPU:  python tools/q3_dist.py --orders 15000000
+  N GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/q3_dist.py ...
+
+Prints one JSON line on rank 0 (and writes it to --out if given)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--orders", type=int, default=15_000_000, help="total orders rows (SF100 = 150 M; lineitem ≈ 4×)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    from datafusion_comet_amd import parallel, tpch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    customer, orders, lineitem, _ = tpch.q3_tables_device(a.orders, world, rank, dev, a.seed)
+    rows_local = customer.num_rows + orders.num_rows + lineitem.num_rows
+    bytes_local = customer.nbytes() + orders.nbytes() + lineitem.nbytes()
+    eng, part = parallel.GpuEngine(local), parallel.HipPartitioner()
+    tot = torch.tensor([rows_local, bytes_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)
+    top = groups = None
+    timings = {}
+    for it in range(a.warmup + a.steps):
+        if it == a.warmup:
+            timings = {}
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        top, groups = parallel.run_q3_distributed(eng, part, customer, orders, lineitem, timings=timings)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    sec = float(dt.item()) / a.steps
+    ok = None
+    if rank == 0 and not a.no_verify:
+        del customer, orders, lineitem
+        torch.cuda.empty_cache()
+        want, want_groups = tpch.q3_torch_reference(a.orders, world, dev, a.seed)
+        got = [(r[0], (r[1] - __import__("datetime").date(1970, 1, 1)).days, r[2], int(r[3].scaleb(4))) for r in top]
+        ok = got == want
+    if rank == 0:
+        line = {"query": "tpch_q3", "orders": a.orders, "n_gpus": world, "rows": int(tot[0].item()), "input_bytes": int(tot[1].item()),
+                "sec_per_run": sec, "rows_per_s": int(tot[0].item()) / sec, "input_GBps": int(tot[1].item()) / sec / 1e9,
+                "stage_ms_rank0": {k: round(v / a.steps * 1e3, 3) for k, v in timings.items() if not k.startswith("exchange_")},
+                "exchange_rows_rank0": timings.get("exchange_rows", 0) // a.steps, "exchange_bytes_rank0": timings.get("exchange_bytes", 0) // a.steps,
+                "groups_rank0": groups, "top1": [str(x) for x in top[0]] if top else None, "verified_vs_torch": ok, "scaling": "strong"}
+        s = json.dumps(line)
+        print(s, flush=True)
+        if a.out:
+            with open(a.out, "w") as f:
+                f.write(s + "\n")
+    if world > 1:
+        dist.destroy_process_group()
+    if ok is False:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()
