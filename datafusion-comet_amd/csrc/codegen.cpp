@@ -1796,7 +1796,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_gagg(const CometKParams prm) { comet::agg_grouped_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_gemit(const CometKParams prm) { comet::agg_grouped_emit_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_grehash(const CometKParams prm) { comet::agg_grouped_rehash_body<P>(prm); }\n";
-    d.kernels = {"k_gagg", "k_gemit", "k_grehash"};
+    src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
+    d.kernels = {"k_gagg", "k_gemit", "k_grehash", "k_pack"};
   }
   d.source = src.str();
   d.explain = ex.str();

@@ -710,29 +710,41 @@ struct Slot {
   u64 acc[NW];
 };
 
-// find-or-insert in a table living in LDS or global memory.  No lane ever waits for another lane
-// while holding a claim, so lanes of one wave probing the same slot cannot deadlock.
+// find-or-insert in the global table.  No lane ever waits for another lane while holding a claim, so lanes of one
+// wave probing the same slot cannot deadlock.
+//
+// Memory ordering without agent-scope fences: an acquire/release pair at agent scope costs an L2 invalidate
+// (buffer_inv sc1) and an L2 write-back (buffer_wbl2 sc1) PER ROW on CDNA3/4 — the per-XCD L2s are not coherent for
+// ordinary accesses — which made the high-cardinality path ~10× slower than its atomics.  Instead EVERY access to a
+// slot is a relaxed agent-scope atomic (sc1: performed at the coherence point, coherent per location), and the
+// owner orders "key + initial accumulators" before "state = READY" by waiting for its stores to be acknowledged
+// (s_waitcnt vmcnt(0)) in between.  A reader only looks at the key after it has seen READY (control dependency).
 template <int NK, int NW, class InitFn>
 CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* key, InitFn init, u64 max_probes,
-                                        unsigned long long* insert_counter = nullptr) {
+                                        u32* insert_counter = nullptr) {
   u64 h = hash_key<NK>(key) & (cap - 1);
   for (u64 probes = 0; probes < max_probes;) {
     Slot<NK, NW>* s = &tbl[h];
-    u32 st = __hip_atomic_load(&s->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    u32 st = __hip_atomic_load(&s->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st == kSlotEmpty) {
       u32 expected = kSlotEmpty;
-      if (__hip_atomic_compare_exchange_strong(&s->state, &expected, kSlotBusy, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE,
+      if (__hip_atomic_compare_exchange_strong(&s->state, &expected, kSlotBusy, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT)) {
+        u64 acc0[NW];
+        init(acc0);
 #pragma unroll
-        for (int k = 0; k < NK; k++) s->key[k] = key[k];
-        init(s->acc);
-        __hip_atomic_store(&s->state, kSlotReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (insert_counter) atomicAdd(insert_counter, 1ull);
+        for (int k = 0; k < NK; k++) __hip_atomic_store(&s->key[k], key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < NW; k++) __hip_atomic_store(&s->acc[k], acc0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&s->state, kSlotReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (insert_counter) (*insert_counter)++;   // per-lane count, added to the table's group counter once per wave
         return s;
       }
       continue;  // lost the race: re-read this slot
     }
     if (st == kSlotBusy) continue;  // owner is publishing the key; re-read
+    __asm__ volatile("" ::: "memory");
     bool eq = true;
 #pragma unroll
     for (int k = 0; k < NK; k++) eq &= (__hip_atomic_load(&s->key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[k]);
@@ -864,9 +876,20 @@ struct GroupCtx {
   Slot<P::NK, P::NW>* glb;
   u64 glb_cap;
   unsigned int* err;                    // err[0] flags; ((u64*)err)[1] = number of groups in the global table
-  CDEV unsigned long long* counter() const { return (unsigned long long*)err + 1; }
+  mutable u32 inserted = 0;             // groups this lane inserted into the global table (flushed by flush_inserted)
+  CDEV u32* counter() const { return &inserted; }
+  CDEV bool table_full() const { return (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 32u) != 0; }
+  CDEV void set_full() const { if (!table_full()) atomicOr(err, 32u); }
 };
-constexpr u64 kMaxGlobalProbes = 1024;  // beyond this the table counts as full (host grows it and re-runs)
+
+// one atomic per wave instead of one per inserted group (a single hot address serialises at the L2)
+CDEV void flush_inserted(unsigned int* err, u32 inserted) {
+  u32 v = inserted;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  if (lane_id() == 0 && v) atomicAdd((unsigned long long*)err + 1, (unsigned long long)v);
+}
+constexpr u64 kMaxGlobalProbes = 128;  // beyond this the table counts as full (host grows it and re-runs)
 constexpr u32 kNoOrdinal = 0xffffffffu;
 
 template <class P>
@@ -970,8 +993,9 @@ CDEV void group_update(const GroupCtx<P>& g, bool active, const u64* key, const 
     for (int k = 0; k < P::NPW; k++) lds_word_apply<P>(&ls->acc[k], k, pv[k]);
     return;
   }
+  if (g.table_full()) return;   // this pass is void: the host grows the table and re-runs the chunk
   Slot<P::NK, P::NW>* s = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
-  if (!s) { atomicOr(g.err, 32u); return; }
+  if (!s) { g.set_full(); return; }
   u64 val[P::NW];
   P::fold(pv, val);
   slot_apply<P, __HIP_MEMORY_SCOPE_AGENT>(&s->acc[0], val);
@@ -1009,13 +1033,19 @@ CDEV void agg_grouped_body(const CometKParams& prm) {
     typename P::L cur, nxt;
     i64 base = (i64)blockIdx.x * tile;
     if (base < n) P::tile_load(prm, base, n, cur);
-    for (; base < n; base += stride) {
+    for (u32 it = 0; base < n; base += stride, it++) {
       if (base + stride < n) P::tile_load(prm, base + stride, n, nxt);
       P::tile_grouped(prm, base, n, cur, g, kacc);
       cur = nxt;
+      // the pass is void once any lane found the table full (the host grows it and re-runs the chunk): stop early
+      if ((it < 8 || (it & 7) == 7) && g.table_full()) break;
     }
   } else {
-    for (i64 base = (i64)blockIdx.x * tile; base < n; base += stride) P::tile_grouped(prm, base, n, g, kacc);
+    u32 it = 0;
+    for (i64 base = (i64)blockIdx.x * tile; base < n; base += stride, it++) {
+      P::tile_grouped(prm, base, n, g, kacc);
+      if ((it < 8 || (it & 7) == 7) && g.table_full()) break;
+    }
   }
   __syncthreads();
   // level 0 → level 1: sum the private copies into the group's LDS slot (one thread per (group, word))
@@ -1038,11 +1068,12 @@ CDEV void agg_grouped_body(const CometKParams& prm) {
 #pragma unroll
       for (int k = 0; k < P::NPW; k++) pw[k] = ls->acc[k];
       P::fold(pw, val);
-      S* gs = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
+      S* gs = g.table_full() ? nullptr : table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
       if (gs) slot_apply<P, __HIP_MEMORY_SCOPE_AGENT>(&gs->acc[0], val);
-      else atomicOr(g.err, 32u);
+      else g.set_full();
     }
   }
+  flush_inserted(g.err, g.inserted);
   // kernel-level accumulators: wave reduce, one global atomic per wave
   if (P::NKW > 0) {
 #pragma unroll
@@ -1086,12 +1117,13 @@ CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
   typedef Slot<P::NK, P::NW> S;
   const S* old = (const S*)prm.out[3];
   S* nt = (S*)prm.out[0];
+  u32 inserted = 0;
   for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < prm.iarg[1]; i += (i64)gridDim.x * kBlock) {
     if (old[i].state == kSlotReady) {
       u64 key[P::NK];
 #pragma unroll
       for (int k = 0; k < P::NK; k++) key[k] = old[i].key[k];
-      S* gs = table_find_or_insert<P::NK, P::NW>(nt, (u64)prm.iarg[0], key, SlotInit<P>(), (u64)prm.iarg[0], (unsigned long long*)prm.out[2] + 1);
+      S* gs = table_find_or_insert<P::NK, P::NW>(nt, (u64)prm.iarg[0], key, SlotInit<P>(), (u64)prm.iarg[0], &inserted);
       if (gs) {
 #pragma unroll
         for (int k = 0; k < P::NW; k++) gs->acc[k] = old[i].acc[k];  // unique key per old slot: plain copy
@@ -1100,6 +1132,7 @@ CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
       }
     }
   }
+  flush_inserted((unsigned int*)prm.out[2], inserted);
 }
 
 // ---------------------------------------------------------------------------------------------

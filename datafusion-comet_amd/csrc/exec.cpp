@@ -132,6 +132,9 @@ extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int3
 
 namespace {
 
+int fixed_width(const DType& t);
+int out_width(const OutCol& oc) { return oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
+
 int fixed_width(const DType& t) {
   switch (t.id) {
     case TypeId::Int8: return 1;
@@ -726,6 +729,53 @@ void ExecutionContext::finish_aggregate() {
   ready_.push_back(std::move(b));
 }
 
+// Grouped aggregate result left in HBM (stage boundary of a multi-GPU plan: Partial states feed the next stage's exchange
+// or Final aggregate without touching the host).  Utf8 group keys are not supported on this path yet.
+DevTable ExecutionContext::grouped_to_device() {
+  DevTable empty;
+  if (!agg_variant_) {   // no input rows → no groups: an empty table with the plan's output types
+    std::vector<bool> none(in_types_.size(), false);
+    auto pv = planned_variant(*plan_, plan_hash_, none, false, has_join_ ? &in_types_ : nullptr);
+    for (auto& oc : pv->desc.out_cols) {
+      empty.types.push_back(oc.type);
+      empty.cols.push_back(DeviceColumnView());
+      empty.has_valid.push_back(false);
+    }
+    return empty;
+  }
+  Variant& v = *agg_variant_;
+  const PipelineDesc& d = v.desc;
+  uint64_t ngroups = 0;
+  HIP_CHECK(hipMemcpyAsync(&ngroups, (char*)err_flags_.p + 8, 8, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  const size_t ncol = d.out_cols.size();
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  prm.out[0] = group_table_.p;
+  prm.iarg[0] = group_cap_;
+  scratch_counts_.ensure(64);
+  HIP_CHECK(hipMemsetAsync(scratch_counts_.p, 0, 8, stream_));
+  prm.out[1] = scratch_counts_.p;
+  prm.out[kOutErr] = err_flags_.p;
+  std::vector<std::shared_ptr<DevBuf>> vals(ncol), vbytes(ncol);
+  for (size_t j = 0; j < ncol; j++) {
+    vals[j] = std::make_shared<DevBuf>();
+    vbytes[j] = std::make_shared<DevBuf>();
+    vals[j]->ensure((size_t)std::max<uint64_t>(ngroups, 1) * out_width(d.out_cols[j]) + 16);
+    vbytes[j]->ensure((size_t)std::max<uint64_t>(ngroups, 1) + 16);
+    HIP_CHECK(hipMemsetAsync(vbytes[j]->p, 1, (size_t)std::max<uint64_t>(ngroups, 1), stream_));
+    prm.out[kOutFirstCol + 2 * j] = vals[j]->p;
+    prm.out[kOutFirstCol + 2 * j + 1] = vbytes[j]->p;
+  }
+  if (ngroups) launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
+  DevTable t = outputs_to_table(v, vals, vbytes, (int64_t)ngroups);
+  t.owners.push_back(v.mod);
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  return t;
+}
+
 void ExecutionContext::finish_grouped() {
   if (!agg_variant_) return;  // no input rows → no groups → no output batch
   Variant& v = *agg_variant_;
@@ -818,11 +868,39 @@ void ExecutionContext::finish_grouped() {
 // Pull host batches from the JVM stream until a chunk is full; copy through pinned staging to HBM.
 // Gather host batches of input `input` (up to max_rows rows) into one chunk resident in HBM.
 // Returns false when nothing was read (stream exhausted); `rows` may be 0 with more to come only for empty batches.
+// The stream's schema must be what the Scan declares (the reference casts mismatching inputs to the declared types,
+// operators/scan.rs:134-164; casting is not implemented here, so a mismatch is an error instead of garbage).
+void ExecutionContext::validate_input_schema(size_t input, const std::vector<DType>& types) {
+  if (schema_checked_.size() <= input) schema_checked_.resize(input + 1, false);
+  if (schema_checked_[input]) return;
+  InputSource& in = inputs_[input];
+  ArrowSchema sch;
+  memset(&sch, 0, sizeof sch);
+  int rc = in.kind == 0 ? in.host->get_schema(in.host, &sch) : in.dev->get_schema(in.dev, &sch);
+  if (rc != 0 || !sch.release) throw CometError("input stream: get_schema failed");
+  std::string err;
+  if ((size_t)sch.n_children != types.size()) {
+    err = "Scan declares " + std::to_string(types.size()) + " field(s) but the input stream has " + std::to_string(sch.n_children);
+  } else {
+    for (size_t c = 0; c < types.size() && err.empty(); c++) {
+      const ArrowSchema* f = sch.children[c];
+      const char* fmt = f->dictionary ? f->dictionary->format : f->format;
+      if (!format_matches(fmt, types[c]))
+        err = "Scan input column " + std::to_string(c) + " has Arrow format '" + (fmt ? fmt : "?") + "' but the plan declares " + types[c].str() +
+              " (casting scan inputs to the declared type is not supported by the MI355X native engine yet)";
+    }
+  }
+  sch.release(&sch);
+  if (!err.empty()) throw CometError(err);
+  schema_checked_[input] = true;
+}
+
 bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& in_types_, int64_t max_rows,
                                        std::vector<DeviceColumnView>& views, std::vector<bool>& has_valid, int64_t& rows_out) {
   InputSource& in = inputs_[input];
   rows_out = 0;
   if (in.exhausted) return false;
+  validate_input_schema(input, in_types_);
   if (staging_.size() <= input) staging_.resize(input + 1);
   if (!staging_[input]) staging_[input].reset(new Staging());
   auto& stage_vals_ = staging_[input]->stage_vals;
@@ -1108,6 +1186,7 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
   InputSource& in = inputs_[input];
   rows = 0;
   if (in.exhausted) return false;
+  validate_input_schema(input, types);
   auto da = std::make_shared<ArrowDeviceArray>();
   memset(da.get(), 0, sizeof(ArrowDeviceArray));
   int rc = in.dev->get_next(in.dev, da.get());
@@ -1188,9 +1267,6 @@ bool ExecutionContext::pull_device_batch() {
 // Plans with joins: every join input is materialised in HBM (chains are fused pipelines, joins are the
 // materialisation points), then the root chain streams over the top join's output.
 // ---------------------------------------------------------------------------------------------
-namespace {
-int out_width(const OutCol& oc) { return oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
-}  // namespace
 
 // dense outputs written by an emit kernel (values + validity BYTES) → Arrow-layout device table (validity bitmaps)
 DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals,
@@ -1564,10 +1640,16 @@ void release_fmt_schema(ArrowSchema* s) {
 int64_t ExecutionContext::execute_device(ArrowDeviceArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
   Timer t;
   start();
-  if (sink_ != SinkKind::Output)
-    throw CometError("comet_execute_plan_device: aggregate results are small and are exported through comet_execute_plan");
+  if (sink_ == SinkKind::AggNoGroup)
+    throw CometError("comet_execute_plan_device: an ungrouped aggregate result is one row and is exported through comet_execute_plan");
   if (finished_) return -1;
-  DevTable tab = materialize(*plan_);
+  DevTable tab;
+  if (sink_ == SinkKind::AggGrouped) {
+    run_to_completion();
+    tab = grouped_to_device();
+  } else {
+    tab = materialize(*plan_);
+  }
   HIP_CHECK(hipStreamSynchronize(stream_));
   check_device_errors();
   collect_timings();

@@ -118,6 +118,7 @@ class ExecutionContext {
   void process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n);
   void finish_aggregate();
   void finish_grouped();
+  DevTable grouped_to_device();
   std::vector<DType> infer_schema(const Operator& op);
   DevTable materialize(const Operator& op);
   DevTable scan_parquet(const Operator& native_scan);
@@ -132,6 +133,7 @@ class ExecutionContext {
                        std::vector<bool>& has_valid, int64_t& rows);
   bool pull_device_table(size_t input, const std::vector<DType>& types, std::vector<DeviceColumnView>& views, std::vector<bool>& has_valid,
                          int64_t& rows, std::shared_ptr<void>& keepalive);
+  void validate_input_schema(size_t input, const std::vector<DType>& types);
   void export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
   void check_device_errors();
   void raise_device_errors(uint32_t flags);
@@ -165,6 +167,7 @@ class ExecutionContext {
   int64_t bytes_scanned_ = 0;
 
   std::vector<std::unique_ptr<Staging>> staging_;   // per input stream
+  std::vector<bool> schema_checked_;                // per input stream
 
   // aggregate state
   DevBuf partials_;

@@ -327,6 +327,13 @@ class DeviceInput:
         self.released = True
         self._c.release = None
 
+    def close(self) -> None:
+        """Drop the table and the ctypes callbacks.  The callbacks are bound methods, i.e. reference cycles through self:
+        without this the HBM tensors of a finished stage would live until the cyclic GC happens to run."""
+        self.table = None
+        self._keep = []
+        self._cb_schema = self._cb_next = self._cb_err = self._cb_release = self._cb_arr_release = None
+
     def rearm(self) -> "DeviceInput":
         """Make the (released) stream usable for another plan over the same resident table (bench loops)."""
         self._emitted = False

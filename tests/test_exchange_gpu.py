@@ -94,8 +94,8 @@ def test_hash_partitioner_places_rows_like_spark(built):
 def test_execute_plan_device_equals_host_path(built):
     t = tpch.lineitem_q6(300_000, seed=4)
     D = tpch.DEC
-    plan = S.project(S.filter_(S.scan([S.T_DATE, D, D, D]), S.lt(S.col(2, D), S.lit(2400, D))),
-                     [S.col(0, S.T_DATE), S.math("add", S.col(1, D), S.col(2, D), S.decimal(13, 2)), S.col(3, D)])
+    plan = S.project(S.filter_(S.scan([D, D, D, S.T_DATE]), S.lt(S.col(0, D), S.lit(2400, D))),
+                     [S.col(3, S.T_DATE), S.math("add", S.col(1, D), S.col(2, D), S.decimal(13, 2)), S.col(0, D)])
     host = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 3, plan.encode(), batch_size=0))
     for inp in (native.HostInput.from_table(t), native.DeviceInput(native.DeviceTable.from_arrow(t))):
         dev = native.execute_to_device([inp], 3, plan.encode())
@@ -103,9 +103,35 @@ def test_execute_plan_device_equals_host_path(built):
         got = dev.to_arrow()
         assert [f.type for f in got.schema] == [f.type for f in host.schema]
         assert got.rename_columns(host.column_names).equals(host)
-    # aggregates are exported through the host call only
-    with pytest.raises(native.CometNativeException, match="aggregate"):
+    # a stream whose schema is not what the Scan declares is rejected (the reference would cast, scan.rs:134-164)
+    bad = S.project(S.scan([S.T_DATE, D, D, D]), [S.col(0, S.T_DATE)])
+    with pytest.raises(native.CometNativeException, match="declares"):
+        native.execute_to_device([native.HostInput.from_table(t)], 1, bad.encode())
+    # an ungrouped aggregate (one row) is exported through the host call only
+    with pytest.raises(native.CometNativeException, match="ungrouped"):
         native.execute_to_device([native.HostInput.from_table(t)], 2, tpch.q6_plan().encode())
+
+
+def test_grouped_aggregate_states_stay_on_device(built):
+    from oracle import oracle as O
+    rng = np.random.default_rng(12)
+    n = 400_000
+    t = pa.table({"k": pa.array(rng.integers(0, 150_000, n), pa.int64()), "d": pa.array(rng.integers(9000, 9100, n), pa.int32()).cast(pa.date32()),
+                  "m": tpch._dec128_array(rng.integers(-10**9, 10**9, n), 12, 2)})
+    D = tpch.DEC
+    plan = S.hash_agg(S.scan([S.T_INT64, S.T_DATE, D]), [S.col(0, S.T_INT64), S.col(1, S.T_DATE)],
+                      [S.sum_(S.col(2, D), S.decimal(22, 2)), S.count(S.col(2, D))])
+    dev = native.execute_to_device([native.DeviceInput(native.DeviceTable.from_arrow(t))], 5, plan.encode())
+    want = O.run_plan_to_arrow(S, plan, t)
+    assert dev.num_rows == want.num_rows > 300_000          # high cardinality: the global table grows several times
+    assert _rows(dev.to_arrow()) == _rows(want)
+    # and the resident states feed the Final stage directly
+    fplan = S.final_of(plan, dev.schema)
+    got = pa.Table.from_batches(native.execute_to_table([native.DeviceInput(dev)], 4, fplan.encode(), batch_size=0))
+    assert _rows(got) == _rows(O.run_plan_to_arrow(S, fplan, want))
+    # no input rows → an empty resident table
+    empty = native.execute_to_device([native.HostInput.from_table(t.slice(0, 0))], 5, plan.encode())
+    assert empty.num_rows == 0
 
 
 def test_device_output_of_join_feeds_next_plan(built):
