@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--rows", type=int, default=SF10_ROWS, help="lineitem rows per GPU (default: SF10)")
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--q3-orders", type=int, default=150_000_000,
+                    help="extra leg: TPC-H Q3 (hash joins + RCCL exchange) over all ranks, total orders rows (SF100 = 150 M, strong scaling); 0 = skip")
+    ap.add_argument("--q3-timeout", type=int, default=420)
     args = ap.parse_args()
 
     import numpy as np
@@ -102,6 +105,15 @@ def main():
         fin = native.execute_to_table([native.HostInput.from_table(states)], 1, fplan.encode(), device_id=local_rank)
         final_value = str(fin[0].column(0)[0])
 
+    # Extra leg (reported under "q3", never part of `value`): BASELINE.json config 4, TPC-H Q3 partitioned over the ranks with
+    # RCCL all-to-all exchanges (tools/q3_dist.py).  It runs in a CHILD process per rank with its own rendezvous port so that a
+    # failure or hang there cannot take the Q6 line down: the child is killed by PID after --q3-timeout seconds.
+    q3 = None
+    if args.q3_orders > 0:
+        del dtab, dinput
+        torch.cuda.empty_cache()
+        q3 = run_q3_leg(args, rank, local_rank, world)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rows_per_s = n * world * args.steps / elapsed
@@ -140,9 +152,43 @@ def main():
             line["cpu_baseline"] = {"value": m / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
                                     "sample": f"first {m} rows of the same lineitem shard, operator-at-a-time C restatement "
                                               f"(oracle/comet_oracle.c o_q6_reference_pipeline, 8192-row batches), {cdt:.2f} s"}
+        if q3 is not None:
+            line["q3"] = q3
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_q3_leg(args, rank, local_rank, world):
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"comet_q3_{os.getpid()}.json")
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1017)
+    env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"] = str(rank), str(local_rank), str(world)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1", "--out", out]
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        try:
+            log, _ = p.communicate(timeout=args.q3_timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return {"error": f"timed out after {args.q3_timeout} s"}
+        if rank != 0:
+            return None
+        if p.returncode != 0 or not os.path.exists(out):
+            return {"error": f"exit code {p.returncode}", "log_tail": log[-600:]}
+        with open(out) as f:
+            res = json.loads(f.read())
+        os.unlink(out)
+        return res
+    except Exception as e:  # the extra leg must never break the headline line
+        return {"error": repr(e)} if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -578,16 +578,25 @@ CDEV void filter_mask_body(const CometKParams& prm) {
   }
 }
 
-// exclusive scan over counts[0..ntiles) in place; counts[ntiles] = total.  One block.
+// exclusive scan over counts[0..ntiles) in place; counts[ntiles] = total.  One block; every thread owns kScanItems
+// consecutive elements per round, so a round covers 4096 elements between barriers.
+constexpr int kScanItems = 16;
 CDEV void tile_scan_body(u64* counts, i64 ntiles) {
   __shared__ u64 s_wave[kBlock / kWave];
   __shared__ u64 s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  for (i64 base = 0; base < ntiles; base += kBlock) {
-    i64 i = base + threadIdx.x;
-    u64 v = i < ntiles ? counts[i] : 0;
-    u64 x = v;  // inclusive scan within wave
+  const i64 round = (i64)kBlock * kScanItems;
+  for (i64 base = 0; base < ntiles; base += round) {
+    const i64 first = base + (i64)threadIdx.x * kScanItems;
+    u64 v[kScanItems];
+    u64 sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+      v[j] = first + j < ntiles ? counts[first + j] : 0;
+      sum += v[j];
+    }
+    u64 x = sum;  // inclusive scan of the per-thread sums within the wave
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
       u32 lo = __shfl_up((u32)x, d, kWave), hi = __shfl_up((u32)(x >> 32), d, kWave);
@@ -598,8 +607,13 @@ CDEV void tile_scan_body(u64* counts, i64 ntiles) {
     __syncthreads();
     u64 woff = 0;
     for (int w = 0; w < wave_id(); w++) woff += s_wave[w];
-    u64 carry = s_carry;
-    if (i < ntiles) counts[i] = carry + woff + x - v;
+    const u64 carry = s_carry;
+    u64 run = carry + woff + x - sum;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+      if (first + j < ntiles) counts[first + j] = run;
+      run += v[j];
+    }
     __syncthreads();
     if (threadIdx.x == kBlock - 1) s_carry = carry + woff + x;
     __syncthreads();

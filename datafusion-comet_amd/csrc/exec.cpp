@@ -495,16 +495,13 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       // checkpoint: if the table fills up mid-chunk some rows are dropped, so the chunk is re-run from the checkpoint
       group_backup_.ensure((size_t)group_cap_ * slot_bytes);
       HIP_CHECK(hipMemcpyAsync(group_backup_.p, group_table_.p, (size_t)group_cap_ * slot_bytes, hipMemcpyDeviceToDevice, stream_));
-      uint64_t groups_before = 0;
-      HIP_CHECK(hipMemcpyAsync(&groups_before, (char*)err_flags_.p + 8, 8, hipMemcpyDeviceToHost, stream_));
       prm.out[0] = group_table_.p;
       prm.iarg[0] = group_cap_;
       timed_begin();
       launch(v, "k_gagg", grid, prm);
       timed_end();
       uint32_t flags[4];
-      HIP_CHECK(hipMemcpyAsync(flags, err_flags_.p, 16, hipMemcpyDeviceToHost, stream_));
-      HIP_CHECK(hipStreamSynchronize(stream_));
+      read_small(flags, err_flags_.p, 16);
       uint64_t groups_now;
       memcpy(&groups_now, &flags[2], 8);
       const bool full = (flags[0] & 32u) != 0;
@@ -515,7 +512,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       DevBuf bigger;
       alloc_table(bigger, new_cap);
       uint32_t zero4[4] = {flags[0] & ~32u, flags[1], 0, 0};
-      HIP_CHECK(hipMemcpyAsync(err_flags_.p, zero4, 16, hipMemcpyHostToDevice, stream_));
+      write_small(err_flags_.p, zero4, 16);
       CometKParams rp;
       memset(&rp, 0, sizeof rp);
       rp.out[0] = bigger.p;
@@ -528,7 +525,6 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       std::swap(group_table_.p, bigger.p);
       std::swap(group_table_.cap, bigger.cap);
       group_cap_ = new_cap;
-      (void)groups_before;
       if (!full) break;
     }
     return;
@@ -568,8 +564,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       prm.iarg[0] = ntiles;
       launch(v, "k_scan", 1, prm);
       uint64_t total = 0;
-      HIP_CHECK(hipMemcpyAsync(&total, (char*)scratch_counts_.p + (size_t)ntiles * 8, 8, hipMemcpyDeviceToHost, stream_));
-      HIP_CHECK(hipStreamSynchronize(stream_));
+      read_small(&total, (char*)scratch_counts_.p + (size_t)ntiles * 8, 8);
       out_rows = (int64_t)total;
       if (out_rows > 0) {
         bind_outputs(out_rows);
@@ -632,6 +627,21 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
   throw CometError("internal: unsupported sink");
 }
 
+// Small host↔device transfers go through a pinned scratch block: a copy to/from PAGEABLE memory makes the runtime set up
+// staging for the stream, which was measured at 9–24 ms on the first such copy of each plan (profiles/r1_q3_*).
+void ExecutionContext::read_small(void* dst, const void* dev_src, size_t n) {
+  small_host_.ensure(4096);
+  HIP_CHECK(hipMemcpyAsync(small_host_.p, dev_src, n, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  memcpy(dst, small_host_.p, n);
+}
+void ExecutionContext::write_small(void* dev_dst, const void* src, size_t n) {
+  small_host_.ensure(4096);
+  HIP_CHECK(hipStreamSynchronize(stream_));   // the scratch may still be the source of an earlier async copy
+  memcpy((char*)small_host_.p + 2048, src, n);
+  HIP_CHECK(hipMemcpyAsync(dev_dst, (char*)small_host_.p + 2048, n, hipMemcpyHostToDevice, stream_));
+}
+
 void ExecutionContext::timed_begin() {
   hipEvent_t a = pool_get_event(device_id_), b = pool_get_event(device_id_);
   timed_.emplace_back(a, b);
@@ -652,8 +662,7 @@ void ExecutionContext::collect_timings() {
 void ExecutionContext::check_device_errors() {
   if (!err_flags_.p) return;
   uint32_t flags[4] = {0, 0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(flags, err_flags_.p, 16, hipMemcpyDeviceToHost, stream_));
-  HIP_CHECK(hipStreamSynchronize(stream_));
+  read_small(flags, err_flags_.p, 16);
   collect_timings();
   raise_device_errors(flags[0]);
 }
@@ -746,8 +755,7 @@ DevTable ExecutionContext::grouped_to_device() {
   Variant& v = *agg_variant_;
   const PipelineDesc& d = v.desc;
   uint64_t ngroups = 0;
-  HIP_CHECK(hipMemcpyAsync(&ngroups, (char*)err_flags_.p + 8, 8, hipMemcpyDeviceToHost, stream_));
-  HIP_CHECK(hipStreamSynchronize(stream_));
+  read_small(&ngroups, (char*)err_flags_.p + 8, 8);
   check_device_errors();
   const size_t ncol = d.out_cols.size();
   CometKParams prm;
@@ -781,8 +789,7 @@ void ExecutionContext::finish_grouped() {
   Variant& v = *agg_variant_;
   const PipelineDesc& d = v.desc;
   uint64_t ngroups = 0;
-  HIP_CHECK(hipMemcpyAsync(&ngroups, (char*)err_flags_.p + 8, 8, hipMemcpyDeviceToHost, stream_));
-  HIP_CHECK(hipStreamSynchronize(stream_));
+  read_small(&ngroups, (char*)err_flags_.p + 8, 8);
   check_device_errors();
   if (ngroups == 0) return;
   const size_t ncol = d.out_cols.size();
@@ -809,12 +816,22 @@ void ExecutionContext::finish_grouped() {
     prm.out[kOutFirstCol + 2 * j + 1] = out_valid_[j]->p;
   }
   launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
-  std::vector<std::vector<uint8_t>> hv(ncol), hk(ncol);
+  // results come back through pooled pinned buffers (a pageable destination would be staged by the runtime at a fraction of the rate)
+  struct HostSpan {
+    PinnedBuf buf;
+    size_t n = 0;
+    const uint8_t* data() const { return (const uint8_t*)buf.p; }
+    const uint8_t* begin() const { return data(); }
+    uint8_t operator[](size_t i) const { return data()[i]; }
+  };
+  std::vector<HostSpan> hv(ncol), hk(ncol);
   for (size_t j = 0; j < ncol; j++) {
-    hv[j].resize((size_t)ngroups * widths[j]);
-    hk[j].resize((size_t)ngroups);
-    HIP_CHECK(hipMemcpyAsync(hv[j].data(), out_vals_[j]->p, hv[j].size(), hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipMemcpyAsync(hk[j].data(), out_valid_[j]->p, hk[j].size(), hipMemcpyDeviceToHost, stream_));
+    hv[j].n = (size_t)ngroups * widths[j];
+    hk[j].n = (size_t)ngroups;
+    hv[j].buf.ensure(hv[j].n + 16);
+    hk[j].buf.ensure(hk[j].n + 16);
+    HIP_CHECK(hipMemcpyAsync(hv[j].buf.p, out_vals_[j]->p, hv[j].n, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(hk[j].buf.p, out_valid_[j]->p, hk[j].n, hipMemcpyDeviceToHost, stream_));
   }
   HIP_CHECK(hipStreamSynchronize(stream_));
   check_device_errors();
@@ -850,14 +867,16 @@ void ExecutionContext::finish_grouped() {
         c.values.assign(hv[j].begin() + (size_t)off * w, hv[j].begin() + (size_t)(off + len) * w);
       }
       if (oc.nullable) {
-        int64_t nulls = 0;
-        std::vector<uint8_t> bm((size_t)((len + 7) / 8), 0);
-        for (int64_t i = 0; i < len; i++) {
-          if (hk[j][(size_t)(off + i)]) bm[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
-          else nulls++;
+        const uint8_t* vb = hk[j].data() + off;
+        int64_t valid = 0;
+        for (int64_t i = 0; i < len; i++) valid += vb[i] != 0;
+        c.null_count = len - valid;
+        if (c.null_count) {
+          std::vector<uint8_t> bm((size_t)((len + 7) / 8), 0);
+          for (int64_t i = 0; i < len; i++)
+            if (vb[i]) bm[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+          c.validity = std::move(bm);
         }
-        c.null_count = nulls;
-        if (nulls) c.validity = std::move(bm);
       }
       b.cols.push_back(std::move(c));
     }
@@ -1055,8 +1074,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
       dev_vals_[c]->ensure((size_t)(rows + 1) * 4 + 16);
       pq_launch_u32_scan((const uint32_t*)lengths->p, rows, (uint64_t*)tiles->p, (int32_t*)dev_vals_[c]->p, stream_);
       int32_t total = 0;
-      HIP_CHECK(hipMemcpyAsync(&total, (char*)dev_vals_[c]->p + (size_t)rows * 4, 4, hipMemcpyDeviceToHost, stream_));
-      HIP_CHECK(hipStreamSynchronize(stream_));
+      read_small(&total, (char*)dev_vals_[c]->p + (size_t)rows * 4, 4);
       dev_aux_[c]->ensure((size_t)std::max(total, 1) + 16);
       for (auto& pt : parts)
         comet_launch_dict_gather_str_copy(pt.idx->p, iw, (const uint8_t*)vbytes->p + pt.at, (const int32_t*)pt.doffs->p, (const uint8_t*)pt.dbytes->p, pt.len,
@@ -1186,10 +1204,14 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
   InputSource& in = inputs_[input];
   rows = 0;
   if (in.exhausted) return false;
+  static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
+  Timer tm;
   validate_input_schema(input, types);
+  const double t_schema = tm.ns();
   auto da = std::make_shared<ArrowDeviceArray>();
   memset(da.get(), 0, sizeof(ArrowDeviceArray));
   int rc = in.dev->get_next(in.dev, da.get());
+  if (trace) fprintf(stderr, "[comet] device input %zu: get_schema %.3f ms, get_next %.3f ms\n", input, t_schema / 1e6, (tm.ns() - t_schema) / 1e6);
   if (rc != 0) {
     const char* m = in.dev->get_last_error ? in.dev->get_last_error(in.dev) : nullptr;
     throw CometError(std::string("input ArrowDeviceArrayStream.get_next failed: ") + (m ? m : "unknown error"));
@@ -1230,9 +1252,8 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
     const ArrowArray* col = da->array.children[c];
     const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
     int32_t ends[2] = {0, 0};
-    HIP_CHECK(hipMemcpyAsync(&ends[0], off, 4, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipMemcpyAsync(&ends[1], off + rows, 4, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    read_small(&ends[0], off, 4);
+    read_small(&ends[1], off + rows, 4);
     const int64_t total = (int64_t)ends[1] - ends[0];
     if (total % rows != 0 || total / rows > 15) continue;
     const int32_t L = (int32_t)(total / rows);
@@ -1240,8 +1261,7 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
     HIP_CHECK(hipMemsetAsync(flag, 0, 4, stream_));
     if (comet_launch_utf8_uniform(off, rows, L, flag, stream_) != 0) continue;
     uint32_t f = 1;
-    HIP_CHECK(hipMemcpyAsync(&f, flag, 4, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    read_small(&f, flag, 4);
     HIP_CHECK(hipMemsetAsync(flag, 0, 4, stream_));
     if (f == 0) {
       views[c].fixed_len = L;
@@ -1364,8 +1384,7 @@ DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTab
     prm.iarg[0] = ntiles;
     launch(v, "k_scan", 1, prm);
     uint64_t total = 0;
-    HIP_CHECK(hipMemcpyAsync(&total, (char*)scratch_counts_.p + (size_t)ntiles * 8, 8, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    read_small(&total, (char*)scratch_counts_.p + (size_t)ntiles * 8, 8);
     out_rows = (int64_t)total;
     bind(std::max<int64_t>(out_rows, 1));
     if (out_rows > 0) launch(v, "k_emit", grid, prm);
@@ -1448,8 +1467,7 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
     launch(v, "k_jcount", grid, prm);
     launch(v, "k_jscan", 1, prm);
     uint64_t total = 0;
-    HIP_CHECK(hipMemcpyAsync(&total, (char*)tiles.p + (size_t)ntiles * 8, 8, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    read_small(&total, (char*)tiles.p + (size_t)ntiles * 8, 8);
     out_rows = (int64_t)total;
   }
   for (size_t c = 0; c < ncol; c++) {
@@ -1473,6 +1491,12 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
 }
 
 DevTable ExecutionContext::materialize(const Operator& op) {
+  static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
+  Timer tm;
+  struct Report {
+    const Operator& op; Timer& tm; bool on;
+    ~Report() { if (on) fprintf(stderr, "[comet] materialize %s: %.3f ms (incl. children)\n", op_name(op.proto_tag), tm.ns() / 1e6); }
+  } report{op, tm, trace};
   if (op.kind == OpKind::Scan) {
     const size_t input = scan_input_.at(&op);
     DevTable t;

@@ -137,6 +137,8 @@ class ExecutionContext {
   void export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
   void check_device_errors();
   void raise_device_errors(uint32_t flags);
+  void read_small(void* dst, const void* dev_src, size_t n);
+  void write_small(void* dev_dst, const void* src, size_t n);
   void timed_begin();
   void timed_end();
   void collect_timings();
@@ -174,6 +176,7 @@ class ExecutionContext {
   int64_t n_partials_ = 0;
   DevBuf err_flags_;
   PinnedBuf result_host_;
+  PinnedBuf small_host_;   // 4 KiB pinned scratch for flag / count read-backs
   DevBuf group_table_, group_backup_;
   int64_t group_cap_ = 0;
   DevBuf scratch_mask_, scratch_counts_;

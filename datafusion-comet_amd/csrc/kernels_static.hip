@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) void pmod_kernel(const u32* hashes, i64 n, i32
 
 // Are all n Utf8 values exactly L bytes long?  (lets the fused kernels address the bytes directly, see ld_str_fixed)
 __global__ __launch_bounds__(256) void utf8_uniform_kernel(const i32* off, i64 n, i32 L, u32* flag) {
-  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256)
-    if (off[i + 1] - off[i] != L) *flag = 1;
+  bool bad = false;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n && !bad; i += (i64)gridDim.x * 256) bad = off[i + 1] - off[i] != L;
+  // one store per wave at most: millions of lanes storing to the same word serialise at the L2
+  if (__ballot(bad) != 0 && lane_id() == 0) *flag = 1;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -433,8 +433,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       offsets->ensure((size_t)(total_rows + 1) * 4 + 16);
       pq_launch_u32_scan((const uint32_t*)lengths->p, total_rows, (uint64_t*)tiles->p, (int32_t*)offsets->p, stream_);
       int32_t total_bytes = 0;
-      HIP_CHECK(hipMemcpyAsync(&total_bytes, (char*)offsets->p + (size_t)total_rows * 4, 4, hipMemcpyDeviceToHost, stream_));
-      HIP_CHECK(hipStreamSynchronize(stream_));
+      read_small(&total_bytes, (char*)offsets->p + (size_t)total_rows * 4, 4);
       auto data = std::make_shared<DevBuf>();
       data->ensure((size_t)std::max(total_bytes, 1) + 16);
       size_t k = 0;

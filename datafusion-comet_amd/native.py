@@ -493,15 +493,23 @@ def execute_to_table(inputs: Sequence, num_output_cols: int, plan: bytes, **kw) 
 
 def execute_to_device(inputs: Sequence, num_output_cols: int, plan: bytes, device_id: int = 0, config: bytes = b"") -> DeviceTable:
     """createPlan → executePlanDevice → releasePlan; the result keeps its buffers alive after the plan is released."""
+    import time
+    trace = os.environ.get("COMET_TRACE_STAGES")
     keep = list(inputs)
+    t0 = time.perf_counter()
     h = Native.createPlan(keep, plan, config, 1, 0, device_id)
+    t1 = time.perf_counter()
     try:
         t = Native.executePlanDevice(h, num_output_cols)
+        t2 = time.perf_counter()
         if t is None:
             raise CometNativeException("plan produced no device batch")
         return t
     finally:
         Native.releasePlan(h)
+        if trace:
+            t3 = time.perf_counter()
+            print(f"[comet] createPlan {1e3 * (t1 - t0):.2f} ms, executePlanDevice {1e3 * (t2 - t1):.2f} ms, releasePlan {1e3 * (t3 - t2):.2f} ms", flush=True)
 
 
 def _stream_ptr() -> int:

@@ -327,16 +327,16 @@ def q3_torch_reference(n_orders: int, world: int, device="cuda:0", seed: int = 3
     cutoff = days(1995, 3, 15)
     n_c_total = max(1, n_orders // 10)
     building = torch.zeros(n_c_total + 1, dtype=torch.bool, device=device)
-    shards = []
-    for r in range(world):
+    for r in range(world):      # pass 1: which customers are in the BUILDING segment
         _, _, _, raw = q3_tables_device(n_orders, world, r, device, seed)
         nc = raw["seg"].numel()
         building[raw["c0"] + 1: raw["c0"] + nc + 1] = raw["seg"] == SEGMENTS.index(b"BUILDING")
-        shards.append(raw)
+        del raw
     revenue = torch.zeros(n_orders, dtype=torch.int64, device=device)
     hit = torch.zeros(n_orders, dtype=torch.bool, device=device)
     odate_all = torch.zeros(n_orders, dtype=torch.int32, device=device)
-    for raw in shards:
+    for r in range(world):      # pass 2: one shard resident at a time
+        _, _, _, raw = q3_tables_device(n_orders, world, r, device, seed)
         no = raw["ocust"].numel()
         ok_order = building[raw["ocust"]] & (raw["odate"] < cutoff)
         odate_all[raw["o0"]: raw["o0"] + no] = raw["odate"]
@@ -344,6 +344,7 @@ def q3_torch_reference(n_orders: int, world: int, device="cuda:0", seed: int = 3
         idx = raw["lo"][keep] + raw["o0"]
         revenue.index_add_(0, idx, raw["price"][keep] * (100 - raw["disc"][keep]))
         hit[idx] = True
+        del raw, ok_order, keep, idx
     groups = int(hit.sum().item())
     cand = torch.nonzero(hit).reshape(-1)
     rev = revenue[cand]
