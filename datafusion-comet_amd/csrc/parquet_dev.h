@@ -4,8 +4,8 @@
 #define COMET_PARQUET_DEV_H
 #include <stdint.h>
 
-typedef struct PqPage {        /* one data page of a column chunk */
-  int64_t row_start;           /* first row of the page within the column chunk (flat columns: values == rows) */
+typedef struct PqPage {        /* one data page of a column (all selected row groups of a column are decoded by one launch) */
+  int64_t row_start;           /* first row of the page within the column (flat columns: values == rows) */
   int64_t values_off;          /* staged-byte offset of the PLAIN values, or of the hybrid-encoded dictionary indices */
   int64_t str_first;           /* PLAIN BYTE_ARRAY pages: index of the page's first value in the string offset table */
   int32_t num_values;
@@ -13,7 +13,8 @@ typedef struct PqPage {        /* one data page of a column chunk */
   int32_t bit_width;           /* dictionary index width */
   int32_t def_run_first, def_run_count;   /* definition-level runs (count 0: every value valid) */
   int32_t idx_run_first, idx_run_count;   /* dictionary-index runs */
-  int32_t pad;
+  int32_t dict_offs_first;     /* strings: index of this page's dictionary in the offsets table */
+  int64_t dict_off;            /* byte offset of this page's dictionary (its row group's) in the dictionary buffer */
 } PqPage;
 
 typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section */

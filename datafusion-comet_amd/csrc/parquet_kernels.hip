@@ -111,7 +111,7 @@ __device__ __forceinline__ i128 pq_flba_to_i128(const u8* p, int len) {
 }
 __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
   for (i64 row = (i64)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (i64)gridDim.x * 256) {
-    const bool valid = a.valid_out[row] != 0;
+    const bool valid = !a.valid_out || a.valid_out[row] != 0;   // valid_out == NULL: the chunk has no NULLs
     const u8* src = nullptr;
     u32 boolbit = 0;
     if (valid) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
       const i32 v = a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[pg.row_start]) : (i32)(row - pg.row_start);
       if (pg.encoding == 1) {
         u32 idx = pq_hybrid_value(a.idx_runs, pg.idx_run_first, pg.idx_run_count, a.bytes, pg.bit_width, v);
-        src = a.dict + (i64)idx * a.width;
+        src = a.dict + pg.dict_off + (i64)idx * a.width;
       } else if (a.kind == PQ_BOOL) {
         boolbit = (a.bytes[pg.values_off + (v >> 3)] >> (v & 7)) & 1;
       } else {
@@ -147,8 +147,9 @@ __device__ __forceinline__ void pq_string_ref(const PqDecodeArgs& a, i64 row, co
   const i32 v = a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[pg.row_start]) : (i32)(row - pg.row_start);
   if (pg.encoding == 1) {
     u32 idx = pq_hybrid_value(a.idx_runs, pg.idx_run_first, pg.idx_run_count, a.bytes, pg.bit_width, v);
-    p = a.dict + a.dict_offs[idx];
-    len = (u32)(a.dict_offs[idx + 1] - a.dict_offs[idx]);
+    const i32* doffs = a.dict_offs + pg.dict_offs_first;
+    p = a.dict + pg.dict_off + doffs[idx];
+    len = (u32)(doffs[idx + 1] - doffs[idx]);
   } else {
     // PLAIN BYTE_ARRAY: value bytes start 4 bytes after the previous value's end; offsets were prescanned on the host
     const i64 o = a.plain_str_offs[pg.str_first + v];
@@ -159,7 +160,7 @@ __device__ __forceinline__ void pq_string_ref(const PqDecodeArgs& a, i64 row, co
 __global__ __launch_bounds__(256) void pq_string_lengths_kernel(PqDecodeArgs a) {
   for (i64 row = (i64)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (i64)gridDim.x * 256) {
     u32 len = 0;
-    if (a.valid_out[row]) {
+    if (!a.valid_out || a.valid_out[row]) {
       const u8* p;
       pq_string_ref(a, row, p, len);
     }
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void pq_string_lengths_kernel(PqDecodeArgs a) 
 }
 __global__ __launch_bounds__(256) void pq_string_copy_kernel(PqDecodeArgs a) {
   for (i64 row = (i64)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (i64)gridDim.x * 256) {
-    if (!a.valid_out[row]) continue;
+    if (a.valid_out && !a.valid_out[row]) continue;
     const u8* p;
     u32 len;
     pq_string_ref(a, row, p, len);

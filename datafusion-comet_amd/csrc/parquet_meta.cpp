@@ -326,15 +326,20 @@ void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, siz
       return;
     case SNAPPY: snappy_decompress(src, src_len, dst, dst_len); return;
     case ZSTD: {
-      static zstd_decompress_fn fn = nullptr;
-      static zstd_iserror_fn iserr = nullptr;
-      if (!fn) {
-        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) throw CometError("parquet: zstd pages need libzstd.so.1, which could not be loaded");
-        fn = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
-        iserr = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
-        if (!fn || !iserr) throw CometError("parquet: libzstd.so.1 lacks ZSTD_decompress");
-      }
+      struct Zstd {   // resolved once; magic statics make this safe when scan threads race here
+        zstd_decompress_fn fn = nullptr;
+        zstd_iserror_fn iserr = nullptr;
+        Zstd() {
+          void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
+          if (!h) return;
+          fn = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
+          iserr = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+        }
+      };
+      static const Zstd z;
+      if (!z.fn || !z.iserr) throw CometError("parquet: zstd pages need libzstd.so.1 (ZSTD_decompress), which could not be loaded");
+      const zstd_decompress_fn fn = z.fn;
+      const zstd_iserror_fn iserr = z.iserr;
       size_t rc = fn(dst, dst_len, src, src_len);
       if (iserr(rc) || rc != dst_len) throw CometError("parquet: zstd decompression failed");
       return;

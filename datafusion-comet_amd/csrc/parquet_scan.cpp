@@ -4,12 +4,20 @@
 // Reference path: NativeScan arm planner.rs:1523-1668 → init_datasource_exec parquet/parquet_exec.rs:60-211
 // (column model SURVEY Appendix C.12: output = required_schema fields; row groups chosen by byte-range midpoint).
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <exception>
+#include <mutex>
+#include <thread>
 
 #include "exec.hpp"
 #include "parquet_dev.h"
@@ -29,28 +37,91 @@ namespace comet {
 
 namespace {
 
-struct MappedFile {
-  const uint8_t* data = nullptr;
-  size_t size = 0;
+// Process-wide pool of scan threads (the counterpart of the reference's tokio worker threads, jni_api.rs:133-170): shared by every
+// plan of the process, started on first use, never torn down.  Persistent threads keep their scratch buffers across scans.
+class ScanPool {
+ public:
+  static ScanPool& get() {
+    static ScanPool* p = new ScanPool();   // intentionally leaked
+    return *p;
+  }
+  int size() const { return (int)nthreads_; }
+  void submit(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      q_.push_back(std::move(f));
+    }
+    cv_.notify_one();
+  }
+
+ private:
+  ScanPool() {
+    size_t n = std::min<size_t>(64, std::max(1u, std::thread::hardware_concurrency() / 2));
+    if (const char* e = getenv("COMET_SCAN_THREADS")) n = (size_t)std::max(1, atoi(e));
+    nthreads_ = n;
+    for (size_t i = 0; i < n; i++) std::thread([this]() { run(); }).detach();
+  }
+  void run() {
+    while (true) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return !q_.empty(); });
+        f = std::move(q_.front());
+        q_.pop_front();
+      }
+      f();
+    }
+  }
+  size_t nthreads_ = 1;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+};
+
+// A Parquet file opened for positional reads.  Column chunks are pread() by the scan threads into their own scratch
+// (no mmap: tearing down a mapping of several hundred MB costs milliseconds of page-table work after every scan).
+struct OpenFile {
   int fd = -1;
-  explicit MappedFile(const std::string& path) {
+  size_t size = 0;
+  std::vector<uint8_t> footer;   // "PAR1" + FileMetaData + length + "PAR1": what parse_footer needs
+  explicit OpenFile(const std::string& path) {
     fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw CometError("cannot open Parquet file " + path);
     struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); throw CometError("cannot stat " + path); }
+    if (fstat(fd, &st) != 0) { close(fd); fd = -1; throw CometError("cannot stat " + path); }
     size = (size_t)st.st_size;
-    if (size) {
-      void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-      if (p == MAP_FAILED) { close(fd); throw CometError("cannot mmap " + path); }
-      data = (const uint8_t*)p;
+    try {
+      uint8_t head[4], tail[8];
+      if (size < 12) throw CometError("not a Parquet file (too short): " + path);
+      read_at(head, 4, 0);
+      read_at(tail, 8, (int64_t)size - 8);
+      uint32_t mlen;
+      memcpy(&mlen, tail, 4);
+      if ((size_t)mlen + 12 > size) throw CometError("parquet: bad footer length");
+      footer.resize(4 + (size_t)mlen + 8);
+      memcpy(footer.data(), head, 4);
+      read_at(footer.data() + 4, (size_t)mlen + 8, (int64_t)size - 8 - (int64_t)mlen);
+    } catch (...) {
+      close(fd);
+      fd = -1;
+      throw;
     }
   }
-  ~MappedFile() {
-    if (data) munmap((void*)data, size);
+  void read_at(uint8_t* dst, size_t n, int64_t off) const {
+    size_t got = 0;
+    while (got < n) {
+      ssize_t r = pread(fd, dst + got, n - got, (off_t)(off + (int64_t)got));
+      if (r < 0 && errno == EINTR) continue;
+      if (r <= 0) throw CometError("parquet: short read");
+      got += (size_t)r;
+    }
+  }
+  ~OpenFile() {
     if (fd >= 0) close(fd);
   }
-  MappedFile(const MappedFile&) = delete;
-  MappedFile& operator=(const MappedFile&) = delete;
+  OpenFile(const OpenFile&) = delete;
+  OpenFile& operator=(const OpenFile&) = delete;
 };
 
 std::string path_from_uri(const std::string& uri) {
@@ -170,14 +241,188 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, bool cas
   return cp;
 }
 
-struct ChunkBuffers {   // device + host staging for one column chunk; kept alive until the stream is idle
-  DevBuf bytes, pages, def_runs, idx_runs, dict, dict_offs, str_offs;
-  PinnedBuf h_bytes, h_tables;
+// Host half of one column chunk (one column of one row group): page walk, decompression straight into the column's pinned
+// staging block at the chunk's slot, hybrid-run tables.  Independent of every other chunk, so chunks are prepared by a
+// pool of host threads (scan_parquet); the calling thread then concatenates a column's tables and decodes the WHOLE column
+// (all row groups) with one upload and one launch per kernel.
+struct HostChunk {
+  ColumnPlan cp;
+  int max_def = 0;
+  bool no_nulls = true;            // every definition level of the chunk equals max_def (or the column is required)
+  int64_t n_rows = 0;
+  int64_t compressed = 0;
+  size_t spos = 0;                 // staged page bytes actually used
+  std::vector<PqPage> pages;
+  std::vector<PqRun> def_runs, idx_runs;
+  std::vector<uint8_t> dict_bytes;
+  std::vector<int32_t> dict_offs;
+  std::vector<int64_t> str_offs;
+  std::exception_ptr err;
 };
+
+struct ChunkSource {
+  const OpenFile* file;
+  const pq::FileMeta* meta;
+  int rg;
+};
+
+// bytes the staged (decompressed) pages of a column chunk may take
+size_t staged_capacity(const pq::ColumnMeta& cm) { return ((size_t)cm.total_uncompressed + 64 + 15) & ~(size_t)15; }
+
+void decode_chunk_host(const ChunkSource& src, const StructField& want, HostChunk& hc, uint8_t* staged, size_t staged_cap) {
+  const pq::RowGroup& rg = src.meta->row_groups[(size_t)src.rg];
+  ColumnPlan cp = plan_column(want, *src.meta, true);
+  if ((size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
+  const pq::ColumnMeta& cm = rg.columns[(size_t)cp.leaf];
+  hc.cp = cp;
+  const int max_def = cp.el.repetition == 1 ? 1 : 0;
+  hc.max_def = max_def;
+  hc.n_rows = rg.num_rows;
+  hc.compressed = cm.total_compressed;
+  size_t spos = 0;
+  std::vector<PqPage>& pages = hc.pages;
+  std::vector<PqRun>&def_runs = hc.def_runs, &idx_runs = hc.idx_runs;
+  std::vector<uint8_t>& dict_bytes = hc.dict_bytes;
+  std::vector<int32_t>& dict_offs = hc.dict_offs;
+  std::vector<int64_t>& str_offs = hc.str_offs;
+
+  int64_t off = (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < cm.data_page_offset) ? cm.dictionary_page_offset : cm.data_page_offset;
+  const int64_t chunk_end = off + cm.total_compressed;
+  if (off < 0 || (size_t)chunk_end > src.file->size) throw CometError("parquet: column chunk outside the file");
+  // the whole (compressed) chunk into this thread's scratch, then parse from memory
+  static thread_local std::vector<uint8_t> raw;
+  if (raw.size() < (size_t)cm.total_compressed + 16) raw.resize((size_t)cm.total_compressed + 16);
+  src.file->read_at(raw.data(), (size_t)cm.total_compressed, off);
+  const uint8_t* chunk_data = raw.data() - off;   // so that chunk_data + file_offset addresses the byte
+  int64_t values_seen = 0;
+  std::vector<uint8_t> tmp;
+  while (values_seen < cm.num_values && off < chunk_end) {
+    pq::PageHeader h = pq::parse_page_header(chunk_data + off, (size_t)(chunk_end - off));
+    const uint8_t* body = chunk_data + off + h.header_len;
+    off += (int64_t)h.header_len + h.compressed_size;
+    if (h.type == pq::DICTIONARY_PAGE) {
+      tmp.resize((size_t)h.uncompressed_size + 8);
+      pq::decompress(cm.codec, body, (size_t)h.compressed_size, tmp.data(), (size_t)h.uncompressed_size);
+      if (h.encoding != pq::PLAIN && h.encoding != pq::PLAIN_DICTIONARY) throw CometError("parquet: unsupported dictionary page encoding");
+      if (cp.is_string) {
+        dict_offs.assign(1, 0);
+        size_t p = 0;
+        for (int i = 0; i < h.num_values; i++) {
+          if (p + 4 > (size_t)h.uncompressed_size) throw CometError("parquet: truncated dictionary page");
+          uint32_t len;
+          memcpy(&len, tmp.data() + p, 4);
+          p += 4;
+          if (p + len > (size_t)h.uncompressed_size) throw CometError("parquet: truncated dictionary page");
+          dict_bytes.insert(dict_bytes.end(), tmp.begin() + (long)p, tmp.begin() + (long)(p + len));
+          p += len;
+          dict_offs.push_back((int32_t)dict_bytes.size());
+        }
+      } else {
+        dict_bytes.assign(tmp.begin(), tmp.begin() + h.uncompressed_size);
+      }
+      continue;
+    }
+    if (h.type != pq::DATA_PAGE && h.type != pq::DATA_PAGE_V2) continue;   // index pages etc.
+    if (spos + (size_t)h.uncompressed_size + 16 > staged_cap) {
+      // total_uncompressed_size excludes nothing we stage, but stay safe against odd writers
+      throw CometError("parquet: column chunk larger than its declared uncompressed size");
+    }
+    PqPage pg;
+    memset(&pg, 0, sizeof pg);
+    pg.row_start = values_seen;
+    pg.num_values = h.num_values;
+    size_t page_begin = spos, vals_begin, page_end;
+    if (h.type == pq::DATA_PAGE) {
+      pq::decompress(cm.codec, body, (size_t)h.compressed_size, staged + spos, (size_t)h.uncompressed_size);
+      page_end = spos + (size_t)h.uncompressed_size;
+      size_t p = page_begin;
+      if (max_def > 0) {
+        if (h.def_encoding != pq::RLE) throw CometError("parquet: only RLE definition levels are supported");
+        uint32_t dl;
+        memcpy(&dl, staged + p, 4);
+        p += 4;
+        pg.def_run_first = (int32_t)def_runs.size();
+        parse_hybrid_runs(staged, p, p + dl, 1, h.num_values, def_runs);
+        pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
+        p += dl;
+      }
+      vals_begin = p;
+    } else {
+      // v2: levels are never compressed and precede the (optionally compressed) values
+      if (h.rep_bytes) throw CometError("parquet: repetition levels are not supported");
+      memcpy(staged + spos, body, (size_t)h.def_bytes);
+      if (max_def > 0 && h.def_bytes) {
+        pg.def_run_first = (int32_t)def_runs.size();
+        parse_hybrid_runs(staged, spos, spos + (size_t)h.def_bytes, 1, h.num_values, def_runs);
+        pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
+      }
+      vals_begin = spos + (size_t)h.def_bytes;
+      const size_t vcomp = (size_t)h.compressed_size - (size_t)h.def_bytes, vun = (size_t)h.uncompressed_size - (size_t)h.def_bytes;
+      pq::decompress(h.v2_compressed ? cm.codec : pq::UNCOMPRESSED, body + h.def_bytes, vcomp, staged + vals_begin, vun);
+      page_end = vals_begin + vun;
+    }
+    if (h.encoding == pq::PLAIN) {
+      pg.encoding = 0;
+      pg.values_off = (int64_t)vals_begin;
+      if (cp.is_string) {
+        pg.str_first = (int64_t)str_offs.size();
+        size_t p = vals_begin;
+        while (p + 4 <= page_end) {
+          uint32_t len;
+          memcpy(&len, staged + p, 4);
+          p += 4;
+          str_offs.push_back((int64_t)p);
+          p += len;
+        }
+      }
+    } else if (h.encoding == pq::RLE_DICTIONARY || h.encoding == pq::PLAIN_DICTIONARY) {
+      pg.encoding = 1;
+      pg.bit_width = staged[vals_begin];
+      if (pg.bit_width > 32) throw CometError("parquet: dictionary index bit width > 32");
+      pg.values_off = (int64_t)vals_begin + 1;
+      pg.idx_run_first = (int32_t)idx_runs.size();
+      if (pg.bit_width == 0) {
+        PqRun r;
+        memset(&r, 0, sizeof r);
+        r.is_rle = 1;
+        r.count = h.num_values;
+        idx_runs.push_back(r);
+      } else {
+        parse_hybrid_runs(staged, vals_begin + 1, page_end, pg.bit_width, -1, idx_runs);
+      }
+      pg.idx_run_count = (int32_t)idx_runs.size() - pg.idx_run_first;
+      if (pg.idx_run_count == 0) {   // page of NULLs only
+        PqRun r;
+        memset(&r, 0, sizeof r);
+        r.is_rle = 1;
+        r.count = h.num_values;
+        idx_runs.push_back(r);
+        pg.idx_run_count = 1;
+      }
+    } else if (h.encoding == pq::RLE && cp.kind == PQ_BOOL) {
+      throw CometError("parquet: RLE-encoded booleans are not supported yet");
+    } else {
+      throw CometError("parquet: value encoding " + std::to_string(h.encoding) + " is not supported yet (PLAIN and RLE_DICTIONARY are)");
+    }
+    spos = page_end;
+    values_seen += h.num_values;
+    pages.push_back(pg);
+  }
+  if (values_seen != hc.n_rows) throw CometError("parquet: column chunk values do not add up to the row group's rows (nested data?)");
+  if (pages.empty()) throw CometError("parquet: column chunk without data pages");
+  memset(staged + spos, 0, 16);
+  hc.spos = spos;
+  for (const PqRun& r : def_runs)
+    if (!r.is_rle || r.rle_value != (uint32_t)max_def) { hc.no_nulls = false; break; }
+  str_offs.push_back(0);   // sentinel
+}
 
 }  // namespace
 
 DevTable ExecutionContext::scan_parquet(const Operator& op) {
+  static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   if (!op.partition_schema.empty()) throw CometError("Hive-partition columns are not supported by the GPU Parquet scan yet");
   const size_t ncol = op.required_schema.size();
   DevTable out;
@@ -187,12 +432,12 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (op.files.empty()) return out;   // EmptyExec (planner.rs:1548-1556)
 
   // pass 1: open files, pick row groups (midpoint rule), total rows
-  struct Sel { std::shared_ptr<MappedFile> file; std::shared_ptr<pq::FileMeta> meta; int rg; int64_t row_off; };
+  struct Sel { std::shared_ptr<OpenFile> file; std::shared_ptr<pq::FileMeta> meta; int rg; int64_t row_off; };
   std::vector<Sel> sels;
   int64_t total_rows = 0;
   for (auto& pf : op.files) {
-    auto mf = std::make_shared<MappedFile>(path_from_uri(pf.file_path));
-    auto fm = std::make_shared<pq::FileMeta>(pq::parse_footer(mf->data, mf->size));
+    auto mf = std::make_shared<OpenFile>(path_from_uri(pf.file_path));
+    auto fm = std::make_shared<pq::FileMeta>(pq::parse_footer(mf->footer.data(), mf->footer.size()));
     for (size_t g = 0; g < fm->row_groups.size(); g++) {
       const pq::RowGroup& rg = fm->row_groups[g];
       if (rg.columns.empty()) continue;
@@ -212,220 +457,216 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (total_rows == 0) return out;
   if (total_rows >= ((int64_t)1 << 31)) throw CometError("GPU Parquet scan: more than 2^31 rows in one partition");
 
-  std::vector<std::shared_ptr<ChunkBuffers>> keep;
+  if (trace) fprintf(stderr, "[comet] parquet: footers + row-group selection done at %.2f ms\n", ms_since());
+  // Host threads prepare the column chunks (decompression dominates: ~1 GB/s per core for zstd) straight into one pinned
+  // block per column; this thread concatenates a finished column's tables, uploads and decodes the whole column at once.
+  // spark.comet.gpu.scanThreads / COMET_SCAN_THREADS bound the pool.
+  const size_t nsel = sels.size();
+  const size_t ntasks = ncol * nsel;
+  std::vector<HostChunk> chunks(ntasks);
+  std::vector<ColumnPlan> plans(ncol);
+  std::vector<std::vector<size_t>> slot_off(ncol, std::vector<size_t>(nsel + 1, 0));
+  std::vector<std::unique_ptr<PinnedBuf>> col_staged(ncol);
+  for (size_t c = 0; c < ncol; c++) {
+    for (size_t si = 0; si < nsel; si++) {
+      ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, true);
+      const pq::RowGroup& rg = sels[si].meta->row_groups[(size_t)sels[si].rg];
+      if ((size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
+      if (si == 0) plans[c] = cp;
+      else if (cp.kind != plans[c].kind || cp.src_width != plans[c].src_width || cp.is_string != plans[c].is_string)
+        throw CometError("parquet: column '" + op.required_schema[c].name + "' has different physical types across files");
+      slot_off[c][si + 1] = slot_off[c][si] + staged_capacity(rg.columns[(size_t)cp.leaf]);
+    }
+    col_staged[c].reset(new PinnedBuf());
+    col_staged[c]->ensure(slot_off[c][nsel] + 64);
+  }
+  // shared state outlives this frame only through the shared_ptr the tasks hold
+  struct Progress {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> done;
+    size_t finished = 0;
+    std::atomic<bool> cancelled{false};
+  };
+  auto prog = std::make_shared<Progress>();
+  prog->done.assign(ntasks, 0);
+  int max_inflight = ScanPool::get().size();
+  for (auto& kv : config_)
+    if (kv.first == "spark.comet.gpu.scanThreads") max_inflight = std::max(1, atoi(kv.second.c_str()));
+  (void)max_inflight;
+  auto run_task = [&](size_t t) {
+    const size_t c = t / nsel, si = t % nsel;
+    ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg};
+    decode_chunk_host(src, op.required_schema[c], chunks[t], (uint8_t*)col_staged[c]->p + slot_off[c][si], slot_off[c][si + 1] - slot_off[c][si]);
+  };
+  for (size_t t = 0; t < ntasks; t++) {
+    ScanPool::get().submit([prog, t, &run_task, &chunks]() {
+      if (!prog->cancelled.load()) {
+        try {
+          run_task(t);
+        } catch (...) {
+          chunks[t].err = std::current_exception();
+        }
+      }
+      {
+        std::lock_guard<std::mutex> lk(prog->mu);
+        prog->done[t] = 1;
+        prog->finished++;
+      }
+      prog->cv.notify_all();
+    });
+  }
+  // whatever happens below, no task may still reference this frame when it unwinds
+  struct Drain {
+    std::shared_ptr<Progress> p; size_t n;
+    ~Drain() {
+      p->cancelled.store(true);
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv.wait(lk, [&] { return p->finished == n; });
+    }
+  } drain{prog, ntasks};
+  auto wait_for = [&](size_t t) {
+    std::unique_lock<std::mutex> lk(prog->mu);
+    prog->cv.wait(lk, [&] { return prog->done[t] != 0; });
+    if (chunks[t].err) std::rethrow_exception(chunks[t].err);
+  };
+
+  struct ColumnDevice { DevBuf bytes, tables; PinnedBuf h_tables; };
+  std::vector<std::shared_ptr<ColumnDevice>> keep;
+  hipStream_t copy_stream = nullptr;
+  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  std::vector<hipEvent_t> events;
+  struct StreamGuard {
+    hipStream_t& s; std::vector<hipEvent_t>& ev;
+    ~StreamGuard() {
+      if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+      for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+  } stream_guard{copy_stream, events};
+  auto get_event = [&]() {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    events.push_back(e);
+    return e;
+  };
   auto tiles = std::make_shared<DevBuf>();
   tiles->ensure((size_t)((total_rows + 1023) / 1024 + 2) * 8);
   auto vidx = std::make_shared<DevBuf>();
-  vidx->ensure((size_t)total_rows * 4 + 16);
 
   for (size_t c = 0; c < ncol; c++) {
-    const StructField& want = op.required_schema[c];
+    const ColumnPlan& cp = plans[c];
     auto values = std::make_shared<DevBuf>();
     auto valid_bytes = std::make_shared<DevBuf>();
     auto lengths = std::make_shared<DevBuf>();
-    valid_bytes->ensure((size_t)total_rows + 16);
+    const bool is_string = cp.is_string;
+    auto cd = std::make_shared<ColumnDevice>();
+    keep.push_back(cd);
+    // the column's page bytes cross PCIe in slices as soon as their chunks are ready, on the copy stream
+    cd->bytes.ensure(slot_off[c][nsel] + 64);
     bool any_optional = false;
-    std::vector<PqDecodeArgs> string_args;   // replayed for the copy phase
-    bool is_string = false;
-    int out_width = 0;
-    for (auto& sel : sels) {
-      const pq::RowGroup& rg = sel.meta->row_groups[sel.rg];
-      ColumnPlan cp = plan_column(want, *sel.meta, true);
-      if ((size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
-      const pq::ColumnMeta& cm = rg.columns[cp.leaf];
-      is_string = cp.is_string;
-      out_width = cp.out_width;
-      if (!values->p && !cp.is_string) values->ensure((size_t)total_rows * cp.out_width + 16);
-      if (cp.is_string && !lengths->p) lengths->ensure((size_t)total_rows * 4 + 16);
-      const int max_def = cp.el.repetition == 1 ? 1 : 0;
-      any_optional |= max_def > 0;
-      const int64_t n_rows = rg.num_rows;
-
-      auto cb = std::make_shared<ChunkBuffers>();
-      keep.push_back(cb);
-      cb->h_bytes.ensure((size_t)cm.total_uncompressed + 64);
-      uint8_t* staged = (uint8_t*)cb->h_bytes.p;
-      size_t spos = 0;
-      std::vector<PqPage> pages;
-      std::vector<PqRun> def_runs, idx_runs;
-      std::vector<uint8_t> dict_bytes;
-      std::vector<int32_t> dict_offs;
-      std::vector<int64_t> str_offs;
-
-      int64_t off = (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < cm.data_page_offset) ? cm.dictionary_page_offset : cm.data_page_offset;
-      const int64_t chunk_end = off + cm.total_compressed;
-      if (off < 0 || (size_t)chunk_end > sel.file->size) throw CometError("parquet: column chunk outside the file");
-      bytes_scanned_ += cm.total_compressed;
-      int64_t values_seen = 0;
-      std::vector<uint8_t> tmp;
-      while (values_seen < cm.num_values && off < chunk_end) {
-        pq::PageHeader h = pq::parse_page_header(sel.file->data + off, (size_t)(chunk_end - off));
-        const uint8_t* body = sel.file->data + off + h.header_len;
-        off += (int64_t)h.header_len + h.compressed_size;
-        if (h.type == pq::DICTIONARY_PAGE) {
-          tmp.resize((size_t)h.uncompressed_size + 8);
-          pq::decompress(cm.codec, body, (size_t)h.compressed_size, tmp.data(), (size_t)h.uncompressed_size);
-          if (h.encoding != pq::PLAIN && h.encoding != pq::PLAIN_DICTIONARY) throw CometError("parquet: unsupported dictionary page encoding");
-          if (cp.is_string) {
-            dict_offs.assign(1, 0);
-            size_t p = 0;
-            for (int i = 0; i < h.num_values; i++) {
-              if (p + 4 > (size_t)h.uncompressed_size) throw CometError("parquet: truncated dictionary page");
-              uint32_t len;
-              memcpy(&len, tmp.data() + p, 4);
-              p += 4;
-              if (p + len > (size_t)h.uncompressed_size) throw CometError("parquet: truncated dictionary page");
-              dict_bytes.insert(dict_bytes.end(), tmp.begin() + (long)p, tmp.begin() + (long)(p + len));
-              p += len;
-              dict_offs.push_back((int32_t)dict_bytes.size());
-            }
-          } else {
-            dict_bytes.assign(tmp.begin(), tmp.begin() + h.uncompressed_size);
-          }
-          continue;
-        }
-        if (h.type != pq::DATA_PAGE && h.type != pq::DATA_PAGE_V2) continue;   // index pages etc.
-        if (spos + (size_t)h.uncompressed_size + 16 > cb->h_bytes.cap) {
-          // total_uncompressed_size excludes nothing we stage, but stay safe against odd writers
-          throw CometError("parquet: column chunk larger than its declared uncompressed size");
-        }
-        PqPage pg;
-        memset(&pg, 0, sizeof pg);
-        pg.row_start = values_seen;
-        pg.num_values = h.num_values;
-        size_t page_begin = spos, vals_begin, page_end;
-        if (h.type == pq::DATA_PAGE) {
-          pq::decompress(cm.codec, body, (size_t)h.compressed_size, staged + spos, (size_t)h.uncompressed_size);
-          page_end = spos + (size_t)h.uncompressed_size;
-          size_t p = page_begin;
-          if (max_def > 0) {
-            if (h.def_encoding != pq::RLE) throw CometError("parquet: only RLE definition levels are supported");
-            uint32_t dl;
-            memcpy(&dl, staged + p, 4);
-            p += 4;
-            pg.def_run_first = (int32_t)def_runs.size();
-            parse_hybrid_runs(staged, p, p + dl, 1, h.num_values, def_runs);
-            pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
-            p += dl;
-          }
-          vals_begin = p;
-        } else {
-          // v2: levels are never compressed and precede the (optionally compressed) values
-          if (h.rep_bytes) throw CometError("parquet: repetition levels are not supported");
-          memcpy(staged + spos, body, (size_t)h.def_bytes);
-          if (max_def > 0 && h.def_bytes) {
-            pg.def_run_first = (int32_t)def_runs.size();
-            parse_hybrid_runs(staged, spos, spos + (size_t)h.def_bytes, 1, h.num_values, def_runs);
-            pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
-          }
-          vals_begin = spos + (size_t)h.def_bytes;
-          const size_t vcomp = (size_t)h.compressed_size - (size_t)h.def_bytes, vun = (size_t)h.uncompressed_size - (size_t)h.def_bytes;
-          pq::decompress(h.v2_compressed ? cm.codec : pq::UNCOMPRESSED, body + h.def_bytes, vcomp, staged + vals_begin, vun);
-          page_end = vals_begin + vun;
-        }
-        if (h.encoding == pq::PLAIN) {
-          pg.encoding = 0;
-          pg.values_off = (int64_t)vals_begin;
-          if (cp.is_string) {
-            pg.str_first = (int64_t)str_offs.size();
-            size_t p = vals_begin;
-            while (p + 4 <= page_end) {
-              uint32_t len;
-              memcpy(&len, staged + p, 4);
-              p += 4;
-              str_offs.push_back((int64_t)p);
-              p += len;
-            }
-          }
-        } else if (h.encoding == pq::RLE_DICTIONARY || h.encoding == pq::PLAIN_DICTIONARY) {
-          pg.encoding = 1;
-          pg.bit_width = staged[vals_begin];
-          if (pg.bit_width > 32) throw CometError("parquet: dictionary index bit width > 32");
-          pg.values_off = (int64_t)vals_begin + 1;
-          pg.idx_run_first = (int32_t)idx_runs.size();
-          if (pg.bit_width == 0) {
-            PqRun r;
-            memset(&r, 0, sizeof r);
-            r.is_rle = 1;
-            r.count = h.num_values;
-            idx_runs.push_back(r);
-          } else {
-            parse_hybrid_runs(staged, vals_begin + 1, page_end, pg.bit_width, -1, idx_runs);
-          }
-          pg.idx_run_count = (int32_t)idx_runs.size() - pg.idx_run_first;
-          if (pg.idx_run_count == 0) {   // page of NULLs only
-            PqRun r;
-            memset(&r, 0, sizeof r);
-            r.is_rle = 1;
-            r.count = h.num_values;
-            idx_runs.push_back(r);
-            pg.idx_run_count = 1;
-          }
-        } else if (h.encoding == pq::RLE && cp.kind == PQ_BOOL) {
-          throw CometError("parquet: RLE-encoded booleans are not supported yet");
-        } else {
-          throw CometError("parquet: value encoding " + std::to_string(h.encoding) + " is not supported yet (PLAIN and RLE_DICTIONARY are)");
-        }
-        spos = page_end;
-        values_seen += h.num_values;
-        pages.push_back(pg);
+    size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0;
+    const size_t kSlice = 8;   // chunks per upload
+    for (size_t s0 = 0; s0 < nsel; s0 += kSlice) {
+      const size_t s1 = std::min(nsel, s0 + kSlice);
+      for (size_t si = s0; si < s1; si++) {
+        wait_for(c * nsel + si);
+        HostChunk& hc = chunks[c * nsel + si];
+        bytes_scanned_ += hc.compressed;
+        any_optional |= hc.max_def > 0 && !hc.no_nulls;
+        n_pages += hc.pages.size();
+        n_def += hc.no_nulls ? 0 : hc.def_runs.size();
+        n_idx += hc.idx_runs.size();
+        n_dict += (hc.dict_bytes.size() + 15) & ~(size_t)15;
+        n_doffs += hc.dict_offs.size();
+        n_soffs += hc.str_offs.size();
       }
-      if (values_seen != n_rows) throw CometError("parquet: column chunk values do not add up to the row group's rows (nested data?)");
-      if (pages.empty()) throw CometError("parquet: column chunk without data pages");
-      memset(staged + spos, 0, 16);
+      HIP_CHECK(hipMemcpyAsync((char*)cd->bytes.p + slot_off[c][s0], (char*)col_staged[c]->p + slot_off[c][s0], slot_off[c][s1] - slot_off[c][s0],
+                               hipMemcpyHostToDevice, copy_stream));
+    }
+    if (trace) fprintf(stderr, "[comet] parquet: column %zu host chunks ready at %.2f ms\n", c, ms_since());
+    // concatenate the chunks' tables: offsets become column-global
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t o = 0;
+    const size_t off_pages = o; o = al(o + n_pages * sizeof(PqPage));
+    const size_t off_def = o; o = al(o + n_def * sizeof(PqRun) + 16);
+    const size_t off_idx = o; o = al(o + n_idx * sizeof(PqRun) + 16);
+    const size_t off_dict = o; o = al(o + n_dict + 16);
+    const size_t off_doffs = o; o = al(o + n_doffs * 4 + 16);
+    const size_t off_soffs = o; o = al(o + n_soffs * 8 + 16);
+    cd->h_tables.ensure(o + 16);
+    char* tb_h = (char*)cd->h_tables.p;
+    {
+      PqPage* P = (PqPage*)(tb_h + off_pages);
+      PqRun* D = (PqRun*)(tb_h + off_def);
+      PqRun* I = (PqRun*)(tb_h + off_idx);
+      uint8_t* DB = (uint8_t*)(tb_h + off_dict);
+      int32_t* DO = (int32_t*)(tb_h + off_doffs);
+      int64_t* SO = (int64_t*)(tb_h + off_soffs);
+      size_t ip = 0, id = 0, ii = 0, idb = 0, ido = 0, iso = 0;
+      for (size_t si = 0; si < nsel; si++) {
+        HostChunk& hc = chunks[c * nsel + si];
+        const int64_t base = (int64_t)slot_off[c][si];
+        const bool nulls = hc.max_def > 0 && !hc.no_nulls;
+        for (const PqPage& src : hc.pages) {
+          PqPage pg = src;
+          pg.row_start += sels[si].row_off;
+          pg.values_off += base;
+          pg.str_first += (int64_t)iso;
+          if (nulls) pg.def_run_first += (int32_t)id;
+          else pg.def_run_first = pg.def_run_count = 0;
+          pg.idx_run_first += (int32_t)ii;
+          pg.dict_off = (int64_t)idb;
+          pg.dict_offs_first = (int32_t)ido;
+          P[ip++] = pg;
+        }
+        if (nulls)
+          for (const PqRun& r : hc.def_runs) { D[id] = r; D[id].byte_off += base; id++; }
+        for (const PqRun& r : hc.idx_runs) { I[ii] = r; I[ii].byte_off += base; ii++; }
+        if (!hc.dict_bytes.empty()) memcpy(DB + idb, hc.dict_bytes.data(), hc.dict_bytes.size());
+        idb += (hc.dict_bytes.size() + 15) & ~(size_t)15;
+        if (!hc.dict_offs.empty()) memcpy(DO + ido, hc.dict_offs.data(), hc.dict_offs.size() * 4);
+        ido += hc.dict_offs.size();
+        for (int64_t v : hc.str_offs) SO[iso++] = v ? v + base : 0;
+      }
+      if (n_pages >= ((size_t)1 << 31) || n_idx >= ((size_t)1 << 31)) throw CometError("parquet: too many pages / runs in one column");
+    }
+    cd->tables.ensure(o + 16);
+    HIP_CHECK(hipMemcpyAsync(cd->tables.p, cd->h_tables.p, o, hipMemcpyHostToDevice, copy_stream));
+    hipEvent_t ev = get_event();
+    HIP_CHECK(hipEventRecord(ev, copy_stream));
+    HIP_CHECK(hipStreamWaitEvent(stream_, ev, 0));
+    const char* tb = (const char*)cd->tables.p;
 
-      // tables → one pinned block → device
-      const size_t sz_pages = pages.size() * sizeof(PqPage), sz_def = def_runs.size() * sizeof(PqRun), sz_idx = idx_runs.size() * sizeof(PqRun);
-      const size_t sz_do = dict_offs.size() * 4, sz_so = (str_offs.size() + 1) * 8;
-      cb->bytes.ensure(spos + 16);
-      HIP_CHECK(hipMemcpyAsync(cb->bytes.p, staged, spos + 16, hipMemcpyHostToDevice, stream_));
-      auto up = [&](DevBuf& d, const void* src, size_t n) {
-        d.ensure(n + 16);
-        if (n) HIP_CHECK(hipMemcpy(d.p, src, n, hipMemcpyHostToDevice));   // small tables: synchronous copy from pageable memory
-      };
-      up(cb->pages, pages.data(), sz_pages);
-      up(cb->def_runs, def_runs.data(), sz_def);
-      up(cb->idx_runs, idx_runs.data(), sz_idx);
-      up(cb->dict, dict_bytes.data(), dict_bytes.size());
-      up(cb->dict_offs, dict_offs.data(), sz_do);
-      str_offs.push_back(0);
-      up(cb->str_offs, str_offs.data(), sz_so);
-
-      PqDecodeArgs a;
-      memset(&a, 0, sizeof a);
-      a.pages = (const PqPage*)cb->pages.p;
-      a.npages = (int32_t)pages.size();
-      a.max_def = max_def;
-      a.def_runs = (const PqRun*)cb->def_runs.p;
-      a.idx_runs = (const PqRun*)cb->idx_runs.p;
-      a.bytes = (const uint8_t*)cb->bytes.p;
-      a.dict = (const uint8_t*)cb->dict.p;
-      a.dict_offs = (const int32_t*)cb->dict_offs.p;
-      a.plain_str_offs = (const int64_t*)cb->str_offs.p;
-      a.n_rows = n_rows;
-      a.kind = cp.kind;
-      a.width = cp.src_width;
-      a.valid_out = (uint8_t*)valid_bytes->p + sel.row_off;
-      a.vidx = (uint32_t*)vidx->p + sel.row_off;
+    PqDecodeArgs a;
+    memset(&a, 0, sizeof a);
+    a.pages = (const PqPage*)(tb + off_pages);
+    a.npages = (int32_t)n_pages;
+    a.max_def = any_optional ? 1 : 0;
+    a.def_runs = (const PqRun*)(tb + off_def);
+    a.idx_runs = (const PqRun*)(tb + off_idx);
+    a.bytes = (const uint8_t*)cd->bytes.p;
+    a.dict = (const uint8_t*)(tb + off_dict);
+    a.dict_offs = (const int32_t*)(tb + off_doffs);
+    a.plain_str_offs = (const int64_t*)(tb + off_soffs);
+    a.n_rows = total_rows;
+    a.kind = cp.kind;
+    a.width = cp.src_width;
+    if (any_optional) {
+      valid_bytes->ensure((size_t)total_rows + 16);
+      if (!vidx->p) vidx->ensure((size_t)total_rows * 4 + 16);
+      a.valid_out = (uint8_t*)valid_bytes->p;
+      a.vidx = (uint32_t*)vidx->p;
       pq_launch_validity(&a, stream_);
-      if (max_def > 0) pq_launch_vidx(a.valid_out, n_rows, (uint64_t*)tiles->p, a.vidx, stream_);
-      if (!cp.is_string) {
-        a.values_out = (char*)values->p + (size_t)sel.row_off * cp.out_width;
-        pq_launch_decode_fixed(&a, stream_);
-      } else {
-        a.lengths_out = (uint32_t*)lengths->p + sel.row_off;
-        pq_launch_string_lengths(&a, stream_);
-        string_args.push_back(a);
-      }
-      // vidx is reused by the next chunk of this column: keep launches ordered on the single stream (they are)
-      if (cp.is_string) {
-        // the copy phase needs vidx again: give string chunks their own index buffer
-        auto own = std::make_shared<DevBuf>();
-        own->ensure((size_t)n_rows * 4 + 16);
-        if (max_def > 0) HIP_CHECK(hipMemcpyAsync(own->p, a.vidx, (size_t)n_rows * 4, hipMemcpyDeviceToDevice, stream_));
-        string_args.back().vidx = (uint32_t*)own->p;
-        out.owners.push_back(own);
-      }
+      pq_launch_vidx(a.valid_out, total_rows, (uint64_t*)tiles->p, a.vidx, stream_);
+    }
+    if (!is_string) {
+      values->ensure((size_t)total_rows * cp.out_width + 16);
+      a.values_out = values->p;
+      pq_launch_decode_fixed(&a, stream_);
+    } else {
+      lengths->ensure((size_t)total_rows * 4 + 16);
+      a.lengths_out = (uint32_t*)lengths->p;
+      pq_launch_string_lengths(&a, stream_);
     }
     DeviceColumnView cv;
     if (is_string) {
@@ -436,13 +677,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       read_small(&total_bytes, (char*)offsets->p + (size_t)total_rows * 4, 4);
       auto data = std::make_shared<DevBuf>();
       data->ensure((size_t)std::max(total_bytes, 1) + 16);
-      size_t k = 0;
-      for (auto& sel : sels) {
-        PqDecodeArgs a = string_args[k++];
-        a.str_offsets = (const int32_t*)offsets->p + sel.row_off;
-        a.str_bytes_out = (uint8_t*)data->p;
-        pq_launch_string_copy(&a, stream_);
-      }
+      a.str_offsets = (const int32_t*)offsets->p;
+      a.str_bytes_out = (uint8_t*)data->p;
+      pq_launch_string_copy(&a, stream_);
       cv.data = offsets->p;
       cv.aux = data->p;
       out.owners.push_back(offsets);
@@ -456,7 +693,6 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       out.owners.push_back(bits);
       out.owners.push_back(values);
     } else {
-      (void)out_width;
       cv.data = values->p;
       out.owners.push_back(values);
     }
@@ -471,11 +707,25 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     out.owners.push_back(valid_bytes);
     out.cols[c] = cv;
   }
+  if (trace) fprintf(stderr, "[comet] parquet: all launches issued at %.2f ms\n", ms_since());
   HIP_CHECK(hipStreamSynchronize(stream_));
+  if (trace) fprintf(stderr, "[comet] parquet: device idle at %.2f ms\n", ms_since());
   out.owners.push_back(tiles);
   out.owners.push_back(vidx);
   // staging buffers can go back to the pools now that the stream is idle
   keep.clear();
+  if (trace) fprintf(stderr, "[comet] parquet: device buffers released at %.2f ms\n", ms_since());
+  // the run tables are many large vectors (one munmap each when freed): give them to a throw-away thread instead of paying
+  // ~5 ms of page-table teardown on the query's critical path
+  {
+    auto* garbage = new std::vector<HostChunk>(std::move(chunks));
+    std::thread([garbage]() { delete garbage; }).detach();
+  }
+  if (trace) fprintf(stderr, "[comet] parquet: host tables handed off at %.2f ms\n", ms_since());
+  col_staged.clear();
+  if (trace) fprintf(stderr, "[comet] parquet: staging released at %.2f ms\n", ms_since());
+  sels.clear();
+  if (trace) fprintf(stderr, "[comet] parquet: files closed at %.2f ms\n", ms_since());
   return out;
 }
 

@@ -78,8 +78,8 @@ def lineitem_q1(n: int, seed: int = 1) -> pa.Table:
 
 # ------------------------------------------------------------------ plans
 
-def q6_plan(mode: int = S.PARTIAL) -> S.Operator:
-    """TPC-H Q6 stage 1:
+def q6_plan(mode: int = S.PARTIAL, source: "S.Operator" = None) -> S.Operator:
+    """TPC-H Q6 stage 1; `source` replaces the Scan leaf (e.g. a NativeScan over Parquet files):
     HashAgg(Partial, sum(CheckOverflow(price*disc → dec(25,4))) : dec(35,4))
       ← Project[price, disc] ← Filter(shipdate >= 1994-01-01 AND shipdate < 1995-01-01 AND
                                        disc >= 0.05 AND disc <= 0.07 AND qty < 24.00) ← Scan."""
@@ -91,7 +91,7 @@ def q6_plan(mode: int = S.PARTIAL) -> S.Operator:
         S.gt_eq(disc, S.lit(5, DEC))),
         S.lt_eq(disc, S.lit(7, DEC))),
         S.lt(qty, S.lit(2400, DEC)))
-    f = S.filter_(S.scan(fields), pred)
+    f = S.filter_(source if source is not None else S.scan(fields), pred)
     p = S.project(f, [price, disc])
     revenue = S.check_overflow(S.math("multiply", S.col(0, DEC), S.col(1, DEC), S.decimal(25, 4)), S.decimal(25, 4))
     return S.hash_agg(p, [], [S.sum_(revenue, S.decimal(35, 4))], mode)
