@@ -109,16 +109,77 @@ __device__ __forceinline__ i128 pq_flba_to_i128(const u8* p, int len) {
   for (int k = 0; k < len; k++) v = (v << 8) | p[k];
   return (i128)v;
 }
+// little-endian loads from arbitrarily aligned page bytes (gfx9+ global loads may be unaligned)
+__device__ __forceinline__ u32 pq_ld32(const u8* p) { u32 x; __builtin_memcpy(&x, p, 4); return x; }
+__device__ __forceinline__ u64 pq_ld64(const u8* p) { u64 x; __builtin_memcpy(&x, p, 8); return x; }
+__device__ __forceinline__ i64 pq_uniform_i64(i64 v) {
+  return (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v));
+}
+
+// Every block decodes one CONTIGUOUS slice of the column, tile after tile, and the 64 rows of a wave are consecutive.
+// So the page and the hybrid run of a wave's first row only ever move FORWARD: they are found by binary search once per
+// block and then advanced with wave-uniform loads (amortised O(1) per tile), and each lane steps forward from the wave's
+// run to its own.  (One lane per row with two binary searches per row was latency-bound at ~1 TB/s.)
 __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
-  for (i64 row = (i64)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (i64)gridDim.x * 256) {
-    const bool valid = !a.valid_out || a.valid_out[row] != 0;   // valid_out == NULL: the chunk has no NULLs
+  const i64 per_block = (((a.n_rows + gridDim.x - 1) / gridDim.x) + 255) / 256 * 256;
+  const i64 begin = (i64)blockIdx.x * per_block;
+  const i64 end = begin + per_block < a.n_rows ? begin + per_block : a.n_rows;
+  const int wave_first = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  int p0 = -1, run0 = -1, run_page = -1;
+  for (i64 base = begin; base < end; base += 256) {
+    const i64 row0 = base + wave_first;                      // first row of this wave's 64 (wave-uniform)
+    if (row0 >= end) break;
+    const i64 row = base + threadIdx.x;
+    const bool in_range = row < end;
+    if (p0 < 0) p0 = pq_find_page(a.pages, a.npages, row0);
+    else
+      while (p0 + 1 < a.npages && a.pages[p0 + 1].row_start <= row0) p0++;
+    int p = p0;
+    if (in_range)
+      while (p + 1 < a.npages && a.pages[p + 1].row_start <= row) p++;
+    const bool valid = in_range && (!a.valid_out || a.valid_out[row] != 0);   // valid_out == NULL: the column has no NULLs
     const u8* src = nullptr;
     u32 boolbit = 0;
+    const PqPage pg0 = a.pages[p0];
+    if (pg0.encoding == 1) {
+      const i32 v0 = a.max_def > 0 ? (i32)(a.vidx[row0] - a.vidx[pg0.row_start]) : (i32)(row0 - pg0.row_start);
+      const int last0 = pg0.idx_run_first + pg0.idx_run_count - 1;
+      if (run_page != p0) {
+        int lo = pg0.idx_run_first, hi = last0;
+        while (lo < hi) {
+          int mid = (lo + hi + 1) >> 1;
+          if (a.idx_runs[mid].value_start <= v0) lo = mid;
+          else hi = mid - 1;
+        }
+        run0 = lo;
+        run_page = p0;
+      } else {
+        while (run0 < last0 && a.idx_runs[run0 + 1].value_start <= v0) run0++;
+      }
+    } else {
+      run_page = -1;
+    }
     if (valid) {
-      const PqPage pg = a.pages[pq_find_page(a.pages, a.npages, row)];
+      const PqPage pg = a.pages[p];
       const i32 v = a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[pg.row_start]) : (i32)(row - pg.row_start);
       if (pg.encoding == 1) {
-        u32 idx = pq_hybrid_value(a.idx_runs, pg.idx_run_first, pg.idx_run_count, a.bytes, pg.bit_width, v);
+        u32 idx;
+        if (p == p0 && run_page == p0) {
+          int r = run0;
+          const int last = pg.idx_run_first + pg.idx_run_count - 1;
+          while (r < last && a.idx_runs[r + 1].value_start <= v) r++;
+          const PqRun rn = a.idx_runs[r];
+          if (rn.is_rle) {
+            idx = rn.rle_value;
+          } else {
+            const int bw = pg.bit_width;
+            const i64 bit = (i64)(v - rn.value_start) * bw;
+            const u64 w = pq_ld64(a.bytes + rn.byte_off + (bit >> 3));   // bw <= 32 → the value fits in 5 bytes; staging is padded
+            idx = (u32)((w >> (bit & 7)) & ((bw >= 32) ? 0xffffffffull : ((1ull << bw) - 1)));
+          }
+        } else {
+          idx = pq_hybrid_value(a.idx_runs, pg.idx_run_first, pg.idx_run_count, a.bytes, pg.bit_width, v);
+        }
         src = a.dict + pg.dict_off + (i64)idx * a.width;
       } else if (a.kind == PQ_BOOL) {
         boolbit = (a.bytes[pg.values_off + (v >> 3)] >> (v & 7)) & 1;
@@ -126,14 +187,15 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
         src = a.bytes + pg.values_off + (i64)v * a.width;
       }
     }
+    if (!in_range) continue;
     switch (a.kind) {
-      case PQ_COPY4: { u32 x = 0; if (valid) x = (u32)src[0] | ((u32)src[1] << 8) | ((u32)src[2] << 16) | ((u32)src[3] << 24); ((u32*)a.values_out)[row] = x; break; }
-      case PQ_COPY8: { u64 x = 0; if (valid) for (int k = 0; k < 8; k++) x |= (u64)src[k] << (8 * k); ((u64*)a.values_out)[row] = x; break; }
-      case PQ_I32_TO_I64: { i32 x = 0; if (valid) x = (i32)((u32)src[0] | ((u32)src[1] << 8) | ((u32)src[2] << 16) | ((u32)src[3] << 24)); ((i64*)a.values_out)[row] = (i64)x; break; }
-      case PQ_I32_TO_I16: { i32 x = 0; if (valid) x = (i32)((u32)src[0] | ((u32)src[1] << 8) | ((u32)src[2] << 16) | ((u32)src[3] << 24)); ((i16*)a.values_out)[row] = (i16)x; break; }
-      case PQ_I32_TO_I8: { i32 x = 0; if (valid) x = (i32)((u32)src[0] | ((u32)src[1] << 8) | ((u32)src[2] << 16) | ((u32)src[3] << 24)); ((i8*)a.values_out)[row] = (i8)x; break; }
-      case PQ_I32_TO_DEC: { i32 x = 0; if (valid) x = (i32)((u32)src[0] | ((u32)src[1] << 8) | ((u32)src[2] << 16) | ((u32)src[3] << 24)); ((i128*)a.values_out)[row] = (i128)x; break; }
-      case PQ_I64_TO_DEC: { u64 x = 0; if (valid) for (int k = 0; k < 8; k++) x |= (u64)src[k] << (8 * k); ((i128*)a.values_out)[row] = (i128)(i64)x; break; }
+      case PQ_COPY4: ((u32*)a.values_out)[row] = valid ? pq_ld32(src) : 0u; break;
+      case PQ_COPY8: ((u64*)a.values_out)[row] = valid ? pq_ld64(src) : 0ull; break;
+      case PQ_I32_TO_I64: ((i64*)a.values_out)[row] = valid ? (i64)(i32)pq_ld32(src) : 0; break;
+      case PQ_I32_TO_I16: ((i16*)a.values_out)[row] = valid ? (i16)(i32)pq_ld32(src) : (i16)0; break;
+      case PQ_I32_TO_I8: ((i8*)a.values_out)[row] = valid ? (i8)(i32)pq_ld32(src) : (i8)0; break;
+      case PQ_I32_TO_DEC: ((i128*)a.values_out)[row] = valid ? (i128)(i32)pq_ld32(src) : (i128)0; break;
+      case PQ_I64_TO_DEC: ((i128*)a.values_out)[row] = valid ? (i128)(i64)pq_ld64(src) : (i128)0; break;
       case PQ_FLBA_TO_DEC: ((i128*)a.values_out)[row] = valid ? pq_flba_to_i128(src, a.width) : (i128)0; break;
       case PQ_BOOL: ((u8*)a.values_out)[row] = (u8)(valid ? boolbit : 0); break;
       default: break;
@@ -229,6 +291,10 @@ __global__ __launch_bounds__(256) void pq_u32_scan_apply_kernel(const u32* in, i
 }
 __global__ __launch_bounds__(256) void pq_pack_kernel(const u8* bytes, u8* bitmap, i64 n) { pack_validity_body(bytes, bitmap, n); }
 
+static int grid_slices(i64 n) {   // contiguous slices of >= 4 tiles, enough blocks to fill 256 CUs several times over
+  i64 g = (n + 1023) / 1024;
+  return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
 static int grid_rows(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -246,7 +312,7 @@ void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* 
   hipLaunchKernelGGL(pq_tile_scan_kernel, 1, 256, 0, s, (u64*)tiles, (i64)((n + 1023) / 1024));
   hipLaunchKernelGGL(pq_vidx_kernel, grid_tiles(n), 256, 0, s, valid, (i64)n, (const u64*)tiles, (u32*)vidx);
 }
-void pq_launch_decode_fixed(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_decode_fixed_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }
+void pq_launch_decode_fixed(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_decode_fixed_kernel, grid_slices(a->n_rows), 256, 0, (hipStream_t)st, *a); }
 void pq_launch_string_lengths(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_string_lengths_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }
 void pq_launch_string_copy(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_string_copy_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }
 void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st) {
