@@ -489,6 +489,26 @@ struct Gen {
     const int p1 = a.t.precision, s1 = a.t.scale, p2 = b.t.precision, s2 = b.t.scale;
     const bool mul = e.kind == ExprKind::Multiply;
     const bool addsub = e.kind == ExprKind::Add || e.kind == ExprKind::Subtract;
+    if (e.kind == ExprKind::Divide) {
+      // planner.rs:1028-1057 → decimal_div (spark-expr/src/math_funcs/div.rs:71-165)
+      if (!e.has_dtype || e.dtype.id != TypeId::Decimal) throw CometError("Expected Decimal128 return type");
+      const int s3 = e.dtype.scale;
+      const int l_exp = std::max(0, s2 + s3 + 1 - s1), r_exp = std::max(0, s1 - (s2 + s3 + 1));
+      if (l_exp > 38 || p1 + l_exp > 76 || p2 + r_exp > 38)
+        throw CometError("Decimal division " + a.t.str() + " / " + b.t.str() + " -> " + e.dtype.str() + " needs more than 256-bit intermediates; not supported by the GPU pipeline yet");
+      a = named(a);
+      b = named(b);
+      Val r;
+      r.rep = Rep::I128;
+      r.t = e.dtype;
+      r.ok = and_ok(a.ok, b.ok);
+      std::string val = newvar("i128"), dz = newvar("bool");
+      stmt(val + " = comet::dec_div(" + as128(a) + ", " + as128(b) + ", " + lit_u128(pow10_u128(l_exp)) + ", " + lit_u128(pow10_u128(r_exp)) + ", " + dz + ");");
+      if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, dz), 8);
+      r.v = val;
+      r.maxabs = ~(u128)0 >> 1;   // unchecked: the plan's CheckOverflow bounds it
+      return r;
+    }
     if (!mul && !addsub) throw CometError(std::string("Decimal ") + expr_name(e.proto_tag) + " is not supported in the GPU pipeline yet");
     const int smax = std::max(s1, s2);
     // planner.rs:1000-1008
@@ -760,6 +780,20 @@ struct Gen {
     return r;
   }
 
+  // c ? t : f with SQL NULL handling: a NULL condition selects f (If: conditional_funcs/if_expr.rs:103; CaseWhen alike)
+  Val select(const Val& c, const Val& t, const Val& f) {
+    if (t.rep != f.rep) throw CometError("If / CaseWhen branches have different types");
+    std::string cond = "(" + and_ok(c.ok, c.v) + ")";
+    Val r = t;
+    r.maxabs = std::max(t.maxabs, f.maxabs);
+    r.v = "(" + cond + " ? " + t.v + " : " + f.v + ")";
+    if (!t.ok.empty() || !f.ok.empty())
+      r.ok = "(" + cond + " ? " + (t.ok.empty() ? "true" : t.ok) + " : " + (f.ok.empty() ? "true" : f.ok) + ")";
+    else r.ok = "";
+    r.wide_decimal = false;
+    return r;
+  }
+
   Val gen(const ExprP& ep) {
     const Expr& e = *ep;
     std::string key = key_of(ep);
@@ -851,16 +885,23 @@ struct Gen {
       }
       case ExprKind::If: {
         if (e.children.size() != 3) throw CometError("If needs three children");
-        Val c = named(gen(e.children[0])), t = named(gen(e.children[1])), f = named(gen(e.children[2]));
-        if (t.rep != f.rep) throw CometError("If branches have different types");
-        std::string cond = "(" + and_ok(c.ok, c.v) + ")";
-        Val r = t;
-        r.maxabs = std::max(t.maxabs, f.maxabs);
-        r.v = "(" + cond + " ? " + t.v + " : " + f.v + ")";
-        if (!t.ok.empty() || !f.ok.empty())
-          r.ok = "(" + cond + " ? " + (t.ok.empty() ? "true" : t.ok) + " : " + (f.ok.empty() ? "true" : f.ok) + ")";
-        else r.ok = "";
-        r.wide_decimal = false;
+        return select(named(gen(e.children[0])), named(gen(e.children[1])), named(gen(e.children[2])));
+      }
+      case ExprKind::CaseWhen: {
+        // planner.rs:677-704 → DataFusion CaseExpr without base expression: the first WHEN that is TRUE (not NULL) picks its
+        // THEN; no match → ELSE, or NULL without one.  Lowered to a chain of selects built from the last pair backwards.
+        const size_t n = (size_t)e.n_when;
+        if (n == 0 || (e.children.size() != 2 * n && e.children.size() != 2 * n + 1)) throw CometError("CaseWhen: when/then lists differ in length");
+        std::vector<Val> thens;
+        for (size_t i = 0; i < n; i++) thens.push_back(named(gen(e.children[n + i])));
+        Val r;
+        if (e.children.size() == 2 * n + 1) {
+          r = named(gen(e.children[2 * n]));
+        } else {
+          r = thens[0];       // typed NULL: same representation, never valid
+          r.ok = "false";
+        }
+        for (size_t i = n; i-- > 0;) r = named(select(named(gen(e.children[i])), thens[i], r));
         return r;
       }
       case ExprKind::In: {

@@ -240,6 +240,29 @@ CDEV i256 i256_div_pow10_half_up(const i256& v, u128 divisor) {
   }
   return neg ? i256_negate(q) : q;
 }
+// Spark decimal division (spark-expr/src/math_funcs/div.rs:71-165, non-integral): with L = l·10^l_exp, R = r·10^r_exp
+//   div = trunc(L / R);  res = (div + sign(div)·5) / 10 (truncating)  →  round-half-up at the result scale;
+// a quotient that does not fit i128 becomes i128::MAX (quotient_to_i128, div.rs:57-68); R = 0 yields 0 here (the caller
+// raises DIVIDE_BY_ZERO in ANSI mode; in the other modes Spark has already replaced zero divisors by NULL).
+// lmul = 10^l_exp, rmul = 10^r_exp; requires |r|·rmul < 2^127 (checked at plan time through the precisions).
+CDEV i128 dec_div(i128 l, i128 r, u128 lmul, u128 rmul, bool& div_by_zero) {
+  const u128 R = uabs128(r) * rmul;
+  div_by_zero = R == 0;
+  if (div_by_zero) return 0;
+  const bool neg = (l < 0) != (r < 0);
+  i256 L = u128_mul_u128(uabs128(l), lmul), q;
+  u128 rem;
+  u256_divmod_u128(L, R, q, rem);
+  i256 five;
+  five.w[0] = 5; five.w[1] = five.w[2] = five.w[3] = 0;
+  i256 q10;
+  u256_divmod_u128(i256_add(q, five), 10, q10, rem);
+  const i128 kMax = (i128)(((u128)1 << 127) - 1);
+  if (q10.w[3] != 0 || q10.w[2] != 0 || (q10.w[1] >> 63) != 0) return kMax;   // to_i128() failed → i128::MAX
+  const i128 mag = (i128)(((u128)q10.w[1] << 64) | q10.w[0]);
+  return neg ? -mag : mag;
+}
+
 // result > bound || result < -bound with bound = 10^p - 1 < 2^127 (check_overflow_and_convert,
 // wide_decimal_binary_expr.rs:335-350).  On success the value fits in i128.
 CDEV bool i256_fits_bound(const i256& v, u128 bound, i128& out) {

@@ -64,6 +64,7 @@ struct Expr {
   EvalMode eval_mode = EvalMode::Legacy;
   bool fail_on_error = false;     // CheckOverflow / UnaryMinus
   bool negated = false;           // In
+  int n_when = 0;                 // CaseWhen: children = when[0..n) ++ then[0..n) ++ [else]
   int bound_index = -1;           // Bound
   // Literal payload
   bool lit_null = false;

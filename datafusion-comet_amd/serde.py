@@ -120,7 +120,7 @@ class Expr:
     # field numbers of Expr.expr_struct (expr.proto:30-107)
     TAGS = dict(literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
                 lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, eq_null_safe=32,
-                neq_null_safe=33, remainder=37, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
+                neq_null_safe=33, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
                 unbound=51)
 
     def encode(self) -> bytes:
@@ -157,6 +157,11 @@ class Expr:
                 body += _f_varint(3, 1)
         elif k == "if_":
             body = b"".join(_f_msg(i + 1, c.encode()) for i, c in enumerate(self.children))
+        elif k == "case_when":   # children = when* then* [else]; index = number of WHEN branches
+            n = self.index
+            body = b"".join(_f_msg(2, c.encode()) for c in self.children[:n]) + b"".join(_f_msg(3, c.encode()) for c in self.children[n:2 * n])
+            if len(self.children) == 2 * n + 1:
+                body += _f_msg(4, self.children[2 * n].encode())
         else:  # BinaryExpr / UnaryExpr
             body = b"".join(_f_msg(i + 1, c.encode()) for i, c in enumerate(self.children))
         return _f_msg(tag, body)
@@ -243,6 +248,12 @@ def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY) -> Expr:
 
 def if_(c: Expr, t: Expr, f: Expr) -> Expr:
     return Expr("if_", [c, t, f])
+
+
+def case_when(branches: Sequence, else_: Optional[Expr] = None) -> Expr:
+    """CASE WHEN c1 THEN v1 ... [ELSE e] END; branches = [(when, then), ...] (expr.proto:473-483)."""
+    whens, thens = [b[0] for b in branches], [b[1] for b in branches]
+    return Expr("case_when", whens + thens + ([else_] if else_ is not None else []), index=len(branches))
 
 
 def in_(value: Expr, items: Sequence[Expr], negated: bool = False) -> Expr:

@@ -214,6 +214,21 @@ class Evaluator:
             vals = np.where(sel, t.values, f.values) if t.dtype.type_id != S.DECIMAL else np.where(sel, t.values, f.values)
             ok = np.where(sel, t.ok(), f.ok())
             return Col(t.dtype, vals, None if ok.all() else ok)
+        if k == "case_when":
+            # planner.rs:677-704 → DataFusion CaseExpr (no base expression): first WHEN that is TRUE wins, else ELSE / NULL
+            nw = e.index
+            thens = [self.eval(x, cols, n) for x in e.children[nw:2 * nw]]
+            if len(e.children) == 2 * nw + 1:
+                r = self.eval(e.children[2 * nw], cols, n)
+                vals, ok = r.values.copy(), r.ok().copy()
+            else:
+                vals, ok = thens[0].values.copy(), np.zeros(n, bool)
+            for i in range(nw - 1, -1, -1):
+                c = self.eval(e.children[i], cols, n)
+                sel = c.ok() & c.values.astype(bool)
+                vals = np.where(sel, thens[i].values, vals)
+                ok = np.where(sel, thens[i].ok(), ok)
+            return Col(thens[0].dtype, vals, None if ok.all() else ok)
         if k == "in_":
             v = self.eval(e.children[0], cols, n)
             hit = np.zeros(n, bool)
@@ -266,7 +281,25 @@ class Evaluator:
             p1, s1, p2, s2 = a.dtype.precision, a.dtype.scale, b.dtype.precision, b.dtype.scale
             mul = e.kind == "multiply"
             addsub = e.kind in ("add", "subtract")
-            assert mul or addsub, "decimal divide not in oracle yet"
+            if e.kind == "divide":
+                # decimal_div: spark-expr/src/math_funcs/div.rs:71-165 (non-integral), exact Python integers
+                s3 = e.dtype.scale
+                l_exp, r_exp = max(0, s2 + s3 + 1 - s1), max(0, s1 - (s2 + s3 + 1))
+                live = np.ones(n, bool) if valid is None else valid
+                res = []
+                for i in range(n):
+                    L, R = dec_to_int(a.values, i) * 10 ** l_exp, dec_to_int(b.values, i) * 10 ** r_exp
+                    if R == 0:
+                        if e.eval_mode == S.ANSI and live[i]:
+                            raise OracleError("DIVIDE_BY_ZERO")
+                        res.append(0)
+                        continue
+                    div = abs(L) // abs(R) * (-1 if (L < 0) != (R < 0) else 1)      # BigInt division truncates toward zero
+                    q = (div - 5 if div < 0 else div + 5)
+                    q = abs(q) // 10 * (-1 if q < 0 else 1)
+                    res.append(q if -2**127 <= q < 2**127 else 2**127 - 1)           # to_i128().unwrap_or(i128::MAX)
+                return Col(e.dtype, ints_to_dec(res), valid)
+            assert mul or addsub, f"decimal {e.kind} not in oracle"
             wide = (addsub and max(s1, s2) + max(p1 - s1, p2 - s2) >= 38) or (mul and p1 + p2 >= 38)  # planner.rs:1000-1008
             av, bv = np.ascontiguousarray(a.values), np.ascontiguousarray(b.values)
             out = np.zeros(n, DEC128)

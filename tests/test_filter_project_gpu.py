@@ -113,3 +113,72 @@ def test_decimal_projection_narrow_and_wide(built):
     assert got.column(0).combine_chunks().equals(want.column(0).combine_chunks())
     assert got.column(1).combine_chunks().equals(want.column(1).combine_chunks())
     assert got.schema.field(1).type == pa.decimal128(38, 6)
+
+
+def test_case_when_projection_and_conditional_sum(built):
+    # CASE WHEN (expr.proto:473-483, planner.rs:677-704): first TRUE branch wins, NULL conditions fall through, no ELSE → NULL;
+    # and the TPC-H Q14 shape sum(CASE WHEN c THEN x ELSE 0 END) as a grouped aggregate input
+    from datafusion_comet_amd import tpch
+    n = 60_000
+    rng = np.random.default_rng(21)
+    k = pa.array(rng.integers(0, 10, n), pa.int32(), mask=rng.random(n) < 0.1)
+    v = tpch._dec128_array(rng.integers(-10**6, 10**6, n), 12, 2)
+    f = pa.array(rng.standard_normal(n), pa.float64(), mask=rng.random(n) < 0.1)
+    table = pa.table({"k": k, "v": v, "f": f})
+    D = S.decimal(12, 2)
+    ck, cv, cf = S.col(0, S.T_INT32), S.col(1, D), S.col(2, S.T_DOUBLE)
+    i32 = lambda x: S.lit(x, S.T_INT32)
+    e1 = S.case_when([(S.lt(ck, i32(3)), cv), (S.lt(ck, i32(6)), S.lit(12345, D))], S.lit(0, D))        # with ELSE
+    e2 = S.case_when([(S.gt(cf, S.lit(0.5, S.T_DOUBLE)), cf), (S.is_null(ck), S.lit(-1.0, S.T_DOUBLE))])   # no ELSE → NULL
+    e3 = S.case_when([(S.eq(ck, i32(1)), i32(10)), (S.eq(ck, i32(1)), i32(20)), (S.gt_eq(ck, i32(8)), ck)], S.lit(None, S.T_INT32))
+    plan = S.project(S.scan([S.T_INT32, D, S.T_DOUBLE]), [e1, e2, e3])
+    got = pa.Table.from_batches(_run(plan, table, 3))
+    want = _oracle(plan, table)
+    for i in range(3):
+        assert got.column(i).combine_chunks().equals(want.column(i).combine_chunks()), f"column {i}"
+    assert got.column(1).null_count > 0 and got.column(2).null_count > 0
+    agg = S.hash_agg(S.project(S.scan([S.T_INT32, D, S.T_DOUBLE]), [ck, e1]), [S.col(0, S.T_INT32)], [S.sum_(S.col(1, D), S.decimal(22, 2))])
+    rows = lambda t: sorted(zip(*[t.column(i).to_pylist() for i in range(t.num_columns)]), key=lambda r: (r[0] is None, r[0] or 0))
+    assert rows(pa.Table.from_batches(_run(agg, table, 3, batch_size=0))) == rows(_oracle(agg, table))
+
+
+def test_decimal_division(built):
+    # decimal_div (spark-expr/src/math_funcs/div.rs:71-165): result scale via (s2 + s3 + 1) widening, HALF_UP at the last
+    # digit, zero divisor → NULL through the If the Scala serde wraps around it (nullIfWhenPrimitive), ANSI → DIVIDE_BY_ZERO
+    from datafusion_comet_amd import tpch
+    n = 30_000
+    rng = np.random.default_rng(33)
+    D = S.decimal(12, 2)
+    lv = rng.integers(-10**11, 10**11, n)
+    rv = rng.integers(-10**6, 10**6, n)
+    rv[::17] = 0
+    lv[:4] = [15, -15, 10**12 - 1, -(10**12 - 1)]
+    rv[:4] = [200, 200, 1, 3]
+    table = pa.table({"l": tpch._dec128_array(lv, 12, 2), "r": tpch._dec128_array(rv, 12, 2),
+                      "w": pa.array([__import__("decimal").Decimal(int(x)).scaleb(-6) for x in rng.integers(-10**17, 10**17, n)], pa.decimal128(38, 6))})
+    W = S.decimal(38, 6)
+    cl, cr, cw = S.col(0, D), S.col(1, D), S.col(2, W)
+    nz = lambda c, t: S.if_(S.eq(c, S.lit(0, t)), S.lit(None, t), c)            # what Spark's serde emits for a non-ANSI divisor
+    R1 = S.decimal(27, 15)      # decimal(12,2) / decimal(12,2)
+    R2 = S.decimal(38, 6)       # decimal(38,6) / decimal(12,2), precision-capped by Spark
+    e1 = S.check_overflow(S.math("divide", cl, nz(cr, D), R1), R1)
+    e2 = S.check_overflow(S.math("divide", cw, nz(cr, D), R2), R2)
+    plan = S.project(S.scan([D, D, W]), [e1, e2])
+    got = pa.Table.from_batches(_run(plan, table, 2))
+    want = _oracle(plan, table)
+    for i in range(2):
+        assert got.column(i).combine_chunks().equals(want.column(i).combine_chunks()), f"column {i}"
+    from decimal import Decimal
+    assert got.column(0)[0].as_py() == Decimal("0.075000000000000") and got.column(0)[1].as_py() == Decimal("-0.075000000000000")
+    assert got.column(0).null_count >= n // 17
+    # exact-integer cross oracle for the HALF_UP rule
+    for i in (2, 3, 100, 101):
+        l, r = int(lv[i]), int(rv[i])
+        if r:
+            num, den = abs(l) * 10**15, abs(r)
+            q = (2 * num + den) // (2 * den) * (-1 if (l < 0) != (r < 0) else 1)
+            assert int(got.column(0)[i].as_py().scaleb(15)) == q
+    # ANSI: a zero divisor raises
+    ansi = S.project(S.scan([D, D, W]), [S.math("divide", cl, cr, R1, S.ANSI)])
+    with pytest.raises(native.CometQueryExecutionException, match="DIVIDE_BY_ZERO"):
+        _run(ansi, table, 1)
