@@ -1262,8 +1262,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         if (op.agg_mode == AggMode::Partial) {
           for (auto& c : a.children) in.children.push_back(substitute(c, cols, memo));
           if (a.filter) in.filter = substitute(a.filter, cols, memo);
-        } else if (op.agg_mode == AggMode::Final) {
-          // Final: the aggregate's inputs are the Partial state columns that follow the group columns, in order
+        } else if (op.agg_mode == AggMode::Final || op.agg_mode == AggMode::PartialMerge) {
+          // Final / PartialMerge: the aggregate's inputs are the Partial state columns that follow the group columns, in order
           // (AggregateExec Final mode; the serialized children are unbound, operators.scala:1786-1792)
           int arity = 1;
           if (a.kind == AggKind::Avg) arity = 2;
@@ -1357,9 +1357,9 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
 
   // ---------------- Aggregate sinks ----------------
-  if (agg->agg_mode == AggMode::PartialMerge)
-    throw CometError("HashAggregate mode PartialMerge is not supported by the fused GPU pipeline yet");
-  const bool final_mode = agg->agg_mode == AggMode::Final;
+  // Final and PartialMerge both MERGE Partial states (merge_batch); Final then evaluates, PartialMerge re-emits the state
+  const bool final_mode = agg->agg_mode == AggMode::Final || agg->agg_mode == AggMode::PartialMerge;
+  const bool emit_state = agg->agg_mode == AggMode::PartialMerge;
   const bool grouped = !group_exprs.empty();
   d.sink = grouped ? SinkKind::AggGrouped : SinkKind::AggNoGroup;
   AggLowering al(g, grouped);
@@ -1489,6 +1489,21 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
               fin += "      comet::sum_overflow_decide(acc + " + W + ", " + kw(amax) + ", " + kw(sflags) + ", acc[" + std::to_string(cnt.word) + "], " +
                      lit_u128(bound) + ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
               g.uses_err = true;
+              if (emit_state) {
+                // merged state (sum_decimal.rs:281-295 after :309-368): sum is NULL once any side overflowed, is_empty only
+                // if every merged state was empty
+                fin += "      bool sovf = acc[" + std::to_string(any_ovf.word) + "] != 0 || ovf || !comet::dec_fits(total, " + lit_u128(bound) + ");\n";
+                fin += "      bool empty = acc[" + std::to_string(cnt.word) + "] == 0 && acc[" + std::to_string(any_ovf.word) + "] == 0;\n";
+                fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = sovf ? (i128)0 : total;\n";
+                fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = sovf ? 0 : 1;\n";
+                fin += "      ((u8*)" + out_val(out_j + 1) + ")" + ROW + " = empty ? 1 : 0;\n    }\n";
+                OutCol s0; s0.type = st; s0.nullable = true;
+                OutCol s1; s1.type = DType::of(TypeId::Bool); s1.nullable = false;
+                d.out_cols.push_back(s0);
+                d.out_cols.push_back(s1);
+                out_j += 2;
+                ex << "  agg(partial-merge): sum_decimal -> (" << st.str() << ", is_empty)\n";
+              } else {
               // evaluate (sum_decimal.rs:264-279): NULL if empty, overflowed, or out of precision
               fin += "      bool isnull = acc[" + std::to_string(cnt.word) + "] == 0 || acc[" + std::to_string(any_ovf.word) + "] != 0 || ovf || !comet::dec_fits(total, " + lit_u128(bound) + ");\n";
               fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = isnull ? (i128)0 : total;\n";
@@ -1497,6 +1512,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
               d.out_cols.push_back(oc);
               out_j++;
               ex << "  agg(final): sum_decimal -> " << st.str() << "\n";
+              }
             } else {
               // AvgDecimal merge (avg_decimal.rs:542-595) + evaluate (:597-636, avg() :670-689): state = (sum nullable, count)
               if (!s2.t.is_integer()) throw CometError("Final AvgDecimal expects (sum, count) state columns");
@@ -1518,8 +1534,26 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
                      lit_u128(bound) + ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
               g.uses_err = true;
               fin += "      i64 count = (i64)acc[" + std::to_string(cnt.word) + "];\n";
+              // grouped (AvgDecimalGroupsAccumulator::merge_batch, avg_decimal.rs:542-595): a NULL partial sum / count or an
+              // overflowing merge step clears is_not_null for good.  Ungrouped (AvgDecimalAccumulator::merge_batch, :331-356):
+              // arrow's sum() skips NULL partial sums and only the batch total is checked against the precision.
+              if (grouped) fin += "      bool sum_ok = acc[" + std::to_string(bad.word) + "] == 0 && !ovf;\n";
+              else fin += "      bool sum_ok = acc[" + std::to_string(nsum.word) + "] != 0 && comet::dec_fits(total, " + lit_u128(bound) + ");\n";
+              if (emit_state) {
+                // state: grouped sums and counts share the is_not_null mask (:638-653); ungrouped (sum Option, count) (:301-306)
+                fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = sum_ok ? total : (i128)0;\n";
+                fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = sum_ok ? 1 : 0;\n";
+                fin += std::string("      ((i64*)") + out_val(out_j + 1) + ")" + ROW + " = " + (grouped ? "sum_ok ? count : 0" : "count") + ";\n";
+                fin += std::string("      ((u8*)") + out_ok(out_j + 1) + ")" + ROW + " = " + (grouped ? "sum_ok ? 1 : 0" : "1") + ";\n    }\n";
+                OutCol s0; s0.type = st; s0.nullable = true;
+                OutCol s1; s1.type = DType::of(TypeId::Int64); s1.nullable = true;
+                d.out_cols.push_back(s0);
+                d.out_cols.push_back(s1);
+                out_j += 2;
+                ex << "  agg(partial-merge): avg_decimal -> (" << st.str() << ", count)\n";
+              } else {
               fin += "      i128 avgv = 0;\n";
-              fin += "      bool has = acc[" + std::to_string(bad.word) + "] == 0 && !ovf && count != 0 && comet::dec_avg(total, count, " +
+              fin += "      bool has = sum_ok && count != 0 && comet::dec_avg(total, count, " +
                      lit_i128((i128)pow10_u128(up)) + ", " + lit_u128(tbound) + ", avgv);\n";
               fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = has ? avgv : (i128)0;\n";
               fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = has ? 1 : 0;\n    }\n";
@@ -1527,6 +1561,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
               d.out_cols.push_back(oc);
               out_j++;
               ex << "  agg(final): avg_decimal -> " << a.dtype.str() << "\n";
+              }
             }
           } else if (!is_avg && a.dtype.is_integer()) {
             // SumInteger merge (sum_int.rs:494-530): wrapping sum of the non-null partial sums, NULL if none
@@ -1548,6 +1583,22 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             PrimSlot nsum = al.get(Prim::Cnt, vk, "", sv.ok, "");
             PrimSlot sum = al.get(Prim::SumF64, vk, "", sv.ok, sv.v);
             const std::string S = std::to_string(sum.word);
+            if (is_avg && emit_state) {
+              // AvgAccumulator / AvgGroupsAccumulator state after merge (avg.rs:139-176): (sum, count)
+              Val s2 = g.named(g.gen(in.children.at(1)));
+              PrimSlot cnt = al.get(Prim::SumI64, vk + "#cnt", "", s2.ok, s2.v, (u128)1 << 63);
+              fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = __longlong_as_double((i64)acc[" + S + "]);\n";
+              fin += std::string("    ((u8*)") + out_ok(out_j) + ")" + ROW + " = " + (grouped ? "1" : "acc[" + std::to_string(nsum.word) + "] ? 1 : 0") + ";\n";
+              fin += "    ((i64*)" + out_val(out_j + 1) + ")" + ROW + " = (i64)acc[" + std::to_string(cnt.word) + "];\n";
+              fin += "    ((u8*)" + out_ok(out_j + 1) + ")" + ROW + " = 1;\n";
+              OutCol s0; s0.type = DType::of(TypeId::Double); s0.nullable = true;
+              OutCol s1; s1.type = DType::of(TypeId::Int64); s1.nullable = true;
+              d.out_cols.push_back(s0);
+              d.out_cols.push_back(s1);
+              out_j += 2;
+              ex << "  agg(partial-merge): avg_f64 -> (Float64, count)\n";
+              break;
+            }
             if (is_avg) {
               Val s2 = g.named(g.gen(in.children.at(1)));
               PrimSlot cnt = al.get(Prim::SumI64, vk + "#cnt", "", s2.ok, s2.v, (u128)1 << 63);

@@ -355,6 +355,10 @@ int o_avgdec_avg(i128 sum, int64_t count, int target_precision, int target_scale
   *out = nv;
   return 1;
 }
+/* ctypes-friendly entry: __int128 by pointer */
+int o_avgdec_avg_p(const i128* sum, int64_t count, int target_precision, int target_scale, int sum_scale, i128* out) {
+  return o_avgdec_avg(*sum, count, target_precision, target_scale, sum_scale, out);
+}
 int o_avgdec_evaluate(const AvgDecState* s, int target_precision, int target_scale, int sum_scale, i128* out) {
   if (!s->is_not_null || s->count == 0) return 0;               /* :613-616 */
   return o_avgdec_avg(s->sum, s->count, target_precision, target_scale, sum_scale, out);

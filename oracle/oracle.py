@@ -586,7 +586,7 @@ def _hash_agg(S, ev: Evaluator, op, child: List[Col], n: int) -> List[Col]:
         if op.mode == S.PARTIAL:
             out += _agg_partial(S, ev, a, child, n, gid, ng, grouped)
         else:
-            cols, used = _agg_final(S, a, child, state_col, n, gid, ng, grouped)
+            cols, used = _agg_final(S, a, child, state_col, n, gid, ng, grouped, emit_state=op.mode == S.PARTIAL_MERGE)
             state_col += used
             out += cols
     return out
@@ -700,7 +700,8 @@ def _agg_partial(S, ev, a, child, n, gid, ng, grouped) -> List[Col]:
     raise NotImplementedError(f"oracle aggregate {a.kind}")
 
 
-def _agg_final(S, a, child, state_col, n, gid, ng, grouped):
+def _agg_final(S, a, child, state_col, n, gid, ng, grouped, emit_state=False):
+    """merge_batch of each accumulator over Partial state rows, then evaluate (Final) or state (PartialMerge)."""
     if a.kind == "count":
         c = child[state_col]
         out = np.zeros(ng, np.int64)
@@ -716,6 +717,11 @@ def _agg_final(S, a, child, state_col, n, gid, ng, grouped):
                                   a.dtype.precision, int(a.eval_mode == S.ANSI))
             if rc:
                 raise OracleError("ARITHMETIC_OVERFLOW sum")
+        if emit_state:   # state(): (sum Option, is_empty) — sum_decimal.rs:281-295
+            vals = [_limbs_to_int(st_.sum) if st_.has_sum else 0 for st_ in states]
+            okb = np.array([bool(st_.has_sum) for st_ in states], bool)
+            emp = np.array([bool(st_.is_empty) for st_ in states], bool)
+            return [Col(a.dtype, ints_to_dec(vals), None if okb.all() else okb), Col(S.T_BOOL, emp, None)], 2
         vals, ok = [], []
         for s in states:
             out = (ctypes.c_uint64 * 2)()
@@ -724,6 +730,22 @@ def _agg_final(S, a, child, state_col, n, gid, ng, grouped):
             ok.append(bool(has))
         okb = np.array(ok, bool)
         return [Col(a.dtype, ints_to_dec(vals), None if okb.all() else okb)], 2
+    if a.kind == "avg" and a.dtype.type_id == S.DECIMAL and not grouped:
+        # AvgDecimalAccumulator::merge_batch (avg_decimal.rs:331-356): arrow sum() skips NULLs, one precision check on the batch total
+        sc, cc = child[state_col], child[state_col + 1]
+        count = sum(int(cc.values[i]) for i in range(n) if cc.ok()[i])
+        parts = [dec_to_int(sc.values, i) for i in range(n) if sc.ok()[i]]
+        total = None
+        if parts:
+            t = sum(parts)
+            t = (t + 2**127) % 2**128 - 2**127                       # wrapping i128 add
+            total = t if abs(t) <= 10 ** a.sum_dtype.precision - 1 else None
+        if emit_state:   # state(): (sum Option, count) — :301-306
+            return [Col(a.sum_dtype, ints_to_dec([total or 0]), None if total is not None else np.array([False])),
+                    Col(S.T_INT64, np.array([count], np.int64), None)], 2
+        out = (ctypes.c_uint64 * 2)()
+        has = total is not None and count != 0 and C.o_avgdec_avg_p(ctypes.byref(_i128(total)), ctypes.c_int64(count), a.dtype.precision, a.dtype.scale, a.sum_dtype.scale, out)
+        return [Col(a.dtype, ints_to_dec([_limbs_to_int(out) if has else 0]), None if has else np.array([False]))], 2
     if a.kind == "avg" and a.dtype.type_id == S.DECIMAL:
         sc, cc = child[state_col], child[state_col + 1]
         states = (AvgDecState * ng)()
@@ -734,6 +756,12 @@ def _agg_final(S, a, child, state_col, n, gid, ng, grouped):
                                   int(cc.ok()[i]), a.sum_dtype.precision, int(a.eval_mode == S.ANSI))
             if rc:
                 raise OracleError("ARITHMETIC_OVERFLOW avg")
+        if emit_state:   # AvgDecimalGroupsAccumulator::state (avg_decimal.rs:638-653): sums and counts share the is_not_null mask
+            okb = np.array([bool(st_.is_not_null) for st_ in states], bool)
+            vals = [_limbs_to_int(st_.sum) if st_.is_not_null else 0 for st_ in states]
+            cnts = np.array([st_.count if st_.is_not_null else 0 for st_ in states], np.int64)
+            v = None if okb.all() else okb
+            return [Col(a.sum_dtype, ints_to_dec(vals), v), Col(S.T_INT64, cnts, v)], 2
         vals, ok = [], []
         for s in states:
             out = (ctypes.c_uint64 * 2)()
@@ -759,6 +787,13 @@ def _agg_final(S, a, child, state_col, n, gid, ng, grouped):
             if sc.ok()[i]:
                 sums[gid[i]] += sc.values[i]
             cnts[gid[i]] += int(cc.values[i])
+        if emit_state:   # (sum, count) — avg.rs:139-176; the ungrouped sum is Some once a non-NULL partial sum arrived
+            anysum = np.zeros(ng, bool)
+            for i in range(n):
+                if sc.ok()[i]:
+                    anysum[gid[i]] = True
+            v = None if (grouped or anysum.all()) else anysum
+            return [Col(S.T_DOUBLE, sums, v), Col(S.T_INT64, cnts, None)], 2
         hb = cnts > 0
         with np.errstate(all="ignore"):
             res = np.where(hb, sums / np.where(hb, cnts, 1), 0.0)

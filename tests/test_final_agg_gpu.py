@@ -1,6 +1,7 @@
 """GPU parity for Final-mode aggregation (merge_batch + evaluate of each accumulator): per-shard Partial plans on
 the GPU, their state rows concatenated (what the exchange between Spark stages does), then the Final plan on
 the GPU — compared with the oracle's Final over the same states AND with the oracle's single-pass answer."""
+import numpy as np
 import pyarrow as pa
 import pytest
 
@@ -87,3 +88,54 @@ def test_final_with_overflowed_partial_is_null(built):
     # sum beyond the precision → NULL
     states3 = pa.table({"s": pa.array([Decimal("99999999.99"), Decimal("0.01")], D), "e": pa.array([False, False])})
     assert _run(fplan, states3, 1).column(0).to_pylist() == [None]
+
+
+def _merge_plan(partial_plan, state_schema, mode):
+    f = S.final_of(partial_plan, state_schema)
+    return S.hash_agg(f.children[0], f.exprs, f.aggs, mode)
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+def test_partial_merge_then_final(built, grouped):
+    """Partial → PartialMerge (merge_batch + state) → Final equals Partial → Final and the single-pass answer; the PartialMerge
+    output itself is compared with the oracle's restatement of each accumulator's state() after merge_batch."""
+    from oracle import oracle as O
+    from decimal import Decimal
+    rng = np.random.default_rng(44)
+    n = 120_000
+    D = S.decimal(12, 2)
+    table = pa.table({"k": pa.array(rng.integers(0, 7, n), pa.int32()),
+                      "v": tpch._dec128_array(rng.integers(-10**9, 10**9, n), 12, 2),
+                      "f": pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.2),
+                      "i": pa.array(rng.integers(-10**6, 10**6, n), pa.int64(), mask=rng.random(n) < 0.3)})
+    fields = [S.T_INT32, D, S.T_DOUBLE, S.T_INT64]
+    ck, cv, cf, ci = (S.col(i, t) for i, t in enumerate(fields))
+    aggs = [S.sum_(cv, S.decimal(22, 2)), S.avg(cv, S.decimal(16, 6), S.decimal(22, 2)), S.avg(cf, S.T_DOUBLE, S.T_DOUBLE), S.sum_(ci, S.T_INT64),
+            S.count(ci), S.min_(cv, D), S.max_(cf, S.T_DOUBLE)]
+    partial = S.hash_agg(S.scan(fields), [ck] if grouped else [], aggs)
+    ncols_state = (1 if grouped else 0) + 2 + 2 + 2 + 1 + 1 + 1 + 1
+    shards = _shards(table, 6)
+    states = [_run(partial, sh, ncols_state, batch_size=0) for sh in shards]
+    pm = _merge_plan(partial, states[0].schema, S.PARTIAL_MERGE)
+    merged = [_run(pm, pa.concat_tables(states[:3]), ncols_state, batch_size=0), _run(pm, pa.concat_tables(states[3:]), ncols_state, batch_size=0)]
+    rows = lambda t: sorted(zip(*[t.column(i).to_pylist() for i in range(t.num_columns)]), key=lambda r: tuple((x is None, str(x)) for x in r[:1]))
+    want_merged = O.run_plan_to_arrow(S, pm, pa.concat_tables(states[:3]))
+    if grouped:
+        got_m, want_m = rows(merged[0]), rows(want_merged)
+        assert len(got_m) == len(want_m) == 7
+        for g, w in zip(got_m, want_m):
+            assert g[:3] == w[:3] and g[3:5] == w[3:5] and g[6:] == w[6:]          # decimals, ints, counts, min/max: exact
+            assert g[5] == pytest.approx(w[5], rel=1e-12)                          # float sums: order-dependent
+    assert [f.type for f in merged[0].schema] == [f.type for f in states[0].schema]
+    fplan = _merge_plan(partial, states[0].schema, S.FINAL)
+    nfinal = (1 if grouped else 0) + 7
+    via_merge = _run(fplan, pa.concat_tables(merged), nfinal, batch_size=0)
+    direct = _run(fplan, pa.concat_tables(states), nfinal, batch_size=0)
+    one = O.run_plan_to_arrow(S, fplan, O.run_plan_to_arrow(S, partial, table))
+    fa = 3 if grouped else 2        # position of avg(f) in the final output
+    for a, b in zip(rows(via_merge), rows(direct)):
+        assert a[:fa] == b[:fa] and a[fa + 1:] == b[fa + 1:]
+        assert a[fa] == pytest.approx(b[fa], rel=1e-12)
+    for a, b in zip(rows(via_merge), rows(one)):
+        assert a[:fa] == b[:fa] and a[fa + 1:-1] == b[fa + 1:-1]
+        assert a[fa] == pytest.approx(b[fa], rel=1e-9) and a[-1] == pytest.approx(b[-1])
