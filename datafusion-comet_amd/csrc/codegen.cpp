@@ -1904,16 +1904,22 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
                            const std::vector<bool>& rvalid) {
   if (j.kind != OpKind::HashJoin) throw CometError("internal: generate_join on a non-join");
   if (j.left_keys.size() != j.right_keys.size() || j.left_keys.empty()) throw CometError("HashJoin needs matching, non-empty key lists");
-  int mode;
+  int mode = 0;
+  bool keep_left = false, keep_right = false;   // outer joins: which side's unmatched rows survive
   switch (j.join_type) {
-    case JoinType::Inner: mode = 0; break;
+    case JoinType::Inner: break;
     case JoinType::LeftSemi: mode = 1; break;
     case JoinType::LeftAnti: mode = 2; break;
-    default: throw CometError("HashJoin type " + std::to_string((int)j.join_type) + " (outer joins) is not supported by the MI355X native engine yet");
+    case JoinType::LeftOuter: keep_left = true; break;
+    case JoinType::RightOuter: keep_right = true; break;
+    case JoinType::FullOuter: keep_left = keep_right = true; break;
+    default: throw CometError("HashJoin type " + std::to_string((int)j.join_type) + " is not supported by the MI355X native engine yet");
   }
   if (j.null_aware_anti) throw CometError("null-aware anti join is not supported by the MI355X native engine yet");
   const bool build_left = j.build_side == BuildSide::Left;
   if (mode != 0 && build_left) throw CometError("LeftSemi/LeftAnti with BuildLeft is not supported by the MI355X native engine yet");
+  const bool outer_probe = build_left ? keep_right : keep_left;    // the probe side is the preserved one
+  const bool outer_build = build_left ? keep_left : keep_right;
   const std::vector<DType>& bt = build_left ? lt : rt;
   const std::vector<DType>& pt = build_left ? rt : lt;
   const std::vector<bool>& bv = build_left ? lvalid : rvalid;
@@ -1930,6 +1936,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   std::ostringstream src, ex;
   src << "// generated by datafusion-comet_amd codegen — hash join\n#include \"comet_device.hpp\"\nusing namespace comet;\n";
   src << "struct P {\n  static constexpr int R = 1;\n  static constexpr int MODE = " << mode << ";\n";
+  src << "  static constexpr bool OUTER_PROBE = " << (outer_probe ? "true" : "false") << ", OUTER_BUILD = " << (outer_build ? "true" : "false") << ";\n";
 
   // key words of one side
   auto key_fn = [&](const char* name, const char* rowvar, const std::vector<DType>& types, const std::vector<bool>& valid, int base,
@@ -2024,33 +2031,54 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
         << g.decls << g.body() << "    return " << e << ";\n  }\n";
   }
   {
-    // emit(i, j, pos): output = left columns then right columns (Inner); left columns only (Semi/Anti)
-    Gen g(ct, cv);
-    g.locate = locate_combined;
+    // emit(i, j, pos): output = left columns then right columns (Inner / outer); left columns only (Semi/Anti).
+    // Outer joins add emit_probe_only(j, pos) / emit_build_only(i, pos): the other side's columns are NULL.
     const int nout = mode == 0 ? nl + nr : nl;
     if (nout * 2 + kOutFirstCol > 44) throw CometError("too many output columns for one GPU hash join");
     for (int c = 0; c < nout; c++) {
       if (ct[c].id == TypeId::String || ct[c].id == TypeId::Bytes) throw CometError("Utf8 payload columns are not supported in a GPU hash join yet");
-      Val v = g.column(c);
+      const bool is_left = c < nl;
       OutCol oc;
       oc.type = ct[c];
-      oc.nullable = !v.ok.empty();
+      oc.nullable = cv[c] || (is_left ? keep_right : keep_left);   // the non-preserved side is NULL-extended
       d.out_cols.push_back(oc);
-      const char* st = store_ctype(v.t);
-      std::string val = v.v;
-      if (v.t.id == TypeId::Decimal) val = v.rep == Rep::I128 ? v.v : "(i128)" + v.v;
-      else if (v.t.id == TypeId::Bool) val = "(u8)(" + v.v + " ? 1 : 0)";
-      else val = std::string("(") + st + ")" + v.v;
-      std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * c) + "]", ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * c + 1) + "]";
-      if (!v.ok.empty()) {
-        g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = " + v.ok + " ? " + val + " : (" + st + ")0;");
-        g.stmt("((u8*)" + ob + ")[pos] = " + v.ok + " ? 1 : 0;");
-      } else {
-        g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = " + val + ";");
-      }
     }
-    src << "  static __device__ __forceinline__ void emit(const CometKParams& prm, i64 i, i64 j, i64 pos) {\n    bool k[R] = {true};\n"
-        << g.decls << g.body() << "  }\n";
+    // variant 0 = both rows, 1 = probe row only, 2 = build row only
+    for (int variant = 0; variant < 3; variant++) {
+      if (variant == 1 && !outer_probe) continue;
+      if (variant == 2 && !outer_build) continue;
+      Gen g(ct, cv);
+      g.locate = locate_combined;
+      for (int c = 0; c < nout; c++) {
+        const bool in_build = ((c < nl) == build_left);
+        const bool absent = (variant == 1 && in_build) || (variant == 2 && !in_build);
+        const char* st = store_ctype(ct[c]);
+        std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * c) + "]", ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * c + 1) + "]";
+        if (absent) {
+          g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = (" + st + ")0;");
+          g.stmt("((u8*)" + ob + ")[pos] = 0;");
+          continue;
+        }
+        Val v = g.column(c);
+        std::string val = v.v;
+        if (v.t.id == TypeId::Decimal) val = v.rep == Rep::I128 ? v.v : "(i128)" + v.v;
+        else if (v.t.id == TypeId::Bool) val = "(u8)(" + v.v + " ? 1 : 0)";
+        else val = std::string("(") + st + ")" + v.v;
+        if (!v.ok.empty()) {
+          g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = " + v.ok + " ? " + val + " : (" + st + ")0;");
+          g.stmt("((u8*)" + ob + ")[pos] = " + v.ok + " ? 1 : 0;");
+        } else {
+          g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = " + val + ";");
+          if (d.out_cols[c].nullable) g.stmt("((u8*)" + ob + ")[pos] = 1;");
+        }
+      }
+      const char* sig = variant == 0 ? "emit(const CometKParams& prm, i64 i, i64 j, i64 pos)"
+                        : variant == 1 ? "emit_probe_only(const CometKParams& prm, i64 j, i64 pos)"
+                                       : "emit_build_only(const CometKParams& prm, i64 i, i64 pos)";
+      src << "  static __device__ __forceinline__ void " << sig << " {\n    bool k[R] = {true};\n" << g.decls << g.body() << "  }\n";
+    }
+    if (!outer_probe) src << "  static __device__ __forceinline__ void emit_probe_only(const CometKParams&, i64, i64) {}\n";
+    if (!outer_build) src << "  static __device__ __forceinline__ void emit_build_only(const CometKParams&, i64, i64) {}\n";
   }
   src << "};\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbuild(const CometKParams prm) { comet::join_build_body<P>(prm); }\n";
@@ -2058,8 +2086,13 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jscan(const CometKParams prm) { comet::tile_scan_body((u64*)prm.out[comet::kJoinTileCounts], prm.iarg[2]); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jemit(const CometKParams prm) { comet::join_emit_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
-  d.kernels = {"k_jbuild", "k_jcount", "k_jscan", "k_jemit", "k_pack"};
-  ex << "  hash join: " << (mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti") << ", build " << (build_left ? "left" : "right") << ", "
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbcount(const CometKParams prm) { comet::join_build_unmatched_count_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbscan(const CometKParams prm) { comet::tile_scan_body((u64*)prm.out[comet::kJoinBuildTiles], prm.iarg[3]); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbemit(const CometKParams prm) { comet::join_build_unmatched_emit_body<P>(prm); }\n";
+  d.kernels = {"k_jbuild", "k_jcount", "k_jscan", "k_jemit", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit"};
+  d.join_outer_build = outer_build;
+  const char* jt_name = keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";
+  ex << "  hash join: " << jt_name << ", build " << (build_left ? "left" : "right") << ", "
      << j.left_keys.size() << " key(s)\n";
   d.in_types = ct;
   d.source = src.str();

@@ -1186,8 +1186,14 @@ CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
 // prm.in[0 .. NB) = build columns, prm.in[NB ..) = probe columns; prm.iarg[0] = table capacity (power of two),
 // iarg[1] = build rows, prm.n = probe rows; out[0] = head, out[1] = next, out[2] = err, out[3] = per-row counts (u32),
 // out[kJoinTileCounts] = tile counts/offsets.
+// Outer joins: P::OUTER_PROBE keeps probe rows without a match (build columns NULL, P::emit_probe_only); P::OUTER_BUILD keeps
+// build rows no probe row matched — the count pass marks matched build rows in out[kJoinMatched] (one byte per build row),
+// join_build_unmatched_count / _emit then append them after the matched output (probe columns NULL, P::emit_build_only);
+// out[kJoinBuildTiles] = their tile counts/offsets, iarg[3] = number of build tiles, iarg[4] = first output row of that tail.
 // ---------------------------------------------------------------------------------------------
 constexpr int kJoinTileCounts = 44;
+constexpr int kJoinMatched = 45;
+constexpr int kJoinBuildTiles = 46;
 
 template <class P>
 CDEV void join_build_body(const CometKParams& prm) {
@@ -1212,11 +1218,13 @@ CDEV u32 join_row_matches(const CometKParams& prm, i64 j) {
     for (i32 i = head[h]; i >= 0; i = next[i]) {
       if (P::match(prm, (i64)i, j)) {
         c++;
+        if (P::OUTER_BUILD) ((u8*)prm.out[kJoinMatched])[i] = 1;   // racing stores of the same value
         if (P::MODE != 0) break;  // semi / anti only need existence
       }
     }
   }
   if (P::MODE == 2) c = c ? 0u : 1u;
+  if (P::OUTER_PROBE && c == 0) c = 1;   // the unmatched probe row itself, NULL-extended
   return c;
 }
 
@@ -1282,14 +1290,70 @@ CDEV void join_emit_body(const CometKParams& prm) {
         if (P::MODE != 0) {
           P::emit(prm, -1, j, pos);
         } else {
-          u64 h = P::phash(prm, j) & ((u64)prm.iarg[0] - 1);
-          for (i32 i = head[h]; i >= 0; i = next[i]) {
-            if (P::match(prm, (i64)i, j)) P::emit(prm, (i64)i, j, pos++);
+          u32 emitted = 0;
+          if (!P::OUTER_PROBE || P::pvalid(prm, j)) {
+            u64 h = P::phash(prm, j) & ((u64)prm.iarg[0] - 1);
+            for (i32 i = head[h]; i >= 0; i = next[i]) {
+              if (P::match(prm, (i64)i, j)) { P::emit(prm, (i64)i, j, pos++); emitted++; }
+            }
           }
+          if (P::OUTER_PROBE && emitted == 0) P::emit_probe_only(prm, j, pos);
         }
       }
       __syncthreads();
       if (threadIdx.x == kBlock - 1) s_run = run + woff + x;
+      __syncthreads();
+    }
+  }
+}
+
+// build rows nobody matched (outer joins that preserve the build side): count per tile, then emit after the matched rows
+template <class P>
+CDEV void join_build_unmatched_count_body(const CometKParams& prm) {
+  const i64 nb = prm.iarg[1];
+  const u8* matched = (const u8*)prm.out[kJoinMatched];
+  u64* tile_counts = (u64*)prm.out[kJoinBuildTiles];
+  const i64 ntiles = (nb + kMaskTileRows - 1) / kMaskTileRows;
+  __shared__ u32 s_cnt;
+  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    u32 local = 0;
+#pragma unroll
+    for (int r = 0; r < kMaskTileRows / kBlock; r++) {
+      i64 i = t * kMaskTileRows + r * kBlock + threadIdx.x;
+      local += (u32)__popcll(__ballot(i < nb && !matched[i])) * (lane_id() == 0 ? 1u : 0u);
+    }
+    if (lane_id() == 0) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[t] = s_cnt;
+    __syncthreads();
+  }
+}
+template <class P>
+CDEV void join_build_unmatched_emit_body(const CometKParams& prm) {
+  const i64 nb = prm.iarg[1];
+  const u8* matched = (const u8*)prm.out[kJoinMatched];
+  const u64* tile_off = (const u64*)prm.out[kJoinBuildTiles];
+  const i64 ntiles = (nb + kMaskTileRows - 1) / kMaskTileRows;
+  __shared__ u32 s_wave[kBlock / kWave];
+  __shared__ u32 s_run;
+  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int r = 0; r < kMaskTileRows / kBlock; r++) {
+      i64 i = t * kMaskTileRows + r * kBlock + threadIdx.x;
+      const bool keep = i < nb && !matched[i];
+      const u64 b = __ballot(keep);
+      const u32 below = (u32)__popcll(b & ((1ull << lane_id()) - 1));
+      if (lane_id() == 0) s_wave[wave_id()] = (u32)__popcll(b);
+      __syncthreads();
+      u32 woff = 0;
+      for (int w = 0; w < wave_id(); w++) woff += s_wave[w];
+      const u32 run = s_run;
+      if (keep) P::emit_build_only(prm, i, prm.iarg[4] + (i64)tile_off[t] + run + woff + below);
+      __syncthreads();
+      if (threadIdx.x == 0) s_run = run + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
       __syncthreads();
     }
   }

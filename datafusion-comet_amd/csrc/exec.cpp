@@ -1443,12 +1443,22 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
   while (cap < 2 * B.rows) cap <<= 1;
   const int64_t n = P.rows;
   const int64_t ntiles = (n + 1023) / 1024;
-  DevBuf head, next, counts, tiles;
+  DevBuf head, next, counts, tiles, matched, btiles;
   head.ensure((size_t)cap * 4);
   next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4);
   counts.ensure((size_t)std::max<int64_t>(n, 1) * 4);
   tiles.ensure((size_t)(ntiles + 1) * 8);
   HIP_CHECK(hipMemsetAsync(head.p, 0xff, (size_t)cap * 4, stream_));
+  const bool outer_build = d.join_outer_build;
+  const int64_t nbtiles = (B.rows + 1023) / 1024;
+  if (outer_build) {
+    matched.ensure((size_t)std::max<int64_t>(B.rows, 1));
+    btiles.ensure((size_t)(nbtiles + 1) * 8);
+    HIP_CHECK(hipMemsetAsync(matched.p, 0, (size_t)std::max<int64_t>(B.rows, 1), stream_));
+    prm.out[45] = matched.p;
+    prm.out[46] = btiles.p;
+    prm.iarg[3] = nbtiles;
+  }
   prm.n = n;
   prm.iarg[0] = cap;
   prm.iarg[1] = B.rows;
@@ -1460,7 +1470,7 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
   prm.out[44] = tiles.p;
   timed_begin();
   if (B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
-  int64_t out_rows = 0;
+  int64_t out_rows = 0, tail_rows = 0;
   const size_t ncol = d.out_cols.size();
   std::vector<std::shared_ptr<DevBuf>> vals(ncol), vbytes(ncol);
   if (n > 0) {
@@ -1471,18 +1481,30 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
     read_small(&total, (char*)tiles.p + (size_t)ntiles * 8, 8);
     out_rows = (int64_t)total;
   }
+  if (outer_build && B.rows > 0) {
+    // build rows without a match follow the probe-driven rows
+    launch(v, "k_jbcount", (int)std::min<int64_t>(nbtiles, 256 * 8), prm);
+    launch(v, "k_jbscan", 1, prm);
+    uint64_t total = 0;
+    read_small(&total, (char*)btiles.p + (size_t)nbtiles * 8, 8);
+    tail_rows = (int64_t)total;
+    prm.iarg[4] = out_rows;
+  }
+  const int64_t all_rows = out_rows + tail_rows;
   for (size_t c = 0; c < ncol; c++) {
     vals[c] = std::make_shared<DevBuf>();
-    vals[c]->ensure((size_t)std::max<int64_t>(out_rows, 1) * out_width(d.out_cols[c]) + 16);
+    vals[c]->ensure((size_t)std::max<int64_t>(all_rows, 1) * out_width(d.out_cols[c]) + 16);
     prm.out[kOutFirstCol + 2 * c] = vals[c]->p;
     vbytes[c] = std::make_shared<DevBuf>();
     if (d.out_cols[c].nullable) {
-      vbytes[c]->ensure((size_t)std::max<int64_t>(out_rows, 1) + 16);
+      vbytes[c]->ensure((size_t)std::max<int64_t>(all_rows, 1) + 16);
       prm.out[kOutFirstCol + 2 * c + 1] = vbytes[c]->p;
     }
   }
   if (out_rows > 0) launch(v, "k_jemit", (int)std::min<int64_t>(ntiles, 256 * 8), prm);
+  if (tail_rows > 0) launch(v, "k_jbemit", (int)std::min<int64_t>(nbtiles, 256 * 8), prm);
   timed_end();
+  out_rows = all_rows;
   DevTable out = outputs_to_table(v, vals, vbytes, out_rows);
   HIP_CHECK(hipStreamSynchronize(stream_));  // head/next/counts go back to the pool when this frame ends
   out.owners.push_back(v.mod);

@@ -526,6 +526,27 @@ def _hash_join(S, ev: "Evaluator", op, left: List[Col], right: List[Col]) -> Lis
         return pairs
     matched = np.zeros(nl, bool)
     matched[li] = True
+    if op.join_type in (S.LEFT_OUTER, S.RIGHT_OUTER, S.FULL_OUTER):
+        # the preserved side's unmatched rows follow, the other side NULL (planner.rs:2448-2460 → DataFusion HashJoinExec)
+        rmatched = np.zeros(nr, bool)
+        rmatched[ri] = True
+        out = pairs
+
+        def null_cols(cols, k):
+            return [Col(c.dtype, np.zeros(k, c.values.dtype) if c.values.dtype != object else np.array([""] * k, dtype=object), np.zeros(k, bool)) for c in cols]
+
+        def concat(a: Col, b: Col) -> Col:
+            va = a.ok() if (a.valid is not None or b.valid is not None) else None
+            return Col(a.dtype, np.concatenate([a.values, b.values]), None if va is None else np.concatenate([a.ok(), b.ok()]))
+        if op.join_type in (S.LEFT_OUTER, S.FULL_OUTER):
+            sel = np.nonzero(~matched)[0]
+            extra = [_take(c, sel) for c in left] + null_cols(right, len(sel))
+            out = [concat(a, b) for a, b in zip(out, extra)]
+        if op.join_type in (S.RIGHT_OUTER, S.FULL_OUTER):
+            sel = np.nonzero(~rmatched)[0]
+            extra = null_cols(left, len(sel)) + [_take(c, sel) for c in right]
+            out = [concat(a, b) for a, b in zip(out, extra)]
+        return out
     sel = np.nonzero(matched if op.join_type == S.LEFT_SEMI else ~matched)[0]
     return [_take(c, sel) for c in left]
 

@@ -88,7 +88,33 @@ def test_tpch_q3_two_joins_and_grouped_aggregate(built):
     assert got.schema.field(3).type == pa.decimal128(36, 4)
 
 
-def test_unsupported_outer_join_is_rejected(built):
-    plan = S.hash_join(S.scan([S.T_INT64]), S.scan([S.T_INT64]), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.FULL_OUTER)
-    with pytest.raises(native.CometNativeException, match="outer"):
-        native.compile_plan(plan.encode())
+@pytest.mark.parametrize("jt", [S.LEFT_OUTER, S.RIGHT_OUTER, S.FULL_OUTER])
+@pytest.mark.parametrize("build", [S.BUILD_LEFT, S.BUILD_RIGHT])
+def test_outer_joins(built, jt, build):
+    # planner.rs:2448-2460: the preserved side's unmatched rows (NULL keys included) come out NULL-extended, whichever side is built
+    left, right = _tables(4000, 3000, 11)
+    plan = S.hash_join(S.scan([S.T_INT64, S.T_INT32]), S.scan([S.T_INT64, S.T_DOUBLE]), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, build)
+    got, want = _run(plan, [left, right], 4, batch_size=0), _oracle(plan, [left, right])
+    assert got.num_rows == want.num_rows
+    assert _rows(got) == _rows(want)
+    nulls_right = sum(1 for r in _rows(got) if r[2] is None and r[3] is None)
+    nulls_left = sum(1 for r in _rows(got) if r[0] is None and r[1] is None)
+    assert (nulls_right > 0) == (jt in (S.LEFT_OUTER, S.FULL_OUTER)) and (nulls_left > 0) == (jt in (S.RIGHT_OUTER, S.FULL_OUTER))
+
+
+def test_outer_join_with_condition_empty_sides_and_projection_on_top(built):
+    left, right = _tables(3000, 2500, 12, nulls=False)
+    cond = S.gt(S.col(1, S.T_INT32), S.lit(0, S.T_INT32))          # residual over left ++ right: left.v > 0
+    j = S.hash_join(S.scan([S.T_INT64, S.T_INT32]), S.scan([S.T_INT64, S.T_DOUBLE]), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)],
+                    S.FULL_OUTER, S.BUILD_RIGHT, cond)
+    plan = S.project(j, [S.col(0, S.T_INT64), S.col(3, S.T_DOUBLE), S.is_null(S.col(2, S.T_INT64))])
+    got, want = _run(plan, [left, right], 3, batch_size=0), _oracle(plan, [left, right])
+    assert _rows(got) == _rows(want) and got.num_rows > 3000
+    # an empty build side: every probe row survives a probe-preserving outer join
+    lo = S.hash_join(S.scan([S.T_INT64, S.T_INT32]), S.scan([S.T_INT64, S.T_DOUBLE]), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.LEFT_OUTER, S.BUILD_RIGHT)
+    got = _run(lo, [left, right.slice(0, 0)], 4, batch_size=0)
+    assert got.num_rows == left.num_rows and got.column(3).null_count == left.num_rows
+    # an empty probe side: every build row survives a build-preserving outer join
+    ro = S.hash_join(S.scan([S.T_INT64, S.T_INT32]), S.scan([S.T_INT64, S.T_DOUBLE]), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.RIGHT_OUTER, S.BUILD_RIGHT)
+    got = _run(ro, [left.slice(0, 0), right], 4, batch_size=0)
+    assert got.num_rows == right.num_rows and got.column(0).null_count == right.num_rows
