@@ -1917,9 +1917,13 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   }
   if (j.null_aware_anti) throw CometError("null-aware anti join is not supported by the MI355X native engine yet");
   const bool build_left = j.build_side == BuildSide::Left;
-  if (mode != 0 && build_left) throw CometError("LeftSemi/LeftAnti with BuildLeft is not supported by the MI355X native engine yet");
-  const bool outer_probe = build_left ? keep_right : keep_left;    // the probe side is the preserved one
-  const bool outer_build = build_left ? keep_left : keep_right;
+  // LeftSemi / LeftAnti built on the LEFT: the output is a subset of the BUILD rows — the probe pass only marks the build rows
+  // it matched (all of them: MODE 0 walks the whole chain), the tail pass then emits the marked (semi) or unmarked (anti) ones
+  const bool build_only = mode != 0 && build_left;
+  const bool keep_matched = build_only && mode == 1;
+  if (build_only) mode = 0;
+  const bool outer_probe = !build_only && (build_left ? keep_right : keep_left);    // the probe side is the preserved one
+  const bool outer_build = build_only || (build_left ? keep_left : keep_right);
   const std::vector<DType>& bt = build_left ? lt : rt;
   const std::vector<DType>& pt = build_left ? rt : lt;
   const std::vector<bool>& bv = build_left ? lvalid : rvalid;
@@ -1936,7 +1940,8 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   std::ostringstream src, ex;
   src << "// generated by datafusion-comet_amd codegen — hash join\n#include \"comet_device.hpp\"\nusing namespace comet;\n";
   src << "struct P {\n  static constexpr int R = 1;\n  static constexpr int MODE = " << mode << ";\n";
-  src << "  static constexpr bool OUTER_PROBE = " << (outer_probe ? "true" : "false") << ", OUTER_BUILD = " << (outer_build ? "true" : "false") << ";\n";
+  src << "  static constexpr bool OUTER_PROBE = " << (outer_probe ? "true" : "false") << ", OUTER_BUILD = " << (outer_build ? "true" : "false")
+      << ", BUILD_KEEP_MATCHED = " << (keep_matched ? "true" : "false") << ";\n";
 
   // key words of one side
   auto key_fn = [&](const char* name, const char* rowvar, const std::vector<DType>& types, const std::vector<bool>& valid, int base,
@@ -2033,7 +2038,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   {
     // emit(i, j, pos): output = left columns then right columns (Inner / outer); left columns only (Semi/Anti).
     // Outer joins add emit_probe_only(j, pos) / emit_build_only(i, pos): the other side's columns are NULL.
-    const int nout = mode == 0 ? nl + nr : nl;
+    const int nout = (mode == 0 && !build_only) ? nl + nr : nl;
     if (nout * 2 + kOutFirstCol > 44) throw CometError("too many output columns for one GPU hash join");
     for (int c = 0; c < nout; c++) {
       if (ct[c].id == TypeId::String || ct[c].id == TypeId::Bytes) throw CometError("Utf8 payload columns are not supported in a GPU hash join yet");
@@ -2091,7 +2096,8 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbemit(const CometKParams prm) { comet::join_build_unmatched_emit_body<P>(prm); }\n";
   d.kernels = {"k_jbuild", "k_jcount", "k_jscan", "k_jemit", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit"};
   d.join_outer_build = outer_build;
-  const char* jt_name = keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";
+  d.join_build_only = build_only;
+  const char* jt_name = build_only ? (keep_matched ? "LeftSemi" : "LeftAnti") : keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";
   ex << "  hash join: " << jt_name << ", build " << (build_left ? "left" : "right") << ", "
      << j.left_keys.size() << " key(s)\n";
   d.in_types = ct;

@@ -35,6 +35,7 @@ struct PipelineDesc {
   std::vector<std::string> kernels;  // extern "C" kernel names present in `source`
   // static row bound under which decimal sums cannot overflow (Appendix C.1 rule); 0 = no limit
   long long max_rows_exact = 0;
+  bool join_build_only = false;     // LeftSemi/LeftAnti built on the left: only the tail pass produces rows
   bool join_outer_build = false;    // hash join that must also emit the build rows no probe row matched
   std::string explain;             // human-readable fused plan
   std::vector<std::string> op_names;  // operator names root→leaf (metrics tree / tracing label)

@@ -1307,7 +1307,8 @@ CDEV void join_emit_body(const CometKParams& prm) {
   }
 }
 
-// build rows nobody matched (outer joins that preserve the build side): count per tile, then emit after the matched rows
+// build rows nobody matched (outer joins that preserve the build side; LeftAnti built on the left) — or, with
+// P::BUILD_KEEP_MATCHED, the build rows that WERE matched (LeftSemi built on the left): count per tile, then emit
 template <class P>
 CDEV void join_build_unmatched_count_body(const CometKParams& prm) {
   const i64 nb = prm.iarg[1];
@@ -1322,7 +1323,7 @@ CDEV void join_build_unmatched_count_body(const CometKParams& prm) {
 #pragma unroll
     for (int r = 0; r < kMaskTileRows / kBlock; r++) {
       i64 i = t * kMaskTileRows + r * kBlock + threadIdx.x;
-      local += (u32)__popcll(__ballot(i < nb && !matched[i])) * (lane_id() == 0 ? 1u : 0u);
+      local += (u32)__popcll(__ballot(i < nb && (matched[i] != 0) == P::BUILD_KEEP_MATCHED)) * (lane_id() == 0 ? 1u : 0u);
     }
     if (lane_id() == 0) atomicAdd(&s_cnt, local);
     __syncthreads();
@@ -1343,7 +1344,7 @@ CDEV void join_build_unmatched_emit_body(const CometKParams& prm) {
     __syncthreads();
     for (int r = 0; r < kMaskTileRows / kBlock; r++) {
       i64 i = t * kMaskTileRows + r * kBlock + threadIdx.x;
-      const bool keep = i < nb && !matched[i];
+      const bool keep = i < nb && (matched[i] != 0) == P::BUILD_KEEP_MATCHED;
       const u64 b = __ballot(keep);
       const u32 below = (u32)__popcll(b & ((1ull << lane_id()) - 1));
       if (lane_id() == 0) s_wave[wave_id()] = (u32)__popcll(b);

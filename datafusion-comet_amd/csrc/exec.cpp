@@ -1479,7 +1479,7 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
     launch(v, "k_jscan", 1, prm);
     uint64_t total = 0;
     read_small(&total, (char*)tiles.p + (size_t)ntiles * 8, 8);
-    out_rows = (int64_t)total;
+    out_rows = d.join_build_only ? 0 : (int64_t)total;
   }
   if (outer_build && B.rows > 0) {
     // build rows without a match follow the probe-driven rows

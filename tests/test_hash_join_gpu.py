@@ -45,11 +45,12 @@ def test_inner_join_with_duplicates_and_null_keys(built, build):
     assert _rows(got) == _rows(want)
 
 
+@pytest.mark.parametrize("build", [S.BUILD_LEFT, S.BUILD_RIGHT])
 @pytest.mark.parametrize("jt", [S.LEFT_SEMI, S.LEFT_ANTI])
-def test_semi_and_anti_join(built, jt):
+def test_semi_and_anti_join(built, jt, build):
     left, right = _tables(5000, 700, 2)
     plan = S.hash_join(S.scan([S.T_INT64, S.T_INT32]), S.scan([S.T_INT64, S.T_DOUBLE]), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)],
-                       jt, S.BUILD_RIGHT)
+                       jt, build)
     got, want = _run(plan, [left, right], 2, batch_size=0), _oracle(plan, [left, right])
     assert _rows(got) == _rows(want)
     assert got.num_rows > 0
