@@ -145,6 +145,9 @@ def exchange(table, key_cols, partitioner, group=None):
             valid.append(_pack_bits(a2a(vb.reshape(n_in, 1)).reshape(-1)))
         else:
             valid.append(None)
+    if dev.type == "cuda":
+        # the collectives were enqueued on torch's stream; libcomet reads these buffers on ITS OWN stream next
+        torch.cuda.current_stream(dev).synchronize()
     return DeviceTable(part.schema, n_out, vals, valid, table.device, [None] * len(vals))
 
 
