@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--q3-orders", type=int, default=150_000_000,
                     help="extra leg: TPC-H Q3 (hash joins + RCCL exchange) over all ranks, total orders rows (SF100 = 150 M, strong scaling); 0 = skip")
     ap.add_argument("--q3-timeout", type=int, default=420)
+    ap.add_argument("--no-parquet-leg", action="store_true", help="skip the extra leg: SF10 Q6 straight from a zstd Parquet file (1 GPU only)")
+    ap.add_argument("--q1-rows", type=int, default=600_037_902,
+                    help="extra leg: TPC-H Q1 stage 1 on HBM-resident columns, lineitem rows per GPU (SF100 = 600,037,902); 0 = skip")
     args = ap.parse_args()
 
     import numpy as np
@@ -109,10 +112,19 @@ def main():
     # RCCL all-to-all exchanges (tools/q3_dist.py).  It runs in a CHILD process per rank with its own rendezvous port so that a
     # failure or hang there cannot take the Q6 line down: the child is killed by PID after --q3-timeout seconds.
     q3 = None
-    if args.q3_orders > 0:
+    if True:
         del dtab, dinput
         torch.cuda.empty_cache()
+    if args.q3_orders > 0:
         q3 = run_q3_leg(args, rank, local_rank, world)
+    pq = None
+    if world == 1 and not args.no_parquet_leg:
+        pq = run_child_leg([os.path.join(ROOT, "tools", "parquet_q6.py"), "--rows", str(args.rows), "--codec", "zstd", "--steps", "5"],
+                           rank, local_rank, world, args.q3_timeout, port_offset=3017)
+    q1 = None
+    if args.q1_rows > 0:
+        q1 = run_child_leg([os.path.join(ROOT, "tools", "q1_sf100.py"), "--rows", str(args.q1_rows), "--steps", "5", "--seed", str(1 + rank)],
+                           rank, local_rank, world, args.q3_timeout, port_offset=2017)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -154,31 +166,42 @@ def main():
                                               f"(oracle/comet_oracle.c o_q6_reference_pipeline, 8192-row batches), {cdt:.2f} s"}
         if q3 is not None:
             line["q3"] = q3
+        if q1 is not None:
+            line["q1_sf100_per_gpu"] = q1
+        if pq is not None:
+            line["q6_from_parquet"] = pq
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
 
 def run_q3_leg(args, rank, local_rank, world):
+    return run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1"],
+                         rank, local_rank, world, args.q3_timeout, port_offset=1017)
+
+
+def run_child_leg(cmd_tail, rank, local_rank, world, timeout, port_offset):
+    """Run a tool as a child process of this rank (same RANK/WORLD_SIZE, its own rendezvous port); rank 0 returns the tool's
+    one-line JSON (--out), every failure becomes {"error": ...}.  A hung child is killed by PID after `timeout` seconds."""
     import subprocess
     import tempfile
-    out = os.path.join(tempfile.gettempdir(), f"comet_q3_{os.getpid()}.json")
+    out = os.path.join(tempfile.gettempdir(), f"comet_leg_{os.getpid()}_{port_offset}.json")
     env = dict(os.environ)
     env["MASTER_ADDR"] = "127.0.0.1"
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1017)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)
     env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"] = str(rank), str(local_rank), str(world)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1", "--out", out]
+    cmd = [sys.executable] + list(cmd_tail) + ["--out", out]
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         try:
-            log, _ = p.communicate(timeout=args.q3_timeout)
+            log, _ = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             p.kill()
             p.communicate()
-            return {"error": f"timed out after {args.q3_timeout} s"}
+            return {"error": f"timed out after {timeout} s"} if rank == 0 else None
         if rank != 0:
             return None
         if p.returncode != 0 or not os.path.exists(out):
@@ -187,7 +210,7 @@ def run_q3_leg(args, rank, local_rank, world):
             res = json.loads(f.read())
         os.unlink(out)
         return res
-    except Exception as e:  # the extra leg must never break the headline line
+    except Exception as e:  # an extra leg must never break the headline line
         return {"error": repr(e)} if rank == 0 else None
 
 

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--dir", default="/tmp")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-dictionary", action="store_true")
+    ap.add_argument("--out", default="", help="also write the JSON line here")
     a = ap.parse_args()
     import pyarrow as pa
     import pyarrow.parquet as papq
@@ -65,10 +66,14 @@ def main():
     cpu1 = time.perf_counter() - t0
     best = min(times)
     decoded = a.rows * tpch.Q6_BYTES_PER_ROW
-    print(json.dumps({"query": "tpch_q6_parquet", "rows": a.rows, "codec": a.codec, "dictionary": not a.no_dictionary, "file_bytes": fsize,
+    line = json.dumps({"query": "tpch_q6_parquet", "rows": a.rows, "codec": a.codec, "dictionary": not a.no_dictionary, "file_bytes": fsize,
                       "sec_best": best, "sec_median": sorted(times)[len(times) // 2], "sec_all": [round(t, 4) for t in times], "rows_per_s": a.rows / best,
                       "encoded_GBps": fsize / best / 1e9, "decoded_arrow_GBps": decoded / best / 1e9, "result": want, "matches_resident_plan": ok,
-                      "pyarrow_read_s_all_cores": cpu, "pyarrow_read_s_1_core": cpu1, "host_cores": os.cpu_count()}))
+                      "pyarrow_read_s_all_cores": cpu, "pyarrow_read_s_1_core": cpu1, "host_cores": os.cpu_count()})
+    print(line)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(line + "\n")
     if not ok:
         sys.exit(3)
 
