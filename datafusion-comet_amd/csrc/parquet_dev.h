@@ -27,7 +27,9 @@ typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section 
 
 /* output conversions */
 enum { PQ_COPY4 = 0, PQ_COPY8 = 1, PQ_I32_TO_I64 = 2, PQ_I32_TO_DEC = 3, PQ_I64_TO_DEC = 4, PQ_FLBA_TO_DEC = 5, PQ_BOOL = 6,
-       PQ_I32_TO_I16 = 7, PQ_I32_TO_I8 = 8 };
+       PQ_I32_TO_I16 = 7, PQ_I32_TO_I8 = 8,
+       /* schema adaptation (parquet/schema_adapter.rs, parquet_support.rs:141-240) */
+       PQ_F32_TO_F64 = 9, PQ_I32_TO_F64 = 10, PQ_INT96_TO_TS_MICROS = 11 };
 
 typedef struct PqDecodeArgs {
   const PqPage* pages;
@@ -41,7 +43,9 @@ typedef struct PqDecodeArgs {
   const int64_t* plain_str_offs; /* PLAIN BYTE_ARRAY data pages: staged-byte offset of each value's bytes (+1 sentinel per page) */
   int64_t n_rows;              /* rows of this column chunk */
   int32_t kind;                /* PQ_* conversion */
-  int32_t width;               /* source value width in bytes (FLBA length, 4, 8) */
+  int32_t width;               /* source value width in bytes (FLBA length, 4, 8, 12) */
+  int32_t dec_scale_up;        /* PQ_*_TO_DEC: multiply the unscaled value by 10^dec_scale_up (decimal scale widening) */
+  int32_t pad0;
   uint8_t* valid_out;          /* per-row validity bytes (at the chunk's row offset) */
   uint32_t* vidx;              /* per-row exclusive count of non-null rows before it (scratch) */
   void* values_out;            /* typed output at the chunk's row offset */

@@ -112,6 +112,11 @@ __device__ __forceinline__ i128 pq_flba_to_i128(const u8* p, int len) {
 // little-endian loads from arbitrarily aligned page bytes (gfx9+ global loads may be unaligned)
 __device__ __forceinline__ u32 pq_ld32(const u8* p) { u32 x; __builtin_memcpy(&x, p, 4); return x; }
 __device__ __forceinline__ u64 pq_ld64(const u8* p) { u64 x; __builtin_memcpy(&x, p, 8); return x; }
+__device__ __forceinline__ i128 pq_pow10(int k) {
+  i128 r = 1;
+  for (int i = 0; i < k; i++) r *= 10;
+  return r;
+}
 __device__ __forceinline__ i64 pq_uniform_i64(i64 v) {
   return (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v));
 }
@@ -194,9 +199,18 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
       case PQ_I32_TO_I64: ((i64*)a.values_out)[row] = valid ? (i64)(i32)pq_ld32(src) : 0; break;
       case PQ_I32_TO_I16: ((i16*)a.values_out)[row] = valid ? (i16)(i32)pq_ld32(src) : (i16)0; break;
       case PQ_I32_TO_I8: ((i8*)a.values_out)[row] = valid ? (i8)(i32)pq_ld32(src) : (i8)0; break;
-      case PQ_I32_TO_DEC: ((i128*)a.values_out)[row] = valid ? (i128)(i32)pq_ld32(src) : (i128)0; break;
-      case PQ_I64_TO_DEC: ((i128*)a.values_out)[row] = valid ? (i128)(i64)pq_ld64(src) : (i128)0; break;
-      case PQ_FLBA_TO_DEC: ((i128*)a.values_out)[row] = valid ? pq_flba_to_i128(src, a.width) : (i128)0; break;
+      case PQ_I32_TO_DEC: ((i128*)a.values_out)[row] = valid ? (i128)(i32)pq_ld32(src) * pq_pow10(a.dec_scale_up) : (i128)0; break;
+      case PQ_I64_TO_DEC: ((i128*)a.values_out)[row] = valid ? (i128)(i64)pq_ld64(src) * pq_pow10(a.dec_scale_up) : (i128)0; break;
+      case PQ_FLBA_TO_DEC: ((i128*)a.values_out)[row] = valid ? pq_flba_to_i128(src, a.width) * pq_pow10(a.dec_scale_up) : (i128)0; break;
+      case PQ_F32_TO_F64: ((double*)a.values_out)[row] = valid ? (double)__uint_as_float(pq_ld32(src)) : 0.0; break;
+      case PQ_I32_TO_F64: ((double*)a.values_out)[row] = valid ? (double)(i32)pq_ld32(src) : 0.0; break;
+      case PQ_INT96_TO_TS_MICROS: {
+        // INT96 = 8 bytes nanoseconds of day (LE) + 4 bytes Julian day (LE); 2440588 = Julian day of 1970-01-01
+        i64 us = 0;
+        if (valid) us = ((i64)(i32)pq_ld32(src + 8) - 2440588) * 86400000000ll + (i64)(pq_ld64(src) / 1000ull);
+        ((i64*)a.values_out)[row] = us;
+        break;
+      }
       case PQ_BOOL: ((u8*)a.values_out)[row] = (u8)(valid ? boolbit : 0); break;
       default: break;
     }

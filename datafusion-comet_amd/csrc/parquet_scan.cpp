@@ -194,7 +194,20 @@ struct ColumnPlan {
   int src_width = 0;
   int out_width = 0;      // bytes per output value (0 strings)
   bool is_string = false;
+  int dec_scale_up = 0;   // decimal scale widening: unscaled value × 10^dec_scale_up
+  bool missing = false;   // the file has no such column: every value is NULL (schema evolution)
 };
+
+int out_width_of(const DType& t) {
+  switch (t.id) {
+    case TypeId::Bool: case TypeId::Int8: return 1;
+    case TypeId::Int16: return 2;
+    case TypeId::Int32: case TypeId::Date: case TypeId::Float: return 4;
+    case TypeId::Decimal: return 16;
+    case TypeId::String: case TypeId::Bytes: return 0;
+    default: return 8;
+  }
+}
 
 ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, bool case_sensitive) {
   ColumnPlan cp;
@@ -209,7 +222,14 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, bool cas
     }
     leaf++;
   }
-  if (cp.leaf < 0) throw CometError("Parquet column '" + want.name + "' not found (missing-column defaults are not supported by the GPU scan yet)");
+  if (cp.leaf < 0) {
+    // a column the file does not have reads as NULL (Spark schema evolution; schema_adapter.rs:352-525 without default values)
+    cp.missing = true;
+    cp.is_string = want.dtype.id == TypeId::String || want.dtype.id == TypeId::Bytes;
+    cp.out_width = out_width_of(want.dtype);
+    cp.kind = -2;
+    return cp;
+  }
   if (cp.el.repetition == 2) throw CometError("repeated Parquet columns are not supported by the GPU scan yet");
   const DType& t = want.dtype;
   const int pt = cp.el.type;
@@ -221,18 +241,28 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, bool cas
     case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz:
       if (pt == pq::INT64) { cp.kind = PQ_COPY8; cp.src_width = 8; }
       else if (pt == pq::INT32 && t.id == TypeId::Int64) { cp.kind = PQ_I32_TO_I64; cp.src_width = 4; }   // type promotion (schema_adapter.rs)
+      else if (pt == pq::INT96 && t.id != TypeId::Int64) { cp.kind = PQ_INT96_TO_TS_MICROS; cp.src_width = 12; }   // legacy Spark/Impala timestamps
       else throw bad();
       cp.out_width = 8;
       break;
     case TypeId::Float: if (pt != pq::FLOAT) throw bad(); cp.kind = PQ_COPY4; cp.src_width = 4; cp.out_width = 4; break;
-    case TypeId::Double: if (pt != pq::DOUBLE) throw bad(); cp.kind = PQ_COPY8; cp.src_width = 8; cp.out_width = 8; break;
+    case TypeId::Double:
+      if (pt == pq::DOUBLE) { cp.kind = PQ_COPY8; cp.src_width = 8; }
+      else if (pt == pq::FLOAT) { cp.kind = PQ_F32_TO_F64; cp.src_width = 4; }     // FLOAT → DOUBLE promotion
+      else if (pt == pq::INT32) { cp.kind = PQ_I32_TO_F64; cp.src_width = 4; }     // INT32 → DOUBLE promotion
+      else throw bad();
+      cp.out_width = 8;
+      break;
     case TypeId::Bool: if (pt != pq::BOOLEAN) throw bad(); cp.kind = PQ_BOOL; cp.src_width = 0; cp.out_width = 1; break;
     case TypeId::Decimal:
       if (pt == pq::INT32) { cp.kind = PQ_I32_TO_DEC; cp.src_width = 4; }
       else if (pt == pq::INT64) { cp.kind = PQ_I64_TO_DEC; cp.src_width = 8; }
       else if (pt == pq::FLBA && cp.el.type_length >= 1 && cp.el.type_length <= 16) { cp.kind = PQ_FLBA_TO_DEC; cp.src_width = cp.el.type_length; }
       else throw bad();
-      if (cp.el.scale != t.scale) throw CometError("Parquet decimal scale differs from the requested type (decimal widening is not supported by the GPU scan yet)");
+      // decimal widening (parquet_support.rs): a larger scale multiplies the unscaled value, provided the integer digits still fit
+      if (cp.el.scale > t.scale || (t.precision - t.scale) < (cp.el.precision - cp.el.scale))
+        throw CometError("Parquet column '" + want.name + "': decimal(" + std::to_string(cp.el.precision) + "," + std::to_string(cp.el.scale) + ") cannot be read as " + t.str() + " without losing digits");
+      cp.dec_scale_up = t.scale - cp.el.scale;
       cp.out_width = 16;
       break;
     case TypeId::String: case TypeId::Bytes: if (pt != pq::BYTE_ARRAY) throw bad(); cp.is_string = true; break;
@@ -269,9 +299,10 @@ struct ChunkSource {
 // bytes the staged (decompressed) pages of a column chunk may take
 size_t staged_capacity(const pq::ColumnMeta& cm) { return ((size_t)cm.total_uncompressed + 64 + 15) & ~(size_t)15; }
 
-void decode_chunk_host(const ChunkSource& src, const StructField& want, HostChunk& hc, uint8_t* staged, size_t staged_cap) {
+void decode_chunk_host(const ChunkSource& src, const StructField& want, bool case_sensitive, HostChunk& hc, uint8_t* staged, size_t staged_cap) {
   const pq::RowGroup& rg = src.meta->row_groups[(size_t)src.rg];
-  ColumnPlan cp = plan_column(want, *src.meta, true);
+  ColumnPlan cp = plan_column(want, *src.meta, case_sensitive);
+  if (cp.missing) throw CometError("internal: chunk task for a missing column");
   if ((size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
   const pq::ColumnMeta& cm = rg.columns[(size_t)cp.leaf];
   hc.cp = cp;
@@ -469,13 +500,14 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   std::vector<std::unique_ptr<PinnedBuf>> col_staged(ncol);
   for (size_t c = 0; c < ncol; c++) {
     for (size_t si = 0; si < nsel; si++) {
-      ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, true);
+      ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, op.case_sensitive);
       const pq::RowGroup& rg = sels[si].meta->row_groups[(size_t)sels[si].rg];
-      if ((size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
+      if (!cp.missing && (size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
       if (si == 0) plans[c] = cp;
-      else if (cp.kind != plans[c].kind || cp.src_width != plans[c].src_width || cp.is_string != plans[c].is_string)
-        throw CometError("parquet: column '" + op.required_schema[c].name + "' has different physical types across files");
-      slot_off[c][si + 1] = slot_off[c][si] + staged_capacity(rg.columns[(size_t)cp.leaf]);
+      else if (cp.missing != plans[c].missing || cp.kind != plans[c].kind || cp.src_width != plans[c].src_width || cp.is_string != plans[c].is_string ||
+               cp.dec_scale_up != plans[c].dec_scale_up)
+        throw CometError("parquet: column '" + op.required_schema[c].name + "' differs in presence or physical type across the files of one partition");
+      slot_off[c][si + 1] = slot_off[c][si] + (cp.missing ? 0 : staged_capacity(rg.columns[(size_t)cp.leaf]));
     }
     col_staged[c].reset(new PinnedBuf());
     col_staged[c]->ensure(slot_off[c][nsel] + 64);
@@ -497,7 +529,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   auto run_task = [&](size_t t) {
     const size_t c = t / nsel, si = t % nsel;
     ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg};
-    decode_chunk_host(src, op.required_schema[c], chunks[t], (uint8_t*)col_staged[c]->p + slot_off[c][si], slot_off[c][si + 1] - slot_off[c][si]);
+    if (plans[c].missing) return;
+    decode_chunk_host(src, op.required_schema[c], op.case_sensitive, chunks[t], (uint8_t*)col_staged[c]->p + slot_off[c][si], slot_off[c][si + 1] - slot_off[c][si]);
   };
   for (size_t t = 0; t < ntasks; t++) {
     ScanPool::get().submit([prog, t, &run_task, &chunks]() {
@@ -555,6 +588,28 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
 
   for (size_t c = 0; c < ncol; c++) {
     const ColumnPlan& cp = plans[c];
+    if (cp.missing) {
+      for (int64_t di : op.default_values_indexes)
+        if ((size_t)di == c) throw CometError("Parquet column '" + op.required_schema[c].name + "' is missing and has a default value: defaults are not supported by the GPU scan yet");
+      // all-NULL column: zeroed values, zeroed validity bitmap
+      DeviceColumnView mv;
+      auto zeros = std::make_shared<DevBuf>();
+      const size_t vb = cp.is_string ? (size_t)(total_rows + 1) * 4 : out.types[c].id == TypeId::Bool ? (size_t)((total_rows + 7) / 8) : (size_t)total_rows * cp.out_width;
+      zeros->ensure(vb + 16);
+      HIP_CHECK(hipMemsetAsync(zeros->p, 0, vb + 16, stream_));
+      auto bm = std::make_shared<DevBuf>();
+      bm->ensure((size_t)((total_rows + 7) / 8) + 16);
+      HIP_CHECK(hipMemsetAsync(bm->p, 0, (size_t)((total_rows + 7) / 8) + 16, stream_));
+      mv.data = zeros->p;
+      mv.valid = (const uint8_t*)bm->p;
+      if (cp.is_string) mv.aux = zeros->p;   // no bytes are ever addressed (all offsets 0)
+      out.has_valid[c] = true;
+      out.cols[c] = mv;
+      out.owners.push_back(zeros);
+      out.owners.push_back(bm);
+      for (size_t si = 0; si < nsel; si++) wait_for(c * nsel + si);
+      continue;
+    }
     auto values = std::make_shared<DevBuf>();
     auto valid_bytes = std::make_shared<DevBuf>();
     auto lengths = std::make_shared<DevBuf>();
@@ -651,6 +706,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     a.n_rows = total_rows;
     a.kind = cp.kind;
     a.width = cp.src_width;
+    a.dec_scale_up = cp.dec_scale_up;
     if (any_optional) {
       valid_bytes->ensure((size_t)total_rows + 16);
       if (!vidx->p) vidx->ensure((size_t)total_rows * 4 + 16);

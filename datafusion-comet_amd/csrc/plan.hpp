@@ -148,6 +148,8 @@ struct Operator {
   std::vector<int64_t> projection_vector;
   std::vector<PartitionedFile> files;
   std::string session_timezone;
+  bool case_sensitive = false;                 // NativeScanCommon.case_sensitive (proto3 default)
+  std::vector<int64_t> default_values_indexes;  // required_schema positions that carry a default value
 };
 
 // proto.cpp

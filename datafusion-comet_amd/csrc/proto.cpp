@@ -284,6 +284,8 @@ void decode_native_scan(Reader r, Operator& op) {
         else if (f2 == 4 && wt2 == 2) op.data_filters.push_back(decode_expr(c.sub()));
         else if (f2 == 5) c.repeated_varint(wt2, [&](uint64_t v) { op.projection_vector.push_back((int64_t)v); });
         else if (f2 == 6 && wt2 == 2) op.session_timezone = c.bytes();
+        else if (f2 == 8) c.repeated_varint(wt2, [&](uint64_t v) { op.default_values_indexes.push_back((int64_t)v); });
+        else if (f2 == 9 && wt2 == 0) op.case_sensitive = c.varint() != 0;
         else if (f2 == 12 && wt2 == 2) op.scan_source = c.bytes();
         else if (f2 == 13 && wt2 == 2) op.scan_fields.push_back(decode_datatype(c.sub()));
         else c.skip(wt2);

@@ -339,6 +339,7 @@ class Operator:
 
     # native_scan
     field_names: List[str] = field(default_factory=list)
+    case_sensitive: bool = True
     files: List[tuple] = field(default_factory=list)          # (path, start, length, file_size)
 
     TAGS = dict(scan=100, projection=101, filter=102, hash_agg=104, hash_join=109, native_scan=111)
@@ -365,7 +366,7 @@ class Operator:
             common = b"".join(_f_msg(1, sf(n, t)) for n, t in zip(self.field_names, self.fields))
             common += b"".join(_f_msg(2, sf(n, t)) for n, t in zip(self.field_names, self.fields))
             common += b"".join(_f_varint(5, i) for i in range(len(self.fields)))
-            common += _f_bytes(6, b"UTC") + _f_varint(9, 1) + _f_bytes(12, b"parquet") + b"".join(_f_msg(13, t.encode()) for t in self.fields)
+            common += _f_bytes(6, b"UTC") + (_f_varint(9, 1) if self.case_sensitive else b"") + _f_bytes(12, b"parquet") + b"".join(_f_msg(13, t.encode()) for t in self.fields)
             part = b""
             for path, start, length, size in self.files:
                 pf = _f_bytes(1, ("file://" + path).encode())
@@ -414,7 +415,7 @@ def final_of(partial_plan: "Operator", state_schema) -> "Operator":
     return hash_agg(scan(fields), [col(i, fields[i]) for i in range(ng)], partial_plan.aggs, FINAL)
 
 
-def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType]) -> Operator:
+def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType], case_sensitive: bool = True) -> Operator:
     """Parquet scan of `files` (paths, or (path, start, length, size) byte-range splits) producing columns `names`."""
     import os
     fl = []
@@ -424,7 +425,7 @@ def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType]
             fl.append((f, 0, sz, sz))
         else:
             fl.append(tuple(f))
-    return Operator("native_scan", fields=list(types), field_names=list(names), files=fl)
+    return Operator("native_scan", fields=list(types), field_names=list(names), files=fl, case_sensitive=case_sensitive)
 
 
 INNER, LEFT_OUTER, RIGHT_OUTER, FULL_OUTER, LEFT_SEMI, LEFT_ANTI = range(6)

@@ -121,6 +121,43 @@ def test_empty_file_list_and_missing_column(built, tmp_path):
     assert native.execute_to_table([], 1, plan.encode()) == []
     path = str(tmp_path / "m.parquet")
     papq.write_table(t, path)
-    bad = S.native_scan([path], ["nope"], [S.T_INT32])
-    with pytest.raises(native.CometNativeException, match="not found"):
-        native.execute_to_table([], 1, bad.encode())
+    # a column the file does not have reads as NULL (schema evolution), like the reference's schema adapter
+    missing = S.native_scan([path], ["nope", "i32"], [S.T_INT32, S.T_INT32])
+    got = pa.Table.from_batches(native.execute_to_table([], 2, missing.encode(), batch_size=0))
+    assert got.column(0).null_count == 10 and got.column(1).equals(t.column("i32"))
+
+
+def test_schema_adaptation(built, tmp_path):
+    """Per-file schema reconciliation (parquet/schema_adapter.rs, parquet_support.rs:141-240): widening promotions,
+    decimal precision/scale widening, legacy INT96 timestamps, a column the file does not have (→ NULL), case-insensitive names."""
+    import datetime
+    n = 40_000
+    rng = np.random.default_rng(8)
+    ts = pa.array(rng.integers(0, 2 * 10**15, n), pa.int64(), mask=rng.random(n) < 0.1).cast(pa.timestamp("us"))
+    t = pa.table({
+        "I": pa.array(rng.integers(-2**31, 2**31 - 1, n), pa.int32(), mask=rng.random(n) < 0.1),
+        "f": pa.array(rng.standard_normal(n).astype(np.float32), pa.float32(), mask=rng.random(n) < 0.1),
+        "d": pa.array([Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**8, 10**8, n)], pa.decimal128(9, 2), mask=rng.random(n) < 0.1),
+        "ts": ts,
+    })
+    path = str(tmp_path / "adapt.parquet")
+    papq.write_table(t, path, row_group_size=15_000, use_deprecated_int96_timestamps=True, store_decimal_as_integer=True)
+    assert papq.ParquetFile(path).schema.column(3).physical_type == "INT96"
+    names = ["i", "F", "i", "d", "TS", "not_in_file", "missing_str"]       # read twice with different promotions; names differ in case
+    types = [S.T_INT64, S.T_DOUBLE, S.T_DOUBLE, S.decimal(20, 6), S.DataType(S.TIMESTAMP_NTZ), S.T_INT32, S.T_STRING]
+    plan = S.native_scan([path], names, types, case_sensitive=False)
+    got = pa.Table.from_batches(native.execute_to_table([], len(names), plan.encode(), batch_size=0))
+    want = [t.column("I").cast(pa.int64()), t.column("f").cast(pa.float64()), t.column("I").cast(pa.float64()), t.column("d").cast(pa.decimal128(20, 6)),
+            t.column("ts")]
+    for i, w in enumerate(want):
+        g = got.column(i).combine_chunks()
+        assert g.type == w.type or (i == 4 and pa.types.is_timestamp(g.type)), (i, g.type, w.type)
+        assert g.cast(w.type).equals(w.combine_chunks()), f"column {names[i]}"
+    assert got.column(5).null_count == n and got.column(6).null_count == n and got.column(5).type == pa.int32()
+    # a case-sensitive scan does not find "i" / "TS": they read as NULL columns
+    plan_cs = S.native_scan([path], ["i", "f"], [S.T_INT64, S.T_DOUBLE], case_sensitive=True)
+    got_cs = pa.Table.from_batches(native.execute_to_table([], 2, plan_cs.encode(), batch_size=0))
+    assert got_cs.column(0).null_count == n and got_cs.column(1).null_count == t.column("f").null_count
+    # narrowing is refused
+    with pytest.raises(native.CometNativeException, match="without losing digits"):
+        native.execute_to_table([], 1, S.native_scan([path], ["d"], [S.decimal(9, 1)]).encode())
