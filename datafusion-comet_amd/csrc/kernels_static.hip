@@ -45,7 +45,20 @@ __global__ __launch_bounds__(256) void pmod_kernel(const u32* hashes, i64 n, i32
 // Are all n Utf8 values exactly L bytes long?  (lets the fused kernels address the bytes directly, see ld_str_fixed)
 __global__ __launch_bounds__(256) void utf8_uniform_kernel(const i32* off, i64 n, i32 L, u32* flag) {
   bool bad = false;
-  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n && !bad; i += (i64)gridDim.x * 256) bad = off[i + 1] - off[i] != L;
+  if ((((uintptr_t)off) & 15) == 0) {
+    // four offsets per 16-byte load; the first offset of the next group comes from the neighbouring lane
+    const i64 ngroups = n / 4;
+    for (i64 g = (i64)blockIdx.x * 256 + threadIdx.x; g < (ngroups + 255) / 256 * 256 && !__all(bad); g += (i64)gridDim.x * 256) {
+      const bool in = g < ngroups;
+      int4 v = in ? ((const int4*)off)[g] : make_int4(0, 0, 0, 0);
+      i32 nx = __shfl_down(v.x, 1, 64);
+      if (in && (lane_id() == 63 || g + 1 >= ngroups)) nx = off[4 * g + 4];
+      if (in) bad |= (v.y - v.x != L) | (v.z - v.y != L) | (v.w - v.z != L) | (nx - v.w != L);
+    }
+    for (i64 i = ngroups * 4 + (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) bad |= off[i + 1] - off[i] != L;
+  } else {
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n && !bad; i += (i64)gridDim.x * 256) bad = off[i + 1] - off[i] != L;
+  }
   // one store per wave at most: millions of lanes storing to the same word serialise at the L2
   if (__ballot(bad) != 0 && lane_id() == 0) *flag = 1;
 }

@@ -97,3 +97,31 @@ def test_multi_column_chain_matches_oracle(built):
     O.C.o_pmod_array(O._p(want), ctypes.c_int64(n), 8, O._p(want_p))
     assert np.array_equal(out.cpu().numpy(), want_p)
     assert 0 <= out.min().item() and out.max().item() < 8
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 256, 1027, 100_003])
+def test_utf8_uniform_length_check(built, n):
+    """The per-chunk check that lets the fused kernels address fixed-length strings directly: exact for every n, for a deviation at
+    any position (first / last / lane boundaries), and for offset buffers that are not 16-byte aligned."""
+    import ctypes
+    import torch
+    lib = native.lib()
+    lib.comet_launch_utf8_uniform.restype = ctypes.c_int
+    lib.comet_launch_utf8_uniform.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L = 3
+    base = np.arange(n + 1, dtype=np.int32) * L
+
+    def check(offs, shift):
+        buf = torch.zeros(n + 1 + 4, dtype=torch.int32, device="cuda")
+        buf[shift:shift + n + 1] = torch.from_numpy(offs).cuda()
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        assert lib.comet_launch_utf8_uniform(buf.data_ptr() + 4 * shift, n, L, flag.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        return int(flag.item()) == 0
+
+    for shift in (0, 1):
+        assert check(base, shift)
+        for pos in sorted({0, n - 1, n // 2, min(63, n - 1), min(64, n - 1), min(255, n - 1), max(0, n - 2)}):
+            bad = base.copy()
+            bad[pos + 1:] += 1            # value `pos` is one byte longer
+            assert not check(bad, shift), (pos, shift)
