@@ -356,3 +356,55 @@ def q3_torch_reference(n_orders: int, world: int, device="cuda:0", seed: int = 3
         rows.append(((oi // 8) * 32 + (oi % 8) + 1, int(odate_all[oi].item()), 0, int(rev[p].item())))
     rows.sort(key=lambda r: (-r[3], r[1], r[0]))
     return rows[:top], groups
+
+
+def q1_check_against_torch(out: pa.Table, chk: dict) -> list:
+    """Compare a Q1 stage-1 result (Partial states) with independent torch reductions of the generating tensors: per group the
+    row count, sum(l_quantity) and sum(l_extendedprice), exact.  Returns a list of mismatch descriptions (empty = all good)."""
+    keep = chk["ship"] <= days(1998, 9, 2)
+    rows = {(r[0], r[1]): r for r in zip(*[out.column(i).to_pylist() for i in range(out.num_columns)])}
+    problems = []
+    for rf in "ANR":
+        for ls in "FO":
+            m = keep & (chk["rf"] == ord(rf)) & (chk["ls"] == ord(ls))
+            cnt = int(m.sum().item())
+            if cnt == 0:
+                if (rf, ls) in rows:
+                    problems.append(f"group {rf}{ls} should not exist")
+                continue
+            if (rf, ls) not in rows:
+                problems.append(f"group {rf}{ls} missing")
+                continue
+            r = rows[(rf, ls)]
+            sq = int((chk["qty"][m] * 100).sum().item())
+            sp = int(chk["price"][m].sum().item())
+            if not (r[-1] == cnt and int(r[2].scaleb(2)) == sq and int(r[4].scaleb(2)) == sp):
+                problems.append(f"group {rf}{ls}: got count {r[-1]} sum_qty {r[2]} sum_price {r[4]}, want {cnt} {sq} {sp}")
+    return problems
+
+
+def lineitem_q6_device(n: int, device="cuda:0", seed: int = 6):
+    """Q6's four lineitem columns generated in HBM (same distributions as lineitem_q6) + the generating tensors."""
+    import torch
+    from .native import DeviceTable
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def dec(v):
+        buf = torch.zeros((n, 2), dtype=torch.int64, device=device)
+        buf[:, 0] = v
+        return buf.view(torch.uint8).reshape(-1)
+    qty = torch.randint(1, 51, (n,), generator=g, device=device, dtype=torch.int64)
+    price = qty * torch.randint(90000, 210001, (n,), generator=g, device=device, dtype=torch.int64)
+    disc = torch.randint(0, 11, (n,), generator=g, device=device, dtype=torch.int64)
+    ship = torch.randint(days(1992, 1, 2), days(1998, 12, 1) + 1, (n,), generator=g, device=device, dtype=torch.int32)
+    schema = pa.schema([("l_quantity", pa.decimal128(12, 2)), ("l_extendedprice", pa.decimal128(12, 2)), ("l_discount", pa.decimal128(12, 2)),
+                        ("l_shipdate", pa.date32())])
+    t = DeviceTable(schema, n, [dec(qty * 100), dec(price), dec(disc), ship.view(torch.uint8).reshape(-1)], [None] * 4, device)
+    return t, {"qty": qty, "price": price, "disc": disc, "ship": ship}
+
+
+def q6_torch_reference(chk: dict) -> int:
+    """Unscaled (scale 4) Q6 revenue of the generating tensors, exact int64."""
+    m = (chk["ship"] >= days(1994, 1, 1)) & (chk["ship"] < days(1995, 1, 1)) & (chk["disc"] >= 5) & (chk["disc"] <= 7) & (chk["qty"] < 24)
+    return int((chk["price"][m] * chk["disc"][m]).sum().item())

@@ -46,22 +46,10 @@ def main():
     print(f"SF100 Q1: rows={n} kernel={k:.3f} ms -> {n / k / 1e6:.1f} Grows/s, algorithmic {n * tpch.Q1_BYTES_PER_ROW / k / 1e6:.0f} GB/s "
           f"({n * tpch.Q1_BYTES_PER_ROW / k / 1e6 / 8000:.3f} of 8 TB/s)")
     # independent check with torch reductions
-    keep = chk["ship"] <= tpch.days(1998, 9, 2)
-    rows = {(r[0], r[1]): r for r in zip(*[out.column(i).to_pylist() for i in range(out.num_columns)])}
-    ok = True
-    for rf in "ANR":
-        for ls in "FO":
-            m = keep & (chk["rf"] == ord(rf)) & (chk["ls"] == ord(ls))
-            cnt = int(m.sum().item())
-            if cnt == 0:
-                ok &= (rf, ls) not in rows
-                continue
-            r = rows[(rf, ls)]
-            sq = int((chk["qty"][m] * 100).sum().item())
-            sp = int(chk["price"][m].sum().item())
-            good = r[-1] == cnt and int(r[2].scaleb(2)) == sq and int(r[4].scaleb(2)) == sp
-            print(f"  group {rf}{ls}: count {r[-1]} sum_qty {r[2]} sum_base_price {r[4]}  {'OK' if good else 'MISMATCH'}")
-            ok &= good
+    problems = tpch.q1_check_against_torch(out, chk)
+    for pr in problems:
+        print("  MISMATCH", pr)
+    ok = not problems
     print("torch cross-check:", "PASS" if ok else "FAIL")
     if args.out:
         w = min(wall[1:])
