@@ -1206,7 +1206,10 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   while (true) {
     chain.push_back(cur);
     if (cur->kind == OpKind::Scan) break;
-    if (cur->kind == OpKind::HashJoin || cur->kind == OpKind::NativeScan) {
+    // materialised sources: joins, Parquet scans, sorts, limits — and an aggregate BELOW other operators (nothing fuses
+    // across a pipeline breaker: its result is materialised in HBM and read like a scan)
+    if (cur->kind == OpKind::HashJoin || cur->kind == OpKind::NativeScan || cur->kind == OpKind::Sort || cur->kind == OpKind::Limit ||
+        (cur->kind == OpKind::HashAgg && cur != &root)) {
       if (!source_types) throw CometError("internal: materialised source without a schema");
       break;
     }
@@ -2106,5 +2109,74 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   return d;
 }
 
-}  // namespace comet
+// ---------------------------------------------------------------------------------------------
+// Sort keys (Sort operator, planner.rs:1488-1522 → DataFusion SortExec): every row gets an order-preserving byte string —
+// per sort expression one NULL-ordering byte (NULLS FIRST: NULL = 0x00 < 0x01; NULLS LAST: NULL = 0x01 > 0x00) followed by the
+// value big-endian with the sign bit flipped (floats through the IEEE totalOrder key), inverted for DESC; NULL rows carry zero
+// value bytes.  The bytes are stored as PLANES (plane b = byte b of every row) so that the executor's LSD radix sort reads one
+// plane per pass.  prm.out[0] = planes (W × n bytes), prm.n = rows.
+// ---------------------------------------------------------------------------------------------
+PipelineDesc generate_sort_keys(const Operator& sort, const std::vector<DType>& types, const std::vector<bool>& valid) {
+  if (sort.kind != OpKind::Sort || sort.sort_orders.empty()) throw CometError("Sort needs at least one sort expression");
+  PipelineDesc d;
+  d.sink = SinkKind::Output;
+  d.R = 1;
+  d.op_names.push_back("Sort");
+  d.in_types = types;
+  std::ostringstream src, ex;
+  src << "// generated by datafusion-comet_amd codegen — sort keys\n#include \"comet_device.hpp\"\nusing namespace comet;\n";
+  src << "struct P {\n  static constexpr int R = 1;\n";
+  Gen g(types, valid);
+  g.locate = [](int idx) { return std::make_pair(idx, std::string("i")); };
+  int W = 0;
+  std::vector<std::string> stores;   // statements writing the bytes of one row
+  for (auto& k : sort.sort_orders) {
+    Val v = g.named(g.gen(k.child));
+    const std::string ok = v.ok.empty() ? "true" : v.ok;
+    const std::string inv = k.descending ? "~" : "";
+    // NULL-ordering byte
+    stores.push_back("K[(i64)" + std::to_string(W) + " * n + i] = (u8)(" + ok + " ? " + (k.nulls_last ? "0" : "1") + " : " + (k.nulls_last ? "1" : "0") + ");");
+    W++;
+    int nb = 0;
+    std::string word;   // unsigned order-preserving word(s)
+    switch (v.rep) {
+      case Rep::B: nb = 1; word = "(u64)(" + v.v + " ? 1 : 0)"; break;
+      case Rep::I32: nb = 4; word = "(u64)((u32)(i32)" + v.v + " ^ 0x80000000u)"; break;
+      case Rep::I64: nb = v.t.id == TypeId::Decimal ? 16 : 8; word = "((u64)(i64)" + v.v + " ^ 0x8000000000000000ull)"; break;
+      case Rep::F32: nb = 4; word = "(u64)((u32)comet::f32_total_key(" + v.v + ") ^ 0x80000000u)"; break;
+      case Rep::F64: nb = 8; word = "((u64)comet::f64_total_key(" + v.v + ") ^ 0x8000000000000000ull)"; break;
+      case Rep::I128: nb = 16; break;
+      default: throw CometError("Sort on " + v.t.str() + " is not supported by the MI355X native engine yet");
+    }
+    if (nb == 16) {
+      // 128-bit: hi word (sign flipped) then lo word; a narrow decimal (i64 rep) sign-extends
+      const std::string v128 = v.rep == Rep::I128 ? v.v : "(i128)(i64)" + v.v;
+      const std::string hi = "(comet::hi64(" + v128 + ") ^ 0x8000000000000000ull)", lo = "comet::lo64(" + v128 + ")";
+      for (int b = 0; b < 8; b++)
+        stores.push_back("K[(i64)" + std::to_string(W + b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + hi + " >> " + std::to_string(56 - 8 * b) + ")) : 0);");
+      for (int b = 0; b < 8; b++)
+        stores.push_back("K[(i64)" + std::to_string(W + 8 + b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + lo + " >> " + std::to_string(56 - 8 * b) + ")) : 0);");
+    } else {
+      for (int b = 0; b < nb; b++)
+        stores.push_back("K[(i64)" + std::to_string(W + b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + word + " >> " + std::to_string(8 * (nb - 1 - b)) + ")) : 0);");
+    }
+    W += nb;
+    ex << "  sort key: " << explain_expr(k.child) << (k.descending ? " DESC" : " ASC") << (k.nulls_last ? " NULLS LAST" : " NULLS FIRST") << "\n";
+  }
+  if (W > 255) throw CometError("Sort key wider than 255 bytes");
+  for (auto& st : stores) g.stmt(st);
+  std::string body = g.decls + g.body();
+  for (size_t p0 = body.find("[r]"); p0 != std::string::npos; p0 = body.find("[r]")) body.replace(p0, 3, "[0]");
+  src << "  static __device__ __forceinline__ void keys(const CometKParams& prm, i64 i) {\n    u8* K = (u8*)prm.out[0];\n    const i64 n = prm.n;\n"
+      << "    bool k[R] = {true};\n" << body << "  }\n};\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_sortkey(const CometKParams prm) {\n"
+      << "  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < prm.n; i += (i64)gridDim.x * 256) P::keys(prm, i);\n}\n";
+  d.kernels = {"k_sortkey"};
+  d.sort_key_bytes = W;
+  if (sort.fetch >= 0) ex << "  fetch " << sort.fetch << "\n";
+  d.source = src.str();
+  d.explain = ex.str();
+  return d;
+}
 
+}  // namespace comet

@@ -35,6 +35,7 @@ struct PipelineDesc {
   std::vector<std::string> kernels;  // extern "C" kernel names present in `source`
   // static row bound under which decimal sums cannot overflow (Appendix C.1 rule); 0 = no limit
   long long max_rows_exact = 0;
+  int sort_key_bytes = 0;           // generate_sort_keys: width of one row's key
   bool join_build_only = false;     // LeftSemi/LeftAnti built on the left: only the tail pass produces rows
   bool join_outer_build = false;    // hash join that must also emit the build rows no probe row matched
   std::string explain;             // human-readable fused plan
@@ -47,6 +48,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
                                const std::vector<DType>* source_types = nullptr, const std::vector<int>* str_fixed_len = nullptr);
 
 // Hash join of two materialised tables (left/right = the join's children in plan order).
+// Sort: the kernel that writes every row's order-preserving key bytes (byte planes)
+PipelineDesc generate_sort_keys(const Operator& sort, const std::vector<DType>& types, const std::vector<bool>& has_validity);
 PipelineDesc generate_join(const Operator& join, const std::vector<DType>& left_types, const std::vector<DType>& right_types,
                            const std::vector<bool>& left_has_validity, const std::vector<bool>& right_has_validity);
 

@@ -118,6 +118,25 @@ __global__ __launch_bounds__(256) void take_bits_kernel(const u8* src, const u32
   }
 }
 
+// ---- LSD radix sort over key byte planes (Sort operator): one pass = gather the pass's digit through the current permutation,
+// group stably by digit with the partition kernels above (P = 256), compose the permutations with a take.
+__global__ __launch_bounds__(256) void sort_iota_kernel(u32* perm, i64 n, u32 first) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) perm[i] = first + (u32)i;
+}
+__global__ __launch_bounds__(256) void sort_gather_digit_kernel(const u8* plane, const u32* perm, i64 n, i32* digit) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) digit[i] = (i32)plane[perm[i]];
+}
+// flags[b] = 1 iff plane b holds more than one distinct byte (constant planes need no pass)
+__global__ __launch_bounds__(256) void sort_plane_varies_kernel(const u8* planes, i64 n, int W, u32* flags) {
+  const int b = blockIdx.y;
+  if (b >= W) return;
+  const u8* plane = planes + (i64)b * n;
+  const u8 first = plane[0];
+  bool diff = false;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n && !diff; i += (i64)gridDim.x * 256) diff = plane[i] != first;
+  if (__ballot(diff) != 0 && lane_id() == 0) flags[b] = 1;
+}
+
 int grid_for(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -156,6 +175,23 @@ int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n
     case 8: hipLaunchKernelGGL(take_kernel<u64>, grid_for(n), 256, 0, st, (const u64*)src, idx, (i64)n, (u64*)dst); break;
     case 16: hipLaunchKernelGGL(take_kernel<i128>, grid_for(n), 256, 0, st, (const i128*)src, idx, (i64)n, (i128*)dst); break;
     default: return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(sort_iota_kernel, grid_for(n), 256, 0, (hipStream_t)stream, perm, (i64)n, first);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_sort_gather_digit(const uint8_t* plane, const uint32_t* perm, int64_t n, int32_t* digit, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(sort_gather_digit_kernel, grid_for(n), 256, 0, (hipStream_t)stream, plane, perm, (i64)n, digit);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_sort_plane_varies(const uint8_t* planes, int64_t n, int W, uint32_t* flags, void* stream) {
+  if (n > 0 && W > 0) {
+    i64 g = (n + 255) / 256;
+    dim3 grid((unsigned)(g > 512 ? 512 : g), (unsigned)W);
+    hipLaunchKernelGGL(sort_plane_varies_kernel, grid, 256, 0, (hipStream_t)stream, planes, (i64)n, W, flags);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -128,6 +128,13 @@ extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const 
                                                  int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
+extern "C" int64_t comet_partition_tiles(int64_t n);
+extern "C" int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
+                                              uint32_t* row_indices, void* stream);
+extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream);
+extern "C" int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stream);
+extern "C" int comet_launch_sort_gather_digit(const uint8_t* plane, const uint32_t* perm, int64_t n, int32_t* digit, void* stream);
+extern "C" int comet_launch_sort_plane_varies(const uint8_t* planes, int64_t n, int W, uint32_t* flags, void* stream);
 extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream);
 
 namespace {
@@ -291,7 +298,11 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
   std::function<void(const Operator&)> walk = [&](const Operator& op) {
     node_id_[&op] = (int)node_id_.size();
     if (op.kind == OpKind::Scan) scan_input_[&op] = scan_input_.size();
-    if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan) has_join_ = true;   // sources materialised in HBM
+    if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan || op.kind == OpKind::Sort || op.kind == OpKind::Limit) has_join_ = true;   // sources materialised in HBM
+    if (op.kind == OpKind::HashAgg && &op != plan_.get()) {
+      // an aggregate below other operators: materialised too, unless it is the sink of the root chain (checked below)
+      nested_aggs_.push_back(&op);
+    }
     if (op.kind == OpKind::Unsupported)
       throw CometError(std::string("Operator ") + op_name(op.proto_tag) + " is not supported by the MI355X native engine");
     for (auto& c : op.children) walk(*c);
@@ -302,10 +313,11 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     throw CometError("Plan has " + std::to_string(scan_input_.size()) + " Scan leaves but " + std::to_string(inputs_.size()) + " input streams were given");
   // the root chain ends at a Scan or at the first join below it
   root_source_ = plan_.get();
-  while (root_source_->kind != OpKind::Scan && root_source_->kind != OpKind::HashJoin && root_source_->kind != OpKind::NativeScan) {
+  while (!is_source(*root_source_, plan_.get())) {
     if (root_source_->children.size() != 1) throw CometError(std::string(op_name(root_source_->proto_tag)) + " expects exactly one child");
     root_source_ = root_source_->children[0].get();
   }
+  if (root_source_->kind == OpKind::HashAgg) has_join_ = true;   // operators above an aggregate: the aggregate is materialised
   // Validate the plan shape eagerly (generated, not compiled) so that unsupported operators fail at createPlan
   // like the reference's planner would on first execute.
   if (!has_join_) {
@@ -328,8 +340,33 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
 }
 
 // Output schema of a sub-plan (no data needed): Scan fields, chain outputs, join = left ++ right (semi/anti: left)
+// Where a fused chain stops: Scan leaves and everything whose result is materialised in HBM — joins, Parquet scans, sorts,
+// limits, and an aggregate that is not the top of the chain being fused.
+bool ExecutionContext::is_source(const Operator& op, const Operator* chain_top) {
+  switch (op.kind) {
+    case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: return true;
+    case OpKind::HashAgg: return &op != chain_top;
+    default: return false;
+  }
+}
+
 std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
   if (op.kind == OpKind::Scan) return op.scan_fields;
+  if (op.kind == OpKind::Sort || op.kind == OpKind::Limit) {
+    if (op.children.size() != 1) throw CometError(std::string(op_name(op.proto_tag)) + " expects exactly one child");
+    std::vector<DType> st = infer_schema(*op.children[0]);
+    if (op.kind == OpKind::Sort) {
+      std::vector<bool> none(st.size(), false);
+      PipelineDesc d = generate_sort_keys(op, st, none);   // validates the sort expressions
+      if (compile_in_infer_) jit_compile(d.source);
+      explain_ += d.explain;
+    } else {
+      if (op.limit != -1 && op.offset > op.limit)
+        throw CometError("Invalid limit/offset combination: [" + std::to_string(op.limit) + ". " + std::to_string(op.offset) + "]");
+      explain_ += "  limit " + std::to_string(op.limit) + " offset " + std::to_string(op.offset) + "\n";
+    }
+    return st;
+  }
   if (op.kind == OpKind::NativeScan) {
     if (!op.partition_schema.empty()) throw CometError("Hive-partition columns are not supported by the GPU Parquet scan yet");
     std::vector<DType> out;
@@ -349,14 +386,15 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     return out;
   }
   const Operator* src = &op;
-  while (src->kind != OpKind::Scan && src->kind != OpKind::HashJoin && src->kind != OpKind::NativeScan) {
+  do {
     if (src->children.size() != 1) throw CometError(std::string(op_name(src->proto_tag)) + " expects exactly one child");
     src = src->children[0].get();
-  }
+  } while (!is_source(*src, &op));
   std::vector<DType> st = infer_schema(*src);
   std::vector<bool> none(st.size(), false);
   PipelineDesc d = generate_pipeline(op, none, &st);
-  if (d.sink != SinkKind::Output) throw CometError("an aggregate below a join in the same native plan is not supported yet");
+  if (d.sink == SinkKind::AggNoGroup && &op != plan_.get())
+    throw CometError("an ungrouped aggregate below other operators in the same native plan is not supported yet");
   if (compile_in_infer_) jit_compile(d.source);
   explain_ += d.explain;
   std::vector<DType> out;
@@ -1339,7 +1377,7 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
 // Filter/Project chain `top` over the resident table `in` → resident table
 DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTable& in) {
   auto pv = planned_variant(top, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&top] + 1)), in.has_valid, true, &in.types);
-  if (pv->desc.sink != SinkKind::Output) throw CometError("an aggregate below a join in the same native plan is not supported yet");
+  if (pv->desc.sink != SinkKind::Output) throw CometError("internal: run_chain_to_device on an aggregate chain");
   Variant v;
   v.desc = pv->desc;
   v.mod = jit_load(pv->code);
@@ -1563,13 +1601,178 @@ DevTable ExecutionContext::materialize(const Operator& op) {
     DevTable r = materialize(*op.children[1]);
     return hash_join(op, l, r);
   }
+  if (op.kind == OpKind::Sort) {
+    DevTable in = materialize(*op.children[0]);
+    return sort_table(op, in);
+  }
+  if (op.kind == OpKind::Limit) {
+    // LocalLimitExec / GlobalLimitExec (planner.rs:1436-1470): rows [offset, limit) of the child, in its order
+    DevTable in = materialize(*op.children[0]);
+    const int64_t off = std::min<int64_t>(std::max(0, op.offset), in.rows);
+    const int64_t end = op.limit < 0 ? in.rows : std::min<int64_t>(in.rows, op.limit);
+    return take_rows(in, nullptr, off, std::max<int64_t>(0, end - off), nullptr);
+  }
+  if (op.kind == OpKind::HashAgg) return nested_aggregate(op);   // an aggregate below other operators
   // Filter / Projection chain: fused over its source
   const Operator* src = &op;
-  while (src->kind != OpKind::Scan && src->kind != OpKind::HashJoin && src->kind != OpKind::NativeScan) src = src->children[0].get();
+  do src = src->children[0].get(); while (!is_source(*src, &op));
   DevTable in = materialize(*src);
   DevTable out = run_chain_to_device(op, in);
   HIP_CHECK(hipStreamSynchronize(stream_));
   return out;
+}
+
+// rows [first, first + rows) of `in` in the order given by dev_perm (nullptr = identity) → a new resident table
+DevTable ExecutionContext::take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner) {
+  DevTable out;
+  out.rows = rows;
+  out.types = in.types;
+  out.has_valid = in.has_valid;
+  out.cols.assign(in.cols.size(), DeviceColumnView());
+  std::shared_ptr<DevBuf> perm = perm_owner;
+  if (!dev_perm) {
+    perm = std::make_shared<DevBuf>();
+    perm->ensure((size_t)std::max<int64_t>(rows, 1) * 4);
+    if (comet_launch_sort_iota((uint32_t*)perm->p, rows, (uint32_t)first, stream_) != 0) throw CometError("limit: launch failed");
+    dev_perm = (const uint32_t*)perm->p;
+    first = 0;
+  }
+  const uint32_t* idx = dev_perm + first;
+  for (size_t c = 0; c < in.cols.size(); c++) {
+    const DType& t = in.types[c];
+    if (t.id == TypeId::String || t.id == TypeId::Bytes) throw CometError("Utf8 columns cannot pass through Sort / Limit on the GPU yet");
+    if (in.cols[c].offset != 0) throw CometError("Sort / Limit over a column with a non-zero Arrow offset is not supported yet");
+    const int w = t.id == TypeId::Bool ? 0 : fixed_width(t);
+    auto vals = std::make_shared<DevBuf>();
+    vals->ensure((w ? (size_t)std::max<int64_t>(rows, 1) * w : (size_t)((rows + 7) / 8)) + 16);
+    if (rows && comet_launch_take(w, in.cols[c].data, idx, rows, vals->p, stream_) != 0) throw CometError("take: unsupported width");
+    out.cols[c].data = vals->p;
+    out.owners.push_back(vals);
+    if (in.has_valid[c]) {
+      auto bm = std::make_shared<DevBuf>();
+      bm->ensure((size_t)((rows + 7) / 8) + 16);
+      if (rows && comet_launch_take(0, in.cols[c].valid, idx, rows, bm->p, stream_) != 0) throw CometError("take: validity");
+      out.cols[c].valid = (const uint8_t*)bm->p;
+      out.owners.push_back(bm);
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));   // `in` (and the permutation) may be released by the caller
+  return out;
+}
+
+// Sort (planner.rs:1488-1522 → SortExec with fetch / skip): order-preserving key bytes per row (generated kernel), LSD radix
+// sort of a row permutation over the byte planes that actually vary, then one take per column of rows [skip, skip+fetch).
+DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
+  const int64_t n = in.rows;
+  if (n >= ((int64_t)1 << 32)) throw CometError("Sort: more than 2^32 rows in one partition");
+  std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&sop] + 1))) + ":S:" + validity_key(in.has_valid);
+  std::shared_ptr<PlannedVariant> pv;
+  {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    if (it != g_plan_cache.end()) pv = it->second;
+  }
+  if (!pv) {
+    pv = std::make_shared<PlannedVariant>();
+    pv->desc = generate_sort_keys(sop, in.types, in.has_valid);
+    pv->code = jit_compile(pv->desc.source);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plan_cache[key] = pv;
+  }
+  const int64_t skip = std::min<int64_t>(std::max(0, sop.skip), n);
+  const int64_t keep = sop.fetch >= 0 ? std::min<int64_t>(n, sop.fetch) : n;     // fetch counts from the first row (GlobalLimit(skip) on top)
+  const int64_t out_rows = std::max<int64_t>(0, keep - skip);
+  if (n == 0 || out_rows == 0) return take_rows(in, nullptr, 0, 0, nullptr);
+  Variant v;
+  v.desc = pv->desc;
+  v.mod = jit_load(pv->code);
+  const int W = v.desc.sort_key_bytes;
+  auto planes = std::make_shared<DevBuf>();
+  planes->ensure((size_t)W * (size_t)n + 16);
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  prm.n = n;
+  for (size_t i = 0; i < in.cols.size(); i++) {
+    prm.in[i].data = in.cols[i].data;
+    prm.in[i].valid = in.has_valid[i] ? in.cols[i].valid : nullptr;
+    prm.in[i].aux = in.cols[i].aux;
+    prm.in[i].offset = in.cols[i].offset;
+  }
+  prm.out[0] = planes->p;
+  prm.out[kOutErr] = err_flags_.p;
+  timed_begin();
+  launch(v, "k_sortkey", (int)std::min<int64_t>((n + 255) / 256, 256 * 8), prm);
+  // which planes vary at all?
+  DevBuf flags;
+  flags.ensure((size_t)W * 4 + 16);
+  HIP_CHECK(hipMemsetAsync(flags.p, 0, (size_t)W * 4, stream_));
+  if (comet_launch_sort_plane_varies((const uint8_t*)planes->p, n, W, (uint32_t*)flags.p, stream_) != 0) throw CometError("sort: launch failed");
+  std::vector<uint32_t> varies((size_t)W);
+  small_host_.ensure(4096);
+  HIP_CHECK(hipMemcpyAsync(small_host_.p, flags.p, (size_t)W * 4, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  memcpy(varies.data(), small_host_.p, (size_t)W * 4);
+  auto perm = std::make_shared<DevBuf>();
+  auto perm2 = std::make_shared<DevBuf>();
+  DevBuf digit, ridx, hist, starts;
+  perm->ensure((size_t)n * 4 + 16);
+  perm2->ensure((size_t)n * 4 + 16);
+  digit.ensure((size_t)n * 4 + 16);
+  ridx.ensure((size_t)n * 4 + 16);
+  const int64_t Wt = comet_partition_tiles(n);
+  hist.ensure(((size_t)256 * (size_t)Wt + 1) * 8 + 16);
+  starts.ensure(257 * 8);
+  uint32_t* bad = (uint32_t*)((char*)hist.p + ((size_t)256 * (size_t)Wt + 1) * 8);
+  HIP_CHECK(hipMemsetAsync(bad, 0, 4, stream_));
+  if (comet_launch_sort_iota((uint32_t*)perm->p, n, 0, stream_) != 0) throw CometError("sort: launch failed");
+  int passes = 0;
+  for (int b = W - 1; b >= 0; b--) {
+    if (!varies[(size_t)b]) continue;
+    const uint8_t* plane = (const uint8_t*)planes->p + (size_t)b * (size_t)n;
+    if (comet_launch_sort_gather_digit(plane, (const uint32_t*)perm->p, n, (int32_t*)digit.p, stream_) != 0 ||
+        comet_launch_partition_indices((const int32_t*)digit.p, n, 256, (uint64_t*)hist.p, bad, (int64_t*)starts.p, (uint32_t*)ridx.p, stream_) != 0 ||
+        comet_launch_take(4, perm->p, (const uint32_t*)ridx.p, n, perm2->p, stream_) != 0)
+      throw CometError("sort: launch failed");
+    std::swap(perm, perm2);
+    passes++;
+  }
+  timed_end();
+  if (getenv("COMET_TRACE_STAGES")) fprintf(stderr, "[comet] sort: %lld rows, key %d bytes, %d radix passes\n", (long long)n, W, passes);
+  DevTable out = take_rows(in, (const uint32_t*)perm->p, skip, out_rows, perm);
+  out.owners.push_back(v.mod);
+  return out;
+}
+
+// An aggregate below other operators (Sort / Project / Filter / join over a HashAggregate): it runs as its own execution
+// context over the input streams of its sub-tree, and its grouped result is handed over resident in HBM.
+DevTable ExecutionContext::nested_aggregate(const Operator& agg) {
+  // the Scan leaves of the sub-tree, in depth-first order, are a contiguous range of this context's inputs
+  std::vector<size_t> idx;
+  std::function<void(const Operator&)> walk = [&](const Operator& op) {
+    if (op.kind == OpKind::Scan) idx.push_back(scan_input_.at(&op));
+    for (auto& c : op.children) walk(*c);
+  };
+  walk(agg);
+  std::vector<InputSource> sub_inputs;
+  for (size_t i : idx) {
+    sub_inputs.push_back(inputs_[i]);
+    inputs_[i].host = nullptr;      // ownership moves to the sub-context (it releases the streams)
+    inputs_[i].dev = nullptr;
+    inputs_[i].exhausted = true;
+  }
+  // the sub-plan shares the Operator nodes: wrap the node in a non-owning shared_ptr
+  OperatorP sub_plan(const_cast<Operator*>(&agg), [](Operator*) {});
+  ExecutionContext sub(sub_plan, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&agg] + 1)), config_, sub_inputs, 0, device_id_);
+  if (sub.sink_ != SinkKind::AggGrouped) throw CometError("an ungrouped aggregate below other operators in the same native plan is not supported yet");
+  sub.start();
+  sub.run_to_completion();
+  DevTable t = sub.grouped_to_device();
+  input_rows += sub.input_rows;
+  for (auto& pr : sub.timed_) (void)pr;
+  sub.collect_timings();
+  last_kernel_ms += sub.last_kernel_ms;
+  last_kernel_launches += sub.last_kernel_launches;
+  return t;
 }
 
 // resident table → host batches of ≤ batch_size rows (root of a plan that ends in a join)

@@ -124,6 +124,10 @@ class ExecutionContext {
   DevTable scan_parquet(const Operator& native_scan);
   DevTable run_chain_to_device(const Operator& top, const DevTable& in);
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
+  DevTable sort_table(const Operator& s, const DevTable& in);
+  DevTable take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner);
+  DevTable nested_aggregate(const Operator& agg);
+  static bool is_source(const Operator& op, const Operator* chain_top);
   DevTable outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals, const std::vector<std::shared_ptr<DevBuf>>& valid_bytes,
                             int64_t rows);
   void table_to_host_batches(const DevTable& t);
@@ -162,6 +166,7 @@ class ExecutionContext {
   SinkKind sink_ = SinkKind::Output;
   bool has_join_ = false;
   bool compile_in_infer_ = false;
+  std::vector<const Operator*> nested_aggs_;       // aggregates that are not the plan root (materialised by sub-contexts)
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from
   std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)
   std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index

@@ -142,6 +142,10 @@ struct Operator {
   bool null_aware_anti = false;
   // Limit
   int limit = -1, offset = 0;
+  // Sort (operator.proto:641-645; SortOrder expr.proto:385-389)
+  struct SortKey { ExprP child; bool descending = false; bool nulls_last = false; };
+  std::vector<SortKey> sort_orders;
+  int fetch = -1, skip = 0;
   // NativeScan
   std::vector<StructField> required_schema, data_schema, partition_schema;
   std::vector<ExprP> data_filters;

@@ -364,6 +364,36 @@ OperatorP decode_operator_r(Reader r) {
           else b.skip(wt2);
         }
         break;
+      case 103:
+        op->kind = OpKind::Sort;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) {
+            // Expr { sort_order = 19 : SortOrder { child = 1, direction = 2, null_ordering = 3 } }
+            Reader e = b.sub();
+            Operator::SortKey k;
+            while (!e.done()) {
+              int wt3, f3 = e.tag(wt3);
+              if (f3 == 19 && wt3 == 2) {
+                Reader so = e.sub();
+                while (!so.done()) {
+                  int wt4, f4 = so.tag(wt4);
+                  if (f4 == 1 && wt4 == 2) k.child = decode_expr(so.sub());
+                  else if (f4 == 2 && wt4 == 0) k.descending = so.varint() == 1;
+                  else if (f4 == 3 && wt4 == 0) k.nulls_last = so.varint() == 1;
+                  else so.skip(wt4);
+                }
+              } else {
+                e.skip(wt3);
+              }
+            }
+            if (!k.child) throw CometError("Sort: sort_orders entry is not a SortOrder expression");
+            op->sort_orders.push_back(k);
+          } else if (f2 == 3 && wt2 == 0) op->fetch = (int)(int32_t)b.varint();
+          else if (f2 == 4 && wt2 == 0) op->skip = (int)(int32_t)b.varint();
+          else b.skip(wt2);
+        }
+        break;
       case 105:
         op->kind = OpKind::Limit;
         while (!b.done()) {

@@ -340,9 +340,15 @@ class Operator:
     # native_scan
     field_names: List[str] = field(default_factory=list)
     case_sensitive: bool = True
+    # sort / limit
+    sort_orders: List[tuple] = field(default_factory=list)   # (expr, descending, nulls_last)
+    fetch: Optional[int] = None
+    skip: int = 0
+    limit: int = -1
+    offset: int = 0
     files: List[tuple] = field(default_factory=list)          # (path, start, length, file_size)
 
-    TAGS = dict(scan=100, projection=101, filter=102, hash_agg=104, hash_join=109, native_scan=111)
+    TAGS = dict(scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, hash_join=109, native_scan=111)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -359,6 +365,18 @@ class Operator:
             body += b"".join(_f_msg(2, a.encode()) for a in self.aggs)
             if self.mode:
                 body += _f_varint(5, self.mode)
+        elif self.kind == "sort":
+            # Sort{sort_orders=1 (Expr{sort_order=19 SortOrder{child=1,direction=2,null_ordering=3}}), fetch=3, skip=4} (operator.proto:641-645)
+            body = b""
+            for e, desc, nulls_last in self.sort_orders:
+                so = _f_msg(1, e.encode()) + (_f_varint(2, 1) if desc else b"") + (_f_varint(3, 1) if nulls_last else b"")
+                body += _f_msg(1, _f_msg(19, so))
+            if self.fetch is not None:
+                body += _f_varint(3, self.fetch)
+            if self.skip:
+                body += _f_varint(4, self.skip)
+        elif self.kind == "limit":
+            body = (_f_varint(1, self.limit) if self.limit else b"") + (_f_varint(2, self.offset) if self.offset else b"")
         elif self.kind == "native_scan":
             # NativeScan{common=1 NativeScanCommon{required_schema=1,data_schema=2,projection_vector=5,session_timezone=6,
             # case_sensitive=9,source=12,fields=13}, file_partition=2 SparkFilePartition{partitioned_file=1}} (operator.proto:103-190)
@@ -405,6 +423,16 @@ def project(child: Operator, exprs: Sequence[Expr]) -> Operator:
 
 def hash_agg(child: Operator, grouping: Sequence[Expr], aggs: Sequence[AggExpr], mode: int = PARTIAL) -> Operator:
     return Operator("hash_agg", [child], exprs=list(grouping), aggs=list(aggs), mode=mode)
+
+
+def sort(child: Operator, orders: Sequence, fetch: Optional[int] = None, skip: int = 0) -> Operator:
+    """orders: (expr, descending) or (expr, descending, nulls_last); Spark's defaults are ASC NULLS FIRST / DESC NULLS LAST."""
+    so = [(o[0], bool(o[1]), bool(o[2]) if len(o) > 2 else bool(o[1])) for o in orders]
+    return Operator("sort", [child], sort_orders=so, fetch=fetch, skip=skip)
+
+
+def limit(child: Operator, n: int, offset: int = 0) -> Operator:
+    return Operator("limit", [child], limit=n, offset=offset)
 
 
 def final_of(partial_plan: "Operator", state_schema) -> "Operator":

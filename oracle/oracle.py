@@ -470,6 +470,47 @@ def run_plan(S, op, table) -> List[Col]:
         return [ev.eval(e, child, n) for e in op.exprs]
     if k == "hash_agg":
         return _hash_agg(S, ev, op, child, n)
+    if k == "limit":
+        # LocalLimitExec / GlobalLimitExec (planner.rs:1436-1470): rows [offset, limit)
+        lo = min(max(0, op.offset), n)
+        hi = n if op.limit < 0 else min(n, op.limit)
+        return [_take(c, np.arange(lo, max(lo, hi))) for c in child]
+    if k == "sort":
+        # SortExec (planner.rs:1488-1522): lexicographic over the sort orders; NULLS FIRST/LAST per key; floats in IEEE totalOrder
+        # (arrow-ord); ties in arbitrary order (tests compare the keys and the multiset); fetch, then skip
+        import functools
+        keys = [(ev.eval(e, child, n), desc, nl) for e, desc, nl in op.sort_orders]
+
+        def total(c, i):
+            v = c.values[i]
+            if c.dtype.type_id == S.DECIMAL:
+                return dec_to_int(c.values, i)
+            if c.dtype.type_id in (S.FLOAT, S.DOUBLE):
+                bits = np.array([v], dtype=np.float64 if c.dtype.type_id == S.DOUBLE else np.float32).view(np.int64 if c.dtype.type_id == S.DOUBLE else np.int32)[0]
+                w = 63 if c.dtype.type_id == S.DOUBLE else 31
+                return int(bits) ^ (((1 << w) - 1) if bits < 0 else 0)
+            return v.item() if hasattr(v, "item") else v
+
+        def cmp(i, j):
+            for c, desc, nulls_last in keys:
+                ni, nj = not c.ok()[i], not c.ok()[j]
+                if ni or nj:
+                    if ni and nj:
+                        continue
+                    first = i if ni else j            # the NULL row
+                    r = -1 if first == i else 1
+                    return r if not nulls_last else -r
+                a, b = total(c, i), total(c, j)
+                if a != b:
+                    r = -1 if a < b else 1
+                    return -r if desc else r
+            return 0
+        order = sorted(range(n), key=functools.cmp_to_key(cmp))
+        if op.fetch is not None and op.fetch >= 0:
+            order = order[:op.fetch]
+        if op.skip:
+            order = order[op.skip:]
+        return [_take(c, np.array(order, dtype=np.int64)) for c in child]
     raise NotImplementedError(k)
 
 
