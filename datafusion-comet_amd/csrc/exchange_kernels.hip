@@ -16,7 +16,13 @@ using namespace comet;
 
 namespace {
 
-constexpr int kPartTile = 8192;  // rows per wave tile
+constexpr int kPartTileMax = 8192;  // rows per wave tile for large inputs
+// rows per wave tile: large tiles keep the histogram small, but a small input must still fill the GPU (≥ ~4096 waves)
+__host__ __device__ inline i64 part_tile_rows(i64 n) {
+  i64 t = n / 4096;
+  t = (t + 63) / 64 * 64;
+  return t < 512 ? 512 : (t > kPartTileMax ? kPartTileMax : t);
+}
 
 // Visit the groups of equal partition id among the active lanes of this wave, in lane order of their first member.
 // f(leader_lane, pid_of_group, member_mask) is called uniformly by the whole wave.
@@ -34,6 +40,7 @@ __device__ __forceinline__ void for_each_group(i32 pid, bool active, F f) {
 
 __global__ __launch_bounds__(256) void part_hist_kernel(const i32* pids, i64 n, i32 P, i64 W, u64* hist, u32* bad) {
   extern __shared__ u32 s_cnt[];  // [4][P]
+  const i64 tile = part_tile_rows(n);
   u32* mine = s_cnt + wave_id() * P;
   const i64 block_tiles = (W + 3) / 4;
   for (i64 bt = blockIdx.x; bt < block_tiles; bt += gridDim.x) {
@@ -41,7 +48,7 @@ __global__ __launch_bounds__(256) void part_hist_kernel(const i32* pids, i64 n, 
     for (int p = lane_id(); p < P; p += kWave) mine[p] = 0;
     __syncthreads();
     if (g < W) {
-      const i64 lo = g * kPartTile, hi = lo + kPartTile < n ? lo + kPartTile : n;
+      const i64 lo = g * tile, hi = lo + tile < n ? lo + tile : n;
       for (i64 base = lo; base < hi; base += kWave) {
         const i64 i = base + lane_id();
         const bool active = i < hi;
@@ -67,6 +74,7 @@ __global__ __launch_bounds__(256) void part_starts_kernel(const u64* scanned, i3
 
 __global__ __launch_bounds__(256) void part_index_kernel(const i32* pids, i64 n, i32 P, i64 W, const u64* scanned, u32* row_indices) {
   extern __shared__ u32 s_cnt[];
+  const i64 tile = part_tile_rows(n);
   u32* run = s_cnt + wave_id() * P;
   const i64 block_tiles = (W + 3) / 4;
   const u64 lt = (1ull << lane_id()) - 1;
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(256) void part_index_kernel(const i32* pids, i64 n,
       for (int p = lane_id(); p < P; p += kWave) run[p] = (u32)scanned[(i64)p * W + g];
     __syncthreads();
     if (g < W) {
-      const i64 lo = g * kPartTile, hi = lo + kPartTile < n ? lo + kPartTile : n;
+      const i64 lo = g * tile, hi = lo + tile < n ? lo + tile : n;
       for (i64 base = lo; base < hi; base += kWave) {
         const i64 i = base + lane_id();
         const bool active = i < hi;
@@ -137,6 +145,38 @@ __global__ __launch_bounds__(256) void sort_plane_varies_kernel(const u8* planes
   if (__ballot(diff) != 0 && lane_id() == 0) flags[b] = 1;
 }
 
+// ---- TopK pre-selection (Sort with fetch ≪ rows): radix select from the most significant varying plane down.
+// hist[d] = number of candidates whose digit is d
+__global__ __launch_bounds__(256) void sort_hist256_kernel(const u8* plane, const u32* cand, i64 m, unsigned long long* hist) {
+  __shared__ u32 s_h[256];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < m; i += (i64)gridDim.x * 256) atomicAdd(&s_h[plane[cand[i]]], 1u);
+  __syncthreads();
+  if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+}
+// candidates with digit < dstar are certainly among the first K: append them to `sure`; digit == dstar stay candidates
+__global__ __launch_bounds__(256) void sort_select_kernel(const u8* plane, const u32* cand, i64 m, int dstar, u32* sure, u32* next_cand, u32* counters) {
+  for (i64 base = (i64)blockIdx.x * 256; base < m; base += (i64)gridDim.x * 256) {
+    const i64 i = base + threadIdx.x;
+    const bool in = i < m;
+    const u32 row = in ? cand[i] : 0;
+    const int d = in ? (int)plane[row] : 256;
+    const bool a = d < dstar, b = d == dstar;
+    const u64 ma = __ballot(a), mb = __ballot(b);
+    u32 offa = 0, offb = 0;
+    if (lane_id() == 0) {
+      if (ma) offa = atomicAdd(&counters[0], (u32)__popcll(ma));
+      if (mb) offb = atomicAdd(&counters[1], (u32)__popcll(mb));
+    }
+    offa = __shfl(offa, 0, kWave);
+    offb = __shfl(offb, 0, kWave);
+    const u64 lt = (1ull << lane_id()) - 1;
+    if (a) sure[offa + (u32)__popcll(ma & lt)] = row;
+    if (b) next_cand[offb + (u32)__popcll(mb & lt)] = row;
+  }
+}
+
 int grid_for(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -146,7 +186,7 @@ int grid_for(i64 n) {
 
 extern "C" {
 
-int64_t comet_partition_tiles(int64_t n) { return n <= 0 ? 1 : (n + kPartTile - 1) / kPartTile; }
+int64_t comet_partition_tiles(int64_t n) { return n <= 0 ? 1 : (n + part_tile_rows(n) - 1) / part_tile_rows(n); }
 
 // hist: (P*W + 1) u64 scratch; bad: one zeroed u32; starts: P+1 i64; row_indices: n u32
 int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
@@ -154,7 +194,7 @@ int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, ui
   hipStream_t st = (hipStream_t)stream;
   const i64 W = comet_partition_tiles(n);
   const i64 block_tiles = (W + 3) / 4;
-  const int grid = (int)(block_tiles > 256 * 8 ? 256 * 8 : block_tiles);
+  const int grid = (int)(block_tiles > 256 * 16 ? 256 * 16 : block_tiles);
   const size_t lds = (size_t)4 * (size_t)P * sizeof(u32);
   hipLaunchKernelGGL(part_hist_kernel, grid, 256, lds, st, pids, (i64)n, P, W, (u64*)hist, bad);
   hipLaunchKernelGGL(part_scan_kernel, 1, 256, 0, st, (u64*)hist, (i64)P * W);
@@ -185,6 +225,15 @@ int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stre
 }
 int comet_launch_sort_gather_digit(const uint8_t* plane, const uint32_t* perm, int64_t n, int32_t* digit, void* stream) {
   if (n > 0) hipLaunchKernelGGL(sort_gather_digit_kernel, grid_for(n), 256, 0, (hipStream_t)stream, plane, perm, (i64)n, digit);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_sort_hist256(const uint8_t* plane, const uint32_t* cand, int64_t m, uint64_t* hist, void* stream) {
+  if (m > 0) hipLaunchKernelGGL(sort_hist256_kernel, grid_for(m), 256, 0, (hipStream_t)stream, plane, cand, (i64)m, (unsigned long long*)hist);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_sort_select(const uint8_t* plane, const uint32_t* cand, int64_t m, int dstar, uint32_t* sure, uint32_t* next_cand, uint32_t* counters,
+                             void* stream) {
+  if (m > 0) hipLaunchKernelGGL(sort_select_kernel, grid_for(m), 256, 0, (hipStream_t)stream, plane, cand, (i64)m, dstar, sure, next_cand, counters);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_sort_plane_varies(const uint8_t* planes, int64_t n, int W, uint32_t* flags, void* stream) {

@@ -135,6 +135,9 @@ extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx
 extern "C" int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stream);
 extern "C" int comet_launch_sort_gather_digit(const uint8_t* plane, const uint32_t* perm, int64_t n, int32_t* digit, void* stream);
 extern "C" int comet_launch_sort_plane_varies(const uint8_t* planes, int64_t n, int W, uint32_t* flags, void* stream);
+extern "C" int comet_launch_sort_hist256(const uint8_t* plane, const uint32_t* cand, int64_t m, uint64_t* hist, void* stream);
+extern "C" int comet_launch_sort_select(const uint8_t* plane, const uint32_t* cand, int64_t m, int dstar, uint32_t* sure, uint32_t* next_cand, uint32_t* counters,
+                                        void* stream);
 extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream);
 
 namespace {
@@ -1714,30 +1717,77 @@ DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
   memcpy(varies.data(), small_host_.p, (size_t)W * 4);
   auto perm = std::make_shared<DevBuf>();
   auto perm2 = std::make_shared<DevBuf>();
-  DevBuf digit, ridx, hist, starts;
   perm->ensure((size_t)n * 4 + 16);
   perm2->ensure((size_t)n * 4 + 16);
-  digit.ensure((size_t)n * 4 + 16);
-  ridx.ensure((size_t)n * 4 + 16);
-  const int64_t Wt = comet_partition_tiles(n);
+  if (comet_launch_sort_iota((uint32_t*)perm->p, n, 0, stream_) != 0) throw CometError("sort: launch failed");
+  int64_t ns = n;   // rows that take part in the full sort
+  int select_passes = 0;
+  if (sop.fetch >= 0 && keep * 8 < n) {
+    // TopK: radix select from the most significant varying plane down.  `sure` rows are certainly among the first `keep`;
+    // only the bucket that straddles the K-th position stays a candidate.  What is left (sure ∪ candidates) is sorted.
+    auto sure = std::make_shared<DevBuf>();
+    sure->ensure((size_t)n * 4 + 16);
+    DevBuf sel;   // [0..255] u64 histogram, then two u32 counters
+    sel.ensure(256 * 8 + 16);
+    HIP_CHECK(hipMemsetAsync((char*)sel.p + 256 * 8, 0, 8, stream_));
+    uint32_t* counters = (uint32_t*)((char*)sel.p + 256 * 8);
+    int64_t m = n, need = keep, nsure = 0;
+    for (int b = 0; b < W && m > std::max<int64_t>(4096, need); b++) {
+      if (!varies[(size_t)b]) continue;
+      const uint8_t* plane = (const uint8_t*)planes->p + (size_t)b * (size_t)n;
+      HIP_CHECK(hipMemsetAsync(sel.p, 0, 256 * 8, stream_));
+      if (comet_launch_sort_hist256(plane, (const uint32_t*)perm->p, m, (uint64_t*)sel.p, stream_) != 0) throw CometError("sort: launch failed");
+      uint64_t h[256];
+      HIP_CHECK(hipMemcpyAsync(small_host_.p, sel.p, 256 * 8, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      memcpy(h, small_host_.p, sizeof h);
+      int dstar = 255;
+      int64_t below = 0;
+      for (int dgt = 0; dgt < 256; dgt++) {
+        if (below + (int64_t)h[dgt] >= need) { dstar = dgt; break; }
+        below += (int64_t)h[dgt];
+      }
+      uint32_t cnt2[2] = {(uint32_t)nsure, 0};
+      write_small(counters, cnt2, 8);
+      if (comet_launch_sort_select(plane, (const uint32_t*)perm->p, m, dstar, (uint32_t*)sure->p, (uint32_t*)perm2->p, counters, stream_) != 0)
+        throw CometError("sort: launch failed");
+      std::swap(perm, perm2);
+      nsure += below;
+      need -= below;
+      m = (int64_t)h[dstar];
+      select_passes++;
+    }
+    // rows to sort = sure ++ remaining candidates
+    if (select_passes) {
+      HIP_CHECK(hipMemcpyAsync((char*)sure->p + (size_t)nsure * 4, perm->p, (size_t)m * 4, hipMemcpyDeviceToDevice, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      perm = sure;
+      ns = nsure + m;
+    }
+  }
+  DevBuf digit, ridx, hist, starts;
+  digit.ensure((size_t)ns * 4 + 16);
+  ridx.ensure((size_t)ns * 4 + 16);
+  const int64_t Wt = comet_partition_tiles(ns);
   hist.ensure(((size_t)256 * (size_t)Wt + 1) * 8 + 16);
   starts.ensure(257 * 8);
   uint32_t* bad = (uint32_t*)((char*)hist.p + ((size_t)256 * (size_t)Wt + 1) * 8);
   HIP_CHECK(hipMemsetAsync(bad, 0, 4, stream_));
-  if (comet_launch_sort_iota((uint32_t*)perm->p, n, 0, stream_) != 0) throw CometError("sort: launch failed");
   int passes = 0;
   for (int b = W - 1; b >= 0; b--) {
     if (!varies[(size_t)b]) continue;
     const uint8_t* plane = (const uint8_t*)planes->p + (size_t)b * (size_t)n;
-    if (comet_launch_sort_gather_digit(plane, (const uint32_t*)perm->p, n, (int32_t*)digit.p, stream_) != 0 ||
-        comet_launch_partition_indices((const int32_t*)digit.p, n, 256, (uint64_t*)hist.p, bad, (int64_t*)starts.p, (uint32_t*)ridx.p, stream_) != 0 ||
-        comet_launch_take(4, perm->p, (const uint32_t*)ridx.p, n, perm2->p, stream_) != 0)
+    if (comet_launch_sort_gather_digit(plane, (const uint32_t*)perm->p, ns, (int32_t*)digit.p, stream_) != 0 ||
+        comet_launch_partition_indices((const int32_t*)digit.p, ns, 256, (uint64_t*)hist.p, bad, (int64_t*)starts.p, (uint32_t*)ridx.p, stream_) != 0 ||
+        comet_launch_take(4, perm->p, (const uint32_t*)ridx.p, ns, perm2->p, stream_) != 0)
       throw CometError("sort: launch failed");
     std::swap(perm, perm2);
     passes++;
   }
   timed_end();
-  if (getenv("COMET_TRACE_STAGES")) fprintf(stderr, "[comet] sort: %lld rows, key %d bytes, %d radix passes\n", (long long)n, W, passes);
+  if (getenv("COMET_TRACE_STAGES"))
+    fprintf(stderr, "[comet] sort: %lld rows, key %d bytes, %d select passes -> %lld rows sorted in %d radix passes\n", (long long)n, W, select_passes,
+            (long long)ns, passes);
   DevTable out = take_rows(in, (const uint32_t*)perm->p, skip, out_rows, perm);
   out.owners.push_back(v.mod);
   return out;

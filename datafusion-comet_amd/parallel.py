@@ -238,12 +238,18 @@ def run_q3_distributed(engine, partitioner, customer, orders, lineitem, group=No
     t0 = clock()
     partial = engine.run_device(plan, [j1, l], ncols)      # Partial states stay in HBM
     t1 = clock()
-    final = engine.run_host(S.final_of(plan, partial.schema), [partial], 4) if partial.num_rows else None
+    # Final aggregate + TakeOrdered (Sort with fetch 10: revenue DESC, o_orderdate ASC, then l_orderkey so that ties are
+    # deterministic) in ONE native plan: only this rank's ten best rows leave the GPU
+    groups = partial.num_rows                      # groups are partition-local: one Partial state row per group
+    local = []
+    if groups:
+        f = S.final_of(plan, partial.schema)
+        top = S.sort(f, [(S.col(3, S.decimal(36, 4)), True, True), (S.col(1, S.T_DATE), False, False), (S.col(0, S.T_INT64), False, False)], fetch=10)
+        t = engine.run_host(top, [partial], 4)
+        local = list(zip(*[t.column(i).to_pylist() for i in range(t.num_columns)])) if t is not None else []
     if timings is not None:
         timings["join2agg"] = timings.get("join2agg", 0.0) + (t1 - t0)
-        timings["final_agg"] = timings.get("final_agg", 0.0) + (clock() - t1)
-    local = q3_top10(final)
-    groups = final.num_rows if final is not None else 0
+        timings["final_agg_top10"] = timings.get("final_agg_top10", 0.0) + (clock() - t1)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local, groups
     rank = dist.get_rank(group)
