@@ -1307,7 +1307,29 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     Gen ge(d.in_types, in_has_validity);
     if (str_fixed_len) ge.str_fixed_len = *str_fixed_len;
     for (auto& c : cols) {
+      const bool is_str_type = c->kind == ExprKind::Bound && c->bound_index >= 0 && (size_t)c->bound_index < d.in_types.size() &&
+                               (d.in_types[(size_t)c->bound_index].id == TypeId::String || d.in_types[(size_t)c->bound_index].id == TypeId::Bytes);
+      if (is_str_type) {
+        // a Utf8 column passed through: emit the source row index, the executor gathers the string afterwards
+        const int src = c->bound_index;
+        ge.in_used[(size_t)src] = true;
+        Val v;
+        v.t = d.in_types[(size_t)src];
+        v.rep = Rep::I64;
+        v.v = "idx[r]";
+        if (in_has_validity[(size_t)src]) v.ok = "comet::ld_valid(prm.in[" + std::to_string(ge.locate(src).first) + "], idx[r])";
+        v = ge.named(v);
+        outs.push_back(v);
+        OutCol oc;
+        oc.type = v.t;
+        oc.nullable = !v.ok.empty();
+        oc.gather_src = src;
+        d.out_cols.push_back(oc);
+        ex << "  output: " << explain_expr(c) << " : " << v.t.str() << " (gathered)\n";
+        continue;
+      }
       Val v = ge.named(ge.gen(c));
+      if (v.rep == Rep::STR) throw CometError("computed Utf8 values cannot be projected by the GPU pipeline yet (only Utf8 columns passed through)");
       outs.push_back(v);
       OutCol oc;
       oc.type = v.t;
@@ -1320,6 +1342,11 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       const Val& v = outs[j];
       std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * j) + "]";
       std::string ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * j + 1) + "]";
+      if (d.out_cols[j].gather_src >= 0) {
+        ge.stmt("((u32*)" + vb + ")[pos[r]] = (u32)" + v.v + ";");
+        if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");
+        continue;
+      }
       const char* st = store_ctype(v.t);
       std::string val = v.v;
       if (v.t.id == TypeId::Decimal) val = v.rep == Rep::I128 ? v.v : "(i128)" + v.v;
@@ -2044,11 +2071,11 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
     const int nout = (mode == 0 && !build_only) ? nl + nr : nl;
     if (nout * 2 + kOutFirstCol > 44) throw CometError("too many output columns for one GPU hash join");
     for (int c = 0; c < nout; c++) {
-      if (ct[c].id == TypeId::String || ct[c].id == TypeId::Bytes) throw CometError("Utf8 payload columns are not supported in a GPU hash join yet");
       const bool is_left = c < nl;
       OutCol oc;
       oc.type = ct[c];
       oc.nullable = cv[c] || (is_left ? keep_right : keep_left);   // the non-preserved side is NULL-extended
+      if (ct[c].id == TypeId::String || ct[c].id == TypeId::Bytes) oc.gather_src = c;   // Utf8 payload: row index now, gathered after the emit
       d.out_cols.push_back(oc);
     }
     // variant 0 = both rows, 1 = probe row only, 2 = build row only
@@ -2060,8 +2087,22 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
       for (int c = 0; c < nout; c++) {
         const bool in_build = ((c < nl) == build_left);
         const bool absent = (variant == 1 && in_build) || (variant == 2 && !in_build);
-        const char* st = store_ctype(ct[c]);
         std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * c) + "]", ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * c + 1) + "]";
+        if (d.out_cols[c].gather_src >= 0) {
+          // Utf8 payload: the source row (build row i or probe row j); NULL when the side is absent or the value is NULL
+          auto loc = locate_combined(c);
+          if (absent) {
+            g.stmt("((u32*)" + vb + ")[pos] = 0u;");
+            g.stmt("((u8*)" + ob + ")[pos] = 0;");
+          } else {
+            g.in_used[(size_t)c] = true;
+            g.stmt("((u32*)" + vb + ")[pos] = (u32)" + loc.second + ";");
+            if (d.out_cols[c].nullable)
+              g.stmt("((u8*)" + ob + ")[pos] = " + (cv[c] ? "comet::ld_valid(prm.in[" + std::to_string(loc.first) + "], " + loc.second + ") ? 1 : 0" : std::string("1")) + ";");
+          }
+          continue;
+        }
+        const char* st = store_ctype(ct[c]);
         if (absent) {
           g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = (" + st + ")0;");
           g.stmt("((u8*)" + ob + ")[pos] = 0;");

@@ -17,6 +17,10 @@ struct OutCol {
   bool nullable = true;
   // AggGrouped string keys come back packed (≤7 bytes + length) in a u64; host expands to Utf8.
   bool packed_string = false;
+  // Utf8/Binary column passed through unchanged: the emit kernel writes the SOURCE ROW INDEX (u32) of every output row and
+  // the executor gathers offsets + bytes afterwards (any string length).  gather_src = source column; for joins it indexes
+  // left ++ right.  -1 = not a gathered column.
+  int gather_src = -1;
 };
 
 // How the host must treat each group-key word / accumulator word of a grouped aggregate.

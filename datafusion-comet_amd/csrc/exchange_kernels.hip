@@ -177,6 +177,32 @@ __global__ __launch_bounds__(256) void sort_select_kernel(const u8* plane, const
   }
 }
 
+// ---- Utf8 take: out row k = source row idx[k].  A row is NULL (→ empty) when its byte in `ok_bytes` is 0 (per OUTPUT row, as
+// written by an emit kernel) or its bit in `src_valid_bits` is 0 (per SOURCE row); either may be null.  Three steps:
+// lengths → exclusive scan into the new offsets → byte copy.
+__device__ __forceinline__ bool utf8_row_valid(const u8* ok_bytes, const u8* src_valid_bits, i64 k, u32 r) {
+  if (ok_bytes && !ok_bytes[k]) return false;
+  if (src_valid_bits && !((src_valid_bits[r >> 3] >> (r & 7)) & 1)) return false;
+  return true;
+}
+__global__ __launch_bounds__(256) void take_utf8_lengths_kernel(const i32* offs, const u32* idx, const u8* ok_bytes, const u8* src_valid_bits, i64 n,
+                                                                u32* lengths) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+    const u32 r = idx[k];
+    lengths[k] = utf8_row_valid(ok_bytes, src_valid_bits, k, r) ? (u32)(offs[r + 1] - offs[r]) : 0u;
+  }
+}
+__global__ __launch_bounds__(256) void take_utf8_copy_kernel(const i32* offs, const u8* bytes, const u32* idx, const u8* ok_bytes, const u8* src_valid_bits,
+                                                             i64 n, const i32* out_offs, u8* out_bytes) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+    const i32 len = out_offs[k + 1] - out_offs[k];
+    if (len <= 0) continue;
+    const u8* src = bytes + offs[idx[k]];
+    u8* dst = out_bytes + out_offs[k];
+    for (i32 b = 0; b < len; b++) dst[b] = src[b];
+  }
+}
+
 int grid_for(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -219,6 +245,17 @@ int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t n,
+                                   uint32_t* lengths, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(take_utf8_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offs, idx, ok_bytes, src_valid_bits, (i64)n, lengths);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits,
+                                int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream) {
+  if (n > 0)
+    hipLaunchKernelGGL(take_utf8_copy_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offs, bytes, idx, ok_bytes, src_valid_bits, (i64)n, out_offs, out_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stream) {
   if (n > 0) hipLaunchKernelGGL(sort_iota_kernel, grid_for(n), 256, 0, (hipStream_t)stream, perm, (i64)n, first);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -132,6 +132,11 @@ extern "C" int64_t comet_partition_tiles(int64_t n);
 extern "C" int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
                                               uint32_t* row_indices, void* stream);
 extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream);
+extern "C" int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t n,
+                                              uint32_t* lengths, void* stream);
+extern "C" int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits,
+                                           int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
+extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 extern "C" int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stream);
 extern "C" int comet_launch_sort_gather_digit(const uint8_t* plane, const uint32_t* perm, int64_t n, int32_t* digit, void* stream);
 extern "C" int comet_launch_sort_plane_varies(const uint8_t* planes, int64_t n, int W, uint32_t* flags, void* stream);
@@ -143,7 +148,7 @@ extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int3
 namespace {
 
 int fixed_width(const DType& t);
-int out_width(const OutCol& oc) { return oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
+int out_width(const OutCol& oc) { return oc.gather_src >= 0 ? 4 : oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
 
 int fixed_width(const DType& t) {
   switch (t.id) {
@@ -329,6 +334,8 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     auto pv = planned_variant(*plan_, plan_hash_, none, false);
     explain_ = pv->desc.explain;
     sink_ = pv->desc.sink;
+    if (sink_ == SinkKind::Output)
+      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0;   // Utf8 pass-through needs the gather step
   } else {
     in_types_ = infer_schema(*root_source_);
     if (plan_.get() != root_source_) {
@@ -572,6 +579,8 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
   }
 
   if (d.sink == SinkKind::Output) {
+    for (auto& oc : d.out_cols)
+      if (oc.gather_src >= 0) throw CometError("internal: gathered Utf8 outputs must go through the materialising path");
     const size_t ncol = d.out_cols.size();
     const int64_t ntiles = (n + 1023) / 1024;
     int64_t out_rows = n;
@@ -1331,18 +1340,56 @@ bool ExecutionContext::pull_device_batch() {
 // ---------------------------------------------------------------------------------------------
 
 // dense outputs written by an emit kernel (values + validity BYTES) → Arrow-layout device table (validity bitmaps)
+// out row k = source string idx[k] (Arrow Utf8: int32 offsets + bytes), any length: lengths → scan → copy
+void ExecutionContext::take_utf8(const DeviceColumnView& src, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t rows,
+                                 DeviceColumnView& out, std::vector<std::shared_ptr<void>>& owners) {
+  auto offsets = std::make_shared<DevBuf>();
+  offsets->ensure((size_t)(rows + 1) * 4 + 16);
+  auto data = std::make_shared<DevBuf>();
+  if (rows == 0) {
+    HIP_CHECK(hipMemsetAsync(offsets->p, 0, 4, stream_));
+    data->ensure(16);
+  } else {
+    DevBuf lengths, tiles;
+    lengths.ensure((size_t)rows * 4 + 16);
+    tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+    const int32_t* offs = (const int32_t*)src.data + src.offset;
+    if (comet_launch_take_utf8_lengths(offs, idx, ok_bytes, src_valid_bits, rows, (uint32_t*)lengths.p, stream_) != 0) throw CometError("take_utf8: launch failed");
+    pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)offsets->p, stream_);
+    int32_t total = 0;
+    read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
+    if (total < 0) throw CometError("Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+    data->ensure((size_t)std::max(total, 1) + 16);
+    if (comet_launch_take_utf8_copy(offs, (const uint8_t*)src.aux, idx, ok_bytes, src_valid_bits, rows, (const int32_t*)offsets->p, (uint8_t*)data->p, stream_) != 0)
+      throw CometError("take_utf8: launch failed");
+    HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
+  }
+  out.data = offsets->p;
+  out.aux = data->p;
+  out.offset = 0;
+  owners.push_back(offsets);
+  owners.push_back(data);
+}
+
 DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals,
-                                            const std::vector<std::shared_ptr<DevBuf>>& valid_bytes, int64_t rows) {
+                                            const std::vector<std::shared_ptr<DevBuf>>& valid_bytes, int64_t rows, const GatherSource& gather_source) {
   const PipelineDesc& d = v.desc;
   DevTable t;
   t.rows = rows;
   for (size_t j = 0; j < d.out_cols.size(); j++) {
     const OutCol& oc = d.out_cols[j];
-    if (oc.packed_string) throw CometError("Utf8 columns cannot cross a GPU join/pipeline boundary yet");
+    if (oc.packed_string) throw CometError("packed Utf8 group keys cannot cross a GPU pipeline boundary yet");
     DeviceColumnView cv;
     cv.data = vals[j]->p;
     t.owners.push_back(vals[j]);
     bool hv = false;
+    if (oc.gather_src >= 0) {
+      // the emit kernel wrote source row indices: gather the strings now
+      if (!gather_source) throw CometError("internal: gathered Utf8 column without a source table");
+      auto src = gather_source(oc.gather_src);
+      const DeviceColumnView& sc = src.first->cols[(size_t)src.second];
+      take_utf8(sc, (const uint32_t*)vals[j]->p, (oc.nullable && rows) ? (const uint8_t*)valid_bytes[j]->p : nullptr, nullptr, rows, cv, t.owners);
+    }
     if (oc.type.id == TypeId::Bool) {
       // kernels store booleans as bytes; Arrow wants bits
       auto bits = std::make_shared<DevBuf>();
@@ -1435,7 +1482,7 @@ DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTab
     launch(v, "k_emit", (int)std::min<int64_t>((n + 255) / 256, 256 * 8), prm);
   }
   timed_end();
-  DevTable out = outputs_to_table(v, vals, vbytes, out_rows);
+  DevTable out = outputs_to_table(v, vals, vbytes, out_rows, [&](int c) { return std::make_pair(&in, c); });
   out.owners.push_back(v.mod);
   return out;
 }
@@ -1546,7 +1593,8 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
   if (tail_rows > 0) launch(v, "k_jbemit", (int)std::min<int64_t>(nbtiles, 256 * 8), prm);
   timed_end();
   out_rows = all_rows;
-  DevTable out = outputs_to_table(v, vals, vbytes, out_rows);
+  const int nleft = (int)L.cols.size();
+  DevTable out = outputs_to_table(v, vals, vbytes, out_rows, [&](int c) { return c < nleft ? std::make_pair(&L, c) : std::make_pair(&R, c - nleft); });
   HIP_CHECK(hipStreamSynchronize(stream_));  // head/next/counts go back to the pool when this frame ends
   out.owners.push_back(v.mod);
   join_build_rows_ += B.rows;
@@ -1643,7 +1691,18 @@ DevTable ExecutionContext::take_rows(const DevTable& in, const uint32_t* dev_per
   const uint32_t* idx = dev_perm + first;
   for (size_t c = 0; c < in.cols.size(); c++) {
     const DType& t = in.types[c];
-    if (t.id == TypeId::String || t.id == TypeId::Bytes) throw CometError("Utf8 columns cannot pass through Sort / Limit on the GPU yet");
+    if (t.id == TypeId::String || t.id == TypeId::Bytes) {
+      if (in.cols[c].offset != 0 && in.has_valid[c]) throw CometError("Sort / Limit over a nullable Utf8 column with a non-zero Arrow offset is not supported yet");
+      take_utf8(in.cols[c], idx, nullptr, in.has_valid[c] ? in.cols[c].valid : nullptr, rows, out.cols[c], out.owners);
+      if (in.has_valid[c]) {
+        auto bm = std::make_shared<DevBuf>();
+        bm->ensure((size_t)((rows + 7) / 8) + 16);
+        if (rows && comet_launch_take(0, in.cols[c].valid, idx, rows, bm->p, stream_) != 0) throw CometError("take: validity");
+        out.cols[c].valid = (const uint8_t*)bm->p;
+        out.owners.push_back(bm);
+      }
+      continue;
+    }
     if (in.cols[c].offset != 0) throw CometError("Sort / Limit over a column with a non-zero Arrow offset is not supported yet");
     const int w = t.id == TypeId::Bool ? 0 : fixed_width(t);
     auto vals = std::make_shared<DevBuf>();
@@ -2001,14 +2060,12 @@ int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_sch
       else finish_aggregate();
       finished_ = true;
     } else {
-      if (has_join_) {
-        if (plan_.get() == root_source_) {
-          // the join itself is the plan root: export its materialised output
-          DevTable t = materialize(*root_source_);
-          table_to_host_batches(t);
-        } else {
-          run_to_completion();
-        }
+      if (has_join_ || materialize_root_) {
+        // a plan over materialised sources (joins, Parquet scans, sorts, limits, nested aggregates) or one that passes Utf8
+        // columns through: the whole result is produced resident in HBM, then copied out in batches
+        DevTable t = materialize(*plan_);
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        table_to_host_batches(t);
         finished_ = true;
       }
       while (ready_.empty() && !finished_) {

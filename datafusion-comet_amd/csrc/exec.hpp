@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -128,8 +129,11 @@ class ExecutionContext {
   DevTable take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner);
   DevTable nested_aggregate(const Operator& agg);
   static bool is_source(const Operator& op, const Operator* chain_top);
+  typedef std::function<std::pair<const DevTable*, int>(int)> GatherSource;   // OutCol::gather_src → (table, column)
   DevTable outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals, const std::vector<std::shared_ptr<DevBuf>>& valid_bytes,
-                            int64_t rows);
+                            int64_t rows, const GatherSource& gather_source = nullptr);
+  void take_utf8(const DeviceColumnView& src, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t rows,
+                 DeviceColumnView& out, std::vector<std::shared_ptr<void>>& owners);
   void table_to_host_batches(const DevTable& t);
   bool pull_host_chunk();
   bool pull_device_batch();
@@ -165,6 +169,7 @@ class ExecutionContext {
   std::string explain_;
   SinkKind sink_ = SinkKind::Output;
   bool has_join_ = false;
+  bool materialize_root_ = false;   // plain Scan chain whose outputs need the materialising path (Utf8 pass-through)
   bool compile_in_infer_ = false;
   std::vector<const Operator*> nested_aggs_;       // aggregates that are not the plan root (materialised by sub-contexts)
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from
