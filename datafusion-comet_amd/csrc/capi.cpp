@@ -20,6 +20,12 @@ extern "C" int comet_launch_partition_indices(const int32_t* pids, int64_t n, in
                                               uint32_t* row_indices, void* stream);
 extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream);
 
+extern "C" int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t n,
+                                              uint32_t* lengths, void* stream);
+extern "C" int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits,
+                                           int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
+extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
+
 namespace {
 
 std::mutex g_mu;
@@ -226,6 +232,38 @@ int32_t comet_take_column(int32_t width_bytes, const void* src, const uint32_t* 
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     if (comet_launch_take(width_bytes, src, row_indices, n, dst, hip_stream) != 0)
       throw CometError("take_column: unsupported value width " + std::to_string(width_bytes));
+    return 0;
+  });
+}
+
+int64_t comet_take_utf8_offsets(const int32_t* offsets, const uint8_t* validity_bits, const uint32_t* row_indices, int64_t n,
+                                int32_t* out_offsets, void* hip_stream) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (n <= 0) {
+      if (hipMemsetAsync(out_offsets, 0, 4, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) throw CometError("take_utf8_offsets: memset failed");
+      return 0;
+    }
+    DevBuf lengths, tiles;
+    PinnedBuf host;
+    lengths.ensure((size_t)n * 4 + 16);
+    tiles.ensure((size_t)((n + 1023) / 1024 + 2) * 8);
+    host.ensure(64);
+    if (comet_launch_take_utf8_lengths(offsets, row_indices, nullptr, validity_bits, n, (uint32_t*)lengths.p, st) != 0) throw CometError("take_utf8_offsets: launch failed");
+    pq_launch_u32_scan((const uint32_t*)lengths.p, n, (uint64_t*)tiles.p, out_offsets, st);
+    if (hipMemcpyAsync(host.p, out_offsets + n, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      throw CometError(std::string("take_utf8_offsets: ") + hipGetErrorString(hipGetLastError()));
+    const int32_t total = *(const int32_t*)host.p;
+    if (total < 0) throw CometError("Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+    return (int64_t)total;
+  });
+}
+
+int32_t comet_take_utf8_bytes(const int32_t* offsets, const uint8_t* bytes, const uint8_t* validity_bits, const uint32_t* row_indices, int64_t n,
+                              const int32_t* out_offsets, uint8_t* out_bytes, void* hip_stream) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    if (comet_launch_take_utf8_copy(offsets, bytes, row_indices, nullptr, validity_bits, n, out_offsets, out_bytes, hip_stream) != 0)
+      throw CometError("take_utf8_bytes: launch failed");
     return 0;
   });
 }

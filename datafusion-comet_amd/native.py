@@ -72,6 +72,10 @@ def _load() -> ctypes.CDLL:
     lib.comet_partition_indices.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p, c.c_void_p]
     lib.comet_take_column.restype = c.c_int32
     lib.comet_take_column.argtypes = [c.c_int32, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    lib.comet_take_utf8_offsets.restype = c.c_int64
+    lib.comet_take_utf8_offsets.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    lib.comet_take_utf8_bytes.restype = c.c_int32
+    lib.comet_take_utf8_bytes.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p]
     return lib
 
 
@@ -553,7 +557,25 @@ def partition_table(table: DeviceTable, pids, num_partitions: int):
     vals, valid, aux = [], [], []
     for i, f in enumerate(table.schema):
         if pa.types.is_string(f.type) or pa.types.is_binary(f.type):
-            raise CometNativeException("Utf8 columns cannot cross the GPU exchange yet")
+            # Utf8: new offsets first (returns the byte total), then the bytes
+            vptr = table.validity[i].data_ptr() if table.validity[i] is not None else None
+            offs = torch.empty(((n + 1) * 4,), dtype=torch.uint8, device=dev)
+            total = lib().comet_take_utf8_offsets(table.values[i].data_ptr() if table.values[i].numel() else None, vptr, idx.data_ptr(), n, offs.data_ptr(), st)
+            if total < 0:
+                _raise_last(0)
+            data = torch.empty((max(int(total), 1),), dtype=torch.uint8, device=dev)
+            if n and lib().comet_take_utf8_bytes(table.values[i].data_ptr(), table.aux[i].data_ptr(), vptr, idx.data_ptr(), n, offs.data_ptr(), data.data_ptr(), st) != 0:
+                _raise_last(0)
+            vals.append(offs)
+            aux.append(data)
+            if table.validity[i] is not None:
+                vb = torch.empty(((n + 7) // 8,), dtype=torch.uint8, device=dev)
+                if n and lib().comet_take_column(0, table.validity[i].data_ptr(), idx.data_ptr(), n, vb.data_ptr(), st) != 0:
+                    _raise_last(0)
+                valid.append(vb)
+            else:
+                valid.append(None)
+            continue
         w = value_width(f.type)
         out = torch.empty(((n + 7) // 8 if w == 0 else n * w,), dtype=torch.uint8, device=dev)
         if n and lib().comet_take_column(w, table.values[i].data_ptr(), idx.data_ptr(), n, out.data_ptr(), st) != 0:

@@ -131,10 +131,34 @@ def exchange(table, key_cols, partitioner, group=None):
         dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv, input_split_sizes=send, group=group)
         return out
 
-    vals, valid = [], []
+    vals, valid, auxs = [], [], []
     for i, f in enumerate(part.schema):
         if pa.types.is_string(f.type) or pa.types.is_binary(f.type):
-            raise NotImplementedError("Utf8 columns cannot cross the exchange yet")
+            # Utf8: the lengths travel one int32 per row, the bytes with per-partition BYTE split sizes; the receiver rebuilds
+            # the offsets with a prefix sum
+            offs = part.values[i].view(torch.int32)[: n_in + 1]
+            lens = (offs[1:] - offs[:-1]).contiguous()
+            cut = offs[torch.tensor(starts, dtype=torch.int64, device=dev)].to(torch.int64)
+            send_b = (cut[1:] - cut[:-1]).contiguous()
+            recv_b = torch.empty_like(send_b)
+            dist.all_to_all_single(recv_b, send_b, group=group)
+            send_bl, recv_bl = [int(x) for x in send_b.tolist()], [int(x) for x in recv_b.tolist()]
+            rl = a2a(lens.view(torch.uint8).reshape(n_in, 4)).reshape(-1).view(torch.int32)
+            data_in = part.aux[i][: sum(send_bl)].reshape(-1, 1)
+            data_out = torch.empty((sum(recv_bl), 1), dtype=torch.uint8, device=dev)
+            dist.all_to_all_single(data_out, data_in.contiguous(), output_split_sizes=recv_bl, input_split_sizes=send_bl, group=group)
+            new_offs = torch.zeros(n_out + 1, dtype=torch.int32, device=dev)
+            if n_out:
+                new_offs[1:] = torch.cumsum(rl, 0, dtype=torch.int32)
+            vals.append(new_offs.view(torch.uint8).reshape(-1))
+            auxs.append(data_out.reshape(-1) if data_out.numel() else torch.zeros(1, dtype=torch.uint8, device=dev))
+            if any_valid[i]:
+                vb = _unpack_bits(part.validity[i], n_in) if part.validity[i] is not None else torch.ones(n_in, dtype=torch.uint8, device=dev)
+                valid.append(_pack_bits(a2a(vb.reshape(n_in, 1)).reshape(-1)))
+            else:
+                valid.append(None)
+            continue
+        auxs.append(None)
         w = value_width(f.type)
         if w == 0:   # Boolean values travel one byte per row (partition boundaries are not byte aligned)
             vals.append(_pack_bits(a2a(_unpack_bits(part.values[i], n_in).reshape(n_in, 1)).reshape(-1)))
@@ -148,7 +172,7 @@ def exchange(table, key_cols, partitioner, group=None):
     if dev.type == "cuda":
         # the collectives were enqueued on torch's stream; libcomet reads these buffers on ITS OWN stream next
         torch.cuda.current_stream(dev).synchronize()
-    return DeviceTable(part.schema, n_out, vals, valid, table.device, [None] * len(vals))
+    return DeviceTable(part.schema, n_out, vals, valid, table.device, auxs)
 
 
 class GpuEngine:

@@ -112,6 +112,15 @@ int32_t comet_partition_indices(const int32_t* partition_ids, int64_t n, int32_t
 int32_t comet_take_column(int32_t width_bytes, const void* src, const uint32_t* row_indices, int64_t n, void* dst,
                           void* hip_stream);
 
+/* The same take for a Utf8 / Binary column (int32 offsets + bytes), in two steps because the byte total is only known after
+ * the first: comet_take_utf8_offsets writes the n + 1 new offsets and RETURNS the total number of bytes (it synchronises
+ * hip_stream; -2 on error); comet_take_utf8_bytes then copies the string bytes into out_bytes (asynchronous).
+ * validity_bits (may be NULL) is the SOURCE column's validity bitmap: NULL rows contribute no bytes. */
+int64_t comet_take_utf8_offsets(const int32_t* offsets, const uint8_t* validity_bits, const uint32_t* row_indices, int64_t n,
+                                int32_t* out_offsets, void* hip_stream);
+int32_t comet_take_utf8_bytes(const int32_t* offsets, const uint8_t* bytes, const uint8_t* validity_bits, const uint32_t* row_indices,
+                              int64_t n, const int32_t* out_offsets, uint8_t* out_bytes, void* hip_stream);
+
 /* Host-only description of a Parquet footer as parsed by the library's own Thrift reader (rows, row groups, schema
  * elements, per-chunk codec/offsets) — the metadata the NativeScan path (native/core/src/parquet/parquet_exec.rs:60-211)
  * plans from.  Returns 0, or -2 on error. */

@@ -31,7 +31,9 @@ def _worker(rank, world, port, q):
         t = pa.table({"k": pa.array(rng.integers(0, 1000, n), pa.int64(), mask=rng.random(n) < 0.1),
                       "d": pa.array(rng.integers(-10**5, 10**5, n), pa.int32()).cast(pa.date32()),
                       "b": pa.array(rng.random(n) < 0.5, mask=(rng.random(n) < 0.2) if rank == 0 else None),
-                      "m": pa.array([__import__("decimal").Decimal(int(x)).scaleb(-2) for x in rng.integers(-10**9, 10**9, n)], pa.decimal128(12, 2))})
+                      "m": pa.array([__import__("decimal").Decimal(int(x)).scaleb(-2) for x in rng.integers(-10**9, 10**9, n)], pa.decimal128(12, 2)),
+                      "s": pa.array(np.array(["", "a", "Customer#000000001", "x" * 70, "naïve ☕"], dtype=object)[rng.integers(0, 5, n)], pa.utf8(),
+                                    mask=rng.random(n) < 0.15)})
         got = parallel.exchange(native.DeviceTable.from_arrow(t, "cpu"), [0], part).to_arrow()
         pids = O.hash_partition_ids(S, got, [0], world)
         ok_place = bool((pids == rank).all())

@@ -78,7 +78,9 @@ def test_hash_partitioner_places_rows_like_spark(built):
     t = pa.table({"k": pa.array(rng.integers(-10**12, 10**12, n), pa.int64(), mask=rng.random(n) < 0.05),
                   "d": pa.array(rng.integers(0, 20000, n), pa.int32()).cast(pa.date32()),
                   "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1),
-                  "m": tpch._dec128_array(rng.integers(0, 10**9, n), 12, 2)})
+                  "m": tpch._dec128_array(rng.integers(0, 10**9, n), 12, 2),
+                  "s": pa.array(np.array(["", "a", "Customer#000000001", "x" * 70, "naïve ☕"], dtype=object)[rng.integers(0, 5, n)], pa.utf8(),
+                                mask=rng.random(n) < 0.15)})
     dt = native.DeviceTable.from_arrow(t)
     for keys in ([0], [1, 0], [3]):
         pids = native.partition_ids(dt, keys, 8)
