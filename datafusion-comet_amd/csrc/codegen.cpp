@@ -780,6 +780,93 @@ struct Gen {
     return r;
   }
 
+  // ---- direct Utf8 comparisons (device/comet_device.hpp utf8_cmp*) ----
+  bool is_str_col(const ExprP& x) const {
+    return x->kind == ExprKind::Bound && x->bound_index >= 0 && (size_t)x->bound_index < in_types.size() &&
+           (in_types[(size_t)x->bound_index].id == TypeId::String || in_types[(size_t)x->bound_index].id == TypeId::Bytes);
+  }
+  static bool is_str_lit(const ExprP& x) {
+    return x->kind == ExprKind::Literal && !x->lit_null && (x->dtype.id == TypeId::String || x->dtype.id == TypeId::Bytes);
+  }
+  static std::string c_bytes(const std::string& b) {
+    static const char* hx = "0123456789abcdef";
+    std::string o = "\"";
+    for (unsigned char ch : b) { o += "\\x"; o += hx[ch >> 4]; o += hx[ch & 15]; o += "\"\""; }   // "\x41""\x42": hex escapes never run together
+    return o + "\"";
+  }
+  // a Val that only carries the column's validity (no string load)
+  Val str_col_validity(int idx) {
+    in_used[(size_t)idx] = true;
+    Val v;
+    v.t = in_types[(size_t)idx];
+    v.rep = Rep::B;
+    v.v = "true";
+    if (in_valid[(size_t)idx]) {
+      auto loc = locate(idx);
+      std::string o = newloadvar("bool");
+      load(o + " = comet::ld_valid(prm.in[" + std::to_string(loc.first) + "], " + loc.second + ");");
+      v.ok = o;
+    }
+    return v;
+  }
+  static std::string cmp_to_bool(ExprKind k, const std::string& c, bool swapped) {
+    // c = cmp(column, other); swapped: the expression was  other <op> column
+    switch (k) {
+      case ExprKind::Eq: case ExprKind::EqNullSafe: return "(" + c + " == 0)";
+      case ExprKind::Neq: case ExprKind::NeqNullSafe: return "(" + c + " != 0)";
+      case ExprKind::Gt: return "(" + c + (swapped ? " < 0)" : " > 0)");
+      case ExprKind::GtEq: return "(" + c + (swapped ? " <= 0)" : " >= 0)");
+      case ExprKind::Lt: return "(" + c + (swapped ? " > 0)" : " < 0)");
+      case ExprKind::LtEq: return "(" + c + (swapped ? " >= 0)" : " <= 0)");
+      default: throw CometError("bad comparison");
+    }
+  }
+  Val str_compare_lit(ExprKind k, int idx, const Expr& lit, bool swapped) {
+    Val valid = str_col_validity(idx);
+    auto loc = locate(idx);
+    const std::string col = "prm.in[" + std::to_string(loc.first) + "]";
+    const std::string n = std::to_string(lit.lit_bytes.size());
+    const bool eqlike = k == ExprKind::Eq || k == ExprKind::Neq || k == ExprKind::EqNullSafe || k == ExprKind::NeqNullSafe;
+    std::string b = newvar("bool");
+    if (eqlike) {
+      const bool neg = k == ExprKind::Neq || k == ExprKind::NeqNullSafe;
+      stmt(b + " = " + (neg ? "!" : "") + "comet::utf8_eq_lit(" + col + ", " + loc.second + ", " + c_bytes(lit.lit_bytes) + ", " + n + ");");
+    } else {
+      stmt(b + " = " + cmp_to_bool(k, "comet::utf8_cmp_lit(" + col + ", " + loc.second + ", " + c_bytes(lit.lit_bytes) + ", " + n + ")", swapped) + ";");
+    }
+    Val r;
+    r.t = DType::of(TypeId::Bool);
+    r.rep = Rep::B;
+    if (k == ExprKind::EqNullSafe || k == ExprKind::NeqNullSafe) {
+      // the literal is not NULL: <=> is false (and its negation true) for a NULL column value
+      if (valid.ok.empty()) r.v = b;
+      else r.v = k == ExprKind::EqNullSafe ? "(" + valid.ok + " && " + b + ")" : "(!" + valid.ok + " || " + b + ")";
+      return r;
+    }
+    r.v = valid.ok.empty() ? b : "(" + valid.ok + " && " + b + ")";
+    r.ok = valid.ok;
+    return r;
+  }
+  Val str_compare_cols(ExprKind k, int ia, int ib) {
+    Val va = str_col_validity(ia), vb = str_col_validity(ib);
+    auto la = locate(ia), lb = locate(ib);
+    std::string b = newvar("bool");
+    stmt(b + " = " + cmp_to_bool(k, "comet::utf8_cmp(prm.in[" + std::to_string(la.first) + "], " + la.second + ", prm.in[" + std::to_string(lb.first) + "], " +
+                                        lb.second + ")", false) + ";");
+    Val r;
+    r.t = DType::of(TypeId::Bool);
+    r.rep = Rep::B;
+    const std::string aok = va.ok.empty() ? "true" : va.ok, bok = vb.ok.empty() ? "true" : vb.ok;
+    if (k == ExprKind::EqNullSafe || k == ExprKind::NeqNullSafe) {
+      const std::string e2 = "((" + aok + " && " + bok + " && " + (k == ExprKind::EqNullSafe ? b : "!" + b) + ") || (!" + aok + " && !" + bok + "))";
+      r.v = k == ExprKind::EqNullSafe ? e2 : "(!" + e2 + ")";
+      return r;
+    }
+    r.v = "(" + aok + " && " + bok + " && " + b + ")";
+    r.ok = and_ok(va.ok, vb.ok);
+    return r;
+  }
+
   // c ? t : f with SQL NULL handling: a NULL condition selects f (If: conditional_funcs/if_expr.rs:103; CaseWhen alike)
   Val select(const Val& c, const Val& t, const Val& f) {
     if (t.rep != f.rep) throw CometError("If / CaseWhen branches have different types");
@@ -818,6 +905,14 @@ struct Gen {
       case ExprKind::Eq: case ExprKind::Neq: case ExprKind::Gt: case ExprKind::GtEq: case ExprKind::Lt: case ExprKind::LtEq:
       case ExprKind::EqNullSafe: case ExprKind::NeqNullSafe: {
         if (e.children.size() != 2) throw CometError("comparison needs two children");
+        {
+          // Utf8 column against a Utf8 literal or another Utf8 column: compare the bytes in place (any length, all six
+          // operators) instead of going through the packed ≤15-byte form
+          const ExprP &c0 = e.children[0], &c1 = e.children[1];
+          if (is_str_col(c0) && is_str_lit(c1)) return str_compare_lit(e.kind, c0->bound_index, *c1, false);
+          if (is_str_lit(c0) && is_str_col(c1)) return str_compare_lit(e.kind, c1->bound_index, *c0, true);
+          if (is_str_col(c0) && is_str_col(c1)) return str_compare_cols(e.kind, c0->bound_index, c1->bound_index);
+        }
         Val a = gen(e.children[0]), b = gen(e.children[1]);
         return compare(e.kind, a, b);
       }
@@ -834,7 +929,8 @@ struct Gen {
         return r;
       }
       case ExprKind::IsNull: case ExprKind::IsNotNull: {
-        Val a = gen(e.children.at(0));
+        // a Utf8 column's NULL-ness needs its validity bit only, never the (packed, ≤15-byte) value
+        Val a = is_str_col(e.children.at(0)) ? str_col_validity(e.children[0]->bound_index) : gen(e.children.at(0));
         Val r;
         r.t = DType::of(TypeId::Bool);
         r.rep = Rep::B;
@@ -905,9 +1001,16 @@ struct Gen {
         return r;
       }
       case ExprKind::In: {
-        Val v = named(gen(e.children.at(0)));
+        const bool direct = is_str_col(e.children.at(0));
+        Val v = direct ? str_col_validity(e.children[0]->bound_index) : named(gen(e.children.at(0)));
         std::string any = "false", anynull = "false";
         for (size_t i = 1; i < e.children.size(); i++) {
+          if (direct && is_str_lit(e.children[i])) {
+            Val c = str_compare_lit(ExprKind::Eq, e.children[0]->bound_index, *e.children[i], false);
+            any = "(" + any + " || " + c.v + ")";
+            continue;
+          }
+          if (direct) throw CometError("IN over a Utf8 column expects Utf8 literals");
           Val li = gen(e.children[i]);
           Val c = compare(ExprKind::Eq, v, li);
           std::string lok = li.ok.empty() ? "true" : li.ok;

@@ -85,6 +85,45 @@ CDEV str16 ld_str16(const CometCol& c, i64 i, bool& toolong) {
   return r;
 }
 
+// Direct Utf8 comparisons for predicates: byte-wise unsigned lexicographic order (Spark's UTF8String binary compare, arrow-ord's
+// string kernels), any length, no packing.  Returns <0, 0, >0.
+CDEV int utf8_cmp_lit(const CometCol& c, i64 i, const char* lit, i32 n) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], len = off[j + 1] - lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  const i32 m = len < n ? len : n;
+  for (i32 k = 0; k < m; k++) {
+    const u8 x = p[k], y = (u8)lit[k];
+    if (x != y) return x < y ? -1 : 1;
+  }
+  return len < n ? -1 : (len > n ? 1 : 0);
+}
+CDEV bool utf8_eq_lit(const CometCol& c, i64 i, const char* lit, i32 n) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j];
+  if (off[j + 1] - lo != n) return false;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  for (i32 k = 0; k < n; k++)
+    if (p[k] != (u8)lit[k]) return false;
+  return true;
+}
+CDEV int utf8_cmp(const CometCol& a, i64 i, const CometCol& b, i64 j) {
+  const COMET_GLOBAL i32* oa = (const COMET_GLOBAL i32*)a.data;
+  const COMET_GLOBAL i32* ob = (const COMET_GLOBAL i32*)b.data;
+  const i64 ia = a.offset + i, jb = b.offset + j;
+  const i32 la = oa[ia + 1] - oa[ia], lb = ob[jb + 1] - ob[jb];
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)a.aux + oa[ia];
+  const COMET_GLOBAL u8* q = (const COMET_GLOBAL u8*)b.aux + ob[jb];
+  const i32 m = la < lb ? la : lb;
+  for (i32 k = 0; k < m; k++) {
+    const u8 x = p[k], y = q[k];
+    if (x != y) return x < y ? -1 : 1;
+  }
+  return la < lb ? -1 : (la > lb ? 1 : 0);
+}
+
 // Utf8 column whose values all have the same length LEN (≤ 15; verified by the executor before this variant is
 // chosen): the bytes of row i sit at aux + (offset + i)·LEN, so neither the int32 offsets nor a dependent load is
 // needed (TPC-H flag/status columns: LEN = 1).

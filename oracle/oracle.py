@@ -262,6 +262,14 @@ class Evaluator:
             C.o_cmp_i128(op, _p(np.ascontiguousarray(a.values)), _p(np.ascontiguousarray(b.values)), _p(out), ctypes.c_int64(len(a)))
             return out.astype(bool)
         x, y = a.values, b.values
+        if a.dtype.type_id in (S.STRING, S.BYTES):
+            # byte-wise unsigned lexicographic order of the UTF-8 encodings (Spark UTF8String.compareTo, arrow-ord string kernels);
+            # NULL slots hold None: compare as empty, the validity mask removes them later
+            enc = lambda v: b"" if v is None else (v.encode() if isinstance(v, str) else bytes(v))
+            xs, ys = [enc(v) for v in x], [enc(v) for v in y]
+            f = {"eq": lambda p, q: p == q, "neq": lambda p, q: p != q, "lt": lambda p, q: p < q, "lt_eq": lambda p, q: p <= q,
+                 "gt": lambda p, q: p > q, "gt_eq": lambda p, q: p >= q}[k]
+            return np.array([f(p, q) for p, q in zip(xs, ys)], dtype=bool)
         if a.dtype.type_id in (S.FLOAT, S.DOUBLE):
             # arrow-ord compares floats with IEEE totalOrder
             it = np.int64 if a.dtype.type_id == S.DOUBLE else np.int32

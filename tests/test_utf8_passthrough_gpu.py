@@ -87,3 +87,23 @@ def test_sort_limit_and_parquet_with_strings(built, tmp_path):
     got = pa.Table.from_batches(native.execute_to_table([], 2, plan.encode(), batch_size=0))
     keep = t.filter(pa.compute.greater(t.column("id"), n // 2))
     assert got.column(0).combine_chunks().equals(keep.column("s").combine_chunks()) and got.column(1).equals(keep.column("id"))
+
+
+def test_string_predicates_any_length(built):
+    """=, <>, <, <=, >, >=, <=>, IN between a Utf8 column and literals / another column: bytes compared in place (unsigned
+    lexicographic, like Spark's UTF8String and arrow-ord), no 15-byte limit, NULLs three-valued."""
+    rng = np.random.default_rng(5)
+    n = 80_000
+    t = pa.table({"a": _strings(rng, n), "b": _strings(rng, n, 0.05), "id": pa.array(np.arange(n), pa.int64())})
+    A, B = S.col(0, S.T_STRING), S.col(1, S.T_STRING)
+    lit = lambda x: S.lit(x, S.T_STRING)
+    long_lit = "the quick brown fox jumps over the lazy dog " * 3
+    preds = [S.eq(A, lit("Customer#000000001")), S.neq(A, lit("BUILDING")), S.gt_eq(A, lit("a")), S.lt(A, lit(long_lit)), S.gt(lit("n"), A),
+             S.lt_eq(A, B), S.neq(A, B), S.eq(B, A), S.in_(A, [lit("BUILDING"), lit(long_lit), lit("")]), S.in_(A, [lit("x" * 300)], negated=True),
+             S.or_(S.eq(A, lit("naïve café ☕")), S.is_null(A)),
+             S.eq_null_safe(A, B), S.not_(S.eq_null_safe(A, lit("a")))]
+    for i, pred in enumerate(preds):
+        plan = S.project(S.filter_(S.scan([S.T_STRING, S.T_STRING, S.T_INT64]), pred), [S.col(2, S.T_INT64)])
+        got, want = _run(plan, [t], 1), _oracle(plan, [t])
+        assert (got.column(0).to_pylist() if got is not None else []) == want.column(0).to_pylist(), f"predicate {i}"
+        assert want.num_rows > 0
