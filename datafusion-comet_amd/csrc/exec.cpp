@@ -20,6 +20,15 @@ struct Pools {
   std::mutex mu;
   std::map<std::pair<int, size_t>, std::vector<void*>> dev_free;   // (device, class bytes) → blocks
   std::map<size_t, std::vector<void*>> pinned_free;
+  // idle blocks are kept for reuse up to these caps (a long-lived executor must not pin HBM it no longer uses);
+  // COMET_POOL_MAX_BYTES / COMET_PINNED_POOL_MAX_BYTES override (bytes)
+  std::map<int, size_t> dev_cached;
+  size_t pinned_cached = 0;
+  size_t dev_cap = (size_t)96 << 30, pinned_cap = (size_t)16 << 30;
+  Pools() {
+    if (const char* e = getenv("COMET_POOL_MAX_BYTES")) dev_cap = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("COMET_PINNED_POOL_MAX_BYTES")) pinned_cap = (size_t)strtoull(e, nullptr, 10);
+  }
   std::map<int, std::vector<hipStream_t>> streams;
   std::map<int, std::vector<hipEvent_t>> events;
 };
@@ -50,17 +59,42 @@ void DevBuf::ensure(size_t n) {
     if (!fl.empty()) {
       p = fl.back();
       fl.pop_back();
+      pools().dev_cached[dev] -= cls;
       cap = cls;
       return;
     }
   }
-  HIP_CHECK(hipMalloc(&p, cls));
+  if (hipMalloc(&p, cls) != hipSuccess) {
+    // out of memory: hand every idle block of this device back to the driver and try once more
+    (void)hipGetLastError();
+    std::vector<void*> victims;
+    {
+      std::lock_guard<std::mutex> lk(pools().mu);
+      for (auto& kv : pools().dev_free)
+        if (kv.first.first == dev) {
+          victims.insert(victims.end(), kv.second.begin(), kv.second.end());
+          kv.second.clear();
+        }
+      pools().dev_cached[dev] = 0;
+    }
+    for (void* v : victims) (void)hipFree(v);
+    p = nullptr;
+    HIP_CHECK(hipMalloc(&p, cls));
+  }
   cap = cls;
 }
 void DevBuf::release() {
   if (p) {
-    std::lock_guard<std::mutex> lk(pools().mu);
-    pools().dev_free[{dev, cap}].push_back(p);
+    bool keep;
+    {
+      std::lock_guard<std::mutex> lk(pools().mu);
+      keep = pools().dev_cached[dev] + cap <= pools().dev_cap;
+      if (keep) {
+        pools().dev_free[{dev, cap}].push_back(p);
+        pools().dev_cached[dev] += cap;
+      }
+    }
+    if (!keep) (void)hipFree(p);   // over the cap: give the block back to the driver (hipFree waits for the device)
   }
   p = nullptr;
   cap = 0;
@@ -75,6 +109,7 @@ void PinnedBuf::ensure(size_t n) {
     if (!fl.empty()) {
       p = fl.back();
       fl.pop_back();
+      pools().pinned_cached -= cls;
       cap = cls;
       return;
     }
@@ -84,8 +119,16 @@ void PinnedBuf::ensure(size_t n) {
 }
 void PinnedBuf::release() {
   if (p) {
-    std::lock_guard<std::mutex> lk(pools().mu);
-    pools().pinned_free[cap].push_back(p);
+    bool keep;
+    {
+      std::lock_guard<std::mutex> lk(pools().mu);
+      keep = pools().pinned_cached + cap <= pools().pinned_cap;
+      if (keep) {
+        pools().pinned_free[cap].push_back(p);
+        pools().pinned_cached += cap;
+      }
+    }
+    if (!keep) (void)hipHostFree(p);
   }
   p = nullptr;
   cap = 0;
