@@ -356,6 +356,15 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     }
     if (op.kind == OpKind::Unsupported)
       throw CometError(std::string("Operator ") + op_name(op.proto_tag) + " is not supported by the MI355X native engine");
+    if (op.kind == OpKind::HashJoin && op.smj) {
+      // synthetic Sort over the join output: left keys keep their column indices in left ++ right; a RightOuter join is ordered
+      // by the right keys (shifted past the left columns, resolved when the schema is known)
+      auto so = std::make_shared<Operator>();
+      so->kind = OpKind::Sort;
+      so->proto_tag = 103;
+      smj_sorts_[&op] = so;
+      node_id_[so.get()] = (int)node_id_.size();
+    }
     for (auto& c : op.children) walk(*c);
   };
   walk(*plan_);
@@ -434,6 +443,25 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     PipelineDesc d = generate_join(op, l, r, lv, rv);   // validates keys / join type
     if (compile_in_infer_) jit_compile(d.source);
     explain_ += d.explain;
+    if (op.smj) {
+      Operator& so = *smj_sorts_.at(&op);
+      so.sort_orders.clear();
+      const bool by_right = op.join_type == JoinType::RightOuter;
+      const std::vector<ExprP>& keys = by_right ? op.right_keys : op.left_keys;
+      std::function<ExprP(const ExprP&)> shift = [&](const ExprP& e) -> ExprP {
+        auto n = std::make_shared<Expr>(*e);
+        if (e->kind == ExprKind::Bound) n->bound_index = e->bound_index + (int)l.size();
+        for (auto& c : n->children) c = shift(c);
+        return n;
+      };
+      for (size_t k = 0; k < keys.size(); k++) {
+        Operator::SortKey sk;
+        sk.child = by_right ? shift(keys[k]) : keys[k];
+        if (k < op.smj_sort_options.size()) { sk.descending = op.smj_sort_options[k].first; sk.nulls_last = op.smj_sort_options[k].second; }
+        so.sort_orders.push_back(sk);
+      }
+      explain_ += "  (sort-merge join: output ordered by the join keys)\n";
+    }
     std::vector<DType> out;
     for (auto& c : d.out_cols) out.push_back(c.type);
     return out;
@@ -1693,7 +1721,10 @@ DevTable ExecutionContext::materialize(const Operator& op) {
   if (op.kind == OpKind::HashJoin) {
     DevTable l = materialize(*op.children[0]);
     DevTable r = materialize(*op.children[1]);
-    return hash_join(op, l, r);
+    DevTable j = hash_join(op, l, r);
+    if (!op.smj) return j;
+    // SortMergeJoin: its output is ordered by the join keys (SortMergeJoinExec streams the sorted inputs, planner.rs:2126-2191)
+    return sort_table(*smj_sorts_.at(&op), j);
   }
   if (op.kind == OpKind::Sort) {
     DevTable in = materialize(*op.children[0]);

@@ -171,7 +171,8 @@ class ExecutionContext {
   bool has_join_ = false;
   bool materialize_root_ = false;   // plain Scan chain whose outputs need the materialising path (Utf8 pass-through)
   bool compile_in_infer_ = false;
-  std::vector<const Operator*> nested_aggs_;       // aggregates that are not the plan root (materialised by sub-contexts)
+  std::vector<const Operator*> nested_aggs_;
+  std::map<const Operator*, OperatorP> smj_sorts_;  // SortMergeJoin node → synthetic Sort over its output       // aggregates that are not the plan root (materialised by sub-contexts)
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from
   std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)
   std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index

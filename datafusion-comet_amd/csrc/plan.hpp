@@ -93,7 +93,7 @@ struct AggExpr {
 
 // Operator.op_struct oneof tags (operator.proto:32-79)
 enum class OpKind : int {
-  Scan = 100, Projection = 101, Filter = 102, Sort = 103, HashAgg = 104, Limit = 105, HashJoin = 109,
+  Scan = 100, Projection = 101, Filter = 102, Sort = 103, HashAgg = 104, Limit = 105, HashJoin = 109,   // SortMergeJoin (108) decodes to HashJoin + smj
   NativeScan = 111, Unsupported = -1
 };
 
@@ -140,6 +140,9 @@ struct Operator {
   ExprP join_condition;
   BuildSide build_side = BuildSide::Left;
   bool null_aware_anti = false;
+  // SortMergeJoin (operator.proto:765-771): executed as a hash join whose output is then sorted by the join keys
+  bool smj = false;
+  std::vector<std::pair<bool, bool>> smj_sort_options;   // per key: (descending, nulls_last)
   // Limit
   int limit = -1, offset = 0;
   // Sort (operator.proto:641-645; SortOrder expr.proto:385-389)

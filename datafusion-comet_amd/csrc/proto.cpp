@@ -403,6 +403,39 @@ OperatorP decode_operator_r(Reader r) {
           else b.skip(wt2);
         }
         break;
+      case 108:
+        // SortMergeJoin{left_join_keys=1, right_join_keys=2, join_type=3, sort_options=4 (SortOrder exprs), condition=5}
+        op->kind = OpKind::HashJoin;
+        op->smj = true;
+        op->build_side = BuildSide::Right;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) op->left_keys.push_back(decode_expr(b.sub()));
+          else if (f2 == 2 && wt2 == 2) op->right_keys.push_back(decode_expr(b.sub()));
+          else if (f2 == 3 && wt2 == 0) op->join_type = (JoinType)b.varint();
+          else if (f2 == 4 && wt2 == 2) {
+            Reader e = b.sub();
+            std::pair<bool, bool> opt(false, false);
+            while (!e.done()) {
+              int wt3, f3 = e.tag(wt3);
+              if (f3 == 19 && wt3 == 2) {
+                Reader so = e.sub();
+                while (!so.done()) {
+                  int wt4, f4 = so.tag(wt4);
+                  if (f4 == 2 && wt4 == 0) opt.first = so.varint() == 1;
+                  else if (f4 == 3 && wt4 == 0) opt.second = so.varint() == 1;
+                  else so.skip(wt4);
+                }
+              } else {
+                e.skip(wt3);
+              }
+            }
+            op->smj_sort_options.push_back(opt);
+          } else if (f2 == 5 && wt2 == 2) op->join_condition = decode_expr(b.sub());
+          else b.skip(wt2);
+        }
+        if (op->join_type == JoinType::RightOuter) op->build_side = BuildSide::Left;   // probe (= preserved) side streams
+        break;
       case 109:
         op->kind = OpKind::HashJoin;
         while (!b.done()) {

@@ -348,7 +348,7 @@ class Operator:
     offset: int = 0
     files: List[tuple] = field(default_factory=list)          # (path, start, length, file_size)
 
-    TAGS = dict(scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, hash_join=109, native_scan=111)
+    TAGS = dict(scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -393,6 +393,16 @@ class Operator:
                 pf += _f_varint(3, length) + _f_varint(4, size)
                 part += _f_msg(1, pf)
             body = _f_msg(1, common) + _f_msg(2, part)
+        elif self.kind == "sort_merge_join":
+            # SortMergeJoin{left_join_keys=1,right_join_keys=2,join_type=3,sort_options=4,condition=5} (operator.proto:765-771)
+            body = b"".join(_f_msg(1, e.encode()) for e in self.left_keys) + b"".join(_f_msg(2, e.encode()) for e in self.right_keys)
+            if self.join_type:
+                body += _f_varint(3, self.join_type)
+            for e, desc, nulls_last in self.sort_orders:
+                so = _f_msg(1, e.encode()) + (_f_varint(2, 1) if desc else b"") + (_f_varint(3, 1) if nulls_last else b"")
+                body += _f_msg(4, _f_msg(19, so))
+            if self.condition is not None:
+                body += _f_msg(5, self.condition.encode())
         elif self.kind == "hash_join":
             # HashJoin{left_join_keys=1,right_join_keys=2,join_type=3,condition=4,build_side=5} (operator.proto:754-763)
             body = b"".join(_f_msg(1, e.encode()) for e in self.left_keys) + b"".join(_f_msg(2, e.encode()) for e in self.right_keys)
@@ -465,6 +475,14 @@ def hash_join(left: Operator, right: Operator, left_keys: Sequence[Expr], right_
     """Keys are bound to each side's own schema; `condition` to the concatenated left ++ right schema."""
     return Operator("hash_join", [left, right], left_keys=list(left_keys), right_keys=list(right_keys), join_type=join_type,
                     build_side=build_side, condition=condition)
+
+
+def sort_merge_join(left: Operator, right: Operator, left_keys: Sequence[Expr], right_keys: Sequence[Expr], join_type: int = INNER,
+                    condition: Optional[Expr] = None, descending: bool = False) -> Operator:
+    """SortMergeJoin: same keys / join types as hash_join; sort_options carry the key ordering of the (sorted) inputs."""
+    so = [(k, descending, descending) for k in left_keys]
+    return Operator("sort_merge_join", [left, right], left_keys=list(left_keys), right_keys=list(right_keys), join_type=join_type,
+                    condition=condition, sort_orders=so)
 
 
 def config_map(entries: dict) -> bytes:

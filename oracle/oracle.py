@@ -463,10 +463,36 @@ def run_plan(S, op, table) -> List[Col]:
         t = pa.concat_tables(parts) if parts else pa.table({n: pa.array([], type=pa.null()) for n in op.field_names})
         t = t.select(list(op.field_names))
         return [col_from_arrow(S, t.column(i), ty) for i, ty in enumerate(op.fields)]
-    if k == "hash_join":
+    if k in ("hash_join", "sort_merge_join"):
         left = run_plan(S, op.children[0], table)
         right = run_plan(S, op.children[1], table)
-        return _hash_join(S, ev, op, left, right)
+        out = _hash_join(S, ev, op, left, right)
+        if k == "sort_merge_join" and out:
+            # SortMergeJoinExec emits in join-key order (planner.rs:2126-2191): order the pairs by the preserved side's keys
+            import functools
+            n = len(out[0])
+            by_right = op.join_type == S.RIGHT_OUTER
+            keys = op.right_keys if by_right else op.left_keys
+            nl = len(left)
+            cols = out[nl:] if by_right else out
+            kc = [(ev.eval(e, cols, n), so[1], so[2]) for e, so in zip(keys, op.sort_orders)]
+
+            def cmp(i, j):
+                for c, desc, nulls_last in kc:
+                    ni, nj = not c.ok()[i], not c.ok()[j]
+                    if ni or nj:
+                        if ni and nj:
+                            continue
+                        r = -1 if ni else 1
+                        return r if not nulls_last else -r
+                    a, b = c.values[i], c.values[j]
+                    if a != b:
+                        r = -1 if a < b else 1
+                        return -r if desc else r
+                return 0
+            order = np.array(sorted(range(n), key=functools.cmp_to_key(cmp)), dtype=np.int64)
+            out = [_take(c, order) for c in out]
+        return out
     child = run_plan(S, op.children[0], table)
     n = len(child[0]) if child else 0
     if k == "filter":

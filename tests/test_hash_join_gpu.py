@@ -119,3 +119,16 @@ def test_outer_join_with_condition_empty_sides_and_projection_on_top(built):
     ro = S.hash_join(S.scan([S.T_INT64, S.T_INT32]), S.scan([S.T_INT64, S.T_DOUBLE]), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.RIGHT_OUTER, S.BUILD_RIGHT)
     got = _run(ro, [left.slice(0, 0), right], 4, batch_size=0)
     assert got.num_rows == right.num_rows and got.column(0).null_count == right.num_rows
+
+
+@pytest.mark.parametrize("jt", [S.INNER, S.LEFT_OUTER, S.RIGHT_OUTER, S.FULL_OUTER, S.LEFT_SEMI, S.LEFT_ANTI])
+def test_sort_merge_join_operator(built, jt):
+    """SortMergeJoin (operator.proto:765-771, planner.rs:2126-2191) runs as hash join + sort of the output by the join keys:
+    same rows as the oracle, and the preserved side's key column comes out in key order."""
+    left, right = _tables(5000, 4000, 21)
+    plan = S.sort_merge_join(S.scan([S.T_INT64, S.T_INT32]), S.scan([S.T_INT64, S.T_DOUBLE]), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt)
+    ncols = 2 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 4
+    got, want = _run(plan, [left, right], ncols, batch_size=0), _oracle(plan, [left, right])
+    assert _rows(got) == _rows(want) and got.num_rows > 0
+    kcol = 2 if jt == S.RIGHT_OUTER else 0
+    assert got.column(kcol).to_pylist() == want.column(kcol).to_pylist()       # NULLS FIRST, ascending
