@@ -2216,7 +2216,10 @@ std::string ExecutionContext::metrics_proto() {
     MetricNode n;
     n.metrics.emplace_back("output_rows", root ? output_rows_ : 0);
     n.metrics.emplace_back("elapsed_compute", root ? (int64_t)elapsed_compute_ns_ : 0);
-    if (op.kind == OpKind::NativeScan) n.metrics.emplace_back("bytes_scanned", bytes_scanned_);
+    if (op.kind == OpKind::NativeScan) {
+      n.metrics.emplace_back("bytes_scanned", bytes_scanned_);
+      n.metrics.emplace_back("row_groups_pruned_statistics", row_groups_pruned_);
+    }
     for (auto& c : op.children) n.children.push_back(build(*c, false));
     return n;
   };

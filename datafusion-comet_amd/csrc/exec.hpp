@@ -178,6 +178,7 @@ class ExecutionContext {
   std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index
   int64_t join_build_rows_ = 0, join_probe_rows_ = 0;
   int64_t bytes_scanned_ = 0;
+  int64_t row_groups_pruned_ = 0;
 
   std::vector<std::unique_ptr<Staging>> staging_;   // per input stream
   std::vector<bool> schema_checked_;                // per input stream

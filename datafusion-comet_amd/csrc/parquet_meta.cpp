@@ -131,6 +131,24 @@ ColumnMeta read_column_meta(TReader& r) {
       case 7: m.total_compressed = r.zigzag(); break;
       case 9: m.data_page_offset = r.zigzag(); break;
       case 11: m.dictionary_page_offset = r.zigzag(); break;
+      case 12: {   // Statistics
+        int16_t f2 = 0;
+        std::string mn, mx, mn_old, mx_old;
+        bool has_new = false, has_old = false;
+        while (int t2 = r.field(f2)) {
+          switch (f2) {
+            case 1: mx_old = r.binary(); has_old = true; break;
+            case 2: mn_old = r.binary(); break;
+            case 3: m.null_count = r.zigzag(); break;
+            case 5: mx = r.binary(); has_new = true; break;
+            case 6: mn = r.binary(); break;
+            default: r.skip(t2);
+          }
+        }
+        if (has_new) { m.min_value = mn; m.max_value = mx; m.has_min_max = true; }
+        else if (has_old) { m.min_value = mn_old; m.max_value = mx_old; m.has_min_max = true; }   // signed physical types only (checked by the user)
+        break;
+      }
       default: r.skip(t);
     }
   }

@@ -32,6 +32,10 @@ struct ColumnMeta {
   int64_t num_values = 0;
   int64_t total_uncompressed = 0, total_compressed = 0;
   int64_t data_page_offset = 0, dictionary_page_offset = 0;
+  // Statistics (parquet.thrift Statistics: 3 null_count, 5 max_value, 6 min_value; 1/2 = deprecated max/min, signed order only)
+  bool has_min_max = false;
+  std::string min_value, max_value;   // PLAIN-encoded
+  int64_t null_count = -1;            // -1 = not recorded
 };
 
 struct RowGroup {

@@ -187,6 +187,35 @@ void parse_hybrid_runs(const uint8_t* staged, size_t pos, size_t end, int bw, in
   }
 }
 
+// ---- row-group pruning from column-chunk statistics (the reference pushes data_filters into DataFusion's ParquetSource, which
+// prunes row groups by min/max; parquet_exec.rs:60-211).  Only an optimisation: the plan's Filter still runs on what is read.
+// A row group is skipped when some conjunct `column <op> literal` cannot be TRUE for any row given [min, max] (and for
+// IS NOT NULL when every value is NULL).  Integers, dates, timestamps and INT32/INT64-backed decimals are handled.
+bool stat_i64(const pq::ColumnMeta& cm, const pq::SchemaElement& el, int64_t& mn, int64_t& mx) {
+  if (!cm.has_min_max) return false;
+  auto rd = [&](const std::string& b, int64_t& v) {
+    if (el.type == pq::INT32 && b.size() == 4) { int32_t x; memcpy(&x, b.data(), 4); v = x; return true; }
+    if (el.type == pq::INT64 && b.size() == 8) { memcpy(&v, b.data(), 8); return true; }
+    return false;
+  };
+  return rd(cm.min_value, mn) && rd(cm.max_value, mx);
+}
+bool lit_i64(const Expr& e, int64_t& v) {
+  if (e.kind != ExprKind::Literal || e.lit_null) return false;
+  switch (e.dtype.id) {
+    case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Int64: case TypeId::Date: case TypeId::Timestamp: case TypeId::TimestampNtz:
+      v = e.lit_i64;
+      return true;
+    case TypeId::Decimal:
+      if (e.lit_dec > (i128)INT64_MAX || e.lit_dec < (i128)INT64_MIN) return false;
+      v = (int64_t)e.lit_dec;
+      return true;
+    default: return false;
+  }
+}
+// can `pred` be proven FALSE (or NULL) for every row of the row group?
+bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::FileMeta& fm, const pq::RowGroup& rg, bool case_sensitive);
+
 struct ColumnPlan {
   int leaf = -1;          // index into row_group.columns
   pq::SchemaElement el;
@@ -275,6 +304,63 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, bool cas
 // staging block at the chunk's slot, hybrid-run tables.  Independent of every other chunk, so chunks are prepared by a
 // pool of host threads (scan_parquet); the calling thread then concatenates a column's tables and decodes the WHOLE column
 // (all row groups) with one upload and one launch per kernel.
+bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::FileMeta& fm, const pq::RowGroup& rg, bool case_sensitive) {
+  if (pred.kind == ExprKind::And) {
+    for (auto& c : pred.children)
+      if (prunes(*c, schema, fm, rg, case_sensitive)) return true;
+    return false;
+  }
+  if (pred.kind == ExprKind::Or) {
+    for (auto& c : pred.children)
+      if (!prunes(*c, schema, fm, rg, case_sensitive)) return false;
+    return !pred.children.empty();
+  }
+  auto column_of = [&](const Expr& b, const pq::ColumnMeta*& cm, const pq::SchemaElement*& el, DType& want) {
+    if (b.kind != ExprKind::Bound || b.bound_index < 0 || (size_t)b.bound_index >= schema.size()) return false;
+    const StructField& f = schema[(size_t)b.bound_index];
+    int leaf = 0;
+    for (size_t i = 1; i < fm.schema.size(); i++) {
+      const pq::SchemaElement& e = fm.schema[i];
+      if (e.num_children > 0) return false;
+      if ((case_sensitive && e.name == f.name) || (!case_sensitive && iequals(e.name, f.name))) {
+        if ((size_t)leaf >= rg.columns.size()) return false;
+        cm = &rg.columns[(size_t)leaf];
+        el = &e;
+        want = f.dtype;
+        return true;
+      }
+      leaf++;
+    }
+    return false;
+  };
+  if (pred.kind == ExprKind::IsNotNull && pred.children.size() == 1) {
+    const pq::ColumnMeta* cm; const pq::SchemaElement* el; DType t;
+    if (!column_of(*pred.children[0], cm, el, t)) return false;
+    return cm->null_count >= 0 && cm->null_count == cm->num_values && cm->num_values > 0;
+  }
+  const bool cmp = pred.kind == ExprKind::Eq || pred.kind == ExprKind::Lt || pred.kind == ExprKind::LtEq || pred.kind == ExprKind::Gt || pred.kind == ExprKind::GtEq;
+  if (!cmp || pred.children.size() != 2) return false;
+  const Expr *l = pred.children[0].get(), *r = pred.children[1].get();
+  ExprKind k = pred.kind;
+  if (l->kind == ExprKind::Literal) {   // literal <op> column  →  column <flipped op> literal
+    std::swap(l, r);
+    k = k == ExprKind::Lt ? ExprKind::Gt : k == ExprKind::LtEq ? ExprKind::GtEq : k == ExprKind::Gt ? ExprKind::Lt : k == ExprKind::GtEq ? ExprKind::LtEq : k;
+  }
+  const pq::ColumnMeta* cm; const pq::SchemaElement* el; DType t;
+  int64_t v, mn, mx;
+  if (!column_of(*l, cm, el, t) || !lit_i64(*r, v) || !stat_i64(*cm, *el, mn, mx)) return false;
+  if (t.id == TypeId::Decimal && (el->scale != t.scale || !(r->dtype.id == TypeId::Decimal && r->dtype.scale == t.scale))) return false;   // same scale only
+  if (t.id != TypeId::Decimal && r->dtype.id == TypeId::Decimal) return false;
+  switch (k) {
+    case ExprKind::Eq: return v < mn || v > mx;
+    case ExprKind::Lt: return mn >= v;
+    case ExprKind::LtEq: return mn > v;
+    case ExprKind::Gt: return mx <= v;
+    case ExprKind::GtEq: return mx < v;
+    default: return false;
+  }
+}
+
 struct HostChunk {
   ColumnPlan cp;
   int max_def = 0;
@@ -479,6 +565,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       int64_t mid = start + comp / 2;
       const bool whole = pf.length <= 0;
       if (!whole && !(mid >= pf.start && mid < pf.start + pf.length)) continue;
+      bool skip = false;
+      for (auto& df : op.data_filters)
+        if (prunes(*df, op.required_schema, *fm, rg, op.case_sensitive)) { skip = true; break; }
+      if (skip) { row_groups_pruned_++; continue; }
       sels.push_back({mf, fm, (int)g, total_rows});
       total_rows += rg.num_rows;
     }

@@ -340,6 +340,7 @@ class Operator:
     # native_scan
     field_names: List[str] = field(default_factory=list)
     case_sensitive: bool = True
+    data_filters: List[Expr] = field(default_factory=list)    # pushed-down predicates (row-group pruning only)
     # sort / limit
     sort_orders: List[tuple] = field(default_factory=list)   # (expr, descending, nulls_last)
     fetch: Optional[int] = None
@@ -383,6 +384,7 @@ class Operator:
             sf = lambda n, t: _f_bytes(1, n.encode()) + _f_msg(2, t.encode()) + _f_varint(3, 1)
             common = b"".join(_f_msg(1, sf(n, t)) for n, t in zip(self.field_names, self.fields))
             common += b"".join(_f_msg(2, sf(n, t)) for n, t in zip(self.field_names, self.fields))
+            common += b"".join(_f_msg(4, e.encode()) for e in self.data_filters)
             common += b"".join(_f_varint(5, i) for i in range(len(self.fields)))
             common += _f_bytes(6, b"UTC") + (_f_varint(9, 1) if self.case_sensitive else b"") + _f_bytes(12, b"parquet") + b"".join(_f_msg(13, t.encode()) for t in self.fields)
             part = b""
@@ -453,7 +455,8 @@ def final_of(partial_plan: "Operator", state_schema) -> "Operator":
     return hash_agg(scan(fields), [col(i, fields[i]) for i in range(ng)], partial_plan.aggs, FINAL)
 
 
-def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType], case_sensitive: bool = True) -> Operator:
+def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType], case_sensitive: bool = True,
+                data_filters: Sequence[Expr] = ()) -> Operator:
     """Parquet scan of `files` (paths, or (path, start, length, size) byte-range splits) producing columns `names`."""
     import os
     fl = []
@@ -463,7 +466,7 @@ def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType]
             fl.append((f, 0, sz, sz))
         else:
             fl.append(tuple(f))
-    return Operator("native_scan", fields=list(types), field_names=list(names), files=fl, case_sensitive=case_sensitive)
+    return Operator("native_scan", fields=list(types), field_names=list(names), files=fl, case_sensitive=case_sensitive, data_filters=list(data_filters))
 
 
 INNER, LEFT_OUTER, RIGHT_OUTER, FULL_OUTER, LEFT_SEMI, LEFT_ANTI = range(6)
