@@ -10,6 +10,8 @@
 // order inside each partition (same result as the reference's reverse fill).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "device/comet_device.hpp"
 
 using namespace comet;
@@ -203,6 +205,20 @@ __global__ __launch_bounds__(256) void take_utf8_copy_kernel(const i32* offs, co
   }
 }
 
+// ---- constant columns (Hive partition values of a Parquet scan): dst[first .. first+n) = value
+template <class T>
+__global__ __launch_bounds__(256) void fill_kernel(T* dst, i64 n, T value) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[i] = value;
+}
+// Utf8 constant: offsets[i] = base + i·len for i in [0, n]; bytes = the value repeated n times
+__global__ __launch_bounds__(256) void fill_utf8_kernel(i32* offsets, u8* bytes, i64 n, i32 base, i32 len, const u8* value) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i <= n; i += (i64)gridDim.x * 256) {
+    offsets[i] = base + (i32)i * len;
+    if (i < n)
+      for (i32 b = 0; b < len; b++) bytes[(i64)base + i * len + b] = value[b];
+  }
+}
+
 int grid_for(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -254,6 +270,24 @@ int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const
                                 int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream) {
   if (n > 0)
     hipLaunchKernelGGL(take_utf8_copy_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offs, bytes, idx, ok_bytes, src_valid_bits, (i64)n, out_offs, out_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// width ∈ {1,2,4,8,16}: value points to `width` bytes on the HOST
+int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0) return 0;
+  switch (width) {
+    case 1: hipLaunchKernelGGL(fill_kernel<u8>, grid_for(n), 256, 0, st, (u8*)dst, (i64)n, *(const u8*)value); break;
+    case 2: hipLaunchKernelGGL(fill_kernel<unsigned short>, grid_for(n), 256, 0, st, (unsigned short*)dst, (i64)n, *(const unsigned short*)value); break;
+    case 4: hipLaunchKernelGGL(fill_kernel<u32>, grid_for(n), 256, 0, st, (u32*)dst, (i64)n, *(const u32*)value); break;
+    case 8: hipLaunchKernelGGL(fill_kernel<u64>, grid_for(n), 256, 0, st, (u64*)dst, (i64)n, *(const u64*)value); break;
+    case 16: { i128 v; memcpy(&v, value, 16); hipLaunchKernelGGL(fill_kernel<i128>, grid_for(n), 256, 0, st, (i128*)dst, (i64)n, v); break; }
+    default: return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_fill_utf8(int32_t* offsets, uint8_t* bytes, int64_t n, int32_t base, int32_t len, const uint8_t* dev_value, void* stream) {
+  hipLaunchKernelGGL(fill_utf8_kernel, grid_for(n + 1), 256, 0, (hipStream_t)stream, offsets, bytes, (i64)n, base, len, dev_value);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stream) {

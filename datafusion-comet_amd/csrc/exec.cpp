@@ -430,9 +430,9 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     return st;
   }
   if (op.kind == OpKind::NativeScan) {
-    if (!op.partition_schema.empty()) throw CometError("Hive-partition columns are not supported by the GPU Parquet scan yet");
     std::vector<DType> out;
     for (auto& f : op.required_schema) out.push_back(f.dtype);
+    for (auto& f : op.partition_schema) out.push_back(f.dtype);   // Hive partition columns follow the file columns
     explain_ += "  parquet scan: " + std::to_string(op.files.size()) + " file(s), " + std::to_string(out.size()) + " column(s)\n";
     return out;
   }

@@ -23,6 +23,8 @@
 #include "parquet_dev.h"
 #include "parquet_meta.hpp"
 
+extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
+extern "C" int comet_launch_fill_utf8(int32_t* offsets, uint8_t* bytes, int64_t n, int32_t base, int32_t len, const uint8_t* dev_value, void* stream);
 extern "C" {
 void pq_launch_validity(const PqDecodeArgs* a, void* st);
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st);
@@ -540,16 +542,17 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-  if (!op.partition_schema.empty()) throw CometError("Hive-partition columns are not supported by the GPU Parquet scan yet");
   const size_t ncol = op.required_schema.size();
+  const size_t npart = op.partition_schema.size();
   DevTable out;
   for (auto& f : op.required_schema) out.types.push_back(f.dtype);
-  out.cols.assign(ncol, DeviceColumnView());
-  out.has_valid.assign(ncol, false);
+  for (auto& f : op.partition_schema) out.types.push_back(f.dtype);
+  out.cols.assign(ncol + npart, DeviceColumnView());
+  out.has_valid.assign(ncol + npart, false);
   if (op.files.empty()) return out;   // EmptyExec (planner.rs:1548-1556)
 
   // pass 1: open files, pick row groups (midpoint rule), total rows
-  struct Sel { std::shared_ptr<OpenFile> file; std::shared_ptr<pq::FileMeta> meta; int rg; int64_t row_off; };
+  struct Sel { std::shared_ptr<OpenFile> file; std::shared_ptr<pq::FileMeta> meta; int rg; int64_t row_off; const PartitionedFile* pf; int64_t rows; };
   std::vector<Sel> sels;
   int64_t total_rows = 0;
   for (auto& pf : op.files) {
@@ -569,7 +572,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       for (auto& df : op.data_filters)
         if (prunes(*df, op.required_schema, *fm, rg, op.case_sensitive)) { skip = true; break; }
       if (skip) { row_groups_pruned_++; continue; }
-      sels.push_back({mf, fm, (int)g, total_rows});
+      sels.push_back({mf, fm, (int)g, total_rows, &pf, rg.num_rows});
       total_rows += rg.num_rows;
     }
   }
@@ -852,6 +855,93 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     }
     out.owners.push_back(valid_bytes);
     out.cols[c] = cv;
+  }
+  // Hive partition columns: one constant per file (SparkPartitionedFile.partition_values, operator.proto:103-109), appended after
+  // the file columns (planner.rs:1558-1575); a NULL partition value clears the validity of its rows
+  for (size_t p = 0; p < npart; p++) {
+    const DType& t = op.partition_schema[p].dtype;
+    const bool is_str = t.id == TypeId::String || t.id == TypeId::Bytes;
+    const int w = is_str ? 0 : (t.id == TypeId::Bool ? 1 : out_width_of(t));
+    auto vals = std::make_shared<DevBuf>();
+    auto bytes = std::make_shared<DevBuf>();
+    auto vbytes = std::make_shared<DevBuf>();
+    vbytes->ensure((size_t)total_rows + 16);
+    bool any_null = false;
+    int64_t str_total = 0;
+    if (is_str) {
+      for (auto& sel : sels) {
+        if (p >= sel.pf->partition_values.size()) throw CometError("parquet: file without a value for partition column '" + op.partition_schema[p].name + "'");
+        const Expr& lit = *sel.pf->partition_values[p];
+        if (!lit.lit_null) str_total += (int64_t)lit.lit_bytes.size() * sel.rows;
+      }
+      if (str_total >= ((int64_t)1 << 31)) throw CometError("parquet: partition string column exceeds 2 GiB");
+      vals->ensure((size_t)(total_rows + 1) * 4 + 16);
+      bytes->ensure((size_t)std::max<int64_t>(str_total, 1) + 16);
+    } else {
+      vals->ensure((size_t)total_rows * (size_t)w + 16);
+    }
+    int64_t str_pos = 0;
+    std::vector<std::shared_ptr<DevBuf>> lit_keep;
+    for (auto& sel : sels) {
+      if (p >= sel.pf->partition_values.size()) throw CometError("parquet: file without a value for partition column '" + op.partition_schema[p].name + "'");
+      const Expr& lit = *sel.pf->partition_values[p];
+      if (lit.kind != ExprKind::Literal) throw CometError("parquet: partition value is not a literal");
+      const uint8_t ok = lit.lit_null ? 0 : 1;
+      any_null |= lit.lit_null;
+      if (comet_launch_fill(1, (uint8_t*)vbytes->p + sel.row_off, sel.rows, &ok, stream_) != 0) throw CometError("partition column: launch failed");
+      if (is_str) {
+        const int32_t len = lit.lit_null ? 0 : (int32_t)lit.lit_bytes.size();
+        auto dv = std::make_shared<DevBuf>();
+        dv->ensure((size_t)std::max(len, 1) + 16);
+        if (len) {
+          small_host_.ensure(4096);
+          if (len > 2048) throw CometError("parquet: partition string value longer than 2048 bytes");
+          write_small(dv->p, lit.lit_bytes.data(), (size_t)len);
+        }
+        lit_keep.push_back(dv);
+        if (comet_launch_fill_utf8((int32_t*)vals->p + sel.row_off, (uint8_t*)bytes->p, sel.rows, (int32_t)str_pos, len, (const uint8_t*)dv->p, stream_) != 0)
+          throw CometError("partition column: launch failed");
+        str_pos += (int64_t)len * sel.rows;
+      } else {
+        unsigned char raw[16] = {0};
+        switch (t.id) {
+          case TypeId::Bool: raw[0] = lit.lit_bool ? 1 : 0; break;
+          case TypeId::Int8: { int8_t x = (int8_t)lit.lit_i64; memcpy(raw, &x, 1); break; }
+          case TypeId::Int16: { int16_t x = (int16_t)lit.lit_i64; memcpy(raw, &x, 2); break; }
+          case TypeId::Int32: case TypeId::Date: { int32_t x = (int32_t)lit.lit_i64; memcpy(raw, &x, 4); break; }
+          case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: memcpy(raw, &lit.lit_i64, 8); break;
+          case TypeId::Float: { float x = (float)lit.lit_f64; memcpy(raw, &x, 4); break; }
+          case TypeId::Double: memcpy(raw, &lit.lit_f64, 8); break;
+          case TypeId::Decimal: memcpy(raw, &lit.lit_dec, 16); break;
+          default: throw CometError("parquet: partition column of type " + t.str() + " is not supported by the GPU scan yet");
+        }
+        if (comet_launch_fill(w, (char*)vals->p + (size_t)sel.row_off * (size_t)w, sel.rows, raw, stream_) != 0) throw CometError("partition column: launch failed");
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));   // literal staging buffers
+    DeviceColumnView cv;
+    cv.data = vals->p;
+    out.owners.push_back(vals);
+    if (is_str) {
+      cv.aux = bytes->p;
+      out.owners.push_back(bytes);
+    } else if (t.id == TypeId::Bool) {
+      auto bits = std::make_shared<DevBuf>();
+      bits->ensure((size_t)((total_rows + 7) / 8) + 16);
+      pq_launch_pack((const uint8_t*)vals->p, (uint8_t*)bits->p, total_rows, stream_);
+      cv.data = bits->p;
+      out.owners.push_back(bits);
+    }
+    if (any_null) {
+      auto bm = std::make_shared<DevBuf>();
+      bm->ensure((size_t)((total_rows + 7) / 8) + 16);
+      pq_launch_pack((const uint8_t*)vbytes->p, (uint8_t*)bm->p, total_rows, stream_);
+      cv.valid = (const uint8_t*)bm->p;
+      out.has_valid[ncol + p] = true;
+      out.owners.push_back(bm);
+    }
+    out.owners.push_back(vbytes);
+    out.cols[ncol + p] = cv;
   }
   if (trace) fprintf(stderr, "[comet] parquet: all launches issued at %.2f ms\n", ms_since());
   HIP_CHECK(hipStreamSynchronize(stream_));

@@ -341,6 +341,8 @@ class Operator:
     field_names: List[str] = field(default_factory=list)
     case_sensitive: bool = True
     data_filters: List[Expr] = field(default_factory=list)    # pushed-down predicates (row-group pruning only)
+    partition_fields: List[tuple] = field(default_factory=list)   # Hive partition columns: (name, DataType)
+    partition_values: List[tuple] = field(default_factory=list)   # per file: one python value per partition column (None = NULL)
     # sort / limit
     sort_orders: List[tuple] = field(default_factory=list)   # (expr, descending, nulls_last)
     fetch: Optional[int] = None
@@ -384,15 +386,18 @@ class Operator:
             sf = lambda n, t: _f_bytes(1, n.encode()) + _f_msg(2, t.encode()) + _f_varint(3, 1)
             common = b"".join(_f_msg(1, sf(n, t)) for n, t in zip(self.field_names, self.fields))
             common += b"".join(_f_msg(2, sf(n, t)) for n, t in zip(self.field_names, self.fields))
+            common += b"".join(_f_msg(3, sf(n, t)) for n, t in self.partition_fields)
             common += b"".join(_f_msg(4, e.encode()) for e in self.data_filters)
             common += b"".join(_f_varint(5, i) for i in range(len(self.fields)))
             common += _f_bytes(6, b"UTC") + (_f_varint(9, 1) if self.case_sensitive else b"") + _f_bytes(12, b"parquet") + b"".join(_f_msg(13, t.encode()) for t in self.fields)
             part = b""
-            for path, start, length, size in self.files:
+            for fi, (path, start, length, size) in enumerate(self.files):
                 pf = _f_bytes(1, ("file://" + path).encode())
                 if start:
                     pf += _f_varint(2, start)
                 pf += _f_varint(3, length) + _f_varint(4, size)
+                if self.partition_values:
+                    pf += b"".join(_f_msg(5, lit(v, t).encode()) for v, (_, t) in zip(self.partition_values[fi], self.partition_fields))
                 part += _f_msg(1, pf)
             body = _f_msg(1, common) + _f_msg(2, part)
         elif self.kind == "sort_merge_join":
@@ -456,7 +461,7 @@ def final_of(partial_plan: "Operator", state_schema) -> "Operator":
 
 
 def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType], case_sensitive: bool = True,
-                data_filters: Sequence[Expr] = ()) -> Operator:
+                data_filters: Sequence[Expr] = (), partition_fields: Sequence[tuple] = (), partition_values: Sequence[tuple] = ()) -> Operator:
     """Parquet scan of `files` (paths, or (path, start, length, size) byte-range splits) producing columns `names`."""
     import os
     fl = []
@@ -466,7 +471,8 @@ def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType]
             fl.append((f, 0, sz, sz))
         else:
             fl.append(tuple(f))
-    return Operator("native_scan", fields=list(types), field_names=list(names), files=fl, case_sensitive=case_sensitive, data_filters=list(data_filters))
+    return Operator("native_scan", fields=list(types), field_names=list(names), files=fl, case_sensitive=case_sensitive, data_filters=list(data_filters),
+                    partition_fields=list(partition_fields), partition_values=list(partition_values))
 
 
 INNER, LEFT_OUTER, RIGHT_OUTER, FULL_OUTER, LEFT_SEMI, LEFT_ANTI = range(6)

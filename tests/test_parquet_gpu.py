@@ -207,3 +207,32 @@ def test_row_group_pruning_from_statistics(built, tmp_path):
     # a filter that excludes everything prunes every row group: empty result
     nothing = S.native_scan([path], t.schema.names, types, data_filters=[S.gt(S.lit(tpch.days(1990, 1, 1), S.T_DATE), d)])
     assert native.execute_to_table([], 3, nothing.encode()) == []
+
+
+def test_hive_partition_columns(built, tmp_path):
+    """Partition columns are appended after the file columns as one constant per file (operator.proto:103-109, planner.rs:1558-1575),
+    NULL partition values included; a filter / aggregate above sees them like any column."""
+    rng = np.random.default_rng(14)
+    files, parts, want_tabs = [], [], []
+    pvals = [(2023, "eu-west", tpch.days(2023, 1, 5)), (2024, None, tpch.days(2024, 2, 6)), (2025, "a much longer region name than fifteen bytes", None)]
+    for i, pv in enumerate(pvals):
+        n = 5000 + 777 * i
+        t = pa.table({"x": pa.array(rng.integers(0, 100, n), pa.int64()), "s": pa.array(["v%d" % (j % 7) for j in range(n)])})
+        path = str(tmp_path / f"part{i}.parquet")
+        papq.write_table(t, path, row_group_size=2000)
+        files.append(path)
+        parts.append(pv)
+        want_tabs.append(t.append_column("year", pa.array([pv[0]] * n, pa.int32())).append_column("region", pa.array([pv[1]] * n, pa.utf8()))
+                         .append_column("day", pa.array([pv[2]] * n, pa.int32()).cast(pa.date32())))
+    want = pa.concat_tables(want_tabs)
+    pf = [("year", S.T_INT32), ("region", S.T_STRING), ("day", S.T_DATE)]
+    scan = S.native_scan(files, ["x", "s"], [S.T_INT64, S.T_STRING], partition_fields=pf, partition_values=parts)
+    got = pa.Table.from_batches(native.execute_to_table([], 5, scan.encode(), batch_size=0))
+    for i, name in enumerate(want.schema.names):
+        assert got.column(i).combine_chunks().equals(want.column(name).combine_chunks()), name
+    # filter on a partition column + aggregate grouped by it
+    plan = S.hash_agg(S.filter_(scan, S.gt(S.col(2, S.T_INT32), S.lit(2023, S.T_INT32))), [S.col(2, S.T_INT32)], [S.count(S.col(0, S.T_INT64)), S.sum_(S.col(0, S.T_INT64), S.T_INT64)])
+    res = pa.Table.from_batches(native.execute_to_table([], 3, plan.encode(), batch_size=0))
+    rows = sorted(zip(*[res.column(i).to_pylist() for i in range(3)]))
+    exp = sorted((y, c.num_rows, sum(c.column("x").to_pylist())) for y, c in ((2024, want_tabs[1]), (2025, want_tabs[2])))
+    assert rows == exp
