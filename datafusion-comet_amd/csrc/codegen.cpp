@@ -236,6 +236,8 @@ struct Gen {
     k << (int)e->kind << ":" << (int)e->dtype.id << "," << e->dtype.precision << "," << e->dtype.scale << ":"
       << (int)e->eval_mode << e->fail_on_error << e->negated;
     if (e->kind == ExprKind::Bound) k << "#" << e->bound_index;
+    if (e->kind == ExprKind::ScalarFunc) k << "F" << e->func;
+    if (e->kind == ExprKind::CaseWhen) k << "W" << e->n_when;
     if (e->kind == ExprKind::Literal) {
       k << "L" << e->lit_case << e->lit_null << e->lit_bool << ":" << e->lit_i64 << ":";
       uint64_t fb;
@@ -780,6 +782,98 @@ struct Gen {
     return r;
   }
 
+  // ScalarFunc (expr.proto:466-471 → create_comet_physical_fun, comet_scalar_funcs.rs): the subset whose results are defined
+  // exactly (integer / IEEE operations): ceil, floor, abs, sqrt, signum, isnan, datepart.  Everything else is rejected by name.
+  Val scalar_func(const Expr& e) {
+    const std::string& f = e.func;
+    auto arg = [&](size_t i) { return named(gen(e.children.at(i))); };
+    Val r;
+    if (f == "ceil" || f == "floor") {
+      // spark_ceil / spark_floor (math_funcs/ceil.rs:24-84): Float → Int64 (`as i64`), Int64 unchanged, Decimal(s > 0) → div_ceil by 10^s
+      Val a = arg(0);
+      const bool up = f == "ceil";
+      r.ok = a.ok;
+      if (a.rep == Rep::F64 || a.rep == Rep::F32) {
+        r.t = DType::of(TypeId::Int64);
+        r.rep = Rep::I64;
+        r.v = "comet::f64_to_i64_sat(" + std::string(up ? "ceil" : "floor") + "((double)" + a.v + "))";
+        return r;
+      }
+      if (a.t.id == TypeId::Int64) return a;
+      if (a.t.id == TypeId::Decimal && a.t.scale > 0) {
+        if (!e.has_dtype || e.dtype.id != TypeId::Decimal) throw CometError(f + ": expected a Decimal128 return type");
+        r.t = e.dtype;
+        r.rep = Rep::I128;
+        r.v = std::string("comet::dec_div_") + (up ? "ceil" : "floor") + "(" + as128(a) + ", " + lit_i128((i128)pow10_u128(a.t.scale)) + ")";
+        r.maxabs = a.maxabs == kUnbounded ? kUnbounded : a.maxabs / pow10_u128(a.t.scale) + 1;
+        return r;
+      }
+      throw CometError("Unsupported data type " + a.t.str() + " for function " + f);
+    }
+    if (f == "abs") {
+      // spark_abs (math_funcs/abs.rs): wrapping_abs in LEGACY mode, ARITHMETIC_OVERFLOW for MIN in ANSI mode (second argument)
+      Val a = arg(0);
+      bool fail = e.fail_on_error;
+      if (e.children.size() == 2 && e.children[1]->kind == ExprKind::Literal && e.children[1]->dtype.id == TypeId::Bool) fail = e.children[1]->lit_bool;
+      r = a;
+      switch (a.rep) {
+        case Rep::F64: r.v = "fabs(" + a.v + ")"; return r;
+        case Rep::F32: r.v = "fabsf(" + a.v + ")"; return r;
+        case Rep::I128: r.v = "(" + a.v + " < 0 ? (i128)((u128)0 - (u128)" + a.v + ") : " + a.v + ")"; return r;
+        case Rep::I32: case Rep::I64: {
+          if (a.t.id == TypeId::Decimal) { r.v = "(" + a.v + " < 0 ? -" + a.v + " : " + a.v + ")"; return r; }
+          const std::string ct = a.t.id == TypeId::Int64 ? "i64" : a.t.id == TypeId::Int32 ? "i32" : a.t.id == TypeId::Int16 ? "i16" : "i8";
+          const std::string ut = a.t.id == TypeId::Int64 ? "u64" : a.t.id == TypeId::Int32 ? "u32" : a.t.id == TypeId::Int16 ? "unsigned short" : "u8";
+          const std::string mn = a.t.id == TypeId::Int64 ? "(i64)0x8000000000000000ull" : a.t.id == TypeId::Int32 ? "(i32)0x80000000" : a.t.id == TypeId::Int16 ? "-32768" : "-128";
+          if (fail) raise_if(and_ok(a.ok, "(" + a.v + " == " + mn + ")"), 1);
+          r.v = std::string("(") + rep_ctype(a.rep) + ")(" + ct + ")(" + a.v + " < 0 ? (" + ut + ")0 - (" + ut + ")(" + ct + ")" + a.v + " : (" + ut + ")(" + ct + ")" + a.v + ")";
+          return r;
+        }
+        default: throw CometError("Unsupported data type " + a.t.str() + " for function abs");
+      }
+    }
+    if (f == "sqrt") {
+      Val a = arg(0);
+      if (a.rep != Rep::F64) throw CometError("sqrt expects a Float64 argument");
+      r = a;
+      r.v = "__dsqrt_rn(" + a.v + ")";
+      return r;
+    }
+    if (f == "signum") {
+      Val a = arg(0);
+      if (a.rep != Rep::F64) throw CometError("signum expects a Float64 argument");
+      r = a;
+      r.v = "(" + a.v + " != " + a.v + " ? " + a.v + " : (" + a.v + " > 0.0 ? 1.0 : (" + a.v + " < 0.0 ? -1.0 : 0.0)))";   // 0 and -0 give 0 (DataFusion signum)
+      return r;
+    }
+    if (f == "isnan") {
+      // spark_isnan (predicate_funcs/is_nan.rs:26-67): NULL → false, never NULL
+      Val a = arg(0);
+      if (a.rep != Rep::F64 && a.rep != Rep::F32) throw CometError("Unsupported data type " + a.t.str() + " for function isnan");
+      r.t = DType::of(TypeId::Bool);
+      r.rep = Rep::B;
+      r.v = "(" + (a.ok.empty() ? std::string("true") : a.ok) + " && " + a.v + " != " + a.v + ")";
+      return r;
+    }
+    if (f == "datepart" || f == "date_part") {
+      // CometGetDateField (serde/datetime.scala:36-80): datepart(<field literal>, date) → Int32
+      if (e.children.size() != 2 || e.children[0]->kind != ExprKind::Literal) throw CometError("datepart expects (field literal, date)");
+      std::string part = e.children[0]->lit_bytes;
+      for (auto& ch : part) ch = (char)tolower((unsigned char)ch);
+      int code = part == "year" ? 0 : part == "month" ? 1 : part == "day" ? 2 : part == "quarter" ? 3 : part == "dow" ? 4 : part == "doy" ? 5 : -1;
+      if (code < 0) throw CometError("datepart field '" + part + "' is not supported by the MI355X native engine yet");
+      Val a = arg(1);
+      if (a.t.id != TypeId::Date) throw CometError("datepart over " + a.t.str() + " is not supported by the MI355X native engine yet");
+      r.t = DType::of(TypeId::Int32);
+      r.rep = Rep::I32;
+      r.ok = a.ok;
+      r.v = "comet::date_part(" + a.v + ", " + std::to_string(code) + ")";
+      r.maxabs = 6000000;
+      return r;
+    }
+    throw CometError("Scalar function '" + f + "' is not supported by the MI355X native engine");
+  }
+
   // ---- direct Utf8 comparisons (device/comet_device.hpp utf8_cmp*) ----
   bool is_str_col(const ExprP& x) const {
     return x->kind == ExprKind::Bound && x->bound_index >= 0 && (size_t)x->bound_index < in_types.size() &&
@@ -979,6 +1073,7 @@ struct Gen {
         }
         return r;
       }
+      case ExprKind::ScalarFunc: return scalar_func(e);
       case ExprKind::If: {
         if (e.children.size() != 3) throw CometError("If needs three children");
         return select(named(gen(e.children[0])), named(gen(e.children[1])), named(gen(e.children[2])));

@@ -193,6 +193,13 @@ void decode_expr_body(Reader r, Expr& e) {
       case ExprKind::If:
         if (f >= 1 && f <= 3 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
         break;
+      case ExprKind::ScalarFunc:
+        // ScalarFunc{func=1, args=2, return_type=3, fail_on_error=4} (expr.proto:466-471)
+        if (f == 1 && wt == 2) { e.func = r.bytes(); handled = true; }
+        else if (f == 2 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 3 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
+        else if (f == 4 && wt == 0) { e.fail_on_error = r.varint() != 0; handled = true; }
+        break;
       case ExprKind::CaseWhen:
         // expr = 1 is never set by Spark (expr.proto:474-479); when = 2 and then = 3 are parallel lists, else_expr = 4.
         // proto3 writes fields in number order, so the children arrive as when* then* [else]
@@ -220,7 +227,7 @@ ExprP decode_expr(Reader r) {
     switch (f) {
       case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
       case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
-      case 15: case 16: case 17: case 18: case 25: case 32: case 33: case 37: case 38: case 39: case 40: case 41:
+      case 15: case 16: case 17: case 18: case 25: case 31: case 32: case 33: case 37: case 38: case 39: case 40: case 41:
       case 44: case 45: case 51:
         e->kind = (ExprKind)f;
         if (e->kind == ExprKind::Bound) e->bound_index = 0;  // proto3 omits zero-valued scalars

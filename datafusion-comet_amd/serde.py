@@ -119,7 +119,7 @@ class Expr:
 
     # field numbers of Expr.expr_struct (expr.proto:30-107)
     TAGS = dict(literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
-                lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, eq_null_safe=32,
+                lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, scalar_func=31, eq_null_safe=32,
                 neq_null_safe=33, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
                 unbound=51)
 
@@ -157,6 +157,12 @@ class Expr:
                 body += _f_varint(3, 1)
         elif k == "if_":
             body = b"".join(_f_msg(i + 1, c.encode()) for i, c in enumerate(self.children))
+        elif k == "scalar_func":   # ScalarFunc{func=1, args=2, return_type=3, fail_on_error=4}; value = function name
+            body = _f_bytes(1, self.value.encode()) + b"".join(_f_msg(2, c.encode()) for c in self.children)
+            if self.dtype is not None:
+                body += _f_msg(3, self.dtype.encode())
+            if self.fail_on_error:
+                body += _f_varint(4, 1)
         elif k == "case_when":   # children = when* then* [else]; index = number of WHEN branches
             n = self.index
             body = b"".join(_f_msg(2, c.encode()) for c in self.children[:n]) + b"".join(_f_msg(3, c.encode()) for c in self.children[n:2 * n])
@@ -248,6 +254,16 @@ def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY) -> Expr:
 
 def if_(c: Expr, t: Expr, f: Expr) -> Expr:
     return Expr("if_", [c, t, f])
+
+
+def scalar_func(name: str, args: Sequence[Expr], return_type: Optional[DataType] = None, fail_on_error: bool = False) -> Expr:
+    """ScalarFunc (expr.proto:466-471), e.g. scalar_func("ceil", [x], T_INT64)."""
+    return Expr("scalar_func", list(args), dtype=return_type, value=name, fail_on_error=fail_on_error)
+
+
+def date_part(field_name: str, date_expr: Expr) -> Expr:
+    """What CometGetDateField emits for year()/month()/…: Cast(datepart(<field>, date) AS int) (serde/datetime.scala:36-80)."""
+    return cast(scalar_func("datepart", [lit(field_name, T_STRING), date_expr]), T_INT32)
 
 
 def case_when(branches: Sequence, else_: Optional[Expr] = None) -> Expr:

@@ -214,6 +214,8 @@ class Evaluator:
             vals = np.where(sel, t.values, f.values) if t.dtype.type_id != S.DECIMAL else np.where(sel, t.values, f.values)
             ok = np.where(sel, t.ok(), f.ok())
             return Col(t.dtype, vals, None if ok.all() else ok)
+        if k == "scalar_func":
+            return self._scalar_func(e, cols, n)
         if k == "case_when":
             # planner.rs:677-704 → DataFusion CaseExpr (no base expression): first WHEN that is TRUE wins, else ELSE / NULL
             nw = e.index
@@ -240,6 +242,62 @@ class Evaluator:
             ok = v.ok() & (hit | ~anynull)
             return Col(S.T_BOOL, ~hit if e.negated else hit, None if ok.all() else ok)
         raise NotImplementedError(f"oracle: expression {k}")
+
+    def _scalar_func(self, e, cols, n) -> Col:
+        """The exactly-defined ScalarFunc subset (comet_scalar_funcs.rs → math_funcs/{ceil,floor,abs}.rs, predicate_funcs/is_nan.rs,
+        DataFusion sqrt / signum / date_part)."""
+        S = self.S
+        f = e.value
+        if f in ("datepart", "date_part"):
+            import datetime
+            part = e.children[0].value.lower()
+            a = self.eval(e.children[1], cols, n)
+            out = np.zeros(n, np.int32)
+            for i in range(n):
+                if a.ok()[i]:
+                    d = datetime.date(1970, 1, 1) + datetime.timedelta(days=int(a.values[i]))
+                    out[i] = {"year": d.year, "month": d.month, "day": d.day, "quarter": (d.month - 1) // 3 + 1, "dow": (d.weekday() + 1) % 7,
+                              "doy": d.timetuple().tm_yday}[part]
+            return Col(S.T_INT32, out, a.valid)
+        a = self.eval(e.children[0], cols, n)
+        tid = a.dtype.type_id
+        if f in ("ceil", "floor"):
+            if tid in (S.FLOAT, S.DOUBLE):
+                with np.errstate(all="ignore"):
+                    x = (np.ceil if f == "ceil" else np.floor)(a.values.astype(np.float64))
+                out = np.zeros(n, np.int64)
+                for i in range(n):                                   # Rust `as i64`: saturating, NaN → 0
+                    v = x[i]
+                    out[i] = 0 if v != v else (2**63 - 1 if v >= 2.0**63 else (-2**63 if v <= -2.0**63 else int(v)))
+                return Col(S.T_INT64, out, a.valid)
+            if tid == S.INT64:
+                return a
+            if tid == S.DECIMAL and a.dtype.scale > 0:
+                d = 10 ** a.dtype.scale
+                vals = [(-((-dec_to_int(a.values, i)) // d) if f == "ceil" else dec_to_int(a.values, i) // d) for i in range(n)]
+                return Col(e.dtype, ints_to_dec(vals), a.valid)
+            raise OracleError(f"{f} over {a.dtype}")
+        if f == "abs":
+            fail = e.fail_on_error or (len(e.children) == 2 and bool(e.children[1].value))
+            if tid in (S.FLOAT, S.DOUBLE):
+                return Col(a.dtype, np.abs(a.values), a.valid)
+            if tid == S.DECIMAL:
+                return Col(a.dtype, ints_to_dec([abs(dec_to_int(a.values, i)) for i in range(n)]), a.valid)
+            info = np.iinfo(a.values.dtype)
+            if fail and ((a.values == info.min) & a.ok()).any():
+                raise OracleError("ARITHMETIC_OVERFLOW integer")
+            with np.errstate(over="ignore"):
+                return Col(a.dtype, np.where(a.values < 0, (0 - a.values.astype(np.int64)).astype(a.values.dtype), a.values), a.valid)   # wrapping_abs
+        if f == "sqrt":
+            with np.errstate(all="ignore"):
+                return Col(S.T_DOUBLE, np.sqrt(a.values.astype(np.float64)), a.valid)
+        if f == "signum":
+            x = a.values.astype(np.float64)
+            return Col(S.T_DOUBLE, np.where(x != x, x, np.where(x > 0, 1.0, np.where(x < 0, -1.0, 0.0))), a.valid)
+        if f == "isnan":
+            x = a.values.astype(np.float64)
+            return Col(S.T_BOOL, a.ok() & (x != x), None)
+        raise NotImplementedError(f"oracle: scalar function {f}")
 
     def _literal(self, e, n) -> Col:
         S = self.S
