@@ -489,6 +489,12 @@ ExecutionContext::~ExecutionContext() {
     if (in.host && in.host->release) in.host->release(in.host);
     if (in.dev && in.dev->release) in.dev->release(in.dev);
   }
+  for (auto& st : staging_)
+    if (st && st->busy) {
+      (void)hipEventSynchronize(st->busy);
+      pool_put_event(device_id_, st->busy);
+      st->busy = nullptr;
+    }
   if (stream_) {
     (void)hipStreamSynchronize(stream_);  // pooled buffers go back only once the stream is idle
     for (auto& pr : timed_) { pool_put_event(device_id_, pr.first); pool_put_event(device_id_, pr.second); }
@@ -1042,14 +1048,23 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
   rows_out = 0;
   if (in.exhausted) return false;
   validate_input_schema(input, in_types_);
-  if (staging_.size() <= input) staging_.resize(input + 1);
-  if (!staging_[input]) staging_[input].reset(new Staging());
-  auto& stage_vals_ = staging_[input]->stage_vals;
-  auto& stage_valid_ = staging_[input]->stage_valid;
-  auto& stage_aux_ = staging_[input]->stage_aux;
-  auto& dev_vals_ = staging_[input]->dev_vals;
-  auto& dev_valid_ = staging_[input]->dev_valid;
-  auto& dev_aux_ = staging_[input]->dev_aux;
+  // two staging sets per input: while the GPU still reads chunk k (H2D + kernel are asynchronous) the host fills the other set
+  // with chunk k+1; a set is reused only after the event recorded behind its last consumer has fired
+  const size_t slot = input * 2 + (size_t)(stage_parity_ & 1);
+  if (staging_.size() <= slot) staging_.resize(slot + 1);
+  if (!staging_[slot]) staging_[slot].reset(new Staging());
+  Staging& stg = *staging_[slot];
+  if (stg.busy) {
+    HIP_CHECK(hipEventSynchronize(stg.busy));
+    pool_put_event(device_id_, stg.busy);
+    stg.busy = nullptr;
+  }
+  auto& stage_vals_ = stg.stage_vals;
+  auto& stage_valid_ = stg.stage_valid;
+  auto& stage_aux_ = stg.stage_aux;
+  auto& dev_vals_ = stg.dev_vals;
+  auto& dev_valid_ = stg.dev_valid;
+  auto& dev_aux_ = stg.dev_aux;
   const size_t nc = in_types_.size();
   if (stage_vals_.size() != nc) {
     stage_vals_.resize(nc);
@@ -1103,8 +1118,8 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
   std::vector<size_t> aux_bytes(nc, 0);
   std::vector<int> str_uniform_(nc, -1);
   // index width of dictionary-encoded columns comes from the stream schema (fetched once per input)
-  if (staging_[input]->dict_index_width.empty()) {
-    staging_[input]->dict_index_width.assign(nc, 0);
+  if (stg.dict_index_width.empty()) {
+    stg.dict_index_width.assign(nc, 0);
     bool any_dict = false;
     for (auto& a : held)
       for (size_t c = 0; c < nc; c++) any_dict |= a.children[c]->dictionary != nullptr;
@@ -1116,7 +1131,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
         const ArrowSchema* f = sch.children[c];
         if (f->dictionary && f->format) {
           int w = f->format[0] == 'c' || f->format[0] == 'C' ? 1 : f->format[0] == 's' || f->format[0] == 'S' ? 2 : f->format[0] == 'i' || f->format[0] == 'I' ? 4 : 8;
-          staging_[input]->dict_index_width[c] = w;
+          stg.dict_index_width[c] = w;
         }
       }
       sch.release(&sch);
@@ -1130,7 +1145,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
     if (!is_dict) continue;
     // ---- dictionary unpack on the device (K1): indices + dictionary go up, a gather kernel writes the plain column
     const DType& t = in_types_[c];
-    const int iw = staging_[input]->dict_index_width[c];
+    const int iw = stg.dict_index_width[c];
     if (!iw) throw CometError("dictionary-encoded column without an index type in the stream schema");
     const bool is_str = t.id == TypeId::String || t.id == TypeId::Bytes;
     const int w = is_str ? 0 : (t.id == TypeId::Bool ? -1 : fixed_width(t));
@@ -1271,6 +1286,8 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
     stage_vals_[c]->ensure(vbytes + 16);
     if (has_valid[c]) stage_valid_[c]->ensure((size_t)((rows + 7) / 8) + 16);
     int64_t at = 0;
+    struct CopyJob { char* dst; const char* src; size_t n; };
+    std::vector<CopyJob> jobs;
     for (auto& a : held) {
       const ArrowArray* col = a.children[c];
       if (col->dictionary) throw CometError("dictionary-encoded input columns are not unpacked on the GPU path yet");
@@ -1279,7 +1296,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
       if (w) {
         // Decimal128 buffers from the JVM may be only 8-byte aligned (aligned_stream_reader.rs:95-107);
         // the staging copy realigns them.
-        memcpy((char*)stage_vals_[c]->p + (size_t)at * w, (const char*)col->buffers[1] + (size_t)off * w, (size_t)len * w);
+        jobs.push_back({(char*)stage_vals_[c]->p + (size_t)at * w, (const char*)col->buffers[1] + (size_t)off * w, (size_t)len * w});
       } else {
         bit_append((uint8_t*)stage_vals_[c]->p, at, (const uint8_t*)col->buffers[1], off, len);
       }
@@ -1288,6 +1305,23 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
         else bit_fill_ones((uint8_t*)stage_valid_[c]->p, at, len);
       }
       at += len;
+    }
+    if (vbytes >= ((size_t)8 << 20)) {
+      // split big single copies so that one huge batch is spread too
+      std::vector<CopyJob> pieces;
+      const size_t kPiece = (size_t)4 << 20;
+      for (auto& j : jobs)
+        for (size_t o = 0; o < j.n; o += kPiece) pieces.push_back({j.dst + o, j.src + o, std::min(kPiece, j.n - o)});
+      jobs.swap(pieces);
+    }
+    if (vbytes >= ((size_t)8 << 20) && jobs.size() > 1) {
+      // a large column: the batch copies are spread over the scan threads (one thread tops out near 10–15 GB/s, PCIe needs 45+)
+      const size_t parts = std::min<size_t>(16, jobs.size());
+      scan_pool_parallel(parts, [&](size_t pidx) {
+        for (size_t j = pidx; j < jobs.size(); j += parts) memcpy(jobs[j].dst, jobs[j].src, jobs[j].n);
+      });
+    } else {
+      for (auto& j : jobs) memcpy(j.dst, j.src, j.n);
     }
     dev_vals_[c]->ensure(vbytes + 16);
     HIP_CHECK(hipMemcpyAsync(dev_vals_[c]->p, stage_vals_[c]->p, vbytes, hipMemcpyHostToDevice, stream_));
@@ -1316,7 +1350,11 @@ bool ExecutionContext::pull_host_chunk() {
   if (!pull_host_table(0, in_types_, chunk_rows_, views, has_valid, rows)) return false;
   if (rows > 0) {
     process_chunk(views, has_valid, rows);
-    HIP_CHECK(hipStreamSynchronize(stream_));  // staging buffers are reused by the next chunk
+    // no host-side wait: mark this staging set busy until the work queued so far is done, and switch to the other set
+    Staging& stg = *staging_[(size_t)(stage_parity_ & 1)];
+    stg.busy = pool_get_event(device_id_);
+    HIP_CHECK(hipEventRecord(stg.busy, stream_));
+    stage_parity_ ^= 1;
   }
   return !inputs_[0].exhausted;
 }

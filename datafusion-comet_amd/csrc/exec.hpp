@@ -82,12 +82,16 @@ struct Staging {  // host→device staging of one input stream (one chunk at a t
   std::vector<std::unique_ptr<PinnedBuf>> stage_vals, stage_valid, stage_aux;
   std::vector<std::unique_ptr<DevBuf>> dev_vals, dev_valid, dev_aux;
   std::vector<int> dict_index_width;   // per column: byte width of dictionary indices (0 = not dictionary-encoded)
+  hipEvent_t busy = nullptr;           // recorded behind the last GPU work that reads this set
 };
 
 struct Variant {  // one JIT specialisation of the pipeline (per input-validity pattern)
   PipelineDesc desc;
   std::shared_ptr<LoadedModule> mod;
 };
+
+// parquet_scan.cpp: run fn(0..n-1) on the process-wide scan threads and wait
+void scan_pool_parallel(size_t n, const std::function<void(size_t)>& fn);
 
 class ExecutionContext {
  public:
@@ -181,6 +185,7 @@ class ExecutionContext {
   int64_t row_groups_pruned_ = 0;
 
   std::vector<std::unique_ptr<Staging>> staging_;   // per input stream
+  int stage_parity_ = 0;                            // which of the two staging sets the next streamed chunk uses
   std::vector<bool> schema_checked_;                // per input stream
 
   // aggregate state

@@ -81,6 +81,37 @@ class ScanPool {
   std::deque<std::function<void()>> q_;
 };
 
+}  // namespace
+
+// fn(0) … fn(n-1) on the scan threads; returns when all are done (used for the staging copies of host input batches too)
+void scan_pool_parallel(size_t n, const std::function<void(size_t)>& fn) {
+  if (n == 0) return;
+  if (n == 1) { fn(0); return; }
+  struct State { std::mutex mu; std::condition_variable cv; size_t left; std::exception_ptr err; };
+  auto st = std::make_shared<State>();
+  st->left = n;
+  for (size_t i = 0; i < n; i++) {
+    ScanPool::get().submit([st, i, &fn]() {
+      try {
+        fn(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(st->mu);
+        if (!st->err) st->err = std::current_exception();
+      }
+      {
+        std::lock_guard<std::mutex> lk(st->mu);
+        st->left--;
+      }
+      st->cv.notify_all();
+    });
+  }
+  std::unique_lock<std::mutex> lk(st->mu);
+  st->cv.wait(lk, [&] { return st->left == 0; });
+  if (st->err) std::rethrow_exception(st->err);
+}
+
+namespace {
+
 // A Parquet file opened for positional reads.  Column chunks are pread() by the scan threads into their own scratch
 // (no mmap: tearing down a mapping of several hundred MB costs milliseconds of page-table work after every scan).
 struct OpenFile {
