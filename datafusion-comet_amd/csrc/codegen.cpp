@@ -616,6 +616,23 @@ struct Gen {
       if (!(a.t.is_integer() && b.t.is_integer())) throw CometError("integer arithmetic on non-integer operands");
       const char* ct = r.rep == Rep::I64 ? "i64" : "i32";
       const char* ut = r.rep == Rep::I64 ? "u64" : "u32";
+      if (e.kind == ExprKind::Remainder) {
+        // create_modulo_expr / spark_modulo (math_funcs/modulo_expr.rs): a zero divisor is NULL outside ANSI mode (null_if_zero) and
+        // REMAINDER_BY_ZERO in ANSI mode; the sign follows the dividend; MIN % -1 = 0 (wrapping_rem)
+        a = named(a);
+        b = named(b);
+        const std::string bz = "((" + std::string(ct) + ")" + b.v + " == 0)";
+        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, bz), 8);
+        else {
+          std::string o = newvar("bool");
+          stmt(o + " = " + and_ok(r.ok, "!" + bz) + ";");
+          r.ok = o;
+        }
+        r.v = std::string("((") + bz + " || (" + ct + ")" + b.v + " == -1) ? (" + ct + ")0 : (" + ct + ")((" + ct + ")" + a.v + " % (" + ct + ")" + b.v + "))";
+        if (rt.id == TypeId::Int8) r.v = "(i32)(i8)" + r.v;
+        if (rt.id == TypeId::Int16) r.v = "(i32)(i16)" + r.v;
+        return r;
+      }
       std::string op;
       const char* builtin = nullptr;
       switch (e.kind) {
@@ -653,6 +670,20 @@ struct Gen {
     }
     if (rt.is_float()) {
       const char* ct = r.rep == Rep::F64 ? "double" : "float";
+      if (e.kind == ExprKind::Remainder) {
+        // fmod = Rust's / Java's %; zero divisor: NULL (null_if_zero) or REMAINDER_BY_ZERO in ANSI mode (checked_float_modulo)
+        a = named(a);
+        b = named(b);
+        const std::string bz = "((" + std::string(ct) + ")" + b.v + " == 0)";
+        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, bz), 8);
+        else {
+          std::string o = newvar("bool");
+          stmt(o + " = " + and_ok(r.ok, "!" + bz) + ";");
+          r.ok = o;
+        }
+        r.v = std::string(r.rep == Rep::F64 ? "fmod" : "fmodf") + "((" + ct + ")" + a.v + ", (" + ct + ")" + b.v + ")";
+        return r;
+      }
       std::string op;
       switch (e.kind) {
         case ExprKind::Add: op = "+"; break;

@@ -201,7 +201,7 @@ class Evaluator:
         if k == "is_not_null":
             a = self.eval(e.children[0], cols, n)
             return Col(S.T_BOOL, a.ok().copy(), None)
-        if k in ("add", "subtract", "multiply", "divide"):
+        if k in ("add", "subtract", "multiply", "divide", "remainder"):
             a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
             return self._arith(e, a, b)
         if k == "check_overflow":
@@ -387,6 +387,22 @@ class Evaluator:
             sm = max(s1, s2)
             return Col(S.decimal(min(38, max(p1 - s1, p2 - s2) + sm + 1), sm), out, valid)
         rt = e.dtype
+        if e.kind == "remainder" and rt.type_id in (S.INT8, S.INT16, S.INT32, S.INT64, S.FLOAT, S.DOUBLE):
+            # create_modulo_expr (math_funcs/modulo_expr.rs): zero divisor → NULL (ANSI: error); sign of the dividend; MIN % -1 = 0
+            nt = _np_dtype(S, rt)
+            x, y = a.values.astype(nt), b.values.astype(nt)
+            zero = y == 0
+            live = np.ones(n, bool) if valid is None else valid
+            if e.eval_mode == S.ANSI and (zero & live).any():
+                raise OracleError("REMAINDER_BY_ZERO / DIVIDE_BY_ZERO")
+            with np.errstate(all="ignore"):
+                if rt.type_id in (S.FLOAT, S.DOUBLE):
+                    r = np.fmod(x, np.where(zero, 1, y)).astype(nt)
+                else:
+                    ys = np.where(zero | (y == -1), 1, y)
+                    r = np.where(y == -1, 0, np.fmod(x, ys)).astype(nt)
+            v2 = live & ~zero
+            return Col(rt, np.where(v2, r, 0).astype(nt), None if v2.all() else v2)
         if rt.type_id in (S.INT8, S.INT16, S.INT32, S.INT64):
             nt = _np_dtype(S, rt)
             x, y = a.values.astype(np.int64), b.values.astype(np.int64)

@@ -228,3 +228,34 @@ def test_scalar_functions_exact_subset(built):
         _run(ansi, table=t, ncols=1)
     with pytest.raises(native.CometNativeException, match="levenshtein"):
         native.compile_plan(S.project(S.scan([S.T_DOUBLE]), [sf("levenshtein", [S.col(0, S.T_DOUBLE)], S.T_INT32)]).encode())
+
+
+def test_remainder_int_and_float(built):
+    # create_modulo_expr (math_funcs/modulo_expr.rs): zero divisor → NULL (ANSI: error), sign of the dividend, MIN % -1 = 0, fmod for floats
+    n = 40_000
+    rng = np.random.default_rng(88)
+    a = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    b = rng.integers(-50, 50, n).astype(np.int32)
+    a[:3] = [-2**31, 7, -7]
+    b[:3] = [-1, 0, 3]
+    l = rng.integers(-2**62, 2**62, n)
+    f = rng.standard_normal(n) * 1000
+    g = rng.standard_normal(n)
+    g[5] = 0.0
+    g[6] = -0.0
+    t = pa.table({"a": pa.array(a, mask=rng.random(n) < 0.1), "b": pa.array(b), "l": pa.array(l), "f": pa.array(f), "g": pa.array(g, mask=rng.random(n) < 0.1)})
+    fields = [S.T_INT32, S.T_INT32, S.T_INT64, S.T_DOUBLE, S.T_DOUBLE]
+    A, B, L, F, G = (S.col(i, ty) for i, ty in enumerate(fields))
+    outs = [S.math("remainder", A, B, S.T_INT32), S.math("remainder", L, S.lit(-7, S.T_INT64), S.T_INT64), S.math("remainder", L, S.cast(B, S.T_INT64), S.T_INT64),
+            S.math("remainder", F, G, S.T_DOUBLE), S.math("remainder", F, S.lit(2.5, S.T_DOUBLE), S.T_DOUBLE)]
+    plan = S.project(S.scan(fields), outs)
+    got = pa.Table.from_batches(_run(plan, table=t, ncols=5, batch_size=0))
+    want = _oracle(plan, t)
+    for i in range(5):
+        g_, w_ = got.column(i).combine_chunks(), want.column(i).combine_chunks()
+        assert g_.is_valid().equals(w_.is_valid()), i
+        assert g_.fill_null(0).to_numpy().tobytes() == w_.fill_null(0).to_numpy().tobytes(), f"column {i}"
+    assert got.column(0)[0].as_py() == 0 and got.column(0)[1].as_py() is None and got.column(0)[2].as_py() == -1
+    ansi = S.project(S.scan(fields), [S.math("remainder", A, B, S.T_INT32, S.ANSI)])
+    with pytest.raises(native.CometQueryExecutionException, match="DIVIDE_BY_ZERO"):
+        _run(ansi, table=t, ncols=1)
