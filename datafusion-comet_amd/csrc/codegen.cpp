@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <sstream>
@@ -69,6 +70,11 @@ std::string lit_i128(i128 v) {
 }
 std::string lit_u128(u128 v) { return "(u128)" + lit_i128((i128)v); }
 std::string lit_i64(int64_t v) { return "(i64)" + hex64((uint64_t)v); }
+std::string lit_f64(double v) {   // exact: the bit pattern
+  uint64_t b;
+  memcpy(&b, &v, 8);
+  return "__longlong_as_double((i64)" + hex64(b) + ")";
+}
 
 struct Val {
   std::string v;    // C expression (per-row vars carry the [r] suffix already)
@@ -755,6 +761,65 @@ struct Gen {
       return x;
     }
     if (from.id == TypeId::Date && to.id == TypeId::Date) return c;
+    if (from.is_float() && is_intlike(to)) {
+      // conversion_funcs/numeric.rs:311-425 — Int8/Int16: (value as i32) as i8/i16; Int32/Int64: value as i32/i64 (saturating, NaN → 0).
+      // ANSI: NaN or |value| as dest == dest::MAX (i32::MAX for the narrow types, then try_from) → CAST_OVERFLOW
+      c = named(c);
+      const std::string d = "(double)" + c.v;
+      if (to.id == TypeId::Int64) {
+        r.v = "comet::f64_to_i64_sat(" + d + ")";
+        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(c.ok, "(" + d + " != " + d + " || comet::f64_to_i64_sat(fabs(" + d + ")) == (i64)0x7fffffffffffffffll)"), 2);
+      } else {
+        const std::string i32v = "comet::f64_to_i32_sat(" + d + ")";
+        if (to.id == TypeId::Int32) r.v = i32v;
+        else r.v = std::string("(i32)(") + (to.id == TypeId::Int8 ? "i8" : "i16") + ")" + i32v;
+        if (e.eval_mode == EvalMode::Ansi) {
+          std::string ovf = "(" + d + " != " + d + " || comet::f64_to_i32_sat(fabs(" + d + ")) == (i32)0x7fffffff";
+          if (to.id != TypeId::Int32) ovf += " || (i32)(" + std::string(to.id == TypeId::Int8 ? "i8" : "i16") + ")" + i32v + " != " + i32v;
+          raise_if(and_ok(c.ok, ovf + ")"), 2);
+        }
+      }
+      r.maxabs = type_maxabs(to);
+      return r;
+    }
+    if (from.id == TypeId::Decimal && is_intlike(to)) {
+      // numeric.rs:426-560 — truncate toward zero by 10^scale, then `as` (two's-complement truncation; narrow types go through i32).
+      // ANSI: |truncated| > dest::MAX (i32::MAX, then try_from, for the narrow types) → CAST_OVERFLOW
+      c = named(c);
+      std::string t = newvar("i128");
+      stmt(t + " = " + as128(c) + " / " + lit_i128((i128)pow10_u128(from.scale)) + ";");
+      const char* nt = to.id == TypeId::Int64 ? "i64" : "i32";
+      std::string v = std::string("(") + nt + ")" + t;
+      if (to.id == TypeId::Int8 || to.id == TypeId::Int16) v = std::string("(i32)(") + (to.id == TypeId::Int8 ? "i8" : "i16") + ")" + v;
+      r.v = v;
+      if (e.eval_mode == EvalMode::Ansi) {
+        const std::string mx = to.id == TypeId::Int64 ? "(u128)0x7fffffffffffffffull" : "(u128)0x7fffffffu";
+        std::string ovf = "(comet::uabs128(" + t + ") > " + mx;
+        if (to.id == TypeId::Int8 || to.id == TypeId::Int16) ovf += " || " + v + " != (i32)" + t;
+        raise_if(and_ok(c.ok, ovf + ")"), 2);
+      }
+      r.maxabs = type_maxabs(to);
+      return r;
+    }
+    if (from.id == TypeId::Decimal && to.is_float()) {
+      // arrow cast (the reference defers to DataFusion here): (value as f64) / 10^scale; Float32 narrows the double result
+      const std::string d = "((double)" + as128(c) + " / " + lit_f64(std::pow(10.0, from.scale)) + ")";
+      r.v = to.id == TypeId::Double ? d : "(float)" + d;
+      return r;
+    }
+    if (from.id == TypeId::Double && to.id == TypeId::Float) {
+      r.v = "(float)" + c.v;
+      return r;
+    }
+    if (from.id == TypeId::Bool && (is_intlike(to) || to.is_float())) {
+      r.v = std::string("(") + rep_ctype(r.rep) + ")(" + c.v + " ? 1 : 0)";
+      r.maxabs = 1;
+      return r;
+    }
+    if ((is_intlike(from) || from.is_float()) && to.id == TypeId::Bool) {
+      r.v = "(" + c.v + " != 0)";
+      return r;
+    }
     throw CometError("Cast from " + from.str() + " to " + to.str() + " is not supported in the GPU pipeline yet");
   }
 

@@ -95,6 +95,13 @@ CDEV i64 f64_to_i64_sat(double x) {
   if (x <= -9223372036854775808.0) return (i64)0x8000000000000000ull;
   return (i64)x;
 }
+// Rust `x as i32` for a float: saturating, NaN → 0 (conversion_funcs/numeric.rs cast_float_to_int*)
+CDEV i32 f64_to_i32_sat(double x) {
+  if (x != x) return 0;
+  if (x >= 2147483648.0) return (i32)0x7fffffff;
+  if (x <= -2147483648.0) return (i32)0x80000000;
+  return (i32)x;
+}
 // div_ceil / div_floor of the unscaled value by 10^scale (decimal_ceil_f / decimal_floor_f)
 CDEV i128 dec_div_ceil(i128 x, i128 d) { i128 q = x / d, r = x % d; return (r > 0) ? q + 1 : q; }
 CDEV i128 dec_div_floor(i128 x, i128 d) { i128 q = x / d, r = x % d; return (r < 0) ? q - 1 : q; }

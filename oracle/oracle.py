@@ -494,6 +494,64 @@ class Evaluator:
             return Col(to, ints_to_dec([v if o else 0 for v, o in zip(vals, ok)]), None if v2.all() else v2)
         if frm.type_id == S.DECIMAL and to.type_id == S.DECIMAL:
             return self._rescale(c, to, e.eval_mode == S.ANSI)
+        n = len(c)
+        wrap = {S.INT8: 8, S.INT16: 16, S.INT32: 32, S.INT64: 64}
+
+        def as_int(v, bits):       # Rust `as` between integers: two's-complement truncation
+            v &= (1 << bits) - 1
+            return v - (1 << bits) if v >> (bits - 1) else v
+
+        def sat(x, bits):          # Rust float `as iN`: saturating, NaN → 0
+            if x != x:
+                return 0
+            lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+            return lo if x <= lo else (hi if x >= hi + 1 else int(x))
+        if frm.type_id in (S.FLOAT, S.DOUBLE) and to.type_id in ints:
+            # conversion_funcs/numeric.rs:311-425
+            out, ovf = [], np.zeros(n, bool)
+            narrow = to.type_id in (S.INT8, S.INT16)
+            for i, x in enumerate(c.values.astype(np.float64)):
+                w = 64 if to.type_id == S.INT64 else 32
+                v = sat(float(x), w)
+                ovf[i] = (x != x) or sat(abs(float(x)), w) == (1 << (w - 1)) - 1
+                if narrow:
+                    nv = as_int(v, wrap[to.type_id])
+                    ovf[i] |= nv != v
+                    v = nv
+                out.append(v)
+            if e.eval_mode == S.ANSI and (ovf & c.ok()).any():
+                raise OracleError("CAST_OVERFLOW")
+            return Col(to, np.array(out, dtype=_np_dtype(S, to)), c.valid)
+        if frm.type_id == S.DECIMAL and to.type_id in ints:
+            # numeric.rs:426-560: truncate toward zero by 10^scale, then `as`
+            d = 10 ** frm.scale
+            out, ovf = [], np.zeros(n, bool)
+            for i in range(n):
+                v = dec_to_int(c.values, i)
+                t = abs(v) // d * (-1 if v < 0 else 1)
+                if to.type_id == S.INT64:
+                    ovf[i] = abs(t) > 2**63 - 1
+                    out.append(as_int(t, 64))
+                else:
+                    ovf[i] = abs(t) > 2**31 - 1
+                    v32 = as_int(t, 32)
+                    nv = as_int(v32, wrap[to.type_id])
+                    ovf[i] |= nv != v32
+                    out.append(nv)
+            if e.eval_mode == S.ANSI and (ovf & c.ok()).any():
+                raise OracleError("CAST_OVERFLOW")
+            return Col(to, np.array(out, dtype=_np_dtype(S, to)), c.valid)
+        if frm.type_id == S.DECIMAL and to.type_id in (S.FLOAT, S.DOUBLE):
+            div = float(10.0 ** frm.scale)
+            vals = np.array([float(dec_to_int(c.values, i)) / div for i in range(n)], np.float64)     # int → f64 rounds to nearest even, like `as f64`
+            return Col(to, vals.astype(_np_dtype(S, to)), c.valid)
+        if frm.type_id == S.DOUBLE and to.type_id == S.FLOAT:
+            with np.errstate(all="ignore"):
+                return Col(to, c.values.astype(np.float32), c.valid)
+        if frm.type_id == S.BOOL and to.type_id in ints + (S.FLOAT, S.DOUBLE):
+            return Col(to, c.values.astype(_np_dtype(S, to)), c.valid)
+        if frm.type_id in ints + (S.FLOAT, S.DOUBLE) and to.type_id == S.BOOL:
+            return Col(to, c.values != 0, c.valid)
         raise NotImplementedError(f"oracle cast {frm} → {to}")
 
 

@@ -259,3 +259,37 @@ def test_remainder_int_and_float(built):
     ansi = S.project(S.scan(fields), [S.math("remainder", A, B, S.T_INT32, S.ANSI)])
     with pytest.raises(native.CometQueryExecutionException, match="DIVIDE_BY_ZERO"):
         _run(ansi, table=t, ncols=1)
+
+
+def test_more_casts(built):
+    """Float/Decimal → integral (Rust `as`: saturating for floats, truncating for decimals; narrow types via i32 — numeric.rs:311-560),
+    Decimal → Float, Double → Float, Boolean ↔ numeric; ANSI overflow → CAST_OVERFLOW."""
+    from datafusion_comet_amd import tpch
+    n = 30_000
+    rng = np.random.default_rng(99)
+    f = rng.standard_normal(n) * 1e5
+    f[:10] = [np.nan, np.inf, -np.inf, 3e9, -3e9, 1e19, -1e19, 127.9, -128.9, 40000.5]
+    t = pa.table({"f": pa.array(f, mask=rng.random(n) < 0.1), "d": tpch._dec128_array(rng.integers(-10**11, 10**11, n), 12, 2),
+                  "w": pa.array([__import__("decimal").Decimal(int(x) * 10**12).scaleb(-6) for x in rng.integers(-10**17, 10**17, n)], pa.decimal128(38, 6)),
+                  "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1), "i": pa.array(rng.integers(-3, 4, n), pa.int32())})
+    D, W = S.decimal(12, 2), S.decimal(38, 6)
+    fields = [S.T_DOUBLE, D, W, S.T_BOOL, S.T_INT32]
+    F, Dc, Wc, B, I = (S.col(i, ty) for i, ty in enumerate(fields))
+    outs = [S.cast(F, S.T_INT8), S.cast(F, S.T_INT16), S.cast(F, S.T_INT32), S.cast(F, S.T_INT64), S.cast(F, S.T_FLOAT),
+            S.cast(Dc, S.T_INT8), S.cast(Dc, S.T_INT32), S.cast(Dc, S.T_INT64), S.cast(Wc, S.T_INT16), S.cast(Wc, S.T_INT64),
+            S.cast(Dc, S.T_DOUBLE), S.cast(Wc, S.T_DOUBLE), S.cast(Dc, S.T_FLOAT),
+            S.cast(B, S.T_INT32), S.cast(B, S.T_DOUBLE), S.cast(I, S.T_BOOL), S.cast(F, S.T_BOOL)]
+    plan = S.project(S.scan(fields), outs)
+    got = pa.Table.from_batches(_run(plan, table=t, ncols=len(outs), batch_size=0))
+    want = _oracle(plan, t)
+    for i in range(len(outs)):
+        g_, w_ = got.column(i).combine_chunks(), want.column(i).combine_chunks()
+        assert g_.type == w_.type, i
+        assert g_.is_valid().equals(w_.is_valid()), i
+        if pa.types.is_boolean(g_.type):
+            assert g_.equals(w_), i
+        else:
+            assert g_.fill_null(0).to_numpy().tobytes() == w_.fill_null(0).to_numpy().tobytes(), f"column {i}"
+    for e in (S.cast(F, S.T_INT32, S.ANSI), S.cast(Wc, S.T_INT16, S.ANSI)):
+        with pytest.raises(native.CometQueryExecutionException, match="CAST_OVERFLOW"):
+            _run(S.project(S.scan(fields), [e]), table=t, ncols=1)
