@@ -1,11 +1,15 @@
 // extern "C" boundary (include/comet_amd.h).  Every entry catches all C++ exceptions: the reference
 // wraps each JNI entry in try_unwrap_or_throw (native/jni-bridge/src/errors.rs:832-850).
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 
 #include "../../include/comet_amd.h"
 #include "exec.hpp"
+#include "shuffle_format.hpp"
 
 using namespace comet;
 
@@ -84,7 +88,19 @@ int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* c
       s.kind = input_kinds ? input_kinds[i] : 0;
       if (s.kind == COMET_INPUT_HOST_STREAM) s.host = (ArrowArrayStream*)inputs[i];
       else if (s.kind == COMET_INPUT_DEVICE_STREAM) s.dev = (ArrowDeviceArrayStream*)inputs[i];
-      else throw CometError("unknown input kind " + std::to_string(s.kind));
+      else if (s.kind == COMET_INPUT_SHUFFLE_BLOCKS) {
+        // a ShuffleScan leaf: blocks are decoded on the host into Arrow batches and then take the host-stream path
+        std::vector<const Operator*> leaves;
+        std::function<void(const Operator&)> walk = [&](const Operator& o) {
+          if (o.kind == OpKind::Scan) leaves.push_back(&o);
+          for (auto& c : o.children) walk(*c);
+        };
+        walk(*op);
+        if ((size_t)i >= leaves.size()) throw CometError("more inputs than Scan leaves");
+        auto* bs = (comet::CometShuffleBlockStreamC*)inputs[i];   // same layout as struct CometShuffleBlockStream
+        s.kind = COMET_INPUT_HOST_STREAM;
+        s.host = shuffle_blocks_as_arrow_stream(bs, leaves[(size_t)i]->scan_fields);
+      } else throw CometError("unknown input kind " + std::to_string(s.kind));
       ins.push_back(s);
     }
     std::shared_ptr<ExecutionContext> ctx;
@@ -277,7 +293,74 @@ const char* comet_version(void) { return "comet-mi355x 0.1.0 (gfx950)"; }
 #include <iterator>
 
 #include "parquet_meta.hpp"
-extern "C" int32_t comet_parquet_describe(const char* path, char* out, size_t cap) {
+extern "C" int64_t comet_decode_shuffle_block(const uint8_t* block, int64_t len, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas,
+                                   int32_t n_out) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    if (!block || len < 0) throw CometError("decodeShuffleBlock: null block");
+    HostBatch b = decode_shuffle_block(block, (size_t)len);
+    const int64_t rows = b.rows;
+    export_host_batch(b, out_arrays, out_schemas, n_out);
+    return rows;
+  });
+}
+
+namespace {
+DType dtype_from_format(const char* f) {
+  std::string s = f ? f : "";
+  if (s == "b") return DType::of(TypeId::Bool);
+  if (s == "c") return DType::of(TypeId::Int8);
+  if (s == "s") return DType::of(TypeId::Int16);
+  if (s == "i") return DType::of(TypeId::Int32);
+  if (s == "l") return DType::of(TypeId::Int64);
+  if (s == "f") return DType::of(TypeId::Float);
+  if (s == "g") return DType::of(TypeId::Double);
+  if (s == "u") return DType::of(TypeId::String);
+  if (s == "z") return DType::of(TypeId::Bytes);
+  if (s == "tdD") return DType::of(TypeId::Date);
+  if (s == "tsu:") return DType::of(TypeId::TimestampNtz);
+  if (s.rfind("tsu:", 0) == 0) return DType::of(TypeId::Timestamp);
+  if (s.rfind("d:", 0) == 0) {
+    int p = 0, sc = 0, bits = 128;
+    if (sscanf(s.c_str(), "d:%d,%d,%d", &p, &sc, &bits) >= 2 && bits == 128) return DType::decimal(p, sc);
+  }
+  throw CometError("encodeShuffleBlock: Arrow format '" + s + "' is not supported");
+}
+}  // namespace
+
+int32_t comet_encode_shuffle_block(struct ArrowArray** arrays, struct ArrowSchema** schemas, int32_t n_cols, int32_t codec,
+                                   int32_t compression_level, uint8_t** out, int64_t* out_len) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    if (!out || !out_len) throw CometError("encodeShuffleBlock: null output");
+    if (codec < 0 || codec > 3) throw CometError("Unsupported shuffle compression codec: " + std::to_string(codec));
+    std::vector<ColumnSlice> cols((size_t)n_cols);
+    int64_t rows = n_cols ? arrays[0]->length : 0;
+    for (int i = 0; i < n_cols; i++) {
+      const ArrowArray* a = arrays[i];
+      if (a->length != rows) throw CometError("encodeShuffleBlock: columns differ in length");
+      if (a->dictionary) throw CometError("encodeShuffleBlock: dictionary-encoded input is not supported");
+      ColumnSlice& c = cols[(size_t)i];
+      c.type = dtype_from_format(schemas[i]->format);
+      c.validity = a->null_count != 0 ? (const uint8_t*)a->buffers[0] : nullptr;
+      c.values = a->buffers[1];
+      c.data = a->n_buffers > 2 ? (const uint8_t*)a->buffers[2] : nullptr;
+      c.first = a->offset;
+    }
+    std::vector<uint8_t> bytes;
+    encode_shuffle_block(cols, rows, (ShuffleCodec)codec, compression_level, bytes);
+    *out_len = (int64_t)bytes.size();
+    *out = nullptr;
+    if (!bytes.empty()) {
+      *out = (uint8_t*)malloc(bytes.size());
+      if (!*out) throw CometError("encodeShuffleBlock: out of memory");
+      memcpy(*out, bytes.data(), bytes.size());
+    }
+    return 0;
+  });
+}
+
+void comet_free_buffer(uint8_t* p) { free(p); }
+
+int32_t comet_parquet_describe(const char* path, char* out, size_t cap) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     std::ifstream f(path, std::ios::binary);
     if (!f) throw CometError(std::string("cannot open ") + path);

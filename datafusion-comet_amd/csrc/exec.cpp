@@ -1,6 +1,12 @@
 #include "exec.hpp"
+#include "shuffle_format.hpp"
 
+#include <cerrno>
+#include <fcntl.h>
+#include <unistd.h>
 #include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -172,6 +178,9 @@ extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const 
 extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
 extern "C" int64_t comet_partition_tiles(int64_t n);
+extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
+extern "C" int comet_launch_murmur3(int type_id, int precision, const void* values, const uint8_t* validity, const void* aux, int64_t n, uint32_t* hashes, void* stream);
+extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out, void* stream);
 extern "C" int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
                                               uint32_t* row_indices, void* stream);
 extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream);
@@ -237,25 +246,6 @@ void bit_fill_ones(uint8_t* dst, int64_t dst_off, int64_t n) {
       dst[d >> 3] |= (uint8_t)(1u << (d & 7));
       i++;
     }
-  }
-}
-
-std::string expected_format(const DType& t) {
-  switch (t.id) {
-    case TypeId::Bool: return "b";
-    case TypeId::Int8: return "c";
-    case TypeId::Int16: return "s";
-    case TypeId::Int32: return "i";
-    case TypeId::Int64: return "l";
-    case TypeId::Float: return "f";
-    case TypeId::Double: return "g";
-    case TypeId::Date: return "tdD";
-    case TypeId::Timestamp: return "tsu:UTC";
-    case TypeId::TimestampNtz: return "tsu:";
-    case TypeId::String: return "u";
-    case TypeId::Bytes: return "z";
-    case TypeId::Decimal: return "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale);
-    default: return "?";
   }
 }
 
@@ -349,7 +339,23 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
   std::function<void(const Operator&)> walk = [&](const Operator& op) {
     node_id_[&op] = (int)node_id_.size();
     if (op.kind == OpKind::Scan) scan_input_[&op] = scan_input_.size();
-    if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan || op.kind == OpKind::Sort || op.kind == OpKind::Limit) has_join_ = true;   // sources materialised in HBM
+    if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan || op.kind == OpKind::Sort || op.kind == OpKind::Limit || op.kind == OpKind::ShuffleWriter)
+      has_join_ = true;   // sources materialised in HBM
+    if (op.kind == OpKind::ShuffleWriter) {
+      if (&op != plan_.get()) throw CometError("ShuffleWriter must be the root of a native plan");
+      bool computed = false;
+      for (auto& e : op.shuffle_hash_exprs) computed |= e->kind != ExprKind::Bound;
+      if (computed) {
+        // hash expressions that are not plain column references: evaluated by a Projection(child columns ++ expressions) fused
+        // over the child (its project_list is filled in when the child's schema is known)
+        auto pr = std::make_shared<Operator>();
+        pr->kind = OpKind::Projection;
+        pr->proto_tag = 101;
+        pr->children = op.children;
+        shuffle_projs_[&op] = pr;
+        node_id_[pr.get()] = (int)node_id_.size();
+      }
+    }
     if (op.kind == OpKind::HashAgg && &op != plan_.get()) {
       // an aggregate below other operators: materialised too, unless it is the sink of the root chain (checked below)
       nested_aggs_.push_back(&op);
@@ -406,7 +412,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
 // limits, and an aggregate that is not the top of the chain being fused.
 bool ExecutionContext::is_source(const Operator& op, const Operator* chain_top) {
   switch (op.kind) {
-    case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: return true;
+    case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: case OpKind::ShuffleWriter: return true;
     case OpKind::HashAgg: return &op != chain_top;
     default: return false;
   }
@@ -428,6 +434,41 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       explain_ += "  limit " + std::to_string(op.limit) + " offset " + std::to_string(op.offset) + "\n";
     }
     return st;
+  }
+  if (op.kind == OpKind::ShuffleWriter) {
+    // ShuffleWriterExec (shuffle_writer.rs:60-110): consumes its child, writes the data + index files, yields no batches
+    if (op.children.size() != 1) throw CometError("ShuffleWriter expects exactly one child");
+    std::vector<DType> st = infer_schema(*op.children[0]);
+    if (op.shuffle_partitioning == Operator::Partitioning::Range)
+      throw CometError("ShuffleWriter: range partitioning is not supported by the MI355X native engine yet (hash, single and round-robin are)");
+    if (op.shuffle_num_partitions < 1) throw CometError("ShuffleWriter: num_partitions must be positive");
+    if (op.shuffle_num_partitions > 4096) throw CometError("ShuffleWriter: more than 4096 output partitions are not supported yet");
+    if (op.shuffle_codec < 0 || op.shuffle_codec > 3) throw CometError("Unsupported shuffle compression codec: " + std::to_string(op.shuffle_codec));
+    if (op.shuffle_data_file.empty() || op.shuffle_index_file.empty()) throw CometError("ShuffleWriter: output_data_file / output_index_file missing");
+    for (auto& e : op.shuffle_hash_exprs)
+      if (e->kind == ExprKind::Bound && (e->bound_index < 0 || (size_t)e->bound_index >= st.size()))
+        throw CometError("ShuffleWriter: hash expression references column " + std::to_string(e->bound_index) + " of " + std::to_string(st.size()));
+    for (auto& t : st)
+      if (expected_format(t) == "?") throw CometError("ShuffleWriter: column type " + t.str() + " is not supported");
+    auto sp = shuffle_projs_.find(&op);
+    if (sp != shuffle_projs_.end()) {
+      Operator& pr = *sp->second;
+      pr.project_list.clear();
+      for (size_t i = 0; i < st.size(); i++) {
+        auto b = std::make_shared<Expr>();
+        b->kind = ExprKind::Bound;
+        b->proto_tag = 3;
+        b->bound_index = (int)i;
+        b->dtype = st[i];
+        b->has_dtype = true;
+        pr.project_list.push_back(b);
+      }
+      for (auto& e : op.shuffle_hash_exprs)
+        if (e->kind != ExprKind::Bound) pr.project_list.push_back(e);
+      infer_schema(pr);   // validates (and, under compile_only, compiles) the fused chain
+    }
+    explain_ += "  shuffle writer: " + std::to_string(op.shuffle_num_partitions) + " partition(s), codec " + std::to_string(op.shuffle_codec) + "\n";
+    return {};
   }
   if (op.kind == OpKind::NativeScan) {
     std::vector<DType> out;
@@ -1775,6 +1816,7 @@ DevTable ExecutionContext::materialize(const Operator& op) {
     const int64_t end = op.limit < 0 ? in.rows : std::min<int64_t>(in.rows, op.limit);
     return take_rows(in, nullptr, off, std::max<int64_t>(0, end - off), nullptr);
   }
+  if (op.kind == OpKind::ShuffleWriter) return write_shuffle(op);
   if (op.kind == OpKind::HashAgg) return nested_aggregate(op);   // an aggregate below other operators
   // Filter / Projection chain: fused over its source
   const Operator* src = &op;
@@ -1783,6 +1825,242 @@ DevTable ExecutionContext::materialize(const Operator& op) {
   DevTable out = run_chain_to_device(op, in);
   HIP_CHECK(hipStreamSynchronize(stream_));
   return out;
+}
+
+
+// ShuffleWriter (native/shuffle/src/shuffle_writer.rs:166-300, partitioners/multi_partition.rs:265-457, single_partition.rs):
+// the child's whole output is resident in HBM; partition ids (Spark murmur3 seed 42 chained over the hash expressions → pmod),
+// the stable per-partition row order and the per-column gathers all run on the GPU (the exchange kernels), ONE download brings the
+// partition-major table to pinned host memory, and the host threads frame it: per partition, blocks of ≤ batch_size rows in input
+// order (partitioned_batch_iterator.rs:100-124), each an Arrow IPC stream behind the 20-byte header, codec applied per block
+// (shuffle_block_writer.rs:179-238).  Data file = partitions back to back; index file = num_partitions + 1 little-endian i64 offsets
+// (writers/local/local_partition_writer.rs:255-295).
+DevTable ExecutionContext::write_shuffle(const Operator& sw) {
+  static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
+  Timer tm;
+  double t_last = 0;
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const double now = tm.ns() / 1e6;
+    fprintf(stderr, "[comet] shuffle write: %s %.3f ms\n", what, now - t_last);
+    t_last = now;
+  };
+  auto sp = shuffle_projs_.find(&sw);
+  const Operator& child = sp != shuffle_projs_.end() ? *sp->second : *sw.children[0];
+  DevTable in = materialize(child);
+  const int64_t n = in.rows;
+  lap("child");
+  const int P = sw.shuffle_partitioning == Operator::Partitioning::Single ? 1 : sw.shuffle_num_partitions;
+  size_t n_payload = in.cols.size();
+  std::vector<int> key_cols;
+  if (sw.shuffle_partitioning == Operator::Partitioning::Hash) {
+    size_t appended = 0;
+    for (auto& e : sw.shuffle_hash_exprs) appended += e->kind != ExprKind::Bound;
+    n_payload -= appended;
+    size_t next = n_payload;
+    for (auto& e : sw.shuffle_hash_exprs) key_cols.push_back(e->kind == ExprKind::Bound ? e->bound_index : (int)next++);
+  } else if (sw.shuffle_partitioning == Operator::Partitioning::RoundRobin) {
+    // "round robin" = hash of the first max_hash_columns columns (multi_partition.rs:386-437)
+    const size_t k = sw.shuffle_max_hash_columns <= 0 ? n_payload : std::min<size_t>((size_t)sw.shuffle_max_hash_columns, n_payload);
+    for (size_t i = 0; i < k; i++) key_cols.push_back((int)i);
+  }
+  if (n >= (int64_t)1 << 32) throw CometError("ShuffleWriter: more than 2^32 rows in one task are not supported (u32 row indices, multi_partition.rs)");
+  std::vector<int64_t> starts((size_t)P + 1, 0);
+  starts[(size_t)P] = n;
+  DevTable grouped;
+  if (P > 1 && n > 0) {
+    DevBuf hashes, pids, dstarts, hist;
+    auto ridx = std::make_shared<DevBuf>();
+    hashes.ensure((size_t)n * 4);
+    pids.ensure((size_t)n * 4);
+    ridx->ensure((size_t)n * 4 + 16);
+    dstarts.ensure(((size_t)P + 1) * 8);
+    const uint32_t seed = 42;
+    if (comet_launch_fill(4, hashes.p, n, &seed, stream_) != 0) throw CometError("shuffle: launch failed");
+    for (int c : key_cols) {
+      const DeviceColumnView& v = in.cols[(size_t)c];
+      if (v.offset != 0) throw CometError("ShuffleWriter: hash key column with a non-zero Arrow offset is not supported yet");
+      if (comet_launch_murmur3((int)in.types[(size_t)c].id, in.types[(size_t)c].precision, v.data, in.has_valid[(size_t)c] ? v.valid : nullptr, v.aux, n,
+                               (uint32_t*)hashes.p, stream_) != 0)
+        throw CometError("ShuffleWriter: cannot hash a column of type " + in.types[(size_t)c].str());
+    }
+    const int64_t W = comet_partition_tiles(n);
+    const size_t hist_bytes = ((size_t)P * (size_t)W + 1) * 8;
+    hist.ensure(hist_bytes + 8);
+    uint32_t* bad = (uint32_t*)((char*)hist.p + hist_bytes);
+    HIP_CHECK(hipMemsetAsync(bad, 0, 4, stream_));
+    if (comet_launch_pmod((const uint32_t*)hashes.p, n, P, (int32_t*)pids.p, stream_) != 0 ||
+        comet_launch_partition_indices((const int32_t*)pids.p, n, P, (uint64_t*)hist.p, bad, (int64_t*)dstarts.p, (uint32_t*)ridx->p, stream_) != 0)
+      throw CometError("shuffle: launch failed");
+    HIP_CHECK(hipMemcpyAsync(starts.data(), dstarts.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    DevTable payload = in;
+    payload.types.resize(n_payload);
+    payload.cols.resize(n_payload);
+    payload.has_valid.resize(n_payload);
+    grouped = take_rows(payload, (const uint32_t*)ridx->p, 0, n, ridx);
+  } else {
+    grouped = in;
+    grouped.types.resize(n_payload);
+    grouped.cols.resize(n_payload);
+    grouped.has_valid.resize(n_payload);
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  lap("partition (murmur3, pmod, indices, takes)");
+
+  // one download of the partition-major table
+  std::vector<std::unique_ptr<PinnedBuf>> hv(n_payload), hb(n_payload), hd(n_payload);
+  for (size_t j = 0; j < n_payload && n > 0; j++) {
+    const DType& ty = grouped.types[j];
+    const DeviceColumnView& v = grouped.cols[j];
+    if (v.offset != 0) throw CometError("ShuffleWriter: input column with a non-zero Arrow offset is not supported yet");
+    const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
+    const size_t bytes = is_str ? (size_t)(n + 1) * 4 : ty.id == TypeId::Bool ? (size_t)((n + 7) / 8) : (size_t)n * fixed_width(ty);
+    hv[j].reset(new PinnedBuf());
+    hv[j]->ensure(bytes + 8);
+    HIP_CHECK(hipMemcpyAsync(hv[j]->p, v.data, bytes, hipMemcpyDeviceToHost, stream_));
+    if (grouped.has_valid[j]) {
+      hb[j].reset(new PinnedBuf());
+      hb[j]->ensure((size_t)((n + 7) / 8) + 8);
+      HIP_CHECK(hipMemcpyAsync(hb[j]->p, v.valid, (size_t)((n + 7) / 8), hipMemcpyDeviceToHost, stream_));
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  for (size_t j = 0; j < n_payload && n > 0; j++) {
+    const DType& ty = grouped.types[j];
+    if (ty.id != TypeId::String && ty.id != TypeId::Bytes) continue;
+    const int32_t* offs = (const int32_t*)hv[j]->p;
+    if (offs[0] != 0) throw CometError("ShuffleWriter: Utf8 column whose offsets do not start at 0");
+    hd[j].reset(new PinnedBuf());
+    hd[j]->ensure((size_t)offs[n] + 8);
+    if (offs[n]) HIP_CHECK(hipMemcpyAsync(hd[j]->p, grouped.cols[j].aux, (size_t)offs[n], hipMemcpyDeviceToHost, stream_));
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+
+  lap("download");
+  // frame every partition on the host threads
+  const int64_t bs = batch_size_ > 0 ? batch_size_ : std::max<int64_t>(n, 1);
+  const ShuffleCodec codec = (ShuffleCodec)sw.shuffle_codec;
+  // Blocks in file order — (partition, first row, rows) — grouped into runs of consecutive blocks of ≈4 MiB of column data.  The
+  // scan threads encode whole runs (one output buffer per run, allocated once); this thread writes finished runs to the data
+  // file in order while later runs are still being encoded.
+  struct BlockTask { int p; int64_t first, rows; };
+  std::vector<BlockTask> tasks;
+  for (int p = 0; p < P; p++)
+    for (int64_t r = starts[(size_t)p]; r < starts[(size_t)p + 1]; r += bs) tasks.push_back({p, r, std::min(bs, starts[(size_t)p + 1] - r)});
+  size_t row_bytes = 0;
+  for (size_t j = 0; j < n_payload; j++) {
+    const DType& ty = grouped.types[j];
+    const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
+    row_bytes += is_str ? 4 + (n > 0 ? (size_t)(((const int32_t*)hv[j]->p)[n] / n) + 1 : 0) : ty.id == TypeId::Bool ? 1 : (size_t)fixed_width(ty);
+    if (hb[j]) row_bytes += 1;
+  }
+  struct Run {
+    size_t first = 0, last = 0;      // tasks [first, last)
+    std::vector<uint8_t> bytes;
+    std::vector<size_t> block_size;  // per task
+    std::string error;
+    bool done = false;
+    double encode_ms = 0;
+  };
+  std::vector<Run> runs;
+  for (size_t t = 0; t < tasks.size();) {
+    size_t e = t, acc = 0;
+    while (e < tasks.size() && acc < (size_t)(4 << 20)) acc += (size_t)tasks[e++].rows * std::max<size_t>(row_bytes, 1);
+    Run r;
+    r.first = t;
+    r.last = e;
+    runs.push_back(std::move(r));
+    t = e;
+  }
+  std::mutex mu;
+  std::condition_variable cv;
+  for (size_t ri = 0; ri < runs.size(); ri++) {
+    scan_pool_submit([&, ri]() {
+      Run& r = runs[ri];
+      Timer rt;
+      try {
+        size_t est = 0;
+        for (size_t t = r.first; t < r.last; t++) est += (size_t)tasks[t].rows * row_bytes + 2048;
+        r.bytes.reserve(est + est / 8 + (64 << 10));
+        std::vector<ColumnSlice> cols(n_payload);
+        for (size_t j = 0; j < n_payload; j++) {
+          cols[j].type = grouped.types[j];
+          cols[j].validity = hb[j] ? (const uint8_t*)hb[j]->p : nullptr;
+          cols[j].values = hv[j]->p;
+          cols[j].data = hd[j] ? (const uint8_t*)hd[j]->p : nullptr;
+        }
+        for (size_t t = r.first; t < r.last; t++) {
+          for (auto& c : cols) c.first = tasks[t].first;
+          r.block_size.push_back(encode_shuffle_block(cols, tasks[t].rows, codec, sw.shuffle_compression_level, r.bytes));
+        }
+      } catch (const std::exception& e) {
+        r.error = e.what();
+      } catch (...) {
+        r.error = "shuffle writer: unknown error while encoding a block";
+      }
+      r.encode_ms = rt.ns() / 1e6;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        r.done = true;
+      }
+      cv.notify_all();
+    });
+  }
+  const int fd = open(sw.shuffle_data_file.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  std::string failure;
+  if (fd < 0) failure = "shuffle write error: cannot create " + sw.shuffle_data_file + ": " + strerror(errno);
+  std::vector<int64_t> offsets((size_t)P + 1, 0);
+  int64_t file_pos = 0;
+  int next_p = 0;
+  double wait_ms = 0, write_ms = 0, enc_sum = 0, enc_max = 0;
+  for (size_t ri = 0; ri < runs.size(); ri++) {   // every run is waited for, also after a failure: the tasks reference this frame
+    Run& r = runs[ri];
+    {
+      Timer wt;
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return r.done; });
+      wait_ms += wt.ns() / 1e6;
+    }
+    enc_sum += r.encode_ms;
+    enc_max = std::max(enc_max, r.encode_ms);
+    Timer wrt;
+    if (failure.empty() && !r.error.empty()) failure = r.error;
+    if (!failure.empty()) continue;
+    int64_t pos = file_pos;
+    for (size_t t = r.first; t < r.last; t++) {
+      while (next_p <= tasks[t].p) offsets[(size_t)next_p++] = pos;
+      pos += (int64_t)r.block_size[t - r.first];
+    }
+    size_t done = 0;
+    while (done < r.bytes.size()) {
+      const ssize_t w = write(fd, r.bytes.data() + done, r.bytes.size() - done);
+      if (w <= 0) {
+        failure = "shuffle write error: " + std::string(strerror(errno)) + " (" + sw.shuffle_data_file + ")";
+        break;
+      }
+      done += (size_t)w;
+    }
+    file_pos = pos;
+    std::vector<uint8_t>().swap(r.bytes);
+    write_ms += wrt.ns() / 1e6;
+  }
+  if (trace)
+    fprintf(stderr, "[comet] shuffle write: %zu runs, encode cpu %.1f ms total (max %.2f ms/run), writer waited %.1f ms, wrote for %.1f ms\n", runs.size(),
+            enc_sum, enc_max, wait_ms, write_ms);
+  while (next_p <= P) offsets[(size_t)next_p++] = file_pos;
+  if (fd >= 0 && close(fd) != 0 && failure.empty()) failure = "shuffle write error: closing " + sw.shuffle_data_file + " failed";
+  if (!failure.empty()) throw CometError(failure);
+  lap("encode blocks + write data file (overlapped)");
+  FILE* xf = fopen(sw.shuffle_index_file.c_str(), "wb");
+  if (!xf) throw CometError("shuffle write error: cannot create " + sw.shuffle_index_file + ": " + strerror(errno));
+  const bool ok = fwrite(offsets.data(), 8, offsets.size(), xf) == offsets.size();
+  if (fclose(xf) != 0 || !ok) throw CometError("shuffle write error: writing " + sw.shuffle_index_file + " failed");
+  shuffle_bytes_written_ += offsets[(size_t)P];
+  lap("write files");
+  DevTable none;
+  return none;
 }
 
 // rows [first, first + rows) of `in` in the order given by dev_perm (nullptr = identity) → a new resident table
@@ -2199,52 +2477,8 @@ int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_sch
 // Arrow C Data export (prepare_output, jni_api.rs:674-742): one moved ArrowArray + ArrowSchema per
 // output column, offset 0, buffers owned by the array until the consumer calls release.
 // ---------------------------------------------------------------------------------------------
-namespace {
-struct ExportedColumn {
-  HostColumn col;
-  const void* buffers[3];
-  std::string format;
-};
-void release_array(ArrowArray* a) {
-  delete (ExportedColumn*)a->private_data;
-  a->release = nullptr;
-}
-void release_schema(ArrowSchema* s) {
-  delete (std::string*)s->private_data;
-  s->release = nullptr;
-}
-}  // namespace
-
 void ExecutionContext::export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
-  if ((size_t)n_out != b.cols.size())
-    throw CometError("Output column count mismatch: expected " + std::to_string(n_out) + ", got " + std::to_string(b.cols.size()));
-  for (int j = 0; j < n_out; j++) {
-    auto* ec = new ExportedColumn();
-    ec->col = std::move(b.cols[j]);
-    ec->format = expected_format(ec->col.type);
-    ArrowArray* a = out_arrays[j];
-    memset(a, 0, sizeof *a);
-    a->length = ec->col.length;
-    a->null_count = ec->col.null_count;
-    a->offset = 0;
-    const bool is_str = ec->col.type.id == TypeId::String || ec->col.type.id == TypeId::Bytes;
-    a->n_buffers = is_str ? 3 : 2;
-    ec->buffers[0] = ec->col.null_count ? ec->col.validity.data() : nullptr;
-    ec->buffers[1] = ec->col.values.data();
-    static const uint8_t kEmpty[1] = {0};
-    ec->buffers[2] = is_str ? (ec->col.data.empty() ? (const void*)kEmpty : (const void*)ec->col.data.data()) : nullptr;
-    a->buffers = ec->buffers;
-    a->private_data = ec;
-    a->release = release_array;
-    ArrowSchema* s = out_schemas[j];
-    memset(s, 0, sizeof *s);
-    auto* fmt = new std::string(ec->format);
-    s->format = fmt->c_str();
-    s->name = "";
-    s->flags = ARROW_FLAG_NULLABLE;
-    s->private_data = fmt;
-    s->release = release_schema;
-  }
+  export_host_batch(b, out_arrays, out_schemas, n_out);
 }
 
 std::string ExecutionContext::metrics_proto() {

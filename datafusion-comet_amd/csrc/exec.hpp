@@ -92,6 +92,8 @@ struct Variant {  // one JIT specialisation of the pipeline (per input-validity 
 
 // parquet_scan.cpp: run fn(0..n-1) on the process-wide scan threads and wait
 void scan_pool_parallel(size_t n, const std::function<void(size_t)>& fn);
+// queue one task on the same threads (FIFO) without waiting
+void scan_pool_submit(std::function<void()> fn);
 
 class ExecutionContext {
  public:
@@ -132,6 +134,7 @@ class ExecutionContext {
   DevTable sort_table(const Operator& s, const DevTable& in);
   DevTable take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner);
   DevTable nested_aggregate(const Operator& agg);
+  DevTable write_shuffle(const Operator& sw);
   static bool is_source(const Operator& op, const Operator* chain_top);
   typedef std::function<std::pair<const DevTable*, int>(int)> GatherSource;   // OutCol::gather_src → (table, column)
   DevTable outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals, const std::vector<std::shared_ptr<DevBuf>>& valid_bytes,
@@ -176,6 +179,8 @@ class ExecutionContext {
   bool materialize_root_ = false;   // plain Scan chain whose outputs need the materialising path (Utf8 pass-through)
   bool compile_in_infer_ = false;
   std::vector<const Operator*> nested_aggs_;
+  std::map<const Operator*, OperatorP> shuffle_projs_;   // ShuffleWriter with computed hash expressions → synthetic Projection(child ++ hash exprs)
+  int64_t shuffle_bytes_written_ = 0;
   std::map<const Operator*, OperatorP> smj_sorts_;  // SortMergeJoin node → synthetic Sort over its output       // aggregates that are not the plan root (materialised by sub-contexts)
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from
   std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)

@@ -17,10 +17,41 @@ namespace {
 
 JavaVM* g_vm = nullptr;
 
+struct BlockIterator;
 struct JavaSide {                 // global refs held for the lifetime of a plan (jni_api.rs:423-436,517-527)
   std::vector<jobject> iterators;
   jobject metrics_node = nullptr;
 };
+
+// The JNIEnv of the Native.executePlan call running on this thread: input callbacks (CometShuffleBlockIterator.hasNext /
+// getBuffer) are made on the calling task thread with that call's env, like the reference does before polling
+// (shuffle_scan.rs:112-135 "JNI calls cannot happen from within poll_next on tokio threads").
+thread_local JNIEnv* t_env = nullptr;
+
+// org.apache.comet.CometShuffleBlockIterator seen as a CometShuffleBlockStream (native/jni-bridge/src/shuffle_block_iterator.rs:40-66)
+struct BlockIterator {
+  CometShuffleBlockStream c;
+  jobject iter;                // global ref, owned by JavaSide::iterators
+  jmethodID has_next, get_buffer;
+  std::string error;
+};
+int64_t bi_next(CometShuffleBlockStream* self, const uint8_t** data) {
+  auto* b = (BlockIterator*)self->private_data;
+  JNIEnv* env = t_env;
+  if (!env) { b->error = "shuffle block iterator polled outside Native.executePlan"; return -2; }
+  const jint len = jni_CallIntMethod0(env, b->iter, b->has_next);   // reads the next block, returns its length or -1
+  if (jni_ExceptionCheck(env)) { b->error = "CometShuffleBlockIterator.hasNext threw"; return -2; }
+  if (len == -1) return -1;
+  jobject buf = jni_CallObjectMethod0(env, b->iter, b->get_buffer);
+  if (jni_ExceptionCheck(env) || !buf) { b->error = "CometShuffleBlockIterator.getBuffer failed"; return -2; }
+  void* p = jni_GetDirectBufferAddress(env, buf);
+  jni_DeleteLocalRef(env, buf);
+  if (!p) { b->error = "CometShuffleBlockIterator.getBuffer did not return a direct ByteBuffer"; return -2; }
+  *data = (const uint8_t*)p;
+  return len;
+}
+const char* bi_error(CometShuffleBlockStream* self) { return ((BlockIterator*)self->private_data)->error.c_str(); }
+void bi_release(CometShuffleBlockStream* self) { delete (BlockIterator*)self->private_data; }
 std::mutex g_mu;
 std::map<jlong, JavaSide> g_java;
 
@@ -112,9 +143,32 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
     // native side takes ownership of the C struct at that address (scan.rs:98-106)
     jclass cls = jni_GetObjectClass(env, it);
     jmethodID mid = cls ? jni_GetMethodID(env, cls, "memoryAddress", "()J") : nullptr;
-    if (!mid || jni_ExceptionCheck(env)) {
-      throw_java(env, COMET_ERR_NATIVE, "input iterator is not an org.apache.arrow.c.ArrowArrayStream (CometShuffleBlockIterator inputs are not supported by the MI355X engine yet)");
-      return 0;
+    if (!mid) {
+      // not an ArrowArrayStream: a CometShuffleBlockIterator feeding a ShuffleScan leaf (jni_api.rs:455-470)?
+      if (jni_ExceptionCheck(env)) jni_ExceptionClear(env);   // NoSuchMethodError from the probe above
+      jmethodID has_next = cls ? jni_GetMethodID(env, cls, "hasNext", "()I") : nullptr;
+      jmethodID get_buffer = has_next ? jni_GetMethodID(env, cls, "getBuffer", "()Ljava/nio/ByteBuffer;") : nullptr;
+      if (!has_next || !get_buffer) {
+        if (jni_ExceptionCheck(env)) jni_ExceptionClear(env);
+        for (size_t k = 0; k < inputs.size(); k++)
+          if (kinds[k] == COMET_INPUT_SHUFFLE_BLOCKS) bi_release((CometShuffleBlockStream*)inputs[k]);
+        for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
+        throw_java(env, COMET_ERR_NATIVE, "input iterator is neither an org.apache.arrow.c.ArrowArrayStream nor an org.apache.comet.CometShuffleBlockIterator");
+        return 0;
+      }
+      auto* b = new BlockIterator();
+      b->iter = jni_NewGlobalRef(env, it);
+      b->has_next = has_next;
+      b->get_buffer = get_buffer;
+      b->c.next_block = bi_next;
+      b->c.get_last_error = bi_error;
+      b->c.release = bi_release;
+      b->c.private_data = b;
+      inputs.push_back(&b->c);
+      kinds.push_back(COMET_INPUT_SHUFFLE_BLOCKS);
+      js.iterators.push_back(b->iter);
+      jni_DeleteLocalRef(env, it);
+      continue;
     }
     jlong addr = jni_CallLongMethod0(env, it, mid);
     if (jni_ExceptionCheck(env)) return 0;
@@ -153,7 +207,9 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_executePlan(JNIEnv* env, jc
     arrays[(size_t)i] = (struct ArrowArray*)(intptr_t)aa[(size_t)i];
     schemas[(size_t)i] = (struct ArrowSchema*)(intptr_t)sa[(size_t)i];
   }
+  t_env = env;
   int64_t rows = comet_execute_plan(handle, arrays.data(), schemas.data(), (int32_t)n);
+  t_env = nullptr;
   if (rows == -2) {
     throw_java(env, comet_last_error_kind(handle), comet_last_error(handle));
     return 0;
@@ -193,7 +249,7 @@ JNIEXPORT void JNICALL Java_org_apache_comet_Native_traceEnd(JNIEnv*, jclass, js
 JNIEXPORT void JNICALL Java_org_apache_comet_Native_logMemoryUsage(JNIEnv*, jclass, jstring, jlong) {}
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_getRustThreadId(JNIEnv*, jclass) { return 0; }
 
-// Shuffle-writer and columnar-to-row entry points (jni_api.rs:1047,1130,1163,1253,1275,1363): outside the hot path
+// JVM-shuffle (row-based) and columnar-to-row entry points (jni_api.rs:1047,1130,1253,1275,1363): outside the hot path
 // (SURVEY §8b "must exist").  They resolve, throw CometNativeException and return the type's zero value, so a Spark plan that
 // reaches them fails with a clear message instead of an UnsatisfiedLinkError.
 #define COMET_UNSUPPORTED(env, what) throw_java(env, COMET_ERR_NATIVE, what " is not implemented by the MI355X engine (libcomet.so, hot path only)")
@@ -205,9 +261,31 @@ JNIEXPORT jlongArray JNICALL Java_org_apache_comet_Native_writeSortedFileNative(
 JNIEXPORT void JNICALL Java_org_apache_comet_Native_sortRowPartitionsNative(JNIEnv* env, jclass, jlong, jlong, jboolean) {
   COMET_UNSUPPORTED(env, "Native.sortRowPartitionsNative");
 }
-JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_decodeShuffleBlock(JNIEnv* env, jclass, jobject, jint, jlongArray, jlongArray, jboolean) {
-  COMET_UNSUPPORTED(env, "Native.decodeShuffleBlock");
-  return 0;
+// Native.decodeShuffleBlock (jni_api.rs:1163-1181): one block in a direct ByteBuffer → Arrow C Data structs at the given addresses
+JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_decodeShuffleBlock(JNIEnv* env, jclass, jobject byteBuffer, jint length, jlongArray arrayAddrs,
+                                                                        jlongArray schemaAddrs, jboolean /*tracingEnabled*/) {
+  void* p = byteBuffer ? jni_GetDirectBufferAddress(env, byteBuffer) : nullptr;
+  if (!p) { throw_java(env, COMET_ERR_NATIVE, "decodeShuffleBlock: not a direct ByteBuffer"); return 0; }
+  const jsize n = arrayAddrs ? jni_GetArrayLength(env, arrayAddrs) : 0;
+  const jsize ns = schemaAddrs ? jni_GetArrayLength(env, schemaAddrs) : 0;
+  if (n != ns) { throw_java(env, COMET_ERR_NATIVE, "arrayAddrs and schemaAddrs differ in length"); return 0; }
+  std::vector<jlong> aa((size_t)n), sa((size_t)n);
+  if (n) {
+    jni_GetLongArrayRegion(env, arrayAddrs, 0, n, aa.data());
+    jni_GetLongArrayRegion(env, schemaAddrs, 0, n, sa.data());
+  }
+  std::vector<struct ArrowArray*> arrays((size_t)n);
+  std::vector<struct ArrowSchema*> schemas((size_t)n);
+  for (jsize i = 0; i < n; i++) {
+    arrays[(size_t)i] = (struct ArrowArray*)(intptr_t)aa[(size_t)i];
+    schemas[(size_t)i] = (struct ArrowSchema*)(intptr_t)sa[(size_t)i];
+  }
+  const int64_t rows = comet_decode_shuffle_block((const uint8_t*)p, length, arrays.data(), schemas.data(), (int32_t)n);
+  if (rows < 0) {
+    throw_java(env, comet_last_error_kind(0), comet_last_error(0));
+    return 0;
+  }
+  return (jlong)rows;
 }
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_columnarToRowInit(JNIEnv* env, jclass, jobjectArray, jint) {
   COMET_UNSUPPORTED(env, "Native.columnarToRowInit");

@@ -19,6 +19,8 @@
 #include <mutex>
 #include <thread>
 
+#include <sched.h>
+
 #include "exec.hpp"
 #include "parquet_dev.h"
 #include "parquet_meta.hpp"
@@ -58,7 +60,28 @@ class ScanPool {
 
  private:
   ScanPool() {
+    // CPUs this process may actually burn: the cgroup quota (containers: a 256-thread host often grants 16 CPUs; more busy
+    // threads than that only get throttled — measured 10.5 GB/s of LZ4 with 64 threads against 18.6 GB/s with 32 under a
+    // 16-CPU quota), the affinity mask, and half the hardware threads (SMT siblings add little to byte-crunching loops)
     size_t n = std::min<size_t>(64, std::max(1u, std::thread::hardware_concurrency() / 2));
+    {
+      cpu_set_t set;
+      if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<size_t>(n, (size_t)std::max(1, CPU_COUNT(&set)));
+      long long quota = -1, period = 100000;
+      if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "max 100000" or "<quota> <period>"
+        char q[64] = {0};
+        if (fscanf(f, "%63s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+      } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+        fclose(f1);
+        if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+          if (fscanf(f2, "%lld", &period) != 1) period = 100000;
+          fclose(f2);
+        }
+      }
+      if (quota > 0 && period > 0) n = std::min<size_t>(n, (size_t)std::max<long long>(1, (quota + period - 1) / period) * 2);
+    }
     if (const char* e = getenv("COMET_SCAN_THREADS")) n = (size_t)std::max(1, atoi(e));
     nthreads_ = n;
     for (size_t i = 0; i < n; i++) std::thread([this]() { run(); }).detach();
@@ -84,6 +107,8 @@ class ScanPool {
 }  // namespace
 
 // fn(0) … fn(n-1) on the scan threads; returns when all are done (used for the staging copies of host input batches too)
+void scan_pool_submit(std::function<void()> fn) { ScanPool::get().submit(std::move(fn)); }
+
 void scan_pool_parallel(size_t n, const std::function<void(size_t)>& fn) {
   if (n == 0) return;
   if (n == 1) { fn(0); return; }

@@ -94,7 +94,7 @@ struct AggExpr {
 
 // Operator.op_struct oneof tags (operator.proto:32-79)
 enum class OpKind : int {
-  Scan = 100, Projection = 101, Filter = 102, Sort = 103, HashAgg = 104, Limit = 105, HashJoin = 109,   // SortMergeJoin (108) decodes to HashJoin + smj
+  Scan = 100, Projection = 101, Filter = 102, Sort = 103, HashAgg = 104, Limit = 105, ShuffleWriter = 106, HashJoin = 109,   // SortMergeJoin (108) decodes to HashJoin + smj
   NativeScan = 111, Unsupported = -1
 };
 
@@ -158,6 +158,17 @@ struct Operator {
   std::string session_timezone;
   bool case_sensitive = false;                 // NativeScanCommon.case_sensitive (proto3 default)
   std::vector<int64_t> default_values_indexes;  // required_schema positions that carry a default value
+  // ShuffleScan (operator.proto:134-138) decodes to Scan with this flag: its input is a stream of shuffle blocks
+  bool shuffle_scan = false;
+  // ShuffleWriter (operator.proto:688-707; Partitioning partitioning.proto:29-66)
+  enum class Partitioning : int { Hash = 1, Single = 2, Range = 3, RoundRobin = 4 };
+  Partitioning shuffle_partitioning = Partitioning::Single;
+  std::vector<ExprP> shuffle_hash_exprs;
+  int shuffle_num_partitions = 1;
+  int shuffle_max_hash_columns = 0;
+  std::string shuffle_data_file, shuffle_index_file;
+  int shuffle_codec = 0;              // CompressionCodec: 0 None, 1 Zstd, 2 Lz4, 3 Snappy
+  int shuffle_compression_level = 1;
 };
 
 // proto.cpp

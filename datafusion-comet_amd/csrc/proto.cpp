@@ -343,6 +343,45 @@ OperatorP decode_operator_r(Reader r) {
           else b.skip(wt2);
         }
         break;
+      case 116:   // ShuffleScan{fields = 1, source = 2}
+        op->kind = OpKind::Scan;
+        op->shuffle_scan = true;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) op->scan_fields.push_back(decode_datatype(b.sub()));
+          else if (f2 == 2 && wt2 == 2) op->scan_source = b.bytes();
+          else b.skip(wt2);
+        }
+        break;
+      case 106:
+        op->kind = OpKind::ShuffleWriter;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) {
+            Reader pr = b.sub();
+            while (!pr.done()) {
+              int wt3, f3 = pr.tag(wt3);
+              if (wt3 != 2) { pr.skip(wt3); continue; }
+              Reader q = pr.sub();
+              op->shuffle_partitioning = (Operator::Partitioning)f3;
+              if (f3 == 2) op->shuffle_num_partitions = 1;
+              while (!q.done()) {
+                int wt4, f4 = q.tag(wt4);
+                if (f3 == 1 && f4 == 1 && wt4 == 2) op->shuffle_hash_exprs.push_back(decode_expr(q.sub()));
+                else if (f3 == 1 && f4 == 2 && wt4 == 0) op->shuffle_num_partitions = (int)(int32_t)q.varint();
+                else if (f3 == 3 && f4 == 2 && wt4 == 0) op->shuffle_num_partitions = (int)(int32_t)q.varint();
+                else if (f3 == 4 && f4 == 1 && wt4 == 0) op->shuffle_num_partitions = (int)(int32_t)q.varint();
+                else if (f3 == 4 && f4 == 2 && wt4 == 0) op->shuffle_max_hash_columns = (int)(int32_t)q.varint();
+                else q.skip(wt4);
+              }
+            }
+          } else if (f2 == 3 && wt2 == 2) op->shuffle_data_file = b.bytes();
+          else if (f2 == 4 && wt2 == 2) op->shuffle_index_file = b.bytes();
+          else if (f2 == 5 && wt2 == 0) op->shuffle_codec = (int)b.varint();
+          else if (f2 == 6 && wt2 == 0) op->shuffle_compression_level = (int)(int32_t)b.varint();
+          else b.skip(wt2);
+        }
+        break;
       case 101:
         op->kind = OpKind::Projection;
         while (!b.done()) {

@@ -76,6 +76,13 @@ def _load() -> ctypes.CDLL:
     lib.comet_take_utf8_offsets.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
     lib.comet_take_utf8_bytes.restype = c.c_int32
     lib.comet_take_utf8_bytes.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.comet_decode_shuffle_block.restype = c.c_int64
+    lib.comet_decode_shuffle_block.argtypes = [c.c_void_p, c.c_int64, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p), c.c_int32]
+    lib.comet_encode_shuffle_block.restype = c.c_int32
+    lib.comet_encode_shuffle_block.argtypes = [c.POINTER(c.c_void_p), c.POINTER(c.c_void_p), c.c_int32, c.c_int32, c.c_int32,
+                                               c.POINTER(c.c_void_p), c.POINTER(c.c_int64)]
+    lib.comet_free_buffer.restype = None
+    lib.comet_free_buffer.argtypes = [c.c_void_p]
     return lib
 
 
@@ -348,6 +355,104 @@ class DeviceInput:
 
 
 # --------------------------------------------------------------------------- Native (Native.scala)
+
+
+class CometShuffleBlockStreamC(ctypes.Structure):
+    _fields_ = [("next_block", ctypes.c_void_p), ("get_last_error", ctypes.c_void_p), ("release", ctypes.c_void_p),
+                ("private_data", ctypes.c_void_p)]
+
+
+class ShuffleBlockInput:
+    """Input of a ShuffleScan leaf: plays org.apache.comet.CometShuffleBlockIterator — hands the library one shuffle block at a
+    time, each starting at its codec tag (struct CometShuffleBlockStream, include/comet_amd.h)."""
+    kind = 2  # COMET_INPUT_SHUFFLE_BLOCKS
+
+    def __init__(self, blocks: Sequence[bytes]):
+        self._blocks = list(blocks)
+        self._pos = 0
+        self._cur = None
+        self._next_t = ctypes.CFUNCTYPE(ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p))
+        self._err_t = ctypes.CFUNCTYPE(ctypes.c_char_p, ctypes.c_void_p)
+        self._rel_t = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+        self._cbs = (self._next_t(self._next), self._err_t(lambda _s: None), self._rel_t(lambda _s: None))
+        self._c = CometShuffleBlockStreamC()
+        self._c.next_block = ctypes.cast(self._cbs[0], ctypes.c_void_p).value
+        self._c.get_last_error = ctypes.cast(self._cbs[1], ctypes.c_void_p).value
+        self._c.release = ctypes.cast(self._cbs[2], ctypes.c_void_p).value
+
+    @staticmethod
+    def from_files(data_file: str, index_file: str, partition: int) -> "ShuffleBlockInput":
+        """The blocks of one reduce partition of a (data, index) pair written by ShuffleWriter, headers stripped the way the JVM
+        reader strips them (8-byte length and 8-byte field count)."""
+        return ShuffleBlockInput(read_shuffle_partition(data_file, index_file, partition))
+
+    @property
+    def address(self) -> int:
+        return ctypes.addressof(self._c)
+
+    def _next(self, _self, out) -> int:
+        if self._pos >= len(self._blocks):
+            return -1
+        b = self._blocks[self._pos]
+        self._pos += 1
+        self._cur = ctypes.create_string_buffer(b, len(b))
+        out[0] = ctypes.addressof(self._cur)
+        return len(b)
+
+
+def read_shuffle_partition(data_file: str, index_file: str, partition: int) -> List[bytes]:
+    """Splits partition `partition` of a shuffle data file into blocks (each returned from its codec tag on): the index file
+    holds num_partitions + 1 little-endian int64 offsets (local_partition_writer.rs:255-295), every block starts with its
+    u64le length and u64le field count (shuffle_block_writer.rs:86-137)."""
+    import struct
+    idx = open(index_file, "rb").read()
+    offs = struct.unpack("<%dq" % (len(idx) // 8), idx)
+    with open(data_file, "rb") as f:
+        f.seek(offs[partition])
+        buf = f.read(offs[partition + 1] - offs[partition])
+    out, p = [], 0
+    while p < len(buf):
+        n, = struct.unpack_from("<q", buf, p)
+        out.append(buf[p + 16:p + 8 + n])
+        p += 8 + n
+    return out
+
+
+def decode_shuffle_block(block: bytes, num_cols: int) -> pa.RecordBatch:
+    """Native.decodeShuffleBlock: one block (from its codec tag) → a record batch."""
+    l = lib()
+    arrays = [ArrowArrayC() for _ in range(num_cols)]
+    schemas = [ArrowSchemaC() for _ in range(num_cols)]
+    aaddr = (ctypes.c_void_p * max(num_cols, 1))(*[ctypes.addressof(a) for a in arrays])
+    saddr = (ctypes.c_void_p * max(num_cols, 1))(*[ctypes.addressof(s) for s in schemas])
+    rows = l.comet_decode_shuffle_block(block, len(block), aaddr, saddr, num_cols)
+    if rows < 0:
+        _raise_last(0)
+    cols = [pa.Array._import_from_c(ctypes.addressof(a), ctypes.addressof(s)) for a, s in zip(arrays, schemas)]
+    return pa.RecordBatch.from_arrays(cols, names=[f"c{i}" for i in range(len(cols))])
+
+
+def encode_shuffle_block(batch: pa.RecordBatch, codec: int = 0, level: int = 1) -> bytes:
+    """ShuffleBlockWriter::write_batch on host columns: the complete block including its length and field-count words."""
+    l = lib()
+    n = batch.num_columns
+    arrays = [ArrowArrayC() for _ in range(n)]
+    schemas = [ArrowSchemaC() for _ in range(n)]
+    for i in range(n):
+        batch.column(i)._export_to_c(ctypes.addressof(arrays[i]), ctypes.addressof(schemas[i]))
+    aaddr = (ctypes.c_void_p * max(n, 1))(*[ctypes.addressof(a) for a in arrays])
+    saddr = (ctypes.c_void_p * max(n, 1))(*[ctypes.addressof(s) for s in schemas])
+    out = ctypes.c_void_p()
+    out_len = ctypes.c_int64()
+    rc = l.comet_encode_shuffle_block(aaddr, saddr, n, codec, level, ctypes.byref(out), ctypes.byref(out_len))
+    # give the exported structs back to pyarrow so that their release callbacks run
+    for a, s in zip(arrays, schemas):
+        pa.Array._import_from_c(ctypes.addressof(a), ctypes.addressof(s))
+    if rc != 0:
+        _raise_last(0)
+    data = ctypes.string_at(out.value, out_len.value) if out_len.value else b""
+    l.comet_free_buffer(out)
+    return data
 
 
 def _raise_last(handle: int):

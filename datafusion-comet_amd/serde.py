@@ -366,8 +366,16 @@ class Operator:
     limit: int = -1
     offset: int = 0
     files: List[tuple] = field(default_factory=list)          # (path, start, length, file_size)
+    # shuffle_writer
+    partitioning: str = "single"                # hash | single | round_robin | range
+    num_partitions: int = 1
+    max_hash_columns: int = 0
+    data_file: str = ""
+    index_file: str = ""
+    codec: int = 0                              # CompressionCodec: 0 None, 1 Zstd, 2 Lz4, 3 Snappy
+    compression_level: int = 1
 
-    TAGS = dict(scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
+    TAGS = dict(shuffle_writer=106, shuffle_scan=116, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -375,6 +383,25 @@ class Operator:
             out += _f_varint(2, self.plan_id)
         if self.kind == "scan":
             body = b"".join(_f_msg(1, f.encode()) for f in self.fields) + _f_bytes(2, b"test_scan")
+        elif self.kind == "shuffle_scan":
+            # ShuffleScan{fields=1, source=2} (operator.proto:134-138)
+            body = b"".join(_f_msg(1, f.encode()) for f in self.fields) + _f_bytes(2, b"CometShuffleExchangeExec [id=test]")
+        elif self.kind == "shuffle_writer":
+            # ShuffleWriter{partitioning=1, output_data_file=3, output_index_file=4, codec=5, compression_level=6} (operator.proto:688-707);
+            # Partitioning{hash_partition=1{hash_expression=1,num_partitions=2}, single_partition=2, range_partition=3{num_partitions=2},
+            # round_robin_partition=4{num_partitions=1,max_hash_columns=2}} (partitioning.proto:29-66)
+            if self.partitioning == "hash":
+                part = _f_msg(1, b"".join(_f_msg(1, e.encode()) for e in self.exprs) + _f_varint(2, self.num_partitions))
+            elif self.partitioning == "single":
+                part = _f_msg(2, b"")
+            elif self.partitioning == "range":
+                part = _f_msg(3, _f_varint(2, self.num_partitions))
+            else:
+                part = _f_msg(4, _f_varint(1, self.num_partitions) + (_f_varint(2, self.max_hash_columns) if self.max_hash_columns else b""))
+            body = _f_msg(1, part) + _f_bytes(3, self.data_file.encode()) + _f_bytes(4, self.index_file.encode())
+            if self.codec:
+                body += _f_varint(5, self.codec)
+            body += _f_varint(6, self.compression_level)
         elif self.kind == "projection":
             body = b"".join(_f_msg(1, e.encode()) for e in self.exprs)
         elif self.kind == "filter":
@@ -444,6 +471,21 @@ class Operator:
 
 def scan(fields: Sequence[DataType]) -> Operator:
     return Operator("scan", fields=list(fields))
+
+
+def shuffle_scan(fields: Sequence[DataType]) -> Operator:
+    """Leaf fed by a stream of shuffle blocks (CometShuffleBlockIterator in the JVM, native.ShuffleBlockInput here)."""
+    return Operator("shuffle_scan", fields=list(fields))
+
+
+CODEC_NONE, CODEC_ZSTD, CODEC_LZ4, CODEC_SNAPPY = 0, 1, 2, 3
+
+
+def shuffle_writer(child: Operator, data_file: str, index_file: str, partitioning: str = "single", hash_exprs: Sequence[Expr] = (),
+                   num_partitions: int = 1, codec: int = CODEC_NONE, compression_level: int = 1, max_hash_columns: int = 0) -> Operator:
+    return Operator("shuffle_writer", [child], exprs=list(hash_exprs), partitioning=partitioning, num_partitions=num_partitions,
+                    data_file=data_file, index_file=index_file, codec=codec, compression_level=compression_level,
+                    max_hash_columns=max_hash_columns)
 
 
 def filter_(child: Operator, predicate: Expr) -> Operator:

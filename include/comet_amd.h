@@ -27,6 +27,19 @@ struct ArrowDeviceArray;
 /* how input i is handed over */
 #define COMET_INPUT_HOST_STREAM 0   /* struct ArrowArrayStream*       — JVM path (CometNativeArrowSource.scala:67) */
 #define COMET_INPUT_DEVICE_STREAM 1 /* struct ArrowDeviceArrayStream* — ARROW_DEVICE_ROCM buffers already in HBM */
+#define COMET_INPUT_SHUFFLE_BLOCKS 2 /* struct CometShuffleBlockStream*  — input of a ShuffleScan leaf (operator.proto:134-138) */
+
+/* The C face of org.apache.comet.CometShuffleBlockIterator (what the reference's ShuffleScanExec pulls through JNI,
+ * native/core/src/execution/operators/shuffle_scan.rs:139-171): next_block plays hasNext() + getBuffer() — it returns the
+ * length of the next block and points *data at its bytes, which start at the 4-byte codec tag (the 8-byte length and
+ * 8-byte field-count words of the on-disk block are already consumed) and stay valid until the next call; -1 at the end,
+ * -2 on error.  The library takes ownership and calls release when the plan is released. */
+struct CometShuffleBlockStream {
+  int64_t (*next_block)(struct CometShuffleBlockStream* self, const uint8_t** data);
+  const char* (*get_last_error)(struct CometShuffleBlockStream* self);
+  void (*release)(struct CometShuffleBlockStream* self);
+  void* private_data;
+};
 
 /* error kinds → Java exception class (native/jni-bridge/src/errors.rs:473-560) */
 #define COMET_ERR_NATIVE 0          /* org/apache/comet/CometNativeException(msg) */
@@ -120,6 +133,23 @@ int64_t comet_take_utf8_offsets(const int32_t* offsets, const uint8_t* validity_
                                 int32_t* out_offsets, void* hip_stream);
 int32_t comet_take_utf8_bytes(const int32_t* offsets, const uint8_t* bytes, const uint8_t* validity_bits, const uint32_t* row_indices,
                               int64_t n, const int32_t* out_offsets, uint8_t* out_bytes, void* hip_stream);
+
+/* Replaces Java_org_apache_comet_Native_decodeShuffleBlock (native/core/src/execution/jni_api.rs:1163-1181 →
+ * read_ipc_compressed, native/shuffle/src/ipc.rs:23-52): decodes ONE shuffle block — 4-byte codec tag "NONE" / "ZSTD" / "LZ4_" /
+ * "SNAP" followed by the (compressed) Arrow IPC stream — and moves its single record batch into the caller-allocated Arrow C Data
+ * structs, one per column, dictionary-encoded columns unpacked.  Host-side only (the block is host bytes and so is the result).
+ * Returns the number of rows, or -2 on error (comet_last_error(0)). */
+int64_t comet_decode_shuffle_block(const uint8_t* block, int64_t len, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas,
+                                   int32_t n_out);
+
+/* The framing step of the shuffle writer on its own (ShuffleBlockWriter::write_batch, native/shuffle/src/writers/
+ * shuffle_block_writer.rs:179-238): encodes the host-resident columns (Arrow C Data, one array + schema per column, any offset) as ONE
+ * complete block — u64le length, u64le field count, codec tag, Arrow IPC stream under `codec` (0 none, 1 zstd, 2 lz4 frame,
+ * 3 snappy framing; operator.proto:679-686).  The ShuffleWriter operator (106) runs the same code after the GPU has partitioned the
+ * rows.  *out is malloc'ed (free with comet_free_buffer); zero rows produce no block (*out_len = 0).  Returns 0, or -2 on error. */
+int32_t comet_encode_shuffle_block(struct ArrowArray** arrays, struct ArrowSchema** schemas, int32_t n_cols, int32_t codec,
+                                   int32_t compression_level, uint8_t** out, int64_t* out_len);
+void comet_free_buffer(uint8_t* p);
 
 /* Host-only description of a Parquet footer as parsed by the library's own Thrift reader (rows, row groups, schema
  * elements, per-chunk codec/offsets) — the metadata the NativeScan path (native/core/src/parquet/parquet_exec.rs:60-211)

@@ -573,7 +573,7 @@ def run_plan(S, op, table) -> List[Col]:
         table = _ScanQueue(list(table))
     ev = Evaluator(S)
     k = op.kind
-    if k == "scan":
+    if k in ("scan", "shuffle_scan"):   # ShuffleScan: the decoded blocks of its input, concatenated (shuffle_scan.rs:139-190)
         t = table.pop()
         assert t.num_columns == len(op.fields)
         return [col_from_arrow(S, t.column(i), ty) for i, ty in enumerate(op.fields)]
@@ -1083,6 +1083,21 @@ def hash_partition_ids(S, table: pa.Table, key_cols, num_partitions: int) -> np.
         elif t in (pa.int32(), pa.date32(), pa.int16(), pa.int8()):
             a = np.ascontiguousarray(np.asarray(arr.cast(pa.int32()).fill_null(0)), dtype=np.int32)
             C.o_murmur3_i32(_p(a), _p(vb), ctypes.c_int64(n), _p(h))
+        elif pa.types.is_boolean(t):   # booleans hash as i32 0 / 1 (hash_funcs/utils.rs:573-600)
+            a = np.ascontiguousarray(np.asarray(arr.fill_null(False)).astype(np.int32))
+            C.o_murmur3_i32(_p(a), _p(vb), ctypes.c_int64(n), _p(h))
+        elif t == pa.float32():
+            a = np.ascontiguousarray(np.asarray(arr.fill_null(0)), dtype=np.float32)
+            C.o_murmur3_f32(_p(a), _p(vb), ctypes.c_int64(n), _p(h))
+        elif t == pa.float64():
+            a = np.ascontiguousarray(np.asarray(arr.fill_null(0)), dtype=np.float64)
+            C.o_murmur3_f64(_p(a), _p(vb), ctypes.c_int64(n), _p(h))
+        elif pa.types.is_string(t) or pa.types.is_binary(t):
+            enc = [b"" if v is None else (v.encode() if isinstance(v, str) else v) for v in arr.to_pylist()]
+            offs = np.zeros(n + 1, np.int32)
+            offs[1:] = np.cumsum([len(e) for e in enc])
+            data = np.frombuffer(b"".join(enc) + b"\0", np.uint8).copy()
+            C.o_murmur3_utf8(_p(offs), _p(data), _p(vb), ctypes.c_int64(n), _p(h))
         else:
             raise OracleError(f"hash partitioning on {t} is not restated")
     out = np.zeros(max(n, 1), np.int32)

@@ -1,0 +1,186 @@
+"""CPU restatement of Comet's native shuffle files — TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench cpu_baseline).
+
+Follows the reference's writer and reader, with pyarrow standing in for the arrow-ipc crate (both implement the same
+Arrow IPC stream specification) and for the zstd / lz4-frame / raw-snappy codecs:
+
+* partition ids: Spark murmur3 (seed 42) chained over the hash expressions → pmod
+  (native/shuffle/src/partitioners/multi_partition.rs:296-312, comet_partitioning.rs:51-57); "round robin" = the same hash
+  over the first max_hash_columns columns (multi_partition.rs:386-437); single partition = everything in partition 0.
+* row order: rows of a partition keep their input order and are cut into blocks of at most batch_size rows
+  (multi_partition.rs:54-103, partitioned_batch_iterator.rs:100-124).
+* block: u64le length of the rest | u64le field count | 4-byte codec tag | Arrow IPC stream (schema, one record batch, EOS)
+  raw / as one zstd frame / as one LZ4 frame / in Snappy framing format; zero-row batches write nothing
+  (writers/shuffle_block_writer.rs:86-137,179-238).
+* files: data = the partitions back to back, index = num_partitions + 1 little-endian i64 offsets
+  (writers/local/local_partition_writer.rs:255-295).
+* reader: the tag selects the decoder, the FIRST record batch of the stream is the block's content (native/shuffle/src/ipc.rs:23-52).
+
+Parity pinning: the block layout constants above are the reference's own (`header_bytes`, tags, `to_le_bytes`); the IPC payload
+is checked in both directions against pyarrow (tests/test_shuffle_format_cpu.py), i.e. against an independent implementation of
+the same specification the reference's arrow-ipc crate implements.  The reference's Rust tests for this path
+(shuffle_writer.rs:700-1430) are round trips through its own reader and carry no byte-level golden vectors.
+"""
+import io
+import struct
+from typing import List, Sequence
+
+import numpy as np
+import pyarrow as pa
+
+from . import oracle as O
+
+TAGS = {0: b"NONE", 1: b"ZSTD", 2: b"LZ4_", 3: b"SNAP"}
+_SNAPPY_STREAM_ID = b"\xff\x06\x00\x00sNaPpY"
+
+
+def _crc32c_table():
+    t = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        t.append(c)
+    return t
+
+
+_CRC = _crc32c_table()
+
+
+def crc32c(b: bytes) -> int:
+    c = 0xFFFFFFFF
+    for x in b:
+        c = _CRC[(c ^ x) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _mask(crc: int) -> int:
+    return (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def snappy_frame_encode(raw: bytes) -> bytes:
+    """Snappy framing format (framing_format.txt): stream identifier + chunks of ≤ 65536 uncompressed bytes."""
+    out = [_SNAPPY_STREAM_ID]
+    for off in range(0, len(raw), 65536):
+        chunk = raw[off:off + 65536]
+        comp = pa.compress(chunk, codec="snappy", asbytes=True)
+        body = struct.pack("<I", _mask(crc32c(chunk))) + comp
+        out.append(b"\x00" + struct.pack("<I", len(body))[:3] + body)
+    return b"".join(out)
+
+
+def snappy_frame_decode(buf: bytes) -> bytes:
+    out, p = [], 0
+    while p < len(buf):
+        kind = buf[p]
+        n = int.from_bytes(buf[p + 1:p + 4], "little")
+        body = buf[p + 4:p + 4 + n]
+        p += 4 + n
+        if kind == 0xFF:
+            assert body == b"sNaPpY"
+        elif kind in (0, 1):
+            want, = struct.unpack_from("<I", body, 0)
+            if kind == 1:
+                chunk = body[4:]
+            else:
+                # raw snappy carries its uncompressed length as a varint preamble
+                ulen, shift, k = 0, 0, 4
+                while True:
+                    b = body[k]
+                    k += 1
+                    ulen |= (b & 0x7F) << shift
+                    if not b & 0x80:
+                        break
+                    shift += 7
+                chunk = pa.decompress(body[4:], decompressed_size=ulen, codec="snappy", asbytes=True)
+            assert _mask(crc32c(chunk)) == want, "snappy chunk checksum"
+            out.append(chunk)
+        elif 2 <= kind <= 0x7F:
+            raise ValueError("reserved unskippable snappy chunk")
+    return b"".join(out)
+
+
+def ipc_stream(batch: pa.RecordBatch) -> bytes:
+    sink = io.BytesIO()
+    with pa.ipc.new_stream(sink, batch.schema) as w:
+        w.write_batch(batch)
+    return sink.getvalue()
+
+
+def encode_block(batch: pa.RecordBatch, codec: int = 0, level: int = 1) -> bytes:
+    """ShuffleBlockWriter::write_batch (shuffle_block_writer.rs:179-238)."""
+    if batch.num_rows == 0:
+        return b""
+    raw = ipc_stream(batch)
+    if codec == 0:
+        payload = raw
+    elif codec == 1:
+        sink = pa.BufferOutputStream()   # streaming encoder, like zstd::Encoder: the frame does not record its content size
+        z = pa.CompressedOutputStream(sink, "zstd")
+        z.write(raw)
+        z.close()
+        payload = sink.getvalue().to_pybytes()
+    elif codec == 2:
+        sink = pa.BufferOutputStream()
+        z = pa.CompressedOutputStream(sink, "lz4")   # LZ4 frame format
+        z.write(raw)
+        z.close()
+        payload = sink.getvalue().to_pybytes()
+    else:
+        payload = snappy_frame_encode(raw)
+    rest = struct.pack("<q", batch.num_columns) + TAGS[codec] + payload
+    return struct.pack("<q", len(rest)) + rest
+
+
+def decode_block(block: bytes) -> pa.RecordBatch:
+    """read_ipc_compressed (ipc.rs:23-52); `block` starts at the codec tag."""
+    tag, payload = block[:4], block[4:]
+    if tag == b"ZSTD":
+        payload = pa.CompressedInputStream(pa.BufferReader(payload), "zstd").read()
+    elif tag == b"LZ4_":
+        payload = pa.CompressedInputStream(pa.BufferReader(payload), "lz4").read()
+    elif tag == b"SNAP":
+        payload = snappy_frame_decode(payload)
+    elif tag != b"NONE":
+        raise ValueError(f"Failed to decode batch: invalid compression codec: {tag!r}")
+    return pa.ipc.open_stream(payload).read_next_batch()
+
+
+def partition_rows(S, table: pa.Table, partitioning: str, key_cols: Sequence[int], num_partitions: int, max_hash_columns: int = 0):
+    """→ (starts[P+1], row_indices[n]) of the shuffle writer for this input."""
+    n = table.num_rows
+    if partitioning == "single":
+        return np.array([0, n], np.int64), np.arange(n, dtype=np.uint32)
+    if partitioning == "round_robin":
+        k = table.num_columns if max_hash_columns <= 0 else min(max_hash_columns, table.num_columns)
+        key_cols = list(range(k))
+    pids = O.hash_partition_ids(S, table, key_cols, num_partitions)[:n]
+    starts, idx = O.partition_starts_and_indices(pids, num_partitions)
+    return starts.astype(np.int64), idx
+
+
+def shuffle_write(S, table: pa.Table, partitioning: str, key_cols: Sequence[int], num_partitions: int, batch_size: int, codec: int = 0,
+                  level: int = 1, max_hash_columns: int = 0):
+    """→ (data file bytes, index file bytes, per-partition list of row-index arrays)."""
+    P = 1 if partitioning == "single" else num_partitions
+    starts, idx = partition_rows(S, table, partitioning, key_cols, P, max_hash_columns)
+    parts, offsets, rows = [], [0], []
+    for p in range(P):
+        sel = idx[starts[p]:starts[p + 1]]
+        rows.append(sel)
+        chunk = b""
+        for r in range(0, len(sel), batch_size):
+            b = table.take(pa.array(sel[r:r + batch_size])).combine_chunks()
+            chunk += encode_block(b.to_batches()[0] if b.num_rows else pa.RecordBatch.from_pylist([], b.schema), codec, level)
+        parts.append(chunk)
+        offsets.append(offsets[-1] + len(chunk))
+    return b"".join(parts), struct.pack("<%dq" % (P + 1), *offsets), rows
+
+
+def read_partition(data: bytes, index: bytes, partition: int) -> List[pa.RecordBatch]:
+    offs = struct.unpack("<%dq" % (len(index) // 8), index)
+    buf, p, out = data[offs[partition]:offs[partition + 1]], 0, []
+    while p < len(buf):
+        n, = struct.unpack_from("<q", buf, p)
+        out.append(decode_block(buf[p + 16:p + 8 + n]))
+        p += 8 + n
+    return out

@@ -16,12 +16,13 @@ def load():
     m = ctypes.CDLL(_SO)
     vp = ctypes.c_void_p
     m.mock_env.restype = vp
-    for f in ("mock_bytes", "mock_longs", "mock_objs", "mock_stream", "mock_plain_object", "mock_metrics_node", "mock_string"):
+    for f in ("mock_bytes", "mock_longs", "mock_objs", "mock_stream", "mock_plain_object", "mock_metrics_node", "mock_string", "mock_block_iterator"):
         getattr(m, f).restype = vp
     m.mock_bytes.argtypes = [ctypes.c_char_p, ctypes.c_int64]
     m.mock_longs.argtypes = [vp, ctypes.c_int64]
     m.mock_objs.argtypes = [vp, ctypes.c_int64]
     m.mock_stream.argtypes = [ctypes.c_int64]
+    m.mock_block_iterator.argtypes = [vp, ctypes.c_int64]
     m.mock_string.argtypes = [ctypes.c_char_p]
     m.mock_metrics_len.restype = ctypes.c_int64
     m.mock_metrics_len.argtypes = [vp]
@@ -64,6 +65,21 @@ class Jvm:
         s = (ctypes.c_int64 * max(len(schema_addrs), 1))(*schema_addrs)
         return self.lib.Java_org_apache_comet_Native_executePlan(self.env, None, 0, 0, handle, self.m.mock_longs(a, len(array_addrs)),
                                                                  self.m.mock_longs(s, len(schema_addrs)))
+
+    def block_iterator(self, blocks):
+        """A CometShuffleBlockIterator stand-in over `blocks` (each from its codec tag on)."""
+        objs = [self.m.mock_bytes(b, len(b)) for b in blocks]
+        arr = (ctypes.c_void_p * max(len(objs), 1))(*objs)
+        return self.m.mock_block_iterator(arr, len(objs))
+
+    def decode_shuffle_block(self, block: bytes, array_addrs, schema_addrs):
+        f = self.lib.Java_org_apache_comet_Native_decodeShuffleBlock
+        f.restype = ctypes.c_int64
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint8]
+        a = (ctypes.c_int64 * max(len(array_addrs), 1))(*array_addrs)
+        s = (ctypes.c_int64 * max(len(schema_addrs), 1))(*schema_addrs)
+        return f(self.env, None, self.m.mock_bytes(block, len(block)), len(block), self.m.mock_longs(a, len(array_addrs)),
+                 self.m.mock_longs(s, len(schema_addrs)), 0)
 
     def release_plan(self, handle):
         self.lib.Java_org_apache_comet_Native_releasePlan(self.env, None, handle)

@@ -8,7 +8,7 @@
 
 #include "../../datafusion-comet_amd/csrc/third_party/jni_min.h"
 
-enum { K_BYTES = 1, K_LONGS, K_OBJS, K_STREAM, K_METRICS, K_STRING, K_CLASS };
+enum { K_BYTES = 1, K_LONGS, K_OBJS, K_STREAM, K_METRICS, K_STRING, K_CLASS, K_BLOCKITER };
 typedef struct MObj {
   int kind;
   int64_t len;
@@ -28,7 +28,8 @@ static int g_live_global_refs;
 static MObj g_cls_stream = {K_CLASS, 0, 0, 0, 0, "org/apache/arrow/c/ArrowArrayStream"};
 static MObj g_cls_metrics = {K_CLASS, 0, 0, 0, 0, "org/apache/spark/sql/comet/CometMetricNode"};
 static MObj g_cls_other = {K_CLASS, 0, 0, 0, 0, "java/lang/Object"};
-static int g_mid_memaddr, g_mid_setall;
+static MObj g_cls_blockiter = {K_CLASS, 0, 0, 0, 0, "org/apache/comet/CometShuffleBlockIterator"};
+static int g_mid_memaddr, g_mid_setall, g_mid_hasnext, g_mid_getbuffer;
 
 static jclass f_FindClass(JNIEnv* e, const char* n) { (void)e; MObj* c = calloc(1, sizeof *c); c->kind = K_CLASS; c->cname = strdup(n); return c; }
 static jint f_ThrowNew(JNIEnv* e, jclass c, const char* m) {
@@ -43,15 +44,33 @@ static void f_DeleteGlobalRef(JNIEnv* e, jobject o) { (void)e; if (o) { ((MObj*)
 static void f_DeleteLocalRef(JNIEnv* e, jobject o) { (void)e; (void)o; }
 static jclass f_GetObjectClass(JNIEnv* e, jobject o) {
   (void)e; MObj* m = o;
-  return m->kind == K_STREAM ? (jclass)&g_cls_stream : m->kind == K_METRICS ? (jclass)&g_cls_metrics : (jclass)&g_cls_other;
+  return m->kind == K_STREAM ? (jclass)&g_cls_stream : m->kind == K_METRICS ? (jclass)&g_cls_metrics :
+         m->kind == K_BLOCKITER ? (jclass)&g_cls_blockiter : (jclass)&g_cls_other;
 }
 static jmethodID f_GetMethodID(JNIEnv* e, jclass c, const char* n, const char* sig) {
   (void)e;
   if (c == &g_cls_stream && !strcmp(n, "memoryAddress") && !strcmp(sig, "()J")) return &g_mid_memaddr;
   if (c == &g_cls_metrics && !strcmp(n, "set_all_from_bytes") && !strcmp(sig, "([B)V")) return &g_mid_setall;
+  if (c == &g_cls_blockiter && !strcmp(n, "hasNext") && !strcmp(sig, "()I")) return &g_mid_hasnext;
+  if (c == &g_cls_blockiter && !strcmp(n, "getBuffer") && !strcmp(sig, "()Ljava/nio/ByteBuffer;")) return &g_mid_getbuffer;
   return NULL;   /* a real JVM would also raise NoSuchMethodError */
 }
 static jlong f_CallLongMethod(JNIEnv* e, jobject o, jmethodID m, ...) { (void)e; return m == &g_mid_memaddr ? ((MObj*)o)->addr : 0; }
+/* K_BLOCKITER: data = MObj** blocks (K_BYTES standing in for direct ByteBuffers), len = count, addr = cursor */
+static jint f_CallIntMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
+  (void)e; MObj* it = o;
+  if (m != &g_mid_hasnext) return 0;
+  if (it->addr >= it->len) return -1;
+  it->addr++;
+  return (jint)((MObj**)it->data)[it->addr - 1]->len;
+}
+static jobject f_CallObjectMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
+  (void)e; MObj* it = o;
+  if (m != &g_mid_getbuffer || it->addr < 1) return NULL;
+  return ((MObj**)it->data)[it->addr - 1];
+}
+static void* f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return b && ((MObj*)b)->kind == K_BYTES ? ((MObj*)b)->data : NULL; }
+static void f_ExceptionClear(JNIEnv* e) { (void)e; g_exc_pending = 0; }
 static void f_CallVoidMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
   (void)e;
   if (m != &g_mid_setall) return;
@@ -82,12 +101,17 @@ JNIEnv* mock_env(void) {
   g_tab.fn[JNI_GetObjectArrayElement] = (void*)f_GetObjectArrayElement; g_tab.fn[JNI_NewByteArray] = (void*)f_NewByteArray;
   g_tab.fn[JNI_GetByteArrayRegion] = (void*)f_GetByteArrayRegion; g_tab.fn[JNI_SetByteArrayRegion] = (void*)f_SetByteArrayRegion;
   g_tab.fn[JNI_GetLongArrayRegion] = (void*)f_GetLongArrayRegion; g_tab.fn[JNI_GetJavaVM] = (void*)f_GetJavaVM;
+  g_tab.fn[JNI_CallIntMethod] = (void*)f_CallIntMethod; g_tab.fn[JNI_CallObjectMethod] = (void*)f_CallObjectMethod;
+  g_tab.fn[JNI_GetDirectBufferAddress] = (void*)f_GetDirectBufferAddress; g_tab.fn[JNI_ExceptionClear] = (void*)f_ExceptionClear;
   return (JNIEnv*)&g_env;
 }
 void* mock_bytes(const void* p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_BYTES; o->len = n; o->data = malloc((size_t)n + 1); memcpy(o->data, p, (size_t)n); return o; }
 void* mock_longs(const int64_t* p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_LONGS; o->len = n; o->data = malloc((size_t)n * 8 + 8); memcpy(o->data, p, (size_t)n * 8); return o; }
 void* mock_objs(void** p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_OBJS; o->len = n; o->data = malloc((size_t)n * 8 + 8); memcpy(o->data, p, (size_t)n * 8); return o; }
 void* mock_stream(int64_t addr) { MObj* o = calloc(1, sizeof *o); o->kind = K_STREAM; o->addr = addr; return o; }
+void* mock_block_iterator(void** blocks, int64_t n) {
+  MObj* o = calloc(1, sizeof *o); o->kind = K_BLOCKITER; o->len = n; o->data = malloc((size_t)n * 8 + 8); memcpy(o->data, blocks, (size_t)n * 8); return o;
+}
 void* mock_plain_object(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_OBJS; return o; }
 void* mock_metrics_node(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_METRICS; return o; }
 void* mock_string(const char* s) { MObj* o = calloc(1, sizeof *o); o->kind = K_STRING; o->data = strdup(s); return o; }

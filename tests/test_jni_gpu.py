@@ -58,3 +58,32 @@ def test_ansi_overflow_raises_query_execution_exception(built):
     plan2 = S.project(S.scan([D, D]), [S.math("add", S.col(0, D), S.col(1, D), D)])
     out = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(table)], 1, plan2.encode()))
     assert out.column(0).to_pylist() == [None, __import__("decimal").Decimal(6)]
+
+
+def test_shuffle_scan_through_jni_block_iterator(built):
+    """A reduce-side plan as Spark runs it: iterators[0] is a CometShuffleBlockIterator whose hasNext()/getBuffer() the native
+    side calls from executePlan (shuffle_scan.rs:139-171); the blocks here are written by the oracle's (pyarrow) writer."""
+    import numpy as np
+    from oracle import oracle as O, shuffle_oracle as SO
+    jvm = Jvm(native.lib())
+    rng = np.random.default_rng(3)
+    n = 30_000
+    t = pa.table({"k": pa.array(rng.integers(0, 50, n), pa.int64(), mask=rng.random(n) < 0.05),
+                  "v": tpch._dec128_array(rng.integers(-10**9, 10**9, n), 12, 2)})
+    fields = [S.T_INT64, S.decimal(12, 2)]
+    blocks = [SO.encode_block(b, c)[16:] for c, b in zip([1, 2, 3, 0, 1, 2, 3, 0], t.to_batches(max_chunksize=4000))]
+    plan = S.hash_agg(S.shuffle_scan(fields), [S.col(0, S.T_INT64)], [S.sum_(S.col(1, fields[1]), S.decimal(22, 2)), S.count(S.col(1, fields[1]))], S.PARTIAL)
+    h = jvm.create_plan([], plan.encode(), iterator_objects=[jvm.block_iterator(blocks)], batch_size=0)
+    assert h > 0, jvm.exception()
+    arrays = [native.ArrowArrayC() for _ in range(4)]
+    schemas = [native.ArrowSchemaC() for _ in range(4)]
+    rows = jvm.execute_plan(h, [ctypes.addressof(a) for a in arrays], [ctypes.addressof(s) for s in schemas])
+    assert rows == 51, jvm.exception()
+    cols = [pa.Array._import_from_c(ctypes.addressof(a), ctypes.addressof(s)) for a, s in zip(arrays, schemas)]
+    want = O.run_plan_to_arrow(S, plan, [t])
+    key = lambda r: (r[0] is None, r[0] or 0)
+    got_rows = sorted(zip(*[c.to_pylist() for c in cols]), key=key)
+    want_rows = sorted(zip(*[want.column(i).to_pylist() for i in range(4)]), key=key)
+    assert got_rows == want_rows
+    jvm.release_plan(h)
+    assert jvm.m.mock_live_global_refs() == 0

@@ -83,3 +83,34 @@ def test_execute_with_mismatched_address_arrays(jvm):
 def test_invalid_handle(jvm):
     rows = jvm.execute_plan(987654, [], [])
     assert rows == 0 and jvm.exception()[0] == "org/apache/comet/CometNativeException"
+
+
+def test_decode_shuffle_block_through_jni(jvm):
+    """Native.decodeShuffleBlock (jni_api.rs:1163-1181): direct ByteBuffer in, Arrow C Data structs out; errors become
+    CometNativeException."""
+    import numpy as np
+    from oracle import shuffle_oracle as SO
+    b = pa.record_batch({"k": pa.array(np.arange(1000), pa.int64()), "s": pa.array([None if i % 5 == 0 else "v%d" % i for i in range(1000)])})
+    for codec in (0, 1, 2, 3):
+        blk = SO.encode_block(b, codec)[16:]
+        arrays = [native.ArrowArrayC() for _ in range(2)]
+        schemas = [native.ArrowSchemaC() for _ in range(2)]
+        rows = jvm.decode_shuffle_block(blk, [ctypes.addressof(a) for a in arrays], [ctypes.addressof(s) for s in schemas])
+        assert rows == 1000, jvm.exception()
+        cols = [pa.Array._import_from_c(ctypes.addressof(a), ctypes.addressof(s)) for a, s in zip(arrays, schemas)]
+        assert cols[0].equals(b.column(0)) and cols[1].equals(b.column(1))
+    a, s = native.ArrowArrayC(), native.ArrowSchemaC()
+    assert jvm.decode_shuffle_block(b"BZIP" + b"\0" * 64, [ctypes.addressof(a)], [ctypes.addressof(s)]) == 0
+    cls, msg = jvm.exception()
+    assert cls == "org/apache/comet/CometNativeException" and "invalid compression codec" in msg
+
+
+def test_shuffle_block_iterator_is_accepted_for_a_shuffle_scan_leaf(jvm):
+    """createPlan binds a CometShuffleBlockIterator (hasNext()I / getBuffer()) to a ShuffleScan leaf; global refs balance."""
+    it = jvm.block_iterator([])
+    plan = S.filter_(S.shuffle_scan([S.T_INT64]), S.is_not_null(S.col(0, S.T_INT64)))
+    h = jvm.create_plan([], plan.encode(), iterator_objects=[it])
+    assert h > 0, jvm.exception()
+    assert jvm.m.mock_live_global_refs() == 1
+    jvm.release_plan(h)
+    assert jvm.m.mock_live_global_refs() == 0

@@ -1,0 +1,171 @@
+"""Native shuffle write / read: ShuffleWriter (operator 106) partitions on the GPU — murmur3 → pmod → stable
+partition indices → per-column takes, the exchange kernels — and frames the partitions into Comet's data + index files;
+ShuffleScan (operator 116) reads such blocks back into a plan.  The oracle is oracle/shuffle_oracle.py (partitioning by the
+pinned murmur3 / pmod / partition-index restatements, blocks via pyarrow's IPC implementation).  Files are compared block by
+block after decoding: same rows in the same order in every block of every partition."""
+import decimal
+import os
+import struct
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native, serde as S, tpch
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(n, seed=21):
+    rng = np.random.default_rng(seed)
+    return pa.table({
+        "k": pa.array(rng.integers(-1000, 1000, n), pa.int64(), mask=rng.random(n) < 0.05),
+        "s": pa.array([None if i % 17 == 0 else "name-%d" % (i * 31 % 257) for i in range(n)], pa.string()),
+        "d": tpch._dec128_array(rng.integers(-10**10, 10**10, n), 12, 2),
+        "f": pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.1),
+        "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2),
+        "dt": pa.array(rng.integers(8000, 12000, n).astype(np.int32), pa.date32()),
+        "i": pa.array(rng.integers(-2**31, 2**31, n).astype(np.int32)),
+    })
+
+
+FIELDS = [S.T_INT64, S.T_STRING, S.decimal(12, 2), S.T_DOUBLE, S.T_BOOL, S.T_DATE, S.T_INT32]
+
+
+def _write(plan_child, tables, tmp_path, ncols_check=None, **kw):
+    data, index = str(tmp_path / "shuffle.data"), str(tmp_path / "shuffle.index")
+    batch_size = kw.pop("batch_size", 8192)
+    plan = S.shuffle_writer(plan_child, data, index, **kw)
+    out = native.execute_to_table([native.HostInput.from_table(t) for t in tables], 0, plan.encode(), batch_size=batch_size)
+    assert out == []                       # ShuffleWriterExec yields no batches
+    return data, index
+
+
+def _check_files(data, index, table, rows_per_partition, batch_size, codec):
+    from oracle import shuffle_oracle as SO
+    raw, idx = open(data, "rb").read(), open(index, "rb").read()
+    P = len(rows_per_partition)
+    offs = struct.unpack("<%dq" % (P + 1), idx)
+    assert offs[0] == 0 and offs[-1] == len(raw) and list(offs) == sorted(offs)
+    total = 0
+    for p in range(P):
+        want = table.take(pa.array(rows_per_partition[p]))
+        blocks = SO.read_partition(raw, idx, p)
+        sizes = [b.num_rows for b in blocks]
+        n = want.num_rows
+        assert sizes == [batch_size] * (n // batch_size) + ([n % batch_size] if n % batch_size else []), (p, sizes[:4], n)
+        # every block carries the codec tag asked for
+        q = offs[p]
+        while q < offs[p + 1]:
+            ln, nf = struct.unpack_from("<qq", raw, q)
+            assert nf == table.num_columns and raw[q + 16:q + 20] == SO.TAGS[codec]
+            q += 8 + ln
+        if blocks:
+            got = pa.Table.from_batches(blocks)
+            for c in range(table.num_columns):
+                assert got.column(c).combine_chunks().equals(want.column(c).combine_chunks()), (p, c)
+        total += n
+    assert total == table.num_rows
+
+
+@pytest.mark.parametrize("codec", [S.CODEC_NONE, S.CODEC_ZSTD, S.CODEC_LZ4, S.CODEC_SNAPPY])
+def test_hash_partitioned_files_match_oracle(built, tmp_path, codec):
+    from oracle import shuffle_oracle as SO
+    t = _table(60_000)
+    data, index = _write(S.scan(FIELDS), [t], tmp_path, partitioning="hash", hash_exprs=[S.col(0, FIELDS[0]), S.col(1, FIELDS[1])],
+                         num_partitions=7, codec=codec, batch_size=4096)
+    _, _, rows = SO.shuffle_write(S, t, "hash", [0, 1], 7, 4096)
+    _check_files(data, index, t, rows, 4096, codec)
+
+
+def test_many_partitions_decimal_and_date_keys(built, tmp_path):
+    from oracle import shuffle_oracle as SO
+    t = _table(100_000, seed=4)
+    data, index = _write(S.scan(FIELDS), [t], tmp_path, partitioning="hash", hash_exprs=[S.col(2, FIELDS[2]), S.col(5, FIELDS[5]), S.col(4, FIELDS[4])],
+                         num_partitions=200, codec=S.CODEC_LZ4, batch_size=8192)
+    _, _, rows = SO.shuffle_write(S, t, "hash", [2, 5, 4], 200, 8192)
+    _check_files(data, index, t, rows, 8192, S.CODEC_LZ4)
+
+
+def test_single_and_round_robin(built, tmp_path):
+    from oracle import shuffle_oracle as SO
+    t = _table(30_000, seed=8)
+    d1 = tmp_path / "single"
+    d1.mkdir()
+    data, index = _write(S.scan(FIELDS), [t], d1, partitioning="single", codec=S.CODEC_ZSTD, batch_size=5000)
+    _check_files(data, index, t, [np.arange(t.num_rows)], 5000, S.CODEC_ZSTD)
+    for mhc in (0, 3):
+        d2 = tmp_path / f"rr{mhc}"
+        d2.mkdir()
+        data, index = _write(S.scan(FIELDS), [t], d2, partitioning="round_robin", num_partitions=5, max_hash_columns=mhc, batch_size=8192)
+        _, _, rows = SO.shuffle_write(S, t, "round_robin", [], 5, 8192, max_hash_columns=mhc)
+        _check_files(data, index, t, rows, 8192, S.CODEC_NONE)
+
+
+def test_computed_hash_expression_over_a_filter_project_chain(built, tmp_path):
+    from oracle import oracle as O, shuffle_oracle as SO
+    t = _table(40_000, seed=12)
+    k, i = S.col(0, S.T_INT64), S.col(6, S.T_INT32)
+    child = S.project(S.filter_(S.scan(FIELDS), S.gt(i, S.lit(0, S.T_INT32))), [k, S.col(1, S.T_STRING), S.math("add", k, S.lit(5, S.T_INT64), S.T_INT64), S.col(2, FIELDS[2])])
+    out_fields = [S.T_INT64, S.T_STRING, S.T_INT64, FIELDS[2]]
+    # hash on (k + 5) * 3 — not a column of the child: evaluated by a fused projection, never written to the file
+    hexpr = S.math("multiply", S.col(2, S.T_INT64), S.lit(3, S.T_INT64), S.T_INT64)
+    data, index = _write(child, [t], tmp_path, partitioning="hash", hash_exprs=[hexpr, S.col(1, S.T_STRING)], num_partitions=9, batch_size=8192)
+    want_child = O.run_plan_to_arrow(S, child, [t])
+    keyed = O.run_plan_to_arrow(S, S.project(S.scan(out_fields), [hexpr, S.col(1, S.T_STRING)]), [want_child])
+    _, _, rows = SO.shuffle_write(S, keyed, "hash", [0, 1], 9, 8192)
+    _check_files(data, index, want_child, rows, 8192, S.CODEC_NONE)
+
+
+def test_two_stage_aggregate_through_shuffle_files(built, tmp_path):
+    """Partial aggregate → ShuffleWriter (hash on the group key) → per reduce partition: ShuffleScan → Final aggregate.
+    The union over the partitions equals the single-stage result, and every group lands in exactly one partition."""
+    from oracle import oracle as O
+    t = _table(80_000, seed=30)
+    D = FIELDS[2]
+    scan = S.scan(FIELDS)
+    partial = S.hash_agg(scan, [S.col(0, S.T_INT64)], [S.sum_(S.col(2, D), S.decimal(22, 2)), S.count(S.col(3, S.T_DOUBLE))], S.PARTIAL)
+    state = O.run_plan_to_arrow(S, partial, [t])
+    P = 6
+    data, index = _write(partial, [t], tmp_path, partitioning="hash", hash_exprs=[S.col(0, S.T_INT64)], num_partitions=P, codec=S.CODEC_ZSTD, batch_size=1000)
+    final = S.final_of(partial, state.schema)
+    final.children[0] = S.shuffle_scan(final.children[0].fields)
+    got_rows, seen = [], set()
+    for p in range(P):
+        inp = native.ShuffleBlockInput.from_files(data, index, p)
+        out = native.execute_to_table([inp], 3, final.encode(), batch_size=0)
+        if not out:
+            continue
+        tb = pa.Table.from_batches(out)
+        keys = tb.column(0).to_pylist()
+        assert not (set(keys) & seen)
+        seen |= set(keys)
+        got_rows += list(zip(keys, tb.column(1).to_pylist(), tb.column(2).to_pylist()))
+    single = O.run_plan_to_arrow(S, S.hash_agg(scan, partial.exprs, partial.aggs, S.PARTIAL), [t])
+    want = O.run_plan_to_arrow(S, S.final_of(partial, state.schema), [single])
+    want_rows = list(zip(want.column(0).to_pylist(), want.column(1).to_pylist(), want.column(2).to_pylist()))
+    key = lambda r: (r[0] is None, r[0] or 0)
+    assert sorted(got_rows, key=key) == sorted(want_rows, key=key)
+
+
+def test_shuffle_scan_reads_oracle_written_blocks(built):
+    from oracle import oracle as O, shuffle_oracle as SO
+    t = _table(20_000, seed=2)
+    blocks = [SO.encode_block(b, codec)[16:] for codec, b in zip([0, 1, 2, 3, 1], t.to_batches(max_chunksize=4096))]
+    plan = S.project(S.filter_(S.shuffle_scan(FIELDS), S.is_not_null(S.col(0, S.T_INT64))), [S.col(0, S.T_INT64), S.col(1, S.T_STRING), S.col(2, FIELDS[2])])
+    got = pa.Table.from_batches(native.execute_to_table([native.ShuffleBlockInput(blocks)], 3, plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, [t])
+    for c in range(3):
+        assert got.column(c).combine_chunks().equals(want.column(c).combine_chunks()), c
+
+
+def test_empty_input_writes_empty_files(built, tmp_path):
+    t = _table(100).slice(0, 0)
+    data, index = _write(S.scan(FIELDS), [t], tmp_path, partitioning="hash", hash_exprs=[S.col(0, S.T_INT64)], num_partitions=4)
+    assert os.path.getsize(data) == 0 and open(index, "rb").read() == b"\0" * 40
+
+
+def test_unsupported_partitioning_fails_at_create_plan(built, tmp_path):
+    plan = S.shuffle_writer(S.scan(FIELDS), str(tmp_path / "d"), str(tmp_path / "i"), partitioning="range", num_partitions=4)
+    with pytest.raises(native.CometNativeException, match="range partitioning"):
+        native.Native.createPlan([native.HostInput.from_table(_table(10))], plan.encode())

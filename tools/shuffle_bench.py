@@ -1,0 +1,64 @@
+"""Shuffle-writer throughput on one GPU: a resident table → ShuffleWriter(hash(key), P partitions) → data + index files.
+Usage: python tools/shuffle_bench.py [--rows N] [--partitions P] [--codec none|zstd|lz4|snappy] [--out json]"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=20_000_000)
+    ap.add_argument("--partitions", type=int, default=200)
+    ap.add_argument("--codec", default="lz4")
+    ap.add_argument("--batch-size", type=int, default=8192)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import pyarrow as pa
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    from datafusion_comet_amd import native, serde as S
+    n = a.rows
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(7)
+    key = torch.randint(0, 150_000_000, (n,), generator=gen, device=dev, dtype=torch.int64)
+    price = torch.randint(90_000, 10_000_000, (n,), generator=gen, device=dev, dtype=torch.int64)
+    dec = torch.stack([price, torch.zeros_like(price)], dim=1).contiguous().view(torch.uint8).reshape(-1)   # decimal128 LE limbs
+    date = torch.randint(8000, 10500, (n,), generator=gen, device=dev, dtype=torch.int32)
+    prio = torch.randint(0, 5, (n,), generator=gen, device=dev, dtype=torch.int32)
+    schema = pa.schema([("k", pa.int64()), ("p", pa.decimal128(12, 2)), ("d", pa.date32()), ("s", pa.int32())])
+    table = native.DeviceTable(schema, n, [key.view(torch.uint8), dec, date.view(torch.uint8), prio.view(torch.uint8)], [None] * 4, dev)
+    fields = [S.T_INT64, S.decimal(12, 2), S.T_DATE, S.T_INT32]
+    codec = dict(none=0, zstd=1, lz4=2, snappy=3)[a.codec]
+    arrow_bytes = n * (8 + 16 + 4 + 4)
+    best = None
+    with tempfile.TemporaryDirectory(dir=a.dir) as td:
+        data, index = os.path.join(td, "s.data"), os.path.join(td, "s.index")
+        plan = S.shuffle_writer(S.scan(fields), data, index, partitioning="hash", hash_exprs=[S.col(0, S.T_INT64)], num_partitions=a.partitions, codec=codec).encode()
+        for r in range(a.reps + 1):
+            inp = native.DeviceInput(table)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = native.execute_to_table([inp], 0, plan, batch_size=a.batch_size)
+            dt = time.perf_counter() - t0
+            inp.close()
+            assert out == []
+            if r > 0:
+                best = dt if best is None else min(best, dt)
+        size = os.path.getsize(data)
+    res = {"rows": n, "partitions": a.partitions, "codec": a.codec, "seconds": best, "rows_per_s": n / best, "arrow_GB_per_s": arrow_bytes / best / 1e9,
+           "file_bytes": size, "ratio": size / arrow_bytes}
+    print(json.dumps(res))
+    if a.out:
+        json.dump(res, open(a.out, "w"))
+
+
+if __name__ == "__main__":
+    main()
