@@ -1907,6 +1907,7 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
   }
   HIP_CHECK(hipStreamSynchronize(stream_));
   check_device_errors();
+  shuffle_repart_ns_ += tm.ns();
   lap("partition (murmur3, pmod, indices, takes)");
 
   // one download of the partition-major table
@@ -1942,6 +1943,7 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
   // frame every partition on the host threads
   const int64_t bs = batch_size_ > 0 ? batch_size_ : std::max<int64_t>(n, 1);
   const ShuffleCodec codec = (ShuffleCodec)sw.shuffle_codec;
+  const double write_t0 = tm.ns();
   // Blocks in file order — (partition, first row, rows) — grouped into runs of consecutive blocks of ≈4 MiB of column data.  The
   // scan threads encode whole runs (one output buffer per run, allocated once); this thread writes finished runs to the data
   // file in order while later runs are still being encoded.
@@ -2058,6 +2060,8 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
   const bool ok = fwrite(offsets.data(), 8, offsets.size(), xf) == offsets.size();
   if (fclose(xf) != 0 || !ok) throw CometError("shuffle write error: writing " + sw.shuffle_index_file + " failed");
   shuffle_bytes_written_ += offsets[(size_t)P];
+  shuffle_write_ns_ += tm.ns() - write_t0;
+  shuffle_data_size_ += (int64_t)row_bytes * n;
   lap("write files");
   DevTable none;
   return none;
@@ -2488,6 +2492,13 @@ std::string ExecutionContext::metrics_proto() {
     MetricNode n;
     n.metrics.emplace_back("output_rows", root ? output_rows_ : 0);
     n.metrics.emplace_back("elapsed_compute", root ? (int64_t)elapsed_compute_ns_ : 0);
+    if (op.kind == OpKind::ShuffleWriter) {   // ShufflePartitionerMetrics (native/shuffle/src/metrics.rs:24-71)
+      n.metrics.emplace_back("data_size", shuffle_data_size_);
+      n.metrics.emplace_back("repart_time", (int64_t)shuffle_repart_ns_);
+      n.metrics.emplace_back("write_time", (int64_t)shuffle_write_ns_);
+      n.metrics.emplace_back("spill_count", 0);
+      n.metrics.emplace_back("spilled_bytes", 0);
+    }
     if (op.kind == OpKind::NativeScan) {
       n.metrics.emplace_back("bytes_scanned", bytes_scanned_);
       n.metrics.emplace_back("row_groups_pruned_statistics", row_groups_pruned_);
