@@ -1351,7 +1351,7 @@ struct AggLowering {
       const std::string kk = std::to_string(nkw++);
       if (p == Prim::AMaxHi) {
         kops.push_back("G_UMAX64");
-        kfeed_code += "        if (" + c + ") { u64 t_ = comet::hi64((i128)comet::uabs128(" + x + ")) + 1ull; if (t_ > kacc[" + kk + "]) kacc[" + kk + "] = t_; }\n";
+        kfeed_code += "        if (" + c + ") { u64 t_ = comet::amax_enc(comet::uabs128(" + x + ")); if (t_ > kacc[" + kk + "]) kacc[" + kk + "] = t_; }\n";
       } else {
         kops.push_back("G_OR64");
         kfeed_code += "        if (" + c + ") kacc[" + kk + "] |= ((" + x + ") < 0) ? 2ull : (((" + x + ") > 0) ? 1ull : 0ull);\n";
@@ -1424,11 +1424,11 @@ struct AggLowering {
         else feed("comet::acc_feed_i192(acc + " + w + ", " + x + ");");
         break;
       case Prim::AMaxHi:
-        // hi64(|v|) + 1 (0 = no value yet): max|v| < word · 2^64
+        // amax_enc(|v|) (0 = no value yet): a monotone one-word upper bound of max|v|
         init_code += "    a[" + w + "] = 0;\n";
         combine_code += "    if (b[" + w + "] > a[" + w + "]) a[" + w + "] = b[" + w + "];\n";
         ops({"G_UMAX64"}, {"0ull"});
-        feed("{ u64 t_ = comet::hi64((i128)comet::uabs128(" + x + ")) + 1ull; if (t_ > acc[" + w + "]) acc[" + w + "] = t_; }");
+        feed("{ u64 t_ = comet::amax_enc(comet::uabs128(" + x + ")); if (t_ > acc[" + w + "]) acc[" + w + "] = t_; }");
         break;
       case Prim::SignFlags:
         init_code += "    a[" + w + "] = 0;\n";
@@ -1535,7 +1535,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   std::vector<ExprP> preds;
   const Operator* agg = nullptr;
   std::vector<ExprP> group_exprs;
-  struct AggIn { const AggExpr* a; std::vector<ExprP> children; ExprP filter; };
+  struct AggIn { const AggExpr* a; std::vector<ExprP> children; ExprP filter; AggMode mode = AggMode::Partial; };
   std::vector<AggIn> agg_ins;
   size_t final_state_pos = 0;
   for (int i = (int)chain.size() - 2; i >= 0; i--) {
@@ -1553,23 +1553,33 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     } else if (op.kind == OpKind::HashAgg) {
       agg = &op;
       for (auto& e : op.grouping_exprs) group_exprs.push_back(substitute(e, cols, memo));
-      for (auto& a : op.agg_exprs) {
+      // per-expression modes (HashAggregate.expr_modes, planner.rs:1274-1345): a Partial-mode operator may carry PartialMerge
+      // expressions — the count(DISTINCT) rewrite merges the other aggregates' states while it starts counting — whose state
+      // columns sit in the child's output from initial_input_buffer_offset on
+      if (!op.expr_modes.empty() && op.expr_modes.size() != op.agg_exprs.size())
+        throw CometError("HashAggregate: expr_modes has " + std::to_string(op.expr_modes.size()) + " entries for " + std::to_string(op.agg_exprs.size()) + " aggregates");
+      const size_t state_base = op.expr_modes.empty() ? op.grouping_exprs.size() : (size_t)std::max(0, op.initial_input_buffer_offset);
+      for (size_t ai = 0; ai < op.agg_exprs.size(); ai++) {
+        const AggExpr& a = op.agg_exprs[ai];
         AggIn in;
         in.a = &a;
-        if (op.agg_mode == AggMode::Partial) {
+        in.mode = op.expr_modes.empty() ? op.agg_mode : (AggMode)op.expr_modes[ai];
+        if (in.mode == AggMode::Partial) {
           for (auto& c : a.children) in.children.push_back(substitute(c, cols, memo));
           if (a.filter) in.filter = substitute(a.filter, cols, memo);
-        } else if (op.agg_mode == AggMode::Final || op.agg_mode == AggMode::PartialMerge) {
+        } else if (in.mode == AggMode::Final || in.mode == AggMode::PartialMerge) {
           // Final / PartialMerge: the aggregate's inputs are the Partial state columns that follow the group columns, in order
           // (AggregateExec Final mode; the serialized children are unbound, operators.scala:1786-1792)
           int arity = 1;
           if (a.kind == AggKind::Avg) arity = 2;
           if (a.kind == AggKind::Sum && a.dtype.id == TypeId::Decimal) arity = 2;
           for (int k = 0; k < arity; k++) {
-            size_t idx = op.grouping_exprs.size() + final_state_pos++;
+            size_t idx = state_base + final_state_pos++;
             if (idx >= cols.size()) throw CometError("Final aggregate: state column " + std::to_string(idx) + " is out of bound");
             in.children.push_back(cols[idx]);
           }
+        } else {
+          throw CometError("Unsupported aggregate mode: " + std::to_string((int)in.mode));
         }
         agg_ins.push_back(in);
       }
@@ -1682,8 +1692,6 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
 
   // ---------------- Aggregate sinks ----------------
   // Final and PartialMerge both MERGE Partial states (merge_batch); Final then evaluates, PartialMerge re-emits the state
-  const bool final_mode = agg->agg_mode == AggMode::Final || agg->agg_mode == AggMode::PartialMerge;
-  const bool emit_state = agg->agg_mode == AggMode::PartialMerge;
   const bool grouped = !group_exprs.empty();
   d.sink = grouped ? SinkKind::AggGrouped : SinkKind::AggNoGroup;
   AggLowering al(g, grouped);
@@ -1767,6 +1775,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       guard = Gen::and_ok(f.ok, f.v);
     }
     auto guarded = [&](const std::string& ok) { return Gen::and_ok(guard, ok); };
+    const bool final_mode = in.mode == AggMode::Final || in.mode == AggMode::PartialMerge;
+    const bool emit_state = in.mode == AggMode::PartialMerge;
     if (final_mode) {
       // ---- Final mode: merge Partial states (merge_batch + evaluate of each accumulator) ----
       auto okx = [](const Val& v) { return v.ok.empty() ? std::string("true") : v.ok; };

@@ -548,15 +548,40 @@ CDEV void acc_fmax64(u64* a, const u64* b) {
 // sum leaves the precision it stays NULL).  A parallel reduction only sees totals, so decide exactness
 // from order-independent facts:
 //   1. cnt · max|v| ≤ bound            → no prefix can overflow, the total is the answer
-//      (max|v| is tracked coarsely as hi64(|v|)+1, one word, so the grouped path can use atomicMax)
+//      (max|v| is tracked as one monotone word, amax_enc, so that it reduces with an unsigned max)
 //   2. all values share one sign       → prefixes are monotone, overflow ⇔ |total| > bound (192-bit total)
 //   3. otherwise                       → cannot be decided without the row order: flag err bit 4
-CDEV void sum_overflow_decide(const u64* sum192, u64 amax_hi_plus1, u64 signflags, u64 cnt, u128 bound, bool& ovf,
+// max|v| travels as ONE monotone word so that it can be reduced with an unsigned max: bit length in the top byte, the leading 56
+// bits below it, rounded UP — amax_dec(amax_enc(a)) ≥ a with a relative slack < 2^-55 (0 = no value yet).
+CDEV u64 amax_enc(u128 a) {
+  if (a == 0) a = 1;
+  const u64 hi = (u64)(a >> 64), lo = (u64)a;
+  int L = hi ? 128 - __builtin_clzll(hi) : 64 - __builtin_clzll(lo);
+  u64 mant;
+  if (L <= 56) {
+    mant = lo << (56 - L);
+  } else {
+    const int sh = L - 56;
+    mant = (u64)(a >> sh);
+    if ((a & ((((u128)1) << sh) - 1)) != 0) mant += 1;
+    if (mant >> 56) { mant >>= 1; L += 1; }
+  }
+  return ((u64)L << 56) | mant;
+}
+CDEV u128 amax_dec(u64 e) {
+  const int L = (int)(e >> 56);
+  const u64 mant = e & ((1ull << 56) - 1);
+  if (L <= 56) return (u128)(mant >> (56 - L));
+  if (L > 128) return ~(u128)0;
+  return (u128)mant << (L - 56);
+}
+
+CDEV void sum_overflow_decide(const u64* sum192, u64 amax_word, u64 signflags, u64 cnt, u128 bound, bool& ovf,
                               unsigned int* err) {
   ovf = false;
-  if (cnt == 0 || amax_hi_plus1 == 0) return;
-  // case 1: max|v| < amax_hi_plus1·2^64, so cnt·max|v| < cnt·amax_hi_plus1·2^64 ≤ bound
-  if ((u128)amax_hi_plus1 * (u128)cnt <= (bound >> 64)) return;
+  if (cnt == 0 || amax_word == 0) return;
+  // case 1: cnt · max|v| ≤ bound — no prefix of any order can leave the precision
+  if (amax_dec(amax_word) <= bound / (u128)cnt) return;
   // |total| from the three limbs
   bool neg = (sum192[2] >> 63) != 0;
   u64 l0 = sum192[0], l1 = sum192[1], l2 = sum192[2];

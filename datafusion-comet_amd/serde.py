@@ -345,6 +345,8 @@ class Operator:
     predicate: Optional[Expr] = None
     aggs: List[AggExpr] = field(default_factory=list)
     mode: int = PARTIAL
+    expr_modes: List[int] = field(default_factory=list)      # hash_agg: per-aggregate modes (HashAggregate.expr_modes = 6)
+    initial_input_buffer_offset: int = 0                     # hash_agg: first state column of the PartialMerge aggregates (= 7)
     plan_id: int = 0
     raw_tag: int = 0                            # 'raw': arbitrary op_struct tag with empty body (negative tests)
     left_keys: List[Expr] = field(default_factory=list)       # hash_join
@@ -411,6 +413,9 @@ class Operator:
             body += b"".join(_f_msg(2, a.encode()) for a in self.aggs)
             if self.mode:
                 body += _f_varint(5, self.mode)
+            body += b"".join(_f_varint(6, m) for m in self.expr_modes)
+            if self.initial_input_buffer_offset:
+                body += _f_varint(7, self.initial_input_buffer_offset)
         elif self.kind == "sort":
             # Sort{sort_orders=1 (Expr{sort_order=19 SortOrder{child=1,direction=2,null_ordering=3}}), fetch=3, skip=4} (operator.proto:641-645)
             body = b""
@@ -496,8 +501,12 @@ def project(child: Operator, exprs: Sequence[Expr]) -> Operator:
     return Operator("projection", [child], exprs=list(exprs))
 
 
-def hash_agg(child: Operator, grouping: Sequence[Expr], aggs: Sequence[AggExpr], mode: int = PARTIAL) -> Operator:
-    return Operator("hash_agg", [child], exprs=list(grouping), aggs=list(aggs), mode=mode)
+def hash_agg(child: Operator, grouping: Sequence[Expr], aggs: Sequence[AggExpr], mode: int = PARTIAL, expr_modes: Sequence[int] = (),
+             initial_input_buffer_offset: int = 0) -> Operator:
+    """expr_modes: per-aggregate PARTIAL / PARTIAL_MERGE for Spark's mixed-mode aggregate of the count(DISTINCT) rewrite; the
+    PARTIAL_MERGE aggregates read their state columns from the child starting at initial_input_buffer_offset."""
+    return Operator("hash_agg", [child], exprs=list(grouping), aggs=list(aggs), mode=mode, expr_modes=list(expr_modes),
+                    initial_input_buffer_offset=initial_input_buffer_offset)
 
 
 def sort(child: Operator, orders: Sequence, fetch: Optional[int] = None, skip: int = 0) -> Operator:

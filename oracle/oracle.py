@@ -809,12 +809,16 @@ def _hash_agg(S, ev: Evaluator, op, child: List[Col], n: int) -> List[Col]:
         first = np.full(ng, n, np.int64)
         np.minimum.at(first, gid, np.arange(n, dtype=np.int64))
         out.append(_take(src, first))
-    state_col = len(op.exprs)
-    for a in op.aggs:
-        if op.mode == S.PARTIAL:
+    # per-expression modes (planner.rs:1274-1345): PartialMerge aggregates of a Partial operator merge the state columns that
+    # start at initial_input_buffer_offset (MergeAsPartial, execution/merge_as_partial.rs)
+    modes = list(getattr(op, "expr_modes", None) or [])
+    state_col = op.initial_input_buffer_offset if modes else len(op.exprs)
+    for i, a in enumerate(op.aggs):
+        m = modes[i] if modes else op.mode
+        if m == S.PARTIAL:
             out += _agg_partial(S, ev, a, child, n, gid, ng, grouped)
         else:
-            cols, used = _agg_final(S, a, child, state_col, n, gid, ng, grouped, emit_state=op.mode == S.PARTIAL_MERGE)
+            cols, used = _agg_final(S, a, child, state_col, n, gid, ng, grouped, emit_state=m == S.PARTIAL_MERGE)
             state_col += used
             out += cols
     return out

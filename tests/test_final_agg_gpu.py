@@ -139,3 +139,77 @@ def test_partial_merge_then_final(built, grouped):
     for a, b in zip(rows(via_merge), rows(one)):
         assert a[:fa] == b[:fa] and a[fa + 1:-1] == b[fa + 1:-1]
         assert a[fa] == pytest.approx(b[fa], rel=1e-9) and a[-1] == pytest.approx(b[-1])
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_count_distinct_rewrite_with_mixed_mode_aggregate(built, grouped):
+    """Spark plans `count(DISTINCT a), sum(b), avg(f)` as four aggregates (TPC-DS Q95's tail): Partial by (g, a) → PartialMerge by (g, a) →
+    a Partial-mode aggregate by g whose sum/avg are PartialMerge (states read from initial_input_buffer_offset) while count(a) starts
+    counting (HashAggregate.expr_modes, planner.rs:1274-1345, merge_as_partial.rs) → Final.  Every stage on the GPU against the oracle, and
+    the end result against a direct computation."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    n = 120_000
+    g = rng.integers(0, 9, n)
+    a = rng.integers(0, 3000, n)
+    b = rng.integers(-10**9, 10**9, n)
+    f = rng.standard_normal(n)
+    am = rng.random(n) < 0.03
+    t = pa.table({"g": pa.array(g, pa.int32()), "a": pa.array(a, pa.int64(), mask=am), "b": tpch._dec128_array(b, 12, 2),
+                  "f": pa.array(f, mask=rng.random(n) < 0.1)})
+    D, SD = S.decimal(12, 2), S.decimal(22, 2)
+    fields = [S.T_INT32, S.T_INT64, D, S.T_DOUBLE]
+    keys1 = ([S.col(0, S.T_INT32)] if grouped else []) + [S.col(1, S.T_INT64)]
+    aggs = [S.sum_(S.col(2, D), SD), S.avg(S.col(3, S.T_DOUBLE), S.T_DOUBLE, S.T_DOUBLE)]
+    s1 = S.hash_agg(S.scan(fields), keys1, aggs, S.PARTIAL)
+    nk = len(keys1)
+
+    def stage(plan, tables, ncols):
+        return pa.concat_tables([_run(plan, tb, ncols) for tb in tables])
+
+    def canon(tb, nkeys):
+        rows = list(zip(*[tb.column(i).to_pylist() for i in range(tb.num_columns)]))
+        return sorted(rows, key=lambda r: tuple((x is None, x if x is not None else 0) for x in r[:nkeys]) if nkeys else 0)
+
+    # stage 1 on three shards (as three map tasks), stage 2 merges them per (g, a)
+    st1 = stage(s1, _shards(t, 3), nk + 4)
+    want1 = pa.concat_tables([O.run_plan_to_arrow(S, s1, sh) for sh in _shards(t, 3)])
+    close = lambda x, y: abs(x - y) <= 1e-9 * max(1.0, abs(y))       # float sums: summation order is unspecified
+    for r, w in zip(canon(st1, nk)[:500], canon(want1, nk)[:500]):
+        assert r[:nk + 2] == w[:nk + 2] and r[nk + 3] == w[nk + 3] and close(r[nk + 2], w[nk + 2])
+    f1 = [S.from_arrow_type(x.type) for x in st1.schema]
+    s2 = S.hash_agg(S.scan(f1), [S.col(i, f1[i]) for i in range(nk)], aggs, S.PARTIAL_MERGE)
+    st2 = _run(s2, st1, st1.num_columns)
+    want2 = O.run_plan_to_arrow(S, s2, st1)
+    c2, w2 = canon(st2, nk), canon(want2, nk)
+    assert len(c2) == len(w2)
+    for r, w in zip(c2, w2):
+        assert r[:nk + 2] == w[:nk + 2] and r[nk + 3] == w[nk + 3] and abs(r[nk + 2] - w[nk + 2]) <= 1e-9 * max(1.0, abs(w[nk + 2]))
+    # stage 3: mixed modes — sum / avg merge their states, count(a) is a fresh Partial count over the (now distinct) a values
+    f2 = [S.from_arrow_type(x.type) for x in st2.schema]
+    keys3 = [S.col(0, S.T_INT32)] if grouped else []
+    s3 = S.hash_agg(S.scan(f2), keys3, aggs + [S.count(S.col(nk - 1, S.T_INT64))], S.PARTIAL,
+                    expr_modes=[S.PARTIAL_MERGE, S.PARTIAL_MERGE, S.PARTIAL], initial_input_buffer_offset=nk)
+    want3 = O.run_plan_to_arrow(S, s3, st2)
+    st3 = _run(s3, st2, want3.num_columns)
+    nk3 = len(keys3)
+    c3, w3 = canon(st3, nk3), canon(want3, nk3)
+    assert len(c3) == len(w3)
+    for r, w in zip(c3, w3):
+        assert r[:nk3 + 2] == w[:nk3 + 2] and r[nk3 + 3:] == w[nk3 + 3:] and abs(r[nk3 + 2] - w[nk3 + 2]) <= 1e-9 * max(1.0, abs(w[nk3 + 2]))
+    # stage 4: Final
+    f3 = [S.from_arrow_type(x.type) for x in st3.schema]
+    s4 = S.hash_agg(S.scan(f3), [S.col(i, f3[i]) for i in range(nk3)], aggs + [S.count(S.col(0, S.T_INT64))], S.FINAL)
+    res = _run(s4, st3, nk3 + 3)
+    # direct computation
+    import decimal
+    groups = sorted(set(g.tolist())) if grouped else [None]
+    got_rows = {(r[0] if grouped else None): r[nk3:] for r in canon(res, nk3)}
+    for gv in groups:
+        sel = (g == gv) if grouped else np.ones(n, bool)
+        want_sum = decimal.Decimal(int(b[sel].sum())).scaleb(-2)
+        fv = np.asarray(t.column(3).is_valid()) & sel
+        want_avg = float(f[fv].sum() / fv.sum())
+        want_cnt = len(set(a[sel & ~am].tolist()))
+        s_, a_, c_ = got_rows[gv]
+        assert s_ == want_sum and c_ == want_cnt and abs(a_ - want_avg) <= 1e-9 * max(1.0, abs(want_avg)), (gv, s_, want_sum, c_, want_cnt)
