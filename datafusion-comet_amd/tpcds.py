@@ -1,0 +1,153 @@
+"""TPC-DS Q95 (BASELINE config 5) as the native plan Comet runs for it, on dsdgen-shaped synthetic tables.
+
+The plan follows the reference's approved plan (spark/src/test/resources/tpcds-plan-stability/approved-plans-v1_4/q95/extended.txt):
+five scans of web_sales, the `ws_wh` self-join with its `<>` residual, two LeftSemi sort-merge joins, three broadcast hash
+joins against filtered dimensions (Utf8 equality on ca_state / web_company_name), and the four-aggregate count(DISTINCT)
+rewrite whose third aggregate mixes PartialMerge and Partial expressions.  Exchanges are stage boundaries in Spark; within one
+partition the operators between them form the native plans built here (stage A: everything up to the mixed-mode aggregate,
+stage B: the Final aggregate).
+
+    with ws_wh as (select ws1.ws_order_number, ws1.ws_warehouse_sk wh1, ws2.ws_warehouse_sk wh2
+                   from web_sales ws1, web_sales ws2
+                   where ws1.ws_order_number = ws2.ws_order_number and ws1.ws_warehouse_sk <> ws2.ws_warehouse_sk)
+    select count(distinct ws_order_number), sum(ws_ext_ship_cost), sum(ws_net_profit)
+    from web_sales ws1, date_dim, customer_address, web_site
+    where d_date between '1999-02-01' and date '1999-02-01' + 60 days
+      and ws1.ws_ship_date_sk = d_date_sk and ws1.ws_ship_addr_sk = ca_address_sk and ca_state = 'IL'
+      and ws1.ws_web_site_sk = web_site_sk and web_company_name = 'pri'
+      and ws1.ws_order_number in (select ws_order_number from ws_wh)
+      and ws1.ws_order_number in (select wr_order_number from web_returns, ws_wh where wr_order_number = ws_wh.ws_order_number)
+"""
+import datetime
+import decimal
+from typing import Dict, List, Tuple
+
+import numpy as np
+import pyarrow as pa
+
+from . import serde as S
+from . import tpch
+
+D72 = S.decimal(7, 2)
+D172 = S.decimal(17, 2)
+DATE_SK0 = 2450815            # d_date_sk of 1998-01-01 in dsdgen's calendar
+DATE0 = datetime.date(1998, 1, 1)
+Q95_D0, Q95_D1 = datetime.date(1999, 2, 1), datetime.date(1999, 4, 2)
+STATES = ["IL", "TX", "CA", "NY", "GA", "OH", "VA", "KY", "MO", "IN", "NC", "KS", "MI", "TN", "IA"]
+COMPANIES = ["pri", "able", "ought", "ese", "anti", "cally"]
+
+WEB_SALES_FIELDS = [S.T_INT64, S.T_INT32, S.T_INT32, S.T_INT32, S.T_INT32, D72, D72]
+# ws_order_number, ws_warehouse_sk, ws_ship_date_sk, ws_ship_addr_sk, ws_web_site_sk, ws_ext_ship_cost, ws_net_profit
+
+
+def q95_tables(n_orders: int, seed: int = 95, null_frac: float = 0.02) -> Dict[str, pa.Table]:
+    rng = np.random.default_rng(seed)
+    items = rng.integers(1, 9, n_orders)                          # line items per order
+    order = np.repeat(np.arange(1, n_orders + 1, dtype=np.int64), items)
+    n = len(order)
+    # most orders ship from one warehouse; a third ship from several (those are the ws_wh orders)
+    base_wh = np.repeat(rng.integers(1, 6, n_orders), items)
+    multi = np.repeat(rng.random(n_orders) < 0.35, items)
+    wh = np.where(multi & (rng.random(n) < 0.5), rng.integers(1, 6, n), base_wh).astype(np.int32)
+    n_days, n_addr, n_site = 730, max(50, n_orders // 20), 30
+    ship_date = (DATE_SK0 + rng.integers(0, n_days, n)).astype(np.int32)
+    addr = rng.integers(1, n_addr + 1, n).astype(np.int32)
+    site = rng.integers(1, n_site + 1, n).astype(np.int32)
+    cost = rng.integers(0, 500_000, n)
+    profit = rng.integers(-500_000, 900_000, n)
+    m = lambda: rng.random(n) < null_frac
+    web_sales = pa.table({
+        "ws_order_number": pa.array(order),
+        "ws_warehouse_sk": pa.array(wh, mask=m()),
+        "ws_ship_date_sk": pa.array(ship_date, mask=m()),
+        "ws_ship_addr_sk": pa.array(addr, mask=m()),
+        "ws_web_site_sk": pa.array(site, mask=m()),
+        "ws_ext_ship_cost": tpch._dec128_array(cost, 7, 2),
+        "ws_net_profit": tpch._dec128_array(profit, 7, 2),
+    })
+    returned = rng.random(n) < 0.10
+    wr_orders = order[returned]
+    web_returns = pa.table({"wr_order_number": pa.array(wr_orders, mask=rng.random(len(wr_orders)) < null_frac)})
+    date_dim = pa.table({"d_date_sk": pa.array((DATE_SK0 + np.arange(n_days)).astype(np.int32)),
+                         "d_date": pa.array(np.arange(n_days, dtype=np.int32) + (DATE0 - datetime.date(1970, 1, 1)).days, pa.int32()).cast(pa.date32())})
+    customer_address = pa.table({"ca_address_sk": pa.array(np.arange(1, n_addr + 1, dtype=np.int32)),
+                                 "ca_state": pa.array([None if rng.random() < null_frac else STATES[int(i)] for i in rng.integers(0, len(STATES), n_addr)])})
+    web_site = pa.table({"web_site_sk": pa.array(np.arange(1, n_site + 1, dtype=np.int32)),
+                         "web_company_name": pa.array([COMPANIES[int(i)] for i in rng.integers(0, len(COMPANIES), n_site)])})
+    return dict(web_sales=web_sales, web_returns=web_returns, date_dim=date_dim, customer_address=customer_address, web_site=web_site)
+
+
+def _days(d: datetime.date) -> int:
+    return (d - datetime.date(1970, 1, 1)).days
+
+
+def q95_plans() -> Tuple[S.Operator, S.Operator, List[str]]:
+    """→ (stage A plan, stage B plan, names of the tables feeding stage A's scan leaves in depth-first order)."""
+    c = S.col
+    I64, I32 = S.T_INT64, S.T_INT32
+    leaves: List[str] = []
+
+    def scan(name, fields):
+        leaves.append(name)
+        return S.scan(fields)
+
+    def ws_order_wh():      # Project[order, warehouse](Filter(isnotnull(order) AND isnotnull(warehouse)))
+        f = S.filter_(scan("web_sales", WEB_SALES_FIELDS), S.and_(S.is_not_null(c(0, I64)), S.is_not_null(c(1, I32))))
+        return S.project(f, [c(0, I64), c(1, I32)])
+
+    def ws_wh():            # Project[ws_order_number](ws1 ⋈ ws2 on order number, wh1 <> wh2)
+        j = S.sort_merge_join(ws_order_wh(), ws_order_wh(), [c(0, I64)], [c(0, I64)], S.INNER, condition=S.not_(S.eq(c(1, I32), c(3, I32))))
+        return S.project(j, [c(0, I64)])
+
+    # the probe side: ws1 with the columns the query needs (leaf order: this scan comes first)
+    ws1 = S.project(S.filter_(scan("web_sales", WEB_SALES_FIELDS),
+                              S.and_(S.and_(S.is_not_null(c(2, I32)), S.is_not_null(c(3, I32))), S.is_not_null(c(4, I32)))),
+                    [c(0, I64), c(2, I32), c(3, I32), c(4, I32), c(5, D72), c(6, D72)])
+    semi1 = S.sort_merge_join(ws1, ws_wh(), [c(0, I64)], [c(0, I64)], S.LEFT_SEMI)
+    wr = S.project(S.filter_(scan("web_returns", [I64]), S.is_not_null(c(0, I64))), [c(0, I64)])
+    wr_wh = S.project(S.sort_merge_join(wr, ws_wh(), [c(0, I64)], [c(0, I64)], S.INNER), [c(0, I64)])
+    semi2 = S.sort_merge_join(semi1, wr_wh, [c(0, I64)], [c(0, I64)], S.LEFT_SEMI)
+    # broadcast joins against the filtered dimensions (build side = the dimension)
+    dd = S.project(S.filter_(scan("date_dim", [I32, S.T_DATE]),
+                             S.and_(S.and_(S.gt_eq(c(1, S.T_DATE), S.lit(_days(Q95_D0), S.T_DATE)), S.lt_eq(c(1, S.T_DATE), S.lit(_days(Q95_D1), S.T_DATE))),
+                                    S.is_not_null(c(0, I32)))), [c(0, I32)])
+    j1 = S.project(S.hash_join(semi2, dd, [c(1, I32)], [c(0, I32)], S.INNER, S.BUILD_RIGHT), [c(0, I64), c(2, I32), c(3, I32), c(4, D72), c(5, D72)])
+    ca = S.project(S.filter_(scan("customer_address", [I32, S.T_STRING]),
+                             S.and_(S.eq(c(1, S.T_STRING), S.lit("IL", S.T_STRING)), S.is_not_null(c(0, I32)))), [c(0, I32)])
+    j2 = S.project(S.hash_join(j1, ca, [c(1, I32)], [c(0, I32)], S.INNER, S.BUILD_RIGHT), [c(0, I64), c(2, I32), c(3, D72), c(4, D72)])
+    site = S.project(S.filter_(scan("web_site", [I32, S.T_STRING]),
+                               S.and_(S.eq(c(1, S.T_STRING), S.lit("pri", S.T_STRING)), S.is_not_null(c(0, I32)))), [c(0, I32)])
+    j3 = S.project(S.hash_join(j2, site, [c(1, I32)], [c(0, I32)], S.INNER, S.BUILD_RIGHT), [c(0, I64), c(2, D72), c(3, D72)])
+    # count(DISTINCT ws_order_number), sum(cost), sum(profit): Partial by order → PartialMerge by order → mixed → Final
+    sums = [S.sum_(c(1, D72), D172), S.sum_(c(2, D72), D172)]
+    a1 = S.hash_agg(j3, [c(0, I64)], sums, S.PARTIAL)
+    a2 = S.hash_agg(a1, [c(0, I64)], sums, S.PARTIAL_MERGE)
+    a3 = S.hash_agg(a2, [], sums + [S.count(c(0, I64))], S.PARTIAL, expr_modes=[S.PARTIAL_MERGE, S.PARTIAL_MERGE, S.PARTIAL], initial_input_buffer_offset=1)
+    stage_b = S.hash_agg(S.scan([D172, S.T_BOOL, D172, S.T_BOOL, I64]), [], sums + [S.count(c(0, I64))], S.FINAL)
+    return a3, stage_b, leaves
+
+
+def q95_reference(t: Dict[str, pa.Table]):
+    """Direct evaluation with Python sets / numpy — independent of both the engine and the oracle."""
+    ws = t["web_sales"]
+    order = np.asarray(ws.column(0))
+    wh = ws.column(1).to_pylist()
+    by = {}
+    for o, w in zip(order.tolist(), wh):
+        if w is not None:
+            by.setdefault(o, set()).add(w)
+    ws_wh = {o for o, s in by.items() if len(s) > 1}
+    wr = {o for o in t["web_returns"].column(0).to_pylist() if o is not None and o in ws_wh}
+    dates = {sk for sk, d in zip(t["date_dim"].column(0).to_pylist(), t["date_dim"].column(1).to_pylist()) if Q95_D0 <= d <= Q95_D1}
+    addrs = {sk for sk, s in zip(t["customer_address"].column(0).to_pylist(), t["customer_address"].column(1).to_pylist()) if s == "IL"}
+    sites = {sk for sk, s in zip(t["web_site"].column(0).to_pylist(), t["web_site"].column(1).to_pylist()) if s == "pri"}
+    orders, cost, profit = set(), decimal.Decimal(0), decimal.Decimal(0)
+    rows = 0
+    for o, d, a, s, c_, p in zip(order.tolist(), ws.column(2).to_pylist(), ws.column(3).to_pylist(), ws.column(4).to_pylist(),
+                                 ws.column(5).to_pylist(), ws.column(6).to_pylist()):
+        if d in dates and a in addrs and s in sites and o in ws_wh and o in wr:
+            orders.add(o)
+            cost += c_
+            profit += p
+            rows += 1
+    return len(orders), (cost if rows else None), (profit if rows else None)
