@@ -374,6 +374,26 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     for (auto& c : op.children) walk(*c);
   };
   walk(*plan_);
+  // Which sort-merge joins must really deliver their output in key order?  Only those whose row order can reach something that
+  // looks at it: the plan's output, a Limit, a shuffle file.  Aggregates, sorts and every join here (sort-merge joins run as hash
+  // joins and do not need sorted inputs) forget the order of their inputs, so the sort below them would be wasted work
+  // (TPC-DS Q95: five sorts of up to 68 M rows).
+  std::function<void(const Operator&, bool)> mark = [&](const Operator& op, bool order_visible) {
+    if (op.kind == OpKind::HashJoin && op.smj && order_visible) smj_needs_sort_.insert(&op);
+    for (size_t i = 0; i < op.children.size(); i++) {
+      bool v = order_visible;
+      switch (op.kind) {
+        case OpKind::HashAgg: case OpKind::Sort: v = false; break;
+        case OpKind::HashJoin:
+          // a plain hash join streams its probe side: the probe order shows in the output; a sort-merge join re-sorts (or not)
+          v = !op.smj && order_visible && (op.build_side == BuildSide::Left ? i == 1 : i == 0);
+          break;
+        default: break;   // Projection / Filter / Limit / ShuffleWriter keep their input's order
+      }
+      mark(*op.children[i], v);
+    }
+  };
+  mark(*plan_, true);
   if (scan_input_.empty() && !has_join_) throw CometError("Plan has no Scan leaf: only Scan-rooted pipelines are supported by the MI355X native engine");
   if (inputs_.size() != scan_input_.size())
     throw CometError("Plan has " + std::to_string(scan_input_.size()) + " Scan leaves but " + std::to_string(inputs_.size()) + " input streams were given");
@@ -1801,7 +1821,7 @@ DevTable ExecutionContext::materialize(const Operator& op) {
     DevTable l = materialize(*op.children[0]);
     DevTable r = materialize(*op.children[1]);
     DevTable j = hash_join(op, l, r);
-    if (!op.smj) return j;
+    if (!op.smj || !smj_needs_sort_.count(&op)) return j;
     // SortMergeJoin: its output is ordered by the join keys (SortMergeJoinExec streams the sorted inputs, planner.rs:2126-2191)
     return sort_table(*smj_sorts_.at(&op), j);
   }

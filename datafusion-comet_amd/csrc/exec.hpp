@@ -6,6 +6,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <vector>
@@ -182,6 +183,7 @@ class ExecutionContext {
   std::map<const Operator*, OperatorP> shuffle_projs_;   // ShuffleWriter with computed hash expressions → synthetic Projection(child ++ hash exprs)
   int64_t shuffle_bytes_written_ = 0, shuffle_data_size_ = 0;
   double shuffle_repart_ns_ = 0, shuffle_write_ns_ = 0;
+  std::set<const Operator*> smj_needs_sort_;       // sort-merge joins whose output order is observable (others skip the sort)
   std::map<const Operator*, OperatorP> smj_sorts_;  // SortMergeJoin node → synthetic Sort over its output       // aggregates that are not the plan root (materialised by sub-contexts)
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from
   std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)

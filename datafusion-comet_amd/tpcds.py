@@ -24,6 +24,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 import pyarrow as pa
+import pyarrow.compute  # noqa: F401
 
 from . import serde as S
 from . import tpch
@@ -151,3 +152,35 @@ def q95_reference(t: Dict[str, pa.Table]):
             profit += p
             rows += 1
     return len(orders), (cost if rows else None), (profit if rows else None)
+
+
+def q95_reference_numpy(t: Dict[str, pa.Table]):
+    """Vectorised direct evaluation for bench-sized inputs (exact: int64 cents)."""
+    ws = t["web_sales"]
+    col = lambda i: ws.column(i).combine_chunks()
+    order = np.asarray(col(0))
+    wh_ok = np.asarray(col(1).is_valid())
+    wh = np.asarray(col(1).fill_null(0))
+    # orders with more than one distinct non-null warehouse
+    pairs = np.unique(np.stack([order[wh_ok], wh[wh_ok].astype(np.int64)], axis=1), axis=0)
+    uo, cnt = np.unique(pairs[:, 0], return_counts=True)
+    ws_wh = uo[cnt > 1]
+    wr = t["web_returns"].column(0).combine_chunks()
+    wr = np.asarray(wr.drop_null())
+    wr = np.intersect1d(wr, ws_wh)
+    dd = t["date_dim"]
+    dsk = np.asarray(dd.column(0))
+    dval = np.asarray(dd.column(1).cast(pa.int32()))
+    dates = dsk[(dval >= _days(Q95_D0)) & (dval <= _days(Q95_D1))]
+    ca = t["customer_address"]
+    addrs = np.asarray(ca.column(0))[np.asarray(pa.compute.equal(ca.column(1), "IL").fill_null(False))]
+    sites = np.asarray(t["web_site"].column(0))[np.asarray(pa.compute.equal(t["web_site"].column(1), "pri").fill_null(False))]
+    keep = (np.isin(np.asarray(col(2).fill_null(-1)), dates) & np.asarray(col(2).is_valid()) &
+            np.isin(np.asarray(col(3).fill_null(-1)), addrs) & np.asarray(col(3).is_valid()) &
+            np.isin(np.asarray(col(4).fill_null(-1)), sites) & np.asarray(col(4).is_valid()) &
+            np.isin(order, wr))
+    cents = lambda i: np.frombuffer(col(i).buffers()[1], dtype=np.int64)[::2][col(i).offset:col(i).offset + len(order)]
+    n = int(keep.sum())
+    cost = decimal.Decimal(int(cents(5)[keep].sum())).scaleb(-2) if n else None
+    profit = decimal.Decimal(int(cents(6)[keep].sum())).scaleb(-2) if n else None
+    return int(len(np.unique(order[keep]))), cost, profit
