@@ -884,6 +884,28 @@ struct Gen {
     const std::string& f = e.func;
     auto arg = [&](size_t i) { return named(gen(e.children.at(i))); };
     Val r;
+    if (f == "starts_with" || f == "ends_with" || f == "contains") {
+      // byte-wise (UTF8_BINARY) tests of a Utf8 column against a literal (strings.scala:343-360 → DataFusion starts_with / ends_with / contains)
+      if (e.children.size() != 2 || !is_str_col(e.children[0]) || !is_str_lit(e.children[1]))
+        throw CometError(f + " is supported for a Utf8 column and a literal");
+      return str_pred_lit("utf8_" + f + "_lit", e.children[0]->bound_index, e.children[1]->lit_bytes);
+    }
+    if (f == "length" || f == "char_length" || f == "character_length" || f == "octet_length" || f == "bit_length") {
+      if (e.children.size() != 1 || !is_str_col(e.children[0])) throw CometError(f + " is supported for a Utf8 column");
+      const int idx = e.children[0]->bound_index;
+      Val valid = str_col_validity(idx);
+      auto loc = locate(idx);
+      const bool chars = f != "octet_length" && f != "bit_length";
+      r.t = DType::of(TypeId::Int32);
+      r.rep = Rep::I32;
+      r.ok = valid.ok;
+      std::string v = newvar("i32");
+      stmt(v + " = " + (valid.ok.empty() ? "" : valid.ok + " ? ") + "comet::" + (chars ? "utf8_char_length" : "utf8_octet_length") + "(prm.in[" + std::to_string(loc.first) +
+           "], " + loc.second + ")" + (f == "bit_length" ? " * 8" : "") + (valid.ok.empty() ? "" : " : 0") + ";");
+      r.v = v;
+      r.maxabs = (u128)1 << 31;
+      return r;
+    }
     if (f == "ceil" || f == "floor") {
       // spark_ceil / spark_floor (math_funcs/ceil.rs:24-84): Float → Int64 (`as i64`), Int64 unchanged, Decimal(s > 0) → div_ceil by 10^s
       Val a = arg(0);
@@ -1037,6 +1059,41 @@ struct Gen {
     r.ok = valid.ok;
     return r;
   }
+  // boolean predicate `fn(column, literal bytes)` evaluated on the bytes in place; NULL for a NULL column value
+  Val str_pred_lit(const std::string& fn, int idx, const std::string& lit, bool negate = false) {
+    Val valid = str_col_validity(idx);
+    auto loc = locate(idx);
+    std::string b = newvar("bool");
+    stmt(b + " = " + (negate ? "!" : "") + "comet::" + fn + "(prm.in[" + std::to_string(loc.first) + "], " + loc.second + ", " + c_bytes(lit) + ", " +
+         std::to_string(lit.size()) + ");");
+    Val r;
+    r.t = DType::of(TypeId::Bool);
+    r.rep = Rep::B;
+    r.v = valid.ok.empty() ? b : "(" + valid.ok + " && " + b + ")";
+    r.ok = valid.ok;
+    return r;
+  }
+  // LIKE (expr.proto:56 → DataFusion LikeExpr): patterns without `_` / escapes of the shapes lit, lit%, %lit, %lit% become
+  // equality / prefix / suffix / substring tests (what arrow-string's like kernel does too); everything else runs the matcher
+  Val like(const Expr& e) {
+    if (e.children.size() != 2 || !is_str_col(e.children[0]) || !is_str_lit(e.children[1]))
+      throw CometError("LIKE is supported for a Utf8 column and a literal pattern");
+    const int idx = e.children[0]->bound_index;
+    const std::string& p = e.children[1]->lit_bytes;
+    const bool special = p.find('_') != std::string::npos || p.find('\\') != std::string::npos;
+    if (!special) {
+      if (p.find('%') == std::string::npos) return str_pred_lit("utf8_eq_lit", idx, p);
+      const bool lead = p.front() == '%', trail = p.size() > 1 && p.back() == '%';
+      const size_t b = lead ? 1 : 0, en = p.size() - (trail ? 1 : 0);
+      const std::string mid = p.substr(b, en - b);
+      if (mid.find('%') == std::string::npos) {
+        if (lead && trail) return str_pred_lit("utf8_contains_lit", idx, mid);
+        if (lead) return str_pred_lit("utf8_ends_with_lit", idx, mid);      // "%" alone: every non-NULL value ends with ""
+        if (trail) return str_pred_lit("utf8_starts_with_lit", idx, mid);
+      }
+    }
+    return str_pred_lit("utf8_like_lit", idx, p);
+  }
   Val str_compare_cols(ExprKind k, int ia, int ib) {
     Val va = str_col_validity(ia), vb = str_col_validity(ib);
     auto la = locate(ia), lb = locate(ib);
@@ -1170,6 +1227,7 @@ struct Gen {
         return r;
       }
       case ExprKind::ScalarFunc: return scalar_func(e);
+      case ExprKind::Like: return like(e);
       case ExprKind::If: {
         if (e.children.size() != 3) throw CometError("If needs three children");
         return select(named(gen(e.children[0])), named(gen(e.children[1])), named(gen(e.children[2])));

@@ -158,6 +158,89 @@ CDEV bool utf8_eq_lit(const CometCol& c, i64 i, const char* lit, i32 n) {
     if (p[k] != (u8)lit[k]) return false;
   return true;
 }
+// ---- byte-wise string predicates against a literal (UTF8_BINARY collation: the reference compares raw bytes too,
+// spark/src/main/scala/org/apache/comet/serde/strings.scala:343-360) ----
+CDEV bool utf8_starts_with_lit(const CometCol& c, i64 i, const char* lit, i32 n) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j];
+  if (off[j + 1] - lo < n) return false;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  for (i32 k = 0; k < n; k++)
+    if (p[k] != (u8)lit[k]) return false;
+  return true;
+}
+CDEV bool utf8_ends_with_lit(const CometCol& c, i64 i, const char* lit, i32 n) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 hi = off[j + 1];
+  if (hi - off[j] < n) return false;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + (hi - n);
+  for (i32 k = 0; k < n; k++)
+    if (p[k] != (u8)lit[k]) return false;
+  return true;
+}
+CDEV bool utf8_contains_lit(const CometCol& c, i64 i, const char* lit, i32 n) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], len = off[j + 1] - lo;
+  if (n == 0) return true;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  const u8 first = (u8)lit[0];
+  for (i32 s = 0; s + n <= len; s++) {
+    if (p[s] != first) continue;
+    i32 k = 1;
+    while (k < n && p[s + k] == (u8)lit[k]) k++;
+    if (k == n) return true;
+  }
+  return false;
+}
+// SQL LIKE with `%` (any run of characters), `_` (exactly one CHARACTER — a whole UTF-8 code point) and `\` escaping the next
+// pattern byte (Spark's default escape; strings.scala:314-341 rejects any other).  Iterative matcher that backtracks to the last `%`.
+CDEV i32 utf8_next_char(const COMET_GLOBAL u8* p, i32 at, i32 len) {
+  at++;
+  while (at < len && (p[at] & 0xC0) == 0x80) at++;
+  return at;
+}
+CDEV bool utf8_like_lit(const CometCol& c, i64 i, const char* pat, i32 m) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], len = off[j + 1] - lo;
+  const COMET_GLOBAL u8* s = (const COMET_GLOBAL u8*)c.aux + lo;
+  i32 si = 0, pi = 0, star_p = -1, star_s = 0;
+  while (si < len) {
+    if (pi < m) {
+      const u8 pc = (u8)pat[pi];
+      if (pc == '%') { star_p = ++pi; star_s = si; continue; }
+      if (pc == '_') { si = utf8_next_char(s, si, len); pi++; continue; }
+      const bool esc = pc == '\\' && pi + 1 < m;
+      const u8 want = esc ? (u8)pat[pi + 1] : pc;
+      if (s[si] == want) { si++; pi += esc ? 2 : 1; continue; }
+    }
+    if (star_p < 0) return false;
+    pi = star_p;
+    star_s = utf8_next_char(s, star_s, len);
+    si = star_s;
+  }
+  while (pi < m && pat[pi] == '%') pi++;
+  return pi == m;
+}
+// number of characters (code points): bytes that are not UTF-8 continuation bytes (DataFusion character_length → Int32)
+CDEV i32 utf8_char_length(const CometCol& c, i64 i) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], len = off[j + 1] - lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  i32 n = 0;
+  for (i32 k = 0; k < len; k++) n += (p[k] & 0xC0) != 0x80;
+  return n;
+}
+CDEV i32 utf8_octet_length(const CometCol& c, i64 i) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  return off[j + 1] - off[j];
+}
+
 CDEV int utf8_cmp(const CometCol& a, i64 i, const CometCol& b, i64 j) {
   const COMET_GLOBAL i32* oa = (const COMET_GLOBAL i32*)a.data;
   const COMET_GLOBAL i32* ob = (const COMET_GLOBAL i32*)b.data;

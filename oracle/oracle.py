@@ -214,6 +214,23 @@ class Evaluator:
             vals = np.where(sel, t.values, f.values) if t.dtype.type_id != S.DECIMAL else np.where(sel, t.values, f.values)
             ok = np.where(sel, t.ok(), f.ok())
             return Col(t.dtype, vals, None if ok.all() else ok)
+        if k == "like":
+            # Expr.like → DataFusion LikeExpr → arrow-string `like` (SQL LIKE, escape `\`, `_` = one character, `%` = any run,
+            # newlines included); restated with Python's regex engine over code points — a different algorithm from the device matcher
+            import re
+            a, pat = self.eval(e.children[0], cols, n), e.children[1].value
+            rx, i = "", 0
+            while i < len(pat):
+                ch = pat[i]
+                if ch == "\\" and i + 1 < len(pat):
+                    rx += re.escape(pat[i + 1])
+                    i += 2
+                    continue
+                rx += ".*" if ch == "%" else "." if ch == "_" else re.escape(ch)
+                i += 1
+            cre = re.compile(rx, re.DOTALL)
+            vals = np.array([bool(cre.fullmatch(v)) if v is not None else False for v in a.values], dtype=bool)
+            return Col(S.T_BOOL, vals & a.ok(), a.valid)
         if k == "scalar_func":
             return self._scalar_func(e, cols, n)
         if k == "case_when":
@@ -259,6 +276,16 @@ class Evaluator:
                     out[i] = {"year": d.year, "month": d.month, "day": d.day, "quarter": (d.month - 1) // 3 + 1, "dow": (d.weekday() + 1) % 7,
                               "doy": d.timetuple().tm_yday}[part]
             return Col(S.T_INT32, out, a.valid)
+        if f in ("starts_with", "ends_with", "contains"):
+            # byte-wise on the UTF-8 encodings (UTF8_BINARY collation; strings.scala:343-360)
+            a, lit = self.eval(e.children[0], cols, n), e.children[1].value.encode()
+            fn = {"starts_with": bytes.startswith, "ends_with": bytes.endswith, "contains": lambda v, l: l in v}[f]
+            vals = np.array([fn(v.encode(), lit) if v is not None else False for v in a.values], dtype=bool)
+            return Col(S.T_BOOL, vals & a.ok(), a.valid)
+        if f in ("length", "char_length", "character_length", "octet_length", "bit_length"):
+            a = self.eval(e.children[0], cols, n)
+            g = (lambda v: len(v)) if f in ("length", "char_length", "character_length") else (lambda v: len(v.encode()) * (8 if f == "bit_length" else 1))
+            return Col(S.T_INT32, np.array([g(v) if v is not None else 0 for v in a.values], dtype=np.int32), a.valid)
         a = self.eval(e.children[0], cols, n)
         tid = a.dtype.type_id
         if f in ("ceil", "floor"):

@@ -107,3 +107,38 @@ def test_string_predicates_any_length(built):
         got, want = _run(plan, [t], 1), _oracle(plan, [t])
         assert (got.column(0).to_pylist() if got is not None else []) == want.column(0).to_pylist(), f"predicate {i}"
         assert want.num_rows > 0
+
+
+def test_like_and_string_predicates(built):
+    """LIKE (Expr.like = 26) with %, _ and \\-escapes over multi-byte UTF-8, the prefix / suffix / substring fast paths, starts_with /
+    ends_with / contains and the length functions — evaluated on the column bytes in place; oracle: Python's regex engine over code points."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(41)
+    words = ["PROMO BRUSHED COPPER", "STANDARD POLISHED BRASS", "special requests", "green almond", "forest green", "", "%", "a_b", "a%b", "50% off",
+             "über-größe", "日本語テキスト", "naïve café", "x", "xy", "line\nbreak", "special packages requests", "Customer Complaints", "ab", "abc", "a\\b"]
+    n = 40_000
+    vals = [None if rng.random() < 0.05 else words[int(i)] + ("" if rng.random() < 0.7 else str(int(rng.integers(0, 50)))) for i in rng.integers(0, len(words), n)]
+    t = pa.table({"s": pa.array(vals, pa.string()), "id": pa.array(np.arange(n), pa.int64())})
+    fields = [S.T_STRING, S.T_INT64]
+    s, i = S.col(0, S.T_STRING), S.col(1, S.T_INT64)
+    L = lambda p: S.lit(p, S.T_STRING)
+    patterns = ["%green%", "PROMO%", "%BRASS", "%special%requests%", "a_b", "a\\_b", "a\\%b", "%", "%%", "", "_", "__", "_%", "%_", "日本%", "%テ_スト", "über-gr__e",
+                "%é", "x%y", "%\n%", "50\\% off", "%off%", "abc", "ab_", "%a%b%c%", "a\\\\b", "_b%", "%b_"]
+    preds = [S.like(s, L(p)) for p in patterns]
+    preds += [S.scalar_func(f, [s, L(x)], S.T_BOOL) for f in ("starts_with", "ends_with", "contains") for x in ("", "a", "green", "é", "语")]
+    lens = [S.scalar_func(f, [s], S.T_INT32) for f in ("length", "octet_length", "bit_length")]
+    exprs = preds + lens
+    labels = patterns + ["fn"] * (len(exprs) - len(patterns))
+    for at in range(0, len(exprs), 10):        # a pipeline carries a bounded number of output columns
+        chunk = exprs[at:at + 10]
+        plan = S.project(S.scan(fields), chunk + [i])
+        got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], len(chunk) + 1, plan.encode(), batch_size=0))
+        want = O.run_plan_to_arrow(S, plan, [t])
+        for c in range(len(chunk) + 1):
+            assert got.column(c).combine_chunks().equals(want.column(c).combine_chunks()), (at + c, labels[at + c] if at + c < len(labels) else "id")
+    # as filters (Kleene: NULL rows drop), TPC-H style: p_type LIKE 'PROMO%', o_comment NOT LIKE '%special%requests%'
+    fplan = S.project(S.filter_(S.scan(fields), S.and_(S.not_(S.like(s, L("%special%requests%"))), S.or_(S.like(s, L("PROMO%")), S.like(s, L("%green%"))))), [i, s])
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 2, fplan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, fplan, [t])
+    assert got.column(0).to_pylist() == want.column(0).to_pylist() and got.column(1).to_pylist() == want.column(1).to_pylist()
+    assert 0 < got.num_rows < n
