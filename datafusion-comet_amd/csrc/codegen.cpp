@@ -1551,7 +1551,7 @@ std::string explain_expr(const ExprP& e) {
 // generate_pipeline
 // ---------------------------------------------------------------------------------------------
 PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity, const std::vector<DType>* source_types,
-                               const std::vector<int>* str_fixed_len) {
+                               const std::vector<int>* str_fixed_len, const std::vector<int>* dict_id_col) {
   // 1. walk root → leaf collecting the chain; the chain ends at a Scan or at a materialised source (a join's output)
   std::vector<const Operator*> chain;
   const Operator* cur = &root;
@@ -1761,6 +1761,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
 
   // ---- group keys → packed key words (word 0 = NULL bitmask of the keys)
   std::string key_code, key_emit;
+  std::vector<ExprP> synthetic_exprs;
   int nk = 0;
   if (grouped) {
     nk = 1;
@@ -1771,7 +1772,28 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       std::string ok_expr;
       const std::string vb = out_val(out_j), ob = out_ok(out_j);
       const std::string nullbit = std::to_string(1ull << kj) + "ull";
-      if (false) {
+      const bool direct_str = ge->kind == ExprKind::Bound && ge->bound_index >= 0 && (size_t)ge->bound_index < d.in_types.size() &&
+                              (d.in_types[(size_t)ge->bound_index].id == TypeId::String || d.in_types[(size_t)ge->bound_index].id == TypeId::Bytes);
+      if (direct_str) d.str_key_cols.push_back(ge->bound_index);
+      const int id_col = direct_str && dict_id_col && (size_t)ge->bound_index < dict_id_col->size() ? (*dict_id_col)[(size_t)ge->bound_index] : -1;
+      if (id_col >= 0) {
+        // Utf8 key of any length: group on the representative row index, emit it as the gather index of the source column
+        auto idx = std::make_shared<Expr>();
+        idx->kind = ExprKind::Bound;
+        idx->proto_tag = 3;
+        idx->bound_index = id_col;
+        idx->dtype = DType::of(TypeId::Int64);
+        idx->has_dtype = true;
+        synthetic_exprs.push_back(idx);   // Gen memoises by node address: the node must outlive the generation
+        Val v = g.named(g.gen(idx));
+        ok_expr = v.ok;
+        const std::string okc = ok_expr.empty() ? "true" : ok_expr;
+        const std::string k0 = std::to_string(nk);
+        key_code += "        key[" + k0 + "] = (" + okc + ") ? (u64)(i64)" + v.v + " : 0ull;\n";
+        key_emit += "    ((u32*)" + vb + ")[pos] = (u32)key[" + k0 + "];\n";
+        nk += 1;
+        oc.type = d.in_types[(size_t)ge->bound_index];
+        oc.gather_src = ge->bound_index;
       } else {
         Val v = g.named(g.gen(ge));
         ok_expr = v.ok;

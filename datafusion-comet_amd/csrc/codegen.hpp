@@ -44,12 +44,19 @@ struct PipelineDesc {
   bool join_outer_build = false;    // hash join that must also emit the build rows no probe row matched
   std::string explain;             // human-readable fused plan
   std::vector<std::string> op_names;  // operator names root→leaf (metrics tree / tracing label)
+  // grouped aggregates: source columns that serve DIRECTLY as Utf8 group keys (the executor measures their longest value: above 15
+  // bytes the key travels as a representative row index instead of packed bytes, see dict_id_col)
+  std::vector<int> str_key_cols;
 };
 
 // `in_has_validity[i]` tells whether input column i arrives with a validity bitmap in this batch
 // chunk; kernels are specialised on it.  Throws CometError for unsupported plans.
+// dict_id_col (optional, one entry per source column): index of an appended Int64 input column that holds, for every row, the index
+// of the representative row of that row's string (strdict_kernels.hip), or -1.  A Utf8 group key that is such a column is grouped
+// on the index and emitted as a gathered column (OutCol::gather_src) — strings of any length.
 PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in_has_validity,
-                               const std::vector<DType>* source_types = nullptr, const std::vector<int>* str_fixed_len = nullptr);
+                               const std::vector<DType>* source_types = nullptr, const std::vector<int>* str_fixed_len = nullptr,
+                               const std::vector<int>* dict_id_col = nullptr);
 
 // Hash join of two materialised tables (left/right = the join's children in plan order).
 // Sort: the kernel that writes every row's order-preserving key bytes (byte planes)

@@ -177,6 +177,11 @@ extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const 
                                                  int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
+extern "C" int comet_launch_str_max_len(const int32_t* offs, int64_t n, uint32_t* out_max, void* stream);
+extern "C" int comet_launch_str_dict_build(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t n, uint32_t* table, int64_t slots,
+                                           int64_t* rep, void* stream);
+extern "C" int comet_launch_str_dict_lookup(const int32_t* build_offs, const uint8_t* build_bytes, const uint32_t* table, int64_t slots, const int32_t* offs,
+                                            const uint8_t* bytes, const uint8_t* valid_bits, int64_t n, int64_t* rep, uint8_t* ok, void* stream);
 extern "C" int64_t comet_partition_tiles(int64_t n);
 extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
 extern "C" int comet_launch_murmur3(int type_id, int precision, const void* values, const uint8_t* validity, const void* aux, int64_t n, uint32_t* hashes, void* stream);
@@ -294,8 +299,13 @@ std::map<std::string, std::shared_ptr<PlannedVariant>> g_plan_cache;
 
 static std::shared_ptr<PlannedVariant> planned_variant(const Operator& plan, uint64_t plan_hash, const std::vector<bool>& has_valid,
                                                        bool compile, const std::vector<DType>* source_types = nullptr,
-                                                       const std::vector<int>* str_fixed_len = nullptr) {
+                                                       const std::vector<int>* str_fixed_len = nullptr,
+                                                       const std::vector<int>* dict_id_col = nullptr) {
   std::string key = std::to_string(plan_hash) + ":" + validity_key(has_valid);
+  if (dict_id_col) {
+    key += ":D";
+    for (int c : *dict_id_col) key += std::to_string(c) + ",";
+  }
   if (str_fixed_len) {
     key += ":L";
     for (int l : *str_fixed_len) key += std::to_string(l) + ",";
@@ -312,7 +322,7 @@ static std::shared_ptr<PlannedVariant> planned_variant(const Operator& plan, uin
   }
   if (!pv) {
     pv = std::make_shared<PlannedVariant>();
-    pv->desc = generate_pipeline(plan, has_valid, source_types, str_fixed_len);
+    pv->desc = generate_pipeline(plan, has_valid, source_types, str_fixed_len, dict_id_col);
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto res = g_plan_cache.emplace(key, pv);
     pv = res.first->second;
@@ -414,6 +424,9 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     sink_ = pv->desc.sink;
     if (sink_ == SinkKind::Output)
       for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0;   // Utf8 pass-through needs the gather step
+    // a grouped aggregate keyed by Utf8 columns sees its whole input at once (like a join input): only then can strings longer
+    // than the packed 15 bytes be swapped for representative row indices (prepare_dict_keys)
+    if (sink_ == SinkKind::AggGrouped && !pv->desc.str_key_cols.empty()) has_join_ = true;
   } else {
     in_types_ = infer_schema(*root_source_);
     if (plan_.get() != root_source_) {
@@ -596,7 +609,8 @@ Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid, const
   for (int l : str_fixed_len) { key += std::to_string(l) + ","; any_fixed |= l >= 0; }
   auto it = variants_.find(key);
   if (it != variants_.end()) return it->second;
-  auto pv = planned_variant(*plan_, plan_hash_, has_valid, true, has_join_ ? &in_types_ : nullptr, any_fixed ? &str_fixed_len : nullptr);
+  auto pv = planned_variant(*plan_, plan_hash_, has_valid, true, has_join_ ? &in_types_ : nullptr, any_fixed ? &str_fixed_len : nullptr,
+                            dict_id_col_.empty() ? nullptr : &dict_id_col_);
   Variant v;
   v.desc = pv->desc;
   v.mod = jit_load(pv->code);
@@ -608,6 +622,67 @@ void ExecutionContext::launch(Variant& v, const char* kernel, int grid, CometKPa
   hipFunction_t fn = v.mod->fn(kernel);
   void* args[] = {&prm};
   HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream_, args, nullptr));
+}
+
+// Utf8 group keys longer than the 15 bytes that fit the packed key words: replace them by representative row indices
+// (strdict_kernels.hip).  `src` is the aggregate's complete, resident input; an Int64 index column is appended per long key column
+// and the pipeline is generated with dict_id_col so that it groups on the index and emits it as the gather index of the string.
+void ExecutionContext::prepare_dict_keys(DevTable& src) {
+  if (src.rows == 0) return;
+  std::vector<bool> none(in_types_.size(), false);
+  auto pv = planned_variant(*plan_, plan_hash_, none, false, &in_types_);
+  std::vector<int> key_cols = pv->desc.str_key_cols;
+  std::sort(key_cols.begin(), key_cols.end());
+  key_cols.erase(std::unique(key_cols.begin(), key_cols.end()), key_cols.end());
+  if (key_cols.empty()) return;
+  const int64_t n = src.rows;
+  std::vector<int> id_col(src.cols.size(), -1);
+  bool any = false;
+  // Packed keys (≤ 15 bytes) are cheaper, but one long column — or a result that must stay on the device, where packed strings
+  // cannot be expanded by the host — switches every Utf8 key column of the aggregate to row indices.
+  bool need = device_result_;
+  for (int c : key_cols) {
+    const DeviceColumnView& sc = src.cols[(size_t)c];
+    if (sc.offset != 0) return;     // sliced producer arrays keep the packed path (and its 15-byte limit)
+    if (need) break;
+    uint32_t* mx = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 1);   // last word of the error/aux block: scratch
+    HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
+    if (comet_launch_str_max_len((const int32_t*)sc.data, n, mx, stream_) != 0) throw CometError("string keys: launch failed");
+    uint32_t longest = 0;
+    read_small(&longest, mx, 4);
+    HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
+    need = longest > 15;
+  }
+  if (!need || src.cols.size() + key_cols.size() > COMET_MAX_IN) return;
+  for (int c : key_cols) {
+    const DeviceColumnView& sc = src.cols[(size_t)c];
+    if (n >= ((int64_t)1 << 32) - 1) throw CometError("Utf8 group keys longer than 15 bytes over more than 2^32 rows are not supported");
+    int64_t slots = 1024;
+    while (slots < 2 * n) slots <<= 1;
+    DevBuf table;   // only needed while the indices are computed
+    table.ensure((size_t)slots * 4);
+    HIP_CHECK(hipMemsetAsync(table.p, 0, (size_t)slots * 4, stream_));
+    auto rep = std::make_shared<DevBuf>();
+    rep->ensure((size_t)n * 8 + 16);
+    if (comet_launch_str_dict_build((const int32_t*)sc.data, (const uint8_t*)sc.aux, src.has_valid[(size_t)c] ? sc.valid : nullptr, n, (uint32_t*)table.p, slots,
+                                    (int64_t*)rep->p, stream_) != 0)
+      throw CometError("string keys: launch failed");
+    HIP_CHECK(hipStreamSynchronize(stream_));   // `table` goes back to the pool here
+    DeviceColumnView idv;
+    idv.data = rep->p;
+    idv.valid = sc.valid;
+    id_col[(size_t)c] = (int)src.cols.size();
+    src.types.push_back(DType::of(TypeId::Int64));
+    src.cols.push_back(idv);
+    src.has_valid.push_back(src.has_valid[(size_t)c]);
+    src.owners.push_back(rep);
+    any = true;
+  }
+  if (!any) return;
+  id_col.resize(src.cols.size(), -1);
+  dict_id_col_ = id_col;
+  in_types_ = src.types;
+  dict_src_ = src;   // the emit step gathers the key strings from here
 }
 
 // one chunk of input rows resident in HBM → run the fused pipeline on it
@@ -966,7 +1041,9 @@ DevTable ExecutionContext::grouped_to_device() {
     prm.out[kOutFirstCol + 2 * j + 1] = vbytes[j]->p;
   }
   if (ngroups) launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
-  DevTable t = outputs_to_table(v, vals, vbytes, (int64_t)ngroups);
+  GatherSource gs = nullptr;
+  if (!dict_id_col_.empty()) gs = [this](int c) { return std::make_pair((const DevTable*)&dict_src_, c); };
+  DevTable t = outputs_to_table(v, vals, vbytes, (int64_t)ngroups, gs);
   t.owners.push_back(v.mod);
   HIP_CHECK(hipStreamSynchronize(stream_));
   check_device_errors();
@@ -981,6 +1058,12 @@ void ExecutionContext::finish_grouped() {
   read_small(&ngroups, (char*)err_flags_.p + 8, 8);
   check_device_errors();
   if (ngroups == 0) return;
+  if (!dict_id_col_.empty()) {
+    // keys that travelled as row indices: gather the strings on the device, then copy the finished table out
+    DevTable t = grouped_to_device();
+    table_to_host_batches(t);
+    return;
+  }
   const size_t ncol = d.out_cols.size();
   CometKParams prm;
   memset(&prm, 0, sizeof prm);
@@ -2287,6 +2370,7 @@ DevTable ExecutionContext::nested_aggregate(const Operator& agg) {
   OperatorP sub_plan(const_cast<Operator*>(&agg), [](Operator*) {});
   ExecutionContext sub(sub_plan, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&agg] + 1)), config_, sub_inputs, 0, device_id_);
   if (sub.sink_ != SinkKind::AggGrouped) throw CometError("an ungrouped aggregate below other operators in the same native plan is not supported yet");
+  sub.device_result_ = true;
   sub.start();
   sub.run_to_completion();
   DevTable t = sub.grouped_to_device();
@@ -2369,6 +2453,7 @@ void ExecutionContext::run_to_completion() {
   if (has_join_) {
     DevTable src = materialize(*root_source_);
     if (plan_.get() == root_source_) throw CometError("internal: bare join root");
+    if (sink_ == SinkKind::AggGrouped) prepare_dict_keys(src);
     process_chunk(src.cols, src.has_valid, src.rows);
     HIP_CHECK(hipStreamSynchronize(stream_));
     return;
@@ -2418,6 +2503,7 @@ int64_t ExecutionContext::execute_device(ArrowDeviceArray** out_arrays, ArrowSch
   if (finished_) return -1;
   DevTable tab;
   if (sink_ == SinkKind::AggGrouped) {
+    device_result_ = true;
     run_to_completion();
     tab = grouped_to_device();
   } else {

@@ -136,6 +136,7 @@ class ExecutionContext {
   DevTable take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner);
   DevTable nested_aggregate(const Operator& agg);
   DevTable write_shuffle(const Operator& sw);
+  void prepare_dict_keys(DevTable& src);
   static bool is_source(const Operator& op, const Operator* chain_top);
   typedef std::function<std::pair<const DevTable*, int>(int)> GatherSource;   // OutCol::gather_src → (table, column)
   DevTable outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals, const std::vector<std::shared_ptr<DevBuf>>& valid_bytes,
@@ -183,6 +184,9 @@ class ExecutionContext {
   std::map<const Operator*, OperatorP> shuffle_projs_;   // ShuffleWriter with computed hash expressions → synthetic Projection(child ++ hash exprs)
   int64_t shuffle_bytes_written_ = 0, shuffle_data_size_ = 0;
   double shuffle_repart_ns_ = 0, shuffle_write_ns_ = 0;
+  std::vector<int> dict_id_col_;                   // per source column: appended row-index column standing in for a long Utf8 group key
+  bool device_result_ = false;                     // the grouped result stays in HBM (nested aggregate / execute_device)
+  DevTable dict_src_;                              // the aggregate's input while such keys are in flight
   std::set<const Operator*> smj_needs_sort_;       // sort-merge joins whose output order is observable (others skip the sort)
   std::map<const Operator*, OperatorP> smj_sorts_;  // SortMergeJoin node → synthetic Sort over its output       // aggregates that are not the plan root (materialised by sub-contexts)
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from

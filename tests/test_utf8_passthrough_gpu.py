@@ -142,3 +142,48 @@ def test_like_and_string_predicates(built):
     want = O.run_plan_to_arrow(S, fplan, [t])
     assert got.column(0).to_pylist() == want.column(0).to_pylist() and got.column(1).to_pylist() == want.column(1).to_pylist()
     assert 0 < got.num_rows < n
+
+
+def _key_rows(tb, nkeys):
+    rows = list(zip(*[tb.column(i).to_pylist() for i in range(tb.num_columns)]))
+    return sorted(rows, key=lambda r: tuple((x is None, x if x is not None else "") if isinstance(x, (str, type(None))) else (False, x) for x in r[:nkeys]))
+
+
+@pytest.mark.parametrize("mode", ["partial", "final", "below_sort"])
+def test_group_by_strings_of_any_length(built, mode):
+    """Utf8 group keys longer than the 15 bytes that fit the packed key words (TPC-H Q10: c_name, c_address, c_comment; TPC-DS item ids):
+    the keys travel as representative row indices (strdict_kernels.hip) and come back as gathered strings."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    n = 60_000
+    names = ["Customer#%09d" % i for i in range(400)]                                  # 18 bytes
+    addrs = ["".join(chr(97 + (i * 7 + j) % 26) for j in range(5 + i % 36)) + " Straße %d" % i for i in range(300)]   # 15..50 bytes, multi-byte
+    ni, ai = rng.integers(0, len(names), n), rng.integers(0, len(addrs), n)
+    t = pa.table({
+        "name": pa.array([None if rng.random() < 0.03 else names[int(i)] for i in ni], pa.string()),
+        "addr": pa.array([None if rng.random() < 0.03 else addrs[int(i)] for i in ai], pa.string()),
+        "flag": pa.array([["A", "N", "R"][int(i) % 3] for i in ni], pa.string()),
+        "v": tpch._dec128_array(rng.integers(-10**8, 10**8, n), 12, 2),
+    })
+    D, SD = S.decimal(12, 2), S.decimal(22, 2)
+    fields = [S.T_STRING, S.T_STRING, S.T_STRING, D]
+    keys = [S.col(0, S.T_STRING), S.col(2, S.T_STRING), S.col(1, S.T_STRING)]
+    aggs = [S.sum_(S.col(3, D), SD), S.count(S.col(3, D))]
+    partial = S.hash_agg(S.scan(fields), keys, aggs, S.PARTIAL)
+    run = lambda plan, tb, nc: pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(tb)], nc, plan.encode(), batch_size=0))
+    if mode == "partial":
+        got, want = run(partial, t, 6), O.run_plan_to_arrow(S, partial, [t])
+        assert _key_rows(got, 3) == _key_rows(want, 3)
+        return
+    if mode == "final":
+        states = pa.concat_tables([run(partial, t.slice(0, n // 2), 6), run(partial, t.slice(n // 2), 6)])
+        final = S.final_of(partial, states.schema)
+        got, want = run(final, states, 5), O.run_plan_to_arrow(S, final, [states])
+        assert _key_rows(got, 3) == _key_rows(want, 3)
+        one = O.run_plan_to_arrow(S, S.final_of(partial, states.schema), [O.run_plan_to_arrow(S, partial, [t])])
+        assert _key_rows(got, 3) == _key_rows(one, 3)
+        return
+    # an aggregate below a Sort (nested context, device-resident result): ORDER BY sum DESC LIMIT 25 (sums are distinct here)
+    plan = S.sort(partial, [(S.col(3, SD), True)], fetch=25)
+    got, want = run(plan, t, 6), O.run_plan_to_arrow(S, plan, [t])
+    assert got.to_pylist() == want.to_pylist()
