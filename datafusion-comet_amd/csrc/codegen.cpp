@@ -235,6 +235,7 @@ struct Gen {
     return x;
   }
 
+  std::vector<ExprP> keymemo_alive;
   std::string key_of(const ExprP& e) {
     auto it = keymemo.find(e.get());
     if (it != keymemo.end()) return it->second;
@@ -254,6 +255,7 @@ struct Gen {
     for (auto& c : e->children) k << key_of(c) << ";";
     k << ")";
     keymemo[e.get()] = k.str();
+    keymemo_alive.push_back(e);   // the memo is keyed by node address: keep every memoised node alive so that no address is reused
     return k.str();
   }
 

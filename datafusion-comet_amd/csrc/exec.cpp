@@ -1740,10 +1740,112 @@ DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTab
   return out;
 }
 
+// Join keys that are Utf8 columns with values longer than the 15 bytes of a packed key: an exact string dictionary is built over the
+// right column (strdict_kernels.hip), the left column is looked up in it, and the join runs on the two Int64 row-index columns
+// instead (a left string without a partner gets a NULL index: NULL keys never match, outer joins still emit the row).  The index
+// columns are appended to the inputs and dropped from the result.
 DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const DevTable& R) {
+  auto is_str = [](const DType& t) { return t.id == TypeId::String || t.id == TypeId::Bytes; };
+  std::vector<size_t> sk;
+  for (size_t k = 0; k < j.left_keys.size() && k < j.right_keys.size(); k++) {
+    const ExprP &a = j.left_keys[k], &b = j.right_keys[k];
+    if (a->kind == ExprKind::Bound && b->kind == ExprKind::Bound && a->bound_index >= 0 && b->bound_index >= 0 && (size_t)a->bound_index < L.types.size() &&
+        (size_t)b->bound_index < R.types.size() && is_str(L.types[(size_t)a->bound_index]) && is_str(R.types[(size_t)b->bound_index]) &&
+        L.cols[(size_t)a->bound_index].offset == 0 && R.cols[(size_t)b->bound_index].offset == 0)
+      sk.push_back(k);
+  }
+  if (sk.empty() || L.rows == 0 || R.rows == 0 || L.cols.size() + R.cols.size() + 2 * sk.size() > COMET_MAX_IN) return hash_join_impl(j, j, L, R, "");
+  auto longest = [&](const DevTable& t, int c) {
+    uint32_t* mx = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 1);
+    HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
+    if (comet_launch_str_max_len((const int32_t*)t.cols[(size_t)c].data, t.rows, mx, stream_) != 0) throw CometError("string keys: launch failed");
+    uint32_t v = 0;
+    read_small(&v, mx, 4);
+    HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
+    return v;
+  };
+  bool need = false;
+  for (size_t k : sk) need = need || longest(L, j.left_keys[k]->bound_index) > 15 || longest(R, j.right_keys[k]->bound_index) > 15;
+  if (!need) return hash_join_impl(j, j, L, R, "");
+  if (R.rows >= ((int64_t)1 << 32) - 1) throw CometError("Utf8 join keys longer than 15 bytes over more than 2^32 rows are not supported");
+  DevTable l2 = L, r2 = R;
+  Operator jj = j;
+  auto bound = [](int idx) {
+    auto e = std::make_shared<Expr>();
+    e->kind = ExprKind::Bound;
+    e->proto_tag = 3;
+    e->bound_index = idx;
+    e->dtype = DType::of(TypeId::Int64);
+    e->has_dtype = true;
+    return e;
+  };
+  for (size_t k : sk) {
+    const int lc = j.left_keys[k]->bound_index, rc = j.right_keys[k]->bound_index;
+    const DeviceColumnView &lv = L.cols[(size_t)lc], &rv = R.cols[(size_t)rc];
+    int64_t slots = 1024;
+    while (slots < 2 * R.rows) slots <<= 1;
+    DevBuf table;
+    table.ensure((size_t)slots * 4);
+    HIP_CHECK(hipMemsetAsync(table.p, 0, (size_t)slots * 4, stream_));
+    auto rrep = std::make_shared<DevBuf>(), lrep = std::make_shared<DevBuf>(), lbits = std::make_shared<DevBuf>();
+    DevBuf lok;
+    rrep->ensure((size_t)R.rows * 8 + 16);
+    lrep->ensure((size_t)L.rows * 8 + 16);
+    lok.ensure((size_t)L.rows + 16);
+    lbits->ensure((size_t)((L.rows + 7) / 8) + 16);
+    if (comet_launch_str_dict_build((const int32_t*)rv.data, (const uint8_t*)rv.aux, R.has_valid[(size_t)rc] ? rv.valid : nullptr, R.rows, (uint32_t*)table.p, slots,
+                                    (int64_t*)rrep->p, stream_) != 0 ||
+        comet_launch_str_dict_lookup((const int32_t*)rv.data, (const uint8_t*)rv.aux, (const uint32_t*)table.p, slots, (const int32_t*)lv.data, (const uint8_t*)lv.aux,
+                                     L.has_valid[(size_t)lc] ? lv.valid : nullptr, L.rows, (int64_t*)lrep->p, (uint8_t*)lok.p, stream_) != 0)
+      throw CometError("string keys: launch failed");
+    pq_launch_pack((const uint8_t*)lok.p, (uint8_t*)lbits->p, L.rows, stream_);
+    HIP_CHECK(hipStreamSynchronize(stream_));   // `table` and `lok` go back to the pool
+    DeviceColumnView rid, lid;
+    rid.data = rrep->p;
+    rid.valid = rv.valid;
+    lid.data = lrep->p;
+    lid.valid = (const uint8_t*)lbits->p;
+    jj.right_keys[k] = bound((int)r2.cols.size());
+    jj.left_keys[k] = bound((int)l2.cols.size());
+    r2.types.push_back(DType::of(TypeId::Int64));
+    r2.cols.push_back(rid);
+    r2.has_valid.push_back(R.has_valid[(size_t)rc]);
+    r2.owners.push_back(rrep);
+    l2.types.push_back(DType::of(TypeId::Int64));
+    l2.cols.push_back(lid);
+    l2.has_valid.push_back(true);
+    l2.owners.push_back(lrep);
+    l2.owners.push_back(lbits);
+  }
+  const size_t nl = L.cols.size(), nr = R.cols.size(), extra = sk.size();
+  if (jj.join_condition) {
+    // the residual condition addresses left ++ right: the right columns moved up by the index columns appended to the left
+    std::function<ExprP(const ExprP&)> shift = [&](const ExprP& e) -> ExprP {
+      auto c = std::make_shared<Expr>(*e);
+      if (e->kind == ExprKind::Bound && (size_t)e->bound_index >= nl) c->bound_index = e->bound_index + (int)extra;
+      for (auto& ch : c->children) ch = shift(ch);
+      return c;
+    };
+    jj.join_condition = shift(j.join_condition);
+  }
+  DevTable out = hash_join_impl(j, jj, l2, r2, ":SD");
+  // drop the index columns: the result is left' ++ right' (semi / anti joins: left' only)
+  auto drop = [&](size_t first, size_t count) {
+    if (first + count > out.cols.size()) return;
+    out.types.erase(out.types.begin() + (long)first, out.types.begin() + (long)(first + count));
+    out.cols.erase(out.cols.begin() + (long)first, out.cols.begin() + (long)(first + count));
+    out.has_valid.erase(out.has_valid.begin() + (long)first, out.has_valid.begin() + (long)(first + count));
+  };
+  if (out.cols.size() == nl + extra + nr + extra) drop(nl + extra + nr, extra);
+  else if (out.cols.size() != nl + extra) throw CometError("internal: unexpected join output width with string keys");
+  drop(nl, extra);
+  return out;
+}
+
+DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& j, const DevTable& L, const DevTable& R, const std::string& key_suffix) {
   // planned once per (join node, validity patterns)
-  std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&j] + 1))) + ":J:" + validity_key(L.has_valid) + "|" +
-                    validity_key(R.has_valid);
+  std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&node] + 1))) + ":J:" + validity_key(L.has_valid) + "|" +
+                    validity_key(R.has_valid) + key_suffix;
   std::shared_ptr<PlannedVariant> pv;
   {
     std::lock_guard<std::mutex> lk(g_plan_mu);

@@ -132,6 +132,7 @@ class ExecutionContext {
   DevTable scan_parquet(const Operator& native_scan);
   DevTable run_chain_to_device(const Operator& top, const DevTable& in);
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
+  DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix);
   DevTable sort_table(const Operator& s, const DevTable& in);
   DevTable take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner);
   DevTable nested_aggregate(const Operator& agg);

@@ -187,3 +187,24 @@ def test_group_by_strings_of_any_length(built, mode):
     plan = S.sort(partial, [(S.col(3, SD), True)], fetch=25)
     got, want = run(plan, t, 6), O.run_plan_to_arrow(S, plan, [t])
     assert got.to_pylist() == want.to_pylist()
+
+
+@pytest.mark.parametrize("jt,build", [(S.INNER, S.BUILD_RIGHT), (S.LEFT_OUTER, S.BUILD_RIGHT), (S.FULL_OUTER, S.BUILD_LEFT), (S.LEFT_SEMI, S.BUILD_RIGHT),
+                                      (S.LEFT_ANTI, S.BUILD_LEFT), (S.RIGHT_OUTER, S.BUILD_LEFT)])
+def test_join_on_strings_of_any_length(built, jt, build):
+    """Join keys that are Utf8 columns longer than 15 bytes (TPC-DS item ids, names): dictionary over the right column, lookup of the left,
+    join on row indices; with a second (integer) key and a residual condition that addresses columns of both sides."""
+    rng = np.random.default_rng(23)
+    nl, nr = 9000, 5000
+    ids = ["AAAAAAAA%08dXYZ-é" % i for i in range(1200)]          # 21 bytes, multi-byte tail
+    pick = lambda n, hi: [None if rng.random() < 0.04 else ids[int(i)] for i in rng.integers(0, hi, n)]
+    left = pa.table({"item": pa.array(pick(nl, 1000), pa.string()), "g": pa.array(rng.integers(0, 3, nl), pa.int32()), "q": pa.array(rng.integers(0, 100, nl), pa.int64())})
+    right = pa.table({"w": pa.array(rng.integers(0, 100, nr), pa.int64()), "g": pa.array(rng.integers(0, 3, nr), pa.int32()), "item": pa.array(pick(nr, 1200), pa.string())})
+    lf, rf = [S.T_STRING, S.T_INT32, S.T_INT64], [S.T_INT64, S.T_INT32, S.T_STRING]
+    cond = S.lt(S.col(2, S.T_INT64), S.col(3, S.T_INT64)) if jt in (S.INNER, S.LEFT_SEMI) else None        # left.q < right.w
+    plan = S.hash_join(S.scan(lf), S.scan(rf), [S.col(0, S.T_STRING), S.col(1, S.T_INT32)], [S.col(2, S.T_STRING), S.col(1, S.T_INT32)], jt, build, condition=cond)
+    ncols = 3 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 6
+    got, want = _run(plan, [left, right], ncols), _oracle(plan, [left, right])
+    assert got.num_rows == want.num_rows > 0
+    assert got.schema.types == want.schema.types
+    assert _rows(got) == _rows(want)
