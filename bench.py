@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--q3-orders", type=int, default=150_000_000,
                     help="extra leg: TPC-H Q3 (hash joins + RCCL exchange) over all ranks, total orders rows (SF100 = 150 M, strong scaling); 0 = skip")
     ap.add_argument("--q3-timeout", type=int, default=420)
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the 1-GPU extra legs: TPC-DS Q95 (4 M orders, verified) and the native shuffle write")
     ap.add_argument("--no-parquet-leg", action="store_true", help="skip the extra leg: SF10 Q6 straight from a zstd Parquet file (1 GPU only)")
     ap.add_argument("--q1-rows", type=int, default=600_037_902,
                     help="extra leg: TPC-H Q1 stage 1 on HBM-resident columns, lineitem rows per GPU (SF100 = 600,037,902); 0 = skip")
@@ -121,6 +122,12 @@ def main():
     if world == 1 and not args.no_parquet_leg:
         pq = run_child_leg([os.path.join(ROOT, "tools", "parquet_q6.py"), "--rows", str(args.rows), "--codec", "zstd", "--steps", "5"],
                            rank, local_rank, world, args.q3_timeout, port_offset=3017)
+    q95 = shuf = None
+    if world == 1 and not args.no_extra_legs:
+        # BASELINE config 5 (TPC-DS Q95, here at a quarter of SF100 so that its numpy verification stays short) and §8 f1 (native shuffle write)
+        q95 = run_child_leg([os.path.join(ROOT, "tools", "q95_bench.py"), "--orders", "4000000", "--reps", "2"], rank, local_rank, world, args.q3_timeout, port_offset=4017)
+        shuf = run_child_leg([os.path.join(ROOT, "tools", "shuffle_bench.py"), "--rows", "20000000", "--codec", "lz4", "--reps", "2"], rank, local_rank, world,
+                             args.q3_timeout, port_offset=5017)
     q1 = None
     if args.q1_rows > 0:
         q1 = run_child_leg([os.path.join(ROOT, "tools", "q1_sf100.py"), "--rows", str(args.q1_rows), "--steps", "5", "--seed", str(1 + rank)],
@@ -188,6 +195,10 @@ def main():
             line["q1_sf100_per_gpu"] = q1
         if pq is not None:
             line["q6_from_parquet"] = pq
+        if q95 is not None:
+            line["tpcds_q95"] = q95
+        if shuf is not None:
+            line["shuffle_write"] = shuf
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
