@@ -224,6 +224,25 @@ int grid_for(i64 n) {
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
 }
 
+__global__ __launch_bounds__(256) void range_pid_kernel(const u8* __restrict__ planes, i64 n, int W, const u8* __restrict__ bkeys, int B,
+                                                        i32* __restrict__ pids) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    int lo = 0, hi = B;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const u8* b = bkeys + (size_t)mid * (size_t)W;
+      int c = 0;   // compare(bound, row)
+      for (int p = 0; p < W; p++) {
+        const u8 x = b[p], y = planes[(size_t)p * (size_t)n + (size_t)i];
+        if (x != y) { c = x < y ? -1 : 1; break; }
+      }
+      if (c <= 0) lo = mid + 1;
+      else hi = mid;
+    }
+    pids[i] = lo;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -305,6 +324,13 @@ int comet_launch_sort_hist256(const uint8_t* plane, const uint32_t* cand, int64_
 int comet_launch_sort_select(const uint8_t* plane, const uint32_t* cand, int64_t m, int dstar, uint32_t* sure, uint32_t* next_cand, uint32_t* counters,
                              void* stream) {
   if (m > 0) hipLaunchKernelGGL(sort_select_kernel, grid_for(m), 256, 0, (hipStream_t)stream, plane, cand, (i64)m, dstar, sure, next_cand, counters);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// Range partitioning (multi_partition.rs:332-366): partition id = number of boundary rows ≤ the row under the sort order, i.e. an
+// upper-bound binary search over the boundaries' order-preserving key bytes.  planes: W byte planes of n rows (k_sortkey layout),
+// bkeys: B boundary keys of W bytes each, row-major, ascending.
+int comet_launch_range_partition_ids(const uint8_t* planes, int64_t n, int W, const uint8_t* bkeys, int B, int32_t* pids, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(range_pid_kernel, grid_for(n), 256, 0, (hipStream_t)stream, planes, (i64)n, W, bkeys, B, pids);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_sort_plane_varies(const uint8_t* planes, int64_t n, int W, uint32_t* flags, void* stream) {

@@ -196,6 +196,7 @@ extern "C" int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* b
 extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 extern "C" int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stream);
 extern "C" int comet_launch_sort_gather_digit(const uint8_t* plane, const uint32_t* perm, int64_t n, int32_t* digit, void* stream);
+extern "C" int comet_launch_range_partition_ids(const uint8_t* planes, int64_t n, int W, const uint8_t* bkeys, int B, int32_t* pids, void* stream);
 extern "C" int comet_launch_sort_plane_varies(const uint8_t* planes, int64_t n, int W, uint32_t* flags, void* stream);
 extern "C" int comet_launch_sort_hist256(const uint8_t* plane, const uint32_t* cand, int64_t m, uint64_t* hist, void* stream);
 extern "C" int comet_launch_sort_select(const uint8_t* plane, const uint32_t* cand, int64_t m, int dstar, uint32_t* sure, uint32_t* next_cand, uint32_t* counters,
@@ -355,6 +356,17 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
       if (&op != plan_.get()) throw CometError("ShuffleWriter must be the root of a native plan");
       bool computed = false;
       for (auto& e : op.shuffle_hash_exprs) computed |= e->kind != ExprKind::Bound;
+      for (auto& k : op.shuffle_sort_orders) computed |= k.child->kind != ExprKind::Bound;
+      if (op.shuffle_partitioning == Operator::Partitioning::Range) {
+        // range partitioning compares order-preserving key bytes: one synthetic Sort describes the rows' keys, one the boundaries'
+        for (int t = 0; t < 2; t++) {
+          auto so = std::make_shared<Operator>();
+          so->kind = OpKind::Sort;
+          so->proto_tag = 103;
+          (t == 0 ? range_sort_ : range_bsort_)[&op] = so;
+          node_id_[so.get()] = (int)node_id_.size();
+        }
+      }
       if (computed) {
         // hash expressions that are not plain column references: evaluated by a Projection(child columns ++ expressions) fused
         // over the child (its project_list is filled in when the child's schema is known)
@@ -472,8 +484,6 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     // ShuffleWriterExec (shuffle_writer.rs:60-110): consumes its child, writes the data + index files, yields no batches
     if (op.children.size() != 1) throw CometError("ShuffleWriter expects exactly one child");
     std::vector<DType> st = infer_schema(*op.children[0]);
-    if (op.shuffle_partitioning == Operator::Partitioning::Range)
-      throw CometError("ShuffleWriter: range partitioning is not supported by the MI355X native engine yet (hash, single and round-robin are)");
     if (op.shuffle_num_partitions < 1) throw CometError("ShuffleWriter: num_partitions must be positive");
     if (op.shuffle_num_partitions > 4096) throw CometError("ShuffleWriter: more than 4096 output partitions are not supported yet");
     if (op.shuffle_codec < 0 || op.shuffle_codec > 3) throw CometError("Unsupported shuffle compression codec: " + std::to_string(op.shuffle_codec));
@@ -498,7 +508,53 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       }
       for (auto& e : op.shuffle_hash_exprs)
         if (e->kind != ExprKind::Bound) pr.project_list.push_back(e);
-      infer_schema(pr);   // validates (and, under compile_only, compiles) the fused chain
+      for (auto& k : op.shuffle_sort_orders)
+        if (k.child->kind != ExprKind::Bound) pr.project_list.push_back(k.child);
+      st = infer_schema(pr);   // validates (and, under compile_only, compiles) the fused chain; st now includes the computed key columns
+    }
+    if (op.shuffle_partitioning == Operator::Partitioning::Range) {
+      // RangePartition (partitioning.proto:52-56; planner.rs:3298-3358): rows are compared with the boundary rows under sort_orders
+      if (op.shuffle_sort_orders.empty()) throw CometError("ShuffleWriter: range partitioning without sort orders");
+      for (auto& row : op.shuffle_bounds) {
+        if (row.size() != op.shuffle_sort_orders.size()) throw CometError("ShuffleWriter: a range boundary row has " + std::to_string(row.size()) + " values for " +
+                                                                           std::to_string(op.shuffle_sort_orders.size()) + " sort orders");
+        for (auto& e : row)
+          if (e->kind != ExprKind::Literal) throw CometError("ShuffleWriter: range boundaries must be literals");
+      }
+      if ((int)op.shuffle_bounds.size() + 1 > op.shuffle_num_partitions)
+        throw CometError("ShuffleWriter: " + std::to_string(op.shuffle_bounds.size()) + " range boundaries need more than " + std::to_string(op.shuffle_num_partitions) + " partitions");
+      Operator& so = *range_sort_.at(&op);
+      Operator& sb = *range_bsort_.at(&op);
+      so.sort_orders.clear();
+      sb.sort_orders.clear();
+      std::vector<DType> btypes;
+      size_t next = st.size();
+      for (auto& k : op.shuffle_sort_orders) next -= k.child->kind != ExprKind::Bound;
+      size_t computed_at = next;
+      for (size_t i = 0; i < op.shuffle_sort_orders.size(); i++) {
+        const Operator::SortKey& k = op.shuffle_sort_orders[i];
+        const int col = k.child->kind == ExprKind::Bound ? k.child->bound_index : (int)computed_at++;
+        if (col < 0 || (size_t)col >= st.size()) throw CometError("ShuffleWriter: range sort order references column " + std::to_string(col));
+        auto mk = [&](int idx, const DType& t) {
+          auto b = std::make_shared<Expr>();
+          b->kind = ExprKind::Bound;
+          b->proto_tag = 3;
+          b->bound_index = idx;
+          b->dtype = t;
+          b->has_dtype = true;
+          return b;
+        };
+        Operator::SortKey a = k, b = k;
+        a.child = mk(col, st[(size_t)col]);
+        b.child = mk((int)i, st[(size_t)col]);
+        so.sort_orders.push_back(a);
+        sb.sort_orders.push_back(b);
+        btypes.push_back(st[(size_t)col]);
+      }
+      std::vector<bool> none(st.size(), false), bnone(btypes.size(), true);
+      PipelineDesc d1 = generate_sort_keys(so, st, none), d2 = generate_sort_keys(sb, btypes, bnone);
+      if (d1.sort_key_bytes != d2.sort_key_bytes) throw CometError("internal: range boundary keys and row keys differ in width");
+      if (compile_in_infer_) { jit_compile(d1.source); jit_compile(d2.source); }
     }
     explain_ += "  shuffle writer: " + std::to_string(op.shuffle_num_partitions) + " partition(s), codec " + std::to_string(op.shuffle_codec) + "\n";
     return {};
@@ -2058,10 +2114,13 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
   const int P = sw.shuffle_partitioning == Operator::Partitioning::Single ? 1 : sw.shuffle_num_partitions;
   size_t n_payload = in.cols.size();
   std::vector<int> key_cols;
-  if (sw.shuffle_partitioning == Operator::Partitioning::Hash) {
-    size_t appended = 0;
+  {
+    size_t appended = 0;   // computed key expressions sit behind the payload columns (the synthetic projection of the constructor)
     for (auto& e : sw.shuffle_hash_exprs) appended += e->kind != ExprKind::Bound;
+    for (auto& k : sw.shuffle_sort_orders) appended += k.child->kind != ExprKind::Bound;
     n_payload -= appended;
+  }
+  if (sw.shuffle_partitioning == Operator::Partitioning::Hash) {
     size_t next = n_payload;
     for (auto& e : sw.shuffle_hash_exprs) key_cols.push_back(e->kind == ExprKind::Bound ? e->bound_index : (int)next++);
   } else if (sw.shuffle_partitioning == Operator::Partitioning::RoundRobin) {
@@ -2080,8 +2139,38 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
     pids.ensure((size_t)n * 4);
     ridx->ensure((size_t)n * 4 + 16);
     dstarts.ensure(((size_t)P + 1) * 8);
+    const bool by_range = sw.shuffle_partitioning == Operator::Partitioning::Range;
+    std::shared_ptr<DevBuf> planes;
+    DevBuf bkeys;
+    if (by_range) {
+      // order-preserving key bytes of every row and of every boundary row (same generated kernel, same widths), then an
+      // upper-bound search per row: partition = number of boundaries ≤ row (multi_partition.rs:352-358)
+      int W = 0, Wb = 0;
+      planes = sort_key_planes(*range_sort_.at(&sw), in, W);
+      const int B = (int)sw.shuffle_bounds.size();
+      std::vector<DType> btypes;
+      for (auto& k : range_sort_.at(&sw)->sort_orders) btypes.push_back(k.child->dtype);
+      DevTable bt = literal_table(sw.shuffle_bounds, btypes);
+      std::vector<uint8_t> rowmajor((size_t)std::max(B, 1) * (size_t)std::max(W, 1), 0);
+      if (B > 0) {
+        auto bplanes = sort_key_planes(*range_bsort_.at(&sw), bt, Wb);
+        if (Wb != W) throw CometError("internal: range boundary keys and row keys differ in width");
+        std::vector<uint8_t> pl((size_t)W * (size_t)B);
+        HIP_CHECK(hipMemcpyAsync(pl.data(), bplanes->p, pl.size(), hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        for (int b = 0; b < B; b++)
+          for (int p = 0; p < W; p++) rowmajor[(size_t)b * W + p] = pl[(size_t)p * B + b];
+        for (int b = 1; b < B; b++)
+          if (memcmp(&rowmajor[(size_t)(b - 1) * W], &rowmajor[(size_t)b * W], (size_t)W) > 0) throw CometError("ShuffleWriter: range boundaries are not in ascending order");
+      }
+      bkeys.ensure(rowmajor.size() + 16);
+      HIP_CHECK(hipMemcpyAsync(bkeys.p, rowmajor.data(), rowmajor.size(), hipMemcpyHostToDevice, stream_));
+      if (comet_launch_range_partition_ids((const uint8_t*)planes->p, n, W, (const uint8_t*)bkeys.p, B, (int32_t*)pids.p, stream_) != 0)
+        throw CometError("shuffle: launch failed");
+      HIP_CHECK(hipStreamSynchronize(stream_));   // rowmajor (pageable) must outlive the upload
+    }
     const uint32_t seed = 42;
-    if (comet_launch_fill(4, hashes.p, n, &seed, stream_) != 0) throw CometError("shuffle: launch failed");
+    if (!by_range && comet_launch_fill(4, hashes.p, n, &seed, stream_) != 0) throw CometError("shuffle: launch failed");
     for (int c : key_cols) {
       const DeviceColumnView& v = in.cols[(size_t)c];
       if (v.offset != 0) throw CometError("ShuffleWriter: hash key column with a non-zero Arrow offset is not supported yet");
@@ -2094,7 +2183,7 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
     hist.ensure(hist_bytes + 8);
     uint32_t* bad = (uint32_t*)((char*)hist.p + hist_bytes);
     HIP_CHECK(hipMemsetAsync(bad, 0, 4, stream_));
-    if (comet_launch_pmod((const uint32_t*)hashes.p, n, P, (int32_t*)pids.p, stream_) != 0 ||
+    if ((!by_range && comet_launch_pmod((const uint32_t*)hashes.p, n, P, (int32_t*)pids.p, stream_) != 0) ||
         comet_launch_partition_indices((const int32_t*)pids.p, n, P, (uint64_t*)hist.p, bad, (int64_t*)dstarts.p, (uint32_t*)ridx->p, stream_) != 0)
       throw CometError("shuffle: launch failed");
     HIP_CHECK(hipMemcpyAsync(starts.data(), dstarts.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, stream_));
@@ -2323,9 +2412,9 @@ DevTable ExecutionContext::take_rows(const DevTable& in, const uint32_t* dev_per
 
 // Sort (planner.rs:1488-1522 → SortExec with fetch / skip): order-preserving key bytes per row (generated kernel), LSD radix
 // sort of a row permutation over the byte planes that actually vary, then one take per column of rows [skip, skip+fetch).
-DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
+// order-preserving key bytes of every row of `in` under sop.sort_orders, as W byte planes of n rows (plane p of row i at p·n + i)
+std::shared_ptr<DevBuf> ExecutionContext::sort_key_planes(const Operator& sop, const DevTable& in, int& W) {
   const int64_t n = in.rows;
-  if (n >= ((int64_t)1 << 32)) throw CometError("Sort: more than 2^32 rows in one partition");
   std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&sop] + 1))) + ":S:" + validity_key(in.has_valid);
   std::shared_ptr<PlannedVariant> pv;
   {
@@ -2340,16 +2429,13 @@ DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     g_plan_cache[key] = pv;
   }
-  const int64_t skip = std::min<int64_t>(std::max(0, sop.skip), n);
-  const int64_t keep = sop.fetch >= 0 ? std::min<int64_t>(n, sop.fetch) : n;     // fetch counts from the first row (GlobalLimit(skip) on top)
-  const int64_t out_rows = std::max<int64_t>(0, keep - skip);
-  if (n == 0 || out_rows == 0) return take_rows(in, nullptr, 0, 0, nullptr);
   Variant v;
   v.desc = pv->desc;
   v.mod = jit_load(pv->code);
-  const int W = v.desc.sort_key_bytes;
+  W = v.desc.sort_key_bytes;
   auto planes = std::make_shared<DevBuf>();
-  planes->ensure((size_t)W * (size_t)n + 16);
+  planes->ensure((size_t)W * (size_t)std::max<int64_t>(n, 1) + 16);
+  if (n == 0) return planes;
   CometKParams prm;
   memset(&prm, 0, sizeof prm);
   prm.n = n;
@@ -2361,8 +2447,74 @@ DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
   }
   prm.out[0] = planes->p;
   prm.out[kOutErr] = err_flags_.p;
-  timed_begin();
   launch(v, "k_sortkey", (int)std::min<int64_t>((n + 255) / 256, 256 * 8), prm);
+  planes_owner_ = v.mod;   // the module must stay loaded until the launch has run; callers synchronise before returning
+  return planes;
+}
+
+// a small resident table from literal rows (range-partition boundaries): one column per entry of `types`
+DevTable ExecutionContext::literal_table(const std::vector<std::vector<ExprP>>& rows, const std::vector<DType>& types) {
+  DevTable t;
+  const int64_t n = (int64_t)rows.size();
+  t.rows = n;
+  for (size_t c = 0; c < types.size(); c++) {
+    const DType& ty = types[c];
+    const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
+    std::vector<uint8_t> vals, data, valid((size_t)((n + 7) / 8) + 1, 0);
+    std::vector<int32_t> offs(1, 0);
+    const int w = is_str ? 0 : ty.id == TypeId::Bool ? 0 : fixed_width(ty);
+    if (ty.id == TypeId::Bool) vals.assign((size_t)((n + 7) / 8) + 1, 0);
+    for (int64_t r = 0; r < n; r++) {
+      const Expr& e = *rows[(size_t)r][c];
+      if (!e.lit_null) valid[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));
+      if (is_str) {
+        if (!e.lit_null) data.insert(data.end(), e.lit_bytes.begin(), e.lit_bytes.end());
+        offs.push_back((int32_t)data.size());
+      } else if (ty.id == TypeId::Bool) {
+        if (!e.lit_null && e.lit_bool) vals[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));
+      } else {
+        uint8_t buf[16] = {0};
+        if (!e.lit_null) {
+          if (ty.id == TypeId::Decimal) { i128 v = e.lit_dec; memcpy(buf, &v, 16); }
+          else if (ty.id == TypeId::Double) { double v = e.lit_f64; memcpy(buf, &v, 8); }
+          else if (ty.id == TypeId::Float) { float v = (float)e.lit_f64; memcpy(buf, &v, 4); }
+          else { int64_t v = e.lit_i64; memcpy(buf, &v, 8); }   // little endian: the low `w` bytes are the narrower integer
+        }
+        vals.insert(vals.end(), buf, buf + w);
+      }
+    }
+    auto up = [&](const void* p, size_t bytes) {
+      auto b = std::make_shared<DevBuf>();
+      b->ensure(bytes + 16);
+      if (bytes) HIP_CHECK(hipMemcpy(b->p, p, bytes, hipMemcpyHostToDevice));
+      t.owners.push_back(b);
+      return b->p;
+    };
+    DeviceColumnView v;
+    if (is_str) {
+      v.data = up(offs.data(), offs.size() * 4);
+      v.aux = up(data.data(), data.size());
+    } else {
+      v.data = up(vals.data(), vals.size());
+    }
+    v.valid = (const uint8_t*)up(valid.data(), valid.size());
+    t.types.push_back(ty);
+    t.cols.push_back(v);
+    t.has_valid.push_back(true);
+  }
+  return t;
+}
+
+DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
+  const int64_t n = in.rows;
+  if (n >= ((int64_t)1 << 32)) throw CometError("Sort: more than 2^32 rows in one partition");
+  const int64_t skip = std::min<int64_t>(std::max(0, sop.skip), n);
+  const int64_t keep = sop.fetch >= 0 ? std::min<int64_t>(n, sop.fetch) : n;     // fetch counts from the first row (GlobalLimit(skip) on top)
+  const int64_t out_rows = std::max<int64_t>(0, keep - skip);
+  if (n == 0 || out_rows == 0) return take_rows(in, nullptr, 0, 0, nullptr);
+  timed_begin();
+  int W = 0;
+  auto planes = sort_key_planes(sop, in, W);
   // which planes vary at all?
   DevBuf flags;
   flags.ensure((size_t)W * 4 + 16);
@@ -2446,8 +2598,7 @@ DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
   if (getenv("COMET_TRACE_STAGES"))
     fprintf(stderr, "[comet] sort: %lld rows, key %d bytes, %d select passes -> %lld rows sorted in %d radix passes\n", (long long)n, W, select_passes,
             (long long)ns, passes);
-  DevTable out = take_rows(in, (const uint32_t*)perm->p, skip, out_rows, perm);
-  out.owners.push_back(v.mod);
+  DevTable out = take_rows(in, (const uint32_t*)perm->p, skip, out_rows, perm);   // synchronises the stream: the key kernel has run
   return out;
 }
 

@@ -134,6 +134,8 @@ class ExecutionContext {
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
   DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix);
   DevTable sort_table(const Operator& s, const DevTable& in);
+  std::shared_ptr<DevBuf> sort_key_planes(const Operator& s, const DevTable& in, int& W);
+  DevTable literal_table(const std::vector<std::vector<ExprP>>& rows, const std::vector<DType>& types);
   DevTable take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner);
   DevTable nested_aggregate(const Operator& agg);
   DevTable write_shuffle(const Operator& sw);
@@ -182,6 +184,8 @@ class ExecutionContext {
   bool materialize_root_ = false;   // plain Scan chain whose outputs need the materialising path (Utf8 pass-through)
   bool compile_in_infer_ = false;
   std::vector<const Operator*> nested_aggs_;
+  std::map<const Operator*, OperatorP> range_sort_, range_bsort_;   // ShuffleWriter(range) → synthetic Sort over its rows / its boundary rows
+  std::shared_ptr<void> planes_owner_;
   std::map<const Operator*, OperatorP> shuffle_projs_;   // ShuffleWriter with computed hash expressions → synthetic Projection(child ++ hash exprs)
   int64_t shuffle_bytes_written_ = 0, shuffle_data_size_ = 0;
   double shuffle_repart_ns_ = 0, shuffle_write_ns_ = 0;

@@ -164,6 +164,8 @@ struct Operator {
   enum class Partitioning : int { Hash = 1, Single = 2, Range = 3, RoundRobin = 4 };
   Partitioning shuffle_partitioning = Partitioning::Single;
   std::vector<ExprP> shuffle_hash_exprs;
+  std::vector<SortKey> shuffle_sort_orders;             // RangePartition.sort_orders
+  std::vector<std::vector<ExprP>> shuffle_bounds;       // RangePartition.boundary_rows: one literal per sort order, ascending in that order
   int shuffle_num_partitions = 1;
   int shuffle_max_hash_columns = 0;
   std::string shuffle_data_file, shuffle_index_file;

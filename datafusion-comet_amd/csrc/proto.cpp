@@ -324,6 +324,28 @@ void decode_native_scan(Reader r, Operator& op) {
   }
 }
 
+// Expr { sort_order = 19 : SortOrder { child = 1, direction = 2, null_ordering = 3 } } (expr.proto:385-389)
+Operator::SortKey decode_sort_order_expr(Reader e, const char* what) {
+  Operator::SortKey k;
+  while (!e.done()) {
+    int wt3, f3 = e.tag(wt3);
+    if (f3 == 19 && wt3 == 2) {
+      Reader so = e.sub();
+      while (!so.done()) {
+        int wt4, f4 = so.tag(wt4);
+        if (f4 == 1 && wt4 == 2) k.child = decode_expr(so.sub());
+        else if (f4 == 2 && wt4 == 0) k.descending = so.varint() == 1;
+        else if (f4 == 3 && wt4 == 0) k.nulls_last = so.varint() == 1;
+        else so.skip(wt4);
+      }
+    } else {
+      e.skip(wt3);
+    }
+  }
+  if (!k.child) throw CometError(std::string(what) + ": sort_orders entry is not a SortOrder expression");
+  return k;
+}
+
 OperatorP decode_operator_r(Reader r) {
   auto op = std::make_shared<Operator>();
   while (!r.done()) {
@@ -370,6 +392,17 @@ OperatorP decode_operator_r(Reader r) {
                 if (f3 == 1 && f4 == 1 && wt4 == 2) op->shuffle_hash_exprs.push_back(decode_expr(q.sub()));
                 else if (f3 == 1 && f4 == 2 && wt4 == 0) op->shuffle_num_partitions = (int)(int32_t)q.varint();
                 else if (f3 == 3 && f4 == 2 && wt4 == 0) op->shuffle_num_partitions = (int)(int32_t)q.varint();
+                else if (f3 == 3 && f4 == 1 && wt4 == 2) op->shuffle_sort_orders.push_back(decode_sort_order_expr(q.sub(), "RangePartition"));
+                else if (f3 == 3 && f4 == 4 && wt4 == 2) {
+                  Reader br = q.sub();
+                  std::vector<ExprP> row;
+                  while (!br.done()) {
+                    int wt5, f5 = br.tag(wt5);
+                    if (f5 == 1 && wt5 == 2) row.push_back(decode_expr(br.sub()));
+                    else br.skip(wt5);
+                  }
+                  op->shuffle_bounds.push_back(row);
+                }
                 else if (f3 == 4 && f4 == 1 && wt4 == 0) op->shuffle_num_partitions = (int)(int32_t)q.varint();
                 else if (f3 == 4 && f4 == 2 && wt4 == 0) op->shuffle_max_hash_columns = (int)(int32_t)q.varint();
                 else q.skip(wt4);

@@ -377,6 +377,7 @@ class Operator:
     index_file: str = ""
     codec: int = 0                              # CompressionCodec: 0 None, 1 Zstd, 2 Lz4, 3 Snappy
     compression_level: int = 1
+    bounds: List[list] = field(default_factory=list)          # range partitioning: boundary rows (lists of literal Exprs), ascending
 
     TAGS = dict(shuffle_writer=106, shuffle_scan=116, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
 
@@ -398,7 +399,15 @@ class Operator:
             elif self.partitioning == "single":
                 part = _f_msg(2, b"")
             elif self.partitioning == "range":
-                part = _f_msg(3, _f_varint(2, self.num_partitions))
+                # RangePartition{sort_orders=1 (Expr{sort_order=19}), num_partitions=2, boundary_rows=4 (BoundaryRow{partition_bounds=1})}
+                rp = b""
+                for e, desc, nulls_last in self.sort_orders:
+                    so = _f_msg(1, e.encode()) + (_f_varint(2, 1) if desc else b"") + (_f_varint(3, 1) if nulls_last else b"")
+                    rp += _f_msg(1, _f_msg(19, so))
+                rp += _f_varint(2, self.num_partitions)
+                for row in self.bounds:
+                    rp += _f_msg(4, b"".join(_f_msg(1, v.encode()) for v in row))
+                part = _f_msg(3, rp)
             else:
                 part = _f_msg(4, _f_varint(1, self.num_partitions) + (_f_varint(2, self.max_hash_columns) if self.max_hash_columns else b""))
             body = _f_msg(1, part) + _f_bytes(3, self.data_file.encode()) + _f_bytes(4, self.index_file.encode())
@@ -488,10 +497,14 @@ CODEC_NONE, CODEC_ZSTD, CODEC_LZ4, CODEC_SNAPPY = 0, 1, 2, 3
 
 
 def shuffle_writer(child: Operator, data_file: str, index_file: str, partitioning: str = "single", hash_exprs: Sequence[Expr] = (),
-                   num_partitions: int = 1, codec: int = CODEC_NONE, compression_level: int = 1, max_hash_columns: int = 0) -> Operator:
+                   num_partitions: int = 1, codec: int = CODEC_NONE, compression_level: int = 1, max_hash_columns: int = 0,
+                   sort_orders: Sequence = (), bounds: Sequence = ()) -> Operator:
+    """partitioning "range": sort_orders as for sort() — (expr, descending[, nulls_last]) — and `bounds`, the boundary rows (one
+    literal per sort order, ascending under that order); a row goes to partition #(bounds ≤ row)."""
+    so = [(o[0], bool(o[1]), bool(o[2]) if len(o) > 2 else bool(o[1])) for o in sort_orders]
     return Operator("shuffle_writer", [child], exprs=list(hash_exprs), partitioning=partitioning, num_partitions=num_partitions,
                     data_file=data_file, index_file=index_file, codec=codec, compression_level=compression_level,
-                    max_hash_columns=max_hash_columns)
+                    max_hash_columns=max_hash_columns, sort_orders=so, bounds=[list(r) for r in bounds])
 
 
 def filter_(child: Operator, predicate: Expr) -> Operator:

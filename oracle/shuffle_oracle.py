@@ -145,6 +145,48 @@ def decode_block(block: bytes) -> pa.RecordBatch:
     return pa.ipc.open_stream(payload).read_next_batch()
 
 
+def _cmp_values(a, b, descending: bool, nulls_last: bool) -> int:
+    """Order of two values under one SortOrder, the way arrow's RowConverter orders them (NULL placement is independent of the
+    direction; floats: −0.0 = 0.0 is not assumed — IEEE total order like the row format; strings by UTF-8 bytes)."""
+    if a is None or b is None:
+        if a is None and b is None:
+            return 0
+        first = -1 if not nulls_last else 1
+        return first if a is None else -first
+    if isinstance(a, str):
+        a, b = a.encode(), b.encode()
+    if isinstance(a, float):
+        key = lambda x: (lambda bits: bits ^ 0xFFFFFFFFFFFFFFFF if bits >> 63 else bits | (1 << 63))(struct.unpack("<Q", struct.pack("<d", x))[0])
+        a, b = key(a), key(b)
+    c = (a > b) - (a < b)
+    return -c if descending else c
+
+
+def range_partition_ids(keys: Sequence[Sequence], orders: Sequence[tuple], bounds: Sequence[Sequence]) -> np.ndarray:
+    """multi_partition.rs:332-366: partition id = bounds.partition_point(|bound| bound <= row).  keys: one list of values per sort
+    order; orders: (descending, nulls_last) per sort order; bounds: boundary rows, ascending."""
+    n = len(keys[0]) if keys else 0
+
+    def cmp_rows(x, y):
+        for (d, nl), a, b in zip(orders, x, y):
+            c = _cmp_values(a, b, d, nl)
+            if c:
+                return c
+        return 0
+    out = np.zeros(n, np.int32)
+    for i in range(n):
+        row = [k[i] for k in keys]
+        lo, hi = 0, len(bounds)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if cmp_rows(bounds[mid], row) <= 0:
+                lo = mid + 1
+            else:
+                hi = mid
+        out[i] = lo
+    return out
+
+
 def partition_rows(S, table: pa.Table, partitioning: str, key_cols: Sequence[int], num_partitions: int, max_hash_columns: int = 0):
     """→ (starts[P+1], row_indices[n]) of the shuffle writer for this input."""
     n = table.num_rows

@@ -169,3 +169,33 @@ def test_unsupported_partitioning_fails_at_create_plan(built, tmp_path):
     plan = S.shuffle_writer(S.scan(FIELDS), str(tmp_path / "d"), str(tmp_path / "i"), partitioning="range", num_partitions=4)
     with pytest.raises(native.CometNativeException, match="range partitioning"):
         native.Native.createPlan([native.HostInput.from_table(_table(10))], plan.encode())
+
+
+def test_range_partitioning_matches_oracle(built, tmp_path):
+    """RangePartition (what Spark plans below every global ORDER BY): partition = number of boundary rows ≤ the row under the sort orders
+    (multi_partition.rs:332-366) — order-preserving key bytes on the device + an upper-bound search; DESC / NULLS LAST, a decimal and a
+    date key, NULL keys, duplicate-heavy keys that sit exactly on boundaries."""
+    from oracle import shuffle_oracle as SO
+    from oracle import oracle as O
+    t = _table(50_000, seed=77)
+    k, d, dt = S.col(0, S.T_INT64), S.col(2, FIELDS[2]), S.col(5, S.T_DATE)
+    import decimal
+    cases = [
+        ([(k, False, False)], [[S.lit(v, S.T_INT64)] for v in (-900, -500, -500, 0, 1, 777)], 8),
+        ([(dt, True, True), (d, False, False)], [[S.lit(11000, S.T_DATE), S.lit(decimal.Decimal("0.00"), FIELDS[2])], [S.lit(9500, S.T_DATE), S.lit(decimal.Decimal("-5000.25"), FIELDS[2])],
+                                                   [S.lit(9500, S.T_DATE), S.lit(decimal.Decimal("12345.67"), FIELDS[2])], [S.lit(8200, S.T_DATE), S.lit(None, FIELDS[2])]], 5),
+        ([(k, True, False)], [], 1),
+    ]
+    for ci, (orders, bounds, P) in enumerate(cases):
+        dd = tmp_path / f"r{ci}"
+        dd.mkdir()
+        data, index = _write(S.scan(FIELDS), [t], dd, partitioning="range", sort_orders=orders, bounds=bounds, num_partitions=P, batch_size=8192)
+        keys = [(t.column(e.index).cast(pa.int32()) if pa.types.is_date(t.column(e.index).type) else t.column(e.index)).to_pylist() for e, _, _ in orders]
+        bvals = [[b.value for b in row] for row in bounds]
+        pids = SO.range_partition_ids(keys, [(desc, nl) for _, desc, nl in orders], bvals)
+        starts, idx = O.partition_starts_and_indices(pids, P)
+        rows = [idx[starts[p]:starts[p + 1]] for p in range(P)]
+        assert sum(len(r) for r in rows) == t.num_rows
+        _check_files(data, index, t, rows, 8192, S.CODEC_NONE)
+        if P > 1:
+            assert sum(1 for r in rows if len(r)) >= 3
