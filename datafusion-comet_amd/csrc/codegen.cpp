@@ -886,6 +886,32 @@ struct Gen {
     const std::string& f = e.func;
     auto arg = [&](size_t i) { return named(gen(e.children.at(i))); };
     Val r;
+    if (f == "substring" || f == "substr") {
+      // Spark Substring (strings.scala:209) on a Utf8 column with literal position / length: a computed string of at most 15 bytes,
+      // packed in registers — usable as a group / join key and in comparisons (TPC-H Q22: substring(c_phone, 1, 2))
+      auto int_lit = [](const ExprP& x, long long& out) {
+        if (x->kind != ExprKind::Literal || x->lit_null) return false;
+        out = x->lit_i64;
+        return x->dtype.is_integer();
+      };
+      long long pos = 0, len = 0x7fffffffLL;
+      if (e.children.size() < 2 || e.children.size() > 3 || !is_str_col(e.children[0]) || !int_lit(e.children[1], pos) || (e.children.size() == 3 && !int_lit(e.children[2], len)))
+        throw CometError("substring is supported for a Utf8 column with literal position and length");
+      pos = std::max<long long>(std::min<long long>(pos, 0x7fffffffLL), -0x7fffffffLL);
+      len = std::max<long long>(std::min<long long>(len, 0x7fffffffLL), -0x7fffffffLL);
+      const int idx = e.children[0]->bound_index;
+      Val valid = str_col_validity(idx);
+      auto loc = locate(idx);
+      uses_err = true;
+      std::string v = newvar("comet::str16");
+      stmt("{ bool tl_ = false; " + v + " = comet::utf8_substr16(prm.in[" + std::to_string(loc.first) + "], " + loc.second + ", " + std::to_string(pos) + ", " + std::to_string(len) +
+           ", tl_); if (tl_) atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], 64u); }");
+      r.t = DType::of(TypeId::String);
+      r.rep = Rep::STR;
+      r.v = v;
+      r.ok = valid.ok;
+      return r;
+    }
     if (f == "starts_with" || f == "ends_with" || f == "contains") {
       // byte-wise (UTF8_BINARY) tests of a Utf8 column against a literal (strings.scala:343-360 → DataFusion starts_with / ends_with / contains)
       if (e.children.size() != 2 || !is_str_col(e.children[0]) || !is_str_lit(e.children[1]))

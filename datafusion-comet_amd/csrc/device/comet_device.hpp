@@ -85,6 +85,43 @@ CDEV str16 ld_str16(const CometCol& c, i64 i, bool& toolong) {
   return r;
 }
 
+// substring(str, pos, len) with Spark's rules (UTF8String.substringSQL): 1-based, CHARACTER positions; pos 0 behaves like 1; a negative
+// pos counts from the end; the window [start, start + len) is clipped to the string.  The result is built straight from the column
+// bytes into the packed form, so the source may have any length — only a RESULT longer than 15 bytes sets `toolong`.
+CDEV str16 utf8_substr16(const CometCol& c, i64 i, i32 pos, i32 len, bool& toolong) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], nbytes = off[j + 1] - lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  str16 r;
+  r.a = 0;
+  r.b = 0;
+  i64 start;
+  if (pos > 0) start = (i64)pos - 1;
+  else if (pos < 0) {
+    i32 nchars = 0;
+    for (i32 k = 0; k < nbytes; k++) nchars += (p[k] & 0xC0) != 0x80;
+    start = (i64)nchars + pos;
+  } else start = 0;
+  const i64 until = start + (i64)len;
+  if (until <= start || start >= nbytes) return r;   // empty string (length byte 0)
+  // byte range of characters [start, until)
+  i32 k = 0;
+  i64 ch = 0;
+  while (k < nbytes && ch < start) { k++; while (k < nbytes && (p[k] & 0xC0) == 0x80) k++; ch++; }
+  const i32 b0 = k;
+  while (k < nbytes && ch < until) { k++; while (k < nbytes && (p[k] & 0xC0) == 0x80) k++; ch++; }
+  i32 n = k - b0;
+  if (n > 15) { toolong = true; n = 15; }
+  for (i32 q = 0; q < n; q++) {
+    const u64 byte = p[b0 + q];
+    if (q < 8) r.a |= byte << (8 * q);
+    else r.b |= byte << (8 * (q - 8));
+  }
+  r.b |= (u64)n << 56;
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Scalar functions (ScalarFunc, expr.proto:466-471): the exact, integer/IEEE-defined subset.
 // ---------------------------------------------------------------------------------------------

@@ -1,4 +1,5 @@
 #include "parquet_meta.hpp"
+#include "shuffle_format.hpp"
 
 #include <dlfcn.h>
 
@@ -362,7 +363,47 @@ void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, siz
       if (iserr(rc) || rc != dst_len) throw CometError("parquet: zstd decompression failed");
       return;
     }
-    default: throw CometError("parquet: compression codec " + std::to_string(codec) + " is not supported yet (UNCOMPRESSED, SNAPPY, ZSTD are)");
+    case LZ4_RAW: {   // one raw LZ4 block per page (parquet-format Compression.md)
+      const size_t got = lz4_decompress_block(src, src_len, dst, dst_len, 0);
+      if (got != dst_len) throw CometError("parquet: lz4 page decompressed to " + std::to_string(got) + " bytes, expected " + std::to_string(dst_len));
+      return;
+    }
+    case GZIP: {
+      // zlib through dlopen (no headers in the image: z_stream restated; the layout is part of zlib's stable ABI)
+      struct ZStream {
+        const uint8_t* next_in; unsigned avail_in; unsigned long total_in;
+        uint8_t* next_out; unsigned avail_out; unsigned long total_out;
+        const char* msg; void* state; void* zalloc; void* zfree; void* opaque;
+        int data_type; unsigned long adler; unsigned long reserved;
+      };
+      struct Zlib {
+        int (*init2)(ZStream*, int, const char*, int) = nullptr;
+        int (*inflate)(ZStream*, int) = nullptr;
+        int (*end)(ZStream*) = nullptr;
+        Zlib() {
+          void* h = dlopen("libz.so.1", RTLD_NOW | RTLD_GLOBAL);
+          if (!h) return;
+          init2 = (decltype(init2))dlsym(h, "inflateInit2_");
+          inflate = (decltype(inflate))dlsym(h, "inflate");
+          end = (decltype(end))dlsym(h, "inflateEnd");
+        }
+      };
+      static const Zlib z;
+      if (!z.init2 || !z.inflate || !z.end) throw CometError("parquet: gzip pages need libz.so.1, which could not be loaded");
+      ZStream st;
+      memset(&st, 0, sizeof st);
+      if (z.init2(&st, 15 + 32 /* zlib or gzip header */, "1.2.11", (int)sizeof st) != 0) throw CometError("parquet: inflateInit2 failed");
+      st.next_in = src;
+      st.avail_in = (unsigned)src_len;
+      st.next_out = dst;
+      st.avail_out = (unsigned)dst_len;
+      const int rc = z.inflate(&st, 4 /* Z_FINISH */);
+      const unsigned long produced = st.total_out;
+      z.end(&st);
+      if (rc != 1 /* Z_STREAM_END */ || produced != dst_len) throw CometError("parquet: gzip decompression failed");
+      return;
+    }
+    default: throw CometError("parquet: compression codec " + std::to_string(codec) + " is not supported yet (UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4_RAW are)");
   }
 }
 

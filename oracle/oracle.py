@@ -276,6 +276,19 @@ class Evaluator:
                     out[i] = {"year": d.year, "month": d.month, "day": d.day, "quarter": (d.month - 1) // 3 + 1, "dow": (d.weekday() + 1) % 7,
                               "doy": d.timetuple().tm_yday}[part]
             return Col(S.T_INT32, out, a.valid)
+        if f in ("substring", "substr"):
+            # Spark UTF8String.substringSQL: 1-based character positions, 0 like 1, negative from the end, window clipped to the string
+            a = self.eval(e.children[0], cols, n)
+            pos = int(e.children[1].value)
+            ln = int(e.children[2].value) if len(e.children) > 2 else 2**31 - 1
+
+            def sub(v):
+                start = pos - 1 if pos > 0 else (len(v) + pos if pos < 0 else 0)
+                until = start + ln
+                if until <= start or start >= len(v.encode()):
+                    return ""
+                return v[max(start, 0):max(until, 0)]
+            return Col(S.T_STRING, np.array([sub(v) if v is not None else None for v in a.values], dtype=object), a.valid)
         if f in ("starts_with", "ends_with", "contains"):
             # byte-wise on the UTF-8 encodings (UTF8_BINARY collation; strings.scala:343-360)
             a, lit = self.eval(e.children[0], cols, n), e.children[1].value.encode()

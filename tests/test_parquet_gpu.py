@@ -60,7 +60,7 @@ def _assert_same(got: pa.Table, want: pa.Table):
         assert g.equals(w), f"column {name} differs"
 
 
-@pytest.mark.parametrize("compression", ["NONE", "SNAPPY", "ZSTD"])
+@pytest.mark.parametrize("compression", ["NONE", "SNAPPY", "ZSTD", "LZ4", "GZIP"])
 @pytest.mark.parametrize("use_dictionary", [True, False])
 def test_roundtrip_all_types(built, tmp_path, compression, use_dictionary):
     t = _mixed_table(30_000, seed=1)

@@ -208,3 +208,30 @@ def test_join_on_strings_of_any_length(built, jt, build):
     assert got.num_rows == want.num_rows > 0
     assert got.schema.types == want.schema.types
     assert _rows(got) == _rows(want)
+
+
+def test_substring_as_filter_and_group_key(built):
+    """TPC-H Q22's shape: WHERE substring(c_phone, 1, 2) IN (…) GROUP BY substring(c_phone, 1, 2) — a computed string of ≤ 15 bytes built
+    from the column bytes (Spark's 1-based, character-wise substring incl. pos 0, negative pos and clipping), used as predicate and key."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(22)
+    n = 50_000
+    phones = ["%02d-%03d-%03d-%04d" % tuple(rng.integers(10, 35, 1).tolist() + rng.integers(100, 999, 3).tolist()) for _ in range(n)]
+    odd = ["", "7", "ü1-x", "日本語テキスト-long-tail-beyond-fifteen-bytes", "ab"]
+    vals = [None if rng.random() < 0.03 else (odd[int(rng.integers(0, len(odd)))] if rng.random() < 0.05 else phones[i]) for i in range(n)]
+    t = pa.table({"c_phone": pa.array(vals, pa.string()), "c_acctbal": tpch._dec128_array(rng.integers(-99999, 999999, n), 12, 2)})
+    D, SD = S.decimal(12, 2), S.decimal(22, 2)
+    s, I = S.col(0, S.T_STRING), (lambda v: S.lit(v, S.T_INT32))
+    code = S.scalar_func("substring", [s, I(1), I(2)], S.T_STRING)
+    flt = S.in_(code, [S.lit(x, S.T_STRING) for x in ("13", "31", "23", "29", "30", "18", "17", "日本")])
+    plan = S.hash_agg(S.filter_(S.scan([S.T_STRING, D]), S.and_(flt, S.gt(S.col(1, D), S.lit(__import__("decimal").Decimal("0.00"), D)))),
+                      [code], [S.count(S.col(1, D)), S.sum_(S.col(1, D), SD)], S.PARTIAL)
+    run = lambda p, nc: pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], nc, p.encode(), batch_size=0))
+    got, want = run(plan, 4), O.run_plan_to_arrow(S, plan, [t])
+    assert _rows(got) == _rows(want) and got.num_rows >= 7
+    for pos, ln in ((0, 2), (-4, 3), (4, 100), (-100, 3), (2, 0), (3, -1), (-2, 15)):
+        key = S.scalar_func("substring", [s, I(pos), I(ln)], S.T_STRING)
+        keep = S.lt(S.scalar_func("octet_length", [s], S.T_INT32), S.lit(16, S.T_INT32))      # results stay within the packed 15 bytes
+        p2 = S.hash_agg(S.filter_(S.scan([S.T_STRING, D]), keep), [key], [S.count(S.col(1, D))], S.PARTIAL)
+        got, want = run(p2, 2), O.run_plan_to_arrow(S, p2, [t])
+        assert _rows(got) == _rows(want), (pos, ln)
