@@ -978,6 +978,86 @@ struct Gen {
         default: throw CometError("Unsupported data type " + a.t.str() + " for function abs");
       }
     }
+    if (f == "date_add" || f == "date_sub") {
+      // Date32 ± Int8/16/32 days, wrapping like the JVM's int arithmetic (planner.rs:1059-1092 → datafusion-spark SparkDateAdd / SparkDateSub)
+      Val a = arg(0), b = arg(1);
+      if (a.t.id != TypeId::Date || !(b.t.id == TypeId::Int8 || b.t.id == TypeId::Int16 || b.t.id == TypeId::Int32))
+        throw CometError(f + " expects (Date32, Int8 | Int16 | Int32)");
+      r.t = DType::of(TypeId::Date);
+      r.rep = Rep::I32;
+      r.ok = and_ok(a.ok, b.ok);
+      r.v = "(i32)((u32)" + a.v + (f == "date_add" ? " + " : " - ") + "(u32)" + b.v + ")";
+      r.maxabs = (u128)1 << 31;
+      return r;
+    }
+    if (f == "date_diff" || f == "datediff") {
+      // SparkDateDiff (datetime_funcs/date_diff.rs:72-110): end − start in days, wrapping, Int32
+      Val a = arg(0), b = arg(1);
+      if (a.t.id != TypeId::Date || b.t.id != TypeId::Date) throw CometError("date_diff expects two Date32 arguments");
+      r.t = DType::of(TypeId::Int32);
+      r.rep = Rep::I32;
+      r.ok = and_ok(a.ok, b.ok);
+      r.v = "(i32)((u32)" + a.v + " - (u32)" + b.v + ")";
+      r.maxabs = (u128)1 << 32;
+      return r;
+    }
+    if (f == "round") {
+      // spark_round (math_funcs/round.rs:160-260): HALF_UP at a literal decimal position.  Decimal128: (x + sign·half) / div [· mul];
+      // Int32/Int64 with a negative position: round to a power of ten, wrapping (LEGACY) or ARITHMETIC_OVERFLOW (fail_on_error)
+      if (e.children.size() != 2 || e.children[1]->kind != ExprKind::Literal || e.children[1]->lit_null || !e.children[1]->dtype.is_integer())
+        throw CometError("round expects a literal integer position");
+      const long long point = e.children[1]->lit_i64;
+      Val a = arg(0);
+      r.ok = a.ok;
+      if (a.t.id == TypeId::Decimal) {
+        if (!e.has_dtype || e.dtype.id != TypeId::Decimal) throw CometError("round: expected a Decimal128 return type");
+        r.t = e.dtype;
+        r.rep = rep_for_type(e.dtype);
+        const int scale = a.t.scale;
+        std::string x = as128(a), val;
+        if (point < 0) {
+          const long long ex = -point + scale;
+          if (ex >= 39) val = "(i128)0";
+          else {
+            const i128 div = (i128)pow10_u128((int)ex), mul = (i128)pow10_u128((int)-point);
+            val = "((" + x + " + (" + x + " < 0 ? -" + lit_i128(div / 2) + " : (" + x + " > 0 ? " + lit_i128(div / 2) + " : (i128)0))) / " + lit_i128(div) + " * " + lit_i128(mul) + ")";
+          }
+        } else {
+          const int drop = scale - (int)std::min<long long>(scale, point);
+          const i128 div = (i128)pow10_u128(drop);
+          val = drop == 0 ? x : "((" + x + " + (" + x + " < 0 ? -" + lit_i128(div / 2) + " : (" + x + " > 0 ? " + lit_i128(div / 2) + " : (i128)0))) / " + lit_i128(div) + ")";
+        }
+        r.v = r.rep == Rep::I128 ? val : "(i64)(" + val + ")";
+        r.maxabs = kUnbounded;
+        r.maxabs = std::min<u128>(type_maxabs(e.dtype), kUnbounded);
+        return r;
+      }
+      if ((a.t.id == TypeId::Int64 || a.t.id == TypeId::Int32) && point < 0) {
+        const bool is64 = a.t.id == TypeId::Int64;
+        const int digits = is64 ? 18 : 9;
+        if (-point > digits) throw CometError("round: a position below -" + std::to_string(digits) + " for " + a.t.str() + " is not supported yet");
+        const long long div = (long long)pow10_u128((int)-point), half = div / 2;
+        const std::string T = is64 ? "i64" : "i32", U = is64 ? "u64" : "u32";
+        const std::string x = "(" + T + ")" + a.v;
+        std::string rem = newvar(T.c_str());
+        stmt(rem + " = " + x + " % (" + T + ")" + std::to_string(div) + "ll;");
+        std::string base = newvar(T.c_str());
+        stmt(base + " = (" + T + ")((" + U + ")" + x + " - (" + U + ")" + rem + ");");
+        std::string adj = newvar(T.c_str());
+        stmt(adj + " = " + rem + " <= -(" + T + ")" + std::to_string(half) + "ll ? -(" + T + ")" + std::to_string(div) + "ll : (" + rem + " >= (" + T + ")" + std::to_string(half) + "ll ? (" + T + ")" +
+             std::to_string(div) + "ll : (" + T + ")0);");
+        if (e.fail_on_error) {
+          const std::string mx = is64 ? "(i64)0x7fffffffffffffffll" : "(i32)0x7fffffff", mn = is64 ? "(i64)0x8000000000000000ull" : "(i32)0x80000000";
+          raise_if(and_ok(a.ok, "((" + adj + " > 0 && " + base + " > " + mx + " - " + adj + ") || (" + adj + " < 0 && " + base + " < " + mn + " - " + adj + "))"), 1);
+        }
+        r.t = a.t;
+        r.rep = a.rep;
+        r.v = "(" + std::string(rep_ctype(a.rep)) + ")(" + T + ")((" + U + ")" + base + " + (" + U + ")" + adj + ")";
+        r.maxabs = type_maxabs(a.t);
+        return r;
+      }
+      throw CometError("round is supported for Decimal128 and, with a negative position, Int32 / Int64 (got " + a.t.str() + ")");
+    }
     if (f == "sqrt") {
       Val a = arg(0);
       if (a.rep != Rep::F64) throw CometError("sqrt expects a Float64 argument");

@@ -276,6 +276,44 @@ class Evaluator:
                     out[i] = {"year": d.year, "month": d.month, "day": d.day, "quarter": (d.month - 1) // 3 + 1, "dow": (d.weekday() + 1) % 7,
                               "doy": d.timetuple().tm_yday}[part]
             return Col(S.T_INT32, out, a.valid)
+        if f in ("date_add", "date_sub", "date_diff", "datediff"):
+            # wrapping 32-bit day arithmetic (datafusion-spark SparkDateAdd / SparkDateSub; datetime_funcs/date_diff.rs:72-110)
+            a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            x, y = a.values.astype(np.int64), b.values.astype(np.int64)
+            z = x + y if f == "date_add" else x - y
+            z = ((z + 2**31) % 2**32 - 2**31).astype(np.int32)
+            return Col(S.T_INT32 if f in ("date_diff", "datediff") else S.T_DATE, z, self._and_valid(a.valid, b.valid))
+        if f == "round":
+            # spark_round (math_funcs/round.rs:160-260)
+            a = self.eval(e.children[0], cols, n)
+            point = int(e.children[1].value)
+            trunc_div = lambda p, q: abs(p) // q * (1 if p >= 0 else -1)
+            if a.dtype.type_id == S.DECIMAL:
+                scale, out = a.dtype.scale, []
+                for i in range(n):
+                    x = dec_to_int(a.values, i)
+                    sg = (x > 0) - (x < 0)
+                    if point < 0:
+                        ex = -point + scale
+                        v = 0 if ex >= 39 else trunc_div(x + sg * (10**ex // 2), 10**ex) * 10**(-point)
+                    else:
+                        div = 10**(scale - min(scale, point))
+                        v = trunc_div(x + sg * (div // 2), div)
+                    out.append(v)
+                return Col(e.dtype, ints_to_dec(out), a.valid)
+            bits = 64 if a.dtype.type_id == S.INT64 else 32
+            div = 10**(-point)
+            half, out, ovf = div // 2, [], np.zeros(n, bool)
+            for i in range(n):
+                x = int(a.values[i])
+                rem = abs(x) % div * (1 if x >= 0 else -1)       # Rust `%`: sign of the dividend
+                v = x - rem + (-div if rem <= -half else div if rem >= half else 0)
+                ovf[i] = not (-(1 << (bits - 1)) <= v < (1 << (bits - 1)))
+                v &= (1 << bits) - 1
+                out.append(v - (1 << bits) if v >> (bits - 1) else v)
+            if e.fail_on_error and (ovf & a.ok()).any():
+                raise OracleError("ARITHMETIC_OVERFLOW")
+            return Col(a.dtype, np.array(out, dtype=_np_dtype(S, a.dtype)), a.valid)
         if f in ("substring", "substr"):
             # Spark UTF8String.substringSQL: 1-based character positions, 0 like 1, negative from the end, window clipped to the string
             a = self.eval(e.children[0], cols, n)

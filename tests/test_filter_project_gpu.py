@@ -293,3 +293,47 @@ def test_more_casts(built):
     for e in (S.cast(F, S.T_INT32, S.ANSI), S.cast(Wc, S.T_INT16, S.ANSI)):
         with pytest.raises(native.CometQueryExecutionException, match="CAST_OVERFLOW"):
             _run(S.project(S.scan(fields), [e]), table=t, ncols=1)
+
+
+def test_round_and_date_arithmetic(built):
+    """spark_round (math_funcs/round.rs:160-260: HALF_UP on Decimal128 at positive / zero / negative positions, Int32 / Int64 at negative
+    positions incl. wrap-around and ANSI overflow) and date_add / date_sub / date_diff (wrapping day arithmetic)."""
+    from datafusion_comet_amd import tpch
+    import decimal
+    n = 40_000
+    rng = np.random.default_rng(5)
+    i64 = rng.integers(-10**12, 10**12, n)
+    i64[:6] = [2**63 - 1, -2**63, 5, -5, 15, -15]
+    i32 = rng.integers(-2**31, 2**31, n).astype(np.int32)
+    i32[:4] = [2**31 - 1, -2**31, 2147483645, -2147483645]
+    t = pa.table({"d": tpch._dec128_array(rng.integers(-10**11, 10**11, n), 12, 2),
+                  "w": pa.array([decimal.Decimal(int(x) * 10**11 + 55555).scaleb(-6) for x in rng.integers(-10**17, 10**17, n)], pa.decimal128(38, 6)),
+                  "l": pa.array(i64, mask=rng.random(n) < 0.05), "i": pa.array(i32),
+                  "dt": pa.array(rng.integers(-20000, 40000, n).astype(np.int32), pa.int32()).cast(pa.date32()),
+                  "dt2": pa.array(rng.integers(0, 20000, n).astype(np.int32), pa.int32(), mask=rng.random(n) < 0.1).cast(pa.date32()),
+                  "k": pa.array(rng.integers(-400, 400, n).astype(np.int32))})
+    D, W = S.decimal(12, 2), S.decimal(38, 6)
+    fields = [D, W, S.T_INT64, S.T_INT32, S.T_DATE, S.T_DATE, S.T_INT32]
+    d, w, l, i, dt, dt2, k = (S.col(j, ty) for j, ty in enumerate(fields))
+    P = lambda v: S.lit(v, S.T_INT64)
+    rnd = lambda x, p, ty, **kw: S.scalar_func("round", [x, P(p)], ty, **kw)
+    outs = [rnd(d, 1, S.decimal(12, 1)), rnd(d, 0, S.decimal(11, 0)), rnd(d, 2, S.decimal(12, 2)), rnd(d, 5, S.decimal(12, 2)), rnd(d, -2, S.decimal(11, 0)),
+            rnd(w, 3, S.decimal(36, 3)), rnd(w, -4, S.decimal(33, 0)), rnd(w, 0, S.decimal(33, 0)),
+            rnd(l, -1, S.T_INT64), rnd(l, -3, S.T_INT64), rnd(l, -18, S.T_INT64), rnd(i, -2, S.T_INT32), rnd(i, -9, S.T_INT32),
+            S.scalar_func("date_add", [dt, k], S.T_DATE), S.scalar_func("date_sub", [dt, k], S.T_DATE), S.scalar_func("date_diff", [dt, dt2], S.T_INT32)]
+    for at in range(0, len(outs), 8):
+        chunk = outs[at:at + 8]
+        plan = S.project(S.scan(fields), chunk)
+        got = pa.Table.from_batches(_run(plan, table=t, ncols=len(chunk), batch_size=0))
+        want = _oracle(plan, t)
+        for c in range(len(chunk)):
+            assert got.column(c).combine_chunks().equals(want.column(c).combine_chunks()), at + c
+    # ANSI: rounding Long.MaxValue to tens leaves the type (an Int32 cannot overflow at the positions its powers of ten allow)
+    from oracle import oracle as O
+    e = rnd(l, -1, S.T_INT64, fail_on_error=True)
+    with pytest.raises(native.CometQueryExecutionException, match="ARITHMETIC_OVERFLOW"):
+        _run(S.project(S.scan(fields), [e]), table=t, ncols=1)
+    with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW"):
+        _oracle(S.project(S.scan(fields), [e]), t)
+    ok = rnd(i, -2, S.T_INT32, fail_on_error=True)
+    assert pa.Table.from_batches(_run(S.project(S.scan(fields), [ok]), table=t, ncols=1)).num_rows == n
