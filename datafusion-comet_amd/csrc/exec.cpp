@@ -350,7 +350,8 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
   std::function<void(const Operator&)> walk = [&](const Operator& op) {
     node_id_[&op] = (int)node_id_.size();
     if (op.kind == OpKind::Scan) scan_input_[&op] = scan_input_.size();
-    if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan || op.kind == OpKind::Sort || op.kind == OpKind::Limit || op.kind == OpKind::ShuffleWriter)
+    if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan || op.kind == OpKind::Sort || op.kind == OpKind::Limit || op.kind == OpKind::ShuffleWriter ||
+        op.kind == OpKind::Expand)
       has_join_ = true;   // sources materialised in HBM
     if (op.kind == OpKind::ShuffleWriter) {
       if (&op != plan_.get()) throw CometError("ShuffleWriter must be the root of a native plan");
@@ -457,7 +458,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
 // limits, and an aggregate that is not the top of the chain being fused.
 bool ExecutionContext::is_source(const Operator& op, const Operator* chain_top) {
   switch (op.kind) {
-    case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: case OpKind::ShuffleWriter: return true;
+    case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: case OpKind::ShuffleWriter: case OpKind::Expand: return true;
     case OpKind::HashAgg: return &op != chain_top;
     default: return false;
   }
@@ -479,6 +480,93 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       explain_ += "  limit " + std::to_string(op.limit) + " offset " + std::to_string(op.offset) + "\n";
     }
     return st;
+  }
+  if (op.kind == OpKind::Expand) {
+    // ExpandExec (operators/expand.rs; planner.rs:1913-1948): every input row yields one output row per projection (grouping sets /
+    // rollup / cube, the count(DISTINCT …) rewrite over several columns).  Each projection is a fused Projection over the resident child;
+    // all of them write into ONE set of output buffers at their row offset.  NULL literals of Utf8 (or unknown) type — the "not in this
+    // grouping set" marker — are not generated code: their rows are simply marked invalid.
+    if (op.children.size() != 1) throw CometError("Expand expects exactly one child");
+    std::vector<DType> st = infer_schema(*op.children[0]);
+    const size_t ncol = op.expand_projections.empty() ? 0 : op.expand_projections[0].size();
+    ExpandInfo info;
+    std::vector<std::vector<DType>> types(op.expand_projections.size(), std::vector<DType>(ncol));
+    std::vector<std::vector<bool>> known(op.expand_projections.size(), std::vector<bool>(ncol, false));
+    std::vector<std::vector<int>> gsrc(op.expand_projections.size(), std::vector<int>(ncol, -1));
+    auto is_null_lit = [](const ExprP& e) { return e->kind == ExprKind::Literal && e->lit_null; };
+    auto scan_of = [&]() {
+      auto sc = std::make_shared<Operator>();
+      sc->kind = OpKind::Scan;
+      sc->proto_tag = 100;
+      sc->scan_fields = st;
+      return sc;
+    };
+    // pass 1: types of everything that is not a NULL literal
+    for (size_t p = 0; p < op.expand_projections.size(); p++) {
+      auto pr = std::make_shared<Operator>();
+      pr->kind = OpKind::Projection;
+      pr->proto_tag = 101;
+      pr->children.push_back(scan_of());
+      std::vector<size_t> at;
+      for (size_t j = 0; j < ncol; j++)
+        if (!is_null_lit(op.expand_projections[p][j])) { pr->project_list.push_back(op.expand_projections[p][j]); at.push_back(j); }
+      if (pr->project_list.empty()) continue;
+      std::vector<bool> none(st.size(), false);
+      PipelineDesc d = generate_pipeline(*pr, none, &st);
+      for (size_t k = 0; k < at.size(); k++) { types[p][at[k]] = d.out_cols[k].type; known[p][at[k]] = true; gsrc[p][at[k]] = d.out_cols[k].gather_src; }
+    }
+    for (size_t j = 0; j < ncol; j++) {
+      OutCol oc;
+      bool have = false;
+      for (size_t p = 0; p < op.expand_projections.size(); p++) {
+        if (!known[p][j]) continue;
+        if (!have) { oc.type = types[p][j]; oc.gather_src = gsrc[p][j]; have = true; }
+        else if (types[p][j] != oc.type || gsrc[p][j] != oc.gather_src)
+          throw CometError("Expand: column " + std::to_string(j) + " differs between the projections (" + oc.type.str() + " vs " + types[p][j].str() + ")");
+      }
+      if (!have) {
+        const DType& lt = op.expand_projections[0][j]->dtype;
+        if (lt.id == TypeId::Null || lt.id == TypeId::Unknown) throw CometError("Expand: column " + std::to_string(j) + " is NULL in every projection and carries no type");
+        if (lt.id == TypeId::String || lt.id == TypeId::Bytes) throw CometError("Expand: a Utf8 column that is NULL in every projection is not supported yet");
+        oc.type = lt;
+      }
+      oc.nullable = true;
+      info.out_cols.push_back(oc);
+    }
+    // pass 2: the projections as executed
+    for (size_t p = 0; p < op.expand_projections.size(); p++) {
+      ExpandPart part;
+      part.proj = std::make_shared<Operator>();
+      part.proj->kind = OpKind::Projection;
+      part.proj->proto_tag = 101;
+      part.proj->children.push_back(scan_of());
+      for (size_t j = 0; j < ncol; j++) {
+        const ExprP& e = op.expand_projections[p][j];
+        const DType& ut = info.out_cols[j].type;
+        if (is_null_lit(e) && (ut.id == TypeId::String || ut.id == TypeId::Bytes)) { part.null_cols.push_back((int)j); continue; }
+        if (is_null_lit(e)) {
+          auto typed = std::make_shared<Expr>(*e);
+          typed->dtype = ut;
+          typed->has_dtype = true;
+          part.proj->project_list.push_back(typed);
+        } else {
+          part.proj->project_list.push_back(e);
+        }
+        part.out_col.push_back((int)j);
+      }
+      node_id_[part.proj.get()] = (int)node_id_.size();
+      if (!part.proj->project_list.empty()) {
+        std::vector<bool> none(st.size(), false);
+        PipelineDesc d = generate_pipeline(*part.proj, none, &st);
+        if (compile_in_infer_) jit_compile(d.source);
+      }
+      info.parts.push_back(part);
+    }
+    explain_ += "  expand: " + std::to_string(info.parts.size()) + " projection(s) of " + std::to_string(ncol) + " column(s)\n";
+    std::vector<DType> out;
+    for (auto& oc : info.out_cols) out.push_back(oc.type);
+    expand_info_[&op] = info;
+    return out;
   }
   if (op.kind == OpKind::ShuffleWriter) {
     // ShuffleWriterExec (shuffle_writer.rs:60-110): consumes its child, writes the data + index files, yields no batches
@@ -2078,6 +2166,10 @@ DevTable ExecutionContext::materialize(const Operator& op) {
     return take_rows(in, nullptr, off, std::max<int64_t>(0, end - off), nullptr);
   }
   if (op.kind == OpKind::ShuffleWriter) return write_shuffle(op);
+  if (op.kind == OpKind::Expand) {
+    DevTable in = materialize(*op.children[0]);
+    return expand(op, in);
+  }
   if (op.kind == OpKind::HashAgg) return nested_aggregate(op);   // an aggregate below other operators
   // Filter / Projection chain: fused over its source
   const Operator* src = &op;
@@ -2088,6 +2180,67 @@ DevTable ExecutionContext::materialize(const Operator& op) {
   return out;
 }
 
+
+
+DevTable ExecutionContext::expand(const Operator& ex, const DevTable& in) {
+  const ExpandInfo& info = expand_info_.at(&ex);
+  const size_t ncol = info.out_cols.size(), P = info.parts.size();
+  const int64_t n = in.rows, total = n * (int64_t)P;
+  if (total >= ((int64_t)1 << 32)) throw CometError("Expand: more than 2^32 output rows in one partition");
+  Variant u;   // unified description of the output columns; k_pack comes from the first generated projection
+  u.desc.out_cols = info.out_cols;
+  std::vector<std::shared_ptr<DevBuf>> vals(ncol), vbytes(ncol);
+  for (size_t c = 0; c < ncol; c++) {
+    vals[c] = std::make_shared<DevBuf>();
+    vbytes[c] = std::make_shared<DevBuf>();
+    vals[c]->ensure((size_t)std::max<int64_t>(total, 1) * (size_t)out_width(info.out_cols[c]) + 16);
+    vbytes[c]->ensure((size_t)std::max<int64_t>(total, 1) + 16);
+    HIP_CHECK(hipMemsetAsync(vbytes[c]->p, 1, (size_t)std::max<int64_t>(total, 1), stream_));   // outputs the kernels treat as non-nullable stay valid
+  }
+  timed_begin();
+  for (size_t p = 0; p < P; p++) {
+    const ExpandPart& part = info.parts[p];
+    const int64_t base = (int64_t)p * n;
+    if (!part.proj->project_list.empty()) {
+      auto pv = planned_variant(*part.proj, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[part.proj.get()] + 1)), in.has_valid, true, &in.types);
+      Variant v;
+      v.desc = pv->desc;
+      v.mod = jit_load(pv->code);
+      if (!u.mod) u.mod = v.mod;
+      CometKParams prm;
+      memset(&prm, 0, sizeof prm);
+      prm.n = n;
+      for (size_t i = 0; i < in.cols.size(); i++) {
+        prm.in[i].data = in.cols[i].data;
+        prm.in[i].valid = in.has_valid[i] ? in.cols[i].valid : nullptr;
+        prm.in[i].aux = in.cols[i].aux;
+        prm.in[i].offset = in.cols[i].offset;
+      }
+      prm.out[kOutErr] = err_flags_.p;
+      for (size_t k = 0; k < part.out_col.size(); k++) {
+        const size_t c = (size_t)part.out_col[k];
+        prm.out[kOutFirstCol + 2 * k] = (char*)vals[c]->p + (size_t)base * (size_t)out_width(info.out_cols[c]);
+        prm.out[kOutFirstCol + 2 * k + 1] = (char*)vbytes[c]->p + (size_t)base;
+      }
+      if (n) launch(v, "k_emit", (int)std::min<int64_t>((n + 255) / 256, 256 * 8), prm);
+      u.desc.kernels = v.desc.kernels;
+      HIP_CHECK(hipStreamSynchronize(stream_));   // v (and its module reference) goes out of scope
+    }
+    for (int c : part.null_cols) {
+      if (!n) continue;
+      HIP_CHECK(hipMemsetAsync((char*)vbytes[(size_t)c]->p + (size_t)base, 0, (size_t)n, stream_));
+      HIP_CHECK(hipMemsetAsync((char*)vals[(size_t)c]->p + (size_t)base * (size_t)out_width(info.out_cols[(size_t)c]), 0,
+                               (size_t)n * (size_t)out_width(info.out_cols[(size_t)c]), stream_));
+    }
+  }
+  timed_end();
+  if (!u.mod) throw CometError("Expand: every projection consists of NULL literals only");
+  DevTable out = outputs_to_table(u, vals, vbytes, total, [&](int c) { return std::make_pair(&in, c); });
+  out.owners.push_back(u.mod);
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  return out;
+}
 
 // ShuffleWriter (native/shuffle/src/shuffle_writer.rs:166-300, partitioners/multi_partition.rs:265-457, single_partition.rs):
 // the child's whole output is resident in HBM; partition ids (Spark murmur3 seed 42 chained over the hash expressions → pmod),

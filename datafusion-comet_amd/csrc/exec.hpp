@@ -139,6 +139,7 @@ class ExecutionContext {
   DevTable take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner);
   DevTable nested_aggregate(const Operator& agg);
   DevTable write_shuffle(const Operator& sw);
+  DevTable expand(const Operator& ex, const DevTable& in);
   void prepare_dict_keys(DevTable& src);
   static bool is_source(const Operator& op, const Operator* chain_top);
   typedef std::function<std::pair<const DevTable*, int>(int)> GatherSource;   // OutCol::gather_src → (table, column)
@@ -184,6 +185,16 @@ class ExecutionContext {
   bool materialize_root_ = false;   // plain Scan chain whose outputs need the materialising path (Utf8 pass-through)
   bool compile_in_infer_ = false;
   std::vector<const Operator*> nested_aggs_;
+  struct ExpandPart {
+    OperatorP proj;                 // Projection(non-NULL-string expressions) over a synthetic Scan of the child's schema
+    std::vector<int> out_col;       // functor output j → Expand output column
+    std::vector<int> null_cols;     // Expand output columns that are an untyped / Utf8 NULL literal in this projection
+  };
+  struct ExpandInfo {
+    std::vector<ExpandPart> parts;
+    std::vector<OutCol> out_cols;   // unified output schema
+  };
+  std::map<const Operator*, ExpandInfo> expand_info_;
   std::map<const Operator*, OperatorP> range_sort_, range_bsort_;   // ShuffleWriter(range) → synthetic Sort over its rows / its boundary rows
   std::shared_ptr<void> planes_owner_;
   std::map<const Operator*, OperatorP> shuffle_projs_;   // ShuffleWriter with computed hash expressions → synthetic Projection(child ++ hash exprs)

@@ -375,6 +375,20 @@ OperatorP decode_operator_r(Reader r) {
           else b.skip(wt2);
         }
         break;
+      case 107: {
+        op->kind = OpKind::Expand;
+        std::vector<ExprP> all;
+        int per = 0;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) all.push_back(decode_expr(b.sub()));
+          else if (f2 == 3 && wt2 == 0) per = (int)(int32_t)b.varint();
+          else b.skip(wt2);
+        }
+        if (per <= 0 || all.empty() || all.size() % (size_t)per != 0) throw CometError("Expand: project_list does not split into projections of num_expr_per_project expressions");
+        for (size_t i = 0; i < all.size(); i += (size_t)per) op->expand_projections.emplace_back(all.begin() + (long)i, all.begin() + (long)(i + (size_t)per));
+        break;
+      }
       case 106:
         op->kind = OpKind::ShuffleWriter;
         while (!b.done()) {

@@ -378,8 +378,9 @@ class Operator:
     codec: int = 0                              # CompressionCodec: 0 None, 1 Zstd, 2 Lz4, 3 Snappy
     compression_level: int = 1
     bounds: List[list] = field(default_factory=list)          # range partitioning: boundary rows (lists of literal Exprs), ascending
+    projections: List[list] = field(default_factory=list)     # expand: one list of Exprs per projection
 
-    TAGS = dict(shuffle_writer=106, shuffle_scan=116, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
+    TAGS = dict(shuffle_writer=106, shuffle_scan=116, expand=107, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -387,6 +388,9 @@ class Operator:
             out += _f_varint(2, self.plan_id)
         if self.kind == "scan":
             body = b"".join(_f_msg(1, f.encode()) for f in self.fields) + _f_bytes(2, b"test_scan")
+        elif self.kind == "expand":
+            # Expand{project_list=1 (all projections back to back), num_expr_per_project=3} (operator.proto:738-741)
+            body = b"".join(_f_msg(1, e.encode()) for proj in self.projections for e in proj) + _f_varint(3, len(self.projections[0]))
         elif self.kind == "shuffle_scan":
             # ShuffleScan{fields=1, source=2} (operator.proto:134-138)
             body = b"".join(_f_msg(1, f.encode()) for f in self.fields) + _f_bytes(2, b"CometShuffleExchangeExec [id=test]")
@@ -486,6 +490,11 @@ class Operator:
 
 def scan(fields: Sequence[DataType]) -> Operator:
     return Operator("scan", fields=list(fields))
+
+
+def expand(child: Operator, projections: Sequence[Sequence[Expr]]) -> Operator:
+    """One output row per input row and projection (grouping sets / rollup / cube)."""
+    return Operator("expand", [child], projections=[list(p) for p in projections])
 
 
 def shuffle_scan(fields: Sequence[DataType]) -> Operator:

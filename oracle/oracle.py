@@ -712,6 +712,32 @@ def run_plan(S, op, table) -> List[Col]:
         return [_take(c, idx) for c in child]
     if k == "projection":
         return [ev.eval(e, child, n) for e in op.exprs]
+    if k == "expand":
+        # ExpandExec (operators/expand.rs; planner.rs:1913-1948): each projection over the input, results stacked.  Row order between
+        # projections is an implementation detail (the reference interleaves per input batch); tests compare multisets.
+        parts = []
+        for proj in op.projections:
+            row = []
+            for e in proj:
+                if e.kind == "literal" and e.value is None:
+                    row.append(None)                      # untyped NULL: takes the column's type from another projection
+                else:
+                    row.append(ev.eval(e, child, n))
+            parts.append(row)
+        out = []
+        for j in range(len(op.projections[0])):
+            proto = next(r[j] for r in parts if r[j] is not None)
+            vals, oks = [], []
+            for r in parts:
+                if r[j] is None:
+                    vals.append(np.zeros(n, dtype=proto.values.dtype) if proto.values.dtype != object else np.array([None] * n, dtype=object))
+                    oks.append(np.zeros(n, bool))
+                else:
+                    vals.append(r[j].values)
+                    oks.append(r[j].ok())
+            ok = np.concatenate(oks)
+            out.append(Col(proto.dtype, np.concatenate(vals), None if ok.all() else ok))
+        return out
     if k == "hash_agg":
         return _hash_agg(S, ev, op, child, n)
     if k == "limit":
