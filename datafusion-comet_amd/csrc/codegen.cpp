@@ -1668,7 +1668,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     if (cur->kind == OpKind::Scan) break;
     // materialised sources: joins, Parquet scans, sorts, limits — and an aggregate BELOW other operators (nothing fuses
     // across a pipeline breaker: its result is materialised in HBM and read like a scan)
-    if (cur->kind == OpKind::HashJoin || cur->kind == OpKind::NativeScan || cur->kind == OpKind::Sort || cur->kind == OpKind::Limit || cur->kind == OpKind::Expand ||
+    if (cur->kind == OpKind::HashJoin || cur->kind == OpKind::NativeScan || cur->kind == OpKind::Sort || cur->kind == OpKind::Limit || cur->kind == OpKind::Expand || cur->kind == OpKind::Window ||
         (cur->kind == OpKind::HashAgg && cur != &root)) {
       if (!source_types) throw CometError("internal: materialised source without a schema");
       break;
@@ -2662,13 +2662,37 @@ PipelineDesc generate_sort_keys(const Operator& sort, const std::vector<DType>& 
   Gen g(types, valid);
   g.locate = [](int idx) { return std::make_pair(idx, std::string("i")); };
   int W = 0;
+  std::string dyn;                   // "+ prm.iarg[1] + …": plane offset contributed by the Utf8 keys seen so far
+  auto off = [&](int add) { return "((i64)" + std::to_string(W + add) + dyn + ")"; };
   std::vector<std::string> stores;   // statements writing the bytes of one row
   for (auto& k : sort.sort_orders) {
+    const std::string inv = k.descending ? "~" : "";
+    const bool str_col = k.child->kind == ExprKind::Bound && k.child->bound_index >= 0 && (size_t)k.child->bound_index < types.size() &&
+                         (types[(size_t)k.child->bound_index].id == TypeId::String || types[(size_t)k.child->bound_index].id == TypeId::Bytes);
+    if (str_col) {
+      // Utf8 column of any length: NULL-ordering byte, the bytes zero-padded to the column's longest value, then the length (big endian) —
+      // unsigned byte order like Spark's UTF8String.compareTo; equal padded bytes are ordered by length, so "ab" < "ab\0"
+      if (d.sort_str_cols.size() >= 6) throw CometError("Sort: more than 6 Utf8 sort keys are not supported");
+      const int idx = k.child->bound_index;
+      const std::string slot = "prm.iarg[" + std::to_string(1 + d.sort_str_cols.size()) + "]";
+      Val valid = g.str_col_validity(idx);
+      const std::string ok = valid.ok.empty() ? "true" : valid.ok;
+      const std::string c = "prm.in[" + std::to_string(idx) + "]";
+      stores.push_back("K[" + off(0) + " * n + i] = (u8)(" + ok + " ? " + (k.nulls_last ? "0" : "1") + " : " + (k.nulls_last ? "1" : "0") + ");");
+      stores.push_back("{ const i32* off_ = (const i32*)" + c + ".data; const i64 j_ = " + c + ".offset + i; const i32 lo_ = off_[j_], len_ = off_[j_ + 1] - lo_;"
+                       " const u8* p_ = (const u8*)" + c + ".aux + lo_; const i64 L_ = " + slot + " - 4; const i64 base_ = " + off(1) + ";"
+                       " for (i64 q_ = 0; q_ < L_; q_++) K[(base_ + q_) * n + i] = (u8)(" + ok + " ? " + inv + "(u8)(q_ < len_ ? p_[q_] : 0) : 0);"
+                       " for (int b_ = 0; b_ < 4; b_++) K[(base_ + L_ + b_) * n + i] = (u8)(" + ok + " ? " + inv + "(u8)((u32)len_ >> (24 - 8 * b_)) : 0); }");
+      W += 1;
+      dyn += " + " + slot;
+      d.sort_str_cols.push_back(idx);
+      ex << "  sort key: " << explain_expr(k.child) << (k.descending ? " DESC" : " ASC") << (k.nulls_last ? " NULLS LAST" : " NULLS FIRST") << "\n";
+      continue;
+    }
     Val v = g.named(g.gen(k.child));
     const std::string ok = v.ok.empty() ? "true" : v.ok;
-    const std::string inv = k.descending ? "~" : "";
     // NULL-ordering byte
-    stores.push_back("K[(i64)" + std::to_string(W) + " * n + i] = (u8)(" + ok + " ? " + (k.nulls_last ? "0" : "1") + " : " + (k.nulls_last ? "1" : "0") + ");");
+    stores.push_back("K[" + off(0) + " * n + i] = (u8)(" + ok + " ? " + (k.nulls_last ? "0" : "1") + " : " + (k.nulls_last ? "1" : "0") + ");");
     W++;
     int nb = 0;
     std::string word;   // unsigned order-preserving word(s)
@@ -2679,6 +2703,17 @@ PipelineDesc generate_sort_keys(const Operator& sort, const std::vector<DType>& 
       case Rep::F32: nb = 4; word = "(u64)((u32)comet::f32_total_key(" + v.v + ") ^ 0x80000000u)"; break;
       case Rep::F64: nb = 8; word = "((u64)comet::f64_total_key(" + v.v + ") ^ 0x8000000000000000ull)"; break;
       case Rep::I128: nb = 16; break;
+      case Rep::STR: {
+        // a computed string (≤ 15 bytes, packed): its 15 zero-padded bytes, then the length
+        for (int b = 0; b < 15; b++) {
+          const std::string byte = b < 8 ? "(" + v.v + ".a >> " + std::to_string(8 * b) + ")" : "(" + v.v + ".b >> " + std::to_string(8 * (b - 8)) + ")";
+          stores.push_back("K[" + off(b) + " * n + i] = (u8)(" + ok + " ? " + inv + "(u8)" + byte + " : 0);");
+        }
+        stores.push_back("K[" + off(15) + " * n + i] = (u8)(" + ok + " ? " + inv + "(u8)(" + v.v + ".b >> 56) : 0);");
+        W += 16;
+        ex << "  sort key: " << explain_expr(k.child) << (k.descending ? " DESC" : " ASC") << (k.nulls_last ? " NULLS LAST" : " NULLS FIRST") << "\n";
+        continue;
+      }
       default: throw CometError("Sort on " + v.t.str() + " is not supported by the MI355X native engine yet");
     }
     if (nb == 16) {
@@ -2686,12 +2721,12 @@ PipelineDesc generate_sort_keys(const Operator& sort, const std::vector<DType>& 
       const std::string v128 = v.rep == Rep::I128 ? v.v : "(i128)(i64)" + v.v;
       const std::string hi = "(comet::hi64(" + v128 + ") ^ 0x8000000000000000ull)", lo = "comet::lo64(" + v128 + ")";
       for (int b = 0; b < 8; b++)
-        stores.push_back("K[(i64)" + std::to_string(W + b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + hi + " >> " + std::to_string(56 - 8 * b) + ")) : 0);");
+        stores.push_back("K[" + off(b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + hi + " >> " + std::to_string(56 - 8 * b) + ")) : 0);");
       for (int b = 0; b < 8; b++)
-        stores.push_back("K[(i64)" + std::to_string(W + 8 + b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + lo + " >> " + std::to_string(56 - 8 * b) + ")) : 0);");
+        stores.push_back("K[" + off(8 + b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + lo + " >> " + std::to_string(56 - 8 * b) + ")) : 0);");
     } else {
       for (int b = 0; b < nb; b++)
-        stores.push_back("K[(i64)" + std::to_string(W + b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + word + " >> " + std::to_string(8 * (nb - 1 - b)) + ")) : 0);");
+        stores.push_back("K[" + off(b) + " * n + i] = (u8)(" + ok + " ? (" + inv + "(" + word + " >> " + std::to_string(8 * (nb - 1 - b)) + ")) : 0);");
     }
     W += nb;
     ex << "  sort key: " << explain_expr(k.child) << (k.descending ? " DESC" : " ASC") << (k.nulls_last ? " NULLS LAST" : " NULLS FIRST") << "\n";

@@ -39,7 +39,10 @@ struct PipelineDesc {
   std::vector<std::string> kernels;  // extern "C" kernel names present in `source`
   // static row bound under which decimal sums cannot overflow (Appendix C.1 rule); 0 = no limit
   long long max_rows_exact = 0;
-  int sort_key_bytes = 0;           // generate_sort_keys: width of one row's key
+  int sort_key_bytes = 0;           // generate_sort_keys: width of one row's key (the fixed part when Utf8 columns are sort keys)
+  // generate_sort_keys: Utf8 COLUMNS used as sort keys, in key order.  Their key bytes are the value zero-padded to the longest value of
+  // the column plus a 4-byte length; the executor measures that length L_s and passes L_s + 4 in prm.iarg[1 + s] (at most 6 such keys)
+  std::vector<int> sort_str_cols;
   bool join_build_only = false;     // LeftSemi/LeftAnti built on the left: only the tail pass produces rows
   bool join_outer_build = false;    // hash join that must also emit the build rows no probe row matched
   std::string explain;             // human-readable fused plan

@@ -177,6 +177,13 @@ extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const 
                                                  int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
+extern "C" int comet_launch_window_flags(const uint8_t* part_planes, int Wp, const uint8_t* order_planes, int Wo, int64_t n, uint32_t* fpart, uint32_t* fpeer, void* stream);
+extern "C" int comet_launch_window_first(const uint32_t* fpart, const int32_t* sp, const uint32_t* fpeer, const int32_t* sg, int64_t n, uint32_t* first_part,
+                                         uint32_t* first_peer, void* stream);
+extern "C" int comet_launch_window_rank(int kind, int64_t arg, const int32_t* sp, const int32_t* sg, const uint32_t* first_part, const uint32_t* first_peer, int64_t n,
+                                        void* out, void* stream);
+extern "C" int comet_launch_window_offset(int64_t shift, const int32_t* sp, const uint32_t* first_part, int64_t n, uint32_t* idx, uint8_t* ok, void* stream);
+extern "C" int comet_launch_window_offset_valid(const uint32_t* idx, const uint8_t* ok, const uint8_t* src_valid_bits, int64_t n, uint8_t* out_ok, void* stream);
 extern "C" int comet_launch_str_max_len(const int32_t* offs, int64_t n, uint32_t* out_max, void* stream);
 extern "C" int comet_launch_str_dict_build(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t n, uint32_t* table, int64_t slots,
                                            int64_t* rep, void* stream);
@@ -351,8 +358,17 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     node_id_[&op] = (int)node_id_.size();
     if (op.kind == OpKind::Scan) scan_input_[&op] = scan_input_.size();
     if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan || op.kind == OpKind::Sort || op.kind == OpKind::Limit || op.kind == OpKind::ShuffleWriter ||
-        op.kind == OpKind::Expand)
-      has_join_ = true;   // sources materialised in HBM
+        op.kind == OpKind::Expand || op.kind == OpKind::Window)
+      has_join_ = true;
+    if (op.kind == OpKind::Window) {
+      for (int t = 0; t < 2; t++) {
+        auto so = std::make_shared<Operator>();
+        so->kind = OpKind::Sort;
+        so->proto_tag = 103;
+        (t == 0 ? window_psort_ : window_osort_)[&op] = so;
+        node_id_[so.get()] = (int)node_id_.size();
+      }
+    }   // sources materialised in HBM
     if (op.kind == OpKind::ShuffleWriter) {
       if (&op != plan_.get()) throw CometError("ShuffleWriter must be the root of a native plan");
       bool computed = false;
@@ -458,7 +474,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
 // limits, and an aggregate that is not the top of the chain being fused.
 bool ExecutionContext::is_source(const Operator& op, const Operator* chain_top) {
   switch (op.kind) {
-    case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: case OpKind::ShuffleWriter: case OpKind::Expand: return true;
+    case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: case OpKind::ShuffleWriter: case OpKind::Expand: case OpKind::Window: return true;
     case OpKind::HashAgg: return &op != chain_top;
     default: return false;
   }
@@ -480,6 +496,47 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       explain_ += "  limit " + std::to_string(op.limit) + " offset " + std::to_string(op.offset) + "\n";
     }
     return st;
+  }
+  if (op.kind == OpKind::Window) {
+    // WindowAggExec / BoundedWindowAggExec (planner.rs:2267-2379): child columns ++ one column per window expression
+    if (op.children.size() != 1) throw CometError("Window expects exactly one child");
+    std::vector<DType> st = infer_schema(*op.children[0]);
+    Operator& ps = *window_psort_.at(&op);
+    Operator& os = *window_osort_.at(&op);
+    ps.sort_orders.clear();
+    for (auto& e : op.window_partition) {
+      Operator::SortKey k;
+      k.child = e;
+      ps.sort_orders.push_back(k);
+    }
+    os.sort_orders = op.window_order;
+    std::vector<bool> none(st.size(), false);
+    if (!ps.sort_orders.empty()) { PipelineDesc d = generate_sort_keys(ps, st, none); if (compile_in_infer_) jit_compile(d.source); }
+    if (!os.sort_orders.empty()) { PipelineDesc d = generate_sort_keys(os, st, none); if (compile_in_infer_) jit_compile(d.source); }
+    std::vector<DType> out = st;
+    for (auto& fn : op.window_fns) {
+      if (fn.is_agg) throw CometError("Window: aggregate functions over a frame are not supported by the MI355X native engine yet (ranking, ntile, lag and lead are)");
+      const std::string& f = fn.func;
+      auto int_lit = [](const ExprP& x) { return x->kind == ExprKind::Literal && !x->lit_null && x->dtype.is_integer(); };
+      if (f == "row_number" || f == "rank" || f == "dense_rank") out.push_back(DType::of(TypeId::Int32));
+      else if (f == "percent_rank" || f == "cume_dist") out.push_back(DType::of(TypeId::Double));
+      else if (f == "ntile") {
+        if (fn.args.size() != 1 || !int_lit(fn.args[0]) || fn.args[0]->lit_i64 <= 0) throw CometError("ntile expects a positive literal bucket count");
+        out.push_back(DType::of(TypeId::Int32));
+      } else if (f == "lag" || f == "lead") {
+        if (fn.args.size() < 1 || fn.args.size() > 3 || fn.args[0]->kind != ExprKind::Bound || fn.args[0]->bound_index < 0 || (size_t)fn.args[0]->bound_index >= st.size())
+          throw CometError(f + " is supported for a column argument");
+        if (fn.args.size() >= 2 && !int_lit(fn.args[1])) throw CometError(f + " expects a literal offset");
+        if (fn.args.size() == 3 && !(fn.args[2]->kind == ExprKind::Literal && fn.args[2]->lit_null)) throw CometError(f + " with a non-NULL default value is not supported yet");
+        if (fn.ignore_nulls) throw CometError(f + " IGNORE NULLS is not supported yet");
+        out.push_back(st[(size_t)fn.args[0]->bound_index]);
+      } else {
+        throw CometError(f + " not supported for window function");
+      }
+    }
+    explain_ += "  window: " + std::to_string(op.window_fns.size()) + " function(s), " + std::to_string(op.window_partition.size()) + " partition key(s), " +
+                std::to_string(op.window_order.size()) + " order key(s)\n";
+    return out;
   }
   if (op.kind == OpKind::Expand) {
     // ExpandExec (operators/expand.rs; planner.rs:1913-1948): every input row yields one output row per projection (grouping sets /
@@ -2170,6 +2227,10 @@ DevTable ExecutionContext::materialize(const Operator& op) {
     DevTable in = materialize(*op.children[0]);
     return expand(op, in);
   }
+  if (op.kind == OpKind::Window) {
+    DevTable in = materialize(*op.children[0]);
+    return window(op, in);
+  }
   if (op.kind == OpKind::HashAgg) return nested_aggregate(op);   // an aggregate below other operators
   // Filter / Projection chain: fused over its source
   const Operator* src = &op;
@@ -2181,6 +2242,105 @@ DevTable ExecutionContext::materialize(const Operator& op) {
 }
 
 
+
+// Window: ranking / ntile / lag / lead over input sorted by (partition keys, order keys) — see window_kernels.hip
+DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
+  const int64_t n = in.rows;
+  if (n >= ((int64_t)1 << 31)) throw CometError("Window: more than 2^31 rows in one partition of the plan");
+  DevTable out = in;
+  auto add_col = [&](const DType& t, std::shared_ptr<DevBuf> data, std::shared_ptr<DevBuf> valid_bits, std::shared_ptr<DevBuf> aux = nullptr) {
+    DeviceColumnView v;
+    v.data = data ? data->p : nullptr;
+    v.valid = valid_bits ? (const uint8_t*)valid_bits->p : nullptr;
+    v.aux = aux ? aux->p : nullptr;
+    out.types.push_back(t);
+    out.cols.push_back(v);
+    out.has_valid.push_back(valid_bits != nullptr);
+    if (data) out.owners.push_back(data);
+    if (valid_bits) out.owners.push_back(valid_bits);
+    if (aux) out.owners.push_back(aux);
+  };
+  if (n == 0) {
+    for (size_t k = 0; k < w.window_fns.size(); k++) {
+      const std::string& f = w.window_fns[k].func;
+      DType t = (f == "percent_rank" || f == "cume_dist") ? DType::of(TypeId::Double) : (f == "lag" || f == "lead") ? in.types[(size_t)w.window_fns[k].args[0]->bound_index] : DType::of(TypeId::Int32);
+      add_col(t, nullptr, nullptr);
+    }
+    return out;
+  }
+  timed_begin();
+  int Wp = 0, Wo = 0;
+  std::shared_ptr<DevBuf> pp, po;
+  if (!window_psort_.at(&w)->sort_orders.empty()) pp = sort_key_planes(*window_psort_.at(&w), in, Wp);
+  if (!window_osort_.at(&w)->sort_orders.empty()) po = sort_key_planes(*window_osort_.at(&w), in, Wo);
+  DevBuf fpart, fpeer, tiles;
+  auto sp = std::make_shared<DevBuf>(), sg = std::make_shared<DevBuf>(), first_part = std::make_shared<DevBuf>(), first_peer = std::make_shared<DevBuf>();
+  fpart.ensure((size_t)n * 4 + 16);
+  fpeer.ensure((size_t)n * 4 + 16);
+  tiles.ensure((size_t)((n + 1023) / 1024 + 2) * 8);
+  sp->ensure((size_t)(n + 2) * 4);
+  sg->ensure((size_t)(n + 2) * 4);
+  first_part->ensure((size_t)(n + 2) * 4);
+  first_peer->ensure((size_t)(n + 2) * 4);
+  if (comet_launch_window_flags(pp ? (const uint8_t*)pp->p : nullptr, Wp, po ? (const uint8_t*)po->p : nullptr, Wo, n, (uint32_t*)fpart.p, (uint32_t*)fpeer.p, stream_) != 0)
+    throw CometError("window: launch failed");
+  pq_launch_u32_scan((const uint32_t*)fpart.p, n, (uint64_t*)tiles.p, (int32_t*)sp->p, stream_);
+  pq_launch_u32_scan((const uint32_t*)fpeer.p, n, (uint64_t*)tiles.p, (int32_t*)sg->p, stream_);
+  if (comet_launch_window_first((const uint32_t*)fpart.p, (const int32_t*)sp->p, (const uint32_t*)fpeer.p, (const int32_t*)sg->p, n, (uint32_t*)first_part->p,
+                                (uint32_t*)first_peer->p, stream_) != 0)
+    throw CometError("window: launch failed");
+  for (auto& fn : w.window_fns) {
+    const std::string& f = fn.func;
+    int kind = f == "row_number" ? 0 : f == "rank" ? 1 : f == "dense_rank" ? 2 : f == "percent_rank" ? 3 : f == "cume_dist" ? 4 : f == "ntile" ? 5 : -1;
+    if (kind >= 0) {
+      const bool dbl = kind == 3 || kind == 4;
+      auto data = std::make_shared<DevBuf>();
+      data->ensure((size_t)n * (dbl ? 8 : 4) + 16);
+      if (comet_launch_window_rank(kind, kind == 5 ? fn.args[0]->lit_i64 : 0, (const int32_t*)sp->p, (const int32_t*)sg->p, (const uint32_t*)first_part->p,
+                                   (const uint32_t*)first_peer->p, n, data->p, stream_) != 0)
+        throw CometError("window: launch failed");
+      add_col(DType::of(dbl ? TypeId::Double : TypeId::Int32), data, nullptr);
+      continue;
+    }
+    // lag / lead: a gather with NULL outside the partition
+    const int c = fn.args[0]->bound_index;
+    const int64_t k = fn.args.size() >= 2 ? fn.args[1]->lit_i64 : 1;
+    const int64_t shift = f == "lag" ? -k : k;
+    const DType& t = in.types[(size_t)c];
+    const DeviceColumnView& sc = in.cols[(size_t)c];
+    if (sc.offset != 0) throw CometError(f + " over a column with a non-zero Arrow offset is not supported yet");
+    DevBuf ok;
+    auto idx = std::make_shared<DevBuf>(), okv = std::make_shared<DevBuf>(), bits = std::make_shared<DevBuf>();
+    idx->ensure((size_t)n * 4 + 16);
+    ok.ensure((size_t)n + 16);
+    okv->ensure((size_t)n + 16);
+    bits->ensure((size_t)((n + 7) / 8) + 16);
+    if (comet_launch_window_offset(shift, (const int32_t*)sp->p, (const uint32_t*)first_part->p, n, (uint32_t*)idx->p, (uint8_t*)ok.p, stream_) != 0 ||
+        comet_launch_window_offset_valid((const uint32_t*)idx->p, (const uint8_t*)ok.p, in.has_valid[(size_t)c] ? sc.valid : nullptr, n, (uint8_t*)okv->p, stream_) != 0)
+      throw CometError("window: launch failed");
+    pq_launch_pack((const uint8_t*)okv->p, (uint8_t*)bits->p, n, stream_);
+    if (t.id == TypeId::String || t.id == TypeId::Bytes) {
+      DeviceColumnView ov;
+      take_utf8(sc, (const uint32_t*)idx->p, (const uint8_t*)okv->p, nullptr, n, ov, out.owners);
+      ov.valid = (const uint8_t*)bits->p;
+      out.types.push_back(t);
+      out.cols.push_back(ov);
+      out.has_valid.push_back(true);
+      out.owners.push_back(bits);
+    } else {
+      const int wd = t.id == TypeId::Bool ? 0 : fixed_width(t);
+      auto data = std::make_shared<DevBuf>();
+      data->ensure((wd ? (size_t)n * (size_t)wd : (size_t)((n + 7) / 8)) + 16);
+      if (comet_launch_take(wd, sc.data, (const uint32_t*)idx->p, n, data->p, stream_) != 0) throw CometError("window: take failed");
+      add_col(t, data, bits);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));   // `ok` goes back to the pool; idx / okv are released with this scope
+  }
+  timed_end();
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  check_device_errors();
+  return out;
+}
 
 DevTable ExecutionContext::expand(const Operator& ex, const DevTable& in) {
   const ExpandInfo& info = expand_info_.at(&ex);
@@ -2299,14 +2459,23 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
       // order-preserving key bytes of every row and of every boundary row (same generated kernel, same widths), then an
       // upper-bound search per row: partition = number of boundaries ≤ row (multi_partition.rs:352-358)
       int W = 0, Wb = 0;
-      planes = sort_key_planes(*range_sort_.at(&sw), in, W);
       const int B = (int)sw.shuffle_bounds.size();
       std::vector<DType> btypes;
       for (auto& k : range_sort_.at(&sw)->sort_orders) btypes.push_back(k.child->dtype);
       DevTable bt = literal_table(sw.shuffle_bounds, btypes);
+      // Utf8 keys: rows and boundaries must be padded to the same length — the longer of the two
+      std::vector<int64_t> lr, lb;
+      {
+        int w0 = 0;
+        (void)sort_key_planes(*range_sort_.at(&sw), in, w0, &lr, true);              // measure only
+        if (B > 0) (void)sort_key_planes(*range_bsort_.at(&sw), bt, w0, &lb, true);
+        for (size_t s = 0; s < lr.size(); s++) lr[s] = std::max<int64_t>(lr[s], s < lb.size() ? lb[s] : 0);
+        lb = lr;
+      }
+      planes = sort_key_planes(*range_sort_.at(&sw), in, W, &lr);
       std::vector<uint8_t> rowmajor((size_t)std::max(B, 1) * (size_t)std::max(W, 1), 0);
       if (B > 0) {
-        auto bplanes = sort_key_planes(*range_bsort_.at(&sw), bt, Wb);
+        auto bplanes = sort_key_planes(*range_bsort_.at(&sw), bt, Wb, &lb);
         if (Wb != W) throw CometError("internal: range boundary keys and row keys differ in width");
         std::vector<uint8_t> pl((size_t)W * (size_t)B);
         HIP_CHECK(hipMemcpyAsync(pl.data(), bplanes->p, pl.size(), hipMemcpyDeviceToHost, stream_));
@@ -2566,7 +2735,7 @@ DevTable ExecutionContext::take_rows(const DevTable& in, const uint32_t* dev_per
 // Sort (planner.rs:1488-1522 → SortExec with fetch / skip): order-preserving key bytes per row (generated kernel), LSD radix
 // sort of a row permutation over the byte planes that actually vary, then one take per column of rows [skip, skip+fetch).
 // order-preserving key bytes of every row of `in` under sop.sort_orders, as W byte planes of n rows (plane p of row i at p·n + i)
-std::shared_ptr<DevBuf> ExecutionContext::sort_key_planes(const Operator& sop, const DevTable& in, int& W) {
+std::shared_ptr<DevBuf> ExecutionContext::sort_key_planes(const Operator& sop, const DevTable& in, int& W, std::vector<int64_t>* str_len, bool measure_only) {
   const int64_t n = in.rows;
   std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&sop] + 1))) + ":S:" + validity_key(in.has_valid);
   std::shared_ptr<PlannedVariant> pv;
@@ -2586,11 +2755,34 @@ std::shared_ptr<DevBuf> ExecutionContext::sort_key_planes(const Operator& sop, c
   v.desc = pv->desc;
   v.mod = jit_load(pv->code);
   W = v.desc.sort_key_bytes;
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  // Utf8 sort keys: padded to the longest value of the column (measured here, or imposed by the caller when two tables must share
+  // one key layout — range-partition boundaries)
+  std::vector<int64_t> lens;
+  for (size_t s = 0; s < v.desc.sort_str_cols.size(); s++) {
+    int64_t L = 0;
+    if (str_len && s < str_len->size() && !measure_only) L = (*str_len)[s];
+    else if (n > 0) {
+      const DeviceColumnView& sc = in.cols[(size_t)v.desc.sort_str_cols[s]];
+      uint32_t* mx = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 1);
+      HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
+      if (comet_launch_str_max_len((const int32_t*)sc.data + sc.offset, n, mx, stream_) != 0) throw CometError("sort: launch failed");
+      uint32_t longest = 0;
+      read_small(&longest, mx, 4);
+      HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
+      L = longest;
+    }
+    lens.push_back(L);
+    prm.iarg[1 + s] = L + 4;
+    W += (int)(L + 4);
+  }
+  if (str_len) *str_len = lens;
+  if (measure_only) return nullptr;
+  if (W > 1000) throw CometError("Sort key wider than 1000 bytes (Utf8 sort keys are padded to their longest value)");
   auto planes = std::make_shared<DevBuf>();
   planes->ensure((size_t)W * (size_t)std::max<int64_t>(n, 1) + 16);
   if (n == 0) return planes;
-  CometKParams prm;
-  memset(&prm, 0, sizeof prm);
   prm.n = n;
   for (size_t i = 0; i < in.cols.size(); i++) {
     prm.in[i].data = in.cols[i].data;
@@ -2674,7 +2866,7 @@ DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
   HIP_CHECK(hipMemsetAsync(flags.p, 0, (size_t)W * 4, stream_));
   if (comet_launch_sort_plane_varies((const uint8_t*)planes->p, n, W, (uint32_t*)flags.p, stream_) != 0) throw CometError("sort: launch failed");
   std::vector<uint32_t> varies((size_t)W);
-  small_host_.ensure(4096);
+  small_host_.ensure(std::max<size_t>(4096, (size_t)W * 4));
   HIP_CHECK(hipMemcpyAsync(small_host_.p, flags.p, (size_t)W * 4, hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipStreamSynchronize(stream_));
   memcpy(varies.data(), small_host_.p, (size_t)W * 4);

@@ -134,12 +134,13 @@ class ExecutionContext {
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
   DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix);
   DevTable sort_table(const Operator& s, const DevTable& in);
-  std::shared_ptr<DevBuf> sort_key_planes(const Operator& s, const DevTable& in, int& W);
+  std::shared_ptr<DevBuf> sort_key_planes(const Operator& s, const DevTable& in, int& W, std::vector<int64_t>* str_len = nullptr, bool measure_only = false);
   DevTable literal_table(const std::vector<std::vector<ExprP>>& rows, const std::vector<DType>& types);
   DevTable take_rows(const DevTable& in, const uint32_t* dev_perm, int64_t first, int64_t rows, std::shared_ptr<DevBuf> perm_owner);
   DevTable nested_aggregate(const Operator& agg);
   DevTable write_shuffle(const Operator& sw);
   DevTable expand(const Operator& ex, const DevTable& in);
+  DevTable window(const Operator& w, const DevTable& in);
   void prepare_dict_keys(DevTable& src);
   static bool is_source(const Operator& op, const Operator* chain_top);
   typedef std::function<std::pair<const DevTable*, int>(int)> GatherSource;   // OutCol::gather_src → (table, column)
@@ -195,6 +196,7 @@ class ExecutionContext {
     std::vector<OutCol> out_cols;   // unified output schema
   };
   std::map<const Operator*, ExpandInfo> expand_info_;
+  std::map<const Operator*, OperatorP> window_psort_, window_osort_;   // Window → synthetic Sorts describing its partition / order keys
   std::map<const Operator*, OperatorP> range_sort_, range_bsort_;   // ShuffleWriter(range) → synthetic Sort over its rows / its boundary rows
   std::shared_ptr<void> planes_owner_;
   std::map<const Operator*, OperatorP> shuffle_projs_;   // ShuffleWriter with computed hash expressions → synthetic Projection(child ++ hash exprs)

@@ -94,7 +94,7 @@ struct AggExpr {
 
 // Operator.op_struct oneof tags (operator.proto:32-79)
 enum class OpKind : int {
-  Scan = 100, Projection = 101, Filter = 102, Sort = 103, HashAgg = 104, Limit = 105, ShuffleWriter = 106, Expand = 107, HashJoin = 109,   // SortMergeJoin (108) decodes to HashJoin + smj
+  Scan = 100, Projection = 101, Filter = 102, Sort = 103, HashAgg = 104, Limit = 105, ShuffleWriter = 106, Expand = 107, HashJoin = 109, Window = 110,   // SortMergeJoin (108) decodes to HashJoin + smj
   NativeScan = 111, Unsupported = -1
 };
 
@@ -158,6 +158,19 @@ struct Operator {
   std::string session_timezone;
   bool case_sensitive = false;                 // NativeScanCommon.case_sensitive (proto3 default)
   std::vector<int64_t> default_values_indexes;  // required_schema positions that carry a default value
+  // Window (operator.proto:793-862): child columns ++ one column per window expression; input sorted by (partition, order) keys
+  struct WindowFn {
+    std::string func;               // built_in_window_function: ScalarFunc name (row_number, rank, dense_rank, percent_rank, cume_dist, ntile, lag, lead)
+    std::vector<ExprP> args;
+    bool is_agg = false;            // agg_func present (aggregate over a frame)
+    DType result_type;
+    bool has_result_type = false;
+    bool ignore_nulls = false;
+  };
+  std::vector<WindowFn> window_fns;
+  std::shared_ptr<Operator> window_child;   // Window.child (used when Operator.children is empty)
+  std::vector<SortKey> window_order;
+  std::vector<ExprP> window_partition;
   // Expand (operator.proto:738-741): project_list holds num_expr_per_project expressions per projection, back to back
   std::vector<std::vector<ExprP>> expand_projections;
   // ShuffleScan (operator.proto:134-138) decodes to Scan with this flag: its input is a stream of shuffle blocks

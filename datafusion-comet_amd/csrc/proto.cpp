@@ -375,6 +375,37 @@ OperatorP decode_operator_r(Reader r) {
           else b.skip(wt2);
         }
         break;
+      case 110: {
+        // Window{window_expr=1 (WindowExpr{built_in_window_function=1, agg_func=2, spec=3, ignore_nulls=4, result_type=5}), order_by_list=2,
+        //        partition_by_list=3, child=4}
+        op->kind = OpKind::Window;
+        OperatorP own_child;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) {
+            Reader w = b.sub();
+            Operator::WindowFn fn;
+            while (!w.done()) {
+              int wt3, f3 = w.tag(wt3);
+              if (f3 == 1 && wt3 == 2) {
+                ExprP e = decode_expr(w.sub());
+                if (e->kind != ExprKind::ScalarFunc) throw CometError(std::string(expr_name(e->proto_tag)) + " not supported for window function");
+                fn.func = e->func;
+                fn.args = e->children;
+              } else if (f3 == 2 && wt3 == 2) { fn.is_agg = true; w.skip(wt3); }
+              else if (f3 == 4 && wt3 == 0) fn.ignore_nulls = w.varint() != 0;
+              else if (f3 == 5 && wt3 == 2) { fn.result_type = decode_datatype(w.sub()); fn.has_result_type = true; }
+              else w.skip(wt3);
+            }
+            op->window_fns.push_back(fn);
+          } else if (f2 == 2 && wt2 == 2) op->window_order.push_back(decode_sort_order_expr(b.sub(), "Window"));
+          else if (f2 == 3 && wt2 == 2) op->window_partition.push_back(decode_expr(b.sub()));
+          else if (f2 == 4 && wt2 == 2) own_child = decode_operator_r(b.sub());
+          else b.skip(wt2);
+        }
+        if (own_child) op->window_child = own_child;
+        break;
+      }
       case 107: {
         op->kind = OpKind::Expand;
         std::vector<ExprP> all;
@@ -550,6 +581,7 @@ OperatorP decode_operator_r(Reader r) {
         op->kind = OpKind::Unsupported;
     }
   }
+  if (op->kind == OpKind::Window && op->children.empty() && op->window_child) op->children.push_back(op->window_child);
   return op;
 }
 

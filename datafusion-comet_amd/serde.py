@@ -379,8 +379,10 @@ class Operator:
     compression_level: int = 1
     bounds: List[list] = field(default_factory=list)          # range partitioning: boundary rows (lists of literal Exprs), ascending
     projections: List[list] = field(default_factory=list)     # expand: one list of Exprs per projection
+    window_fns: List[tuple] = field(default_factory=list)     # window: (function name, argument Exprs, result DataType)
+    partition_by: List[Expr] = field(default_factory=list)    # window
 
-    TAGS = dict(shuffle_writer=106, shuffle_scan=116, expand=107, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
+    TAGS = dict(shuffle_writer=106, shuffle_scan=116, expand=107, window=110, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -388,6 +390,19 @@ class Operator:
             out += _f_varint(2, self.plan_id)
         if self.kind == "scan":
             body = b"".join(_f_msg(1, f.encode()) for f in self.fields) + _f_bytes(2, b"test_scan")
+        elif self.kind == "window":
+            # Window{window_expr=1 (WindowExpr{built_in_window_function=1 (Expr.scalarFunc), spec=3, result_type=5}), order_by_list=2, partition_by_list=3}
+            # (operator.proto:793-862); the frame in spec is what Spark sends for ranking functions: ROWS UNBOUNDED PRECEDING .. CURRENT ROW
+            def so_expr(e, desc, nulls_last):
+                return _f_msg(19, _f_msg(1, e.encode()) + (_f_varint(2, 1) if desc else b"") + (_f_varint(3, 1) if nulls_last else b""))
+            frame = _f_msg(2, _f_msg(1, b"")) + _f_msg(3, _f_msg(3, b""))
+            spec = b"".join(_f_msg(1, e.encode()) for e in self.partition_by) + b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders) + _f_msg(3, frame)
+            body = b""
+            for name, args, rtype in self.window_fns:
+                fn = Expr("scalar_func", list(args), value=name)
+                body += _f_msg(1, _f_msg(1, fn.encode()) + _f_msg(3, spec) + _f_msg(5, rtype.encode()))
+            body += b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders)
+            body += b"".join(_f_msg(3, e.encode()) for e in self.partition_by)
         elif self.kind == "expand":
             # Expand{project_list=1 (all projections back to back), num_expr_per_project=3} (operator.proto:738-741)
             body = b"".join(_f_msg(1, e.encode()) for proj in self.projections for e in proj) + _f_varint(3, len(self.projections[0]))
@@ -495,6 +510,13 @@ def scan(fields: Sequence[DataType]) -> Operator:
 def expand(child: Operator, projections: Sequence[Sequence[Expr]]) -> Operator:
     """One output row per input row and projection (grouping sets / rollup / cube)."""
     return Operator("expand", [child], projections=[list(p) for p in projections])
+
+
+def window(child: Operator, partition_by: Sequence[Expr], order_by: Sequence, fns: Sequence[tuple]) -> Operator:
+    """fns: (name, [argument Exprs], result DataType) with name in row_number / rank / dense_rank / percent_rank / cume_dist / ntile / lag / lead;
+    order_by as for sort().  The child must deliver its rows sorted by (partition_by, order_by) — Spark plans that Sort."""
+    so = [(o[0], bool(o[1]), bool(o[2]) if len(o) > 2 else bool(o[1])) for o in order_by]
+    return Operator("window", [child], partition_by=list(partition_by), sort_orders=so, window_fns=[(n, list(a), t) for n, a, t in fns])
 
 
 def shuffle_scan(fields: Sequence[DataType]) -> Operator:

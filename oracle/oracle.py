@@ -712,6 +712,67 @@ def run_plan(S, op, table) -> List[Col]:
         return [_take(c, idx) for c in child]
     if k == "projection":
         return [ev.eval(e, child, n) for e in op.exprs]
+    if k == "window":
+        # WindowAggExec over sorted input (planner.rs:2267-2379): partitions / peer groups are runs of equal keys in the given order
+        pk = [ev.eval(e, child, n) for e in op.partition_by]
+        okeys = [ev.eval(e, child, n) for e, _, _ in op.sort_orders]
+
+        def cell(c, i):
+            if not c.ok()[i]:
+                return None
+            return dec_to_int(c.values, i) if c.dtype.type_id == S.DECIMAL else (c.values[i].item() if hasattr(c.values[i], "item") else c.values[i])
+        ptuple = [tuple(cell(c, i) for c in pk) for i in range(n)]
+        otuple = [tuple(cell(c, i) for c in okeys) for i in range(n)]
+        ps, gs = [0] * n, [0] * n          # partition start / peer-group start of every row
+        for i in range(n):
+            newp = i == 0 or ptuple[i] != ptuple[i - 1]
+            ps[i] = i if newp else ps[i - 1]
+            gs[i] = i if (newp or otuple[i] != otuple[i - 1]) else gs[i - 1]
+        pe, ge = [0] * n, [0] * n          # one past the partition / peer-group end
+        for i in range(n - 1, -1, -1):
+            pe[i] = i + 1 if (i == n - 1 or ps[i + 1] != ps[i]) else pe[i + 1]
+            ge[i] = i + 1 if (i == n - 1 or gs[i + 1] != gs[i]) else ge[i + 1]
+        out = list(child)
+        for name, args, rtype in op.window_fns:
+            if name in ("lag", "lead"):
+                src = ev.eval(args[0], child, n)
+                kk = int(args[1].value) if len(args) > 1 else 1
+                sh = -kk if name == "lag" else kk
+                idx = np.array([i + sh if ps[i] <= i + sh < pe[i] else -1 for i in range(n)], dtype=np.int64)
+                okv = (idx >= 0) & src.ok()[np.maximum(idx, 0)]
+                vals = src.values[np.maximum(idx, 0)]
+                if src.values.dtype == object:
+                    vals = np.array([v if o else None for v, o in zip(vals, okv)], dtype=object)
+                out.append(Col(src.dtype, vals, None if okv.all() else okv))
+                continue
+            rows = [pe[i] - ps[i] for i in range(n)]
+            rank = [gs[i] - ps[i] + 1 for i in range(n)]
+            if name == "row_number":
+                v = np.array([i - ps[i] + 1 for i in range(n)], np.int32)
+            elif name == "rank":
+                v = np.array(rank, np.int32)
+            elif name == "dense_rank":
+                dr, cur = [0] * n, 0
+                for i in range(n):
+                    cur = 1 if ps[i] == i else (cur + 1 if gs[i] == i else cur)
+                    dr[i] = cur
+                v = np.array(dr, np.int32)
+            elif name == "percent_rank":
+                v = np.array([(rank[i] - 1) / (rows[i] - 1) if rows[i] > 1 else 0.0 for i in range(n)], np.float64)
+            elif name == "cume_dist":
+                v = np.array([(ge[i] - ps[i]) / rows[i] for i in range(n)], np.float64)
+            elif name == "ntile":
+                kb = int(args[0].value)
+                res = []
+                for i in range(n):
+                    i0, q, r = i - ps[i], rows[i] // kb, rows[i] % kb
+                    thr = r * (q + 1)
+                    res.append(i0 // (q + 1) + 1 if i0 < thr else (i0 + 1 if q == 0 else (i0 - thr) // q + r + 1))
+                v = np.array(res, np.int32)
+            else:
+                raise NotImplementedError(f"oracle: window function {name}")
+            out.append(Col(S.T_DOUBLE if v.dtype == np.float64 else S.T_INT32, v, None))
+        return out
     if k == "expand":
         # ExpandExec (operators/expand.rs; planner.rs:1913-1948): each projection over the input, results stacked.  Row order between
         # projections is an implementation detail (the reference interleaves per input batch); tests compare multisets.

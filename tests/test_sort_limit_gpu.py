@@ -89,3 +89,25 @@ def test_tpch_q3_in_one_native_plan_with_take_ordered(built):
     final = O.run_plan_to_arrow(S, f, pstates)
     want = parallel.q3_top10(final)
     assert _cols(got, [0, 1, 2, 3]) == want and got.num_rows == 10
+
+
+@pytest.mark.parametrize("fetch", [None, 37])
+def test_sort_by_strings_of_any_length(built, fetch):
+    """ORDER BY Utf8 columns (TPC-H Q1's returnflag / linestatus, names, comments): key bytes = the value zero-padded to the column's longest
+    value + its length — unsigned byte order like UTF8String.compareTo, prefixes first — sorted by the same LSD radix passes over the planes
+    that vary; DESC, NULLS LAST, empty strings, embedded multi-byte characters, a computed substring key, and TopK."""
+    rng = np.random.default_rng(33)
+    n = 30_000
+    words = ["", "a", "ab", "ab\x00", "abc", "abd", "b", "Customer#000000001", "Customer#000000002", "Customer#00000001", "über", "ue", "zebra", "日本", "日本語", "Zebra",
+             "a much longer string that shares a long common prefix with others — 1", "a much longer string that shares a long common prefix with others — 2"]
+    s1 = [None if rng.random() < 0.05 else words[int(i)] for i in rng.integers(0, len(words), n)]
+    s2 = [None if rng.random() < 0.05 else "%s-%04d" % (words[int(i) % 7], int(j)) for i, j in zip(rng.integers(0, 50, n), rng.integers(0, 3000, n))]
+    t = pa.table({"s1": pa.array(s1, pa.string()), "s2": pa.array(s2, pa.string()), "id": pa.array(np.arange(n, dtype=np.int64)), "k": pa.array(rng.integers(0, 4, n), pa.int32())})
+    fields = [S.T_STRING, S.T_STRING, S.T_INT64, S.T_INT32]
+    a, b, i, k = (S.col(j, ty) for j, ty in enumerate(fields))
+    sub = S.scalar_func("substring", [b, S.lit(1, S.T_INT32), S.lit(3, S.T_INT32)], S.T_STRING)
+    for orders in ([(a, False, False), (b, True, True), (i, False, False)], [(k, True, False), (a, True, False), (i, True, True)], [(sub, False, True), (a, False, True), (i, False, False)]):
+        plan = S.sort(S.scan(fields), orders, fetch=fetch)
+        got, want = _run(plan, [t], 4), _oracle(plan, [t])
+        assert got.column(2).to_pylist() == want.column(2).to_pylist(), [o[1:] for o in orders]      # id makes the order total
+        assert got.column(0).to_pylist() == want.column(0).to_pylist()

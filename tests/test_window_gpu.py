@@ -1,0 +1,79 @@
+"""Window operator (110): ranking functions, ntile, lag and lead over input sorted by (partition keys, order keys) — the Sort Spark plans
+below every Window.  Flags on adjacent rows' order-preserving key bytes, two prefix sums and closed forms per function (window_kernels.hip)
+against the oracle's row-by-row evaluation.  Ties: Sort is not stable, so only tie-invariant functions are compared on tied keys."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native, serde as S, tpch
+
+pytestmark = pytest.mark.gpu
+
+D = S.decimal(12, 2)
+FIELDS = [S.T_STRING, S.T_INT32, D, S.T_INT64, S.T_STRING, S.T_DOUBLE]
+
+
+def _table(n, seed, unique_order):
+    rng = np.random.default_rng(seed)
+    cat = [None if rng.random() < 0.03 else ["Books", "Music", "Shoes", "Home"][int(i)] for i in rng.integers(0, 4, n)]
+    store = rng.integers(0, 5, n).astype(np.int32)
+    amount = rng.integers(0, 60, n) * 100 if not unique_order else rng.permutation(n) * 7 - 1000
+    return pa.table({"cat": pa.array(cat, pa.string()), "store": pa.array(store, mask=rng.random(n) < 0.03),
+                     "amount": tpch._dec128_array(np.asarray(amount, dtype=np.int64), 12, 2) if unique_order else
+                     pa.array([None if rng.random() < 0.05 else __import__("decimal").Decimal(int(a)).scaleb(-2) for a in amount], pa.decimal128(12, 2)),
+                     "id": pa.array(np.arange(n, dtype=np.int64)),
+                     "label": pa.array([None if rng.random() < 0.1 else "label-%d-with-a-long-tail" % int(i) for i in rng.integers(0, 500, n)]),
+                     "f": pa.array(rng.random(n), mask=rng.random(n) < 0.1)})
+
+
+def _plan(fns):
+    cat, store, amount = S.col(0, S.T_STRING), S.col(1, S.T_INT32), S.col(2, D)
+    order = [(amount, True, True)]
+    sorted_child = S.sort(S.scan(FIELDS), [(cat, False, False), (store, False, False)] + order)
+    return S.window(sorted_child, [cat, store], order, fns)
+
+
+def _rows(tb):
+    return sorted(zip(*[tb.column(i).to_pylist() for i in range(tb.num_columns)]), key=lambda r: r[3])
+
+
+def test_ranking_with_ties(built):
+    from oracle import oracle as O
+    t = _table(40_000, 7, unique_order=False)
+    fns = [("rank", [], S.T_INT32), ("dense_rank", [], S.T_INT32), ("percent_rank", [], S.T_DOUBLE), ("cume_dist", [], S.T_DOUBLE)]
+    plan = _plan(fns)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 10, plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, [t])
+    assert got.schema.types == want.schema.types
+    assert _rows(got) == _rows(want)
+    assert max(got.column(6).to_pylist()) > 50 and max(got.column(7).to_pylist()) > 20
+
+
+def test_all_functions_on_unique_order_keys(built):
+    from oracle import oracle as O
+    t = _table(30_000, 11, unique_order=True)
+    fns = [("row_number", [], S.T_INT32), ("rank", [], S.T_INT32), ("ntile", [S.lit(4, S.T_INT32)], S.T_INT32),
+           ("lag", [S.col(2, D), S.lit(1, S.T_INT32), S.lit(None, D)], D), ("lead", [S.col(4, S.T_STRING), S.lit(2, S.T_INT32), S.lit(None, S.T_STRING)], S.T_STRING),
+           ("lag", [S.col(5, S.T_DOUBLE), S.lit(3, S.T_INT32), S.lit(None, S.T_DOUBLE)], S.T_DOUBLE), ("lead", [S.col(3, S.T_INT64)], S.T_INT64)]
+    plan = _plan(fns)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 13, plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, [t])
+    assert got.schema.types == want.schema.types
+    assert _rows(got) == _rows(want)
+    # Window below other operators: top 3 per (cat, store) by amount — filter on the rank column above the Window
+    top = S.project(S.filter_(plan, S.lt_eq(S.col(6, S.T_INT32), S.lit(3, S.T_INT32))), [S.col(0, S.T_STRING), S.col(1, S.T_INT32), S.col(3, S.T_INT64), S.col(6, S.T_INT32)])
+    got2 = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 4, top.encode(), batch_size=0))
+    want2 = O.run_plan_to_arrow(S, top, [t])
+    key = lambda tb: sorted(zip(*[tb.column(i).to_pylist() for i in range(4)]), key=lambda r: r[2])
+    assert key(got2) == key(want2) and got2.num_rows <= 3 * 5 * 6
+
+
+def test_window_without_partition_or_order(built):
+    from oracle import oracle as O
+    t = _table(5_000, 3, unique_order=True)
+    plan = S.window(S.sort(S.scan(FIELDS), [(S.col(3, S.T_INT64), False, False)]), [], [(S.col(3, S.T_INT64), False, False)],
+                    [("row_number", [], S.T_INT32), ("lag", [S.col(3, S.T_INT64), S.lit(1, S.T_INT32)], S.T_INT64)])
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 8, plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, [t])
+    assert _rows(got) == _rows(want)
+    assert got.column(6).to_pylist() == list(range(1, 5001))
