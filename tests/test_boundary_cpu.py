@@ -44,7 +44,7 @@ def test_create_plan_failure_releases_input_stream(built):
     import pyarrow as pa
     t = pa.table({"a": pa.array([1, 2, 3], pa.int32())})
     inp = native.HostInput.from_table(t)
-    plan = S.Operator("raw", [S.scan([S.T_INT32])], raw_tag=110)  # Window
+    plan = S.Operator("raw", [S.scan([S.T_INT32])], raw_tag=114)  # Explode
     with pytest.raises(native.CometNativeException):
         native.Native.createPlan([inp], plan.encode())
     # ownership was transferred: the stream must have been released (release == NULL afterwards)

@@ -53,11 +53,11 @@ def test_create_release_balances_global_refs_and_releases_stream(jvm):
 def test_unsupported_plan_throws_comet_native_exception(jvm):
     t = pa.table({"a": pa.array([1], pa.int32())})
     inp = native.HostInput.from_table(t)
-    plan = S.Operator("raw", [S.scan([S.T_INT32])], raw_tag=110)   # Window
+    plan = S.Operator("raw", [S.scan([S.T_INT32])], raw_tag=114)   # Explode
     h = jvm.create_plan([inp.address], plan.encode())
     assert h == 0                                       # JNIDefault zero value (errors.rs:390-450)
     cls, msg = jvm.exception()
-    assert cls == "org/apache/comet/CometNativeException" and "Window" in msg
+    assert cls == "org/apache/comet/CometNativeException" and "Explode" in msg
     assert jvm.m.mock_live_global_refs() == 0
     assert not inp._c.release
 
