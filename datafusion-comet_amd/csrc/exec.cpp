@@ -177,6 +177,11 @@ extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const 
                                                  int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
+extern "C" int comet_launch_window_widen(int width, const void* src, const uint8_t* valid_bits, int64_t n, void* out128, void* hi128, uint32_t* ok, void* stream);
+extern "C" int comet_launch_scan128(const void* in128, int64_t n, void* tiles, void* out128, void* stream);
+extern "C" int comet_launch_window_agg(int fn, int frame, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,
+                                       const uint32_t* first_peer, int64_t n, const void* bound16, const void* scaler16, const void* avg_bound16, void* out, uint8_t* out_ok,
+                                       void* stream);
 extern "C" int comet_launch_window_flags(const uint8_t* part_planes, int Wp, const uint8_t* order_planes, int Wo, int64_t n, uint32_t* fpart, uint32_t* fpeer, void* stream);
 extern "C" int comet_launch_window_first(const uint32_t* fpart, const int32_t* sp, const uint32_t* fpeer, const int32_t* sg, int64_t n, uint32_t* first_part,
                                          uint32_t* first_peer, void* stream);
@@ -515,7 +520,26 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     if (!os.sort_orders.empty()) { PipelineDesc d = generate_sort_keys(os, st, none); if (compile_in_infer_) jit_compile(d.source); }
     std::vector<DType> out = st;
     for (auto& fn : op.window_fns) {
-      if (fn.is_agg) throw CometError("Window: aggregate functions over a frame are not supported by the MI355X native engine yet (ranking, ntile, lag and lead are)");
+      if (fn.is_agg) {
+        // SUM / COUNT / AVG of exact types over a frame that starts at the partition start (whole partition, or up to the current row /
+        // peer group) — the frames the reference runs with its own Spark-exact accumulators (planner.rs:2953-2972)
+        const AggExpr& a = fn.agg;
+        if (fn.frame_lower != 0 || fn.frame_upper == 1)
+          throw CometError("Window: only frames from UNBOUNDED PRECEDING to CURRENT ROW / UNBOUNDED FOLLOWING are supported for aggregate window functions");
+        if (a.children.size() != 1) throw CometError("Window: aggregate window functions take one argument");
+        const ExprP& arg = a.children[0];
+        const bool lit = arg->kind == ExprKind::Literal;
+        if (!lit && (arg->kind != ExprKind::Bound || arg->bound_index < 0 || (size_t)arg->bound_index >= st.size()))
+          throw CometError("Window: the argument of an aggregate window function must be a column (or a literal for COUNT)");
+        const DType at = lit ? arg->dtype : st[(size_t)arg->bound_index];
+        if (a.kind == AggKind::Count) out.push_back(DType::of(TypeId::Int64));
+        else if (lit) throw CometError("Window: SUM / AVG of a literal is not supported");
+        else if (a.kind == AggKind::Sum && at.id == TypeId::Decimal && a.dtype.id == TypeId::Decimal) out.push_back(a.dtype);
+        else if (a.kind == AggKind::Sum && at.is_integer()) out.push_back(DType::of(TypeId::Int64));
+        else if (a.kind == AggKind::Avg && at.id == TypeId::Decimal && a.dtype.id == TypeId::Decimal) out.push_back(a.dtype);
+        else throw CometError("Window: aggregate (tag " + std::to_string(a.proto_tag) + ") over " + at.str() + " is not supported yet (SUM / AVG of decimals, SUM of integers, COUNT are)");
+        continue;
+      }
       const std::string& f = fn.func;
       auto int_lit = [](const ExprP& x) { return x->kind == ExprKind::Literal && !x->lit_null && x->dtype.is_integer(); };
       if (f == "row_number" || f == "rank" || f == "dense_rank") out.push_back(DType::of(TypeId::Int32));
@@ -2243,7 +2267,13 @@ DevTable ExecutionContext::materialize(const Operator& op) {
 
 
 
-// Window: ranking / ntile / lag / lead over input sorted by (partition keys, order keys) — see window_kernels.hip
+static u128 pow10_u128_host(int p) {
+  u128 r = 1;
+  for (int i = 0; i < p; i++) r *= 10;
+  return r;
+}
+
+// Window: ranking / ntile / lag / lead and prefix-sum aggregates over input sorted by (partition keys, order keys) — see window_kernels.hip
 DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
   const int64_t n = in.rows;
   if (n >= ((int64_t)1 << 31)) throw CometError("Window: more than 2^31 rows in one partition of the plan");
@@ -2263,6 +2293,12 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
   if (n == 0) {
     for (size_t k = 0; k < w.window_fns.size(); k++) {
       const std::string& f = w.window_fns[k].func;
+      if (w.window_fns[k].is_agg) {
+        const AggExpr& a = w.window_fns[k].agg;
+        const bool dec = a.dtype.id == TypeId::Decimal && a.kind != AggKind::Count;
+        add_col(dec ? a.dtype : DType::of(TypeId::Int64), nullptr, nullptr);
+        continue;
+      }
       DType t = (f == "percent_rank" || f == "cume_dist") ? DType::of(TypeId::Double) : (f == "lag" || f == "lead") ? in.types[(size_t)w.window_fns[k].args[0]->bound_index] : DType::of(TypeId::Int32);
       add_col(t, nullptr, nullptr);
     }
@@ -2289,7 +2325,77 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
   if (comet_launch_window_first((const uint32_t*)fpart.p, (const int32_t*)sp->p, (const uint32_t*)fpeer.p, (const int32_t*)sg->p, n, (uint32_t*)first_part->p,
                                 (uint32_t*)first_peer->p, stream_) != 0)
     throw CometError("window: launch failed");
+  struct Prefix { std::shared_ptr<DevBuf> S, SH, C; };   // 128-bit inclusive sums (low part), sums of the high 64 bits (wide decimals only), non-NULL prefix counts
+  std::map<int, Prefix> prefix;                           // by argument column
   for (auto& fn : w.window_fns) {
+    if (fn.is_agg) {
+      const AggExpr& a = fn.agg;
+      const ExprP& arg = a.children[0];
+      const int c = arg->kind == ExprKind::Bound ? arg->bound_index : -1 - (int)(arg->lit_null ? 1 : 0);   // literals: −1 non-NULL, −2 NULL
+      auto it = prefix.find(c);
+      if (it == prefix.end()) {
+        auto S = std::make_shared<DevBuf>(), C = std::make_shared<DevBuf>();
+        std::shared_ptr<DevBuf> SH;
+        DevBuf wide, wide_hi, okf, t128, t32;
+        wide.ensure((size_t)n * 16 + 16);
+        okf.ensure((size_t)n * 4 + 16);
+        S->ensure((size_t)n * 16 + 16);
+        C->ensure((size_t)(n + 2) * 4);
+        t128.ensure((size_t)((n + 2047) / 2048 + 2) * 16);
+        t32.ensure((size_t)((n + 1023) / 1024 + 2) * 8);
+        const void* src = nullptr;
+        const uint8_t* vb = nullptr;
+        int width = 8;
+        if (c >= 0) {
+          const DeviceColumnView& sc = in.cols[(size_t)c];
+          if (sc.offset != 0) throw CometError("Window: aggregate over a column with a non-zero Arrow offset is not supported yet");
+          src = sc.data;
+          vb = in.has_valid[(size_t)c] ? sc.valid : nullptr;
+          width = in.types[(size_t)c].id == TypeId::Decimal ? 16 : fixed_width(in.types[(size_t)c]);
+        } else if (c == -2) {
+          // COUNT(NULL literal): no row counts — an all-zero validity bitmap
+          okf.ensure((size_t)((n + 7) / 8) + (size_t)n * 4 + 32);
+        }
+        DevBuf zero_bits;
+        if (c == -2) {
+          zero_bits.ensure((size_t)((n + 7) / 8) + 16);
+          HIP_CHECK(hipMemsetAsync(zero_bits.p, 0, (size_t)((n + 7) / 8), stream_));
+          vb = (const uint8_t*)zero_bits.p;
+        }
+        const bool split = c >= 0 && in.types[(size_t)c].id == TypeId::Decimal && in.types[(size_t)c].precision > 18;
+        if (split) {
+          wide_hi.ensure((size_t)n * 16 + 16);
+          SH = std::make_shared<DevBuf>();
+          SH->ensure((size_t)n * 16 + 16);
+        }
+        if (comet_launch_window_widen(width, src, vb, n, wide.p, split ? wide_hi.p : nullptr, (uint32_t*)okf.p, stream_) != 0 ||
+            comet_launch_scan128(wide.p, n, t128.p, S->p, stream_) != 0 || (split && comet_launch_scan128(wide_hi.p, n, t128.p, SH->p, stream_) != 0))
+          throw CometError("window: launch failed");
+        pq_launch_u32_scan((const uint32_t*)okf.p, n, (uint64_t*)t32.p, (int32_t*)C->p, stream_);
+        HIP_CHECK(hipStreamSynchronize(stream_));   // scratch goes back to the pool
+        it = prefix.emplace(c, Prefix{S, SH, C}).first;
+      }
+      const DType at = c >= 0 ? in.types[(size_t)c] : arg->dtype;
+      int fnk = a.kind == AggKind::Count ? 2 : a.kind == AggKind::Avg ? 3 : (at.id == TypeId::Decimal ? 0 : 1);
+      const int frame = fn.frame_upper == 0 ? 0 : (fn.frame_rows ? 1 : 2);
+      const DType rt = fnk == 2 || fnk == 1 ? DType::of(TypeId::Int64) : a.dtype;
+      // precision bounds: SUM checks the result type; AVG checks the sum type, scales by 10^(result scale − sum scale) and checks the result type
+      const DType sum_t = fnk == 3 ? a.sum_dtype : a.dtype;
+      u128 bound = fnk == 0 || fnk == 3 ? pow10_u128_host(sum_t.precision) - 1 : 0, avg_bound = fnk == 3 ? pow10_u128_host(a.dtype.precision) - 1 : 0;
+      i128 scaler = fnk == 3 ? (i128)pow10_u128_host(std::max(0, a.dtype.scale - sum_t.scale)) : 1;
+      auto data = std::make_shared<DevBuf>(), okb = std::make_shared<DevBuf>(), bits = std::make_shared<DevBuf>();
+      data->ensure((size_t)n * (fnk == 0 || fnk == 3 ? 16 : 8) + 16);
+      okb->ensure((size_t)n + 16);
+      bits->ensure((size_t)((n + 7) / 8) + 16);
+      if (comet_launch_window_agg(fnk, frame, it->second.S->p, it->second.SH ? it->second.SH->p : nullptr, (const int32_t*)it->second.C->p, (const int32_t*)sp->p, (const int32_t*)sg->p,
+                                  (const uint32_t*)first_part->p, (const uint32_t*)first_peer->p, n, &bound, &scaler, &avg_bound, data->p, (uint8_t*)okb->p, stream_) != 0)
+        throw CometError("window: launch failed");
+      pq_launch_pack((const uint8_t*)okb->p, (uint8_t*)bits->p, n, stream_);
+      add_col(rt, data, fnk == 2 ? nullptr : bits);
+      if (fnk == 2) out.owners.push_back(bits);
+      out.owners.push_back(okb);
+      continue;
+    }
     const std::string& f = fn.func;
     int kind = f == "row_number" ? 0 : f == "rank" ? 1 : f == "dense_rank" ? 2 : f == "percent_rank" ? 3 : f == "cume_dist" ? 4 : f == "ntile" ? 5 : -1;
     if (kind >= 0) {

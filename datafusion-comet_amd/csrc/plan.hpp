@@ -163,6 +163,9 @@ struct Operator {
     std::string func;               // built_in_window_function: ScalarFunc name (row_number, rank, dense_rank, percent_rank, cume_dist, ntile, lag, lead)
     std::vector<ExprP> args;
     bool is_agg = false;            // agg_func present (aggregate over a frame)
+    AggExpr agg;                    // the aggregate (children, result type)
+    bool frame_rows = true;         // WindowFrame.frame_type: ROWS (proto3 default) or RANGE
+    int frame_lower = 0, frame_upper = 2;   // 0 = UNBOUNDED, 1 = offset (PRECEDING / FOLLOWING), 2 = CURRENT ROW
     DType result_type;
     bool has_result_type = false;
     bool ignore_nulls = false;

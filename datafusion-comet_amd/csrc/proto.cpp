@@ -392,7 +392,30 @@ OperatorP decode_operator_r(Reader r) {
                 if (e->kind != ExprKind::ScalarFunc) throw CometError(std::string(expr_name(e->proto_tag)) + " not supported for window function");
                 fn.func = e->func;
                 fn.args = e->children;
-              } else if (f3 == 2 && wt3 == 2) { fn.is_agg = true; w.skip(wt3); }
+              } else if (f3 == 2 && wt3 == 2) { fn.is_agg = true; fn.agg = decode_agg_expr(w.sub()); }
+              else if (f3 == 3 && wt3 == 2) {
+                // WindowSpecDefinition{partitionSpec=1, orderSpec=2, frameSpecification=3 WindowFrame{frame_type=1, lower_bound=2, upper_bound=3}}
+                Reader sp = w.sub();
+                while (!sp.done()) {
+                  int wt4, f4 = sp.tag(wt4);
+                  if (f4 != 3 || wt4 != 2) { sp.skip(wt4); continue; }
+                  Reader fr = sp.sub();
+                  while (!fr.done()) {
+                    int wt5, f5 = fr.tag(wt5);
+                    if (f5 == 1 && wt5 == 0) fn.frame_rows = fr.varint() == 0;
+                    else if ((f5 == 2 || f5 == 3) && wt5 == 2) {
+                      Reader bd = fr.sub();
+                      int kind = f5 == 2 ? 0 : 2;   // proto3 default when the oneof is empty
+                      while (!bd.done()) {
+                        int wt6, f6 = bd.tag(wt6);
+                        kind = f6 == 1 ? 0 : f6 == 2 ? 1 : 2;
+                        bd.skip(wt6);
+                      }
+                      (f5 == 2 ? fn.frame_lower : fn.frame_upper) = kind;
+                    } else fr.skip(wt5);
+                  }
+                }
+              }
               else if (f3 == 4 && wt3 == 0) fn.ignore_nulls = w.varint() != 0;
               else if (f3 == 5 && wt3 == 2) { fn.result_type = decode_datatype(w.sub()); fn.has_result_type = true; }
               else w.skip(wt3);

@@ -10,6 +10,8 @@
 // and lag / lead are a gather with index i ∓ k when that row lies inside the partition (otherwise NULL).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "device/comet_device.hpp"
 
 using namespace comet;
@@ -93,9 +95,159 @@ __global__ __launch_bounds__(256) void window_offset_valid_kernel(const u32* __r
   }
 }
 
+// ---- aggregates over frames that start at the partition start (the only frames Comet hands to its own Spark-exact accumulators,
+// planner.rs:2953-2972): SUM / COUNT / AVG of exact types come from ONE inclusive prefix sum of the argument widened to 128 bits
+// (wrap-around cancels in the difference S[end−1] − S[start−1]) and one prefix count of its non-NULL rows:
+//   whole partition            [ps, pe)          ROWS  … CURRENT ROW   [ps, i + 1)          RANGE … CURRENT ROW   [ps, end of i's peer group)
+__global__ __launch_bounds__(256) void window_widen_kernel(int width, const void* __restrict__ src, const u8* __restrict__ valid_bits, i64 n,
+                                                           i128* __restrict__ out, i128* __restrict__ hi, u32* __restrict__ ok) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    const bool v = !valid_bits || ((valid_bits[i >> 3] >> (i & 7)) & 1);
+    i128 x = 0;
+    if (v && src) {
+      switch (width) {
+        case 1: x = ((const i8*)src)[i]; break;
+        case 2: x = ((const i16*)src)[i]; break;
+        case 4: x = ((const i32*)src)[i]; break;
+        case 8: x = ((const i64*)src)[i]; break;
+        default: x = ((const i128*)src)[i]; break;
+      }
+    }
+    if (hi) {   // wide decimals: the high and the low 64 bits are summed separately, so that no partition sum can wrap unnoticed
+      out[i] = (i128)(u64)x;
+      hi[i] = (i128)(i64)(x >> 64);
+    } else {
+      out[i] = x;
+    }
+    ok[i] = v ? 1u : 0u;
+  }
+}
+
+constexpr int kScanTile = 2048;   // rows per block in the 128-bit scan (256 threads × 8)
+
+__global__ __launch_bounds__(256) void scan128_tile_sum_kernel(const i128* __restrict__ in, i64 n, u128* __restrict__ tiles) {
+  __shared__ u128 part[256];
+  const i64 base = (i64)blockIdx.x * kScanTile;
+  u128 s = 0;
+  for (int k = 0; k < kScanTile / 256; k++) {
+    const i64 i = base + (i64)threadIdx.x * (kScanTile / 256) + k;
+    if (i < n) s += (u128)in[i];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tiles[blockIdx.x] = part[0];
+}
+__global__ void scan128_tiles_kernel(u128* tiles, i64 ntiles) {   // one thread: exclusive scan of the tile sums (ntiles = n / 2048)
+  if (threadIdx.x || blockIdx.x) return;
+  u128 run = 0;
+  for (i64 t = 0; t < ntiles; t++) {
+    const u128 v = tiles[t];
+    tiles[t] = run;
+    run += v;
+  }
+}
+__global__ __launch_bounds__(256) void scan128_apply_kernel(const i128* __restrict__ in, i64 n, const u128* __restrict__ tiles, i128* __restrict__ out) {
+  __shared__ u128 part[256];
+  const int per = kScanTile / 256;
+  const i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * per;
+  u128 loc[kScanTile / 256];
+  u128 s = 0;
+  for (int k = 0; k < per; k++) {
+    const i64 i = base + k;
+    s += i < n ? (u128)in[i] : (u128)0;
+    loc[k] = s;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  // exclusive scan of the 256 per-thread sums (Hillis–Steele on LDS)
+  for (int st = 1; st < 256; st <<= 1) {
+    u128 add = (int)threadIdx.x >= st ? part[threadIdx.x - st] : (u128)0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const u128 before = tiles[blockIdx.x] + (threadIdx.x ? part[threadIdx.x - 1] : (u128)0);
+  for (int k = 0; k < per; k++) {
+    const i64 i = base + k;
+    if (i < n) out[i] = (i128)(before + loc[k]);
+  }
+}
+
+enum { WA_SUM_DEC = 0, WA_SUM_INT = 1, WA_COUNT = 2, WA_AVG_DEC = 3 };
+enum { WF_WHOLE = 0, WF_ROWS_CURRENT = 1, WF_RANGE_CURRENT = 2 };
+
+// S: inclusive 128-bit prefix sums of the argument, C: exclusive prefix counts (n + 1) of its non-NULL rows
+__global__ __launch_bounds__(256) void window_agg_kernel(int fn, int frame, const i128* __restrict__ S, const i128* __restrict__ SH, const i32* __restrict__ C, const i32* __restrict__ sp,
+                                                         const i32* __restrict__ sg, const u32* __restrict__ first_part, const u32* __restrict__ first_peer, i64 n,
+                                                         u128 bound, i128 scaler, u128 avg_bound, void* __restrict__ out, u8* __restrict__ out_ok) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    const i32 p = sp[i + 1] - 1, g = sg[i + 1] - 1;
+    const i64 start = first_part[p];
+    const i64 end = frame == WF_WHOLE ? (i64)first_part[p + 1] : frame == WF_ROWS_CURRENT ? i + 1 : (i64)first_peer[g + 1];
+    i128 total = (i128)((u128)S[end - 1] - (start ? (u128)S[start - 1] : (u128)0));
+    bool wrapped = false;
+    if (SH) {
+      // total = hi·2^64 + lo with both parts exact; anything that does not fit 127 bits is far beyond every decimal precision
+      const i128 hs = SH[end - 1] - (start ? SH[start - 1] : (i128)0);
+      if (hs >= ((i128)1 << 63) || hs < -((i128)1 << 63)) wrapped = true;
+      else wrapped = __builtin_add_overflow((i128)((u128)hs << 64), total, &total);
+    }
+    const i64 cnt = wrapped ? 0 : (i64)C[end] - (i64)C[start];   // a wrapped sum evaluates to NULL like an overflowed one
+    switch (fn) {
+      case WA_SUM_DEC: {   // SumDecimal evaluate (sum_decimal.rs:264-279): NULL if no value or out of precision
+        const bool ok = cnt > 0 && dec_fits(total, bound);
+        ((i128*)out)[i] = ok ? total : (i128)0;
+        out_ok[i] = ok ? 1 : 0;
+        break;
+      }
+      case WA_SUM_INT: ((i64*)out)[i] = cnt > 0 ? (i64)total : 0; out_ok[i] = cnt > 0 ? 1 : 0; break;   // SumInteger: wrapping, NULL if no value
+      case WA_COUNT: ((i64*)out)[i] = cnt; out_ok[i] = 1; break;
+      case WA_AVG_DEC: {   // AvgDecimal evaluate (avg_decimal.rs:597-636, 670-689)
+        i128 v = 0;
+        const bool ok = cnt > 0 && dec_fits(total, bound) && dec_avg(total, cnt, scaler, avg_bound, v);
+        ((i128*)out)[i] = ok ? v : (i128)0;
+        out_ok[i] = ok ? 1 : 0;
+        break;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int comet_launch_window_widen(int width, const void* src, const uint8_t* valid_bits, int64_t n, void* out128, void* hi128, uint32_t* ok, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(window_widen_kernel, grid_for(n), 256, 0, (hipStream_t)stream, width, src, valid_bits, (i64)n, (i128*)out128, (i128*)hi128, ok);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// inclusive prefix sums of n 128-bit integers (wrapping); tiles: (n / 2048 + 2) × 16 bytes of scratch
+int comet_launch_scan128(const void* in128, int64_t n, void* tiles, void* out128, void* stream) {
+  if (n <= 0) return 0;
+  const int64_t nt = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(scan128_tile_sum_kernel, (int)nt, 256, 0, (hipStream_t)stream, (const i128*)in128, (i64)n, (u128*)tiles);
+  hipLaunchKernelGGL(scan128_tiles_kernel, 1, 64, 0, (hipStream_t)stream, (u128*)tiles, (i64)nt);
+  hipLaunchKernelGGL(scan128_apply_kernel, (int)nt, 256, 0, (hipStream_t)stream, (const i128*)in128, (i64)n, (const u128*)tiles, (i128*)out128);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_window_agg(int fn, int frame, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,
+                            const uint32_t* first_peer, int64_t n, const void* bound16, const void* scaler16, const void* avg_bound16, void* out, uint8_t* out_ok,
+                            void* stream) {
+  u128 bound, avg_bound;
+  i128 scaler;
+  memcpy(&bound, bound16, 16);
+  memcpy(&scaler, scaler16, 16);
+  memcpy(&avg_bound, avg_bound16, 16);
+  if (n > 0)
+    hipLaunchKernelGGL(window_agg_kernel, grid_for(n), 256, 0, (hipStream_t)stream, fn, frame, (const i128*)S128, (const i128*)SH128, C, sp, sg, first_part, first_peer, (i64)n, bound, scaler,
+                       avg_bound, out, out_ok);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 
 int comet_launch_window_flags(const uint8_t* part_planes, int Wp, const uint8_t* order_planes, int Wo, int64_t n, uint32_t* fpart, uint32_t* fpeer, void* stream) {
   if (n > 0) hipLaunchKernelGGL(window_flags_kernel, grid_for(n), 256, 0, (hipStream_t)stream, part_planes, Wp, order_planes, Wo, (i64)n, fpart, fpeer);

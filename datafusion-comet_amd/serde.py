@@ -398,7 +398,15 @@ class Operator:
             frame = _f_msg(2, _f_msg(1, b"")) + _f_msg(3, _f_msg(3, b""))
             spec = b"".join(_f_msg(1, e.encode()) for e in self.partition_by) + b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders) + _f_msg(3, frame)
             body = b""
-            for name, args, rtype in self.window_fns:
+            for wf in self.window_fns:
+                if wf[0] == "agg":
+                    # aggregate over a frame: ("agg", AggExpr, result type, (rows|range, unbounded|current, unbounded|current))
+                    _, agg, rtype, (ftype, lo, up) = wf
+                    fr = (_f_varint(1, 1) if ftype == "range" else b"") + _f_msg(2, _f_msg(1 if lo == "unbounded" else 3, b"")) + _f_msg(3, _f_msg(1 if up == "unbounded" else 3, b""))
+                    aspec = b"".join(_f_msg(1, e.encode()) for e in self.partition_by) + b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders) + _f_msg(3, fr)
+                    body += _f_msg(1, _f_msg(2, agg.encode()) + _f_msg(3, aspec) + _f_msg(5, rtype.encode()))
+                    continue
+                name, args, rtype = wf
                 fn = Expr("scalar_func", list(args), value=name)
                 body += _f_msg(1, _f_msg(1, fn.encode()) + _f_msg(3, spec) + _f_msg(5, rtype.encode()))
             body += b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders)
@@ -516,7 +524,7 @@ def window(child: Operator, partition_by: Sequence[Expr], order_by: Sequence, fn
     """fns: (name, [argument Exprs], result DataType) with name in row_number / rank / dense_rank / percent_rank / cume_dist / ntile / lag / lead;
     order_by as for sort().  The child must deliver its rows sorted by (partition_by, order_by) — Spark plans that Sort."""
     so = [(o[0], bool(o[1]), bool(o[2]) if len(o) > 2 else bool(o[1])) for o in order_by]
-    return Operator("window", [child], partition_by=list(partition_by), sort_orders=so, window_fns=[(n, list(a), t) for n, a, t in fns])
+    return Operator("window", [child], partition_by=list(partition_by), sort_orders=so, window_fns=[tuple(f) for f in fns])
 
 
 def shuffle_scan(fields: Sequence[DataType]) -> Operator:

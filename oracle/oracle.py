@@ -733,7 +733,46 @@ def run_plan(S, op, table) -> List[Col]:
             pe[i] = i + 1 if (i == n - 1 or ps[i + 1] != ps[i]) else pe[i + 1]
             ge[i] = i + 1 if (i == n - 1 or gs[i + 1] != gs[i]) else ge[i + 1]
         out = list(child)
-        for name, args, rtype in op.window_fns:
+        for wf in op.window_fns:
+            if wf[0] == "agg":
+                # SUM / COUNT / AVG over [partition start, frame end): exact integer arithmetic, evaluated like the aggregates'
+                # Final step (sum_decimal.rs:264-279, sum_int.rs, avg_decimal.rs:597-689)
+                _, a, rtype, (ftype, lo, up) = wf
+                assert lo == "unbounded"
+                arg = ev.eval(a.children[0], child, n)
+                isdec = arg.dtype.type_id == S.DECIMAL
+                ival = [(dec_to_int(arg.values, i) if isdec else int(arg.values[i])) if arg.ok()[i] else None for i in range(n)]
+                vals, oks = [], []
+                for i in range(n):
+                    end = pe[i] if up == "unbounded" else (i + 1 if ftype == "rows" else ge[i])
+                    win = [v for v in ival[ps[i]:end] if v is not None]
+                    if a.kind == "count":
+                        vals.append(len(win)); oks.append(True); continue
+                    if not win:
+                        vals.append(0); oks.append(False); continue
+                    tot = sum(win)
+                    if a.kind == "sum" and not isdec:
+                        tot &= (1 << 64) - 1
+                        vals.append(tot - (1 << 64) if tot >> 63 else tot); oks.append(True); continue
+                    st = a.sum_dtype if a.kind == "avg" else a.dtype
+                    if abs(tot) > 10**st.precision - 1:
+                        vals.append(0); oks.append(False); continue
+                    if a.kind == "sum":
+                        vals.append(tot); oks.append(True); continue
+                    v = tot * 10**max(0, a.dtype.scale - st.scale)
+                    c = len(win)
+                    q, r = abs(v) // c, abs(v) % c
+                    q = q + 1 if r >= (c + 1) // 2 else q
+                    q = q if v >= 0 else -q
+                    okv = abs(q) <= 10**a.dtype.precision - 1
+                    vals.append(q if okv else 0); oks.append(okv)
+                okn = np.array(oks, bool)
+                if a.kind == "count" or (a.kind == "sum" and not isdec):
+                    out.append(Col(S.T_INT64, np.array(vals, np.int64), None if okn.all() else okn))
+                else:
+                    out.append(Col(a.dtype, ints_to_dec(vals), None if okn.all() else okn))
+                continue
+            name, args, rtype = wf
             if name in ("lag", "lead"):
                 src = ev.eval(args[0], child, n)
                 kk = int(args[1].value) if len(args) > 1 else 1
