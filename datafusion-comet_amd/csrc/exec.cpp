@@ -773,8 +773,6 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
   std::vector<DType> st = infer_schema(*src);
   std::vector<bool> none(st.size(), false);
   PipelineDesc d = generate_pipeline(op, none, &st);
-  if (d.sink == SinkKind::AggNoGroup && &op != plan_.get())
-    throw CometError("an ungrouped aggregate below other operators in the same native plan is not supported yet");
   if (compile_in_infer_) jit_compile(d.source);
   explain_ += d.explain;
   std::vector<DType> out;
@@ -3073,16 +3071,51 @@ DevTable ExecutionContext::nested_aggregate(const Operator& agg) {
   // the sub-plan shares the Operator nodes: wrap the node in a non-owning shared_ptr
   OperatorP sub_plan(const_cast<Operator*>(&agg), [](Operator*) {});
   ExecutionContext sub(sub_plan, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&agg] + 1)), config_, sub_inputs, 0, device_id_);
-  if (sub.sink_ != SinkKind::AggGrouped) throw CometError("an ungrouped aggregate below other operators in the same native plan is not supported yet");
+  if (sub.sink_ != SinkKind::AggGrouped && sub.sink_ != SinkKind::AggNoGroup) throw CometError("internal: nested aggregate without an aggregate sink");
   sub.device_result_ = true;
   sub.start();
   sub.run_to_completion();
-  DevTable t = sub.grouped_to_device();
+  DevTable t;
+  if (sub.sink_ == SinkKind::AggNoGroup) {
+    // an ungrouped aggregate yields exactly one row (TPC-H Q14 / Q17 / Q19 compute on it): finish it the usual way, then put that row
+    // back into HBM for the operators above
+    sub.finish_aggregate();
+    if (sub.ready_.empty()) throw CometError("internal: ungrouped aggregate produced no row");
+    t = host_batch_to_table(sub.ready_.front());
+    sub.ready_.clear();
+  } else {
+    t = sub.grouped_to_device();
+  }
   input_rows += sub.input_rows;
   for (auto& pr : sub.timed_) (void)pr;
   sub.collect_timings();
   last_kernel_ms += sub.last_kernel_ms;
   last_kernel_launches += sub.last_kernel_launches;
+  return t;
+}
+
+// a (small) host batch → resident table
+DevTable ExecutionContext::host_batch_to_table(const HostBatch& b) {
+  DevTable t;
+  t.rows = b.rows;
+  auto up = [&](const std::vector<uint8_t>& v) -> const void* {
+    auto d = std::make_shared<DevBuf>();
+    d->ensure(v.size() + 16);
+    if (!v.empty()) HIP_CHECK(hipMemcpy(d->p, v.data(), v.size(), hipMemcpyHostToDevice));
+    t.owners.push_back(d);
+    return d->p;
+  };
+  for (const HostColumn& c : b.cols) {
+    DeviceColumnView v;
+    v.data = up(c.values);
+    const bool is_str = c.type.id == TypeId::String || c.type.id == TypeId::Bytes;
+    if (is_str) v.aux = up(c.data);
+    const bool hv = c.null_count > 0 && !c.validity.empty();
+    if (hv) v.valid = (const uint8_t*)up(c.validity);
+    t.types.push_back(c.type);
+    t.cols.push_back(v);
+    t.has_valid.push_back(hv);
+  }
   return t;
 }
 

@@ -149,6 +149,7 @@ class ExecutionContext {
   void take_utf8(const DeviceColumnView& src, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t rows,
                  DeviceColumnView& out, std::vector<std::shared_ptr<void>>& owners);
   void table_to_host_batches(const DevTable& t);
+  DevTable host_batch_to_table(const HostBatch& b);
   bool pull_host_chunk();
   bool pull_device_batch();
   bool pull_host_table(size_t input, const std::vector<DType>& types, int64_t max_rows, std::vector<DeviceColumnView>& views,

@@ -210,6 +210,10 @@ class Expr:
 
 
 def lit(value, dtype: DataType) -> Expr:
+    """Decimal literals carry the UNSCALED integer (literal.proto:38); a decimal.Decimal is converted with the type's scale."""
+    import decimal as _d
+    if dtype.type_id == DECIMAL and isinstance(value, _d.Decimal):
+        value = int(value.scaleb(dtype.scale).to_integral_exact())
     return Expr("literal", dtype=dtype, value=value)
 
 

@@ -191,7 +191,8 @@ def test_range_partitioning_matches_oracle(built, tmp_path):
         dd.mkdir()
         data, index = _write(S.scan(FIELDS), [t], dd, partitioning="range", sort_orders=orders, bounds=bounds, num_partitions=P, batch_size=8192)
         keys = [(t.column(e.index).cast(pa.int32()) if pa.types.is_date(t.column(e.index).type) else t.column(e.index)).to_pylist() for e, _, _ in orders]
-        bvals = [[b.value for b in row] for row in bounds]
+        unscale = lambda b: decimal.Decimal(b.value).scaleb(-b.dtype.scale) if (b.dtype.type_id == S.DECIMAL and b.value is not None) else b.value
+        bvals = [[unscale(b) for b in row] for row in bounds]
         pids = SO.range_partition_ids(keys, [(desc, nl) for _, desc, nl in orders], bvals)
         starts, idx = O.partition_starts_and_indices(pids, P)
         rows = [idx[starts[p]:starts[p + 1]] for p in range(P)]

@@ -1,0 +1,142 @@
+"""More TPC-H query shapes end to end on the GPU, each against the oracle and a direct Python evaluation:
+Q12 (IN on strings, column-to-column date comparisons, conditional sums, ORDER BY a string key), Q14 (LIKE inside CASE WHEN, a wide-decimal
+product, a decimal quotient of two aggregates) and Q19 (an OR of three conjunctions mixing string IN, BETWEEN and equality)."""
+import datetime
+import decimal
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native, serde as S, tpch
+
+pytestmark = pytest.mark.gpu
+
+D = S.decimal(12, 2)
+I64, I32, STR, DATE = S.T_INT64, S.T_INT32, S.T_STRING, S.T_DATE
+MODES = ["MAIL", "SHIP", "AIR", "REG AIR", "RAIL", "TRUCK", "FOB"]
+PRIOS = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]
+TYPES = ["PROMO BRUSHED COPPER", "STANDARD POLISHED BRASS", "PROMO PLATED STEEL", "ECONOMY ANODIZED TIN", "MEDIUM BURNISHED NICKEL", "PROMO"]
+BRANDS = ["Brand#12", "Brand#23", "Brand#34", "Brand#45"]
+CONTAINERS = ["SM CASE", "SM BOX", "SM PACK", "SM PKG", "MED BAG", "MED BOX", "MED PKG", "MED PACK", "LG CASE", "LG BOX", "LG PACK", "LG PKG", "JUMBO JAR"]
+INSTRUCT = ["DELIVER IN PERSON", "COLLECT COD", "NONE", "TAKE BACK RETURN"]
+
+
+def _tables(no=20_000, nparts=2_000, seed=12):
+    rng = np.random.default_rng(seed)
+    orders = pa.table({"o_orderkey": pa.array(np.arange(1, no + 1, dtype=np.int64)), "o_orderpriority": pa.array([PRIOS[int(i)] for i in rng.integers(0, 5, no)])})
+    items = rng.integers(1, 8, no)
+    lo = np.repeat(np.arange(1, no + 1, dtype=np.int64), items)
+    n = len(lo)
+    ship = rng.integers(tpch.days(1993, 6, 1), tpch.days(1995, 6, 1), n).astype(np.int32)
+    commit = (ship + rng.integers(-40, 40, n)).astype(np.int32)
+    receipt = (ship + rng.integers(1, 40, n)).astype(np.int32)
+    d32 = lambda a: pa.array(a, pa.int32()).cast(pa.date32())
+    lineitem = pa.table({
+        "l_orderkey": pa.array(lo), "l_partkey": pa.array(rng.integers(1, nparts + 1, n)),
+        "l_quantity": tpch._dec128_array(rng.integers(1, 51, n) * 100, 12, 2), "l_extendedprice": tpch._dec128_array(rng.integers(90_000, 10_000_000, n), 12, 2),
+        "l_discount": tpch._dec128_array(rng.integers(0, 11, n), 12, 2), "l_shipdate": d32(ship), "l_commitdate": d32(commit), "l_receiptdate": d32(receipt),
+        "l_shipmode": pa.array([None if rng.random() < 0.01 else MODES[int(i)] for i in rng.integers(0, len(MODES), n)]),
+        "l_shipinstruct": pa.array([INSTRUCT[int(i)] for i in rng.integers(0, 4, n)]),
+    })
+    part = pa.table({"p_partkey": pa.array(np.arange(1, nparts + 1, dtype=np.int64)), "p_type": pa.array([TYPES[int(i)] for i in rng.integers(0, len(TYPES), nparts)]),
+                     "p_brand": pa.array([BRANDS[int(i)] for i in rng.integers(0, 4, nparts)]), "p_container": pa.array([CONTAINERS[int(i)] for i in rng.integers(0, len(CONTAINERS), nparts)]),
+                     "p_size": pa.array(rng.integers(1, 51, nparts).astype(np.int32))})
+    return orders, lineitem, part
+
+
+LI = [I64, I64, D, D, D, DATE, DATE, DATE, STR, STR]
+run = lambda plan, tbs, nc: pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(x) for x in tbs], nc, plan.encode(), batch_size=0))
+rows = lambda tb: list(zip(*[tb.column(i).to_pylist() for i in range(tb.num_columns)]))
+date = lambda y, m, d: (datetime.date(y, m, d) - datetime.date(1970, 1, 1)).days
+c = S.col
+L = lambda s: S.lit(s, STR)
+
+
+def _revenue(price, disc):
+    one_minus = S.check_overflow(S.math("subtract", S.lit(100, D), disc, S.decimal(13, 2)), S.decimal(13, 2))
+    return S.check_overflow(S.math("multiply", price, one_minus, S.decimal(26, 4)), S.decimal(26, 4))
+
+
+def test_q12_shipping_modes(built):
+    from oracle import oracle as O
+    orders, lineitem, _ = _tables()
+    li = S.filter_(S.scan(LI), S.and_(S.and_(S.in_(c(8, STR), [L("MAIL"), L("SHIP")]), S.and_(S.lt(c(6, DATE), c(7, DATE)), S.lt(c(5, DATE), c(6, DATE)))),
+                                      S.and_(S.gt_eq(c(7, DATE), S.lit(date(1994, 1, 1), DATE)), S.lt(c(7, DATE), S.lit(date(1995, 1, 1), DATE)))))
+    j = S.hash_join(S.scan([I64, STR]), S.project(li, [c(0, I64), c(8, STR)]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)   # o_orderkey, prio, l_orderkey, shipmode
+    urgent = S.or_(S.eq(c(1, STR), L("1-URGENT")), S.eq(c(1, STR), L("2-HIGH")))
+    one, zero = S.lit(1, I32), S.lit(0, I32)
+    p = S.project(j, [c(3, STR), S.case_when([(urgent, one)], zero), S.case_when([(S.and_(S.neq(c(1, STR), L("1-URGENT")), S.neq(c(1, STR), L("2-HIGH"))), one)], zero)])
+    partial = S.hash_agg(p, [c(0, STR)], [S.sum_(c(1, I32), I64), S.sum_(c(2, I32), I64)], S.PARTIAL)
+    st = run(partial, [orders, lineitem], 3)
+    final = S.sort(S.final_of(partial, st.schema), [(c(0, STR), False, False)])
+    got, want = run(final, [st], 3), O.run_plan_to_arrow(S, final, [O.run_plan_to_arrow(S, partial, [orders, lineitem])])
+    assert rows(got) == rows(want)
+    prio = dict(zip(orders.column(0).to_pylist(), orders.column(1).to_pylist()))
+    ref = {}
+    for k, sd, cd, rd, m in zip(*[lineitem.column(i).to_pylist() for i in (0, 5, 6, 7, 8)]):
+        if m in ("MAIL", "SHIP") and cd < rd and sd < cd and datetime.date(1994, 1, 1) <= rd < datetime.date(1995, 1, 1):
+            hi = prio[k] in ("1-URGENT", "2-HIGH")
+            a = ref.setdefault(m, [0, 0])
+            a[0 if hi else 1] += 1
+    assert rows(got) == [(m, ref[m][0], ref[m][1]) for m in sorted(ref)]
+
+
+def test_q14_promotion_effect(built):
+    from oracle import oracle as O
+    _, lineitem, part = _tables()
+    li = S.project(S.filter_(S.scan(LI), S.and_(S.gt_eq(c(5, DATE), S.lit(date(1995, 1, 1), DATE)), S.lt(c(5, DATE), S.lit(date(1995, 2, 1), DATE)))), [c(1, I64), c(3, D), c(4, D)])
+    j = S.hash_join(li, S.project(S.scan([I64, STR, STR, STR, I32]), [c(0, I64), c(1, STR)]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)   # partkey, price, disc, p_partkey, p_type
+    rev = _revenue(c(1, D), c(2, D))
+    R = S.decimal(26, 4)
+    p = S.project(j, [S.case_when([(S.like(c(4, STR), L("PROMO%")), rev)], S.lit(decimal.Decimal("0.0000"), R)), rev])
+    partial = S.hash_agg(p, [], [S.sum_(c(0, R), S.decimal(36, 4)), S.sum_(c(1, R), S.decimal(36, 4))], S.PARTIAL)
+    st = run(partial, [lineitem, part], 4)
+    assert rows(st) == rows(O.run_plan_to_arrow(S, partial, [lineitem, part]))
+    SD = S.decimal(36, 4)
+    # 100.00 * promo / total: Spark types the product decimal(38,6) and the quotient decimal(38,6)
+    fin = S.final_of(partial, st.schema)
+    hundred = S.lit(decimal.Decimal("100.00"), S.decimal(5, 2))
+    prod = S.check_overflow(S.math("multiply", hundred, c(0, SD), S.decimal(38, 6)), S.decimal(38, 6))
+    quot = S.check_overflow(S.math("divide", prod, c(1, SD), S.decimal(38, 6)), S.decimal(38, 6))
+    plan_b = S.project(fin, [quot])
+    got, want = run(plan_b, [st], 1), O.run_plan_to_arrow(S, plan_b, [st])
+    assert rows(got) == rows(want)
+    ptype = dict(zip(part.column(0).to_pylist(), part.column(1).to_pylist()))
+    promo = total = decimal.Decimal(0)
+    for pk, price, disc, sd in zip(*[lineitem.column(i).to_pylist() for i in (1, 3, 4, 5)]):
+        if datetime.date(1995, 1, 1) <= sd < datetime.date(1995, 2, 1):
+            r = price * (1 - disc)
+            total += r
+            if ptype[pk].startswith("PROMO"):
+                promo += r
+    exact = (decimal.Decimal(100) * promo / total).quantize(decimal.Decimal("0.000001"), rounding=decimal.ROUND_HALF_UP)
+    assert got.column(0).to_pylist() == [exact]
+
+
+def test_q19_discounted_revenue(built):
+    from oracle import oracle as O
+    _, lineitem, part = _tables()
+    li = S.project(S.filter_(S.scan(LI), S.and_(S.in_(c(8, STR), [L("AIR"), L("REG AIR")]), S.eq(c(9, STR), L("DELIVER IN PERSON")))), [c(1, I64), c(2, D), c(3, D), c(4, D)])
+    j = S.hash_join(li, S.scan([I64, STR, STR, STR, I32]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)   # partkey, qty, price, disc | p_partkey, type, brand, container, size
+    qty, brand, cont, size = c(1, D), c(6, STR), c(7, STR), c(8, I32)
+    dq = lambda v: S.lit(decimal.Decimal(v), D)
+    between = lambda x, lo, hi: S.and_(S.gt_eq(x, lo), S.lt_eq(x, hi))
+    branch = lambda b, conts, q0, q1, s1: S.and_(S.and_(S.eq(brand, L(b)), S.in_(cont, [L(x) for x in conts])), S.and_(between(qty, dq(q0), dq(q1)), between(size, S.lit(1, I32), S.lit(s1, I32))))
+    cond = S.or_(S.or_(branch("Brand#12", ["SM CASE", "SM BOX", "SM PACK", "SM PKG"], "1.00", "11.00", 5), branch("Brand#23", ["MED BAG", "MED BOX", "MED PKG", "MED PACK"], "10.00", "20.00", 10)),
+                 branch("Brand#34", ["LG CASE", "LG BOX", "LG PACK", "LG PKG"], "20.00", "30.00", 15))
+    partial = S.hash_agg(S.project(S.filter_(j, cond), [_revenue(c(2, D), c(3, D))]), [], [S.sum_(c(0, S.decimal(26, 4)), S.decimal(36, 4))], S.PARTIAL)
+    st = run(partial, [lineitem, part], 2)
+    got = run(S.final_of(partial, st.schema), [st], 1)
+    assert rows(st) == rows(O.run_plan_to_arrow(S, partial, [lineitem, part]))
+    pinfo = {r[0]: r for r in rows(part)}
+    tot, any_ = decimal.Decimal(0), False
+    for pk, q, price, disc, m, ins in zip(*[lineitem.column(i).to_pylist() for i in (1, 2, 3, 4, 8, 9)]):
+        if m in ("AIR", "REG AIR") and ins == "DELIVER IN PERSON":
+            _, _, b, ct, sz = pinfo[pk]
+            if ((b == "Brand#12" and ct in ("SM CASE", "SM BOX", "SM PACK", "SM PKG") and 1 <= q <= 11 and 1 <= sz <= 5) or
+                    (b == "Brand#23" and ct in ("MED BAG", "MED BOX", "MED PKG", "MED PACK") and 10 <= q <= 20 and 1 <= sz <= 10) or
+                    (b == "Brand#34" and ct in ("LG CASE", "LG BOX", "LG PACK", "LG PKG") and 20 <= q <= 30 and 1 <= sz <= 15)):
+                tot += price * (1 - disc)
+                any_ = True
+    assert got.column(0).to_pylist() == [tot if any_ else None] and any_
