@@ -1799,11 +1799,12 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         continue;
       }
       Val v = ge.named(ge.gen(c));
-      if (v.rep == Rep::STR) throw CometError("computed Utf8 values cannot be projected by the GPU pipeline yet (only Utf8 columns passed through)");
       outs.push_back(v);
       OutCol oc;
       oc.type = v.t;
       oc.nullable = !v.ok.empty();
+      // a computed string (literal, substring, CASE over those — at most 15 bytes): stored packed, expanded to offsets + bytes by the executor
+      oc.packed_string = v.rep == Rep::STR;
       d.out_cols.push_back(oc);
       ex << "  output: " << explain_expr(c) << " : " << v.t.str() << "\n";
     }
@@ -1814,6 +1815,11 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       std::string ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * j + 1) + "]";
       if (d.out_cols[j].gather_src >= 0) {
         ge.stmt("((u32*)" + vb + ")[pos[r]] = (u32)" + v.v + ";");
+        if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");
+        continue;
+      }
+      if (d.out_cols[j].packed_string) {
+        ge.stmt("((comet::str16*)" + vb + ")[pos[r]] = " + (v.ok.empty() ? v.v : "(" + v.ok + " ? " + v.v + " : comet::str16{0ull, 0ull})") + ";");
         if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");
         continue;
       }

@@ -189,6 +189,8 @@ extern "C" int comet_launch_window_rank(int kind, int64_t arg, const int32_t* sp
                                         void* out, void* stream);
 extern "C" int comet_launch_window_offset(int64_t shift, const int32_t* sp, const uint32_t* first_part, int64_t n, uint32_t* idx, uint8_t* ok, void* stream);
 extern "C" int comet_launch_window_offset_valid(const uint32_t* idx, const uint8_t* ok, const uint8_t* src_valid_bits, int64_t n, uint8_t* out_ok, void* stream);
+extern "C" int comet_launch_str16_lengths(const void* packed, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream);
+extern "C" int comet_launch_str16_copy(const void* packed, const int32_t* offsets, int64_t n, uint8_t* bytes, void* stream);
 extern "C" int comet_launch_str_max_len(const int32_t* offs, int64_t n, uint32_t* out_max, void* stream);
 extern "C" int comet_launch_str_dict_build(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t n, uint32_t* table, int64_t slots,
                                            int64_t* rep, void* stream);
@@ -457,7 +459,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     explain_ = pv->desc.explain;
     sink_ = pv->desc.sink;
     if (sink_ == SinkKind::Output)
-      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0;   // Utf8 pass-through needs the gather step
+      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0 || oc.packed_string;   // Utf8 outputs are finished on the device (gather / unpack)
     // a grouped aggregate keyed by Utf8 columns sees its whole input at once (like a join input): only then can strings longer
     // than the packed 15 bytes be swapped for representative row indices (prepare_dict_keys)
     if (sink_ == SinkKind::AggGrouped && !pv->desc.str_key_cols.empty()) has_join_ = true;
@@ -594,15 +596,19 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       if (pr->project_list.empty()) continue;
       std::vector<bool> none(st.size(), false);
       PipelineDesc d = generate_pipeline(*pr, none, &st);
-      for (size_t k = 0; k < at.size(); k++) { types[p][at[k]] = d.out_cols[k].type; known[p][at[k]] = true; gsrc[p][at[k]] = d.out_cols[k].gather_src; }
+      for (size_t k = 0; k < at.size(); k++) {
+        types[p][at[k]] = d.out_cols[k].type;
+        known[p][at[k]] = true;
+        gsrc[p][at[k]] = d.out_cols[k].packed_string ? -2 : d.out_cols[k].gather_src;   // −2: a computed (packed) string
+      }
     }
     for (size_t j = 0; j < ncol; j++) {
       OutCol oc;
       bool have = false;
       for (size_t p = 0; p < op.expand_projections.size(); p++) {
         if (!known[p][j]) continue;
-        if (!have) { oc.type = types[p][j]; oc.gather_src = gsrc[p][j]; have = true; }
-        else if (types[p][j] != oc.type || gsrc[p][j] != oc.gather_src)
+        if (!have) { oc.type = types[p][j]; oc.gather_src = gsrc[p][j] == -2 ? -1 : gsrc[p][j]; oc.packed_string = gsrc[p][j] == -2; have = true; }
+        else if (types[p][j] != oc.type || gsrc[p][j] != (oc.packed_string ? -2 : oc.gather_src))
           throw CometError("Expand: column " + std::to_string(j) + " differs between the projections (" + oc.type.str() + " vs " + types[p][j].str() + ")");
       }
       if (!have) {
@@ -1854,11 +1860,31 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
   t.rows = rows;
   for (size_t j = 0; j < d.out_cols.size(); j++) {
     const OutCol& oc = d.out_cols[j];
-    if (oc.packed_string) throw CometError("packed Utf8 group keys cannot cross a GPU pipeline boundary yet");
     DeviceColumnView cv;
     cv.data = vals[j]->p;
     t.owners.push_back(vals[j]);
     bool hv = false;
+    if (oc.packed_string) {
+      // packed ≤ 15-byte strings (computed values, short group keys) → offsets + bytes: lengths, prefix sum, copy
+      DevBuf lengths, tiles;
+      auto offsets = std::make_shared<DevBuf>(), bytes = std::make_shared<DevBuf>();
+      lengths.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
+      tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+      offsets->ensure((size_t)(rows + 2) * 4);
+      if (rows == 0) HIP_CHECK(hipMemsetAsync(offsets->p, 0, 8, stream_));
+      if (comet_launch_str16_lengths(vals[j]->p, (oc.nullable && rows) ? (const uint8_t*)valid_bytes[j]->p : nullptr, rows, (uint32_t*)lengths.p, stream_) != 0)
+        throw CometError("packed strings: launch failed");
+      if (rows) pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)offsets->p, stream_);
+      int32_t total = 0;
+      if (rows) read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
+      bytes->ensure((size_t)total + 16);
+      if (comet_launch_str16_copy(vals[j]->p, (const int32_t*)offsets->p, rows, (uint8_t*)bytes->p, stream_) != 0) throw CometError("packed strings: launch failed");
+      HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
+      cv.data = offsets->p;
+      cv.aux = bytes->p;
+      t.owners.push_back(offsets);
+      t.owners.push_back(bytes);
+    }
     if (oc.gather_src >= 0) {
       // the emit kernel wrote source row indices: gather the strings now
       if (!gather_source) throw CometError("internal: gathered Utf8 column without a source table");

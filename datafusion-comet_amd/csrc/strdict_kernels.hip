@@ -100,6 +100,18 @@ __global__ __launch_bounds__(256) void str_dict_lookup_kernel(const i32* __restr
   }
 }
 
+// packed strings (≤ 15 bytes: bytes 0-7 in word a, 8-14 in the low 56 bits of word b, length in b's top byte) → Arrow lengths / bytes
+__global__ __launch_bounds__(256) void str16_lengths_kernel(const u64* __restrict__ packed, const u8* __restrict__ ok, i64 n, u32* __restrict__ lengths) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) lengths[i] = (ok && !ok[i]) ? 0u : (u32)(packed[2 * i + 1] >> 56);
+}
+__global__ __launch_bounds__(256) void str16_copy_kernel(const u64* __restrict__ packed, const i32* __restrict__ offs, i64 n, u8* __restrict__ bytes) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    const i32 lo = offs[i], len = offs[i + 1] - lo;
+    const u64 a = packed[2 * i], b = packed[2 * i + 1];
+    for (i32 k = 0; k < len; k++) bytes[lo + k] = (u8)(k < 8 ? a >> (8 * k) : b >> (8 * (k - 8)));
+  }
+}
+
 int grid_for(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -126,6 +138,15 @@ int comet_launch_str_dict_lookup(const int32_t* build_offs, const uint8_t* build
   if (n > 0)
     hipLaunchKernelGGL(str_dict_lookup_kernel, grid_for(n), 256, 0, (hipStream_t)stream, build_offs, build_bytes, table, (u64)slots - 1, offs, bytes,
                        valid_bits, (i64)n, (i64*)rep, ok);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int comet_launch_str16_lengths(const void* packed, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(str16_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, (const u64*)packed, ok_bytes, (i64)n, lengths);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_str16_copy(const void* packed, const int32_t* offsets, int64_t n, uint8_t* bytes, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(str16_copy_kernel, grid_for(n), 256, 0, (hipStream_t)stream, (const u64*)packed, offsets, (i64)n, bytes);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -235,3 +235,30 @@ def test_substring_as_filter_and_group_key(built):
         p2 = S.hash_agg(S.filter_(S.scan([S.T_STRING, D]), keep), [key], [S.count(S.col(1, D))], S.PARTIAL)
         got, want = run(p2, 2), O.run_plan_to_arrow(S, p2, [t])
         assert _rows(got) == _rows(want), (pos, ln)
+
+
+def test_project_computed_strings(built):
+    """String literals, substring results and CASE / IF over them as OUTPUT columns (TPC-DS: `'store channel' as channel`, bucket labels):
+    packed in registers, stored as 16 bytes and expanded to offsets + bytes on the device — through Projection, above a join, and as an
+    aggregate's grouping column coming back from a nested context."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    n = 40_000
+    t = pa.table({"phone": pa.array([None if rng.random() < 0.05 else "%02d-%03d-%04d" % tuple(rng.integers(10, 99, 1).tolist() + rng.integers(100, 999, 1).tolist() + rng.integers(1000, 9999, 1).tolist()) for _ in range(n)]),
+                  "k": pa.array(rng.integers(0, 5, n), pa.int32(), mask=rng.random(n) < 0.1), "v": pa.array(rng.integers(0, 1000, n), pa.int64())})
+    fields = [S.T_STRING, S.T_INT32, S.T_INT64]
+    s, k, v = (S.col(i, ty) for i, ty in enumerate(fields))
+    L, I = (lambda x: S.lit(x, S.T_STRING)), (lambda x: S.lit(x, S.T_INT32))
+    code = S.scalar_func("substring", [s, I(1), I(2)], S.T_STRING)
+    label = S.case_when([(S.eq(k, I(0)), L("store channel")), (S.eq(k, I(1)), L("catalog channel")), (S.lt(k, I(4)), L(""))], L("web channel"))
+    plan = S.project(S.filter_(S.scan(fields), S.gt(v, S.lit(100, S.T_INT64))), [v, code, L("constant"), label, S.if_(S.is_null(k), S.lit(None, S.T_STRING), code), s])
+    run = lambda p, nc: pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], nc, p.encode(), batch_size=0))
+    got, want = run(plan, 6), O.run_plan_to_arrow(S, plan, [t])
+    assert got.schema.types == want.schema.types
+    for c in range(6):
+        assert got.column(c).combine_chunks().equals(want.column(c).combine_chunks()), c
+    # grouped by the computed label, then sorted (the aggregate's result stays on the device below the Sort)
+    agg = S.hash_agg(S.project(S.scan(fields), [label, code, v]), [S.col(0, S.T_STRING), S.col(1, S.T_STRING)], [S.sum_(S.col(2, S.T_INT64), S.T_INT64)], S.PARTIAL)
+    p2 = S.sort(agg, [(S.col(0, S.T_STRING), False, False), (S.col(1, S.T_STRING), True, True)])
+    got2, want2 = run(p2, 3), O.run_plan_to_arrow(S, p2, [t])
+    assert got2.to_pylist() == want2.to_pylist()
