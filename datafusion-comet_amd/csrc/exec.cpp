@@ -874,6 +874,7 @@ void ExecutionContext::prepare_dict_keys(DevTable& src) {
     const DeviceColumnView& sc = src.cols[(size_t)c];
     if (sc.offset != 0) return;     // sliced producer arrays keep the packed path (and its 15-byte limit)
     if (need) break;
+    if (sc.fixed_len >= 0 && sc.fixed_len <= 15) continue;   // already known to hold values of one short length (TPC-H Q1's flag columns): nothing to measure
     uint32_t* mx = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 1);   // last word of the error/aux block: scratch
     HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
     if (comet_launch_str_max_len((const int32_t*)sc.data, n, mx, stream_) != 0) throw CometError("string keys: launch failed");
