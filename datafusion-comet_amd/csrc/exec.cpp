@@ -177,6 +177,7 @@ extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const 
                                                  int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
+extern "C" int comet_launch_window_default(int width, const uint8_t* inside, int64_t n, const void* value, void* data, uint8_t* ok_bytes, void* stream);
 extern "C" int comet_launch_window_widen(int width, const void* src, const uint8_t* valid_bits, int64_t n, void* out128, void* hi128, uint32_t* ok, void* stream);
 extern "C" int comet_launch_scan128(const void* in128, int64_t n, void* tiles, void* out128, void* stream);
 extern "C" int comet_launch_window_agg(int fn, int frame, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,
@@ -553,7 +554,11 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
         if (fn.args.size() < 1 || fn.args.size() > 3 || fn.args[0]->kind != ExprKind::Bound || fn.args[0]->bound_index < 0 || (size_t)fn.args[0]->bound_index >= st.size())
           throw CometError(f + " is supported for a column argument");
         if (fn.args.size() >= 2 && !int_lit(fn.args[1])) throw CometError(f + " expects a literal offset");
-        if (fn.args.size() == 3 && !(fn.args[2]->kind == ExprKind::Literal && fn.args[2]->lit_null)) throw CometError(f + " with a non-NULL default value is not supported yet");
+        if (fn.args.size() == 3 && fn.args[2]->kind != ExprKind::Literal) throw CometError(f + " default value must be a literal");
+        if (fn.args.size() == 3 && !fn.args[2]->lit_null) {
+          const DType& at = st[(size_t)fn.args[0]->bound_index];
+          if (at.id == TypeId::String || at.id == TypeId::Bytes || at.id == TypeId::Bool) throw CometError(f + " with a non-NULL default value over " + at.str() + " is not supported yet");
+        }
         if (fn.ignore_nulls) throw CometError(f + " IGNORE NULLS is not supported yet");
         out.push_back(st[(size_t)fn.args[0]->bound_index]);
       } else {
@@ -2449,7 +2454,8 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
     if (comet_launch_window_offset(shift, (const int32_t*)sp->p, (const uint32_t*)first_part->p, n, (uint32_t*)idx->p, (uint8_t*)ok.p, stream_) != 0 ||
         comet_launch_window_offset_valid((const uint32_t*)idx->p, (const uint8_t*)ok.p, in.has_valid[(size_t)c] ? sc.valid : nullptr, n, (uint8_t*)okv->p, stream_) != 0)
       throw CometError("window: launch failed");
-    pq_launch_pack((const uint8_t*)okv->p, (uint8_t*)bits->p, n, stream_);
+    const bool has_default = fn.args.size() == 3 && !fn.args[2]->lit_null;
+    if (!has_default) pq_launch_pack((const uint8_t*)okv->p, (uint8_t*)bits->p, n, stream_);
     if (t.id == TypeId::String || t.id == TypeId::Bytes) {
       DeviceColumnView ov;
       take_utf8(sc, (const uint32_t*)idx->p, (const uint8_t*)okv->p, nullptr, n, ov, out.owners);
@@ -2463,6 +2469,17 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
       auto data = std::make_shared<DevBuf>();
       data->ensure((wd ? (size_t)n * (size_t)wd : (size_t)((n + 7) / 8)) + 16);
       if (comet_launch_take(wd, sc.data, (const uint32_t*)idx->p, n, data->p, stream_) != 0) throw CometError("window: take failed");
+      if (has_default) {
+        // rows whose offset row is outside the partition take the literal default (lag(x, k, d))
+        const Expr& lit = *fn.args[2];
+        uint8_t buf[16] = {0};
+        if (t.id == TypeId::Decimal) { i128 v = lit.lit_dec; memcpy(buf, &v, 16); }
+        else if (t.id == TypeId::Double) { double v = lit.lit_f64; memcpy(buf, &v, 8); }
+        else if (t.id == TypeId::Float) { float v = (float)lit.lit_f64; memcpy(buf, &v, 4); }
+        else { int64_t v = lit.lit_i64; memcpy(buf, &v, 8); }
+        if (comet_launch_window_default(wd, (const uint8_t*)ok.p, n, buf, data->p, (uint8_t*)okv->p, stream_) != 0) throw CometError("window: launch failed");
+        pq_launch_pack((const uint8_t*)okv->p, (uint8_t*)bits->p, n, stream_);
+      }
       add_col(t, data, bits);
     }
     HIP_CHECK(hipStreamSynchronize(stream_));   // `ok` goes back to the pool; idx / okv are released with this scope

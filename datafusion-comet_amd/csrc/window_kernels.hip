@@ -217,9 +217,30 @@ __global__ __launch_bounds__(256) void window_agg_kernel(int fn, int frame, cons
   }
 }
 
+// lag / lead with a non-NULL default: rows whose offset row lies outside the partition take the default value (a NULL source value stays NULL)
+template <class T>
+__global__ __launch_bounds__(256) void window_default_kernel(const u8* __restrict__ inside, i64 n, T value, T* __restrict__ data, u8* __restrict__ ok_bytes) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256)
+    if (!inside[i]) { data[i] = value; ok_bytes[i] = 1; }
+}
+
 }  // namespace
 
 extern "C" {
+
+int comet_launch_window_default(int width, const uint8_t* inside, int64_t n, const void* value, void* data, uint8_t* ok_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0) return 0;
+  switch (width) {
+    case 1: hipLaunchKernelGGL(window_default_kernel<u8>, grid_for(n), 256, 0, st, inside, (i64)n, *(const u8*)value, (u8*)data, ok_bytes); break;
+    case 2: hipLaunchKernelGGL(window_default_kernel<unsigned short>, grid_for(n), 256, 0, st, inside, (i64)n, *(const unsigned short*)value, (unsigned short*)data, ok_bytes); break;
+    case 4: hipLaunchKernelGGL(window_default_kernel<u32>, grid_for(n), 256, 0, st, inside, (i64)n, *(const u32*)value, (u32*)data, ok_bytes); break;
+    case 8: hipLaunchKernelGGL(window_default_kernel<u64>, grid_for(n), 256, 0, st, inside, (i64)n, *(const u64*)value, (u64*)data, ok_bytes); break;
+    case 16: { i128 v; memcpy(&v, value, 16); hipLaunchKernelGGL(window_default_kernel<i128>, grid_for(n), 256, 0, st, inside, (i64)n, v, (i128*)data, ok_bytes); break; }
+    default: return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int comet_launch_window_widen(int width, const void* src, const uint8_t* valid_bits, int64_t n, void* out128, void* hi128, uint32_t* ok, void* stream) {
   if (n > 0) hipLaunchKernelGGL(window_widen_kernel, grid_for(n), 256, 0, (hipStream_t)stream, width, src, valid_bits, (i64)n, (i128*)out128, (i128*)hi128, ok);

@@ -780,6 +780,10 @@ def run_plan(S, op, table) -> List[Col]:
                 idx = np.array([i + sh if ps[i] <= i + sh < pe[i] else -1 for i in range(n)], dtype=np.int64)
                 okv = (idx >= 0) & src.ok()[np.maximum(idx, 0)]
                 vals = src.values[np.maximum(idx, 0)]
+                if len(args) > 2 and args[2].value is not None:      # rows whose offset row is outside the partition take the default
+                    dflt = ev.eval(args[2], child, n)
+                    vals = np.where(idx < 0, dflt.values, vals) if vals.dtype != object else vals
+                    okv = okv | (idx < 0)
                 if src.values.dtype == object:
                     vals = np.array([v if o else None for v, o in zip(vals, okv)], dtype=object)
                 out.append(Col(src.dtype, vals, None if okv.all() else okv))

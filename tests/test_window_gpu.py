@@ -54,9 +54,10 @@ def test_all_functions_on_unique_order_keys(built):
     t = _table(30_000, 11, unique_order=True)
     fns = [("row_number", [], S.T_INT32), ("rank", [], S.T_INT32), ("ntile", [S.lit(4, S.T_INT32)], S.T_INT32),
            ("lag", [S.col(2, D), S.lit(1, S.T_INT32), S.lit(None, D)], D), ("lead", [S.col(4, S.T_STRING), S.lit(2, S.T_INT32), S.lit(None, S.T_STRING)], S.T_STRING),
-           ("lag", [S.col(5, S.T_DOUBLE), S.lit(3, S.T_INT32), S.lit(None, S.T_DOUBLE)], S.T_DOUBLE), ("lead", [S.col(3, S.T_INT64)], S.T_INT64)]
+           ("lag", [S.col(5, S.T_DOUBLE), S.lit(3, S.T_INT32), S.lit(None, S.T_DOUBLE)], S.T_DOUBLE), ("lead", [S.col(3, S.T_INT64)], S.T_INT64),
+           ("lag", [S.col(2, D), S.lit(2, S.T_INT32), S.lit(__import__("decimal").Decimal("-1.50"), D)], D), ("lead", [S.col(5, S.T_DOUBLE), S.lit(1, S.T_INT32), S.lit(0.25, S.T_DOUBLE)], S.T_DOUBLE)]
     plan = _plan(fns)
-    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 13, plan.encode(), batch_size=0))
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 15, plan.encode(), batch_size=0))
     want = O.run_plan_to_arrow(S, plan, [t])
     assert got.schema.types == want.schema.types
     assert _rows(got) == _rows(want)
