@@ -20,6 +20,7 @@ extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, 
 
 // exchange_kernels.hip
 extern "C" int64_t comet_partition_tiles(int64_t n);
+extern "C" int64_t comet_partition_scratch_bytes(int64_t n, int32_t P);
 extern "C" int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
                                               uint32_t* row_indices, void* stream);
 extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream);
@@ -231,7 +232,7 @@ int32_t comet_partition_indices(const int32_t* partition_ids, int64_t n, int32_t
     const int64_t W = comet_partition_tiles(n);
     DevBuf scratch;   // histogram + one flag word; returned to the pool once the stream is idle
     const size_t hist_bytes = ((size_t)num_partitions * (size_t)W + 1) * 8;
-    scratch.ensure(hist_bytes + 8);
+    scratch.ensure((size_t)comet_partition_scratch_bytes(n, num_partitions));
     uint32_t* bad = (uint32_t*)((char*)scratch.p + hist_bytes);
     if (hipMemsetAsync(bad, 0, 4, st) != hipSuccess) throw CometError("partition_indices: memset failed");
     if (comet_launch_partition_indices(partition_ids, n, num_partitions, (uint64_t*)scratch.p, bad, partition_starts, partition_row_indices, st) != 0)

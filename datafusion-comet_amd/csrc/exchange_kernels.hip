@@ -70,6 +70,49 @@ __global__ __launch_bounds__(256) void part_hist_kernel(const i32* pids, i64 n, 
 
 __global__ __launch_bounds__(256) void part_scan_kernel(u64* hist, i64 len) { tile_scan_body(hist, len); }
 
+// The same exclusive scan spread over many blocks for long histograms (a radix-sort pass over 20 M rows scans 1 M counters; one block
+// needs 240 µs for that): chunk sums → scan of the sums (one block) → every block scans its chunk of 4096 counters from its carry.
+constexpr i64 kScanChunk = 4096;
+__global__ __launch_bounds__(256) void part_scan_sums_kernel(const u64* __restrict__ hist, i64 len, u64* __restrict__ sums) {
+  __shared__ u64 s_part[256];
+  const i64 first = (i64)blockIdx.x * kScanChunk + (i64)threadIdx.x * 16;
+  u64 s = 0;
+  for (int j = 0; j < 16; j++) s += first + j < len ? hist[first + j] : 0;
+  s_part[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) s_part[threadIdx.x] += s_part[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = s_part[0];
+}
+__global__ __launch_bounds__(256) void part_scan_apply_kernel(u64* __restrict__ hist, i64 len, const u64* __restrict__ sums, i64 nblocks) {
+  __shared__ u64 s_wave[kBlock / kWave];
+  const i64 first = (i64)blockIdx.x * kScanChunk + (i64)threadIdx.x * 16;
+  u64 v[16];
+  u64 sum = 0;
+  for (int j = 0; j < 16; j++) {
+    v[j] = first + j < len ? hist[first + j] : 0;
+    sum += v[j];
+  }
+  u64 x = sum;
+  for (int d = 1; d < kWave; d <<= 1) {
+    u32 lo = __shfl_up((u32)x, d, kWave), hi = __shfl_up((u32)(x >> 32), d, kWave);
+    u64 y = ((u64)hi << 32) | lo;
+    if (lane_id() >= d) x += y;
+  }
+  if (lane_id() == kWave - 1) s_wave[wave_id()] = x;
+  __syncthreads();
+  u64 woff = 0;
+  for (int w = 0; w < wave_id(); w++) woff += s_wave[w];
+  u64 run = sums[blockIdx.x] + woff + x - sum;
+  for (int j = 0; j < 16; j++) {
+    if (first + j < len) hist[first + j] = run;
+    run += v[j];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) hist[len] = sums[nblocks];
+}
+
 __global__ __launch_bounds__(256) void part_starts_kernel(const u64* scanned, i32 P, i64 W, i64 n, i64* starts) {
   for (int p = threadIdx.x; p <= P; p += 256) starts[p] = p == P ? n : (i64)scanned[(i64)p * W];
 }
@@ -194,14 +237,16 @@ __global__ __launch_bounds__(256) void take_utf8_lengths_kernel(const i32* offs,
     lengths[k] = utf8_row_valid(ok_bytes, src_valid_bits, k, r) ? (u32)(offs[r + 1] - offs[r]) : 0u;
   }
 }
+// eight lanes copy one value: they write consecutive bytes, so a wave stores 8 contiguous runs instead of 64 scattered bytes per step
 __global__ __launch_bounds__(256) void take_utf8_copy_kernel(const i32* offs, const u8* bytes, const u32* idx, const u8* ok_bytes, const u8* src_valid_bits,
                                                              i64 n, const i32* out_offs, u8* out_bytes) {
-  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
-    const i32 len = out_offs[k + 1] - out_offs[k];
+  const int sub = threadIdx.x & 7;
+  for (i64 k = ((i64)blockIdx.x * 256 + threadIdx.x) >> 3; k < n; k += ((i64)gridDim.x * 256) >> 3) {
+    const i32 lo = out_offs[k], len = out_offs[k + 1] - lo;
     if (len <= 0) continue;
     const u8* src = bytes + offs[idx[k]];
-    u8* dst = out_bytes + out_offs[k];
-    for (i32 b = 0; b < len; b++) dst[b] = src[b];
+    u8* dst = out_bytes + lo;
+    for (i32 b = sub; b < len; b += 8) dst[b] = src[b];
   }
 }
 
@@ -248,6 +293,12 @@ __global__ __launch_bounds__(256) void range_pid_kernel(const u8* __restrict__ p
 extern "C" {
 
 int64_t comet_partition_tiles(int64_t n) { return n <= 0 ? 1 : (n + part_tile_rows(n) - 1) / part_tile_rows(n); }
+// bytes of the `hist` scratch of comet_launch_partition_indices: P·W counters + their total, one flag word (at byte offset (P·W + 1)·8), and
+// the chunk sums of the multi-block scan
+int64_t comet_partition_scratch_bytes(int64_t n, int32_t P) {
+  const int64_t len = (int64_t)P * comet_partition_tiles(n);
+  return (len + 2 + (len + kScanChunk - 1) / kScanChunk + 2) * 8;
+}
 
 // hist: (P*W + 1) u64 scratch; bad: one zeroed u32; starts: P+1 i64; row_indices: n u32
 int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
@@ -258,7 +309,15 @@ int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, ui
   const int grid = (int)(block_tiles > 256 * 16 ? 256 * 16 : block_tiles);
   const size_t lds = (size_t)4 * (size_t)P * sizeof(u32);
   hipLaunchKernelGGL(part_hist_kernel, grid, 256, lds, st, pids, (i64)n, P, W, (u64*)hist, bad);
-  hipLaunchKernelGGL(part_scan_kernel, 1, 256, 0, st, (u64*)hist, (i64)P * W);
+  const i64 len = (i64)P * W, nb = (len + kScanChunk - 1) / kScanChunk;
+  if (nb <= 8) {
+    hipLaunchKernelGGL(part_scan_kernel, 1, 256, 0, st, (u64*)hist, len);
+  } else {
+    u64* sums = (u64*)hist + len + 2;   // behind the counters, their total and the flag word (comet_partition_scratch_bytes)
+    hipLaunchKernelGGL(part_scan_sums_kernel, (int)nb, 256, 0, st, (const u64*)hist, len, sums);
+    hipLaunchKernelGGL(part_scan_kernel, 1, 256, 0, st, sums, nb);
+    hipLaunchKernelGGL(part_scan_apply_kernel, (int)nb, 256, 0, st, (u64*)hist, len, (const u64*)sums, nb);
+  }
   hipLaunchKernelGGL(part_starts_kernel, 1, 256, 0, st, (const u64*)hist, P, W, (i64)n, (i64*)starts);
   if (n > 0) hipLaunchKernelGGL(part_index_kernel, grid, 256, lds, st, pids, (i64)n, P, W, (const u64*)hist, row_indices);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -288,7 +347,7 @@ int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_t* idx, con
 int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits,
                                 int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream) {
   if (n > 0)
-    hipLaunchKernelGGL(take_utf8_copy_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offs, bytes, idx, ok_bytes, src_valid_bits, (i64)n, out_offs, out_bytes);
+    hipLaunchKernelGGL(take_utf8_copy_kernel, grid_for(n * 8), 256, 0, (hipStream_t)stream, offs, bytes, idx, ok_bytes, src_valid_bits, (i64)n, out_offs, out_bytes);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // width ∈ {1,2,4,8,16}: value points to `width` bytes on the HOST

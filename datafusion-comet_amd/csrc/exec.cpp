@@ -198,6 +198,7 @@ extern "C" int comet_launch_str_dict_build(const int32_t* offs, const uint8_t* b
 extern "C" int comet_launch_str_dict_lookup(const int32_t* build_offs, const uint8_t* build_bytes, const uint32_t* table, int64_t slots, const int32_t* offs,
                                             const uint8_t* bytes, const uint8_t* valid_bits, int64_t n, int64_t* rep, uint8_t* ok, void* stream);
 extern "C" int64_t comet_partition_tiles(int64_t n);
+extern "C" int64_t comet_partition_scratch_bytes(int64_t n, int32_t P);
 extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
 extern "C" int comet_launch_murmur3(int type_id, int precision, const void* values, const uint8_t* validity, const void* aux, int64_t n, uint32_t* hashes, void* stream);
 extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out, void* stream);
@@ -2650,7 +2651,7 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
     }
     const int64_t W = comet_partition_tiles(n);
     const size_t hist_bytes = ((size_t)P * (size_t)W + 1) * 8;
-    hist.ensure(hist_bytes + 8);
+    hist.ensure((size_t)comet_partition_scratch_bytes(n, P));
     uint32_t* bad = (uint32_t*)((char*)hist.p + hist_bytes);
     HIP_CHECK(hipMemsetAsync(bad, 0, 4, stream_));
     if ((!by_range && comet_launch_pmod((const uint32_t*)hashes.p, n, P, (int32_t*)pids.p, stream_) != 0) ||
@@ -3072,7 +3073,7 @@ DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
   digit.ensure((size_t)ns * 4 + 16);
   ridx.ensure((size_t)ns * 4 + 16);
   const int64_t Wt = comet_partition_tiles(ns);
-  hist.ensure(((size_t)256 * (size_t)Wt + 1) * 8 + 16);
+  hist.ensure((size_t)comet_partition_scratch_bytes(ns, 256));
   starts.ensure(257 * 8);
   uint32_t* bad = (uint32_t*)((char*)hist.p + ((size_t)256 * (size_t)Wt + 1) * 8);
   HIP_CHECK(hipMemsetAsync(bad, 0, 4, stream_));

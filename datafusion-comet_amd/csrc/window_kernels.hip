@@ -141,10 +141,21 @@ __global__ __launch_bounds__(256) void scan128_tile_sum_kernel(const i128* __res
   }
   if (threadIdx.x == 0) tiles[blockIdx.x] = part[0];
 }
-__global__ void scan128_tiles_kernel(u128* tiles, i64 ntiles) {   // one thread: exclusive scan of the tile sums (ntiles = n / 2048)
-  if (threadIdx.x || blockIdx.x) return;
-  u128 run = 0;
-  for (i64 t = 0; t < ntiles; t++) {
+__global__ __launch_bounds__(256) void scan128_tiles_kernel(u128* tiles, i64 ntiles) {   // one block: exclusive scan of the tile sums
+  __shared__ u128 part[256];
+  const i64 per = (ntiles + 255) / 256, lo = (i64)threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
+  u128 s = 0;
+  for (i64 t = lo; t < hi; t++) s += tiles[t];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 1; st < 256; st <<= 1) {
+    u128 add = (int)threadIdx.x >= st ? part[threadIdx.x - st] : (u128)0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  u128 run = threadIdx.x ? part[threadIdx.x - 1] : (u128)0;
+  for (i64 t = lo; t < hi; t++) {
     const u128 v = tiles[t];
     tiles[t] = run;
     run += v;
@@ -251,7 +262,7 @@ int comet_launch_scan128(const void* in128, int64_t n, void* tiles, void* out128
   if (n <= 0) return 0;
   const int64_t nt = (n + kScanTile - 1) / kScanTile;
   hipLaunchKernelGGL(scan128_tile_sum_kernel, (int)nt, 256, 0, (hipStream_t)stream, (const i128*)in128, (i64)n, (u128*)tiles);
-  hipLaunchKernelGGL(scan128_tiles_kernel, 1, 64, 0, (hipStream_t)stream, (u128*)tiles, (i64)nt);
+  hipLaunchKernelGGL(scan128_tiles_kernel, 1, 256, 0, (hipStream_t)stream, (u128*)tiles, (i64)nt);
   hipLaunchKernelGGL(scan128_apply_kernel, (int)nt, 256, 0, (hipStream_t)stream, (const i128*)in128, (i64)n, (const u128*)tiles, (i128*)out128);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
