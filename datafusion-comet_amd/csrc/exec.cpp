@@ -2383,12 +2383,9 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
           src = sc.data;
           vb = in.has_valid[(size_t)c] ? sc.valid : nullptr;
           width = in.types[(size_t)c].id == TypeId::Decimal ? 16 : fixed_width(in.types[(size_t)c]);
-        } else if (c == -2) {
-          // COUNT(NULL literal): no row counts — an all-zero validity bitmap
-          okf.ensure((size_t)((n + 7) / 8) + (size_t)n * 4 + 32);
         }
         DevBuf zero_bits;
-        if (c == -2) {
+        if (c == -2) {   // COUNT(NULL literal): no row counts — an all-zero validity bitmap
           zero_bits.ensure((size_t)((n + 7) / 8) + 16);
           HIP_CHECK(hipMemsetAsync(zero_bits.p, 0, (size_t)((n + 7) / 8), stream_));
           vb = (const uint8_t*)zero_bits.p;

@@ -249,7 +249,7 @@ JNIEXPORT void JNICALL Java_org_apache_comet_Native_traceEnd(JNIEnv*, jclass, js
 JNIEXPORT void JNICALL Java_org_apache_comet_Native_logMemoryUsage(JNIEnv*, jclass, jstring, jlong) {}
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_getRustThreadId(JNIEnv*, jclass) { return 0; }
 
-// JVM-shuffle (row-based) and columnar-to-row entry points (jni_api.rs:1047,1130,1253,1275,1363): outside the hot path
+// JVM-shuffle (row-based) entry points (jni_api.rs:1047,1130): outside the hot path
 // (SURVEY §8b "must exist").  They resolve, throw CometNativeException and return the type's zero value, so a Spark plan that
 // reaches them fails with a clear message instead of an UnsatisfiedLinkError.
 #define COMET_UNSUPPORTED(env, what) throw_java(env, COMET_ERR_NATIVE, what " is not implemented by the MI355X engine (libcomet.so, hot path only)")
@@ -287,14 +287,46 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_decodeShuffleBlock(JNIEnv* 
   }
   return (jlong)rows;
 }
-JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_columnarToRowInit(JNIEnv* env, jclass, jobjectArray, jint) {
-  COMET_UNSUPPORTED(env, "Native.columnarToRowInit");
-  return 0;
+// Native.columnarToRowInit / Convert / Close (jni_api.rs:1253-1377).  The serialized schema is not needed: the types come with the
+// Arrow C Data structs of every batch.
+JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_columnarToRowInit(JNIEnv* env, jclass, jobjectArray /*serializedSchema*/, jint batchSize) {
+  const int64_t h = comet_columnar_to_row_init(batchSize, pick_device(0));
+  if (h == 0) throw_java(env, COMET_ERR_NATIVE, comet_columnar_to_row_error(0));
+  return (jlong)h;
 }
-JNIEXPORT jobject JNICALL Java_org_apache_comet_Native_columnarToRowConvert(JNIEnv* env, jclass, jlong, jlongArray, jlongArray, jint) {
-  COMET_UNSUPPORTED(env, "Native.columnarToRowConvert");
-  return nullptr;
+JNIEXPORT jobject JNICALL Java_org_apache_comet_Native_columnarToRowConvert(JNIEnv* env, jclass, jlong handle, jlongArray arrayAddrs, jlongArray schemaAddrs, jint numRows) {
+  const jsize n = arrayAddrs ? jni_GetArrayLength(env, arrayAddrs) : 0;
+  const jsize ns = schemaAddrs ? jni_GetArrayLength(env, schemaAddrs) : 0;
+  if (n != ns) { throw_java(env, COMET_ERR_NATIVE, "arrayAddrs and schemaAddrs differ in length"); return nullptr; }
+  std::vector<jlong> aa((size_t)n), sa((size_t)n);
+  if (n) {
+    jni_GetLongArrayRegion(env, arrayAddrs, 0, n, aa.data());
+    jni_GetLongArrayRegion(env, schemaAddrs, 0, n, sa.data());
+  }
+  std::vector<struct ArrowArray*> arrays((size_t)n);
+  std::vector<struct ArrowSchema*> schemas((size_t)n);
+  for (jsize i = 0; i < n; i++) {
+    arrays[(size_t)i] = (struct ArrowArray*)(intptr_t)aa[(size_t)i];
+    schemas[(size_t)i] = (struct ArrowSchema*)(intptr_t)sa[(size_t)i];
+  }
+  const uint8_t* buf = nullptr;
+  const int32_t *offs = nullptr, *lens = nullptr;
+  if (comet_columnar_to_row_convert(handle, arrays.data(), schemas.data(), (int32_t)n, numRows, &buf, &offs, &lens) != 0) {
+    throw_java(env, COMET_ERR_NATIVE, comet_columnar_to_row_error(handle));
+    return nullptr;
+  }
+  // new NativeColumnarToRowInfo(long memoryAddress, int[] offsets, int[] lengths)
+  jobject jo = jni_NewIntArray(env, numRows), jl = jni_NewIntArray(env, numRows);
+  if (!jo || !jl) return nullptr;
+  if (numRows) {
+    jni_SetIntArrayRegion(env, jo, 0, numRows, (const jint*)offs);
+    jni_SetIntArrayRegion(env, jl, 0, numRows, (const jint*)lens);
+  }
+  jclass cls = jni_FindClass(env, "org/apache/comet/NativeColumnarToRowInfo");
+  jmethodID ctor = cls ? jni_GetMethodID(env, cls, "<init>", "(J[I[I)V") : nullptr;
+  if (!ctor) { throw_java(env, COMET_ERR_NATIVE, "org.apache.comet.NativeColumnarToRowInfo(long, int[], int[]) not found"); return nullptr; }
+  return jni_NewObject3(env, cls, ctor, (jlong)(intptr_t)buf, jo, jl);
 }
-JNIEXPORT void JNICALL Java_org_apache_comet_Native_columnarToRowClose(JNIEnv*, jclass, jlong) {}
+JNIEXPORT void JNICALL Java_org_apache_comet_Native_columnarToRowClose(JNIEnv*, jclass, jlong handle) { comet_columnar_to_row_close(handle); }
 
 }  // extern "C"

@@ -81,6 +81,15 @@ def _load() -> ctypes.CDLL:
     lib.comet_encode_shuffle_block.restype = c.c_int32
     lib.comet_encode_shuffle_block.argtypes = [c.POINTER(c.c_void_p), c.POINTER(c.c_void_p), c.c_int32, c.c_int32, c.c_int32,
                                                c.POINTER(c.c_void_p), c.POINTER(c.c_int64)]
+    lib.comet_columnar_to_row_init.restype = c.c_int64
+    lib.comet_columnar_to_row_init.argtypes = [c.c_int32, c.c_int32]
+    lib.comet_columnar_to_row_convert.restype = c.c_int32
+    lib.comet_columnar_to_row_convert.argtypes = [c.c_int64, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p), c.c_int32, c.c_int64, c.POINTER(c.c_void_p),
+                                                  c.POINTER(c.c_void_p), c.POINTER(c.c_void_p)]
+    lib.comet_columnar_to_row_close.restype = None
+    lib.comet_columnar_to_row_close.argtypes = [c.c_int64]
+    lib.comet_columnar_to_row_error.restype = c.c_char_p
+    lib.comet_columnar_to_row_error.argtypes = [c.c_int64]
     lib.comet_free_buffer.restype = None
     lib.comet_free_buffer.argtypes = [c.c_void_p]
     return lib
@@ -453,6 +462,40 @@ def encode_shuffle_block(batch: pa.RecordBatch, codec: int = 0, level: int = 1) 
     data = ctypes.string_at(out.value, out_len.value) if out_len.value else b""
     l.comet_free_buffer(out)
     return data
+
+
+class ColumnarToRow:
+    """Native.columnarToRowInit / Convert / Close: Arrow columns → Spark UnsafeRow bytes (one bytes object per row)."""
+
+    def __init__(self, batch_size: int = 8192, device_id: int = 0):
+        self.handle = lib().comet_columnar_to_row_init(batch_size, device_id)
+        if not self.handle:
+            raise CometNativeException("columnarToRowInit failed")
+
+    def convert(self, batch: pa.RecordBatch, num_rows: Optional[int] = None) -> List[bytes]:
+        l = lib()
+        n = batch.num_columns
+        rows = batch.num_rows if num_rows is None else num_rows
+        arrays = [ArrowArrayC() for _ in range(n)]
+        schemas = [ArrowSchemaC() for _ in range(n)]
+        for i in range(n):
+            batch.column(i)._export_to_c(ctypes.addressof(arrays[i]), ctypes.addressof(schemas[i]))
+        aaddr = (ctypes.c_void_p * max(n, 1))(*[ctypes.addressof(a) for a in arrays])
+        saddr = (ctypes.c_void_p * max(n, 1))(*[ctypes.addressof(s) for s in schemas])
+        buf, offs, lens = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        rc = l.comet_columnar_to_row_convert(self.handle, aaddr, saddr, n, rows, ctypes.byref(buf), ctypes.byref(offs), ctypes.byref(lens))
+        if rc != 0:
+            raise CometNativeException((l.comet_columnar_to_row_error(self.handle) or b"").decode(errors="replace"))
+        if rows == 0:
+            return []
+        o = (ctypes.c_int32 * rows).from_address(offs.value)
+        ln = (ctypes.c_int32 * rows).from_address(lens.value)
+        return [ctypes.string_at(buf.value + o[i], ln[i]) for i in range(rows)]
+
+    def close(self):
+        if self.handle:
+            lib().comet_columnar_to_row_close(self.handle)
+            self.handle = 0
 
 
 def _raise_last(handle: int):

@@ -151,6 +151,20 @@ int32_t comet_encode_shuffle_block(struct ArrowArray** arrays, struct ArrowSchem
                                    int32_t compression_level, uint8_t** out, int64_t* out_len);
 void comet_free_buffer(uint8_t* p);
 
+/* Replace Java_org_apache_comet_Native_columnarToRow{Init,Convert,Close} (native/core/src/execution/jni_api.rs:1253-1377 →
+ * ColumnarToRowContext, columnar_to_row.rs:866-1345): Arrow columns → Spark UnsafeRow bytes.  init returns a handle (0 on error).
+ * convert takes OWNERSHIP of the n_cols Arrow C Data structs (host memory, one array + schema per column, offset 0; released before it
+ * returns), converts the first num_rows rows on the GPU of the handle and points *out_buffer at the row bytes, *out_offsets / *out_lengths
+ * at num_rows int32 entries — all in host memory owned by the handle and valid until its next convert or close.  Row layout as the
+ * reference writes it: null bitset, one 8-byte slot per field (integers sign-extended, floats as their bits, Decimal128(p ≤ 18) as the
+ * unscaled long, variable-length fields as (offset << 32) | length), then the variable-length data padded to 8 bytes; wide decimals as
+ * their minimal big-endian two's-complement bytes.  Returns 0, or -2 on error (comet_columnar_to_row_error). */
+int64_t comet_columnar_to_row_init(int32_t batch_size, int32_t device_id);
+int32_t comet_columnar_to_row_convert(int64_t handle, struct ArrowArray** arrays, struct ArrowSchema** schemas, int32_t n_cols, int64_t num_rows,
+                                      const uint8_t** out_buffer, const int32_t** out_offsets, const int32_t** out_lengths);
+void comet_columnar_to_row_close(int64_t handle);
+const char* comet_columnar_to_row_error(int64_t handle);
+
 /* Host-only description of a Parquet footer as parsed by the library's own Thrift reader (rows, row groups, schema
  * elements, per-chunk codec/offsets) — the metadata the NativeScan path (native/core/src/parquet/parquet_exec.rs:60-211)
  * plans from.  Returns 0, or -2 on error. */

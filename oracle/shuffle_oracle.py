@@ -226,3 +226,58 @@ def read_partition(data: bytes, index: bytes, partition: int) -> List[pa.RecordB
         out.append(decode_block(buf[p + 16:p + 8 + n]))
         p += 8 + n
     return out
+
+
+# --------------------------------------------------------------------------- columnar → UnsafeRow (columnar_to_row.rs:949-1345)
+
+
+def unsafe_rows(batch: pa.RecordBatch) -> List[bytes]:
+    """The reference's ColumnarToRowContext::convert restated: null bitset | 8-byte slots | variable-length data padded to 8.
+    Integers sign-extend into the slot, floats store their bits (f32 zero-extended), Decimal128(p ≤ 18) the unscaled long; Utf8 / Binary /
+    wide decimals (minimal big-endian two's complement, i128_to_spark_decimal_bytes :1532-1558) go to the variable part with
+    (offset << 32) | length in the slot; NULL and zero-length values leave the slot 0."""
+    import decimal
+    ncols, n = batch.num_columns, batch.num_rows
+    bitset = ((ncols + 63) // 64) * 8
+    cols = [batch.column(i) for i in range(ncols)]
+    out = []
+    for r in range(n):
+        fixed = bytearray(bitset + 8 * ncols)
+        var = bytearray()
+        for c, arr in enumerate(cols):
+            t = arr.type
+            v = arr[r]
+            if not v.is_valid:
+                fixed[c // 64 * 8 + (c % 64) // 8] |= 1 << (c % 8)
+                continue
+            slot = 0
+            data = None
+            if pa.types.is_boolean(t):
+                slot = int(v.as_py())
+            elif pa.types.is_integer(t):
+                slot = v.as_py() & 0xFFFFFFFFFFFFFFFF
+            elif pa.types.is_date32(t) or pa.types.is_timestamp(t):
+                slot = v.value & 0xFFFFFFFFFFFFFFFF
+            elif pa.types.is_float32(t):
+                slot = struct.unpack("<I", struct.pack("<f", v.as_py()))[0]
+            elif pa.types.is_float64(t):
+                slot = struct.unpack("<Q", struct.pack("<d", v.as_py()))[0]
+            elif pa.types.is_decimal(t):
+                unscaled = int(v.as_py().scaleb(t.scale).to_integral_exact())
+                if t.precision <= 18:
+                    slot = unscaled & 0xFFFFFFFFFFFFFFFF
+                else:
+                    nbytes = max(1, (unscaled.bit_length() + 8) // 8) if unscaled >= 0 else max(1, ((-unscaled - 1).bit_length() + 8) // 8)
+                    data = unscaled.to_bytes(nbytes, "big", signed=True)
+            elif pa.types.is_string(t) or pa.types.is_binary(t):
+                data = v.as_py().encode() if pa.types.is_string(t) else v.as_py()
+            else:
+                raise NotImplementedError(str(t))
+            if data is not None:
+                if len(data) > 0:
+                    off = len(fixed) + len(var)
+                    var += data + b"\0" * (-len(data) % 8)
+                    slot = (off << 32) | len(data)
+            fixed[bitset + 8 * c:bitset + 8 * c + 8] = struct.pack("<Q", slot)
+        out.append(bytes(fixed) + bytes(var))
+    return out

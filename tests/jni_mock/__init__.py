@@ -23,6 +23,12 @@ def load():
     m.mock_objs.argtypes = [vp, ctypes.c_int64]
     m.mock_stream.argtypes = [ctypes.c_int64]
     m.mock_block_iterator.argtypes = [vp, ctypes.c_int64]
+    for f in ("mock_info_address", "mock_info_rows"):
+        getattr(m, f).restype = ctypes.c_int64
+        getattr(m, f).argtypes = [vp]
+    for f in ("mock_info_offsets", "mock_info_lengths"):
+        getattr(m, f).restype = vp
+        getattr(m, f).argtypes = [vp]
     m.mock_string.argtypes = [ctypes.c_char_p]
     m.mock_metrics_len.restype = ctypes.c_int64
     m.mock_metrics_len.argtypes = [vp]
@@ -80,6 +86,36 @@ class Jvm:
         s = (ctypes.c_int64 * max(len(schema_addrs), 1))(*schema_addrs)
         return f(self.env, None, self.m.mock_bytes(block, len(block)), len(block), self.m.mock_longs(a, len(array_addrs)),
                  self.m.mock_longs(s, len(schema_addrs)), 0)
+
+    def columnar_to_row(self, batch):
+        """columnarToRowInit → Convert → Close; returns the rows as bytes objects read from the NativeColumnarToRowInfo the shim built."""
+        import pyarrow as pa  # noqa: F401
+        from datafusion_comet_amd import native
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+        init = self.lib.Java_org_apache_comet_Native_columnarToRowInit
+        init.restype, init.argtypes = i64, [vp, vp, vp, i32]
+        conv = self.lib.Java_org_apache_comet_Native_columnarToRowConvert
+        conv.restype, conv.argtypes = vp, [vp, vp, i64, vp, vp, i32]
+        close = self.lib.Java_org_apache_comet_Native_columnarToRowClose
+        close.restype, close.argtypes = None, [vp, vp, i64]
+        h = init(self.env, None, None, 8192)
+        n = batch.num_columns
+        arrays = [native.ArrowArrayC() for _ in range(n)]
+        schemas = [native.ArrowSchemaC() for _ in range(n)]
+        for i in range(n):
+            batch.column(i)._export_to_c(ctypes.addressof(arrays[i]), ctypes.addressof(schemas[i]))
+        a = (ctypes.c_int64 * max(n, 1))(*[ctypes.addressof(x) for x in arrays])
+        s = (ctypes.c_int64 * max(n, 1))(*[ctypes.addressof(x) for x in schemas])
+        info = conv(self.env, None, h, self.m.mock_longs(a, n), self.m.mock_longs(s, n), batch.num_rows)
+        rows = None
+        if info:
+            k = self.m.mock_info_rows(info)
+            base = self.m.mock_info_address(info)
+            offs = (ctypes.c_int32 * k).from_address(self.m.mock_info_offsets(info))
+            lens = (ctypes.c_int32 * k).from_address(self.m.mock_info_lengths(info))
+            rows = [ctypes.string_at(base + offs[i], lens[i]) for i in range(k)]
+        close(self.env, None, h)
+        return rows
 
     def release_plan(self, handle):
         self.lib.Java_org_apache_comet_Native_releasePlan(self.env, None, handle)

@@ -8,7 +8,7 @@
 
 #include "../../datafusion-comet_amd/csrc/third_party/jni_min.h"
 
-enum { K_BYTES = 1, K_LONGS, K_OBJS, K_STREAM, K_METRICS, K_STRING, K_CLASS, K_BLOCKITER };
+enum { K_BYTES = 1, K_LONGS, K_OBJS, K_STREAM, K_METRICS, K_STRING, K_CLASS, K_BLOCKITER, K_INTS, K_INFO };
 typedef struct MObj {
   int kind;
   int64_t len;
@@ -29,7 +29,7 @@ static MObj g_cls_stream = {K_CLASS, 0, 0, 0, 0, "org/apache/arrow/c/ArrowArrayS
 static MObj g_cls_metrics = {K_CLASS, 0, 0, 0, 0, "org/apache/spark/sql/comet/CometMetricNode"};
 static MObj g_cls_other = {K_CLASS, 0, 0, 0, 0, "java/lang/Object"};
 static MObj g_cls_blockiter = {K_CLASS, 0, 0, 0, 0, "org/apache/comet/CometShuffleBlockIterator"};
-static int g_mid_memaddr, g_mid_setall, g_mid_hasnext, g_mid_getbuffer;
+static int g_mid_memaddr, g_mid_setall, g_mid_hasnext, g_mid_getbuffer, g_mid_info_ctor;
 
 static jclass f_FindClass(JNIEnv* e, const char* n) { (void)e; MObj* c = calloc(1, sizeof *c); c->kind = K_CLASS; c->cname = strdup(n); return c; }
 static jint f_ThrowNew(JNIEnv* e, jclass c, const char* m) {
@@ -51,6 +51,8 @@ static jmethodID f_GetMethodID(JNIEnv* e, jclass c, const char* n, const char* s
   (void)e;
   if (c == &g_cls_stream && !strcmp(n, "memoryAddress") && !strcmp(sig, "()J")) return &g_mid_memaddr;
   if (c == &g_cls_metrics && !strcmp(n, "set_all_from_bytes") && !strcmp(sig, "([B)V")) return &g_mid_setall;
+  if (c && ((MObj*)c)->kind == K_CLASS && ((MObj*)c)->cname && !strcmp(((MObj*)c)->cname, "org/apache/comet/NativeColumnarToRowInfo") && !strcmp(n, "<init>") && !strcmp(sig, "(J[I[I)V"))
+    return &g_mid_info_ctor;
   if (c == &g_cls_blockiter && !strcmp(n, "hasNext") && !strcmp(sig, "()I")) return &g_mid_hasnext;
   if (c == &g_cls_blockiter && !strcmp(n, "getBuffer") && !strcmp(sig, "()Ljava/nio/ByteBuffer;")) return &g_mid_getbuffer;
   return NULL;   /* a real JVM would also raise NoSuchMethodError */
@@ -71,6 +73,21 @@ static jobject f_CallObjectMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
 }
 static void* f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return b && ((MObj*)b)->kind == K_BYTES ? ((MObj*)b)->data : NULL; }
 static void f_ExceptionClear(JNIEnv* e) { (void)e; g_exc_pending = 0; }
+/* K_INTS: data = int32[len]; K_INFO (NativeColumnarToRowInfo): addr = memory address, data = MObj*[2] {offsets, lengths} */
+static jobject f_NewIntArray(JNIEnv* e, jsize n) { (void)e; MObj* o = calloc(1, sizeof *o); o->kind = K_INTS; o->len = n; o->data = calloc((size_t)n + 1, 4); return o; }
+static void f_SetIntArrayRegion(JNIEnv* e, jobject a, jsize s, jsize l, const jint* b) { (void)e; memcpy((jint*)((MObj*)a)->data + s, b, (size_t)l * 4); }
+static jobject f_NewObject(JNIEnv* e, jclass c, jmethodID m, ...) {
+  (void)e; (void)c;
+  if (m != &g_mid_info_ctor) return NULL;
+  va_list ap; va_start(ap, m);
+  MObj* o = calloc(1, sizeof *o); o->kind = K_INFO;
+  o->addr = va_arg(ap, jlong);
+  MObj** parts = malloc(2 * sizeof(MObj*));
+  parts[0] = va_arg(ap, MObj*); parts[1] = va_arg(ap, MObj*);
+  va_end(ap);
+  o->data = parts;
+  return o;
+}
 static void f_CallVoidMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
   (void)e;
   if (m != &g_mid_setall) return;
@@ -103,6 +120,7 @@ JNIEnv* mock_env(void) {
   g_tab.fn[JNI_GetLongArrayRegion] = (void*)f_GetLongArrayRegion; g_tab.fn[JNI_GetJavaVM] = (void*)f_GetJavaVM;
   g_tab.fn[JNI_CallIntMethod] = (void*)f_CallIntMethod; g_tab.fn[JNI_CallObjectMethod] = (void*)f_CallObjectMethod;
   g_tab.fn[JNI_GetDirectBufferAddress] = (void*)f_GetDirectBufferAddress; g_tab.fn[JNI_ExceptionClear] = (void*)f_ExceptionClear;
+  g_tab.fn[JNI_NewIntArray] = (void*)f_NewIntArray; g_tab.fn[JNI_SetIntArrayRegion] = (void*)f_SetIntArrayRegion; g_tab.fn[JNI_NewObject] = (void*)f_NewObject;
   return (JNIEnv*)&g_env;
 }
 void* mock_bytes(const void* p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_BYTES; o->len = n; o->data = malloc((size_t)n + 1); memcpy(o->data, p, (size_t)n); return o; }
@@ -112,6 +130,10 @@ void* mock_stream(int64_t addr) { MObj* o = calloc(1, sizeof *o); o->kind = K_ST
 void* mock_block_iterator(void** blocks, int64_t n) {
   MObj* o = calloc(1, sizeof *o); o->kind = K_BLOCKITER; o->len = n; o->data = malloc((size_t)n * 8 + 8); memcpy(o->data, blocks, (size_t)n * 8); return o;
 }
+int64_t mock_info_address(void* o) { return ((MObj*)o)->addr; }
+int64_t mock_info_rows(void* o) { return ((MObj**)((MObj*)o)->data)[0]->len; }
+const void* mock_info_offsets(void* o) { return ((MObj**)((MObj*)o)->data)[0]->data; }
+const void* mock_info_lengths(void* o) { return ((MObj**)((MObj*)o)->data)[1]->data; }
 void* mock_plain_object(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_OBJS; return o; }
 void* mock_metrics_node(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_METRICS; return o; }
 void* mock_string(const char* s) { MObj* o = calloc(1, sizeof *o); o->kind = K_STRING; o->data = strdup(s); return o; }

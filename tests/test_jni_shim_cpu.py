@@ -25,12 +25,12 @@ def test_jni_symbols_exported(built):
 
 
 def test_out_of_scope_entry_points_throw_instead_of_unsatisfied_link(jvm):
-    f = jvm.lib.Java_org_apache_comet_Native_columnarToRowInit
-    f.restype = ctypes.c_int64
-    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
-    assert f(jvm.env, None, None, 8192) == 0
+    f = jvm.lib.Java_org_apache_comet_Native_sortRowPartitionsNative
+    f.restype = None
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint8]
+    f(jvm.env, None, 0, 0, 0)
     cls, msg = jvm.exception()
-    assert cls == "org/apache/comet/CometNativeException" and "columnarToRowInit" in msg
+    assert cls == "org/apache/comet/CometNativeException" and "sortRowPartitionsNative" in msg
 
 
 def test_create_release_balances_global_refs_and_releases_stream(jvm):
