@@ -3129,7 +3129,6 @@ DevTable ExecutionContext::nested_aggregate(const Operator& agg) {
     t = sub.grouped_to_device();
   }
   input_rows += sub.input_rows;
-  for (auto& pr : sub.timed_) (void)pr;
   sub.collect_timings();
   last_kernel_ms += sub.last_kernel_ms;
   last_kernel_launches += sub.last_kernel_launches;
