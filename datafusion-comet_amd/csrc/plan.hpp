@@ -141,6 +141,7 @@ struct Operator {
   ExprP join_condition;
   BuildSide build_side = BuildSide::Left;
   bool null_aware_anti = false;
+  bool bnlj = false;                           // BroadcastNestedLoopJoin (117): no equi-keys, only the condition
   // SortMergeJoin (operator.proto:765-771): executed as a hash join whose output is then sorted by the join keys
   bool smj = false;
   std::vector<std::pair<bool, bool>> smj_sort_options;   // per key: (descending, nulls_last)

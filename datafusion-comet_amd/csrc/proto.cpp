@@ -375,6 +375,30 @@ OperatorP decode_operator_r(Reader r) {
           else b.skip(wt2);
         }
         break;
+      case 117: {
+        // BroadcastNestedLoopJoin{join_type=1, build_side=2, condition=3} (operator.proto:773-777; planner.rs:1386-1430 → NestedLoopJoinExec):
+        // executed as a hash join on a CONSTANT key — every build row sits in one chain that each probe row walks with the condition
+        op->kind = OpKind::HashJoin;
+        op->bnlj = true;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 0) op->join_type = (JoinType)b.varint();
+          else if (f2 == 2 && wt2 == 0) op->build_side = (BuildSide)b.varint();
+          else if (f2 == 3 && wt2 == 2) op->join_condition = decode_expr(b.sub());
+          else b.skip(wt2);
+        }
+        for (int side = 0; side < 2; side++) {
+          auto k = std::make_shared<Expr>();
+          k->kind = ExprKind::Literal;
+          k->proto_tag = 2;
+          k->dtype = DType::of(TypeId::Int32);
+          k->has_dtype = true;
+          k->lit_case = 3;
+          k->lit_i64 = 0;
+          (side == 0 ? op->left_keys : op->right_keys).push_back(k);
+        }
+        break;
+      }
       case 110: {
         // Window{window_expr=1 (WindowExpr{built_in_window_function=1, agg_func=2, spec=3, ignore_nulls=4, result_type=5}), order_by_list=2,
         //        partition_by_list=3, child=4}

@@ -386,7 +386,7 @@ class Operator:
     window_fns: List[tuple] = field(default_factory=list)     # window: (function name, argument Exprs, result DataType)
     partition_by: List[Expr] = field(default_factory=list)    # window
 
-    TAGS = dict(shuffle_writer=106, shuffle_scan=116, expand=107, window=110, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
+    TAGS = dict(shuffle_writer=106, shuffle_scan=116, expand=107, window=110, bnlj=117, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -499,6 +499,11 @@ class Operator:
                 body += _f_msg(4, _f_msg(19, so))
             if self.condition is not None:
                 body += _f_msg(5, self.condition.encode())
+        elif self.kind == "bnlj":
+            # BroadcastNestedLoopJoin{join_type=1, build_side=2, condition=3} (operator.proto:773-777)
+            body = (_f_varint(1, self.join_type) if self.join_type else b"") + (_f_varint(2, self.build_side) if self.build_side else b"")
+            if self.condition is not None:
+                body += _f_msg(3, self.condition.encode())
         elif self.kind == "hash_join":
             # HashJoin{left_join_keys=1,right_join_keys=2,join_type=3,condition=4,build_side=5} (operator.proto:754-763)
             body = b"".join(_f_msg(1, e.encode()) for e in self.left_keys) + b"".join(_f_msg(2, e.encode()) for e in self.right_keys)
@@ -608,6 +613,11 @@ def hash_join(left: Operator, right: Operator, left_keys: Sequence[Expr], right_
     """Keys are bound to each side's own schema; `condition` to the concatenated left ++ right schema."""
     return Operator("hash_join", [left, right], left_keys=list(left_keys), right_keys=list(right_keys), join_type=join_type,
                     build_side=build_side, condition=condition)
+
+
+def nested_loop_join(left: Operator, right: Operator, join_type: int = INNER, build_side: int = BUILD_RIGHT, condition: Optional[Expr] = None) -> Operator:
+    """BroadcastNestedLoopJoin: no equi-keys; `condition` (bound to left ++ right) decides, None = cross join."""
+    return Operator("bnlj", [left, right], join_type=join_type, build_side=build_side, condition=condition)
 
 
 def sort_merge_join(left: Operator, right: Operator, left_keys: Sequence[Expr], right_keys: Sequence[Expr], join_type: int = INNER,

@@ -673,7 +673,7 @@ def run_plan(S, op, table) -> List[Col]:
         t = pa.concat_tables(parts) if parts else pa.table({n: pa.array([], type=pa.null()) for n in op.field_names})
         t = t.select(list(op.field_names))
         return [col_from_arrow(S, t.column(i), ty) for i, ty in enumerate(op.fields)]
-    if k in ("hash_join", "sort_merge_join"):
+    if k in ("hash_join", "sort_merge_join", "bnlj"):
         left = run_plan(S, op.children[0], table)
         right = run_plan(S, op.children[1], table)
         out = _hash_join(S, ev, op, left, right)

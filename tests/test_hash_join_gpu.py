@@ -132,3 +132,27 @@ def test_sort_merge_join_operator(built, jt):
     assert _rows(got) == _rows(want) and got.num_rows > 0
     kcol = 2 if jt == S.RIGHT_OUTER else 0
     assert got.column(kcol).to_pylist() == want.column(kcol).to_pylist()       # NULLS FIRST, ascending
+
+
+@pytest.mark.parametrize("jt,build", [(S.INNER, S.BUILD_RIGHT), (S.LEFT_OUTER, S.BUILD_RIGHT), (S.LEFT_SEMI, S.BUILD_RIGHT), (S.LEFT_ANTI, S.BUILD_RIGHT), (S.INNER, S.BUILD_LEFT),
+                                      (S.FULL_OUTER, S.BUILD_LEFT)])
+def test_broadcast_nested_loop_join(built, jt, build):
+    """BroadcastNestedLoopJoin (117): joins without an equality — a range condition between the sides, and a plain cross join."""
+    import numpy as np
+    import pyarrow as pa
+    from oracle import oracle as O
+    rng = np.random.default_rng(51)
+    nl, nr = 3000, 40
+    left = pa.table({"x": pa.array(rng.integers(0, 1000, nl), pa.int64(), mask=rng.random(nl) < 0.05), "id": pa.array(np.arange(nl), pa.int64())})
+    right = pa.table({"lo": pa.array(rng.integers(0, 900, nr), pa.int64()), "hi": pa.array(rng.integers(100, 1000, nr), pa.int64(), mask=rng.random(nr) < 0.1), "tag": pa.array(["band-%02d" % i for i in range(nr)])})
+    lf, rf = [S.T_INT64, S.T_INT64], [S.T_INT64, S.T_INT64, S.T_STRING]
+    cond = S.and_(S.gt_eq(S.col(0, S.T_INT64), S.col(2, S.T_INT64)), S.lt(S.col(0, S.T_INT64), S.col(3, S.T_INT64)))      # left.x in [right.lo, right.hi)
+    plan = S.nested_loop_join(S.scan(lf), S.scan(rf), jt, build, cond)
+    ncols = 2 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 5
+    run = lambda p, nc: pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(left), native.HostInput.from_table(right)], nc, p.encode(), batch_size=0))
+    got, want = run(plan, ncols), O.run_plan_to_arrow(S, plan, [left, right])
+    key = lambda tb: sorted(zip(*[tb.column(i).to_pylist() for i in range(tb.num_columns)]), key=lambda r: tuple((v is None, str(v)) for v in r))
+    assert got.num_rows == want.num_rows > 0 and key(got) == key(want)
+    if jt == S.INNER and build == S.BUILD_RIGHT:
+        cross = S.nested_loop_join(S.scan(lf), S.scan(rf), S.INNER, S.BUILD_RIGHT, None)
+        assert run(cross, 5).num_rows == nl * nr
