@@ -1271,6 +1271,31 @@ struct Gen {
         Val a = gen(e.children[0]), b = gen(e.children[1]);
         return compare(e.kind, a, b);
       }
+      case ExprKind::BitAnd: case ExprKind::BitOr: case ExprKind::BitXor: case ExprKind::ShiftLeft: case ExprKind::ShiftRight: {
+        // Spark BitwiseAnd / Or / Xor (same integral type on both sides) and ShiftLeft / ShiftRight (Java semantics: the shift count is
+        // taken modulo the width of the value, >> is arithmetic)
+        if (e.children.size() != 2) throw CometError("bitwise expression needs two children");
+        Val a = named(gen(e.children[0])), b = named(gen(e.children[1]));
+        if (!a.t.is_integer() || !b.t.is_integer()) throw CometError("bitwise operators expect integral operands");
+        const bool shift = e.kind == ExprKind::ShiftLeft || e.kind == ExprKind::ShiftRight;
+        if (!shift && a.t.id != b.t.id) throw CometError("bitwise operator on different integral types");
+        const bool is64 = a.t.id == TypeId::Int64;
+        const std::string T = is64 ? "i64" : "i32", U = is64 ? "u64" : "u32";
+        Val r = a;
+        r.ok = and_ok(a.ok, b.ok);
+        r.maxabs = type_maxabs(a.t);
+        std::string v;
+        if (e.kind == ExprKind::BitAnd) v = "(" + T + ")" + a.v + " & (" + T + ")" + b.v;
+        else if (e.kind == ExprKind::BitOr) v = "(" + T + ")" + a.v + " | (" + T + ")" + b.v;
+        else if (e.kind == ExprKind::BitXor) v = "(" + T + ")" + a.v + " ^ (" + T + ")" + b.v;
+        else if (e.kind == ExprKind::ShiftLeft) v = "(" + T + ")((" + U + ")(" + T + ")" + a.v + " << ((int)" + b.v + " & " + (is64 ? "63" : "31") + "))";
+        else v = "(" + T + ")" + a.v + " >> ((int)" + b.v + " & " + (is64 ? "63" : "31") + ")";
+        // narrow types keep their width: Byte / Short results wrap like the JVM's (byte) / (short) casts
+        if (a.t.id == TypeId::Int8) v = "(i32)(i8)(" + v + ")";
+        else if (a.t.id == TypeId::Int16) v = "(i32)(i16)(" + v + ")";
+        r.v = "(" + std::string(rep_ctype(a.rep)) + ")(" + v + ")";
+        return r;
+      }
       case ExprKind::And: case ExprKind::Or: {
         if (e.children.size() != 2) throw CometError("AND/OR needs two children");
         Val a = gen(e.children[0]), b = gen(e.children[1]);

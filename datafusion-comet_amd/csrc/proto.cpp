@@ -227,7 +227,7 @@ ExprP decode_expr(Reader r) {
     switch (f) {
       case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
       case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
-      case 15: case 16: case 17: case 18: case 25: case 26: case 31: case 32: case 33: case 37: case 38: case 39: case 40: case 41:
+      case 15: case 16: case 17: case 18: case 25: case 26: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 38: case 39: case 40: case 41:
       case 44: case 45: case 51:
         e->kind = (ExprKind)f;
         if (e->kind == ExprKind::Bound) e->bound_index = 0;  // proto3 omits zero-valued scalars

@@ -214,6 +214,28 @@ class Evaluator:
             vals = np.where(sel, t.values, f.values) if t.dtype.type_id != S.DECIMAL else np.where(sel, t.values, f.values)
             ok = np.where(sel, t.ok(), f.ok())
             return Col(t.dtype, vals, None if ok.all() else ok)
+        if k in ("bit_and", "bit_or", "bit_xor", "shift_left", "shift_right"):
+            # Spark BitwiseAnd / Or / Xor, ShiftLeft / ShiftRight with Java semantics (count modulo the value's width, arithmetic >>)
+            a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            bits = {S.INT8: 8, S.INT16: 16, S.INT32: 32, S.INT64: 64}[a.dtype.type_id]
+            wbits = 64 if bits == 64 else 32
+            out = []
+            for x, y in zip(a.values.tolist(), b.values.tolist()):
+                if k == "bit_and":
+                    v = x & y
+                elif k == "bit_or":
+                    v = x | y
+                elif k == "bit_xor":
+                    v = x ^ y
+                elif k == "shift_left":
+                    v = x << (y & (wbits - 1))
+                else:
+                    v = x >> (y & (wbits - 1))
+                v &= (1 << wbits) - 1                      # int / long arithmetic first …
+                v = v - (1 << wbits) if v >> (wbits - 1) else v
+                v &= (1 << bits) - 1                       # … then the narrowing cast of Byte / Short results
+                out.append(v - (1 << bits) if v >> (bits - 1) else v)
+            return Col(a.dtype, np.array(out, dtype=_np_dtype(S, a.dtype)), self._and_valid(a.valid, b.valid))
         if k == "like":
             # Expr.like → DataFusion LikeExpr → arrow-string `like` (SQL LIKE, escape `\`, `_` = one character, `%` = any run,
             # newlines included); restated with Python's regex engine over code points — a different algorithm from the device matcher

@@ -337,3 +337,33 @@ def test_round_and_date_arithmetic(built):
         _oracle(S.project(S.scan(fields), [e]), t)
     ok = rnd(i, -2, S.T_INT32, fail_on_error=True)
     assert pa.Table.from_batches(_run(S.project(S.scan(fields), [ok]), table=t, ncols=1)).num_rows == n
+
+
+def test_bitwise_and_shifts(built):
+    """BitwiseAnd / BitwiseOr / BitwiseXor (expr.proto:46-48 tags 34-36) and ShiftRight / ShiftLeft (tags 42-43): Java semantics — the
+    count is taken modulo the value's width, >> is arithmetic, Byte / Short results wrap to their width; NULL if either side is."""
+    n = 30_000
+    rng = np.random.default_rng(9)
+    i64 = rng.integers(-2**63, 2**63 - 1, n)
+    i64[:4] = [2**63 - 1, -2**63, -1, 0]
+    i32 = rng.integers(-2**31, 2**31, n).astype(np.int32)
+    t = pa.table({"l": pa.array(i64, mask=rng.random(n) < 0.05), "l2": pa.array(rng.integers(-2**63, 2**63 - 1, n)),
+                  "i": pa.array(i32), "i2": pa.array(rng.integers(-2**31, 2**31, n).astype(np.int32), mask=rng.random(n) < 0.05),
+                  "s": pa.array(rng.integers(-2**15, 2**15, n).astype(np.int16)), "s2": pa.array(rng.integers(-2**15, 2**15, n).astype(np.int16)),
+                  "k": pa.array(rng.integers(-70, 70, n).astype(np.int32))})
+    fields = [S.T_INT64, S.T_INT64, S.T_INT32, S.T_INT32, S.T_INT16, S.T_INT16, S.T_INT32]
+    l, l2, i, i2, s, s2, k = (S.col(j, ty) for j, ty in enumerate(fields))
+    outs = [S.bit_and(l, l2), S.bit_or(l, l2), S.bit_xor(l, l2), S.shift_left(l, k), S.shift_right(l, k),
+            S.bit_and(i, i2), S.bit_or(i, i2), S.bit_xor(i, i2), S.shift_left(i, k), S.shift_right(i, k),
+            S.bit_and(s, s2), S.bit_or(s, s2), S.bit_xor(s, s2), S.bit_and(i, S.lit(0xFF, S.T_INT32))]
+    for at in range(0, len(outs), 7):
+        chunk = outs[at:at + 7]
+        plan = S.project(S.scan(fields), chunk)
+        got = pa.Table.from_batches(_run(plan, table=t, ncols=len(chunk), batch_size=0))
+        want = _oracle(plan, t)
+        for c in range(len(chunk)):
+            assert got.column(c).combine_chunks().equals(want.column(c).combine_chunks()), at + c
+    # and as a predicate: flags & 4 != 0
+    plan = S.filter_(S.scan(fields), S.neq(S.bit_and(i, S.lit(4, S.T_INT32)), S.lit(0, S.T_INT32)))
+    got = pa.Table.from_batches(_run(plan, table=t, ncols=len(fields), batch_size=0))
+    assert got.equals(_oracle(plan, t))
