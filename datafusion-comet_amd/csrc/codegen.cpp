@@ -499,8 +499,9 @@ struct Gen {
     const int p1 = a.t.precision, s1 = a.t.scale, p2 = b.t.precision, s2 = b.t.scale;
     const bool mul = e.kind == ExprKind::Multiply;
     const bool addsub = e.kind == ExprKind::Add || e.kind == ExprKind::Subtract;
-    if (e.kind == ExprKind::Divide) {
-      // planner.rs:1028-1057 → decimal_div (spark-expr/src/math_funcs/div.rs:71-165)
+    if (e.kind == ExprKind::Divide || e.kind == ExprKind::IntegralDivide) {
+      // planner.rs:1028-1057 → decimal_div / decimal_integral_div (spark-expr/src/math_funcs/div.rs:40-165)
+      const bool integral = e.kind == ExprKind::IntegralDivide;
       if (!e.has_dtype || e.dtype.id != TypeId::Decimal) throw CometError("Expected Decimal128 return type");
       const int s3 = e.dtype.scale;
       const int l_exp = std::max(0, s2 + s3 + 1 - s1), r_exp = std::max(0, s1 - (s2 + s3 + 1));
@@ -513,8 +514,11 @@ struct Gen {
       r.t = e.dtype;
       r.ok = and_ok(a.ok, b.ok);
       std::string val = newvar("i128"), dz = newvar("bool");
-      stmt(val + " = comet::dec_div(" + as128(a) + ", " + as128(b) + ", " + lit_u128(pow10_u128(l_exp)) + ", " + lit_u128(pow10_u128(r_exp)) + ", " + dz + ");");
+      stmt(val + " = comet::dec_div(" + as128(a) + ", " + as128(b) + ", " + lit_u128(pow10_u128(l_exp)) + ", " + lit_u128(pow10_u128(r_exp)) + ", " + dz + (integral ? ", true" : "") + ");");
       if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, dz), 8);
+      // quotient_to_i128 (div.rs:57-68): with check_divide_overflow under ANSI a quotient outside LONG raises ARITHMETIC_OVERFLOW
+      if (integral && e.check_divide_overflow && e.eval_mode == EvalMode::Ansi)
+        raise_if(and_ok(r.ok, "(" + val + " != (i128)(i64)" + val + ")"), 1);
       r.v = val;
       r.maxabs = ~(u128)0 >> 1;   // unchecked: the plan's CheckOverflow bounds it
       return r;
@@ -613,6 +617,8 @@ struct Gen {
 
   Val arithmetic(const Expr& e, Val a, Val b) {
     if (a.t.id == TypeId::Decimal && b.t.id == TypeId::Decimal) return decimal_binary(e, a, b);
+    // CometIntegralDivide always casts both sides to Decimal first (serde/arithmetic.scala:283-300)
+    if (e.kind == ExprKind::IntegralDivide) throw CometError("IntegralDivide expects Decimal128 operands");
     if (!e.has_dtype) throw CometError("arithmetic expression without return_type");
     const DType& rt = e.dtype;
     Val r;
@@ -1223,7 +1229,14 @@ struct Gen {
   }
 
   // c ? t : f with SQL NULL handling: a NULL condition selects f (If: conditional_funcs/if_expr.rs:103; CaseWhen alike)
-  Val select(const Val& c, const Val& t, const Val& f) {
+  Val select(const Val& c, const Val& t0, const Val& f0) {
+    Val t = t0, f = f0;
+    // decimals of one type may sit in 64 or 128 bits depending on their static bound: meet in 128
+    if (t.rep != f.rep && t.t.id == TypeId::Decimal && f.t.id == TypeId::Decimal && (t.rep == Rep::I64 || t.rep == Rep::I128) &&
+        (f.rep == Rep::I64 || f.rep == Rep::I128)) {
+      t.v = as128(t); t.rep = Rep::I128;
+      f.v = as128(f); f.rep = Rep::I128;
+    }
     if (t.rep != f.rep) throw CometError("If / CaseWhen branches have different types");
     std::string cond = "(" + and_ok(c.ok, c.v) + ")";
     Val r = t;
@@ -1252,7 +1265,8 @@ struct Gen {
     switch (e.kind) {
       case ExprKind::Bound: return column(e.bound_index);
       case ExprKind::Literal: return literal(e);
-      case ExprKind::Add: case ExprKind::Subtract: case ExprKind::Multiply: case ExprKind::Divide: case ExprKind::Remainder: {
+      case ExprKind::Add: case ExprKind::Subtract: case ExprKind::Multiply: case ExprKind::Divide: case ExprKind::Remainder:
+      case ExprKind::IntegralDivide: {
         if (e.children.size() != 2) throw CometError("binary expression needs two children");
         Val a = gen(e.children[0]), b = gen(e.children[1]);
         return arithmetic(e, a, b);

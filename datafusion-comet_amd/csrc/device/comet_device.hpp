@@ -453,7 +453,7 @@ CDEV i256 i256_div_pow10_half_up(const i256& v, u128 divisor) {
 // a quotient that does not fit i128 becomes i128::MAX (quotient_to_i128, div.rs:57-68); R = 0 yields 0 here (the caller
 // raises DIVIDE_BY_ZERO in ANSI mode; in the other modes Spark has already replaced zero divisors by NULL).
 // lmul = 10^l_exp, rmul = 10^r_exp; requires |r|·rmul < 2^127 (checked at plan time through the precisions).
-CDEV i128 dec_div(i128 l, i128 r, u128 lmul, u128 rmul, bool& div_by_zero) {
+CDEV i128 dec_div(i128 l, i128 r, u128 lmul, u128 rmul, bool& div_by_zero, bool integral = false) {
   const u128 R = uabs128(r) * rmul;
   div_by_zero = R == 0;
   if (div_by_zero) return 0;
@@ -464,6 +464,7 @@ CDEV i128 dec_div(i128 l, i128 r, u128 lmul, u128 rmul, bool& div_by_zero) {
   i256 five;
   five.w[0] = 5; five.w[1] = five.w[2] = five.w[3] = 0;
   i256 q10;
+  if (integral) five.w[0] = 0;   // decimal_integral_div truncates: (l / r) / 10 without the ±5
   u256_divmod_u128(i256_add(q, five), 10, q10, rem);
   const i128 kMax = (i128)(((u128)1 << 127) - 1);
   if (q10.w[3] != 0 || q10.w[2] != 0 || (q10.w[1] >> 63) != 0) return kMax;   // to_i128() failed → i128::MAX

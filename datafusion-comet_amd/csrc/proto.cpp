@@ -162,10 +162,11 @@ void decode_expr_body(Reader r, Expr& e) {
         else if (f == 2 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
         break;
       case ExprKind::Add: case ExprKind::Subtract: case ExprKind::Multiply: case ExprKind::Divide:
-      case ExprKind::Remainder:
+      case ExprKind::Remainder: case ExprKind::IntegralDivide:
         if ((f == 1 || f == 2) && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
         else if (f == 4 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
         else if (f == 5 && wt == 0) { e.eval_mode = (EvalMode)r.varint(); handled = true; }
+        else if (f == 6 && wt == 0) { e.check_divide_overflow = r.varint() != 0; handled = true; }
         break;
       case ExprKind::Cast:
         if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
@@ -227,7 +228,7 @@ ExprP decode_expr(Reader r) {
     switch (f) {
       case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
       case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
-      case 15: case 16: case 17: case 18: case 25: case 26: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 38: case 39: case 40: case 41:
+      case 15: case 16: case 17: case 18: case 25: case 26: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
       case 44: case 45: case 51:
         e->kind = (ExprKind)f;
         if (e->kind == ExprKind::Bound) e->bound_index = 0;  // proto3 omits zero-valued scalars

@@ -116,11 +116,12 @@ class Expr:
     eval_mode: int = LEGACY
     fail_on_error: bool = False
     negated: bool = False
+    check_divide_overflow: bool = False   # MathExpr field 6 (integral_divide only)
 
     # field numbers of Expr.expr_struct (expr.proto:30-107)
     TAGS = dict(literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
                 lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, like=26, scalar_func=31, eq_null_safe=32,
-                neq_null_safe=33, bit_and=34, bit_or=35, bit_xor=36, shift_right=42, shift_left=43, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
+                neq_null_safe=33, bit_and=34, bit_or=35, bit_xor=36, shift_right=42, shift_left=43, integral_divide=59, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
                 unbound=51)
 
     def encode(self) -> bytes:
@@ -132,11 +133,13 @@ class Expr:
             body = (_f_varint(1, self.index) if self.index else b"") + _f_msg(2, self.dtype.encode())
         elif k == "unbound":
             body = _f_bytes(1, b"col") + _f_msg(2, self.dtype.encode())
-        elif k in ("add", "subtract", "multiply", "divide", "remainder"):
+        elif k in ("add", "subtract", "multiply", "divide", "remainder", "integral_divide"):
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.children[1].encode())
             body += _f_msg(4, self.dtype.encode())
             if self.eval_mode:
                 body += _f_varint(5, self.eval_mode)
+            if getattr(self, "check_divide_overflow", False):
+                body += _f_varint(6, 1)
         elif k == "cast":
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_bytes(3, b"UTC")
             if self.eval_mode:
@@ -248,6 +251,21 @@ def is_not_null(a: Expr) -> Expr:
 
 def math(kind: str, a: Expr, b: Expr, return_type: DataType, eval_mode: int = LEGACY) -> Expr:
     return Expr(kind, [a, b], dtype=return_type, eval_mode=eval_mode)
+
+
+def integral_divide(a: Expr, a_type: DataType, b: Expr, b_type: DataType, eval_mode: int = LEGACY, check_divide_overflow: bool = False) -> Expr:
+    """Spark's `a div b` exactly as CometIntegralDivide serialises it (serde/arithmetic.scala:283-345): integral operands are cast to
+    Decimal(19,0), a zero divisor becomes NULL outside ANSI mode (nullIfWhenPrimitive), decimal_integral_div produces Decimal(intDig, 0),
+    CheckOverflow bounds it and a LEGACY cast brings it to Long."""
+    def as_dec(x, t):
+        return (x, t) if t.type_id == DECIMAL else (cast(x, decimal(19, 0)), decimal(19, 0))
+    (l, lt), (r, rt) = as_dec(a, a_type), as_dec(b, b_type)
+    if eval_mode != ANSI:
+        r = if_(eq(r, lit(0, rt)), lit(None, rt), r)
+    int_dig = lt.precision - lt.scale + rt.scale
+    out_t = decimal(min(int_dig if int_dig else 1, 38), 0)
+    d = Expr("integral_divide", [l, r], dtype=out_t, eval_mode=eval_mode, check_divide_overflow=check_divide_overflow)
+    return cast(check_overflow(d, out_t, fail_on_error=eval_mode == ANSI), T_INT64)
 
 
 def check_overflow(child: Expr, dtype: DataType, fail_on_error: bool = False) -> Expr:

@@ -201,7 +201,7 @@ class Evaluator:
         if k == "is_not_null":
             a = self.eval(e.children[0], cols, n)
             return Col(S.T_BOOL, a.ok().copy(), None)
-        if k in ("add", "subtract", "multiply", "divide", "remainder"):
+        if k in ("add", "subtract", "multiply", "divide", "remainder", "integral_divide"):
             a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
             return self._arith(e, a, b)
         if k == "check_overflow":
@@ -447,8 +447,9 @@ class Evaluator:
             p1, s1, p2, s2 = a.dtype.precision, a.dtype.scale, b.dtype.precision, b.dtype.scale
             mul = e.kind == "multiply"
             addsub = e.kind in ("add", "subtract")
-            if e.kind == "divide":
-                # decimal_div: spark-expr/src/math_funcs/div.rs:71-165 (non-integral), exact Python integers
+            if e.kind in ("divide", "integral_divide"):
+                # decimal_div / decimal_integral_div: spark-expr/src/math_funcs/div.rs:40-165, exact Python integers
+                integral = e.kind == "integral_divide"
                 s3 = e.dtype.scale
                 l_exp, r_exp = max(0, s2 + s3 + 1 - s1), max(0, s1 - (s2 + s3 + 1))
                 live = np.ones(n, bool) if valid is None else valid
@@ -461,8 +462,10 @@ class Evaluator:
                         res.append(0)
                         continue
                     div = abs(L) // abs(R) * (-1 if (L < 0) != (R < 0) else 1)      # BigInt division truncates toward zero
-                    q = (div - 5 if div < 0 else div + 5)
+                    q = div if integral else (div - 5 if div < 0 else div + 5)
                     q = abs(q) // 10 * (-1 if q < 0 else 1)
+                    if integral and getattr(e, "check_divide_overflow", False) and e.eval_mode == S.ANSI and live[i] and not -2**63 <= q < 2**63:
+                        raise OracleError("ARITHMETIC_OVERFLOW")     # quotient_to_i128, div.rs:57-68
                     res.append(q if -2**127 <= q < 2**127 else 2**127 - 1)           # to_i128().unwrap_or(i128::MAX)
                 return Col(e.dtype, ints_to_dec(res), valid)
             assert mul or addsub, f"decimal {e.kind} not in oracle"
