@@ -10,6 +10,7 @@
 #include "../../include/comet_amd.h"
 #include "exec.hpp"
 #include "shuffle_format.hpp"
+#include "row_shuffle.hpp"
 
 using namespace comet;
 
@@ -360,6 +361,32 @@ int32_t comet_encode_shuffle_block(struct ArrowArray** arrays, struct ArrowSchem
 }
 
 void comet_free_buffer(uint8_t* p) { free(p); }
+
+void comet_sort_row_partitions(int64_t* records, int64_t n) {
+  if (records && n > 1) comet::sort_row_partitions(records, (size_t)n);
+}
+
+int32_t comet_write_sorted_rows(const int64_t* row_addresses, const int32_t* row_sizes, int64_t row_num, const uint8_t* const* serialized_datatypes,
+                                const int32_t* datatype_lens, int32_t n_cols, const char* file_path, int32_t batch_size, int32_t checksum_enabled,
+                                int32_t checksum_algo, int64_t current_checksum, const char* compression_codec, int32_t compression_level,
+                                int64_t out_result[3]) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    if (!file_path || !out_result || row_num < 0 || n_cols < 0) throw CometError("writeSortedFileNative: bad arguments");
+    std::vector<DType> schema((size_t)n_cols);
+    for (int i = 0; i < n_cols; i++) schema[(size_t)i] = comet::decode_datatype_bytes(serialized_datatypes[i], (size_t)datatype_lens[i]);
+    const std::string codec = compression_codec ? compression_codec : "";
+    // jni_api.rs:1086-1091: unknown names fall back to the LZ4 frame codec
+    const ShuffleCodec c = codec == "zstd" ? ShuffleCodec::Zstd : codec == "snappy" ? ShuffleCodec::Snappy : ShuffleCodec::Lz4;
+    const bool has_initial = current_checksum != INT64_MIN;
+    comet::SortedFileResult r = comet::write_sorted_rows(row_addresses, row_sizes, (size_t)row_num, schema, file_path, (size_t)batch_size,
+                                                         checksum_enabled != 0, checksum_algo, has_initial, (uint32_t)current_checksum, c,
+                                                         compression_level);
+    out_result[0] = r.written;
+    out_result[1] = r.has_checksum ? (int64_t)r.checksum : INT64_MIN;
+    out_result[2] = r.encode_nanos;
+    return 0;
+  });
+}
 
 int32_t comet_parquet_describe(const char* path, char* out, size_t cap) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {

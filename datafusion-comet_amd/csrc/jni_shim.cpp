@@ -249,17 +249,54 @@ JNIEXPORT void JNICALL Java_org_apache_comet_Native_traceEnd(JNIEnv*, jclass, js
 JNIEXPORT void JNICALL Java_org_apache_comet_Native_logMemoryUsage(JNIEnv*, jclass, jstring, jlong) {}
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_getRustThreadId(JNIEnv*, jclass) { return 0; }
 
-// JVM-shuffle (row-based) entry points (jni_api.rs:1047,1130): outside the hot path
-// (SURVEY §8b "must exist").  They resolve, throw CometNativeException and return the type's zero value, so a Spark plan that
-// reaches them fails with a clear message instead of an UnsatisfiedLinkError.
-#define COMET_UNSUPPORTED(env, what) throw_java(env, COMET_ERR_NATIVE, what " is not implemented by the MI355X engine (libcomet.so, hot path only)")
-JNIEXPORT jlongArray JNICALL Java_org_apache_comet_Native_writeSortedFileNative(JNIEnv* env, jclass, jlongArray, jintArray, jobjectArray, jstring,
-                                                                                jdouble, jint, jboolean, jint, jlong, jstring, jint, jboolean) {
-  COMET_UNSUPPORTED(env, "Native.writeSortedFileNative");
-  return nullptr;
+// JVM-shuffle (row-based) entry points (jni_api.rs:1047,1130): host-memory work on Spark's UnsafeRow pages (row_shuffle.cpp)
+// Native.writeSortedFileNative (Native.scala:146-158, jni_api.rs:1043-1127): the JVM shuffle sorter's rows → shuffle blocks appended to a file.
+// preferDictionaryRatio only chooses between a dictionary and a plain encoding of string columns in the reference (row.rs:1440-1486);
+// readers unpack dictionaries (shuffle_scan.rs:175-183), so the plain encoding written here decodes to the same batches.
+JNIEXPORT jlongArray JNICALL Java_org_apache_comet_Native_writeSortedFileNative(JNIEnv* env, jclass, jlongArray addresses, jintArray rowSizes,
+                                                                                jobjectArray datatypes, jstring file, jdouble /*preferDictionaryRatio*/,
+                                                                                jint batchSize, jboolean checksumEnabled, jint checksumAlgo,
+                                                                                jlong currentChecksum, jstring compressionCodec, jint compressionLevel,
+                                                                                jboolean /*tracingEnabled*/) {
+  const jsize n = addresses ? jni_GetArrayLength(env, addresses) : 0;
+  const jsize ns = rowSizes ? jni_GetArrayLength(env, rowSizes) : 0;
+  if (n != ns) { throw_java(env, COMET_ERR_NATIVE, "writeSortedFileNative: addresses and rowSizes differ in length"); return nullptr; }
+  std::vector<jlong> addrs((size_t)n);
+  std::vector<jint> sizes((size_t)n);
+  if (n) {
+    jni_GetLongArrayRegion(env, addresses, 0, n, addrs.data());
+    jni_GetIntArrayRegion(env, rowSizes, 0, n, sizes.data());
+  }
+  const jsize nc = datatypes ? jni_GetArrayLength(env, datatypes) : 0;
+  std::vector<std::vector<uint8_t>> types((size_t)nc);
+  std::vector<const uint8_t*> tptr((size_t)nc);
+  std::vector<int32_t> tlen((size_t)nc);
+  for (jsize i = 0; i < nc; i++) {
+    jbyteArray b = (jbyteArray)jni_GetObjectArrayElement(env, datatypes, i);
+    const jsize len = b ? jni_GetArrayLength(env, b) : 0;
+    types[(size_t)i].resize((size_t)len + 1);
+    if (len) jni_GetByteArrayRegion(env, b, 0, len, (jbyte*)types[(size_t)i].data());
+    if (b) jni_DeleteLocalRef(env, b);
+    tptr[(size_t)i] = types[(size_t)i].data();
+    tlen[(size_t)i] = (int32_t)len;
+  }
+  const char* path = file ? jni_GetStringUTFChars(env, file) : nullptr;
+  const char* codec = compressionCodec ? jni_GetStringUTFChars(env, compressionCodec) : nullptr;
+  int64_t res[3] = {0, 0, 0};
+  const int32_t rc = comet_write_sorted_rows((const int64_t*)addrs.data(), (const int32_t*)sizes.data(), n, tptr.data(), tlen.data(), (int32_t)nc, path, batchSize,
+                                             checksumEnabled ? 1 : 0, checksumAlgo, currentChecksum, codec, compressionLevel, res);
+  if (path) jni_ReleaseStringUTFChars(env, file, path);
+  if (codec) jni_ReleaseStringUTFChars(env, compressionCodec, codec);
+  if (rc != 0) { throw_java(env, comet_last_error_kind(0), comet_last_error(0)); return nullptr; }
+  jlongArray out = (jlongArray)jni_NewLongArray(env, 3);
+  if (!out) { throw_java(env, COMET_ERR_NATIVE, "writeSortedFileNative: cannot allocate the result array"); return nullptr; }
+  jni_SetLongArrayRegion(env, out, 0, 3, (const jlong*)res);
+  return out;
 }
-JNIEXPORT void JNICALL Java_org_apache_comet_Native_sortRowPartitionsNative(JNIEnv* env, jclass, jlong, jlong, jboolean) {
-  COMET_UNSUPPORTED(env, "Native.sortRowPartitionsNative");
+// Native.sortRowPartitionsNative (jni_api.rs:1130-1160)
+JNIEXPORT void JNICALL Java_org_apache_comet_Native_sortRowPartitionsNative(JNIEnv* env, jclass, jlong address, jlong size, jboolean /*tracingEnabled*/) {
+  if (address == 0 || size < 0) { throw_java(env, COMET_ERR_NATIVE, "sortRowPartitionsNative: null address or negative size"); return; }
+  comet_sort_row_partitions((int64_t*)(intptr_t)address, size);
 }
 // Native.decodeShuffleBlock (jni_api.rs:1163-1181): one block in a direct ByteBuffer → Arrow C Data structs at the given addresses
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_decodeShuffleBlock(JNIEnv* env, jclass, jobject byteBuffer, jint length, jlongArray arrayAddrs,

@@ -80,8 +80,8 @@ uint32_t xxh32(const uint8_t* p, size_t n, uint32_t seed) {
   return h;
 }
 
-__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(const uint8_t* p, size_t n) {   // the x86 CRC32 instruction IS CRC-32C
-  uint64_t c = 0xFFFFFFFFu;
+__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(const uint8_t* p, size_t n, uint32_t init) {   // the x86 CRC32 instruction IS CRC-32C
+  uint64_t c = init ^ 0xFFFFFFFFu;
   while (n >= 8) {
     uint64_t v;
     memcpy(&v, p, 8);
@@ -94,11 +94,11 @@ __attribute__((target("sse4.2"))) static uint32_t crc32c_hw(const uint8_t* p, si
   return c32 ^ 0xFFFFFFFFu;
 }
 
-uint32_t crc32c(const uint8_t* p, size_t n) {
+uint32_t crc32c(const uint8_t* p, size_t n, uint32_t init) {
   static const bool hw = __builtin_cpu_supports("sse4.2");
-  if (hw) return crc32c_hw(p, n);
+  if (hw) return crc32c_hw(p, n, init);
   static const Crc32cTable tab;
-  uint32_t c = 0xFFFFFFFFu;
+  uint32_t c = init ^ 0xFFFFFFFFu;
   for (size_t i = 0; i < n; i++) c = tab.t[(c ^ p[i]) & 0xFF] ^ (c >> 8);
   return c ^ 0xFFFFFFFFu;
 }

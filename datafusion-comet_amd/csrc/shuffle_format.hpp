@@ -41,7 +41,7 @@ void snappy_compress_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out
 void lz4_compress_block(const uint8_t* src, size_t n, std::vector<uint8_t>& out);
 size_t lz4_decompress_block(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap, size_t dst_pos);
 uint32_t xxh32(const uint8_t* p, size_t n, uint32_t seed);
-uint32_t crc32c(const uint8_t* p, size_t n);
+uint32_t crc32c(const uint8_t* p, size_t n, uint32_t init = 0);   // init = the running value (crc32c_append)
 
 // move a HostBatch into caller-allocated Arrow C Data structs, one per column (prepare_output, jni_api.rs:674-742)
 void export_host_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);

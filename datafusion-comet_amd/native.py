@@ -81,6 +81,11 @@ def _load() -> ctypes.CDLL:
     lib.comet_encode_shuffle_block.restype = c.c_int32
     lib.comet_encode_shuffle_block.argtypes = [c.POINTER(c.c_void_p), c.POINTER(c.c_void_p), c.c_int32, c.c_int32, c.c_int32,
                                                c.POINTER(c.c_void_p), c.POINTER(c.c_int64)]
+    lib.comet_sort_row_partitions.restype = None
+    lib.comet_sort_row_partitions.argtypes = [c.c_void_p, c.c_int64]
+    lib.comet_write_sorted_rows.restype = c.c_int32
+    lib.comet_write_sorted_rows.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.POINTER(c.c_char_p), c.c_void_p, c.c_int32, c.c_char_p, c.c_int32,
+                                            c.c_int32, c.c_int32, c.c_int64, c.c_char_p, c.c_int32, c.POINTER(c.c_int64)]
     lib.comet_columnar_to_row_init.restype = c.c_int64
     lib.comet_columnar_to_row_init.argtypes = [c.c_int32, c.c_int32]
     lib.comet_columnar_to_row_convert.restype = c.c_int32
@@ -462,6 +467,35 @@ def encode_shuffle_block(batch: pa.RecordBatch, codec: int = 0, level: int = 1) 
     data = ctypes.string_at(out.value, out_len.value) if out_len.value else b""
     l.comet_free_buffer(out)
     return data
+
+
+NO_CHECKSUM = -2**63   # Long.MinValue: "no checksum yet" / "checksums disabled" (jni_api.rs:1078-1083, 1110-1116)
+
+
+def sort_row_partitions(records) -> None:
+    """Native.sortRowPartitionsNative: sorts a contiguous int64 numpy array in place, ascending."""
+    import numpy as np
+    assert records.dtype == np.int64 and records.flags["C_CONTIGUOUS"]
+    lib().comet_sort_row_partitions(records.ctypes.data, len(records))
+
+
+def write_sorted_rows(row_addresses, row_sizes, datatypes, path: str, batch_size: int, codec: str = "lz4", level: int = 1,
+                      checksum_enabled: bool = False, checksum_algo: int = 0, current_checksum: int = NO_CHECKSUM):
+    """Native.writeSortedFileNative: UnsafeRows at `row_addresses` (int64 array) / `row_sizes` (int32 array) with the serde DataTypes
+    `datatypes` are appended to `path` as shuffle blocks; returns (bytes written, checksum or NO_CHECKSUM, encode nanoseconds)."""
+    import numpy as np
+    l = lib()
+    a = np.ascontiguousarray(row_addresses, dtype=np.int64)
+    s = np.ascontiguousarray(row_sizes, dtype=np.int32)
+    enc = [t.encode() for t in datatypes]
+    tp = (ctypes.c_char_p * max(len(enc), 1))(*enc)
+    tl = np.array([len(e) for e in enc] or [0], dtype=np.int32)
+    out = (ctypes.c_int64 * 3)()
+    rc = l.comet_write_sorted_rows(a.ctypes.data, s.ctypes.data, len(a), tp, tl.ctypes.data, len(enc), path.encode(), batch_size,
+                                   1 if checksum_enabled else 0, checksum_algo, current_checksum, codec.encode(), level, out)
+    if rc != 0:
+        _raise_last(0)
+    return out[0], out[1], out[2]
 
 
 class ColumnarToRow:

@@ -165,6 +165,22 @@ int32_t comet_columnar_to_row_convert(int64_t handle, struct ArrowArray** arrays
 void comet_columnar_to_row_close(int64_t handle);
 const char* comet_columnar_to_row_error(int64_t handle);
 
+/* Replace Java_org_apache_comet_Native_sortRowPartitionsNative (native/core/src/execution/jni_api.rs:1130-1160): sorts the n packed
+ * i64 records (partition id in the high bits, row pointer below) of Spark's shuffle sorter in place, ascending as signed longs. */
+void comet_sort_row_partitions(int64_t* records, int64_t n);
+
+/* Replace Java_org_apache_comet_Native_writeSortedFileNative (jni_api.rs:1043-1127 → process_sorted_row_partition,
+ * native/shuffle/src/spark_unsafe/row.rs:1342-1438): reads row_num Spark UnsafeRows (address + size each) of n_cols fields whose types
+ * are the serialized spark_expression.DataType messages, and APPENDS them to file_path as shuffle blocks of at most batch_size rows
+ * (same block format as comet_encode_shuffle_block).  compression_codec is "zstd" | "lz4" | "snappy"; anything else means lz4, as in
+ * the reference.  checksum_algo: 0 CRC32, 1 Adler32, 2 CRC32C, continued from current_checksum unless that is INT64_MIN.
+ * out_result = {bytes written, checksum or INT64_MIN when disabled, nanoseconds spent encoding}.  Host-memory work (the rows are JVM
+ * off-heap pages).  Returns 0, or -2 on error (comet_last_error(0)). */
+int32_t comet_write_sorted_rows(const int64_t* row_addresses, const int32_t* row_sizes, int64_t row_num, const uint8_t* const* serialized_datatypes,
+                                const int32_t* datatype_lens, int32_t n_cols, const char* file_path, int32_t batch_size, int32_t checksum_enabled,
+                                int32_t checksum_algo, int64_t current_checksum, const char* compression_codec, int32_t compression_level,
+                                int64_t out_result[3]);
+
 /* Host-only description of a Parquet footer as parsed by the library's own Thrift reader (rows, row groups, schema
  * elements, per-chunk codec/offsets) — the metadata the NativeScan path (native/core/src/parquet/parquet_exec.rs:60-211)
  * plans from.  Returns 0, or -2 on error. */

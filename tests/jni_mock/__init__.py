@@ -16,11 +16,15 @@ def load():
     m = ctypes.CDLL(_SO)
     vp = ctypes.c_void_p
     m.mock_env.restype = vp
-    for f in ("mock_bytes", "mock_longs", "mock_objs", "mock_stream", "mock_plain_object", "mock_metrics_node", "mock_string", "mock_block_iterator"):
+    for f in ("mock_bytes", "mock_longs", "mock_objs", "mock_stream", "mock_plain_object", "mock_metrics_node", "mock_string", "mock_block_iterator", "mock_ints", "mock_array_data"):
         getattr(m, f).restype = vp
     m.mock_bytes.argtypes = [ctypes.c_char_p, ctypes.c_int64]
     m.mock_longs.argtypes = [vp, ctypes.c_int64]
     m.mock_objs.argtypes = [vp, ctypes.c_int64]
+    m.mock_ints.argtypes = [vp, ctypes.c_int64]
+    m.mock_array_data.argtypes = [vp]
+    m.mock_array_len.restype = ctypes.c_int64
+    m.mock_array_len.argtypes = [vp]
     m.mock_stream.argtypes = [ctypes.c_int64]
     m.mock_block_iterator.argtypes = [vp, ctypes.c_int64]
     for f in ("mock_info_address", "mock_info_rows"):
@@ -116,6 +120,30 @@ class Jvm:
             rows = [ctypes.string_at(base + offs[i], lens[i]) for i in range(k)]
         close(self.env, None, h)
         return rows
+
+    def sort_row_partitions(self, address: int, size: int):
+        f = self.lib.Java_org_apache_comet_Native_sortRowPartitionsNative
+        f.restype, f.argtypes = None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint8]
+        f(self.env, None, address, size, 0)
+
+    def write_sorted_file(self, addresses, row_sizes, datatypes, path: str, batch_size: int, checksum_enabled: bool, checksum_algo: int,
+                          current_checksum: int, codec: str, level: int = 1, prefer_dictionary_ratio: float = 10.0):
+        """Native.writeSortedFileNative with the argument list of Native.scala:146-158; returns the three longs or None (exception pending)."""
+        vp, i64, i32, u8 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint8
+        f = self.lib.Java_org_apache_comet_Native_writeSortedFileNative
+        f.restype = vp
+        f.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_double, i32, u8, i32, i64, vp, i32, u8]
+        a = (i64 * max(len(addresses), 1))(*addresses)
+        s = (i32 * max(len(row_sizes), 1))(*row_sizes)
+        objs = [self.m.mock_bytes(t, len(t)) for t in datatypes]
+        arr = (vp * max(len(objs), 1))(*objs)
+        out = f(self.env, None, self.m.mock_longs(a, len(addresses)), self.m.mock_ints(s, len(row_sizes)), self.m.mock_objs(arr, len(objs)),
+                self.m.mock_string(path.encode()), prefer_dictionary_ratio, batch_size, 1 if checksum_enabled else 0, checksum_algo, current_checksum,
+                self.m.mock_string(codec.encode()), level, 0)
+        if not out:
+            return None
+        k = self.m.mock_array_len(out)
+        return list((i64 * k).from_address(self.m.mock_array_data(out)))
 
     def release_plan(self, handle):
         self.lib.Java_org_apache_comet_Native_releasePlan(self.env, None, handle)

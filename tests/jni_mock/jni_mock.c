@@ -105,6 +105,9 @@ static jobject f_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { (vo
 static jbyteArray f_NewByteArray(JNIEnv* e, jsize n) { (void)e; MObj* o = calloc(1, sizeof *o); o->kind = K_BYTES; o->len = n; o->data = calloc(1, (size_t)n + 1); return o; }
 static void f_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, jbyte* b) { (void)e; memcpy(b, (char*)((MObj*)a)->data + s, (size_t)l); }
 static void f_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, const jbyte* b) { (void)e; memcpy((char*)((MObj*)a)->data + s, b, (size_t)l); }
+static void f_GetIntArrayRegion(JNIEnv* e, jintArray a, jsize s, jsize l, jint* b) { (void)e; memcpy(b, (jint*)((MObj*)a)->data + s, (size_t)l * 4); }
+static jobject f_NewLongArray(JNIEnv* e, jsize n) { (void)e; MObj* o = calloc(1, sizeof *o); o->kind = K_LONGS; o->len = n; o->data = calloc((size_t)n + 1, 8); return o; }
+static void f_SetLongArrayRegion(JNIEnv* e, jobject a, jsize s, jsize l, const jlong* b) { (void)e; memcpy((jlong*)((MObj*)a)->data + s, b, (size_t)l * 8); }
 static void f_GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, jlong* b) { (void)e; memcpy(b, (jlong*)((MObj*)a)->data + s, (size_t)l * 8); }
 static jint f_GetJavaVM(JNIEnv* e, JavaVM** vm) { (void)e; *vm = (JavaVM*)&g_vm; return 0; }
 
@@ -120,11 +123,15 @@ JNIEnv* mock_env(void) {
   g_tab.fn[JNI_GetLongArrayRegion] = (void*)f_GetLongArrayRegion; g_tab.fn[JNI_GetJavaVM] = (void*)f_GetJavaVM;
   g_tab.fn[JNI_CallIntMethod] = (void*)f_CallIntMethod; g_tab.fn[JNI_CallObjectMethod] = (void*)f_CallObjectMethod;
   g_tab.fn[JNI_GetDirectBufferAddress] = (void*)f_GetDirectBufferAddress; g_tab.fn[JNI_ExceptionClear] = (void*)f_ExceptionClear;
+  g_tab.fn[JNI_GetIntArrayRegion] = (void*)f_GetIntArrayRegion; g_tab.fn[JNI_NewLongArray] = (void*)f_NewLongArray; g_tab.fn[JNI_SetLongArrayRegion] = (void*)f_SetLongArrayRegion;
   g_tab.fn[JNI_NewIntArray] = (void*)f_NewIntArray; g_tab.fn[JNI_SetIntArrayRegion] = (void*)f_SetIntArrayRegion; g_tab.fn[JNI_NewObject] = (void*)f_NewObject;
   return (JNIEnv*)&g_env;
 }
 void* mock_bytes(const void* p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_BYTES; o->len = n; o->data = malloc((size_t)n + 1); memcpy(o->data, p, (size_t)n); return o; }
 void* mock_longs(const int64_t* p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_LONGS; o->len = n; o->data = malloc((size_t)n * 8 + 8); memcpy(o->data, p, (size_t)n * 8); return o; }
+void* mock_ints(const int32_t* p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_INTS; o->len = n; o->data = malloc((size_t)n * 4 + 8); memcpy(o->data, p, (size_t)n * 4); return o; }
+const void* mock_array_data(void* o) { return ((MObj*)o)->data; }
+int64_t mock_array_len(void* o) { return ((MObj*)o)->len; }
 void* mock_objs(void** p, int64_t n) { MObj* o = calloc(1, sizeof *o); o->kind = K_OBJS; o->len = n; o->data = malloc((size_t)n * 8 + 8); memcpy(o->data, p, (size_t)n * 8); return o; }
 void* mock_stream(int64_t addr) { MObj* o = calloc(1, sizeof *o); o->kind = K_STREAM; o->addr = addr; return o; }
 void* mock_block_iterator(void** blocks, int64_t n) {

@@ -1,0 +1,197 @@
+"""The row-based (JVM columnar) shuffle entry points — host-memory work, so these run without a GPU:
+Native.sortRowPartitionsNative (jni_api.rs:1130-1160) and Native.writeSortedFileNative (jni_api.rs:1043-1127 →
+process_sorted_row_partition, native/shuffle/src/spark_unsafe/row.rs:1342-1438).  The rows are produced by the oracle's UnsafeRow
+writer; the files are read back with the oracle's block decoder (pyarrow IPC + codecs) and the checksums are checked against zlib."""
+import ctypes
+import decimal
+import os
+import struct
+import zlib
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native, serde as S
+from oracle import shuffle_oracle as SO
+
+from tests.jni_mock import Jvm
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    return native.lib()
+
+
+def _table(n, seed=3):
+    rng = np.random.default_rng(seed)
+    null = lambda p=0.1: rng.random(n) < p
+    words = ["", "a", "shuffle", "x" * 37, "wavefront-64", "héllo wörld", "0123456789abcdef"]
+    decimal.getcontext().prec = 60          # scaleb rounds to the context precision (28 by default)
+    dec_small = [decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**11, 10**11, n)]
+    dec_wide = [decimal.Decimal(int(v) * 10**15 + int(w)).scaleb(-6) for v, w in zip(rng.integers(-10**17, 10**17, n), rng.integers(0, 10**15, n))]
+    dec_wide[:4] = [decimal.Decimal(0), decimal.Decimal(-1).scaleb(-6), decimal.Decimal(10**38 - 1).scaleb(-6), decimal.Decimal(-(10**38 - 1)).scaleb(-6)]
+    cols = {
+        "b": pa.array(rng.random(n) < 0.5, mask=null()),
+        "i8": pa.array(rng.integers(-128, 128, n).astype(np.int8), mask=null()),
+        "i16": pa.array(rng.integers(-2**15, 2**15, n).astype(np.int16)),
+        "i32": pa.array(rng.integers(-2**31, 2**31, n).astype(np.int32), mask=null()),
+        "i64": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=null()),
+        "f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=null()),
+        "f64": pa.array(rng.standard_normal(n), mask=null()),
+        "s": pa.array([words[k] for k in rng.integers(0, len(words), n)], pa.string(), mask=null(0.2)),
+        "bin": pa.array([bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in rng.integers(0, 20, n)], pa.binary(), mask=null()),
+        "d": pa.array(rng.integers(-20000, 40000, n).astype(np.int32), pa.int32()).cast(pa.date32()),
+        "ts": pa.array(rng.integers(-10**15, 10**15, n), pa.int64(), mask=null()).cast(pa.timestamp("us", tz="UTC")),
+        "dec": pa.array(dec_small, pa.decimal128(12, 2), mask=null()),
+        "wide": pa.array(dec_wide, pa.decimal128(38, 6), mask=null()),
+    }
+    types = [S.T_BOOL, S.T_INT8, S.T_INT16, S.T_INT32, S.T_INT64, S.T_FLOAT, S.T_DOUBLE, S.T_STRING, S.DataType(S.BYTES), S.T_DATE, S.T_TIMESTAMP,
+             S.decimal(12, 2), S.decimal(38, 6)]
+    return pa.table(cols), types
+
+
+def _rows_in_memory(batch):
+    """UnsafeRows laid out back to back in one buffer, as Spark's memory pages hold them; (buffer, addresses, sizes)."""
+    rows = SO.unsafe_rows(batch)
+    buf = ctypes.create_string_buffer(b"".join(rows), sum(len(r) for r in rows) + 8)
+    base = ctypes.addressof(buf)
+    sizes = np.array([len(r) for r in rows], dtype=np.int32)
+    addrs = base + np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.int64)]) if len(rows) else np.zeros(0, np.int64)
+    return buf, np.asarray(addrs, dtype=np.int64), sizes
+
+
+def _read_blocks(path):
+    data = open(path, "rb").read()
+    out, at = [], 0
+    while at < len(data):
+        (rest,) = struct.unpack_from("<Q", data, at)
+        out.append(SO.decode_block(data[at + 16:at + 8 + rest]))
+        at += 8 + rest
+    return out, data
+
+
+def _same(got: pa.Table, want: pa.Table):
+    assert got.num_rows == want.num_rows and got.num_columns == want.num_columns
+    for c in range(want.num_columns):
+        g, w = got.column(c).combine_chunks(), want.column(c).combine_chunks()
+        assert g.type == w.type, (c, g.type, w.type)
+        assert g.equals(w), c
+
+
+def test_sort_row_partitions(built):
+    """rdxsort on the i64 slice: ascending signed order, in place; small, large, duplicated, negative and degenerate inputs."""
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 2, 255, 256, 1000, 300_000):
+        a = rng.integers(-2**63, 2**63 - 1, n)
+        want = np.sort(a)
+        native.sort_row_partitions(a)
+        assert (a == want).all()
+    # what the sorter really sorts: partition id in the top 24 bits over a 40-bit row pointer (most bytes equal between records)
+    pid = rng.integers(0, 200, 200_000).astype(np.int64)
+    ptr = rng.integers(0, 2**27, 200_000).astype(np.int64) * 8
+    packed = (pid << 40) | ptr
+    want = np.sort(packed)
+    native.sort_row_partitions(packed)
+    assert (packed == want).all()
+    same = np.full(5000, 42, np.int64)
+    native.sort_row_partitions(same)
+    assert (same == 42).all()
+
+
+@pytest.mark.parametrize("codec", ["zstd", "lz4", "snappy"])
+def test_write_sorted_rows_roundtrip(built, tmp_path, codec):
+    t, types = _table(2500)
+    batch = t.combine_chunks().to_batches()[0]
+    buf, addrs, sizes = _rows_in_memory(batch)
+    path = str(tmp_path / "sorted.data")
+    written, checksum, nanos = native.write_sorted_rows(addrs, sizes, types, path, batch_size=1000, codec=codec)
+    blocks, data = _read_blocks(path)
+    assert written == len(data) == os.path.getsize(path)
+    assert checksum == native.NO_CHECKSUM and nanos > 0
+    assert [b.num_rows for b in blocks] == [1000, 1000, 500]          # one block per batch_size rows (row.rs:1391-1431)
+    assert data[16:20] == {"zstd": b"ZSTD", "lz4": b"LZ4_", "snappy": b"SNAP"}[codec]
+    _same(pa.Table.from_batches(blocks), t)
+    # the file is opened for append (row.rs:1380-1383): a second call adds blocks after the first ones
+    w2, _, _ = native.write_sorted_rows(addrs[:10], sizes[:10], types, path, batch_size=1000, codec=codec)
+    blocks2, data2 = _read_blocks(path)
+    assert len(data2) == written + w2 and len(blocks2) == 4 and blocks2[3].num_rows == 10
+    _same(pa.Table.from_batches(blocks2[3:]), t.slice(0, 10))
+
+
+def test_write_sorted_rows_checksums(built, tmp_path):
+    """CRC32 / Adler32 / CRC32C over the bytes written, fresh or continued from Spark's running value (writers/checksum.rs:39-110)."""
+    t, types = _table(700, seed=5)
+    batch = t.combine_chunks().to_batches()[0]
+    buf, addrs, sizes = _rows_in_memory(batch)
+
+    def crc32c(b, init=0):
+        c = init ^ 0xFFFFFFFF
+        tab = SO._crc32c_table()
+        for x in b:
+            c = tab[(c ^ x) & 0xFF] ^ (c >> 8)
+        return c ^ 0xFFFFFFFF
+    assert crc32c(b"123456789") == 0xE3069283                         # the CRC-32C check value
+    for algo, ref in ((0, lambda b, i=None: zlib.crc32(b) if i is None else zlib.crc32(b, i)),
+                      (1, lambda b, i=None: zlib.adler32(b) if i is None else zlib.adler32(b, i)),
+                      (2, lambda b, i=None: crc32c(b) if i is None else crc32c(b, i))):
+        path = str(tmp_path / f"c{algo}.data")
+        w, cs, _ = native.write_sorted_rows(addrs, sizes, types, path, batch_size=256, codec="lz4", checksum_enabled=True, checksum_algo=algo)
+        data = open(path, "rb").read()
+        assert w == len(data) and cs == ref(data)
+        w2, cs2, _ = native.write_sorted_rows(addrs[:100], sizes[:100], types, path, batch_size=256, codec="lz4", checksum_enabled=True,
+                                              checksum_algo=algo, current_checksum=cs)
+        data2 = open(path, "rb").read()
+        assert cs2 == ref(data2) == ref(data2[len(data):], cs)
+    with pytest.raises(native.CometNativeException, match="Unsupported checksum algorithm"):
+        native.write_sorted_rows(addrs, sizes, types, str(tmp_path / "bad.data"), batch_size=256, checksum_enabled=True, checksum_algo=7)
+
+
+def test_write_sorted_rows_edges(built, tmp_path):
+    t, types = _table(50, seed=7)
+    batch = t.combine_chunks().to_batches()[0]
+    buf, addrs, sizes = _rows_in_memory(batch)
+    # no rows: nothing is written, the file exists (created by the open)
+    path = str(tmp_path / "empty.data")
+    assert native.write_sorted_rows(addrs[:0], sizes[:0], types, path, batch_size=10)[0] == 0
+    assert os.path.getsize(path) == 0
+    # an unknown codec name means LZ4 (jni_api.rs:1086-1091)
+    path = str(tmp_path / "odd.data")
+    native.write_sorted_rows(addrs, sizes, types, path, batch_size=100, codec="brotli")
+    assert open(path, "rb").read()[16:20] == b"LZ4_"
+    # rows in a different order than memory order (what a sort produces)
+    order = np.random.default_rng(1).permutation(50)
+    path = str(tmp_path / "perm.data")
+    native.write_sorted_rows(addrs[order], sizes[order], types, path, batch_size=100)
+    _same(pa.Table.from_batches(_read_blocks(path)[0]), t.take(pa.array(order)))
+    # a row too short for its schema is rejected instead of read past
+    with pytest.raises(native.CometNativeException, match="shorter than its fixed-width region"):
+        native.write_sorted_rows(addrs[:1], np.array([16], np.int32), types, str(tmp_path / "short.data"), batch_size=10)
+    with pytest.raises(native.CometNativeException, match="cannot open"):
+        native.write_sorted_rows(addrs, sizes, types, str(tmp_path / "no" / "such" / "dir.data"), batch_size=10)
+
+
+def test_jni_row_shuffle_entries(built, tmp_path):
+    """The same two entry points through their JNI exports with Native.scala's argument lists (146-158, 168-171)."""
+    jvm = Jvm(built)
+    a = np.random.default_rng(2).integers(-2**63, 2**63 - 1, 10_000)
+    want = np.sort(a)
+    jvm.sort_row_partitions(a.ctypes.data, len(a))
+    assert jvm.exception() is None and (a == want).all()
+    jvm.sort_row_partitions(0, 5)
+    assert "null address" in jvm.exception()[1]
+    t, types = _table(300, seed=11)
+    batch = t.combine_chunks().to_batches()[0]
+    buf, addrs, sizes = _rows_in_memory(batch)
+    path = str(tmp_path / "jni.data")
+    res = jvm.write_sorted_file(addrs.tolist(), sizes.tolist(), [x.encode() for x in types], path, 128, True, 0, native.NO_CHECKSUM, "zstd", 3)
+    assert jvm.exception() is None
+    blocks, data = _read_blocks(path)
+    assert res[0] == len(data) and res[1] == zlib.crc32(data) and res[2] > 0
+    _same(pa.Table.from_batches(blocks), t)
+    res = jvm.write_sorted_file(addrs.tolist(), sizes.tolist(), [x.encode() for x in types], str(tmp_path / "none" / "x.data"), 128, False, 0,
+                                native.NO_CHECKSUM, "lz4")
+    cls, msg = jvm.exception()
+    assert res is None and cls == "org/apache/comet/CometNativeException" and "cannot open" in msg
