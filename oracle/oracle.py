@@ -298,6 +298,30 @@ class Evaluator:
                     out[i] = {"year": d.year, "month": d.month, "day": d.day, "quarter": (d.month - 1) // 3 + 1, "dow": (d.weekday() + 1) % 7,
                               "doy": d.timetuple().tm_yday}[part]
             return Col(S.T_INT32, out, a.valid)
+        if f == "murmur3_hash":
+            # spark_murmur3_hash (hash_funcs/murmur3.rs:24-70): seed literal last, NULLs skipped, result never NULL
+            C = _lib()
+            seed = e.children[-1]
+            if seed.kind != "literal" or seed.value is None or seed.dtype.type_id != S.INT32:
+                raise OracleError("The seed of function murmur3_hash must be an Int32 scalar value")
+            h = np.full(max(n, 1), seed.value & 0xFFFFFFFF, np.uint32)
+            for ch in e.children[:-1]:
+                a = self.eval(ch, cols, n)
+                vb = None if a.valid is None else np.ascontiguousarray(a.valid.astype(np.uint8))
+                tid = a.dtype.type_id
+                if tid == S.DECIMAL:
+                    C.o_murmur3_decimal(_p(np.ascontiguousarray(a.values)), ctypes.c_int32(a.dtype.precision), _p(vb), ctypes.c_int64(n), _p(h))
+                elif tid in (S.INT64, S.TIMESTAMP, S.TIMESTAMP_NTZ):
+                    C.o_murmur3_i64(_p(np.ascontiguousarray(a.values, dtype=np.int64)), _p(vb), ctypes.c_int64(n), _p(h))
+                elif tid in (S.INT8, S.INT16, S.INT32, S.DATE, S.BOOL):
+                    C.o_murmur3_i32(_p(np.ascontiguousarray(a.values.astype(np.int32))), _p(vb), ctypes.c_int64(n), _p(h))
+                elif tid == S.FLOAT:
+                    C.o_murmur3_f32(_p(np.ascontiguousarray(a.values, dtype=np.float32)), _p(vb), ctypes.c_int64(n), _p(h))
+                elif tid == S.DOUBLE:
+                    C.o_murmur3_f64(_p(np.ascontiguousarray(a.values, dtype=np.float64)), _p(vb), ctypes.c_int64(n), _p(h))
+                else:
+                    raise OracleError(f"murmur3_hash over {a.dtype} is not restated")
+            return Col(S.T_INT32, h[:n].view(np.int32).copy(), None)
         if f in ("date_add", "date_sub", "date_diff", "datediff"):
             # wrapping 32-bit day arithmetic (datafusion-spark SparkDateAdd / SparkDateSub; datetime_funcs/date_diff.rs:72-110)
             a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)

@@ -411,3 +411,40 @@ def test_integral_divide(built):
         _run(chk, table=t2, ncols=1)
     with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW"):
         _oracle(chk, t2)
+
+
+def test_murmur3_hash_expression(built):
+    """Spark's hash(...) = murmur3_hash(cols..., seed literal) (hash_funcs/murmur3.rs:24-70): every non-NULL value folds into the running
+    hash in argument order, per-type encodings as in the partitioning hash, never NULL; also over a computed operand."""
+    from datafusion_comet_amd import tpch
+    n = 40_000
+    rng = np.random.default_rng(21)
+    f64 = rng.standard_normal(n)
+    f64[:3] = [0.0, -0.0, np.nan]
+    t = pa.table({"b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1), "i8": pa.array(rng.integers(-128, 128, n).astype(np.int8)),
+                  "i32": pa.array(rng.integers(-2**31, 2**31, n).astype(np.int32), mask=rng.random(n) < 0.1),
+                  "i64": pa.array(rng.integers(-2**63, 2**63 - 1, n), mask=rng.random(n) < 0.1),
+                  "f32": pa.array(rng.standard_normal(n).astype(np.float32)), "f64": pa.array(f64, mask=rng.random(n) < 0.1),
+                  "d": tpch._dec128_array(rng.integers(-10**11, 10**11, n), 12, 2), "w": tpch._dec128_array(rng.integers(-10**17, 10**17, n), 30, 4),
+                  "dt": pa.array(rng.integers(-20000, 40000, n).astype(np.int32), pa.int32()).cast(pa.date32())})
+    D, W = S.decimal(12, 2), S.decimal(30, 4)
+    fields = [S.T_BOOL, S.T_INT8, S.T_INT32, S.T_INT64, S.T_FLOAT, S.T_DOUBLE, D, W, S.T_DATE]
+    c = [S.col(j, ty) for j, ty in enumerate(fields)]
+    seed = S.lit(42, S.T_INT32)
+    h = lambda *xs, s=seed: S.scalar_func("murmur3_hash", list(xs) + [s], S.T_INT32)
+    outs = [h(c[0]), h(c[1]), h(c[2]), h(c[3]), h(c[4]), h(c[5]), h(c[6]), h(c[7]), h(c[8]), h(*c), h(c[2], c[3], s=S.lit(-7, S.T_INT32)),
+            h(S.math("add", c[3], S.lit(1, S.T_INT64), S.T_INT64))]
+    for at in range(0, len(outs), 6):
+        chunk = outs[at:at + 6]
+        plan = S.project(S.scan(fields), chunk)
+        got = pa.Table.from_batches(_run(plan, table=t, ncols=len(chunk), batch_size=0))
+        want = _oracle(plan, t)
+        for k in range(len(chunk)):
+            assert got.column(k).null_count == 0
+            assert got.column(k).combine_chunks().equals(want.column(k).combine_chunks()), at + k
+    # pmod(hash(keys), n) as computed in a projection equals the shuffle writer's partition ids for the same keys
+    from oracle import oracle as O
+    ids = O.hash_partition_ids(S, t, [2, 3], 200)
+    plan = S.project(S.scan(fields), [h(c[2], c[3])])
+    hv = pa.Table.from_batches(_run(plan, table=t, ncols=1, batch_size=0)).column(0).to_numpy().astype(np.int64)
+    assert ((hv % 200 + 200) % 200 == ids).all()

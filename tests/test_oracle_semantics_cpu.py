@@ -116,3 +116,34 @@ def test_shuffle_block_layout_known_answers():
     assert SO.encode_block(b.slice(0, 0), 1) == b""
     data, index, rows = SO.shuffle_write(S, pa.Table.from_batches([b]), "single", [], 1, 8192)
     assert np.frombuffer(index, "<i8").tolist() == [0, len(data)] and [r.tolist() for r in rows] == [[0, 1, 2]]
+
+
+def test_murmur3_hash_and_bitwise_known_answers():
+    """hash(...) = murmur3_hash with seed 42 against the reference's own vectors (spark-expr/src/hash_funcs/murmur3.rs:209-265), NULL
+    skipping and chaining; Java's shift / bitwise results; `div` truncation."""
+    u = lambda xs: [x - (1 << 32) if x >= 1 << 31 else x for x in xs]
+    seed = S.lit(42, S.T_INT32)
+    h = lambda *cols: S.scalar_func("murmur3_hash", list(cols) + [seed], S.T_INT32)
+    t = pa.table({"i8": pa.array([1, 0, -1, 127, -128], pa.int8()), "i32": pa.array([1, 0, -1, 2**31 - 1, -2**31], pa.int32()),
+                  "i64": pa.array([1, 0, -1, 2**63 - 1, -2**63], pa.int64()), "f64": pa.array([1.0, 0.0, -0.0, -1.0, 99999999999.99999999999]),
+                  "n": pa.array([None, 5, None, 7, None], pa.int32())})
+    fields = [S.T_INT8, S.T_INT32, S.T_INT64, S.T_DOUBLE, S.T_INT32]
+    c = [S.col(i, ty) for i, ty in enumerate(fields)]
+    proj = lambda e: S.project(S.scan(fields), [e])
+    assert _col(proj(h(c[0])), t) == u([0xdea578e3, 0x379fae8f, 0xa0590e3d, 0x43b4d8ed, 0x422a1365])
+    assert _col(proj(h(c[1])), t) == u([0xdea578e3, 0x379fae8f, 0xa0590e3d, 0x07fb67e7, 0x2b1f0fc6])
+    assert _col(proj(h(c[2])), t) == u([0x99f0149d, 0x9c67b85d, 0xc8008529, 0xa05b5d7b, 0xcd1e64fb])
+    assert _col(proj(h(c[3])), t) == u([0xe4876492, 0x9c67b85d, 0x9c67b85d, 0x13d81357, 0xb87e1595])
+    # a NULL leaves the running hash alone: hash(n, i32) == hash(i32) where n is NULL; the result is never NULL
+    both, only = _col(proj(h(c[4], c[1])), t), _col(proj(h(c[1])), t)
+    assert [both[i] == only[i] for i in range(5)] == [True, False, True, False, True] and None not in both
+    # Java: 1 << 33 on an int shifts by 1; -8 >> 1 = -4; (byte)(0x7f << 1) wraps; 7 div -2 = -3
+    t2 = pa.table({"a": pa.array([1, -8, 0x40000000], pa.int32()), "k": pa.array([33, 1, 1], pa.int32()), "l": pa.array([7, -7, -2**63], pa.int64()),
+                   "m": pa.array([-2, 2, -1], pa.int64())})
+    f2 = [S.T_INT32, S.T_INT32, S.T_INT64, S.T_INT64]
+    a, k, l, m = (S.col(i, ty) for i, ty in enumerate(f2))
+    p2 = lambda e: S.project(S.scan(f2), [e])
+    assert _col(p2(S.shift_left(a, k)), t2) == [2, -16, -2**31]
+    assert _col(p2(S.shift_right(a, k)), t2) == [0, -4, 0x20000000]
+    assert _col(p2(S.bit_xor(a, k)), t2) == [1 ^ 33, -8 ^ 1, 0x40000001]
+    assert _col(p2(S.integral_divide(l, S.T_INT64, m, S.T_INT64)), t2) == [-3, -3, -2**63]
