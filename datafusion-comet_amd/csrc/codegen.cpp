@@ -996,38 +996,40 @@ struct Gen {
       r.maxabs = (u128)1 << 31;
       return r;
     }
-    if (f == "murmur3_hash") {
+    if (f == "murmur3_hash" || f == "xxhash64") {
+      const bool xx = f == "xxhash64";   // spark_xxhash64 (hash_funcs/xxhash64.rs:31-82): Int64 seed, Int64 result, XXH64 of the same value bytes
       // spark_murmur3_hash (hash_funcs/murmur3.rs:24-70) = Spark's hash(...): the last argument is the Int32 seed literal; every non-NULL
       // value folds into the running hash in argument order (hash_funcs/utils.rs:573-760), NULLs leave it unchanged; never NULL.
       // Same per-type functions as the shuffle writer's partitioning hash.
-      if (e.children.size() < 2) throw CometError("murmur3_hash expects at least one value and a seed");
+      if (e.children.size() < 2) throw CometError(f + " expects at least one value and a seed");
       const Expr& seed = *e.children.back();
-      if (seed.kind != ExprKind::Literal || seed.lit_null || !seed.has_dtype || seed.dtype.id != TypeId::Int32)
-        throw CometError("The seed of function murmur3_hash must be an Int32 scalar value");
-      const std::string h = newvar("u32");
-      stmt(h + " = " + std::to_string((uint32_t)(int32_t)seed.lit_i64) + "u;");
+      if (seed.kind != ExprKind::Literal || seed.lit_null || !seed.has_dtype || seed.dtype.id != (xx ? TypeId::Int64 : TypeId::Int32))
+        throw CometError("The seed of function " + f + " must be an " + (xx ? "Int64" : "Int32") + " scalar value");
+      const std::string h = newvar(xx ? "u64" : "u32");
+      stmt(h + " = " + (xx ? std::to_string((uint64_t)seed.lit_i64) + "ull;" : std::to_string((uint32_t)(int32_t)seed.lit_i64) + "u;"));
+      const std::string P = xx ? "comet::xxh64_hash_" : "comet::mm3_hash_";
       for (size_t i = 0; i + 1 < e.children.size(); i++) {
         Val a = arg(i);
         std::string call;
         switch (a.t.id) {
-          case TypeId::Bool: call = "comet::mm3_hash_i32((" + a.v + ") ? 1 : 0, " + h + ")"; break;
-          case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Date: call = "comet::mm3_hash_i32((i32)" + a.v + ", " + h + ")"; break;
-          case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: call = "comet::mm3_hash_i64((i64)" + a.v + ", " + h + ")"; break;
-          case TypeId::Float: call = "comet::mm3_hash_f32((float)" + a.v + ", " + h + ")"; break;
-          case TypeId::Double: call = "comet::mm3_hash_f64((double)" + a.v + ", " + h + ")"; break;
+          case TypeId::Bool: call = P + "i32((" + a.v + ") ? 1 : 0, " + h + ")"; break;
+          case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Date: call = P + "i32((i32)" + a.v + ", " + h + ")"; break;
+          case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: call = P + "i64((i64)" + a.v + ", " + h + ")"; break;
+          case TypeId::Float: call = P + "f32((float)" + a.v + ", " + h + ")"; break;
+          case TypeId::Double: call = P + "f64((double)" + a.v + ", " + h + ")"; break;
           case TypeId::Decimal:
             // precision ≤ 18 hashes the unscaled long, wider ones their 16 little-endian bytes (hash_array_decimal)
-            call = a.t.precision <= 18 ? "comet::mm3_hash_i64((i64)" + a.v + ", " + h + ")" : "comet::mm3_hash_i128(" + as128(a) + ", " + h + ")";
+            call = a.t.precision <= 18 ? P + "i64((i64)" + a.v + ", " + h + ")" : P + "i128(" + as128(a) + ", " + h + ")";
             break;
-          default: throw CometError("murmur3_hash over " + a.t.str() + " is not supported by the MI355X native engine yet");
+          default: throw CometError(f + " over " + a.t.str() + " is not supported by the MI355X native engine yet");
         }
         stmt((a.ok.empty() ? std::string() : "if (" + a.ok + ") ") + h + " = " + call + ";");
       }
-      r.t = DType::of(TypeId::Int32);
-      r.rep = Rep::I32;
+      r.t = DType::of(xx ? TypeId::Int64 : TypeId::Int32);
+      r.rep = xx ? Rep::I64 : Rep::I32;
       r.ok = "";
-      r.v = "(i32)" + h;
-      r.maxabs = (u128)1 << 31;
+      r.v = (xx ? "(i64)" : "(i32)") + h;
+      r.maxabs = (u128)1 << (xx ? 63 : 31);
       return r;
     }
     if (f == "date_diff" || f == "datediff") {

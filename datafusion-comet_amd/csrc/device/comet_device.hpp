@@ -562,6 +562,35 @@ CDEV u32 mm3_hash_bytes(const u8* p, i32 len, u32 seed) {
   for (i32 i = aligned; i < len; i++) h = mm3_mix_h1(h, mm3_mix_k1((u32)(i32)(i8)p[i]));  // sign-extended tail bytes
   return mm3_fmix(h, (u32)len);
 }
+// XXH64 of 4, 8 or 16 little-endian bytes (twox-hash XxHash64::oneshot as called by hash_funcs/xxhash64.rs:80-82; inputs shorter than
+// 32 bytes take the short path: seed + PRIME5 + len, then 8-byte, 4-byte rounds and the avalanche).
+CDEV u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+#define COMET_XXH_P1 0x9E3779B185EBCA87ull
+#define COMET_XXH_P2 0xC2B2AE3D27D4EB4Full
+#define COMET_XXH_P3 0x165667B19E3779F9ull
+#define COMET_XXH_P4 0x85EBCA77C2B2AE63ull
+#define COMET_XXH_P5 0x27D4EB2F165667C5ull
+CDEV u64 xxh64_word(u64 h, u64 w) {
+  const u64 k = rotl64(w * COMET_XXH_P2, 31) * COMET_XXH_P1;
+  return rotl64(h ^ k, 27) * COMET_XXH_P1 + COMET_XXH_P4;
+}
+CDEV u64 xxh64_avalanche(u64 h) {
+  h ^= h >> 33; h *= COMET_XXH_P2; h ^= h >> 29; h *= COMET_XXH_P3; h ^= h >> 32;
+  return h;
+}
+CDEV u64 xxh64_hash_i32(i32 v, u64 seed) {
+  u64 h = seed + COMET_XXH_P5 + 4ull;
+  h ^= (u64)(u32)v * COMET_XXH_P1;
+  h = rotl64(h, 23) * COMET_XXH_P2 + COMET_XXH_P3;
+  return xxh64_avalanche(h);
+}
+CDEV u64 xxh64_hash_i64(i64 v, u64 seed) { return xxh64_avalanche(xxh64_word(seed + COMET_XXH_P5 + 8ull, (u64)v)); }
+CDEV u64 xxh64_hash_i128(i128 v, u64 seed) {
+  const u128 u = (u128)v;
+  return xxh64_avalanche(xxh64_word(xxh64_word(seed + COMET_XXH_P5 + 16ull, (u64)u), (u64)(u >> 64)));
+}
+CDEV u64 xxh64_hash_f64(double d, u64 seed) { return xxh64_hash_i64((d == 0.0) ? 0 : __double_as_longlong(d), seed); }   // -0.0 hashes as 0
+CDEV u64 xxh64_hash_f32(float f, u64 seed) { return xxh64_hash_i32((f == 0.0f) ? 0 : __float_as_int(f), seed); }
 CDEV i32 pmod(u32 hash, i32 n) {
   i32 r = (i32)hash % n;
   return r < 0 ? (r + n) % n : r;

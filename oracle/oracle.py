@@ -298,6 +298,38 @@ class Evaluator:
                     out[i] = {"year": d.year, "month": d.month, "day": d.day, "quarter": (d.month - 1) // 3 + 1, "dow": (d.weekday() + 1) % 7,
                               "doy": d.timetuple().tm_yday}[part]
             return Col(S.T_INT32, out, a.valid)
+        if f == "xxhash64":
+            # spark_xxhash64 (hash_funcs/xxhash64.rs:31-82): XXH64 (the `xxhash` package here, twox-hash there) of each non-NULL value's
+            # little-endian bytes, seeded with the running hash; value encodings as for murmur3 (hash_funcs/utils.rs:50-225)
+            import xxhash
+            seed = e.children[-1]
+            if seed.kind != "literal" or seed.value is None or seed.dtype.type_id != S.INT64:
+                raise OracleError("The seed of function xxhash64 must be an Int64 scalar value")
+            h = [seed.value & 0xFFFFFFFFFFFFFFFF] * n
+            for ch in e.children[:-1]:
+                a = self.eval(ch, cols, n)
+                ok = a.ok()
+                tid = a.dtype.type_id
+                for i in range(n):
+                    if not ok[i]:
+                        continue
+                    if tid == S.DECIMAL:
+                        v = dec_to_int(a.values, i)
+                        b = (v & (2**64 - 1)).to_bytes(8, "little") if a.dtype.precision <= 18 else (v & (2**128 - 1)).to_bytes(16, "little")
+                    elif tid in (S.INT64, S.TIMESTAMP, S.TIMESTAMP_NTZ):
+                        b = (int(a.values[i]) & (2**64 - 1)).to_bytes(8, "little")
+                    elif tid in (S.INT8, S.INT16, S.INT32, S.DATE, S.BOOL):
+                        b = (int(a.values[i]) & (2**32 - 1)).to_bytes(4, "little")
+                    elif tid == S.FLOAT:
+                        x = np.float32(a.values[i])
+                        b = (0).to_bytes(4, "little") if x == 0 else x.tobytes()
+                    elif tid == S.DOUBLE:
+                        x = np.float64(a.values[i])
+                        b = (0).to_bytes(8, "little") if x == 0 else x.tobytes()
+                    else:
+                        raise OracleError(f"xxhash64 over {a.dtype} is not restated")
+                    h[i] = xxhash.xxh64_intdigest(b, h[i])
+            return Col(S.T_INT64, np.array(h, dtype=np.uint64).view(np.int64).copy() if n else np.zeros(0, np.int64), None)
         if f == "murmur3_hash":
             # spark_murmur3_hash (hash_funcs/murmur3.rs:24-70): seed literal last, NULLs skipped, result never NULL
             C = _lib()

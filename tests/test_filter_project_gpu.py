@@ -414,7 +414,7 @@ def test_integral_divide(built):
 
 
 def test_murmur3_hash_expression(built):
-    """Spark's hash(...) = murmur3_hash(cols..., seed literal) (hash_funcs/murmur3.rs:24-70): every non-NULL value folds into the running
+    """Spark's hash(...) = murmur3_hash(cols..., seed literal) and xxhash64(cols..., seed) (hash_funcs/murmur3.rs:24-70): every non-NULL value folds into the running
     hash in argument order, per-type encodings as in the partitioning hash, never NULL; also over a computed operand."""
     from datafusion_comet_amd import tpch
     n = 40_000
@@ -434,6 +434,9 @@ def test_murmur3_hash_expression(built):
     h = lambda *xs, s=seed: S.scalar_func("murmur3_hash", list(xs) + [s], S.T_INT32)
     outs = [h(c[0]), h(c[1]), h(c[2]), h(c[3]), h(c[4]), h(c[5]), h(c[6]), h(c[7]), h(c[8]), h(*c), h(c[2], c[3], s=S.lit(-7, S.T_INT32)),
             h(S.math("add", c[3], S.lit(1, S.T_INT64), S.T_INT64))]
+    # xxhash64 (hash_funcs/xxhash64.rs:31-82): Int64 seed and result, the same value encodings
+    x = lambda *xs, s=S.lit(42, S.T_INT64): S.scalar_func("xxhash64", list(xs) + [s], S.T_INT64)
+    outs += [x(c[0]), x(c[1]), x(c[2]), x(c[3]), x(c[4]), x(c[5]), x(c[6]), x(c[7]), x(c[8]), x(*c), x(c[2], c[3], s=S.lit(-7, S.T_INT64)), x(h(c[3]))]
     for at in range(0, len(outs), 6):
         chunk = outs[at:at + 6]
         plan = S.project(S.scan(fields), chunk)

@@ -134,6 +134,14 @@ def test_murmur3_hash_and_bitwise_known_answers():
     assert _col(proj(h(c[1])), t) == u([0xdea578e3, 0x379fae8f, 0xa0590e3d, 0x07fb67e7, 0x2b1f0fc6])
     assert _col(proj(h(c[2])), t) == u([0x99f0149d, 0x9c67b85d, 0xc8008529, 0xa05b5d7b, 0xcd1e64fb])
     assert _col(proj(h(c[3])), t) == u([0xe4876492, 0x9c67b85d, 0x9c67b85d, 0x13d81357, 0xb87e1595])
+    # xxhash64 with Spark's seed 42 (spark-expr/src/hash_funcs/xxhash64.rs:155-240)
+    u64 = lambda xs: [x - (1 << 64) if x >= 1 << 63 else x for x in xs]
+    x = lambda *cols: S.scalar_func("xxhash64", list(cols) + [S.lit(42, S.T_INT64)], S.T_INT64)
+    assert _col(proj(x(c[0])), t) == u64([0xa309b38455455929, 0x3229fbc4681e48f3, 0x1bfdda8861c06e45, 0x77cc15d9f9f2cdc2, 0x39bc22b9e94d81d0])
+    assert _col(proj(x(c[1])), t) == u64([0xa309b38455455929, 0x3229fbc4681e48f3, 0x1bfdda8861c06e45, 0x14f0ac009c21721c, 0x1cc7cb8d034769cd])
+    assert _col(proj(x(c[2])), t) == u64([0x9ed50fd59358d232, 0xb71b47ebda15746c, 0x358ae035bfb46fd2, 0xd2f1c616ae7eb306, 0x88608019c494c1f4])
+    xf = _col(proj(x(c[3])), t)
+    assert xf[1] == xf[2] == u64([0xb71b47ebda15746c])[0]                        # 0.0 and -0.0 hash like the long 0
     # a NULL leaves the running hash alone: hash(n, i32) == hash(i32) where n is NULL; the result is never NULL
     both, only = _col(proj(h(c[4], c[1])), t), _col(proj(h(c[1])), t)
     assert [both[i] == only[i] for i in range(5)] == [True, False, True, False, True] and None not in both
