@@ -1,12 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — TPC-H SF10 Q6 stage 1 (scan→filter→project→partial sum) on HBM-resident Arrow columns.
+"""bench.py — TPC-H SF100 Q1 stage 1 (scan → filter → project → partial 2-key hash aggregate, decimal arithmetic) on HBM-resident
+Arrow columns: the configuration BASELINE.json's metric is quoted on (configs[2], 600,037,902 lineitem rows = 46.8 GB per GPU).
 
-One "step" = one execution of the plan over the rank's lineitem shard through the C ABI
-(createPlan → executePlan → releasePlan, exactly what one Spark task does).  Q6 shards by contiguous row
-ranges with no data-path collective: each rank owns SF10 rows (weak scaling), rank 0
-prints one JSON line.  roofline.achieved uses SURVEY §8(d)'s algorithmic bytes (52 B/row) over the
-kernel time measured with HIP events on the plan's stream; cpu_baseline times the oracle's
-operator-at-a-time restatement of the reference pipeline on one host core over a bounded sample.
+One "step" = one execution of the plan over the rank's lineitem shard through the C ABI (createPlan → executePlan until -1 →
+releasePlan: exactly what one Spark task does).  Q1 shards by contiguous row ranges with no data-path collective:
+every rank owns SF100 rows (weak scaling), rank 0 prints ONE JSON line.
+
+  value                  whole-job rows/s at task level (createPlan..releasePlan, every launch of the task included)
+  roofline               the dominant kernel k_gagg: SURVEY §8(d)'s algorithmic 78 B/row × the rows one launch processes ÷ the kernel's
+                         average duration, measured with HIP events on the plan's stream inside libcomet (comet_plan_kernel_stats);
+                         `traffic` = HBM bytes per launch measured IN THIS RUN by two rocprofv3 passes (--pmc FETCH_SIZE / WRITE_SIZE)
+                         over tools/resident.py at the same row count (null when rocprofv3 is unavailable or --no-pmc)
+  cpu_baseline           the oracle's operator-at-a-time C restatement of the reference's Q1 pipeline (oracle/comet_oracle.c
+                         o_q1_reference_pipeline) on the first rows of the SAME shard: one thread, and the cgroup's CPU quota of threads
+  paths                  the same query through the boundary's other on-ramps on a bounded sample: host ArrowArrayStream (what the JVM
+                         hands over; PCIe-bound) and NativeScan over Parquet — never `value`
+  q6_sf100 / q6_sf10     extra legs: Q6 stage 1; Q6's staged loads skip most cache lines of the later columns, so its honest
+                         roofline fraction is the PHYSICAL one (PMC bytes ÷ kernel time); both are printed, never a frac > 1
+  q3                     BASELINE configs[3]: SF100 Q3 hash joins partitioned over the ranks (strong scaling) with per-stage ms
 """
 import argparse
 import json
@@ -17,28 +28,45 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SF100_ROWS = 600_037_902
 SF10_ROWS = 59_986_052
 HBM_PEAK_GBS = 8000.0
+
+
+def cpu_quota() -> int:
+    """Threads this container may keep busy: the cgroup CPU quota when there is one, else the visible CPUs."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=SF10_ROWS, help="lineitem rows per GPU (default: SF10)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=20_000_000)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=SF100_ROWS, help="lineitem rows per GPU (default: SF100)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=8_000_000, help="rows per CPU thread for the cpu_baseline legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--no-paths", action="store_true", help="skip the host-stream / Parquet path legs")
+    ap.add_argument("--path-rows", type=int, default=20_000_000)
     ap.add_argument("--q3-orders", type=int, default=150_000_000,
-                    help="extra leg: TPC-H Q3 (hash joins + RCCL exchange) over all ranks, total orders rows (SF100 = 150 M, strong scaling); 0 = skip")
-    ap.add_argument("--q3-timeout", type=int, default=420)
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the 1-GPU extra legs: TPC-DS Q95 (4 M orders, verified) and the native shuffle write")
-    ap.add_argument("--no-parquet-leg", action="store_true", help="skip the extra leg: SF10 Q6 straight from a zstd Parquet file (1 GPU only)")
-    ap.add_argument("--q1-rows", type=int, default=600_037_902,
-                    help="extra leg: TPC-H Q1 stage 1 on HBM-resident columns, lineitem rows per GPU (SF100 = 600,037,902); 0 = skip")
+                    help="extra leg: TPC-H Q3 over all ranks, total orders rows (SF100 = 150 M, strong scaling); 0 = skip")
+    ap.add_argument("--leg-timeout", type=int, default=420)
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip every extra leg (Q6, Q3, paths, PMC): headline + cpu_baseline only")
     args = ap.parse_args()
 
-    import numpy as np
+    import pyarrow as pa
     import torch
     import torch.distributed as dist
 
@@ -51,30 +79,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 
-    from datafusion_comet_amd import native, serde as S, tpch
+    from datafusion_comet_amd import native, serde as S, tpch, parallel
 
-    plan = tpch.q6_plan()
+    plan = tpch.q1_plan()
     plan_bytes = plan.encode()
-    table = tpch.lineitem_q6(args.rows, seed=6 + rank)
-    dtab = native.DeviceTable.from_arrow(table, dev)
     n = args.rows
-
-    dinput = native.DeviceInput(dtab, device_id=local_rank)
+    dtab, chk = tpch.lineitem_q1_device(n, device=dev, seed=1 + rank)
+    torch.cuda.synchronize()
+    ncols = tpch.Q1_NUM_OUTPUT_COLS
 
     def step():
         # one Spark task: createPlan → executePlan until -1 → releasePlan over the rank's resident shard
-        it = native.CometExecIterator([dinput.rearm()], tpch.Q6_NUM_OUTPUT_COLS, plan_bytes, device_id=local_rank)
-        out = list(it_batches(it))
+        it = native.CometExecIterator([native.DeviceInput(dtab, device_id=local_rank)], ncols, plan_bytes, device_id=local_rank)
+        out = []
+        while True:
+            b = native.Native.executePlan(it.handle, ncols)
+            if b is None:
+                break
+            out.append(b)
         stats = it.kernel_stats()
         it.close()
         return out, stats
-
-    def it_batches(it):
-        while True:
-            b = native.Native.executePlan(it.handle, it.num_output_cols)
-            if b is None:
-                return
-            yield b
 
     def barrier():
         if world > 1:
@@ -98,115 +123,210 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # outside the timed region: gather the per-rank Partial states on rank 0 and run the Final stage there
-    # (the only cross-rank step of a Q6/Q1-shaped plan) — proves the N-GPU answer is the merged one
-    import pyarrow as pa
-    from datafusion_comet_amd import parallel
-    states = parallel.gather_partial_states(pa.Table.from_batches(result) if result else None, 0)
-    final_value = None
+    # ---- outside the timed region -------------------------------------------------------------------------------------------
+    # (1) every aggregate of every group of this rank's Partial states against exact torch reductions of the generating tensors
+    out_tab = pa.Table.from_batches(result)
+    problems = tpch.q1_check_against_torch(out_tab, chk)
+    ok_local = torch.tensor([0 if problems else 1], device=dev)
+    if world > 1:
+        dist.all_reduce(ok_local, op=dist.ReduceOp.MIN)
+    verified = bool(ok_local.item())
+    # (2) the only cross-rank step of a Q1-shaped plan: gather the Partial states on rank 0, Final there
+    states = parallel.gather_partial_states(out_tab, 0)
+    final_rows = None
     if rank == 0 and states is not None:
-        fplan = S.hash_agg(S.scan([S.decimal(35, 4), S.T_BOOL]), [], plan.aggs, S.FINAL)
-        fin = native.execute_to_table([native.HostInput.from_table(states)], 1, fplan.encode(), device_id=local_rank)
-        final_value = str(fin[0].column(0)[0])
+        fplan = S.final_of(plan, states.schema)
+        fin = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(states)], 10, fplan.encode(), device_id=local_rank))
+        final_rows = sorted([[str(v) for v in r] for r in zip(*[fin.column(i).to_pylist() for i in range(fin.num_columns)])])
 
-    # Extra leg (reported under "q3", never part of `value`): BASELINE.json config 4, TPC-H Q3 partitioned over the ranks with
-    # RCCL all-to-all exchanges (tools/q3_dist.py).  It runs in a CHILD process per rank with its own rendezvous port so that a
-    # failure or hang there cannot take the Q6 line down: the child is killed by PID after --q3-timeout seconds.
-    q3 = None
-    if True:
-        del dtab, dinput
-        torch.cuda.empty_cache()
-    if args.q3_orders > 0:
-        q3 = run_q3_leg(args, rank, local_rank, world)
-    pq = None
-    if world == 1 and not args.no_parquet_leg:
-        pq = run_child_leg([os.path.join(ROOT, "tools", "parquet_q6.py"), "--rows", str(args.rows), "--codec", "zstd", "--steps", "5"],
-                           rank, local_rank, world, args.q3_timeout, port_offset=3017)
-    q95 = shuf = None
-    if world == 1 and not args.no_extra_legs:
-        # BASELINE config 5 (TPC-DS Q95, here at a quarter of SF100 so that its numpy verification stays short) and §8 f1 (native shuffle write)
-        q95 = run_child_leg([os.path.join(ROOT, "tools", "q95_bench.py"), "--orders", "4000000", "--reps", "2"], rank, local_rank, world, args.q3_timeout, port_offset=4017)
-        shuf = run_child_leg([os.path.join(ROOT, "tools", "shuffle_bench.py"), "--rows", "20000000", "--codec", "lz4", "--reps", "2"], rank, local_rank, world,
-                             args.q3_timeout, port_offset=5017)
-    q1 = None
-    if args.q1_rows > 0:
-        q1 = run_child_leg([os.path.join(ROOT, "tools", "q1_sf100.py"), "--rows", str(args.q1_rows), "--steps", "5", "--seed", str(1 + rank)],
-                           rank, local_rank, world, args.q3_timeout, port_offset=2017)
+    # (3) CPU baseline on the first rows of the same shard, and the GPU's answer for exactly those rows as a parity check
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, dtab, plan_bytes, local_rank)
+
+    del dtab, chk
+    torch.cuda.empty_cache()
+
+    legs = {}
+    if not args.no_extra_legs:
+        if world == 1:
+            legs["q6"] = run_child_leg([os.path.join(ROOT, "tools", "resident.py"), "--query", "q6", "--rows", str(args.rows), "--steps", "5"],
+                                       rank, local_rank, world, args.leg_timeout, 2017)
+            if args.rows != SF10_ROWS:
+                legs["q6_sf10"] = run_child_leg([os.path.join(ROOT, "tools", "resident.py"), "--query", "q6", "--rows", str(SF10_ROWS), "--steps", "10"],
+                                                rank, local_rank, world, args.leg_timeout, 2117)
+            if not args.no_pmc:
+                legs["pmc"] = measure_traffic(args, local_rank) if rank == 0 else None
+            if not args.no_paths:
+                legs["paths"] = run_child_leg([os.path.join(ROOT, "tools", "paths.py"), "--query", "q1", "--rows", str(args.path_rows)],
+                                              rank, local_rank, world, args.leg_timeout, 3017)
+        if args.q3_orders > 0:
+            legs["q3"] = run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1"],
+                                       rank, local_rank, world, args.leg_timeout, 1017)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rows_per_s = n * world * args.steps / elapsed
         avg_kernel_ms = kernel_ms / max(launches, 1)
-        algo_bytes = n * tpch.Q6_BYTES_PER_ROW            # per launch: one launch processes the rank's n rows
+        algo_bytes = n * tpch.Q1_BYTES_PER_ROW            # per launch: one k_gagg launch processes the rank's n rows
         achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
-        # same command, gfx950 x2 FETCH correction applied); only valid for the row count it was measured on
-        traffic = None
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "q6_sf10_traffic.json")))
-            if t["rows"] == n:
-                traffic = t["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        pmc = legs.get("pmc") or {}
+        traffic = (pmc.get("k_gagg") or {}).get("traffic_bytes_per_launch")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": "k_gagg", "kernel_ms": avg_kernel_ms, "launches_timed": launches,
+                "algorithmic_bytes": algo_bytes,
+                "task_level": {"ms": ms_per_step, "algorithmic_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9,
+                               "frac": algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if traffic:
+            roof["physical"] = {"GBps": traffic / (avg_kernel_ms * 1e-3) / 1e9, "frac": traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "bytes_per_row": traffic / n, "note": pmc.get("note")}
         line = {
-            "metric": "rows/sec, TPC-H Q6 scan->filter->agg (HBM-resident Arrow columns)",
+            "metric": "rows/sec, TPC-H SF100 Q1 scan->filter->agg (HBM-resident Arrow columns)",
             "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i128 (Decimal128) / i32 (Date32)", "data": "synthetic",
-            "config": {"workload": "TPC-H SF10 Q6 stage 1 (Filter 5 conjuncts -> Project -> partial SumDecimal) per GPU",
-                       "rows_per_gpu": n, "bytes_per_row_algorithmic": tpch.Q6_BYTES_PER_ROW, "parallelism": f"row-range shards x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_agg",
-                         "kernel_ms": avg_kernel_ms, "algorithmic_bytes": algo_bytes},
-            "result_check": {"rank0_partial_sum": str(result[0].column(0)[0]) if result else None, "final_revenue_all_ranks": final_value},
+            "dtype": "i128 (Decimal128; 256-bit products) / i32 (Date32) / u8 (Utf8 keys)", "data": "synthetic",
+            "config": {"workload": f"TPC-H {'SF100' if n == SF100_ROWS else 'SF10' if n == SF10_ROWS else str(n) + ' rows of'} Q1 stage 1 "
+                                   "(Filter -> Project, 3 decimal ops incl. one 256-bit multiply -> partial HashAggregate, 2 Utf8 keys, 8 aggregates) per GPU",
+                       "rows_per_gpu": n, "bytes_per_row_algorithmic": tpch.Q1_BYTES_PER_ROW, "parallelism": f"row-range shards x{world}"},
+            "roofline": roof,
+            "result_check": {"all_8_aggregates_of_all_groups_match_torch_on_every_rank": verified, "mismatches_rank0": problems[:4],
+                             "groups_rank0": out_tab.num_rows, "final_rows_all_ranks": final_rows},
         }
-        if not args.no_cpu_baseline:
-            from oracle import oracle as O
-            m = min(args.cpu_sample_rows, n)
-            sample = table.slice(0, m)
-            O.q6_reference_pipeline(sample.slice(0, 100_000), tpch.days(1994, 1, 1), tpch.days(1995, 1, 1), 5, 7, 2400)
-            c0 = time.perf_counter()
-            O.q6_reference_pipeline(sample, tpch.days(1994, 1, 1), tpch.days(1995, 1, 1), 5, 7, 2400)
-            cdt = time.perf_counter() - c0
-            line["cpu_baseline"] = {"value": m / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
-                                    "sample": f"first {m} rows of the same lineitem shard, operator-at-a-time C restatement "
-                                              f"(oracle/comet_oracle.c o_q6_reference_pipeline, 8192-row batches), {cdt:.2f} s"}
-            # the same port on many host cores (one slice per thread; ctypes releases the GIL), as SURVEY §8(d) asks: 1 and all cores
-            try:
-                from concurrent.futures import ThreadPoolExecutor
-                threads = max(1, min(os.cpu_count() or 1, 64))
-                big = table                                         # the whole SF10 shard: still a bounded sample (≈ 0.5 s per core)
-                per = (big.num_rows + threads - 1) // threads
-                slices = [big.slice(i * per, per) for i in range(threads) if i * per < big.num_rows]
-                run = lambda sl: O.q6_reference_pipeline(sl, tpch.days(1994, 1, 1), tpch.days(1995, 1, 1), 5, 7, 2400)
-                with ThreadPoolExecutor(len(slices)) as ex:
-                    list(ex.map(run, [sl.slice(0, 1000) for sl in slices]))          # spin the pool up
-                    c0 = time.perf_counter()
-                    parts = list(ex.map(run, slices))
-                    cdt2 = time.perf_counter() - c0
-                line["cpu_baseline_all_cores"] = {"value": big.num_rows / cdt2, "unit": "rows/s", "cores": len(slices), "kind": "port",
-                                                  "sample": f"all {big.num_rows} rows, one contiguous slice per thread, {cdt2:.2f} s",
-                                                  "partial_sums_add_up": str(sum(p[0] for p in parts)) == (str(result[0].column(0)[0]).replace(".", "") if result else None)}
-            except Exception as e:   # never break the headline line
-                line["cpu_baseline_all_cores"] = {"error": repr(e)}
-        if q3 is not None:
-            line["q3"] = q3
-        if q1 is not None:
-            line["q1_sf100_per_gpu"] = q1
-        if pq is not None:
-            line["q6_from_parquet"] = pq
-        if q95 is not None:
-            line["tpcds_q95"] = q95
-        if shuf is not None:
-            line["shuffle_write"] = shuf
+        if cpu is not None:
+            line["cpu_baseline"] = cpu.pop("one_thread")
+            line["cpu_baseline_all_cores"] = cpu.pop("all_threads")
+            line["cpu_baseline_parity"] = cpu
+        paths = legs.get("paths")
+        if paths is not None and "error" not in paths:
+            line["paths"] = {"hbm_resident": {"rows_per_s": rows_per_s / world, "rows": n, "note": "the headline, per GPU"},
+                             "sample_rows": paths["rows"], "hbm_resident_on_sample": paths["hbm_resident"],
+                             "host_arrow_stream": paths["host_arrow_stream"], "parquet": paths["parquet"]}
+        elif paths is not None:
+            line["paths"] = paths
+        for key in ("q6", "q6_sf10"):
+            leg = legs.get(key)
+            if leg is None:
+                continue
+            q = leg.get("q6", leg)
+            if "error" not in q:
+                tr = (pmc.get("k_agg") or {}).get("traffic_bytes_per_launch") if key == "q6" else None
+                q["roofline"] = {"bound": "hbm", "kernel": "k_agg", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_GBps": q["algorithmic_GBps"],
+                                 "traffic": tr,
+                                 "achieved": (tr / (q["kernel_ms"] * 1e-3) / 1e9) if tr else None,
+                                 "frac": (tr / (q["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
+                                 "note": "frac is PHYSICAL (PMC bytes / kernel time): lane-predicated staged loads skip most cache lines of "
+                                         "the later columns, so algorithmic bytes / time exceeds the HBM peak and is not a bandwidth"}
+            line["q6_sf100" if key == "q6" and args.rows == SF100_ROWS else key] = q
+        if legs.get("q3") is not None:
+            line["q3"] = legs["q3"]
+        if pmc:
+            line["pmc"] = pmc
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
 
-def run_q3_leg(args, rank, local_rank, world):
-    return run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1"],
-                         rank, local_rank, world, args.q3_timeout, port_offset=1017)
+def cpu_baseline(args, dtab, plan_bytes, local_rank):
+    """The C port of the reference pipeline on host cores over the first rows of the shard (downloaded from HBM), 1 thread and the
+    cgroup quota of threads; the GPU plan over the same first rows must give the same states (bit-exact)."""
+    import numpy as np
+    import pyarrow as pa
+    from concurrent.futures import ThreadPoolExecutor
+    from datafusion_comet_amd import native, tpch
+    from oracle import oracle as O
+    threads = cpu_quota()
+    per = min(args.cpu_sample_rows, dtab.num_rows)
+    m = min(per * threads, dtab.num_rows)
+    sample = dtab.slice(0, m).to_arrow()
+    cutoff = tpch.days(1998, 9, 2)
+    O.q1_reference_pipeline(sample.slice(0, 100_000), cutoff)
+    reps = 4                                       # ≥ 2 s of CPU work per leg at the ≈15 M rows/s one core reaches
+    c0 = time.perf_counter()
+    for _ in range(reps):
+        one = O.q1_reference_pipeline(sample.slice(0, per), cutoff)
+    dt1 = time.perf_counter() - c0
+    slices = [sample.slice(i * per, min(per, m - i * per)) for i in range((m + per - 1) // per)]
+
+    def work(sl):
+        for _ in range(reps):
+            r = O.q1_reference_pipeline(sl, cutoff)                                               # ctypes releases the GIL
+        return r
+    with ThreadPoolExecutor(len(slices)) as ex:
+        list(ex.map(lambda sl: O.q1_reference_pipeline(sl.slice(0, 1000), cutoff), slices))      # spin the pool up
+        c0 = time.perf_counter()
+        parts = list(ex.map(work, slices))
+        dtn = time.perf_counter() - c0
+    # parity: GPU Partial states over exactly the one-thread sample
+    got = pa.Table.from_batches(native.execute_to_table([native.DeviceInput(dtab.slice(0, per), device_id=local_rank)],
+                                                        tpch.Q1_NUM_OUTPUT_COLS, plan_bytes, device_id=local_rank))
+    same = True
+    rows = {(r[0], r[1]): r for r in zip(*[got.column(i).to_pylist() for i in range(got.num_columns)])}
+    if set(rows) != set(one):
+        same = False
+    else:
+        for k, st in one.items():
+            r = rows[k]
+            g = [int(r[2].scaleb(2)), int(r[4].scaleb(2)), int(r[6].scaleb(4)), int(r[8].scaleb(6)), int(r[10].scaleb(2)), int(r[12].scaleb(2)),
+                 int(r[14].scaleb(2))]
+            same &= g == st["sums"] and [r[11], r[13], r[15], r[16]] == st["counts"]
+    what = "operator-at-a-time C restatement of the reference's Q1 stage-1 pipeline (oracle/comet_oracle.c o_q1_reference_pipeline, 8192-row batches)"
+    return {"one_thread": {"value": reps * per / dt1, "unit": "rows/s", "cores": 1, "kind": "port",
+                           "sample": f"first {per} rows of the same lineitem shard x {reps} passes, {what}, {dt1:.2f} s"},
+            "all_threads": {"value": reps * m / dtn, "unit": "rows/s", "cores": len(slices), "kind": "port",
+                            "sample": f"first {m} rows, one contiguous {per}-row slice per thread x {reps} passes ({len(slices)} threads = the cgroup CPU quota), {dtn:.2f} s",
+                            "groups": sorted("".join(k) for k in set().union(*[set(p) for p in parts]))},
+            "gpu_states_equal_cpu_states_on_the_one_thread_sample": bool(same)}
+
+
+def measure_traffic(args, local_rank):
+    """HBM bytes per launch of k_gagg (Q1) and k_agg (Q6) at this run's row count: two rocprofv3 passes (FETCH_SIZE needs 3 of the 4
+    TCC slots, WRITE_SIZE 2 — MI355X_MICROARCH.md) over tools/resident.py.  gfx950's FETCH_SIZE reports half the bytes of a coalesced
+    streaming read, so it is doubled as that guide prescribes (calibrated there for 16 B/lane loads; tools/pmc_calibrate.py checks the
+    4 and 8 B/lane loads these kernels issue — profiles/)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return {"error": "rocprofv3 not found"}
+    res, raw = {}, {}
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    env["LOCAL_RANK"] = str(local_rank)
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="comet_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.join(ROOT, "tools", "resident.py"), "--query", "q1,q6", "--rows", str(args.rows), "--steps", "2", "--no-check"]
+        try:
+            p = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.leg_timeout)
+            if p.returncode != 0:
+                return {"error": f"rocprofv3 {counter} pass exit code {p.returncode}", "log_tail": p.stdout[-400:]}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"].split("(")[0]
+                    if name in ("k_gagg", "k_agg") and r["Counter_Name"] == counter:
+                        raw.setdefault((name, counter), []).append(float(r["Counter_Value"]))
+        except subprocess.TimeoutExpired:
+            return {"error": f"rocprofv3 {counter} pass timed out"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    for name in ("k_gagg", "k_agg"):
+        f, w = raw.get((name, "FETCH_SIZE")), raw.get((name, "WRITE_SIZE"))
+        if not f or not w:
+            continue
+        f, w = f[1:] or f, w[1:] or w           # the first launch also pages the freshly generated table in
+        fetch = 2.0 * 1024.0 * sum(f) / len(f)  # KiB → B, ×2 gfx950 correction
+        write = 1024.0 * sum(w) / len(w)
+        res[name] = {"traffic_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "launches": len(f),
+                     "bytes_per_row": (fetch + write) / args.rows}
+    res["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace) in this run; FETCH_SIZE x2 per "
+                   "MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)")
+    res["rows"] = args.rows
+    return res
 
 
 def run_child_leg(cmd_tail, rank, local_rank, world, timeout, port_offset):

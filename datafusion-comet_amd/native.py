@@ -218,6 +218,19 @@ class DeviceTable:
         return (sum(v.numel() for v in self.values) + sum(v.numel() for v in self.validity if v is not None)
                 + sum(v.numel() for v in self.aux if v is not None))
 
+    def slice(self, start: int, length: int) -> "DeviceTable":
+        """Zero-copy row range (columns without validity only; Utf8 keeps its whole data buffer, offsets stay absolute)."""
+        vals = []
+        for f, v, valid in zip(self.schema, self.values, self.validity):
+            if valid is not None:
+                raise ValueError("DeviceTable.slice: columns with validity bitmaps are not supported")
+            if pa.types.is_string(f.type) or pa.types.is_binary(f.type):
+                vals.append(v[start * 4:(start + length + 1) * 4])
+            else:
+                w = value_width(f.type)
+                vals.append(v[start * w:(start + length) * w])
+        return DeviceTable(self.schema, length, vals, [None] * len(vals), self.device, list(self.aux))
+
     def to_arrow(self) -> pa.Table:
         """Copy back to host memory as a pyarrow Table (tests / small results only)."""
         import numpy as np

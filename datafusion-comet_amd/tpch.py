@@ -101,7 +101,7 @@ Q6_NUM_OUTPUT_COLS = 2  # (sum dec(35,4), is_empty bool)
 Q6_BYTES_PER_ROW = 4 + 16 + 16 + 16  # Arrow layout of the four referenced columns
 
 
-def q1_plan(mode: int = S.PARTIAL) -> S.Operator:
+def q1_plan(mode: int = S.PARTIAL, source: "S.Operator" = None) -> S.Operator:
     """TPC-H Q1 stage 1.  Scan order: qty, price, disc, tax, returnflag, linestatus, shipdate.
     HashAgg(Partial, keys=[returnflag, linestatus],
             [sum(qty) d(22,2), sum(price) d(22,2), sum(disc_price) d(36,4), sum(charge) d(38,6),
@@ -112,7 +112,7 @@ def q1_plan(mode: int = S.PARTIAL) -> S.Operator:
       ← Filter(shipdate <= 1998-09-02) ← Scan."""
     fields = [DEC, DEC, DEC, DEC, S.T_STRING, S.T_STRING, S.T_DATE]
     qty, price, disc, tax, rf, ls, ship = (S.col(i, t) for i, t in enumerate(fields))
-    f = S.filter_(S.scan(fields), S.lt_eq(ship, S.lit(days(1998, 9, 2), S.T_DATE)))
+    f = S.filter_(source if source is not None else S.scan(fields), S.lt_eq(ship, S.lit(days(1998, 9, 2), S.T_DATE)))
     one = S.lit(100, S.decimal(12, 2))   # Spark promotes the literal 1 to decimal(12,2)? it sends Decimal(1,0) cast; keep (12,2)
     one_minus = S.check_overflow(S.math("subtract", one, disc, S.decimal(13, 2)), S.decimal(13, 2))
     one_plus = S.check_overflow(S.math("add", one, tax, S.decimal(13, 2)), S.decimal(13, 2))
@@ -249,12 +249,16 @@ def lineitem_q1_device(n: int, device="cuda:0", seed: int = 1):
     rf = torch.where(late, torch.tensor(ord("N"), device=device, dtype=torch.uint8),
                      torch.where(coin, torch.tensor(ord("R"), device=device, dtype=torch.uint8), torch.tensor(ord("A"), device=device, dtype=torch.uint8)))
     ls = torch.where(late, torch.tensor(ord("O"), device=device, dtype=torch.uint8), torch.tensor(ord("F"), device=device, dtype=torch.uint8))
+    # dbgen's fourth group: a sliver of ('N','F') from orders straddling the cutoff (q1.sql.out:6-9 has 38 854 of 6 M rows)
+    straddle = (~late) & (ship > days(1995, 6, 17) - 60) & (torch.rand((n,), generator=g, device=device) < 0.3)
+    rf = torch.where(straddle, torch.tensor(ord("N"), device=device, dtype=torch.uint8), rf)
+    del late, coin, straddle
     offs = torch.arange(n + 1, device=device, dtype=torch.int32).view(torch.uint8).reshape(-1)
     schema = pa.schema([("l_quantity", pa.decimal128(12, 2)), ("l_extendedprice", pa.decimal128(12, 2)), ("l_discount", pa.decimal128(12, 2)),
                         ("l_tax", pa.decimal128(12, 2)), ("l_returnflag", pa.utf8()), ("l_linestatus", pa.utf8()), ("l_shipdate", pa.date32())])
     values = [dec(qty * 100), dec(price), dec(disc), dec(tax), offs, offs.clone(), ship.view(torch.uint8).reshape(-1)]
     aux = [None, None, None, None, rf, ls, None]
-    checks = {"qty": qty, "price": price, "ship": ship, "rf": rf, "ls": ls}
+    checks = {"qty": qty, "price": price, "disc": disc, "tax": tax, "ship": ship, "rf": rf, "ls": ls}
     return DeviceTable(schema, n, values, [None] * 7, device, aux), checks
 
 
@@ -359,11 +363,16 @@ def q3_torch_reference(n_orders: int, world: int, device="cuda:0", seed: int = 3
 
 
 def q1_check_against_torch(out: pa.Table, chk: dict) -> list:
-    """Compare a Q1 stage-1 result (Partial states) with independent torch reductions of the generating tensors: per group the
-    row count, sum(l_quantity) and sum(l_extendedprice), exact.  Returns a list of mismatch descriptions (empty = all good)."""
+    """Compare a Q1 stage-1 result (Partial states, q1_plan() column order) with independent torch reductions of the generating
+    tensors — ALL eight aggregates of every group, exact: count(1), sum_qty, sum_base_price, sum_disc_price = Σ price·(100 − disc)
+    (scale 4), sum_charge = Σ price·(100 − disc)·(100 + tax) (scale 6; exceeds int64 at SF100, so the per-row disc_price is split
+    into a high and a low 16-bit part summed separately and recombined with Python ints), and the three avg states (sum, count).
+    Returns a list of mismatch descriptions (empty = all good)."""
+    import torch
     keep = chk["ship"] <= days(1998, 9, 2)
     rows = {(r[0], r[1]): r for r in zip(*[out.column(i).to_pylist() for i in range(out.num_columns)])}
     problems = []
+    seen = set()
     for rf in "ANR":
         for ls in "FO":
             m = keep & (chk["rf"] == ord(rf)) & (chk["ls"] == ord(ls))
@@ -375,11 +384,31 @@ def q1_check_against_torch(out: pa.Table, chk: dict) -> list:
             if (rf, ls) not in rows:
                 problems.append(f"group {rf}{ls} missing")
                 continue
+            seen.add((rf, ls))
             r = rows[(rf, ls)]
-            sq = int((chk["qty"][m] * 100).sum().item())
-            sp = int(chk["price"][m].sum().item())
-            if not (r[-1] == cnt and int(r[2].scaleb(2)) == sq and int(r[4].scaleb(2)) == sp):
-                problems.append(f"group {rf}{ls}: got count {r[-1]} sum_qty {r[2]} sum_price {r[4]}, want {cnt} {sq} {sp}")
+            mi = m.to(torch.int64)
+            sq = int((chk["qty"] * mi).sum().item()) * 100
+            sp = int((chk["price"] * mi).sum().item())
+            sd = int((chk["disc"] * mi).sum().item())
+            dp = chk["price"] * (100 - chk["disc"]) * mi                  # ≤ 1.05e9 per row
+            sdp = int(dp.sum().item())
+            f = 100 + chk["tax"]
+            sch = (int(((dp >> 16) * f).sum().item()) << 16) + int(((dp & 0xFFFF) * f).sum().item())
+            del dp, f, mi
+            # columns: rf, ls, (sum, is_empty)×4, (sum, count)×3, count
+            got = {"sum_qty": int(r[2].scaleb(2)), "sum_base_price": int(r[4].scaleb(2)), "sum_disc_price": int(r[6].scaleb(4)),
+                   "sum_charge": int(r[8].scaleb(6)), "avg_qty.sum": int(r[10].scaleb(2)), "avg_qty.count": r[11],
+                   "avg_price.sum": int(r[12].scaleb(2)), "avg_price.count": r[13], "avg_disc.sum": int(r[14].scaleb(2)),
+                   "avg_disc.count": r[15], "count": r[16], "is_empty": (r[3], r[5], r[7], r[9])}
+            want = {"sum_qty": sq, "sum_base_price": sp, "sum_disc_price": sdp, "sum_charge": sch, "avg_qty.sum": sq, "avg_qty.count": cnt,
+                    "avg_price.sum": sp, "avg_price.count": cnt, "avg_disc.sum": sd, "avg_disc.count": cnt, "count": cnt,
+                    "is_empty": (False, False, False, False)}
+            for k in want:
+                if got[k] != want[k]:
+                    problems.append(f"group {rf}{ls} {k}: got {got[k]}, want {want[k]}")
+    for k in rows:
+        if k not in seen:
+            problems.append(f"unexpected group {k}")
     return problems
 
 

@@ -209,7 +209,12 @@ int64_t o_wide_decimal(int op, const i128* l, int s1, const i128* r, int s2, int
 
 /* Decimal128Type::is_valid_decimal_precision as used by CheckOverflow — checkoverflow.rs:128-160:
  * never rescales, only |v| <= 10^p - 1. */
-int o_dec_fits(i128 v, int p) { i128 b = pow10_i128(p) - 1; return v <= b && v >= -b; }
+static i128 g_pow10_tab[40];   /* MAX_DECIMAL128_FOR_EACH_PRECISION, as a lazily filled table like arrow's constant array */
+int o_dec_fits(i128 v, int p) {
+  if (g_pow10_tab[1] == 0) { i128 r = 1; for (int i = 0; i < 40; i++) { g_pow10_tab[i] = r; if (i < 38) r *= 10; } }
+  i128 b = g_pow10_tab[p] - 1;
+  return v <= b && v >= -b;
+}
 void o_check_overflow(const i128* v, int p, uint8_t* ok, int64_t n) { for (int64_t i = 0; i < n; i++) ok[i] = (uint8_t)o_dec_fits(v[i], p); }
 
 /* rescale_and_check — decimal_rescale_check.rs:108-150 */
@@ -427,6 +432,130 @@ void o_q6_reference_pipeline(const i128* qty, const i128* price, const i128* dis
   }
   *out_sum = st.sum; *out_has_sum = st.has_sum; *out_is_empty = st.is_empty;
   free(m0); free(m1); free(fprice); free(fdisc); free(prod); free(ok);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CPU baseline: TPC-H Q1 stage 1 executed the way the reference executes it (call stack SURVEY.md §3.4):
+ * operator at a time over batches of `batch` rows.  FilterExec (shipdate <= cutoff) + filter_record_batch over the six
+ * carried columns; ProjectionExec materialises every expression node (1 - disc, CheckOverflow, price * that, CheckOverflow,
+ * 1 + tax, CheckOverflow, the WideDecimalBinaryExpr multiply → decimal(38,6)); AggregateExec(Partial) computes a group id
+ * per row from the two Utf8 keys (hash → open-addressing table holding the key bytes, like GroupValuesRows) and feeds
+ * SumDecimal ×4, AvgDecimal ×3 and count group accumulators row at a time (sum_decimal.rs:441-475, avg_decimal.rs:483-494).
+ *   keys: Arrow Utf8 (int32 offsets + bytes), values ≤ 15 bytes.  States come back in first-seen group order.
+ *   out_keys: max_groups × 2 × 16 bytes (length byte + bytes); out_sums: max_groups × 7 i128
+ *   (sum_qty, sum_price, sum_disc_price, sum_charge, avg_qty.sum, avg_price.sum, avg_disc.sum); out_flags: max_groups × 7
+ *   (1 = sum present / not overflowed); out_counts: max_groups × 4 (avg counts ×3, count(1)).  Returns the number of groups,
+ *   or -1 when more than max_groups groups appear.  Single thread.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint8_t k[2][16]; } Q1Key;
+static uint64_t q1_key_hash(const Q1Key* k) {
+  uint64_t h = 1469598103934665603ull;
+  const uint8_t* b = (const uint8_t*)k;
+  for (int i = 0; i < 32; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+int64_t o_q1_reference_pipeline(const i128* qty, const i128* price, const i128* disc, const i128* tax,
+                                const int32_t* rf_off, const uint8_t* rf_bytes, const int32_t* ls_off, const uint8_t* ls_bytes,
+                                const int32_t* ship, int64_t n, int32_t cutoff, int64_t batch, int64_t max_groups,
+                                uint8_t* out_keys, i128* out_sums, uint8_t* out_flags, int64_t* out_counts) {
+  enum { CAP = 1024 };
+  if (max_groups > CAP / 2) max_groups = CAP / 2;
+  Q1Key* gkeys = (Q1Key*)calloc((size_t)max_groups, sizeof(Q1Key));
+  int32_t* table = (int32_t*)malloc(CAP * sizeof(int32_t));
+  for (int i = 0; i < CAP; i++) table[i] = -1;
+  SumDecState* sd = (SumDecState*)malloc((size_t)max_groups * 4 * sizeof(SumDecState));
+  AvgDecState* ad = (AvgDecState*)malloc((size_t)max_groups * 3 * sizeof(AvgDecState));
+  int64_t* cnt = (int64_t*)calloc((size_t)max_groups, sizeof(int64_t));
+  for (int64_t g = 0; g < max_groups * 4; g++) o_sumdec_init(&sd[g]);
+  for (int64_t g = 0; g < max_groups * 3; g++) o_avgdec_init(&ad[g]);
+  uint8_t* m = (uint8_t*)malloc((size_t)batch);
+  i128* f[4];
+  for (int c = 0; c < 4; c++) f[c] = (i128*)malloc((size_t)batch * 16);
+  Q1Key* fk = (Q1Key*)malloc((size_t)batch * sizeof(Q1Key));
+  i128* one = (i128*)malloc((size_t)batch * 16);
+  i128* one_minus = (i128*)malloc((size_t)batch * 16);
+  i128* one_plus = (i128*)malloc((size_t)batch * 16);
+  i128* disc_price = (i128*)malloc((size_t)batch * 16);
+  i128* charge = (i128*)malloc((size_t)batch * 16);
+  uint8_t* ok1 = (uint8_t*)malloc((size_t)batch);
+  uint8_t* ok2 = (uint8_t*)malloc((size_t)batch);
+  uint8_t* ok3 = (uint8_t*)malloc((size_t)batch);
+  uint8_t* ok4 = (uint8_t*)malloc((size_t)batch);
+  int64_t* gid = (int64_t*)malloc((size_t)batch * 8);
+  for (int64_t i = 0; i < batch; i++) one[i] = 100;           /* literal 1.00 as decimal(12,2), expanded per batch */
+  int64_t ngroups = 0, rc = 0;
+  for (int64_t base = 0; base < n && rc >= 0; base += batch) {
+    int64_t len = n - base < batch ? n - base : batch;
+    for (int64_t i = 0; i < len; i++) m[i] = ship[base + i] <= cutoff;                 /* FilterExec predicate */
+    int64_t k = 0;                                                                     /* filter_record_batch, 6 columns */
+    for (int64_t i = 0; i < len; i++) if (m[i]) { f[0][k] = qty[base + i]; k++; }
+    k = 0; for (int64_t i = 0; i < len; i++) if (m[i]) { f[1][k] = price[base + i]; k++; }
+    k = 0; for (int64_t i = 0; i < len; i++) if (m[i]) { f[2][k] = disc[base + i]; k++; }
+    k = 0; for (int64_t i = 0; i < len; i++) if (m[i]) { f[3][k] = tax[base + i]; k++; }
+    k = 0;
+    for (int64_t i = 0; i < len; i++) if (m[i]) {
+      Q1Key* q = &fk[k++];
+      memset(q, 0, sizeof(Q1Key));
+      int32_t a = rf_off[base + i], b = rf_off[base + i + 1] - a; if (b > 15) b = 15;
+      q->k[0][0] = (uint8_t)b; memcpy(&q->k[0][1], rf_bytes + a, (size_t)b);
+      a = ls_off[base + i]; b = ls_off[base + i + 1] - a; if (b > 15) b = 15;
+      q->k[1][0] = (uint8_t)b; memcpy(&q->k[1][1], ls_bytes + a, (size_t)b);
+    }
+    if (k == 0) continue;
+    /* ProjectionExec: one array per expression node */
+    o_dec_addsub(one, 2, f[2], 2, 1, one_minus, k);  o_check_overflow(one_minus, 13, ok1, k);       /* 1 - l_discount → d(13,2) */
+    o_dec_mul(f[1], one_minus, disc_price, k);       o_check_overflow(disc_price, 26, ok2, k);      /* price * (1 - disc) → d(26,4) */
+    for (int64_t i = 0; i < k; i++) ok2[i] &= ok1[i];
+    o_dec_addsub(one, 2, f[3], 2, 0, one_plus, k);   o_check_overflow(one_plus, 13, ok3, k);        /* 1 + l_tax → d(13,2) */
+    o_wide_decimal(2, disc_price, 4, one_plus, 2, 38, 6, charge, ok4, k);                           /* i256 multiply → d(38,6) */
+    for (int64_t i = 0; i < k; i++) ok4[i] &= ok2[i] & ok3[i];
+    /* AggregateExec(Partial): group ids from the key bytes */
+    for (int64_t i = 0; i < k; i++) {
+      uint64_t h = q1_key_hash(&fk[i]) & (CAP - 1);
+      for (;;) {
+        int32_t g = table[h];
+        if (g < 0) {
+          if (ngroups == max_groups) { rc = -1; break; }
+          gkeys[ngroups] = fk[i]; table[h] = (int32_t)ngroups; gid[i] = ngroups++; break;
+        }
+        if (memcmp(&gkeys[g], &fk[i], sizeof(Q1Key)) == 0) { gid[i] = g; break; }
+        h = (h + 1) & (CAP - 1);
+      }
+      if (rc < 0) break;
+    }
+    if (rc < 0) break;
+    o_sumdec_update_groups(sd + 0 * max_groups, f[0], NULL, gid, k, 22, 0);
+    o_sumdec_update_groups(sd + 1 * max_groups, f[1], NULL, gid, k, 22, 0);
+    o_sumdec_update_groups(sd + 2 * max_groups, disc_price, ok2, gid, k, 36, 0);
+    o_sumdec_update_groups(sd + 3 * max_groups, charge, ok4, gid, k, 38, 0);
+    o_avgdec_update_groups(ad + 0 * max_groups, f[0], NULL, gid, k, 22);
+    o_avgdec_update_groups(ad + 1 * max_groups, f[1], NULL, gid, k, 22);
+    o_avgdec_update_groups(ad + 2 * max_groups, f[2], NULL, gid, k, 22);
+    for (int64_t i = 0; i < k; i++) cnt[gid[i]] += 1;                                               /* count(1) */
+  }
+  if (rc >= 0) {
+    rc = ngroups;
+    for (int64_t g = 0; g < ngroups; g++) {
+      memcpy(out_keys + g * 32, &gkeys[g], 32);
+      for (int a = 0; a < 4; a++) {
+        const SumDecState* s = &sd[a * max_groups + g];
+        out_sums[g * 7 + a] = s->has_sum ? s->sum : 0;
+        out_flags[g * 7 + a] = (uint8_t)(s->has_sum && !s->is_empty);
+      }
+      for (int a = 0; a < 3; a++) {
+        const AvgDecState* s = &ad[a * max_groups + g];
+        out_sums[g * 7 + 4 + a] = s->sum;
+        out_flags[g * 7 + 4 + a] = (uint8_t)s->is_not_null;
+        out_counts[g * 4 + a] = s->count;
+      }
+      out_counts[g * 4 + 3] = cnt[g];
+    }
+  }
+  free(gkeys); free(table); free(sd); free(ad); free(cnt); free(m);
+  for (int c = 0; c < 4; c++) free(f[c]);
+  free(fk); free(one); free(one_minus); free(one_plus); free(disc_price); free(charge);
+  free(ok1); free(ok2); free(ok3); free(ok4); free(gid);
+  return rc;
 }
 
 /* layout self-check used by the Python binding */

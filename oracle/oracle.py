@@ -1419,3 +1419,39 @@ def q6_reference_pipeline(table: pa.Table, d0: int, d1: int, disc_lo: int, disc_
                               _p(np.ascontiguousarray(ship)), ctypes.c_int64(n), ctypes.c_int32(d0), ctypes.c_int32(d1),
                               lits, ctypes.c_int64(batch), out, ctypes.byref(has), ctypes.byref(empty))
     return _limbs_to_int(out), bool(has.value), bool(empty.value)
+
+
+def q1_reference_pipeline(table: pa.Table, cutoff: int, batch: int = 8192, max_groups: int = 64) -> dict:
+    """Runs comet_oracle.c's operator-at-a-time Q1 stage-1 pipeline over a lineitem_q1-shaped table (columns l_quantity,
+    l_extendedprice, l_discount, l_tax, l_returnflag, l_linestatus, l_shipdate).  Returns {(returnflag, linestatus):
+    {"sums": [7 exact ints: sum_qty, sum_price, sum_disc_price, sum_charge, avg sums ×3], "present": [7 bools],
+    "counts": [avg counts ×3, count(1)]}} — the Partial states of q1_plan()."""
+    n = table.num_rows
+    cols = [table.column(i).combine_chunks() if isinstance(table.column(i), pa.ChunkedArray) else table.column(i) for i in range(7)]
+    dec = [np.ascontiguousarray(np.frombuffer(c.buffers()[1], dtype=DEC128)[c.offset:c.offset + n]) for c in cols[:4]]
+
+    def utf8(c):
+        off = np.ascontiguousarray(np.frombuffer(c.buffers()[1], dtype=np.int32)[c.offset:c.offset + n + 1])
+        data = np.frombuffer(c.buffers()[2], dtype=np.uint8) if c.buffers()[2] is not None else np.zeros(1, np.uint8)
+        return off, data
+    rf_off, rf_b = utf8(cols[4])
+    ls_off, ls_b = utf8(cols[5])
+    ship = np.ascontiguousarray(np.frombuffer(cols[6].buffers()[1], dtype=np.int32)[cols[6].offset:cols[6].offset + n])
+    keys = np.zeros(max_groups * 32, np.uint8)
+    sums = np.zeros(max_groups * 7, DEC128)
+    flags = np.zeros(max_groups * 7, np.uint8)
+    counts = np.zeros(max_groups * 4, np.int64)
+    C.o_q1_reference_pipeline.restype = ctypes.c_int64
+    ng = C.o_q1_reference_pipeline(_p(dec[0]), _p(dec[1]), _p(dec[2]), _p(dec[3]), _p(rf_off), _p(rf_b), _p(ls_off), _p(ls_b), _p(ship),
+                                   ctypes.c_int64(n), ctypes.c_int32(cutoff), ctypes.c_int64(batch), ctypes.c_int64(max_groups),
+                                   _p(keys), _p(sums), _p(flags), _p(counts))
+    if ng < 0:
+        raise OracleError("more groups than max_groups")
+    out = {}
+    for g in range(ng):
+        k = keys[g * 32:(g + 1) * 32]
+        key = tuple(bytes(k[16 * j + 1:16 * j + 1 + int(k[16 * j])]).decode() for j in range(2))
+        out[key] = {"sums": [_limbs_to_int((sums["lo"][g * 7 + a], int(sums["hi"][g * 7 + a]) & 0xFFFFFFFFFFFFFFFF)) for a in range(7)],
+                    "present": [bool(flags[g * 7 + a]) for a in range(7)],
+                    "counts": [int(counts[g * 4 + a]) for a in range(4)]}
+    return out

@@ -48,7 +48,7 @@ def test_q1_sf100_groups_match_torch_reductions(built):
     dt, chk = tpch.lineitem_q1_device(n)
     torch.cuda.synchronize()
     out = _run_device(tpch.q1_plan(), dt, tpch.Q1_NUM_OUTPUT_COLS)
-    assert out.num_rows == 3                                      # A/F, N/O, R/F (the generator has no receipt date, hence no N/F group)
+    assert out.num_rows == 4                                      # A/F, N/F, N/O, R/F like dbgen (q1.sql.out:6-9)
     assert tpch.q1_check_against_torch(out, chk) == []
     assert sum(out.column(out.num_columns - 1).to_pylist()) == int((chk["ship"] <= tpch.days(1998, 9, 2)).sum().item())
     del dt, chk
