@@ -24,6 +24,7 @@ typedef unsigned long long u64;
 typedef int i32;
 typedef unsigned int u32;
 typedef short i16;
+typedef unsigned short u16;
 typedef signed char i8;
 typedef unsigned char u8;
 typedef __int128 i128;

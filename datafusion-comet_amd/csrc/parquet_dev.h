@@ -15,6 +15,12 @@ typedef struct PqPage {        /* one data page of a column (all selected row gr
   int32_t idx_run_first, idx_run_count;   /* dictionary-index runs */
   int32_t dict_offs_first;     /* strings: index of this page's dictionary in the offsets table */
   int64_t dict_off;            /* byte offset of this page's dictionary (its row group's) in the dictionary buffer */
+  /* conversion of THIS page's values: files of one partition may store a column with different physical types (schema
+   * evolution), and a column a file lacks is a synthetic page of NULLs or of its default value */
+  int32_t kind;                /* PQ_* conversion */
+  int32_t width;               /* source value width in bytes (FLBA length, 4, 8, 12) */
+  int32_t dec_scale_up;        /* PQ_*_TO_DEC: multiply the unscaled value by 10^dec_scale_up (decimal scale widening) */
+  int32_t pad1;
 } PqPage;
 
 typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section */
@@ -29,7 +35,9 @@ typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section 
 enum { PQ_COPY4 = 0, PQ_COPY8 = 1, PQ_I32_TO_I64 = 2, PQ_I32_TO_DEC = 3, PQ_I64_TO_DEC = 4, PQ_FLBA_TO_DEC = 5, PQ_BOOL = 6,
        PQ_I32_TO_I16 = 7, PQ_I32_TO_I8 = 8,
        /* schema adaptation (parquet/schema_adapter.rs, parquet_support.rs:141-240) */
-       PQ_F32_TO_F64 = 9, PQ_I32_TO_F64 = 10, PQ_INT96_TO_TS_MICROS = 11 };
+       PQ_F32_TO_F64 = 9, PQ_I32_TO_F64 = 10, PQ_INT96_TO_TS_MICROS = 11,
+       /* logical-type conversions: TIMESTAMP(MILLIS) → µs, UINT_32 → int64, UINT_64 → decimal(20,0) */
+       PQ_I64_MILLIS_TO_MICROS = 12, PQ_U32_TO_I64 = 13, PQ_U64_TO_DEC = 14 };
 
 typedef struct PqDecodeArgs {
   const PqPage* pages;
@@ -42,9 +50,7 @@ typedef struct PqDecodeArgs {
   const int32_t* dict_offs;    /* strings: dictionary offsets (n_dict + 1) */
   const int64_t* plain_str_offs; /* PLAIN BYTE_ARRAY data pages: staged-byte offset of each value's bytes (+1 sentinel per page) */
   int64_t n_rows;              /* rows of this column chunk */
-  int32_t kind;                /* PQ_* conversion */
-  int32_t width;               /* source value width in bytes (FLBA length, 4, 8, 12) */
-  int32_t dec_scale_up;        /* PQ_*_TO_DEC: multiply the unscaled value by 10^dec_scale_up (decimal scale widening) */
+  int32_t out_width;           /* bytes per output value (fixed-width columns) */
   int32_t pad0;
   uint8_t* valid_out;          /* per-row validity bytes (at the chunk's row offset) */
   uint32_t* vidx;              /* per-row exclusive count of non-null rows before it (scratch) */

@@ -164,8 +164,11 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
     } else {
       run_page = -1;
     }
+    int kind = 0, dec_up = 0;
     if (valid) {
       const PqPage pg = a.pages[p];
+      kind = pg.kind;
+      dec_up = pg.dec_scale_up;
       const i32 v = a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[pg.row_start]) : (i32)(row - pg.row_start);
       if (pg.encoding == 1) {
         u32 idx;
@@ -185,33 +188,45 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
         } else {
           idx = pq_hybrid_value(a.idx_runs, pg.idx_run_first, pg.idx_run_count, a.bytes, pg.bit_width, v);
         }
-        src = a.dict + pg.dict_off + (i64)idx * a.width;
-      } else if (a.kind == PQ_BOOL) {
+        src = a.dict + pg.dict_off + (i64)idx * pg.width;
+      } else if (pg.kind == PQ_BOOL) {
         boolbit = (a.bytes[pg.values_off + (v >> 3)] >> (v & 7)) & 1;
       } else {
-        src = a.bytes + pg.values_off + (i64)v * a.width;
+        src = a.bytes + pg.values_off + (i64)v * pg.width;
       }
     }
     if (!in_range) continue;
-    switch (a.kind) {
-      case PQ_COPY4: ((u32*)a.values_out)[row] = valid ? pq_ld32(src) : 0u; break;
-      case PQ_COPY8: ((u64*)a.values_out)[row] = valid ? pq_ld64(src) : 0ull; break;
-      case PQ_I32_TO_I64: ((i64*)a.values_out)[row] = valid ? (i64)(i32)pq_ld32(src) : 0; break;
-      case PQ_I32_TO_I16: ((i16*)a.values_out)[row] = valid ? (i16)(i32)pq_ld32(src) : (i16)0; break;
-      case PQ_I32_TO_I8: ((i8*)a.values_out)[row] = valid ? (i8)(i32)pq_ld32(src) : (i8)0; break;
-      case PQ_I32_TO_DEC: ((i128*)a.values_out)[row] = valid ? (i128)(i32)pq_ld32(src) * pq_pow10(a.dec_scale_up) : (i128)0; break;
-      case PQ_I64_TO_DEC: ((i128*)a.values_out)[row] = valid ? (i128)(i64)pq_ld64(src) * pq_pow10(a.dec_scale_up) : (i128)0; break;
-      case PQ_FLBA_TO_DEC: ((i128*)a.values_out)[row] = valid ? pq_flba_to_i128(src, a.width) * pq_pow10(a.dec_scale_up) : (i128)0; break;
-      case PQ_F32_TO_F64: ((double*)a.values_out)[row] = valid ? (double)__uint_as_float(pq_ld32(src)) : 0.0; break;
-      case PQ_I32_TO_F64: ((double*)a.values_out)[row] = valid ? (double)(i32)pq_ld32(src) : 0.0; break;
+    if (!valid) {
+      // NULL rows (and rows of pages that carry no value) store zeros of the column's output width
+      switch (a.out_width) {
+        case 1: ((u8*)a.values_out)[row] = 0; break;
+        case 2: ((u16*)a.values_out)[row] = 0; break;
+        case 4: ((u32*)a.values_out)[row] = 0u; break;
+        case 8: ((u64*)a.values_out)[row] = 0ull; break;
+        default: ((i128*)a.values_out)[row] = (i128)0; break;
+      }
+      continue;
+    }
+    switch (kind) {
+      case PQ_COPY4: ((u32*)a.values_out)[row] = pq_ld32(src); break;
+      case PQ_COPY8: ((u64*)a.values_out)[row] = pq_ld64(src); break;
+      case PQ_I32_TO_I64: ((i64*)a.values_out)[row] = (i64)(i32)pq_ld32(src); break;
+      case PQ_I32_TO_I16: ((i16*)a.values_out)[row] = (i16)(i32)pq_ld32(src); break;
+      case PQ_I32_TO_I8: ((i8*)a.values_out)[row] = (i8)(i32)pq_ld32(src); break;
+      case PQ_I32_TO_DEC: ((i128*)a.values_out)[row] = (i128)(i32)pq_ld32(src) * pq_pow10(dec_up); break;
+      case PQ_I64_TO_DEC: ((i128*)a.values_out)[row] = (i128)(i64)pq_ld64(src) * pq_pow10(dec_up); break;
+      case PQ_FLBA_TO_DEC: ((i128*)a.values_out)[row] = pq_flba_to_i128(src, a.pages[p].width) * pq_pow10(dec_up); break;
+      case PQ_F32_TO_F64: ((double*)a.values_out)[row] = (double)__uint_as_float(pq_ld32(src)); break;
+      case PQ_I32_TO_F64: ((double*)a.values_out)[row] = (double)(i32)pq_ld32(src); break;
       case PQ_INT96_TO_TS_MICROS: {
         // INT96 = 8 bytes nanoseconds of day (LE) + 4 bytes Julian day (LE); 2440588 = Julian day of 1970-01-01
-        i64 us = 0;
-        if (valid) us = ((i64)(i32)pq_ld32(src + 8) - 2440588) * 86400000000ll + (i64)(pq_ld64(src) / 1000ull);
-        ((i64*)a.values_out)[row] = us;
+        ((i64*)a.values_out)[row] = ((i64)(i32)pq_ld32(src + 8) - 2440588) * 86400000000ll + (i64)(pq_ld64(src) / 1000ull);
         break;
       }
-      case PQ_BOOL: ((u8*)a.values_out)[row] = (u8)(valid ? boolbit : 0); break;
+      case PQ_I64_MILLIS_TO_MICROS: ((i64*)a.values_out)[row] = (i64)((u64)pq_ld64(src) * 1000ull); break;   // wrapping like arrow's cast kernel multiply
+      case PQ_U32_TO_I64: ((i64*)a.values_out)[row] = (i64)(u64)pq_ld32(src); break;
+      case PQ_U64_TO_DEC: ((i128*)a.values_out)[row] = (i128)(u128)(u64)pq_ld64(src) * pq_pow10(dec_up); break;
+      case PQ_BOOL: ((u8*)a.values_out)[row] = (u8)boolbit; break;
       default: break;
     }
   }

@@ -107,8 +107,57 @@ SchemaElement read_schema_element(TReader& r) {
       case 6: e.converted_type = (int)r.zigzag(); break;
       case 7: e.scale = (int)r.zigzag(); break;
       case 8: e.precision = (int)r.zigzag(); break;
+      case 9: e.field_id = (int)r.zigzag(); break;
+      case 10: {   // LogicalType union (parquet.thrift): 5 DECIMAL, 7 TIME, 8 TIMESTAMP, 10 INTEGER; the rest carry nothing the scan needs
+        int16_t f2 = 0;
+        while (int t2 = r.field(f2)) {
+          if (t2 != 12) { r.skip(t2); continue; }
+          int16_t f3 = 0;
+          if (f2 == 8 || f2 == 7) {           // TimestampType / TimeType { 1: isAdjustedToUTC, 2: TimeUnit unit }
+            int unit = 0;
+            bool utc = true;
+            while (int t3 = r.field(f3)) {
+              if (f3 == 1 && (t3 == 1 || t3 == 2)) utc = t3 == 1;
+              else if (f3 == 2 && t3 == 12) {   // TimeUnit union: 1 MILLIS, 2 MICROS, 3 NANOS (empty structs)
+                int16_t f4 = 0;
+                while (int t4 = r.field(f4)) { unit = f4; r.skip(t4); }
+              } else r.skip(t3);
+            }
+            if (f2 == 8) { e.ts_unit = unit; e.ts_utc = utc; }
+            else e.is_time = true;
+          } else if (f2 == 10) {              // IntType { 1: i8 bitWidth, 2: bool isSigned }
+            while (int t3 = r.field(f3)) {
+              if (f3 == 1 && t3 == 3) e.int_bits = (int)(int8_t)r.byte();
+              else if (f3 == 2 && (t3 == 1 || t3 == 2)) e.int_signed = t3 == 1;
+              else r.skip(t3);
+            }
+          } else if (f2 == 5) {               // DecimalType { 1: scale, 2: precision }
+            while (int t3 = r.field(f3)) {
+              if (f3 == 1) e.scale = (int)r.zigzag();
+              else if (f3 == 2) e.precision = (int)r.zigzag();
+              else r.skip(t3);
+            }
+          } else {
+            while (int t3 = r.field(f3)) r.skip(t3);
+          }
+        }
+        break;
+      }
       default: r.skip(t);
     }
+  }
+  // older writers only set converted_type (parquet.thrift ConvertedType)
+  switch (e.converted_type) {
+    case 7: case 8: e.is_time = true; break;                       // TIME_MILLIS / TIME_MICROS
+    case 9: if (!e.ts_unit) e.ts_unit = 1; break;                  // TIMESTAMP_MILLIS
+    case 10: if (!e.ts_unit) e.ts_unit = 2; break;                 // TIMESTAMP_MICROS
+    case 11: case 12: case 13: case 14:                            // UINT_8 / 16 / 32 / 64
+      if (!e.int_bits) { e.int_bits = 8 << (e.converted_type - 11); e.int_signed = false; }
+      break;
+    case 15: case 16: case 17: case 18:                            // INT_8 / 16 / 32 / 64
+      if (!e.int_bits) { e.int_bits = 8 << (e.converted_type - 15); e.int_signed = true; }
+      break;
+    default: break;
   }
   return e;
 }

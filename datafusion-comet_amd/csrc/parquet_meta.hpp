@@ -23,6 +23,13 @@ struct SchemaElement {
   int num_children = 0;
   int converted_type = -1;
   int scale = 0, precision = 0;
+  int field_id = -1;      // SchemaElement.field_id (9), -1 = absent
+  // from LogicalType (10) or, for older writers, converted_type (6)
+  int ts_unit = 0;        // timestamps: 0 = not a timestamp, 1 millis, 2 micros, 3 nanos
+  bool ts_utc = true;     // isAdjustedToUTC
+  int int_bits = 0;       // INTEGER annotation: 8 / 16 / 32 / 64, 0 = none
+  bool int_signed = true;
+  bool is_time = false;   // TIME_MILLIS / TIME_MICROS / TIME(…)
 };
 
 struct ColumnMeta {

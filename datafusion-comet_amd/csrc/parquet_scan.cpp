@@ -296,21 +296,89 @@ int out_width_of(const DType& t) {
   }
 }
 
-ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, bool case_sensitive) {
+// per-scan options of the schema adapter (parquet/schema_adapter.rs, parquet_support.rs SparkParquetOptions)
+struct ScanOptions {
+  bool case_sensitive = false;
+  bool match_by_id = false;            // use_field_id && the requested schema carries at least one field id
+  bool ignore_missing_field_id = false;
+  bool allow_type_promotion = false;
+  bool allow_timestamp_ltz_to_ntz = false;
+  static ScanOptions of(const Operator& op) {
+    ScanOptions o;
+    o.case_sensitive = op.case_sensitive;
+    bool ids = false;
+    for (auto& f : op.required_schema) ids |= f.field_id >= 0;
+    o.match_by_id = op.use_field_id && ids;
+    o.ignore_missing_field_id = op.ignore_missing_field_id;
+    o.allow_type_promotion = op.allow_type_promotion;
+    o.allow_timestamp_ltz_to_ntz = op.allow_timestamp_ltz_to_ntz;
+    return o;
+  }
+};
+
+std::string json_escape(const std::string& v) {
+  std::string o;
+  for (char ch : v) {
+    if (ch == '"' || ch == '\\') { o.push_back('\\'); o.push_back(ch); }
+    else if ((unsigned char)ch < 0x20) o += ' ';
+    else o.push_back(ch);
+  }
+  return o;
+}
+// the reference reports these through SparkError → CometQueryExecutionException JSON (native/common/src/error.rs:191-222, 528-560)
+CometError spark_error(const std::string& type, const std::string& params_json) {
+  return CometError("{\"errorType\":\"" + type + "\",\"params\":{" + params_json + "}}", 1);
+}
+const char* parquet_primitive_name(int pt) {
+  switch (pt) {
+    case pq::BOOLEAN: return "BOOLEAN"; case pq::INT32: return "INT32"; case pq::INT64: return "INT64"; case pq::INT96: return "INT96";
+    case pq::FLOAT: return "FLOAT"; case pq::DOUBLE: return "DOUBLE"; case pq::BYTE_ARRAY: return "BINARY"; default: return "FIXED_LEN_BYTE_ARRAY";
+  }
+}
+std::string spark_catalog_name(const DType& t) {   // schema_adapter.rs spark_catalog_name
+  switch (t.id) {
+    case TypeId::Bool: return "boolean"; case TypeId::Int8: return "tinyint"; case TypeId::Int16: return "smallint"; case TypeId::Int32: return "int";
+    case TypeId::Int64: return "bigint"; case TypeId::Float: return "float"; case TypeId::Double: return "double"; case TypeId::String: return "string";
+    case TypeId::Bytes: return "binary"; case TypeId::Date: return "date"; case TypeId::Timestamp: return "timestamp"; case TypeId::TimestampNtz: return "timestamp_ntz";
+    case TypeId::Decimal: return "decimal(" + std::to_string(t.precision) + "," + std::to_string(t.scale) + ")";
+    default: return "unknown";
+  }
+}
+CometError schema_convert_error(const std::string& column, int pt, const DType& t) {
+  return spark_error("ParquetSchemaConvert", "\"filePath\":\"\",\"column\":\"[" + json_escape(column) + "]\",\"physicalType\":\"" + parquet_primitive_name(pt) +
+                                                 "\",\"sparkType\":\"" + spark_catalog_name(t) + "\"");
+}
+
+// Which leaf of the file holds the requested column (schema_adapter.rs:76-250 remap_physical_schema, Spark's clipParquetGroupFields):
+// a requested field that carries a field id is looked up by id ONLY (no fall-back to its name) when id matching is on; the others by
+// name, exact or ASCII-case-insensitive; more than one candidate is an error; none means the column is missing from this file.
+ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, const ScanOptions& so) {
   ColumnPlan cp;
-  int leaf = 0;
+  bool file_has_ids = false;
+  for (size_t i = 1; i < fm.schema.size(); i++) {
+    if (fm.schema[i].num_children > 0) throw CometError("nested Parquet schemas are not supported by the GPU scan yet");
+    file_has_ids |= fm.schema[i].field_id >= 0;
+  }
+  if (so.match_by_id && !so.ignore_missing_field_id && !file_has_ids) throw spark_error("ParquetMissingFieldIds", "");
+  const bool by_id = so.match_by_id && want.field_id >= 0;
+  std::vector<int> hits;
   for (size_t i = 1; i < fm.schema.size(); i++) {
     const pq::SchemaElement& e = fm.schema[i];
-    if (e.num_children > 0) throw CometError("nested Parquet schemas are not supported by the GPU scan yet");
-    if ((case_sensitive && e.name == want.name) || (!case_sensitive && iequals(e.name, want.name))) {
-      cp.leaf = leaf;
-      cp.el = e;
-      break;
-    }
-    leaf++;
+    const bool hit = by_id ? e.field_id == want.field_id : (so.case_sensitive ? e.name == want.name : iequals(e.name, want.name));
+    if (hit) hits.push_back((int)i);
+  }
+  if (hits.size() > 1) {
+    std::string names;
+    for (int h : hits) names += (names.empty() ? "" : ", ") + fm.schema[(size_t)h].name;
+    if (by_id) throw spark_error("DuplicateFieldByFieldId", "\"requiredId\":" + std::to_string(want.field_id) + ",\"matchedFields\":\"" + json_escape(names) + "\"");
+    throw spark_error("DuplicateFieldCaseInsensitive", "\"requiredFieldName\":\"" + json_escape(want.name) + "\",\"matchedOrcFields\":\"[" + json_escape(names) + "]\"");
+  }
+  if (hits.size() == 1) {
+    cp.leaf = hits[0] - 1;
+    cp.el = fm.schema[(size_t)hits[0]];
   }
   if (cp.leaf < 0) {
-    // a column the file does not have reads as NULL (Spark schema evolution; schema_adapter.rs:352-525 without default values)
+    // a column the file does not have reads as NULL, or as its default value (schema evolution; schema_adapter.rs replace_missing_with_defaults)
     cp.missing = true;
     cp.is_string = want.dtype.id == TypeId::String || want.dtype.id == TypeId::Bytes;
     cp.out_width = out_width_of(want.dtype);
@@ -321,13 +389,36 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, bool cas
   const DType& t = want.dtype;
   const int pt = cp.el.type;
   auto bad = [&]() { return CometError("Parquet column '" + want.name + "': physical type " + std::to_string(pt) + " cannot be read as " + t.str() + " by the GPU scan yet"); };
+  // Logical annotations decide what the physical integers mean (the reference reads through the arrow parquet reader, which applies
+  // them, then the schema adapter casts to the Spark type): TIMESTAMP(MILLIS) is scaled to microseconds, unsigned integers are
+  // zero-extended into the wider Spark type (Spark maps UINT_8 → short, UINT_16 → int, UINT_32 → long, UINT_64 → decimal(20,0));
+  // what this scan cannot convert is an error, never a silent reinterpretation.
+  const pq::SchemaElement& el = cp.el;
+  if (el.is_time) throw CometError("Parquet column '" + want.name + "': TIME columns are not supported by the GPU scan yet");
+  if (el.ts_unit == 3) throw CometError("Parquet column '" + want.name + "': TIMESTAMP(NANOS) is not supported by the GPU scan yet");
+  const bool is_unsigned = el.int_bits > 0 && !el.int_signed;
+  if (is_unsigned) {
+    const bool ok = (el.int_bits == 8 && (t.id == TypeId::Int16 || t.id == TypeId::Int32 || t.id == TypeId::Int64)) ||
+                    (el.int_bits == 16 && (t.id == TypeId::Int32 || t.id == TypeId::Int64)) ||
+                    (el.int_bits == 32 && t.id == TypeId::Int64) ||
+                    (el.int_bits == 64 && t.id == TypeId::Decimal && t.precision - t.scale >= 20);
+    if (!ok) throw CometError("Parquet column '" + want.name + "': UINT_" + std::to_string(el.int_bits) + " cannot be read as " + t.str() + " by the GPU scan");
+  }
+  // a TimestampLTZ column (isAdjustedToUTC, or INT96) read as TimestampNTZ: Spark 3.x rejects it (SPARK-36182), 4.0+ allows it
+  if (t.id == TypeId::TimestampNtz && !so.allow_timestamp_ltz_to_ntz && ((el.ts_unit != 0 && el.ts_utc) || pt == pq::INT96))
+    throw schema_convert_error(want.name, pt, t);
+  if (el.ts_unit != 0 && !(t.id == TypeId::Timestamp || t.id == TypeId::TimestampNtz || t.id == TypeId::Int64))
+    throw CometError("Parquet column '" + want.name + "': a TIMESTAMP column cannot be read as " + t.str());
   switch (t.id) {
     case TypeId::Int32: case TypeId::Date: if (pt != pq::INT32) throw bad(); cp.kind = PQ_COPY4; cp.src_width = 4; cp.out_width = 4; break;
     case TypeId::Int16: if (pt != pq::INT32) throw bad(); cp.kind = PQ_I32_TO_I16; cp.src_width = 4; cp.out_width = 2; break;
     case TypeId::Int8: if (pt != pq::INT32) throw bad(); cp.kind = PQ_I32_TO_I8; cp.src_width = 4; cp.out_width = 1; break;
     case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz:
-      if (pt == pq::INT64) { cp.kind = PQ_COPY8; cp.src_width = 8; }
-      else if (pt == pq::INT32 && t.id == TypeId::Int64) { cp.kind = PQ_I32_TO_I64; cp.src_width = 4; }   // type promotion (schema_adapter.rs)
+      if (pt == pq::INT64) { cp.kind = (el.ts_unit == 1 && t.id != TypeId::Int64) ? PQ_I64_MILLIS_TO_MICROS : PQ_COPY8; cp.src_width = 8; }
+      else if (pt == pq::INT32 && t.id == TypeId::Int64) {   // type promotion (schema_adapter.rs:749-771): rejected on Spark 3.x
+        if (!so.allow_type_promotion && !is_unsigned) throw schema_convert_error(want.name, pt, t);
+        cp.kind = (is_unsigned && el.int_bits == 32) ? PQ_U32_TO_I64 : PQ_I32_TO_I64; cp.src_width = 4;
+      }
       else if (pt == pq::INT96 && t.id != TypeId::Int64) { cp.kind = PQ_INT96_TO_TS_MICROS; cp.src_width = 12; }   // legacy Spark/Impala timestamps
       else throw bad();
       cp.out_width = 8;
@@ -335,14 +426,17 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, bool cas
     case TypeId::Float: if (pt != pq::FLOAT) throw bad(); cp.kind = PQ_COPY4; cp.src_width = 4; cp.out_width = 4; break;
     case TypeId::Double:
       if (pt == pq::DOUBLE) { cp.kind = PQ_COPY8; cp.src_width = 8; }
-      else if (pt == pq::FLOAT) { cp.kind = PQ_F32_TO_F64; cp.src_width = 4; }     // FLOAT → DOUBLE promotion
-      else if (pt == pq::INT32) { cp.kind = PQ_I32_TO_F64; cp.src_width = 4; }     // INT32 → DOUBLE promotion
+      else if (pt == pq::FLOAT || pt == pq::INT32) {                                // FLOAT → DOUBLE, INT32 → DOUBLE promotions
+        if (!so.allow_type_promotion) throw schema_convert_error(want.name, pt, t);
+        cp.kind = pt == pq::FLOAT ? PQ_F32_TO_F64 : PQ_I32_TO_F64; cp.src_width = 4;
+      }
       else throw bad();
       cp.out_width = 8;
       break;
     case TypeId::Bool: if (pt != pq::BOOLEAN) throw bad(); cp.kind = PQ_BOOL; cp.src_width = 0; cp.out_width = 1; break;
     case TypeId::Decimal:
       if (pt == pq::INT32) { cp.kind = PQ_I32_TO_DEC; cp.src_width = 4; }
+      else if (pt == pq::INT64 && is_unsigned) { cp.kind = PQ_U64_TO_DEC; cp.src_width = 8; cp.dec_scale_up = t.scale; cp.out_width = 16; return cp; }   // UINT_64 → decimal(20,0)
       else if (pt == pq::INT64) { cp.kind = PQ_I64_TO_DEC; cp.src_width = 8; }
       else if (pt == pq::FLBA && cp.el.type_length >= 1 && cp.el.type_length <= 16) { cp.kind = PQ_FLBA_TO_DEC; cp.src_width = cp.el.type_length; }
       else throw bad();
@@ -407,6 +501,8 @@ bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::
   const pq::ColumnMeta* cm; const pq::SchemaElement* el; DType t;
   int64_t v, mn, mx;
   if (!column_of(*l, cm, el, t) || !lit_i64(*r, v) || !stat_i64(*cm, *el, mn, mx)) return false;
+  // statistics are in the file's unit / signedness: do not compare them with a microsecond or signed literal
+  if ((el->ts_unit != 0 && el->ts_unit != 2) || (el->int_bits > 0 && !el->int_signed) || el->type == pq::INT96) return false;
   if (t.id == TypeId::Decimal && (el->scale != t.scale || !(r->dtype.id == TypeId::Decimal && r->dtype.scale == t.scale))) return false;   // same scale only
   if (t.id != TypeId::Decimal && r->dtype.id == TypeId::Decimal) return false;
   switch (k) {
@@ -443,9 +539,9 @@ struct ChunkSource {
 // bytes the staged (decompressed) pages of a column chunk may take
 size_t staged_capacity(const pq::ColumnMeta& cm) { return ((size_t)cm.total_uncompressed + 64 + 15) & ~(size_t)15; }
 
-void decode_chunk_host(const ChunkSource& src, const StructField& want, bool case_sensitive, HostChunk& hc, uint8_t* staged, size_t staged_cap) {
+void decode_chunk_host(const ChunkSource& src, const StructField& want, const ScanOptions& so, HostChunk& hc, uint8_t* staged, size_t staged_cap) {
   const pq::RowGroup& rg = src.meta->row_groups[(size_t)src.rg];
-  ColumnPlan cp = plan_column(want, *src.meta, case_sensitive);
+  ColumnPlan cp = plan_column(want, *src.meta, so);
   if (cp.missing) throw CometError("internal: chunk task for a missing column");
   if ((size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
   const pq::ColumnMeta& cm = rg.columns[(size_t)cp.leaf];
@@ -506,6 +602,9 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, bool cas
     memset(&pg, 0, sizeof pg);
     pg.row_start = values_seen;
     pg.num_values = h.num_values;
+    pg.kind = cp.kind;
+    pg.width = cp.src_width;
+    pg.dec_scale_up = cp.dec_scale_up;
     size_t page_begin = spos, vals_begin, page_end;
     if (h.type == pq::DATA_PAGE) {
       pq::decompress(cm.codec, body, (size_t)h.compressed_size, staged + spos, (size_t)h.uncompressed_size);
@@ -592,6 +691,84 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, bool cas
   str_offs.push_back(0);   // sentinel
 }
 
+// A column this file does not have (schema evolution): one synthetic page covering the row group — all NULL, or the column's default
+// value (NativeScanCommon.default_values; schema_adapter.rs replace_missing_with_defaults) as a one-entry dictionary every row points at.
+size_t synth_capacity(const DType& t, int64_t rows) { return t.id == TypeId::Bool ? (size_t)((rows + 7) / 8) + 32 : 32; }
+void synth_chunk(const StructField& want, const Expr* dflt, int64_t rows, HostChunk& hc, uint8_t* staged, size_t cap) {
+  const DType& t = want.dtype;
+  const bool is_null = !dflt || dflt->lit_null;
+  if (dflt && dflt->kind != ExprKind::Literal) throw CometError("Parquet column '" + want.name + "': default value is not a literal");
+  hc.cp.missing = true;
+  hc.cp.is_string = t.id == TypeId::String || t.id == TypeId::Bytes;
+  hc.cp.out_width = out_width_of(t);
+  hc.n_rows = rows;
+  hc.compressed = 0;
+  hc.max_def = is_null ? 1 : 0;
+  hc.no_nulls = !is_null;
+  PqPage pg;
+  memset(&pg, 0, sizeof pg);
+  pg.num_values = (int32_t)rows;
+  if (is_null) {
+    PqRun r;
+    memset(&r, 0, sizeof r);
+    r.is_rle = 1;
+    r.count = (int32_t)rows;
+    r.rle_value = 0;
+    hc.def_runs.push_back(r);
+    pg.def_run_first = 0;
+    pg.def_run_count = 1;
+  }
+  pg.encoding = 1;
+  pg.bit_width = 0;
+  PqRun ir;
+  memset(&ir, 0, sizeof ir);
+  ir.is_rle = 1;
+  ir.count = (int32_t)rows;
+  hc.idx_runs.push_back(ir);
+  pg.idx_run_first = 0;
+  pg.idx_run_count = 1;
+  size_t spos = 0;
+  unsigned char raw[16] = {0};
+  auto dict = [&](int kind, int width) {
+    pg.kind = kind;
+    pg.width = width;
+    hc.dict_bytes.assign(raw, raw + 16);
+  };
+  switch (t.id) {
+    case TypeId::Bool: {
+      pg.kind = PQ_BOOL;
+      pg.encoding = 0;
+      pg.values_off = 0;
+      spos = (size_t)((rows + 7) / 8);
+      if (spos + 16 > cap) throw CometError("internal: synthetic boolean page does not fit its slot");
+      memset(staged, (!is_null && dflt->lit_bool) ? 0xff : 0x00, spos);
+      break;
+    }
+    case TypeId::Int8: case TypeId::Int16: { int32_t x = is_null ? 0 : (int32_t)dflt->lit_i64; memcpy(raw, &x, 4); dict(t.id == TypeId::Int8 ? PQ_I32_TO_I8 : PQ_I32_TO_I16, 4); break; }
+    case TypeId::Int32: case TypeId::Date: { int32_t x = is_null ? 0 : (int32_t)dflt->lit_i64; memcpy(raw, &x, 4); dict(PQ_COPY4, 4); break; }
+    case TypeId::Float: { float x = is_null ? 0.f : (float)dflt->lit_f64; memcpy(raw, &x, 4); dict(PQ_COPY4, 4); break; }
+    case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: { int64_t x = is_null ? 0 : dflt->lit_i64; memcpy(raw, &x, 8); dict(PQ_COPY8, 8); break; }
+    case TypeId::Double: { double x = is_null ? 0.0 : dflt->lit_f64; memcpy(raw, &x, 8); dict(PQ_COPY8, 8); break; }
+    case TypeId::Decimal: {
+      u128 v = is_null ? 0 : (u128)dflt->lit_dec;
+      for (int k = 0; k < 16; k++) raw[k] = (unsigned char)(v >> (8 * (15 - k)));   // FIXED_LEN_BYTE_ARRAY decimals are big-endian
+      dict(PQ_FLBA_TO_DEC, 16);
+      break;
+    }
+    case TypeId::String: case TypeId::Bytes: {
+      const std::string& b = is_null ? std::string() : dflt->lit_bytes;
+      hc.dict_bytes.assign(b.begin(), b.end());
+      hc.dict_offs = {0, (int32_t)b.size()};
+      break;
+    }
+    default: throw CometError("Parquet column '" + want.name + "' is missing from a file and its type " + t.str() + " cannot be synthesised by the GPU scan yet");
+  }
+  memset(staged + spos, 0, 16);
+  hc.spos = spos;
+  hc.pages.push_back(pg);
+  hc.str_offs.push_back(0);   // sentinel
+}
+
 }  // namespace
 
 DevTable ExecutionContext::scan_parquet(const Operator& op) {
@@ -606,6 +783,14 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   out.cols.assign(ncol + npart, DeviceColumnView());
   out.has_valid.assign(ncol + npart, false);
   if (op.files.empty()) return out;   // EmptyExec (planner.rs:1548-1556)
+  if (op.encryption_enabled) throw CometError("Parquet modular encryption is not supported by the GPU scan");
+  const ScanOptions so = ScanOptions::of(op);
+  if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
+  auto default_of = [&](size_t c) -> const Expr* {
+    for (size_t k = 0; k < op.default_values_indexes.size(); k++)
+      if ((size_t)op.default_values_indexes[k] == c) return op.default_values[k].get();
+    return nullptr;
+  };
 
   // pass 1: open files, pick row groups (midpoint rule), total rows
   struct Sel { std::shared_ptr<OpenFile> file; std::shared_ptr<pq::FileMeta> meta; int rg; int64_t row_off; const PartitionedFile* pf; int64_t rows; };
@@ -644,20 +829,27 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   const size_t nsel = sels.size();
   const size_t ntasks = ncol * nsel;
   std::vector<HostChunk> chunks(ntasks);
-  std::vector<ColumnPlan> plans(ncol);
+  std::vector<ColumnPlan> plans(ncol);            // what the column looks like in the files that have it (string-ness, output width)
+  std::vector<char> chunk_missing(ntasks, 0);     // per (column, row group): this file lacks the column
+  std::vector<char> all_missing(ncol, 0);         // no selected file has the column and it has no default: all-NULL fast path
   std::vector<std::vector<size_t>> slot_off(ncol, std::vector<size_t>(nsel + 1, 0));
   std::vector<std::unique_ptr<PinnedBuf>> col_staged(ncol);
   for (size_t c = 0; c < ncol; c++) {
+    bool have = false;
+    const Expr* dflt = default_of(c);
     for (size_t si = 0; si < nsel; si++) {
-      ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, op.case_sensitive);
+      ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
       const pq::RowGroup& rg = sels[si].meta->row_groups[(size_t)sels[si].rg];
       if (!cp.missing && (size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
-      if (si == 0) plans[c] = cp;
-      else if (cp.missing != plans[c].missing || cp.kind != plans[c].kind || cp.src_width != plans[c].src_width || cp.is_string != plans[c].is_string ||
-               cp.dec_scale_up != plans[c].dec_scale_up)
-        throw CometError("parquet: column '" + op.required_schema[c].name + "' differs in presence or physical type across the files of one partition");
-      slot_off[c][si + 1] = slot_off[c][si] + (cp.missing ? 0 : staged_capacity(rg.columns[(size_t)cp.leaf]));
+      chunk_missing[c * nsel + si] = cp.missing;
+      if (!cp.missing && !have) { plans[c] = cp; have = true; }
+      slot_off[c][si + 1] = slot_off[c][si] + (cp.missing ? synth_capacity(op.required_schema[c].dtype, rg.num_rows) : staged_capacity(rg.columns[(size_t)cp.leaf]));
     }
+    if (!have) {
+      plans[c] = plan_column(op.required_schema[c], *sels[0].meta, so);
+      all_missing[c] = dflt == nullptr || dflt->lit_null;
+    }
+    plans[c].out_width = out_width_of(op.required_schema[c].dtype);
     col_staged[c].reset(new PinnedBuf());
     col_staged[c]->ensure(slot_off[c][nsel] + 64);
   }
@@ -678,8 +870,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   auto run_task = [&](size_t t) {
     const size_t c = t / nsel, si = t % nsel;
     ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg};
-    if (plans[c].missing) return;
-    decode_chunk_host(src, op.required_schema[c], op.case_sensitive, chunks[t], (uint8_t*)col_staged[c]->p + slot_off[c][si], slot_off[c][si + 1] - slot_off[c][si]);
+    if (all_missing[c]) return;
+    uint8_t* slot = (uint8_t*)col_staged[c]->p + slot_off[c][si];
+    const size_t cap = slot_off[c][si + 1] - slot_off[c][si];
+    if (chunk_missing[t]) synth_chunk(op.required_schema[c], default_of(c), sels[si].rows, chunks[t], slot, cap);
+    else decode_chunk_host(src, op.required_schema[c], so, chunks[t], slot, cap);
   };
   for (size_t t = 0; t < ntasks; t++) {
     ScanPool::get().submit([prog, t, &run_task, &chunks]() {
@@ -737,9 +932,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
 
   for (size_t c = 0; c < ncol; c++) {
     const ColumnPlan& cp = plans[c];
-    if (cp.missing) {
-      for (int64_t di : op.default_values_indexes)
-        if ((size_t)di == c) throw CometError("Parquet column '" + op.required_schema[c].name + "' is missing and has a default value: defaults are not supported by the GPU scan yet");
+    if (all_missing[c]) {
       // all-NULL column: zeroed values, zeroed validity bitmap
       DeviceColumnView mv;
       auto zeros = std::make_shared<DevBuf>();
@@ -853,9 +1046,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     a.dict_offs = (const int32_t*)(tb + off_doffs);
     a.plain_str_offs = (const int64_t*)(tb + off_soffs);
     a.n_rows = total_rows;
-    a.kind = cp.kind;
-    a.width = cp.src_width;
-    a.dec_scale_up = cp.dec_scale_up;
+    a.out_width = cp.out_width;
     if (any_optional) {
       valid_bytes->ensure((size_t)total_rows + 16);
       if (!vidx->p) vidx->ensure((size_t)total_rows * 4 + 16);

@@ -107,6 +107,7 @@ struct StructField {  // SparkStructField (operator.proto:117-124)
   std::string name;
   DType dtype;
   bool nullable = true;
+  int field_id = -1;   // metadata["PARQUET:field_id"] (CometParquetUtils.PARQUET_FIELD_ID_META_KEY), -1 = none
 };
 
 struct PartitionedFile {  // SparkPartitionedFile (operator.proto:103-109)
@@ -159,7 +160,11 @@ struct Operator {
   std::vector<PartitionedFile> files;
   std::string session_timezone;
   bool case_sensitive = false;                 // NativeScanCommon.case_sensitive (proto3 default)
+  std::vector<ExprP> default_values;            // NativeScanCommon.default_values (literals), parallel to default_values_indexes
   std::vector<int64_t> default_values_indexes;  // required_schema positions that carry a default value
+  bool encryption_enabled = false;
+  bool use_field_id = false, ignore_missing_field_id = false;
+  bool allow_type_promotion = false, allow_timestamp_ltz_to_ntz = false;   // proto3 defaults (Spark 3.x behaviour)
   // Window (operator.proto:793-862): child columns ++ one column per window expression; input sorted by (partition, order) keys
   struct WindowFn {
     std::string func;               // built_in_window_function: ScalarFunc name (row_number, rank, dense_rank, percent_rank, cume_dist, ntile, lag, lead)

@@ -1,6 +1,7 @@
 // Hand-written proto3 wire decoder for Comet's plan messages (no protoc / libprotobuf in this image).
 // Field numbers follow native/proto/src/proto/{operator,expr,types,literal,config,metric}.proto; the
 // reference decodes the same bytes with prost in native/core/src/execution/serde.rs:45-58.
+#include <cstdlib>
 #include <cstring>
 
 #include "plan.hpp"
@@ -274,6 +275,21 @@ StructField decode_struct_field(Reader r) {
     if (f == 1 && wt == 2) s.name = r.bytes();
     else if (f == 2 && wt == 2) s.dtype = decode_datatype(r.sub());
     else if (f == 3 && wt == 0) s.nullable = r.varint() != 0;
+    else if (f == 4 && wt == 2) {   // map<string,string> metadata: only "PARQUET:field_id" is consumed (schema_adapter.rs:67-73)
+      Reader e = r.sub();
+      std::string k, v;
+      while (!e.done()) {
+        int wt2, f2 = e.tag(wt2);
+        if (f2 == 1 && wt2 == 2) k = e.bytes();
+        else if (f2 == 2 && wt2 == 2) v = e.bytes();
+        else e.skip(wt2);
+      }
+      if (k == "PARQUET:field_id") {
+        char* endp = nullptr;
+        long id = strtol(v.c_str(), &endp, 10);
+        if (endp && *endp == 0 && !v.empty()) s.field_id = (int)id;   // parse::<i32>().ok(): unparsable ids are ignored
+      }
+    }
     else r.skip(wt);
   }
   return s;
@@ -292,7 +308,13 @@ void decode_native_scan(Reader r, Operator& op) {
         else if (f2 == 4 && wt2 == 2) op.data_filters.push_back(decode_expr(c.sub()));
         else if (f2 == 5) c.repeated_varint(wt2, [&](uint64_t v) { op.projection_vector.push_back((int64_t)v); });
         else if (f2 == 6 && wt2 == 2) op.session_timezone = c.bytes();
+        else if (f2 == 7 && wt2 == 2) op.default_values.push_back(decode_expr(c.sub()));
         else if (f2 == 8) c.repeated_varint(wt2, [&](uint64_t v) { op.default_values_indexes.push_back((int64_t)v); });
+        else if (f2 == 11 && wt2 == 0) op.encryption_enabled = c.varint() != 0;
+        else if (f2 == 15 && wt2 == 0) op.use_field_id = c.varint() != 0;
+        else if (f2 == 16 && wt2 == 0) op.ignore_missing_field_id = c.varint() != 0;
+        else if (f2 == 17 && wt2 == 0) op.allow_type_promotion = c.varint() != 0;
+        else if (f2 == 18 && wt2 == 0) op.allow_timestamp_ltz_to_ntz = c.varint() != 0;
         else if (f2 == 9 && wt2 == 0) op.case_sensitive = c.varint() != 0;
         else if (f2 == 12 && wt2 == 2) op.scan_source = c.bytes();
         else if (f2 == 13 && wt2 == 2) op.scan_fields.push_back(decode_datatype(c.sub()));

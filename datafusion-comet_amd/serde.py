@@ -385,6 +385,12 @@ class Operator:
     data_filters: List[Expr] = field(default_factory=list)    # pushed-down predicates (row-group pruning only)
     partition_fields: List[tuple] = field(default_factory=list)   # Hive partition columns: (name, DataType)
     partition_values: List[tuple] = field(default_factory=list)   # per file: one python value per partition column (None = NULL)
+    field_ids: List[Optional[int]] = field(default_factory=list)  # per required column: Parquet field id (metadata "PARQUET:field_id") or None
+    use_field_id: bool = False
+    ignore_missing_field_id: bool = False
+    allow_type_promotion: bool = True             # Spark 4.x behaviour (ShimCometConf); False = Spark 3.x: widening reads are rejected
+    allow_timestamp_ltz_to_ntz: bool = True
+    default_values: dict = field(default_factory=dict)            # required-schema position → python value of the column's default
     # sort / limit
     sort_orders: List[tuple] = field(default_factory=list)   # (expr, descending, nulls_last)
     fetch: Optional[int] = None
@@ -491,13 +497,23 @@ class Operator:
         elif self.kind == "native_scan":
             # NativeScan{common=1 NativeScanCommon{required_schema=1,data_schema=2,projection_vector=5,session_timezone=6,
             # case_sensitive=9,source=12,fields=13}, file_partition=2 SparkFilePartition{partitioned_file=1}} (operator.proto:103-190)
-            sf = lambda n, t: _f_bytes(1, n.encode()) + _f_msg(2, t.encode()) + _f_varint(3, 1)
-            common = b"".join(_f_msg(1, sf(n, t)) for n, t in zip(self.field_names, self.fields))
-            common += b"".join(_f_msg(2, sf(n, t)) for n, t in zip(self.field_names, self.fields))
+            def sf(n, t, fid=None):
+                out = _f_bytes(1, n.encode()) + _f_msg(2, t.encode()) + _f_varint(3, 1)
+                if fid is not None:   # map<string,string> metadata = 4 (CometParquetUtils.PARQUET_FIELD_ID_META_KEY)
+                    out += _f_msg(4, _f_bytes(1, b"PARQUET:field_id") + _f_bytes(2, str(fid).encode()))
+                return out
+            ids = list(self.field_ids) + [None] * (len(self.fields) - len(self.field_ids))
+            common = b"".join(_f_msg(1, sf(n, t, i)) for n, t, i in zip(self.field_names, self.fields, ids))
+            common += b"".join(_f_msg(2, sf(n, t, i)) for n, t, i in zip(self.field_names, self.fields, ids))
             common += b"".join(_f_msg(3, sf(n, t)) for n, t in self.partition_fields)
             common += b"".join(_f_msg(4, e.encode()) for e in self.data_filters)
             common += b"".join(_f_varint(5, i) for i in range(len(self.fields)))
-            common += _f_bytes(6, b"UTC") + (_f_varint(9, 1) if self.case_sensitive else b"") + _f_bytes(12, b"parquet") + b"".join(_f_msg(13, t.encode()) for t in self.fields)
+            common += _f_bytes(6, b"UTC")
+            dv = sorted(self.default_values.items())
+            common += b"".join(_f_msg(7, lit(v, self.fields[i]).encode()) for i, v in dv) + b"".join(_f_varint(8, i) for i, _ in dv)
+            common += (_f_varint(9, 1) if self.case_sensitive else b"") + _f_bytes(12, b"parquet") + b"".join(_f_msg(13, t.encode()) for t in self.fields)
+            common += (_f_varint(15, 1) if self.use_field_id else b"") + (_f_varint(16, 1) if self.ignore_missing_field_id else b"")
+            common += (_f_varint(17, 1) if self.allow_type_promotion else b"") + (_f_varint(18, 1) if self.allow_timestamp_ltz_to_ntz else b"")
             part = b""
             for fi, (path, start, length, size) in enumerate(self.files):
                 pf = _f_bytes(1, ("file://" + path).encode())
@@ -609,7 +625,9 @@ def final_of(partial_plan: "Operator", state_schema) -> "Operator":
 
 
 def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType], case_sensitive: bool = True,
-                data_filters: Sequence[Expr] = (), partition_fields: Sequence[tuple] = (), partition_values: Sequence[tuple] = ()) -> Operator:
+                data_filters: Sequence[Expr] = (), partition_fields: Sequence[tuple] = (), partition_values: Sequence[tuple] = (),
+                field_ids: Sequence = (), use_field_id: bool = False, ignore_missing_field_id: bool = False, allow_type_promotion: bool = True,
+                allow_timestamp_ltz_to_ntz: bool = True, default_values: Optional[dict] = None) -> Operator:
     """Parquet scan of `files` (paths, or (path, start, length, size) byte-range splits) producing columns `names`."""
     import os
     fl = []
@@ -620,7 +638,9 @@ def native_scan(files: Sequence, names: Sequence[str], types: Sequence[DataType]
         else:
             fl.append(tuple(f))
     return Operator("native_scan", fields=list(types), field_names=list(names), files=fl, case_sensitive=case_sensitive, data_filters=list(data_filters),
-                    partition_fields=list(partition_fields), partition_values=list(partition_values))
+                    partition_fields=list(partition_fields), partition_values=list(partition_values), field_ids=list(field_ids),
+                    use_field_id=use_field_id, ignore_missing_field_id=ignore_missing_field_id, allow_type_promotion=allow_type_promotion,
+                    allow_timestamp_ltz_to_ntz=allow_timestamp_ltz_to_ntz, default_values=dict(default_values or {}))
 
 
 INNER, LEFT_OUTER, RIGHT_OUTER, FULL_OUTER, LEFT_SEMI, LEFT_ANTI = range(6)

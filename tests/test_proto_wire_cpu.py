@@ -196,10 +196,12 @@ def enum_no(msg, field_name, value_name):
 JOIN_TYPES = ["Inner", "LeftOuter", "RightOuter", "FullOuter", "LeftSemi", "LeftAnti"]
 
 
-def set_struct_field(pb, name, t):
+def set_struct_field(pb, name, t, fid=None):
     pb.name = name
     set_dtype(pb.data_type, t)
     pb.nullable = True
+    if fid is not None:
+        pb.metadata["PARQUET:field_id"] = str(fid)
 
 
 def set_op(pb, op):
@@ -281,16 +283,22 @@ def set_op(pb, op):
         j.SetInParent()
     elif k == "native_scan":
         c = pb.native_scan.common
-        for n, t in zip(op.field_names, op.fields):
-            set_struct_field(c.required_schema.add(), n, t)
-        for n, t in zip(op.field_names, op.fields):
-            set_struct_field(c.data_schema.add(), n, t)
+        ids = list(op.field_ids) + [None] * (len(op.fields) - len(op.field_ids))
+        for n, t, i in zip(op.field_names, op.fields, ids):
+            set_struct_field(c.required_schema.add(), n, t, i)
+        for n, t, i in zip(op.field_names, op.fields, ids):
+            set_struct_field(c.data_schema.add(), n, t, i)
         for n, t in op.partition_fields:
             set_struct_field(c.partition_schema.add(), n, t)
         for e in op.data_filters:
             set_expr(c.data_filters.add(), e)
         c.projection_vector.extend(range(len(op.fields)))
         c.session_timezone = "UTC"
+        for i, v in sorted(op.default_values.items()):
+            set_expr(c.default_values.add(), S.lit(v, op.fields[i]))
+            c.default_values_indexes.append(i)
+        c.use_field_id, c.ignore_missing_field_id = op.use_field_id, op.ignore_missing_field_id
+        c.allow_type_promotion, c.allow_timestamp_ltz_to_ntz = op.allow_type_promotion, op.allow_timestamp_ltz_to_ntz
         c.case_sensitive = op.case_sensitive
         c.source = "parquet"
         for t in op.fields:
@@ -403,6 +411,9 @@ def corpus():
     plans["native_scan"] = S.native_scan([("/data/a.parquet", 0, 100, 100), ("/data/b.parquet", 4, 50, 200)], ["a", "b"], [I64, DEC], case_sensitive=False,
                                          data_filters=[S.gt(S.col(0, I64), S.lit(5, I64))], partition_fields=[("p", I32), ("q", STR)],
                                          partition_values=[(1, "x"), (None, "y")])
+    plans["native_scan_field_ids"] = S.native_scan([("/data/a.parquet", 0, 100, 100)], ["a", "b", "c"], [I64, DEC, STR], field_ids=[7, None, 9], use_field_id=True,
+                                                   ignore_missing_field_id=True, allow_type_promotion=False, allow_timestamp_ltz_to_ntz=False,
+                                                   default_values={1: 12345, 2: "dflt"})
     return plans
 
 
