@@ -1921,10 +1921,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         << "    bool k[R] = {true}; i64 idx[R] = {i}; i64 pos[R] = {p};\n"
         << ge.decls << ge.body() << "  }\n};\n";
     if (d.has_filter) {
-      src << "extern \"C\" __global__ __launch_bounds__(256) void k_mask(const CometKParams prm) { comet::filter_mask_body<P>(prm); }\n";
-      src << "extern \"C\" __global__ __launch_bounds__(256) void k_scan(const CometKParams prm) { comet::tile_scan_body((u64*)prm.out[1], prm.iarg[0]); }\n";
-      src << "extern \"C\" __global__ __launch_bounds__(256) void k_emit(const CometKParams prm) { comet::filter_emit_body<P>(prm); }\n";
-      d.kernels = {"k_mask", "k_scan", "k_emit"};
+      src << "extern \"C\" __global__ __launch_bounds__(256) void k_filter(const CometKParams prm) { comet::filter_fused_body<P>(prm); }\n";
+      d.kernels = {"k_filter"};
     } else {
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_emit(const CometKParams prm) { comet::project_body<P>(prm); }\n";
       d.kernels = {"k_emit"};

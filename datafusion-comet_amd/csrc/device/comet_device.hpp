@@ -947,6 +947,105 @@ CDEV void filter_emit_body(const CometKParams& prm) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel template B' — filter (+project) with ORDER-PRESERVING compaction in ONE pass (decoupled look-back).
+// Every tile (kFuseRows consecutive rows) is claimed through a ticket counter, so a tile's predecessors are always held by blocks
+// that are already running: evaluate the predicate (ballot word per wave and row slot), scan the tile's 32 wave counts in LDS,
+// publish the tile's survivor count in its status word, look back over the predecessors' words (a whole wave reads 64 of them at a
+// time) until one carries an inclusive prefix, publish this tile's inclusive prefix, then the survivors evaluate the projection and
+// store at their dense position.  Every input column is fetched once (the projection's loads of predicate columns hit the cache the
+// predicate just filled); nothing but the outputs is written.  Status word = flag (bits 63..62: 1 aggregate, 2 inclusive prefix) |
+// count; one relaxed agent-scope atomic publishes flag and value together, so no fence is needed (the per-XCD L2s are bypassed
+// for these words only).
+//   prm.out[0] = status words (u64 × ntiles, zeroed);  prm.out[1] = { u32 ticket; u32 pad; u64 total } (zeroed)
+// ---------------------------------------------------------------------------------------------
+constexpr int kFuseR = 8;                              // row slots per thread
+constexpr int kFuseRows = kFuseR * kBlock;             // 2048 rows per tile
+constexpr u64 kTileAgg = 1ull << 62, kTileIncl = 2ull << 62, kTileVal = (1ull << 62) - 1;
+
+template <class P>
+CDEV void filter_fused_body(const CometKParams& prm) {
+  const i64 n = prm.n;
+  u64* status = (u64*)prm.out[0];
+  u32* ticket = (u32*)prm.out[1];
+  u64* total_out = (u64*)prm.out[1] + 1;
+  const i64 ntiles = (n + kFuseRows - 1) / kFuseRows;
+  constexpr int NC = kFuseR * (kBlock / kWave);        // 32 (slot, wave) counts per tile, in row order
+  __shared__ u32 s_cnt[NC];
+  __shared__ u32 s_tile;
+  __shared__ u64 s_excl;
+  const int lane = lane_id(), wv = wave_id();
+  const u64 lt = (1ull << lane) - 1;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const i64 tile = (i64)s_tile;
+    if (tile >= ntiles) break;
+    const i64 base = tile * kFuseRows;
+    u32 bits = 0;
+    u64 below = 0;                                     // 8 bits per slot: survivors in lower lanes of my wave
+#pragma unroll
+    for (int r = 0; r < kFuseR; r++) {
+      const i64 i = base + r * kBlock + threadIdx.x;
+      const bool k = (i < n) && P::keep(prm, i);
+      const u64 b = __ballot(k);
+      if (lane == 0) s_cnt[r * (kBlock / kWave) + wv] = (u32)__popcll(b);
+      below |= (u64)__popcll(b & lt) << (8 * r);
+      bits |= (k ? 1u : 0u) << r;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      u32 c = lane < NC ? s_cnt[lane] : 0u;
+      u32 x = c;                                       // inclusive scan across the first 32 lanes
+#pragma unroll
+      for (int d = 1; d < NC; d <<= 1) {
+        u32 y = __shfl_up(x, d, kWave);
+        if (lane >= d) x += y;
+      }
+      if (lane < NC) s_cnt[lane] = x - c;
+      const u64 tile_total = (u64)__shfl(x, NC - 1, kWave);
+      u64 excl = 0;
+      if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(&status[0], kTileIncl | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (lane == 0) __hip_atomic_store(&status[tile], kTileAgg | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i64 look = tile - 1;                           // lane l inspects tile look - l
+        for (;;) {
+          const i64 t = look - lane;
+          u64 st;
+          do {
+            st = t >= 0 ? __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kTileIncl;   // before tile 0: prefix 0
+          } while (__ballot((st >> 62) == 0) != 0);    // a predecessor has not published yet: it is running, poll again
+          const u64 incl = __ballot((st >> 62) == 2);
+          const int first = incl ? __ffsll((unsigned long long)incl) - 1 : kWave;   // nearest tile carrying an inclusive prefix
+          u64 v = lane <= first ? (st & kTileVal) : 0ull;
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+          excl += v;
+          if (incl) break;
+          look -= kWave;
+        }
+        if (lane == 0) __hip_atomic_store(&status[tile], kTileIncl | (excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        s_excl = excl;
+        if (tile == ntiles - 1) *total_out = excl + tile_total;
+      }
+    }
+    __syncthreads();
+    const u64 tile_off = s_excl;
+#pragma unroll
+    for (int r = 0; r < kFuseR; r++) {
+      if ((bits >> r) & 1u) {
+        const i64 i = base + r * kBlock + threadIdx.x;
+        const i64 pos = (i64)(tile_off + s_cnt[r * (kBlock / kWave) + wv] + ((below >> (8 * r)) & 0xff));
+        P::emit(prm, i, pos);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Pure projection (no filter): dense, position = row.
 template <class P>
 CDEV void project_body(const CometKParams& prm) {

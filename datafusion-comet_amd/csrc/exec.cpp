@@ -1031,7 +1031,6 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     for (auto& oc : d.out_cols)
       if (oc.gather_src >= 0) throw CometError("internal: gathered Utf8 outputs must go through the materialising path");
     const size_t ncol = d.out_cols.size();
-    const int64_t ntiles = (n + 1023) / 1024;
     int64_t out_rows = n;
     if (out_vals_.size() < ncol) {
       out_vals_.resize(ncol);
@@ -1054,21 +1053,9 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     };
     timed_begin();
     if (d.has_filter) {
-      scratch_mask_.ensure((size_t)((n + 63) / 64) * 8 + 64);
-      scratch_counts_.ensure((size_t)(ntiles + 1) * 8);
-      prm.out[0] = scratch_mask_.p;
-      prm.out[1] = scratch_counts_.p;
-      int grid = (int)std::min<int64_t>(ntiles, 256 * 8);
-      launch(v, "k_mask", grid, prm);
-      prm.iarg[0] = ntiles;
-      launch(v, "k_scan", 1, prm);
-      uint64_t total = 0;
-      read_small(&total, (char*)scratch_counts_.p + (size_t)ntiles * 8, 8);
-      out_rows = (int64_t)total;
-      if (out_rows > 0) {
-        bind_outputs(out_rows);
-        launch(v, "k_emit", grid, prm);
-      }
+      // one pass: the survivor count is only known afterwards, so the outputs are sized for the whole chunk
+      bind_outputs(n);
+      out_rows = launch_fused_filter(v, prm, n);
     } else {
       bind_outputs(n);
       int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
@@ -1933,6 +1920,22 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
   return t;
 }
 
+// Single-pass filter + compaction (comet_device.hpp filter_fused_body): tile status words and the ticket / total block are zeroed,
+// one launch, then the survivor count comes back.  Outputs must already be bound with room for n rows.
+int64_t ExecutionContext::launch_fused_filter(Variant& v, CometKParams& prm, int64_t n) {
+  const int64_t ntiles = (n + 2047) / 2048;
+  scratch_mask_.ensure((size_t)ntiles * 8 + 64);
+  scratch_counts_.ensure(64);
+  HIP_CHECK(hipMemsetAsync(scratch_mask_.p, 0, (size_t)ntiles * 8, stream_));
+  HIP_CHECK(hipMemsetAsync(scratch_counts_.p, 0, 16, stream_));
+  prm.out[0] = scratch_mask_.p;
+  prm.out[1] = scratch_counts_.p;
+  launch(v, "k_filter", (int)std::min<int64_t>(ntiles, 256 * 8), prm);
+  uint64_t total = 0;
+  read_small(&total, (char*)scratch_counts_.p + 8, 8);
+  return (int64_t)total;
+}
+
 // Filter/Project chain `top` over the resident table `in` → resident table
 DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTable& in) {
   auto pv = planned_variant(top, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&top] + 1)), in.has_valid, true, &in.types);
@@ -1972,20 +1975,8 @@ DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTab
     bind(1);
     out_rows = 0;
   } else if (d.has_filter) {
-    const int64_t ntiles = (n + 1023) / 1024;
-    scratch_mask_.ensure((size_t)((n + 63) / 64) * 8 + 64);
-    scratch_counts_.ensure((size_t)(ntiles + 1) * 8);
-    prm.out[0] = scratch_mask_.p;
-    prm.out[1] = scratch_counts_.p;
-    int grid = (int)std::min<int64_t>(ntiles, 256 * 8);
-    launch(v, "k_mask", grid, prm);
-    prm.iarg[0] = ntiles;
-    launch(v, "k_scan", 1, prm);
-    uint64_t total = 0;
-    read_small(&total, (char*)scratch_counts_.p + (size_t)ntiles * 8, 8);
-    out_rows = (int64_t)total;
-    bind(std::max<int64_t>(out_rows, 1));
-    if (out_rows > 0) launch(v, "k_emit", grid, prm);
+    bind(n);
+    out_rows = launch_fused_filter(v, prm, n);
   } else {
     bind(n);
     launch(v, "k_emit", (int)std::min<int64_t>((n + 255) / 256, 256 * 8), prm);

@@ -130,6 +130,7 @@ class ExecutionContext {
   std::vector<DType> infer_schema(const Operator& op);
   DevTable materialize(const Operator& op);
   DevTable scan_parquet(const Operator& native_scan);
+  int64_t launch_fused_filter(Variant& v, CometKParams& prm, int64_t n);
   DevTable run_chain_to_device(const Operator& top, const DevTable& in);
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
   DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix);
