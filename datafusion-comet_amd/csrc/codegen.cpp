@@ -1912,24 +1912,31 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       }
     }
     for (size_t i = 0; i < d.in_types.size(); i++) d.in_used.push_back(g.in_used[i] || ge.in_used[i]);
-    src << "struct P {\n  static constexpr int R = 1;\n";
-    // keep(): single row, stages degenerate to nested ifs via k[0]
-    src << "  static __device__ __forceinline__ bool keep(const CometKParams& prm, i64 i) {\n"
-        << "    bool k[R] = {true}; i64 idx[R] = {i};\n"
-        << g.decls << g.body() << "    return k[0];\n  }\n";
-    src << "  static __device__ __forceinline__ void emit(const CometKParams& prm, i64 i, i64 p) {\n"
-        << "    bool k[R] = {true}; i64 idx[R] = {i}; i64 pos[R] = {p};\n"
-        << ge.decls << ge.body() << "  }\n};\n";
     if (d.has_filter) {
+      // tile-wise functors for the single-pass filter kernel: R row slots per thread; every stage first issues the loads of all R
+      // rows, then computes / stores, so a thread keeps R × (columns) loads in flight instead of one row's
+      int fr = 8;
+      if (const char* e = getenv("COMET_EXPERIMENT")) fr = std::max(1, std::min(16, atoi(e)));
+      d.R = fr;
+      src << "struct P {\n  static constexpr int R = " << fr << ";\n";
+      src << "  static __device__ __forceinline__ void keep_tile(const CometKParams& prm, i64 base, i64 n, bool* k) {\n"
+          << "    i64 idx[R];\n    _Pragma(\"unroll\") for (int r = 0; r < R; r++) { idx[r] = base + (i64)r * comet::kBlock + threadIdx.x; k[r] = idx[r] < n; }\n"
+          << g.decls << g.body() << "  }\n";
+      src << "  static __device__ __forceinline__ void emit_tile(const CometKParams& prm, const bool* k, const i64* idx, const i64* pos) {\n"
+          << ge.decls << ge.body() << "  }\n};\n";
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_filter(const CometKParams prm) { comet::filter_fused_body<P>(prm); }\n";
       d.kernels = {"k_filter"};
     } else {
+      d.R = 1;
+      src << "struct P {\n  static constexpr int R = 1;\n";
+      src << "  static __device__ __forceinline__ void emit(const CometKParams& prm, i64 i, i64 p) {\n"
+          << "    bool k[R] = {true}; i64 idx[R] = {i}; i64 pos[R] = {p};\n"
+          << ge.decls << ge.body() << "  }\n};\n";
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_emit(const CometKParams prm) { comet::project_body<P>(prm); }\n";
       d.kernels = {"k_emit"};
     }
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
     d.kernels.push_back("k_pack");
-    d.R = 1;
     d.source = src.str();
     d.explain = ex.str();
     return d;

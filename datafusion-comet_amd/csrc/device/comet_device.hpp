@@ -949,7 +949,7 @@ CDEV void filter_emit_body(const CometKParams& prm) {
 
 // ---------------------------------------------------------------------------------------------
 // Kernel template B' — filter (+project) with ORDER-PRESERVING compaction in ONE pass (decoupled look-back).
-// Every tile (kFuseRows consecutive rows) is claimed through a ticket counter, so a tile's predecessors are always held by blocks
+// Every tile (P::R·256 consecutive rows) is claimed through a ticket counter, so a tile's predecessors are always held by blocks
 // that are already running: evaluate the predicate (ballot word per wave and row slot), scan the tile's 32 wave counts in LDS,
 // publish the tile's survivor count in its status word, look back over the predecessors' words (a whole wave reads 64 of them at a
 // time) until one carries an inclusive prefix, publish this tile's inclusive prefix, then the survivors evaluate the projection and
@@ -959,18 +959,22 @@ CDEV void filter_emit_body(const CometKParams& prm) {
 // for these words only).
 //   prm.out[0] = status words (u64 × ntiles, zeroed);  prm.out[1] = { u32 ticket; u32 pad; u64 total } (zeroed)
 // ---------------------------------------------------------------------------------------------
-constexpr int kFuseR = 8;                              // row slots per thread
-constexpr int kFuseRows = kFuseR * kBlock;             // 2048 rows per tile
 constexpr u64 kTileAgg = 1ull << 62, kTileIncl = 2ull << 62, kTileVal = (1ull << 62) - 1;
 
+//   P::R                                   row slots per thread (tile = R·256 consecutive rows; slot r of thread t is row base + r·256 + t)
+//   P::keep_tile(prm, base, n, k[R])       k[r] = the predicate is TRUE and valid for slot r (staged: later conjuncts load only for survivors)
+//   P::emit_tile(prm, k[R], idx[R], pos[R]) evaluate the outputs of the surviving slots and store them at pos[r]
 template <class P>
 CDEV void filter_fused_body(const CometKParams& prm) {
+  constexpr int R = P::R;
+  static_assert(R <= 16, "one wave scans the R·4 (slot, wave) counts of a tile");
+  constexpr i64 kRows = (i64)R * kBlock;
   const i64 n = prm.n;
   u64* status = (u64*)prm.out[0];
   u32* ticket = (u32*)prm.out[1];
   u64* total_out = (u64*)prm.out[1] + 1;
-  const i64 ntiles = (n + kFuseRows - 1) / kFuseRows;
-  constexpr int NC = kFuseR * (kBlock / kWave);        // 32 (slot, wave) counts per tile, in row order
+  const i64 ntiles = (n + kRows - 1) / kRows;
+  constexpr int NC = R * (kBlock / kWave);             // (slot, wave) counts per tile, in row order (≤ 32)
   __shared__ u32 s_cnt[NC];
   __shared__ u32 s_tile;
   __shared__ u64 s_excl;
@@ -981,22 +985,20 @@ CDEV void filter_fused_body(const CometKParams& prm) {
     __syncthreads();
     const i64 tile = (i64)s_tile;
     if (tile >= ntiles) break;
-    const i64 base = tile * kFuseRows;
-    u32 bits = 0;
-    u64 below = 0;                                     // 8 bits per slot: survivors in lower lanes of my wave
+    const i64 base = tile * kRows;
+    bool k[R];
+    P::keep_tile(prm, base, n, k);
+    u32 below[(R + 3) / 4] = {};                       // 8 bits per slot: survivors in lower lanes of my wave
 #pragma unroll
-    for (int r = 0; r < kFuseR; r++) {
-      const i64 i = base + r * kBlock + threadIdx.x;
-      const bool k = (i < n) && P::keep(prm, i);
-      const u64 b = __ballot(k);
+    for (int r = 0; r < R; r++) {
+      const u64 b = __ballot(k[r]);
       if (lane == 0) s_cnt[r * (kBlock / kWave) + wv] = (u32)__popcll(b);
-      below |= (u64)__popcll(b & lt) << (8 * r);
-      bits |= (k ? 1u : 0u) << r;
+      below[r >> 2] |= (u32)__popcll(b & lt) << (8 * (r & 3));
     }
     __syncthreads();
     if (wv == 0) {
       u32 c = lane < NC ? s_cnt[lane] : 0u;
-      u32 x = c;                                       // inclusive scan across the first 32 lanes
+      u32 x = c;                                       // inclusive scan across the first NC lanes
 #pragma unroll
       for (int d = 1; d < NC; d <<= 1) {
         u32 y = __shfl_up(x, d, kWave);
@@ -1034,14 +1036,13 @@ CDEV void filter_fused_body(const CometKParams& prm) {
     }
     __syncthreads();
     const u64 tile_off = s_excl;
+    i64 idx[R], pos[R];
 #pragma unroll
-    for (int r = 0; r < kFuseR; r++) {
-      if ((bits >> r) & 1u) {
-        const i64 i = base + r * kBlock + threadIdx.x;
-        const i64 pos = (i64)(tile_off + s_cnt[r * (kBlock / kWave) + wv] + ((below >> (8 * r)) & 0xff));
-        P::emit(prm, i, pos);
-      }
+    for (int r = 0; r < R; r++) {
+      idx[r] = base + (i64)r * kBlock + threadIdx.x;
+      pos[r] = (i64)(tile_off + s_cnt[r * (kBlock / kWave) + wv] + ((below[r >> 2] >> (8 * (r & 3))) & 0xff));
     }
+    P::emit_tile(prm, k, idx, pos);
     __syncthreads();
   }
 }

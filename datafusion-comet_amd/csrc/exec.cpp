@@ -1923,7 +1923,8 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
 // Single-pass filter + compaction (comet_device.hpp filter_fused_body): tile status words and the ticket / total block are zeroed,
 // one launch, then the survivor count comes back.  Outputs must already be bound with room for n rows.
 int64_t ExecutionContext::launch_fused_filter(Variant& v, CometKParams& prm, int64_t n) {
-  const int64_t ntiles = (n + 2047) / 2048;
+  const int64_t tile_rows = 256 * (int64_t)v.desc.R;   // P::R row slots per thread
+  const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
   scratch_mask_.ensure((size_t)ntiles * 8 + 64);
   scratch_counts_.ensure(64);
   HIP_CHECK(hipMemsetAsync(scratch_mask_.p, 0, (size_t)ntiles * 8, stream_));
