@@ -1568,6 +1568,74 @@ struct AggLowering {
 
   AggLowering(Gen& gen, bool grp) : g(gen), grouped(grp) {}
 
+  // ---- exact Float64 sum: 192-bit fixed-point sum + class word per group; exponent range per kernel ----
+  struct FSum { int word; int cls; int fidx; };
+  std::map<std::string, FSum> fsums;
+  std::vector<PipelineDesc::FixSum> fix_sums;
+  std::string kexport_code;   // ungrouped: thread 0 of each block publishes the exponent words with atomic max
+  static std::string fscale(int fidx) { return "comet::fix_scale(prm.iarg[" + std::to_string(kFixScaleArg) + "], " + std::to_string(fidx) + ")"; }
+  std::string fread(const FSum& f) const {
+    return "comet::fix192_to_f64(acc + " + std::to_string(f.word) + ", " + fscale(f.fidx) + ", acc[" + std::to_string(f.cls) + "])";
+  }
+  FSum get_fsum(const std::string& vkey, const std::string& fkey, const std::string& cond, const std::string& x) {
+    const std::string key = "fsum|" + vkey + "|" + fkey;
+    auto it = fsums.find(key);
+    if (it != fsums.end()) return it->second;
+    if ((int)fix_sums.size() >= kFixMaxSums) throw CometError("more than " + std::to_string(kFixMaxSums) + " distinct Float64 sums / averages in one aggregate are not supported by the GPU pipeline yet");
+    const int fidx = (int)fix_sums.size();
+    const std::string c = cond.empty() ? "true" : cond;
+    const std::string xd = "(double)(" + x + ")", S = fscale(fidx);
+    FSum f;
+    f.fidx = fidx;
+    f.word = nw;
+    nw += 3;
+    f.cls = nw;
+    nw += 1;
+    const std::string w = std::to_string(f.word), w1 = std::to_string(f.word + 1), w2 = std::to_string(f.word + 2), cw = std::to_string(f.cls);
+    init_code += "    a[" + w + "] = 0; a[" + w1 + "] = 0; a[" + w2 + "] = 0; a[" + cw + "] = 0;\n";
+    combine_code += "    comet::acc_add192(a + " + w + ", b + " + w + "); comet::acc_or64(a + " + cw + ", b + " + cw + ");\n";
+    for (auto* q : {"G_ADD192", "G_CONT", "G_CONT", "G_OR64"}) gops.push_back(q);
+    for (int k = 0; k < 4; k++) gident.push_back("0ull");
+    PipelineDesc::FixSum fs;
+    fs.word = f.word;
+    if (grouped) {
+      int j0 = -1;
+      for (int t = 0; t < 4; t++) {
+        int j = pword("G_ADD64", "0ull");
+        if (t == 0) j0 = j;
+        pv_code += "        pv[" + std::to_string(j) + "] = (" + c + ") ? comet::f64_fix_limb(" + xd + ", " + S + ", " + std::to_string(t) + ") : 0ull;\n";
+      }
+      int jc = pword("G_OR64", "0ull");
+      pv_code += "        pv[" + std::to_string(jc) + "] = (" + c + ") ? comet::f64_class(" + xd + ") : 0ull;\n";
+      fold_code += "    { u64 t3_[3]; comet::limbs_to_i192(pw + " + std::to_string(j0) + ", 4, t3_); val[" + w + "] = t3_[0]; val[" + w1 + "] = t3_[1]; val[" + w2 +
+                   "] = t3_[2]; val[" + cw + "] = pw[" + std::to_string(jc) + "]; }\n";
+      fs.aux_hi = nkw++;
+      fs.aux_lo = nkw++;
+      kops.push_back("G_UMAX64");
+      kops.push_back("G_UMAX64");
+      kfeed_code += "        if (" + c + ") { u64 h_ = comet::f64_exp_hi(" + xd + "), l_ = comet::f64_exp_lo(" + xd + "); if (h_ > kacc[" + std::to_string(fs.aux_hi) +
+                    "]) kacc[" + std::to_string(fs.aux_hi) + "] = h_; if (l_ > kacc[" + std::to_string(fs.aux_lo) + "]) kacc[" + std::to_string(fs.aux_lo) + "] = l_; }\n";
+    } else {
+      const int hw = nw, lw = nw + 1;
+      nw += 2;
+      const std::string H = std::to_string(hw), L = std::to_string(lw);
+      init_code += "    a[" + H + "] = 0; a[" + L + "] = 0;\n";
+      combine_code += "    if (b[" + H + "] > a[" + H + "]) a[" + H + "] = b[" + H + "]; if (b[" + L + "] > a[" + L + "]) a[" + L + "] = b[" + L + "];\n";
+      gops.push_back("G_UMAX64"); gops.push_back("G_UMAX64");
+      gident.push_back("0ull"); gident.push_back("0ull");
+      const std::string body = "{ const double xd_ = " + xd + "; comet::acc_feed_fix192(acc + " + w + ", xd_, " + S + "); acc[" + cw + "] |= comet::f64_class(xd_); " +
+                               "const u64 h_ = comet::f64_exp_hi(xd_), l_ = comet::f64_exp_lo(xd_); if (h_ > acc[" + H + "]) acc[" + H + "] = h_; if (l_ > acc[" + L + "]) acc[" + L + "] = l_; }";
+      g.stmt(cond.empty() ? body : "if (" + cond + ") " + body);
+      fs.aux_hi = 2 * fidx;
+      fs.aux_lo = 2 * fidx + 1;
+      kexport_code += "    atomicMax(aux + " + std::to_string(fs.aux_hi) + ", (unsigned long long)acc[" + H + "]); atomicMax(aux + " + std::to_string(fs.aux_lo) +
+                      ", (unsigned long long)acc[" + L + "]);\n";
+    }
+    fix_sums.push_back(fs);
+    fsums[key] = f;
+    return f;
+  }
+
   int pword(const char* op, const char* ident) {
     pops.push_back(op);
     pident.push_back(ident);
@@ -2189,13 +2257,13 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             if (sv.rep != Rep::F64) throw CometError("Final float aggregate expects a Float64 state column");
             const std::string vk = "fin:" + g.key_of(in.children[0]);
             PrimSlot nsum = al.get(Prim::Cnt, vk, "", sv.ok, "");
-            PrimSlot sum = al.get(Prim::SumF64, vk, "", sv.ok, sv.v);
-            const std::string S = std::to_string(sum.word);
+            const AggLowering::FSum fsum = al.get_fsum(vk, "", sv.ok, sv.v);
+            const std::string SUMX = al.fread(fsum);
             if (is_avg && emit_state) {
               // AvgAccumulator / AvgGroupsAccumulator state after merge (avg.rs:139-176): (sum, count)
               Val s2 = g.named(g.gen(in.children.at(1)));
               PrimSlot cnt = al.get(Prim::SumI64, vk + "#cnt", "", s2.ok, s2.v, (u128)1 << 63);
-              fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = __longlong_as_double((i64)acc[" + S + "]);\n";
+              fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = " + SUMX + ";\n";
               fin += std::string("    ((u8*)") + out_ok(out_j) + ")" + ROW + " = " + (grouped ? "1" : "acc[" + std::to_string(nsum.word) + "] ? 1 : 0") + ";\n";
               fin += "    ((i64*)" + out_val(out_j + 1) + ")" + ROW + " = (i64)acc[" + std::to_string(cnt.word) + "];\n";
               fin += "    ((u8*)" + out_ok(out_j + 1) + ")" + ROW + " = 1;\n";
@@ -2211,10 +2279,10 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
               Val s2 = g.named(g.gen(in.children.at(1)));
               PrimSlot cnt = al.get(Prim::SumI64, vk + "#cnt", "", s2.ok, s2.v, (u128)1 << 63);
               fin += "    { i64 count = (i64)acc[" + std::to_string(cnt.word) + "];\n";
-              fin += "      ((double*)" + out_val(out_j) + ")" + ROW + " = count ? comet::fp_div(__longlong_as_double((i64)acc[" + S + "]), (double)count) : 0.0;\n";
+              fin += "      ((double*)" + out_val(out_j) + ")" + ROW + " = count ? comet::fp_div(" + SUMX + ", (double)count) : 0.0;\n";
               fin += "      ((u8*)" + out_ok(out_j) + ")" + ROW + " = count ? 1 : 0; }\n";
             } else {
-              fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = __longlong_as_double((i64)acc[" + S + "]);\n";
+              fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = " + SUMX + ";\n";
               fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + std::to_string(nsum.word) + "] ? 1 : 0;\n";
             }
             OutCol oc; oc.type = DType::of(TypeId::Double); oc.nullable = true;
@@ -2366,11 +2434,11 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
           if (!(v.rep == Rep::F64 || v.rep == Rep::F32 || v.rep == Rep::I32 || v.rep == Rep::I64))
             throw CometError("float sum/avg over " + v.t.str() + " is not supported in the GPU pipeline yet");
           PrimSlot cnt = al.get(Prim::Cnt, vkey, fkey, cond, "");
-          PrimSlot sum = al.get(Prim::SumF64, "f64:" + vkey, fkey, cond, v.v);
-          std::string S = std::to_string(sum.word), C = std::to_string(cnt.word);
+          const AggLowering::FSum fsum = al.get_fsum("f64:" + vkey, fkey, cond, v.v);
+          const std::string SUMX = al.fread(fsum), C = std::to_string(cnt.word);
           if (is_avg) {
             // AvgAccumulator::state (avg.rs:139-144): ungrouped sum is Some once any batch arrived; grouped never NULL
-            fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = __longlong_as_double((i64)acc[" + S + "]);\n";
+            fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = " + SUMX + ";\n";
             fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = " + (grouped ? std::string("1") : "acc[" + rowcnt_word + "] ? 1 : 0") + ";\n";
             fin += "    ((i64*)" + out_val(out_j + 1) + ")" + ROW + " = (i64)acc[" + C + "];\n";
             fin += "    ((u8*)" + out_ok(out_j + 1) + ")" + ROW + " = 1;\n";
@@ -2381,7 +2449,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             out_j += 2;
             ex << "  agg: avg_f64 -> (Float64, count)\n";
           } else {
-            fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = __longlong_as_double((i64)acc[" + S + "]);\n";
+            fin += "    ((double*)" + out_val(out_j) + ")" + ROW + " = " + SUMX + ";\n";
             fin += "    ((u8*)" + out_ok(out_j) + ")" + ROW + " = acc[" + C + "] ? 1 : 0;\n";
             OutCol s0; s0.type = DType::of(TypeId::Double); s0.nullable = true;
             d.out_cols.push_back(s0);
@@ -2429,6 +2497,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
   if (d.out_cols.size() * 2 + kOutFirstCol > COMET_MAX_OUT) throw CometError("too many aggregate state columns for one GPU pipeline");
   d.NW = al.nw;
+  d.fix_sums = al.fix_sums;
   d.NK = nk;
   d.R = grouped ? 2 : 4;
   if (const char* e = getenv("COMET_GEN_R")) d.R = std::max(1, std::min(8, atoi(e)));
@@ -2448,6 +2517,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     } else {
       src << "  static __device__ __forceinline__ void tile(const CometKParams& prm, i64 base, i64 n, u64* acc) {\n" << rowinit << g.decls << g.body() << "  }\n";
     }
+    src << "  static __device__ __forceinline__ void kexport(const CometKParams& prm, const u64* acc) {\n"
+        << "    unsigned long long* aux = (unsigned long long*)prm.out[" << kOutErr << "] + 2; (void)aux;\n" << al.kexport_code << "  }\n";
     src << "  static __device__ __forceinline__ void finalize(const CometKParams& prm, const u64* acc) {\n" << fin << "  }\n};\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg(const CometKParams prm) { comet::agg_nogroup_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_agg_final(const CometKParams prm) { comet::agg_nogroup_final_body<P>(prm); }\n";

@@ -50,7 +50,16 @@ struct PipelineDesc {
   // grouped aggregates: source columns that serve DIRECTLY as Utf8 group keys (the executor measures their longest value: above 15
   // bytes the key travels as a representative row index instead of packed bytes, see dict_id_col)
   std::vector<int> str_key_cols;
+  // exact Float64 sums (comet_device.hpp "Exact Float64 sums"): per sum f its first canonical accumulator word (3 words, 192-bit fixed
+  // point) and the aux words (u64 index after the 16-byte error header) that collect the exponent range seen; the scales travel packed
+  // 16 bits each in prm.iarg[kFixScaleArg]
+  struct FixSum { int word = 0; int aux_hi = 0, aux_lo = 0; };
+  std::vector<FixSum> fix_sums;
 };
+constexpr int kFixScaleArg = 6;
+constexpr int kFixMaxSums = 4;
+constexpr int kFixW = 158;            // must equal comet::kFixW
+constexpr int kFixDefaultScale = -94; // window [2^-94, 2^64): doubles from 2^-42 to 2^64 with every mantissa bit, without a re-run
 
 // `in_has_validity[i]` tells whether input column i arrives with a validity bitmap in this batch
 // chunk; kernels are specialised on it.  Throws CometError for unsupported plans.

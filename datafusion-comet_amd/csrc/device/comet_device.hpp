@@ -695,6 +695,106 @@ CDEV void acc_fmax64(u64* a, const u64* b) {
   if (f64_total_key(__longlong_as_double((i64)b[0])) > f64_total_key(__longlong_as_double((i64)a[0]))) a[0] = b[0];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact Float64 sums.  The reference adds doubles one after the other in row order (agg_funcs/avg.rs:239-280, DataFusion's sum), so
+// its result depends on batch and partition boundaries; a parallel sum cannot reproduce one particular order.  Instead every value is
+// converted to FIXED POINT — an integer multiple of 2^s — and summed with the integer machinery (192-bit accumulators, the 43-bit limbs
+// of the grouped path): integer addition is associative, so the result is the same for every grid size and every order, and it is the
+// EXACT real sum whenever all addends lie in the window  2^s ≤ lowest set bit,  |x| < 2^(s + kFixW).  The final state is that exact sum
+// rounded once to nearest-even, i.e. within half an ULP of the true sum — which is what any ordering of the reference's additions
+// approximates within its own (n−1)·ε·Σ|x| error.  The executor picks s per sum from the exponents it observes (tracked below) and
+// re-runs a chunk whose values did not fit; addends whose low bits fall below 2^s are truncated toward zero (only when one sum spans
+// more than kFixW − 53 = 105 binary orders of magnitude), which bounds the error by rows · 2^s.
+// ±inf and NaN do not enter the fixed-point sum; a class word remembers them and the result follows IEEE (inf − inf = NaN).
+// ---------------------------------------------------------------------------------------------
+constexpr int kFixW = 158;      // 158 value bits + 33 bits of row-count headroom + sign = 192
+CDEV int fix_scale(i64 packed, int f) { return (int)(i16)(u16)((u64)packed >> (16 * f)); }
+// finite non-zero x = ±m · 2^q with 0 < m < 2^53
+CDEV bool f64_parts(double x, u64& m, int& q) {
+  const u64 b = (u64)__double_as_longlong(x);
+  const int be = (int)((b >> 52) & 0x7ff);
+  const u64 frac = b & ((1ull << 52) - 1);
+  if (be == 0x7ff) return false;
+  if (be == 0) { m = frac; q = -1074; } else { m = frac | (1ull << 52); q = be - 1075; }
+  return m != 0;
+}
+CDEV u64 f64_class(double x) {            // 1 = +inf, 2 = −inf, 4 = NaN
+  const u64 b = (u64)__double_as_longlong(x);
+  if (((b >> 52) & 0x7ff) != 0x7ff) return 0;
+  if (b & ((1ull << 52) - 1)) return 4;
+  return (b >> 63) ? 2 : 1;
+}
+// exponent tracking words, both monotone under an unsigned max (0 = no finite non-zero value yet):
+//   hi = 1200 + top  where |x| < 2^top;   lo = 1200 − low  where 2^low is x's lowest set bit
+CDEV u64 f64_exp_hi(double x) { u64 m; int q; return f64_parts(x, m, q) ? (u64)(1200 + q + 64 - __builtin_clzll(m)) : 0ull; }
+CDEV u64 f64_exp_lo(double x) { u64 m; int q; return f64_parts(x, m, q) ? (u64)(1200 - (q + __builtin_ctzll(m))) : 0ull; }
+// limb j (kLimbBits = 43 bits, carrying x's sign) of trunc(x / 2^s)
+CDEV u64 f64_fix_limb(double x, int s, int j) {
+  u64 m; int q;
+  if (!f64_parts(x, m, q)) return 0;
+  const int sh = q - s - 43 * j;
+  u64 v;
+  if (sh >= 43 || sh <= -53) v = 0;
+  else if (sh >= 0) v = (m << sh) & ((1ull << 43) - 1);
+  else v = (m >> -sh) & ((1ull << 43) - 1);
+  return x < 0 ? (u64)(-(i64)v) : v;
+}
+// acc (192-bit two's complement) += trunc(x / 2^s)
+CDEV void acc_feed_fix192(u64* a, double x, int s) {
+  u64 m; int q;
+  if (!f64_parts(x, m, q)) return;
+  u64 t[3] = {0, 0, 0};
+  const int sh = q - s;
+  if (sh < 0) {
+    if (sh > -53) t[0] = m >> -sh;
+  } else {
+    const int ws = sh >> 6, bs = sh & 63;
+    if (ws < 3) t[ws] = m << bs;
+    if (bs && ws + 1 < 3) t[ws + 1] = m >> (64 - bs);
+  }
+  if (x < 0) {
+    t[0] = ~t[0]; t[1] = ~t[1]; t[2] = ~t[2];
+    if (++t[0] == 0) { if (++t[1] == 0) ++t[2]; }
+  }
+  acc_add192(a, t);
+}
+// the accumulated integer t (192-bit) · 2^s → nearest double (ties to even), with the IEEE outcome of any inf / NaN addends
+CDEV double fix192_to_f64(const u64* t, int s, u64 cls) {
+  if ((cls & 4) || ((cls & 1) && (cls & 2))) return __longlong_as_double(0x7ff8000000000000ll);
+  if (cls & 1) return __longlong_as_double(0x7ff0000000000000ll);
+  if (cls & 2) return __longlong_as_double((i64)0xfff0000000000000ull);
+  u64 w0 = t[0], w1 = t[1], w2 = t[2];
+  const bool neg = (w2 >> 63) != 0;
+  if (neg) {
+    w0 = ~w0; w1 = ~w1; w2 = ~w2;
+    if (++w0 == 0) { if (++w1 == 0) ++w2; }
+  }
+  const int L = w2 ? 192 - __builtin_clzll(w2) : (w1 ? 128 - __builtin_clzll(w1) : (w0 ? 64 - __builtin_clzll(w0) : 0));
+  if (L == 0) return 0.0;
+  int e_lsb = s + L - 53;                 // weight of the result's last mantissa bit …
+  if (e_lsb < -1074) e_lsb = -1074;       // … but never below the subnormal grid
+  const int shift = e_lsb - s;
+  u64 mant;
+  if (shift <= 0) {
+    mant = w0;                            // the whole integer fits the mantissa: exact
+    e_lsb = s;
+  } else {
+    // mant = t >> shift, rounded to nearest even on the dropped bits
+    const int ws = shift >> 6, bs = shift & 63;
+    const u64 w[4] = {w0, w1, w2, 0};
+    mant = w[ws] >> bs;
+    if (bs) mant |= w[ws + 1] << (64 - bs);
+    const int gb = shift - 1;             // guard bit
+    const bool guard = (w[gb >> 6] >> (gb & 63)) & 1;
+    bool sticky = false;
+    for (int k = 0; k < (gb >> 6); k++) sticky |= w[k] != 0;
+    sticky |= (w[gb >> 6] & ((1ull << (gb & 63)) - 1)) != 0;
+    if (guard && (sticky || (mant & 1))) mant += 1;
+  }
+  const double r = ldexp((double)mant, e_lsb);   // mant ≤ 2^53: exact conversion, one exact scaling (or overflow to inf)
+  return neg ? -r : r;
+}
+
 // SumDecimal overflow is prefix-order dependent in the reference (sum_decimal.rs:417-438: once a running
 // sum leaves the precision it stays NULL).  A parallel reduction only sees totals, so decide exactness
 // from order-independent facts:
@@ -804,6 +904,7 @@ CDEV void agg_nogroup_body(const CometKParams& prm) {
     u64* dst = (u64*)prm.out[0] + (i64)blockIdx.x * P::NW;
 #pragma unroll
     for (int k = 0; k < P::NW; k++) dst[k] = acc[k];
+    P::kexport(prm, acc);   // exponent range of exact float sums → aux words (the executor sizes the fixed-point window from them)
   }
 }
 

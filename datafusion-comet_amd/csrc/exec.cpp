@@ -217,6 +217,7 @@ extern "C" int comet_launch_sort_plane_varies(const uint8_t* planes, int64_t n, 
 extern "C" int comet_launch_sort_hist256(const uint8_t* plane, const uint32_t* cand, int64_t m, uint64_t* hist, void* stream);
 extern "C" int comet_launch_sort_select(const uint8_t* plane, const uint32_t* cand, int64_t m, int dstar, uint32_t* sure, uint32_t* next_cand, uint32_t* counters,
                                         void* stream);
+extern "C" int comet_launch_fix_rescale(uint64_t* base, int64_t count, int64_t stride_words, int32_t word_off, int32_t shift, void* stream);
 extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream);
 
 namespace {
@@ -958,9 +959,23 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       std::swap(partials_.cap, bigger.cap);
     }
     prm.out[kOutPartials] = (char*)partials_.p + (size_t)n_partials_ * d.NW * 8;
-    timed_begin();
-    launch(v, "k_agg", grid, prm);
-    timed_end();
+    for (int attempt = 0;; attempt++) {
+      prm.iarg[kFixScaleArg] = packed_fix_scales(d);
+      timed_begin();
+      launch(v, "k_agg", grid, prm);
+      timed_end();
+      if (d.fix_sums.empty()) break;
+      uint64_t aux[2 + 2 * kFixMaxSums];
+      read_small(aux, err_flags_.p, sizeof aux);
+      std::vector<int> shift;
+      if (attempt >= 3 || !adjust_fix_scales(d, aux + 2, shift)) break;
+      // the window moved: earlier chunks' partials follow it, this chunk's partials are simply overwritten by the re-run
+      for (size_t f = 0; f < shift.size(); f++)
+        if (shift[f] > 0 && n_partials_ > 0 &&
+            comet_launch_fix_rescale((uint64_t*)partials_.p, n_partials_, d.NW, d.fix_sums[f].word, shift[f], stream_) != 0)
+          throw CometError("float sum rescale: launch failed");
+    }
+    fix_has_state_ = fix_has_state_ || !d.fix_sums.empty();
     n_partials_ += grid;
     return;
   }
@@ -994,15 +1009,33 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       HIP_CHECK(hipMemcpyAsync(group_backup_.p, group_table_.p, (size_t)group_cap_ * slot_bytes, hipMemcpyDeviceToDevice, stream_));
       prm.out[0] = group_table_.p;
       prm.iarg[0] = group_cap_;
+      prm.iarg[kFixScaleArg] = packed_fix_scales(d);
       timed_begin();
       launch(v, "k_gagg", grid, prm);
       timed_end();
+      uint64_t head[2 + (kErrBytes - 16) / 8];
       uint32_t flags[4];
-      read_small(flags, err_flags_.p, 16);
+      read_small(head, err_flags_.p, d.fix_sums.empty() ? 16 : sizeof head);
+      memcpy(flags, head, 16);
       uint64_t groups_now;
       memcpy(&groups_now, &flags[2], 8);
       const bool full = (flags[0] & 32u) != 0;
-      if (!full && (int64_t)groups_now * 2 <= group_cap_) break;
+      if (!full && !d.fix_sums.empty() && fix_attempts_ < 3) {
+        std::vector<int> shift;
+        if (adjust_fix_scales(d, head + 2, shift)) {
+          // a float sum's window moved: back to the checkpoint (table and group counter), shift what earlier chunks accumulated, run again
+          fix_attempts_++;
+          HIP_CHECK(hipMemcpyAsync(group_table_.p, group_backup_.p, (size_t)group_cap_ * slot_bytes, hipMemcpyDeviceToDevice, stream_));
+          uint32_t restore[4] = {flags[0], flags[1], 0, 0};
+          memcpy(&restore[2], &groups_committed_, 8);
+          write_small(err_flags_.p, restore, 16);
+          for (size_t f = 0; f < shift.size(); f++)
+            if (shift[f] > 0 && comet_launch_fix_rescale((uint64_t*)group_table_.p, group_cap_, (int64_t)(slot_bytes / 8), 1 + d.NK + d.fix_sums[f].word, shift[f], stream_) != 0)
+              throw CometError("float sum rescale: launch failed");
+          continue;
+        }
+      }
+      if (!full && (int64_t)groups_now * 2 <= group_cap_) { groups_committed_ = groups_now; break; }
       // grow ×8 and rehash; after a "full" event restart this chunk from the checkpoint
       int64_t new_cap = group_cap_ * 8;
       if (new_cap > ((int64_t)1 << 28)) throw CometError("group table would exceed 2^28 slots");
@@ -1022,8 +1055,10 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       std::swap(group_table_.p, bigger.p);
       std::swap(group_table_.cap, bigger.cap);
       group_cap_ = new_cap;
-      if (!full) break;
+      if (!full) { groups_committed_ = groups_now; break; }
     }
+    fix_attempts_ = 0;
+    fix_has_state_ = fix_has_state_ || !d.fix_sums.empty();
     return;
   }
 
@@ -1196,6 +1231,7 @@ void ExecutionContext::finish_aggregate() {
     prm.out[kOutFirstCol + 2 * j] = base + j * 32;
     prm.out[kOutFirstCol + 2 * j + 1] = base + j * 32 + 16;
   }
+  prm.iarg[kFixScaleArg] = packed_fix_scales(d);
   launch(v, "k_agg_final", 1, prm);
   result_host_.ensure(block_bytes);
   HIP_CHECK(hipMemcpyAsync(result_host_.p, err_flags_.p, block_bytes, hipMemcpyDeviceToHost, stream_));
@@ -1263,6 +1299,7 @@ DevTable ExecutionContext::grouped_to_device() {
     prm.out[kOutFirstCol + 2 * j] = vals[j]->p;
     prm.out[kOutFirstCol + 2 * j + 1] = vbytes[j]->p;
   }
+  prm.iarg[kFixScaleArg] = packed_fix_scales(d);
   if (ngroups) launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
   GatherSource gs = nullptr;
   if (!dict_id_col_.empty()) gs = [this](int c) { return std::make_pair((const DevTable*)&dict_src_, c); };
@@ -1310,6 +1347,7 @@ void ExecutionContext::finish_grouped() {
     prm.out[kOutFirstCol + 2 * j] = out_vals_[j]->p;
     prm.out[kOutFirstCol + 2 * j + 1] = out_valid_[j]->p;
   }
+  prm.iarg[kFixScaleArg] = packed_fix_scales(d);
   launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
   // results come back through pooled pinned buffers (a pageable destination would be staged by the runtime at a fraction of the rate)
   struct HostSpan {
@@ -1918,6 +1956,40 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
     t.has_valid.push_back(hv);
   }
   return t;
+}
+
+// ---- exact Float64 sums: window bookkeeping (device side: comet_device.hpp "Exact Float64 sums") ----
+
+long long ExecutionContext::packed_fix_scales(const PipelineDesc& d) {
+  if (fix_scales_.size() != d.fix_sums.size()) fix_scales_.assign(d.fix_sums.size(), kFixDefaultScale);
+  uint64_t p = 0;
+  for (size_t f = 0; f < fix_scales_.size(); f++) p |= (uint64_t)(uint16_t)(int16_t)fix_scales_[f] << (16 * f);
+  return (long long)p;
+}
+
+// After a chunk: do the addends seen so far (aux words: 1200 + top and 1200 − low, maxima over every chunk of this execution) fit the
+// fixed-point window [2^s, 2^(s + kFixW)) of every sum?  Returns true when scales changed and the chunk has to be run again;
+// shift_right[f] > 0 means accumulators of earlier chunks must first be shifted right by that many bits.
+//   * a value at or above 2^(s + kFixW) would lose HIGH bits: the window moves up (with 10 bits of slack), always;
+//   * bits below 2^s are only truncated (error < rows · 2^s): the window moves down when nothing has been accumulated yet —
+//     to the lowest bit seen when the whole range fits (then the sum is exact), else as low as the top value allows.
+bool ExecutionContext::adjust_fix_scales(const PipelineDesc& d, const uint64_t* aux, std::vector<int>& shift_right) {
+  bool rerun = false;
+  shift_right.assign(d.fix_sums.size(), 0);
+  for (size_t f = 0; f < d.fix_sums.size(); f++) {
+    const uint64_t hi = aux[d.fix_sums[f].aux_hi], lo = aux[d.fix_sums[f].aux_lo];
+    if (hi == 0) continue;                      // no finite non-zero addend yet
+    const int top = (int)hi - 1200, low = 1200 - (int)lo, s = fix_scales_[f];
+    int target = s;
+    if (top > s + kFixW) target = top + 10 - kFixW;
+    else if (low < s && !fix_has_state_) target = (top - low <= kFixW - 10) ? low : top + 2 - kFixW;
+    if (target < -1300) target = -1300;
+    if (target == s) continue;
+    if (target > s && fix_has_state_) shift_right[f] = target - s;
+    fix_scales_[f] = target;
+    rerun = true;
+  }
+  return rerun;
 }
 
 // Single-pass filter + compaction (comet_device.hpp filter_fused_body): tile status words and the ticket / total block are zeroed,

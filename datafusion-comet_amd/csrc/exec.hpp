@@ -223,6 +223,13 @@ class ExecutionContext {
   // aggregate state
   DevBuf partials_;
   int64_t n_partials_ = 0;
+  // exact Float64 sums: the fixed-point scale of every sum of the aggregate (codegen.hpp kFixDefaultScale until the data say otherwise)
+  std::vector<int> fix_scales_;
+  bool fix_has_state_ = false;        // an earlier chunk already contributed to the accumulators at these scales
+  int fix_attempts_ = 0;
+  uint64_t groups_committed_ = 0;     // grouped: groups in the global table after the last completed chunk
+  long long packed_fix_scales(const PipelineDesc& d);
+  bool adjust_fix_scales(const PipelineDesc& d, const uint64_t* aux, std::vector<int>& shift_right);
   DevBuf err_flags_;
   PinnedBuf result_host_;
   PinnedBuf small_host_;   // 4 KiB pinned scratch for flag / count read-backs

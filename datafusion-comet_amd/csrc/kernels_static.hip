@@ -140,6 +140,30 @@ extern "C" int comet_launch_murmur3(int type_id, int precision, const void* valu
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// exact Float64 sums: the fixed-point window of a sum moved up by `shift` bits — arithmetic right shift of the 192-bit accumulator at
+// word `word_off` of every record (partials of an ungrouped aggregate, slots of a group table)
+__global__ __launch_bounds__(256) void fix_rescale_kernel(u64* base, i64 count, i64 stride, i32 word_off, i32 shift) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) {
+    u64* t = base + i * stride + word_off;
+    const u64 w[3] = {t[0], t[1], t[2]};
+    const u64 sign = (w[2] >> 63) ? ~0ull : 0ull;
+    u64 r[3];
+    const int ws = shift >> 6, bs = shift & 63;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const u64 lo = k + ws < 3 ? w[k + ws] : sign;
+      const u64 hi = k + ws + 1 < 3 ? w[k + ws + 1] : sign;
+      r[k] = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+    }
+    t[0] = r[0]; t[1] = r[1]; t[2] = r[2];
+  }
+}
+extern "C" int comet_launch_fix_rescale(uint64_t* base, int64_t count, int64_t stride_words, int32_t word_off, int32_t shift, void* stream) {
+  if (count <= 0 || shift <= 0) return 0;
+  hipLaunchKernelGGL(fix_rescale_kernel, grid_for(count), 256, 0, (hipStream_t)stream, (u64*)base, (i64)count, (i64)stride_words, word_off, shift > 191 ? 191 : shift);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(utf8_uniform_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offsets, (i64)n, L, flag);
@@ -214,6 +238,7 @@ struct Q6Static {
       acc_feed_i128(acc + 1, (i128)price[r] * (i128)disc[r]);
     }
   }
+  static __device__ __forceinline__ void kexport(const CometKParams&, const u64*) {}
   static __device__ __forceinline__ void finalize(const CometKParams& prm, const u64* acc) {
     ((i128*)prm.out[4])[0] = mk128(acc[2], acc[1]);
     ((u8*)prm.out[5])[0] = 1;

@@ -175,3 +175,122 @@ def test_device_decimal_source_on_host(tmp_path):
         assert bool(fits) == (abs(scaled) <= bound), (a, b, k, p_out)
         if fits:
             assert _from_words(out) == scaled
+
+
+# --------------------------------------------------------------------------- exact Float64 sums
+
+def _build_fix(tmp_path):
+    src = open(_HDR).read()
+    a = src.index("constexpr int kFixW = 158;")
+    b = src.index("// SumDecimal overflow is prefix-order dependent in the reference")
+    add = src[src.index("CDEV void acc_add192(u64* a, const u64* b) {"):src.index("CDEV void acc_umax128(")]
+    l0 = src.index("// Σ_j sext(w[j]) · 2^(43·j) as a 192-bit two's-complement number")
+    limbs = src[l0:src.index("\n}\n", l0) + 3]
+    shim = """
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+typedef long long i64; typedef unsigned long long u64; typedef int i32; typedef unsigned int u32; typedef short i16; typedef unsigned short u16;
+typedef signed char i8; typedef unsigned char u8; typedef __int128 i128; typedef unsigned __int128 u128;
+#define CDEV static inline
+constexpr int kLimbBits = 43;
+static inline i64 __double_as_longlong(double d) { i64 x; memcpy(&x, &d, 8); return x; }
+static inline double __longlong_as_double(i64 v) { double x; memcpy(&x, &v, 8); return x; }
+""" + add + src[a:b] + limbs + """
+extern "C" {
+// sum n doubles at scale s: through the 192-bit feeder (mode 0) or through the four 43-bit limbs of the grouped path (mode 1)
+double t_fix_sum(const double* x, i64 n, int s, int mode, u64* exp_out) {
+  u64 acc[3] = {0, 0, 0}, limb[4] = {0, 0, 0, 0}, cls = 0, hi = 0, lo = 0;
+  for (i64 i = 0; i < n; i++) {
+    if (mode == 0) acc_feed_fix192(acc, x[i], s);
+    else for (int j = 0; j < 4; j++) limb[j] += f64_fix_limb(x[i], s, j);
+    cls |= f64_class(x[i]);
+    u64 h = f64_exp_hi(x[i]), l = f64_exp_lo(x[i]);
+    if (h > hi) hi = h;
+    if (l > lo) lo = l;
+  }
+  if (mode == 1) limbs_to_i192(limb, 4, acc);
+  exp_out[0] = hi; exp_out[1] = lo;
+  return fix192_to_f64(acc, s, cls);
+}
+int t_fix_scale(i64 packed, int f) { return fix_scale(packed, f); }
+}
+"""
+    c = tmp_path / "dev_fix.cpp"
+    c.write_text(shim)
+    so = tmp_path / "libdevfix.so"
+    subprocess.check_call(["g++", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-function", "-o", str(so), str(c)])
+    m = ctypes.CDLL(str(so))
+    m.t_fix_sum.restype = ctypes.c_double
+    m.t_fix_sum.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    m.t_fix_scale.restype = ctypes.c_int
+    m.t_fix_scale.argtypes = [ctypes.c_int64, ctypes.c_int]
+    return m
+
+
+def _window(xs):
+    """(low, top): 2^low = lowest set bit of any addend, every |x| < 2^top — what the executor derives from the tracked exponent words."""
+    import math
+    lo, top = None, None
+    for x in xs:
+        if x == 0 or math.isinf(x) or math.isnan(x):
+            continue
+        m, e = math.frexp(abs(x))                 # |x| = m · 2^e, 0.5 ≤ m < 1
+        mant = int(m * (1 << 53))                 # exact
+        low = e - 53 + ((mant & -mant).bit_length() - 1)
+        lo = low if lo is None else min(lo, low)
+        top = e if top is None else max(top, e)
+    return lo, top
+
+
+def test_exact_float_sum_device_source_on_host(tmp_path):
+    """The fixed-point Float64 sum the GPU pipelines use, run on the host from the same source text: with every addend inside the window the
+    result is the correctly rounded exact sum — Python's math.fsum — bit for bit, through both feeders, whatever the magnitudes and signs."""
+    import math
+    m = _build_fix(tmp_path)
+    rng = np.random.default_rng(17)
+    exp_out = (ctypes.c_uint64 * 2)()
+
+    def run(xs, s, mode):
+        a = np.ascontiguousarray(np.asarray(xs, dtype=np.float64))
+        return m.t_fix_sum(a.ctypes.data, len(a), s, mode, exp_out)
+
+    cases = [
+        rng.standard_normal(5000) * 1e6,
+        rng.random(3000),
+        np.concatenate([rng.standard_normal(2000) * 1e15, -rng.standard_normal(2000) * 1e-10]),      # 83 binary orders of magnitude
+        np.array([1e16, 1.0, -1e16, 1.0, 3.0, 1e-3]),                                                 # sequential f64 addition loses the 1.0s
+        np.array([0.1] * 10),
+        np.array([5e-324, 5e-324, -5e-324, 2.2250738585072014e-308]),                                 # subnormals
+        np.array([1.7976931348623157e308, -1.7976931348623157e308, 1e292]),
+        np.array([-0.0, 0.0]),
+        rng.integers(-2**40, 2**40, 4000).astype(np.float64) / 1024.0,
+        np.array([2.0**-60, 2.0**40, -2.0**40]),
+    ]
+    for xs in cases:
+        want = math.fsum(xs.tolist())
+        lo, top = _window(xs.tolist())
+        s = -94 if lo is None else lo
+        assert lo is None or top - lo <= 158
+        for mode in (0, 1):
+            got = run(xs, s, mode)
+            assert got == want and math.copysign(1, got) == math.copysign(1, want + 0.0), (xs[:4], mode, got, want)
+        if lo is not None:
+            assert (int(exp_out[0]) - 1200, 1200 - int(exp_out[1])) == (top, lo)
+    # any scale at or below the lowest set bit gives the same bits; results never depend on the order of the addends
+    xs = rng.standard_normal(1000) * 1e3
+    lo, top = _window(xs.tolist())
+    base = run(xs, lo, 0)
+    assert base == math.fsum(xs.tolist()) == run(xs, lo - 20, 1) == run(rng.permutation(xs), lo - 7, 0)
+    # a scale above the lowest bits truncates toward zero, by less than rows · 2^s
+    s_hi = lo + 30
+    assert abs(run(xs, s_hi, 0) - base) <= len(xs) * 2.0 ** s_hi
+    # IEEE outcome of non-finite addends
+    inf, nan = float("inf"), float("nan")
+    assert run([1.0, inf, 2.0], -94, 0) == inf and run([1.0, -inf], -94, 1) == -inf
+    assert math.isnan(run([inf, -inf, 1.0], -94, 0)) and math.isnan(run([1.0, nan], -94, 1))
+    # packed scales round-trip through the kernel argument word
+    packed = sum(((v & 0xFFFF) << (16 * i)) for i, v in enumerate([-94, 100, -1300, 0]))
+    if packed >= 1 << 63:
+        packed -= 1 << 64
+    assert [m.t_fix_scale(packed, i) for i in range(4)] == [-94, 100, -1300, 0]
