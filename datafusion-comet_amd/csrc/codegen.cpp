@@ -2534,7 +2534,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     int cap = 1024;
     while (cap > 16 && cap * slot_bytes > 10 * 1024) cap >>= 1;
     d.lds_cap = cap;
-    if (al.nkw > (kErrBytes - 16) / 8) throw CometError("too many overflow-tracked sums in one aggregate");
+    if (al.nkw > (kErrBytes - 16 - 64) / 8) throw   // the last 64 bytes of the block are scratch words of the executor
+       CometError("too many overflow-tracked sums in one aggregate");
     src << "  static constexpr int NK = " << d.NK << ";\n  static constexpr int NPW = " << al.npw << ";\n  static constexpr int NKW = " << al.nkw
         << ";\n  static constexpr int LDS_CAP = " << cap << ";\n  static constexpr int GC = " << gc << ";\n  static constexpr int COPIES = " << copies << ";\n";
     auto emit_switch = [&](const char* sig, const std::vector<std::string>& v, const char* prefix, const char* dflt) {

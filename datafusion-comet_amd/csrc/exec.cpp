@@ -1810,27 +1810,47 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
     }
   }
   rows = da->array.length;
-  // Utf8 columns: check on the device whether all values share one length (one pass over the offsets, 4 B/row);
-  // if so the fused kernels skip the offsets and the dependent byte load altogether
-  for (size_t c = 0; c < nc && rows > 0; c++) {
-    if (types[c].id != TypeId::String) continue;
-    const ArrowArray* col = da->array.children[c];
-    const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
-    int32_t ends[2] = {0, 0};
-    read_small(&ends[0], off, 4);
-    read_small(&ends[1], off + rows, 4);
-    const int64_t total = (int64_t)ends[1] - ends[0];
-    if (total % rows != 0 || total / rows > 15) continue;
-    const int32_t L = (int32_t)(total / rows);
-    uint32_t* flag = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 1);   // last word of the error/aux block: scratch
-    HIP_CHECK(hipMemsetAsync(flag, 0, 4, stream_));
-    if (comet_launch_utf8_uniform(off, rows, L, flag, stream_) != 0) continue;
-    uint32_t f = 1;
-    read_small(&f, flag, 4);
-    HIP_CHECK(hipMemsetAsync(flag, 0, 4, stream_));
-    if (f == 0) {
-      views[c].fixed_len = L;
-      views[c].aux = (const char*)col->buffers[2] + ends[0] - (int64_t)col->offset * L;
+  // Utf8 columns: check on the device whether all values share one length (one pass over the offsets, 4 B/row); if so the fused
+  // kernels skip the offsets and the dependent byte load altogether.  All columns at once: the first / last offsets of every column
+  // come back with ONE synchronisation, the verification launches run back to back, their flags come back with a second one.
+  std::vector<size_t> scols;
+  for (size_t c = 0; c < nc && rows > 0; c++)
+    if (types[c].id == TypeId::String) scols.push_back(c);
+  if (!scols.empty() && scols.size() <= 16) {
+    small_host_.ensure(4096);
+    int32_t* ends = (int32_t*)small_host_.p;                 // [2 k], [2 k + 1] = first / last offset of string column k
+    for (size_t k = 0; k < scols.size(); k++) {
+      const ArrowArray* col = da->array.children[scols[k]];
+      const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
+      HIP_CHECK(hipMemcpyAsync(ends + 2 * k, off, 4, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipMemcpyAsync(ends + 2 * k + 1, off + rows, 4, hipMemcpyDeviceToHost, stream_));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    std::vector<int32_t> first(scols.size()), len(scols.size(), -1);
+    uint32_t* flags = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 16);   // last 16 words of the error/aux block: scratch
+    HIP_CHECK(hipMemsetAsync(flags, 0, 64, stream_));
+    bool any = false;
+    for (size_t k = 0; k < scols.size(); k++) {
+      first[k] = ends[2 * k];
+      const int64_t total = (int64_t)ends[2 * k + 1] - ends[2 * k];
+      if (total % rows != 0 || total / rows > 15 || total < 0) continue;
+      const ArrowArray* col = da->array.children[scols[k]];
+      const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
+      if (comet_launch_utf8_uniform(off, rows, (int32_t)(total / rows), flags + k, stream_) != 0) continue;
+      len[k] = (int32_t)(total / rows);
+      any = true;
+    }
+    if (any) {
+      uint32_t f[16];
+      read_small(f, flags, 64);
+      HIP_CHECK(hipMemsetAsync(flags, 0, 64, stream_));
+      for (size_t k = 0; k < scols.size(); k++) {
+        if (len[k] < 0 || f[k] != 0) continue;
+        const size_t c = scols[k];
+        const ArrowArray* col = da->array.children[c];
+        views[c].fixed_len = len[k];
+        views[c].aux = (const char*)col->buffers[2] + first[k] - (int64_t)col->offset * len[k];
+      }
     }
   }
   return true;

@@ -43,24 +43,35 @@ __global__ __launch_bounds__(256) void pmod_kernel(const u32* hashes, i64 n, i32
 }
 
 // Are all n Utf8 values exactly L bytes long?  (lets the fused kernels address the bytes directly, see ld_str_fixed)
+// Streaming read of the offsets: four independent 16-byte loads per lane and iteration; offset i must equal off[0] + i·L, so no value
+// depends on its neighbour and nothing is exchanged between lanes.
 __global__ __launch_bounds__(256) void utf8_uniform_kernel(const i32* off, i64 n, i32 L, u32* flag) {
   bool bad = false;
-  if ((((uintptr_t)off) & 15) == 0) {
-    // four offsets per 16-byte load; the first offset of the next group comes from the neighbouring lane
-    const i64 ngroups = n / 4;
-    for (i64 g = (i64)blockIdx.x * 256 + threadIdx.x; g < (ngroups + 255) / 256 * 256 && !__all(bad); g += (i64)gridDim.x * 256) {
-      const bool in = g < ngroups;
-      int4 v = in ? ((const int4*)off)[g] : make_int4(0, 0, 0, 0);
-      i32 nx = __shfl_down(v.x, 1, 64);
-      if (in && (lane_id() == 63 || g + 1 >= ngroups)) nx = off[4 * g + 4];
-      if (in) bad |= (v.y - v.x != L) | (v.z - v.y != L) | (v.w - v.z != L) | (nx - v.w != L);
+  const i32 o0 = off[0];
+  const i64 total = n + 1;                                   // offsets to check
+  i64 head = 0;                                              // elements before the first 16-byte boundary
+  while (head < total && ((((uintptr_t)(off + head)) & 15) != 0)) head++;
+  const int4* v4 = (const int4*)(off + head);
+  const i64 ngroups = (total - head) / 4;
+  constexpr int U = 4;
+  for (i64 g0 = ((i64)blockIdx.x * 256 + threadIdx.x) * U; g0 < ngroups; g0 += (i64)gridDim.x * 256 * U) {
+    int4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = g0 + u < ngroups ? v4[g0 + u] : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (g0 + u < ngroups) {
+        const i64 i = head + 4 * (g0 + u);
+        const i32 e = o0 + (i32)(i * L);                      // wraps like the offsets would; compared for equality only
+        bad |= (v[u].x != e) | (v[u].y != e + L) | (v[u].z != e + 2 * L) | (v[u].w != e + 3 * L);
+      }
     }
-    for (i64 i = ngroups * 4 + (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) bad |= off[i + 1] - off[i] != L;
-  } else {
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n && !bad; i += (i64)gridDim.x * 256) bad = off[i + 1] - off[i] != L;
   }
-  // one store per wave at most: millions of lanes storing to the same word serialise at the L2
-  if (__ballot(bad) != 0 && lane_id() == 0) *flag = 1;
+  if (blockIdx.x == 0) {
+    for (i64 i = threadIdx.x; i < head; i += 256) bad |= off[i] != o0 + (i32)(i * L);
+    for (i64 i = head + ngroups * 4 + threadIdx.x; i < total; i += 256) bad |= off[i] != o0 + (i32)(i * L);
+  }
+  if (__any(bad) && lane_id() == 0) atomicOr(flag, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
