@@ -81,10 +81,32 @@ int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* c
                           int32_t device_id) {
   (void)partition_count;
   return guarded(nullptr, (int64_t)0, [&]() -> int64_t {
+    // Ownership of every input stream passes to the library with this call (the reference takes the C structs over as soon as it has
+    // their addresses): whatever fails below — plan decoding, an unknown input kind, planning itself — each stream is released once.
+    struct Guard {
+      void** raw; const int32_t* kinds; int32_t n;
+      std::vector<InputSource> ins;      // streams already wrapped (a shuffle-block wrapper owns its block stream)
+      int32_t wrapped = 0;               // raw inputs [0, wrapped) are represented in `ins`
+      bool armed = true;
+      ~Guard() {
+        if (!armed) return;
+        for (auto& s : ins) {
+          if (s.host && s.host->release) s.host->release(s.host);
+          if (s.dev && s.dev->release) s.dev->release(s.dev);
+        }
+        for (int32_t i = wrapped; i < n; i++) {
+          const int32_t k = kinds ? kinds[i] : 0;
+          if (!raw || !raw[i]) continue;
+          if (k == COMET_INPUT_HOST_STREAM) { auto* h = (ArrowArrayStream*)raw[i]; if (h->release) h->release(h); }
+          else if (k == COMET_INPUT_DEVICE_STREAM) { auto* d = (ArrowDeviceArrayStream*)raw[i]; if (d->release) d->release(d); }
+          else if (k == COMET_INPUT_SHUFFLE_BLOCKS) { auto* b = (comet::CometShuffleBlockStreamC*)raw[i]; if (b->release) b->release(b); }
+        }
+      }
+    } guard{inputs, input_kinds, n_inputs};
     if (!plan || plan_len == 0) throw CometError("empty plan");
     OperatorP op = decode_operator(plan, plan_len);
     auto cfg = (config && config_len) ? decode_config_map(config, config_len) : std::vector<std::pair<std::string, std::string>>();
-    std::vector<InputSource> ins;
+    std::vector<InputSource>& ins = guard.ins;
     for (int i = 0; i < n_inputs; i++) {
       InputSource s;
       s.kind = input_kinds ? input_kinds[i] : 0;
@@ -104,18 +126,10 @@ int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* c
         s.host = shuffle_blocks_as_arrow_stream(bs, leaves[(size_t)i]->scan_fields);
       } else throw CometError("unknown input kind " + std::to_string(s.kind));
       ins.push_back(s);
+      guard.wrapped = i + 1;
     }
-    std::shared_ptr<ExecutionContext> ctx;
-    try {
-      ctx = std::make_shared<ExecutionContext>(op, plan_bytes_hash(plan, plan_len), cfg, ins, batch_size, device_id);
-    } catch (...) {
-      // ownership of the streams was transferred to us: release them even when planning fails
-      for (auto& s : ins) {
-        if (s.host && s.host->release) s.host->release(s.host);
-        if (s.dev && s.dev->release) s.dev->release(s.dev);
-      }
-      throw;
-    }
+    std::shared_ptr<ExecutionContext> ctx = std::make_shared<ExecutionContext>(op, plan_bytes_hash(plan, plan_len), cfg, ins, batch_size, device_id);
+    guard.armed = false;                 // the context owns the streams from here on
     std::lock_guard<std::mutex> lk(g_mu);
     int64_t h = g_next++;
     g_ctx[h] = ctx;

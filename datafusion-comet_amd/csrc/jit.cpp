@@ -9,7 +9,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <condition_variable>
 #include <mutex>
+#include <set>
+#include <thread>
 
 #include "plan.hpp"
 
@@ -49,21 +52,46 @@ std::string cache_dir() {
 
 std::mutex g_mu;
 std::map<std::string, std::shared_ptr<CodeObject>> g_mem_cache;
+// single flight: tasks of one stage start together and ask for the same plan shape at the same moment — one of them compiles,
+// the others wait for its result instead of compiling (and writing the cache file) as well
+std::condition_variable g_cv;
+std::set<std::string> g_in_flight;
+
+// the compiler that produced a cached code object is part of its identity: a ROCm upgrade must not load stale objects
+std::string toolchain_tag() {
+  int major = 0, minor = 0;
+  hiprtcVersion(&major, &minor);
+  return std::to_string(major) + "." + std::to_string(minor);
+}
+// a code object is an ELF image; anything else in the cache (a truncated or foreign file) is ignored and recompiled
+bool looks_like_code_object(const std::vector<char>& b) { return b.size() > 64 && b[0] == 0x7f && b[1] == 'E' && b[2] == 'L' && b[3] == 'F'; }
 
 }  // namespace
 
 std::shared_ptr<CodeObject> jit_compile(const std::string& source) {
   // the key covers the generated source AND the hand-written headers it instantiates
-  static const uint64_t h2 = fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader));
+  static const uint64_t h2 = fnv1a(toolchain_tag(), fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader)));
   uint64_t h1 = fnv1a(source);
   char keybuf[64];
   snprintf(keybuf, sizeof keybuf, "%016llx_%016llx", (unsigned long long)h1, (unsigned long long)h2);
   std::string key = keybuf;
   {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_mem_cache.find(key);
-    if (it != g_mem_cache.end()) return it->second;
+    std::unique_lock<std::mutex> lk(g_mu);
+    for (;;) {
+      auto it = g_mem_cache.find(key);
+      if (it != g_mem_cache.end()) return it->second;
+      if (!g_in_flight.count(key)) break;
+      g_cv.wait(lk);                       // another thread is compiling this very key
+    }
+    g_in_flight.insert(key);
   }
+  struct Flight {                          // whatever happens below, waiters are released
+    std::string key;
+    ~Flight() {
+      { std::lock_guard<std::mutex> lk(g_mu); g_in_flight.erase(key); }
+      g_cv.notify_all();
+    }
+  } flight{key};
   if (const char* dd = getenv("COMET_JIT_DUMP_DIR")) {
     mkdir(dd, 0755);
     std::ofstream f(std::string(dd) + "/" + key + ".hip");
@@ -76,7 +104,7 @@ std::shared_ptr<CodeObject> jit_compile(const std::string& source) {
     if (f) {
       auto co = std::make_shared<CodeObject>();
       co->bytes.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-      if (!co->bytes.empty()) {
+      if (looks_like_code_object(co->bytes)) {
         std::lock_guard<std::mutex> lk(g_mu);
         g_mem_cache[key] = co;
         return co;
@@ -109,7 +137,8 @@ std::shared_ptr<CodeObject> jit_compile(const std::string& source) {
   hiprtcDestroyProgram(&prog);
   if (disk) {
     mkdir(dir.c_str(), 0755);
-    std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    // unique per process AND thread, renamed into place only when complete: a reader never sees a partial file
+    std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "_" + std::to_string((unsigned long long)std::hash<std::thread::id>()(std::this_thread::get_id()));
     std::ofstream f(tmp, std::ios::binary);
     if (f) {
       f.write(co->bytes.data(), (std::streamsize)co->bytes.size());

@@ -3,6 +3,7 @@
 // Each export is a thin shim over the JVM-free C ABI (include/comet_amd.h): unpack Java arrays/objects,
 // call comet_*, map failures to the Java exception classes the reference throws
 // (native/jni-bridge/src/errors.rs:473-560) and return the type's zero value (errors.rs:390-470).
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -21,6 +22,8 @@ struct BlockIterator;
 struct JavaSide {                 // global refs held for the lifetime of a plan (jni_api.rs:423-436,517-527)
   std::vector<jobject> iterators;
   jobject metrics_node = nullptr;
+  long long metrics_interval_ms = 0;                           // createPlan's metricsUpdateInterval (jni_api.rs:906-909)
+  std::chrono::steady_clock::time_point last_metrics_push;
 };
 
 // The JNIEnv of the Native.executePlan call running on this thread: input callbacks (CometShuffleBlockIterator.hasNext /
@@ -128,7 +131,7 @@ JNIEXPORT jboolean JNICALL Java_org_apache_comet_NativeBase_isObjectStoreSchemeS
 // Native.createPlan (jni_api.rs:371-562)
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
     JNIEnv* env, jclass, jlong /*id*/, jobjectArray iterators, jbyteArray plan, jbyteArray configMap, jint partitionCount,
-    jobject metricsNode, jlong /*metricsUpdateInterval*/, jobject /*taskMemoryManager*/, jobjectArray /*localDirs*/, jint batchSize,
+    jobject metricsNode, jlong metricsUpdateInterval, jobject /*taskMemoryManager*/, jobjectArray /*localDirs*/, jint batchSize,
     jboolean /*offHeapMode*/, jstring /*memoryPoolType*/, jlong /*memoryLimit*/, jlong /*memoryLimitPerTask*/, jlong taskAttemptId,
     jlong /*taskCPUs*/, jobject /*keyUnwrapper*/, jobject /*taskContext*/, jobject /*classLoader*/) {
   std::vector<uint8_t> plan_b = byte_array(env, plan), cfg_b = byte_array(env, configMap);
@@ -136,9 +139,17 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
   std::vector<void*> inputs;
   std::vector<int32_t> kinds;
   const jsize n_it = iterators ? jni_GetArrayLength(env, iterators) : 0;
+  // an error before comet_create_plan is reached: nothing has been handed to the library yet — drop what this call created (block
+  // iterator wrappers, global refs); the Arrow streams stay with the JVM, which closes them when createPlan throws
+  auto abandon = [&]() {
+    for (size_t k = 0; k < inputs.size(); k++)
+      if (kinds[k] == COMET_INPUT_SHUFFLE_BLOCKS) bi_release((CometShuffleBlockStream*)inputs[k]);
+    for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
+    js.iterators.clear();
+  };
   for (jsize i = 0; i < n_it; i++) {
     jobject it = jni_GetObjectArrayElement(env, iterators, i);
-    if (!it) { throw_java(env, COMET_ERR_NATIVE, "null input iterator"); return 0; }
+    if (!it) { abandon(); throw_java(env, COMET_ERR_NATIVE, "null input iterator"); return 0; }
     // org.apache.arrow.c.ArrowArrayStream.memoryAddress()J (native/jni-bridge/src/arrow_array_stream.rs:45); the
     // native side takes ownership of the C struct at that address (scan.rs:98-106)
     jclass cls = jni_GetObjectClass(env, it);
@@ -150,9 +161,7 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
       jmethodID get_buffer = has_next ? jni_GetMethodID(env, cls, "getBuffer", "()Ljava/nio/ByteBuffer;") : nullptr;
       if (!has_next || !get_buffer) {
         if (jni_ExceptionCheck(env)) jni_ExceptionClear(env);
-        for (size_t k = 0; k < inputs.size(); k++)
-          if (kinds[k] == COMET_INPUT_SHUFFLE_BLOCKS) bi_release((CometShuffleBlockStream*)inputs[k]);
-        for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
+        abandon();
         throw_java(env, COMET_ERR_NATIVE, "input iterator is neither an org.apache.arrow.c.ArrowArrayStream nor an org.apache.comet.CometShuffleBlockIterator");
         return 0;
       }
@@ -171,7 +180,7 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
       continue;
     }
     jlong addr = jni_CallLongMethod0(env, it, mid);
-    if (jni_ExceptionCheck(env)) return 0;
+    if (jni_ExceptionCheck(env)) { abandon(); return 0; }   // the pending Java throwable is re-thrown as is
     inputs.push_back((void*)(intptr_t)addr);
     kinds.push_back(COMET_INPUT_HOST_STREAM);
     js.iterators.push_back(jni_NewGlobalRef(env, it));
@@ -180,11 +189,14 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
   int64_t h = comet_create_plan(plan_b.data(), plan_b.size(), cfg_b.empty() ? nullptr : cfg_b.data(), cfg_b.size(), inputs.data(),
                                 kinds.data(), (int32_t)inputs.size(), partitionCount, batchSize, pick_device(taskAttemptId));
   if (h == 0) {
+    // comet_create_plan released every stream it was handed (the block-iterator wrappers included); only the global refs are ours
     for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
     throw_java(env, comet_last_error_kind(0), comet_last_error(0));
     return 0;
   }
   if (metricsNode) js.metrics_node = jni_NewGlobalRef(env, metricsNode);
+  js.metrics_interval_ms = (long long)metricsUpdateInterval;
+  js.last_metrics_push = std::chrono::steady_clock::now();
   std::lock_guard<std::mutex> lk(g_mu);
   g_java[h] = js;
   return (jlong)h;
@@ -214,15 +226,23 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_executePlan(JNIEnv* env, jc
     throw_java(env, comet_last_error_kind(handle), comet_last_error(handle));
     return 0;
   }
-  if (rows == -1) {
-    jobject node = nullptr;
-    {
-      std::lock_guard<std::mutex> lk(g_mu);
-      auto it = g_java.find(handle);
-      if (it != g_java.end()) node = it->second.metrics_node;
+  // metrics reach the JVM at end of stream and, while batches flow, at most every metricsUpdateInterval ms (jni_api.rs:897-909)
+  jobject node = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_java.find(handle);
+    if (it != g_java.end()) {
+      JavaSide& js = it->second;
+      const auto now = std::chrono::steady_clock::now();
+      const bool due = js.metrics_interval_ms > 0 &&
+                       std::chrono::duration_cast<std::chrono::milliseconds>(now - js.last_metrics_push).count() >= js.metrics_interval_ms;
+      if (rows == -1 || due) {
+        node = js.metrics_node;
+        js.last_metrics_push = now;
+      }
     }
-    push_metrics(env, handle, node);
   }
+  if (node) push_metrics(env, handle, node);
   return (jlong)rows;
 }
 

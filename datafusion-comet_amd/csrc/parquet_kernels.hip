@@ -316,7 +316,9 @@ __global__ __launch_bounds__(256) void pq_u32_scan_apply_kernel(const u32* in, i
       __syncthreads();
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (i32)tile_off[ntiles];
+  // the grand total is kept in 64 bits: more than INT32_MAX comes back as -1 (every caller turns a negative total into its "exceeds
+  // 2 GiB" error) instead of wrapping to a small positive size
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_off[ntiles] > 0x7fffffffull ? (i32)-1 : (i32)tile_off[ntiles];
 }
 __global__ __launch_bounds__(256) void pq_pack_kernel(const u8* bytes, u8* bitmap, i64 n) { pack_validity_body(bytes, bitmap, n); }
 

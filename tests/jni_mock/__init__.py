@@ -36,6 +36,8 @@ def load():
     m.mock_string.argtypes = [ctypes.c_char_p]
     m.mock_metrics_len.restype = ctypes.c_int64
     m.mock_metrics_len.argtypes = [vp]
+    m.mock_metrics_pushes.restype = ctypes.c_int64
+    m.mock_metrics_pushes.argtypes = [vp]
     m.mock_metrics_bytes.restype = vp
     m.mock_metrics_bytes.argtypes = [vp]
     m.mock_exception_class.restype = ctypes.c_char_p
@@ -62,13 +64,13 @@ class Jvm:
         r.argtypes = [vp, vp, i64]
 
     def create_plan(self, stream_addrs, plan: bytes, config: bytes = b"", batch_size=8192, metrics_node=None, task_attempt_id=0,
-                    iterator_objects=None):
+                    iterator_objects=None, metrics_interval_ms=1000):
         objs = iterator_objects if iterator_objects is not None else [self.m.mock_stream(a) for a in stream_addrs]
         arr = (ctypes.c_void_p * max(len(objs), 1))(*objs)
         its = self.m.mock_objs(arr, len(objs))
         return self.lib.Java_org_apache_comet_Native_createPlan(
             self.env, None, 1, its, self.m.mock_bytes(plan, len(plan)), self.m.mock_bytes(config, len(config)) if config else None, 1,
-            metrics_node, 1000, None, None, batch_size, 1, None, 0, 0, task_attempt_id, 1, None, None, None)
+            metrics_node, metrics_interval_ms, None, None, batch_size, 1, None, 0, 0, task_attempt_id, 1, None, None, None)
 
     def execute_plan(self, handle, array_addrs, schema_addrs):
         a = (ctypes.c_int64 * max(len(array_addrs), 1))(*array_addrs)

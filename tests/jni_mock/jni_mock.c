@@ -97,6 +97,7 @@ static void f_CallVoidMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
   node->data = malloc((size_t)arr->len ? (size_t)arr->len : 1);
   memcpy(node->data, arr->data, (size_t)arr->len);
   node->len = arr->len;
+  node->addr++;   /* number of set_all_from_bytes up-calls on this node */
 }
 static const char* f_GetStringUTFChars(JNIEnv* e, jstring s, jboolean* c) { (void)e; if (c) *c = 0; return ((MObj*)s)->data; }
 static void f_ReleaseStringUTFChars(JNIEnv* e, jstring s, const char* c) { (void)e; (void)s; (void)c; }
@@ -145,6 +146,7 @@ void* mock_plain_object(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_OBJS
 void* mock_metrics_node(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_METRICS; return o; }
 void* mock_string(const char* s) { MObj* o = calloc(1, sizeof *o); o->kind = K_STRING; o->data = strdup(s); return o; }
 int64_t mock_metrics_len(void* n) { return ((MObj*)n)->len; }
+long long mock_metrics_pushes(void* node) { return ((MObj*)node)->addr; }
 const void* mock_metrics_bytes(void* n) { return ((MObj*)n)->data; }
 int mock_exception_pending(void) { return g_exc_pending; }
 const char* mock_exception_class(void) { return g_exc_class; }

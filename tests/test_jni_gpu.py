@@ -87,3 +87,36 @@ def test_shuffle_scan_through_jni_block_iterator(built):
     assert got_rows == want_rows
     jvm.release_plan(h)
     assert jvm.m.mock_live_global_refs() == 0
+
+
+def test_metrics_are_pushed_periodically_while_batches_flow(built):
+    """createPlan's metricsUpdateInterval (jni_api.rs:897-909): CometMetricNode.set_all_from_bytes is called while the stream is being
+    drained — at most once per interval — and once more at the end, not only at release."""
+    import time
+    import numpy as np
+    jvm = Jvm(native.lib())
+    n = 100_000
+    table = pa.table({"a": pa.array(np.arange(n, dtype=np.int64))})
+    plan = S.filter_(S.scan([S.T_INT64]), S.gt_eq(S.col(0, S.T_INT64), S.lit(0, S.T_INT64)))
+    inp = native.HostInput.from_table(table)
+    node = jvm.m.mock_metrics_node()
+    h = jvm.create_plan([inp.address], plan.encode(), metrics_node=node, batch_size=8192, metrics_interval_ms=2)
+    assert h > 0, jvm.exception()
+    batches = total = 0
+    while True:
+        arrays, schemas = [native.ArrowArrayC()], [native.ArrowSchemaC()]
+        rows = jvm.execute_plan(h, [ctypes.addressof(arrays[0])], [ctypes.addressof(schemas[0])])
+        if rows == -1:
+            break
+        assert rows > 0, jvm.exception()
+        total += pa.Array._import_from_c(ctypes.addressof(arrays[0]), ctypes.addressof(schemas[0])).__len__()
+        batches += 1
+        if batches == 3:
+            mid_stream = jvm.m.mock_metrics_pushes(node)
+        time.sleep(0.004)
+    assert total == n and batches >= 10
+    assert mid_stream >= 1                                   # pushed before the stream ended
+    assert 2 <= jvm.m.mock_metrics_pushes(node) <= batches + 1
+    jvm.release_plan(h)
+    metrics, _ = S.decode_metric_node(ctypes.string_at(jvm.m.mock_metrics_bytes(node), jvm.m.mock_metrics_len(node)))
+    assert metrics["output_rows"] == n
