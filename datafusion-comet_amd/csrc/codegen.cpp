@@ -2621,7 +2621,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   src << "// generated by datafusion-comet_amd codegen — hash join\n#include \"comet_device.hpp\"\nusing namespace comet;\n";
   src << "struct P {\n  static constexpr int R = 1;\n  static constexpr int MODE = " << mode << ";\n";
   src << "  static constexpr bool OUTER_PROBE = " << (outer_probe ? "true" : "false") << ", OUTER_BUILD = " << (outer_build ? "true" : "false")
-      << ", BUILD_KEEP_MATCHED = " << (keep_matched ? "true" : "false") << ";\n";
+      << ", BUILD_KEEP_MATCHED = " << (keep_matched ? "true" : "false") << ", BUILD_ONLY = " << (build_only ? "true" : "false") << ";\n";
 
   // key words of one side
   auto key_fn = [&](const char* name, const char* rowvar, const std::vector<DType>& types, const std::vector<bool>& valid, int base,
@@ -2781,14 +2781,14 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   }
   src << "};\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbuild(const CometKParams prm) { comet::join_build_body<P>(prm); }\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jcount(const CometKParams prm) { comet::join_count_body<P>(prm); }\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jscan(const CometKParams prm) { comet::tile_scan_body((u64*)prm.out[comet::kJoinTileCounts], prm.iarg[2]); }\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jemit(const CometKParams prm) { comet::join_emit_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbcount(const CometKParams prm) { comet::join_build_unmatched_count_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbscan(const CometKParams prm) { comet::tile_scan_body((u64*)prm.out[comet::kJoinBuildTiles], prm.iarg[3]); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbemit(const CometKParams prm) { comet::join_build_unmatched_emit_body<P>(prm); }\n";
-  d.kernels = {"k_jbuild", "k_jcount", "k_jscan", "k_jemit", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit"};
+  // single-pass probes (comet_device.hpp template D'): the chained global table, or an LDS table for small build sides
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe(const CometKParams prm) { comet::join_probe_fused_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jlds(const CometKParams prm) { comet::join_probe_lds_body<P>(prm); }\n";
+  d.kernels = {"k_jbuild", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jlds"};
   d.join_outer_build = outer_build;
   d.join_build_only = build_only;
   const char* jt_name = build_only ? (keep_matched ? "LeftSemi" : "LeftAnti") : keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";

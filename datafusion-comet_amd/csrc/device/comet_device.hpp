@@ -1641,8 +1641,7 @@ CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
 // Kernel template D — hash join (reference: planner.rs:2192-2266 → DataFusion HashJoinExec; NULL keys never
 // match, planner.rs:2225-2227).  Build side: bucket-chained table over the build rows,
 //   head[cap] (i32, -1 = empty) and next[n_build]; insertion is one atomicExch per row, duplicates chain.
-// Probe side, two passes so the output is sized exactly: join_count (matches per probe row + per-tile sums),
-// tile scan, join_emit (block prefix inside the tile, then one output row per match).
+// Probe side: template D' below (single pass; counts and emits together).
 //   P::bvalid(prm,i) / P::pvalid(prm,j)   all key columns non-NULL
 //   P::bhash(prm,i)  / P::phash(prm,j)    64-bit hash of the key words
 //   P::match(prm,i,j)                     keys equal (and residual join condition TRUE)
@@ -1670,105 +1669,6 @@ CDEV void join_build_body(const CometKParams& prm) {
     if (!P::bvalid(prm, i)) continue;
     u64 h = P::bhash(prm, i) & mask;
     next[i] = atomicExch(&head[h], (i32)i);
-  }
-}
-
-template <class P>
-CDEV u32 join_row_matches(const CometKParams& prm, i64 j) {
-  const i32* head = (const i32*)prm.out[0];
-  const i32* next = (const i32*)prm.out[1];
-  u32 c = 0;
-  if (P::pvalid(prm, j)) {
-    u64 h = P::phash(prm, j) & ((u64)prm.iarg[0] - 1);
-    for (i32 i = head[h]; i >= 0; i = next[i]) {
-      if (P::match(prm, (i64)i, j)) {
-        c++;
-        if (P::OUTER_BUILD) ((u8*)prm.out[kJoinMatched])[i] = 1;   // racing stores of the same value
-        if (P::MODE != 0) break;  // semi / anti only need existence
-      }
-    }
-  }
-  if (P::MODE == 2) c = c ? 0u : 1u;
-  if (P::OUTER_PROBE && c == 0) c = 1;   // the unmatched probe row itself, NULL-extended
-  return c;
-}
-
-template <class P>
-CDEV void join_count_body(const CometKParams& prm) {
-  const i64 n = prm.n;
-  u32* counts = (u32*)prm.out[3];
-  u64* tile_counts = (u64*)prm.out[kJoinTileCounts];
-  const i64 ntiles = (n + kMaskTileRows - 1) / kMaskTileRows;
-  __shared__ u32 s_cnt;
-  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    u32 local = 0;
-#pragma unroll
-    for (int r = 0; r < kMaskTileRows / kBlock; r++) {
-      i64 j = t * kMaskTileRows + r * kBlock + threadIdx.x;
-      if (j < n) {
-        u32 c = join_row_matches<P>(prm, j);
-        counts[j] = c;
-        local += c;
-      }
-    }
-    // wave reduce then one LDS atomic per wave
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) local += __shfl_xor(local, m, kWave);
-    if (lane_id() == 0) atomicAdd(&s_cnt, local);
-    __syncthreads();
-    if (threadIdx.x == 0) tile_counts[t] = s_cnt;
-    __syncthreads();
-  }
-}
-
-template <class P>
-CDEV void join_emit_body(const CometKParams& prm) {
-  const i64 n = prm.n;
-  const u32* counts = (const u32*)prm.out[3];
-  const u64* tile_off = (const u64*)prm.out[kJoinTileCounts];
-  const i32* head = (const i32*)prm.out[0];
-  const i32* next = (const i32*)prm.out[1];
-  const i64 ntiles = (n + kMaskTileRows - 1) / kMaskTileRows;
-  __shared__ u32 s_wave[kBlock / kWave];
-  __shared__ u32 s_run;
-  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    if (threadIdx.x == 0) s_run = 0;
-    __syncthreads();
-    for (int r = 0; r < kMaskTileRows / kBlock; r++) {
-      i64 j = t * kMaskTileRows + r * kBlock + threadIdx.x;
-      u32 c = j < n ? counts[j] : 0;
-      u32 x = c;  // inclusive scan across the wave
-#pragma unroll
-      for (int d = 1; d < kWave; d <<= 1) {
-        u32 y = __shfl_up(x, d, kWave);
-        if (lane_id() >= d) x += y;
-      }
-      if (lane_id() == kWave - 1) s_wave[wave_id()] = x;
-      __syncthreads();
-      u32 woff = 0;
-      for (int w = 0; w < wave_id(); w++) woff += s_wave[w];
-      const u32 run = s_run;
-      i64 pos = (i64)tile_off[t] + run + woff + (x - c);
-      if (c) {
-        if (P::MODE != 0) {
-          P::emit(prm, -1, j, pos);
-        } else {
-          u32 emitted = 0;
-          if (!P::OUTER_PROBE || P::pvalid(prm, j)) {
-            u64 h = P::phash(prm, j) & ((u64)prm.iarg[0] - 1);
-            for (i32 i = head[h]; i >= 0; i = next[i]) {
-              if (P::match(prm, (i64)i, j)) { P::emit(prm, (i64)i, j, pos++); emitted++; }
-            }
-          }
-          if (P::OUTER_PROBE && emitted == 0) P::emit_probe_only(prm, j, pos);
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x == kBlock - 1) s_run = run + woff + x;
-      __syncthreads();
-    }
   }
 }
 
@@ -1823,6 +1723,167 @@ CDEV void join_build_unmatched_emit_body(const CometKParams& prm) {
       __syncthreads();
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel template D' — single-pass probe.  Template D walks every probe row's chain twice (count, then emit) with a scan launch in
+// between, because FilterExec-style ordered output needs exact positions.  A join's output order is unspecified in the reference
+// (HashJoinExec emits per probe batch in hash-table order), so one pass suffices: every thread probes R rows and remembers per row
+// the number of matches and the first matching build row; the tile's total is one block reduction + ONE global atomic that reserves
+// its output range; rows with a single match (the common, FK-shaped case) are emitted from the remembered row, only multi-match rows
+// walk their chain again.  The output buffers have a capacity: beyond it rows are counted, not written, and the executor re-runs the
+// kernel with the exact size (only many-to-many joins ever need that).
+// Two sources of candidates share the tile logic:
+//   * join_probe_fused_body: the chained global table of template D (build side of any size);
+//   * join_probe_lds_body: a build side of ≤ kJoinLdsMaxBuild rows (dimension tables, broadcast joins) is hashed ONCE per block into
+//     an open-addressing table in LDS (u32 row + u16 hash tag per slot, linear probing) and probed there — no HBM access per probe row
+//     except the key / condition check of a slot whose tag already matched ("hash-join probe staged through LDS open-addressing
+//     tables", north_star).  Radix-partitioning BOTH sides so that larger build sides fit LDS was built and measured in round 2
+//     (DESIGN §4c): the 4096-way scatter of 324 M probe pairs ran at 1.4 TB/s — one 8-byte write transaction per row — which made the
+//     partitioned join slower than this single-pass probe of the global table, so it was removed.
+//   out[47] = { u64 emitted },  iarg[6] = output capacity
+// ---------------------------------------------------------------------------------------------
+constexpr int kJoinLdsCap = 8192;
+constexpr int kJoinLdsMaxBuild = 6144;
+constexpr u32 kJoinEmpty = 0xffffffffu;
+constexpr int kJoinR = 8;                    // probe rows per thread and tile
+
+// candidates of probe row j in the global chained table
+template <class P>
+struct JoinGlobalTable {
+  const i32* head;
+  const i32* next;
+  u64 mask;
+  template <class F>
+  CDEV void for_each(const CometKParams& prm, i64 j, u64 h, F f) const {   // f(build row) returns false to stop
+    for (i32 i = head[h & mask]; i >= 0; i = next[i])
+      if (P::match(prm, (i64)i, j) && !f((u32)i)) break;
+  }
+};
+// candidates in the block's LDS table
+template <class P>
+struct JoinLdsTable {
+  const COMET_LDS u32* rows;             // address_space(3): ds_read, not FLAT (a FLAT access waits for every outstanding global load)
+  const COMET_LDS unsigned short* tags;
+  template <class F>
+  CDEV void for_each(const CometKParams& prm, i64 j, u64 h, F f) const {
+    const u32 hi = (u32)(h >> 16);
+    u32 slot = (hi >> 16) & (kJoinLdsCap - 1);
+    for (u32 row; (row = rows[slot]) != kJoinEmpty; slot = (slot + 1) & (kJoinLdsCap - 1))
+      if (tags[slot] == (unsigned short)hi && P::match(prm, (i64)row, j) && !f(row)) break;
+  }
+};
+
+template <class P, class T>
+CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
+  const i64 n = prm.n;
+  const i64 cap_out = prm.iarg[6];
+  unsigned long long* emitted = (unsigned long long*)prm.out[47];
+  u8* matched = (u8*)prm.out[kJoinMatched];
+  __shared__ u32 s_wave[kBlock / kWave];
+  __shared__ unsigned long long s_base;
+  const int lane = lane_id(), wv = wave_id();
+  constexpr i64 kTile = (i64)kJoinR * kBlock;
+  for (i64 base = (i64)blockIdx.x * kTile; base < n; base += (i64)gridDim.x * kTile) {
+    u32 cnt[kJoinR], first[kJoinR], e[kJoinR];
+    u64 hs[kJoinR];
+    u32 mine = 0;
+#pragma unroll
+    for (int r = 0; r < kJoinR; r++) {
+      const i64 j = base + (i64)r * kBlock + threadIdx.x;
+      cnt[r] = 0;
+      first[r] = kJoinEmpty;
+      hs[r] = 0;
+      const bool active = j < n;
+      if (active && P::pvalid(prm, j)) {
+        hs[r] = P::phash(prm, j);
+        u32 c = 0, f0 = kJoinEmpty;
+        table.for_each(prm, j, hs[r], [&](u32 row) {
+          if (c == 0) f0 = row;
+          c++;
+          if (P::OUTER_BUILD) matched[row] = 1;    // racing stores of the same value
+          return P::MODE == 0;                     // semi / anti only need existence
+        });
+        cnt[r] = c;
+        first[r] = f0;
+      }
+      if (!active || P::BUILD_ONLY) e[r] = 0;
+      else if (P::MODE == 1) e[r] = cnt[r] ? 1u : 0u;
+      else if (P::MODE == 2) e[r] = cnt[r] ? 0u : 1u;
+      else e[r] = (cnt[r] == 0 && P::OUTER_PROBE) ? 1u : cnt[r];
+      mine += e[r];
+    }
+    // exclusive prefix of `mine` across the block, the tile's total → one global reservation
+    u32 x = mine;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const u32 y = __shfl_up(x, d, kWave);
+      if (lane >= d) x += y;
+    }
+    if (lane == kWave - 1) s_wave[wv] = x;
+    __syncthreads();
+    u32 woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; w++) {
+      if (w < wv) woff += s_wave[w];
+      total += s_wave[w];
+    }
+    if (threadIdx.x == 0 && total) s_base = atomicAdd(emitted, (unsigned long long)total);
+    __syncthreads();
+    if (total) {
+      i64 pos = (i64)s_base + woff + (x - mine);
+#pragma unroll
+      for (int r = 0; r < kJoinR; r++) {
+        if (!e[r]) continue;
+        const i64 j = base + (i64)r * kBlock + threadIdx.x;
+        if (P::MODE != 0) {
+          if (pos < cap_out) P::emit(prm, -1, j, pos);
+          pos++;
+        } else if (cnt[r] == 0) {
+          if (pos < cap_out) P::emit_probe_only(prm, j, pos);
+          pos++;
+        } else if (cnt[r] == 1) {
+          if (pos < cap_out) P::emit(prm, (i64)first[r], j, pos);
+          pos++;
+        } else {
+          table.for_each(prm, j, hs[r], [&](u32 row) {
+            if (pos < cap_out) P::emit(prm, (i64)row, j, pos);
+            pos++;
+            return true;
+          });
+        }
+      }
+    }
+    __syncthreads();   // s_wave / s_base are reused by the next tile
+  }
+}
+
+template <class P>
+CDEV void join_probe_fused_body(const CometKParams& prm) {
+  JoinGlobalTable<P> t{(const i32*)prm.out[0], (const i32*)prm.out[1], (u64)prm.iarg[0] - 1};
+  join_probe_tiles<P>(prm, t);
+}
+
+template <class P>
+CDEV void join_probe_lds_body(const CometKParams& prm) {
+  const i64 nbuild = prm.iarg[1];
+  __shared__ u32 s_rows[kJoinLdsCap];
+  __shared__ unsigned short s_tags[kJoinLdsCap];
+  for (int s2 = threadIdx.x; s2 < kJoinLdsCap; s2 += kBlock) s_rows[s2] = kJoinEmpty;
+  __syncthreads();
+  for (i64 i = threadIdx.x; i < nbuild; i += kBlock) {
+    if (!P::bvalid(prm, i)) continue;
+    const u32 hi = (u32)(P::bhash(prm, i) >> 16);
+    u32 slot = (hi >> 16) & (kJoinLdsCap - 1);
+    for (;;) {
+      const u32 old = atomicCAS(&s_rows[slot], kJoinEmpty, (u32)i);
+      if (old == kJoinEmpty) { s_tags[slot] = (unsigned short)hi; break; }
+      slot = (slot + 1) & (kJoinLdsCap - 1);
+    }
+  }
+  __syncthreads();
+  JoinLdsTable<P> t{(const COMET_LDS u32*)s_rows, (const COMET_LDS unsigned short*)s_tags};
+  join_probe_tiles<P>(prm, t);
 }
 
 }  // namespace comet

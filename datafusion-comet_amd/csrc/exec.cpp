@@ -2225,12 +2225,9 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   int64_t cap = 1024;
   while (cap < 2 * B.rows) cap <<= 1;
   const int64_t n = P.rows;
-  const int64_t ntiles = (n + 1023) / 1024;
-  DevBuf head, next, counts, tiles, matched, btiles;
+  DevBuf head, next, matched, btiles;
   head.ensure((size_t)cap * 4);
   next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4);
-  counts.ensure((size_t)std::max<int64_t>(n, 1) * 4);
-  tiles.ensure((size_t)(ntiles + 1) * 8);
   HIP_CHECK(hipMemsetAsync(head.p, 0xff, (size_t)cap * 4, stream_));
   const bool outer_build = d.join_outer_build;
   const int64_t nbtiles = (B.rows + 1023) / 1024;
@@ -2245,25 +2242,48 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   prm.n = n;
   prm.iarg[0] = cap;
   prm.iarg[1] = B.rows;
-  prm.iarg[2] = ntiles;
   prm.out[0] = head.p;
   prm.out[1] = next.p;
   prm.out[kOutErr] = err_flags_.p;
-  prm.out[3] = counts.p;
-  prm.out[44] = tiles.p;
   timed_begin();
-  if (B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
   int64_t out_rows = 0, tail_rows = 0;
   const size_t ncol = d.out_cols.size();
   std::vector<std::shared_ptr<DevBuf>> vals(ncol), vbytes(ncol);
-  if (n > 0) {
-    int grid = (int)std::min<int64_t>(ntiles, 256 * 8);
-    launch(v, "k_jcount", grid, prm);
-    launch(v, "k_jscan", 1, prm);
-    uint64_t total = 0;
-    read_small(&total, (char*)tiles.p + (size_t)ntiles * 8, 8);
-    out_rows = d.join_build_only ? 0 : (int64_t)total;
+  auto bind_outputs = [&](int64_t rows_cap) {
+    for (size_t c = 0; c < ncol; c++) {
+      if (!vals[c]) vals[c] = std::make_shared<DevBuf>();
+      vals[c]->ensure((size_t)std::max<int64_t>(rows_cap, 1) * out_width(d.out_cols[c]) + 16);
+      prm.out[kOutFirstCol + 2 * c] = vals[c]->p;
+      if (!vbytes[c]) vbytes[c] = std::make_shared<DevBuf>();
+      if (d.out_cols[c].nullable) {
+        vbytes[c]->ensure((size_t)std::max<int64_t>(rows_cap, 1) + 16);
+        prm.out[kOutFirstCol + 2 * c + 1] = vbytes[c]->p;
+      }
+    }
+  };
+  // ---- single-pass probe (comet_device.hpp template D'): a small build side is hashed into LDS by every block, a large one into the
+  // chained global table; either way the probe counts and emits in one launch, reserving output ranges with one atomic per tile ----
+  const bool use_lds = B.rows > 0 && B.rows <= 6144 && getenv("COMET_JOIN_GLOBAL_TABLE") == nullptr;
+  if (!use_lds && B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+  DevBuf emitted_buf;
+  emitted_buf.ensure(64);
+  prm.out[47] = emitted_buf.p;
+  // FK-shaped joins emit at most one row per probe row; anything beyond the capacity is counted, not written, and the probe re-run
+  int64_t out_cap = d.join_build_only ? 1 : n + 1024;
+  for (int attempt = 0; n > 0; attempt++) {
+    bind_outputs(out_cap);
+    prm.iarg[6] = out_cap;
+    HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 8, stream_));
+    const int64_t ptiles = (n + 2047) / 2048;
+    launch(v, use_lds ? "k_jlds" : "k_jprobe", (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
+    uint64_t emitted = 0;
+    read_small(&emitted, emitted_buf.p, 8);
+    out_rows = d.join_build_only ? 0 : (int64_t)emitted;
+    if (out_rows <= out_cap) break;
+    if (attempt == 1) throw CometError("internal: hash join output exceeded its exact size");
+    out_cap = out_rows;
   }
+  const int64_t probe_capacity = n > 0 ? out_cap : 0;
   if (outer_build && B.rows > 0) {
     // build rows without a match follow the probe-driven rows
     launch(v, "k_jbcount", (int)std::min<int64_t>(nbtiles, 256 * 8), prm);
@@ -2274,17 +2294,17 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     prm.iarg[4] = out_rows;
   }
   const int64_t all_rows = out_rows + tail_rows;
-  for (size_t c = 0; c < ncol; c++) {
-    vals[c] = std::make_shared<DevBuf>();
-    vals[c]->ensure((size_t)std::max<int64_t>(all_rows, 1) * out_width(d.out_cols[c]) + 16);
-    prm.out[kOutFirstCol + 2 * c] = vals[c]->p;
-    vbytes[c] = std::make_shared<DevBuf>();
-    if (d.out_cols[c].nullable) {
-      vbytes[c]->ensure((size_t)std::max<int64_t>(all_rows, 1) + 16);
-      prm.out[kOutFirstCol + 2 * c + 1] = vbytes[c]->p;
+  if (all_rows > probe_capacity || (ncol > 0 && !vals[0])) {
+    // the unmatched build rows follow the probe-driven rows: grow the output buffers, keeping what the probe wrote
+    std::vector<std::shared_ptr<DevBuf>> ov = vals, ob = vbytes;
+    for (size_t c = 0; c < ncol; c++) { vals[c].reset(); vbytes[c].reset(); }
+    bind_outputs(all_rows);
+    for (size_t c = 0; c < ncol && out_rows > 0; c++) {
+      HIP_CHECK(hipMemcpyAsync(vals[c]->p, ov[c]->p, (size_t)out_rows * out_width(d.out_cols[c]), hipMemcpyDeviceToDevice, stream_));
+      if (d.out_cols[c].nullable) HIP_CHECK(hipMemcpyAsync(vbytes[c]->p, ob[c]->p, (size_t)out_rows, hipMemcpyDeviceToDevice, stream_));
     }
+    HIP_CHECK(hipStreamSynchronize(stream_));   // the old buffers return to the pool
   }
-  if (out_rows > 0) launch(v, "k_jemit", (int)std::min<int64_t>(ntiles, 256 * 8), prm);
   if (tail_rows > 0) launch(v, "k_jbemit", (int)std::min<int64_t>(nbtiles, 256 * 8), prm);
   timed_end();
   out_rows = all_rows;
