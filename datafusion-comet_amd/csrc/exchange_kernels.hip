@@ -264,6 +264,13 @@ __global__ __launch_bounds__(256) void fill_utf8_kernel(i32* offsets, u8* bytes,
   }
 }
 
+__global__ __launch_bounds__(256) void take_valid_bytes_kernel(const u8* bits, const u32* idx, i64 n, u8* out) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+    const u32 r = idx[k];
+    out[k] = (bits[r >> 3] >> (r & 7)) & 1;
+  }
+}
+
 int grid_for(i64 n) {
   i64 g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -320,6 +327,14 @@ int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, ui
   }
   hipLaunchKernelGGL(part_starts_kernel, 1, 256, 0, st, (const u64*)hist, P, W, (i64)n, (i64*)starts);
   if (n > 0) hipLaunchKernelGGL(part_index_kernel, grid, 256, lds, st, pids, (i64)n, P, W, (const u64*)hist, row_indices);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// out_bytes[k] = validity bit of row idx[k] as one byte (validity crosses the exchange one byte per row: partition boundaries are not
+// byte aligned)
+int comet_launch_take_valid_bytes(const uint8_t* valid_bits, const uint32_t* idx, int64_t n, uint8_t* out_bytes, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(take_valid_bytes_kernel, grid_for(n), 256, 0, (hipStream_t)stream, valid_bits, idx, (i64)n, out_bytes);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

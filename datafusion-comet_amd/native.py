@@ -95,6 +95,23 @@ def _load() -> ctypes.CDLL:
     lib.comet_columnar_to_row_close.argtypes = [c.c_int64]
     lib.comet_columnar_to_row_error.restype = c.c_char_p
     lib.comet_columnar_to_row_error.argtypes = [c.c_int64]
+    lib.comet_comm_unique_id.restype = c.c_int32
+    lib.comet_comm_unique_id.argtypes = [c.c_void_p]
+    lib.comet_comm_init_rank.restype = c.c_int64
+    lib.comet_comm_init_rank.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.c_int32]
+    lib.comet_comm_init_local.restype = c.c_int64
+    lib.comet_comm_init_local.argtypes = [c.c_int64, c.c_int32, c.c_int32, c.c_int32]
+    lib.comet_comm_destroy.restype = None
+    lib.comet_comm_destroy.argtypes = [c.c_int64]
+    lib.comet_exchange.restype = c.c_int64
+    lib.comet_exchange.argtypes = [c.c_int64, c.c_int32, c.c_void_p, c.c_int64, c.POINTER(c.c_int32), c.c_int32]
+    lib.comet_exchange_result_rows.restype = c.c_int64
+    lib.comet_exchange_result_rows.argtypes = [c.c_int64]
+    lib.comet_exchange_result_column.restype = c.c_int32
+    lib.comet_exchange_result_column.argtypes = [c.c_int64, c.c_int32, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p)]
+    lib.comet_exchange_result_release.restype = None
+    lib.comet_exchange_result_release.argtypes = [c.c_int64]
+    lib.comet_exchange_last_error.restype = c.c_char_p
     lib.comet_free_buffer.restype = None
     lib.comet_free_buffer.argtypes = [c.c_void_p]
     return lib
@@ -795,3 +812,77 @@ def compile_plan(plan: bytes) -> str:
     if rc != 0:
         _raise_last(0)
     return buf.value.decode()
+
+
+# --------------------------------------------------------------------------- in-library exchange (csrc/exchange.cpp)
+
+
+class CometExchangeColumnC(ctypes.Structure):
+    _fields_ = [("type_id", ctypes.c_int32), ("precision", ctypes.c_int32), ("values", ctypes.c_void_p), ("validity", ctypes.c_void_p)]
+
+
+class _ExchangeResult:
+    """Owns a comet_exchange result; the tensors built over its buffers keep it alive."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            lib().comet_exchange_result_release(self.handle)
+        except Exception:
+            pass
+
+
+class NativeComm:
+    """One rank of an in-library communicator: RCCL between processes (`unique_id` from NativeComm.unique_id() on rank 0, moved to the
+    other ranks by the launcher), or the in-process transport between the task threads of one process (`local_group`)."""
+
+    def __init__(self, world: int, rank: int, device_id: int = 0, unique_id: Optional[bytes] = None, local_group: Optional[int] = None):
+        if local_group is not None:
+            self.handle = lib().comet_comm_init_local(local_group, world, rank, device_id)
+        else:
+            buf = ctypes.create_string_buffer(unique_id if unique_id is not None else bytes(128), 128)
+            self.handle = lib().comet_comm_init_rank(buf, world, rank, device_id)
+        if not self.handle:
+            raise CometNativeException((lib().comet_exchange_last_error() or b"").decode())
+        self.world, self.rank, self.device_id = world, rank, device_id
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        if lib().comet_comm_unique_id(buf) != 0:
+            raise CometNativeException((lib().comet_exchange_last_error() or b"").decode())
+        return buf.raw
+
+    def close(self):
+        if self.handle:
+            lib().comet_comm_destroy(self.handle)
+            self.handle = 0
+
+    def exchange(self, table: "DeviceTable", key_cols: Sequence[int]) -> "DeviceTable":
+        """Collective hash exchange of this rank's shard on `key_cols` (fixed-width columns); returns partition `rank`."""
+        import torch
+        from . import serde as S
+        torch.cuda.current_stream(torch.device(table.device)).synchronize()     # the producer's work is complete before libcomet's stream reads
+        n = len(table.values)
+        cols = (CometExchangeColumnC * max(n, 1))()
+        for i, f in enumerate(table.schema):
+            t = S.from_arrow_type(f.type)
+            cols[i].type_id, cols[i].precision = t.type_id, t.precision
+            cols[i].values = table.values[i].data_ptr() if table.values[i].numel() else None
+            cols[i].validity = table.validity[i].data_ptr() if table.validity[i] is not None else None
+        keys = (ctypes.c_int32 * max(len(key_cols), 1))(*key_cols)
+        h = lib().comet_exchange(self.handle, n, cols, table.num_rows, keys, len(key_cols))
+        if not h:
+            raise CometNativeException((lib().comet_exchange_last_error() or b"").decode())
+        owner = _ExchangeResult(h)
+        rows = lib().comet_exchange_result_rows(h)
+        vals, valid = [], []
+        for i, f in enumerate(table.schema):
+            pv, pb = ctypes.c_void_p(), ctypes.c_void_p()
+            lib().comet_exchange_result_column(h, i, ctypes.byref(pv), ctypes.byref(pb))
+            w = value_width(f.type)
+            vals.append(torch.as_tensor(_DeviceBuffer(owner, pv.value, rows * w), device=table.device) if rows else torch.empty(0, dtype=torch.uint8, device=table.device))
+            valid.append(torch.as_tensor(_DeviceBuffer(owner, pb.value, (rows + 7) // 8), device=table.device) if (pb.value and rows) else None)
+        return DeviceTable(table.schema, rows, vals, valid, table.device, [None] * n)

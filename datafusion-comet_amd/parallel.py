@@ -85,6 +85,25 @@ class HipPartitioner:
         return native.partition_table(table, pids, num_partitions)
 
 
+class NativeExchange:
+    """Exchange done inside libcomet.so (csrc/exchange.cpp): partitioning kernels + RCCL send/recv groups (or the in-process transport),
+    no torch collective on the data path.  `comm` is a native.NativeComm."""
+
+    def __init__(self, comm):
+        self.comm = comm
+
+
+def native_comm_from_process_group(device_id: int, group=None):
+    """One NativeComm per rank of the torch process group: rank 0 draws the RCCL unique id, the launcher's rendezvous (the control
+    plane only) carries it to the other ranks."""
+    import torch.distributed as dist
+    from . import native
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [native.NativeComm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return native.NativeComm(world, rank, device_id, unique_id=box[0])
+
+
 def _unpack_bits(bits, n):
     import torch
     sh = torch.arange(8, device=bits.device, dtype=torch.uint8)
@@ -110,9 +129,11 @@ def exchange(table, key_cols, partitioner, group=None):
     import torch.distributed as dist
     from .native import DeviceTable, value_width
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    part, starts = partitioner(table, key_cols, world)
     if world == 1:
-        return part
+        return table        # one partition: nothing to hash or move (the reference's writer takes its SinglePartition path, no hashing)
+    if isinstance(partitioner, NativeExchange):
+        return partitioner.comm.exchange(table, key_cols)
+    part, starts = partitioner(table, key_cols, world)
     dev = part.values[0].device if part.values else torch.device(table.device)
     send = [starts[i + 1] - starts[i] for i in range(world)]
     t_send = torch.tensor(send, dtype=torch.int64, device=dev)

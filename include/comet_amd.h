@@ -134,6 +134,32 @@ int64_t comet_take_utf8_offsets(const int32_t* offsets, const uint8_t* validity_
 int32_t comet_take_utf8_bytes(const int32_t* offsets, const uint8_t* bytes, const uint8_t* validity_bits, const uint32_t* row_indices,
                               int64_t n, const int32_t* out_offsets, uint8_t* out_bytes, void* hip_stream);
 
+/* ---- in-library hash exchange between GPUs (csrc/exchange.cpp) ----------------------------------------------------
+ * The step Spark's exchange performs between two native stages, done GPU to GPU: rows are hash-partitioned exactly as the reference's
+ * shuffle writer does (murmur3 seed 42 chained over the key columns → pmod → partition_starts / partition_row_indices,
+ * native/shuffle/src/partitioners/multi_partition.rs:54-103, comet_partitioning.rs:51-57) and every rank receives partition `rank`:
+ * sender after sender in rank order, each sender's rows in input order.
+ *   comet_comm_unique_id / comet_comm_init_rank   one process per GPU: RCCL (dlopen'ed); the 128-byte id travels out of band
+ *   comet_comm_init_local                         N task threads of one process (one GPU each, or shared): in-process rendezvous +
+ *                                                 peer copies; every rank of `group_id` must call it with the same world size
+ * All calls return 0 / a positive handle on success; on failure -2 / 0 and comet_exchange_last_error() (thread local) tells why. */
+typedef struct CometExchangeColumn {
+  int32_t type_id;          /* spark_expression.DataType.DataTypeId of a fixed-width type */
+  int32_t precision;        /* decimals: selects the 8- or 16-byte hash form (hash_funcs/utils.rs:573-760) */
+  const void* values;       /* device pointer */
+  const uint8_t* validity;  /* device Arrow bitmap or NULL */
+} CometExchangeColumn;
+int32_t comet_comm_unique_id(uint8_t* out128);
+int64_t comet_comm_init_rank(const uint8_t* id128, int32_t world, int32_t rank, int32_t device_id);
+int64_t comet_comm_init_local(int64_t group_id, int32_t world, int32_t rank, int32_t device_id);
+void comet_comm_destroy(int64_t comm);
+/* Collective: every rank of the communicator calls it with its shard (rows may be 0).  Returns a result handle. */
+int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* cols, int64_t rows, const int32_t* key_cols, int32_t n_keys);
+int64_t comet_exchange_result_rows(int64_t result);
+int32_t comet_exchange_result_column(int64_t result, int32_t col, void** values, void** validity);   /* device pointers owned by the result */
+void comet_exchange_result_release(int64_t result);
+const char* comet_exchange_last_error(void);
+
 /* Replaces Java_org_apache_comet_Native_decodeShuffleBlock (native/core/src/execution/jni_api.rs:1163-1181 →
  * read_ipc_compressed, native/shuffle/src/ipc.rs:23-52): decodes ONE shuffle block — 4-byte codec tag "NONE" / "ZSTD" / "LZ4_" /
  * "SNAP" followed by the (compressed) Arrow IPC stream — and moves its single record batch into the caller-allocated Arrow C Data

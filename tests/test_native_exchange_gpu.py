@@ -1,0 +1,77 @@
+"""The exchange inside libcomet.so (csrc/exchange.cpp): several ranks meet through the in-process transport (threads of one
+process — the Spark-executor shape; here all on the one GPU of the test box), every rank receives exactly the rows Spark's HashPartitioning
+sends it (murmur3 seed 42 → pmod, the oracle's restatement), sender after sender, each sender's rows in input order; NULL keys hash as Spark
+hashes them; validity survives.  The RCCL transport is driven with a 1-rank communicator (AllGather + a send/recv group to itself): symbol
+binding, datatype constants and group semantics on real hardware; the N-rank run is bench.py --gpus N (tools/q3_dist.py)."""
+import threading
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native, serde as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _shard(seed, n):
+    rng = np.random.default_rng(seed)
+    return pa.table({
+        "k": pa.array(rng.integers(-10**12, 10**12, n), pa.int64(), mask=rng.random(n) < 0.05),
+        "d": pa.array(rng.integers(8000, 12000, n).astype(np.int32), pa.int32()).cast(pa.date32()),
+        "v": pa.array([__import__("decimal").Decimal(int(x)).scaleb(-2) for x in rng.integers(-10**10, 10**10, n)], pa.decimal128(12, 2),
+                      mask=(rng.random(n) < 0.1) if seed % 2 else None),
+        "f": pa.array(rng.standard_normal(n)),
+    })
+
+
+def _expected(shards, world, key_cols):
+    from oracle import oracle as O
+    out = []
+    for r in range(world):
+        parts = []
+        for sh in shards:
+            pids = O.hash_partition_ids(S, sh, key_cols, world)
+            parts.append(sh.filter(pa.array(pids == r)))
+        out.append(pa.concat_tables(parts))
+    return out
+
+
+@pytest.mark.parametrize("world,keys", [(2, [0]), (4, [0, 1]), (3, [2])])
+def test_local_transport_delivers_sparks_partitions(built, world, keys):
+    shards = [_shard(100 + r, 20_000 + 777 * r) for r in range(world)]
+    shards[-1] = shards[-1].slice(0, 0) if world == 3 else shards[-1]           # an empty sender
+    want = _expected(shards, world, keys)
+    got, errs = [None] * world, []
+    group = 7000 + world
+
+    def rank_main(r):
+        try:
+            comm = native.NativeComm(world, r, 0, local_group=group)
+            dt = native.DeviceTable.from_arrow(shards[r])
+            got[r] = comm.exchange(dt, keys).to_arrow()
+            again = comm.exchange(dt, keys).to_arrow()                        # a communicator is reusable
+            assert again.equals(got[r])
+            comm.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    for r in range(world):
+        assert got[r].num_rows == want[r].num_rows
+        for c in range(4):
+            assert got[r].column(c).to_pylist() == want[r].column(c).to_pylist(), (r, c)
+
+
+def test_rccl_transport_with_a_one_rank_communicator(built, monkeypatch):
+    monkeypatch.setenv("COMET_EXCHANGE_FORCE_RCCL", "1")
+    sh = _shard(5, 30_000)
+    comm = native.NativeComm(1, 0, 0, unique_id=native.NativeComm.unique_id())
+    out = comm.exchange(native.DeviceTable.from_arrow(sh), [0]).to_arrow()
+    comm.close()
+    for c in range(4):
+        assert out.column(c).to_pylist() == sh.column(c).to_pylist()
