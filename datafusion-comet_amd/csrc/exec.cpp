@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -281,6 +282,126 @@ bool format_matches(const char* fmt, const DType& t) {
     return f == e || f == e + ",128";
   }
   return f == expected_format(t);
+}
+
+// ---- ScanExec's cast of stream columns to the declared types (operators/scan.rs:281-291 → arrow::compute::cast_with_options with the
+// default CastOptions: safe, i.e. a value the target cannot hold becomes NULL) — the numeric / temporal / decimal subset the JVM side can
+// produce: integer widths and signedness, float widths, int ↔ float, Date64, timestamp units, decimal precision / scale, LargeUtf8 ----
+struct SrcFmt {
+  enum Cls { Unknown, Int, UInt, F32, F64, Date32, Date64, Ts, Dec, Utf8, LargeUtf8, Bool } cls = Unknown;
+  int width = 0;
+  int64_t per_second = 0;   // Ts: ticks per second
+  int p = 0, s = 0;         // Dec
+};
+SrcFmt parse_src_format(const char* fmt) {
+  SrcFmt f;
+  if (!fmt) return f;
+  const std::string x = fmt;
+  auto intw = [&](char c) { return c == 'c' || c == 'C' ? 1 : c == 's' || c == 'S' ? 2 : c == 'i' || c == 'I' ? 4 : 8; };
+  if (x.size() == 1 && strchr("csil", x[0])) { f.cls = SrcFmt::Int; f.width = intw(x[0]); }
+  else if (x.size() == 1 && strchr("CSIL", x[0])) { f.cls = SrcFmt::UInt; f.width = intw(x[0]); }
+  else if (x == "f") { f.cls = SrcFmt::F32; f.width = 4; }
+  else if (x == "g") { f.cls = SrcFmt::F64; f.width = 8; }
+  else if (x == "b") { f.cls = SrcFmt::Bool; }
+  else if (x == "u" || x == "z") { f.cls = SrcFmt::Utf8; }
+  else if (x == "U" || x == "Z") { f.cls = SrcFmt::LargeUtf8; }
+  else if (x == "tdD") { f.cls = SrcFmt::Date32; f.width = 4; }
+  else if (x == "tdm") { f.cls = SrcFmt::Date64; f.width = 8; }
+  else if (x.rfind("ts", 0) == 0 && x.size() >= 4 && x[3] == ':') {
+    f.cls = SrcFmt::Ts; f.width = 8;
+    f.per_second = x[2] == 's' ? 1 : x[2] == 'm' ? 1000 : x[2] == 'u' ? 1000000 : x[2] == 'n' ? 1000000000 : 0;
+    if (!f.per_second) f.cls = SrcFmt::Unknown;
+  } else if (x.rfind("d:", 0) == 0) {
+    int bits = 128;
+    if (sscanf(x.c_str(), "d:%d,%d,%d", &f.p, &f.s, &bits) >= 2 && bits == 128) { f.cls = SrcFmt::Dec; f.width = 16; }
+  }
+  return f;
+}
+bool scan_cast_supported(const SrcFmt& f, const DType& t) {
+  const bool tint = t.is_integer(), tflt = t.is_float();
+  switch (f.cls) {
+    case SrcFmt::Int: case SrcFmt::UInt: return tint || tflt || t.id == TypeId::Decimal || (f.cls == SrcFmt::Int && f.width == 4 && t.id == TypeId::Date) ||
+                                                (f.cls == SrcFmt::Int && f.width == 8 && (t.id == TypeId::Timestamp || t.id == TypeId::TimestampNtz));
+    case SrcFmt::F32: case SrcFmt::F64: return tint || tflt;
+    case SrcFmt::Date32: return t.id == TypeId::Int32 || t.id == TypeId::Int64;
+    case SrcFmt::Date64: return t.id == TypeId::Date || t.id == TypeId::Int64;
+    case SrcFmt::Ts: return t.id == TypeId::Timestamp || t.id == TypeId::TimestampNtz || t.id == TypeId::Int64;
+    case SrcFmt::Dec: return t.id == TypeId::Decimal || tint;
+    case SrcFmt::LargeUtf8: return t.id == TypeId::String || t.id == TypeId::Bytes;
+    default: return false;
+  }
+}
+i128 cast_pow10(int e) { i128 r = 1; for (int i = 0; i < e; i++) r *= 10; return r; }
+// one source value (row `i` of a column buffer) → the declared type at dst; false = NULL (safe cast)
+bool scan_cast_value(const SrcFmt& f, const char* src, int64_t i, const DType& t, char* dst) {
+  // read
+  int64_t iv = 0; uint64_t uv = 0; double dv = 0; i128 xv = 0;
+  enum { I, U, D, X } k = I;
+  switch (f.cls) {
+    case SrcFmt::Int: case SrcFmt::Date32: case SrcFmt::Date64: case SrcFmt::Ts:
+      switch (f.width) { case 1: iv = ((const int8_t*)src)[i]; break; case 2: iv = ((const int16_t*)src)[i]; break; case 4: { int32_t v; memcpy(&v, src + i * 4, 4); iv = v; break; }
+                         default: memcpy(&iv, src + i * 8, 8); }
+      break;
+    case SrcFmt::UInt:
+      switch (f.width) { case 1: uv = ((const uint8_t*)src)[i]; break; case 2: { uint16_t v; memcpy(&v, src + i * 2, 2); uv = v; break; } case 4: { uint32_t v; memcpy(&v, src + i * 4, 4); uv = v; break; }
+                         default: memcpy(&uv, src + i * 8, 8); }
+      k = U;
+      break;
+    case SrcFmt::F32: { float v; memcpy(&v, src + i * 4, 4); dv = v; k = D; break; }
+    case SrcFmt::F64: memcpy(&dv, src + i * 8, 8); k = D; break;
+    case SrcFmt::Dec: memcpy(&xv, src + i * 16, 16); k = X; break;
+    default: return false;
+  }
+  // temporal rescaling first (integers)
+  if (f.cls == SrcFmt::Date64 && t.id == TypeId::Date) iv = iv / 86400000;            // arrow: ms / MILLISECONDS_IN_DAY (truncating)
+  if (f.cls == SrcFmt::Ts && (t.id == TypeId::Timestamp || t.id == TypeId::TimestampNtz) && f.per_second != 1000000) {
+    if (f.per_second > 1000000) iv = iv / (f.per_second / 1000000);                     // finer → µs: truncating division (arrow unary `/`)
+    else if (__builtin_mul_overflow(iv, (int64_t)(1000000 / f.per_second), &iv)) return false;   // coarser → µs: checked multiply
+  }
+  auto store_int = [&](i128 v) -> bool {   // range-checked narrowing (num::cast): out of range → NULL
+    switch (t.id) {
+      case TypeId::Int8: if (v < -128 || v > 127) return false; { int8_t o = (int8_t)v; memcpy(dst, &o, 1); } return true;
+      case TypeId::Int16: if (v < -32768 || v > 32767) return false; { int16_t o = (int16_t)v; memcpy(dst, &o, 2); } return true;
+      case TypeId::Int32: case TypeId::Date: if (v < INT32_MIN || v > INT32_MAX) return false; { int32_t o = (int32_t)v; memcpy(dst, &o, 4); } return true;
+      default: if (v < (i128)INT64_MIN || v > (i128)INT64_MAX) return false; { int64_t o = (int64_t)v; memcpy(dst, &o, 8); } return true;
+    }
+  };
+  if (t.is_integer() || t.id == TypeId::Date || t.id == TypeId::Timestamp || t.id == TypeId::TimestampNtz) {
+    if (k == I) return store_int(iv);
+    if (k == U) return store_int((i128)uv);
+    if (k == D) {                          // float → int: truncate toward zero; NaN / out of range → NULL
+      if (!(dv == dv)) return false;
+      const double tr = dv < 0 ? ceil(dv) : floor(dv);
+      if (tr < -9223372036854775808.0 || tr >= 9223372036854775808.0) return false;
+      return store_int((i128)(int64_t)tr);
+    }
+    // decimal → int: unscaled / 10^scale (truncating), then the range check
+    return store_int(xv / cast_pow10(f.s));
+  }
+  if (t.id == TypeId::Float || t.id == TypeId::Double) {
+    const double v = k == I ? (double)iv : k == U ? (double)uv : dv;
+    if (t.id == TypeId::Float) { float o = k == I ? (float)iv : k == U ? (float)uv : (float)dv; memcpy(dst, &o, 4); }
+    else memcpy(dst, &v, 8);
+    return true;
+  }
+  if (t.id == TypeId::Decimal) {
+    i128 v;
+    const i128 bound = cast_pow10(t.precision) - 1;
+    if (k == X) {
+      const int up = t.scale - f.s;
+      if (up >= 0) { if (__builtin_mul_overflow(xv, cast_pow10(up), &v)) return false; }
+      else {
+        const i128 div = cast_pow10(-up), half = div / 2, d = xv / div, r = xv % div;   // round half away from zero
+        v = xv >= 0 ? (r >= half ? d + 1 : d) : (r <= -half ? d - 1 : d);
+      }
+    } else if (k == I || k == U) {
+      if (__builtin_mul_overflow(k == I ? (i128)iv : (i128)uv, cast_pow10(t.scale), &v)) return false;
+    } else return false;
+    if (v > bound || v < -bound) return false;
+    memcpy(dst, &v, 16);
+    return true;
+  }
+  return false;
 }
 
 const Operator* find_scan(const Operator* op) {
@@ -1437,9 +1558,15 @@ void ExecutionContext::validate_input_schema(size_t input, const std::vector<DTy
     for (size_t c = 0; c < types.size() && err.empty(); c++) {
       const ArrowSchema* f = sch.children[c];
       const char* fmt = f->dictionary ? f->dictionary->format : f->format;
-      if (!format_matches(fmt, types[c]))
-        err = "Scan input column " + std::to_string(c) + " has Arrow format '" + (fmt ? fmt : "?") + "' but the plan declares " + types[c].str() +
-              " (casting scan inputs to the declared type is not supported by the MI355X native engine yet)";
+      if (format_matches(fmt, types[c])) continue;
+      if (in.kind == 0 && !f->dictionary && scan_cast_supported(parse_src_format(fmt), types[c])) {
+        if (scan_cast_from_.size() <= input) scan_cast_from_.resize(input + 1);
+        scan_cast_from_[input].resize(types.size());
+        scan_cast_from_[input][c] = fmt;
+        continue;
+      }
+      err = "Scan input column " + std::to_string(c) + " has Arrow format '" + (fmt ? fmt : "?") + "' but the plan declares " + types[c].str() +
+            " (this cast of a scan input is not supported by the MI355X native engine" + (in.kind == 0 ? ")" : "; device-resident inputs are never cast)");
     }
   }
   sch.release(&sch);
@@ -1520,6 +1647,13 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
   for (auto& a : held)
     for (size_t c = 0; c < nc; c++)
       if (a.children[c]->null_count != 0 && a.children[c]->buffers[0]) has_valid[c] = true;
+  std::vector<SrcFmt> cast_from(nc);
+  if (scan_cast_from_.size() > input)
+    for (size_t c = 0; c < nc && c < scan_cast_from_[input].size(); c++)
+      if (!scan_cast_from_[input][c].empty()) {
+        cast_from[c] = parse_src_format(scan_cast_from_[input][c].c_str());
+        if (cast_from[c].cls != SrcFmt::LargeUtf8) has_valid[c] = true;   // a safe cast turns what does not fit into NULL
+      }
   std::vector<size_t> aux_bytes(nc, 0);
   std::vector<int> str_uniform_(nc, -1);
   // index width of dictionary-encoded columns comes from the stream schema (fetched once per input)
@@ -1639,10 +1773,13 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
     if (t.id == TypeId::String || t.id == TypeId::Bytes) {
       // Utf8: int32 offsets rebased to the chunk + concatenated bytes
       size_t total_bytes = 0;
+      const bool large = cast_from[c].cls == SrcFmt::LargeUtf8;     // LargeUtf8 / LargeBinary: int64 offsets, cast to the declared Utf8
+      auto off_at = [large](const ArrowArray* col, int64_t i) -> int64_t {
+        return large ? ((const int64_t*)col->buffers[1])[col->offset + i] : (int64_t)((const int32_t*)col->buffers[1])[col->offset + i];
+      };
       for (auto& a : held) {
         const ArrowArray* col = a.children[c];
-        const int32_t* off = (const int32_t*)col->buffers[1];
-        total_bytes += (size_t)(off[col->offset + col->length] - off[col->offset]);
+        total_bytes += (size_t)(off_at(col, col->length) - off_at(col, 0));
       }
       if (total_bytes > 0x7fffffffull) throw CometError("Utf8 chunk exceeds 2 GiB of string bytes; lower spark.comet.gpu.chunkRows");
       stage_vals_[c]->ensure((size_t)(rows + 1) * 4 + 16);
@@ -1655,15 +1792,15 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
       for (auto& a : held) {
         const ArrowArray* col = a.children[c];
         if (col->dictionary) throw CometError("dictionary-encoded input columns are not unpacked on the GPU path yet");
-        const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
-        const int32_t base = off[0];
+        const int64_t base = off_at(col, 0);
         for (int64_t i = 0; i < col->length; i++) {
-          so[at + i] = pos + (off[i] - base);
-          const int len = off[i + 1] - off[i];
+          const int64_t o = off_at(col, i);
+          so[at + i] = pos + (int32_t)(o - base);
+          const int len = (int)(off_at(col, i + 1) - o);
           if (uniform == -2) uniform = len;
           else if (uniform != len) uniform = -1;
         }
-        size_t nb = (size_t)(off[col->length] - base);
+        size_t nb = (size_t)(off_at(col, col->length) - base);
         if (nb) memcpy((char*)stage_aux_[c]->p + pos, (const char*)col->buffers[2] + base, nb);
         if (has_valid[c]) {
           if (col->null_count != 0 && col->buffers[0]) bit_append((uint8_t*)stage_valid_[c]->p, at, (const uint8_t*)col->buffers[0], col->offset, col->length);
@@ -1698,6 +1835,25 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
       if (col->dictionary) throw CometError("dictionary-encoded input columns are not unpacked on the GPU path yet");
       const int64_t len = col->length, off = col->offset;
       if (len != a.length) throw CometError("ragged input batch");
+      if (cast_from[c].cls != SrcFmt::Unknown) {
+        // ScanExec's cast to the declared type, fused into the staging copy; validity = source validity AND "the value fits"
+        if (col->null_count != 0 && col->buffers[0]) bit_append((uint8_t*)stage_valid_[c]->p, at, (const uint8_t*)col->buffers[0], off, len);
+        else bit_fill_ones((uint8_t*)stage_valid_[c]->p, at, len);
+        if (!w) throw CometError("casting a scan input to Boolean is not supported");
+        const char* src = (const char*)col->buffers[1] + (size_t)off * (size_t)cast_from[c].width;
+        char* dst = (char*)stage_vals_[c]->p + (size_t)at * w;
+        uint8_t* vb = (uint8_t*)stage_valid_[c]->p;
+        for (int64_t i = 0; i < len; i++) {
+          const int64_t bit = at + i;
+          const bool ok = ((vb[bit >> 3] >> (bit & 7)) & 1) && scan_cast_value(cast_from[c], src, i, t, dst + (size_t)i * w);
+          if (!ok) {
+            vb[bit >> 3] &= (uint8_t)~(1u << (bit & 7));
+            memset(dst + (size_t)i * w, 0, (size_t)w);
+          }
+        }
+        at += len;
+        continue;
+      }
       if (w) {
         // Decimal128 buffers from the JVM may be only 8-byte aligned (aligned_stream_reader.rs:95-107);
         // the staging copy realigns them.

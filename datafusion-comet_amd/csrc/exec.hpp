@@ -219,6 +219,10 @@ class ExecutionContext {
   std::vector<std::unique_ptr<Staging>> staging_;   // per input stream
   int stage_parity_ = 0;                            // which of the two staging sets the next streamed chunk uses
   std::vector<bool> schema_checked_;                // per input stream
+  // ScanExec casts a stream column whose Arrow type differs from the declared one (operators/scan.rs:281-291, arrow cast_with_options,
+  // safe mode: a value that does not fit becomes NULL).  Per input stream and column: the source column's Arrow format when a cast is
+  // needed ("" = the types agree); the conversion happens in the pinned staging copy every host batch goes through anyway
+  std::vector<std::vector<std::string>> scan_cast_from_;
 
   // aggregate state
   DevBuf partials_;
