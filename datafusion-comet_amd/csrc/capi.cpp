@@ -137,6 +137,141 @@ int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* c
   });
 }
 
+// ---- org.apache.comet.parquet.Native: the record-batch reader the iceberg-compat scan drives (native/core/src/parquet/mod.rs:133-330).
+// One file (byte ranges select its row groups), schemas as Arrow IPC schema messages, an optional pushed filter; every batch is decoded
+// by the same NativeScan machinery as Operator.native_scan (parquet_scan.cpp), columns are handed out one at a time. ----
+namespace {
+struct ParquetReader {
+  std::shared_ptr<ExecutionContext> ctx;
+  std::vector<ArrowArray> arrays;
+  std::vector<ArrowSchema> schemas;
+  bool have_batch = false, done = false;
+  std::string error;
+  void drop_batch() {
+    for (auto& a : arrays) if (a.release) a.release(&a);
+    for (auto& sc : schemas) if (sc.release) sc.release(&sc);
+    have_batch = false;
+  }
+  ~ParquetReader() { drop_batch(); }
+};
+std::mutex g_pq_mu;
+std::map<int64_t, std::shared_ptr<ParquetReader>> g_pq;
+int64_t g_pq_next = 1;
+std::shared_ptr<ParquetReader> pq_lookup(int64_t h) {
+  std::lock_guard<std::mutex> lk(g_pq_mu);
+  auto it = g_pq.find(h);
+  return it == g_pq.end() ? nullptr : it->second;
+}
+// the pushed filter is bound to data_schema positions; the scan's pruning binds to required_schema — re-bind by name, or drop the filter
+// (it is a pruning hint only: parquet_exec.rs:166-176)
+ExprP rebind_filter(const ExprP& e, const std::vector<StructField>& data, const std::vector<StructField>& required, bool& ok) {
+  if (!e) return e;
+  auto n = std::make_shared<Expr>(*e);
+  if (e->kind == ExprKind::Bound) {
+    n->bound_index = -1;
+    if (e->bound_index >= 0 && (size_t)e->bound_index < data.size())
+      for (size_t i = 0; i < required.size(); i++)
+        if (required[i].name == data[(size_t)e->bound_index].name) n->bound_index = (int)i;
+    if (n->bound_index < 0) ok = false;
+    return n;
+  }
+  for (auto& c : n->children) c = rebind_filter(c, data, required, ok);
+  return n;
+}
+}  // namespace
+
+int64_t comet_parquet_reader_init(const char* file_path, int64_t file_size, const int64_t* starts, const int64_t* lengths, int32_t n_ranges,
+                                  const uint8_t* filter, size_t filter_len, const uint8_t* required_schema_ipc, size_t required_len,
+                                  const uint8_t* data_schema_ipc, size_t data_len, const char* session_timezone, int32_t batch_size,
+                                  int32_t case_sensitive, int32_t device_id) {
+  return guarded(nullptr, (int64_t)0, [&]() -> int64_t {
+    if (!file_path || !required_schema_ipc) throw CometError("initRecordBatchReader: file path and required schema are mandatory");
+    auto op = std::make_shared<Operator>();
+    op->kind = OpKind::NativeScan;
+    op->proto_tag = 111;
+    op->required_schema = decode_ipc_schema(required_schema_ipc, required_len);
+    op->data_schema = data_schema_ipc && data_len ? decode_ipc_schema(data_schema_ipc, data_len) : op->required_schema;
+    for (auto& f : op->required_schema) op->scan_fields.push_back(f.dtype);
+    for (size_t i = 0; i < op->required_schema.size(); i++) op->projection_vector.push_back((int64_t)i);
+    op->session_timezone = session_timezone ? session_timezone : "UTC";
+    op->case_sensitive = case_sensitive != 0;
+    op->allow_type_promotion = true;            // the JVM side already validated the types (TypeUtil.checkParquetType), mod.rs:228-229
+    op->allow_timestamp_ltz_to_ntz = true;
+    const std::string path = file_path;
+    if (n_ranges <= 0) {
+      PartitionedFile pf;
+      pf.file_path = path; pf.start = 0; pf.length = file_size; pf.file_size = file_size;
+      op->files.push_back(pf);
+    }
+    for (int32_t i = 0; i < n_ranges; i++) {
+      PartitionedFile pf;
+      pf.file_path = path; pf.start = starts[i]; pf.length = lengths[i]; pf.file_size = file_size;
+      op->files.push_back(pf);
+    }
+    if (filter && filter_len) {
+      bool ok = true;
+      ExprP f = rebind_filter(decode_expr_bytes(filter, filter_len), op->data_schema, op->required_schema, ok);
+      if (ok) op->data_filters.push_back(f);
+    }
+    uint64_t h = plan_bytes_hash(required_schema_ipc, required_len) ^ 0x70617271ull;
+    auto r = std::make_shared<ParquetReader>();
+    r->ctx = std::make_shared<ExecutionContext>(op, h, std::vector<std::pair<std::string, std::string>>(), std::vector<InputSource>(), batch_size, device_id);
+    r->arrays.resize(op->required_schema.size());
+    r->schemas.resize(op->required_schema.size());
+    for (auto& a : r->arrays) memset(&a, 0, sizeof a);
+    for (auto& sc : r->schemas) memset(&sc, 0, sizeof sc);
+    std::lock_guard<std::mutex> lk(g_pq_mu);
+    int64_t handle = g_pq_next++;
+    g_pq[handle] = r;
+    return handle;
+  });
+}
+
+int32_t comet_parquet_reader_next(int64_t handle) {
+  auto r = pq_lookup(handle);
+  if (!r) { t_last_error = "invalid parquet reader handle"; return -2; }
+  return guarded(r->ctx.get(), (int32_t)-2, [&]() -> int32_t {
+    r->drop_batch();
+    if (r->done) return 0;
+    std::vector<ArrowArray*> ap;
+    std::vector<ArrowSchema*> sp;
+    for (auto& a : r->arrays) ap.push_back(&a);
+    for (auto& sc : r->schemas) sp.push_back(&sc);
+    const int64_t rows = r->ctx->execute(ap.data(), sp.data(), (int)ap.size());
+    if (rows < 0) { r->done = true; return 0; }          // end of file (mod.rs:268-276: rows_read stays 0)
+    if (rows > INT32_MAX) throw CometError("readNextRecordBatch: batch larger than 2^31 rows");
+    r->have_batch = true;
+    return (int32_t)rows;
+  });
+}
+
+int32_t comet_parquet_reader_column(int64_t handle, int32_t column, struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+  auto r = pq_lookup(handle);
+  if (!r) { t_last_error = "invalid parquet reader handle"; return -2; }
+  return guarded(r->ctx.get(), (int32_t)-2, [&]() -> int32_t {
+    if (!r->have_batch) throw CometError("There is no more data to read");      // mod.rs:305-307
+    if (column < 0 || (size_t)column >= r->arrays.size()) throw CometError("currentColumnBatch: column index out of range");
+    if (!r->arrays[(size_t)column].release) throw CometError("currentColumnBatch: this column of the current batch was already taken");
+    *out_array = r->arrays[(size_t)column];                  // move (Arrow C data interface: copy the struct, mark the source released)
+    *out_schema = r->schemas[(size_t)column];
+    r->arrays[(size_t)column].release = nullptr;
+    r->schemas[(size_t)column].release = nullptr;
+    return 0;
+  });
+}
+
+void comet_parquet_reader_close(int64_t handle) {
+  std::shared_ptr<ParquetReader> r;
+  {
+    std::lock_guard<std::mutex> lk(g_pq_mu);
+    auto it = g_pq.find(handle);
+    if (it == g_pq.end()) return;
+    r = it->second;
+    g_pq.erase(it);
+  }
+  r.reset();
+}
+
 int64_t comet_execute_plan(int64_t handle, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas, int32_t n_out) {
   auto ctx = lookup(handle);
   if (!ctx) {

@@ -386,4 +386,48 @@ JNIEXPORT jobject JNICALL Java_org_apache_comet_Native_columnarToRowConvert(JNIE
 }
 JNIEXPORT void JNICALL Java_org_apache_comet_Native_columnarToRowClose(JNIEnv*, jclass, jlong handle) { comet_columnar_to_row_close(handle); }
 
+
+// ---- org.apache.comet.parquet.Native (native/core/src/parquet/mod.rs:135-330): the record-batch reader of the iceberg-compat scan ----
+JNIEXPORT jlong JNICALL Java_org_apache_comet_parquet_Native_initRecordBatchReader(
+    JNIEnv* env, jclass, jstring filePath, jlong fileSize, jlongArray starts, jlongArray lengths, jbyteArray filter, jbyteArray requiredSchema,
+    jbyteArray dataSchema, jstring sessionTimezone, jint batchSize, jboolean caseSensitive, jboolean /*returnNullStructIfAllFieldsMissing*/,
+    jobject /*objectStoreOptions*/, jobject keyUnwrapper, jobject /*metricsNode*/) {
+  if (keyUnwrapper) { throw_java(env, COMET_ERR_NATIVE, "Parquet modular encryption is not supported by the MI355X native engine"); return 0; }
+  if (!filePath) { throw_java(env, COMET_ERR_NATIVE, "initRecordBatchReader: null file path"); return 0; }
+  const char* p = jni_GetStringUTFChars(env, filePath);
+  std::string path = p ? p : "";
+  if (p) jni_ReleaseStringUTFChars(env, filePath, p);
+  std::string tz = "UTC";
+  if (sessionTimezone) {
+    const char* t = jni_GetStringUTFChars(env, sessionTimezone);
+    if (t) { tz = t; jni_ReleaseStringUTFChars(env, sessionTimezone, t); }
+  }
+  const jsize ns = starts ? jni_GetArrayLength(env, starts) : 0, nl = lengths ? jni_GetArrayLength(env, lengths) : 0;
+  if (ns != nl) { throw_java(env, COMET_ERR_NATIVE, "initRecordBatchReader: starts and lengths differ in length"); return 0; }
+  std::vector<jlong> st((size_t)ns), ln((size_t)ns);
+  if (ns) {
+    jni_GetLongArrayRegion(env, starts, 0, ns, st.data());
+    jni_GetLongArrayRegion(env, lengths, 0, ns, ln.data());
+  }
+  std::vector<uint8_t> f = byte_array(env, filter), rs = byte_array(env, requiredSchema), ds = byte_array(env, dataSchema);
+  static_assert(sizeof(jlong) == sizeof(int64_t), "jlong is 64 bits");
+  int64_t h = comet_parquet_reader_init(path.c_str(), (int64_t)fileSize, (const int64_t*)st.data(), (const int64_t*)ln.data(), (int32_t)ns,
+                                        f.empty() ? nullptr : f.data(), f.size(), rs.empty() ? nullptr : rs.data(), rs.size(),
+                                        ds.empty() ? nullptr : ds.data(), ds.size(), tz.c_str(), (int32_t)batchSize, caseSensitive ? 1 : 0, pick_device(0));
+  if (h == 0) { throw_java(env, comet_last_error_kind(0), comet_last_error(0)); return 0; }
+  return (jlong)h;
+}
+JNIEXPORT jint JNICALL Java_org_apache_comet_parquet_Native_readNextRecordBatch(JNIEnv* env, jclass, jlong handle) {
+  const int32_t rows = comet_parquet_reader_next((int64_t)handle);
+  if (rows == -2) { throw_java(env, comet_last_error_kind(0), comet_last_error(0)); return 0; }
+  return (jint)rows;
+}
+JNIEXPORT void JNICALL Java_org_apache_comet_parquet_Native_currentColumnBatch(JNIEnv* env, jclass, jlong handle, jint columnIdx, jlong arrayAddr,
+                                                                               jlong schemaAddr) {
+  if (comet_parquet_reader_column((int64_t)handle, (int32_t)columnIdx, (struct ArrowArray*)(intptr_t)arrayAddr, (struct ArrowSchema*)(intptr_t)schemaAddr) != 0)
+    throw_java(env, comet_last_error_kind(0), comet_last_error(0));
+}
+JNIEXPORT void JNICALL Java_org_apache_comet_parquet_Native_closeRecordBatchReader(JNIEnv*, jclass, jlong handle) {
+  comet_parquet_reader_close((int64_t)handle);
+}
 }  // extern "C"

@@ -200,6 +200,7 @@ struct Operator {
 
 // proto.cpp
 OperatorP decode_operator(const uint8_t* data, size_t len);
+ExprP decode_expr_bytes(const uint8_t* data, size_t len);   // one serialized spark_expression.Expr
 DType decode_datatype_bytes(const uint8_t* data, size_t len);   // one serialized spark_expression.DataType (types.proto:27-41)
 std::vector<std::pair<std::string, std::string>> decode_config_map(const uint8_t* data, size_t len);
 // NativeMetricNode encoder (metric.proto:26-29)

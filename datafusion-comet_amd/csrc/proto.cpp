@@ -663,6 +663,7 @@ void put_varint(std::string& s, uint64_t v) {
 }  // namespace
 
 OperatorP decode_operator(const uint8_t* data, size_t len) { return decode_operator_r(Reader(data, len)); }
+ExprP decode_expr_bytes(const uint8_t* data, size_t len) { return decode_expr(Reader(data, len)); }
 DType decode_datatype_bytes(const uint8_t* data, size_t len) { return decode_datatype(Reader(data, len)); }
 
 std::vector<std::pair<std::string, std::string>> decode_config_map(const uint8_t* data, size_t len) {

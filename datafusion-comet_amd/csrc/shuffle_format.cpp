@@ -943,6 +943,42 @@ HostColumn unpack_dictionary(const HostColumn& idx, int index_width, const HostC
   return out;
 }
 
+// The Schema message at the head of an Arrow IPC stream → field names, types and nullability (the JVM hands schemas over this way:
+// parquet/util/jni.rs deserialize_schema = StreamReader::try_new(bytes).schema()).  Field custom_metadata "PARQUET:field_id" is kept.
+std::vector<StructField> decode_ipc_schema_impl(const uint8_t* p, size_t n) {
+  size_t pos = 0;
+  if (n < 8) throw CometError("Arrow IPC schema: truncated");
+  int32_t meta_len;
+  if (rd<uint32_t>(p) == 0xFFFFFFFFu) { meta_len = rd<int32_t>(p + 4); pos = 8; }
+  else { meta_len = rd<int32_t>(p); pos = 4; }
+  if (meta_len < 8 || pos + (size_t)meta_len > n) throw CometError("Arrow IPC schema: truncated metadata");
+  FbTable msg;
+  msg.buf = p + pos;
+  msg.len = (size_t)meta_len;
+  msg.pos = rd<uint32_t>(msg.buf);
+  if (msg.pos + 4 > msg.len || msg.get<uint8_t>(1, 0) != MSG_Schema) throw CometError("Arrow IPC schema: the stream does not start with a Schema message");
+  FbTable header = msg.child(2);
+  if (!header.valid()) throw CometError("Arrow IPC schema: message without header");
+  std::vector<StructField> out;
+  size_t first;
+  const size_t nf = header.vec(1, 4, first);
+  for (size_t i = 0; i < nf; i++) {
+    FbTable f = header.elem_table(first, i);
+    StructField sf;
+    sf.name = f.str(0);
+    sf.nullable = f.get<uint8_t>(1, 0) != 0;
+    sf.dtype = type_from_fb(f.get<uint8_t>(2, 0), f.child(3));
+    size_t kv0;
+    const size_t nkv = f.vec(6, 4, kv0);        // Field.custom_metadata: [KeyValue{key, value}]
+    for (size_t k = 0; k < nkv; k++) {
+      FbTable kv = f.elem_table(kv0, k);
+      if (kv.str(0) == "PARQUET:field_id") sf.field_id = atoi(kv.str(1).c_str());
+    }
+    out.push_back(sf);
+  }
+  return out;
+}
+
 HostBatch decode_ipc_stream(const uint8_t* p, size_t n) {
   std::vector<IpcField> fields;
   std::map<int64_t, HostColumn> dictionaries;
@@ -1035,6 +1071,8 @@ HostBatch decode_ipc_stream(const uint8_t* p, size_t n) {
 const uint8_t kIpcEos[8] = {0xff, 0xff, 0xff, 0xff, 0, 0, 0, 0};
 
 }  // namespace
+
+std::vector<StructField> decode_ipc_schema(const uint8_t* p, size_t n) { return decode_ipc_schema_impl(p, n); }
 
 size_t encode_shuffle_block(const std::vector<ColumnSlice>& cols, int64_t rows, ShuffleCodec codec, int level, std::vector<uint8_t>& out) {
   if (rows == 0) return 0;

@@ -57,6 +57,9 @@ struct CometShuffleBlockStreamC {
 };
 // wraps it as an ArrowArrayStream of struct arrays (one per block), so a ShuffleScan leaf runs through the same host-input
 // path as a Scan leaf; takes ownership of `blocks`
+// schema message of an Arrow IPC stream → fields (names, types, nullability, PARQUET:field_id)
+std::vector<StructField> decode_ipc_schema(const uint8_t* p, size_t n);
+
 ArrowArrayStream* shuffle_blocks_as_arrow_stream(CometShuffleBlockStreamC* blocks, std::vector<DType> types);
 
 }  // namespace comet

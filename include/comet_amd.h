@@ -134,6 +134,20 @@ int64_t comet_take_utf8_offsets(const int32_t* offsets, const uint8_t* validity_
 int32_t comet_take_utf8_bytes(const int32_t* offsets, const uint8_t* bytes, const uint8_t* validity_bits, const uint32_t* row_indices,
                               int64_t n, const int32_t* out_offsets, uint8_t* out_bytes, void* hip_stream);
 
+/* ---- org.apache.comet.parquet.Native — the record-batch reader of the iceberg-compat scan path ----------------------------------
+ * Replaces Java_org_apache_comet_parquet_Native_{initRecordBatchReader, readNextRecordBatch, currentColumnBatch, closeRecordBatchReader}
+ * (native/core/src/parquet/mod.rs:135-330).  required / data schema: the bytes of an Arrow IPC stream's Schema message (what the JVM
+ * sends; parquet/util/jni.rs:21-27); filter: one serialized spark_expression.Expr bound to data_schema, or NULL; starts / lengths: byte
+ * ranges selecting row groups by their midpoint.  next returns the rows of the batch now current (0 = end of file); column MOVES one
+ * column of the current batch into caller-allocated Arrow C structs.  Errors: 0 / -2 and comet_last_error(0). */
+int64_t comet_parquet_reader_init(const char* file_path, int64_t file_size, const int64_t* starts, const int64_t* lengths, int32_t n_ranges,
+                                  const uint8_t* filter, size_t filter_len, const uint8_t* required_schema_ipc, size_t required_len,
+                                  const uint8_t* data_schema_ipc, size_t data_len, const char* session_timezone, int32_t batch_size,
+                                  int32_t case_sensitive, int32_t device_id);
+int32_t comet_parquet_reader_next(int64_t handle);
+int32_t comet_parquet_reader_column(int64_t handle, int32_t column, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+void comet_parquet_reader_close(int64_t handle);
+
 /* ---- in-library hash exchange between GPUs (csrc/exchange.cpp) ----------------------------------------------------
  * The step Spark's exchange performs between two native stages, done GPU to GPU: rows are hash-partitioned exactly as the reference's
  * shuffle writer does (murmur3 seed 42 chained over the key columns → pmod → partition_starts / partition_row_indices,

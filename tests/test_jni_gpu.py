@@ -120,3 +120,83 @@ def test_metrics_are_pushed_periodically_while_batches_flow(built):
     jvm.release_plan(h)
     metrics, _ = S.decode_metric_node(ctypes.string_at(jvm.m.mock_metrics_bytes(node), jvm.m.mock_metrics_len(node)))
     assert metrics["output_rows"] == n
+
+
+def test_parquet_native_reader_reads_a_reference_fixture_batch_by_batch(built, tmp_path):
+    """org.apache.comet.parquet.Native through its JNI exports (parquet/mod.rs:135-330): initRecordBatchReader with Arrow IPC schema bytes,
+    byte ranges and a pushed filter, readNextRecordBatch until 0, currentColumnBatch moving every column of a batch, closeRecordBatchReader —
+    over one of the reference's own fixture files and over a larger multi-row-group file."""
+    import os
+    import numpy as np
+    import pyarrow.parquet as papq
+    jvm = Jvm(native.lib())
+    L = jvm.lib
+    init = L.Java_org_apache_comet_parquet_Native_initRecordBatchReader
+    init.restype = ctypes.c_int64
+    init.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] + [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_uint8, ctypes.c_uint8] + [ctypes.c_void_p] * 3
+    nxt = L.Java_org_apache_comet_parquet_Native_readNextRecordBatch
+    nxt.restype = ctypes.c_int32
+    nxt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    col = L.Java_org_apache_comet_parquet_Native_currentColumnBatch
+    col.restype = None
+    col.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]
+    close = L.Java_org_apache_comet_parquet_Native_closeRecordBatchReader
+    close.restype = None
+    close.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+
+    def read_all(path, required: pa.Schema, data: pa.Schema, ranges, batch_size, flt=None):
+        size = os.path.getsize(path)
+        st = (ctypes.c_int64 * len(ranges))(*[r[0] for r in ranges])
+        ln = (ctypes.c_int64 * len(ranges))(*[r[1] for r in ranges])
+        rs, ds = required.serialize().to_pybytes(), data.serialize().to_pybytes()
+        fb = flt.encode() if flt is not None else None
+        h = init(jvm.env, None, jvm.m.mock_string(("file://" + path).encode()), size, jvm.m.mock_longs(st, len(ranges)), jvm.m.mock_longs(ln, len(ranges)),
+                 jvm.m.mock_bytes(fb, len(fb)) if fb else None, jvm.m.mock_bytes(rs, len(rs)), jvm.m.mock_bytes(ds, len(ds)), jvm.m.mock_string(b"UTC"),
+                 batch_size, 1, 0, None, None, None)
+        assert h > 0, jvm.exception()
+        batches = []
+        while True:
+            rows = nxt(jvm.env, None, h)
+            assert not jvm.m.mock_exception_pending(), jvm.exception()
+            if rows == 0:
+                break
+            cols = []
+            for i in range(len(required)):
+                a, s = native.ArrowArrayC(), native.ArrowSchemaC()
+                col(jvm.env, None, h, i, ctypes.addressof(a), ctypes.addressof(s))
+                assert not jvm.m.mock_exception_pending(), jvm.exception()
+                cols.append(pa.Array._import_from_c(ctypes.addressof(a), ctypes.addressof(s)))
+                assert len(cols[-1]) == rows
+            batches.append(cols)
+        # taking a column when no batch is current is the reference's "There is no more data to read"
+        a, s = native.ArrowArrayC(), native.ArrowSchemaC()
+        col(jvm.env, None, h, 0, ctypes.addressof(a), ctypes.addressof(s))
+        exc = jvm.exception()
+        assert exc is not None and "no more data" in exc[1]
+        close(jvm.env, None, h)
+        return batches
+
+    fx = os.path.join(os.path.dirname(__file__), "golden", "parquet", "decimal32-written-as-64-bit-dict.snappy.parquet")
+    want = papq.read_table(fx)
+    got = read_all(fx, want.schema, want.schema, [(0, os.path.getsize(fx))], 500)
+    assert len(got) == 5 and [len(b[0]) for b in got] == [500, 500, 500, 500, 48]
+    assert pa.concat_arrays([b[0] for b in got]).to_pylist() == want.column(0).to_pylist()
+
+    rng = np.random.default_rng(9)
+    n = 50_000
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64)), "v": pa.array(rng.standard_normal(n)), "s": pa.array([f"r{i % 97}" for i in range(n)])})
+    path = str(tmp_path / "rg.parquet")
+    papq.write_table(t, path, row_group_size=10_000)
+    required = pa.schema([t.schema.field("s"), t.schema.field("k")])              # a projection in another order than the file
+    got = read_all(path, required, t.schema, [(0, os.path.getsize(path))], 8192)
+    assert pa.concat_arrays([b[0] for b in got]).to_pylist() == t.column("s").to_pylist()
+    assert pa.concat_arrays([b[1] for b in got]).to_pylist() == t.column("k").to_pylist()
+    # a pushed filter bound to the DATA schema (k is column 0 there, column 1 in the required schema) prunes whole row groups
+    flt = S.gt_eq(S.col(0, S.T_INT64), S.lit(30_000, S.T_INT64))
+    got = read_all(path, required, t.schema, [(0, os.path.getsize(path))], 8192, flt)
+    assert pa.concat_arrays([b[1] for b in got]).to_pylist() == list(range(30_000, n))
+    # byte ranges: the first half of the file selects the row groups whose midpoint lies there
+    half = read_all(path, required, t.schema, [(0, os.path.getsize(path) // 2)], 8192)
+    ks = pa.concat_arrays([b[1] for b in half]).to_pylist()
+    assert 0 < len(ks) < n and len(ks) % 10_000 == 0 and ks == list(range(len(ks)))
+    assert jvm.m.mock_live_global_refs() == 0

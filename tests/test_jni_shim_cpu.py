@@ -20,7 +20,11 @@ def test_jni_symbols_exported(built):
     for n in ("NativeBase_init", "NativeBase_isFeatureEnabled", "Native_createPlan", "Native_executePlan", "Native_releasePlan",
               "Native_traceBegin", "Native_traceEnd", "Native_logMemoryUsage", "Native_getRustThreadId",
               "Native_writeSortedFileNative", "Native_sortRowPartitionsNative", "Native_decodeShuffleBlock",
-              "Native_columnarToRowInit", "Native_columnarToRowConvert", "Native_columnarToRowClose"):
+              "Native_columnarToRowInit", "Native_columnarToRowConvert", "Native_columnarToRowClose",
+              "NativeBase_release", "NativeBase_isObjectStoreSchemeSupported",
+              # org.apache.comet.parquet.Native (native/core/src/parquet/mod.rs:135,250,295,318): with these all 21 JNI exports of the reference resolve
+              "parquet_Native_initRecordBatchReader", "parquet_Native_readNextRecordBatch", "parquet_Native_currentColumnBatch",
+              "parquet_Native_closeRecordBatchReader"):
         assert hasattr(lib, "Java_org_apache_comet_" + n)
 
 
