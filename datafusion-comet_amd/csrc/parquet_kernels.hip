@@ -121,113 +121,190 @@ __device__ __forceinline__ i64 pq_uniform_i64(i64 v) {
   return (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v));
 }
 
-// Every block decodes one CONTIGUOUS slice of the column, tile after tile, and the 64 rows of a wave are consecutive.
-// So the page and the hybrid run of a wave's first row only ever move FORWARD: they are found by binary search once per
-// block and then advanced with wave-uniform loads (amortised O(1) per tile), and each lane steps forward from the wave's
-// run to its own.  (One lane per row with two binary searches per row was latency-bound at ~1 TB/s.)
+// Every block decodes one CONTIGUOUS slice of the column; a wave takes 64·R consecutive rows per step (every lane R consecutive rows
+// of them), so the page and the hybrid run of a wave's first row only ever move FORWARD.
+//   * The wave keeps its current page and run — and the row / value index at which the NEXT page / run starts — in wave-uniform
+//     scalars: the common step needs no table load at all, only "am I still before the next boundary" compares.  (A PqPage / PqRun
+//     struct copy lives in scratch memory: measured, every step paid scratch round trips.)
+//   * R rows per lane would give R independent index → dictionary → store chains per lane and let a lane's bit-packed indices come out
+//     of ONE 8-byte load; measured on MI355X (profiles/r2_parquet_decode.txt) R = 4 was no faster than R = 1 — with 256 rows per wave
+//     step every second step crosses a ≤ 504-value run and sends lanes down the per-element path — so R = 1 is what runs.
+//   * Elements beyond the wave's page or run (a boundary inside the 256 rows) find their page / run by stepping forward from the wave's.
+// The value of an element is produced as a 128-bit payload whose low out_width bytes are stored.
+struct PqElem { i128 val; bool ok; };
+
+__device__ __forceinline__ i128 pq_convert(int kind, const u8* src, int width, int dec_up, u32 boolbit) {
+  switch (kind) {
+    case PQ_COPY4: return (i128)(u128)pq_ld32(src);
+    case PQ_COPY8: return (i128)(u128)pq_ld64(src);
+    case PQ_I32_TO_I64: return (i128)(i64)(i32)pq_ld32(src);
+    case PQ_I32_TO_I16: return (i128)(i16)(i32)pq_ld32(src);
+    case PQ_I32_TO_I8: return (i128)(i8)(i32)pq_ld32(src);
+    case PQ_I32_TO_DEC: return (i128)(i32)pq_ld32(src) * pq_pow10(dec_up);
+    case PQ_I64_TO_DEC: return (i128)(i64)pq_ld64(src) * pq_pow10(dec_up);
+    case PQ_FLBA_TO_DEC: return pq_flba_to_i128(src, width) * pq_pow10(dec_up);
+    case PQ_F32_TO_F64: { const double d = (double)__uint_as_float(pq_ld32(src)); return (i128)(u128)(u64)__double_as_longlong(d); }
+    case PQ_I32_TO_F64: { const double d = (double)(i32)pq_ld32(src); return (i128)(u128)(u64)__double_as_longlong(d); }
+    case PQ_INT96_TO_TS_MICROS:
+      // INT96 = 8 bytes nanoseconds of day (LE) + 4 bytes Julian day (LE); 2440588 = Julian day of 1970-01-01
+      return (i128)(((i64)(i32)pq_ld32(src + 8) - 2440588) * 86400000000ll + (i64)(pq_ld64(src) / 1000ull));
+    case PQ_I64_MILLIS_TO_MICROS: return (i128)(i64)((u64)pq_ld64(src) * 1000ull);   // wrapping like arrow's cast kernel multiply
+    case PQ_U32_TO_I64: return (i128)(u128)pq_ld32(src);
+    case PQ_U64_TO_DEC: return (i128)(u128)(u64)pq_ld64(src) * pq_pow10(dec_up);
+    case PQ_BOOL: return (i128)boolbit;
+    default: return 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
-  const i64 per_block = (((a.n_rows + gridDim.x - 1) / gridDim.x) + 255) / 256 * 256;
+  constexpr int R = 1;                                   // consecutive rows per lane
+  constexpr i64 kTile = 256 * R;                         // rows per block and step (256 per wave)
+  const i64 per_block = (((a.n_rows + gridDim.x - 1) / gridDim.x) + kTile - 1) / kTile * kTile;
   const i64 begin = (i64)blockIdx.x * per_block;
   const i64 end = begin + per_block < a.n_rows ? begin + per_block : a.n_rows;
-  const int wave_first = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
-  int p0 = -1, run0 = -1, run_page = -1;
-  for (i64 base = begin; base < end; base += 256) {
-    const i64 row0 = base + wave_first;                      // first row of this wave's 64 (wave-uniform)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63u);
+  constexpr i64 kNever = 0x7fffffffffffffffll;
+  const u8* __restrict__ bytes = a.bytes;
+  const u8* __restrict__ dict = a.dict;
+  int p = -1;                                   // the wave's page …
+  i64 pg_row_start = 0, pg_values_off = 0, pg_dict_off = 0, next_page_row = -1;   // … and the first row of the page after it
+  i32 pg_encoding = 0, pg_bit_width = 0, pg_kind = 0, pg_width = 0, pg_dec_up = 0, pg_idx_first = 0, pg_idx_count = 0;
+  int r = -1, run_page = -1;                    // the wave's run (dictionary pages) …
+  i64 rn_byte_off = 0;
+  i32 rn_value_start = 0, rn_is_rle = 0, next_run_val = 0;   // … and the first value index of the run after it (within the page)
+  u32 rn_rle_value = 0;
+  for (i64 base = begin; base < end; base += kTile) {
+    const i64 row0 = base + (i64)wave * (64 * R);          // first of this wave's 256 rows (wave-uniform)
     if (row0 >= end) break;
-    const i64 row = base + threadIdx.x;
-    const bool in_range = row < end;
-    if (p0 < 0) p0 = pq_find_page(a.pages, a.npages, row0);
-    else
-      while (p0 + 1 < a.npages && a.pages[p0 + 1].row_start <= row0) p0++;
-    int p = p0;
-    if (in_range)
-      while (p + 1 < a.npages && a.pages[p + 1].row_start <= row) p++;
-    const bool valid = in_range && (!a.valid_out || a.valid_out[row] != 0);   // valid_out == NULL: the column has no NULLs
-    const u8* src = nullptr;
-    u32 boolbit = 0;
-    const PqPage pg0 = a.pages[p0];
-    if (pg0.encoding == 1) {
-      const i32 v0 = a.max_def > 0 ? (i32)(a.vidx[row0] - a.vidx[pg0.row_start]) : (i32)(row0 - pg0.row_start);
-      const int last0 = pg0.idx_run_first + pg0.idx_run_count - 1;
-      if (run_page != p0) {
-        int lo = pg0.idx_run_first, hi = last0;
+    if (p < 0 || row0 >= next_page_row) {
+      if (p < 0) p = pq_find_page(a.pages, a.npages, row0);
+      else
+        while (p + 1 < a.npages && a.pages[p + 1].row_start <= row0) p++;
+      const PqPage* q = a.pages + p;
+      pg_row_start = q->row_start; pg_values_off = q->values_off; pg_dict_off = q->dict_off;
+      pg_encoding = q->encoding; pg_bit_width = q->bit_width; pg_kind = q->kind; pg_width = q->width; pg_dec_up = q->dec_scale_up;
+      pg_idx_first = q->idx_run_first; pg_idx_count = q->idx_run_count;
+      next_page_row = p + 1 < a.npages ? a.pages[p + 1].row_start : kNever;
+    }
+    if (pg_encoding == 1) {
+      // the run holding the wave's first value
+      const i32 v0 = a.max_def > 0 ? (i32)(a.vidx[row0] - a.vidx[pg_row_start]) : (i32)(row0 - pg_row_start);
+      const int last0 = pg_idx_first + pg_idx_count - 1;
+      bool reload = false;
+      if (run_page != p) {
+        int lo = pg_idx_first, hi = last0;
         while (lo < hi) {
           int mid = (lo + hi + 1) >> 1;
           if (a.idx_runs[mid].value_start <= v0) lo = mid;
           else hi = mid - 1;
         }
-        run0 = lo;
-        run_page = p0;
-      } else {
-        while (run0 < last0 && a.idx_runs[run0 + 1].value_start <= v0) run0++;
+        r = lo;
+        run_page = p;
+        reload = true;
+      } else if (v0 >= next_run_val) {
+        while (r < last0 && a.idx_runs[r + 1].value_start <= v0) r++;
+        reload = true;
       }
-    } else {
-      run_page = -1;
+      if (reload) {
+        const PqRun* q = a.idx_runs + r;
+        rn_byte_off = q->byte_off; rn_value_start = q->value_start; rn_is_rle = q->is_rle; rn_rle_value = q->rle_value;
+        next_run_val = r < last0 ? a.idx_runs[r + 1].value_start : 0x7fffffff;
+      }
     }
-    int kind = 0, dec_up = 0;
-    if (valid) {
-      const PqPage pg = a.pages[p];
-      kind = pg.kind;
-      dec_up = pg.dec_scale_up;
-      const i32 v = a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[pg.row_start]) : (i32)(row - pg.row_start);
-      if (pg.encoding == 1) {
+    const i64 lrow = row0 + (i64)lane * R;                 // this lane's first row
+    // ---- phase 1: where does every element's value come from (index loads happen here) ----
+    const u8* src[R];
+    u32 boolbit[R];
+    i32 kind[R], width[R], dec_up[R];
+    bool ok[R];
+    // fast path: the lane's rows lie in the wave's page and bit-packed run and the column has no NULLs → ONE load holds all indices
+    const bool no_nulls = a.max_def == 0;
+    const i32 lv0 = (i32)(lrow - pg_row_start);
+    const bool all_here = lrow + R <= end && lrow + R <= next_page_row;
+    const bool packed_fast = pg_encoding == 1 && no_nulls && all_here && !rn_is_rle && lv0 + R <= next_run_val && pg_bit_width * R <= 56;
+    u64 packed = 0;
+    if (packed_fast) {
+      const i64 bit = (i64)(lv0 - rn_value_start) * pg_bit_width;
+      packed = pq_ld64(bytes + rn_byte_off + (bit >> 3)) >> (bit & 7);
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const i64 row = lrow + k;
+      ok[k] = row < end && (!a.valid_out || a.valid_out[row] != 0);
+      src[k] = nullptr;
+      boolbit[k] = 0;
+      kind[k] = pg_kind; width[k] = pg_width; dec_up[k] = pg_dec_up;
+      if (!ok[k]) continue;
+      if (packed_fast) {
+        const u32 idx = (u32)((packed >> (k * pg_bit_width)) & ((1ull << pg_bit_width) - 1));
+        src[k] = dict + pg_dict_off + (i64)idx * pg_width;
+        continue;
+      }
+      // the element's own page: the wave's, unless a page boundary falls inside this step
+      i64 l_row_start = pg_row_start, l_values_off = pg_values_off, l_dict_off = pg_dict_off;
+      i32 l_encoding = pg_encoding, l_bit_width = pg_bit_width, l_idx_first = pg_idx_first, l_idx_count = pg_idx_count;
+      const bool here = row < next_page_row;
+      if (!here) {
+        int qi = p;
+        while (qi + 1 < a.npages && a.pages[qi + 1].row_start <= row) qi++;
+        const PqPage* q = a.pages + qi;
+        l_row_start = q->row_start; l_values_off = q->values_off; l_dict_off = q->dict_off;
+        l_encoding = q->encoding; l_bit_width = q->bit_width; kind[k] = q->kind; width[k] = q->width; dec_up[k] = q->dec_scale_up;
+        l_idx_first = q->idx_run_first; l_idx_count = q->idx_run_count;
+      }
+      const i32 v = a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[l_row_start]) : (i32)(row - l_row_start);
+      if (l_encoding == 1) {
         u32 idx;
-        if (p == p0 && run_page == p0) {
-          int r = run0;
-          const int last = pg.idx_run_first + pg.idx_run_count - 1;
-          while (r < last && a.idx_runs[r + 1].value_start <= v) r++;
-          const PqRun rn = a.idx_runs[r];
-          if (rn.is_rle) {
-            idx = rn.rle_value;
+        if (here && v < next_run_val) {            // v ≥ rn_value_start holds: v ≥ v0 ≥ the run's first value
+          if (rn_is_rle) {
+            idx = rn_rle_value;
           } else {
-            const int bw = pg.bit_width;
-            const i64 bit = (i64)(v - rn.value_start) * bw;
-            const u64 w = pq_ld64(a.bytes + rn.byte_off + (bit >> 3));   // bw <= 32 → the value fits in 5 bytes; staging is padded
+            const int bw = l_bit_width;
+            const i64 bit = (i64)(v - rn_value_start) * bw;
+            const u64 w = pq_ld64(bytes + rn_byte_off + (bit >> 3));   // bw <= 32 → the value fits in 5 bytes; staging is padded
+            idx = (u32)((w >> (bit & 7)) & ((bw >= 32) ? 0xffffffffull : ((1ull << bw) - 1)));
+          }
+        } else if (here) {
+          // a later run of the wave's page: step forward from the wave's run
+          int rr = r;
+          const int last = l_idx_first + l_idx_count - 1;
+          while (rr < last && a.idx_runs[rr + 1].value_start <= v) rr++;
+          const PqRun* q = a.idx_runs + rr;
+          if (q->is_rle) {
+            idx = q->rle_value;
+          } else {
+            const int bw = l_bit_width;
+            const i64 bit = (i64)(v - q->value_start) * bw;
+            const u64 w = pq_ld64(bytes + q->byte_off + (bit >> 3));
             idx = (u32)((w >> (bit & 7)) & ((bw >= 32) ? 0xffffffffull : ((1ull << bw) - 1)));
           }
         } else {
-          idx = pq_hybrid_value(a.idx_runs, pg.idx_run_first, pg.idx_run_count, a.bytes, pg.bit_width, v);
+          idx = pq_hybrid_value(a.idx_runs, l_idx_first, l_idx_count, bytes, l_bit_width, v);
         }
-        src = a.dict + pg.dict_off + (i64)idx * pg.width;
-      } else if (pg.kind == PQ_BOOL) {
-        boolbit = (a.bytes[pg.values_off + (v >> 3)] >> (v & 7)) & 1;
+        src[k] = dict + l_dict_off + (i64)idx * width[k];
+      } else if (kind[k] == PQ_BOOL) {
+        boolbit[k] = (bytes[l_values_off + (v >> 3)] >> (v & 7)) & 1;
       } else {
-        src = a.bytes + pg.values_off + (i64)v * pg.width;
+        src[k] = bytes + l_values_off + (i64)v * width[k];
       }
     }
-    if (!in_range) continue;
-    if (!valid) {
-      // NULL rows (and rows of pages that carry no value) store zeros of the column's output width
+    // ---- phase 2: the values (dictionary / page loads), all issued before any store ----
+    i128 val[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) val[k] = ok[k] ? pq_convert(kind[k], src[k], width[k], dec_up[k], boolbit[k]) : (i128)0;   // NULL rows store zeros
+    // ---- phase 3: stores (a lane's four values are contiguous) ----
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const i64 row = lrow + k;
+      if (row >= end) continue;
       switch (a.out_width) {
-        case 1: ((u8*)a.values_out)[row] = 0; break;
-        case 2: ((u16*)a.values_out)[row] = 0; break;
-        case 4: ((u32*)a.values_out)[row] = 0u; break;
-        case 8: ((u64*)a.values_out)[row] = 0ull; break;
-        default: ((i128*)a.values_out)[row] = (i128)0; break;
+        case 1: ((u8*)a.values_out)[row] = (u8)val[k]; break;
+        case 2: ((u16*)a.values_out)[row] = (u16)val[k]; break;
+        case 4: ((u32*)a.values_out)[row] = (u32)val[k]; break;
+        case 8: ((u64*)a.values_out)[row] = (u64)val[k]; break;
+        default: ((i128*)a.values_out)[row] = val[k]; break;
       }
-      continue;
-    }
-    switch (kind) {
-      case PQ_COPY4: ((u32*)a.values_out)[row] = pq_ld32(src); break;
-      case PQ_COPY8: ((u64*)a.values_out)[row] = pq_ld64(src); break;
-      case PQ_I32_TO_I64: ((i64*)a.values_out)[row] = (i64)(i32)pq_ld32(src); break;
-      case PQ_I32_TO_I16: ((i16*)a.values_out)[row] = (i16)(i32)pq_ld32(src); break;
-      case PQ_I32_TO_I8: ((i8*)a.values_out)[row] = (i8)(i32)pq_ld32(src); break;
-      case PQ_I32_TO_DEC: ((i128*)a.values_out)[row] = (i128)(i32)pq_ld32(src) * pq_pow10(dec_up); break;
-      case PQ_I64_TO_DEC: ((i128*)a.values_out)[row] = (i128)(i64)pq_ld64(src) * pq_pow10(dec_up); break;
-      case PQ_FLBA_TO_DEC: ((i128*)a.values_out)[row] = pq_flba_to_i128(src, a.pages[p].width) * pq_pow10(dec_up); break;
-      case PQ_F32_TO_F64: ((double*)a.values_out)[row] = (double)__uint_as_float(pq_ld32(src)); break;
-      case PQ_I32_TO_F64: ((double*)a.values_out)[row] = (double)(i32)pq_ld32(src); break;
-      case PQ_INT96_TO_TS_MICROS: {
-        // INT96 = 8 bytes nanoseconds of day (LE) + 4 bytes Julian day (LE); 2440588 = Julian day of 1970-01-01
-        ((i64*)a.values_out)[row] = ((i64)(i32)pq_ld32(src + 8) - 2440588) * 86400000000ll + (i64)(pq_ld64(src) / 1000ull);
-        break;
-      }
-      case PQ_I64_MILLIS_TO_MICROS: ((i64*)a.values_out)[row] = (i64)((u64)pq_ld64(src) * 1000ull); break;   // wrapping like arrow's cast kernel multiply
-      case PQ_U32_TO_I64: ((i64*)a.values_out)[row] = (i64)(u64)pq_ld32(src); break;
-      case PQ_U64_TO_DEC: ((i128*)a.values_out)[row] = (i128)(u128)(u64)pq_ld64(src) * pq_pow10(dec_up); break;
-      case PQ_BOOL: ((u8*)a.values_out)[row] = (u8)boolbit; break;
-      default: break;
     }
   }
 }
