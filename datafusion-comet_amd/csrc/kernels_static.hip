@@ -175,6 +175,38 @@ extern "C" int comet_launch_fix_rescale(uint64_t* base, int64_t count, int64_t s
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// Calibration of rocprofv3's FETCH_SIZE on this GPU: a streaming read of `n_bytes` with 4, 8 or 16 bytes per lane and load (the widths
+// the fused pipelines issue for Date32 / Int64-or-narrow-decimal / Decimal128 columns).  tools/pmc_calibrate.py compares the counter with
+// the known byte count (MI355X_MICROARCH.md calibrates the ×2 correction for 16 B/lane only).
+template <class T>
+__global__ __launch_bounds__(256) void calib_read_kernel(const T* p, i64 n, u64* sink) {
+  u64 acc = 0;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    const T v = p[i];
+    const u32* w = (const u32*)&v;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); k++) acc += w[k];
+  }
+  if (acc == 0x123456789abcdefull) *sink = acc;   // never true in practice: keeps the loads alive
+}
+struct CalibB16 { u32 w[4]; };
+// the access pattern of ld_dec_lo: the low 8 bytes of every 16-byte Decimal128 value (every cache line is touched, half of its bytes used)
+__global__ __launch_bounds__(256) void calib_read_lo8_kernel(const u64* p, i64 n, u64* sink) {
+  u64 acc = 0;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) acc += p[2 * i];
+  if (acc == 0x123456789abcdefull) *sink = acc;
+}
+extern "C" int comet_calib_read(const void* p, int64_t n_bytes, int32_t lane_bytes, uint64_t* sink, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = 256 * 8;
+  if (lane_bytes == 4) hipLaunchKernelGGL(calib_read_kernel<u32>, grid, 256, 0, st, (const u32*)p, (i64)(n_bytes / 4), (u64*)sink);
+  else if (lane_bytes == 8) hipLaunchKernelGGL(calib_read_kernel<u64>, grid, 256, 0, st, (const u64*)p, (i64)(n_bytes / 8), (u64*)sink);
+  else if (lane_bytes == 16) hipLaunchKernelGGL(calib_read_kernel<CalibB16>, grid, 256, 0, st, (const CalibB16*)p, (i64)(n_bytes / 16), (u64*)sink);
+  else if (lane_bytes == 816) hipLaunchKernelGGL(calib_read_lo8_kernel, grid, 256, 0, st, (const u64*)p, (i64)(n_bytes / 16), (u64*)sink);
+  else return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(utf8_uniform_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offsets, (i64)n, L, flag);
