@@ -52,13 +52,13 @@ def main():
     vals = {}
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "calib_read_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
-                k = r["Kernel_Name"]
-                w = 816 if "lo8" in k else 4 if "<unsigned int>" in k else 8 if "long" in k else 16
+            k = r["Kernel_Name"]
+            if "calib_read" in k and r["Counter_Name"] == "FETCH_SIZE":
+                w = 816 if "lo8" in k else 4 if "<unsigned int>" in k else 16 if "CalibB16>" in k else 8
                 vals.setdefault(w, []).append(float(r["Counter_Value"]))
     shutil.rmtree(d, ignore_errors=True)
     print(f"# FETCH_SIZE calibration: streaming read of {NBYTES} bytes, 256 x 8 blocks, rocprofv3 --pmc FETCH_SIZE (KiB)")
-    print("# lane_bytes  launches  FETCH_SIZE_bytes(avg)  true_bytes  true/counter")
+    print("# lane_bytes (816 = the low 8 bytes of every 16)  launches  FETCH_SIZE_bytes(avg)  true_bytes  true/counter")
     for w in sorted(vals):
         v = vals[w][1:] or vals[w]
         c = 1024.0 * sum(v) / len(v)
