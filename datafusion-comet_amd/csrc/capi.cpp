@@ -10,6 +10,7 @@
 #include "../../include/comet_amd.h"
 #include "exec.hpp"
 #include "shuffle_format.hpp"
+#include "parquet_meta.hpp"
 #include "row_shuffle.hpp"
 
 using namespace comet;
@@ -352,6 +353,13 @@ int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size
       memcpy(out, ex.data(), n);
       out[n] = 0;
     }
+    return 0;
+  });
+}
+
+int32_t comet_page_decompress(int32_t codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    pq::decompress(codec, src, src_len, dst, dst_len);
     return 0;
   });
 }

@@ -3646,6 +3646,7 @@ std::string ExecutionContext::metrics_proto() {
     if (op.kind == OpKind::NativeScan) {
       n.metrics.emplace_back("bytes_scanned", bytes_scanned_);
       n.metrics.emplace_back("row_groups_pruned_statistics", row_groups_pruned_);
+      n.metrics.emplace_back("pages_decompressed_on_device", pages_inflated_on_device_);
     }
     for (auto& c : op.children) n.children.push_back(build(*c, false));
     return n;

@@ -215,6 +215,7 @@ class ExecutionContext {
   int64_t join_build_rows_ = 0, join_probe_rows_ = 0;
   int64_t bytes_scanned_ = 0;
   int64_t row_groups_pruned_ = 0;
+  int64_t pages_inflated_on_device_ = 0;   // data pages decompressed by snappy_kernels.hip
 
   std::vector<std::unique_ptr<Staging>> staging_;   // per input stream
   int stage_parity_ = 0;                            // which of the two staging sets the next streamed chunk uses

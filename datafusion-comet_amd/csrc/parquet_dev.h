@@ -31,13 +31,21 @@ typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section 
   uint32_t rle_value;
 } PqRun;
 
+typedef struct PqInflate {     /* one compressed page body the device decompresses (snappy_kernels.hip); offsets relative to the column's byte buffer */
+  int64_t src_off;             /* compressed bytes, 16-byte aligned, readable up to the next multiple of 16 */
+  int64_t dst_off;             /* where the decompressed page goes, 16-byte aligned */
+  int32_t src_len, dst_len;
+} PqInflate;
+
 /* output conversions */
 enum { PQ_COPY4 = 0, PQ_COPY8 = 1, PQ_I32_TO_I64 = 2, PQ_I32_TO_DEC = 3, PQ_I64_TO_DEC = 4, PQ_FLBA_TO_DEC = 5, PQ_BOOL = 6,
        PQ_I32_TO_I16 = 7, PQ_I32_TO_I8 = 8,
        /* schema adaptation (parquet/schema_adapter.rs, parquet_support.rs:141-240) */
        PQ_F32_TO_F64 = 9, PQ_I32_TO_F64 = 10, PQ_INT96_TO_TS_MICROS = 11,
        /* logical-type conversions: TIMESTAMP(MILLIS) → µs, UINT_32 → int64, UINT_64 → decimal(20,0) */
-       PQ_I64_MILLIS_TO_MICROS = 12, PQ_U32_TO_I64 = 13, PQ_U64_TO_DEC = 14 };
+       PQ_I64_MILLIS_TO_MICROS = 12, PQ_U32_TO_I64 = 13, PQ_U64_TO_DEC = 14,
+       /* RLE-encoded BOOLEAN pages (data page v2 writers): runs of 1-bit indices into the two-entry table {0, 1} */
+       PQ_COPY1 = 15 };
 
 typedef struct PqDecodeArgs {
   const PqPage* pages;

@@ -152,6 +152,7 @@ __device__ __forceinline__ i128 pq_convert(int kind, const u8* src, int width, i
     case PQ_U32_TO_I64: return (i128)(u128)pq_ld32(src);
     case PQ_U64_TO_DEC: return (i128)(u128)(u64)pq_ld64(src) * pq_pow10(dec_up);
     case PQ_BOOL: return (i128)boolbit;
+    case PQ_COPY1: return (i128)(u128)src[0];
     default: return 0;
   }
 }

@@ -1,3 +1,4 @@
+#include <algorithm>
 #include "parquet_meta.hpp"
 #include "shuffle_format.hpp"
 
@@ -236,6 +237,9 @@ RowGroup read_row_group(TReader& r) {
 }
 
 // ---- snappy (raw format) — https://github.com/google/snappy/blob/main/format_description.txt -------
+// Columnar pages compress to millions of tiny elements (a PLAIN page of 8-byte decimals is ~4 output bytes per element), so the loop is
+// built around fixed-size moves: while 16 bytes of slack remain on both sides, a literal of up to 16 bytes and a copy of up to 16 bytes
+// from at least 8 bytes back are two 8-byte loads and stores each, whatever their length; everything else takes the careful path.
 void snappy_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_len) {
   size_t i = 0;
   uint64_t ulen = 0;
@@ -246,10 +250,86 @@ void snappy_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_le
     ulen |= (uint64_t)(b & 0x7f) << sh;
     if (!(b & 0x80)) break;
     sh += 7;
+    if (sh > 35) throw CometError("snappy: bad preamble");
   }
   if (ulen != dst_len) throw CometError("snappy: uncompressed length mismatch");
   size_t o = 0;
+  auto move16 = [](uint8_t* d, const uint8_t* s) {
+    uint64_t a, b;
+    memcpy(&a, s, 8);
+    memcpy(&b, s + 8, 8);
+    memcpy(d, &a, 8);
+    memcpy(d + 8, &b, 8);
+  };
   while (i < n) {
+    const uint8_t tag = src[i++];
+    uint32_t len, off;
+    const uint32_t kind = tag & 3;
+    if (kind == 0) {
+      len = (tag >> 2) + 1;
+      if (len <= 16 && i + 16 <= n && o + 16 <= dst_len) {
+        move16(dst + o, src + i);
+        i += len;
+        o += len;
+        continue;
+      }
+      if (len > 60) {
+        uint32_t nb = len - 60;
+        if (i + nb > n) throw CometError("snappy: truncated literal length");
+        len = 0;
+        for (uint32_t k = 0; k < nb; k++) len |= (uint32_t)src[i + k] << (8 * k);
+        len += 1;
+        i += nb;
+      }
+      if (i + len > n || o + len > dst_len || i + len < i) throw CometError("snappy: literal overruns buffer");
+      memcpy(dst + o, src + i, len);
+      i += len;
+      o += len;
+      continue;
+    }
+    if (kind == 1) {
+      len = ((tag >> 2) & 7) + 4;
+      if (i >= n) throw CometError("snappy: truncated copy");
+      off = ((uint32_t)(tag >> 5) << 8) | src[i++];
+    } else if (kind == 2) {
+      len = (tag >> 2) + 1;
+      if (i + 2 > n) throw CometError("snappy: truncated copy");
+      off = src[i] | ((uint32_t)src[i + 1] << 8);
+      i += 2;
+    } else {
+      len = (tag >> 2) + 1;
+      if (i + 4 > n) throw CometError("snappy: truncated copy");
+      off = src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16) | ((uint32_t)src[i + 3] << 24);
+      i += 4;
+    }
+    if (off == 0 || off > o || o + len > dst_len) throw CometError("snappy: bad copy");
+    if (len <= 16 && off >= 8 && o + 16 <= dst_len) {
+      // two 8-byte moves IN ORDER: with 8 <= offset < 16 the second one reads bytes the first one just wrote
+      uint64_t a;
+      memcpy(&a, dst + o - off, 8);
+      memcpy(dst + o, &a, 8);
+      memcpy(&a, dst + o - off + 8, 8);
+      memcpy(dst + o + 8, &a, 8);
+    } else if (off >= len) {
+      memcpy(dst + o, dst + o - off, len);
+    } else {
+      for (uint32_t k = 0; k < len; k++) dst[o + k] = dst[o + k - off];  // overlaps its own output: byte by byte
+    }
+    o += len;
+  }
+  if (o != dst_len) throw CometError("snappy: short output");
+}
+
+// The first `want` bytes of a snappy stream (fewer if the stream is shorter): what the host needs of a v1 data page whose body the device
+// decompresses — the definition levels in front of the values.  Returns the bytes produced.
+size_t snappy_prefix_impl(const uint8_t* src, size_t n, uint8_t* dst, size_t want) {
+  size_t i = 0;
+  while (true) {
+    if (i >= n) throw CometError("snappy: truncated preamble");
+    if (!(src[i++] & 0x80)) break;
+  }
+  size_t o = 0;
+  while (i < n && o < want) {
     uint8_t tag = src[i++];
     uint32_t len, off;
     switch (tag & 3) {
@@ -263,10 +343,11 @@ void snappy_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_le
           len += 1;
           i += nb;
         }
-        if (i + len > n || o + len > dst_len) throw CometError("snappy: literal overruns buffer");
-        memcpy(dst + o, src + i, len);
+        if (i + len > n) throw CometError("snappy: literal overruns buffer");
+        const size_t take = std::min<size_t>(len, want - o);
+        memcpy(dst + o, src + i, take);
         i += len;
-        o += len;
+        o += take;
         continue;
       }
       case 1:
@@ -286,11 +367,12 @@ void snappy_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_le
         off = src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16) | ((uint32_t)src[i + 3] << 24);
         i += 4;
     }
-    if (off == 0 || off > o || o + len > dst_len) throw CometError("snappy: bad copy");
-    for (uint32_t k = 0; k < len; k++) dst[o + k] = dst[o + k - off];  // may overlap: byte by byte
-    o += len;
+    if (off == 0 || off > o) throw CometError("snappy: bad copy");
+    const size_t take = std::min<size_t>(len, want - o);
+    for (size_t k = 0; k < take; k++) dst[o + k] = dst[o + k - off];
+    o += take;
   }
-  if (o != dst_len) throw CometError("snappy: short output");
+  return o;
 }
 
 typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
@@ -385,6 +467,8 @@ PageHeader parse_page_header(const uint8_t* p, size_t avail) {
   h.header_len = (size_t)(r.p - p);
   return h;
 }
+
+size_t snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t want) { return snappy_prefix_impl(src, n, dst, want); }
 
 void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) {
   switch (codec) {

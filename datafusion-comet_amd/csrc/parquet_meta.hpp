@@ -73,6 +73,8 @@ PageHeader parse_page_header(const uint8_t* p, size_t avail);
 
 // decompress one page body; throws CometError for unsupported codecs
 void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len);
+// first `want` bytes of a raw snappy stream (the levels in front of a v1 page's values); returns the bytes produced
+size_t snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t want);
 
 }  // namespace pq
 }  // namespace comet

@@ -35,6 +35,7 @@ void pq_launch_string_lengths(const PqDecodeArgs* a, void* st);
 void pq_launch_string_copy(const PqDecodeArgs* a, void* st);
 void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
+void pq_launch_snappy(const PqInflate* jobs, int njobs, uint8_t* bytes, uint32_t* err, void* st);
 }
 
 namespace comet {
@@ -303,6 +304,7 @@ struct ScanOptions {
   bool ignore_missing_field_id = false;
   bool allow_type_promotion = false;
   bool allow_timestamp_ltz_to_ntz = false;
+  bool device_snappy = true;          // ship snappy PLAIN pages compressed and decompress them on the GPU (snappy_kernels.hip)
   static ScanOptions of(const Operator& op) {
     ScanOptions o;
     o.case_sensitive = op.case_sensitive;
@@ -521,7 +523,9 @@ struct HostChunk {
   bool no_nulls = true;            // every definition level of the chunk equals max_def (or the column is required)
   int64_t n_rows = 0;
   int64_t compressed = 0;
-  size_t spos = 0;                 // staged page bytes actually used
+  size_t spos = 0;                 // staged (uploaded) bytes actually used
+  size_t ipos = 0;                 // bytes of the device-decompressed region used
+  std::vector<PqInflate> inflate;  // page bodies the device decompresses (offsets relative to the chunk's slot in either region)
   std::vector<PqPage> pages;
   std::vector<PqRun> def_runs, idx_runs;
   std::vector<uint8_t> dict_bytes;
@@ -537,7 +541,11 @@ struct ChunkSource {
 };
 
 // bytes the staged (decompressed) pages of a column chunk may take
-size_t staged_capacity(const pq::ColumnMeta& cm) { return ((size_t)cm.total_uncompressed + 64 + 15) & ~(size_t)15; }
+// (device-decompressed pages start on 16-byte boundaries: at most one per 4 KiB of page data, hence the 1/256)
+size_t staged_capacity(const pq::ColumnMeta& cm) { return ((size_t)cm.total_uncompressed + (size_t)cm.total_uncompressed / 256 + 128 + 15) & ~(size_t)15; }
+// offsets into the device-decompressed region carry this bit until the column's tables are assembled
+constexpr int64_t kInflatedBit = (int64_t)1 << 62;
+constexpr int32_t kMinDevicePage = 4096;
 
 void decode_chunk_host(const ChunkSource& src, const StructField& want, const ScanOptions& so, HostChunk& hc, uint8_t* staged, size_t staged_cap) {
   const pq::RowGroup& rg = src.meta->row_groups[(size_t)src.rg];
@@ -606,6 +614,61 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     pg.width = cp.src_width;
     pg.dec_scale_up = cp.dec_scale_up;
     size_t page_begin = spos, vals_begin, page_end;
+    // Device decompression: PLAIN fixed-width values under snappy need nothing from the host but the definition levels (the first bytes
+    // of a v1 page's stream; outside the stream in a v2 page), so the body crosses PCIe compressed and a GPU workgroup inflates it.
+    const bool dev_page = so.device_snappy && cm.codec == pq::SNAPPY && h.encoding == pq::PLAIN && !cp.is_string && h.uncompressed_size >= kMinDevicePage &&
+                          h.compressed_size <= h.uncompressed_size && (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.compressed_size > h.def_bytes));
+    if (dev_page) {
+      const size_t ipage = (hc.ipos + 15) & ~(size_t)15;
+      size_t comp_off = 0, comp_len = (size_t)h.compressed_size, un_len = (size_t)h.uncompressed_size, lvl = 0;
+      if (h.type == pq::DATA_PAGE) {
+        if (max_def > 0) {
+          if (h.def_encoding != pq::RLE) throw CometError("parquet: only RLE definition levels are supported");
+          uint8_t pre[4];
+          if (pq::snappy_prefix(body, comp_len, pre, 4) != 4) throw CometError("parquet: data page shorter than its level header");
+          uint32_t dl;
+          memcpy(&dl, pre, 4);
+          lvl = 4 + (size_t)dl;
+          if (lvl > un_len) throw CometError("parquet: definition levels longer than their page");
+          tmp.resize(lvl + 8);
+          if (pq::snappy_prefix(body, comp_len, tmp.data(), lvl) != lvl) throw CometError("parquet: data page shorter than its definition levels");
+          const size_t first = def_runs.size();
+          pg.def_run_first = (int32_t)first;
+          // positions in the coordinates of the decompressed region, where the device will put these same bytes
+          parse_hybrid_runs(tmp.data() - ipage, ipage + 4, ipage + lvl, 1, h.num_values, def_runs);
+          pg.def_run_count = (int32_t)(def_runs.size() - first);
+          for (size_t r = first; r < def_runs.size(); r++) def_runs[r].byte_off |= kInflatedBit;
+        }
+      } else {
+        memcpy(staged + spos, body, (size_t)h.def_bytes);
+        if (max_def > 0 && h.def_bytes) {
+          pg.def_run_first = (int32_t)def_runs.size();
+          parse_hybrid_runs(staged, spos, spos + (size_t)h.def_bytes, 1, h.num_values, def_runs);
+          pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
+        }
+        spos += (size_t)h.def_bytes;
+        comp_off = (size_t)h.def_bytes;
+        comp_len -= (size_t)h.def_bytes;
+        un_len -= (size_t)h.def_bytes;
+      }
+      const size_t cpos = (spos + 15) & ~(size_t)15;
+      if (cpos + comp_len + 32 > staged_cap || ipage + un_len + 32 > staged_cap) throw CometError("parquet: column chunk larger than its declared uncompressed size");
+      memcpy(staged + cpos, body + comp_off, comp_len);
+      memset(staged + cpos + comp_len, 0, 16);
+      PqInflate job;
+      job.src_off = (int64_t)cpos;
+      job.dst_off = (int64_t)ipage;
+      job.src_len = (int32_t)comp_len;
+      job.dst_len = (int32_t)un_len;
+      hc.inflate.push_back(job);
+      spos = cpos + comp_len;
+      hc.ipos = ipage + un_len;
+      pg.encoding = 0;
+      pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
+      values_seen += h.num_values;
+      pages.push_back(pg);
+      continue;
+    }
     if (h.type == pq::DATA_PAGE) {
       pq::decompress(cm.codec, body, (size_t)h.compressed_size, staged + spos, (size_t)h.uncompressed_size);
       page_end = spos + (size_t)h.uncompressed_size;
@@ -674,7 +737,28 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
         pg.idx_run_count = 1;
       }
     } else if (h.encoding == pq::RLE && cp.kind == PQ_BOOL) {
-      throw CometError("parquet: RLE-encoded booleans are not supported yet");
+      // RLE booleans (what data-page-v2 writers emit): a 4-byte length, then hybrid runs of 1-bit values — decoded as indices into {0, 1}
+      if (vals_begin + 4 > page_end) throw CometError("parquet: truncated RLE boolean page");
+      uint32_t rl;
+      memcpy(&rl, staged + vals_begin, 4);
+      if (vals_begin + 4 + (size_t)rl > page_end) throw CometError("parquet: RLE boolean data longer than its page");
+      if (dict_bytes.empty()) { dict_bytes.assign(16, 0); dict_bytes[1] = 1; }
+      pg.encoding = 1;
+      pg.bit_width = 1;
+      pg.kind = PQ_COPY1;
+      pg.width = 1;
+      pg.values_off = (int64_t)vals_begin + 4;
+      pg.idx_run_first = (int32_t)idx_runs.size();
+      parse_hybrid_runs(staged, vals_begin + 4, vals_begin + 4 + (size_t)rl, 1, -1, idx_runs);
+      pg.idx_run_count = (int32_t)idx_runs.size() - pg.idx_run_first;
+      if (pg.idx_run_count == 0) {   // page of NULLs only
+        PqRun r;
+        memset(&r, 0, sizeof r);
+        r.is_rle = 1;
+        r.count = h.num_values;
+        idx_runs.push_back(r);
+        pg.idx_run_count = 1;
+      }
     } else {
       throw CometError("parquet: value encoding " + std::to_string(h.encoding) + " is not supported yet (PLAIN and RLE_DICTIONARY are)");
     }
@@ -784,7 +868,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   out.has_valid.assign(ncol + npart, false);
   if (op.files.empty()) return out;   // EmptyExec (planner.rs:1548-1556)
   if (op.encryption_enabled) throw CometError("Parquet modular encryption is not supported by the GPU scan");
-  const ScanOptions so = ScanOptions::of(op);
+  ScanOptions so = ScanOptions::of(op);
+  if (const char* e = getenv("COMET_DEVICE_DECOMPRESS")) so.device_snappy = atoi(e) != 0;
+  for (auto& kv : config_)
+    if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy = kv.second != "false" && kv.second != "0";
   if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
   auto default_of = [&](size_t c) -> const Expr* {
     for (size_t k = 0; k < op.default_values_indexes.size(); k++)
@@ -928,6 +1015,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   };
   auto tiles = std::make_shared<DevBuf>();
   tiles->ensure((size_t)((total_rows + 1023) / 1024 + 2) * 8);
+  // one word per column: first failing page of the device decompression (job << 8 | code), 0 = fine
+  auto inflate_err = std::make_shared<DevBuf>();
+  inflate_err->ensure(ncol * 4 + 16);
+  HIP_CHECK(hipMemsetAsync(inflate_err->p, 0, ncol * 4 + 16, stream_));
   auto vidx = std::make_shared<DevBuf>();
 
   for (size_t c = 0; c < ncol; c++) {
@@ -959,27 +1050,29 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     auto cd = std::make_shared<ColumnDevice>();
     keep.push_back(cd);
     // the column's page bytes cross PCIe in slices as soon as their chunks are ready, on the copy stream
-    cd->bytes.ensure(slot_off[c][nsel] + 64);
+    // [0, S): what the host staged (decompressed pages, or compressed bodies for the device); [S, 2S): pages the device decompresses
+    const size_t S = (slot_off[c][nsel] + 64 + 15) & ~(size_t)15;
+    const bool may_inflate = so.device_snappy && !cp.is_string && !cp.missing;
+    cd->bytes.ensure(may_inflate ? 2 * S + 64 : S);
     bool any_optional = false;
-    size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0;
-    const size_t kSlice = 8;   // chunks per upload
-    for (size_t s0 = 0; s0 < nsel; s0 += kSlice) {
-      const size_t s1 = std::min(nsel, s0 + kSlice);
-      for (size_t si = s0; si < s1; si++) {
-        wait_for(c * nsel + si);
-        HostChunk& hc = chunks[c * nsel + si];
-        bytes_scanned_ += hc.compressed;
-        any_optional |= hc.max_def > 0 && !hc.no_nulls;
-        n_pages += hc.pages.size();
-        n_def += hc.no_nulls ? 0 : hc.def_runs.size();
-        n_idx += hc.idx_runs.size();
-        n_dict += (hc.dict_bytes.size() + 15) & ~(size_t)15;
-        n_doffs += hc.dict_offs.size();
-        n_soffs += hc.str_offs.size();
-      }
-      HIP_CHECK(hipMemcpyAsync((char*)cd->bytes.p + slot_off[c][s0], (char*)col_staged[c]->p + slot_off[c][s0], slot_off[c][s1] - slot_off[c][s0],
-                               hipMemcpyHostToDevice, copy_stream));
+    size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0, n_jobs = 0;
+    for (size_t si = 0; si < nsel; si++) {
+      wait_for(c * nsel + si);
+      HostChunk& hc = chunks[c * nsel + si];
+      bytes_scanned_ += hc.compressed;
+      any_optional |= hc.max_def > 0 && !hc.no_nulls;
+      n_pages += hc.pages.size();
+      n_def += hc.no_nulls ? 0 : hc.def_runs.size();
+      n_idx += hc.idx_runs.size();
+      n_dict += (hc.dict_bytes.size() + 15) & ~(size_t)15;
+      n_doffs += hc.dict_offs.size();
+      n_soffs += hc.str_offs.size();
+      n_jobs += hc.inflate.size();
+      // only the bytes the chunk actually staged cross PCIe
+      HIP_CHECK(hipMemcpyAsync((char*)cd->bytes.p + slot_off[c][si], (char*)col_staged[c]->p + slot_off[c][si],
+                               std::min(hc.spos + 16, slot_off[c][si + 1] - slot_off[c][si]), hipMemcpyHostToDevice, copy_stream));
     }
+    if (n_jobs && !may_inflate) throw CometError("internal: device pages in a column without a decompression region");
     if (trace) fprintf(stderr, "[comet] parquet: column %zu host chunks ready at %.2f ms\n", c, ms_since());
     // concatenate the chunks' tables: offsets become column-global
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -990,6 +1083,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const size_t off_dict = o; o = al(o + n_dict + 16);
     const size_t off_doffs = o; o = al(o + n_doffs * 4 + 16);
     const size_t off_soffs = o; o = al(o + n_soffs * 8 + 16);
+    const size_t off_jobs = o; o = al(o + n_jobs * sizeof(PqInflate) + 16);
     cd->h_tables.ensure(o + 16);
     char* tb_h = (char*)cd->h_tables.p;
     {
@@ -999,15 +1093,24 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       uint8_t* DB = (uint8_t*)(tb_h + off_dict);
       int32_t* DO = (int32_t*)(tb_h + off_doffs);
       int64_t* SO = (int64_t*)(tb_h + off_soffs);
-      size_t ip = 0, id = 0, ii = 0, idb = 0, ido = 0, iso = 0;
+      PqInflate* J = (PqInflate*)(tb_h + off_jobs);
+      size_t ip = 0, id = 0, ii = 0, idb = 0, ido = 0, iso = 0, ij = 0;
       for (size_t si = 0; si < nsel; si++) {
         HostChunk& hc = chunks[c * nsel + si];
         const int64_t base = (int64_t)slot_off[c][si];
+        // an offset into the chunk's slot of the staged region, or (flagged) of the device-decompressed region behind it
+        auto global_off = [&](int64_t v) { return (v & kInflatedBit) ? (v & ~kInflatedBit) + base + (int64_t)S : v + base; };
         const bool nulls = hc.max_def > 0 && !hc.no_nulls;
+        for (const PqInflate& src : hc.inflate) {
+          PqInflate job = src;
+          job.src_off += base;
+          job.dst_off += base + (int64_t)S;
+          J[ij++] = job;
+        }
         for (const PqPage& src : hc.pages) {
           PqPage pg = src;
           pg.row_start += sels[si].row_off;
-          pg.values_off += base;
+          pg.values_off = global_off(pg.values_off);
           pg.str_first += (int64_t)iso;
           if (nulls) pg.def_run_first += (int32_t)id;
           else pg.def_run_first = pg.def_run_count = 0;
@@ -1017,7 +1120,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
           P[ip++] = pg;
         }
         if (nulls)
-          for (const PqRun& r : hc.def_runs) { D[id] = r; D[id].byte_off += base; id++; }
+          for (const PqRun& r : hc.def_runs) { D[id] = r; D[id].byte_off = global_off(r.byte_off); id++; }
         for (const PqRun& r : hc.idx_runs) { I[ii] = r; I[ii].byte_off += base; ii++; }
         if (!hc.dict_bytes.empty()) memcpy(DB + idb, hc.dict_bytes.data(), hc.dict_bytes.size());
         idb += (hc.dict_bytes.size() + 15) & ~(size_t)15;
@@ -1033,6 +1136,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     HIP_CHECK(hipEventRecord(ev, copy_stream));
     HIP_CHECK(hipStreamWaitEvent(stream_, ev, 0));
     const char* tb = (const char*)cd->tables.p;
+    if (n_jobs) {
+      if (n_jobs >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
+      pq_launch_snappy((const PqInflate*)(tb + off_jobs), (int)n_jobs, (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+      pages_inflated_on_device_ += (int64_t)n_jobs;
+    }
 
     PqDecodeArgs a;
     memset(&a, 0, sizeof a);
@@ -1193,6 +1301,16 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (trace) fprintf(stderr, "[comet] parquet: all launches issued at %.2f ms\n", ms_since());
   HIP_CHECK(hipStreamSynchronize(stream_));
   if (trace) fprintf(stderr, "[comet] parquet: device idle at %.2f ms\n", ms_since());
+  {
+    std::vector<uint32_t> ierr(ncol, 0);
+    for (size_t c0 = 0; c0 < ncol; c0 += 512) {   // read_small carries up to 4 KiB
+      const size_t n = std::min<size_t>(512, ncol - c0);
+      read_small(ierr.data() + c0, (char*)inflate_err->p + c0 * 4, n * 4);
+    }
+    for (size_t c = 0; c < ncol; c++)
+      if (ierr[c]) throw CometError("Parquet column '" + op.required_schema[c].name + "': corrupt snappy data page (device decompression, page job " +
+                                    std::to_string(ierr[c] >> 8) + ", code " + std::to_string(ierr[c] & 0xff) + ")");
+  }
   out.owners.push_back(tiles);
   out.owners.push_back(vidx);
   // staging buffers can go back to the pools now that the stream is idle

@@ -114,6 +114,10 @@ def _load() -> ctypes.CDLL:
     lib.comet_exchange_last_error.restype = c.c_char_p
     lib.comet_free_buffer.restype = None
     lib.comet_free_buffer.argtypes = [c.c_void_p]
+    lib.comet_page_decompress.restype = c.c_int32
+    lib.comet_page_decompress.argtypes = [c.c_int32, c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]
+    lib.comet_snappy_inflate_pages.restype = c.c_int64
+    lib.comet_snappy_inflate_pages.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p, c.c_int32, c.POINTER(c.c_double)]
     return lib
 
 
@@ -886,3 +890,33 @@ class NativeComm:
             vals.append(torch.as_tensor(_DeviceBuffer(owner, pv.value, rows * w), device=table.device) if rows else torch.empty(0, dtype=torch.uint8, device=table.device))
             valid.append(torch.as_tensor(_DeviceBuffer(owner, pb.value, (rows + 7) // 8), device=table.device) if (pb.value and rows) else None)
         return DeviceTable(table.schema, rows, vals, valid, table.device, [None] * n)
+
+
+def snappy_inflate_pages(streams, page_lens, device_id: int = 0):
+    """Run the device snappy kernel (csrc/snappy_kernels.hip) over raw snappy streams held in host memory — the diagnostic entry
+    comet_snappy_inflate_pages.  Returns (pages, kernel_ms); raises CometNativeException naming the first corrupt page."""
+    import numpy as np
+    n = len(streams)
+    slen = np.array([len(s) for s in streams], np.int32)
+    soff = np.zeros(n, np.int64)
+    soff[1:] = np.cumsum(slen[:-1], dtype=np.int64)
+    blob = np.frombuffer(b"".join(streams) + b"\0", np.uint8)
+    plen = np.array(page_lens, np.int32)
+    ooff = np.zeros(n, np.int64)
+    ooff[1:] = np.cumsum(plen[:-1], dtype=np.int64)
+    out = np.zeros(int(plen.sum()) + 1, np.uint8)
+    ms = ctypes.c_double(0.0)
+    rc = lib().comet_snappy_inflate_pages(blob.ctypes.data, soff.ctypes.data, slen.ctypes.data, plen.ctypes.data, n, out.ctypes.data, ooff.ctypes.data,
+                                          device_id, ctypes.byref(ms))
+    if rc != 0:
+        raise CometNativeException(f"snappy page {rc >> 8}: code {rc & 0xff}" if rc > 0 else "HIP error in comet_snappy_inflate_pages")
+    return [out[int(o):int(o) + int(l)].tobytes() for o, l in zip(ooff, plen)], ms.value
+
+
+def page_decompress(codec: int, data: bytes, uncompressed_size: int) -> bytes:
+    """one Parquet page body through the scan's HOST codecs (comet_page_decompress); codec = Parquet CompressionCodec number"""
+    import numpy as np
+    out = np.zeros(max(uncompressed_size, 1), np.uint8)
+    if lib().comet_page_decompress(codec, data, len(data), out.ctypes.data, uncompressed_size) != 0:
+        _raise_last(0)
+    return out[:uncompressed_size].tobytes()

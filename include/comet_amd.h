@@ -148,6 +148,21 @@ int32_t comet_parquet_reader_next(int64_t handle);
 int32_t comet_parquet_reader_column(int64_t handle, int32_t column, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 void comet_parquet_reader_close(int64_t handle);
 
+/* ---- the host page codecs (csrc/parquet_meta.cpp) ---------------------------------------------------------------------------------------
+ * What the scan's host threads run on the pages the device does not decompress itself: Parquet CompressionCodec 0 UNCOMPRESSED, 1 SNAPPY,
+ * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and
+ * comet_last_error(0). */
+int32_t comet_page_decompress(int32_t codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len);
+
+/* ---- device-side page decompression (csrc/snappy_kernels.hip) — diagnostic entry ------------------------------------------------------
+ * The Parquet scan ships snappy-compressed PLAIN data pages across PCIe as they are and one GPU workgroup per page decompresses them
+ * (the reference decompresses on the task's CPU core inside the parquet crate's page reader, driven from native/core/src/parquet/mod.rs).
+ * This call runs that kernel over `npages` raw snappy streams in host memory — for parity tests and for timing the kernel alone; the
+ * scan itself never goes through host memory.  Returns 0; (page << 8 | code) for the first corrupt page (code 1 preamble / length,
+ * 2 truncated, 3 bad copy offset, 4 output overrun, 5 short output); -1 for a HIP error.  *kernel_ms: the launch's duration. */
+int64_t comet_snappy_inflate_pages(const uint8_t* streams, const int64_t* stream_off, const int32_t* stream_len, const int32_t* page_len,
+                                   int32_t npages, uint8_t* out, const int64_t* out_off, int32_t device_id, double* kernel_ms);
+
 /* ---- in-library hash exchange between GPUs (csrc/exchange.cpp) ----------------------------------------------------
  * The step Spark's exchange performs between two native stages, done GPU to GPU: rows are hash-partitioned exactly as the reference's
  * shuffle writer does (murmur3 seed 42 chained over the key columns → pmod → partition_starts / partition_row_indices,

@@ -1,0 +1,100 @@
+"""Device-side snappy decompression of Parquet data pages (csrc/snappy_kernels.hip): the kernel alone on raw streams — the
+same hand-built and pyarrow-compressed streams the CPU suite runs through the 64-lane emulation (tests/test_snappy_emu_cpu.py) — and the
+scan with PLAIN snappy pages (v1 with the levels inside the stream, v2 with the levels outside) against pyarrow's reader, with the host
+decompression path as a second opinion."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as papq
+import pytest
+
+from datafusion_comet_amd import native, serde as S
+from tests.test_parquet_gpu import _assert_same, _mixed_table, _types
+from tests.test_snappy_emu_cpu import build
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kernel_on_raw_streams(built):
+    rng = np.random.default_rng(5)
+    noise = lambda n: ("lit", rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    far = [noise(40_000), noise(50_000), noise(33), ("copy", (64, 90_000)), ("copy", (11, 60_000)), noise(5), ("copy", (20, 3)), ("copy", (64, 1)),
+           noise(70_000), ("copy", (64, 150_000)), ("copy", (7, 70_064)), noise(1)]
+    chain = [("lit", b"0123456789abcdef")]
+    for k in range(300):
+        chain.append(("copy", (4 + k % 8, 1 + k % 13)))
+        if k % 5 == 0:
+            chain.append(("lit", bytes([k & 0xFF, (k * 7) & 0xFF])))
+    pages = [b"", b"a", b"hello hello hello hello hello hello", bytes(70_000), b"abcdefg" * 9000,
+             rng.integers(90_000, 10_000_000, 131_072).astype(np.int64).tobytes(),          # a 1 MiB page of decimal(12,2)-as-INT64
+             rng.integers(0, 50, 40_000).astype(np.int32).tobytes(), rng.standard_normal(131_072).tobytes(),
+             " ".join(rng.choice(["alpha", "beta", "gamma", "lineitem", "orders", "MI355X"], 50_000)).encode()]
+    streams = [pa.compress(p, codec="snappy", asbytes=True) for p in pages]
+    for elems in (far, chain):
+        for wide in (False, True):
+            s, raw = build(elems, wide)
+            streams.append(s)
+            pages.append(raw)
+    got, ms = native.snappy_inflate_pages(streams, [len(p) for p in pages])
+    for i, (g, w) in enumerate(zip(got, pages)):
+        assert g == w, f"page {i} ({len(w)} bytes) differs"
+    print(f"{len(pages)} pages, {sum(map(len, pages))} bytes: {ms:.3f} ms")
+
+
+def test_kernel_reports_corrupt_pages(built):
+    raw = np.random.default_rng(7).integers(0, 1000, 5000).astype(np.int64).tobytes()
+    good = pa.compress(raw, codec="snappy", asbytes=True)
+    for stream, n, code in [(good, len(raw) + 1, 1), (good + b"\x00a", len(raw), 4)]:
+        with pytest.raises(native.CometNativeException, match=f"code {code}"):
+            native.snappy_inflate_pages([good, stream], [len(raw), n])
+    broken = bytearray(build([("lit", b"abcd"), ("copy", (4, 4))])[0])
+    broken[-1] = 9
+    with pytest.raises(native.CometNativeException, match="page 1: code 3"):
+        native.snappy_inflate_pages([good, bytes(broken)], [len(raw), 8])
+
+
+def _scan_with_metrics(path, table, device):
+    plan = S.native_scan([path], table.schema.names, _types(table.schema))
+    it = native.CometExecIterator([], table.num_columns, plan.encode(), batch_size=0,
+                                  config=S.config_map({"spark.comet.gpu.scan.deviceDecompress": "true" if device else "false"}))
+    batches = []
+    while True:
+        b = native.Native.executePlan(it.handle, table.num_columns)
+        if b is None:
+            break
+        batches.append(b)
+    m = S.decode_metric_node(it.metrics())
+    it.close()
+    while m[1]:
+        m = m[1][0]
+    return pa.Table.from_batches(batches), m[0]
+
+
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+def test_scan_of_plain_snappy_pages(built, tmp_path, version):
+    """PLAIN pages (dictionary off) so every fixed-width column takes the device path: NULLs put definition levels in front of the values
+    inside a v1 page's stream (the host reads just that prefix), outside the stream in a v2 page"""
+    t = _mixed_table(300_000, 31)
+    path = str(tmp_path / f"plain_v{version[0]}.parquet")
+    papq.write_table(t, path, compression="snappy", use_dictionary=False, data_page_version=version, row_group_size=120_000, data_page_size=256 << 10)
+    want = papq.read_table(path)
+    got, m = _scan_with_metrics(path, t, True)
+    _assert_same(got, want)
+    assert m["pages_decompressed_on_device"] > 20
+    host, mh = _scan_with_metrics(path, t, False)
+    _assert_same(host, want)
+    assert mh["pages_decompressed_on_device"] == 0
+
+
+def test_mixed_chunks_dictionary_then_plain(built, tmp_path):
+    """pyarrow falls back from dictionary to PLAIN pages once the dictionary page is full: one column chunk then holds host-decoded
+    dictionary pages followed by device-decompressed PLAIN pages — the TPC-H l_extendedprice layout"""
+    rng = np.random.default_rng(32)
+    n = 1_500_000
+    t = pa.table({"price": pa.array(rng.integers(90_000, 10_000_000, n), pa.int64()),
+                  "qty": pa.array(rng.integers(1, 51, n), pa.int64(), mask=rng.random(n) < 0.05),
+                  "f": pa.array(rng.standard_normal(n))})
+    path = str(tmp_path / "mixed.parquet")
+    papq.write_table(t, path, compression="snappy", use_dictionary=True, row_group_size=1 << 20, data_page_size=1 << 20)
+    got, m = _scan_with_metrics(path, t, True)
+    _assert_same(got, papq.read_table(path))
+    assert m["pages_decompressed_on_device"] >= 8

@@ -1,0 +1,55 @@
+"""The scan's host page codecs (csrc/parquet_meta.cpp, comet_page_decompress) against pyarrow's codecs — no GPU needed.  The snappy decoder
+is hand-written (fixed-size fast paths for the tiny elements columnar pages compress to), so it gets the same streams as the device
+kernel's emulation: pyarrow-compressed pages of every shape plus hand-built ones (overlapping copies, 8 <= offset < 16 copies that read
+what the first half of the move just wrote, 4-byte offsets) and corrupt input."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native
+from tests.test_snappy_emu_cpu import build
+
+SNAPPY, GZIP, ZSTD, LZ4_RAW = 1, 2, 6, 7
+
+
+def pages():
+    rng = np.random.default_rng(11)
+    return [b"", b"a", b"hello hello hello hello hello hello", bytes(70_000), b"abcdefg" * 9000, b"0123456789" * 5000,
+            rng.integers(90_000, 10_000_000, 131_072).astype(np.int64).tobytes(), rng.integers(0, 50, 40_000).astype(np.int32).tobytes(),
+            rng.standard_normal(50_000).tobytes(), " ".join(rng.choice(["alpha", "beta", "gamma", "lineitem", "orders"], 50_000)).encode(),
+            rng.integers(0, 4, 100_000, dtype=np.uint8).tobytes()]
+
+
+@pytest.mark.parametrize("codec,name", [(SNAPPY, "snappy"), (GZIP, "gzip"), (ZSTD, "zstd"), (LZ4_RAW, "lz4_raw")])
+def test_codecs_round_trip_pyarrow_pages(built, codec, name):
+    for raw in pages():
+        if not raw and name != "snappy":
+            continue
+        comp = pa.compress(raw, codec=name, asbytes=True)
+        assert native.page_decompress(codec, comp, len(raw)) == raw, (name, len(raw))
+
+
+def test_snappy_hand_built_streams(built):
+    rng = np.random.default_rng(12)
+    noise = lambda n: ("lit", rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    elems = [noise(40), ("copy", (16, 8)), ("copy", (16, 9)), ("copy", (13, 15)), ("copy", (16, 16)), ("copy", (12, 7)), ("copy", (4, 1)),
+             noise(3), ("copy", (64, 3)), noise(16), noise(17), noise(61), noise(70_000), ("copy", (64, 69_000)), ("copy", (11, 12)), noise(1)]
+    for k in range(200):
+        elems.append(("copy", (4 + k % 13, 1 + k % 19)))
+        if k % 3 == 0:
+            elems.append(noise(1 + k % 18))
+    for wide in (False, True):
+        stream, raw = build(elems, wide)
+        assert native.page_decompress(SNAPPY, stream, len(raw)) == raw
+
+
+def test_snappy_corrupt_streams(built):
+    raw = np.random.default_rng(13).integers(0, 1000, 5000).astype(np.int64).tobytes()
+    good = pa.compress(raw, codec="snappy", asbytes=True)
+    for stream, n in [(good, len(raw) + 1), (good[:-3], len(raw)), (good + b"\x00a", len(raw)), (b"\x80\x80\x80\x80\x80\x80\x80", 5)]:
+        with pytest.raises(native.CometNativeException, match="snappy"):
+            native.page_decompress(SNAPPY, stream, n)
+    bad = bytearray(build([("lit", b"abcd"), ("copy", (4, 4))])[0])
+    bad[-1] = 9
+    with pytest.raises(native.CometNativeException, match="bad copy"):
+        native.page_decompress(SNAPPY, bytes(bad), 8)

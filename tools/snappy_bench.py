@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Time the device snappy kernel alone (comet_snappy_inflate_pages) on Parquet-like pages: 1 MiB PLAIN pages of decimal(12,2)-as-INT64
+(TPC-H l_extendedprice: ~4 output bytes per snappy element), of doubles (incompressible: 64 KiB literals) and of low-cardinality int32.
+One JSON line: pages, decompressed bytes, kernel ms, GB/s of output."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pages", type=int, default=480)
+    ap.add_argument("--page-bytes", type=int, default=1 << 20)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import numpy as np
+    import pyarrow as pa
+    from datafusion_comet_amd import native
+    rng = np.random.default_rng(1)
+    n8 = a.page_bytes // 8
+    kinds = {
+        "decimal_int64": lambda: rng.integers(90_000, 10_000_000, n8).astype(np.int64).tobytes(),
+        "double": lambda: rng.standard_normal(n8).tobytes(),
+        "int32_lowcard": lambda: rng.integers(0, 50, a.page_bytes // 4).astype(np.int32).tobytes(),
+    }
+    res = {"pages": a.pages, "page_bytes": a.page_bytes}
+    for name, gen in kinds.items():
+        distinct = [gen() for _ in range(8)]
+        comp = [pa.compress(p, codec="snappy", asbytes=True) for p in distinct]
+        pages = [distinct[i % 8] for i in range(a.pages)]
+        streams = [comp[i % 8] for i in range(a.pages)]
+        best = None
+        for _ in range(3):
+            got, ms = native.snappy_inflate_pages(streams, [len(p) for p in pages])
+            best = ms if best is None else min(best, ms)
+        assert all(g == w for g, w in zip(got, pages))
+        total = sum(map(len, pages))
+        res[name] = {"compressed_ratio": sum(map(len, streams)) / total, "kernel_ms": best, "out_GBps": total / best / 1e6}
+    line = json.dumps(res)
+    print(line)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(line + "\n")
+
+
+if __name__ == "__main__":
+    main()
