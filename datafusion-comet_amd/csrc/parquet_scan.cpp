@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cerrno>
 #include <atomic>
 #include <chrono>
@@ -304,7 +305,10 @@ struct ScanOptions {
   bool ignore_missing_field_id = false;
   bool allow_type_promotion = false;
   bool allow_timestamp_ltz_to_ntz = false;
-  bool device_snappy = true;          // ship snappy PLAIN pages compressed and decompress them on the GPU (snappy_kernels.hip)
+  // ship snappy PLAIN pages compressed and decompress them on the GPU (snappy_kernels.hip): 1 yes, 0 no, -1 decide per scan from the bytes
+  // such pages hold and the host threads there are to decompress them (scan_parquet)
+  int device_snappy_mode = -1;
+  bool device_snappy = false;
   static ScanOptions of(const Operator& op) {
     ScanOptions o;
     o.case_sensitive = op.case_sensitive;
@@ -869,9 +873,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (op.files.empty()) return out;   // EmptyExec (planner.rs:1548-1556)
   if (op.encryption_enabled) throw CometError("Parquet modular encryption is not supported by the GPU scan");
   ScanOptions so = ScanOptions::of(op);
-  if (const char* e = getenv("COMET_DEVICE_DECOMPRESS")) so.device_snappy = atoi(e) != 0;
+  if (const char* e = getenv("COMET_DEVICE_DECOMPRESS")) so.device_snappy_mode = !strcmp(e, "auto") ? -1 : atoi(e) != 0;
   for (auto& kv : config_)
-    if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy = kv.second != "false" && kv.second != "0";
+    if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy_mode = kv.second == "auto" ? -1 : (kv.second != "false" && kv.second != "0");
   if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
   auto default_of = [&](size_t c) -> const Expr* {
     for (size_t k = 0; k < op.default_values_indexes.size(); k++)
@@ -953,7 +957,35 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   int max_inflight = ScanPool::get().size();
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scanThreads") max_inflight = std::max(1, atoi(kv.second.c_str()));
-  (void)max_inflight;
+  // Columns are taken largest first: the big PLAIN columns are the ones whose pages the device decompresses, and that kernel then runs
+  // while the host threads are still preparing the small (dictionary-encoded) columns.
+  std::vector<size_t> order(ncol);
+  std::vector<int64_t> col_bytes(ncol, 0);
+  int64_t plain_snappy_bytes = 0;     // uncompressed bytes of chunks that are snappy, fixed-width and (by bytes per value) mostly PLAIN
+  for (size_t c = 0; c < ncol; c++) {
+    order[c] = c;
+    for (size_t si = 0; si < nsel; si++) {
+      if (chunk_missing[c * nsel + si]) continue;
+      ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
+      const pq::ColumnMeta& cm = sels[si].meta->row_groups[(size_t)sels[si].rg].columns[(size_t)cp.leaf];
+      col_bytes[c] += cm.total_compressed;
+      if (cm.codec == pq::SNAPPY && !cp.is_string && cp.src_width > 0 && cm.num_values > 0 &&
+          (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values)
+        plain_snappy_bytes += cm.total_uncompressed;
+    }
+  }
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return col_bytes[a] > col_bytes[b]; });
+  // Measured on MI355X (profiles/r2_snappy_kernel.json): the kernel takes ~18 ms per 1 MiB page of 8-byte decimals whatever the number of
+  // pages up to 512 in flight (2 workgroups per CU), a host core decompresses the same bytes at ~1 GB/s.  Few host threads (a Spark task
+  // has one core) or many pages: the device wins; a small scan on a many-core host: the host threads do.
+  if (so.device_snappy_mode >= 0) {
+    so.device_snappy = so.device_snappy_mode != 0;
+  } else {
+    const double host_ms = (double)plain_snappy_bytes / 1e6 / (double)std::max(1, std::min(max_inflight, ScanPool::get().size()));
+    const double device_ms = 18.0 * std::ceil((double)plain_snappy_bytes / (512.0 * 1048576.0));
+    so.device_snappy = plain_snappy_bytes > 0 && device_ms < host_ms;
+  }
+  if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy PLAIN pages, decompressed on the %s\n", (double)plain_snappy_bytes / 1e6, so.device_snappy ? "device" : "host");
   auto run_task = [&](size_t t) {
     const size_t c = t / nsel, si = t % nsel;
     ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg};
@@ -963,7 +995,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     if (chunk_missing[t]) synth_chunk(op.required_schema[c], default_of(c), sels[si].rows, chunks[t], slot, cap);
     else decode_chunk_host(src, op.required_schema[c], so, chunks[t], slot, cap);
   };
-  for (size_t t = 0; t < ntasks; t++) {
+  for (size_t ti = 0; ti < ntasks; ti++) {
+    const size_t t = order[ti / nsel] * nsel + ti % nsel;
     ScanPool::get().submit([prog, t, &run_task, &chunks]() {
       if (!prog->cancelled.load()) {
         try {
@@ -1021,7 +1054,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   HIP_CHECK(hipMemsetAsync(inflate_err->p, 0, ncol * 4 + 16, stream_));
   auto vidx = std::make_shared<DevBuf>();
 
-  for (size_t c = 0; c < ncol; c++) {
+  for (size_t oi = 0; oi < ncol; oi++) {
+    const size_t c = order[oi];
     const ColumnPlan& cp = plans[c];
     if (all_missing[c]) {
       // all-NULL column: zeroed values, zeroed validity bitmap
