@@ -18,6 +18,9 @@ every rank owns SF100 rows (weak scaling), rank 0 prints ONE JSON line.
   q6_sf100 / q6_sf10     extra legs: Q6 stage 1; Q6's staged loads skip most cache lines of the later columns, so its honest
                          roofline fraction is the PHYSICAL one (PMC bytes ÷ kernel time); both are printed, never a frac > 1
   q3                     BASELINE configs[3]: SF100 Q3 hash joins partitioned over the ranks (strong scaling) with per-stage ms
+  q95                    BASELINE configs[4]: TPC-DS SF100 Q95 (≈16 M orders), web_sales / web_returns hash-exchanged on the order number,
+                         stage A partition-local, Final on rank 0 (strong scaling); verified against numpy at this size in
+                         profiles/r2_q95_dist.json and at test sizes in tests/ (the numpy evaluation takes ~40 s, so not inside the bench)
 """
 import argparse
 import json
@@ -60,6 +63,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-paths", action="store_true", help="skip the host-stream / Parquet path legs")
     ap.add_argument("--path-rows", type=int, default=20_000_000)
+    ap.add_argument("--q95-orders", type=int, default=16_000_000, help="total TPC-DS orders of the q95 leg (0 = skip; SF100 = 16 M)")
     ap.add_argument("--q3-orders", type=int, default=150_000_000,
                     help="extra leg: TPC-H Q3 over all ranks, total orders rows (SF100 = 150 M, strong scaling); 0 = skip")
     ap.add_argument("--leg-timeout", type=int, default=420)
@@ -163,6 +167,9 @@ def main():
         if args.q3_orders > 0:
             legs["q3"] = run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1"],
                                        rank, local_rank, world, args.leg_timeout, 1017)
+        if args.q95_orders > 0:
+            legs["q95"] = run_child_leg([os.path.join(ROOT, "tools", "q95_dist.py"), "--orders", str(args.q95_orders), "--steps", "2", "--warmup", "1", "--no-verify"],
+                                        rank, local_rank, world, args.leg_timeout, 1517)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -219,6 +226,8 @@ def main():
             line["q6_sf100" if key == "q6" and args.rows == SF100_ROWS else key] = q
         if legs.get("q3") is not None:
             line["q3"] = legs["q3"]
+        if legs.get("q95") is not None:
+            line["q95"] = legs["q95"]
         if pmc:
             line["pmc"] = pmc
         print(json.dumps(line))

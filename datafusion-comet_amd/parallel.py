@@ -305,3 +305,50 @@ def run_q3_distributed(engine, partitioner, customer, orders, lineitem, group=No
     merged = [r for part in out for r in part]
     merged.sort(key=lambda r: (-r[3], r[1], r[0]))
     return merged[:10], groups
+
+
+def run_q95_distributed(engine, partitioner, tables, group=None, timings: Optional[dict] = None):
+    """TPC-DS Q95 (BASELINE config 5) over the ranks of `group`.  `tables`: this rank's arbitrary shard of web_sales and web_returns plus
+    full copies of date_dim / customer_address / web_site (the reference broadcasts those: BroadcastHashJoin in the approved plan).
+
+    Every join of the fact tables — the ws_wh self-join, both LeftSemi joins, web_returns ⋈ ws_wh — is on the order number, which is also
+    the count(DISTINCT) key, so ONE hash exchange of web_sales and one of web_returns on that key (the hashpartitioning(ws_order_number)
+    exchanges under the plan's sort-merge joins) make everything up to the mixed-mode aggregate partition-local: each rank runs stage A
+    of tpcds.q95_plans() on its partition and emits one row of states; the distinct counts add up because no order lives on two ranks.
+    The state rows meet on rank 0 (Spark's single-partition exchange before the Final aggregate), which runs stage B.
+    Returns (count, sum_cost, sum_profit) on rank 0, None elsewhere."""
+    import time
+    import torch.distributed as dist
+    from . import native, tpcds
+    stage_a, stage_b, leaves = tpcds.q95_plans()
+
+    def clock():
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        return time.perf_counter()
+
+    t0 = clock()
+    ws = exchange(tables["web_sales"], [0], partitioner, group)
+    wr = exchange(tables["web_returns"], [0], partitioner, group)
+    t1 = clock()
+    local = dict(tables, web_sales=ws, web_returns=wr)
+    states = engine.run_host(stage_a, [local[n] for n in leaves], 5)      # one row: (sum, isEmpty, sum, isEmpty, count)
+    t2 = clock()
+    if timings is not None:
+        timings["exchange"] = timings.get("exchange", 0.0) + (t1 - t0)
+        timings["stage_a"] = timings.get("stage_a", 0.0) + (t2 - t1)
+        timings["exchange_rows"] = timings.get("exchange_rows", 0) + tables["web_sales"].num_rows + tables["web_returns"].num_rows
+        nb = lambda t: t.nbytes() if isinstance(t, native.DeviceTable) else t.nbytes
+        timings["exchange_bytes"] = timings.get("exchange_bytes", 0) + nb(tables["web_sales"]) + nb(tables["web_returns"])
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    merged = gather_partial_states(states, 0, group) if distributed else states
+    if distributed and dist.get_rank(group) != 0:
+        return None
+    out = engine.run_host(stage_b, [merged], 3)
+    if timings is not None:
+        timings["stage_b"] = timings.get("stage_b", 0.0) + (clock() - t2)
+    return out.column(2)[0].as_py(), out.column(0)[0].as_py(), out.column(1)[0].as_py()

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""TPC-DS Q95 (BASELINE config 5) over N GPUs of one node — one process per GPU (torch.distributed, backend nccl = RCCL): every rank
+holds 1/N of web_sales and web_returns in HBM, the two fact tables are hash-exchanged on the order number (in-library RCCL exchange, or
+torch's all_to_all), stage A runs partition-local, rank 0 merges the state rows with the Final aggregate (parallel.run_q95_distributed).
+Strong scaling: --orders is the total.  `--simulate-ranks R` (one process, one GPU): R task threads meet through libcomet's in-process exchange transport and each runs stage A on its
+partition — the multi-rank data path on a 1-GPU box.
+
+  single GPU:  python tools/q95_dist.py --orders 16000000
+  N GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/q95_dist.py ...
+
+One JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--orders", type=int, default=16_000_000, help="total orders (SF100 ≈ 16 M orders ≈ 72 M web_sales rows)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"])
+    ap.add_argument("--simulate-ranks", type=int, default=0)
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import numpy as np
+    import pyarrow as pa
+    import torch
+    import torch.distributed as dist
+    from datafusion_comet_amd import native, parallel, tpcds
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    t = tpcds.q95_tables(a.orders)          # same seed on every rank; each keeps its row range of the two fact tables
+    shard = lambda tb, w, r: tb.slice(*parallel.shard_range(tb.num_rows, w, r))
+    eng = parallel.GpuEngine(local)
+    part = parallel.HipPartitioner()
+    exchange_kind = "none (one partition)"
+    if world > 1:
+        exchange_kind = "torch.distributed all_to_all_single"
+        if a.exchange == "native":
+            try:
+                part = parallel.NativeExchange(parallel.native_comm_from_process_group(local))
+                exchange_kind = "in-library (libcomet.so: partition kernels + RCCL ncclSend/ncclRecv groups)"
+            except Exception as e:
+                exchange_kind = f"torch.distributed all_to_all_single (in-library transport unavailable: {e})"
+    dims = {k: t[k] for k in ("date_dim", "customer_address", "web_site")}
+    rows = t["web_sales"].num_rows + t["web_returns"].num_rows
+    timings, got, sec = {}, None, None
+    if a.simulate_ranks > 1:
+        # R task threads of ONE process on this GPU — the Spark-executor shape — meet through libcomet's in-process transport: each holds 1/R
+        # of the fact tables, exchanges them on the order number (partition kernels + peer copies), runs stage A on its partition; the
+        # main thread merges the R state rows with the Final aggregate
+        import threading
+        R = a.simulate_ranks
+        stage_a, stage_b, leaves = tpcds.q95_plans()
+        shards = [dict(dims, web_sales=native.DeviceTable.from_arrow(shard(t["web_sales"], R, r), dev),
+                       web_returns=native.DeviceTable.from_arrow(shard(t["web_returns"], R, r), dev)) for r in range(R)]
+        times = []
+        for it in range(a.warmup + a.steps):
+            states, errs = [None] * R, []
+
+            def rank_main(r, group):
+                try:
+                    torch.cuda.set_device(local)
+                    comm = native.NativeComm(R, r, local, local_group=group)
+                    ex = parallel.NativeExchange(comm)
+                    loc = dict(shards[r], web_sales=ex.comm.exchange(shards[r]["web_sales"], [0]), web_returns=ex.comm.exchange(shards[r]["web_returns"], [0]))
+                    states[r] = parallel.GpuEngine(local).run_host(stage_a, [loc[n] for n in leaves], 5)
+                    comm.close()
+                except Exception as e:      # noqa: BLE001
+                    errs.append(repr(e))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ts = [threading.Thread(target=rank_main, args=(r, 9500 + it)) for r in range(R)]
+            for th in ts:
+                th.start()
+            for th in ts:
+                th.join()
+            if errs:
+                raise RuntimeError("; ".join(errs))
+            out = eng.run_host(stage_b, [pa.concat_tables(states)], 3)
+            torch.cuda.synchronize()
+            if it >= a.warmup:
+                times.append(time.perf_counter() - t0)
+        got = (out.column(2)[0].as_py(), out.column(0)[0].as_py(), out.column(1)[0].as_py())
+        sec = min(times)
+        exchange_kind = f"in-library, in-process transport: {R} task threads on one GPU (partition kernels + peer copies)"
+    else:
+        mine = dict(dims, web_sales=native.DeviceTable.from_arrow(shard(t["web_sales"], world, rank), dev),
+                    web_returns=native.DeviceTable.from_arrow(shard(t["web_returns"], world, rank), dev))
+        for it in range(a.warmup + a.steps):
+            if it == a.warmup:
+                timings = {}
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            got = parallel.run_q95_distributed(eng, part, mine, timings=timings)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        sec = float(dt.item()) / a.steps
+    ok = None
+    if rank == 0:
+        if not a.no_verify:
+            ok = got == tpcds.q95_reference_numpy(t)
+        line = {"query": "tpcds_q95", "orders": a.orders, "n_gpus": world, "simulated_ranks": a.simulate_ranks, "fact_rows": rows, "sec_per_run": sec,
+                "fact_rows_per_s": rows / sec, "stage_ms_rank0": {k: round(v / a.steps * 1e3, 3) for k, v in timings.items() if not k.startswith("exchange_")},
+                "exchange": exchange_kind, "result": [got[0], str(got[1]), str(got[2])], "verified_vs_numpy": ok, "scaling": "strong"}
+        s = json.dumps(line)
+        print(s, flush=True)
+        if a.out:
+            with open(a.out, "w") as f:
+                f.write(s + "\n")
+    if world > 1:
+        dist.destroy_process_group()
+    if ok is False:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()
