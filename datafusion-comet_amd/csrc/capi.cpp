@@ -300,7 +300,25 @@ void comet_release_plan(int64_t handle) {
     ctx = it->second;
     g_ctx.erase(it);
   }
-  guarded(nullptr, 0, [&]() -> int { ctx.reset(); return 0; });
+  guarded(nullptr, 0, [&]() -> int {
+    std::shared_ptr<MemAccount> mem = ctx->memory_account();
+    ctx.reset();          // (another thread still inside a call keeps the context alive until it returns)
+    mem->detach();        // whatever outlives the plan is no longer charged to the task; the manager is not called again
+    return 0;
+  });
+}
+
+int32_t comet_plan_set_memory_manager(int64_t handle, int64_t (*acquire)(void*, int64_t), void (*release)(void*, int64_t), void* ctx_, int64_t task_id) {
+  auto ctx = lookup(handle);
+  if (!ctx) return -2;
+  ctx->set_memory_manager(acquire, release, ctx_, (long long)task_id);
+  return 0;
+}
+
+void comet_plan_memory_stats(int64_t handle, int64_t* out4) {
+  auto ctx = lookup(handle);
+  if (!ctx || !out4) return;
+  ctx->memory_stats(out4);
 }
 
 const char* comet_last_error(int64_t handle) {

@@ -55,40 +55,117 @@ int current_device() {
 }
 }  // namespace
 
+namespace {
+thread_local std::shared_ptr<MemAccount> t_account;
+void raise_peak(std::atomic<int64_t>& peak, int64_t v) {
+  int64_t p = peak.load(std::memory_order_relaxed);
+  while (v > p && !peak.compare_exchange_weak(p, v, std::memory_order_relaxed)) {}
+}
+}  // namespace
+AccountScope::AccountScope(std::shared_ptr<MemAccount> a) : prev(t_account) { t_account = std::move(a); }
+AccountScope::~AccountScope() { t_account = prev; }
+void MemAccount::flush() {
+  if (std::this_thread::get_id() != owner) return;
+  std::lock_guard<std::mutex> lk(cb_mu);
+  const int64_t n = pending_release.exchange(0);
+  if (n > 0 && release) release(ctx, n);
+}
+void MemAccount::detach() {
+  std::lock_guard<std::mutex> lk(cb_mu);
+  pending_release.store(0);
+  const int64_t left = host_used.load();
+  if (left > 0 && release) release(ctx, left);     // buffers that outlive the plan (exported batches) are no longer the task's
+  acquire = nullptr;
+  release = nullptr;
+  detached = true;
+}
+void MemAccount::grow_host(int64_t n) {
+  if (n <= 0) return;
+  flush();
+  {
+    std::lock_guard<std::mutex> lk(cb_mu);
+    if (acquire && std::this_thread::get_id() == owner) {
+      const int64_t got = acquire(ctx, n);
+      if (got < n) {
+        if (got > 0 && release) release(ctx, got);
+        throw CometError("Task " + std::to_string(task_id) + " failed to acquire " + std::to_string(n) + " bytes, only got " + std::to_string(got < 0 ? 0 : got) +
+                         ". Reserved: " + std::to_string(host_used.load()));
+      }
+    }
+  }
+  raise_peak(host_peak, host_used.fetch_add(n) + n);
+}
+void MemAccount::shrink_host(int64_t n) {
+  if (n <= 0) return;
+  host_used.fetch_sub(n);
+  std::lock_guard<std::mutex> lk(cb_mu);
+  if (!release || detached) return;
+  if (std::this_thread::get_id() == owner) {
+    const int64_t queued = pending_release.exchange(0);
+    release(ctx, n + queued);
+  } else {
+    pending_release.fetch_add(n);
+  }
+}
+void MemAccount::grow_dev(int64_t n) {
+  if (n <= 0) return;
+  const int64_t now = dev_used.fetch_add(n) + n;
+  if (dev_limit > 0 && now > dev_limit) {
+    dev_used.fetch_sub(n);
+    throw CometError("Task " + std::to_string(task_id) + ": GPU memory budget exceeded (spark.comet.gpu.memory.limit = " + std::to_string(dev_limit) +
+                     " bytes, " + std::to_string(now - n) + " in use, " + std::to_string(n) + " more requested)");
+  }
+  raise_peak(dev_peak, now);
+}
+void MemAccount::shrink_dev(int64_t n) {
+  if (n > 0) dev_used.fetch_sub(n);
+}
+
 void DevBuf::ensure(size_t n) {
   if (n <= cap) return;
   release();
   const size_t cls = size_class(n);
   dev = current_device();
-  {
-    std::lock_guard<std::mutex> lk(pools().mu);
-    auto& fl = pools().dev_free[{dev, cls}];
-    if (!fl.empty()) {
-      p = fl.back();
-      fl.pop_back();
-      pools().dev_cached[dev] -= cls;
-      cap = cls;
-      return;
-    }
+  if (t_account) {
+    t_account->grow_dev((int64_t)cls);      // may throw: over the plan's HBM budget
+    acct = t_account;
   }
-  if (hipMalloc(&p, cls) != hipSuccess) {
-    // out of memory: hand every idle block of this device back to the driver and try once more
-    (void)hipGetLastError();
-    std::vector<void*> victims;
+  try {
     {
       std::lock_guard<std::mutex> lk(pools().mu);
-      for (auto& kv : pools().dev_free)
-        if (kv.first.first == dev) {
-          victims.insert(victims.end(), kv.second.begin(), kv.second.end());
-          kv.second.clear();
-        }
-      pools().dev_cached[dev] = 0;
+      auto& fl = pools().dev_free[{dev, cls}];
+      if (!fl.empty()) {
+        p = fl.back();
+        fl.pop_back();
+        pools().dev_cached[dev] -= cls;
+        cap = cls;
+        return;
+      }
     }
-    for (void* v : victims) (void)hipFree(v);
+    if (hipMalloc(&p, cls) != hipSuccess) {
+      // out of memory: hand every idle block of this device back to the driver and try once more
+      (void)hipGetLastError();
+      std::vector<void*> victims;
+      {
+        std::lock_guard<std::mutex> lk(pools().mu);
+        for (auto& kv : pools().dev_free)
+          if (kv.first.first == dev) {
+            victims.insert(victims.end(), kv.second.begin(), kv.second.end());
+            kv.second.clear();
+          }
+        pools().dev_cached[dev] = 0;
+      }
+      for (void* v : victims) (void)hipFree(v);
+      p = nullptr;
+      HIP_CHECK(hipMalloc(&p, cls));
+    }
+    cap = cls;
+  } catch (...) {
+    if (acct) acct->shrink_dev((int64_t)cls);
+    acct.reset();
     p = nullptr;
-    HIP_CHECK(hipMalloc(&p, cls));
+    throw;
   }
-  cap = cls;
 }
 void DevBuf::release() {
   if (p) {
@@ -102,7 +179,9 @@ void DevBuf::release() {
       }
     }
     if (!keep) (void)hipFree(p);   // over the cap: give the block back to the driver (hipFree waits for the device)
+    if (acct) acct->shrink_dev((int64_t)cap);
   }
+  acct.reset();
   p = nullptr;
   cap = 0;
 }
@@ -110,19 +189,30 @@ void PinnedBuf::ensure(size_t n) {
   if (n <= cap) return;
   release();
   const size_t cls = size_class(n);
-  {
-    std::lock_guard<std::mutex> lk(pools().mu);
-    auto& fl = pools().pinned_free[cls];
-    if (!fl.empty()) {
-      p = fl.back();
-      fl.pop_back();
-      pools().pinned_cached -= cls;
-      cap = cls;
-      return;
-    }
+  if (t_account) {
+    t_account->grow_host((int64_t)cls);     // may throw: the host's memory manager granted less
+    acct = t_account;
   }
-  HIP_CHECK(hipHostMalloc(&p, cls, hipHostMallocDefault));
-  cap = cls;
+  try {
+    {
+      std::lock_guard<std::mutex> lk(pools().mu);
+      auto& fl = pools().pinned_free[cls];
+      if (!fl.empty()) {
+        p = fl.back();
+        fl.pop_back();
+        pools().pinned_cached -= cls;
+        cap = cls;
+        return;
+      }
+    }
+    HIP_CHECK(hipHostMalloc(&p, cls, hipHostMallocDefault));
+    cap = cls;
+  } catch (...) {
+    if (acct) acct->shrink_host((int64_t)cls);
+    acct.reset();
+    p = nullptr;
+    throw;
+  }
 }
 void PinnedBuf::release() {
   if (p) {
@@ -136,7 +226,9 @@ void PinnedBuf::release() {
       }
     }
     if (!keep) (void)hipHostFree(p);
+    if (acct) acct->shrink_host((int64_t)cap);
   }
+  acct.reset();
   p = nullptr;
   cap = 0;
 }
@@ -480,8 +572,10 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     : plan_(std::move(plan)), plan_hash_(plan_hash), config_(std::move(config)), inputs_(std::move(inputs)), batch_size_(batch_size),
       device_id_(device_id) {
   chunk_rows_ = 4 << 20;
+  mem_->owner = std::this_thread::get_id();
   for (auto& kv : config_) {
     if (kv.first == "spark.comet.gpu.chunkRows") chunk_rows_ = std::max<long long>(1024, atoll(kv.second.c_str()));
+    if (kv.first == "spark.comet.gpu.memory.limit") mem_->dev_limit = std::max<long long>(0, atoll(kv.second.c_str()));
   }
   if (const char* e = getenv("COMET_GPU_CHUNK_ROWS")) chunk_rows_ = std::max<long long>(1024, atoll(e));
   // Scan leaves in depth-first, left-before-right order map to the input streams (planner.rs:1726, :2391)
@@ -915,6 +1009,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
 }
 
 ExecutionContext::~ExecutionContext() {
+  mem_->owner = std::this_thread::get_id();   // the buffers die on this thread (after this body): their bytes go back to the manager from here
   // Dropping the context releases the input streams back to their producer (scan.rs:41-44).
   for (auto& in : inputs_) {
     if (in.host && in.host->release) in.host->release(in.host);
@@ -3533,7 +3628,23 @@ void release_fmt_schema(ArrowSchema* s) {
 
 // The stage boundary for multi-GPU plans: a Filter/Project/HashJoin plan's output stays resident so that the
 // exchange (murmur3 → pmod → partition scatter → RCCL all-to-all) never touches the host.  One batch = the whole result.
+void ExecutionContext::set_memory_manager(int64_t (*acquire)(void*, int64_t), void (*release)(void*, int64_t), void* ctx, long long task_id) {
+  mem_->acquire = acquire;
+  mem_->release = release;
+  mem_->ctx = ctx;
+  mem_->task_id = task_id;
+}
+void ExecutionContext::memory_stats(int64_t out[4]) {
+  out[0] = mem_->host_used.load();
+  out[1] = mem_->host_peak.load();
+  out[2] = mem_->dev_used.load();
+  out[3] = mem_->dev_peak.load();
+}
+
 int64_t ExecutionContext::execute_device(ArrowDeviceArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
+  mem_->owner = std::this_thread::get_id();      // Spark may move a task's calls between threads; the up-calls go with the caller
+  AccountScope account(mem_);
+  mem_->flush();
   Timer t;
   start();
   if (sink_ == SinkKind::AggNoGroup)
@@ -3588,6 +3699,9 @@ int64_t ExecutionContext::execute_device(ArrowDeviceArray** out_arrays, ArrowSch
 }
 
 int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
+  mem_->owner = std::this_thread::get_id();
+  AccountScope account(mem_);
+  mem_->flush();
   Timer t;
   start();
   const bool is_agg = sink_ != SinkKind::Output;

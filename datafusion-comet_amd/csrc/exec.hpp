@@ -1,6 +1,9 @@
 // Execution context: the MI355X counterpart of the reference's ExecutionContext
 // (native/core/src/execution/jni_api.rs:306-365) — one per Spark task / plan handle.
 #pragma once
+#include <mutex>
+#include <thread>
+#include <atomic>
 #include <hip/hip_runtime_api.h>
 
 #include <deque>
@@ -19,10 +22,42 @@
 
 namespace comet {
 
+// Native memory one plan (one Spark task) holds, the way the reference's CometUnifiedMemoryPool reports it
+// (native/core/src/execution/memory_pools/unified_pool.rs:64-150): every growth of PINNED HOST staging asks the host's memory manager
+// (CometTaskMemoryManager.acquireMemory over JNI; comet_plan_set_memory_manager over the C ABI) and fails with the reference's
+// "failed to acquire" error when less than the request is granted; every release hands the bytes back.  HBM is not Spark's to grant: it is
+// held against the plan's own budget (spark.comet.gpu.memory.limit, bytes; 0 = the device's capacity).  A buffer remembers the account it
+// was charged to, so it is credited back wherever and whenever it dies; releases that happen off the task thread are queued and handed
+// to the manager at the task thread's next call (the JNI up-call needs that thread's JNIEnv).
+struct MemAccount {
+  int64_t (*acquire)(void* ctx, int64_t bytes) = nullptr;
+  void (*release)(void* ctx, int64_t bytes) = nullptr;
+  void* ctx = nullptr;
+  long long task_id = 0;
+  int64_t dev_limit = 0;
+  std::atomic<int64_t> host_used{0}, host_peak{0}, dev_used{0}, dev_peak{0}, pending_release{0};
+  std::thread::id owner;
+  void grow_host(int64_t n);     // throws CometError when the manager grants less
+  void shrink_host(int64_t n);
+  void grow_dev(int64_t n);      // throws CometError over the budget
+  void shrink_dev(int64_t n);
+  void flush();                  // task thread: hand queued releases to the manager
+  void detach();                 // the plan is gone: give back whatever is still charged and stop calling the manager
+  std::mutex cb_mu;              // serialises up-calls against detach()
+  bool detached = false;
+};
+// the account buffers allocated on this thread are charged to (set while a plan runs on it)
+struct AccountScope {
+  std::shared_ptr<MemAccount> prev;
+  explicit AccountScope(std::shared_ptr<MemAccount> a);
+  ~AccountScope();
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   int dev = 0;
+  std::shared_ptr<MemAccount> acct;
   void ensure(size_t n);
   void release();
   ~DevBuf() { release(); }
@@ -33,6 +68,7 @@ struct DevBuf {
 struct PinnedBuf {
   void* p = nullptr;
   size_t cap = 0;
+  std::shared_ptr<MemAccount> acct;
   void ensure(size_t n);
   void release();
   ~PinnedBuf() { release(); }
@@ -107,6 +143,10 @@ class ExecutionContext {
   // same, but the (single) result batch stays in HBM and is exported as ARROW_DEVICE_ROCM arrays
   int64_t execute_device(ArrowDeviceArray** out_arrays, ArrowSchema** out_schemas, int n_out);
   std::string metrics_proto();
+  // the host's memory manager for this plan's pinned staging (see MemAccount); stats: host used / peak, device used / peak
+  void set_memory_manager(int64_t (*acquire)(void*, int64_t), void (*release)(void*, int64_t), void* ctx, long long task_id);
+  void memory_stats(int64_t out[4]);
+  std::shared_ptr<MemAccount> memory_account() const { return mem_; }
   const std::string& explain();
   // CPU-only: plan + generate + hiprtc-compile the all-valid variant (used by build()/tests w/o GPU)
   static std::string compile_only(OperatorP plan, uint64_t plan_hash);
@@ -215,6 +255,7 @@ class ExecutionContext {
   int64_t join_build_rows_ = 0, join_probe_rows_ = 0;
   int64_t bytes_scanned_ = 0;
   int64_t row_groups_pruned_ = 0;
+  std::shared_ptr<MemAccount> mem_ = std::make_shared<MemAccount>();
   int64_t pages_inflated_on_device_ = 0;   // data pages decompressed by snappy_kernels.hip
 
   std::vector<std::unique_ptr<Staging>> staging_;   // per input stream

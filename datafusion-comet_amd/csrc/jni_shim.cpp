@@ -23,6 +23,7 @@ struct JavaSide {                 // global refs held for the lifetime of a plan
   std::vector<jobject> iterators;
   jobject metrics_node = nullptr;
   long long metrics_interval_ms = 0;                           // createPlan's metricsUpdateInterval (jni_api.rs:906-909)
+  struct MemoryManager* memory = nullptr;                      // createPlan's taskMemoryManager (owned; freed by releasePlan)
   std::chrono::steady_clock::time_point last_metrics_push;
 };
 
@@ -30,6 +31,27 @@ struct JavaSide {                 // global refs held for the lifetime of a plan
 // getBuffer) are made on the calling task thread with that call's env, like the reference does before polling
 // (shuffle_scan.rs:112-135 "JNI calls cannot happen from within poll_next on tokio threads").
 thread_local JNIEnv* t_env = nullptr;
+
+// org.apache.spark.CometTaskMemoryManager: acquireMemory(J)J / releaseMemory(J)V (native/jni-bridge/src/comet_task_memory_manager.rs:32-60),
+// called the way CometUnifiedMemoryPool calls them (unified_pool.rs:64-80) — on the task thread, with the env of the JNI call in progress
+struct MemoryManager {
+  jobject obj = nullptr;       // global ref
+  jmethodID acquire = nullptr, release = nullptr;
+};
+int64_t mm_acquire(void* ctx, int64_t bytes) {
+  auto* m = (MemoryManager*)ctx;
+  JNIEnv* env = t_env;
+  if (!env || !m->obj) return bytes;          // outside a JNI call nothing can be asked: grant (the bytes are still counted)
+  const jlong got = jni_CallLongMethodJ(env, m->obj, m->acquire, (jlong)bytes);
+  if (jni_ExceptionCheck(env)) return 0;      // the pending throwable surfaces when the native call returns
+  return (int64_t)got;
+}
+void mm_release(void* ctx, int64_t bytes) {
+  auto* m = (MemoryManager*)ctx;
+  JNIEnv* env = t_env;
+  if (!env || !m->obj) return;
+  jni_CallVoidMethodJ(env, m->obj, m->release, (jlong)bytes);
+}
 
 // org.apache.comet.CometShuffleBlockIterator seen as a CometShuffleBlockStream (native/jni-bridge/src/shuffle_block_iterator.rs:40-66)
 struct BlockIterator {
@@ -131,7 +153,7 @@ JNIEXPORT jboolean JNICALL Java_org_apache_comet_NativeBase_isObjectStoreSchemeS
 // Native.createPlan (jni_api.rs:371-562)
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
     JNIEnv* env, jclass, jlong /*id*/, jobjectArray iterators, jbyteArray plan, jbyteArray configMap, jint partitionCount,
-    jobject metricsNode, jlong metricsUpdateInterval, jobject /*taskMemoryManager*/, jobjectArray /*localDirs*/, jint batchSize,
+    jobject metricsNode, jlong metricsUpdateInterval, jobject taskMemoryManager, jobjectArray /*localDirs*/, jint batchSize,
     jboolean /*offHeapMode*/, jstring /*memoryPoolType*/, jlong /*memoryLimit*/, jlong /*memoryLimitPerTask*/, jlong taskAttemptId,
     jlong /*taskCPUs*/, jobject /*keyUnwrapper*/, jobject /*taskContext*/, jobject /*classLoader*/) {
   std::vector<uint8_t> plan_b = byte_array(env, plan), cfg_b = byte_array(env, configMap);
@@ -193,6 +215,20 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
     for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
     throw_java(env, comet_last_error_kind(0), comet_last_error(0));
     return 0;
+  }
+  if (taskMemoryManager) {
+    jclass cls = jni_GetObjectClass(env, taskMemoryManager);
+    jmethodID acq = cls ? jni_GetMethodID(env, cls, "acquireMemory", "(J)J") : nullptr;
+    jmethodID rel = acq ? jni_GetMethodID(env, cls, "releaseMemory", "(J)V") : nullptr;
+    if (acq && rel) {
+      js.memory = new MemoryManager();
+      js.memory->obj = jni_NewGlobalRef(env, taskMemoryManager);
+      js.memory->acquire = acq;
+      js.memory->release = rel;
+      comet_plan_set_memory_manager(h, mm_acquire, mm_release, js.memory, (int64_t)taskAttemptId);
+    } else if (jni_ExceptionCheck(env)) {
+      jni_ExceptionClear(env);      // not a CometTaskMemoryManager: run unaccounted rather than fail the task
+    }
   }
   if (metricsNode) js.metrics_node = jni_NewGlobalRef(env, metricsNode);
   js.metrics_interval_ms = (long long)metricsUpdateInterval;
@@ -258,7 +294,13 @@ JNIEXPORT void JNICALL Java_org_apache_comet_Native_releasePlan(JNIEnv* env, jcl
     }
   }
   push_metrics(env, handle, js.metrics_node);
+  t_env = env;                   // the plan's buffers go back to the task memory manager from this call
   comet_release_plan(handle);
+  t_env = nullptr;
+  if (js.memory) {
+    jni_DeleteGlobalRef(env, js.memory->obj);
+    delete js.memory;
+  }
   for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
   if (js.metrics_node) jni_DeleteGlobalRef(env, js.metrics_node);
 }

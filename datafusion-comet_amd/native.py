@@ -114,6 +114,10 @@ def _load() -> ctypes.CDLL:
     lib.comet_exchange_last_error.restype = c.c_char_p
     lib.comet_free_buffer.restype = None
     lib.comet_free_buffer.argtypes = [c.c_void_p]
+    lib.comet_plan_memory_stats.restype = None
+    lib.comet_plan_memory_stats.argtypes = [c.c_int64, c.c_void_p]
+    lib.comet_plan_set_memory_manager.restype = c.c_int32
+    lib.comet_plan_set_memory_manager.argtypes = [c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64]
     lib.comet_page_decompress.restype = c.c_int32
     lib.comet_page_decompress.argtypes = [c.c_int32, c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]
     lib.comet_snappy_inflate_pages.restype = c.c_int64

@@ -148,6 +148,17 @@ int32_t comet_parquet_reader_next(int64_t handle);
 int32_t comet_parquet_reader_column(int64_t handle, int32_t column, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 void comet_parquet_reader_close(int64_t handle);
 
+/* ---- memory accounting (csrc/exec.hpp MemAccount) --------------------------------------------------------------------------------------
+ * Replaces CometUnifiedMemoryPool (native/core/src/execution/memory_pools/unified_pool.rs:64-150): call right after comet_create_plan.
+ * Every growth of the plan's PINNED HOST staging calls acquire(ctx, bytes) on the thread that is inside comet_execute_plan — the JNI shim
+ * forwards to CometTaskMemoryManager.acquireMemory(J)J — and the plan fails with the reference's "Task N failed to acquire B bytes, only
+ * got G. Reserved: R" when less is granted (the partial grant is released first); release(ctx, bytes) hands bytes back (releases that
+ * happen on other threads are queued until the task thread's next call; comet_release_plan returns whatever is left).  HBM is held against
+ * the plan's own budget, config key spark.comet.gpu.memory.limit (bytes).  stats: {host bytes in use, host peak, HBM in use, HBM peak}. */
+int32_t comet_plan_set_memory_manager(int64_t plan, int64_t (*acquire)(void* ctx, int64_t bytes), void (*release)(void* ctx, int64_t bytes), void* ctx,
+                                      int64_t task_id);
+void comet_plan_memory_stats(int64_t plan, int64_t* out4);
+
 /* ---- the host page codecs (csrc/parquet_meta.cpp) ---------------------------------------------------------------------------------------
  * What the scan's host threads run on the pages the device does not decompress itself: Parquet CompressionCodec 0 UNCOMPRESSED, 1 SNAPPY,
  * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and

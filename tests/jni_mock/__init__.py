@@ -34,6 +34,10 @@ def load():
         getattr(m, f).restype = vp
         getattr(m, f).argtypes = [vp]
     m.mock_string.argtypes = [ctypes.c_char_p]
+    m.mock_memory_manager.restype = vp
+    m.mock_memory_manager.argtypes = [ctypes.c_int64]
+    m.mock_memory_stats.restype = ctypes.POINTER(ctypes.c_int64)
+    m.mock_memory_stats.argtypes = [vp]
     m.mock_metrics_len.restype = ctypes.c_int64
     m.mock_metrics_len.argtypes = [vp]
     m.mock_metrics_pushes.restype = ctypes.c_int64
@@ -64,13 +68,27 @@ class Jvm:
         r.argtypes = [vp, vp, i64]
 
     def create_plan(self, stream_addrs, plan: bytes, config: bytes = b"", batch_size=8192, metrics_node=None, task_attempt_id=0,
-                    iterator_objects=None, metrics_interval_ms=1000):
+                    iterator_objects=None, metrics_interval_ms=1000, memory_manager=None):
         objs = iterator_objects if iterator_objects is not None else [self.m.mock_stream(a) for a in stream_addrs]
         arr = (ctypes.c_void_p * max(len(objs), 1))(*objs)
         its = self.m.mock_objs(arr, len(objs))
         return self.lib.Java_org_apache_comet_Native_createPlan(
             self.env, None, 1, its, self.m.mock_bytes(plan, len(plan)), self.m.mock_bytes(config, len(config)) if config else None, 1,
-            metrics_node, metrics_interval_ms, None, None, batch_size, 1, None, 0, 0, task_attempt_id, 1, None, None, None)
+            metrics_node, metrics_interval_ms, memory_manager, None, batch_size, 1, None, 0, 0, task_attempt_id, 1, None, None, None)
+
+    def memory_manager(self, limit: int):
+        """a CometTaskMemoryManager with `limit` bytes to grant; .stats() → dict"""
+        obj = self.m.mock_memory_manager(limit)
+        m = self.m
+
+        class _MM:
+            handle = obj
+
+            @staticmethod
+            def stats():
+                st = m.mock_memory_stats(obj)
+                return dict(limit=st[0], used=st[1], peak=st[2], acquires=st[3], releases=st[4], refused=st[5])
+        return _MM
 
     def execute_plan(self, handle, array_addrs, schema_addrs):
         a = (ctypes.c_int64 * max(len(array_addrs), 1))(*array_addrs)

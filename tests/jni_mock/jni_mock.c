@@ -8,7 +8,7 @@
 
 #include "../../datafusion-comet_amd/csrc/third_party/jni_min.h"
 
-enum { K_BYTES = 1, K_LONGS, K_OBJS, K_STREAM, K_METRICS, K_STRING, K_CLASS, K_BLOCKITER, K_INTS, K_INFO };
+enum { K_BYTES = 1, K_LONGS, K_OBJS, K_STREAM, K_METRICS, K_STRING, K_CLASS, K_BLOCKITER, K_INTS, K_INFO, K_MEMMGR };
 typedef struct MObj {
   int kind;
   int64_t len;
@@ -29,7 +29,8 @@ static MObj g_cls_stream = {K_CLASS, 0, 0, 0, 0, "org/apache/arrow/c/ArrowArrayS
 static MObj g_cls_metrics = {K_CLASS, 0, 0, 0, 0, "org/apache/spark/sql/comet/CometMetricNode"};
 static MObj g_cls_other = {K_CLASS, 0, 0, 0, 0, "java/lang/Object"};
 static MObj g_cls_blockiter = {K_CLASS, 0, 0, 0, 0, "org/apache/comet/CometShuffleBlockIterator"};
-static int g_mid_memaddr, g_mid_setall, g_mid_hasnext, g_mid_getbuffer, g_mid_info_ctor;
+static MObj g_cls_memmgr = {K_CLASS, 0, 0, 0, 0, "org/apache/spark/CometTaskMemoryManager"};
+static int g_mid_memaddr, g_mid_setall, g_mid_hasnext, g_mid_getbuffer, g_mid_info_ctor, g_mid_acquire, g_mid_release;
 
 static jclass f_FindClass(JNIEnv* e, const char* n) { (void)e; MObj* c = calloc(1, sizeof *c); c->kind = K_CLASS; c->cname = strdup(n); return c; }
 static jint f_ThrowNew(JNIEnv* e, jclass c, const char* m) {
@@ -45,7 +46,7 @@ static void f_DeleteLocalRef(JNIEnv* e, jobject o) { (void)e; (void)o; }
 static jclass f_GetObjectClass(JNIEnv* e, jobject o) {
   (void)e; MObj* m = o;
   return m->kind == K_STREAM ? (jclass)&g_cls_stream : m->kind == K_METRICS ? (jclass)&g_cls_metrics :
-         m->kind == K_BLOCKITER ? (jclass)&g_cls_blockiter : (jclass)&g_cls_other;
+         m->kind == K_BLOCKITER ? (jclass)&g_cls_blockiter : m->kind == K_MEMMGR ? (jclass)&g_cls_memmgr : (jclass)&g_cls_other;
 }
 static jmethodID f_GetMethodID(JNIEnv* e, jclass c, const char* n, const char* sig) {
   (void)e;
@@ -55,9 +56,25 @@ static jmethodID f_GetMethodID(JNIEnv* e, jclass c, const char* n, const char* s
     return &g_mid_info_ctor;
   if (c == &g_cls_blockiter && !strcmp(n, "hasNext") && !strcmp(sig, "()I")) return &g_mid_hasnext;
   if (c == &g_cls_blockiter && !strcmp(n, "getBuffer") && !strcmp(sig, "()Ljava/nio/ByteBuffer;")) return &g_mid_getbuffer;
+  if (c == &g_cls_memmgr && !strcmp(n, "acquireMemory") && !strcmp(sig, "(J)J")) return &g_mid_acquire;
+  if (c == &g_cls_memmgr && !strcmp(n, "releaseMemory") && !strcmp(sig, "(J)V")) return &g_mid_release;
   return NULL;   /* a real JVM would also raise NoSuchMethodError */
 }
-static jlong f_CallLongMethod(JNIEnv* e, jobject o, jmethodID m, ...) { (void)e; return m == &g_mid_memaddr ? ((MObj*)o)->addr : 0; }
+/* K_MEMMGR (CometTaskMemoryManager): data = int64[6] {limit, used, peak, acquire calls, release calls, bytes refused} */
+static jlong f_CallLongMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
+  (void)e;
+  if (m == &g_mid_memaddr) return ((MObj*)o)->addr;
+  if (m == &g_mid_acquire) {
+    va_list ap; va_start(ap, m); jlong want = va_arg(ap, jlong); va_end(ap);
+    int64_t* st = ((MObj*)o)->data;
+    int64_t room = st[0] - st[1];
+    int64_t got = want <= room ? want : (room > 0 ? room : 0);   /* Spark grants what is left, possibly less than asked */
+    st[1] += got; if (st[1] > st[2]) st[2] = st[1];
+    st[3]++; st[5] += want - got;
+    return got;
+  }
+  return 0;
+}
 /* K_BLOCKITER: data = MObj** blocks (K_BYTES standing in for direct ByteBuffers), len = count, addr = cursor */
 static jint f_CallIntMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
   (void)e; MObj* it = o;
@@ -90,6 +107,12 @@ static jobject f_NewObject(JNIEnv* e, jclass c, jmethodID m, ...) {
 }
 static void f_CallVoidMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
   (void)e;
+  if (m == &g_mid_release) {
+    va_list ap; va_start(ap, m); jlong n = va_arg(ap, jlong); va_end(ap);
+    int64_t* st = ((MObj*)o)->data;
+    st[1] -= n; st[4]++;
+    return;
+  }
   if (m != &g_mid_setall) return;
   va_list ap; va_start(ap, m); MObj* arr = va_arg(ap, MObj*); va_end(ap);
   MObj* node = o;
@@ -142,6 +165,8 @@ int64_t mock_info_address(void* o) { return ((MObj*)o)->addr; }
 int64_t mock_info_rows(void* o) { return ((MObj**)((MObj*)o)->data)[0]->len; }
 const void* mock_info_offsets(void* o) { return ((MObj**)((MObj*)o)->data)[0]->data; }
 const void* mock_info_lengths(void* o) { return ((MObj**)((MObj*)o)->data)[1]->data; }
+void* mock_memory_manager(int64_t limit) { MObj* o = calloc(1, sizeof *o); o->kind = K_MEMMGR; int64_t* st = calloc(6, 8); st[0] = limit; o->data = st; return o; }
+const int64_t* mock_memory_stats(void* o) { return ((MObj*)o)->data; }
 void* mock_plain_object(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_OBJS; return o; }
 void* mock_metrics_node(void) { MObj* o = calloc(1, sizeof *o); o->kind = K_METRICS; return o; }
 void* mock_string(const char* s) { MObj* o = calloc(1, sizeof *o); o->kind = K_STRING; o->data = strdup(s); return o; }

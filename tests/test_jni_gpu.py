@@ -200,3 +200,58 @@ def test_parquet_native_reader_reads_a_reference_fixture_batch_by_batch(built, t
     ks = pa.concat_arrays([b[1] for b in half]).to_pylist()
     assert 0 < len(ks) < n and len(ks) % 10_000 == 0 and ks == list(range(len(ks)))
     assert jvm.m.mock_live_global_refs() == 0
+
+
+def test_pinned_staging_is_charged_to_the_task_memory_manager(built):
+    """createPlan's taskMemoryManager (unified_pool.rs:64-150): every growth of the plan's pinned host staging goes through
+    CometTaskMemoryManager.acquireMemory on the task thread, everything is handed back by releasePlan, and a manager that grants less than
+    asked fails the task with the reference's message (after the partial grant is released)."""
+    jvm = Jvm(native.lib())
+    table = tpch.lineitem_q6(400_000, seed=9)
+    plan = tpch.q6_plan()
+
+    def run(mm):
+        inp = native.HostInput.from_table(table)
+        h = jvm.create_plan([inp.address], plan.encode(), task_attempt_id=77, memory_manager=mm.handle)
+        assert h > 0, jvm.exception()
+        arrays = [native.ArrowArrayC() for _ in range(2)]
+        schemas = [native.ArrowSchemaC() for _ in range(2)]
+        rows = jvm.execute_plan(h, [ctypes.addressof(a) for a in arrays], [ctypes.addressof(s) for s in schemas])
+        stats = (ctypes.c_int64 * 4)()
+        native.lib().comet_plan_memory_stats(h, stats)
+        during = mm.stats()
+        jvm.release_plan(h)
+        return rows, during, list(stats)
+
+    roomy = jvm.memory_manager(1 << 40)
+    rows, during, stats = run(roomy)
+    assert rows == 1, jvm.exception()
+    assert during["acquires"] > 0 and during["peak"] >= 400_000 * 8          # at least one column of the chunk staged in pinned memory
+    assert stats[1] == during["peak"] and stats[3] > 0                       # the plan's own counters agree with what Spark granted
+    after = roomy.stats()
+    assert after["used"] == 0 and after["releases"] > 0 and after["refused"] == 0
+
+    tight = jvm.memory_manager(64 << 10)                                     # 64 KiB: the first staging block does not fit
+    rows, during, _ = run(tight)
+    assert rows == 0
+    cls, msg = jvm.exception()
+    assert cls == "org/apache/comet/CometNativeException"
+    assert "Task 77 failed to acquire" in msg and "only got" in msg
+    jvm.m.mock_exception_clear()
+    assert tight.stats()["used"] == 0 and tight.stats()["refused"] > 0       # the partial grant went back; nothing leaks
+    assert jvm.m.mock_live_global_refs() == 0
+
+
+def test_hbm_budget_of_a_plan(built):
+    """spark.comet.gpu.memory.limit: HBM is not Spark's to grant, so a plan holds it against its own budget and fails loudly over it;
+    comet_plan_memory_stats reports what a run peaked at."""
+    table = tpch.lineitem_q1(300_000, seed=5)
+    plan = tpch.q1_plan().encode()
+    with pytest.raises(native.CometNativeException, match="GPU memory budget exceeded"):
+        native.execute_to_table([native.HostInput.from_table(table)], tpch.Q1_NUM_OUTPUT_COLS, plan, config=S.config_map({"spark.comet.gpu.memory.limit": str(1 << 20)}))
+    it = native.CometExecIterator([native.HostInput.from_table(table)], tpch.Q1_NUM_OUTPUT_COLS, plan, config=S.config_map({"spark.comet.gpu.memory.limit": str(8 << 30)}))
+    assert sum(b.num_rows for b in it) == 4
+    stats = (ctypes.c_int64 * 4)()
+    native.lib().comet_plan_memory_stats(it.handle, stats)
+    assert 0 < stats[3] < (8 << 30) and stats[1] > 0
+    it.close()

@@ -118,3 +118,23 @@ def test_shuffle_block_iterator_is_accepted_for_a_shuffle_scan_leaf(jvm):
     assert jvm.m.mock_live_global_refs() == 1
     jvm.release_plan(h)
     assert jvm.m.mock_live_global_refs() == 0
+
+
+def test_task_memory_manager_is_bound_and_released(jvm):
+    """createPlan takes a global ref on the CometTaskMemoryManager and binds acquireMemory(J)J / releaseMemory(J)V
+    (comet_task_memory_manager.rs:32-60); releasePlan drops it.  An object without those methods is ignored, not an error."""
+    mm = jvm.memory_manager(1 << 30)
+    inp = native.HostInput.from_table(tpch.lineitem_q6(10))
+    h = jvm.create_plan([inp.address], tpch.q6_plan().encode(), memory_manager=mm.handle)
+    assert h > 0 and jvm.exception() is None
+    assert jvm.m.mock_live_global_refs() == 2          # iterator + memory manager
+    stats = (ctypes.c_int64 * 4)(9, 9, 9, 9)
+    jvm.lib.comet_plan_memory_stats.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+    jvm.lib.comet_plan_memory_stats(h, stats)
+    assert list(stats) == [0, 0, 0, 0]                 # nothing staged before the first executePlan
+    jvm.release_plan(h)
+    assert jvm.m.mock_live_global_refs() == 0 and mm.stats()["used"] == 0
+    inp2 = native.HostInput.from_table(tpch.lineitem_q6(10))
+    h2 = jvm.create_plan([inp2.address], tpch.q6_plan().encode(), memory_manager=jvm.m.mock_plain_object())
+    assert h2 > 0 and jvm.exception() is None and jvm.m.mock_live_global_refs() == 1
+    jvm.release_plan(h2)
