@@ -3,6 +3,7 @@
 // buffer is copied back into pinned host memory that stays valid until the next convert / close — the contract of
 // ColumnarToRowContext::convert (buffer pointer + per-row offsets and lengths).
 #include <cstring>
+#include <climits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -131,25 +132,112 @@ int32_t comet_columnar_to_row_convert(int64_t handle, struct ArrowArray** arrays
       c.col_bufs.push_back(std::move(b));
       return d;
     };
+    // Host-side normalisation before the upload: a sliced array (offset != 0) and a dictionary-encoded array (the reference unpacks
+    // dictionaries first, columnar_to_row.rs "maybe_cast_dictionary") become plain zero-offset buffers; the temporaries live until
+    // the uploads have completed (first stream synchronisation below).
+    struct Plain { std::vector<uint8_t> valid, values, data; };
+    std::vector<std::unique_ptr<Plain>> temps;
+    auto get_bit = [](const uint8_t* bits, int64_t i) { return bits ? ((bits[i >> 3] >> (i & 7)) & 1) != 0 : true; };
     for (int i = 0; i < n_cols; i++) {
       const ArrowArray* a = arrays[i];
       if (a->length < n) throw CometError("columnarToRowConvert: column " + std::to_string(i) + " has fewer rows than num_rows");
-      if (a->offset != 0) throw CometError("columnarToRowConvert: arrays with a non-zero offset are not supported yet");
-      if (a->dictionary) throw CometError("columnarToRowConvert: dictionary-encoded columns are not supported yet");
       C2RCol& col = cols[(size_t)i];
-      col.kind = kind_of(schemas[i]->format);
       col.pad = 0;
-      col.valid_bits = (a->null_count != 0 && a->buffers[0]) ? (const uint8_t*)upload(a->buffers[0], (size_t)((n + 7) / 8)) : nullptr;
       col.data = nullptr;
+      const uint8_t* in_valid = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;
+      const int64_t off0 = a->offset;
+      if (a->dictionary) {
+        const ArrowArray* d = a->dictionary;
+        if (!schemas[i]->dictionary) throw CometError("columnarToRowConvert: dictionary array without a dictionary schema");
+        col.kind = kind_of(schemas[i]->dictionary->format);
+        const std::string ifmt = schemas[i]->format ? schemas[i]->format : "";
+        const int iw = (ifmt == "c" || ifmt == "C") ? 1 : (ifmt == "s" || ifmt == "S") ? 2 : (ifmt == "i" || ifmt == "I") ? 4 : (ifmt == "l" || ifmt == "L") ? 8 : 0;
+        if (!iw) throw CometError("columnarToRowConvert: dictionary index type '" + ifmt + "' is not supported");
+        const bool isigned = ifmt[0] >= 'a';
+        const uint8_t* ip = (const uint8_t*)a->buffers[1];
+        const uint8_t* dvalid = (d->null_count != 0 && d->n_buffers > 0) ? (const uint8_t*)d->buffers[0] : nullptr;
+        auto index_at = [&](int64_t r) -> int64_t {
+          const uint8_t* q = ip + (size_t)(off0 + r) * (size_t)iw;
+          switch (iw) {
+            case 1: return isigned ? (int64_t) * (const int8_t*)q : (int64_t)*q;
+            case 2: { uint16_t v; memcpy(&v, q, 2); return isigned ? (int64_t)(int16_t)v : (int64_t)v; }
+            case 4: { uint32_t v; memcpy(&v, q, 4); return isigned ? (int64_t)(int32_t)v : (int64_t)v; }
+            default: { int64_t v; memcpy(&v, q, 8); return v; }
+          }
+        };
+        auto t = std::make_unique<Plain>();
+        t->valid.assign((size_t)((n + 7) / 8) + 1, 0);
+        bool any_null = false;
+        std::vector<int64_t> idx((size_t)n, -1);
+        for (int64_t r = 0; r < n; r++) {
+          bool ok = get_bit(in_valid, off0 + r);
+          int64_t k = -1;
+          if (ok) {
+            k = index_at(r);
+            if (k < 0 || k >= d->length) throw CometError("columnarToRowConvert: dictionary index out of range");
+            ok = get_bit(dvalid, d->offset + k);
+          }
+          if (ok) { t->valid[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7)); idx[(size_t)r] = d->offset + k; }
+          else any_null = true;
+        }
+        if (col.kind == 9) {
+          const int32_t* doff = (const int32_t*)d->buffers[1];
+          const uint8_t* dbytes = (const uint8_t*)d->buffers[2];
+          t->values.resize((size_t)(n + 1) * 4);
+          int32_t* o = (int32_t*)t->values.data();
+          int64_t pos = 0;
+          for (int64_t r = 0; r < n; r++) {
+            o[r] = (int32_t)pos;
+            if (idx[(size_t)r] >= 0) pos += doff[idx[(size_t)r] + 1] - doff[idx[(size_t)r]];
+            if (pos > INT32_MAX) throw CometError("columnarToRow: the strings of one dictionary column exceed 2 GiB");
+          }
+          o[n] = (int32_t)pos;
+          t->data.resize((size_t)pos + 1);
+          for (int64_t r = 0; r < n; r++)
+            if (idx[(size_t)r] >= 0) memcpy(t->data.data() + o[r], dbytes + doff[idx[(size_t)r]], (size_t)(o[r + 1] - o[r]));
+          col.values = upload(t->values.data(), (size_t)(n + 1) * 4);
+          col.data = (const uint8_t*)upload(t->data.data(), (size_t)pos);
+        } else if (col.kind == 0) {
+          t->values.assign((size_t)((n + 7) / 8) + 1, 0);
+          const uint8_t* dv = (const uint8_t*)d->buffers[1];
+          for (int64_t r = 0; r < n; r++)
+            if (idx[(size_t)r] >= 0 && get_bit(dv, idx[(size_t)r])) t->values[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));
+          col.values = upload(t->values.data(), (size_t)((n + 7) / 8));
+        } else {
+          const size_t w = (size_t)width_of(col.kind);
+          t->values.assign((size_t)n * w + 16, 0);
+          const uint8_t* dv = (const uint8_t*)d->buffers[1];
+          for (int64_t r = 0; r < n; r++)
+            if (idx[(size_t)r] >= 0) memcpy(t->values.data() + (size_t)r * w, dv + (size_t)idx[(size_t)r] * w, w);
+          col.values = upload(t->values.data(), (size_t)n * w);
+        }
+        col.valid_bits = any_null ? (const uint8_t*)upload(t->valid.data(), (size_t)((n + 7) / 8)) : nullptr;
+        temps.push_back(std::move(t));
+        continue;
+      }
+      col.kind = kind_of(schemas[i]->format);
+      // validity and Boolean values are bit-addressed: a sliced array needs them re-packed from bit `offset`
+      auto repack = [&](const uint8_t* bits) -> const uint8_t* {
+        if (off0 == 0) return bits;
+        auto t = std::make_unique<Plain>();
+        t->valid.assign((size_t)((n + 7) / 8) + 1, 0);
+        for (int64_t r = 0; r < n; r++)
+          if (get_bit(bits, off0 + r)) t->valid[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));
+        const uint8_t* q = t->valid.data();
+        temps.push_back(std::move(t));
+        return q;
+      };
+      col.valid_bits = in_valid ? (const uint8_t*)upload(repack(in_valid), (size_t)((n + 7) / 8)) : nullptr;
       if (col.kind == 9) {
-        const int32_t* off = (const int32_t*)a->buffers[1];
+        const int32_t* off = (const int32_t*)a->buffers[1] + off0;      // offsets stay absolute into the data buffer
         col.values = upload(off, (size_t)(n + 1) * 4);
         const size_t total = n > 0 ? (size_t)off[n] : 0;
         col.data = (const uint8_t*)upload(a->buffers[2], total);
       } else if (col.kind == 0) {
-        col.values = upload(a->buffers[1], (size_t)((n + 7) / 8));
+        col.values = upload(repack((const uint8_t*)a->buffers[1]), (size_t)((n + 7) / 8));
       } else {
-        col.values = upload(a->buffers[1], (size_t)n * (size_t)width_of(col.kind));
+        const size_t w = (size_t)width_of(col.kind);
+        col.values = upload((const uint8_t*)a->buffers[1] + (size_t)off0 * w, (size_t)n * w);
       }
     }
     const int bitset_bytes = ((n_cols + 63) / 64) * 8, fixed_size = bitset_bytes + 8 * n_cols;

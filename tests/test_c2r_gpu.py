@@ -62,3 +62,32 @@ def test_through_the_jni_exports(built):
     rows = jvm.columnar_to_row(b)
     assert rows is not None, jvm.exception()
     assert rows == SO.unsafe_rows(b)
+
+
+def test_dictionary_encoded_and_sliced_inputs(built):
+    """Dictionary arrays are unpacked first (the reference: columnar_to_row.rs casts dictionaries to their value type) — every index width,
+    NULL indices and NULL dictionary entries, strings / decimals / booleans as values — and arrays exported with a non-zero offset (a
+    slice of a larger batch: validity and Boolean bits start mid-byte) convert like their materialised copies."""
+    from oracle import shuffle_oracle as SO
+    rng = np.random.default_rng(8)
+    n = 3000
+    plain = _batch(n, 8)
+    cols, names = [], []
+    words = pa.array([None if i % 13 == 0 else ["", "a", "lineitem", "värde", "x" * 40][i % 5] for i in range(n)], pa.string())
+    plain = plain.append_column("low", words)
+    for name, idx_type in (("low", pa.int8()), ("s", pa.int32()), ("dec", pa.int16()), ("i64", pa.int32()), ("f64", pa.int64()), ("b", pa.uint8()), ("wide", pa.uint16()), ("date", pa.int32())):
+        cols.append(plain.column(name).dictionary_encode().cast(pa.dictionary(idx_type, plain.column(name).type)))
+        names.append(name)
+    # a dictionary whose ENTRY is NULL (not only its indices)
+    d = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 3, n), pa.int32(), mask=rng.random(n) < 0.1), pa.array(["x", None, "zzz"]))
+    cols.append(d)
+    names.append("dnull")
+    b = pa.record_batch(cols, names=names)
+    want_src = pa.record_batch([c.dictionary_decode() for c in cols], names=names)
+    c = native.ColumnarToRow()
+    assert c.convert(b) == SO.unsafe_rows(want_src)
+    # slices: offsets 1, 7 and 1001 (not byte aligned), through plain and dictionary columns alike
+    for off, length in ((1, 50), (7, 1000), (1001, 1999)):
+        assert c.convert(plain.slice(off, length)) == SO.unsafe_rows(pa.record_batch([x.take(pa.array(range(off, off + length))) for x in plain.columns], names=plain.schema.names))
+        assert c.convert(b.slice(off, length)) == SO.unsafe_rows(want_src.slice(off, length))
+    c.close()

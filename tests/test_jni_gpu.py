@@ -250,7 +250,7 @@ def test_hbm_budget_of_a_plan(built):
     with pytest.raises(native.CometNativeException, match="GPU memory budget exceeded"):
         native.execute_to_table([native.HostInput.from_table(table)], tpch.Q1_NUM_OUTPUT_COLS, plan, config=S.config_map({"spark.comet.gpu.memory.limit": str(1 << 20)}))
     it = native.CometExecIterator([native.HostInput.from_table(table)], tpch.Q1_NUM_OUTPUT_COLS, plan, config=S.config_map({"spark.comet.gpu.memory.limit": str(8 << 30)}))
-    assert sum(b.num_rows for b in it) == 4
+    assert native.Native.executePlan(it.handle, tpch.Q1_NUM_OUTPUT_COLS).num_rows == 4
     stats = (ctypes.c_int64 * 4)()
     native.lib().comet_plan_memory_stats(it.handle, stats)
     assert 0 < stats[3] < (8 << 30) and stats[1] > 0
