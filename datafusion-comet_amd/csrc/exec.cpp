@@ -3761,6 +3761,7 @@ std::string ExecutionContext::metrics_proto() {
       n.metrics.emplace_back("bytes_scanned", bytes_scanned_);
       n.metrics.emplace_back("row_groups_pruned_statistics", row_groups_pruned_);
       n.metrics.emplace_back("pages_decompressed_on_device", pages_inflated_on_device_);
+      n.metrics.emplace_back("page_index_rows_pruned", rows_pruned_page_index_);
     }
     for (auto& c : op.children) n.children.push_back(build(*c, false));
     return n;

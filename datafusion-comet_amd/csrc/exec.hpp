@@ -256,6 +256,7 @@ class ExecutionContext {
   int64_t bytes_scanned_ = 0;
   int64_t row_groups_pruned_ = 0;
   std::shared_ptr<MemAccount> mem_ = std::make_shared<MemAccount>();
+  int64_t rows_pruned_page_index_ = 0;     // rows the Parquet page index ruled out (never decoded)
   int64_t pages_inflated_on_device_ = 0;   // data pages decompressed by snappy_kernels.hip
 
   std::vector<std::unique_ptr<Staging>> staging_;   // per input stream

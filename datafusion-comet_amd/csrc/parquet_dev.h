@@ -20,6 +20,10 @@ typedef struct PqPage {        /* one data page of a column (all selected row gr
   int32_t kind;                /* PQ_* conversion */
   int32_t width;               /* source value width in bytes (FLBA length, 4, 8, 12) */
   int32_t dec_scale_up;        /* PQ_*_TO_DEC: multiply the unscaled value by 10^dec_scale_up (decimal scale widening) */
+  /* page-index pruning keeps only some rows of a page: an entry then covers the kept rows [row_start, row_start + num_values) of the
+   * OUTPUT, which are the page's rows lvl_skip … — the page's first lvl_skip levels and first val_skip (non-NULL) values are passed over */
+  int32_t lvl_skip;
+  int32_t val_skip;
   int32_t pad1;
 } PqPage;
 

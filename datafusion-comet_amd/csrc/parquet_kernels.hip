@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void pq_validity_kernel(PqDecodeArgs a) {
       const PqPage pg = a.pages[pq_find_page(a.pages, a.npages, row)];
       if (pg.def_run_count > 0) {
         int bw = a.max_def == 1 ? 1 : (32 - __clz(a.max_def));
-        u32 lvl = pq_hybrid_value(a.def_runs, pg.def_run_first, pg.def_run_count, a.bytes, bw, (i32)(row - pg.row_start));
+        u32 lvl = pq_hybrid_value(a.def_runs, pg.def_run_first, pg.def_run_count, a.bytes, bw, (i32)(row - pg.row_start) + pg.lvl_skip);
         valid = lvl == (u32)a.max_def;
       }
     }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
   const u8* __restrict__ dict = a.dict;
   int p = -1;                                   // the wave's page …
   i64 pg_row_start = 0, pg_values_off = 0, pg_dict_off = 0, next_page_row = -1;   // … and the first row of the page after it
-  i32 pg_encoding = 0, pg_bit_width = 0, pg_kind = 0, pg_width = 0, pg_dec_up = 0, pg_idx_first = 0, pg_idx_count = 0;
+  i32 pg_encoding = 0, pg_bit_width = 0, pg_kind = 0, pg_width = 0, pg_dec_up = 0, pg_idx_first = 0, pg_idx_count = 0, pg_val_skip = 0;
   int r = -1, run_page = -1;                    // the wave's run (dictionary pages) …
   i64 rn_byte_off = 0;
   i32 rn_value_start = 0, rn_is_rle = 0, next_run_val = 0;   // … and the first value index of the run after it (within the page)
@@ -185,12 +185,12 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
       const PqPage* q = a.pages + p;
       pg_row_start = q->row_start; pg_values_off = q->values_off; pg_dict_off = q->dict_off;
       pg_encoding = q->encoding; pg_bit_width = q->bit_width; pg_kind = q->kind; pg_width = q->width; pg_dec_up = q->dec_scale_up;
-      pg_idx_first = q->idx_run_first; pg_idx_count = q->idx_run_count;
+      pg_idx_first = q->idx_run_first; pg_idx_count = q->idx_run_count; pg_val_skip = q->val_skip;
       next_page_row = p + 1 < a.npages ? a.pages[p + 1].row_start : kNever;
     }
     if (pg_encoding == 1) {
       // the run holding the wave's first value
-      const i32 v0 = a.max_def > 0 ? (i32)(a.vidx[row0] - a.vidx[pg_row_start]) : (i32)(row0 - pg_row_start);
+      const i32 v0 = (a.max_def > 0 ? (i32)(a.vidx[row0] - a.vidx[pg_row_start]) : (i32)(row0 - pg_row_start)) + pg_val_skip;
       const int last0 = pg_idx_first + pg_idx_count - 1;
       bool reload = false;
       if (run_page != p) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
     bool ok[R];
     // fast path: the lane's rows lie in the wave's page and bit-packed run and the column has no NULLs → ONE load holds all indices
     const bool no_nulls = a.max_def == 0;
-    const i32 lv0 = (i32)(lrow - pg_row_start);
+    const i32 lv0 = (i32)(lrow - pg_row_start) + pg_val_skip;
     const bool all_here = lrow + R <= end && lrow + R <= next_page_row;
     const bool packed_fast = pg_encoding == 1 && no_nulls && all_here && !rn_is_rle && lv0 + R <= next_run_val && pg_bit_width * R <= 56;
     u64 packed = 0;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
       }
       // the element's own page: the wave's, unless a page boundary falls inside this step
       i64 l_row_start = pg_row_start, l_values_off = pg_values_off, l_dict_off = pg_dict_off;
-      i32 l_encoding = pg_encoding, l_bit_width = pg_bit_width, l_idx_first = pg_idx_first, l_idx_count = pg_idx_count;
+      i32 l_encoding = pg_encoding, l_bit_width = pg_bit_width, l_idx_first = pg_idx_first, l_idx_count = pg_idx_count, l_val_skip = pg_val_skip;
       const bool here = row < next_page_row;
       if (!here) {
         int qi = p;
@@ -252,9 +252,9 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
         const PqPage* q = a.pages + qi;
         l_row_start = q->row_start; l_values_off = q->values_off; l_dict_off = q->dict_off;
         l_encoding = q->encoding; l_bit_width = q->bit_width; kind[k] = q->kind; width[k] = q->width; dec_up[k] = q->dec_scale_up;
-        l_idx_first = q->idx_run_first; l_idx_count = q->idx_run_count;
+        l_idx_first = q->idx_run_first; l_idx_count = q->idx_run_count; l_val_skip = q->val_skip;
       }
-      const i32 v = a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[l_row_start]) : (i32)(row - l_row_start);
+      const i32 v = (a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[l_row_start]) : (i32)(row - l_row_start)) + l_val_skip;
       if (l_encoding == 1) {
         u32 idx;
         if (here && v < next_run_val) {            // v ≥ rn_value_start holds: v ≥ v0 ≥ the run's first value
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
 // 4. strings: lengths, then (after the host-driven offset scan) bytes
 __device__ __forceinline__ void pq_string_ref(const PqDecodeArgs& a, i64 row, const u8*& p, u32& len) {
   const PqPage pg = a.pages[pq_find_page(a.pages, a.npages, row)];
-  const i32 v = a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[pg.row_start]) : (i32)(row - pg.row_start);
+  const i32 v = (a.max_def > 0 ? (i32)(a.vidx[row] - a.vidx[pg.row_start]) : (i32)(row - pg.row_start)) + pg.val_skip;
   if (pg.encoding == 1) {
     u32 idx = pq_hybrid_value(a.idx_runs, pg.idx_run_first, pg.idx_run_count, a.bytes, pg.bit_width, v);
     const i32* doffs = a.dict_offs + pg.dict_offs_first;

@@ -216,13 +216,22 @@ RowGroup read_row_group(TReader& r) {
         uint32_t n;
         r.list_header(et, n);
         for (uint32_t i = 0; i < n; i++) {
-          // ColumnChunk { 1 file_path, 2 file_offset, 3 meta_data }
+          // ColumnChunk { 1 file_path, 2 file_offset, 3 meta_data, 4 offset_index_offset, 5 offset_index_length, 6 column_index_offset,
+          //               7 column_index_length }
           int16_t f2 = 0;
           ColumnMeta cm;
+          int64_t oio = 0, cio = 0;
+          int32_t oil = 0, cil = 0;
           while (int t2 = r.field(f2)) {
             if (f2 == 3 && t2 == 12) cm = read_column_meta(r);
+            else if (f2 == 4 && t2 == 6) oio = r.zigzag();
+            else if (f2 == 5 && t2 == 5) oil = (int32_t)r.zigzag();
+            else if (f2 == 6 && t2 == 6) cio = r.zigzag();
+            else if (f2 == 7 && t2 == 5) cil = (int32_t)r.zigzag();
             else r.skip(t2);
           }
+          cm.offset_index_offset = oio; cm.offset_index_length = oil;
+          cm.column_index_offset = cio; cm.column_index_length = cil;
           g.columns.push_back(std::move(cm));
         }
         break;
@@ -469,6 +478,54 @@ PageHeader parse_page_header(const uint8_t* p, size_t avail) {
 }
 
 size_t snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t want) { return snappy_prefix_impl(src, n, dst, want); }
+
+PageIndex parse_page_index(const uint8_t* column_index, size_t ci_len, const uint8_t* offset_index, size_t oi_len) {
+  PageIndex pi;
+  {
+    // OffsetIndex { 1: list<PageLocation{1 offset, 2 compressed_page_size, 3 first_row_index}> page_locations }
+    TReader r(offset_index, oi_len);
+    int16_t fid = 0;
+    while (int t = r.field(fid)) {
+      if (fid == 1 && t == 9) {
+        int et;
+        uint32_t n;
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) {
+          int16_t f2 = 0;
+          int64_t first = 0;
+          while (int t2 = r.field(f2)) {
+            if (f2 == 3) first = r.zigzag();
+            else r.skip(t2);
+          }
+          pi.first_row.push_back(first);
+        }
+      } else r.skip(t);
+    }
+  }
+  {
+    // ColumnIndex { 1: list<bool> null_pages, 2: list<binary> min_values, 3: list<binary> max_values, 4: boundary_order, 5: list<i64> null_counts }
+    TReader r(column_index, ci_len);
+    int16_t fid = 0;
+    while (int t = r.field(fid)) {
+      int et;
+      uint32_t n;
+      if (fid == 1 && t == 9) {
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) pi.null_page.push_back(r.byte() == 1);     // compact protocol: a bool in a list is one byte, 1 = true
+      } else if ((fid == 2 || fid == 3) && t == 9) {
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) (fid == 2 ? pi.min_value : pi.max_value).push_back(r.binary());
+      } else if (fid == 5 && t == 9) {
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) pi.null_count.push_back(r.zigzag());
+      } else r.skip(t);
+    }
+  }
+  const size_t n = pi.first_row.size();
+  if (pi.null_page.size() != n || pi.min_value.size() != n || pi.max_value.size() != n || (!pi.null_count.empty() && pi.null_count.size() != n))
+    throw CometError("parquet: ColumnIndex and OffsetIndex disagree on the number of pages");
+  return pi;
+}
 
 void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) {
   switch (codec) {

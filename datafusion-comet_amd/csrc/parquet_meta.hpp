@@ -43,7 +43,19 @@ struct ColumnMeta {
   bool has_min_max = false;
   std::string min_value, max_value;   // PLAIN-encoded
   int64_t null_count = -1;            // -1 = not recorded
+  // page index (ColumnChunk fields 4-7): where the OffsetIndex / ColumnIndex of this chunk sit in the file (0 = the writer wrote none)
+  int64_t offset_index_offset = 0, column_index_offset = 0;
+  int32_t offset_index_length = 0, column_index_length = 0;
 };
+
+// The page index of one column chunk (parquet.thrift ColumnIndex / OffsetIndex): one entry per DATA page, in file order.
+struct PageIndex {
+  std::vector<int64_t> first_row;          // OffsetIndex.page_locations[i].first_row_index (row-group relative)
+  std::vector<char> null_page;             // ColumnIndex.null_pages: the page holds only NULLs (min / max are then meaningless)
+  std::vector<std::string> min_value, max_value;   // PLAIN-encoded
+  std::vector<int64_t> null_count;         // empty if the writer recorded none
+};
+PageIndex parse_page_index(const uint8_t* column_index, size_t ci_len, const uint8_t* offset_index, size_t oi_len);
 
 struct RowGroup {
   std::vector<ColumnMeta> columns;

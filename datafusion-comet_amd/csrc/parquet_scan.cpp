@@ -458,6 +458,95 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, const Sc
   return cp;
 }
 
+// Statistics of a column chunk or of one of its pages, seen the same way (PLAIN-encoded min / max)
+struct StatView {
+  bool has_min_max = false;
+  const std::string* mn = nullptr;
+  const std::string* mx = nullptr;
+  int64_t null_count = -1, num_values = 0;
+  bool all_null = false;
+};
+bool stat_i64(const StatView& sv, const pq::SchemaElement& el, int64_t& mn, int64_t& mx) {
+  if (!sv.has_min_max || !sv.mn || !sv.mx) return false;
+  auto rd = [&](const std::string& b, int64_t& v) {
+    if (el.type == pq::INT32 && b.size() == 4) { int32_t x; memcpy(&x, b.data(), 4); v = x; return true; }
+    if (el.type == pq::INT64 && b.size() == 8) { memcpy(&v, b.data(), 8); return true; }
+    return false;
+  };
+  return rd(*sv.mn, mn) && rd(*sv.mx, mx);
+}
+// the file column a bound reference of a pushed-down filter names: its leaf index, schema element and the type the scan reads it as
+struct LeafCol { int leaf = -1; const pq::SchemaElement* el = nullptr; DType want; };
+bool leaf_column(const Expr& b, const std::vector<StructField>& schema, const pq::FileMeta& fm, size_t ncols_in_rg, bool case_sensitive, LeafCol& out) {
+  if (b.kind != ExprKind::Bound || b.bound_index < 0 || (size_t)b.bound_index >= schema.size()) return false;
+  const StructField& f = schema[(size_t)b.bound_index];
+  int leaf = 0;
+  for (size_t i = 1; i < fm.schema.size(); i++) {
+    const pq::SchemaElement& e = fm.schema[i];
+    if (e.num_children > 0) return false;
+    if ((case_sensitive && e.name == f.name) || (!case_sensitive && iequals(e.name, f.name))) {
+      if ((size_t)leaf >= ncols_in_rg) return false;
+      out.leaf = leaf;
+      out.el = &e;
+      out.want = f.dtype;
+      return true;
+    }
+    leaf++;
+  }
+  return false;
+}
+// A leaf predicate (IsNotNull(col), col <cmp> literal) split into its parts; false = not a shape statistics can decide
+struct LeafPred { ExprKind kind; const Expr* col = nullptr; const Expr* lit = nullptr; };
+bool leaf_pred(const Expr& pred, LeafPred& lp) {
+  if (pred.kind == ExprKind::IsNotNull && pred.children.size() == 1) {
+    lp.kind = ExprKind::IsNotNull;
+    lp.col = pred.children[0].get();
+    return true;
+  }
+  const bool cmp = pred.kind == ExprKind::Eq || pred.kind == ExprKind::Lt || pred.kind == ExprKind::LtEq || pred.kind == ExprKind::Gt || pred.kind == ExprKind::GtEq;
+  if (!cmp || pred.children.size() != 2) return false;
+  const Expr *l = pred.children[0].get(), *r = pred.children[1].get();
+  ExprKind k = pred.kind;
+  if (l->kind == ExprKind::Literal) {   // literal <op> column  →  column <flipped op> literal
+    std::swap(l, r);
+    k = k == ExprKind::Lt ? ExprKind::Gt : k == ExprKind::LtEq ? ExprKind::GtEq : k == ExprKind::Gt ? ExprKind::Lt : k == ExprKind::GtEq ? ExprKind::LtEq : k;
+  }
+  lp.kind = k;
+  lp.col = l;
+  lp.lit = r;
+  return true;
+}
+// do these statistics prove the leaf predicate FALSE (or NULL) for every row they cover?
+bool stats_prove_false(const LeafPred& lp, const LeafCol& c, const StatView& sv) {
+  if (lp.kind == ExprKind::IsNotNull) return sv.all_null || (sv.null_count >= 0 && sv.null_count == sv.num_values && sv.num_values > 0);
+  if (sv.all_null) return true;       // a comparison with NULL is never true
+  int64_t v, mn, mx;
+  const pq::SchemaElement* el = c.el;
+  const DType& t = c.want;
+  if (!lit_i64(*lp.lit, v) || !stat_i64(sv, *el, mn, mx)) return false;
+  // statistics are in the file's unit / signedness: do not compare them with a microsecond or signed literal
+  if ((el->ts_unit != 0 && el->ts_unit != 2) || (el->int_bits > 0 && !el->int_signed) || el->type == pq::INT96) return false;
+  if (t.id == TypeId::Decimal && (el->scale != t.scale || !(lp.lit->dtype.id == TypeId::Decimal && lp.lit->dtype.scale == t.scale))) return false;   // same scale only
+  if (t.id != TypeId::Decimal && lp.lit->dtype.id == TypeId::Decimal) return false;
+  switch (lp.kind) {
+    case ExprKind::Eq: return v < mn || v > mx;
+    case ExprKind::Lt: return mn >= v;
+    case ExprKind::LtEq: return mn > v;
+    case ExprKind::Gt: return mx <= v;
+    case ExprKind::GtEq: return mx < v;
+    default: return false;
+  }
+}
+StatView chunk_stats(const pq::ColumnMeta& cm) {
+  StatView sv;
+  sv.has_min_max = cm.has_min_max;
+  sv.mn = &cm.min_value;
+  sv.mx = &cm.max_value;
+  sv.null_count = cm.null_count;
+  sv.num_values = cm.num_values;
+  return sv;
+}
+
 // Host half of one column chunk (one column of one row group): page walk, decompression straight into the column's pinned
 // staging block at the chunk's slot, hybrid-run tables.  Independent of every other chunk, so chunks are prepared by a
 // pool of host threads (scan_parquet); the calling thread then concatenates a column's tables and decodes the WHOLE column
@@ -473,52 +562,104 @@ bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::
       if (!prunes(*c, schema, fm, rg, case_sensitive)) return false;
     return !pred.children.empty();
   }
-  auto column_of = [&](const Expr& b, const pq::ColumnMeta*& cm, const pq::SchemaElement*& el, DType& want) {
-    if (b.kind != ExprKind::Bound || b.bound_index < 0 || (size_t)b.bound_index >= schema.size()) return false;
-    const StructField& f = schema[(size_t)b.bound_index];
-    int leaf = 0;
-    for (size_t i = 1; i < fm.schema.size(); i++) {
-      const pq::SchemaElement& e = fm.schema[i];
-      if (e.num_children > 0) return false;
-      if ((case_sensitive && e.name == f.name) || (!case_sensitive && iequals(e.name, f.name))) {
-        if ((size_t)leaf >= rg.columns.size()) return false;
-        cm = &rg.columns[(size_t)leaf];
-        el = &e;
-        want = f.dtype;
-        return true;
+  LeafPred lp;
+  LeafCol col;
+  if (!leaf_pred(pred, lp) || !leaf_column(*lp.col, schema, fm, rg.columns.size(), case_sensitive, col)) return false;
+  return stats_prove_false(lp, col, chunk_stats(rg.columns[(size_t)col.leaf]));
+}
+
+// ---- page-index pruning: which ROWS of a row group can a pushed-down filter still be true for? ---------------------------------------
+// Sorted, disjoint [begin, end) row ranges (row-group relative).
+typedef std::vector<std::pair<int64_t, int64_t>> Ranges;
+Ranges ranges_and(const Ranges& a, const Ranges& b) {
+  Ranges o;
+  size_t i = 0, j = 0;
+  while (i < a.size() && j < b.size()) {
+    const int64_t lo = std::max(a[i].first, b[j].first), hi = std::min(a[i].second, b[j].second);
+    if (lo < hi) o.emplace_back(lo, hi);
+    if (a[i].second < b[j].second) i++;
+    else j++;
+  }
+  return o;
+}
+Ranges ranges_or(const Ranges& a, const Ranges& b) {
+  Ranges all(a);
+  all.insert(all.end(), b.begin(), b.end());
+  std::sort(all.begin(), all.end());
+  Ranges o;
+  for (auto& r : all) {
+    if (!o.empty() && r.first <= o.back().second) o.back().second = std::max(o.back().second, r.second);
+    else o.push_back(r);
+  }
+  return o;
+}
+int64_t ranges_rows(const Ranges& r) {
+  int64_t n = 0;
+  for (auto& x : r) n += x.second - x.first;
+  return n;
+}
+// loads (once per column chunk) and caches the page index of the chunks a filter refers to
+struct PageIndexCache {
+  const OpenFile* file;
+  const pq::RowGroup* rg;
+  std::map<int, std::shared_ptr<pq::PageIndex>> by_leaf;   // nullptr = the chunk has no (usable) page index
+  const pq::PageIndex* get(int leaf) {
+    auto it = by_leaf.find(leaf);
+    if (it != by_leaf.end()) return it->second.get();
+    std::shared_ptr<pq::PageIndex> pi;
+    const pq::ColumnMeta& cm = rg->columns[(size_t)leaf];
+    if (cm.column_index_offset > 0 && cm.column_index_length > 0 && cm.offset_index_offset > 0 && cm.offset_index_length > 0 &&
+        (size_t)(cm.column_index_offset + cm.column_index_length) <= file->size && (size_t)(cm.offset_index_offset + cm.offset_index_length) <= file->size) {
+      try {
+        std::vector<uint8_t> ci((size_t)cm.column_index_length), oi((size_t)cm.offset_index_length);
+        file->read_at(ci.data(), ci.size(), cm.column_index_offset);
+        file->read_at(oi.data(), oi.size(), cm.offset_index_offset);
+        pi = std::make_shared<pq::PageIndex>(pq::parse_page_index(ci.data(), ci.size(), oi.data(), oi.size()));
+        if (pi->first_row.empty() || pi->first_row[0] != 0) pi.reset();
+      } catch (const CometError&) {
+        pi.reset();      // an index this reader cannot make sense of prunes nothing
       }
-      leaf++;
     }
-    return false;
-  };
-  if (pred.kind == ExprKind::IsNotNull && pred.children.size() == 1) {
-    const pq::ColumnMeta* cm; const pq::SchemaElement* el; DType t;
-    if (!column_of(*pred.children[0], cm, el, t)) return false;
-    return cm->null_count >= 0 && cm->null_count == cm->num_values && cm->num_values > 0;
+    by_leaf[leaf] = pi;
+    return pi.get();
   }
-  const bool cmp = pred.kind == ExprKind::Eq || pred.kind == ExprKind::Lt || pred.kind == ExprKind::LtEq || pred.kind == ExprKind::Gt || pred.kind == ExprKind::GtEq;
-  if (!cmp || pred.children.size() != 2) return false;
-  const Expr *l = pred.children[0].get(), *r = pred.children[1].get();
-  ExprKind k = pred.kind;
-  if (l->kind == ExprKind::Literal) {   // literal <op> column  →  column <flipped op> literal
-    std::swap(l, r);
-    k = k == ExprKind::Lt ? ExprKind::Gt : k == ExprKind::LtEq ? ExprKind::GtEq : k == ExprKind::Gt ? ExprKind::Lt : k == ExprKind::GtEq ? ExprKind::LtEq : k;
+};
+// rows of the row group for which `pred` may still be true, by the page statistics (ColumnIndex) of the columns it refers to
+Ranges may_match(const Expr& pred, const std::vector<StructField>& schema, const pq::FileMeta& fm, const pq::RowGroup& rg, bool case_sensitive, PageIndexCache& pic) {
+  const Ranges all{{0, rg.num_rows}};
+  if (pred.kind == ExprKind::And) {
+    Ranges r = all;
+    for (auto& c : pred.children) r = ranges_and(r, may_match(*c, schema, fm, rg, case_sensitive, pic));
+    return r;
   }
-  const pq::ColumnMeta* cm; const pq::SchemaElement* el; DType t;
-  int64_t v, mn, mx;
-  if (!column_of(*l, cm, el, t) || !lit_i64(*r, v) || !stat_i64(*cm, *el, mn, mx)) return false;
-  // statistics are in the file's unit / signedness: do not compare them with a microsecond or signed literal
-  if ((el->ts_unit != 0 && el->ts_unit != 2) || (el->int_bits > 0 && !el->int_signed) || el->type == pq::INT96) return false;
-  if (t.id == TypeId::Decimal && (el->scale != t.scale || !(r->dtype.id == TypeId::Decimal && r->dtype.scale == t.scale))) return false;   // same scale only
-  if (t.id != TypeId::Decimal && r->dtype.id == TypeId::Decimal) return false;
-  switch (k) {
-    case ExprKind::Eq: return v < mn || v > mx;
-    case ExprKind::Lt: return mn >= v;
-    case ExprKind::LtEq: return mn > v;
-    case ExprKind::Gt: return mx <= v;
-    case ExprKind::GtEq: return mx < v;
-    default: return false;
+  if (pred.kind == ExprKind::Or) {
+    if (pred.children.empty()) return all;
+    Ranges r;
+    for (auto& c : pred.children) r = ranges_or(r, may_match(*c, schema, fm, rg, case_sensitive, pic));
+    return r;
   }
+  LeafPred lp;
+  LeafCol col;
+  if (!leaf_pred(pred, lp) || !leaf_column(*lp.col, schema, fm, rg.columns.size(), case_sensitive, col)) return all;
+  const pq::PageIndex* pi = pic.get(col.leaf);
+  if (!pi) return all;
+  Ranges r;
+  const size_t np = pi->first_row.size();
+  for (size_t k = 0; k < np; k++) {
+    const int64_t lo = pi->first_row[k], hi = k + 1 < np ? pi->first_row[k + 1] : rg.num_rows;
+    if (hi <= lo) continue;
+    StatView sv;
+    sv.all_null = pi->null_page[k] != 0;
+    sv.has_min_max = !sv.all_null;
+    sv.mn = &pi->min_value[k];
+    sv.mx = &pi->max_value[k];
+    sv.num_values = hi - lo;
+    sv.null_count = pi->null_count.empty() ? -1 : pi->null_count[k];
+    if (stats_prove_false(lp, col, sv)) continue;
+    if (!r.empty() && r.back().second == lo) r.back().second = hi;
+    else r.emplace_back(lo, hi);
+  }
+  return r;
 }
 
 struct HostChunk {
@@ -529,6 +670,7 @@ struct HostChunk {
   int64_t compressed = 0;
   size_t spos = 0;                 // staged (uploaded) bytes actually used
   size_t ipos = 0;                 // bytes of the device-decompressed region used
+  int64_t pages_skipped = 0;       // data pages the page index ruled out
   std::vector<PqInflate> inflate;  // page bodies the device decompresses (offsets relative to the chunk's slot in either region)
   std::vector<PqPage> pages;
   std::vector<PqRun> def_runs, idx_runs;
@@ -542,6 +684,7 @@ struct ChunkSource {
   const OpenFile* file;
   const pq::FileMeta* meta;
   int rg;
+  const Ranges* keep;      // rows of the row group the page index could not rule out (nullptr: all of them)
 };
 
 // bytes the staged (decompressed) pages of a column chunk may take
@@ -560,7 +703,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   hc.cp = cp;
   const int max_def = cp.el.repetition == 1 ? 1 : 0;
   hc.max_def = max_def;
-  hc.n_rows = rg.num_rows;
+  hc.n_rows = src.keep ? ranges_rows(*src.keep) : rg.num_rows;
   hc.compressed = cm.total_compressed;
   size_t spos = 0;
   std::vector<PqPage>& pages = hc.pages;
@@ -577,8 +720,56 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   if (raw.size() < (size_t)cm.total_compressed + 16) raw.resize((size_t)cm.total_compressed + 16);
   src.file->read_at(raw.data(), (size_t)cm.total_compressed, off);
   const uint8_t* chunk_data = raw.data() - off;   // so that chunk_data + file_offset addresses the byte
-  int64_t values_seen = 0;
+  int64_t values_seen = 0;      // rows of the row group the pages walked so far cover
+  int64_t out_pos = 0;          // kept rows emitted so far (the chunk's output rows)
+  size_t keep_i = 0;            // first kept range that may still overlap the next page
   std::vector<uint8_t> tmp;
+  // the kept pieces of the page [r0, r1): one PqPage entry each, passing over the page's first levels / non-NULL values
+  // (`levels`: the bytes the page's definition-level runs refer to, addressed like the runs' byte_off without its region flag)
+  auto emit = [&](const PqPage& pg, int64_t r0, int64_t r1, const uint8_t* levels) {
+    auto non_null_before = [&](int64_t upto) -> int64_t {      // values among the page's first `upto` levels
+      if (max_def == 0 || pg.def_run_count == 0) return upto;
+      int64_t cnt = 0;
+      for (int32_t k = 0; k < pg.def_run_count; k++) {
+        const PqRun& r = def_runs[(size_t)(pg.def_run_first + k)];
+        if (r.value_start >= upto) break;
+        const int64_t m = std::min<int64_t>(r.count, upto - r.value_start);
+        if (r.is_rle) {
+          if (r.rle_value == (uint32_t)max_def) cnt += m;
+        } else {
+          const uint8_t* b = levels + (r.byte_off & ~kInflatedBit);
+          for (int64_t i = 0; i < m; i++) cnt += (b[i >> 3] >> (i & 7)) & 1;     // max_def == 1: one bit per level
+        }
+      }
+      return cnt;
+    };
+    if (!src.keep) {
+      PqPage q = pg;
+      q.row_start = out_pos;
+      pages.push_back(q);
+      out_pos += r1 - r0;
+      return;
+    }
+    const Ranges& keep = *src.keep;
+    while (keep_i < keep.size() && keep[keep_i].second <= r0) keep_i++;
+    for (size_t k = keep_i; k < keep.size() && keep[k].first < r1; k++) {
+      const int64_t a = std::max(keep[k].first, r0), b = std::min(keep[k].second, r1);
+      if (a >= b) continue;
+      PqPage q = pg;
+      q.row_start = out_pos;
+      q.num_values = (int32_t)(b - a);
+      q.lvl_skip = (int32_t)(a - r0);
+      q.val_skip = (int32_t)non_null_before(a - r0);
+      pages.push_back(q);
+      out_pos += b - a;
+    }
+  };
+  auto page_is_kept = [&](int64_t r0, int64_t r1) {
+    if (!src.keep) return true;
+    const Ranges& keep = *src.keep;
+    while (keep_i < keep.size() && keep[keep_i].second <= r0) keep_i++;
+    return keep_i < keep.size() && keep[keep_i].first < r1;
+  };
   while (values_seen < cm.num_values && off < chunk_end) {
     pq::PageHeader h = pq::parse_page_header(chunk_data + off, (size_t)(chunk_end - off));
     const uint8_t* body = chunk_data + off + h.header_len;
@@ -606,6 +797,11 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       continue;
     }
     if (h.type != pq::DATA_PAGE && h.type != pq::DATA_PAGE_V2) continue;   // index pages etc.
+    if (!page_is_kept(values_seen, values_seen + h.num_values)) {            // ruled out by the page index: not even decompressed
+      values_seen += h.num_values;
+      hc.pages_skipped++;
+      continue;
+    }
     if (spos + (size_t)h.uncompressed_size + 16 > staged_cap) {
       // total_uncompressed_size excludes nothing we stage, but stay safe against odd writers
       throw CometError("parquet: column chunk larger than its declared uncompressed size");
@@ -669,8 +865,8 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       hc.ipos = ipage + un_len;
       pg.encoding = 0;
       pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
+      emit(pg, values_seen, values_seen + h.num_values, tmp.data() - ipage);
       values_seen += h.num_values;
-      pages.push_back(pg);
       continue;
     }
     if (h.type == pq::DATA_PAGE) {
@@ -767,10 +963,10 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       throw CometError("parquet: value encoding " + std::to_string(h.encoding) + " is not supported yet (PLAIN and RLE_DICTIONARY are)");
     }
     spos = page_end;
+    emit(pg, values_seen, values_seen + h.num_values, staged);
     values_seen += h.num_values;
-    pages.push_back(pg);
   }
-  if (values_seen != hc.n_rows) throw CometError("parquet: column chunk values do not add up to the row group's rows (nested data?)");
+  if (values_seen != rg.num_rows || out_pos != hc.n_rows) throw CometError("parquet: column chunk values do not add up to the row group's rows (nested data?)");
   if (pages.empty()) throw CometError("parquet: column chunk without data pages");
   memset(staged + spos, 0, 16);
   hc.spos = spos;
@@ -883,8 +1079,13 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     return nullptr;
   };
 
+  bool page_index = true;
+  if (const char* e = getenv("COMET_PARQUET_PAGE_INDEX")) page_index = atoi(e) != 0;
+  for (auto& kv : config_)
+    if (kv.first == "spark.comet.gpu.scan.pageIndex" || kv.first == "spark.sql.parquet.columnindex.access.enabled") page_index = kv.second != "false" && kv.second != "0";
   // pass 1: open files, pick row groups (midpoint rule), total rows
-  struct Sel { std::shared_ptr<OpenFile> file; std::shared_ptr<pq::FileMeta> meta; int rg; int64_t row_off; const PartitionedFile* pf; int64_t rows; };
+  struct Sel { std::shared_ptr<OpenFile> file; std::shared_ptr<pq::FileMeta> meta; int rg; int64_t row_off; const PartitionedFile* pf; int64_t rows;
+               std::shared_ptr<Ranges> keep; };      // keep: the rows the page index could not rule out (null: all of them)
   std::vector<Sel> sels;
   int64_t total_rows = 0;
   for (auto& pf : op.files) {
@@ -904,8 +1105,25 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       for (auto& df : op.data_filters)
         if (prunes(*df, op.required_schema, *fm, rg, op.case_sensitive)) { skip = true; break; }
       if (skip) { row_groups_pruned_++; continue; }
-      sels.push_back({mf, fm, (int)g, total_rows, &pf, rg.num_rows});
-      total_rows += rg.num_rows;
+      // page index (ColumnIndex / OffsetIndex, parquet_exec.rs enables DataFusion's page-index pruning): the rows a pushed-down filter can
+      // still be true for; pages outside them are neither decompressed nor uploaded, and the scan emits only the kept rows — the Filter
+      // above re-checks every row it gets, exactly as it does after row-group pruning
+      std::shared_ptr<Ranges> keep;
+      int64_t rows = rg.num_rows;
+      if (page_index && !op.data_filters.empty()) {
+        PageIndexCache pic{mf.get(), &rg, {}};
+        Ranges r{{0, rg.num_rows}};
+        for (auto& df : op.data_filters) r = ranges_and(r, may_match(*df, op.required_schema, *fm, rg, op.case_sensitive, pic));
+        const int64_t kept = ranges_rows(r);
+        if (kept == 0) { row_groups_pruned_++; rows_pruned_page_index_ += rg.num_rows; continue; }
+        if (kept < rg.num_rows) {
+          keep = std::make_shared<Ranges>(std::move(r));
+          rows = kept;
+          rows_pruned_page_index_ += rg.num_rows - kept;
+        }
+      }
+      sels.push_back({mf, fm, (int)g, total_rows, &pf, rows, keep});
+      total_rows += rows;
     }
   }
   out.rows = total_rows;
@@ -988,7 +1206,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy PLAIN pages, decompressed on the %s\n", (double)plain_snappy_bytes / 1e6, so.device_snappy ? "device" : "host");
   auto run_task = [&](size_t t) {
     const size_t c = t / nsel, si = t % nsel;
-    ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg};
+    ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg, sels[si].keep.get()};
     if (all_missing[c]) return;
     uint8_t* slot = (uint8_t*)col_staged[c]->p + slot_off[c][si];
     const size_t cap = slot_off[c][si + 1] - slot_off[c][si];
