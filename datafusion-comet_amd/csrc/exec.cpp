@@ -1881,29 +1881,55 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
       stage_aux_[c]->ensure(total_bytes + 16);
       if (has_valid[c]) stage_valid_[c]->ensure((size_t)((rows + 7) / 8) + 16);
       int32_t* so = (int32_t*)stage_vals_[c]->p;
+      // one job per input batch: where its rows and bytes land is a running sum over the batches; rebasing the offsets, copying the
+      // bytes and noticing whether all values share one length are independent per batch and spread over the scan threads (a single
+      // thread walking 4 M offsets per chunk was what held the Utf8 columns of the host path below the PCIe rate)
+      struct StrJob { const ArrowArray* col; int64_t at; int32_t pos; int uniform; };
+      std::vector<StrJob> sjobs;
       int64_t at = 0;
       int32_t pos = 0;
-      int uniform = -2;   // -2 no value seen yet, -1 lengths differ, else the common length
       for (auto& a : held) {
         const ArrowArray* col = a.children[c];
         if (col->dictionary) throw CometError("dictionary-encoded input columns are not unpacked on the GPU path yet");
+        sjobs.push_back({col, at, pos, -2});
+        pos += (int32_t)(off_at(col, col->length) - off_at(col, 0));
+        at += col->length;
+      }
+      auto run_job = [&](StrJob& j) {
+        const ArrowArray* col = j.col;
         const int64_t base = off_at(col, 0);
+        int uniform = -2;   // -2 no value seen yet, -1 lengths differ, else the common length
+        int32_t* dst = so + j.at;
         for (int64_t i = 0; i < col->length; i++) {
           const int64_t o = off_at(col, i);
-          so[at + i] = pos + (int32_t)(o - base);
+          dst[i] = j.pos + (int32_t)(o - base);
           const int len = (int)(off_at(col, i + 1) - o);
           if (uniform == -2) uniform = len;
           else if (uniform != len) uniform = -1;
         }
-        size_t nb = (size_t)(off_at(col, col->length) - base);
-        if (nb) memcpy((char*)stage_aux_[c]->p + pos, (const char*)col->buffers[2] + base, nb);
-        if (has_valid[c]) {
-          if (col->null_count != 0 && col->buffers[0]) bit_append((uint8_t*)stage_valid_[c]->p, at, (const uint8_t*)col->buffers[0], col->offset, col->length);
-          else bit_fill_ones((uint8_t*)stage_valid_[c]->p, at, col->length);
-        }
-        pos += (int32_t)nb;
-        at += col->length;
+        j.uniform = uniform;
+        const size_t nb = (size_t)(off_at(col, col->length) - base);
+        if (nb) memcpy((char*)stage_aux_[c]->p + j.pos, (const char*)col->buffers[2] + base, nb);
+      };
+      if (rows >= (1 << 20) && sjobs.size() > 1) {
+        const size_t parts = std::min<size_t>(16, sjobs.size());
+        scan_pool_parallel(parts, [&](size_t pidx) {
+          for (size_t k = pidx; k < sjobs.size(); k += parts) run_job(sjobs[k]);
+        });
+      } else {
+        for (auto& j : sjobs) run_job(j);
       }
+      int uniform = -2;
+      for (auto& j : sjobs) {
+        if (j.col->length == 0) continue;
+        if (uniform == -2) uniform = j.uniform;
+        else if (uniform != j.uniform) uniform = -1;
+      }
+      if (has_valid[c])       // bitmaps are small and batches need not start on a byte boundary: appended in order on this thread
+        for (auto& j : sjobs) {
+          if (j.col->null_count != 0 && j.col->buffers[0]) bit_append((uint8_t*)stage_valid_[c]->p, j.at, (const uint8_t*)j.col->buffers[0], j.col->offset, j.col->length);
+          else bit_fill_ones((uint8_t*)stage_valid_[c]->p, j.at, j.col->length);
+        }
       so[rows] = pos;
       dev_vals_[c]->ensure((size_t)(rows + 1) * 4 + 16);
       dev_aux_[c]->ensure(total_bytes + 16);
