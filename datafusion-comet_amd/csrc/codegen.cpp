@@ -886,6 +886,59 @@ struct Gen {
     return r;
   }
 
+  // Output-only string functions of a Utf8 column (ScalarFunc substring / trim family / rpad / lpad / read_side_padding with literal
+  // arguments): the row's result is described as a comet::strview — which bytes of the source value, how many pad characters — and the
+  // column is assembled by the executor, so the result may have any length (as an operand of another expression these functions take
+  // the packed ≤ 15-byte path of scalar_func, or are rejected).  Returns false when `e` is not of that shape.
+  bool string_view(const Expr& e, Val& out, OutCol& oc) {
+    if (e.kind != ExprKind::ScalarFunc || e.children.empty() || !is_str_col(e.children[0])) return false;
+    const std::string& f = e.func;
+    auto int_lit = [](const ExprP& x, long long& v) {
+      if (x->kind != ExprKind::Literal || x->lit_null || !x->dtype.is_integer()) return false;
+      v = x->lit_i64;
+      return true;
+    };
+    auto clamp32 = [](long long v) { return std::max<long long>(std::min<long long>(v, 0x7fffffffLL), -0x7fffffffLL); };
+    const int idx = e.children[0]->bound_index;
+    std::string call;
+    if (f == "substring" || f == "substr") {
+      long long pos = 0, len = 0x7fffffffLL;
+      if (e.children.size() < 2 || e.children.size() > 3 || !int_lit(e.children[1], pos) || (e.children.size() == 3 && !int_lit(e.children[2], len))) return false;
+      call = "utf8_view_substr(@, " + std::to_string(clamp32(pos)) + ", " + std::to_string(clamp32(len)) + ")";
+    } else if (f == "trim" || f == "btrim" || f == "ltrim" || f == "rtrim") {
+      if (e.children.size() != 1) return false;      // a trim string is a different function
+      call = std::string("utf8_view_trim(@, ") + (f == "ltrim" ? "1" : f == "rtrim" ? "2" : "3") + ")";
+    } else if (f == "rpad" || f == "lpad" || f == "read_side_padding") {
+      long long n = 0;
+      if (e.children.size() < 2 || e.children.size() > 3 || !int_lit(e.children[1], n)) return false;
+      std::string pat = " ";
+      if (e.children.size() == 3) {
+        if (!is_str_lit(e.children[2])) return false;
+        pat = e.children[2]->lit_bytes;
+      }
+      size_t chars = 0;
+      for (unsigned char ch : pat) chars += (ch & 0xC0) != 0x80;
+      if (pat.size() > 64 || chars > 32) throw CometError(f + ": pad strings of more than 32 characters are not supported");
+      oc.pad_pattern = pat;
+      oc.pad_left = f == "lpad";
+      call = "utf8_view_pad(@, " + std::to_string(clamp32(n)) + ", " + (f == "read_side_padding" ? "false" : "true") + ")";
+    } else {
+      return false;
+    }
+    Val valid = str_col_validity(idx);
+    auto loc = locate(idx);
+    const std::string args = "prm.in[" + std::to_string(loc.first) + "], " + loc.second;
+    call.replace(call.find('@'), 1, args);
+    std::string v = newvar("comet::strview");
+    stmt(v + " = comet::" + call + ";");
+    out.t = DType::of(TypeId::String);
+    out.rep = Rep::I64;      // opaque to everything but the store below
+    out.v = v;
+    out.ok = valid.ok;
+    oc.view_src = idx;
+    return true;
+  }
+
   // ScalarFunc (expr.proto:466-471 → create_comet_physical_fun, comet_scalar_funcs.rs): the subset whose results are defined
   // exactly (integer / IEEE operations): ceil, floor, abs, sqrt, signum, isnan, datepart.  Everything else is rejected by name.
   Val scalar_func(const Expr& e) {
@@ -1941,6 +1994,19 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         ex << "  output: " << explain_expr(c) << " : " << v.t.str() << " (gathered)\n";
         continue;
       }
+      {
+        // a string function of a Utf8 COLUMN with literal arguments whose result is a slice of the value plus padding: any length
+        OutCol voc;
+        Val vv;
+        if (ge.string_view(*c, vv, voc)) {
+          outs.push_back(vv);
+          voc.type = vv.t;
+          voc.nullable = !vv.ok.empty();
+          d.out_cols.push_back(voc);
+          ex << "  output: " << explain_expr(c) << " : " << vv.t.str() << " (string view of column " << voc.view_src << ")\n";
+          continue;
+        }
+      }
       Val v = ge.named(ge.gen(c));
       outs.push_back(v);
       OutCol oc;
@@ -1956,6 +2022,11 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       const Val& v = outs[j];
       std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * j) + "]";
       std::string ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * j + 1) + "]";
+      if (d.out_cols[j].view_src >= 0) {
+        ge.stmt("((comet::strview*)" + vb + ")[pos[r]] = " + v.v + ";");
+        if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");
+        continue;
+      }
       if (d.out_cols[j].gather_src >= 0) {
         ge.stmt("((u32*)" + vb + ")[pos[r]] = (u32)" + v.v + ";");
         if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");

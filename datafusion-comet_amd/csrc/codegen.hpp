@@ -21,6 +21,11 @@ struct OutCol {
   // the executor gathers offsets + bytes afterwards (any string length).  gather_src = source column; for joins it indexes
   // left ++ right.  -1 = not a gathered column.
   int gather_src = -1;
+  // Utf8 RESULT of any length that is a slice of source column view_src plus padding (substring, trim, rpad / lpad, read-side padding):
+  // the kernel writes a comet::strview (16 bytes) per output row, the executor sizes and writes offsets + bytes afterwards
+  int view_src = -1;
+  std::string pad_pattern;          // the pad string (≤ 64 bytes, ≤ 32 characters)
+  bool pad_left = false;
 };
 
 // How the host must treat each group-key word / accumulator word of a grouped aggregate.

@@ -123,6 +123,67 @@ CDEV str16 utf8_substr16(const CometCol& c, i64 i, i32 pos, i32 len, bool& toolo
   return r;
 }
 
+// A string RESULT of any length that is a slice of a source value plus padding: (source row, first byte and byte count inside that
+// value, number of pad CHARACTERS).  The projection's kernel writes one of these per output row; the executor then sizes and writes
+// the Utf8 column (strview kernels, exchange_kernels.hip).  substring / trim / rpad / lpad / read-side padding all reduce to it.
+struct strview { u32 row, start, len, pad; };
+CDEV strview utf8_view_substr(const CometCol& c, i64 i, i32 pos, i32 len) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], nbytes = off[j + 1] - lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  strview r = {(u32)i, 0u, 0u, 0u};
+  i64 start;
+  if (pos > 0) start = (i64)pos - 1;
+  else if (pos < 0) {
+    i32 nchars = 0;
+    for (i32 k = 0; k < nbytes; k++) nchars += (p[k] & 0xC0) != 0x80;
+    start = (i64)nchars + pos;
+  } else start = 0;
+  // Spark's substringSQL: a window that starts before the string is clipped to it (its end stays where it was)
+  i64 until = start + (i64)len;
+  if (start < 0) start = 0;
+  if (until <= start || start >= nbytes) return r;
+  i32 k = 0;
+  i64 ch = 0;
+  while (k < nbytes && ch < start) { k++; while (k < nbytes && (p[k] & 0xC0) == 0x80) k++; ch++; }
+  const i32 b0 = k;
+  while (k < nbytes && ch < until) { k++; while (k < nbytes && (p[k] & 0xC0) == 0x80) k++; ch++; }
+  r.start = (u32)b0;
+  r.len = (u32)(k - b0);
+  return r;
+}
+// mode: 1 leading, 2 trailing, 3 both — the space character U+0020 only (Spark's trim without a trim string)
+CDEV strview utf8_view_trim(const CometCol& c, i64 i, int mode) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], nbytes = off[j + 1] - lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  i32 a = 0, b = nbytes;
+  if (mode & 1) while (a < b && p[a] == 0x20) a++;
+  if (mode & 2) while (b > a && p[b - 1] == 0x20) b--;
+  strview r = {(u32)i, (u32)a, (u32)(b - a), 0u};
+  return r;
+}
+// pad (or, with `truncate`, cut) the value to `target` characters: rpad / lpad truncate, read-side padding of CHAR(n) columns does not
+// (static_invoke/char_varchar_utils/read_side_padding.rs:35-47)
+CDEV strview utf8_view_pad(const CometCol& c, i64 i, i32 target, bool truncate) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], nbytes = off[j + 1] - lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  strview r = {(u32)i, 0u, (u32)nbytes, 0u};
+  if (target < 0) target = 0;
+  i32 k = 0, ch = 0;
+  while (k < nbytes && ch < target) { k++; while (k < nbytes && (p[k] & 0xC0) == 0x80) k++; ch++; }
+  if (k < nbytes) {            // longer than the target: first `target` characters, or the whole value
+    if (truncate) r.len = (u32)k;
+  } else {
+    r.pad = (u32)(target - ch);
+  }
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Scalar functions (ScalarFunc, expr.proto:466-471): the exact, integer/IEEE-defined subset.
 // ---------------------------------------------------------------------------------------------

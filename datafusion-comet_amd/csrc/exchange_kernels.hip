@@ -250,6 +250,37 @@ __global__ __launch_bounds__(256) void take_utf8_copy_kernel(const i32* offs, co
   }
 }
 
+// ---- string views (comet_device.hpp strview): a slice of a source value plus pad characters from a repeating pattern ----
+struct StrView { u32 row, start, len, pad; };
+struct PadPattern {          // ≤ 32 characters / 64 bytes; char_off[i] = byte offset of the first i characters of one repetition
+  u32 nchars, nbytes;
+  u8 bytes[64];
+  u8 char_off[36];
+};
+__device__ __forceinline__ u32 pad_byte_count(const PadPattern& pp, u32 chars) {
+  if (pp.nchars == 0) return 0;
+  return (chars / pp.nchars) * pp.nbytes + pp.char_off[chars % pp.nchars];
+}
+__global__ __launch_bounds__(256) void strview_lengths_kernel(const StrView* v, const u8* ok_bytes, i64 n, PadPattern pp, u32* lengths) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256)
+    lengths[k] = (!ok_bytes || ok_bytes[k]) ? v[k].len + pad_byte_count(pp, v[k].pad) : 0u;
+}
+__global__ __launch_bounds__(256) void strview_copy_kernel(const StrView* v, const u8* ok_bytes, const i32* src_offs, const u8* src_bytes, i64 n, PadPattern pp,
+                                                           int pad_left, const i32* out_offs, u8* out_bytes) {
+  const int sub = threadIdx.x & 7;
+  for (i64 k = ((i64)blockIdx.x * 256 + threadIdx.x) >> 3; k < n; k += ((i64)gridDim.x * 256) >> 3) {
+    const i32 lo = out_offs[k], total = out_offs[k + 1] - lo;
+    if (total <= 0) continue;
+    const StrView sv = v[k];
+    const i32 padb = total - (i32)sv.len;
+    const u8* src = src_bytes + src_offs[sv.row] + sv.start;
+    u8* dst = out_bytes + lo;
+    const i32 val_at = pad_left ? padb : 0, pad_at = pad_left ? 0 : (i32)sv.len;
+    for (i32 b = sub; b < (i32)sv.len; b += 8) dst[val_at + b] = src[b];
+    for (i32 b = sub; b < padb; b += 8) dst[pad_at + b] = pp.bytes[(u32)b % pp.nbytes];
+  }
+}
+
 // ---- constant columns (Hive partition values of a Parquet scan): dst[first .. first+n) = value
 template <class T>
 __global__ __launch_bounds__(256) void fill_kernel(T* dst, i64 n, T value) {
@@ -363,6 +394,36 @@ int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const
                                 int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream) {
   if (n > 0)
     hipLaunchKernelGGL(take_utf8_copy_kernel, grid_for(n * 8), 256, 0, (hipStream_t)stream, offs, bytes, idx, ok_bytes, src_valid_bits, (i64)n, out_offs, out_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// pattern: the pad string's bytes (≤ 64 bytes, ≤ 32 characters; validated by the caller)
+static PadPattern make_pattern(const uint8_t* pattern, int32_t nbytes) {
+  PadPattern pp;
+  memset(&pp, 0, sizeof pp);
+  pp.nbytes = (u32)nbytes;
+  u32 ch = 0;
+  for (int32_t b = 0; b < nbytes; b++) {
+    pp.bytes[b] = pattern[b];
+    if ((pattern[b] & 0xC0) != 0x80) pp.char_off[ch++] = (u8)b;
+  }
+  pp.char_off[ch] = (u8)nbytes;
+  pp.nchars = ch;
+  return pp;
+}
+int comet_launch_strview_lengths(const void* views, const uint8_t* ok_bytes, int64_t n, const uint8_t* pattern, int32_t pattern_bytes, uint32_t* lengths, void* stream) {
+  if (pattern_bytes < 0 || pattern_bytes > 64) return -1;
+  const PadPattern pp = make_pattern(pattern, pattern_bytes);
+  if (pp.nchars > 32) return -1;
+  if (n > 0) hipLaunchKernelGGL(strview_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, (const StrView*)views, ok_bytes, (i64)n, pp, lengths);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_strview_copy(const void* views, const uint8_t* ok_bytes, const int32_t* src_offs, const uint8_t* src_bytes, int64_t n, const uint8_t* pattern,
+                              int32_t pattern_bytes, int pad_left, const int32_t* out_offs, uint8_t* out_bytes, void* stream) {
+  if (pattern_bytes < 0 || pattern_bytes > 64) return -1;
+  const PadPattern pp = make_pattern(pattern, pattern_bytes);
+  if (n > 0)
+    hipLaunchKernelGGL(strview_copy_kernel, grid_for(n * 8), 256, 0, (hipStream_t)stream, (const StrView*)views, ok_bytes, src_offs, src_bytes, (i64)n, pp, pad_left,
+                       out_offs, out_bytes);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // width ∈ {1,2,4,8,16}: value points to `width` bytes on the HOST

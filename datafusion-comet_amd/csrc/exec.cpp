@@ -283,6 +283,9 @@ extern "C" int comet_launch_window_rank(int kind, int64_t arg, const int32_t* sp
                                         void* out, void* stream);
 extern "C" int comet_launch_window_offset(int64_t shift, const int32_t* sp, const uint32_t* first_part, int64_t n, uint32_t* idx, uint8_t* ok, void* stream);
 extern "C" int comet_launch_window_offset_valid(const uint32_t* idx, const uint8_t* ok, const uint8_t* src_valid_bits, int64_t n, uint8_t* out_ok, void* stream);
+extern "C" int comet_launch_strview_lengths(const void* views, const uint8_t* ok_bytes, int64_t n, const uint8_t* pattern, int32_t pattern_bytes, uint32_t* lengths, void* stream);
+extern "C" int comet_launch_strview_copy(const void* views, const uint8_t* ok_bytes, const int32_t* src_offs, const uint8_t* src_bytes, int64_t n, const uint8_t* pattern,
+                                         int32_t pattern_bytes, int pad_left, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" int comet_launch_str16_lengths(const void* packed, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream);
 extern "C" int comet_launch_str16_copy(const void* packed, const int32_t* offsets, int64_t n, uint8_t* bytes, void* stream);
 extern "C" int comet_launch_str_max_len(const int32_t* offs, int64_t n, uint32_t* out_max, void* stream);
@@ -316,7 +319,7 @@ extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int3
 namespace {
 
 int fixed_width(const DType& t);
-int out_width(const OutCol& oc) { return oc.gather_src >= 0 ? 4 : oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
+int out_width(const OutCol& oc) { return oc.view_src >= 0 ? 16 : oc.gather_src >= 0 ? 4 : oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
 
 int fixed_width(const DType& t) {
   switch (t.id) {
@@ -677,7 +680,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     explain_ = pv->desc.explain;
     sink_ = pv->desc.sink;
     if (sink_ == SinkKind::Output)
-      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0 || oc.packed_string;   // Utf8 outputs are finished on the device (gather / unpack)
+      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0 || oc.packed_string || oc.view_src >= 0;   // Utf8 outputs are finished on the device (gather / unpack)
     // a grouped aggregate keyed by Utf8 columns sees its whole input at once (like a join input): only then can strings longer
     // than the packed 15 bytes be swapped for representative row indices (prepare_dict_keys)
     if (sink_ == SinkKind::AggGrouped && !pv->desc.str_key_cols.empty()) has_join_ = true;
@@ -821,6 +824,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       for (size_t k = 0; k < at.size(); k++) {
         types[p][at[k]] = d.out_cols[k].type;
         known[p][at[k]] = true;
+        if (d.out_cols[k].view_src >= 0) throw CometError("Expand: string functions with results of any length are not supported inside a grouping-set projection yet");
         gsrc[p][at[k]] = d.out_cols[k].packed_string ? -2 : d.out_cols[k].gather_src;   // −2: a computed (packed) string
       }
     }
@@ -1280,7 +1284,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
 
   if (d.sink == SinkKind::Output) {
     for (auto& oc : d.out_cols)
-      if (oc.gather_src >= 0) throw CometError("internal: gathered Utf8 outputs must go through the materialising path");
+      if (oc.gather_src >= 0 || oc.view_src >= 0) throw CometError("internal: gathered Utf8 outputs must go through the materialising path");
     const size_t ncol = d.out_cols.size();
     int64_t out_rows = n;
     if (out_vals_.size() < ncol) {
@@ -2125,8 +2129,10 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
         if (len[k] < 0 || f[k] != 0) continue;
         const size_t c = scols[k];
         const ArrowArray* col = da->array.children[c];
+        // value i then sits at aux + (offset + i)·len.  Only claimed when that base IS the data buffer (an unsliced column), because the
+        // offset-based accessors (substring, LIKE, views …) of the same kernels keep addressing aux + offsets[i]
+        if ((int64_t)first[k] != (int64_t)col->offset * len[k]) continue;
         views[c].fixed_len = len[k];
-        views[c].aux = (const char*)col->buffers[2] + first[k] - (int64_t)col->offset * len[k];
       }
     }
   }
@@ -2208,6 +2214,36 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
       if (rows) read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
       bytes->ensure((size_t)total + 16);
       if (comet_launch_str16_copy(vals[j]->p, (const int32_t*)offsets->p, rows, (uint8_t*)bytes->p, stream_) != 0) throw CometError("packed strings: launch failed");
+      HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
+      cv.data = offsets->p;
+      cv.aux = bytes->p;
+      t.owners.push_back(offsets);
+      t.owners.push_back(bytes);
+    }
+    if (oc.view_src >= 0) {
+      // the emit kernel wrote one strview per row (source row, byte slice, pad characters): lengths, prefix sum, copy
+      if (!gather_source) throw CometError("internal: string-view column without a source table");
+      auto src = gather_source(oc.view_src);
+      const DeviceColumnView& sc = src.first->cols[(size_t)src.second];
+      if (sc.fixed_len >= 0 && !sc.data) throw CometError("internal: string view over a column without offsets");
+      const uint8_t* okb = (oc.nullable && rows) ? (const uint8_t*)valid_bytes[j]->p : nullptr;
+      const uint8_t* pat = (const uint8_t*)oc.pad_pattern.data();
+      const int32_t patn = (int32_t)oc.pad_pattern.size();
+      DevBuf lengths, tiles;
+      auto offsets = std::make_shared<DevBuf>(), bytes = std::make_shared<DevBuf>();
+      lengths.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
+      tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+      offsets->ensure((size_t)(rows + 2) * 4);
+      if (rows == 0) HIP_CHECK(hipMemsetAsync(offsets->p, 0, 8, stream_));
+      if (comet_launch_strview_lengths(vals[j]->p, okb, rows, pat, patn, (uint32_t*)lengths.p, stream_) != 0) throw CometError("string view: launch failed");
+      if (rows) pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)offsets->p, stream_);
+      int32_t total = 0;
+      if (rows) read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
+      if (total < 0) throw CometError("Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+      bytes->ensure((size_t)total + 16);
+      if (comet_launch_strview_copy(vals[j]->p, okb, (const int32_t*)sc.data + sc.offset, (const uint8_t*)sc.aux, rows, pat, patn, oc.pad_left ? 1 : 0,
+                                    (const int32_t*)offsets->p, (uint8_t*)bytes->p, stream_) != 0)
+        throw CometError("string view: launch failed");
       HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
       cv.data = offsets->p;
       cv.aux = bytes->p;

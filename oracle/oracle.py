@@ -405,6 +405,24 @@ class Evaluator:
                     return ""
                 return v[max(start, 0):max(until, 0)]
             return Col(S.T_STRING, np.array([sub(v) if v is not None else None for v in a.values], dtype=object), a.valid)
+        if f in ("trim", "btrim", "ltrim", "rtrim") and len(e.children) == 1:
+            # Spark's trim without a trim string removes the space character U+0020 only (UTF8String.trim / trimLeft / trimRight)
+            a = self.eval(e.children[0], cols, n)
+            fn = {"trim": lambda v: v.strip(" "), "btrim": lambda v: v.strip(" "), "ltrim": lambda v: v.lstrip(" "), "rtrim": lambda v: v.rstrip(" ")}[f]
+            return Col(S.T_STRING, np.array([fn(v) if v is not None else None for v in a.values], dtype=object), a.valid)
+        if f in ("rpad", "lpad", "read_side_padding"):
+            # static_invoke/char_varchar_utils/read_side_padding.rs:35-47,345-420: pad to `length` CHARACTERS with the pattern repeated;
+            # rpad / lpad cut a longer value to `length` characters, read-side padding of CHAR(n) columns leaves it alone
+            a = self.eval(e.children[0], cols, n)
+            length = max(int(e.children[1].value), 0)
+            pat = e.children[2].value if len(e.children) > 2 else " "
+
+            def pad(v):
+                if len(v) >= length:
+                    return v[:length] if f != "read_side_padding" else v
+                fill = (pat * (length // max(len(pat), 1) + 1))[:length - len(v)] if pat else ""
+                return fill + v if f == "lpad" else v + fill
+            return Col(S.T_STRING, np.array([pad(v) if v is not None else None for v in a.values], dtype=object), a.valid)
         if f in ("starts_with", "ends_with", "contains"):
             # byte-wise on the UTF-8 encodings (UTF8_BINARY collation; strings.scala:343-360)
             a, lit = self.eval(e.children[0], cols, n), e.children[1].value.encode()

@@ -39,6 +39,22 @@ def test_substring_known_answers():
     assert _col(sub(2, -1), t) == ["", "", None]
 
 
+def test_trim_and_padding_known_answers():
+    # Spark docs: trim('    SparkSQL   ') = 'SparkSQL'; rpad('hi', 5, '??') = 'hi???'; rpad('hi', 1, '??') = 'h'; lpad('hi', 5, '??') = '???hi'; rpad('hi', 5) = 'hi   '.
+    # The reference's read_side_padding tests (read_side_padding.rs tests): a CHAR(5) value 'hi' reads as 'hi   ', a longer value is left as it is.
+    t = pa.table({"s": pa.array(["    SparkSQL   ", "hi", "日本", "hello world", "", None])})
+    s, I, L = S.col(0, S.T_STRING), lambda v: S.lit(v, S.T_INT32), lambda v: S.lit(v, S.T_STRING)
+    f = lambda name, *a: S.project(S.scan([S.T_STRING]), [S.scalar_func(name, [s] + list(a), S.T_STRING)])
+    assert _col(f("trim"), t) == ["SparkSQL", "hi", "日本", "hello world", "", None]
+    assert _col(f("ltrim"), t)[0] == "SparkSQL   " and _col(f("rtrim"), t)[0] == "    SparkSQL"
+    assert _col(f("rpad", I(5), L("??")), t)[1:] == ["hi???", "日本???", "hello", "?????", None]
+    assert _col(f("rpad", I(1), L("??")), t)[1:3] == ["h", "日"]
+    assert _col(f("lpad", I(5), L("??")), t)[1:3] == ["???hi", "???日本"]
+    assert _col(f("rpad", I(5)), t)[1] == "hi   "
+    assert _col(f("rpad", I(7), L("abc")), t)[1] == "hiabcab"
+    assert _col(f("read_side_padding", I(5)), t)[1:] == ["hi   ", "日本   ", "hello world", "     ", None]
+
+
 def test_round_known_answers():
     # Spark docs: round(2.5, 0) = 3 (HALF_UP); the reference's tests: round(-2.5) = -3, round(125, -1) = 130, round(-125, -1) = -130
     D = S.decimal(5, 1)
