@@ -11,6 +11,7 @@
 #include "exec.hpp"
 #include "shuffle_format.hpp"
 #include "parquet_meta.hpp"
+#include "regex.hpp"
 #include "row_shuffle.hpp"
 
 using namespace comet;
@@ -372,6 +373,13 @@ int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size
       out[n] = 0;
     }
     return 0;
+  });
+}
+
+int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t value_len) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    const RegexDfa d = compile_rlike(pattern ? pattern : "");
+    return regex_dfa_match(d, value, value_len) ? 1 : 0;
   });
 }
 

@@ -12,6 +12,7 @@
 //   CheckOverflow        planner.rs:600-649, spark-expr/src/math_funcs/internal/checkoverflow.rs:103-160
 //   aggregates           planner.rs:2558-2700, spark-expr/src/agg_funcs/*.rs (state schemas)
 #include "codegen.hpp"
+#include "regex.hpp"
 #include "kparams.h"
 
 #include <cstdio>
@@ -1297,6 +1298,26 @@ struct Gen {
     }
     return str_pred_lit("utf8_like_lit", idx, p);
   }
+  // RLike (expr.proto:55 → predicate_funcs/rlike.rs: regex::Regex::is_match, an unanchored search): the pattern is compiled on the host
+  // into a byte-level search DFA (regex.cpp — the exactly reproducible subset, everything else refused by name) whose tables are
+  // emitted into the kernel source as constants
+  Val rlike(const Expr& e) {
+    if (e.children.size() != 2 || !is_str_col(e.children[0]) || !is_str_lit(e.children[1]))
+      throw CometError("RLIKE is supported for a Utf8 column and a literal pattern");
+    const int idx = e.children[0]->bound_index;
+    const RegexDfa dfa = compile_rlike(e.children[1]->lit_bytes);
+    Val valid = str_col_validity(idx);
+    auto loc = locate(idx);
+    std::string b = newvar("bool");
+    stmt(b + " = comet::utf8_rlike(prm.in[" + std::to_string(loc.first) + "], " + loc.second + ", " + c_bytes(std::string((const char*)dfa.trans.data(), dfa.trans.size())) + ", " +
+         c_bytes(std::string((const char*)dfa.flags.data(), dfa.flags.size())) + ");");
+    Val r;
+    r.t = DType::of(TypeId::Bool);
+    r.rep = Rep::B;
+    r.v = valid.ok.empty() ? b : "(" + valid.ok + " && " + b + ")";
+    r.ok = valid.ok;
+    return r;
+  }
   Val str_compare_cols(ExprKind k, int ia, int ib) {
     Val va = str_col_validity(ia), vb = str_col_validity(ib);
     auto la = locate(ia), lb = locate(ib);
@@ -1464,6 +1485,7 @@ struct Gen {
       }
       case ExprKind::ScalarFunc: return scalar_func(e);
       case ExprKind::Like: return like(e);
+      case ExprKind::RLike: return rlike(e);
       case ExprKind::If: {
         if (e.children.size() != 3) throw CometError("If needs three children");
         return select(named(gen(e.children[0])), named(gen(e.children[1])), named(gen(e.children[2])));

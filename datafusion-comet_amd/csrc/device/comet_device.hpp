@@ -301,6 +301,21 @@ CDEV i32 utf8_next_char(const COMET_GLOBAL u8* p, i32 at, i32 len) {
   while (at < len && (p[at] & 0xC0) == 0x80) at++;
   return at;
 }
+// RLIKE: walk the search automaton the host compiled from the pattern (csrc/regex.cpp): trans[state][byte] → state; flags bit 0 = a match
+// has been found (answer true at once), bit 1 = a match if the text ends in this state.  One table lookup per byte of the value.
+CDEV bool utf8_rlike(const CometCol& c, i64 i, const char* trans, const char* flags) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], nbytes = off[j + 1] - lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  if (flags[0] & 1) return true;
+  u32 st = 0;
+  for (i32 k = 0; k < nbytes; k++) {
+    st = (u8)trans[st * 256u + p[k]];
+    if (flags[st] & 1) return true;
+  }
+  return (flags[st] & 2) != 0;
+}
 CDEV bool utf8_like_lit(const CometCol& c, i64 i, const char* pat, i32 m) {
   const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
   const i64 j = c.offset + i;

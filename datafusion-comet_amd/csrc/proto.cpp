@@ -229,7 +229,7 @@ ExprP decode_expr(Reader r) {
     switch (f) {
       case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
       case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
-      case 15: case 16: case 17: case 18: case 25: case 26: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
+      case 15: case 16: case 17: case 18: case 25: case 26: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
       case 44: case 45: case 51:
         e->kind = (ExprKind)f;
         if (e->kind == ExprKind::Bound) e->bound_index = 0;  // proto3 omits zero-valued scalars
@@ -748,7 +748,7 @@ const char* expr_name(int t) {
     case 6: return "Multiply"; case 7: return "Divide"; case 8: return "Cast"; case 9: return "Eq";
     case 10: return "Neq"; case 11: return "Gt"; case 12: return "GtEq"; case 13: return "Lt"; case 14: return "LtEq";
     case 15: return "IsNull"; case 16: return "IsNotNull"; case 17: return "And"; case 18: return "Or";
-    case 19: return "SortOrder"; case 25: return "CheckOverflow"; case 26: return "Like"; case 31: return "ScalarFunc";
+    case 19: return "SortOrder"; case 25: return "CheckOverflow"; case 26: return "Like"; case 30: return "RLike"; case 31: return "ScalarFunc";
     case 32: return "EqNullSafe"; case 33: return "NeqNullSafe"; case 37: return "Remainder"; case 38: return "CaseWhen";
     case 39: return "In"; case 40: return "Not"; case 41: return "UnaryMinus"; case 44: return "If";
     case 45: return "NormalizeNaNAndZero"; default: return "Expr";

@@ -1,0 +1,415 @@
+// RLIKE patterns → a byte-level DFA the generated kernels walk (device/comet_device.hpp utf8_rlike).
+//
+// The reference evaluates RLike with the Rust `regex` crate: Regex::new(pattern)?.is_match(value) — an unanchored search over the value's
+// Unicode scalar values (native/spark-expr/src/predicate_funcs/rlike.rs:47-90).  This compiler accepts the part of that syntax whose meaning
+// can be reproduced EXACTLY over UTF-8 bytes and refuses the rest by name, so an unsupported pattern fails at createPlan (the JVM side then
+// keeps the expression on Spark) instead of matching differently:
+//   literals (any UTF-8), `.` (any scalar value but \n), classes [a-z0-9_] / [^…] with ASCII members, escapes of punctuation and \t \n \r,
+//   grouping ( ) and (?: ), alternation |, * + ? {m} {m,} {m,n} (lazy forms mean the same for a yes/no answer), ^ and $ (start / end of
+//   the text, as in the crate without the m flag).
+// Refused: \d \w \s \b and the other Perl / Unicode classes (they are Unicode-aware in the crate: an ASCII rendering would differ on
+// non-ASCII text), flags like (?i), look-around and back-references (the crate refuses those too), non-ASCII class members, counted
+// repetitions above 64.
+//
+// Construction: parse → Thompson NFA over byte sets (a `.` or a negated class becomes the UTF-8 sequence alternation) → subset
+// construction of the SEARCH automaton (the start state is re-injected after every byte; ^ is passable only before the first byte).
+// A state that contains MATCH is absorbing — the kernel returns true there; `$` is decided by a per-state "accepts at end of text" flag.
+#include "regex.hpp"
+
+#include <algorithm>
+#include <array>
+#include <map>
+#include <set>
+
+#include "plan.hpp"
+
+namespace comet {
+namespace {
+
+typedef std::array<uint64_t, 4> ByteSet;
+void bs_add(ByteSet& s, int b) { s[(size_t)b >> 6] |= (uint64_t)1 << (b & 63); }
+bool bs_has(const ByteSet& s, int b) { return (s[(size_t)b >> 6] >> (b & 63)) & 1; }
+ByteSet bs_range(int lo, int hi) {
+  ByteSet s{};
+  for (int b = lo; b <= hi; b++) bs_add(s, b);
+  return s;
+}
+
+struct Node;
+typedef std::shared_ptr<Node> NodeP;
+struct Node {
+  enum Kind { Bytes, Cat, Alt, Repeat, Bol, Eol, Empty } kind = Empty;
+  ByteSet set{};
+  std::vector<NodeP> kids;
+  int min = 0, max = -1;   // Repeat: max −1 = unbounded
+};
+NodeP mk(Node::Kind k) {
+  auto n = std::make_shared<Node>();
+  n->kind = k;
+  return n;
+}
+NodeP mk_bytes(const ByteSet& s) {
+  auto n = mk(Node::Bytes);
+  n->set = s;
+  return n;
+}
+NodeP mk_cat(std::vector<NodeP> kids) {
+  if (kids.empty()) return mk(Node::Empty);
+  if (kids.size() == 1) return kids[0];
+  auto n = mk(Node::Cat);
+  n->kids = std::move(kids);
+  return n;
+}
+NodeP mk_alt(std::vector<NodeP> kids) {
+  if (kids.size() == 1) return kids[0];
+  auto n = mk(Node::Alt);
+  n->kids = std::move(kids);
+  return n;
+}
+// every UTF-8 encoded scalar value of two or more bytes (well-formed sequences, surrogates excluded like the crate's utf8 ranges)
+NodeP multibyte() {
+  const ByteSet cont = bs_range(0x80, 0xBF);
+  auto seq = [&](std::vector<ByteSet> parts) {
+    std::vector<NodeP> k;
+    for (auto& p : parts) k.push_back(mk_bytes(p));
+    return mk_cat(k);
+  };
+  return mk_alt({seq({bs_range(0xC2, 0xDF), cont}),
+                 seq({bs_range(0xE0, 0xE0), bs_range(0xA0, 0xBF), cont}), seq({bs_range(0xE1, 0xEC), cont, cont}), seq({bs_range(0xED, 0xED), bs_range(0x80, 0x9F), cont}),
+                 seq({bs_range(0xEE, 0xEF), cont, cont}),
+                 seq({bs_range(0xF0, 0xF0), bs_range(0x90, 0xBF), cont, cont}), seq({bs_range(0xF1, 0xF3), cont, cont, cont}), seq({bs_range(0xF4, 0xF4), bs_range(0x80, 0x8F), cont, cont})});
+}
+// one scalar value: the ASCII members of `ascii`, plus (if `and_multibyte`) everything beyond ASCII
+NodeP one_char(const ByteSet& ascii, bool and_multibyte) {
+  std::vector<NodeP> alts;
+  bool any = false;
+  for (int b = 0; b < 128; b++) any |= bs_has(ascii, b);
+  if (any) alts.push_back(mk_bytes(ascii));
+  if (and_multibyte) alts.push_back(multibyte());
+  if (alts.empty()) {        // a class nothing can match: a byte set with no member
+    return mk_bytes(ByteSet{});
+  }
+  return mk_alt(alts);
+}
+
+struct Parser {
+  const std::string& p;
+  size_t i = 0;
+  explicit Parser(const std::string& s) : p(s) {}
+  [[noreturn]] void fail(const std::string& why) const { throw CometError("RLIKE pattern '" + p + "' is not supported by the MI355X native engine: " + why); }
+  bool more() const { return i < p.size(); }
+  NodeP parse_alt() {
+    std::vector<NodeP> alts;
+    alts.push_back(parse_cat());
+    while (more() && p[i] == '|') {
+      i++;
+      alts.push_back(parse_cat());
+    }
+    return mk_alt(alts);
+  }
+  NodeP parse_cat() {
+    std::vector<NodeP> items;
+    while (more() && p[i] != '|' && p[i] != ')') items.push_back(parse_repeat());
+    return mk_cat(items);
+  }
+  NodeP parse_repeat() {
+    NodeP a = parse_atom();
+    while (more()) {
+      int mn, mx;
+      const char ch = p[i];
+      if (ch == '*') { mn = 0; mx = -1; i++; }
+      else if (ch == '+') { mn = 1; mx = -1; i++; }
+      else if (ch == '?') { mn = 0; mx = 1; i++; }
+      else if (ch == '{') {
+        size_t j = i + 1;
+        auto num = [&](int& v) {
+          if (j >= p.size() || p[j] < '0' || p[j] > '9') return false;
+          long long x = 0;
+          while (j < p.size() && p[j] >= '0' && p[j] <= '9') { x = x * 10 + (p[j] - '0'); if (x > 1000) fail("a repetition count above 64"); j++; }
+          v = (int)x;
+          return true;
+        };
+        if (!num(mn)) fail("'{' that does not start a counted repetition");
+        mx = mn;
+        if (j < p.size() && p[j] == ',') {
+          j++;
+          if (j < p.size() && p[j] == '}') mx = -1;
+          else if (!num(mx)) fail("a malformed counted repetition");
+        }
+        if (j >= p.size() || p[j] != '}') fail("a malformed counted repetition");
+        if (mn > 64 || mx > 64 || (mx >= 0 && mx < mn)) fail("a repetition count above 64 (or max below min)");
+        i = j + 1;
+      } else break;
+      if (more() && (p[i] == '?')) i++;                    // lazy: same language
+      else if (more() && p[i] == '+') fail("possessive quantifiers");
+      if (a->kind == Node::Bol || a->kind == Node::Eol) fail("a quantifier on an anchor");
+      auto r = mk(Node::Repeat);
+      r->kids.push_back(a);
+      r->min = mn;
+      r->max = mx;
+      a = r;
+    }
+    return a;
+  }
+  // the byte of an escaped punctuation / control character, or -1
+  int simple_escape(char c) const {
+    switch (c) {
+      case 't': return '\t';
+      case 'n': return '\n';
+      case 'r': return '\r';
+      case 'f': return '\f';
+      case 'v': return '\v';
+      default: break;
+    }
+    if ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) return -1;   // \d \w \b \1 \p{..} \x.. …: not reproduced
+    if ((unsigned char)c >= 0x80) return -1;
+    return (unsigned char)c;
+  }
+  NodeP parse_atom() {
+    const unsigned char ch = (unsigned char)p[i];
+    if (ch == '(') {
+      i++;
+      if (more() && p[i] == '?') {
+        if (i + 1 < p.size() && p[i + 1] == ':') i += 2;
+        else fail("group flags, named groups and look-around ((?…) other than (?:…))");
+      }
+      NodeP inner = parse_alt();
+      if (!more() || p[i] != ')') fail("an unclosed group");
+      i++;
+      return inner;
+    }
+    if (ch == '[') return parse_class();
+    if (ch == '.') {
+      i++;
+      ByteSet s = bs_range(0, 127);
+      s[0] &= ~((uint64_t)1 << '\n');
+      return one_char(s, true);
+    }
+    if (ch == '^') { i++; return mk(Node::Bol); }
+    if (ch == '$') { i++; return mk(Node::Eol); }
+    if (ch == '*' || ch == '+' || ch == '?') fail("a quantifier with nothing to repeat");
+    if (ch == '{') fail("'{' that does not follow an item");
+    if (ch == '\\') {
+      if (i + 1 >= p.size()) fail("a trailing backslash");
+      const int b = simple_escape(p[i + 1]);
+      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (Perl / Unicode classes, word boundaries, back-references and hex escapes are Unicode-aware in the reference)");
+      i += 2;
+      ByteSet s{};
+      bs_add(s, b);
+      return mk_bytes(s);
+    }
+    // a literal character: its UTF-8 bytes in sequence form ONE item (a quantifier after "é" repeats both bytes)
+    std::vector<NodeP> seq;
+    do {
+      ByteSet s{};
+      bs_add(s, (unsigned char)p[i]);
+      seq.push_back(mk_bytes(s));
+      i++;
+    } while (ch >= 0x80 && more() && ((unsigned char)p[i] & 0xC0) == 0x80);
+    return mk_cat(seq);
+  }
+  NodeP parse_class() {
+    i++;   // [
+    bool neg = false;
+    if (more() && p[i] == '^') { neg = true; i++; }
+    ByteSet s{};
+    bool first = true;
+    while (true) {
+      if (!more()) fail("an unclosed character class");
+      unsigned char c = (unsigned char)p[i];
+      if (c == ']' && !first) { i++; break; }
+      first = false;
+      if (c == '[') fail("nested classes and [:posix:] classes");
+      if (c == '&' && i + 1 < p.size() && p[i + 1] == '&') fail("class intersections");
+      int lo;
+      if (c == '\\') {
+        if (i + 1 >= p.size()) fail("a trailing backslash");
+        lo = simple_escape(p[i + 1]);
+        if (lo < 0) fail(std::string("the escape \\") + p[i + 1] + " inside a class");
+        i += 2;
+      } else {
+        if (c >= 0x80) fail("non-ASCII members of a character class");
+        lo = c;
+        i++;
+      }
+      int hi = lo;
+      if (i + 1 < p.size() && p[i] == '-' && p[i + 1] != ']') {
+        unsigned char d = (unsigned char)p[i + 1];
+        if (d == '\\') {
+          if (i + 2 >= p.size()) fail("a trailing backslash");
+          hi = simple_escape(p[i + 2]);
+          if (hi < 0) fail("an escape class as a range end");
+          i += 3;
+        } else {
+          if (d >= 0x80) fail("non-ASCII members of a character class");
+          if (d == '[') fail("nested classes");
+          hi = d;
+          i += 2;
+        }
+        if (hi < lo) fail("a reversed range in a character class");
+      }
+      for (int b = lo; b <= hi; b++) bs_add(s, b);
+    }
+    if (!neg) return one_char(s, false);
+    ByteSet inv{};
+    for (int b = 0; b < 128; b++)
+      if (!bs_has(s, b)) bs_add(inv, b);
+    return one_char(inv, true);
+  }
+};
+
+// ---- Thompson NFA ----
+struct NState {
+  enum Kind { Byte, Split, Bol, Eol, Match } kind = Match;
+  ByteSet set{};
+  int out = -1, out2 = -1;
+};
+struct Nfa {
+  std::vector<NState> st;
+  int add(NState::Kind k) {
+    if (st.size() > 6000) throw CometError("RLIKE pattern is too large for the MI355X native engine (more than 6000 automaton states)");
+    NState s;
+    s.kind = k;
+    st.push_back(s);
+    return (int)st.size() - 1;
+  }
+};
+// builds the fragment for `n` ending in state `next`; returns its entry state
+int build(Nfa& nfa, const NodeP& n, int next) {
+  switch (n->kind) {
+    case Node::Empty: return next;
+    case Node::Bytes: {
+      const int s = nfa.add(NState::Byte);
+      nfa.st[(size_t)s].set = n->set;
+      nfa.st[(size_t)s].out = next;
+      return s;
+    }
+    case Node::Bol: case Node::Eol: {
+      const int s = nfa.add(n->kind == Node::Bol ? NState::Bol : NState::Eol);
+      nfa.st[(size_t)s].out = next;
+      return s;
+    }
+    case Node::Cat: {
+      int cur = next;
+      for (size_t k = n->kids.size(); k-- > 0;) cur = build(nfa, n->kids[k], cur);
+      return cur;
+    }
+    case Node::Alt: {
+      int cur = build(nfa, n->kids.back(), next);
+      for (size_t k = n->kids.size() - 1; k-- > 0;) {
+        const int a = build(nfa, n->kids[k], next);
+        const int s = nfa.add(NState::Split);
+        nfa.st[(size_t)s].out = a;
+        nfa.st[(size_t)s].out2 = cur;
+        cur = s;
+      }
+      return cur;
+    }
+    case Node::Repeat: {
+      const NodeP& kid = n->kids[0];
+      int cur = next;
+      if (n->max < 0) {
+        // kid* : loop state
+        const int loop = nfa.add(NState::Split);
+        const int body = build(nfa, kid, loop);
+        nfa.st[(size_t)loop].out = body;
+        nfa.st[(size_t)loop].out2 = next;
+        cur = loop;
+      } else {
+        for (int k = 0; k < n->max - n->min; k++) {      // optional copies, innermost last
+          const int body = build(nfa, kid, cur);
+          const int s = nfa.add(NState::Split);
+          nfa.st[(size_t)s].out = body;
+          nfa.st[(size_t)s].out2 = next;
+          cur = s;
+        }
+      }
+      for (int k = 0; k < n->min; k++) cur = build(nfa, kid, cur);
+      return cur;
+    }
+  }
+  return next;
+}
+
+void closure(const Nfa& nfa, std::vector<int>& stack, std::set<int>& seen, bool at_start, bool at_end) {
+  while (!stack.empty()) {
+    const int s = stack.back();
+    stack.pop_back();
+    if (s < 0 || !seen.insert(s).second) continue;
+    const NState& st = nfa.st[(size_t)s];
+    switch (st.kind) {
+      case NState::Split: stack.push_back(st.out); stack.push_back(st.out2); break;
+      case NState::Bol: if (at_start) stack.push_back(st.out); break;
+      case NState::Eol: if (at_end) stack.push_back(st.out); break;
+      default: break;
+    }
+  }
+}
+
+}  // namespace
+
+RegexDfa compile_rlike(const std::string& pattern) {
+  Parser ps(pattern);
+  NodeP ast = ps.parse_alt();
+  if (ps.more()) ps.fail("an unmatched ')'");
+  Nfa nfa;
+  const int match = nfa.add(NState::Match);
+  const int start = build(nfa, ast, match);
+
+  auto closed = [&](const std::set<int>& core, bool inject_start, bool at_start, bool at_end) {
+    std::vector<int> stack(core.begin(), core.end());
+    if (inject_start) stack.push_back(start);
+    std::set<int> seen;
+    closure(nfa, stack, seen, at_start, at_end);
+    return seen;
+  };
+  RegexDfa dfa;
+  std::map<std::set<int>, int> ids;
+  std::vector<std::set<int>> sets;
+  std::vector<bool> initial;
+  auto intern = [&](const std::set<int>& s, bool is_initial) {
+    auto it = ids.find(s);
+    if (it != ids.end() && !is_initial) return it->second;
+    if (sets.size() >= 200) throw CometError("RLIKE pattern '" + pattern + "' needs more than 200 automaton states: not supported by the MI355X native engine");
+    const int id = (int)sets.size();
+    if (!is_initial) ids[s] = id;
+    sets.push_back(s);
+    initial.push_back(is_initial);
+    return id;
+  };
+  intern(closed({}, true, true, false), true);      // state 0: before the first byte (^ passable)
+  for (size_t cur = 0; cur < sets.size(); cur++) {
+    const std::set<int> S = sets[cur];              // (copy: `sets` grows below)
+    uint8_t flags = 0;
+    if (S.count(match)) flags |= 1;
+    // end of text here: $ becomes passable; the start state may still be injected (an empty remainder can match, e.g. "x*$")
+    if (closed(S, true, initial[cur], true).count(match)) flags |= 2;
+    dfa.flags.push_back(flags);
+    dfa.trans.resize((cur + 1) * 256, 0);
+    if (flags & 1) continue;                        // absorbing: the kernel has already answered true
+    for (int b = 0; b < 256; b++) {
+      std::set<int> core;
+      for (int s : S) {
+        const NState& st = nfa.st[(size_t)s];
+        if (st.kind == NState::Byte && bs_has(st.set, b)) core.insert(st.out);
+      }
+      const int to = intern(closed(core, true, false, false), false);
+      dfa.trans[cur * 256 + (size_t)b] = (uint8_t)to;
+    }
+  }
+  dfa.nstates = (int)sets.size();
+  dfa.trans.resize((size_t)dfa.nstates * 256, 0);
+  return dfa;
+}
+
+bool regex_dfa_match(const RegexDfa& d, const uint8_t* s, size_t n) {
+  int st = 0;
+  if (d.flags[0] & 1) return true;
+  for (size_t k = 0; k < n; k++) {
+    st = d.trans[(size_t)st * 256 + s[k]];
+    if (d.flags[(size_t)st] & 1) return true;
+  }
+  return (d.flags[(size_t)st] & 2) != 0;
+}
+
+}  // namespace comet

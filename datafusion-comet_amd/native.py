@@ -118,6 +118,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_plan_memory_stats.argtypes = [c.c_int64, c.c_void_p]
     lib.comet_plan_set_memory_manager.restype = c.c_int32
     lib.comet_plan_set_memory_manager.argtypes = [c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64]
+    lib.comet_rlike_match.restype = c.c_int32
+    lib.comet_rlike_match.argtypes = [c.c_char_p, c.c_char_p, c.c_size_t]
     lib.comet_page_decompress.restype = c.c_int32
     lib.comet_page_decompress.argtypes = [c.c_int32, c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]
     lib.comet_snappy_inflate_pages.restype = c.c_int64
@@ -924,3 +926,12 @@ def page_decompress(codec: int, data: bytes, uncompressed_size: int) -> bytes:
     if lib().comet_page_decompress(codec, data, len(data), out.ctypes.data, uncompressed_size) != 0:
         _raise_last(0)
     return out[:uncompressed_size].tobytes()
+
+
+def rlike_match(pattern: str, value: str) -> bool:
+    """compile `pattern` like the planner does for RLike and walk the tables over `value` on the host (comet_rlike_match)"""
+    v = value.encode()
+    rc = lib().comet_rlike_match(pattern.encode(), v, len(v))
+    if rc < 0:
+        _raise_last(0)
+    return rc == 1

@@ -120,7 +120,7 @@ class Expr:
 
     # field numbers of Expr.expr_struct (expr.proto:30-107)
     TAGS = dict(literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
-                lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, like=26, scalar_func=31, eq_null_safe=32,
+                lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, like=26, rlike=30, scalar_func=31, eq_null_safe=32,
                 neq_null_safe=33, bit_and=34, bit_or=35, bit_xor=36, shift_right=42, shift_left=43, integral_divide=59, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
                 unbound=51)
 
@@ -235,6 +235,7 @@ and_, or_ = _bin("and_"), _bin("or_")
 eq_null_safe = _bin("eq_null_safe")
 bit_and, bit_or, bit_xor, shift_left, shift_right = (_bin(k) for k in ("bit_and", "bit_or", "bit_xor", "shift_left", "shift_right"))
 like = _bin("like")            # Expr.like = 26: BinaryExpr(string, pattern)
+rlike = _bin("rlike")          # Expr.rlike = 30: BinaryExpr(string, pattern)
 
 
 def not_(a: Expr) -> Expr:

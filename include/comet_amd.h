@@ -159,6 +159,12 @@ int32_t comet_plan_set_memory_manager(int64_t plan, int64_t (*acquire)(void* ctx
                                       int64_t task_id);
 void comet_plan_memory_stats(int64_t plan, int64_t* out4);
 
+/* ---- RLIKE pattern compiler (csrc/regex.cpp) — diagnostic entry -------------------------------------------------------------------------
+ * Compiles `pattern` the way the planner does for an RLike expression (the exactly reproducible subset of the Rust regex syntax the
+ * reference evaluates with, predicate_funcs/rlike.rs) and walks the resulting tables over `value` on the host: 1 match, 0 no match,
+ * -2 and comet_last_error(0) for a pattern outside the subset.  Needs no GPU; the device walks the same tables. */
+int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t value_len);
+
 /* ---- the host page codecs (csrc/parquet_meta.cpp) ---------------------------------------------------------------------------------------
  * What the scan's host threads run on the pages the device does not decompress itself: Parquet CompressionCodec 0 UNCOMPRESSED, 1 SNAPPY,
  * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and

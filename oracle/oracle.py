@@ -253,6 +253,28 @@ class Evaluator:
             cre = re.compile(rx, re.DOTALL)
             vals = np.array([bool(cre.fullmatch(v)) if v is not None else False for v in a.values], dtype=bool)
             return Col(S.T_BOOL, vals & a.ok(), a.valid)
+        if k == "rlike":
+            # predicate_funcs/rlike.rs:47-90: regex::Regex::is_match — an unanchored search over Unicode scalar values; `$` is the end of the
+            # text only (Python's `$` would also match before a trailing newline, hence \Z).  Restated with Python's backtracking engine
+            # for the constructs both engines read alike; the device walks a DFA built by csrc/regex.cpp
+            import re
+            a, pat = self.eval(e.children[0], cols, n), e.children[1].value
+            rx, i, in_class = "", 0, False
+            while i < len(pat):
+                ch = pat[i]
+                if ch == "\\" and i + 1 < len(pat):
+                    rx += pat[i:i + 2]
+                    i += 2
+                    continue
+                if ch == "[":
+                    in_class = True
+                elif ch == "]":
+                    in_class = False
+                rx += "\\Z" if (ch == "$" and not in_class) else ch
+                i += 1
+            cre = re.compile(rx)
+            vals = np.array([bool(cre.search(v)) if v is not None else False for v in a.values], dtype=bool)
+            return Col(S.T_BOOL, vals & a.ok(), a.valid)
         if k == "scalar_func":
             return self._scalar_func(e, cols, n)
         if k == "case_when":

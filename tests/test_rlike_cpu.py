@@ -1,0 +1,102 @@
+"""The RLIKE pattern compiler (csrc/regex.cpp) on the CPU: the DFA tables the device walks, walked on the host (comet_rlike_match), against
+Python's backtracking engine on the syntax both read alike — the reference's own cases (predicate_funcs/rlike.rs tests and the Scala suite's
+RLIKE patterns), documented Spark examples, UTF-8 text, anchors, counted repetitions, classes, and a randomised comparison over generated
+patterns and strings.  Constructs the reference's `regex` crate reads in a Unicode-aware way (\\d \\w \\s \\b, (?i) …) must be REFUSED."""
+import random
+import re
+
+import pytest
+
+from datafusion_comet_amd import native
+
+
+def want(pattern, value):
+    # `$` → end of text only (regex crate without the m flag); nothing else differs inside the accepted subset
+    rx, i, in_class = "", 0, False
+    while i < len(pattern):
+        ch = pattern[i]
+        if ch == "\\" and i + 1 < len(pattern):
+            rx += pattern[i:i + 2]
+            i += 2
+            continue
+        if ch == "[":
+            in_class = True
+        elif ch == "]":
+            in_class = False
+        rx += "\\Z" if (ch == "$" and not in_class) else ch
+        i += 1
+    return re.search(rx, value) is not None
+
+
+CASES = [
+    # the reference's tests: rlike.rs "test_string_input" style and CometExpressionSuite's RLIKE queries
+    ("R[a-z]+", ["Rose", "Robert", "rose", "R", "aRb", ""]),
+    ("^R", ["Rose", "aRose", "R", ""]),
+    ("e$", ["Rose", "Rosen", "e", "e\n", ""]),
+    ("^Ro.*se$", ["Rose", "Roxxse", "Rose!", "xRose"]),
+    ("a|bc|d+", ["xyz", "a", "bc", "b", "ddd", "c"]),
+    ("(ab)*c", ["c", "abc", "ababc", "abab", "xc"]),
+    ("a{2,3}b", ["ab", "aab", "aaab", "aaaab", "b"]),
+    ("a{2}", ["a", "aa", "aaa"]),
+    ("a{2,}$", ["aa", "aaaaaa", "aab"]),
+    ("x?y+?z*?", ["y", "xy", "z", ""]),
+    ("[^abc]", ["a", "abc", "abcd", "é", ""]),
+    ("[a-c0-9_-]+$", ["a-1_", "a-1_!", "-", "é"]),
+    ("^[^,]+,[^,]+$", ["a,b", "a,b,c", ",", "a,"]),
+    ("colou?r", ["color", "colour", "colr", "a colour b"]),
+    (r"1\.5", ["1.5", "125", "x1.5y"]),
+    (r"\(x\)\[y\]\{z\}\|\\", ["(x)[y]{z}|\\", "(x)[y]{z}|"]),
+    ("a.c", ["abc", "a\nc", "aéc", "a☕c", "ac", "a😀c"]),
+    ("^.{3}$", ["abc", "日本語", "ab", "abcd", "a😀c", "ab\n"]),
+    ("日本", ["日本語", "本日", "日", ""]),
+    ("é+$", ["café", "caféé", "cafe", "éa"]),
+    ("", ["", "x"]),
+    ("^$", ["", "x", "\n"]),
+    ("$", ["", "x"]),
+    ("^", ["", "x"]),
+    ("(a|^b)c", ["bc", "xbc", "ac", "xac"]),
+    ("(^a|b$)", ["ab", "ba", "xay"]),
+    ("(?:ab|cd)+ef", ["abef", "abcdabef", "ef", "abe"]),
+    ("[.]+", ["...", "abc"]),
+    ("[]a]", ["]", "a", "b"]),
+    ("[a\\]b]", ["]", "b", "c"]),
+    ("\t", ["a\tb", "ab"]),
+]
+
+
+@pytest.mark.parametrize("pattern,values", CASES)
+def test_known_patterns(built, pattern, values):
+    for v in values:
+        assert native.rlike_match(pattern, v) == want(pattern, v), (pattern, v)
+
+
+def test_random_patterns_against_the_backtracking_engine(built):
+    rnd = random.Random(7)
+    atoms = ["a", "b", "c", ".", "[ab]", "[^a]", "é", "(ab|c)", "(?:a|bc)", "\\."]
+    quant = ["", "", "", "*", "+", "?", "{2}", "{1,2}", "{0,3}"]
+    alphabet = ["a", "b", "c", ".", "é", "\n", "x"]
+    refused = 0
+    for _ in range(400):
+        body = "".join(rnd.choice(atoms) + rnd.choice(quant) for _ in range(rnd.randint(1, 5)))
+        if rnd.random() < 0.3:
+            body = body + "|" + "".join(rnd.choice(atoms) for _ in range(rnd.randint(1, 3)))
+        pattern = ("^" if rnd.random() < 0.3 else "") + body + ("$" if rnd.random() < 0.3 else "")
+        try:
+            native.rlike_match(pattern, "")
+        except native.CometNativeException as e:       # a pattern whose search automaton is too large is refused, never approximated
+            assert "automaton states" in str(e), pattern
+            refused += 1
+            continue
+        for _ in range(12):
+            v = "".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 8)))
+            assert native.rlike_match(pattern, v) == want(pattern, v), (pattern, v)
+    assert refused < 40
+
+
+@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("a\\b", "escape"), ("(?i)abc", "group flags"), ("(?P<n>a)", "group flags"),
+                                         ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[é]", "non-ASCII"), ("[[:alpha:]]", "nested"), ("a{100}", "repetition"),
+                                         ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
+                                         ("\\p{L}", "escape"), ("\\x41", "escape"), ("a{,2}", "counted repetition")])
+def test_constructs_the_reference_reads_differently_are_refused(built, pattern, why):
+    with pytest.raises(native.CometNativeException, match="not supported"):
+        native.rlike_match(pattern, "abc")
