@@ -273,7 +273,12 @@ extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n,
 extern "C" int comet_launch_window_default(int width, const uint8_t* inside, int64_t n, const void* value, void* data, uint8_t* ok_bytes, void* stream);
 extern "C" int comet_launch_window_widen(int width, const void* src, const uint8_t* valid_bits, int64_t n, void* out128, void* hi128, uint32_t* ok, void* stream);
 extern "C" int comet_launch_scan128(const void* in128, int64_t n, void* tiles, void* out128, void* stream);
-extern "C" int comet_launch_window_agg(int fn, int frame, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,
+extern "C" int comet_launch_window_running_extreme(const void* vals128, const uint32_t* ok, const int32_t* sp, int64_t n, int backward, int is_max, void* local, void* tiles, void* out_v,
+                                                   uint8_t* out_has, void* stream);
+extern "C" int comet_launch_window_minmax(int is_max, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const void* vals128, const uint32_t* ok, const void* P, const uint8_t* Ph,
+                                          const void* Q, const uint8_t* Qh, const int32_t* sp, const int32_t* sg, const uint32_t* first_part, const uint32_t* first_peer, int64_t n,
+                                          int out_width, void* out, uint8_t* out_ok, void* stream);
+extern "C" int comet_launch_window_agg(int fn, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,
                                        const uint32_t* first_peer, int64_t n, const void* bound16, const void* scaler16, const void* avg_bound16, void* out, uint8_t* out_ok,
                                        void* stream);
 extern "C" int comet_launch_window_flags(const uint8_t* part_planes, int Wp, const uint8_t* order_planes, int Wo, int64_t n, uint32_t* fpart, uint32_t* fpeer, void* stream);
@@ -747,8 +752,13 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
         // SUM / COUNT / AVG of exact types over a frame that starts at the partition start (whole partition, or up to the current row /
         // peer group) — the frames the reference runs with its own Spark-exact accumulators (planner.rs:2953-2972)
         const AggExpr& a = fn.agg;
-        if (fn.frame_lower != 0 || fn.frame_upper == 1)
-          throw CometError("Window: only frames from UNBOUNDED PRECEDING to CURRENT ROW / UNBOUNDED FOLLOWING are supported for aggregate window functions");
+        // frames: every combination of UNBOUNDED / CURRENT ROW bounds, and ROWS frames with literal offsets (n PRECEDING / n FOLLOWING);
+        // RANGE frames with value offsets need a search over the order key and are not supported
+        if (fn.frame_range_literal || (!fn.frame_rows && (fn.frame_lower == 1 || fn.frame_upper == 1)))
+          throw CometError("Window: RANGE frames with a value offset (RANGE BETWEEN x PRECEDING …) are not supported yet");
+        const bool minmax = a.kind == AggKind::Min || a.kind == AggKind::Max;
+        if (minmax && fn.frame_lower == 1 && fn.frame_upper == 1 && fn.frame_upper_off - fn.frame_lower_off > 4096)
+          throw CometError("Window: MIN / MAX over a sliding frame wider than 4096 rows is not supported yet");
         if (a.children.size() != 1) throw CometError("Window: aggregate window functions take one argument");
         const ExprP& arg = a.children[0];
         const bool lit = arg->kind == ExprKind::Literal;
@@ -756,11 +766,12 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
           throw CometError("Window: the argument of an aggregate window function must be a column (or a literal for COUNT)");
         const DType at = lit ? arg->dtype : st[(size_t)arg->bound_index];
         if (a.kind == AggKind::Count) out.push_back(DType::of(TypeId::Int64));
-        else if (lit) throw CometError("Window: SUM / AVG of a literal is not supported");
+        else if (lit) throw CometError("Window: SUM / AVG / MIN / MAX of a literal is not supported");
+        else if (minmax && (at.is_integer() || at.id == TypeId::Decimal || at.id == TypeId::Date || at.id == TypeId::Timestamp || at.id == TypeId::TimestampNtz)) out.push_back(at);
         else if (a.kind == AggKind::Sum && at.id == TypeId::Decimal && a.dtype.id == TypeId::Decimal) out.push_back(a.dtype);
         else if (a.kind == AggKind::Sum && at.is_integer()) out.push_back(DType::of(TypeId::Int64));
         else if (a.kind == AggKind::Avg && at.id == TypeId::Decimal && a.dtype.id == TypeId::Decimal) out.push_back(a.dtype);
-        else throw CometError("Window: aggregate (tag " + std::to_string(a.proto_tag) + ") over " + at.str() + " is not supported yet (SUM / AVG of decimals, SUM of integers, COUNT are)");
+        else throw CometError("Window: aggregate (tag " + std::to_string(a.proto_tag) + ") over " + at.str() + " is not supported yet (SUM / AVG of decimals, SUM of integers, COUNT, MIN / MAX of integers, decimals, dates and timestamps are)");
         continue;
       }
       const std::string& f = fn.func;
@@ -2744,7 +2755,8 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
       if (w.window_fns[k].is_agg) {
         const AggExpr& a = w.window_fns[k].agg;
         const bool dec = a.dtype.id == TypeId::Decimal && a.kind != AggKind::Count;
-        add_col(dec ? a.dtype : DType::of(TypeId::Int64), nullptr, nullptr);
+        if (a.kind == AggKind::Min || a.kind == AggKind::Max) add_col(in.types[(size_t)a.children[0]->bound_index], nullptr, nullptr);
+        else add_col(dec ? a.dtype : DType::of(TypeId::Int64), nullptr, nullptr);
         continue;
       }
       DType t = (f == "percent_rank" || f == "cume_dist") ? DType::of(TypeId::Double) : (f == "lag" || f == "lead") ? in.types[(size_t)w.window_fns[k].args[0]->bound_index] : DType::of(TypeId::Int32);
@@ -2779,6 +2791,46 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
     if (fn.is_agg) {
       const AggExpr& a = fn.agg;
       const ExprP& arg = a.children[0];
+      auto bound_kind = [&](int k, bool upper) { return k == 0 ? 0 : k == 1 ? 3 : (fn.frame_rows ? 1 : 2); (void)upper; };   // → WB_* of window_kernels.hip
+      const int lo_kind = bound_kind(fn.frame_lower, false), hi_kind = bound_kind(fn.frame_upper, true);
+      if (a.kind == AggKind::Min || a.kind == AggKind::Max) {
+        // the frame's extreme: running extremes per partition from its start (P) and towards its end (Q) — two segmented scans — answer
+        // every frame that touches a partition edge; a frame bounded on both sides is walked row by row (≤ 4097 rows)
+        const int cc = arg->bound_index;
+        const DeviceColumnView& sc = in.cols[(size_t)cc];
+        if (sc.offset != 0) throw CometError("Window: aggregate over a column with a non-zero Arrow offset is not supported yet");
+        const DType& at = in.types[(size_t)cc];
+        const int width = at.id == TypeId::Decimal ? 16 : fixed_width(at);
+        const int is_max = a.kind == AggKind::Max ? 1 : 0;
+        DevBuf wide, okf, local, tl, P, Ph, Q, Qh;
+        wide.ensure((size_t)n * 16 + 16);
+        okf.ensure((size_t)n * 4 + 16);
+        if (comet_launch_window_widen(width, sc.data, in.has_valid[(size_t)cc] ? sc.valid : nullptr, n, wide.p, nullptr, (uint32_t*)okf.p, stream_) != 0) throw CometError("window: launch failed");
+        const bool need_p = lo_kind == 0, need_q = lo_kind != 0 && hi_kind == 0;
+        if (need_p || need_q) {
+          local.ensure((size_t)n * 32 + 64);
+          tl.ensure((size_t)((n + 1023) / 1024 + 2) * 64 + 64);
+          DevBuf& V = need_p ? P : Q;
+          DevBuf& H = need_p ? Ph : Qh;
+          V.ensure((size_t)n * 16 + 16);
+          H.ensure((size_t)n + 16);
+          if (comet_launch_window_running_extreme(wide.p, (const uint32_t*)okf.p, (const int32_t*)sp->p, n, need_p ? 0 : 1, is_max, local.p, tl.p, V.p, (uint8_t*)H.p, stream_) != 0)
+            throw CometError("window: launch failed");
+        }
+        auto data = std::make_shared<DevBuf>(), okb = std::make_shared<DevBuf>(), bits = std::make_shared<DevBuf>();
+        data->ensure((size_t)n * (size_t)width + 16);
+        okb->ensure((size_t)n + 16);
+        bits->ensure((size_t)((n + 7) / 8) + 16);
+        if (comet_launch_window_minmax(is_max, lo_kind, fn.frame_lower_off, hi_kind, fn.frame_upper_off, wide.p, (const uint32_t*)okf.p, P.p, (const uint8_t*)Ph.p, Q.p, (const uint8_t*)Qh.p,
+                                       (const int32_t*)sp->p, (const int32_t*)sg->p, (const uint32_t*)first_part->p, (const uint32_t*)first_peer->p, n, width, data->p, (uint8_t*)okb->p,
+                                       stream_) != 0)
+          throw CometError("window: launch failed");
+        pq_launch_pack((const uint8_t*)okb->p, (uint8_t*)bits->p, n, stream_);
+        HIP_CHECK(hipStreamSynchronize(stream_));   // scratch goes back to the pool
+        add_col(at, data, bits);
+        out.owners.push_back(okb);
+        continue;
+      }
       const int c = arg->kind == ExprKind::Bound ? arg->bound_index : -1 - (int)(arg->lit_null ? 1 : 0);   // literals: −1 non-NULL, −2 NULL
       auto it = prefix.find(c);
       if (it == prefix.end()) {
@@ -2822,7 +2874,6 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
       }
       const DType at = c >= 0 ? in.types[(size_t)c] : arg->dtype;
       int fnk = a.kind == AggKind::Count ? 2 : a.kind == AggKind::Avg ? 3 : (at.id == TypeId::Decimal ? 0 : 1);
-      const int frame = fn.frame_upper == 0 ? 0 : (fn.frame_rows ? 1 : 2);
       const DType rt = fnk == 2 || fnk == 1 ? DType::of(TypeId::Int64) : a.dtype;
       // precision bounds: SUM checks the result type; AVG checks the sum type, scales by 10^(result scale − sum scale) and checks the result type
       const DType sum_t = fnk == 3 ? a.sum_dtype : a.dtype;
@@ -2832,7 +2883,7 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
       data->ensure((size_t)n * (fnk == 0 || fnk == 3 ? 16 : 8) + 16);
       okb->ensure((size_t)n + 16);
       bits->ensure((size_t)((n + 7) / 8) + 16);
-      if (comet_launch_window_agg(fnk, frame, it->second.S->p, it->second.SH ? it->second.SH->p : nullptr, (const int32_t*)it->second.C->p, (const int32_t*)sp->p, (const int32_t*)sg->p,
+      if (comet_launch_window_agg(fnk, lo_kind, fn.frame_lower_off, hi_kind, fn.frame_upper_off, it->second.S->p, it->second.SH ? it->second.SH->p : nullptr, (const int32_t*)it->second.C->p, (const int32_t*)sp->p, (const int32_t*)sg->p,
                                   (const uint32_t*)first_part->p, (const uint32_t*)first_peer->p, n, &bound, &scaler, &avg_bound, data->p, (uint8_t*)okb->p, stream_) != 0)
         throw CometError("window: launch failed");
       pq_launch_pack((const uint8_t*)okb->p, (uint8_t*)bits->p, n, stream_);

@@ -173,6 +173,9 @@ struct Operator {
     AggExpr agg;                    // the aggregate (children, result type)
     bool frame_rows = true;         // WindowFrame.frame_type: ROWS (proto3 default) or RANGE
     int frame_lower = 0, frame_upper = 2;   // 0 = UNBOUNDED, 1 = offset (PRECEDING / FOLLOWING), 2 = CURRENT ROW
+    // offset bounds: rows relative to the current row, negative = PRECEDING, positive = FOLLOWING (both bounds; planner.rs:3016-3030)
+    int64_t frame_lower_off = 0, frame_upper_off = 0;
+    bool frame_range_literal = false;       // a RANGE frame with a value offset (Preceding / Following.range_offset)
     DType result_type;
     bool has_result_type = false;
     bool ignore_nulls = false;

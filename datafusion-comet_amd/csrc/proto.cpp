@@ -453,12 +453,22 @@ OperatorP decode_operator_r(Reader r) {
                     else if ((f5 == 2 || f5 == 3) && wt5 == 2) {
                       Reader bd = fr.sub();
                       int kind = f5 == 2 ? 0 : 2;   // proto3 default when the oneof is empty
+                      int64_t off = 0;
                       while (!bd.done()) {
                         int wt6, f6 = bd.tag(wt6);
                         kind = f6 == 1 ? 0 : f6 == 2 ? 1 : 2;
-                        bd.skip(wt6);
+                        if (f6 == 2 && wt6 == 2) {
+                          // Preceding / Following { int64 offset = 1; Literal range_offset = 2 } (operator.proto:831-845)
+                          Reader pf = bd.sub();
+                          while (!pf.done()) {
+                            int wt7, f7 = pf.tag(wt7);
+                            if (f7 == 1 && wt7 == 0) off = (int64_t)pf.varint();
+                            else { if (f7 == 2) fn.frame_range_literal = true; pf.skip(wt7); }
+                          }
+                        } else bd.skip(wt6);
                       }
                       (f5 == 2 ? fn.frame_lower : fn.frame_upper) = kind;
+                      (f5 == 2 ? fn.frame_lower_off : fn.frame_upper_off) = off;
                     } else fr.skip(wt5);
                   }
                 }

@@ -189,25 +189,47 @@ __global__ __launch_bounds__(256) void scan128_apply_kernel(const i128* __restri
 }
 
 enum { WA_SUM_DEC = 0, WA_SUM_INT = 1, WA_COUNT = 2, WA_AVG_DEC = 3 };
-enum { WF_WHOLE = 0, WF_ROWS_CURRENT = 1, WF_RANGE_CURRENT = 2 };
+// A frame bound: the partition's edge, the current row (ROWS) or its peer group (RANGE), or the current row ± a literal number of rows
+// (negative = PRECEDING, positive = FOLLOWING — the sign convention of the plan, planner.rs:3016-3030).
+enum { WB_UNBOUNDED = 0, WB_CURRENT_ROW = 1, WB_CURRENT_RANGE = 2, WB_ROWS_OFFSET = 3 };
+struct WFrame { int lo_kind, hi_kind; i64 lo_off, hi_off; };
+// rows [start, end) of row i's frame, clipped to its partition [ps, pe); empty frames come back with end == start
+__device__ __forceinline__ void frame_bounds(const WFrame& f, i64 i, i64 ps, i64 pe, i64 gs, i64 ge, i64& start, i64& end) {
+  switch (f.lo_kind) {
+    case WB_UNBOUNDED: start = ps; break;
+    case WB_CURRENT_ROW: start = i; break;
+    case WB_CURRENT_RANGE: start = gs; break;
+    default: start = i + f.lo_off; break;
+  }
+  switch (f.hi_kind) {
+    case WB_UNBOUNDED: end = pe; break;
+    case WB_CURRENT_ROW: end = i + 1; break;
+    case WB_CURRENT_RANGE: end = ge; break;
+    default: end = i + f.hi_off + 1; break;
+  }
+  if (start < ps) start = ps;
+  if (end > pe) end = pe;
+  if (end < start) end = start;
+}
 
 // S: inclusive 128-bit prefix sums of the argument, C: exclusive prefix counts (n + 1) of its non-NULL rows
-__global__ __launch_bounds__(256) void window_agg_kernel(int fn, int frame, const i128* __restrict__ S, const i128* __restrict__ SH, const i32* __restrict__ C, const i32* __restrict__ sp,
+__global__ __launch_bounds__(256) void window_agg_kernel(int fn, WFrame frame, const i128* __restrict__ S, const i128* __restrict__ SH, const i32* __restrict__ C, const i32* __restrict__ sp,
                                                          const i32* __restrict__ sg, const u32* __restrict__ first_part, const u32* __restrict__ first_peer, i64 n,
                                                          u128 bound, i128 scaler, u128 avg_bound, void* __restrict__ out, u8* __restrict__ out_ok) {
   for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
     const i32 p = sp[i + 1] - 1, g = sg[i + 1] - 1;
-    const i64 start = first_part[p];
-    const i64 end = frame == WF_WHOLE ? (i64)first_part[p + 1] : frame == WF_ROWS_CURRENT ? i + 1 : (i64)first_peer[g + 1];
-    i128 total = (i128)((u128)S[end - 1] - (start ? (u128)S[start - 1] : (u128)0));
+    i64 start, end;
+    frame_bounds(frame, i, (i64)first_part[p], (i64)first_part[p + 1], (i64)first_peer[g], (i64)first_peer[g + 1], start, end);
+    const bool empty = end <= start;
+    i128 total = empty ? (i128)0 : (i128)((u128)S[end - 1] - (start ? (u128)S[start - 1] : (u128)0));
     bool wrapped = false;
-    if (SH) {
+    if (SH && !empty) {
       // total = hi·2^64 + lo with both parts exact; anything that does not fit 127 bits is far beyond every decimal precision
       const i128 hs = SH[end - 1] - (start ? SH[start - 1] : (i128)0);
       if (hs >= ((i128)1 << 63) || hs < -((i128)1 << 63)) wrapped = true;
       else wrapped = __builtin_add_overflow((i128)((u128)hs << 64), total, &total);
     }
-    const i64 cnt = wrapped ? 0 : (i64)C[end] - (i64)C[start];   // a wrapped sum evaluates to NULL like an overflowed one
+    const i64 cnt = (wrapped || empty) ? 0 : (i64)C[end] - (i64)C[start];   // a wrapped sum evaluates to NULL like an overflowed one
     switch (fn) {
       case WA_SUM_DEC: {   // SumDecimal evaluate (sum_decimal.rs:264-279): NULL if no value or out of precision
         const bool ok = cnt > 0 && dec_fits(total, bound);
@@ -225,6 +247,109 @@ __global__ __launch_bounds__(256) void window_agg_kernel(int fn, int frame, cons
         break;
       }
     }
+  }
+}
+
+// ---- MIN / MAX over frames -------------------------------------------------------------------------------------------------------
+// Running extremes per partition: P[i] = extreme of the non-NULL values of rows [partition start, i], Q[i] = of rows [i, partition end).
+// A segmented inclusive scan in three launches (tile scan in LDS → carries across tiles → apply), run forwards for P and backwards for Q.
+// An element is (partition ordinal, value, "holds a value"); combining left ⊕ right keeps right when the partitions differ.
+struct MM { i32 pid; u32 has; i128 v; };
+__device__ __forceinline__ MM mm_combine(const MM& a, const MM& b, int is_max) {
+  if (a.pid != b.pid || !a.has) return b;
+  if (!b.has) { MM r = a; r.pid = b.pid; return r; }
+  MM r = b;
+  r.v = is_max ? (a.v > b.v ? a.v : b.v) : (a.v < b.v ? a.v : b.v);
+  return r;
+}
+constexpr int kMMTile = 1024;
+// element at scan position j (forwards: row j; backwards: row n − 1 − j)
+__device__ __forceinline__ MM mm_load(const i128* vals, const u32* ok, const i32* sp, i64 n, i64 j, int backward) {
+  MM e;
+  if (j >= n) { e.pid = -1; e.has = 0; e.v = 0; return e; }
+  const i64 i = backward ? n - 1 - j : j;
+  e.pid = sp[i + 1] - 1;
+  e.has = ok[i] ? 1u : 0u;
+  e.v = vals[i];
+  return e;
+}
+__global__ __launch_bounds__(256) void mm_tile_kernel(const i128* __restrict__ vals, const u32* __restrict__ ok, const i32* __restrict__ sp, i64 n, int backward, int is_max,
+                                                      MM* __restrict__ local, MM* __restrict__ tile_last) {
+  __shared__ MM part[256];
+  const i64 base = (i64)blockIdx.x * kMMTile + (i64)threadIdx.x * 4;
+  MM loc[4];
+  MM run = mm_load(vals, ok, sp, n, base, backward);
+  loc[0] = run;
+  for (int k = 1; k < 4; k++) {
+    run = mm_combine(run, mm_load(vals, ok, sp, n, base + k, backward), is_max);
+    loc[k] = run;
+  }
+  part[threadIdx.x] = run;
+  __syncthreads();
+  for (int st = 1; st < 256; st <<= 1) {
+    MM left = part[threadIdx.x];
+    if ((int)threadIdx.x >= st) left = mm_combine(part[threadIdx.x - st], part[threadIdx.x], is_max);
+    __syncthreads();
+    part[threadIdx.x] = left;
+    __syncthreads();
+  }
+  for (int k = 0; k < 4; k++) {
+    const i64 j = base + k;
+    if (j >= n) break;
+    local[j] = threadIdx.x ? mm_combine(part[threadIdx.x - 1], loc[k], is_max) : loc[k];
+  }
+  if (threadIdx.x == 255) tile_last[blockIdx.x] = part[255];
+}
+// carries: tile_carry[t] = the running element at the end of tile t − 1 (pid −1 for tile 0); one thread — n / 1024 steps
+__global__ void mm_carry_kernel(const MM* __restrict__ tile_last, i64 ntiles, int is_max, MM* __restrict__ tile_carry) {
+  MM run;
+  run.pid = -1; run.has = 0; run.v = 0;
+  for (i64 t = 0; t < ntiles; t++) {
+    tile_carry[t] = run;
+    const MM last = tile_last[t];
+    run = last.pid < 0 ? run : mm_combine(run, last, is_max);
+  }
+}
+__global__ __launch_bounds__(256) void mm_apply_kernel(const MM* __restrict__ local, const MM* __restrict__ tile_carry, i64 n, int backward, int is_max, i128* __restrict__ out_v,
+                                                       u8* __restrict__ out_has) {
+  for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < n; j += (i64)gridDim.x * 256) {
+    const MM r = mm_combine(tile_carry[j / kMMTile], local[j], is_max);
+    const i64 i = backward ? n - 1 - j : j;
+    out_v[i] = r.v;
+    out_has[i] = (u8)r.has;
+  }
+}
+// the frame's extreme from the running extremes; a frame bounded on both sides is walked (its width is capped by the planner)
+__global__ __launch_bounds__(256) void window_minmax_kernel(int is_max, WFrame frame, const i128* __restrict__ vals, const u32* __restrict__ ok, const i128* __restrict__ P,
+                                                            const u8* __restrict__ Ph, const i128* __restrict__ Q, const u8* __restrict__ Qh, const i32* __restrict__ sp,
+                                                            const i32* __restrict__ sg, const u32* __restrict__ first_part, const u32* __restrict__ first_peer, i64 n, int out_width,
+                                                            void* __restrict__ out, u8* __restrict__ out_ok) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    const i32 p = sp[i + 1] - 1, g = sg[i + 1] - 1;
+    i64 start, end;
+    frame_bounds(frame, i, (i64)first_part[p], (i64)first_part[p + 1], (i64)first_peer[g], (i64)first_peer[g + 1], start, end);
+    i128 v = 0;
+    bool has = false;
+    if (end > start) {
+      if (frame.lo_kind == WB_UNBOUNDED) { v = P[end - 1]; has = Ph[end - 1] != 0; }
+      else if (frame.hi_kind == WB_UNBOUNDED) { v = Q[start]; has = Qh[start] != 0; }
+      else
+        for (i64 k = start; k < end; k++)
+          if (ok[k]) {
+            const i128 x = vals[k];
+            if (!has || (is_max ? x > v : x < v)) v = x;
+            has = true;
+          }
+    }
+    if (!has) v = 0;
+    switch (out_width) {
+      case 1: ((u8*)out)[i] = (u8)v; break;
+      case 2: ((unsigned short*)out)[i] = (unsigned short)v; break;
+      case 4: ((u32*)out)[i] = (u32)v; break;
+      case 8: ((u64*)out)[i] = (u64)v; break;
+      default: ((i128*)out)[i] = v; break;
+    }
+    out_ok[i] = has ? 1 : 0;
   }
 }
 
@@ -266,7 +391,27 @@ int comet_launch_scan128(const void* in128, int64_t n, void* tiles, void* out128
   hipLaunchKernelGGL(scan128_apply_kernel, (int)nt, 256, 0, (hipStream_t)stream, (const i128*)in128, (i64)n, (const u128*)tiles, (i128*)out128);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int comet_launch_window_agg(int fn, int frame, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,
+// one direction of the running extremes: scratch `local` n × 32 bytes, `tiles` 2 × (n / 1024 + 1) × 32 bytes
+int comet_launch_window_running_extreme(const void* vals128, const uint32_t* ok, const int32_t* sp, int64_t n, int backward, int is_max, void* local, void* tiles, void* out_v,
+                                        uint8_t* out_has, void* stream) {
+  if (n <= 0) return 0;
+  const int64_t nt = (n + kMMTile - 1) / kMMTile;
+  MM* tl = (MM*)tiles;
+  hipLaunchKernelGGL(mm_tile_kernel, (int)nt, 256, 0, (hipStream_t)stream, (const i128*)vals128, ok, sp, (i64)n, backward, is_max, (MM*)local, tl);
+  hipLaunchKernelGGL(mm_carry_kernel, 1, 1, 0, (hipStream_t)stream, (const MM*)tl, (i64)nt, is_max, tl + nt);
+  hipLaunchKernelGGL(mm_apply_kernel, grid_for(n), 256, 0, (hipStream_t)stream, (const MM*)local, (const MM*)(tl + nt), (i64)n, backward, is_max, (i128*)out_v, out_has);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_window_minmax(int is_max, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const void* vals128, const uint32_t* ok, const void* P, const uint8_t* Ph,
+                               const void* Q, const uint8_t* Qh, const int32_t* sp, const int32_t* sg, const uint32_t* first_part, const uint32_t* first_peer, int64_t n,
+                               int out_width, void* out, uint8_t* out_ok, void* stream) {
+  WFrame f{lo_kind, hi_kind, (i64)lo_off, (i64)hi_off};
+  if (n > 0)
+    hipLaunchKernelGGL(window_minmax_kernel, grid_for(n), 256, 0, (hipStream_t)stream, is_max, f, (const i128*)vals128, ok, (const i128*)P, Ph, (const i128*)Q, Qh, sp, sg, first_part,
+                       first_peer, (i64)n, out_width, out, out_ok);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_window_agg(int fn, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,
                             const uint32_t* first_peer, int64_t n, const void* bound16, const void* scaler16, const void* avg_bound16, void* out, uint8_t* out_ok,
                             void* stream) {
   u128 bound, avg_bound;
@@ -275,7 +420,7 @@ int comet_launch_window_agg(int fn, int frame, const void* S128, const void* SH1
   memcpy(&scaler, scaler16, 16);
   memcpy(&avg_bound, avg_bound16, 16);
   if (n > 0)
-    hipLaunchKernelGGL(window_agg_kernel, grid_for(n), 256, 0, (hipStream_t)stream, fn, frame, (const i128*)S128, (const i128*)SH128, C, sp, sg, first_part, first_peer, (i64)n, bound, scaler,
+    hipLaunchKernelGGL(window_agg_kernel, grid_for(n), 256, 0, (hipStream_t)stream, fn, WFrame{lo_kind, hi_kind, (i64)lo_off, (i64)hi_off}, (const i128*)S128, (const i128*)SH128, C, sp, sg, first_part, first_peer, (i64)n, bound, scaler,
                        avg_bound, out, out_ok);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

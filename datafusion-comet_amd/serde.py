@@ -431,8 +431,17 @@ class Operator:
             for wf in self.window_fns:
                 if wf[0] == "agg":
                     # aggregate over a frame: ("agg", AggExpr, result type, (rows|range, unbounded|current, unbounded|current))
+                    # a bound is "unbounded", "current" or an int: rows relative to the current row, negative = PRECEDING, positive = FOLLOWING —
+                    # carried by Preceding.offset / Following.offset whichever side it is on (operator.proto:815-845, planner.rs:3016-3030)
                     _, agg, rtype, (ftype, lo, up) = wf
-                    fr = (_f_varint(1, 1) if ftype == "range" else b"") + _f_msg(2, _f_msg(1 if lo == "unbounded" else 3, b"")) + _f_msg(3, _f_msg(1 if up == "unbounded" else 3, b""))
+
+                    def bound(b):
+                        if b == "unbounded":
+                            return _f_msg(1, b"")
+                        if b == "current":
+                            return _f_msg(3, b"")
+                        return _f_msg(2, _f_varint(1, int(b) & 0xFFFFFFFFFFFFFFFF) if int(b) != 0 else b"")
+                    fr = (_f_varint(1, 1) if ftype == "range" else b"") + _f_msg(2, bound(lo)) + _f_msg(3, bound(up))
                     aspec = b"".join(_f_msg(1, e.encode()) for e in self.partition_by) + b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders) + _f_msg(3, fr)
                     body += _f_msg(1, _f_msg(2, agg.encode()) + _f_msg(3, aspec) + _f_msg(5, rtype.encode()))
                     continue

@@ -859,14 +859,19 @@ def run_plan(S, op, table) -> List[Col]:
                 # SUM / COUNT / AVG over [partition start, frame end): exact integer arithmetic, evaluated like the aggregates'
                 # Final step (sum_decimal.rs:264-279, sum_int.rs, avg_decimal.rs:597-689)
                 _, a, rtype, (ftype, lo, up) = wf
-                assert lo == "unbounded"
                 arg = ev.eval(a.children[0], child, n)
                 isdec = arg.dtype.type_id == S.DECIMAL
                 ival = [(dec_to_int(arg.values, i) if isdec else int(arg.values[i])) if arg.ok()[i] else None for i in range(n)]
                 vals, oks = [], []
                 for i in range(n):
-                    end = pe[i] if up == "unbounded" else (i + 1 if ftype == "rows" else ge[i])
-                    win = [v for v in ival[ps[i]:end] if v is not None]
+                    # the frame, clipped to the partition: a bound is the partition edge, the current row (ROWS) / its peer group (RANGE),
+                    # or the current row ± rows (negative = PRECEDING)
+                    start = ps[i] if lo == "unbounded" else ((i if ftype == "rows" else gs[i]) if lo == "current" else i + int(lo))
+                    end = pe[i] if up == "unbounded" else ((i + 1 if ftype == "rows" else ge[i]) if up == "current" else i + int(up) + 1)
+                    start, end = max(start, ps[i]), min(end, pe[i])
+                    win = [v for v in ival[start:max(end, start)] if v is not None]
+                    if a.kind in ("min", "max"):
+                        vals.append((min(win) if a.kind == "min" else max(win)) if win else 0); oks.append(bool(win)); continue
                     if a.kind == "count":
                         vals.append(len(win)); oks.append(True); continue
                     if not win:
@@ -888,6 +893,9 @@ def run_plan(S, op, table) -> List[Col]:
                     okv = abs(q) <= 10**a.dtype.precision - 1
                     vals.append(q if okv else 0); oks.append(okv)
                 okn = np.array(oks, bool)
+                if a.kind in ("min", "max"):
+                    out.append(Col(arg.dtype, ints_to_dec(vals) if isdec else np.array(vals, dtype=arg.values.dtype), None if okn.all() else okn))
+                    continue
                 if a.kind == "count" or (a.kind == "sum" and not isdec):
                     out.append(Col(S.T_INT64, np.array(vals, np.int64), None if okn.all() else okn))
                 else:

@@ -113,3 +113,44 @@ def test_aggregates_over_partition_and_running_frames(built):
     got2 = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t2)], 9, plan2.encode(), batch_size=0))
     want2 = O.run_plan_to_arrow(S, plan2, [t2])
     assert _rows(got2) == _rows(want2)
+
+
+def test_sliding_frames_and_min_max(built):
+    """ROWS frames with literal offsets on either side (n PRECEDING / n FOLLOWING, both bounds on one side of the row, frames that fall off the
+    partition and come back empty), frames that start at the current row, and MIN / MAX over every frame shape (planner.rs:2953-3100): sums
+    and counts from prefix-sum differences, extremes from running extremes per partition (frames touching a partition edge) or a walk of the
+    frame (bounded on both sides).  Unique order keys: ROWS frames depend on the position among peers."""
+    from oracle import oracle as O
+    t = _table(25_000, 15, unique_order=True)
+    t = t.set_column(2, "amount", pa.array([None if i % 11 == 0 else v for i, v in enumerate(t.column(2).to_pylist())], pa.decimal128(12, 2)))
+    # order by the id-like unique column instead of amount (which now has NULLs): keep amount as the argument
+    cat, store, amount, ident = S.col(0, S.T_STRING), S.col(1, S.T_INT32), S.col(2, D), S.col(3, S.T_INT64)
+    order = [(ident, True, True)]
+    child = S.sort(S.scan(FIELDS), [(cat, False, False), (store, False, False)] + order)
+    SD, AD = S.decimal(22, 2), S.decimal(16, 6)
+    frames = [("rows", -2, 2), ("rows", -3, "current"), ("rows", "current", 4), ("rows", -5, -2), ("rows", 1, 3), ("rows", "unbounded", 1), ("rows", -1, "unbounded"),
+              ("rows", "current", "unbounded"), ("rows", "current", "current"), ("range", "current", "unbounded"), ("rows", -2000, 2000)]
+    fns = []
+    for fr in frames:
+        fns += [("agg", S.sum_(amount, SD), SD, fr), ("agg", S.count(amount), S.T_INT64, fr), ("agg", S.min_(amount, D), D, fr), ("agg", S.max_(ident, S.T_INT64), S.T_INT64, fr)]
+    fns += [("agg", S.avg(amount, AD, SD), AD, ("rows", -2, 2)), ("agg", S.min_(S.col(1, S.T_INT32), S.T_INT32), S.T_INT32, ("rows", "unbounded", "unbounded")),
+            ("agg", S.max_(amount, D), D, ("range", "unbounded", "current"))]
+    plan = S.window(child, [cat, store], order, fns)
+    ncols = len(FIELDS) + len(fns)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], ncols, plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, [t])
+    assert got.schema.types == want.schema.types
+    assert _rows(got) == _rows(want)
+    assert got.column(len(FIELDS) + 4 * 3).null_count > 0        # SUM over (5 PRECEDING, 2 PRECEDING): empty at the head of every partition → NULL
+
+
+def test_frames_the_engine_refuses(built):
+    t = _table(100, 16, unique_order=True)
+    cat, store, amount = S.col(0, S.T_STRING), S.col(1, S.T_INT32), S.col(2, D)
+    order = [(amount, True, True)]
+    child = S.sort(S.scan(FIELDS), [(cat, False, False), (store, False, False)] + order)
+    for fn, msg in ((("agg", S.sum_(amount, S.decimal(22, 2)), S.decimal(22, 2), ("range", -2, "current")), "RANGE frames with a value offset"),
+                    (("agg", S.min_(amount, D), D, ("rows", -5000, 5000)), "wider than 4096"),
+                    (("agg", S.min_(S.col(5, S.T_DOUBLE), S.T_DOUBLE), S.T_DOUBLE, ("rows", "unbounded", "current")), "not supported yet")):
+        with pytest.raises(native.CometNativeException, match=msg):
+            native.execute_to_table([native.HostInput.from_table(t)], len(FIELDS) + 1, S.window(child, [cat, store], order, [fn]).encode(), batch_size=0)
