@@ -28,11 +28,14 @@ typedef struct PqPage {        /* one data page of a column (all selected row gr
 } PqPage;
 
 typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section */
-  int64_t byte_off;            /* bit-packed: staged-byte offset of the run's first group */
+  int64_t byte_off;            /* bit-packed: staged-byte offset of the run's first group; PLAIN chunk: of its first value */
   int32_t value_start;         /* index of the run's first value within its page section */
   int32_t count;
-  int32_t is_rle;
+  int32_t is_rle;              /* 0 bit-packed, 1 RLE, 2 = a chunk of a PLAIN page's values (index runs only: the unit of work of the
+                                  run-at-a-time decode kernel; the row-at-a-time kernel never looks at the runs of a PLAIN page) */
   uint32_t rle_value;
+  int32_t page;                /* index runs: the page (column-global index) the run belongs to */
+  int32_t pad;
 } PqRun;
 
 typedef struct PqInflate {     /* one compressed page body the device decompresses (snappy_kernels.hip); offsets relative to the column's byte buffer */
@@ -63,7 +66,7 @@ typedef struct PqDecodeArgs {
   const int64_t* plain_str_offs; /* PLAIN BYTE_ARRAY data pages: staged-byte offset of each value's bytes (+1 sentinel per page) */
   int64_t n_rows;              /* rows of this column chunk */
   int32_t out_width;           /* bytes per output value (fixed-width columns) */
-  int32_t pad0;
+  int32_t n_idx_runs;          /* entries of idx_runs (run-at-a-time kernel) */
   uint8_t* valid_out;          /* per-row validity bytes (at the chunk's row offset) */
   uint32_t* vidx;              /* per-row exclusive count of non-null rows before it (scratch) */
   void* values_out;            /* typed output at the chunk's row offset */

@@ -5,6 +5,7 @@
 // <varint header><payload>, header LSB 1 = bit-packed groups of 8, LSB 0 = RLE).  The reference delegates this to the
 // `parquet` 58.4.0 crate (native/core/src/parquet/parquet_exec.rs:145-147); pyarrow is the independent checker.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "device/comet_device.hpp"
 #include "parquet_dev.h"
@@ -310,6 +311,184 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
   }
 }
 
+// 3b. values, a RUN at a time (columns without NULLs): one wave per unit of work — a bit-packed run of dictionary indices (≤ 504 values as
+// the writers emit them), an RLE run, or a 4096-value chunk of a PLAIN page.  Everything about the unit is wave-uniform (one PqRun and one
+// PqPage, loaded once through the scalar path); lane l decodes values l, l + 64, l + 128, … of the unit, eight per pass with all index and
+// dictionary loads issued before the first store, and consecutive lanes store consecutive rows.  The row-at-a-time kernel above spends a
+// dependent index → dictionary → store chain per 64 rows and drops to a per-element path at every run boundary; here there are no
+// boundaries inside a unit.
+template <int OW>
+__device__ __forceinline__ void pq_store(void* out, i64 row, i128 v) {
+  if (OW == 1) ((u8*)out)[row] = (u8)v;
+  else if (OW == 2) ((u16*)out)[row] = (u16)v;
+  else if (OW == 4) ((u32*)out)[row] = (u32)v;
+  else if (OW == 8) ((u64*)out)[row] = (u64)v;
+  else ((i128*)out)[row] = v;
+}
+// CV: how a source value becomes the stored value — the common conversions get straight-line code (the generic pq_convert pays a
+// switch and, for decimals, a 128-bit multiply by 10^0 per value): 1 copy 4 bytes, 2 copy 8 bytes, 3 INT64 → Decimal128 without
+// rescaling, 4 INT32 → Decimal128 without rescaling, 0 everything else
+template <int CV>
+__device__ __forceinline__ i128 pq_cv(int kind, const u8* src, int width, int dec_up) {
+  if (CV == 1) return (i128)(u128)pq_ld32(src);
+  if (CV == 2) return (i128)(u128)pq_ld64(src);
+  if (CV == 3) return (i128)(i64)pq_ld64(src);
+  if (CV == 4) return (i128)(i32)pq_ld32(src);
+  return pq_convert(kind, src, width, dec_up, 0);
+}
+#define PQ_LDS __attribute__((address_space(3)))
+constexpr int kUnitLdsBytes = 2048;        // a wave's LDS slice for one unit's packed indices (504 values × 32 bits = 2016 bytes)
+template <int OW, int CV>
+__device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, const PqRun& rn, const PqPage& pg, int lane, PQ_LDS u32* lds) {
+  const u8* __restrict__ bytes = a.bytes;
+  const u8* __restrict__ dict = a.dict + pg.dict_off;
+  const i64 row0 = pg.row_start + rn.value_start;
+  i32 count = rn.count;
+  if (rn.value_start + count > pg.num_values) count = pg.num_values - rn.value_start;   // the last bit-packed group of a page is padded to 8 values
+  const int kind = pg.kind, width = pg.width, dec_up = pg.dec_scale_up;
+  if (rn.is_rle == 1) {
+    const i128 v = pq_cv<CV>(kind, dict + (i64)rn.rle_value * width, width, dec_up);
+    for (i32 j = lane; j < count; j += 64) pq_store<OW>(a.values_out, row0 + j, v);
+    return;
+  }
+  constexpr int U = 4;     // values per lane per pass: 4 keeps the kernel at 68 VGPRs (7 waves per SIMD); 8 needs 103 (4 waves) and measured slower
+  if (rn.is_rle == 2) {
+    // PLAIN values (booleans: one bit per value)
+    const u8* src = bytes + rn.byte_off;
+    for (i32 base = 0; base < count; base += 64 * U) {
+      i128 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const i32 j = base + u * 64 + lane;
+        v[u] = 0;
+        if (j < count) v[u] = (CV == 0 && kind == PQ_BOOL) ? (i128)((src[j >> 3] >> (j & 7)) & 1) : pq_cv<CV>(kind, src + (i64)j * width, width, dec_up);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const i32 j = base + u * 64 + lane;
+        if (j < count) pq_store<OW>(a.values_out, row0 + j, v[u]);
+      }
+    }
+    return;
+  }
+  // bit-packed dictionary indices.  What limits this path is the number of loads in flight, not bytes: one 4-byte load per 6-bit index
+  // wastes a load slot on 6 bits.  So the wave first copies the unit's packed bytes (≤ 2 KiB for 504 values) into its LDS slice with
+  // one or two 16-byte loads per lane, then every lane picks its indices out of LDS (values lane, lane + 64, …: consecutive lanes
+  // still store consecutive rows).
+  const int bw = pg.bit_width;
+  const u8* packed = bytes + rn.byte_off;
+  const i32 nbytes = (i32)(((i64)count * bw + 7) >> 3);
+  if (nbytes <= kUnitLdsBytes) {
+    for (i32 o = lane * 16; o < nbytes; o += 64 * 16) {
+      u64 lo = pq_ld64(packed + o), hi = pq_ld64(packed + o + 8);      // (reads up to 15 bytes past the run: the staging is padded)
+      lds[(o >> 2) + 0] = (u32)lo;
+      lds[(o >> 2) + 1] = (u32)(lo >> 32);
+      lds[(o >> 2) + 2] = (u32)hi;
+      lds[(o >> 2) + 3] = (u32)(hi >> 32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const u64 mask = bw >= 32 ? 0xffffffffull : ((1ull << bw) - 1);
+    for (i32 base = 0; base < count; base += 64 * U) {
+      u32 idx[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const i32 j = base + u * 64 + lane;
+        const u32 bit = (u32)j * (u32)bw;
+        const u32 wi = bit >> 5;
+        idx[u] = j < count ? (u32)(((((u64)lds[wi + 1]) << 32 | lds[wi]) >> (bit & 31)) & mask) : 0u;
+      }
+      i128 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = pq_cv<CV>(kind, dict + (i64)idx[u] * width, width, dec_up);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const i32 j = base + u * 64 + lane;
+        if (j < count) pq_store<OW>(a.values_out, row0 + j, v[u]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();      // the slice is overwritten by the wave's next unit
+    return;
+  }
+  // a run longer than the LDS slice (writers do not emit them; a hand-made file could): indices straight from memory
+  for (i32 base = 0; base < count; base += 64 * U) {
+    u32 idx[U];
+    const u64 mask = bw >= 32 ? 0xffffffffull : ((1ull << bw) - 1);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const i32 j = base + u * 64 + lane;
+      const i64 bit = (i64)j * bw;
+      idx[u] = j < count ? (u32)((pq_ld64(packed + (bit >> 3)) >> (bit & 7)) & mask) : 0u;
+    }
+    i128 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = pq_cv<CV>(kind, dict + (i64)idx[u] * width, width, dec_up);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const i32 j = base + u * 64 + lane;
+      if (j < count) pq_store<OW>(a.values_out, row0 + j, v[u]);
+    }
+  }
+}
+__device__ __forceinline__ PqRun pq_load_run_uniform(const PqRun* rp) {
+  PqRun rn;
+  rn.byte_off = pq_uniform_i64(rp->byte_off);
+  rn.value_start = __builtin_amdgcn_readfirstlane(rp->value_start);
+  rn.count = __builtin_amdgcn_readfirstlane(rp->count);
+  rn.is_rle = __builtin_amdgcn_readfirstlane(rp->is_rle);
+  rn.rle_value = (u32)__builtin_amdgcn_readfirstlane((int)rp->rle_value);
+  rn.page = __builtin_amdgcn_readfirstlane(rp->page);
+  rn.pad = 0;
+  return rn;
+}
+__global__ __launch_bounds__(256) void pq_decode_runs_kernel(PqDecodeArgs a) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // every wave takes a CONTIGUOUS range of units: consecutive units share their page (its entry is reloaded only when the page changes),
+  // read adjacent index bytes and write adjacent rows; the next unit's table entry is loaded while the current unit is being decoded,
+  // so the only dependent memory accesses left per unit are index → dictionary → store
+  __shared__ u32 s_idx[4][kUnitLdsBytes / 4 + 8];
+  PQ_LDS u32* lds = (PQ_LDS u32*)s_idx[wave];      // address_space(3): ds_read / ds_write, not FLAT (a FLAT access waits for every outstanding global load)
+  const i64 nwaves = (i64)gridDim.x * 4;
+  const i64 per = ((i64)a.n_idx_runs + nwaves - 1) / nwaves;
+  const i64 w = (i64)blockIdx.x * 4 + wave;
+  const i64 begin = w * per, end = begin + per < a.n_idx_runs ? begin + per : (i64)a.n_idx_runs;
+  if (begin >= end) return;
+  int cur_page = -1;
+  PqPage pg;
+  PqRun next = pq_load_run_uniform(a.idx_runs + begin);
+  for (i64 r = begin; r < end; r++) {
+    const PqRun rn = next;
+    if (r + 1 < end) next = pq_load_run_uniform(a.idx_runs + r + 1);
+    if (rn.page != cur_page) {
+      const PqPage* pp = a.pages + rn.page;
+      pg.row_start = pq_uniform_i64(pp->row_start);
+      pg.dict_off = pq_uniform_i64(pp->dict_off);
+      pg.num_values = __builtin_amdgcn_readfirstlane(pp->num_values);
+      pg.bit_width = __builtin_amdgcn_readfirstlane(pp->bit_width);
+      pg.kind = __builtin_amdgcn_readfirstlane(pp->kind);
+      pg.width = __builtin_amdgcn_readfirstlane(pp->width);
+      pg.dec_scale_up = __builtin_amdgcn_readfirstlane(pp->dec_scale_up);
+      cur_page = rn.page;
+    }
+    // the conversion class is wave-uniform: one branch per unit, straight-line code inside
+    const int cv = pg.kind == PQ_COPY4 ? 1 : pg.kind == PQ_COPY8 ? 2 : (pg.kind == PQ_I64_TO_DEC && pg.dec_scale_up == 0) ? 3 : (pg.kind == PQ_I32_TO_DEC && pg.dec_scale_up == 0) ? 4 : 0;
+    if (cv == 1 && a.out_width == 4) pq_decode_unit<4, 1>(a, rn, pg, lane, lds);
+    else if (cv == 2 && a.out_width == 8) pq_decode_unit<8, 2>(a, rn, pg, lane, lds);
+    else if (cv == 3 && a.out_width == 16) pq_decode_unit<16, 3>(a, rn, pg, lane, lds);
+    else if (cv == 4 && a.out_width == 16) pq_decode_unit<16, 4>(a, rn, pg, lane, lds);
+    else
+      switch (a.out_width) {
+        case 1: pq_decode_unit<1, 0>(a, rn, pg, lane, lds); break;
+        case 2: pq_decode_unit<2, 0>(a, rn, pg, lane, lds); break;
+        case 4: pq_decode_unit<4, 0>(a, rn, pg, lane, lds); break;
+        case 8: pq_decode_unit<8, 0>(a, rn, pg, lane, lds); break;
+        default: pq_decode_unit<16, 0>(a, rn, pg, lane, lds); break;
+      }
+  }
+}
+
 // 4. strings: lengths, then (after the host-driven offset scan) bytes
 __device__ __forceinline__ void pq_string_ref(const PqDecodeArgs& a, i64 row, const u8*& p, u32& len) {
   const PqPage pg = a.pages[pq_find_page(a.pages, a.npages, row)];
@@ -420,6 +599,11 @@ void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* 
   hipLaunchKernelGGL(pq_tile_count_kernel, grid_tiles(n), 256, 0, s, valid, (i64)n, (u64*)tiles);
   hipLaunchKernelGGL(pq_tile_scan_kernel, 1, 256, 0, s, (u64*)tiles, (i64)((n + 1023) / 1024));
   hipLaunchKernelGGL(pq_vidx_kernel, grid_tiles(n), 256, 0, s, valid, (i64)n, (const u64*)tiles, (u32*)vidx);
+}
+void pq_launch_decode_runs(const PqDecodeArgs* a, void* st) {
+  if (a->n_idx_runs <= 0) return;
+  const int blocks = (int)std::min<i64>(((i64)a->n_idx_runs + 3) / 4, 256 * 16);
+  hipLaunchKernelGGL(pq_decode_runs_kernel, blocks, 256, 0, (hipStream_t)st, *a);
 }
 void pq_launch_decode_fixed(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_decode_fixed_kernel, grid_slices(a->n_rows), 256, 0, (hipStream_t)st, *a); }
 void pq_launch_string_lengths(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_string_lengths_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }

@@ -32,6 +32,7 @@ extern "C" {
 void pq_launch_validity(const PqDecodeArgs* a, void* st);
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st);
 void pq_launch_decode_fixed(const PqDecodeArgs* a, void* st);
+void pq_launch_decode_runs(const PqDecodeArgs* a, void* st);
 void pq_launch_string_lengths(const PqDecodeArgs* a, void* st);
 void pq_launch_string_copy(const PqDecodeArgs* a, void* st);
 void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
@@ -770,6 +771,23 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     while (keep_i < keep.size() && keep[keep_i].second <= r0) keep_i++;
     return keep_i < keep.size() && keep[keep_i].first < r1;
   };
+  // a PLAIN page's values cut into chunks of 4096: the units the run-at-a-time decode kernel hands to its waves
+  constexpr int32_t kPlainChunk = 4096;
+  auto plain_chunks = [&](PqPage& pg, int64_t values_off_flagged) {
+    if (cp.is_string) return;
+    pg.idx_run_first = (int32_t)idx_runs.size();
+    const int64_t unit_bits = cp.kind == PQ_BOOL ? 1 : (int64_t)cp.src_width * 8;
+    for (int32_t v = 0; v < pg.num_values; v += kPlainChunk) {
+      PqRun r;
+      memset(&r, 0, sizeof r);
+      r.is_rle = 2;
+      r.value_start = v;
+      r.count = std::min(kPlainChunk, pg.num_values - v);
+      r.byte_off = values_off_flagged + ((int64_t)v * unit_bits) / 8;
+      idx_runs.push_back(r);
+    }
+    pg.idx_run_count = (int32_t)idx_runs.size() - pg.idx_run_first;
+  };
   while (values_seen < cm.num_values && off < chunk_end) {
     pq::PageHeader h = pq::parse_page_header(chunk_data + off, (size_t)(chunk_end - off));
     const uint8_t* body = chunk_data + off + h.header_len;
@@ -865,6 +883,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       hc.ipos = ipage + un_len;
       pg.encoding = 0;
       pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
+      plain_chunks(pg, pg.values_off);
       emit(pg, values_seen, values_seen + h.num_values, tmp.data() - ipage);
       values_seen += h.num_values;
       continue;
@@ -901,6 +920,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     if (h.encoding == pq::PLAIN) {
       pg.encoding = 0;
       pg.values_off = (int64_t)vals_begin;
+      plain_chunks(pg, pg.values_off);
       if (cp.is_string) {
         pg.str_first = (int64_t)str_offs.size();
         size_t p = vals_begin;
@@ -1023,6 +1043,18 @@ void synth_chunk(const StructField& want, const Expr* dflt, int64_t rows, HostCh
       pg.kind = PQ_BOOL;
       pg.encoding = 0;
       pg.values_off = 0;
+      // PLAIN bits: the page's runs are chunks of its values (the units of the run-at-a-time kernel), not an index run
+      hc.idx_runs.clear();
+      for (int64_t v = 0; v < rows; v += 4096) {
+        PqRun r;
+        memset(&r, 0, sizeof r);
+        r.is_rle = 2;
+        r.value_start = (int32_t)v;
+        r.count = (int32_t)std::min<int64_t>(4096, rows - v);
+        r.byte_off = v / 8;
+        hc.idx_runs.push_back(r);
+      }
+      pg.idx_run_count = (int32_t)hc.idx_runs.size();
       spos = (size_t)((rows + 7) / 8);
       if (spos + 16 > cap) throw CometError("internal: synthetic boolean page does not fit its slot");
       memset(staged, (!is_null && dflt->lit_bool) ? 0xff : 0x00, spos);
@@ -1338,6 +1370,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const size_t off_jobs = o; o = al(o + n_jobs * sizeof(PqInflate) + 16);
     cd->h_tables.ensure(o + 16);
     char* tb_h = (char*)cd->h_tables.p;
+    bool runs_kernel_ok = true;
     {
       PqPage* P = (PqPage*)(tb_h + off_pages);
       PqRun* D = (PqRun*)(tb_h + off_def);
@@ -1347,6 +1380,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       int64_t* SO = (int64_t*)(tb_h + off_soffs);
       PqInflate* J = (PqInflate*)(tb_h + off_jobs);
       size_t ip = 0, id = 0, ii = 0, idb = 0, ido = 0, iso = 0, ij = 0;
+      runs_kernel_ok = true;
       for (size_t si = 0; si < nsel; si++) {
         HostChunk& hc = chunks[c * nsel + si];
         const int64_t base = (int64_t)slot_off[c][si];
@@ -1373,7 +1407,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         }
         if (nulls)
           for (const PqRun& r : hc.def_runs) { D[id] = r; D[id].byte_off = global_off(r.byte_off); id++; }
-        for (const PqRun& r : hc.idx_runs) { I[ii] = r; I[ii].byte_off += base; ii++; }
+        for (const PqRun& r : hc.idx_runs) { I[ii] = r; I[ii].byte_off = global_off(r.byte_off); ii++; }
+        // every index run (and PLAIN chunk) learns its page: the run-at-a-time kernel starts from the run
+        for (size_t gp = ip - hc.pages.size(); gp < ip; gp++)
+          for (int32_t r = P[gp].idx_run_first; r < P[gp].idx_run_first + P[gp].idx_run_count; r++) I[r].page = (int32_t)gp;
+        runs_kernel_ok &= sels[si].keep == nullptr;      // pieces of a pruned page share their page's runs: those columns take the row-at-a-time kernel
         if (!hc.dict_bytes.empty()) memcpy(DB + idb, hc.dict_bytes.data(), hc.dict_bytes.size());
         idb += (hc.dict_bytes.size() + 15) & ~(size_t)15;
         if (!hc.dict_offs.empty()) memcpy(DO + ido, hc.dict_offs.data(), hc.dict_offs.size() * 4);
@@ -1407,6 +1445,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     a.plain_str_offs = (const int64_t*)(tb + off_soffs);
     a.n_rows = total_rows;
     a.out_width = cp.out_width;
+    a.n_idx_runs = (int32_t)n_idx;
     if (any_optional) {
       valid_bytes->ensure((size_t)total_rows + 16);
       if (!vidx->p) vidx->ensure((size_t)total_rows * 4 + 16);
@@ -1418,7 +1457,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     if (!is_string) {
       values->ensure((size_t)total_rows * cp.out_width + 16);
       a.values_out = values->p;
-      pq_launch_decode_fixed(&a, stream_);
+      // a column without NULLs (and without pruned pages) is decoded a RUN at a time: a wave takes one bit-packed run / RLE run / chunk of
+      // a PLAIN page and every lane decodes 8 of its values with all loads in flight at once; otherwise row by row
+      static const bool force_rows = getenv("COMET_PQ_DECODE_ROWS") != nullptr;
+      if (!any_optional && runs_kernel_ok && !force_rows) pq_launch_decode_runs(&a, stream_);
+      else pq_launch_decode_fixed(&a, stream_);
     } else {
       lengths->ensure((size_t)total_rows * 4 + 16);
       a.lengths_out = (uint32_t*)lengths->p;
