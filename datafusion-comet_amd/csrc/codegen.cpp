@@ -1948,6 +1948,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         AggIn in;
         in.a = &a;
         in.mode = op.expr_modes.empty() ? op.agg_mode : (AggMode)op.expr_modes[ai];
+        if (ai == 0) d.merges_states = in.mode != AggMode::Partial;
+        else d.merges_states = d.merges_states && in.mode != AggMode::Partial;
         if (in.mode == AggMode::Partial) {
           for (auto& c : a.children) in.children.push_back(substitute(c, cols, memo));
           if (a.filter) in.filter = substitute(a.filter, cols, memo);

@@ -60,6 +60,9 @@ struct PipelineDesc {
   // 16 bits each in prm.iarg[kFixScaleArg]
   struct FixSum { int word = 0; int aux_hi = 0, aux_lo = 0; };
   std::vector<FixSum> fix_sums;
+  // grouped aggregate whose input rows are Partial states (Final / PartialMerge): about one input row per group and partition, so the
+  // executor sizes the group table from the row count instead of growing it from the small default
+  bool merges_states = false;
 };
 constexpr int kFixScaleArg = 6;
 constexpr int kFixMaxSums = 4;

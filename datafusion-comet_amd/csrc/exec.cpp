@@ -1223,6 +1223,11 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     if (group_cap_ == 0) {
       // start small: low-cardinality group-bys (TPC-H Q1: 4 groups) must not pay for a table sized by the row count
       int64_t want = 1 << 16;
+      if (d.merges_states) {
+        // merging Partial states: roughly one input row per group (SF100 Q3's Final aggregate: 1.13 M rows, 1.13 M groups) — size the table for
+        // the chunk at once instead of filling and growing it twice (3.9 ms → one pass)
+        while (want < 2 * n && want < ((int64_t)1 << 26)) want <<= 1;
+      }
       group_cap_ = want;
       alloc_table(group_table_, group_cap_);
       HIP_CHECK(hipMemsetAsync((char*)err_flags_.p + 8, 0, 8, stream_));
