@@ -69,6 +69,209 @@ int kind_of(const char* fmt) {
 }
 int width_of(int kind) { return kind == 1 ? 1 : kind == 2 ? 2 : kind == 3 || kind == 5 ? 4 : kind == 4 || kind == 6 ? 8 : 16; }
 
+// ---- nested types (struct / list / map; columnar_to_row.rs:570-830, 1602-1900) ------------------------------------------------------------
+// A batch with a nested column is converted on the HOST: the input arrays are host memory handed over by the JVM, the rows go back to host
+// memory, and a nested value is a variable-length tree (a nested row per struct, UnsafeArrayData per list, two of them per map) that the
+// one-thread-per-row device kernel has no layout for.  The flat columns of such a batch take the same host writer.
+struct HType {
+  enum Kind { Bool, I8, I16, I32, I64, F32, F64, DecLong, DecWide, Bin, LargeBin, Struct, List, LargeList, Map } kind = I64;
+  std::vector<HType> kids;
+  bool nested() const { return kind >= Struct; }
+};
+HType htype_of(const ArrowSchema* s) {
+  HType t;
+  const std::string f = s->format ? s->format : "";
+  if (s->dictionary) throw CometError("columnarToRowConvert: dictionary-encoded children of nested columns are not supported yet");
+  if (f == "+s") {
+    t.kind = HType::Struct;
+    for (int64_t k = 0; k < s->n_children; k++) t.kids.push_back(htype_of(s->children[k]));
+    return t;
+  }
+  if (f == "+l" || f == "+L") {
+    t.kind = f == "+l" ? HType::List : HType::LargeList;
+    if (s->n_children != 1) throw CometError("columnarToRowConvert: malformed list type");
+    t.kids.push_back(htype_of(s->children[0]));
+    return t;
+  }
+  if (f == "+m") {
+    t.kind = HType::Map;
+    if (s->n_children != 1 || s->children[0]->n_children != 2) throw CometError("columnarToRowConvert: malformed map type");
+    t.kids.push_back(htype_of(s->children[0]->children[0]));
+    t.kids.push_back(htype_of(s->children[0]->children[1]));
+    return t;
+  }
+  if (f == "U" || f == "Z") { t.kind = HType::LargeBin; return t; }
+  switch (kind_of(s->format)) {
+    case 0: t.kind = HType::Bool; break;
+    case 1: t.kind = HType::I8; break;
+    case 2: t.kind = HType::I16; break;
+    case 3: t.kind = HType::I32; break;
+    case 4: t.kind = HType::I64; break;
+    case 5: t.kind = HType::F32; break;
+    case 6: t.kind = HType::F64; break;
+    case 7: t.kind = HType::DecLong; break;
+    case 8: t.kind = HType::DecWide; break;
+    default: t.kind = HType::Bin; break;
+  }
+  return t;
+}
+bool any_nested(const HType& t) { return t.nested() || t.kind == HType::LargeBin; }
+
+inline bool h_valid(const ArrowArray* a, int64_t i) {
+  if (a->null_count == 0 || a->n_buffers < 1 || !a->buffers[0]) return true;
+  const int64_t b = a->offset + i;
+  return (((const uint8_t*)a->buffers[0])[b >> 3] >> (b & 7)) & 1;
+}
+inline size_t round8(size_t n) { return (n + 7) & ~(size_t)7; }
+inline void put_u64(std::vector<uint8_t>& buf, size_t at, uint64_t v) { memcpy(buf.data() + at, &v, 8); }
+inline void set_null(std::vector<uint8_t>& buf, size_t bitset_start, int64_t idx) { buf[bitset_start + (size_t)(idx >> 3)] |= (uint8_t)(1u << (idx & 7)); }
+
+// the 8-byte slot of a fixed-width value (get_field_value :1356-1400); false for variable-length types
+bool h_fixed_slot(const HType& t, const ArrowArray* a, int64_t i, uint64_t& slot) {
+  const int64_t j = a->offset + i;
+  switch (t.kind) {
+    case HType::Bool: slot = (((const uint8_t*)a->buffers[1])[j >> 3] >> (j & 7)) & 1; return true;
+    case HType::I8: slot = (uint64_t)(int64_t)((const int8_t*)a->buffers[1])[j]; return true;
+    case HType::I16: slot = (uint64_t)(int64_t)((const int16_t*)a->buffers[1])[j]; return true;
+    case HType::I32: slot = (uint64_t)(int64_t)((const int32_t*)a->buffers[1])[j]; return true;
+    case HType::I64: case HType::F64: slot = ((const uint64_t*)a->buffers[1])[j]; return true;
+    case HType::F32: slot = ((const uint32_t*)a->buffers[1])[j]; return true;
+    case HType::DecLong: slot = ((const uint64_t*)a->buffers[1])[2 * j]; return true;      // the low 64 bits of the unscaled value
+    default: return false;
+  }
+}
+size_t h_write_array_range(std::vector<uint8_t>& buf, const HType& et, const ArrowArray* values, int64_t start, int64_t n);
+
+// appends the bytes of variable-length value i of `a` (padded to 8) and returns the UNPADDED length (write_nested_variable_to_buffer :1841-1900)
+size_t h_write_value(std::vector<uint8_t>& buf, const HType& t, const ArrowArray* a, int64_t i) {
+  const int64_t j = a->offset + i;
+  auto append_padded = [&](const uint8_t* p, size_t n) {
+    const size_t at = buf.size();
+    buf.resize(at + round8(n), 0);
+    if (n) memcpy(buf.data() + at, p, n);
+    return n;
+  };
+  switch (t.kind) {
+    case HType::Bin: {
+      const int32_t* off = (const int32_t*)a->buffers[1];
+      return append_padded((const uint8_t*)a->buffers[2] + off[j], (size_t)(off[j + 1] - off[j]));
+    }
+    case HType::LargeBin: {
+      const int64_t* off = (const int64_t*)a->buffers[1];
+      return append_padded((const uint8_t*)a->buffers[2] + off[j], (size_t)(off[j + 1] - off[j]));
+    }
+    case HType::DecWide: {
+      // minimal big-endian two's complement (i128_to_spark_decimal_bytes :1532-1558)
+      const uint8_t* le = (const uint8_t*)a->buffers[1] + 16 * (size_t)j;
+      uint8_t be[16];
+      for (int k = 0; k < 16; k++) be[k] = le[15 - k];
+      const uint8_t sign = (be[0] & 0x80) ? 0xFF : 0x00;
+      int startb = 0;
+      while (startb < 15 && be[startb] == sign && ((be[startb + 1] & 0x80) == (sign & 0x80))) startb++;
+      return append_padded(be + startb, (size_t)(16 - startb));
+    }
+    case HType::Struct: {
+      // a nested row: null bitset | 8-byte slots | variable part; offsets relative to the struct's start (write_struct_to_buffer :1653-1730)
+      const size_t nf = t.kids.size(), bitset = ((nf + 63) / 64) * 8, start = buf.size();
+      buf.resize(start + bitset + 8 * nf, 0);
+      for (size_t f = 0; f < nf; f++) {
+        const ArrowArray* child = a->children[f];
+        if (!h_valid(child, j)) { set_null(buf, start, (int64_t)f); continue; }
+        uint64_t slot = 0;
+        if (!h_fixed_slot(t.kids[f], child, j, slot)) {
+          const size_t len = h_write_value(buf, t.kids[f], child, j);
+          if (len > 0) slot = ((uint64_t)(buf.size() - round8(len) - start) << 32) | (uint64_t)len;
+        }
+        put_u64(buf, start + bitset + 8 * f, slot);
+      }
+      return buf.size() - start;
+    }
+    case HType::List: {
+      const int32_t* off = (const int32_t*)a->buffers[1];
+      return h_write_array_range(buf, t.kids[0], a->children[0], off[j], off[j + 1] - off[j]);
+    }
+    case HType::LargeList: {
+      const int64_t* off = (const int64_t*)a->buffers[1];
+      return h_write_array_range(buf, t.kids[0], a->children[0], off[j], off[j + 1] - off[j]);
+    }
+    case HType::Map: {
+      // 8-byte size of the key array | key array | value array (write_map_to_buffer :1788-1836)
+      const int32_t* off = (const int32_t*)a->buffers[1];
+      const ArrowArray* entries = a->children[0];
+      const int64_t first = entries->offset + off[j], cnt = off[j + 1] - off[j];
+      const size_t start = buf.size();
+      buf.resize(start + 8, 0);
+      const size_t ksize = h_write_array_range(buf, t.kids[0], entries->children[0], first, cnt);
+      put_u64(buf, start, (uint64_t)ksize);
+      h_write_array_range(buf, t.kids[1], entries->children[1], first, cnt);
+      return buf.size() - start;
+    }
+    default: throw CometError("internal: fixed-width type in the variable-length writer");
+  }
+}
+
+// UnsafeArrayData of values[start, start + n): element count | null bitset | elements at their natural width (rounded up to 8) | variable
+// part, offsets relative to the array's start (write_range_to_buffer :570-616).  Primitive elements are copied whatever their validity.
+size_t h_write_array_range(std::vector<uint8_t>& buf, const HType& et, const ArrowArray* values, int64_t start, int64_t n) {
+  const size_t arr_start = buf.size(), bitset = (size_t)((n + 63) / 64) * 8;
+  size_t esize = 8;
+  switch (et.kind) {
+    case HType::Bool: case HType::I8: esize = 1; break;
+    case HType::I16: esize = 2; break;
+    case HType::I32: case HType::F32: esize = 4; break;
+    default: esize = 8; break;
+  }
+  buf.resize(arr_start + 8 + bitset + round8((size_t)n * esize), 0);
+  put_u64(buf, arr_start, (uint64_t)n);
+  const size_t bits_at = arr_start + 8, elems_at = bits_at + bitset;
+  for (int64_t k = 0; k < n; k++) {
+    const int64_t i = start + k;
+    const bool valid = h_valid(values, i);
+    if (!valid) set_null(buf, bits_at, k);
+    uint64_t slot = 0;
+    const bool primitive = et.kind == HType::I8 || et.kind == HType::I16 || et.kind == HType::I32 || et.kind == HType::I64 || et.kind == HType::F32 || et.kind == HType::F64;
+    if (primitive) {                      // bulk-copied by the reference: the slot holds the buffer's bytes even when the element is NULL
+      h_fixed_slot(et, values, i, slot);
+      memcpy(buf.data() + elems_at + (size_t)k * esize, &slot, esize);
+      continue;
+    }
+    if (!valid) continue;
+    if (h_fixed_slot(et, values, i, slot)) {
+      memcpy(buf.data() + elems_at + (size_t)k * esize, &slot, esize);
+      continue;
+    }
+    const size_t len = h_write_value(buf, et, values, i);
+    if (len > 0) slot = ((uint64_t)(buf.size() - round8(len) - arr_start) << 32) | (uint64_t)len;
+    put_u64(buf, elems_at + (size_t)k * 8, slot);
+  }
+  return buf.size() - arr_start;
+}
+
+// every row of the batch, host side; returns total bytes
+size_t host_rows(const std::vector<HType>& types, struct ArrowArray** arrays, int n_cols, int64_t n, std::vector<uint8_t>& buf, int32_t* offs, int32_t* lens) {
+  const size_t bitset = (size_t)((n_cols + 63) / 64) * 8, fixed = bitset + 8 * (size_t)n_cols;
+  buf.clear();
+  for (int64_t r = 0; r < n; r++) {
+    const size_t start = buf.size();
+    buf.resize(start + fixed, 0);
+    for (int c = 0; c < n_cols; c++) {
+      const ArrowArray* a = arrays[c];
+      if (!h_valid(a, r)) { set_null(buf, start, c); continue; }
+      uint64_t slot = 0;
+      if (!h_fixed_slot(types[(size_t)c], a, r, slot)) {
+        const size_t len = h_write_value(buf, types[(size_t)c], a, r);
+        if (len > 0) slot = ((uint64_t)(buf.size() - round8(len) - start) << 32) | (uint64_t)len;
+      }
+      put_u64(buf, start + bitset + 8 * (size_t)c, slot);
+    }
+    if (buf.size() > (size_t)INT32_MAX) throw CometError("columnarToRow: the rows of one batch exceed 2 GiB");
+    offs[r] = (int32_t)start;
+    lens[r] = (int32_t)(buf.size() - start);
+  }
+  offs[n] = (int32_t)buf.size();
+  return buf.size();
+}
+
 }  // namespace
 
 extern "C" {
@@ -121,6 +324,33 @@ int32_t comet_columnar_to_row_convert(int64_t handle, struct ArrowArray** arrays
     if (!c.stream) C2R_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     const int64_t n = num_rows;
     if (n < 0) throw CometError("columnarToRowConvert: num_rows is negative");
+    {
+      // a nested column (or a 64-bit-offset string column) anywhere: the whole batch takes the host writer
+      bool nested = false;
+      for (int i = 0; i < n_cols && !nested; i++) {
+        const std::string f = schemas[i]->format ? schemas[i]->format : "";
+        nested = !schemas[i]->dictionary && (f == "+s" || f == "+l" || f == "+L" || f == "+m" || f == "U" || f == "Z");
+      }
+      if (nested) {
+        std::vector<HType> types;
+        for (int i = 0; i < n_cols; i++) {
+          if (schemas[i]->dictionary) throw CometError("columnarToRowConvert: a dictionary-encoded column next to a nested column is not supported yet");
+          if (arrays[i]->length < n) throw CometError("columnarToRowConvert: column " + std::to_string(i) + " has fewer rows than num_rows");
+          types.push_back(htype_of(schemas[i]));
+        }
+        c.host_off.ensure((size_t)(n + 2) * 4);
+        c.host_len.ensure((size_t)std::max<int64_t>(n, 1) * 4 + 16);
+        std::vector<uint8_t> rows;
+        const size_t total = host_rows(types, arrays, n_cols, n, rows, (int32_t*)c.host_off.p, (int32_t*)c.host_len.p);
+        c.host_out.ensure(total + 16);
+        if (total) memcpy(c.host_out.p, rows.data(), total);
+        *out_buffer = (const uint8_t*)c.host_out.p;
+        *out_offsets = (const int32_t*)c.host_off.p;
+        *out_lengths = (const int32_t*)c.host_len.p;
+        release_all();
+        return 0;
+      }
+    }
     std::vector<C2RCol> cols((size_t)n_cols);
     c.col_bufs.clear();
     auto upload = [&](const void* p, size_t bytes) -> const void* {

@@ -231,6 +231,108 @@ def read_partition(data: bytes, index: bytes, partition: int) -> List[pa.RecordB
 # --------------------------------------------------------------------------- columnar → UnsafeRow (columnar_to_row.rs:949-1345)
 
 
+def _dec_bytes(unscaled: int) -> bytes:
+    nbytes = max(1, (unscaled.bit_length() + 8) // 8) if unscaled >= 0 else max(1, ((-unscaled - 1).bit_length() + 8) // 8)
+    return unscaled.to_bytes(nbytes, "big", signed=True)
+
+
+def _fixed_slot(t, arr, i):
+    """the 8-byte slot of a fixed-width value in a row / nested struct (get_field_value :1356-1400), or None for variable-length types"""
+    v = arr[i]
+    if pa.types.is_boolean(t):
+        return int(v.as_py())
+    if pa.types.is_integer(t):
+        return v.as_py() & 0xFFFFFFFFFFFFFFFF
+    if pa.types.is_date32(t) or pa.types.is_timestamp(t):
+        return v.value & 0xFFFFFFFFFFFFFFFF
+    if pa.types.is_float32(t):
+        return struct.unpack("<I", struct.pack("<f", v.as_py()))[0]
+    if pa.types.is_float64(t):
+        return struct.unpack("<Q", struct.pack("<d", v.as_py()))[0]
+    if pa.types.is_decimal(t) and t.precision <= 18:
+        return int(v.as_py().scaleb(t.scale).to_integral_exact()) & 0xFFFFFFFFFFFFFFFF
+    return None
+
+
+def _nested_value(arr, i) -> bytes:
+    """write_nested_variable_to_buffer (:1841-1900) for value i of `arr`: the unpadded bytes of a variable-length value"""
+    t = arr.type
+    v = arr[i]
+    if pa.types.is_string(t):
+        return v.as_py().encode()
+    if pa.types.is_binary(t):
+        return v.as_py()
+    if pa.types.is_decimal(t):
+        return _dec_bytes(int(v.as_py().scaleb(t.scale).to_integral_exact()))
+    if pa.types.is_struct(t):
+        # write_struct_to_buffer (:1653-1730): a nested row — null bitset | 8-byte slots | variable part, offsets relative to the struct's start
+        nf = t.num_fields
+        bitset = ((nf + 63) // 64) * 8
+        fixed, var = bytearray(bitset + 8 * nf), bytearray()
+        for f in range(nf):
+            child = arr.field(f)
+            if not child[i].is_valid:
+                fixed[f // 64 * 8 + (f % 64) // 8] |= 1 << (f % 8)
+                continue
+            slot = _fixed_slot(child.type, child, i)
+            if slot is None:
+                data = _nested_value(child, i)
+                slot = 0
+                if len(data) > 0:
+                    off = len(fixed) + len(var)
+                    var += data + b"\0" * (-len(data) % 8)
+                    slot = (off << 32) | len(data)
+            fixed[bitset + 8 * f:bitset + 8 * f + 8] = struct.pack("<Q", slot)
+        return bytes(fixed) + bytes(var)
+    if pa.types.is_list(t) or pa.types.is_large_list(t):
+        offs = arr.offsets.to_pylist()
+        return _array_range(arr.values, offs[i], offs[i + 1] - offs[i])
+    if pa.types.is_map(t):
+        # write_map_to_buffer (:1788-1836): 8-byte size of the key array | key array | value array
+        offs = arr.offsets.to_pylist()
+        keys = _array_range(arr.keys, offs[i], offs[i + 1] - offs[i])
+        vals = _array_range(arr.items, offs[i], offs[i + 1] - offs[i])
+        return struct.pack("<q", len(keys)) + keys + vals
+    raise NotImplementedError(str(t))
+
+
+def _array_range(values, start, n) -> bytes:
+    """UnsafeArrayData of values[start:start+n] (write_range_to_buffer :570-616): element count | null bitset | elements at their natural
+    width, rounded up to 8 | variable part (offsets relative to the array's start).  Primitive elements are copied in bulk — the bytes of a
+    NULL slot are whatever the Arrow buffer holds (zeros for arrays built by pyarrow) — every other type leaves a NULL slot zero."""
+    t = values.type
+    bitset = ((n + 63) // 64) * 8
+    if pa.types.is_boolean(t) or pa.types.is_int8(t):
+        esize = 1
+    elif pa.types.is_int16(t):
+        esize = 2
+    elif pa.types.is_int32(t) or pa.types.is_float32(t) or pa.types.is_date32(t):
+        esize = 4
+    else:
+        esize = 8
+    head = bytearray(struct.pack("<q", n)) + bytearray(bitset)
+    elems = bytearray(-(-n * esize // 8) * 8)
+    var = bytearray()
+    base = 8 + bitset + len(elems)
+    for k in range(n):
+        v = values[start + k]
+        if not v.is_valid:
+            head[8 + k // 8] |= 1 << (k % 8)
+            continue
+        slot = _fixed_slot(t, values, start + k)
+        if slot is None:
+            data = _nested_value(values, start + k)
+            slot = 0
+            if len(data) > 0:
+                off = base + len(var)
+                var += data + b"\0" * (-len(data) % 8)
+                slot = (off << 32) | len(data)
+            elems[k * 8:k * 8 + 8] = struct.pack("<Q", slot)
+        else:
+            elems[k * esize:(k + 1) * esize] = struct.pack("<Q", slot)[:esize]
+    return bytes(head) + bytes(elems) + bytes(var)
+
+
 def unsafe_rows(batch: pa.RecordBatch) -> List[bytes]:
     """The reference's ColumnarToRowContext::convert restated: null bitset | 8-byte slots | variable-length data padded to 8.
     Integers sign-extend into the slot, floats store their bits (f32 zero-extended), Decimal128(p ≤ 18) the unscaled long; Utf8 / Binary /
@@ -271,6 +373,8 @@ def unsafe_rows(batch: pa.RecordBatch) -> List[bytes]:
                     data = unscaled.to_bytes(nbytes, "big", signed=True)
             elif pa.types.is_string(t) or pa.types.is_binary(t):
                 data = v.as_py().encode() if pa.types.is_string(t) else v.as_py()
+            elif pa.types.is_struct(t) or pa.types.is_list(t) or pa.types.is_large_list(t) or pa.types.is_map(t):
+                data = _nested_value(arr, r)
             else:
                 raise NotImplementedError(str(t))
             if data is not None:

@@ -91,3 +91,42 @@ def test_dictionary_encoded_and_sliced_inputs(built):
         assert c.convert(plain.slice(off, length)) == SO.unsafe_rows(pa.record_batch([x.take(pa.array(range(off, off + length))) for x in plain.columns], names=plain.schema.names))
         assert c.convert(b.slice(off, length)) == SO.unsafe_rows(want_src.slice(off, length))
     c.close()
+
+
+def test_nested_types(built):
+    """struct / list / map columns (columnar_to_row.rs:570-830, 1602-1900): a nested row per struct, UnsafeArrayData per list (elements at their
+    natural width, variable-length elements behind them), key and value arrays per map — nested in each other, NULL at every level, empty
+    lists and maps, wide decimals and strings inside, next to flat columns; sliced input included.  These batches are written on the host."""
+    from oracle import shuffle_oracle as SO
+    rng = np.random.default_rng(12)
+    n = 2000
+    def maybe(p, f):
+        return None if rng.random() < p else f()
+    ints = lambda: [maybe(0.2, lambda: int(rng.integers(-2**31, 2**31))) for _ in range(int(rng.integers(0, 6)))]
+    strs = lambda: [maybe(0.2, lambda: "é" * int(rng.integers(0, 12))) for _ in range(int(rng.integers(0, 4)))]
+    point = lambda: {"x": maybe(0.1, lambda: float(rng.standard_normal())), "tag": maybe(0.2, lambda: "t%d" % int(rng.integers(0, 1000))),
+                     "amt": maybe(0.2, lambda: decimal.Decimal(int(rng.integers(-10**9, 10**9)) * 10**20).scaleb(-4)), "pts": maybe(0.2, ints)}
+    point_t = pa.struct([("x", pa.float64()), ("tag", pa.string()), ("amt", pa.decimal128(38, 4)), ("pts", pa.list_(pa.int32()))])
+    b = pa.record_batch({
+        "id": pa.array(np.arange(n, dtype=np.int64)),
+        "ints": pa.array([maybe(0.1, ints) for _ in range(n)], pa.list_(pa.int32())),
+        "strs": pa.array([maybe(0.1, strs) for _ in range(n)], pa.list_(pa.string())),
+        "bools": pa.array([maybe(0.1, lambda: [maybe(0.2, lambda: bool(rng.random() < 0.5)) for _ in range(int(rng.integers(0, 70)))]) for _ in range(n)], pa.list_(pa.bool_())),
+        "point": pa.array([maybe(0.1, point) for _ in range(n)], point_t),
+        "points": pa.array([maybe(0.1, lambda: [maybe(0.2, point) for _ in range(int(rng.integers(0, 3)))]) for _ in range(n)], pa.list_(point_t)),
+        "m": pa.array([maybe(0.1, lambda: [("k%d" % j, maybe(0.2, lambda: int(rng.integers(0, 10**12)))) for j in range(int(rng.integers(0, 4)))]) for _ in range(n)],
+                      pa.map_(pa.string(), pa.int64())),
+        "mm": pa.array([maybe(0.2, lambda: [(int(j), [("a", 1.5), ("b", None)][: int(rng.integers(0, 3))]) for j in range(int(rng.integers(0, 3)))]) for _ in range(n)],
+                       pa.map_(pa.int32(), pa.map_(pa.string(), pa.float64()))),
+        "ll": pa.array([maybe(0.1, lambda: [maybe(0.2, ints) for _ in range(int(rng.integers(0, 3)))]) for _ in range(n)], pa.list_(pa.list_(pa.int32()))),
+        "dec": pa.array([maybe(0.1, lambda: [decimal.Decimal(int(rng.integers(-10**10, 10**10))).scaleb(-2)]) for _ in range(n)], pa.list_(pa.decimal128(12, 2))),
+        "s": pa.array(["row %d" % i for i in range(n)], pa.string()),
+    })
+    c = native.ColumnarToRow()
+    got, want = c.convert(b), SO.unsafe_rows(b)
+    assert len(got) == n
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, f"row {i}"
+    sl = b.slice(777, 1000)
+    assert c.convert(sl) == SO.unsafe_rows(pa.record_batch([x.take(pa.array(range(777, 1777))) for x in b.columns], names=b.schema.names))
+    c.close()
