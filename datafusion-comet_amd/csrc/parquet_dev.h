@@ -24,7 +24,7 @@ typedef struct PqPage {        /* one data page of a column (all selected row gr
    * OUTPUT, which are the page's rows lvl_skip … — the page's first lvl_skip levels and first val_skip (non-NULL) values are passed over */
   int32_t lvl_skip;
   int32_t val_skip;
-  int32_t pad1;
+  int32_t value_count;         /* non-NULL values of the page (= num_values for a page without NULLs): what its runs / PLAIN bytes hold */
 } PqPage;
 
 typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section */
@@ -73,6 +73,7 @@ typedef struct PqDecodeArgs {
   uint32_t* lengths_out;       /* strings: per-row byte length */
   const int32_t* str_offsets;  /* strings (copy phase): output offsets at the chunk's row offset */
   uint8_t* str_bytes_out;      /* strings (copy phase): output data buffer */
+  void* dense_out;             /* run-at-a-time kernel on a column with NULLs: values go here densely (value ordinal), expanded to rows afterwards */
 } PqDecodeArgs;
 
 #endif

@@ -339,16 +339,18 @@ __device__ __forceinline__ i128 pq_cv(int kind, const u8* src, int width, int de
 #define PQ_LDS __attribute__((address_space(3)))
 constexpr int kUnitLdsBytes = 2048;        // a wave's LDS slice for one unit's packed indices (504 values × 32 bits = 2016 bytes)
 template <int OW, int CV>
-__device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, const PqRun& rn, const PqPage& pg, int lane, PQ_LDS u32* lds) {
+__device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out, const PqRun& rn, const PqPage& pg, int lane, PQ_LDS u32* lds) {
   const u8* __restrict__ bytes = a.bytes;
   const u8* __restrict__ dict = a.dict + pg.dict_off;
+  // where value 0 of the page goes: its first row — or, for a column with NULLs, its ordinal among the column's non-NULL values (the
+  // caller put that in pg.row_start and passes the dense buffer as `out`)
   const i64 row0 = pg.row_start + rn.value_start;
   i32 count = rn.count;
-  if (rn.value_start + count > pg.num_values) count = pg.num_values - rn.value_start;   // the last bit-packed group of a page is padded to 8 values
+  if (rn.value_start + count > pg.value_count) count = pg.value_count - rn.value_start;   // the last bit-packed group of a page is padded to 8 values
   const int kind = pg.kind, width = pg.width, dec_up = pg.dec_scale_up;
   if (rn.is_rle == 1) {
     const i128 v = pq_cv<CV>(kind, dict + (i64)rn.rle_value * width, width, dec_up);
-    for (i32 j = lane; j < count; j += 64) pq_store<OW>(a.values_out, row0 + j, v);
+    for (i32 j = lane; j < count; j += 64) pq_store<OW>(out, row0 + j, v);
     return;
   }
   constexpr int U = 4;     // values per lane per pass: 4 keeps the kernel at 68 VGPRs (7 waves per SIMD); 8 needs 103 (4 waves) and measured slower
@@ -366,7 +368,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, const PqRu
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const i32 j = base + u * 64 + lane;
-        if (j < count) pq_store<OW>(a.values_out, row0 + j, v[u]);
+        if (j < count) pq_store<OW>(out, row0 + j, v[u]);
       }
     }
     return;
@@ -405,7 +407,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, const PqRu
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const i32 j = base + u * 64 + lane;
-        if (j < count) pq_store<OW>(a.values_out, row0 + j, v[u]);
+        if (j < count) pq_store<OW>(out, row0 + j, v[u]);
       }
     }
     __builtin_amdgcn_wave_barrier();      // the slice is overwritten by the wave's next unit
@@ -427,7 +429,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, const PqRu
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const i32 j = base + u * 64 + lane;
-      if (j < count) pq_store<OW>(a.values_out, row0 + j, v[u]);
+      if (j < count) pq_store<OW>(out, row0 + j, v[u]);
     }
   }
 }
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(256) void pq_decode_runs_kernel(PqDecodeArgs a) {
   if (begin >= end) return;
   int cur_page = -1;
   PqPage pg;
+  void* out = a.dense_out ? a.dense_out : a.values_out;
   PqRun next = pq_load_run_uniform(a.idx_runs + begin);
   for (i64 r = begin; r < end; r++) {
     const PqRun rn = next;
@@ -464,8 +467,9 @@ __global__ __launch_bounds__(256) void pq_decode_runs_kernel(PqDecodeArgs a) {
     if (rn.page != cur_page) {
       const PqPage* pp = a.pages + rn.page;
       pg.row_start = pq_uniform_i64(pp->row_start);
+      if (a.dense_out) pg.row_start = (i64)(u32)__builtin_amdgcn_readfirstlane((int)a.vidx[pg.row_start]);   // non-NULL values before the page
       pg.dict_off = pq_uniform_i64(pp->dict_off);
-      pg.num_values = __builtin_amdgcn_readfirstlane(pp->num_values);
+      pg.value_count = __builtin_amdgcn_readfirstlane(pp->value_count);
       pg.bit_width = __builtin_amdgcn_readfirstlane(pp->bit_width);
       pg.kind = __builtin_amdgcn_readfirstlane(pp->kind);
       pg.width = __builtin_amdgcn_readfirstlane(pp->width);
@@ -474,18 +478,33 @@ __global__ __launch_bounds__(256) void pq_decode_runs_kernel(PqDecodeArgs a) {
     }
     // the conversion class is wave-uniform: one branch per unit, straight-line code inside
     const int cv = pg.kind == PQ_COPY4 ? 1 : pg.kind == PQ_COPY8 ? 2 : (pg.kind == PQ_I64_TO_DEC && pg.dec_scale_up == 0) ? 3 : (pg.kind == PQ_I32_TO_DEC && pg.dec_scale_up == 0) ? 4 : 0;
-    if (cv == 1 && a.out_width == 4) pq_decode_unit<4, 1>(a, rn, pg, lane, lds);
-    else if (cv == 2 && a.out_width == 8) pq_decode_unit<8, 2>(a, rn, pg, lane, lds);
-    else if (cv == 3 && a.out_width == 16) pq_decode_unit<16, 3>(a, rn, pg, lane, lds);
-    else if (cv == 4 && a.out_width == 16) pq_decode_unit<16, 4>(a, rn, pg, lane, lds);
+    if (cv == 1 && a.out_width == 4) pq_decode_unit<4, 1>(a, out, rn, pg, lane, lds);
+    else if (cv == 2 && a.out_width == 8) pq_decode_unit<8, 2>(a, out, rn, pg, lane, lds);
+    else if (cv == 3 && a.out_width == 16) pq_decode_unit<16, 3>(a, out, rn, pg, lane, lds);
+    else if (cv == 4 && a.out_width == 16) pq_decode_unit<16, 4>(a, out, rn, pg, lane, lds);
     else
       switch (a.out_width) {
-        case 1: pq_decode_unit<1, 0>(a, rn, pg, lane, lds); break;
-        case 2: pq_decode_unit<2, 0>(a, rn, pg, lane, lds); break;
-        case 4: pq_decode_unit<4, 0>(a, rn, pg, lane, lds); break;
-        case 8: pq_decode_unit<8, 0>(a, rn, pg, lane, lds); break;
-        default: pq_decode_unit<16, 0>(a, rn, pg, lane, lds); break;
+        case 1: pq_decode_unit<1, 0>(a, out, rn, pg, lane, lds); break;
+        case 2: pq_decode_unit<2, 0>(a, out, rn, pg, lane, lds); break;
+        case 4: pq_decode_unit<4, 0>(a, out, rn, pg, lane, lds); break;
+        case 8: pq_decode_unit<8, 0>(a, out, rn, pg, lane, lds); break;
+        default: pq_decode_unit<16, 0>(a, out, rn, pg, lane, lds); break;
       }
+  }
+}
+
+// a column with NULLs decoded run by run: the values sit densely in dense_out by their ordinal; row r takes value vidx[r] if it is valid
+__global__ __launch_bounds__(256) void pq_expand_nulls_kernel(PqDecodeArgs a) {
+  for (i64 row = (i64)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (i64)gridDim.x * 256) {
+    const bool ok = a.valid_out[row] != 0;
+    const i64 v = a.vidx[row];
+    switch (a.out_width) {
+      case 1: ((u8*)a.values_out)[row] = ok ? ((const u8*)a.dense_out)[v] : (u8)0; break;
+      case 2: ((u16*)a.values_out)[row] = ok ? ((const u16*)a.dense_out)[v] : (u16)0; break;
+      case 4: ((u32*)a.values_out)[row] = ok ? ((const u32*)a.dense_out)[v] : 0u; break;
+      case 8: ((u64*)a.values_out)[row] = ok ? ((const u64*)a.dense_out)[v] : 0ull; break;
+      default: ((i128*)a.values_out)[row] = ok ? ((const i128*)a.dense_out)[v] : (i128)0; break;
+    }
   }
 }
 
@@ -605,6 +624,7 @@ void pq_launch_decode_runs(const PqDecodeArgs* a, void* st) {
   const int blocks = (int)std::min<i64>(((i64)a->n_idx_runs + 3) / 4, 256 * 16);
   hipLaunchKernelGGL(pq_decode_runs_kernel, blocks, 256, 0, (hipStream_t)st, *a);
 }
+void pq_launch_expand_nulls(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_expand_nulls_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }
 void pq_launch_decode_fixed(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_decode_fixed_kernel, grid_slices(a->n_rows), 256, 0, (hipStream_t)st, *a); }
 void pq_launch_string_lengths(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_string_lengths_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }
 void pq_launch_string_copy(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_string_copy_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }

@@ -33,6 +33,7 @@ void pq_launch_validity(const PqDecodeArgs* a, void* st);
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st);
 void pq_launch_decode_fixed(const PqDecodeArgs* a, void* st);
 void pq_launch_decode_runs(const PqDecodeArgs* a, void* st);
+void pq_launch_expand_nulls(const PqDecodeArgs* a, void* st);
 void pq_launch_string_lengths(const PqDecodeArgs* a, void* st);
 void pq_launch_string_copy(const PqDecodeArgs* a, void* st);
 void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
@@ -725,9 +726,27 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   int64_t out_pos = 0;          // kept rows emitted so far (the chunk's output rows)
   size_t keep_i = 0;            // first kept range that may still overlap the next page
   std::vector<uint8_t> tmp;
+  // a PLAIN page's values cut into chunks of 4096: the units the run-at-a-time decode kernel hands to its waves
+  constexpr int32_t kPlainChunk = 4096;
+  auto plain_chunks = [&](PqPage& pg, int64_t values_off_flagged) {
+    if (cp.is_string) return;
+    pg.idx_run_first = (int32_t)idx_runs.size();
+    const int64_t unit_bits = cp.kind == PQ_BOOL ? 1 : (int64_t)cp.src_width * 8;
+    for (int32_t v = 0; v < pg.value_count; v += kPlainChunk) {
+      PqRun r;
+      memset(&r, 0, sizeof r);
+      r.is_rle = 2;
+      r.value_start = v;
+      r.count = std::min(kPlainChunk, pg.value_count - v);
+      r.byte_off = values_off_flagged + ((int64_t)v * unit_bits) / 8;
+      idx_runs.push_back(r);
+    }
+    pg.idx_run_count = (int32_t)idx_runs.size() - pg.idx_run_first;
+  };
   // the kept pieces of the page [r0, r1): one PqPage entry each, passing over the page's first levels / non-NULL values
   // (`levels`: the bytes the page's definition-level runs refer to, addressed like the runs' byte_off without its region flag)
-  auto emit = [&](const PqPage& pg, int64_t r0, int64_t r1, const uint8_t* levels) {
+  auto emit = [&](const PqPage& pg_in, int64_t r0, int64_t r1, const uint8_t* levels) {
+    PqPage pg = pg_in;
     auto non_null_before = [&](int64_t upto) -> int64_t {      // values among the page's first `upto` levels
       if (max_def == 0 || pg.def_run_count == 0) return upto;
       int64_t cnt = 0;
@@ -744,6 +763,9 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       }
       return cnt;
     };
+    // what the page's runs / PLAIN bytes hold: its non-NULL values; a PLAIN page's values are cut into the run-at-a-time kernel's chunks
+    pg.value_count = (int32_t)non_null_before(pg.num_values);
+    if (pg.encoding == 0) plain_chunks(pg, pg.values_off);
     if (!src.keep) {
       PqPage q = pg;
       q.row_start = out_pos;
@@ -770,23 +792,6 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     const Ranges& keep = *src.keep;
     while (keep_i < keep.size() && keep[keep_i].second <= r0) keep_i++;
     return keep_i < keep.size() && keep[keep_i].first < r1;
-  };
-  // a PLAIN page's values cut into chunks of 4096: the units the run-at-a-time decode kernel hands to its waves
-  constexpr int32_t kPlainChunk = 4096;
-  auto plain_chunks = [&](PqPage& pg, int64_t values_off_flagged) {
-    if (cp.is_string) return;
-    pg.idx_run_first = (int32_t)idx_runs.size();
-    const int64_t unit_bits = cp.kind == PQ_BOOL ? 1 : (int64_t)cp.src_width * 8;
-    for (int32_t v = 0; v < pg.num_values; v += kPlainChunk) {
-      PqRun r;
-      memset(&r, 0, sizeof r);
-      r.is_rle = 2;
-      r.value_start = v;
-      r.count = std::min(kPlainChunk, pg.num_values - v);
-      r.byte_off = values_off_flagged + ((int64_t)v * unit_bits) / 8;
-      idx_runs.push_back(r);
-    }
-    pg.idx_run_count = (int32_t)idx_runs.size() - pg.idx_run_first;
   };
   while (values_seen < cm.num_values && off < chunk_end) {
     pq::PageHeader h = pq::parse_page_header(chunk_data + off, (size_t)(chunk_end - off));
@@ -883,8 +888,9 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       hc.ipos = ipage + un_len;
       pg.encoding = 0;
       pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
-      plain_chunks(pg, pg.values_off);
-      emit(pg, values_seen, values_seen + h.num_values, tmp.data() - ipage);
+      // the level bytes the runs refer to: a v1 page's were decoded into `tmp` (addressed in the coordinates of the decompressed region), a v2
+      // page's were copied into the staged region
+      emit(pg, values_seen, values_seen + h.num_values, h.type == pq::DATA_PAGE ? tmp.data() - ipage : staged);
       values_seen += h.num_values;
       continue;
     }
@@ -920,7 +926,6 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     if (h.encoding == pq::PLAIN) {
       pg.encoding = 0;
       pg.values_off = (int64_t)vals_begin;
-      plain_chunks(pg, pg.values_off);
       if (cp.is_string) {
         pg.str_first = (int64_t)str_offs.size();
         size_t p = vals_begin;
@@ -1012,6 +1017,7 @@ void synth_chunk(const StructField& want, const Expr* dflt, int64_t rows, HostCh
   PqPage pg;
   memset(&pg, 0, sizeof pg);
   pg.num_values = (int32_t)rows;
+  pg.value_count = is_null ? 0 : (int32_t)rows;
   if (is_null) {
     PqRun r;
     memset(&r, 0, sizeof r);
@@ -1460,8 +1466,23 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       // a column without NULLs (and without pruned pages) is decoded a RUN at a time: a wave takes one bit-packed run / RLE run / chunk of
       // a PLAIN page and every lane decodes 8 of its values with all loads in flight at once; otherwise row by row
       static const bool force_rows = getenv("COMET_PQ_DECODE_ROWS") != nullptr;
-      if (!any_optional && runs_kernel_ok && !force_rows) pq_launch_decode_runs(&a, stream_);
-      else pq_launch_decode_fixed(&a, stream_);
+      if (runs_kernel_ok && !force_rows) {
+        if (any_optional) {
+          // with NULLs a page's runs hold fewer values than it has rows: the values are decoded densely by their ordinal among the
+          // column's non-NULL values (vidx of the page's first row + index in the page), then spread to their rows
+          auto dense = std::make_shared<DevBuf>();
+          dense->ensure((size_t)total_rows * cp.out_width + 16);
+          a.dense_out = dense->p;
+          pq_launch_decode_runs(&a, stream_);
+          pq_launch_expand_nulls(&a, stream_);
+          a.dense_out = nullptr;
+          out.owners.push_back(dense);
+        } else {
+          pq_launch_decode_runs(&a, stream_);
+        }
+      } else {
+        pq_launch_decode_fixed(&a, stream_);
+      }
     } else {
       lengths->ensure((size_t)total_rows * 4 + 16);
       a.lengths_out = (uint32_t*)lengths->p;
