@@ -164,11 +164,21 @@ def main():
             if not args.no_paths:
                 legs["paths"] = run_child_leg([os.path.join(ROOT, "tools", "paths.py"), "--query", "q1", "--rows", str(args.path_rows)],
                                               rank, local_rank, world, args.leg_timeout, 3017)
+        # multi-GPU legs: the in-library exchange (RCCL send / recv groups inside libcomet.so) is probed first with a short timeout; if the
+        # probe fails or hangs the legs run over torch.distributed's all_to_all instead, and say so — a leg must never stall the line
+        exchange = "native"
+        if world > 1 and (args.q3_orders > 0 or args.q95_orders > 0):
+            probe = run_child_leg([os.path.join(ROOT, "tools", "exchange_probe.py")], rank, local_rank, world, 90, 917)
+            ok_t = torch.tensor([1 if (rank != 0 or (probe is not None and probe.get("ok"))) else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            if not bool(ok_t.item()):
+                exchange = "torch"
+            legs["exchange_probe"] = probe
         if args.q3_orders > 0:
-            legs["q3"] = run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1"],
+            legs["q3"] = run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1", "--exchange", exchange],
                                        rank, local_rank, world, args.leg_timeout, 1017)
         if args.q95_orders > 0:
-            legs["q95"] = run_child_leg([os.path.join(ROOT, "tools", "q95_dist.py"), "--orders", str(args.q95_orders), "--steps", "2", "--warmup", "1", "--no-verify"],
+            legs["q95"] = run_child_leg([os.path.join(ROOT, "tools", "q95_dist.py"), "--orders", str(args.q95_orders), "--steps", "2", "--warmup", "1", "--no-verify", "--exchange", exchange],
                                         rank, local_rank, world, args.leg_timeout, 1517)
 
     if rank == 0:
@@ -228,6 +238,8 @@ def main():
             line["q3"] = legs["q3"]
         if legs.get("q95") is not None:
             line["q95"] = legs["q95"]
+        if legs.get("exchange_probe") is not None:
+            line["exchange_probe"] = legs["exchange_probe"]
         if pmc:
             line["pmc"] = pmc
         print(json.dumps(line))
