@@ -1,0 +1,242 @@
+// Hash joins of materialised tables (build, single-pass probe, outer-build tail).
+#include "exec_internal.hpp"
+
+namespace comet {
+// Join keys that are Utf8 columns with values longer than the 15 bytes of a packed key: an exact string dictionary is built over the
+// right column (strdict_kernels.hip), the left column is looked up in it, and the join runs on the two Int64 row-index columns
+// instead (a left string without a partner gets a NULL index: NULL keys never match, outer joins still emit the row).  The index
+// columns are appended to the inputs and dropped from the result.
+DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const DevTable& R) {
+  auto is_str = [](const DType& t) { return t.id == TypeId::String || t.id == TypeId::Bytes; };
+  std::vector<size_t> sk;
+  for (size_t k = 0; k < j.left_keys.size() && k < j.right_keys.size(); k++) {
+    const ExprP &a = j.left_keys[k], &b = j.right_keys[k];
+    if (a->kind == ExprKind::Bound && b->kind == ExprKind::Bound && a->bound_index >= 0 && b->bound_index >= 0 && (size_t)a->bound_index < L.types.size() &&
+        (size_t)b->bound_index < R.types.size() && is_str(L.types[(size_t)a->bound_index]) && is_str(R.types[(size_t)b->bound_index]) &&
+        L.cols[(size_t)a->bound_index].offset == 0 && R.cols[(size_t)b->bound_index].offset == 0)
+      sk.push_back(k);
+  }
+  if (sk.empty() || L.rows == 0 || R.rows == 0 || L.cols.size() + R.cols.size() + 2 * sk.size() > COMET_MAX_IN) return hash_join_impl(j, j, L, R, "");
+  auto longest = [&](const DevTable& t, int c) {
+    uint32_t* mx = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 1);
+    HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
+    if (comet_launch_str_max_len((const int32_t*)t.cols[(size_t)c].data, t.rows, mx, stream_) != 0) throw CometError("string keys: launch failed");
+    uint32_t v = 0;
+    read_small(&v, mx, 4);
+    HIP_CHECK(hipMemsetAsync(mx, 0, 4, stream_));
+    return v;
+  };
+  bool need = false;
+  for (size_t k : sk) need = need || longest(L, j.left_keys[k]->bound_index) > 15 || longest(R, j.right_keys[k]->bound_index) > 15;
+  if (!need) return hash_join_impl(j, j, L, R, "");
+  if (R.rows >= ((int64_t)1 << 32) - 1) throw CometError("Utf8 join keys longer than 15 bytes over more than 2^32 rows are not supported");
+  DevTable l2 = L, r2 = R;
+  Operator jj = j;
+  auto bound = [](int idx) {
+    auto e = std::make_shared<Expr>();
+    e->kind = ExprKind::Bound;
+    e->proto_tag = 3;
+    e->bound_index = idx;
+    e->dtype = DType::of(TypeId::Int64);
+    e->has_dtype = true;
+    return e;
+  };
+  for (size_t k : sk) {
+    const int lc = j.left_keys[k]->bound_index, rc = j.right_keys[k]->bound_index;
+    const DeviceColumnView &lv = L.cols[(size_t)lc], &rv = R.cols[(size_t)rc];
+    int64_t slots = 1024;
+    while (slots < 2 * R.rows) slots <<= 1;
+    DevBuf table;
+    table.ensure((size_t)slots * 4);
+    HIP_CHECK(hipMemsetAsync(table.p, 0, (size_t)slots * 4, stream_));
+    auto rrep = std::make_shared<DevBuf>(), lrep = std::make_shared<DevBuf>(), lbits = std::make_shared<DevBuf>();
+    DevBuf lok;
+    rrep->ensure((size_t)R.rows * 8 + 16);
+    lrep->ensure((size_t)L.rows * 8 + 16);
+    lok.ensure((size_t)L.rows + 16);
+    lbits->ensure((size_t)((L.rows + 7) / 8) + 16);
+    if (comet_launch_str_dict_build((const int32_t*)rv.data, (const uint8_t*)rv.aux, R.has_valid[(size_t)rc] ? rv.valid : nullptr, R.rows, (uint32_t*)table.p, slots,
+                                    (int64_t*)rrep->p, stream_) != 0 ||
+        comet_launch_str_dict_lookup((const int32_t*)rv.data, (const uint8_t*)rv.aux, (const uint32_t*)table.p, slots, (const int32_t*)lv.data, (const uint8_t*)lv.aux,
+                                     L.has_valid[(size_t)lc] ? lv.valid : nullptr, L.rows, (int64_t*)lrep->p, (uint8_t*)lok.p, stream_) != 0)
+      throw CometError("string keys: launch failed");
+    pq_launch_pack((const uint8_t*)lok.p, (uint8_t*)lbits->p, L.rows, stream_);
+    HIP_CHECK(hipStreamSynchronize(stream_));   // `table` and `lok` go back to the pool
+    DeviceColumnView rid, lid;
+    rid.data = rrep->p;
+    rid.valid = rv.valid;
+    lid.data = lrep->p;
+    lid.valid = (const uint8_t*)lbits->p;
+    jj.right_keys[k] = bound((int)r2.cols.size());
+    jj.left_keys[k] = bound((int)l2.cols.size());
+    r2.types.push_back(DType::of(TypeId::Int64));
+    r2.cols.push_back(rid);
+    r2.has_valid.push_back(R.has_valid[(size_t)rc]);
+    r2.owners.push_back(rrep);
+    l2.types.push_back(DType::of(TypeId::Int64));
+    l2.cols.push_back(lid);
+    l2.has_valid.push_back(true);
+    l2.owners.push_back(lrep);
+    l2.owners.push_back(lbits);
+  }
+  const size_t nl = L.cols.size(), nr = R.cols.size(), extra = sk.size();
+  if (jj.join_condition) {
+    // the residual condition addresses left ++ right: the right columns moved up by the index columns appended to the left
+    std::function<ExprP(const ExprP&)> shift = [&](const ExprP& e) -> ExprP {
+      auto c = std::make_shared<Expr>(*e);
+      if (e->kind == ExprKind::Bound && (size_t)e->bound_index >= nl) c->bound_index = e->bound_index + (int)extra;
+      for (auto& ch : c->children) ch = shift(ch);
+      return c;
+    };
+    jj.join_condition = shift(j.join_condition);
+  }
+  DevTable out = hash_join_impl(j, jj, l2, r2, ":SD");
+  // drop the index columns: the result is left' ++ right' (semi / anti joins: left' only)
+  auto drop = [&](size_t first, size_t count) {
+    if (first + count > out.cols.size()) return;
+    out.types.erase(out.types.begin() + (long)first, out.types.begin() + (long)(first + count));
+    out.cols.erase(out.cols.begin() + (long)first, out.cols.begin() + (long)(first + count));
+    out.has_valid.erase(out.has_valid.begin() + (long)first, out.has_valid.begin() + (long)(first + count));
+  };
+  if (out.cols.size() == nl + extra + nr + extra) drop(nl + extra + nr, extra);
+  else if (out.cols.size() != nl + extra) throw CometError("internal: unexpected join output width with string keys");
+  drop(nl, extra);
+  return out;
+}
+
+DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& j, const DevTable& L, const DevTable& R, const std::string& key_suffix) {
+  // planned once per (join node, validity patterns)
+  std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&node] + 1))) + ":J:" + validity_key(L.has_valid) + "|" +
+                    validity_key(R.has_valid) + key_suffix;
+  std::shared_ptr<PlannedVariant> pv;
+  {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    if (it != g_plan_cache.end()) pv = it->second;
+  }
+  if (!pv) {
+    pv = std::make_shared<PlannedVariant>();
+    pv->desc = generate_join(j, L.types, R.types, L.has_valid, R.has_valid);
+    pv->code = jit_compile(pv->desc.source);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plan_cache[key] = pv;
+  }
+  Variant v;
+  v.desc = pv->desc;
+  v.mod = jit_load(pv->code);
+  const PipelineDesc& d = v.desc;
+  const bool build_left = j.build_side == BuildSide::Left;
+  const DevTable& B = build_left ? L : R;
+  const DevTable& P = build_left ? R : L;
+  if (B.rows >= ((int64_t)1 << 31)) throw CometError("hash join build side exceeds 2^31 rows");
+  const size_t nb = B.cols.size(), np = P.cols.size();
+  CometKParams prm;
+  memset(&prm, 0, sizeof prm);
+  for (size_t i = 0; i < nb; i++) {
+    prm.in[i].data = B.cols[i].data;
+    prm.in[i].valid = B.has_valid[i] ? B.cols[i].valid : nullptr;
+    prm.in[i].aux = B.cols[i].aux;
+    prm.in[i].offset = B.cols[i].offset;
+  }
+  for (size_t i = 0; i < np; i++) {
+    prm.in[nb + i].data = P.cols[i].data;
+    prm.in[nb + i].valid = P.has_valid[i] ? P.cols[i].valid : nullptr;
+    prm.in[nb + i].aux = P.cols[i].aux;
+    prm.in[nb + i].offset = P.cols[i].offset;
+  }
+  int64_t cap = 1024;
+  while (cap < 2 * B.rows) cap <<= 1;
+  const int64_t n = P.rows;
+  DevBuf head, next, matched, btiles;
+  head.ensure((size_t)cap * 4);
+  next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4);
+  HIP_CHECK(hipMemsetAsync(head.p, 0xff, (size_t)cap * 4, stream_));
+  const bool outer_build = d.join_outer_build;
+  const int64_t nbtiles = (B.rows + 1023) / 1024;
+  if (outer_build) {
+    matched.ensure((size_t)std::max<int64_t>(B.rows, 1));
+    btiles.ensure((size_t)(nbtiles + 1) * 8);
+    HIP_CHECK(hipMemsetAsync(matched.p, 0, (size_t)std::max<int64_t>(B.rows, 1), stream_));
+    prm.out[45] = matched.p;
+    prm.out[46] = btiles.p;
+    prm.iarg[3] = nbtiles;
+  }
+  prm.n = n;
+  prm.iarg[0] = cap;
+  prm.iarg[1] = B.rows;
+  prm.out[0] = head.p;
+  prm.out[1] = next.p;
+  prm.out[kOutErr] = err_flags_.p;
+  timed_begin();
+  int64_t out_rows = 0, tail_rows = 0;
+  const size_t ncol = d.out_cols.size();
+  std::vector<std::shared_ptr<DevBuf>> vals(ncol), vbytes(ncol);
+  auto bind_outputs = [&](int64_t rows_cap) {
+    for (size_t c = 0; c < ncol; c++) {
+      if (!vals[c]) vals[c] = std::make_shared<DevBuf>();
+      vals[c]->ensure((size_t)std::max<int64_t>(rows_cap, 1) * out_width(d.out_cols[c]) + 16);
+      prm.out[kOutFirstCol + 2 * c] = vals[c]->p;
+      if (!vbytes[c]) vbytes[c] = std::make_shared<DevBuf>();
+      if (d.out_cols[c].nullable) {
+        vbytes[c]->ensure((size_t)std::max<int64_t>(rows_cap, 1) + 16);
+        prm.out[kOutFirstCol + 2 * c + 1] = vbytes[c]->p;
+      }
+    }
+  };
+  // ---- single-pass probe (comet_device.hpp template D'): a small build side is hashed into LDS by every block, a large one into the
+  // chained global table; either way the probe counts and emits in one launch, reserving output ranges with one atomic per tile ----
+  const bool use_lds = B.rows > 0 && B.rows <= 6144 && getenv("COMET_JOIN_GLOBAL_TABLE") == nullptr;
+  if (!use_lds && B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+  DevBuf emitted_buf;
+  emitted_buf.ensure(64);
+  prm.out[47] = emitted_buf.p;
+  // FK-shaped joins emit at most one row per probe row; anything beyond the capacity is counted, not written, and the probe re-run
+  int64_t out_cap = d.join_build_only ? 1 : n + 1024;
+  for (int attempt = 0; n > 0; attempt++) {
+    bind_outputs(out_cap);
+    prm.iarg[6] = out_cap;
+    HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 8, stream_));
+    const int64_t ptiles = (n + 2047) / 2048;
+    launch(v, use_lds ? "k_jlds" : "k_jprobe", (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
+    uint64_t emitted = 0;
+    read_small(&emitted, emitted_buf.p, 8);
+    out_rows = d.join_build_only ? 0 : (int64_t)emitted;
+    if (out_rows <= out_cap) break;
+    if (attempt == 1) throw CometError("internal: hash join output exceeded its exact size");
+    out_cap = out_rows;
+  }
+  const int64_t probe_capacity = n > 0 ? out_cap : 0;
+  if (outer_build && B.rows > 0) {
+    // build rows without a match follow the probe-driven rows
+    launch(v, "k_jbcount", (int)std::min<int64_t>(nbtiles, 256 * 8), prm);
+    launch(v, "k_jbscan", 1, prm);
+    uint64_t total = 0;
+    read_small(&total, (char*)btiles.p + (size_t)nbtiles * 8, 8);
+    tail_rows = (int64_t)total;
+    prm.iarg[4] = out_rows;
+  }
+  const int64_t all_rows = out_rows + tail_rows;
+  if (all_rows > probe_capacity || (ncol > 0 && !vals[0])) {
+    // the unmatched build rows follow the probe-driven rows: grow the output buffers, keeping what the probe wrote
+    std::vector<std::shared_ptr<DevBuf>> ov = vals, ob = vbytes;
+    for (size_t c = 0; c < ncol; c++) { vals[c].reset(); vbytes[c].reset(); }
+    bind_outputs(all_rows);
+    for (size_t c = 0; c < ncol && out_rows > 0; c++) {
+      HIP_CHECK(hipMemcpyAsync(vals[c]->p, ov[c]->p, (size_t)out_rows * out_width(d.out_cols[c]), hipMemcpyDeviceToDevice, stream_));
+      if (d.out_cols[c].nullable) HIP_CHECK(hipMemcpyAsync(vbytes[c]->p, ob[c]->p, (size_t)out_rows, hipMemcpyDeviceToDevice, stream_));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));   // the old buffers return to the pool
+  }
+  if (tail_rows > 0) launch(v, "k_jbemit", (int)std::min<int64_t>(nbtiles, 256 * 8), prm);
+  timed_end();
+  out_rows = all_rows;
+  const int nleft = (int)L.cols.size();
+  DevTable out = outputs_to_table(v, vals, vbytes, out_rows, [&](int c) { return c < nleft ? std::make_pair(&L, c) : std::make_pair(&R, c - nleft); });
+  HIP_CHECK(hipStreamSynchronize(stream_));  // head/next/counts go back to the pool when this frame ends
+  out.owners.push_back(v.mod);
+  join_build_rows_ += B.rows;
+  join_probe_rows_ += P.rows;
+  return out;
+}
+
+}  // namespace comet
