@@ -376,6 +376,22 @@ int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size
   });
 }
 
+int64_t comet_parquet_prune_report(const uint8_t* plan, size_t plan_len, int32_t page_index, char* out, size_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    OperatorP op = decode_operator(plan, plan_len);
+    const Operator* scan = op.get();
+    while (scan && scan->kind != OpKind::NativeScan) scan = scan->children.empty() ? nullptr : scan->children[0].get();
+    if (!scan) throw CometError("comet_parquet_prune_report: the plan holds no NativeScan");
+    const std::string j = parquet_prune_report(*scan, page_index != 0);
+    if (out && cap) {
+      const size_t n = std::min(cap - 1, j.size());
+      memcpy(out, j.data(), n);
+      out[n] = 0;
+    }
+    return (int64_t)j.size();
+  });
+}
+
 int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t value_len) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     const RegexDfa d = compile_rlike(pattern ? pattern : "");

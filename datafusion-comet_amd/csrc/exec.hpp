@@ -129,6 +129,8 @@ struct Variant {  // one JIT specialisation of the pipeline (per input-validity 
 
 // parquet_scan.cpp: run fn(0..n-1) on the process-wide scan threads and wait
 void scan_pool_parallel(size_t n, const std::function<void(size_t)>& fn);
+// row-group / page-index selection of a NativeScan as JSON (parquet_scan.cpp; host only)
+std::string parquet_prune_report(const Operator& native_scan, bool page_index);
 // queue one task on the same threads (FIFO) without waiting
 void scan_pool_submit(std::function<void()> fn);
 

@@ -1091,7 +1091,82 @@ void synth_chunk(const StructField& want, const Expr* dflt, int64_t rows, HostCh
   hc.str_offs.push_back(0);   // sentinel
 }
 
+// One selected row group of a scan: its file, its place in the output, and the rows the page index could not rule out (null: all of them)
+struct Sel {
+  std::shared_ptr<OpenFile> file;
+  std::shared_ptr<pq::FileMeta> meta;
+  int rg;
+  int64_t row_off;
+  const PartitionedFile* pf;
+  int64_t rows;
+  std::shared_ptr<Ranges> keep;
+};
+// Which row groups does this partition's scan read (the byte-range midpoint rule of the Parquet readers), which of them survive the
+// pushed-down filters' min / max statistics, and — with a page index (ColumnIndex / OffsetIndex; parquet_exec.rs turns on DataFusion's
+// page-index pruning) — which ROWS of the survivors can the filters still be true for.  Pages outside those rows are neither decompressed
+// nor uploaded and the scan emits only the kept rows; the Filter above re-checks every row it gets, as it does after row-group pruning.
+void select_row_groups(const Operator& op, bool page_index, std::vector<Sel>& sels, int64_t& total_rows, int64_t& row_groups_pruned, int64_t& rows_pruned_page_index) {
+  for (auto& pf : op.files) {
+    auto mf = std::make_shared<OpenFile>(path_from_uri(pf.file_path));
+    auto fm = std::make_shared<pq::FileMeta>(pq::parse_footer(mf->footer.data(), mf->footer.size()));
+    for (size_t g = 0; g < fm->row_groups.size(); g++) {
+      const pq::RowGroup& rg = fm->row_groups[g];
+      if (rg.columns.empty()) continue;
+      const pq::ColumnMeta& c0 = rg.columns[0];
+      int64_t start = (c0.dictionary_page_offset > 0 && c0.dictionary_page_offset < c0.data_page_offset) ? c0.dictionary_page_offset : c0.data_page_offset;
+      int64_t comp = rg.total_compressed;
+      if (comp <= 0) { comp = 0; for (auto& c : rg.columns) comp += c.total_compressed; }
+      int64_t mid = start + comp / 2;
+      const bool whole = pf.length <= 0;
+      if (!whole && !(mid >= pf.start && mid < pf.start + pf.length)) continue;
+      bool skip = false;
+      for (auto& df : op.data_filters)
+        if (prunes(*df, op.required_schema, *fm, rg, op.case_sensitive)) { skip = true; break; }
+      if (skip) { row_groups_pruned++; continue; }
+      std::shared_ptr<Ranges> keep;
+      int64_t rows = rg.num_rows;
+      if (page_index && !op.data_filters.empty()) {
+        PageIndexCache pic{mf.get(), &rg, {}};
+        Ranges r{{0, rg.num_rows}};
+        for (auto& df : op.data_filters) r = ranges_and(r, may_match(*df, op.required_schema, *fm, rg, op.case_sensitive, pic));
+        const int64_t kept = ranges_rows(r);
+        if (kept == 0) { row_groups_pruned++; rows_pruned_page_index += rg.num_rows; continue; }
+        if (kept < rg.num_rows) {
+          keep = std::make_shared<Ranges>(std::move(r));
+          rows = kept;
+          rows_pruned_page_index += rg.num_rows - kept;
+        }
+      }
+      sels.push_back({mf, fm, (int)g, total_rows, &pf, rows, keep});
+      total_rows += rows;
+    }
+  }
+}
+
 }  // namespace
+
+// What select_row_groups decides for a NativeScan, as JSON — host only (footers and page indexes are read, no page is): the CPU-side
+// check of row-group and page-index pruning (include/comet_amd.h comet_parquet_prune_report).
+std::string parquet_prune_report(const Operator& op, bool page_index) {
+  std::vector<Sel> sels;
+  int64_t total = 0, rg_pruned = 0, rows_pruned = 0;
+  select_row_groups(op, page_index, sels, total, rg_pruned, rows_pruned);
+  std::string j = "{\"rows\": " + std::to_string(total) + ", \"row_groups_pruned\": " + std::to_string(rg_pruned) + ", \"page_index_rows_pruned\": " + std::to_string(rows_pruned) +
+                  ", \"row_groups\": [";
+  for (size_t i = 0; i < sels.size(); i++) {
+    const Sel& sl = sels[i];
+    const int64_t n = sl.meta->row_groups[(size_t)sl.rg].num_rows;
+    j += std::string(i ? ", " : "") + "{\"row_group\": " + std::to_string(sl.rg) + ", \"num_rows\": " + std::to_string(n) + ", \"keep\": [";
+    if (sl.keep) {
+      for (size_t k = 0; k < sl.keep->size(); k++)
+        j += std::string(k ? ", " : "") + "[" + std::to_string((*sl.keep)[k].first) + ", " + std::to_string((*sl.keep)[k].second) + "]";
+    } else {
+      j += "[0, " + std::to_string(n) + "]";
+    }
+    j += "]}";
+  }
+  return j + "]}";
+}
 
 DevTable ExecutionContext::scan_parquet(const Operator& op) {
   static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
@@ -1121,49 +1196,12 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (const char* e = getenv("COMET_PARQUET_PAGE_INDEX")) page_index = atoi(e) != 0;
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scan.pageIndex" || kv.first == "spark.sql.parquet.columnindex.access.enabled") page_index = kv.second != "false" && kv.second != "0";
-  // pass 1: open files, pick row groups (midpoint rule), total rows
-  struct Sel { std::shared_ptr<OpenFile> file; std::shared_ptr<pq::FileMeta> meta; int rg; int64_t row_off; const PartitionedFile* pf; int64_t rows;
-               std::shared_ptr<Ranges> keep; };      // keep: the rows the page index could not rule out (null: all of them)
+  // pass 1: open files, pick row groups (midpoint rule), prune by statistics and page index, total rows
   std::vector<Sel> sels;
-  int64_t total_rows = 0;
-  for (auto& pf : op.files) {
-    auto mf = std::make_shared<OpenFile>(path_from_uri(pf.file_path));
-    auto fm = std::make_shared<pq::FileMeta>(pq::parse_footer(mf->footer.data(), mf->footer.size()));
-    for (size_t g = 0; g < fm->row_groups.size(); g++) {
-      const pq::RowGroup& rg = fm->row_groups[g];
-      if (rg.columns.empty()) continue;
-      const pq::ColumnMeta& c0 = rg.columns[0];
-      int64_t start = (c0.dictionary_page_offset > 0 && c0.dictionary_page_offset < c0.data_page_offset) ? c0.dictionary_page_offset : c0.data_page_offset;
-      int64_t comp = rg.total_compressed;
-      if (comp <= 0) { comp = 0; for (auto& c : rg.columns) comp += c.total_compressed; }
-      int64_t mid = start + comp / 2;
-      const bool whole = pf.length <= 0;
-      if (!whole && !(mid >= pf.start && mid < pf.start + pf.length)) continue;
-      bool skip = false;
-      for (auto& df : op.data_filters)
-        if (prunes(*df, op.required_schema, *fm, rg, op.case_sensitive)) { skip = true; break; }
-      if (skip) { row_groups_pruned_++; continue; }
-      // page index (ColumnIndex / OffsetIndex, parquet_exec.rs enables DataFusion's page-index pruning): the rows a pushed-down filter can
-      // still be true for; pages outside them are neither decompressed nor uploaded, and the scan emits only the kept rows — the Filter
-      // above re-checks every row it gets, exactly as it does after row-group pruning
-      std::shared_ptr<Ranges> keep;
-      int64_t rows = rg.num_rows;
-      if (page_index && !op.data_filters.empty()) {
-        PageIndexCache pic{mf.get(), &rg, {}};
-        Ranges r{{0, rg.num_rows}};
-        for (auto& df : op.data_filters) r = ranges_and(r, may_match(*df, op.required_schema, *fm, rg, op.case_sensitive, pic));
-        const int64_t kept = ranges_rows(r);
-        if (kept == 0) { row_groups_pruned_++; rows_pruned_page_index_ += rg.num_rows; continue; }
-        if (kept < rg.num_rows) {
-          keep = std::make_shared<Ranges>(std::move(r));
-          rows = kept;
-          rows_pruned_page_index_ += rg.num_rows - kept;
-        }
-      }
-      sels.push_back({mf, fm, (int)g, total_rows, &pf, rows, keep});
-      total_rows += rows;
-    }
-  }
+  int64_t total_rows = 0, rg_pruned = 0, rows_pruned = 0;
+  select_row_groups(op, page_index, sels, total_rows, rg_pruned, rows_pruned);
+  row_groups_pruned_ += rg_pruned;
+  rows_pruned_page_index_ += rows_pruned;
   out.rows = total_rows;
   bytes_scanned_ = 0;
   if (total_rows == 0) return out;

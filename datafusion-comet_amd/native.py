@@ -118,6 +118,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_plan_memory_stats.argtypes = [c.c_int64, c.c_void_p]
     lib.comet_plan_set_memory_manager.restype = c.c_int32
     lib.comet_plan_set_memory_manager.argtypes = [c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64]
+    lib.comet_parquet_prune_report.restype = c.c_int64
+    lib.comet_parquet_prune_report.argtypes = [c.c_char_p, c.c_size_t, c.c_int32, c.c_char_p, c.c_size_t]
     lib.comet_rlike_match.restype = c.c_int32
     lib.comet_rlike_match.argtypes = [c.c_char_p, c.c_char_p, c.c_size_t]
     lib.comet_page_decompress.restype = c.c_int32
@@ -935,3 +937,13 @@ def rlike_match(pattern: str, value: str) -> bool:
     if rc < 0:
         _raise_last(0)
     return rc == 1
+
+
+def parquet_prune_report(plan: bytes, page_index: bool = True) -> dict:
+    """row-group / page-index selection of the plan's NativeScan (comet_parquet_prune_report; host only)"""
+    import json
+    buf = ctypes.create_string_buffer(1 << 20)
+    n = lib().comet_parquet_prune_report(plan, len(plan), 1 if page_index else 0, buf, len(buf))
+    if n < 0:
+        _raise_last(0)
+    return json.loads(buf.value.decode())

@@ -159,6 +159,13 @@ int32_t comet_plan_set_memory_manager(int64_t plan, int64_t (*acquire)(void* ctx
                                       int64_t task_id);
 void comet_plan_memory_stats(int64_t plan, int64_t* out4);
 
+/* ---- Parquet scan planning — diagnostic entry ------------------------------------------------------------------------------------------
+ * What the scan of a serialized plan's NativeScan would read: the row groups its byte ranges select, those the pushed-down data_filters
+ * rule out by min / max statistics, and (page_index != 0) the row ranges of the survivors the page index leaves — as JSON
+ * {"rows", "row_groups_pruned", "page_index_rows_pruned", "row_groups": [{"row_group", "num_rows", "keep": [[begin, end), …]}]}.
+ * Reads footers and page indexes only; needs no GPU.  Returns the JSON's length (truncated to cap − 1 in `out`), or -2. */
+int64_t comet_parquet_prune_report(const uint8_t* plan, size_t plan_len, int32_t page_index, char* out, size_t cap);
+
 /* ---- RLIKE pattern compiler (csrc/regex.cpp) — diagnostic entry -------------------------------------------------------------------------
  * Compiles `pattern` the way the planner does for an RLike expression (the exactly reproducible subset of the Rust regex syntax the
  * reference evaluates with, predicate_funcs/rlike.rs) and walks the resulting tables over `value` on the host: 1 match, 0 no match,
