@@ -994,6 +994,23 @@ struct Gen {
       r.maxabs = (u128)1 << 31;
       return r;
     }
+    if (f == "coalesce") {
+      // the first non-NULL argument (Spark Coalesce → DataFusion's coalesce): a chain of selects from the last argument backwards
+      if (e.children.empty()) throw CometError("coalesce needs at least one argument");
+      Val acc = named(gen(e.children.back()));
+      for (size_t k = e.children.size() - 1; k-- > 0;) {
+        Val a = named(gen(e.children[k]));
+        if (a.ok.empty()) { acc = a; continue; }      // never NULL: everything after it is dead
+        Val is_set;
+        is_set.t = DType::of(TypeId::Bool);
+        is_set.rep = Rep::B;
+        is_set.v = a.ok;
+        Val picked = a;
+        picked.ok = "";                                // inside the branch it IS set
+        acc = named(select(is_set, picked, acc));
+      }
+      return acc;
+    }
     if (f == "ceil" || f == "floor") {
       // spark_ceil / spark_floor (math_funcs/ceil.rs:24-84): Float → Int64 (`as i64`), Int64 unchanged, Decimal(s > 0) → div_ceil by 10^s
       Val a = arg(0);

@@ -445,6 +445,16 @@ class Evaluator:
                 fill = (pat * (length // max(len(pat), 1) + 1))[:length - len(v)] if pat else ""
                 return fill + v if f == "lpad" else v + fill
             return Col(S.T_STRING, np.array([pad(v) if v is not None else None for v in a.values], dtype=object), a.valid)
+        if f == "coalesce":
+            # the first non-NULL argument
+            args = [self.eval(c, cols, n) for c in e.children]
+            out_vals = args[-1].values.copy()
+            out_ok = args[-1].ok().copy()
+            for a in reversed(args[:-1]):
+                ok = a.ok()
+                out_vals = np.where(ok, a.values, out_vals) if a.values.dtype != object else np.array([x if k else y for x, y, k in zip(a.values, out_vals, ok)], dtype=object)
+                out_ok = ok | out_ok
+            return Col(args[0].dtype, out_vals, None if out_ok.all() else out_ok)
         if f in ("starts_with", "ends_with", "contains"):
             # byte-wise on the UTF-8 encodings (UTF8_BINARY collation; strings.scala:343-360)
             a, lit = self.eval(e.children[0], cols, n), e.children[1].value.encode()

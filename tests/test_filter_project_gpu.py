@@ -451,3 +451,31 @@ def test_murmur3_hash_expression(built):
     plan = S.project(S.scan(fields), [h(c[2], c[3])])
     hv = pa.Table.from_batches(_run(plan, table=t, ncols=1, batch_size=0)).column(0).to_numpy().astype(np.int64)
     assert ((hv % 200 + 200) % 200 == ids).all()
+
+
+def test_coalesce(built):
+    """coalesce(a, b, …): the first non-NULL argument — integers, doubles, decimals whose arguments sit in different widths, dates, packed
+    strings, a literal fallback that makes the result non-nullable, and as a filter operand."""
+    from decimal import Decimal
+    from oracle import oracle as O
+    rng = np.random.default_rng(23)
+    n = 50_000
+    m = lambda p: rng.random(n) < p
+    D = S.decimal(12, 2)
+    t = pa.table({"a": pa.array(rng.integers(-10**9, 10**9, n), pa.int64(), mask=m(0.5)), "b": pa.array(rng.integers(-10**9, 10**9, n), pa.int64(), mask=m(0.5)),
+                  "x": pa.array(rng.standard_normal(n), mask=m(0.4)), "y": pa.array(rng.standard_normal(n), mask=m(0.4)),
+                  "d": pa.array([Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**11, 10**11, n)], pa.decimal128(12, 2), mask=m(0.6)),
+                  "e": pa.array([Decimal(int(v)).scaleb(-2) for v in rng.integers(-100, 100, n)], pa.decimal128(12, 2), mask=m(0.3)),
+                  "s": pa.array(np.array(["", "A", "N", "lineitem"], dtype=object)[rng.integers(0, 4, n)], pa.utf8(), mask=m(0.5))})
+    types = [S.T_INT64, S.T_INT64, S.T_DOUBLE, S.T_DOUBLE, D, D, S.T_STRING]
+    c = lambda i: S.col(i, types[i])
+    co = lambda args, ty: S.scalar_func("coalesce", args, ty)
+    exprs = [co([c(0), c(1)], S.T_INT64), co([c(0), c(1), S.lit(-1, S.T_INT64)], S.T_INT64), co([c(2), c(3)], S.T_DOUBLE), co([c(4), c(5)], D),
+             co([c(4), S.math("add", c(5), c(5), D)], D), co([c(6), S.lit("none", S.T_STRING)], S.T_STRING), co([c(0)], S.T_INT64)]
+    plan = S.project(S.filter_(S.scan(types), S.gt(co([c(0), c(1), S.lit(0, S.T_INT64)], S.T_INT64), S.lit(-5 * 10**8, S.T_INT64))), exprs)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], len(exprs), plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, t)
+    assert got.num_rows == want.num_rows and 0 < got.num_rows < n
+    for i in range(len(exprs)):
+        assert got.column(i).to_pylist() == want.column(i).to_pylist(), f"expression {i}"
+    assert got.column(1).null_count == 0
