@@ -430,6 +430,16 @@ JNIEXPORT void JNICALL Java_org_apache_comet_Native_columnarToRowClose(JNIEnv*, 
 
 
 // ---- org.apache.comet.parquet.Native (native/core/src/parquet/mod.rs:135-330): the record-batch reader of the iceberg-compat scan ----
+// errors of the file format itself (footer, Thrift, page walk, codecs: messages that start "parquet:") are the reference's CometError::Parquet →
+// org/apache/comet/ParquetRuntimeException (jni-bridge/src/errors.rs:333-336); everything else keeps its class
+static void throw_reader_error(JNIEnv* env) {
+  const char* msg = comet_last_error(0);
+  if (msg && (strncmp(msg, "parquet:", 8) == 0 || strncmp(msg, "snappy:", 7) == 0) && !jni_ExceptionCheck(env)) {
+    jclass c = jni_FindClass(env, "org/apache/comet/ParquetRuntimeException");
+    if (c) { jni_ThrowNew(env, c, msg); return; }
+  }
+  throw_java(env, comet_last_error_kind(0), msg);
+}
 JNIEXPORT jlong JNICALL Java_org_apache_comet_parquet_Native_initRecordBatchReader(
     JNIEnv* env, jclass, jstring filePath, jlong fileSize, jlongArray starts, jlongArray lengths, jbyteArray filter, jbyteArray requiredSchema,
     jbyteArray dataSchema, jstring sessionTimezone, jint batchSize, jboolean caseSensitive, jboolean /*returnNullStructIfAllFieldsMissing*/,
@@ -456,18 +466,18 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_parquet_Native_initRecordBatchRead
   int64_t h = comet_parquet_reader_init(path.c_str(), (int64_t)fileSize, (const int64_t*)st.data(), (const int64_t*)ln.data(), (int32_t)ns,
                                         f.empty() ? nullptr : f.data(), f.size(), rs.empty() ? nullptr : rs.data(), rs.size(),
                                         ds.empty() ? nullptr : ds.data(), ds.size(), tz.c_str(), (int32_t)batchSize, caseSensitive ? 1 : 0, pick_device(0));
-  if (h == 0) { throw_java(env, comet_last_error_kind(0), comet_last_error(0)); return 0; }
+  if (h == 0) { throw_reader_error(env); return 0; }
   return (jlong)h;
 }
 JNIEXPORT jint JNICALL Java_org_apache_comet_parquet_Native_readNextRecordBatch(JNIEnv* env, jclass, jlong handle) {
   const int32_t rows = comet_parquet_reader_next((int64_t)handle);
-  if (rows == -2) { throw_java(env, comet_last_error_kind(0), comet_last_error(0)); return 0; }
+  if (rows == -2) { throw_reader_error(env); return 0; }
   return (jint)rows;
 }
 JNIEXPORT void JNICALL Java_org_apache_comet_parquet_Native_currentColumnBatch(JNIEnv* env, jclass, jlong handle, jint columnIdx, jlong arrayAddr,
                                                                                jlong schemaAddr) {
   if (comet_parquet_reader_column((int64_t)handle, (int32_t)columnIdx, (struct ArrowArray*)(intptr_t)arrayAddr, (struct ArrowSchema*)(intptr_t)schemaAddr) != 0)
-    throw_java(env, comet_last_error_kind(0), comet_last_error(0));
+    throw_reader_error(env);
 }
 JNIEXPORT void JNICALL Java_org_apache_comet_parquet_Native_closeRecordBatchReader(JNIEnv*, jclass, jlong handle) {
   comet_parquet_reader_close((int64_t)handle);

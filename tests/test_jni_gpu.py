@@ -200,6 +200,20 @@ def test_parquet_native_reader_reads_a_reference_fixture_batch_by_batch(built, t
     ks = pa.concat_arrays([b[1] for b in half]).to_pylist()
     assert 0 < len(ks) < n and len(ks) % 10_000 == 0 and ks == list(range(len(ks)))
     assert jvm.m.mock_live_global_refs() == 0
+    # a file that is not Parquet: the format error surfaces as the reference's ParquetRuntimeException (errors.rs:333-336)
+    junk = str(tmp_path / "junk.parquet")
+    with open(junk, "wb") as f:
+        f.write(b"PAR1" + b"\x00" * 64 + (1 << 20).to_bytes(4, "little") + b"PAR1")
+    rs = required.serialize().to_pybytes()
+    h = init(jvm.env, None, jvm.m.mock_string(("file://" + junk).encode()), os.path.getsize(junk), jvm.m.mock_longs((ctypes.c_int64 * 1)(0), 1),
+             jvm.m.mock_longs((ctypes.c_int64 * 1)(os.path.getsize(junk)), 1), None, jvm.m.mock_bytes(rs, len(rs)), jvm.m.mock_bytes(rs, len(rs)), jvm.m.mock_string(b"UTC"),
+             8192, 1, 0, None, None, None)
+    rows = nxt(jvm.env, None, h) if h > 0 else 0
+    cls, msg = jvm.exception()
+    assert rows == 0 and cls == "org/apache/comet/ParquetRuntimeException" and "parquet:" in msg
+    jvm.m.mock_exception_clear()
+    if h > 0:
+        close(jvm.env, None, h)
 
 
 def test_pinned_staging_is_charged_to_the_task_memory_manager(built):
