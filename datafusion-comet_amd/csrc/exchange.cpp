@@ -11,8 +11,9 @@
 // partition_row_indices exactly as the reference's shuffle writer computes them (multi_partition.rs:54-103) → one `take` per buffer
 // into partition order → transport → the received slices, sender after sender in rank order, each sender's rows in their input
 // order.  Validity travels one byte per row (partition boundaries are not byte aligned) and is packed again on arrival.
-// Fixed-width columns (ints, floats, dates, timestamps, decimals) with or without validity; Utf8 / Boolean columns still take the
-// harness path (parallel.exchange).
+// Fixed-width columns (ints, floats, dates, timestamps, decimals), Boolean (bit-packed values travel one byte per row like validity)
+// and Utf8 / Binary: the lengths travel one int32 per row, the bytes — gathered into partition order — with per-partition BYTE counts
+// (a second count exchange), and the receiver rebuilds its int32 offsets with one prefix sum over the received lengths.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -37,6 +38,11 @@ extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx
 extern "C" int comet_launch_take_valid_bytes(const uint8_t* valid_bits, const uint32_t* idx, int64_t n, uint8_t* out_bytes, void* stream);
 extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
 extern "C" void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
+extern "C" void pq_launch_u32_scan(const uint32_t* lengths, int64_t n, uint64_t* tiles, int32_t* offsets, void* st);
+extern "C" int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t n,
+                                              uint32_t* lengths, void* stream);
+extern "C" int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits,
+                                           int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 
 namespace comet {
 namespace {
@@ -131,7 +137,8 @@ int64_t g_next_comm = 1;
 
 struct ExchangeResult {
   int64_t rows = 0;
-  std::vector<std::unique_ptr<DevBuf>> values, validity;   // validity[c] null ⇔ column arrives without a bitmap
+  std::vector<std::unique_ptr<DevBuf>> values, validity, aux;   // validity[c] null ⇔ column arrives without a bitmap; aux[c]: Utf8 bytes
+  std::vector<int64_t> aux_bytes;
   int device = 0;
 };
 std::mutex g_res_mu;
@@ -159,8 +166,11 @@ auto guarded(F f, decltype(f()) err) -> decltype(f()) {
   return err;
 }
 
+constexpr int kUtf8Column = 0, kBoolColumn = -1;   // value_width of the two kinds that are not fixed-width byte columns
 int value_width(int type_id) {
   switch ((TypeId)type_id) {
+    case TypeId::Bool: return kBoolColumn;
+    case TypeId::String: case TypeId::Bytes: return kUtf8Column;
     case TypeId::Int8: return 1;
     case TypeId::Int16: return 2;
     case TypeId::Int32: case TypeId::Date: case TypeId::Float: return 4;
@@ -266,6 +276,8 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
     res->device = c->device;
     res->values.resize((size_t)n_cols);
     res->validity.resize((size_t)n_cols);
+    res->aux.resize((size_t)n_cols);
+    res->aux_bytes.assign((size_t)n_cols, 0);
     std::vector<int> width((size_t)n_cols);
     for (int i = 0; i < n_cols; i++) width[(size_t)i] = value_width(cols[i].type_id);
 
@@ -281,7 +293,7 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
       if (comet_launch_fill(4, hashes.p, rows, &seed, st) != 0) throw CometError("exchange: launch failed");
       for (int k = 0; k < n_keys; k++) {
         const CometExchangeColumn& kc = cols[key_cols[k]];
-        if (comet_murmur3_column(kc.type_id, kc.precision, kc.values, kc.validity, nullptr, rows, (uint32_t*)hashes.p, st) != 0)
+        if (comet_murmur3_column(kc.type_id, kc.precision, kc.values, kc.validity, kc.aux, rows, (uint32_t*)hashes.p, st) != 0)
           throw CometError(std::string("exchange: murmur3: ") + comet_last_error(0));
       }
       if (comet_pmod_partition((const uint32_t*)hashes.p, rows, world, (int32_t*)pids.p, st) != 0) throw CometError("exchange: pmod failed");
@@ -298,51 +310,65 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
       XHIP(hipStreamSynchronize(st));
       memcpy(starts.data(), hs.p, (size_t)(world + 1) * 8);
     }
-    // 3. counts: who sends how many rows to whom
-    std::vector<int64_t> send((size_t)world), recv((size_t)world);
-    for (int p = 0; p < world; p++) send[(size_t)p] = starts[(size_t)p + 1] - starts[(size_t)p];
-    std::vector<int64_t> all_starts;            // local transport: every rank's starts
-    if (world == 1 && !c->nccl) {
-      recv[0] = send[0];
-    } else if (c->nccl) {
-      Rccl& r = Rccl::get();
-      DevBuf dsend, dall;
-      PinnedBuf hsend, hall;
-      dsend.ensure((size_t)world * 8 + 16);
-      dall.ensure((size_t)world * world * 8 + 16);
-      hsend.ensure((size_t)world * 8 + 16);
-      hall.ensure((size_t)world * world * 8 + 16);
-      memcpy(hsend.p, send.data(), (size_t)world * 8);
-      XHIP(hipMemcpyAsync(dsend.p, hsend.p, (size_t)world * 8, hipMemcpyHostToDevice, st));
-      r.check(r.AllGather(dsend.p, dall.p, (size_t)world, kNcclInt64, c->nccl, st), "ncclAllGather");
-      XHIP(hipMemcpyAsync(hall.p, dall.p, (size_t)world * world * 8, hipMemcpyDeviceToHost, st));
-      XHIP(hipStreamSynchronize(st));
-      const int64_t* m = (const int64_t*)hall.p;   // m[s · world + d] = rows rank s sends to rank d
-      for (int s = 0; s < world; s++) recv[(size_t)s] = m[(size_t)s * world + c->rank];
-    } else {
-      LocalGroup& g = *c->local;
-      { std::lock_guard<std::mutex> lk(g.mu); g.starts[(size_t)c->rank] = starts; }
-      g.barrier();
-      { std::lock_guard<std::mutex> lk(g.mu);
-        for (int s = 0; s < world; s++) recv[(size_t)s] = g.starts[(size_t)s][(size_t)c->rank + 1] - g.starts[(size_t)s][(size_t)c->rank]; }
-    }
-    int64_t n_out = 0;
-    std::vector<int64_t> roff((size_t)world + 1, 0);
-    for (int s = 0; s < world; s++) { roff[(size_t)s] = n_out; n_out += recv[(size_t)s]; }
-    roff[(size_t)world] = n_out;
+    // 3. counts: who sends how many units (rows, or bytes of a Utf8 column) to whom.  `my_starts` = world + 1 unit offsets of my send
+    //    buffer in partition order; collective — every rank calls it the same number of times, in the same order.
+    struct Split {
+      std::vector<int64_t> starts, send, recv, roff, peer_off;   // peer_off[s]: where my slice begins in sender s's buffer (local transport)
+      int64_t total = 0;                                         // units this rank receives
+    };
+    auto make_split = [&](const std::vector<int64_t>& my_starts) {
+      Split sp;
+      sp.starts = my_starts;
+      sp.send.assign((size_t)world, 0); sp.recv.assign((size_t)world, 0); sp.peer_off.assign((size_t)world, 0);
+      for (int p = 0; p < world; p++) sp.send[(size_t)p] = my_starts[(size_t)p + 1] - my_starts[(size_t)p];
+      if (world == 1 && !c->nccl) {
+        sp.recv[0] = sp.send[0];
+      } else if (c->nccl) {
+        Rccl& r = Rccl::get();
+        DevBuf dsend, dall;
+        PinnedBuf hsend, hall;
+        dsend.ensure((size_t)world * 8 + 16);
+        dall.ensure((size_t)world * world * 8 + 16);
+        hsend.ensure((size_t)world * 8 + 16);
+        hall.ensure((size_t)world * world * 8 + 16);
+        memcpy(hsend.p, sp.send.data(), (size_t)world * 8);
+        XHIP(hipMemcpyAsync(dsend.p, hsend.p, (size_t)world * 8, hipMemcpyHostToDevice, st));
+        r.check(r.AllGather(dsend.p, dall.p, (size_t)world, kNcclInt64, c->nccl, st), "ncclAllGather");
+        XHIP(hipMemcpyAsync(hall.p, dall.p, (size_t)world * world * 8, hipMemcpyDeviceToHost, st));
+        XHIP(hipStreamSynchronize(st));
+        const int64_t* m = (const int64_t*)hall.p;   // m[s · world + d] = units rank s sends to rank d
+        for (int s = 0; s < world; s++) sp.recv[(size_t)s] = m[(size_t)s * world + c->rank];
+      } else {
+        LocalGroup& g = *c->local;
+        { std::lock_guard<std::mutex> lk(g.mu); g.starts[(size_t)c->rank] = my_starts; }
+        g.barrier();
+        { std::lock_guard<std::mutex> lk(g.mu);
+          for (int s = 0; s < world; s++) {
+            sp.peer_off[(size_t)s] = g.starts[(size_t)s][(size_t)c->rank];
+            sp.recv[(size_t)s] = g.starts[(size_t)s][(size_t)c->rank + 1] - sp.peer_off[(size_t)s];
+          } }
+        g.barrier();      // everyone has read: the slot may be published again (the byte counts of a Utf8 column, the next exchange)
+      }
+      sp.roff.assign((size_t)world + 1, 0);
+      for (int s = 0; s < world; s++) { sp.roff[(size_t)s] = sp.total; sp.total += sp.recv[(size_t)s]; }
+      sp.roff[(size_t)world] = sp.total;
+      return sp;
+    };
+    const Split R = make_split(starts);
+    const int64_t n_out = R.total;
     res->rows = n_out;
     if (n_out >= ((int64_t)1 << 31)) throw CometError("exchange: a rank would receive 2^31 rows or more");
 
     // 4. every buffer: take into partition order, then move the slices
-    auto move = [&](const void* send_buf, void* recv_buf, int w) {   // w bytes per row
+    auto move = [&](const void* send_buf, void* recv_buf, int w, const Split& sp) {   // w bytes per unit
       if (world == 1 && !c->nccl) {
-        if (n_out) XHIP(hipMemcpyAsync(recv_buf, send_buf, (size_t)n_out * (size_t)w, hipMemcpyDeviceToDevice, st));
+        if (sp.total) XHIP(hipMemcpyAsync(recv_buf, send_buf, (size_t)sp.total * (size_t)w, hipMemcpyDeviceToDevice, st));
       } else if (c->nccl) {
         Rccl& r = Rccl::get();
         r.check(r.GroupStart(), "ncclGroupStart");
         for (int p = 0; p < world; p++) {
-          if (send[(size_t)p]) r.check(r.Send((const char*)send_buf + (size_t)starts[(size_t)p] * (size_t)w, (size_t)send[(size_t)p] * (size_t)w, kNcclUint8, p, c->nccl, st), "ncclSend");
-          if (recv[(size_t)p]) r.check(r.Recv((char*)recv_buf + (size_t)roff[(size_t)p] * (size_t)w, (size_t)recv[(size_t)p] * (size_t)w, kNcclUint8, p, c->nccl, st), "ncclRecv");
+          if (sp.send[(size_t)p]) r.check(r.Send((const char*)send_buf + (size_t)sp.starts[(size_t)p] * (size_t)w, (size_t)sp.send[(size_t)p] * (size_t)w, kNcclUint8, p, c->nccl, st), "ncclSend");
+          if (sp.recv[(size_t)p]) r.check(r.Recv((char*)recv_buf + (size_t)sp.roff[(size_t)p] * (size_t)w, (size_t)sp.recv[(size_t)p] * (size_t)w, kNcclUint8, p, c->nccl, st), "ncclRecv");
         }
         r.check(r.GroupEnd(), "ncclGroupEnd");
       } else {
@@ -352,13 +378,12 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
         g.barrier();                                              // every send buffer is published (and its event recorded)
         for (int s = 0; s < world; s++) {
           const void* src;
-          int64_t off;
           hipEvent_t ev;
-          { std::lock_guard<std::mutex> lk(g.mu); src = g.send_ptr[(size_t)s]; off = g.starts[(size_t)s][(size_t)c->rank]; ev = g.ready[(size_t)s]; }
-          if (!recv[(size_t)s]) continue;
+          { std::lock_guard<std::mutex> lk(g.mu); src = g.send_ptr[(size_t)s]; ev = g.ready[(size_t)s]; }
+          if (!sp.recv[(size_t)s]) continue;
           XHIP(hipStreamWaitEvent(st, ev, 0));
-          XHIP(hipMemcpyAsync((char*)recv_buf + (size_t)roff[(size_t)s] * (size_t)w, (const char*)src + (size_t)off * (size_t)w, (size_t)recv[(size_t)s] * (size_t)w,
-                              hipMemcpyDeviceToDevice, st));
+          XHIP(hipMemcpyAsync((char*)recv_buf + (size_t)sp.roff[(size_t)s] * (size_t)w, (const char*)src + (size_t)sp.peer_off[(size_t)s] * (size_t)w,
+                              (size_t)sp.recv[(size_t)s] * (size_t)w, hipMemcpyDeviceToDevice, st));
         }
         XHIP(hipStreamSynchronize(st));                           // my pulls are done …
         g.barrier();                                              // … and so are everybody's: the send buffers may be reused
@@ -391,17 +416,64 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
         g.barrier();      // nobody overwrites its flags (next exchange) before everyone has read them
       }
     }
-    DevBuf send_buf, vbytes_send, vbytes_recv;
+    DevBuf send_buf, vbytes_send, vbytes_recv, lengths, send_offs, recv_lengths, tiles;
+    const size_t rows1 = (size_t)std::max<int64_t>(rows, 1), out1 = (size_t)std::max<int64_t>(n_out, 1);
     for (int i = 0; i < n_cols; i++) {
       const int w = width[(size_t)i];
-      send_buf.ensure((size_t)std::max<int64_t>(rows, 1) * (size_t)w + 16);
-      if (rows > 0 && comet_launch_take(w, cols[i].values, (const uint32_t*)idx.p, rows, send_buf.p, st) != 0) throw CometError("exchange: take failed");
       res->values[(size_t)i].reset(new DevBuf());
-      res->values[(size_t)i]->ensure((size_t)std::max<int64_t>(n_out, 1) * (size_t)w + 16);
-      move(send_buf.p, res->values[(size_t)i]->p, w);
+      if (w > 0) {
+        send_buf.ensure(rows1 * (size_t)w + 16);
+        if (rows > 0 && comet_launch_take(w, cols[i].values, (const uint32_t*)idx.p, rows, send_buf.p, st) != 0) throw CometError("exchange: take failed");
+        res->values[(size_t)i]->ensure(out1 * (size_t)w + 16);
+        move(send_buf.p, res->values[(size_t)i]->p, w, R);
+      } else if (w == kBoolColumn) {
+        // bit-packed values: one byte per row on the wire (partition boundaries are not byte aligned), packed again on arrival
+        vbytes_send.ensure(rows1 + 16);
+        vbytes_recv.ensure(out1 + 16);
+        if (rows > 0 && comet_launch_take_valid_bytes((const uint8_t*)cols[i].values, (const uint32_t*)idx.p, rows, (uint8_t*)vbytes_send.p, st) != 0)
+          throw CometError("exchange: take failed");
+        move(vbytes_send.p, vbytes_recv.p, 1, R);
+        res->values[(size_t)i]->ensure((size_t)((n_out + 7) / 8) + 16);
+        if (n_out > 0) pq_launch_pack((const uint8_t*)vbytes_recv.p, (uint8_t*)res->values[(size_t)i]->p, n_out, st);
+      } else {
+        // Utf8 / Binary: lengths (0 for NULL rows) → offsets of my send bytes → the bytes in partition order
+        const int32_t* offs = (const int32_t*)cols[i].values;
+        lengths.ensure(rows1 * 4 + 16);
+        send_offs.ensure((rows1 + 1) * 4 + 16);
+        tiles.ensure((size_t)((std::max(rows, n_out) + 1023) / 1024 + 2) * 8);
+        std::vector<int64_t> bstarts((size_t)world + 1, 0);
+        if (rows > 0) {
+          if (comet_launch_take_utf8_lengths(offs, (const uint32_t*)idx.p, nullptr, cols[i].validity, rows, (uint32_t*)lengths.p, st) != 0)
+            throw CometError("exchange: take failed");
+          pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)send_offs.p, st);
+          PinnedBuf hb;
+          hb.ensure((size_t)(world + 1) * 4 + 16);
+          for (int p = 0; p <= world; p++)
+            XHIP(hipMemcpyAsync((char*)hb.p + (size_t)p * 4, (const char*)send_offs.p + (size_t)starts[(size_t)p] * 4, 4, hipMemcpyDeviceToHost, st));
+          XHIP(hipStreamSynchronize(st));
+          for (int p = 0; p <= world; p++) bstarts[(size_t)p] = ((const int32_t*)hb.p)[p];
+          if (bstarts[(size_t)world] < 0) throw CometError("exchange: Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+        }
+        send_buf.ensure((size_t)std::max<int64_t>(bstarts[(size_t)world], 1) + 16);
+        if (rows > 0 && comet_launch_take_utf8_copy(offs, cols[i].aux, (const uint32_t*)idx.p, nullptr, cols[i].validity, rows, (const int32_t*)send_offs.p,
+                                                    (uint8_t*)send_buf.p, st) != 0)
+          throw CometError("exchange: take failed");
+        const Split B = make_split(bstarts);
+        if (B.total >= ((int64_t)1 << 31)) throw CometError("exchange: a rank would receive 2 GiB or more of one Utf8 column");
+        recv_lengths.ensure(out1 * 4 + 16);
+        move(lengths.p, recv_lengths.p, 4, R);
+        res->aux[(size_t)i].reset(new DevBuf());
+        res->aux[(size_t)i]->ensure((size_t)std::max<int64_t>(B.total, 1) + 16);
+        move(send_buf.p, res->aux[(size_t)i]->p, 1, B);
+        res->aux_bytes[(size_t)i] = B.total;
+        // the received slices arrive sender after sender, each in row order: one prefix sum over the lengths is the offsets buffer
+        res->values[(size_t)i]->ensure((out1 + 1) * 4 + 16);
+        if (n_out > 0) pq_launch_u32_scan((const uint32_t*)recv_lengths.p, n_out, (uint64_t*)tiles.p, (int32_t*)res->values[(size_t)i]->p, st);
+        else XHIP(hipMemsetAsync(res->values[(size_t)i]->p, 0, 4, st));
+      }
       if (has_valid[(size_t)i]) {
-        vbytes_send.ensure((size_t)std::max<int64_t>(rows, 1) + 16);
-        vbytes_recv.ensure((size_t)std::max<int64_t>(n_out, 1) + 16);
+        vbytes_send.ensure(rows1 + 16);
+        vbytes_recv.ensure(out1 + 16);
         if (rows > 0) {
           if (cols[i].validity) {
             if (comet_launch_take_valid_bytes(cols[i].validity, (const uint32_t*)idx.p, rows, (uint8_t*)vbytes_send.p, st) != 0) throw CometError("exchange: take failed");
@@ -409,7 +481,7 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
             XHIP(hipMemsetAsync(vbytes_send.p, 1, (size_t)rows, st));
           }
         }
-        move(vbytes_send.p, vbytes_recv.p, 1);
+        move(vbytes_send.p, vbytes_recv.p, 1, R);
         res->validity[(size_t)i].reset(new DevBuf());
         res->validity[(size_t)i]->ensure((size_t)((n_out + 7) / 8) + 16);
         if (n_out > 0) pq_launch_pack((const uint8_t*)vbytes_recv.p, (uint8_t*)res->validity[(size_t)i]->p, n_out, st);
@@ -435,6 +507,15 @@ int32_t comet_exchange_result_column(int64_t result, int32_t col, void** values,
   if (it == g_results.end() || col < 0 || (size_t)col >= it->second->values.size()) return -2;
   *values = it->second->values[(size_t)col]->p;
   *validity = it->second->validity[(size_t)col] ? it->second->validity[(size_t)col]->p : nullptr;
+  return 0;
+}
+
+int32_t comet_exchange_result_aux(int64_t result, int32_t col, void** bytes, int64_t* n_bytes) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  auto it = g_results.find(result);
+  if (it == g_results.end() || col < 0 || (size_t)col >= it->second->values.size()) return -2;
+  *bytes = it->second->aux[(size_t)col] ? it->second->aux[(size_t)col]->p : nullptr;
+  *n_bytes = it->second->aux_bytes[(size_t)col];
   return 0;
 }
 

@@ -109,6 +109,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_exchange_result_rows.argtypes = [c.c_int64]
     lib.comet_exchange_result_column.restype = c.c_int32
     lib.comet_exchange_result_column.argtypes = [c.c_int64, c.c_int32, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p)]
+    lib.comet_exchange_result_aux.restype = c.c_int32
+    lib.comet_exchange_result_aux.argtypes = [c.c_int64, c.c_int32, c.POINTER(c.c_void_p), c.POINTER(c.c_int64)]
     lib.comet_exchange_result_release.restype = None
     lib.comet_exchange_result_release.argtypes = [c.c_int64]
     lib.comet_exchange_last_error.restype = c.c_char_p
@@ -830,7 +832,8 @@ def compile_plan(plan: bytes) -> str:
 
 
 class CometExchangeColumnC(ctypes.Structure):
-    _fields_ = [("type_id", ctypes.c_int32), ("precision", ctypes.c_int32), ("values", ctypes.c_void_p), ("validity", ctypes.c_void_p)]
+    _fields_ = [("type_id", ctypes.c_int32), ("precision", ctypes.c_int32), ("values", ctypes.c_void_p), ("validity", ctypes.c_void_p),
+                ("aux", ctypes.c_void_p)]
 
 
 class _ExchangeResult:
@@ -873,7 +876,8 @@ class NativeComm:
             self.handle = 0
 
     def exchange(self, table: "DeviceTable", key_cols: Sequence[int]) -> "DeviceTable":
-        """Collective hash exchange of this rank's shard on `key_cols` (fixed-width columns); returns partition `rank`."""
+        """Collective hash exchange of this rank's shard on `key_cols` (fixed-width, Boolean, Utf8 / Binary columns); returns
+        partition `rank`."""
         import torch
         from . import serde as S
         torch.cuda.current_stream(torch.device(table.device)).synchronize()     # the producer's work is complete before libcomet's stream reads
@@ -884,20 +888,35 @@ class NativeComm:
             cols[i].type_id, cols[i].precision = t.type_id, t.precision
             cols[i].values = table.values[i].data_ptr() if table.values[i].numel() else None
             cols[i].validity = table.validity[i].data_ptr() if table.validity[i] is not None else None
+            cols[i].aux = table.aux[i].data_ptr() if table.aux[i] is not None and table.aux[i].numel() else None
         keys = (ctypes.c_int32 * max(len(key_cols), 1))(*key_cols)
         h = lib().comet_exchange(self.handle, n, cols, table.num_rows, keys, len(key_cols))
         if not h:
             raise CometNativeException((lib().comet_exchange_last_error() or b"").decode())
         owner = _ExchangeResult(h)
         rows = lib().comet_exchange_result_rows(h)
-        vals, valid = [], []
+        vals, valid, aux = [], [], []
+        empty = lambda: torch.empty(0, dtype=torch.uint8, device=table.device)
         for i, f in enumerate(table.schema):
             pv, pb = ctypes.c_void_p(), ctypes.c_void_p()
             lib().comet_exchange_result_column(h, i, ctypes.byref(pv), ctypes.byref(pb))
-            w = value_width(f.type)
-            vals.append(torch.as_tensor(_DeviceBuffer(owner, pv.value, rows * w), device=table.device) if rows else torch.empty(0, dtype=torch.uint8, device=table.device))
+            is_str = pa.types.is_string(f.type) or pa.types.is_binary(f.type)
+            if is_str:
+                nb = (rows + 1) * 4                      # the rebuilt offsets (always rows + 1 of them)
+            elif pa.types.is_boolean(f.type):
+                nb = (rows + 7) // 8
+            else:
+                nb = rows * value_width(f.type)
+            vals.append(torch.as_tensor(_DeviceBuffer(owner, pv.value, nb), device=table.device) if nb else empty())
             valid.append(torch.as_tensor(_DeviceBuffer(owner, pb.value, (rows + 7) // 8), device=table.device) if (pb.value and rows) else None)
-        return DeviceTable(table.schema, rows, vals, valid, table.device, [None] * n)
+            if is_str:
+                pd_, nbytes = ctypes.c_void_p(), ctypes.c_int64()
+                lib().comet_exchange_result_aux(h, i, ctypes.byref(pd_), ctypes.byref(nbytes))
+                aux.append(torch.as_tensor(_DeviceBuffer(owner, pd_.value, nbytes.value), device=table.device) if nbytes.value
+                           else torch.zeros(1, dtype=torch.uint8, device=table.device))
+            else:
+                aux.append(None)
+        return DeviceTable(table.schema, rows, vals, valid, table.device, aux)
 
 
 def snappy_inflate_pages(streams, page_lens, device_id: int = 0):

@@ -197,10 +197,11 @@ int64_t comet_snappy_inflate_pages(const uint8_t* streams, const int64_t* stream
  *                                                 peer copies; every rank of `group_id` must call it with the same world size
  * All calls return 0 / a positive handle on success; on failure -2 / 0 and comet_exchange_last_error() (thread local) tells why. */
 typedef struct CometExchangeColumn {
-  int32_t type_id;          /* spark_expression.DataType.DataTypeId of a fixed-width type */
+  int32_t type_id;          /* spark_expression.DataType.DataTypeId: fixed-width types, BOOL (bit-packed values), STRING / BYTES */
   int32_t precision;        /* decimals: selects the 8- or 16-byte hash form (hash_funcs/utils.rs:573-760) */
-  const void* values;       /* device pointer */
+  const void* values;       /* device pointer; STRING / BYTES: the rows + 1 int32 offsets */
   const uint8_t* validity;  /* device Arrow bitmap or NULL */
+  const uint8_t* aux;       /* STRING / BYTES: the value bytes; NULL otherwise */
 } CometExchangeColumn;
 int32_t comet_comm_unique_id(uint8_t* out128);
 int64_t comet_comm_init_rank(const uint8_t* id128, int32_t world, int32_t rank, int32_t device_id);
@@ -210,6 +211,8 @@ void comet_comm_destroy(int64_t comm);
 int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* cols, int64_t rows, const int32_t* key_cols, int32_t n_keys);
 int64_t comet_exchange_result_rows(int64_t result);
 int32_t comet_exchange_result_column(int64_t result, int32_t col, void** values, void** validity);   /* device pointers owned by the result */
+/* STRING / BYTES columns: the received value bytes (values = the rows + 1 rebuilt int32 offsets); NULL / 0 for other columns */
+int32_t comet_exchange_result_aux(int64_t result, int32_t col, void** bytes, int64_t* n_bytes);
 void comet_exchange_result_release(int64_t result);
 const char* comet_exchange_last_error(void);
 

@@ -1,7 +1,7 @@
 """The exchange inside libcomet.so (csrc/exchange.cpp): several ranks meet through the in-process transport (threads of one
 process — the Spark-executor shape; here all on the one GPU of the test box), every rank receives exactly the rows Spark's HashPartitioning
 sends it (murmur3 seed 42 → pmod, the oracle's restatement), sender after sender, each sender's rows in input order; NULL keys hash as Spark
-hashes them; validity survives.  The RCCL transport is driven with a 1-rank communicator (AllGather + a send/recv group to itself): symbol
+hashes them; validity survives; Utf8 columns arrive with rebuilt offsets, Boolean columns re-packed.  The RCCL transport is driven with a 1-rank communicator (AllGather + a send/recv group to itself): symbol
 binding, datatype constants and group semantics on real hardware; the N-rank run is bench.py --gpus N (tools/q3_dist.py)."""
 import threading
 
@@ -22,6 +22,10 @@ def _shard(seed, n):
         "v": pa.array([__import__("decimal").Decimal(int(x)).scaleb(-2) for x in rng.integers(-10**10, 10**10, n)], pa.decimal128(12, 2),
                       mask=(rng.random(n) < 0.1) if seed % 2 else None),
         "f": pa.array(rng.standard_normal(n)),
+        # Utf8 (empty values, multi-byte characters, a few long ones) and Boolean travel too: lengths + bytes, one byte per bit
+        "s": pa.array([("" if x % 11 == 0 else "né" * (x % 5) + str(x) + ("/" + "z" * 300 if x % 97 == 0 else "")) for x in rng.integers(0, 5000, n)],
+                      pa.string(), mask=rng.random(n) < 0.07),
+        "b": pa.array(rng.random(n) < 0.5, pa.bool_(), mask=(rng.random(n) < 0.2) if seed % 3 == 0 else None),
     })
 
 
@@ -37,13 +41,13 @@ def _expected(shards, world, key_cols):
     return out
 
 
-@pytest.mark.parametrize("world,keys", [(2, [0]), (4, [0, 1]), (3, [2])])
+@pytest.mark.parametrize("world,keys", [(2, [0]), (4, [0, 1]), (3, [2]), (3, [4]), (4, [5, 4, 0])])
 def test_local_transport_delivers_sparks_partitions(built, world, keys):
     shards = [_shard(100 + r, 20_000 + 777 * r) for r in range(world)]
     shards[-1] = shards[-1].slice(0, 0) if world == 3 else shards[-1]           # an empty sender
     want = _expected(shards, world, keys)
     got, errs = [None] * world, []
-    group = 7000 + world
+    group = 7000 + world * 16 + sum(keys)
 
     def rank_main(r):
         try:
@@ -63,7 +67,7 @@ def test_local_transport_delivers_sparks_partitions(built, world, keys):
     assert not errs, errs
     for r in range(world):
         assert got[r].num_rows == want[r].num_rows
-        for c in range(4):
+        for c in range(6):
             assert got[r].column(c).to_pylist() == want[r].column(c).to_pylist(), (r, c)
 
 
@@ -73,5 +77,5 @@ def test_rccl_transport_with_a_one_rank_communicator(built, monkeypatch):
     comm = native.NativeComm(1, 0, 0, unique_id=native.NativeComm.unique_id())
     out = comm.exchange(native.DeviceTable.from_arrow(sh), [0]).to_arrow()
     comm.close()
-    for c in range(4):
+    for c in range(6):
         assert out.column(c).to_pylist() == sh.column(c).to_pylist()
