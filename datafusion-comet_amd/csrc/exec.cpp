@@ -1222,6 +1222,7 @@ std::string ExecutionContext::metrics_proto() {
       n.metrics.emplace_back("write_time", (int64_t)shuffle_write_ns_);
       n.metrics.emplace_back("spill_count", 0);
       n.metrics.emplace_back("spilled_bytes", 0);
+      n.metrics.emplace_back("staging_peak_bytes", shuffle_staged_peak_);   // largest slab of the partition-major table held in pinned host memory
     }
     if (op.kind == OpKind::NativeScan) {
       n.metrics.emplace_back("bytes_scanned", bytes_scanned_);

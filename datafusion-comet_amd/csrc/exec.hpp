@@ -244,7 +244,7 @@ class ExecutionContext {
   std::map<const Operator*, OperatorP> range_sort_, range_bsort_;   // ShuffleWriter(range) → synthetic Sort over its rows / its boundary rows
   std::shared_ptr<void> planes_owner_;
   std::map<const Operator*, OperatorP> shuffle_projs_;   // ShuffleWriter with computed hash expressions → synthetic Projection(child ++ hash exprs)
-  int64_t shuffle_bytes_written_ = 0, shuffle_data_size_ = 0;
+  int64_t shuffle_bytes_written_ = 0, shuffle_data_size_ = 0, shuffle_staged_peak_ = 0;
   double shuffle_repart_ns_ = 0, shuffle_write_ns_ = 0;
   std::vector<int> dict_id_col_;                   // per source column: appended row-index column standing in for a long Utf8 group key
   bool device_result_ = false;                     // the grouped result stays in HBM (nested aggregate / execute_device)

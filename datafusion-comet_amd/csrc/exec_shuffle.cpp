@@ -126,54 +126,43 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
   shuffle_repart_ns_ += tm.ns();
   lap("partition (murmur3, pmod, indices, takes)");
 
-  // one download of the partition-major table
-  std::vector<std::unique_ptr<PinnedBuf>> hv(n_payload), hb(n_payload), hd(n_payload);
-  for (size_t j = 0; j < n_payload && n > 0; j++) {
-    const DType& ty = grouped.types[j];
-    const DeviceColumnView& v = grouped.cols[j];
-    if (v.offset != 0) throw CometError("ShuffleWriter: input column with a non-zero Arrow offset is not supported yet");
-    const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
-    const size_t bytes = is_str ? (size_t)(n + 1) * 4 : ty.id == TypeId::Bool ? (size_t)((n + 7) / 8) : (size_t)n * fixed_width(ty);
-    hv[j].reset(new PinnedBuf());
-    hv[j]->ensure(bytes + 8);
-    HIP_CHECK(hipMemcpyAsync(hv[j]->p, v.data, bytes, hipMemcpyDeviceToHost, stream_));
-    if (grouped.has_valid[j]) {
-      hb[j].reset(new PinnedBuf());
-      hb[j]->ensure((size_t)((n + 7) / 8) + 8);
-      HIP_CHECK(hipMemcpyAsync(hb[j]->p, v.valid, (size_t)((n + 7) / 8), hipMemcpyDeviceToHost, stream_));
-    }
-  }
-  HIP_CHECK(hipStreamSynchronize(stream_));
-  for (size_t j = 0; j < n_payload && n > 0; j++) {
-    const DType& ty = grouped.types[j];
-    if (ty.id != TypeId::String && ty.id != TypeId::Bytes) continue;
-    const int32_t* offs = (const int32_t*)hv[j]->p;
-    if (offs[0] != 0) throw CometError("ShuffleWriter: Utf8 column whose offsets do not start at 0");
-    hd[j].reset(new PinnedBuf());
-    hd[j]->ensure((size_t)offs[n] + 8);
-    if (offs[n]) HIP_CHECK(hipMemcpyAsync(hd[j]->p, grouped.cols[j].aux, (size_t)offs[n], hipMemcpyDeviceToHost, stream_));
-  }
-  HIP_CHECK(hipStreamSynchronize(stream_));
-
-  lap("download");
-  // frame every partition on the host threads
+  // The partition-major table stays in HBM; it crosses to the host in SLABS of consecutive blocks (≈ staging_bytes of column data, two
+  // pinned staging sets: slab k+1 is downloading while slab k is framed and written), so the writer's host footprint is bounded by the
+  // staging size whatever the task's output — the role spilling plays in the reference's writer (multi_partition.rs:439-457), without
+  // the temporary files: partitions are contiguous row ranges here, so the data file is written front to back in one pass.
   const int64_t bs = batch_size_ > 0 ? batch_size_ : std::max<int64_t>(n, 1);
   const ShuffleCodec codec = (ShuffleCodec)sw.shuffle_codec;
+  size_t staging_bytes = (size_t)256 << 20;
+  for (auto& kv : config_)
+    if (kv.first == "spark.comet.gpu.shuffle.stagingBytes") staging_bytes = (size_t)std::max<long long>(1 << 16, atoll(kv.second.c_str()));
+  if (const char* e = getenv("COMET_SHUFFLE_STAGING_BYTES")) staging_bytes = (size_t)std::max<long long>(1 << 16, atoll(e));
+  size_t row_bytes = 0;
+  std::vector<char> is_str(n_payload, 0);
+  for (size_t j = 0; j < n_payload; j++) {
+    const DType& ty = grouped.types[j];
+    const DeviceColumnView& v = grouped.cols[j];
+    if (n > 0 && v.offset != 0) throw CometError("ShuffleWriter: input column with a non-zero Arrow offset is not supported yet");
+    is_str[j] = ty.id == TypeId::String || ty.id == TypeId::Bytes;
+    if (is_str[j]) {
+      int32_t ends[2] = {0, 0};
+      if (n > 0) {
+        read_small(&ends[0], v.data, 4);
+        read_small(&ends[1], (const char*)v.data + (size_t)n * 4, 4);
+        if (ends[0] != 0) throw CometError("ShuffleWriter: Utf8 column whose offsets do not start at 0");
+      }
+      row_bytes += 4 + (n > 0 ? (size_t)(ends[1] / n) + 1 : 0);
+    } else {
+      row_bytes += ty.id == TypeId::Bool ? 1 : (size_t)fixed_width(ty);
+    }
+    if (grouped.has_valid[j]) row_bytes += 1;
+  }
   const double write_t0 = tm.ns();
-  // Blocks in file order — (partition, first row, rows) — grouped into runs of consecutive blocks of ≈4 MiB of column data.  The
-  // scan threads encode whole runs (one output buffer per run, allocated once); this thread writes finished runs to the data
-  // file in order while later runs are still being encoded.
+  // Blocks in file order — (partition, first row, rows) — grouped into runs of consecutive blocks of ≈4 MiB of column data (the unit a
+  // scan thread encodes into one output buffer), runs grouped into slabs.
   struct BlockTask { int p; int64_t first, rows; };
   std::vector<BlockTask> tasks;
   for (int p = 0; p < P; p++)
     for (int64_t r = starts[(size_t)p]; r < starts[(size_t)p + 1]; r += bs) tasks.push_back({p, r, std::min(bs, starts[(size_t)p + 1] - r)});
-  size_t row_bytes = 0;
-  for (size_t j = 0; j < n_payload; j++) {
-    const DType& ty = grouped.types[j];
-    const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
-    row_bytes += is_str ? 4 + (n > 0 ? (size_t)(((const int32_t*)hv[j]->p)[n] / n) + 1 : 0) : ty.id == TypeId::Bool ? 1 : (size_t)fixed_width(ty);
-    if (hb[j]) row_bytes += 1;
-  }
   struct Run {
     size_t first = 0, last = 0;      // tasks [first, last)
     std::vector<uint8_t> bytes;
@@ -182,91 +171,216 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
     bool done = false;
     double encode_ms = 0;
   };
+  struct Slab {
+    size_t run0 = 0, run1 = 0;       // runs [run0, run1)
+    int64_t base = 0, end = 0;       // rows [base, end) are staged; base is a multiple of 8 (bitmaps are copied from a byte boundary)
+  };
   std::vector<Run> runs;
-  for (size_t t = 0; t < tasks.size();) {
-    size_t e = t, acc = 0;
-    while (e < tasks.size() && acc < (size_t)(4 << 20)) acc += (size_t)tasks[e++].rows * std::max<size_t>(row_bytes, 1);
-    Run r;
-    r.first = t;
-    r.last = e;
-    runs.push_back(std::move(r));
-    t = e;
+  std::vector<Slab> slabs;
+  {
+    const size_t rb = std::max<size_t>(row_bytes, 1);
+    const size_t run_target = std::min<size_t>((size_t)4 << 20, std::max<size_t>(staging_bytes / 64, (size_t)64 << 10));   // ≥ 64 runs per slab keep every scan thread busy
+    size_t slab_acc = 0;
+    for (size_t t = 0; t < tasks.size();) {
+      size_t e = t, acc = 0;
+      while (e < tasks.size() && acc < run_target) acc += (size_t)tasks[e++].rows * rb;
+      Run r;
+      r.first = t;
+      r.last = e;
+      if (slabs.empty() || slab_acc + acc > staging_bytes) {
+        Slab sl;
+        sl.run0 = runs.size();
+        sl.base = tasks[t].first & ~(int64_t)7;
+        slabs.push_back(sl);
+        slab_acc = 0;
+      }
+      slab_acc += acc;
+      runs.push_back(std::move(r));
+      slabs.back().run1 = runs.size();
+      slabs.back().end = tasks[e - 1].first + tasks[e - 1].rows;
+      t = e;
+    }
   }
+  // Utf8 columns: the byte range of every slab (offsets at its first and last row), fetched up front so a slab is ONE group of copies
+  std::vector<std::vector<int32_t>> str_lo(n_payload), str_hi(n_payload);
+  {
+    PinnedBuf hb;
+    size_t n_str = 0;
+    for (size_t j = 0; j < n_payload; j++) n_str += is_str[j];
+    hb.ensure(n_str * slabs.size() * 8 + 16);
+    size_t k = 0;
+    for (size_t j = 0; j < n_payload; j++) {
+      if (!is_str[j]) continue;
+      for (auto& sl : slabs) {
+        HIP_CHECK(hipMemcpyAsync((char*)hb.p + k * 4, (const char*)grouped.cols[j].data + (size_t)sl.base * 4, 4, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync((char*)hb.p + k * 4 + 4, (const char*)grouped.cols[j].data + (size_t)sl.end * 4, 4, hipMemcpyDeviceToHost, stream_));
+        k += 2;
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    k = 0;
+    for (size_t j = 0; j < n_payload; j++) {
+      if (!is_str[j]) continue;
+      for (size_t q = 0; q < slabs.size(); q++, k += 2) {
+        str_lo[j].push_back(((const int32_t*)hb.p)[k]);
+        str_hi[j].push_back(((const int32_t*)hb.p)[k + 1]);
+      }
+    }
+  }
+  struct Staging {
+    std::vector<std::unique_ptr<PinnedBuf>> hv, hb, hd;
+    hipEvent_t ready = nullptr;
+  };
+  Staging stage[2];
+  for (auto& sg : stage) {
+    sg.hv.resize(n_payload); sg.hb.resize(n_payload); sg.hd.resize(n_payload);
+    HIP_CHECK(hipEventCreateWithFlags(&sg.ready, hipEventDisableTiming));
+  }
+  struct EventGuard { Staging* s; ~EventGuard() { for (int i = 0; i < 2; i++) if (s[i].ready) (void)hipEventDestroy(s[i].ready); } } event_guard{stage};
+  size_t staged_peak = 0;
+  auto download = [&](size_t q) {
+    const Slab& sl = slabs[q];
+    Staging& sg = stage[q & 1];
+    const int64_t rows = sl.end - sl.base;
+    size_t total = 0;
+    for (size_t j = 0; j < n_payload; j++) {
+      const DType& ty = grouped.types[j];
+      const DeviceColumnView& v = grouped.cols[j];
+      size_t skip, bytes;
+      if (is_str[j]) { skip = (size_t)sl.base * 4; bytes = (size_t)(rows + 1) * 4; }
+      else if (ty.id == TypeId::Bool) { skip = (size_t)(sl.base / 8); bytes = (size_t)((rows + 7) / 8); }
+      else { skip = (size_t)sl.base * (size_t)fixed_width(ty); bytes = (size_t)rows * (size_t)fixed_width(ty); }
+      if (!sg.hv[j]) sg.hv[j].reset(new PinnedBuf());
+      sg.hv[j]->ensure(bytes + 8);
+      HIP_CHECK(hipMemcpyAsync(sg.hv[j]->p, (const char*)v.data + skip, bytes, hipMemcpyDeviceToHost, stream_));
+      total += bytes;
+      if (grouped.has_valid[j]) {
+        if (!sg.hb[j]) sg.hb[j].reset(new PinnedBuf());
+        sg.hb[j]->ensure((size_t)((rows + 7) / 8) + 8);
+        HIP_CHECK(hipMemcpyAsync(sg.hb[j]->p, (const char*)v.valid + (size_t)(sl.base / 8), (size_t)((rows + 7) / 8), hipMemcpyDeviceToHost, stream_));
+        total += (size_t)((rows + 7) / 8);
+      }
+      if (is_str[j]) {
+        const size_t nb = (size_t)(str_hi[j][q] - str_lo[j][q]);
+        if (!sg.hd[j]) sg.hd[j].reset(new PinnedBuf());
+        sg.hd[j]->ensure(nb + 8);
+        if (nb) HIP_CHECK(hipMemcpyAsync(sg.hd[j]->p, (const char*)v.aux + (size_t)str_lo[j][q], nb, hipMemcpyDeviceToHost, stream_));
+        total += nb;
+      }
+    }
+    HIP_CHECK(hipEventRecord(sg.ready, stream_));
+    staged_peak = std::max(staged_peak, total);
+  };
   std::mutex mu;
   std::condition_variable cv;
-  for (size_t ri = 0; ri < runs.size(); ri++) {
-    scan_pool_submit([&, ri]() {
-      Run& r = runs[ri];
-      Timer rt;
-      try {
-        size_t est = 0;
-        for (size_t t = r.first; t < r.last; t++) est += (size_t)tasks[t].rows * row_bytes + 2048;
-        r.bytes.reserve(est + est / 8 + (64 << 10));
-        std::vector<ColumnSlice> cols(n_payload);
-        for (size_t j = 0; j < n_payload; j++) {
-          cols[j].type = grouped.types[j];
-          cols[j].validity = hb[j] ? (const uint8_t*)hb[j]->p : nullptr;
-          cols[j].values = hv[j]->p;
-          cols[j].data = hd[j] ? (const uint8_t*)hd[j]->p : nullptr;
+  auto submit = [&](size_t q) {      // the slab's copies are complete: its runs go to the scan threads
+    const Slab& sl = slabs[q];
+    const Staging* sg = &stage[q & 1];
+    for (size_t ri = sl.run0; ri < sl.run1; ri++) {
+      scan_pool_submit([&, ri, sg, q, base = sl.base]() {
+        Run& r = runs[ri];
+        Timer rt;
+        try {
+          size_t est = 0;
+          for (size_t t = r.first; t < r.last; t++) est += (size_t)tasks[t].rows * row_bytes + 2048;
+          r.bytes.reserve(est + est / 8 + (64 << 10));
+          std::vector<ColumnSlice> cols(n_payload);
+          for (size_t j = 0; j < n_payload; j++) {
+            cols[j].type = grouped.types[j];
+            cols[j].validity = sg->hb[j] ? (const uint8_t*)sg->hb[j]->p : nullptr;
+            cols[j].values = sg->hv[j]->p;
+            cols[j].data = sg->hd[j] ? (const uint8_t*)sg->hd[j]->p : nullptr;
+            cols[j].data_origin = is_str[j] ? str_lo[j][q] : 0;
+          }
+          for (size_t t = r.first; t < r.last; t++) {
+            for (auto& c : cols) c.first = tasks[t].first - base;
+            r.block_size.push_back(encode_shuffle_block(cols, tasks[t].rows, codec, sw.shuffle_compression_level, r.bytes));
+          }
+        } catch (const std::exception& e) {
+          r.error = e.what();
+        } catch (...) {
+          r.error = "shuffle writer: unknown error while encoding a block";
         }
-        for (size_t t = r.first; t < r.last; t++) {
-          for (auto& c : cols) c.first = tasks[t].first;
-          r.block_size.push_back(encode_shuffle_block(cols, tasks[t].rows, codec, sw.shuffle_compression_level, r.bytes));
+        r.encode_ms = rt.ns() / 1e6;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          r.done = true;
         }
-      } catch (const std::exception& e) {
-        r.error = e.what();
-      } catch (...) {
-        r.error = "shuffle writer: unknown error while encoding a block";
-      }
-      r.encode_ms = rt.ns() / 1e6;
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        r.done = true;
-      }
-      cv.notify_all();
-    });
-  }
+        cv.notify_all();
+      });
+    }
+  };
   const int fd = open(sw.shuffle_data_file.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
   std::string failure;
   if (fd < 0) failure = "shuffle write error: cannot create " + sw.shuffle_data_file + ": " + strerror(errno);
   std::vector<int64_t> offsets((size_t)P + 1, 0);
   int64_t file_pos = 0;
   int next_p = 0;
-  double wait_ms = 0, write_ms = 0, enc_sum = 0, enc_max = 0;
-  for (size_t ri = 0; ri < runs.size(); ri++) {   // every run is waited for, also after a failure: the tasks reference this frame
-    Run& r = runs[ri];
-    {
-      Timer wt;
-      std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return r.done; });
-      wait_ms += wt.ns() / 1e6;
-    }
-    enc_sum += r.encode_ms;
-    enc_max = std::max(enc_max, r.encode_ms);
-    Timer wrt;
-    if (failure.empty() && !r.error.empty()) failure = r.error;
-    if (!failure.empty()) continue;
-    int64_t pos = file_pos;
-    for (size_t t = r.first; t < r.last; t++) {
-      while (next_p <= tasks[t].p) offsets[(size_t)next_p++] = pos;
-      pos += (int64_t)r.block_size[t - r.first];
-    }
-    size_t done = 0;
-    while (done < r.bytes.size()) {
-      const ssize_t w = write(fd, r.bytes.data() + done, r.bytes.size() - done);
-      if (w <= 0) {
-        failure = "shuffle write error: " + std::string(strerror(errno)) + " (" + sw.shuffle_data_file + ")";
-        break;
+  double wait_ms = 0, write_ms = 0, enc_sum = 0, enc_max = 0, copy_wait_ms = 0;
+  size_t submitted = 0;                   // slabs whose runs have been handed to the scan threads (every one of them must be waited for)
+  auto wait_runs = [&](size_t q) {        // write slab q's runs to the data file in order, as they finish
+    for (size_t ri = slabs[q].run0; ri < slabs[q].run1; ri++) {
+      Run& r = runs[ri];
+      {
+        Timer wt;
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return r.done; });
+        wait_ms += wt.ns() / 1e6;
       }
-      done += (size_t)w;
+      enc_sum += r.encode_ms;
+      enc_max = std::max(enc_max, r.encode_ms);
+      Timer wrt;
+      if (failure.empty() && !r.error.empty()) failure = r.error;
+      if (!failure.empty()) continue;
+      int64_t pos = file_pos;
+      for (size_t t = r.first; t < r.last; t++) {
+        while (next_p <= tasks[t].p) offsets[(size_t)next_p++] = pos;
+        pos += (int64_t)r.block_size[t - r.first];
+      }
+      size_t done = 0;
+      while (done < r.bytes.size()) {
+        const ssize_t w = write(fd, r.bytes.data() + done, r.bytes.size() - done);
+        if (w <= 0) {
+          failure = "shuffle write error: " + std::string(strerror(errno)) + " (" + sw.shuffle_data_file + ")";
+          break;
+        }
+        done += (size_t)w;
+      }
+      file_pos = pos;
+      std::vector<uint8_t>().swap(r.bytes);
+      write_ms += wrt.ns() / 1e6;
     }
-    file_pos = pos;
-    std::vector<uint8_t>().swap(r.bytes);
-    write_ms += wrt.ns() / 1e6;
+  };
+  try {
+    if (!slabs.empty() && failure.empty()) download(0);
+    for (size_t q = 0; q < slabs.size() && failure.empty(); q++) {
+      {
+        Timer ct;
+        HIP_CHECK(hipEventSynchronize(stage[q & 1].ready));
+        copy_wait_ms += ct.ns() / 1e6;
+      }
+      submit(q);
+      submitted = q + 1;
+      if (q >= 1) wait_runs(q - 1);                      // staging set (q+1)&1 is free again …
+      if (q + 1 < slabs.size() && failure.empty()) download(q + 1);   // … and refilled while slab q is being framed
+    }
+    if (submitted) wait_runs(submitted - 1);
+  } catch (...) {
+    // the scan threads reference this frame: every submitted run is waited for before the error leaves
+    for (size_t q = 0; q < submitted; q++)
+      for (size_t ri = slabs[q].run0; ri < slabs[q].run1; ri++) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return runs[ri].done; });
+      }
+    (void)hipStreamSynchronize(stream_);
+    if (fd >= 0) close(fd);
+    throw;
   }
+  HIP_CHECK(hipStreamSynchronize(stream_));
   if (trace)
-    fprintf(stderr, "[comet] shuffle write: %zu runs, encode cpu %.1f ms total (max %.2f ms/run), writer waited %.1f ms, wrote for %.1f ms\n", runs.size(),
-            enc_sum, enc_max, wait_ms, write_ms);
+    fprintf(stderr, "[comet] shuffle write: %zu slabs (≤ %.1f MiB staged), %zu runs, encode cpu %.1f ms total (max %.2f ms/run), writer waited %.1f ms for runs, "
+            "%.1f ms for copies, wrote for %.1f ms\n", slabs.size(), staged_peak / 1048576.0, runs.size(), enc_sum, enc_max, wait_ms, copy_wait_ms, write_ms);
+  shuffle_staged_peak_ = std::max<int64_t>(shuffle_staged_peak_, (int64_t)staged_peak);
   while (next_p <= P) offsets[(size_t)next_p++] = file_pos;
   if (fd >= 0 && close(fd) != 0 && failure.empty()) failure = "shuffle write error: closing " + sw.shuffle_data_file + " failed";
   if (!failure.empty()) throw CometError(failure);

@@ -698,7 +698,7 @@ void write_batch_message(const std::vector<ColumnSlice>& cols, int64_t rows, std
       int32_t* o = (int32_t*)(body.data() + at);
       for (int64_t i = 0; i <= rows; i++) o[i] = offs[i] - base;
       while (body.size() % 8) body.push_back(0);
-      add_buffer(c.data + base, (size_t)(offs[rows] - base));
+      add_buffer(c.data + ((int64_t)base - c.data_origin), (size_t)(offs[rows] - base));
     } else if (c.type.id == TypeId::Bool) {
       slice_bits((const uint8_t*)c.values, c.first, rows, bits);
       add_buffer(bits.data(), bits.size());

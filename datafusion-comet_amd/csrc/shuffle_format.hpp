@@ -25,7 +25,8 @@ struct ColumnSlice {
   DType type;
   const uint8_t* validity = nullptr;   // bitmap addressed from row 0 of the buffers, or nullptr (no nulls)
   const void* values = nullptr;        // fixed-width values / boolean bits / int32 offsets, addressed from row 0
-  const uint8_t* data = nullptr;       // Utf8 / Binary bytes
+  const uint8_t* data = nullptr;       // Utf8 / Binary bytes: data[0] is byte `data_origin` of the column's value bytes
+  int64_t data_origin = 0;
   int64_t first = 0;
 };
 

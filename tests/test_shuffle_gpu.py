@@ -78,6 +78,24 @@ def test_hash_partitioned_files_match_oracle(built, tmp_path, codec):
     _check_files(data, index, t, rows, 4096, codec)
 
 
+def test_small_staging_slabs_write_the_same_files(built, tmp_path, monkeypatch):
+    """The partition-major table crosses to the host in slabs through two pinned staging sets (the writer's bounded host footprint, in
+    place of the reference's spill files): with a 64 KiB staging size the task below is ~100 slabs whose boundaries fall inside
+    partitions, inside bitmap bytes and inside the Utf8 bytes — the files are byte for byte the ones a single slab writes."""
+    from oracle import shuffle_oracle as SO
+    t = _table(120_000, seed=77)
+    kw = dict(partitioning="hash", hash_exprs=[S.col(0, FIELDS[0]), S.col(6, FIELDS[6])], num_partitions=13, codec=S.CODEC_NONE, batch_size=1000)
+    d1, d2 = tmp_path / "one", tmp_path / "many"
+    d1.mkdir(); d2.mkdir()
+    data1, index1 = _write(S.scan(FIELDS), [t], d1, **kw)
+    monkeypatch.setenv("COMET_SHUFFLE_STAGING_BYTES", str(64 << 10))
+    data2, index2 = _write(S.scan(FIELDS), [t], d2, **kw)
+    assert open(index1, "rb").read() == open(index2, "rb").read()
+    assert open(data1, "rb").read() == open(data2, "rb").read()
+    _, _, rows = SO.shuffle_write(S, t, "hash", [0, 6], 13, 1000)
+    _check_files(data2, index2, t, rows, 1000, S.CODEC_NONE)
+
+
 def test_many_partitions_decimal_and_date_keys(built, tmp_path):
     from oracle import shuffle_oracle as SO
     t = _table(100_000, seed=4)
