@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--rows", type=int, default=SF100_ROWS, help="lineitem rows per GPU (default: SF100)")
     ap.add_argument("--cpu-sample-rows", type=int, default=8_000_000, help="rows per CPU thread for the cpu_baseline legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-string-hints", action="store_true", help="do not declare the CHAR(1) key columns' fixed length in the Arrow field metadata")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-paths", action="store_true", help="skip the host-stream / Parquet path legs")
     ap.add_argument("--path-rows", type=int, default=20_000_000)
@@ -88,13 +89,18 @@ def main():
     plan = tpch.q1_plan()
     plan_bytes = plan.encode()
     n = args.rows
-    dtab, chk = tpch.lineitem_q1_device(n, device=dev, seed=1 + rank)
+    dtab_plain, chk = tpch.lineitem_q1_device(n, device=dev, seed=1 + rank)
+    # The resident shard is immutable for the life of the bench: its owner measures ONCE that the two CHAR(1) key columns hold one byte per
+    # value and says so in the Arrow field metadata (comet:utf8_fixed_len); the engine then checks the end points per task instead of
+    # re-reading 4 B/row of offsets ("cache the Utf8 uniform-length verdict per buffer").  The same loop WITHOUT the
+    # metadata is timed below and reported next to the headline.
+    dtab = dtab_plain if args.no_string_hints else dtab_plain.with_string_hints()
     torch.cuda.synchronize()
     ncols = tpch.Q1_NUM_OUTPUT_COLS
 
-    def step():
+    def step(table=None):
         # one Spark task: createPlan → executePlan until -1 → releasePlan over the rank's resident shard
-        it = native.CometExecIterator([native.DeviceInput(dtab, device_id=local_rank)], ncols, plan_bytes, device_id=local_rank)
+        it = native.CometExecIterator([native.DeviceInput(table if table is not None else dtab, device_id=local_rank)], ncols, plan_bytes, device_id=local_rank)
         out = []
         while True:
             b = native.Native.executePlan(it.handle, ncols)
@@ -127,6 +133,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # the same tasks over the table WITHOUT the fixed-length metadata (every task verifies the offsets of both key columns on the device)
+    elapsed_unhinted = None
+    if not args.no_string_hints:
+        step(dtab_plain)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(dtab_plain)
+        barrier()
+        elapsed_unhinted = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([elapsed_unhinted], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed_unhinted = float(tmax.item())
+
     # ---- outside the timed region -------------------------------------------------------------------------------------------
     # (1) every aggregate of every group of this rank's Partial states against exact torch reductions of the generating tensors
     out_tab = pa.Table.from_batches(result)
@@ -148,7 +169,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, dtab, plan_bytes, local_rank)
 
-    del dtab, chk
+    del dtab, dtab_plain, chk
     torch.cuda.empty_cache()
 
     legs = {}
@@ -193,7 +214,13 @@ def main():
                 "traffic": traffic, "kernel": "k_gagg", "kernel_ms": avg_kernel_ms, "launches_timed": launches,
                 "algorithmic_bytes": algo_bytes,
                 "task_level": {"ms": ms_per_step, "algorithmic_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9,
-                               "frac": algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                               "frac": algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "utf8_fixed_len_metadata": not args.no_string_hints}}
+        if elapsed_unhinted is not None:
+            ms_u = elapsed_unhinted / args.steps * 1e3
+            roof["task_level_offsets_verified_every_task"] = {
+                "ms": ms_u, "rows_per_s": n * world * args.steps / elapsed_unhinted, "frac": algo_bytes / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "same tasks over the same shard without the comet:utf8_fixed_len field metadata: each task re-reads the offsets of both key columns"}
         if traffic:
             roof["physical"] = {"GBps": traffic / (avg_kernel_ms * 1e-3) / 1e9, "frac": traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "bytes_per_row": traffic / n, "note": pmc.get("note")}

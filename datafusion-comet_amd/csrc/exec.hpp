@@ -164,6 +164,7 @@ class ExecutionContext {
  private:
   void run_to_completion();
   void start();
+  std::vector<std::vector<int>> fixed_len_hint_;   // per device input, per column: producer-asserted uniform Utf8 length, -1 = none
   Variant& variant_for(const std::vector<bool>& has_valid, const std::vector<int>& str_fixed_len);
   void process_chunk(const std::vector<DeviceColumnView>& cols, const std::vector<bool>& has_valid, int64_t n);
   void finish_aggregate();
@@ -286,6 +287,7 @@ class ExecutionContext {
   int64_t group_cap_ = 0;
   DevBuf scratch_mask_, scratch_counts_;
   std::vector<std::unique_ptr<DevBuf>> out_vals_, out_valid_;
+  DevBuf emit_arena_;   // finish_grouped: values + validity bytes of every output column of one emit
 
   std::deque<HostBatch> ready_;
   int64_t output_rows_ = 0;

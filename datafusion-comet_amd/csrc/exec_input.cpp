@@ -16,6 +16,32 @@ void ExecutionContext::validate_input_schema(size_t input, const std::vector<DTy
   int rc = in.kind == 0 ? in.host->get_schema(in.host, &sch) : in.dev->get_schema(in.dev, &sch);
   if (rc != 0 || !sch.release) throw CometError("input stream: get_schema failed");
   std::string err;
+  if (in.kind == 1 && (size_t)sch.n_children == types.size()) {
+    // Producer hint on a device-resident Utf8 field: metadata "comet:utf8_fixed_len" = L asserts that every value occupies exactly L
+    // bytes (the owner of an immutable resident table measures that once — native.DeviceTable.with_string_hints — instead of every
+    // task re-reading 4 B/row of offsets).  The end points are still checked per batch (pull_device_table).
+    if (fixed_len_hint_.size() <= input) fixed_len_hint_.resize(input + 1);
+    fixed_len_hint_[input].assign(types.size(), -1);
+    for (size_t c = 0; c < types.size(); c++) {
+      const char* md = sch.children[c]->metadata;
+      if (!md || types[c].id != TypeId::String) continue;
+      int32_t npairs;
+      memcpy(&npairs, md, 4);
+      const char* q = md + 4;
+      for (int32_t k = 0; k < npairs; k++) {
+        int32_t kl, vl;
+        memcpy(&kl, q, 4);
+        const char* key = q + 4;
+        memcpy(&vl, key + kl, 4);
+        const char* val = key + kl + 4;
+        if (kl == 20 && !memcmp(key, "comet:utf8_fixed_len", 20) && vl > 0 && vl < 4) {
+          const int L = atoi(std::string(val, (size_t)vl).c_str());
+          if (L >= 0 && L <= 15) fixed_len_hint_[input][c] = L;
+        }
+        q = val + vl;
+      }
+    }
+  }
   if ((size_t)sch.n_children != types.size()) {
     err = "Scan declares " + std::to_string(types.size()) + " field(s) but the input stream has " + std::to_string(sch.n_children);
   } else {
@@ -479,6 +505,15 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
     for (size_t k = 0; k < scols.size(); k++) {
       first[k] = ends[2 * k];
       const int64_t total = (int64_t)ends[2 * k + 1] - ends[2 * k];
+      const int hint = input < fixed_len_hint_.size() && scols[k] < fixed_len_hint_[input].size() ? fixed_len_hint_[input][scols[k]] : -1;
+      if (hint >= 0) {
+        // the producer vouches for the offsets in between; a batch whose end points contradict it is refused
+        if (total != (int64_t)hint * rows)
+          throw CometError("device input column " + std::to_string(scols[k]) + " is declared comet:utf8_fixed_len=" + std::to_string(hint) + " but holds " +
+                           std::to_string(total) + " bytes in " + std::to_string(rows) + " rows");
+        if ((int64_t)first[k] == (int64_t)da->array.children[scols[k]]->offset * hint) views[scols[k]].fixed_len = hint;
+        continue;
+      }
       if (total % rows != 0 || total / rows > 15 || total < 0) continue;
       const ArrowArray* col = da->array.children[scols[k]];
       const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;

@@ -400,8 +400,14 @@ void ExecutionContext::finish_grouped() {
   Variant& v = *agg_variant_;
   const PipelineDesc& d = v.desc;
   uint64_t ngroups = 0;
-  read_small(&ngroups, (char*)err_flags_.p + 8, 8);
-  check_device_errors();
+  {
+    // error flags (word 0) and the group count (bytes 8-15) come back with ONE small copy
+    uint32_t head[4] = {0, 0, 0, 0};
+    read_small(head, err_flags_.p, 16);
+    collect_timings();
+    raise_device_errors(head[0]);
+    memcpy(&ngroups, head + 2, 8);
+  }
   if (ngroups == 0) return;
   if (!dict_id_col_.empty()) {
     // keys that travelled as row indices: gather the strings on the device, then copy the finished table out
@@ -418,38 +424,45 @@ void ExecutionContext::finish_grouped() {
   HIP_CHECK(hipMemsetAsync(scratch_counts_.p, 0, 8, stream_));
   prm.out[1] = scratch_counts_.p;
   prm.out[kOutErr] = err_flags_.p;
-  out_vals_.resize(ncol);
-  out_valid_.resize(ncol);
+  // Every output column of the emit lives in ONE device arena — [values of column 0 … values of column n-1][validity bytes of all
+  // columns] — so the validity defaults are one memset and the results come back with one D2H copy into one pinned buffer (a Q1-shaped
+  // aggregate emits 10 columns of a handful of groups: 20 memsets + 20 copies of a few bytes each were ~0.25 ms of a 7.8 ms task).
   std::vector<int> widths(ncol);
+  std::vector<size_t> val_off(ncol);
+  size_t arena = 0;
   for (size_t j = 0; j < ncol; j++) {
-    if (!out_vals_[j]) out_vals_[j].reset(new DevBuf());
-    if (!out_valid_[j]) out_valid_[j].reset(new DevBuf());
     const OutCol& oc = d.out_cols[j];
     widths[j] = oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type));
-    out_vals_[j]->ensure((size_t)ngroups * widths[j] + 16);
-    out_valid_[j]->ensure((size_t)ngroups + 16);
-    HIP_CHECK(hipMemsetAsync(out_valid_[j]->p, 1, (size_t)ngroups, stream_));
-    prm.out[kOutFirstCol + 2 * j] = out_vals_[j]->p;
-    prm.out[kOutFirstCol + 2 * j + 1] = out_valid_[j]->p;
+    val_off[j] = arena;
+    arena += ((size_t)ngroups * (size_t)widths[j] + 15) & ~(size_t)15;
+  }
+  const size_t valid_base = arena, valid_stride = ((size_t)ngroups + 15) & ~(size_t)15;
+  arena += valid_stride * ncol;
+  emit_arena_.ensure(arena + 16);
+  HIP_CHECK(hipMemsetAsync((char*)emit_arena_.p + valid_base, 1, valid_stride * ncol, stream_));
+  for (size_t j = 0; j < ncol; j++) {
+    prm.out[kOutFirstCol + 2 * j] = (char*)emit_arena_.p + val_off[j];
+    prm.out[kOutFirstCol + 2 * j + 1] = (char*)emit_arena_.p + valid_base + j * valid_stride;
   }
   prm.iarg[kFixScaleArg] = packed_fix_scales(d);
   launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
-  // results come back through pooled pinned buffers (a pageable destination would be staged by the runtime at a fraction of the rate)
+  // results come back through a pooled pinned buffer (a pageable destination would be staged by the runtime at a fraction of the rate)
   struct HostSpan {
-    PinnedBuf buf;
+    const uint8_t* p = nullptr;
     size_t n = 0;
-    const uint8_t* data() const { return (const uint8_t*)buf.p; }
-    const uint8_t* begin() const { return data(); }
-    uint8_t operator[](size_t i) const { return data()[i]; }
+    const uint8_t* data() const { return p; }
+    const uint8_t* begin() const { return p; }
+    uint8_t operator[](size_t i) const { return p[i]; }
   };
+  PinnedBuf host_arena;
+  host_arena.ensure(arena + 16);
+  HIP_CHECK(hipMemcpyAsync(host_arena.p, emit_arena_.p, arena, hipMemcpyDeviceToHost, stream_));
   std::vector<HostSpan> hv(ncol), hk(ncol);
   for (size_t j = 0; j < ncol; j++) {
+    hv[j].p = (const uint8_t*)host_arena.p + val_off[j];
     hv[j].n = (size_t)ngroups * widths[j];
+    hk[j].p = (const uint8_t*)host_arena.p + valid_base + j * valid_stride;
     hk[j].n = (size_t)ngroups;
-    hv[j].buf.ensure(hv[j].n + 16);
-    hk[j].buf.ensure(hk[j].n + 16);
-    HIP_CHECK(hipMemcpyAsync(hv[j].buf.p, out_vals_[j]->p, hv[j].n, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipMemcpyAsync(hk[j].buf.p, out_valid_[j]->p, hk[j].n, hipMemcpyDeviceToHost, stream_));
   }
   HIP_CHECK(hipStreamSynchronize(stream_));
   check_device_errors();

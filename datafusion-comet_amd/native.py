@@ -245,6 +245,33 @@ class DeviceTable:
                 aux.append(None)
         return DeviceTable(table.schema, table.num_rows, vals, valid, device, aux)
 
+    def with_string_hints(self) -> "DeviceTable":
+        """The same resident table with field metadata ``comet:utf8_fixed_len`` = L on every Utf8 column whose values all occupy exactly L ≤ 15
+        bytes (TPC-H's CHAR(1) flags).  The owner of an immutable resident table measures this ONCE here; the engine then checks only the end
+        points of each batch instead of re-reading 4 B/row of offsets in every task (exec_input.cpp pull_device_table).  The metadata is an
+        assertion by the producer: set it only on buffers that do not change while the table is in use."""
+        import torch
+        fields = []
+        for i, f in enumerate(self.schema):
+            if pa.types.is_string(f.type) and self.num_rows > 0:
+                offs = self.values[i].view(torch.int32)[: self.num_rows + 1]
+                total = int(offs[-1]) - int(offs[0])
+                L = total // self.num_rows
+                if int(offs[0]) == 0 and total == L * self.num_rows and L <= 15:
+                    ok = True
+                    step = 1 << 26
+                    for a in range(0, self.num_rows, step):     # in slices: no n-sized temporaries next to a table that fills the HBM
+                        b = min(self.num_rows, a + step)
+                        ok = ok and bool(((offs[a + 1:b + 1] - offs[a:b]) == L).all())
+                        if not ok:
+                            break
+                    if ok:
+                        md = dict(f.metadata or {})
+                        md[b"comet:utf8_fixed_len"] = str(L).encode()
+                        f = f.with_metadata(md)
+            fields.append(f)
+        return DeviceTable(pa.schema(fields, metadata=self.schema.metadata), self.num_rows, self.values, self.validity, self.device, self.aux)
+
     def nbytes(self) -> int:
         return (sum(v.numel() for v in self.values) + sum(v.numel() for v in self.validity if v is not None)
                 + sum(v.numel() for v in self.aux if v is not None))

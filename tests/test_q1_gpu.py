@@ -46,6 +46,28 @@ def test_q1_device_resident_matches_oracle(built):
     assert _rows(got) == _rows(want)
 
 
+def test_q1_device_resident_with_fixed_length_metadata(built):
+    """The owner of a resident table may declare a Utf8 column's uniform value length in the field metadata (comet:utf8_fixed_len, measured
+    once by DeviceTable.with_string_hints); the engine then checks the end points only.  Same answer as without the metadata; a declaration
+    the batch's end points contradict is refused; columns whose lengths vary get no metadata."""
+    table = tpch.lineitem_q1(300_000, seed=11)
+    plan = tpch.q1_plan()
+    dev = native.DeviceTable.from_arrow(table, "cuda:0")
+    hinted = dev.with_string_hints()
+    flagged = [f.name for f in hinted.schema if f.metadata and b"comet:utf8_fixed_len" in f.metadata]
+    assert len(flagged) == 2 and all(hinted.schema.field(n).metadata[b"comet:utf8_fixed_len"] == b"1" for n in flagged)
+    got = _run(plan, [native.DeviceInput(hinted)], tpch.Q1_NUM_OUTPUT_COLS)
+    assert _rows(got) == _rows(_oracle(plan, table))
+    # a wrong declaration (2 bytes per value over one-byte values) does not survive the end-point check
+    lying = native.DeviceTable(pa.schema([f.with_metadata({b"comet:utf8_fixed_len": b"2"}) if f.name in flagged else f for f in dev.schema]),
+                               dev.num_rows, dev.values, dev.validity, dev.device, dev.aux)
+    with pytest.raises(native.CometNativeException, match="comet:utf8_fixed_len=2"):
+        _run(plan, [native.DeviceInput(lying)], tpch.Q1_NUM_OUTPUT_COLS)
+    # values of different lengths: nothing is declared
+    mixed = native.DeviceTable.from_arrow(pa.table({"s": pa.array(["a", "bc", "d", ""])}), "cuda:0").with_string_hints()
+    assert not mixed.schema.field(0).metadata
+
+
 def test_q1_chunked_equals_unchunked(built):
     table = tpch.lineitem_q1(100_000, seed=2)
     plan = tpch.q1_plan()
