@@ -1716,7 +1716,12 @@ CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
 // ---------------------------------------------------------------------------------------------
 // Kernel template D — hash join (reference: planner.rs:2192-2266 → DataFusion HashJoinExec; NULL keys never
 // match, planner.rs:2225-2227).  Build side: bucket-chained table over the build rows,
-//   head[cap] (i32, -1 = empty) and next[n_build]; insertion is one atomicExch per row, duplicates chain.
+//   head[cap] (u32, 0xffffffff = empty: bits [0, B) = newest build row of the bucket, B = iarg[2] = bits needed for a build row index;
+//   bits [B, 31) = tag bits of that row's hash; bit 31 = "the chain holds more than one row") and next[n_build]; insertion is one
+//   atomicExch per row, duplicates chain.  The tag and the flag let the probe settle most rows with ONE random access: an empty bucket,
+//   or a single-row bucket whose tag differs, is a miss without touching the build keys or next[] (a probe-side FK join misses or hits
+//   single-row buckets almost always).  The table stays 4 bytes per bucket — an 8-byte head with a 31-bit tag was measured too: the
+//   probe of SF100 Q3's second join got SLOWER (the 256 MB head array no longer sits in the 256 MB Infinity Cache).
 // Probe side: template D' below (single pass; counts and emits together).
 //   P::bvalid(prm,i) / P::pvalid(prm,j)   all key columns non-NULL
 //   P::bhash(prm,i)  / P::phash(prm,j)    64-bit hash of the key words
@@ -1735,16 +1740,27 @@ constexpr int kJoinTileCounts = 44;
 constexpr int kJoinMatched = 45;
 constexpr int kJoinBuildTiles = 46;
 
+constexpr u32 kJoinNoRow = 0xffffffffu;
+constexpr u32 kJoinChainBit = 1u << 31;
+// the bucket index uses the hash's low bits, the tag its high bits; B index bits leave 31 − B tag bits (B ≤ 31; a row index is never all
+// ones in B bits, so no entry equals the empty marker)
+CDEV u32 join_head_entry(u64 h, u32 row, int ib) { return ((u32)(h >> 33) << ib) & 0x7fffffffu | row; }
+
 template <class P>
 CDEV void join_build_body(const CometKParams& prm) {
-  i32* head = (i32*)prm.out[0];
+  u32* head = (u32*)prm.out[0];
   i32* next = (i32*)prm.out[1];
   const u64 mask = (u64)prm.iarg[0] - 1;
   const i64 nb = prm.iarg[1];
+  const int ib = (int)prm.iarg[2];
   for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < nb; i += (i64)gridDim.x * kBlock) {
     if (!P::bvalid(prm, i)) continue;
-    u64 h = P::bhash(prm, i) & mask;
-    next[i] = atomicExch(&head[h], (i32)i);
+    const u64 h = P::bhash(prm, i);
+    const u32 old = atomicExch(&head[h & mask], join_head_entry(h, (u32)i, ib));
+    next[i] = old == kJoinNoRow ? -1 : (i32)(old & ((1u << ib) - 1u));
+    // a bucket that already held a row: whatever its head is from now on, its chain is longer than one (monotone, so the OR may land
+    // on a newer head)
+    if (old != kJoinNoRow) atomicOr(&head[h & mask], kJoinChainBit);
   }
 }
 
@@ -1827,12 +1843,20 @@ constexpr int kJoinR = 8;                    // probe rows per thread and tile
 // candidates of probe row j in the global chained table
 template <class P>
 struct JoinGlobalTable {
-  const i32* head;
+  const u32* head;
   const i32* next;
   u64 mask;
+  int ib;
   template <class F>
   CDEV void for_each(const CometKParams& prm, i64 j, u64 h, F f) const {   // f(build row) returns false to stop
-    for (i32 i = head[h & mask]; i >= 0; i = next[i])
+    const u32 e = head[h & mask];
+    if (e == kJoinNoRow) return;
+    const u32 rowmask = (1u << ib) - 1u, first = e & rowmask;
+    if (!(e & kJoinChainBit)) {                       // one row in the bucket: its tag decides whether the keys are worth reading
+      if (((e ^ join_head_entry(h, 0, ib)) & ~rowmask) == 0 && P::match(prm, (i64)first, j)) f(first);
+      return;
+    }
+    for (i32 i = (i32)first; i >= 0; i = next[i])
       if (P::match(prm, (i64)i, j) && !f((u32)i)) break;
   }
 };
@@ -1936,7 +1960,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
 
 template <class P>
 CDEV void join_probe_fused_body(const CometKParams& prm) {
-  JoinGlobalTable<P> t{(const i32*)prm.out[0], (const i32*)prm.out[1], (u64)prm.iarg[0] - 1};
+  JoinGlobalTable<P> t{(const u32*)prm.out[0], (const i32*)prm.out[1], (u64)prm.iarg[0] - 1, (int)prm.iarg[2]};
   join_probe_tiles<P>(prm, t);
 }
 

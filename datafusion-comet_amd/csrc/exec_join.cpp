@@ -148,7 +148,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   while (cap < 2 * B.rows) cap <<= 1;
   const int64_t n = P.rows;
   DevBuf head, next, matched, btiles;
-  head.ensure((size_t)cap * 4);
+  head.ensure((size_t)cap * 4);     // u32 per bucket: newest row | tag | chain flag (comet_device.hpp template D)
   next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4);
   HIP_CHECK(hipMemsetAsync(head.p, 0xff, (size_t)cap * 4, stream_));
   const bool outer_build = d.join_outer_build;
@@ -164,6 +164,12 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   prm.n = n;
   prm.iarg[0] = cap;
   prm.iarg[1] = B.rows;
+  {
+    int ib = 1;                                   // bits of a build row index: rows ≤ 2^ib − 1, so an index is never all ones
+    while (ib < 31 && ((int64_t)1 << ib) - 1 < std::max<int64_t>(B.rows, 1)) ib++;
+    if (((int64_t)1 << ib) - 1 < B.rows) throw CometError("HashJoin: build sides of 2^31 rows or more are not supported");
+    prm.iarg[2] = ib;
+  }
   prm.out[0] = head.p;
   prm.out[1] = next.p;
   prm.out[kOutErr] = err_flags_.p;
