@@ -240,12 +240,21 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
         // SUM / COUNT / AVG of exact types over a frame that starts at the partition start (whole partition, or up to the current row /
         // peer group) — the frames the reference runs with its own Spark-exact accumulators (planner.rs:2953-2972)
         const AggExpr& a = fn.agg;
-        // frames: every combination of UNBOUNDED / CURRENT ROW bounds, and ROWS frames with literal offsets (n PRECEDING / n FOLLOWING);
-        // RANGE frames with value offsets need a search over the order key and are not supported
-        if (fn.frame_range_literal || (!fn.frame_rows && (fn.frame_lower == 1 || fn.frame_upper == 1)))
-          throw CometError("Window: RANGE frames with a value offset (RANGE BETWEEN x PRECEDING …) are not supported yet");
+        // frames: every combination of UNBOUNDED / CURRENT ROW bounds, ROWS frames with literal offsets (n PRECEDING / n FOLLOWING), and
+        // RANGE frames with value offsets over ONE integer ORDER BY key (x PRECEDING below, y FOLLOWING above — all the JVM side sends,
+        // CometWindowExec.scala:588-632; it keeps DATE / DECIMAL keys in Spark): two binary searches per row over the key
+        if (!fn.frame_rows && (fn.frame_lower == 1 || fn.frame_upper == 1)) {
+          if (op.window_order.size() != 1) throw CometError("Window: a RANGE frame with a value offset needs exactly one ORDER BY expression");
+          const ExprP& ok = op.window_order[0].child;
+          const DType kt = ok->kind == ExprKind::Bound && ok->bound_index >= 0 && (size_t)ok->bound_index < st.size() ? st[(size_t)ok->bound_index] : DType();
+          if (!kt.is_integer())
+            throw CometError("Window: RANGE frames with a value offset are supported over one integer ORDER BY column (got " + (kt.id == TypeId::Unknown ? std::string("an expression") : kt.str()) + ")");
+          for (const ExprP& r : {fn.frame_lower == 1 ? fn.frame_lower_range : ExprP(), fn.frame_upper == 1 ? fn.frame_upper_range : ExprP()})
+            if (r && (!r->dtype.is_integer() || r->lit_null || r->lit_i64 < 0))
+              throw CometError("Window: a RANGE frame offset must be a non-negative integer literal of the ORDER BY column's type");
+        }
         const bool minmax = a.kind == AggKind::Min || a.kind == AggKind::Max;
-        if (minmax && fn.frame_lower == 1 && fn.frame_upper == 1 && fn.frame_upper_off - fn.frame_lower_off > 4096)
+        if (minmax && fn.frame_rows && fn.frame_lower == 1 && fn.frame_upper == 1 && fn.frame_upper_off - fn.frame_lower_off > 4096)
           throw CometError("Window: MIN / MAX over a sliding frame wider than 4096 rows is not supported yet");
         if (a.children.size() != 1) throw CometError("Window: aggregate window functions take one argument");
         const ExprP& arg = a.children[0];

@@ -67,8 +67,33 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
     if (fn.is_agg) {
       const AggExpr& a = fn.agg;
       const ExprP& arg = a.children[0];
-      auto bound_kind = [&](int k, bool upper) { return k == 0 ? 0 : k == 1 ? 3 : (fn.frame_rows ? 1 : 2); (void)upper; };   // → WB_* of window_kernels.hip
+      auto bound_kind = [&](int k, bool upper) { return k == 0 ? 0 : k == 1 ? (fn.frame_rows ? 3 : 4) : (fn.frame_rows ? 1 : 2); (void)upper; };   // → WB_* of window_kernels.hip
       const int lo_kind = bound_kind(fn.frame_lower, false), hi_kind = bound_kind(fn.frame_upper, true);
+      // RANGE frames with value offsets: the bounds are row positions searched over the ORDER BY key (window_range_bounds_kernel); the
+      // frame kernels then read them from these arrays (their address travels in the offset slot of the frame)
+      int64_t lo_off = fn.frame_lower_off, hi_off = fn.frame_upper_off;
+      std::shared_ptr<DevBuf> range_lo, range_hi;
+      if (lo_kind == 4 || hi_kind == 4) {
+        const Operator::SortKey& ok = w.window_order[0];
+        const int kc = ok.child->bound_index;
+        const DeviceColumnView& kcol = in.cols[(size_t)kc];
+        if (kcol.offset != 0) throw CometError("Window: ORDER BY column with a non-zero Arrow offset is not supported yet");
+        range_lo = std::make_shared<DevBuf>();
+        range_hi = std::make_shared<DevBuf>();
+        range_lo->ensure((size_t)n * 4 + 16);
+        range_hi->ensure((size_t)n * 4 + 16);
+        // magnitudes: the literal when the plan carries one, else |offset| (planner.rs:3032-3035, :3091-3094)
+        const int64_t dlo = fn.frame_lower_range ? fn.frame_lower_range->lit_i64 : (fn.frame_lower_off < 0 ? -fn.frame_lower_off : fn.frame_lower_off);
+        const int64_t dhi = fn.frame_upper_range ? fn.frame_upper_range->lit_i64 : fn.frame_upper_off;
+        if (comet_launch_window_range_bounds(fixed_width(in.types[(size_t)kc]), kcol.data, in.has_valid[(size_t)kc] ? kcol.valid : nullptr, (const int32_t*)sp->p,
+                                             (const uint32_t*)first_part->p, n, ok.descending ? 1 : 0, ok.nulls_last ? 0 : 1, lo_kind == 4, dlo, hi_kind == 4, dhi,
+                                             (int32_t*)range_lo->p, (int32_t*)range_hi->p, stream_) != 0)
+          throw CometError("window: launch failed");
+        if (lo_kind == 4) lo_off = (int64_t)(uintptr_t)range_lo->p;
+        if (hi_kind == 4) hi_off = (int64_t)(uintptr_t)range_hi->p;
+        out.owners.push_back(range_lo);
+        out.owners.push_back(range_hi);
+      }
       if (a.kind == AggKind::Min || a.kind == AggKind::Max) {
         // the frame's extreme: running extremes per partition from its start (P) and towards its end (Q) — two segmented scans — answer
         // every frame that touches a partition edge; a frame bounded on both sides is walked row by row (≤ 4097 rows)
@@ -97,7 +122,7 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
         data->ensure((size_t)n * (size_t)width + 16);
         okb->ensure((size_t)n + 16);
         bits->ensure((size_t)((n + 7) / 8) + 16);
-        if (comet_launch_window_minmax(is_max, lo_kind, fn.frame_lower_off, hi_kind, fn.frame_upper_off, wide.p, (const uint32_t*)okf.p, P.p, (const uint8_t*)Ph.p, Q.p, (const uint8_t*)Qh.p,
+        if (comet_launch_window_minmax(is_max, lo_kind, lo_off, hi_kind, hi_off, wide.p, (const uint32_t*)okf.p, P.p, (const uint8_t*)Ph.p, Q.p, (const uint8_t*)Qh.p,
                                        (const int32_t*)sp->p, (const int32_t*)sg->p, (const uint32_t*)first_part->p, (const uint32_t*)first_peer->p, n, width, data->p, (uint8_t*)okb->p,
                                        stream_) != 0)
           throw CometError("window: launch failed");
@@ -159,7 +184,7 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
       data->ensure((size_t)n * (fnk == 0 || fnk == 3 ? 16 : 8) + 16);
       okb->ensure((size_t)n + 16);
       bits->ensure((size_t)((n + 7) / 8) + 16);
-      if (comet_launch_window_agg(fnk, lo_kind, fn.frame_lower_off, hi_kind, fn.frame_upper_off, it->second.S->p, it->second.SH ? it->second.SH->p : nullptr, (const int32_t*)it->second.C->p, (const int32_t*)sp->p, (const int32_t*)sg->p,
+      if (comet_launch_window_agg(fnk, lo_kind, lo_off, hi_kind, hi_off, it->second.S->p, it->second.SH ? it->second.SH->p : nullptr, (const int32_t*)it->second.C->p, (const int32_t*)sp->p, (const int32_t*)sg->p,
                                   (const uint32_t*)first_part->p, (const uint32_t*)first_peer->p, n, &bound, &scaler, &avg_bound, data->p, (uint8_t*)okb->p, stream_) != 0)
         throw CometError("window: launch failed");
       pq_launch_pack((const uint8_t*)okb->p, (uint8_t*)bits->p, n, stream_);

@@ -176,6 +176,7 @@ struct Operator {
     // offset bounds: rows relative to the current row, negative = PRECEDING, positive = FOLLOWING (both bounds; planner.rs:3016-3030)
     int64_t frame_lower_off = 0, frame_upper_off = 0;
     bool frame_range_literal = false;       // a RANGE frame with a value offset (Preceding / Following.range_offset)
+    ExprP frame_lower_range, frame_upper_range;   // that offset: a literal of the ORDER BY key's type, magnitude only (CometWindowExec.scala:588-632)
     DType result_type;
     bool has_result_type = false;
     bool ignore_nulls = false;

@@ -463,7 +463,13 @@ OperatorP decode_operator_r(Reader r) {
                           while (!pf.done()) {
                             int wt7, f7 = pf.tag(wt7);
                             if (f7 == 1 && wt7 == 0) off = (int64_t)pf.varint();
-                            else { if (f7 == 2) fn.frame_range_literal = true; pf.skip(wt7); }
+                            else if (f7 == 2 && wt7 == 2) {
+                              fn.frame_range_literal = true;
+                              auto lit = std::make_shared<Expr>();
+                              lit->kind = ExprKind::Literal;
+                              decode_literal(pf.sub(), *lit);
+                              (f5 == 2 ? fn.frame_lower_range : fn.frame_upper_range) = lit;
+                            } else pf.skip(wt7);
                           }
                         } else bd.skip(wt6);
                       }

@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void scan128_apply_kernel(const i128* __restri
 enum { WA_SUM_DEC = 0, WA_SUM_INT = 1, WA_COUNT = 2, WA_AVG_DEC = 3 };
 // A frame bound: the partition's edge, the current row (ROWS) or its peer group (RANGE), or the current row ± a literal number of rows
 // (negative = PRECEDING, positive = FOLLOWING — the sign convention of the plan, planner.rs:3016-3030).
-enum { WB_UNBOUNDED = 0, WB_CURRENT_ROW = 1, WB_CURRENT_RANGE = 2, WB_ROWS_OFFSET = 3 };
+// WB_RANGE_OFFSET: a RANGE frame with a value offset — the bound was searched per row over the ORDER BY key (window_range_bounds_kernel);
+// the frame then carries the device array of row positions in place of the offset.
+enum { WB_UNBOUNDED = 0, WB_CURRENT_ROW = 1, WB_CURRENT_RANGE = 2, WB_ROWS_OFFSET = 3, WB_RANGE_OFFSET = 4 };
 struct WFrame { int lo_kind, hi_kind; i64 lo_off, hi_off; };
 // rows [start, end) of row i's frame, clipped to its partition [ps, pe); empty frames come back with end == start
 __device__ __forceinline__ void frame_bounds(const WFrame& f, i64 i, i64 ps, i64 pe, i64 gs, i64 ge, i64& start, i64& end) {
@@ -199,12 +201,14 @@ __device__ __forceinline__ void frame_bounds(const WFrame& f, i64 i, i64 ps, i64
     case WB_UNBOUNDED: start = ps; break;
     case WB_CURRENT_ROW: start = i; break;
     case WB_CURRENT_RANGE: start = gs; break;
+    case WB_RANGE_OFFSET: start = (i64)((const i32*)f.lo_off)[i]; break;
     default: start = i + f.lo_off; break;
   }
   switch (f.hi_kind) {
     case WB_UNBOUNDED: end = pe; break;
     case WB_CURRENT_ROW: end = i + 1; break;
     case WB_CURRENT_RANGE: end = ge; break;
+    case WB_RANGE_OFFSET: end = (i64)((const i32*)f.hi_off)[i]; break;
     default: end = i + f.hi_off + 1; break;
   }
   if (start < ps) start = ps;
@@ -246,6 +250,71 @@ __global__ __launch_bounds__(256) void window_agg_kernel(int fn, WFrame frame, c
         out_ok[i] = ok ? 1 : 0;
         break;
       }
+    }
+  }
+}
+
+// ---- RANGE frames with value offsets -----------------------------------------------------------------------------------------------
+// RANGE BETWEEN a PRECEDING AND b FOLLOWING over ONE integer ORDER BY key (the shape the JVM side sends: magnitudes only, the lower bound
+// always PRECEDING, the upper always FOLLOWING — CometWindowExec.scala:588-632 → planner.rs:3031-3037,3090-3096): the frame of row i holds
+// the partition's rows whose key lies within [key_i − a, key_i + b] in SORT order (descending keys: [key_i + a, key_i − b]).  As in
+// DataFusion's WindowFrameStateRange the target is computed in the key's own width with wrapping arithmetic, a NULL key's target is NULL
+// (its frame is its NULL peers), and each bound is the first row that does not sort before (lower) / sorts after (upper) the target.  Rows
+// are sorted, so both are binary searches over the partition.  The reference advances its bounds monotonically along a partition, which
+// differs from this stateless search only when key ± offset wraps.
+__device__ __forceinline__ i64 wr_key(const void* keys, int width, i64 k) {
+  switch (width) {
+    case 1: return (i64)((const signed char*)keys)[k];
+    case 2: return (i64)((const short*)keys)[k];
+    case 4: return (i64)((const i32*)keys)[k];
+    default: return ((const i64*)keys)[k];
+  }
+}
+__device__ __forceinline__ i64 wr_wrap(i64 x, int width) {
+  switch (width) {
+    case 1: return (i64)(signed char)x;
+    case 2: return (i64)(short)x;
+    case 4: return (i64)(i32)x;
+    default: return x;
+  }
+}
+// does row k sort strictly before (dir = 0) / strictly after (dir = 1) the target?
+__device__ __forceinline__ bool wr_cmp(const void* keys, const u8* valid, int width, i64 k, bool t_null, i64 t, int desc, int nulls_first, int dir) {
+  const bool k_null = valid && !((valid[k >> 3] >> (k & 7)) & 1);
+  if (k_null || t_null) {
+    if (k_null && t_null) return false;
+    const bool k_first = k_null ? nulls_first != 0 : nulls_first == 0;   // the row sorts before the target
+    return dir == 0 ? k_first : !k_first;
+  }
+  const i64 v = wr_key(keys, width, k);
+  const bool before = desc ? v > t : v < t, after = desc ? v < t : v > t;
+  return dir == 0 ? before : after;
+}
+__global__ __launch_bounds__(256) void window_range_bounds_kernel(int width, const void* __restrict__ keys, const u8* __restrict__ valid, const i32* __restrict__ sp,
+                                                                  const u32* __restrict__ first_part, i64 n, int desc, int nulls_first, int has_lo, i64 dlo, int has_hi, i64 dhi,
+                                                                  i32* __restrict__ out_lo, i32* __restrict__ out_hi) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    const i32 p = sp[i + 1] - 1;
+    const i64 ps = (i64)first_part[p], pe = (i64)first_part[p + 1];
+    const bool i_null = valid && !((valid[i >> 3] >> (i & 7)) & 1);
+    const i64 v = i_null ? 0 : wr_key(keys, width, i);
+    if (has_lo) {
+      const i64 t = wr_wrap((i64)(desc ? (u64)v + (u64)dlo : (u64)v - (u64)dlo), width);
+      i64 a = ps, b = pe;                       // first row in [ps, pe) that does not sort before the target
+      while (a < b) {
+        const i64 m = (a + b) >> 1;
+        if (wr_cmp(keys, valid, width, m, i_null, t, desc, nulls_first, 0)) a = m + 1; else b = m;
+      }
+      out_lo[i] = (i32)a;
+    }
+    if (has_hi) {
+      const i64 t = wr_wrap((i64)(desc ? (u64)v - (u64)dhi : (u64)v + (u64)dhi), width);
+      i64 a = ps, b = pe;                       // first row that sorts after the target
+      while (a < b) {
+        const i64 m = (a + b) >> 1;
+        if (!wr_cmp(keys, valid, width, m, i_null, t, desc, nulls_first, 1)) a = m + 1; else b = m;
+      }
+      out_hi[i] = (i32)a;
     }
   }
 }
@@ -409,6 +478,13 @@ int comet_launch_window_minmax(int is_max, int lo_kind, int64_t lo_off, int hi_k
   if (n > 0)
     hipLaunchKernelGGL(window_minmax_kernel, grid_for(n), 256, 0, (hipStream_t)stream, is_max, f, (const i128*)vals128, ok, (const i128*)P, Ph, (const i128*)Q, Qh, sp, sg, first_part,
                        first_peer, (i64)n, out_width, out, out_ok);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_window_range_bounds(int width, const void* keys, const uint8_t* valid, const int32_t* sp, const uint32_t* first_part, int64_t n, int desc, int nulls_first,
+                                     int has_lo, int64_t dlo, int has_hi, int64_t dhi, int32_t* out_lo, int32_t* out_hi, void* stream) {
+  if (n > 0)
+    hipLaunchKernelGGL(window_range_bounds_kernel, grid_for(n), 256, 0, (hipStream_t)stream, width, keys, valid, sp, first_part, (i64)n, desc, nulls_first, has_lo, (i64)dlo, has_hi,
+                       (i64)dhi, out_lo, out_hi);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_window_agg(int fn, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,

@@ -432,10 +432,13 @@ class Operator:
                 if wf[0] == "agg":
                     # aggregate over a frame: ("agg", AggExpr, result type, (rows|range, unbounded|current, unbounded|current))
                     # a bound is "unbounded", "current" or an int: rows relative to the current row, negative = PRECEDING, positive = FOLLOWING —
-                    # carried by Preceding.offset / Following.offset whichever side it is on (operator.proto:815-845, planner.rs:3016-3030)
+                    # carried by Preceding.offset / Following.offset whichever side it is on (operator.proto:815-845, planner.rs:3016-3030);
+                    # RANGE frames: ("value", literal of the ORDER BY key's type) = that much PRECEDING (lower) / FOLLOWING (upper)
                     _, agg, rtype, (ftype, lo, up) = wf
 
                     def bound(b):
+                        if isinstance(b, tuple):       # ("value", literal Expr): a RANGE frame's value offset (Preceding / Following.range_offset)
+                            return _f_msg(2, _f_msg(2, b[1]._encode_literal()))
                         if b == "unbounded":
                             return _f_msg(1, b"")
                         if b == "current":

@@ -876,8 +876,40 @@ def run_plan(S, op, table) -> List[Col]:
                 for i in range(n):
                     # the frame, clipped to the partition: a bound is the partition edge, the current row (ROWS) / its peer group (RANGE),
                     # or the current row ± rows (negative = PRECEDING)
-                    start = ps[i] if lo == "unbounded" else ((i if ftype == "rows" else gs[i]) if lo == "current" else i + int(lo))
-                    end = pe[i] if up == "unbounded" else ((i + 1 if ftype == "rows" else ge[i]) if up == "current" else i + int(up) + 1)
+                    if isinstance(lo, tuple) or isinstance(up, tuple):
+                        # RANGE with value offsets (DataFusion WindowFrameStateRange as the reference configures it, planner.rs:3031-3037,
+                        # 3090-3096): target = key ∓ offset in SORT order, computed in the key's width with wrapping arithmetic, NULL for a
+                        # NULL key; lower bound = first row that does not sort before its target, upper = first row that sorts after it
+                        kcol, (_, kdesc, knl) = okeys[0], op.sort_orders[0]
+                        bits = 8 * kcol.values.dtype.itemsize
+
+                        def wrapk(x):
+                            x &= (1 << bits) - 1
+                            return x - (1 << bits) if x >> (bits - 1) else x
+                        kv = lambda r: int(kcol.values[r]) if kcol.ok()[r] else None
+
+                        def sorts_before(r, t):
+                            a = kv(r)
+                            if a is None or t is None:
+                                return False if (a is None and t is None) else ((a is None) == (not knl))
+                            return a > t if kdesc else a < t
+
+                        def sorts_after(r, t):
+                            a = kv(r)
+                            if a is None or t is None:
+                                return False if (a is None and t is None) else ((a is None) == bool(knl))
+                            return a < t if kdesc else a > t
+                        cur = kv(i)
+                    if isinstance(lo, tuple):
+                        t = None if cur is None else wrapk(cur + int(lo[1].value) if kdesc else cur - int(lo[1].value))
+                        start = next((r for r in range(ps[i], pe[i]) if not sorts_before(r, t)), pe[i])
+                    else:
+                        start = ps[i] if lo == "unbounded" else ((i if ftype == "rows" else gs[i]) if lo == "current" else i + int(lo))
+                    if isinstance(up, tuple):
+                        t = None if cur is None else wrapk(cur - int(up[1].value) if kdesc else cur + int(up[1].value))
+                        end = next((r for r in range(ps[i], pe[i]) if sorts_after(r, t)), pe[i])
+                    else:
+                        end = pe[i] if up == "unbounded" else ((i + 1 if ftype == "rows" else ge[i]) if up == "current" else i + int(up) + 1)
                     start, end = max(start, ps[i]), min(end, pe[i])
                     win = [v for v in ival[start:max(end, start)] if v is not None]
                     if a.kind in ("min", "max"):

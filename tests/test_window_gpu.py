@@ -144,6 +144,46 @@ def test_sliding_frames_and_min_max(built):
     assert got.column(len(FIELDS) + 4 * 3).null_count > 0        # SUM over (5 PRECEDING, 2 PRECEDING): empty at the head of every partition → NULL
 
 
+@pytest.mark.parametrize("desc,nulls_last", [(False, False), (True, True), (False, True)])
+def test_range_frames_with_value_offsets(built, desc, nulls_last):
+    """RANGE BETWEEN a PRECEDING AND b FOLLOWING over one integer ORDER BY key (planner.rs:3031-3037, 3090-3096; the JVM side sends magnitudes,
+    CometWindowExec.scala:588-632): the frame holds the partition's rows whose key lies within [key − a, key + b] in sort order — ties are
+    peers, so every function is tie invariant; NULL keys frame their NULL peers; an offset on one side combines with UNBOUNDED / CURRENT ROW
+    on the other; keys near the type's limits wrap in the key's own width like the reference's ScalarValue arithmetic."""
+    from oracle import oracle as O
+    n = 3000                                                                  # ~100 rows per partition: the oracle scans a partition per row and function
+    rng = np.random.default_rng(31 + int(desc) + 2 * int(nulls_last))
+    day = rng.integers(0, 60, n).astype(np.int32)
+    day[:8] = np.int32(2**31 - 1) - np.arange(8, dtype=np.int32)               # day + 10 wraps for these
+    t = pa.table({"g": pa.array(rng.integers(0, 30, n).astype(np.int32)), "day": pa.array(day, mask=rng.random(n) < 0.04),
+                  "amount": tpch._dec128_array(rng.integers(-5000, 5000, n), 12, 2), "id": pa.array(np.arange(n, dtype=np.int64)),
+                  "small": pa.array(rng.integers(-120, 120, n).astype(np.int8))})
+    fields = [S.T_INT32, S.T_INT32, D, S.T_INT64, S.T_INT8]
+    g, dayc, amount, ident = S.col(0, S.T_INT32), S.col(1, S.T_INT32), S.col(2, D), S.col(3, S.T_INT64)
+    order = [(dayc, desc, nulls_last)]
+    child = S.sort(S.scan(fields), [(g, False, False)] + order)
+    v = lambda k: ("value", S.lit(k, S.T_INT32))
+    frames = [("range", v(3), v(3)), ("range", v(10), "current"), ("range", "current", v(7)), ("range", "unbounded", v(2)), ("range", v(0), "unbounded"), ("range", v(0), v(0)),
+              ("range", v(40), v(40))]
+    SD = S.decimal(22, 2)
+    fns = []
+    for fr in frames:
+        fns += [("agg", S.sum_(amount, SD), SD, fr), ("agg", S.count(amount), S.T_INT64, fr), ("agg", S.min_(amount, D), D, fr), ("agg", S.max_(ident, S.T_INT64), S.T_INT64, fr)]
+    plan = S.window(child, [g], order, fns)
+    ncols = len(fields) + len(fns)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], ncols, plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, [t])
+    assert got.schema.types == want.schema.types
+    assert _rows(got) == _rows(want)
+    # an int8 key: the target wraps at 8 bits (−120 − 20 → +116), whatever the row's position
+    small = S.col(4, S.T_INT8)
+    order8 = [(small, desc, nulls_last)]
+    plan8 = S.window(S.sort(S.scan(fields), [(g, False, False)] + order8), [g], order8,
+                     [("agg", S.count(amount), S.T_INT64, ("range", ("value", S.lit(20, S.T_INT8)), ("value", S.lit(5, S.T_INT8))))])
+    got8 = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], len(fields) + 1, plan8.encode(), batch_size=0))
+    assert _rows(got8) == _rows(O.run_plan_to_arrow(S, plan8, [t]))
+
+
 def test_frames_the_engine_refuses(built):
     t = _table(100, 16, unique_order=True)
     cat, store, amount = S.col(0, S.T_STRING), S.col(1, S.T_INT32), S.col(2, D)
