@@ -346,8 +346,19 @@ def set_op(pb, op):
             ftype, lo, up = frame
             f = sp.frameSpecification
             f.frame_type = enum_no(f, "frame_type", "Range" if ftype == "range" else "Rows")
-            (f.lower_bound.unboundedPreceding if lo == "unbounded" else f.lower_bound.currentRow).SetInParent()
-            (f.upper_bound.unboundedFollowing if up == "unbounded" else f.upper_bound.currentRow).SetInParent()
+            for side, b, unb, off in ((f.lower_bound, lo, "unboundedPreceding", "preceding"), (f.upper_bound, up, "unboundedFollowing", "following")):
+                if isinstance(b, tuple):          # RANGE value offset: Preceding / Following.range_offset = the typed literal
+                    tmp = w.partition_by_list.add().__class__()
+                    set_expr(tmp, b[1])
+                    getattr(side, off).range_offset.CopyFrom(tmp.literal)
+                    del w.partition_by_list[-1]
+                elif b == "unbounded":
+                    getattr(side, unb).SetInParent()
+                elif b == "current":
+                    side.currentRow.SetInParent()
+                else:                             # ROWS offset, negative = PRECEDING
+                    getattr(side, off).offset = int(b)
+                    getattr(side, off).SetInParent()
         for wf in op.window_fns:
             we = w.window_expr.add()
             if wf[0] == "agg":
@@ -403,7 +414,10 @@ def corpus():
     plans["expand"] = S.expand(sc(), [[a, s], [a, S.lit(None, STR)]])
     plans["window"] = S.window(sc(), [s], [(d, False, False)], [("row_number", [], I32), ("lag", [a, S.lit(1, I32)], I64),
                                                                ("agg", S.sum_(x, S.decimal(22, 2)), S.decimal(22, 2), ("range", "unbounded", "current")),
-                                                               ("agg", S.count(a), I64, ("rows", "unbounded", "unbounded"))])
+                                                               ("agg", S.count(a), I64, ("rows", "unbounded", "unbounded")),
+                                                               ("agg", S.min_(a, I64), I64, ("rows", -3, 2)), ("agg", S.max_(a, I64), I64, ("rows", 0, "current"))])
+    plans["window_range_offsets"] = S.window(sc(), [s], [(a, True, True)], [("agg", S.count(x), I64, ("range", ("value", S.lit(5, I64)), ("value", S.lit(0, I64)))),
+                                                                              ("agg", S.sum_(x, S.decimal(22, 2)), S.decimal(22, 2), ("range", "unbounded", ("value", S.lit(7, I64))))])
     for i, (part, kw) in enumerate([("hash", dict(hash_exprs=[a, s], num_partitions=7)), ("single", {}), ("round_robin", dict(num_partitions=5, max_hash_columns=2)),
                                     ("range", dict(sort_orders=[(a, False, False)], num_partitions=3, bounds=[[S.lit(10, I64)], [S.lit(20, I64)]]))]):
         plans[f"shuffle_writer_{part}"] = S.shuffle_writer(sc(), "/tmp/d.data", "/tmp/d.index", part, codec=i, **kw)
@@ -471,7 +485,7 @@ def test_proto_cpp_accepts_protobufs_own_bytes(pool):
     from datafusion_comet_amd import native
     Op = cls(pool, "spark.spark_operator.Operator")
     plans = corpus()
-    for name in ("tpch_0", "tpch_1", "tpch_q3_single", "tpcds_q95_a", "tpcds_q95_b", "sort_limit", "expand", "window"):
+    for name in ("tpch_0", "tpch_1", "tpch_q3_single", "tpcds_q95_a", "tpcds_q95_b", "sort_limit", "expand", "window", "window_range_offsets"):
         by_name = Op()
         set_op(by_name, plans[name])
         theirs = by_name.SerializeToString(deterministic=True)
