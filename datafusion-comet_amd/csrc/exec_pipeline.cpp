@@ -121,8 +121,16 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
         }
       }
       if (!full && (int64_t)groups_now * 2 <= group_cap_) { groups_committed_ = groups_now; break; }
-      // grow ×8 and rehash; after a "full" event restart this chunk from the checkpoint
+      // grow and rehash; after a "full" event restart this chunk from the checkpoint.  A table that is merely more than half full grows ×8.
+      // A FULL table voided a whole pass over the chunk (blocks merge their LDS tables at their end, so nobody notices early) and says the
+      // chunk holds far more groups than slots: grow ×64, but no further than twice the chunk's rows ever need (SF100 Q3's second join
+      // feeds 30 M rows / 1.13 M groups into a 2^16-slot table: one voided pass instead of two)
       int64_t new_cap = group_cap_ * 8;
+      if (full) {
+        int64_t need = 1 << 16;
+        while (need < 2 * n && need < ((int64_t)1 << 28)) need <<= 1;
+        new_cap = std::max(new_cap, std::min(group_cap_ * 64, need));
+      }
       if (new_cap > ((int64_t)1 << 28)) throw CometError("group table would exceed 2^28 slots");
       DevBuf bigger;
       alloc_table(bigger, new_cap);
