@@ -28,11 +28,13 @@ void ExecutionContext::validate_input_schema(size_t input, const std::vector<DTy
       int32_t npairs;
       memcpy(&npairs, md, 4);
       const char* q = md + 4;
-      for (int32_t k = 0; k < npairs; k++) {
+      for (int32_t k = 0; k < npairs && k < 4096; k++) {
         int32_t kl, vl;
         memcpy(&kl, q, 4);
+        if (kl < 0 || kl > (1 << 20)) break;       // not a metadata block this reader walks any further
         const char* key = q + 4;
         memcpy(&vl, key + kl, 4);
+        if (vl < 0 || vl > (1 << 24)) break;
         const char* val = key + kl + 4;
         if (kl == 20 && !memcmp(key, "comet:utf8_fixed_len", 20) && vl > 0 && vl < 4) {
           const int L = atoi(std::string(val, (size_t)vl).c_str());
