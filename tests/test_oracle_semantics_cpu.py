@@ -105,6 +105,43 @@ def test_window_known_answers():
     assert cols[10] == [1, 2, 3, 4, 1, 2]
 
 
+def test_range_frame_value_offsets_known_answers():
+    """RANGE BETWEEN a PRECEDING AND b FOLLOWING: hand-computed frames (the SQL standard's example shape: a sum over the days within reach),
+    then a vectorised restatement — numpy searchsorted over the sorted keys — on random data, ascending and descending."""
+    day = [1, 2, 2, 5, 9, None]
+    amt = [10, 20, 30, 40, 50, 60]
+    t = pa.table({"g": pa.array([0] * 6, pa.int32()), "day": pa.array(day, pa.int32()), "amt": pa.array(amt, pa.int64())})
+    f = [S.T_INT32, S.T_INT32, S.T_INT64]
+    g, d, a = S.col(0, S.T_INT32), S.col(1, S.T_INT32), S.col(2, S.T_INT64)
+    v = lambda k: ("value", S.lit(k, S.T_INT32))
+    fns = [("agg", S.sum_(a, S.T_INT64), S.T_INT64, ("range", v(1), v(1))), ("agg", S.count(a), S.T_INT64, ("range", v(3), "current")),
+           ("agg", S.sum_(a, S.T_INT64), S.T_INT64, ("range", "current", v(4))), ("agg", S.max_(a, S.T_INT64), S.T_INT64, ("range", v(0), v(0)))]
+    out = O.run_plan_to_arrow(S, S.window(S.scan(f), [g], [(d, False, True)], fns), [t])       # ascending, NULLs last
+    cols = [out.column(3 + i).to_pylist() for i in range(len(fns))]
+    assert cols[0] == [60, 60, 60, 40, 50, 60]        # day 1: days 0..2 = 10+20+30; day 5: 4..6; day 9: 8..10; the NULL day frames its NULL peers
+    assert cols[1] == [1, 3, 3, 3, 1, 1]              # days [day − 3, day]: day 5 sees 2, 2, 5
+    assert cols[2] == [100, 90, 90, 90, 50, 60]       # days [day, day + 4]: day 1 sees 1, 2, 2, 5; day 5 sees 5, 9
+    assert cols[3] == [10, 30, 30, 40, 50, 60]        # 0 PRECEDING .. 0 FOLLOWING = the peers
+    rng = np.random.default_rng(12)
+    for desc in (False, True):
+        n, lo, hi = 400, 3, 5
+        key = np.sort(rng.integers(-50, 50, n).astype(np.int64))
+        key = key[::-1].copy() if desc else key
+        val = rng.integers(0, 1000, n).astype(np.int64)
+        t2 = pa.table({"k": pa.array(key), "v": pa.array(val)})
+        k, vv = S.col(0, S.T_INT64), S.col(1, S.T_INT64)
+        fr = ("range", ("value", S.lit(lo, S.T_INT64)), ("value", S.lit(hi, S.T_INT64)))
+        got = O.run_plan_to_arrow(S, S.window(S.scan([S.T_INT64, S.T_INT64]), [], [(k, desc, desc)], [("agg", S.sum_(vv, S.T_INT64), S.T_INT64, fr)]), [t2]).column(2).to_pylist()
+        asc = key[::-1] if desc else key              # positions in ascending order
+        vasc = val[::-1] if desc else val
+        csum = np.concatenate([[0], np.cumsum(vasc)])
+        # ascending: keys in [k − lo, k + hi]; descending order turns PRECEDING into "larger": keys in [k − hi, k + lo]
+        a0 = np.searchsorted(asc, asc - (hi if desc else lo), "left")
+        a1 = np.searchsorted(asc, asc + (lo if desc else hi), "right")
+        want = csum[a1] - csum[a0]
+        assert got == list(want[::-1] if desc else want)
+
+
 def test_range_partition_known_answers():
     # multi_partition.rs:352-358: partition = bounds.partition_point(|bound| bound <= row)
     ids = SO.range_partition_ids([[1, 5, 5, 9, None, 10]], [(False, False)], [[5], [9]])
