@@ -235,15 +235,8 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     if (!ps.sort_orders.empty()) { PipelineDesc d = generate_sort_keys(ps, st, none); if (compile_in_infer_) jit_compile(d.source); }
     if (!os.sort_orders.empty()) { PipelineDesc d = generate_sort_keys(os, st, none); if (compile_in_infer_) jit_compile(d.source); }
     std::vector<DType> out = st;
-    for (auto& fn : op.window_fns) {
-      if (fn.is_agg) {
-        // SUM / COUNT / AVG of exact types over a frame that starts at the partition start (whole partition, or up to the current row /
-        // peer group) — the frames the reference runs with its own Spark-exact accumulators (planner.rs:2953-2972)
-        const AggExpr& a = fn.agg;
-        // frames: every combination of UNBOUNDED / CURRENT ROW bounds, ROWS frames with literal offsets (n PRECEDING / n FOLLOWING), and
-        // RANGE frames with value offsets over ONE integer ORDER BY key (x PRECEDING below, y FOLLOWING above — all the JVM side sends,
-        // CometWindowExec.scala:588-632; it keeps DATE / DECIMAL keys in Spark): two binary searches per row over the key
-        if (!fn.frame_rows && (fn.frame_lower == 1 || fn.frame_upper == 1)) {
+    auto check_range_frame = [&](const Operator::WindowFn& fn) {
+      if (!fn.frame_rows && (fn.frame_lower == 1 || fn.frame_upper == 1)) {
           if (op.window_order.size() != 1) throw CometError("Window: a RANGE frame with a value offset needs exactly one ORDER BY expression");
           const ExprP& ok = op.window_order[0].child;
           const DType kt = ok->kind == ExprKind::Bound && ok->bound_index >= 0 && (size_t)ok->bound_index < st.size() ? st[(size_t)ok->bound_index] : DType();
@@ -253,6 +246,16 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
             if (r && (!r->dtype.is_integer() || r->lit_null || r->lit_i64 < 0))
               throw CometError("Window: a RANGE frame offset must be a non-negative integer literal of the ORDER BY column's type");
         }
+    };
+    for (auto& fn : op.window_fns) {
+      if (fn.is_agg) {
+        // SUM / COUNT / AVG of exact types over a frame that starts at the partition start (whole partition, or up to the current row /
+        // peer group) — the frames the reference runs with its own Spark-exact accumulators (planner.rs:2953-2972)
+        const AggExpr& a = fn.agg;
+        // frames: every combination of UNBOUNDED / CURRENT ROW bounds, ROWS frames with literal offsets (n PRECEDING / n FOLLOWING), and
+        // RANGE frames with value offsets over ONE integer ORDER BY key (x PRECEDING below, y FOLLOWING above — all the JVM side sends,
+        // CometWindowExec.scala:588-632; it keeps DATE / DECIMAL keys in Spark): two binary searches per row over the key
+        check_range_frame(fn);
         const bool minmax = a.kind == AggKind::Min || a.kind == AggKind::Max;
         if (minmax && fn.frame_rows && fn.frame_lower == 1 && fn.frame_upper == 1 && fn.frame_upper_off - fn.frame_lower_off > 4096)
           throw CometError("Window: MIN / MAX over a sliding frame wider than 4096 rows is not supported yet");
@@ -262,6 +265,12 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
         if (!lit && (arg->kind != ExprKind::Bound || arg->bound_index < 0 || (size_t)arg->bound_index >= st.size()))
           throw CometError("Window: the argument of an aggregate window function must be a column (or a literal for COUNT)");
         const DType at = lit ? arg->dtype : st[(size_t)arg->bound_index];
+        if (a.kind == AggKind::First || a.kind == AggKind::Last) {
+          // FIRST_VALUE / LAST_VALUE (planner.rs:3243-3251): the value of the frame's first / last row — or non-NULL row — of any flat type
+          if (lit) throw CometError("Window: FIRST_VALUE / LAST_VALUE of a literal is not supported");
+          out.push_back(at);
+          continue;
+        }
         if (a.kind == AggKind::Count) out.push_back(DType::of(TypeId::Int64));
         else if (lit) throw CometError("Window: SUM / AVG / MIN / MAX of a literal is not supported");
         else if (minmax && (at.is_integer() || at.id == TypeId::Decimal || at.id == TypeId::Date || at.id == TypeId::Timestamp || at.id == TypeId::TimestampNtz)) out.push_back(at);
@@ -288,6 +297,13 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
           if (at.id == TypeId::String || at.id == TypeId::Bytes || at.id == TypeId::Bool) throw CometError(f + " with a non-NULL default value over " + at.str() + " is not supported yet");
         }
         if (fn.ignore_nulls) throw CometError(f + " IGNORE NULLS is not supported yet");
+        out.push_back(st[(size_t)fn.args[0]->bound_index]);
+      } else if (f == "nth_value") {
+        // nth_value(column, n) over the spec's frame (CometWindowExec.scala:293-306): the frame's n-th row (or n-th non-NULL row)
+        if (fn.args.size() != 2 || fn.args[0]->kind != ExprKind::Bound || fn.args[0]->bound_index < 0 || (size_t)fn.args[0]->bound_index >= st.size())
+          throw CometError("nth_value is supported for a column argument");
+        if (!int_lit(fn.args[1]) || fn.args[1]->lit_i64 <= 0) throw CometError("nth_value expects a positive literal offset");
+        check_range_frame(fn);
         out.push_back(st[(size_t)fn.args[0]->bound_index]);
       } else {
         throw CometError(f + " not supported for window function");

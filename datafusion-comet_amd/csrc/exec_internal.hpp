@@ -35,6 +35,9 @@ extern "C" int comet_launch_window_minmax(int is_max, int lo_kind, int64_t lo_of
                                           int out_width, void* out, uint8_t* out_ok, void* stream);
 extern "C" int comet_launch_window_range_bounds(int width, const void* keys, const uint8_t* valid, const int32_t* sp, const uint32_t* first_part, int64_t n, int desc, int nulls_first,
                                                 int has_lo, int64_t dlo, int has_hi, int64_t dhi, int32_t* out_lo, int32_t* out_hi, void* stream);
+extern "C" int comet_launch_window_valid_flags(const uint8_t* valid, int64_t n, uint32_t* flags, void* stream);
+extern "C" int comet_launch_window_pick(int mode, int64_t nth, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const int32_t* C, const int32_t* sp, const int32_t* sg,
+                                        const uint32_t* first_part, const uint32_t* first_peer, int64_t n, uint32_t* idx, uint8_t* ok, void* stream);
 extern "C" int comet_launch_window_agg(int fn, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,
                                        const uint32_t* first_peer, int64_t n, const void* bound16, const void* scaler16, const void* avg_bound16, void* out, uint8_t* out_ok,
                                        void* stream);

@@ -31,11 +31,11 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
       if (w.window_fns[k].is_agg) {
         const AggExpr& a = w.window_fns[k].agg;
         const bool dec = a.dtype.id == TypeId::Decimal && a.kind != AggKind::Count;
-        if (a.kind == AggKind::Min || a.kind == AggKind::Max) add_col(in.types[(size_t)a.children[0]->bound_index], nullptr, nullptr);
+        if (a.kind == AggKind::Min || a.kind == AggKind::Max || a.kind == AggKind::First || a.kind == AggKind::Last) add_col(in.types[(size_t)a.children[0]->bound_index], nullptr, nullptr);
         else add_col(dec ? a.dtype : DType::of(TypeId::Int64), nullptr, nullptr);
         continue;
       }
-      DType t = (f == "percent_rank" || f == "cume_dist") ? DType::of(TypeId::Double) : (f == "lag" || f == "lead") ? in.types[(size_t)w.window_fns[k].args[0]->bound_index] : DType::of(TypeId::Int32);
+      DType t = (f == "percent_rank" || f == "cume_dist") ? DType::of(TypeId::Double) : (f == "lag" || f == "lead" || f == "nth_value") ? in.types[(size_t)w.window_fns[k].args[0]->bound_index] : DType::of(TypeId::Int32);
       add_col(t, nullptr, nullptr);
     }
     return out;
@@ -61,17 +61,79 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
   if (comet_launch_window_first((const uint32_t*)fpart.p, (const int32_t*)sp->p, (const uint32_t*)fpeer.p, (const int32_t*)sg->p, n, (uint32_t*)first_part->p,
                                 (uint32_t*)first_peer->p, stream_) != 0)
     throw CometError("window: launch failed");
-  struct Prefix { std::shared_ptr<DevBuf> S, SH, C; };   // 128-bit inclusive sums (low part), sums of the high 64 bits (wide decimals only), non-NULL prefix counts
-  std::map<int, Prefix> prefix;                           // by argument column
-  for (auto& fn : w.window_fns) {
-    if (fn.is_agg) {
-      const AggExpr& a = fn.agg;
-      const ExprP& arg = a.children[0];
+  // out row i = row idx[i] of column c where ok[i], else NULL (or the literal `dflt`): the tail of lag / lead / first / last / nth_value
+  auto gather_rows = [&](int c, const std::shared_ptr<DevBuf>& idx, DevBuf& ok, const Expr* dflt) {
+    const DType& t = in.types[(size_t)c];
+    const DeviceColumnView& sc = in.cols[(size_t)c];
+    auto okv = std::make_shared<DevBuf>(), bits = std::make_shared<DevBuf>();
+    okv->ensure((size_t)n + 16);
+    bits->ensure((size_t)((n + 7) / 8) + 16);
+    if (comet_launch_window_offset_valid((const uint32_t*)idx->p, (const uint8_t*)ok.p, in.has_valid[(size_t)c] ? sc.valid : nullptr, n, (uint8_t*)okv->p, stream_) != 0)
+      throw CometError("window: launch failed");
+    const bool has_default = dflt != nullptr;
+    if (!has_default) pq_launch_pack((const uint8_t*)okv->p, (uint8_t*)bits->p, n, stream_);
+    if (t.id == TypeId::String || t.id == TypeId::Bytes) {
+      DeviceColumnView ov;
+      take_utf8(sc, (const uint32_t*)idx->p, (const uint8_t*)okv->p, nullptr, n, ov, out.owners);
+      ov.valid = (const uint8_t*)bits->p;
+      out.types.push_back(t);
+      out.cols.push_back(ov);
+      out.has_valid.push_back(true);
+      out.owners.push_back(bits);
+    } else {
+      const int wd = t.id == TypeId::Bool ? 0 : fixed_width(t);
+      auto data = std::make_shared<DevBuf>();
+      data->ensure((wd ? (size_t)n * (size_t)wd : (size_t)((n + 7) / 8)) + 16);
+      if (comet_launch_take(wd, sc.data, (const uint32_t*)idx->p, n, data->p, stream_) != 0) throw CometError("window: take failed");
+      if (has_default) {
+        // rows whose offset row is outside the partition take the literal default (lag(x, k, d))
+        const Expr& lit = *dflt;
+        uint8_t buf[16] = {0};
+        if (t.id == TypeId::Decimal) { i128 v = lit.lit_dec; memcpy(buf, &v, 16); }
+        else if (t.id == TypeId::Double) { double v = lit.lit_f64; memcpy(buf, &v, 8); }
+        else if (t.id == TypeId::Float) { float v = (float)lit.lit_f64; memcpy(buf, &v, 4); }
+        else { int64_t v = lit.lit_i64; memcpy(buf, &v, 8); }
+        if (comet_launch_window_default(wd, (const uint8_t*)ok.p, n, buf, data->p, (uint8_t*)okv->p, stream_) != 0) throw CometError("window: launch failed");
+        pq_launch_pack((const uint8_t*)okv->p, (uint8_t*)bits->p, n, stream_);
+      }
+      add_col(t, data, bits);
+    }
+    out.owners.push_back(okv);
+    out.owners.push_back(idx);
+  };
+  // FIRST_VALUE / LAST_VALUE / nth_value: the frame's first / last / n-th row — or non-NULL row (IGNORE NULLS: a binary search over the
+  // column's non-NULL prefix counts inside the frame) — then the same gather as lag / lead
+  auto pick_and_gather = [&](int c, int mode, int64_t nth, bool ignore_nulls, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off) {
+    const DeviceColumnView& sc = in.cols[(size_t)c];
+    if (sc.offset != 0) throw CometError("Window: a column with a non-zero Arrow offset is not supported yet");
+    DevBuf ok, flags, t32, counts;
+    auto idx = std::make_shared<DevBuf>();
+    idx->ensure((size_t)n * 4 + 16);
+    ok.ensure((size_t)n + 16);
+    const int32_t* C = nullptr;
+    if (ignore_nulls && in.has_valid[(size_t)c]) {
+      flags.ensure((size_t)n * 4 + 16);
+      counts.ensure((size_t)(n + 2) * 4);
+      t32.ensure((size_t)((n + 1023) / 1024 + 2) * 8);
+      if (comet_launch_window_valid_flags(sc.valid, n, (uint32_t*)flags.p, stream_) != 0) throw CometError("window: launch failed");
+      pq_launch_u32_scan((const uint32_t*)flags.p, n, (uint64_t*)t32.p, (int32_t*)counts.p, stream_);
+      C = (const int32_t*)counts.p;
+    }
+    if (comet_launch_window_pick(mode, nth, lo_kind, lo_off, hi_kind, hi_off, C, (const int32_t*)sp->p, (const int32_t*)sg->p, (const uint32_t*)first_part->p,
+                                 (const uint32_t*)first_peer->p, n, (uint32_t*)idx->p, (uint8_t*)ok.p, stream_) != 0)
+      throw CometError("window: launch failed");
+    gather_rows(c, idx, ok, nullptr);
+    HIP_CHECK(hipStreamSynchronize(stream_));   // scratch goes back to the pool
+  };
+  // a window function's frame as the kernels take it: WB_* kinds and offsets (RANGE value offsets: the address of the searched row positions)
+  auto frame_of = [&](const Operator::WindowFn& fn, int& lo_kind, int& hi_kind, int64_t& lo_off, int64_t& hi_off) {
       auto bound_kind = [&](int k, bool upper) { return k == 0 ? 0 : k == 1 ? (fn.frame_rows ? 3 : 4) : (fn.frame_rows ? 1 : 2); (void)upper; };   // → WB_* of window_kernels.hip
-      const int lo_kind = bound_kind(fn.frame_lower, false), hi_kind = bound_kind(fn.frame_upper, true);
+      lo_kind = bound_kind(fn.frame_lower, false);
+      hi_kind = bound_kind(fn.frame_upper, true);
       // RANGE frames with value offsets: the bounds are row positions searched over the ORDER BY key (window_range_bounds_kernel); the
       // frame kernels then read them from these arrays (their address travels in the offset slot of the frame)
-      int64_t lo_off = fn.frame_lower_off, hi_off = fn.frame_upper_off;
+      lo_off = fn.frame_lower_off;
+      hi_off = fn.frame_upper_off;
       std::shared_ptr<DevBuf> range_lo, range_hi;
       if (lo_kind == 4 || hi_kind == 4) {
         const Operator::SortKey& ok = w.window_order[0];
@@ -93,6 +155,20 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
         if (hi_kind == 4) hi_off = (int64_t)(uintptr_t)range_hi->p;
         out.owners.push_back(range_lo);
         out.owners.push_back(range_hi);
+      }
+  };
+  struct Prefix { std::shared_ptr<DevBuf> S, SH, C; };   // 128-bit inclusive sums (low part), sums of the high 64 bits (wide decimals only), non-NULL prefix counts
+  std::map<int, Prefix> prefix;                           // by argument column
+  for (auto& fn : w.window_fns) {
+    if (fn.is_agg) {
+      const AggExpr& a = fn.agg;
+      const ExprP& arg = a.children[0];
+      int lo_kind, hi_kind;
+      int64_t lo_off, hi_off;
+      frame_of(fn, lo_kind, hi_kind, lo_off, hi_off);
+      if (a.kind == AggKind::First || a.kind == AggKind::Last) {
+        pick_and_gather(arg->bound_index, a.kind == AggKind::First ? 0 : 1, 0, fn.ignore_nulls || a.ignore_nulls, lo_kind, lo_off, hi_kind, hi_off);
+        continue;
       }
       if (a.kind == AggKind::Min || a.kind == AggKind::Max) {
         // the frame's extreme: running extremes per partition from its start (P) and towards its end (Q) — two segmented scans — answer
@@ -205,50 +281,24 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
       add_col(DType::of(dbl ? TypeId::Double : TypeId::Int32), data, nullptr);
       continue;
     }
+    if (f == "nth_value") {
+      int lo_kind, hi_kind;
+      int64_t lo_off, hi_off;
+      frame_of(fn, lo_kind, hi_kind, lo_off, hi_off);
+      pick_and_gather(fn.args[0]->bound_index, 2, fn.args[1]->lit_i64, fn.ignore_nulls, lo_kind, lo_off, hi_kind, hi_off);
+      continue;
+    }
     // lag / lead: a gather with NULL outside the partition
     const int c = fn.args[0]->bound_index;
     const int64_t k = fn.args.size() >= 2 ? fn.args[1]->lit_i64 : 1;
     const int64_t shift = f == "lag" ? -k : k;
-    const DType& t = in.types[(size_t)c];
-    const DeviceColumnView& sc = in.cols[(size_t)c];
-    if (sc.offset != 0) throw CometError(f + " over a column with a non-zero Arrow offset is not supported yet");
+    if (in.cols[(size_t)c].offset != 0) throw CometError(f + " over a column with a non-zero Arrow offset is not supported yet");
     DevBuf ok;
-    auto idx = std::make_shared<DevBuf>(), okv = std::make_shared<DevBuf>(), bits = std::make_shared<DevBuf>();
+    auto idx = std::make_shared<DevBuf>();
     idx->ensure((size_t)n * 4 + 16);
     ok.ensure((size_t)n + 16);
-    okv->ensure((size_t)n + 16);
-    bits->ensure((size_t)((n + 7) / 8) + 16);
-    if (comet_launch_window_offset(shift, (const int32_t*)sp->p, (const uint32_t*)first_part->p, n, (uint32_t*)idx->p, (uint8_t*)ok.p, stream_) != 0 ||
-        comet_launch_window_offset_valid((const uint32_t*)idx->p, (const uint8_t*)ok.p, in.has_valid[(size_t)c] ? sc.valid : nullptr, n, (uint8_t*)okv->p, stream_) != 0)
-      throw CometError("window: launch failed");
-    const bool has_default = fn.args.size() == 3 && !fn.args[2]->lit_null;
-    if (!has_default) pq_launch_pack((const uint8_t*)okv->p, (uint8_t*)bits->p, n, stream_);
-    if (t.id == TypeId::String || t.id == TypeId::Bytes) {
-      DeviceColumnView ov;
-      take_utf8(sc, (const uint32_t*)idx->p, (const uint8_t*)okv->p, nullptr, n, ov, out.owners);
-      ov.valid = (const uint8_t*)bits->p;
-      out.types.push_back(t);
-      out.cols.push_back(ov);
-      out.has_valid.push_back(true);
-      out.owners.push_back(bits);
-    } else {
-      const int wd = t.id == TypeId::Bool ? 0 : fixed_width(t);
-      auto data = std::make_shared<DevBuf>();
-      data->ensure((wd ? (size_t)n * (size_t)wd : (size_t)((n + 7) / 8)) + 16);
-      if (comet_launch_take(wd, sc.data, (const uint32_t*)idx->p, n, data->p, stream_) != 0) throw CometError("window: take failed");
-      if (has_default) {
-        // rows whose offset row is outside the partition take the literal default (lag(x, k, d))
-        const Expr& lit = *fn.args[2];
-        uint8_t buf[16] = {0};
-        if (t.id == TypeId::Decimal) { i128 v = lit.lit_dec; memcpy(buf, &v, 16); }
-        else if (t.id == TypeId::Double) { double v = lit.lit_f64; memcpy(buf, &v, 8); }
-        else if (t.id == TypeId::Float) { float v = (float)lit.lit_f64; memcpy(buf, &v, 4); }
-        else { int64_t v = lit.lit_i64; memcpy(buf, &v, 8); }
-        if (comet_launch_window_default(wd, (const uint8_t*)ok.p, n, buf, data->p, (uint8_t*)okv->p, stream_) != 0) throw CometError("window: launch failed");
-        pq_launch_pack((const uint8_t*)okv->p, (uint8_t*)bits->p, n, stream_);
-      }
-      add_col(t, data, bits);
-    }
+    if (comet_launch_window_offset(shift, (const int32_t*)sp->p, (const uint32_t*)first_part->p, n, (uint32_t*)idx->p, (uint8_t*)ok.p, stream_) != 0) throw CometError("window: launch failed");
+    gather_rows(c, idx, ok, fn.args.size() == 3 && !fn.args[2]->lit_null ? fn.args[2].get() : nullptr);
     HIP_CHECK(hipStreamSynchronize(stream_));   // `ok` goes back to the pool; idx / okv are released with this scope
   }
   timed_end();

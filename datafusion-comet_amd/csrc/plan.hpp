@@ -90,6 +90,7 @@ struct AggExpr {
   DType sum_dtype;                // Avg.sum_datatype
   EvalMode eval_mode = EvalMode::Legacy;
   ExprP filter;                   // AggExpr.filter = 89
+  bool ignore_nulls = false;      // First / Last
   uint64_t expr_id = 0;
 };
 

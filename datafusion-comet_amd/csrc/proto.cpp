@@ -261,6 +261,7 @@ AggExpr decode_agg_expr(Reader r) {
       else if (f2 == 3 && wt2 == 2 && a.kind == AggKind::Avg) a.sum_dtype = decode_datatype(b.sub());
       else if (f2 == 3 && wt2 == 0 && a.kind == AggKind::Sum) a.eval_mode = (EvalMode)b.varint();
       else if (f2 == 4 && wt2 == 0 && a.kind == AggKind::Avg) a.eval_mode = (EvalMode)b.varint();
+      else if (f2 == 3 && wt2 == 0 && (a.kind == AggKind::First || a.kind == AggKind::Last)) a.ignore_nulls = b.varint() != 0;   // expr.proto:210-220
       else b.skip(wt2);
     }
   }

@@ -319,6 +319,43 @@ __global__ __launch_bounds__(256) void window_range_bounds_kernel(int width, con
   }
 }
 
+// ---- FIRST_VALUE / LAST_VALUE / nth_value over a frame ---------------------------------------------------------------------------------
+// The row whose value the function returns: the frame's first / last / n-th row, or — IGNORE NULLS, C = exclusive prefix counts of the
+// column's non-NULL rows — its first / last / n-th non-NULL row: the smallest k in the frame with C[k + 1] ≥ C[start] + want (C is
+// monotone: a binary search).  No such row → ok = 0 (the result is NULL); the gather kernels of lag / lead take it from there.
+enum { WP_FIRST = 0, WP_LAST = 1, WP_NTH = 2 };
+__global__ __launch_bounds__(256) void window_valid_flags_kernel(const u8* __restrict__ valid, i64 n, u32* __restrict__ flags) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) flags[i] = (valid[i >> 3] >> (i & 7)) & 1u;
+}
+__global__ __launch_bounds__(256) void window_pick_kernel(int mode, i64 nth, WFrame frame, const i32* __restrict__ C, const i32* __restrict__ sp, const i32* __restrict__ sg,
+                                                          const u32* __restrict__ first_part, const u32* __restrict__ first_peer, i64 n, u32* __restrict__ idx,
+                                                          u8* __restrict__ ok) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    const i32 p = sp[i + 1] - 1, g = sg[i + 1] - 1;
+    i64 start, end;
+    frame_bounds(frame, i, (i64)first_part[p], (i64)first_part[p + 1], (i64)first_peer[g], (i64)first_peer[g + 1], start, end);
+    i64 pick = -1;
+    if (end > start) {
+      if (!C) {
+        pick = mode == WP_FIRST ? start : mode == WP_LAST ? end - 1 : (start + nth - 1 < end ? start + nth - 1 : -1);
+      } else {
+        const i64 base = (i64)C[start], total = (i64)C[end] - base;
+        const i64 want = mode == WP_FIRST ? 1 : mode == WP_LAST ? total : nth;
+        if (want >= 1 && want <= total) {
+          i64 a = start, b = end - 1;
+          while (a < b) {
+            const i64 m = (a + b) >> 1;
+            if ((i64)C[m + 1] >= base + want) b = m; else a = m + 1;
+          }
+          pick = a;
+        }
+      }
+    }
+    idx[i] = pick >= 0 ? (u32)pick : 0u;
+    ok[i] = pick >= 0 ? 1 : 0;
+  }
+}
+
 // ---- MIN / MAX over frames -------------------------------------------------------------------------------------------------------
 // Running extremes per partition: P[i] = extreme of the non-NULL values of rows [partition start, i], Q[i] = of rows [i, partition end).
 // A segmented inclusive scan in three launches (tile scan in LDS → carries across tiles → apply), run forwards for P and backwards for Q.
@@ -485,6 +522,17 @@ int comet_launch_window_range_bounds(int width, const void* keys, const uint8_t*
   if (n > 0)
     hipLaunchKernelGGL(window_range_bounds_kernel, grid_for(n), 256, 0, (hipStream_t)stream, width, keys, valid, sp, first_part, (i64)n, desc, nulls_first, has_lo, (i64)dlo, has_hi,
                        (i64)dhi, out_lo, out_hi);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_window_valid_flags(const uint8_t* valid, int64_t n, uint32_t* flags, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(window_valid_flags_kernel, grid_for(n), 256, 0, (hipStream_t)stream, valid, (i64)n, flags);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_window_pick(int mode, int64_t nth, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const int32_t* C, const int32_t* sp, const int32_t* sg,
+                             const uint32_t* first_part, const uint32_t* first_peer, int64_t n, uint32_t* idx, uint8_t* ok, void* stream) {
+  if (n > 0)
+    hipLaunchKernelGGL(window_pick_kernel, grid_for(n), 256, 0, (hipStream_t)stream, mode, (i64)nth, WFrame{lo_kind, hi_kind, (i64)lo_off, (i64)hi_off}, C, sp, sg, first_part, first_peer,
+                       (i64)n, idx, ok);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_window_agg(int fn, int lo_kind, int64_t lo_off, int hi_kind, int64_t hi_off, const void* S128, const void* SH128, const int32_t* C, const int32_t* sp, const int32_t* sg, const uint32_t* first_part,

@@ -306,14 +306,15 @@ def in_(value: Expr, items: Sequence[Expr], negated: bool = False) -> Expr:
 
 @dataclass
 class AggExpr:
-    kind: str                       # count | sum | min | max | avg
+    kind: str                       # count | sum | min | max | avg | first | last
     children: List[Expr]
     dtype: Optional[DataType] = None      # result type
     sum_dtype: Optional[DataType] = None  # avg
     eval_mode: int = LEGACY
     filter: Optional[Expr] = None
+    ignore_nulls: bool = False      # first | last
 
-    TAGS = dict(count=2, sum=3, min=4, max=5, avg=6)
+    TAGS = dict(count=2, sum=3, min=4, max=5, avg=6, first=7, last=8)
 
     def encode(self) -> bytes:
         if self.kind == "count":
@@ -324,6 +325,8 @@ class AggExpr:
                 body += _f_varint(3, self.eval_mode)
         elif self.kind in ("min", "max"):
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode())
+        elif self.kind in ("first", "last"):      # First / Last{child=1, datatype=2, ignore_nulls=3} (expr.proto:210-220)
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + (_f_varint(3, 1) if self.ignore_nulls else b"")
         elif self.kind == "avg":
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_msg(3, self.sum_dtype.encode())
             if self.eval_mode:
@@ -354,6 +357,14 @@ def min_(child: Expr, dtype: DataType) -> AggExpr:
 
 def max_(child: Expr, dtype: DataType) -> AggExpr:
     return AggExpr("max", [child], dtype=dtype)
+
+
+def first_(child: Expr, dtype: DataType, ignore_nulls: bool = False) -> AggExpr:
+    return AggExpr("first", [child], dtype=dtype, ignore_nulls=ignore_nulls)
+
+
+def last_(child: Expr, dtype: DataType, ignore_nulls: bool = False) -> AggExpr:
+    return AggExpr("last", [child], dtype=dtype, ignore_nulls=ignore_nulls)
 
 
 # --------------------------------------------------------------------------- operators (operator.proto)
@@ -446,11 +457,27 @@ class Operator:
                         return _f_msg(2, _f_varint(1, int(b) & 0xFFFFFFFFFFFFFFFF) if int(b) != 0 else b"")
                     fr = (_f_varint(1, 1) if ftype == "range" else b"") + _f_msg(2, bound(lo)) + _f_msg(3, bound(up))
                     aspec = b"".join(_f_msg(1, e.encode()) for e in self.partition_by) + b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders) + _f_msg(3, fr)
-                    body += _f_msg(1, _f_msg(2, agg.encode()) + _f_msg(3, aspec) + _f_msg(5, rtype.encode()))
+                    # First / Last: the JVM side repeats their ignoreNulls in WindowExpr.ignore_nulls = 4 (CometWindowExec.scala:249-256)
+                    body += _f_msg(1, _f_msg(2, agg.encode()) + _f_msg(3, aspec) + (_f_varint(4, 1) if agg.ignore_nulls else b"") + _f_msg(5, rtype.encode()))
                     continue
-                name, args, rtype = wf
+                name, args, rtype = wf[:3]
                 fn = Expr("scalar_func", list(args), value=name)
-                body += _f_msg(1, _f_msg(1, fn.encode()) + _f_msg(3, spec) + _f_msg(5, rtype.encode()))
+                wspec = spec
+                if len(wf) > 3:      # nth_value: (name, args, result type, frame, ignore_nulls)
+                    ftype, lo, up = wf[3]
+
+                    def bound2(b):
+                        if isinstance(b, tuple):
+                            return _f_msg(2, _f_msg(2, b[1]._encode_literal()))
+                        if b == "unbounded":
+                            return _f_msg(1, b"")
+                        if b == "current":
+                            return _f_msg(3, b"")
+                        return _f_msg(2, _f_varint(1, int(b) & 0xFFFFFFFFFFFFFFFF) if int(b) != 0 else b"")
+                    fr = (_f_varint(1, 1) if ftype == "range" else b"") + _f_msg(2, bound2(lo)) + _f_msg(3, bound2(up))
+                    wspec = b"".join(_f_msg(1, e.encode()) for e in self.partition_by) + b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders) + _f_msg(3, fr)
+                ign = _f_varint(4, 1) if len(wf) > 4 and wf[4] else b""
+                body += _f_msg(1, _f_msg(1, fn.encode()) + _f_msg(3, wspec) + ign + _f_msg(5, rtype.encode()))
             body += b"".join(_f_msg(2, so_expr(*o)) for o in self.sort_orders)
             body += b"".join(_f_msg(3, e.encode()) for e in self.partition_by)
         elif self.kind == "expand":

@@ -863,6 +863,62 @@ def run_plan(S, op, table) -> List[Col]:
         for i in range(n - 1, -1, -1):
             pe[i] = i + 1 if (i == n - 1 or ps[i + 1] != ps[i]) else pe[i + 1]
             ge[i] = i + 1 if (i == n - 1 or gs[i + 1] != gs[i]) else ge[i + 1]
+        def frame_rows(i, frame):
+            """rows [start, end) of row i's frame, clipped to its partition: a bound is the partition edge, the current row (ROWS) / its peer group
+            (RANGE), the current row ± rows (negative = PRECEDING), or — ("value", literal) — a RANGE value offset"""
+            ftype, lo, up = frame
+            if isinstance(lo, tuple) or isinstance(up, tuple):
+                # RANGE with value offsets (DataFusion WindowFrameStateRange as the reference configures it, planner.rs:3031-3037,
+                # 3090-3096): target = key ∓ offset in SORT order, computed in the key's width with wrapping arithmetic, NULL for a
+                # NULL key; lower bound = first row that does not sort before its target, upper = first row that sorts after it
+                kcol, (_, kdesc, knl) = okeys[0], op.sort_orders[0]
+                bits = 8 * kcol.values.dtype.itemsize
+
+                def wrapk(x):
+                    x &= (1 << bits) - 1
+                    return x - (1 << bits) if x >> (bits - 1) else x
+                kv = lambda r: int(kcol.values[r]) if kcol.ok()[r] else None
+
+                def sorts_before(r, t):
+                    a = kv(r)
+                    if a is None or t is None:
+                        return False if (a is None and t is None) else ((a is None) == (not knl))
+                    return a > t if kdesc else a < t
+
+                def sorts_after(r, t):
+                    a = kv(r)
+                    if a is None or t is None:
+                        return False if (a is None and t is None) else ((a is None) == bool(knl))
+                    return a < t if kdesc else a > t
+                cur = kv(i)
+            if isinstance(lo, tuple):
+                t = None if cur is None else wrapk(cur + int(lo[1].value) if kdesc else cur - int(lo[1].value))
+                start = next((r for r in range(ps[i], pe[i]) if not sorts_before(r, t)), pe[i])
+            else:
+                start = ps[i] if lo == "unbounded" else ((i if ftype == "rows" else gs[i]) if lo == "current" else i + int(lo))
+            if isinstance(up, tuple):
+                t = None if cur is None else wrapk(cur - int(up[1].value) if kdesc else cur + int(up[1].value))
+                end = next((r for r in range(ps[i], pe[i]) if sorts_after(r, t)), pe[i])
+            else:
+                end = pe[i] if up == "unbounded" else ((i + 1 if ftype == "rows" else ge[i]) if up == "current" else i + int(up) + 1)
+            start, end = max(start, ps[i]), min(end, pe[i])
+            return start, max(end, start)
+
+        def pick_rows(src, frame, mode, nth, ignore_nulls):
+            """first_value / last_value / nth_value: the row of the frame whose value is returned (−1: none), NULLs skipped on request"""
+            idx = np.full(n, -1, np.int64)
+            okf = src.ok()
+            for i in range(n):
+                start, end = frame_rows(i, frame)
+                rows = [r for r in range(start, end) if okf[r]] if ignore_nulls else list(range(start, end))
+                k = 0 if mode == "first" else len(rows) - 1 if mode == "last" else nth - 1
+                if 0 <= k < len(rows):
+                    idx[i] = rows[k]
+            okv = (idx >= 0) & okf[np.maximum(idx, 0)]
+            vals = src.values[np.maximum(idx, 0)]
+            if src.values.dtype == object:
+                vals = np.array([v if o else None for v, o in zip(vals, okv)], dtype=object)
+            return Col(src.dtype, vals, None if okv.all() else okv)
         out = list(child)
         for wf in op.window_fns:
             if wf[0] == "agg":
@@ -870,47 +926,14 @@ def run_plan(S, op, table) -> List[Col]:
                 # Final step (sum_decimal.rs:264-279, sum_int.rs, avg_decimal.rs:597-689)
                 _, a, rtype, (ftype, lo, up) = wf
                 arg = ev.eval(a.children[0], child, n)
+                if a.kind in ("first", "last"):
+                    out.append(pick_rows(arg, (ftype, lo, up), a.kind, 0, a.ignore_nulls))
+                    continue
                 isdec = arg.dtype.type_id == S.DECIMAL
                 ival = [(dec_to_int(arg.values, i) if isdec else int(arg.values[i])) if arg.ok()[i] else None for i in range(n)]
                 vals, oks = [], []
                 for i in range(n):
-                    # the frame, clipped to the partition: a bound is the partition edge, the current row (ROWS) / its peer group (RANGE),
-                    # or the current row ± rows (negative = PRECEDING)
-                    if isinstance(lo, tuple) or isinstance(up, tuple):
-                        # RANGE with value offsets (DataFusion WindowFrameStateRange as the reference configures it, planner.rs:3031-3037,
-                        # 3090-3096): target = key ∓ offset in SORT order, computed in the key's width with wrapping arithmetic, NULL for a
-                        # NULL key; lower bound = first row that does not sort before its target, upper = first row that sorts after it
-                        kcol, (_, kdesc, knl) = okeys[0], op.sort_orders[0]
-                        bits = 8 * kcol.values.dtype.itemsize
-
-                        def wrapk(x):
-                            x &= (1 << bits) - 1
-                            return x - (1 << bits) if x >> (bits - 1) else x
-                        kv = lambda r: int(kcol.values[r]) if kcol.ok()[r] else None
-
-                        def sorts_before(r, t):
-                            a = kv(r)
-                            if a is None or t is None:
-                                return False if (a is None and t is None) else ((a is None) == (not knl))
-                            return a > t if kdesc else a < t
-
-                        def sorts_after(r, t):
-                            a = kv(r)
-                            if a is None or t is None:
-                                return False if (a is None and t is None) else ((a is None) == bool(knl))
-                            return a < t if kdesc else a > t
-                        cur = kv(i)
-                    if isinstance(lo, tuple):
-                        t = None if cur is None else wrapk(cur + int(lo[1].value) if kdesc else cur - int(lo[1].value))
-                        start = next((r for r in range(ps[i], pe[i]) if not sorts_before(r, t)), pe[i])
-                    else:
-                        start = ps[i] if lo == "unbounded" else ((i if ftype == "rows" else gs[i]) if lo == "current" else i + int(lo))
-                    if isinstance(up, tuple):
-                        t = None if cur is None else wrapk(cur - int(up[1].value) if kdesc else cur + int(up[1].value))
-                        end = next((r for r in range(ps[i], pe[i]) if sorts_after(r, t)), pe[i])
-                    else:
-                        end = pe[i] if up == "unbounded" else ((i + 1 if ftype == "rows" else ge[i]) if up == "current" else i + int(up) + 1)
-                    start, end = max(start, ps[i]), min(end, pe[i])
+                    start, end = frame_rows(i, (ftype, lo, up))
                     win = [v for v in ival[start:max(end, start)] if v is not None]
                     if a.kind in ("min", "max"):
                         vals.append((min(win) if a.kind == "min" else max(win)) if win else 0); oks.append(bool(win)); continue
@@ -943,7 +966,10 @@ def run_plan(S, op, table) -> List[Col]:
                 else:
                     out.append(Col(a.dtype, ints_to_dec(vals), None if okn.all() else okn))
                 continue
-            name, args, rtype = wf
+            name, args, rtype = wf[:3]
+            if name == "nth_value":
+                out.append(pick_rows(ev.eval(args[0], child, n), wf[3], "nth", int(args[1].value), bool(wf[4]) if len(wf) > 4 else False))
+                continue
             if name in ("lag", "lead"):
                 src = ev.eval(args[0], child, n)
                 kk = int(args[1].value) if len(args) > 1 else 1

@@ -184,6 +184,8 @@ def set_agg(pb, a):
             set_dtype(sub.sum_datatype, a.sum_dtype)
         if a.kind in ("sum", "avg"):
             sub.eval_mode = sub.DESCRIPTOR.fields_by_name["eval_mode"].enum_type.values_by_name[EVAL[a.eval_mode]].number
+        if a.kind in ("first", "last") and a.ignore_nulls:
+            sub.ignore_nulls = True
     sub.SetInParent()
     if a.filter is not None:
         set_expr(pb.filter, a.filter)
@@ -365,10 +367,14 @@ def set_op(pb, op):
                 _, agg, rtype, frame = wf
                 set_agg(we.agg_func, agg)
                 spec(we.spec, frame)
+                if getattr(agg, "ignore_nulls", False):
+                    we.ignore_nulls = True
             else:
-                name, args, rtype = wf
+                name, args, rtype = wf[:3]
                 set_expr(we.built_in_window_function, S.Expr("scalar_func", list(args), value=name))
-                spec(we.spec, ("rows", "unbounded", "current"))
+                spec(we.spec, wf[3] if len(wf) > 3 else ("rows", "unbounded", "current"))
+                if len(wf) > 4 and wf[4]:
+                    we.ignore_nulls = True
             set_dtype(we.result_type, rtype)
         for e, desc, nl in op.sort_orders:
             set_sort_order(w.order_by_list.add(), e, desc, nl)
@@ -416,6 +422,9 @@ def corpus():
                                                                ("agg", S.sum_(x, S.decimal(22, 2)), S.decimal(22, 2), ("range", "unbounded", "current")),
                                                                ("agg", S.count(a), I64, ("rows", "unbounded", "unbounded")),
                                                                ("agg", S.min_(a, I64), I64, ("rows", -3, 2)), ("agg", S.max_(a, I64), I64, ("rows", 0, "current"))])
+    plans["window_first_last_nth"] = S.window(sc(), [s], [(a, False, False)], [("agg", S.first_(x, DEC, True), DEC, ("rows", -1, 1)), ("agg", S.last_(s, STR), STR, ("range", "unbounded", "current")),
+                                                                                ("nth_value", [x, S.lit(2, I64)], DEC, ("rows", "unbounded", "unbounded"), True),
+                                                                                ("nth_value", [s, S.lit(1, I64)], STR, ("rows", -2, "current"))])
     plans["window_range_offsets"] = S.window(sc(), [s], [(a, True, True)], [("agg", S.count(x), I64, ("range", ("value", S.lit(5, I64)), ("value", S.lit(0, I64)))),
                                                                               ("agg", S.sum_(x, S.decimal(22, 2)), S.decimal(22, 2), ("range", "unbounded", ("value", S.lit(7, I64))))])
     for i, (part, kw) in enumerate([("hash", dict(hash_exprs=[a, s], num_partitions=7)), ("single", {}), ("round_robin", dict(num_partitions=5, max_hash_columns=2)),
@@ -485,7 +494,7 @@ def test_proto_cpp_accepts_protobufs_own_bytes(pool):
     from datafusion_comet_amd import native
     Op = cls(pool, "spark.spark_operator.Operator")
     plans = corpus()
-    for name in ("tpch_0", "tpch_1", "tpch_q3_single", "tpcds_q95_a", "tpcds_q95_b", "sort_limit", "expand", "window", "window_range_offsets"):
+    for name in ("tpch_0", "tpch_1", "tpch_q3_single", "tpcds_q95_a", "tpcds_q95_b", "sort_limit", "expand", "window", "window_range_offsets", "window_first_last_nth"):
         by_name = Op()
         set_op(by_name, plans[name])
         theirs = by_name.SerializeToString(deterministic=True)
