@@ -392,6 +392,19 @@ int64_t comet_parquet_prune_report(const uint8_t* plan, size_t plan_len, int32_t
   });
 }
 
+int64_t comet_parquet_host_plain_values(const uint8_t* plan, size_t plan_len, int32_t column, uint8_t* out, size_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    OperatorP op = decode_operator(plan, plan_len);
+    const Operator* scan = op.get();
+    while (scan && scan->kind != OpKind::NativeScan) scan = scan->children.empty() ? nullptr : scan->children[0].get();
+    if (!scan) throw CometError("comet_parquet_host_plain_values: the plan holds no NativeScan");
+    if (column < 0) throw CometError("comet_parquet_host_plain_values: negative column");
+    const std::vector<uint8_t> v = parquet_host_plain_values(*scan, (size_t)column);
+    if (out && cap) memcpy(out, v.data(), std::min(cap, v.size()));
+    return (int64_t)v.size();
+  });
+}
+
 int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t value_len) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     const RegexDfa d = compile_rlike(pattern ? pattern : "");

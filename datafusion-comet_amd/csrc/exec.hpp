@@ -131,6 +131,8 @@ struct Variant {  // one JIT specialisation of the pipeline (per input-validity 
 void scan_pool_parallel(size_t n, const std::function<void(size_t)>& fn);
 // row-group / page-index selection of a NativeScan as JSON (parquet_scan.cpp; host only)
 std::string parquet_prune_report(const Operator& native_scan, bool page_index);
+// host-staged PLAIN value bytes of one column of a NativeScan (parquet_scan.cpp; host only, a test hook)
+std::vector<uint8_t> parquet_host_plain_values(const Operator& native_scan, size_t column);
 // queue one task on the same threads (FIFO) without waiting
 void scan_pool_submit(std::function<void()> fn);
 

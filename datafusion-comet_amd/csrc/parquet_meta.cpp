@@ -169,6 +169,16 @@ ColumnMeta read_column_meta(TReader& r) {
   while (int t = r.field(fid)) {
     switch (fid) {
       case 1: m.type = (int)r.zigzag(); break;
+      case 2: {   // encodings used anywhere in the chunk
+        int et;
+        uint32_t n;
+        r.list_header(et, n);
+        for (uint32_t i = 0; i < n; i++) {
+          const int e = (int)r.zigzag();
+          if (e == DELTA_BINARY_PACKED || e == DELTA_LENGTH_BYTE_ARRAY || e == DELTA_BYTE_ARRAY) m.delta_encoded = true;
+        }
+        break;
+      }
       case 3: {
         int et;
         uint32_t n;
@@ -594,6 +604,114 @@ void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, siz
       return;
     }
     default: throw CometError("parquet: compression codec " + std::to_string(codec) + " is not supported yet (UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4_RAW are)");
+  }
+}
+
+// ---- DELTA_BINARY_PACKED / DELTA_LENGTH_BYTE_ARRAY / BYTE_STREAM_SPLIT → PLAIN (parquet-format Encodings.md) ----------------------------
+namespace {
+uint64_t delta_uleb(const uint8_t*& p, const uint8_t* end) {
+  uint64_t v = 0;
+  for (int shift = 0; shift < 70; shift += 7) {
+    if (p >= end) throw CometError("parquet: truncated DELTA_BINARY_PACKED header");
+    const uint8_t b = *p++;
+    v |= (uint64_t)(b & 0x7f) << (shift < 64 ? shift : 63);
+    if (!(b & 0x80)) return v;
+  }
+  throw CometError("parquet: malformed varint in a DELTA_BINARY_PACKED page");
+}
+int64_t delta_zigzag(uint64_t u) { return (int64_t)(u >> 1) ^ -(int64_t)(u & 1); }
+}  // namespace
+
+// header: block size, miniblocks per block, total value count (ULEB128), first value (zigzag); per block: min delta (zigzag), one bit
+// width per miniblock, then the miniblocks — (value − previous − min delta) bit-packed LSB first, always values_per_miniblock of them
+// (the last one padded); miniblocks wholly behind the last value are not stored.  Sums wrap (the spec computes in the column's width).
+std::vector<int64_t> delta_binary_unpack(const uint8_t* src, size_t len, int64_t max_values, size_t* consumed) {
+  const uint8_t* p = src;
+  const uint8_t* end = src + len;
+  const uint64_t block = delta_uleb(p, end), mini = delta_uleb(p, end), total = delta_uleb(p, end);
+  const int64_t first = delta_zigzag(delta_uleb(p, end));
+  if (block == 0 || block % 128 || mini == 0 || block % mini || (block / mini) % 32 || block > (1u << 20))
+    throw CometError("parquet: DELTA_BINARY_PACKED block layout " + std::to_string(block) + " / " + std::to_string(mini) + " is not valid");
+  if (total > (uint64_t)std::max<int64_t>(max_values, 0)) throw CometError("parquet: DELTA_BINARY_PACKED block holds " + std::to_string(total) + " values, its page only " + std::to_string(max_values));
+  const uint64_t vpm = block / mini;
+  std::vector<int64_t> out;
+  out.reserve((size_t)total);
+  if (total == 0) { if (consumed) *consumed = (size_t)(p - src); return out; }
+  out.push_back(first);
+  uint64_t prev = (uint64_t)first;
+  while (out.size() < total) {
+    const int64_t min_delta = delta_zigzag(delta_uleb(p, end));
+    if ((uint64_t)(end - p) < mini) throw CometError("parquet: truncated DELTA_BINARY_PACKED block");
+    const uint8_t* widths = p;
+    p += mini;
+    for (uint64_t m = 0; m < mini && out.size() < total; m++) {
+      const int bw = widths[m];
+      if (bw > 64) throw CometError("parquet: DELTA_BINARY_PACKED bit width " + std::to_string(bw));
+      const size_t bytes = (size_t)(vpm * (uint64_t)bw / 8);
+      if ((size_t)(end - p) < bytes) throw CometError("parquet: truncated DELTA_BINARY_PACKED miniblock");
+      const uint64_t mask = bw == 64 ? ~0ull : ((1ull << bw) - 1);
+      uint64_t bitpos = 0;
+      for (uint64_t v = 0; v < vpm && out.size() < total; v++, bitpos += (uint64_t)bw) {
+        uint64_t x = 0;
+        if (bw) {
+          const size_t b0 = (size_t)(bitpos >> 3);
+          const int sh = (int)(bitpos & 7);
+          uint8_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+          memcpy(w, p + b0, std::min<size_t>(9, bytes - b0));
+          uint64_t lo;
+          memcpy(&lo, w, 8);
+          x = sh ? (lo >> sh) | ((uint64_t)w[8] << (64 - sh)) : lo;
+          x &= mask;
+        }
+        prev = prev + (uint64_t)min_delta + x;
+        out.push_back((int64_t)prev);
+      }
+      p += bytes;
+    }
+  }
+  if (consumed) *consumed = (size_t)(p - src);
+  return out;
+}
+
+void delta_binary_to_plain(const uint8_t* src, size_t len, int width, int64_t max_values, std::vector<uint8_t>& out) {
+  const std::vector<int64_t> v = delta_binary_unpack(src, len, max_values, nullptr);
+  const size_t at = out.size();
+  out.resize(at + v.size() * (size_t)width);
+  if (width == 8) {
+    if (!v.empty()) memcpy(out.data() + at, v.data(), v.size() * 8);
+  } else if (width == 4) {
+    for (size_t i = 0; i < v.size(); i++) {
+      const int32_t x = (int32_t)v[i];
+      memcpy(out.data() + at + i * 4, &x, 4);
+    }
+  } else {
+    throw CometError("parquet: DELTA_BINARY_PACKED over a " + std::to_string(width) + "-byte physical type");
+  }
+}
+
+void delta_length_byte_array_to_plain(const uint8_t* src, size_t len, int64_t max_values, std::vector<uint8_t>& out) {
+  size_t used = 0;
+  const std::vector<int64_t> lens = delta_binary_unpack(src, len, max_values, &used);
+  size_t p = used;
+  for (int64_t l : lens) {
+    if (l < 0 || l > 0x7fffffff || (size_t)l > len - p) throw CometError("parquet: DELTA_LENGTH_BYTE_ARRAY value runs past its page");
+    const uint32_t l32 = (uint32_t)l;
+    const size_t at = out.size();
+    out.resize(at + 4 + (size_t)l);
+    memcpy(out.data() + at, &l32, 4);
+    if (l) memcpy(out.data() + at + 4, src + p, (size_t)l);
+    p += (size_t)l;
+  }
+}
+
+void byte_stream_split_to_plain(const uint8_t* src, size_t len, int width, std::vector<uint8_t>& out) {
+  if (width <= 0 || len % (size_t)width) throw CometError("parquet: BYTE_STREAM_SPLIT page size is not a multiple of the value width");
+  const size_t n = len / (size_t)width, at = out.size();
+  out.resize(at + len);
+  uint8_t* dst = out.data() + at;
+  for (int k = 0; k < width; k++) {
+    const uint8_t* stream = src + (size_t)k * n;
+    for (size_t i = 0; i < n; i++) dst[i * (size_t)width + (size_t)k] = stream[i];
   }
 }
 

@@ -11,7 +11,8 @@ namespace comet {
 namespace pq {
 
 enum PhysType : int { BOOLEAN = 0, INT32 = 1, INT64 = 2, INT96 = 3, FLOAT = 4, DOUBLE = 5, BYTE_ARRAY = 6, FLBA = 7 };
-enum Encoding : int { PLAIN = 0, PLAIN_DICTIONARY = 2, RLE = 3, BIT_PACKED = 4, RLE_DICTIONARY = 8 };
+enum Encoding : int { PLAIN = 0, PLAIN_DICTIONARY = 2, RLE = 3, BIT_PACKED = 4, DELTA_BINARY_PACKED = 5, DELTA_LENGTH_BYTE_ARRAY = 6, DELTA_BYTE_ARRAY = 7,
+                      RLE_DICTIONARY = 8, BYTE_STREAM_SPLIT = 9 };
 enum Codec : int { UNCOMPRESSED = 0, SNAPPY = 1, GZIP = 2, LZO = 3, BROTLI = 4, LZ4 = 5, ZSTD = 6, LZ4_RAW = 7 };
 enum PageType : int { DATA_PAGE = 0, INDEX_PAGE = 1, DICTIONARY_PAGE = 2, DATA_PAGE_V2 = 3 };
 
@@ -39,6 +40,7 @@ struct ColumnMeta {
   int64_t num_values = 0;
   int64_t total_uncompressed = 0, total_compressed = 0;
   int64_t data_page_offset = 0, dictionary_page_offset = 0;
+  bool delta_encoded = false;   // ColumnMetaData.encodings names a DELTA_* encoding: decoded pages outgrow total_uncompressed_size
   // Statistics (parquet.thrift Statistics: 3 null_count, 5 max_value, 6 min_value; 1/2 = deprecated max/min, signed order only)
   bool has_min_max = false;
   std::string min_value, max_value;   // PLAIN-encoded
@@ -87,6 +89,13 @@ PageHeader parse_page_header(const uint8_t* p, size_t avail);
 void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len);
 // first `want` bytes of a raw snappy stream (the levels in front of a v1 page's values); returns the bytes produced
 size_t snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t want);
+// Value encodings the device kernels do not read are rewritten as PLAIN on the host (parquet-format Encodings.md): DELTA_BINARY_PACKED
+// (INT32 / INT64, `width` = 4 / 8), DELTA_LENGTH_BYTE_ARRAY (→ 4-byte length + bytes per value), BYTE_STREAM_SPLIT (`width` bytes per value).
+// `src` holds the page's value bytes; the PLAIN bytes are appended to `out`.  Throws on truncated or inconsistent input.
+void delta_binary_to_plain(const uint8_t* src, size_t len, int width, int64_t max_values, std::vector<uint8_t>& out);
+void delta_length_byte_array_to_plain(const uint8_t* src, size_t len, int64_t max_values, std::vector<uint8_t>& out);
+void byte_stream_split_to_plain(const uint8_t* src, size_t len, int width, std::vector<uint8_t>& out);
+std::vector<int64_t> delta_binary_unpack(const uint8_t* src, size_t len, int64_t max_values, size_t* consumed);
 
 }  // namespace pq
 }  // namespace comet

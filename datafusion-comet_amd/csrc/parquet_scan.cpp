@@ -691,7 +691,11 @@ struct ChunkSource {
 
 // bytes the staged (decompressed) pages of a column chunk may take
 // (device-decompressed pages start on 16-byte boundaries: at most one per 4 KiB of page data, hence the 1/256)
-size_t staged_capacity(const pq::ColumnMeta& cm) { return ((size_t)cm.total_uncompressed + (size_t)cm.total_uncompressed / 256 + 128 + 15) & ~(size_t)15; }
+// A chunk with DELTA_* pages is rewritten as PLAIN on the host and outgrows its declared size: at most 8 bytes per value more.
+size_t staged_capacity(const pq::ColumnMeta& cm) {
+  const size_t delta = cm.delta_encoded ? (size_t)std::max<int64_t>(cm.num_values, 0) * 8 + 64 : 0;
+  return ((size_t)cm.total_uncompressed + (size_t)cm.total_uncompressed / 256 + delta + 128 + 15) & ~(size_t)15;
+}
 // offsets into the device-decompressed region carry this bit until the column's tables are assembled
 constexpr int64_t kInflatedBit = (int64_t)1 << 62;
 constexpr int32_t kMinDevicePage = 4096;
@@ -923,7 +927,30 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       pq::decompress(h.v2_compressed ? cm.codec : pq::UNCOMPRESSED, body + h.def_bytes, vcomp, staged + vals_begin, vun);
       page_end = vals_begin + vun;
     }
-    if (h.encoding == pq::PLAIN) {
+    int value_encoding = h.encoding;
+    if (value_encoding == pq::DELTA_BINARY_PACKED || value_encoding == pq::DELTA_LENGTH_BYTE_ARRAY || value_encoding == pq::BYTE_STREAM_SPLIT) {
+      // encodings the device kernels do not read: the page's values are rewritten as PLAIN in place (parquet_meta.cpp); delta pages grow,
+      // which staged_capacity allowed for
+      std::vector<uint8_t> plain;
+      const uint8_t* vsrc = staged + vals_begin;
+      const size_t vlen = page_end - vals_begin;
+      if (value_encoding == pq::DELTA_BINARY_PACKED) {
+        if (cp.is_string || (cp.src_width != 4 && cp.src_width != 8) || cm.type == pq::FLOAT || cm.type == pq::DOUBLE)
+          throw CometError("parquet: DELTA_BINARY_PACKED values of a column that is not INT32 / INT64");
+        pq::delta_binary_to_plain(vsrc, vlen, cp.src_width, h.num_values, plain);
+      } else if (value_encoding == pq::DELTA_LENGTH_BYTE_ARRAY) {
+        if (!cp.is_string) throw CometError("parquet: DELTA_LENGTH_BYTE_ARRAY values of a column that is not BYTE_ARRAY");
+        pq::delta_length_byte_array_to_plain(vsrc, vlen, h.num_values, plain);
+      } else {
+        if (cp.is_string || cp.src_width <= 0) throw CometError("parquet: BYTE_STREAM_SPLIT values of a variable-length column");
+        pq::byte_stream_split_to_plain(vsrc, vlen, cp.src_width, plain);
+      }
+      if (vals_begin + plain.size() + 16 > staged_cap) throw CometError("parquet: decoded " + std::string(value_encoding == pq::BYTE_STREAM_SPLIT ? "BYTE_STREAM_SPLIT" : "DELTA") + " page does not fit the column chunk's staging slot");
+      if (!plain.empty()) memcpy(staged + vals_begin, plain.data(), plain.size());
+      page_end = vals_begin + plain.size();
+      value_encoding = pq::PLAIN;
+    }
+    if (value_encoding == pq::PLAIN) {
       pg.encoding = 0;
       pg.values_off = (int64_t)vals_begin;
       if (cp.is_string) {
@@ -985,7 +1012,8 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
         pg.idx_run_count = 1;
       }
     } else {
-      throw CometError("parquet: value encoding " + std::to_string(h.encoding) + " is not supported yet (PLAIN and RLE_DICTIONARY are)");
+      throw CometError("parquet: value encoding " + std::to_string(h.encoding) + (h.encoding == pq::DELTA_BYTE_ARRAY ? " (DELTA_BYTE_ARRAY)" : "") +
+                       " is not supported yet (PLAIN, RLE_DICTIONARY, RLE booleans, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY and BYTE_STREAM_SPLIT are)");
     }
     spos = page_end;
     emit(pg, values_seen, values_seen + h.num_values, staged);
@@ -1166,6 +1194,43 @@ std::string parquet_prune_report(const Operator& op, bool page_index) {
     j += "]}";
   }
   return j + "]}";
+}
+
+// Diagnostic (host only, no device): the PLAIN value bytes the host stages for one column of a NativeScan — every selected row group,
+// page after page, NULLs left out; BYTE_ARRAY values as 4-byte length + bytes.  Pages whose values reach the device as dictionary indices
+// are refused.  What the CPU tests read to check the host-side rewriting of DELTA_* / BYTE_STREAM_SPLIT pages against pyarrow.
+std::vector<uint8_t> parquet_host_plain_values(const Operator& op, size_t col) {
+  if (col >= op.required_schema.size()) throw CometError("parquet_host_plain_values: no such column");
+  ScanOptions so = ScanOptions::of(op);
+  so.device_snappy = false;
+  std::vector<Sel> sels;
+  int64_t total = 0, rg_pruned = 0, rows_pruned = 0;
+  select_row_groups(op, false, sels, total, rg_pruned, rows_pruned);
+  std::vector<uint8_t> out;
+  for (const Sel& sl : sels) {
+    ColumnPlan cp = plan_column(op.required_schema[col], *sl.meta, so);
+    if (cp.missing) continue;
+    const pq::ColumnMeta& cm = sl.meta->row_groups[(size_t)sl.rg].columns[(size_t)cp.leaf];
+    std::vector<uint8_t> staged(staged_capacity(cm) + 64);
+    HostChunk hc;
+    ChunkSource src{sl.file.get(), sl.meta.get(), sl.rg, nullptr};
+    decode_chunk_host(src, op.required_schema[col], so, hc, staged.data(), staged.size());
+    for (const PqPage& pg : hc.pages) {
+      if (pg.encoding != 0) throw CometError("parquet_host_plain_values: the column has dictionary-encoded pages");
+      if (hc.cp.is_string) {
+        for (int32_t k = 0; k < pg.value_count; k++) {
+          const int64_t off = hc.str_offs[(size_t)(pg.str_first + k)];
+          uint32_t len;
+          memcpy(&len, staged.data() + off - 4, 4);
+          out.insert(out.end(), staged.data() + off - 4, staged.data() + off + len);
+        }
+      } else {
+        const uint8_t* v = staged.data() + pg.values_off;
+        out.insert(out.end(), v, v + (size_t)pg.value_count * (size_t)pg.width);
+      }
+    }
+  }
+  return out;
 }
 
 DevTable ExecutionContext::scan_parquet(const Operator& op) {

@@ -109,6 +109,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_exchange_result_rows.argtypes = [c.c_int64]
     lib.comet_exchange_result_column.restype = c.c_int32
     lib.comet_exchange_result_column.argtypes = [c.c_int64, c.c_int32, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p)]
+    lib.comet_parquet_host_plain_values.restype = c.c_int64
+    lib.comet_parquet_host_plain_values.argtypes = [c.c_char_p, c.c_size_t, c.c_int32, c.c_void_p, c.c_size_t]
     lib.comet_exchange_result_aux.restype = c.c_int32
     lib.comet_exchange_result_aux.argtypes = [c.c_int64, c.c_int32, c.POINTER(c.c_void_p), c.POINTER(c.c_int64)]
     lib.comet_exchange_result_release.restype = None
@@ -983,6 +985,17 @@ def rlike_match(pattern: str, value: str) -> bool:
     if rc < 0:
         _raise_last(0)
     return rc == 1
+
+
+def parquet_host_plain_values(plan: bytes, column: int) -> bytes:
+    """PLAIN value bytes the scan stages on the host for one column of the plan's NativeScan (comet_parquet_host_plain_values; host only)"""
+    n = lib().comet_parquet_host_plain_values(plan, len(plan), column, None, 0)
+    if n < 0:
+        _raise_last(0)
+    buf = ctypes.create_string_buffer(max(int(n), 1))
+    if lib().comet_parquet_host_plain_values(plan, len(plan), column, buf, n) < 0:
+        _raise_last(0)
+    return buf.raw[:n]
 
 
 def parquet_prune_report(plan: bytes, page_index: bool = True) -> dict:
