@@ -176,6 +176,7 @@ ColumnMeta read_column_meta(TReader& r) {
         for (uint32_t i = 0; i < n; i++) {
           const int e = (int)r.zigzag();
           if (e == DELTA_BINARY_PACKED || e == DELTA_LENGTH_BYTE_ARRAY || e == DELTA_BYTE_ARRAY) m.delta_encoded = true;
+          if (e == DELTA_BYTE_ARRAY) m.prefix_encoded = true;
         }
         break;
       }
@@ -712,6 +713,42 @@ void byte_stream_split_to_plain(const uint8_t* src, size_t len, int width, std::
   for (int k = 0; k < width; k++) {
     const uint8_t* stream = src + (size_t)k * n;
     for (size_t i = 0; i < n; i++) dst[i * (size_t)width + (size_t)k] = stream[i];
+  }
+}
+
+size_t delta_byte_array_plain_size(const uint8_t* src, size_t len, int64_t max_values) {
+  size_t used = 0, used2 = 0;
+  const std::vector<int64_t> prefix = delta_binary_unpack(src, len, max_values, &used);
+  const std::vector<int64_t> suffix = delta_binary_unpack(src + used, len - used, max_values, &used2);
+  if (prefix.size() != suffix.size()) throw CometError("parquet: DELTA_BYTE_ARRAY prefix and suffix counts differ");
+  size_t total = 0;
+  for (size_t i = 0; i < prefix.size(); i++) {
+    if (prefix[i] < 0 || suffix[i] < 0 || prefix[i] > 0x7fffffff || suffix[i] > 0x7fffffff) throw CometError("parquet: DELTA_BYTE_ARRAY length out of range");
+    total += 4 + (size_t)prefix[i] + (size_t)suffix[i];
+    if (total > ((size_t)1 << 40)) throw CometError("parquet: DELTA_BYTE_ARRAY page decodes to more than 1 TiB");
+  }
+  return total;
+}
+
+void delta_byte_array_to_plain(const uint8_t* src, size_t len, int64_t max_values, std::vector<uint8_t>& out) {
+  size_t used = 0, used2 = 0;
+  const std::vector<int64_t> prefix = delta_binary_unpack(src, len, max_values, &used);
+  const std::vector<int64_t> suffix = delta_binary_unpack(src + used, len - used, max_values, &used2);
+  if (prefix.size() != suffix.size()) throw CometError("parquet: DELTA_BYTE_ARRAY prefix and suffix counts differ");
+  size_t p = used + used2;          // the suffix bytes, back to back
+  size_t prev_at = 0, prev_len = 0; // the previous value inside `out` (its bytes, behind its length word)
+  for (size_t i = 0; i < prefix.size(); i++) {
+    const int64_t pl = prefix[i], sl = suffix[i];
+    if (pl < 0 || sl < 0 || (size_t)pl > prev_len || (size_t)sl > len - p) throw CometError("parquet: DELTA_BYTE_ARRAY value " + std::to_string(i) + " is inconsistent with its page");
+    const uint32_t l32 = (uint32_t)(pl + sl);
+    const size_t at = out.size();
+    out.resize(at + 4 + (size_t)l32);
+    memcpy(out.data() + at, &l32, 4);
+    if (pl) memcpy(out.data() + at + 4, out.data() + prev_at, (size_t)pl);     // out may have moved: addressed by offset
+    if (sl) memcpy(out.data() + at + 4 + (size_t)pl, src + p, (size_t)sl);
+    p += (size_t)sl;
+    prev_at = at + 4;
+    prev_len = l32;
   }
 }
 

@@ -41,6 +41,7 @@ struct ColumnMeta {
   int64_t total_uncompressed = 0, total_compressed = 0;
   int64_t data_page_offset = 0, dictionary_page_offset = 0;
   bool delta_encoded = false;   // ColumnMetaData.encodings names a DELTA_* encoding: decoded pages outgrow total_uncompressed_size
+  bool prefix_encoded = false;  // … DELTA_BYTE_ARRAY among them: the decoded size is only known after reading the pages' length blocks
   // Statistics (parquet.thrift Statistics: 3 null_count, 5 max_value, 6 min_value; 1/2 = deprecated max/min, signed order only)
   bool has_min_max = false;
   std::string min_value, max_value;   // PLAIN-encoded
@@ -95,6 +96,10 @@ size_t snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t want);
 void delta_binary_to_plain(const uint8_t* src, size_t len, int width, int64_t max_values, std::vector<uint8_t>& out);
 void delta_length_byte_array_to_plain(const uint8_t* src, size_t len, int64_t max_values, std::vector<uint8_t>& out);
 void byte_stream_split_to_plain(const uint8_t* src, size_t len, int width, std::vector<uint8_t>& out);
+// DELTA_BYTE_ARRAY (incremental encoding: a DELTA_BINARY_PACKED block of prefix lengths, then the suffixes as DELTA_LENGTH_BYTE_ARRAY) →
+// PLAIN; and the PLAIN size alone (Σ 4 + prefix + suffix), from the two length blocks
+void delta_byte_array_to_plain(const uint8_t* src, size_t len, int64_t max_values, std::vector<uint8_t>& out);
+size_t delta_byte_array_plain_size(const uint8_t* src, size_t len, int64_t max_values);
 std::vector<int64_t> delta_binary_unpack(const uint8_t* src, size_t len, int64_t max_values, size_t* consumed);
 
 }  // namespace pq

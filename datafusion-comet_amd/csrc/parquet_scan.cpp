@@ -700,6 +700,52 @@ size_t staged_capacity(const pq::ColumnMeta& cm) {
 constexpr int64_t kInflatedBit = (int64_t)1 << 62;
 constexpr int32_t kMinDevicePage = 4096;
 
+// DELTA_BYTE_ARRAY pages are prefix-compressed: what they decode to is only known from their length blocks.  One extra pass over such a
+// chunk (read, decompress, decode the two length blocks of every page) sizes its staging slot; nothing else pays for it.
+size_t prefix_encoded_plain_bytes(const ChunkSource& src, const pq::ColumnMeta& cm, int max_def) {
+  int64_t off = (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < cm.data_page_offset) ? cm.dictionary_page_offset : cm.data_page_offset;
+  const int64_t chunk_end = off + cm.total_compressed;
+  if (off < 0 || (size_t)chunk_end > src.file->size) throw CometError("parquet: column chunk outside the file");
+  std::vector<uint8_t> raw((size_t)cm.total_compressed + 16), page;
+  src.file->read_at(raw.data(), (size_t)cm.total_compressed, off);
+  const uint8_t* chunk_data = raw.data() - off;
+  size_t total = 0;
+  int64_t values_seen = 0;
+  while (values_seen < cm.num_values && off < chunk_end) {
+    pq::PageHeader h = pq::parse_page_header(chunk_data + off, (size_t)(chunk_end - off));
+    const uint8_t* body = chunk_data + off + h.header_len;
+    off += (int64_t)h.header_len + h.compressed_size;
+    if (h.type != pq::DATA_PAGE && h.type != pq::DATA_PAGE_V2) continue;
+    values_seen += h.num_values;
+    if (h.encoding != pq::DELTA_BYTE_ARRAY) continue;
+    if (h.uncompressed_size < 0 || h.compressed_size < 0 || h.uncompressed_size > (1 << 30)) throw CometError("parquet: implausible page size");
+    page.resize((size_t)h.uncompressed_size + 16);
+    size_t vbegin = 0, vend = 0;
+    if (h.type == pq::DATA_PAGE) {
+      pq::decompress(cm.codec, body, (size_t)h.compressed_size, page.data(), (size_t)h.uncompressed_size);
+      vend = (size_t)h.uncompressed_size;
+      if (max_def > 0) {
+        if (vend < 4) throw CometError("parquet: truncated data page");
+        uint32_t dl;
+        memcpy(&dl, page.data(), 4);
+        vbegin = 4 + (size_t)dl;
+      }
+    } else {
+      if (h.def_bytes < 0 || h.rep_bytes < 0 || h.def_bytes + h.rep_bytes > h.compressed_size) throw CometError("parquet: v2 page levels longer than the page");
+      const size_t lv = (size_t)h.def_bytes + (size_t)h.rep_bytes;
+      pq::decompress(h.v2_compressed ? cm.codec : pq::UNCOMPRESSED, body + lv, (size_t)h.compressed_size - lv, page.data(), (size_t)h.uncompressed_size - lv);
+      vend = (size_t)h.uncompressed_size - lv;
+    }
+    if (vbegin > vend) throw CometError("parquet: definition levels longer than their page");
+    total += pq::delta_byte_array_plain_size(page.data() + vbegin, vend - vbegin, h.num_values) + 16;
+  }
+  return total;
+}
+// staging slot of one column chunk: its declared size, what DELTA pages add, and for prefix-compressed strings what they measure to
+size_t chunk_staging_capacity(const ChunkSource& src, const pq::ColumnMeta& cm, int max_def) {
+  return staged_capacity(cm) + (cm.prefix_encoded ? ((prefix_encoded_plain_bytes(src, cm, max_def) + 15) & ~(size_t)15) : 0);
+}
+
 void decode_chunk_host(const ChunkSource& src, const StructField& want, const ScanOptions& so, HostChunk& hc, uint8_t* staged, size_t staged_cap) {
   const pq::RowGroup& rg = src.meta->row_groups[(size_t)src.rg];
   ColumnPlan cp = plan_column(want, *src.meta, so);
@@ -928,7 +974,8 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       page_end = vals_begin + vun;
     }
     int value_encoding = h.encoding;
-    if (value_encoding == pq::DELTA_BINARY_PACKED || value_encoding == pq::DELTA_LENGTH_BYTE_ARRAY || value_encoding == pq::BYTE_STREAM_SPLIT) {
+    if (value_encoding == pq::DELTA_BINARY_PACKED || value_encoding == pq::DELTA_LENGTH_BYTE_ARRAY || value_encoding == pq::DELTA_BYTE_ARRAY ||
+        value_encoding == pq::BYTE_STREAM_SPLIT) {
       // encodings the device kernels do not read: the page's values are rewritten as PLAIN in place (parquet_meta.cpp); delta pages grow,
       // which staged_capacity allowed for
       std::vector<uint8_t> plain;
@@ -941,6 +988,9 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       } else if (value_encoding == pq::DELTA_LENGTH_BYTE_ARRAY) {
         if (!cp.is_string) throw CometError("parquet: DELTA_LENGTH_BYTE_ARRAY values of a column that is not BYTE_ARRAY");
         pq::delta_length_byte_array_to_plain(vsrc, vlen, h.num_values, plain);
+      } else if (value_encoding == pq::DELTA_BYTE_ARRAY) {
+        if (!cp.is_string) throw CometError("parquet: DELTA_BYTE_ARRAY values of a column that is not BYTE_ARRAY");
+        pq::delta_byte_array_to_plain(vsrc, vlen, h.num_values, plain);
       } else {
         if (cp.is_string || cp.src_width <= 0) throw CometError("parquet: BYTE_STREAM_SPLIT values of a variable-length column");
         pq::byte_stream_split_to_plain(vsrc, vlen, cp.src_width, plain);
@@ -1012,8 +1062,8 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
         pg.idx_run_count = 1;
       }
     } else {
-      throw CometError("parquet: value encoding " + std::to_string(h.encoding) + (h.encoding == pq::DELTA_BYTE_ARRAY ? " (DELTA_BYTE_ARRAY)" : "") +
-                       " is not supported yet (PLAIN, RLE_DICTIONARY, RLE booleans, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY and BYTE_STREAM_SPLIT are)");
+      throw CometError("parquet: value encoding " + std::to_string(h.encoding) +
+                       " is not supported (PLAIN, RLE_DICTIONARY, RLE booleans, the three DELTA encodings and BYTE_STREAM_SPLIT are)");
     }
     spos = page_end;
     emit(pg, values_seen, values_seen + h.num_values, staged);
@@ -1211,9 +1261,9 @@ std::vector<uint8_t> parquet_host_plain_values(const Operator& op, size_t col) {
     ColumnPlan cp = plan_column(op.required_schema[col], *sl.meta, so);
     if (cp.missing) continue;
     const pq::ColumnMeta& cm = sl.meta->row_groups[(size_t)sl.rg].columns[(size_t)cp.leaf];
-    std::vector<uint8_t> staged(staged_capacity(cm) + 64);
-    HostChunk hc;
     ChunkSource src{sl.file.get(), sl.meta.get(), sl.rg, nullptr};
+    std::vector<uint8_t> staged(chunk_staging_capacity(src, cm, cp.el.repetition == 1 ? 1 : 0) + 64);
+    HostChunk hc;
     decode_chunk_host(src, op.required_schema[col], so, hc, staged.data(), staged.size());
     for (const PqPage& pg : hc.pages) {
       if (pg.encoding != 0) throw CometError("parquet_host_plain_values: the column has dictionary-encoded pages");
@@ -1293,7 +1343,14 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       if (!cp.missing && (size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
       chunk_missing[c * nsel + si] = cp.missing;
       if (!cp.missing && !have) { plans[c] = cp; have = true; }
-      slot_off[c][si + 1] = slot_off[c][si] + (cp.missing ? synth_capacity(op.required_schema[c].dtype, rg.num_rows) : staged_capacity(rg.columns[(size_t)cp.leaf]));
+      size_t cap_bytes;
+      if (cp.missing) {
+        cap_bytes = synth_capacity(op.required_schema[c].dtype, rg.num_rows);
+      } else {
+        ChunkSource csrc{sels[si].file.get(), sels[si].meta.get(), sels[si].rg, nullptr};
+        cap_bytes = chunk_staging_capacity(csrc, rg.columns[(size_t)cp.leaf], cp.el.repetition == 1 ? 1 : 0);   // reads the chunk only if it holds DELTA_BYTE_ARRAY pages
+      }
+      slot_off[c][si + 1] = slot_off[c][si] + cap_bytes;
     }
     if (!have) {
       plans[c] = plan_column(op.required_schema[c], *sels[0].meta, so);

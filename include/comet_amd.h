@@ -166,7 +166,7 @@ void comet_plan_memory_stats(int64_t plan, int64_t* out4);
  * Reads footers and page indexes only; needs no GPU.  Returns the JSON's length (truncated to cap − 1 in `out`), or -2. */
 int64_t comet_parquet_prune_report(const uint8_t* plan, size_t plan_len, int32_t page_index, char* out, size_t cap);
 /* Diagnostic, host only: the PLAIN value bytes the scan stages for column `column` of the plan's NativeScan (selected row groups, page after
- * page, NULLs left out, BYTE_ARRAY values as 4-byte length + bytes) — DELTA_BINARY_PACKED / DELTA_LENGTH_BYTE_ARRAY / BYTE_STREAM_SPLIT pages are
+ * page, NULLs left out, BYTE_ARRAY values as 4-byte length + bytes) — DELTA_BINARY_PACKED / DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY / BYTE_STREAM_SPLIT pages are
  * rewritten as PLAIN on the host (the reference reads them through arrow-rs, parquet/parquet_exec.rs:60-211).  Returns the byte count (the first
  * `cap` bytes are copied), -2 on error (comet_last_error(0)). */
 int64_t comet_parquet_host_plain_values(const uint8_t* plan, size_t plan_len, int32_t column, uint8_t* out, size_t cap);

@@ -71,11 +71,14 @@ def test_roundtrip_all_types(built, tmp_path, compression, use_dictionary):
 
 @pytest.mark.parametrize("version,codec", [("2.0", "snappy"), ("1.0", "zstd")])
 def test_delta_and_byte_stream_split_encodings(built, tmp_path, version, codec):
-    """what data-page-v2 writers emit instead of PLAIN: DELTA_BINARY_PACKED ints / dates, DELTA_LENGTH_BYTE_ARRAY strings, BYTE_STREAM_SPLIT
+    """what data-page-v2 writers emit instead of PLAIN: DELTA_BINARY_PACKED ints / dates, DELTA_LENGTH_BYTE_ARRAY and prefix-compressed DELTA_BYTE_ARRAY strings, BYTE_STREAM_SPLIT
     floats (rewritten as PLAIN on the host, tests/test_parquet_encodings_cpu.py), next to dictionary columns, with NULLs and several row groups"""
     t = _mixed_table(40_000, 23)
+    rng = np.random.default_rng(5)
+    t = t.append_column("p", pa.array(sorted("Customer#%09d/BUILDING" % int(k) for k in rng.integers(0, 10**6, t.num_rows)), mask=rng.random(t.num_rows) < 0.1))
     path = str(tmp_path / "v2.parquet")
-    enc = {"i32": "DELTA_BINARY_PACKED", "i64": "DELTA_BINARY_PACKED", "d": "DELTA_BINARY_PACKED", "s": "DELTA_LENGTH_BYTE_ARRAY", "f64": "BYTE_STREAM_SPLIT", "f32": "BYTE_STREAM_SPLIT"}
+    enc = {"i32": "DELTA_BINARY_PACKED", "i64": "DELTA_BINARY_PACKED", "d": "DELTA_BINARY_PACKED", "s": "DELTA_LENGTH_BYTE_ARRAY", "p": "DELTA_BYTE_ARRAY", "f64": "BYTE_STREAM_SPLIT",
+           "f32": "BYTE_STREAM_SPLIT"}
     papq.write_table(t, path, use_dictionary=["lowcard"], column_encoding=enc, data_page_version=version, compression=codec, row_group_size=15_000, data_page_size=1 << 13)
     _assert_same(_scan(path, t), t)
 
