@@ -296,7 +296,6 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
           const DType& at = st[(size_t)fn.args[0]->bound_index];
           if (at.id == TypeId::String || at.id == TypeId::Bytes || at.id == TypeId::Bool) throw CometError(f + " with a non-NULL default value over " + at.str() + " is not supported yet");
         }
-        if (fn.ignore_nulls) throw CometError(f + " IGNORE NULLS is not supported yet");
         out.push_back(st[(size_t)fn.args[0]->bound_index]);
       } else if (f == "nth_value") {
         // nth_value(column, n) over the spec's frame (CometWindowExec.scala:293-306): the frame's n-th row (or n-th non-NULL row)

@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void window_range_bounds_kernel(int width, con
 // The row whose value the function returns: the frame's first / last / n-th row, or — IGNORE NULLS, C = exclusive prefix counts of the
 // column's non-NULL rows — its first / last / n-th non-NULL row: the smallest k in the frame with C[k + 1] ≥ C[start] + want (C is
 // monotone: a binary search).  No such row → ok = 0 (the result is NULL); the gather kernels of lag / lead take it from there.
-enum { WP_FIRST = 0, WP_LAST = 1, WP_NTH = 2 };
+// WP_LAG / WP_LEAD (IGNORE NULLS, the frame is the whole partition): the nth non-NULL row strictly before / after the current one
+enum { WP_FIRST = 0, WP_LAST = 1, WP_NTH = 2, WP_LAG = 3, WP_LEAD = 4 };
 __global__ __launch_bounds__(256) void window_valid_flags_kernel(const u8* __restrict__ valid, i64 n, u32* __restrict__ flags) {
   for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) flags[i] = (valid[i >> 3] >> (i & 7)) & 1u;
 }
@@ -337,10 +338,12 @@ __global__ __launch_bounds__(256) void window_pick_kernel(int mode, i64 nth, WFr
     i64 pick = -1;
     if (end > start) {
       if (!C) {
-        pick = mode == WP_FIRST ? start : mode == WP_LAST ? end - 1 : (start + nth - 1 < end ? start + nth - 1 : -1);
+        pick = mode == WP_FIRST ? start : mode == WP_LAST ? end - 1 : mode == WP_LAG ? (i - nth >= start ? i - nth : -1) : mode == WP_LEAD ? (i + nth < end ? i + nth : -1)
+                                                                   : (start + nth - 1 < end ? start + nth - 1 : -1);
       } else {
         const i64 base = (i64)C[start], total = (i64)C[end] - base;
-        const i64 want = mode == WP_FIRST ? 1 : mode == WP_LAST ? total : nth;
+        // the ordinal, among the frame's non-NULL rows, of the one wanted
+        const i64 want = mode == WP_FIRST ? 1 : mode == WP_LAST ? total : mode == WP_LAG ? (i64)C[i] - base - nth + 1 : mode == WP_LEAD ? (i64)C[i + 1] - base + nth : nth;
         if (want >= 1 && want <= total) {
           i64 a = start, b = end - 1;
           while (a < b) {

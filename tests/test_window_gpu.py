@@ -186,7 +186,8 @@ def test_range_frames_with_value_offsets(built, desc, nulls_last):
 
 def test_first_last_and_nth_value(built):
     """FIRST_VALUE / LAST_VALUE (the First / Last aggregates over a frame, planner.rs:3243-3251) and nth_value (CometWindowExec.scala:293-306),
-    respecting and ignoring NULLs, over ROWS frames, frames touching the partition edges and a RANGE frame with value offsets; decimal,
+    respecting and ignoring NULLs, over ROWS frames, frames touching the partition edges and a RANGE frame with value offsets; lag / lead
+    IGNORE NULLS; decimal,
     string and integer arguments.  Unique order keys: which row is first depends on the position among peers."""
     from oracle import oracle as O
     n = 4000
@@ -206,6 +207,10 @@ def test_first_last_and_nth_value(built):
         for ign in (False, True):
             fns += [("agg", S.first_(amount, D, ign), D, fr), ("agg", S.last_(label, S.T_STRING, ign), S.T_STRING, fr), ("agg", S.last_(ident, S.T_INT64, ign), S.T_INT64, fr),
                     ("nth_value", [amount, S.lit(2, S.T_INT64)], D, fr, ign), ("nth_value", [label, S.lit(3, S.T_INT64)], S.T_STRING, fr, ign)]
+    # lag / lead IGNORE NULLS: the k-th non-NULL row before / after, with and without a default
+    whole = ("rows", "unbounded", "unbounded")
+    fns += [("lag", [amount, S.lit(1, S.T_INT32)], D, whole, True), ("lead", [amount, S.lit(2, S.T_INT32), S.lit(__import__("decimal").Decimal("-1.00"), D)], D, whole, True),
+            ("lag", [label, S.lit(3, S.T_INT32)], S.T_STRING, whole, True), ("lead", [amount, S.lit(1, S.T_INT32)], D, whole, False)]
     plan = S.window(child, [g], order, fns)
     ncols = len(fields) + len(fns)
     got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], ncols, plan.encode(), batch_size=0))
