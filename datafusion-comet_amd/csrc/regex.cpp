@@ -7,9 +7,13 @@
 //   literals (any UTF-8), `.` (any scalar value but \n), classes [a-z0-9_] / [^…] with ASCII members, escapes of punctuation and \t \n \r,
 //   grouping ( ) and (?: ), alternation |, * + ? {m} {m,} {m,n} (lazy forms mean the same for a yes/no answer), ^ and $ (start / end of
 //   the text, as in the crate without the m flag).
+//   A leading (?i) makes the whole pattern case insensitive the way the crate does it — Unicode SIMPLE case folding — which for ASCII
+//   letters means: the other ASCII case, and for k / s also U+212A KELVIN SIGN / U+017F LATIN SMALL LETTER LONG S (the only non-ASCII
+//   scalar values that fold to an ASCII letter); non-ASCII literals under (?i), and negated classes that would have to exclude those two,
+//   are refused.
 // Refused: \d \w \s \b and the other Perl / Unicode classes (they are Unicode-aware in the crate: an ASCII rendering would differ on
-// non-ASCII text), flags like (?i), look-around and back-references (the crate refuses those too), non-ASCII class members, counted
-// repetitions above 64.
+// non-ASCII text), other flags and scoped flag groups, look-around and back-references (the crate refuses those too), non-ASCII class
+// members, counted repetitions above 64.
 //
 // Construction: parse → Thompson NFA over byte sets (a `.` or a negated class becomes the UTF-8 sequence alternation) → subset
 // construction of the SEARCH automaton (the start state is re-injected after every byte; ^ is passable only before the first byte).
@@ -95,7 +99,22 @@ NodeP one_char(const ByteSet& ascii, bool and_multibyte) {
 struct Parser {
   const std::string& p;
   size_t i = 0;
-  explicit Parser(const std::string& s) : p(s) {}
+  bool icase = false;     // a leading (?i)
+  explicit Parser(const std::string& s) : p(s) {
+    if (p.compare(0, 4, "(?i)") == 0) { icase = true; i = 4; }
+  }
+  static bool is_letter(int b) { return (b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z'); }
+  // the non-ASCII scalar values whose simple case folding is the ASCII letter b (CaseFolding.txt: 212A → k, 017F → s), as UTF-8 sequences
+  static NodeP fold_partner(int b) {
+    auto seq = [](std::initializer_list<int> bytes) {
+      std::vector<NodeP> k;
+      for (int x : bytes) { ByteSet s{}; bs_add(s, x); k.push_back(mk_bytes(s)); }
+      return mk_cat(k);
+    };
+    if (b == 'k' || b == 'K') return seq({0xE2, 0x84, 0xAA});
+    if (b == 's' || b == 'S') return seq({0xC5, 0xBF});
+    return nullptr;
+  }
   [[noreturn]] void fail(const std::string& why) const { throw CometError("RLIKE pattern '" + p + "' is not supported by the MI355X native engine: " + why); }
   bool more() const { return i < p.size(); }
   NodeP parse_alt() {
@@ -171,7 +190,7 @@ struct Parser {
       i++;
       if (more() && p[i] == '?') {
         if (i + 1 < p.size() && p[i + 1] == ':') i += 2;
-        else fail("group flags, named groups and look-around ((?…) other than (?:…))");
+        else fail("group flags, named groups and look-around ((?…) other than (?:…) and a leading (?i))");
       }
       NodeP inner = parse_alt();
       if (!more() || p[i] != ')') fail("an unclosed group");
@@ -197,6 +216,15 @@ struct Parser {
       ByteSet s{};
       bs_add(s, b);
       return mk_bytes(s);
+    }
+    if (icase && ch >= 0x80) fail("case-insensitive matching of a non-ASCII literal");
+    if (icase && is_letter(ch)) {
+      i++;
+      ByteSet s{};
+      bs_add(s, ch | 0x20);
+      bs_add(s, ch & ~0x20);
+      NodeP extra = fold_partner(ch);
+      return extra ? mk_alt({mk_bytes(s), extra}) : mk_bytes(s);
     }
     // a literal character: its UTF-8 bytes in sequence form ONE item (a quantifier after "é" repeats both bytes)
     std::vector<NodeP> seq;
@@ -250,7 +278,23 @@ struct Parser {
       }
       for (int b = lo; b <= hi; b++) bs_add(s, b);
     }
-    if (!neg) return one_char(s, false);
+    bool has_k = false, has_s = false;
+    if (icase) {
+      // the class is folded first, then (if asked) negated — [^a] under (?i) is [^aA]
+      for (int b = 'a'; b <= 'z'; b++)
+        if (bs_has(s, b) || bs_has(s, b & ~0x20)) { bs_add(s, b); bs_add(s, b & ~0x20); }
+      has_k = bs_has(s, 'k');
+      has_s = bs_has(s, 's');
+      if (neg && (has_k || has_s)) fail("a negated class holding k or s under (?i) (it would have to exclude U+212A / U+017F)");
+    }
+    if (!neg) {
+      NodeP base = one_char(s, false);
+      if (!has_k && !has_s) return base;
+      std::vector<NodeP> alts{base};
+      if (has_k) alts.push_back(fold_partner('k'));
+      if (has_s) alts.push_back(fold_partner('s'));
+      return mk_alt(alts);
+    }
     ByteSet inv{};
     for (int b = 0; b < 128; b++)
       if (!bs_has(s, b)) bs_add(inv, b);

@@ -1,7 +1,8 @@
 """The RLIKE pattern compiler (csrc/regex.cpp) on the CPU: the DFA tables the device walks, walked on the host (comet_rlike_match), against
 Python's backtracking engine on the syntax both read alike — the reference's own cases (predicate_funcs/rlike.rs tests and the Scala suite's
 RLIKE patterns), documented Spark examples, UTF-8 text, anchors, counted repetitions, classes, and a randomised comparison over generated
-patterns and strings.  Constructs the reference's `regex` crate reads in a Unicode-aware way (\\d \\w \\s \\b, (?i) …) must be REFUSED."""
+patterns and strings.  Constructs the reference's `regex` crate reads in a Unicode-aware way (\\d \\w \\s \\b, scoped flags …) must be REFUSED; a leading (?i) is
+reproduced through Unicode simple case folding (K / KELVIN SIGN, s / LONG S)."""
 import random
 import re
 
@@ -93,7 +94,35 @@ def test_random_patterns_against_the_backtracking_engine(built):
     assert refused < 40
 
 
-@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("a\\b", "escape"), ("(?i)abc", "group flags"), ("(?P<n>a)", "group flags"),
+def simple_fold(text):
+    """Unicode simple case folding restricted to what can fold to ASCII: the ASCII letters, U+212A KELVIN SIGN → k, U+017F LONG S → s
+    (CaseFolding.txt statuses C / S — what the regex crate's (?i) uses; unlike str.lower() / re.IGNORECASE it leaves ı and İ alone)"""
+    return "".join("k" if c == "\u212a" else "s" if c == "\u017f" else c.lower() if c.isascii() else c for c in text)
+
+
+ICASE = [
+    ("(?i)rose", ["Rose", "ROSE", "a rOsE b", "rOſe", "roze", ""]),
+    ("(?i)^k+$", ["kK\u212a", "K", "\u212a\u212a", "kx", "\u212b"]),          # KELVIN SIGN folds to k; ANGSTROM SIGN (212B) folds to å, not to an ASCII letter
+    ("(?i)[a-f]+[0-9]$", ["ABC1", "abcdef9", "g1", "Fe2"]),
+    ("(?i)[q-t]x", ["Sx", "ſx", "tX", "ux", "\u212ax"]),                        # a class holding s matches LONG S
+    ("(?i)[h-l]z", ["\u212aZ", "Kz", "mz"]),
+    ("(?i)[^a-c]", ["ABC", "abc", "abcd", "D", "é"]),                           # folded first, then negated: [^a-cA-C]
+    ("(?i)a.c|x{2}", ["AbC", "xx", "Xx", "x", "a\nc"]),
+    ("(?i)istanbul", ["ISTANBUL", "İstanbul", "ıstanbul", "istanbul"]),         # neither dotted capital İ nor dotless ı folds to i
+    ("(?i)1\\.5e", ["1.5E", "1x5e"]),
+]
+
+
+@pytest.mark.parametrize("pattern,values", ICASE)
+def test_leading_case_insensitive_flag(built, pattern, values):
+    """(?i) as the crate reads it: simple case folding.  Expected answers: the pattern without the flag, lower-cased, searched in the folded
+    text (valid here because the ICASE patterns hold only lower-case literals and lower-case class ranges)."""
+    inner = pattern[4:]
+    for v in values:
+        assert native.rlike_match(pattern, v) == want(inner, simple_fold(v)), (pattern, v)
+
+
+@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?s)a.c", "group flags"), ("(?i)café", "non-ASCII"), ("(?i)[^k]", "negated class"), ("(?P<n>a)", "group flags"),
                                          ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[é]", "non-ASCII"), ("[[:alpha:]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
                                          ("\\p{L}", "escape"), ("\\x41", "escape"), ("a{,2}", "counted repetition")])
