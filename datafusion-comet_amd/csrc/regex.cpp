@@ -5,6 +5,7 @@
 // can be reproduced EXACTLY over UTF-8 bytes and refuses the rest by name, so an unsupported pattern fails at createPlan (the JVM side then
 // keeps the expression on Spark) instead of matching differently:
 //   literals (any UTF-8), `.` (any scalar value but \n), classes [a-z0-9_] / [^…] with ASCII members, escapes of punctuation and \t \n \r,
+//   hexadecimal escapes of scalar values (\x41 \x{1F600} \u00e9 \U0001F600),
 //   grouping ( ) and (?: ), alternation |, * + ? {m} {m,} {m,n} (lazy forms mean the same for a yes/no answer), ^ and $ (start / end of
 //   the text, as in the crate without the m flag).
 //   A leading (?i) makes the whole pattern case insensitive the way the crate does it — Unicode SIMPLE case folding — which for ASCII
@@ -170,6 +171,64 @@ struct Parser {
     }
     return a;
   }
+  // \xHH \x{H…} \uHHHH \u{H…} \UHHHHHHHH \U{H…} at p[at] == '\\': the scalar value and the escape's length, or -1 (not such an escape).
+  // Malformed digits, surrogates and values beyond U+10FFFF are refused like the crate refuses them.
+  int hex_escape(size_t at, size_t& len) const {
+    if (at + 1 >= p.size()) return -1;
+    const char k = p[at + 1];
+    if (k != 'x' && k != 'u' && k != 'U') return -1;
+    auto hexval = [](char c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; };
+    size_t j = at + 2;
+    long cp = 0;
+    if (j < p.size() && p[j] == '{') {
+      j++;
+      size_t digits = 0;
+      while (j < p.size() && p[j] != '}') {
+        const int h = hexval(p[j]);
+        if (h < 0 || ++digits > 8) fail("a malformed hexadecimal escape");
+        cp = cp * 16 + h;
+        j++;
+      }
+      if (j >= p.size() || digits == 0) fail("a malformed hexadecimal escape");
+      j++;
+    } else {
+      const size_t want = k == 'x' ? 2 : k == 'u' ? 4 : 8;
+      for (size_t d = 0; d < want; d++, j++) {
+        const int h = j < p.size() ? hexval(p[j]) : -1;
+        if (h < 0) fail("a malformed hexadecimal escape");
+        cp = cp * 16 + h;
+      }
+    }
+    if (cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) fail("a hexadecimal escape that is not a Unicode scalar value");
+    len = j - at;
+    return (int)cp;
+  }
+  static std::string utf8_of(int cp) {
+    std::string o;
+    if (cp < 0x80) o += (char)cp;
+    else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+    else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+    else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+    return o;
+  }
+  // one literal scalar value as an item: its UTF-8 bytes in sequence (under (?i): an ASCII letter in both cases plus its fold partner)
+  NodeP literal_item(int cp) {
+    if (icase && cp >= 0x80) fail("case-insensitive matching of a non-ASCII literal");
+    if (icase && is_letter(cp)) {
+      ByteSet s{};
+      bs_add(s, cp | 0x20);
+      bs_add(s, cp & ~0x20);
+      NodeP extra = fold_partner(cp);
+      return extra ? mk_alt({mk_bytes(s), extra}) : mk_bytes(s);
+    }
+    std::vector<NodeP> seq;
+    for (unsigned char b : utf8_of(cp)) {
+      ByteSet s{};
+      bs_add(s, b);
+      seq.push_back(mk_bytes(s));
+    }
+    return mk_cat(seq);
+  }
   // the byte of an escaped punctuation / control character, or -1
   int simple_escape(char c) const {
     switch (c) {
@@ -210,8 +269,14 @@ struct Parser {
     if (ch == '{') fail("'{' that does not follow an item");
     if (ch == '\\') {
       if (i + 1 >= p.size()) fail("a trailing backslash");
+      size_t hlen = 0;
+      const int cp = hex_escape(i, hlen);
+      if (cp >= 0) {
+        i += hlen;
+        return literal_item(cp);
+      }
       const int b = simple_escape(p[i + 1]);
-      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (Perl / Unicode classes, word boundaries, back-references and hex escapes are Unicode-aware in the reference)");
+      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (Perl / Unicode classes, word boundaries and back-references are Unicode-aware in the reference)");
       i += 2;
       ByteSet s{};
       bs_add(s, b);
@@ -252,9 +317,17 @@ struct Parser {
       int lo;
       if (c == '\\') {
         if (i + 1 >= p.size()) fail("a trailing backslash");
-        lo = simple_escape(p[i + 1]);
-        if (lo < 0) fail(std::string("the escape \\") + p[i + 1] + " inside a class");
-        i += 2;
+        size_t hlen = 0;
+        const int cp = hex_escape(i, hlen);
+        if (cp >= 0x80) fail("non-ASCII members of a character class");
+        if (cp >= 0) {
+          lo = cp;
+          i += hlen;
+        } else {
+          lo = simple_escape(p[i + 1]);
+          if (lo < 0) fail(std::string("the escape \\") + p[i + 1] + " inside a class");
+          i += 2;
+        }
       } else {
         if (c >= 0x80) fail("non-ASCII members of a character class");
         lo = c;
@@ -265,9 +338,17 @@ struct Parser {
         unsigned char d = (unsigned char)p[i + 1];
         if (d == '\\') {
           if (i + 2 >= p.size()) fail("a trailing backslash");
-          hi = simple_escape(p[i + 2]);
-          if (hi < 0) fail("an escape class as a range end");
-          i += 3;
+          size_t hlen = 0;
+          const int cp = hex_escape(i + 1, hlen);
+          if (cp >= 0x80) fail("non-ASCII members of a character class");
+          if (cp >= 0) {
+            hi = cp;
+            i += 1 + hlen;
+          } else {
+            hi = simple_escape(p[i + 2]);
+            if (hi < 0) fail("an escape class as a range end");
+            i += 3;
+          }
         } else {
           if (d >= 0x80) fail("non-ASCII members of a character class");
           if (d == '[') fail("nested classes");

@@ -62,6 +62,12 @@ CASES = [
     ("[]a]", ["]", "a", "b"]),
     ("[a\\]b]", ["]", "b", "c"]),
     ("\t", ["a\tb", "ab"]),
+    # hexadecimal escapes name scalar values (\xFF is U+00FF, two UTF-8 bytes — not the byte 0xFF)
+    ("\\x41+$", ["AAA", "Aa", "a"]),
+    ("caf\\u00e9", ["café", "cafe", "CAFÉ"]),
+    ("\\xff", ["ÿ", "y", "\xff"]),
+    ("\\U0001F600{2}", ["😀😀", "😀", "a😀😀b"]),
+    ("[\\x30-\\x39]+[\\x2e]$", ["2024.", "a.", "7"]),
 ]
 
 
@@ -92,6 +98,12 @@ def test_random_patterns_against_the_backtracking_engine(built):
             v = "".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 8)))
             assert native.rlike_match(pattern, v) == want(pattern, v), (pattern, v)
     assert refused < 40
+
+
+@pytest.mark.parametrize("braced,plain", [("\\x{41}b", "\\x41b"), ("\\u{e9}+", "\\u00e9+"), ("^\\x{1F600}$", "^\\U0001F600$"), ("\\U{65}", "e")])
+def test_braced_hex_escapes_mean_their_plain_forms(built, braced, plain):
+    for v in ["Ab", "éé", "😀", "e", "x", ""]:
+        assert native.rlike_match(braced, v) == want(plain, v), (braced, v)
 
 
 def simple_fold(text):
@@ -125,7 +137,8 @@ def test_leading_case_insensitive_flag(built, pattern, values):
 @pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?s)a.c", "group flags"), ("(?i)café", "non-ASCII"), ("(?i)[^k]", "negated class"), ("(?P<n>a)", "group flags"),
                                          ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[é]", "non-ASCII"), ("[[:alpha:]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
-                                         ("\\p{L}", "escape"), ("\\x41", "escape"), ("a{,2}", "counted repetition")])
+                                         ("\\p{L}", "escape"), ("\\xZ1", "hexadecimal"), ("\\x{110000}", "scalar value"), ("\\uD800", "scalar value"), ("\\u12", "hexadecimal"), ("[\\u00e9]", "non-ASCII"),
+                                         ("(?i)\\u00e9", "non-ASCII"), ("a{,2}", "counted repetition")])
 def test_constructs_the_reference_reads_differently_are_refused(built, pattern, why):
     with pytest.raises(native.CometNativeException, match="not supported"):
         native.rlike_match(pattern, "abc")
