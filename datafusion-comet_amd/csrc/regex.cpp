@@ -4,7 +4,7 @@
 // Unicode scalar values (native/spark-expr/src/predicate_funcs/rlike.rs:47-90).  This compiler accepts the part of that syntax whose meaning
 // can be reproduced EXACTLY over UTF-8 bytes and refuses the rest by name, so an unsupported pattern fails at createPlan (the JVM side then
 // keeps the expression on Spark) instead of matching differently:
-//   literals (any UTF-8), `.` (any scalar value but \n), classes [a-z0-9_] / [^…] with ASCII members, escapes of punctuation and \t \n \r,
+//   literals (any UTF-8), `.` (any scalar value but \n), classes [a-z0-9_] / [^…] whose members are any scalar values (beyond ASCII: the UTF-8 byte-range sequences of utf8-ranges), escapes of punctuation and \t \n \r,
 //   hexadecimal escapes of scalar values (\x41 \x{1F600} \u00e9 \U0001F600),
 //   grouping ( ) and (?: ), alternation |, * + ? {m} {m,} {m,n} (lazy forms mean the same for a yes/no answer), ^ and $ (start / end of
 //   the text, as in the crate without the m flag).
@@ -14,7 +14,7 @@
 //   are refused.
 // Refused: \d \w \s \b and the other Perl / Unicode classes (they are Unicode-aware in the crate: an ASCII rendering would differ on
 // non-ASCII text), other flags and scoped flag groups, look-around and back-references (the crate refuses those too), non-ASCII class
-// members, counted repetitions above 64.
+// members under (?i), counted repetitions above 64.
 //
 // Construction: parse → Thompson NFA over byte sets (a `.` or a negated class becomes the UTF-8 sequence alternation) → subset
 // construction of the SEARCH automaton (the start state is re-injected after every byte; ^ is passable only before the first byte).
@@ -301,85 +301,126 @@ struct Parser {
     } while (ch >= 0x80 && more() && ((unsigned char)p[i] & 0xC0) == 0x80);
     return mk_cat(seq);
   }
+  // one scalar value of the pattern at p[i] (UTF-8 decoded; the pattern is valid UTF-8 — it arrived as a Java String)
+  int decode_utf8_at(size_t& at) const {
+    const unsigned char c = (unsigned char)p[at];
+    if (c < 0x80) { at++; return c; }
+    const int n = c >= 0xF0 ? 4 : c >= 0xE0 ? 3 : 2;
+    if (at + (size_t)n > p.size()) fail("a truncated UTF-8 sequence in the pattern");
+    int cp = c & (0x7F >> n);
+    for (int k = 1; k < n; k++) cp = (cp << 6) | ((unsigned char)p[at + (size_t)k] & 0x3F);
+    at += (size_t)n;
+    return cp;
+  }
+  // a class member at p[i]: a literal scalar value or an escape of one
+  int class_member() {
+    if (!more()) fail("an unclosed character class");
+    if (p[i] != '\\') return decode_utf8_at(i);
+    if (i + 1 >= p.size()) fail("a trailing backslash");
+    size_t hlen = 0;
+    const int cp = hex_escape(i, hlen);
+    if (cp >= 0) { i += hlen; return cp; }
+    const int b = simple_escape(p[i + 1]);
+    if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " inside a class");
+    i += 2;
+    return b;
+  }
   NodeP parse_class() {
     i++;   // [
     bool neg = false;
     if (more() && p[i] == '^') { neg = true; i++; }
-    ByteSet s{};
+    ByteSet s{};                                  // ASCII members
+    std::vector<std::pair<int, int>> wide;        // members beyond ASCII, as ranges of scalar values
     bool first = true;
     while (true) {
       if (!more()) fail("an unclosed character class");
-      unsigned char c = (unsigned char)p[i];
+      const unsigned char c = (unsigned char)p[i];
       if (c == ']' && !first) { i++; break; }
       first = false;
       if (c == '[') fail("nested classes and [:posix:] classes");
       if (c == '&' && i + 1 < p.size() && p[i + 1] == '&') fail("class intersections");
-      int lo;
-      if (c == '\\') {
-        if (i + 1 >= p.size()) fail("a trailing backslash");
-        size_t hlen = 0;
-        const int cp = hex_escape(i, hlen);
-        if (cp >= 0x80) fail("non-ASCII members of a character class");
-        if (cp >= 0) {
-          lo = cp;
-          i += hlen;
-        } else {
-          lo = simple_escape(p[i + 1]);
-          if (lo < 0) fail(std::string("the escape \\") + p[i + 1] + " inside a class");
-          i += 2;
-        }
-      } else {
-        if (c >= 0x80) fail("non-ASCII members of a character class");
-        lo = c;
-        i++;
-      }
+      const int lo = class_member();
       int hi = lo;
       if (i + 1 < p.size() && p[i] == '-' && p[i + 1] != ']') {
-        unsigned char d = (unsigned char)p[i + 1];
-        if (d == '\\') {
-          if (i + 2 >= p.size()) fail("a trailing backslash");
-          size_t hlen = 0;
-          const int cp = hex_escape(i + 1, hlen);
-          if (cp >= 0x80) fail("non-ASCII members of a character class");
-          if (cp >= 0) {
-            hi = cp;
-            i += 1 + hlen;
-          } else {
-            hi = simple_escape(p[i + 2]);
-            if (hi < 0) fail("an escape class as a range end");
-            i += 3;
-          }
-        } else {
-          if (d >= 0x80) fail("non-ASCII members of a character class");
-          if (d == '[') fail("nested classes");
-          hi = d;
-          i += 2;
-        }
+        if (p[i + 1] == '[') fail("nested classes");
+        i++;
+        hi = class_member();
         if (hi < lo) fail("a reversed range in a character class");
       }
-      for (int b = lo; b <= hi; b++) bs_add(s, b);
+      for (int b = lo; b <= hi && b < 128; b++) bs_add(s, b);
+      if (hi >= 128) wide.emplace_back(std::max(lo, 128), hi);
     }
     bool has_k = false, has_s = false;
     if (icase) {
+      if (!wide.empty()) fail("non-ASCII members of a character class under (?i)");
       // the class is folded first, then (if asked) negated — [^a] under (?i) is [^aA]
       for (int b = 'a'; b <= 'z'; b++)
         if (bs_has(s, b) || bs_has(s, b & ~0x20)) { bs_add(s, b); bs_add(s, b & ~0x20); }
       has_k = bs_has(s, 'k');
       has_s = bs_has(s, 's');
-      if (neg && (has_k || has_s)) fail("a negated class holding k or s under (?i) (it would have to exclude U+212A / U+017F)");
+      // U+017F LONG S and U+212A KELVIN SIGN fold to s / k: members of the folded class
+      if (has_s) wide.emplace_back(0x17F, 0x17F);
+      if (has_k) wide.emplace_back(0x212A, 0x212A);
     }
-    if (!neg) {
-      NodeP base = one_char(s, false);
-      if (!has_k && !has_s) return base;
-      std::vector<NodeP> alts{base};
-      if (has_k) alts.push_back(fold_partner('k'));
-      if (has_s) alts.push_back(fold_partner('s'));
-      return mk_alt(alts);
+    std::sort(wide.begin(), wide.end());
+    if (neg) {
+      ByteSet inv{};
+      for (int b = 0; b < 128; b++)
+        if (!bs_has(s, b)) bs_add(inv, b);
+      s = inv;
+      std::vector<std::pair<int, int>> rest;
+      int next = 128;
+      for (auto& r : wide) {
+        if (r.first > next) rest.emplace_back(next, r.first - 1);
+        next = std::max(next, r.second + 1);
+      }
+      if (next <= 0x10FFFF) rest.emplace_back(next, 0x10FFFF);
+      wide = rest;
     }
-    ByteSet inv{};
-    for (int b = 0; b < 128; b++)
-      if (!bs_has(s, b)) bs_add(inv, b);
-    return one_char(inv, true);
+    std::vector<NodeP> alts;
+    bool any = false;
+    for (int b = 0; b < 128; b++) any |= bs_has(s, b);
+    if (any) alts.push_back(mk_bytes(s));
+    if (wide.size() == 1 && wide[0].first == 128 && wide[0].second == 0x10FFFF) alts.push_back(multibyte());
+    else for (auto& r : wide) utf8_range_items(r.first, r.second, alts);
+    if (alts.empty()) return mk_bytes(ByteSet{});     // a class nothing can match
+    return mk_alt(alts);
+  }
+  // scalar values [lo, hi] (beyond ASCII) as alternatives of byte-range sequences: split at the surrogate gap and at the encoded-length
+  // boundaries, then until the continuation bytes of every piece span full ranges (the construction of the crate's utf8-ranges)
+  static void utf8_range_items(int lo, int hi, std::vector<NodeP>& out) {
+    if (lo > hi) return;
+    if (lo <= 0xDFFF && hi >= 0xD800) {          // surrogates are not scalar values
+      utf8_range_items(lo, 0xD7FF, out);
+      utf8_range_items(0xE000, hi, out);
+      return;
+    }
+    for (int mx : {0x7F, 0x7FF, 0xFFFF})
+      if (lo <= mx && hi > mx) {
+        utf8_range_items(lo, mx, out);
+        utf8_range_items(mx + 1, hi, out);
+        return;
+      }
+    const int n = hi < 0x80 ? 1 : hi < 0x800 ? 2 : hi < 0x10000 ? 3 : 4;
+    for (int k = 1; k < n; k++) {
+      const int m = (1 << (6 * k)) - 1;
+      if ((lo & ~m) != (hi & ~m)) {
+        if ((lo & m) != 0) {
+          utf8_range_items(lo, lo | m, out);
+          utf8_range_items((lo | m) + 1, hi, out);
+          return;
+        }
+        if ((hi & m) != m) {
+          utf8_range_items(lo, (hi & ~m) - 1, out);
+          utf8_range_items(hi & ~m, hi, out);
+          return;
+        }
+      }
+    }
+    const std::string a = utf8_of(lo), b = utf8_of(hi);
+    std::vector<NodeP> seq;
+    for (size_t k = 0; k < a.size(); k++) seq.push_back(mk_bytes(bs_range((unsigned char)a[k], (unsigned char)b[k])));
+    out.push_back(mk_cat(seq));
   }
 };
 
