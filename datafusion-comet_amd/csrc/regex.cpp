@@ -12,8 +12,9 @@
 //   letters means: the other ASCII case, and for k / s also U+212A KELVIN SIGN / U+017F LATIN SMALL LETTER LONG S (the only non-ASCII
 //   scalar values that fold to an ASCII letter); non-ASCII literals under (?i), and negated classes that would have to exclude those two,
 //   are refused.
-// Refused: \d \w \s \b and the other Perl / Unicode classes (they are Unicode-aware in the crate: an ASCII rendering would differ on
-// non-ASCII text), other flags and scoped flag groups, look-around and back-references (the crate refuses those too), non-ASCII class
+//   \s / \S (the White_Space property: the same 25 scalar values in every Unicode version).
+// Refused: \d \w \b and the other Perl / Unicode classes (Unicode-aware in the crate and growing with every Unicode release: neither an
+// ASCII rendering nor a table of another version would match it), other flags and scoped flag groups, look-around and back-references (the crate refuses those too), non-ASCII class
 // members under (?i), counted repetitions above 64.
 //
 // Construction: parse → Thompson NFA over byte sets (a `.` or a negated class becomes the UTF-8 sequence alternation) → subset
@@ -275,8 +276,16 @@ struct Parser {
         i += hlen;
         return literal_item(cp);
       }
+      if (p[i + 1] == 's' || p[i + 1] == 'S') {
+        ByteSet ws{};
+        std::vector<std::pair<int, int>> wide;
+        add_white_space(ws, wide);
+        const bool negate = p[i + 1] == 'S';
+        i += 2;
+        return finish_class(ws, wide, negate, true);
+      }
       const int b = simple_escape(p[i + 1]);
-      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (Perl / Unicode classes, word boundaries and back-references are Unicode-aware in the reference)");
+      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (\\d \\w \\b and the Unicode classes grow with every Unicode release; back-references do not exist in the reference)");
       i += 2;
       ByteSet s{};
       bs_add(s, b);
@@ -339,6 +348,12 @@ struct Parser {
       first = false;
       if (c == '[') fail("nested classes and [:posix:] classes");
       if (c == '&' && i + 1 < p.size() && p[i + 1] == '&') fail("class intersections");
+      if (c == '\\' && i + 1 < p.size() && p[i + 1] == 's') {      // [\s,;]: the White_Space members join the class
+        if (icase) fail("\\s inside a class under (?i)");
+        add_white_space(s, wide);
+        i += 2;
+        continue;
+      }
       const int lo = class_member();
       int hi = lo;
       if (i + 1 < p.size() && p[i] == '-' && p[i + 1] != ']') {
@@ -350,9 +365,21 @@ struct Parser {
       for (int b = lo; b <= hi && b < 128; b++) bs_add(s, b);
       if (hi >= 128) wide.emplace_back(std::max(lo, 128), hi);
     }
+    return finish_class(s, wide, neg, false);
+  }
+  // White_Space (\\s): stable across Unicode versions, so it can be reproduced exactly (the other Perl classes cannot: \\d and \\w grow
+  // with every Unicode release)
+  static void add_white_space(ByteSet& s, std::vector<std::pair<int, int>>& wide) {
+    for (int b = 9; b <= 13; b++) bs_add(s, b);
+    bs_add(s, 32);
+    for (auto r : {std::pair<int, int>{0x85, 0x85}, {0xA0, 0xA0}, {0x1680, 0x1680}, {0x2000, 0x200A}, {0x2028, 0x2029}, {0x202F, 0x202F}, {0x205F, 0x205F}, {0x3000, 0x3000}})
+      wide.push_back(r);
+  }
+  // members collected → the class's node: case folding, negation, ASCII byte set + UTF-8 range sequences
+  NodeP finish_class(ByteSet s, std::vector<std::pair<int, int>> wide, bool neg, bool perl) {
     bool has_k = false, has_s = false;
     if (icase) {
-      if (!wide.empty()) fail("non-ASCII members of a character class under (?i)");
+      if (!wide.empty() && !perl) fail("non-ASCII members of a character class under (?i)");
       // the class is folded first, then (if asked) negated — [^a] under (?i) is [^aA]
       for (int b = 'a'; b <= 'z'; b++)
         if (bs_has(s, b) || bs_has(s, b & ~0x20)) { bs_add(s, b); bs_add(s, b & ~0x20); }

@@ -141,6 +141,20 @@ def test_random_scalar_value_ranges(built):
                 assert native.rlike_match(pattern, v) == want(pattern, v), (pattern, hex(cp))
 
 
+WS = "\\t-\\r \\x85\\xa0\\u1680\\u2000-\\u200a\\u2028\\u2029\\u202f\\u205f\\u3000"      # the White_Space property, spelled out as class members
+
+
+@pytest.mark.parametrize("pattern,spelled", [("a\\sb", "a[%s]b" % WS), ("^\\S+$", "^[^%s]+$" % WS), ("^\\s*$", "^[%s]*$" % WS), ("[\\s,;]+x", "[%s,;]+x" % WS),
+                                             ("(?i)K\\s\\S", "[kK\u212a][%s][^%s]" % (WS, WS))])
+def test_white_space_class(built, pattern, spelled):
+    """\\s / \\S are the White_Space property in the crate — 25 scalar values, the same in every Unicode version; NOT Python's \\s (which adds
+    U+001C..U+001F) and not Java's (ASCII only): the expected answers come from the property spelled out as a class"""
+    values = ["a b", "a\tb", "a\u00a0b", "a\u2003b", "a\u3000b", "a\u0085b", "a\u001cb", "a\u200bb", "a\u180eb", "ab", " ", "", "\u2028", "x y", " ,;x", "\u1680;x",
+              "k x", "\u212a\u2009y", "K  "]
+    for v in values:
+        assert native.rlike_match(pattern, v) == want(spelled, v), (pattern, v)
+
+
 def simple_fold(text):
     """Unicode simple case folding restricted to what can fold to ASCII: the ASCII letters, U+212A KELVIN SIGN → k, U+017F LONG S → s
     (CaseFolding.txt statuses C / S — what the regex crate's (?i) uses; unlike str.lower() / re.IGNORECASE it leaves ı and İ alone)"""
@@ -169,7 +183,7 @@ def test_leading_case_insensitive_flag(built, pattern, values):
         assert native.rlike_match(pattern, v) == want(inner, simple_fold(v)), (pattern, v)
 
 
-@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?s)a.c", "group flags"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
+@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("[\\S]", "escape"), ("[\\d]", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?s)a.c", "group flags"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
                                          ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[z-a]", "reversed"), ("[[:alpha:]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
                                          ("\\p{L}", "escape"), ("\\xZ1", "hexadecimal"), ("\\x{110000}", "scalar value"), ("\\uD800", "scalar value"), ("\\u12", "hexadecimal"),
