@@ -12,7 +12,7 @@
 //   letters means: the other ASCII case, and for k / s also U+212A KELVIN SIGN / U+017F LATIN SMALL LETTER LONG S (the only non-ASCII
 //   scalar values that fold to an ASCII letter); non-ASCII literals under (?i), and negated classes that would have to exclude those two,
 //   are refused.
-//   \s / \S (the White_Space property: the same 25 scalar values in every Unicode version).
+//   [[:alpha:]] and the other POSIX bracket classes (ASCII-only in the crate), \s / \S (the White_Space property: the same 25 scalar values in every Unicode version).
 // Refused: \d \w \b and the other Perl / Unicode classes (Unicode-aware in the crate and growing with every Unicode release: neither an
 // ASCII rendering nor a table of another version would match it), other flags and scoped flag groups, look-around and back-references (the crate refuses those too), non-ASCII class
 // members under (?i), counted repetitions above 64.
@@ -346,7 +346,31 @@ struct Parser {
       const unsigned char c = (unsigned char)p[i];
       if (c == ']' && !first) { i++; break; }
       first = false;
-      if (c == '[') fail("nested classes and [:posix:] classes");
+      if (c == '[' && i + 1 < p.size() && p[i + 1] == ':') {
+        // [:name:] — the POSIX classes are ASCII-only in the crate, so they mean the same bytes here
+        const size_t close = p.find(":]", i + 2);
+        if (close == std::string::npos) fail("an unclosed [:posix:] class");
+        const std::string name = p.substr(i + 2, close - (i + 2));
+        auto add = [&](int lo, int hi) { for (int b = lo; b <= hi; b++) bs_add(s, b); };
+        if (name == "alnum") { add('0', '9'); add('A', 'Z'); add('a', 'z'); }
+        else if (name == "alpha") { add('A', 'Z'); add('a', 'z'); }
+        else if (name == "ascii") add(0, 127);
+        else if (name == "blank") { add(' ', ' '); add('\t', '\t'); }
+        else if (name == "cntrl") { add(0, 31); add(127, 127); }
+        else if (name == "digit") add('0', '9');
+        else if (name == "graph") add('!', '~');
+        else if (name == "lower") add('a', 'z');
+        else if (name == "print") add(' ', '~');
+        else if (name == "punct") { add('!', '/'); add(':', '@'); add('[', '`'); add('{', '~'); }
+        else if (name == "space") { add('\t', '\r'); add(' ', ' '); }
+        else if (name == "upper") add('A', 'Z');
+        else if (name == "word") { add('0', '9'); add('A', 'Z'); add('a', 'z'); add('_', '_'); }
+        else if (name == "xdigit") { add('0', '9'); add('A', 'F'); add('a', 'f'); }
+        else fail("the class [:" + name + ":] (negated and unknown POSIX classes)");
+        i = close + 2;
+        continue;
+      }
+      if (c == '[') fail("nested classes");
       if (c == '&' && i + 1 < p.size() && p[i + 1] == '&') fail("class intersections");
       if (c == '\\' && i + 1 < p.size() && p[i + 1] == 's') {      // [\s,;]: the White_Space members join the class
         if (icase) fail("\\s inside a class under (?i)");

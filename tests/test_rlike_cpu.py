@@ -141,6 +141,21 @@ def test_random_scalar_value_ranges(built):
                 assert native.rlike_match(pattern, v) == want(pattern, v), (pattern, hex(cp))
 
 
+POSIX = {"alnum": "0-9A-Za-z", "alpha": "A-Za-z", "ascii": "\\x00-\\x7f", "blank": " \\t", "cntrl": "\\x00-\\x1f\\x7f", "digit": "0-9", "graph": "!-~", "lower": "a-z",
+         "print": " -~", "punct": "!-/:-@\\[-`{-~", "space": "\\t-\\r ", "upper": "A-Z", "word": "0-9A-Za-z_", "xdigit": "0-9A-Fa-f"}
+
+
+@pytest.mark.parametrize("name", sorted(POSIX))
+def test_posix_bracket_classes_are_ascii(built, name):
+    """[[:name:]]: ASCII-only in the crate (unlike \\d \\w), so each is its documented byte set — checked byte by byte and on non-ASCII text,
+    alone, negated as a whole and next to other members"""
+    for cp in list(range(1, 128)) + [0xE9, 0x660, 0x3000, 0x1F600]:          # not NUL: the C ABI takes NUL-terminated patterns and values
+        v = chr(cp)
+        assert native.rlike_match("^[[:%s:]]$" % name, v) == want("^[%s]$" % POSIX[name], v), (name, cp)
+        assert native.rlike_match("^[^[:%s:]]$" % name, v) == want("^[^%s]$" % POSIX[name], v), (name, cp)
+    assert native.rlike_match("^[[:%s:]é-]+$" % name, "é-") is True
+
+
 WS = "\\t-\\r \\x85\\xa0\\u1680\\u2000-\\u200a\\u2028\\u2029\\u202f\\u205f\\u3000"      # the White_Space property, spelled out as class members
 
 
@@ -184,7 +199,7 @@ def test_leading_case_insensitive_flag(built, pattern, values):
 
 
 @pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("[\\S]", "escape"), ("[\\d]", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?s)a.c", "group flags"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
-                                         ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[z-a]", "reversed"), ("[[:alpha:]]", "nested"), ("a{100}", "repetition"),
+                                         ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[z-a]", "reversed"), ("[[:^alpha:]]", "POSIX"), ("[[:alfa:]]", "POSIX"), ("[a[b]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
                                          ("\\p{L}", "escape"), ("\\xZ1", "hexadecimal"), ("\\x{110000}", "scalar value"), ("\\uD800", "scalar value"), ("\\u12", "hexadecimal"),
                                          ("(?i)\\u00e9", "non-ASCII"), ("a{,2}", "counted repetition")])
