@@ -8,6 +8,7 @@
 //   hexadecimal escapes of scalar values (\x41 \x{1F600} \u00e9 \U0001F600),
 //   grouping ( ) and (?: ), alternation |, * + ? {m} {m,} {m,n} (lazy forms mean the same for a yes/no answer), ^ and $ (start / end of
 //   the text, as in the crate without the m flag).
+//   \A and \z (start / end of the text), a leading (?s) (`.` matches \n too), alone or combined with (?i).
 //   A leading (?i) makes the whole pattern case insensitive the way the crate does it — Unicode SIMPLE case folding — which for ASCII
 //   letters means: the other ASCII case, and for k / s also U+212A KELVIN SIGN / U+017F LATIN SMALL LETTER LONG S (the only non-ASCII
 //   scalar values that fold to an ASCII letter); non-ASCII literals under (?i), and negated classes that would have to exclude those two,
@@ -102,8 +103,15 @@ struct Parser {
   const std::string& p;
   size_t i = 0;
   bool icase = false;     // a leading (?i)
+  bool dotall = false;    // a leading (?s): `.` matches \n too
   explicit Parser(const std::string& s) : p(s) {
-    if (p.compare(0, 4, "(?i)") == 0) { icase = true; i = 4; }
+    // leading flags (?i) (?s) (?is) (?si): they hold for the whole pattern
+    if (p.compare(0, 2, "(?") == 0) {
+      size_t j = 2;
+      bool fi = false, fs = false;
+      while (j < p.size() && (p[j] == 'i' || p[j] == 's')) { (p[j] == 'i' ? fi : fs) = true; j++; }
+      if (j > 2 && j < p.size() && p[j] == ')') { icase = fi; dotall = fs; i = j + 1; }
+    }
   }
   static bool is_letter(int b) { return (b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z'); }
   // the non-ASCII scalar values whose simple case folding is the ASCII letter b (CaseFolding.txt: 212A → k, 017F → s), as UTF-8 sequences
@@ -261,7 +269,7 @@ struct Parser {
     if (ch == '.') {
       i++;
       ByteSet s = bs_range(0, 127);
-      s[0] &= ~((uint64_t)1 << '\n');
+      if (!dotall) s[0] &= ~((uint64_t)1 << '\n');
       return one_char(s, true);
     }
     if (ch == '^') { i++; return mk(Node::Bol); }
@@ -276,6 +284,8 @@ struct Parser {
         i += hlen;
         return literal_item(cp);
       }
+      if (p[i + 1] == 'A') { i += 2; return mk(Node::Bol); }      // \A / \z: start / end of the text — what ^ / $ mean here anyway
+      if (p[i + 1] == 'z') { i += 2; return mk(Node::Eol); }
       if (p[i + 1] == 's' || p[i + 1] == 'S') {
         ByteSet ws{};
         std::vector<std::pair<int, int>> wide;

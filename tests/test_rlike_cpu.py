@@ -156,6 +156,13 @@ def test_posix_bracket_classes_are_ascii(built, name):
     assert native.rlike_match("^[[:%s:]é-]+$" % name, "é-") is True
 
 
+@pytest.mark.parametrize("pattern,spelled", [("\\Aab", "\\Aab"), ("ab\\z", "ab\\Z"), ("\\A\\z", "\\A\\Z"), ("(?s)a.c", "a[\\x00-\\U0010ffff]c"), ("(?s)^.+$", "^[\\x00-\\U0010ffff]+$"),
+                                             ("(?is)A.K", "[aA][\\x00-\\U0010ffff][kK\u212a]"), ("(?si)x\\z", "[xX]\\Z")])
+def test_text_anchors_and_the_dotall_flag(built, pattern, spelled):
+    for v in ["ab", "xab", "abx", "", "a\nc", "abc", "A\n\u212a", "a\n\n", "\n", "X", "x\n"]:
+        assert native.rlike_match(pattern, v) == want(spelled, v), (pattern, v)
+
+
 WS = "\\t-\\r \\x85\\xa0\\u1680\\u2000-\\u200a\\u2028\\u2029\\u202f\\u205f\\u3000"      # the White_Space property, spelled out as class members
 
 
@@ -198,7 +205,7 @@ def test_leading_case_insensitive_flag(built, pattern, values):
         assert native.rlike_match(pattern, v) == want(inner, simple_fold(v)), (pattern, v)
 
 
-@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("[\\S]", "escape"), ("[\\d]", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?s)a.c", "group flags"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
+@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("[\\S]", "escape"), ("[\\d]", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?m)^a", "group flags"), ("(?x)a b", "group flags"), ("a\\Z", "escape"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
                                          ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[z-a]", "reversed"), ("[[:^alpha:]]", "POSIX"), ("[[:alfa:]]", "POSIX"), ("[a[b]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
                                          ("\\p{L}", "escape"), ("\\xZ1", "hexadecimal"), ("\\x{110000}", "scalar value"), ("\\uD800", "scalar value"), ("\\u12", "hexadecimal"),
