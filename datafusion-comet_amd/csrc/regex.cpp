@@ -8,7 +8,8 @@
 //   hexadecimal escapes of scalar values (\x41 \x{1F600} \u00e9 \U0001F600),
 //   grouping ( ) and (?: ), alternation |, * + ? {m} {m,} {m,n} (lazy forms mean the same for a yes/no answer), ^ and $ (start / end of
 //   the text, as in the crate without the m flag).
-//   \A and \z (start / end of the text), a leading (?s) (`.` matches \n too), alone or combined with (?i).
+//   \A and \z (start / end of the text), leading (?s) (`.` matches \n too) and (?m) (^ / $ also at line boundaries), alone or combined
+//   with each other and (?i).
 //   A leading (?i) makes the whole pattern case insensitive the way the crate does it — Unicode SIMPLE case folding — which for ASCII
 //   letters means: the other ASCII case, and for k / s also U+212A KELVIN SIGN / U+017F LATIN SMALL LETTER LONG S (the only non-ASCII
 //   scalar values that fold to an ASCII letter); non-ASCII literals under (?i), and negated classes that would have to exclude those two,
@@ -104,13 +105,14 @@ struct Parser {
   size_t i = 0;
   bool icase = false;     // a leading (?i)
   bool dotall = false;    // a leading (?s): `.` matches \n too
+  bool multiline = false; // a leading (?m): ^ also matches after a \n, $ also before one
   explicit Parser(const std::string& s) : p(s) {
-    // leading flags (?i) (?s) (?is) (?si): they hold for the whole pattern
+    // leading flags (?i) (?s) (?m), alone or combined: they hold for the whole pattern
     if (p.compare(0, 2, "(?") == 0) {
       size_t j = 2;
-      bool fi = false, fs = false;
-      while (j < p.size() && (p[j] == 'i' || p[j] == 's')) { (p[j] == 'i' ? fi : fs) = true; j++; }
-      if (j > 2 && j < p.size() && p[j] == ')') { icase = fi; dotall = fs; i = j + 1; }
+      bool fi = false, fs = false, fm = false;
+      while (j < p.size() && (p[j] == 'i' || p[j] == 's' || p[j] == 'm')) { (p[j] == 'i' ? fi : p[j] == 's' ? fs : fm) = true; j++; }
+      if (j > 2 && j < p.size() && p[j] == ')') { icase = fi; dotall = fs; multiline = fm; i = j + 1; }
     }
   }
   static bool is_letter(int b) { return (b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z'); }
@@ -284,7 +286,8 @@ struct Parser {
         i += hlen;
         return literal_item(cp);
       }
-      if (p[i + 1] == 'A') { i += 2; return mk(Node::Bol); }      // \A / \z: start / end of the text — what ^ / $ mean here anyway
+      if ((p[i + 1] == 'A' || p[i + 1] == 'z') && multiline) fail("\\A / \\z under (?m)");
+      if (p[i + 1] == 'A') { i += 2; return mk(Node::Bol); }      // \A / \z: start / end of the text — what ^ / $ mean without (?m)
       if (p[i + 1] == 'z') { i += 2; return mk(Node::Eol); }
       if (p[i + 1] == 's' || p[i + 1] == 'S') {
         ByteSet ws{};
@@ -591,17 +594,17 @@ RegexDfa compile_rlike(const std::string& pattern) {
     return seen;
   };
   RegexDfa dfa;
-  std::map<std::set<int>, int> ids;
+  std::map<std::pair<std::set<int>, bool>, int> ids;
   std::vector<std::set<int>> sets;
-  std::vector<bool> initial;
-  auto intern = [&](const std::set<int>& s, bool is_initial) {
-    auto it = ids.find(s);
+  std::vector<bool> initial;                         // ^ is passable in this state: before the first byte, or (?m) right behind a \n
+  auto intern = [&](const std::set<int>& s, bool is_initial, bool line_start = false) {
+    auto it = ids.find({s, line_start});
     if (it != ids.end() && !is_initial) return it->second;
     if (sets.size() >= 200) throw CometError("RLIKE pattern '" + pattern + "' needs more than 200 automaton states: not supported by the MI355X native engine");
     const int id = (int)sets.size();
-    if (!is_initial) ids[s] = id;
+    if (!is_initial) ids[{s, line_start}] = id;
     sets.push_back(s);
-    initial.push_back(is_initial);
+    initial.push_back(is_initial || line_start);
     return id;
   };
   intern(closed({}, true, true, false), true);      // state 0: before the first byte (^ passable)
@@ -614,13 +617,22 @@ RegexDfa compile_rlike(const std::string& pattern) {
     dfa.flags.push_back(flags);
     dfa.trans.resize((cur + 1) * 256, 0);
     if (flags & 1) continue;                        // absorbing: the kernel has already answered true
+    // (?m): in front of a \n byte `$` is passable (so that byte steps from the set closed that way — a set that already holds MATCH answers
+    // true at once), and behind it `^` is
+    const std::set<int> S_eol = ps.multiline ? closed(S, true, initial[cur], true) : std::set<int>();
     for (int b = 0; b < 256; b++) {
-      std::set<int> core;
-      for (int s : S) {
-        const NState& st = nfa.st[(size_t)s];
-        if (st.kind == NState::Byte && bs_has(st.set, b)) core.insert(st.out);
+      const bool nl = ps.multiline && b == '\n';
+      int to;
+      if (nl && S_eol.count(match)) {
+        to = intern(std::set<int>{match}, false);
+      } else {
+        std::set<int> core;
+        for (int s : (nl ? S_eol : S)) {
+          const NState& st = nfa.st[(size_t)s];
+          if (st.kind == NState::Byte && bs_has(st.set, b)) core.insert(st.out);
+        }
+        to = intern(closed(core, true, nl, false), false, nl);
       }
-      const int to = intern(closed(core, true, false, false), false);
       dfa.trans[cur * 256 + (size_t)b] = (uint8_t)to;
     }
   }

@@ -163,6 +163,13 @@ def test_text_anchors_and_the_dotall_flag(built, pattern, spelled):
         assert native.rlike_match(pattern, v) == want(spelled, v), (pattern, v)
 
 
+@pytest.mark.parametrize("pattern", ["(?m)^b", "(?m)a$", "(?m)^$", "(?m)^a.c$", "(?ms)^a.c$", "(?im)^B$", "(?m)x*$", "(?m)^(ab|c)+$", "(?m)a$\\nb", "(?m)^a|b$", "(?m)$^"])
+def test_multi_line_flag(built, pattern):
+    """(?m): ^ also matches right after a \\n and $ right before one — the same rule Python's MULTILINE applies"""
+    for v in ["b", "a\nb", "a\nbc", "ab\n", "a", "xa\nb", "", "\n", "\n\n", "a\n\nb", "abc\nc\nab", "a\nc", "x\nabc\ny", "B\nb", "a\r\nb", "c", "ab"]:
+        assert native.rlike_match(pattern, v) == (re.search(pattern, v) is not None), (pattern, v)
+
+
 WS = "\\t-\\r \\x85\\xa0\\u1680\\u2000-\\u200a\\u2028\\u2029\\u202f\\u205f\\u3000"      # the White_Space property, spelled out as class members
 
 
@@ -205,7 +212,7 @@ def test_leading_case_insensitive_flag(built, pattern, values):
         assert native.rlike_match(pattern, v) == want(inner, simple_fold(v)), (pattern, v)
 
 
-@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("[\\S]", "escape"), ("[\\d]", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?m)^a", "group flags"), ("(?x)a b", "group flags"), ("a\\Z", "escape"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
+@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("[\\S]", "escape"), ("[\\d]", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?x)a b", "group flags"), ("(?m)\\Aa", "under"), ("(?U)a", "group flags"), ("a\\Z", "escape"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
                                          ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[z-a]", "reversed"), ("[[:^alpha:]]", "POSIX"), ("[[:alfa:]]", "POSIX"), ("[a[b]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
                                          ("\\p{L}", "escape"), ("\\xZ1", "hexadecimal"), ("\\x{110000}", "scalar value"), ("\\uD800", "scalar value"), ("\\u12", "hexadecimal"),
