@@ -714,6 +714,8 @@ size_t prefix_encoded_plain_bytes(const ChunkSource& src, const pq::ColumnMeta& 
   while (values_seen < cm.num_values && off < chunk_end) {
     pq::PageHeader h = pq::parse_page_header(chunk_data + off, (size_t)(chunk_end - off));
     const uint8_t* body = chunk_data + off + h.header_len;
+    if (h.compressed_size < 0 || h.uncompressed_size < 0 || (int64_t)h.header_len + h.compressed_size > chunk_end - off)
+      throw CometError("parquet: page of " + std::to_string(h.compressed_size) + " bytes runs past its column chunk");
     off += (int64_t)h.header_len + h.compressed_size;
     if (h.type != pq::DATA_PAGE && h.type != pq::DATA_PAGE_V2) continue;
     values_seen += h.num_values;
@@ -795,6 +797,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   };
   // the kept pieces of the page [r0, r1): one PqPage entry each, passing over the page's first levels / non-NULL values
   // (`levels`: the bytes the page's definition-level runs refer to, addressed like the runs' byte_off without its region flag)
+  size_t cur_values_end = 0;    // end of the current page's staged value bytes (0: a device-inflated page, checked by the kernel's error word)
   auto emit = [&](const PqPage& pg_in, int64_t r0, int64_t r1, const uint8_t* levels) {
     PqPage pg = pg_in;
     auto non_null_before = [&](int64_t upto) -> int64_t {      // values among the page's first `upto` levels
@@ -815,6 +818,9 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     };
     // what the page's runs / PLAIN bytes hold: its non-NULL values; a PLAIN page's values are cut into the run-at-a-time kernel's chunks
     pg.value_count = (int32_t)non_null_before(pg.num_values);
+    if (pg.encoding == 0 && !cp.is_string && cur_values_end && cp.kind != PQ_BOOL && !(pg.values_off & kInflatedBit) &&
+        (uint64_t)pg.values_off + (uint64_t)pg.value_count * (uint64_t)pg.width > cur_values_end)
+      throw CometError("parquet: a PLAIN page holds fewer bytes than its " + std::to_string(pg.value_count) + " values need");
     if (pg.encoding == 0) plain_chunks(pg, pg.values_off);
     if (!src.keep) {
       PqPage q = pg;
@@ -846,6 +852,8 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   while (values_seen < cm.num_values && off < chunk_end) {
     pq::PageHeader h = pq::parse_page_header(chunk_data + off, (size_t)(chunk_end - off));
     const uint8_t* body = chunk_data + off + h.header_len;
+    if (h.compressed_size < 0 || h.uncompressed_size < 0 || (int64_t)h.header_len + h.compressed_size > chunk_end - off)
+      throw CometError("parquet: page of " + std::to_string(h.compressed_size) + " bytes runs past its column chunk");
     off += (int64_t)h.header_len + h.compressed_size;
     if (h.type == pq::DICTIONARY_PAGE) {
       tmp.resize((size_t)h.uncompressed_size + 8);
@@ -951,8 +959,10 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       if (max_def > 0) {
         if (h.def_encoding != pq::RLE) throw CometError("parquet: only RLE definition levels are supported");
         uint32_t dl;
+        if (p + 4 > page_end) throw CometError("parquet: truncated data page");
         memcpy(&dl, staged + p, 4);
         p += 4;
+        if ((size_t)dl > page_end - p) throw CometError("parquet: definition levels longer than their page");
         pg.def_run_first = (int32_t)def_runs.size();
         parse_hybrid_runs(staged, p, p + dl, 1, h.num_values, def_runs);
         pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
@@ -962,6 +972,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     } else {
       // v2: levels are never compressed and precede the (optionally compressed) values
       if (h.rep_bytes) throw CometError("parquet: repetition levels are not supported");
+      if (h.def_bytes < 0 || h.def_bytes > h.compressed_size || h.def_bytes > h.uncompressed_size) throw CometError("parquet: v2 page levels longer than the page");
       memcpy(staged + spos, body, (size_t)h.def_bytes);
       if (max_def > 0 && h.def_bytes) {
         pg.def_run_first = (int32_t)def_runs.size();
@@ -1066,6 +1077,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
                        " is not supported (PLAIN, RLE_DICTIONARY, RLE booleans, the three DELTA encodings and BYTE_STREAM_SPLIT are)");
     }
     spos = page_end;
+    cur_values_end = dev_page ? 0 : page_end;
     emit(pg, values_seen, values_seen + h.num_values, staged);
     values_seen += h.num_values;
   }
