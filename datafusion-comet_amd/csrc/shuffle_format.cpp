@@ -858,6 +858,11 @@ HostColumn read_plain_column(const DType& type, BodyCursor& cur, int64_t rows_ex
   c.length = node.first;
   c.null_count = node.second;
   if (rows_expected >= 0 && c.length != rows_expected) throw CometError("shuffle block: column length differs from the batch length");
+  // what arrow's own reader refuses as well: a block from disk is not trusted to describe itself consistently
+  if (c.length < 0 || c.length > 0x7fffffff) throw CometError("shuffle block: column length " + std::to_string(c.length) + " out of range");
+  if (c.null_count < 0 || c.null_count > c.length) throw CometError("shuffle block: null count " + std::to_string(c.null_count) + " of a column of " + std::to_string(c.length) + " rows");
+  if (type.id == TypeId::Decimal && (type.precision < 1 || type.precision > 38 || type.scale < 0 || type.scale > type.precision))
+    throw CometError("shuffle block: decimal(" + std::to_string(type.precision) + "," + std::to_string(type.scale) + ") is not a Spark decimal type");
   auto vb = cur.next_buffer();
   const size_t bm = (size_t)((c.length + 7) / 8);
   if (c.null_count > 0) {

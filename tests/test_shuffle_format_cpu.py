@@ -113,3 +113,31 @@ def test_decode_errors(built):
     bad[len(bad) // 2] ^= 0x40
     with pytest.raises(native.CometNativeException):
         native.decode_shuffle_block(bytes(bad), 14)
+
+
+@pytest.mark.parametrize("codec", [0, 1, 2, 3])
+def test_corrupted_blocks_fail_cleanly(built, codec):
+    """shuffle blocks come back from disk / the network: overwritten, truncated or extended bytes of the codec frame, the IPC flatbuffers or the
+    buffers give an exception or a batch — never a crash or a read outside the block (offsets, lengths and vtables are all checked)"""
+    import random
+    b = _batch(300, seed=9)
+    blk = native.encode_shuffle_block(b, codec)[16:]
+    rng = random.Random(1000 + codec)
+    outcomes = {"ok": 0, "error": 0}
+    for trial in range(400):
+        bad = bytearray(blk)
+        k = trial % 4
+        if k == 0:
+            bad = bad[: rng.randrange(0, len(bad))]
+        elif k == 1:
+            bad += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 9)))
+        else:
+            lim = len(bad) if k == 2 else min(len(bad), 700)          # everywhere / concentrated on the frame header and the flatbuffers
+            for _ in range(rng.randrange(1, 4)):
+                bad[rng.randrange(0, lim)] = rng.choice([0, 0xFF, 0x80, rng.randrange(256)])
+        try:
+            native.decode_shuffle_block(bytes(bad), b.num_columns).validate()      # what comes back is structurally sound Arrow
+            outcomes["ok"] += 1
+        except native.CometNativeException:
+            outcomes["error"] += 1
+    assert outcomes["error"] > 0, outcomes
