@@ -53,3 +53,33 @@ def test_snappy_corrupt_streams(built):
     bad[-1] = 9
     with pytest.raises(native.CometNativeException, match="bad copy"):
         native.page_decompress(SNAPPY, bytes(bad), 8)
+
+
+@pytest.mark.parametrize("codec,name", [(SNAPPY, "snappy"), (GZIP, "gzip"), (ZSTD, "zstd"), (LZ4_RAW, "lz4_raw")])
+def test_corrupted_page_bodies_fail_cleanly(built, codec, name):
+    """page bodies come from files: overwritten, truncated and extended compressed bytes, and a wrong declared size, give an exception or
+    exactly `uncompressed_size` bytes — the hand-written snappy / LZ4 decoders never write past the output or read past the input"""
+    import random
+    rng = random.Random(40 + codec)
+    srcs = [pages()[2], pages()[4][:20_000], pages()[7][:30_000], pages()[9][:25_000]]
+    outcomes = {"ok": 0, "error": 0}
+    for raw in srcs:
+        comp = pa.compress(raw, codec=name, asbytes=True) if name != "lz4_raw" else pa.Codec("lz4_raw").compress(raw, asbytes=True)
+        for trial in range(150):
+            bad = bytearray(comp)
+            k = trial % 4
+            size = len(raw)
+            if k == 0:
+                bad = bad[: rng.randrange(0, len(bad))]
+            elif k == 1:
+                size = max(0, len(raw) + rng.choice([-1, 1, -100, 100, -len(raw) // 2]))
+            else:
+                for _ in range(rng.randrange(1, 4)):
+                    bad[rng.randrange(0, len(bad))] = rng.choice([0, 0xFF, 0x80, rng.randrange(256)])
+            # straight through the C entry, with canaries behind the output: nothing may be written past `size` bytes
+            buf = np.full(size + 64, 0xA5, np.uint8)
+            data = bytes(bad)
+            rc = native.lib().comet_page_decompress(codec, data, len(data), buf.ctypes.data, size)
+            assert (buf[size:] == 0xA5).all(), (name, trial, "wrote past the output")
+            outcomes["ok" if rc == 0 else "error"] += 1
+    assert outcomes["error"] > 0, outcomes
