@@ -103,6 +103,7 @@ NodeP one_char(const ByteSet& ascii, bool and_multibyte) {
 struct Parser {
   const std::string& p;
   size_t i = 0;
+  int depth = 0;          // open groups (the descent is recursive)
   bool icase = false;     // a leading (?i)
   bool dotall = false;    // a leading (?s): `.` matches \n too
   bool multiline = false; // a leading (?m): ^ also matches after a \n, $ also before one
@@ -257,6 +258,8 @@ struct Parser {
   NodeP parse_atom() {
     const unsigned char ch = (unsigned char)p[i];
     if (ch == '(') {
+      if (++depth > 100) fail("groups nested more than 100 deep");
+      struct Leave { int& d; ~Leave() { d--; } } leave{depth};
       i++;
       if (more() && p[i] == '?') {
         if (i + 1 < p.size() && p[i + 1] == ':') i += 2;

@@ -220,3 +220,27 @@ def test_leading_case_insensitive_flag(built, pattern, values):
 def test_constructs_the_reference_reads_differently_are_refused(built, pattern, why):
     with pytest.raises(native.CometNativeException, match="not supported"):
         native.rlike_match(pattern, "abc")
+
+
+def test_garbage_patterns_fail_cleanly(built):
+    """patterns are user input: any string of metacharacters compiles to a DFA or is refused — no crash, no hang, no state explosion past the cap"""
+    rng = random.Random(4242)
+    alphabet = list("ab0-^$.|()[]{}*+?\\,:=!<>idswxuAzZ19") + ["é", "K", "(?", "[:", ":]", "\\x", "\\u", "{2,", "(?i)", "(?s)", "(?m)", "[^", "\\\\"]
+    outcomes = {"ok": 0, "refused": 0}
+    for _ in range(4000):
+        pattern = "".join(rng.choice(alphabet) for _ in range(rng.randrange(1, 14)))
+        try:
+            native.rlike_match(pattern, "a0-b éK\n")
+            outcomes["ok"] += 1
+        except native.CometNativeException:
+            outcomes["refused"] += 1
+    assert outcomes["ok"] > 200 and outcomes["refused"] > 200, outcomes
+
+
+def test_pathological_patterns_are_bounded(built):
+    """deep nesting, huge literals and nested counted repetitions are refused before they cost stack or memory"""
+    for pat in ["(" * 50000 + "a" + ")" * 50000, "(?:" * 101 + "a" + ")" * 101, "(a{64}){64}{64}", "a" * 100000]:
+        with pytest.raises(native.CometNativeException, match="nested more than 100 deep|too large"):
+            native.rlike_match(pat, "a")
+    assert native.rlike_match("(" * 99 + "a" + ")" * 99, "xax") is True
+    assert native.rlike_match("[" + "a-z" * 50000 + "]", "q") is True
