@@ -13,6 +13,7 @@ namespace {
 struct Reader {
   const uint8_t* p;
   const uint8_t* end;
+  int depth = 0;     // message nesting: prost, which decodes these bytes in the reference, stops at 100 levels ("recursion limit reached")
   Reader(const uint8_t* d, size_t n) : p(d), end(d + n) {}
   bool done() const { return p >= end; }
   uint64_t varint() {
@@ -38,6 +39,8 @@ struct Reader {
     uint64_t n = varint();
     if ((uint64_t)(end - p) < n) throw CometError("protobuf: truncated length-delimited field");
     Reader r(p, (size_t)n);
+    r.depth = depth + 1;
+    if (r.depth > 100) throw CometError("failed to decode Protobuf message: recursion limit reached");
     p += n;
     return r;
   }

@@ -42,3 +42,29 @@ def test_corrupted_plans_fail_cleanly(built, name):
         except native.CometNativeException:
             outcomes["error"] += 1
     assert outcomes["error"] > 0, outcomes
+
+
+def test_nesting_is_bounded_like_prost(built):
+    """prost, which decodes these bytes in the reference, refuses messages nested more than 100 levels ("recursion limit reached"); the
+    hand-written decoder applies the same bound, so a plan of 100 000 nested NOTs is an error, not a stack overflow"""
+    from datafusion_comet_amd import serde as S
+
+    def varint(n):
+        out = b""
+        while True:
+            b, n = n & 0x7F, n >> 7
+            out += bytes([b | 0x80]) if n else bytes([b])
+            if not n:
+                return out
+    fmsg = lambda f, payload: varint((f << 3) | 2) + varint(len(payload)) + payload
+    scan = S.scan([S.T_BOOL]).encode()
+    for depth, ok in ((10, True), (45, True), (60, False), (100_000, False)):
+        e = S.lit(True, S.T_BOOL).encode()
+        for _ in range(depth):
+            e = fmsg(40, fmsg(1, e))                       # Expr{not = 40: UnaryExpr{child = 1: Expr}}: two levels per NOT
+        plan = fmsg(1, scan) + fmsg(102, fmsg(1, e))       # Operator{children = 1, filter = 102: Filter{predicate = 1}}
+        if ok:
+            assert native.compile_plan(plan)
+        else:
+            with pytest.raises(native.CometNativeException, match="recursion limit reached"):
+                native.compile_plan(plan)
