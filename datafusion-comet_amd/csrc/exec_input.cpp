@@ -1,5 +1,8 @@
 // Plan inputs: host ArrowArrayStreams staged through pinned memory (casts, dictionaries, Utf8 rebasing), device streams consumed in place.
 #include "exec_internal.hpp"
+#include <mutex>
+#include <set>
+#include <tuple>
 
 namespace comet {
 // Pull host batches from the JVM stream until a chunk is full; copy through pinned staging to HBM.
@@ -438,6 +441,27 @@ bool ExecutionContext::pull_host_chunk() {
   return !inputs_[0].exhausted;
 }
 
+
+// Verdicts of utf8_uniform_kernel for DECLARED columns (comet:utf8_fixed_len), process-wide: the declaration promises an immutable
+// buffer, so (offsets address, rows, length, first offset) identifies what was verified.  Bounded; cleared when full.
+namespace {
+struct UniformKey {
+  const void* off; int64_t rows; int32_t len; int32_t first;
+  bool operator<(const UniformKey& o) const { return std::tie(off, rows, len, first) < std::tie(o.off, o.rows, o.len, o.first); }
+};
+std::mutex g_uniform_mu;
+std::set<UniformKey> g_uniform_ok;
+bool uniform_verdict_known(const void* off, int64_t rows, int32_t len, int32_t first) {
+  std::lock_guard<std::mutex> g(g_uniform_mu);
+  return g_uniform_ok.count(UniformKey{off, rows, len, first}) != 0;
+}
+void remember_uniform_verdict(const void* off, int64_t rows, int32_t len, int32_t first) {
+  std::lock_guard<std::mutex> g(g_uniform_mu);
+  if (g_uniform_ok.size() >= 4096) g_uniform_ok.clear();
+  g_uniform_ok.insert(UniformKey{off, rows, len, first});
+}
+}  // namespace
+
 bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>& types, std::vector<DeviceColumnView>& views,
                                          std::vector<bool>& has_valid, int64_t& rows, std::shared_ptr<void>& keepalive) {
   InputSource& in = inputs_[input];
@@ -501,6 +525,7 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
     }
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::vector<int32_t> first(scols.size()), len(scols.size(), -1);
+    std::vector<bool> declared(scols.size(), false);
     uint32_t* flags = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 16);   // last 16 words of the error/aux block: scratch
     HIP_CHECK(hipMemsetAsync(flags, 0, 64, stream_));
     bool any = false;
@@ -508,17 +533,27 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
       first[k] = ends[2 * k];
       const int64_t total = (int64_t)ends[2 * k + 1] - ends[2 * k];
       const int hint = input < fixed_len_hint_.size() && scols[k] < fixed_len_hint_[input].size() ? fixed_len_hint_[input][scols[k]] : -1;
+      const ArrowArray* col = da->array.children[scols[k]];
+      const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
       if (hint >= 0) {
-        // the producer vouches for the offsets in between; a batch whose end points contradict it is refused
+        // A declaration is a promise about an IMMUTABLE buffer, and it is still verified: the end points on every batch, every offset in
+        // between by utf8_uniform_kernel the first time this (offsets address, rows, length) is seen in the process — the verdict is
+        // remembered, so the tasks after the first pay nothing.  A batch that contradicts the declaration is refused, never mis-read.
         if (total != (int64_t)hint * rows)
           throw CometError("device input column " + std::to_string(scols[k]) + " is declared comet:utf8_fixed_len=" + std::to_string(hint) + " but holds " +
                            std::to_string(total) + " bytes in " + std::to_string(rows) + " rows");
-        if ((int64_t)first[k] == (int64_t)da->array.children[scols[k]]->offset * hint) views[scols[k]].fixed_len = hint;
+        if ((int64_t)first[k] != (int64_t)col->offset * hint) continue;      // a sliced column: offset-based accessors only
+        if (uniform_verdict_known(off, rows, hint, first[k])) {
+          views[scols[k]].fixed_len = hint;
+          continue;
+        }
+        if (comet_launch_utf8_uniform(off, rows, hint, flags + k, stream_) != 0) continue;
+        len[k] = hint;
+        declared[k] = true;
+        any = true;
         continue;
       }
       if (total % rows != 0 || total / rows > 15 || total < 0) continue;
-      const ArrowArray* col = da->array.children[scols[k]];
-      const int32_t* off = (const int32_t*)col->buffers[1] + col->offset;
       if (comet_launch_utf8_uniform(off, rows, (int32_t)(total / rows), flags + k, stream_) != 0) continue;
       len[k] = (int32_t)(total / rows);
       any = true;
@@ -528,9 +563,18 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
       read_small(f, flags, 64);
       HIP_CHECK(hipMemsetAsync(flags, 0, 64, stream_));
       for (size_t k = 0; k < scols.size(); k++) {
-        if (len[k] < 0 || f[k] != 0) continue;
+        if (len[k] < 0) continue;
         const size_t c = scols[k];
         const ArrowArray* col = da->array.children[c];
+        if (declared[k]) {
+          if (f[k] != 0)
+            throw CometError("device input column " + std::to_string(c) + " is declared comet:utf8_fixed_len=" + std::to_string(len[k]) +
+                             " but its offsets are not " + std::to_string(len[k]) + " bytes apart (the byte total alone matches)");
+          remember_uniform_verdict((const int32_t*)col->buffers[1] + col->offset, rows, len[k], first[k]);
+          views[c].fixed_len = len[k];
+          continue;
+        }
+        if (f[k] != 0) continue;
         // value i then sits at aux + (offset + i)·len.  Only claimed when that base IS the data buffer (an unsliced column), because the
         // offset-based accessors (substring, LIKE, views …) of the same kernels keep addressing aux + offsets[i]
         if ((int64_t)first[k] != (int64_t)col->offset * len[k]) continue;

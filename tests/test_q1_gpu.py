@@ -68,6 +68,29 @@ def test_q1_device_resident_with_fixed_length_metadata(built):
     assert not mixed.schema.field(0).metadata
 
 
+def test_fixed_length_declaration_that_keeps_the_byte_total_is_refused(built):
+    """lengths 0,2,0,2,… declared as 1 keep the byte total (and both end points) right.  Every declared column is
+    verified by utf8_uniform_kernel the first time its buffer is seen (the verdict is cached per buffer address afterwards), so the lie is
+    refused instead of producing wrong groups; a truthful declaration on the same plan still runs, twice (second task = cached verdict)."""
+    n = 4096
+    keys = ["" if i % 2 == 0 else "ab" for i in range(n)]
+    t = pa.table({"k": pa.array(keys, pa.string()), "v": pa.array(range(n), pa.int64())})
+    plan = S.hash_agg(S.scan([S.T_STRING, S.T_INT64]), [S.col(0, S.T_STRING)], [S.count(S.col(1, S.T_INT64))], mode=S.PARTIAL)
+    dev = native.DeviceTable.from_arrow(t, "cuda:0")
+    assert _rows(_run(plan, [native.DeviceInput(dev)], 2)) == [("", n // 2), ("ab", n // 2)]
+    lying = native.DeviceTable(pa.schema([dev.schema.field(0).with_metadata({b"comet:utf8_fixed_len": b"1"}), dev.schema.field(1)]),
+                               dev.num_rows, dev.values, dev.validity, dev.device, dev.aux)
+    for _ in range(2):          # never cached as good
+        with pytest.raises(native.CometNativeException, match="offsets are not 1 bytes apart"):
+            _run(plan, [native.DeviceInput(lying)], 2)
+    t2 = pa.table({"k": pa.array(["x" if i % 3 else "y" for i in range(n)], pa.string()), "v": pa.array(range(n), pa.int64())})
+    dev2 = native.DeviceTable.from_arrow(t2, "cuda:0").with_string_hints()
+    assert dev2.schema.field(0).metadata[b"comet:utf8_fixed_len"] == b"1"
+    a = _rows(_run(plan, [native.DeviceInput(dev2)], 2))
+    b = _rows(_run(plan, [native.DeviceInput(dev2)], 2))
+    assert a == b == [("x", n - (n + 2) // 3), ("y", (n + 2) // 3)]
+
+
 def test_q1_chunked_equals_unchunked(built):
     table = tpch.lineitem_q1(100_000, seed=2)
     plan = tpch.q1_plan()

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+    ap.add_argument("--exchange", default="native", choices=["native", "torch", "torch-fallback"],
                     help="native: the exchange runs inside libcomet.so (partition kernels + RCCL send/recv groups); torch: torch.distributed all_to_all")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -43,10 +43,11 @@ def main():
     bytes_local = customer.nbytes() + orders.nbytes() + lineitem.nbytes()
     eng, part = parallel.GpuEngine(local), parallel.HipPartitioner()
     exchange_kind = "torch.distributed all_to_all_single" if world > 1 else "none (one partition)"
+    transport = "none (1 rank)" if world == 1 else ("torch" if a.exchange == "torch" else "torch-fallback")
     if world > 1 and a.exchange == "native":
         try:
             part = parallel.NativeExchange(parallel.native_comm_from_process_group(local))
-            exchange_kind = "in-library (libcomet.so: partition kernels + RCCL ncclSend/ncclRecv groups)"
+            exchange_kind, transport = "in-library (libcomet.so: partition kernels + RCCL ncclSend/ncclRecv groups)", "rccl"
         except Exception as e:      # keep the leg alive on a box where librccl cannot be bound; say so in the result
             exchange_kind = f"torch.distributed all_to_all_single (in-library transport unavailable: {e})"
     tot = torch.tensor([rows_local, bytes_local], dtype=torch.int64, device=dev)
@@ -81,7 +82,7 @@ def main():
                 "sec_per_run": sec, "rows_per_s": int(tot[0].item()) / sec, "input_GBps": int(tot[1].item()) / sec / 1e9,
                 "stage_ms_rank0": {k: round(v / a.steps * 1e3, 3) for k, v in timings.items() if not k.startswith("exchange_")},
                 "exchange_rows_rank0": timings.get("exchange_rows", 0) // a.steps, "exchange_bytes_rank0": timings.get("exchange_bytes", 0) // a.steps,
-                "exchange": exchange_kind, "groups_rank0": groups, "top1": [str(x) for x in top[0]] if top else None, "verified_vs_torch": ok, "scaling": "strong"}
+                "exchange": exchange_kind, "exchange_transport": transport, "groups_rank0": groups, "top1": [str(x) for x in top[0]] if top else None, "verified_vs_torch": ok, "scaling": "strong"}
         s = json.dumps(line)
         print(s, flush=True)
         if a.out:

@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--orders", type=int, default=16_000_000, help="total orders (SF100 ≈ 16 M orders ≈ 72 M web_sales rows)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--exchange", default="native", choices=["native", "torch"])
+    ap.add_argument("--exchange", default="native", choices=["native", "torch", "torch-fallback"])
     ap.add_argument("--simulate-ranks", type=int, default=0)
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--verify", default="torch", choices=["torch", "numpy", "both"],
+                    help="independent evaluation the answer is compared with: torch on the GPU (≈ 1 s at SF100 size) or numpy on the host (≈ 40 s)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import numpy as np
@@ -45,13 +47,13 @@ def main():
     shard = lambda tb, w, r: tb.slice(*parallel.shard_range(tb.num_rows, w, r))
     eng = parallel.GpuEngine(local)
     part = parallel.HipPartitioner()
-    exchange_kind = "none (one partition)"
+    exchange_kind, transport = "none (one partition)", "none (1 rank)"
     if world > 1:
-        exchange_kind = "torch.distributed all_to_all_single"
+        exchange_kind, transport = "torch.distributed all_to_all_single", "torch" if a.exchange == "torch" else "torch-fallback"
         if a.exchange == "native":
             try:
                 part = parallel.NativeExchange(parallel.native_comm_from_process_group(local))
-                exchange_kind = "in-library (libcomet.so: partition kernels + RCCL ncclSend/ncclRecv groups)"
+                exchange_kind, transport = "in-library (libcomet.so: partition kernels + RCCL ncclSend/ncclRecv groups)", "rccl"
             except Exception as e:
                 exchange_kind = f"torch.distributed all_to_all_single (in-library transport unavailable: {e})"
     dims = {k: t[k] for k in ("date_dim", "customer_address", "web_site")}
@@ -95,7 +97,7 @@ def main():
                 times.append(time.perf_counter() - t0)
         got = (out.column(2)[0].as_py(), out.column(0)[0].as_py(), out.column(1)[0].as_py())
         sec = min(times)
-        exchange_kind = f"in-library, in-process transport: {R} task threads on one GPU (partition kernels + peer copies)"
+        exchange_kind, transport = f"in-library, in-process transport: {R} task threads on one GPU (partition kernels + peer copies)", "in-process"
     else:
         mine = dict(dims, web_sales=native.DeviceTable.from_arrow(shard(t["web_sales"], world, rank), dev),
                     web_returns=native.DeviceTable.from_arrow(shard(t["web_returns"], world, rank), dev))
@@ -114,13 +116,22 @@ def main():
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         sec = float(dt.item()) / a.steps
-    ok = None
+    ok, verified_by = None, None
     if rank == 0:
         if not a.no_verify:
-            ok = got == tpcds.q95_reference_numpy(t)
+            del eng, part
+            torch.cuda.empty_cache()
+            v0 = time.perf_counter()
+            ok = True
+            if a.verify in ("torch", "both"):
+                ok = ok and got == tpcds.q95_reference_torch(t, dev)
+            if a.verify in ("numpy", "both"):
+                ok = ok and got == tpcds.q95_reference_numpy(t)
+            verified_by = f"{a.verify} ({time.perf_counter() - v0:.1f} s)"
         line = {"query": "tpcds_q95", "orders": a.orders, "n_gpus": world, "simulated_ranks": a.simulate_ranks, "fact_rows": rows, "sec_per_run": sec,
                 "fact_rows_per_s": rows / sec, "stage_ms_rank0": {k: round(v / a.steps * 1e3, 3) for k, v in timings.items() if not k.startswith("exchange_")},
-                "exchange": exchange_kind, "result": [got[0], str(got[1]), str(got[2])], "verified_vs_numpy": ok, "scaling": "strong"}
+                "exchange": exchange_kind, "exchange_transport": transport, "result": [got[0], str(got[1]), str(got[2])], "verified": ok,
+                "verified_by": verified_by, "scaling": "strong"}
         s = json.dumps(line)
         print(s, flush=True)
         if a.out:
