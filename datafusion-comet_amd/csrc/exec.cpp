@@ -245,6 +245,13 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
           for (const ExprP& r : {fn.frame_lower == 1 ? fn.frame_lower_range : ExprP(), fn.frame_upper == 1 ? fn.frame_upper_range : ExprP()})
             if (r && (!r->dtype.is_integer() || r->lit_null || r->lit_i64 < 0))
               throw CometError("Window: a RANGE frame offset must be a non-negative integer literal of the ORDER BY column's type");
+            else if (r) {
+              // key ± offset is evaluated in the key's width (window_range_bounds_kernel wraps there): an offset the key type cannot hold
+              // would wrap to a small one instead of covering the partition
+              const int bits = kt.id == TypeId::Int8 ? 7 : kt.id == TypeId::Int16 ? 15 : kt.id == TypeId::Int32 ? 31 : 63;
+              if (bits < 63 && (r->lit_i64 >> bits) != 0)
+                throw CometError("Window: RANGE frame offset " + std::to_string(r->lit_i64) + " does not fit the ORDER BY column's type " + kt.str());
+            }
         }
     };
     for (auto& fn : op.window_fns) {
@@ -291,6 +298,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
         if (fn.args.size() < 1 || fn.args.size() > 3 || fn.args[0]->kind != ExprKind::Bound || fn.args[0]->bound_index < 0 || (size_t)fn.args[0]->bound_index >= st.size())
           throw CometError(f + " is supported for a column argument");
         if (fn.args.size() >= 2 && !int_lit(fn.args[1])) throw CometError(f + " expects a literal offset");
+        if (fn.ignore_nulls && fn.args.size() >= 2 && fn.args[1]->lit_i64 == 0) throw CometError(f + " IGNORE NULLS with offset 0 is not supported");
         if (fn.args.size() == 3 && fn.args[2]->kind != ExprKind::Literal) throw CometError(f + " default value must be a literal");
         if (fn.args.size() == 3 && !fn.args[2]->lit_null) {
           const DType& at = st[(size_t)fn.args[0]->bound_index];

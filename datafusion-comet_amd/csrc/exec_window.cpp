@@ -298,7 +298,7 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
     idx->ensure((size_t)n * 4 + 16);
     ok.ensure((size_t)n + 16);
     const Expr* dflt = fn.args.size() == 3 && !fn.args[2]->lit_null ? fn.args[2].get() : nullptr;
-    if (fn.ignore_nulls && in.has_valid[(size_t)c] && k >= 1) {
+    if (fn.ignore_nulls && in.has_valid[(size_t)c] && k != 0) {
       // IGNORE NULLS: the k-th non-NULL row before / after the current one — the pick kernel's search over the non-NULL prefix counts,
       // with the whole partition as the frame
       DevBuf flags, t32, counts;
@@ -307,7 +307,9 @@ DevTable ExecutionContext::window(const Operator& w, const DevTable& in) {
       t32.ensure((size_t)((n + 1023) / 1024 + 2) * 8);
       if (comet_launch_window_valid_flags(in.cols[(size_t)c].valid, n, (uint32_t*)flags.p, stream_) != 0) throw CometError("window: launch failed");
       pq_launch_u32_scan((const uint32_t*)flags.p, n, (uint64_t*)t32.p, (int32_t*)counts.p, stream_);
-      if (comet_launch_window_pick(f == "lag" ? 3 : 4, k, 0, 0, 0, 0, (const int32_t*)counts.p, (const int32_t*)sp->p, (const int32_t*)sg->p, (const uint32_t*)first_part->p,
+      // a negative offset looks the other way: lag(x, -k) = lead(x, k) (k = 0 with IGNORE NULLS is refused at createPlan)
+      const bool backwards = (f == "lag") == (k > 0);
+      if (comet_launch_window_pick(backwards ? 3 : 4, k > 0 ? k : -k, 0, 0, 0, 0, (const int32_t*)counts.p, (const int32_t*)sp->p, (const int32_t*)sg->p, (const uint32_t*)first_part->p,
                                    (const uint32_t*)first_peer->p, n, (uint32_t*)idx->p, (uint8_t*)ok.p, stream_) != 0)
         throw CometError("window: launch failed");
       gather_rows(c, idx, ok, dflt);

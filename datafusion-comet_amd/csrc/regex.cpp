@@ -146,6 +146,8 @@ struct Parser {
   }
   NodeP parse_repeat() {
     NodeP a = parse_atom();
+    int stacked = 0;      // a{1}{1}{1}… nests one Repeat per quantifier without adding NFA states on the way down; build() and the node
+                          // destructor recurse once per level, and regex-syntax refuses what nests deeper than its nest_limit as well
     while (more()) {
       int mn, mx;
       const char ch = p[i];
@@ -175,6 +177,7 @@ struct Parser {
       if (more() && (p[i] == '?')) i++;                    // lazy: same language
       else if (more() && p[i] == '+') fail("possessive quantifiers");
       if (a->kind == Node::Bol || a->kind == Node::Eol) fail("a quantifier on an anchor");
+      if (++stacked + depth > 100) fail("quantifiers stacked more than 100 deep");
       auto r = mk(Node::Repeat);
       r->kids.push_back(a);
       r->min = mn;
@@ -253,6 +256,7 @@ struct Parser {
     }
     if ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) return -1;   // \d \w \b \1 \p{..} \x.. …: not reproduced
     if ((unsigned char)c >= 0x80) return -1;
+    if (c == '<' || c == '>') return -1;      // \< / \> are word-boundary assertions in regex-syntax 0.8 (and an error inside a class), not literals
     return (unsigned char)c;
   }
   NodeP parse_atom() {

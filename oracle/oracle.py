@@ -974,14 +974,16 @@ def run_plan(S, op, table) -> List[Col]:
                 src = ev.eval(args[0], child, n)
                 kk = int(args[1].value) if len(args) > 1 else 1
                 sh = -kk if name == "lag" else kk
-                if len(wf) > 4 and wf[4] and kk >= 1:
-                    # IGNORE NULLS: the kk-th non-NULL row before (lag) / after (lead) the current one, inside the partition
+                if len(wf) > 4 and wf[4] and kk != 0:
+                    # IGNORE NULLS: the |kk|-th non-NULL row before (lag) / after (lead) the current one, inside the partition; a negative
+                    # offset looks the other way (DataFusion's WindowShift keeps one signed shift: lag(x, -k) = lead(x, k))
                     okf = src.ok()
                     idx = np.full(n, -1, np.int64)
+                    back = (name == "lag") == (kk > 0)
                     for i in range(n):
-                        rows = [r for r in (range(i - 1, ps[i] - 1, -1) if name == "lag" else range(i + 1, pe[i])) if okf[r]]
-                        if len(rows) >= kk:
-                            idx[i] = rows[kk - 1]
+                        rows = [r for r in (range(i - 1, ps[i] - 1, -1) if back else range(i + 1, pe[i])) if okf[r]]
+                        if len(rows) >= abs(kk):
+                            idx[i] = rows[abs(kk) - 1]
                 else:
                     idx = np.array([i + sh if ps[i] <= i + sh < pe[i] else -1 for i in range(n)], dtype=np.int64)
                 okv = (idx >= 0) & src.ok()[np.maximum(idx, 0)]

@@ -216,7 +216,9 @@ def test_leading_case_insensitive_flag(built, pattern, values):
                                          ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[z-a]", "reversed"), ("[[:^alpha:]]", "POSIX"), ("[[:alfa:]]", "POSIX"), ("[a[b]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
                                          ("\\p{L}", "escape"), ("\\xZ1", "hexadecimal"), ("\\x{110000}", "scalar value"), ("\\uD800", "scalar value"), ("\\u12", "hexadecimal"),
-                                         ("(?i)\\u00e9", "non-ASCII"), ("a{,2}", "counted repetition")])
+                                         ("(?i)\\u00e9", "non-ASCII"), ("a{,2}", "counted repetition"),
+                                         # regex-syntax 0.8.11: \< and \> are start / end-of-word assertions, and an error inside a class
+                                         ("a\\<b", "escape"), ("a\\>", "escape"), ("[\\<]", "escape"), ("[a\\>]", "escape")])
 def test_constructs_the_reference_reads_differently_are_refused(built, pattern, why):
     with pytest.raises(native.CometNativeException, match="not supported"):
         native.rlike_match(pattern, "abc")
@@ -242,5 +244,13 @@ def test_pathological_patterns_are_bounded(built):
     for pat in ["(" * 50000 + "a" + ")" * 50000, "(?:" * 101 + "a" + ")" * 101, "(a{64}){64}{64}", "a" * 100000]:
         with pytest.raises(native.CometNativeException, match="nested more than 100 deep|too large"):
             native.rlike_match(pat, "a")
+    # stacked quantifiers nest one Repeat per quantifier without adding states: bounded like groups (300 000 of them used to overflow the stack)
+    for pat in ["a" + "{1}" * 300000, "a" + "{1}" * 101, "(?:" * 60 + "a" + ")" * 60 + "?" * 0 + "{1}" * 0 + "*" * 0, "a" + "?" * 250]:
+        if pat.startswith("(?:"):
+            assert native.rlike_match(pat, "xa") is True
+            continue
+        with pytest.raises(native.CometNativeException, match="stacked more than 100 deep"):
+            native.rlike_match(pat, "a")
+    assert native.rlike_match("a" + "{1}" * 50, "xa") is True
     assert native.rlike_match("(" * 99 + "a" + ")" * 99, "xax") is True
     assert native.rlike_match("[" + "a-z" * 50000 + "]", "q") is True

@@ -210,7 +210,9 @@ def test_first_last_and_nth_value(built):
     # lag / lead IGNORE NULLS: the k-th non-NULL row before / after, with and without a default
     whole = ("rows", "unbounded", "unbounded")
     fns += [("lag", [amount, S.lit(1, S.T_INT32)], D, whole, True), ("lead", [amount, S.lit(2, S.T_INT32), S.lit(__import__("decimal").Decimal("-1.00"), D)], D, whole, True),
-            ("lag", [label, S.lit(3, S.T_INT32)], S.T_STRING, whole, True), ("lead", [amount, S.lit(1, S.T_INT32)], D, whole, False)]
+            ("lag", [label, S.lit(3, S.T_INT32)], S.T_STRING, whole, True), ("lead", [amount, S.lit(1, S.T_INT32)], D, whole, False),
+            # a negative offset looks the other way, IGNORE NULLS included (it used to fall through to the plain offset path)
+            ("lag", [amount, S.lit(-2, S.T_INT32)], D, whole, True), ("lead", [label, S.lit(-1, S.T_INT32)], S.T_STRING, whole, True)]
     plan = S.window(child, [g], order, fns)
     ncols = len(fields) + len(fns)
     got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], ncols, plan.encode(), batch_size=0))
@@ -229,6 +231,23 @@ def test_frames_the_engine_refuses(built):
     child = S.sort(S.scan(FIELDS), [(cat, False, False), (store, False, False)] + order)
     for fn, msg in ((("agg", S.sum_(amount, S.decimal(22, 2)), S.decimal(22, 2), ("range", -2, "current")), "RANGE frames with a value offset"),
                     (("agg", S.min_(amount, D), D, ("rows", -5000, 5000)), "wider than 4096"),
+                    (("lag", [amount, S.lit(0, S.T_INT32)], D, ("rows", "unbounded", "unbounded"), True), "offset 0"),
                     (("agg", S.min_(S.col(5, S.T_DOUBLE), S.T_DOUBLE), S.T_DOUBLE, ("rows", "unbounded", "current")), "not supported yet")):
         with pytest.raises(native.CometNativeException, match=msg):
             native.execute_to_table([native.HostInput.from_table(t)], len(FIELDS) + 1, S.window(child, [cat, store], order, [fn]).encode(), batch_size=0)
+
+
+def test_range_offset_wider_than_the_order_key_is_refused(built):
+    """key ± offset is evaluated in the key's width, so an Int64 literal of 2^32 over an Int32 ORDER BY key would wrap to offset 0
+    instead of covering the partition — refused at createPlan; the largest offset the key type holds still runs."""
+    t = pa.table({"g": pa.array(np.zeros(50, np.int32)), "k": pa.array(np.arange(50, dtype=np.int32)), "v": pa.array(np.arange(50, dtype=np.int64))})
+    g, k, v = S.col(0, S.T_INT32), S.col(1, S.T_INT32), S.col(2, S.T_INT64)
+    order = [(k, False, False)]
+    child = S.sort(S.scan([S.T_INT32, S.T_INT32, S.T_INT64]), [(g, False, False)] + order)
+
+    def plan(lit):
+        return S.window(child, [g], order, [("agg", S.count(v), S.T_INT64, ("range", ("value", lit), "current"))])
+    with pytest.raises(native.CometNativeException, match="does not fit the ORDER BY column's type"):
+        native.execute_to_table([native.HostInput.from_table(t)], 4, plan(S.lit(1 << 32, S.T_INT64)).encode(), batch_size=0)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 4, plan(S.lit((1 << 31) - 1, S.T_INT64)).encode(), batch_size=0))
+    assert sorted(got.column(3).to_pylist()) == list(range(1, 51))
