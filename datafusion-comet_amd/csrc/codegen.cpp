@@ -2692,8 +2692,39 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
 // generate_join: key hashing / equality / residual condition / output gather functor for the hash-join templates
 // (join_build_body, join_count_body, join_emit_body).  Reference: planner.rs:2192-2266, :2415-2555.
 // ---------------------------------------------------------------------------------------------
-PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, const std::vector<DType>& rt, const std::vector<bool>& lvalid,
-                           const std::vector<bool>& rvalid) {
+void fold_chain(const Operator& top, const Operator& source, const std::vector<DType>& source_types, std::vector<ExprP>& cols, std::vector<ExprP>& preds) {
+  std::vector<const Operator*> chain;
+  for (const Operator* cur = &top; cur != &source; cur = cur->children[0].get()) {
+    if ((cur->kind != OpKind::Filter && cur->kind != OpKind::Projection) || cur->children.size() != 1) throw CometError("internal: fold_chain over a non-chain");
+    chain.push_back(cur);
+  }
+  cols.clear();
+  preds.clear();
+  for (size_t i = 0; i < source_types.size(); i++) {
+    auto b = std::make_shared<Expr>();
+    b->kind = ExprKind::Bound;
+    b->proto_tag = 3;
+    b->bound_index = (int)i;
+    b->dtype = source_types[i];
+    b->has_dtype = true;
+    cols.push_back(b);
+  }
+  for (int i = (int)chain.size() - 1; i >= 0; i--) {
+    const Operator& op = *chain[(size_t)i];
+    std::map<const Expr*, ExprP> memo;
+    if (op.kind == OpKind::Filter) {
+      if (!op.predicate) throw CometError("Filter without predicate");
+      split_conjuncts(substitute(op.predicate, cols, memo), preds);
+    } else {
+      std::vector<ExprP> nc;
+      for (auto& e : op.project_list) nc.push_back(substitute(e, cols, memo));
+      cols = nc;
+    }
+  }
+}
+
+PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, const std::vector<DType>& rt_in, const std::vector<bool>& lvalid_in,
+                           const std::vector<bool>& rvalid_in, const JoinFusion* fu) {
   if (j.kind != OpKind::HashJoin) throw CometError("internal: generate_join on a non-join");
   if (j.left_keys.size() != j.right_keys.size() || j.left_keys.empty()) throw CometError("HashJoin needs matching, non-empty key lists");
   int mode = 0;
@@ -2716,14 +2747,59 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   if (build_only) mode = 0;
   const bool outer_probe = !build_only && (build_left ? keep_right : keep_left);    // the probe side is the preserved one
   const bool outer_build = build_only || (build_left ? keep_left : keep_right);
-  const std::vector<DType>& bt = build_left ? lt : rt;
-  const std::vector<DType>& pt = build_left ? rt : lt;
-  const std::vector<bool>& bv = build_left ? lvalid : rvalid;
-  const std::vector<bool>& pv = build_left ? rvalid : lvalid;
-  const int nb = (int)bt.size(), np = (int)pt.size(), nl = (int)lt.size(), nr = (int)rt.size();
+  const std::vector<DType>& bt = build_left ? lt_in : rt_in;
+  const std::vector<bool>& bv = build_left ? lvalid_in : rvalid_in;
+  // The probe side: the materialised child — or, with a fused probe chain (JoinFusion), the chain's SOURCE table; the child's columns
+  // are then expressions over the source columns (fu->cols), its Filters conjuncts over them (fu->preds, P::pkeep).
+  const std::vector<DType>& pt = fu ? fu->src_types : (build_left ? rt_in : lt_in);      // PHYSICAL probe columns
+  const std::vector<bool>& pv = fu ? fu->src_valid : (build_left ? rvalid_in : lvalid_in);
+  if (fu && pt.size() != pv.size()) throw CometError("internal: fused probe source validity arity mismatch");
+  const int nb = (int)bt.size(), np = (int)pt.size();
+  const int nprobe_logical = fu ? (int)fu->cols.size() : np;
+  const int nl = build_left ? nb : nprobe_logical, nr = build_left ? nprobe_logical : nb;
   if (nb + np > COMET_MAX_IN) throw CometError("too many columns for one GPU hash join");
   const std::vector<ExprP>& bkeys = build_left ? j.left_keys : j.right_keys;
-  const std::vector<ExprP>& pkeys = build_left ? j.right_keys : j.left_keys;
+  const std::vector<ExprP>& pkeys_logical = build_left ? j.right_keys : j.left_keys;
+  std::vector<ExprP> pkeys;
+  {
+    std::map<const Expr*, ExprP> memo;
+    for (auto& k : pkeys_logical) pkeys.push_back(fu ? substitute(k, fu->cols, memo) : k);
+  }
+  // physical combined schema = kernel argument order: build columns (row i), then probe columns (row j)
+  std::vector<DType> ct(bt);
+  ct.insert(ct.end(), pt.begin(), pt.end());
+  std::vector<bool> cv(bv);
+  cv.insert(cv.end(), pv.begin(), pv.end());
+  auto locate_combined = [=](int c) { return std::make_pair(c, std::string(c < nb ? "i" : "j")); };
+  auto mk_bound = [](int idx, const DType& t) {
+    auto b = std::make_shared<Expr>();
+    b->kind = ExprKind::Bound;
+    b->proto_tag = 3;
+    b->bound_index = idx;
+    b->dtype = t;
+    b->has_dtype = true;
+    return ExprP(b);
+  };
+  std::function<ExprP(const ExprP&, int)> shift_bound = [&](const ExprP& e, int by) -> ExprP {
+    if (e->kind == ExprKind::Bound) {
+      auto n = std::make_shared<Expr>(*e);
+      n->bound_index = e->bound_index + by;
+      return n;
+    }
+    if (e->children.empty()) return e;
+    auto n = std::make_shared<Expr>(*e);
+    for (auto& c : n->children) c = shift_bound(c, by);
+    return n;
+  };
+  // logical column c of left ++ right (what keys, condition and output refer to) as an expression over the physical schema
+  std::vector<ExprP> phys;
+  for (int c = 0; c < nl + nr; c++) {
+    const bool is_left = c < nl;
+    const int local = is_left ? c : c - nl;
+    if (is_left == build_left) phys.push_back(mk_bound(local, bt[(size_t)local]));
+    else if (!fu) phys.push_back(mk_bound(nb + local, pt[(size_t)local]));
+    else phys.push_back(shift_bound(fu->cols[(size_t)local], nb));
+  }
 
   PipelineDesc d;
   d.sink = SinkKind::Output;
@@ -2777,17 +2853,19 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   int nwp = key_fn("phash", "j", pt, pv, nb, pkeys, true);
   if (nwb != nwp) throw CometError("HashJoin key types differ between the two sides");
 
-  // combined schema left ++ right: where does combined column c live?
-  std::vector<DType> ct(lt);
-  ct.insert(ct.end(), rt.begin(), rt.end());
-  std::vector<bool> cv(lvalid);
-  cv.insert(cv.end(), rvalid.begin(), rvalid.end());
-  auto locate_combined = [=](int c) {
-    const bool is_left = c < nl;
-    const int local = is_left ? c : c - nl;
-    const bool in_build = (is_left == build_left);
-    return std::make_pair(in_build ? local : nb + local, std::string(in_build ? "i" : "j"));
-  };
+  // P::pkeep(j): the Filters of a fused probe chain, conjunct by conjunct (columns load only for rows still alive); a row that fails is
+  // not part of the probe side at all (outer / anti joins do not emit it either)
+  if (fu && !fu->preds.empty()) {
+    Gen g(pt, pv);
+    g.locate = [nb](int idx) { return std::make_pair(nb + idx, std::string("j")); };
+    for (auto& p : fu->preds) {
+      g.add_predicate(p);
+      ex << "  probe filter (fused into the probe kernel): " << explain_expr(p) << "\n";
+    }
+    src << "  static __device__ __forceinline__ bool pkeep(const CometKParams& prm, i64 j) {\n    bool k[R] = {true};\n" << g.decls << g.body() << "    return k[0];\n  }\n";
+  } else {
+    src << "  static __device__ __forceinline__ bool pkeep(const CometKParams&, i64) { return true; }\n";
+  }
   {
     // match(i, j): every key pair equal (NULL never equals) and the residual condition TRUE
     Gen g(ct, cv);
@@ -2807,13 +2885,15 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
         for (auto& c : n->children) c = shift(c);
         return n;
       };
-      Val a = g.gen(j.left_keys[k]);
-      Val b = g.gen(shift(j.right_keys[k]));
+      std::map<const Expr*, ExprP> m2;
+      Val a = g.gen(substitute(j.left_keys[k], phys, m2));
+      Val b = g.gen(substitute(shift(j.right_keys[k]), phys, m2));
       Val c = g.compare(ExprKind::Eq, a, b);
       cond = Gen::and_ok(cond, Gen::and_ok(c.ok, c.v));
     }
     if (j.join_condition) {
-      Val c = g.gen(j.join_condition);
+      std::map<const Expr*, ExprP> m2;
+      Val c = g.gen(substitute(j.join_condition, phys, m2));
       if (c.rep != Rep::B) throw CometError("join condition must be boolean");
       cond = Gen::and_ok(cond, Gen::and_ok(c.ok, c.v));
       ex << "  condition: " << explain_expr(j.join_condition) << "\n";
@@ -2832,13 +2912,29 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
     // Outer joins add emit_probe_only(j, pos) / emit_build_only(i, pos): the other side's columns are NULL.
     const int nout = (mode == 0 && !build_only) ? nl + nr : nl;
     if (nout * 2 + kOutFirstCol > 44) throw CometError("too many output columns for one GPU hash join");
-    for (int c = 0; c < nout; c++) {
-      const bool is_left = c < nl;
-      OutCol oc;
-      oc.type = ct[c];
-      oc.nullable = cv[c] || (is_left ? keep_right : keep_left);   // the non-preserved side is NULL-extended
-      if (ct[c].id == TypeId::String || ct[c].id == TypeId::Bytes) oc.gather_src = c;   // Utf8 payload: row index now, gathered after the emit
-      d.out_cols.push_back(oc);
+    auto is_str_bound = [&](const ExprP& e) {
+      return e->kind == ExprKind::Bound && e->bound_index >= 0 && (size_t)e->bound_index < ct.size() &&
+             (ct[(size_t)e->bound_index].id == TypeId::String || ct[(size_t)e->bound_index].id == TypeId::Bytes);
+    };
+    {
+      Gen g0(ct, cv);             // types and nullability of the output columns (a fused probe column is a computed expression)
+      g0.locate = locate_combined;
+      for (int c = 0; c < nout; c++) {
+        const bool is_left = c < nl;
+        const ExprP& e = phys[(size_t)c];
+        OutCol oc;
+        if (is_str_bound(e)) {
+          oc.type = ct[(size_t)e->bound_index];
+          oc.nullable = cv[(size_t)e->bound_index] || (is_left ? keep_right : keep_left);
+          oc.gather_src = e->bound_index;     // Utf8 payload: row index now, gathered after the emit (index into build ++ probe columns)
+        } else {
+          Val v = g0.gen(e);
+          if (v.rep == Rep::STR) throw CometError("a computed Utf8 column below a fused join probe is not supported");
+          oc.type = v.t;
+          oc.nullable = !v.ok.empty() || (is_left ? keep_right : keep_left);   // the non-preserved side is NULL-extended
+        }
+        d.out_cols.push_back(oc);
+      }
     }
     // variant 0 = both rows, 1 = probe row only, 2 = build row only
     for (int variant = 0; variant < 3; variant++) {
@@ -2849,28 +2945,30 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
       for (int c = 0; c < nout; c++) {
         const bool in_build = ((c < nl) == build_left);
         const bool absent = (variant == 1 && in_build) || (variant == 2 && !in_build);
+        const ExprP& e = phys[(size_t)c];
         std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * c) + "]", ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * c + 1) + "]";
         if (d.out_cols[c].gather_src >= 0) {
           // Utf8 payload: the source row (build row i or probe row j); NULL when the side is absent or the value is NULL
-          auto loc = locate_combined(c);
+          const int pc = e->bound_index;
+          auto loc = locate_combined(pc);
           if (absent) {
             g.stmt("((u32*)" + vb + ")[pos] = 0u;");
             g.stmt("((u8*)" + ob + ")[pos] = 0;");
           } else {
-            g.in_used[(size_t)c] = true;
+            g.in_used[(size_t)pc] = true;
             g.stmt("((u32*)" + vb + ")[pos] = (u32)" + loc.second + ";");
             if (d.out_cols[c].nullable)
-              g.stmt("((u8*)" + ob + ")[pos] = " + (cv[c] ? "comet::ld_valid(prm.in[" + std::to_string(loc.first) + "], " + loc.second + ") ? 1 : 0" : std::string("1")) + ";");
+              g.stmt("((u8*)" + ob + ")[pos] = " + (cv[(size_t)pc] ? "comet::ld_valid(prm.in[" + std::to_string(loc.first) + "], " + loc.second + ") ? 1 : 0" : std::string("1")) + ";");
           }
           continue;
         }
-        const char* st = store_ctype(ct[c]);
+        const char* st = store_ctype(d.out_cols[c].type);
         if (absent) {
           g.stmt("((" + std::string(st) + "*)" + vb + ")[pos] = (" + st + ")0;");
           g.stmt("((u8*)" + ob + ")[pos] = 0;");
           continue;
         }
-        Val v = g.column(c);
+        Val v = g.gen(e);
         std::string val = v.v;
         if (v.t.id == TypeId::Decimal) val = v.rep == Rep::I128 ? v.v : "(i128)" + v.v;
         else if (v.t.id == TypeId::Bool) val = "(u8)(" + v.v + " ? 1 : 0)";
@@ -2905,7 +3003,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt, cons
   d.join_build_only = build_only;
   const char* jt_name = build_only ? (keep_matched ? "LeftSemi" : "LeftAnti") : keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";
   ex << "  hash join: " << jt_name << ", build " << (build_left ? "left" : "right") << ", "
-     << j.left_keys.size() << " key(s)\n";
+     << j.left_keys.size() << " key(s)" << (fu ? ", probe side fused with its Filter / Projection chain" : "") << "\n";
   d.in_types = ct;
   d.source = src.str();
   d.explain = ex.str();

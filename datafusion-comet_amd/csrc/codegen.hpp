@@ -81,8 +81,21 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
 // Hash join of two materialised tables (left/right = the join's children in plan order).
 // Sort: the kernel that writes every row's order-preserving key bytes (byte planes)
 PipelineDesc generate_sort_keys(const Operator& sort, const std::vector<DType>& types, const std::vector<bool>& has_validity);
+// Probe-side fusion (DataFusion's HashJoinExec STREAMS its probe side, planner.rs:2192-2266; materialising the probe child first costs a
+// write and a read of every surviving row): when the probe child is a chain of Filters / Projections over a source, the join kernel
+// reads the SOURCE table — the child's columns are expressions over the source columns, its Filters run inside the probe kernel.
+struct JoinFusion {
+  std::vector<DType> src_types;   // the chain's source table = the physical probe side
+  std::vector<bool> src_valid;
+  std::vector<ExprP> cols;        // probe child column c as an expression over the source columns
+  std::vector<ExprP> preds;       // the chain's Filter conjuncts over the source columns
+};
+// left / right types and validity describe the join's children; with `probe_fusion` the probe side's entries are ignored
 PipelineDesc generate_join(const Operator& join, const std::vector<DType>& left_types, const std::vector<DType>& right_types,
-                           const std::vector<bool>& left_has_validity, const std::vector<bool>& right_has_validity);
+                           const std::vector<bool>& left_has_validity, const std::vector<bool>& right_has_validity,
+                           const JoinFusion* probe_fusion = nullptr);
+// the (cols, preds) of a Filter / Projection chain `top … down to (excluding) source`, over the source columns
+void fold_chain(const Operator& top, const Operator& source, const std::vector<DType>& source_types, std::vector<ExprP>& cols, std::vector<ExprP>& preds);
 
 // index of out[] slots used by the generated kernels (must match exec.cpp)
 constexpr int kOutPartials = 0;      // AggNoGroup: partials;  Output: mask words

@@ -1723,6 +1723,7 @@ CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
 //   single-row buckets almost always).  The table stays 4 bytes per bucket — an 8-byte head with a 31-bit tag was measured too: the
 //   probe of SF100 Q3's second join got SLOWER (the 256 MB head array no longer sits in the 256 MB Infinity Cache).
 // Probe side: template D' below (single pass; counts and emits together).
+//   P::pkeep(prm,j)                       the probe row exists at all: the Filters of a probe-side chain fused into the kernel
 //   P::bvalid(prm,i) / P::pvalid(prm,j)   all key columns non-NULL
 //   P::bhash(prm,i)  / P::phash(prm,j)    64-bit hash of the key words
 //   P::match(prm,i,j)                     keys equal (and residual join condition TRUE)
@@ -1894,7 +1895,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
       cnt[r] = 0;
       first[r] = kJoinEmpty;
       hs[r] = 0;
-      const bool active = j < n;
+      const bool active = j < n && P::pkeep(prm, j);     // pkeep: the Filters of a probe chain fused into this kernel (else constant true)
       if (active && P::pvalid(prm, j)) {
         hs[r] = P::phash(prm, j);
         u32 c = 0, f0 = kJoinEmpty;

@@ -72,7 +72,9 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
   for (auto& kv : config_) {
     if (kv.first == "spark.comet.gpu.chunkRows") chunk_rows_ = std::max<long long>(1024, atoll(kv.second.c_str()));
     if (kv.first == "spark.comet.gpu.memory.limit") mem_->dev_limit = std::max<long long>(0, atoll(kv.second.c_str()));
+    if (kv.first == "spark.comet.gpu.join.fuseProbe") fuse_probe_ = kv.second != "false" && kv.second != "0";
   }
+  if (const char* e = getenv("COMET_JOIN_FUSE_PROBE")) fuse_probe_ = atoi(e) != 0;
   if (const char* e = getenv("COMET_GPU_CHUNK_ROWS")) chunk_rows_ = std::max<long long>(1024, atoll(e));
   // Scan leaves in depth-first, left-before-right order map to the input streams (planner.rs:1726, :2391)
   std::function<void(const Operator&)> walk = [&](const Operator& op) {
@@ -199,6 +201,42 @@ bool ExecutionContext::is_source(const Operator& op, const Operator* chain_top) 
     case OpKind::HashAgg: return &op != chain_top;
     default: return false;
   }
+}
+
+// Can this join read its probe chain's source directly?  The probe child must be a chain of Filters / Projections over a source
+// (Scan, Parquet scan, another join, …), no join key pair may be two Utf8 columns (those may need the string dictionary of hash_join,
+// which works on materialised columns), and the fused functor must generate — a computed Utf8 column in the chain's output does not.
+bool ExecutionContext::plan_fused_probe(const Operator& join, const std::vector<DType>& build_types, PipelineDesc& desc) {
+  fused_probe_.erase(&join);
+  if (!fuse_probe_ || join.children.size() != 2) return false;
+  const bool build_left = join.build_side == BuildSide::Left;
+  const Operator& child = *join.children[build_left ? 1 : 0];
+  if (child.kind != OpKind::Filter && child.kind != OpKind::Projection) return false;
+  const Operator* src = &child;
+  while (!is_source(*src, &child)) {
+    if ((src->kind != OpKind::Filter && src->kind != OpKind::Projection) || src->children.size() != 1) return false;
+    src = src->children[0].get();
+  }
+  for (size_t k = 0; k < join.left_keys.size() && k < join.right_keys.size(); k++) {
+    auto strk = [](const ExprP& e) { return e->kind == ExprKind::Bound && (!e->has_dtype || e->dtype.id == TypeId::String || e->dtype.id == TypeId::Bytes); };
+    if (strk(join.left_keys[k]) && strk(join.right_keys[k])) return false;
+  }
+  const std::string explain_before = explain_;
+  FusedProbe fp;
+  fp.source = src;
+  try {
+    fp.fu.src_types = infer_schema(*src);
+    fp.fu.src_valid.assign(fp.fu.src_types.size(), false);
+    fold_chain(child, *src, fp.fu.src_types, fp.fu.cols, fp.fu.preds);
+    std::vector<DType> none_t;
+    std::vector<bool> bv(build_types.size(), false), none_v;
+    desc = generate_join(join, build_left ? build_types : none_t, build_left ? none_t : build_types, build_left ? bv : none_v, build_left ? none_v : bv, &fp.fu);
+  } catch (const CometError&) {
+    explain_ = explain_before;    // the unfused path reports its own errors
+    return false;
+  }
+  fused_probe_[&join] = fp;
+  return true;
 }
 
 std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
@@ -500,11 +538,45 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
   }
   if (op.kind == OpKind::HashJoin) {
     if (op.children.size() != 2) throw CometError("HashJoin expects two children");
-    std::vector<DType> l = infer_schema(*op.children[0]), r = infer_schema(*op.children[1]);
-    std::vector<bool> lv(l.size(), false), rv(r.size(), false);
-    PipelineDesc d = generate_join(op, l, r, lv, rv);   // validates keys / join type
+    // the probe child: fused into the probe kernel when it is a Filter / Projection chain over a source (plan_fused_probe)
+    const size_t pi = op.build_side == BuildSide::Left ? 1 : 0;
+    std::vector<DType> l, r;
+    PipelineDesc d;
+    bool fused = false;
+    if (pi == 1) {
+      l = infer_schema(*op.children[0]);
+      fused = plan_fused_probe(op, l, d);
+      if (!fused) r = infer_schema(*op.children[1]);
+    } else {
+      // explain order stays left, right: decide on the left (probe) child once the right (build) schema is known
+      const std::string before = explain_;
+      explain_.clear();
+      r = infer_schema(*op.children[1]);
+      const std::string right_explain = explain_;
+      explain_ = before;
+      fused = plan_fused_probe(op, r, d);
+      if (!fused) l = infer_schema(*op.children[0]);
+      explain_ += right_explain;
+    }
+    if (!fused) {
+      std::vector<bool> lv(l.size(), false), rv(r.size(), false);
+      d = generate_join(op, l, r, lv, rv);   // validates keys / join type
+    }
     if (compile_in_infer_) jit_compile(d.source);
     explain_ += d.explain;
+    if (fused) {
+      // the logical schema of the fused child, for the sort-merge sort keys below: left ++ right as the join emits it
+      const size_t nbuild = pi == 1 ? l.size() : r.size();
+      std::vector<DType> probe_types;
+      const size_t nprobe = fused_probe_.at(&op).fu.cols.size();
+      if (d.out_cols.size() == nbuild + nprobe) {
+        for (size_t c = 0; c < nprobe; c++) probe_types.push_back(d.out_cols[(pi == 1 ? nbuild : 0) + c].type);
+      } else {
+        probe_types.assign(nprobe, DType());     // semi / anti joins emit the left side only; the width is all that is needed
+        if (pi == 0) for (size_t c = 0; c < nprobe && c < d.out_cols.size(); c++) probe_types[c] = d.out_cols[c].type;
+      }
+      (pi == 1 ? r : l) = probe_types;
+    }
     if (op.smj) {
       Operator& so = *smj_sorts_.at(&op);
       so.sort_orders.clear();
@@ -907,9 +979,21 @@ DevTable ExecutionContext::materialize(const Operator& op) {
     return t;
   }
   if (op.kind == OpKind::HashJoin) {
-    DevTable l = materialize(*op.children[0]);
-    DevTable r = materialize(*op.children[1]);
-    DevTable j = hash_join(op, l, r);
+    auto fit = fused_probe_.find(&op);
+    DevTable j;
+    if (fit != fused_probe_.end()) {
+      // the probe child's Filters / Projections run inside the probe kernel over the chain's source table
+      const bool build_left = op.build_side == BuildSide::Left;
+      DevTable b = materialize(*op.children[build_left ? 0 : 1]);
+      DevTable s = materialize(*fit->second.source);
+      JoinFusion fu = fit->second.fu;
+      fu.src_valid = s.has_valid;
+      j = build_left ? hash_join_impl(op, op, b, s, ":F", &fu) : hash_join_impl(op, op, s, b, ":F", &fu);
+    } else {
+      DevTable l = materialize(*op.children[0]);
+      DevTable r = materialize(*op.children[1]);
+      j = hash_join(op, l, r);
+    }
     if (!op.smj || !smj_needs_sort_.count(&op)) return j;
     // SortMergeJoin: its output is ordered by the join keys (SortMergeJoinExec streams the sorted inputs, planner.rs:2126-2191)
     return sort_table(*smj_sorts_.at(&op), j);

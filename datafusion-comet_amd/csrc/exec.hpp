@@ -178,7 +178,11 @@ class ExecutionContext {
   int64_t launch_fused_filter(Variant& v, CometKParams& prm, int64_t n);
   DevTable run_chain_to_device(const Operator& top, const DevTable& in);
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
-  DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix);
+  DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix,
+                          const JoinFusion* fused_probe = nullptr);
+  // Probe-side fusion (codegen.hpp JoinFusion): decided per join at createPlan (infer_schema)
+  struct FusedProbe { const Operator* source = nullptr; JoinFusion fu; };
+  bool plan_fused_probe(const Operator& join, const std::vector<DType>& build_types, PipelineDesc& desc);
   DevTable sort_table(const Operator& s, const DevTable& in);
   std::shared_ptr<DevBuf> sort_key_planes(const Operator& s, const DevTable& in, int& W, std::vector<int64_t>* str_len = nullptr, bool measure_only = false);
   DevTable literal_table(const std::vector<std::vector<ExprP>>& rows, const std::vector<DType>& types);
@@ -252,6 +256,8 @@ class ExecutionContext {
   std::vector<int> dict_id_col_;                   // per source column: appended row-index column standing in for a long Utf8 group key
   bool device_result_ = false;                     // the grouped result stays in HBM (nested aggregate / execute_device)
   DevTable dict_src_;                              // the aggregate's input while such keys are in flight
+  std::map<const Operator*, FusedProbe> fused_probe_;   // joins that read their probe chain's source table directly
+  bool fuse_probe_ = true;                         // spark.comet.gpu.join.fuseProbe
   std::set<const Operator*> smj_needs_sort_;       // sort-merge joins whose output order is observable (others skip the sort)
   std::map<const Operator*, OperatorP> smj_sorts_;  // SortMergeJoin node → synthetic Sort over its output       // aggregates that are not the plan root (materialised by sub-contexts)
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from

@@ -104,7 +104,9 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
   return out;
 }
 
-DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& j, const DevTable& L, const DevTable& R, const std::string& key_suffix) {
+DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& j, const DevTable& L, const DevTable& R, const std::string& key_suffix,
+                                          const JoinFusion* fused_probe) {
+  // with `fused_probe` the probe-side table (R when the build side is left) is the SOURCE of the probe chain
   // planned once per (join node, validity patterns)
   std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&node] + 1))) + ":J:" + validity_key(L.has_valid) + "|" +
                     validity_key(R.has_valid) + key_suffix;
@@ -116,7 +118,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   }
   if (!pv) {
     pv = std::make_shared<PlannedVariant>();
-    pv->desc = generate_join(j, L.types, R.types, L.has_valid, R.has_valid);
+    pv->desc = generate_join(j, L.types, R.types, L.has_valid, R.has_valid, fused_probe);
     pv->code = jit_compile(pv->desc.source);
     std::lock_guard<std::mutex> lk(g_plan_mu);
     g_plan_cache[key] = pv;
@@ -236,8 +238,10 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   if (tail_rows > 0) launch(v, "k_jbemit", (int)std::min<int64_t>(nbtiles, 256 * 8), prm);
   timed_end();
   out_rows = all_rows;
-  const int nleft = (int)L.cols.size();
-  DevTable out = outputs_to_table(v, vals, vbytes, out_rows, [&](int c) { return c < nleft ? std::make_pair(&L, c) : std::make_pair(&R, c - nleft); });
+  // gathered Utf8 payload columns name their source by its kernel-argument index: build columns, then probe columns
+  const int nbuild = (int)nb;
+  DevTable out = outputs_to_table(v, vals, vbytes, out_rows, [&](int c) { return c < nbuild ? std::make_pair(&B, c) : std::make_pair(&P, c - nbuild); });
+  if (fused_probe) check_device_errors();     // the chain's expressions may raise ANSI errors; an unfused chain checks after its own launch
   HIP_CHECK(hipStreamSynchronize(stream_));  // head/next/counts go back to the pool when this frame ends
   out.owners.push_back(v.mod);
   join_build_rows_ += B.rows;

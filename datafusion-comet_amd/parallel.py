@@ -307,6 +307,40 @@ def run_q3_distributed(engine, partitioner, customer, orders, lineitem, group=No
     return merged[:10], groups
 
 
+def run_q3_single(engine, customer, orders, lineitem, timings: Optional[dict] = None):
+    """TPC-H Q3 on ONE partition as ONE native plan (tpch.q3_plan: customer ⋈ orders ⋈ lineitem → Project → Partial aggregate) followed by
+    the Final aggregate + TakeOrdered plan.  Nothing is exchanged, so nothing has to be materialised for an exchange: both probe sides are
+    Filter / Projection chains over their scans and run INSIDE the probe kernels (JoinFusion) — the orders and lineitem tables are read
+    once, by the probes.  Returns (top-10 rows, number of result groups)."""
+    import time
+    from . import serde as S, tpch
+
+    def clock():
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        return time.perf_counter()
+
+    plan = tpch.q3_plan()
+    t0 = clock()
+    partial = engine.run_device(plan, [customer, orders, lineitem], tpch.Q3_NUM_OUTPUT_COLS)
+    t1 = clock()
+    groups = partial.num_rows
+    local = []
+    if groups:
+        f = S.final_of(plan, partial.schema)
+        top = S.sort(f, [(S.col(3, S.decimal(36, 4)), True, True), (S.col(1, S.T_DATE), False, False), (S.col(0, S.T_INT64), False, False)], fetch=10)
+        t = engine.run_host(top, [partial], 4)
+        local = list(zip(*[t.column(i).to_pylist() for i in range(t.num_columns)])) if t is not None else []
+    if timings is not None:
+        timings["joins_partial_agg"] = timings.get("joins_partial_agg", 0.0) + (t1 - t0)
+        timings["final_agg_top10"] = timings.get("final_agg_top10", 0.0) + (clock() - t1)
+    return local, groups
+
+
 def run_q95_distributed(engine, partitioner, tables, group=None, timings: Optional[dict] = None):
     """TPC-DS Q95 (BASELINE config 5) over the ranks of `group`.  `tables`: this rank's arbitrary shard of web_sales and web_returns plus
     full copies of date_dim / customer_address / web_site (the reference broadcasts those: BroadcastHashJoin in the approved plan).

@@ -134,7 +134,7 @@ Q1_BYTES_PER_ROW = 4 + 4 * 16 + 2 * (4 + 1)
 
 def warm_plans():
     """Plans whose fused kernels build() pre-compiles into the code-object cache."""
-    return [q6_plan(), q1_plan()] + [pl for pl, _, _ in q3_stage_plans().values()]
+    return [q6_plan(), q1_plan(), q3_plan()] + [pl for pl, _, _ in q3_stage_plans().values()]
 
 
 # ------------------------------------------------------------------ Q3 (SURVEY §3.5, §8d config 4)

@@ -156,3 +156,78 @@ def test_broadcast_nested_loop_join(built, jt, build):
     if jt == S.INNER and build == S.BUILD_RIGHT:
         cross = S.nested_loop_join(S.scan(lf), S.scan(rf), S.INNER, S.BUILD_RIGHT, None)
         assert run(cross, 5).num_rows == nl * nr
+
+
+# ---- probe-side fusion: the probe child's Filter / Projection chain runs inside the probe kernel (codegen.hpp JoinFusion) ----
+def _fusion_tables(seed):
+    rng = np.random.default_rng(seed)
+    nl, nr = 6000, 2500
+    left = pa.table({"k": pa.array(rng.integers(0, 80, nl), pa.int64(), mask=rng.random(nl) < 0.08),
+                     "v": pa.array(rng.integers(-1000, 1000, nl), pa.int32(), mask=rng.random(nl) < 0.05),
+                     "s": pa.array([None if rng.random() < 0.1 else "payload-string-number-%d" % int(x) for x in rng.integers(0, 400, nl)]),
+                     "d": tpch._dec128_array(rng.integers(-10**9, 10**9, nl), 12, 2)})
+    right = pa.table({"k": pa.array(rng.integers(0, 90, nr), pa.int64(), mask=rng.random(nr) < 0.08), "w": pa.array(rng.random(nr))})
+    return left, right
+
+
+LFIELDS = [S.T_INT64, S.T_INT32, S.T_STRING, S.decimal(12, 2)]
+RFIELDS = [S.T_INT64, S.T_DOUBLE]
+
+
+def _probe_chain():
+    """Filter → Project (reordered columns, a computed decimal, the key shifted by a computed expression) → Filter over the left scan"""
+    D = S.decimal(12, 2)
+    f1 = S.filter_(S.scan(LFIELDS), S.gt(S.col(1, S.T_INT32), S.lit(-600, S.T_INT32)))                       # NULL v fails too
+    p = S.project(f1, [S.col(2, S.T_STRING), S.math("add", S.col(0, S.T_INT64), S.lit(3, S.T_INT64), S.T_INT64), S.col(3, D),
+                       S.check_overflow(S.math("add", S.col(3, D), S.lit(__import__("decimal").Decimal("1.50"), D), S.decimal(13, 2)), S.decimal(13, 2))])
+    return S.filter_(p, S.lt(S.col(2, D), S.lit(__import__("decimal").Decimal("5000000.00"), D)))            # → (s, k + 3, d, d + 1.50)
+
+
+@pytest.mark.parametrize("jt", [S.INNER, S.LEFT_OUTER, S.RIGHT_OUTER, S.FULL_OUTER, S.LEFT_SEMI, S.LEFT_ANTI])
+def test_fused_probe_chain_matches_oracle_and_the_unfused_join(built, jt):
+    """The probe child (left, build = right) is a chain: rows its Filters drop are not part of the join at all (not NULL-extended by
+    the outer joins, not kept by the anti join), its computed columns are evaluated for emitted rows only, its Utf8 payload is gathered
+    from the SOURCE table.  Same multiset as the oracle and as the engine with spark.comet.gpu.join.fuseProbe=false."""
+    left, right = _fusion_tables(21)
+    j = S.hash_join(_probe_chain(), S.scan(RFIELDS), [S.col(1, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_RIGHT)
+    ncols = 4 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 6
+    explain = native.compile_plan(j.encode())
+    assert "probe side fused" in explain and "probe filter (fused into the probe kernel)" in explain
+    got = _run(j, [left, right], ncols, batch_size=0)
+    unfused = _run(j, [left, right], ncols, batch_size=0, config=S.config_map({"spark.comet.gpu.join.fuseProbe": "false"}))
+    want = _oracle(j, [left, right])
+    assert got.schema.types == want.schema.types == unfused.schema.types
+    assert _rows(got) == _rows(want) == _rows(unfused)
+    assert got.num_rows > 100
+
+
+def test_fused_probe_on_the_right_with_a_residual_condition(built):
+    left, right = _fusion_tables(22)
+    # build = left (plain scan), probe = right chain; the condition reads a computed probe column and a build column
+    rchain = S.project(S.filter_(S.scan(RFIELDS), S.lt(S.col(1, S.T_DOUBLE), S.lit(0.8, S.T_DOUBLE))),
+                       [S.math("multiply", S.col(1, S.T_DOUBLE), S.lit(100.0, S.T_DOUBLE), S.T_DOUBLE), S.col(0, S.T_INT64)])
+    cond = S.gt(S.cast(S.col(1, S.T_INT32), S.T_DOUBLE), S.col(4, S.T_DOUBLE))          # left.v > right.w * 100
+    for jt in (S.INNER, S.LEFT_OUTER, S.FULL_OUTER):
+        j = S.hash_join(S.scan(LFIELDS), rchain, [S.col(0, S.T_INT64)], [S.col(1, S.T_INT64)], jt, S.BUILD_LEFT, cond)
+        assert "probe side fused" in native.compile_plan(j.encode())
+        got, want = _run(j, [left, right], 6, batch_size=0), _oracle(j, [left, right])
+        assert _rows(got) == _rows(want) and got.num_rows > 0
+
+
+def test_fused_probe_whose_filter_keeps_nothing_and_device_resident_inputs(built):
+    left, right = _fusion_tables(23)
+    none = S.filter_(S.scan(LFIELDS), S.gt(S.col(1, S.T_INT32), S.lit(5000, S.T_INT32)))
+    j = S.hash_join(none, S.scan(RFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.LEFT_OUTER, S.BUILD_RIGHT)
+    assert _run(j, [left, right], 6, batch_size=0) is None
+    # RightOuter over an empty probe side: every build row, NULL-extended
+    j = S.hash_join(none, S.scan(RFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.RIGHT_OUTER, S.BUILD_RIGHT)
+    got = _run(j, [left, right], 6, batch_size=0)
+    assert got.num_rows == right.num_rows and got.column(0).null_count == right.num_rows
+    # HBM-resident inputs take the same fused kernel (the scan is zero-copy: the probe kernel reads the caller's buffers)
+    nn_left = pa.table({"k": pa.array(np.arange(5000, dtype=np.int64) % 97), "v": pa.array(np.arange(5000, dtype=np.int32) - 2500)})
+    nn_right = pa.table({"k": pa.array(np.arange(60, dtype=np.int64)), "w": pa.array(np.arange(60, dtype=np.float64))})
+    chain = S.project(S.filter_(S.scan([S.T_INT64, S.T_INT32]), S.gt(S.col(1, S.T_INT32), S.lit(0, S.T_INT32))), [S.col(0, S.T_INT64), S.col(1, S.T_INT32)])
+    j = S.hash_join(chain, S.scan(RFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.INNER, S.BUILD_RIGHT)
+    dl, dr = native.DeviceTable.from_arrow(nn_left, "cuda:0"), native.DeviceTable.from_arrow(nn_right, "cuda:0")
+    out = native.execute_to_table([native.DeviceInput(dl), native.DeviceInput(dr)], 4, j.encode(), batch_size=0)
+    assert _rows(pa.Table.from_batches(out)) == _rows(_oracle(j, [nn_left, nn_right]))

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--plan", default="auto", choices=["auto", "staged"],
+                    help="auto: one native plan on one rank (tpch.q3_plan, fused probe chains), the staged plans with exchanges on N; staged: always the stages")
     ap.add_argument("--exchange", default="native", choices=["native", "torch", "torch-fallback"],
                     help="native: the exchange runs inside libcomet.so (partition kernels + RCCL send/recv groups); torch: torch.distributed all_to_all")
     ap.add_argument("--out", default="")
@@ -55,6 +57,9 @@ def main():
         dist.all_reduce(tot)
     top = groups = None
     timings = {}
+    # one partition: nothing is exchanged, so the query is ONE native plan whose probe chains run inside the probe kernels; N partitions:
+    # the plan cut at its three exchanges (every stage output is materialised for its exchange)
+    single_plan = world == 1 and a.plan != "staged"
     for it in range(a.warmup + a.steps):
         if it == a.warmup:
             timings = {}
@@ -62,7 +67,10 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        top, groups = parallel.run_q3_distributed(eng, part, customer, orders, lineitem, timings=timings)
+        if single_plan:
+            top, groups = parallel.run_q3_single(eng, customer, orders, lineitem, timings=timings)
+        else:
+            top, groups = parallel.run_q3_distributed(eng, part, customer, orders, lineitem, timings=timings)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -82,7 +90,7 @@ def main():
                 "sec_per_run": sec, "rows_per_s": int(tot[0].item()) / sec, "input_GBps": int(tot[1].item()) / sec / 1e9,
                 "stage_ms_rank0": {k: round(v / a.steps * 1e3, 3) for k, v in timings.items() if not k.startswith("exchange_")},
                 "exchange_rows_rank0": timings.get("exchange_rows", 0) // a.steps, "exchange_bytes_rank0": timings.get("exchange_bytes", 0) // a.steps,
-                "exchange": exchange_kind, "exchange_transport": transport, "groups_rank0": groups, "top1": [str(x) for x in top[0]] if top else None, "verified_vs_torch": ok, "scaling": "strong"}
+                "plan": "one native plan (fused probe chains)" if single_plan else "5 stage plans cut at the exchanges", "exchange": exchange_kind, "exchange_transport": transport, "groups_rank0": groups, "top1": [str(x) for x in top[0]] if top else None, "verified_vs_torch": ok, "scaling": "strong"}
         s = json.dumps(line)
         print(s, flush=True)
         if a.out:
