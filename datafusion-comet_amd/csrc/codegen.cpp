@@ -2810,6 +2810,10 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   src << "struct P {\n  static constexpr int R = 1;\n  static constexpr int MODE = " << mode << ";\n";
   src << "  static constexpr bool OUTER_PROBE = " << (outer_probe ? "true" : "false") << ", OUTER_BUILD = " << (outer_build ? "true" : "false")
       << ", BUILD_KEEP_MATCHED = " << (keep_matched ? "true" : "false") << ", BUILD_ONLY = " << (build_only ? "true" : "false") << ";\n";
+  // semi / anti joins that keep PROBE rows and have no residual condition only ask whether a key exists on the build side: one build row
+  // per run of equal keys is enough (comet_device.hpp "Runs of equal keys")
+  const bool dedup_build = mode != 0 && !j.join_condition;
+  src << "  static constexpr bool DEDUP_BUILD = " << (dedup_build ? "true" : "false") << ";\n";
 
   // key words of one side
   auto key_fn = [&](const char* name, const char* rowvar, const std::vector<DType>& types, const std::vector<bool>& valid, int base,
@@ -2840,6 +2844,18 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
         src << "    kw[" << w << "] = " << e << ";\n";
       }
       src << "    return comet::hash_key<" << words.size() << ">(kw);\n  }\n";
+      if (std::string(name) == "bhash") {
+        // the same key words handed out (run detection compares neighbouring build rows word by word: exact, unlike their hashes)
+        src << "  static constexpr int NKW = " << words.size() << ";\n";
+        src << "  static __device__ __forceinline__ void bkeys(const CometKParams& prm, i64 " << rowvar << ", u64* kw) {\n"
+            << "    bool k[R] = {true};\n" << g.decls << g.body();
+        for (size_t w = 0; w < words.size(); w++) {
+          std::string e = words[w];
+          for (size_t p0 = e.find("[r]"); p0 != std::string::npos; p0 = e.find("[r]")) e.replace(p0, 3, "[0]");
+          src << "    kw[" << w << "] = " << e << ";\n";
+        }
+        src << "  }\n";
+      }
     } else {
       std::string e = okall.empty() ? "true" : okall;
       for (size_t p0 = e.find("[r]"); p0 != std::string::npos; p0 = e.find("[r]")) e.replace(p0, 3, "[0]");
@@ -2991,6 +3007,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   }
   src << "};\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbuild(const CometKParams prm) { comet::join_build_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbcnt(const CometKParams prm) { comet::join_build_count_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbcount(const CometKParams prm) { comet::join_build_unmatched_count_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbscan(const CometKParams prm) { comet::tile_scan_body((u64*)prm.out[comet::kJoinBuildTiles], prm.iarg[3]); }\n";
@@ -2998,7 +3015,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   // single-pass probes (comet_device.hpp template D'): the chained global table, or an LDS table for small build sides
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe(const CometKParams prm) { comet::join_probe_fused_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jlds(const CometKParams prm) { comet::join_probe_lds_body<P>(prm); }\n";
-  d.kernels = {"k_jbuild", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jlds"};
+  d.kernels = {"k_jbuild", "k_jbcnt", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jlds"};
   d.join_outer_build = outer_build;
   d.join_build_only = build_only;
   const char* jt_name = build_only ? (keep_matched ? "LeftSemi" : "LeftAnti") : keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";

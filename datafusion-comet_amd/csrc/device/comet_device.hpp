@@ -1743,9 +1743,44 @@ constexpr int kJoinBuildTiles = 46;
 
 constexpr u32 kJoinNoRow = 0xffffffffu;
 constexpr u32 kJoinChainBit = 1u << 31;
+constexpr i32 kJoinFollower = -2;     // next[] of a build row that continues the run of equal keys its predecessor started
 // the bucket index uses the hash's low bits, the tag its high bits; B index bits leave 31 − B tag bits (B ≤ 31; a row index is never all
 // ones in B bits, so no entry equals the empty marker)
 CDEV u32 join_head_entry(u64 h, u32 row, int ib) { return ((u32)(h >> 33) << ib) & 0x7fffffffu | row; }
+
+// Runs of equal keys.  Fact tables arrive clustered by their join key (the lines of an order, the items of a ticket): the rows of one key
+// are NEIGHBOURS, and a wave holds 64 consecutive rows.  A row whose key equals its left neighbour's (inside the wave) is a FOLLOWER: it
+// does not touch the table at all — next[row] = kJoinFollower marks it — and only the run's first row, its LEADER, is inserted (one
+// atomicExch per run instead of one per row, and no two lanes of a wave ever hit the same bucket with the same key).  The probe, having
+// reached a leader, walks the followers that sit right behind it (contiguous rows: the same cache lines).  Keys whose rows are scattered
+// simply form runs of length one.  P::DEDUP_BUILD (semi / anti joins without a residual condition: only the key's existence matters):
+// followers are dropped altogether.
+//   P::NKW, P::bkeys(prm, i, kw)   the key words of build row i (what bhash hashes)
+template <class P>
+CDEV bool join_build_classify(const CometKParams& prm, i64 i, i64 nb, u64& h, bool& has_follower) {   // → leader?; writes next[] of non-leaders
+  i32* next = (i32*)prm.out[1];
+  const int lane = lane_id();
+  const bool valid = i < nb && P::bvalid(prm, i);
+  u64 kw[P::NKW];
+#pragma unroll
+  for (int w = 0; w < P::NKW; w++) kw[w] = 0;
+  if (valid) P::bkeys(prm, i, kw);
+  bool same = valid && lane > 0;
+#pragma unroll
+  for (int w = 0; w < P::NKW; w++) {
+    const u32 lo = __shfl_up((u32)kw[w], 1, kWave), hi = __shfl_up((u32)(kw[w] >> 32), 1, kWave);
+    same = same && (((u64)hi << 32) | lo) == kw[w];
+  }
+  same = same && __shfl_up(valid ? 1 : 0, 1, kWave) != 0;
+  const u64 followers = __ballot(same);
+  has_follower = lane < kWave - 1 && ((followers >> (lane + 1)) & 1ull) != 0 && !P::DEDUP_BUILD;
+  h = hash_key<P::NKW>(kw);
+  if (i < nb && !P::DEDUP_BUILD) {
+    if (same) next[i] = kJoinFollower;
+    else if (!valid) next[i] = -1;          // a NULL key: never in the table, and it ends the run before it
+  }
+  return valid && !same;
+}
 
 template <class P>
 CDEV void join_build_body(const CometKParams& prm) {
@@ -1754,15 +1789,45 @@ CDEV void join_build_body(const CometKParams& prm) {
   const u64 mask = (u64)prm.iarg[0] - 1;
   const i64 nb = prm.iarg[1];
   const int ib = (int)prm.iarg[2];
-  for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < nb; i += (i64)gridDim.x * kBlock) {
-    if (!P::bvalid(prm, i)) continue;
-    const u64 h = P::bhash(prm, i);
-    const u32 old = atomicExch(&head[h & mask], join_head_entry(h, (u32)i, ib));
+  // wave-uniform loop: lane l of a wave holds row wbase + l
+  for (i64 wbase = (i64)blockIdx.x * kBlock + (i64)wave_id() * kWave; wbase < nb; wbase += (i64)gridDim.x * kBlock) {
+    const i64 i = wbase + lane_id();
+    u64 h;
+    bool has_follower;
+    if (!join_build_classify<P>(prm, i, nb, h, has_follower)) continue;
+    // the chain bit says "this bucket holds more than one ROW": another leader, or followers behind this one
+    const u32 old = atomicExch(&head[h & mask], join_head_entry(h, (u32)i, ib) | (has_follower ? kJoinChainBit : 0u));
     next[i] = old == kJoinNoRow ? -1 : (i32)(old & ((1u << ib) - 1u));
     // a bucket that already held a row: whatever its head is from now on, its chain is longer than one (monotone, so the OR may land
     // on a newer head)
     if (old != kJoinNoRow) atomicOr(&head[h & mask], kJoinChainBit);
   }
+}
+
+// how many leaders the build will insert: sizes the bucket array by KEYS-ish instead of rows (a clustered fact table has several rows
+// per key; its bucket array then fits the caches four times better).  out[0] = { u64 leaders }
+template <class P>
+CDEV void join_build_count_body(const CometKParams& prm) {
+  const i64 nb = prm.iarg[1];
+  unsigned long long* total = (unsigned long long*)prm.out[0];
+  u32 mine = 0;
+  for (i64 wbase = (i64)blockIdx.x * kBlock + (i64)wave_id() * kWave; wbase < nb; wbase += (i64)gridDim.x * kBlock) {
+    const i64 i = wbase + lane_id();
+    const bool valid = i < nb && P::bvalid(prm, i);
+    u64 kw[P::NKW];
+#pragma unroll
+    for (int w = 0; w < P::NKW; w++) kw[w] = 0;
+    if (valid) P::bkeys(prm, i, kw);
+    bool same = valid && lane_id() > 0;
+#pragma unroll
+    for (int w = 0; w < P::NKW; w++) {
+      const u32 lo = __shfl_up((u32)kw[w], 1, kWave), hi = __shfl_up((u32)(kw[w] >> 32), 1, kWave);
+      same = same && (((u64)hi << 32) | lo) == kw[w];
+    }
+    same = same && __shfl_up(valid ? 1 : 0, 1, kWave) != 0;
+    mine += (u32)__popcll(__ballot(valid && !same));
+  }
+  if (lane_id() == 0 && mine) atomicAdd(total, (unsigned long long)mine);
 }
 
 // build rows nobody matched (outer joins that preserve the build side; LeftAnti built on the left) — or, with
@@ -1848,17 +1913,25 @@ struct JoinGlobalTable {
   const i32* next;
   u64 mask;
   int ib;
+  i64 nb;
+  // the one access every probe row needs; the tile loads it for all its rows before it looks at any of them
+  CDEV u32 peek(u64 h) const { return head[h & mask]; }
   template <class F>
-  CDEV void for_each(const CometKParams& prm, i64 j, u64 h, F f) const {   // f(build row) returns false to stop
-    const u32 e = head[h & mask];
+  CDEV void for_each(const CometKParams& prm, i64 j, u64 h, u32 e, F f) const {   // f(build row) returns false to stop
     if (e == kJoinNoRow) return;
     const u32 rowmask = (1u << ib) - 1u, first = e & rowmask;
     if (!(e & kJoinChainBit)) {                       // one row in the bucket: its tag decides whether the keys are worth reading
       if (((e ^ join_head_entry(h, 0, ib)) & ~rowmask) == 0 && P::match(prm, (i64)first, j)) f(first);
       return;
     }
-    for (i32 i = (i32)first; i >= 0; i = next[i])
-      if (P::match(prm, (i64)i, j) && !f((u32)i)) break;
+    for (i32 i = (i32)first; i >= 0;) {
+      const i32 nx = next[i];
+      if (P::match(prm, (i64)i, j) && !f((u32)i)) return;
+      if (!P::DEDUP_BUILD)                            // the leader's followers: the rows right behind it (same key, maybe another condition)
+        for (i64 k = (i64)i + 1; k < nb && next[k] == kJoinFollower; k++)
+          if (P::match(prm, k, j) && !f((u32)k)) return;
+      i = nx;
+    }
   }
 };
 // candidates in the block's LDS table
@@ -1866,8 +1939,10 @@ template <class P>
 struct JoinLdsTable {
   const COMET_LDS u32* rows;             // address_space(3): ds_read, not FLAT (a FLAT access waits for every outstanding global load)
   const COMET_LDS unsigned short* tags;
+  CDEV u32 peek(u64 h) const { return rows[((u32)(h >> 32)) & (kJoinLdsCap - 1)]; }
   template <class F>
-  CDEV void for_each(const CometKParams& prm, i64 j, u64 h, F f) const {
+  CDEV void for_each(const CometKParams& prm, i64 j, u64 h, u32 e, F f) const {
+    if (e == kJoinEmpty) return;
     const u32 hi = (u32)(h >> 16);
     u32 slot = (hi >> 16) & (kJoinLdsCap - 1);
     for (u32 row; (row = rows[slot]) != kJoinEmpty; slot = (slot + 1) & (kJoinLdsCap - 1))
@@ -1875,53 +1950,108 @@ struct JoinLdsTable {
   }
 };
 
+// One tile = kJoinR × 256 probe rows; every WAVE owns the 8 × 64 of them that its lanes load (coalesced), and works on its own:
+//   0. filter: P::pkeep (the Filters of a fused probe chain) and P::pvalid per row; the rows that take part are COMPACTED into the wave's
+//      list in LDS (ballot + popcount, no barrier: the list is the wave's own) — after a 50 % filter the probe phase runs with full
+//      waves instead of half-empty ones;
+//   1. probe, 64 list entries at a time, in three sweeps over the wave's (up to 8) slices: all key loads and hashes, then ALL bucket-head
+//      loads — up to eight random accesses in flight per lane, where one-row-at-a-time probing has one and spends 90 % of its cycles
+//      waiting (SQ_WAIT_ANY, profiles/r3_q95_join_pmc.txt) —, then the rows are settled one by one (most need nothing more: an empty
+//      bucket, or a single row with another tag);
+//   2. output positions in (wave, slice, lane) order — a wave's consecutive list entries are consecutive input rows, so a clustered
+//      probe side gives a (locally) clustered join output, which the next join's build exploits (runs); one atomic per tile reserves
+//      the range.
 template <class P, class T>
 CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
   const i64 n = prm.n;
   const i64 cap_out = prm.iarg[6];
   unsigned long long* emitted = (unsigned long long*)prm.out[47];
   u8* matched = (u8*)prm.out[kJoinMatched];
+  __shared__ unsigned short s_list[kBlock / kWave][kJoinR * kWave];
   __shared__ u32 s_wave[kBlock / kWave];
   __shared__ unsigned long long s_base;
   const int lane = lane_id(), wv = wave_id();
+  const u64 lt = (1ull << lane) - 1ull;
+  COMET_LDS unsigned short* list = (COMET_LDS unsigned short*)s_list[wv];
   constexpr i64 kTile = (i64)kJoinR * kBlock;
   for (i64 base = (i64)blockIdx.x * kTile; base < n; base += (i64)gridDim.x * kTile) {
-    u32 cnt[kJoinR], first[kJoinR], e[kJoinR];
-    u64 hs[kJoinR];
-    u32 mine = 0;
+    // ---- 0. filter + wave-local compaction ----
+    u32 m = 0;
 #pragma unroll
     for (int r = 0; r < kJoinR; r++) {
       const i64 j = base + (i64)r * kBlock + threadIdx.x;
-      cnt[r] = 0;
-      first[r] = kJoinEmpty;
-      hs[r] = 0;
-      const bool active = j < n && P::pkeep(prm, j);     // pkeep: the Filters of a probe chain fused into this kernel (else constant true)
-      if (active && P::pvalid(prm, j)) {
-        hs[r] = P::phash(prm, j);
-        u32 c = 0, f0 = kJoinEmpty;
-        table.for_each(prm, j, hs[r], [&](u32 row) {
-          if (c == 0) f0 = row;
-          c++;
-          if (P::OUTER_BUILD) matched[row] = 1;    // racing stores of the same value
-          return P::MODE == 0;                     // semi / anti only need existence
-        });
-        cnt[r] = c;
-        first[r] = f0;
-      }
-      if (!active || P::BUILD_ONLY) e[r] = 0;
-      else if (P::MODE == 1) e[r] = cnt[r] ? 1u : 0u;
-      else if (P::MODE == 2) e[r] = cnt[r] ? 0u : 1u;
-      else e[r] = (cnt[r] == 0 && P::OUTER_PROBE) ? 1u : cnt[r];
-      mine += e[r];
+      const bool keep = j < n && P::pkeep(prm, j);
+      const bool can_match = keep && P::pvalid(prm, j);
+      const u64 b = __ballot(keep);
+      if (keep) list[m + (u32)__popcll(b & lt)] = (unsigned short)((u32)(r * kBlock + (int)threadIdx.x) | (can_match ? 0u : 0x8000u));
+      m += (u32)__popcll(b);
     }
-    // exclusive prefix of `mine` across the block, the tile's total → one global reservation
-    u32 x = mine;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nslice = (int)((m + kWave - 1) / kWave);      // wave-uniform
+    // ---- 1. probe: key loads + hashes of every slice, then every bucket head, then row by row ----
+    u64 hs[kJoinR];
+    u32 he[kJoinR];
+    u32 keyed = 0;                                   // bit q: my entry of slice q exists and has a non-NULL key (it can match)
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const u32 y = __shfl_up(x, d, kWave);
-      if (lane >= d) x += y;
+    for (int q = 0; q < kJoinR; q++) {
+      hs[q] = 0;
+      if (q < nslice) {
+        const u32 k = (u32)q * kWave + (u32)lane;
+        if (k < m) {
+          const u32 ent = list[k];
+          if (!(ent & 0x8000u)) {
+            hs[q] = P::phash(prm, base + (i64)(ent & 0x7fffu));
+            keyed |= 1u << q;
+          }
+        }
+      }
     }
-    if (lane == kWave - 1) s_wave[wv] = x;
+#pragma unroll
+    for (int q = 0; q < kJoinR; q++) he[q] = (q < nslice && ((keyed >> q) & 1u)) ? table.peek(hs[q]) : kJoinNoRow;
+    // settle the rows; positions as we go: slice after slice inside the wave (exclusive scan of the emit counts + the wave's running total)
+    u32 first[kJoinR], excl[kJoinR];
+    u32 cls = 0;                                     // 2 bits per slice: 0 nothing to emit, 1 probe row alone, 2 one build row (first[q]), 3 several
+    u32 run = 0;
+#pragma unroll
+    for (int q = 0; q < kJoinR; q++) {
+      first[q] = kJoinEmpty;
+      excl[q] = 0;
+      if (q < nslice) {                              // wave-uniform
+        const u32 k = (u32)q * kWave + (u32)lane;
+        u32 eq = 0;
+        if (k < m) {
+          u32 c = 0, f0 = kJoinEmpty;
+          if ((keyed >> q) & 1u) {
+            const i64 j = base + (i64)(list[k] & 0x7fffu);
+            table.for_each(prm, j, hs[q], he[q], [&](u32 row) {
+              if (c == 0) f0 = row;
+              c++;
+              if (P::OUTER_BUILD) matched[row] = 1;    // racing stores of the same value
+              return P::MODE == 0;                     // semi / anti only need existence
+            });
+          }
+          first[q] = f0;
+          if (P::BUILD_ONLY) eq = 0;
+          else if (P::MODE == 1) eq = c ? 1u : 0u;
+          else if (P::MODE == 2) eq = c ? 0u : 1u;
+          else eq = (c == 0 && P::OUTER_PROBE) ? 1u : c;
+          const u32 kind = eq == 0 ? 0u : (P::MODE != 0 || c == 0) ? 1u : c == 1 ? 2u : 3u;
+          cls |= kind << (2 * q);
+        }
+        u32 x = eq;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+          const u32 y = __shfl_up(x, d, kWave);
+          if (lane >= d) x += y;
+        }
+        excl[q] = run + x - eq;
+        run += __shfl(x, kWave - 1, kWave);
+      }
+    }
+    // ---- 2. wave after wave inside the tile, ONE global reservation ----
+    if (lane == 0) s_wave[wv] = run;
     __syncthreads();
     u32 woff = 0, total = 0;
 #pragma unroll
@@ -1931,23 +2061,24 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
     }
     if (threadIdx.x == 0 && total) s_base = atomicAdd(emitted, (unsigned long long)total);
     __syncthreads();
-    if (total) {
-      i64 pos = (i64)s_base + woff + (x - mine);
+    // ---- 3. emit ----
+    if (total && cls) {
 #pragma unroll
-      for (int r = 0; r < kJoinR; r++) {
-        if (!e[r]) continue;
-        const i64 j = base + (i64)r * kBlock + threadIdx.x;
-        if (P::MODE != 0) {
-          if (pos < cap_out) P::emit(prm, -1, j, pos);
-          pos++;
-        } else if (cnt[r] == 0) {
-          if (pos < cap_out) P::emit_probe_only(prm, j, pos);
-          pos++;
-        } else if (cnt[r] == 1) {
-          if (pos < cap_out) P::emit(prm, (i64)first[r], j, pos);
-          pos++;
+      for (int q = 0; q < kJoinR; q++) {
+        const u32 kind = (cls >> (2 * q)) & 3u;
+        if (q >= nslice || !kind) continue;
+        const i64 j = base + (i64)(list[(u32)q * kWave + (u32)lane] & 0x7fffu);
+        i64 pos = (i64)s_base + woff + excl[q];
+        if (kind == 1) {
+          if (pos < cap_out) {
+            if (P::MODE != 0) P::emit(prm, -1, j, pos);
+            else P::emit_probe_only(prm, j, pos);
+          }
+        } else if (kind == 2) {
+          if (pos < cap_out) P::emit(prm, (i64)first[q], j, pos);
         } else {
-          table.for_each(prm, j, hs[r], [&](u32 row) {
+          const u64 h = P::phash(prm, j);            // several matches (rare outside many-to-many joins): walk the candidates again
+          table.for_each(prm, j, h, table.peek(h), [&](u32 row) {
             if (pos < cap_out) P::emit(prm, (i64)row, j, pos);
             pos++;
             return true;
@@ -1955,13 +2086,13 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
         }
       }
     }
-    __syncthreads();   // s_wave / s_base are reused by the next tile
+    __syncthreads();   // s_wave / s_base / the lists are reused by the next tile
   }
 }
 
 template <class P>
 CDEV void join_probe_fused_body(const CometKParams& prm) {
-  JoinGlobalTable<P> t{(const u32*)prm.out[0], (const i32*)prm.out[1], (u64)prm.iarg[0] - 1, (int)prm.iarg[2]};
+  JoinGlobalTable<P> t{(const u32*)prm.out[0], (const i32*)prm.out[1], (u64)prm.iarg[0] - 1, (int)prm.iarg[2], prm.iarg[1]};
   join_probe_tiles<P>(prm, t);
 }
 

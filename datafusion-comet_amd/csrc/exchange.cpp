@@ -27,6 +27,8 @@
 #include <vector>
 
 #include "../../include/comet_amd.h"
+#include "exchange_core.hpp"
+#include "exchange_tcp.hpp"
 #include "exec.hpp"
 #include "plan.hpp"
 
@@ -124,21 +126,183 @@ struct LocalGroup {
 std::mutex g_groups_mu;
 std::map<int64_t, std::shared_ptr<LocalGroup>> g_groups;
 
+// ---- transports (exchange_core.hpp Transport) ----
+// RCCL: one process per GPU; everything is enqueued on the communicator's stream, the counts cross through device memory
+class RcclTransport : public xchg::Transport {
+ public:
+  RcclTransport(ncclComm_t comm, int world, int rank, hipStream_t st) : comm_(comm), world_(world), rank_(rank), st_(st) {}
+  int world() const override { return world_; }
+  int rank() const override { return rank_; }
+  bool host_memory() const override { return false; }
+  void allgather_i64(const int64_t* mine, int n, int64_t* all) override {
+    Rccl& r = Rccl::get();
+    DevBuf dsend, dall;
+    PinnedBuf hsend, hall;
+    dsend.ensure((size_t)n * 8 + 16);
+    dall.ensure((size_t)n * world_ * 8 + 16);
+    hsend.ensure((size_t)n * 8 + 16);
+    hall.ensure((size_t)n * world_ * 8 + 16);
+    memcpy(hsend.p, mine, (size_t)n * 8);
+    XHIP(hipMemcpyAsync(dsend.p, hsend.p, (size_t)n * 8, hipMemcpyHostToDevice, st_));
+    r.check(r.AllGather(dsend.p, dall.p, (size_t)n, kNcclInt64, comm_, st_), "ncclAllGather");
+    XHIP(hipMemcpyAsync(hall.p, dall.p, (size_t)n * world_ * 8, hipMemcpyDeviceToHost, st_));
+    XHIP(hipStreamSynchronize(st_));
+    memcpy(all, hall.p, (size_t)n * world_ * 8);
+  }
+  void alltoallv(const void* send_buf, void* recv_buf, int w, const xchg::Split& sp) override {
+    // ONE group of send / recv pairs per buffer: xGMI is point to point, the all-to-all maps one to one onto the links
+    Rccl& r = Rccl::get();
+    r.check(r.GroupStart(), "ncclGroupStart");
+    for (int p = 0; p < world_; p++) {
+      if (sp.send[(size_t)p]) r.check(r.Send((const char*)send_buf + (size_t)sp.starts[(size_t)p] * (size_t)w, (size_t)sp.send[(size_t)p] * (size_t)w, kNcclUint8, p, comm_, st_), "ncclSend");
+      if (sp.recv[(size_t)p]) r.check(r.Recv((char*)recv_buf + (size_t)sp.roff[(size_t)p] * (size_t)w, (size_t)sp.recv[(size_t)p] * (size_t)w, kNcclUint8, p, comm_, st_), "ncclRecv");
+    }
+    r.check(r.GroupEnd(), "ncclGroupEnd");
+  }
+
+ private:
+  ncclComm_t comm_;
+  int world_, rank_;
+  hipStream_t st_;
+};
+
+// N task threads of one process: publish through the group's slots, pull the slices with peer copies
+class LocalTransport : public xchg::Transport {
+ public:
+  LocalTransport(std::shared_ptr<LocalGroup> g, int rank, hipStream_t st, hipEvent_t ready) : g_(std::move(g)), rank_(rank), st_(st), ready_(ready) {}
+  int world() const override { return g_->world; }
+  int rank() const override { return rank_; }
+  bool host_memory() const override { return false; }
+  void allgather_i64(const int64_t* mine, int n, int64_t* all) override {
+    LocalGroup& g = *g_;
+    { std::lock_guard<std::mutex> lk(g.mu); g.starts[(size_t)rank_].assign(mine, mine + n); }
+    g.barrier();
+    { std::lock_guard<std::mutex> lk(g.mu);
+      for (int s = 0; s < g.world; s++) {
+        if ((int)g.starts[(size_t)s].size() != n) throw CometError("exchange: local ranks disagree about the collective they are in");
+        memcpy(all + (size_t)s * (size_t)n, g.starts[(size_t)s].data(), (size_t)n * 8);
+      } }
+    g.barrier();      // everyone has read: the slot may be published again
+  }
+  void alltoallv(const void* send_buf, void* recv_buf, int w, const xchg::Split& sp) override {
+    LocalGroup& g = *g_;
+    XHIP(hipEventRecord(ready_, st_));
+    { std::lock_guard<std::mutex> lk(g.mu); g.send_ptr[(size_t)rank_] = send_buf; }
+    g.barrier();                                              // every send buffer is published (and its event recorded)
+    for (int s = 0; s < g.world; s++) {
+      const void* src;
+      hipEvent_t ev;
+      { std::lock_guard<std::mutex> lk(g.mu); src = g.send_ptr[(size_t)s]; ev = g.ready[(size_t)s]; }
+      if (!sp.recv[(size_t)s]) continue;
+      XHIP(hipStreamWaitEvent(st_, ev, 0));
+      XHIP(hipMemcpyAsync((char*)recv_buf + (size_t)sp.roff[(size_t)s] * (size_t)w, (const char*)src + (size_t)sp.peer_off[(size_t)s] * (size_t)w,
+                          (size_t)sp.recv[(size_t)s] * (size_t)w, hipMemcpyDeviceToDevice, st_));
+    }
+    XHIP(hipStreamSynchronize(st_));                          // my pulls are done …
+    g.barrier();                                              // … and so are everybody's: the send buffers may be reused
+  }
+
+ private:
+  std::shared_ptr<LocalGroup> g_;
+  int rank_;
+  hipStream_t st_;
+  hipEvent_t ready_;
+};
+
+// one rank, no wire
+class SelfTransport : public xchg::Transport {
+ public:
+  int world() const override { return 1; }
+  int rank() const override { return 0; }
+  bool host_memory() const override { return false; }
+  bool self_only() const override { return true; }
+  void allgather_i64(const int64_t* mine, int n, int64_t* all) override { memcpy(all, mine, (size_t)n * 8); }
+  void alltoallv(const void*, void*, int, const xchg::Split&) override { throw CometError("exchange: internal: self transport asked to move bytes"); }
+};
+
 struct Comm {
   int world = 1, rank = 0, device = 0;
   ncclComm_t nccl = nullptr;
   std::shared_ptr<LocalGroup> local;
+  std::unique_ptr<xchg::TcpTransport> tcp;
   hipStream_t stream = nullptr;
   hipEvent_t ready = nullptr;
+  const char* transport_name() const { return nccl ? "rccl" : tcp ? "tcp" : local ? "in-process" : "none (1 rank)"; }
 };
 std::mutex g_comm_mu;
 std::map<int64_t, std::shared_ptr<Comm>> g_comms;
 int64_t g_next_comm = 1;
 
+// ---- the memory space of the product: HBM buffers and the partition / take / scan / pack kernels ----
+struct HipOps {
+  using Buf = DevBuf;
+  using HostBuf = PinnedBuf;
+  static constexpr bool kDeviceMemory = true;
+  hipStream_t st;
+  DevBuf scratch, tiles, dstarts;
+  PinnedBuf hs;
+  void fill_u32(uint32_t* dst, int64_t n, uint32_t v) {
+    if (comet_launch_fill(4, dst, n, &v, st) != 0) throw CometError("exchange: launch failed");
+  }
+  void murmur3(const CometExchangeColumn& kc, int64_t rows, uint32_t* hashes) {
+    if (comet_murmur3_column(kc.type_id, kc.precision, kc.values, kc.validity, kc.aux, rows, hashes, st) != 0)
+      throw CometError(std::string("exchange: murmur3: ") + comet_last_error(0));
+  }
+  void pmod(const uint32_t* hashes, int64_t rows, int world, int32_t* pids) {
+    if (comet_pmod_partition(hashes, rows, world, pids, st) != 0) throw CometError("exchange: pmod failed");
+  }
+  void partition_indices(const int32_t* pids, int64_t rows, int world, int64_t* host_starts, uint32_t* idx) {
+    scratch.ensure((size_t)comet_partition_scratch_bytes(rows, world));
+    dstarts.ensure((size_t)(world + 1) * 8 + 16);
+    const size_t hist_bytes = ((size_t)world * (size_t)comet_partition_tiles(rows) + 1) * 8;
+    uint32_t* bad = (uint32_t*)((char*)scratch.p + hist_bytes);
+    XHIP(hipMemsetAsync(bad, 0, 4, st));
+    if (comet_launch_partition_indices(pids, rows, world, (uint64_t*)scratch.p, bad, (int64_t*)dstarts.p, idx, st) != 0)
+      throw CometError("exchange: partition launch failed");
+    hs.ensure((size_t)(world + 1) * 8 + 16);
+    XHIP(hipMemcpyAsync(hs.p, dstarts.p, (size_t)(world + 1) * 8, hipMemcpyDeviceToHost, st));
+    XHIP(hipStreamSynchronize(st));
+    memcpy(host_starts, hs.p, (size_t)(world + 1) * 8);
+  }
+  void take(int w, const void* src, const uint32_t* idx, int64_t n, void* dst) {
+    if (comet_launch_take(w, src, idx, n, dst, st) != 0) throw CometError("exchange: take failed");
+  }
+  void take_valid_bytes(const uint8_t* bits, const uint32_t* idx, int64_t n, uint8_t* out) {
+    if (comet_launch_take_valid_bytes(bits, idx, n, out, st) != 0) throw CometError("exchange: take failed");
+  }
+  void take_utf8_lengths(const int32_t* offs, const uint32_t* idx, const uint8_t* valid_bits, int64_t n, uint32_t* lengths) {
+    if (comet_launch_take_utf8_lengths(offs, idx, nullptr, valid_bits, n, lengths, st) != 0) throw CometError("exchange: take failed");
+  }
+  void take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* valid_bits, int64_t n, const int32_t* out_offs, uint8_t* out) {
+    if (comet_launch_take_utf8_copy(offs, bytes, idx, nullptr, valid_bits, n, out_offs, out, st) != 0) throw CometError("exchange: take failed");
+  }
+  void scan_u32(const uint32_t* lengths, int64_t n, int32_t* offsets) {
+    tiles.ensure((size_t)((n + 1023) / 1024 + 2) * 8);
+    pq_launch_u32_scan(lengths, n, (uint64_t*)tiles.p, offsets, st);
+  }
+  void pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n) { pq_launch_pack(bytes, bitmap, n, st); }
+  void set_bytes(void* p, int v, size_t n) { XHIP(hipMemsetAsync(p, v, n, st)); }
+  void read_i32_at(const int32_t* base, const int64_t* positions, int count, int32_t* out_host) {
+    hs.ensure((size_t)count * 4 + 16);
+    for (int k = 0; k < count; k++) XHIP(hipMemcpyAsync((char*)hs.p + (size_t)k * 4, base + positions[k], 4, hipMemcpyDeviceToHost, st));
+    XHIP(hipStreamSynchronize(st));
+    memcpy(out_host, hs.p, (size_t)count * 4);
+  }
+  void copy(void* dst, const void* src, size_t n) { XHIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, st)); }
+  void to_host(void* host, const void* src, size_t n) {
+    XHIP(hipMemcpyAsync(host, src, n, hipMemcpyDeviceToHost, st));
+    XHIP(hipStreamSynchronize(st));
+  }
+  void from_host(void* dst, const void* host, size_t n) {
+    XHIP(hipMemcpyAsync(dst, host, n, hipMemcpyHostToDevice, st));
+    XHIP(hipStreamSynchronize(st));      // the staging buffer is reused by the next column
+  }
+  void before_transport() {}             // RCCL and the local transport order themselves on the stream
+  void sync() { XHIP(hipStreamSynchronize(st)); }
+};
+
 struct ExchangeResult {
-  int64_t rows = 0;
-  std::vector<std::unique_ptr<DevBuf>> values, validity, aux;   // validity[c] null ⇔ column arrives without a bitmap; aux[c]: Utf8 bytes
-  std::vector<int64_t> aux_bytes;
+  xchg::Result<HipOps> r;
   int device = 0;
 };
 std::mutex g_res_mu;
@@ -164,20 +328,6 @@ auto guarded(F f, decltype(f()) err) -> decltype(f()) {
     t_error = "unknown native error";
   }
   return err;
-}
-
-constexpr int kUtf8Column = 0, kBoolColumn = -1;   // value_width of the two kinds that are not fixed-width byte columns
-int value_width(int type_id) {
-  switch ((TypeId)type_id) {
-    case TypeId::Bool: return kBoolColumn;
-    case TypeId::String: case TypeId::Bytes: return kUtf8Column;
-    case TypeId::Int8: return 1;
-    case TypeId::Int16: return 2;
-    case TypeId::Int32: case TypeId::Date: case TypeId::Float: return 4;
-    case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: case TypeId::Double: return 8;
-    case TypeId::Decimal: return 16;
-    default: throw CometError("exchange: column type " + std::to_string(type_id) + " is not supported by the in-library exchange yet");
-  }
 }
 
 }  // namespace
@@ -250,6 +400,17 @@ int64_t comet_comm_init_local(int64_t group_id, int32_t world, int32_t rank, int
   }, (int64_t)0);
 }
 
+int64_t comet_comm_init_tcp(const char* peers, int32_t world, int32_t rank, int32_t device_id, int32_t timeout_ms) {
+  return guarded([&]() -> int64_t {
+    if (world < 1 || rank < 0 || rank >= world) throw CometError("exchange: bad rank / world");
+    if (!peers) throw CometError("exchange: tcp transport needs the peer list");
+    auto c = std::make_shared<Comm>();
+    c->world = world; c->rank = rank; c->device = device_id;
+    c->tcp.reset(new xchg::TcpTransport(peers, world, rank, timeout_ms));     // blocks until every pair of ranks is connected (or the deadline)
+    return register_comm(c);
+  }, (int64_t)0);
+}
+
 void comet_comm_destroy(int64_t comm) {
   std::shared_ptr<Comm> c;
   {
@@ -269,225 +430,23 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
   return guarded([&]() -> int64_t {
     auto c = find_comm(comm);
     XHIP(hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    const int world = c->world;
-    if (rows < 0 || rows >= ((int64_t)1 << 31)) throw CometError("exchange: row count must be below 2^31");
     auto res = std::make_shared<ExchangeResult>();
     res->device = c->device;
-    res->values.resize((size_t)n_cols);
-    res->validity.resize((size_t)n_cols);
-    res->aux.resize((size_t)n_cols);
-    res->aux_bytes.assign((size_t)n_cols, 0);
-    std::vector<int> width((size_t)n_cols);
-    for (int i = 0; i < n_cols; i++) width[(size_t)i] = value_width(cols[i].type_id);
-
-    // 1. partition ids: Spark's murmur3 (seed 42) chained over the key columns, then pmod
-    DevBuf hashes, pids, idx, dstarts, scratch;
-    hashes.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
-    pids.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
-    idx.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
-    dstarts.ensure((size_t)(world + 1) * 8 + 16);
-    std::vector<int64_t> starts((size_t)world + 1, 0);
-    if (rows > 0) {
-      uint32_t seed = 42;
-      if (comet_launch_fill(4, hashes.p, rows, &seed, st) != 0) throw CometError("exchange: launch failed");
-      for (int k = 0; k < n_keys; k++) {
-        const CometExchangeColumn& kc = cols[key_cols[k]];
-        if (comet_murmur3_column(kc.type_id, kc.precision, kc.values, kc.validity, kc.aux, rows, (uint32_t*)hashes.p, st) != 0)
-          throw CometError(std::string("exchange: murmur3: ") + comet_last_error(0));
-      }
-      if (comet_pmod_partition((const uint32_t*)hashes.p, rows, world, (int32_t*)pids.p, st) != 0) throw CometError("exchange: pmod failed");
-      // 2. partition_starts / partition_row_indices (stable inside every partition)
-      scratch.ensure((size_t)comet_partition_scratch_bytes(rows, world));
-      const size_t hist_bytes = ((size_t)world * (size_t)comet_partition_tiles(rows) + 1) * 8;
-      uint32_t* bad = (uint32_t*)((char*)scratch.p + hist_bytes);
-      XHIP(hipMemsetAsync(bad, 0, 4, st));
-      if (comet_launch_partition_indices((const int32_t*)pids.p, rows, world, (uint64_t*)scratch.p, bad, (int64_t*)dstarts.p, (uint32_t*)idx.p, st) != 0)
-        throw CometError("exchange: partition launch failed");
-      PinnedBuf hs;
-      hs.ensure((size_t)(world + 1) * 8 + 16);
-      XHIP(hipMemcpyAsync(hs.p, dstarts.p, (size_t)(world + 1) * 8, hipMemcpyDeviceToHost, st));
-      XHIP(hipStreamSynchronize(st));
-      memcpy(starts.data(), hs.p, (size_t)(world + 1) * 8);
+    HipOps ops;
+    ops.st = c->stream;
+    // the orchestration is exchange_core.hpp's, whatever the wire
+    if (c->nccl) {
+      RcclTransport t(c->nccl, c->world, c->rank, c->stream);
+      xchg::run(ops, t, n_cols, cols, rows, key_cols, n_keys, res->r);
+    } else if (c->tcp) {
+      xchg::run(ops, *c->tcp, n_cols, cols, rows, key_cols, n_keys, res->r);
+    } else if (c->world > 1) {
+      LocalTransport t(c->local, c->rank, c->stream, c->ready);
+      xchg::run(ops, t, n_cols, cols, rows, key_cols, n_keys, res->r);
+    } else {
+      SelfTransport t;
+      xchg::run(ops, t, n_cols, cols, rows, key_cols, n_keys, res->r);
     }
-    // 3. counts: who sends how many units (rows, or bytes of a Utf8 column) to whom.  `my_starts` = world + 1 unit offsets of my send
-    //    buffer in partition order; collective — every rank calls it the same number of times, in the same order.
-    struct Split {
-      std::vector<int64_t> starts, send, recv, roff, peer_off;   // peer_off[s]: where my slice begins in sender s's buffer (local transport)
-      int64_t total = 0;                                         // units this rank receives
-    };
-    auto make_split = [&](const std::vector<int64_t>& my_starts) {
-      Split sp;
-      sp.starts = my_starts;
-      sp.send.assign((size_t)world, 0); sp.recv.assign((size_t)world, 0); sp.peer_off.assign((size_t)world, 0);
-      for (int p = 0; p < world; p++) sp.send[(size_t)p] = my_starts[(size_t)p + 1] - my_starts[(size_t)p];
-      if (world == 1 && !c->nccl) {
-        sp.recv[0] = sp.send[0];
-      } else if (c->nccl) {
-        Rccl& r = Rccl::get();
-        DevBuf dsend, dall;
-        PinnedBuf hsend, hall;
-        dsend.ensure((size_t)world * 8 + 16);
-        dall.ensure((size_t)world * world * 8 + 16);
-        hsend.ensure((size_t)world * 8 + 16);
-        hall.ensure((size_t)world * world * 8 + 16);
-        memcpy(hsend.p, sp.send.data(), (size_t)world * 8);
-        XHIP(hipMemcpyAsync(dsend.p, hsend.p, (size_t)world * 8, hipMemcpyHostToDevice, st));
-        r.check(r.AllGather(dsend.p, dall.p, (size_t)world, kNcclInt64, c->nccl, st), "ncclAllGather");
-        XHIP(hipMemcpyAsync(hall.p, dall.p, (size_t)world * world * 8, hipMemcpyDeviceToHost, st));
-        XHIP(hipStreamSynchronize(st));
-        const int64_t* m = (const int64_t*)hall.p;   // m[s · world + d] = units rank s sends to rank d
-        for (int s = 0; s < world; s++) sp.recv[(size_t)s] = m[(size_t)s * world + c->rank];
-      } else {
-        LocalGroup& g = *c->local;
-        { std::lock_guard<std::mutex> lk(g.mu); g.starts[(size_t)c->rank] = my_starts; }
-        g.barrier();
-        { std::lock_guard<std::mutex> lk(g.mu);
-          for (int s = 0; s < world; s++) {
-            sp.peer_off[(size_t)s] = g.starts[(size_t)s][(size_t)c->rank];
-            sp.recv[(size_t)s] = g.starts[(size_t)s][(size_t)c->rank + 1] - sp.peer_off[(size_t)s];
-          } }
-        g.barrier();      // everyone has read: the slot may be published again (the byte counts of a Utf8 column, the next exchange)
-      }
-      sp.roff.assign((size_t)world + 1, 0);
-      for (int s = 0; s < world; s++) { sp.roff[(size_t)s] = sp.total; sp.total += sp.recv[(size_t)s]; }
-      sp.roff[(size_t)world] = sp.total;
-      return sp;
-    };
-    const Split R = make_split(starts);
-    const int64_t n_out = R.total;
-    res->rows = n_out;
-    if (n_out >= ((int64_t)1 << 31)) throw CometError("exchange: a rank would receive 2^31 rows or more");
-
-    // 4. every buffer: take into partition order, then move the slices
-    auto move = [&](const void* send_buf, void* recv_buf, int w, const Split& sp) {   // w bytes per unit
-      if (world == 1 && !c->nccl) {
-        if (sp.total) XHIP(hipMemcpyAsync(recv_buf, send_buf, (size_t)sp.total * (size_t)w, hipMemcpyDeviceToDevice, st));
-      } else if (c->nccl) {
-        Rccl& r = Rccl::get();
-        r.check(r.GroupStart(), "ncclGroupStart");
-        for (int p = 0; p < world; p++) {
-          if (sp.send[(size_t)p]) r.check(r.Send((const char*)send_buf + (size_t)sp.starts[(size_t)p] * (size_t)w, (size_t)sp.send[(size_t)p] * (size_t)w, kNcclUint8, p, c->nccl, st), "ncclSend");
-          if (sp.recv[(size_t)p]) r.check(r.Recv((char*)recv_buf + (size_t)sp.roff[(size_t)p] * (size_t)w, (size_t)sp.recv[(size_t)p] * (size_t)w, kNcclUint8, p, c->nccl, st), "ncclRecv");
-        }
-        r.check(r.GroupEnd(), "ncclGroupEnd");
-      } else {
-        LocalGroup& g = *c->local;
-        XHIP(hipEventRecord(c->ready, st));
-        { std::lock_guard<std::mutex> lk(g.mu); g.send_ptr[(size_t)c->rank] = send_buf; }
-        g.barrier();                                              // every send buffer is published (and its event recorded)
-        for (int s = 0; s < world; s++) {
-          const void* src;
-          hipEvent_t ev;
-          { std::lock_guard<std::mutex> lk(g.mu); src = g.send_ptr[(size_t)s]; ev = g.ready[(size_t)s]; }
-          if (!sp.recv[(size_t)s]) continue;
-          XHIP(hipStreamWaitEvent(st, ev, 0));
-          XHIP(hipMemcpyAsync((char*)recv_buf + (size_t)sp.roff[(size_t)s] * (size_t)w, (const char*)src + (size_t)sp.peer_off[(size_t)s] * (size_t)w,
-                              (size_t)sp.recv[(size_t)s] * (size_t)w, hipMemcpyDeviceToDevice, st));
-        }
-        XHIP(hipStreamSynchronize(st));                           // my pulls are done …
-        g.barrier();                                              // … and so are everybody's: the send buffers may be reused
-      }
-    };
-    // does the column carry validity on ANY rank?  (a rank without NULLs still has to send validity bytes then)
-    std::vector<int64_t> has_valid((size_t)n_cols, 0);
-    for (int i = 0; i < n_cols; i++) has_valid[(size_t)i] = cols[i].validity ? 1 : 0;
-    if ((world > 1 || c->nccl) && n_cols > 0) {
-      if (c->nccl) {
-        Rccl& r = Rccl::get();
-        DevBuf d1, d2;
-        PinnedBuf h1, h2;
-        d1.ensure((size_t)n_cols * 8 + 16); d2.ensure((size_t)n_cols * world * 8 + 16);
-        h1.ensure((size_t)n_cols * 8 + 16); h2.ensure((size_t)n_cols * world * 8 + 16);
-        memcpy(h1.p, has_valid.data(), (size_t)n_cols * 8);
-        XHIP(hipMemcpyAsync(d1.p, h1.p, (size_t)n_cols * 8, hipMemcpyHostToDevice, st));
-        r.check(r.AllGather(d1.p, d2.p, (size_t)n_cols, kNcclInt64, c->nccl, st), "ncclAllGather");
-        XHIP(hipMemcpyAsync(h2.p, d2.p, (size_t)n_cols * world * 8, hipMemcpyDeviceToHost, st));
-        XHIP(hipStreamSynchronize(st));
-        for (int s = 0; s < world; s++)
-          for (int i = 0; i < n_cols; i++) has_valid[(size_t)i] |= ((const int64_t*)h2.p)[(size_t)s * n_cols + i];
-      } else {
-        LocalGroup& g = *c->local;
-        { std::lock_guard<std::mutex> lk(g.mu); g.flags[(size_t)c->rank] = has_valid; }
-        g.barrier();
-        { std::lock_guard<std::mutex> lk(g.mu);
-          for (int s = 0; s < world; s++)
-            for (int i = 0; i < n_cols && (size_t)i < g.flags[(size_t)s].size(); i++) has_valid[(size_t)i] |= g.flags[(size_t)s][(size_t)i]; }
-        g.barrier();      // nobody overwrites its flags (next exchange) before everyone has read them
-      }
-    }
-    DevBuf send_buf, vbytes_send, vbytes_recv, lengths, send_offs, recv_lengths, tiles;
-    const size_t rows1 = (size_t)std::max<int64_t>(rows, 1), out1 = (size_t)std::max<int64_t>(n_out, 1);
-    for (int i = 0; i < n_cols; i++) {
-      const int w = width[(size_t)i];
-      res->values[(size_t)i].reset(new DevBuf());
-      if (w > 0) {
-        send_buf.ensure(rows1 * (size_t)w + 16);
-        if (rows > 0 && comet_launch_take(w, cols[i].values, (const uint32_t*)idx.p, rows, send_buf.p, st) != 0) throw CometError("exchange: take failed");
-        res->values[(size_t)i]->ensure(out1 * (size_t)w + 16);
-        move(send_buf.p, res->values[(size_t)i]->p, w, R);
-      } else if (w == kBoolColumn) {
-        // bit-packed values: one byte per row on the wire (partition boundaries are not byte aligned), packed again on arrival
-        vbytes_send.ensure(rows1 + 16);
-        vbytes_recv.ensure(out1 + 16);
-        if (rows > 0 && comet_launch_take_valid_bytes((const uint8_t*)cols[i].values, (const uint32_t*)idx.p, rows, (uint8_t*)vbytes_send.p, st) != 0)
-          throw CometError("exchange: take failed");
-        move(vbytes_send.p, vbytes_recv.p, 1, R);
-        res->values[(size_t)i]->ensure((size_t)((n_out + 7) / 8) + 16);
-        if (n_out > 0) pq_launch_pack((const uint8_t*)vbytes_recv.p, (uint8_t*)res->values[(size_t)i]->p, n_out, st);
-      } else {
-        // Utf8 / Binary: lengths (0 for NULL rows) → offsets of my send bytes → the bytes in partition order
-        const int32_t* offs = (const int32_t*)cols[i].values;
-        lengths.ensure(rows1 * 4 + 16);
-        send_offs.ensure((rows1 + 1) * 4 + 16);
-        tiles.ensure((size_t)((std::max(rows, n_out) + 1023) / 1024 + 2) * 8);
-        std::vector<int64_t> bstarts((size_t)world + 1, 0);
-        if (rows > 0) {
-          if (comet_launch_take_utf8_lengths(offs, (const uint32_t*)idx.p, nullptr, cols[i].validity, rows, (uint32_t*)lengths.p, st) != 0)
-            throw CometError("exchange: take failed");
-          pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)send_offs.p, st);
-          PinnedBuf hb;
-          hb.ensure((size_t)(world + 1) * 4 + 16);
-          for (int p = 0; p <= world; p++)
-            XHIP(hipMemcpyAsync((char*)hb.p + (size_t)p * 4, (const char*)send_offs.p + (size_t)starts[(size_t)p] * 4, 4, hipMemcpyDeviceToHost, st));
-          XHIP(hipStreamSynchronize(st));
-          for (int p = 0; p <= world; p++) bstarts[(size_t)p] = ((const int32_t*)hb.p)[p];
-          if (bstarts[(size_t)world] < 0) throw CometError("exchange: Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
-        }
-        send_buf.ensure((size_t)std::max<int64_t>(bstarts[(size_t)world], 1) + 16);
-        if (rows > 0 && comet_launch_take_utf8_copy(offs, cols[i].aux, (const uint32_t*)idx.p, nullptr, cols[i].validity, rows, (const int32_t*)send_offs.p,
-                                                    (uint8_t*)send_buf.p, st) != 0)
-          throw CometError("exchange: take failed");
-        const Split B = make_split(bstarts);
-        if (B.total >= ((int64_t)1 << 31)) throw CometError("exchange: a rank would receive 2 GiB or more of one Utf8 column");
-        recv_lengths.ensure(out1 * 4 + 16);
-        move(lengths.p, recv_lengths.p, 4, R);
-        res->aux[(size_t)i].reset(new DevBuf());
-        res->aux[(size_t)i]->ensure((size_t)std::max<int64_t>(B.total, 1) + 16);
-        move(send_buf.p, res->aux[(size_t)i]->p, 1, B);
-        res->aux_bytes[(size_t)i] = B.total;
-        // the received slices arrive sender after sender, each in row order: one prefix sum over the lengths is the offsets buffer
-        res->values[(size_t)i]->ensure((out1 + 1) * 4 + 16);
-        if (n_out > 0) pq_launch_u32_scan((const uint32_t*)recv_lengths.p, n_out, (uint64_t*)tiles.p, (int32_t*)res->values[(size_t)i]->p, st);
-        else XHIP(hipMemsetAsync(res->values[(size_t)i]->p, 0, 4, st));
-      }
-      if (has_valid[(size_t)i]) {
-        vbytes_send.ensure(rows1 + 16);
-        vbytes_recv.ensure(out1 + 16);
-        if (rows > 0) {
-          if (cols[i].validity) {
-            if (comet_launch_take_valid_bytes(cols[i].validity, (const uint32_t*)idx.p, rows, (uint8_t*)vbytes_send.p, st) != 0) throw CometError("exchange: take failed");
-          } else {
-            XHIP(hipMemsetAsync(vbytes_send.p, 1, (size_t)rows, st));
-          }
-        }
-        move(vbytes_send.p, vbytes_recv.p, 1, R);
-        res->validity[(size_t)i].reset(new DevBuf());
-        res->validity[(size_t)i]->ensure((size_t)((n_out + 7) / 8) + 16);
-        if (n_out > 0) pq_launch_pack((const uint8_t*)vbytes_recv.p, (uint8_t*)res->validity[(size_t)i]->p, n_out, st);
-      }
-    }
-    XHIP(hipStreamSynchronize(st));     // scratch buffers return to the pool; the result is complete
     std::lock_guard<std::mutex> lk(g_res_mu);
     int64_t h = g_next_res++;
     g_results[h] = res;
@@ -495,27 +454,33 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
   }, (int64_t)0);
 }
 
+const char* comet_comm_transport(int64_t comm) {
+  std::lock_guard<std::mutex> lk(g_comm_mu);
+  auto it = g_comms.find(comm);
+  return it == g_comms.end() ? "" : it->second->transport_name();
+}
+
 int64_t comet_exchange_result_rows(int64_t result) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   auto it = g_results.find(result);
-  return it == g_results.end() ? -1 : it->second->rows;
+  return it == g_results.end() ? -1 : it->second->r.rows;
 }
 
 int32_t comet_exchange_result_column(int64_t result, int32_t col, void** values, void** validity) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   auto it = g_results.find(result);
-  if (it == g_results.end() || col < 0 || (size_t)col >= it->second->values.size()) return -2;
-  *values = it->second->values[(size_t)col]->p;
-  *validity = it->second->validity[(size_t)col] ? it->second->validity[(size_t)col]->p : nullptr;
+  if (it == g_results.end() || col < 0 || (size_t)col >= it->second->r.values.size()) return -2;
+  *values = it->second->r.values[(size_t)col]->p;
+  *validity = it->second->r.validity[(size_t)col] ? it->second->r.validity[(size_t)col]->p : nullptr;
   return 0;
 }
 
 int32_t comet_exchange_result_aux(int64_t result, int32_t col, void** bytes, int64_t* n_bytes) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   auto it = g_results.find(result);
-  if (it == g_results.end() || col < 0 || (size_t)col >= it->second->values.size()) return -2;
-  *bytes = it->second->aux[(size_t)col] ? it->second->aux[(size_t)col]->p : nullptr;
-  *n_bytes = it->second->aux_bytes[(size_t)col];
+  if (it == g_results.end() || col < 0 || (size_t)col >= it->second->r.values.size()) return -2;
+  *bytes = it->second->r.aux[(size_t)col] ? it->second->r.aux[(size_t)col]->p : nullptr;
+  *n_bytes = it->second->r.aux_bytes[(size_t)col];
   return 0;
 }
 

@@ -76,10 +76,93 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
   }
   if (const char* e = getenv("COMET_JOIN_FUSE_PROBE")) fuse_probe_ = atoi(e) != 0;
   if (const char* e = getenv("COMET_GPU_CHUNK_ROWS")) chunk_rows_ = std::max<long long>(1024, atoll(e));
+  // Semi-join reduction.  A LeftSemi / LeftAnti join only asks whether its build side HOLDS a key: how often is irrelevant.  An Inner join
+  // below it whose output is projected onto columns of ONE of its sides therefore only has to say which rows of that side have a partner
+  // — a LeftSemi join, whose output has at most one row per input row instead of one per matching pair (TPC-DS Q95: the ws_wh self-join
+  // emits 68 M pairs where 25 M rows carry the same keys), and whose own build side is duplicate-insensitive in turn.  Same SET of rows,
+  // so the consumer's answer is unchanged; the reference executes the plan as written (DataFusion has no such rule).
+  // (the Scan leaves are bound to the input streams first, in the plan's own depth-first order: the rule may swap a join's children)
+  {
+    std::function<void(const Operator&)> bind_scans = [&](const Operator& op) {
+      if (op.kind == OpKind::Scan) scan_input_.emplace(&op, scan_input_.size());
+      for (auto& c : op.children) bind_scans(*c);
+    };
+    bind_scans(*plan_);
+  }
+  bool semi_reduction = true;
+  for (auto& kv : config_)
+    if (kv.first == "spark.comet.gpu.join.semiReduction") semi_reduction = kv.second != "false" && kv.second != "0";
+  if (const char* e = getenv("COMET_JOIN_SEMI_REDUCTION")) semi_reduction = atoi(e) != 0;
+  if (semi_reduction) {
+    std::function<void(Operator&, bool)> reduce = [&](Operator& op, bool set_only) {   // set_only: the consumer looks at the SET of op's rows
+      if (op.kind == OpKind::Projection && set_only && op.children.size() == 1 && op.children[0]->kind == OpKind::HashJoin) {
+        Operator& j = *op.children[0];
+        if (j.join_type == JoinType::Inner && !j.null_aware_anti && j.children.size() == 2 && j.left_keys.size() == j.right_keys.size()) {
+          // which join output columns does the projection read?  (left ++ right; the child schemas are not inferred yet: the left width
+          // comes from the largest column index the left keys / the condition can tell apart — so take it from the children instead)
+          std::function<int(const Operator&)> width = [&](const Operator& o) -> int {
+            switch (o.kind) {
+              case OpKind::Scan: return (int)o.scan_fields.size();
+              case OpKind::NativeScan: return (int)(o.required_schema.size() + o.partition_schema.size());
+              case OpKind::Projection: return (int)o.project_list.size();
+              case OpKind::Filter: case OpKind::Sort: case OpKind::Limit: return o.children.size() == 1 ? width(*o.children[0]) : -1;
+              case OpKind::HashJoin: {
+                if (o.children.size() != 2) return -1;
+                const int l = width(*o.children[0]), r = width(*o.children[1]);
+                if (l < 0 || r < 0) return -1;
+                return (o.join_type == JoinType::LeftSemi || o.join_type == JoinType::LeftAnti) ? l : l + r;
+              }
+              default: return -1;     // aggregates, windows, expands: not needed for this rule
+            }
+          };
+          const int nl = width(*j.children[0]), nr = width(*j.children[1]);
+          bool any_left = false, any_right = false, ok = nl >= 0 && nr >= 0;
+          std::function<void(const ExprP&)> refs = [&](const ExprP& e) {
+            if (e->kind == ExprKind::Bound) {
+              if (e->bound_index < 0 || e->bound_index >= nl + nr) ok = false;
+              else (e->bound_index < nl ? any_left : any_right) = true;
+            }
+            for (auto& c : e->children) refs(c);
+          };
+          for (auto& e : op.project_list) refs(e);
+          if (ok && any_left != any_right) {
+            if (any_right) {
+              // keep the RIGHT side: swap the children so that it becomes the left of a LeftSemi join
+              std::function<ExprP(const ExprP&, bool)> remap = [&](const ExprP& e, bool combined) -> ExprP {
+                auto n = std::make_shared<Expr>(*e);
+                if (e->kind == ExprKind::Bound) n->bound_index = combined ? (e->bound_index >= nl ? e->bound_index - nl : e->bound_index + nr) : e->bound_index - nl;
+                for (auto& c : n->children) c = remap(c, combined);
+                return n;
+              };
+              std::swap(j.children[0], j.children[1]);
+              std::swap(j.left_keys, j.right_keys);
+              j.build_side = j.build_side == BuildSide::Left ? BuildSide::Right : BuildSide::Left;
+              if (j.join_condition) j.join_condition = remap(j.join_condition, true);
+              for (auto& e : op.project_list) e = remap(e, false);
+            }
+            j.join_type = JoinType::LeftSemi;
+          }
+        }
+      }
+      for (size_t i = 0; i < op.children.size(); i++) {
+        bool child_set_only = false;
+        switch (op.kind) {
+          case OpKind::Projection: case OpKind::Filter: child_set_only = set_only; break;
+          case OpKind::HashJoin:
+            if ((op.join_type == JoinType::LeftSemi || op.join_type == JoinType::LeftAnti) && !op.null_aware_anti) child_set_only = i == 1 ? true : set_only;
+            else child_set_only = set_only;      // duplicates on either side of a join only duplicate its output rows
+            break;
+          default: break;                        // aggregates, limits, windows, sorts, shuffle writers count their rows
+        }
+        reduce(*op.children[i], child_set_only);
+      }
+    };
+    reduce(*plan_, false);
+  }
   // Scan leaves in depth-first, left-before-right order map to the input streams (planner.rs:1726, :2391)
   std::function<void(const Operator&)> walk = [&](const Operator& op) {
     node_id_[&op] = (int)node_id_.size();
-    if (op.kind == OpKind::Scan) scan_input_[&op] = scan_input_.size();
+    if (op.kind == OpKind::Scan && !scan_input_.count(&op)) scan_input_.emplace(&op, scan_input_.size());   // (bound above, before the semi-join reduction)
     if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan || op.kind == OpKind::Sort || op.kind == OpKind::Limit || op.kind == OpKind::ShuffleWriter ||
         op.kind == OpKind::Expand || op.kind == OpKind::Window)
       has_join_ = true;

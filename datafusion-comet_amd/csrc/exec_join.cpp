@@ -146,12 +146,30 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     prm.in[nb + i].aux = P.cols[i].aux;
     prm.in[nb + i].offset = P.cols[i].offset;
   }
-  int64_t cap = 1024;
-  while (cap < 2 * B.rows) cap <<= 1;
   const int64_t n = P.rows;
-  DevBuf head, next, matched, btiles;
-  head.ensure((size_t)cap * 4);     // u32 per bucket: newest row | tag | chain flag (comet_device.hpp template D)
-  next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4);
+  const bool use_lds = B.rows > 0 && B.rows <= 6144 && getenv("COMET_JOIN_GLOBAL_TABLE") == nullptr;
+  DevBuf head, next, matched, btiles, emitted_buf;
+  emitted_buf.ensure(64);
+  prm.n = n;
+  prm.iarg[1] = B.rows;
+  // The bucket array holds one entry per RUN of equal neighbouring keys (comet_device.hpp "Runs of equal keys"), not one per row: a large
+  // build side is counted first (one coalesced pass over its key columns) so that a clustered fact table — several rows per key — gets
+  // a bucket array sized by its runs, which stays in the caches several times better than one sized by its rows.
+  int64_t entries = B.rows;
+  static const bool count_runs = getenv("COMET_JOIN_COUNT_RUNS") == nullptr || atoi(getenv("COMET_JOIN_COUNT_RUNS")) != 0;
+  if (!use_lds && count_runs && B.rows >= (1 << 20)) {
+    HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 8, stream_));
+    prm.out[0] = emitted_buf.p;
+    prm.out[kOutErr] = err_flags_.p;
+    launch(v, "k_jbcnt", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+    uint64_t leaders = 0;
+    read_small(&leaders, emitted_buf.p, 8);
+    entries = std::min<int64_t>(B.rows, (int64_t)leaders);
+  }
+  int64_t cap = 1024;
+  while (cap < 2 * entries) cap <<= 1;
+  head.ensure((size_t)cap * 4);     // u32 per bucket: newest run leader | tag | "more than one row" flag (comet_device.hpp template D)
+  next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4 + 16);
   HIP_CHECK(hipMemsetAsync(head.p, 0xff, (size_t)cap * 4, stream_));
   const bool outer_build = d.join_outer_build;
   const int64_t nbtiles = (B.rows + 1023) / 1024;
@@ -163,9 +181,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     prm.out[46] = btiles.p;
     prm.iarg[3] = nbtiles;
   }
-  prm.n = n;
   prm.iarg[0] = cap;
-  prm.iarg[1] = B.rows;
   {
     int ib = 1;                                   // bits of a build row index: rows ≤ 2^ib − 1, so an index is never all ones
     while (ib < 31 && ((int64_t)1 << ib) - 1 < std::max<int64_t>(B.rows, 1)) ib++;
@@ -193,10 +209,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   };
   // ---- single-pass probe (comet_device.hpp template D'): a small build side is hashed into LDS by every block, a large one into the
   // chained global table; either way the probe counts and emits in one launch, reserving output ranges with one atomic per tile ----
-  const bool use_lds = B.rows > 0 && B.rows <= 6144 && getenv("COMET_JOIN_GLOBAL_TABLE") == nullptr;
   if (!use_lds && B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
-  DevBuf emitted_buf;
-  emitted_buf.ensure(64);
   prm.out[47] = emitted_buf.p;
   // FK-shaped joins emit at most one row per probe row; anything beyond the capacity is counted, not written, and the probe re-run
   int64_t out_cap = d.join_build_only ? 1 : n + 1024;

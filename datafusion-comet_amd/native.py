@@ -101,6 +101,10 @@ def _load() -> ctypes.CDLL:
     lib.comet_comm_init_rank.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.c_int32]
     lib.comet_comm_init_local.restype = c.c_int64
     lib.comet_comm_init_local.argtypes = [c.c_int64, c.c_int32, c.c_int32, c.c_int32]
+    lib.comet_comm_init_tcp.restype = c.c_int64
+    lib.comet_comm_init_tcp.argtypes = [c.c_char_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32]
+    lib.comet_comm_transport.restype = c.c_char_p
+    lib.comet_comm_transport.argtypes = [c.c_int64]
     lib.comet_comm_destroy.restype = None
     lib.comet_comm_destroy.argtypes = [c.c_int64]
     lib.comet_exchange.restype = c.c_int64
@@ -882,8 +886,12 @@ class NativeComm:
     """One rank of an in-library communicator: RCCL between processes (`unique_id` from NativeComm.unique_id() on rank 0, moved to the
     other ranks by the launcher), or the in-process transport between the task threads of one process (`local_group`)."""
 
-    def __init__(self, world: int, rank: int, device_id: int = 0, unique_id: Optional[bytes] = None, local_group: Optional[int] = None):
-        if local_group is not None:
+    def __init__(self, world: int, rank: int, device_id: int = 0, unique_id: Optional[bytes] = None, local_group: Optional[int] = None,
+                 tcp_peers: Optional[str] = None, timeout_ms: int = 0):
+        if tcp_peers is not None:
+            # one process per rank over TCP ("host:port,host:port,…", one entry per rank): host memory on the wire
+            self.handle = lib().comet_comm_init_tcp(tcp_peers.encode(), world, rank, device_id, timeout_ms)
+        elif local_group is not None:
             self.handle = lib().comet_comm_init_local(local_group, world, rank, device_id)
         else:
             buf = ctypes.create_string_buffer(unique_id if unique_id is not None else bytes(128), 128)
@@ -891,6 +899,11 @@ class NativeComm:
         if not self.handle:
             raise CometNativeException((lib().comet_exchange_last_error() or b"").decode())
         self.world, self.rank, self.device_id = world, rank, device_id
+
+    @property
+    def transport(self) -> str:
+        """"rccl" | "tcp" | "in-process" | "none (1 rank)": the wire this communicator moves its slices over"""
+        return (lib().comet_comm_transport(self.handle) or b"").decode()
 
     @staticmethod
     def unique_id() -> bytes:

@@ -200,6 +200,7 @@ int64_t comet_snappy_inflate_pages(const uint8_t* streams, const int64_t* stream
  *   comet_comm_unique_id / comet_comm_init_rank   one process per GPU: RCCL (dlopen'ed); the 128-byte id travels out of band
  *   comet_comm_init_local                         N task threads of one process (one GPU each, or shared): in-process rendezvous +
  *                                                 peer copies; every rank of `group_id` must call it with the same world size
+ *   comet_comm_init_tcp                           one process per rank over TCP sockets (host memory on the wire)
  * All calls return 0 / a positive handle on success; on failure -2 / 0 and comet_exchange_last_error() (thread local) tells why. */
 typedef struct CometExchangeColumn {
   int32_t type_id;          /* spark_expression.DataType.DataTypeId: fixed-width types, BOOL (bit-packed values), STRING / BYTES */
@@ -211,6 +212,13 @@ typedef struct CometExchangeColumn {
 int32_t comet_comm_unique_id(uint8_t* out128);
 int64_t comet_comm_init_rank(const uint8_t* id128, int32_t world, int32_t rank, int32_t device_id);
 int64_t comet_comm_init_local(int64_t group_id, int32_t world, int32_t rank, int32_t device_id);
+/* TCP transport: one process per rank, host memory on the wire (HBM buffers are staged through pinned memory) — for ranks without an
+ * RCCL-capable fabric between them, and what the CPU-only multi-process tests drive the exchange over.  `peers` = "host:port,host:port,…",
+ * one entry per rank (rank r listens on its own port); blocks until every pair of ranks is connected or `timeout_ms` (0 = 60 s) passed.
+ * A peer that dies or stays silent for `timeout_ms` during an exchange fails that exchange with an error naming it — nothing hangs. */
+int64_t comet_comm_init_tcp(const char* peers, int32_t world, int32_t rank, int32_t device_id, int32_t timeout_ms);
+/* "rccl" | "tcp" | "in-process" | "none (1 rank)": the wire this communicator moves its slices over */
+const char* comet_comm_transport(int64_t comm);
 void comet_comm_destroy(int64_t comm);
 /* Collective: every rank of the communicator calls it with its shard (rows may be 0).  Returns a result handle. */
 int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* cols, int64_t rows, const int32_t* key_cols, int32_t n_keys);

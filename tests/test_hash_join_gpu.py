@@ -231,3 +231,67 @@ def test_fused_probe_whose_filter_keeps_nothing_and_device_resident_inputs(built
     dl, dr = native.DeviceTable.from_arrow(nn_left, "cuda:0"), native.DeviceTable.from_arrow(nn_right, "cuda:0")
     out = native.execute_to_table([native.DeviceInput(dl), native.DeviceInput(dr)], 4, j.encode(), batch_size=0)
     assert _rows(pa.Table.from_batches(out)) == _rows(_oracle(j, [nn_left, nn_right]))
+
+
+# ---- runs of equal keys on the build side (comet_device.hpp "Runs of equal keys"), semi-join reduction ----
+def _clustered(n, seed, keys_per_run=4.5, null_frac=0.03):
+    """a fact-table-shaped side: rows of one key are neighbours (runs of random length, crossing the 64-row wave boundaries), NULL keys
+    sprinkled INSIDE runs, a second column that differs inside a run (what a residual condition looks at)"""
+    rng = np.random.default_rng(seed)
+    lens = rng.geometric(1.0 / keys_per_run, n)
+    key = np.repeat(np.arange(len(lens), dtype=np.int64) * 3 + 7, lens)[:n]
+    return pa.table({"k": pa.array(key, mask=rng.random(n) < null_frac), "w": pa.array(rng.integers(0, 4, n).astype(np.int32), mask=rng.random(n) < null_frac),
+                     "id": pa.array(np.arange(n, dtype=np.int64))})
+
+
+CFIELDS = [S.T_INT64, S.T_INT32, S.T_INT64]
+
+
+@pytest.mark.parametrize("jt", [S.INNER, S.LEFT_OUTER, S.FULL_OUTER, S.LEFT_SEMI, S.LEFT_ANTI])
+@pytest.mark.parametrize("build", [S.BUILD_LEFT, S.BUILD_RIGHT])
+@pytest.mark.parametrize("cond", [False, True])
+def test_clustered_keys_on_both_sides(built, jt, build, cond):
+    """Self-join-shaped inputs: both sides clustered by the key, about 4.5 rows per key, a residual condition that holds for some rows of
+    a run and not for others (the ws_wh self-join of TPC-DS Q95: w1 <> w2).  The build inserts one row per run; the probe walks the run."""
+    left, right = _clustered(9000, 31), _clustered(8000, 32)
+    c = S.not_(S.eq(S.col(1, S.T_INT32), S.col(4, S.T_INT32))) if cond else None
+    j = S.hash_join(S.scan(CFIELDS), S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, build, c)
+    ncols = 3 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 6
+    got, want = _run(j, [left, right], ncols, batch_size=0), _oracle(j, [left, right])
+    assert got.num_rows == want.num_rows > 1000
+    assert _rows(got) == _rows(want)
+
+
+def test_build_side_above_a_million_rows_is_sized_by_its_runs(built):
+    """≥ 2^20 build rows: the runs are counted first (k_jbcnt) and the bucket array sized by them; 4.5 rows per key, NULL keys, a condition"""
+    build_t, probe_t = _clustered(1_100_000, 41), _clustered(3000, 42)
+    probe_t = probe_t.set_column(0, "k", pa.array(np.asarray(build_t.column(0).fill_null(7))[::366][:3000].astype(np.int64)))     # keys that exist
+    c = S.not_(S.eq(S.col(1, S.T_INT32), S.col(4, S.T_INT32)))
+    for jt in (S.INNER, S.LEFT_SEMI):
+        j = S.hash_join(S.scan(CFIELDS), S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_RIGHT, c)
+        got, want = _run(j, [probe_t, build_t], 6 if jt == S.INNER else 3, batch_size=0), _oracle(j, [probe_t, build_t])
+        assert got.num_rows == want.num_rows > 2000
+        assert _rows(got) == _rows(want)
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_semi_join_reduction_keeps_the_answer(built, side):
+    """x IN (SELECT k FROM b JOIN c ON …): the Inner join under the semi join's build side is projected onto one of its sides, so the
+    engine runs it as a LeftSemi join (children swapped when the projection keeps the right side) — same rows as the plan as written
+    (spark.comet.gpu.join.semiReduction=false) and as the oracle; input streams stay bound to their Scan leaves."""
+    a, b, c_ = _clustered(5000, 51), _clustered(6000, 52), _clustered(4000, 53)
+    cond = S.not_(S.eq(S.col(1, S.T_INT32), S.col(4, S.T_INT32)))
+    inner = S.hash_join(S.scan(CFIELDS), S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.INNER, S.BUILD_RIGHT, cond)
+    proj = S.project(inner, [S.col(0, S.T_INT64)] if side == "left" else [S.math("add", S.col(3, S.T_INT64), S.lit(0, S.T_INT64), S.T_INT64)])
+    plan = S.hash_join(S.scan(CFIELDS), proj, [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.LEFT_SEMI, S.BUILD_RIGHT)
+    explain = native.compile_plan(plan.encode())
+    assert explain.count("LeftSemi") == 2 and "Inner" not in explain
+    got = _run(plan, [a, b, c_], 3, batch_size=0)
+    asis = _run(plan, [a, b, c_], 3, batch_size=0, config=S.config_map({"spark.comet.gpu.join.semiReduction": "false"}))
+    want = _oracle(plan, [a, b, c_])
+    assert _rows(got) == _rows(want) == _rows(asis) and 100 < got.num_rows < 5000
+    # the inner join's output multiplicity matters to an aggregate above it: no reduction there
+    agg = S.hash_agg(proj, [S.col(0, S.T_INT64)], [S.count(S.col(0, S.T_INT64))])
+    assert "Inner" in native.compile_plan(agg.encode())
+    got, want = _run(agg, [b, c_], 2, batch_size=0), _oracle(agg, [b, c_])
+    assert _rows(got) == _rows(want)

@@ -79,3 +79,47 @@ def test_rccl_transport_with_a_one_rank_communicator(built, monkeypatch):
     comm.close()
     for c in range(6):
         assert out.column(c).to_pylist() == sh.column(c).to_pylist()
+
+
+def test_tcp_transport_between_processes_on_the_gpu(built, tmp_path):
+    """comet_comm_init_tcp: two and three PROCESSES (own HIP contexts, the one GPU of the test box) exchange through sockets — HBM
+    buffers staged through pinned memory, the orchestration of exchange_core.hpp unchanged — and every rank receives Spark's partition."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import pyarrow as pa
+from datafusion_comet_amd import native
+import test_native_exchange_gpu as T
+world, rank, peers, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+native.lib()
+sh = T._shard(300 + rank, 9000 + 500 * rank)
+comm = native.NativeComm(world, rank, 0, tcp_peers=peers, timeout_ms=30000)
+assert comm.transport == "tcp"
+got = comm.exchange(native.DeviceTable.from_arrow(sh), [0, 4]).to_arrow()
+comm.close()
+with pa.OSFile(out, "wb") as f, pa.ipc.new_file(f, got.schema) as w:
+    w.write_table(got)
+""" % (root, os.path.join(root, "tests"))
+    for world in (2, 3):
+        socks = [socket.socket() for _ in range(world)]
+        for s_ in socks:
+            s_.bind(("127.0.0.1", 0))
+        peers = ",".join("127.0.0.1:%d" % s_.getsockname()[1] for s_ in socks)
+        for s_ in socks:
+            s_.close()
+        procs = [subprocess.Popen([sys.executable, "-c", child, str(world), str(r), peers, str(tmp_path / f"w{world}r{r}.arrow")], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = [p.communicate(timeout=300)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), [l[-600:] for l in logs]
+        want = _expected([_shard(300 + r, 9000 + 500 * r) for r in range(world)], world, [0, 4])
+        for r in range(world):
+            got = pa.ipc.open_file(str(tmp_path / f"w{world}r{r}.arrow")).read_all()
+            assert got.num_rows == want[r].num_rows
+            for c in range(6):
+                assert got.column(c).to_pylist() == want[r].column(c).to_pylist(), (world, r, c)
