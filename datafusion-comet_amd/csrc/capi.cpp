@@ -376,6 +376,26 @@ int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size
   });
 }
 
+int32_t comet_check_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap) {
+  int32_t rc = guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    OperatorP op = decode_operator(plan, plan_len);
+    std::string ex = ExecutionContext::check_only(op, plan_bytes_hash(plan, plan_len));
+    if (out && cap) {
+      size_t n = std::min(cap - 1, ex.size());
+      memcpy(out, ex.data(), n);
+      out[n] = 0;
+    }
+    return 0;
+  });
+  if (rc != 0 && out && cap) {          // the reason, where the description would have gone
+    const char* why = comet_last_error(0);
+    size_t n = std::min(cap - 1, strlen(why));
+    memcpy(out, why, n);
+    out[n] = 0;
+  }
+  return rc;
+}
+
 int64_t comet_parquet_prune_report(const uint8_t* plan, size_t plan_len, int32_t page_index, char* out, size_t cap) {
   return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
     OperatorP op = decode_operator(plan, plan_len);

@@ -720,6 +720,20 @@ ExecutionContext::~ExecutionContext() {
 
 const std::string& ExecutionContext::explain() { return explain_; }
 
+// Would createPlan accept this plan?  Everything createPlan validates — decoding, operator and expression support, types — without
+// compiling anything and without a GPU: planning a stage on the driver can ask before it commits to the native path.
+std::string ExecutionContext::check_only(OperatorP plan, uint64_t plan_hash) {
+  size_t nscan = 0;
+  std::function<void(const Operator&)> cnt = [&](const Operator& op) {
+    if (op.kind == OpKind::Scan) nscan++;
+    for (auto& c : op.children) cnt(*c);
+  };
+  cnt(*plan);
+  std::vector<InputSource> ins(nscan);
+  ExecutionContext ctx(plan, plan_hash, {}, ins, 8192, 0);
+  return ctx.explain_;
+}
+
 std::string ExecutionContext::compile_only(OperatorP plan, uint64_t plan_hash) {
   // count Scan leaves to fabricate the (never used) input list
   size_t nscan = 0;

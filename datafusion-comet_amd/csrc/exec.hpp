@@ -154,6 +154,7 @@ class ExecutionContext {
   const std::string& explain();
   // CPU-only: plan + generate + hiprtc-compile the all-valid variant (used by build()/tests w/o GPU)
   static std::string compile_only(OperatorP plan, uint64_t plan_hash);
+  static std::string check_only(OperatorP plan, uint64_t plan_hash);
 
   std::string last_error;
   int last_error_kind = 0;

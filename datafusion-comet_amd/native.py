@@ -61,6 +61,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_plan_kernel_stats.argtypes = [c.c_int64, c.POINTER(c.c_double), c.POINTER(c.c_int64), c.POINTER(c.c_int64)]
     lib.comet_compile_plan.restype = c.c_int32
     lib.comet_compile_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_char_p, c.c_size_t]
+    lib.comet_check_plan.restype = c.c_int32
+    lib.comet_check_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_char_p, c.c_size_t]
     lib.comet_murmur3_column.restype = c.c_int32
     lib.comet_murmur3_column.argtypes = [c.c_int32, c.c_int32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
     lib.comet_pmod_partition.restype = c.c_int32
@@ -850,6 +852,14 @@ def partition_table(table: DeviceTable, pids, num_partitions: int):
             valid.append(None)
     torch.cuda.current_stream().synchronize()
     return DeviceTable(table.schema, n, vals, valid, dev, aux), [int(x) for x in starts.cpu().tolist()]
+
+
+def check_plan(plan: bytes):
+    """comet_check_plan: would createPlan accept this plan?  → (True, description) or (False, the refusal naming the operator / expression).
+    Nothing is compiled and no GPU is touched."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    rc = lib().comet_check_plan(plan, len(plan), buf, len(buf))
+    return rc == 0, buf.value.decode(errors="replace")
 
 
 def compile_plan(plan: bytes) -> str:

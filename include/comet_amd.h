@@ -99,6 +99,12 @@ void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launche
  * writes a description into out (NUL terminated, truncated to cap), -2 on error (comet_last_error(0)). */
 int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap);
 
+/* "Will createPlan accept this plan?" — decode + plan + generate, nothing compiled, no GPU touched (milliseconds): for the JVM side's
+ * planning-time decision between the native stage and Spark's own (Comet decides per operator / expression while it serializes the
+ * plan, spark/src/main/scala/org/apache/comet/serde/QueryPlanSerde.scala:743,910; a native library that refuses at createPlan would
+ * fail the task instead).  Returns 0 and a description in out, or -2 and the refusal — the operator / expression by name — in out. */
+int32_t comet_check_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap);
+
 /* Spark-compatible murmur3 (seed chaining) + pmod partition ids for the exchange step — replaces
  * create_murmur3_hashes (native/spark-expr/src/hash_funcs/murmur3.rs:185-198) and pmod
  * (native/shuffle/src/comet_partitioning.rs:51-57).  All pointers are DEVICE pointers.

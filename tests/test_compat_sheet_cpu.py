@@ -1,0 +1,55 @@
+"""COMPAT.md — which Spark operators / expressions libcomet.so accepts and the Comet configuration for the rest — is generated
+(tools/compat_sheet.py) and probed: every expression class the sheet lists as accepted has a probe plan that comet_check_plan accepts
+(decode + plan + generate, no compilation, no GPU); function names behind a sample of the classes it tells the JVM to keep are refused BY
+NAME; and the committed file equals the generator's output."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import compat_sheet as C                                        # noqa: E402
+from datafusion_comet_amd import native, serde as S             # noqa: E402
+
+
+def test_every_accepted_expression_class_is_accepted_by_check_plan(built):
+    P = C.probes()
+    listed = {n for names in C.REFERENCE_EXPRESSIONS.values() for n in names.split()}
+    assert set(P) <= listed, set(P) - listed                    # the sheet only speaks about classes the reference serializes
+    for cls, (expr, _) in P.items():
+        ok, msg = native.check_plan(C.probe_plan(expr).encode())
+        assert ok, (cls, msg)
+
+
+@pytest.mark.parametrize("cls,func,args", [("Upper", "upper", "s"), ("Lower", "lower", "s"), ("Concat", "concat", "ss"), ("Sin", "sin", "f"), ("Reverse", "reverse", "s"),
+                                           ("Md5", "md5", "s"), ("Pow", "power", "ff"), ("Hex", "hex", "i"), ("InitCap", "initcap", "s"), ("Exp", "exp", "f")])
+def test_functions_the_sheet_disables_are_refused_by_name(built, cls, func, args):
+    assert cls not in C.probes()
+    col = {"s": S.col(4, S.T_STRING), "f": S.col(2, S.T_DOUBLE), "i": S.col(1, S.T_INT64)}
+    rt = S.T_STRING if args[0] == "s" else S.T_DOUBLE
+    ok, msg = native.check_plan(C.probe_plan(S.scalar_func(func, [col[a] for a in args], rt)).encode())
+    assert not ok and func in msg, msg
+    assert f"spark.comet.expression.{cls}.enabled=false" in C.render()
+
+
+def test_refusals_below_the_class_level_and_unsupported_operators(built):
+    # Cast is ONE class: numeric casts run, string casts are refused at createPlan — what comet_check_plan exists for
+    ok, _ = native.check_plan(C.probe_plan(S.cast(S.col(0, S.T_INT32), S.T_DOUBLE)).encode())
+    assert ok
+    ok, msg = native.check_plan(C.probe_plan(S.cast(S.col(0, S.T_INT32), S.T_STRING)).encode())
+    assert not ok and "Cast" in msg
+    # an operator the engine does not run (Explode = 114) is refused by name
+    explode = S.Operator.__new__(S.Operator)
+    plan = S.project(S.scan([S.T_INT32]), [S.col(0, S.T_INT32)]).encode()
+    bogus = S._f_msg(1, plan) + S._f_msg(114, b"")
+    ok, msg = native.check_plan(bogus)
+    assert not ok and "Explode" in msg
+    text = C.render()
+    assert "--conf spark.comet.exec.explode.enabled=false" in text and "--conf spark.comet.exec.sample.enabled=false" in text
+
+
+def test_the_committed_sheet_is_the_generators_output(built):
+    with open(os.path.join(ROOT, "COMPAT.md")) as f:
+        assert f.read() == C.render(), "COMPAT.md is stale: python tools/compat_sheet.py --write"
