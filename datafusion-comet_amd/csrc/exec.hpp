@@ -258,6 +258,7 @@ class ExecutionContext {
   bool device_result_ = false;                     // the grouped result stays in HBM (nested aggregate / execute_device)
   DevTable dict_src_;                              // the aggregate's input while such keys are in flight
   std::map<const Operator*, FusedProbe> fused_probe_;   // joins that read their probe chain's source table directly
+  int64_t ramp_rows_ = 0;                          // host streams: size of the next chunk while the pipeline fills (doubles up to chunk_rows_)
   bool fuse_probe_ = true;                         // spark.comet.gpu.join.fuseProbe
   std::set<const Operator*> smj_needs_sort_;       // sort-merge joins whose output order is observable (others skip the sort)
   std::map<const Operator*, OperatorP> smj_sorts_;  // SortMergeJoin node → synthetic Sort over its output       // aggregates that are not the plan root (materialised by sub-contexts)

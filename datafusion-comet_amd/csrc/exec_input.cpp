@@ -429,7 +429,12 @@ bool ExecutionContext::pull_host_chunk() {
   std::vector<DeviceColumnView> views;
   std::vector<bool> has_valid;
   int64_t rows = 0;
-  if (!pull_host_table(0, in_types_, chunk_rows_, views, has_valid, rows)) return false;
+  // The first chunks are small and double up to chunkRows: nothing can overlap the staging of the FIRST chunk (the GPU and the link idle
+  // while it is gathered), so it should be short; from then on chunk k + 1 is staged while chunk k crosses PCIe and is consumed.
+  if (ramp_rows_ <= 0) ramp_rows_ = std::max<int64_t>(chunk_rows_ / 16, std::min<int64_t>(chunk_rows_, 65536));
+  const int64_t want_rows = std::min<int64_t>(chunk_rows_, ramp_rows_);
+  ramp_rows_ = std::min<int64_t>(chunk_rows_, ramp_rows_ * 2);
+  if (!pull_host_table(0, in_types_, want_rows, views, has_valid, rows)) return false;
   if (rows > 0) {
     process_chunk(views, has_valid, rows);
     // no host-side wait: mark this staging set busy until the work queued so far is done, and switch to the other set

@@ -377,6 +377,7 @@ DevTable ExecutionContext::grouped_to_device() {
   uint64_t ngroups = 0;
   read_small(&ngroups, (char*)err_flags_.p + 8, 8);
   check_device_errors();
+  if (getenv("COMET_TRACE_STAGES")) fprintf(stderr, "[comet] grouped result: %llu groups in a table of %lld slots x %zu bytes\n", (unsigned long long)ngroups, (long long)group_cap_, (size_t)(8 + 8 * (d.NK + d.NW)));
   const size_t ncol = d.out_cols.size();
   CometKParams prm;
   memset(&prm, 0, sizeof prm);

@@ -42,6 +42,8 @@ typedef struct PqInflate {     /* one compressed page body the device decompress
   int64_t src_off;             /* compressed bytes, 16-byte aligned, readable up to the next multiple of 16 */
   int64_t dst_off;             /* where the decompressed page goes, 16-byte aligned */
   int32_t src_len, dst_len;
+  int32_t preamble;            /* length of the stream's varint preamble (the host has seen the compressed bytes): where its first element starts */
+  int32_t pad;
 } PqInflate;
 
 /* output conversions */

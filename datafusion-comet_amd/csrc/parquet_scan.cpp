@@ -24,6 +24,8 @@
 
 #include "exec.hpp"
 #include "parquet_dev.h"
+#include "device/snappy2.hpp"
+#include "snappy2.hpp"
 #include "parquet_meta.hpp"
 
 extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
@@ -941,6 +943,8 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       job.dst_off = (int64_t)ipage;
       job.src_len = (int32_t)comp_len;
       job.dst_len = (int32_t)un_len;
+      job.preamble = comet_snappy2::preamble_length(body + comp_off, (int32_t)comp_len);     // where the stream's first element starts
+      job.pad = 0;
       hc.inflate.push_back(job);
       spos = cpos + comp_len;
       hc.ipos = ipage + un_len;
@@ -1456,7 +1460,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     if (chunks[t].err) std::rethrow_exception(chunks[t].err);
   };
 
-  struct ColumnDevice { DevBuf bytes, tables; PinnedBuf h_tables; };
+  struct ColumnDevice { DevBuf bytes, tables; PinnedBuf h_tables; Snappy2Scratch snappy2; };
   std::vector<std::shared_ptr<ColumnDevice>> keep;
   hipStream_t copy_stream = nullptr;
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
@@ -1606,7 +1610,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const char* tb = (const char*)cd->tables.p;
     if (n_jobs) {
       if (n_jobs >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
-      pq_launch_snappy((const PqInflate*)(tb + off_jobs), (int)n_jobs, (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+      // the multi-kernel pipeline (snappy2.cpp: every lane of the GPU on the column's pages); COMET_SNAPPY_ONE_WAVE=1 keeps the one-wave-per-
+      // page kernel for comparison
+      static const bool one_wave = getenv("COMET_SNAPPY_ONE_WAVE") != nullptr && atoi(getenv("COMET_SNAPPY_ONE_WAVE")) != 0;
+      if (one_wave) pq_launch_snappy((const PqInflate*)(tb + off_jobs), (int)n_jobs, (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+      else cd->snappy2.run((const PqInflate*)(tb_h + off_jobs), (const PqInflate*)(tb + off_jobs), (int)n_jobs, (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
       pages_inflated_on_device_ += (int64_t)n_jobs;
     }
 

@@ -75,7 +75,29 @@ __global__ __launch_bounds__(64) void pq_snappy_kernel(const PqInflate* __restri
 #endif
   if (rc != 0 && threadIdx.x == 0) atomicCAS(err, 0u, ((uint32_t)j << 8) | (uint32_t)rc);
 }
+// the pages the multi-kernel pipeline (snappy2_kernels.hip) flagged: status 1 = a legal stream that is not fragment-shaped → decompress it
+// here, one wave per page; status ≥ 16 = corrupt → report it
+__global__ __launch_bounds__(64) void pq_snappy_fallback_kernel(const PqInflate* __restrict__ jobs, int njobs, uint8_t* bytes, const uint32_t* __restrict__ status, uint32_t* err) {
+  __shared__ Lds s_lds;
+  const int j = (int)blockIdx.x;
+  if (j >= njobs) return;
+  const uint32_t st = status[j];
+  if (st == 0) return;
+  if (st >= 16) {
+    if (threadIdx.x == 0) atomicCAS(err, 0u, ((uint32_t)j << 8) | (st == 16 ? (uint32_t)ERR_PREAMBLE : st == 18 ? (uint32_t)ERR_BAD_COPY : st == 19 ? (uint32_t)ERR_OVERRUN : (uint32_t)ERR_TRUNCATED));
+    return;
+  }
+  const PqInflate job = jobs[j];
+  DevWave w;
+  const int rc = inflate_page(w, (SNAPPY_LDS Lds*)&s_lds, bytes + job.src_off, job.src_len, bytes + job.dst_off, job.dst_len);
+  if (rc != 0 && threadIdx.x == 0) atomicCAS(err, 0u, ((uint32_t)j << 8) | (uint32_t)rc);
+}
 }  // namespace
+
+extern "C" void pq_launch_snappy_fallback(const PqInflate* jobs, int njobs, uint8_t* bytes, const uint32_t* status, uint32_t* err, void* st) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(pq_snappy_fallback_kernel, njobs, 64, 0, (hipStream_t)st, jobs, njobs, bytes, status, err);
+}
 
 extern "C" void pq_launch_snappy(const PqInflate* jobs, int njobs, uint8_t* bytes, uint32_t* err, void* st) {
   if (njobs <= 0) return;

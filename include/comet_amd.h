@@ -197,6 +197,12 @@ int32_t comet_page_decompress(int32_t codec, const uint8_t* src, size_t src_len,
  * 2 truncated, 3 bad copy offset, 4 output overrun, 5 short output); -1 for a HIP error.  *kernel_ms: the launch's duration. */
 int64_t comet_snappy_inflate_pages(const uint8_t* streams, const int64_t* stream_off, const int32_t* stream_len, const int32_t* page_len,
                                    int32_t npages, uint8_t* out, const int64_t* out_off, int32_t device_id, double* kernel_ms);
+/* The same through the MULTI-KERNEL pipeline the scan uses since round 3 (csrc/device/snappy2.hpp: window transfer functions → chunk
+ * functions → one hop per chunk → element list → pointer jumping per 64 KiB fragment; pages that are not fragment-shaped fall back to the
+ * one-wave kernel inside the same call).  status_out (optional, npages words): what the pipeline made of each page before the fallback —
+ * 0 decoded, 1 handed to the one-wave kernel, >= 16 corrupt.  *kernel_ms: all launches of one decompression (scratch already sized). */
+int64_t comet_snappy2_inflate_pages(const uint8_t* streams, const int64_t* stream_off, const int32_t* stream_len, const int32_t* page_len,
+                                    int32_t npages, uint8_t* out, const int64_t* out_off, int32_t device_id, double* kernel_ms, uint32_t* status_out);
 
 /* ---- in-library hash exchange between GPUs (csrc/exchange.cpp) ----------------------------------------------------
  * The step Spark's exchange performs between two native stages, done GPU to GPU: rows are hash-partitioned exactly as the reference's

@@ -38,6 +38,50 @@ def test_kernel_on_raw_streams(built):
     for i, (g, w) in enumerate(zip(got, pages)):
         assert g == w, f"page {i} ({len(w)} bytes) differs"
     print(f"{len(pages)} pages, {sum(map(len, pages))} bytes: {ms:.3f} ms")
+    # the multi-kernel pipeline over the same streams: pyarrow's pages are fragment-shaped and decoded by it, the hand-built ones with copies
+    # across 64 KiB boundaries are handed to the one-wave kernel inside the same call — every page comes back exact either way
+    got2, ms2, status = native.snappy2_inflate_pages(streams, [len(p) for p in pages])
+    for i, (g, w) in enumerate(zip(got2, pages)):
+        assert g == w, f"pipeline: page {i} ({len(w)} bytes, status {status[i]}) differs"
+    assert status[:9] == [0] * 9 and 1 in status[9:]
+    print(f"pipeline: {ms2:.3f} ms, pages to the fallback: {sum(1 for x in status if x == 1)}")
+
+
+def test_pipeline_on_many_large_pages_and_the_emulation_corners(built):
+    """sizes the CPU emulation cannot afford: 96 pages of 1 MiB (decimal-as-INT64, doubles, low-cardinality ints, sorted keys), plus the
+    corner streams of tests/test_snappy2_emu_cpu.py on the real kernels"""
+    from tests.test_snappy_emu_cpu import literal, copy, varint
+    rng = np.random.default_rng(15)
+    n8 = (1 << 20) // 8
+    gens = [lambda: rng.integers(90_000, 10_000_000, n8).astype(np.int64).tobytes(), lambda: rng.standard_normal(n8).tobytes(),
+            lambda: rng.integers(0, 50, (1 << 20) // 4).astype(np.int32).tobytes(), lambda: (np.arange(n8, dtype=np.int64) * 1000 + int(rng.integers(0, 10**9))).tobytes()]
+    pages = [gens[i % 4]() for i in range(96)]
+    streams = [pa.compress(p, codec="snappy", asbytes=True) for p in pages]
+    noise = lambda n: ("lit", rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    deep = [("lit", b"0123456789abcdef")]
+    for k in range(6000):
+        deep.append(("copy", (4 + k % 8, 1 + k % 13)))
+        if k % 5 == 0:
+            deep.append(("lit", bytes([k & 0xFF, (k * 7) & 0xFF])))
+    corners = [build(deep), build([noise(5000), ("copy", (10, 77)), noise(61), noise(3), ("copy", (64, 5000)), noise(300)] + [("copy", (5, 9)), noise(2)] * 900),
+               build([noise(60), noise(61), noise(256), noise(257), noise(65_536 - 60 - 61 - 256 - 257), noise(100), ("copy", (64, 90)), ("copy", (11, 100))], wide=True),
+               build([noise(65_536)]), build([noise(65_536), noise(1)]), build([noise(65_000), noise(1000), noise(10)])]
+    for s_, raw in corners:
+        streams.append(s_)
+        pages.append(raw)
+    got, ms, status = native.snappy2_inflate_pages(streams, [len(p) for p in pages])
+    for i, (g, w) in enumerate(zip(got, pages)):
+        assert g == w, f"page {i} ({len(w)} bytes, status {status[i]}) differs"
+    assert status[:96] == [0] * 96 and status[-1] == 1 and status[-6:-1] == [0] * 5
+    total = sum(map(len, pages))
+    print(f"pipeline: {len(pages)} pages, {total} bytes in {ms:.3f} ms = {total / ms / 1e6:.1f} GB/s")
+    # corrupt pages: the pipeline's checks, reported through the same error word
+    raw = rng.integers(0, 1000, 50_000).astype(np.int64).tobytes()
+    good = pa.compress(raw, codec="snappy", asbytes=True)
+    for stream, n in [(varint(len(raw) + 1) + good[len(varint(len(raw))):], len(raw) + 1), (good[:-7], len(raw)),
+                      (varint(12) + literal(b"abcdefgh") + bytes([1, 0]), 12), (varint(12) + literal(b"abcdefgh") + copy(4, 9), 12)]:
+        with pytest.raises(native.CometNativeException, match="page 1: code"):
+            native.snappy2_inflate_pages([good, stream], [len(raw), n])
 
 
 def test_kernel_reports_corrupt_pages(built):

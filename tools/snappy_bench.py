@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the device snappy kernel alone (comet_snappy_inflate_pages) on Parquet-like pages: 1 MiB PLAIN pages of decimal(12,2)-as-INT64
+"""Time the device snappy decompressors alone (the multi-kernel pipeline comet_snappy2_inflate_pages and the one-wave-per-page kernel comet_snappy_inflate_pages) on Parquet-like pages: 1 MiB PLAIN pages of decimal(12,2)-as-INT64
 (TPC-H l_extendedprice: ~4 output bytes per snappy element), of doubles (incompressible: 64 KiB literals) and of low-cardinality int32.
 One JSON line: pages, decompressed bytes, kernel ms, GB/s of output."""
 import argparse
@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--pages", type=int, default=480)
     ap.add_argument("--page-bytes", type=int, default=1 << 20)
     ap.add_argument("--out", default="")
+    ap.add_argument("--skip-one-wave", action="store_true")
     a = ap.parse_args()
     import numpy as np
     import pyarrow as pa
@@ -32,13 +33,20 @@ def main():
         comp = [pa.compress(p, codec="snappy", asbytes=True) for p in distinct]
         pages = [distinct[i % 8] for i in range(a.pages)]
         streams = [comp[i % 8] for i in range(a.pages)]
-        best = None
-        for _ in range(3):
-            got, ms = native.snappy_inflate_pages(streams, [len(p) for p in pages])
-            best = ms if best is None else min(best, ms)
-        assert all(g == w for g, w in zip(got, pages))
         total = sum(map(len, pages))
-        res[name] = {"compressed_ratio": sum(map(len, streams)) / total, "kernel_ms": best, "out_GBps": total / best / 1e6}
+        res[name] = {"compressed_ratio": sum(map(len, streams)) / total}
+        for label, fn in (("pipeline", native.snappy2_inflate_pages), ("one_wave_per_page", native.snappy_inflate_pages)):
+            if label == "one_wave_per_page" and a.skip_one_wave:
+                continue
+            best = None
+            for _ in range(3):
+                r = fn(streams, [len(p) for p in pages])
+                got, ms = r[0], r[1]
+                best = ms if best is None else min(best, ms)
+            assert all(g == w for g, w in zip(got, pages))
+            res[name][label] = {"kernel_ms": best, "out_GBps": total / best / 1e6}
+            if label == "pipeline":
+                res[name][label]["pages_to_fallback"] = sum(1 for x in r[2] if x == 1)
     line = json.dumps(res)
     print(line)
     if a.out:
