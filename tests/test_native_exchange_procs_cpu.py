@@ -117,10 +117,13 @@ def test_a_peer_that_dies_mid_exchange_is_an_error_not_a_hang(host_lib, tmp_path
     wait_all(procs, timeout=60)
     assert time.time() - t0 < 40
     assert procs[2].returncode == 0
+    msgs = []
     for r in (0, 1):
         assert procs[r].returncode == 3
-        msg = (tmp_path / f"r{r}.arrow.err").read_text()
-        assert "rank 2" in msg and ("closed its connection" in msg or "is gone" in msg), msg
+        msgs.append((tmp_path / f"r{r}.arrow.err").read_text())
+        assert "closed its connection" in msgs[-1] or "is gone" in msgs[-1], msgs[-1]
+    # whoever notices first names the rank that died; the other survivor may only see that first one leave
+    assert any("rank 2" in m for m in msgs), msgs
 
 
 def test_a_silent_peer_times_out_with_its_name(host_lib, tmp_path):
