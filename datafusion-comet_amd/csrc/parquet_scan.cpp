@@ -1407,14 +1407,14 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     }
   }
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return col_bytes[a] > col_bytes[b]; });
-  // Measured on MI355X (profiles/r2_snappy_kernel.json): the kernel takes ~18 ms per 1 MiB page of 8-byte decimals whatever the number of
-  // pages up to 512 in flight (2 workgroups per CU), a host core decompresses the same bytes at ~1 GB/s.  Few host threads (a Spark task
-  // has one core) or many pages: the device wins; a small scan on a many-core host: the host threads do.
+  // Measured on MI355X (profiles/r3_snappy_pipeline.json): the multi-kernel pipeline inflates PLAIN pages at 70–80 GB/s of output whatever
+  // their number (it parallelises inside the pages), plus about half a millisecond of launches; a host core decompresses the same bytes at
+  // ~1 GB/s.  Only a small scan on a host with many idle threads is better off on the host.
   if (so.device_snappy_mode >= 0) {
     so.device_snappy = so.device_snappy_mode != 0;
   } else {
     const double host_ms = (double)plain_snappy_bytes / 1e6 / (double)std::max(1, std::min(max_inflight, ScanPool::get().size()));
-    const double device_ms = 18.0 * std::ceil((double)plain_snappy_bytes / (512.0 * 1048576.0));
+    const double device_ms = 0.5 + (double)plain_snappy_bytes / 60e6;
     so.device_snappy = plain_snappy_bytes > 0 && device_ms < host_ms;
   }
   if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy PLAIN pages, decompressed on the %s\n", (double)plain_snappy_bytes / 1e6, so.device_snappy ? "device" : "host");

@@ -11,10 +11,10 @@
 #include "snappy2.hpp"
 
 extern "C" {
-void sn2_launch_window(const void* pages, const int32_t* chunk_page, const uint8_t* bytes, void* fns, int64_t nchunks, void* st);
-void sn2_launch_chain(void* pages, int npages, const uint8_t* bytes, const void* fns, void* ins, uint32_t* status, void* st);
+void sn2_launch_window(const void* pages, const int32_t* chunk_page, const uint8_t* bytes, void* fns, const uint32_t* status, int64_t nchunks, void* st);
+void sn2_launch_chain(void* pages, int npages, const uint8_t* bytes, const void* fns, void* ins, int32_t* frag_chunk, uint32_t* status, void* st);
 void sn2_launch_emit(const void* pages, const int32_t* chunk_page, const uint8_t* bytes, const void* ins, void* elems, const uint32_t* status, int64_t nchunks, void* st);
-void sn2_launch_exec(const void* pages, const int32_t* frag_page, uint8_t* bytes, const void* elems, uint32_t* status, int64_t nfrags, void* st);
+void sn2_launch_exec(const void* pages, const int32_t* frag_page, uint8_t* bytes, const void* elems, const void* ins, const int32_t* frag_chunk, uint32_t* status, int64_t nfrags, void* st);
 void pq_launch_snappy_fallback(const PqInflate* jobs, int njobs, uint8_t* bytes, const uint32_t* status, uint32_t* err, void* st);
 }
 
@@ -40,10 +40,14 @@ void Snappy2Scratch::run(const PqInflate* jobs_host, const PqInflate* jobs_dev, 
     pl.pages[(size_t)i].elem_first = nelems;
     nelems += (i64)sl[(size_t)i] / 2 + 2;
   }
-  const size_t b_pages = sizeof(Page) * (size_t)njobs, b_cp = 4 * (size_t)pl.nchunks + 16, b_fp = 4 * (size_t)pl.nfrags + 16;
+  const size_t b_pages = sizeof(Page) * (size_t)njobs, b_cp = 4 * (size_t)pl.nchunks + 16, b_fp = 4 * (size_t)pl.nfrags + 16, b_st = 4 * (size_t)njobs + 16;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t o_pages = 0, o_cp = al(b_pages), o_fp = o_cp + al(b_cp), total = o_fp + al(b_fp);
+  const size_t o_pages = 0, o_cp = al(b_pages), o_fp = o_cp + al(b_cp), o_st = o_fp + al(b_fp), total = o_st + al(b_st);
   h_tables.ensure(total + 16);
+  // a page that did not compress (doubles, random keys) is one long literal per 64 KiB block: the one-wave kernel copies those at
+  // hundreds of GB/s and there is nothing for the pipeline to parallelise — routed there up front
+  uint32_t* st0 = (uint32_t*)((char*)h_tables.p + o_st);
+  for (int i = 0; i < njobs; i++) st0[i] = ((i64)sl[(size_t)i] * 100 >= (i64)dl[(size_t)i] * 97 && dl[(size_t)i] >= 4096) ? (uint32_t)ST_FALLBACK : (uint32_t)ST_OK;
   memcpy((char*)h_tables.p + o_pages, pl.pages.data(), b_pages);
   if (pl.nchunks) memcpy((char*)h_tables.p + o_cp, pl.chunk_page.data(), 4 * (size_t)pl.nchunks);
   if (pl.nfrags) memcpy((char*)h_tables.p + o_fp, pl.frag_page.data(), 4 * (size_t)pl.nfrags);
@@ -53,12 +57,13 @@ void Snappy2Scratch::run(const PqInflate* jobs_host, const PqInflate* jobs_dev, 
   ins.ensure(sizeof(ChunkIn) * (size_t)pl.nchunks + 16);
   elems.ensure(sizeof(Elem) * (size_t)nelems + 16);
   status.ensure(4 * (size_t)njobs + 16);
-  HIP_CHECK(hipMemsetAsync(status.p, 0, 4 * (size_t)njobs, st));
+  frag_chunk.ensure(4 * (size_t)pl.nfrags + 16);
   char* tb = (char*)tables.p;
-  sn2_launch_window(tb + o_pages, (const int32_t*)(tb + o_cp), bytes_dev, fns.p, pl.nchunks, st);
-  sn2_launch_chain(tb + o_pages, njobs, bytes_dev, fns.p, ins.p, (uint32_t*)status.p, st);
+  HIP_CHECK(hipMemcpyAsync(status.p, tb + o_st, 4 * (size_t)njobs, hipMemcpyDeviceToDevice, st));
+  sn2_launch_window(tb + o_pages, (const int32_t*)(tb + o_cp), bytes_dev, fns.p, (const uint32_t*)status.p, pl.nchunks, st);
+  sn2_launch_chain(tb + o_pages, njobs, bytes_dev, fns.p, ins.p, (int32_t*)frag_chunk.p, (uint32_t*)status.p, st);
   sn2_launch_emit(tb + o_pages, (const int32_t*)(tb + o_cp), bytes_dev, ins.p, elems.p, (const uint32_t*)status.p, pl.nchunks, st);
-  sn2_launch_exec(tb + o_pages, (const int32_t*)(tb + o_fp), bytes_dev, elems.p, (uint32_t*)status.p, pl.nfrags, st);
+  sn2_launch_exec(tb + o_pages, (const int32_t*)(tb + o_fp), bytes_dev, elems.p, ins.p, (const int32_t*)frag_chunk.p, (uint32_t*)status.p, pl.nfrags, st);
   // what the pipeline would not decode — legal streams that are not fragment-shaped — goes to the one-wave kernel; errors to `err`
   pq_launch_snappy_fallback(jobs_dev, njobs, bytes_dev, (const uint32_t*)status.p, err_dev, st);
   chunks_ += pl.nchunks;

@@ -9,7 +9,7 @@
 namespace comet {
 
 struct Snappy2Scratch {
-  DevBuf tables, fns, ins, elems, status;
+  DevBuf tables, fns, ins, elems, status, frag_chunk;
   PinnedBuf h_tables;
   int64_t chunks_ = 0, frags_ = 0;
   // jobs: the pages to decompress (offsets into bytes_dev; `preamble` filled in by the host, which has seen the compressed bytes), once

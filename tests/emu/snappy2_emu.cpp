@@ -28,18 +28,20 @@ extern "C" int64_t sn2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
   std::vector<u32> status((size_t)npages, 0);
   std::vector<ChunkFn> fns((size_t)pl.nchunks * kWin);
   std::vector<ChunkIn> ins((size_t)pl.nchunks);
+  std::vector<i32> frag_chunk((size_t)pl.nfrags + 1, 0);
   auto L = std::make_unique<ChunkLds>();
   // kernel A
   for (i64 c = 0; c < pl.nchunks; c++) {
     const Page& pg = pl.pages[(size_t)pl.chunk_page[(size_t)c]];
     const i64 chunk_pos = (i64)pg.body + (c - pg.chunk_first) * (i64)kChunk;
-    for (int t = 0; t < kWins; t++) chunk_tables(L.get(), bytes.data() + pg.src_off, pg.src_len, chunk_pos, t);
+    for (int t = 0; t < kWins; t++) chunk_stage(L.get(), bytes.data() + pg.src_off, pg.src_len, chunk_pos, t);
+    for (int t = 0; t < kWins; t++) chunk_tables(L.get(), pg.src_len, chunk_pos, t);
     for (int t = 0; t < kWins; t++) fns[(size_t)(c * kWin + t)] = chunk_compose(L.get(), t, (i64)pg.src_len - chunk_pos);
   }
   // kernel B
   for (int i = 0; i < npages; i++) {
     if (body[(size_t)i] == 0) { status[(size_t)i] = ST_ERR_PREAMBLE; continue; }
-    page_chain(&pl.pages[(size_t)i], bytes.data(), fns.data(), ins.data(), status.data(), i);
+    page_chain(&pl.pages[(size_t)i], bytes.data(), fns.data(), ins.data(), frag_chunk.data(), status.data(), i);
   }
   i64 nelems = 0;
   for (int i = 0; i < npages; i++) {
@@ -55,7 +57,8 @@ extern "C" int64_t sn2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
     if (in.entry == kNoEntry) continue;
     const Page& pg = pl.pages[(size_t)pi];
     const i64 chunk_pos = (i64)pg.body + (c - pg.chunk_first) * (i64)kChunk;
-    for (int t = 0; t < kWins; t++) chunk_tables(L.get(), bytes.data() + pg.src_off, pg.src_len, chunk_pos, t);
+    for (int t = 0; t < kWins; t++) chunk_stage(L.get(), bytes.data() + pg.src_off, pg.src_len, chunk_pos, t);
+    for (int t = 0; t < kWins; t++) chunk_tables(L.get(), pg.src_len, chunk_pos, t);
     chunk_window_entries(L.get(), in, (i64)pg.src_len - chunk_pos);
     for (int t = 0; t < kWins; t++) chunk_emit(L.get(), chunk_pos, pg.src_len, elems.data() + pg.elem_first, t);
   }
@@ -64,7 +67,7 @@ extern "C" int64_t sn2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
   int max_rounds = 0;
   for (i64 f = 0; f < pl.nfrags; f++) {
     const int pi = pl.frag_page[(size_t)f];
-    if (status[(size_t)pi] >= (u32)ST_ERR_PREAMBLE) continue;
+    if (status[(size_t)pi] != (u32)ST_OK) continue;
     const Page& pg = pl.pages[(size_t)pi];
     const u32 frag_out = (u32)(f - pg.frag_first) * (u32)kFrag;
     const u32 frag_end = frag_out + (u32)kFrag < (u32)pg.dst_len ? frag_out + (u32)kFrag : (u32)pg.dst_len;
@@ -72,17 +75,21 @@ extern "C" int64_t sn2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
     const Elem* pe = elems.data() + pg.elem_first;
     memset(X->src, 0xee, sizeof X->src);          // (uninitialised on the device: make a coverage bug visible)
     X->nbig = X->covered = X->changed = X->flags = 0;
-    u32 lo, hi;
-    frag_range(pe, pg.nelems, frag_out, frag_end, lo, hi);
+    X->lo = X->hi = 0xffffffffu;
+    const i32 fl = (i32)(f - pg.frag_first);
+    for (int t = 0; t < kExecThreads; t++)
+      frag_range_search(X.get(), pe, pg.nelems, ins.data() + pg.chunk_first, pg.nchunks, frag_chunk[(size_t)f], fl + 1 < pg.nfrags ? frag_chunk[(size_t)f + 1] : -1, frag_out, frag_end, t, kExecThreads);
+    const u32 lo = X->lo, hi = X->hi;
     const u8* src = bytes.data() + pg.src_off;
     u8* dst = bytes.data() + pg.dst_off;
     for (int t = 0; t < kExecThreads; t++) frag_scatter(X.get(), pe, lo, hi, frag_out, frag_end, src, dst, t, kExecThreads);
     for (int t = 0; t < kExecThreads; t++) frag_big_literals(X.get(), frag_out, src, dst, t, kExecThreads);
-    if (X->flags || X->covered != frag_len) {
+    if ((X->flags & 3u) || X->covered != frag_len) {
       const u32 code = (X->flags & 2u) ? (u32)ST_ERR_BAD_COPY : (X->flags & 1u) ? (u32)ST_FALLBACK : (u32)ST_ERR_LENGTH;
       if (code > status[(size_t)pi]) status[(size_t)pi] = code;
       continue;
     }
+    if (!(X->flags & 4u)) continue;
     int round = 0;
     for (; round < 18; round++) {
       bool any = false;
