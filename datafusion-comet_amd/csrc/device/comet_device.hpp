@@ -1680,24 +1680,48 @@ CDEV void agg_grouped_emit_body(const CometKParams& prm) {
   typedef Slot<P::NK, P::NW> S;
   const S* tbl = (const S*)prm.out[0];
   const i64 cap = prm.iarg[0];
-  // one atomic per WAVE reserves the output rows of its ready slots (a counter bumped once per group serialises at the L2: 1.13 M groups
-  // of SF100 Q3 took 0.83 ms that way); the order of the groups is unspecified either way
-  const int lane = lane_id();
-  for (i64 wbase = (i64)blockIdx.x * kBlock + (i64)wave_id() * kWave; wbase < cap; wbase += (i64)gridDim.x * kBlock) {
-    const i64 i = wbase + lane;
-    const bool ready = i < cap && tbl[i].state == kSlotReady;
-    const u64 b = __ballot(ready);
-    if (!b) continue;
-    const int leader = __ffsll((unsigned long long)b) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd((unsigned long long*)prm.out[1], (unsigned long long)__popcll(b));
-    const u32 lo = __shfl((u32)base, leader, kWave), hi = __shfl((u32)(base >> 32), leader, kWave);
-    if (ready) P::emit_group(prm, tbl[i].key, tbl[i].acc, (i64)((((u64)hi) << 32) | lo) + (i64)__popcll(b & ((1ull << lane) - 1ull)));
+  // ONE atomic per 2048 slots reserves the output rows of their ready groups: atomics on one address serialise at the L2 (~13 ns each —
+  // one per wave was 65 K of them, 0.83 ms for the 1.13 M groups of SF100 Q3 whatever else the kernel did); the groups' order is
+  // unspecified either way
+  const int lane = lane_id(), wv = wave_id();
+  constexpr int R = 8;
+  __shared__ u32 s_wave[kBlock / kWave];
+  __shared__ unsigned long long s_base;
+  for (i64 base = (i64)blockIdx.x * kBlock * R; base < cap; base += (i64)gridDim.x * kBlock * R) {
+    u32 ready = 0, before[R];
+    u32 run = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const i64 i = base + (i64)r * kBlock + threadIdx.x;
+      const bool rd = i < cap && tbl[i].state == kSlotReady;
+      const u64 b = __ballot(rd);
+      before[r] = run + (u32)__popcll(b & ((1ull << lane) - 1ull));
+      run += (u32)__popcll(b);
+      ready |= rd ? 1u << r : 0u;
+    }
+    if (lane == 0) s_wave[wv] = run;
+    __syncthreads();
+    u32 woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; w++) {
+      if (w < wv) woff += s_wave[w];
+      total += s_wave[w];
+    }
+    if (threadIdx.x == 0 && total) s_base = atomicAdd((unsigned long long*)prm.out[1], (unsigned long long)total);
+    __syncthreads();
+    if (ready) {
+      const i64 at = (i64)s_base + woff;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if ((ready >> r) & 1u) {
+          const i64 i = base + (i64)r * kBlock + threadIdx.x;
+          P::emit_group(prm, tbl[i].key, tbl[i].acc, at + before[r]);
+        }
+    }
+    __syncthreads();   // s_wave / s_base are reused
   }
 }
 
-// Move every group of an old table into a larger one (growth between chunks).
-//   prm.out[0] new table, iarg[0] new capacity, prm.out[3] old table, iarg[1] old capacity
 template <class P>
 CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
   typedef Slot<P::NK, P::NW> S;

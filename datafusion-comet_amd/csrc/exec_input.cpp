@@ -1,10 +1,35 @@
 // Plan inputs: host ArrowArrayStreams staged through pinned memory (casts, dictionaries, Utf8 rebasing), device streams consumed in place.
 #include "exec_internal.hpp"
+#include <emmintrin.h>
 #include <mutex>
 #include <set>
 #include <tuple>
 
 namespace comet {
+
+// Copy into pinned staging memory with streaming (non-temporal) stores: the destination is written once and next read by the DMA engine,
+// so pulling its cache lines in first (what ordinary stores do) only costs memory bandwidth — the staging copy, not PCIe, was what held
+// the host-stream path at 37–40 GB/s (one read + read-for-ownership + write per byte; glibc switches to streaming stores only for copies
+// far larger than the 128 KiB an 8192-row batch contributes per column).
+static void stream_copy(void* dst, const void* src, size_t n) {
+  char* d = (char*)dst;
+  const char* s = (const char*)src;
+  if (n < 4096) { memcpy(d, s, n); return; }
+  const size_t head = (size_t)(-(intptr_t)d) & 15;              // up to the destination's next 16-byte boundary
+  if (head) { memcpy(d, s, head); d += head; s += head; n -= head; }
+  size_t blocks = n / 64;
+  for (; blocks; blocks--, d += 64, s += 64) {
+    const __m128i a = _mm_loadu_si128((const __m128i*)s), b = _mm_loadu_si128((const __m128i*)(s + 16)), c = _mm_loadu_si128((const __m128i*)(s + 32)),
+                  e = _mm_loadu_si128((const __m128i*)(s + 48));
+    _mm_stream_si128((__m128i*)d, a);
+    _mm_stream_si128((__m128i*)(d + 16), b);
+    _mm_stream_si128((__m128i*)(d + 32), c);
+    _mm_stream_si128((__m128i*)(d + 48), e);
+  }
+  _mm_sfence();
+  if (n & 63) memcpy(d, s, n & 63);
+}
+
 // Pull host batches from the JVM stream until a chunk is full; copy through pinned staging to HBM.
 // Gather host batches of input `input` (up to max_rows rows) into one chunk resident in HBM.
 // Returns false when nothing was read (stream exhausted); `rows` may be 0 with more to come only for empty batches.
@@ -309,7 +334,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
         }
         j.uniform = uniform;
         const size_t nb = (size_t)(off_at(col, col->length) - base);
-        if (nb) memcpy((char*)stage_aux_[c]->p + j.pos, (const char*)col->buffers[2] + base, nb);
+        if (nb) stream_copy((char*)stage_aux_[c]->p + j.pos, (const char*)col->buffers[2] + base, nb);
       };
       if (rows >= (1 << 20) && sjobs.size() > 1) {
         const size_t parts = std::min<size_t>(16, sjobs.size());
@@ -400,10 +425,10 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
       // a large column: the batch copies are spread over the scan threads (one thread tops out near 10–15 GB/s, PCIe needs 45+)
       const size_t parts = std::min<size_t>(16, jobs.size());
       scan_pool_parallel(parts, [&](size_t pidx) {
-        for (size_t j = pidx; j < jobs.size(); j += parts) memcpy(jobs[j].dst, jobs[j].src, jobs[j].n);
+        for (size_t j = pidx; j < jobs.size(); j += parts) stream_copy(jobs[j].dst, jobs[j].src, jobs[j].n);
       });
     } else {
-      for (auto& j : jobs) memcpy(j.dst, j.src, j.n);
+      for (auto& j : jobs) stream_copy(j.dst, j.src, j.n);
     }
     dev_vals_[c]->ensure(vbytes + 16);
     HIP_CHECK(hipMemcpyAsync(dev_vals_[c]->p, stage_vals_[c]->p, vbytes, hipMemcpyHostToDevice, stream_));
@@ -431,7 +456,7 @@ bool ExecutionContext::pull_host_chunk() {
   int64_t rows = 0;
   // The first chunks are small and double up to chunkRows: nothing can overlap the staging of the FIRST chunk (the GPU and the link idle
   // while it is gathered), so it should be short; from then on chunk k + 1 is staged while chunk k crosses PCIe and is consumed.
-  if (ramp_rows_ <= 0) ramp_rows_ = std::max<int64_t>(chunk_rows_ / 16, std::min<int64_t>(chunk_rows_, 65536));
+  if (ramp_rows_ <= 0) ramp_rows_ = std::max<int64_t>(chunk_rows_ / 4, std::min<int64_t>(chunk_rows_, 65536));
   const int64_t want_rows = std::min<int64_t>(chunk_rows_, ramp_rows_);
   ramp_rows_ = std::min<int64_t>(chunk_rows_, ramp_rows_ * 2);
   if (!pull_host_table(0, in_types_, want_rows, views, has_valid, rows)) return false;
