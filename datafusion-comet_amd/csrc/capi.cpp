@@ -432,6 +432,15 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
   });
 }
 
+int64_t comet_snappy_view_read(const uint8_t* src, size_t src_len, int32_t max_elems, const int64_t* offsets, int32_t n, uint8_t* out) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    pq::SnappyView v;
+    if (!v.build(src, src_len, (size_t)max_elems)) return -1;
+    for (int32_t i = 0; i < n; i++) out[i] = v.at((size_t)offsets[i]);
+    return (int64_t)v.out_len;
+  });
+}
+
 int32_t comet_page_decompress(int32_t codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     pq::decompress(codec, src, src_len, dst, dst_len);

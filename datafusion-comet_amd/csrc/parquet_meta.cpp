@@ -490,6 +490,86 @@ PageHeader parse_page_header(const uint8_t* p, size_t avail) {
 
 size_t snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t want) { return snappy_prefix_impl(src, n, dst, want); }
 
+bool SnappyView::build(const uint8_t* src, size_t n, size_t max_elems) {
+  stream = src;
+  stream_len = n;
+  els.clear();
+  last = 0;
+  size_t i = 0;
+  uint64_t ulen = 0;
+  for (int sh = 0;; sh += 7) {
+    if (i >= n || sh > 28) return false;
+    const uint8_t b = src[i++];
+    ulen |= (uint64_t)(b & 0x7f) << sh;
+    if (!(b & 0x80)) break;
+  }
+  out_len = (size_t)ulen;
+  uint64_t o = 0;
+  while (i < n) {
+    if (els.size() >= max_elems) return false;
+    const uint8_t tag = src[i++];
+    El e;
+    e.out_pos = (uint32_t)o;
+    switch (tag & 3) {
+      case 0: {
+        uint32_t len = (tag >> 2) + 1;
+        if (len > 60) {
+          const uint32_t nb = len - 60;
+          if (i + nb > n) return false;
+          len = 0;
+          for (uint32_t k = 0; k < nb; k++) len |= (uint32_t)src[i + k] << (8 * k);
+          if (len == 0xffffffffu) return false;
+          len += 1;
+          i += nb;
+        }
+        if (i + len > n) return false;
+        e.len = len; e.src = (uint32_t)i; e.copy = 0;
+        i += len;
+        break;
+      }
+      case 1:
+        if (i >= n) return false;
+        e.len = ((tag >> 2) & 7) + 4; e.src = ((uint32_t)(tag >> 5) << 8) | src[i]; e.copy = 1;
+        i += 1;
+        break;
+      case 2:
+        if (i + 2 > n) return false;
+        e.len = (tag >> 2) + 1; e.src = (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8); e.copy = 1;
+        i += 2;
+        break;
+      default:
+        if (i + 4 > n) return false;
+        e.len = (tag >> 2) + 1; e.src = (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16) | ((uint32_t)src[i + 3] << 24); e.copy = 1;
+        i += 4;
+        break;
+    }
+    if (e.copy && (e.src == 0 || e.src > o)) return false;
+    o += e.len;
+    if (o > ulen) return false;
+    els.push_back(e);
+  }
+  return o == ulen;
+}
+
+uint8_t SnappyView::at(size_t o) const {
+  for (int depth = 0; depth < 4096; depth++) {
+    if (o >= out_len || els.empty()) throw CometError("snappy: read beyond the page");
+    size_t k = last;
+    if (k >= els.size() || els[k].out_pos > o || (size_t)els[k].out_pos + els[k].len <= o) {
+      if (k + 1 < els.size() && els[k + 1].out_pos <= o && (size_t)els[k + 1].out_pos + els[k + 1].len > o) k = k + 1;     // the usual case: reading forwards
+      else {
+        size_t a = 0, b = els.size();
+        while (a + 1 < b) { const size_t m = (a + b) / 2; if (els[m].out_pos <= o) a = m; else b = m; }
+        k = a;
+      }
+    }
+    const El& e = els[k];
+    if (!e.copy) { last = k; return stream[e.src + (o - e.out_pos)]; }
+    o = (size_t)e.out_pos - e.src + ((o - e.out_pos) % e.src);     // a copy: the byte `offset` back — for a copy that overlaps itself (offset < length) taken modulo the offset, so that every step lands BEFORE the element: at most one step per element
+  }
+  throw CometError("snappy: copy chain too deep for a sparse read");
+}
+
 PageIndex parse_page_index(const uint8_t* column_index, size_t ci_len, const uint8_t* offset_index, size_t oi_len) {
   PageIndex pi;
   {

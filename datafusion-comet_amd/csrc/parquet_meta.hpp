@@ -90,6 +90,21 @@ PageHeader parse_page_header(const uint8_t* p, size_t avail);
 void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len);
 // first `want` bytes of a raw snappy stream (the levels in front of a v1 page's values); returns the bytes produced
 size_t snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t want);
+
+// Random access to the OUTPUT of a raw snappy stream without producing it: the element list (a few entries per 64 KiB for data that
+// does not compress — bit-packed dictionary indices are such data) maps an output position to a literal byte of the compressed stream
+// or, through copies, to an earlier output position.  The scan reads the run headers of a dictionary-encoded page this way and ships
+// the page compressed for the device to inflate, instead of decompressing it on a host core just to look at a few hundred header bytes.
+struct SnappyView {
+  struct El { uint32_t out_pos, len, src; uint8_t copy; };
+  const uint8_t* stream = nullptr;
+  size_t stream_len = 0, out_len = 0;
+  std::vector<El> els;
+  mutable size_t last = 0;
+  // false: malformed, or more than max_elems elements (a page that compresses well: decompressing it is cheap, do that instead)
+  bool build(const uint8_t* src, size_t n, size_t max_elems);
+  uint8_t at(size_t o) const;      // byte o of the output; throws CometError on a malformed reference
+};
 // Value encodings the device kernels do not read are rewritten as PLAIN on the host (parquet-format Encodings.md): DELTA_BINARY_PACKED
 // (INT32 / INT64, `width` = 4 / 8), DELTA_LENGTH_BYTE_ARRAY (→ 4-byte length + bytes per value), BYTE_STREAM_SPLIT (`width` bytes per value).
 // `src` holds the page's value bytes; the PLAIN bytes are appended to `out`.  Throws on truncated or inconsistent input.

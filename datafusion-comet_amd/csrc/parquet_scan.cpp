@@ -213,7 +213,9 @@ bool iequals(const std::string& a, const std::string& b) {
 }
 
 // parse the run headers of an RLE/bit-packed hybrid section living at staged[pos, end)
-void parse_hybrid_runs(const uint8_t* staged, size_t pos, size_t end, int bw, int32_t max_values, std::vector<PqRun>& runs) {
+// `get(pos)` = byte at staged position pos: a pointer into decompressed bytes, or a sparse view of a still-compressed page (SnappyView)
+template <class Get>
+void parse_hybrid_runs_from(const Get& get, size_t pos, size_t end, int bw, int32_t max_values, std::vector<PqRun>& runs) {
   int32_t vstart = 0;
   const int vbytes = (bw + 7) / 8;
   while (pos < end && (max_values < 0 || vstart < max_values)) {
@@ -221,7 +223,7 @@ void parse_hybrid_runs(const uint8_t* staged, size_t pos, size_t end, int bw, in
     int sh = 0;
     while (true) {
       if (pos >= end) throw CometError("parquet: truncated hybrid run header");
-      uint8_t b = staged[pos++];
+      uint8_t b = get(pos++);
       h |= (uint64_t)(b & 0x7f) << sh;
       if (!(b & 0x80)) break;
       sh += 7;
@@ -241,7 +243,7 @@ void parse_hybrid_runs(const uint8_t* staged, size_t pos, size_t end, int bw, in
       uint32_t v = 0;
       for (int k = 0; k < vbytes; k++) {
         if (pos >= end) throw CometError("parquet: truncated RLE run");
-        v |= (uint32_t)staged[pos++] << (8 * k);
+        v |= (uint32_t)get(pos++) << (8 * k);
       }
       r.rle_value = v;
     }
@@ -249,6 +251,9 @@ void parse_hybrid_runs(const uint8_t* staged, size_t pos, size_t end, int bw, in
     vstart += r.count;
     runs.push_back(r);
   }
+}
+void parse_hybrid_runs(const uint8_t* staged, size_t pos, size_t end, int bw, int32_t max_values, std::vector<PqRun>& runs) {
+  parse_hybrid_runs_from([staged](size_t p) { return staged[p]; }, pos, end, bw, max_values, runs);
 }
 
 // ---- row-group pruning from column-chunk statistics (the reference pushes data_filters into DataFusion's ParquetSource, which
@@ -313,6 +318,7 @@ struct ScanOptions {
   // such pages hold and the host threads there are to decompress them (scan_parquet)
   int device_snappy_mode = -1;
   bool device_snappy = false;
+  bool device_dict_pages = true;       // dictionary-encoded snappy pages cross PCIe compressed too (COMET_DEVICE_DICT_PAGES=0: host-inflated as before)
   static ScanOptions of(const Operator& op) {
     ScanOptions o;
     o.case_sensitive = op.case_sensitive;
@@ -899,8 +905,18 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     size_t page_begin = spos, vals_begin, page_end;
     // Device decompression: PLAIN fixed-width values under snappy need nothing from the host but the definition levels (the first bytes
     // of a v1 page's stream; outside the stream in a v2 page), so the body crosses PCIe compressed and a GPU workgroup inflates it.
-    const bool dev_page = so.device_snappy && cm.codec == pq::SNAPPY && h.encoding == pq::PLAIN && !cp.is_string && h.uncompressed_size >= kMinDevicePage &&
-                          h.compressed_size <= h.uncompressed_size && (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.compressed_size > h.def_bytes));
+    const bool dev_shape = so.device_snappy && cm.codec == pq::SNAPPY && !cp.is_string && h.uncompressed_size >= kMinDevicePage &&
+                           h.compressed_size <= h.uncompressed_size && (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.compressed_size > h.def_bytes));
+    bool dev_page = dev_shape && h.encoding == pq::PLAIN;
+    // … and so do dictionary-encoded pages: the run headers of the index section are read THROUGH the compressed stream (SnappyView:
+    // bit-packed indices do not compress, the stream is a handful of long literals), so the host does not inflate 1 MiB to look at a few
+    // hundred header bytes — decompressing these pages on host threads was what the scan waited for once the PLAIN pages had moved to
+    // the device (SF10 Q6: 8 of 14 ms).  A page that compresses into many elements is inflated on the host as before (it is small).
+    pq::SnappyView view;
+    const bool dev_dict = dev_shape && !dev_page && (h.encoding == pq::RLE_DICTIONARY || h.encoding == pq::PLAIN_DICTIONARY) && so.device_dict_pages &&
+                          view.build(body + (h.type == pq::DATA_PAGE ? 0 : h.def_bytes), (size_t)h.compressed_size - (h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes), 2048) &&
+                          view.out_len == (size_t)h.uncompressed_size - (h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes);
+    dev_page = dev_page || dev_dict;
     if (dev_page) {
       const size_t ipage = (hc.ipos + 15) & ~(size_t)15;
       size_t comp_off = 0, comp_len = (size_t)h.compressed_size, un_len = (size_t)h.uncompressed_size, lvl = 0;
@@ -948,8 +964,39 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       hc.inflate.push_back(job);
       spos = cpos + comp_len;
       hc.ipos = ipage + un_len;
-      pg.encoding = 0;
-      pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
+      if (dev_dict) {
+        // the index section as the device will see it: [lvl] = bit width, then the hybrid runs; positions in the decompressed region
+        if (lvl + 1 > un_len) throw CometError("parquet: dictionary-encoded page without a bit width");
+        auto get = [&](size_t p) { return view.at(p - ipage); };
+        pg.encoding = 1;
+        pg.bit_width = get(ipage + lvl);
+        if (pg.bit_width > 32) throw CometError("parquet: dictionary index bit width > 32");
+        pg.values_off = (int64_t)(ipage + lvl + 1) | kInflatedBit;
+        const size_t first = idx_runs.size();
+        pg.idx_run_first = (int32_t)first;
+        if (pg.bit_width == 0) {
+          PqRun r;
+          memset(&r, 0, sizeof r);
+          r.is_rle = 1;
+          r.count = h.num_values;
+          idx_runs.push_back(r);
+        } else {
+          parse_hybrid_runs_from(get, ipage + lvl + 1, ipage + un_len, pg.bit_width, -1, idx_runs);
+          for (size_t r = first; r < idx_runs.size(); r++) idx_runs[r].byte_off |= kInflatedBit;
+        }
+        pg.idx_run_count = (int32_t)(idx_runs.size() - first);
+        if (pg.idx_run_count == 0) {   // page of NULLs only
+          PqRun r;
+          memset(&r, 0, sizeof r);
+          r.is_rle = 1;
+          r.count = h.num_values;
+          idx_runs.push_back(r);
+          pg.idx_run_count = 1;
+        }
+      } else {
+        pg.encoding = 0;
+        pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
+      }
       // the level bytes the runs refer to: a v1 page's were decoded into `tmp` (addressed in the coordinates of the decompressed region), a v2
       // page's were copied into the staged region
       emit(pg, values_seen, values_seen + h.num_values, h.type == pq::DATA_PAGE ? tmp.data() - ipage : staged);
@@ -1314,6 +1361,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (op.encryption_enabled) throw CometError("Parquet modular encryption is not supported by the GPU scan");
   ScanOptions so = ScanOptions::of(op);
   if (const char* e = getenv("COMET_DEVICE_DECOMPRESS")) so.device_snappy_mode = !strcmp(e, "auto") ? -1 : atoi(e) != 0;
+  if (const char* e = getenv("COMET_DEVICE_DICT_PAGES")) so.device_dict_pages = atoi(e) != 0;
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy_mode = kv.second == "auto" ? -1 : (kv.second != "false" && kv.second != "0");
   if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
@@ -1401,8 +1449,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
       const pq::ColumnMeta& cm = sels[si].meta->row_groups[(size_t)sels[si].rg].columns[(size_t)cp.leaf];
       col_bytes[c] += cm.total_compressed;
+      // snappy chunks of fixed-width columns are what the device inflates: PLAIN pages, and dictionary-encoded pages whose run headers the
+      // host reads through the compressed stream
       if (cm.codec == pq::SNAPPY && !cp.is_string && cp.src_width > 0 && cm.num_values > 0 &&
-          (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values)
+          (so.device_dict_pages || (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values))
         plain_snappy_bytes += cm.total_uncompressed;
     }
   }
@@ -1417,7 +1467,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const double device_ms = 0.5 + (double)plain_snappy_bytes / 60e6;
     so.device_snappy = plain_snappy_bytes > 0 && device_ms < host_ms;
   }
-  if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy PLAIN pages, decompressed on the %s\n", (double)plain_snappy_bytes / 1e6, so.device_snappy ? "device" : "host");
+  if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy pages of fixed-width columns, decompressed on the %s\n", (double)plain_snappy_bytes / 1e6, so.device_snappy ? "device" : "host");
   auto run_task = [&](size_t t) {
     const size_t c = t / nsel, si = t % nsel;
     ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg, sels[si].keep.get()};
@@ -1460,7 +1510,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     if (chunks[t].err) std::rethrow_exception(chunks[t].err);
   };
 
-  struct ColumnDevice { DevBuf bytes, tables; PinnedBuf h_tables; Snappy2Scratch snappy2; };
+  struct ColumnDevice { DevBuf bytes, tables; PinnedBuf h_tables; std::vector<std::unique_ptr<Snappy2Scratch>> snappy2; };
   std::vector<std::shared_ptr<ColumnDevice>> keep;
   hipStream_t copy_stream = nullptr;
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
@@ -1522,6 +1572,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     cd->bytes.ensure(may_inflate ? 2 * S + 64 : S);
     bool any_optional = false;
     size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0, n_jobs = 0;
+    static const bool one_wave_snappy = getenv("COMET_SNAPPY_ONE_WAVE") != nullptr && atoi(getenv("COMET_SNAPPY_ONE_WAVE")) != 0;
+    std::vector<PqInflate> group_jobs;
+    size_t group_bytes = 0;
     for (size_t si = 0; si < nsel; si++) {
       wait_for(c * nsel + si);
       HostChunk& hc = chunks[c * nsel + si];
@@ -1537,6 +1590,28 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       // only the bytes the chunk actually staged cross PCIe
       HIP_CHECK(hipMemcpyAsync((char*)cd->bytes.p + slot_off[c][si], (char*)col_staged[c]->p + slot_off[c][si],
                                std::min(hc.spos + 16, slot_off[c][si + 1] - slot_off[c][si]), hipMemcpyHostToDevice, copy_stream));
+      // Pages the device decompresses: the pipeline is launched for a GROUP of chunks as soon as their slices are across, so it runs
+      // while the column's later chunks are still being read and uploaded (launched once per column it started only after the last slice:
+      // 7 ms of decompression behind 10 ms of upload, SF10 Q6).  COMET_SNAPPY_ONE_WAVE=1 keeps the one-wave-per-page kernel, per column.
+      if (!one_wave_snappy)
+        for (const PqInflate& src : hc.inflate) {
+          PqInflate job = src;
+          job.src_off += (int64_t)slot_off[c][si];
+          job.dst_off += (int64_t)slot_off[c][si] + (int64_t)S;
+          group_jobs.push_back(job);
+          group_bytes += (size_t)job.src_len;
+        }
+      if (!group_jobs.empty() && (group_bytes >= ((size_t)48 << 20) || si + 1 == nsel)) {
+        if (group_jobs.size() >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
+        hipEvent_t gev = get_event();
+        HIP_CHECK(hipEventRecord(gev, copy_stream));
+        HIP_CHECK(hipStreamWaitEvent(stream_, gev, 0));
+        cd->snappy2.emplace_back(new Snappy2Scratch());
+        cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+        pages_inflated_on_device_ += (int64_t)group_jobs.size();
+        group_jobs.clear();
+        group_bytes = 0;
+      }
     }
     if (n_jobs && !may_inflate) throw CometError("internal: device pages in a column without a decompression region");
     if (trace) fprintf(stderr, "[comet] parquet: column %zu host chunks ready at %.2f ms\n", c, ms_since());
@@ -1610,12 +1685,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const char* tb = (const char*)cd->tables.p;
     if (n_jobs) {
       if (n_jobs >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
-      // the multi-kernel pipeline (snappy2.cpp: every lane of the GPU on the column's pages); COMET_SNAPPY_ONE_WAVE=1 keeps the one-wave-per-
-      // page kernel for comparison
-      static const bool one_wave = getenv("COMET_SNAPPY_ONE_WAVE") != nullptr && atoi(getenv("COMET_SNAPPY_ONE_WAVE")) != 0;
-      if (one_wave) pq_launch_snappy((const PqInflate*)(tb + off_jobs), (int)n_jobs, (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
-      else cd->snappy2.run((const PqInflate*)(tb_h + off_jobs), (const PqInflate*)(tb + off_jobs), (int)n_jobs, (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
-      pages_inflated_on_device_ += (int64_t)n_jobs;
+      // (the multi-kernel pipeline was launched group by group while the slices crossed PCIe, above)
+      if (one_wave_snappy) {
+        pq_launch_snappy((const PqInflate*)(tb + off_jobs), (int)n_jobs, (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+        pages_inflated_on_device_ += (int64_t)n_jobs;
+      }
     }
 
     PqDecodeArgs a;

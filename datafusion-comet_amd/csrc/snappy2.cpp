@@ -22,7 +22,7 @@ namespace comet {
 
 using namespace comet_snappy2;
 
-void Snappy2Scratch::run(const PqInflate* jobs_host, const PqInflate* jobs_dev, int njobs, uint8_t* bytes_dev, uint32_t* err_dev, hipStream_t st) {
+void Snappy2Scratch::run(const PqInflate* jobs_host, int njobs, uint8_t* bytes_dev, uint32_t* err_dev, hipStream_t st) {
   if (njobs <= 0) return;
   std::vector<i64> so((size_t)njobs), dof((size_t)njobs);
   std::vector<i32> sl((size_t)njobs), dl((size_t)njobs), body((size_t)njobs);
@@ -42,8 +42,10 @@ void Snappy2Scratch::run(const PqInflate* jobs_host, const PqInflate* jobs_dev, 
   }
   const size_t b_pages = sizeof(Page) * (size_t)njobs, b_cp = 4 * (size_t)pl.nchunks + 16, b_fp = 4 * (size_t)pl.nfrags + 16, b_st = 4 * (size_t)njobs + 16;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t o_pages = 0, o_cp = al(b_pages), o_fp = o_cp + al(b_cp), o_st = o_fp + al(b_fp), total = o_st + al(b_st);
+  const size_t b_jobs = sizeof(PqInflate) * (size_t)njobs;
+  const size_t o_pages = 0, o_cp = al(b_pages), o_fp = o_cp + al(b_cp), o_st = o_fp + al(b_fp), o_jobs = o_st + al(b_st), total = o_jobs + al(b_jobs);
   h_tables.ensure(total + 16);
+  memcpy((char*)h_tables.p + o_jobs, jobs_host, b_jobs);
   // a page that did not compress (doubles, random keys) is one long literal per 64 KiB block: the one-wave kernel copies those at
   // hundreds of GB/s and there is nothing for the pipeline to parallelise — routed there up front
   uint32_t* st0 = (uint32_t*)((char*)h_tables.p + o_st);
@@ -65,7 +67,7 @@ void Snappy2Scratch::run(const PqInflate* jobs_host, const PqInflate* jobs_dev, 
   sn2_launch_emit(tb + o_pages, (const int32_t*)(tb + o_cp), bytes_dev, ins.p, elems.p, (const uint32_t*)status.p, pl.nchunks, st);
   sn2_launch_exec(tb + o_pages, (const int32_t*)(tb + o_fp), bytes_dev, elems.p, ins.p, (const int32_t*)frag_chunk.p, (uint32_t*)status.p, pl.nfrags, st);
   // what the pipeline would not decode — legal streams that are not fragment-shaped — goes to the one-wave kernel; errors to `err`
-  pq_launch_snappy_fallback(jobs_dev, njobs, bytes_dev, (const uint32_t*)status.p, err_dev, st);
+  pq_launch_snappy_fallback((const PqInflate*)(tb + o_jobs), njobs, bytes_dev, (const uint32_t*)status.p, err_dev, st);
   chunks_ += pl.nchunks;
   frags_ += pl.nfrags;
 }
@@ -112,12 +114,12 @@ extern "C" int64_t comet_snappy2_inflate_pages(const uint8_t* streams, const int
     Snappy2Scratch sc;
     // the first call sizes the scratch buffers (allocation is not decompression): run once untimed when a time is asked for
     if (kernel_ms) {
-      sc.run(jobs.data(), (const PqInflate*)djobs.p, npages, (uint8_t*)bytes.p, (uint32_t*)derr.p, st);
+      sc.run(jobs.data(), npages, (uint8_t*)bytes.p, (uint32_t*)derr.p, st);
       HIP_CHECK(hipStreamSynchronize(st));
       HIP_CHECK(hipMemset(derr.p, 0, 4));
     }
     HIP_CHECK(hipEventRecord(e0, st));
-    sc.run(jobs.data(), (const PqInflate*)djobs.p, npages, (uint8_t*)bytes.p, (uint32_t*)derr.p, st);
+    sc.run(jobs.data(), npages, (uint8_t*)bytes.p, (uint32_t*)derr.p, st);
     HIP_CHECK(hipEventRecord(e1, st));
     HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;

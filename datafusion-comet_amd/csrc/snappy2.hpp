@@ -12,9 +12,9 @@ struct Snappy2Scratch {
   DevBuf tables, fns, ins, elems, status, frag_chunk;
   PinnedBuf h_tables;
   int64_t chunks_ = 0, frags_ = 0;
-  // jobs: the pages to decompress (offsets into bytes_dev; `preamble` filled in by the host, which has seen the compressed bytes), once
-  // in host memory and once on the device; err_dev: one word, first failing page as (page << 8 | code)
-  void run(const PqInflate* jobs_host, const PqInflate* jobs_dev, int njobs, uint8_t* bytes_dev, uint32_t* err_dev, hipStream_t st);
+  // jobs: the pages to decompress (offsets into bytes_dev; `preamble` filled in by the host, which has seen the compressed bytes), in host
+  // memory — uploaded with the pipeline's own tables; err_dev: one word, first failing page as (page << 8 | code)
+  void run(const PqInflate* jobs_host, int njobs, uint8_t* bytes_dev, uint32_t* err_dev, hipStream_t st);
 };
 
 }  // namespace comet

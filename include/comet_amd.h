@@ -188,6 +188,11 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
  * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and
  * comet_last_error(0). */
 int32_t comet_page_decompress(int32_t codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len);
+/* Diagnostic entry for the scan's sparse reads of snappy pages (parquet_meta.hpp SnappyView: the run headers of a dictionary-encoded page
+ * are read through the compressed stream, the page itself is inflated on the device): the bytes at `offsets` of the stream's OUTPUT.
+ * Returns the uncompressed length, -1 when the stream is malformed or has more than max_elems elements (the scan then inflates the
+ * page on the host), -2 on a reference outside the page (comet_last_error(0)). */
+int64_t comet_snappy_view_read(const uint8_t* src, size_t src_len, int32_t max_elems, const int64_t* offsets, int32_t n, uint8_t* out);
 
 /* ---- device-side page decompression (csrc/snappy_kernels.hip) — diagnostic entry ------------------------------------------------------
  * The Parquet scan ships snappy-compressed PLAIN data pages across PCIe as they are and one GPU workgroup per page decompresses them

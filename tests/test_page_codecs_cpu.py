@@ -83,3 +83,31 @@ def test_corrupted_page_bodies_fail_cleanly(built, codec, name):
             assert (buf[size:] == 0xA5).all(), (name, trial, "wrote past the output")
             outcomes["ok" if rc == 0 else "error"] += 1
     assert outcomes["error"] > 0, outcomes
+
+
+def test_sparse_reads_through_a_snappy_stream():
+    """pq::SnappyView (comet_snappy_view_read): bytes of a snappy stream's OUTPUT read without producing it — what the scan does for the run
+    headers of dictionary-encoded pages it ships compressed.  Against pyarrow's decompression: incompressible data (bit-packed indices: a few
+    long literals), text with overlapping copies, runs (offset 1); too many elements → -1 (the scan inflates that page on the host)."""
+    import ctypes
+    import numpy as np
+    import pyarrow as pa
+    from datafusion_comet_amd import native
+    lib = native.lib()
+    lib.comet_snappy_view_read.restype = ctypes.c_int64
+    rng = np.random.default_rng(3)
+    raws = [rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes(),
+            b"".join([b"abcabcabd" * 3000, bytes(5000), rng.integers(0, 64, 20_000, dtype=np.uint8).tobytes(), b"x" * 70_000]),
+            np.repeat(rng.integers(0, 50, 3000), 40).astype(np.int32).tobytes()]
+    for raw in raws:
+        stream = pa.compress(raw, codec="snappy", asbytes=True)
+        offs = np.concatenate([np.arange(0, min(len(raw), 5000)), rng.integers(0, len(raw), 4000), [len(raw) - 1]]).astype(np.int64)
+        out = np.zeros(len(offs), np.uint8)
+        rc = lib.comet_snappy_view_read(stream, ctypes.c_size_t(len(stream)), 1 << 20, ctypes.c_void_p(offs.ctypes.data), len(offs), ctypes.c_void_p(out.ctypes.data))
+        assert rc == len(raw)
+        assert out.tobytes() == bytes(raw[int(o)] for o in offs)
+        few = lib.comet_snappy_view_read(stream, ctypes.c_size_t(len(stream)), 2, ctypes.c_void_p(offs.ctypes.data), 1, ctypes.c_void_p(out.ctypes.data))
+        assert few in (-1, len(raw))
+    stream = pa.compress(raws[1], codec="snappy", asbytes=True)
+    assert lib.comet_snappy_view_read(stream, ctypes.c_size_t(len(stream)), 8, ctypes.c_void_p(offs.ctypes.data), 1, ctypes.c_void_p(out.ctypes.data)) == -1
+    assert lib.comet_snappy_view_read(stream[:-3], ctypes.c_size_t(len(stream) - 3), 1 << 20, ctypes.c_void_p(offs.ctypes.data), 1, ctypes.c_void_p(out.ctypes.data)) == -1
