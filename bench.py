@@ -23,6 +23,8 @@ every rank owns SF100 rows (weak scaling), rank 0 prints ONE JSON line.
                          stage A partition-local, Final on rank 0 (strong scaling); the answer is verified inside the leg against an
                          independent torch evaluation on the GPU (tpcds.q95_reference_torch, ≈ 1 s)
   cold_create_plan_ms    hiprtc compilation behind createPlan for the Q1 plan with an EMPTY code-object cache (tools/cold_plan.py)
+  q6_sf10_parquet        BASELINE configs[1]: SF10 Q6 from snappy / zstd Parquet end to end (tools/parquet_q6.py)
+  snappy_pipeline        the device snappy decompressor alone on 1 MiB pages (tools/snappy_bench.py)
 """
 import argparse
 import json
@@ -187,6 +189,12 @@ def main():
                 legs["pmc"] = measure_traffic(args, local_rank) if rank == 0 else None
             legs["cold_plan"] = run_child_leg([os.path.join(ROOT, "tools", "cold_plan.py"), "--query", "q1"], rank, local_rank, world, 120, 4017)
             if not args.no_paths:
+                # BASELINE configs[1]: TPC-H SF10 Q6 straight from Parquet (scan + 3-predicate filter + sum), end to end, snappy and zstd
+                for codec in ("snappy", "zstd"):
+                    legs["pq6_" + codec] = run_child_leg([os.path.join(ROOT, "tools", "parquet_q6.py"), "--codec", codec, "--steps", "4"],
+                                                         rank, local_rank, world, args.leg_timeout, 5017 + (0 if codec == "snappy" else 100))
+                legs["snappy"] = run_child_leg([os.path.join(ROOT, "tools", "snappy_bench.py"), "--pages", "240", "--skip-one-wave"], rank, local_rank, world, 180, 5317)
+            if not args.no_paths:
                 legs["paths"] = run_child_leg([os.path.join(ROOT, "tools", "paths.py"), "--query", "q1", "--rows", str(args.path_rows)],
                                               rank, local_rank, world, args.leg_timeout, 3017)
         # multi-GPU legs: the in-library exchange (RCCL send / recv groups inside libcomet.so) is probed first with a short timeout; if the
@@ -272,6 +280,15 @@ def main():
             line["q3"] = legs["q3"]
         if legs.get("q95") is not None:
             line["q95"] = legs["q95"]
+        pq6 = {c: legs.get("pq6_" + c) for c in ("snappy", "zstd") if legs.get("pq6_" + c) is not None}
+        if pq6:
+            line["q6_sf10_parquet"] = {c: ({"ms_best": v["sec_best"] * 1e3, "ms_median": v["sec_median"] * 1e3, "rows_per_s": v["rows_per_s"], "file_bytes": v["file_bytes"],
+                                            "matches_resident_plan": v["matches_resident_plan"], "pyarrow_read_s_all_cores": v["pyarrow_read_s_all_cores"]} if "error" not in v else v)
+                                       for c, v in pq6.items()}
+            line["q6_sf10_parquet"]["note"] = ("BASELINE configs[1] end to end (createPlan .. releasePlan over the file in the page cache): footer + page walk on the host, "
+                                               "snappy pages inflated on the device (multi-kernel pipeline), zstd pages on host threads, decode + fused Q6 kernel on the device")
+        if legs.get("snappy") is not None:
+            line["snappy_pipeline"] = legs["snappy"]
         if legs.get("cold_plan") is not None:
             cp = legs["cold_plan"]
             line["cold_create_plan_ms"] = cp.get("cold_create_plan_ms")

@@ -1986,9 +1986,10 @@ struct JoinGlobalTable {
         i64 k = (i64)i + 1;
         i32 fk = nf;
         while (k < nb && fk == kJoinFollower) {
+          const i32 fnext = k + 1 < nb ? next[k + 1] : 0;      // the next marker travels with this follower's key / condition loads: one latency per follower
           if (P::match(prm, k, j) && !f((u32)k)) return;
           k++;
-          fk = k < nb ? next[k] : 0;
+          fk = fnext;
         }
       }
       if (nx < 0) return;

@@ -348,8 +348,31 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
   i32 count = rn.count;
   if (rn.value_start + count > pg.value_count) count = pg.value_count - rn.value_start;   // the last bit-packed group of a page is padded to 8 values
   const int kind = pg.kind, width = pg.width, dec_up = pg.dec_scale_up;
+  // 4- and 8-byte outputs: a lane that stores ONE value per instruction moves 256 / 512 bytes per wave store — a quarter / half of what
+  // the 16-byte outputs move.  When the unit's first row is 16-byte aligned in the output, every lane takes VN CONSECUTIVE values instead
+  // and stores them as one 16-byte vector (1 KiB per wave store); l_shipdate-like columns (INT32 → Date32) ran at half the rate of the
+  // Decimal128 ones before.
+  constexpr int VN = OW == 4 ? 4 : OW == 8 ? 2 : 1;
+  typedef u32 V4 __attribute__((ext_vector_type(4)));
+  const bool vec = VN > 1 && ((((uintptr_t)out + (uintptr_t)row0 * (uintptr_t)OW) & 15u) == 0);
+  auto store_vec = [&](i32 j0, const i128* v, i32 nvalid) {      // values j0 … j0 + VN − 1 of the unit (nvalid of them exist)
+    if (nvalid >= VN) {
+      V4 x;
+      if (OW == 4) { x[0] = (u32)v[0]; x[1] = (u32)v[1]; x[2] = (u32)v[2]; x[3] = (u32)v[3]; }
+      else { const u64 a = (u64)v[0], b = (u64)v[VN - 1]; x[0] = (u32)a; x[1] = (u32)(a >> 32); x[2] = (u32)b; x[3] = (u32)(b >> 32); }
+      *(V4*)((u8*)out + (row0 + j0) * (i64)OW) = x;
+    } else {
+      for (int k = 0; k < nvalid; k++) pq_store<OW>(out, row0 + j0 + k, v[k]);
+    }
+  };
   if (rn.is_rle == 1) {
     const i128 v = pq_cv<CV>(kind, dict + (i64)rn.rle_value * width, width, dec_up);
+    if (vec) {
+      i128 vv[VN];
+      for (int k = 0; k < VN; k++) vv[k] = v;
+      for (i32 j0 = lane * VN; j0 < count; j0 += 64 * VN) store_vec(j0, vv, count - j0 < VN ? count - j0 : VN);
+      return;
+    }
     for (i32 j = lane; j < count; j += 64) pq_store<OW>(out, row0 + j, v);
     return;
   }
@@ -357,6 +380,25 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
   if (rn.is_rle == 2) {
     // PLAIN values (booleans: one bit per value)
     const u8* src = bytes + rn.byte_off;
+    if (vec && !(CV == 0 && kind == PQ_BOOL)) {
+      constexpr int G = U / VN > 0 ? U / VN : 1;       // vectors per lane and pass
+      for (i32 base = 0; base < count; base += 64 * VN * G) {
+        i128 v[G][VN];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+          for (int k = 0; k < VN; k++) {
+            const i32 j = base + (g * 64 + lane) * VN + k;
+            v[g][k] = j < count ? pq_cv<CV>(kind, src + (i64)j * width, width, dec_up) : (i128)0;
+          }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const i32 j0 = base + (g * 64 + lane) * VN;
+          if (j0 < count) store_vec(j0, v[g], count - j0 < VN ? count - j0 : VN);
+        }
+      }
+      return;
+    }
     for (i32 base = 0; base < count; base += 64 * U) {
       i128 v[U];
 #pragma unroll
@@ -392,6 +434,33 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const u64 mask = bw >= 32 ? 0xffffffffull : ((1ull << bw) - 1);
+    if (vec) {
+      constexpr int G = U / VN > 0 ? U / VN : 1;
+      for (i32 base = 0; base < count; base += 64 * VN * G) {
+        u32 idx[G][VN];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+          for (int k = 0; k < VN; k++) {
+            const i32 j = base + (g * 64 + lane) * VN + k;
+            const u32 bit = (u32)j * (u32)bw;
+            const u32 wi = bit >> 5;
+            idx[g][k] = j < count ? (u32)(((((u64)lds[wi + 1]) << 32 | lds[wi]) >> (bit & 31)) & mask) : 0u;
+          }
+        i128 v[G][VN];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+          for (int k = 0; k < VN; k++) v[g][k] = pq_cv<CV>(kind, dict + (i64)idx[g][k] * width, width, dec_up);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const i32 j0 = base + (g * 64 + lane) * VN;
+          if (j0 < count) store_vec(j0, v[g], count - j0 < VN ? count - j0 : VN);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();      // the slice is overwritten by the wave's next unit
+      return;
+    }
     for (i32 base = 0; base < count; base += 64 * U) {
       u32 idx[U];
 #pragma unroll
