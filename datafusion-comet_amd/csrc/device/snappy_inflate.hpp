@@ -49,7 +49,7 @@ struct Lds {
 #define SNAPPY_LDS
 #endif
 
-// src: 16-byte aligned, readable up to the next multiple of 16 past src_len.  dst: 16-byte aligned.  Returns an ERR_* code (uniform).
+// src: any alignment, readable up to the next multiple of 16 past src_len.  dst: 16-byte aligned.  Returns an ERR_* code (uniform).
 template <class W>
 SNAPPY_FN int inflate_page(W& w, SNAPPY_LDS Lds* lds, const u8* src, int src_len, u8* dst, int dst_len) {
   const int lane = w.lane();
@@ -60,7 +60,7 @@ SNAPPY_FN int inflate_page(W& w, SNAPPY_LDS Lds* lds, const u8* src, int src_len
   auto load_half = [&](int base) {
     V4 v = {0, 0, 0, 0};
     const int a = base + lane * 16;
-    if (a < src_len16) v = *(const V4*)(src + a);
+    if (a < src_len16) __builtin_memcpy(&v, src + a, 16);      // any alignment: a body read in place sits where the file put it
     return v;
   };
   int in_hi = 0;                // compressed bytes [in_hi - kIn, in_hi) are in `in`

@@ -46,6 +46,12 @@ typedef struct PqInflate {     /* one compressed page body the device decompress
   int32_t pad;
 } PqInflate;
 
+typedef struct PqCopyDesc {    /* one slice the upload kernel pulls from pinned host memory into HBM (both 16-byte aligned, len a multiple of 16) */
+  const uint8_t* src;
+  uint8_t* dst;
+  uint64_t len;
+} PqCopyDesc;
+
 /* output conversions */
 enum { PQ_COPY4 = 0, PQ_COPY8 = 1, PQ_I32_TO_I64 = 2, PQ_I32_TO_DEC = 3, PQ_I64_TO_DEC = 4, PQ_FLBA_TO_DEC = 5, PQ_BOOL = 6,
        PQ_I32_TO_I16 = 7, PQ_I32_TO_I8 = 8,

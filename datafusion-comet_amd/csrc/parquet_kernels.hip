@@ -680,6 +680,30 @@ static int grid_tiles(i64 n) {
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
+// Pulls slices of pinned host memory into HBM: workgroup (x, y) moves the x-th 64 KiB piece of slice y — sixteen 16-byte loads per thread
+// in flight across PCIe, then sixteen stores.  One launch moves every slice that is ready (parquet_scan.cpp: a hipMemcpyAsync per slice
+// costs ≈ 40 µs of latency whatever its size).
+__global__ __launch_bounds__(256) void pq_upload_kernel(const PqCopyDesc* __restrict__ descs) {
+  typedef unsigned V4 __attribute__((vector_size(16)));
+  const PqCopyDesc d = descs[blockIdx.y];
+  const u64 piece = (u64)blockIdx.x << 16;
+  if (piece >= d.len) return;
+  const u64 nvec = (d.len - piece < 65536 ? d.len - piece : 65536) >> 4;
+  const V4* src = (const V4*)(d.src + piece);
+  V4* dst = (V4*)(d.dst + piece);
+  V4 v[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const u64 i = (u64)threadIdx.x + (u64)k * 256;
+    if (i < nvec) v[k] = __builtin_nontemporal_load(src + i);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const u64 i = (u64)threadIdx.x + (u64)k * 256;
+    if (i < nvec) dst[i] = v[k];
+  }
+}
+
 extern "C" {
 void pq_launch_validity(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_validity_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st) {
@@ -705,5 +729,12 @@ void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t*
 }
 void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st) {
   hipLaunchKernelGGL(pq_pack_kernel, grid_rows(n), 256, 0, (hipStream_t)st, bytes, bitmap, (i64)n);
+}
+void pq_launch_upload(const PqCopyDesc* descs, int n, void* st) {
+  if (n <= 0) return;
+  uint64_t longest = 0;
+  for (int i = 0; i < n; i++) longest = std::max<uint64_t>(longest, descs[i].len);      // (the descriptors sit in pinned host memory: the host reads them too)
+  if (!longest) return;
+  hipLaunchKernelGGL(pq_upload_kernel, dim3((unsigned)((longest + 65535) >> 16), (unsigned)n), 256, 0, (hipStream_t)st, descs);
 }
 }

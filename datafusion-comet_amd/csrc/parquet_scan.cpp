@@ -41,6 +41,7 @@ void pq_launch_string_copy(const PqDecodeArgs* a, void* st);
 void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
 void pq_launch_pack(const uint8_t* bytes, uint8_t* bitmap, int64_t n, void* st);
 void pq_launch_snappy(const PqInflate* jobs, int njobs, uint8_t* bytes, uint32_t* err, void* st);
+void pq_launch_upload(const PqCopyDesc* descs, int n, void* st);
 }
 
 namespace comet {
@@ -318,6 +319,7 @@ struct ScanOptions {
   // such pages hold and the host threads there are to decompress them (scan_parquet)
   int device_snappy_mode = -1;
   bool device_snappy = false;
+  bool read_in_place = true;           // chunks whose pages the device inflates are pread() straight into their pinned slot; page bodies are uploaded from where they land (COMET_PARQUET_READ_IN_PLACE=0: read into scratch, copy bodies)
   bool device_dict_pages = true;       // dictionary-encoded snappy pages cross PCIe compressed too (COMET_DEVICE_DICT_PAGES=0: host-inflated as before)
   static ScanOptions of(const Operator& op) {
     ScanOptions o;
@@ -679,6 +681,7 @@ struct HostChunk {
   int64_t n_rows = 0;
   int64_t compressed = 0;
   size_t spos = 0;                 // staged (uploaded) bytes actually used
+  size_t raw_lo = 0, raw_hi = 0;   // slot-relative extent of the page bodies that were read in place (behind the staged bytes) and cross PCIe from there
   size_t ipos = 0;                 // bytes of the device-decompressed region used
   int64_t pages_skipped = 0;       // data pages the page index ruled out
   std::vector<PqInflate> inflate;  // page bodies the device decompresses (offsets relative to the chunk's slot in either region)
@@ -752,11 +755,17 @@ size_t prefix_encoded_plain_bytes(const ChunkSource& src, const pq::ColumnMeta& 
   return total;
 }
 // staging slot of one column chunk: its declared size, what DELTA pages add, and for prefix-compressed strings what they measure to
-size_t chunk_staging_capacity(const ChunkSource& src, const pq::ColumnMeta& cm, int max_def) {
-  return staged_capacity(cm) + (cm.prefix_encoded ? ((prefix_encoded_plain_bytes(src, cm, max_def) + 15) & ~(size_t)15) : 0);
+// A chunk that is read in place gets the file's bytes BEHIND what the host may stage: [0, front) as before, [front, front + raw) the chunk as
+// it sits in the file.  Page bodies the device inflates cross PCIe from there — the second pass over them (scratch → staging) was half of
+// the host's work per scan once the device did the decompression.
+size_t in_place_extra(const pq::ColumnMeta& cm) { return ((size_t)std::max<int64_t>(cm.total_compressed, 0) + 64 + 15) & ~(size_t)15; }
+bool in_place_shape(const pq::ColumnMeta& cm, bool is_string, const ScanOptions& so) { return so.read_in_place && cm.codec == pq::SNAPPY && !is_string && !cm.prefix_encoded; }
+size_t chunk_staging_capacity(const ChunkSource& src, const pq::ColumnMeta& cm, int max_def, bool is_string, const ScanOptions& so) {
+  return staged_capacity(cm) + (cm.prefix_encoded ? ((prefix_encoded_plain_bytes(src, cm, max_def) + 15) & ~(size_t)15) : 0) +
+         (in_place_shape(cm, is_string, so) ? in_place_extra(cm) : 0);
 }
 
-void decode_chunk_host(const ChunkSource& src, const StructField& want, const ScanOptions& so, HostChunk& hc, uint8_t* staged, size_t staged_cap) {
+void decode_chunk_host(const ChunkSource& src, const StructField& want, const ScanOptions& so, HostChunk& hc, uint8_t* staged, size_t slot_cap) {
   const pq::RowGroup& rg = src.meta->row_groups[(size_t)src.rg];
   ColumnPlan cp = plan_column(want, *src.meta, so);
   if (cp.missing) throw CometError("internal: chunk task for a missing column");
@@ -777,11 +786,21 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   int64_t off = (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < cm.data_page_offset) ? cm.dictionary_page_offset : cm.data_page_offset;
   const int64_t chunk_end = off + cm.total_compressed;
   if (off < 0 || (size_t)chunk_end > src.file->size) throw CometError("parquet: column chunk outside the file");
-  // the whole (compressed) chunk into this thread's scratch, then parse from memory
+  // the whole (compressed) chunk into the back of its slot when the device will inflate its pages (their bodies are uploaded from where they
+  // land), else into this thread's scratch; then parse from memory
   static thread_local std::vector<uint8_t> raw;
-  if (raw.size() < (size_t)cm.total_compressed + 16) raw.resize((size_t)cm.total_compressed + 16);
-  src.file->read_at(raw.data(), (size_t)cm.total_compressed, off);
-  const uint8_t* chunk_data = raw.data() - off;   // so that chunk_data + file_offset addresses the byte
+  size_t staged_cap = slot_cap;
+  const bool in_place = so.device_snappy && in_place_shape(cm, cp.is_string, so) && slot_cap >= in_place_extra(cm) + 256;
+  uint8_t* rawp;
+  if (in_place) {
+    staged_cap = slot_cap - in_place_extra(cm);
+    rawp = staged + staged_cap;
+  } else {
+    if (raw.size() < (size_t)cm.total_compressed + 16) raw.resize((size_t)cm.total_compressed + 16);
+    rawp = raw.data();
+  }
+  src.file->read_at(rawp, (size_t)cm.total_compressed, off);
+  const uint8_t* chunk_data = rawp - off;         // so that chunk_data + file_offset addresses the byte
   int64_t values_seen = 0;      // rows of the row group the pages walked so far cover
   int64_t out_pos = 0;          // kept rows emitted so far (the chunk's output rows)
   size_t keep_i = 0;            // first kept range that may still overlap the next page
@@ -905,8 +924,11 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     size_t page_begin = spos, vals_begin, page_end;
     // Device decompression: PLAIN fixed-width values under snappy need nothing from the host but the definition levels (the first bytes
     // of a v1 page's stream; outside the stream in a v2 page), so the body crosses PCIe compressed and a GPU workgroup inflates it.
+    // (a page that did not compress — bit-packed dictionary indices of random values, doubles — is a little LARGER than its content: read
+    // in place it crosses as it is and the one-wave kernel copies it at HBM speed; staged by copy it must fit the slot's uncompressed size)
+    const int64_t dev_max_compressed = in_place ? (int64_t)h.uncompressed_size + h.uncompressed_size / 6 + 64 : (int64_t)h.uncompressed_size;
     const bool dev_shape = so.device_snappy && cm.codec == pq::SNAPPY && !cp.is_string && h.uncompressed_size >= kMinDevicePage &&
-                           h.compressed_size <= h.uncompressed_size && (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.compressed_size > h.def_bytes));
+                           h.compressed_size <= dev_max_compressed && (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.compressed_size > h.def_bytes));
     bool dev_page = dev_shape && h.encoding == pq::PLAIN;
     // … and so do dictionary-encoded pages: the run headers of the index section are read THROUGH the compressed stream (SnappyView:
     // bit-packed indices do not compress, the stream is a handful of long literals), so the host does not inflate 1 MiB to look at a few
@@ -950,10 +972,19 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
         comp_len -= (size_t)h.def_bytes;
         un_len -= (size_t)h.def_bytes;
       }
-      const size_t cpos = (spos + 15) & ~(size_t)15;
-      if (cpos + comp_len + 32 > staged_cap || ipage + un_len + 32 > staged_cap) throw CometError("parquet: column chunk larger than its declared uncompressed size");
-      memcpy(staged + cpos, body + comp_off, comp_len);
-      memset(staged + cpos + comp_len, 0, 16);
+      size_t cpos;
+      if (in_place) {
+        // the body stays where pread() put it (any alignment; the bytes behind it are the next page's header or the slot's slack)
+        cpos = (size_t)(body + comp_off - staged);
+        if (ipage + un_len + 32 > staged_cap) throw CometError("parquet: column chunk larger than its declared uncompressed size");
+        if (hc.raw_hi == 0) hc.raw_lo = cpos;
+        hc.raw_hi = cpos + comp_len;
+      } else {
+        cpos = (spos + 15) & ~(size_t)15;
+        if (cpos + comp_len + 32 > staged_cap || ipage + un_len + 32 > staged_cap) throw CometError("parquet: column chunk larger than its declared uncompressed size");
+        memcpy(staged + cpos, body + comp_off, comp_len);
+        memset(staged + cpos + comp_len, 0, 16);
+      }
       PqInflate job;
       job.src_off = (int64_t)cpos;
       job.dst_off = (int64_t)ipage;
@@ -962,7 +993,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       job.preamble = comet_snappy2::preamble_length(body + comp_off, (int32_t)comp_len);     // where the stream's first element starts
       job.pad = 0;
       hc.inflate.push_back(job);
-      spos = cpos + comp_len;
+      if (!in_place) spos = cpos + comp_len;
       hc.ipos = ipage + un_len;
       if (dev_dict) {
         // the index section as the device will see it: [lvl] = bit width, then the hybrid runs; positions in the decompressed region
@@ -1325,7 +1356,7 @@ std::vector<uint8_t> parquet_host_plain_values(const Operator& op, size_t col) {
     if (cp.missing) continue;
     const pq::ColumnMeta& cm = sl.meta->row_groups[(size_t)sl.rg].columns[(size_t)cp.leaf];
     ChunkSource src{sl.file.get(), sl.meta.get(), sl.rg, nullptr};
-    std::vector<uint8_t> staged(chunk_staging_capacity(src, cm, cp.el.repetition == 1 ? 1 : 0) + 64);
+    std::vector<uint8_t> staged(chunk_staging_capacity(src, cm, cp.el.repetition == 1 ? 1 : 0, cp.is_string, so) + 64);
     HostChunk hc;
     decode_chunk_host(src, op.required_schema[col], so, hc, staged.data(), staged.size());
     for (const PqPage& pg : hc.pages) {
@@ -1362,6 +1393,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   ScanOptions so = ScanOptions::of(op);
   if (const char* e = getenv("COMET_DEVICE_DECOMPRESS")) so.device_snappy_mode = !strcmp(e, "auto") ? -1 : atoi(e) != 0;
   if (const char* e = getenv("COMET_DEVICE_DICT_PAGES")) so.device_dict_pages = atoi(e) != 0;
+  if (const char* e = getenv("COMET_PARQUET_READ_IN_PLACE")) so.read_in_place = atoi(e) != 0;
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy_mode = kv.second == "auto" ? -1 : (kv.second != "false" && kv.second != "0");
   if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
@@ -1412,7 +1444,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         cap_bytes = synth_capacity(op.required_schema[c].dtype, rg.num_rows);
       } else {
         ChunkSource csrc{sels[si].file.get(), sels[si].meta.get(), sels[si].rg, nullptr};
-        cap_bytes = chunk_staging_capacity(csrc, rg.columns[(size_t)cp.leaf], cp.el.repetition == 1 ? 1 : 0);   // reads the chunk only if it holds DELTA_BYTE_ARRAY pages
+        cap_bytes = chunk_staging_capacity(csrc, rg.columns[(size_t)cp.leaf], cp.el.repetition == 1 ? 1 : 0, cp.is_string, so);   // reads the chunk only if it holds DELTA_BYTE_ARRAY pages
       }
       slot_off[c][si + 1] = slot_off[c][si] + cap_bytes;
     }
@@ -1512,21 +1544,75 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
 
   struct ColumnDevice { DevBuf bytes, tables; PinnedBuf h_tables; std::vector<std::unique_ptr<Snappy2Scratch>> snappy2; };
   std::vector<std::shared_ptr<ColumnDevice>> keep;
+  // The chunks' slices cross PCIe as soon as they are ready, one hipMemcpyAsync each (≈ 40 µs of submission and completion latency per copy
+  // whatever its size).  Two alternatives sit behind switches because they were measured and lost (SF10 Q6 from snappy Parquet, 16.6 ms
+  // with one copy per slice): COMET_PQ_UPLOAD=kernel batches the ready slices into ONE launch of a kernel that reads the pinned staging
+  // memory across PCIe itself (22.5 ms: the SDMA engines move a slice at 50+ GB/s, a kernel's reads of host memory reach half of that);
+  // COMET_PQ_COPY_STREAMS=n spreads the copies over n streams (17–18 ms, noisier).
   hipStream_t copy_stream = nullptr;
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  std::vector<hipStream_t> extra_streams;
   std::vector<hipEvent_t> events;
+  PinnedBuf upload_descs;
   struct StreamGuard {
-    hipStream_t& s; std::vector<hipEvent_t>& ev;
+    hipStream_t& s; std::vector<hipStream_t>& extra; std::vector<hipEvent_t>& ev;
     ~StreamGuard() {
+      for (hipStream_t x : extra) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); }
       if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
       for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     }
-  } stream_guard{copy_stream, events};
+  } stream_guard{copy_stream, extra_streams, events};
   auto get_event = [&]() {
     hipEvent_t e;
     HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     events.push_back(e);
     return e;
+  };
+  static const bool upload_by_kernel = getenv("COMET_PQ_UPLOAD") && !strcmp(getenv("COMET_PQ_UPLOAD"), "kernel");
+  static const int n_copy_streams = getenv("COMET_PQ_COPY_STREAMS") ? std::max(1, std::min(8, atoi(getenv("COMET_PQ_COPY_STREAMS")))) : 1;
+  for (int k = 1; k < n_copy_streams && !upload_by_kernel; k++) {
+    hipStream_t x;
+    HIP_CHECK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    extra_streams.push_back(x);
+  }
+  const size_t max_descs = ntasks * 2 + ncol + 16;
+  upload_descs.ensure(max_descs * sizeof(PqCopyDesc) + 64);
+  size_t descs_used = 0, batch_first = 0, rr = 0;
+  std::vector<char> stream_dirty(extra_streams.size() + 1, 0);
+  auto upload = [&](void* dst, const void* src, size_t len) {
+    if (!len) return;
+    if (upload_by_kernel) {
+      if (descs_used >= max_descs) throw CometError("internal: upload descriptor array too small");
+      PqCopyDesc& d = ((PqCopyDesc*)upload_descs.p)[descs_used++];
+      d.src = (const uint8_t*)src;
+      d.dst = (uint8_t*)dst;
+      d.len = (uint64_t)len;
+    } else {
+      const size_t k = rr++ % (extra_streams.size() + 1);
+      HIP_CHECK(hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, k ? extra_streams[k - 1] : copy_stream));
+      stream_dirty[k] = 1;
+    }
+  };
+  // everything queued so far is on its way (kernel path: one launch for the batch)
+  auto upload_flush = [&]() {
+    if (upload_by_kernel && descs_used > batch_first) {
+      pq_launch_upload((const PqCopyDesc*)upload_descs.p + batch_first, (int)(descs_used - batch_first), copy_stream);
+      batch_first = descs_used;
+    }
+  };
+  // `waiter` runs behind every upload queued so far
+  auto upload_fence = [&](hipStream_t waiter) {
+    upload_flush();
+    hipEvent_t e = get_event();
+    HIP_CHECK(hipEventRecord(e, copy_stream));
+    HIP_CHECK(hipStreamWaitEvent(waiter, e, 0));
+    for (size_t k = 0; k < extra_streams.size(); k++)
+      if (stream_dirty[k + 1]) {
+        hipEvent_t x = get_event();
+        HIP_CHECK(hipEventRecord(x, extra_streams[k]));
+        HIP_CHECK(hipStreamWaitEvent(waiter, x, 0));
+        stream_dirty[k + 1] = 0;
+      }
   };
   auto tiles = std::make_shared<DevBuf>();
   tiles->ensure((size_t)((total_rows + 1023) / 1024 + 2) * 8);
@@ -1578,6 +1664,12 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     for (size_t si = 0; si < nsel; si++) {
       wait_for(c * nsel + si);
       HostChunk& hc = chunks[c * nsel + si];
+      // is the chunk behind this one ready too?  Then its slices join this batch (one launch for all of them)
+      bool next_ready = false;
+      if (si + 1 < nsel) {
+        std::lock_guard<std::mutex> lk(prog->mu);
+        next_ready = prog->done[c * nsel + si + 1] != 0;
+      }
       bytes_scanned_ += hc.compressed;
       any_optional |= hc.max_def > 0 && !hc.no_nulls;
       n_pages += hc.pages.size();
@@ -1588,8 +1680,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       n_soffs += hc.str_offs.size();
       n_jobs += hc.inflate.size();
       // only the bytes the chunk actually staged cross PCIe
-      HIP_CHECK(hipMemcpyAsync((char*)cd->bytes.p + slot_off[c][si], (char*)col_staged[c]->p + slot_off[c][si],
-                               std::min(hc.spos + 16, slot_off[c][si + 1] - slot_off[c][si]), hipMemcpyHostToDevice, copy_stream));
+      if (hc.spos) upload((char*)cd->bytes.p + slot_off[c][si], (char*)col_staged[c]->p + slot_off[c][si], std::min((hc.spos + 16 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]));
+      if (hc.raw_hi > hc.raw_lo) {      // page bodies read in place: from where pread() put them (+ the few bytes behind the last one the kernels' vector loads touch)
+        const size_t lo = hc.raw_lo & ~(size_t)15, hi = std::min((hc.raw_hi + 32 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]);
+        upload((char*)cd->bytes.p + slot_off[c][si] + lo, (char*)col_staged[c]->p + slot_off[c][si] + lo, hi - lo);
+      }
       // Pages the device decompresses: the pipeline is launched for a GROUP of chunks as soon as their slices are across, so it runs
       // while the column's later chunks are still being read and uploaded (launched once per column it started only after the last slice:
       // 7 ms of decompression behind 10 ms of upload, SF10 Q6).  COMET_SNAPPY_ONE_WAVE=1 keeps the one-wave-per-page kernel, per column.
@@ -1601,11 +1696,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
           group_jobs.push_back(job);
           group_bytes += (size_t)job.src_len;
         }
-      if (!group_jobs.empty() && (group_bytes >= ((size_t)48 << 20) || si + 1 == nsel)) {
+      const bool group_full = !group_jobs.empty() && (group_bytes >= ((size_t)48 << 20) || si + 1 == nsel);
+      if (!next_ready || group_full) upload_flush();
+      if (group_full) {
         if (group_jobs.size() >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
-        hipEvent_t gev = get_event();
-        HIP_CHECK(hipEventRecord(gev, copy_stream));
-        HIP_CHECK(hipStreamWaitEvent(stream_, gev, 0));
+        upload_fence(stream_);
         cd->snappy2.emplace_back(new Snappy2Scratch());
         cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
         pages_inflated_on_device_ += (int64_t)group_jobs.size();
@@ -1678,10 +1773,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       if (n_pages >= ((size_t)1 << 31) || n_idx >= ((size_t)1 << 31)) throw CometError("parquet: too many pages / runs in one column");
     }
     cd->tables.ensure(o + 16);
-    HIP_CHECK(hipMemcpyAsync(cd->tables.p, cd->h_tables.p, o, hipMemcpyHostToDevice, copy_stream));
-    hipEvent_t ev = get_event();
-    HIP_CHECK(hipEventRecord(ev, copy_stream));
-    HIP_CHECK(hipStreamWaitEvent(stream_, ev, 0));
+    upload(cd->tables.p, cd->h_tables.p, (o + 15) & ~(size_t)15);
+    upload_fence(stream_);
     const char* tb = (const char*)cd->tables.p;
     if (n_jobs) {
       if (n_jobs >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");

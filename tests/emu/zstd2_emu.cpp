@@ -1,0 +1,130 @@
+// TEST INFRASTRUCTURE: the zstd pipeline (csrc/device/zstd2.hpp — the SAME source the gfx950 kernels compile) run on the host: the threads
+// of a workgroup run one after the other inside each phase, the workgroups one after the other, workgroup memory is an ordinary struct.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "device/zstd2.hpp"
+
+using namespace comet_zstd2;
+
+// → 0; status_out[i]: 0 decoded, 1 the host walk would not send the page to the device, ≥ 16 corrupt
+extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* stream_off, const int32_t* stream_len, const int32_t* page_len, int32_t npages,
+                                         uint8_t* out, const int64_t* out_off, uint32_t* status_out, int32_t* info_out /* [0] max jump rounds, [1] blocks, [2] records, [3] literal bytes, [4 … 19] PageWalk::seen summed */) {
+  auto up16 = [](int64_t v) { return (v + 15) & ~(int64_t)15; };
+  std::vector<ZPage> pages((size_t)npages);
+  std::vector<ZBlock> blocks;
+  std::vector<i32> block_page;
+  std::vector<u32> status((size_t)npages, 0);
+  i64 in_total = 0, out_total = 0, nrecs = 0, nlits = 0;
+  i64 seen[16] = {0};
+  for (int i = 0; i < npages; i++) { pages[(size_t)i].src_off = in_total; in_total = up16(in_total + stream_len[i]) + 16; }
+  for (int i = 0; i < npages; i++) { pages[(size_t)i].dst_off = in_total + out_total; out_total = up16(out_total + page_len[i]) + 16; }
+  std::vector<u8> bytes((size_t)(in_total + out_total) + 1024, 0);
+  for (int i = 0; i < npages; i++) {
+    ZPage& pg = pages[(size_t)i];
+    memcpy(bytes.data() + pg.src_off, streams + stream_off[i], (size_t)stream_len[i]);
+    pg.src_len = stream_len[i];
+    pg.dst_len = page_len[i];
+    PageWalk w;
+    pg.block_first = (i32)blocks.size();
+    pg.nblocks = 0;
+    pg.nrecs = 0;
+    pg.rec_first = nrecs;
+    pg.lit_first = nlits;
+    if (!scan_page(streams + stream_off[i], (u32)stream_len[i], (u32)page_len[i], w)) { status[(size_t)i] = 1; continue; }
+    pg.nblocks = (i32)w.blocks.size();
+    for (int k = 0; k < 16; k++) seen[k] += w.seen[k];
+    for (const ZBlock& b : w.blocks) { blocks.push_back(b); block_page.push_back(i); }
+    pg.nrecs = w.nrecs;
+    nrecs += w.nrecs;
+    nlits += w.nlits;
+  }
+  std::vector<ZRec> recs((size_t)nrecs + 1);
+  std::vector<u8> lits((size_t)nlits + 64, 0xcd);
+  // kernel A
+  auto E = std::make_unique<EntLds>();
+  for (size_t bi = 0; bi < blocks.size(); bi++) {
+    const int pi = block_page[bi];
+    const ZPage& pg = pages[(size_t)pi];
+    ZBlock& b = blocks[bi];
+    const u8* src = bytes.data() + pg.src_off;
+    memset(E.get(), 0xee, sizeof(EntLds));
+    E->status = 0;
+    E->huf_log = 0;
+    ent_huf_table(E.get(), src, b);                              // thread 0
+    ent_seq_tables(E.get(), src, b, (u32)pg.src_len);            // thread 64
+    for (int t = 0; t < 64; t++) ent_literals(E.get(), src, b, lits.data() + pg.lit_first, t);
+    ent_sequences(E.get(), src, &b, recs.data() + pg.rec_first); // thread 64
+    if (E->status && E->status > status[(size_t)pi]) status[(size_t)pi] = E->status;
+  }
+  // kernel B
+  for (int i = 0; i < npages; i++)
+    if (status[(size_t)i] == ST_OK) page_blocks(pages[(size_t)i], blocks.data(), status.data(), i);
+  // kernel C
+  auto S = std::make_unique<ScanLds>();
+  for (size_t bi = 0; bi < blocks.size(); bi++) {
+    const int pi = block_page[bi];
+    if (status[(size_t)pi] != ST_OK) continue;
+    const ZPage& pg = pages[(size_t)pi];
+    const ZBlock& b = blocks[bi];
+    ZRec* r = recs.data() + pg.rec_first + b.rec_first;
+    const u32 n = b.nseq + 1;
+    S->carry_out = b.out_base;
+    S->carry_lit = b.lit_first;
+    S->status = 0;
+    for (u32 tile = 0; tile < n; tile += kScanThreads * kScanPer) {
+      for (int t = 0; t < kScanThreads; t++) scan_tile_sums(S.get(), r, n, tile, t);
+      for (int step = 0; step < kScanSteps; step++)
+        for (int t = 0; t < kScanThreads; t++) scan_tile_step(S.get(), step, t);
+      for (int t = 0; t < kScanThreads; t++) scan_tile_write(S.get(), r, n, tile, b, t);
+      scan_tile_carry(S.get());
+    }
+    if (S->status && S->status > status[(size_t)pi]) status[(size_t)pi] = S->status;
+  }
+  // kernel D
+  auto X = std::make_unique<ZExecLds>();
+  int max_rounds = 0;
+  for (int pi = 0; pi < npages; pi++) {
+    if (status[(size_t)pi] != ST_OK) continue;
+    const ZPage& pg = pages[(size_t)pi];
+    const ZRec* pr = recs.data() + pg.rec_first;
+    const u32 nrec = pg.nrecs;
+    u8* dst = bytes.data() + pg.dst_off;
+    const u8* pl = lits.data() + pg.lit_first;
+    u32 lo = 0;
+    bool bad = false;
+    for (u32 f0 = 0; f0 < (u32)pg.dst_len && !bad; f0 += kFrag) {
+      const u32 f1 = f0 + kFrag < (u32)pg.dst_len ? f0 + kFrag : (u32)pg.dst_len, frag_len = f1 - f0;
+      memset(X->e.src, 0xee, sizeof X->e.src);
+      X->e.covered = X->e.changed = X->e.flags = 0;
+      X->nq = 0;
+      X->next_lo = nrec;
+      for (int t = 0; t < kExecThreads; t++) zfrag_scatter(X.get(), pr, nrec, lo, f0, f1, pl, dst, t, kExecThreads);
+      for (int t = 0; t < kExecThreads; t++) zfrag_long_parts(X.get(), f0, pl, dst, t, kExecThreads);
+      if ((X->e.flags & 3u) || X->e.covered != frag_len) {
+        status[(size_t)pi] = (X->e.flags & 2u) ? (u32)ST_ERR_OFFSET : (u32)ST_ERR_LENGTH;
+        bad = true;
+        break;
+      }
+      lo = X->next_lo;
+      if (!(X->e.flags & 4u)) continue;
+      int round = 0;
+      for (; round < 20; round++) {
+        bool any = false;
+        for (int t = 0; t < kExecThreads; t++) any |= comet_snappy2::frag_jump(&X->e, frag_len, t, kExecThreads);
+        if (!any) break;
+      }
+      if (round > max_rounds) max_rounds = round;
+      for (int t = 0; t < kExecThreads; t++) comet_snappy2::frag_resolve(&X->e, f0, frag_len, dst, t, kExecThreads);
+    }
+  }
+  for (int i = 0; i < npages; i++) {
+    status_out[i] = status[(size_t)i];
+    if (status[(size_t)i] == ST_OK && page_len[i]) memcpy(out + out_off[i], bytes.data() + pages[(size_t)i].dst_off, (size_t)page_len[i]);
+  }
+  if (info_out) { info_out[0] = max_rounds; info_out[1] = (int32_t)blocks.size(); info_out[2] = (int32_t)nrecs; info_out[3] = (int32_t)nlits; for (int k = 0; k < 16; k++) info_out[4 + k] = (int32_t)seen[k]; }
+  return 0;
+}

@@ -3,12 +3,14 @@
 order, times relative to the burst's first event, copies with their size and rate.  A burst = events separated by less than 5 ms.
 Usage: timeline.py <kernel_trace.csv> <memory_copy_trace.csv>"""
 import csv
+import re
 import sys
 
 ev = []
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    n = n.split("(")[0].split("::")[-1][:28]
+    m = re.search(r"(sn2_\w+|zs2_\w+|pq_\w+|k_\w+|__amd\w+)", n)
+    n = m.group(1)[:28] if m else n.split("(")[0].split("::")[-1][:28]
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K " + n, 0))
 for r in csv.DictReader(open(sys.argv[2])):
     b = int(r.get("Bytes") or r.get("Size") or 0)
@@ -22,8 +24,11 @@ for e in ev:
         cur = []
     cur.append(e)
 bursts.append(cur)
-big = [b for b in bursts if len(b) > 20]
+big = [b for b in bursts if any(x[2].startswith(("K sn2_", "K zs2_", "K pq_decode")) for x in b)] or [b for b in bursts if len(b) > 20]
 b = big[-1] if big else bursts[-1]
+# the last scan of the burst: from the last idle gap of > 1.5 ms before its first decompression / decode kernel
+first = next((i for i in range(len(b) - 1, -1, -1) if b[i][2].startswith("K k_agg") and i < len(b) - 8), -1)
+b = b[first + 1:]
 t0 = b[0][0]
 print(f"burst of {len(b)} events, {(max(x[1] for x in b) - t0) / 1e6:.2f} ms")
 # aggregate consecutive events of the same name
