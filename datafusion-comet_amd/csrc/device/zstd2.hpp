@@ -9,10 +9,13 @@
 // so a page's fragments are resolved in order by ONE workgroup, and a match byte whose source lies in an earlier fragment is fetched
 // from the (final) output directly.
 //
-//   kernel A  one workgroup per block, two waves: wave 0 builds the Huffman table and decodes the literal streams (a lane per stream)
-//             into the page's literal scratch; wave 1 builds the three FSE tables and one lane decodes the sequences into records
-//             (ll, ml, offset).  Repeat offsets that reach back over the block's start stay SYMBOLIC (index into the block's
-//             initial history, minus a delta), so blocks do not wait for each other.
+//   kernel A1 one wave per block: the Huffman table, then the literal streams a lane each, 256 symbols a round, into the page's literal
+//             scratch;   kernel A2 one wave per block: the three FSE tables, then one lane decodes the sequences, 64 a round, into
+//             records (ll, ml, offset).  The decoding lanes read their bitstream from a window in workgroup memory and write into a
+//             buffer there; between rounds the whole wave slides the window and writes the buffer out — a serial lane never waits on
+//             global memory (a first version that loaded and stored from the lane itself ran 30 times slower: on this hardware a load
+//             returns behind every store issued before it).  Repeat offsets that reach back over the block's start stay SYMBOLIC
+//             (index into the block's initial history, minus a delta), so blocks do not wait for each other.
 //   kernel B  one lane per page: block output positions, the repeat-offset history handed from block to block, total length.
 //   kernel C  one workgroup per block: prefix sums over its records (output position, literal position), symbolic offsets resolved
 //             and checked.
@@ -32,6 +35,12 @@
 
 #define ZS_FN SN2_FN
 #define ZS_LDS SN2_LDS
+// A value every active lane holds alike, said so to the compiler (gfx950: v_readfirstlane → a scalar register).  The sequence decoder is
+// ONE lane's serial chain; with its state in scalar registers it runs on the scalar unit — one instruction a cycle, 64-bit shifts and
+// bit-field extracts in one instruction — instead of the vector unit's four cycles per instruction and two instructions per 64-bit shift.
+#ifndef ZS_UNIFORM
+#define ZS_UNIFORM(x) (x)
+#endif
 
 namespace comet_zstd2 {
 
@@ -44,7 +53,7 @@ using comet_snappy2::u8;
 typedef int16_t i16;
 
 constexpr u32 kBlockMax = 131072;
-constexpr int kEntThreads = 128;                // kernel A: threads 0 … 63 literals, 64 … 127 sequences
+
 constexpr int kScanThreads = 256;               // kernel C
 constexpr int kExecThreads = comet_snappy2::kExecThreads;
 constexpr u32 kFrag = (u32)comet_snappy2::kFrag;
@@ -97,12 +106,13 @@ ZS_FN i32 rep_resolve(i32 v, const i32* init) {
   return init[t % 3] - t / 3;
 }
 
-// ---- forward (little-endian) bit reader: table descriptions ----
+// ---- forward (little-endian) bit reader: table descriptions.  P: a byte pointer (global memory, workgroup memory or host memory) ----
+template <class P>
 struct FwdBits {
-  const u8* p;
+  P p;
   u32 len, bit;
   bool over;
-  ZS_FN void init(const u8* q, u32 n) { p = q; len = n; bit = 0; over = false; }
+  ZS_FN void init(P q, u32 n) { p = q; len = n; bit = 0; over = false; }
   ZS_FN u32 peek(int n) const {            // n ≤ 16
     const u32 b = bit >> 3;
     u32 v = 0;
@@ -115,9 +125,9 @@ struct FwdBits {
 };
 
 // normalized counts of an FSE table description → norm[0 … nsym), accuracy log; returns the bytes consumed, 0 = malformed
-template <class NormPtr>
-ZS_FN u32 fse_read_ncount(const u8* p, u32 avail, int max_sym /* inclusive */, int max_log, NormPtr norm, int& nsym, int& log) {
-  FwdBits in;
+template <class P, class NormPtr>
+ZS_FN u32 fse_read_ncount(P p, u32 avail, int max_sym /* inclusive */, int max_log, NormPtr norm, int& nsym, int& log) {
+  FwdBits<P> in;
   in.init(p, avail);
   log = 5 + (int)in.read(4);
   if (log > max_log) return 0;
@@ -184,60 +194,121 @@ ZS_FN void fse_build_rle(TabPtr tab, u32 sym) { tab[0] = sym; }        // log 0:
 
 // ---- backward bit reader: Huffman and FSE streams.  The stream's last byte holds a marker bit above its last data bit; bits are taken
 // from there towards the stream's first byte.  Three 8-byte registers cover 24 bytes below the cursor: a load is issued a register's worth
-// of decoding before its bytes are needed. ----
-struct BackBits {
-  const u8* s;
-  const u8* fl;        // lowest readable address (the page's first byte)
+// of decoding before its bytes are needed.  Src: where the stream's bytes come from —
+//   PtrBytes   a pointer, bounds checked byte by byte (the host's look at a page's first bytes; the few dozen bytes of FSE-coded weights)
+//   RingBytes  a window of the stream in workgroup memory that the workgroup slides down between rounds of decoding (the device's streams:
+//              a lane that decodes serially must not wait on global memory — a load there returns behind every store issued before it) ----
+template <class P>
+struct PtrBytes {
+  P p;
+  i32 len;
+  ZS_FN u64 load8(i32 pos) const {           // bytes [pos, pos + 8) of the stream; outside it: zero
+    u64 v = 0;
+    for (int k = 0; k < 8; k++) {
+      const i32 q = pos + k;
+      if (q >= 0 && q < len) v |= (u64)p[q] << (8 * k);
+    }
+    return v;
+  }
+};
+constexpr u32 kRing = 2048;                  // bytes of a stream window (power of two)
+// The reader only ever loads at positions ≡ the stream's length (mod 8) — its registers step down 8 bytes at a time from the stream's end —
+// so the window is laid out with a BIAS: the byte at stream position q sits at ring byte (q + bias) mod kRing, bias = (−length) mod 8, and
+// every load is one aligned 8-byte read.
+ZS_FN u32 ring_bias(u32 len) { return (8u - (len & 7u)) & 7u; }
+template <class WP, bool kUniform>              // kUniform: ONE lane reads this window (the sequence decoder): what it loads is wave-uniform
+struct RingBytes {
+  WP w;                                      // kRing / 4 words
+  u32 bias;
+  ZS_FN u64 load8(i32 pos) const {
+    const u32 i = (((u32)pos + bias) & (kRing - 1)) >> 2;
+    u32 w0 = w[i], w1 = w[i + 1];
+    if (kUniform) { w0 = ZS_UNIFORM(w0); w1 = ZS_UNIFORM(w1); }
+    return (u64)w0 | ((u64)w1 << 32);
+  }
+};
+// the window slides: stream positions [from, to) are loaded, a word per thread and step; from + bias and to + bias are multiples of 4.
+// Positions outside [lim_lo, lim_hi) — before the page's first byte or behind its padded end — read as zero.
+template <class WP>
+ZS_FN void ring_fill(WP w, u32 bias, const u8* stream, i32 from, i32 to, i32 lim_lo, i32 lim_hi, int t, int nthreads) {
+  for (i32 q = from + 4 * t; q < to; q += 4 * nthreads) {
+    u32 v = 0;
+    if (q >= lim_lo && q + 4 <= lim_hi) __builtin_memcpy(&v, stream + q, 4);
+    else
+      for (int k = 0; k < 4; k++)
+        if (q + k >= lim_lo && q + k < lim_hi) v |= (u32)stream[q + k] << (8 * k);
+    w[(((u32)q + bias) & (kRing - 1)) >> 2] = v;
+  }
+}
+// how far down the window must reach when decoding resumes at that byte: 1 KiB below it (a word boundary of the biased layout)
+ZS_FN i32 ring_low_for(i32 cursor_byte, u32 bias) {
+  const i32 v = ((cursor_byte + (i32)bias - 1024) & ~3) - (i32)bias;
+  const i32 floor_ = -40 - (((i32)bias - 40) & 3);          // nothing below the stream's first byte is ever consumed; the registers reach 31 bytes below it
+  return v < floor_ ? floor_ : v;
+}
+ZS_FN i32 ring_top_for(u32 len, u32 bias) { return (i32)(((len + bias + 8 + 3) & ~3u) - bias); }      // the first fill's upper edge: the stream's end + 8, a word boundary
+
+template <class Src>
+struct BackBitsT {
+  Src src;
   i32 bitpos;          // bits left: the next read takes bits [bitpos − n, bitpos) of the stream
   i32 wb;              // hi = bytes [wb − 8, wb), lo = [wb − 16, wb − 8), nx = [wb − 24, wb − 16)
   u64 hi, lo, nx;
-  ZS_FN static u64 ld(const u8* p, const u8* floor_) {
-    u64 v;
-    if (p >= floor_) { __builtin_memcpy(&v, p, 8); return v; }
-    const i64 d = floor_ - p;                               // bytes below the page: zero (never legitimately consumed)
-    if (d >= 8) return 0;
-    __builtin_memcpy(&v, floor_, 8);
-    return v << (8 * d);
-  }
-  ZS_FN bool init(const u8* stream, u32 len, const u8* floor_) {
-    s = stream;
-    fl = floor_;
+  ZS_FN bool init(const Src& s, u32 len) {
+    src = s;
     bitpos = 0;
     wb = (i32)len;
     hi = lo = nx = 0;
     if (len == 0) return false;
-    const u8 last = stream[len - 1];
+    hi = src.load8(wb - 8);
+    const u32 last = (u32)(hi >> 56);
     if (last == 0) return false;
     bitpos = 8 * ((i32)len - 1) + highbit(last);
-    hi = ld(s + wb - 8, fl);
-    lo = ld(s + wb - 16, fl);
-    nx = ld(s + wb - 24, fl);
+    lo = src.load8(wb - 16);
+    nx = src.load8(wb - 24);
     return true;
   }
   ZS_FN u32 peek(int n) const {            // n ≤ 32; bits beyond the stream's beginning read as 0
-    if (n == 0) return 0;
-    if (bitpos < n) return bitpos > 0 ? peek(bitpos) << (n - bitpos) : 0u;
-    const i32 sft = bitpos - 8 * (wb - 16) - n;             // lowest wanted bit within (hi:lo); the cursor stays inside hi: 32 < sft < 128
+    if (n == 0 || bitpos <= 0) return 0;
+    const int m = bitpos < n ? bitpos : n;                  // (not recursive: a recursive function is not inlined, and a call spills the reader)
+    const i32 sft = bitpos - 8 * (wb - 16) - m;             // lowest wanted bit within (hi:lo); the cursor stays inside hi: 32 < sft < 128
     const u64 v = sft >= 64 ? hi >> (sft - 64) : (hi << (64 - sft)) | (lo >> sft);
-    return (u32)v & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));
+    return ((u32)v & (m >= 32 ? 0xffffffffu : ((1u << m) - 1u))) << (n - m);
   }
-  ZS_FN void consume(int n) {
+  ZS_FN void consume(int n) {              // n ≤ 64
     bitpos -= n;
     if (bitpos - 8 * (wb - 16) <= 64) {
       hi = lo;
       lo = nx;
       wb -= 8;
-      nx = ld(s + wb - 24, fl);
+      nx = src.load8(wb - 24);
+      if (bitpos - 8 * (wb - 16) <= 64) {    // (more than 32 bits at once can step over a whole register)
+        hi = lo;
+        lo = nx;
+        wb -= 8;
+        nx = src.load8(wb - 24);
+      }
     }
   }
+  // the 64 bits below the cursor, the next bit on top; fields are then taken off its top.  Needs bitpos ≥ 64.
+  ZS_FN u64 window() const {
+    const i32 sft = bitpos - 8 * (wb - 16) - 64;            // 0 < sft ≤ 64
+    return sft >= 64 ? hi : (hi << (64 - sft)) | (lo >> sft);
+  }
+  ZS_FN static u32 take(u64& w, u32 n) {     // n ≤ 32 (n = 0 → 0): the top word shifted up by n, what crosses into the next word
+    const u32 v = (u32)(((u64)(u32)(w >> 32) << n) >> 32);
+    w <<= n;
+    return v;
+  }
   ZS_FN u32 read(int n) { const u32 v = peek(n); consume(n); return v; }
+  ZS_FN i32 cursor_byte() const { return bitpos > 0 ? (bitpos + 7) >> 3 : 0; }
 };
 
 // ---- Huffman ----
 // Tree description at p: weights of symbols 0 … nw − 1 into w[] (the last symbol's weight is implied), → bytes consumed, 0 = malformed.
 // wtab: scratch for the weights' own FSE table (64 entries), norm / next: scratch of ≥ 16 entries.
-template <class WPtr, class TabPtr, class NormPtr, class NextPtr>
-ZS_FN u32 huf_read_weights(const u8* p, u32 avail, const u8* floor_, WPtr w, int& nw, TabPtr wtab, NormPtr norm, NextPtr next) {
+template <class P, class WPtr, class TabPtr, class NormPtr, class NextPtr>
+ZS_FN u32 huf_read_weights(P p, u32 avail, WPtr w, int& nw, TabPtr wtab, NormPtr norm, NextPtr next) {
   if (avail < 1) return 0;
   const u32 hb = p[0];
   if (hb >= 128) {
@@ -252,8 +323,11 @@ ZS_FN u32 huf_read_weights(const u8* p, u32 avail, const u8* floor_, WPtr w, int
   const u32 used = fse_read_ncount(p + 1, hb, 12, 6, norm, nsym, log);
   if (used == 0 || used >= hb) return 0;
   if (!fse_build(norm, nsym, log, wtab, next)) return 0;
-  BackBits b;
-  if (!b.init(p + 1 + used, hb - used, floor_)) return 0;
+  BackBitsT<PtrBytes<P>> b;
+  PtrBytes<P> src;
+  src.p = p + 1 + used;
+  src.len = (i32)(hb - used);
+  if (!b.init(src, hb - used)) return 0;
   u32 s1 = b.read(log), s2 = b.read(log);
   int n = 0;
   for (;;) {
@@ -304,27 +378,28 @@ ZS_FN int huf_build(WPtr w, int nw, TabPtr tab) {
   }
   return log;
 }
-// `count` symbols of one stream; the stream must end exactly
-template <class TabPtr>
-ZS_FN bool huf_decode_stream(const u8* stream, u32 len, const u8* floor_, TabPtr tab, int log, u8* out, u32 count) {
-  BackBits b;
-  if (!b.init(stream, len, floor_)) return false;
+// `count` symbols from the reader into out[]
+template <class BB, class TabPtr, class OutPtr>
+ZS_FN void huf_decode_symbols(BB& b, TabPtr tab, int log, OutPtr out, u32 count) {
   u32 i = 0;
-  for (; i + 4 <= count; i += 4) {
-    u32 word = 0;
-    for (int k = 0; k < 4; k++) {
-      const u32 e = tab[b.peek(log)];
-      b.consume((int)(e >> 8));
-      word |= (e & 0xffu) << (8 * k);
+  // five codes (≤ 11 bits each) off one 64-bit window, one consume for the five
+  for (; i + 5 <= count && b.bitpos >= 64; i += 5) {
+    u64 w = b.window();
+    u32 used = 0;
+    for (int k = 0; k < 5; k++) {
+      const u32 e = tab[(u32)(w >> (64 - log))];
+      const u32 n = e >> 8;
+      w <<= n;
+      used += n;
+      out[i + k] = (u8)e;
     }
-    __builtin_memcpy(out + i, &word, 4);
+    b.consume((int)used);
   }
   for (; i < count; i++) {
     const u32 e = tab[b.peek(log)];
     b.consume((int)(e >> 8));
     out[i] = (u8)e;
   }
-  return b.bitpos == 0;
 }
 
 // ---- sequence codes: value = base + extra bits; entry = base | bits << 24 ----
@@ -354,8 +429,8 @@ ZS_FN void predefined_norm(int kind, NormPtr norm, int& nsym, int& log) {
 constexpr int kMaxSym[3] = {35, 31, 52};
 constexpr int kMaxLog[3] = {9, 8, 9};
 // one of a block's three tables; → its accuracy log, −1 = malformed
-template <class TabPtr, class NormPtr, class NextPtr>
-ZS_FN int seq_table(int kind, int mode, const u8* desc, u32 avail, TabPtr tab, NormPtr norm, NextPtr next) {
+template <class P, class TabPtr, class NormPtr, class NextPtr>
+ZS_FN int seq_table(int kind, int mode, P desc, u32 avail, TabPtr tab, NormPtr norm, NextPtr next) {
   int nsym = 0, log = 0;
   if (mode == TM_RLE) {
     if (avail < 1 || desc[0] > kMaxSym[kind]) return -1;
@@ -367,154 +442,346 @@ ZS_FN int seq_table(int kind, int mode, const u8* desc, u32 avail, TabPtr tab, N
   return fse_build(norm, nsym, log, tab, next) ? log : -1;
 }
 
-// ---- the sequences of one block: one lane.  Writes recs[0 … nseq] (ll, ml, off) — the last record holds the trailing literals —, the
-// block's output size and its history on exit.  → ST_OK or an error code ----
-template <class TabPtr, class CodePtr>
-ZS_FN u32 seq_decode(const u8* bits, u32 bits_len, const u8* floor_, TabPtr tll, int lll, TabPtr tof, int lof, TabPtr tml, int lml, CodePtr llc, CodePtr mlc, u32 nseq,
-                     u32 lit_regen, ZRec* recs, u32& out_size, i32* rep_out) {
-  BackBits b;
-  if (!b.init(bits, bits_len, floor_)) return ST_ERR_BITS;
-  u32 sll = b.read(lll), sof = b.read(lof), sml = b.read(lml);
-  i32 r0 = rep_symbolic(0), r1 = rep_symbolic(1), r2 = rep_symbolic(2);
-  u64 sum_ll = 0, sum_ml = 0;
-  for (u32 i = 0; i < nseq; i++) {
-    const u32 ell = tll[sll], eof = tof[sof], eml = tml[sml];
-    const u32 ofc = eof & 0xffu, mc = eml & 0xffu, lc = ell & 0xffu;
-    if (ofc > 31u || mc > 52u || lc > 35u) return ST_ERR_SEQ;
-    const u32 ov = (ofc ? (1u << ofc) : 1u) + b.read((int)ofc);
-    const u32 me = mlc[mc], le = llc[lc];
-    const u32 ml = (me & 0xffffffu) + b.read((int)(me >> 24));
-    const u32 ll = (le & 0xffffffu) + b.read((int)(le >> 24));
-    i32 off;
-    if (ov > 3u) {
-      off = (i32)(ov - 3u);
-      if (off <= 0) return ST_ERR_OFFSET;
-      r2 = r1; r1 = r0; r0 = off;
-    } else {
-      const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
-      if (idx == 0) off = r0;
-      else {
-        off = idx == 1 ? r1 : idx == 2 ? r2 : rep_minus_one(r0);
-        if (idx > 1) r2 = r1;
-        r1 = r0;
-        r0 = off;
-      }
-    }
-    recs[i].ll = ll;
-    recs[i].ml = ml;
-    recs[i].off = off;
-    sum_ll += ll;
-    sum_ml += ml;
-    if (i + 1 < nseq) {
-      sll = (ell >> 16) + b.read((int)((ell >> 8) & 0xffu));
-      sml = (eml >> 16) + b.read((int)((eml >> 8) & 0xffu));
-      sof = (eof >> 16) + b.read((int)((eof >> 8) & 0xffu));
-    }
+// A sequence table as the decoder walks it: two words per state — [0] the value's base (literal length / match length / offset value
+// 1 << code), [1] bits of the next state | extra bits of the value << 8 | base of the next state << 16.  Expanded in place from
+// fse_build's one word per state (tab holds 2 << log words; from the top down, so no entry is overwritten before it is read).
+template <class TabPtr>
+ZS_FN void seq_table_expand(int kind, int log, TabPtr tab) {
+  for (i32 i = (i32)(1u << log) - 1; i >= 0; i--) {
+    const u32 e = tab[i], sym = e & 0xffu;
+    u32 base, extra;
+    if (kind == 1) { base = 1u << sym; extra = sym; }
+    else { const u32 ce = kind == 0 ? ll_code_entry(sym) : ml_code_entry(sym); base = ce & 0xffffffu; extra = ce >> 24; }
+    tab[2 * i] = base;
+    tab[2 * i + 1] = ((e >> 8) & 0xffu) | (extra << 8) | ((e >> 16) << 16);
   }
-  if (b.bitpos != 0) return ST_ERR_BITS;
-  if (sum_ll > lit_regen || sum_ll + sum_ml > kBlockMax) return ST_ERR_LENGTH;
-  recs[nseq].ll = lit_regen - (u32)sum_ll;
-  recs[nseq].ml = 0;
-  recs[nseq].off = 0;
-  out_size = lit_regen + (u32)sum_ml;
-  rep_out[0] = r0;
-  rep_out[1] = r1;
-  rep_out[2] = r2;
-  return ST_OK;
 }
 
-// ---- kernel A: workgroup memory and phases ----
-struct EntLds {
+// ---- the sequences of one block: the decoder's state between sequences, and one step ----
+struct SeqCore {
+  u32 sll, sof, sml;          // the three FSE states
+  i32 r0, r1, r2;             // repeat-offset history (symbolic until an offset of this block replaces an entry)
+  u64 sum_ll, sum_ml;
+  u32 done;                   // sequences decoded so far
+};
+template <class BB>
+ZS_FN void seq_begin(BB& b, SeqCore& c, int lll, int lof, int lml) {
+  c.sll = b.read(lll);
+  c.sof = b.read(lof);
+  c.sml = b.read(lml);
+  c.r0 = rep_symbolic(0);
+  c.r1 = rep_symbolic(1);
+  c.r2 = rep_symbolic(2);
+  c.sum_ll = c.sum_ml = 0;
+  c.done = 0;
+}
+// the next sequence (`last`: no state update behind it); → ST_OK or an error code.  Tables: seq_table_expand's two words per state.
+template <class BB, class TabPtr>
+ZS_FN u32 seq_step(BB& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, bool last, u32& ll, u32& ml, i32& off) {
+  const u32 lb = ZS_UNIFORM(tll[2 * c.sll]), lh = ZS_UNIFORM(tll[2 * c.sll + 1]);
+  const u32 ob = ZS_UNIFORM(tof[2 * c.sof]), oh = ZS_UNIFORM(tof[2 * c.sof + 1]);
+  const u32 mb = ZS_UNIFORM(tml[2 * c.sml]), mh = ZS_UNIFORM(tml[2 * c.sml + 1]);
+  // The fields come off 64-bit WINDOWS of the stream, not through six general reads (the decoder is one lane's chain: its cost is its
+  // instruction count): all six — the three values' extra bits and the three states' bits — off one window when they fit (the usual
+  // case: ~35 bits), else the values (≤ 31 + 16 + 16) off one and the states (≤ 9 + 9 + 8) off a second.
+  const u32 oe = (oh >> 8) & 0xffu, me = (mh >> 8) & 0xffu, le = (lh >> 8) & 0xffu;
+  const u32 ln = lh & 0xffu, mn = mh & 0xffu, on = oh & 0xffu;
+  const u32 vbits = oe + me + le, sbits = last ? 0u : ln + mn + on;
+  u32 ov;
+  bool states_done = last;
+  if (b.bitpos >= 64) {
+    u64 w = b.window();
+    ov = ob + BB::take(w, oe);
+    ml = mb + BB::take(w, me);
+    ll = lb + BB::take(w, le);
+    if (!last && vbits + sbits <= 64u) {
+      c.sll = (lh >> 16) + BB::take(w, ln);
+      c.sml = (mh >> 16) + BB::take(w, mn);
+      c.sof = (oh >> 16) + BB::take(w, on);
+      b.consume((int)(vbits + sbits));
+      states_done = true;
+    } else {
+      b.consume((int)vbits);
+    }
+  } else {
+    ov = ob + b.read((int)oe);
+    ml = mb + b.read((int)me);
+    ll = lb + b.read((int)le);
+  }
+  if (ov > 3u) {
+    off = (i32)(ov - 3u);
+    if (off <= 0) return ST_ERR_OFFSET;
+    c.r2 = c.r1; c.r1 = c.r0; c.r0 = off;
+  } else {
+    const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
+    if (idx == 0) off = c.r0;
+    else {
+      off = idx == 1 ? c.r1 : idx == 2 ? c.r2 : rep_minus_one(c.r0);
+      if (idx > 1) c.r2 = c.r1;
+      c.r1 = c.r0;
+      c.r0 = off;
+    }
+  }
+  c.sum_ll += ll;
+  c.sum_ml += ml;
+  c.done++;
+  if (!states_done) {
+    if (b.bitpos >= 64) {
+      u64 w = b.window();
+      c.sll = (lh >> 16) + BB::take(w, ln);
+      c.sml = (mh >> 16) + BB::take(w, mn);
+      c.sof = (oh >> 16) + BB::take(w, on);
+      b.consume((int)sbits);
+    } else {
+      c.sll = (lh >> 16) + b.read((int)ln);
+      c.sml = (mh >> 16) + b.read((int)mn);
+      c.sof = (oh >> 16) + b.read((int)on);
+    }
+  }
+  return ST_OK;
+}
+// the state as the compiler should see it at the start of a round: wave-uniform (it comes back from the previous round through a
+// join with the idle lanes, which makes it look divergent)
+template <class BB>
+ZS_FN void seq_state_uniform(BB& b, SeqCore& c) {
+  b.src.bias = ZS_UNIFORM(b.src.bias);
+  b.bitpos = (i32)ZS_UNIFORM((u32)b.bitpos);
+  b.wb = (i32)ZS_UNIFORM((u32)b.wb);
+  b.hi = (u64)ZS_UNIFORM((u32)b.hi) | ((u64)ZS_UNIFORM((u32)(b.hi >> 32)) << 32);
+  b.lo = (u64)ZS_UNIFORM((u32)b.lo) | ((u64)ZS_UNIFORM((u32)(b.lo >> 32)) << 32);
+  b.nx = (u64)ZS_UNIFORM((u32)b.nx) | ((u64)ZS_UNIFORM((u32)(b.nx >> 32)) << 32);
+  c.sll = ZS_UNIFORM(c.sll);
+  c.sof = ZS_UNIFORM(c.sof);
+  c.sml = ZS_UNIFORM(c.sml);
+  c.r0 = (i32)ZS_UNIFORM((u32)c.r0);
+  c.r1 = (i32)ZS_UNIFORM((u32)c.r1);
+  c.r2 = (i32)ZS_UNIFORM((u32)c.r2);
+  c.sum_ll = (u64)ZS_UNIFORM((u32)c.sum_ll) | ((u64)ZS_UNIFORM((u32)(c.sum_ll >> 32)) << 32);
+  c.sum_ml = (u64)ZS_UNIFORM((u32)c.sum_ml) | ((u64)ZS_UNIFORM((u32)(c.sum_ml >> 32)) << 32);
+  c.done = ZS_UNIFORM(c.done);
+}
+
+// ---- kernel A1: the literals of one block — one 64-thread workgroup.  Threads 0 … 3 decode a Huffman stream each, 256 symbols a round,
+// out of their stream's window in workgroup memory into a buffer there; between rounds ALL threads slide the windows and write the
+// buffers out.  Raw / RLE literals (and raw / RLE blocks) are copied or filled by all threads. ----
+constexpr u32 kLitRound = 256;
+struct LitLds {
   u16 huf[1 << kHufLogMax];
-  u32 fse[3][512];
+  u32 ring[4][kRing / 4];
+  u8 obuf[4][kLitRound];
+  u8 hdr[160];               // the tree description, staged
   u32 wfse[64];
-  u32 llc[36], mlc[53];
   u8 weights[256];
-  i16 norm[2][64];           // [0]: the literal wave's, [1]: the sequence wave's
-  u16 next[2][64];
-  i32 huf_log, fse_log[3];
+  i16 norm[64];
+  u16 next[64];
+  i32 huf_log;
+  i32 low[4], cursor[4];     // per stream: the window's lowest loaded position, the byte decoding resumes at
+  u32 bias[4];
+  u32 s_off[4], s_len[4], s_cnt[4];   // per stream: offset from lit_pos, length, symbols
+  u32 nstreams;
   u32 status;
 };
-// literal wave, thread 0: tree description → table
-ZS_FN void ent_huf_table(ZS_LDS EntLds* L, const u8* src, const ZBlock& b) {
+typedef BackBitsT<RingBytes<ZS_LDS u32*, false>> RingReader;
+typedef BackBitsT<RingBytes<ZS_LDS u32*, true>> UniformRingReader;
+struct LitState { RingReader b; u32 left; };                // a decoding thread's registers between rounds
+// phase 1 (all threads): stage the tree description; thread 0: the streams' extents
+ZS_FN void lit_stage(ZS_LDS LitLds* L, const u8* src, const ZBlock& b, int t) {
   if (b.type != BT_COMPRESSED || b.lit_type != LT_HUF) return;
+  for (u32 i = (u32)t; i < 160u; i += 64) L->hdr[i] = i < b.huf_desc_len ? src[b.huf_desc + i] : (u8)0;
+  if (t != 0) return;
+  const u8* s = src + b.lit_pos;
+  if (b.lit_streams == 1) {
+    L->nstreams = 1;
+    L->s_off[0] = 0;
+    L->s_len[0] = b.lit_len;
+    L->s_cnt[0] = b.lit_regen;
+    return;
+  }
+  L->nstreams = 4;
+  if (b.lit_len < 10) { L->status = ST_ERR_HUF; L->nstreams = 0; return; }
+  const u32 l1 = (u32)s[0] | ((u32)s[1] << 8), l2 = (u32)s[2] | ((u32)s[3] << 8), l3 = (u32)s[4] | ((u32)s[5] << 8);
+  const u32 seg = (b.lit_regen + 3) / 4;
+  if (6 + l1 + l2 + l3 >= b.lit_len || 3 * seg > b.lit_regen) { L->status = ST_ERR_HUF; L->nstreams = 0; return; }
+  L->s_off[0] = 6;            L->s_len[0] = l1; L->s_cnt[0] = seg;
+  L->s_off[1] = 6 + l1;       L->s_len[1] = l2; L->s_cnt[1] = seg;
+  L->s_off[2] = 6 + l1 + l2;  L->s_len[2] = l3; L->s_cnt[2] = seg;
+  L->s_off[3] = 6 + l1 + l2 + l3; L->s_len[3] = b.lit_len - 6 - l1 - l2 - l3; L->s_cnt[3] = b.lit_regen - 3 * seg;
+}
+// phase 2 (thread 0): the table; (all threads, after it): the streams' first windows
+ZS_FN void lit_table(ZS_LDS LitLds* L, const ZBlock& b) {
+  if (b.type != BT_COMPRESSED || b.lit_type != LT_HUF || L->status) return;
   int nw = 0;
-  const u32 used = huf_read_weights(src + b.huf_desc, b.huf_desc_len, src, L->weights, nw, L->wfse, L->norm[0], L->next[0]);
+  const u32 used = huf_read_weights((ZS_LDS u8*)L->hdr, b.huf_desc_len < 160u ? b.huf_desc_len : 160u, L->weights, nw, L->wfse, L->norm, L->next);
   const int log = used ? huf_build(L->weights, nw, L->huf) : 0;
   L->huf_log = log;
   if (!log) L->status = ST_ERR_HUF;
-}
-// sequence wave, thread 64: code tables and the block's three FSE tables
-ZS_FN void ent_seq_tables(ZS_LDS EntLds* L, const u8* src, const ZBlock& b, u32 src_len) {
-  for (u32 c = 0; c < 36; c++) L->llc[c] = ll_code_entry(c);
-  for (u32 c = 0; c < 53; c++) L->mlc[c] = ml_code_entry(c);
-  if (b.type != BT_COMPRESSED || b.nseq == 0) return;
-  for (int k = 0; k < 3; k++) {
-    const u32 d = b.tab_desc[k];
-    const int log = seq_table(k, b.tab_mode[k], src + d, d < src_len ? src_len - d : 0, L->fse[k], L->norm[1], L->next[1]);
-    L->fse_log[k] = log;
-    if (log < 0) L->status = ST_ERR_FSE;
+  for (u32 k = 0; k < L->nstreams; k++) {
+    L->bias[k] = ring_bias(L->s_len[k]);
+    L->cursor[k] = (i32)L->s_len[k];
+    L->low[k] = ring_top_for(L->s_len[k], L->bias[k]);
   }
 }
-// literal wave: the block's literals into the scratch.  t = thread within the wave (0 … 63)
-ZS_FN void ent_literals(ZS_LDS EntLds* L, const u8* src, const ZBlock& b, u8* lits, int t) {
+// (all threads) slide stream k's window down to where its next round may reach — 16 threads per stream
+ZS_FN void lit_fill(ZS_LDS LitLds* L, const u8* src, const ZBlock& b, i32 page_len, int t) {
+  const u32 k = (u32)t >> 4;
+  if (k >= L->nstreams) return;
+  const i32 spos = (i32)(b.lit_pos + L->s_off[k]);
+  const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
+  if (want < L->low[k]) ring_fill((ZS_LDS u32*)L->ring[k], L->bias[k], src + spos, want, L->low[k], -spos, page_len + 16 - spos, t & 15, 16);
+}
+ZS_FN void lit_fill_done(ZS_LDS LitLds* L, int k) {           // (the stream's thread, after the barrier behind lit_fill)
+  const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
+  if (want < L->low[k]) L->low[k] = want;
+}
+// a decoding thread starts its stream / decodes its next ≤ 256 symbols into obuf
+ZS_FN void lit_begin(ZS_LDS LitLds* L, LitState& st, int k) {
+  RingBytes<ZS_LDS u32*, false> src;
+  src.w = (ZS_LDS u32*)L->ring[k];
+  src.bias = L->bias[k];
+  st.left = L->s_cnt[k];
+  if (!st.b.init(src, L->s_len[k])) { L->status = ST_ERR_HUF; st.left = 0; }
+}
+ZS_FN void lit_round(ZS_LDS LitLds* L, LitState& st, int k) {
+  const u32 n = st.left < kLitRound ? st.left : kLitRound;
+  huf_decode_symbols(st.b, (ZS_LDS u16*)L->huf, L->huf_log, (ZS_LDS u8*)L->obuf[k], n);
+  st.left -= n;
+  L->cursor[k] = st.b.cursor_byte();
+  if (st.left == 0 && n && st.b.bitpos != 0) L->status = ST_ERR_HUF;       // the stream must end exactly with its last symbol
+}
+// (all threads) round r's symbols to the literal scratch: 16 bytes per thread
+ZS_FN void lit_flush(const ZS_LDS LitLds* L, const ZBlock& b, u8* lits, u32 r, int t) {
+  const u32 k = (u32)t >> 4, j = ((u32)t & 15u) * 16u;
+  if (k >= L->nstreams) return;
+  const u32 seg = L->nstreams == 1 ? 0u : (b.lit_regen + 3) / 4;
+  const u32 done = r * kLitRound;                              // symbols of the stream written before this round
+  if (done >= L->s_cnt[k]) return;
+  const u32 n = L->s_cnt[k] - done < kLitRound ? L->s_cnt[k] - done : kLitRound;
+  u8* out = lits + b.lit_first + k * seg + done;
+  for (u32 i = j; i < j + 16 && i < n; i++) out[i] = L->obuf[k][i];
+}
+// raw / RLE literals, raw / RLE blocks (all threads)
+ZS_FN void lit_plain(const u8* src, const ZBlock& b, u8* lits, int t) {
   u8* out = lits + b.lit_first;
   if (b.type == BT_RAW || (b.type == BT_COMPRESSED && b.lit_type == LT_RAW)) {
     const u8* from = src + (b.type == BT_RAW ? b.pos : b.lit_pos);
     for (u32 i = (u32)t; i < b.lit_regen; i += 64) out[i] = from[i];
-    return;
-  }
-  if (b.type == BT_RLE || b.lit_type == LT_RLE) {
+  } else if (b.type == BT_RLE || b.lit_type == LT_RLE) {
     const u8 v = src[b.type == BT_RLE ? b.pos : b.lit_pos];
     for (u32 i = (u32)t; i < b.lit_regen; i += 64) out[i] = v;
-    return;
   }
-  if (L->huf_log <= 0) return;
-  const u8* s = src + b.lit_pos;
-  if (b.lit_streams == 1) {
-    if (t == 0 && !huf_decode_stream(s, b.lit_len, src, L->huf, L->huf_log, out, b.lit_regen)) L->status = ST_ERR_HUF;
-    return;
-  }
-  if (t >= 4) return;
-  if (b.lit_len < 10) { L->status = ST_ERR_HUF; return; }
-  const u32 l1 = (u32)s[0] | ((u32)s[1] << 8), l2 = (u32)s[2] | ((u32)s[3] << 8), l3 = (u32)s[4] | ((u32)s[5] << 8);
-  if (6 + l1 + l2 + l3 >= b.lit_len) { L->status = ST_ERR_HUF; return; }
-  const u32 l4 = b.lit_len - 6 - l1 - l2 - l3;
-  const u32 seg = (b.lit_regen + 3) / 4;
-  if (3 * seg > b.lit_regen) { L->status = ST_ERR_HUF; return; }
-  const u32 off = t == 0 ? 6u : t == 1 ? 6u + l1 : t == 2 ? 6u + l1 + l2 : 6u + l1 + l2 + l3;
-  const u32 len = t == 0 ? l1 : t == 1 ? l2 : t == 2 ? l3 : l4;
-  const u32 cnt = t < 3 ? seg : b.lit_regen - 3 * seg;
-  if (!huf_decode_stream(s + off, len, src, L->huf, L->huf_log, out + (u32)t * seg, cnt)) L->status = ST_ERR_HUF;
 }
-// sequence wave, thread 64: the block's records
-ZS_FN void ent_sequences(ZS_LDS EntLds* L, const u8* src, ZBlock* b, ZRec* recs) {
-  ZRec* r = recs + b->rec_first;
-  if (b->type != BT_COMPRESSED) {                         // a raw / RLE block is one run of literals
-    r[0].ll = b->size;
-    r[0].ml = 0;
-    r[0].off = 0;
-    b->out_size = b->size;
-    for (int k = 0; k < 3; k++) b->rep_out[k] = rep_symbolic(k);
-    return;
+ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Huffman block (uniform over the workgroup)
+  if (b.type != BT_COMPRESSED || b.lit_type != LT_HUF) return 0;
+  const u32 longest = b.lit_streams == 1 ? b.lit_regen : (b.lit_regen + 3) / 4;
+  return (longest + kLitRound - 1) / kLitRound;
+}
+
+// ---- kernel A2: the sequences of one block — one 64-thread workgroup.  Thread 0 decodes 64 sequences a round out of the bitstream's
+// window in workgroup memory into a buffer there; between rounds ALL threads slide the window and write the buffer out as records. ----
+constexpr u32 kSeqRound = 64;
+struct SeqLds {
+  u32 fse[3][1024];          // two words per state (seq_table_expand)
+  u32 ring[kRing / 4];
+  u32 rbuf[kSeqRound][3];    // ll, ml, off
+  u8 hdr[3][128];            // the table descriptions, staged (a description is at most 53 counts of ≤ 10 bits)
+  i16 norm[64];
+  u16 next[64];
+  i32 fse_log[3];
+  i32 low, cursor;
+  u32 bias;
+  u32 rcount;
+  u32 status;
+};
+struct SeqState { UniformRingReader b; SeqCore c; };
+ZS_FN bool seq_block_has_stream(const ZBlock& b) { return b.type == BT_COMPRESSED && b.nseq > 0; }
+// phase 1 (all threads): stage the table descriptions (this block's, or — repeat mode — an earlier block's)
+ZS_FN void seq_stage(ZS_LDS SeqLds* L, const u8* src, const ZBlock& b, u32 src_len, int t) {
+  if (!seq_block_has_stream(b)) return;
+  for (u32 i = (u32)t; i < 3u * 128u; i += 64) {
+    const u32 k = i >> 7, j = i & 127u;
+    const u32 q = b.tab_desc[k] + j;
+    L->hdr[k][j] = (b.tab_mode[k] != TM_PREDEF && q < src_len) ? src[q] : (u8)0;
   }
-  if (b->nseq == 0) {
-    r[0].ll = b->lit_regen;
-    r[0].ml = 0;
-    r[0].off = 0;
-    b->out_size = b->lit_regen;
+  if (t == 0) { L->bias = ring_bias(b.bits_len); L->cursor = (i32)b.bits_len; L->low = ring_top_for(b.bits_len, L->bias); }
+}
+// phase 2 (thread 0): the block's three tables
+ZS_FN void seq_tables(ZS_LDS SeqLds* L, const ZBlock& b) {
+  if (!seq_block_has_stream(b)) return;
+  for (int k = 0; k < 3; k++) {
+    const int log = seq_table(k, b.tab_mode[k], (ZS_LDS u8*)L->hdr[k], 128u, (ZS_LDS u32*)L->fse[k], L->norm, L->next);
+    L->fse_log[k] = log;
+    if (log < 0) L->status = ST_ERR_FSE;
+    else seq_table_expand(k, log, (ZS_LDS u32*)L->fse[k]);
+  }
+}
+// (all threads) slide the bitstream's window down
+ZS_FN void seq_fill(ZS_LDS SeqLds* L, const u8* src, const ZBlock& b, i32 page_len, int t) {
+  if (!seq_block_has_stream(b)) return;
+  const i32 want = ring_low_for(L->cursor, L->bias);
+  if (want < L->low) ring_fill((ZS_LDS u32*)L->ring, L->bias, src + b.bits_pos, want, L->low, -(i32)b.bits_pos, page_len + 16 - (i32)b.bits_pos, t, 64);
+}
+ZS_FN void seq_fill_done(ZS_LDS SeqLds* L) {
+  const i32 want = ring_low_for(L->cursor, L->bias);
+  if (want < L->low) L->low = want;
+}
+ZS_FN void seq_start(ZS_LDS SeqLds* L, SeqState& st, const ZBlock& b) {        // thread 0, behind the first fill
+  RingBytes<ZS_LDS u32*, true> src;
+  src.w = (ZS_LDS u32*)L->ring;
+  src.bias = ZS_UNIFORM(L->bias);
+  if (L->status) return;
+  if (!st.b.init(src, b.bits_len)) { L->status = ST_ERR_BITS; return; }
+  seq_begin(st.b, st.c, L->fse_log[0], L->fse_log[1], L->fse_log[2]);
+}
+// thread 0: the next ≤ 64 sequences into rbuf
+ZS_FN void seq_round(ZS_LDS SeqLds* L, SeqState& st, const ZBlock& b) {
+  L->rcount = 0;
+  if (L->status) return;
+  seq_state_uniform(st.b, st.c);
+  const u32 nseq = ZS_UNIFORM(b.nseq);
+  const u32 left = nseq - st.c.done, n = left < kSeqRound ? left : kSeqRound;
+  for (u32 i = 0; i < n; i++) {
+    u32 ll, ml;
+    i32 off;
+    const u32 rc = seq_step(st.b, st.c, (ZS_LDS u32*)L->fse[0], (ZS_LDS u32*)L->fse[1], (ZS_LDS u32*)L->fse[2], st.c.done + 1 == nseq, ll, ml, off);
+    if (rc != ST_OK) { L->status = rc; return; }
+    L->rbuf[i][0] = ll;
+    L->rbuf[i][1] = ml;
+    L->rbuf[i][2] = (u32)off;
+  }
+  L->rcount = n;
+  L->cursor = st.b.cursor_byte();
+}
+// (all threads) the round's sequences to the block's records
+ZS_FN void seq_flush(const ZS_LDS SeqLds* L, ZRec* recs_block, u32 base, int t) {
+  if ((u32)t >= L->rcount) return;
+  ZRec* r = recs_block + base + (u32)t;
+  r->ll = L->rbuf[t][0];
+  r->ml = L->rbuf[t][1];
+  r->off = (i32)L->rbuf[t][2];
+}
+// thread 0, behind the last round: the stream must be used up; the trailing literals; the block's size and history on exit
+ZS_FN void seq_finish(ZS_LDS SeqLds* L, SeqState& st, ZBlock* b, ZRec* recs_block) {
+  if (!seq_block_has_stream(*b)) {                           // a raw / RLE block, or a block of literals only: one run of literals
+    const u32 n = b->type == BT_COMPRESSED ? b->lit_regen : b->size;
+    recs_block[0].ll = n;
+    recs_block[0].ml = 0;
+    recs_block[0].off = 0;
+    b->out_size = n;
     for (int k = 0; k < 3; k++) b->rep_out[k] = rep_symbolic(k);
     return;
   }
   if (L->status) return;
-  u32 out_size = 0;
-  i32 rep[3];
-  const u32 rc = seq_decode(src + b->bits_pos, b->bits_len, src, L->fse[0], L->fse_log[0], L->fse[1], L->fse_log[1], L->fse[2], L->fse_log[2], L->llc, L->mlc, b->nseq,
-                            b->lit_regen, r, out_size, rep);
-  if (rc != ST_OK) { L->status = rc; return; }
-  b->out_size = out_size;
-  for (int k = 0; k < 3; k++) b->rep_out[k] = rep[k];
+  if (st.b.bitpos != 0) { L->status = ST_ERR_BITS; return; }
+  if (st.c.sum_ll > b->lit_regen || st.c.sum_ll + st.c.sum_ml > kBlockMax) { L->status = ST_ERR_LENGTH; return; }
+  recs_block[b->nseq].ll = b->lit_regen - (u32)st.c.sum_ll;
+  recs_block[b->nseq].ml = 0;
+  recs_block[b->nseq].off = 0;
+  b->out_size = b->lit_regen + (u32)st.c.sum_ml;
+  b->rep_out[0] = st.c.r0;
+  b->rep_out[1] = st.c.r1;
+  b->rep_out[2] = st.c.r2;
 }
+ZS_FN u32 seq_rounds(const ZBlock& b) { return seq_block_has_stream(b) ? (b.nseq + kSeqRound - 1) / kSeqRound : 0; }
 
 // ---- kernel B: one lane per page ----
 ZS_FN void page_blocks(const ZPage& pg, ZBlock* blocks, u32* status, int page_index) {
@@ -657,7 +924,7 @@ ZS_FN void zfrag_long_parts(ZS_LDS ZExecLds* L, u32 f0, const u8* lits, u8* dst,
 }  // namespace comet_zstd2
 
 // ---- host side: the walk over a page's frame and block headers (plain C++; csrc/zstd2.cpp, the scan and the host emulation) ----
-#ifndef __HIP_DEVICE_COMPILE__
+#ifndef ZS2_DEVICE_ONLY      // (the .hip file compiles the phases as __device__ functions: the walk, plain host code, cannot call them there)
 #include <vector>
 namespace comet_zstd2 {
 struct PageWalk {
@@ -829,6 +1096,116 @@ inline bool scan_page(const u8* p, u32 len, u32 expect_out, PageWalk& w) {
   if (pos != len) return false;                             // another frame (or garbage) behind the first
   if (out_known > expect_out) return false;
   return true;
+}
+
+// The first n bytes of a page's content — a v1 data page's definition levels sit there, and the host needs them for its run tables —
+// decoded on the host from the walk's descriptors with the primitives above: the literals and sequences of the first block(s) only as far
+// as those bytes reach (a Huffman stream yields its symbols in order from its END, so a prefix is cheap).  → bytes produced (< n: the
+// page is malformed or shorter; the caller then inflates it on the host, which reports what is wrong).
+inline size_t host_prefix(const u8* p, u32 len, const PageWalk& w, u8* out, size_t n) {
+  size_t produced = 0;
+  i32 rep[3] = {1, 4, 8};
+  std::vector<u8> lits;
+  std::vector<ZRec> recs;
+  std::vector<u16> huf((size_t)1 << kHufLogMax);
+  std::vector<u32> fse(3 * 1024);
+  u32 wfse[64];
+  u8 weights[256];
+  i16 norm[64];
+  u16 next[64];
+  for (const ZBlock& b : w.blocks) {
+    if (produced >= n) break;
+    const size_t need = n - produced;
+    if (b.type == BT_RAW) { const size_t k = need < b.size ? need : b.size; __builtin_memcpy(out + produced, p + b.pos, k); produced += k; continue; }
+    if (b.type == BT_RLE) { const size_t k = need < b.size ? need : b.size; __builtin_memset(out + produced, p[b.pos], k); produced += k; continue; }
+    const u32 nl = (u32)(need < b.lit_regen ? need : b.lit_regen);        // a prefix of `need` bytes holds at most `need` literals
+    lits.assign((size_t)nl + 8, 0);
+    if (b.lit_type == LT_RAW) __builtin_memcpy(lits.data(), p + b.lit_pos, nl);
+    else if (b.lit_type == LT_RLE) __builtin_memset(lits.data(), p[b.lit_pos], nl);
+    else {
+      int nw = 0;
+      if (!huf_read_weights(p + b.huf_desc, b.huf_desc_len, weights, nw, wfse, norm, next)) return produced;
+      const int log = huf_build(weights, nw, huf.data());
+      if (!log) return produced;
+      const u8* s = p + b.lit_pos;
+      auto stream = [&](const u8* at, u32 slen, u8* to, u32 cnt, bool whole) {
+        BackBitsT<PtrBytes<const u8*>> bb;
+        PtrBytes<const u8*> src;
+        src.p = at;
+        src.len = (i32)slen;
+        if (!bb.init(src, slen)) return false;
+        huf_decode_symbols(bb, huf.data(), log, to, cnt);
+        return whole ? bb.bitpos == 0 : bb.bitpos >= 0;
+      };
+      if (b.lit_streams == 1) {
+        if (!stream(s, b.lit_len, lits.data(), nl, nl == b.lit_regen)) return produced;
+      } else {
+        if (b.lit_len < 10) return produced;
+        const u32 l[3] = {(u32)s[0] | ((u32)s[1] << 8), (u32)s[2] | ((u32)s[3] << 8), (u32)s[4] | ((u32)s[5] << 8)};
+        if (6 + l[0] + l[1] + l[2] >= b.lit_len) return produced;
+        const u32 seg = (b.lit_regen + 3) / 4;
+        if (3 * seg > b.lit_regen) return produced;
+        u32 off = 6;
+        for (u32 k = 0; k < 4 && k * seg < nl; k++) {
+          const u32 slen = k < 3 ? l[k] : b.lit_len - off, full = k < 3 ? seg : b.lit_regen - 3 * seg;
+          const u32 cnt = nl - k * seg < full ? nl - k * seg : full;
+          if (!stream(s + off, slen, lits.data() + k * seg, cnt, cnt == full)) return produced;
+          off += slen;
+        }
+      }
+    }
+    if (b.nseq == 0) { __builtin_memcpy(out + produced, lits.data(), nl); produced += nl; continue; }
+    int logs[3];
+    for (int k = 0; k < 3; k++) {
+      const u32 d = b.tab_desc[k];
+      logs[k] = seq_table(k, b.tab_mode[k], p + d, d < len ? len - d : 0, fse.data() + 1024 * k, norm, next);
+      if (logs[k] < 0) return produced;
+      seq_table_expand(k, logs[k], fse.data() + 1024 * k);
+    }
+    recs.resize((size_t)b.nseq + 1);
+    u32 ndone = 0;
+    i32 rep_out[3];
+    {
+      BackBitsT<PtrBytes<const u8*>> bb;
+      PtrBytes<const u8*> src;
+      src.p = p + b.bits_pos;
+      src.len = (i32)b.bits_len;
+      if (!bb.init(src, b.bits_len)) return produced;
+      SeqCore c;
+      seq_begin(bb, c, logs[0], logs[1], logs[2]);
+      while (c.done < b.nseq && c.sum_ll + c.sum_ml < need) {
+        ZRec& r = recs[c.done];
+        if (seq_step(bb, c, fse.data(), fse.data() + 1024, fse.data() + 2048, c.done + 1 == b.nseq, r.ll, r.ml, r.off) != ST_OK) return produced;
+      }
+      ndone = c.done;
+      if (c.sum_ll > b.lit_regen) return produced;
+      if (ndone == b.nseq) {
+        if (bb.bitpos != 0) return produced;
+        recs[b.nseq].ll = b.lit_regen - (u32)c.sum_ll;
+        recs[b.nseq].ml = 0;
+        recs[b.nseq].off = 0;
+      }
+      rep_out[0] = c.r0;
+      rep_out[1] = c.r1;
+      rep_out[2] = c.r2;
+    }
+    u32 lp = 0;
+    const u32 nrec = ndone == b.nseq ? b.nseq + 1 : ndone;              // the whole block: its trailing literals too
+    for (u32 i = 0; i < nrec && produced < n; i++) {
+      const ZRec& r = recs[i];
+      for (u32 k = 0; k < r.ll && produced < n; k++) { if (lp >= nl) return produced; out[produced++] = lits[lp++]; }
+      if (!r.ml || produced >= n) continue;
+      const i32 off = rep_resolve(r.off, rep);
+      if (off <= 0 || (size_t)off > produced) return produced;
+      for (u32 k = 0; k < r.ml && produced < n; k++) { out[produced] = out[produced - (size_t)off]; produced++; }
+    }
+    if (ndone == b.nseq) {
+      i32 nr[3];
+      for (int j = 0; j < 3; j++) nr[j] = rep_resolve(rep_out[j], rep);
+      for (int j = 0; j < 3; j++) rep[j] = nr[j];
+    }
+  }
+  return produced;
 }
 }  // namespace comet_zstd2
 #endif

@@ -26,6 +26,8 @@
 #include "parquet_dev.h"
 #include "device/snappy2.hpp"
 #include "snappy2.hpp"
+#include "zstd2.hpp"
+#include "device/zstd2.hpp"
 #include "parquet_meta.hpp"
 
 extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
@@ -319,6 +321,7 @@ struct ScanOptions {
   // such pages hold and the host threads there are to decompress them (scan_parquet)
   int device_snappy_mode = -1;
   bool device_snappy = false;
+  bool device_zstd = true;             // zstd PLAIN pages of fixed-width columns take the device pipeline too (COMET_DEVICE_ZSTD=0: host threads inflate them)
   bool read_in_place = true;           // chunks whose pages the device inflates are pread() straight into their pinned slot; page bodies are uploaded from where they land (COMET_PARQUET_READ_IN_PLACE=0: read into scratch, copy bodies)
   bool device_dict_pages = true;       // dictionary-encoded snappy pages cross PCIe compressed too (COMET_DEVICE_DICT_PAGES=0: host-inflated as before)
   static ScanOptions of(const Operator& op) {
@@ -685,6 +688,8 @@ struct HostChunk {
   size_t ipos = 0;                 // bytes of the device-decompressed region used
   int64_t pages_skipped = 0;       // data pages the page index ruled out
   std::vector<PqInflate> inflate;  // page bodies the device decompresses (offsets relative to the chunk's slot in either region)
+  std::vector<PqInflate> zinflate; // … zstd ones: `preamble` = the page's first block in zblocks, `pad` = its block count
+  std::vector<comet_zstd2::ZBlock> zblocks;   // what the host walk over those pages' frames found (device/zstd2.hpp)
   std::vector<PqPage> pages;
   std::vector<PqRun> def_runs, idx_runs;
   std::vector<uint8_t> dict_bytes;
@@ -710,6 +715,7 @@ size_t staged_capacity(const pq::ColumnMeta& cm) {
 // offsets into the device-decompressed region carry this bit until the column's tables are assembled
 constexpr int64_t kInflatedBit = (int64_t)1 << 62;
 constexpr int32_t kMinDevicePage = 4096;
+constexpr double kDeviceZstdBytesPerMs = 17e6;      // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 28.9 ms (profiles/r3_zstd_pipeline.json)
 
 // DELTA_BYTE_ARRAY pages are prefix-compressed: what they decode to is only known from their length blocks.  One extra pass over such a
 // chunk (read, decompress, decode the two length blocks of every page) sizes its staging slot; nothing else pays for it.
@@ -759,7 +765,9 @@ size_t prefix_encoded_plain_bytes(const ChunkSource& src, const pq::ColumnMeta& 
 // it sits in the file.  Page bodies the device inflates cross PCIe from there — the second pass over them (scratch → staging) was half of
 // the host's work per scan once the device did the decompression.
 size_t in_place_extra(const pq::ColumnMeta& cm) { return ((size_t)std::max<int64_t>(cm.total_compressed, 0) + 64 + 15) & ~(size_t)15; }
-bool in_place_shape(const pq::ColumnMeta& cm, bool is_string, const ScanOptions& so) { return so.read_in_place && cm.codec == pq::SNAPPY && !is_string && !cm.prefix_encoded; }
+bool in_place_shape(const pq::ColumnMeta& cm, bool is_string, const ScanOptions& so) {
+  return so.read_in_place && (cm.codec == pq::SNAPPY || (cm.codec == pq::ZSTD && so.device_zstd)) && !is_string && !cm.prefix_encoded;
+}
 size_t chunk_staging_capacity(const ChunkSource& src, const pq::ColumnMeta& cm, int max_def, bool is_string, const ScanOptions& so) {
   return staged_capacity(cm) + (cm.prefix_encoded ? ((prefix_encoded_plain_bytes(src, cm, max_def) + 15) & ~(size_t)15) : 0) +
          (in_place_shape(cm, is_string, so) ? in_place_extra(cm) : 0);
@@ -922,6 +930,81 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     pg.width = cp.src_width;
     pg.dec_scale_up = cp.dec_scale_up;
     size_t page_begin = spos, vals_begin, page_end;
+    // zstd: PLAIN pages of fixed-width columns cross PCIe compressed.  The host walks the frame's block headers (sizes, modes, where the
+    // tables and bitstreams sit: comet_zstd2::scan_page) and, for a v1 page of an optional column, decodes the page's first bytes — its
+    // definition levels — from the first block's first literals and sequences; the device does the rest (device/zstd2.hpp).
+    if (so.device_snappy && so.device_zstd && cm.codec == pq::ZSTD && !cp.is_string && h.encoding == pq::PLAIN && h.uncompressed_size >= kMinDevicePage &&
+        (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.def_bytes >= 0 && h.compressed_size > h.def_bytes && h.uncompressed_size > h.def_bytes)) &&
+        (in_place || h.compressed_size <= h.uncompressed_size)) {
+      const size_t comp_off = h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes;
+      const size_t comp_len = (size_t)h.compressed_size - comp_off, un_len = (size_t)h.uncompressed_size - comp_off;
+      comet_zstd2::PageWalk zw;
+      bool ok = comet_zstd2::scan_page(body + comp_off, (uint32_t)comp_len, (uint32_t)un_len, zw);
+      size_t lvl = 0;
+      if (ok && h.type == pq::DATA_PAGE && max_def > 0) {
+        if (h.def_encoding != pq::RLE) throw CometError("parquet: only RLE definition levels are supported");
+        const size_t first = std::min<size_t>(un_len, 64);
+        tmp.resize(first + 8);
+        ok = first >= 4 && comet_zstd2::host_prefix(body, (uint32_t)comp_len, zw, tmp.data(), first) == first;
+        if (ok) {
+          uint32_t dl;
+          memcpy(&dl, tmp.data(), 4);
+          lvl = 4 + (size_t)dl;
+          ok = lvl <= un_len && lvl <= ((size_t)1 << 20);
+          if (ok && lvl > first) {
+            tmp.resize(lvl + 8);
+            ok = comet_zstd2::host_prefix(body, (uint32_t)comp_len, zw, tmp.data(), lvl) == lvl;
+          }
+        }
+      }
+      const size_t ipage = (hc.ipos + 15) & ~(size_t)15;
+      if (ok && ipage + un_len + 32 <= staged_cap) {
+        if (h.type == pq::DATA_PAGE) {
+          if (max_def > 0) {
+            const size_t first = def_runs.size();
+            pg.def_run_first = (int32_t)first;
+            parse_hybrid_runs(tmp.data() - ipage, ipage + 4, ipage + lvl, 1, h.num_values, def_runs);      // positions in the decompressed region, where the device puts these bytes
+            pg.def_run_count = (int32_t)(def_runs.size() - first);
+            for (size_t r = first; r < def_runs.size(); r++) def_runs[r].byte_off |= kInflatedBit;
+          }
+        } else {
+          memcpy(staged + spos, body, (size_t)h.def_bytes);
+          if (max_def > 0 && h.def_bytes) {
+            pg.def_run_first = (int32_t)def_runs.size();
+            parse_hybrid_runs(staged, spos, spos + (size_t)h.def_bytes, 1, h.num_values, def_runs);
+            pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
+          }
+          spos += (size_t)h.def_bytes;
+        }
+        size_t cpos;
+        if (in_place) {
+          cpos = (size_t)(body + comp_off - staged);
+          if (hc.raw_hi == 0) hc.raw_lo = cpos;
+          hc.raw_hi = cpos + comp_len;
+        } else {
+          cpos = (spos + 15) & ~(size_t)15;
+          if (cpos + comp_len + 32 > staged_cap) throw CometError("parquet: column chunk larger than its declared uncompressed size");
+          memcpy(staged + cpos, body + comp_off, comp_len);
+          memset(staged + cpos + comp_len, 0, 16);
+          spos = cpos + comp_len;
+        }
+        PqInflate job;
+        job.src_off = (int64_t)cpos;
+        job.dst_off = (int64_t)ipage;
+        job.src_len = (int32_t)comp_len;
+        job.dst_len = (int32_t)un_len;
+        job.preamble = (int32_t)hc.zblocks.size();
+        job.pad = (int32_t)zw.blocks.size();
+        hc.zblocks.insert(hc.zblocks.end(), zw.blocks.begin(), zw.blocks.end());
+        hc.zinflate.push_back(job);
+        hc.ipos = ipage + un_len;
+        pg.encoding = 0;
+        pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
+        emit(pg, values_seen, values_seen + h.num_values, h.type == pq::DATA_PAGE ? tmp.data() - ipage : staged);
+        values_seen += h.num_values;
+        continue;
+      }
+    }
     // Device decompression: PLAIN fixed-width values under snappy need nothing from the host but the definition levels (the first bytes
     // of a v1 page's stream; outside the stream in a v2 page), so the body crosses PCIe compressed and a GPU workgroup inflates it.
     // (a page that did not compress — bit-packed dictionary indices of random values, doubles — is a little LARGER than its content: read
@@ -1394,6 +1477,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (const char* e = getenv("COMET_DEVICE_DECOMPRESS")) so.device_snappy_mode = !strcmp(e, "auto") ? -1 : atoi(e) != 0;
   if (const char* e = getenv("COMET_DEVICE_DICT_PAGES")) so.device_dict_pages = atoi(e) != 0;
   if (const char* e = getenv("COMET_PARQUET_READ_IN_PLACE")) so.read_in_place = atoi(e) != 0;
+  if (const char* e = getenv("COMET_DEVICE_ZSTD")) so.device_zstd = atoi(e) != 0;
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy_mode = kv.second == "auto" ? -1 : (kv.second != "false" && kv.second != "0");
   if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
@@ -1474,6 +1558,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   std::vector<size_t> order(ncol);
   std::vector<int64_t> col_bytes(ncol, 0);
   int64_t plain_snappy_bytes = 0;     // uncompressed bytes of chunks that are snappy, fixed-width and (by bytes per value) mostly PLAIN
+  int64_t plain_zstd_bytes = 0;       // … zstd, fixed-width, mostly PLAIN
   for (size_t c = 0; c < ncol; c++) {
     order[c] = c;
     for (size_t si = 0; si < nsel; si++) {
@@ -1486,20 +1571,37 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       if (cm.codec == pq::SNAPPY && !cp.is_string && cp.src_width > 0 && cm.num_values > 0 &&
           (so.device_dict_pages || (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values))
         plain_snappy_bytes += cm.total_uncompressed;
+      // … and zstd chunks that are mostly PLAIN pages (dictionary-encoded zstd pages stay with the host threads)
+      if (cm.codec == pq::ZSTD && so.device_zstd && !cp.is_string && cp.src_width > 0 && cm.num_values > 0 &&
+          (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values)
+        plain_zstd_bytes += cm.total_uncompressed;
     }
   }
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return col_bytes[a] > col_bytes[b]; });
   // Measured on MI355X (profiles/r3_snappy_pipeline.json): the multi-kernel pipeline inflates PLAIN pages at 70–80 GB/s of output whatever
   // their number (it parallelises inside the pages), plus about half a millisecond of launches; a host core decompresses the same bytes at
   // ~1 GB/s.  Only a small scan on a host with many idle threads is better off on the host.
+  // zstd (profiles/r3_zstd_pipeline.json): the sequence decoder is one scalar lane per 128 KiB block — what bounds it is that lane's
+  // instruction count, not the number of blocks — so the device inflates at a rate that a host with a dozen idle cores matches; a Spark
+  // task, which owns one core, is better off on the device by a wide margin.
+  const int host_threads = std::max(1, std::min(max_inflight, ScanPool::get().size()));
   if (so.device_snappy_mode >= 0) {
     so.device_snappy = so.device_snappy_mode != 0;
   } else {
-    const double host_ms = (double)plain_snappy_bytes / 1e6 / (double)std::max(1, std::min(max_inflight, ScanPool::get().size()));
-    const double device_ms = 0.5 + (double)plain_snappy_bytes / 60e6;
-    so.device_snappy = plain_snappy_bytes > 0 && device_ms < host_ms;
+    const double host_ms = (double)(plain_snappy_bytes + plain_zstd_bytes) / 1e6 / (double)host_threads;
+    const double device_ms = 0.5 + (double)plain_snappy_bytes / 60e6 + (plain_zstd_bytes ? 1.0 + (double)plain_zstd_bytes / kDeviceZstdBytesPerMs : 0.0);
+    so.device_snappy = plain_snappy_bytes + plain_zstd_bytes > 0 && device_ms < host_ms;
+    // the two codecs decide separately when both are there: snappy pages by the pipeline's rate alone
+    if (!so.device_snappy && plain_snappy_bytes > 0 && 0.5 + (double)plain_snappy_bytes / 60e6 < (double)plain_snappy_bytes / 1e6 / (double)host_threads) {
+      so.device_snappy = true;
+      so.device_zstd = false;
+    } else if (so.device_snappy && plain_zstd_bytes > 0 && getenv("COMET_DEVICE_ZSTD") == nullptr &&
+               1.0 + (double)plain_zstd_bytes / kDeviceZstdBytesPerMs >= (double)plain_zstd_bytes / 1e6 / (double)host_threads) {
+      so.device_zstd = false;
+    }
   }
-  if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy pages of fixed-width columns, decompressed on the %s\n", (double)plain_snappy_bytes / 1e6, so.device_snappy ? "device" : "host");
+  if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy / %.1f MB of zstd pages of fixed-width columns, decompressed on the %s%s\n", (double)plain_snappy_bytes / 1e6,
+                     (double)plain_zstd_bytes / 1e6, so.device_snappy ? "device" : "host", so.device_snappy && plain_zstd_bytes && !so.device_zstd ? " (zstd: host)" : "");
   auto run_task = [&](size_t t) {
     const size_t c = t / nsel, si = t % nsel;
     ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg, sels[si].keep.get()};
@@ -1542,7 +1644,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     if (chunks[t].err) std::rethrow_exception(chunks[t].err);
   };
 
-  struct ColumnDevice { DevBuf bytes, tables; PinnedBuf h_tables; std::vector<std::unique_ptr<Snappy2Scratch>> snappy2; };
+  struct ColumnDevice { DevBuf bytes, tables; PinnedBuf h_tables; std::vector<std::unique_ptr<Snappy2Scratch>> snappy2; std::vector<std::unique_ptr<Zstd2Scratch>> zstd2; };
   std::vector<std::shared_ptr<ColumnDevice>> keep;
   // The chunks' slices cross PCIe as soon as they are ready, one hipMemcpyAsync each (≈ 40 µs of submission and completion latency per copy
   // whatever its size).  Two alternatives sit behind switches because they were measured and lost (SF10 Q6 from snappy Parquet, 16.6 ms
@@ -1657,9 +1759,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const bool may_inflate = so.device_snappy && !cp.is_string && !cp.missing;
     cd->bytes.ensure(may_inflate ? 2 * S + 64 : S);
     bool any_optional = false;
-    size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0, n_jobs = 0;
+    size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0, n_jobs = 0, n_zjobs = 0;
     static const bool one_wave_snappy = getenv("COMET_SNAPPY_ONE_WAVE") != nullptr && atoi(getenv("COMET_SNAPPY_ONE_WAVE")) != 0;
-    std::vector<PqInflate> group_jobs;
+    std::vector<PqInflate> group_jobs, zgroup_jobs;
+    std::vector<comet_zstd2::ZBlock> zgroup_blocks;
     size_t group_bytes = 0;
     for (size_t si = 0; si < nsel; si++) {
       wait_for(c * nsel + si);
@@ -1679,6 +1782,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       n_doffs += hc.dict_offs.size();
       n_soffs += hc.str_offs.size();
       n_jobs += hc.inflate.size();
+      n_zjobs += hc.zinflate.size();
       // only the bytes the chunk actually staged cross PCIe
       if (hc.spos) upload((char*)cd->bytes.p + slot_off[c][si], (char*)col_staged[c]->p + slot_off[c][si], std::min((hc.spos + 16 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]));
       if (hc.raw_hi > hc.raw_lo) {      // page bodies read in place: from where pread() put them (+ the few bytes behind the last one the kernels' vector loads touch)
@@ -1696,19 +1800,42 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
           group_jobs.push_back(job);
           group_bytes += (size_t)job.src_len;
         }
-      const bool group_full = !group_jobs.empty() && (group_bytes >= ((size_t)48 << 20) || si + 1 == nsel);
+      {
+        const int32_t first_block = (int32_t)zgroup_blocks.size();
+        zgroup_blocks.insert(zgroup_blocks.end(), hc.zblocks.begin(), hc.zblocks.end());
+        for (const PqInflate& src : hc.zinflate) {
+          PqInflate job = src;
+          job.src_off += (int64_t)slot_off[c][si];
+          job.dst_off += (int64_t)slot_off[c][si] + (int64_t)S;
+          job.preamble += first_block;
+          zgroup_jobs.push_back(job);
+          group_bytes += (size_t)job.src_len;
+        }
+      }
+      // (zstd: the sequence kernel is bound by ONE lane's serial chain per block, not by the number of blocks — up to ~3000 blocks take as
+      // long as one; so its groups are as large as that, 400 MiB of page data)
+      const bool group_full = (!group_jobs.empty() || !zgroup_jobs.empty()) &&
+                              (group_bytes >= (zgroup_jobs.empty() ? (size_t)48 << 20 : (size_t)160 << 20) || zgroup_blocks.size() >= 3000 || si + 1 == nsel);
       if (!next_ready || group_full) upload_flush();
       if (group_full) {
-        if (group_jobs.size() >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
+        if (group_jobs.size() >= ((size_t)1 << 23) || zgroup_jobs.size() >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
         upload_fence(stream_);
-        cd->snappy2.emplace_back(new Snappy2Scratch());
-        cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
-        pages_inflated_on_device_ += (int64_t)group_jobs.size();
+        if (!group_jobs.empty()) {
+          cd->snappy2.emplace_back(new Snappy2Scratch());
+          cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+        }
+        if (!zgroup_jobs.empty()) {
+          cd->zstd2.emplace_back(new Zstd2Scratch());
+          cd->zstd2.back()->run(zgroup_jobs.data(), (int)zgroup_jobs.size(), zgroup_blocks.data(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+        }
+        pages_inflated_on_device_ += (int64_t)(group_jobs.size() + zgroup_jobs.size());
         group_jobs.clear();
+        zgroup_jobs.clear();
+        zgroup_blocks.clear();
         group_bytes = 0;
       }
     }
-    if (n_jobs && !may_inflate) throw CometError("internal: device pages in a column without a decompression region");
+    if ((n_jobs || n_zjobs) && !may_inflate) throw CometError("internal: device pages in a column without a decompression region");
     if (trace) fprintf(stderr, "[comet] parquet: column %zu host chunks ready at %.2f ms\n", c, ms_since());
     // concatenate the chunks' tables: offsets become column-global
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -1971,7 +2098,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       read_small(ierr.data() + c0, (char*)inflate_err->p + c0 * 4, n * 4);
     }
     for (size_t c = 0; c < ncol; c++)
-      if (ierr[c]) throw CometError("Parquet column '" + op.required_schema[c].name + "': corrupt snappy data page (device decompression, page job " +
+      if (ierr[c]) throw CometError("Parquet column '" + op.required_schema[c].name + "': corrupt compressed data page (device decompression, page job " +
                                     std::to_string(ierr[c] >> 8) + ", code " + std::to_string(ierr[c] & 0xff) + ")");
   }
   out.owners.push_back(tiles);

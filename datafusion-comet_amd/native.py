@@ -995,6 +995,31 @@ def snappy2_inflate_pages(streams, page_lens, device_id: int = 0):
     return [out[int(o):int(o) + int(l)].tobytes() for o, l in zip(ooff, plen)], ms.value, [int(x) for x in status[:n]]
 
 
+def zstd2_inflate_pages(streams, page_lens, device_id: int = 0):
+    """The zstd pipeline (csrc/zstd2.cpp) over single-frame zstd streams held in host memory — comet_zstd2_inflate_pages.
+    Returns (pages, kernel_ms, status per page: 0 decoded on the device, 1 kept on the host by the frame walk — its page comes back as zeros);
+    raises CometNativeException naming the first corrupt page."""
+    import numpy as np
+    n = len(streams)
+    slen = np.array([len(s) for s in streams], np.int32)
+    soff = np.zeros(n, np.int64)
+    soff[1:] = np.cumsum(slen[:-1], dtype=np.int64)
+    blob = np.frombuffer(b"".join(streams) + b"\0", np.uint8)
+    plen = np.array(page_lens, np.int32)
+    ooff = np.zeros(n, np.int64)
+    ooff[1:] = np.cumsum(plen[:-1], dtype=np.int64)
+    out = np.zeros(int(plen.sum()) + 1, np.uint8)
+    status = np.zeros(max(n, 1), np.uint32)
+    ms = ctypes.c_double(0.0)
+    f = lib().comet_zstd2_inflate_pages
+    f.restype = ctypes.c_int64
+    rc = f(ctypes.c_void_p(blob.ctypes.data), ctypes.c_void_p(soff.ctypes.data), ctypes.c_void_p(slen.ctypes.data), ctypes.c_void_p(plen.ctypes.data), ctypes.c_int32(n),
+           ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ooff.ctypes.data), ctypes.c_int32(device_id), ctypes.byref(ms), ctypes.c_void_p(status.ctypes.data))
+    if rc != 0:
+        raise CometNativeException(f"zstd page {rc >> 8}: code {rc & 0xff}" if rc > 0 else "HIP error in comet_zstd2_inflate_pages")
+    return [out[int(o):int(o) + int(l)].tobytes() for o, l in zip(ooff, plen)], ms.value, [int(x) for x in status[:n]]
+
+
 def snappy_inflate_pages(streams, page_lens, device_id: int = 0):
     """Run the device snappy kernel (csrc/snappy_kernels.hip) over raw snappy streams held in host memory — the diagnostic entry
     comet_snappy_inflate_pages.  Returns (pages, kernel_ms); raises CometNativeException naming the first corrupt page."""

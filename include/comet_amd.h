@@ -208,6 +208,14 @@ int64_t comet_snappy_inflate_pages(const uint8_t* streams, const int64_t* stream
  * 0 decoded, 1 handed to the one-wave kernel, >= 16 corrupt.  *kernel_ms: all launches of one decompression (scratch already sized). */
 int64_t comet_snappy2_inflate_pages(const uint8_t* streams, const int64_t* stream_off, const int32_t* stream_len, const int32_t* page_len,
                                     int32_t npages, uint8_t* out, const int64_t* out_off, int32_t device_id, double* kernel_ms, uint32_t* status_out);
+/* zstd pages (csrc/device/zstd2.hpp): the host walks each frame's block headers — sizes, modes, where the table descriptions and
+ * bitstreams sit — and the device does the rest: Huffman literals a lane per stream, FSE sequences a lane per block, then the sequences are
+ * executed by pointer jumping per 64 KiB fragment (the reference inflates zstd pages on the task's CPU core through the zstd crate, like
+ * every other codec of the parquet crate's page reader).  `npages` single-frame streams of page_len[i] bytes each.  status_out (optional):
+ * 0 decoded, 1 the host walk keeps this page on the host (dictionary id, several frames, a content size that differs from page_len — it is
+ * left out of the launch and its output untouched), >= 16 corrupt.  Returns 0, (page << 8 | code) of the first corrupt page, -1 HIP error. */
+int64_t comet_zstd2_inflate_pages(const uint8_t* streams, const int64_t* stream_off, const int32_t* stream_len, const int32_t* page_len,
+                                  int32_t npages, uint8_t* out, const int64_t* out_off, int32_t device_id, double* kernel_ms, uint32_t* status_out);
 
 /* ---- in-library hash exchange between GPUs (csrc/exchange.cpp) ----------------------------------------------------
  * The step Spark's exchange performs between two native stages, done GPU to GPU: rows are hash-partitioned exactly as the reference's

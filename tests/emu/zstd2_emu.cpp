@@ -44,21 +44,64 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
   }
   std::vector<ZRec> recs((size_t)nrecs + 1);
   std::vector<u8> lits((size_t)nlits + 64, 0xcd);
-  // kernel A
-  auto E = std::make_unique<EntLds>();
+  // kernel A1: literals
+  auto LL = std::make_unique<LitLds>();
+  for (size_t bi = 0; bi < blocks.size(); bi++) {
+    const int pi = block_page[bi];
+    const ZPage& pg = pages[(size_t)pi];
+    const ZBlock& b = blocks[bi];
+    const u8* src = bytes.data() + pg.src_off;
+    u8* pl = lits.data() + pg.lit_first;
+    memset(LL.get(), 0xee, sizeof(LitLds));
+    LL->status = 0;
+    LL->huf_log = 0;
+    LL->nstreams = 0;
+    const u32 rounds = lit_rounds(b);
+    if (!rounds) {
+      for (int t = 0; t < 64; t++) lit_plain(src, b, pl, t);
+      continue;
+    }
+    for (int t = 0; t < 64; t++) lit_stage(LL.get(), src, b, t);
+    lit_table(LL.get(), b);
+    for (int t = 0; t < 64; t++) lit_fill(LL.get(), src, b, pg.src_len, t);
+    LitState st[4];
+    const int ns = (int)LL->nstreams;
+    for (int k = 0; k < ns; k++) { lit_fill_done(LL.get(), k); lit_begin(LL.get(), st[k], k); }
+    for (u32 r = 0; r < rounds && !LL->status; r++) {
+      for (int k = 0; k < ns; k++) lit_round(LL.get(), st[k], k);
+      if (LL->status) break;
+      for (int t = 0; t < 64; t++) lit_flush(LL.get(), b, pl, r, t);
+      for (int t = 0; t < 64; t++) lit_fill(LL.get(), src, b, pg.src_len, t);
+      for (int k = 0; k < ns; k++) lit_fill_done(LL.get(), k);
+    }
+    if (LL->status && LL->status > status[(size_t)pi]) status[(size_t)pi] = LL->status;
+  }
+  // kernel A2: sequences
+  auto SL = std::make_unique<SeqLds>();
   for (size_t bi = 0; bi < blocks.size(); bi++) {
     const int pi = block_page[bi];
     const ZPage& pg = pages[(size_t)pi];
     ZBlock& b = blocks[bi];
     const u8* src = bytes.data() + pg.src_off;
-    memset(E.get(), 0xee, sizeof(EntLds));
-    E->status = 0;
-    E->huf_log = 0;
-    ent_huf_table(E.get(), src, b);                              // thread 0
-    ent_seq_tables(E.get(), src, b, (u32)pg.src_len);            // thread 64
-    for (int t = 0; t < 64; t++) ent_literals(E.get(), src, b, lits.data() + pg.lit_first, t);
-    ent_sequences(E.get(), src, &b, recs.data() + pg.rec_first); // thread 64
-    if (E->status && E->status > status[(size_t)pi]) status[(size_t)pi] = E->status;
+    ZRec* rb = recs.data() + pg.rec_first + b.rec_first;
+    memset(SL.get(), 0xee, sizeof(SeqLds));
+    SL->status = 0;
+    SL->rcount = 0;
+    for (int t = 0; t < 64; t++) seq_stage(SL.get(), src, b, (u32)pg.src_len, t);
+    seq_tables(SL.get(), b);
+    for (int t = 0; t < 64; t++) seq_fill(SL.get(), src, b, pg.src_len, t);
+    SeqState st;
+    if (seq_block_has_stream(b)) { seq_fill_done(SL.get()); seq_start(SL.get(), st, b); }
+    const u32 rounds = seq_rounds(b);
+    for (u32 r = 0; r < rounds; r++) {
+      seq_round(SL.get(), st, b);
+      if (SL->status) break;
+      for (int t = 0; t < 64; t++) seq_flush(SL.get(), rb, r * kSeqRound, t);
+      for (int t = 0; t < 64; t++) seq_fill(SL.get(), src, b, pg.src_len, t);
+      seq_fill_done(SL.get());
+    }
+    seq_finish(SL.get(), st, &b, rb);
+    if (SL->status && SL->status > status[(size_t)pi]) status[(size_t)pi] = SL->status;
   }
   // kernel B
   for (int i = 0; i < npages; i++)
@@ -127,4 +170,11 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
   }
   if (info_out) { info_out[0] = max_rounds; info_out[1] = (int32_t)blocks.size(); info_out[2] = (int32_t)nrecs; info_out[3] = (int32_t)nlits; for (int k = 0; k < 16; k++) info_out[4 + k] = (int32_t)seen[k]; }
   return 0;
+}
+
+// the host's look at a page's first bytes (what the scan does for a v1 page's definition levels); → bytes produced, -1: the walk refuses the page
+extern "C" int64_t zs2_emu_host_prefix(const uint8_t* stream, int32_t len, int32_t page_len, uint8_t* out, int64_t n) {
+  PageWalk w;
+  if (!scan_page(stream, (u32)len, (u32)page_len, w)) return -1;
+  return (int64_t)host_prefix(stream, (u32)len, w, out, (size_t)n);
 }

@@ -1,0 +1,194 @@
+"""The zstd pipeline (csrc/device/zstd2.hpp: host walk over the frame's block headers → Huffman literals a lane per stream, FSE sequences
+a lane per block → block positions and repeat-offset history per page → record positions → pointer jumping per 64 KiB fragment) run on the
+CPU: the same phases the gfx950 kernels call, with the threads of a workgroup looped (tests/emu/zstd2_emu.cpp).  Frames: libzstd's, through
+pyarrow, at levels −5 … 22 over the page shapes a scan meets (every literal and table mode the format has turns up, asserted through the
+walk's counters), streaming frames without a content size, hand-built frames for the corners no compressor emits on demand; frames the walk
+must keep on the host; damaged frames under AddressSanitizer — an error or bytes, never a stray access."""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEEN = "raw_block rle_block compressed_block lit_raw lit_rle lit_huffman lit_treeless one_stream four_streams weights_fse weights_direct " \
+       "table_predefined table_rle table_fse table_repeat no_sequences".split()
+CSRC = os.path.join(ROOT, "datafusion-comet_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("zstd2_emu") / "libzstd2_emu.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", so], check=True)
+    lib = ctypes.CDLL(so)
+    lib.zs2_emu_inflate_pages.restype = ctypes.c_int64
+    lib.zs2_emu_host_prefix.restype = ctypes.c_int64
+
+    def inflate(streams, page_lens):
+        n = len(streams)
+        slen = np.array([len(s) for s in streams], np.int32)
+        soff = np.zeros(n, np.int64)
+        soff[1:] = np.cumsum(slen[:-1], dtype=np.int64)
+        blob = np.frombuffer(b"".join(streams) + b"\0", np.uint8)
+        plen = np.array(page_lens, np.int32)
+        ooff = np.zeros(n, np.int64)
+        ooff[1:] = np.cumsum(plen[:-1], dtype=np.int64)
+        out = np.zeros(int(plen.sum()) + 1, np.uint8)
+        status = np.zeros(n, np.uint32)
+        info = np.zeros(24, np.int32)
+        lib.zs2_emu_inflate_pages(ctypes.c_void_p(blob.ctypes.data), ctypes.c_void_p(soff.ctypes.data), ctypes.c_void_p(slen.ctypes.data),
+                                  ctypes.c_void_p(plen.ctypes.data), ctypes.c_int32(n), ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ooff.ctypes.data),
+                                  ctypes.c_void_p(status.ctypes.data), ctypes.c_void_p(info.ctypes.data))
+        seen = dict(zip(SEEN, (int(x) for x in info[4:20])))
+        return [int(s) for s in status], [out[int(o):int(o) + int(l)].tobytes() for o, l in zip(ooff, plen)], seen
+
+    def prefix(stream, page_len, n):
+        sb = np.frombuffer(stream + b"\0" * 16, np.uint8)
+        out = np.zeros(n + 8, np.uint8)
+        got = lib.zs2_emu_host_prefix(ctypes.c_void_p(sb.ctypes.data), ctypes.c_int32(len(stream)), ctypes.c_int32(page_len), ctypes.c_void_p(out.ctypes.data), ctypes.c_int64(n))
+        return got, out[:max(got, 0)].tobytes()
+    inflate.prefix = prefix
+    return inflate
+
+
+def scan_pages(seed=7, big=1 << 20):
+    rng = np.random.default_rng(seed)
+    words = " ".join(rng.choice(["alpha", "beta", "gamma", "lineitem", "orders", "MI355X", "zstd", "fse"], big // 4)).encode()
+    return [
+        rng.integers(90_000, 10_000_000, big // 8).astype(np.int64).tobytes(),           # decimal(12,2)-as-INT64: a sequence or two per value
+        rng.integers(0, 50, big // 4).astype(np.int32).tobytes(),
+        words[:big],
+        (np.arange(big // 8, dtype=np.int64) * 1000).tobytes(),                          # sorted keys: matches at offset 8, repeat offsets all the way
+        bytes(big),                                                                      # RLE blocks
+        rng.integers(0, 256, big, dtype=np.uint8).tobytes(),                             # raw blocks
+        rng.integers(0, 4, big, dtype=np.uint8).tobytes(),                               # Huffman-only: few sequences, four long streams
+        b"".join(rng.integers(0, 256, 300, dtype=np.uint8).tobytes() * 40 for _ in range(big // 13_000)),   # long matches, some across fragments
+        b"a", b"hello hello hello hello hello hello", b"abcdefg" * 9000,
+    ]
+
+
+def test_libzstd_frames_at_every_level(emu):
+    pages = scan_pages()
+    total = dict.fromkeys(SEEN, 0)
+    for level in (-5, 1, 3, 7, 12, 19, 22):
+        codec = pa.Codec("zstd", compression_level=level)
+        streams = [codec.compress(p, asbytes=True) for p in pages]
+        status, got, seen = emu(streams, [len(p) for p in pages])
+        assert status == [0] * len(pages), (level, status)
+        for i, (g, p) in enumerate(zip(got, pages)):
+            assert g == p, (level, i)
+        for k, v in seen.items():
+            total[k] += v
+    # every branch of the format libzstd emits on such data has been through the decoder
+    for k in ("raw_block", "rle_block", "compressed_block", "lit_raw", "lit_huffman", "lit_treeless", "one_stream", "four_streams", "weights_fse", "weights_direct",
+              "table_predefined", "table_rle", "table_fse", "table_repeat"):
+        assert total[k] > 0, (k, total)
+
+
+def test_streaming_frames_without_a_content_size(emu):
+    """what a streaming writer (parquet-mr's ZstdOutputStream, pyarrow's CompressedOutputStream) produces: a window descriptor, no size"""
+    pages = scan_pages(seed=8, big=300_000)
+    streams = []
+    for p in pages:
+        sink = pa.BufferOutputStream()
+        out = pa.CompressedOutputStream(sink, "zstd")
+        for i in range(0, len(p), 100_000):
+            out.write(p[i:i + 100_000])
+        out.close()
+        streams.append(sink.getvalue().to_pybytes())
+    assert all((s[4] >> 6) == 0 and not (s[4] & 0x20) for s in streams)                 # no content size field, not single-segment
+    status, got, _ = emu(streams, [len(p) for p in pages])
+    assert status == [0] * len(pages)
+    assert got == pages
+
+
+def frame(blocks, content_size=None):
+    """a zstd frame from (kind, payload) blocks: kind 'raw' bytes, 'rle' (byte, count), 'comp' the compressed block's bytes"""
+    out = bytearray(b"\x28\xb5\x2f\xfd")
+    if content_size is None:
+        out += bytes([0x00, 0x58])                      # no content size, window descriptor: 2 MiB
+    else:
+        out += bytes([0xa0]) + struct.pack("<I", content_size)      # single segment, 4-byte content size
+    for i, (kind, payload) in enumerate(blocks):
+        last = 1 if i + 1 == len(blocks) else 0
+        if kind == "raw":
+            out += struct.pack("<I", last | (0 << 1) | (len(payload) << 3))[:3] + payload
+        elif kind == "rle":
+            out += struct.pack("<I", last | (1 << 1) | (payload[1] << 3))[:3] + bytes([payload[0]])
+        else:
+            out += struct.pack("<I", last | (2 << 1) | (len(payload) << 3))[:3] + payload
+    return bytes(out)
+
+
+def test_hand_built_corners(emu):
+    # RLE literals and no sequences at all: literals header type 1, 5-bit size (27 × 'x'), then a zero sequence count
+    rle_lits = bytes([(27 << 3) | 1, ord("x"), 0])
+    # raw literals + ONE sequence with predefined tables: literals "abcdef", ll 6 ml 12 offset 6 (offset value 9 = code 3, extra 1)
+    # bitstream (read backwards): LL state (6 bits) → code 6 is state …; built instead by searching the predefined tables through the decoder:
+    # simpler and sufficient here: a raw block, an RLE block and the compressed block above in one frame, and output positions that straddle
+    pages, streams = [], []
+    body = [("raw", b"0123456789" * 7000), ("rle", (ord("z"), 70_000)), ("comp", rle_lits), ("raw", b"tail")]
+    pages.append(b"0123456789" * 7000 + b"z" * 70_000 + b"x" * 27 + b"tail")
+    streams.append(frame(body))
+    streams.append(frame(body, content_size=len(pages[0])))
+    pages.append(pages[0])
+    # an empty last block
+    streams.append(frame([("raw", b"abc"), ("raw", b"")]))
+    pages.append(b"abc")
+    status, got, seen = emu(streams, [len(p) for p in pages])
+    assert status == [0, 0, 0]
+    assert got == pages
+    assert seen["lit_rle"] == 2 and seen["no_sequences"] == 2 and seen["rle_block"] == 2
+
+
+def test_frames_the_walk_keeps_on_the_host(emu):
+    raw = b"some page bytes " * 500
+    good = pa.Codec("zstd", compression_level=3).compress(raw, asbytes=True)
+    with_dict_id = bytearray(good)
+    with_dict_id[4] |= 1                                   # dictionary id flag: a field the frame does not have → refused before anything is read
+    two_frames = good + good
+    skippable = b"\x50\x2a\x4d\x18" + struct.pack("<I", 4) + b"abcd" + good
+    wrong_size = good
+    truncated = good[:-3]
+    status, _, _ = emu([bytes(with_dict_id), two_frames, skippable, wrong_size, truncated, good], [len(raw), 2 * len(raw), len(raw), len(raw) + 1, len(raw), len(raw)])
+    assert status[:5] == [1, 1, 1, 1, 1] and status[5] == 0
+
+
+def test_host_prefix_is_the_pages_first_bytes(emu):
+    """a v1 data page keeps its definition levels in front of the values inside the compressed stream: the host decodes just those bytes"""
+    pages = scan_pages(seed=9, big=400_000)
+    for level in (1, 3, 19):
+        codec = pa.Codec("zstd", compression_level=level)
+        for p in pages:
+            s = codec.compress(p, asbytes=True)
+            for n in (1, 4, 11, 100, 5000, 70_000, 200_000, len(p)):
+                n = min(n, len(p))
+                got, b = emu.prefix(s, len(p), n)
+                assert got == n and b == p[:n], (level, len(p), n, got)
+
+
+def test_damaged_frames_under_address_sanitizer(tmp_path):
+    exe = str(tmp_path / "zstd2_fuzz")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + CSRC,
+                        os.path.join(ROOT, "tests", "emu", "zstd2_fuzz.cpp"), os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and "asan" in (r.stderr or "").lower():
+        pytest.skip("no AddressSanitizer runtime in this image")
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(11)
+    pages = [rng.integers(90_000, 10_000_000, 9000).astype(np.int64).tobytes(), rng.integers(0, 50, 30_000).astype(np.int32).tobytes(),
+             " ".join(rng.choice(["alpha", "beta", "gamma"], 20_000)).encode(), rng.integers(0, 4, 70_000, dtype=np.uint8).tobytes(),
+             (np.arange(20_000, dtype=np.int64) * 1000).tobytes(), bytes(10_000) + rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()]
+    path = str(tmp_path / "frames.bin")
+    with open(path, "wb") as f:
+        for level in (1, 3, 19):
+            codec = pa.Codec("zstd", compression_level=level)
+            for p in pages:
+                s = codec.compress(p, asbytes=True)
+                f.write(struct.pack("<II", len(s), len(p)) + s)
+    r = subprocess.run([exe, path, "60", "5"], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    ran, accepted, refused, corrupt = (int(x) for x in r.stdout.split())
+    assert ran == 18 * 60 and refused > 50 and corrupt > 200, r.stdout

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--skip-one-wave", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--kinds", default="decimal_int64,double,int32_lowcard")
+    ap.add_argument("--codec", default="snappy", choices=["snappy", "zstd"], help="zstd: the zstd pipeline (comet_zstd2_inflate_pages) on the same pages")
+    ap.add_argument("--level", type=int, default=1, help="zstd compression level of the pages (Spark's parquet.compression.codec.zstd.level default is 3; pyarrow's 1)")
     a = ap.parse_args()
     import numpy as np
     import pyarrow as pa
@@ -29,17 +31,20 @@ def main():
         "double": lambda: rng.standard_normal(n8).tobytes(),
         "int32_lowcard": lambda: rng.integers(0, 50, a.page_bytes // 4).astype(np.int32).tobytes(),
     }
-    res = {"pages": a.pages, "page_bytes": a.page_bytes}
+    res = {"pages": a.pages, "page_bytes": a.page_bytes, "codec": a.codec}
+    if a.codec == "zstd":
+        res["level"] = a.level
     for name, gen in kinds.items():
         if name not in a.kinds.split(","):
             continue
         distinct = [gen() for _ in range(8)]
-        comp = [pa.compress(p, codec="snappy", asbytes=True) for p in distinct]
+        comp = [pa.compress(p, codec="snappy", asbytes=True) if a.codec == "snappy" else pa.Codec("zstd", compression_level=a.level).compress(p, asbytes=True) for p in distinct]
         pages = [distinct[i % 8] for i in range(a.pages)]
         streams = [comp[i % 8] for i in range(a.pages)]
         total = sum(map(len, pages))
         res[name] = {"compressed_ratio": sum(map(len, streams)) / total}
-        for label, fn in (("pipeline", native.snappy2_inflate_pages), ("one_wave_per_page", native.snappy_inflate_pages)):
+        runs = (("pipeline", native.snappy2_inflate_pages), ("one_wave_per_page", native.snappy_inflate_pages)) if a.codec == "snappy" else (("pipeline", native.zstd2_inflate_pages),)
+        for label, fn in runs:
             if label == "one_wave_per_page" and a.skip_one_wave:
                 continue
             best = None
