@@ -405,7 +405,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
       for (int u = 0; u < U; u++) {
         const i32 j = base + u * 64 + lane;
         v[u] = 0;
-        if (j < count) v[u] = (CV == 0 && kind == PQ_BOOL) ? (i128)((src[j >> 3] >> (j & 7)) & 1) : pq_cv<CV>(kind, src + (i64)j * width, width, dec_up);
+        if (j < count) v[u] = (CV == 0 && kind == PQ_BOOL) ? (i128)((src[(j + rn.pad) >> 3] >> ((j + rn.pad) & 7)) & 1) : pq_cv<CV>(kind, src + (i64)j * width, width, dec_up);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -421,7 +421,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
   // still store consecutive rows).
   const int bw = pg.bit_width;
   const u8* packed = bytes + rn.byte_off;
-  const i32 nbytes = (i32)(((i64)count * bw + 7) >> 3);
+  const i32 nbytes = (i32)(((i64)count * bw + rn.pad + 7) >> 3);
   if (nbytes <= kUnitLdsBytes) {
     for (i32 o = lane * 16; o < nbytes; o += 64 * 16) {
       u64 lo = pq_ld64(packed + o), hi = pq_ld64(packed + o + 8);      // (reads up to 15 bytes past the run: the staging is padded)
@@ -443,7 +443,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
 #pragma unroll
           for (int k = 0; k < VN; k++) {
             const i32 j = base + (g * 64 + lane) * VN + k;
-            const u32 bit = (u32)j * (u32)bw;
+            const u32 bit = (u32)j * (u32)bw + (u32)rn.pad;
             const u32 wi = bit >> 5;
             idx[g][k] = j < count ? (u32)(((((u64)lds[wi + 1]) << 32 | lds[wi]) >> (bit & 31)) & mask) : 0u;
           }
@@ -466,7 +466,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const i32 j = base + u * 64 + lane;
-        const u32 bit = (u32)j * (u32)bw;
+        const u32 bit = (u32)j * (u32)bw + (u32)rn.pad;
         const u32 wi = bit >> 5;
         idx[u] = j < count ? (u32)(((((u64)lds[wi + 1]) << 32 | lds[wi]) >> (bit & 31)) & mask) : 0u;
       }
@@ -489,7 +489,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const i32 j = base + u * 64 + lane;
-      const i64 bit = (i64)j * bw;
+      const i64 bit = (i64)j * bw + rn.pad;
       idx[u] = j < count ? (u32)((pq_ld64(packed + (bit >> 3)) >> (bit & 7)) & mask) : 0u;
     }
     i128 v[U];
@@ -510,7 +510,7 @@ __device__ __forceinline__ PqRun pq_load_run_uniform(const PqRun* rp) {
   rn.is_rle = __builtin_amdgcn_readfirstlane(rp->is_rle);
   rn.rle_value = (u32)__builtin_amdgcn_readfirstlane((int)rp->rle_value);
   rn.page = __builtin_amdgcn_readfirstlane(rp->page);
-  rn.pad = 0;
+  rn.pad = __builtin_amdgcn_readfirstlane(rp->pad);     // first bit of the unit inside its first byte (units clipped to a kept piece of a pruned page)
   return rn;
 }
 __global__ __launch_bounds__(256) void pq_decode_runs_kernel(PqDecodeArgs a) {

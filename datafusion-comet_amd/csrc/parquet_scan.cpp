@@ -866,6 +866,17 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     }
     const Ranges& keep = *src.keep;
     while (keep_i < keep.size() && keep[keep_i].second <= r0) keep_i++;
+    // Fixed-width columns: every kept piece gets its OWN units for the run-at-a-time kernel — the page's runs (or PLAIN chunks) clipped to
+    // the piece's values, a bit-packed run possibly starting inside a byte (PqRun.pad = the bit) — so pruned scans decode at the same rate
+    // as full ones (they took the row-at-a-time kernel, a quarter of the HBM roofline).  The page's own runs leave the table: nothing
+    // refers to them any more.  (Strings keep the shared runs and the row-at-a-time path; COMET_PQ_DECODE_ROWS keeps it for everything.)
+    static const bool clip_units = getenv("COMET_PQ_DECODE_ROWS") == nullptr;
+    const bool clip = clip_units && !cp.is_string;
+    std::vector<PqRun> page_runs;
+    if (clip) {
+      page_runs.assign(idx_runs.begin() + pg.idx_run_first, idx_runs.begin() + pg.idx_run_first + pg.idx_run_count);
+      idx_runs.resize((size_t)pg.idx_run_first);
+    }
     for (size_t k = keep_i; k < keep.size() && keep[k].first < r1; k++) {
       const int64_t a = std::max(keep[k].first, r0), b = std::min(keep[k].second, r1);
       if (a >= b) continue;
@@ -874,6 +885,26 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       q.num_values = (int32_t)(b - a);
       q.lvl_skip = (int32_t)(a - r0);
       q.val_skip = (int32_t)non_null_before(a - r0);
+      if (clip) {
+        const int64_t v0 = q.val_skip, v1 = std::min<int64_t>(non_null_before(b - r0), pg.value_count);
+        q.idx_run_first = (int32_t)idx_runs.size();
+        for (const PqRun& r : page_runs) {
+          const int64_t lo = std::max<int64_t>(r.value_start, v0), hi = std::min<int64_t>((int64_t)r.value_start + r.count, v1);
+          if (lo >= hi) continue;
+          PqRun c = r;
+          const int64_t skip = lo - r.value_start;
+          c.value_start = (int32_t)(lo - v0);
+          c.count = (int32_t)(hi - lo);
+          if (r.is_rle != 1) {
+            const int64_t unit_bits = r.is_rle == 0 ? (int64_t)pg.bit_width : (cp.kind == PQ_BOOL ? 1 : (int64_t)cp.src_width * 8);
+            c.byte_off += (skip * unit_bits) / 8;
+            c.pad = (int32_t)((skip * unit_bits) % 8);
+          }
+          idx_runs.push_back(c);
+        }
+        q.idx_run_count = (int32_t)idx_runs.size() - q.idx_run_first;
+        q.value_count = (int32_t)std::max<int64_t>(v1 - v0, 0);
+      }
       pages.push_back(q);
       out_pos += b - a;
     }
@@ -1890,7 +1921,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         // every index run (and PLAIN chunk) learns its page: the run-at-a-time kernel starts from the run
         for (size_t gp = ip - hc.pages.size(); gp < ip; gp++)
           for (int32_t r = P[gp].idx_run_first; r < P[gp].idx_run_first + P[gp].idx_run_count; r++) I[r].page = (int32_t)gp;
-        runs_kernel_ok &= sels[si].keep == nullptr;      // pieces of a pruned page share their page's runs: those columns take the row-at-a-time kernel
+        // (pieces of a pruned page have their own clipped units unless COMET_PQ_DECODE_ROWS keeps the shared runs and the row-at-a-time kernel)
+        runs_kernel_ok &= sels[si].keep == nullptr || getenv("COMET_PQ_DECODE_ROWS") == nullptr;
         if (!hc.dict_bytes.empty()) memcpy(DB + idb, hc.dict_bytes.data(), hc.dict_bytes.size());
         idb += (hc.dict_bytes.size() + 15) & ~(size_t)15;
         if (!hc.dict_offs.empty()) memcpy(DO + ido, hc.dict_offs.data(), hc.dict_offs.size() * 4);

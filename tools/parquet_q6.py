@@ -21,20 +21,30 @@ def main():
     ap.add_argument("--dir", default="/tmp")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-dictionary", action="store_true")
+    ap.add_argument("--clustered", action="store_true", help="rows in l_shipdate order (a table clustered by date), written with page indexes, and Q6's date range pushed into the scan as data filters: "
+                    "most pages are pruned, the pages at the range's ends are kept in pieces")
     ap.add_argument("--out", default="", help="also write the JSON line here")
     a = ap.parse_args()
     import pyarrow as pa
     import pyarrow.parquet as papq
     from datafusion_comet_amd import native, serde as S, tpch
-    path = os.path.join(a.dir, f"lineitem_q6_{a.rows}_{a.codec}{'_plain' if a.no_dictionary else ''}.parquet")
+    path = os.path.join(a.dir, f"lineitem_q6_{a.rows}_{a.codec}{'_plain' if a.no_dictionary else ''}{'_clustered' if a.clustered else ''}.parquet")
     table = tpch.lineitem_q6(a.rows, seed=6)
+    if a.clustered:
+        import pyarrow.compute as pc
+        table = table.take(pc.sort_indices(table, sort_keys=[(table.schema.names[3], "ascending")]))
     if not os.path.exists(path):
         t0 = time.perf_counter()
         papq.write_table(table, path, row_group_size=1 << 20, compression=None if a.codec == "none" else a.codec,
-                         use_dictionary=not a.no_dictionary, store_decimal_as_integer=True, data_page_size=1 << 20)
+                         use_dictionary=not a.no_dictionary, store_decimal_as_integer=True, data_page_size=(64 << 10) if a.clustered else (1 << 20),
+                         write_page_index=a.clustered)
         print(f"wrote {path}: {os.path.getsize(path) / 1e6:.1f} MB in {time.perf_counter() - t0:.1f} s", file=sys.stderr)
     fsize = os.path.getsize(path)
-    src = S.native_scan([path], table.schema.names, [tpch.DEC, tpch.DEC, tpch.DEC, S.T_DATE])
+    filters = []
+    if a.clustered:
+        ship = S.col(3, S.T_DATE)
+        filters = [S.gt_eq(ship, S.lit(tpch.days(1994, 1, 1), S.T_DATE)), S.lt(ship, S.lit(tpch.days(1995, 1, 1), S.T_DATE))]
+    src = S.native_scan([path], table.schema.names, [tpch.DEC, tpch.DEC, tpch.DEC, S.T_DATE], data_filters=filters)
     plan = tpch.q6_plan(source=src).encode()
     want = None
     times = []
