@@ -25,6 +25,7 @@ every rank owns SF100 rows (weak scaling), rank 0 prints ONE JSON line.
   cold_create_plan_ms    hiprtc compilation behind createPlan for the Q1 plan with an EMPTY code-object cache (tools/cold_plan.py)
   q6_sf10_parquet        BASELINE configs[1]: SF10 Q6 from snappy / zstd Parquet end to end (tools/parquet_q6.py)
   snappy_pipeline        the device snappy decompressor alone on 1 MiB pages (tools/snappy_bench.py)
+  zstd_pipeline          the device zstd decompressor alone on 1 MiB pages (tools/snappy_bench.py --codec zstd)
 """
 import argparse
 import json
@@ -193,7 +194,14 @@ def main():
                 for codec in ("snappy", "zstd"):
                     legs["pq6_" + codec] = run_child_leg([os.path.join(ROOT, "tools", "parquet_q6.py"), "--codec", codec, "--steps", "4"],
                                                          rank, local_rank, world, args.leg_timeout, 5017 + (0 if codec == "snappy" else 100))
+                # … and what one Spark task sees (it owns ONE core): zstd PLAIN pages inflated on the device vs on that core
+                legs["pq6_zstd_task_device"] = run_child_leg([os.path.join(ROOT, "tools", "parquet_q6.py"), "--codec", "zstd", "--steps", "3", "--scan-threads", "1"],
+                                                             rank, local_rank, world, args.leg_timeout, 5217)
+                legs["pq6_zstd_task_host"] = run_child_leg([os.path.join(ROOT, "tools", "parquet_q6.py"), "--codec", "zstd", "--steps", "3", "--scan-threads", "1",
+                                                            "--device-decompress", "false"], rank, local_rank, world, args.leg_timeout, 5267)
                 legs["snappy"] = run_child_leg([os.path.join(ROOT, "tools", "snappy_bench.py"), "--pages", "240", "--skip-one-wave"], rank, local_rank, world, 180, 5317)
+                legs["zstd"] = run_child_leg([os.path.join(ROOT, "tools", "snappy_bench.py"), "--codec", "zstd", "--level", "1", "--pages", "240", "--kinds", "decimal_int64,int32_lowcard"],
+                                             rank, local_rank, world, 180, 5417)
             if not args.no_paths:
                 legs["paths"] = run_child_leg([os.path.join(ROOT, "tools", "paths.py"), "--query", "q1", "--rows", str(args.path_rows)],
                                               rank, local_rank, world, args.leg_timeout, 3017)
@@ -283,12 +291,21 @@ def main():
         pq6 = {c: legs.get("pq6_" + c) for c in ("snappy", "zstd") if legs.get("pq6_" + c) is not None}
         if pq6:
             line["q6_sf10_parquet"] = {c: ({"ms_best": v["sec_best"] * 1e3, "ms_median": v["sec_median"] * 1e3, "rows_per_s": v["rows_per_s"], "file_bytes": v["file_bytes"],
-                                            "matches_resident_plan": v["matches_resident_plan"], "pyarrow_read_s_all_cores": v["pyarrow_read_s_all_cores"]} if "error" not in v else v)
+                                            "matches_resident_plan": v["matches_resident_plan"], "pyarrow_read_s_all_cores": v["pyarrow_read_s_all_cores"],
+                                            "pages_decompressed_on_device": v.get("pages_decompressed_on_device")} if "error" not in v else v)
                                        for c, v in pq6.items()}
+            task = {k: legs.get("pq6_zstd_task_" + k) for k in ("device", "host")}
+            if all(v is not None and "error" not in v for v in task.values()):
+                line["q6_sf10_parquet"]["zstd_one_scan_thread"] = {k: {"ms_best": v["sec_best"] * 1e3, "pages_decompressed_on_device": v.get("pages_decompressed_on_device"),
+                                                                       "matches_resident_plan": v["matches_resident_plan"]} for k, v in task.items()}
             line["q6_sf10_parquet"]["note"] = ("BASELINE configs[1] end to end (createPlan .. releasePlan over the file in the page cache): footer + page walk on the host, "
-                                               "snappy pages inflated on the device (multi-kernel pipeline), zstd pages on host threads, decode + fused Q6 kernel on the device")
+                                               "snappy pages inflated on the device (multi-kernel pipeline); zstd PLAIN pages on the device or on host threads, whichever the scan's "
+                                               "thread count favours (pages_decompressed_on_device says which; zstd_one_scan_thread = what a Spark task with one core sees); "
+                                               "decode + fused Q6 kernel on the device")
         if legs.get("snappy") is not None:
             line["snappy_pipeline"] = legs["snappy"]
+        if legs.get("zstd") is not None:
+            line["zstd_pipeline"] = legs["zstd"]
         if legs.get("cold_plan") is not None:
             cp = legs["cold_plan"]
             line["cold_create_plan_ms"] = cp.get("cold_create_plan_ms")

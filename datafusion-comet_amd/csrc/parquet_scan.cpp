@@ -1609,6 +1609,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     }
   }
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return col_bytes[a] > col_bytes[b]; });
+  // COMET_PQ_ORDER=small_first: the small columns' chunks are prepared and sent first (their slices cross in latency-bound copies that then
+  // overlap the big column's host work), the big column last; =big_first (default) starts the device pipeline of the big column as early as possible
+  static const bool small_first = getenv("COMET_PQ_ORDER") != nullptr && !strcmp(getenv("COMET_PQ_ORDER"), "small_first");
+  if (small_first) std::reverse(order.begin(), order.end());
   // Measured on MI355X (profiles/r3_snappy_pipeline.json): the multi-kernel pipeline inflates PLAIN pages at 70–80 GB/s of output whatever
   // their number (it parallelises inside the pages), plus about half a millisecond of launches; a host core decompresses the same bytes at
   // ~1 GB/s.  Only a small scan on a host with many idle threads is better off on the host.

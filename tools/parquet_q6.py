@@ -6,6 +6,7 @@ value decode), filtered and aggregated by the fused Q6 kernel.  Prints one JSON 
 decode kernels' share (HIP events via comet_plan_kernel_stats are for the aggregate only; use rocprofv3 for the split)
 and a pyarrow.parquet read of the same file on the host cores as the CPU reference."""
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -24,6 +25,8 @@ def main():
     ap.add_argument("--clustered", action="store_true", help="rows in l_shipdate order (a table clustered by date), written with page indexes, and Q6's date range pushed into the scan as data filters: "
                     "most pages are pruned, the pages at the range's ends are kept in pieces")
     ap.add_argument("--out", default="", help="also write the JSON line here")
+    ap.add_argument("--scan-threads", type=int, default=0, help="host threads the scan may use (spark.comet.gpu.scanThreads; 1 = what a Spark task owns)")
+    ap.add_argument("--device-decompress", default="auto", choices=["auto", "true", "false"], help="spark.comet.gpu.scan.deviceDecompress")
     a = ap.parse_args()
     import pyarrow as pa
     import pyarrow.parquet as papq
@@ -46,15 +49,32 @@ def main():
         filters = [S.gt_eq(ship, S.lit(tpch.days(1994, 1, 1), S.T_DATE)), S.lt(ship, S.lit(tpch.days(1995, 1, 1), S.T_DATE))]
     src = S.native_scan([path], table.schema.names, [tpch.DEC, tpch.DEC, tpch.DEC, S.T_DATE], data_filters=filters)
     plan = tpch.q6_plan(source=src).encode()
+    cfg = {"spark.comet.gpu.scan.deviceDecompress": a.device_decompress}
+    if a.scan_threads:
+        cfg["spark.comet.gpu.scanThreads"] = str(a.scan_threads)
+    conf = S.config_map(cfg)
     want = None
     times = []
+    on_device = None
     for it in range(a.steps + 1):
         t0 = time.perf_counter()
-        h = native.Native.createPlan([], plan, b"", 1, 8192, 0)
+        h = native.Native.createPlan([], plan, conf, 1, 8192, 0)
         t1 = time.perf_counter()
         out = [native.Native.executePlan(h, tpch.Q6_NUM_OUTPUT_COLS)]
         t2 = time.perf_counter()
         assert native.Native.executePlan(h, tpch.Q6_NUM_OUTPUT_COLS) is None
+        if on_device is None:
+            try:
+                lib = native.lib()
+                n = lib.comet_plan_metrics(h, None, 0)
+                buf = ctypes.create_string_buffer(max(int(n), 1))
+                lib.comet_plan_metrics(h, buf, n)
+                m = S.decode_metric_node(buf.raw[:n])
+                while m and m[1]:
+                    m = m[1][0]
+                on_device = m[0].get("pages_decompressed_on_device") if m else None
+            except Exception:
+                on_device = -1
         native.Native.releasePlan(h)
         dt = time.perf_counter() - t0
         if os.environ.get("COMET_TRACE_STAGES"):
@@ -79,7 +99,8 @@ def main():
     line = json.dumps({"query": "tpch_q6_parquet", "rows": a.rows, "codec": a.codec, "dictionary": not a.no_dictionary, "file_bytes": fsize,
                       "sec_best": best, "sec_median": sorted(times)[len(times) // 2], "sec_all": [round(t, 4) for t in times], "rows_per_s": a.rows / best,
                       "encoded_GBps": fsize / best / 1e9, "decoded_arrow_GBps": decoded / best / 1e9, "result": want, "matches_resident_plan": ok,
-                      "pyarrow_read_s_all_cores": cpu, "pyarrow_read_s_1_core": cpu1, "host_cores": os.cpu_count()})
+                      "pyarrow_read_s_all_cores": cpu, "pyarrow_read_s_1_core": cpu1, "host_cores": os.cpu_count(),
+                      "scan_threads": a.scan_threads or None, "device_decompress": a.device_decompress, "pages_decompressed_on_device": on_device})
     print(line)
     if a.out:
         with open(a.out, "w") as f:
