@@ -35,12 +35,6 @@
 
 #define ZS_FN SN2_FN
 #define ZS_LDS SN2_LDS
-// A value every active lane holds alike, said so to the compiler (gfx950: v_readfirstlane → a scalar register).  The sequence decoder is
-// ONE lane's serial chain; with its state in scalar registers it runs on the scalar unit — one instruction a cycle, 64-bit shifts and
-// bit-field extracts in one instruction — instead of the vector unit's four cycles per instruction and two instructions per 64-bit shift.
-#ifndef ZS_UNIFORM
-#define ZS_UNIFORM(x) (x)
-#endif
 
 namespace comet_zstd2 {
 
@@ -216,14 +210,13 @@ constexpr u32 kRing = 2048;                  // bytes of a stream window (power 
 // so the window is laid out with a BIAS: the byte at stream position q sits at ring byte (q + bias) mod kRing, bias = (−length) mod 8, and
 // every load is one aligned 8-byte read.
 ZS_FN u32 ring_bias(u32 len) { return (8u - (len & 7u)) & 7u; }
-template <class WP, bool kUniform>              // kUniform: ONE lane reads this window (the sequence decoder): what it loads is wave-uniform
+template <class WP, bool kUnused>
 struct RingBytes {
   WP w;                                      // kRing / 4 words
   u32 bias;
   ZS_FN u64 load8(i32 pos) const {
     const u32 i = (((u32)pos + bias) & (kRing - 1)) >> 2;
-    u32 w0 = w[i], w1 = w[i + 1];
-    if (kUniform) { w0 = ZS_UNIFORM(w0); w1 = ZS_UNIFORM(w1); }
+    const u32 w0 = w[i], w1 = w[i + 1];
     return (u64)w0 | ((u64)w1 << 32);
   }
 };
@@ -478,9 +471,9 @@ ZS_FN void seq_begin(BB& b, SeqCore& c, int lll, int lof, int lml) {
 // the next sequence (`last`: no state update behind it); → ST_OK or an error code.  Tables: seq_table_expand's two words per state.
 template <class BB, class TabPtr>
 ZS_FN u32 seq_step(BB& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, bool last, u32& ll, u32& ml, i32& off) {
-  const u32 lb = ZS_UNIFORM(tll[2 * c.sll]), lh = ZS_UNIFORM(tll[2 * c.sll + 1]);
-  const u32 ob = ZS_UNIFORM(tof[2 * c.sof]), oh = ZS_UNIFORM(tof[2 * c.sof + 1]);
-  const u32 mb = ZS_UNIFORM(tml[2 * c.sml]), mh = ZS_UNIFORM(tml[2 * c.sml + 1]);
+  const u32 lb = tll[2 * c.sll], lh = tll[2 * c.sll + 1];
+  const u32 ob = tof[2 * c.sof], oh = tof[2 * c.sof + 1];
+  const u32 mb = tml[2 * c.sml], mh = tml[2 * c.sml + 1];
   // The fields come off 64-bit WINDOWS of the stream, not through six general reads (the decoder is one lane's chain: its cost is its
   // instruction count): all six — the three values' extra bits and the three states' bits — off one window when they fit (the usual
   // case: ~35 bits), else the values (≤ 31 + 16 + 16) off one and the states (≤ 9 + 9 + 8) off a second.
@@ -540,27 +533,6 @@ ZS_FN u32 seq_step(BB& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, bool l
   }
   return ST_OK;
 }
-// the state as the compiler should see it at the start of a round: wave-uniform (it comes back from the previous round through a
-// join with the idle lanes, which makes it look divergent)
-template <class BB>
-ZS_FN void seq_state_uniform(BB& b, SeqCore& c) {
-  b.src.bias = ZS_UNIFORM(b.src.bias);
-  b.bitpos = (i32)ZS_UNIFORM((u32)b.bitpos);
-  b.wb = (i32)ZS_UNIFORM((u32)b.wb);
-  b.hi = (u64)ZS_UNIFORM((u32)b.hi) | ((u64)ZS_UNIFORM((u32)(b.hi >> 32)) << 32);
-  b.lo = (u64)ZS_UNIFORM((u32)b.lo) | ((u64)ZS_UNIFORM((u32)(b.lo >> 32)) << 32);
-  b.nx = (u64)ZS_UNIFORM((u32)b.nx) | ((u64)ZS_UNIFORM((u32)(b.nx >> 32)) << 32);
-  c.sll = ZS_UNIFORM(c.sll);
-  c.sof = ZS_UNIFORM(c.sof);
-  c.sml = ZS_UNIFORM(c.sml);
-  c.r0 = (i32)ZS_UNIFORM((u32)c.r0);
-  c.r1 = (i32)ZS_UNIFORM((u32)c.r1);
-  c.r2 = (i32)ZS_UNIFORM((u32)c.r2);
-  c.sum_ll = (u64)ZS_UNIFORM((u32)c.sum_ll) | ((u64)ZS_UNIFORM((u32)(c.sum_ll >> 32)) << 32);
-  c.sum_ml = (u64)ZS_UNIFORM((u32)c.sum_ml) | ((u64)ZS_UNIFORM((u32)(c.sum_ml >> 32)) << 32);
-  c.done = ZS_UNIFORM(c.done);
-}
-
 // ---- kernel A1: the literals of one block — one 64-thread workgroup.  Threads 0 … 3 decode a Huffman stream each, 256 symbols a round,
 // out of their stream's window in workgroup memory into a buffer there; between rounds ALL threads slide the windows and write the
 // buffers out.  Raw / RLE literals (and raw / RLE blocks) are copied or filled by all threads. ----
@@ -582,7 +554,6 @@ struct LitLds {
   u32 status;
 };
 typedef BackBitsT<RingBytes<ZS_LDS u32*, false>> RingReader;
-typedef BackBitsT<RingBytes<ZS_LDS u32*, true>> UniformRingReader;
 struct LitState { RingReader b; u32 left; };                // a decoding thread's registers between rounds
 // phase 1 (all threads): stage the tree description; thread 0: the streams' extents
 ZS_FN void lit_stage(ZS_LDS LitLds* L, const u8* src, const ZBlock& b, int t) {
@@ -676,103 +647,113 @@ ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Hu
   return (longest + kLitRound - 1) / kLitRound;
 }
 
-// ---- kernel A2: the sequences of one block — one 64-thread workgroup.  Thread 0 decodes 64 sequences a round out of the bitstream's
-// window in workgroup memory into a buffer there; between rounds ALL threads slide the window and write the buffer out as records. ----
-constexpr u32 kSeqRound = 64;
+// ---- kernel A2: the sequences of FOUR blocks — one 64-thread workgroup, 16 threads per block.  A block's sequences are one serial chain
+// (three interleaved FSE states over one backward bitstream), and a SIMD issues one instruction per four cycles whatever the instruction
+// does for how many lanes: a first version with ONE decoding lane per wave, its state in scalar registers, sat at the machine's issue rate
+// (62.9 M sequences × ≈ 235 instructions over 1024 SIMDs = 24 ms for 480 pages).  Here four lanes of a wave — the first thread of each
+// group of 16 — decode four blocks at once, 32 sequences a round, out of their bitstream's window in workgroup memory into a buffer
+// there; between rounds every group slides its window and writes its buffer out as records.  Four, because the expanded tables of a block
+// take 10 KiB of workgroup memory: 52 KiB per workgroup, three workgroups per CU. ----
+constexpr int kSeqLanes = 4;
+constexpr u32 kSeqRound = 32;
 struct SeqLds {
-  u32 fse[3][1024];          // two words per state (seq_table_expand)
-  u32 ring[kRing / 4];
-  u32 rbuf[kSeqRound][3];    // ll, ml, off
-  u8 hdr[3][128];            // the table descriptions, staged (a description is at most 53 counts of ≤ 10 bits)
-  i16 norm[64];
-  u16 next[64];
-  i32 fse_log[3];
-  i32 low, cursor;
-  u32 bias;
-  u32 rcount;
-  u32 status;
+  u32 fse_ll[kSeqLanes][1024], fse_of[kSeqLanes][512], fse_ml[kSeqLanes][1024];     // two words per state (seq_table_expand); offsets: log ≤ 8
+  u32 ring[kSeqLanes][kRing / 4];
+  u32 rbuf[kSeqLanes][kSeqRound][3];    // ll, ml, off
+  u8 hdr[kSeqLanes][3][128];            // the table descriptions, staged (a description is at most 53 counts of ≤ 10 bits)
+  i16 norm[kSeqLanes][64];
+  u16 next[kSeqLanes][64];
+  i32 fse_log[kSeqLanes][3];
+  i32 low[kSeqLanes], cursor[kSeqLanes];
+  u32 bias[kSeqLanes];
+  u32 rcount[kSeqLanes];
+  u32 rounds[kSeqLanes];
+  u32 status[kSeqLanes];
 };
-struct SeqState { UniformRingReader b; SeqCore c; };
+struct SeqState { RingReader b; SeqCore c; };
 ZS_FN bool seq_block_has_stream(const ZBlock& b) { return b.type == BT_COMPRESSED && b.nseq > 0; }
-// phase 1 (all threads): stage the table descriptions (this block's, or — repeat mode — an earlier block's)
-ZS_FN void seq_stage(ZS_LDS SeqLds* L, const u8* src, const ZBlock& b, u32 src_len, int t) {
+ZS_FN u32 seq_rounds(const ZBlock& b) { return seq_block_has_stream(b) ? (b.nseq + kSeqRound - 1) / kSeqRound : 0; }
+// k: the block's group (0 … 3), tt: the thread within the group (0 … 15); "the group's thread" = its thread 0
+// phase 1 (the group): stage the table descriptions (this block's, or — repeat mode — an earlier block's)
+ZS_FN void seq_stage(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, u32 src_len, int tt) {
+  if (tt == 0) { L->status[k] = 0; L->rcount[k] = 0; L->rounds[k] = seq_rounds(b); }
   if (!seq_block_has_stream(b)) return;
-  for (u32 i = (u32)t; i < 3u * 128u; i += 64) {
-    const u32 k = i >> 7, j = i & 127u;
-    const u32 q = b.tab_desc[k] + j;
-    L->hdr[k][j] = (b.tab_mode[k] != TM_PREDEF && q < src_len) ? src[q] : (u8)0;
+  for (u32 i = (u32)tt; i < 3u * 128u; i += 16) {
+    const u32 kind = i >> 7, j = i & 127u;
+    const u32 q = b.tab_desc[kind] + j;
+    L->hdr[k][kind][j] = (b.tab_mode[kind] != TM_PREDEF && q < src_len) ? src[q] : (u8)0;
   }
-  if (t == 0) { L->bias = ring_bias(b.bits_len); L->cursor = (i32)b.bits_len; L->low = ring_top_for(b.bits_len, L->bias); }
+  if (tt == 0) { L->bias[k] = ring_bias(b.bits_len); L->cursor[k] = (i32)b.bits_len; L->low[k] = ring_top_for(b.bits_len, L->bias[k]); }
 }
-// phase 2 (thread 0): the block's three tables
-ZS_FN void seq_tables(ZS_LDS SeqLds* L, const ZBlock& b) {
+ZS_FN ZS_LDS u32* seq_tab(ZS_LDS SeqLds* L, int k, int kind) { return kind == 0 ? (ZS_LDS u32*)L->fse_ll[k] : kind == 1 ? (ZS_LDS u32*)L->fse_of[k] : (ZS_LDS u32*)L->fse_ml[k]; }
+// phase 2 (the group's thread): the block's three tables
+ZS_FN void seq_tables(ZS_LDS SeqLds* L, int k, const ZBlock& b) {
   if (!seq_block_has_stream(b)) return;
-  for (int k = 0; k < 3; k++) {
-    const int log = seq_table(k, b.tab_mode[k], (ZS_LDS u8*)L->hdr[k], 128u, (ZS_LDS u32*)L->fse[k], L->norm, L->next);
-    L->fse_log[k] = log;
-    if (log < 0) L->status = ST_ERR_FSE;
-    else seq_table_expand(k, log, (ZS_LDS u32*)L->fse[k]);
+  for (int kind = 0; kind < 3; kind++) {
+    const int log = seq_table(kind, b.tab_mode[kind], (ZS_LDS u8*)L->hdr[k][kind], 128u, seq_tab(L, k, kind), L->norm[k], L->next[k]);
+    L->fse_log[k][kind] = log;
+    if (log < 0) L->status[k] = ST_ERR_FSE;
+    else seq_table_expand(kind, log, seq_tab(L, k, kind));
   }
 }
-// (all threads) slide the bitstream's window down
-ZS_FN void seq_fill(ZS_LDS SeqLds* L, const u8* src, const ZBlock& b, i32 page_len, int t) {
+// (the group) slide the bitstream's window down
+ZS_FN void seq_fill(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, i32 page_len, int tt) {
   if (!seq_block_has_stream(b)) return;
-  const i32 want = ring_low_for(L->cursor, L->bias);
-  if (want < L->low) ring_fill((ZS_LDS u32*)L->ring, L->bias, src + b.bits_pos, want, L->low, -(i32)b.bits_pos, page_len + 16 - (i32)b.bits_pos, t, 64);
+  const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
+  if (want < L->low[k]) ring_fill((ZS_LDS u32*)L->ring[k], L->bias[k], src + b.bits_pos, want, L->low[k], -(i32)b.bits_pos, page_len + 16 - (i32)b.bits_pos, tt, 16);
 }
-ZS_FN void seq_fill_done(ZS_LDS SeqLds* L) {
-  const i32 want = ring_low_for(L->cursor, L->bias);
-  if (want < L->low) L->low = want;
+ZS_FN void seq_fill_done(ZS_LDS SeqLds* L, int k) {          // (the group's thread, behind the barrier that follows seq_fill)
+  const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
+  if (want < L->low[k]) L->low[k] = want;
 }
-ZS_FN void seq_start(ZS_LDS SeqLds* L, SeqState& st, const ZBlock& b) {        // thread 0, behind the first fill
-  RingBytes<ZS_LDS u32*, true> src;
-  src.w = (ZS_LDS u32*)L->ring;
-  src.bias = ZS_UNIFORM(L->bias);
-  if (L->status) return;
-  if (!st.b.init(src, b.bits_len)) { L->status = ST_ERR_BITS; return; }
-  seq_begin(st.b, st.c, L->fse_log[0], L->fse_log[1], L->fse_log[2]);
+ZS_FN void seq_start(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {        // the group's thread, behind the first fill
+  RingBytes<ZS_LDS u32*, false> src;
+  src.w = (ZS_LDS u32*)L->ring[k];
+  src.bias = L->bias[k];
+  if (L->status[k]) return;
+  if (!st.b.init(src, b.bits_len)) { L->status[k] = ST_ERR_BITS; return; }
+  seq_begin(st.b, st.c, L->fse_log[k][0], L->fse_log[k][1], L->fse_log[k][2]);
 }
-// thread 0: the next ≤ 64 sequences into rbuf
-ZS_FN void seq_round(ZS_LDS SeqLds* L, SeqState& st, const ZBlock& b) {
-  L->rcount = 0;
-  if (L->status) return;
-  seq_state_uniform(st.b, st.c);
-  const u32 nseq = ZS_UNIFORM(b.nseq);
-  const u32 left = nseq - st.c.done, n = left < kSeqRound ? left : kSeqRound;
+// the group's thread: the block's next ≤ 32 sequences into rbuf
+ZS_FN void seq_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
+  L->rcount[k] = 0;
+  if (L->status[k] || !seq_block_has_stream(b)) return;
+  const u32 left = b.nseq - st.c.done, n = left < kSeqRound ? left : kSeqRound;
   for (u32 i = 0; i < n; i++) {
     u32 ll, ml;
     i32 off;
-    const u32 rc = seq_step(st.b, st.c, (ZS_LDS u32*)L->fse[0], (ZS_LDS u32*)L->fse[1], (ZS_LDS u32*)L->fse[2], st.c.done + 1 == nseq, ll, ml, off);
-    if (rc != ST_OK) { L->status = rc; return; }
-    L->rbuf[i][0] = ll;
-    L->rbuf[i][1] = ml;
-    L->rbuf[i][2] = (u32)off;
+    const u32 rc = seq_step(st.b, st.c, (ZS_LDS u32*)L->fse_ll[k], (ZS_LDS u32*)L->fse_of[k], (ZS_LDS u32*)L->fse_ml[k], st.c.done + 1 == b.nseq, ll, ml, off);
+    if (rc != ST_OK) { L->status[k] = rc; return; }
+    L->rbuf[k][i][0] = ll;
+    L->rbuf[k][i][1] = ml;
+    L->rbuf[k][i][2] = (u32)off;
   }
-  L->rcount = n;
-  L->cursor = st.b.cursor_byte();
+  L->rcount[k] = n;
+  L->cursor[k] = st.b.cursor_byte();
 }
-// (all threads) the round's sequences to the block's records
-ZS_FN void seq_flush(const ZS_LDS SeqLds* L, ZRec* recs_block, u32 base, int t) {
-  if ((u32)t >= L->rcount) return;
-  ZRec* r = recs_block + base + (u32)t;
-  r->ll = L->rbuf[t][0];
-  r->ml = L->rbuf[t][1];
-  r->off = (i32)L->rbuf[t][2];
+// (the group) the round's sequences to the block's records
+ZS_FN void seq_flush(const ZS_LDS SeqLds* L, int k, ZRec* recs_block, u32 base, int tt) {
+  for (u32 i = (u32)tt; i < L->rcount[k]; i += 16) {
+    ZRec* r = recs_block + base + i;
+    r->ll = L->rbuf[k][i][0];
+    r->ml = L->rbuf[k][i][1];
+    r->off = (i32)L->rbuf[k][i][2];
+  }
 }
-// thread 0, behind the last round: the stream must be used up; the trailing literals; the block's size and history on exit
-ZS_FN void seq_finish(ZS_LDS SeqLds* L, SeqState& st, ZBlock* b, ZRec* recs_block) {
+// the group's thread, behind the last round: the stream must be used up; the trailing literals; the block's size and history on exit
+ZS_FN void seq_finish(ZS_LDS SeqLds* L, int k, SeqState& st, ZBlock* b, ZRec* recs_block) {
   if (!seq_block_has_stream(*b)) {                           // a raw / RLE block, or a block of literals only: one run of literals
     const u32 n = b->type == BT_COMPRESSED ? b->lit_regen : b->size;
     recs_block[0].ll = n;
     recs_block[0].ml = 0;
     recs_block[0].off = 0;
     b->out_size = n;
-    for (int k = 0; k < 3; k++) b->rep_out[k] = rep_symbolic(k);
+    for (int j = 0; j < 3; j++) b->rep_out[j] = rep_symbolic(j);
     return;
   }
-  if (L->status) return;
-  if (st.b.bitpos != 0) { L->status = ST_ERR_BITS; return; }
-  if (st.c.sum_ll > b->lit_regen || st.c.sum_ll + st.c.sum_ml > kBlockMax) { L->status = ST_ERR_LENGTH; return; }
+  if (L->status[k]) return;
+  if (st.b.bitpos != 0) { L->status[k] = ST_ERR_BITS; return; }
+  if (st.c.sum_ll > b->lit_regen || st.c.sum_ll + st.c.sum_ml > kBlockMax) { L->status[k] = ST_ERR_LENGTH; return; }
   recs_block[b->nseq].ll = b->lit_regen - (u32)st.c.sum_ll;
   recs_block[b->nseq].ml = 0;
   recs_block[b->nseq].off = 0;
@@ -781,7 +762,6 @@ ZS_FN void seq_finish(ZS_LDS SeqLds* L, SeqState& st, ZBlock* b, ZRec* recs_bloc
   b->rep_out[1] = st.c.r1;
   b->rep_out[2] = st.c.r2;
 }
-ZS_FN u32 seq_rounds(const ZBlock& b) { return seq_block_has_stream(b) ? (b.nseq + kSeqRound - 1) / kSeqRound : 0; }
 
 // ---- kernel B: one lane per page ----
 ZS_FN void page_blocks(const ZPage& pg, ZBlock* blocks, u32* status, int page_index) {

@@ -1,6 +1,6 @@
 // The zstd pipeline on gfx950 (device/zstd2.hpp holds the algorithm as phases; this file gives the phases their workgroups, barriers and
-// workgroup memory).  Kernels A1 / A2: one wave per block — the literals (Huffman: a lane per stream) / the sequences (one lane), decoding
-// in rounds out of a window of the bitstream in workgroup memory; ≈ 17 / 10 KiB of LDS.  Kernel B: one thread per page.  Kernel C: one 256-thread workgroup per block.
+// workgroup memory).  Kernels A1 / A2: one wave per block — the literals (Huffman: a lane per stream) / the sequences of four blocks (a lane per block), decoding
+// in rounds out of a window of the bitstream in workgroup memory; ≈ 14 / 52 KiB of LDS.  Kernel B: one thread per page.  Kernel C: one 256-thread workgroup per block.
 // Kernel D: one 1024-thread workgroup per page, its 64 KiB fragments in order, 144 KiB of LDS (one per CU).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,7 +13,6 @@
 #define SN2_ATOMIC_ADD_LDS(p, v) __hip_atomic_fetch_add((uint32_t*)(p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define SN2_ATOMIC_MIN_LDS(p, v) __hip_atomic_fetch_min((uint32_t*)(p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define ZS2_DEVICE_ONLY
-#define ZS_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #include "device/zstd2.hpp"
 
 namespace {
@@ -58,40 +57,48 @@ __global__ __launch_bounds__(64) void zs2_literals_kernel(const ZPage* __restric
   if (t == 0 && s.status) atomicMax(&status[pi], s.status);
 }
 
-__global__ __launch_bounds__(64) void zs2_sequences_kernel(const ZPage* __restrict__ pages, ZBlock* blocks, const i32* __restrict__ block_page,
+__global__ __launch_bounds__(64) void zs2_sequences_kernel(const ZPage* __restrict__ pages, ZBlock* blocks, const i32* __restrict__ block_page, i64 nblocks,
                                                            const u8* __restrict__ bytes, ZRec* recs_all, u32* status) {
   __shared__ SeqLds s;
   ZS_LDS SeqLds* L = (ZS_LDS SeqLds*)&s;
-  const i64 bi = blockIdx.x;
-  const int pi = block_page[bi];
-  const ZPage pg = pages[pi];
-  const ZBlock blk = blocks[bi];
+  const int t = (int)threadIdx.x, k = t >> 4, tt = t & 15;
+  const i64 bi = (i64)blockIdx.x * kSeqLanes + k;          // this group's block
+  const bool have = bi < nblocks;
+  ZBlock blk;
+  ZPage pg;
+  int pi = 0;
+  if (have) {
+    pi = block_page[bi];
+    pg = pages[pi];
+    blk = blocks[bi];
+  } else {                                                 // (the last workgroup's spare groups: a block without a stream, nothing to write)
+    __builtin_memset(&blk, 0, sizeof blk);
+    __builtin_memset(&pg, 0, sizeof pg);
+    blk.type = 3;
+  }
   const u8* src = bytes + pg.src_off;
   ZRec* recs = recs_all + pg.rec_first + blk.rec_first;
-  const int t = (int)threadIdx.x;
-  if (t == 0) { s.status = 0; s.rcount = 0; }
+  seq_stage(L, k, src, blk, (u32)pg.src_len, tt);
   __syncthreads();
-  seq_stage(L, src, blk, (u32)pg.src_len, t);
+  if (tt == 0) seq_tables(L, k, blk);
   __syncthreads();
-  if (t == 0) seq_tables(L, blk);
-  __syncthreads();
-  seq_fill(L, src, blk, pg.src_len, t);
+  seq_fill(L, k, src, blk, pg.src_len, tt);
   __syncthreads();
   SeqState st;
-  if (t == 0 && seq_block_has_stream(blk)) { seq_fill_done(L); seq_start(L, st, blk); }
-  const u32 rounds = seq_rounds(blk);
+  if (tt == 0 && seq_block_has_stream(blk)) { seq_fill_done(L, k); seq_start(L, k, st, blk); }
+  u32 rounds = 0;
+  for (int j = 0; j < kSeqLanes; j++) rounds = s.rounds[j] > rounds ? s.rounds[j] : rounds;
   for (u32 r = 0; r < rounds; r++) {
-    if (t == 0) seq_round(L, st, blk);
+    if (tt == 0) seq_round(L, k, st, blk);
     __syncthreads();
-    if (s.status) break;
-    seq_flush(L, recs, r * kSeqRound, t);
-    seq_fill(L, src, blk, pg.src_len, t);
+    seq_flush(L, k, recs, r * kSeqRound, tt);
+    seq_fill(L, k, src, blk, pg.src_len, tt);
     __syncthreads();
-    if (t == 0) seq_fill_done(L);
+    if (tt == 0) seq_fill_done(L, k);
   }
-  if (t == 0) {
-    seq_finish(L, st, &blocks[bi], recs);
-    if (s.status) atomicMax(&status[pi], s.status);
+  if (tt == 0 && have) {
+    seq_finish(L, k, st, &blocks[bi], recs);
+    if (s.status[k]) atomicMax(&status[pi], s.status[k]);
   }
 }
 
@@ -190,7 +197,8 @@ __global__ __launch_bounds__(64) void zs2_report_kernel(const u32* __restrict__ 
 extern "C" {
 void zs2_launch_entropy(const void* pages, void* blocks, const int32_t* block_page, const uint8_t* bytes, uint8_t* lits, void* recs, uint32_t* status, int64_t nblocks, void* st) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(zs2_sequences_kernel, (unsigned)nblocks, 64, 0, (hipStream_t)st, (const ZPage*)pages, (ZBlock*)blocks, block_page, bytes, (ZRec*)recs, status);
+  hipLaunchKernelGGL(zs2_sequences_kernel, (unsigned)((nblocks + kSeqLanes - 1) / kSeqLanes), 64, 0, (hipStream_t)st, (const ZPage*)pages, (ZBlock*)blocks, block_page, (i64)nblocks, bytes,
+                     (ZRec*)recs, status);
   hipLaunchKernelGGL(zs2_literals_kernel, (unsigned)nblocks, 64, 0, (hipStream_t)st, (const ZPage*)pages, (const ZBlock*)blocks, block_page, bytes, lits, status);
 }
 void zs2_launch_blocks(const void* pages, int npages, void* blocks, uint32_t* status, void* st) {

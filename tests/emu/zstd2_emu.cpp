@@ -76,32 +76,39 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
     }
     if (LL->status && LL->status > status[(size_t)pi]) status[(size_t)pi] = LL->status;
   }
-  // kernel A2: sequences
+  // kernel A2: sequences, four blocks per workgroup (16 threads each; a group's thread 0 decodes)
   auto SL = std::make_unique<SeqLds>();
-  for (size_t bi = 0; bi < blocks.size(); bi++) {
-    const int pi = block_page[bi];
-    const ZPage& pg = pages[(size_t)pi];
-    ZBlock& b = blocks[bi];
-    const u8* src = bytes.data() + pg.src_off;
-    ZRec* rb = recs.data() + pg.rec_first + b.rec_first;
+  for (size_t b0 = 0; b0 < blocks.size(); b0 += kSeqLanes) {
     memset(SL.get(), 0xee, sizeof(SeqLds));
-    SL->status = 0;
-    SL->rcount = 0;
-    for (int t = 0; t < 64; t++) seq_stage(SL.get(), src, b, (u32)pg.src_len, t);
-    seq_tables(SL.get(), b);
-    for (int t = 0; t < 64; t++) seq_fill(SL.get(), src, b, pg.src_len, t);
-    SeqState st;
-    if (seq_block_has_stream(b)) { seq_fill_done(SL.get()); seq_start(SL.get(), st, b); }
-    const u32 rounds = seq_rounds(b);
-    for (u32 r = 0; r < rounds; r++) {
-      seq_round(SL.get(), st, b);
-      if (SL->status) break;
-      for (int t = 0; t < 64; t++) seq_flush(SL.get(), rb, r * kSeqRound, t);
-      for (int t = 0; t < 64; t++) seq_fill(SL.get(), src, b, pg.src_len, t);
-      seq_fill_done(SL.get());
+    ZBlock none;
+    memset(&none, 0, sizeof none);
+    none.type = 3;
+    ZPage nopage;
+    memset(&nopage, 0, sizeof nopage);
+    auto blk = [&](int k) -> ZBlock& { return b0 + (size_t)k < blocks.size() ? blocks[b0 + (size_t)k] : none; };
+    auto page = [&](int k) -> const ZPage& { return b0 + (size_t)k < blocks.size() ? pages[(size_t)block_page[b0 + (size_t)k]] : nopage; };
+    auto srcp = [&](int k) { return bytes.data() + page(k).src_off; };
+    auto recp = [&](int k) { return recs.data() + page(k).rec_first + blk(k).rec_first; };
+    for (int t = 0; t < 64; t++) seq_stage(SL.get(), t >> 4, srcp(t >> 4), blk(t >> 4), (u32)page(t >> 4).src_len, t & 15);
+    for (int k = 0; k < kSeqLanes; k++) seq_tables(SL.get(), k, blk(k));
+    for (int t = 0; t < 64; t++) seq_fill(SL.get(), t >> 4, srcp(t >> 4), blk(t >> 4), page(t >> 4).src_len, t & 15);
+    SeqState st[kSeqLanes];
+    u32 rounds = 0;
+    for (int k = 0; k < kSeqLanes; k++) {
+      if (seq_block_has_stream(blk(k))) { seq_fill_done(SL.get(), k); seq_start(SL.get(), k, st[k], blk(k)); }
+      rounds = SL->rounds[k] > rounds ? SL->rounds[k] : rounds;
     }
-    seq_finish(SL.get(), st, &b, rb);
-    if (SL->status && SL->status > status[(size_t)pi]) status[(size_t)pi] = SL->status;
+    for (u32 r = 0; r < rounds; r++) {
+      for (int k = 0; k < kSeqLanes; k++) seq_round(SL.get(), k, st[k], blk(k));
+      for (int t = 0; t < 64; t++) seq_flush(SL.get(), t >> 4, recp(t >> 4), r * kSeqRound, t & 15);
+      for (int t = 0; t < 64; t++) seq_fill(SL.get(), t >> 4, srcp(t >> 4), blk(t >> 4), page(t >> 4).src_len, t & 15);
+      for (int k = 0; k < kSeqLanes; k++) seq_fill_done(SL.get(), k);
+    }
+    for (int k = 0; k < kSeqLanes && b0 + (size_t)k < blocks.size(); k++) {
+      seq_finish(SL.get(), k, st[k], &blk(k), recp(k));
+      const int pi = block_page[b0 + (size_t)k];
+      if (SL->status[k] && SL->status[k] > status[(size_t)pi]) status[(size_t)pi] = SL->status[k];
+    }
   }
   // kernel B
   for (int i = 0; i < npages; i++)
