@@ -684,6 +684,7 @@ struct HostChunk {
   int64_t n_rows = 0;
   int64_t compressed = 0;
   size_t spos = 0;                 // staged (uploaded) bytes actually used
+  int64_t dev_dict = -1;           // the chunk's dictionary page is inflated by the device: its offset in the device-decompressed region (else −1: dict_bytes holds it)
   size_t raw_lo = 0, raw_hi = 0;   // slot-relative extent of the page bodies that were read in place (behind the staged bytes) and cross PCIe from there
   size_t ipos = 0;                 // bytes of the device-decompressed region used
   int64_t pages_skipped = 0;       // data pages the page index ruled out
@@ -922,6 +923,43 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       throw CometError("parquet: page of " + std::to_string(h.compressed_size) + " bytes runs past its column chunk");
     off += (int64_t)h.header_len + h.compressed_size;
     if (h.type == pq::DICTIONARY_PAGE) {
+      // A fixed-width dictionary (PLAIN values) of a chunk that is read in place: the device inflates it like a data page and the decode
+      // kernels index it where it lands — the host neither decompresses it nor sends it again with the column's tables (TPC-H
+      // l_extendedprice: a 1 MiB dictionary per row group before the writer falls back to PLAIN pages).
+      if (in_place && !cp.is_string && hc.dev_dict < 0 && (h.encoding == pq::PLAIN || h.encoding == pq::PLAIN_DICTIONARY) && h.uncompressed_size >= kMinDevicePage &&
+          (int64_t)h.compressed_size <= (int64_t)h.uncompressed_size + h.uncompressed_size / 6 + 64) {
+        const size_t ipage = (hc.ipos + 15) & ~(size_t)15, un_len = (size_t)h.uncompressed_size, comp_len = (size_t)h.compressed_size;
+        bool ok = ipage + un_len + 32 <= staged_cap;
+        PqInflate job;
+        job.src_off = (int64_t)(body - staged);
+        job.dst_off = (int64_t)ipage;
+        job.src_len = (int32_t)comp_len;
+        job.dst_len = (int32_t)un_len;
+        job.pad = 0;
+        comet_zstd2::PageWalk zw;
+        if (ok && cm.codec == pq::SNAPPY) {
+          job.preamble = comet_snappy2::preamble_length(body, (int32_t)comp_len);
+          ok = job.preamble > 0;
+          if (ok) hc.inflate.push_back(job);
+        } else if (ok && cm.codec == pq::ZSTD && so.device_zstd) {
+          ok = comet_zstd2::scan_page(body, (uint32_t)comp_len, (uint32_t)un_len, zw);
+          if (ok) {
+            job.preamble = (int32_t)hc.zblocks.size();
+            job.pad = (int32_t)zw.blocks.size();
+            hc.zblocks.insert(hc.zblocks.end(), zw.blocks.begin(), zw.blocks.end());
+            hc.zinflate.push_back(job);
+          }
+        } else {
+          ok = false;
+        }
+        if (ok) {
+          if (hc.raw_hi == 0) hc.raw_lo = (size_t)job.src_off;
+          hc.raw_hi = (size_t)job.src_off + comp_len;
+          hc.ipos = ipage + un_len;
+          hc.dev_dict = (int64_t)ipage;
+          continue;
+        }
+      }
       tmp.resize((size_t)h.uncompressed_size + 8);
       pq::decompress(cm.codec, body, (size_t)h.compressed_size, tmp.data(), (size_t)h.uncompressed_size);
       if (h.encoding != pq::PLAIN && h.encoding != pq::PLAIN_DICTIONARY) throw CometError("parquet: unsupported dictionary page encoding");
@@ -1578,6 +1616,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     std::vector<char> done;
     size_t finished = 0;
     std::atomic<bool> cancelled{false};
+    std::atomic<size_t> next{0};
   };
   auto prog = std::make_shared<Progress>();
   prog->done.assign(ntasks, 0);
@@ -1646,22 +1685,29 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     if (chunk_missing[t]) synth_chunk(op.required_schema[c], default_of(c), sels[si].rows, chunks[t], slot, cap);
     else decode_chunk_host(src, op.required_schema[c], so, chunks[t], slot, cap);
   };
-  for (size_t ti = 0; ti < ntasks; ti++) {
-    const size_t t = order[ti / nsel] * nsel + ti % nsel;
-    ScanPool::get().submit([prog, t, &run_task, &chunks]() {
-      if (!prog->cancelled.load()) {
-        try {
-          run_task(t);
-        } catch (...) {
-          chunks[t].err = std::current_exception();
+  // `max_inflight` workers take the chunks in order (spark.comet.gpu.scanThreads: a task's share of the executor's pool — one, for a
+  // Spark task that owns one core), each from the shared cursor until none is left
+  const size_t nworkers = std::min<size_t>(ntasks, (size_t)std::max(1, std::min(max_inflight, ScanPool::get().size())));
+  for (size_t wk = 0; wk < nworkers; wk++) {
+    ScanPool::get().submit([prog, ntasks, nsel, &order, &run_task, &chunks]() {
+      for (;;) {
+        const size_t ti = prog->next.fetch_add(1);
+        if (ti >= ntasks) break;
+        const size_t t = order[ti / nsel] * nsel + ti % nsel;
+        if (!prog->cancelled.load()) {
+          try {
+            run_task(t);
+          } catch (...) {
+            chunks[t].err = std::current_exception();
+          }
         }
+        {
+          std::lock_guard<std::mutex> lk(prog->mu);
+          prog->done[t] = 1;
+          prog->finished++;
+        }
+        prog->cv.notify_all();
       }
-      {
-        std::lock_guard<std::mutex> lk(prog->mu);
-        prog->done[t] = 1;
-        prog->finished++;
-      }
-      prog->cv.notify_all();
     });
   }
   // whatever happens below, no task may still reference this frame when it unwinds
@@ -1883,6 +1929,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const size_t off_soffs = o; o = al(o + n_soffs * 8 + 16);
     const size_t off_jobs = o; o = al(o + n_jobs * sizeof(PqInflate) + 16);
     cd->h_tables.ensure(o + 16);
+    cd->tables.ensure(o + 16);
     char* tb_h = (char*)cd->h_tables.p;
     bool runs_kernel_ok = true;
     {
@@ -1915,7 +1962,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
           if (nulls) pg.def_run_first += (int32_t)id;
           else pg.def_run_first = pg.def_run_count = 0;
           pg.idx_run_first += (int32_t)ii;
-          pg.dict_off = (int64_t)idb;
+          // (a dictionary the device inflated sits in the column's byte buffer: addressed from the dictionary table's base like the others)
+          pg.dict_off = hc.dev_dict >= 0 ? (int64_t)((char*)cd->bytes.p + base + (int64_t)S + hc.dev_dict - ((char*)cd->tables.p + off_dict)) : (int64_t)idb;
           pg.dict_offs_first = (int32_t)ido;
           P[ip++] = pg;
         }
