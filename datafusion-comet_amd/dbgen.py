@@ -1,0 +1,136 @@
+"""The columns TPC-H Q1, Q3 and Q6 read, as tpch-dbgen generates them — the data behind the reference's own golden answers
+(spark/src/test/resources/tpch-query-results/q{1,3,6}.sql.out, written by CometTPCHQuerySuite over tables that GenTPCHData.scala:33-34
+produces with https://github.com/databricks/tpch-dbgen).  dbgen is not part of the reference's tree (and there is no network here), so this
+restates its published algorithm (TPC-H tools 2.x: rnd.c NextRand / UnifInt, build.c mk_order / mk_cust / rpb_routine / mk_sparse, the seed
+table of driver.c, dists.dss); it is pinned by the three golden files themselves: the generated SF1 tables give exactly those answers
+(tests/test_tpch_golden_cpu.py), down to the last digit of every sum.
+
+What dbgen does, per stream: a Park–Miller generator (seed ← seed · 16807 mod 2^31 − 1), a draw is lo + ⌊seed / (2^31 − 1) · (hi − lo + 1)⌋;
+every column has its own stream, and after every ROW each stream is advanced to a fixed number of draws (its `boundary`: 7 for the lineitem
+columns of an order, 1 for the order's own), so row i's draws start at seed₀ · 16807^(boundary · i) — which is what makes the generation
+data-parallel here (numpy; modular powers by squaring)."""
+from __future__ import annotations
+
+import numpy as np
+import pyarrow as pa
+
+M = 2147483647
+A = 16807
+# driver.c Seed[]: stream → initial value
+SEED = {"O_ODATE": 1066728069, "L_QTY": 209208115, "L_DCNT": 554590007, "L_TAX": 721958466, "L_PKEY": 1808217256, "L_SDTE": 1769349045,
+        "L_CDTE": 904914315, "L_RDTE": 373135028, "L_RFLG": 717419739, "C_MSEG": 1140279430, "O_CKEY": 851767375, "O_LCNT": 1434868289}
+STARTDATE_DAY = 8035          # 1992-01-01 as days since 1970-01-01 (dbgen's STARTDATE 92001)
+CURRENTDATE_OFFSET = 1263     # 1995-06-17 (CURRENTDATE 95168) as days since 1992-01-01
+SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]      # dists.dss msegmnt, equal weights
+
+
+def _mulmod(a: np.ndarray, b) -> np.ndarray:
+    return (a * np.uint64(b)) % np.uint64(M) if np.isscalar(b) else (a * b) % np.uint64(M)
+
+
+def _stream_starts(seed0: int, n_rows: int, boundary: int) -> np.ndarray:
+    """the stream's value BEFORE row i's first draw, i = 0 … n_rows − 1: seed0 · A^(boundary · i) mod M"""
+    step = pow(A, boundary, M)
+    i = np.arange(n_rows, dtype=np.uint64)
+    out = np.full(n_rows, seed0 % M, np.uint64)
+    f = step
+    for b in range(max(1, int(n_rows - 1).bit_length())):
+        out = np.where((i >> np.uint64(b)) & np.uint64(1), _mulmod(out, f), out)
+        f = f * f % M
+    return out
+
+
+def _draw(state: np.ndarray, lo: int, hi: int):
+    """one draw per row: → (values, advanced state); UnifInt's double arithmetic"""
+    state = _mulmod(state, A)
+    return lo + ((state.astype(np.float64) / float(M)) * float(hi - lo + 1)).astype(np.int64), state
+
+
+def _dec(values: np.ndarray, p: int, s: int) -> pa.Array:
+    v = values.astype(np.int64)
+    raw = np.empty(2 * len(v), np.int64)
+    raw[0::2] = v
+    raw[1::2] = v >> 63
+    return pa.Array.from_buffers(pa.decimal128(p, s), len(v), [None, pa.py_buffer(raw.tobytes())])
+
+
+def _utf8_from_choices(idx: np.ndarray, choices) -> pa.Array:
+    lens = np.array([len(c) for c in choices], np.int32)
+    offs = np.zeros(len(idx) + 1, np.int32)
+    offs[1:] = np.cumsum(lens[idx])
+    width = max(lens)
+    table = np.zeros((len(choices), width), np.uint8)
+    for k, c in enumerate(choices):
+        table[k, :len(c)] = np.frombuffer(c, np.uint8)
+    mask = np.arange(width)[None, :] < lens[idx][:, None]
+    data = table[idx][mask].tobytes()
+    return pa.Array.from_buffers(pa.utf8(), len(idx), [None, pa.py_buffer(offs.tobytes()), pa.py_buffer(data)])
+
+
+def customer(sf: int = 1) -> pa.Table:
+    """c_custkey, c_mktsegment (mk_cust: one draw of C_MSEG per customer, pick_str over five equal weights)"""
+    n = 150_000 * sf
+    seg, _ = _draw(_stream_starts(SEED["C_MSEG"], n, 1), 1, 5)
+    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(seg - 1, SEGMENTS)], names=["c_custkey", "c_mktsegment"])
+
+
+def orders_and_lineitem(sf: int = 1):
+    """→ (orders[o_orderkey, o_custkey, o_orderdate, o_shippriority],
+          lineitem[l_orderkey, l_quantity, l_extendedprice, l_discount, l_tax, l_returnflag, l_linestatus, l_shipdate]) in dbgen's row order"""
+    n = 1_500_000 * sf
+    ncust = 150_000 * sf
+    i = np.arange(1, n + 1, dtype=np.int64)
+    okey = ((i >> 3) << 5) | (i & 7)                                     # mk_sparse: the low 3 bits kept, 2 zero bits above them
+    ckey, _ = _draw(_stream_starts(SEED["O_CKEY"], n, 1), 1, ncust)
+    # every third customer places no orders (CUST_MORTALITY): step to a neighbour, alternating +1, −1 (once is always enough)
+    dead = ckey % 3 == 0
+    ckey = np.where(dead, np.minimum(ckey + 1, ncust), ckey)
+    still = ckey % 3 == 0                                                  # (only when the step was clipped at the last key)
+    ckey = np.where(still, ckey - 1, ckey)
+    odate, _ = _draw(_stream_starts(SEED["O_ODATE"], n, 1), 92001, 94406)
+    odate_off = odate - 92001                                              # days since 1992-01-01
+    lines, _ = _draw(_stream_starts(SEED["O_LCNT"], n, 1), 1, 7)
+    orders = pa.table([pa.array(okey), pa.array(ckey), pa.array((odate_off + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()),
+                       pa.array(np.zeros(n, np.int32))], names=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    st = {k: _stream_starts(SEED[k], n, 7) for k in ("L_QTY", "L_DCNT", "L_TAX", "L_PKEY", "L_SDTE", "L_CDTE", "L_RDTE", "L_RFLG")}
+    cols = {k: [] for k in ("okey", "qty", "ep", "disc", "tax", "rflag", "lstat", "ship", "order", "lcnt")}
+    for l in range(7):
+        qty, st["L_QTY"] = _draw(st["L_QTY"], 1, 50)
+        disc, st["L_DCNT"] = _draw(st["L_DCNT"], 0, 10)
+        tax, st["L_TAX"] = _draw(st["L_TAX"], 0, 8)
+        pkey, st["L_PKEY"] = _draw(st["L_PKEY"], 1, 200_000 * sf)
+        sd, st["L_SDTE"] = _draw(st["L_SDTE"], 1, 121)
+        rd, st["L_RDTE"] = _draw(st["L_RDTE"], 1, 30)
+        ship = odate_off + sd
+        receipt = ship + rd
+        # the return flag draws from its stream only when the line has been received by CURRENTDATE
+        received = receipt <= CURRENTDATE_OFFSET
+        has = lines > l
+        rf_draw, adv = _draw(st["L_RFLG"], 1, 2)
+        st["L_RFLG"] = np.where(received & has, adv, st["L_RFLG"])
+        rflag = np.where(received, np.where(rf_draw == 1, 0, 1), 2)      # 0 'R', 1 'A', 2 'N'
+        lstat = np.where(ship <= CURRENTDATE_OFFSET, 0, 1)                # 0 'F', 1 'O'
+        price = 90000 + (pkey // 10) % 20001 + (pkey % 1000) * 100       # rpb_routine, in cents
+        for k, v in (("okey", okey), ("qty", qty), ("ep", price * qty), ("disc", disc), ("tax", tax), ("rflag", rflag), ("lstat", lstat), ("ship", ship),
+                     ("order", i), ("lcnt", np.full(n, l, np.int64))):
+            cols[k].append(v[has])
+    cat = {k: np.concatenate(v) for k, v in cols.items()}
+    order = np.lexsort((cat["lcnt"], cat["order"]))                        # dbgen's row order: by order, then line number
+    c = {k: v[order] for k, v in cat.items()}
+    lineitem = pa.table([pa.array(c["okey"]), _dec(c["qty"] * 100, 12, 2), _dec(c["ep"], 12, 2), _dec(c["disc"], 12, 2), _dec(c["tax"], 12, 2),
+                         _utf8_from_choices(c["rflag"], [b"R", b"A", b"N"]), _utf8_from_choices(c["lstat"], [b"F", b"O"]),
+                         pa.array((c["ship"] + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32())],
+                        names=["l_orderkey", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"])
+    return orders, lineitem
+
+
+def parse_golden(path: str):
+    """rows of a `*.sql.out` file of the reference's TPC-H suite (tab-separated, after the `-- !query output` line)"""
+    rows, on = [], False
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith("-- !query output"):
+            on = True
+        elif on and line:
+            rows.append(line.split("\t"))
+    return rows
