@@ -1,5 +1,5 @@
-"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 — the numbers in
-spark/src/test/resources/tpch-query-results/q{1,3,6}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
+"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q12 / Q14 — the numbers in
+spark/src/test/resources/tpch-query-results/q{1,3,6,12,14}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py; tests/test_tpch_golden_cpu.py pins the generator and the oracle on
 the same files).  Q6 goes in through Parquet (snappy and zstd, pages inflated on the device, and the host path), Q1 and Q3 over
 HBM-resident columns; every stage runs through the C ABI, the Final aggregates included."""
@@ -10,7 +10,7 @@ import pyarrow.parquet as papq
 import pytest
 
 from datafusion_comet_amd import dbgen, native, parallel, serde as S, tpch
-from tests.test_tpch_golden_cpu import GOLD, q1_rows, q3_rows
+from tests.test_tpch_golden_cpu import GOLD, more_layout, q1_rows, q3_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -55,7 +55,22 @@ def test_q1_gives_the_references_answer(built, sf1):
 def test_q3_gives_the_references_answer(built, sf1):
     customer, orders, lineitem = sf1
     li = lineitem.select(["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
+    orders = orders.select(["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
     engine = parallel.GpuEngine(0)
     top, groups = parallel.run_q3_single(engine, native.DeviceTable.from_arrow(customer), native.DeviceTable.from_arrow(orders), native.DeviceTable.from_arrow(li))
     assert groups == 11620                                                                # rows of the full Q3 answer at SF1 (TPC-H answer set)
     assert q3_rows(top) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
+
+
+def test_q12_and_q14_give_the_references_answers(built, sf1):
+    from tests import test_tpch_more_gpu as M
+    _, orders, lineitem = sf1
+    o2, li, pt = more_layout(orders, lineitem, dbgen.part(1))
+    partial = M.q12_partial_plan()
+    st = M.run(partial, [o2, li], 3)
+    final = M.run(M.q12_final_plan(partial, st.schema), [st], 3)
+    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q12.sql.out"))      # MAIL 6202 9324 / SHIP 6200 9262
+    partial = M.q14_partial_plan(tpch.days(1995, 9, 1), tpch.days(1995, 10, 1))
+    st = M.run(partial, [li, pt], 4)
+    final = M.run(M.q14_final_plan(partial, st.schema), [st], 1)
+    assert [[str(final.column(0)[0].as_py())]] == dbgen.parse_golden(os.path.join(GOLD, "q14.sql.out"))                # 16.380779

@@ -58,18 +58,27 @@ def _revenue(price, disc):
     return S.check_overflow(S.math("multiply", price, one_minus, S.decimal(26, 4)), S.decimal(26, 4))
 
 
-def test_q12_shipping_modes(built):
-    from oracle import oracle as O
-    orders, lineitem, _ = _tables()
+def q12_partial_plan():
+    """TPC-H Q12 up to the partial aggregate; inputs: orders[o_orderkey, o_orderpriority], lineitem (the LI layout)"""
     li = S.filter_(S.scan(LI), S.and_(S.and_(S.in_(c(8, STR), [L("MAIL"), L("SHIP")]), S.and_(S.lt(c(6, DATE), c(7, DATE)), S.lt(c(5, DATE), c(6, DATE)))),
                                       S.and_(S.gt_eq(c(7, DATE), S.lit(date(1994, 1, 1), DATE)), S.lt(c(7, DATE), S.lit(date(1995, 1, 1), DATE)))))
     j = S.hash_join(S.scan([I64, STR]), S.project(li, [c(0, I64), c(8, STR)]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)   # o_orderkey, prio, l_orderkey, shipmode
     urgent = S.or_(S.eq(c(1, STR), L("1-URGENT")), S.eq(c(1, STR), L("2-HIGH")))
     one, zero = S.lit(1, I32), S.lit(0, I32)
     p = S.project(j, [c(3, STR), S.case_when([(urgent, one)], zero), S.case_when([(S.and_(S.neq(c(1, STR), L("1-URGENT")), S.neq(c(1, STR), L("2-HIGH"))), one)], zero)])
-    partial = S.hash_agg(p, [c(0, STR)], [S.sum_(c(1, I32), I64), S.sum_(c(2, I32), I64)], S.PARTIAL)
+    return S.hash_agg(p, [c(0, STR)], [S.sum_(c(1, I32), I64), S.sum_(c(2, I32), I64)], S.PARTIAL)
+
+
+def q12_final_plan(partial, state_schema):
+    return S.sort(S.final_of(partial, state_schema), [(c(0, STR), False, False)])
+
+
+def test_q12_shipping_modes(built):
+    from oracle import oracle as O
+    orders, lineitem, _ = _tables()
+    partial = q12_partial_plan()
     st = run(partial, [orders, lineitem], 3)
-    final = S.sort(S.final_of(partial, st.schema), [(c(0, STR), False, False)])
+    final = q12_final_plan(partial, st.schema)
     got, want = run(final, [st], 3), O.run_plan_to_arrow(S, final, [O.run_plan_to_arrow(S, partial, [orders, lineitem])])
     assert rows(got) == rows(want)
     prio = dict(zip(orders.column(0).to_pylist(), orders.column(1).to_pylist()))
@@ -82,24 +91,33 @@ def test_q12_shipping_modes(built):
     assert rows(got) == [(m, ref[m][0], ref[m][1]) for m in sorted(ref)]
 
 
-def test_q14_promotion_effect(built):
-    from oracle import oracle as O
-    _, lineitem, part = _tables()
-    li = S.project(S.filter_(S.scan(LI), S.and_(S.gt_eq(c(5, DATE), S.lit(date(1995, 1, 1), DATE)), S.lt(c(5, DATE), S.lit(date(1995, 2, 1), DATE)))), [c(1, I64), c(3, D), c(4, D)])
+def q14_partial_plan(d0, d1):
+    """TPC-H Q14 up to the partial aggregate, shipdate in [d0, d1); inputs: lineitem (the LI layout), part[p_partkey, p_type, p_brand, p_container, p_size]"""
+    li = S.project(S.filter_(S.scan(LI), S.and_(S.gt_eq(c(5, DATE), S.lit(d0, DATE)), S.lt(c(5, DATE), S.lit(d1, DATE)))), [c(1, I64), c(3, D), c(4, D)])
     j = S.hash_join(li, S.project(S.scan([I64, STR, STR, STR, I32]), [c(0, I64), c(1, STR)]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)   # partkey, price, disc, p_partkey, p_type
     rev = _revenue(c(1, D), c(2, D))
     R = S.decimal(26, 4)
     p = S.project(j, [S.case_when([(S.like(c(4, STR), L("PROMO%")), rev)], S.lit(decimal.Decimal("0.0000"), R)), rev])
-    partial = S.hash_agg(p, [], [S.sum_(c(0, R), S.decimal(36, 4)), S.sum_(c(1, R), S.decimal(36, 4))], S.PARTIAL)
-    st = run(partial, [lineitem, part], 4)
-    assert rows(st) == rows(O.run_plan_to_arrow(S, partial, [lineitem, part]))
+    return S.hash_agg(p, [], [S.sum_(c(0, R), S.decimal(36, 4)), S.sum_(c(1, R), S.decimal(36, 4))], S.PARTIAL)
+
+
+def q14_final_plan(partial, state_schema):
     SD = S.decimal(36, 4)
     # 100.00 * promo / total: Spark types the product decimal(38,6) and the quotient decimal(38,6)
-    fin = S.final_of(partial, st.schema)
+    fin = S.final_of(partial, state_schema)
     hundred = S.lit(decimal.Decimal("100.00"), S.decimal(5, 2))
     prod = S.check_overflow(S.math("multiply", hundred, c(0, SD), S.decimal(38, 6)), S.decimal(38, 6))
     quot = S.check_overflow(S.math("divide", prod, c(1, SD), S.decimal(38, 6)), S.decimal(38, 6))
-    plan_b = S.project(fin, [quot])
+    return S.project(fin, [quot])
+
+
+def test_q14_promotion_effect(built):
+    from oracle import oracle as O
+    _, lineitem, part = _tables()
+    partial = q14_partial_plan(date(1995, 1, 1), date(1995, 2, 1))
+    st = run(partial, [lineitem, part], 4)
+    assert rows(st) == rows(O.run_plan_to_arrow(S, partial, [lineitem, part]))
+    plan_b = q14_final_plan(partial, st.schema)
     got, want = run(plan_b, [st], 1), O.run_plan_to_arrow(S, plan_b, [st])
     assert rows(got) == rows(want)
     ptype = dict(zip(part.column(0).to_pylist(), part.column(1).to_pylist()))
