@@ -317,13 +317,20 @@ __global__ __launch_bounds__(256) void pq_decode_fixed_kernel(PqDecodeArgs a) {
 // dictionary loads issued before the first store, and consecutive lanes store consecutive rows.  The row-at-a-time kernel above spends a
 // dependent index → dictionary → store chain per 64 rows and drops to a per-element path at every run boundary; here there are no
 // boundaries inside a unit.
+// (decoded columns are written once and read by a LATER kernel: streaming stores, which do not claim L2 lines the dictionary and the packed
+// indices want; COMET_PQ_STORE=plain restores ordinary stores)
 template <int OW>
 __device__ __forceinline__ void pq_store(void* out, i64 row, i128 v) {
   if (OW == 1) ((u8*)out)[row] = (u8)v;
   else if (OW == 2) ((u16*)out)[row] = (u16)v;
-  else if (OW == 4) ((u32*)out)[row] = (u32)v;
-  else if (OW == 8) ((u64*)out)[row] = (u64)v;
-  else ((i128*)out)[row] = v;
+  else if (OW == 4) __builtin_nontemporal_store((u32)v, (u32*)out + row);
+  else if (OW == 8) __builtin_nontemporal_store((u64)v, (u64*)out + row);
+  else {
+    typedef u32 V4S __attribute__((ext_vector_type(4)));
+    V4S x;
+    x[0] = (u32)v; x[1] = (u32)((u128)v >> 32); x[2] = (u32)((u128)v >> 64); x[3] = (u32)((u128)v >> 96);
+    __builtin_nontemporal_store(x, (V4S*)((i128*)out + row));
+  }
 }
 // CV: how a source value becomes the stored value — the common conversions get straight-line code (the generic pq_convert pays a
 // switch and, for decimals, a 128-bit multiply by 10^0 per value): 1 copy 4 bytes, 2 copy 8 bytes, 3 INT64 → Decimal128 without
@@ -360,7 +367,7 @@ __device__ __forceinline__ void pq_decode_unit(const PqDecodeArgs& a, void* out,
       V4 x;
       if (OW == 4) { x[0] = (u32)v[0]; x[1] = (u32)v[1]; x[2] = (u32)v[2]; x[3] = (u32)v[3]; }
       else { const u64 a = (u64)v[0], b = (u64)v[VN - 1]; x[0] = (u32)a; x[1] = (u32)(a >> 32); x[2] = (u32)b; x[3] = (u32)(b >> 32); }
-      *(V4*)((u8*)out + (row0 + j0) * (i64)OW) = x;
+      __builtin_nontemporal_store(x, (V4*)((u8*)out + (row0 + j0) * (i64)OW));
     } else {
       for (int k = 0; k < nvalid; k++) pq_store<OW>(out, row0 + j0 + k, v[k]);
     }
@@ -714,7 +721,8 @@ void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* 
 }
 void pq_launch_decode_runs(const PqDecodeArgs* a, void* st) {
   if (a->n_idx_runs <= 0) return;
-  const int blocks = (int)std::min<i64>(((i64)a->n_idx_runs + 3) / 4, 256 * 16);
+  static const int grid_mul = getenv("COMET_PQ_GRID_MUL") ? std::max(1, atoi(getenv("COMET_PQ_GRID_MUL"))) : 16;
+  const int blocks = (int)std::min<i64>(((i64)a->n_idx_runs + 3) / 4, (i64)256 * 16 * grid_mul);
   hipLaunchKernelGGL(pq_decode_runs_kernel, blocks, 256, 0, (hipStream_t)st, *a);
 }
 void pq_launch_expand_nulls(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_expand_nulls_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }

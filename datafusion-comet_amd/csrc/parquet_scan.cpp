@@ -815,7 +815,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   size_t keep_i = 0;            // first kept range that may still overlap the next page
   std::vector<uint8_t> tmp;
   // a PLAIN page's values cut into chunks of 4096: the units the run-at-a-time decode kernel hands to its waves
-  constexpr int32_t kPlainChunk = 4096;
+  static const int32_t kPlainChunk = getenv("COMET_PQ_PLAIN_CHUNK") ? std::max(512, atoi(getenv("COMET_PQ_PLAIN_CHUNK")) & ~511) : 2048;
   auto plain_chunks = [&](PqPage& pg, int64_t values_off_flagged) {
     if (cp.is_string) return;
     pg.idx_run_first = (int32_t)idx_runs.size();
