@@ -19,14 +19,18 @@ A = 16807
 # driver.c Seed[]: stream → initial value
 SEED = {"O_ODATE": 1066728069, "L_QTY": 209208115, "L_DCNT": 554590007, "L_TAX": 721958466, "L_PKEY": 1808217256, "L_SDTE": 1769349045,
         "L_CDTE": 904914315, "L_RDTE": 373135028, "L_RFLG": 717419739, "C_MSEG": 1140279430, "O_CKEY": 851767375, "O_LCNT": 1434868289,
-        "L_SMODE": 675466456, "O_PRIO": 591449447, "P_TYPE": 1841581359}
+        "L_SMODE": 675466456, "O_PRIO": 591449447, "P_TYPE": 1841581359, "L_SHIP": 1371272478, "P_MFG": 1, "P_BRND": 46831694, "P_SIZE": 1193163244,
+        "P_CNTR": 727633698}
 STARTDATE_DAY = 8035          # 1992-01-01 as days since 1970-01-01 (dbgen's STARTDATE 92001)
 CURRENTDATE_OFFSET = 1263     # 1995-06-17 (CURRENTDATE 95168) as days since 1992-01-01
 SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]      # dists.dss msegmnt, equal weights
 PRIORITIES = [b"1-URGENT", b"2-HIGH", b"3-MEDIUM", b"4-NOT SPECIFIED", b"5-LOW"]     # dists.dss o_oprio
-# dists.dss smode, equal weights.  The golden Q12 answer pins MAIL and SHIP to the 5th and 7th entry; the other five names are placed from
-# memory of the file and nothing here depends on which is which
+# dists.dss smode, equal weights.  The golden answers pin MAIL and SHIP to the 5th and 7th entry (Q12) and AIR to the 2nd (Q19); the other four
+# names are placed from memory of the file and no query here depends on which is which
 SHIPMODES = [b"REG AIR", b"AIR", b"RAIL", b"TRUCK", b"MAIL", b"FOB", b"SHIP"]
+INSTRUCTIONS = [b"DELIVER IN PERSON", b"COLLECT COD", b"NONE", b"TAKE BACK RETURN"]      # dists.dss instruct (Q19 pins the first)
+# dists.dss p_cntr: 40 equally weighted names, size syllable outside (Q19's golden answer pins the twelve it names)
+CONTAINERS = [a + b" " + b for a in (b"SM", b"LG", b"MED", b"JUMBO", b"WRAP") for b in (b"CASE", b"BOX", b"BAG", b"JAR", b"PKG", b"PACK", b"CAN", b"DRUM")]
 # dists.dss p_types: 150 equally weighted names, the three syllables nested in this order (Q14's golden answer pins PROMO to the last 25)
 TYPE_SYLLABLES = ([b"STANDARD", b"SMALL", b"MEDIUM", b"LARGE", b"ECONOMY", b"PROMO"], [b"ANODIZED", b"BURNISHED", b"PLATED", b"POLISHED", b"BRUSHED"],
                   [b"TIN", b"NICKEL", b"BRASS", b"STEEL", b"COPPER"])
@@ -84,16 +88,22 @@ def customer(sf: int = 1) -> pa.Table:
 
 
 def part(sf: int = 1) -> pa.Table:
-    """p_partkey, p_type (mk_part: one draw of P_TYPE per part, pick_str over p_types)"""
+    """p_partkey, p_type, p_brand, p_container, p_size (mk_part: one draw per part of P_TYPE / P_MFG and P_BRND / P_CNTR / P_SIZE)"""
     n = 200_000 * sf
     t, _ = _draw(_stream_starts(SEED["P_TYPE"], n, 1), 1, 150)
-    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(t - 1, PART_TYPES)], names=["p_partkey", "p_type"])
+    mfg, _ = _draw(_stream_starts(SEED["P_MFG"], n, 1), 1, 5)
+    brnd, _ = _draw(_stream_starts(SEED["P_BRND"], n, 1), 1, 5)
+    cntr, _ = _draw(_stream_starts(SEED["P_CNTR"], n, 1), 1, 40)
+    size, _ = _draw(_stream_starts(SEED["P_SIZE"], n, 1), 1, 50)
+    brands = [b"Brand#%d%d" % (m, b) for m in range(1, 6) for b in range(1, 6)]
+    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(t - 1, PART_TYPES), _utf8_from_choices((mfg - 1) * 5 + brnd - 1, brands),
+                     _utf8_from_choices(cntr - 1, CONTAINERS), pa.array(size.astype(np.int32))], names=["p_partkey", "p_type", "p_brand", "p_container", "p_size"])
 
 
 def orders_and_lineitem(sf: int = 1):
     """→ (orders[o_orderkey, o_custkey, o_orderdate, o_shippriority, o_orderpriority],
           lineitem[l_orderkey, l_quantity, l_extendedprice, l_discount, l_tax, l_returnflag, l_linestatus, l_shipdate, l_partkey, l_commitdate,
-                   l_receiptdate, l_shipmode]) in dbgen's row order"""
+                   l_receiptdate, l_shipmode, l_shipinstruct]) in dbgen's row order"""
     n = 1_500_000 * sf
     ncust = 150_000 * sf
     i = np.arange(1, n + 1, dtype=np.int64)
@@ -111,8 +121,8 @@ def orders_and_lineitem(sf: int = 1):
     orders = pa.table([pa.array(okey), pa.array(ckey), pa.array((odate_off + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()),
                        pa.array(np.zeros(n, np.int32)), _utf8_from_choices(prio - 1, PRIORITIES)],
                       names=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority"])
-    st = {k: _stream_starts(SEED[k], n, 7) for k in ("L_QTY", "L_DCNT", "L_TAX", "L_PKEY", "L_SDTE", "L_CDTE", "L_RDTE", "L_RFLG", "L_SMODE")}
-    cols = {k: [] for k in ("okey", "qty", "ep", "disc", "tax", "rflag", "lstat", "ship", "order", "lcnt", "pkey", "commit", "receipt", "smode")}
+    st = {k: _stream_starts(SEED[k], n, 7) for k in ("L_QTY", "L_DCNT", "L_TAX", "L_PKEY", "L_SDTE", "L_CDTE", "L_RDTE", "L_RFLG", "L_SMODE", "L_SHIP")}
+    cols = {k: [] for k in ("okey", "qty", "ep", "disc", "tax", "rflag", "lstat", "ship", "order", "lcnt", "pkey", "commit", "receipt", "smode", "instr")}
     for l in range(7):
         qty, st["L_QTY"] = _draw(st["L_QTY"], 1, 50)
         disc, st["L_DCNT"] = _draw(st["L_DCNT"], 0, 10)
@@ -122,6 +132,7 @@ def orders_and_lineitem(sf: int = 1):
         rd, st["L_RDTE"] = _draw(st["L_RDTE"], 1, 30)
         cd, st["L_CDTE"] = _draw(st["L_CDTE"], 30, 90)
         smode, st["L_SMODE"] = _draw(st["L_SMODE"], 1, 7)
+        instr, st["L_SHIP"] = _draw(st["L_SHIP"], 1, 4)
         ship = odate_off + sd
         receipt = ship + rd
         commit = odate_off + cd
@@ -134,7 +145,7 @@ def orders_and_lineitem(sf: int = 1):
         lstat = np.where(ship <= CURRENTDATE_OFFSET, 0, 1)                # 0 'F', 1 'O'
         price = 90000 + (pkey // 10) % 20001 + (pkey % 1000) * 100       # rpb_routine, in cents
         for k, v in (("okey", okey), ("qty", qty), ("ep", price * qty), ("disc", disc), ("tax", tax), ("rflag", rflag), ("lstat", lstat), ("ship", ship),
-                     ("order", i), ("lcnt", np.full(n, l, np.int64)), ("pkey", pkey), ("commit", commit), ("receipt", receipt), ("smode", smode - 1)):
+                     ("order", i), ("lcnt", np.full(n, l, np.int64)), ("pkey", pkey), ("commit", commit), ("receipt", receipt), ("smode", smode - 1), ("instr", instr - 1)):
             cols[k].append(v[has])
     cat = {k: np.concatenate(v) for k, v in cols.items()}
     order = np.lexsort((cat["lcnt"], cat["order"]))                        # dbgen's row order: by order, then line number
@@ -143,9 +154,10 @@ def orders_and_lineitem(sf: int = 1):
                          _utf8_from_choices(c["rflag"], [b"R", b"A", b"N"]), _utf8_from_choices(c["lstat"], [b"F", b"O"]),
                          pa.array((c["ship"] + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()), pa.array(c["pkey"]),
                          pa.array((c["commit"] + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()),
-                         pa.array((c["receipt"] + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()), _utf8_from_choices(c["smode"], SHIPMODES)],
+                         pa.array((c["receipt"] + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()), _utf8_from_choices(c["smode"], SHIPMODES),
+                         _utf8_from_choices(c["instr"], INSTRUCTIONS)],
                         names=["l_orderkey", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate", "l_partkey",
-                               "l_commitdate", "l_receiptdate", "l_shipmode"])
+                               "l_commitdate", "l_receiptdate", "l_shipmode", "l_shipinstruct"])
     return orders, lineitem
 
 

@@ -132,10 +132,10 @@ def test_q14_promotion_effect(built):
     assert got.column(0).to_pylist() == [exact]
 
 
-def test_q19_discounted_revenue(built):
-    from oracle import oracle as O
-    _, lineitem, part = _tables()
-    li = S.project(S.filter_(S.scan(LI), S.and_(S.in_(c(8, STR), [L("AIR"), L("REG AIR")]), S.eq(c(9, STR), L("DELIVER IN PERSON")))), [c(1, I64), c(2, D), c(3, D), c(4, D)])
+def q19_partial_plan(modes=("AIR", "REG AIR")):
+    """TPC-H Q19 up to the partial aggregate; inputs: lineitem (the LI layout), part[p_partkey, p_type, p_brand, p_container, p_size].  (The
+    benchmark's text asks for the modes 'AIR' and 'AIR REG'; no row carries the latter.)"""
+    li = S.project(S.filter_(S.scan(LI), S.and_(S.in_(c(8, STR), [L(m) for m in modes]), S.eq(c(9, STR), L("DELIVER IN PERSON")))), [c(1, I64), c(2, D), c(3, D), c(4, D)])
     j = S.hash_join(li, S.scan([I64, STR, STR, STR, I32]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)   # partkey, qty, price, disc | p_partkey, type, brand, container, size
     qty, brand, cont, size = c(1, D), c(6, STR), c(7, STR), c(8, I32)
     dq = lambda v: S.lit(decimal.Decimal(v), D)
@@ -143,7 +143,13 @@ def test_q19_discounted_revenue(built):
     branch = lambda b, conts, q0, q1, s1: S.and_(S.and_(S.eq(brand, L(b)), S.in_(cont, [L(x) for x in conts])), S.and_(between(qty, dq(q0), dq(q1)), between(size, S.lit(1, I32), S.lit(s1, I32))))
     cond = S.or_(S.or_(branch("Brand#12", ["SM CASE", "SM BOX", "SM PACK", "SM PKG"], "1.00", "11.00", 5), branch("Brand#23", ["MED BAG", "MED BOX", "MED PKG", "MED PACK"], "10.00", "20.00", 10)),
                  branch("Brand#34", ["LG CASE", "LG BOX", "LG PACK", "LG PKG"], "20.00", "30.00", 15))
-    partial = S.hash_agg(S.project(S.filter_(j, cond), [_revenue(c(2, D), c(3, D))]), [], [S.sum_(c(0, S.decimal(26, 4)), S.decimal(36, 4))], S.PARTIAL)
+    return S.hash_agg(S.project(S.filter_(j, cond), [_revenue(c(2, D), c(3, D))]), [], [S.sum_(c(0, S.decimal(26, 4)), S.decimal(36, 4))], S.PARTIAL)
+
+
+def test_q19_discounted_revenue(built):
+    from oracle import oracle as O
+    _, lineitem, part = _tables()
+    partial = q19_partial_plan()
     st = run(partial, [lineitem, part], 2)
     got = run(S.final_of(partial, st.schema), [st], 1)
     assert rows(st) == rows(O.run_plan_to_arrow(S, partial, [lineitem, part]))
