@@ -1,5 +1,5 @@
-"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q12 / Q14 / Q19, as recorded in
-spark/src/test/resources/tpch-query-results/q{1,3,6,12,14,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
+"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q12 / Q14 / Q19, as recorded in
+spark/src/test/resources/tpch-query-results/q{1,3,4,6,12,14,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py: dbgen itself is not in the reference's tree, its algorithm is
 restated and pinned by exactly these files); the oracle evaluates the same plans the GPU tests run (tests/test_tpch_golden_gpu.py)."""
 import datetime
@@ -69,7 +69,7 @@ def test_q3_oracle_gives_the_references_answer(sf1):
     assert q3_rows(parallel.q3_top10(final)) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
 
 
-def test_q12_q14_q19_oracle_give_the_references_answers(sf1):
+def test_q12_q14_q19_q4_oracle_give_the_references_answers(sf1):
     from tests import test_tpch_more_gpu as M
     _, orders, lineitem = sf1
     o2, li, pt = more_layout(orders, lineitem, dbgen.part(1))
@@ -85,3 +85,8 @@ def test_q12_q14_q19_oracle_give_the_references_answers(sf1):
     st = O.run_plan_to_arrow(S, partial, [li, pt])
     final = O.run_plan_to_arrow(S, S.final_of(partial, st.schema), [st])
     assert [[str(final.column(0)[0].as_py())]] == dbgen.parse_golden(os.path.join(GOLD, "q19.sql.out"))                # 3083843.0578
+    partial = M.q4_partial_plan(tpch.days(1993, 7, 1), tpch.days(1993, 10, 1))
+    o4, l4 = orders.select(["o_orderkey", "o_orderdate", "o_orderpriority"]), lineitem.select(["l_orderkey", "l_commitdate", "l_receiptdate"])
+    st = O.run_plan_to_arrow(S, partial, [o4, l4])
+    final = O.run_plan_to_arrow(S, M.q12_final_plan(partial, st.schema), [st])
+    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q4.sql.out"))       # five priorities, ≈ 10 500 orders each

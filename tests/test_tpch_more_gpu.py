@@ -132,6 +132,15 @@ def test_q14_promotion_effect(built):
     assert got.column(0).to_pylist() == [exact]
 
 
+def q4_partial_plan(d0, d1):
+    """TPC-H Q4 up to the partial aggregate: orders of a quarter that have a line received after its commit date (LeftSemi), counted by
+    priority; inputs: orders[o_orderkey, o_orderdate, o_orderpriority], lineitem[l_orderkey, l_commitdate, l_receiptdate]"""
+    o = S.filter_(S.scan([I64, DATE, STR]), S.and_(S.gt_eq(c(1, DATE), S.lit(d0, DATE)), S.lt(c(1, DATE), S.lit(d1, DATE))))
+    li = S.project(S.filter_(S.scan([I64, DATE, DATE]), S.lt(c(1, DATE), c(2, DATE))), [c(0, I64)])
+    j = S.hash_join(o, li, [c(0, I64)], [c(0, I64)], S.LEFT_SEMI, S.BUILD_RIGHT)
+    return S.hash_agg(S.project(j, [c(2, STR)]), [c(0, STR)], [S.count(S.lit(1, I32))], S.PARTIAL)
+
+
 def q19_partial_plan(modes=("AIR", "REG AIR")):
     """TPC-H Q19 up to the partial aggregate; inputs: lineitem (the LI layout), part[p_partkey, p_type, p_brand, p_container, p_size].  (The
     benchmark's text asks for the modes 'AIR' and 'AIR REG'; no row carries the latter.)"""
