@@ -20,7 +20,7 @@ A = 16807
 SEED = {"O_ODATE": 1066728069, "L_QTY": 209208115, "L_DCNT": 554590007, "L_TAX": 721958466, "L_PKEY": 1808217256, "L_SDTE": 1769349045,
         "L_CDTE": 904914315, "L_RDTE": 373135028, "L_RFLG": 717419739, "C_MSEG": 1140279430, "O_CKEY": 851767375, "O_LCNT": 1434868289,
         "L_SMODE": 675466456, "O_PRIO": 591449447, "P_TYPE": 1841581359, "L_SHIP": 1371272478, "P_MFG": 1, "P_BRND": 46831694, "P_SIZE": 1193163244,
-        "P_CNTR": 727633698}
+        "P_CNTR": 727633698, "C_NTRG": 1489529863, "S_NTRG": 110356601, "L_SKEY": 2095021727}
 STARTDATE_DAY = 8035          # 1992-01-01 as days since 1970-01-01 (dbgen's STARTDATE 92001)
 CURRENTDATE_OFFSET = 1263     # 1995-06-17 (CURRENTDATE 95168) as days since 1992-01-01
 SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]      # dists.dss msegmnt, equal weights
@@ -80,11 +80,35 @@ def _utf8_from_choices(idx: np.ndarray, choices) -> pa.Array:
     return pa.Array.from_buffers(pa.utf8(), len(idx), [None, pa.py_buffer(offs.tobytes()), pa.py_buffer(data)])
 
 
+NATIONS = [(b"ALGERIA", 0), (b"ARGENTINA", 1), (b"BRAZIL", 1), (b"CANADA", 1), (b"EGYPT", 4), (b"ETHIOPIA", 0), (b"FRANCE", 3), (b"GERMANY", 3), (b"INDIA", 2),
+           (b"INDONESIA", 2), (b"IRAN", 4), (b"IRAQ", 4), (b"JAPAN", 2), (b"JORDAN", 4), (b"KENYA", 0), (b"MOROCCO", 0), (b"MOZAMBIQUE", 0), (b"PERU", 1),
+           (b"CHINA", 2), (b"ROMANIA", 3), (b"SAUDI ARABIA", 4), (b"VIETNAM", 2), (b"RUSSIA", 3), (b"UNITED KINGDOM", 3), (b"UNITED STATES", 1)]      # dists.dss nations
+REGIONS = [b"AFRICA", b"AMERICA", b"ASIA", b"EUROPE", b"MIDDLE EAST"]
+
+
+def nation() -> pa.Table:
+    return pa.table([pa.array(np.arange(25, dtype=np.int32)), pa.array([n.decode() for n, _ in NATIONS]), pa.array(np.array([r for _, r in NATIONS], np.int32))],
+                    names=["n_nationkey", "n_name", "n_regionkey"])
+
+
+def region() -> pa.Table:
+    return pa.table([pa.array(np.arange(5, dtype=np.int32)), pa.array([r.decode() for r in REGIONS])], names=["r_regionkey", "r_name"])
+
+
 def customer(sf: int = 1) -> pa.Table:
-    """c_custkey, c_mktsegment (mk_cust: one draw of C_MSEG per customer, pick_str over five equal weights)"""
+    """c_custkey, c_mktsegment, c_nationkey (mk_cust: one draw of C_MSEG — pick_str over five equal weights — and of C_NTRG per customer)"""
     n = 150_000 * sf
     seg, _ = _draw(_stream_starts(SEED["C_MSEG"], n, 1), 1, 5)
-    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(seg - 1, SEGMENTS)], names=["c_custkey", "c_mktsegment"])
+    nat, _ = _draw(_stream_starts(SEED["C_NTRG"], n, 1), 0, 24)
+    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(seg - 1, SEGMENTS), pa.array(nat.astype(np.int32))],
+                    names=["c_custkey", "c_mktsegment", "c_nationkey"])
+
+
+def supplier(sf: int = 1) -> pa.Table:
+    """s_suppkey, s_nationkey (mk_supp: one draw of S_NTRG per supplier)"""
+    n = 10_000 * sf
+    nat, _ = _draw(_stream_starts(SEED["S_NTRG"], n, 1), 0, 24)
+    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), pa.array(nat.astype(np.int32))], names=["s_suppkey", "s_nationkey"])
 
 
 def part(sf: int = 1) -> pa.Table:
@@ -103,7 +127,7 @@ def part(sf: int = 1) -> pa.Table:
 def orders_and_lineitem(sf: int = 1):
     """→ (orders[o_orderkey, o_custkey, o_orderdate, o_shippriority, o_orderpriority],
           lineitem[l_orderkey, l_quantity, l_extendedprice, l_discount, l_tax, l_returnflag, l_linestatus, l_shipdate, l_partkey, l_commitdate,
-                   l_receiptdate, l_shipmode, l_shipinstruct]) in dbgen's row order"""
+                   l_receiptdate, l_shipmode, l_shipinstruct, l_suppkey]) in dbgen's row order"""
     n = 1_500_000 * sf
     ncust = 150_000 * sf
     i = np.arange(1, n + 1, dtype=np.int64)
@@ -121,8 +145,8 @@ def orders_and_lineitem(sf: int = 1):
     orders = pa.table([pa.array(okey), pa.array(ckey), pa.array((odate_off + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()),
                        pa.array(np.zeros(n, np.int32)), _utf8_from_choices(prio - 1, PRIORITIES)],
                       names=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority"])
-    st = {k: _stream_starts(SEED[k], n, 7) for k in ("L_QTY", "L_DCNT", "L_TAX", "L_PKEY", "L_SDTE", "L_CDTE", "L_RDTE", "L_RFLG", "L_SMODE", "L_SHIP")}
-    cols = {k: [] for k in ("okey", "qty", "ep", "disc", "tax", "rflag", "lstat", "ship", "order", "lcnt", "pkey", "commit", "receipt", "smode", "instr")}
+    st = {k: _stream_starts(SEED[k], n, 7) for k in ("L_QTY", "L_DCNT", "L_TAX", "L_PKEY", "L_SDTE", "L_CDTE", "L_RDTE", "L_RFLG", "L_SMODE", "L_SHIP", "L_SKEY")}
+    cols = {k: [] for k in ("okey", "qty", "ep", "disc", "tax", "rflag", "lstat", "ship", "order", "lcnt", "pkey", "commit", "receipt", "smode", "instr", "skey")}
     for l in range(7):
         qty, st["L_QTY"] = _draw(st["L_QTY"], 1, 50)
         disc, st["L_DCNT"] = _draw(st["L_DCNT"], 0, 10)
@@ -133,6 +157,7 @@ def orders_and_lineitem(sf: int = 1):
         cd, st["L_CDTE"] = _draw(st["L_CDTE"], 30, 90)
         smode, st["L_SMODE"] = _draw(st["L_SMODE"], 1, 7)
         instr, st["L_SHIP"] = _draw(st["L_SHIP"], 1, 4)
+        snum, st["L_SKEY"] = _draw(st["L_SKEY"], 0, 3)
         ship = odate_off + sd
         receipt = ship + rd
         commit = odate_off + cd
@@ -144,8 +169,10 @@ def orders_and_lineitem(sf: int = 1):
         rflag = np.where(received, np.where(rf_draw == 1, 0, 1), 2)      # 0 'R', 1 'A', 2 'N'
         lstat = np.where(ship <= CURRENTDATE_OFFSET, 0, 1)                # 0 'F', 1 'O'
         price = 90000 + (pkey // 10) % 20001 + (pkey % 1000) * 100       # rpb_routine, in cents
+        nsupp = 10_000 * sf
+        skey = (pkey + snum * (nsupp // 4 + (pkey - 1) // nsupp)) % nsupp + 1     # PART_SUPP_BRIDGE: one of the part's four suppliers
         for k, v in (("okey", okey), ("qty", qty), ("ep", price * qty), ("disc", disc), ("tax", tax), ("rflag", rflag), ("lstat", lstat), ("ship", ship),
-                     ("order", i), ("lcnt", np.full(n, l, np.int64)), ("pkey", pkey), ("commit", commit), ("receipt", receipt), ("smode", smode - 1), ("instr", instr - 1)):
+                     ("order", i), ("lcnt", np.full(n, l, np.int64)), ("pkey", pkey), ("commit", commit), ("receipt", receipt), ("smode", smode - 1), ("instr", instr - 1), ("skey", skey)):
             cols[k].append(v[has])
     cat = {k: np.concatenate(v) for k, v in cols.items()}
     order = np.lexsort((cat["lcnt"], cat["order"]))                        # dbgen's row order: by order, then line number
@@ -155,9 +182,9 @@ def orders_and_lineitem(sf: int = 1):
                          pa.array((c["ship"] + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()), pa.array(c["pkey"]),
                          pa.array((c["commit"] + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()),
                          pa.array((c["receipt"] + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()), _utf8_from_choices(c["smode"], SHIPMODES),
-                         _utf8_from_choices(c["instr"], INSTRUCTIONS)],
+                         _utf8_from_choices(c["instr"], INSTRUCTIONS), pa.array(c["skey"])],
                         names=["l_orderkey", "l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate", "l_partkey",
-                               "l_commitdate", "l_receiptdate", "l_shipmode", "l_shipinstruct"])
+                               "l_commitdate", "l_receiptdate", "l_shipmode", "l_shipinstruct", "l_suppkey"])
     return orders, lineitem
 
 

@@ -1,5 +1,5 @@
-"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q12 / Q14 / Q19, as recorded in
-spark/src/test/resources/tpch-query-results/q{1,3,4,6,12,14,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
+"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q12 / Q14 / Q19, as recorded in
+spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,12,14,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py: dbgen itself is not in the reference's tree, its algorithm is
 restated and pinned by exactly these files); the oracle evaluates the same plans the GPU tests run (tests/test_tpch_golden_gpu.py)."""
 import datetime
@@ -63,13 +63,14 @@ def test_q3_oracle_gives_the_references_answer(sf1):
     customer, orders, lineitem = sf1
     li = lineitem.select(["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
     orders = orders.select(["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    customer = customer.select(["c_custkey", "c_mktsegment"])
     partial = O.run_plan_to_arrow(S, tpch.q3_plan(), [customer, orders, li])
     final = O.run_plan_to_arrow(S, S.final_of(tpch.q3_plan(), partial.schema), partial)
     from datafusion_comet_amd import parallel
     assert q3_rows(parallel.q3_top10(final)) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
 
 
-def test_q12_q14_q19_q4_oracle_give_the_references_answers(sf1):
+def test_q4_q5_q12_q14_q19_oracle_give_the_references_answers(sf1):
     from tests import test_tpch_more_gpu as M
     _, orders, lineitem = sf1
     o2, li, pt = more_layout(orders, lineitem, dbgen.part(1))
@@ -90,3 +91,10 @@ def test_q12_q14_q19_q4_oracle_give_the_references_answers(sf1):
     st = O.run_plan_to_arrow(S, partial, [o4, l4])
     final = O.run_plan_to_arrow(S, M.q12_final_plan(partial, st.schema), [st])
     assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q4.sql.out"))       # five priorities, ≈ 10 500 orders each
+    customer = sf1[0]
+    q5_in = [dbgen.region(), dbgen.nation(), customer.select(["c_custkey", "c_nationkey"]), orders.select(["o_orderkey", "o_custkey", "o_orderdate"]),
+             lineitem.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]), dbgen.supplier(1)]
+    partial = M.q5_partial_plan(tpch.days(1994, 1, 1), tpch.days(1995, 1, 1))
+    st = O.run_plan_to_arrow(S, partial, q5_in)
+    final = O.run_plan_to_arrow(S, M.q5_final_plan(partial, st.schema), [st])
+    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q5.sql.out"))       # five Asian nations by revenue

@@ -1,5 +1,5 @@
-"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q12 / Q14 / Q19 — the numbers in
-spark/src/test/resources/tpch-query-results/q{1,3,4,6,12,14,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
+"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q12 / Q14 / Q19 — the numbers in
+spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,12,14,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py; tests/test_tpch_golden_cpu.py pins the generator and the oracle on
 the same files).  Q6 goes in through Parquet (snappy and zstd, pages inflated on the device, and the host path), Q1 and Q3 over
 HBM-resident columns; every stage runs through the C ABI, the Final aggregates included."""
@@ -56,13 +56,14 @@ def test_q3_gives_the_references_answer(built, sf1):
     customer, orders, lineitem = sf1
     li = lineitem.select(["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
     orders = orders.select(["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    customer = customer.select(["c_custkey", "c_mktsegment"])
     engine = parallel.GpuEngine(0)
     top, groups = parallel.run_q3_single(engine, native.DeviceTable.from_arrow(customer), native.DeviceTable.from_arrow(orders), native.DeviceTable.from_arrow(li))
     assert groups == 11620                                                                # rows of the full Q3 answer at SF1 (TPC-H answer set)
     assert q3_rows(top) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
 
 
-def test_q12_q14_q19_q4_give_the_references_answers(built, sf1):
+def test_q4_q5_q12_q14_q19_give_the_references_answers(built, sf1):
     from tests import test_tpch_more_gpu as M
     _, orders, lineitem = sf1
     o2, li, pt = more_layout(orders, lineitem, dbgen.part(1))
@@ -83,3 +84,10 @@ def test_q12_q14_q19_q4_give_the_references_answers(built, sf1):
     st = M.run(partial, [o4, l4], 2)
     final = M.run(M.q12_final_plan(partial, st.schema), [st], 2)
     assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q4.sql.out"))       # five priorities, ≈ 10 500 orders each
+    customer = sf1[0]
+    q5_in = [dbgen.region(), dbgen.nation(), customer.select(["c_custkey", "c_nationkey"]), orders.select(["o_orderkey", "o_custkey", "o_orderdate"]),
+             lineitem.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]), dbgen.supplier(1)]
+    partial = M.q5_partial_plan(tpch.days(1994, 1, 1), tpch.days(1995, 1, 1))
+    st = M.run(partial, q5_in, 3)
+    final = M.run(M.q5_final_plan(partial, st.schema), [st], 2)
+    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q5.sql.out"))       # five Asian nations by revenue

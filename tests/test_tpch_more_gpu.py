@@ -141,6 +141,25 @@ def q4_partial_plan(d0, d1):
     return S.hash_agg(S.project(j, [c(2, STR)]), [c(0, STR)], [S.count(S.lit(1, I32))], S.PARTIAL)
 
 
+def q5_partial_plan(d0, d1, region_name="ASIA"):
+    """TPC-H Q5 up to the partial aggregate: region ⋈ nation ⋈ customer ⋈ orders ⋈ lineitem ⋈ supplier (the last on the supplier key AND
+    the customer's nation), revenue by nation.  Scan leaves in order: region[r_regionkey, r_name], nation[n_nationkey, n_name, n_regionkey],
+    customer[c_custkey, c_nationkey], orders[o_orderkey, o_custkey, o_orderdate], lineitem[l_orderkey, l_suppkey, l_extendedprice, l_discount],
+    supplier[s_suppkey, s_nationkey]"""
+    reg = S.project(S.filter_(S.scan([I32, STR]), S.eq(c(1, STR), L(region_name))), [c(0, I32)])
+    a = S.project(S.hash_join(reg, S.scan([I32, STR, I32]), [c(0, I32)], [c(2, I32)], S.INNER, S.BUILD_LEFT), [c(1, I32), c(2, STR)])                       # n_nationkey, n_name
+    b = S.project(S.hash_join(a, S.scan([I64, I32]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(2, I64), c(3, I32), c(1, STR)])                   # c_custkey, c_nationkey, n_name
+    o = S.project(S.filter_(S.scan([I64, I64, DATE]), S.and_(S.gt_eq(c(2, DATE), S.lit(d0, DATE)), S.lt(c(2, DATE), S.lit(d1, DATE)))), [c(0, I64), c(1, I64)])
+    cj = S.project(S.hash_join(b, o, [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT), [c(3, I64), c(1, I32), c(2, STR)])                                   # o_orderkey, c_nationkey, n_name
+    dj = S.project(S.hash_join(cj, S.scan([I64, I64, D, D]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT), [c(4, I64), c(1, I32), c(2, STR), c(5, D), c(6, D)])   # l_suppkey, c_nationkey, n_name, price, disc
+    e = S.hash_join(dj, S.scan([I64, I32]), [c(0, I64), c(1, I32)], [c(0, I64), c(1, I32)], S.INNER, S.BUILD_RIGHT)                                         # … s_suppkey, s_nationkey
+    return S.hash_agg(S.project(e, [c(2, STR), _revenue(c(3, D), c(4, D))]), [c(0, STR)], [S.sum_(c(1, S.decimal(26, 4)), S.decimal(36, 4))], S.PARTIAL)
+
+
+def q5_final_plan(partial, state_schema):
+    return S.sort(S.final_of(partial, state_schema), [(c(1, S.decimal(36, 4)), True, True)])
+
+
 def q19_partial_plan(modes=("AIR", "REG AIR")):
     """TPC-H Q19 up to the partial aggregate; inputs: lineitem (the LI layout), part[p_partkey, p_type, p_brand, p_container, p_size].  (The
     benchmark's text asks for the modes 'AIR' and 'AIR REG'; no row carries the latter.)"""
