@@ -160,6 +160,56 @@ def q5_final_plan(partial, state_schema):
     return S.sort(S.final_of(partial, state_schema), [(c(1, S.decimal(36, 4)), True, True)])
 
 
+def _two_nations():
+    return S.project(S.filter_(S.scan([I32, STR, I32]), S.in_(c(1, STR), [L("FRANCE"), L("GERMANY")])), [c(0, I32), c(1, STR)])       # n_nationkey, n_name
+
+
+def q7_partial_plan(d0, d1):
+    """TPC-H Q7 up to the partial aggregate: trade volume between two nations by year.  Scan leaves in order: nation, customer[c_custkey,
+    c_nationkey], orders[o_orderkey, o_custkey], nation, supplier[s_suppkey, s_nationkey], lineitem[l_orderkey, l_suppkey, l_extendedprice,
+    l_discount, l_shipdate]"""
+    cus = S.project(S.hash_join(_two_nations(), S.scan([I64, I32]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(2, I64), c(1, STR)])                 # c_custkey, cust_nation
+    ordj = S.project(S.hash_join(cus, S.scan([I64, I64]), [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT), [c(2, I64), c(1, STR)])                          # o_orderkey, cust_nation
+    sup = S.project(S.hash_join(_two_nations(), S.scan([I64, I32]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(2, I64), c(1, STR)])                 # s_suppkey, supp_nation
+    li = S.filter_(S.scan([I64, I64, D, D, DATE]), S.and_(S.gt_eq(c(4, DATE), S.lit(d0, DATE)), S.lt_eq(c(4, DATE), S.lit(d1, DATE))))
+    j1 = S.project(S.hash_join(sup, li, [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT), [c(2, I64), c(1, STR), c(4, D), c(5, D), c(6, DATE)])                # l_orderkey, supp_nation, price, disc, shipdate
+    pair = S.or_(S.and_(S.eq(c(3, STR), L("FRANCE")), S.eq(c(1, STR), L("GERMANY"))), S.and_(S.eq(c(3, STR), L("GERMANY")), S.eq(c(1, STR), L("FRANCE"))))
+    j2 = S.hash_join(ordj, j1, [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT, condition=pair)            # o_orderkey, cust_nation, l_orderkey, supp_nation, price, disc, shipdate
+    p = S.project(j2, [c(3, STR), c(1, STR), S.date_part("year", c(6, DATE)), _revenue(c(4, D), c(5, D))])
+    return S.hash_agg(p, [c(0, STR), c(1, STR), c(2, I32)], [S.sum_(c(3, S.decimal(26, 4)), S.decimal(36, 4))], S.PARTIAL)
+
+
+def q7_final_plan(partial, state_schema):
+    return S.sort(S.final_of(partial, state_schema), [(c(0, STR), False, False), (c(1, STR), False, False), (c(2, I32), False, False)])
+
+
+def q8_partial_plan(d0, d1, ptype="ECONOMY ANODIZED STEEL", region_name="AMERICA", nation_name="BRAZIL"):
+    """TPC-H Q8 up to the partial aggregate: a nation's share of a region's market for one part type, by year.  Scan leaves in order: region,
+    nation, customer[c_custkey, c_nationkey], orders[o_orderkey, o_custkey, o_orderdate], nation, supplier[s_suppkey, s_nationkey],
+    part[p_partkey, p_type, p_brand, p_container, p_size], lineitem[l_orderkey, l_partkey, l_suppkey, l_extendedprice, l_discount]"""
+    reg = S.project(S.filter_(S.scan([I32, STR]), S.eq(c(1, STR), L(region_name))), [c(0, I32)])
+    n1 = S.project(S.hash_join(reg, S.scan([I32, STR, I32]), [c(0, I32)], [c(2, I32)], S.INNER, S.BUILD_LEFT), [c(1, I32)])
+    cus = S.project(S.hash_join(n1, S.scan([I64, I32]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(1, I64)])
+    o = S.filter_(S.scan([I64, I64, DATE]), S.and_(S.gt_eq(c(2, DATE), S.lit(d0, DATE)), S.lt_eq(c(2, DATE), S.lit(d1, DATE))))
+    ordj = S.project(S.hash_join(cus, o, [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT), [c(1, I64), c(3, DATE)])                                           # o_orderkey, o_orderdate
+    supn = S.project(S.hash_join(S.scan([I32, STR, I32]), S.scan([I64, I32]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(3, I64), c(1, STR)])       # s_suppkey, nation
+    partf = S.project(S.filter_(S.scan([I64, STR, STR, STR, I32]), S.eq(c(1, STR), L(ptype))), [c(0, I64)])
+    lp = S.project(S.hash_join(partf, S.scan([I64, I64, I64, D, D]), [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT), [c(1, I64), c(3, I64), c(4, D), c(5, D)])  # l_orderkey, l_suppkey, price, disc
+    j1 = S.project(S.hash_join(supn, lp, [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT), [c(2, I64), c(4, D), c(5, D), c(1, STR)])                          # l_orderkey, price, disc, nation
+    j2 = S.hash_join(ordj, j1, [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT)                              # o_orderkey, o_orderdate, l_orderkey, price, disc, nation
+    R = S.decimal(26, 4)
+    vol = _revenue(c(3, D), c(4, D))
+    p = S.project(j2, [S.date_part("year", c(1, DATE)), S.case_when([(S.eq(c(5, STR), L(nation_name)), vol)], S.lit(decimal.Decimal("0.0000"), R)), vol])
+    return S.hash_agg(p, [c(0, I32)], [S.sum_(c(1, R), S.decimal(36, 4)), S.sum_(c(2, R), S.decimal(36, 4))], S.PARTIAL)
+
+
+def q8_final_plan(partial, state_schema):
+    SD = S.decimal(36, 4)
+    fin = S.final_of(partial, state_schema)
+    share = S.check_overflow(S.math("divide", c(1, SD), c(2, SD), S.decimal(38, 6)), S.decimal(38, 6))
+    return S.sort(S.project(fin, [c(0, I32), share]), [(c(0, I32), False, False)])
+
+
 def q19_partial_plan(modes=("AIR", "REG AIR")):
     """TPC-H Q19 up to the partial aggregate; inputs: lineitem (the LI layout), part[p_partkey, p_type, p_brand, p_container, p_size].  (The
     benchmark's text asks for the modes 'AIR' and 'AIR REG'; no row carries the latter.)"""
