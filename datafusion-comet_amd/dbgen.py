@@ -96,12 +96,14 @@ def region() -> pa.Table:
 
 
 def customer(sf: int = 1) -> pa.Table:
-    """c_custkey, c_mktsegment, c_nationkey (mk_cust: one draw of C_MSEG — pick_str over five equal weights — and of C_NTRG per customer)"""
+    """c_custkey, c_mktsegment, c_nationkey, c_name (mk_cust: one draw of C_MSEG — pick_str over five equal weights — and of C_NTRG per customer;
+    the name is "Customer#" and the key in nine digits)"""
     n = 150_000 * sf
     seg, _ = _draw(_stream_starts(SEED["C_MSEG"], n, 1), 1, 5)
     nat, _ = _draw(_stream_starts(SEED["C_NTRG"], n, 1), 0, 24)
-    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(seg - 1, SEGMENTS), pa.array(nat.astype(np.int32))],
-                    names=["c_custkey", "c_mktsegment", "c_nationkey"])
+    names = pa.array(["Customer#%09d" % k for k in range(1, n + 1)])
+    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(seg - 1, SEGMENTS), pa.array(nat.astype(np.int32)), names],
+                    names=["c_custkey", "c_mktsegment", "c_nationkey", "c_name"])
 
 
 def supplier(sf: int = 1) -> pa.Table:
@@ -125,7 +127,7 @@ def part(sf: int = 1) -> pa.Table:
 
 
 def orders_and_lineitem(sf: int = 1):
-    """→ (orders[o_orderkey, o_custkey, o_orderdate, o_shippriority, o_orderpriority],
+    """→ (orders[o_orderkey, o_custkey, o_orderdate, o_shippriority, o_orderpriority, o_totalprice],
           lineitem[l_orderkey, l_quantity, l_extendedprice, l_discount, l_tax, l_returnflag, l_linestatus, l_shipdate, l_partkey, l_commitdate,
                    l_receiptdate, l_shipmode, l_shipinstruct, l_suppkey]) in dbgen's row order"""
     n = 1_500_000 * sf
@@ -142,9 +144,7 @@ def orders_and_lineitem(sf: int = 1):
     odate_off = odate - 92001                                              # days since 1992-01-01
     lines, _ = _draw(_stream_starts(SEED["O_LCNT"], n, 1), 1, 7)
     prio, _ = _draw(_stream_starts(SEED["O_PRIO"], n, 1), 1, 5)
-    orders = pa.table([pa.array(okey), pa.array(ckey), pa.array((odate_off + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()),
-                       pa.array(np.zeros(n, np.int32)), _utf8_from_choices(prio - 1, PRIORITIES)],
-                      names=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority"])
+    total = np.zeros(n, np.int64)                                         # o_totalprice, in cents: filled from the lines below
     st = {k: _stream_starts(SEED[k], n, 7) for k in ("L_QTY", "L_DCNT", "L_TAX", "L_PKEY", "L_SDTE", "L_CDTE", "L_RDTE", "L_RFLG", "L_SMODE", "L_SHIP", "L_SKEY")}
     cols = {k: [] for k in ("okey", "qty", "ep", "disc", "tax", "rflag", "lstat", "ship", "order", "lcnt", "pkey", "commit", "receipt", "smode", "instr", "skey")}
     for l in range(7):
@@ -171,9 +171,14 @@ def orders_and_lineitem(sf: int = 1):
         price = 90000 + (pkey // 10) % 20001 + (pkey % 1000) * 100       # rpb_routine, in cents
         nsupp = 10_000 * sf
         skey = (pkey + snum * (nsupp // 4 + (pkey - 1) // nsupp)) % nsupp + 1     # PART_SUPP_BRIDGE: one of the part's four suppliers
+        # mk_order: totalprice += ((eprice · (100 − discount)) / 100) · (100 + tax) / 100 — integer division, left to right
+        total += np.where(has, ((price * qty * (100 - disc)) // 100) * (100 + tax) // 100, 0)
         for k, v in (("okey", okey), ("qty", qty), ("ep", price * qty), ("disc", disc), ("tax", tax), ("rflag", rflag), ("lstat", lstat), ("ship", ship),
                      ("order", i), ("lcnt", np.full(n, l, np.int64)), ("pkey", pkey), ("commit", commit), ("receipt", receipt), ("smode", smode - 1), ("instr", instr - 1), ("skey", skey)):
             cols[k].append(v[has])
+    orders = pa.table([pa.array(okey), pa.array(ckey), pa.array((odate_off + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()),
+                       pa.array(np.zeros(n, np.int32)), _utf8_from_choices(prio - 1, PRIORITIES), _dec(total, 12, 2)],
+                      names=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority", "o_totalprice"])
     cat = {k: np.concatenate(v) for k, v in cols.items()}
     order = np.lexsort((cat["lcnt"], cat["order"]))                        # dbgen's row order: by order, then line number
     c = {k: v[order] for k, v in cat.items()}

@@ -1,5 +1,5 @@
-"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q12 / Q14 / Q19, as recorded in
-spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,12,14,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
+"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q12 / Q14 / Q18 / Q19, as recorded in
+spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,12,14,18,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py: dbgen itself is not in the reference's tree, its algorithm is
 restated and pinned by exactly these files); the oracle evaluates the same plans the GPU tests run (tests/test_tpch_golden_gpu.py)."""
 import datetime
@@ -70,7 +70,7 @@ def test_q3_oracle_gives_the_references_answer(sf1):
     assert q3_rows(parallel.q3_top10(final)) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
 
 
-def test_q4_q5_q7_q8_q12_q14_q19_oracle_give_the_references_answers(sf1):
+def test_q4_q5_q7_q8_q12_q14_q18_q19_oracle_give_the_references_answers(sf1):
     from tests import test_tpch_more_gpu as M
     _, orders, lineitem = sf1
     o2, li, pt = more_layout(orders, lineitem, dbgen.part(1))
@@ -111,3 +111,10 @@ def test_q4_q5_q7_q8_q12_q14_q19_oracle_give_the_references_answers(sf1):
     st = O.run_plan_to_arrow(S, partial, q8_in)
     final = O.run_plan_to_arrow(S, M.q8_final_plan(partial, st.schema), [st])
     assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q8.sql.out"))       # 1995 0.034436 / 1996 0.041486
+    lq = lineitem.select(["l_orderkey", "l_quantity"])
+    q18_in = [lq, orders.select(["o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"]), customer.select(["c_custkey", "c_name"]), lq]
+    partial = M.q18_partial_plan()
+    st = O.run_plan_to_arrow(S, partial, q18_in)
+    final = O.run_plan_to_arrow(S, M.q18_final_plan(partial, st.schema), [st])
+    import re      # (the reference's suite writes every "#<digits>" as "#x" into its result files: CometTPCHQuerySuite's normalisation)
+    assert [[re.sub(r"#\d+", "#x", str(v)) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q18.sql.out"))      # the 57 orders of more than 300 items

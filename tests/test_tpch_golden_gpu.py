@@ -1,5 +1,5 @@
-"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q12 / Q14 / Q19 — the numbers in
-spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,12,14,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
+"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q12 / Q14 / Q18 / Q19 — the numbers in
+spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,12,14,18,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py; tests/test_tpch_golden_cpu.py pins the generator and the oracle on
 the same files).  Q6 goes in through Parquet (snappy and zstd, pages inflated on the device, and the host path), Q1 and Q3 over
 HBM-resident columns; every stage runs through the C ABI, the Final aggregates included."""
@@ -63,7 +63,7 @@ def test_q3_gives_the_references_answer(built, sf1):
     assert q3_rows(top) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
 
 
-def test_q4_q5_q7_q8_q12_q14_q19_give_the_references_answers(built, sf1):
+def test_q4_q5_q7_q8_q12_q14_q18_q19_give_the_references_answers(built, sf1):
     from tests import test_tpch_more_gpu as M
     _, orders, lineitem = sf1
     o2, li, pt = more_layout(orders, lineitem, dbgen.part(1))
@@ -104,3 +104,10 @@ def test_q4_q5_q7_q8_q12_q14_q19_give_the_references_answers(built, sf1):
     st = M.run(partial, q8_in, 5)
     final = M.run(M.q8_final_plan(partial, st.schema), [st], 2)
     assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q8.sql.out"))       # 1995 0.034436 / 1996 0.041486
+    lq = lineitem.select(["l_orderkey", "l_quantity"])
+    q18_in = [lq, orders.select(["o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"]), customer.select(["c_custkey", "c_name"]), lq]
+    partial = M.q18_partial_plan()
+    st = M.run(partial, q18_in, 7)
+    final = M.run(M.q18_final_plan(partial, st.schema), [st], 6)
+    import re      # (the reference's suite writes every "#<digits>" as "#x" into its result files: CometTPCHQuerySuite's normalisation)
+    assert [[re.sub(r"#\d+", "#x", str(v)) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q18.sql.out"))      # the 57 orders of more than 300 items

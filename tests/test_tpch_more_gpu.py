@@ -210,6 +210,24 @@ def q8_final_plan(partial, state_schema):
     return S.sort(S.project(fin, [c(0, I32), share]), [(c(0, I32), False, False)])
 
 
+def q18_partial_plan(threshold="300.00"):
+    """TPC-H Q18 up to the partial aggregate: orders whose lines add up to more than `threshold` items (a Final over a Partial aggregate of all
+    of lineitem, filtered, inside the plan), joined to orders, customer and their lines.  Scan leaves in order: lineitem[l_orderkey, l_quantity],
+    orders[o_orderkey, o_custkey, o_orderdate, o_totalprice], customer[c_custkey, c_name], lineitem[l_orderkey, l_quantity]"""
+    D22 = S.decimal(22, 2)
+    per_order = S.hash_agg(S.scan([I64, D]), [c(0, I64)], [S.sum_(c(1, D), D22)], S.PARTIAL)
+    totals = S.hash_agg(per_order, [c(0, I64)], per_order.aggs, S.FINAL)                                     # l_orderkey, sum(l_quantity)
+    big = S.project(S.filter_(totals, S.gt(c(1, D22), S.lit(decimal.Decimal(threshold), D22))), [c(0, I64)])
+    jo = S.project(S.hash_join(big, S.scan([I64, I64, DATE, D]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT), [c(1, I64), c(2, I64), c(3, DATE), c(4, D)])     # o_orderkey, o_custkey, o_orderdate, o_totalprice
+    jc = S.project(S.hash_join(jo, S.scan([I64, STR]), [c(1, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT), [c(5, STR), c(4, I64), c(0, I64), c(2, DATE), c(3, D)])    # c_name, c_custkey, o_orderkey, o_orderdate, o_totalprice
+    jl = S.hash_join(jc, S.scan([I64, D]), [c(2, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT)                  # … l_orderkey, l_quantity
+    return S.hash_agg(jl, [c(0, STR), c(1, I64), c(2, I64), c(3, DATE), c(4, D)], [S.sum_(c(6, D), D22)], S.PARTIAL)
+
+
+def q18_final_plan(partial, state_schema):
+    return S.sort(S.final_of(partial, state_schema), [(c(4, D), True, True), (c(3, DATE), False, False)], fetch=100)
+
+
 def q19_partial_plan(modes=("AIR", "REG AIR")):
     """TPC-H Q19 up to the partial aggregate; inputs: lineitem (the LI layout), part[p_partkey, p_type, p_brand, p_container, p_size].  (The
     benchmark's text asks for the modes 'AIR' and 'AIR REG'; no row carries the latter.)"""
