@@ -20,7 +20,7 @@ A = 16807
 SEED = {"O_ODATE": 1066728069, "L_QTY": 209208115, "L_DCNT": 554590007, "L_TAX": 721958466, "L_PKEY": 1808217256, "L_SDTE": 1769349045,
         "L_CDTE": 904914315, "L_RDTE": 373135028, "L_RFLG": 717419739, "C_MSEG": 1140279430, "O_CKEY": 851767375, "O_LCNT": 1434868289,
         "L_SMODE": 675466456, "O_PRIO": 591449447, "P_TYPE": 1841581359, "L_SHIP": 1371272478, "P_MFG": 1, "P_BRND": 46831694, "P_SIZE": 1193163244,
-        "P_CNTR": 727633698, "C_NTRG": 1489529863, "S_NTRG": 110356601, "L_SKEY": 2095021727}
+        "P_CNTR": 727633698, "C_NTRG": 1489529863, "S_NTRG": 110356601, "L_SKEY": 2095021727, "C_PHNE": 1521138112, "C_ABAL": 298370230}
 STARTDATE_DAY = 8035          # 1992-01-01 as days since 1970-01-01 (dbgen's STARTDATE 92001)
 CURRENTDATE_OFFSET = 1263     # 1995-06-17 (CURRENTDATE 95168) as days since 1992-01-01
 SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]      # dists.dss msegmnt, equal weights
@@ -96,21 +96,29 @@ def region() -> pa.Table:
 
 
 def customer(sf: int = 1) -> pa.Table:
-    """c_custkey, c_mktsegment, c_nationkey, c_name (mk_cust: one draw of C_MSEG — pick_str over five equal weights — and of C_NTRG per customer;
+    """c_custkey, c_mktsegment, c_nationkey, c_name, c_phone, c_acctbal (mk_cust: one draw of C_MSEG — pick_str over five equal weights — and of C_NTRG per customer;
     the name is "Customer#" and the key in nine digits)"""
     n = 150_000 * sf
     seg, _ = _draw(_stream_starts(SEED["C_MSEG"], n, 1), 1, 5)
     nat, _ = _draw(_stream_starts(SEED["C_NTRG"], n, 1), 0, 24)
     names = pa.array(["Customer#%09d" % k for k in range(1, n + 1)])
-    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(seg - 1, SEGMENTS), pa.array(nat.astype(np.int32)), names],
-                    names=["c_custkey", "c_mktsegment", "c_nationkey", "c_name"])
+    # gen_phone: country code 10 + nation, then three draws of C_PHNE (area code, exchange, number); the balance: one draw of C_ABAL, in cents
+    ph = _stream_starts(SEED["C_PHNE"], n, 3)
+    area, ph = _draw(ph, 100, 999)
+    exch, ph = _draw(ph, 100, 999)
+    num, ph = _draw(ph, 1000, 9999)
+    phones = pa.array(["%02d-%03d-%03d-%04d" % t for t in zip((10 + nat).tolist(), area.tolist(), exch.tolist(), num.tolist())])
+    bal, _ = _draw(_stream_starts(SEED["C_ABAL"], n, 1), -99999, 999999)
+    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(seg - 1, SEGMENTS), pa.array(nat.astype(np.int32)), names, phones, _dec(bal, 12, 2)],
+                    names=["c_custkey", "c_mktsegment", "c_nationkey", "c_name", "c_phone", "c_acctbal"])
 
 
 def supplier(sf: int = 1) -> pa.Table:
     """s_suppkey, s_nationkey (mk_supp: one draw of S_NTRG per supplier)"""
     n = 10_000 * sf
     nat, _ = _draw(_stream_starts(SEED["S_NTRG"], n, 1), 0, 24)
-    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), pa.array(nat.astype(np.int32))], names=["s_suppkey", "s_nationkey"])
+    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), pa.array(nat.astype(np.int32)), pa.array(["Supplier#%09d" % k for k in range(1, n + 1)])],
+                    names=["s_suppkey", "s_nationkey", "s_name"])
 
 
 def part(sf: int = 1) -> pa.Table:
@@ -127,7 +135,7 @@ def part(sf: int = 1) -> pa.Table:
 
 
 def orders_and_lineitem(sf: int = 1):
-    """→ (orders[o_orderkey, o_custkey, o_orderdate, o_shippriority, o_orderpriority, o_totalprice],
+    """→ (orders[o_orderkey, o_custkey, o_orderdate, o_shippriority, o_orderpriority, o_totalprice, o_orderstatus],
           lineitem[l_orderkey, l_quantity, l_extendedprice, l_discount, l_tax, l_returnflag, l_linestatus, l_shipdate, l_partkey, l_commitdate,
                    l_receiptdate, l_shipmode, l_shipinstruct, l_suppkey]) in dbgen's row order"""
     n = 1_500_000 * sf
@@ -145,6 +153,7 @@ def orders_and_lineitem(sf: int = 1):
     lines, _ = _draw(_stream_starts(SEED["O_LCNT"], n, 1), 1, 7)
     prio, _ = _draw(_stream_starts(SEED["O_PRIO"], n, 1), 1, 5)
     total = np.zeros(n, np.int64)                                         # o_totalprice, in cents: filled from the lines below
+    shipped = np.zeros(n, np.int64)                                       # lines with status 'F': the order's status is 'F' if all, 'O' if none, else 'P'
     st = {k: _stream_starts(SEED[k], n, 7) for k in ("L_QTY", "L_DCNT", "L_TAX", "L_PKEY", "L_SDTE", "L_CDTE", "L_RDTE", "L_RFLG", "L_SMODE", "L_SHIP", "L_SKEY")}
     cols = {k: [] for k in ("okey", "qty", "ep", "disc", "tax", "rflag", "lstat", "ship", "order", "lcnt", "pkey", "commit", "receipt", "smode", "instr", "skey")}
     for l in range(7):
@@ -173,12 +182,14 @@ def orders_and_lineitem(sf: int = 1):
         skey = (pkey + snum * (nsupp // 4 + (pkey - 1) // nsupp)) % nsupp + 1     # PART_SUPP_BRIDGE: one of the part's four suppliers
         # mk_order: totalprice += ((eprice · (100 − discount)) / 100) · (100 + tax) / 100 — integer division, left to right
         total += np.where(has, ((price * qty * (100 - disc)) // 100) * (100 + tax) // 100, 0)
+        shipped += np.where(has & (lstat == 0), 1, 0)
         for k, v in (("okey", okey), ("qty", qty), ("ep", price * qty), ("disc", disc), ("tax", tax), ("rflag", rflag), ("lstat", lstat), ("ship", ship),
                      ("order", i), ("lcnt", np.full(n, l, np.int64)), ("pkey", pkey), ("commit", commit), ("receipt", receipt), ("smode", smode - 1), ("instr", instr - 1), ("skey", skey)):
             cols[k].append(v[has])
     orders = pa.table([pa.array(okey), pa.array(ckey), pa.array((odate_off + STARTDATE_DAY).astype(np.int32), pa.int32()).cast(pa.date32()),
-                       pa.array(np.zeros(n, np.int32)), _utf8_from_choices(prio - 1, PRIORITIES), _dec(total, 12, 2)],
-                      names=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority", "o_totalprice"])
+                       pa.array(np.zeros(n, np.int32)), _utf8_from_choices(prio - 1, PRIORITIES), _dec(total, 12, 2),
+                       _utf8_from_choices(np.where(shipped == lines, 0, np.where(shipped == 0, 1, 2)), [b"F", b"O", b"P"])],
+                      names=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority", "o_totalprice", "o_orderstatus"])
     cat = {k: np.concatenate(v) for k, v in cols.items()}
     order = np.lexsort((cat["lcnt"], cat["order"]))                        # dbgen's row order: by order, then line number
     c = {k: v[order] for k, v in cat.items()}

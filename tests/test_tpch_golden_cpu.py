@@ -1,5 +1,5 @@
-"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q12 / Q14 / Q18 / Q19, as recorded in
-spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,12,14,18,19}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
+"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q12 / Q14 / Q18 / Q19 / Q21 / Q22, as recorded in
+spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,12,14,18,19,21,22}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py: dbgen itself is not in the reference's tree, its algorithm is
 restated and pinned by exactly these files); the oracle evaluates the same plans the GPU tests run (tests/test_tpch_golden_gpu.py)."""
 import datetime
@@ -70,51 +70,57 @@ def test_q3_oracle_gives_the_references_answer(sf1):
     assert q3_rows(parallel.q3_top10(final)) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
 
 
-def test_q4_q5_q7_q8_q12_q14_q18_q19_oracle_give_the_references_answers(sf1):
-    from tests import test_tpch_more_gpu as M
-    _, orders, lineitem = sf1
+def _more_inputs(sf1):
+    customer, orders, lineitem = sf1
     o2, li, pt = more_layout(orders, lineitem, dbgen.part(1))
-    partial = M.q12_partial_plan()
-    st = O.run_plan_to_arrow(S, partial, [o2, li])
-    final = O.run_plan_to_arrow(S, M.q12_final_plan(partial, st.schema), [st])
-    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q12.sql.out"))      # MAIL 6202 9324 / SHIP 6200 9262
-    partial = M.q14_partial_plan(tpch.days(1995, 9, 1), tpch.days(1995, 10, 1))
-    st = O.run_plan_to_arrow(S, partial, [li, pt])
-    final = O.run_plan_to_arrow(S, M.q14_final_plan(partial, st.schema), [st])
-    assert [[str(final.column(0)[0].as_py())]] == dbgen.parse_golden(os.path.join(GOLD, "q14.sql.out"))                # 16.380779
-    partial = M.q19_partial_plan(("AIR", "AIR REG"))
-    st = O.run_plan_to_arrow(S, partial, [li, pt])
-    final = O.run_plan_to_arrow(S, S.final_of(partial, st.schema), [st])
-    assert [[str(final.column(0)[0].as_py())]] == dbgen.parse_golden(os.path.join(GOLD, "q19.sql.out"))                # 3083843.0578
-    partial = M.q4_partial_plan(tpch.days(1993, 7, 1), tpch.days(1993, 10, 1))
-    o4, l4 = orders.select(["o_orderkey", "o_orderdate", "o_orderpriority"]), lineitem.select(["l_orderkey", "l_commitdate", "l_receiptdate"])
-    st = O.run_plan_to_arrow(S, partial, [o4, l4])
-    final = O.run_plan_to_arrow(S, M.q12_final_plan(partial, st.schema), [st])
-    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q4.sql.out"))       # five priorities, ≈ 10 500 orders each
-    customer = sf1[0]
-    q5_in = [dbgen.region(), dbgen.nation(), customer.select(["c_custkey", "c_nationkey"]), orders.select(["o_orderkey", "o_custkey", "o_orderdate"]),
-             lineitem.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]), dbgen.supplier(1)]
-    partial = M.q5_partial_plan(tpch.days(1994, 1, 1), tpch.days(1995, 1, 1))
-    st = O.run_plan_to_arrow(S, partial, q5_in)
-    final = O.run_plan_to_arrow(S, M.q5_final_plan(partial, st.schema), [st])
-    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q5.sql.out"))       # five Asian nations by revenue
-    cn, sp = customer.select(["c_custkey", "c_nationkey"]), dbgen.supplier(1)
-    q7_in = [dbgen.nation(), cn, orders.select(["o_orderkey", "o_custkey"]), dbgen.nation(), sp,
-             lineitem.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"])]
-    q8_in = [dbgen.region(), dbgen.nation(), cn, orders.select(["o_orderkey", "o_custkey", "o_orderdate"]), dbgen.nation(), sp, pt,
-             lineitem.select(["l_orderkey", "l_partkey", "l_suppkey", "l_extendedprice", "l_discount"])]
-    partial = M.q7_partial_plan(tpch.days(1995, 1, 1), tpch.days(1996, 12, 31))
-    st = O.run_plan_to_arrow(S, partial, q7_in)
-    final = O.run_plan_to_arrow(S, M.q7_final_plan(partial, st.schema), [st])
-    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q7.sql.out"))       # FRANCE ↔ GERMANY, 1995 and 1996
-    partial = M.q8_partial_plan(tpch.days(1995, 1, 1), tpch.days(1996, 12, 31))
-    st = O.run_plan_to_arrow(S, partial, q8_in)
-    final = O.run_plan_to_arrow(S, M.q8_final_plan(partial, st.schema), [st])
-    assert [[str(v) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q8.sql.out"))       # 1995 0.034436 / 1996 0.041486
+    sp_all = dbgen.supplier(1)
+    cn, sp = customer.select(["c_custkey", "c_nationkey"]), sp_all.select(["s_suppkey", "s_nationkey"])
+    late = lineitem.select(["l_orderkey", "l_suppkey", "l_commitdate", "l_receiptdate"])
     lq = lineitem.select(["l_orderkey", "l_quantity"])
-    q18_in = [lq, orders.select(["o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"]), customer.select(["c_custkey", "c_name"]), lq]
-    partial = M.q18_partial_plan()
-    st = O.run_plan_to_arrow(S, partial, q18_in)
-    final = O.run_plan_to_arrow(S, M.q18_final_plan(partial, st.schema), [st])
-    import re      # (the reference's suite writes every "#<digits>" as "#x" into its result files: CometTPCHQuerySuite's normalisation)
-    assert [[re.sub(r"#\d+", "#x", str(v)) for v in r] for r in M.rows(final)] == dbgen.parse_golden(os.path.join(GOLD, "q18.sql.out"))      # the 57 orders of more than 300 items
+    return {
+        "q4": [orders.select(["o_orderkey", "o_orderdate", "o_orderpriority"]), lineitem.select(["l_orderkey", "l_commitdate", "l_receiptdate"])],
+        "q5": [dbgen.region(), dbgen.nation(), cn, orders.select(["o_orderkey", "o_custkey", "o_orderdate"]),
+               lineitem.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]), sp],
+        "q7": [dbgen.nation(), cn, orders.select(["o_orderkey", "o_custkey"]), dbgen.nation(), sp,
+               lineitem.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"])],
+        "q8": [dbgen.region(), dbgen.nation(), cn, orders.select(["o_orderkey", "o_custkey", "o_orderdate"]), dbgen.nation(), sp, pt,
+               lineitem.select(["l_orderkey", "l_partkey", "l_suppkey", "l_extendedprice", "l_discount"])],
+        "q12": [o2, li], "q14": [li, pt], "q19": [li, pt],
+        "q18": [lq, orders.select(["o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"]), customer.select(["c_custkey", "c_name"]), lq],
+        "q21": [dbgen.nation(), sp_all, late, orders.select(["o_orderkey", "o_orderstatus"]), lineitem.select(["l_orderkey", "l_suppkey"]), late],
+        "q22": [customer.select(["c_custkey", "c_phone", "c_acctbal"]), orders.select(["o_custkey"])],
+    }
+
+
+def golden_case(q, inputs, run_partial, run_final):
+    """(rows the engine gives for TPC-H query `q`, rows of the reference's result file) — the plans of tests/test_tpch_more_gpu.py, run by
+    `run_partial(plan, tables)` / `run_final(plan, [states])` (the oracle here, the GPU in tests/test_tpch_golden_gpu.py)"""
+    import re
+    from tests import test_tpch_more_gpu as M
+    d = tpch.days
+    tb = inputs[q]
+    if q == "q22":
+        ap = M.q22_average_plan()
+        st = run_partial(ap, [tb[0]])
+        average = run_final(S.final_of(ap, st.schema), [st]).column(0)[0].as_py()
+        partial = M.q22_partial_plan(average)
+    else:
+        partial = {"q4": lambda: M.q4_partial_plan(d(1993, 7, 1), d(1993, 10, 1)), "q5": lambda: M.q5_partial_plan(d(1994, 1, 1), d(1995, 1, 1)),
+                   "q7": lambda: M.q7_partial_plan(d(1995, 1, 1), d(1996, 12, 31)), "q8": lambda: M.q8_partial_plan(d(1995, 1, 1), d(1996, 12, 31)),
+                   "q12": M.q12_partial_plan, "q14": lambda: M.q14_partial_plan(d(1995, 9, 1), d(1995, 10, 1)), "q18": M.q18_partial_plan,
+                   "q19": lambda: M.q19_partial_plan(("AIR", "AIR REG")), "q21": M.q21_partial_plan}[q]()
+    st = run_partial(partial, tb)
+    fplan = {"q4": M.q12_final_plan, "q5": M.q5_final_plan, "q7": M.q7_final_plan, "q8": M.q8_final_plan, "q12": M.q12_final_plan, "q14": M.q14_final_plan,
+             "q18": M.q18_final_plan, "q19": lambda p_, sc: S.final_of(p_, sc), "q21": M.q21_final_plan, "q22": M.q12_final_plan}[q](partial, st.schema)
+    final = run_final(fplan, [st])
+    # (the reference's suite writes every "#<digits>" as "#x" into its result files: CometTPCHQuerySuite's normalisation)
+    got = [[re.sub(r"#\d+", "#x", str(v)) for v in r] for r in M.rows(final)]
+    return got, dbgen.parse_golden(os.path.join(GOLD, q + ".sql.out"))
+
+
+# Q18 (a Python aggregation over 1.5 M groups) and Q21 take the oracle a minute each: the GPU suite checks them against the same files
+@pytest.mark.parametrize("q", ["q4", "q5", "q7", "q8", "q12", "q14", "q19", "q22"] + (["q18", "q21"] if os.environ.get("COMET_SLOW_TESTS") else []))
+def test_more_queries_oracle_gives_the_references_answers(sf1, q):
+    run = lambda plan, tables: O.run_plan_to_arrow(S, plan, tables)
+    got, want = golden_case(q, _more_inputs(sf1), run, run)
+    assert got == want

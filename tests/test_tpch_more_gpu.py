@@ -228,6 +228,49 @@ def q18_final_plan(partial, state_schema):
     return S.sort(S.final_of(partial, state_schema), [(c(4, D), True, True), (c(3, DATE), False, False)], fetch=100)
 
 
+def q21_partial_plan(nation_name="SAUDI ARABIA"):
+    """TPC-H Q21 up to the partial aggregate: suppliers of a nation who alone kept a multi-supplier order of status 'F' waiting — a LeftSemi and a
+    LeftAnti join on the order key, each with the residual condition "another supplier".  Scan leaves in order: nation, supplier[s_suppkey,
+    s_nationkey, s_name], lineitem l1[l_orderkey, l_suppkey, l_commitdate, l_receiptdate], orders[o_orderkey, o_orderstatus],
+    lineitem l2[l_orderkey, l_suppkey], lineitem l3[l_orderkey, l_suppkey, l_commitdate, l_receiptdate]"""
+    nat = S.project(S.filter_(S.scan([I32, STR, I32]), S.eq(c(1, STR), L(nation_name))), [c(0, I32)])
+    sup = S.project(S.hash_join(nat, S.scan([I64, I32, STR]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(1, I64), c(3, STR)])                       # s_suppkey, s_name
+    late = lambda: S.project(S.filter_(S.scan([I64, I64, DATE, DATE]), S.gt(c(3, DATE), c(2, DATE))), [c(0, I64), c(1, I64)])                                # l_orderkey, l_suppkey of late lines
+    j1 = S.project(S.hash_join(sup, late(), [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT), [c(1, STR), c(2, I64), c(3, I64)])                             # s_name, l_orderkey, l_suppkey
+    of = S.project(S.filter_(S.scan([I64, STR]), S.eq(c(1, STR), L("F"))), [c(0, I64)])
+    j2 = S.project(S.hash_join(j1, of, [c(1, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT), [c(0, STR), c(1, I64), c(2, I64)])                                  # s_name, l_orderkey, l_suppkey
+    other = S.neq(c(4, I64), c(2, I64))                                                                       # (left ++ right: s_name, l_orderkey, l_suppkey | l_orderkey, l_suppkey)
+    semi = S.hash_join(j2, S.scan([I64, I64]), [c(1, I64)], [c(0, I64)], S.LEFT_SEMI, S.BUILD_RIGHT, condition=other)
+    anti = S.hash_join(semi, late(), [c(1, I64)], [c(0, I64)], S.LEFT_ANTI, S.BUILD_RIGHT, condition=other)
+    return S.hash_agg(S.project(anti, [c(0, STR)]), [c(0, STR)], [S.count(S.lit(1, I32))], S.PARTIAL)
+
+
+def q21_final_plan(partial, state_schema):
+    return S.sort(S.final_of(partial, state_schema), [(c(1, I64), True, True), (c(0, STR), False, False)], fetch=100)
+
+
+Q22_CODES = ["13", "31", "23", "29", "30", "18", "17"]
+
+
+def _q22_code():
+    return S.scalar_func("substring", [c(1, STR), S.lit(1, I32), S.lit(2, I32)], STR)
+
+
+def q22_average_plan():
+    """the scalar subquery of TPC-H Q22: the average positive balance of the customers of seven country codes; input: customer[c_custkey, c_phone, c_acctbal]"""
+    f = S.filter_(S.scan([I64, STR, D]), S.and_(S.gt(c(2, D), S.lit(decimal.Decimal("0.00"), D)), S.in_(_q22_code(), [L(x) for x in Q22_CODES])))
+    return S.hash_agg(f, [], [S.avg(c(2, D), S.decimal(16, 6), S.decimal(22, 2))], S.PARTIAL)
+
+
+def q22_partial_plan(average):
+    """TPC-H Q22 up to the partial aggregate: customers of those codes with a balance above `average` (a decimal(16,6) literal, what Spark
+    puts in place of the subquery) and no orders (LeftAnti); inputs: customer[c_custkey, c_phone, c_acctbal], orders[o_custkey]"""
+    A = S.decimal(16, 6)
+    f = S.filter_(S.scan([I64, STR, D]), S.and_(S.in_(_q22_code(), [L(x) for x in Q22_CODES]), S.gt(S.cast(c(2, D), A), S.lit(average, A))))
+    anti = S.hash_join(f, S.scan([I64]), [c(0, I64)], [c(0, I64)], S.LEFT_ANTI, S.BUILD_RIGHT)
+    return S.hash_agg(S.project(anti, [_q22_code(), c(2, D)]), [c(0, STR)], [S.count(S.lit(1, I32)), S.sum_(c(1, D), S.decimal(22, 2))], S.PARTIAL)
+
+
 def q19_partial_plan(modes=("AIR", "REG AIR")):
     """TPC-H Q19 up to the partial aggregate; inputs: lineitem (the LI layout), part[p_partkey, p_type, p_brand, p_container, p_size].  (The
     benchmark's text asks for the modes 'AIR' and 'AIR REG'; no row carries the latter.)"""
