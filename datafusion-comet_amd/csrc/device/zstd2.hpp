@@ -283,10 +283,23 @@ struct BackBitsT {
       }
     }
   }
-  // the 64 bits below the cursor, the next bit on top; fields are then taken off its top.  Needs bitpos ≥ 64.
+  // The 64 bits below the cursor, the next bit on top; fields are then taken off its top.  No branch, and no condition on where the
+  // cursor is: the registers step down with it below the stream's first byte too (there the source yields bytes nobody may consume — a
+  // stream that does is caught by its final bit count).
   ZS_FN u64 window() const {
-    const i32 sft = bitpos - 8 * (wb - 16) - 64;            // 0 < sft ≤ 64
-    return sft >= 64 ? hi : (hi << (64 - sft)) | (lo >> sft);
+    const u32 sft = (u32)(bitpos - 8 * (wb - 16) - 64);     // 0 < sft ≤ 64 (the register invariant)
+    return (hi << ((64u - sft) & 63u)) | ((lo >> (sft - 1u)) >> 1);
+  }
+  // consume without a branch (n ≤ 64: one register step at most): the candidate for nx is loaded whether or not the registers move —
+  // lanes of one wave decode different streams, and a branch that some take costs all of them both paths
+  ZS_FN void consume_sel(u32 n) {
+    bitpos -= (i32)n;
+    const bool step = bitpos - 8 * (wb - 16) <= 64;
+    const u64 cand = src.load8(wb - 32);
+    hi = step ? lo : hi;
+    lo = step ? nx : lo;
+    nx = step ? cand : nx;
+    wb -= step ? 8 : 0;
   }
   ZS_FN static u32 take(u64& w, u32 n) {     // n ≤ 32 (n = 0 → 0): the top word shifted up by n, what crosses into the next word
     const u32 v = (u32)(((u64)(u32)(w >> 32) << n) >> 32);
@@ -376,7 +389,7 @@ template <class BB, class TabPtr, class OutPtr>
 ZS_FN void huf_decode_symbols(BB& b, TabPtr tab, int log, OutPtr out, u32 count) {
   u32 i = 0;
   // five codes (≤ 11 bits each) off one 64-bit window, one consume for the five
-  for (; i + 5 <= count && b.bitpos >= 64; i += 5) {
+  for (; i + 5 <= count; i += 5) {
     u64 w = b.window();
     u32 used = 0;
     for (int k = 0; k < 5; k++) {
@@ -386,7 +399,7 @@ ZS_FN void huf_decode_symbols(BB& b, TabPtr tab, int log, OutPtr out, u32 count)
       used += n;
       out[i + k] = (u8)e;
     }
-    b.consume((int)used);
+    b.consume_sel(used);
   }
   for (; i < count; i++) {
     const u32 e = tab[b.peek(log)];
@@ -438,13 +451,14 @@ ZS_FN int seq_table(int kind, int mode, P desc, u32 avail, TabPtr tab, NormPtr n
 // A sequence table as the decoder walks it: two words per state — [0] the value's base (literal length / match length / offset value
 // 1 << code), [1] bits of the next state | extra bits of the value << 8 | base of the next state << 16.  Expanded in place from
 // fse_build's one word per state (tab holds 2 << log words; from the top down, so no entry is overwritten before it is read).
-template <class TabPtr>
-ZS_FN void seq_table_expand(int kind, int log, TabPtr tab) {
+// (llc / mlc: ll_code_entry / ml_code_entry of every code, in fast memory — the constant arrays behind those functions sit in global memory)
+template <class TabPtr, class CodePtr>
+ZS_FN void seq_table_expand(int kind, int log, TabPtr tab, CodePtr llc, CodePtr mlc) {
   for (i32 i = (i32)(1u << log) - 1; i >= 0; i--) {
     const u32 e = tab[i], sym = e & 0xffu;
     u32 base, extra;
     if (kind == 1) { base = 1u << sym; extra = sym; }
-    else { const u32 ce = kind == 0 ? ll_code_entry(sym) : ml_code_entry(sym); base = ce & 0xffffffu; extra = ce >> 24; }
+    else { const u32 ce = kind == 0 ? llc[sym] : mlc[sym]; base = ce & 0xffffffu; extra = ce >> 24; }
     tab[2 * i] = base;
     tab[2 * i + 1] = ((e >> 8) & 0xffu) | (extra << 8) | ((e >> 16) << 16);
   }
@@ -469,69 +483,40 @@ ZS_FN void seq_begin(BB& b, SeqCore& c, int lll, int lof, int lml) {
   c.done = 0;
 }
 // the next sequence (`last`: no state update behind it); → ST_OK or an error code.  Tables: seq_table_expand's two words per state.
+// Straight-line code: the three values' extra bits (≤ 31 + 16 + 16) come off one 64-bit window, the three states' bits (≤ 9 + 9 + 8) off a
+// second, the repeat-offset rules are selects.  (Several lanes of a wave decode different blocks: every branch one lane takes is paid by all.)
 template <class BB, class TabPtr>
 ZS_FN u32 seq_step(BB& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, bool last, u32& ll, u32& ml, i32& off) {
   const u32 lb = tll[2 * c.sll], lh = tll[2 * c.sll + 1];
   const u32 ob = tof[2 * c.sof], oh = tof[2 * c.sof + 1];
   const u32 mb = tml[2 * c.sml], mh = tml[2 * c.sml + 1];
-  // The fields come off 64-bit WINDOWS of the stream, not through six general reads (the decoder is one lane's chain: its cost is its
-  // instruction count): all six — the three values' extra bits and the three states' bits — off one window when they fit (the usual
-  // case: ~35 bits), else the values (≤ 31 + 16 + 16) off one and the states (≤ 9 + 9 + 8) off a second.
   const u32 oe = (oh >> 8) & 0xffu, me = (mh >> 8) & 0xffu, le = (lh >> 8) & 0xffu;
   const u32 ln = lh & 0xffu, mn = mh & 0xffu, on = oh & 0xffu;
-  const u32 vbits = oe + me + le, sbits = last ? 0u : ln + mn + on;
-  u32 ov;
-  bool states_done = last;
-  if (b.bitpos >= 64) {
-    u64 w = b.window();
-    ov = ob + BB::take(w, oe);
-    ml = mb + BB::take(w, me);
-    ll = lb + BB::take(w, le);
-    if (!last && vbits + sbits <= 64u) {
-      c.sll = (lh >> 16) + BB::take(w, ln);
-      c.sml = (mh >> 16) + BB::take(w, mn);
-      c.sof = (oh >> 16) + BB::take(w, on);
-      b.consume((int)(vbits + sbits));
-      states_done = true;
-    } else {
-      b.consume((int)vbits);
-    }
-  } else {
-    ov = ob + b.read((int)oe);
-    ml = mb + b.read((int)me);
-    ll = lb + b.read((int)le);
-  }
-  if (ov > 3u) {
-    off = (i32)(ov - 3u);
-    if (off <= 0) return ST_ERR_OFFSET;
-    c.r2 = c.r1; c.r1 = c.r0; c.r0 = off;
-  } else {
-    const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
-    if (idx == 0) off = c.r0;
-    else {
-      off = idx == 1 ? c.r1 : idx == 2 ? c.r2 : rep_minus_one(c.r0);
-      if (idx > 1) c.r2 = c.r1;
-      c.r1 = c.r0;
-      c.r0 = off;
-    }
-  }
+  u64 w = b.window();
+  const u32 ov = ob + BB::take(w, oe);
+  ml = mb + BB::take(w, me);
+  ll = lb + BB::take(w, le);
+  b.consume_sel(oe + me + le);
+  w = b.window();
+  c.sll = (lh >> 16) + BB::take(w, ln);                    // (behind the last sequence: never looked at, and nothing is consumed for them)
+  c.sml = (mh >> 16) + BB::take(w, mn);
+  c.sof = (oh >> 16) + BB::take(w, on);
+  b.consume_sel(last ? 0u : ln + mn + on);
+  // offset value > 3: a new offset, pushed onto the history; 1 … 3: an entry of the history (shifted by one when there are no literals,
+  // the fourth choice then being "the newest entry minus one"), moved to the front
+  const bool rep = ov <= 3u;
+  const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
+  const i32 picked = idx == 0 ? c.r0 : idx == 1 ? c.r1 : idx == 2 ? c.r2 : rep_minus_one(c.r0);
+  off = rep ? picked : (i32)(ov - 3u);
+  const bool keep = rep && idx == 0;
+  const i32 n2 = (!rep || idx > 1) ? c.r1 : c.r2;
+  c.r2 = keep ? c.r2 : n2;
+  c.r1 = keep ? c.r1 : c.r0;
+  c.r0 = keep ? c.r0 : off;
   c.sum_ll += ll;
   c.sum_ml += ml;
   c.done++;
-  if (!states_done) {
-    if (b.bitpos >= 64) {
-      u64 w = b.window();
-      c.sll = (lh >> 16) + BB::take(w, ln);
-      c.sml = (mh >> 16) + BB::take(w, mn);
-      c.sof = (oh >> 16) + BB::take(w, on);
-      b.consume((int)sbits);
-    } else {
-      c.sll = (lh >> 16) + b.read((int)ln);
-      c.sml = (mh >> 16) + b.read((int)mn);
-      c.sof = (oh >> 16) + b.read((int)on);
-    }
-  }
-  return ST_OK;
+  return (!rep && off <= 0) ? (u32)ST_ERR_OFFSET : (u32)ST_OK;
 }
 // ---- kernel A1: the literals of one block — one 64-thread workgroup.  Threads 0 … 3 decode a Huffman stream each, 256 symbols a round,
 // out of their stream's window in workgroup memory into a buffer there; between rounds ALL threads slide the windows and write the
@@ -654,12 +639,17 @@ ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Hu
 // group of 16 — decode four blocks at once, 32 sequences a round, out of their bitstream's window in workgroup memory into a buffer
 // there; between rounds every group slides its window and writes its buffer out as records.  Four, because the expanded tables of a block
 // take 10 KiB of workgroup memory: 52 KiB per workgroup, three workgroups per CU. ----
-constexpr int kSeqLanes = 4;
+#ifndef ZS_SEQ_LANES
+#define ZS_SEQ_LANES 4
+#endif
+constexpr int kSeqLanes = ZS_SEQ_LANES;
+constexpr int kSeqGroup = 64 / kSeqLanes;         // threads per block's group
 constexpr u32 kSeqRound = 32;
 struct SeqLds {
   u32 fse_ll[kSeqLanes][1024], fse_of[kSeqLanes][512], fse_ml[kSeqLanes][1024];     // two words per state (seq_table_expand); offsets: log ≤ 8
   u32 ring[kSeqLanes][kRing / 4];
   u32 rbuf[kSeqLanes][kSeqRound][3];    // ll, ml, off
+  u32 llc[36], mlc[53];                 // the literal-length / match-length codes' (base | extra bits << 24)
   u8 hdr[kSeqLanes][3][128];            // the table descriptions, staged (a description is at most 53 counts of ≤ 10 bits)
   i16 norm[kSeqLanes][64];
   u16 next[kSeqLanes][64];
@@ -677,8 +667,11 @@ ZS_FN u32 seq_rounds(const ZBlock& b) { return seq_block_has_stream(b) ? (b.nseq
 // phase 1 (the group): stage the table descriptions (this block's, or — repeat mode — an earlier block's)
 ZS_FN void seq_stage(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, u32 src_len, int tt) {
   if (tt == 0) { L->status[k] = 0; L->rcount[k] = 0; L->rounds[k] = seq_rounds(b); }
+  const u32 t = (u32)k * (u32)kSeqGroup + (u32)tt;                       // (the workgroup's 64 threads fill the code tables once)
+  if (t < 36u) L->llc[t] = ll_code_entry(t);
+  if (t < 53u) L->mlc[t] = ml_code_entry(t);
   if (!seq_block_has_stream(b)) return;
-  for (u32 i = (u32)tt; i < 3u * 128u; i += 16) {
+  for (u32 i = (u32)tt; i < 3u * 128u; i += (u32)kSeqGroup) {
     const u32 kind = i >> 7, j = i & 127u;
     const u32 q = b.tab_desc[kind] + j;
     L->hdr[k][kind][j] = (b.tab_mode[kind] != TM_PREDEF && q < src_len) ? src[q] : (u8)0;
@@ -693,14 +686,14 @@ ZS_FN void seq_tables(ZS_LDS SeqLds* L, int k, const ZBlock& b) {
     const int log = seq_table(kind, b.tab_mode[kind], (ZS_LDS u8*)L->hdr[k][kind], 128u, seq_tab(L, k, kind), L->norm[k], L->next[k]);
     L->fse_log[k][kind] = log;
     if (log < 0) L->status[k] = ST_ERR_FSE;
-    else seq_table_expand(kind, log, seq_tab(L, k, kind));
+    else seq_table_expand(kind, log, seq_tab(L, k, kind), (ZS_LDS u32*)L->llc, (ZS_LDS u32*)L->mlc);
   }
 }
 // (the group) slide the bitstream's window down
 ZS_FN void seq_fill(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, i32 page_len, int tt) {
   if (!seq_block_has_stream(b)) return;
   const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
-  if (want < L->low[k]) ring_fill((ZS_LDS u32*)L->ring[k], L->bias[k], src + b.bits_pos, want, L->low[k], -(i32)b.bits_pos, page_len + 16 - (i32)b.bits_pos, tt, 16);
+  if (want < L->low[k]) ring_fill((ZS_LDS u32*)L->ring[k], L->bias[k], src + b.bits_pos, want, L->low[k], -(i32)b.bits_pos, page_len + 16 - (i32)b.bits_pos, tt, kSeqGroup);
 }
 ZS_FN void seq_fill_done(ZS_LDS SeqLds* L, int k) {          // (the group's thread, behind the barrier that follows seq_fill)
   const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
@@ -733,7 +726,7 @@ ZS_FN void seq_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
 }
 // (the group) the round's sequences to the block's records
 ZS_FN void seq_flush(const ZS_LDS SeqLds* L, int k, ZRec* recs_block, u32 base, int tt) {
-  for (u32 i = (u32)tt; i < L->rcount[k]; i += 16) {
+  for (u32 i = (u32)tt; i < L->rcount[k]; i += (u32)kSeqGroup) {
     ZRec* r = recs_block + base + i;
     r->ll = L->rbuf[k][i][0];
     r->ml = L->rbuf[k][i][1];
@@ -1089,7 +1082,9 @@ inline size_t host_prefix(const u8* p, u32 len, const PageWalk& w, u8* out, size
   std::vector<ZRec> recs;
   std::vector<u16> huf((size_t)1 << kHufLogMax);
   std::vector<u32> fse(3 * 1024);
-  u32 wfse[64];
+  u32 wfse[64], llc[36], mlc[53];
+  for (u32 c = 0; c < 36; c++) llc[c] = ll_code_entry(c);
+  for (u32 c = 0; c < 53; c++) mlc[c] = ml_code_entry(c);
   u8 weights[256];
   i16 norm[64];
   u16 next[64];
@@ -1140,7 +1135,7 @@ inline size_t host_prefix(const u8* p, u32 len, const PageWalk& w, u8* out, size
       const u32 d = b.tab_desc[k];
       logs[k] = seq_table(k, b.tab_mode[k], p + d, d < len ? len - d : 0, fse.data() + 1024 * k, norm, next);
       if (logs[k] < 0) return produced;
-      seq_table_expand(k, logs[k], fse.data() + 1024 * k);
+      seq_table_expand(k, logs[k], fse.data() + 1024 * k, llc, mlc);
     }
     recs.resize((size_t)b.nseq + 1);
     u32 ndone = 0;

@@ -716,7 +716,7 @@ size_t staged_capacity(const pq::ColumnMeta& cm) {
 // offsets into the device-decompressed region carry this bit until the column's tables are assembled
 constexpr int64_t kInflatedBit = (int64_t)1 << 62;
 constexpr int32_t kMinDevicePage = 4096;
-constexpr double kDeviceZstdBytesPerMs = 19.7e6;    // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 25.5 ms (profiles/r3_zstd_pipeline.json)
+constexpr double kDeviceZstdBytesPerMs = 24.8e6;    // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 20.3 ms (profiles/r3_zstd_pipeline.json)
 
 // DELTA_BYTE_ARRAY pages are prefix-compressed: what they decode to is only known from their length blocks.  One extra pass over such a
 // chunk (read, decompress, decode the two length blocks of every page) sizes its staging slot; nothing else pays for it.

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void zs2_sequences_kernel(const ZPage* __restri
                                                            const u8* __restrict__ bytes, ZRec* recs_all, u32* status) {
   __shared__ SeqLds s;
   ZS_LDS SeqLds* L = (ZS_LDS SeqLds*)&s;
-  const int t = (int)threadIdx.x, k = t >> 4, tt = t & 15;
+  const int t = (int)threadIdx.x, k = t / kSeqGroup, tt = t % kSeqGroup;
   const i64 bi = (i64)blockIdx.x * kSeqLanes + k;          // this group's block
   const bool have = bi < nblocks;
   ZBlock blk;

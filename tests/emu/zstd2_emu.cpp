@@ -89,9 +89,9 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
     auto page = [&](int k) -> const ZPage& { return b0 + (size_t)k < blocks.size() ? pages[(size_t)block_page[b0 + (size_t)k]] : nopage; };
     auto srcp = [&](int k) { return bytes.data() + page(k).src_off; };
     auto recp = [&](int k) { return recs.data() + page(k).rec_first + blk(k).rec_first; };
-    for (int t = 0; t < 64; t++) seq_stage(SL.get(), t >> 4, srcp(t >> 4), blk(t >> 4), (u32)page(t >> 4).src_len, t & 15);
+    for (int t = 0; t < 64; t++) seq_stage(SL.get(), t / kSeqGroup, srcp(t / kSeqGroup), blk(t / kSeqGroup), (u32)page(t / kSeqGroup).src_len, t % kSeqGroup);
     for (int k = 0; k < kSeqLanes; k++) seq_tables(SL.get(), k, blk(k));
-    for (int t = 0; t < 64; t++) seq_fill(SL.get(), t >> 4, srcp(t >> 4), blk(t >> 4), page(t >> 4).src_len, t & 15);
+    for (int t = 0; t < 64; t++) seq_fill(SL.get(), t / kSeqGroup, srcp(t / kSeqGroup), blk(t / kSeqGroup), page(t / kSeqGroup).src_len, t % kSeqGroup);
     SeqState st[kSeqLanes];
     u32 rounds = 0;
     for (int k = 0; k < kSeqLanes; k++) {
@@ -100,8 +100,8 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
     }
     for (u32 r = 0; r < rounds; r++) {
       for (int k = 0; k < kSeqLanes; k++) seq_round(SL.get(), k, st[k], blk(k));
-      for (int t = 0; t < 64; t++) seq_flush(SL.get(), t >> 4, recp(t >> 4), r * kSeqRound, t & 15);
-      for (int t = 0; t < 64; t++) seq_fill(SL.get(), t >> 4, srcp(t >> 4), blk(t >> 4), page(t >> 4).src_len, t & 15);
+      for (int t = 0; t < 64; t++) seq_flush(SL.get(), t / kSeqGroup, recp(t / kSeqGroup), r * kSeqRound, t % kSeqGroup);
+      for (int t = 0; t < 64; t++) seq_fill(SL.get(), t / kSeqGroup, srcp(t / kSeqGroup), blk(t / kSeqGroup), page(t / kSeqGroup).src_len, t % kSeqGroup);
       for (int k = 0; k < kSeqLanes; k++) seq_fill_done(SL.get(), k);
     }
     for (int k = 0; k < kSeqLanes && b0 + (size_t)k < blocks.size(); k++) {
