@@ -20,7 +20,7 @@ A = 16807
 SEED = {"O_ODATE": 1066728069, "L_QTY": 209208115, "L_DCNT": 554590007, "L_TAX": 721958466, "L_PKEY": 1808217256, "L_SDTE": 1769349045,
         "L_CDTE": 904914315, "L_RDTE": 373135028, "L_RFLG": 717419739, "C_MSEG": 1140279430, "O_CKEY": 851767375, "O_LCNT": 1434868289,
         "L_SMODE": 675466456, "O_PRIO": 591449447, "P_TYPE": 1841581359, "L_SHIP": 1371272478, "P_MFG": 1, "P_BRND": 46831694, "P_SIZE": 1193163244,
-        "P_CNTR": 727633698, "C_NTRG": 1489529863, "S_NTRG": 110356601, "L_SKEY": 2095021727, "C_PHNE": 1521138112, "C_ABAL": 298370230}
+        "P_CNTR": 727633698, "C_NTRG": 1489529863, "S_NTRG": 110356601, "L_SKEY": 2095021727, "C_PHNE": 1521138112, "C_ABAL": 298370230, "PS_QTY": 1671059989, "PS_SCST": 1051288424}
 STARTDATE_DAY = 8035          # 1992-01-01 as days since 1970-01-01 (dbgen's STARTDATE 92001)
 CURRENTDATE_OFFSET = 1263     # 1995-06-17 (CURRENTDATE 95168) as days since 1992-01-01
 SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]      # dists.dss msegmnt, equal weights
@@ -132,6 +132,22 @@ def part(sf: int = 1) -> pa.Table:
     brands = [b"Brand#%d%d" % (m, b) for m in range(1, 6) for b in range(1, 6)]
     return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), _utf8_from_choices(t - 1, PART_TYPES), _utf8_from_choices((mfg - 1) * 5 + brnd - 1, brands),
                      _utf8_from_choices(cntr - 1, CONTAINERS), pa.array(size.astype(np.int32))], names=["p_partkey", "p_type", "p_brand", "p_container", "p_size"])
+
+
+def partsupp(sf: int = 1) -> pa.Table:
+    """ps_partkey, ps_suppkey, ps_availqty, ps_supplycost (mk_part: four suppliers per part — PART_SUPP_BRIDGE — with a draw of PS_QTY and of PS_SCST each)"""
+    n, nsupp = 200_000 * sf, 10_000 * sf
+    pk = np.arange(1, n + 1, dtype=np.int64)
+    q, c = _stream_starts(SEED["PS_QTY"], n, 4), _stream_starts(SEED["PS_SCST"], n, 4)
+    cols = [[], [], [], []]
+    for snum in range(4):
+        qty, q = _draw(q, 1, 9999)
+        cost, c = _draw(c, 100, 100000)
+        for k, v in enumerate((pk, (pk + snum * (nsupp // 4 + (pk - 1) // nsupp)) % nsupp + 1, qty, cost)):
+            cols[k].append(v)
+    order = np.lexsort((np.repeat(np.arange(4), n), np.tile(pk, 4)))
+    cat = [np.concatenate(v)[order] for v in cols]
+    return pa.table([pa.array(cat[0]), pa.array(cat[1]), pa.array(cat[2].astype(np.int32)), _dec(cat[3], 12, 2)], names=["ps_partkey", "ps_suppkey", "ps_availqty", "ps_supplycost"])
 
 
 def orders_and_lineitem(sf: int = 1):

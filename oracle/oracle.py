@@ -13,7 +13,7 @@ reference); this file restates the operator semantics:
 Exact Python ``int`` versions of the decimal rules live in ``pyint.py`` and cross-check the C code.
 
 Pinned: against the reference's known-answer vectors (tests/golden/reference_kats.json), its Parquet fixture files, and — end to end —
-its own TPC-H scale-factor-1 answers (tests/golden/tpch_sf1/q{1,3,4,5,6,7,8,12,14,18,19,21,22}.sql.out, over tables regenerated with dbgen's random streams:
+its own TPC-H scale-factor-1 answers (tests/golden/tpch_sf1/q{1,3,4,5,6,7,8,11,12,14,17,18,19,21,22}.sql.out, over tables regenerated with dbgen's random streams:
 tests/test_tpch_golden_cpu.py).
 """
 from __future__ import annotations

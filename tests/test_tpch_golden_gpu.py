@@ -1,5 +1,5 @@
-"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q12 / Q14 / Q18 / Q19 / Q21 / Q22 — the numbers in
-spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,12,14,18,19,21,22}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
+"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q11 / Q12 / Q14 / Q17 / Q18 / Q19 / Q21 / Q22 — the numbers in
+spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,11,12,14,17,18,19,21,22}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py; tests/test_tpch_golden_cpu.py pins the generator and the oracle on
 the same files).  Q6 goes in through Parquet (snappy and zstd, pages inflated on the device, and the host path), Q1 and Q3 over
 HBM-resident columns; every stage runs through the C ABI, the Final aggregates included."""
@@ -63,21 +63,21 @@ def test_q3_gives_the_references_answer(built, sf1):
     assert q3_rows(top) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
 
 
-@pytest.mark.parametrize("q", ["q4", "q5", "q7", "q8", "q12", "q14", "q18", "q19", "q21", "q22"])
+@pytest.mark.parametrize("q", ["q4", "q5", "q7", "q8", "q11", "q12", "q14", "q17", "q18", "q19", "q21", "q22"])
 def test_more_queries_give_the_references_answers(built, sf1, q):
     from tests import test_tpch_more_gpu as M
     from tests.test_tpch_golden_cpu import _more_inputs, golden_case
-    ncols = {"q4": (2, 2), "q5": (3, 2), "q7": (5, 4), "q8": (5, 2), "q12": (3, 3), "q14": (4, 1), "q18": (7, 6), "q19": (2, 1), "q21": (2, 2), "q22": (4, 3)}[q]
+    ncols = {"q4": (2, 2), "q5": (3, 2), "q7": (5, 4), "q8": (5, 2), "q11": (3, 2), "q12": (3, 3), "q14": (4, 1), "q17": (2, 1), "q18": (7, 6), "q19": (2, 1), "q21": (2, 2), "q22": (4, 3)}[q]
     state = {"n": 0}
 
     def run_partial(plan, tables):
         # (the first partial plan of Q22 is its scalar subquery: an ungrouped average, two state columns)
-        n = 2 if (q == "q22" and state["n"] == 0) else ncols[0]
+        n = 2 if (q in ("q22", "q11") and state["n"] == 0) else ncols[0]
         state["n"] += 1
         return M.run(plan, tables, n)
 
     def run_final(plan, tables):
-        n = 1 if (q == "q22" and state["n"] == 1) else ncols[1]
+        n = 1 if (q in ("q22", "q11") and state["n"] == 1) else ncols[1]
         return M.run(plan, tables, n)
     got, want = golden_case(q, _more_inputs(sf1), run_partial, run_final)
     assert got == want

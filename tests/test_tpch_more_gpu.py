@@ -271,6 +271,48 @@ def q22_partial_plan(average):
     return S.hash_agg(S.project(anti, [_q22_code(), c(2, D)]), [c(0, STR)], [S.count(S.lit(1, I32)), S.sum_(c(1, D), S.decimal(22, 2))], S.PARTIAL)
 
 
+def q17_partial_plan(brand="Brand#23", container="MED BOX"):
+    """TPC-H Q17 up to the partial aggregate: lines of one brand's parts in one container whose quantity is below a fifth of the part's average
+    quantity (a Final over a Partial average per part inside the plan, joined back on the part key with the comparison as the join's residual
+    condition).  Scan leaves in order: part, lineitem[l_partkey, l_quantity] (for the averages), part, lineitem[l_partkey, l_quantity, l_extendedprice]"""
+    A, T = S.decimal(16, 6), S.decimal(18, 7)
+    parts = lambda: S.project(S.filter_(S.scan([I64, STR, STR, STR, I32]), S.and_(S.eq(c(2, STR), L(brand)), S.eq(c(3, STR), L(container)))), [c(0, I64)])
+    lq = S.project(S.hash_join(parts(), S.scan([I64, D]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT), [c(1, I64), c(2, D)])                             # l_partkey, l_quantity
+    per_part = S.hash_agg(lq, [c(0, I64)], [S.avg(c(1, D), A, S.decimal(22, 2))], S.PARTIAL)
+    avgs = S.hash_agg(per_part, [c(0, I64)], per_part.aggs, S.FINAL)                                         # l_partkey, avg(l_quantity)
+    fifth = S.check_overflow(S.math("multiply", S.lit(decimal.Decimal("0.2"), S.decimal(1, 1)), c(1, A), T), T)
+    limit = S.project(avgs, [c(0, I64), fifth])                                                              # l_partkey, 0.2 * avg
+    lines = S.project(S.hash_join(parts(), S.scan([I64, D, D]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT), [c(1, I64), c(2, D), c(3, D)])               # l_partkey, l_quantity, l_extendedprice
+    small = S.lt(S.cast(c(3, D), T), c(1, T))                                                                # (left ++ right: l_partkey, limit | l_partkey, l_quantity, l_extendedprice)
+    j = S.hash_join(limit, lines, [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_LEFT, condition=small)
+    return S.hash_agg(S.project(j, [c(4, D)]), [], [S.sum_(c(0, D), S.decimal(22, 2))], S.PARTIAL)
+
+
+def q17_final_plan(partial, state_schema):
+    fin = S.final_of(partial, state_schema)
+    Q = S.decimal(27, 6)
+    return S.project(fin, [S.check_overflow(S.math("divide", c(0, S.decimal(22, 2)), S.lit(decimal.Decimal("7.0"), S.decimal(2, 1)), Q), Q)])
+
+
+def q11_partial_plan(nation_name="GERMANY", grouped=True):
+    """TPC-H Q11 up to the partial aggregate: the stock value (supply cost × available quantity) of a nation's suppliers, by part — or, not
+    grouped, in total (the scalar subquery).  Scan leaves in order: nation, supplier[s_suppkey, s_nationkey], partsupp[ps_partkey, ps_suppkey,
+    ps_availqty, ps_supplycost]"""
+    nat = S.project(S.filter_(S.scan([I32, STR, I32]), S.eq(c(1, STR), L(nation_name))), [c(0, I32)])
+    sup = S.project(S.hash_join(nat, S.scan([I64, I32]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(1, I64)])
+    j = S.hash_join(sup, S.scan([I64, I64, I32, D]), [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT)          # s_suppkey, ps_partkey, ps_suppkey, ps_availqty, ps_supplycost
+    V = S.decimal(23, 2)
+    value = S.check_overflow(S.math("multiply", c(4, D), S.cast(c(3, I32), S.decimal(10, 0)), V), V)
+    p = S.project(j, [c(1, I64), value])
+    return S.hash_agg(p, [c(0, I64)] if grouped else [], [S.sum_(c(1, V), S.decimal(33, 2))], S.PARTIAL)
+
+
+def q11_final_plan(partial, state_schema, threshold):
+    """the parts whose value exceeds `threshold` (what Spark computes from the subquery: its total × 0.0001), most valuable first"""
+    T = S.decimal(33, 2)
+    return S.sort(S.filter_(S.final_of(partial, state_schema), S.gt(c(1, T), S.lit(threshold, T))), [(c(1, T), True, True)])
+
+
 def q19_partial_plan(modes=("AIR", "REG AIR")):
     """TPC-H Q19 up to the partial aggregate; inputs: lineitem (the LI layout), part[p_partkey, p_type, p_brand, p_container, p_size].  (The
     benchmark's text asks for the modes 'AIR' and 'AIR REG'; no row carries the latter.)"""
