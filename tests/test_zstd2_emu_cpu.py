@@ -153,8 +153,11 @@ def test_frames_the_walk_keeps_on_the_host(emu):
     skippable = b"\x50\x2a\x4d\x18" + struct.pack("<I", 4) + b"abcd" + good
     wrong_size = good
     truncated = good[:-3]
-    status, _, _ = emu([bytes(with_dict_id), two_frames, skippable, wrong_size, truncated, good], [len(raw), 2 * len(raw), len(raw), len(raw) + 1, len(raw), len(raw)])
-    assert status[:5] == [1, 1, 1, 1, 1] and status[5] == 0
+    with_checksum = bytearray(frame([("raw", raw)]) + b"\x00\x00\x00\x00")
+    with_checksum[4] |= 0x04                               # content checksum flag: libzstd verifies it, so such a frame is inflated where libzstd runs
+    status, _, _ = emu([bytes(with_dict_id), two_frames, skippable, wrong_size, truncated, bytes(with_checksum), good],
+                       [len(raw), 2 * len(raw), len(raw), len(raw) + 1, len(raw), len(raw), len(raw)])
+    assert status[:6] == [1, 1, 1, 1, 1, 1] and status[6] == 0
 
 
 def test_host_prefix_is_the_pages_first_bytes(emu):
