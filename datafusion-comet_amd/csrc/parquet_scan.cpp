@@ -321,6 +321,7 @@ struct ScanOptions {
   // such pages hold and the host threads there are to decompress them (scan_parquet)
   int device_snappy_mode = -1;
   bool device_snappy = false;
+  bool device_zstd_dict = true;        // … and dictionary-encoded zstd pages: the device inflates them and sends the index sections back for the host to read the run headers (COMET_DEVICE_ZSTD_DICT=0: host threads)
   bool device_zstd = true;             // zstd PLAIN pages of fixed-width columns take the device pipeline too (COMET_DEVICE_ZSTD=0: host threads inflate them)
   bool read_in_place = true;           // chunks whose pages the device inflates are pread() straight into their pinned slot; page bodies are uploaded from where they land (COMET_PARQUET_READ_IN_PLACE=0: read into scratch, copy bodies)
   bool device_dict_pages = true;       // dictionary-encoded snappy pages cross PCIe compressed too (COMET_DEVICE_DICT_PAGES=0: host-inflated as before)
@@ -684,6 +685,9 @@ struct HostChunk {
   int64_t n_rows = 0;
   int64_t compressed = 0;
   size_t spos = 0;                 // staged (uploaded) bytes actually used
+  struct Pending { size_t page; size_t begin, end; int32_t values; };   // a dictionary-encoded page the device inflates: its run headers (bytes [begin, end) of the
+                                                                      // device-decompressed region, slot relative) are read back and parsed once the device has inflated it
+  std::vector<Pending> pending;
   int64_t dev_dict = -1;           // the chunk's dictionary page is inflated by the device: its offset in the device-decompressed region (else −1: dict_bytes holds it)
   size_t raw_lo = 0, raw_hi = 0;   // slot-relative extent of the page bodies that were read in place (behind the staged bytes) and cross PCIe from there
   size_t ipos = 0;                 // bytes of the device-decompressed region used
@@ -1002,7 +1006,11 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     // zstd: PLAIN pages of fixed-width columns cross PCIe compressed.  The host walks the frame's block headers (sizes, modes, where the
     // tables and bitstreams sit: comet_zstd2::scan_page) and, for a v1 page of an optional column, decodes the page's first bytes — its
     // definition levels — from the first block's first literals and sequences; the device does the rest (device/zstd2.hpp).
-    if (so.device_snappy && so.device_zstd && cm.codec == pq::ZSTD && !cp.is_string && h.encoding == pq::PLAIN && h.uncompressed_size >= kMinDevicePage &&
+    // Dictionary-encoded pages go the same way when the chunk is read whole: their run headers cannot be read through an entropy-coded stream,
+    // so the page is registered as PENDING — the device inflates it, the index section comes back over PCIe and the host parses the headers
+    // then (read_columns, "deferred").  The bit width — the index section's first byte — is read here with the levels.
+    const bool z_dict = (h.encoding == pq::RLE_DICTIONARY || h.encoding == pq::PLAIN_DICTIONARY) && so.device_zstd_dict && src.keep == nullptr;
+    if (so.device_snappy && so.device_zstd && cm.codec == pq::ZSTD && !cp.is_string && (h.encoding == pq::PLAIN || z_dict) && h.uncompressed_size >= kMinDevicePage &&
         (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.def_bytes >= 0 && h.compressed_size > h.def_bytes && h.uncompressed_size > h.def_bytes)) &&
         (in_place || h.compressed_size <= h.uncompressed_size)) {
       const size_t comp_off = h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes;
@@ -1020,11 +1028,21 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
           memcpy(&dl, tmp.data(), 4);
           lvl = 4 + (size_t)dl;
           ok = lvl <= un_len && lvl <= ((size_t)1 << 20);
-          if (ok && lvl > first) {
-            tmp.resize(lvl + 8);
-            ok = comet_zstd2::host_prefix(body, (uint32_t)comp_len, zw, tmp.data(), lvl) == lvl;
+          const size_t need = lvl + (z_dict ? 1 : 0);
+          if (ok && need > first) {
+            tmp.resize(need + 8);
+            ok = need <= un_len && comet_zstd2::host_prefix(body, (uint32_t)comp_len, zw, tmp.data(), need) == need;
           }
         }
+      } else if (ok && z_dict) {
+        tmp.resize(16);
+        ok = un_len >= 1 && comet_zstd2::host_prefix(body + comp_off, (uint32_t)comp_len, zw, tmp.data(), 1) == 1;
+      }
+      int zbw = 0;
+      if (ok && z_dict) {
+        ok = lvl + 1 <= un_len;
+        if (ok) zbw = tmp[lvl];
+        if (ok && zbw > 32) throw CometError("parquet: dictionary index bit width > 32");
       }
       const size_t ipage = (hc.ipos + 15) & ~(size_t)15;
       if (ok && ipage + un_len + 32 <= staged_cap) {
@@ -1067,8 +1085,25 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
         hc.zblocks.insert(hc.zblocks.end(), zw.blocks.begin(), zw.blocks.end());
         hc.zinflate.push_back(job);
         hc.ipos = ipage + un_len;
-        pg.encoding = 0;
-        pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
+        if (z_dict) {
+          pg.encoding = 1;
+          pg.bit_width = zbw;
+          pg.values_off = (int64_t)(ipage + lvl + 1) | kInflatedBit;
+          pg.idx_run_first = (int32_t)idx_runs.size();
+          if (zbw == 0 || lvl + 1 == un_len) {             // every index is 0 (or a page of NULLs only): one run, nothing to read back
+            PqRun r;
+            memset(&r, 0, sizeof r);
+            r.is_rle = 1;
+            r.count = h.num_values;
+            idx_runs.push_back(r);
+          } else {
+            hc.pending.push_back({pages.size(), ipage + lvl + 1, ipage + un_len, -1});
+          }
+          pg.idx_run_count = (int32_t)idx_runs.size() - pg.idx_run_first;
+        } else {
+          pg.encoding = 0;
+          pg.values_off = (int64_t)(ipage + lvl) | kInflatedBit;
+        }
         emit(pg, values_seen, values_seen + h.num_values, h.type == pq::DATA_PAGE ? tmp.data() - ipage : staged);
         values_seen += h.num_values;
         continue;
@@ -1547,6 +1582,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (const char* e = getenv("COMET_DEVICE_DICT_PAGES")) so.device_dict_pages = atoi(e) != 0;
   if (const char* e = getenv("COMET_PARQUET_READ_IN_PLACE")) so.read_in_place = atoi(e) != 0;
   if (const char* e = getenv("COMET_DEVICE_ZSTD")) so.device_zstd = atoi(e) != 0;
+  if (const char* e = getenv("COMET_DEVICE_ZSTD_DICT")) so.device_zstd_dict = atoi(e) != 0;
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy_mode = kv.second == "auto" ? -1 : (kv.second != "false" && kv.second != "0");
   if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
@@ -1641,9 +1677,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       if (cm.codec == pq::SNAPPY && !cp.is_string && cp.src_width > 0 && cm.num_values > 0 &&
           (so.device_dict_pages || (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values))
         plain_snappy_bytes += cm.total_uncompressed;
-      // … and zstd chunks that are mostly PLAIN pages (dictionary-encoded zstd pages stay with the host threads)
+      // … and zstd chunks: PLAIN pages, and — when the chunk is read whole — dictionary-encoded pages (index sections come back for their run headers)
       if (cm.codec == pq::ZSTD && so.device_zstd && !cp.is_string && cp.src_width > 0 && cm.num_values > 0 &&
-          (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values)
+          ((so.device_zstd_dict && sels[si].keep == nullptr) || (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values))
         plain_zstd_bytes += cm.total_uncompressed;
     }
   }
@@ -1805,56 +1841,19 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   HIP_CHECK(hipMemsetAsync(inflate_err->p, 0, ncol * 4 + 16, stream_));
   auto vidx = std::make_shared<DevBuf>();
 
-  for (size_t oi = 0; oi < ncol; oi++) {
-    const size_t c = order[oi];
+  // everything behind a column's uploads: its tables (pages, runs, dictionaries) assembled and sent, the decode kernels queued.  A column
+  // with dictionary-encoded pages the DEVICE inflates comes here late — their run headers are read back first (below).
+  static const bool one_wave_snappy = getenv("COMET_SNAPPY_ONE_WAVE") != nullptr && atoi(getenv("COMET_SNAPPY_ONE_WAVE")) != 0;
+  auto finish_column = [&](const size_t c, const std::shared_ptr<ColumnDevice>& cd, const size_t S, const bool may_inflate) {
     const ColumnPlan& cp = plans[c];
-    if (all_missing[c]) {
-      // all-NULL column: zeroed values, zeroed validity bitmap
-      DeviceColumnView mv;
-      auto zeros = std::make_shared<DevBuf>();
-      const size_t vb = cp.is_string ? (size_t)(total_rows + 1) * 4 : out.types[c].id == TypeId::Bool ? (size_t)((total_rows + 7) / 8) : (size_t)total_rows * cp.out_width;
-      zeros->ensure(vb + 16);
-      HIP_CHECK(hipMemsetAsync(zeros->p, 0, vb + 16, stream_));
-      auto bm = std::make_shared<DevBuf>();
-      bm->ensure((size_t)((total_rows + 7) / 8) + 16);
-      HIP_CHECK(hipMemsetAsync(bm->p, 0, (size_t)((total_rows + 7) / 8) + 16, stream_));
-      mv.data = zeros->p;
-      mv.valid = (const uint8_t*)bm->p;
-      if (cp.is_string) mv.aux = zeros->p;   // no bytes are ever addressed (all offsets 0)
-      out.has_valid[c] = true;
-      out.cols[c] = mv;
-      out.owners.push_back(zeros);
-      out.owners.push_back(bm);
-      for (size_t si = 0; si < nsel; si++) wait_for(c * nsel + si);
-      continue;
-    }
+    const bool is_string = cp.is_string;
     auto values = std::make_shared<DevBuf>();
     auto valid_bytes = std::make_shared<DevBuf>();
     auto lengths = std::make_shared<DevBuf>();
-    const bool is_string = cp.is_string;
-    auto cd = std::make_shared<ColumnDevice>();
-    keep.push_back(cd);
-    // the column's page bytes cross PCIe in slices as soon as their chunks are ready, on the copy stream
-    // [0, S): what the host staged (decompressed pages, or compressed bodies for the device); [S, 2S): pages the device decompresses
-    const size_t S = (slot_off[c][nsel] + 64 + 15) & ~(size_t)15;
-    const bool may_inflate = so.device_snappy && !cp.is_string && !cp.missing;
-    cd->bytes.ensure(may_inflate ? 2 * S + 64 : S);
     bool any_optional = false;
     size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0, n_jobs = 0, n_zjobs = 0;
-    static const bool one_wave_snappy = getenv("COMET_SNAPPY_ONE_WAVE") != nullptr && atoi(getenv("COMET_SNAPPY_ONE_WAVE")) != 0;
-    std::vector<PqInflate> group_jobs, zgroup_jobs;
-    std::vector<comet_zstd2::ZBlock> zgroup_blocks;
-    size_t group_bytes = 0;
     for (size_t si = 0; si < nsel; si++) {
-      wait_for(c * nsel + si);
       HostChunk& hc = chunks[c * nsel + si];
-      // is the chunk behind this one ready too?  Then its slices join this batch (one launch for all of them)
-      bool next_ready = false;
-      if (si + 1 < nsel) {
-        std::lock_guard<std::mutex> lk(prog->mu);
-        next_ready = prog->done[c * nsel + si + 1] != 0;
-      }
-      bytes_scanned_ += hc.compressed;
       any_optional |= hc.max_def > 0 && !hc.no_nulls;
       n_pages += hc.pages.size();
       n_def += hc.no_nulls ? 0 : hc.def_runs.size();
@@ -1864,57 +1863,6 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       n_soffs += hc.str_offs.size();
       n_jobs += hc.inflate.size();
       n_zjobs += hc.zinflate.size();
-      // only the bytes the chunk actually staged cross PCIe
-      if (hc.spos) upload((char*)cd->bytes.p + slot_off[c][si], (char*)col_staged[c]->p + slot_off[c][si], std::min((hc.spos + 16 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]));
-      if (hc.raw_hi > hc.raw_lo) {      // page bodies read in place: from where pread() put them (+ the few bytes behind the last one the kernels' vector loads touch)
-        const size_t lo = hc.raw_lo & ~(size_t)15, hi = std::min((hc.raw_hi + 32 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]);
-        upload((char*)cd->bytes.p + slot_off[c][si] + lo, (char*)col_staged[c]->p + slot_off[c][si] + lo, hi - lo);
-      }
-      // Pages the device decompresses: the pipeline is launched for a GROUP of chunks as soon as their slices are across, so it runs
-      // while the column's later chunks are still being read and uploaded (launched once per column it started only after the last slice:
-      // 7 ms of decompression behind 10 ms of upload, SF10 Q6).  COMET_SNAPPY_ONE_WAVE=1 keeps the one-wave-per-page kernel, per column.
-      if (!one_wave_snappy)
-        for (const PqInflate& src : hc.inflate) {
-          PqInflate job = src;
-          job.src_off += (int64_t)slot_off[c][si];
-          job.dst_off += (int64_t)slot_off[c][si] + (int64_t)S;
-          group_jobs.push_back(job);
-          group_bytes += (size_t)job.src_len;
-        }
-      {
-        const int32_t first_block = (int32_t)zgroup_blocks.size();
-        zgroup_blocks.insert(zgroup_blocks.end(), hc.zblocks.begin(), hc.zblocks.end());
-        for (const PqInflate& src : hc.zinflate) {
-          PqInflate job = src;
-          job.src_off += (int64_t)slot_off[c][si];
-          job.dst_off += (int64_t)slot_off[c][si] + (int64_t)S;
-          job.preamble += first_block;
-          zgroup_jobs.push_back(job);
-          group_bytes += (size_t)job.src_len;
-        }
-      }
-      // (zstd: the sequence kernel is bound by ONE lane's serial chain per block, not by the number of blocks — up to ~3000 blocks take as
-      // long as one; so its groups are as large as that, 400 MiB of page data)
-      const bool group_full = (!group_jobs.empty() || !zgroup_jobs.empty()) &&
-                              (group_bytes >= (zgroup_jobs.empty() ? (size_t)48 << 20 : (size_t)160 << 20) || zgroup_blocks.size() >= 3000 || si + 1 == nsel);
-      if (!next_ready || group_full) upload_flush();
-      if (group_full) {
-        if (group_jobs.size() >= ((size_t)1 << 23) || zgroup_jobs.size() >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
-        upload_fence(stream_);
-        if (!group_jobs.empty()) {
-          cd->snappy2.emplace_back(new Snappy2Scratch());
-          cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
-        }
-        if (!zgroup_jobs.empty()) {
-          cd->zstd2.emplace_back(new Zstd2Scratch());
-          cd->zstd2.back()->run(zgroup_jobs.data(), (int)zgroup_jobs.size(), zgroup_blocks.data(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
-        }
-        pages_inflated_on_device_ += (int64_t)(group_jobs.size() + zgroup_jobs.size());
-        group_jobs.clear();
-        zgroup_jobs.clear();
-        zgroup_blocks.clear();
-        group_bytes = 0;
-      }
     }
     if ((n_jobs || n_zjobs) && !may_inflate) throw CometError("internal: device pages in a column without a decompression region");
     if (trace) fprintf(stderr, "[comet] parquet: column %zu host chunks ready at %.2f ms\n", c, ms_since());
@@ -2084,6 +2032,182 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     }
     out.owners.push_back(valid_bytes);
     out.cols[c] = cv;
+  };
+  struct Deferred { size_t c; std::shared_ptr<ColumnDevice> cd; size_t S; bool may_inflate; std::shared_ptr<PinnedBuf> readback; hipEvent_t done; std::vector<size_t> at; };
+  std::vector<Deferred> deferred;
+  for (size_t oi = 0; oi < ncol; oi++) {
+    const size_t c = order[oi];
+    const ColumnPlan& cp = plans[c];
+    if (all_missing[c]) {
+      // all-NULL column: zeroed values, zeroed validity bitmap
+      DeviceColumnView mv;
+      auto zeros = std::make_shared<DevBuf>();
+      const size_t vb = cp.is_string ? (size_t)(total_rows + 1) * 4 : out.types[c].id == TypeId::Bool ? (size_t)((total_rows + 7) / 8) : (size_t)total_rows * cp.out_width;
+      zeros->ensure(vb + 16);
+      HIP_CHECK(hipMemsetAsync(zeros->p, 0, vb + 16, stream_));
+      auto bm = std::make_shared<DevBuf>();
+      bm->ensure((size_t)((total_rows + 7) / 8) + 16);
+      HIP_CHECK(hipMemsetAsync(bm->p, 0, (size_t)((total_rows + 7) / 8) + 16, stream_));
+      mv.data = zeros->p;
+      mv.valid = (const uint8_t*)bm->p;
+      if (cp.is_string) mv.aux = zeros->p;   // no bytes are ever addressed (all offsets 0)
+      out.has_valid[c] = true;
+      out.cols[c] = mv;
+      out.owners.push_back(zeros);
+      out.owners.push_back(bm);
+      for (size_t si = 0; si < nsel; si++) wait_for(c * nsel + si);
+      continue;
+    }
+    auto cd = std::make_shared<ColumnDevice>();
+    keep.push_back(cd);
+    // the column's page bytes cross PCIe in slices as soon as their chunks are ready, on the copy stream
+    // [0, S): what the host staged (decompressed pages, or compressed bodies for the device); [S, 2S): pages the device decompresses
+    const size_t S = (slot_off[c][nsel] + 64 + 15) & ~(size_t)15;
+    const bool may_inflate = so.device_snappy && !cp.is_string && !cp.missing;
+    cd->bytes.ensure(may_inflate ? 2 * S + 64 : S);
+    size_t n_jobs = 0, n_zjobs = 0;
+    std::vector<PqInflate> group_jobs, zgroup_jobs;
+    std::vector<comet_zstd2::ZBlock> zgroup_blocks;
+    size_t group_bytes = 0;
+    for (size_t si = 0; si < nsel; si++) {
+      wait_for(c * nsel + si);
+      HostChunk& hc = chunks[c * nsel + si];
+      // is the chunk behind this one ready too?  Then its slices join this batch (one launch for all of them)
+      bool next_ready = false;
+      if (si + 1 < nsel) {
+        std::lock_guard<std::mutex> lk(prog->mu);
+        next_ready = prog->done[c * nsel + si + 1] != 0;
+      }
+      bytes_scanned_ += hc.compressed;
+      n_jobs += hc.inflate.size();
+      n_zjobs += hc.zinflate.size();
+      // only the bytes the chunk actually staged cross PCIe
+      if (hc.spos) upload((char*)cd->bytes.p + slot_off[c][si], (char*)col_staged[c]->p + slot_off[c][si], std::min((hc.spos + 16 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]));
+      if (hc.raw_hi > hc.raw_lo) {      // page bodies read in place: from where pread() put them (+ the few bytes behind the last one the kernels' vector loads touch)
+        const size_t lo = hc.raw_lo & ~(size_t)15, hi = std::min((hc.raw_hi + 32 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]);
+        upload((char*)cd->bytes.p + slot_off[c][si] + lo, (char*)col_staged[c]->p + slot_off[c][si] + lo, hi - lo);
+      }
+      // Pages the device decompresses: the pipeline is launched for a GROUP of chunks as soon as their slices are across, so it runs
+      // while the column's later chunks are still being read and uploaded (launched once per column it started only after the last slice:
+      // 7 ms of decompression behind 10 ms of upload, SF10 Q6).  COMET_SNAPPY_ONE_WAVE=1 keeps the one-wave-per-page kernel, per column.
+      if (!one_wave_snappy)
+        for (const PqInflate& src : hc.inflate) {
+          PqInflate job = src;
+          job.src_off += (int64_t)slot_off[c][si];
+          job.dst_off += (int64_t)slot_off[c][si] + (int64_t)S;
+          group_jobs.push_back(job);
+          group_bytes += (size_t)job.src_len;
+        }
+      {
+        const int32_t first_block = (int32_t)zgroup_blocks.size();
+        zgroup_blocks.insert(zgroup_blocks.end(), hc.zblocks.begin(), hc.zblocks.end());
+        for (const PqInflate& src : hc.zinflate) {
+          PqInflate job = src;
+          job.src_off += (int64_t)slot_off[c][si];
+          job.dst_off += (int64_t)slot_off[c][si] + (int64_t)S;
+          job.preamble += first_block;
+          zgroup_jobs.push_back(job);
+          group_bytes += (size_t)job.src_len;
+        }
+      }
+      // (zstd: the sequence kernel is bound by ONE lane's serial chain per block, not by the number of blocks — up to ~3000 blocks take as
+      // long as one; so its groups are as large as that, 400 MiB of page data)
+      const bool group_full = (!group_jobs.empty() || !zgroup_jobs.empty()) &&
+                              (group_bytes >= (zgroup_jobs.empty() ? (size_t)48 << 20 : (size_t)160 << 20) || zgroup_blocks.size() >= 3000 || si + 1 == nsel);
+      if (!next_ready || group_full) upload_flush();
+      if (group_full) {
+        if (group_jobs.size() >= ((size_t)1 << 23) || zgroup_jobs.size() >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
+        upload_fence(stream_);
+        if (!group_jobs.empty()) {
+          cd->snappy2.emplace_back(new Snappy2Scratch());
+          cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+        }
+        if (!zgroup_jobs.empty()) {
+          cd->zstd2.emplace_back(new Zstd2Scratch());
+          cd->zstd2.back()->run(zgroup_jobs.data(), (int)zgroup_jobs.size(), zgroup_blocks.data(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+        }
+        pages_inflated_on_device_ += (int64_t)(group_jobs.size() + zgroup_jobs.size());
+        group_jobs.clear();
+        zgroup_jobs.clear();
+        zgroup_blocks.clear();
+        group_bytes = 0;
+      }
+    }
+    // Dictionary-encoded pages the device inflates (zstd: their literals are entropy-coded, the host cannot look through the compressed stream
+    // as it does with snappy): the index sections come BACK once the device has inflated them — a few MB per column at PCIe speed — and the
+    // host reads the run headers out of them (the decoded values never come back).  Such a column is finished behind all uploads.
+    size_t pending_bytes = 0;
+    for (size_t si = 0; si < nsel; si++)
+      for (const HostChunk::Pending& pe : chunks[c * nsel + si].pending) pending_bytes += ((pe.end - pe.begin) + 15) & ~(size_t)15;
+    if (pending_bytes) {
+      Deferred d{c, cd, S, may_inflate, std::make_shared<PinnedBuf>(), get_event(), {}};
+      d.readback->ensure(pending_bytes + 64);
+      size_t at = 0;
+      for (size_t si = 0; si < nsel; si++)
+        for (const HostChunk::Pending& pe : chunks[c * nsel + si].pending) {
+          HIP_CHECK(hipMemcpyAsync((char*)d.readback->p + at, (char*)cd->bytes.p + slot_off[c][si] + S + pe.begin, pe.end - pe.begin, hipMemcpyDeviceToHost, stream_));
+          d.at.push_back(at);
+          at += ((pe.end - pe.begin) + 15) & ~(size_t)15;
+        }
+      HIP_CHECK(hipEventRecord(d.done, stream_));
+      deferred.push_back(std::move(d));
+      if (trace) fprintf(stderr, "[comet] parquet: column %zu waits for %.1f MB of index sections from the device\n", c, (double)pending_bytes / 1e6);
+      continue;
+    }
+    finish_column(c, cd, S, may_inflate);
+  }
+  for (Deferred& d : deferred) {
+    HIP_CHECK(hipEventSynchronize(d.done));
+    // the run headers of every pending page, parsed on the scan threads (a chunk per task), positions in the coordinates of the
+    // device-decompressed region — where the decode kernels will read the indices
+    std::vector<std::exception_ptr> errs(nsel);
+    std::atomic<size_t> left{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t k = 0;
+    for (size_t si = 0; si < nsel; si++) {
+      HostChunk& hc = chunks[d.c * nsel + si];
+      if (hc.pending.empty()) continue;
+      const size_t first = k;
+      k += hc.pending.size();
+      left.fetch_add(1);
+      ScanPool::get().submit([&, si, first]() {
+        try {
+          HostChunk& h = chunks[d.c * nsel + si];
+          for (size_t j = 0; j < h.pending.size(); j++) {
+            const HostChunk::Pending& pe = h.pending[j];
+            PqPage& pg = h.pages[pe.page];
+            const uint8_t* base = (const uint8_t*)d.readback->p + d.at[first + j] - pe.begin;      // so that base + position addresses the byte
+            const size_t r0 = h.idx_runs.size();
+            parse_hybrid_runs(base, pe.begin, pe.end, pg.bit_width, pe.values, h.idx_runs);
+            for (size_t r = r0; r < h.idx_runs.size(); r++) h.idx_runs[r].byte_off |= kInflatedBit;
+            if (h.idx_runs.size() == r0) {   // page of NULLs only
+              PqRun r;
+              memset(&r, 0, sizeof r);
+              r.is_rle = 1;
+              r.count = pg.num_values;
+              h.idx_runs.push_back(r);
+            }
+            pg.idx_run_first = (int32_t)r0;
+            pg.idx_run_count = (int32_t)(h.idx_runs.size() - r0);
+          }
+        } catch (...) {
+          errs[si] = std::current_exception();
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          left.fetch_sub(1);
+        }
+        cv.notify_all();
+      });
+    }
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return left.load() == 0; });
+    }
+    for (auto& e : errs)
+      if (e) std::rethrow_exception(e);
+    finish_column(d.c, d.cd, d.S, d.may_inflate);
   }
   // Hive partition columns: one constant per file (SparkPartitionedFile.partition_values, operator.proto:103-109), appended after
   // the file columns (planner.rs:1558-1575); a NULL partition value clears the validity of its rows

@@ -2,6 +2,8 @@
 and hand-built frames the CPU suite runs through the host emulation (tests/test_zstd2_emu_cpu.py), plus many 1 MiB pages at once — and the
 scan with PLAIN zstd pages (v1 with the levels inside the frame: the host decodes just that prefix; v2 with the levels outside) against
 pyarrow's reader, with the host decompression path as a second opinion."""
+from decimal import Decimal
+
 import numpy as np
 import pyarrow as pa
 import pyarrow.parquet as papq
@@ -118,3 +120,52 @@ def test_mixed_chunks_dictionary_then_plain_zstd(built, tmp_path, level):
     got, m = _scan_with_metrics(path, t, True)
     _assert_same(got, papq.read_table(path))
     assert m["pages_decompressed_on_device"] >= 8
+
+
+def _dict_table(n, seed):
+    rng = np.random.default_rng(seed)
+    runs = np.repeat(rng.integers(0, 7, n // 50 + 1), 50)[:n]                         # long RLE runs between bit-packed ones
+    nulls_block = np.zeros(n, dtype=bool)
+    nulls_block[n // 3: n // 3 + 150_000] = True                                      # whole pages of NULLs only
+    return pa.table({
+        "disc": pa.array(rng.integers(0, 11, n), pa.int64(), mask=rng.random(n) < 0.1),       # 4-bit indices, NULLs: levels in front of them in a v1 page
+        "qty": pa.array(rng.integers(1, 51, n).astype(np.int32), pa.int32()),                 # 6-bit, required
+        "date": pa.array(rng.integers(8000, 10500, n), pa.int32()).cast(pa.date32()),         # 12-bit
+        "runs": pa.array(runs, pa.int64()),
+        "one": pa.array(np.full(n, 42, dtype=np.int64), pa.int64(), mask=rng.random(n) < 0.5),     # one dictionary entry: bit width 0
+        "holes": pa.array(rng.integers(0, 100, n), pa.int64(), mask=nulls_block),
+        "f": pa.array(rng.integers(0, 300, n) * 0.25, pa.float64(), mask=rng.random(n) < 0.02),
+        "dec": pa.array([Decimal(int(v)).scaleb(-2) for v in rng.integers(0, 11, n)], pa.decimal128(12, 2)),
+        "k": pa.array(np.arange(n, dtype=np.int64)),                                          # falls back to PLAIN after the first pages
+    })
+
+
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+def test_scan_of_dictionary_encoded_zstd_pages(built, tmp_path, version, monkeypatch):
+    """dictionary-encoded pages under zstd: the device inflates them, their index sections come back and the host reads the run headers
+    there (read_columns "deferred"); with COMET_DEVICE_ZSTD_DICT=0 host threads inflate them as before — both against pyarrow"""
+    t = _dict_table(1_200_000, 35)
+    path = str(tmp_path / f"dict_zstd_v{version[0]}.parquet")
+    papq.write_table(t, path, compression="zstd", use_dictionary=True, data_page_version=version, row_group_size=500_000, data_page_size=64 << 10)
+    want = papq.read_table(path)
+    got, m = _scan_with_metrics(path, t, True)
+    _assert_same(got, want)
+    monkeypatch.setenv("COMET_DEVICE_ZSTD_DICT", "0")
+    host, mh = _scan_with_metrics(path, t, True)
+    _assert_same(host, want)
+    assert m["pages_decompressed_on_device"] > mh["pages_decompressed_on_device"] + 20
+
+
+def test_dictionary_encoded_zstd_pages_under_a_pruned_scan_stay_on_the_host(built, tmp_path):
+    """a scan that keeps only some row ranges of a chunk clips each page's runs on the host, so it needs them there"""
+    from tests.test_parquet_page_index_gpu import _run
+    t = _dict_table(600_000, 36)
+    path = str(tmp_path / "dict_zstd_pruned.parquet")
+    papq.write_table(t, path, compression="zstd", use_dictionary=True, row_group_size=300_000, data_page_size=32 << 10, write_page_index=True)
+    k = S.col(8, S.T_INT64)
+    lo, hi = 100_000, 140_000
+    filters = [S.gt_eq(k, S.lit(lo, S.T_INT64)), S.lt(k, S.lit(hi, S.T_INT64))]
+    got, m = _run(path, t, filters, {"spark.comet.gpu.scan.deviceDecompress": "true"}, with_filter=S.and_(*filters))
+    assert m["page_index_rows_pruned"] > 0
+    want = papq.read_table(path).slice(lo, hi - lo)
+    _assert_same(got, want)
