@@ -1137,7 +1137,8 @@ inline size_t host_prefix(const u8* p, u32 len, const PageWalk& w, u8* out, size
       if (logs[k] < 0) return produced;
       seq_table_expand(k, logs[k], fse.data() + 1024 * k, llc, mlc);
     }
-    recs.resize((size_t)b.nseq + 1);
+    // (a sequence yields at least its 3 match bytes: `need` bytes take at most need / 3 + 1 of them)
+    recs.resize((size_t)(b.nseq < need / 3 + 2 ? b.nseq : need / 3 + 2) + 1);
     u32 ndone = 0;
     i32 rep_out[3];
     {

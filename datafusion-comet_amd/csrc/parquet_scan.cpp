@@ -321,7 +321,9 @@ struct ScanOptions {
   // such pages hold and the host threads there are to decompress them (scan_parquet)
   int device_snappy_mode = -1;
   bool device_snappy = false;
-  bool device_zstd_dict = true;        // … and dictionary-encoded zstd pages: the device inflates them and sends the index sections back for the host to read the run headers (COMET_DEVICE_ZSTD_DICT=0: host threads)
+  bool device_zstd_dict = false;       // COMET_DEVICE_ZSTD_DICT=1: dictionary-encoded zstd pages are inflated by the device too, their index sections come back and the host reads the run
+                                       // headers there.  Off: measured on SF10 Q6 (profiles/r3_parquet_q6_zstd_dict.txt) the device inflates these Huffman-only pages at 4–7 GB/s
+                                       // (one serial LDS-lookup chain per literal stream) where a host core does 6 GB/s — 87 vs 38 ms with 16 scan threads, 111 vs 97 ms with one
   bool device_zstd = true;             // zstd PLAIN pages of fixed-width columns take the device pipeline too (COMET_DEVICE_ZSTD=0: host threads inflate them)
   bool read_in_place = true;           // chunks whose pages the device inflates are pread() straight into their pinned slot; page bodies are uploaded from where they land (COMET_PARQUET_READ_IN_PLACE=0: read into scratch, copy bodies)
   bool device_dict_pages = true;       // dictionary-encoded snappy pages cross PCIe compressed too (COMET_DEVICE_DICT_PAGES=0: host-inflated as before)
@@ -678,6 +680,16 @@ Ranges may_match(const Expr& pred, const std::vector<StructField>& schema, const
   return r;
 }
 
+// COMET_TRACE_STAGES: where the scan threads' time goes (summed over threads, printed by read_columns)
+static std::atomic<int64_t> g_ns_read{0}, g_ns_walk{0}, g_ns_inflate{0}, g_ns_chunk{0};
+static const bool g_host_timers = getenv("COMET_TRACE_STAGES") != nullptr;
+struct HostTimer {
+  std::atomic<int64_t>* to;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTimer(std::atomic<int64_t>& a) : to(g_host_timers ? &a : nullptr) { if (to) t0 = std::chrono::steady_clock::now(); }
+  ~HostTimer() { if (to) to->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()); }
+};
+
 struct HostChunk {
   ColumnPlan cp;
   int max_def = 0;
@@ -812,7 +824,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     if (raw.size() < (size_t)cm.total_compressed + 16) raw.resize((size_t)cm.total_compressed + 16);
     rawp = raw.data();
   }
-  src.file->read_at(rawp, (size_t)cm.total_compressed, off);
+  { HostTimer tm(g_ns_read); src.file->read_at(rawp, (size_t)cm.total_compressed, off); }
   const uint8_t* chunk_data = rawp - off;         // so that chunk_data + file_offset addresses the byte
   int64_t values_seen = 0;      // rows of the row group the pages walked so far cover
   int64_t out_pos = 0;          // kept rows emitted so far (the chunk's output rows)
@@ -1016,6 +1028,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       const size_t comp_off = h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes;
       const size_t comp_len = (size_t)h.compressed_size - comp_off, un_len = (size_t)h.uncompressed_size - comp_off;
       comet_zstd2::PageWalk zw;
+      HostTimer tm_walk(g_ns_walk);
       bool ok = comet_zstd2::scan_page(body + comp_off, (uint32_t)comp_len, (uint32_t)un_len, zw);
       size_t lvl = 0;
       if (ok && h.type == pq::DATA_PAGE && max_def > 0) {
@@ -1222,7 +1235,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       continue;
     }
     if (h.type == pq::DATA_PAGE) {
-      pq::decompress(cm.codec, body, (size_t)h.compressed_size, staged + spos, (size_t)h.uncompressed_size);
+      { HostTimer tm(g_ns_inflate); pq::decompress(cm.codec, body, (size_t)h.compressed_size, staged + spos, (size_t)h.uncompressed_size); }
       page_end = spos + (size_t)h.uncompressed_size;
       size_t p = page_begin;
       if (max_def > 0) {
@@ -1250,7 +1263,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       }
       vals_begin = spos + (size_t)h.def_bytes;
       const size_t vcomp = (size_t)h.compressed_size - (size_t)h.def_bytes, vun = (size_t)h.uncompressed_size - (size_t)h.def_bytes;
-      pq::decompress(h.v2_compressed ? cm.codec : pq::UNCOMPRESSED, body + h.def_bytes, vcomp, staged + vals_begin, vun);
+      { HostTimer tm(g_ns_inflate); pq::decompress(h.v2_compressed ? cm.codec : pq::UNCOMPRESSED, body + h.def_bytes, vcomp, staged + vals_begin, vun); }
       page_end = vals_begin + vun;
     }
     int value_encoding = h.encoding;
@@ -1719,7 +1732,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     uint8_t* slot = (uint8_t*)col_staged[c]->p + slot_off[c][si];
     const size_t cap = slot_off[c][si + 1] - slot_off[c][si];
     if (chunk_missing[t]) synth_chunk(op.required_schema[c], default_of(c), sels[si].rows, chunks[t], slot, cap);
-    else decode_chunk_host(src, op.required_schema[c], so, chunks[t], slot, cap);
+    else { HostTimer tm(g_ns_chunk); decode_chunk_host(src, op.required_schema[c], so, chunks[t], slot, cap); }
   };
   // `max_inflight` workers take the chunks in order (spark.comet.gpu.scanThreads: a task's share of the executor's pool — one, for a
   // Spark task that owns one core), each from the shared cursor until none is left
@@ -2033,7 +2046,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     out.owners.push_back(valid_bytes);
     out.cols[c] = cv;
   };
-  struct Deferred { size_t c; std::shared_ptr<ColumnDevice> cd; size_t S; bool may_inflate; std::shared_ptr<PinnedBuf> readback; hipEvent_t done; std::vector<size_t> at; };
+  struct Deferred { size_t c; std::shared_ptr<ColumnDevice> cd; size_t S; bool may_inflate; std::shared_ptr<PinnedBuf> readback; hipEvent_t done; std::vector<const uint8_t*> at; };
   std::vector<Deferred> deferred;
   for (size_t oi = 0; oi < ncol; oi++) {
     const size_t c = order[oi];
@@ -2140,15 +2153,33 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     for (size_t si = 0; si < nsel; si++)
       for (const HostChunk::Pending& pe : chunks[c * nsel + si].pending) pending_bytes += ((pe.end - pe.begin) + 15) & ~(size_t)15;
     if (pending_bytes) {
+      // where they land: the chunk's own pinned slot, between its staged bytes and the page bodies read in place — a device-inflated chunk
+      // leaves that part (sized for host-inflated pages) unused; a chunk without the room gets a buffer of its own
       Deferred d{c, cd, S, may_inflate, std::make_shared<PinnedBuf>(), get_event(), {}};
-      d.readback->ensure(pending_bytes + 64);
+      size_t spill = 0;
+      for (size_t si = 0; si < nsel; si++) {
+        const HostChunk& hc = chunks[c * nsel + si];
+        size_t need = 0;
+        for (const HostChunk::Pending& pe : hc.pending) need += ((pe.end - pe.begin) + 15) & ~(size_t)15;
+        const size_t lo = (hc.spos + 63) & ~(size_t)63, hi = hc.raw_hi > hc.raw_lo ? (hc.raw_lo & ~(size_t)15) : slot_off[c][si + 1] - slot_off[c][si];
+        if (lo + need > hi) spill += need;
+      }
+      if (spill) d.readback->ensure(spill + 64);
       size_t at = 0;
-      for (size_t si = 0; si < nsel; si++)
-        for (const HostChunk::Pending& pe : chunks[c * nsel + si].pending) {
-          HIP_CHECK(hipMemcpyAsync((char*)d.readback->p + at, (char*)cd->bytes.p + slot_off[c][si] + S + pe.begin, pe.end - pe.begin, hipMemcpyDeviceToHost, stream_));
-          d.at.push_back(at);
-          at += ((pe.end - pe.begin) + 15) & ~(size_t)15;
+      for (size_t si = 0; si < nsel; si++) {
+        const HostChunk& hc = chunks[c * nsel + si];
+        size_t need = 0;
+        for (const HostChunk::Pending& pe : hc.pending) need += ((pe.end - pe.begin) + 15) & ~(size_t)15;
+        const size_t lo = (hc.spos + 63) & ~(size_t)63, hi = hc.raw_hi > hc.raw_lo ? (hc.raw_lo & ~(size_t)15) : slot_off[c][si + 1] - slot_off[c][si];
+        const bool in_slot = lo + need <= hi;
+        uint8_t* to = in_slot ? (uint8_t*)col_staged[c]->p + slot_off[c][si] + lo : (uint8_t*)d.readback->p + at;
+        if (!in_slot) at += need;
+        for (const HostChunk::Pending& pe : hc.pending) {
+          HIP_CHECK(hipMemcpyAsync(to, (char*)cd->bytes.p + slot_off[c][si] + S + pe.begin, pe.end - pe.begin, hipMemcpyDeviceToHost, stream_));
+          d.at.push_back(to);
+          to += ((pe.end - pe.begin) + 15) & ~(size_t)15;
         }
+      }
       HIP_CHECK(hipEventRecord(d.done, stream_));
       deferred.push_back(std::move(d));
       if (trace) fprintf(stderr, "[comet] parquet: column %zu waits for %.1f MB of index sections from the device\n", c, (double)pending_bytes / 1e6);
@@ -2156,8 +2187,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     }
     finish_column(c, cd, S, may_inflate);
   }
+  if (trace && !deferred.empty()) fprintf(stderr, "[comet] parquet: uploads of all columns issued at %.2f ms\n", ms_since());
   for (Deferred& d : deferred) {
     HIP_CHECK(hipEventSynchronize(d.done));
+    if (trace) fprintf(stderr, "[comet] parquet: column %zu index sections back at %.2f ms\n", d.c, ms_since());
     // the run headers of every pending page, parsed on the scan threads (a chunk per task), positions in the coordinates of the
     // device-decompressed region — where the decode kernels will read the indices
     std::vector<std::exception_ptr> errs(nsel);
@@ -2177,7 +2210,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
           for (size_t j = 0; j < h.pending.size(); j++) {
             const HostChunk::Pending& pe = h.pending[j];
             PqPage& pg = h.pages[pe.page];
-            const uint8_t* base = (const uint8_t*)d.readback->p + d.at[first + j] - pe.begin;      // so that base + position addresses the byte
+            const uint8_t* base = d.at[first + j] - pe.begin;      // so that base + position addresses the byte
             const size_t r0 = h.idx_runs.size();
             parse_hybrid_runs(base, pe.begin, pe.end, pg.bit_width, pe.values, h.idx_runs);
             for (size_t r = r0; r < h.idx_runs.size(); r++) h.idx_runs[r].byte_off |= kInflatedBit;
@@ -2207,6 +2240,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     }
     for (auto& e : errs)
       if (e) std::rethrow_exception(e);
+    if (trace) fprintf(stderr, "[comet] parquet: column %zu run headers parsed at %.2f ms\n", d.c, ms_since());
     finish_column(d.c, d.cd, d.S, d.may_inflate);
   }
   // Hive partition columns: one constant per file (SparkPartitionedFile.partition_values, operator.proto:103-109), appended after
@@ -2297,6 +2331,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     out.cols[ncol + p] = cv;
   }
   if (trace) fprintf(stderr, "[comet] parquet: all launches issued at %.2f ms\n", ms_since());
+  if (trace) fprintf(stderr, "[comet] parquet: scan threads spent %.2f ms on chunks: %.2f reading, %.2f walking zstd frames, %.2f inflating pages\n", (double)g_ns_chunk.exchange(0) / 1e6,
+                     (double)g_ns_read.exchange(0) / 1e6, (double)g_ns_walk.exchange(0) / 1e6, (double)g_ns_inflate.exchange(0) / 1e6);
   HIP_CHECK(hipStreamSynchronize(stream_));
   if (trace) fprintf(stderr, "[comet] parquet: device idle at %.2f ms\n", ms_since());
   {

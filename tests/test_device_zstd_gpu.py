@@ -143,11 +143,12 @@ def _dict_table(n, seed):
 @pytest.mark.parametrize("version", ["1.0", "2.0"])
 def test_scan_of_dictionary_encoded_zstd_pages(built, tmp_path, version, monkeypatch):
     """dictionary-encoded pages under zstd: the device inflates them, their index sections come back and the host reads the run headers
-    there (read_columns "deferred"); with COMET_DEVICE_ZSTD_DICT=0 host threads inflate them as before — both against pyarrow"""
+    there (read_columns "deferred": COMET_DEVICE_ZSTD_DICT=1); by default host threads inflate them — both against pyarrow"""
     t = _dict_table(1_200_000, 35)
     path = str(tmp_path / f"dict_zstd_v{version[0]}.parquet")
     papq.write_table(t, path, compression="zstd", use_dictionary=True, data_page_version=version, row_group_size=500_000, data_page_size=64 << 10)
     want = papq.read_table(path)
+    monkeypatch.setenv("COMET_DEVICE_ZSTD_DICT", "1")
     got, m = _scan_with_metrics(path, t, True)
     _assert_same(got, want)
     monkeypatch.setenv("COMET_DEVICE_ZSTD_DICT", "0")
@@ -156,9 +157,10 @@ def test_scan_of_dictionary_encoded_zstd_pages(built, tmp_path, version, monkeyp
     assert m["pages_decompressed_on_device"] > mh["pages_decompressed_on_device"] + 20
 
 
-def test_dictionary_encoded_zstd_pages_under_a_pruned_scan_stay_on_the_host(built, tmp_path):
+def test_dictionary_encoded_zstd_pages_under_a_pruned_scan_stay_on_the_host(built, tmp_path, monkeypatch):
     """a scan that keeps only some row ranges of a chunk clips each page's runs on the host, so it needs them there"""
     from tests.test_parquet_page_index_gpu import _run
+    monkeypatch.setenv("COMET_DEVICE_ZSTD_DICT", "1")
     t = _dict_table(600_000, 36)
     path = str(tmp_path / "dict_zstd_pruned.parquet")
     papq.write_table(t, path, compression="zstd", use_dictionary=True, row_group_size=300_000, data_page_size=32 << 10, write_page_index=True)
