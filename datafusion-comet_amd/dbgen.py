@@ -1,9 +1,11 @@
-"""The columns TPC-H Q1, Q3 and Q6 read, as tpch-dbgen generates them — the data behind the reference's own golden answers
-(spark/src/test/resources/tpch-query-results/q{1,3,6}.sql.out, written by CometTPCHQuerySuite over tables that GenTPCHData.scala:33-34
-produces with https://github.com/databricks/tpch-dbgen).  dbgen is not part of the reference's tree (and there is no network here), so this
-restates its published algorithm (TPC-H tools 2.x: rnd.c NextRand / UnifInt, build.c mk_order / mk_cust / rpb_routine / mk_sparse, the seed
-table of driver.c, dists.dss); it is pinned by the three golden files themselves: the generated SF1 tables give exactly those answers
-(tests/test_tpch_golden_cpu.py), down to the last digit of every sum.
+"""The columns nineteen of the twenty-two TPC-H queries read, as tpch-dbgen generates them — the data behind the reference's own golden answers
+(spark/src/test/resources/tpch-query-results/q*.sql.out, written by CometTPCHQuerySuite over tables that GenTPCHData.scala:33-34 produces with
+https://github.com/databricks/tpch-dbgen).  dbgen is not part of the reference's tree (and there is no network here), so this restates its
+published algorithm (TPC-H tools 2.x: rnd.c NextRand / UnifInt, build.c mk_order / mk_cust / mk_supp / mk_part / rpb_routine / mk_sparse, bm_utils.c
+a_rnd / agg_str / permute, the seed table of driver.c, dists.dss); it is pinned by the golden files themselves: the generated SF1 tables give exactly those
+answers (tests/test_tpch_golden_cpu.py), down to the last digit of every sum and the last character of every printed address.  Not restated: comment text
+(dbgen cuts it out of a pool of generated sentences) — which leaves out Q2, Q10 and Q13, the queries that print or match it; Q16's predicate on s_comment
+is the outcome of two draws of its own and is generated as a Boolean column.
 
 What dbgen does, per stream: a Park–Miller generator (seed ← seed · 16807 mod 2^31 − 1), a draw is lo + ⌊seed / (2^31 − 1) · (hi − lo + 1)⌋;
 every column has its own stream, and after every ROW each stream is advanced to a fixed number of draws (its `boundary`: 7 for the lineitem
@@ -20,7 +22,8 @@ A = 16807
 SEED = {"O_ODATE": 1066728069, "L_QTY": 209208115, "L_DCNT": 554590007, "L_TAX": 721958466, "L_PKEY": 1808217256, "L_SDTE": 1769349045,
         "L_CDTE": 904914315, "L_RDTE": 373135028, "L_RFLG": 717419739, "C_MSEG": 1140279430, "O_CKEY": 851767375, "O_LCNT": 1434868289,
         "L_SMODE": 675466456, "O_PRIO": 591449447, "P_TYPE": 1841581359, "L_SHIP": 1371272478, "P_MFG": 1, "P_BRND": 46831694, "P_SIZE": 1193163244,
-        "P_CNTR": 727633698, "C_NTRG": 1489529863, "S_NTRG": 110356601, "L_SKEY": 2095021727, "C_PHNE": 1521138112, "C_ABAL": 298370230, "PS_QTY": 1671059989, "PS_SCST": 1051288424}
+        "P_CNTR": 727633698, "C_NTRG": 1489529863, "S_NTRG": 110356601, "L_SKEY": 2095021727, "C_PHNE": 1521138112, "C_ABAL": 298370230, "PS_QTY": 1671059989, "PS_SCST": 1051288424,
+        "P_NAME": 709314158, "S_ADDR": 706178559, "S_PHNE": 884434366, "S_ABAL": 962338209, "BBB_CMNT": 202794285, "BBB_TYPE": 753643799}
 STARTDATE_DAY = 8035          # 1992-01-01 as days since 1970-01-01 (dbgen's STARTDATE 92001)
 CURRENTDATE_OFFSET = 1263     # 1995-06-17 (CURRENTDATE 95168) as days since 1992-01-01
 SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]      # dists.dss msegmnt, equal weights
@@ -113,12 +116,67 @@ def customer(sf: int = 1) -> pa.Table:
                     names=["c_custkey", "c_mktsegment", "c_nationkey", "c_name", "c_phone", "c_acctbal"])
 
 
+# dists.dss colors: 92 equally weighted words, in the file's (alphabetical) order; Q9 / Q20's golden answers depend on where green and forest sit
+COLORS = ("almond antique aquamarine azure beige bisque black blanched blue blush brown burlywood burnished chartreuse chiffon chocolate coral cornflower "
+          "cornsilk cream cyan dark deep dim dodger drab firebrick floral forest frosted gainsboro ghost goldenrod green grey honeydew hot indian ivory khaki "
+          "lace lavender lawn lemon light lime linen magenta maroon medium metallic midnight mint misty moccasin navajo navy olive orange orchid pale papaya "
+          "peach peru pink plum powder puff purple red rose rosy royal saddle salmon sandy seashell sienna sky slate smoke snow spring steel tan thistle tomato "
+          "turquoise violet wheat white yellow").split()
+ALPHA_NUM = b"0123456789abcdefghijklmnopqrstuvwxyz ABCDEFGHIJKLMNOPQRSTUVWXYZ,"      # a_rnd's alphabet, six bits per character
+
+
+def _v_str(seed0: int, n: int, avg: int, boundary: int) -> pa.Array:
+    """V_STR(avg): a_rnd(⌊0.4·avg⌋, ⌊1.6·avg⌋) — one draw for the length, then one draw of [0, MAX_LONG] per five characters, six bits each from the low end"""
+    lo, hi = int(avg * 0.4), int(avg * 1.6)
+    st = _stream_starts(seed0, n, boundary)
+    ln, st = _draw(st, lo, hi)
+    chars = np.zeros((n, hi), np.uint8)
+    alpha = np.frombuffer(ALPHA_NUM, np.uint8)
+    for g in range((hi + 4) // 5):
+        v, st = _draw(st, 0, M)
+        v = -v                 # UnifInt computes this one range, MAX_LONG − 0 + 1, in 32 bits: −2^31 — the draw is negative, shifted arithmetically
+        for k in range(5):
+            if 5 * g + k < hi:
+                chars[:, 5 * g + k] = alpha[(v >> (6 * k)) & 63]
+    mask = np.arange(hi)[None, :] < ln[:, None]
+    offs = np.zeros(n + 1, np.int32)
+    offs[1:] = np.cumsum(ln)
+    return pa.Array.from_buffers(pa.utf8(), n, [None, pa.py_buffer(offs.tobytes()), pa.py_buffer(chars[mask].tobytes())])
+
+
 def supplier(sf: int = 1) -> pa.Table:
-    """s_suppkey, s_nationkey (mk_supp: one draw of S_NTRG per supplier)"""
+    """s_suppkey, s_nationkey, s_name, s_address, s_phone, s_acctbal, s_complaints (mk_supp: the address is V_STR(25) over S_ADDR — nine draws per supplier at most —,
+    one draw of S_NTRG, gen_phone over S_PHNE, one draw of S_ABAL; the comment is text this module does not restate, but whether it carries "Customer … Complaints"
+    — all Q16 asks of it — is two draws of their own: BBB_CMNT ≤ 10 of 10 000 marks the supplier, BBB_TYPE < 50 of 0 … 100 makes it Complaints rather than Recommends)"""
     n = 10_000 * sf
     nat, _ = _draw(_stream_starts(SEED["S_NTRG"], n, 1), 0, 24)
-    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), pa.array(nat.astype(np.int32)), pa.array(["Supplier#%09d" % k for k in range(1, n + 1)])],
-                    names=["s_suppkey", "s_nationkey", "s_name"])
+    ph = _stream_starts(SEED["S_PHNE"], n, 3)
+    area, ph = _draw(ph, 100, 999)
+    exch, ph = _draw(ph, 100, 999)
+    num, ph = _draw(ph, 1000, 9999)
+    phones = pa.array(["%02d-%03d-%03d-%04d" % t for t in zip((10 + nat).tolist(), area.tolist(), exch.tolist(), num.tolist())])
+    bal, _ = _draw(_stream_starts(SEED["S_ABAL"], n, 1), -99999, 999999)
+    bad, _ = _draw(_stream_starts(SEED["BBB_CMNT"], n, 1), 1, 10000)
+    kind, _ = _draw(_stream_starts(SEED["BBB_TYPE"], n, 1), 0, 100)
+    return pa.table([pa.array(np.arange(1, n + 1, dtype=np.int64)), pa.array(nat.astype(np.int32)), pa.array(["Supplier#%09d" % k for k in range(1, n + 1)]),
+                     _v_str(SEED["S_ADDR"], n, 25, 9), phones, _dec(bal, 12, 2), pa.array((bad <= 10) & (kind < 50))],
+                    names=["s_suppkey", "s_nationkey", "s_name", "s_address", "s_phone", "s_acctbal", "s_complaints"])
+
+
+def part_names(sf: int = 1) -> pa.Array:
+    """p_name: agg_str over the colors — the identity permutation of the 92 words is shuffled by 92 draws of P_NAME (swap entry i with a draw of [i, 91]) and the
+    name is the first five words; entry i is final after step i, so five steps per part give the name"""
+    n, nc = 200_000 * sf, len(COLORS)
+    perm = np.tile(np.arange(nc, dtype=np.int16), (n, 1))
+    st = _stream_starts(SEED["P_NAME"], n, nc)
+    rows = np.arange(n)
+    for i in range(5):
+        src, st = _draw(st, i, nc - 1)
+        a, b = perm[rows, src].copy(), perm[rows, i].copy()
+        perm[rows, src], perm[rows, i] = b, a
+    words = np.array(COLORS, dtype=object)
+    first = words[perm[:, :5]]
+    return pa.array([" ".join(r) for r in first.tolist()])
 
 
 def part(sf: int = 1) -> pa.Table:

@@ -3,6 +3,7 @@ Python's backtracking engine on the syntax both read alike — the reference's o
 RLIKE patterns), documented Spark examples, UTF-8 text, anchors, counted repetitions, classes, and a randomised comparison over generated
 patterns and strings.  Constructs the reference's `regex` crate reads in a Unicode-aware way (\\d \\w \\s \\b, scoped flags …) must be REFUSED; a leading (?i) is
 reproduced through Unicode simple case folding (K / KELVIN SIGN, s / LONG S)."""
+import os
 import random
 import re
 
@@ -95,7 +96,7 @@ def test_random_patterns_against_the_backtracking_engine(built):
     quant = ["", "", "", "*", "+", "?", "{2}", "{1,2}", "{0,3}"]
     alphabet = ["a", "b", "c", ".", "é", "\n", "x"]
     refused = 0
-    for _ in range(400):
+    for _ in range(400 if os.environ.get("COMET_SLOW_TESTS") else 150):      # (every call compiles its pattern: 13 ms)
         body = "".join(rnd.choice(atoms) + rnd.choice(quant) for _ in range(rnd.randint(1, 5)))
         if rnd.random() < 0.3:
             body = body + "|" + "".join(rnd.choice(atoms) for _ in range(rnd.randint(1, 3)))

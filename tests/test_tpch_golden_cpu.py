@@ -1,5 +1,5 @@
-"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q11 / Q12 / Q14 / Q17 / Q18 / Q19 / Q21 / Q22, as recorded in
-spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,11,12,14,17,18,19,21,22}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
+"""The CPU oracle against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q9 / Q11 / Q12 / Q14 / Q15 / Q16 / Q17 / Q18 / Q19 / Q20 / Q21 / Q22, as recorded in
+spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,9,11,12,14,15,16,17,18,19,20,21,22}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/).  The tables are
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py: dbgen itself is not in the reference's tree, its algorithm is
 restated and pinned by exactly these files); the oracle evaluates the same plans the GPU tests run (tests/test_tpch_golden_gpu.py)."""
 import datetime
@@ -70,10 +70,24 @@ def test_q3_oracle_gives_the_references_answer(sf1):
     assert q3_rows(parallel.q3_top10(final)) == dbgen.parse_golden(os.path.join(GOLD, "q3.sql.out"))
 
 
+_inputs_of = {}
+
+
 def _more_inputs(sf1):
+    """query → its input tables in scan order (built once per generated data set; the larger ones on first use)"""
+    if id(sf1) not in _inputs_of:
+        _inputs_of.clear()
+        _inputs_of[id(sf1)] = _build_inputs(sf1)
+    return _inputs_of[id(sf1)]
+
+
+def _build_inputs(sf1):
+    import pyarrow as pa
     customer, orders, lineitem = sf1
     o2, li, pt = more_layout(orders, lineitem, dbgen.part(1))
     sp_all = dbgen.supplier(1)
+    psupp = dbgen.partsupp(1)
+    names = lambda: pa.table([pt["p_partkey"], dbgen.part_names(1)], names=["p_partkey", "p_name"])
     cn, sp = customer.select(["c_custkey", "c_nationkey"]), sp_all.select(["s_suppkey", "s_nationkey"])
     late = lineitem.select(["l_orderkey", "l_suppkey", "l_commitdate", "l_receiptdate"])
     lq = lineitem.select(["l_orderkey", "l_quantity"])
@@ -85,12 +99,19 @@ def _more_inputs(sf1):
                lineitem.select(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"])],
         "q8": [dbgen.region(), dbgen.nation(), cn, orders.select(["o_orderkey", "o_custkey", "o_orderdate"]), dbgen.nation(), sp, pt,
                lineitem.select(["l_orderkey", "l_partkey", "l_suppkey", "l_extendedprice", "l_discount"])],
-        "q11": [dbgen.nation(), sp, dbgen.partsupp(1)],
+        "q11": [dbgen.nation(), sp, psupp],
         "q12": [o2, li], "q14": [li, pt], "q19": [li, pt],
         "q17": [pt, lineitem.select(["l_partkey", "l_quantity"]), pt, lineitem.select(["l_partkey", "l_quantity", "l_extendedprice"])],
         "q18": [lq, orders.select(["o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"]), customer.select(["c_custkey", "c_name"]), lq],
-        "q21": [dbgen.nation(), sp_all, late, orders.select(["o_orderkey", "o_orderstatus"]), lineitem.select(["l_orderkey", "l_suppkey"]), late],
+        "q21": [dbgen.nation(), sp_all.select(["s_suppkey", "s_nationkey", "s_name"]), late, orders.select(["o_orderkey", "o_orderstatus"]), lineitem.select(["l_orderkey", "l_suppkey"]), late],
         "q22": [customer.select(["c_custkey", "c_phone", "c_acctbal"]), orders.select(["o_custkey"])],
+        "q9": lambda: [dbgen.nation(), sp, names(),
+                       lineitem.select(["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"]), psupp,
+                       orders.select(["o_orderkey", "o_orderdate"])],
+        "q15": lambda: [sp_all.select(["s_suppkey", "s_name", "s_address", "s_phone"]), lineitem.select(["l_suppkey", "l_extendedprice", "l_discount", "l_shipdate"])],
+        "q16": lambda: [psupp.select(["ps_partkey", "ps_suppkey"]), sp_all.select(["s_suppkey", "s_complaints"]), pt],
+        "q20": lambda: [dbgen.nation(), sp_all.select(["s_suppkey", "s_nationkey", "s_name", "s_address"]), psupp,
+                        names(), lineitem.select(["l_partkey", "l_suppkey", "l_quantity", "l_shipdate"])],
     }
 
 
@@ -100,7 +121,20 @@ def golden_case(q, inputs, run_partial, run_final):
     import re
     from tests import test_tpch_more_gpu as M
     d = tpch.days
-    tb = inputs[q]
+    tb = inputs[q]() if callable(inputs[q]) else inputs[q]
+    mask = lambda tbl: [[re.sub(r"#\d+", "#x", str(v)) for v in r] for r in M.rows(tbl)]
+    if q == "q15":
+        # the view (Partial → Final), the scalar subquery over its rows (Partial → Final), then the outer query with the subquery's value as a literal
+        vp = M.q15_revenue_plan(d(1996, 1, 1), d(1996, 4, 1))
+        st = run_partial(vp, [tb[1]])
+        view = run_final(S.final_of(vp, st.schema), [st])
+        mp = M.q15_max_plan()
+        st = run_partial(mp, [view])
+        best = run_final(S.final_of(mp, st.schema), [st]).column(0)[0].as_py()
+        return mask(run_final(M.q15_top_plan(best), [tb[0], view])), dbgen.parse_golden(os.path.join(GOLD, "q15.sql.out"))
+    if q == "q20":
+        found = run_partial(M.q20_plan(d(1994, 1, 1), d(1995, 1, 1)), tb)
+        return mask(run_final(M.q20_sort_plan(), [found])), dbgen.parse_golden(os.path.join(GOLD, "q20.sql.out"))
     if q == "q11":
         import decimal
         tp = M.q11_partial_plan(grouped=False)
@@ -120,10 +154,10 @@ def golden_case(q, inputs, run_partial, run_final):
     else:
         partial = {"q4": lambda: M.q4_partial_plan(d(1993, 7, 1), d(1993, 10, 1)), "q5": lambda: M.q5_partial_plan(d(1994, 1, 1), d(1995, 1, 1)),
                    "q7": lambda: M.q7_partial_plan(d(1995, 1, 1), d(1996, 12, 31)), "q8": lambda: M.q8_partial_plan(d(1995, 1, 1), d(1996, 12, 31)),
-                   "q12": M.q12_partial_plan, "q17": M.q17_partial_plan, "q14": lambda: M.q14_partial_plan(d(1995, 9, 1), d(1995, 10, 1)), "q18": M.q18_partial_plan,
+                   "q9": M.q9_partial_plan, "q16": M.q16_partial_plan, "q12": M.q12_partial_plan, "q17": M.q17_partial_plan, "q14": lambda: M.q14_partial_plan(d(1995, 9, 1), d(1995, 10, 1)), "q18": M.q18_partial_plan,
                    "q19": lambda: M.q19_partial_plan(("AIR", "AIR REG")), "q21": M.q21_partial_plan}[q]()
     st = run_partial(partial, tb)
-    fplan = {"q4": M.q12_final_plan, "q5": M.q5_final_plan, "q7": M.q7_final_plan, "q8": M.q8_final_plan, "q12": M.q12_final_plan, "q14": M.q14_final_plan, "q17": M.q17_final_plan,
+    fplan = {"q9": M.q9_final_plan, "q16": M.q16_final_plan, "q4": M.q12_final_plan, "q5": M.q5_final_plan, "q7": M.q7_final_plan, "q8": M.q8_final_plan, "q12": M.q12_final_plan, "q14": M.q14_final_plan, "q17": M.q17_final_plan,
              "q18": M.q18_final_plan, "q19": lambda p_, sc: S.final_of(p_, sc), "q21": M.q21_final_plan, "q22": M.q12_final_plan}[q](partial, st.schema)
     final = run_final(fplan, [st])
     # (the reference's suite writes every "#<digits>" as "#x" into its result files: CometTPCHQuerySuite's normalisation)
@@ -132,7 +166,7 @@ def golden_case(q, inputs, run_partial, run_final):
 
 
 # Q18 (a Python aggregation over 1.5 M groups) and Q21 take the oracle a minute each: the GPU suite checks them against the same files
-@pytest.mark.parametrize("q", ["q4", "q5", "q7", "q8", "q11", "q12", "q14", "q17", "q19", "q22"] + (["q18", "q21"] if os.environ.get("COMET_SLOW_TESTS") else []))
+@pytest.mark.parametrize("q", ["q4", "q5", "q7", "q8", "q9", "q11", "q12", "q14", "q15", "q16", "q17", "q19", "q20", "q22"] + (["q18", "q21"] if os.environ.get("COMET_SLOW_TESTS") else []))
 def test_more_queries_oracle_gives_the_references_answers(sf1, q):
     run = lambda plan, tables: O.run_plan_to_arrow(S, plan, tables)
     got, want = golden_case(q, _more_inputs(sf1), run, run)

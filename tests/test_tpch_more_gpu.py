@@ -345,3 +345,93 @@ def test_q19_discounted_revenue(built):
                 tot += price * (1 - disc)
                 any_ = True
     assert got.column(0).to_pylist() == [tot if any_ else None] and any_
+
+
+# ---- plans the oracle runs against the reference's SF1 answers (tests/test_tpch_golden_cpu.py); the GPU suite takes them up once they have run on hardware ----
+
+def q9_partial_plan(word="green"):
+    """TPC-H Q9 up to the partial aggregate: the profit on the parts whose name holds a word, by the supplier's nation and the order's year.  Scan leaves in
+    order: nation, supplier[s_suppkey, s_nationkey], part[p_partkey, p_name], lineitem[l_orderkey, l_partkey, l_suppkey, l_quantity, l_extendedprice,
+    l_discount], partsupp[ps_partkey, ps_suppkey, ps_availqty, ps_supplycost], orders[o_orderkey, o_orderdate]"""
+    parts = S.project(S.filter_(S.scan([I64, STR]), S.like(c(1, STR), L("%" + word + "%"))), [c(0, I64)])
+    lp = S.project(S.hash_join(parts, S.scan([I64, I64, I64, D, D, D]), [c(0, I64)], [c(1, I64)], S.INNER, S.BUILD_LEFT),
+                   [c(1, I64), c(2, I64), c(3, I64), c(4, D), c(5, D), c(6, D)])                             # l_orderkey, l_partkey, l_suppkey, qty, price, disc
+    supn = S.project(S.hash_join(S.scan([I32, STR, I32]), S.scan([I64, I32]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(3, I64), c(1, STR)])        # s_suppkey, nation
+    j1 = S.project(S.hash_join(supn, lp, [c(0, I64)], [c(2, I64)], S.INNER, S.BUILD_LEFT), [c(2, I64), c(3, I64), c(4, I64), c(5, D), c(6, D), c(7, D), c(1, STR)])
+    # l_orderkey, l_partkey, l_suppkey, qty, price, disc, nation | ps_partkey, ps_suppkey, ps_availqty, ps_supplycost
+    j2 = S.project(S.hash_join(j1, S.scan([I64, I64, I32, D]), [c(1, I64), c(2, I64)], [c(0, I64), c(1, I64)], S.INNER, S.BUILD_RIGHT),
+                   [c(0, I64), c(3, D), c(4, D), c(5, D), c(6, STR), c(10, D)])                              # l_orderkey, qty, price, disc, nation, supplycost
+    j3 = S.hash_join(j2, S.scan([I64, DATE]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)               # … o_orderkey, o_orderdate
+    cost = S.check_overflow(S.math("multiply", c(5, D), c(1, D), S.decimal(25, 4)), S.decimal(25, 4))
+    A = S.decimal(27, 4)
+    amount = S.check_overflow(S.math("subtract", _revenue(c(2, D), c(3, D)), cost, A), A)
+    p = S.project(j3, [c(4, STR), S.date_part("year", c(7, DATE)), amount])
+    return S.hash_agg(p, [c(0, STR), c(1, I32)], [S.sum_(c(2, A), S.decimal(37, 4))], S.PARTIAL)
+
+
+def q9_final_plan(partial, state_schema):
+    return S.sort(S.final_of(partial, state_schema), [(c(0, STR), False, False), (c(1, I32), True, True)])
+
+
+def q15_revenue_plan(d0, d1):
+    """the view of TPC-H Q15 up to the partial aggregate: revenue by supplier over a quarter; input: lineitem[l_suppkey, l_extendedprice, l_discount, l_shipdate]"""
+    f = S.filter_(S.scan([I64, D, D, DATE]), S.and_(S.gt_eq(c(3, DATE), S.lit(d0, DATE)), S.lt(c(3, DATE), S.lit(d1, DATE))))
+    return S.hash_agg(S.project(f, [c(0, I64), _revenue(c(1, D), c(2, D))]), [c(0, I64)], [S.sum_(c(1, S.decimal(26, 4)), S.decimal(36, 4))], S.PARTIAL)
+
+
+def q15_max_plan():
+    """the scalar subquery of Q15: the largest revenue; input: the view's rows [supplier_no, total_revenue]"""
+    R = S.decimal(36, 4)
+    return S.hash_agg(S.scan([I64, R]), [], [S.max_(c(1, R), R)], S.PARTIAL)
+
+
+def q15_top_plan(best):
+    """Q15's outer query: the supplier(s) whose revenue equals `best` (what Spark puts in place of the subquery), by key.  Scan leaves in order:
+    supplier[s_suppkey, s_name, s_address, s_phone], the view's rows [supplier_no, total_revenue]"""
+    R = S.decimal(36, 4)
+    top = S.filter_(S.scan([I64, R]), S.eq(c(1, R), S.lit(best, R)))
+    j = S.hash_join(S.scan([I64, STR, STR, STR]), top, [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)
+    return S.sort(S.project(j, [c(0, I64), c(1, STR), c(2, STR), c(3, STR), c(5, R)]), [(c(0, I64), False, False)])
+
+
+def q16_partial_plan(brand="Brand#45", type_prefix="MEDIUM POLISHED", sizes=(49, 14, 23, 45, 19, 3, 36, 9)):
+    """TPC-H Q16 up to the partial aggregate of the outer count: suppliers without complaints (LeftAnti) per brand, type and size, each counted once — the
+    distinct count as Spark plans it, an aggregate over (brand, type, size, supplier) without functions under the counting one.  Scan leaves in order:
+    partsupp[ps_partkey, ps_suppkey], supplier[s_suppkey, s_complaints] (the outcome of s_comment LIKE '%Customer%Complaints%', see dbgen.supplier),
+    part[p_partkey, p_type, p_brand, p_container, p_size]"""
+    bad = S.project(S.filter_(S.scan([I64, S.T_BOOL]), c(1, S.T_BOOL)), [c(0, I64)])
+    ps = S.hash_join(S.scan([I64, I64]), bad, [c(1, I64)], [c(0, I64)], S.LEFT_ANTI, S.BUILD_RIGHT)
+    pf = S.filter_(S.scan([I64, STR, STR, STR, I32]), S.and_(S.and_(S.neq(c(2, STR), L(brand)), S.not_(S.like(c(1, STR), L(type_prefix + "%")))),
+                                                              S.in_(c(4, I32), [S.lit(int(x), I32) for x in sizes])))
+    j = S.hash_join(ps, S.project(pf, [c(0, I64), c(2, STR), c(1, STR), c(4, I32)]), [c(0, I64)], [c(0, I64)], S.INNER, S.BUILD_RIGHT)   # ps_partkey, ps_suppkey | p_partkey, brand, type, size
+    keys = S.project(j, [c(3, STR), c(4, STR), c(5, I32), c(1, I64)])
+    once_p = S.hash_agg(keys, [c(0, STR), c(1, STR), c(2, I32), c(3, I64)], [], S.PARTIAL)
+    once = S.hash_agg(once_p, [c(0, STR), c(1, STR), c(2, I32), c(3, I64)], [], S.FINAL)
+    return S.hash_agg(once, [c(0, STR), c(1, STR), c(2, I32)], [S.count(c(3, I64))], S.PARTIAL)
+
+
+def q16_final_plan(partial, state_schema):
+    return S.sort(S.final_of(partial, state_schema), [(c(3, I64), True, True), (c(0, STR), False, False), (c(1, STR), False, False), (c(2, I32), False, False)])
+
+
+def q20_plan(d0, d1, prefix="forest", nation_name="CANADA"):
+    """TPC-H Q20: the suppliers of a nation holding more of a part whose name starts with a word than half of what they shipped of it in a year (the
+    correlated sum: a Final over a Partial aggregate by part and supplier inside the plan, joined back with the comparison as the residual condition).
+    Scan leaves in order: nation, supplier[s_suppkey, s_nationkey, s_name, s_address], partsupp[ps_partkey, ps_suppkey, ps_availqty, ps_supplycost],
+    part[p_partkey, p_name], lineitem[l_partkey, l_suppkey, l_quantity, l_shipdate]"""
+    D22, H = S.decimal(22, 2), S.decimal(24, 3)
+    nat = S.project(S.filter_(S.scan([I32, STR, I32]), S.eq(c(1, STR), L(nation_name))), [c(0, I32)])
+    sup = S.project(S.hash_join(nat, S.scan([I64, I32, STR, STR]), [c(0, I32)], [c(1, I32)], S.INNER, S.BUILD_LEFT), [c(1, I64), c(3, STR), c(4, STR)])       # s_suppkey, s_name, s_address
+    parts = S.project(S.filter_(S.scan([I64, STR]), S.like(c(1, STR), L(prefix + "%"))), [c(0, I64)])
+    stock = S.project(S.hash_join(S.scan([I64, I64, I32, D]), parts, [c(0, I64)], [c(0, I64)], S.LEFT_SEMI, S.BUILD_RIGHT), [c(0, I64), c(1, I64), c(2, I32)])   # ps_partkey, ps_suppkey, ps_availqty
+    f = S.filter_(S.scan([I64, I64, D, DATE]), S.and_(S.gt_eq(c(3, DATE), S.lit(d0, DATE)), S.lt(c(3, DATE), S.lit(d1, DATE))))
+    sold_p = S.hash_agg(S.project(f, [c(0, I64), c(1, I64), c(2, D)]), [c(0, I64), c(1, I64)], [S.sum_(c(2, D), D22)], S.PARTIAL)
+    sold = S.hash_agg(sold_p, [c(0, I64), c(1, I64)], sold_p.aggs, S.FINAL)                                   # l_partkey, l_suppkey, sum(l_quantity)
+    half = S.project(sold, [c(0, I64), c(1, I64), S.check_overflow(S.math("multiply", S.lit(decimal.Decimal("0.5"), S.decimal(1, 1)), c(2, D22), H), H)])
+    more = S.gt(S.cast(S.cast(c(2, I32), S.decimal(10, 0)), H), c(5, H))                                      # (left ++ right: ps_partkey, ps_suppkey, ps_availqty | l_partkey, l_suppkey, half)
+    holders = S.project(S.hash_join(stock, half, [c(0, I64), c(1, I64)], [c(0, I64), c(1, I64)], S.INNER, S.BUILD_RIGHT, condition=more), [c(1, I64)])
+    return S.project(S.hash_join(sup, holders, [c(0, I64)], [c(0, I64)], S.LEFT_SEMI, S.BUILD_RIGHT), [c(1, STR), c(2, STR)])
+
+
+def q20_sort_plan():
+    return S.sort(S.scan([STR, STR]), [(c(0, STR), False, False)])
