@@ -1,5 +1,5 @@
-"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q11 / Q12 / Q14 / Q17 / Q18 / Q19 / Q21 / Q22 — the numbers in
-spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,11,12,14,17,18,19,21,22}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
+"""The GPU path against the reference's OWN golden answers: TPC-H scale factor 1, Q1 / Q3 / Q6 / Q4 / Q5 / Q7 / Q8 / Q9 / Q11 / Q12 / Q14 / Q15 / Q16 / Q17 / Q18 / Q19 / Q20 / Q21 / Q22 — the numbers in
+spark/src/test/resources/tpch-query-results/q{1,3,4,5,6,7,8,9,11,12,14,15,16,17,18,19,20,21,22}.sql.out of apache/datafusion-comet (copies under tests/golden/tpch_sf1/), over tables
 regenerated with dbgen's random streams (datafusion-comet_amd/dbgen.py; tests/test_tpch_golden_cpu.py pins the generator and the oracle on
 the same files).  Q6 goes in through Parquet (snappy and zstd, pages inflated on the device, and the host path), Q1 and Q3 over
 HBM-resident columns; every stage runs through the C ABI, the Final aggregates included."""
@@ -79,5 +79,25 @@ def test_more_queries_give_the_references_answers(built, sf1, q):
     def run_final(plan, tables):
         n = 1 if (q in ("q22", "q11") and state["n"] == 1) else ncols[1]
         return M.run(plan, tables, n)
+    got, want = golden_case(q, _more_inputs(sf1), run_partial, run_final)
+    assert got == want
+
+
+@pytest.mark.parametrize("q", ["q9", "q15", "q16", "q20"])
+def test_queries_with_generated_names_and_addresses_give_the_references_answers(built, sf1, q):
+    """Q9 (part names), Q15 (a view aggregated twice, printed addresses and phones), Q16 (a distinct count as two aggregates, 18 314 rows) and Q20 (a correlated
+    sum joined back); output columns of each stage in the order golden_case runs them"""
+    from tests import test_tpch_more_gpu as M
+    from tests.test_tpch_golden_cpu import _more_inputs, golden_case
+    partial_cols, final_cols = {"q9": ([4], [3]), "q15": ([3, 1], [2, 1, 5]), "q16": ([4], [4]), "q20": ([2], [2])}[q]
+    calls = {"p": 0, "f": 0}
+
+    def run_partial(plan, tables):
+        calls["p"] += 1
+        return M.run(plan, tables, partial_cols[calls["p"] - 1])
+
+    def run_final(plan, tables):
+        calls["f"] += 1
+        return M.run(plan, tables, final_cols[calls["f"] - 1])
     got, want = golden_case(q, _more_inputs(sf1), run_partial, run_final)
     assert got == want

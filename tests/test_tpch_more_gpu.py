@@ -347,7 +347,7 @@ def test_q19_discounted_revenue(built):
     assert got.column(0).to_pylist() == [tot if any_ else None] and any_
 
 
-# ---- plans the oracle runs against the reference's SF1 answers (tests/test_tpch_golden_cpu.py); the GPU suite takes them up once they have run on hardware ----
+# ---- plans run against the reference's SF1 answers only (tests/test_tpch_golden_cpu.py on the oracle, tests/test_tpch_golden_gpu.py on the GPU) ----
 
 def q9_partial_plan(word="green"):
     """TPC-H Q9 up to the partial aggregate: the profit on the parts whose name holds a word, by the supplier's nation and the order's year.  Scan leaves in
