@@ -518,6 +518,104 @@ ZS_FN u32 seq_step(BB& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, bool l
   c.done++;
   return (!rep && off <= 0) ? (u32)ST_ERR_OFFSET : (u32)ST_OK;
 }
+// ---- the sequence kernel's reader and step.  seq_step above keeps a 192-bit register window alive (three 64-bit registers stepping down by
+// selects, two 128-bit funnel shifts per window): ≈ 170 instructions per sequence in the gfx950 code, and a serial lane is bound by the
+// instructions it issues.  Here NOTHING of the stream is carried between fields: the cursor is a bit position, and the 64 bits below any
+// bit position are three aligned words of the block's window in workgroup memory, funnel-shifted (v_alignbit_b32) — the loads of a
+// step's two windows (values; states) are issued together right behind the table loads. ----
+ZS_FN u32 funnel32(u32 hi, u32 lo, u32 sh) { return (u32)((((u64)hi << 32) | (u64)lo) >> (sh & 31u)); }        // (hi:lo) >> sh, sh < 32
+// the top n bits of a word, n ≤ 31 (n = 0 → 0): one bit-field extract on the device
+#if defined(__HIP_DEVICE_COMPILE__)
+ZS_FN u32 top_field(u32 h, u32 n) { return __builtin_amdgcn_ubfe(h, 32u - n, n); }
+#else
+ZS_FN u32 top_field(u32 h, u32 n) { return n ? h >> (32u - n) : 0u; }
+#endif
+// a choice that must compile to a select: lanes of a wave decode different blocks, a branch that one lane takes is paid by all of them
+#if defined(__clang__)
+#define ZS_SEL(c, a, b) (__builtin_unpredictable(c) ? (a) : (b))
+#else
+#define ZS_SEL(c, a, b) ((c) ? (a) : (b))
+#endif
+struct SeqBits {
+  ZS_LDS u32* w;           // kRing / 4 + 2 words: the window, its first two words repeated behind its last (seq_fill_done)
+  u32 bias8;               // stream bit b sits at window bit b + bias8 + 64 (the 64: a window starts two words below its top word)
+  i32 bitpos;              // bits left: the next field ends just below stream bit `bitpos`
+  ZS_FN u64 below(i32 top) const {               // the 64 stream bits below bit `top`, the highest on top
+    const u32 t = (u32)top + bias8;              // (a cursor that ran below the stream's first bit wraps — in the window too: reads stay inside it)
+    const u32 q = (t >> 5) & (u32)(kRing / 4 - 1);
+    const u32 d0 = w[q], d1 = w[q + 1], d2 = w[q + 2];
+    return ((u64)funnel32(d2, d1, t) << 32) | (u64)funnel32(d1, d0, t);
+  }
+  ZS_FN u32 get(u32 n) {                         // n ≤ 31
+    const u32 v = top_field((u32)(below(bitpos) >> 32), n);
+    bitpos -= (i32)n;
+    return v;
+  }
+  ZS_FN bool init(ZS_LDS u32* ring, u32 bias, u32 len) {
+    w = ring;
+    bias8 = 8u * bias - 64u;
+    bitpos = 0;
+    if (len == 0) return false;
+    const u32 at = (len - 1u + bias) & (kRing - 1);
+    const u32 last = (w[at >> 2] >> (8u * (at & 3u))) & 0xffu;
+    if (last == 0) return false;
+    bitpos = 8 * ((i32)len - 1) + highbit(last);
+    return true;
+  }
+  ZS_FN i32 cursor_byte() const { return bitpos > 0 ? (bitpos + 7) >> 3 : 0; }
+};
+ZS_FN void seq_begin_ring(SeqBits& b, SeqCore& c, int lll, int lof, int lml) {
+  c.sll = b.get((u32)lll);
+  c.sof = b.get((u32)lof);
+  c.sml = b.get((u32)lml);
+  c.r0 = rep_symbolic(0);
+  c.r1 = rep_symbolic(1);
+  c.r2 = rep_symbolic(2);
+  c.sum_ll = c.sum_ml = 0;
+  c.done = 0;
+}
+// the next sequence; `worst`: the smallest new offset seen (≤ 0: one was invalid — the caller looks once per round: no branch in here)
+template <class TabPtr>
+ZS_FN void seq_step_ring(SeqBits& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, bool last, u32& ll, u32& ml, i32& off, i32& worst) {
+  const u32 lb = tll[2 * c.sll], lh = tll[2 * c.sll + 1];
+  const u32 ob = tof[2 * c.sof], oh = tof[2 * c.sof + 1];
+  const u32 mb = tml[2 * c.sml], mh = tml[2 * c.sml + 1];
+  const u32 oe = (oh >> 8) & 0xffu, me = (mh >> 8) & 0xffu, le = (lh >> 8) & 0xffu;
+  const u32 ln = lh & 0xffu, mn = mh & 0xffu, on = oh & 0xffu;
+  const u32 values = oe + me + le, states = ZS_SEL(last, 0u, ln + mn + on);       // ≤ 31 + 16 + 16; ≤ 9 + 9 + 8
+  u64 wv = b.below(b.bitpos), ws = b.below(b.bitpos - (i32)values);
+  b.bitpos -= (i32)(values + states);
+  const u32 ov = ob + top_field((u32)(wv >> 32), oe);
+  wv <<= oe;
+  ml = mb + top_field((u32)(wv >> 32), me);
+  wv <<= me;
+  ll = lb + top_field((u32)(wv >> 32), le);
+  c.sll = (lh >> 16) + top_field((u32)(ws >> 32), ln);     // (behind the last sequence: never looked at, and nothing is consumed for them)
+  ws <<= ln;
+  c.sml = (mh >> 16) + top_field((u32)(ws >> 32), mn);
+  ws <<= mn;
+  c.sof = (oh >> 16) + top_field((u32)(ws >> 32), on);
+  // The repeat-offset rules of seq_step, every candidate computed, every choice a select: a value > 3 is a new offset (pushed onto the
+  // history), 1 … 3 names an entry (shifted by one when there are no literals, the fourth choice being "the newest entry minus one"),
+  // which moves to the front
+  const bool rep = ov <= 3u;
+  const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
+  const i32 r0 = c.r0, r1 = c.r1, r2 = c.r2, less = r0 + ZS_SEL(r0 > 0, -1, -3);
+  i32 picked = ZS_SEL(idx == 2u, r2, less);
+  picked = ZS_SEL(idx == 1u, r1, picked);
+  picked = ZS_SEL(idx == 0u, r0, picked);
+  off = ZS_SEL(rep, picked, (i32)(ov - 3u));
+  const bool front = rep & (idx == 0u), second = rep & (idx <= 1u);
+  c.r2 = ZS_SEL(second, r2, r1);
+  c.r1 = ZS_SEL(front, r1, r0);
+  c.r0 = off;                                                // (front: off IS r0)
+  const i32 fresh = ZS_SEL(rep, 1, off);
+  worst = fresh < worst ? fresh : worst;
+  c.sum_ll += ll;
+  c.sum_ml += ml;
+  c.done++;
+}
+
 // ---- kernel A1: the literals of one block — one 64-thread workgroup.  Threads 0 … 3 decode a Huffman stream each, 256 symbols a round,
 // out of their stream's window in workgroup memory into a buffer there; between rounds ALL threads slide the windows and write the
 // buffers out.  Raw / RLE literals (and raw / RLE blocks) are copied or filled by all threads. ----
@@ -647,7 +745,7 @@ constexpr int kSeqGroup = 64 / kSeqLanes;         // threads per block's group
 constexpr u32 kSeqRound = 32;
 struct SeqLds {
   u32 fse_ll[kSeqLanes][1024], fse_of[kSeqLanes][512], fse_ml[kSeqLanes][1024];     // two words per state (seq_table_expand); offsets: log ≤ 8
-  u32 ring[kSeqLanes][kRing / 4];
+  u32 ring[kSeqLanes][kRing / 4 + 2];   // (+ 2: the first two words again, so that three words in a row never wrap)
   u32 rbuf[kSeqLanes][kSeqRound][3];    // ll, ml, off
   u32 llc[36], mlc[53];                 // the literal-length / match-length codes' (base | extra bits << 24)
   u8 hdr[kSeqLanes][3][128];            // the table descriptions, staged (a description is at most 53 counts of ≤ 10 bits)
@@ -660,7 +758,7 @@ struct SeqLds {
   u32 rounds[kSeqLanes];
   u32 status[kSeqLanes];
 };
-struct SeqState { RingReader b; SeqCore c; };
+struct SeqState { SeqBits b; SeqCore c; };
 ZS_FN bool seq_block_has_stream(const ZBlock& b) { return b.type == BT_COMPRESSED && b.nseq > 0; }
 ZS_FN u32 seq_rounds(const ZBlock& b) { return seq_block_has_stream(b) ? (b.nseq + kSeqRound - 1) / kSeqRound : 0; }
 // k: the block's group (0 … 3), tt: the thread within the group (0 … 15); "the group's thread" = its thread 0
@@ -698,29 +796,30 @@ ZS_FN void seq_fill(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, i32
 ZS_FN void seq_fill_done(ZS_LDS SeqLds* L, int k) {          // (the group's thread, behind the barrier that follows seq_fill)
   const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
   if (want < L->low[k]) L->low[k] = want;
+  L->ring[k][kRing / 4] = L->ring[k][0];
+  L->ring[k][kRing / 4 + 1] = L->ring[k][1];
 }
 ZS_FN void seq_start(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {        // the group's thread, behind the first fill
-  RingBytes<ZS_LDS u32*, false> src;
-  src.w = (ZS_LDS u32*)L->ring[k];
-  src.bias = L->bias[k];
   if (L->status[k]) return;
-  if (!st.b.init(src, b.bits_len)) { L->status[k] = ST_ERR_BITS; return; }
-  seq_begin(st.b, st.c, L->fse_log[k][0], L->fse_log[k][1], L->fse_log[k][2]);
+  if (!st.b.init((ZS_LDS u32*)L->ring[k], L->bias[k], b.bits_len)) { L->status[k] = ST_ERR_BITS; return; }
+  seq_begin_ring(st.b, st.c, L->fse_log[k][0], L->fse_log[k][1], L->fse_log[k][2]);
 }
 // the group's thread: the block's next ≤ 32 sequences into rbuf
 ZS_FN void seq_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
   L->rcount[k] = 0;
   if (L->status[k] || !seq_block_has_stream(b)) return;
-  const u32 left = b.nseq - st.c.done, n = left < kSeqRound ? left : kSeqRound;
+  const u32 nseq = b.nseq, left = nseq - st.c.done, n = left < kSeqRound ? left : kSeqRound;
+  i32 worst = 1;
   for (u32 i = 0; i < n; i++) {
     u32 ll, ml;
     i32 off;
-    const u32 rc = seq_step(st.b, st.c, (ZS_LDS u32*)L->fse_ll[k], (ZS_LDS u32*)L->fse_of[k], (ZS_LDS u32*)L->fse_ml[k], st.c.done + 1 == b.nseq, ll, ml, off);
-    if (rc != ST_OK) { L->status[k] = rc; return; }
+    seq_step_ring(st.b, st.c, (ZS_LDS u32*)L->fse_ll[k], (ZS_LDS u32*)L->fse_of[k], (ZS_LDS u32*)L->fse_ml[k], st.c.done + 1 == nseq, ll, ml, off, worst);
     L->rbuf[k][i][0] = ll;
     L->rbuf[k][i][1] = ml;
     L->rbuf[k][i][2] = (u32)off;
   }
+  if (worst <= 0) { L->status[k] = ST_ERR_OFFSET; return; }
+  if (st.b.bitpos < 0) { L->status[k] = ST_ERR_BITS; return; }           // the stream ran out: nothing more to decode from it
   L->rcount[k] = n;
   L->cursor[k] = st.b.cursor_byte();
 }
