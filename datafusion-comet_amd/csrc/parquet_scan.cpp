@@ -2048,6 +2048,13 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   };
   struct Deferred { size_t c; std::shared_ptr<ColumnDevice> cd; size_t S; bool may_inflate; std::shared_ptr<PinnedBuf> readback; hipEvent_t done; std::vector<const uint8_t*> at; };
   std::vector<Deferred> deferred;
+  // (an error thrown while read-backs are in flight: they land in pinned staging memory that goes back to its pool — wait for them first)
+  struct ReadbackGuard {
+    hipStream_t s;
+    const std::vector<Deferred>& d;
+    bool done = false;
+    ~ReadbackGuard() { if (!done && !d.empty()) (void)hipStreamSynchronize(s); }
+  } readback_guard{stream_, deferred};
   for (size_t oi = 0; oi < ncol; oi++) {
     const size_t c = order[oi];
     const ColumnPlan& cp = plans[c];
@@ -2243,6 +2250,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     if (trace) fprintf(stderr, "[comet] parquet: column %zu run headers parsed at %.2f ms\n", d.c, ms_since());
     finish_column(d.c, d.cd, d.S, d.may_inflate);
   }
+  readback_guard.done = true;
   // Hive partition columns: one constant per file (SparkPartitionedFile.partition_values, operator.proto:103-109), appended after
   // the file columns (planner.rs:1558-1575); a NULL partition value clears the validity of its rows
   for (size_t p = 0; p < npart; p++) {
