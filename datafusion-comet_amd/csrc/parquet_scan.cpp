@@ -732,7 +732,11 @@ size_t staged_capacity(const pq::ColumnMeta& cm) {
 // offsets into the device-decompressed region carry this bit until the column's tables are assembled
 constexpr int64_t kInflatedBit = (int64_t)1 << 62;
 constexpr int32_t kMinDevicePage = 4096;
-constexpr double kDeviceZstdBytesPerMs = 24.8e6;    // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 20.3 ms (profiles/r3_zstd_pipeline.json)
+constexpr double kDeviceZstdBytesPerMs = 31.0e6;    // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 16.1 ms (profiles/r3_zstd_pipeline_lean_step.json)
+// … and what the scan threads still do for a device-inflated zstd page (read it, walk its frame, decode the levels' prefix), and what they do when they inflate it
+// themselves — SF10 Q6 from zstd Parquet, profiles/r3_parquet_q6_zstd_dict.txt: 60 ms for 495 MB of PLAIN pages on one thread; 280 ms of thread time for the file's
+// 661 MB.  With these the device path wins below about ten scan threads (measured: 97 vs 290 ms with one, 38 vs 29 ms with sixteen)
+constexpr double kZstdWalkBytesPerMs = 8.0e6, kHostZstdBytesPerMs = 2.2e6;
 
 // DELTA_BYTE_ARRAY pages are prefix-compressed: what they decode to is only known from their length blocks.  One extra pass over such a
 // chunk (read, decompress, decode the two length blocks of every page) sizes its staging slot; nothing else pays for it.
@@ -1711,17 +1715,12 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (so.device_snappy_mode >= 0) {
     so.device_snappy = so.device_snappy_mode != 0;
   } else {
-    const double host_ms = (double)(plain_snappy_bytes + plain_zstd_bytes) / 1e6 / (double)host_threads;
-    const double device_ms = 0.5 + (double)plain_snappy_bytes / 60e6 + (plain_zstd_bytes ? 1.0 + (double)plain_zstd_bytes / kDeviceZstdBytesPerMs : 0.0);
-    so.device_snappy = plain_snappy_bytes + plain_zstd_bytes > 0 && device_ms < host_ms;
-    // the two codecs decide separately when both are there: snappy pages by the pipeline's rate alone
-    if (!so.device_snappy && plain_snappy_bytes > 0 && 0.5 + (double)plain_snappy_bytes / 60e6 < (double)plain_snappy_bytes / 1e6 / (double)host_threads) {
-      so.device_snappy = true;
-      so.device_zstd = false;
-    } else if (so.device_snappy && plain_zstd_bytes > 0 && getenv("COMET_DEVICE_ZSTD") == nullptr &&
-               1.0 + (double)plain_zstd_bytes / kDeviceZstdBytesPerMs >= (double)plain_zstd_bytes / 1e6 / (double)host_threads) {
-      so.device_zstd = false;
-    }
+    // the two codecs decide separately: snappy pages by the pipeline's rate against ~1 GB/s per host thread, zstd pages by the model above
+    const double T = (double)host_threads, sb = (double)plain_snappy_bytes, zb = (double)plain_zstd_bytes;
+    const bool snappy_on_device = plain_snappy_bytes > 0 && 0.5 + sb / 60e6 < sb / 1e6 / T;
+    const bool zstd_on_device = plain_zstd_bytes > 0 && so.device_zstd && 1.0 + zb / kDeviceZstdBytesPerMs + zb / kZstdWalkBytesPerMs / T < zb / kHostZstdBytesPerMs / T;
+    so.device_snappy = snappy_on_device || zstd_on_device;
+    if (!zstd_on_device && getenv("COMET_DEVICE_ZSTD") == nullptr) so.device_zstd = false;
   }
   if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy / %.1f MB of zstd pages of fixed-width columns, decompressed on the %s%s\n", (double)plain_snappy_bytes / 1e6,
                      (double)plain_zstd_bytes / 1e6, so.device_snappy ? "device" : "host", so.device_snappy && plain_zstd_bytes && !so.device_zstd ? " (zstd: host)" : "");

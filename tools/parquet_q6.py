@@ -31,6 +31,7 @@ def main():
     import pyarrow as pa
     import pyarrow.parquet as papq
     from datafusion_comet_amd import native, serde as S, tpch
+    os.makedirs(a.dir, exist_ok=True)
     path = os.path.join(a.dir, f"lineitem_q6_{a.rows}_{a.codec}{'_plain' if a.no_dictionary else ''}{'_clustered' if a.clustered else ''}.parquet")
     table = tpch.lineitem_q6(a.rows, seed=6)
     if a.clustered:
