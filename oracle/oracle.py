@@ -98,7 +98,15 @@ class Col:
         return len(self.values)
 
     def ok(self) -> np.ndarray:
-        return np.ones(len(self.values), bool) if self.valid is None else self.valid
+        if self.valid is not None:
+            return self.valid
+        # (all valid: one read-only array of ones per column, not one per call — row loops ask for every row)
+        o = self.__dict__.get("_all_ok")
+        if o is None or len(o) != len(self.values):
+            o = np.ones(len(self.values), bool)
+            o.flags.writeable = False
+            self.__dict__["_all_ok"] = o
+        return o
 
 
 def _np_dtype(S, t):
@@ -119,7 +127,9 @@ def col_from_arrow(S, arr: pa.Array, t) -> Col:
     elif t.type_id == S.BOOL:
         vals = np.array(arr.fill_null(False).to_numpy(zero_copy_only=False), dtype=bool)
     elif t.type_id == S.STRING:
-        vals = np.array(arr.to_pylist(), dtype=object)
+        vals = arr.to_numpy(zero_copy_only=False)       # an object array of str (None in NULL slots)
+        if vals.dtype != object:
+            vals = vals.astype(object)
     else:
         nt = _np_dtype(S, t)
         buf = arr.buffers()[1]
@@ -533,6 +543,17 @@ class Evaluator:
         if a.dtype.type_id in (S.STRING, S.BYTES):
             # byte-wise unsigned lexicographic order of the UTF-8 encodings (Spark UTF8String.compareTo, arrow-ord string kernels);
             # NULL slots hold None: compare as empty, the validity mask removes them later
+            if a.dtype.type_id == S.STRING and len(x) and isinstance(x[0], (str, type(None))) and isinstance(y[0], (str, type(None))):
+                # str against str: Python orders strings by code point, which is the byte order of their UTF-8 encodings — numpy's
+                # object loops instead of one Python call per row (the TPC-H golden tests compare tens of millions of strings)
+                xn, yn = np.equal(x, None), np.equal(y, None)
+                xs = np.where(xn, "", x) if xn.any() else x
+                ys = np.where(yn, "", y) if yn.any() else y
+                try:
+                    r = {"eq": np.equal, "neq": np.not_equal, "lt": np.less, "lt_eq": np.less_equal, "gt": np.greater, "gt_eq": np.greater_equal}[k](xs, ys)
+                    return np.asarray(r, dtype=bool)
+                except TypeError:
+                    pass               # (a column that mixes str and bytes: the general path below)
             enc = lambda v: b"" if v is None else (v.encode() if isinstance(v, str) else bytes(v))
             xs, ys = [enc(v) for v in x], [enc(v) for v in y]
             f = {"eq": lambda p, q: p == q, "neq": lambda p, q: p != q, "lt": lambda p, q: p < q, "lt_eq": lambda p, q: p <= q,
@@ -1124,6 +1145,36 @@ def _key_tuple(S, cols: List[Col], i: int):
     return tuple(t)
 
 
+def _join_pairs_sorted(lk: List[Col], rk: List[Col], nl: int, nr: int):
+    """the matching (left row, right row) pairs of an equi-join on integer-like keys, in the order the dictionary loop below gives them
+    (left rows in order, each one's matches by ascending right row) — by a stable sort of the right keys and two binary searches per left
+    row instead of one Python call per row (the TPC-H SF1 tests join millions of rows); → None for other key types.  NULL never matches."""
+    if not lk or not all(c.values.dtype.kind in "iub" for c in lk + rk):
+        return None
+    lok, rok = np.ones(nl, bool), np.ones(nr, bool)
+    for c in lk:
+        lok &= c.ok()
+    for c in rk:
+        rok &= c.ok()
+    if len(lk) == 1:
+        a, b = lk[0].values.astype(np.int64), rk[0].values.astype(np.int64)
+    else:           # several keys: one id per distinct key tuple over both sides
+        rows = np.concatenate([np.stack([c.values.astype(np.int64) for c in lk], axis=1), np.stack([c.values.astype(np.int64) for c in rk], axis=1)])
+        _, inv = np.unique(rows, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        a, b = inv[:nl], inv[nl:]
+    rrows = np.nonzero(rok)[0]
+    order = rrows[np.argsort(b[rrows], kind="stable")]
+    bs = b[order]
+    lo, hi = np.searchsorted(bs, a, "left"), np.searchsorted(bs, a, "right")
+    cnt = np.where(lok, hi - lo, 0)
+    total = int(cnt.sum())
+    li = np.repeat(np.arange(nl, dtype=np.int64), cnt)
+    within = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    ri = order[np.repeat(lo, cnt) + within].astype(np.int64) if total else np.zeros(0, np.int64)
+    return li, ri
+
+
 def _hash_join(S, ev: "Evaluator", op, left: List[Col], right: List[Col]) -> List[Col]:
     """HashJoinExec restated (planner.rs:2192-2266): Inner / LeftSemi / LeftAnti, optional residual condition over
     left ++ right.  Output order is unspecified in the reference; here probe order (tests compare multisets)."""
@@ -1131,18 +1182,22 @@ def _hash_join(S, ev: "Evaluator", op, left: List[Col], right: List[Col]) -> Lis
     nr = len(right[0]) if right else 0
     lk = [ev.eval(e, left, nl) for e in op.left_keys]
     rk = [ev.eval(e, right, nr) for e in op.right_keys]
-    index = {}
-    for i in range(nr):
-        k = _key_tuple(S, rk, i)
-        if k is not None:
-            index.setdefault(k, []).append(i)
-    li, ri = [], []
-    for i in range(nl):
-        k = _key_tuple(S, lk, i)
-        for j in (index.get(k, []) if k is not None else []):
-            li.append(i)
-            ri.append(j)
-    li, ri = np.array(li, np.int64), np.array(ri, np.int64)
+    fast = _join_pairs_sorted(lk, rk, nl, nr)
+    if fast is not None:
+        li, ri = fast
+    else:
+        index = {}
+        for i in range(nr):
+            k = _key_tuple(S, rk, i)
+            if k is not None:
+                index.setdefault(k, []).append(i)
+        li, ri = [], []
+        for i in range(nl):
+            k = _key_tuple(S, lk, i)
+            for j in (index.get(k, []) if k is not None else []):
+                li.append(i)
+                ri.append(j)
+        li, ri = np.array(li, np.int64), np.array(ri, np.int64)
     pairs = [_take(c, li) for c in left] + [_take(c, ri) for c in right]
     if op.condition is not None and len(li):
         c = ev.eval(op.condition, pairs, len(li))

@@ -165,8 +165,7 @@ def golden_case(q, inputs, run_partial, run_final):
     return got, dbgen.parse_golden(os.path.join(GOLD, q + ".sql.out"))
 
 
-# Q18 (a Python aggregation over 1.5 M groups) and Q21 take the oracle a minute each: the GPU suite checks them against the same files
-@pytest.mark.parametrize("q", ["q4", "q5", "q7", "q8", "q9", "q11", "q12", "q14", "q15", "q16", "q17", "q19", "q20", "q22"] + (["q18", "q21"] if os.environ.get("COMET_SLOW_TESTS") else []))
+@pytest.mark.parametrize("q", ["q4", "q5", "q7", "q8", "q9", "q11", "q12", "q14", "q15", "q16", "q17", "q18", "q19", "q20", "q21", "q22"])
 def test_more_queries_oracle_gives_the_references_answers(sf1, q):
     run = lambda plan, tables: O.run_plan_to_arrow(S, plan, tables)
     got, want = golden_case(q, _more_inputs(sf1), run, run)
