@@ -208,3 +208,37 @@ def test_murmur3_hash_and_bitwise_known_answers():
     assert _col(p2(S.shift_right(a, k)), t2) == [0, -4, 0x20000000]
     assert _col(p2(S.bit_xor(a, k)), t2) == [1 ^ 33, -8 ^ 1, 0x40000001]
     assert _col(p2(S.integral_divide(l, S.T_INT64, m, S.T_INT64)), t2) == [-3, -3, -2**63]
+
+
+def test_join_pairs_by_sorting_equal_the_row_at_a_time_join():
+    """the oracle's vectorised equi-join (integer-like keys: stable sort + binary search) against a plain nested evaluation: one and two keys,
+    duplicates on both sides, NULL keys (never match), keys of different widths, Inner / LeftSemi / LeftAnti with a residual condition"""
+    rng = np.random.default_rng(5)
+    nl, nr = 700, 500
+    lk1 = pa.array(rng.integers(0, 40, nl), pa.int64(), mask=rng.random(nl) < 0.1)
+    lk2 = pa.array(rng.integers(0, 3, nl).astype(np.int32), pa.int32(), mask=rng.random(nl) < 0.05)
+    lv = pa.array(rng.integers(0, 1000, nl), pa.int64())
+    rk1 = pa.array(rng.integers(0, 40, nr).astype(np.int32), pa.int32(), mask=rng.random(nr) < 0.1)
+    rk2 = pa.array(rng.integers(0, 3, nr).astype(np.int32), pa.int32(), mask=rng.random(nr) < 0.05)
+    rv = pa.array(rng.integers(0, 1000, nr), pa.int64())
+    left, right = pa.table({"k1": lk1, "k2": lk2, "v": lv}), pa.table({"k1": rk1, "k2": rk2, "v": rv})
+    I64, I32 = S.T_INT64, S.T_INT32
+    L, R = [I64, I32, I64], [I32, I32, I64]
+    lrows, rrows = list(zip(*[left.column(i).to_pylist() for i in range(3)])), list(zip(*[right.column(i).to_pylist() for i in range(3)]))
+    for nkeys in (1, 2):
+        lkeys = [S.cast(S.col(0, I64), I64), S.col(1, I32)][:nkeys]
+        rkeys = [S.cast(S.col(0, I32), I64), S.col(1, I32)][:nkeys]
+        match = lambda a, b: all(a[k] is not None and b[k] is not None and a[k] == b[k] for k in range(nkeys))
+        cond = S.lt(S.col(2, I64), S.col(5, I64))                 # left.v < right.v over left ++ right
+        for jt, residual in ((S.INNER, None), (S.INNER, cond), (S.LEFT_SEMI, cond), (S.LEFT_ANTI, cond), (S.LEFT_ANTI, None)):
+            plan = S.hash_join(S.scan(L), S.scan(R), lkeys, rkeys, jt, S.BUILD_RIGHT, condition=residual)
+            got = O.run_plan_to_arrow(S, plan, [left, right])
+            got_rows = list(zip(*[got.column(i).to_pylist() for i in range(got.num_columns)]))
+            ok = lambda a, b: match(a, b) and (residual is None or a[2] < b[2])
+            if jt == S.INNER:
+                want = [a + b for a in lrows for b in rrows if ok(a, b)]                 # probe order: left rows in order, matches by right row
+                assert got_rows == want, (nkeys, jt)
+            else:
+                hit = [any(ok(a, b) for b in rrows) for a in lrows]
+                want = [a for a, h in zip(lrows, hit) if h == (jt == S.LEFT_SEMI)]
+                assert got_rows == want, (nkeys, jt)
