@@ -170,3 +170,26 @@ def test_more_queries_oracle_gives_the_references_answers(sf1, q):
     run = lambda plan, tables: O.run_plan_to_arrow(S, plan, tables)
     got, want = golden_case(q, _more_inputs(sf1), run, run)
     assert got == want
+
+
+def test_every_golden_plan_is_accepted_by_createplan_and_compiles_for_gfx950(built):
+    """the plans the golden tests run, through the planner's dry run (comet_check_plan) and — the ones with fused pipelines of their own — through code
+    generation and hiprtc for gfx950 (comet_compile_plan needs no GPU): a query shape the GPU suite relies on cannot stop being plannable unnoticed"""
+    import decimal
+    from datafusion_comet_amd import native
+    from tests import test_tpch_more_gpu as M
+    d = tpch.days
+    plans = {
+        "q1": tpch.q1_plan(), "q3": tpch.q3_plan(), "q6": tpch.q6_plan(),
+        "q4": M.q4_partial_plan(d(1993, 7, 1), d(1993, 10, 1)), "q5": M.q5_partial_plan(d(1994, 1, 1), d(1995, 1, 1)), "q7": M.q7_partial_plan(d(1995, 1, 1), d(1996, 12, 31)),
+        "q8": M.q8_partial_plan(d(1995, 1, 1), d(1996, 12, 31)), "q9": M.q9_partial_plan(), "q11": M.q11_partial_plan(), "q11_total": M.q11_partial_plan(grouped=False),
+        "q12": M.q12_partial_plan(), "q14": M.q14_partial_plan(d(1995, 9, 1), d(1995, 10, 1)), "q15_view": M.q15_revenue_plan(d(1996, 1, 1), d(1996, 4, 1)), "q15_max": M.q15_max_plan(),
+        "q15_top": M.q15_top_plan(decimal.Decimal("1772627.2087")), "q16": M.q16_partial_plan(), "q17": M.q17_partial_plan(), "q18": M.q18_partial_plan(), "q19": M.q19_partial_plan(),
+        "q20": M.q20_plan(d(1994, 1, 1), d(1995, 1, 1)), "q20_sort": M.q20_sort_plan(), "q21": M.q21_partial_plan(), "q22_avg": M.q22_average_plan(),
+        "q22": M.q22_partial_plan(decimal.Decimal("4998.769878")),
+    }
+    for name, plan in plans.items():
+        ok, text = native.check_plan(plan.encode())
+        assert ok, (name, text)
+    for name in ("q9", "q16", "q20", "q21"):
+        assert native.compile_plan(plans[name].encode()), name
