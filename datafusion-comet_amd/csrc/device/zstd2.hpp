@@ -616,6 +616,47 @@ ZS_FN void seq_step_ring(SeqBits& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr 
   c.done++;
 }
 
+// The same step over tables of ONE word per state (fse_build's own entries: symbol | bits of the next state << 8 | base of the next state << 16):
+// a literal-length / match-length symbol's base and extra bits come from the code tables shared by the workgroup (one more dependent lookup),
+// an offset symbol's are 1 << symbol and the symbol.  Half the workgroup memory per block: build with -DZS_SEQ_COMPACT=1 -DZS_SEQ_LANES=8
+// (eight decoding lanes per wave, sixteen per CU instead of twelve).  An experiment: not the default, not yet measured on the device.
+template <class TabPtr, class CodePtr>
+ZS_FN void seq_step_ring_compact(SeqBits& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, CodePtr llc, CodePtr mlc, bool last, u32& ll, u32& ml, i32& off, i32& worst) {
+  const u32 el = tll[c.sll], eo = tof[c.sof], em = tml[c.sml];
+  const u32 cl = llc[el & 0xffu], cm = mlc[em & 0xffu];
+  const u32 lb = cl & 0xffffffu, le = cl >> 24, mb = cm & 0xffffffu, me = cm >> 24, oe = eo & 0xffu, ob = 1u << oe;
+  const u32 ln = (el >> 8) & 0xffu, mn = (em >> 8) & 0xffu, on = (eo >> 8) & 0xffu;
+  const u32 values = oe + me + le, states = ZS_SEL(last, 0u, ln + mn + on);
+  u64 wv = b.below(b.bitpos), ws = b.below(b.bitpos - (i32)values);
+  b.bitpos -= (i32)(values + states);
+  const u32 ov = ob + top_field((u32)(wv >> 32), oe);
+  wv <<= oe;
+  ml = mb + top_field((u32)(wv >> 32), me);
+  wv <<= me;
+  ll = lb + top_field((u32)(wv >> 32), le);
+  c.sll = (el >> 16) + top_field((u32)(ws >> 32), ln);
+  ws <<= ln;
+  c.sml = (em >> 16) + top_field((u32)(ws >> 32), mn);
+  ws <<= mn;
+  c.sof = (eo >> 16) + top_field((u32)(ws >> 32), on);
+  const bool rep = ov <= 3u;
+  const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
+  const i32 r0 = c.r0, r1 = c.r1, r2 = c.r2, less = r0 + ZS_SEL(r0 > 0, -1, -3);
+  i32 picked = ZS_SEL(idx == 2u, r2, less);
+  picked = ZS_SEL(idx == 1u, r1, picked);
+  picked = ZS_SEL(idx == 0u, r0, picked);
+  off = ZS_SEL(rep, picked, (i32)(ov - 3u));
+  const bool front = rep & (idx == 0u), second = rep & (idx <= 1u);
+  c.r2 = ZS_SEL(second, r2, r1);
+  c.r1 = ZS_SEL(front, r1, r0);
+  c.r0 = off;
+  const i32 fresh = ZS_SEL(rep, 1, off);
+  worst = fresh < worst ? fresh : worst;
+  c.sum_ll += ll;
+  c.sum_ml += ml;
+  c.done++;
+}
+
 // ---- kernel A1: the literals of one block — one 64-thread workgroup.  Threads 0 … 3 decode a Huffman stream each, 256 symbols a round,
 // out of their stream's window in workgroup memory into a buffer there; between rounds ALL threads slide the windows and write the
 // buffers out.  Raw / RLE literals (and raw / RLE blocks) are copied or filled by all threads. ----
@@ -740,15 +781,28 @@ ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Hu
 #ifndef ZS_SEQ_LANES
 #define ZS_SEQ_LANES 4
 #endif
+#ifndef ZS_SEQ_COMPACT
+#define ZS_SEQ_COMPACT 0
+#endif
 constexpr int kSeqLanes = ZS_SEQ_LANES;
 constexpr int kSeqGroup = 64 / kSeqLanes;         // threads per block's group
 constexpr u32 kSeqRound = 32;
 struct SeqLds {
+#if ZS_SEQ_COMPACT
+  u32 fse_ll[kSeqLanes][512], fse_of[kSeqLanes][256], fse_ml[kSeqLanes][512];       // one word per state (seq_step_ring_compact)
+  u32 ring[kSeqLanes][kRing / 4 + 2];
+  union {                               // (the staged table descriptions are read before the first record is written)
+    u32 rbuf[kSeqLanes][kSeqRound][3];
+    u8 hdr[kSeqLanes][3][128];
+  };
+  u32 llc[36], mlc[53];
+#else
   u32 fse_ll[kSeqLanes][1024], fse_of[kSeqLanes][512], fse_ml[kSeqLanes][1024];     // two words per state (seq_table_expand); offsets: log ≤ 8
   u32 ring[kSeqLanes][kRing / 4 + 2];   // (+ 2: the first two words again, so that three words in a row never wrap)
   u32 rbuf[kSeqLanes][kSeqRound][3];    // ll, ml, off
   u32 llc[36], mlc[53];                 // the literal-length / match-length codes' (base | extra bits << 24)
   u8 hdr[kSeqLanes][3][128];            // the table descriptions, staged (a description is at most 53 counts of ≤ 10 bits)
+#endif
   i16 norm[kSeqLanes][64];
   u16 next[kSeqLanes][64];
   i32 fse_log[kSeqLanes][3];
@@ -784,7 +838,9 @@ ZS_FN void seq_tables(ZS_LDS SeqLds* L, int k, const ZBlock& b) {
     const int log = seq_table(kind, b.tab_mode[kind], (ZS_LDS u8*)L->hdr[k][kind], 128u, seq_tab(L, k, kind), L->norm[k], L->next[k]);
     L->fse_log[k][kind] = log;
     if (log < 0) L->status[k] = ST_ERR_FSE;
+#if !ZS_SEQ_COMPACT
     else seq_table_expand(kind, log, seq_tab(L, k, kind), (ZS_LDS u32*)L->llc, (ZS_LDS u32*)L->mlc);
+#endif
   }
 }
 // (the group) slide the bitstream's window down
@@ -813,7 +869,12 @@ ZS_FN void seq_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
   for (u32 i = 0; i < n; i++) {
     u32 ll, ml;
     i32 off;
+#if ZS_SEQ_COMPACT
+    seq_step_ring_compact(st.b, st.c, (ZS_LDS u32*)L->fse_ll[k], (ZS_LDS u32*)L->fse_of[k], (ZS_LDS u32*)L->fse_ml[k], (ZS_LDS u32*)L->llc, (ZS_LDS u32*)L->mlc,
+                          st.c.done + 1 == nseq, ll, ml, off, worst);
+#else
     seq_step_ring(st.b, st.c, (ZS_LDS u32*)L->fse_ll[k], (ZS_LDS u32*)L->fse_of[k], (ZS_LDS u32*)L->fse_ml[k], st.c.done + 1 == nseq, ll, ml, off, worst);
+#endif
     L->rbuf[k][i][0] = ll;
     L->rbuf[k][i][1] = ml;
     L->rbuf[k][i][2] = (u32)off;

@@ -19,10 +19,12 @@ SEEN = "raw_block rle_block compressed_block lit_raw lit_rle lit_huffman lit_tre
 CSRC = os.path.join(ROOT, "datafusion-comet_amd", "csrc")
 
 
-@pytest.fixture(scope="module")
-def emu(tmp_path_factory):
+# "compact": the sequence kernel's experiment with one-word table entries and eight decoding lanes per workgroup (device/zstd2.hpp, ZS_SEQ_COMPACT) —
+# not the shipped build; kept correct here so that it can be measured on the device as it is
+@pytest.fixture(scope="module", params=[[], ["-DZS_SEQ_COMPACT=1", "-DZS_SEQ_LANES=8"]], ids=["shipped", "compact"])
+def emu(tmp_path_factory, request):
     so = str(tmp_path_factory.mktemp("zstd2_emu") / "libzstd2_emu.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", so], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC] + request.param + [os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", so], check=True)
     lib = ctypes.CDLL(so)
     lib.zs2_emu_inflate_pages.restype = ctypes.c_int64
     lib.zs2_emu_host_prefix.restype = ctypes.c_int64
