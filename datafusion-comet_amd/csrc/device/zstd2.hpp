@@ -784,17 +784,26 @@ ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Hu
 #ifndef ZS_SEQ_COMPACT
 #define ZS_SEQ_COMPACT 0
 #endif
+#ifndef ZS_SEQ_ROUND
+#define ZS_SEQ_ROUND 32       // sequences per round.  -DZS_SEQ_ROUND=64: half as many barriers, window refills and record flushes per sequence (an experiment
+#endif                        // like ZS_SEQ_COMPACT: emulated, not measured on the device; the records' buffer then shares its memory with the staged descriptions)
+#define ZS_SEQ_SHARED_STAGING (ZS_SEQ_COMPACT || ZS_SEQ_ROUND > 32)
 constexpr int kSeqLanes = ZS_SEQ_LANES;
 constexpr int kSeqGroup = 64 / kSeqLanes;         // threads per block's group
-constexpr u32 kSeqRound = 32;
+constexpr u32 kSeqRound = ZS_SEQ_ROUND;
+static_assert(kSeqRound * 89 / 8 + 16 <= 1024, "a round's sequences (≤ 89 bits each) must stay inside the 1 KiB the window keeps below the cursor");
 struct SeqLds {
+#if ZS_SEQ_SHARED_STAGING
 #if ZS_SEQ_COMPACT
   u32 fse_ll[kSeqLanes][512], fse_of[kSeqLanes][256], fse_ml[kSeqLanes][512];       // one word per state (seq_step_ring_compact)
+#else
+  u32 fse_ll[kSeqLanes][1024], fse_of[kSeqLanes][512], fse_ml[kSeqLanes][1024];
+#endif
   u32 ring[kSeqLanes][kRing / 4 + 2];
-  union {                               // (the staged table descriptions are read before the first record is written)
-    u32 rbuf[kSeqLanes][kSeqRound][3];
-    u8 hdr[kSeqLanes][3][128];
-  };
+  union Staging {                       // (a lane's staged table descriptions are read before its first record is written)
+    u32 rbuf[kSeqRound][3];
+    u8 hdr[3][128];
+  } stg[kSeqLanes];
   u32 llc[36], mlc[53];
 #else
   u32 fse_ll[kSeqLanes][1024], fse_of[kSeqLanes][512], fse_ml[kSeqLanes][1024];     // two words per state (seq_table_expand); offsets: log ≤ 8
@@ -812,6 +821,13 @@ struct SeqLds {
   u32 rounds[kSeqLanes];
   u32 status[kSeqLanes];
 };
+#if ZS_SEQ_SHARED_STAGING
+#define ZS_RBUF(L, k) (L)->stg[k].rbuf
+#define ZS_HDR(L, k) (L)->stg[k].hdr
+#else
+#define ZS_RBUF(L, k) (L)->rbuf[k]
+#define ZS_HDR(L, k) (L)->hdr[k]
+#endif
 struct SeqState { SeqBits b; SeqCore c; };
 ZS_FN bool seq_block_has_stream(const ZBlock& b) { return b.type == BT_COMPRESSED && b.nseq > 0; }
 ZS_FN u32 seq_rounds(const ZBlock& b) { return seq_block_has_stream(b) ? (b.nseq + kSeqRound - 1) / kSeqRound : 0; }
@@ -826,7 +842,7 @@ ZS_FN void seq_stage(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, u3
   for (u32 i = (u32)tt; i < 3u * 128u; i += (u32)kSeqGroup) {
     const u32 kind = i >> 7, j = i & 127u;
     const u32 q = b.tab_desc[kind] + j;
-    L->hdr[k][kind][j] = (b.tab_mode[kind] != TM_PREDEF && q < src_len) ? src[q] : (u8)0;
+    ZS_HDR(L, k)[kind][j] = (b.tab_mode[kind] != TM_PREDEF && q < src_len) ? src[q] : (u8)0;
   }
   if (tt == 0) { L->bias[k] = ring_bias(b.bits_len); L->cursor[k] = (i32)b.bits_len; L->low[k] = ring_top_for(b.bits_len, L->bias[k]); }
 }
@@ -835,7 +851,7 @@ ZS_FN ZS_LDS u32* seq_tab(ZS_LDS SeqLds* L, int k, int kind) { return kind == 0 
 ZS_FN void seq_tables(ZS_LDS SeqLds* L, int k, const ZBlock& b) {
   if (!seq_block_has_stream(b)) return;
   for (int kind = 0; kind < 3; kind++) {
-    const int log = seq_table(kind, b.tab_mode[kind], (ZS_LDS u8*)L->hdr[k][kind], 128u, seq_tab(L, k, kind), L->norm[k], L->next[k]);
+    const int log = seq_table(kind, b.tab_mode[kind], (ZS_LDS u8*)ZS_HDR(L, k)[kind], 128u, seq_tab(L, k, kind), L->norm[k], L->next[k]);
     L->fse_log[k][kind] = log;
     if (log < 0) L->status[k] = ST_ERR_FSE;
 #if !ZS_SEQ_COMPACT
@@ -875,9 +891,9 @@ ZS_FN void seq_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
 #else
     seq_step_ring(st.b, st.c, (ZS_LDS u32*)L->fse_ll[k], (ZS_LDS u32*)L->fse_of[k], (ZS_LDS u32*)L->fse_ml[k], st.c.done + 1 == nseq, ll, ml, off, worst);
 #endif
-    L->rbuf[k][i][0] = ll;
-    L->rbuf[k][i][1] = ml;
-    L->rbuf[k][i][2] = (u32)off;
+    ZS_RBUF(L, k)[i][0] = ll;
+    ZS_RBUF(L, k)[i][1] = ml;
+    ZS_RBUF(L, k)[i][2] = (u32)off;
   }
   if (worst <= 0) { L->status[k] = ST_ERR_OFFSET; return; }
   if (st.b.bitpos < 0) { L->status[k] = ST_ERR_BITS; return; }           // the stream ran out: nothing more to decode from it
@@ -888,9 +904,9 @@ ZS_FN void seq_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
 ZS_FN void seq_flush(const ZS_LDS SeqLds* L, int k, ZRec* recs_block, u32 base, int tt) {
   for (u32 i = (u32)tt; i < L->rcount[k]; i += (u32)kSeqGroup) {
     ZRec* r = recs_block + base + i;
-    r->ll = L->rbuf[k][i][0];
-    r->ml = L->rbuf[k][i][1];
-    r->off = (i32)L->rbuf[k][i][2];
+    r->ll = ZS_RBUF(L, k)[i][0];
+    r->ml = ZS_RBUF(L, k)[i][1];
+    r->off = (i32)ZS_RBUF(L, k)[i][2];
   }
 }
 // the group's thread, behind the last round: the stream must be used up; the trailing literals; the block's size and history on exit
