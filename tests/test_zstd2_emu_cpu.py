@@ -22,7 +22,8 @@ CSRC = os.path.join(ROOT, "datafusion-comet_amd", "csrc")
 # "compact": the sequence kernel's experiment with one-word table entries and eight decoding lanes per workgroup (device/zstd2.hpp, ZS_SEQ_COMPACT) —
 # not the shipped build; kept correct here so that it can be measured on the device as it is
 # "round64": 64 instead of 32 sequences between two barriers of the sequence kernel (ZS_SEQ_ROUND) — the second experiment waiting for a device measurement
-@pytest.fixture(scope="module", params=[[], ["-DZS_SEQ_COMPACT=1", "-DZS_SEQ_LANES=8"], ["-DZS_SEQ_ROUND=64"]], ids=["shipped", "compact", "round64"])
+@pytest.fixture(scope="module", params=[[], ["-DZS_SEQ_COMPACT=1", "-DZS_SEQ_LANES=8"], ["-DZS_SEQ_ROUND=64"], ["-DZS_SEQ_COMPACT=1", "-DZS_SEQ_LANES=8", "-DZS_SEQ_ROUND=64"]],
+                ids=["shipped", "compact", "round64", "compact_round64"])
 def emu(tmp_path_factory, request):
     so = str(tmp_path_factory.mktemp("zstd2_emu") / "libzstd2_emu.so")
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC] + request.param + [os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", so], check=True)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds the zstd sequence kernel's experiments (device/zstd2.hpp: ZS_SEQ_ROUND, ZS_SEQ_COMPACT) as whole libraries next to the shipped one:
+# datafusion-comet_amd/variants/libcomet_<name>.so (git-ignored, they travel to the GPU box with gpurun).  Run here (hipcc cross-compiles),
+# then tools/gpu_zstd_variants.sh on the box.  The shipped libcomet.so is rebuilt unchanged at the end.
+set -e
+cd "$(dirname "$0")/../datafusion-comet_amd/csrc"
+mkdir -p ../variants
+build() {   # name, flags
+  touch zstd2_kernels.hip
+  make -s -j8 OUT=../variants/libcomet_$1.so EXTRA_HIPFLAGS="$2"
+  echo "built variants/libcomet_$1.so ($2)"
+}
+build round64 "-DZS_SEQ_ROUND=64"
+build compact "-DZS_SEQ_COMPACT=1 -DZS_SEQ_LANES=8"
+build compact_round64 "-DZS_SEQ_COMPACT=1 -DZS_SEQ_LANES=8 -DZS_SEQ_ROUND=64"
+touch zstd2_kernels.hip
+make -s -j8
+echo "shipped libcomet.so rebuilt"
