@@ -96,7 +96,7 @@ def test_random_patterns_against_the_backtracking_engine(built):
     quant = ["", "", "", "*", "+", "?", "{2}", "{1,2}", "{0,3}"]
     alphabet = ["a", "b", "c", ".", "é", "\n", "x"]
     refused = 0
-    for _ in range(400 if os.environ.get("COMET_SLOW_TESTS") else 150):      # (every call compiles its pattern: 13 ms)
+    for _ in range(400 if os.environ.get("COMET_SLOW_TESTS") else 300):      # (every call compiles its pattern: 13 ms)
         body = "".join(rnd.choice(atoms) + rnd.choice(quant) for _ in range(rnd.randint(1, 5)))
         if rnd.random() < 0.3:
             body = body + "|" + "".join(rnd.choice(atoms) for _ in range(rnd.randint(1, 3)))
