@@ -177,10 +177,11 @@ def test_host_prefix_is_the_pages_first_bytes(emu):
                 assert got == n and b == p[:n], (level, len(p), n, got)
 
 
-def test_damaged_frames_under_address_sanitizer(tmp_path):
+@pytest.mark.parametrize("flags", [[], ["-DZS_SEQ_COMPACT=1", "-DZS_SEQ_LANES=8", "-DZS_SEQ_ROUND=64"]], ids=["shipped", "compact_round64"])
+def test_damaged_frames_under_address_sanitizer(tmp_path, flags):
     exe = str(tmp_path / "zstd2_fuzz")
-    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + CSRC,
-                        os.path.join(ROOT, "tests", "emu", "zstd2_fuzz.cpp"), os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", exe], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + CSRC] + flags +
+                       [os.path.join(ROOT, "tests", "emu", "zstd2_fuzz.cpp"), os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", exe], capture_output=True, text=True)
     if r.returncode != 0 and "asan" in (r.stderr or "").lower():
         pytest.skip("no AddressSanitizer runtime in this image")
     assert r.returncode == 0, r.stderr[-2000:]
