@@ -779,10 +779,10 @@ ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Hu
 // there; between rounds every group slides its window and writes its buffer out as records.  Four, because the expanded tables of a block
 // take 10 KiB of workgroup memory: 52 KiB per workgroup, three workgroups per CU. ----
 #ifndef ZS_SEQ_LANES
-#define ZS_SEQ_LANES 4
+#define ZS_SEQ_LANES 8
 #endif
 #ifndef ZS_SEQ_COMPACT
-#define ZS_SEQ_COMPACT 0
+#define ZS_SEQ_COMPACT 1      // measured (round 4, profiles/r4_zstd_variants.txt): 16.05 -> 10.99 ms for 480 pages — every block of the launch is in flight at once
 #endif
 #ifndef ZS_SEQ_ROUND
 #define ZS_SEQ_ROUND 32       // sequences per round.  -DZS_SEQ_ROUND=64: half as many barriers, window refills and record flushes per sequence (an experiment

@@ -732,7 +732,7 @@ size_t staged_capacity(const pq::ColumnMeta& cm) {
 // offsets into the device-decompressed region carry this bit until the column's tables are assembled
 constexpr int64_t kInflatedBit = (int64_t)1 << 62;
 constexpr int32_t kMinDevicePage = 4096;
-constexpr double kDeviceZstdBytesPerMs = 31.0e6;    // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 16.1 ms (profiles/r3_zstd_pipeline_lean_step.json)
+constexpr double kDeviceZstdBytesPerMs = 45.0e6;    // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 11.0 ms (profiles/r4_zstd_variants.txt)
 // … and what the scan threads still do for a device-inflated zstd page (read it, walk its frame, decode the levels' prefix), and what they do when they inflate it
 // themselves — SF10 Q6 from zstd Parquet, profiles/r3_parquet_q6_zstd_dict.txt: 60 ms for 495 MB of PLAIN pages on one thread; 280 ms of thread time for the file's
 // 661 MB.  With these the device path wins below about ten scan threads (measured: 97 vs 290 ms with one, 38 vs 29 ms with sixteen)

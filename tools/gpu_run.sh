@@ -1,0 +1,85 @@
+#!/bin/bash
+# The one GPU-box script: gpurun -- 'bash tools/gpu_run.sh <tag> <section> [<section> …]'.  Each section is a function below; its output goes
+# under gpurun_out/<tag>/ (merged back by gpurun), a short tail to stdout.  Sections keep their own timeouts so a hung kernel costs one section.
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+TAG=$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+PQ=/tmp/q6pq; mkdir -p $PQ
+
+tests() {          # the whole GPU suite
+  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log | cut -c1-200
+}
+tests_sel() {      # tests matched by $SEL (a -k expression) or the files in $FILES
+  timeout 900 python -m pytest ${FILES:-tests} -m gpu -x -q ${SEL:+-k "$SEL"} > $OUT/pytest_sel.log 2>&1; tail -15 $OUT/pytest_sel.log | cut -c1-220
+}
+smoke() {
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
+}
+bench() {          # the bench line as the driver runs it
+  timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 400 $OUT/bench.json; echo; tail -3 $OUT/bench.err
+}
+bench_stats() {    # rocprofv3 kernel statistics of the headline loop only
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-extra-legs --no-cpu-baseline > $OUT/bench_stats.json 2> /dev/null)
+  grep -E '^"k_|utf8_' $OUT/bench_stats/b_kernel_stats.csv | cut -c1-120
+}
+zstd_variants() {  # the shipped library, then each variant of tools/build_zstd_variants.sh: device parity + the 480-page pipeline
+  cp datafusion-comet_amd/libcomet.so /tmp/libcomet_shipped.so
+  for v in shipped $(ls datafusion-comet_amd/variants 2>/dev/null | sed -n 's/^libcomet_\(.*\)\.so$/\1/p'); do
+    if [ $v = shipped ]; then cp /tmp/libcomet_shipped.so datafusion-comet_amd/libcomet.so; else cp datafusion-comet_amd/variants/libcomet_$v.so datafusion-comet_amd/libcomet.so; fi
+    timeout 180 python -m pytest tests/test_device_zstd_gpu.py -x -q > $OUT/pytest_zstd_$v.log 2>&1
+    echo "== $v: $(tail -1 $OUT/pytest_zstd_$v.log | cut -c1-80)"
+    for rep in 1 2; do
+      timeout 60 python tools/snappy_bench.py --codec zstd --level 1 --pages 480 --kinds decimal_int64 --out $OUT/zstd_${v}_$rep.json > /dev/null 2> $OUT/zstd_${v}_$rep.err
+      cut -c1-300 $OUT/zstd_${v}_$rep.json; echo
+    done
+  done
+  cp /tmp/libcomet_shipped.so datafusion-comet_amd/libcomet.so
+}
+zstd_bench() {     # the 480-page zstd pipeline (levels 1 and 3) + per-kernel statistics
+  for lvl in 1 3; do
+    timeout 90 python tools/snappy_bench.py --codec zstd --level $lvl --pages 480 --kinds decimal_int64,int32_lowcard --out $OUT/zstd_l$lvl.json > /dev/null 2> $OUT/zstd_l$lvl.err; cut -c1-600 $OUT/zstd_l$lvl.json; echo
+  done
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/zstd_stats -o z -- python $GRAFT_REPO_ROOT/tools/snappy_bench.py --codec zstd --level 1 --pages 480 --kinds decimal_int64 --no-check > /dev/null 2>&1)
+  grep -E '^"(zs2|sn2|pq_)' $OUT/zstd_stats/z_kernel_stats.csv | cut -c1-120
+}
+snappy_bench() {
+  timeout 200 python tools/snappy_bench.py --pages 480 --out $OUT/snappy_bench.json > /dev/null 2> $OUT/snappy_bench.err; cut -c1-900 $OUT/snappy_bench.json; echo
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/snappy_stats -o s -- python $GRAFT_REPO_ROOT/tools/snappy_bench.py --pages 480 --kinds decimal_int64 --no-check --skip-one-wave > /dev/null 2>&1)
+  grep -E '^"(sn2|pq_)' $OUT/snappy_stats/s_kernel_stats.csv | cut -c1-120
+}
+parquet_q6() {     # SF10 Q6 from Parquet: codec, scan threads (0 = the box's), device decompression (auto / true / false); host stage timers in the logs
+  for CFG in ${PQ_CFGS:-"snappy 0 auto" "zstd 0 auto" "zstd 0 true" "snappy 1 auto" "zstd 1 auto"}; do
+    set -- $CFG
+    N=pq6_$1_t$2_$3
+    COMET_TRACE_STAGES=1 timeout 240 python tools/parquet_q6.py --codec $1 --dir $PQ --scan-threads $2 --device-decompress $3 --steps 5 --out $OUT/$N.json > $OUT/$N.log 2>&1
+    echo "== $CFG"; cut -c1-420 $OUT/$N.json; echo; grep "parquet:" $OUT/$N.log | tail -${PQ_TRACE_LINES:-14} | cut -c1-230
+  done
+}
+q3_stats() {       # SF100 Q3 on one GPU: kernel statistics + PMC of the probes and the filter (separate passes)
+  Q3="python $GRAFT_REPO_ROOT/tools/q3_dist.py --orders 150000000 --steps 3 --warmup 1 --no-verify"
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q3_stats -o q3 -- $Q3 > $OUT/q3_stats.log 2>&1
+  grep -E '^"k_|^"comet|^"exch' $OUT/q3_stats/q3_kernel_stats.csv | cut -c1-120
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/q3_fetch -o q3 -- $Q3 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/q3_tcc -o q3 -- $Q3 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/q3_sq -o q3 -- $Q3 > /dev/null 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/pmc_join_summary.py $OUT q3 > $OUT/q3_probe_pmc.txt 2>&1; head -60 $OUT/q3_probe_pmc.txt | cut -c1-260
+}
+q3() {
+  timeout 300 python tools/q3_dist.py --orders 150000000 --steps 5 --warmup 2 --out $OUT/q3.json > $OUT/q3.log 2>&1; cut -c1-700 $OUT/q3.json; echo
+}
+q95() {
+  timeout 300 python tools/q95_bench.py --orders 16000000 --reps 3 > $OUT/q95.json 2> $OUT/q95.err; cut -c1-600 $OUT/q95.json; echo
+}
+probes() {         # the box itself: HBM streaming rates, PCIe
+  timeout 200 python tools/hbm_probe.py > $OUT/hbm_probe.json 2>/dev/null; cut -c1-400 $OUT/hbm_probe.json; echo
+  timeout 200 python tools/h2d_probe.py > $OUT/h2d.json 2>/dev/null; cut -c1-400 $OUT/h2d.json; echo
+}
+
+for s in "$@"; do
+  echo "#### $s"; t0=$(date +%s); $s; echo "#### $s done in $(( $(date +%s) - t0 )) s"
+done
+find $OUT -name "*.csv" -size +2M -delete

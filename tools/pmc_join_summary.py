@@ -2,13 +2,14 @@
 """Per-dispatch PMC view of the hash-join kernels of one Q95 run: every rocprofv3 pass directory under <root> (q95_fetch, q95_tcc,
 q95_sq: --pmc … --kernel-trace) lists its k_jbuild / k_jprobe / k_jlds dispatches in launch order — the same program, so ordinal k of
 one pass is ordinal k of the others — with its counters; q95_stats gives the durations.  FETCH_SIZE is KiB and is doubled (gfx950
-counts 64 B per 128-B request, MI355X_MICROARCH.md); WRITE_SIZE is KiB.   Usage: pmc_join_summary.py <root>"""
+counts 64 B per 128-B request, MI355X_MICROARCH.md); WRITE_SIZE is KiB.   Usage: pmc_join_summary.py <root> [prefix=q95]"""
 import csv
 import glob
 import sys
 from collections import OrderedDict, defaultdict
 
 root = sys.argv[1]
+PFX = sys.argv[2] if len(sys.argv) > 2 else "q95"
 KERNELS = ("k_jbuild", "k_jprobe", "k_jlds", "k_filter", "k_jbemit", "k_jbcount")
 
 
@@ -17,14 +18,14 @@ def short(n):
 
 
 durs = defaultdict(list)
-for f in glob.glob(root + "/q95_stats/**/*kernel_trace.csv", recursive=True):
+for f in glob.glob(root + f"/{PFX}_stats/**/*kernel_trace.csv", recursive=True):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     for r in rows:
         k = short(r["Kernel_Name"])
         if k in KERNELS:
             durs[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 per = defaultdict(lambda: defaultdict(dict))      # kernel → ordinal → counter → value
-for d in sorted(glob.glob(root + "/q95_*")):
+for d in sorted(glob.glob(root + f"/{PFX}_*")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         disp = OrderedDict()
         for r in csv.DictReader(open(f)):
