@@ -771,6 +771,334 @@ ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Hu
   return (longest + kLitRound - 1) / kLitRound;
 }
 
+#ifndef ZS_SEQ_SPLIT
+#define ZS_SEQ_SPLIT 1
+#endif
+#if ZS_SEQ_SPLIT
+// ---- kernel A2 (round 4): the sequences of FOUR blocks — one 64-thread workgroup, 16 threads per block; the serial chain carries ONLY what
+// is serial.  A block's sequences are one chain (three interleaved FSE states over one backward bitstream), and one wave issues about one
+// instruction per four cycles whatever the instruction does for how many lanes, so a block costs (instructions per sequence) × 4 cycles ×
+// its sequence count — with every block of a launch in flight at once that IS the kernel's duration.  Round 3's step spent ≈ 100 instructions
+// per sequence in the decoding lane: values, repeat offsets, sums and records all sat in the chain.  Here a round of 64 sequences is
+//   (1) chain    — the group's thread: per sequence only "three table entries → how many bits → the next three states"; it notes the
+//                  entries and the cursor (16 bytes) and moves on: ≈ 40 instructions, one workgroup-memory latency;
+//   (2) values   — the group's 16 threads, four sequences each: literal length, match length and offset value from the noted entries and
+//                  cursor (the bitstream's window is still there);
+//   (3) history  — the repeat-offset rules over the 64 offset values: a recurrence, but one whose steps compose — a scan over the group (below);
+//   (4) flush    — the group: records to global memory, the window slides.
+// Table entries are one word — bits of the next state [0, 5) | extra bits of the value [5, 11) | symbol [11, 17) | word address of the
+// next state's base entry [17, 32) — so that ONE three-operand add of a sequence's entries yields both bit totals (neither field can carry:
+// ≤ 26 and ≤ 63) and the next state's address is an add and a shift.  10 KiB of workgroup memory per block, four workgroups per CU: every
+// block of a 480-page scan is in flight at once. ----
+#ifndef ZS_SEQ_LANES
+#define ZS_SEQ_LANES 4
+#endif
+constexpr int kSeqLanes = ZS_SEQ_LANES;
+constexpr int kSeqGroup = 64 / kSeqLanes;         // threads per block's group
+constexpr u32 kSeqRound = 64;
+static_assert(kSeqRound * 89 / 8 + 16 <= 1024, "a round's sequences (≤ 89 bits each) and the chain's four-word window must stay inside the 1 KiB the window keeps below the cursor");
+constexpr u32 kTabLL = 0, kTabML = 512, kTabOF = 1024, kTabWords = 1280;       // accuracy logs ≤ 9 / 9 / 8
+struct alignas(16) SeqQuad { u32 x, y, z, w; };
+ZS_FN SeqQuad quad_load(const ZS_LDS SeqQuad* p) { SeqQuad v; v.x = p->x; v.y = p->y; v.z = p->z; v.w = p->w; return v; }       // (one 16-byte access on the device)
+ZS_FN void quad_store(ZS_LDS SeqQuad* p, u32 x, u32 y, u32 z, u32 w) { p->x = x; p->y = y; p->z = z; p->w = w; }
+struct alignas(16) SeqBlockLds {
+  u32 ring[kRing / 4 + 4];              // first: the chain's four window words are one address + immediate offsets.  (+ 3: the first three words again, so that four words in a row never wrap)
+  u32 tab[kTabWords];
+  union {
+    SeqQuad chain[kSeqRound];           // (1) → (2): the sequence's three table entries and the cursor in front of it
+    u8 hdr[3][128];                     // the table descriptions, staged (read before the first round)
+  } u;
+  SeqQuad vals[kSeqRound];              // (2) → (3) → (4): ll, ml, offset value → offset (symbolic or real), unused
+  SeqQuad scan[2][64 / ZS_SEQ_LANES];   // (3): the threads' history functions (three slots + a "malformed" mark), double-buffered for the scan
+  i32 hist[2][4];                       // the repeat-offset history in front of round r: hist[r & 1] (symbolic until an offset of this block replaces an entry)
+  u32 sum_ll, sum_ml, pad1[2];          // (checked every round: no overflow in between)
+  i16 norm[64];
+  u16 next[64];
+  i32 fse_log[3];
+  i32 low, cursor;
+  u32 bias, rcount, rounds, status;
+  u32 pad[3];
+};
+struct SeqLds {
+  SeqBlockLds b[kSeqLanes];
+  u32 llc[36], mlc[53];                 // the literal-length / match-length codes' (base | extra bits << 24)
+};
+// A table entry names its successor's base by ADDRESS: on the device the address workgroup memory itself uses (no base register to add in
+// the chain); on the host (emulation) the offset from the workgroup's struct.
+#if defined(ZS2_DEVICE_ONLY)
+ZS_FN u32 seq_lds_addr(const ZS_LDS SeqLds*, const ZS_LDS void* p) { return (u32)(__UINTPTR_TYPE__)p; }
+ZS_FN u32 seq_lds_word(const ZS_LDS SeqLds*, u32 addr) { return *(const ZS_LDS u32*)(__UINTPTR_TYPE__)addr; }
+#else
+ZS_FN u32 seq_lds_addr(const SeqLds* L, const void* p) { return (u32)((const u8*)p - (const u8*)L); }
+ZS_FN u32 seq_lds_word(const SeqLds* L, u32 addr) { u32 v; __builtin_memcpy(&v, (const u8*)L + addr, 4); return v; }
+#endif
+ZS_FN u32 rotr32(u32 v, u32 n) { return funnel32(v, v, n); }                      // by n mod 32 (one v_alignbit_b32)
+#if defined(__HIP_DEVICE_COMPILE__)
+ZS_FN u32 low_field(u32 v, u32 n) { return __builtin_amdgcn_ubfe(v, 0u, n); }    // the low (n mod 32) bits: the width operand is the entry itself
+#else
+ZS_FN u32 low_field(u32 v, u32 n) { return v & ((1u << (n & 31u)) - 1u); }
+#endif
+struct SeqState {
+  u32 aL, aM, aO;             // addresses of the three states' entries
+  u32 tq;                     // the cursor as a window bit: stream bit b ↔ b + 8·bias − 96 (the chain's window = words (tq >> 5) … + 3)
+  u32 done;
+};
+ZS_FN bool seq_block_has_stream(const ZBlock& b) { return b.type == BT_COMPRESSED && b.nseq > 0; }
+ZS_FN u32 seq_rounds(const ZBlock& b) { return seq_block_has_stream(b) ? (b.nseq + kSeqRound - 1) / kSeqRound : 0; }
+ZS_FN i32 seq_bitpos(const ZS_LDS SeqBlockLds* B, u32 tq) { return (i32)(tq + 96u - 8u * B->bias); }
+// k: the block's group, tt: the thread within the group; "the group's thread" = its thread 0
+// phase 1 (the group): stage the table descriptions (this block's, or — repeat mode — an earlier block's)
+ZS_FN void seq_stage(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, u32 src_len, int tt) {
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  if (tt == 0) { B->status = 0; B->rcount = 0; B->rounds = seq_rounds(b); B->sum_ll = B->sum_ml = 0; }
+  const u32 t = (u32)k * (u32)kSeqGroup + (u32)tt;                       // (the workgroup's 64 threads fill the code tables once)
+  if (t < 36u) L->llc[t] = ll_code_entry(t);
+  if (t < 53u) L->mlc[t] = ml_code_entry(t);
+  if (!seq_block_has_stream(b)) return;
+  for (u32 i = (u32)tt; i < 3u * 128u; i += (u32)kSeqGroup) {
+    const u32 kind = i >> 7, j = i & 127u;
+    const u32 q = b.tab_desc[kind] + j;
+    B->u.hdr[kind][j] = (b.tab_mode[kind] != TM_PREDEF && q < src_len) ? src[q] : (u8)0;
+  }
+  if (tt == 0) { B->bias = ring_bias(b.bits_len); B->cursor = (i32)b.bits_len; B->low = ring_top_for(b.bits_len, B->bias); }
+}
+ZS_FN u32 seq_tab_first(int kind) { return kind == 0 ? kTabLL : kind == 1 ? kTabOF : kTabML; }       // (kinds in the format's order: LL, OF, ML)
+// phase 2 (the group's thread): the block's three tables, fse_build's entries repacked for the chain
+ZS_FN void seq_tables(ZS_LDS SeqLds* L, int k, const ZBlock& b) {
+  if (!seq_block_has_stream(b)) return;
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  for (int kind = 0; kind < 3; kind++) {
+    ZS_LDS u32* tab = (ZS_LDS u32*)B->tab + seq_tab_first(kind);
+    const int log = seq_table(kind, b.tab_mode[kind], (ZS_LDS u8*)B->u.hdr[kind], 128u, tab, (ZS_LDS i16*)B->norm, (ZS_LDS u16*)B->next);
+    B->fse_log[kind] = log;
+    if (log < 0) { B->status = ST_ERR_FSE; continue; }
+    const u32 first = seq_lds_addr(L, tab) >> 2;
+    for (u32 i = 0; i < (1u << log); i++) {
+      const u32 e = tab[i], sym = e & 0xffu, nb = (e >> 8) & 0xffu, nx = e >> 16;
+      const u32 extra = kind == 1 ? sym : ((kind == 0 ? L->llc[sym] : L->mlc[sym]) >> 24);
+      tab[i] = nb | (extra << 5) | (sym << 11) | ((first + nx) << 17);
+    }
+  }
+}
+// (the group) slide the bitstream's window down
+ZS_FN void seq_fill(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, i32 page_len, int tt) {
+  if (!seq_block_has_stream(b)) return;
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  const i32 want = ring_low_for(B->cursor, B->bias);
+  if (want < B->low) ring_fill((ZS_LDS u32*)B->ring, B->bias, src + b.bits_pos, want, B->low, -(i32)b.bits_pos, page_len + 16 - (i32)b.bits_pos, tt, kSeqGroup);
+}
+ZS_FN void seq_fill_done(ZS_LDS SeqLds* L, int k) {          // (the group's thread, behind the barrier that follows seq_fill)
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  const i32 want = ring_low_for(B->cursor, B->bias);
+  if (want < B->low) B->low = want;
+  for (int j = 0; j < 3; j++) B->ring[kRing / 4 + j] = B->ring[j];
+}
+ZS_FN void seq_start(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {        // the group's thread, behind the first fill
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  st.done = 0;
+  if (B->status) return;
+  SeqBits rd;
+  if (!rd.init((ZS_LDS u32*)B->ring, B->bias, b.bits_len)) { B->status = ST_ERR_BITS; return; }
+  const u32 sll = rd.get((u32)B->fse_log[0]), sof = rd.get((u32)B->fse_log[1]), sml = rd.get((u32)B->fse_log[2]);
+  st.aL = seq_lds_addr(L, &B->tab[kTabLL + sll]);
+  st.aO = seq_lds_addr(L, &B->tab[kTabOF + sof]);
+  st.aM = seq_lds_addr(L, &B->tab[kTabML + sml]);
+  st.tq = (u32)rd.bitpos + 8u * B->bias - 96u;
+  for (int j = 0; j < 3; j++) B->hist[0][j] = rep_symbolic(j);
+  B->sum_ll = B->sum_ml = 0;
+}
+// (1) the group's thread: the chain over the block's next ≤ 64 sequences
+ZS_FN void seq_chain_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  B->rcount = 0;
+  if (B->status || !seq_block_has_stream(b)) return;
+  const u32 left = b.nseq - st.done, n = left < kSeqRound ? left : kSeqRound;
+  u32 aL = st.aL, aM = st.aM, aO = st.aO, tq = st.tq, nst = 0;
+  for (u32 i = 0; i < n; i++) {
+    const u32 eL = seq_lds_word(L, aL), eM = seq_lds_word(L, aM), eO = seq_lds_word(L, aO);
+    const u32 q = (tq >> 5) & (u32)(kRing / 4 - 1);
+    const u32 w0 = B->ring[q], w1 = B->ring[q + 1], w2 = B->ring[q + 2], w3 = B->ring[q + 3];    // w3 holds stream-window bit tq + 96: the cursor
+    quad_store(&B->u.chain[i], eL, eM, eO, tq);
+    const u32 t = eL + eM + eO;
+    nst = t & 31u;                                   // bits of the three next states (≤ 9 + 9 + 8)
+    const u32 val = (t >> 5) & 63u;                  // extra bits of the three values (≤ 16 + 16 + 31): skipped here, read in (2)
+    // S: the 32 window bits below the values' bits — bit offset u = 1 … 95 of the four words
+    const u32 u = (tq & 31u) + 64u - val;
+    const u32 lo = ZS_SEL(u < 32u, w0, ZS_SEL(u < 64u, w1, w2)), hi = ZS_SEL(u < 32u, w1, ZS_SEL(u < 64u, w2, w3));
+    const u32 S = funnel32(hi, lo, u);
+    // the states' fields sit at the TOP of S, literal length first: rotate each down to bit 0 and cut it with its own entry as the width
+    const u32 sL = 0u - eL, sM = sL - eM, sO = sM - eO;          // (only the low five bits count: −(bits so far))
+    const u32 bL = low_field(rotr32(S, sL), eL), bM = low_field(rotr32(S, sM), eM), bO = low_field(rotr32(S, sO), eO);
+    aL = ((eL >> 17) + bL) << 2;
+    aM = ((eM >> 17) + bM) << 2;
+    aO = ((eO >> 17) + bO) << 2;
+    tq -= val + nst;
+  }
+  st.done += n;
+  if (st.done == b.nseq) tq += nst;                  // behind the last sequence no state is updated: its bits were never there
+  st.aL = aL; st.aM = aM; st.aO = aO; st.tq = tq;
+  if (seq_bitpos(B, tq) < 0) { B->status = ST_ERR_BITS; return; }           // the stream ran out: nothing more to decode from it
+  B->rcount = n;
+  const i32 bp = seq_bitpos(B, tq);
+  B->cursor = bp > 0 ? (bp + 7) >> 3 : 0;
+}
+// (2) the group: the round's values from the noted entries and cursors
+ZS_FN void seq_values(ZS_LDS SeqLds* L, int k, int tt) {
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  const u32 n = B->rcount;
+  for (u32 i = (u32)tt; i < n; i += (u32)kSeqGroup) {
+    const SeqQuad c = quad_load(&B->u.chain[i]);
+    const u32 le = (c.x >> 5) & 63u, me = (c.y >> 5) & 63u, oe = (c.z >> 5) & 63u;
+    const u32 cl = L->llc[(c.x >> 11) & 63u], cm = L->mlc[(c.y >> 11) & 63u];
+    const u32 q = (c.w >> 5) & (u32)(kRing / 4 - 1);
+    const u32 w1 = B->ring[q + 1], w2 = B->ring[q + 2], w3 = B->ring[q + 3];
+    u64 wv = ((u64)funnel32(w3, w2, c.w) << 32) | (u64)funnel32(w2, w1, c.w);       // the 64 bits below the cursor
+    const u32 ov = (1u << oe) + top_field((u32)(wv >> 32), oe);                    // offset value first, then match length, then literal length
+    wv <<= oe;
+    const u32 ml = (cm & 0xffffffu) + top_field((u32)(wv >> 32), me);
+    wv <<= me;
+    const u32 ll = (cl & 0xffffffu) + top_field((u32)(wv >> 32), le);
+    quad_store(&B->vals[i], ll, ml, ov, 0u);
+  }
+}
+// (3) the repeat-offset rules, as a scan.  The rules are a recurrence over three history entries — serial, 27 instructions per sequence, a
+// third of the kernel when the group's thread walked them alone.  But a run of sequences acts on the history as a FUNCTION whose three
+// outputs are each "a real offset" or "input entry j minus d" — exactly the symbolic values blocks already start with (rep_symbolic:
+// −(1 + j + 3·d)) — and such functions compose.  So: (3a) every thread of the group walks ITS four sequences from the symbolic history
+// (−1, −2, −3): the history it ends with is its run's function, the offsets it notes are relative to the run's start; (3b) an inclusive
+// scan over the group's functions (log₂ 16 steps); (3c) every thread evaluates the function of the runs before it on the round's real
+// history → the history its run starts from → its noted offsets become real (or block-symbolic, where the block's own start shows through).
+// The rules themselves (seq_step's, every candidate computed, every choice a select): a value > 3 is a new offset, pushed onto the history;
+// 1 … 3 names an entry (shifted by one when there are no literals, the fourth choice being "the newest entry minus one"), which moves to
+// the front.
+constexpr u32 kSeqPer = kSeqRound / (u32)kSeqGroup;         // sequences per thread and round
+constexpr int kSeqScanSteps = kSeqGroup == 16 ? 4 : kSeqGroup == 8 ? 3 : kSeqGroup == 32 ? 5 : 6;
+static_assert((1 << kSeqScanSteps) == kSeqGroup, "the history scan runs over the group's threads");
+// a history value `a` minus d: a real offset stays real (and must stay positive: `bad`), a symbolic one adds d to its delta
+ZS_FN i32 hist_minus(i32 a, u32 d, u32& bad) {
+  const i32 real = (i32)((u32)a - d), sym = (i32)((u32)a - 3u * d);      // (unsigned: the unused branch of hist_eval may wrap)
+  bad |= (a > 0) & (real <= 0) ? 1u : 0u;
+  return ZS_SEL(a > 0, real, sym);
+}
+// what slot s (> 0: a real offset; ≤ 0: −(1 + j + 3·d) = input entry j minus d) is worth on the inputs a0, a1, a2
+ZS_FN i32 hist_eval(i32 s, i32 a0, i32 a1, i32 a2, u32& bad) {
+  const u32 t = ~(u32)s, d = (u32)(((u64)t * 0xAAAAAAABull) >> 33), j = t - 3u * d;       // (s > 0: t wraps, the result below is not used)
+  const i32 a = ZS_SEL(j == 0u, a0, ZS_SEL(j == 1u, a1, a2));
+  u32 b = 0;
+  const i32 v = hist_minus(a, d, b);
+  bad |= ZS_SEL(s > 0, 0u, b);
+  return ZS_SEL(s > 0, s, v);
+}
+// (3a) (the group) every thread: the rules over its own sequences, from the symbolic history
+ZS_FN void seq_history_local(ZS_LDS SeqLds* L, int k, int tt) {
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  const u32 n = B->rcount, i0 = (u32)tt * kSeqPer;
+  i32 r0 = rep_symbolic(0), r1 = rep_symbolic(1), r2 = rep_symbolic(2), worst = 1;
+  u32 sum_ll = 0, sum_ml = 0;
+  for (u32 i = i0; i < i0 + kSeqPer && i < n; i++) {
+    const SeqQuad v = quad_load(&B->vals[i]);
+    const u32 ll = v.x, ov = v.z;
+    const bool rep = ov <= 3u;
+    const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
+    const i32 less = r0 + ZS_SEL(r0 > 0, -1, -3);
+    i32 picked = ZS_SEL(idx == 2u, r2, less);
+    picked = ZS_SEL(idx == 1u, r1, picked);
+    picked = ZS_SEL(idx == 0u, r0, picked);
+    const i32 off = ZS_SEL(rep, picked, (i32)(ov - 3u));
+    const bool front = rep & (idx == 0u), second = rep & (idx <= 1u);
+    r2 = ZS_SEL(second, r2, r1);
+    r1 = ZS_SEL(front, r1, r0);
+    r0 = off;                                                  // (front: off IS r0)
+    const i32 fresh = ZS_SEL(rep, ZS_SEL(off == 0, 0, 1), off);       // a new offset must be positive; "one less" must not reach zero
+    worst = fresh < worst ? fresh : worst;
+    sum_ll += ll;
+    sum_ml += v.y;
+    B->vals[i].z = (u32)off;
+  }
+  quad_store(&B->scan[0][tt], (u32)r0, (u32)r1, (u32)r2, worst <= 0 ? 1u : 0u);
+  if (i0 < n) { SN2_ATOMIC_ADD_LDS(&B->sum_ll, sum_ll); SN2_ATOMIC_ADD_LDS(&B->sum_ml, sum_ml); }
+}
+// (3b) (the group) step p of the inclusive scan: the function of the runs up to and including this thread's
+ZS_FN void seq_history_step(ZS_LDS SeqLds* L, int k, int p, int tt) {
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  const int from = p & 1, d = 1 << p;
+  SeqQuad t = quad_load(&B->scan[from][tt]);
+  if (tt >= d) {
+    const SeqQuad e = quad_load(&B->scan[from][tt - d]);       // the earlier runs first
+    u32 bad = t.w | e.w;
+    const i32 s0 = hist_eval((i32)t.x, (i32)e.x, (i32)e.y, (i32)e.z, bad), s1 = hist_eval((i32)t.y, (i32)e.x, (i32)e.y, (i32)e.z, bad),
+              s2 = hist_eval((i32)t.z, (i32)e.x, (i32)e.y, (i32)e.z, bad);
+    t.x = (u32)s0; t.y = (u32)s1; t.z = (u32)s2; t.w = bad;
+  }
+  quad_store(&B->scan[from ^ 1][tt], t.x, t.y, t.z, t.w);
+}
+// (3c) (the group) every thread: its run's starting history, its noted offsets made real; the round's last run leaves the history behind
+ZS_FN void seq_history_apply(ZS_LDS SeqLds* L, int k, u32 round, int tt) {
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  const u32 n = B->rcount, i0 = (u32)tt * kSeqPer;
+  if (i0 >= n) return;
+  const i32 h0 = B->hist[round & 1u][0], h1 = B->hist[round & 1u][1], h2 = B->hist[round & 1u][2];
+  u32 bad = 0;
+  i32 a0 = h0, a1 = h1, a2 = h2;
+  if (tt) {
+    const SeqQuad e = quad_load(&B->scan[kSeqScanSteps & 1][tt - 1]);
+    bad = e.w;
+    a0 = hist_eval((i32)e.x, h0, h1, h2, bad);
+    a1 = hist_eval((i32)e.y, h0, h1, h2, bad);
+    a2 = hist_eval((i32)e.z, h0, h1, h2, bad);
+  }
+  for (u32 i = i0; i < i0 + kSeqPer && i < n; i++) B->vals[i].z = (u32)hist_eval((i32)B->vals[i].z, a0, a1, a2, bad);
+  if (i0 + kSeqPer >= n) {                                     // the run that holds the round's last sequence
+    const SeqQuad e = quad_load(&B->scan[kSeqScanSteps & 1][tt]);
+    bad |= e.w;
+    B->hist[(round + 1u) & 1u][0] = hist_eval((i32)e.x, h0, h1, h2, bad);
+    B->hist[(round + 1u) & 1u][1] = hist_eval((i32)e.y, h0, h1, h2, bad);
+    B->hist[(round + 1u) & 1u][2] = hist_eval((i32)e.z, h0, h1, h2, bad);
+  }
+  if (bad) B->status = ST_ERR_OFFSET;
+}
+// (the group's thread) behind (3c): the round's checks
+ZS_FN void seq_round_check(ZS_LDS SeqLds* L, int k) {
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  if (B->status) { B->rcount = 0; return; }
+  if (B->sum_ll > kBlockMax || B->sum_ml > kBlockMax) { B->status = ST_ERR_LENGTH; B->rcount = 0; }     // (checked every round: the sums cannot wrap in between)
+}
+// (4) (the group) the round's sequences to the block's records
+ZS_FN void seq_flush(const ZS_LDS SeqLds* L, int k, ZRec* recs_block, u32 base, int tt) {
+  const ZS_LDS SeqBlockLds* B = &L->b[k];
+  for (u32 i = (u32)tt; i < B->rcount; i += (u32)kSeqGroup) {
+    ZRec* r = recs_block + base + i;
+    const SeqQuad v = quad_load(&B->vals[i]);
+    r->ll = v.x;
+    r->ml = v.y;
+    r->off = (i32)v.z;
+  }
+}
+// the group's thread, behind the last round: the stream must be used up; the trailing literals; the block's size and history on exit
+ZS_FN void seq_finish(ZS_LDS SeqLds* L, int k, SeqState& st, ZBlock* b, ZRec* recs_block) {
+  ZS_LDS SeqBlockLds* B = &L->b[k];
+  if (!seq_block_has_stream(*b)) {                           // a raw / RLE block, or a block of literals only: one run of literals
+    const u32 n = b->type == BT_COMPRESSED ? b->lit_regen : b->size;
+    recs_block[0].ll = n;
+    recs_block[0].ml = 0;
+    recs_block[0].off = 0;
+    b->out_size = n;
+    for (int j = 0; j < 3; j++) b->rep_out[j] = rep_symbolic(j);
+    return;
+  }
+  if (B->status) return;
+  if (st.done != b->nseq || seq_bitpos(B, st.tq) != 0) { B->status = ST_ERR_BITS; return; }
+  if (B->sum_ll > b->lit_regen || B->sum_ll + B->sum_ml > kBlockMax) { B->status = ST_ERR_LENGTH; return; }
+  recs_block[b->nseq].ll = b->lit_regen - B->sum_ll;
+  recs_block[b->nseq].ml = 0;
+  recs_block[b->nseq].off = 0;
+  b->out_size = b->lit_regen + B->sum_ml;
+  const u32 r = seq_rounds(*b) & 1u;
+  for (int j = 0; j < 3; j++) b->rep_out[j] = B->hist[r][j];
+}
+ZS_FN u32 seq_status(const ZS_LDS SeqLds* L, int k) { return L->b[k].status; }
+ZS_FN u32 seq_rounds_of(const ZS_LDS SeqLds* L, int k) { return L->b[k].rounds; }
+#else
 // ---- kernel A2: the sequences of FOUR blocks — one 64-thread workgroup, 16 threads per block.  A block's sequences are one serial chain
 // (three interleaved FSE states over one backward bitstream), and a SIMD issues one instruction per four cycles whatever the instruction
 // does for how many lanes: a first version with ONE decoding lane per wave, its state in scalar registers, sat at the machine's issue rate
@@ -931,6 +1259,10 @@ ZS_FN void seq_finish(ZS_LDS SeqLds* L, int k, SeqState& st, ZBlock* b, ZRec* re
   b->rep_out[1] = st.c.r1;
   b->rep_out[2] = st.c.r2;
 }
+
+ZS_FN u32 seq_status(const ZS_LDS SeqLds* L, int k) { return L->status[k]; }
+ZS_FN u32 seq_rounds_of(const ZS_LDS SeqLds* L, int k) { return L->rounds[k]; }
+#endif
 
 // ---- kernel B: one lane per page ----
 ZS_FN void page_blocks(const ZPage& pg, ZBlock* blocks, u32* status, int page_index) {

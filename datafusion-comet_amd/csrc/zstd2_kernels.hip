@@ -13,6 +13,9 @@
 #define SN2_ATOMIC_ADD_LDS(p, v) __hip_atomic_fetch_add((uint32_t*)(p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define SN2_ATOMIC_MIN_LDS(p, v) __hip_atomic_fetch_min((uint32_t*)(p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define ZS2_DEVICE_ONLY
+#ifndef ZS_SEQ_TIMING_SKIP
+#define ZS_SEQ_TIMING_SKIP 0       // measurement builds only (tools/build_zstd_variants.sh): 1 skips the values phase, 2 the history phase, 4 the flush — wrong output, timing of what is left
+#endif
 #include "device/zstd2.hpp"
 
 namespace {
@@ -87,18 +90,41 @@ __global__ __launch_bounds__(64) void zs2_sequences_kernel(const ZPage* __restri
   SeqState st;
   if (tt == 0 && seq_block_has_stream(blk)) { seq_fill_done(L, k); seq_start(L, k, st, blk); }
   u32 rounds = 0;
-  for (int j = 0; j < kSeqLanes; j++) rounds = s.rounds[j] > rounds ? s.rounds[j] : rounds;
+  for (int j = 0; j < kSeqLanes; j++) rounds = seq_rounds_of(L, j) > rounds ? seq_rounds_of(L, j) : rounds;
   for (u32 r = 0; r < rounds; r++) {
+#if ZS_SEQ_SPLIT
+    if (tt == 0) seq_chain_round(L, k, st, blk);
+    __syncthreads();
+#if !(ZS_SEQ_TIMING_SKIP & 1)
+    seq_values(L, k, tt);
+    __syncthreads();
+#endif
+#if !(ZS_SEQ_TIMING_SKIP & 2)
+    seq_history_local(L, k, tt);
+    __syncthreads();
+    for (int p = 0; p < kSeqScanSteps; p++) {
+      seq_history_step(L, k, p, tt);
+      __syncthreads();
+    }
+    seq_history_apply(L, k, r, tt);
+    __syncthreads();
+    if (tt == 0) seq_round_check(L, k);
+    __syncthreads();
+#endif
+#else
     if (tt == 0) seq_round(L, k, st, blk);
     __syncthreads();
+#endif
+#if !(ZS_SEQ_TIMING_SKIP & 4)
     seq_flush(L, k, recs, r * kSeqRound, tt);
+#endif
     seq_fill(L, k, src, blk, pg.src_len, tt);
     __syncthreads();
     if (tt == 0) seq_fill_done(L, k);
   }
   if (tt == 0 && have) {
     seq_finish(L, k, st, &blocks[bi], recs);
-    if (s.status[k]) atomicMax(&status[pi], s.status[k]);
+    if (seq_status(L, k)) atomicMax(&status[pi], seq_status(L, k));
   }
 }
 

@@ -96,10 +96,20 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
     u32 rounds = 0;
     for (int k = 0; k < kSeqLanes; k++) {
       if (seq_block_has_stream(blk(k))) { seq_fill_done(SL.get(), k); seq_start(SL.get(), k, st[k], blk(k)); }
-      rounds = SL->rounds[k] > rounds ? SL->rounds[k] : rounds;
+      rounds = seq_rounds_of(SL.get(), k) > rounds ? seq_rounds_of(SL.get(), k) : rounds;
     }
     for (u32 r = 0; r < rounds; r++) {
+#if ZS_SEQ_SPLIT
+      for (int k = 0; k < kSeqLanes; k++) seq_chain_round(SL.get(), k, st[k], blk(k));
+      for (int t = 0; t < 64; t++) seq_values(SL.get(), t / kSeqGroup, t % kSeqGroup);
+      for (int t = 0; t < 64; t++) seq_history_local(SL.get(), t / kSeqGroup, t % kSeqGroup);
+      for (int p = 0; p < kSeqScanSteps; p++)
+        for (int t = 0; t < 64; t++) seq_history_step(SL.get(), t / kSeqGroup, p, t % kSeqGroup);
+      for (int t = 0; t < 64; t++) seq_history_apply(SL.get(), t / kSeqGroup, r, t % kSeqGroup);
+      for (int k = 0; k < kSeqLanes; k++) seq_round_check(SL.get(), k);
+#else
       for (int k = 0; k < kSeqLanes; k++) seq_round(SL.get(), k, st[k], blk(k));
+#endif
       for (int t = 0; t < 64; t++) seq_flush(SL.get(), t / kSeqGroup, recp(t / kSeqGroup), r * kSeqRound, t % kSeqGroup);
       for (int t = 0; t < 64; t++) seq_fill(SL.get(), t / kSeqGroup, srcp(t / kSeqGroup), blk(t / kSeqGroup), page(t / kSeqGroup).src_len, t % kSeqGroup);
       for (int k = 0; k < kSeqLanes; k++) seq_fill_done(SL.get(), k);
@@ -107,7 +117,7 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
     for (int k = 0; k < kSeqLanes && b0 + (size_t)k < blocks.size(); k++) {
       seq_finish(SL.get(), k, st[k], &blk(k), recp(k));
       const int pi = block_page[b0 + (size_t)k];
-      if (SL->status[k] && SL->status[k] > status[(size_t)pi]) status[(size_t)pi] = SL->status[k];
+      if (seq_status(SL.get(), k) && seq_status(SL.get(), k) > status[(size_t)pi]) status[(size_t)pi] = seq_status(SL.get(), k);
     }
   }
   // kernel B

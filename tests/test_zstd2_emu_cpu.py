@@ -19,11 +19,9 @@ SEEN = "raw_block rle_block compressed_block lit_raw lit_rle lit_huffman lit_tre
 CSRC = os.path.join(ROOT, "datafusion-comet_amd", "csrc")
 
 
-# "compact": the sequence kernel's experiment with one-word table entries and eight decoding lanes per workgroup (device/zstd2.hpp, ZS_SEQ_COMPACT) —
-# not the shipped build; kept correct here so that it can be measured on the device as it is
-# "round64": 64 instead of 32 sequences between two barriers of the sequence kernel (ZS_SEQ_ROUND) — the second experiment waiting for a device measurement
-@pytest.fixture(scope="module", params=[[], ["-DZS_SEQ_COMPACT=1", "-DZS_SEQ_LANES=8"], ["-DZS_SEQ_ROUND=64"], ["-DZS_SEQ_COMPACT=1", "-DZS_SEQ_LANES=8", "-DZS_SEQ_ROUND=64"]],
-                ids=["shipped", "compact", "round64", "compact_round64"])
+# "split" (shipped since round 4): the sequence kernel's chain carries only the states and the cursor, values and repeat offsets are separate phases;
+# "round3": the previous kernel (one-word tables, eight decoding lanes, everything in the chain: -DZS_SEQ_SPLIT=0) — kept buildable as the fallback
+@pytest.fixture(scope="module", params=[[], ["-DZS_SEQ_SPLIT=0"]], ids=["split", "round3"])
 def emu(tmp_path_factory, request):
     so = str(tmp_path_factory.mktemp("zstd2_emu") / "libzstd2_emu.so")
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC] + request.param + [os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", so], check=True)
@@ -177,7 +175,7 @@ def test_host_prefix_is_the_pages_first_bytes(emu):
                 assert got == n and b == p[:n], (level, len(p), n, got)
 
 
-@pytest.mark.parametrize("flags", [[], ["-DZS_SEQ_COMPACT=1", "-DZS_SEQ_LANES=8", "-DZS_SEQ_ROUND=64"]], ids=["shipped", "compact_round64"])
+@pytest.mark.parametrize("flags", [[], ["-DZS_SEQ_SPLIT=0"]], ids=["split", "round3"])
 def test_damaged_frames_under_address_sanitizer(tmp_path, flags):
     exe = str(tmp_path / "zstd2_fuzz")
     r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + CSRC] + flags +

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the zstd sequence kernel's experiments (device/zstd2.hpp: ZS_SEQ_ROUND, ZS_SEQ_COMPACT) as whole libraries next to the shipped one:
+# Builds variants of the zstd kernels (device/zstd2.hpp switches, given as name:flags arguments) as whole libraries next to the shipped one:
 # datafusion-comet_amd/variants/libcomet_<name>.so (git-ignored, they travel to the GPU box with gpurun).  Run here (hipcc cross-compiles),
 # then tools/gpu_zstd_variants.sh on the box.  The shipped libcomet.so is rebuilt unchanged at the end.
 set -e
@@ -10,9 +10,7 @@ build() {   # name, flags
   make -s -j8 OUT=../variants/libcomet_$1.so EXTRA_HIPFLAGS="$2"
   echo "built variants/libcomet_$1.so ($2)"
 }
-build round64 "-DZS_SEQ_ROUND=64"
-build compact "-DZS_SEQ_COMPACT=1 -DZS_SEQ_LANES=8"
-build compact_round64 "-DZS_SEQ_COMPACT=1 -DZS_SEQ_LANES=8 -DZS_SEQ_ROUND=64"
+for v in "$@"; do build "${v%%:*}" "${v#*:}"; done     # name:flags pairs, e.g.  round3:-DZS_SEQ_SPLIT=0
 touch zstd2_kernels.hip
 make -s -j8
 echo "shipped libcomet.so rebuilt"

@@ -24,16 +24,16 @@ bench_stats() {    # rocprofv3 kernel statistics of the headline loop only
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-extra-legs --no-cpu-baseline > $OUT/bench_stats.json 2> /dev/null)
   grep -E '^"k_|utf8_' $OUT/bench_stats/b_kernel_stats.csv | cut -c1-120
 }
-zstd_variants() {  # the shipped library, then each variant of tools/build_zstd_variants.sh: device parity + the 480-page pipeline
+zstd_variants() {  # the shipped library, then each variant of tools/build_zstd_variants.sh: device parity, the 480-page pipeline, per-kernel averages
   cp datafusion-comet_amd/libcomet.so /tmp/libcomet_shipped.so
   for v in shipped $(ls datafusion-comet_amd/variants 2>/dev/null | sed -n 's/^libcomet_\(.*\)\.so$/\1/p'); do
     if [ $v = shipped ]; then cp /tmp/libcomet_shipped.so datafusion-comet_amd/libcomet.so; else cp datafusion-comet_amd/variants/libcomet_$v.so datafusion-comet_amd/libcomet.so; fi
-    timeout 180 python -m pytest tests/test_device_zstd_gpu.py -x -q > $OUT/pytest_zstd_$v.log 2>&1
-    echo "== $v: $(tail -1 $OUT/pytest_zstd_$v.log | cut -c1-80)"
-    for rep in 1 2; do
-      timeout 60 python tools/snappy_bench.py --codec zstd --level 1 --pages 480 --kinds decimal_int64 --out $OUT/zstd_${v}_$rep.json > /dev/null 2> $OUT/zstd_${v}_$rep.err
-      cut -c1-300 $OUT/zstd_${v}_$rep.json; echo
-    done
+    case $v in t_*) echo "== $v (timing only: output not checked)";;
+      *) timeout 180 python -m pytest tests/test_device_zstd_gpu.py -x -q > $OUT/pytest_zstd_$v.log 2>&1; echo "== $v: $(tail -1 $OUT/pytest_zstd_$v.log | cut -c1-80)"
+         timeout 60 python tools/snappy_bench.py --codec zstd --level 1 --pages 480 --kinds decimal_int64 --out $OUT/zstd_${v}.json > /dev/null 2> $OUT/zstd_${v}.err; cut -c1-300 $OUT/zstd_${v}.json; echo;;
+    esac
+    (cd /tmp && timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/zstd_stats_$v -o z -- python $GRAFT_REPO_ROOT/tools/snappy_bench.py --codec zstd --level 1 --pages 480 --kinds decimal_int64 --no-check > /dev/null 2>&1)
+    grep -E '^"(zs2)' $OUT/zstd_stats_$v/z_kernel_stats.csv | cut -d, -f1,2,4 | tr '\n' ' '; echo
   done
   cp /tmp/libcomet_shipped.so datafusion-comet_amd/libcomet.so
 }
@@ -55,6 +55,15 @@ parquet_q6() {     # SF10 Q6 from Parquet: codec, scan threads (0 = the box's), 
     N=pq6_$1_t$2_$3
     COMET_TRACE_STAGES=1 timeout 240 python tools/parquet_q6.py --codec $1 --dir $PQ --scan-threads $2 --device-decompress $3 --steps 5 --out $OUT/$N.json > $OUT/$N.log 2>&1
     echo "== $CFG"; cut -c1-420 $OUT/$N.json; echo; grep "parquet:" $OUT/$N.log | tail -${PQ_TRACE_LINES:-14} | cut -c1-230
+  done
+}
+pq_timeline() {    # device timeline (kernels + copies) of one SF10 Q6 scan per configuration in $PQ_CFGS
+  for CFG in ${PQ_CFGS:-"snappy 0 auto" "zstd 0 true"}; do
+    set -- $CFG
+    N=tl_$1_t$2_$3
+    (cd /tmp && timeout 240 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/$N -o t -- python $GRAFT_REPO_ROOT/tools/parquet_q6.py --codec $1 --dir $PQ --scan-threads $2 --device-decompress $3 --steps 2 > $OUT/$N.log 2>&1)
+    python tools/timeline.py $(find $OUT/$N -name "*kernel_trace.csv") $(find $OUT/$N -name "*memory_copy_trace.csv") > $OUT/$N.txt 2>&1
+    echo "== $CFG"; head -${TL_LINES:-70} $OUT/$N.txt | cut -c1-200
   done
 }
 q3_stats() {       # SF100 Q3 on one GPU: kernel statistics + PMC of the probes and the filter (separate passes)
