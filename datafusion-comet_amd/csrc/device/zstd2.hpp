@@ -518,11 +518,9 @@ ZS_FN u32 seq_step(BB& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, bool l
   c.done++;
   return (!rep && off <= 0) ? (u32)ST_ERR_OFFSET : (u32)ST_OK;
 }
-// ---- the sequence kernel's reader and step.  seq_step above keeps a 192-bit register window alive (three 64-bit registers stepping down by
-// selects, two 128-bit funnel shifts per window): ≈ 170 instructions per sequence in the gfx950 code, and a serial lane is bound by the
-// instructions it issues.  Here NOTHING of the stream is carried between fields: the cursor is a bit position, and the 64 bits below any
-// bit position are three aligned words of the block's window in workgroup memory, funnel-shifted (v_alignbit_b32) — the loads of a
-// step's two windows (values; states) are issued together right behind the table loads. ----
+// ---- the sequence kernel's bit reader.  seq_step above (the host's prefix decoder uses it) keeps a 192-bit register window alive; the
+// device carries NOTHING of the stream between fields: the cursor is a bit position, and the bits below any bit position are aligned words
+// of the block's window in workgroup memory, funnel-shifted (v_alignbit_b32). ----
 ZS_FN u32 funnel32(u32 hi, u32 lo, u32 sh) { return (u32)((((u64)hi << 32) | (u64)lo) >> (sh & 31u)); }        // (hi:lo) >> sh, sh < 32
 // the top n bits of a word, n ≤ 31 (n = 0 → 0): one bit-field extract on the device
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -564,99 +562,6 @@ struct SeqBits {
   }
   ZS_FN i32 cursor_byte() const { return bitpos > 0 ? (bitpos + 7) >> 3 : 0; }
 };
-ZS_FN void seq_begin_ring(SeqBits& b, SeqCore& c, int lll, int lof, int lml) {
-  c.sll = b.get((u32)lll);
-  c.sof = b.get((u32)lof);
-  c.sml = b.get((u32)lml);
-  c.r0 = rep_symbolic(0);
-  c.r1 = rep_symbolic(1);
-  c.r2 = rep_symbolic(2);
-  c.sum_ll = c.sum_ml = 0;
-  c.done = 0;
-}
-// the next sequence; `worst`: the smallest new offset seen (≤ 0: one was invalid — the caller looks once per round: no branch in here)
-template <class TabPtr>
-ZS_FN void seq_step_ring(SeqBits& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, bool last, u32& ll, u32& ml, i32& off, i32& worst) {
-  const u32 lb = tll[2 * c.sll], lh = tll[2 * c.sll + 1];
-  const u32 ob = tof[2 * c.sof], oh = tof[2 * c.sof + 1];
-  const u32 mb = tml[2 * c.sml], mh = tml[2 * c.sml + 1];
-  const u32 oe = (oh >> 8) & 0xffu, me = (mh >> 8) & 0xffu, le = (lh >> 8) & 0xffu;
-  const u32 ln = lh & 0xffu, mn = mh & 0xffu, on = oh & 0xffu;
-  const u32 values = oe + me + le, states = ZS_SEL(last, 0u, ln + mn + on);       // ≤ 31 + 16 + 16; ≤ 9 + 9 + 8
-  u64 wv = b.below(b.bitpos), ws = b.below(b.bitpos - (i32)values);
-  b.bitpos -= (i32)(values + states);
-  const u32 ov = ob + top_field((u32)(wv >> 32), oe);
-  wv <<= oe;
-  ml = mb + top_field((u32)(wv >> 32), me);
-  wv <<= me;
-  ll = lb + top_field((u32)(wv >> 32), le);
-  c.sll = (lh >> 16) + top_field((u32)(ws >> 32), ln);     // (behind the last sequence: never looked at, and nothing is consumed for them)
-  ws <<= ln;
-  c.sml = (mh >> 16) + top_field((u32)(ws >> 32), mn);
-  ws <<= mn;
-  c.sof = (oh >> 16) + top_field((u32)(ws >> 32), on);
-  // The repeat-offset rules of seq_step, every candidate computed, every choice a select: a value > 3 is a new offset (pushed onto the
-  // history), 1 … 3 names an entry (shifted by one when there are no literals, the fourth choice being "the newest entry minus one"),
-  // which moves to the front
-  const bool rep = ov <= 3u;
-  const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
-  const i32 r0 = c.r0, r1 = c.r1, r2 = c.r2, less = r0 + ZS_SEL(r0 > 0, -1, -3);
-  i32 picked = ZS_SEL(idx == 2u, r2, less);
-  picked = ZS_SEL(idx == 1u, r1, picked);
-  picked = ZS_SEL(idx == 0u, r0, picked);
-  off = ZS_SEL(rep, picked, (i32)(ov - 3u));
-  const bool front = rep & (idx == 0u), second = rep & (idx <= 1u);
-  c.r2 = ZS_SEL(second, r2, r1);
-  c.r1 = ZS_SEL(front, r1, r0);
-  c.r0 = off;                                                // (front: off IS r0)
-  const i32 fresh = ZS_SEL(rep, 1, off);
-  worst = fresh < worst ? fresh : worst;
-  c.sum_ll += ll;
-  c.sum_ml += ml;
-  c.done++;
-}
-
-// The same step over tables of ONE word per state (fse_build's own entries: symbol | bits of the next state << 8 | base of the next state << 16):
-// a literal-length / match-length symbol's base and extra bits come from the code tables shared by the workgroup (one more dependent lookup),
-// an offset symbol's are 1 << symbol and the symbol.  Half the workgroup memory per block: build with -DZS_SEQ_COMPACT=1 -DZS_SEQ_LANES=8
-// (eight decoding lanes per wave, sixteen per CU instead of twelve).  An experiment: not the default, not yet measured on the device.
-template <class TabPtr, class CodePtr>
-ZS_FN void seq_step_ring_compact(SeqBits& b, SeqCore& c, TabPtr tll, TabPtr tof, TabPtr tml, CodePtr llc, CodePtr mlc, bool last, u32& ll, u32& ml, i32& off, i32& worst) {
-  const u32 el = tll[c.sll], eo = tof[c.sof], em = tml[c.sml];
-  const u32 cl = llc[el & 0xffu], cm = mlc[em & 0xffu];
-  const u32 lb = cl & 0xffffffu, le = cl >> 24, mb = cm & 0xffffffu, me = cm >> 24, oe = eo & 0xffu, ob = 1u << oe;
-  const u32 ln = (el >> 8) & 0xffu, mn = (em >> 8) & 0xffu, on = (eo >> 8) & 0xffu;
-  const u32 values = oe + me + le, states = ZS_SEL(last, 0u, ln + mn + on);
-  u64 wv = b.below(b.bitpos), ws = b.below(b.bitpos - (i32)values);
-  b.bitpos -= (i32)(values + states);
-  const u32 ov = ob + top_field((u32)(wv >> 32), oe);
-  wv <<= oe;
-  ml = mb + top_field((u32)(wv >> 32), me);
-  wv <<= me;
-  ll = lb + top_field((u32)(wv >> 32), le);
-  c.sll = (el >> 16) + top_field((u32)(ws >> 32), ln);
-  ws <<= ln;
-  c.sml = (em >> 16) + top_field((u32)(ws >> 32), mn);
-  ws <<= mn;
-  c.sof = (eo >> 16) + top_field((u32)(ws >> 32), on);
-  const bool rep = ov <= 3u;
-  const u32 idx = ov - 1u + (ll == 0 ? 1u : 0u);
-  const i32 r0 = c.r0, r1 = c.r1, r2 = c.r2, less = r0 + ZS_SEL(r0 > 0, -1, -3);
-  i32 picked = ZS_SEL(idx == 2u, r2, less);
-  picked = ZS_SEL(idx == 1u, r1, picked);
-  picked = ZS_SEL(idx == 0u, r0, picked);
-  off = ZS_SEL(rep, picked, (i32)(ov - 3u));
-  const bool front = rep & (idx == 0u), second = rep & (idx <= 1u);
-  c.r2 = ZS_SEL(second, r2, r1);
-  c.r1 = ZS_SEL(front, r1, r0);
-  c.r0 = off;
-  const i32 fresh = ZS_SEL(rep, 1, off);
-  worst = fresh < worst ? fresh : worst;
-  c.sum_ll += ll;
-  c.sum_ml += ml;
-  c.done++;
-}
-
 // ---- kernel A1: the literals of one block — one 64-thread workgroup.  Threads 0 … 3 decode a Huffman stream each, 256 symbols a round,
 // out of their stream's window in workgroup memory into a buffer there; between rounds ALL threads slide the windows and write the
 // buffers out.  Raw / RLE literals (and raw / RLE blocks) are copied or filled by all threads. ----
@@ -771,10 +676,6 @@ ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Hu
   return (longest + kLitRound - 1) / kLitRound;
 }
 
-#ifndef ZS_SEQ_SPLIT
-#define ZS_SEQ_SPLIT 1
-#endif
-#if ZS_SEQ_SPLIT
 // ---- kernel A2 (round 4): the sequences of FOUR blocks — one 64-thread workgroup, 16 threads per block; the serial chain carries ONLY what
 // is serial.  A block's sequences are one chain (three interleaved FSE states over one backward bitstream), and one wave issues about one
 // instruction per four cycles whatever the instruction does for how many lanes, so a block costs (instructions per sequence) × 4 cycles ×
@@ -785,7 +686,7 @@ ZS_FN u32 lit_rounds(const ZBlock& b) {                        // rounds of a Hu
 //   (2) values   — the group's 16 threads, four sequences each: literal length, match length and offset value from the noted entries and
 //                  cursor (the bitstream's window is still there);
 //   (3) history  — the repeat-offset rules over the 64 offset values: a recurrence, but one whose steps compose — a scan over the group (below);
-//   (4) flush    — the group: records to global memory, the window slides.
+//   (4) records  — with (3): every thread writes its four sequences' records (lengths, offset, positions inside the block); the window slides.
 // Table entries are one word — bits of the next state [0, 5) | extra bits of the value [5, 11) | symbol [11, 17) | word address of the
 // next state's base entry [17, 32) — so that ONE three-operand add of a sequence's entries yields both bit totals (neither field can carry:
 // ≤ 26 and ≤ 63) and the next state's address is an add and a shift.  10 KiB of workgroup memory per block, four workgroups per CU: every
@@ -807,11 +708,14 @@ struct alignas(16) SeqBlockLds {
   union {
     SeqQuad chain[kSeqRound];           // (1) → (2): the sequence's three table entries and the cursor in front of it
     u8 hdr[3][128];                     // the table descriptions, staged (read before the first round)
+    struct {                            // (3), when the chain's notes have been read:
+      SeqQuad scan[2][64 / ZS_SEQ_LANES];     // the threads' history functions (three slots + a "malformed" mark), double-buffered for the scan
+      u32 psum[2][64 / ZS_SEQ_LANES][2];      // the threads' literal / match byte counts, scanned with the functions
+    } h;
   } u;
-  SeqQuad vals[kSeqRound];              // (2) → (3) → (4): ll, ml, offset value → offset (symbolic or real), unused
-  SeqQuad scan[2][64 / ZS_SEQ_LANES];   // (3): the threads' history functions (three slots + a "malformed" mark), double-buffered for the scan
+  SeqQuad vals[kSeqRound];              // (2) → (3): ll, ml, offset value → offset relative to the thread's run, unused
   i32 hist[2][4];                       // the repeat-offset history in front of round r: hist[r & 1] (symbolic until an offset of this block replaces an entry)
-  u32 sum_ll, sum_ml, pad1[2];          // (checked every round: no overflow in between)
+  u32 sums[2][2];                       // literal / match bytes in front of round r: sums[r & 1] (checked every round: no overflow in between)
   i16 norm[64];
   u16 next[64];
   i32 fse_log[3];
@@ -819,6 +723,7 @@ struct alignas(16) SeqBlockLds {
   u32 bias, rcount, rounds, status;
   u32 pad[3];
 };
+static_assert(sizeof(SeqBlockLds) * 4 + 512 <= 40960 || ZS_SEQ_LANES != 4, "four workgroups of four blocks must fit a CU's 160 KiB: every block of a 480-page launch in flight at once");
 struct SeqLds {
   SeqBlockLds b[kSeqLanes];
   u32 llc[36], mlc[53];                 // the literal-length / match-length codes' (base | extra bits << 24)
@@ -850,7 +755,7 @@ ZS_FN i32 seq_bitpos(const ZS_LDS SeqBlockLds* B, u32 tq) { return (i32)(tq + 96
 // phase 1 (the group): stage the table descriptions (this block's, or — repeat mode — an earlier block's)
 ZS_FN void seq_stage(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, u32 src_len, int tt) {
   ZS_LDS SeqBlockLds* B = &L->b[k];
-  if (tt == 0) { B->status = 0; B->rcount = 0; B->rounds = seq_rounds(b); B->sum_ll = B->sum_ml = 0; }
+  if (tt == 0) { B->status = 0; B->rcount = 0; B->rounds = seq_rounds(b); B->sums[0][0] = B->sums[0][1] = 0; }
   const u32 t = (u32)k * (u32)kSeqGroup + (u32)tt;                       // (the workgroup's 64 threads fill the code tables once)
   if (t < 36u) L->llc[t] = ll_code_entry(t);
   if (t < 53u) L->mlc[t] = ml_code_entry(t);
@@ -905,7 +810,6 @@ ZS_FN void seq_start(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {  
   st.aM = seq_lds_addr(L, &B->tab[kTabML + sml]);
   st.tq = (u32)rd.bitpos + 8u * B->bias - 96u;
   for (int j = 0; j < 3; j++) B->hist[0][j] = rep_symbolic(j);
-  B->sum_ll = B->sum_ml = 0;
 }
 // (1) the group's thread: the chain over the block's next ≤ 64 sequences
 ZS_FN void seq_chain_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
@@ -1015,70 +919,92 @@ ZS_FN void seq_history_local(ZS_LDS SeqLds* L, int k, int tt) {
     sum_ml += v.y;
     B->vals[i].z = (u32)off;
   }
-  quad_store(&B->scan[0][tt], (u32)r0, (u32)r1, (u32)r2, worst <= 0 ? 1u : 0u);
-  if (i0 < n) { SN2_ATOMIC_ADD_LDS(&B->sum_ll, sum_ll); SN2_ATOMIC_ADD_LDS(&B->sum_ml, sum_ml); }
+  quad_store(&B->u.h.scan[0][tt], (u32)r0, (u32)r1, (u32)r2, worst <= 0 ? 1u : 0u);
+  B->u.h.psum[0][tt][0] = sum_ll;
+  B->u.h.psum[0][tt][1] = sum_ml;
 }
 // (3b) (the group) step p of the inclusive scan: the function of the runs up to and including this thread's
 ZS_FN void seq_history_step(ZS_LDS SeqLds* L, int k, int p, int tt) {
   ZS_LDS SeqBlockLds* B = &L->b[k];
   const int from = p & 1, d = 1 << p;
-  SeqQuad t = quad_load(&B->scan[from][tt]);
+  SeqQuad t = quad_load(&B->u.h.scan[from][tt]);
+  u32 pl = B->u.h.psum[from][tt][0], pm = B->u.h.psum[from][tt][1];
   if (tt >= d) {
-    const SeqQuad e = quad_load(&B->scan[from][tt - d]);       // the earlier runs first
+    pl += B->u.h.psum[from][tt - d][0];
+    pm += B->u.h.psum[from][tt - d][1];
+    const SeqQuad e = quad_load(&B->u.h.scan[from][tt - d]);       // the earlier runs first
     u32 bad = t.w | e.w;
     const i32 s0 = hist_eval((i32)t.x, (i32)e.x, (i32)e.y, (i32)e.z, bad), s1 = hist_eval((i32)t.y, (i32)e.x, (i32)e.y, (i32)e.z, bad),
               s2 = hist_eval((i32)t.z, (i32)e.x, (i32)e.y, (i32)e.z, bad);
     t.x = (u32)s0; t.y = (u32)s1; t.z = (u32)s2; t.w = bad;
   }
-  quad_store(&B->scan[from ^ 1][tt], t.x, t.y, t.z, t.w);
+  quad_store(&B->u.h.scan[from ^ 1][tt], t.x, t.y, t.z, t.w);
+  B->u.h.psum[from ^ 1][tt][0] = pl;
+  B->u.h.psum[from ^ 1][tt][1] = pm;
 }
-// (3c) (the group) every thread: its run's starting history, its noted offsets made real; the round's last run leaves the history behind
-ZS_FN void seq_history_apply(ZS_LDS SeqLds* L, int k, u32 round, int tt) {
+// (3c) + (4) (the group) every thread: its run's starting history and positions; its sequences become records — literal length, match
+// length, the noted offset made real (or block-symbolic), and where the sequence's output and literals start INSIDE the block (kernel C adds
+// the block's own position once kernel B knows it) — written straight to global memory, a thread's four records side by side.  The round's
+// last run leaves the history and the byte counts behind.
+ZS_FN void seq_history_apply(ZS_LDS SeqLds* L, int k, u32 round, ZRec* recs_block, int tt) {
   ZS_LDS SeqBlockLds* B = &L->b[k];
-  const u32 n = B->rcount, i0 = (u32)tt * kSeqPer;
+  const u32 n = B->rcount, i0 = (u32)tt * kSeqPer, fin = (u32)(kSeqScanSteps & 1);
   if (i0 >= n) return;
   const i32 h0 = B->hist[round & 1u][0], h1 = B->hist[round & 1u][1], h2 = B->hist[round & 1u][2];
+  const u32 cl = B->sums[round & 1u][0], cm = B->sums[round & 1u][1];
   u32 bad = 0;
   i32 a0 = h0, a1 = h1, a2 = h2;
+  u32 lit = cl, out = cl + cm;
   if (tt) {
-    const SeqQuad e = quad_load(&B->scan[kSeqScanSteps & 1][tt - 1]);
+    const SeqQuad e = quad_load(&B->u.h.scan[fin][tt - 1]);
     bad = e.w;
     a0 = hist_eval((i32)e.x, h0, h1, h2, bad);
     a1 = hist_eval((i32)e.y, h0, h1, h2, bad);
     a2 = hist_eval((i32)e.z, h0, h1, h2, bad);
+    lit += B->u.h.psum[fin][tt - 1][0];
+    out += B->u.h.psum[fin][tt - 1][0] + B->u.h.psum[fin][tt - 1][1];
   }
-  for (u32 i = i0; i < i0 + kSeqPer && i < n; i++) B->vals[i].z = (u32)hist_eval((i32)B->vals[i].z, a0, a1, a2, bad);
+  ZRec* r = recs_block + round * kSeqRound;
+  for (u32 i = i0; i < i0 + kSeqPer && i < n; i++) {
+    const SeqQuad v = quad_load(&B->vals[i]);
+    r[i].out_pos = out;
+    r[i].lit_pos = lit;
+    r[i].ll = v.x;
+    r[i].ml = v.y;
+    r[i].off = hist_eval((i32)v.z, a0, a1, a2, bad);
+    out += v.x + v.y;
+    lit += v.x;
+  }
   if (i0 + kSeqPer >= n) {                                     // the run that holds the round's last sequence
-    const SeqQuad e = quad_load(&B->scan[kSeqScanSteps & 1][tt]);
+    const SeqQuad e = quad_load(&B->u.h.scan[fin][tt]);
     bad |= e.w;
     B->hist[(round + 1u) & 1u][0] = hist_eval((i32)e.x, h0, h1, h2, bad);
     B->hist[(round + 1u) & 1u][1] = hist_eval((i32)e.y, h0, h1, h2, bad);
     B->hist[(round + 1u) & 1u][2] = hist_eval((i32)e.z, h0, h1, h2, bad);
+    B->sums[(round + 1u) & 1u][0] = cl + B->u.h.psum[fin][tt][0];
+    B->sums[(round + 1u) & 1u][1] = cm + B->u.h.psum[fin][tt][1];
   }
   if (bad) B->status = ST_ERR_OFFSET;
 }
 // (the group's thread) behind (3c): the round's checks
-ZS_FN void seq_round_check(ZS_LDS SeqLds* L, int k) {
+ZS_FN void seq_round_check(ZS_LDS SeqLds* L, int k, u32 round) {
   ZS_LDS SeqBlockLds* B = &L->b[k];
-  if (B->status) { B->rcount = 0; return; }
-  if (B->sum_ll > kBlockMax || B->sum_ml > kBlockMax) { B->status = ST_ERR_LENGTH; B->rcount = 0; }     // (checked every round: the sums cannot wrap in between)
-}
-// (4) (the group) the round's sequences to the block's records
-ZS_FN void seq_flush(const ZS_LDS SeqLds* L, int k, ZRec* recs_block, u32 base, int tt) {
-  const ZS_LDS SeqBlockLds* B = &L->b[k];
-  for (u32 i = (u32)tt; i < B->rcount; i += (u32)kSeqGroup) {
-    ZRec* r = recs_block + base + i;
-    const SeqQuad v = quad_load(&B->vals[i]);
-    r->ll = v.x;
-    r->ml = v.y;
-    r->off = (i32)v.z;
+  if (!B->rcount) {                                            // (a block that is through, or failed: nothing moved — the counts stay where finish looks for them)
+    B->sums[(round + 1u) & 1u][0] = B->sums[round & 1u][0];
+    B->sums[(round + 1u) & 1u][1] = B->sums[round & 1u][1];
+    for (int j = 0; j < 3; j++) B->hist[(round + 1u) & 1u][j] = B->hist[round & 1u][j];
+    return;
   }
+  if (B->status) { B->rcount = 0; return; }
+  if (B->sums[(round + 1u) & 1u][0] > kBlockMax || B->sums[(round + 1u) & 1u][1] > kBlockMax) { B->status = ST_ERR_LENGTH; B->rcount = 0; }     // (every round: the counts cannot wrap in between)
 }
 // the group's thread, behind the last round: the stream must be used up; the trailing literals; the block's size and history on exit
-ZS_FN void seq_finish(ZS_LDS SeqLds* L, int k, SeqState& st, ZBlock* b, ZRec* recs_block) {
+ZS_FN void seq_finish(ZS_LDS SeqLds* L, int k, SeqState& st, ZBlock* b, ZRec* recs_block, u32 rounds_run) {
   ZS_LDS SeqBlockLds* B = &L->b[k];
   if (!seq_block_has_stream(*b)) {                           // a raw / RLE block, or a block of literals only: one run of literals
     const u32 n = b->type == BT_COMPRESSED ? b->lit_regen : b->size;
+    recs_block[0].out_pos = 0;
+    recs_block[0].lit_pos = 0;
     recs_block[0].ll = n;
     recs_block[0].ml = 0;
     recs_block[0].off = 0;
@@ -1087,182 +1013,19 @@ ZS_FN void seq_finish(ZS_LDS SeqLds* L, int k, SeqState& st, ZBlock* b, ZRec* re
     return;
   }
   if (B->status) return;
+  const u32 sum_ll = B->sums[rounds_run & 1u][0], sum_ml = B->sums[rounds_run & 1u][1];
   if (st.done != b->nseq || seq_bitpos(B, st.tq) != 0) { B->status = ST_ERR_BITS; return; }
-  if (B->sum_ll > b->lit_regen || B->sum_ll + B->sum_ml > kBlockMax) { B->status = ST_ERR_LENGTH; return; }
-  recs_block[b->nseq].ll = b->lit_regen - B->sum_ll;
+  if (sum_ll > b->lit_regen || sum_ll + sum_ml > kBlockMax) { B->status = ST_ERR_LENGTH; return; }
+  recs_block[b->nseq].out_pos = sum_ll + sum_ml;
+  recs_block[b->nseq].lit_pos = sum_ll;
+  recs_block[b->nseq].ll = b->lit_regen - sum_ll;
   recs_block[b->nseq].ml = 0;
   recs_block[b->nseq].off = 0;
-  b->out_size = b->lit_regen + B->sum_ml;
-  const u32 r = seq_rounds(*b) & 1u;
-  for (int j = 0; j < 3; j++) b->rep_out[j] = B->hist[r][j];
+  b->out_size = b->lit_regen + sum_ml;
+  for (int j = 0; j < 3; j++) b->rep_out[j] = B->hist[rounds_run & 1u][j];
 }
 ZS_FN u32 seq_status(const ZS_LDS SeqLds* L, int k) { return L->b[k].status; }
 ZS_FN u32 seq_rounds_of(const ZS_LDS SeqLds* L, int k) { return L->b[k].rounds; }
-#else
-// ---- kernel A2: the sequences of FOUR blocks — one 64-thread workgroup, 16 threads per block.  A block's sequences are one serial chain
-// (three interleaved FSE states over one backward bitstream), and a SIMD issues one instruction per four cycles whatever the instruction
-// does for how many lanes: a first version with ONE decoding lane per wave, its state in scalar registers, sat at the machine's issue rate
-// (62.9 M sequences × ≈ 235 instructions over 1024 SIMDs = 24 ms for 480 pages).  Here four lanes of a wave — the first thread of each
-// group of 16 — decode four blocks at once, 32 sequences a round, out of their bitstream's window in workgroup memory into a buffer
-// there; between rounds every group slides its window and writes its buffer out as records.  Four, because the expanded tables of a block
-// take 10 KiB of workgroup memory: 52 KiB per workgroup, three workgroups per CU. ----
-#ifndef ZS_SEQ_LANES
-#define ZS_SEQ_LANES 8
-#endif
-#ifndef ZS_SEQ_COMPACT
-#define ZS_SEQ_COMPACT 1      // measured (round 4, profiles/r4_zstd_variants.txt): 16.05 -> 10.99 ms for 480 pages — every block of the launch is in flight at once
-#endif
-#ifndef ZS_SEQ_ROUND
-#define ZS_SEQ_ROUND 32       // sequences per round.  -DZS_SEQ_ROUND=64: half as many barriers, window refills and record flushes per sequence (an experiment
-#endif                        // like ZS_SEQ_COMPACT: emulated, not measured on the device; the records' buffer then shares its memory with the staged descriptions)
-#define ZS_SEQ_SHARED_STAGING (ZS_SEQ_COMPACT || ZS_SEQ_ROUND > 32)
-constexpr int kSeqLanes = ZS_SEQ_LANES;
-constexpr int kSeqGroup = 64 / kSeqLanes;         // threads per block's group
-constexpr u32 kSeqRound = ZS_SEQ_ROUND;
-static_assert(kSeqRound * 89 / 8 + 16 <= 1024, "a round's sequences (≤ 89 bits each) must stay inside the 1 KiB the window keeps below the cursor");
-struct SeqLds {
-#if ZS_SEQ_SHARED_STAGING
-#if ZS_SEQ_COMPACT
-  u32 fse_ll[kSeqLanes][512], fse_of[kSeqLanes][256], fse_ml[kSeqLanes][512];       // one word per state (seq_step_ring_compact)
-#else
-  u32 fse_ll[kSeqLanes][1024], fse_of[kSeqLanes][512], fse_ml[kSeqLanes][1024];
-#endif
-  u32 ring[kSeqLanes][kRing / 4 + 2];
-  union Staging {                       // (a lane's staged table descriptions are read before its first record is written)
-    u32 rbuf[kSeqRound][3];
-    u8 hdr[3][128];
-  } stg[kSeqLanes];
-  u32 llc[36], mlc[53];
-#else
-  u32 fse_ll[kSeqLanes][1024], fse_of[kSeqLanes][512], fse_ml[kSeqLanes][1024];     // two words per state (seq_table_expand); offsets: log ≤ 8
-  u32 ring[kSeqLanes][kRing / 4 + 2];   // (+ 2: the first two words again, so that three words in a row never wrap)
-  u32 rbuf[kSeqLanes][kSeqRound][3];    // ll, ml, off
-  u32 llc[36], mlc[53];                 // the literal-length / match-length codes' (base | extra bits << 24)
-  u8 hdr[kSeqLanes][3][128];            // the table descriptions, staged (a description is at most 53 counts of ≤ 10 bits)
-#endif
-  i16 norm[kSeqLanes][64];
-  u16 next[kSeqLanes][64];
-  i32 fse_log[kSeqLanes][3];
-  i32 low[kSeqLanes], cursor[kSeqLanes];
-  u32 bias[kSeqLanes];
-  u32 rcount[kSeqLanes];
-  u32 rounds[kSeqLanes];
-  u32 status[kSeqLanes];
-};
-#if ZS_SEQ_SHARED_STAGING
-#define ZS_RBUF(L, k) (L)->stg[k].rbuf
-#define ZS_HDR(L, k) (L)->stg[k].hdr
-#else
-#define ZS_RBUF(L, k) (L)->rbuf[k]
-#define ZS_HDR(L, k) (L)->hdr[k]
-#endif
-struct SeqState { SeqBits b; SeqCore c; };
-ZS_FN bool seq_block_has_stream(const ZBlock& b) { return b.type == BT_COMPRESSED && b.nseq > 0; }
-ZS_FN u32 seq_rounds(const ZBlock& b) { return seq_block_has_stream(b) ? (b.nseq + kSeqRound - 1) / kSeqRound : 0; }
-// k: the block's group (0 … 3), tt: the thread within the group (0 … 15); "the group's thread" = its thread 0
-// phase 1 (the group): stage the table descriptions (this block's, or — repeat mode — an earlier block's)
-ZS_FN void seq_stage(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, u32 src_len, int tt) {
-  if (tt == 0) { L->status[k] = 0; L->rcount[k] = 0; L->rounds[k] = seq_rounds(b); }
-  const u32 t = (u32)k * (u32)kSeqGroup + (u32)tt;                       // (the workgroup's 64 threads fill the code tables once)
-  if (t < 36u) L->llc[t] = ll_code_entry(t);
-  if (t < 53u) L->mlc[t] = ml_code_entry(t);
-  if (!seq_block_has_stream(b)) return;
-  for (u32 i = (u32)tt; i < 3u * 128u; i += (u32)kSeqGroup) {
-    const u32 kind = i >> 7, j = i & 127u;
-    const u32 q = b.tab_desc[kind] + j;
-    ZS_HDR(L, k)[kind][j] = (b.tab_mode[kind] != TM_PREDEF && q < src_len) ? src[q] : (u8)0;
-  }
-  if (tt == 0) { L->bias[k] = ring_bias(b.bits_len); L->cursor[k] = (i32)b.bits_len; L->low[k] = ring_top_for(b.bits_len, L->bias[k]); }
-}
-ZS_FN ZS_LDS u32* seq_tab(ZS_LDS SeqLds* L, int k, int kind) { return kind == 0 ? (ZS_LDS u32*)L->fse_ll[k] : kind == 1 ? (ZS_LDS u32*)L->fse_of[k] : (ZS_LDS u32*)L->fse_ml[k]; }
-// phase 2 (the group's thread): the block's three tables
-ZS_FN void seq_tables(ZS_LDS SeqLds* L, int k, const ZBlock& b) {
-  if (!seq_block_has_stream(b)) return;
-  for (int kind = 0; kind < 3; kind++) {
-    const int log = seq_table(kind, b.tab_mode[kind], (ZS_LDS u8*)ZS_HDR(L, k)[kind], 128u, seq_tab(L, k, kind), L->norm[k], L->next[k]);
-    L->fse_log[k][kind] = log;
-    if (log < 0) L->status[k] = ST_ERR_FSE;
-#if !ZS_SEQ_COMPACT
-    else seq_table_expand(kind, log, seq_tab(L, k, kind), (ZS_LDS u32*)L->llc, (ZS_LDS u32*)L->mlc);
-#endif
-  }
-}
-// (the group) slide the bitstream's window down
-ZS_FN void seq_fill(ZS_LDS SeqLds* L, int k, const u8* src, const ZBlock& b, i32 page_len, int tt) {
-  if (!seq_block_has_stream(b)) return;
-  const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
-  if (want < L->low[k]) ring_fill((ZS_LDS u32*)L->ring[k], L->bias[k], src + b.bits_pos, want, L->low[k], -(i32)b.bits_pos, page_len + 16 - (i32)b.bits_pos, tt, kSeqGroup);
-}
-ZS_FN void seq_fill_done(ZS_LDS SeqLds* L, int k) {          // (the group's thread, behind the barrier that follows seq_fill)
-  const i32 want = ring_low_for(L->cursor[k], L->bias[k]);
-  if (want < L->low[k]) L->low[k] = want;
-  L->ring[k][kRing / 4] = L->ring[k][0];
-  L->ring[k][kRing / 4 + 1] = L->ring[k][1];
-}
-ZS_FN void seq_start(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {        // the group's thread, behind the first fill
-  if (L->status[k]) return;
-  if (!st.b.init((ZS_LDS u32*)L->ring[k], L->bias[k], b.bits_len)) { L->status[k] = ST_ERR_BITS; return; }
-  seq_begin_ring(st.b, st.c, L->fse_log[k][0], L->fse_log[k][1], L->fse_log[k][2]);
-}
-// the group's thread: the block's next ≤ 32 sequences into rbuf
-ZS_FN void seq_round(ZS_LDS SeqLds* L, int k, SeqState& st, const ZBlock& b) {
-  L->rcount[k] = 0;
-  if (L->status[k] || !seq_block_has_stream(b)) return;
-  const u32 nseq = b.nseq, left = nseq - st.c.done, n = left < kSeqRound ? left : kSeqRound;
-  i32 worst = 1;
-  for (u32 i = 0; i < n; i++) {
-    u32 ll, ml;
-    i32 off;
-#if ZS_SEQ_COMPACT
-    seq_step_ring_compact(st.b, st.c, (ZS_LDS u32*)L->fse_ll[k], (ZS_LDS u32*)L->fse_of[k], (ZS_LDS u32*)L->fse_ml[k], (ZS_LDS u32*)L->llc, (ZS_LDS u32*)L->mlc,
-                          st.c.done + 1 == nseq, ll, ml, off, worst);
-#else
-    seq_step_ring(st.b, st.c, (ZS_LDS u32*)L->fse_ll[k], (ZS_LDS u32*)L->fse_of[k], (ZS_LDS u32*)L->fse_ml[k], st.c.done + 1 == nseq, ll, ml, off, worst);
-#endif
-    ZS_RBUF(L, k)[i][0] = ll;
-    ZS_RBUF(L, k)[i][1] = ml;
-    ZS_RBUF(L, k)[i][2] = (u32)off;
-  }
-  if (worst <= 0) { L->status[k] = ST_ERR_OFFSET; return; }
-  if (st.b.bitpos < 0) { L->status[k] = ST_ERR_BITS; return; }           // the stream ran out: nothing more to decode from it
-  L->rcount[k] = n;
-  L->cursor[k] = st.b.cursor_byte();
-}
-// (the group) the round's sequences to the block's records
-ZS_FN void seq_flush(const ZS_LDS SeqLds* L, int k, ZRec* recs_block, u32 base, int tt) {
-  for (u32 i = (u32)tt; i < L->rcount[k]; i += (u32)kSeqGroup) {
-    ZRec* r = recs_block + base + i;
-    r->ll = ZS_RBUF(L, k)[i][0];
-    r->ml = ZS_RBUF(L, k)[i][1];
-    r->off = (i32)ZS_RBUF(L, k)[i][2];
-  }
-}
-// the group's thread, behind the last round: the stream must be used up; the trailing literals; the block's size and history on exit
-ZS_FN void seq_finish(ZS_LDS SeqLds* L, int k, SeqState& st, ZBlock* b, ZRec* recs_block) {
-  if (!seq_block_has_stream(*b)) {                           // a raw / RLE block, or a block of literals only: one run of literals
-    const u32 n = b->type == BT_COMPRESSED ? b->lit_regen : b->size;
-    recs_block[0].ll = n;
-    recs_block[0].ml = 0;
-    recs_block[0].off = 0;
-    b->out_size = n;
-    for (int j = 0; j < 3; j++) b->rep_out[j] = rep_symbolic(j);
-    return;
-  }
-  if (L->status[k]) return;
-  if (st.b.bitpos != 0) { L->status[k] = ST_ERR_BITS; return; }
-  if (st.c.sum_ll > b->lit_regen || st.c.sum_ll + st.c.sum_ml > kBlockMax) { L->status[k] = ST_ERR_LENGTH; return; }
-  recs_block[b->nseq].ll = b->lit_regen - (u32)st.c.sum_ll;
-  recs_block[b->nseq].ml = 0;
-  recs_block[b->nseq].off = 0;
-  b->out_size = b->lit_regen + (u32)st.c.sum_ml;
-  b->rep_out[0] = st.c.r0;
-  b->rep_out[1] = st.c.r1;
-  b->rep_out[2] = st.c.r2;
-}
-
-ZS_FN u32 seq_status(const ZS_LDS SeqLds* L, int k) { return L->status[k]; }
-ZS_FN u32 seq_rounds_of(const ZS_LDS SeqLds* L, int k) { return L->rounds[k]; }
-#endif
 
 // ---- kernel B: one lane per page ----
 ZS_FN void page_blocks(const ZPage& pg, ZBlock* blocks, u32* status, int page_index) {
@@ -1282,50 +1045,22 @@ ZS_FN void page_blocks(const ZPage& pg, ZBlock* blocks, u32* status, int page_in
   if (out != (u64)pg.dst_len) status[page_index] = ST_ERR_LENGTH;
 }
 
-// ---- kernel C: one workgroup per block: output and literal positions of its records (prefix sums), offsets resolved and checked ----
-struct ScanLds {
-  u32 part_out[2][kScanThreads], part_lit[2][kScanThreads];      // double-buffered: scan step k reads [k & 1], writes [(k + 1) & 1]
-  u32 carry_out, carry_lit;
-  u32 status;
-};
-constexpr u32 kScanPer = 8;                                 // records per thread and tile
-constexpr int kScanSteps = 8;                               // log2(kScanThreads)
-// a tile = kScanThreads · kScanPer records.  Phases: sums (every thread its records) → kScanSteps steps of an inclusive scan over the
-// threads' sums → write (positions from the thread's exclusive prefix) → carry (thread 0).  A barrier between any two.
-ZS_FN void scan_tile_sums(ZS_LDS ScanLds* L, const ZRec* r, u32 n, u32 tile, int t) {
-  const u32 a = tile + (u32)t * kScanPer;
-  u32 so = 0, sl = 0;
-  for (u32 k = 0; k < kScanPer; k++)
-    if (a + k < n) { so += r[a + k].ll + r[a + k].ml; sl += r[a + k].ll; }
-  L->part_out[0][t] = so;
-  L->part_lit[0][t] = sl;
-}
-ZS_FN void scan_tile_step(ZS_LDS ScanLds* L, int step, int t) {
-  const int from = step & 1, to = from ^ 1, d = 1 << step;
-  L->part_out[to][t] = L->part_out[from][t] + (t >= d ? L->part_out[from][t - d] : 0u);
-  L->part_lit[to][t] = L->part_lit[from][t] + (t >= d ? L->part_lit[from][t - d] : 0u);
-}
-ZS_FN void scan_tile_carry(ZS_LDS ScanLds* L) {
-  L->carry_out += L->part_out[kScanSteps & 1][kScanThreads - 1];
-  L->carry_lit += L->part_lit[kScanSteps & 1][kScanThreads - 1];
-}
-ZS_FN void scan_tile_write(ZS_LDS ScanLds* L, ZRec* r, u32 n, u32 tile, const ZBlock& b, int t) {
-  const u32 a = tile + (u32)t * kScanPer;
-  u32 o = L->carry_out + (t ? L->part_out[kScanSteps & 1][t - 1] : 0u), l = L->carry_lit + (t ? L->part_lit[kScanSteps & 1][t - 1] : 0u);
-  for (u32 k = 0; k < kScanPer; k++) {
-    if (a + k >= n) break;
-    ZRec x = r[a + k];
-    x.out_pos = o;
-    x.lit_pos = l;
+// ---- kernel C: one workgroup per block, a pass over its records: kernel A left positions relative to the block and offsets that may
+// name the block's initial history; kernel B has since placed the block in its page and handed the history down ----
+ZS_FN u32 fix_records(ZRec* r, u32 n, const ZBlock& b, int t, int nthreads) {
+  u32 status = 0;
+  for (u32 i = (u32)t; i < n; i += (u32)nthreads) {
+    ZRec x = r[i];
+    x.out_pos += b.out_base;
+    x.lit_pos += b.lit_first;
     if (x.ml) {
       const i32 off = rep_resolve(x.off, b.rep_in);
-      if (off <= 0 || (u64)(u32)off > (u64)o + x.ll) L->status = ST_ERR_OFFSET;      // reaches before the page's first byte (no dictionaries here)
+      if (off <= 0 || (u64)(u32)off > (u64)x.out_pos + x.ll) status = ST_ERR_OFFSET;      // reaches before the page's first byte (no dictionaries here)
       x.off = off;
     }
-    r[a + k] = x;
-    o += x.ll + x.ml;
-    l += x.ll;
+    r[i] = x;
   }
+  return status;
 }
 
 // ---- kernel D: one workgroup per page, its fragments in order ----

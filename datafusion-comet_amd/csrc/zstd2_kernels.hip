@@ -1,6 +1,6 @@
 // The zstd pipeline on gfx950 (device/zstd2.hpp holds the algorithm as phases; this file gives the phases their workgroups, barriers and
 // workgroup memory).  Kernels A1 / A2: one wave per block — the literals (Huffman: a lane per stream) / the sequences of four blocks (a lane per block), decoding
-// in rounds out of a window of the bitstream in workgroup memory; ≈ 14 / 52 KiB of LDS.  Kernel B: one thread per page.  Kernel C: one 256-thread workgroup per block.
+// in rounds out of a window of the bitstream in workgroup memory; ≈ 14 / 52 KiB of LDS.  Kernel B: one thread per page.  Kernel C: one 256-thread workgroup per block, a pass over its records.
 // Kernel D: one 1024-thread workgroup per page, its 64 KiB fragments in order, 144 KiB of LDS (one per CU).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,7 +14,7 @@
 #define SN2_ATOMIC_MIN_LDS(p, v) __hip_atomic_fetch_min((uint32_t*)(p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define ZS2_DEVICE_ONLY
 #ifndef ZS_SEQ_TIMING_SKIP
-#define ZS_SEQ_TIMING_SKIP 0       // measurement builds only (tools/build_zstd_variants.sh): 1 skips the values phase, 2 the history phase, 4 the flush — wrong output, timing of what is left
+#define ZS_SEQ_TIMING_SKIP 0       // measurement builds only (tools/build_zstd_variants.sh): 1 skips the values phase, 2 the history / record phase — wrong output, timing of what is left
 #endif
 #include "device/zstd2.hpp"
 
@@ -92,7 +92,6 @@ __global__ __launch_bounds__(64) void zs2_sequences_kernel(const ZPage* __restri
   u32 rounds = 0;
   for (int j = 0; j < kSeqLanes; j++) rounds = seq_rounds_of(L, j) > rounds ? seq_rounds_of(L, j) : rounds;
   for (u32 r = 0; r < rounds; r++) {
-#if ZS_SEQ_SPLIT
     if (tt == 0) seq_chain_round(L, k, st, blk);
     __syncthreads();
 #if !(ZS_SEQ_TIMING_SKIP & 1)
@@ -106,24 +105,16 @@ __global__ __launch_bounds__(64) void zs2_sequences_kernel(const ZPage* __restri
       seq_history_step(L, k, p, tt);
       __syncthreads();
     }
-    seq_history_apply(L, k, r, tt);
-    __syncthreads();
-    if (tt == 0) seq_round_check(L, k);
+    seq_history_apply(L, k, r, recs, tt);
     __syncthreads();
 #endif
-#else
-    if (tt == 0) seq_round(L, k, st, blk);
-    __syncthreads();
-#endif
-#if !(ZS_SEQ_TIMING_SKIP & 4)
-    seq_flush(L, k, recs, r * kSeqRound, tt);
-#endif
+    if (tt == 0) seq_round_check(L, k, r);
     seq_fill(L, k, src, blk, pg.src_len, tt);
     __syncthreads();
     if (tt == 0) seq_fill_done(L, k);
   }
   if (tt == 0 && have) {
-    seq_finish(L, k, st, &blocks[bi], recs);
+    seq_finish(L, k, st, &blocks[bi], recs, rounds);
     if (seq_status(L, k)) atomicMax(&status[pi], seq_status(L, k));
   }
 }
@@ -134,33 +125,15 @@ __global__ __launch_bounds__(64) void zs2_blocks_kernel(const ZPage* __restrict_
   page_blocks(pages[i], blocks, status, i);
 }
 
-__global__ __launch_bounds__(kScanThreads) void zs2_scan_kernel(const ZPage* __restrict__ pages, const ZBlock* __restrict__ blocks, const i32* __restrict__ block_page,
-                                                                ZRec* recs, u32* status) {
-  __shared__ ScanLds s;
-  ZS_LDS ScanLds* L = (ZS_LDS ScanLds*)&s;
+__global__ __launch_bounds__(kScanThreads) void zs2_records_kernel(const ZPage* __restrict__ pages, const ZBlock* __restrict__ blocks, const i32* __restrict__ block_page,
+                                                                   ZRec* recs, u32* status) {
   const i64 bi = blockIdx.x;
   const int pi = block_page[bi];
   if (status[pi] != (u32)ST_OK) return;
   const ZPage pg = pages[pi];
   const ZBlock blk = blocks[bi];
-  ZRec* r = recs + pg.rec_first + blk.rec_first;
-  const u32 n = blk.nseq + 1;
-  const int t = (int)threadIdx.x;
-  if (t == 0) { s.carry_out = blk.out_base; s.carry_lit = blk.lit_first; s.status = 0; }
-  __syncthreads();
-  for (u32 tile = 0; tile < n; tile += (u32)kScanThreads * kScanPer) {
-    scan_tile_sums(L, r, n, tile, t);
-    __syncthreads();
-    for (int step = 0; step < kScanSteps; step++) {
-      scan_tile_step(L, step, t);
-      __syncthreads();
-    }
-    scan_tile_write(L, r, n, tile, blk, t);
-    __syncthreads();
-    if (t == 0) scan_tile_carry(L);
-    __syncthreads();
-  }
-  if (t == 0 && s.status) atomicMax(&status[pi], s.status);
+  const u32 st = fix_records(recs + pg.rec_first + blk.rec_first, blk.nseq + 1, blk, (int)threadIdx.x, kScanThreads);
+  if (st) atomicMax(&status[pi], st);
 }
 
 __global__ __launch_bounds__(kExecThreads) void zs2_exec_kernel(const ZPage* __restrict__ pages, u8* bytes, const u8* __restrict__ lits_all, const ZRec* __restrict__ recs_all, u32* status) {
@@ -231,7 +204,7 @@ void zs2_launch_blocks(const void* pages, int npages, void* blocks, uint32_t* st
   if (npages > 0) hipLaunchKernelGGL(zs2_blocks_kernel, (unsigned)((npages + 63) / 64), 64, 0, (hipStream_t)st, (const ZPage*)pages, npages, (ZBlock*)blocks, status);
 }
 void zs2_launch_scan(const void* pages, const void* blocks, const int32_t* block_page, void* recs, uint32_t* status, int64_t nblocks, void* st) {
-  if (nblocks > 0) hipLaunchKernelGGL(zs2_scan_kernel, (unsigned)nblocks, kScanThreads, 0, (hipStream_t)st, (const ZPage*)pages, (const ZBlock*)blocks, block_page, (ZRec*)recs, status);
+  if (nblocks > 0) hipLaunchKernelGGL(zs2_records_kernel, (unsigned)nblocks, kScanThreads, 0, (hipStream_t)st, (const ZPage*)pages, (const ZBlock*)blocks, block_page, (ZRec*)recs, status);
 }
 void zs2_launch_exec(const void* pages, int npages, uint8_t* bytes, const uint8_t* lits, const void* recs, uint32_t* status, void* st) {
   if (npages > 0) hipLaunchKernelGGL(zs2_exec_kernel, (unsigned)npages, kExecThreads, 0, (hipStream_t)st, (const ZPage*)pages, bytes, lits, (const ZRec*)recs, status);

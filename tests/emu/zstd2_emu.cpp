@@ -99,23 +99,18 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
       rounds = seq_rounds_of(SL.get(), k) > rounds ? seq_rounds_of(SL.get(), k) : rounds;
     }
     for (u32 r = 0; r < rounds; r++) {
-#if ZS_SEQ_SPLIT
       for (int k = 0; k < kSeqLanes; k++) seq_chain_round(SL.get(), k, st[k], blk(k));
       for (int t = 0; t < 64; t++) seq_values(SL.get(), t / kSeqGroup, t % kSeqGroup);
       for (int t = 0; t < 64; t++) seq_history_local(SL.get(), t / kSeqGroup, t % kSeqGroup);
       for (int p = 0; p < kSeqScanSteps; p++)
         for (int t = 0; t < 64; t++) seq_history_step(SL.get(), t / kSeqGroup, p, t % kSeqGroup);
-      for (int t = 0; t < 64; t++) seq_history_apply(SL.get(), t / kSeqGroup, r, t % kSeqGroup);
-      for (int k = 0; k < kSeqLanes; k++) seq_round_check(SL.get(), k);
-#else
-      for (int k = 0; k < kSeqLanes; k++) seq_round(SL.get(), k, st[k], blk(k));
-#endif
-      for (int t = 0; t < 64; t++) seq_flush(SL.get(), t / kSeqGroup, recp(t / kSeqGroup), r * kSeqRound, t % kSeqGroup);
+      for (int t = 0; t < 64; t++) seq_history_apply(SL.get(), t / kSeqGroup, r, recp(t / kSeqGroup), t % kSeqGroup);
+      for (int k = 0; k < kSeqLanes; k++) seq_round_check(SL.get(), k, r);
       for (int t = 0; t < 64; t++) seq_fill(SL.get(), t / kSeqGroup, srcp(t / kSeqGroup), blk(t / kSeqGroup), page(t / kSeqGroup).src_len, t % kSeqGroup);
       for (int k = 0; k < kSeqLanes; k++) seq_fill_done(SL.get(), k);
     }
     for (int k = 0; k < kSeqLanes && b0 + (size_t)k < blocks.size(); k++) {
-      seq_finish(SL.get(), k, st[k], &blk(k), recp(k));
+      seq_finish(SL.get(), k, st[k], &blk(k), recp(k), rounds);
       const int pi = block_page[b0 + (size_t)k];
       if (seq_status(SL.get(), k) && seq_status(SL.get(), k) > status[(size_t)pi]) status[(size_t)pi] = seq_status(SL.get(), k);
     }
@@ -124,25 +119,14 @@ extern "C" int64_t zs2_emu_inflate_pages(const uint8_t* streams, const int64_t* 
   for (int i = 0; i < npages; i++)
     if (status[(size_t)i] == ST_OK) page_blocks(pages[(size_t)i], blocks.data(), status.data(), i);
   // kernel C
-  auto S = std::make_unique<ScanLds>();
   for (size_t bi = 0; bi < blocks.size(); bi++) {
     const int pi = block_page[bi];
     if (status[(size_t)pi] != ST_OK) continue;
     const ZPage& pg = pages[(size_t)pi];
     const ZBlock& b = blocks[bi];
-    ZRec* r = recs.data() + pg.rec_first + b.rec_first;
-    const u32 n = b.nseq + 1;
-    S->carry_out = b.out_base;
-    S->carry_lit = b.lit_first;
-    S->status = 0;
-    for (u32 tile = 0; tile < n; tile += kScanThreads * kScanPer) {
-      for (int t = 0; t < kScanThreads; t++) scan_tile_sums(S.get(), r, n, tile, t);
-      for (int step = 0; step < kScanSteps; step++)
-        for (int t = 0; t < kScanThreads; t++) scan_tile_step(S.get(), step, t);
-      for (int t = 0; t < kScanThreads; t++) scan_tile_write(S.get(), r, n, tile, b, t);
-      scan_tile_carry(S.get());
-    }
-    if (S->status && S->status > status[(size_t)pi]) status[(size_t)pi] = S->status;
+    u32 st = 0;
+    for (int t = 0; t < kScanThreads; t++) { const u32 x = fix_records(recs.data() + pg.rec_first + b.rec_first, b.nseq + 1, b, t, kScanThreads); st = x > st ? x : st; }
+    if (st && st > status[(size_t)pi]) status[(size_t)pi] = st;
   }
   // kernel D
   auto X = std::make_unique<ZExecLds>();

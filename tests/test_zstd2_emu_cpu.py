@@ -19,9 +19,7 @@ SEEN = "raw_block rle_block compressed_block lit_raw lit_rle lit_huffman lit_tre
 CSRC = os.path.join(ROOT, "datafusion-comet_amd", "csrc")
 
 
-# "split" (shipped since round 4): the sequence kernel's chain carries only the states and the cursor, values and repeat offsets are separate phases;
-# "round3": the previous kernel (one-word tables, eight decoding lanes, everything in the chain: -DZS_SEQ_SPLIT=0) — kept buildable as the fallback
-@pytest.fixture(scope="module", params=[[], ["-DZS_SEQ_SPLIT=0"]], ids=["split", "round3"])
+@pytest.fixture(scope="module", params=[[]], ids=["shipped"])
 def emu(tmp_path_factory, request):
     so = str(tmp_path_factory.mktemp("zstd2_emu") / "libzstd2_emu.so")
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC] + request.param + [os.path.join(ROOT, "tests", "emu", "zstd2_emu.cpp"), "-o", so], check=True)
@@ -175,7 +173,7 @@ def test_host_prefix_is_the_pages_first_bytes(emu):
                 assert got == n and b == p[:n], (level, len(p), n, got)
 
 
-@pytest.mark.parametrize("flags", [[], ["-DZS_SEQ_SPLIT=0"]], ids=["split", "round3"])
+@pytest.mark.parametrize("flags", [[]], ids=["shipped"])
 def test_damaged_frames_under_address_sanitizer(tmp_path, flags):
     exe = str(tmp_path / "zstd2_fuzz")
     r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + CSRC] + flags +
