@@ -881,7 +881,7 @@ static_assert((1 << kSeqScanSteps) == kSeqGroup, "the history scan runs over the
 // a history value `a` minus d: a real offset stays real (and must stay positive: `bad`), a symbolic one adds d to its delta
 ZS_FN i32 hist_minus(i32 a, u32 d, u32& bad) {
   const i32 real = (i32)((u32)a - d), sym = (i32)((u32)a - 3u * d);      // (unsigned: the unused branch of hist_eval may wrap)
-  bad |= (a > 0) & (real <= 0) ? 1u : 0u;
+  bad |= ((a > 0) & (real <= 0)) ? 1u : 0u;
   return ZS_SEL(a > 0, real, sym);
 }
 // what slot s (> 0: a real offset; ≤ 0: −(1 + j + 3·d) = input entry j minus d) is worth on the inputs a0, a1, a2

@@ -732,11 +732,12 @@ size_t staged_capacity(const pq::ColumnMeta& cm) {
 // offsets into the device-decompressed region carry this bit until the column's tables are assembled
 constexpr int64_t kInflatedBit = (int64_t)1 << 62;
 constexpr int32_t kMinDevicePage = 4096;
-constexpr double kDeviceZstdBytesPerMs = 45.0e6;    // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 11.0 ms (profiles/r4_zstd_variants.txt)
-// … and what the scan threads still do for a device-inflated zstd page (read it, walk its frame, decode the levels' prefix), and what they do when they inflate it
-// themselves — SF10 Q6 from zstd Parquet, profiles/r3_parquet_q6_zstd_dict.txt: 60 ms for 495 MB of PLAIN pages on one thread; 280 ms of thread time for the file's
-// 661 MB.  With these the device path wins below about ten scan threads (measured: 97 vs 290 ms with one, 38 vs 29 ms with sixteen)
-constexpr double kZstdWalkBytesPerMs = 8.0e6, kHostZstdBytesPerMs = 2.2e6;
+constexpr double kDeviceZstdBytesPerMs = 75.0e6;    // measured: 480 pages of 1 MiB (decimal-as-INT64, level 1) through the zstd pipeline in 6.5 ms (profiles/r4_zstd_kernel_stats.txt)
+// … and what a scan thread does when it inflates such pages itself — SF10 Q6 from zstd Parquet, round 4 (profiles/r4_parquet_q6.txt): 334 ms of thread time for the
+// 495 MB of PLAIN pages on the GPU box's 32 scan threads (1.5 GB/s each; a lone thread reaches 2.2) and the pages then cross PCIe inflated: 27.9 ms for the scan
+// against 19.9–21.7 ms with the pages inflated on the device, whose pipeline (two chains of the sequence kernel side by side, ≈ 8 ms) runs under the uploads.
+// The device path wins up to about forty scan threads.
+constexpr double kHostZstdBytesPerMs = 1.5e6, kDeviceZstdSetupMs = 2.0;
 
 // DELTA_BYTE_ARRAY pages are prefix-compressed: what they decode to is only known from their length blocks.  One extra pass over such a
 // chunk (read, decompress, decode the two length blocks of every page) sizes its staging slot; nothing else pays for it.
@@ -1718,7 +1719,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     // the two codecs decide separately: snappy pages by the pipeline's rate against ~1 GB/s per host thread, zstd pages by the model above
     const double T = (double)host_threads, sb = (double)plain_snappy_bytes, zb = (double)plain_zstd_bytes;
     const bool snappy_on_device = plain_snappy_bytes > 0 && 0.5 + sb / 60e6 < sb / 1e6 / T;
-    const bool zstd_on_device = plain_zstd_bytes > 0 && so.device_zstd && 1.0 + zb / kDeviceZstdBytesPerMs + zb / kZstdWalkBytesPerMs / T < zb / kHostZstdBytesPerMs / T;
+    const bool zstd_on_device = plain_zstd_bytes > 0 && so.device_zstd && kDeviceZstdSetupMs + zb / kDeviceZstdBytesPerMs < zb / kHostZstdBytesPerMs / T;
     so.device_snappy = snappy_on_device || zstd_on_device;
     if (!zstd_on_device && getenv("COMET_DEVICE_ZSTD") == nullptr) so.device_zstd = false;
   }
@@ -1845,12 +1846,50 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         stream_dirty[k + 1] = 0;
       }
   };
+  // The decompression pipelines of a column's chunk groups run on streams of their own, taken in turn: a group's kernels are a chain
+  // (zstd: the sequence kernel lasts as long as ONE block's serial chain whatever the number of blocks — two groups side by side take no
+  // longer than one; snappy: the one-lane-per-page hop kernel and the tails of the others leave most of the GPU idle), so the next group's
+  // first kernels run under the previous group's last ones.  The column's decode kernels wait for every group (join_groups).
+  static const int n_group_streams = getenv("COMET_PQ_GROUP_STREAMS") ? std::max(0, std::min(8, atoi(getenv("COMET_PQ_GROUP_STREAMS")))) : 2;
+  std::vector<hipStream_t> group_streams;
+  std::vector<hipEvent_t> group_events;
+  std::vector<char> group_dirty;
+  struct GroupStreamGuard {
+    std::vector<hipStream_t>& gs;
+    ~GroupStreamGuard() { for (hipStream_t x : gs) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); } }
+  } group_stream_guard{group_streams};
+  size_t group_rr = 0;
+  hipEvent_t groups_may_start = nullptr;      // recorded on stream_ behind the set-up the groups depend on (the error words' memset)
+  auto next_group_stream = [&]() -> hipStream_t {
+    if (n_group_streams == 0) return stream_;
+    const size_t k = group_rr++ % (size_t)n_group_streams;
+    if (k >= group_streams.size()) {
+      hipStream_t x;
+      HIP_CHECK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+      group_streams.push_back(x);
+      group_dirty.push_back(0);
+      HIP_CHECK(hipStreamWaitEvent(x, groups_may_start, 0));
+    }
+    group_dirty[k] = 1;
+    return group_streams[k];
+  };
+  auto join_groups = [&]() {                  // stream_ runs behind every group launched so far
+    for (size_t k = 0; k < group_streams.size(); k++)
+      if (group_dirty[k]) {
+        hipEvent_t e = get_event();
+        HIP_CHECK(hipEventRecord(e, group_streams[k]));
+        HIP_CHECK(hipStreamWaitEvent(stream_, e, 0));
+        group_dirty[k] = 0;
+      }
+  };
   auto tiles = std::make_shared<DevBuf>();
   tiles->ensure((size_t)((total_rows + 1023) / 1024 + 2) * 8);
   // one word per column: first failing page of the device decompression (job << 8 | code), 0 = fine
   auto inflate_err = std::make_shared<DevBuf>();
   inflate_err->ensure(ncol * 4 + 16);
   HIP_CHECK(hipMemsetAsync(inflate_err->p, 0, ncol * 4 + 16, stream_));
+  groups_may_start = get_event();
+  HIP_CHECK(hipEventRecord(groups_may_start, stream_));
   auto vidx = std::make_shared<DevBuf>();
 
   // everything behind a column's uploads: its tables (pages, runs, dictionaries) assembled and sent, the decode kernels queued.  A column
@@ -2087,9 +2126,33 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     size_t n_jobs = 0, n_zjobs = 0;
     std::vector<PqInflate> group_jobs, zgroup_jobs;
     std::vector<comet_zstd2::ZBlock> zgroup_blocks;
-    size_t group_bytes = 0;
+    size_t group_bytes = 0, zstd_chunks_in_group = 0;
+    // A copy costs ≈ 40–60 µs of submission and completion latency whatever its size (a 1 MB slice crosses in 20 µs), and one stream
+    // carries them one after the other: a column of 60 small chunks spent more time between its copies than in them.  So pieces that are
+    // READY and lie close together in the column's staging block cross as ONE copy — the bytes between them (a slot's unused tail) ride
+    // along; a piece waits for company only while no thread would have to wait for it.
+    constexpr size_t kMergeGap = (size_t)512 << 10;
+    size_t pend_lo = 0, pend_hi = 0;
+    auto flush_pieces = [&]() {
+      if (pend_hi > pend_lo) upload((char*)cd->bytes.p + pend_lo, (char*)col_staged[c]->p + pend_lo, pend_hi - pend_lo);
+      pend_lo = pend_hi = 0;
+    };
+    auto push_piece = [&](size_t lo, size_t hi) {
+      if (hi <= lo) return;
+      if (pend_hi > pend_lo && lo >= pend_lo && lo <= pend_hi + kMergeGap) { pend_hi = std::max(pend_hi, hi); return; }
+      flush_pieces();
+      pend_lo = lo;
+      pend_hi = hi;
+    };
     for (size_t si = 0; si < nsel; si++) {
+      {
+        bool ready;
+        { std::lock_guard<std::mutex> lk(prog->mu); ready = prog->done[c * nsel + si] != 0; }
+        if (!ready) { flush_pieces(); upload_flush(); }       // what is ready crosses while this thread waits
+      }
+      const double t_wait = trace ? ms_since() : 0;
       wait_for(c * nsel + si);
+      if (trace && ms_since() - t_wait > 0.3) fprintf(stderr, "[comet] parquet: column %zu waited %.2f ms for chunk %zu (until %.2f ms)\n", c, ms_since() - t_wait, si, ms_since());
       HostChunk& hc = chunks[c * nsel + si];
       // is the chunk behind this one ready too?  Then its slices join this batch (one launch for all of them)
       bool next_ready = false;
@@ -2101,10 +2164,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       n_jobs += hc.inflate.size();
       n_zjobs += hc.zinflate.size();
       // only the bytes the chunk actually staged cross PCIe
-      if (hc.spos) upload((char*)cd->bytes.p + slot_off[c][si], (char*)col_staged[c]->p + slot_off[c][si], std::min((hc.spos + 16 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]));
+      if (hc.spos) push_piece(slot_off[c][si], slot_off[c][si] + std::min((hc.spos + 16 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]));
       if (hc.raw_hi > hc.raw_lo) {      // page bodies read in place: from where pread() put them (+ the few bytes behind the last one the kernels' vector loads touch)
         const size_t lo = hc.raw_lo & ~(size_t)15, hi = std::min((hc.raw_hi + 32 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]);
-        upload((char*)cd->bytes.p + slot_off[c][si] + lo, (char*)col_staged[c]->p + slot_off[c][si] + lo, hi - lo);
+        push_piece(slot_off[c][si] + lo, slot_off[c][si] + hi);
       }
       // Pages the device decompresses: the pipeline is launched for a GROUP of chunks as soon as their slices are across, so it runs
       // while the column's later chunks are still being read and uploaded (launched once per column it started only after the last slice:
@@ -2129,32 +2192,47 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
           group_bytes += (size_t)job.src_len;
         }
       }
-      // (zstd: the sequence kernel is bound by ONE lane's serial chain per block, not by the number of blocks — up to ~3000 blocks take as
-      // long as one; so its groups are as large as that, 400 MiB of page data)
-      const bool group_full = (!group_jobs.empty() || !zgroup_jobs.empty()) &&
-                              (group_bytes >= (zgroup_jobs.empty() ? (size_t)48 << 20 : (size_t)160 << 20) || zgroup_blocks.size() >= 3000 || si + 1 == nsel);
+      // (zstd: the sequence kernel lasts as long as ONE block's serial chain — ≈ 3.4 ms for 16 K sequences — whatever the number of blocks,
+      // up to the 4096 the GPU holds at once, and a stream runs its groups one behind the other: five groups of 1300 blocks on two streams
+      // took three chains in a row (SF10 Q6: device idle at 20.7 ms with every launch issued by 5.3 ms).  Groups of ≈ 2800 blocks: two of
+      // them fill the GPU side by side)
+      // (a launch is a chain's latency however small it is: what is left of the column joins this group when it fits the GPU with it —
+      // judged by the blocks per chunk seen so far)
+      zstd_chunks_in_group += hc.zinflate.empty() ? 0 : 1;
+      const size_t zleft_est = zstd_chunks_in_group ? (nsel - 1 - si) * zgroup_blocks.size() / zstd_chunks_in_group : 0;
+      const bool zfull = zgroup_blocks.size() >= 2800 && zgroup_blocks.size() + zleft_est > 4096;
+      const bool group_full = (!group_jobs.empty() || !zgroup_jobs.empty()) && ((zgroup_jobs.empty() ? group_bytes >= ((size_t)48 << 20) : zfull) || si + 1 == nsel);
+      if (group_full || si + 1 == nsel) flush_pieces();
       if (!next_ready || group_full) upload_flush();
       if (group_full) {
         if (group_jobs.size() >= ((size_t)1 << 23) || zgroup_jobs.size() >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
-        upload_fence(stream_);
+        const double t_launch = trace ? ms_since() : 0;
+        hipStream_t gs = next_group_stream();
+        upload_fence(gs);
         if (!group_jobs.empty()) {
           cd->snappy2.emplace_back(new Snappy2Scratch());
-          cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+          cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, gs);
         }
         if (!zgroup_jobs.empty()) {
           cd->zstd2.emplace_back(new Zstd2Scratch());
-          cd->zstd2.back()->run(zgroup_jobs.data(), (int)zgroup_jobs.size(), zgroup_blocks.data(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, stream_);
+          cd->zstd2.back()->run(zgroup_jobs.data(), (int)zgroup_jobs.size(), zgroup_blocks.data(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, gs);
         }
+        if (trace) fprintf(stderr, "[comet] parquet: column %zu group of %zu snappy / %zu zstd pages (%zu blocks, %.1f MB) up to chunk %zu launched at %.2f ms\n", c, group_jobs.size(),
+                           zgroup_jobs.size(), zgroup_blocks.size(), (double)group_bytes / 1e6, si, ms_since());
+        if (trace && ms_since() - t_launch > 0.3) fprintf(stderr, "[comet] parquet: … that launch took %.2f ms of this thread\n", ms_since() - t_launch);
         pages_inflated_on_device_ += (int64_t)(group_jobs.size() + zgroup_jobs.size());
         group_jobs.clear();
         zgroup_jobs.clear();
         zgroup_blocks.clear();
         group_bytes = 0;
+        zstd_chunks_in_group = 0;
       }
     }
     // Dictionary-encoded pages the device inflates (zstd: their literals are entropy-coded, the host cannot look through the compressed stream
     // as it does with snappy): the index sections come BACK once the device has inflated them — a few MB per column at PCIe speed — and the
     // host reads the run headers out of them (the decoded values never come back).  Such a column is finished behind all uploads.
+    flush_pieces();
+    join_groups();
     size_t pending_bytes = 0;
     for (size_t si = 0; si < nsel; si++)
       for (const HostChunk::Pending& pe : chunks[c * nsel + si].pending) pending_bytes += ((pe.end - pe.begin) + 15) & ~(size_t)15;
@@ -2234,10 +2312,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
           errs[si] = std::current_exception();
         }
         {
-          std::lock_guard<std::mutex> lk(mu);
+          std::lock_guard<std::mutex> lk(mu);     // (notified under the lock: the waiter owns mu / cv and leaves their scope as soon as it sees zero)
           left.fetch_sub(1);
+          cv.notify_all();
         }
-        cv.notify_all();
       });
     }
     {

@@ -1,6 +1,7 @@
 // Host side of the zstd pipeline (device/zstd2.hpp, zstd2_kernels.hip): lays out the page / block tables the host walk produced, sizes the
 // record and literal scratch, queues kernels A–D on the caller's stream — nothing is read back, so the scan stays asynchronous.
 #include "zstd2.hpp"
+#include <algorithm>
 
 #include <hip/hip_runtime.h>
 
@@ -9,7 +10,7 @@
 #include "device/zstd2.hpp"
 
 extern "C" {
-void zs2_launch_entropy(const void* pages, void* blocks, const int32_t* block_page, const uint8_t* bytes, uint8_t* lits, void* recs, uint32_t* status, int64_t nblocks, void* st);
+void zs2_launch_entropy(const void* pages, void* blocks, const int32_t* block_page, const int32_t* order, const uint8_t* bytes, uint8_t* lits, void* recs, uint32_t* status, int64_t nblocks, void* st);
 void zs2_launch_blocks(const void* pages, int npages, void* blocks, uint32_t* status, void* st);
 void zs2_launch_scan(const void* pages, const void* blocks, const int32_t* block_page, void* recs, uint32_t* status, int64_t nblocks, void* st);
 void zs2_launch_exec(const void* pages, int npages, uint8_t* bytes, const uint8_t* lits, const void* recs, uint32_t* status, void* st);
@@ -26,11 +27,12 @@ void Zstd2Scratch::run(const PqInflate* jobs_host, int njobs, const ZBlock* bloc
   for (int i = 0; i < njobs; i++) nblocks += jobs_host[i].pad;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t b_pages = sizeof(ZPage) * (size_t)njobs, b_blocks = sizeof(ZBlock) * (size_t)nblocks + 16, b_bp = 4 * (size_t)nblocks + 16;
-  const size_t o_pages = 0, o_blocks = al(b_pages), o_bp = o_blocks + al(b_blocks), total = o_bp + al(b_bp);
+  const size_t o_pages = 0, o_blocks = al(b_pages), o_bp = o_blocks + al(b_blocks), o_ord = o_bp + al(b_bp), total = o_ord + al(b_bp);
   h_tables.ensure(total + 16);
   ZPage* P = (ZPage*)((char*)h_tables.p + o_pages);
   ZBlock* B = (ZBlock*)((char*)h_tables.p + o_blocks);
   int32_t* BP = (int32_t*)((char*)h_tables.p + o_bp);
+  int32_t* ORD = (int32_t*)((char*)h_tables.p + o_ord);
   int64_t bi = 0;
   for (int i = 0; i < njobs; i++) {
     ZPage& pg = P[i];
@@ -56,6 +58,15 @@ void Zstd2Scratch::run(const PqInflate* jobs_host, int njobs, const ZBlock* bloc
     nrecs += pr;
     nlits += plit;
   }
+  // The sequence kernel lasts as long as its longest chain, and a launch beyond the 4096 blocks a GPU holds at once runs in passes: longest
+  // blocks first, so that the short ones fill the slots the long ones leave (counting sort by sequence count, 1 K sequences per bucket).
+  {
+    std::vector<int32_t> count(130, 0);
+    auto bucket = [](const ZBlock& b) { return 128 - (int)std::min<uint32_t>(128, (b.type == 2 ? b.nseq : 0) >> 10); };
+    for (int64_t k = 0; k < nblocks; k++) count[(size_t)bucket(B[k]) + 1]++;
+    for (size_t k = 1; k < count.size(); k++) count[k] += count[k - 1];
+    for (int64_t k = 0; k < nblocks; k++) ORD[count[(size_t)bucket(B[k])]++] = (int32_t)k;
+  }
   tables.ensure(total + 16);
   HIP_CHECK(hipMemcpyAsync(tables.p, h_tables.p, total, hipMemcpyHostToDevice, st));
   recs.ensure(sizeof(ZRec) * (size_t)nrecs + 64);
@@ -63,7 +74,7 @@ void Zstd2Scratch::run(const PqInflate* jobs_host, int njobs, const ZBlock* bloc
   status.ensure(4 * (size_t)njobs + 16);
   HIP_CHECK(hipMemsetAsync(status.p, 0, 4 * (size_t)njobs, st));
   char* tb = (char*)tables.p;
-  zs2_launch_entropy(tb + o_pages, tb + o_blocks, (const int32_t*)(tb + o_bp), bytes_dev, (uint8_t*)lits.p, recs.p, (uint32_t*)status.p, nblocks, st);
+  zs2_launch_entropy(tb + o_pages, tb + o_blocks, (const int32_t*)(tb + o_bp), (const int32_t*)(tb + o_ord), bytes_dev, (uint8_t*)lits.p, recs.p, (uint32_t*)status.p, nblocks, st);
   zs2_launch_blocks(tb + o_pages, njobs, tb + o_blocks, (uint32_t*)status.p, st);
   zs2_launch_scan(tb + o_pages, tb + o_blocks, (const int32_t*)(tb + o_bp), recs.p, (uint32_t*)status.p, nblocks, st);
   zs2_launch_exec(tb + o_pages, njobs, bytes_dev, (const uint8_t*)lits.p, recs.p, (uint32_t*)status.p, st);

@@ -60,13 +60,14 @@ __global__ __launch_bounds__(64) void zs2_literals_kernel(const ZPage* __restric
   if (t == 0 && s.status) atomicMax(&status[pi], s.status);
 }
 
-__global__ __launch_bounds__(64) void zs2_sequences_kernel(const ZPage* __restrict__ pages, ZBlock* blocks, const i32* __restrict__ block_page, i64 nblocks,
+__global__ __launch_bounds__(64) void zs2_sequences_kernel(const ZPage* __restrict__ pages, ZBlock* blocks, const i32* __restrict__ block_page, const i32* __restrict__ order, i64 nblocks,
                                                            const u8* __restrict__ bytes, ZRec* recs_all, u32* status) {
   __shared__ SeqLds s;
   ZS_LDS SeqLds* L = (ZS_LDS SeqLds*)&s;
   const int t = (int)threadIdx.x, k = t / kSeqGroup, tt = t % kSeqGroup;
-  const i64 bi = (i64)blockIdx.x * kSeqLanes + k;          // this group's block
-  const bool have = bi < nblocks;
+  const i64 slot = (i64)blockIdx.x * kSeqLanes + k;        // this group's block: the launch takes them longest first
+  const bool have = slot < nblocks;
+  const i64 bi = have ? (i64)order[slot] : 0;
   ZBlock blk;
   ZPage pg;
   int pi = 0;
@@ -194,9 +195,9 @@ __global__ __launch_bounds__(64) void zs2_report_kernel(const u32* __restrict__ 
 }  // namespace
 
 extern "C" {
-void zs2_launch_entropy(const void* pages, void* blocks, const int32_t* block_page, const uint8_t* bytes, uint8_t* lits, void* recs, uint32_t* status, int64_t nblocks, void* st) {
+void zs2_launch_entropy(const void* pages, void* blocks, const int32_t* block_page, const int32_t* order, const uint8_t* bytes, uint8_t* lits, void* recs, uint32_t* status, int64_t nblocks, void* st) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(zs2_sequences_kernel, (unsigned)((nblocks + kSeqLanes - 1) / kSeqLanes), 64, 0, (hipStream_t)st, (const ZPage*)pages, (ZBlock*)blocks, block_page, (i64)nblocks, bytes,
+  hipLaunchKernelGGL(zs2_sequences_kernel, (unsigned)((nblocks + kSeqLanes - 1) / kSeqLanes), 64, 0, (hipStream_t)st, (const ZPage*)pages, (ZBlock*)blocks, block_page, order, (i64)nblocks, bytes,
                      (ZRec*)recs, status);
   hipLaunchKernelGGL(zs2_literals_kernel, (unsigned)nblocks, 64, 0, (hipStream_t)st, (const ZPage*)pages, (const ZBlock*)blocks, block_page, bytes, lits, status);
 }

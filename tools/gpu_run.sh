@@ -49,19 +49,30 @@ snappy_bench() {
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/snappy_stats -o s -- python $GRAFT_REPO_ROOT/tools/snappy_bench.py --pages 480 --kinds decimal_int64 --no-check --skip-one-wave > /dev/null 2>&1)
   grep -E '^"(sn2|pq_)' $OUT/snappy_stats/s_kernel_stats.csv | cut -c1-120
 }
-parquet_q6() {     # SF10 Q6 from Parquet: codec, scan threads (0 = the box's), device decompression (auto / true / false); host stage timers in the logs
-  for CFG in ${PQ_CFGS:-"snappy 0 auto" "zstd 0 auto" "zstd 0 true" "snappy 1 auto" "zstd 1 auto"}; do
-    set -- $CFG
-    N=pq6_$1_t$2_$3
-    COMET_TRACE_STAGES=1 timeout 240 python tools/parquet_q6.py --codec $1 --dir $PQ --scan-threads $2 --device-decompress $3 --steps 5 --out $OUT/$N.json > $OUT/$N.log 2>&1
+pq_env_sweep() {   # SF10 Q6 from Parquet under environment switches: "$PQ_ENVS" = ;-separated entries "VAR=a,VAR2=b codec:threads:dev"
+  IFS=';' read -ra ENTRIES <<< "$PQ_ENVS"
+  for E in "${ENTRIES[@]}"; do
+    set -- $E
+    IFS=: read CODEC THREADS DEV <<< "$2"
+    N=sweep_$(echo "$1_$2" | tr -c 'A-Za-z0-9_\n' '_')
+    env $(echo $1 | tr ',' ' ') COMET_TRACE_STAGES=1 timeout 240 python tools/parquet_q6.py --codec $CODEC --dir $PQ --scan-threads $THREADS --device-decompress $DEV --steps 6 --out $OUT/$N.json > $OUT/$N.log 2>&1
+    echo "== $E: $(python -c "import json;d=json.load(open('$OUT/$N.json'));print('best %.2f ms median %.2f ms on-device pages %s' % (1e3*d['sec_best'],1e3*d['sec_median'],d['pages_decompressed_on_device']))" 2>&1 | tail -1)"
+    grep "parquet: \(all launches\|device idle\|scan threads\|column . host\)" $OUT/$N.log | tail -7 | cut -c1-200
+  done
+}
+parquet_q6() {     # SF10 Q6 from Parquet: codec:scan threads (0 = the box's):device decompression (auto / true / false) per entry of $PQ_CFGS; host stage timers in the logs
+  for CFG in ${PQ_CFGS:-snappy:0:auto zstd:0:auto zstd:0:false snappy:1:auto zstd:1:auto}; do
+    IFS=: read CODEC THREADS DEV <<< "$CFG"
+    N=pq6_${CODEC}_t${THREADS}_${DEV}
+    COMET_TRACE_STAGES=1 timeout 240 python tools/parquet_q6.py --codec $CODEC --dir $PQ --scan-threads $THREADS --device-decompress $DEV --steps 5 --out $OUT/$N.json > $OUT/$N.log 2>&1
     echo "== $CFG"; cut -c1-420 $OUT/$N.json; echo; grep "parquet:" $OUT/$N.log | tail -${PQ_TRACE_LINES:-14} | cut -c1-230
   done
 }
 pq_timeline() {    # device timeline (kernels + copies) of one SF10 Q6 scan per configuration in $PQ_CFGS
-  for CFG in ${PQ_CFGS:-"snappy 0 auto" "zstd 0 true"}; do
-    set -- $CFG
-    N=tl_$1_t$2_$3
-    (cd /tmp && timeout 240 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/$N -o t -- python $GRAFT_REPO_ROOT/tools/parquet_q6.py --codec $1 --dir $PQ --scan-threads $2 --device-decompress $3 --steps 2 > $OUT/$N.log 2>&1)
+  for CFG in ${PQ_CFGS:-snappy:0:auto zstd:0:auto}; do
+    IFS=: read CODEC THREADS DEV <<< "$CFG"
+    N=tl_${CODEC}_t${THREADS}_${DEV}
+    (cd /tmp && timeout 240 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/$N -o t -- python $GRAFT_REPO_ROOT/tools/parquet_q6.py --codec $CODEC --dir $PQ --scan-threads $THREADS --device-decompress $DEV --steps 2 > $OUT/$N.log 2>&1)
     python tools/timeline.py $(find $OUT/$N -name "*kernel_trace.csv") $(find $OUT/$N -name "*memory_copy_trace.csv") > $OUT/$N.txt 2>&1
     echo "== $CFG"; head -${TL_LINES:-70} $OUT/$N.txt | cut -c1-200
   done
@@ -82,6 +93,10 @@ q3() {
 }
 q95() {
   timeout 300 python tools/q95_bench.py --orders 16000000 --reps 3 > $OUT/q95.json 2> $OUT/q95.err; cut -c1-600 $OUT/q95.json; echo
+}
+read_probe() {     # page cache -> pinned memory -> device, nothing else: what bounds a scan before the GPU sees a byte
+  ls $PQ/*.parquet > /dev/null 2>&1 || timeout 200 python tools/parquet_q6.py --codec snappy --dir $PQ --steps 1 > /dev/null 2>&1
+  timeout 200 python tools/read_probe.py --file $(ls -S $PQ/*.parquet | head -1) > $OUT/read_probe.json 2> $OUT/read_probe.err; cat $OUT/read_probe.json; tail -2 $OUT/read_probe.err
 }
 probes() {         # the box itself: HBM streaming rates, PCIe
   timeout 200 python tools/hbm_probe.py > $OUT/hbm_probe.json 2>/dev/null; cut -c1-400 $OUT/hbm_probe.json; echo
