@@ -2844,6 +2844,19 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
         src << "    kw[" << w << "] = " << e << ";\n";
       }
       src << "    return comet::hash_key<" << words.size() << ">(kw);\n  }\n";
+      if (std::string(name) == "phash") {
+        // a single integer key: its value handed out too — the probe asks the build side's key bitmap before it touches the table
+        const bool one_int = keys.size() == 1 && words.size() == 1 && (words[0].rfind("(u64)(i64)", 0) == 0);
+        src << "  static constexpr bool KEYMAP = " << (one_int ? "true" : "false") << ";\n";
+        src << "  static __device__ __forceinline__ u64 pkey0(const CometKParams& prm, i64 " << rowvar << ") {\n";
+        if (one_int) {
+          std::string e = words[0];
+          for (size_t p0 = e.find("[r]"); p0 != std::string::npos; p0 = e.find("[r]")) e.replace(p0, 3, "[0]");
+          src << "    bool k[R] = {true};\n" << g.decls << g.body() << "    return " << e << ";\n  }\n";
+        } else {
+          src << "    (void)prm; (void)" << rowvar << "; return 0;\n  }\n";
+        }
+      }
       if (std::string(name) == "bhash") {
         // the same key words handed out (run detection compares neighbouring build rows word by word: exact, unlike their hashes)
         src << "  static constexpr int NKW = " << words.size() << ";\n";

@@ -1772,6 +1772,17 @@ CDEV void agg_grouped_rehash_body(const CometKParams& prm) {
 constexpr int kJoinTileCounts = 44;
 constexpr int kJoinMatched = 45;
 constexpr int kJoinBuildTiles = 46;
+// The build side's KEY BITMAP (round 4).  A join on one integer key whose build keys span a range not much larger than their number
+// (foreign keys: customer keys, order keys) gets one bit per possible key: out[kJoinKeyMap] = { i64 smallest key, u64 bits, u32 words[] },
+// or NULL.  The probe asks it first — a probe row whose key the build side does not hold never touches the hash table, and for the usual
+// shapes the bit is a cache hit: a dimension's key range is a few MB (L2), a fact table probing in key order walks the bitmap
+// sequentially.  SF100 Q3: 80 % of the orders probing the customers of one market segment, and 95 % of the line items probing the open
+// orders, end here instead of at a random 128-byte line of the bucket array (profiles/r4_q3_probe_pmc.txt).
+constexpr int kJoinKeyMap = 44;
+CDEV bool join_keymap_has(const u64* km, u64 key) {
+  const u64 idx = key - km[0];
+  return idx < km[1] && ((((const u32*)(km + 2))[idx >> 5] >> (idx & 31u)) & 1u) != 0;
+}
 
 constexpr u32 kJoinNoRow = 0xffffffffu;
 constexpr u32 kJoinChainBit = 1u << 31;
@@ -1828,6 +1839,13 @@ CDEV void join_build_body(const CometKParams& prm) {
     bool has_follower;
     if (!join_build_classify<P>(prm, i, nb, h, has_follower)) continue;
     // the chain bit says "this bucket holds more than one ROW": another leader, or followers behind this one
+    if (P::KEYMAP && prm.out[kJoinKeyMap]) {                 // the run's key into the key bitmap (followers share it)
+      u64* km = (u64*)prm.out[kJoinKeyMap];
+      u64 kw[P::NKW];
+      P::bkeys(prm, i, kw);
+      const u64 idx = kw[0] - km[0];
+      if (idx < km[1]) atomicOr((u32*)(km + 2) + (idx >> 5), 1u << (idx & 31u));
+    }
     const u32 old = atomicExch(&head[h & mask], join_head_entry(h, (u32)i, ib) | (has_follower ? kJoinChainBit : 0u));
     next[i] = old == kJoinNoRow ? -1 : (i32)(old & ((1u << ib) - 1u));
     // a bucket that already held a row: whatever its head is from now on, its chain is longer than one (monotone, so the OR may land
@@ -1841,8 +1859,9 @@ CDEV void join_build_body(const CometKParams& prm) {
 template <class P>
 CDEV void join_build_count_body(const CometKParams& prm) {
   const i64 nb = prm.iarg[1];
-  unsigned long long* total = (unsigned long long*)prm.out[0];
+  unsigned long long* total = (unsigned long long*)prm.out[0];      // { leaders, smallest key, largest key } — the keys order-preserving as u64 (sign bit flipped)
   u32 mine = 0;
+  u64 kmin = ~0ull, kmax = 0;
   for (i64 wbase = (i64)blockIdx.x * kBlock + (i64)wave_id() * kWave; wbase < nb; wbase += (i64)gridDim.x * kBlock) {
     const i64 i = wbase + lane_id();
     const bool valid = i < nb && P::bvalid(prm, i);
@@ -1850,6 +1869,11 @@ CDEV void join_build_count_body(const CometKParams& prm) {
 #pragma unroll
     for (int w = 0; w < P::NKW; w++) kw[w] = 0;
     if (valid) P::bkeys(prm, i, kw);
+    if (P::KEYMAP && valid) {
+      const u64 o = kw[0] ^ (1ull << 63);
+      kmin = o < kmin ? o : kmin;
+      kmax = o > kmax ? o : kmax;
+    }
     bool same = valid && lane_id() > 0;
 #pragma unroll
     for (int w = 0; w < P::NKW; w++) {
@@ -1860,6 +1884,19 @@ CDEV void join_build_count_body(const CometKParams& prm) {
     mine += (u32)__popcll(__ballot(valid && !same));
   }
   if (lane_id() == 0 && mine) atomicAdd(total, (unsigned long long)mine);
+  if (P::KEYMAP) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+      const u64 a = ((u64)__shfl_xor((u32)(kmin >> 32), d, kWave) << 32) | __shfl_xor((u32)kmin, d, kWave);
+      const u64 b = ((u64)__shfl_xor((u32)(kmax >> 32), d, kWave) << 32) | __shfl_xor((u32)kmax, d, kWave);
+      kmin = a < kmin ? a : kmin;
+      kmax = b > kmax ? b : kmax;
+    }
+    if (lane_id() == 0 && kmin <= kmax) {
+      atomicMin(total + 1, (unsigned long long)kmin);
+      atomicMax(total + 2, (unsigned long long)kmax);
+    }
+  }
 }
 
 // build rows nobody matched (outer joins that preserve the build side; LeftAnti built on the left) — or, with
@@ -2035,6 +2072,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
   const i64 cap_out = prm.iarg[6];
   unsigned long long* emitted = (unsigned long long*)prm.out[47];
   u8* matched = (u8*)prm.out[kJoinMatched];
+  const u64* keymap = (const u64*)prm.out[kJoinKeyMap];
   __shared__ unsigned short s_list[kBlock / kWave][kJoinR * kWave];
   __shared__ u32 s_wave[kBlock / kWave];
   __shared__ unsigned long long s_base;
@@ -2048,8 +2086,11 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
 #pragma unroll
     for (int r = 0; r < kJoinR; r++) {
       const i64 j = base + (i64)r * kBlock + threadIdx.x;
-      const bool keep = j < n && P::pkeep(prm, j);
-      const bool can_match = keep && P::pvalid(prm, j);
+      const bool alive = j < n && P::pkeep(prm, j);
+      bool can_match = alive && P::pvalid(prm, j);
+      if (P::KEYMAP && keymap && can_match) can_match = join_keymap_has(keymap, P::pkey0(prm, j));      // the build side does not hold the key: settled
+      // a row that cannot match only stays where the join still has to say something about it (the preserved side of an outer join, an anti join)
+      const bool keep = alive && (can_match || P::OUTER_PROBE || P::MODE == 2);
       const u64 b = __ballot(keep);
       if (keep) list[m + (u32)__popcll(b & lt)] = (unsigned short)((u32)(r * kBlock + (int)threadIdx.x) | (can_match ? 0u : 0x8000u));
       m += (u32)__popcll(b);

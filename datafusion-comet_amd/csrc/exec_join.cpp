@@ -157,14 +157,31 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   // a bucket array sized by its runs, which stays in the caches several times better than one sized by its rows.
   int64_t entries = B.rows;
   static const bool count_runs = getenv("COMET_JOIN_COUNT_RUNS") == nullptr || atoi(getenv("COMET_JOIN_COUNT_RUNS")) != 0;
+  DevBuf keymap;
   if (!use_lds && count_runs && B.rows >= (1 << 20)) {
-    HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 8, stream_));
+    const uint64_t init[3] = {0, ~0ull, 0};          // leaders, smallest key, largest key (order-preserving u64)
+    write_small(emitted_buf.p, init, sizeof init);
     prm.out[0] = emitted_buf.p;
     prm.out[kOutErr] = err_flags_.p;
     launch(v, "k_jbcnt", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
-    uint64_t leaders = 0;
-    read_small(&leaders, emitted_buf.p, 8);
-    entries = std::min<int64_t>(B.rows, (int64_t)leaders);
+    uint64_t got[3] = {0, 0, 0};
+    read_small(got, emitted_buf.p, sizeof got);
+    entries = std::min<int64_t>(B.rows, (int64_t)got[0]);
+    // The key bitmap (comet_device.hpp kJoinKeyMap): one integer key whose values span at most 64 bits per build row and 2^31 bits — a
+    // foreign key's shape.  k_jbcnt leaves min / max untouched when the kernel has no such key (KEYMAP false).
+    static const bool use_keymap = getenv("COMET_JOIN_KEYMAP") == nullptr || atoi(getenv("COMET_JOIN_KEYMAP")) != 0;
+    if (use_keymap && got[1] <= got[2]) {
+      const uint64_t range = got[2] - got[1] + 1;      // (never 0: the keys are 64-bit values of ≤ 2^31 rows … guarded below anyway)
+      if (range != 0 && range <= ((uint64_t)1 << 31) && range <= (uint64_t)B.rows * 64) {
+        const size_t words = (size_t)((range + 31) / 32);
+        keymap.ensure(16 + words * 4 + 16);
+        HIP_CHECK(hipMemsetAsync((char*)keymap.p + 16, 0, words * 4, stream_));
+        const uint64_t hdr[2] = {got[1] ^ ((uint64_t)1 << 63), range};
+        write_small(keymap.p, hdr, sizeof hdr);
+        prm.out[44] = keymap.p;
+        join_keymap_bytes_ += (int64_t)words * 4;
+      }
+    }
   }
   int64_t cap = 1024;
   while (cap < 2 * entries) cap <<= 1;
