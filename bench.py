@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--q3-orders", type=int, default=150_000_000,
                     help="extra leg: TPC-H Q3 over all ranks, total orders rows (SF100 = 150 M, strong scaling); 0 = skip")
     ap.add_argument("--leg-timeout", type=int, default=420)
+    ap.add_argument("--allow-fallback", action="store_true", help="N > 1: exit 0 even if the multi-GPU legs ran over torch's all_to_all instead of the in-library RCCL exchange")
+    ap.add_argument("--no-executor-leg", action="store_true", help="skip the 8 / 16 concurrent-tasks leg")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip every extra leg (Q6, Q3, paths, PMC): headline + cpu_baseline only")
     args = ap.parse_args()
 
@@ -187,7 +189,9 @@ def main():
                 legs["q6_sf10"] = run_child_leg([os.path.join(ROOT, "tools", "resident.py"), "--query", "q6", "--rows", str(SF10_ROWS), "--steps", "10"],
                                                 rank, local_rank, world, args.leg_timeout, 2117)
             if not args.no_pmc:
-                legs["pmc"] = measure_traffic(args, local_rank) if rank == 0 else None
+                legs["pmc"] = measure_traffic(args, local_rank, args.rows, "q1,q6") if rank == 0 else None
+                if args.rows != SF10_ROWS and rank == 0:
+                    legs["pmc_sf10"] = measure_traffic(args, local_rank, SF10_ROWS, "q6")
             legs["cold_plan"] = run_child_leg([os.path.join(ROOT, "tools", "cold_plan.py"), "--query", "q1"], rank, local_rank, world, 120, 4017)
             if not args.no_paths:
                 # BASELINE configs[1]: TPC-H SF10 Q6 straight from Parquet (scan + 3-predicate filter + sum), end to end, snappy and zstd
@@ -202,6 +206,9 @@ def main():
                 legs["snappy"] = run_child_leg([os.path.join(ROOT, "tools", "snappy_bench.py"), "--pages", "240", "--skip-one-wave"], rank, local_rank, world, 180, 5317)
                 legs["zstd"] = run_child_leg([os.path.join(ROOT, "tools", "snappy_bench.py"), "--codec", "zstd", "--level", "1", "--pages", "240", "--kinds", "decimal_int64,int32_lowcard"],
                                              rank, local_rank, world, 180, 5417)
+            if not args.no_paths and not args.no_executor_leg:
+                # the executor's shape: 8 and 16 plans at once, one host thread and one scan thread each, one GPU, one PCIe link
+                legs["executor"] = run_child_leg([os.path.join(ROOT, "tools", "executor_bench.py"), "--steps", "2", "--busy"], rank, local_rank, world, 600, 5517)
             if not args.no_paths:
                 legs["paths"] = run_child_leg([os.path.join(ROOT, "tools", "paths.py"), "--query", "q1", "--rows", str(args.path_rows)],
                                               rank, local_rank, world, args.leg_timeout, 3017)
@@ -215,11 +222,12 @@ def main():
             if not bool(ok_t.item()):
                 exchange = "torch-fallback"  # the legs report exchange_transport = "torch-fallback", never silently
             legs["exchange_probe"] = probe
+        fb = ["--allow-fallback"] if exchange != "native" else []      # (the child still reports its transport; THIS process turns it into the exit code)
         if args.q3_orders > 0:
-            legs["q3"] = run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1", "--exchange", exchange],
+            legs["q3"] = run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1", "--exchange", exchange] + fb,
                                        rank, local_rank, world, args.leg_timeout, 1017)
         if args.q95_orders > 0:
-            legs["q95"] = run_child_leg([os.path.join(ROOT, "tools", "q95_dist.py"), "--orders", str(args.q95_orders), "--steps", "2", "--warmup", "1", "--verify", "torch", "--exchange", exchange],
+            legs["q95"] = run_child_leg([os.path.join(ROOT, "tools", "q95_dist.py"), "--orders", str(args.q95_orders), "--steps", "2", "--warmup", "1", "--verify", "torch", "--exchange", exchange] + fb,
                                         rank, local_rank, world, args.leg_timeout, 1517)
 
     if rank == 0:
@@ -276,7 +284,7 @@ def main():
                 continue
             q = leg.get("q6", leg)
             if "error" not in q:
-                tr = (pmc.get("k_agg") or {}).get("traffic_bytes_per_launch") if key == "q6" else None
+                tr = ((pmc if key == "q6" else (legs.get("pmc_sf10") or {})).get("k_agg") or {}).get("traffic_bytes_per_launch")
                 q["roofline"] = {"bound": "hbm", "kernel": "k_agg", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_GBps": q["algorithmic_GBps"],
                                  "traffic": tr,
                                  "achieved": (tr / (q["kernel_ms"] * 1e-3) / 1e9) if tr else None,
@@ -294,6 +302,22 @@ def main():
                                             "matches_resident_plan": v["matches_resident_plan"], "pyarrow_read_s_all_cores": v["pyarrow_read_s_all_cores"],
                                             "pages_decompressed_on_device": v.get("pages_decompressed_on_device")} if "error" not in v else v)
                                        for c, v in pq6.items()}
+            # what bounds these legs: the file's bytes cross PCIe once (compressed pages cross compressed), after a copy out of the page cache;
+            # peak = the link rate measured in this run (executor leg's probe), achieved = file bytes / best time; device_stage = the slowest
+            # device stage's own rate on the same page shapes (the decompression pipeline, measured alone)
+            link = (legs.get("executor") or {}).get("pcie_link_GBps_measured")
+            for c in list(pq6):
+                e = line["q6_sf10_parquet"][c]
+                if "error" in e:
+                    continue
+                pipe = ((legs.get("snappy" if c == "snappy" else "zstd") or {}).get("decimal_int64") or {}).get("pipeline") or {}
+                ach = e["file_bytes"] / (e["ms_best"] * 1e-3) / 1e9
+                e["roofline"] = {"bound": "pcie", "peak": link, "unit": "GB/s", "achieved": ach, "frac": (ach / link) if link else None,
+                                 "floor_ms_at_measured_link": (e["file_bytes"] / (link * 1e9) * 1e3) if link else None,
+                                 "device_stage": {"name": f"{c} decompression pipeline (PLAIN decimal-as-INT64 pages)", "out_GBps": pipe.get("out_GBps"),
+                                                  "kernel_ms_240_pages": pipe.get("kernel_ms")},
+                                 "note": "peak = pinned -> device rate measured in this run (64 MiB copies); the file also has to leave the page cache "
+                                         "(pread into pinned memory, tools/read_probe.py) before it can cross"}
             task = {k: legs.get("pq6_zstd_task_" + k) for k in ("device", "host")}
             if all(v is not None and "error" not in v for v in task.values()):
                 line["q6_sf10_parquet"]["zstd_one_scan_thread"] = {k: {"ms_best": v["sec_best"] * 1e3, "pages_decompressed_on_device": v.get("pages_decompressed_on_device"),
@@ -302,6 +326,8 @@ def main():
                                                "snappy pages inflated on the device (multi-kernel pipeline); zstd PLAIN pages on the device or on host threads, whichever the scan's "
                                                "thread count favours (pages_decompressed_on_device says which; zstd_one_scan_thread = what a Spark task with one core sees); "
                                                "decode + fused Q6 kernel on the device")
+        if legs.get("executor") is not None:
+            line["executor_shape"] = legs["executor"]
         if legs.get("snappy") is not None:
             line["snappy_pipeline"] = legs["snappy"]
         if legs.get("zstd") is not None:
@@ -317,6 +343,11 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+        fell_back = not args.no_extra_legs and (args.q3_orders > 0 or args.q95_orders > 0) and exchange != "native"
+        if rank == 0 and not args.no_extra_legs:
+            fell_back = fell_back or any((legs.get(k) or {}).get("exit_code") == 4 for k in ("q3", "q95"))
+        if fell_back and not args.allow_fallback:
+            sys.exit(4)      # the multi-GPU legs did not run over the in-library RCCL exchange: the line says so, and so does the exit code
 
 
 def cpu_baseline(args, dtab, plan_bytes, local_rank):
@@ -372,7 +403,7 @@ def cpu_baseline(args, dtab, plan_bytes, local_rank):
             "gpu_states_equal_cpu_states_on_the_one_thread_sample": bool(same)}
 
 
-def measure_traffic(args, local_rank):
+def measure_traffic(args, local_rank, rows, queries):
     """HBM bytes per launch of k_gagg (Q1) and k_agg (Q6) at this run's row count: two rocprofv3 passes (FETCH_SIZE needs 3 of the 4
     TCC slots, WRITE_SIZE 2 — MI355X_MICROARCH.md) over tools/resident.py.  gfx950's FETCH_SIZE reports half the bytes of a coalesced
     streaming read, so it is doubled as that guide prescribes (calibrated there for 16 B/lane loads; tools/pmc_calibrate.py checks the
@@ -394,7 +425,7 @@ def measure_traffic(args, local_rank):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="comet_pmc_", dir="/tmp")
         cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-               sys.executable, os.path.join(ROOT, "tools", "resident.py"), "--query", "q1,q6", "--rows", str(args.rows), "--steps", "2", "--no-check"]
+               sys.executable, os.path.join(ROOT, "tools", "resident.py"), "--query", queries, "--rows", str(rows), "--steps", "2", "--no-check"]
         try:
             p = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.leg_timeout)
             if p.returncode != 0:
@@ -416,10 +447,10 @@ def measure_traffic(args, local_rank):
         fetch = 2.0 * 1024.0 * sum(f) / len(f)  # KiB → B, ×2 gfx950 correction
         write = 1024.0 * sum(w) / len(w)
         res[name] = {"traffic_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "launches": len(f),
-                     "bytes_per_row": (fetch + write) / args.rows}
+                     "bytes_per_row": (fetch + write) / rows}
     res["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace) in this run; FETCH_SIZE x2 per "
                    "MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)")
-    res["rows"] = args.rows
+    res["rows"] = rows
     return res
 
 
@@ -447,11 +478,16 @@ def run_child_leg(cmd_tail, rank, local_rank, world, timeout, port_offset):
             return {"error": f"timed out after {timeout} s"} if rank == 0 else None
         if rank != 0:
             return None
-        if p.returncode != 0 or not os.path.exists(out):
+        if not os.path.exists(out):
             return {"error": f"exit code {p.returncode}", "log_tail": log[-600:]}
         with open(out) as f:
             res = json.loads(f.read())
         os.unlink(out)
+        if p.returncode != 0:      # the tool wrote its line and then said no (a failed check, an exchange that fell back): keep both
+            res["exit_code"] = p.returncode
+            if p.returncode != 4:
+                res["error"] = f"exit code {p.returncode}"
+                res["log_tail"] = log[-600:]
         return res
     except Exception as e:  # an extra leg must never break the headline line
         return {"error": repr(e)} if rank == 0 else None

@@ -1883,7 +1883,10 @@ CDEV void join_build_count_body(const CometKParams& prm) {
     same = same && __shfl_up(valid ? 1 : 0, 1, kWave) != 0;
     mine += (u32)__popcll(__ballot(valid && !same));
   }
-  if (lane_id() == 0 && mine) atomicAdd(total, (unsigned long long)mine);
+  // one set of atomics per BLOCK: thousands of waves adding to, and taking the minimum / maximum of, the same three words queue up
+  // behind one another (measured: 0.11 → 0.30 ms per launch when every wave did its own)
+  __shared__ u32 s_cnt[kBlock / kWave];
+  __shared__ u64 s_min[kBlock / kWave], s_max[kBlock / kWave];
   if (P::KEYMAP) {
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
@@ -1892,9 +1895,21 @@ CDEV void join_build_count_body(const CometKParams& prm) {
       kmin = a < kmin ? a : kmin;
       kmax = b > kmax ? b : kmax;
     }
-    if (lane_id() == 0 && kmin <= kmax) {
-      atomicMin(total + 1, (unsigned long long)kmin);
-      atomicMax(total + 2, (unsigned long long)kmax);
+  }
+  if (lane_id() == 0) { s_cnt[wave_id()] = mine; s_min[wave_id()] = kmin; s_max[wave_id()] = kmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 c = 0;
+    u64 lo = ~0ull, hi = 0;
+    for (int w = 0; w < kBlock / kWave; w++) {
+      c += s_cnt[w];
+      lo = s_min[w] < lo ? s_min[w] : lo;
+      hi = s_max[w] > hi ? s_max[w] : hi;
+    }
+    if (c) atomicAdd(total, (unsigned long long)c);
+    if (P::KEYMAP && lo <= hi) {
+      atomicMin(total + 1, (unsigned long long)lo);
+      atomicMax(total + 2, (unsigned long long)hi);
     }
   }
 }
@@ -1973,7 +1988,9 @@ CDEV void join_build_unmatched_emit_body(const CometKParams& prm) {
 constexpr int kJoinLdsCap = 8192;
 constexpr int kJoinLdsMaxBuild = 6144;
 constexpr u32 kJoinEmpty = 0xffffffffu;
-constexpr int kJoinR = 8;                    // probe rows per thread and tile
+constexpr int kJoinR = 8;                    // slices of a wave's survivors probed together (eight random accesses in flight per lane)
+constexpr int kJoinR0 = 16;                  // probe rows per thread and tile: the filter / key bitmap phase runs over twice as many rows as one probe batch holds —
+                                             // most rows end there, and a wave's handful of survivors costs the same latency whatever the tile's size
 
 // candidates of probe row j in the global chained table
 template <class P>
@@ -2073,18 +2090,18 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
   unsigned long long* emitted = (unsigned long long*)prm.out[47];
   u8* matched = (u8*)prm.out[kJoinMatched];
   const u64* keymap = (const u64*)prm.out[kJoinKeyMap];
-  __shared__ unsigned short s_list[kBlock / kWave][kJoinR * kWave];
+  __shared__ unsigned short s_list[kBlock / kWave][kJoinR0 * kWave];
   __shared__ u32 s_wave[kBlock / kWave];
   __shared__ unsigned long long s_base;
   const int lane = lane_id(), wv = wave_id();
   const u64 lt = (1ull << lane) - 1ull;
   COMET_LDS unsigned short* list = (COMET_LDS unsigned short*)s_list[wv];
-  constexpr i64 kTile = (i64)kJoinR * kBlock;
+  constexpr i64 kTile = (i64)kJoinR0 * kBlock;
   for (i64 base = (i64)blockIdx.x * kTile; base < n; base += (i64)gridDim.x * kTile) {
     // ---- 0. filter + wave-local compaction ----
     u32 m = 0;
 #pragma unroll
-    for (int r = 0; r < kJoinR; r++) {
+    for (int r = 0; r < kJoinR0; r++) {
       const i64 j = base + (i64)r * kBlock + threadIdx.x;
       const bool alive = j < n && P::pkeep(prm, j);
       bool can_match = alive && P::pvalid(prm, j);
@@ -2098,7 +2115,15 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nslice = (int)((m + kWave - 1) / kWave);      // wave-uniform
+    const int nslice_all = (int)((m + kWave - 1) / kWave);  // wave-uniform
+    // the survivors, eight slices at a time (after a selective filter or key bitmap: one batch, mostly one slice)
+    for (int q0 = 0; q0 < kJoinR0; q0 += kJoinR) {
+    if (!__syncthreads_or(q0 < nslice_all)) break;          // no wave of the block has a slice left (also orders the reuse of s_wave / s_base)
+    const int nslice = nslice_all - q0 < kJoinR ? (nslice_all - q0 < 0 ? 0 : nslice_all - q0) : kJoinR;
+    COMET_LDS unsigned short* const list0 = list;
+    COMET_LDS unsigned short* list = list0 + (u32)q0 * kWave;
+    const u32 m_all = m;
+    const u32 m = m_all > (u32)q0 * kWave ? m_all - (u32)q0 * kWave : 0u;
     // ---- 1. probe: key loads + hashes of every slice, then every bucket head, then row by row ----
     u64 hs[kJoinR];
     u32 he[kJoinR];
@@ -2202,6 +2227,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
         }
       }
     }
+    }                  // batches of slices
     __syncthreads();   // s_wave / s_base / the lists are reused by the next tile
   }
 }

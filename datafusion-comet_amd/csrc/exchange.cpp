@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -63,6 +64,8 @@ struct Rccl {
   int (*GetUniqueId)(NcclUniqueId*) = nullptr;
   int (*CommInitRank)(ncclComm_t*, int, NcclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommCount)(const ncclComm_t, int*) = nullptr;          // (optional: what the communicator itself says about its size / this rank)
+  int (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -83,6 +86,8 @@ struct Rccl {
       r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
       r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
       r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+      r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+      r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
       r.Send = (decltype(r.Send))sym("ncclSend");
       r.Recv = (decltype(r.Recv))sym("ncclRecv");
       r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
@@ -130,7 +135,8 @@ std::map<int64_t, std::shared_ptr<LocalGroup>> g_groups;
 // RCCL: one process per GPU; everything is enqueued on the communicator's stream, the counts cross through device memory
 class RcclTransport : public xchg::Transport {
  public:
-  RcclTransport(ncclComm_t comm, int world, int rank, hipStream_t st) : comm_(comm), world_(world), rank_(rank), st_(st) {}
+  RcclTransport(ncclComm_t comm, int world, int rank, hipStream_t st, std::atomic<int64_t>* sent = nullptr, std::atomic<int64_t>* received = nullptr)
+      : comm_(comm), world_(world), rank_(rank), st_(st), sent_(sent), received_(received) {}
   int world() const override { return world_; }
   int rank() const override { return rank_; }
   bool host_memory() const override { return false; }
@@ -154,6 +160,8 @@ class RcclTransport : public xchg::Transport {
     Rccl& r = Rccl::get();
     r.check(r.GroupStart(), "ncclGroupStart");
     for (int p = 0; p < world_; p++) {
+      if (sent_ && p != rank_) sent_->fetch_add((int64_t)sp.send[(size_t)p] * w);           // bytes that leave this GPU (the rank's own partition stays)
+      if (received_ && p != rank_) received_->fetch_add((int64_t)sp.recv[(size_t)p] * w);
       if (sp.send[(size_t)p]) r.check(r.Send((const char*)send_buf + (size_t)sp.starts[(size_t)p] * (size_t)w, (size_t)sp.send[(size_t)p] * (size_t)w, kNcclUint8, p, comm_, st_), "ncclSend");
       if (sp.recv[(size_t)p]) r.check(r.Recv((char*)recv_buf + (size_t)sp.roff[(size_t)p] * (size_t)w, (size_t)sp.recv[(size_t)p] * (size_t)w, kNcclUint8, p, comm_, st_), "ncclRecv");
     }
@@ -164,6 +172,7 @@ class RcclTransport : public xchg::Transport {
   ncclComm_t comm_;
   int world_, rank_;
   hipStream_t st_;
+  std::atomic<int64_t>*sent_, *received_;
 };
 
 // N task threads of one process: publish through the group's slots, pull the slices with peer copies
@@ -227,6 +236,7 @@ struct Comm {
   std::unique_ptr<xchg::TcpTransport> tcp;
   hipStream_t stream = nullptr;
   hipEvent_t ready = nullptr;
+  std::atomic<int64_t> bytes_sent{0}, bytes_received{0};      // over the RCCL wire, to / from OTHER ranks
   const char* transport_name() const { return nccl ? "rccl" : tcp ? "tcp" : local ? "in-process" : "none (1 rank)"; }
 };
 std::mutex g_comm_mu;
@@ -436,7 +446,7 @@ int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* 
     ops.st = c->stream;
     // the orchestration is exchange_core.hpp's, whatever the wire
     if (c->nccl) {
-      RcclTransport t(c->nccl, c->world, c->rank, c->stream);
+      RcclTransport t(c->nccl, c->world, c->rank, c->stream, &c->bytes_sent, &c->bytes_received);
       xchg::run(ops, t, n_cols, cols, rows, key_cols, n_keys, res->r);
     } else if (c->tcp) {
       xchg::run(ops, *c->tcp, n_cols, cols, rows, key_cols, n_keys, res->r);
@@ -458,6 +468,27 @@ const char* comet_comm_transport(int64_t comm) {
   std::lock_guard<std::mutex> lk(g_comm_mu);
   auto it = g_comms.find(comm);
   return it == g_comms.end() ? "" : it->second->transport_name();
+}
+
+// out[0] = ranks of the communicator AS THE WIRE REPORTS IT (RCCL: ncclCommCount; −1 when the library has no such entry), out[1] = this
+// rank there (ncclCommUserRank), out[2] / out[3] = bytes this rank has sent to / received from other ranks over RCCL since the
+// communicator was made.  A bench line that prints these proves how many ranks RCCL saw without anyone reading logs.
+int32_t comet_comm_stats(int64_t comm, int64_t* out4) {
+  return guarded([&]() -> int32_t {
+    auto c = find_comm(comm);
+    out4[0] = c->world;
+    out4[1] = c->rank;
+    if (c->nccl) {
+      Rccl& r = Rccl::get();
+      int v = -1;
+      out4[0] = (r.CommCount && r.CommCount(c->nccl, &v) == 0) ? v : -1;
+      v = -1;
+      out4[1] = (r.CommUserRank && r.CommUserRank(c->nccl, &v) == 0) ? v : -1;
+    }
+    out4[2] = c->bytes_sent.load();
+    out4[3] = c->bytes_received.load();
+    return 0;
+  }, (int32_t)-1);
 }
 
 int64_t comet_exchange_result_rows(int64_t result) {

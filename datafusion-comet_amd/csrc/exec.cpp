@@ -1200,26 +1200,54 @@ void ExecutionContext::table_to_host_batches(const DevTable& t) {
   const size_t ncol = t.cols.size();
   std::vector<std::vector<uint8_t>> hv(ncol), hb(ncol);
   std::vector<std::vector<uint8_t>> hd(ncol);
+  // what has to come back: values (offsets for Utf8) and validity of every column; then the Utf8 bytes, whose size the offsets tell
+  struct Piece { const void* src; std::vector<uint8_t>* dst; size_t bytes; };
+  // A small result (the last batch of most queries: a few groups, a top-k) comes back through ONE kernel that writes every buffer into
+  // pinned host memory and one synchronisation; a large one with a copy per buffer.
+  auto fetch = [&](std::vector<Piece>& pieces) {
+    size_t total = 0, longest = 0;
+    for (auto& pc : pieces) { pc.dst->resize(pc.bytes); total += (pc.bytes + 15) & ~(size_t)15; longest = std::max(longest, pc.bytes); }
+    if (pieces.empty()) return;
+    static const bool batched = getenv("COMET_EXPORT_BATCHED") == nullptr || atoi(getenv("COMET_EXPORT_BATCHED")) != 0;
+    if (batched && total > 0 && total <= ((size_t)1 << 20) && pieces.size() <= 256) {
+      struct Desc { const uint8_t* src; uint8_t* dst; uint64_t len; };
+      const size_t head = (pieces.size() * sizeof(Desc) + 63) & ~(size_t)63;
+      export_host_.ensure(head + total + 64);
+      Desc* d = (Desc*)export_host_.p;
+      size_t at = head;
+      for (size_t k = 0; k < pieces.size(); k++) {
+        d[k].src = (const uint8_t*)pieces[k].src;
+        d[k].dst = (uint8_t*)export_host_.p + at;
+        d[k].len = pieces[k].bytes;
+        at += (pieces[k].bytes + 15) & ~(size_t)15;
+      }
+      if (comet_launch_copy_small(export_host_.p, (int)pieces.size(), (uint64_t)longest, stream_) != 0) throw CometError("result export: launch failed");
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      for (size_t k = 0; k < pieces.size(); k++)
+        if (pieces[k].bytes) memcpy(pieces[k].dst->data(), d[k].dst, pieces[k].bytes);
+      return;
+    }
+    for (auto& pc : pieces)
+      if (pc.bytes) HIP_CHECK(hipMemcpyAsync(pc.dst->data(), pc.src, pc.bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+  };
+  std::vector<Piece> pieces;
   for (size_t j = 0; j < ncol; j++) {
     const DType& ty = t.types[j];
     const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
     size_t bytes = is_str ? (size_t)(t.rows + 1) * 4 : ty.id == TypeId::Bool ? (size_t)((t.rows + 7) / 8) : (size_t)t.rows * fixed_width(ty);
-    hv[j].resize(bytes);
-    HIP_CHECK(hipMemcpyAsync(hv[j].data(), t.cols[j].data, bytes, hipMemcpyDeviceToHost, stream_));
-    if (t.has_valid[j]) {
-      hb[j].resize((size_t)((t.rows + 7) / 8));
-      HIP_CHECK(hipMemcpyAsync(hb[j].data(), t.cols[j].valid, hb[j].size(), hipMemcpyDeviceToHost, stream_));
-    }
+    pieces.push_back({t.cols[j].data, &hv[j], bytes});
+    if (t.has_valid[j]) pieces.push_back({t.cols[j].valid, &hb[j], (size_t)((t.rows + 7) / 8)});
   }
-  HIP_CHECK(hipStreamSynchronize(stream_));
+  fetch(pieces);
+  pieces.clear();
   for (size_t j = 0; j < ncol; j++) {
     if (t.types[j].id == TypeId::String || t.types[j].id == TypeId::Bytes) {
       const int32_t* offs = (const int32_t*)hv[j].data();
-      hd[j].resize((size_t)offs[t.rows]);
-      if (!hd[j].empty()) HIP_CHECK(hipMemcpyAsync(hd[j].data(), t.cols[j].aux, hd[j].size(), hipMemcpyDeviceToHost, stream_));
+      if (offs[t.rows] > 0) pieces.push_back({t.cols[j].aux, &hd[j], (size_t)offs[t.rows]});
     }
   }
-  HIP_CHECK(hipStreamSynchronize(stream_));
+  fetch(pieces);
   check_device_errors();
   const int64_t bs = batch_size_ > 0 ? batch_size_ : t.rows;
   auto getbit = [](const std::vector<uint8_t>& b, int64_t i) { return (b[(size_t)(i >> 3)] >> (i & 7)) & 1; };

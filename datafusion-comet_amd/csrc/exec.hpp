@@ -293,6 +293,7 @@ class ExecutionContext {
   DevBuf err_flags_;
   PinnedBuf result_host_;
   PinnedBuf small_host_;   // 4 KiB pinned scratch for flag / count read-backs
+  PinnedBuf export_host_;  // a small result's buffers land here side by side (one copy kernel instead of a hipMemcpy per buffer)
   DevBuf group_table_, group_backup_;
   int64_t group_cap_ = 0;
   DevBuf scratch_mask_, scratch_counts_;

@@ -61,6 +61,7 @@ extern "C" int comet_launch_str_dict_lookup(const int32_t* build_offs, const uin
 extern "C" int64_t comet_partition_tiles(int64_t n);
 extern "C" int64_t comet_partition_scratch_bytes(int64_t n, int32_t P);
 extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
+extern "C" int comet_launch_copy_small(const void* descs, int n, uint64_t longest, void* stream);   // descs: pinned { const uint8_t* src; uint8_t* dst; uint64_t len; }
 extern "C" int comet_launch_murmur3(int type_id, int precision, const void* values, const uint8_t* validity, const void* aux, int64_t n, uint32_t* hashes, void* stream);
 extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out, void* stream);
 extern "C" int comet_launch_partition_indices(const int32_t* pids, int64_t n, int32_t P, uint64_t* hist, uint32_t* bad, int64_t* starts,
@@ -71,6 +72,7 @@ extern "C" int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_
 extern "C" int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits,
                                            int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" void pq_launch_u32_scan(const uint32_t* in, int64_t n, uint64_t* tiles, int32_t* out, void* st);
+extern "C" int comet_launch_sort_small(const uint8_t* planes, int64_t n, const uint32_t* cand, int m, const int* plane_idx, int nv, uint32_t* out, void* stream);
 extern "C" int comet_launch_sort_iota(uint32_t* perm, int64_t n, uint32_t first, void* stream);
 extern "C" int comet_launch_sort_gather_digit(const uint8_t* plane, const uint32_t* perm, int64_t n, int32_t* digit, void* stream);
 extern "C" int comet_launch_range_partition_ids(const uint8_t* planes, int64_t n, int W, const uint8_t* bkeys, int B, int32_t* pids, void* stream);

@@ -234,7 +234,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     bind_outputs(out_cap);
     prm.iarg[6] = out_cap;
     HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 8, stream_));
-    const int64_t ptiles = (n + 2047) / 2048;
+    const int64_t ptiles = (n + 4095) / 4096;      // kJoinR0 × 256 probe rows per tile (comet_device.hpp)
     launch(v, use_lds ? "k_jlds" : "k_jprobe", (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
     uint64_t emitted = 0;
     read_small(&emitted, emitted_buf.p, 8);

@@ -239,6 +239,19 @@ DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
       ns = nsure + m;
     }
   }
+  // few rows left (a TopK after its select passes, or a small input): one workgroup sorts them by their varying key bytes
+  std::vector<int> vplanes;
+  for (int b = 0; b < W; b++)
+    if (varies[(size_t)b]) vplanes.push_back(b);
+  static const bool small_sort = getenv("COMET_SORT_SMALL") == nullptr || atoi(getenv("COMET_SORT_SMALL")) != 0;
+  if (small_sort && ns <= 4096 && vplanes.size() <= 16) {
+    if (comet_launch_sort_small((const uint8_t*)planes->p, n, (const uint32_t*)perm->p, (int)ns, vplanes.data(), (int)vplanes.size(), (uint32_t*)perm2->p, stream_) != 0)
+      throw CometError("sort: launch failed");
+    timed_end();
+    if (getenv("COMET_TRACE_STAGES"))
+      fprintf(stderr, "[comet] sort: %lld rows, key %d bytes, %d select passes -> %lld rows sorted by one workgroup\n", (long long)n, W, select_passes, (long long)ns);
+    return take_rows(in, (const uint32_t*)perm2->p, skip, out_rows, perm2);   // synchronises the stream
+  }
   DevBuf digit, ridx, hist, starts;
   digit.ensure((size_t)ns * 4 + 16);
   ridx.ensure((size_t)ns * 4 + 16);

@@ -232,6 +232,31 @@ extern "C" int comet_launch_dict_gather_str_copy(const void* idx, int iw, const 
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// A result's buffers → one block of pinned host memory, in ONE launch (exec.cpp table_to_host_batches): a query's last batch is a handful of
+// small buffers — values and validity of each column — and a hipMemcpy per buffer costs 20–70 µs of latency each, fifteen of them 0.7 ms
+// behind a 15 ms TPC-H Q3 (profiles/r4_q3_timeline.txt) and a tenth of a TPC-H Q1 task.  descs (pinned, read by the device): n × { src, dst, bytes };
+// workgroup y copies piece x of buffer y, bytes one by one at the unaligned ends, words in between.
+struct CometCopyDesc { const uint8_t* src; uint8_t* dst; uint64_t len; };
+__global__ __launch_bounds__(256) void copy_small_kernel(const CometCopyDesc* __restrict__ descs) {
+  const CometCopyDesc d = descs[blockIdx.y];
+  const u64 lo = (u64)blockIdx.x << 14, hi = lo + 16384 < d.len ? lo + 16384 : d.len;
+  if (lo >= d.len) return;
+  if ((((u64)d.src | (u64)d.dst) & 3u) == 0) {
+    const u64 words = (hi - lo) >> 2;
+    const u32* s4 = (const u32*)(d.src + lo);
+    u32* d4 = (u32*)(d.dst + lo);
+    for (u64 i = threadIdx.x; i < words; i += 256) d4[i] = s4[i];
+    for (u64 i = lo + (words << 2) + threadIdx.x; i < hi; i += 256) d.dst[i] = d.src[i];
+  } else {
+    for (u64 i = lo + threadIdx.x; i < hi; i += 256) d.dst[i] = d.src[i];
+  }
+}
+extern "C" int comet_launch_copy_small(const void* descs, int n, uint64_t longest, void* stream) {
+  if (n <= 0 || !longest) return 0;
+  hipLaunchKernelGGL(copy_small_kernel, dim3((unsigned)((longest + 16383) >> 14), (unsigned)n), 256, 0, (hipStream_t)stream, (const CometCopyDesc*)descs);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int comet_launch_pmod(const uint32_t* hashes, int64_t n, int32_t np, int32_t* out, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(pmod_kernel, grid_for(n), 256, 0, (hipStream_t)stream, hashes, (i64)n, np, out);

@@ -915,6 +915,16 @@ class NativeComm:
         """"rccl" | "tcp" | "in-process" | "none (1 rank)": the wire this communicator moves its slices over"""
         return (lib().comet_comm_transport(self.handle) or b"").decode()
 
+    def stats(self) -> dict:
+        """What the wire itself reports: ranks of the communicator (RCCL: ncclCommCount), this rank there, bytes sent to / received from other ranks."""
+        out = (ctypes.c_int64 * 4)()
+        fn = lib().comet_comm_stats
+        fn.restype = ctypes.c_int32
+        fn.argtypes = [ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+        if fn(self.handle, out) != 0:
+            raise CometNativeException((lib().comet_exchange_last_error() or b"").decode())
+        return {"comm_count": int(out[0]), "comm_rank": int(out[1]), "bytes_sent": int(out[2]), "bytes_received": int(out[3])}
+
     @staticmethod
     def unique_id() -> bytes:
         buf = ctypes.create_string_buffer(128)

@@ -244,6 +244,10 @@ int64_t comet_comm_init_local(int64_t group_id, int32_t world, int32_t rank, int
 int64_t comet_comm_init_tcp(const char* peers, int32_t world, int32_t rank, int32_t device_id, int32_t timeout_ms);
 /* "rccl" | "tcp" | "in-process" | "none (1 rank)": the wire this communicator moves its slices over */
 const char* comet_comm_transport(int64_t comm);
+/* out4[0] = ranks of the communicator as the wire itself reports them (RCCL: ncclCommCount, -1 if the library lacks the entry), out4[1] = this
+ * rank there (ncclCommUserRank), out4[2] / out4[3] = bytes sent to / received from other ranks over RCCL so far.  0, or -1 (comet_last_error).
+ * No reference counterpart: the reference's exchange is Spark's shuffle (shuffle_writer.rs:166-300); this is bench / test evidence. */
+int32_t comet_comm_stats(int64_t comm, int64_t* out4);
 void comet_comm_destroy(int64_t comm);
 /* Collective: every rank of the communicator calls it with its shard (rows may be 0).  Returns a result handle. */
 int64_t comet_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* cols, int64_t rows, const int32_t* key_cols, int32_t n_keys);

@@ -94,6 +94,13 @@ q3() {
 q95() {
   timeout 300 python tools/q95_bench.py --orders 16000000 --reps 3 > $OUT/q95.json 2> $OUT/q95.err; cut -c1-600 $OUT/q95.json; echo
 }
+executor() {       # 8 / 16 concurrent plans, one host thread and one scan thread each
+  timeout 600 python tools/executor_bench.py --dir $PQ --steps 2 ${EXEC_ARGS:---busy} --out $OUT/executor.json > $OUT/executor.log 2>&1; python -c "
+import json;d=json.load(open('$OUT/executor.json'));print('link', d.get('pcie_link_GBps_measured'))
+for k,v in d['legs'].items():
+  for t,e in v.items():
+    if t.startswith('tasks_'): print(k,t,{a:(round(b,3) if isinstance(b,float) else b) for a,b in e.items()})" 2>&1 | tail -12; tail -3 $OUT/executor.log | cut -c1-300
+}
 read_probe() {     # page cache -> pinned memory -> device, nothing else: what bounds a scan before the GPU sees a byte
   ls $PQ/*.parquet > /dev/null 2>&1 || timeout 200 python tools/parquet_q6.py --codec snappy --dir $PQ --steps 1 > /dev/null 2>&1
   timeout 200 python tools/read_probe.py --file $(ls -S $PQ/*.parquet | head -1) > $OUT/read_probe.json 2> $OUT/read_probe.err; cat $OUT/read_probe.json; tail -2 $OUT/read_probe.err

@@ -27,6 +27,7 @@ def main():
                     help="auto: one native plan on one rank (tpch.q3_plan, fused probe chains), the staged plans with exchanges on N; staged: always the stages")
     ap.add_argument("--exchange", default="native", choices=["native", "torch", "torch-fallback"],
                     help="native: the exchange runs inside libcomet.so (partition kernels + RCCL send/recv groups); torch: torch.distributed all_to_all")
+    ap.add_argument("--allow-fallback", action="store_true", help="N > 1 ranks: exit 0 even when the exchange did NOT run over the in-library RCCL transport")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import torch
@@ -78,6 +79,16 @@ def main():
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     sec = float(dt.item()) / a.steps
+    # what the wire itself says: RCCL's rank count, and the bytes every rank sent / received over it (gathered: rank 0 prints them all)
+    wire = None
+    if world > 1:
+        st = part.comm.stats() if isinstance(part, parallel.NativeExchange) else {"comm_count": 0, "comm_rank": rank, "bytes_sent": 0, "bytes_received": 0}
+        mine = torch.tensor([st["comm_count"], st["comm_rank"], st["bytes_sent"], st["bytes_received"]], dtype=torch.int64, device=dev)
+        allst = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allst, mine)
+        wire = {"rccl_comm_count_per_rank": [int(x[0]) for x in allst], "rccl_comm_rank_per_rank": [int(x[1]) for x in allst],
+                "rccl_bytes_sent_per_rank": [int(x[2]) for x in allst], "rccl_bytes_received_per_rank": [int(x[3]) for x in allst],
+                "runs_counted": a.warmup + a.steps}
     ok = None
     if rank == 0 and not a.no_verify:
         del customer, orders, lineitem
@@ -90,7 +101,7 @@ def main():
                 "sec_per_run": sec, "rows_per_s": int(tot[0].item()) / sec, "input_GBps": int(tot[1].item()) / sec / 1e9,
                 "stage_ms_rank0": {k: round(v / a.steps * 1e3, 3) for k, v in timings.items() if not k.startswith("exchange_")},
                 "exchange_rows_rank0": timings.get("exchange_rows", 0) // a.steps, "exchange_bytes_rank0": timings.get("exchange_bytes", 0) // a.steps,
-                "plan": "one native plan (fused probe chains)" if single_plan else "5 stage plans cut at the exchanges", "exchange": exchange_kind, "exchange_transport": transport, "groups_rank0": groups, "top1": [str(x) for x in top[0]] if top else None, "verified_vs_torch": ok, "scaling": "strong"}
+                "plan": "one native plan (fused probe chains)" if single_plan else "5 stage plans cut at the exchanges", "exchange": exchange_kind, "exchange_transport": transport, "exchange_wire": wire, "groups_rank0": groups, "top1": [str(x) for x in top[0]] if top else None, "verified_vs_torch": ok, "scaling": "strong"}
         s = json.dumps(line)
         print(s, flush=True)
         if a.out:
@@ -98,6 +109,8 @@ def main():
                 f.write(s + "\n")
     if world > 1:
         dist.destroy_process_group()
+        if transport != "rccl" and not a.allow_fallback:
+            sys.exit(4)      # the exchange did not run over the wire north_star names: never report that as a pass silently
     if ok is False:
         sys.exit(3)
 

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--exchange", default="native", choices=["native", "torch", "torch-fallback"])
+    ap.add_argument("--allow-fallback", action="store_true", help="N > 1 ranks: exit 0 even when the exchange did NOT run over the in-library RCCL transport")
     ap.add_argument("--simulate-ranks", type=int, default=0)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--verify", default="torch", choices=["torch", "numpy", "both"],
@@ -116,6 +117,15 @@ def main():
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         sec = float(dt.item()) / a.steps
+    wire = None
+    if world > 1:
+        st = part.comm.stats() if isinstance(part, parallel.NativeExchange) else {"comm_count": 0, "comm_rank": rank, "bytes_sent": 0, "bytes_received": 0}
+        me = torch.tensor([st["comm_count"], st["comm_rank"], st["bytes_sent"], st["bytes_received"]], dtype=torch.int64, device=dev)
+        allst = [torch.zeros_like(me) for _ in range(world)]
+        dist.all_gather(allst, me)
+        wire = {"rccl_comm_count_per_rank": [int(x[0]) for x in allst], "rccl_comm_rank_per_rank": [int(x[1]) for x in allst],
+                "rccl_bytes_sent_per_rank": [int(x[2]) for x in allst], "rccl_bytes_received_per_rank": [int(x[3]) for x in allst],
+                "runs_counted": a.warmup + a.steps}
     ok, verified_by = None, None
     if rank == 0:
         if not a.no_verify:
@@ -130,7 +140,7 @@ def main():
             verified_by = f"{a.verify} ({time.perf_counter() - v0:.1f} s)"
         line = {"query": "tpcds_q95", "orders": a.orders, "n_gpus": world, "simulated_ranks": a.simulate_ranks, "fact_rows": rows, "sec_per_run": sec,
                 "fact_rows_per_s": rows / sec, "stage_ms_rank0": {k: round(v / a.steps * 1e3, 3) for k, v in timings.items() if not k.startswith("exchange_")},
-                "exchange": exchange_kind, "exchange_transport": transport, "result": [got[0], str(got[1]), str(got[2])], "verified": ok,
+                "exchange": exchange_kind, "exchange_transport": transport, "exchange_wire": wire, "result": [got[0], str(got[1]), str(got[2])], "verified": ok,
                 "verified_by": verified_by, "scaling": "strong"}
         s = json.dumps(line)
         print(s, flush=True)
@@ -141,6 +151,8 @@ def main():
         dist.destroy_process_group()
     if ok is False:
         sys.exit(3)
+    if world > 1 and a.simulate_ranks <= 1 and transport != "rccl" and not a.allow_fallback:
+        sys.exit(4)      # the exchange did not run over the wire north_star names: never a silent pass
 
 
 if __name__ == "__main__":
