@@ -94,7 +94,13 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     if (kv.first == "spark.comet.gpu.join.semiReduction") semi_reduction = kv.second != "false" && kv.second != "0";
   if (const char* e = getenv("COMET_JOIN_SEMI_REDUCTION")) semi_reduction = atoi(e) != 0;
   if (semi_reduction) {
+    // The rewrite changes what the plan's nodes compile to (join type, build side, output width) while the plan BYTES — what plan_hash_ is
+    // taken from, and with it every key of the process-wide kernel cache — stay the same: two contexts running the same bytes with and
+    // without the rule would share each other's variants.  So every rewritten join is folded into plan_hash_ (which joins, swapped or not).
+    uint64_t rewrite_sig = 0;
+    int visit = 0;
     std::function<void(Operator&, bool)> reduce = [&](Operator& op, bool set_only) {   // set_only: the consumer looks at the SET of op's rows
+      const int my_visit = visit++;
       if (op.kind == OpKind::Projection && set_only && op.children.size() == 1 && op.children[0]->kind == OpKind::HashJoin) {
         Operator& j = *op.children[0];
         if (j.join_type == JoinType::Inner && !j.null_aware_anti && j.children.size() == 2 && j.left_keys.size() == j.right_keys.size()) {
@@ -141,6 +147,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
               for (auto& e : op.project_list) e = remap(e, false);
             }
             j.join_type = JoinType::LeftSemi;
+            rewrite_sig = (rewrite_sig ^ (uint64_t)(2 * my_visit + (any_right ? 1 : 0) + 1)) * 1099511628211ull;
           }
         }
       }
@@ -158,6 +165,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
       }
     };
     reduce(*plan_, false);
+    if (rewrite_sig) plan_hash_ ^= rewrite_sig * 0x9E3779B97F4A7C15ull;
   }
   // Scan leaves in depth-first, left-before-right order map to the input streams (planner.rs:1726, :2391)
   std::function<void(const Operator&)> walk = [&](const Operator& op) {

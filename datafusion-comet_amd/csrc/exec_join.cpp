@@ -158,6 +158,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   int64_t entries = B.rows;
   static const bool count_runs = getenv("COMET_JOIN_COUNT_RUNS") == nullptr || atoi(getenv("COMET_JOIN_COUNT_RUNS")) != 0;
   DevBuf keymap;
+  uint64_t keymap_first = 0, keymap_range = 0;       // a candidate for the key bitmap: one integer key whose values span a foreign key's range
   if (!use_lds && count_runs && B.rows >= (1 << 20)) {
     const uint64_t init[3] = {0, ~0ull, 0};          // leaders, smallest key, largest key (order-preserving u64)
     write_small(emitted_buf.p, init, sizeof init);
@@ -169,17 +170,11 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     entries = std::min<int64_t>(B.rows, (int64_t)got[0]);
     // The key bitmap (comet_device.hpp kJoinKeyMap): one integer key whose values span at most 64 bits per build row and 2^31 bits — a
     // foreign key's shape.  k_jbcnt leaves min / max untouched when the kernel has no such key (KEYMAP false).
-    static const bool use_keymap = getenv("COMET_JOIN_KEYMAP") == nullptr || atoi(getenv("COMET_JOIN_KEYMAP")) != 0;
-    if (use_keymap && got[1] <= got[2]) {
+    if (got[1] <= got[2]) {
       const uint64_t range = got[2] - got[1] + 1;      // (never 0: the keys are 64-bit values of ≤ 2^31 rows … guarded below anyway)
       if (range != 0 && range <= ((uint64_t)1 << 31) && range <= (uint64_t)B.rows * 64) {
-        const size_t words = (size_t)((range + 31) / 32);
-        keymap.ensure(16 + words * 4 + 16);
-        HIP_CHECK(hipMemsetAsync((char*)keymap.p + 16, 0, words * 4, stream_));
-        const uint64_t hdr[2] = {got[1] ^ ((uint64_t)1 << 63), range};
-        write_small(keymap.p, hdr, sizeof hdr);
-        prm.out[44] = keymap.p;
-        join_keymap_bytes_ += (int64_t)words * 4;
+        keymap_first = got[1] ^ ((uint64_t)1 << 63);
+        keymap_range = range;
       }
     }
   }
@@ -228,6 +223,34 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   // chained global table; either way the probe counts and emits in one launch, reserving output ranges with one atomic per tile ----
   if (!use_lds && B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
   prm.out[47] = emitted_buf.p;
+  // The key bitmap (comet_device.hpp kJoinKeyMap) pays when probe rows miss: 8192 probe rows, evenly spaced, go through the finished table
+  // first; fewer than half with a partner → one more pass over the build keys sets the bits, and the probe asks them before the table.
+  static const int keymap_mode = getenv("COMET_JOIN_KEYMAP") ? atoi(getenv("COMET_JOIN_KEYMAP")) : -1;      // 0 never, 1 always, default: by the sample
+  // (… and only where the probe side is several times the build side: the bitmap's build pass costs what the build side's atomics cost —
+  // 2.2 ms for each of TPC-DS Q95's 70 M-row builds, whose equally large probe sides it did not speed up)
+  if (keymap_range && keymap_mode != 0 && n >= (1 << 20) && (keymap_mode == 1 || n >= 4 * B.rows)) {
+    bool wanted = keymap_mode == 1;
+    if (!wanted) {
+      const uint64_t zero[2] = {0, 0};
+      write_small(emitted_buf.p, zero, sizeof zero);
+      const int64_t ns = 8192;
+      prm.iarg[5] = ns;
+      launch(v, "k_jsample", (int)((ns + 255) / 256), prm);
+      uint64_t cnt[2] = {0, 0};
+      read_small(cnt, emitted_buf.p, sizeof cnt);
+      wanted = cnt[0] >= 64 && cnt[1] * 2 < cnt[0];
+    }
+    if (wanted) {
+      const size_t words = (size_t)((keymap_range + 31) / 32);
+      keymap.ensure(16 + words * 4 + 16);
+      HIP_CHECK(hipMemsetAsync((char*)keymap.p + 16, 0, words * 4, stream_));
+      const uint64_t hdr[2] = {keymap_first, keymap_range};
+      write_small(keymap.p, hdr, sizeof hdr);
+      prm.out[44] = keymap.p;
+      launch(v, "k_jbmap", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+      join_keymap_bytes_ += (int64_t)words * 4;
+    }
+  }
   // FK-shaped joins emit at most one row per probe row; anything beyond the capacity is counted, not written, and the probe re-run
   int64_t out_cap = d.join_build_only ? 1 : n + 1024;
   for (int attempt = 0; n > 0; attempt++) {

@@ -101,6 +101,15 @@ for k,v in d['legs'].items():
   for t,e in v.items():
     if t.startswith('tasks_'): print(k,t,{a:(round(b,3) if isinstance(b,float) else b) for a,b in e.items()})" 2>&1 | tail -12; tail -3 $OUT/executor.log | cut -c1-300
 }
+q95_stats() {      # kernel statistics of TPC-DS Q95 stage A on one GPU
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q95_stats -o q95 -- python $GRAFT_REPO_ROOT/tools/q95_bench.py --orders 16000000 --reps 2 --verify none > $OUT/q95_stats.log 2>&1)
+  python - <<PYEOF
+import csv,re
+rows=list(csv.DictReader(open("$OUT/q95_stats/q95_kernel_stats.csv")))
+for r in rows[:14]:
+    m=re.search(r"(k_\w+|[a-z_0-9]+_kernel|__amd\w+)", r["Name"]); print(f'{(m.group(1) if m else r["Name"][:30]):28s} calls {r["Calls"]:>4s} total_ms {float(r["TotalDurationNs"])/1e6:9.3f} avg_ms {float(r["AverageNs"])/1e6:8.3f}')
+PYEOF
+}
 read_probe() {     # page cache -> pinned memory -> device, nothing else: what bounds a scan before the GPU sees a byte
   ls $PQ/*.parquet > /dev/null 2>&1 || timeout 200 python tools/parquet_q6.py --codec snappy --dir $PQ --steps 1 > /dev/null 2>&1
   timeout 200 python tools/read_probe.py --file $(ls -S $PQ/*.parquet | head -1) > $OUT/read_probe.json 2> $OUT/read_probe.err; cat $OUT/read_probe.json; tail -2 $OUT/read_probe.err
