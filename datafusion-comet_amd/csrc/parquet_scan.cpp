@@ -24,6 +24,12 @@
 
 #include "exec.hpp"
 #include "parquet_dev.h"
+namespace comet { namespace detail {      // per-process stream / event pools (exec_memory.cpp)
+hipStream_t pool_get_stream(int dev);
+void pool_put_stream(int dev, hipStream_t s);
+hipEvent_t pool_get_event(int dev);
+void pool_put_event(int dev, hipEvent_t e);
+} }
 #include "device/snappy2.hpp"
 #include "snappy2.hpp"
 #include "zstd2.hpp"
@@ -1781,31 +1787,29 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   // with one copy per slice): COMET_PQ_UPLOAD=kernel batches the ready slices into ONE launch of a kernel that reads the pinned staging
   // memory across PCIe itself (22.5 ms: the SDMA engines move a slice at 50+ GB/s, a kernel's reads of host memory reach half of that);
   // COMET_PQ_COPY_STREAMS=n spreads the copies over n streams (17–18 ms, noisier).
-  hipStream_t copy_stream = nullptr;
-  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  // (streams and events come from the process-wide pools: creating a stream costs 10 ms and destroying one 2 ms when eight tasks do it at
+  // once — hipStreamCreateWithFlags was a quarter of the wall time of eight concurrent scans, profiles/r4_executor_hip_api.txt)
+  hipStream_t copy_stream = detail::pool_get_stream(device_id_);
   std::vector<hipStream_t> extra_streams;
   std::vector<hipEvent_t> events;
   PinnedBuf upload_descs;
   struct StreamGuard {
-    hipStream_t& s; std::vector<hipStream_t>& extra; std::vector<hipEvent_t>& ev;
+    int dev; hipStream_t& s; std::vector<hipStream_t>& extra; std::vector<hipEvent_t>& ev;
     ~StreamGuard() {
-      for (hipStream_t x : extra) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); }
-      if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-      for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+      for (hipStream_t x : extra) { (void)hipStreamSynchronize(x); detail::pool_put_stream(dev, x); }
+      if (s) { (void)hipStreamSynchronize(s); detail::pool_put_stream(dev, s); }
+      for (hipEvent_t e : ev) detail::pool_put_event(dev, e);
     }
-  } stream_guard{copy_stream, extra_streams, events};
+  } stream_guard{device_id_, copy_stream, extra_streams, events};
   auto get_event = [&]() {
-    hipEvent_t e;
-    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t e = detail::pool_get_event(device_id_);
     events.push_back(e);
     return e;
   };
   static const bool upload_by_kernel = getenv("COMET_PQ_UPLOAD") && !strcmp(getenv("COMET_PQ_UPLOAD"), "kernel");
   static const int n_copy_streams = getenv("COMET_PQ_COPY_STREAMS") ? std::max(1, std::min(8, atoi(getenv("COMET_PQ_COPY_STREAMS")))) : 1;
   for (int k = 1; k < n_copy_streams && !upload_by_kernel; k++) {
-    hipStream_t x;
-    HIP_CHECK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
-    extra_streams.push_back(x);
+    extra_streams.push_back(detail::pool_get_stream(device_id_));
   }
   const size_t max_descs = ntasks * 2 + ncol + 16;
   upload_descs.ensure(max_descs * sizeof(PqCopyDesc) + 64);
@@ -1855,17 +1859,16 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   std::vector<hipEvent_t> group_events;
   std::vector<char> group_dirty;
   struct GroupStreamGuard {
-    std::vector<hipStream_t>& gs;
-    ~GroupStreamGuard() { for (hipStream_t x : gs) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); } }
-  } group_stream_guard{group_streams};
+    int dev; std::vector<hipStream_t>& gs;
+    ~GroupStreamGuard() { for (hipStream_t x : gs) { (void)hipStreamSynchronize(x); detail::pool_put_stream(dev, x); } }
+  } group_stream_guard{device_id_, group_streams};
   size_t group_rr = 0;
   hipEvent_t groups_may_start = nullptr;      // recorded on stream_ behind the set-up the groups depend on (the error words' memset)
   auto next_group_stream = [&]() -> hipStream_t {
     if (n_group_streams == 0) return stream_;
     const size_t k = group_rr++ % (size_t)n_group_streams;
     if (k >= group_streams.size()) {
-      hipStream_t x;
-      HIP_CHECK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+      hipStream_t x = detail::pool_get_stream(device_id_);
       group_streams.push_back(x);
       group_dirty.push_back(0);
       HIP_CHECK(hipStreamWaitEvent(x, groups_may_start, 0));
@@ -2148,7 +2151,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       {
         bool ready;
         { std::lock_guard<std::mutex> lk(prog->mu); ready = prog->done[c * nsel + si] != 0; }
-        if (!ready) { flush_pieces(); upload_flush(); }       // what is ready crosses while this thread waits
+        // what is ready crosses while this thread waits — once it is worth a copy: a task with one scan thread gets its chunks one by one, and a
+        // hipMemcpyAsync per 0.7 MB chunk cost each of eight concurrent tasks 120 µs a call (profiles/r4_executor_hip_api.txt)
+        if (!ready && pend_hi - pend_lo >= ((size_t)2 << 20)) { flush_pieces(); upload_flush(); }
       }
       const double t_wait = trace ? ms_since() : 0;
       wait_for(c * nsel + si);
