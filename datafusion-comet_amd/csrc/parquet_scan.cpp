@@ -731,6 +731,10 @@ struct ChunkSource {
 // bytes the staged (decompressed) pages of a column chunk may take
 // (device-decompressed pages start on 16-byte boundaries: at most one per 4 KiB of page data, hence the 1/256)
 // A chunk with DELTA_* pages is rewritten as PLAIN on the host and outgrows its declared size: at most 8 bytes per value more.
+// where a chunk starts in its file (its dictionary page when it has one)
+int64_t chunk_file_offset(const pq::ColumnMeta& cm) {
+  return (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < cm.data_page_offset) ? cm.dictionary_page_offset : cm.data_page_offset;
+}
 size_t staged_capacity(const pq::ColumnMeta& cm) {
   const size_t delta = cm.delta_encoded ? (size_t)std::max<int64_t>(cm.num_values, 0) * 8 + 64 : 0;
   return ((size_t)cm.total_uncompressed + (size_t)cm.total_uncompressed / 256 + delta + 128 + 15) & ~(size_t)15;
@@ -748,7 +752,7 @@ constexpr double kHostZstdBytesPerMs = 1.5e6, kDeviceZstdSetupMs = 2.0;
 // DELTA_BYTE_ARRAY pages are prefix-compressed: what they decode to is only known from their length blocks.  One extra pass over such a
 // chunk (read, decompress, decode the two length blocks of every page) sizes its staging slot; nothing else pays for it.
 size_t prefix_encoded_plain_bytes(const ChunkSource& src, const pq::ColumnMeta& cm, int max_def) {
-  int64_t off = (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < cm.data_page_offset) ? cm.dictionary_page_offset : cm.data_page_offset;
+  int64_t off = chunk_file_offset(cm);
   const int64_t chunk_end = off + cm.total_compressed;
   if (off < 0 || (size_t)chunk_end > src.file->size) throw CometError("parquet: column chunk outside the file");
   std::vector<uint8_t> raw((size_t)cm.total_compressed + 16), page;
@@ -797,11 +801,15 @@ bool in_place_shape(const pq::ColumnMeta& cm, bool is_string, const ScanOptions&
   return so.read_in_place && (cm.codec == pq::SNAPPY || (cm.codec == pq::ZSTD && so.device_zstd)) && !is_string && !cm.prefix_encoded;
 }
 size_t chunk_staging_capacity(const ChunkSource& src, const pq::ColumnMeta& cm, int max_def, bool is_string, const ScanOptions& so) {
-  return staged_capacity(cm) + (cm.prefix_encoded ? ((prefix_encoded_plain_bytes(src, cm, max_def) + 15) & ~(size_t)15) : 0) +
-         (in_place_shape(cm, is_string, so) ? in_place_extra(cm) : 0);
+  (void)is_string; (void)so;
+  return staged_capacity(cm) + (cm.prefix_encoded ? ((prefix_encoded_plain_bytes(src, cm, max_def) + 15) & ~(size_t)15) : 0);
 }
 
-void decode_chunk_host(const ChunkSource& src, const StructField& want, const ScanOptions& so, HostChunk& hc, uint8_t* staged, size_t slot_cap) {
+// `raw_area` (optional, above `staged` in the same pinned block, `raw_cap` bytes): where a chunk that is read in place keeps the file's bytes —
+// the raw areas of a column's chunks lie NEXT TO EACH OTHER behind the column's staging slots, so what crosses PCIe compressed is contiguous
+// and a column's ready chunks cross in a handful of copies.  `raw_read`: the scan threads have already read the chunk into it (in pieces).
+void decode_chunk_host(const ChunkSource& src, const StructField& want, const ScanOptions& so, HostChunk& hc, uint8_t* staged, size_t slot_cap,
+                       uint8_t* raw_area = nullptr, size_t raw_cap = 0, bool raw_read = false) {
   const pq::RowGroup& rg = src.meta->row_groups[(size_t)src.rg];
   ColumnPlan cp = plan_column(want, *src.meta, so);
   if (cp.missing) throw CometError("internal: chunk task for a missing column");
@@ -819,23 +827,23 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   std::vector<int32_t>& dict_offs = hc.dict_offs;
   std::vector<int64_t>& str_offs = hc.str_offs;
 
-  int64_t off = (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < cm.data_page_offset) ? cm.dictionary_page_offset : cm.data_page_offset;
+  int64_t off = chunk_file_offset(cm);
   const int64_t chunk_end = off + cm.total_compressed;
   if (off < 0 || (size_t)chunk_end > src.file->size) throw CometError("parquet: column chunk outside the file");
   // the whole (compressed) chunk into the back of its slot when the device will inflate its pages (their bodies are uploaded from where they
   // land), else into this thread's scratch; then parse from memory
   static thread_local std::vector<uint8_t> raw;
-  size_t staged_cap = slot_cap;
-  const bool in_place = so.device_snappy && in_place_shape(cm, cp.is_string, so) && slot_cap >= in_place_extra(cm) + 256;
+  const size_t staged_cap = slot_cap;
+  const bool in_place = so.device_snappy && in_place_shape(cm, cp.is_string, so) && raw_area != nullptr && raw_area > staged && raw_cap >= in_place_extra(cm);
   uint8_t* rawp;
   if (in_place) {
-    staged_cap = slot_cap - in_place_extra(cm);
-    rawp = staged + staged_cap;
+    rawp = raw_area;
   } else {
+    if (raw_read) throw CometError("internal: chunk read in pieces but not decoded in place");
     if (raw.size() < (size_t)cm.total_compressed + 16) raw.resize((size_t)cm.total_compressed + 16);
     rawp = raw.data();
   }
-  { HostTimer tm(g_ns_read); src.file->read_at(rawp, (size_t)cm.total_compressed, off); }
+  if (!raw_read) { HostTimer tm(g_ns_read); src.file->read_at(rawp, (size_t)cm.total_compressed, off); }
   const uint8_t* chunk_data = rawp - off;         // so that chunk_data + file_offset addresses the byte
   int64_t values_seen = 0;      // rows of the row group the pages walked so far cover
   int64_t out_pos = 0;          // kept rows emitted so far (the chunk's output rows)
@@ -1642,6 +1650,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   std::vector<char> chunk_missing(ntasks, 0);     // per (column, row group): this file lacks the column
   std::vector<char> all_missing(ncol, 0);         // no selected file has the column and it has no default: all-NULL fast path
   std::vector<std::vector<size_t>> slot_off(ncol, std::vector<size_t>(nsel + 1, 0));
+  // raw areas (chunks read in place): raw_off[c][si] from raw_base[c], which lies behind the column's last staging slot
+  std::vector<std::vector<size_t>> raw_off(ncol, std::vector<size_t>(nsel + 1, 0));
+  std::vector<size_t> raw_base(ncol, 0);
   std::vector<std::unique_ptr<PinnedBuf>> col_staged(ncol);
   for (size_t c = 0; c < ncol; c++) {
     bool have = false;
@@ -1652,22 +1663,25 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       if (!cp.missing && (size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
       chunk_missing[c * nsel + si] = cp.missing;
       if (!cp.missing && !have) { plans[c] = cp; have = true; }
-      size_t cap_bytes;
+      size_t cap_bytes, raw_bytes = 0;
       if (cp.missing) {
         cap_bytes = synth_capacity(op.required_schema[c].dtype, rg.num_rows);
       } else {
         ChunkSource csrc{sels[si].file.get(), sels[si].meta.get(), sels[si].rg, nullptr};
         cap_bytes = chunk_staging_capacity(csrc, rg.columns[(size_t)cp.leaf], cp.el.repetition == 1 ? 1 : 0, cp.is_string, so);   // reads the chunk only if it holds DELTA_BYTE_ARRAY pages
+        if (in_place_shape(rg.columns[(size_t)cp.leaf], cp.is_string, so)) raw_bytes = in_place_extra(rg.columns[(size_t)cp.leaf]);
       }
       slot_off[c][si + 1] = slot_off[c][si] + cap_bytes;
+      raw_off[c][si + 1] = raw_off[c][si] + raw_bytes;
     }
+    raw_base[c] = (slot_off[c][nsel] + 64 + 63) & ~(size_t)63;
     if (!have) {
       plans[c] = plan_column(op.required_schema[c], *sels[0].meta, so);
       all_missing[c] = dflt == nullptr || dflt->lit_null;
     }
     plans[c].out_width = out_width_of(op.required_schema[c].dtype);
     col_staged[c].reset(new PinnedBuf());
-    col_staged[c]->ensure(slot_off[c][nsel] + 64);
+    col_staged[c]->ensure(raw_base[c] + raw_off[c][nsel] + 64);
   }
   // shared state outlives this frame only through the shared_ptr the tasks hold
   struct Progress {
@@ -1731,27 +1745,85 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   }
   if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy / %.1f MB of zstd pages of fixed-width columns, decompressed on the %s%s\n", (double)plain_snappy_bytes / 1e6,
                      (double)plain_zstd_bytes / 1e6, so.device_snappy ? "device" : "host", so.device_snappy && plain_zstd_bytes && !so.device_zstd ? " (zstd: host)" : "");
-  auto run_task = [&](size_t t) {
+  auto run_task = [&](size_t t, bool raw_read) {
     const size_t c = t / nsel, si = t % nsel;
     ChunkSource src{sels[si].file.get(), sels[si].meta.get(), sels[si].rg, sels[si].keep.get()};
     if (all_missing[c]) return;
     uint8_t* slot = (uint8_t*)col_staged[c]->p + slot_off[c][si];
     const size_t cap = slot_off[c][si + 1] - slot_off[c][si];
+    const size_t rcap = raw_off[c][si + 1] - raw_off[c][si];
+    uint8_t* rarea = rcap ? (uint8_t*)col_staged[c]->p + raw_base[c] + raw_off[c][si] : nullptr;
     if (chunk_missing[t]) synth_chunk(op.required_schema[c], default_of(c), sels[si].rows, chunks[t], slot, cap);
-    else { HostTimer tm(g_ns_chunk); decode_chunk_host(src, op.required_schema[c], so, chunks[t], slot, cap); }
+    else { HostTimer tm(g_ns_chunk); decode_chunk_host(src, op.required_schema[c], so, chunks[t], slot, cap, rarea, rcap, raw_read); }
   };
-  // `max_inflight` workers take the chunks in order (spark.comet.gpu.scanThreads: a task's share of the executor's pool — one, for a
+  // The unit of host work is a PIECE, in the order the device consumes the bytes (columns largest first, their chunks in row order).  A chunk
+  // that is read in place is read in pieces of a couple of MiB by whichever threads are free, and the thread that lands its last piece walks
+  // its pages — so the chunks of a column become ready ONE AFTER THE OTHER at the rate all readers reach together (32 whole-chunk reads
+  // side by side finished together: the first copy of SF10 Q6 left at 2.5 ms, with a third of the file read); every other chunk is one
+  // piece (read, decompress, walk — as before).
+  struct Piece { size_t t; size_t lo, len; bool whole; };
+  std::vector<Piece> pieces;
+  std::unique_ptr<std::atomic<int>[]> pieces_left(new std::atomic<int>[ntasks]);
+  static const size_t kReadPiece = getenv("COMET_PQ_READ_PIECE") ? (size_t)std::max(64 << 10, atoi(getenv("COMET_PQ_READ_PIECE"))) : ((size_t)2 << 20);
+  for (size_t oi = 0; oi < ncol; oi++)
+    for (size_t si = 0; si < nsel; si++) {
+      const size_t c = order[oi], t = c * nsel + si;
+      pieces_left[t].store(1);
+      bool split = false;
+      if (!all_missing[c] && !chunk_missing[t] && raw_off[c][si + 1] > raw_off[c][si] && so.device_snappy) {
+        ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
+        const pq::ColumnMeta& cm = sels[si].meta->row_groups[(size_t)sels[si].rg].columns[(size_t)cp.leaf];
+        const int64_t off = chunk_file_offset(cm);
+        // (a chunk that lies outside its file stays whole: decode_chunk_host says so)
+        if (in_place_shape(cm, cp.is_string, so) && off >= 0 && cm.total_compressed > 0 && (size_t)(off + cm.total_compressed) <= sels[si].file->size &&
+            raw_off[c][si + 1] - raw_off[c][si] >= in_place_extra(cm)) {
+          const size_t total = (size_t)cm.total_compressed;
+          size_t np = 0;
+          for (size_t lo = 0; lo < total;) {
+            size_t len = std::min(kReadPiece, total - lo);
+            if (total - lo - len < kReadPiece / 4) len = total - lo;      // no crumbs
+            pieces.push_back(Piece{t, lo, len, false});
+            lo += len;
+            np++;
+          }
+          pieces_left[t].store((int)np);
+          split = true;
+        }
+      }
+      if (!split) pieces.push_back(Piece{t, 0, 0, true});
+    }
+  const size_t npieces = pieces.size();
+  auto read_piece = [&](const Piece& pc) {
+    const size_t c = pc.t / nsel, si = pc.t % nsel;
+    ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
+    const pq::ColumnMeta& cm = sels[si].meta->row_groups[(size_t)sels[si].rg].columns[(size_t)cp.leaf];
+    HostTimer tc(g_ns_chunk);
+    HostTimer tm(g_ns_read);
+    sels[si].file->read_at((uint8_t*)col_staged[c]->p + raw_base[c] + raw_off[c][si] + pc.lo, pc.len, chunk_file_offset(cm) + (int64_t)pc.lo);
+  };
+  // `max_inflight` workers take the pieces in order (spark.comet.gpu.scanThreads: a task's share of the executor's pool — one, for a
   // Spark task that owns one core), each from the shared cursor until none is left
-  const size_t nworkers = std::min<size_t>(ntasks, (size_t)std::max(1, std::min(max_inflight, ScanPool::get().size())));
+  const size_t nworkers = std::min<size_t>(npieces, (size_t)std::max(1, std::min(max_inflight, ScanPool::get().size())));
+  std::mutex piece_err_mu;
   for (size_t wk = 0; wk < nworkers; wk++) {
-    ScanPool::get().submit([prog, ntasks, nsel, &order, &run_task, &chunks]() {
+    ScanPool::get().submit([prog, npieces, &pieces, &pieces_left, &read_piece, &run_task, &chunks, &piece_err_mu]() {
       for (;;) {
-        const size_t ti = prog->next.fetch_add(1);
-        if (ti >= ntasks) break;
-        const size_t t = order[ti / nsel] * nsel + ti % nsel;
-        if (!prog->cancelled.load()) {
+        const size_t pi = prog->next.fetch_add(1);
+        if (pi >= npieces) break;
+        const Piece& pc = pieces[pi];
+        const size_t t = pc.t;
+        if (!pc.whole && !prog->cancelled.load()) {
           try {
-            run_task(t);
+            read_piece(pc);
+          } catch (...) {
+            std::lock_guard<std::mutex> lk(piece_err_mu);
+            if (!chunks[t].err) chunks[t].err = std::current_exception();
+          }
+        }
+        if (pieces_left[t].fetch_sub(1) != 1) continue;      // another thread lands the chunk's last piece
+        if (!prog->cancelled.load() && !chunks[t].err) {
+          try {
+            run_task(t, !pc.whole);
           } catch (...) {
             chunks[t].err = std::current_exception();
           }
@@ -2123,9 +2195,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     keep.push_back(cd);
     // the column's page bytes cross PCIe in slices as soon as their chunks are ready, on the copy stream
     // [0, S): what the host staged (decompressed pages, or compressed bodies for the device); [S, 2S): pages the device decompresses
-    const size_t S = (slot_off[c][nsel] + 64 + 15) & ~(size_t)15;
+    // (the staged region: the chunks' slots, then their raw areas — what crosses compressed, contiguous; the decompressed region mirrors the slots only)
+    const size_t S = (raw_base[c] + raw_off[c][nsel] + 64 + 15) & ~(size_t)15;
     const bool may_inflate = so.device_snappy && !cp.is_string && !cp.missing;
-    cd->bytes.ensure(may_inflate ? 2 * S + 64 : S);
+    cd->bytes.ensure(may_inflate ? S + ((slot_off[c][nsel] + 64 + 15) & ~(size_t)15) + 64 : S);
     size_t n_jobs = 0, n_zjobs = 0;
     std::vector<PqInflate> group_jobs, zgroup_jobs;
     std::vector<comet_zstd2::ZBlock> zgroup_blocks;
@@ -2134,18 +2207,22 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     // carries them one after the other: a column of 60 small chunks spent more time between its copies than in them.  So pieces that are
     // READY and lie close together in the column's staging block cross as ONE copy — the bytes between them (a slot's unused tail) ride
     // along; a piece waits for company only while no thread would have to wait for it.
+    // Two runs of pieces are open at a time: what the host staged (in the slots) and the chunks' raw areas (behind them, contiguous).
     constexpr size_t kMergeGap = (size_t)512 << 10;
-    size_t pend_lo = 0, pend_hi = 0;
-    auto flush_pieces = [&]() {
-      if (pend_hi > pend_lo) upload((char*)cd->bytes.p + pend_lo, (char*)col_staged[c]->p + pend_lo, pend_hi - pend_lo);
-      pend_lo = pend_hi = 0;
+    size_t pend_lo[2] = {0, 0}, pend_hi[2] = {0, 0};
+    auto flush_run = [&](int w) {
+      if (pend_hi[w] > pend_lo[w]) upload((char*)cd->bytes.p + pend_lo[w], (char*)col_staged[c]->p + pend_lo[w], pend_hi[w] - pend_lo[w]);
+      pend_lo[w] = pend_hi[w] = 0;
     };
+    auto flush_pieces = [&]() { flush_run(0); flush_run(1); };
+    auto pending_piece_bytes = [&]() { return (pend_hi[0] - pend_lo[0]) + (pend_hi[1] - pend_lo[1]); };
     auto push_piece = [&](size_t lo, size_t hi) {
       if (hi <= lo) return;
-      if (pend_hi > pend_lo && lo >= pend_lo && lo <= pend_hi + kMergeGap) { pend_hi = std::max(pend_hi, hi); return; }
-      flush_pieces();
-      pend_lo = lo;
-      pend_hi = hi;
+      const int w = lo >= raw_base[c] ? 1 : 0;
+      if (pend_hi[w] > pend_lo[w] && lo >= pend_lo[w] && lo <= pend_hi[w] + kMergeGap) { pend_hi[w] = std::max(pend_hi[w], hi); return; }
+      flush_run(w);
+      pend_lo[w] = lo;
+      pend_hi[w] = hi;
     };
     for (size_t si = 0; si < nsel; si++) {
       {
@@ -2153,7 +2230,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         { std::lock_guard<std::mutex> lk(prog->mu); ready = prog->done[c * nsel + si] != 0; }
         // what is ready crosses while this thread waits — once it is worth a copy: a task with one scan thread gets its chunks one by one, and a
         // hipMemcpyAsync per 0.7 MB chunk cost each of eight concurrent tasks 120 µs a call (profiles/r4_executor_hip_api.txt)
-        if (!ready && pend_hi - pend_lo >= ((size_t)2 << 20)) { flush_pieces(); upload_flush(); }
+        if (!ready && pending_piece_bytes() >= ((size_t)2 << 20)) { flush_pieces(); upload_flush(); }
       }
       const double t_wait = trace ? ms_since() : 0;
       wait_for(c * nsel + si);
@@ -2171,7 +2248,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       // only the bytes the chunk actually staged cross PCIe
       if (hc.spos) push_piece(slot_off[c][si], slot_off[c][si] + std::min((hc.spos + 16 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]));
       if (hc.raw_hi > hc.raw_lo) {      // page bodies read in place: from where pread() put them (+ the few bytes behind the last one the kernels' vector loads touch)
-        const size_t lo = hc.raw_lo & ~(size_t)15, hi = std::min((hc.raw_hi + 32 + 15) & ~(size_t)15, slot_off[c][si + 1] - slot_off[c][si]);
+        const size_t raw_end = raw_base[c] + raw_off[c][si + 1] - slot_off[c][si];      // slot-relative, like raw_lo / raw_hi
+        const size_t lo = hc.raw_lo & ~(size_t)15, hi = std::min((hc.raw_hi + 32 + 15) & ~(size_t)15, raw_end);
         push_piece(slot_off[c][si] + lo, slot_off[c][si] + hi);
       }
       // Pages the device decompresses: the pipeline is launched for a GROUP of chunks as soon as their slices are across, so it runs
@@ -2250,7 +2328,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         const HostChunk& hc = chunks[c * nsel + si];
         size_t need = 0;
         for (const HostChunk::Pending& pe : hc.pending) need += ((pe.end - pe.begin) + 15) & ~(size_t)15;
-        const size_t lo = (hc.spos + 63) & ~(size_t)63, hi = hc.raw_hi > hc.raw_lo ? (hc.raw_lo & ~(size_t)15) : slot_off[c][si + 1] - slot_off[c][si];
+        const size_t lo = (hc.spos + 63) & ~(size_t)63, hi = slot_off[c][si + 1] - slot_off[c][si];
         if (lo + need > hi) spill += need;
       }
       if (spill) d.readback->ensure(spill + 64);
@@ -2259,7 +2337,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         const HostChunk& hc = chunks[c * nsel + si];
         size_t need = 0;
         for (const HostChunk::Pending& pe : hc.pending) need += ((pe.end - pe.begin) + 15) & ~(size_t)15;
-        const size_t lo = (hc.spos + 63) & ~(size_t)63, hi = hc.raw_hi > hc.raw_lo ? (hc.raw_lo & ~(size_t)15) : slot_off[c][si + 1] - slot_off[c][si];
+        const size_t lo = (hc.spos + 63) & ~(size_t)63, hi = slot_off[c][si + 1] - slot_off[c][si];
         const bool in_slot = lo + need <= hi;
         uint8_t* to = in_slot ? (uint8_t*)col_staged[c]->p + slot_off[c][si] + lo : (uint8_t*)d.readback->p + at;
         if (!in_slot) at += need;
