@@ -2283,7 +2283,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       // judged by the blocks per chunk seen so far)
       zstd_chunks_in_group += hc.zinflate.empty() ? 0 : 1;
       const size_t zleft_est = zstd_chunks_in_group ? (nsel - 1 - si) * zgroup_blocks.size() / zstd_chunks_in_group : 0;
-      const bool zfull = zgroup_blocks.size() >= 2800 && zgroup_blocks.size() + zleft_est > 4096;
+      static const size_t kZGroupBlocks = getenv("COMET_PQ_ZGROUP_BLOCKS") ? (size_t)std::max(64, atoi(getenv("COMET_PQ_ZGROUP_BLOCKS"))) : 2800;
+      const bool zfull = zgroup_blocks.size() >= kZGroupBlocks && zgroup_blocks.size() + zleft_est > (kZGroupBlocks == 2800 ? (size_t)4096 : kZGroupBlocks * 3 / 2);
       const bool group_full = (!group_jobs.empty() || !zgroup_jobs.empty()) && ((zgroup_jobs.empty() ? group_bytes >= ((size_t)48 << 20) : zfull) || si + 1 == nsel);
       if (group_full || si + 1 == nsel) flush_pieces();
       if (!next_ready || group_full) upload_flush();

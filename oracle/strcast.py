@@ -1,0 +1,405 @@
+"""CPU restatement of the reference's string <-> value casts.  TEST INFRASTRUCTURE ONLY: imported by tests/, smoke() and bench.py's
+cpu_baseline leg as the checker, never by the product path.
+
+Each function follows the reference function it cites (paths relative to /root/reference/native/spark-expr/src/conversion_funcs) and is
+pinned on that file's own unit-test vectors (tests/golden/reference_kats.json "string_casts", tests/test_string_casts_cpu.py).  Strings are
+handled as UTF-8 bytes, as the reference does.
+
+A parser returns (value, error): value None = SQL NULL; error is None or the Spark error class the reference raises in that eval mode.
+"""
+from typing import Optional, Tuple
+
+LEGACY, ANSI, TRY = "legacy", "ansi", "try"
+
+CAST_INVALID = "CAST_INVALID_INPUT"
+NUMERIC_OUT_OF_RANGE = "NUMERIC_VALUE_OUT_OF_RANGE"
+
+
+# --------------------------------------------------------------------------- trimming (trim.rs:41-128)
+
+def trim_all_range(b: bytes) -> Tuple[int, int]:
+    """UTF8String.trimAll: bytes <= 0x20 and 0x7F off both ends (trim.rs:47-49, 108-128)."""
+    s, e = 0, len(b)
+    while s < e and (b[s] <= 0x20 or b[s] == 0x7F):
+        s += 1
+    while e > s and (b[e - 1] <= 0x20 or b[e - 1] == 0x7F):
+        e -= 1
+    return s, e
+
+
+def trim_all(b: bytes) -> bytes:
+    s, e = trim_all_range(b)
+    return b[s:e]
+
+
+def trim_java_string(b: bytes) -> bytes:
+    """java.lang.String.trim: bytes <= 0x20 (trim.rs:58-61, 92-96)."""
+    s, e = 0, len(b)
+    while s < e and b[s] <= 0x20:
+        s += 1
+    while e > s and b[e - 1] <= 0x20:
+        e -= 1
+    return b[s:e]
+
+
+# --------------------------------------------------------------------------- string -> boolean (string.rs:260-312)
+
+def string_to_bool(b: bytes, mode: str):
+    t = trim_all(b).lower()        # bytes.lower() folds ASCII only, like eq_ignore_ascii_case
+    if t in (b"t", b"true", b"y", b"yes", b"1"):
+        return True, None
+    if t in (b"f", b"false", b"n", b"no", b"0"):
+        return False, None
+    return None, (CAST_INVALID if mode == ANSI else None)
+
+
+# --------------------------------------------------------------------------- string -> integers (string.rs:853-1115)
+
+def _parse_sign(b: bytes):
+    """string.rs:1107-1115: None for empty input; a lone sign stays part of the digits."""
+    if not b:
+        return None
+    if b[0:1] == b"-" and len(b) > 1:
+        return True, b[1:]
+    if b[0:1] == b"+" and len(b) > 1:
+        return False, b[1:]
+    return False, b
+
+
+def _to_int_generic(b: bytes, mode: str, bits: int):
+    """do_parse_string_to_int_{legacy,ansi,try} over i32 / i64 (string.rs:942-1060): the value is accumulated NEGATIVE, digit by digit, and every
+    step is checked against min / 10 and the subtraction — so what overflows is decided exactly as the reference decides it."""
+    err = CAST_INVALID if mode == ANSI else None
+    sg = _parse_sign(trim_all(b))
+    if sg is None:
+        return None, err
+    negative, digits = sg
+    lo = -(1 << (bits - 1))
+    # Rust integer division truncates toward zero: i32::MIN / 10 = -214748364
+    stop = -((-lo) // 10)
+    result = 0
+    i = 0
+    n = len(digits)
+    while i < n:
+        ch = digits[i]
+        i += 1
+        if ch == 0x2E:      # '.'
+            if mode != LEGACY:
+                return None, err
+            break
+        if not (0x30 <= ch <= 0x39):
+            return None, err
+        if result < stop:
+            return None, err
+        x = result * 10 - (ch - 0x30)
+        if x < lo or x > 0:       # checked_sub failed, or the value left the non-positive range
+            return None, err
+        result = x
+    else:
+        i = n
+    if mode == LEGACY:
+        for ch in digits[i:]:     # the fraction: digits only, values ignored
+            if not (0x30 <= ch <= 0x39):
+                return None, None
+    # finalize_int_result (string.rs:931-937)
+    if negative:
+        return result, None
+    if result == lo:              # checked_neg fails
+        return None, err
+    return -result, None
+
+
+def string_to_int(b: bytes, mode: str, bits: int):
+    """cast_string_to_int (string.rs:853-928): Int8 / Int16 parse as i32 and are then range-checked (string.rs:1063-1103)."""
+    if bits in (32, 64):
+        return _to_int_generic(b, mode, bits)
+    v, err = _to_int_generic(b, mode, 32)
+    if err:
+        return None, err
+    if v is not None and -(1 << (bits - 1)) <= v <= (1 << (bits - 1)) - 1:
+        return v, None
+    return None, (CAST_INVALID if mode == ANSI else None)
+
+
+# --------------------------------------------------------------------------- string -> decimal (string.rs:314-758)
+
+_I128_MAX = (1 << 127) - 1
+
+
+def _digits_to_i128(d: bytes) -> Optional[int]:
+    """string.rs:536-546: None when the value leaves i128."""
+    v = 0
+    for ch in d:
+        v = v * 10 + (ch - 0x30)
+        if v > _I128_MAX:
+            return None
+    return v
+
+
+def _normalize_fullwidth(b: bytes) -> bytes:
+    """string.rs:472-495: U+FF10..U+FF19 (EF BC 90..99) become ASCII digits."""
+    out = bytearray()
+    i = 0
+    while i < len(b):
+        if i + 2 < len(b) and b[i] == 0xEF and b[i + 1] == 0xBC and 0x90 <= b[i + 2] <= 0x99:
+            out.append(b[i + 2] - 0x60)
+            i += 3
+        else:
+            out.append(b[i])
+            i += 1
+    return bytes(out)
+
+
+def _rust_parse_i32(b: bytes) -> Optional[int]:
+    """str::parse::<i32>: optional sign, at least one ASCII digit, no overflow."""
+    if not b:
+        return None
+    neg = False
+    if b[0:1] in (b"+", b"-"):
+        neg = b[0:1] == b"-"
+        b = b[1:]
+    if not b or not all(0x30 <= c <= 0x39 for c in b):
+        return None
+    v = int(b)
+    v = -v if neg else v
+    return v if -(1 << 31) <= v <= (1 << 31) - 1 else None
+
+
+def string_to_decimal(b: bytes, precision: int, scale: int, mode: str):
+    """parse_string_to_decimal + cast_string_to_decimal128_impl (string.rs:335-396, 579-758).  ANSI raises both for the parser's errors and
+    for its Ok(None) (empty, inf / nan, a scale adjustment beyond 38: CAST_INVALID_INPUT); LEGACY / TRY give NULL (string.rs:352-372)."""
+    def fail(cls):
+        return None, (cls if mode == ANSI else None)
+    t = trim_java_string(b)
+    if any(c >= 0x80 for c in t):
+        t = _normalize_fullwidth(t)
+    if not t:
+        return fail(CAST_INVALID)
+    if t.lower() in (b"inf", b"+inf", b"-inf", b"infinity", b"+infinity", b"-infinity", b"nan"):
+        return fail(CAST_INVALID)
+    # parse_decimal_str (string.rs:676-758)
+    pos = 0
+    negative = False
+    if t[0:1] == b"-":
+        negative, pos = True, 1
+    elif t[0:1] == b"+":
+        pos = 1
+    start = pos
+    dot = exp = None
+    while pos < len(t):
+        ch = t[pos]
+        if 0x30 <= ch <= 0x39:
+            pos += 1
+        elif ch == 0x2E and dot is None:
+            dot = pos
+            pos += 1
+        elif ch in (0x65, 0x45):
+            exp = pos
+            break
+        else:
+            return fail(CAST_INVALID)
+    exponent = 0
+    if exp is not None:
+        exponent = _rust_parse_i32(t[exp + 1:])
+        if exponent is None:
+            return fail(CAST_INVALID)
+    mend = exp if exp is not None else pos
+    if dot is not None:
+        ip, fp = t[start:dot], t[dot + 1:mend]
+    else:
+        ip, fp = t[start:mend], b""
+    if not ip and not fp:
+        return fail(CAST_INVALID)
+    iv = _digits_to_i128(ip)
+    fv = _digits_to_i128(fp)
+    if iv is None or fv is None or len(fp) > 38:
+        return fail(CAST_INVALID)
+    mant = iv * 10 ** len(fp) + fv
+    if mant > _I128_MAX:
+        return fail(CAST_INVALID)
+    if negative:
+        mant = -mant
+    final_scale = len(fp) - exponent
+    # parse_string_to_decimal (string.rs:606-663)
+    if mant == 0:
+        if final_scale < -37:
+            return fail(NUMERIC_OUT_OF_RANGE)
+        return 0, None
+    adj = scale - final_scale
+    if adj >= 0:
+        if adj > 38:
+            return fail(CAST_INVALID)
+        v = mant * 10 ** adj
+        if abs(v) > _I128_MAX and v != -(1 << 127):
+            return fail(NUMERIC_OUT_OF_RANGE)
+    else:
+        if -adj > 38:
+            return 0, None
+        d = 10 ** (-adj)
+        q = abs(mant) // d
+        r = abs(mant) % d
+        if r >= d // 2:
+            q += 1
+        v = -q if mant < 0 else q
+    if abs(v) >= 10 ** precision:           # is_validate_decimal_precision
+        return fail(NUMERIC_OUT_OF_RANGE)
+    return v, None
+
+
+# --------------------------------------------------------------------------- string -> date (string.rs:1221-1247, 1896-2046)
+
+def days_from_civil(y: int, m: int, d: int) -> int:
+    """string.rs:1221-1228."""
+    if m <= 2:
+        y, m = y - 1, m + 9
+    else:
+        m -= 3
+    era = y // 400
+    yoe = y - era * 400
+    doy = (153 * m + 2) // 5 + d - 1
+    doe = yoe * 365 + yoe // 4 - yoe // 100 + doy
+    return era * 146097 + doe - 719468
+
+
+def _ymd_to_epoch_day(y: int, m: int, d: int) -> Optional[int]:
+    dim = [31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31]
+    if not 1 <= m <= 12:
+        return None
+    mx = dim[m - 1]
+    if m == 2 and y % 4 == 0 and (y % 100 != 0 or y % 400 == 0):
+        mx = 29
+    if d < 1 or d > mx:
+        return None
+    return days_from_civil(y, m, d)
+
+
+def _wrap_i32(v: int) -> int:
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v >> 31 else v
+
+
+def string_to_date(b: bytes, mode: str):
+    """date_parser (string.rs:1896-2046)."""
+    err = "CAST_INVALID_INPUT" if mode == ANSI else None
+
+    def resolve(y, m, d):
+        days = _ymd_to_epoch_day(y, m, d)
+        if days is None or not -(1 << 31) <= days <= (1 << 31) - 1:
+            return None, err
+        if not -262143 <= y <= 262142:
+            return None, None          # the reference's chrono limit: NULL in every mode
+        return days, None
+    if not b:
+        return None, err
+    j, end = trim_all_range(b)
+    if j == end:
+        return None, err
+    t = b[j:end]
+    if len(t) == 10 and t[4] == 0x2D and t[7] == 0x2D and all(0x30 <= c <= 0x39 for c in t[0:4] + t[5:7] + t[8:10]):
+        return resolve(int(t[0:4]), int(t[5:7]), int(t[8:10]))
+    seg = [1, 1, 1]
+    sign = 1
+    cur = 0
+    val = 0
+    digits = 0
+    if b[j] == 0x2D:
+        sign = -1
+        j += 1
+    elif b[j] == 0x2B:
+        j += 1
+
+    def valid_digits(s, n):
+        return (s == 0 and 4 <= n <= 7) or (s != 0 and 0 < n <= 2)
+    while j < end and cur < 3 and not (b[j] == 0x20 or b[j] == 0x54):
+        ch = b[j]
+        if cur < 2 and ch == 0x2D:
+            if not valid_digits(cur, digits):
+                return None, err
+            seg[cur] = val
+            val = 0
+            digits = 0
+            cur += 1
+        elif not (0x30 <= ch <= 0x39):
+            return None, err
+        else:
+            val = _wrap_i32(val * 10 + (ch - 0x30))
+            digits += 1
+        j += 1
+    if not valid_digits(cur, digits):
+        return None, err
+    if cur < 2 and j < end:
+        return None, err
+    seg[cur] = val
+    return resolve(_wrap_i32(sign * seg[0]), seg[1], seg[2])
+
+
+# --------------------------------------------------------------------------- values -> string
+
+def int_to_string(v: int) -> str:
+    """arrow-cast's integer formatting (the reference defers to DataFusion for Int -> Utf8, numeric.rs:35-47): plain decimal digits."""
+    return str(int(v))
+
+
+def bool_to_string(v: bool) -> str:
+    """arrow-cast boolean -> Utf8 (boolean.rs:25-31): "true" / "false"."""
+    return "true" if v else "false"
+
+
+def decimal_to_string(unscaled: int, scale: int, mode: str) -> str:
+    """LEGACY: decimal128_to_java_string (numeric.rs:660-704) = java.math.BigDecimal.toString; ANSI / TRY: arrow-cast's plain notation
+    (numeric.rs:76-80)."""
+    coeff = str(abs(unscaled))
+    n = len(coeff)
+    sign = "-" if unscaled < 0 else ""
+    adj = -scale + (n - 1)
+    plain = mode != LEGACY or (scale >= 0 and adj >= -6)
+    if plain:
+        if scale <= 0:
+            return sign + coeff + "0" * (-scale) if mode != LEGACY else sign + coeff
+        if n > scale:
+            return sign + coeff[:n - scale] + "." + coeff[n - scale:]
+        return sign + "0." + "0" * (scale - n) + coeff
+    out = sign + (coeff[0] + "." + coeff[1:] if n > 1 else coeff) + "E"
+    if adj > 0:
+        out += "+"
+    return out + str(adj)
+
+
+def civil_from_days(z: int):
+    """Inverse of days_from_civil (the proleptic Gregorian calendar chrono uses)."""
+    z += 719468
+    era = z // 146097
+    doe = z - era * 146097
+    yoe = (doe - doe // 1460 + doe // 36524 - doe // 146096) // 365
+    y = yoe + era * 400
+    doy = doe - (365 * yoe + yoe // 4 - yoe // 100)
+    mp = (5 * doy + 2) // 153
+    d = doy - (153 * mp + 2) // 5 + 1
+    m = mp + 3 if mp < 10 else mp - 9
+    return (y + 1 if m <= 2 else y), m, d
+
+
+def _chrono_year(y: int) -> str:
+    """chrono's %Y: four digits for 0..=9999, otherwise a sign and at least four digits."""
+    if 0 <= y <= 9999:
+        return "%04d" % y
+    return ("+" if y > 0 else "-") + "%04d" % abs(y)
+
+
+def date_to_string(days: int) -> str:
+    """arrow-cast Date32 -> Utf8 (temporal.rs:26-28): chrono's "%Y-%m-%d"."""
+    y, m, d = civil_from_days(int(days))
+    return "%s-%02d-%02d" % (_chrono_year(y), m, d)
+
+
+def timestamp_to_string(micros: int, offset_seconds: int = 0) -> str:
+    """arrow-cast Timestamp(µs) -> Utf8 with "%Y-%m-%d %H:%M:%S%.f" (cast.rs:71) in a fixed-offset zone, then the trailing zeroes of the
+    fraction removed (utils.rs:88-113)."""
+    local = int(micros) + offset_seconds * 1_000_000
+    days, rem = divmod(local, 86_400_000_000)
+    secs, us = divmod(rem, 1_000_000)
+    y, m, d = civil_from_days(days)
+    s = "%s-%02d-%02d %02d:%02d:%02d" % (_chrono_year(y), m, d, secs // 3600, secs // 60 % 60, secs % 60)
+    if us:
+        s += (".%06d" % us).rstrip("0")
+    return s
