@@ -185,6 +185,364 @@ CDEV strview utf8_view_pad(const CometCol& c, i64 i, i32 target, bool truncate) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// String casts (spark-expr/src/conversion_funcs/string.rs, trim.rs, numeric.rs).  Plain byte and integer arithmetic over one value's
+// bytes: this section is also compiled for the host (tests/test_string_casts_cpu.py, g++) and checked there against the reference's own
+// vectors and the oracle's restatement.  Parsers return 0 = a value, 1 = invalid input (NULL, or CAST_INVALID_INPUT under ANSI),
+// 2 = NULL in every eval mode, 3 = out of range (NULL, or NUMERIC_VALUE_OUT_OF_RANGE under ANSI).  mode: 0 LEGACY, 1 ANSI, 2 TRY.
+// ---- string casts: begin
+typedef const COMET_GLOBAL u8* strp;
+// UTF8String.trimAll: bytes ≤ 0x20 and 0x7F (trim.rs:47-49)
+CDEV void str_trim_all(strp p, i32& a, i32& b) {
+  while (a < b && (p[a] <= 0x20 || p[a] == 0x7F)) a++;
+  while (b > a && (p[b - 1] <= 0x20 || p[b - 1] == 0x7F)) b--;
+}
+// java.lang.String.trim: bytes ≤ 0x20 (trim.rs:58-61)
+CDEV void str_trim_java(strp p, i32& a, i32& b) {
+  while (a < b && p[a] <= 0x20) a++;
+  while (b > a && p[b - 1] <= 0x20) b--;
+}
+// p[a, b) equals the lower-case ASCII word w, ignoring ASCII case
+CDEV bool str_is_word(strp p, i32 a, i32 b, const char* w, i32 wn) {
+  if (b - a != wn) return false;
+  for (i32 k = 0; k < wn; k++) {
+    u8 ch = p[a + k];
+    if (ch >= 'A' && ch <= 'Z') ch = (u8)(ch + 32);
+    if (ch != (u8)w[k]) return false;
+  }
+  return true;
+}
+// spark_cast_utf8_to_boolean (string.rs:260-312)
+CDEV int str_to_bool(strp p, i32 n, bool& out) {
+  i32 a = 0, b = n;
+  str_trim_all(p, a, b);
+  if (str_is_word(p, a, b, "t", 1) || str_is_word(p, a, b, "true", 4) || str_is_word(p, a, b, "y", 1) || str_is_word(p, a, b, "yes", 3) || str_is_word(p, a, b, "1", 1)) { out = true; return 0; }
+  if (str_is_word(p, a, b, "f", 1) || str_is_word(p, a, b, "false", 5) || str_is_word(p, a, b, "n", 1) || str_is_word(p, a, b, "no", 2) || str_is_word(p, a, b, "0", 1)) { out = false; return 0; }
+  return 1;
+}
+// do_parse_string_to_int_{legacy,ansi,try} (string.rs:942-1060): accumulated NEGATIVE with the reference's own overflow tests; Int8 / Int16
+// parse as i32 and are range-checked afterwards (string.rs:1063-1103)
+CDEV int str_to_int(strp p, i32 n, int mode, int bits, i64& out) {
+  i32 a = 0, b = n;
+  str_trim_all(p, a, b);
+  if (a == b) return 1;
+  bool neg = false;
+  if ((p[a] == '-' || p[a] == '+') && b - a > 1) { neg = p[a] == '-'; a++; }
+  const i64 lo = bits == 64 ? (i64)0x8000000000000000ull : -(i64)2147483648ll;
+  const i64 stop = lo / 10;                 // truncates toward zero, like Rust
+  i64 r = 0;
+  i32 i = a;
+  for (; i < b; i++) {
+    const u8 ch = p[i];
+    if (ch == '.') {
+      if (mode != 0) return 1;
+      i++;
+      break;
+    }
+    if (ch < '0' || ch > '9') return 1;
+    if (r < stop) return 1;
+    const i64 v = r * 10, d = (i64)(ch - '0');
+    if (v < lo + d) return 1;               // checked_sub
+    r = v - d;
+  }
+  for (; i < b; i++)                        // LEGACY: the fraction is validated and ignored
+    if (p[i] < '0' || p[i] > '9') return 1;
+  if (!neg) {
+    if (r == lo) return 1;                  // checked_neg
+    r = -r;
+  }
+  if (bits == 8 && (r < -128 || r > 127)) return 1;
+  if (bits == 16 && (r < -32768 || r > 32767)) return 1;
+  out = r;
+  return 0;
+}
+CDEV u128 str_pow10(int e) {
+  u128 v = 1;
+  for (int k = 0; k < e; k++) v *= 10;
+  return v;
+}
+// One byte of the value with fullwidth digits (U+FF10..U+FF19 = EF BC 90..99) read as ASCII digits (normalize_fullwidth_digits, string.rs:472-495)
+CDEV u8 str_norm_next(strp p, i32& i, i32 b) {
+  if (p[i] == 0xEF && i + 2 < b && p[i + 1] == 0xBC && p[i + 2] >= 0x90 && p[i + 2] <= 0x99) {
+    const u8 d = (u8)(p[i + 2] - 0x60);
+    i += 3;
+    return d;
+  }
+  return p[i++];
+}
+// the normalized value equals the lower-case ASCII word w, ignoring ASCII case
+CDEV bool str_norm_is_word(strp p, i32 a, i32 b, const char* w, i32 wn) {
+  i32 i = a, k = 0;
+  while (i < b) {
+    u8 ch = str_norm_next(p, i, b);
+    if (ch >= 'A' && ch <= 'Z') ch = (u8)(ch + 32);
+    if (k >= wn || ch != (u8)w[k]) return false;
+    k++;
+  }
+  return k == wn;
+}
+// parse_string_to_decimal + parse_decimal_str (string.rs:579-758) into an unscaled value at (precision, scale)
+CDEV int str_to_decimal(strp p, i32 n, int precision, int scale, i128& out) {
+  const u128 i128_max = ((u128)1 << 127) - 1;
+  i32 a = 0, b = n;
+  str_trim_java(p, a, b);
+  if (a == b) return 1;
+  {
+    // inf / nan spellings (string.rs:549-576)
+    const u8 f = p[a] | 0x20, g = (a + 1 < b) ? (u8)(p[a + 1] | 0x20) : 0;
+    if (f == 'i' || f == 'n' || ((p[a] == '+' || p[a] == '-') && g == 'i')) {
+      if (str_norm_is_word(p, a, b, "inf", 3) || str_norm_is_word(p, a, b, "+inf", 4) || str_norm_is_word(p, a, b, "-inf", 4) || str_norm_is_word(p, a, b, "infinity", 8) ||
+          str_norm_is_word(p, a, b, "+infinity", 9) || str_norm_is_word(p, a, b, "-infinity", 9) || str_norm_is_word(p, a, b, "nan", 3))
+        return 1;
+    }
+  }
+  i32 i = a;
+  bool neg = false;
+  if (p[i] == '-') { neg = true; i++; }
+  else if (p[i] == '+') i++;
+  u128 ip = 0, fp = 0;
+  i32 nint = 0, nfrac = 0;
+  bool dot = false, has_exp = false;
+  while (i < b) {
+    i32 j = i;
+    const u8 ch = str_norm_next(p, j, b);
+    if (ch >= '0' && ch <= '9') {
+      u128& acc = dot ? fp : ip;
+      if (acc > (i128_max - (u128)(ch - '0')) / 10) return 1;        // digits_to_i128 leaves i128
+      acc = acc * 10 + (u128)(ch - '0');
+      if (dot) nfrac++; else nint++;
+    } else if (ch == '.' && !dot) {
+      dot = true;
+    } else if (ch == 'e' || ch == 'E') {
+      has_exp = true;
+      i = j;
+      break;
+    } else {
+      return 1;
+    }
+    i = j;
+  }
+  i64 exponent = 0;
+  if (has_exp) {
+    // str::parse::<i32>: an optional sign, at least one digit, no overflow
+    bool eneg = false;
+    if (i < b && (p[i] == '+' || p[i] == '-')) { eneg = p[i] == '-'; i++; }   // (the sign is ASCII: fullwidth forms are digits only)
+    if (i >= b) return 1;
+    i64 ev = 0;
+    while (i < b) {
+      const u8 ch = str_norm_next(p, i, b);
+      if (ch < '0' || ch > '9') return 1;
+      ev = ev * 10 + (i64)(ch - '0');
+      if (ev > ((i64)1 << 40)) ev = (i64)1 << 40;
+    }
+    exponent = eneg ? -ev : ev;
+    if (exponent > 2147483647ll || exponent < -2147483648ll) return 1;
+  }
+  if (nint == 0 && nfrac == 0) return 1;
+  if (nfrac > 38) return 1;
+  const u128 pf = str_pow10(nfrac);
+  if (ip != 0 && ip > i128_max / pf) return 1;
+  u128 mant = ip * pf;
+  if (mant > i128_max - fp) return 1;
+  mant += fp;
+  const i64 final_scale = (i64)nfrac - exponent;
+  if (mant == 0) {
+    if (final_scale < -37) return 3;
+    out = 0;
+    return 0;
+  }
+  const i64 adj = (i64)scale - final_scale;
+  u128 mag;
+  if (adj >= 0) {
+    if (adj > 38) return 1;
+    const u128 m = str_pow10((int)adj);
+    // i128 checked_mul: −2^127 is representable
+    const u128 lim = neg ? ((u128)1 << 127) : i128_max;
+    if (mant > lim / m) return 3;
+    mag = mant * m;
+  } else {
+    if (-adj > 38) { out = 0; return 0; }
+    const u128 d = str_pow10((int)-adj);
+    mag = mant / d;
+    if (mant % d >= d / 2) mag++;           // HALF_UP (string.rs:520-530)
+  }
+  if (mag >= str_pow10(precision)) return 3;
+  out = neg ? -(i128)mag : (i128)mag;
+  return 0;
+}
+// days_from_civil (string.rs:1221-1228)
+CDEV i64 str_days_from_civil(i64 y, i64 m, i64 d) {
+  if (m <= 2) { y -= 1; m += 9; } else m -= 3;
+  const i64 era = (y >= 0 ? y : y - 399) / 400;
+  const i64 yoe = y - era * 400;
+  const i64 doy = (153 * m + 2) / 5 + d - 1;
+  const i64 doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  return era * 146097 + doe - 719468;
+}
+// resolve_epoch_day (string.rs:1929-1955)
+CDEV int str_resolve_date(i64 y, i64 m, i64 d, i32& out) {
+  if (m < 1 || m > 12) return 1;
+  const bool leap = y % 4 == 0 && (y % 100 != 0 || y % 400 == 0);
+  const i64 mx = m == 2 ? (leap ? 29 : 28) : (m == 4 || m == 6 || m == 9 || m == 11) ? 30 : 31;
+  if (d < 1 || d > mx) return 1;
+  const i64 days = str_days_from_civil(y, m, d);
+  if (days < -2147483648ll || days > 2147483647ll) return 1;
+  if (y < -262143 || y > 262142) return 2;     // beyond chrono's years: NULL in every mode
+  out = (i32)days;
+  return 0;
+}
+// date_parser (string.rs:1896-2046)
+CDEV int str_to_date(strp p, i32 n, i32& out) {
+  if (n == 0) return 1;
+  i32 j = 0, end = n;
+  str_trim_all(p, j, end);
+  if (j == end) return 1;
+  auto dig = [&](i32 k) { return p[k] >= '0' && p[k] <= '9'; };
+  if (end - j == 10 && p[j + 4] == '-' && p[j + 7] == '-' && dig(j) && dig(j + 1) && dig(j + 2) && dig(j + 3) && dig(j + 5) && dig(j + 6) && dig(j + 8) && dig(j + 9)) {
+    const i64 y = (p[j] - '0') * 1000 + (p[j + 1] - '0') * 100 + (p[j + 2] - '0') * 10 + (p[j + 3] - '0');
+    return str_resolve_date(y, (p[j + 5] - '0') * 10 + (p[j + 6] - '0'), (p[j + 8] - '0') * 10 + (p[j + 9] - '0'), out);
+  }
+  i32 seg[3] = {1, 1, 1};
+  i32 sign = 1, cur = 0, digits = 0;
+  u32 val = 0;                                 // Wrapping<i32>
+  if (p[j] == '-') { sign = -1; j++; }
+  else if (p[j] == '+') j++;
+  auto valid_digits = [](i32 s, i32 nd) { return (s == 0 && nd >= 4 && nd <= 7) || (s != 0 && nd > 0 && nd <= 2); };
+  while (j < end && cur < 3 && !(p[j] == ' ' || p[j] == 'T')) {
+    const u8 ch = p[j];
+    if (cur < 2 && ch == '-') {
+      if (!valid_digits(cur, digits)) return 1;
+      seg[cur] = (i32)val;
+      val = 0;
+      digits = 0;
+      cur++;
+    } else if (ch < '0' || ch > '9') {
+      return 1;
+    } else {
+      val = val * 10u + (u32)(ch - '0');
+      digits++;
+    }
+    j++;
+  }
+  if (!valid_digits(cur, digits)) return 1;
+  if (cur < 2 && j < end) return 1;
+  seg[cur] = (i32)val;
+  return str_resolve_date((i64)(i32)((u32)sign * (u32)seg[0]), seg[1], seg[2], out);
+}
+
+// ---- values to strings: each writes at most 48 bytes to `o` and returns the byte count
+CDEV i32 fmt_u128_digits(u128 v, u8* o) {         // decimal digits, no sign
+  u8 tmp[40];
+  i32 k = 0;
+  while (v > (u128)0xFFFFFFFFFFFFFFFFull) { tmp[k++] = (u8)('0' + (int)(v % 10)); v /= 10; }
+  u64 w = (u64)v;
+  do { tmp[k++] = (u8)('0' + (int)(w % 10)); w /= 10; } while (w);
+  for (i32 q = 0; q < k; q++) o[q] = tmp[k - 1 - q];
+  return k;
+}
+// arrow-cast integer → Utf8 (numeric.rs:35-47)
+CDEV i32 fmt_i64(i64 v, u8* o) {
+  i32 k = 0;
+  u64 m = (u64)v;
+  if (v < 0) { o[k++] = '-'; m = 0ull - m; }
+  return k + fmt_u128_digits((u128)m, o + k);
+}
+// arrow-cast boolean → Utf8
+CDEV i32 fmt_bool(bool v, u8* o) {
+  const char* s = v ? "true" : "false";
+  const i32 n = v ? 4 : 5;
+  for (i32 k = 0; k < n; k++) o[k] = (u8)s[k];
+  return n;
+}
+// Decimal128 → Utf8.  java_string: decimal128_to_java_string (numeric.rs:660-704, BigDecimal.toString, LEGACY); else arrow-cast's plain notation
+CDEV i32 fmt_decimal(i128 v, int scale, bool java_string, u8* o) {
+  u8 dg[40];
+  const u128 mag = v < 0 ? (u128)0 - (u128)v : (u128)v;
+  const i32 nd = fmt_u128_digits(mag, dg);
+  const i64 adj = -(i64)scale + (nd - 1);
+  i32 k = 0;
+  if (v < 0) o[k++] = '-';
+  if (!java_string || (scale >= 0 && adj >= -6)) {
+    if (scale <= 0) {
+      for (i32 q = 0; q < nd; q++) o[k++] = dg[q];
+      if (!java_string) for (i32 q = 0; q < -scale && k < 48; q++) o[k++] = '0';
+    } else if (nd > scale) {
+      for (i32 q = 0; q < nd - scale; q++) o[k++] = dg[q];
+      o[k++] = '.';
+      for (i32 q = nd - scale; q < nd; q++) o[k++] = dg[q];
+    } else {
+      o[k++] = '0';
+      o[k++] = '.';
+      for (i32 q = 0; q < scale - nd; q++) o[k++] = '0';
+      for (i32 q = 0; q < nd; q++) o[k++] = dg[q];
+    }
+    return k;
+  }
+  o[k++] = dg[0];
+  if (nd > 1) {
+    o[k++] = '.';
+    for (i32 q = 1; q < nd; q++) o[k++] = dg[q];
+  }
+  o[k++] = 'E';
+  if (adj > 0) o[k++] = '+';
+  return k + fmt_i64(adj, o + k);
+}
+// civil date of an epoch day (the proleptic Gregorian calendar chrono uses)
+CDEV void fmt_civil(i64 z, i64& y, i32& m, i32& d) {
+  z += 719468;
+  const i64 era = (z >= 0 ? z : z - 146096) / 146097;
+  const i64 doe = z - era * 146097;
+  const i64 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const i64 doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const i64 mp = (5 * doy + 2) / 153;
+  d = (i32)(doy - (153 * mp + 2) / 5 + 1);
+  m = (i32)(mp < 10 ? mp + 3 : mp - 9);
+  y = yoe + era * 400 + (m <= 2 ? 1 : 0);
+}
+CDEV i32 fmt_2(i32 v, u8* o) { o[0] = (u8)('0' + v / 10); o[1] = (u8)('0' + v % 10); return 2; }
+// chrono's "%Y-%m-%d": four digits for years 0..9999, otherwise a sign and at least four digits
+CDEV i32 fmt_date(i64 days, u8* o) {
+  i64 y; i32 m, d;
+  fmt_civil(days, y, m, d);
+  i32 k = 0;
+  if (y < 0 || y > 9999) o[k++] = y < 0 ? '-' : '+';
+  const u64 ay = (u64)(y < 0 ? -y : y);
+  u8 dg[24];
+  const i32 nd = fmt_u128_digits((u128)ay, dg);
+  for (i32 q = nd; q < 4; q++) o[k++] = '0';
+  for (i32 q = 0; q < nd; q++) o[k++] = dg[q];
+  o[k++] = '-';
+  k += fmt_2(m, o + k);
+  o[k++] = '-';
+  k += fmt_2(d, o + k);
+  return k;
+}
+// Timestamp(µs) → Utf8 in a fixed-offset zone: "%Y-%m-%d %H:%M:%S%.f" (cast.rs:71) with the fraction's trailing zeroes removed (utils.rs:88-113)
+CDEV i32 fmt_timestamp(i64 micros, i64 offset_seconds, u8* o) {
+  const i128 local = (i128)micros + (i128)offset_seconds * 1000000;
+  const i128 day_us = (i128)86400 * 1000000;
+  i128 days = local / day_us, rem = local % day_us;
+  if (rem < 0) { rem += day_us; days -= 1; }
+  const i64 secs = (i64)(rem / 1000000);
+  i32 us = (i32)(rem % 1000000);
+  i32 k = fmt_date((i64)days, o);
+  o[k++] = ' ';
+  k += fmt_2((i32)(secs / 3600), o + k);
+  o[k++] = ':';
+  k += fmt_2((i32)(secs / 60 % 60), o + k);
+  o[k++] = ':';
+  k += fmt_2((i32)(secs % 60), o + k);
+  if (us) {
+    o[k++] = '.';
+    i32 nd = 6;
+    while (us % 10 == 0) { us /= 10; nd--; }
+    for (i32 q = nd - 1; q >= 0; q--) { o[k + q] = (u8)('0' + us % 10); us /= 10; }
+    k += nd;
+  }
+  return k;
+}
+// ---- string casts: end
+
+// ---------------------------------------------------------------------------------------------
 // Scalar functions (ScalarFunc, expr.proto:466-471): the exact, integer/IEEE-defined subset.
 // ---------------------------------------------------------------------------------------------
 // Rust `x as i64`: saturating, NaN → 0 (spark_ceil / spark_floor: math_funcs/ceil.rs:31-40, floor.rs)
