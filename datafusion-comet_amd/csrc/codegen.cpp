@@ -832,6 +832,55 @@ struct Gen {
     throw CometError("Cast from " + from.str() + " to " + to.str() + " is not supported in the GPU pipeline yet");
   }
 
+  // Cast of a Utf8 COLUMN to boolean / integers / decimal / date (conversion_funcs/string.rs:260-312, 853-1115, 314-758, 1896-2046): parsed from
+  // the column's bytes in place (device/comet_device.hpp "String casts"; the same text is checked on the host against the reference's vectors).
+  // Invalid input is NULL in LEGACY / TRY and an error under ANSI; floats and timestamps are not there yet.
+  Val cast_from_string(const Expr& e, int idx) {
+    const DType& to = e.dtype;
+    const int mode = e.eval_mode == EvalMode::Legacy ? 0 : e.eval_mode == EvalMode::Ansi ? 1 : 2;
+    std::string call, outtype;
+    int err_bit = 9;          // CAST_INVALID_INPUT
+    Val r;
+    r.t = to;
+    r.rep = rep_for_type(to);
+    switch (to.id) {
+      case TypeId::Bool: outtype = "bool"; call = "comet::str_to_bool(sp, sn, @)"; break;
+      case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Int64:
+        outtype = "i64";
+        call = "comet::str_to_int(sp, sn, " + std::to_string(mode) + ", " + std::to_string(type_width(to) * 8) + ", @)";
+        r.maxabs = type_maxabs(to);
+        break;
+      case TypeId::Decimal:
+        outtype = "i128";
+        call = "comet::str_to_decimal(sp, sn, " + std::to_string(to.precision) + ", " + std::to_string(to.scale) + ", @)";
+        r.maxabs = type_maxabs(to);
+        break;
+      case TypeId::Date: outtype = "i32"; call = "comet::str_to_date(sp, sn, @)"; r.maxabs = type_maxabs(to); err_bit = 10; break;
+      default: throw CometError("Cast from string to " + to.str() + " is not supported in the GPU pipeline yet");
+    }
+    Val valid = str_col_validity(idx);
+    auto loc = locate(idx);
+    std::string out = newvar(outtype.c_str()), rc = newvar("int");
+    call.replace(call.find('@'), 1, out);
+    stmt(out + " = 0; " + rc + " = 2; " + (valid.ok.empty() ? "" : "if (" + valid.ok + ") ") + "{ i32 sn; comet::strp sp = comet::utf8_bytes(prm.in[" + std::to_string(loc.first) + "], " +
+         loc.second + ", sn); " + rc + " = " + call + "; }");
+    if (e.eval_mode == EvalMode::Ansi) {
+      raise_if("(" + rc + " == 1)", err_bit);
+      if (to.id == TypeId::Decimal) raise_if("(" + rc + " == 3)", 3);
+    }
+    std::string o = newvar("bool");
+    stmt(o + " = " + rc + " == 0;");
+    r.ok = o;
+    switch (to.id) {
+      case TypeId::Bool: r.v = out; break;
+      case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: r.v = "(i32)" + out; break;
+      case TypeId::Int64: r.v = out; break;
+      case TypeId::Decimal: r.v = r.rep == Rep::I64 ? "(i64)" + out : out; break;
+      default: r.v = out; break;
+    }
+    return r;
+  }
+
   // rescale_and_check (decimal_rescale_check.rs:108-150)
   Val rescale(Val c, int s_in, int p_out, int s_out, bool fail_on_error) {
     Val r;
@@ -937,6 +986,58 @@ struct Gen {
     out.v = v;
     out.ok = valid.ok;
     oc.view_src = idx;
+    return true;
+  }
+
+  // "UTC" / "Z" / "GMT" / "Etc/UTC" / "+HH:MM" / "-HH[:MM[:SS]]" → seconds east of UTC; false for region names (they need the zone's transitions)
+  static bool fixed_zone_offset(const std::string& tz, long long& secs) {
+    if (tz.empty() || tz == "UTC" || tz == "Z" || tz == "GMT" || tz == "Etc/UTC" || tz == "Etc/GMT" || tz == "UCT" || tz == "Etc/UCT") { secs = 0; return true; }
+    std::string s = tz;
+    if (s.rfind("UTC", 0) == 0 || s.rfind("GMT", 0) == 0) s = s.substr(3);
+    if (s.size() < 2 || (s[0] != '+' && s[0] != '-')) return false;
+    int part[3] = {0, 0, 0}, np = 0, nd = 0;
+    for (size_t i = 1; i < s.size(); i++) {
+      if (s[i] == ':') { if (nd == 0 || ++np > 2) return false; nd = 0; continue; }
+      if (s[i] < '0' || s[i] > '9' || ++nd > 2) return false;
+      part[np] = part[np] * 10 + (s[i] - '0');
+    }
+    if (nd == 0 || part[0] > 18 || part[1] > 59 || part[2] > 59) return false;
+    secs = (long long)part[0] * 3600 + part[1] * 60 + part[2];
+    if (s[0] == '-') secs = -secs;
+    return true;
+  }
+
+  // Output-only Cast(value AS STRING) (conversion_funcs/cast.rs:423-449: the reference defers integers, booleans, dates and timestamps to
+  // arrow-cast's formatting and writes LEGACY decimals like java.math.BigDecimal.toString, numeric.rs:593-704).  Returns false when `e` is
+  // not of that shape; floats (Java's shortest-digits algorithm) are not there yet.
+  bool string_format(const Expr& e, Val& out, OutCol& oc) {
+    if (e.kind != ExprKind::Cast || e.dtype.id != TypeId::String || e.children.size() != 1) return false;
+    const ExprP& c = e.children[0];
+    if (is_str_col(c)) return false;
+    // the child's type decides; only expressions whose type is known without generating them twice: generate, then look
+    Val v = gen(c);
+    switch (v.t.id) {
+      case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Int64: oc.fmt_kind = OutCol::FmtInt; break;
+      case TypeId::Bool: oc.fmt_kind = OutCol::FmtBool; break;
+      case TypeId::Decimal:
+        oc.fmt_kind = e.eval_mode == EvalMode::Legacy ? OutCol::FmtDecimalJava : OutCol::FmtDecimal;
+        oc.fmt_arg = v.t.scale;
+        break;
+      case TypeId::Date: oc.fmt_kind = OutCol::FmtDate; break;
+      case TypeId::Timestamp: case TypeId::TimestampNtz: {
+        long long secs = 0;
+        if (v.t.id == TypeId::Timestamp && !fixed_zone_offset(e.func, secs))
+          throw CometError("Cast from timestamp to string in time zone '" + e.func + "' is not supported by the MI355X native engine yet (UTC and fixed offsets are)");
+        oc.fmt_kind = OutCol::FmtTimestamp;
+        oc.fmt_arg = secs;
+        break;
+      }
+      case TypeId::String: return false;      // (generated once more by the caller: the statements above are dead code the compiler drops)
+      default: throw CometError("Cast from " + v.t.str() + " to string is not supported in the GPU pipeline yet");
+    }
+    v = named(v);
+    out = v;
+    if (v.rep == Rep::B) out.v = "(" + v.v + " ? 1 : 0)";
     return true;
   }
 
@@ -1482,7 +1583,11 @@ struct Gen {
         x.is_cast_dec = false;
         return bound_check(x, e.dtype.precision, e.fail_on_error, 3);
       }
-      case ExprKind::Cast: return cast(e, gen(e.children.at(0)));
+      case ExprKind::Cast: {
+        const ExprP& c0 = e.children.at(0);
+        if (is_str_col(c0) && in_types[(size_t)c0->bound_index].id == TypeId::String && e.dtype.id != TypeId::String) return cast_from_string(e, c0->bound_index);
+        return cast(e, gen(c0));
+      }
       case ExprKind::UnaryMinus: {
         Val a = gen(e.children.at(0));
         Val r = a;
@@ -2048,6 +2153,19 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
           continue;
         }
       }
+      {
+        // Cast(<integer | boolean | decimal | date | timestamp> AS STRING): the value travels, the executor writes the digits
+        OutCol foc;
+        Val fv;
+        if (ge.string_format(*c, fv, foc)) {
+          outs.push_back(fv);
+          foc.type = DType::of(TypeId::String);
+          foc.nullable = !fv.ok.empty();
+          d.out_cols.push_back(foc);
+          ex << "  output: " << explain_expr(c) << " : string (formatted value)\n";
+          continue;
+        }
+      }
       Val v = ge.named(ge.gen(c));
       outs.push_back(v);
       OutCol oc;
@@ -2063,6 +2181,11 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       const Val& v = outs[j];
       std::string vb = "prm.out[" + std::to_string(kOutFirstCol + 2 * j) + "]";
       std::string ob = "prm.out[" + std::to_string(kOutFirstCol + 2 * j + 1) + "]";
+      if (d.out_cols[j].fmt_kind) {
+        ge.stmt("((i128*)" + vb + ")[pos[r]] = (i128)" + v.v + ";");
+        if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");
+        continue;
+      }
       if (d.out_cols[j].view_src >= 0) {
         ge.stmt("((comet::strview*)" + vb + ")[pos[r]] = " + v.v + ";");
         if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");

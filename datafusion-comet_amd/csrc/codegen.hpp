@@ -24,6 +24,11 @@ struct OutCol {
   // Utf8 RESULT of any length that is a slice of source column view_src plus padding (substring, trim, rpad / lpad, read-side padding):
   // the kernel writes a comet::strview (16 bytes) per output row, the executor sizes and writes offsets + bytes afterwards
   int view_src = -1;
+  // Utf8 RESULT that is a VALUE written out (Cast … AS STRING of an integer, boolean, decimal, date or timestamp): the kernel stores the value
+  // as an i128 per output row, the executor sizes and writes the column (strfmt kernels).  0 = not such a column
+  enum FmtKind { FmtNone = 0, FmtInt = 1, FmtBool = 2, FmtDecimal = 3, FmtDecimalJava = 4, FmtDate = 5, FmtTimestamp = 6 };
+  int fmt_kind = FmtNone;
+  long long fmt_arg = 0;            // FmtDecimal*: the scale; FmtTimestamp: the zone's offset from UTC in seconds
   std::string pad_pattern;          // the pad string (≤ 64 bytes, ≤ 32 characters)
   bool pad_left = false;
 };

@@ -541,6 +541,13 @@ CDEV i32 fmt_timestamp(i64 micros, i64 offset_seconds, u8* o) {
   return k;
 }
 // ---- string casts: end
+// the bytes of value i of a Utf8 column
+CDEV strp utf8_bytes(const CometCol& c, i64 i, i32& n) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  n = off[j + 1] - off[j];
+  return (strp)c.aux + off[j];
+}
 
 // ---------------------------------------------------------------------------------------------
 // Scalar functions (ScalarFunc, expr.proto:466-471): the exact, integer/IEEE-defined subset.

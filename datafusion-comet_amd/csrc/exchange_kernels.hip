@@ -325,6 +325,33 @@ __global__ __launch_bounds__(256) void strview_copy_kernel(const StrView* v, con
   }
 }
 
+// ---- formatted values (Cast … AS STRING, OutCol::fmt_kind): one i128 per row in, digits out (comet_device.hpp "values to strings") ----
+__device__ __forceinline__ i32 strfmt_one(int kind, long long arg, i128 v, u8* o) {
+  switch (kind) {
+    case 1: return fmt_i64((i64)v, o);
+    case 2: return fmt_bool(v != 0, o);
+    case 3: return fmt_decimal(v, (int)arg, false, o);
+    case 4: return fmt_decimal(v, (int)arg, true, o);
+    case 5: return fmt_date((i64)v, o);
+    default: return fmt_timestamp((i64)v, (i64)arg, o);
+  }
+}
+__global__ __launch_bounds__(256) void strfmt_lengths_kernel(int kind, long long arg, const i128* v, const u8* ok_bytes, i64 n, u32* lengths) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+    u8 buf[48];
+    lengths[k] = (!ok_bytes || ok_bytes[k]) ? (u32)strfmt_one(kind, arg, v[k], buf) : 0u;
+  }
+}
+__global__ __launch_bounds__(256) void strfmt_write_kernel(int kind, long long arg, const i128* v, const u8* ok_bytes, i64 n, const i32* out_offs, u8* out_bytes) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+    if (ok_bytes && !ok_bytes[k]) continue;
+    u8 buf[48];
+    const i32 len = strfmt_one(kind, arg, v[k], buf);
+    u8* dst = out_bytes + out_offs[k];
+    for (i32 b = 0; b < len; b++) dst[b] = buf[b];
+  }
+}
+
 // ---- constant columns (Hive partition values of a Parquet scan): dst[first .. first+n) = value
 template <class T>
 __global__ __launch_bounds__(256) void fill_kernel(T* dst, i64 n, T value) {
@@ -453,6 +480,14 @@ static PadPattern make_pattern(const uint8_t* pattern, int32_t nbytes) {
   pp.char_off[ch] = (u8)nbytes;
   pp.nchars = ch;
   return pp;
+}
+int comet_launch_strfmt_lengths(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(strfmt_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, kind, arg, (const i128*)vals128, ok_bytes, (i64)n, lengths);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_strfmt_write(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(strfmt_write_kernel, grid_for(n), 256, 0, (hipStream_t)stream, kind, arg, (const i128*)vals128, ok_bytes, (i64)n, out_offs, out_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_strview_lengths(const void* views, const uint8_t* ok_bytes, int64_t n, const uint8_t* pattern, int32_t pattern_bytes, uint32_t* lengths, void* stream) {
   if (pattern_bytes < 0 || pattern_bytes > 64) return -1;

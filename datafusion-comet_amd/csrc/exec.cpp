@@ -266,7 +266,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     explain_ = pv->desc.explain;
     sink_ = pv->desc.sink;
     if (sink_ == SinkKind::Output)
-      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0 || oc.packed_string || oc.view_src >= 0;   // Utf8 outputs are finished on the device (gather / unpack)
+      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0 || oc.packed_string || oc.view_src >= 0 || oc.fmt_kind;   // Utf8 outputs are finished on the device (gather / unpack)
     // a grouped aggregate keyed by Utf8 columns sees its whole input at once (like a join input): only then can strings longer
     // than the packed 15 bytes be swapped for representative row indices (prepare_dict_keys)
     if (sink_ == SinkKind::AggGrouped && !pv->desc.str_key_cols.empty()) has_join_ = true;
@@ -484,7 +484,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       for (size_t k = 0; k < at.size(); k++) {
         types[p][at[k]] = d.out_cols[k].type;
         known[p][at[k]] = true;
-        if (d.out_cols[k].view_src >= 0) throw CometError("Expand: string functions with results of any length are not supported inside a grouping-set projection yet");
+        if (d.out_cols[k].view_src >= 0 || d.out_cols[k].fmt_kind) throw CometError("Expand: string functions with results of any length are not supported inside a grouping-set projection yet");
         gsrc[p][at[k]] = d.out_cols[k].packed_string ? -2 : d.out_cols[k].gather_src;   // −2: a computed (packed) string
       }
     }
@@ -908,6 +908,28 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
       if (rows) read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
       bytes->ensure((size_t)total + 16);
       if (comet_launch_str16_copy(vals[j]->p, (const int32_t*)offsets->p, rows, (uint8_t*)bytes->p, stream_) != 0) throw CometError("packed strings: launch failed");
+      HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
+      cv.data = offsets->p;
+      cv.aux = bytes->p;
+      t.owners.push_back(offsets);
+      t.owners.push_back(bytes);
+    }
+    if (oc.fmt_kind) {
+      // the emit kernel wrote one value per row (i128): lengths of the written-out values, prefix sum, digits
+      const uint8_t* okb = (oc.nullable && rows) ? (const uint8_t*)valid_bytes[j]->p : nullptr;
+      DevBuf lengths, tiles;
+      auto offsets = std::make_shared<DevBuf>(), bytes = std::make_shared<DevBuf>();
+      lengths.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
+      tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+      offsets->ensure((size_t)(rows + 2) * 4);
+      if (rows == 0) HIP_CHECK(hipMemsetAsync(offsets->p, 0, 8, stream_));
+      if (comet_launch_strfmt_lengths(oc.fmt_kind, oc.fmt_arg, vals[j]->p, okb, rows, (uint32_t*)lengths.p, stream_) != 0) throw CometError("formatted strings: launch failed");
+      if (rows) pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)offsets->p, stream_);
+      int32_t total = 0;
+      if (rows) read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
+      if (total < 0) throw CometError("Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+      bytes->ensure((size_t)total + 16);
+      if (comet_launch_strfmt_write(oc.fmt_kind, oc.fmt_arg, vals[j]->p, okb, rows, (const int32_t*)offsets->p, (uint8_t*)bytes->p, stream_) != 0) throw CometError("formatted strings: launch failed");
       HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
       cv.data = offsets->p;
       cv.aux = bytes->p;

@@ -48,6 +48,8 @@ extern "C" int comet_launch_window_rank(int kind, int64_t arg, const int32_t* sp
                                         void* out, void* stream);
 extern "C" int comet_launch_window_offset(int64_t shift, const int32_t* sp, const uint32_t* first_part, int64_t n, uint32_t* idx, uint8_t* ok, void* stream);
 extern "C" int comet_launch_window_offset_valid(const uint32_t* idx, const uint8_t* ok, const uint8_t* src_valid_bits, int64_t n, uint8_t* out_ok, void* stream);
+extern "C" int comet_launch_strfmt_lengths(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream);
+extern "C" int comet_launch_strfmt_write(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" int comet_launch_strview_lengths(const void* views, const uint8_t* ok_bytes, int64_t n, const uint8_t* pattern, int32_t pattern_bytes, uint32_t* lengths, void* stream);
 extern "C" int comet_launch_strview_copy(const void* views, const uint8_t* ok_bytes, const int32_t* src_offs, const uint8_t* src_bytes, int64_t n, const uint8_t* pattern,
                                          int32_t pattern_bytes, int pad_left, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
@@ -94,7 +96,7 @@ void pool_put_event(int dev, hipEvent_t e);
 
 // small host helpers (exec_util.cpp)
 int fixed_width(const DType& t);
-inline int out_width(const OutCol& oc) { return oc.view_src >= 0 ? 16 : oc.gather_src >= 0 ? 4 : oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
+inline int out_width(const OutCol& oc) { return (oc.view_src >= 0 || oc.fmt_kind) ? 16 : oc.gather_src >= 0 ? 4 : oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
 void bit_append(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t src_off, int64_t n);
 void bit_fill_ones(uint8_t* dst, int64_t dst_off, int64_t n);
 bool format_matches(const char* fmt, const DType& t);

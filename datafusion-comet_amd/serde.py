@@ -141,7 +141,7 @@ class Expr:
             if getattr(self, "check_divide_overflow", False):
                 body += _f_varint(6, 1)
         elif k == "cast":
-            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_bytes(3, b"UTC")
+            body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_bytes(3, (getattr(self, "timezone", None) or "UTC").encode())
             if self.eval_mode:
                 body += _f_varint(4, self.eval_mode)
         elif k == "check_overflow":
@@ -273,8 +273,10 @@ def check_overflow(child: Expr, dtype: DataType, fail_on_error: bool = False) ->
     return Expr("check_overflow", [child], dtype=dtype, fail_on_error=fail_on_error)
 
 
-def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY) -> Expr:
-    return Expr("cast", [child], dtype=dtype, eval_mode=eval_mode)
+def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY, timezone: str = "UTC") -> Expr:
+    e = Expr("cast", [child], dtype=dtype, eval_mode=eval_mode)
+    e.timezone = timezone
+    return e
 
 
 def if_(c: Expr, t: Expr, f: Expr) -> Expr:

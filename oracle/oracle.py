@@ -111,7 +111,7 @@ class Col:
 
 def _np_dtype(S, t):
     return {S.BOOL: np.bool_, S.INT8: np.int8, S.INT16: np.int16, S.INT32: np.int32, S.INT64: np.int64, S.FLOAT: np.float32,
-            S.DOUBLE: np.float64, S.DATE: np.int32, S.TIMESTAMP: np.int64}.get(t.type_id)
+            S.DOUBLE: np.float64, S.DATE: np.int32, S.TIMESTAMP: np.int64, S.TIMESTAMP_NTZ: np.int64}.get(t.type_id)
 
 
 def col_from_arrow(S, arr: pa.Array, t) -> Col:
@@ -786,7 +786,64 @@ class Evaluator:
             return Col(to, c.values.astype(_np_dtype(S, to)), c.valid)
         if frm.type_id in ints + (S.FLOAT, S.DOUBLE) and to.type_id == S.BOOL:
             return Col(to, c.values != 0, c.valid)
+        if frm.type_id == S.STRING or to.type_id == S.STRING:
+            return self._string_cast(e, c)
         raise NotImplementedError(f"oracle cast {frm} → {to}")
+
+    def _string_cast(self, e, c: Col) -> Col:
+        """Casts from and to strings: oracle/strcast.py restates conversion_funcs/string.rs and numeric.rs:593-704 value by value."""
+        from . import strcast as C
+        S = self.S
+        to, frm = e.dtype, c.dtype
+        n = len(c)
+        ok = c.ok()
+        mode = {S.LEGACY: C.LEGACY, S.ANSI: C.ANSI, S.TRY: C.TRY}[e.eval_mode]
+        ints = {S.INT8: 8, S.INT16: 16, S.INT32: 32, S.INT64: 64}
+        if frm.type_id == S.STRING:
+            vals, valid = [], np.zeros(n, bool)
+            for i in range(n):
+                v = None
+                if ok[i]:
+                    b = c.values[i].encode() if isinstance(c.values[i], str) else bytes(c.values[i])
+                    if to.type_id == S.BOOL:
+                        v, err = C.string_to_bool(b, mode)
+                    elif to.type_id in ints:
+                        v, err = C.string_to_int(b, mode, ints[to.type_id])
+                    elif to.type_id == S.DECIMAL:
+                        v, err = C.string_to_decimal(b, to.precision, to.scale, mode)
+                    elif to.type_id == S.DATE:
+                        v, err = C.string_to_date(b, mode)
+                    else:
+                        raise NotImplementedError(f"oracle cast string → {to}")
+                    if err:
+                        raise OracleError(err)
+                valid[i] = v is not None
+                vals.append(0 if v is None else v)
+            out = ints_to_dec(vals) if to.type_id == S.DECIMAL else np.array(vals, dtype=_np_dtype(S, to))
+            return Col(to, out, None if valid.all() else valid)
+        tz = getattr(e, "timezone", None) or "UTC"
+        off = 0
+        if frm.type_id == S.TIMESTAMP and tz not in ("UTC", "Z", "GMT", "Etc/UTC"):
+            sign = -1 if tz[0] == "-" else 1
+            parts = [int(x) for x in tz[1:].split(":")] + [0, 0]
+            off = sign * (parts[0] * 3600 + parts[1] * 60 + parts[2])
+        out = np.empty(n, dtype=object)
+        for i in range(n):
+            if not ok[i]:
+                out[i] = None
+            elif frm.type_id in ints:
+                out[i] = C.int_to_string(int(c.values[i]))
+            elif frm.type_id == S.BOOL:
+                out[i] = C.bool_to_string(bool(c.values[i]))
+            elif frm.type_id == S.DECIMAL:
+                out[i] = C.decimal_to_string(dec_to_int(c.values, i), frm.scale, mode)
+            elif frm.type_id == S.DATE:
+                out[i] = C.date_to_string(int(c.values[i]))
+            elif frm.type_id in (S.TIMESTAMP, S.TIMESTAMP_NTZ):
+                out[i] = C.timestamp_to_string(int(c.values[i]), off)
+            else:
+                raise NotImplementedError(f"oracle cast {frm} → string")
+        return Col(to, out, c.valid)
 
 
 # --------------------------------------------------------------------------- operators

@@ -1,0 +1,145 @@
+"""Casts from and to strings on the GPU (conversion_funcs/cast.rs:228-420, string.rs, numeric.rs:593-704) against the oracle's
+restatement, which tests/test_string_casts_cpu.py pins on the reference's own vectors: string → boolean / tinyint / smallint / int / bigint /
+decimal / date in LEGACY, TRY and ANSI mode, and integers / booleans / decimals / dates / timestamps → string as output columns."""
+import json
+import os
+import random
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native, serde as S
+
+pytestmark = pytest.mark.gpu
+STR, I32 = S.T_STRING, S.T_INT32
+KATS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")))["string_casts"]
+
+
+def _run(plan, table, ncols, **kw):
+    return pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(table)], ncols, plan.encode(), batch_size=0, **kw))
+
+
+def _check(plan, table, ncols):
+    from oracle import oracle as O
+    got, want = _run(plan, table, ncols), O.run_plan_to_arrow(S, plan, table)
+    assert got.num_rows == want.num_rows
+    for i in range(ncols):
+        gc, wc = got.column(i), want.column(i)
+        assert gc.type == wc.type, (i, gc.type, wc.type)
+        if pa.types.is_date32(gc.type):       # (years beyond datetime.date's: compare the epoch days)
+            gc, wc = gc.cast(pa.int32()), wc.cast(pa.int32())
+        g, w = gc.to_pylist(), wc.to_pylist()
+        if g != w:
+            k = next(j for j in range(len(g)) if g[j] != w[j])
+            raise AssertionError(f"output {i}, row {k}: got {g[k]!r}, want {w[k]!r}, input {[c[k].as_py() for c in table.columns]!r}")
+    return got
+
+
+def _strings(n, seed):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sc_cpu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_string_casts_cpu.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    vals = [b.decode() for b in m._strings(random.Random(seed))]
+    vals += [s for k in ("date_ok_18262", "date_invalid", "date_null_every_mode") for s in KATS[k]] + [s for s, _ in KATS["date_values"]]
+    rng = np.random.default_rng(seed)
+    pick = rng.integers(0, len(vals), n)
+    return pa.table({"s": pa.array([vals[i] for i in pick], pa.utf8(), mask=rng.random(n) < 0.05), "k": pa.array(rng.integers(0, 100, n), pa.int32())})
+
+
+TARGETS = [S.T_BOOL, S.T_INT8, S.T_INT16, S.T_INT32, S.T_INT64, S.decimal(5, 0), S.decimal(10, 2), S.decimal(18, 6), S.decimal(38, 10), S.decimal(38, 38), S.decimal(20, 19), S.T_DATE]
+
+
+@pytest.mark.parametrize("mode", [S.LEGACY, S.TRY])
+def test_string_to_values(built, mode):
+    t = _strings(30_000, 11)
+    s = S.col(0, STR)
+    plan = S.project(S.scan([STR, I32]), [S.cast(s, to, mode) for to in TARGETS] + [S.col(1, I32)])
+    _check(plan, t, len(TARGETS) + 1)
+
+
+def test_ansi_raises_where_the_reference_raises(built):
+    from oracle import oracle as O
+    s = S.col(0, STR)
+    good = pa.table({"s": pa.array([" 12 ", "-7", None, "+0", "127"]), "k": pa.array(np.arange(5, dtype=np.int32))})
+    plan = S.project(S.scan([STR, I32]), [S.cast(s, S.T_INT8, S.ANSI), S.cast(s, S.decimal(10, 2), S.ANSI)])
+    _check(plan, good, 2)
+    dates = pa.table({"s": pa.array(["2020-01-01", " 2020-1-1T", None, "262143-01-01"]), "k": pa.array(np.arange(4, dtype=np.int32))})
+    _check(S.project(S.scan([STR, I32]), [S.cast(s, S.T_DATE, S.ANSI)]), dates, 1)
+    for bad, to, what in [("128", S.T_INT8, "CAST_INVALID_INPUT"), ("1.5", S.T_INT32, "CAST_INVALID_INPUT"), ("abc", S.T_BOOL, "CAST_INVALID_INPUT"), ("1e", S.decimal(10, 2), "CAST_INVALID_INPUT"),
+                         ("123456789", S.decimal(5, 0), "NUMERIC_VALUE_OUT_OF_RANGE"), ("2020-02-30", S.T_DATE, "CAST_INVALID_INPUT"), ("", S.T_DATE, "CAST_INVALID_INPUT")]:
+        tb = pa.table({"s": pa.array(["1", bad, None]), "k": pa.array(np.arange(3, dtype=np.int32))})
+        p = S.project(S.scan([STR, I32]), [S.cast(s, to, S.ANSI)])
+        with pytest.raises(O.OracleError, match=what):
+            O.run_plan_to_arrow(S, p, tb)
+        with pytest.raises(native.CometQueryExecutionException, match=what):
+            _run(p, tb, 1)
+
+
+def test_parsed_values_feed_filters_and_arithmetic(built):
+    """a cast of a string column is an ordinary operand: compared, added, filtered on"""
+    t = _strings(20_000, 12)
+    s = S.col(0, STR)
+    as_int = S.cast(s, S.T_INT32)
+    src = S.filter_(S.scan([STR, I32]), S.gt(as_int, S.lit(0, I32)))
+    got = _check(S.project(src, [S.math("add", as_int, S.col(1, I32), I32), S.cast(s, S.T_DATE), s]), t, 3)
+    assert 0 < got.num_rows < t.num_rows
+
+
+def _values_table(n, seed):
+    rng = np.random.default_rng(seed)
+    py = random.Random(seed)
+    i64 = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    i64[:8] = [0, 1, -1, 2**63 - 1, -2**63, 10**18, -10**18, 9]
+    dec = [py.randrange(-10**py.randrange(1, 38), 10**py.randrange(1, 38)) for _ in range(n)]
+    dec[:4] = [0, 1, -1, 10**37]
+    small = [py.randrange(-10**py.randrange(1, 9), 10**py.randrange(1, 9)) for _ in range(n)]
+    small[:3] = [0, 1, -5]
+    days = rng.integers(-800_000, 3_100_000, n).astype(np.int32)
+    days[:6] = [0, -1, 18262, -719528, -719529, 2932897]
+    us = rng.integers(-6 * 10**16, 3 * 10**17, n, dtype=np.int64)
+    us[:6] = [0, 1, -1, 1_500_000, 86_399_999_999, -62_135_596_800_000_000]
+    us[6:n // 2] = us[6:n // 2] // 1000 * 1000
+    import decimal
+    decimal.getcontext().prec = 60
+    mask = lambda: rng.random(n) < 0.05
+    return pa.table({
+        "i8": pa.array(rng.integers(-128, 128, n).astype(np.int8), mask=mask()), "i16": pa.array(rng.integers(-2**15, 2**15, n).astype(np.int16)),
+        "i32": pa.array(rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)), "i64": pa.array(i64, mask=mask()),
+        "b": pa.array(rng.random(n) < 0.5, mask=mask()),
+        "d38_10": pa.array([decimal.Decimal(v).scaleb(-10) for v in dec], pa.decimal128(38, 10), mask=mask()),
+        "d38_38": pa.array([decimal.Decimal(v).scaleb(-38) for v in dec], pa.decimal128(38, 38)),
+        "d12_2": pa.array([decimal.Decimal(v).scaleb(-2) for v in small], pa.decimal128(12, 2)),
+        "d9_9": pa.array([decimal.Decimal(v).scaleb(-9) for v in small], pa.decimal128(9, 9), mask=mask()),
+        "d10_0": pa.array([decimal.Decimal(v) for v in small], pa.decimal128(10, 0)),
+        "date": pa.array(days, pa.int32(), mask=mask()).cast(pa.date32()),
+        "ts": pa.array(us, pa.timestamp("us", tz="UTC"), mask=mask()),
+        "ntz": pa.array(us, pa.timestamp("us")),
+    })
+
+
+def test_values_to_strings(built):
+    t = _values_table(20_000, 21)
+    types = [S.T_INT8, S.T_INT16, S.T_INT32, S.T_INT64, S.T_BOOL, S.decimal(38, 10), S.decimal(38, 38), S.decimal(12, 2), S.decimal(9, 9), S.decimal(10, 0), S.T_DATE, S.T_TIMESTAMP,
+             S.DataType(S.TIMESTAMP_NTZ)]
+    cols = [S.col(i, ty) for i, ty in enumerate(types)]
+    exprs = [S.cast(c, STR) for c in cols]
+    exprs += [S.cast(cols[5], STR, S.TRY), S.cast(cols[6], STR, S.ANSI), S.cast(cols[8], STR, S.TRY)]           # plain notation instead of BigDecimal.toString
+    exprs += [S.cast(cols[11], STR, S.LEGACY, "+05:30"), S.cast(cols[11], STR, S.LEGACY, "-08:00")]
+    exprs += [S.cast(S.math("add", cols[2], S.lit(1, I32), I32), STR), cols[0]]
+    got = _check(S.project(S.scan(types), exprs), t, len(exprs))
+    assert got.column(3).to_pylist()[3] == str(2**63 - 1)
+    # below a filter, and with no surviving row
+    src = S.filter_(S.scan(types), S.gt(cols[2], S.lit(0, I32)))
+    _check(S.project(src, exprs[:13]), t, 13)
+    none = S.filter_(S.scan(types), S.and_(S.gt(cols[2], S.lit(0, I32)), S.lt(cols[2], S.lit(0, I32))))
+    assert native.execute_to_table([native.HostInput.from_table(t)], 13, S.project(none, exprs[:13]).encode(), batch_size=0) == []
+
+
+def test_region_time_zones_are_refused_by_name(built):
+    t = _values_table(16, 3)
+    types = [S.T_TIMESTAMP]
+    plan = S.project(S.scan(types), [S.cast(S.col(0, S.T_TIMESTAMP), STR, S.LEGACY, "America/Los_Angeles")])
+    with pytest.raises(native.CometNativeException, match="America/Los_Angeles"):
+        _run(plan, t.select(["ts"]), 1)
