@@ -524,6 +524,30 @@ struct Gen {
       r.maxabs = ~(u128)0 >> 1;   // unchecked: the plan's CheckOverflow bounds it
       return r;
     }
+    if (e.kind == ExprKind::Remainder) {
+      // create_modulo_expr (math_funcs/modulo_expr.rs:137-206): arrow-arith's decimal rem at scale max(s1, s2); a zero divisor is NULL outside ANSI
+      // mode (null_if_zero_primitive) and REMAINDER_BY_ZERO in it
+      if (!e.has_dtype || e.dtype.id != TypeId::Decimal) throw CometError("Expected Decimal128 return type");
+      const int smax = std::max(s1, s2);
+      if (e.dtype.scale != smax) throw CometError("Decimal remainder: return type " + e.dtype.str() + " does not have the operands' larger scale");
+      a = named(a);
+      b = named(b);
+      Val r;
+      r.t = e.dtype;
+      r.ok = and_ok(a.ok, b.ok);
+      std::string val = newvar("i128"), dz = newvar("bool");
+      stmt(val + " = comet::dec_rem(" + as128(a) + ", " + as128(b) + ", " + lit_u128(pow10_u128(smax - s1)) + ", " + lit_u128(pow10_u128(smax - s2)) + ", " + dz + ");");
+      if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, dz), 8);
+      else {
+        std::string o = newvar("bool");
+        stmt(o + " = " + and_ok(r.ok, "!" + dz) + ";");
+        r.ok = o;
+      }
+      r.maxabs = type_maxabs(e.dtype);
+      r.rep = rep_for_type(e.dtype);
+      r.v = r.rep == Rep::I64 ? "(i64)" + val : val;
+      return r;
+    }
     if (!mul && !addsub) throw CometError(std::string("Decimal ") + expr_name(e.proto_tag) + " is not supported in the GPU pipeline yet");
     const int smax = std::max(s1, s2);
     // planner.rs:1000-1008

@@ -914,6 +914,27 @@ CDEV i128 dec_div(i128 l, i128 r, u128 lmul, u128 rmul, bool& div_by_zero, bool 
   return neg ? -mag : mag;
 }
 
+// Decimal remainder (create_modulo_expr → arrow-arith's decimal `rem`, math_funcs/modulo_expr.rs:137-206): l·lmul % r·rmul at the larger of the
+// two scales — one of lmul / rmul is 1 — with the sign of the dividend.  The rescaled operand may need 256 bits (where the reference casts both
+// sides to Decimal256); the remainder itself is smaller than either operand's magnitude, so it is an i128 again.
+CDEV i128 dec_rem(i128 l, i128 r, u128 lmul, u128 rmul, bool& div_by_zero) {
+  const u128 rm = uabs128(r), lm = uabs128(l);
+  div_by_zero = rm == 0;
+  if (div_by_zero) return 0;
+  u128 rem;
+  if (rmul != 1) {
+    const i256 R = u128_mul_u128(rm, rmul);
+    if (R.w[2] | R.w[3]) rem = lm;                            // the divisor exceeds every 128-bit dividend
+    else rem = lm % (((u128)R.w[1] << 64) | R.w[0]);
+  } else if (lmul != 1) {
+    i256 q;
+    u256_divmod_u128(u128_mul_u128(lm, lmul), rm, q, rem);
+  } else {
+    rem = lm % rm;
+  }
+  return l < 0 ? -(i128)rem : (i128)rem;
+}
+
 // result > bound || result < -bound with bound = 10^p - 1 < 2^127 (check_overflow_and_convert,
 // wide_decimal_binary_expr.rs:335-350).  On success the value fits in i128.
 CDEV bool i256_fits_bound(const i256& v, u128 bound, i128& out) {

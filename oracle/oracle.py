@@ -599,6 +599,23 @@ class Evaluator:
                         raise OracleError("ARITHMETIC_OVERFLOW")     # quotient_to_i128, div.rs:57-68
                     res.append(q if -2**127 <= q < 2**127 else 2**127 - 1)           # to_i128().unwrap_or(i128::MAX)
                 return Col(e.dtype, ints_to_dec(res), valid)
+            if e.kind == "remainder":
+                # create_modulo_expr → arrow-arith 58.4's decimal `rem` (math_funcs/modulo_expr.rs:137-206): both operands at the larger scale
+                # (in 256 bits where the reference casts to Decimal256), Rust `%` (sign of the dividend); a zero divisor is NULL (ANSI: error)
+                sm = max(s1, s2)
+                live = np.ones(n, bool) if valid is None else valid
+                res, nz = [], np.ones(n, bool)
+                for i in range(n):
+                    L, R = dec_to_int(a.values, i) * 10 ** (sm - s1), dec_to_int(b.values, i) * 10 ** (sm - s2)
+                    if R == 0:
+                        if e.eval_mode == S.ANSI and live[i]:
+                            raise OracleError("REMAINDER_BY_ZERO / DIVIDE_BY_ZERO")
+                        nz[i] = False
+                        res.append(0)
+                        continue
+                    res.append(abs(L) % abs(R) * (-1 if L < 0 else 1))
+                v2 = live & nz
+                return Col(e.dtype, ints_to_dec(res), None if v2.all() else v2)
             assert mul or addsub, f"decimal {e.kind} not in oracle"
             wide = (addsub and max(s1, s2) + max(p1 - s1, p2 - s2) >= 38) or (mul and p1 + p2 >= 38)  # planner.rs:1000-1008
             av, bv = np.ascontiguousarray(a.values), np.ascontiguousarray(b.values)

@@ -261,6 +261,44 @@ def test_remainder_int_and_float(built):
         _run(ansi, table=t, ncols=1)
 
 
+def test_remainder_decimal(built):
+    """Decimal % Decimal (create_modulo_expr, math_funcs/modulo_expr.rs:137-206): operands at the larger scale — through 256 bits where the reference
+    casts to Decimal256 —, sign of the dividend, zero divisor → NULL (ANSI: error); first the reference's own test_modulo_basic_decimal vector."""
+    import decimal
+    decimal.getcontext().prec = 80
+    D184 = S.decimal(18, 4)
+    from datafusion_comet_amd import tpch
+    ref = pa.table({"a": tpch._dec128_array(np.array([3000000000000000000, 2000000000000000000]), 18, 4), "b": tpch._dec128_array(np.array([1000000000000000000, 5000000000000000000]), 18, 4)})
+    got = pa.Table.from_batches(_run(S.project(S.scan([D184, D184]), [S.math("remainder", S.col(0, D184), S.col(1, D184), D184)]), table=ref, ncols=1, batch_size=0))
+    assert np.frombuffer(got.column(0).combine_chunks().buffers()[1], np.int64)[::2].tolist() == [0, 2000000000000000000]
+    n = 30_000
+    rng = np.random.default_rng(5)
+    py = __import__("random").Random(5)
+    def dec(p, s, zeros=False):
+        vals = [py.randrange(-10**py.randrange(1, p + 1), 10**py.randrange(1, p + 1)) for _ in range(n)]
+        if zeros:
+            for k in range(0, n, 97):
+                vals[k] = 0
+        return pa.array([decimal.Decimal(v).scaleb(-s) for v in vals], pa.decimal128(p, s), mask=rng.random(n) < 0.05)
+    cases = [((12, 2), (12, 2)), ((18, 4), (10, 0)), ((10, 0), (18, 6)), ((38, 10), (38, 10)), ((38, 0), (38, 38)), ((38, 38), (38, 0)), ((38, 6), (20, 18)), ((20, 2), (38, 30))]
+    cols, fields, outs = {}, [], []
+    for k, ((p1, s1), (p2, s2)) in enumerate(cases):
+        cols[f"a{k}"], cols[f"b{k}"] = dec(p1, s1), dec(p2, s2, zeros=True)
+        fields += [S.decimal(p1, s1), S.decimal(p2, s2)]
+        rt = S.decimal(min(p1 - s1, p2 - s2) + max(s1, s2), max(s1, s2))       # Spark's result type of Remainder (DecimalPrecision)
+        outs.append(S.math("remainder", S.col(2 * k, fields[-2]), S.col(2 * k + 1, fields[-1]), rt))
+    t = pa.table(cols)
+    plan = S.project(S.scan(fields), outs)
+    got = pa.Table.from_batches(_run(plan, table=t, ncols=len(outs), batch_size=0))
+    want = _oracle(plan, t)
+    for i in range(len(outs)):
+        assert got.column(i).to_pylist() == want.column(i).to_pylist(), f"case {cases[i]}"
+    assert got.column(0).null_count > t.column(0).null_count        # zero divisors became NULL
+    ansi = S.project(S.scan(fields), [S.math("remainder", S.col(0, fields[0]), S.col(1, fields[1]), S.decimal(12, 2), S.ANSI)])
+    with pytest.raises(native.CometQueryExecutionException, match="DIVIDE_BY_ZERO"):
+        _run(ansi, table=t, ncols=1)
+
+
 def test_more_casts(built):
     """Float/Decimal → integral (Rust `as`: saturating for floats, truncating for decimals; narrow types via i32 — numeric.rs:311-560),
     Decimal → Float, Double → Float, Boolean ↔ numeric; ANSI overflow → CAST_OVERFLOW."""

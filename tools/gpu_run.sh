@@ -88,6 +88,11 @@ q3_stats() {       # SF100 Q3 on one GPU: kernel statistics + PMC of the probes 
   cd $GRAFT_REPO_ROOT
   python tools/pmc_join_summary.py $OUT q3 > $OUT/q3_probe_pmc.txt 2>&1; head -60 $OUT/q3_probe_pmc.txt | cut -c1-260
 }
+q3_timeline() {    # device timeline of one SF100 Q3 run (kernels + copies in start order): where the Final aggregate and the top-10 spend their time
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/q3_tl -o t -- python $GRAFT_REPO_ROOT/tools/q3_dist.py --orders 150000000 --steps 2 --warmup 1 --no-verify > $OUT/q3_tl.log 2>&1)
+  python tools/timeline.py $(find $OUT/q3_tl -name "*kernel_trace.csv") $(find $OUT/q3_tl -name "*memory_copy_trace.csv") > $OUT/q3_tl.txt 2>&1
+  head -${TL_LINES:-200} $OUT/q3_tl.txt | cut -c1-160
+}
 q3() {
   timeout 300 python tools/q3_dist.py --orders 150000000 --steps 5 --warmup 2 --out $OUT/q3.json > $OUT/q3.log 2>&1; cut -c1-700 $OUT/q3.json; echo
 }
