@@ -2961,6 +2961,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   // per run of equal keys is enough (comet_device.hpp "Runs of equal keys")
   const bool dedup_build = mode != 0 && !j.join_condition;
   src << "  static constexpr bool DEDUP_BUILD = " << (dedup_build ? "true" : "false") << ";\n";
+  src << "  static constexpr bool HAS_COND = " << (j.join_condition ? "true" : "false") << ";\n";      // a residual condition beside the keys
 
   // key words of one side
   auto key_fn = [&](const char* name, const char* rowvar, const std::vector<DType>& types, const std::vector<bool>& valid, int base,
@@ -3177,8 +3178,11 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jlds(const CometKParams prm) { comet::join_probe_lds_body<P>(prm); }\n";
   // the key bitmap's two helpers: a sample of the probe side through the finished table (does it pay?), and the bitmap's own build pass
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jsample(const CometKParams prm) { comet::join_sample_body<P>(prm); }\n";
+  // the direct map of a unique integer key (no hash table): build rows in key order, and the probe over it
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jdrows(const CometKParams prm) { comet::join_direct_rows_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jdprobe(const CometKParams prm) { comet::join_probe_direct_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbmap(const CometKParams prm) { comet::join_keymap_build_body<P>(prm); }\n";
-  d.kernels = {"k_jbuild", "k_jbcnt", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jlds", "k_jsample", "k_jbmap"};
+  d.kernels = {"k_jbuild", "k_jbcnt", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jlds", "k_jsample", "k_jbmap", "k_jdrows", "k_jdprobe"};
   d.join_outer_build = outer_build;
   d.join_build_only = build_only;
   const char* jt_name = build_only ? (keep_matched ? "LeftSemi" : "LeftAnti") : keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";

@@ -2238,8 +2238,8 @@ CDEV void join_build_body(const CometKParams& prm) {
 template <class P>
 CDEV void join_build_count_body(const CometKParams& prm) {
   const i64 nb = prm.iarg[1];
-  unsigned long long* total = (unsigned long long*)prm.out[0];      // { leaders, smallest key, largest key } — the keys order-preserving as u64 (sign bit flipped)
-  u32 mine = 0;
+  unsigned long long* total = (unsigned long long*)prm.out[0];      // { leaders, smallest key, largest key, rows with a key } — the keys order-preserving as u64 (sign bit flipped)
+  u32 mine = 0, keyed = 0;
   u64 kmin = ~0ull, kmax = 0;
   for (i64 wbase = (i64)blockIdx.x * kBlock + (i64)wave_id() * kWave; wbase < nb; wbase += (i64)gridDim.x * kBlock) {
     const i64 i = wbase + lane_id();
@@ -2261,10 +2261,11 @@ CDEV void join_build_count_body(const CometKParams& prm) {
     }
     same = same && __shfl_up(valid ? 1 : 0, 1, kWave) != 0;
     mine += (u32)__popcll(__ballot(valid && !same));
+    keyed += (u32)__popcll(__ballot(valid));
   }
   // one set of atomics per BLOCK: thousands of waves adding to, and taking the minimum / maximum of, the same three words queue up
   // behind one another (measured: 0.11 → 0.30 ms per launch when every wave did its own)
-  __shared__ u32 s_cnt[kBlock / kWave];
+  __shared__ u32 s_cnt[kBlock / kWave], s_keyed[kBlock / kWave];
   __shared__ u64 s_min[kBlock / kWave], s_max[kBlock / kWave];
   if (P::KEYMAP) {
 #pragma unroll
@@ -2275,17 +2276,19 @@ CDEV void join_build_count_body(const CometKParams& prm) {
       kmax = b > kmax ? b : kmax;
     }
   }
-  if (lane_id() == 0) { s_cnt[wave_id()] = mine; s_min[wave_id()] = kmin; s_max[wave_id()] = kmax; }
+  if (lane_id() == 0) { s_cnt[wave_id()] = mine; s_keyed[wave_id()] = keyed; s_min[wave_id()] = kmin; s_max[wave_id()] = kmax; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    u32 c = 0;
+    u32 c = 0, kd = 0;
     u64 lo = ~0ull, hi = 0;
     for (int w = 0; w < kBlock / kWave; w++) {
       c += s_cnt[w];
+      kd += s_keyed[w];
       lo = s_min[w] < lo ? s_min[w] : lo;
       hi = s_max[w] > hi ? s_max[w] : hi;
     }
     if (c) atomicAdd(total, (unsigned long long)c);
+    if (kd) atomicAdd(total + 3, (unsigned long long)kd);
     if (P::KEYMAP && lo <= hi) {
       atomicMin(total + 1, (unsigned long long)lo);
       atomicMax(total + 2, (unsigned long long)hi);
@@ -2374,6 +2377,7 @@ constexpr int kJoinR0 = 16;                  // probe rows per thread and tile: 
 // candidates of probe row j in the global chained table
 template <class P>
 struct JoinGlobalTable {
+  static constexpr bool BY_KEY = false;      // peek() takes the key's hash
   const u32* head;
   const i32* next;
   u64 mask;
@@ -2436,6 +2440,7 @@ struct JoinGlobalTable {
 // candidates in the block's LDS table
 template <class P>
 struct JoinLdsTable {
+  static constexpr bool BY_KEY = false;
   const COMET_LDS u32* rows;             // address_space(3): ds_read, not FLAT (a FLAT access waits for every outstanding global load)
   const COMET_LDS unsigned short* tags;
   CDEV u32 peek(u64 h) const { return rows[((u32)(h >> 32)) & (kJoinLdsCap - 1)]; }
@@ -2448,6 +2453,42 @@ struct JoinLdsTable {
     u32 slot = (hi >> 16) & (kJoinLdsCap - 1);
     for (u32 row; (row = rows[slot]) != kJoinEmpty; slot = (slot + 1) & (kJoinLdsCap - 1))
       if (tags[slot] == (unsigned short)hi && P::match(prm, (i64)row, j) && !f(row)) break;
+  }
+};
+
+// The DIRECT MAP (round 4): a build side whose one integer key is UNIQUE and spans a foreign key's range (a primary key: the customers of a
+// segment, the open orders) needs no hash table at all.  Its key bitmap (above) is completed by the number of keys below every 128-bit block
+// (ranks[]) and by the build rows in KEY order (rows[]): a probe row whose bit is set finds its build row at rows[ranks[block] + bits below
+// it in the block] — no hash, no tag, no chain, and no look at the build side's key column (the position IS the key; a residual condition
+// is still evaluated).  A fact table probing in key order (the line items of the open orders) walks all three arrays sequentially; a
+// dimension's arrays are a few MB.  out[0] = ranks (u32 per block), out[1] = rows (u32 per build row), out[kJoinKeyMap] = the bitmap.
+template <class P>
+struct JoinDirectTable {
+  static constexpr bool BY_KEY = true;       // peek() takes the key itself
+  const u64* km;
+  const u32* ranks;
+  const u32* rows;
+  CDEV u32 peek(u64 key) const {             // position of the key among the build side's keys (its bit is set: the tile's filter phase looked)
+    const u64 idx = key - km[0];
+    const u64 blk = idx >> 7;
+    const uint4 w = ((const uint4*)(km + 2))[blk];
+    const u32 b = (u32)idx & 127u;
+    u32 c = 0;
+    c += b >= 32 ? (u32)__popc(w.x) : (u32)__popc(w.x & ((1u << (b & 31u)) - 1u));
+    if (b >= 32) c += b >= 64 ? (u32)__popc(w.y) : (u32)__popc(w.y & ((1u << (b & 31u)) - 1u));
+    if (b >= 64) c += b >= 96 ? (u32)__popc(w.z) : (u32)__popc(w.z & ((1u << (b & 31u)) - 1u));
+    if (b >= 96) c += (u32)__popc(w.w & ((1u << (b & 31u)) - 1u));
+    return ranks[blk] + c;
+  }
+  struct Pre { u32 row; bool m; };
+  CDEV Pre prefetch(const CometKParams& prm, i64 j, u64, u32 e) const {
+    Pre p{rows[e], true};
+    if (P::HAS_COND) p.m = P::match(prm, (i64)p.row, j);
+    return p;
+  }
+  template <class F>
+  CDEV void for_each(const CometKParams&, i64, u64, u32, const Pre& pre, F f) const {
+    if (pre.m) f(pre.row);
   }
 };
 
@@ -2515,7 +2556,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
         if (k < m) {
           const u32 ent = list[k];
           if (!(ent & 0x8000u)) {
-            hs[q] = P::phash(prm, base + (i64)(ent & 0x7fffu));
+            hs[q] = T::BY_KEY ? P::pkey0(prm, base + (i64)(ent & 0x7fffu)) : P::phash(prm, base + (i64)(ent & 0x7fffu));
             keyed |= 1u << q;
           }
         }
@@ -2596,7 +2637,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
         } else if (kind == 2) {
           if (pos < cap_out) P::emit(prm, (i64)first[q], j, pos);
         } else {
-          const u64 h = P::phash(prm, j);            // several matches (rare outside many-to-many joins): walk the candidates again
+          const u64 h = T::BY_KEY ? P::pkey0(prm, j) : P::phash(prm, j);            // several matches (rare outside many-to-many joins): walk the candidates again
           const u32 e2 = table.peek(h);
           table.for_each(prm, j, h, e2, table.prefetch(prm, j, h, e2), [&](u32 row) {
             if (pos < cap_out) P::emit(prm, (i64)row, j, pos);
@@ -2650,9 +2691,30 @@ CDEV void join_keymap_build_body(const CometKParams& prm) {
     if (idx < km[1]) {
       u32* w = (u32*)(km + 2) + (idx >> 5);
       const u32 bit = 1u << (idx & 31u);
-      if (!(*w & bit)) atomicOr(w, bit);           // (runs of equal keys: the bit is usually there already)
+      // (runs of equal keys: the bit is usually there already) — a bit that was there means the key is NOT unique: out[47][4] says so
+      if ((*w & bit) || (atomicOr(w, bit) & bit)) ((volatile unsigned long long*)prm.out[47])[4] = 1ull;
     }
   }
+}
+// rows[] of the direct map: every build row at the rank of its key
+template <class P>
+CDEV void join_direct_rows_body(const CometKParams& prm) {
+  if (!P::KEYMAP) return;
+  const u64* km = (const u64*)prm.out[kJoinKeyMap];
+  const JoinDirectTable<P> t{km, (const u32*)prm.out[0], (const u32*)prm.out[1]};
+  u32* rows = (u32*)prm.out[1];
+  const i64 nb = prm.iarg[1];
+  for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < nb; i += (i64)gridDim.x * kBlock) {
+    if (!P::bvalid(prm, i)) continue;
+    u64 kw[P::NKW];
+    P::bkeys(prm, i, kw);
+    if (kw[0] - km[0] < km[1]) rows[t.peek(kw[0])] = (u32)i;
+  }
+}
+template <class P>
+CDEV void join_probe_direct_body(const CometKParams& prm) {
+  const JoinDirectTable<P> t{(const u64*)prm.out[kJoinKeyMap], (const u32*)prm.out[0], (const u32*)prm.out[1]};
+  join_probe_tiles<P>(prm, t);
 }
 
 template <class P>

@@ -1501,6 +1501,11 @@ std::string ExecutionContext::metrics_proto() {
       n.metrics.emplace_back("pages_decompressed_on_device", pages_inflated_on_device_);
       n.metrics.emplace_back("page_index_rows_pruned", rows_pruned_page_index_);
     }
+    if (op.kind == OpKind::HashJoin && root) {      // (the plan's joins together: the counters are the context's)
+      n.metrics.emplace_back("join_build_rows", join_build_rows_);
+      n.metrics.emplace_back("join_probe_rows", join_probe_rows_);
+      n.metrics.emplace_back("join_direct_maps", join_direct_maps_);      // joins probed through the direct map of a unique integer key
+    }
     for (auto& c : op.children) n.children.push_back(build(*c, false));
     return n;
   };

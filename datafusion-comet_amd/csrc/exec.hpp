@@ -265,7 +265,7 @@ class ExecutionContext {
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from
   std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)
   std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index
-  int64_t join_build_rows_ = 0, join_probe_rows_ = 0, join_keymap_bytes_ = 0;
+  int64_t join_build_rows_ = 0, join_probe_rows_ = 0, join_keymap_bytes_ = 0, join_direct_maps_ = 0;
   int64_t bytes_scanned_ = 0;
   int64_t row_groups_pruned_ = 0;
   std::shared_ptr<MemAccount> mem_ = std::make_shared<MemAccount>();

@@ -155,19 +155,20 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   // The bucket array holds one entry per RUN of equal neighbouring keys (comet_device.hpp "Runs of equal keys"), not one per row: a large
   // build side is counted first (one coalesced pass over its key columns) so that a clustered fact table — several rows per key — gets
   // a bucket array sized by its runs, which stays in the caches several times better than one sized by its rows.
-  int64_t entries = B.rows;
+  int64_t entries = B.rows, keyed_rows = -1;
   static const bool count_runs = getenv("COMET_JOIN_COUNT_RUNS") == nullptr || atoi(getenv("COMET_JOIN_COUNT_RUNS")) != 0;
   DevBuf keymap;
   uint64_t keymap_first = 0, keymap_range = 0;       // a candidate for the key bitmap: one integer key whose values span a foreign key's range
   if (!use_lds && count_runs && B.rows >= (1 << 20)) {
-    const uint64_t init[3] = {0, ~0ull, 0};          // leaders, smallest key, largest key (order-preserving u64)
+    const uint64_t init[4] = {0, ~0ull, 0, 0};       // leaders, smallest key, largest key (order-preserving u64), rows with a non-NULL key
     write_small(emitted_buf.p, init, sizeof init);
     prm.out[0] = emitted_buf.p;
     prm.out[kOutErr] = err_flags_.p;
     launch(v, "k_jbcnt", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
-    uint64_t got[3] = {0, 0, 0};
+    uint64_t got[4] = {0, 0, 0, 0};
     read_small(got, emitted_buf.p, sizeof got);
     entries = std::min<int64_t>(B.rows, (int64_t)got[0]);
+    keyed_rows = (int64_t)got[3];
     // The key bitmap (comet_device.hpp kJoinKeyMap): one integer key whose values span at most 64 bits per build row and 2^31 bits — a
     // foreign key's shape.  k_jbcnt leaves min / max untouched when the kernel has no such key (KEYMAP false).
     if (got[1] <= got[2]) {
@@ -178,11 +179,54 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
       }
     }
   }
+  // The DIRECT MAP (comet_device.hpp JoinDirectTable): when that key is also UNIQUE — every build row leads its own run, and the bitmap's build
+  // pass sees no bit twice — the bitmap, the keys below each of its 128-bit blocks and the build rows in key order replace the hash table.
+  static const int direct_mode = getenv("COMET_JOIN_DIRECT") ? atoi(getenv("COMET_JOIN_DIRECT")) : 1;      // 0: never
+  bool direct = false, keymap_built = false;
+  DevBuf dranks, drows, dtiles;
+  auto build_keymap = [&]() {
+    const size_t words = (size_t)((keymap_range + 127) / 128) * 4;       // whole 128-bit blocks
+    keymap.ensure(16 + words * 4 + 16);
+    HIP_CHECK(hipMemsetAsync((char*)keymap.p + 16, 0, words * 4 + 16, stream_));
+    const uint64_t hdr[2] = {keymap_first, keymap_range};
+    write_small(keymap.p, hdr, sizeof hdr);
+    const uint64_t zero = 0;
+    write_small((char*)emitted_buf.p + 32, &zero, 8);                     // "a key came twice"
+    prm.out[44] = keymap.p;
+    prm.out[47] = emitted_buf.p;
+    prm.out[kOutErr] = err_flags_.p;
+    launch(v, "k_jbmap", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+    join_keymap_bytes_ += (int64_t)words * 4;
+    keymap_built = true;
+  };
+  if (keymap_range && direct_mode != 0 && entries == keyed_rows) {       // (no two neighbouring rows share a key: a clustered fact table is spared the pass)
+    build_keymap();
+    uint64_t dup = 1;
+    read_small(&dup, (char*)emitted_buf.p + 32, 8);
+    if (!dup) {
+      const int64_t nblocks = (int64_t)((keymap_range + 127) / 128);
+      DevBuf counts;
+      counts.ensure((size_t)nblocks * 4 + 16);
+      dranks.ensure((size_t)(nblocks + 2) * 4);
+      dtiles.ensure((size_t)((nblocks + 1023) / 1024 + 2) * 8);
+      drows.ensure((size_t)B.rows * 4 + 16);
+      if (comet_launch_popcount128((const char*)keymap.p + 16, nblocks, (uint32_t*)counts.p, stream_) != 0) throw CometError("hash join: launch failed");
+      pq_launch_u32_scan((const uint32_t*)counts.p, nblocks, (uint64_t*)dtiles.p, (int32_t*)dranks.p, stream_);
+      prm.out[0] = dranks.p;
+      prm.out[1] = drows.p;
+      launch(v, "k_jdrows", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+      HIP_CHECK(hipStreamSynchronize(stream_));       // `counts` goes back to the pool
+      direct = true;
+      join_direct_maps_++;
+    }
+  }
   int64_t cap = 1024;
-  while (cap < 2 * entries) cap <<= 1;
-  head.ensure((size_t)cap * 4);     // u32 per bucket: newest run leader | tag | "more than one row" flag (comet_device.hpp template D)
-  next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4 + 16);
-  HIP_CHECK(hipMemsetAsync(head.p, 0xff, (size_t)cap * 4, stream_));
+  if (!direct) {
+    while (cap < 2 * entries) cap <<= 1;
+    head.ensure((size_t)cap * 4);     // u32 per bucket: newest run leader | tag | "more than one row" flag (comet_device.hpp template D)
+    next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4 + 16);
+    HIP_CHECK(hipMemsetAsync(head.p, 0xff, (size_t)cap * 4, stream_));
+  }
   const bool outer_build = d.join_outer_build;
   const int64_t nbtiles = (B.rows + 1023) / 1024;
   if (outer_build) {
@@ -200,8 +244,10 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     if (((int64_t)1 << ib) - 1 < B.rows) throw CometError("HashJoin: build sides of 2^31 rows or more are not supported");
     prm.iarg[2] = ib;
   }
-  prm.out[0] = head.p;
-  prm.out[1] = next.p;
+  if (!direct) {
+    prm.out[0] = head.p;
+    prm.out[1] = next.p;
+  }
   prm.out[kOutErr] = err_flags_.p;
   timed_begin();
   int64_t out_rows = 0, tail_rows = 0;
@@ -221,14 +267,16 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   };
   // ---- single-pass probe (comet_device.hpp template D'): a small build side is hashed into LDS by every block, a large one into the
   // chained global table; either way the probe counts and emits in one launch, reserving output ranges with one atomic per tile ----
-  if (!use_lds && B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+  if (!use_lds && !direct && B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
   prm.out[47] = emitted_buf.p;
   // The key bitmap (comet_device.hpp kJoinKeyMap) pays when probe rows miss: 8192 probe rows, evenly spaced, go through the finished table
   // first; fewer than half with a partner → one more pass over the build keys sets the bits, and the probe asks them before the table.
   static const int keymap_mode = getenv("COMET_JOIN_KEYMAP") ? atoi(getenv("COMET_JOIN_KEYMAP")) : -1;      // 0 never, 1 always, default: by the sample
   // (… and only where the probe side is several times the build side: the bitmap's build pass costs what the build side's atomics cost —
   // 2.2 ms for each of TPC-DS Q95's 70 M-row builds, whose equally large probe sides it did not speed up)
-  if (keymap_range && keymap_mode != 0 && n >= (1 << 20) && (keymap_mode == 1 || n >= 4 * B.rows)) {
+  if (keymap_built && !direct) {
+    // (the bitmap exists already — the build side turned out not to be unique — and filters the probe rows as below)
+  } else if (!direct && keymap_range && keymap_mode != 0 && n >= (1 << 20) && (keymap_mode == 1 || n >= 4 * B.rows)) {
     bool wanted = keymap_mode == 1;
     if (!wanted) {
       const uint64_t zero[2] = {0, 0};
@@ -240,16 +288,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
       read_small(cnt, emitted_buf.p, sizeof cnt);
       wanted = cnt[0] >= 64 && cnt[1] * 2 < cnt[0];
     }
-    if (wanted) {
-      const size_t words = (size_t)((keymap_range + 31) / 32);
-      keymap.ensure(16 + words * 4 + 16);
-      HIP_CHECK(hipMemsetAsync((char*)keymap.p + 16, 0, words * 4, stream_));
-      const uint64_t hdr[2] = {keymap_first, keymap_range};
-      write_small(keymap.p, hdr, sizeof hdr);
-      prm.out[44] = keymap.p;
-      launch(v, "k_jbmap", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
-      join_keymap_bytes_ += (int64_t)words * 4;
-    }
+    if (wanted) build_keymap();
   }
   // FK-shaped joins emit at most one row per probe row; anything beyond the capacity is counted, not written, and the probe re-run
   int64_t out_cap = d.join_build_only ? 1 : n + 1024;
@@ -258,7 +297,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     prm.iarg[6] = out_cap;
     HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 8, stream_));
     const int64_t ptiles = (n + 4095) / 4096;      // kJoinR0 × 256 probe rows per tile (comet_device.hpp)
-    launch(v, use_lds ? "k_jlds" : "k_jprobe", (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
+    launch(v, use_lds ? "k_jlds" : direct ? "k_jdprobe" : "k_jprobe", (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
     uint64_t emitted = 0;
     read_small(&emitted, emitted_buf.p, 8);
     out_rows = d.join_build_only ? 0 : (int64_t)emitted;

@@ -316,3 +316,18 @@ struct Q6Static {
 
 extern "C" __global__ __launch_bounds__(256) void comet_q6_static_agg(const CometKParams prm) { agg_nogroup_body<Q6Static>(prm); }
 extern "C" __global__ __launch_bounds__(256) void comet_q6_static_final(const CometKParams prm) { agg_nogroup_final_body<Q6Static>(prm); }
+
+// ---- direct-map joins (comet_device.hpp JoinDirectTable): keys set per 128-bit block of a build side's key bitmap
+__global__ __launch_bounds__(256) void popcount128_kernel(const uint4* blocks, long long n, unsigned int* counts) {
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
+    const uint4 w = blocks[k];
+    counts[k] = (unsigned int)(__popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w));
+  }
+}
+extern "C" int comet_launch_popcount128(const void* blocks, int64_t n, uint32_t* counts, void* stream) {
+  if (n > 0) {
+    const long long g = (n + 255) / 256;
+    hipLaunchKernelGGL(popcount128_kernel, dim3((unsigned)(g < 256 * 16 ? g : 256 * 16)), dim3(256), 0, (hipStream_t)stream, (const uint4*)blocks, (long long)n, counts);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

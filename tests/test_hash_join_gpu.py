@@ -295,3 +295,59 @@ def test_semi_join_reduction_keeps_the_answer(built, side):
     assert "Inner" in native.compile_plan(agg.encode())
     got, want = _run(agg, [b, c_], 2, batch_size=0), _oracle(agg, [b, c_])
     assert _rows(got) == _rows(want)
+
+
+def _sorted(t):
+    """the table's rows in one canonical order (large outputs: sorted by Arrow, not as Python tuples)"""
+    t = t.rename_columns([f"c{i}" for i in range(t.num_columns)]).combine_chunks()
+    return t.sort_by([(n, "ascending") for n in t.column_names])
+
+
+def _join_metrics(plan, tables, ncols):
+    it = native.CometExecIterator([native.HostInput.from_table(t) for t in tables], ncols, plan.encode(), batch_size=0)
+    batches = []
+    while True:
+        b = native.Native.executePlan(it.handle, ncols)
+        if b is None:
+            break
+        batches.append(b)
+    m = S.decode_metric_node(it.metrics())[0]
+    it.close()
+    return (pa.Table.from_batches(batches) if batches else None), m
+
+
+@pytest.mark.parametrize("jt", [S.INNER, S.LEFT_SEMI, S.LEFT_ANTI, S.LEFT_OUTER, S.RIGHT_OUTER, S.FULL_OUTER])
+def test_unique_integer_build_key_goes_through_the_direct_map(built, jt):
+    """A build side of ≥ 2^20 rows whose one integer key is unique and dense enough (a primary key) is probed through the direct map — key bitmap,
+    keys below each 128-bit block, build rows in key order — instead of a hash table (comet_device.hpp JoinDirectTable): every join type, NULL
+    keys on both sides, probe keys below / above / inside the holes of the build side's range, with and without a residual condition."""
+    rng = np.random.default_rng(61)
+    nb, npr = 1_200_000, 400_000
+    keys = rng.permutation(np.arange(1000, 1000 + 3 * nb, dtype=np.int64))[:nb]                    # unique, every third key of the range, shuffled
+    build_t = pa.table({"k": pa.array(keys, mask=rng.random(nb) < 0.01), "v": pa.array(rng.integers(-1000, 1000, nb), pa.int32()), "id": pa.array(np.arange(nb, dtype=np.int64))})
+    pk = rng.integers(0, 1000 + 3 * nb + 2000, npr).astype(np.int64)
+    pk[:4] = [-5, 0, 999, 1000 + 3 * nb + 1999]
+    probe_t = pa.table({"k": pa.array(pk, mask=rng.random(npr) < 0.02), "v": pa.array(rng.integers(-1000, 1000, npr), pa.int32()), "id": pa.array(np.arange(npr, dtype=np.int64))})
+    for cond in (None, S.lt(S.col(1, S.T_INT32), S.col(4, S.T_INT32))):
+        j = S.hash_join(S.scan(CFIELDS), S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_RIGHT, cond)
+        ncols = 3 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 6
+        got, m = _join_metrics(j, [probe_t, build_t], ncols)
+        want = _oracle(j, [probe_t, build_t])
+        assert m["join_direct_maps"] == 1, m
+        assert got.num_rows == want.num_rows > 1000
+        assert _sorted(got).equals(_sorted(want))
+
+
+def test_a_key_that_comes_twice_falls_back_to_the_hash_table(built):
+    rng = np.random.default_rng(62)
+    nb = 1_100_000
+    keys = rng.permutation(np.arange(0, 2 * nb, dtype=np.int64))[:nb]
+    keys[nb // 2] = keys[7]                                                                          # far apart: no run, found by the bitmap's build pass
+    build_t = pa.table({"k": pa.array(keys), "v": pa.array(rng.integers(-1000, 1000, nb), pa.int32()), "id": pa.array(np.arange(nb, dtype=np.int64))})
+    pk = np.concatenate([rng.integers(0, 2 * nb, 50_000), np.full(5, keys[7])]).astype(np.int64)
+    probe_t = pa.table({"k": pa.array(pk), "v": pa.array(rng.integers(-1000, 1000, len(pk)), pa.int32()), "id": pa.array(np.arange(len(pk), dtype=np.int64))})
+    j = S.hash_join(S.scan(CFIELDS), S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.INNER, S.BUILD_RIGHT)
+    got, m = _join_metrics(j, [probe_t, build_t], 6)
+    want = _oracle(j, [probe_t, build_t])
+    assert m["join_direct_maps"] == 0
+    assert got.num_rows == want.num_rows and _sorted(got).equals(_sorted(want))
