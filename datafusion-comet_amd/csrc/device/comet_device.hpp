@@ -2519,13 +2519,43 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
   constexpr i64 kTile = (i64)kJoinR0 * kBlock;
   for (i64 base = (i64)blockIdx.x * kTile; base < n; base += (i64)gridDim.x * kTile) {
     // ---- 0. filter + wave-local compaction ----
+    // (three sweeps over the thread's sixteen rows — the chain's filters, the keys, the bitmap words — so that each sweep's loads are in flight
+    // together: one loop that filtered, looked up and compacted row after row spent its time in sixteen dependent load latencies)
     u32 m = 0;
+    u32 alive_bits = 0, can_bits = 0;
 #pragma unroll
     for (int r = 0; r < kJoinR0; r++) {
       const i64 j = base + (i64)r * kBlock + threadIdx.x;
-      const bool alive = j < n && P::pkeep(prm, j);
-      bool can_match = alive && P::pvalid(prm, j);
-      if (P::KEYMAP && keymap && can_match) can_match = join_keymap_has(keymap, P::pkey0(prm, j));      // the build side does not hold the key: settled
+      if (j < n && P::pkeep(prm, j)) alive_bits |= 1u << r;
+    }
+    if (P::KEYMAP && keymap) {
+      u64 keys[kJoinR0];
+#pragma unroll
+      for (int r = 0; r < kJoinR0; r++) {
+        const i64 j = base + (i64)r * kBlock + threadIdx.x;
+        keys[r] = 0;
+        if (((alive_bits >> r) & 1u) && P::pvalid(prm, j)) { can_bits |= 1u << r; keys[r] = P::pkey0(prm, j); }
+      }
+      const u64 first = keymap[0], bits = keymap[1];
+      u32 words[kJoinR0];
+#pragma unroll
+      for (int r = 0; r < kJoinR0; r++) {
+        const u64 idx = keys[r] - first;
+        words[r] = (((can_bits >> r) & 1u) && idx < bits) ? ((const u32*)(keymap + 2))[idx >> 5] : 0u;
+      }
+#pragma unroll
+      for (int r = 0; r < kJoinR0; r++)
+        if (!((words[r] >> ((u32)(keys[r] - first) & 31u)) & 1u)) can_bits &= ~(1u << r);      // the build side does not hold the key: settled
+    } else {
+#pragma unroll
+      for (int r = 0; r < kJoinR0; r++) {
+        const i64 j = base + (i64)r * kBlock + threadIdx.x;
+        if (((alive_bits >> r) & 1u) && P::pvalid(prm, j)) can_bits |= 1u << r;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kJoinR0; r++) {
+      const bool alive = ((alive_bits >> r) & 1u) != 0, can_match = ((can_bits >> r) & 1u) != 0;
       // a row that cannot match only stays where the join still has to say something about it (the preserved side of an outer join, an anti join)
       const bool keep = alive && (can_match || P::OUTER_PROBE || P::MODE == 2);
       const u64 b = __ballot(keep);
