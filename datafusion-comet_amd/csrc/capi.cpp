@@ -13,6 +13,7 @@
 #include "parquet_meta.hpp"
 #include "regex.hpp"
 #include "row_shuffle.hpp"
+#include "tz.hpp"
 
 using namespace comet;
 
@@ -422,6 +423,14 @@ int64_t comet_parquet_host_plain_values(const uint8_t* plan, size_t plan_len, in
     const std::vector<uint8_t> v = parquet_host_plain_values(*scan, (size_t)column);
     if (out && cap) memcpy(out, v.data(), std::min(cap, v.size()));
     return (int64_t)v.size();
+  });
+}
+
+int64_t comet_zone_table(const char* zone, int64_t* out, int64_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    const std::vector<int64_t> f = load_zone(zone ? zone : "")->flat();
+    if (out && cap >= (int64_t)f.size()) memcpy(out, f.data(), f.size() * 8);
+    return (int64_t)f.size();
   });
 }
 

@@ -13,6 +13,7 @@
 //   aggregates           planner.rs:2558-2700, spark-expr/src/agg_funcs/*.rs (state schemas)
 #include "codegen.hpp"
 #include "regex.hpp"
+#include "tz.hpp"
 #include "kparams.h"
 
 #include <cstdio>
@@ -794,6 +795,57 @@ struct Gen {
       return x;
     }
     if (from.id == TypeId::Date && to.id == TypeId::Date) return c;
+    {
+      // Temporal casts (conversion_funcs/temporal.rs:37-78, cast.rs:395-415, utils.rs:62-87,269-297): the time zone is the Cast's (Expr::func)
+      const bool from_ts = from.id == TypeId::Timestamp, from_ntz = from.id == TypeId::TimestampNtz;
+      const bool to_ts = to.id == TypeId::Timestamp, to_ntz = to.id == TypeId::TimestampNtz;
+      if ((from_ts || from_ntz) && to.id == TypeId::Date) {
+        c = named(c);
+        const std::string local = from_ts ? local_of(e.func, c) : c.v;
+        r.ok = c.ok;
+        r.v = "(i32)comet::tz_floor_div(" + local + ", 86400000000ll)";
+        r.maxabs = type_maxabs(to);
+        return r;
+      }
+      if (from.id == TypeId::Date && (to_ts || to_ntz)) {
+        c = named(c);
+        const std::string local = "((i64)" + c.v + " * 86400000000ll)";
+        r.v = to_ts ? utc_of(e.func, local, c.ok) : local;
+        r.maxabs = type_maxabs(to);
+        return r;
+      }
+      if ((from_ts || from_ntz) && to.id == TypeId::Int64) {        // spark_cast_postprocess: floor(µs / 10^6)
+        r.v = "comet::tz_floor_div(" + c.v + ", 1000000ll)";
+        r.maxabs = type_maxabs(to);
+        return r;
+      }
+      if (is_intlike(from) && (to_ts || to_ntz)) {                  // cast_int_to_timestamp (numeric.rs:252-267): seconds, saturating
+        c = named(c);
+        std::string v = newvar("i64");
+        stmt("if (__builtin_mul_overflow((i64)" + c.v + ", (i64)1000000, &" + v + ")) " + v + " = " + c.v + " < 0 ? (i64)0x8000000000000000ull : (i64)0x7fffffffffffffffll;");
+        r.v = v;
+        r.maxabs = type_maxabs(to);
+        return r;
+      }
+      if (from.id == TypeId::Bool && (to_ts || to_ntz)) {           // cast_boolean_to_timestamp (boolean.rs:33-50): one microsecond
+        r.v = "(i64)(" + c.v + " ? 1 : 0)";
+        r.maxabs = 1;
+        return r;
+      }
+      if (from_ts && to_ntz) {
+        c = named(c);
+        r.ok = c.ok;
+        r.v = local_of(e.func, c);
+        r.maxabs = type_maxabs(to);
+        return r;
+      }
+      if (from_ntz && to_ts) {
+        c = named(c);
+        r.v = utc_of(e.func, c.v, c.ok);
+        r.maxabs = type_maxabs(to);
+        return r;
+      }
+    }
     if (from.is_float() && is_intlike(to)) {
       // conversion_funcs/numeric.rs:311-425 — Int8/Int16: (value as i32) as i8/i16; Int32/Int64: value as i32/i64 (saturating, NaN → 0).
       // ANSI: NaN or |value| as dest == dest::MAX (i32::MAX for the narrow types, then try_from) → CAST_OVERFLOW
@@ -1013,21 +1065,68 @@ struct Gen {
     return true;
   }
 
-  // "UTC" / "Z" / "GMT" / "Etc/UTC" / "+HH:MM" / "-HH[:MM[:SS]]" → seconds east of UTC; false for region names (they need the zone's transitions)
-  static bool fixed_zone_offset(const std::string& tz, long long& secs) {
-    if (tz.empty() || tz == "UTC" || tz == "Z" || tz == "GMT" || tz == "Etc/UTC" || tz == "Etc/GMT" || tz == "UCT" || tz == "Etc/UCT") { secs = 0; return true; }
-    std::string s = tz;
-    if (s.rfind("UTC", 0) == 0 || s.rfind("GMT", 0) == 0) s = s.substr(3);
-    if (s.size() < 2 || (s[0] != '+' && s[0] != '-')) return false;
-    int part[3] = {0, 0, 0}, np = 0, nd = 0;
-    for (size_t i = 1; i < s.size(); i++) {
-      if (s[i] == ':') { if (nd == 0 || ++np > 2) return false; nd = 0; continue; }
-      if (s[i] < '0' || s[i] > '9' || ++nd > 2) return false;
-      part[np] = part[np] * 10 + (s[i] - '0');
+  // ---- time zones (csrc/tz.cpp): a region zone's table is a constant array of the kernel; fixed offsets are constants of the expression ----
+  std::map<std::string, std::string> zone_vars;
+  std::string zone_table(const std::string& tz) {
+    auto it = zone_vars.find(tz);
+    if (it != zone_vars.end()) return it->second;
+    const std::vector<int64_t> f = load_zone(tz)->flat();
+    const std::string name = "zt" + std::to_string(zone_vars.size());
+    std::string d = "    static const i64 " + name + "[] = {";
+    for (size_t i = 0; i < f.size(); i++) d += (i ? "," : "") + (f[i] >= 0 && f[i] < 100000 ? std::to_string(f[i]) : lit_i64(f[i]));
+    decls += d + "};\n";
+    zone_vars[tz] = name;
+    return name;
+  }
+  // UTC µs → the zone's wall clock as µs.  An instant behind a rule zone's table (the year 2400) raises error bit 11.
+  std::string local_of(const std::string& tz, Val& c) {
+    long long secs = 0;
+    if (fixed_zone_offset(tz, secs)) return secs ? "(" + c.v + " + " + lit_i64(secs * 1000000) + ")" : c.v;
+    c = named(c);
+    const std::string zt = zone_table(tz);
+    std::string v = newvar("i64"), b = newvar("bool");
+    stmt(b + " = false; " + v + " = comet::tz_utc_to_local_us(" + zt + ", " + c.v + ", " + b + ");");
+    raise_if(and_ok(c.ok, b), 11);
+    return v;
+  }
+  // the zone's wall clock µs → UTC µs (resolve_local_datetime, utils.rs:184-205)
+  std::string utc_of(const std::string& tz, const std::string& local, const std::string& ok) {
+    long long secs = 0;
+    if (fixed_zone_offset(tz, secs)) return secs ? "(" + local + " - " + lit_i64(secs * 1000000) + ")" : local;
+    const std::string zt = zone_table(tz);
+    std::string v = newvar("i64"), b = newvar("bool");
+    stmt(b + " = false; " + v + " = comet::tz_local_to_utc_us(" + zt + ", " + local + ", " + b + ");");
+    raise_if(and_ok(ok, b), 11);
+    return v;
+  }
+
+  // Output-only concat(a, b, …) over Utf8 COLUMNS of the source table and literals (Spark's Concat → datafusion-spark's SparkConcat,
+  // jni_api.rs:70: the bytes one after the other, NULL as soon as one argument is NULL).  At most eight parts; false when `e` is not that.
+  bool string_concat(const Expr& e, Val& out, OutCol& oc) {
+    if (e.kind != ExprKind::ScalarFunc || e.func != "concat" || e.children.empty()) return false;
+    if (e.children.size() > 8) throw CometError("concat of more than eight arguments is not supported by the MI355X native engine yet");
+    std::string ok;
+    for (const ExprP& c : e.children) {
+      if (is_str_col(c) && in_types[(size_t)c->bound_index].id == TypeId::String) {
+        Val valid = str_col_validity(c->bound_index);
+        ok = and_ok(ok, valid.ok);
+        oc.concat_cols.push_back(c->bound_index);
+        oc.concat_lits.emplace_back();
+      } else if (is_str_lit(c)) {
+        oc.concat_cols.push_back(-1);
+        oc.concat_lits.push_back(c->lit_bytes);
+      } else {
+        throw CometError("concat is supported over Utf8 columns and literals");
+      }
     }
-    if (nd == 0 || part[0] > 18 || part[1] > 59 || part[2] > 59) return false;
-    secs = (long long)part[0] * 3600 + part[1] * 60 + part[2];
-    if (s[0] == '-') secs = -secs;
+    out.t = DType::of(TypeId::String);
+    out.rep = Rep::I64;        // the source row: opaque to everything but the store
+    out.v = "idx[r]";
+    if (!ok.empty()) {
+      std::string o = newvar("bool");
+      stmt(o + " = " + ok + ";");
+      out.ok = o;
+    }
     return true;
   }
 
@@ -1049,11 +1148,10 @@ struct Gen {
         break;
       case TypeId::Date: oc.fmt_kind = OutCol::FmtDate; break;
       case TypeId::Timestamp: case TypeId::TimestampNtz: {
-        long long secs = 0;
-        if (v.t.id == TypeId::Timestamp && !fixed_zone_offset(e.func, secs))
-          throw CometError("Cast from timestamp to string in time zone '" + e.func + "' is not supported by the MI355X native engine yet (UTC and fixed offsets are)");
+        // (pre_timestamp_cast, utils.rs:299-330: the instant becomes the session zone's wall clock, which is then written out)
+        if (v.t.id == TypeId::Timestamp) { v = named(v); v.v = local_of(e.func, v); }
         oc.fmt_kind = OutCol::FmtTimestamp;
-        oc.fmt_arg = secs;
+        oc.fmt_arg = 0;
         break;
       }
       case TypeId::String: return false;      // (generated once more by the caller: the statements above are dead code the compiler drops)
@@ -1606,6 +1704,20 @@ struct Gen {
         x.wide_decimal = false;
         x.is_cast_dec = false;
         return bound_check(x, e.dtype.precision, e.fail_on_error, 3);
+      }
+      case ExprKind::Hour: case ExprKind::Minute: case ExprKind::Second: {
+        // SparkHour / SparkMinute / SparkSecond (datetime_funcs/extract_date_part.rs:83-110): of the session zone's wall clock; a TIMESTAMP_NTZ is one already
+        Val c = named(gen(e.children.at(0)));
+        if (c.t.id != TypeId::Timestamp && c.t.id != TypeId::TimestampNtz) throw CometError(std::string(expr_name(e.proto_tag)) + " over " + c.t.str() + " is not supported by the MI355X native engine");
+        const std::string local = c.t.id == TypeId::Timestamp ? local_of(e.func, c) : c.v;
+        Val r;
+        r.t = DType::of(TypeId::Int32);
+        r.rep = Rep::I32;
+        r.ok = c.ok;
+        const std::string sec = "(" + local + " - comet::tz_floor_div(" + local + ", 86400000000ll) * 86400000000ll) / 1000000ll";
+        r.v = e.kind == ExprKind::Hour ? "(i32)((" + sec + ") / 3600)" : e.kind == ExprKind::Minute ? "(i32)((" + sec + ") / 60 % 60)" : "(i32)((" + sec + ") % 60)";
+        r.maxabs = 64;
+        return r;
       }
       case ExprKind::Cast: {
         const ExprP& c0 = e.children.at(0);
@@ -2178,6 +2290,19 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         }
       }
       {
+        // concat of Utf8 columns and literals: the source row travels, the executor assembles the column
+        OutCol coc;
+        Val cvl;
+        if (ge.string_concat(*c, cvl, coc)) {
+          outs.push_back(cvl);
+          coc.type = DType::of(TypeId::String);
+          coc.nullable = !cvl.ok.empty();
+          d.out_cols.push_back(coc);
+          ex << "  output: " << explain_expr(c) << " : string (concatenation of " << coc.concat_cols.size() << " parts)\n";
+          continue;
+        }
+      }
+      {
         // Cast(<integer | boolean | decimal | date | timestamp> AS STRING): the value travels, the executor writes the digits
         OutCol foc;
         Val fv;
@@ -2215,7 +2340,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");
         continue;
       }
-      if (d.out_cols[j].gather_src >= 0) {
+      if (d.out_cols[j].gather_src >= 0 || !d.out_cols[j].concat_cols.empty()) {
         ge.stmt("((u32*)" + vb + ")[pos[r]] = (u32)" + v.v + ";");
         if (!v.ok.empty()) ge.stmt("((u8*)" + ob + ")[pos[r]] = " + v.ok + " ? 1 : 0;");
         continue;

@@ -29,6 +29,10 @@ struct OutCol {
   enum FmtKind { FmtNone = 0, FmtInt = 1, FmtBool = 2, FmtDecimal = 3, FmtDecimalJava = 4, FmtDate = 5, FmtTimestamp = 6 };
   int fmt_kind = FmtNone;
   long long fmt_arg = 0;            // FmtDecimal*: the scale; FmtTimestamp: the zone's offset from UTC in seconds
+  // Utf8 RESULT that is the concatenation of Utf8 source columns and literals (concat): the kernel writes the SOURCE ROW INDEX (u32), the
+  // executor sizes and writes the column.  concat_cols[k] = source column of part k, or −1: the literal concat_lits[k].  Empty = not such a column
+  std::vector<int> concat_cols;
+  std::vector<std::string> concat_lits;
   std::string pad_pattern;          // the pad string (≤ 64 bytes, ≤ 32 characters)
   bool pad_left = false;
 };

@@ -550,6 +550,56 @@ CDEV strp utf8_bytes(const CometCol& c, i64 i, i32& n) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Time zones (csrc/tz.cpp flattens a zone into zt = { n, first_off, limit, at[0..n) UTC seconds, off[0..n) seconds east }): the offset in force at
+// an instant, and the instant of a local wall-clock time as chrono-tz's from_local_datetime and the reference's resolve_local_datetime
+// (spark-expr/src/utils.rs:184-205) decide it.  Plain integer code, also compiled for the host (tests/test_time_zones_cpu.py).
+// ---- time zones: begin
+typedef const i64* tzp;      // (a kernel's zone tables are its own constant arrays: generic pointers)
+CDEV i64 tz_floor_div(i64 a, i64 b) { const i64 q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+// transitions at or before the instant
+CDEV i64 tz_span_of(tzp zt, i64 utc_s) {
+  i64 lo = 0, hi = zt[0];
+  while (lo < hi) {
+    const i64 mid = (lo + hi) >> 1;
+    if (zt[3 + mid] <= utc_s) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+CDEV i64 tz_span_offset(tzp zt, i64 span) { return span == 0 ? zt[1] : zt[3 + zt[0] + span - 1]; }
+CDEV i64 tz_offset_at(tzp zt, i64 utc_s) { return tz_span_offset(zt, tz_span_of(zt, utc_s)); }
+// UTC µs → the zone's wall clock as µs (what Timestamp → Date / String / hour() look at); `beyond`: the instant lies behind the table's end
+CDEV i64 tz_utc_to_local_us(tzp zt, i64 us, bool& beyond) {
+  const i64 s = tz_floor_div(us, 1000000);
+  beyond = s >= zt[2];
+  return us + tz_offset_at(zt, s) * 1000000;
+}
+// spans whose wall clock shows local second L: 0 (a gap), 1, or 2 (an overlap: `off` is the EARLIER span's, chrono's Ambiguous(earliest, _))
+CDEV int tz_local_spans(tzp zt, i64 L, i64& off) {
+  const i64 n = zt[0];
+  const i64 g = tz_span_of(zt, L);
+  int cnt = 0;
+  for (i64 j = g - 2; j <= g + 2; j++) {
+    if (j < 0 || j > n) continue;
+    const i64 o = tz_span_offset(zt, j);
+    const i64 u = L - o;
+    if ((j == 0 || zt[3 + j - 1] <= u) && (j == n || u < zt[3 + j])) {
+      if (cnt == 0) off = o;
+      cnt++;
+    }
+  }
+  return cnt;
+}
+// local wall-clock µs → UTC µs (resolve_local_datetime: an overlap takes the earlier instant; a gap takes the offset in force three hours before)
+CDEV i64 tz_local_to_utc_us(tzp zt, i64 local_us, bool& beyond) {
+  const i64 L = tz_floor_div(local_us, 1000000);
+  i64 off = 0;
+  if (tz_local_spans(zt, L, off) == 0 && tz_local_spans(zt, L - 10800, off) == 0) off = 0;
+  beyond = L - off >= zt[2];
+  return local_us - off * 1000000;
+}
+// ---- time zones: end
+
+// ---------------------------------------------------------------------------------------------
 // Scalar functions (ScalarFunc, expr.proto:466-471): the exact, integer/IEEE-defined subset.
 // ---------------------------------------------------------------------------------------------
 // Rust `x as i64`: saturating, NaN → 0 (spark_ceil / spark_floor: math_funcs/ceil.rs:31-40, floor.rs)

@@ -325,6 +325,41 @@ __global__ __launch_bounds__(256) void strview_copy_kernel(const StrView* v, con
   }
 }
 
+// ---- concat (OutCol::concat_cols): per output row the source row; the parts are Utf8 columns of that row and literals ----
+struct ConcatArgs { i32 n; i32 lit_len[8]; const i32* offs[8]; const u8* bytes[8]; i64 first[8]; };
+__global__ __launch_bounds__(256) void concat_lengths_kernel(ConcatArgs a, const u32* rows, const u8* ok_bytes, i64 n, u32* lengths) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+    u32 len = 0;
+    if (!ok_bytes || ok_bytes[k]) {
+      const i64 r = rows[k];
+      for (int p = 0; p < a.n; p++) len += a.offs[p] ? (u32)(a.offs[p][a.first[p] + r + 1] - a.offs[p][a.first[p] + r]) : (u32)a.lit_len[p];
+    }
+    lengths[k] = len;
+  }
+}
+__global__ __launch_bounds__(256) void concat_copy_kernel(ConcatArgs a, const u32* rows, const u8* ok_bytes, i64 n, const i32* out_offs, u8* out_bytes) {
+  const int sub = threadIdx.x & 7;
+  for (i64 k = ((i64)blockIdx.x * 256 + threadIdx.x) >> 3; k < n; k += ((i64)gridDim.x * 256) >> 3) {
+    if (ok_bytes && !ok_bytes[k]) continue;
+    const i64 r = rows[k];
+    u8* dst = out_bytes + out_offs[k];
+    for (int p = 0; p < a.n; p++) {
+      const u8* src;
+      i32 len;
+      if (a.offs[p]) {
+        const i32 lo = a.offs[p][a.first[p] + r];
+        len = a.offs[p][a.first[p] + r + 1] - lo;
+        src = a.bytes[p] + lo;
+      } else {
+        len = a.lit_len[p];
+        src = a.bytes[p];
+      }
+      for (i32 b = sub; b < len; b += 8) dst[b] = src[b];
+      dst += len;
+    }
+  }
+}
+
 // ---- formatted values (Cast … AS STRING, OutCol::fmt_kind): one i128 per row in, digits out (comet_device.hpp "values to strings") ----
 __device__ __forceinline__ i32 strfmt_one(int kind, long long arg, i128 v, u8* o) {
   switch (kind) {
@@ -480,6 +515,14 @@ static PadPattern make_pattern(const uint8_t* pattern, int32_t nbytes) {
   pp.char_off[ch] = (u8)nbytes;
   pp.nchars = ch;
   return pp;
+}
+int comet_launch_concat_lengths(const void* a, const uint32_t* rows, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(concat_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, *(const ConcatArgs*)a, rows, ok_bytes, (i64)n, lengths);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_concat_copy(const void* a, const uint32_t* rows, const uint8_t* ok_bytes, int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(concat_copy_kernel, grid_for(n * 8), 256, 0, (hipStream_t)stream, *(const ConcatArgs*)a, rows, ok_bytes, (i64)n, out_offs, out_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_strfmt_lengths(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream) {
   if (n > 0) hipLaunchKernelGGL(strfmt_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, kind, arg, (const i128*)vals128, ok_bytes, (i64)n, lengths);

@@ -266,7 +266,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     explain_ = pv->desc.explain;
     sink_ = pv->desc.sink;
     if (sink_ == SinkKind::Output)
-      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0 || oc.packed_string || oc.view_src >= 0 || oc.fmt_kind;   // Utf8 outputs are finished on the device (gather / unpack)
+      for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0 || oc.packed_string || oc.view_src >= 0 || oc.fmt_kind || !oc.concat_cols.empty();   // Utf8 outputs are finished on the device (gather / unpack)
     // a grouped aggregate keyed by Utf8 columns sees its whole input at once (like a join input): only then can strings longer
     // than the packed 15 bytes be swapped for representative row indices (prepare_dict_keys)
     if (sink_ == SinkKind::AggGrouped && !pv->desc.str_key_cols.empty()) has_join_ = true;
@@ -484,7 +484,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       for (size_t k = 0; k < at.size(); k++) {
         types[p][at[k]] = d.out_cols[k].type;
         known[p][at[k]] = true;
-        if (d.out_cols[k].view_src >= 0 || d.out_cols[k].fmt_kind) throw CometError("Expand: string functions with results of any length are not supported inside a grouping-set projection yet");
+        if (d.out_cols[k].view_src >= 0 || d.out_cols[k].fmt_kind || !d.out_cols[k].concat_cols.empty()) throw CometError("Expand: string functions with results of any length are not supported inside a grouping-set projection yet");
         gsrc[p][at[k]] = d.out_cols[k].packed_string ? -2 : d.out_cols[k].gather_src;   // −2: a computed (packed) string
       }
     }
@@ -909,6 +909,52 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
       bytes->ensure((size_t)total + 16);
       if (comet_launch_str16_copy(vals[j]->p, (const int32_t*)offsets->p, rows, (uint8_t*)bytes->p, stream_) != 0) throw CometError("packed strings: launch failed");
       HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
+      cv.data = offsets->p;
+      cv.aux = bytes->p;
+      t.owners.push_back(offsets);
+      t.owners.push_back(bytes);
+    }
+    if (!oc.concat_cols.empty()) {
+      // the emit kernel wrote source row indices: the parts' lengths per row, prefix sum, the parts' bytes one after the other
+      if (!gather_source) throw CometError("internal: concat column without a source table");
+      const uint8_t* okb = (oc.nullable && rows) ? (const uint8_t*)valid_bytes[j]->p : nullptr;
+      CometConcatArgs ca;
+      memset(&ca, 0, sizeof ca);
+      ca.n = (int32_t)oc.concat_cols.size();
+      std::string lits;
+      std::vector<size_t> lit_at(oc.concat_cols.size(), 0);
+      for (size_t k = 0; k < oc.concat_cols.size(); k++)
+        if (oc.concat_cols[k] < 0) { lit_at[k] = lits.size(); lits += oc.concat_lits[k]; lits.append((16 - lits.size() % 16) % 16, '\0'); }
+      auto lit_dev = std::make_shared<DevBuf>();
+      lit_dev->ensure(lits.size() + 16);
+      if (!lits.empty()) HIP_CHECK(hipMemcpyAsync(lit_dev->p, lits.data(), lits.size(), hipMemcpyHostToDevice, stream_));
+      for (size_t k = 0; k < oc.concat_cols.size(); k++) {
+        if (oc.concat_cols[k] < 0) {
+          ca.lit_len[k] = (int32_t)oc.concat_lits[k].size();
+          ca.bytes[k] = (const uint8_t*)lit_dev->p + lit_at[k];
+          continue;
+        }
+        auto src = gather_source(oc.concat_cols[k]);
+        const DeviceColumnView& sc = src.first->cols[(size_t)src.second];
+        if (!sc.data) throw CometError("internal: concat over a column without offsets");
+        ca.offs[k] = (const int32_t*)sc.data;
+        ca.bytes[k] = (const uint8_t*)sc.aux;
+        ca.first[k] = sc.offset;
+      }
+      DevBuf lengths, tiles;
+      auto offsets = std::make_shared<DevBuf>(), bytes = std::make_shared<DevBuf>();
+      lengths.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
+      tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+      offsets->ensure((size_t)(rows + 2) * 4);
+      if (rows == 0) HIP_CHECK(hipMemsetAsync(offsets->p, 0, 8, stream_));
+      if (comet_launch_concat_lengths(&ca, (const uint32_t*)vals[j]->p, okb, rows, (uint32_t*)lengths.p, stream_) != 0) throw CometError("concat: launch failed");
+      if (rows) pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)offsets->p, stream_);
+      int32_t total = 0;
+      if (rows) read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
+      if (total < 0) throw CometError("Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+      bytes->ensure((size_t)total + 16);
+      if (comet_launch_concat_copy(&ca, (const uint32_t*)vals[j]->p, okb, rows, (const int32_t*)offsets->p, (uint8_t*)bytes->p, stream_) != 0) throw CometError("concat: launch failed");
+      HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles / the literals go back to the pool
       cv.data = offsets->p;
       cv.aux = bytes->p;
       t.owners.push_back(offsets);

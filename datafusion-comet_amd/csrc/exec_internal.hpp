@@ -48,6 +48,15 @@ extern "C" int comet_launch_window_rank(int kind, int64_t arg, const int32_t* sp
                                         void* out, void* stream);
 extern "C" int comet_launch_window_offset(int64_t shift, const int32_t* sp, const uint32_t* first_part, int64_t n, uint32_t* idx, uint8_t* ok, void* stream);
 extern "C" int comet_launch_window_offset_valid(const uint32_t* idx, const uint8_t* ok, const uint8_t* src_valid_bits, int64_t n, uint8_t* out_ok, void* stream);
+struct CometConcatArgs {      // the parts of a concat (exchange_kernels.hip): a Utf8 column (offsets / bytes / first row) or a literal (bytes = the literal, offsets = NULL)
+  int32_t n;
+  int32_t lit_len[8];
+  const int32_t* offs[8];
+  const uint8_t* bytes[8];
+  int64_t first[8];
+};
+extern "C" int comet_launch_concat_lengths(const CometConcatArgs* a, const uint32_t* rows, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream);
+extern "C" int comet_launch_concat_copy(const CometConcatArgs* a, const uint32_t* rows, const uint8_t* ok_bytes, int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
 extern "C" int comet_launch_popcount128(const void* blocks, int64_t n, uint32_t* counts, void* stream);
 extern "C" int comet_launch_strfmt_lengths(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream);
 extern "C" int comet_launch_strfmt_write(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
@@ -97,7 +106,7 @@ void pool_put_event(int dev, hipEvent_t e);
 
 // small host helpers (exec_util.cpp)
 int fixed_width(const DType& t);
-inline int out_width(const OutCol& oc) { return (oc.view_src >= 0 || oc.fmt_kind) ? 16 : oc.gather_src >= 0 ? 4 : oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
+inline int out_width(const OutCol& oc) { return (oc.view_src >= 0 || oc.fmt_kind) ? 16 : (oc.gather_src >= 0 || !oc.concat_cols.empty()) ? 4 : oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
 void bit_append(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t src_off, int64_t n);
 void bit_fill_ones(uint8_t* dst, int64_t dst_off, int64_t n);
 bool format_matches(const char* fmt, const DType& t);

@@ -161,7 +161,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
 
   if (d.sink == SinkKind::Output) {
     for (auto& oc : d.out_cols)
-      if (oc.gather_src >= 0 || oc.view_src >= 0 || oc.fmt_kind) throw CometError("internal: gathered Utf8 outputs must go through the materialising path");
+      if (oc.gather_src >= 0 || oc.view_src >= 0 || oc.fmt_kind || !oc.concat_cols.empty()) throw CometError("internal: gathered Utf8 outputs must go through the materialising path");
     const size_t ncol = d.out_cols.size();
     int64_t out_rows = n;
     if (out_vals_.size() < ncol) {
@@ -294,6 +294,7 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
   if (f & 8u) throw CometError("{\"errorType\":\"NumericValueOutOfRange\",\"errorClass\":\"NUMERIC_VALUE_OUT_OF_RANGE\",\"params\":{}}", 1);
   if (f & 512u) throw CometError("{\"errorType\":\"CastInvalidValue\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\"}}", 1);
   if (f & 1024u) throw CometError("{\"errorType\":\"InvalidInputInCastToDatetime\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\",\"toType\":\"DATE\"}}", 1);
+  if (f & 2048u) throw CometError("a timestamp lies behind the end of its time zone's table (the year 2400): not supported by the MI355X native engine");
   if (f & 256u) throw CometError("{\"errorType\":\"DivideByZero\",\"errorClass\":\"DIVIDE_BY_ZERO\",\"params\":{}}", 1);
   if (f & 64u) throw CometError("Utf8 group keys longer than 15 bytes are not supported by the GPU hash aggregate yet");
   if (f & 16u)

@@ -178,6 +178,10 @@ void decode_expr_body(Reader r, Expr& e) {
         else if (f == 3 && wt == 2) { e.func = r.bytes(); handled = true; }      // Cast.timezone (expr.proto:346) travels in `func`
         else if (f == 4 && wt == 0) { e.eval_mode = (EvalMode)r.varint(); handled = true; }
         break;
+      case ExprKind::Hour: case ExprKind::Minute: case ExprKind::Second:
+        if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 2 && wt == 2) { e.func = r.bytes(); handled = true; }
+        break;
       case ExprKind::CheckOverflow:
         if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
         else if (f == 2 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
@@ -233,7 +237,7 @@ ExprP decode_expr(Reader r) {
     switch (f) {
       case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
       case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
-      case 15: case 16: case 17: case 18: case 25: case 26: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
+      case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 25: case 26: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
       case 44: case 45: case 51:
         e->kind = (ExprKind)f;
         if (e->kind == ExprKind::Bound) e->bound_index = 0;  // proto3 omits zero-valued scalars
@@ -766,7 +770,7 @@ const char* op_name(int t) {
 const char* expr_name(int t) {
   switch (t) {
     case 2: return "Literal"; case 3: return "BoundReference"; case 4: return "Add"; case 5: return "Subtract";
-    case 6: return "Multiply"; case 7: return "Divide"; case 8: return "Cast"; case 9: return "Eq";
+    case 6: return "Multiply"; case 7: return "Divide"; case 8: return "Cast"; case 9: return "Eq"; case 22: return "Hour"; case 23: return "Minute"; case 24: return "Second";
     case 10: return "Neq"; case 11: return "Gt"; case 12: return "GtEq"; case 13: return "Lt"; case 14: return "LtEq";
     case 15: return "IsNull"; case 16: return "IsNotNull"; case 17: return "And"; case 18: return "Or";
     case 19: return "SortOrder"; case 25: return "CheckOverflow"; case 26: return "Like"; case 30: return "RLike"; case 31: return "ScalarFunc";

@@ -130,6 +130,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_plan_set_memory_manager.argtypes = [c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64]
     lib.comet_parquet_prune_report.restype = c.c_int64
     lib.comet_parquet_prune_report.argtypes = [c.c_char_p, c.c_size_t, c.c_int32, c.c_char_p, c.c_size_t]
+    lib.comet_zone_table.restype = c.c_int64
+    lib.comet_zone_table.argtypes = [c.c_char_p, c.c_void_p, c.c_int64]
     lib.comet_rlike_match.restype = c.c_int32
     lib.comet_rlike_match.argtypes = [c.c_char_p, c.c_char_p, c.c_size_t]
     lib.comet_page_decompress.restype = c.c_int32
@@ -1058,6 +1060,18 @@ def page_decompress(codec: int, data: bytes, uncompressed_size: int) -> bytes:
     if lib().comet_page_decompress(codec, data, len(data), out.ctypes.data, uncompressed_size) != 0:
         _raise_last(0)
     return out[:uncompressed_size].tobytes()
+
+
+def zone_table(zone: str):
+    """the (instant, offset) table a time zone is planned with (comet_zone_table): numpy int64 { n, first offset, limit, at[n], off[n] }"""
+    import numpy as np
+    n = lib().comet_zone_table(zone.encode(), None, 0)
+    if n < 0:
+        _raise_last(0)
+    out = np.zeros(n, np.int64)
+    if lib().comet_zone_table(zone.encode(), out.ctypes.data_as(ctypes.c_void_p), n) != n:
+        _raise_last(0)
+    return out
 
 
 def rlike_match(pattern: str, value: str) -> bool:

@@ -119,7 +119,7 @@ class Expr:
     check_divide_overflow: bool = False   # MathExpr field 6 (integral_divide only)
 
     # field numbers of Expr.expr_struct (expr.proto:30-107)
-    TAGS = dict(literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
+    TAGS = dict(hour=22, minute=23, second=24, literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
                 lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, like=26, rlike=30, scalar_func=31, eq_null_safe=32,
                 neq_null_safe=33, bit_and=34, bit_or=35, bit_xor=36, shift_right=42, shift_left=43, integral_divide=59, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
                 unbound=51)
@@ -140,6 +140,8 @@ class Expr:
                 body += _f_varint(5, self.eval_mode)
             if getattr(self, "check_divide_overflow", False):
                 body += _f_varint(6, 1)
+        elif k in ("hour", "minute", "second"):      # expr.proto:436-453: child = 1, timezone = 2
+            body = _f_msg(1, self.children[0].encode()) + _f_bytes(2, (getattr(self, "timezone", None) or "UTC").encode())
         elif k == "cast":
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_bytes(3, (getattr(self, "timezone", None) or "UTC").encode())
             if self.eval_mode:
@@ -275,6 +277,14 @@ def check_overflow(child: Expr, dtype: DataType, fail_on_error: bool = False) ->
 
 def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY, timezone: str = "UTC") -> Expr:
     e = Expr("cast", [child], dtype=dtype, eval_mode=eval_mode)
+    e.timezone = timezone
+    return e
+
+
+def time_part(kind: str, child: Expr, timezone: str = "UTC") -> Expr:
+    """Hour / Minute / Second of a timestamp in the session time zone (expr.proto:436-453)."""
+    assert kind in ("hour", "minute", "second")
+    e = Expr(kind, [child])
     e.timezone = timezone
     return e
 

@@ -183,6 +183,13 @@ int64_t comet_parquet_host_plain_values(const uint8_t* plan, size_t plan_len, in
  * -2 and comet_last_error(0) for a pattern outside the subset.  Needs no GPU; the device walks the same tables. */
 int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t value_len);
 
+/* ---- time zones (csrc/tz.cpp) -------------------------------------------------------------------------------------------------------------
+ * The table a Cast / date-part expression with `zone` as its time zone is planned with: { n, offset before the first transition, first instant
+ * the table does not answer, n transition instants (UTC seconds), n offsets (seconds east of UTC) } — read from the system's time-zone
+ * database ($TZDIR, /usr/share/zoneinfo; the reference resolves the same names with chrono-tz, conversion_funcs/temporal.rs:58), fixed
+ * offsets ("UTC", "+05:30") without it.  Returns the number of words (written when cap suffices), or -2 and comet_last_error(0).  Needs no GPU. */
+int64_t comet_zone_table(const char* zone, int64_t* out, int64_t cap);
+
 /* ---- the host page codecs (csrc/parquet_meta.cpp) ---------------------------------------------------------------------------------------
  * What the scan's host threads run on the pages the device does not decompress itself: Parquet CompressionCodec 0 UNCOMPRESSED, 1 SNAPPY,
  * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and

@@ -152,7 +152,10 @@ def col_to_arrow(S, c: Col) -> pa.Array:
             nulls = int(mask.sum())
         return pa.Array.from_buffers(pa.decimal128(t.precision, t.scale), n, [vb, pa.py_buffer(vals.tobytes())], null_count=nulls)
     pt = {S.BOOL: pa.bool_(), S.INT8: pa.int8(), S.INT16: pa.int16(), S.INT32: pa.int32(), S.INT64: pa.int64(),
-          S.FLOAT: pa.float32(), S.DOUBLE: pa.float64(), S.DATE: pa.date32(), S.STRING: pa.utf8()}[t.type_id]
+          S.FLOAT: pa.float32(), S.DOUBLE: pa.float64(), S.DATE: pa.date32(), S.STRING: pa.utf8(), S.TIMESTAMP: pa.timestamp("us", tz="UTC"),
+          S.TIMESTAMP_NTZ: pa.timestamp("us")}[t.type_id]
+    if t.type_id in (S.TIMESTAMP, S.TIMESTAMP_NTZ):
+        return pa.array(c.values.astype(np.int64), type=pa.int64(), mask=mask).cast(pt)
     if t.type_id == S.DATE:
         return pa.array(c.values.astype(np.int32), type=pa.int32(), mask=mask).cast(pa.date32())
     if t.type_id == S.STRING:
@@ -206,6 +209,18 @@ class Evaluator:
                 val = (ao & av) | (bo & bv)
                 ok = (ao & av) | (bo & bv) | (ao & bo)
             return Col(S.T_BOOL, val, None if ok.all() else ok)
+        if k in ("hour", "minute", "second"):
+            # SparkHour / SparkMinute / SparkSecond (datetime_funcs/extract_date_part.rs:83-110): of the session zone's wall clock
+            from . import strcast as C
+            a = self.eval(e.children[0], cols, n)
+            tz = getattr(e, "timezone", None) or "UTC"
+            out = np.zeros(n, np.int32)
+            for i in range(n):
+                if a.ok()[i]:
+                    us = int(a.values[i])
+                    sec = (C.utc_to_local_us(tz, us) if a.dtype.type_id == S.TIMESTAMP else us) % 86_400_000_000 // 1_000_000
+                    out[i] = {"hour": sec // 3600, "minute": sec // 60 % 60, "second": sec % 60}[k]
+            return Col(S.T_INT32, out, a.valid)
         if k == "not_":
             a = self.eval(e.children[0], cols, n)
             return Col(S.T_BOOL, ~a.values.astype(bool), a.valid)
@@ -459,6 +474,16 @@ class Evaluator:
                 fill = (pat * (length // max(len(pat), 1) + 1))[:length - len(v)] if pat else ""
                 return fill + v if f == "lpad" else v + fill
             return Col(S.T_STRING, np.array([pad(v) if v is not None else None for v in a.values], dtype=object), a.valid)
+        if f == "concat":
+            # Spark's Concat (datafusion-spark's SparkConcat, jni_api.rs:70): the arguments' bytes one after the other; NULL as soon as one is NULL
+            args = [self.eval(c, cols, n) for c in e.children]
+            ok = np.ones(n, bool)
+            for a in args:
+                ok &= a.ok()
+            out = np.empty(n, dtype=object)
+            for i in range(n):
+                out[i] = "".join(a.values[i] for a in args) if ok[i] else None
+            return Col(S.T_STRING, out, None if ok.all() else ok)
         if f == "coalesce":
             # the first non-NULL argument
             args = [self.eval(c, cols, n) for c in e.children]
@@ -805,6 +830,34 @@ class Evaluator:
             return Col(to, c.values != 0, c.valid)
         if frm.type_id == S.STRING or to.type_id == S.STRING:
             return self._string_cast(e, c)
+        temporal = (S.TIMESTAMP, S.TIMESTAMP_NTZ)
+        if frm.type_id in temporal + (S.DATE,) or to.type_id in temporal:
+            # conversion_funcs/temporal.rs:37-78, cast.rs:395-415, utils.rs:62-87,269-297, numeric.rs:252-267, boolean.rs:33-50
+            from . import strcast as C
+            tz = getattr(e, "timezone", None) or "UTC"
+            ok = c.ok()
+            out = np.zeros(n, np.int64)
+            for i in range(n):
+                if not ok[i]:
+                    continue
+                v = int(c.values[i])
+                if frm.type_id in temporal and to.type_id == S.DATE:
+                    out[i] = (C.utc_to_local_us(tz, v) if frm.type_id == S.TIMESTAMP else v) // 86_400_000_000
+                elif frm.type_id == S.DATE and to.type_id in temporal:
+                    out[i] = C.local_to_utc_us(tz, v * 86_400_000_000) if to.type_id == S.TIMESTAMP else v * 86_400_000_000
+                elif frm.type_id in temporal and to.type_id == S.INT64:
+                    out[i] = v // 1_000_000
+                elif frm.type_id in ints and to.type_id in temporal:
+                    out[i] = max(-2**63, min(2**63 - 1, v * 1_000_000))
+                elif frm.type_id == S.BOOL and to.type_id in temporal:
+                    out[i] = 1 if c.values[i] else 0
+                elif frm.type_id == S.TIMESTAMP and to.type_id == S.TIMESTAMP_NTZ:
+                    out[i] = C.utc_to_local_us(tz, v)
+                elif frm.type_id == S.TIMESTAMP_NTZ and to.type_id == S.TIMESTAMP:
+                    out[i] = C.local_to_utc_us(tz, v)
+                else:
+                    raise NotImplementedError(f"oracle cast {frm} → {to}")
+            return Col(to, out.astype(_np_dtype(S, to)), c.valid)
         raise NotImplementedError(f"oracle cast {frm} → {to}")
 
     def _string_cast(self, e, c: Col) -> Col:
@@ -839,11 +892,6 @@ class Evaluator:
             out = ints_to_dec(vals) if to.type_id == S.DECIMAL else np.array(vals, dtype=_np_dtype(S, to))
             return Col(to, out, None if valid.all() else valid)
         tz = getattr(e, "timezone", None) or "UTC"
-        off = 0
-        if frm.type_id == S.TIMESTAMP and tz not in ("UTC", "Z", "GMT", "Etc/UTC"):
-            sign = -1 if tz[0] == "-" else 1
-            parts = [int(x) for x in tz[1:].split(":")] + [0, 0]
-            off = sign * (parts[0] * 3600 + parts[1] * 60 + parts[2])
         out = np.empty(n, dtype=object)
         for i in range(n):
             if not ok[i]:
@@ -857,7 +905,7 @@ class Evaluator:
             elif frm.type_id == S.DATE:
                 out[i] = C.date_to_string(int(c.values[i]))
             elif frm.type_id in (S.TIMESTAMP, S.TIMESTAMP_NTZ):
-                out[i] = C.timestamp_to_string(int(c.values[i]), off)
+                out[i] = C.timestamp_to_string(C.utc_to_local_us(tz, int(c.values[i])) if frm.type_id == S.TIMESTAMP else int(c.values[i]))
             else:
                 raise NotImplementedError(f"oracle cast {frm} → string")
         return Col(to, out, c.valid)

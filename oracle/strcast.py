@@ -403,3 +403,52 @@ def timestamp_to_string(micros: int, offset_seconds: int = 0) -> str:
     if us:
         s += (".%06d" % us).rstrip("0")
     return s
+
+
+# --------------------------------------------------------------------------- time zones (utils.rs:62-330, temporal.rs:37-78)
+# The reference resolves zone names with chrono-tz; here Python's zoneinfo over the database the tests name in $TZDIR.
+
+def _zone(tz: str):
+    import datetime
+    import zoneinfo
+    if tz in ("", "UTC", "Z", "GMT", "Etc/UTC"):
+        return datetime.timezone.utc
+    if tz[0] in "+-":
+        parts = [int(x) for x in tz[1:].split(":")] + [0, 0]
+        secs = parts[0] * 3600 + parts[1] * 60 + parts[2]
+        return datetime.timezone(datetime.timedelta(seconds=-secs if tz[0] == "-" else secs))
+    return zoneinfo.ZoneInfo(tz)
+
+
+_EPOCH_NAIVE = None
+
+
+def utc_offset_at(tz: str, utc_seconds: int) -> int:
+    """seconds east of UTC in force at the instant (tz.from_utc_datetime)"""
+    import datetime
+    z = _zone(tz)
+    t = datetime.datetime(1970, 1, 1, tzinfo=datetime.timezone.utc) + datetime.timedelta(seconds=utc_seconds)
+    return int(t.astimezone(z).utcoffset().total_seconds())
+
+
+def utc_to_local_us(tz: str, us: int) -> int:
+    return us + utc_offset_at(tz, us // 1_000_000) * 1_000_000
+
+
+def local_to_utc_us(tz: str, local_us: int) -> int:
+    """resolve_local_datetime (utils.rs:184-205): Single / Ambiguous → the (earlier) instant; a gap → the offset of the wall clock three hours
+    before; that one in a gap as well → the wall clock read as UTC."""
+    import datetime
+    z = _zone(tz)
+    utc = datetime.timezone.utc
+
+    def in_gap(naive):
+        return naive.replace(tzinfo=z, fold=0).astimezone(utc).astimezone(z).replace(tzinfo=None) != naive
+    L = local_us // 1_000_000
+    naive = datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=L)
+    if not in_gap(naive):
+        off = int(naive.replace(tzinfo=z, fold=0).utcoffset().total_seconds())
+    else:
+        probe = naive - datetime.timedelta(hours=3)
+        off = 0 if in_gap(probe) else int(probe.replace(tzinfo=z, fold=0).utcoffset().total_seconds())
+    return local_us - off * 1_000_000

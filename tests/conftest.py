@@ -8,6 +8,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the time-zone database: the system's when it has one, else the tzdata wheel's (csrc/tz.cpp reads $TZDIR first; Python's zoneinfo, the tests'
+# referee, searches the same places in the same order)
+if "TZDIR" not in os.environ and not os.path.isdir("/usr/share/zoneinfo"):
+    try:
+        import tzdata
+        os.environ["TZDIR"] = os.path.join(os.path.dirname(tzdata.__file__), "zoneinfo")
+    except ImportError:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

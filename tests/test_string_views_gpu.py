@@ -71,3 +71,35 @@ def test_long_pad_strings_are_refused(built):
     plan = S.project(S.scan([STR, I32]), [S.scalar_func("rpad", [S.col(0, STR), S.lit(200, I32), S.lit("0123456789" * 4, STR)], STR)])
     with pytest.raises(native.CometNativeException, match="32 characters"):
         _run(plan, t, 1)
+
+
+def test_concat_of_columns_and_literals(built):
+    """Spark's Concat (datafusion-spark's SparkConcat, jni_api.rs:70): the arguments' bytes one after the other, NULL as soon as one argument is
+    NULL — Utf8 columns of any length and literals, as an output column; below a filter; with no surviving row; over a device-resident table."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    n = 30_000
+    words = np.array(["", "a", "日本語", "naïve café ☕", "Customer#000000001", "x" * 70, "a much longer value that never fitted fifteen bytes"], dtype=object)
+    t = pa.table({"s": pa.array(words[rng.integers(0, len(words), n)], pa.utf8(), mask=rng.random(n) < 0.1), "k": pa.array(rng.integers(0, 100, n), pa.int32()),
+                  "u": pa.array(words[rng.integers(0, len(words), n)], pa.utf8(), mask=rng.random(n) < 0.05)})
+    fields = [STR, I32, STR]
+    s, u, L = S.col(0, STR), S.col(2, STR), lambda v: S.lit(v, STR)
+    cc = lambda *a: S.scalar_func("concat", list(a), STR)
+    exprs = [cc(s, u), cc(s, L("-"), u, L(" ☕ "), s), cc(L("id: "), u), cc(s), cc(u, u, u, u, u, u, u, u), S.col(1, I32)]
+    plan = S.project(S.scan(fields), exprs)
+    got, want = _run(plan, t, len(exprs)), O.run_plan_to_arrow(S, plan, t)
+    for i in range(len(exprs)):
+        assert got.column(i).to_pylist() == want.column(i).to_pylist(), f"output {i}"
+    assert got.column(0).null_count > t.column(0).null_count
+    src = S.filter_(S.scan(fields), S.lt(S.col(1, I32), S.lit(30, I32)))
+    plan = S.project(src, exprs[:3])
+    got, want = _run(plan, t, 3), O.run_plan_to_arrow(S, plan, t)
+    assert 0 < got.num_rows < n and all(got.column(i).to_pylist() == want.column(i).to_pylist() for i in range(3))
+    none = S.filter_(S.scan(fields), S.lt(S.col(1, I32), S.lit(-1, I32)))
+    assert native.execute_to_table([native.HostInput.from_table(t)], 3, S.project(none, exprs[:3]).encode(), batch_size=0) == []
+    dt = native.DeviceTable.from_arrow(pa.table({"s": pa.array(["ab", "cd", "ef", "gh"] * 5000), "k": pa.array(np.arange(20_000, dtype=np.int32)), "u": pa.array(["xy"] * 20_000)}))
+    plan = S.project(S.scan(fields), [cc(s, L("/"), u)])
+    got = native.execute_to_device([native.DeviceInput(dt)], 1, plan.encode()).to_arrow()
+    assert got.column(0).to_pylist() == ["ab/xy", "cd/xy", "ef/xy", "gh/xy"] * 5000
+    with pytest.raises(native.CometNativeException, match="eight"):
+        native.compile_plan(S.project(S.scan(fields), [cc(*([s] * 9))]).encode())

@@ -1,0 +1,82 @@
+"""Casts between dates, timestamps and integers, timestamps written out as strings, and hour / minute / second — in region time zones (SURVEY
+§8 a6; conversion_funcs/temporal.rs:37-78, cast.rs:395-415, utils.rs:62-330, datetime_funcs/extract_date_part.rs): the zone's table is a
+constant of the fused kernel (csrc/tz.cpp), checked on the CPU against zoneinfo and the reference's vectors (tests/test_time_zones_cpu.py)."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native, serde as S
+
+pytestmark = pytest.mark.gpu
+TS, NTZ, D, I64, STR = S.T_TIMESTAMP, S.DataType(S.TIMESTAMP_NTZ), S.T_DATE, S.T_INT64, S.T_STRING
+ZONES = ["UTC", "America/Los_Angeles", "Asia/Kolkata", "Europe/London", "Australia/Lord_Howe", "Pacific/Apia", "+05:30"]
+
+
+def _table(n, seed):
+    rng = np.random.default_rng(seed)
+    us = rng.integers(-5 * 10**15, 6 * 10**15, n, dtype=np.int64)          # 1811 … 2160
+    # around the daylight-saving switches of 2024 in the zones above, to the second
+    edges = np.array([1710064800, 1710068400, 1730624400, 1730628000, 1711846800, 1729990800, 1712419200, 1728142200, 1325239200, 1325325600], np.int64) * 1_000_000
+    k = len(edges) * 5
+    us[:k] = np.repeat(edges, 5) + np.tile(np.array([-1_000_001, -1, 0, 1, 1_800_000_000]), len(edges))
+    days = rng.integers(-60_000, 70_000, n).astype(np.int32)
+    days[:6] = [0, 19723, 19793, 19800, 20029, 15337]
+    secs = rng.integers(-10**10, 10**10, n)
+    secs[:4] = [0, -1, 2**62, -2**62]
+    m = lambda: rng.random(n) < 0.05
+    return pa.table({"ts": pa.array(us, pa.timestamp("us", tz="UTC"), mask=m()), "ntz": pa.array(us, pa.timestamp("us"), mask=m()),
+                     "d": pa.array(days, pa.int32(), mask=m()).cast(pa.date32()), "s": pa.array(secs, pa.int64(), mask=m()), "b": pa.array(rng.random(n) < 0.5)})
+
+
+FIELDS = [TS, NTZ, D, I64, S.T_BOOL]
+
+
+def _check(exprs, t):
+    from oracle import oracle as O
+    plan = S.project(S.scan(FIELDS), exprs)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], len(exprs), plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, t)
+    for i in range(len(exprs)):
+        g, w = got.column(i), want.column(i)
+        if pa.types.is_timestamp(g.type) or pa.types.is_date(g.type):
+            g, w = g.cast(pa.int64() if pa.types.is_timestamp(g.type) else pa.int32()), w.cast(pa.int64() if pa.types.is_timestamp(w.type) else pa.int32())
+        gl, wl = g.to_pylist(), w.to_pylist()
+        if gl != wl:
+            k = next(j for j in range(len(gl)) if gl[j] != wl[j])
+            raise AssertionError(f"output {i}, row {k}: got {gl[k]!r}, want {wl[k]!r}, input {[c[k].as_py() for c in t.columns]!r}")
+
+
+@pytest.mark.parametrize("tz", ZONES)
+def test_casts_and_time_parts_in_a_time_zone(built, tz):
+    t = _table(20_000, 33)
+    ts, ntz, d, s, b = (S.col(i, ty) for i, ty in enumerate(FIELDS))
+    c = lambda x, to: S.cast(x, to, S.LEGACY, tz)
+    _check([c(ts, D), c(ntz, D), c(d, TS), c(d, NTZ), c(ts, I64), c(ntz, I64), c(s, TS), c(b, TS), c(ts, NTZ), c(ntz, TS), c(ts, STR), c(ntz, STR),
+            S.time_part("hour", ts, tz), S.time_part("minute", ts, tz), S.time_part("second", ts, tz), S.time_part("hour", ntz, tz),
+            S.cast(c(ts, D), STR), c(c(d, TS), STR)], t)
+
+
+def test_the_references_date_to_timestamp_vectors(built):
+    """temporal.rs test_cast_date_to_timestamp"""
+    t = pa.table({"ts": pa.array([0, 0, 0], pa.timestamp("us", tz="UTC")), "ntz": pa.array([0, 0, 0], pa.timestamp("us")), "d": pa.array([0, 19723, 19793], pa.int32()).cast(pa.date32()),
+                  "s": pa.array([0, 0, 0], pa.int64()), "b": pa.array([True, False, True])})
+    non_dst, dst = 1704067200000000, 1710115200000000
+    for zone, want in [("UTC", [0, non_dst, dst]), ("America/Los_Angeles", [28800000000, non_dst + 28800000000, dst + 25200000000]),
+                       ("America/Phoenix", [25200000000, non_dst + 25200000000, dst + 25200000000])]:
+        plan = S.project(S.scan(FIELDS), [S.cast(S.col(2, D), TS, S.LEGACY, zone)])
+        got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 1, plan.encode(), batch_size=0))
+        assert got.column(0).cast(pa.int64()).to_pylist() == want, zone
+
+
+def test_unknown_zones_and_instants_behind_the_table(built):
+    t = _table(64, 1)
+    with pytest.raises(native.CometNativeException, match="Mars/Olympus"):
+        native.compile_plan(S.project(S.scan(FIELDS), [S.cast(S.col(0, TS), D, S.LEGACY, "Mars/Olympus")]).encode())
+    far = t.set_column(0, "ts", pa.array(np.full(64, 14_000_000_000 * 1_000_000, np.int64), pa.timestamp("us", tz="UTC")))      # the year 2413
+    plan = S.project(S.scan(FIELDS), [S.cast(S.col(0, TS), D, S.LEGACY, "Europe/Berlin")])
+    with pytest.raises(native.CometNativeException, match="2400"):
+        native.execute_to_table([native.HostInput.from_table(far)], 1, plan.encode(), batch_size=0)
+    # a zone without rules answers any instant
+    plan = S.project(S.scan(FIELDS), [S.cast(S.col(0, TS), D, S.LEGACY, "Asia/Tokyo")])
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(far)], 1, plan.encode(), batch_size=0))
+    assert got.column(0).cast(pa.int32()).to_pylist()[0] == (14_000_000_000 + 9 * 3600) // 86400
