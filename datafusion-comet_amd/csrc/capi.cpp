@@ -436,8 +436,23 @@ int64_t comet_zone_table(const char* zone, int64_t* out, int64_t cap) {
 
 int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t value_len) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
-    const RegexDfa d = compile_rlike(pattern ? pattern : "");
-    return regex_dfa_match(d, value, value_len) ? 1 : 0;
+    // (the last few patterns stay compiled: a test walks thousands of values through one pattern)
+    static std::mutex mu;
+    static std::map<std::string, std::shared_ptr<const RegexDfa>> cache;
+    const std::string key = pattern ? pattern : "";
+    std::shared_ptr<const RegexDfa> d;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = cache.find(key);
+      if (it != cache.end()) d = it->second;
+    }
+    if (!d) {
+      d = std::make_shared<const RegexDfa>(compile_rlike(key));
+      std::lock_guard<std::mutex> lk(mu);
+      if (cache.size() >= 64) cache.clear();
+      cache[key] = d;
+    }
+    return regex_dfa_match(*d, value, value_len) ? 1 : 0;
   });
 }
 

@@ -1550,7 +1550,8 @@ struct Gen {
     auto loc = locate(idx);
     std::string b = newvar("bool");
     stmt(b + " = comet::utf8_rlike(prm.in[" + std::to_string(loc.first) + "], " + loc.second + ", " + c_bytes(std::string((const char*)dfa.trans.data(), dfa.trans.size())) + ", " +
-         c_bytes(std::string((const char*)dfa.flags.data(), dfa.flags.size())) + ");");
+         c_bytes(std::string((const char*)dfa.flags.data(), dfa.flags.size())) + ", " + c_bytes(std::string((const char*)dfa.classes.data(), dfa.classes.size())) + ", " +
+         std::to_string(dfa.nclasses) + "u);");
     Val r;
     r.t = DType::of(TypeId::Bool);
     r.rep = Rep::B;

@@ -718,7 +718,8 @@ CDEV i32 utf8_next_char(const COMET_GLOBAL u8* p, i32 at, i32 len) {
 }
 // RLIKE: walk the search automaton the host compiled from the pattern (csrc/regex.cpp): trans[state][byte] → state; flags bit 0 = a match
 // has been found (answer true at once), bit 1 = a match if the text ends in this state.  One table lookup per byte of the value.
-CDEV bool utf8_rlike(const CometCol& c, i64 i, const char* trans, const char* flags) {
+// (the table steps on byte CLASSES — bytes no state tells apart — and holds 16-bit states: regex.hpp RegexDfa)
+CDEV bool utf8_rlike(const CometCol& c, i64 i, const char* trans, const char* flags, const char* classes, u32 nclasses) {
   const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
   const i64 j = c.offset + i;
   const i32 lo = off[j], nbytes = off[j + 1] - lo;
@@ -726,7 +727,8 @@ CDEV bool utf8_rlike(const CometCol& c, i64 i, const char* trans, const char* fl
   if (flags[0] & 1) return true;
   u32 st = 0;
   for (i32 k = 0; k < nbytes; k++) {
-    st = (u8)trans[st * 256u + p[k]];
+    const u32 at = (st * nclasses + (u8)classes[p[k]]) * 2u;
+    st = (u32)(u8)trans[at] | ((u32)(u8)trans[at + 1] << 8);
     if (flags[st] & 1) return true;
   }
   return (flags[st] & 2) != 0;

@@ -26,10 +26,12 @@
 
 #include <algorithm>
 #include <array>
+#include <functional>
 #include <map>
 #include <set>
 
 #include "plan.hpp"
+#include "regex_unicode_tables.hpp"
 
 namespace comet {
 namespace {
@@ -45,11 +47,15 @@ ByteSet bs_range(int lo, int hi) {
 
 struct Node;
 typedef std::shared_ptr<Node> NodeP;
+// a big class (\w: 796 ranges of scalar values) as a MINIMAL acyclic byte automaton instead of an alternation of ~1200 UTF-8 range sequences:
+// node 0 is the entry; an edge leads to another node or (−1) to the class's end
+struct TrieNode { std::vector<std::pair<ByteSet, int>> edges; };
 struct Node {
-  enum Kind { Bytes, Cat, Alt, Repeat, Bol, Eol, Empty } kind = Empty;
+  enum Kind { Bytes, Cat, Alt, Repeat, Bol, Eol, Empty, Trie } kind = Empty;
   ByteSet set{};
   std::vector<NodeP> kids;
   int min = 0, max = -1;   // Repeat: max −1 = unbounded
+  std::vector<TrieNode> trie;
 };
 NodeP mk(Node::Kind k) {
   auto n = std::make_shared<Node>();
@@ -72,6 +78,62 @@ NodeP mk_alt(std::vector<NodeP> kids) {
   if (kids.size() == 1) return kids[0];
   auto n = mk(Node::Alt);
   n->kids = std::move(kids);
+  return n;
+}
+std::string utf8_bytes(int cp) {
+  std::string o;
+  if (cp < 0x80) o += (char)cp;
+  else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+  else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+  else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+  return o;
+}
+// the scalar values of `wide` (sorted ranges beyond ASCII, surrogates skipped) as the minimal automaton over their UTF-8 bytes
+NodeP class_trie(const std::vector<std::pair<int, int>>& wide) {
+  struct Raw { std::map<int, int> kid; };      // byte → raw node, −1 = end
+  std::vector<Raw> raw(1);
+  for (auto& r : wide)
+    for (int cp = std::max(r.first, 0x80); cp <= r.second; cp++) {
+      if (cp >= 0xD800 && cp <= 0xDFFF) { cp = 0xDFFF; continue; }
+      const std::string b = utf8_bytes(cp);
+      int n = 0;
+      for (size_t k = 0; k + 1 < b.size(); k++) {
+        auto it = raw[(size_t)n].kid.find((unsigned char)b[k]);
+        if (it == raw[(size_t)n].kid.end()) {
+          raw.emplace_back();
+          const int fresh = (int)raw.size() - 1;
+          raw[(size_t)n].kid[(unsigned char)b[k]] = fresh;
+          n = fresh;
+        } else n = it->second;
+      }
+      raw[(size_t)n].kid[(unsigned char)b.back()] = -1;
+    }
+  // equal subtrees become one node (children first: a raw node's children have larger indices)
+  std::vector<int> canon(raw.size(), -1);
+  std::map<std::vector<std::pair<int, int>>, int> seen;
+  std::vector<std::vector<std::pair<int, int>>> sigs;
+  for (size_t k = raw.size(); k-- > 0;) {
+    std::vector<std::pair<int, int>> sig;
+    for (auto& e : raw[k].kid) sig.emplace_back(e.first, e.second < 0 ? -1 : canon[(size_t)e.second]);
+    auto it = seen.find(sig);
+    if (it == seen.end()) {
+      seen[sig] = (int)sigs.size();
+      canon[k] = (int)sigs.size();
+      sigs.push_back(sig);
+    } else canon[k] = it->second;
+  }
+  // the root was numbered last: make it node 0
+  auto n = mk(Node::Trie);
+  const int root = canon[0], last = (int)sigs.size() - 1;
+  auto renum = [&](int c) { return c < 0 ? -1 : c == root ? 0 : c == 0 ? root : c; };
+  (void)last;
+  n->trie.resize(sigs.size());
+  for (size_t c = 0; c < sigs.size(); c++) {
+    std::map<int, ByteSet> by_target;
+    for (auto& e : sigs[c]) bs_add(by_target[renum(e.second)], e.first);
+    TrieNode& t = n->trie[(size_t)renum((int)c)];
+    for (auto& e : by_target) t.edges.emplace_back(e.second, e.first);
+  }
   return n;
 }
 // every UTF-8 encoded scalar value of two or more bytes (well-formed sequences, surrogates excluded like the crate's utf8 ranges)
@@ -304,8 +366,16 @@ struct Parser {
         i += 2;
         return finish_class(ws, wide, negate, true);
       }
+      if (p[i + 1] == 'd' || p[i + 1] == 'D' || p[i + 1] == 'w' || p[i + 1] == 'W') {
+        ByteSet as{};
+        std::vector<std::pair<int, int>> wide;
+        add_perl_class(p[i + 1] | 0x20, as, wide);
+        const bool negate = p[i + 1] == 'D' || p[i + 1] == 'W';
+        i += 2;
+        return finish_class(as, wide, negate, true);
+      }
       const int b = simple_escape(p[i + 1]);
-      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (\\d \\w \\b and the Unicode classes grow with every Unicode release; back-references do not exist in the reference)");
+      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (\\b and the \\p{…} classes are not reproduced; back-references do not exist in the reference)");
       i += 2;
       ByteSet s{};
       bs_add(s, b);
@@ -398,6 +468,12 @@ struct Parser {
         i += 2;
         continue;
       }
+      if (c == '\\' && i + 1 < p.size() && (p[i + 1] == 'd' || p[i + 1] == 'w')) {      // [\w.-]: the class's members join
+        if (icase) fail("\\d / \\w inside a class under (?i)");
+        add_perl_class(p[i + 1], s, wide);
+        i += 2;
+        continue;
+      }
       const int lo = class_member();
       int hi = lo;
       if (i + 1 < p.size() && p[i] == '-' && p[i + 1] != ']') {
@@ -418,6 +494,16 @@ struct Parser {
     bs_add(s, 32);
     for (auto r : {std::pair<int, int>{0x85, 0x85}, {0xA0, 0xA0}, {0x1680, 0x1680}, {0x2000, 0x200A}, {0x2028, 0x2029}, {0x202F, 0x202F}, {0x205F, 0x205F}, {0x3000, 0x3000}})
       wide.push_back(r);
+  }
+  // \d (General_Category = Nd) and \w (Alphabetic, M, Nd, Pc, Join_Control) as the crate's Unicode 16.0 tables have them
+  // (regex_unicode_tables.hpp: probed from the crate itself, tools/gen_regex_tables.py)
+  static void add_perl_class(char which, ByteSet& s, std::vector<std::pair<int, int>>& wide) {
+    const int (*t)[2] = which == 'd' ? kPerlDigit : kPerlWord;
+    const size_t n = which == 'd' ? sizeof kPerlDigit / sizeof kPerlDigit[0] : sizeof kPerlWord / sizeof kPerlWord[0];
+    for (size_t k = 0; k < n; k++) {
+      for (int b = t[k][0]; b <= t[k][1] && b < 128; b++) bs_add(s, b);
+      if (t[k][1] >= 128) wide.emplace_back(std::max(t[k][0], 128), t[k][1]);
+    }
   }
   // members collected → the class's node: case folding, negation, ASCII byte set + UTF-8 range sequences
   NodeP finish_class(ByteSet s, std::vector<std::pair<int, int>> wide, bool neg, bool perl) {
@@ -453,6 +539,7 @@ struct Parser {
     for (int b = 0; b < 128; b++) any |= bs_has(s, b);
     if (any) alts.push_back(mk_bytes(s));
     if (wide.size() == 1 && wide[0].first == 128 && wide[0].second == 0x10FFFF) alts.push_back(multibyte());
+    else if (wide.size() > 24) alts.push_back(class_trie(wide));      // \w, \W, \D, [^…] of those: one shared automaton instead of a thousand sequences
     else for (auto& r : wide) utf8_range_items(r.first, r.second, alts);
     if (alts.empty()) return mk_bytes(ByteSet{});     // a class nothing can match
     return mk_alt(alts);
@@ -504,7 +591,7 @@ struct NState {
 struct Nfa {
   std::vector<NState> st;
   int add(NState::Kind k) {
-    if (st.size() > 6000) throw CometError("RLIKE pattern is too large for the MI355X native engine (more than 6000 automaton states)");
+    if (st.size() > 40000) throw CometError("RLIKE pattern is too large for the MI355X native engine (more than 40000 automaton states)");
     NState s;
     s.kind = k;
     st.push_back(s);
@@ -525,6 +612,28 @@ int build(Nfa& nfa, const NodeP& n, int next) {
       const int s = nfa.add(n->kind == Node::Bol ? NState::Bol : NState::Eol);
       nfa.st[(size_t)s].out = next;
       return s;
+    }
+    case Node::Trie: {
+      std::vector<int> entry(n->trie.size(), -1);
+      std::function<int(int)> make = [&](int k) -> int {
+        if (entry[(size_t)k] >= 0) return entry[(size_t)k];
+        int cur = -1;
+        for (auto& e : n->trie[(size_t)k].edges) {
+          const int b = nfa.add(NState::Byte);
+          nfa.st[(size_t)b].set = e.first;
+          const int to = e.second < 0 ? next : make(e.second);
+          nfa.st[(size_t)b].out = to;
+          if (cur < 0) cur = b;
+          else {
+            const int sp = nfa.add(NState::Split);
+            nfa.st[(size_t)sp].out = b;
+            nfa.st[(size_t)sp].out2 = cur;
+            cur = sp;
+          }
+        }
+        return entry[(size_t)k] = cur;
+      };
+      return make(0);
     }
     case Node::Cat: {
       int cur = next;
@@ -568,20 +677,37 @@ int build(Nfa& nfa, const NodeP& n, int next) {
   return next;
 }
 
-void closure(const Nfa& nfa, std::vector<int>& stack, std::set<int>& seen, bool at_start, bool at_end) {
-  while (!stack.empty()) {
-    const int s = stack.back();
-    stack.pop_back();
-    if (s < 0 || !seen.insert(s).second) continue;
-    const NState& st = nfa.st[(size_t)s];
-    switch (st.kind) {
-      case NState::Split: stack.push_back(st.out); stack.push_back(st.out2); break;
-      case NState::Bol: if (at_start) stack.push_back(st.out); break;
-      case NState::Eol: if (at_end) stack.push_back(st.out); break;
-      default: break;
+// (sorted vectors and a visited array: the sets of a \\w pattern hold hundreds of states, and std::set made its construction take seconds)
+typedef std::vector<int> StateSet;
+struct Closer {
+  const Nfa& nfa;
+  std::vector<char> mark;
+  std::vector<int> stack;
+  explicit Closer(const Nfa& n) : nfa(n), mark(n.st.size(), 0) {}
+  StateSet run(const StateSet& core, int extra, bool at_start, bool at_end) {
+    StateSet out;
+    stack.assign(core.begin(), core.end());
+    if (extra >= 0) stack.push_back(extra);
+    while (!stack.empty()) {
+      const int s = stack.back();
+      stack.pop_back();
+      if (s < 0 || mark[(size_t)s]) continue;
+      mark[(size_t)s] = 1;
+      out.push_back(s);
+      const NState& st = nfa.st[(size_t)s];
+      switch (st.kind) {
+        case NState::Split: stack.push_back(st.out); stack.push_back(st.out2); break;
+        case NState::Bol: if (at_start) stack.push_back(st.out); break;
+        case NState::Eol: if (at_end) stack.push_back(st.out); break;
+        default: break;
+      }
     }
+    for (int s2 : out) mark[(size_t)s2] = 0;
+    std::sort(out.begin(), out.end());
+    return out;
   }
-}
+};
+bool has_state(const StateSet& s, int x) { return std::binary_search(s.begin(), s.end(), x); }
 
 }  // namespace
 
@@ -593,58 +719,79 @@ RegexDfa compile_rlike(const std::string& pattern) {
   const int match = nfa.add(NState::Match);
   const int start = build(nfa, ast, match);
 
-  auto closed = [&](const std::set<int>& core, bool inject_start, bool at_start, bool at_end) {
-    std::vector<int> stack(core.begin(), core.end());
-    if (inject_start) stack.push_back(start);
-    std::set<int> seen;
-    closure(nfa, stack, seen, at_start, at_end);
-    return seen;
-  };
+  Closer closer(nfa);
+  auto closed = [&](const StateSet& core, bool inject_start, bool at_start, bool at_end) { return closer.run(core, inject_start ? start : -1, at_start, at_end); };
   RegexDfa dfa;
-  std::map<std::pair<std::set<int>, bool>, int> ids;
-  std::vector<std::set<int>> sets;
+  // bytes that every Byte state treats alike step alike: the construction (and the table) work on those classes
+  {
+    std::map<std::vector<bool>, int> sig_id;
+    std::vector<const ByteSet*> sets_seen;
+    std::set<ByteSet> uniq;
+    for (const NState& st : nfa.st)
+      if (st.kind == NState::Byte) uniq.insert(st.set);
+    dfa.classes.assign(256, 0);
+    for (int b = 0; b < 256; b++) {
+      std::vector<bool> sig;
+      sig.reserve(uniq.size() + 1);
+      for (const ByteSet& u : uniq) sig.push_back(bs_has(u, b));
+      sig.push_back(ps.multiline && b == '\n');
+      auto it = sig_id.find(sig);
+      if (it == sig_id.end()) it = sig_id.emplace(sig, (int)sig_id.size()).first;
+      dfa.classes[(size_t)b] = (uint8_t)it->second;
+    }
+    dfa.nclasses = (int)sig_id.size();
+  }
+  std::vector<int> class_byte((size_t)dfa.nclasses, 0);
+  for (int b = 255; b >= 0; b--) class_byte[dfa.classes[(size_t)b]] = b;
+  const size_t NC = (size_t)dfa.nclasses;
+  std::map<std::pair<StateSet, bool>, int> ids;
+  std::vector<StateSet> sets;
   std::vector<bool> initial;                         // ^ is passable in this state: before the first byte, or (?m) right behind a \n
-  auto intern = [&](const std::set<int>& s, bool is_initial, bool line_start = false) {
+  auto intern = [&](const StateSet& s, bool is_initial, bool line_start = false) {
     auto it = ids.find({s, line_start});
     if (it != ids.end() && !is_initial) return it->second;
-    if (sets.size() >= 200) throw CometError("RLIKE pattern '" + pattern + "' needs more than 200 automaton states: not supported by the MI355X native engine");
+    if (sets.size() >= 4096) throw CometError("RLIKE pattern '" + pattern + "' needs more than 4096 automaton states: not supported by the MI355X native engine");
     const int id = (int)sets.size();
     if (!is_initial) ids[{s, line_start}] = id;
     sets.push_back(s);
     initial.push_back(is_initial || line_start);
     return id;
   };
-  intern(closed({}, true, true, false), true);      // state 0: before the first byte (^ passable)
+  intern(closed(StateSet(), true, true, false), true);      // state 0: before the first byte (^ passable)
   for (size_t cur = 0; cur < sets.size(); cur++) {
-    const std::set<int> S = sets[cur];              // (copy: `sets` grows below)
+    const StateSet S = sets[cur];                   // (copy: `sets` grows below)
     uint8_t flags = 0;
-    if (S.count(match)) flags |= 1;
+    if (has_state(S, match)) flags |= 1;
     // end of text here: $ becomes passable; the start state may still be injected (an empty remainder can match, e.g. "x*$")
-    if (closed(S, true, initial[cur], true).count(match)) flags |= 2;
+    if (has_state(closed(S, true, initial[cur], true), match)) flags |= 2;
     dfa.flags.push_back(flags);
-    dfa.trans.resize((cur + 1) * 256, 0);
+    dfa.trans.resize((cur + 1) * NC * 2, 0);
     if (flags & 1) continue;                        // absorbing: the kernel has already answered true
     // (?m): in front of a \n byte `$` is passable (so that byte steps from the set closed that way — a set that already holds MATCH answers
     // true at once), and behind it `^` is
-    const std::set<int> S_eol = ps.multiline ? closed(S, true, initial[cur], true) : std::set<int>();
-    for (int b = 0; b < 256; b++) {
+    const StateSet S_eol = ps.multiline ? closed(S, true, initial[cur], true) : StateSet();
+    // the Byte states of the set, once (not once per class)
+    std::vector<const NState*> byte_states, byte_states_eol;
+    for (int s2 : S) if (nfa.st[(size_t)s2].kind == NState::Byte) byte_states.push_back(&nfa.st[(size_t)s2]);
+    for (int s2 : S_eol) if (nfa.st[(size_t)s2].kind == NState::Byte) byte_states_eol.push_back(&nfa.st[(size_t)s2]);
+    for (size_t bc = 0; bc < NC; bc++) {
+      const int b = class_byte[bc];
       const bool nl = ps.multiline && b == '\n';
       int to;
-      if (nl && S_eol.count(match)) {
-        to = intern(std::set<int>{match}, false);
+      if (nl && has_state(S_eol, match)) {
+        to = intern(StateSet{match}, false);
       } else {
-        std::set<int> core;
-        for (int s : (nl ? S_eol : S)) {
-          const NState& st = nfa.st[(size_t)s];
-          if (st.kind == NState::Byte && bs_has(st.set, b)) core.insert(st.out);
-        }
+        StateSet core;
+        for (const NState* st : (nl ? byte_states_eol : byte_states))
+          if (bs_has(st->set, b)) core.push_back(st->out);
         to = intern(closed(core, true, nl, false), false, nl);
       }
-      dfa.trans[cur * 256 + (size_t)b] = (uint8_t)to;
+      dfa.trans[(cur * NC + bc) * 2] = (uint8_t)(to & 0xff);
+      dfa.trans[(cur * NC + bc) * 2 + 1] = (uint8_t)(to >> 8);
     }
   }
   dfa.nstates = (int)sets.size();
-  dfa.trans.resize((size_t)dfa.nstates * 256, 0);
+  dfa.trans.resize((size_t)dfa.nstates * NC * 2, 0);
   return dfa;
 }
 
@@ -652,7 +799,7 @@ bool regex_dfa_match(const RegexDfa& d, const uint8_t* s, size_t n) {
   int st = 0;
   if (d.flags[0] & 1) return true;
   for (size_t k = 0; k < n; k++) {
-    st = d.trans[(size_t)st * 256 + s[k]];
+    st = d.next(st, s[k]);
     if (d.flags[(size_t)st] & 1) return true;
   }
   return (d.flags[(size_t)st] & 2) != 0;

@@ -7,9 +7,15 @@
 namespace comet {
 
 struct RegexDfa {
-  int nstates = 0;                 // ≤ 200; state 0 = before the first byte
-  std::vector<uint8_t> trans;      // [nstates][256] next state
+  int nstates = 0;                 // ≤ 4096; state 0 = before the first byte
+  int nclasses = 0;                // bytes that no state tells apart share a class
+  std::vector<uint8_t> classes;    // [256] class of a byte
+  std::vector<uint8_t> trans;      // [nstates][nclasses] next state, 16 bits little-endian each
   std::vector<uint8_t> flags;      // bit 0: a match has been found (absorbing); bit 1: a match if the text ends here
+  int next(int state, uint8_t byte) const {
+    const size_t at = ((size_t)state * (size_t)nclasses + classes[byte]) * 2;
+    return trans[at] | (trans[at + 1] << 8);
+  }
 };
 // throws CometError naming the construct for anything outside the subset
 RegexDfa compile_rlike(const std::string& pattern);

@@ -213,7 +213,7 @@ def test_leading_case_insensitive_flag(built, pattern, values):
         assert native.rlike_match(pattern, v) == want(inner, simple_fold(v)), (pattern, v)
 
 
-@pytest.mark.parametrize("pattern,why", [("\\d+", "escape"), ("\\w", "escape"), ("[\\S]", "escape"), ("[\\d]", "escape"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?x)a b", "group flags"), ("(?m)\\Aa", "under"), ("(?U)a", "group flags"), ("a\\Z", "escape"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
+@pytest.mark.parametrize("pattern,why", [("[\\S]", "escape"), ("[\\D]", "escape"), ("[\\W]", "escape"), ("(?i)[\\w]", "under"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?x)a b", "group flags"), ("(?m)\\Aa", "under"), ("(?U)a", "group flags"), ("a\\Z", "escape"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
                                          ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[z-a]", "reversed"), ("[[:^alpha:]]", "POSIX"), ("[[:alfa:]]", "POSIX"), ("[a[b]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
                                          ("\\p{L}", "escape"), ("\\xZ1", "hexadecimal"), ("\\x{110000}", "scalar value"), ("\\uD800", "scalar value"), ("\\u12", "hexadecimal"),
@@ -223,6 +223,40 @@ def test_leading_case_insensitive_flag(built, pattern, values):
 def test_constructs_the_reference_reads_differently_are_refused(built, pattern, why):
     with pytest.raises(native.CometNativeException, match="not supported"):
         native.rlike_match(pattern, "abc")
+
+
+def _rust_word_string(v):
+    """v is one or more \\w characters — decided by the Rust regex crate itself: the `tokenizers` wheel's Whitespace pre-tokenizer splits with
+    the crate's `\\w+|[^\\w\\s]+`, so "a" + v + "a" stays one token exactly when every character of v is a word character"""
+    from tokenizers.pre_tokenizers import Whitespace
+    return len(v) > 0 and len(Whitespace().pre_tokenize_str("a" + v + "a")) == 1
+
+
+def test_perl_classes_are_the_crates_unicode_16_tables(built):
+    """\\d \\D \\w \\W and \\d / \\w inside classes (regex_unicode_tables.hpp, generated by tools/gen_regex_tables.py from the Rust crate inside the
+    tokenizers wheel).  Referees: that crate for \\w (through the wheel), the `regex` module's \\p{Nd} for \\d — which knows Unicode 17, so the ten
+    TOLONG SIKI digits it added are expected NOT to match."""
+    import regex
+    rng = random.Random(99)
+    pool = ["a", "Z", "_", "0", "9", "-", " ", ".", "é", "ß", "日", "٣", "५", "\u200c", "\u200d", "\u0301", "‿", "\U00016D70", "\U00010D4A", "\U00011DE0", "\U00011DB0",
+            "\U0001F600", "\u2028", "€", "\u0378", "\U000E01EF", "\U0010FFFF", "\uFFFD", "ǅ", "Ⅷ", "²"]
+    new_in_17 = {"\U00011DE0", "\U00011DB0"}
+    values = ["".join(rng.choice(pool) for _ in range(rng.randrange(0, 6))) for _ in range(1500)] + pool + [""]
+    nd = regex.compile(r"\p{Nd}")
+    is_digit = lambda ch: ch not in new_in_17 and nd.fullmatch(ch) is not None
+    for v in values:
+        word = [_rust_word_string(ch) for ch in v]
+        digit = [is_digit(ch) for ch in v]
+        assert native.rlike_match(r"^\w+$", v) == (len(v) > 0 and all(word)), repr(v)
+        assert native.rlike_match(r"\W", v) == (not all(word)), repr(v)
+        assert native.rlike_match(r"\d", v) == any(digit), repr(v)
+        assert native.rlike_match(r"^\D*$", v) == (not any(digit)), repr(v)
+        assert native.rlike_match(r"^[\w.-]+$", v) == (len(v) > 0 and all(w or ch in ".-" for w, ch in zip(word, v))), repr(v)
+        assert native.rlike_match(r"^[^\d\s]+$", v) == (len(v) > 0 and not any(d or ch in " \u2028" for d, ch in zip(digit, v))), repr(v)
+        assert native.rlike_match(r"(?i)^\w+x$", v + "X") == (len(v) > 0 and all(word)), repr(v)
+    # every digit is a word character; the classes' sizes are Unicode 16.0's
+    assert native.rlike_match(r"^\d{3}-\d{4}$", "555-0199") and native.rlike_match(r"^\d{3}-\d{4}$", "५५५-०१९९") and not native.rlike_match(r"^\d{3}-\d{4}$", "555-019")
+    assert native.rlike_match(r"^\w+@\w+\.\w+$", "jürgen@müller.de") and not native.rlike_match(r"^\w+@\w+\.\w+$", "a b@c.d")
 
 
 def test_garbage_patterns_fail_cleanly(built):

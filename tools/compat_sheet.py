@@ -83,10 +83,10 @@ def probes():
         "Add": (S.math("add", i64, L(1, S.T_INT64), S.T_INT64), "integers, floats, decimals (narrow and 256-bit wide path)"),
         "Subtract": (S.math("subtract", dec, dec, S.decimal(13, 2)), ""), "Multiply": (S.math("multiply", dec, dec, S.decimal(25, 4)), ""),
         "Divide": (S.math("divide", f64, L(2.0, S.T_DOUBLE), S.T_DOUBLE), "floats and decimals"),
-        "Remainder": (S.math("remainder", i64, L(7, S.T_INT64), S.T_INT64), "integers and floats; DECIMAL remainder is refused"),
+        "Remainder": (S.math("remainder", i64, L(7, S.T_INT64), S.T_INT64), "integers, floats and decimals"),
         "IntegralDivide": (S.integral_divide(i64, S.T_INT64, L(3, S.T_INT64), S.T_INT64), "integers and decimals"),
         "UnaryMinus": (S.Expr("unary_minus", [i64]), ""),
-        "Cast": (S.cast(i32, S.T_INT64), "the numeric matrix (integers, floats, decimals, booleans); casts to / from strings and timestamps are REFUSED"),
+        "Cast": (S.cast(i32, S.T_INT64), "the numeric matrix; string -> boolean / integers / decimal / date; integers, booleans, decimals, dates and timestamps -> string (output columns); date <-> timestamp <-> bigint in any time zone; string -> float / timestamp and float -> string are REFUSED"),
         "CheckOverflow": (S.check_overflow(S.math("add", dec, dec, S.decimal(13, 2)), S.decimal(13, 2)), ""),
         "EqualTo": (S.eq(i32, L(1, S.T_INT32)), "all flat types incl. Utf8 of any length"), "EqualNullSafe": (S.eq_null_safe(i32, L(1, S.T_INT32)), ""),
         "GreaterThan": (S.gt(d, L(9000, S.T_DATE)), ""), "GreaterThanOrEqual": (S.gt_eq(f64, L(0.5, S.T_DOUBLE)), ""), "LessThan": (S.lt(dec, dec), ""),
@@ -95,7 +95,10 @@ def probes():
         "In": (S.in_(i32, [L(1, S.T_INT32), L(2, S.T_INT32)]), ""), "InSet": (S.in_(s, [L("a", S.T_STRING), L("b", S.T_STRING)]), "serialized like In"),
         "CaseWhen": (S.case_when([(S.gt(i32, L(0, S.T_INT32)), i64)], L(0, S.T_INT64)), ""), "If": (S.if_(b, i64, L(0, S.T_INT64)), ""),
         "Coalesce": (f("coalesce", [i64, L(0, S.T_INT64)], S.T_INT64), ""),
-        "Like": (S.like(s, L("a%_b", S.T_STRING)), "% and _, backslash escapes"), "RLike": (S.rlike(s, L("^ab+c$", S.T_STRING)), "the byte-exact subset; \\d \\w \\b and Unicode classes refused by name"),
+        "Concat": (f("concat", [s, L("-", S.T_STRING), s], S.T_STRING), "Utf8 columns and literals, as an output column"),
+        "Hour": (S.time_part("hour", S.cast(d, S.T_TIMESTAMP)), "any time zone of the database"), "Minute": (S.time_part("minute", S.cast(d, S.T_TIMESTAMP)), ""),
+        "Second": (S.time_part("second", S.cast(d, S.T_TIMESTAMP)), ""),
+        "Like": (S.like(s, L("a%_b", S.T_STRING)), "% and _, backslash escapes"), "RLike": (S.rlike(s, L("^ab+c$", S.T_STRING)), "the byte-exact subset incl. \\d \\w (Unicode 16 tables of the crate); \\b and \\p{..} refused by name"),
         "StartsWith": (f("starts_with", [s, L("ab", S.T_STRING)], S.T_BOOL), ""), "EndsWith": (f("ends_with", [s, L("ab", S.T_STRING)], S.T_BOOL), ""),
         "Contains": (f("contains", [s, L("ab", S.T_STRING)], S.T_BOOL), ""),
         "Substring": (f("substring", [s, L(2, S.T_INT32), L(3, S.T_INT32)], S.T_STRING), "literal bounds"), "Left": (f("substring", [s, L(1, S.T_INT32), L(3, S.T_INT32)], S.T_STRING), "serialized as Substring"),
@@ -189,9 +192,11 @@ def render() -> str:
     w("")
     w("## 4. Refusals below the class level (what `comet_check_plan` is for)")
     w("")
-    w("* `Cast`: to / from strings and timestamps; on a device-resident input ANY type mismatch with the declared Scan fields.")
-    w("* `Remainder` of decimals; `Min` / `Max` of decimal(> 18) in grouped aggregates; more than four Float64 sums / averages in one aggregate.")
-    w("* `RLike`: patterns outside the byte-exact subset (`\\\\d \\\\w \\\\b`, Unicode classes, scoped flags, look-around) are refused by name.")
+    w("* `Cast`: string -> float / timestamp, float -> string, casts of a COMPUTED string; a cast to string is an output column (not an operand); on a")
+    w("  device-resident input ANY type mismatch with the declared Scan fields.  Time zones come from the system's database ($TZDIR, /usr/share/zoneinfo).")
+    w("* `Min` / `Max` of decimal(> 18) in grouped aggregates; more than four Float64 sums / averages in one aggregate.")
+    w("* `RLike`: patterns outside the byte-exact subset (`\\\\b`, `\\\\p{..}`, scoped flags, look-around) are refused by name.")
+    w("* `Concat`: of Utf8 columns and literals (at most eight), as an output column.")
     w("* Computed Utf8 values used as operands of further expressions must fit 15 bytes (literals, substring, CASE over those).")
     w("* Window: RANGE frames with value offsets over non-integer keys, floating-point aggregates over frames, MIN / MAX over sliding frames wider")
     w("  than 4096 rows, lag / lead defaults of Utf8 / Boolean type.")
