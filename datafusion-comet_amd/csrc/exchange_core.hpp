@@ -203,7 +203,10 @@ void run(Ops& ops, Transport& t, int32_t n_cols, const CometExchangeColumn* cols
         std::vector<int32_t> at((size_t)world + 1, 0);
         ops.read_i32_at((const int32_t*)send_offs.p, starts.data(), world + 1, at.data());    // byte offset at every partition start
         for (int p = 0; p <= world; p++) bstarts[(size_t)p] = at[(size_t)p];
-        if (bstarts[(size_t)world] < 0) throw Error("exchange: Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+        // (`idx` is a permutation of the column's rows and the column's own offsets are 32-bit, so the lengths sum to less than 2^31 and the
+        // 32-bit prefix sums cannot wrap; the partition starts are checked all the same — ADVICE r3)
+        for (int p = 0; p < world; p++)
+          if (bstarts[(size_t)p] < 0 || bstarts[(size_t)p + 1] < bstarts[(size_t)p]) throw Error("exchange: Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
       }
       send_buf.ensure((size_t)(bstarts[(size_t)world] > 0 ? bstarts[(size_t)world] : 1) + 16);
       if (rows > 0) ops.take_utf8_copy(offs, cols[i].aux, (const uint32_t*)idx.p, cols[i].validity, rows, (const int32_t*)send_offs.p, (uint8_t*)send_buf.p);

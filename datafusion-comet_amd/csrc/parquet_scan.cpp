@@ -1210,6 +1210,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       job.src_len = (int32_t)comp_len;
       job.dst_len = (int32_t)un_len;
       job.preamble = comet_snappy2::preamble_length(body + comp_off, (int32_t)comp_len);     // where the stream's first element starts
+      if (job.preamble <= 0) throw CometError("parquet: malformed snappy page (length preamble)");      // (rejected here like the dictionary page's, not left to the device kernel)
       job.pad = 0;
       hc.inflate.push_back(job);
       if (!in_place) spos = cpos + comp_len;
