@@ -51,7 +51,7 @@ typedef std::shared_ptr<Node> NodeP;
 // node 0 is the entry; an edge leads to another node or (−1) to the class's end
 struct TrieNode { std::vector<std::pair<ByteSet, int>> edges; };
 struct Node {
-  enum Kind { Bytes, Cat, Alt, Repeat, Bol, Eol, Empty, Trie } kind = Empty;
+  enum Kind { Bytes, Cat, Alt, Repeat, Bol, Eol, Empty, Trie, WordB, NotWordB } kind = Empty;
   ByteSet set{};
   std::vector<NodeP> kids;
   int min = 0, max = -1;   // Repeat: max −1 = unbounded
@@ -169,6 +169,7 @@ struct Parser {
   bool icase = false;     // a leading (?i)
   bool dotall = false;    // a leading (?s): `.` matches \n too
   bool multiline = false; // a leading (?m): ^ also matches after a \n, $ also before one
+  bool has_wordb = false; // the pattern holds \b / \B
   explicit Parser(const std::string& s) : p(s) {
     // leading flags (?i) (?s) (?m), alone or combined: they hold for the whole pattern
     if (p.compare(0, 2, "(?") == 0) {
@@ -366,6 +367,13 @@ struct Parser {
         i += 2;
         return finish_class(ws, wide, negate, true);
       }
+      if (p[i + 1] == 'b' || p[i + 1] == 'B') {                       // Unicode word boundary / not a word boundary
+        if (multiline) fail("\\b under (?m)");
+        has_wordb = true;
+        const bool nb = p[i + 1] == 'B';
+        i += 2;
+        return mk(nb ? Node::NotWordB : Node::WordB);
+      }
       if (p[i + 1] == 'd' || p[i + 1] == 'D' || p[i + 1] == 'w' || p[i + 1] == 'W') {
         ByteSet as{};
         std::vector<std::pair<int, int>> wide;
@@ -375,7 +383,7 @@ struct Parser {
         return finish_class(as, wide, negate, true);
       }
       const int b = simple_escape(p[i + 1]);
-      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (\\b and the \\p{…} classes are not reproduced; back-references do not exist in the reference)");
+      if (b < 0) fail(std::string("the escape \\") + p[i + 1] + " (the \\p{…} classes are not reproduced; back-references do not exist in the reference)");
       i += 2;
       ByteSet s{};
       bs_add(s, b);
@@ -584,7 +592,7 @@ struct Parser {
 
 // ---- Thompson NFA ----
 struct NState {
-  enum Kind { Byte, Split, Bol, Eol, Match } kind = Match;
+  enum Kind { Byte, Split, Bol, Eol, Match, WordB, NotWordB } kind = Match;
   ByteSet set{};
   int out = -1, out2 = -1;
 };
@@ -610,6 +618,11 @@ int build(Nfa& nfa, const NodeP& n, int next) {
     }
     case Node::Bol: case Node::Eol: {
       const int s = nfa.add(n->kind == Node::Bol ? NState::Bol : NState::Eol);
+      nfa.st[(size_t)s].out = next;
+      return s;
+    }
+    case Node::WordB: case Node::NotWordB: {
+      const int s = nfa.add(n->kind == Node::WordB ? NState::WordB : NState::NotWordB);
       nfa.st[(size_t)s].out = next;
       return s;
     }
@@ -709,6 +722,186 @@ struct Closer {
 };
 bool has_state(const StateSet& s, int x) { return std::binary_search(s.begin(), s.end(), x); }
 
+// ---- patterns with \b / \B ----
+// A word boundary looks at the character BEFORE the position and the one BEHIND it (Unicode \w, the text's ends count as non-word).  Over
+// bytes: the automaton carries, beside its threads, a classifier of the character it is inside of (the \w automaton: which node, or "not a
+// word character, k bytes to go") and whether the last complete character was a word character.  A thread that passes \b at a character
+// boundary knows the left side and is TAGGED with what the right side has to be (1: a word character, 2: anything else or the end); when the
+// classifier completes the next character the tags are checked and dropped.  Threads are numbered state·3 + tag.
+struct WordClassifier {
+  std::vector<TrieNode> trie;      // multi-byte \w
+  std::vector<int> rem;            // bytes still to come below each node
+  ByteSet ascii{};
+  int nonword_base = 0;            // cs ≥ nonword_base: not a word character, cs − nonword_base + 1 continuation bytes to go
+  WordClassifier() {
+    std::vector<std::pair<int, int>> wide;
+    Parser::add_perl_class('w', ascii, wide);
+    trie = class_trie(wide)->trie;
+    rem.assign(trie.size(), 0);
+    std::function<int(int)> depth = [&](int k) -> int {
+      if (rem[(size_t)k]) return rem[(size_t)k];
+      const int to = trie[(size_t)k].edges[0].second;
+      return rem[(size_t)k] = 1 + (to < 0 ? 0 : depth(to));
+    };
+    for (size_t k = 0; k < trie.size(); k++) depth((int)k);
+    nonword_base = (int)trie.size() + 1;
+  }
+  // cs: 0 = between characters; 1 + node = inside a character that may still be a word character.  → the next cs; `done` / `word` when the byte ends a character
+  int step(int cs, int b, bool& done, bool& word) const {
+    done = false;
+    word = false;
+    if (cs >= nonword_base) {
+      const int left = cs - nonword_base;      // continuation bytes behind this one
+      if (left == 0) { done = true; return 0; }
+      return cs - 1;
+    }
+    if (cs == 0 && b < 0x80) { done = true; word = bs_has(ascii, b); return 0; }
+    if (cs == 0 && (b < 0xC2 || b > 0xF4)) { done = true; return 0; }      // (never in valid UTF-8: a character of its own, not a word character)
+    const int node = cs == 0 ? 0 : cs - 1;
+    for (auto& e : trie[(size_t)node].edges)
+      if (bs_has(e.first, b)) {
+        if (e.second < 0) { done = true; word = true; return 0; }
+        return e.second + 1;
+      }
+    const int left = cs == 0 ? (b >= 0xF0 ? 3 : b >= 0xE0 ? 2 : 1) : rem[(size_t)node] - 1;
+    if (left == 0) { done = true; return 0; }
+    return nonword_base + left - 1;
+  }
+};
+
+RegexDfa compile_with_word_boundaries(const std::string& pattern, const Nfa& nfa, int start, int match) {
+  static const WordClassifier wc;
+  RegexDfa dfa;
+  {
+    std::set<ByteSet> uniq;
+    for (const NState& st : nfa.st)
+      if (st.kind == NState::Byte) uniq.insert(st.set);
+    for (const TrieNode& t : wc.trie)
+      for (auto& e : t.edges) uniq.insert(e.first);
+    uniq.insert(wc.ascii);
+    for (int lim : {0x80, 0xC2, 0xE0, 0xF0, 0xF5}) uniq.insert(bs_range(0, lim - 1));
+    std::map<std::vector<bool>, int> sig_id;
+    dfa.classes.assign(256, 0);
+    for (int b = 0; b < 256; b++) {
+      std::vector<bool> sig;
+      for (const ByteSet& u : uniq) sig.push_back(bs_has(u, b));
+      auto it = sig_id.find(sig);
+      if (it == sig_id.end()) it = sig_id.emplace(sig, (int)sig_id.size()).first;
+      dfa.classes[(size_t)b] = (uint8_t)it->second;
+    }
+    dfa.nclasses = (int)sig_id.size();
+  }
+  const size_t NC = (size_t)dfa.nclasses;
+  std::vector<int> class_byte(NC, 0);
+  for (int b = 255; b >= 0; b--) class_byte[dfa.classes[(size_t)b]] = b;
+
+  std::vector<char> mark(nfa.st.size() * 3, 0);
+  std::vector<int> stack;
+  // closure of tagged threads.  boundary: between characters (only there \b can be passed); prev_word: the character before; at_end: the text ends here
+  auto closed = [&](const StateSet& core, bool inject, bool boundary, bool prev_word, bool at_start, bool at_end) {
+    StateSet out;
+    stack.assign(core.begin(), core.end());
+    if (inject) stack.push_back(start * 3);
+    while (!stack.empty()) {
+      const int t = stack.back();
+      stack.pop_back();
+      if (t < 0 || mark[(size_t)t]) continue;
+      mark[(size_t)t] = 1;
+      out.push_back(t);
+      const int sidx = t / 3, tag = t % 3;
+      const NState& st = nfa.st[(size_t)sidx];
+      switch (st.kind) {
+        case NState::Split: stack.push_back(st.out * 3 + tag); stack.push_back(st.out2 * 3 + tag); break;
+        case NState::Bol: if (at_start) stack.push_back(st.out * 3 + tag); break;
+        case NState::Eol: if (at_end && tag != 1) stack.push_back(st.out * 3); break;        // the end is "not a word character"
+        case NState::WordB: case NState::NotWordB: {
+          if (!boundary) break;
+          const bool want_differ = st.kind == NState::WordB;
+          if (at_end) {
+            if (tag == 1) break;
+            if ((prev_word != false) == want_differ) stack.push_back(st.out * 3);
+            break;
+          }
+          const int need = (want_differ ? !prev_word : prev_word) ? 1 : 2;
+          if (tag == 0 || tag == need) stack.push_back(st.out * 3 + need);
+          break;
+        }
+        default: break;
+      }
+    }
+    for (int t : out) mark[(size_t)t] = 0;
+    std::sort(out.begin(), out.end());
+    return out;
+  };
+  struct Key {
+    StateSet set; int cs; bool prev_word;
+    bool operator<(const Key& o) const { return cs != o.cs ? cs < o.cs : prev_word != o.prev_word ? prev_word < o.prev_word : set < o.set; }
+  };
+  std::map<Key, int> ids;
+  std::vector<Key> keys;
+  auto intern = [&](Key k, bool is_initial) {
+    if (!is_initial) {
+      auto it = ids.find(k);
+      if (it != ids.end()) return it->second;
+    }
+    if (keys.size() >= 4096) throw CometError("RLIKE pattern '" + pattern + "' needs more than 4096 automaton states: not supported by the MI355X native engine");
+    const int id = (int)keys.size();
+    if (!is_initial) ids[k] = id;
+    keys.push_back(std::move(k));
+    return id;
+  };
+  intern(Key{closed(StateSet(), true, true, false, true, false), 0, false}, true);      // state 0: before the first byte
+  for (size_t cur = 0; cur < keys.size(); cur++) {
+    const Key K = keys[cur];
+    const bool initial = cur == 0;
+    uint8_t flags = 0;
+    if (has_state(K.set, match * 3)) flags |= 1;        // (an untagged MATCH: a tagged one still waits for the character behind it)
+    if (K.cs == 0) {
+      // the text ends here: tags asking for "no word character" are met, the others die; $ and \b read the end
+      StateSet core;
+      for (int t : K.set)
+        if (t % 3 != 1) core.push_back(t - t % 3);
+      if (has_state(closed(core, true, true, K.prev_word, initial, true), match * 3)) flags |= 2;
+    }
+    dfa.flags.push_back(flags);
+    dfa.trans.resize((cur + 1) * NC * 2, 0);
+    if (flags & 1) continue;
+    for (size_t bc = 0; bc < NC; bc++) {
+      const int b = class_byte[bc];
+      bool done = false, word = false;
+      const int cs2 = wc.step(K.cs, b, done, word);
+      StateSet core;
+      for (int t : K.set) {
+        const NState& st = nfa.st[(size_t)(t / 3)];
+        if (st.kind != NState::Byte || !bs_has(st.set, b)) continue;
+        int tag = t % 3;
+        if (done && tag != 0) {
+          if ((tag == 1) != word) continue;       // the character behind the boundary is not what the thread needed
+          tag = 0;
+        }
+        core.push_back(st.out * 3 + tag);
+      }
+      if (done) {
+        // a MATCH that waited for this character
+        for (int t : K.set)
+          if (t / 3 == match && t % 3 != 0 && ((t % 3 == 1) == word)) core.push_back(match * 3);
+      } else {
+        for (int t : K.set)
+          if (t / 3 == match && t % 3 != 0) core.push_back(t);
+      }
+      std::sort(core.begin(), core.end());
+      core.erase(std::unique(core.begin(), core.end()), core.end());
+      const bool pw = done ? word : K.prev_word;
+      const int to = intern(Key{closed(core, true, done, pw, false, false), cs2, pw}, false);
+      dfa.trans[(cur * NC + bc) * 2] = (uint8_t)(to & 0xff);
+      dfa.trans[(cur * NC + bc) * 2 + 1] = (uint8_t)(to >> 8);
+    }
+  }
+  dfa.nstates = (int)keys.size();
+  dfa.trans.resize((size_t)dfa.nstates * NC * 2, 0);
+  return dfa;
+}
+
 }  // namespace
 
 RegexDfa compile_rlike(const std::string& pattern) {
@@ -718,6 +911,7 @@ RegexDfa compile_rlike(const std::string& pattern) {
   Nfa nfa;
   const int match = nfa.add(NState::Match);
   const int start = build(nfa, ast, match);
+  if (ps.has_wordb) return compile_with_word_boundaries(pattern, nfa, start, match);
 
   Closer closer(nfa);
   auto closed = [&](const StateSet& core, bool inject_start, bool at_start, bool at_end) { return closer.run(core, inject_start ? start : -1, at_start, at_end); };

@@ -213,7 +213,7 @@ def test_leading_case_insensitive_flag(built, pattern, values):
         assert native.rlike_match(pattern, v) == want(inner, simple_fold(v)), (pattern, v)
 
 
-@pytest.mark.parametrize("pattern,why", [("[\\S]", "escape"), ("[\\D]", "escape"), ("[\\W]", "escape"), ("(?i)[\\w]", "under"), ("a\\b", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?x)a b", "group flags"), ("(?m)\\Aa", "under"), ("(?U)a", "group flags"), ("a\\Z", "escape"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
+@pytest.mark.parametrize("pattern,why", [("[\\S]", "escape"), ("[\\D]", "escape"), ("[\\W]", "escape"), ("(?i)[\\w]", "under"), ("[\\b]", "escape"), ("a(?i)bc", "group flags"), ("(?i:ab)c", "group flags"), ("(?x)a b", "group flags"), ("(?m)\\Aa", "under"), ("(?U)a", "group flags"), ("a\\Z", "escape"), ("(?i)café", "non-ASCII"), ("(?i)[é]", "non-ASCII"), ("(?P<n>a)", "group flags"),
                                          ("(?=a)", "group flags"), ("(a)\\1", "escape"), ("[z-a]", "reversed"), ("[[:^alpha:]]", "POSIX"), ("[[:alfa:]]", "POSIX"), ("[a[b]]", "nested"), ("a{100}", "repetition"),
                                          ("a++", "possessive"), ("*a", "nothing to repeat"), ("(a", "unclosed"), ("a)", "unmatched"), ("[a", "unclosed"),
                                          ("\\p{L}", "escape"), ("\\xZ1", "hexadecimal"), ("\\x{110000}", "scalar value"), ("\\uD800", "scalar value"), ("\\u12", "hexadecimal"),
@@ -257,6 +257,62 @@ def test_perl_classes_are_the_crates_unicode_16_tables(built):
     # every digit is a word character; the classes' sizes are Unicode 16.0's
     assert native.rlike_match(r"^\d{3}-\d{4}$", "555-0199") and native.rlike_match(r"^\d{3}-\d{4}$", "५५५-०१९९") and not native.rlike_match(r"^\d{3}-\d{4}$", "555-019")
     assert native.rlike_match(r"^\w+@\w+\.\w+$", "jürgen@müller.de") and not native.rlike_match(r"^\w+@\w+\.\w+$", "a b@c.d")
+
+
+def _crate_classes():
+    """[…] class bodies of the crate's \\w and \\d for Python's re, from the generated tables (checked against the crate itself above)"""
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "datafusion-comet_amd", "csrc", "regex_unicode_tables.hpp")).read()
+
+    def body(name):
+        t = src[src.index(name):]
+        t = t[:t.index("};")]
+        return "".join("\\U%08x-\\U%08x" % (int(a, 16), int(b, 16)) for a, b in re.findall(r"\{0x([0-9A-F]+), 0x([0-9A-F]+)\}", t))
+    return body("kPerlWord"), body("kPerlDigit")
+
+
+def want_unicode(pattern, value, _cache={}):
+    """the backtracking referee for patterns with \\w \\d \\b \\B: the Perl classes become explicit classes of the crate's tables, a word boundary
+    becomes the look-around pair it abbreviates"""
+    if "w" not in _cache:
+        _cache["w"], _cache["d"] = _crate_classes()
+    W, D = _cache["w"], _cache["d"]
+    wb = "(?:(?<=[%s])(?![%s])|(?<![%s])(?=[%s]))" % (W, W, W, W)
+    nb = "(?:(?<=[%s])(?=[%s])|(?<![%s])(?![%s]))" % (W, W, W, W)
+    rx, i = "", 0
+    while i < len(pattern):
+        ch = pattern[i]
+        if ch == "\\" and i + 1 < len(pattern):
+            nx = pattern[i + 1]
+            rx += {"b": wb, "B": nb, "w": "[%s]" % W, "W": "[^%s]" % W, "d": "[%s]" % D, "D": "[^%s]" % D}.get(nx, pattern[i:i + 2])
+            i += 2
+            continue
+        rx += "\\Z" if ch == "$" else ch
+        i += 1
+    return re.search(rx, value) is not None
+
+
+WORD_BOUNDARIES = ["\\bfoo\\b", "\\b\\w+\\b", "foo\\B", "\\Bfoo", "^\\b", "\\b$", "\\b\\d+\\b", "é\\b", "\\b日本", "a\\b-", "\\b(?:cat|dog)s?\\b", "x\\b\\by", "x\\b\\By", "-\\b\\b-", "\\b", "\\B", "^\\B$",
+                   "\\b.\\b", "(?:\\bfoo\\b ?)+$", "\\w\\b\\W\\b\\w", "\\B-\\B", "(?i)\\bFoo\\b", "(?s)a\\b.\\bb", "o\\b|\\bz", "\\b[a-c]{2}\\b", "1\\b2", "1\\B2"]
+
+
+def test_word_boundaries(built):
+    """\\b / \\B (Unicode, the text's ends are not word characters): the search automaton carries the class of the character it is inside of and
+    tags threads with what the character behind a boundary has to be (csrc/regex.cpp compile_with_word_boundaries)"""
+    rng = random.Random(5)
+    pool = ["foo", "foo", "o", "z", "cat", "dogs", " ", "-", ".", "é", "日本", "٣", "12", "1", "2", "_", "\u0301", "\u200d", "€", "😀", "x", "y", "a", "b", "ab", "\n", "F", "fOO"]
+    values = ["", "foo", "foo bar", "afoo", "fooa", "foo-", "-foo-", "日本語", "x日本", "é", "éa", "aé-", "a-", "12 34", "a1", "1 2", "12", "xy", "--", "a b", "cats and dogs", "scat", "e\u0301 ", "a\u200db"] + \
+             ["".join(rng.choice(pool) for _ in range(rng.randrange(0, 6))) for _ in range(400)]
+    for pattern in WORD_BOUNDARIES:
+        for v in values:
+            if pattern.startswith("(?i)"):        # (these hold ASCII letters only: the folded pattern over the folded text)
+                w = want_unicode(pattern[4:].lower(), v.lower())
+            elif pattern.startswith("(?s)"):      # `.` also matches \n
+                w = want_unicode(pattern[4:].replace(".", "[\\s\\S]"), v)
+            else:
+                w = want_unicode(pattern, v)
+            assert native.rlike_match(pattern, v) == w, (pattern, v)
+    with pytest.raises(native.CometNativeException, match="under"):
+        native.rlike_match("(?m)\\bfoo", "foo")
 
 
 def test_garbage_patterns_fail_cleanly(built):

@@ -21,7 +21,9 @@ def _table(n, seed=9):
 
 @pytest.mark.parametrize("pattern", ["R[a-z]+", "^R", "e$", "^[^,]+,[^,]+$", "colou?r", "日本", "é$", "^.{4}$", "(ab|c)+d?", "special.*requests", "^$", "x{50,}R", "1\\.5", "line.two",
                                      # the Perl classes (the crate's Unicode 16 tables; on these words Python's re agrees)
-                                     "^\\d\\.\\d$", "^\\w+$", "\\w\\W\\w", "^[\\w#]+\\d{9}$", "^\\D+$"])
+                                     "^\\d\\.\\d$", "^\\w+$", "\\w\\W\\w", "^[\\w#]+\\d{9}$", "^\\D+$",
+                                     # word boundaries
+                                     "\\bRose\\b", "\\b\\w{5}\\b", "e\\B", "\\bline\\b.*\\btwo\\b"])
 def test_projection_and_filter_match_the_oracle(built, pattern):
     from oracle import oracle as O
     t = _table(30_000)
@@ -39,7 +41,7 @@ def test_projection_and_filter_match_the_oracle(built, pattern):
 
 def test_unsupported_patterns_fail_at_create_plan(built):
     t = _table(10)
-    for pattern in ("a\\b", "a(?i)rose", "\\p{L}+"):
+    for pattern in ("(?m)a\\b", "a(?i)rose", "\\p{L}+"):
         plan = S.project(S.scan([STR, I32]), [S.rlike(S.col(0, STR), S.lit(pattern, STR))])
         with pytest.raises(native.CometNativeException, match="RLIKE pattern .* is not supported"):
             native.execute_to_table([native.HostInput.from_table(t)], 1, plan.encode())

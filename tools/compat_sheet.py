@@ -98,7 +98,7 @@ def probes():
         "Concat": (f("concat", [s, L("-", S.T_STRING), s], S.T_STRING), "Utf8 columns and literals, as an output column"),
         "Hour": (S.time_part("hour", S.cast(d, S.T_TIMESTAMP)), "any time zone of the database"), "Minute": (S.time_part("minute", S.cast(d, S.T_TIMESTAMP)), ""),
         "Second": (S.time_part("second", S.cast(d, S.T_TIMESTAMP)), ""),
-        "Like": (S.like(s, L("a%_b", S.T_STRING)), "% and _, backslash escapes"), "RLike": (S.rlike(s, L("^ab+c$", S.T_STRING)), "the byte-exact subset incl. \\d \\w (Unicode 16 tables of the crate); \\b and \\p{..} refused by name"),
+        "Like": (S.like(s, L("a%_b", S.T_STRING)), "% and _, backslash escapes"), "RLike": (S.rlike(s, L("^ab+c$", S.T_STRING)), "the byte-exact subset incl. \\d \\w \\b (Unicode 16 tables of the crate); \\p{..} refused by name"),
         "StartsWith": (f("starts_with", [s, L("ab", S.T_STRING)], S.T_BOOL), ""), "EndsWith": (f("ends_with", [s, L("ab", S.T_STRING)], S.T_BOOL), ""),
         "Contains": (f("contains", [s, L("ab", S.T_STRING)], S.T_BOOL), ""),
         "Substring": (f("substring", [s, L(2, S.T_INT32), L(3, S.T_INT32)], S.T_STRING), "literal bounds"), "Left": (f("substring", [s, L(1, S.T_INT32), L(3, S.T_INT32)], S.T_STRING), "serialized as Substring"),
@@ -195,7 +195,7 @@ def render() -> str:
     w("* `Cast`: string -> float / timestamp, float -> string, casts of a COMPUTED string; a cast to string is an output column (not an operand); on a")
     w("  device-resident input ANY type mismatch with the declared Scan fields.  Time zones come from the system's database ($TZDIR, /usr/share/zoneinfo).")
     w("* `Min` / `Max` of decimal(> 18) in grouped aggregates; more than four Float64 sums / averages in one aggregate.")
-    w("* `RLike`: patterns outside the byte-exact subset (`\\\\b`, `\\\\p{..}`, scoped flags, look-around) are refused by name.")
+    w("* `RLike`: patterns outside the byte-exact subset (`\\\\p{..}`, scoped flags, look-around, `\\\\b` under `(?m)`) are refused by name.")
     w("* `Concat`: of Utf8 columns and literals (at most eight), as an output column.")
     w("* Computed Utf8 values used as operands of further expressions must fit 15 bytes (literals, substring, CASE over those).")
     w("* Window: RANGE frames with value offsets over non-integer keys, floating-point aggregates over frames, MIN / MAX over sliding frames wider")
