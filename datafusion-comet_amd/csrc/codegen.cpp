@@ -1031,6 +1031,12 @@ struct Gen {
       long long pos = 0, len = 0x7fffffffLL;
       if (e.children.size() < 2 || e.children.size() > 3 || !int_lit(e.children[1], pos) || (e.children.size() == 3 && !int_lit(e.children[2], len))) return false;
       call = "utf8_view_substr(@, " + std::to_string(clamp32(pos)) + ", " + std::to_string(clamp32(len)) + ")";
+    } else if (f == "upper" || f == "lower") {
+      // DataFusion's upper / lower = Rust's str::to_uppercase / to_lowercase (the reference's Upper / Lower under spark.comet.caseConversion.enabled):
+      // the whole value as a view, mapped by the executor's case kernels
+      if (e.children.size() != 1) return false;
+      oc.case_mode = f == "lower" ? 1 : 2;
+      call = "utf8_view_substr(@, 1, 2147483647)";
     } else if (f == "trim" || f == "btrim" || f == "ltrim" || f == "rtrim") {
       if (e.children.size() != 1) return false;      // a trim string is a different function
       call = std::string("utf8_view_trim(@, ") + (f == "ltrim" ? "1" : f == "rtrim" ? "2" : "3") + ")";

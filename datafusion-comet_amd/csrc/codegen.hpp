@@ -33,6 +33,7 @@ struct OutCol {
   // executor sizes and writes the column.  concat_cols[k] = source column of part k, or −1: the literal concat_lits[k].  Empty = not such a column
   std::vector<int> concat_cols;
   std::vector<std::string> concat_lits;
+  int case_mode = 0;                // a view whose bytes are case-mapped on the way out: 1 lower, 2 upper (device/case_map.hpp)
   std::string pad_pattern;          // the pad string (≤ 64 bytes, ≤ 32 characters)
   bool pad_left = false;
 };

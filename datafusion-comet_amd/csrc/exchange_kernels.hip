@@ -325,6 +325,27 @@ __global__ __launch_bounds__(256) void strview_copy_kernel(const StrView* v, con
   }
 }
 
+// ---- upper / lower (OutCol::case_mode): Rust's str::to_uppercase / to_lowercase over a view's bytes (device/case_map.hpp) ----
+#define CASE_TABLE_QUAL __device__ static const
+#include "device/case_map.hpp"
+__global__ __launch_bounds__(256) void strcase_lengths_kernel(const StrView* v, const u8* ok_bytes, const i32* src_offs, const u8* src_bytes, i64 n, int mode, u32* lengths) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+    u32 len = 0;
+    if (!ok_bytes || ok_bytes[k]) {
+      const StrView sv = v[k];
+      len = (u32)case_map_value(src_bytes + src_offs[sv.row] + sv.start, (i32)sv.len, mode, nullptr);
+    }
+    lengths[k] = len;
+  }
+}
+__global__ __launch_bounds__(256) void strcase_write_kernel(const StrView* v, const u8* ok_bytes, const i32* src_offs, const u8* src_bytes, i64 n, int mode, const i32* out_offs, u8* out_bytes) {
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+    if (ok_bytes && !ok_bytes[k]) continue;
+    const StrView sv = v[k];
+    (void)case_map_value(src_bytes + src_offs[sv.row] + sv.start, (i32)sv.len, mode, out_bytes + out_offs[k]);
+  }
+}
+
 // ---- concat (OutCol::concat_cols): per output row the source row; the parts are Utf8 columns of that row and literals ----
 struct ConcatArgs { i32 n; i32 lit_len[8]; const i32* offs[8]; const u8* bytes[8]; i64 first[8]; };
 __global__ __launch_bounds__(256) void concat_lengths_kernel(ConcatArgs a, const u32* rows, const u8* ok_bytes, i64 n, u32* lengths) {
@@ -515,6 +536,15 @@ static PadPattern make_pattern(const uint8_t* pattern, int32_t nbytes) {
   pp.char_off[ch] = (u8)nbytes;
   pp.nchars = ch;
   return pp;
+}
+int comet_launch_strcase_lengths(const void* views, const uint8_t* ok_bytes, const int32_t* src_offs, const uint8_t* src_bytes, int64_t n, int mode, uint32_t* lengths, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(strcase_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, (const StrView*)views, ok_bytes, src_offs, src_bytes, (i64)n, mode, lengths);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_strcase_write(const void* views, const uint8_t* ok_bytes, const int32_t* src_offs, const uint8_t* src_bytes, int64_t n, int mode, const int32_t* out_offs, uint8_t* out_bytes,
+                               void* stream) {
+  if (n > 0) hipLaunchKernelGGL(strcase_write_kernel, grid_for(n), 256, 0, (hipStream_t)stream, (const StrView*)views, ok_bytes, src_offs, src_bytes, (i64)n, mode, out_offs, out_bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_concat_lengths(const void* a, const uint32_t* rows, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream) {
   if (n > 0) hipLaunchKernelGGL(concat_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, *(const ConcatArgs*)a, rows, ok_bytes, (i64)n, lengths);

@@ -997,14 +997,18 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
       tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
       offsets->ensure((size_t)(rows + 2) * 4);
       if (rows == 0) HIP_CHECK(hipMemsetAsync(offsets->p, 0, 8, stream_));
-      if (comet_launch_strview_lengths(vals[j]->p, okb, rows, pat, patn, (uint32_t*)lengths.p, stream_) != 0) throw CometError("string view: launch failed");
+      const int32_t* src_offs = (const int32_t*)sc.data + sc.offset;
+      if (oc.case_mode ? comet_launch_strcase_lengths(vals[j]->p, okb, src_offs, (const uint8_t*)sc.aux, rows, oc.case_mode, (uint32_t*)lengths.p, stream_) != 0
+                       : comet_launch_strview_lengths(vals[j]->p, okb, rows, pat, patn, (uint32_t*)lengths.p, stream_) != 0)
+        throw CometError("string view: launch failed");
       if (rows) pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)offsets->p, stream_);
       int32_t total = 0;
       if (rows) read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
       if (total < 0) throw CometError("Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
       bytes->ensure((size_t)total + 16);
-      if (comet_launch_strview_copy(vals[j]->p, okb, (const int32_t*)sc.data + sc.offset, (const uint8_t*)sc.aux, rows, pat, patn, oc.pad_left ? 1 : 0,
-                                    (const int32_t*)offsets->p, (uint8_t*)bytes->p, stream_) != 0)
+      if (oc.case_mode ? comet_launch_strcase_write(vals[j]->p, okb, src_offs, (const uint8_t*)sc.aux, rows, oc.case_mode, (const int32_t*)offsets->p, (uint8_t*)bytes->p, stream_) != 0
+                       : comet_launch_strview_copy(vals[j]->p, okb, src_offs, (const uint8_t*)sc.aux, rows, pat, patn, oc.pad_left ? 1 : 0, (const int32_t*)offsets->p, (uint8_t*)bytes->p,
+                                                   stream_) != 0)
         throw CometError("string view: launch failed");
       HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
       cv.data = offsets->p;

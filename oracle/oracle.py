@@ -474,6 +474,15 @@ class Evaluator:
                 fill = (pat * (length // max(len(pat), 1) + 1))[:length - len(v)] if pat else ""
                 return fill + v if f == "lpad" else v + fill
             return Col(S.T_STRING, np.array([pad(v) if v is not None else None for v in a.values], dtype=object), a.valid)
+        if f in ("upper", "lower"):
+            # DataFusion's upper / lower = Rust's str::to_uppercase / to_lowercase: full Unicode case mapping without locale and the Final_Sigma rule —
+            # which is what Python's str.upper() / str.lower() implement too (for the Unicode version Python carries; the device tables are checked
+            # against Rust's own standard library in tests/test_case_map_cpu.py)
+            a = self.eval(e.children[0], cols, n)
+            out = np.empty(n, dtype=object)
+            for i in range(n):
+                out[i] = (a.values[i].upper() if f == "upper" else a.values[i].lower()) if a.ok()[i] else None
+            return Col(S.T_STRING, out, a.valid)
         if f == "concat":
             # Spark's Concat (datafusion-spark's SparkConcat, jni_api.rs:70): the arguments' bytes one after the other; NULL as soon as one is NULL
             args = [self.eval(c, cols, n) for c in e.children]

@@ -103,3 +103,20 @@ def test_concat_of_columns_and_literals(built):
     assert got.column(0).to_pylist() == ["ab/xy", "cd/xy", "ef/xy", "gh/xy"] * 5000
     with pytest.raises(native.CometNativeException, match="eight"):
         native.compile_plan(S.project(S.scan(fields), [cc(*([s] * 9))]).encode())
+
+
+def test_upper_and_lower(built):
+    """DataFusion's upper / lower = Rust's str::to_uppercase / to_lowercase (the reference's Upper / Lower under
+    spark.comet.caseConversion.enabled): full case mapping — ß → SS, İ → i̇, ﬁ → FI — and the Final_Sigma rule, results longer and shorter than
+    their sources; the tables are Rust's own (tests/test_case_map_cpu.py), the oracle here is Python's str.upper() / str.lower()."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(12)
+    n = 30_000
+    words = np.array(["", "Hello World", "straße", "Straße", "ΟΔΥΣΣΕΥΣ", "ΑΣ.", "Σ", "İstanbul", "ıI", "ǅemal", "ﬁnal ﬂight", "ŉ", "日本語テキスト", "naïve café ☕", "tschüß",
+                      "Customer#000000001", "x" * 70 + "ß", "MiXeD 123 _-", "ǰ ΐ ᾳ ᾼ", "😀 emoji"], dtype=object)
+    t = pa.table({"s": pa.array(words[rng.integers(0, len(words), n)], pa.utf8(), mask=rng.random(n) < 0.1), "k": pa.array(rng.integers(0, 100, n), pa.int32())})
+    s = S.col(0, STR)
+    exprs = [S.scalar_func("upper", [s], STR), S.scalar_func("lower", [s], STR), s, S.col(1, I32)]
+    got = _check(exprs, t)
+    assert "STRASSE" in got.column(0).to_pylist() and "οδυσσευς" in got.column(1).to_pylist()
+    _check(exprs[:2], t, S.filter_(S.scan([STR, I32]), S.lt(S.col(1, I32), S.lit(20, I32))))

@@ -96,6 +96,8 @@ def probes():
         "CaseWhen": (S.case_when([(S.gt(i32, L(0, S.T_INT32)), i64)], L(0, S.T_INT64)), ""), "If": (S.if_(b, i64, L(0, S.T_INT64)), ""),
         "Coalesce": (f("coalesce", [i64, L(0, S.T_INT64)], S.T_INT64), ""),
         "Concat": (f("concat", [s, L("-", S.T_STRING), s], S.T_STRING), "Utf8 columns and literals, as an output column"),
+        "Upper": (f("upper", [s], S.T_STRING), "a Utf8 column, as an output column (Rust's to_uppercase: what the reference runs under spark.comet.caseConversion.enabled)"),
+        "Lower": (f("lower", [s], S.T_STRING), "a Utf8 column, as an output column"),
         "Hour": (S.time_part("hour", S.cast(d, S.T_TIMESTAMP)), "any time zone of the database"), "Minute": (S.time_part("minute", S.cast(d, S.T_TIMESTAMP)), ""),
         "Second": (S.time_part("second", S.cast(d, S.T_TIMESTAMP)), ""),
         "Like": (S.like(s, L("a%_b", S.T_STRING)), "% and _, backslash escapes"), "RLike": (S.rlike(s, L("^ab+c$", S.T_STRING)), "the byte-exact subset incl. \\d \\w \\b (Unicode 16 tables of the crate); \\p{..} refused by name"),
