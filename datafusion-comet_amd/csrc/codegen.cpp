@@ -47,6 +47,17 @@ u128 sat_add(u128 a, u128 b) {
   return r;
 }
 
+thread_local bool g_uses_ryu = false;      // the source being generated calls into comet_ryu.hpp (Float → Decimal)
+std::string with_optional_headers(std::string src) {
+  if (g_uses_ryu) {
+    const std::string inc = "using namespace comet;\n";
+    const size_t at = src.find(inc);
+    if (at != std::string::npos) src.insert(at + inc.size(), "namespace comet {\n#include \"comet_ryu.hpp\"\n}\n");
+  }
+  g_uses_ryu = false;
+  return src;
+}
+
 enum class Rep { B, I32, I64, I128, F32, F64, STR };  // STR: Utf8 of ≤15 bytes packed in comet::str16
 
 const char* rep_ctype(Rep r) {
@@ -886,6 +897,21 @@ struct Gen {
       r.maxabs = type_maxabs(to);
       return r;
     }
+    if (from.is_float() && to.id == TypeId::Decimal) {
+      // cast_floating_point_to_decimal128 (numeric.rs:884-990): BigDecimal(Double.toString(d)).setScale(scale, HALF_UP) — the SHORTEST digits (Ryu,
+      // comet_ryu.hpp) are rounded; NaN / infinity are NULL in every mode, a result beyond the precision is NULL (ANSI: NUMERIC_VALUE_OUT_OF_RANGE)
+      g_uses_ryu = true;
+      c = named(c);
+      std::string out = newvar("i128"), rc = newvar("int");
+      stmt(out + " = 0; " + rc + " = comet::f64_bits_to_decimal((u64)__double_as_longlong((double)" + c.v + "), " + std::to_string(to.precision) + ", " + std::to_string(to.scale) + ", " + out + ");");
+      if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(c.ok, "(" + rc + " == 3)"), 3);
+      std::string o = newvar("bool");
+      stmt(o + " = " + and_ok(c.ok, "(" + rc + " == 0)") + ";");
+      r.ok = o;
+      r.v = r.rep == Rep::I64 ? "(i64)" + out : out;
+      r.maxabs = type_maxabs(to);
+      return r;
+    }
     if (from.id == TypeId::Decimal && to.is_float()) {
       // arrow cast (the reference defers to DataFusion here): (value as f64) / 10^scale; Float32 narrows the double result
       const std::string d = "((double)" + as128(c) + " / " + lit_f64(std::pow(10.0, from.scale)) + ")";
@@ -1153,6 +1179,9 @@ struct Gen {
         oc.fmt_arg = v.t.scale;
         break;
       case TypeId::Date: oc.fmt_kind = OutCol::FmtDate; break;
+      // spark_cast_float64_to_utf8 / float32 (numeric.rs:137-221): the shortest digits, plain between 10⁻³ and 10⁷, else d.dddE±n; the value's BITS travel
+      case TypeId::Double: oc.fmt_kind = OutCol::FmtFloat64; v = named(v); v.v = "__double_as_longlong(" + v.v + ")"; v.rep = Rep::I64; break;
+      case TypeId::Float: oc.fmt_kind = OutCol::FmtFloat32; v = named(v); v.v = "(i64)(u32)__float_as_int(" + v.v + ")"; v.rep = Rep::I64; break;
       case TypeId::Timestamp: case TypeId::TimestampNtz: {
         // (pre_timestamp_cast, utils.rs:299-330: the instant becomes the session zone's wall clock, which is then written out)
         if (v.t.id == TypeId::Timestamp) { v = named(v); v.v = local_of(e.func, v); }
@@ -2396,7 +2425,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     }
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
     d.kernels.push_back("k_pack");
-    d.source = src.str();
+    d.source = with_optional_headers(src.str());
     d.explain = ex.str();
     return d;
   }
@@ -2962,7 +2991,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
     d.kernels = {"k_gagg", "k_gemit", "k_grehash", "k_pack"};
   }
-  d.source = src.str();
+  d.source = with_optional_headers(src.str());
   d.explain = ex.str();
   return d;
 }
@@ -3321,7 +3350,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   ex << "  hash join: " << jt_name << ", build " << (build_left ? "left" : "right") << ", "
      << j.left_keys.size() << " key(s)" << (fu ? ", probe side fused with its Filter / Projection chain" : "") << "\n";
   d.in_types = ct;
-  d.source = src.str();
+  d.source = with_optional_headers(src.str());
   d.explain = ex.str();
   return d;
 }
@@ -3426,7 +3455,7 @@ PipelineDesc generate_sort_keys(const Operator& sort, const std::vector<DType>& 
   d.kernels = {"k_sortkey"};
   d.sort_key_bytes = W;
   if (sort.fetch >= 0) ex << "  fetch " << sort.fetch << "\n";
-  d.source = src.str();
+  d.source = with_optional_headers(src.str());
   d.explain = ex.str();
   return d;
 }

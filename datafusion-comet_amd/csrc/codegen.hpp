@@ -26,7 +26,7 @@ struct OutCol {
   int view_src = -1;
   // Utf8 RESULT that is a VALUE written out (Cast … AS STRING of an integer, boolean, decimal, date or timestamp): the kernel stores the value
   // as an i128 per output row, the executor sizes and writes the column (strfmt kernels).  0 = not such a column
-  enum FmtKind { FmtNone = 0, FmtInt = 1, FmtBool = 2, FmtDecimal = 3, FmtDecimalJava = 4, FmtDate = 5, FmtTimestamp = 6 };
+  enum FmtKind { FmtNone = 0, FmtInt = 1, FmtBool = 2, FmtDecimal = 3, FmtDecimalJava = 4, FmtDate = 5, FmtTimestamp = 6, FmtFloat64 = 7, FmtFloat32 = 8 };
   int fmt_kind = FmtNone;
   long long fmt_arg = 0;            // FmtDecimal*: the scale; FmtTimestamp: the zone's offset from UTC in seconds
   // Utf8 RESULT that is the concatenation of Utf8 source columns and literals (concat): the kernel writes the SOURCE ROW INDEX (u32), the

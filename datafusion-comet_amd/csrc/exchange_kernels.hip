@@ -381,6 +381,8 @@ __global__ __launch_bounds__(256) void concat_copy_kernel(ConcatArgs a, const u3
   }
 }
 
+#define RYU_TABLE_QUAL __device__ static const
+#include "device/ryu.hpp"
 // ---- formatted values (Cast … AS STRING, OutCol::fmt_kind): one i128 per row in, digits out (comet_device.hpp "values to strings") ----
 __device__ __forceinline__ i32 strfmt_one(int kind, long long arg, i128 v, u8* o) {
   switch (kind) {
@@ -389,6 +391,8 @@ __device__ __forceinline__ i32 strfmt_one(int kind, long long arg, i128 v, u8* o
     case 3: return fmt_decimal(v, (int)arg, false, o);
     case 4: return fmt_decimal(v, (int)arg, true, o);
     case 5: return fmt_date((i64)v, o);
+    case 7: return fmt_f64_bits((u64)v, o);
+    case 8: return fmt_f32_bits((u32)v, o);
     default: return fmt_timestamp((i64)v, (i64)arg, o);
   }
 }

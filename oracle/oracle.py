@@ -837,6 +837,18 @@ class Evaluator:
             return Col(to, c.values.astype(_np_dtype(S, to)), c.valid)
         if frm.type_id in ints + (S.FLOAT, S.DOUBLE) and to.type_id == S.BOOL:
             return Col(to, c.values != 0, c.valid)
+        if frm.type_id in (S.FLOAT, S.DOUBLE) and to.type_id == S.DECIMAL:
+            from . import strcast as C
+            vals, valid = [], np.zeros(n, bool)
+            for i in range(n):
+                v = None
+                if c.ok()[i]:
+                    v, err = C.float_to_decimal(float(c.values[i]), to.precision, to.scale)
+                    if err and e.eval_mode == S.ANSI:
+                        raise OracleError("NUMERIC_VALUE_OUT_OF_RANGE")
+                valid[i] = v is not None
+                vals.append(v or 0)
+            return Col(to, ints_to_dec(vals), None if valid.all() else valid)
         if frm.type_id == S.STRING or to.type_id == S.STRING:
             return self._string_cast(e, c)
         temporal = (S.TIMESTAMP, S.TIMESTAMP_NTZ)
@@ -911,6 +923,8 @@ class Evaluator:
                 out[i] = C.bool_to_string(bool(c.values[i]))
             elif frm.type_id == S.DECIMAL:
                 out[i] = C.decimal_to_string(dec_to_int(c.values, i), frm.scale, mode)
+            elif frm.type_id in (S.FLOAT, S.DOUBLE):
+                out[i] = C.float_to_string(c.values[i], frm.type_id == S.FLOAT)
             elif frm.type_id == S.DATE:
                 out[i] = C.date_to_string(int(c.values[i]))
             elif frm.type_id in (S.TIMESTAMP, S.TIMESTAMP_NTZ):

@@ -427,6 +427,8 @@ def utc_offset_at(tz: str, utc_seconds: int) -> int:
     """seconds east of UTC in force at the instant (tz.from_utc_datetime)"""
     import datetime
     z = _zone(tz)
+    if isinstance(z, datetime.timezone):          # a fixed offset: no calendar needed (years beyond datetime's stay representable)
+        return int(z.utcoffset(None).total_seconds())
     t = datetime.datetime(1970, 1, 1, tzinfo=datetime.timezone.utc) + datetime.timedelta(seconds=utc_seconds)
     return int(t.astimezone(z).utcoffset().total_seconds())
 
@@ -441,6 +443,8 @@ def local_to_utc_us(tz: str, local_us: int) -> int:
     import datetime
     z = _zone(tz)
     utc = datetime.timezone.utc
+    if isinstance(z, datetime.timezone):
+        return local_us - int(z.utcoffset(None).total_seconds()) * 1_000_000
 
     def in_gap(naive):
         return naive.replace(tzinfo=z, fold=0).astimezone(utc).astimezone(z).replace(tzinfo=None) != naive
@@ -452,3 +456,71 @@ def local_to_utc_us(tz: str, local_us: int) -> int:
         probe = naive - datetime.timedelta(hours=3)
         off = 0 if in_gap(probe) else int(probe.replace(tzinfo=z, fold=0).utcoffset().total_seconds())
     return local_us - off * 1_000_000
+
+
+# --------------------------------------------------------------------------- floats (numeric.rs:137-221, 884-990)
+
+def _shortest_digits(x, is32: bool):
+    """(mantissa without trailing zeroes, exponent) of the shortest decimal that reads back as the same float — Python's repr() for doubles,
+    numpy's unique formatting for floats: the digits the `ryu` crate and Rust's Display produce"""
+    import decimal
+    import numpy as np
+    text = np.format_float_scientific(np.float32(x), unique=True) if is32 else repr(abs(float(x)))
+    t = decimal.Decimal(text).as_tuple()
+    m, e = int("".join(map(str, t.digits))), t.exponent
+    while m and m % 10 == 0:
+        m //= 10
+        e += 1
+    return abs(m), e
+
+
+def float_to_string(x, is32: bool) -> str:
+    """spark_cast_float64_to_utf8 / float32 (numeric.rs:137-221)"""
+    import math
+    import numpy as np
+    x = float(np.float32(x)) if is32 else float(x)
+    if x != x:
+        return "NaN"
+    if math.isinf(x):
+        return "Infinity" if x > 0 else "-Infinity"
+    sign = "-" if math.copysign(1.0, x) < 0 else ""
+    a = abs(x)
+    if a == 0:
+        return sign + "0.0"
+    if a == (float(np.float32(1.4e-45)) if is32 else 5e-324):
+        return sign + ("1.4E-45" if is32 else "4.9E-324")
+    m, e = _shortest_digits(a, is32)
+    d = str(m)
+    n = len(d)
+    lo, hi = (float(np.float32(0.001)), float(np.float32(1e7))) if is32 else (0.001, 1e7)
+    if lo <= a < hi:
+        point = n + e
+        if point <= 0:
+            return sign + "0." + "0" * -point + d
+        if point >= n:
+            return sign + d + "0" * (point - n) + ".0"
+        return sign + d[:point] + "." + d[point:]
+    return sign + d[0] + "." + (d[1:] if n > 1 else "0") + "E" + str(e + n - 1)
+
+
+def float_to_decimal(x, precision: int, scale: int):
+    """float_to_decimal128 (numeric.rs:955-990): the shortest digits of the value AS A DOUBLE, HALF_UP at the target scale; (None, None) for NaN /
+    infinity, (None, "overflow") beyond the precision"""
+    import math
+    x = float(x)
+    if x != x or math.isinf(x):
+        return None, None
+    if x == 0:
+        return 0, None
+    m, e = _shortest_digits(x, False)
+    shift = e + scale
+    if shift >= 0:
+        v = m * 10 ** shift if shift <= 38 else None
+    elif -shift > 38:
+        v = 0
+    else:
+        d = 10 ** -shift
+        v = m // d + (1 if m % d >= d // 2 else 0)
+    if v is None or v >= 10 ** precision:
+        return None, "overflow"
+    return (-v if x < 0 else v), None

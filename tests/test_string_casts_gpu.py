@@ -137,9 +137,35 @@ def test_values_to_strings(built):
     assert native.execute_to_table([native.HostInput.from_table(t)], 13, S.project(none, exprs[:13]).encode(), batch_size=0) == []
 
 
-def test_region_time_zones_are_refused_by_name(built):
+def test_floats_to_strings_and_decimals(built):
+    """Float → String (numeric.rs:137-221: the shortest digits, Java's notation) and Float → Decimal (numeric.rs:884-990: the shortest digits rounded
+    HALF_UP, not the binary value — 0.5153125 at scale 6 is 0.515313); the Ryu routine is checked on the host against Python's repr() and numpy
+    (tests/test_ryu_cpu.py)."""
+    rng = np.random.default_rng(31)
+    n = 30_000
+    d = rng.standard_normal(n) * 10.0 ** rng.integers(-12, 12, n)
+    d[:14] = [0.0, -0.0, 1.0, 0.001, 1e-4, 1e7, 9999999.0, 5e-324, float("nan"), float("inf"), float("-inf"), 0.5153125, 1.7976931348623157e308, 123456.789]
+    bits = rng.integers(0, 2**63, n // 4).astype(np.uint64)
+    d[100:100 + n // 4] = bits.view(np.float64)
+    f = (rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n)).astype(np.float32)
+    f[:8] = [0.0, 1.0, 0.1, 1e7, 3.4028235e38, 1.4e-45, 16777216.0, float("nan")]
+    t = pa.table({"d": pa.array(d, mask=rng.random(n) < 0.05), "f": pa.array(f, mask=rng.random(n) < 0.05)})
+    D, F = S.col(0, S.T_DOUBLE), S.col(1, S.T_FLOAT)
+    exprs = [S.cast(D, STR), S.cast(F, STR), S.cast(D, S.decimal(38, 18)), S.cast(D, S.decimal(18, 2)), S.cast(D, S.decimal(10, 6)), S.cast(F, S.decimal(20, 10)), S.cast(D, S.decimal(38, 6), S.TRY)]
+    got = _check(S.project(S.scan([S.T_DOUBLE, S.T_FLOAT]), exprs), t, len(exprs))
+    assert got.column(0).to_pylist()[:8] == ["0.0", "-0.0", "1.0", "0.001", "1.0E-4", "1.0E7", "9999999.0", "4.9E-324"]
+    from oracle import oracle as O
+    bad = pa.table({"d": pa.array([1.0, 1e30]), "f": pa.array(np.array([1.0, 2.0], np.float32))})
+    p = S.project(S.scan([S.T_DOUBLE, S.T_FLOAT]), [S.cast(D, S.decimal(10, 2), S.ANSI)])
+    with pytest.raises(O.OracleError, match="NUMERIC_VALUE_OUT_OF_RANGE"):
+        O.run_plan_to_arrow(S, p, bad)
+    with pytest.raises(native.CometQueryExecutionException, match="NUMERIC_VALUE_OUT_OF_RANGE"):
+        _run(p, bad, 1)
+
+
+def test_unknown_time_zones_are_refused_by_name(built):
+    """region zones come from the time-zone database (tests/test_temporal_casts_gpu.py); a name it does not hold fails createPlan"""
     t = _values_table(16, 3)
-    types = [S.T_TIMESTAMP]
-    plan = S.project(S.scan(types), [S.cast(S.col(0, S.T_TIMESTAMP), STR, S.LEGACY, "America/Los_Angeles")])
-    with pytest.raises(native.CometNativeException, match="America/Los_Angeles"):
+    plan = S.project(S.scan([S.T_TIMESTAMP]), [S.cast(S.col(0, S.T_TIMESTAMP), STR, S.LEGACY, "Mars/Olympus")])
+    with pytest.raises(native.CometNativeException, match="Mars/Olympus"):
         _run(plan, t.select(["ts"]), 1)
