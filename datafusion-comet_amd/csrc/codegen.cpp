@@ -48,13 +48,19 @@ u128 sat_add(u128 a, u128 b) {
 }
 
 thread_local bool g_uses_ryu = false;      // the source being generated calls into comet_ryu.hpp (Float → Decimal)
+thread_local bool g_uses_strtod = false;   // … into comet_strtod.hpp (String → Float / Double)
 std::string with_optional_headers(std::string src) {
   if (g_uses_ryu) {
     const std::string inc = "using namespace comet;\n";
     const size_t at = src.find(inc);
     if (at != std::string::npos) src.insert(at + inc.size(), "namespace comet {\n#include \"comet_ryu.hpp\"\n}\n");
   }
-  g_uses_ryu = false;
+  if (g_uses_strtod) {
+    const std::string inc = "using namespace comet;\n";
+    const size_t at = src.find(inc);
+    if (at != std::string::npos) src.insert(at + inc.size(), "namespace comet {\n#include \"comet_strtod.hpp\"\n}\n");
+  }
+  g_uses_ryu = g_uses_strtod = false;
   return src;
 }
 
@@ -936,7 +942,7 @@ struct Gen {
 
   // Cast of a Utf8 COLUMN to boolean / integers / decimal / date (conversion_funcs/string.rs:260-312, 853-1115, 314-758, 1896-2046): parsed from
   // the column's bytes in place (device/comet_device.hpp "String casts"; the same text is checked on the host against the reference's vectors).
-  // Invalid input is NULL in LEGACY / TRY and an error under ANSI; floats and timestamps are not there yet.
+  // Invalid input is NULL in LEGACY / TRY and an error under ANSI; timestamps are not there yet.
   Val cast_from_string(const Expr& e, int idx) {
     const DType& to = e.dtype;
     const int mode = e.eval_mode == EvalMode::Legacy ? 0 : e.eval_mode == EvalMode::Ansi ? 1 : 2;
@@ -958,6 +964,12 @@ struct Gen {
         r.maxabs = type_maxabs(to);
         break;
       case TypeId::Date: outtype = "i32"; call = "comet::str_to_date(sp, sn, @)"; r.maxabs = type_maxabs(to); err_bit = 10; break;
+      case TypeId::Float: case TypeId::Double:
+        // cast_string_to_float (string.rs:177-258): a correctly rounded conversion (comet_strtod.hpp), straight to the target's width
+        g_uses_strtod = true;
+        outtype = "u64";
+        call = std::string("comet::str_to_float_bits((const u8*)sp, sn, ") + (to.id == TypeId::Float ? "true" : "false") + ", @)";
+        break;
       default: throw CometError("Cast from string to " + to.str() + " is not supported in the GPU pipeline yet");
     }
     Val valid = str_col_validity(idx);
@@ -978,6 +990,8 @@ struct Gen {
       case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: r.v = "(i32)" + out; break;
       case TypeId::Int64: r.v = out; break;
       case TypeId::Decimal: r.v = r.rep == Rep::I64 ? "(i64)" + out : out; break;
+      case TypeId::Double: r.v = "__longlong_as_double((i64)" + out + ")"; break;
+      case TypeId::Float: r.v = "__int_as_float((i32)(u32)" + out + ")"; break;
       default: r.v = out; break;
     }
     return r;

@@ -904,6 +904,8 @@ class Evaluator:
                         v, err = C.string_to_decimal(b, to.precision, to.scale, mode)
                     elif to.type_id == S.DATE:
                         v, err = C.string_to_date(b, mode)
+                    elif to.type_id in (S.FLOAT, S.DOUBLE):
+                        v, err = C.string_to_float(b, mode, to.type_id == S.FLOAT)
                     else:
                         raise NotImplementedError(f"oracle cast string → {to}")
                     if err:

@@ -524,3 +524,49 @@ def float_to_decimal(x, precision: int, scale: int):
     if v is None or v >= 10 ** precision:
         return None, "overflow"
     return (-v if x < 0 else v), None
+
+
+def string_to_float(b: bytes, mode: str, is32: bool):
+    """cast_string_to_float (string.rs:177-258): String.trim, the names of infinity / NaN, one trailing d / D / f / F, Rust's float grammar; the
+    conversion is correctly rounded straight to the target's width (Python's float() for doubles; exact rational rounding for floats)."""
+    import re
+    import numpy as np
+    err = CAST_INVALID if mode == ANSI else None
+    t = trim_java_string(b)
+    try:
+        s = t.decode("ascii")
+    except UnicodeDecodeError:
+        return None, err
+    low = s.lower()
+    if low in ("inf", "+inf", "infinity", "+infinity"):
+        return float("inf"), None
+    if low in ("-inf", "-infinity"):
+        return float("-inf"), None
+    if low == "nan":
+        return float("nan"), None
+    if s[-1:] in ("d", "D", "f", "F"):
+        s = s[:-1]
+    m = re.fullmatch(r"([+-]?)(inf|infinity|nan|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?)", s, re.IGNORECASE)
+    if not m:
+        return None, err
+    if m.group(2).lower() in ("inf", "infinity", "nan"):
+        return float(m.group(1) + m.group(2)), None
+    if not is32:
+        return float(s), None
+    from fractions import Fraction
+    q = Fraction(s)
+    neg = s.startswith("-")
+    q = abs(q)
+    if q == 0:
+        return -0.0 if neg else 0.0, None
+    e = q.numerator.bit_length() - q.denominator.bit_length()
+    if Fraction(2) ** e > q:
+        e -= 1
+    e = max(e, -126)
+    scaled = q / Fraction(2) ** (e - 23)
+    mant = scaled.numerator // scaled.denominator
+    rem = scaled - mant
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and mant & 1):
+        mant += 1
+    v = float("inf") if (e + (1 if mant == 1 << 24 else 0)) > 127 else float(Fraction(mant) * Fraction(2) ** (e - 23))
+    return float(np.float32(-v if neg else v)), None

@@ -163,6 +163,37 @@ def test_floats_to_strings_and_decimals(built):
         _run(p, bad, 1)
 
 
+def test_strings_to_floats(built):
+    """cast_string_to_float (string.rs:177-258): correctly rounded straight to the target's width (tests/test_strtod_cpu.py checks the routine against
+    Python's float() and exact rationals), String.trim, inf / nan, one trailing d / f; bits compared, NaN included"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sd_cpu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_strtod_cpu.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    vals = [v for v in m._numbers(random.Random(5), 6000) if len(v) < 400]
+    vals += ["inf", "+INF", "-Infinity", "NaN", " 1.5 ", "1.5d", "1.5F", "1e5f", "nand", "", ".", "1e", "1.5x", "0x10", "１２", "1.5\x7f", "-0", "1.", ".5", "1e999", "1e-999", "abc"]
+    rng = np.random.default_rng(6)
+    n = 20_000
+    t = pa.table({"s": pa.array([vals[i] for i in rng.integers(0, len(vals), n)], pa.utf8(), mask=rng.random(n) < 0.05), "k": pa.array(rng.integers(0, 9, n), pa.int32())})
+    from oracle import oracle as O
+    s = S.col(0, STR)
+    for mode in (S.LEGACY, S.TRY):
+        plan = S.project(S.scan([STR, I32]), [S.cast(s, S.T_DOUBLE, mode), S.cast(s, S.T_FLOAT, mode)])
+        got, want = _run(plan, t, 2), O.run_plan_to_arrow(S, plan, t)
+        for i, (ty, w) in enumerate([(np.uint64, 8), (np.uint32, 4)]):
+            g, x = got.column(i).combine_chunks(), want.column(i).combine_chunks()
+            assert g.is_valid().equals(x.is_valid()), i
+            gb, xb = np.frombuffer(g.buffers()[1], ty)[:n], np.frombuffer(x.buffers()[1], ty)[:n]
+            ok = np.asarray(g.is_valid())
+            nan = np.isnan(np.asarray(x.fill_null(0)))
+            bad = np.nonzero(ok & ~nan & (gb != xb))[0]
+            assert len(bad) == 0, (i, t.column(0)[int(bad[0])].as_py(), hex(int(gb[bad[0]])), hex(int(xb[bad[0]])))
+            assert (np.isnan(np.asarray(g.fill_null(0))) == nan).all()
+    bad = pa.table({"s": pa.array(["1.5", "1.5x"]), "k": pa.array(np.arange(2, dtype=np.int32))})
+    with pytest.raises(native.CometQueryExecutionException, match="CAST_INVALID_INPUT"):
+        _run(S.project(S.scan([STR, I32]), [S.cast(s, S.T_DOUBLE, S.ANSI)]), bad, 1)
+
+
 def test_unknown_time_zones_are_refused_by_name(built):
     """region zones come from the time-zone database (tests/test_temporal_casts_gpu.py); a name it does not hold fails createPlan"""
     t = _values_table(16, 3)
