@@ -49,6 +49,7 @@ u128 sat_add(u128 a, u128 b) {
 
 thread_local bool g_uses_ryu = false;      // the source being generated calls into comet_ryu.hpp (Float → Decimal)
 thread_local bool g_uses_strtod = false;   // … into comet_strtod.hpp (String → Float / Double)
+thread_local bool g_uses_strts = false;    // … into comet_strts.hpp (String → Timestamp)
 std::string with_optional_headers(std::string src) {
   if (g_uses_ryu) {
     const std::string inc = "using namespace comet;\n";
@@ -60,7 +61,12 @@ std::string with_optional_headers(std::string src) {
     const size_t at = src.find(inc);
     if (at != std::string::npos) src.insert(at + inc.size(), "namespace comet {\n#include \"comet_strtod.hpp\"\n}\n");
   }
-  g_uses_ryu = g_uses_strtod = false;
+  if (g_uses_strts) {
+    const std::string inc = "using namespace comet;\n";
+    const size_t at = src.find(inc);
+    if (at != std::string::npos) src.insert(at + inc.size(), "namespace comet {\n#include \"comet_strts.hpp\"\n}\n");
+  }
+  g_uses_ryu = g_uses_strtod = g_uses_strts = false;
   return src;
 }
 
@@ -942,7 +948,7 @@ struct Gen {
 
   // Cast of a Utf8 COLUMN to boolean / integers / decimal / date (conversion_funcs/string.rs:260-312, 853-1115, 314-758, 1896-2046): parsed from
   // the column's bytes in place (device/comet_device.hpp "String casts"; the same text is checked on the host against the reference's vectors).
-  // Invalid input is NULL in LEGACY / TRY and an error under ANSI; timestamps are not there yet.
+  // Invalid input is NULL in LEGACY / TRY and an error under ANSI.
   Val cast_from_string(const Expr& e, int idx) {
     const DType& to = e.dtype;
     const int mode = e.eval_mode == EvalMode::Legacy ? 0 : e.eval_mode == EvalMode::Ansi ? 1 : 2;
@@ -964,6 +970,27 @@ struct Gen {
         r.maxabs = type_maxabs(to);
         break;
       case TypeId::Date: outtype = "i32"; call = "comet::str_to_date(sp, sn, @)"; r.maxabs = type_maxabs(to); err_bit = 10; break;
+      case TypeId::Timestamp: case TypeId::TimestampNtz: {
+        // cast_string_to_timestamp / _ntz (string.rs:798-852 → timestamp_parser, comet_strts.hpp): the reference's fourteen shapes and zone suffixes in the
+        // session zone.  Refused at run time (the task fails, it is not answered differently): a NAMED zone inside a value (the kernel holds the
+        // session zone's table), a time-only value ("T12:34": the reference gives it TODAY's date), an instant behind the zone table's end.
+        g_uses_strts = true;
+        outtype = "i64";
+        if (to.id == TypeId::Timestamp) {
+          long long secs = 0;
+          std::string zt;
+          if (fixed_zone_offset(e.func, secs)) {
+            zt = "ztf" + std::to_string(nvar++);
+            decls += "    static const i64 " + zt + "[] = {0, " + std::to_string(secs) + ", (i64)0x7fffffffffffffffll};\n";
+          } else zt = zone_table(e.func);
+          call = "comet::str_to_timestamp((const u8*)sp, sn, " + zt + ", " + (e.is_spark4_plus ? "true" : "false") + ", (i64)0x8000000000000000ull, @)";
+        } else {
+          call = "comet::str_to_timestamp_ntz((const u8*)sp, sn, @)";
+        }
+        r.maxabs = type_maxabs(to);
+        err_bit = 10;
+        break;
+      }
       case TypeId::Float: case TypeId::Double:
         // cast_string_to_float (string.rs:177-258): a correctly rounded conversion (comet_strtod.hpp), straight to the target's width
         g_uses_strtod = true;
@@ -981,6 +1008,10 @@ struct Gen {
     if (e.eval_mode == EvalMode::Ansi) {
       raise_if("(" + rc + " == 1)", err_bit);
       if (to.id == TypeId::Decimal) raise_if("(" + rc + " == 3)", 3);
+    }
+    if (to.id == TypeId::Timestamp || to.id == TypeId::TimestampNtz) {
+      raise_if("(" + rc + " == 4 || " + rc + " == 6)", 12);
+      raise_if("(" + rc + " == 5)", 11);
     }
     std::string o = newvar("bool");
     stmt(o + " = " + rc + " == 0;");

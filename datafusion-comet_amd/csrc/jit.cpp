@@ -23,6 +23,7 @@ extern const char* const kEmbeddedDeviceHeader;
 extern const char* const kEmbeddedKParamsHeader;
 extern const char* const kEmbeddedRyuHeader;
 extern const char* const kEmbeddedStrtodHeader;
+extern const char* const kEmbeddedStrtsHeader;
 
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) {
@@ -72,7 +73,7 @@ bool looks_like_code_object(const std::vector<char>& b) { return b.size() > 64 &
 
 std::shared_ptr<CodeObject> jit_compile(const std::string& source) {
   // the key covers the generated source AND the hand-written headers it instantiates
-  static const uint64_t h2 = fnv1a(toolchain_tag(), fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader, fnv1a(kEmbeddedRyuHeader, fnv1a(kEmbeddedStrtodHeader)))));
+  static const uint64_t h2 = fnv1a(toolchain_tag(), fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader, fnv1a(kEmbeddedRyuHeader, fnv1a(kEmbeddedStrtodHeader, fnv1a(kEmbeddedStrtsHeader))))));
   uint64_t h1 = fnv1a(source);
   char keybuf[64];
   snprintf(keybuf, sizeof keybuf, "%016llx_%016llx", (unsigned long long)h1, (unsigned long long)h2);
@@ -114,9 +115,9 @@ std::shared_ptr<CodeObject> jit_compile(const std::string& source) {
     }
   }
   hiprtcProgram prog;
-  const char* headers[] = {kEmbeddedDeviceHeader, kEmbeddedKParamsHeader, kEmbeddedRyuHeader, kEmbeddedStrtodHeader};
-  const char* names[] = {"comet_device.hpp", "kparams.h", "comet_ryu.hpp", "comet_strtod.hpp"};
-  if (hiprtcCreateProgram(&prog, source.c_str(), "comet_pipeline.hip", 4, headers, names) != HIPRTC_SUCCESS)
+  const char* headers[] = {kEmbeddedDeviceHeader, kEmbeddedKParamsHeader, kEmbeddedRyuHeader, kEmbeddedStrtodHeader, kEmbeddedStrtsHeader};
+  const char* names[] = {"comet_device.hpp", "kparams.h", "comet_ryu.hpp", "comet_strtod.hpp", "comet_strts.hpp"};
+  if (hiprtcCreateProgram(&prog, source.c_str(), "comet_pipeline.hip", 5, headers, names) != HIPRTC_SUCCESS)
     throw CometError("hiprtcCreateProgram failed");
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"};
   hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);

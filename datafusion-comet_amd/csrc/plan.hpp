@@ -65,6 +65,7 @@ struct Expr {
   EvalMode eval_mode = EvalMode::Legacy;
   bool fail_on_error = false;     // CheckOverflow / UnaryMinus
   bool check_divide_overflow = false;   // IntegralDivide (MathExpr field 6)
+  bool is_spark4_plus = false;    // Cast (expr.proto:349-351): Spark 4's reading of leading whitespace before T-prefixed time-only strings
   bool negated = false;           // In
   std::string func;               // ScalarFunc.func
   int n_when = 0;                 // CaseWhen: children = when[0..n) ++ then[0..n) ++ [else]

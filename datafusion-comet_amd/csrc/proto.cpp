@@ -176,6 +176,7 @@ void decode_expr_body(Reader r, Expr& e) {
         if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
         else if (f == 2 && wt == 2) { e.dtype = decode_datatype(r.sub()); e.has_dtype = true; handled = true; }
         else if (f == 3 && wt == 2) { e.func = r.bytes(); handled = true; }      // Cast.timezone (expr.proto:346) travels in `func`
+        else if (f == 6 && wt == 0) { e.is_spark4_plus = r.varint() != 0; handled = true; }
         else if (f == 4 && wt == 0) { e.eval_mode = (EvalMode)r.varint(); handled = true; }
         break;
       case ExprKind::Hour: case ExprKind::Minute: case ExprKind::Second:

@@ -146,6 +146,8 @@ class Expr:
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_bytes(3, (getattr(self, "timezone", None) or "UTC").encode())
             if self.eval_mode:
                 body += _f_varint(4, self.eval_mode)
+            if getattr(self, "is_spark4_plus", False):
+                body += _f_varint(6, 1)
         elif k == "check_overflow":
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode())
             if self.fail_on_error:
@@ -275,9 +277,10 @@ def check_overflow(child: Expr, dtype: DataType, fail_on_error: bool = False) ->
     return Expr("check_overflow", [child], dtype=dtype, fail_on_error=fail_on_error)
 
 
-def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY, timezone: str = "UTC") -> Expr:
+def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY, timezone: str = "UTC", is_spark4_plus: bool = False) -> Expr:
     e = Expr("cast", [child], dtype=dtype, eval_mode=eval_mode)
     e.timezone = timezone
+    e.is_spark4_plus = is_spark4_plus
     return e
 
 

@@ -906,6 +906,10 @@ class Evaluator:
                         v, err = C.string_to_date(b, mode)
                     elif to.type_id in (S.FLOAT, S.DOUBLE):
                         v, err = C.string_to_float(b, mode, to.type_id == S.FLOAT)
+                    elif to.type_id == S.TIMESTAMP:
+                        v, err = C.string_to_timestamp(b, mode, getattr(e, "timezone", None) or "UTC", bool(getattr(e, "is_spark4_plus", False)))
+                    elif to.type_id == S.TIMESTAMP_NTZ:
+                        v, err = C.string_to_timestamp_ntz(b, mode)
                     else:
                         raise NotImplementedError(f"oracle cast string → {to}")
                     if err:

@@ -570,3 +570,285 @@ def string_to_float(b: bytes, mode: str, is32: bool):
         mant += 1
     v = float("inf") if (e + (1 if mant == 1 << 24 else 0)) > 127 else float(Fraction(mant) * Fraction(2) ** (e - 23))
     return float(np.float32(-v if neg else v)), None
+
+
+# --------------------------------------------------------------------------- string -> timestamp / timestamp_ntz (string.rs:798-852, 1125-1900)
+# The reference matches fourteen regular expressions (Unicode \d), splits the value on [T -:.] and lets failed integer parses fall back to
+# defaults; both are restated as they are.  Time-only values ("T12:34", "12:34:56") take TODAY's date in the zone: `now_us` says what today is.
+
+import re as _re
+
+_WS = set([9, 10, 11, 12, 13, 32, 0x85, 0xA0, 0x1680, 0x2028, 0x2029, 0x202F, 0x205F, 0x3000] + list(range(0x2000, 0x200B)))
+_RX = {k: _re.compile(v) for k, v in {
+    "year": r"-?\d{4,6}", "month": r"-?\d{4,7}-\d{2}", "day": r"-?\d{4,7}-\d{2}-\d{2}", "hour": r"-?\d{4,7}-\d{2}-\d{2}[T ]\d{1,2}",
+    "minute": r"-?\d{4,7}-\d{2}-\d{2}[T ]\d{2}:\d{2}", "second": r"-?\d{4,7}-\d{2}-\d{2}[T ]\d{2}:\d{2}:\d{2}",
+    "microsecond": r"-?\d{4,7}-\d{2}-\d{2}[T ]\d{2}:\d{2}:\d{2}\.\d+", "t_h": r"T\d{1,2}", "t_hm": r"T\d{1,2}:\d{1,2}", "t_hms": r"T\d{1,2}:\d{1,2}:\d{1,2}",
+    "t_hmsu": r"T\d{1,2}:\d{1,2}:\d{1,2}\.\d+", "b_hm": r"\d{1,2}:\d{1,2}", "b_hms": r"\d{1,2}:\d{1,2}:\d{1,2}", "b_hmsu": r"\d{1,2}:\d{1,2}:\d{1,2}\.\d+"}.items()}
+_DATE_KINDS = ["year", "month", "day", "hour", "minute", "second", "microsecond"]
+_TIME_KINDS = ["t_h", "t_hm", "t_hms", "t_hmsu", "b_hm", "b_hms", "b_hmsu"]
+
+
+def _trim_ws(s: str, left=True, right=True) -> str:
+    a, b = 0, len(s)
+    while left and a < b and ord(s[a]) in _WS:
+        a += 1
+    while right and b > a and ord(s[b - 1]) in _WS:
+        b -= 1
+    return s[a:b]
+
+
+def _rust_int(s: str, signed: bool, bits: int = 32):
+    """str::parse::<i32 / u32>: an optional sign ('-' for signed types only), ASCII digits, no overflow"""
+    if not s:
+        return None
+    t = s
+    neg = False
+    if t[0] == "+" or (signed and t[0] == "-"):
+        neg = t[0] == "-"
+        t = t[1:]
+    if not t or any(c < "0" or c > "9" for c in t):
+        return None
+    v = -int(t) if neg else int(t)
+    lo, hi = (-(1 << (bits - 1)), (1 << (bits - 1)) - 1) if signed else (0, (1 << bits) - 1)
+    return v if lo <= v <= hi else None
+
+
+def _ts_info(value: str, kind: str):
+    """parse_to_timestamp_info (string.rs:1125-1205) → (y, mo, d, h, mi, s, us) or None"""
+    sign, part = (-1, value[1:]) if value.startswith("-") else (1, value)
+    parts = _re.split(r"[T \-:.]", part)
+
+    def nxt(i, signed, default):
+        if i >= len(parts):
+            return default
+        v = _rust_int(parts[i], signed)
+        return default if v is None else v
+    y = _rust_int(parts[0], True)
+    year = sign * (0 if y is None else y)
+    if not -290309 <= year <= 294248:
+        return None
+    mo, d, h, mi, s = nxt(1, False, 1), nxt(2, False, 1), nxt(3, False, 0), nxt(4, False, 0), nxt(5, False, 0)
+    us = 0
+    if len(parts) > 6:
+        ms = parts[6].encode()[:6]
+        try:
+            v = _rust_int(ms.decode(), False)
+        except UnicodeDecodeError:
+            v = None
+        us = (0 if v is None else v) * 10 ** (6 - len(ms))
+    info = [1, 1, 1, 0, 0, 0, 0]
+    got = [year, mo, d, h, mi, s, us]
+    for k in range(_DATE_KINDS.index(kind) + 1):
+        info[k] = got[k]
+    return info
+
+
+def _local_candidates(tz: str, local_s: int):
+    """offsets of the spans whose wall clock shows local second L (chrono-tz from_local_datetime): [] a gap, [o] single, [o1, o2] ambiguous"""
+    import datetime
+    z = _zone(tz)
+    if isinstance(z, datetime.timezone):
+        return [int(z.utcoffset(None).total_seconds())]
+    # (years beyond datetime's: before the zone's first transition its local mean time holds — a single offset; far in the future the device
+    # refuses the value anyway, the year 9999 stands in)
+    local_s = max(-62135510400, min(local_s, 253402214400))
+    naive = datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=local_s)
+    utc = datetime.timezone.utc
+    out = []
+    for fold in (0, 1):
+        aware = naive.replace(tzinfo=z, fold=fold)
+        if aware.astimezone(utc).astimezone(z).replace(tzinfo=None) == naive:
+            o = int(aware.utcoffset().total_seconds())
+            if o not in out:
+                out.append(o)
+    return out
+
+
+def _ts_to_micros(info, tz: str):
+    """parse_timestamp_to_micros (string.rs:1249-1348)"""
+    y, mo, d, h, mi, s, us = info
+    if not (h < 24 and mi < 60 and s < 60):
+        return None
+    days = _ymd_to_epoch_day(y, mo, d)
+    if days is not None and -262143 <= y <= 262142:
+        local = days * 86400 + h * 3600 + mi * 60 + s
+        c = _local_candidates(tz, local)
+        if c:
+            off = c[0]
+        else:
+            c = _local_candidates(tz, local - 10800)
+            if not c:
+                return None
+            off = c[0]
+        return (local - off) * 1_000_000 + us
+    if -262144 <= y <= 262143 or days is None:
+        return None
+    c = _local_candidates(tz, 0)
+    off = c[0] if c else 0
+    v = (days * 86400 + h * 3600 + mi * 60 + s - off) * 1_000_000 + us
+    return v if -(1 << 63) <= v < (1 << 63) else None
+
+
+def _parse_sign_offset(s: str):
+    """string.rs:1493-1531"""
+    if s == "":
+        return 0
+    if s[0] == "+":
+        sign = 1
+    elif s[0] == "-":
+        sign = -1
+    else:
+        return None
+    rest = s[1:]
+    if not rest:
+        return None
+    if ":" in rest:
+        hs, ms = rest.split(":", 1)
+        if not ms:
+            return None
+        h, m = _rust_int(hs, True), _rust_int(ms, True)
+        if h is None or m is None:
+            return None
+    else:
+        if len(rest.encode()) in (1, 2):
+            h, m = _rust_int(rest, True), 0
+        elif len(rest.encode()) == 4 and rest.isascii():
+            h, m = _rust_int(rest[:2], True), _rust_int(rest[2:], True)
+        else:
+            return None
+        if h is None or m is None:
+            return None
+    if not (0 <= h <= 18 and 0 <= m <= 59):
+        return None
+    return sign * (h * 3600 + m * 60)
+
+
+def _fixed_zone(secs: int) -> str:
+    a = abs(secs)
+    return "%s%02d:%02d" % ("-" if secs < 0 else "+", a // 3600, a % 3600 // 60)
+
+
+def _extract_offset_suffix(value: str):
+    """string.rs:1566-1641 → (prefix, zone name) or None"""
+    if value.endswith("Z"):
+        return value[:-1], "UTC"
+    for prefix in (" UTC", "UTC", " GMT", "GMT", " UT", "UT"):
+        pos = value.rfind(prefix)
+        if pos >= 0:
+            secs = _parse_sign_offset(value[pos + len(prefix):])
+            if secs is not None:
+                return value[:pos], _fixed_zone(secs)
+    for abbr, secs in ((" EST", -18000), ("EST", -18000), (" MST", -25200), ("MST", -25200), (" HST", -36000), ("HST", -36000)):
+        pos = value.rfind(abbr)
+        if pos >= 0 and pos + len(abbr) == len(value):
+            return value[:pos], _fixed_zone(secs)
+    sp = value.rfind(" ")
+    if sp >= 0:
+        name = value[sp + 1:]
+        if "/" in name:
+            try:
+                import zoneinfo
+                zoneinfo.ZoneInfo(name)
+                return value[:sp], name
+            except Exception:      # noqa: BLE001 — not a zone of the database
+                pass
+    pos = max(value.rfind("+"), value.rfind("-"))
+    if pos >= 0:
+        secs = _parse_sign_offset(value[pos:])
+        if secs is not None:
+            return value[:pos], _fixed_zone(secs)
+    return None
+
+
+def _time_only(value: str, tz: str, now_us: int):
+    """parse_str_to_time_only_timestamp (string.rs:1855-1893): today's date in the zone with the value's time of day"""
+    t = value[1:] if value.startswith("T") else value
+    cp = t.split(":", 2)
+    hour = _rust_int(cp[0], False) or 0
+    minute = (_rust_int(cp[1], False) or 0) if len(cp) > 1 else 0
+    sec, ns = 0, 0
+    if len(cp) > 2:
+        sf = cp[2]
+        dot = sf.find(".")
+        sec = _rust_int(sf[:dot] if dot >= 0 else sf, False) or 0
+        if dot >= 0:
+            frac = sf[dot + 1:].encode()[:6].decode(errors="ignore")
+            ns = (_rust_int(frac.ljust(6, "0"), False) or 0) * 1000
+    if hour >= 24 or minute >= 60 or sec >= 60:
+        return None
+    local_now = utc_to_local_us(tz, now_us)
+    day = local_now // 86_400_000_000
+    local = day * 86400 + hour * 3600 + minute * 60 + sec
+    c = _local_candidates(tz, local)
+    if len(c) != 1:                       # DateTime::with_hour…: `single()` — a gap or an overlap gives None
+        return None
+    return (local - c[0]) * 1_000_000 + ns // 1000
+
+
+def _leading_plus(value: str):
+    if not value.startswith("+"):
+        return value
+    rest = value[1:]
+    i = next((k for k, c in enumerate(rest) if not ("0" <= c <= "9")), None)
+    if i is not None and i >= 1 and rest[i] == "-":
+        return rest
+    return None
+
+
+def string_to_timestamp(b: bytes, mode: str, tz: str, spark4: bool, now_us: int = 0):
+    """cast_string_to_timestamp → timestamp_parser (string.rs:798-829, 1406-1491, 1667-1731)"""
+    err = CAST_INVALID if mode == ANSI else None
+    value = _trim_ws(b.decode("utf-8"), left=False)        # the cast's trim_end
+    trimmed = _trim_ws(value)
+    if not trimmed:
+        return None, None
+    if spark4 and len(value) > len(_trim_ws(value, right=False)) and any(_RX[k].fullmatch(trimmed) for k in ("t_h", "t_hm", "t_hms", "t_hmsu")):
+        return None, err
+    value = _leading_plus(trimmed)
+    if value is None:
+        return None, None
+    zone = tz
+    if not any(r.fullmatch(value) for r in _RX.values()):
+        sfx = _extract_offset_suffix(value)
+        if sfx:
+            value, zone = sfx
+    for k in _DATE_KINDS + _TIME_KINDS:
+        if _RX[k].fullmatch(value):
+            if k in _DATE_KINDS:
+                info = _ts_info(value, k)
+                v = None if info is None else _ts_to_micros(info, zone)
+            else:
+                v = _time_only(value, zone, now_us)
+            return (v, None) if v is not None else (None, err)
+    return None, err
+
+
+def string_to_timestamp_ntz(b: bytes, mode: str, allow_time_zone: bool = True):
+    """cast_string_to_timestamp_ntz → timestamp_ntz_parser (string.rs:831-852, 1733-1853)"""
+    err = CAST_INVALID if mode == ANSI else None
+    value = _trim_ws(b.decode("utf-8"))
+    if not value:
+        return None, None
+    value = _leading_plus(value)
+    if value is None:
+        return None, None
+    if any(_RX[k].fullmatch(value) for k in _TIME_KINDS):
+        return None, err
+    if not any(_RX[k].fullmatch(value) for k in _DATE_KINDS):
+        sfx = _extract_offset_suffix(value)
+        if sfx:
+            if not allow_time_zone:
+                return None, err
+            value = _trim_ws(sfx[0], left=False)
+    for k in _DATE_KINDS:
+        if _RX[k].fullmatch(value):
+            info = _ts_info(value, k)
+            if info is None:
+                return None, None
+            y, mo, d, h, mi, s, us = info
+            days = _ymd_to_epoch_day(y, mo, d)
+            if days is None or h >= 24 or mi >= 60 or s >= 60:
+                return None, err
+            v = (days * 86400 + h * 3600 + mi * 60 + s) * 1_000_000 + us
+            return (v, None) if -(1 << 63) <= v < (1 << 63) else (None, err)
+    return None, err

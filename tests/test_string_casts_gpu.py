@@ -194,6 +194,59 @@ def test_strings_to_floats(built):
         _run(S.project(S.scan([STR, I32]), [S.cast(s, S.T_DOUBLE, S.ANSI)]), bad, 1)
 
 
+def _timestamp_strings(n, seed):
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("ts_cpu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_string_timestamps_cpu.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    vals = m._values(random.Random(seed), 6000) + [v[1] for v in m.KATS]
+    # what the kernel refuses instead of answering is kept out of the parity run (and checked below): a zone NAME inside the value, a time of day without a date
+    vals = [v for v in vals if "/" not in v and not re.match(r"^\+?([Tt]|\d{1,2}:)", v.strip().lstrip("\u3000"))]
+    rng = np.random.default_rng(seed)
+    return pa.table({"s": pa.array([vals[i] for i in rng.integers(0, len(vals), n)], pa.utf8(), mask=rng.random(n) < 0.05), "k": pa.array(rng.integers(0, 9, n), pa.int32())})
+
+
+@pytest.mark.parametrize("tz", ["UTC", "America/New_York", "Asia/Kolkata", "Pacific/Apia", "+05:30"])
+def test_strings_to_timestamps(built, tz):
+    """cast_string_to_timestamp / _ntz (string.rs:798-852, 1406-1853; tests/test_string_timestamps_cpu.py pins the oracle and the kernel's parser on the
+    reference's 103 vectors): every shape, zone suffix and the session zone's gaps and overlaps, LEGACY and TRY, Spark 3 and 4 readings"""
+    t = _timestamp_strings(20_000, 21)
+    s = S.col(0, STR)
+    for mode in (S.LEGACY, S.TRY):
+        plan = S.project(S.scan([STR, I32]), [S.cast(s, S.T_TIMESTAMP, mode, tz), S.cast(s, S.T_TIMESTAMP, mode, tz, is_spark4_plus=True), S.cast(s, S.DataType(S.TIMESTAMP_NTZ), mode), S.col(1, I32)])
+        from oracle import oracle as O
+        got, want = _run(plan, t, 4), O.run_plan_to_arrow(S, plan, t)
+        for i in range(3):
+            g, w = got.column(i).combine_chunks(), want.column(i).combine_chunks()
+            assert g.type == w.type, (i, g.type, w.type)
+            g, w = g.cast(pa.int64()).to_pylist(), w.cast(pa.int64()).to_pylist()
+            if g != w:
+                k = next(j for j in range(len(g)) if g[j] != w[j])
+                raise AssertionError(f"{tz} mode {mode} output {i}: got {g[k]!r}, want {w[k]!r}, input {t.column(0)[k].as_py()!r}")
+
+
+def test_timestamp_strings_under_ansi_and_the_refusals(built):
+    from oracle import oracle as O
+    s = S.col(0, STR)
+    good = pa.table({"s": pa.array(["2020-01-01T12:34:56.123456", " 2020-03-08 02:30:00 ", None, "2021-06-01 UTC+07:30", "", "0119704"]), "k": pa.array(np.arange(6, dtype=np.int32))})
+    plan = S.project(S.scan([STR, I32]), [S.cast(s, S.T_TIMESTAMP, S.ANSI, "America/New_York"), S.cast(s, S.DataType(S.TIMESTAMP_NTZ), S.ANSI)])
+    got, want = _run(plan, good, 2), O.run_plan_to_arrow(S, plan, good)
+    for i in range(2):
+        assert got.column(i).cast(pa.int64()).to_pylist() == want.column(i).cast(pa.int64()).to_pylist(), i
+    for bad, to in [("2020-13-01", S.T_TIMESTAMP), ("2020-01-01T25:00:00", S.DataType(S.TIMESTAMP_NTZ)), ("yesterday", S.T_TIMESTAMP)]:
+        tb = pa.table({"s": pa.array(["2020-01-01", bad, None]), "k": pa.array(np.arange(3, dtype=np.int32))})
+        p = S.project(S.scan([STR, I32]), [S.cast(s, to, S.ANSI, "Asia/Kolkata")])
+        with pytest.raises(O.OracleError, match="CAST_INVALID_INPUT"):
+            O.run_plan_to_arrow(S, p, tb)
+        with pytest.raises(native.CometQueryExecutionException, match="CAST_INVALID_INPUT"):
+            _run(p, tb, 1)
+    for refused in ["2020-01-01T12:34:56 Europe/Moscow", "T12:34", "12:34:56"]:
+        tb = pa.table({"s": pa.array(["2020-01-01", refused]), "k": pa.array(np.arange(2, dtype=np.int32))})
+        with pytest.raises(native.CometQueryExecutionException, match="names a time zone inside the value"):
+            _run(S.project(S.scan([STR, I32]), [S.cast(s, S.T_TIMESTAMP, S.LEGACY, "UTC")]), tb, 1)
+
+
 def test_unknown_time_zones_are_refused_by_name(built):
     """region zones come from the time-zone database (tests/test_temporal_casts_gpu.py); a name it does not hold fails createPlan"""
     t = _values_table(16, 3)
