@@ -566,11 +566,20 @@ CDEV i64 tz_span_of(tzp zt, i64 utc_s) {
   return lo;
 }
 CDEV i64 tz_span_offset(tzp zt, i64 span) { return span == 0 ? zt[1] : zt[3 + zt[0] + span - 1]; }
-CDEV i64 tz_offset_at(tzp zt, i64 utc_s) { return tz_span_offset(zt, tz_span_of(zt, utc_s)); }
-// UTC µs → the zone's wall clock as µs (what Timestamp → Date / String / hour() look at); `beyond`: the instant lies behind the table's end
+// Behind the table's end (zt[2]) the zone's daylight-saving rule goes on for ever, and the Gregorian calendar — weekdays included — repeats every
+// 400 years = 146097 days: an instant there is read 400-year periods earlier, inside the table's last, rule-generated 400 years (csrc/tz.cpp
+// expands the rule that far).  java.time's ZoneRules — Spark's answers — apply the last rule the same way.
+CDEV i64 tz_fold(i64 limit, i64 s) {
+  const i64 period = 146097ll * 86400ll;
+  return s < limit ? s : s - ((s - limit) / period + 1) * period;
+}
+CDEV i64 tz_offset_at(tzp zt, i64 utc_s) { return tz_span_offset(zt, tz_span_of(zt, tz_fold(zt[2], utc_s))); }
+// (a wall-clock second folds a day earlier than an instant: its spans' instants lie within a day of it)
+CDEV i64 tz_fold_local(tzp zt, i64 L) { return tz_fold(zt[2] == (i64)0x7fffffffffffffffll ? zt[2] : zt[2] - 86400, L); }
+// UTC µs → the zone's wall clock as µs (what Timestamp → Date / String / hour() look at)
 CDEV i64 tz_utc_to_local_us(tzp zt, i64 us, bool& beyond) {
   const i64 s = tz_floor_div(us, 1000000);
-  beyond = s >= zt[2];
+  beyond = false;
   return us + tz_offset_at(zt, s) * 1000000;
 }
 // spans whose wall clock shows local second L: 0 (a gap), 1, or 2 (an overlap: `off` is the EARLIER span's, chrono's Ambiguous(earliest, _))
@@ -591,10 +600,10 @@ CDEV int tz_local_spans(tzp zt, i64 L, i64& off) {
 }
 // local wall-clock µs → UTC µs (resolve_local_datetime: an overlap takes the earlier instant; a gap takes the offset in force three hours before)
 CDEV i64 tz_local_to_utc_us(tzp zt, i64 local_us, bool& beyond) {
-  const i64 L = tz_floor_div(local_us, 1000000);
+  const i64 L = tz_fold_local(zt, tz_floor_div(local_us, 1000000));
   i64 off = 0;
   if (tz_local_spans(zt, L, off) == 0 && tz_local_spans(zt, L - 10800, off) == 0) off = 0;
-  beyond = L - off >= zt[2];
+  beyond = false;
   return local_us - off * 1000000;
 }
 // ---- time zones: end

@@ -2,8 +2,7 @@
 // (Unicode \d), splits the value on [T -:.] and lets integer parses that fail fall back to defaults; a zone suffix (Z, UTC±h:mm, GMT…, EST / MST /
 // HST, ±hh:mm, ±hhmm) replaces the session zone.  Restated here shape by shape over the value's bytes.  Needs the "time zones" section of
 // comet_device.hpp (tz_local_spans …) and regex_unicode_tables.hpp (\d).  Return codes: 0 a value, 1 invalid (NULL, CAST_INVALID_INPUT under ANSI),
-// 2 NULL in every mode, 4 a NAMED zone inside the value (" Europe/Moscow": the device holds the session zone's table only), 5 an instant
-// behind the zone table's end, 6 a time-only value when the caller passes no "today".  Time-only values ("T12:34", "12:34:56") take today's date in the zone: `now_us` says what today is.
+// 2 NULL in every mode, 4 a NAMED zone inside the value (" Europe/Moscow": the device holds the session zone's table only), 6 a time-only value when the caller passes no "today".  Time-only values ("T12:34", "12:34:56") take today's date in the zone: `now_us` says what today is.
 #pragma once
 #include "../regex_unicode_tables.hpp"
 #ifndef STRTS_ENTRY
@@ -167,7 +166,7 @@ CDEV bool ts_epoch_day(i64 y, i64 m, i64 d, i64& days) {      // ymd_to_epoch_da
 struct TsZone { tzp zt; bool fixed; i64 off; };
 CDEV int ts_zone_spans(const TsZone& z, i64 L, i64& off) {
   if (z.fixed) { off = z.off; return 1; }
-  return tz_local_spans(z.zt, L, off);
+  return tz_local_spans(z.zt, tz_fold_local(z.zt, L), off);
 }
 // parse_timestamp_to_micros (string.rs:1249-1348)
 CDEV int ts_to_micros(const TsInfo& t, const TsZone& z, i64& out) {
@@ -179,7 +178,6 @@ CDEV int ts_to_micros(const TsInfo& t, const TsZone& z, i64& out) {
     const i64 L = days * 86400 + h * 3600 + mi * 60 + s;
     i64 off = 0;
     if (ts_zone_spans(z, L, off) == 0 && ts_zone_spans(z, L - 10800, off) == 0) return 1;
-    if (!z.fixed && L - off >= z.zt[2]) return 5;
     out = (L - off) * 1000000 + t.f[6];
     return 0;
   }

@@ -203,8 +203,9 @@ std::shared_ptr<const ZoneTable> parse_tzif(const std::vector<uint8_t>& b, const
     else if (z->off.back() != px.std_off) { /* the file's last type and its footer disagree: the footer describes the time after the last transition */ z->at.push_back(last + 1); z->off.push_back(px.std_off); }
     return z;
   }
-  // a zone with daylight-saving rules: its transitions up to the year 2400
-  const int64_t kLastYear = 2400;
+  // a zone with daylight-saving rules: the rule expanded over 400 years behind the file's last transition and a little more — the device reads a
+  // later instant 400-year periods earlier (comet_device.hpp tz_fold), inside [limit − 400 years, limit), which must be all the rule's
+  const int64_t kLastYear = z->at.empty() ? 2400 : std::max<int64_t>(2400, year_of(last) + 403);
   const int64_t y0 = z->at.empty() ? 1900 : std::max<int64_t>(year_of(last) - 1, 1800);
   for (int64_t y = y0; y < kLastYear; y++) {
     // DST starts at the rule's wall time on the STANDARD clock and ends at its wall time on the DST clock

@@ -15,7 +15,8 @@ struct ZoneTable {
   std::vector<int64_t> at;
   std::vector<int32_t> off;
   int32_t first_off = 0;
-  // the table answers instants below `limit` (a zone whose rules go on for ever is expanded up to the year 2400; INT64_MAX: no end)
+  // the table answers instants below `limit`; later ones are read 400-year periods earlier (a zone whose rule goes on for ever is expanded over
+  // the 400 years behind its last explicit transition; INT64_MAX: no rule, no end)
   int64_t limit = INT64_MAX;
   // the layout the device functions read (comet_device.hpp "time zones"): { n, first_off, limit, at[0..n), off[0..n) }
   std::vector<int64_t> flat() const;

@@ -423,12 +423,25 @@ def _zone(tz: str):
 _EPOCH_NAIVE = None
 
 
+_FOLD_FROM = 16725225600          # 2500-01-01T00:00:00Z: behind every explicit transition of the database, and far inside datetime's range
+_FOLD_PERIOD = 146097 * 86400     # the Gregorian calendar, weekdays included, repeats every 400 years — and with it a zone's final rule
+
+
+def _fold(seconds: int) -> int:
+    """a late instant (or wall-clock second) read 400-year periods earlier: the zone's last rule holds for ever (java.time ZoneRules, Spark's
+    answers), Python's datetime ends with the year 9999"""
+    if seconds < _FOLD_FROM:
+        return seconds
+    return seconds - ((seconds - _FOLD_FROM) // _FOLD_PERIOD + 1) * _FOLD_PERIOD
+
+
 def utc_offset_at(tz: str, utc_seconds: int) -> int:
     """seconds east of UTC in force at the instant (tz.from_utc_datetime)"""
     import datetime
     z = _zone(tz)
     if isinstance(z, datetime.timezone):          # a fixed offset: no calendar needed (years beyond datetime's stay representable)
         return int(z.utcoffset(None).total_seconds())
+    utc_seconds = max(-62135510400, _fold(utc_seconds))      # (before the year 1: the zone's local mean time, as in the year 1)
     t = datetime.datetime(1970, 1, 1, tzinfo=datetime.timezone.utc) + datetime.timedelta(seconds=utc_seconds)
     return int(t.astimezone(z).utcoffset().total_seconds())
 
@@ -448,7 +461,7 @@ def local_to_utc_us(tz: str, local_us: int) -> int:
 
     def in_gap(naive):
         return naive.replace(tzinfo=z, fold=0).astimezone(utc).astimezone(z).replace(tzinfo=None) != naive
-    L = local_us // 1_000_000
+    L = max(-62135510400, _fold(local_us // 1_000_000))
     naive = datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=L)
     if not in_gap(naive):
         off = int(naive.replace(tzinfo=z, fold=0).utcoffset().total_seconds())
@@ -649,9 +662,8 @@ def _local_candidates(tz: str, local_s: int):
     z = _zone(tz)
     if isinstance(z, datetime.timezone):
         return [int(z.utcoffset(None).total_seconds())]
-    # (years beyond datetime's: before the zone's first transition its local mean time holds — a single offset; far in the future the device
-    # refuses the value anyway, the year 9999 stands in)
-    local_s = max(-62135510400, min(local_s, 253402214400))
+    # (years beyond datetime's: before the zone's first transition its local mean time holds — a single offset; late ones fold)
+    local_s = max(-62135510400, _fold(local_s))
     naive = datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=local_s)
     utc = datetime.timezone.utc
     out = []

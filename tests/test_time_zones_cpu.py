@@ -69,10 +69,10 @@ def test_offsets_at_instants_agree_with_zoneinfo(dev):
         n = int(t[0])
         at = t[3:3 + n]
         assert (np.diff(at) > 0).all()
-        # every transition's second, the seconds around it, and random instants from 1850 to 2399
-        probes = [int(x) + d for x in at for d in (-1, 0, 1)] + [rng.randrange(-3_786_825_600, 13_569_465_600) for _ in range(3000)]
+        # every transition's second, the seconds around it, and random instants from 1850 to 9998 (behind the table's end the device folds by 400 years)
+        probes = [int(x) + d for x in at for d in (-1, 0, 1)] + [rng.randrange(-3_786_825_600, 13_569_465_600) for _ in range(3000)] + [rng.randrange(13_000_000_000, 253_370_000_000) for _ in range(3000)]
         for s in probes:
-            if not (-3_786_825_600 <= s < int(t[2])):
+            if s < -3_786_825_600:
                 continue
             want = int((EPOCH + datetime.timedelta(seconds=s)).astimezone(zi).utcoffset().total_seconds())
             assert dev.t_offset(p, ctypes.c_int64(s)) == want, (name, s)
@@ -102,9 +102,11 @@ def test_wall_clock_times_resolve_like_the_reference(dev):
         n = int(t[0])
         at, off = t[3:3 + n], t[3 + n:3 + 2 * n]
         # wall-clock seconds around every transition (inside gaps and overlaps), and random ones
-        locs = [int(a) + int(o) + d for a, o in zip(at, off) for d in (-7200, -3601, -1800, -1, 0, 1, 1800, 3599, 3600, 7200)] + [rng.randrange(-3_000_000_000, 13_000_000_000) for _ in range(2000)]
+        locs = [int(a) + int(o) + d for a, o in zip(at, off) for d in (-7200, -3601, -1800, -1, 0, 1, 1800, 3599, 3600, 7200)] + [rng.randrange(-3_000_000_000, 13_000_000_000) for _ in range(2000)] + [rng.randrange(13_000_000_000, 253_370_000_000) for _ in range(2000)]
+        # … and the same offsets from every transition of the table's last years, moved 400 and 7200 years on (gaps and overlaps behind the table's end)
+        locs += [int(a) + int(o) + d + k * 146097 * 86400 for a, o in zip(at[-6:], off[-6:]) for d in (-3601, -1, 0, 1800, 3599, 3600) for k in (1, 18)]
         for L in locs:
-            if not (-3_700_000_000 <= L < int(t[2]) - 200_000):
+            if L < -3_700_000_000:
                 continue
             naive = datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=L)
             want = L - _resolve_offset(zi, naive)
@@ -123,13 +125,22 @@ def test_the_references_date_to_timestamp_vectors(dev):
         assert [dev.t_to_utc(p, ctypes.c_int64(d * 86_400_000_000), ctypes.byref(b)) for d in (0, 19723, 19793)] == want, zone
 
 
-def test_instants_behind_the_table_are_flagged(dev):
-    t, p = _zt("America/Los_Angeles")
-    b = ctypes.c_int()
-    dev.t_to_local(p, ctypes.c_int64(13_600_000_000 * 1_000_000), ctypes.byref(b))       # the year 2400
-    assert b.value == 1
-    dev.t_to_local(p, ctypes.c_int64(4_000_000_000 * 1_000_000), ctypes.byref(b))
-    assert b.value == 0
-    t, p = _zt("Asia/Tokyo")                                                                 # no rules after 1951: no end
-    dev.t_to_local(p, ctypes.c_int64(2**62), ctypes.byref(b))
-    assert b.value == 0
+def test_instants_behind_the_table_follow_the_last_rule(dev):
+    """the Gregorian calendar repeats every 400 years, weekdays included: behind the table's end the device reads an instant 400-year periods
+    earlier — here against zoneinfo moved by a DIFFERENT number of periods, far beyond datetime's year 9999"""
+    rng = random.Random(9)
+    period = 146097 * 86400
+    for name in ZONES:
+        zi = zoneinfo.ZoneInfo(name)
+        t, p = _zt(name)
+        for _ in range(400):
+            s = rng.randrange(20_000_000_000, 9_000_000_000_000)                       # up to the year 287,000 — where int64 microseconds end
+            k = (s - 16_725_225_600) // period + 1
+            want = int((EPOCH + datetime.timedelta(seconds=s - k * period)).astimezone(zi).utcoffset().total_seconds())
+            assert dev.t_offset(p, ctypes.c_int64(s)) == want, (name, s)
+            b = ctypes.c_int()
+            assert dev.t_to_local(p, ctypes.c_int64(s * 1_000_000 + 7), ctypes.byref(b)) == (s + want) * 1_000_000 + 7 and not b.value
+            # a wall-clock second (not in a gap or an overlap with overwhelming odds — checked) comes back to its instant
+            naive = datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=s + want - k * period)
+            if not _in_gap(zi, naive) and naive.replace(tzinfo=zi, fold=0).utcoffset() == naive.replace(tzinfo=zi, fold=1).utcoffset():
+                assert dev.t_to_utc(p, ctypes.c_int64((s + want) * 1_000_000), ctypes.byref(b)) == s * 1_000_000, (name, s)
