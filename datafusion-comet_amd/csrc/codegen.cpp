@@ -988,7 +988,7 @@ struct Gen {
           call = "comet::str_to_timestamp_ntz((const u8*)sp, sn, @)";
         }
         r.maxabs = type_maxabs(to);
-        err_bit = 10;
+        err_bit = to.id == TypeId::Timestamp ? 13 : 14;
         break;
       }
       case TypeId::Float: case TypeId::Double:

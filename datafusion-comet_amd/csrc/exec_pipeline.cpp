@@ -294,6 +294,8 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
   if (f & 8u) throw CometError("{\"errorType\":\"NumericValueOutOfRange\",\"errorClass\":\"NUMERIC_VALUE_OUT_OF_RANGE\",\"params\":{}}", 1);
   if (f & 512u) throw CometError("{\"errorType\":\"CastInvalidValue\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\"}}", 1);
   if (f & 1024u) throw CometError("{\"errorType\":\"InvalidInputInCastToDatetime\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\",\"toType\":\"DATE\"}}", 1);
+  if (f & 8192u) throw CometError("{\"errorType\":\"InvalidInputInCastToDatetime\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\",\"toType\":\"TIMESTAMP\"}}", 1);
+  if (f & 16384u) throw CometError("{\"errorType\":\"InvalidInputInCastToDatetime\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\",\"toType\":\"TIMESTAMP_NTZ\"}}", 1);
   if (f & 4096u) throw CometError("a string cast to a timestamp names a time zone inside the value, or holds a time of day without a date (which takes the current date): not supported by the MI355X native engine");
   if (f & 2048u) throw CometError("a timestamp lies behind the end of its time zone's table (the year 2400): not supported by the MI355X native engine");
   if (f & 256u) throw CometError("{\"errorType\":\"DivideByZero\",\"errorClass\":\"DIVIDE_BY_ZERO\",\"params\":{}}", 1);
