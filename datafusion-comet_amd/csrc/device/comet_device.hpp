@@ -48,8 +48,20 @@ CDEV u128 uabs128(i128 v) { return v < 0 ? (u128)0 - (u128)v : (u128)v; }
 // kernel-argument struct makes the compiler emit FLAT loads, which bump lgkmcnt as well as vmcnt and thereby
 // couple every LDS wait to the outstanding HBM loads.
 #define COMET_GLOBAL __attribute__((address_space(1)))
+#ifdef COMET_LD_NT
 template <class T>
-CDEV T ld(const CometCol& c, i64 i) { return ((const COMET_GLOBAL T*)c.data)[c.offset + i]; }
+CDEV T ld_stream(const COMET_GLOBAL T* p) { return __builtin_nontemporal_load(p); }
+template <>
+CDEV i128 ld_stream<i128>(const COMET_GLOBAL i128* p) {
+  const u64 lo = __builtin_nontemporal_load((const COMET_GLOBAL u64*)p), hi = __builtin_nontemporal_load((const COMET_GLOBAL u64*)p + 1);
+  return (i128)(((u128)hi << 64) | lo);
+}
+#else
+template <class T>
+CDEV T ld_stream(const COMET_GLOBAL T* p) { return *p; }
+#endif
+template <class T>
+CDEV T ld(const CometCol& c, i64 i) { return ld_stream(&((const COMET_GLOBAL T*)c.data)[c.offset + i]); }
 CDEV bool ld_valid(const CometCol& c, i64 i) {
   i64 j = c.offset + i;
   return (((const COMET_GLOBAL u8*)c.valid)[j >> 3] >> (j & 7)) & 1;
@@ -60,7 +72,7 @@ CDEV bool ld_bool(const CometCol& c, i64 i) {
   return (((const COMET_GLOBAL u8*)c.data)[j >> 3] >> (j & 7)) & 1;
 }
 // Decimal128 whose precision ≤ 18: the upper limb is sign extension, read only the lower one.
-CDEV i64 ld_dec_lo(const CometCol& c, i64 i) { return ((const COMET_GLOBAL i64*)c.data)[2 * (c.offset + i)]; }
+CDEV i64 ld_dec_lo(const CometCol& c, i64 i) { return ld_stream(&((const COMET_GLOBAL i64*)c.data)[2 * (c.offset + i)]); }
 
 // Utf8 values of ≤ 15 bytes packed into two words (bytes 0-7 in a, bytes 8-14 in the low 56 bits of b,
 // length in the top byte of b): injective, so equality and grouping on the packed form are exact.
@@ -1355,7 +1367,13 @@ CDEV void sum_overflow_decide(const u64* sum192, u64 amax_word, u64 signflags, u
   ovf = false;
   if (cnt == 0 || amax_word == 0) return;
   // case 1: cnt · max|v| ≤ bound — no prefix of any order can leave the precision
-  if (amax_dec(amax_word) <= bound / (u128)cnt) return;
+  // (cnt · max|v| ≤ bound without the 128-bit division a quotient would cost per group: the 192-bit product's upper limb must be 0)
+  {
+    const u128 a = amax_dec(amax_word);
+    const u128 p0 = (u128)(u64)a * (u128)cnt, p1 = (u128)(u64)(a >> 64) * (u128)cnt;
+    const u128 mid = (p0 >> 64) + (u128)(u64)p1;
+    if ((u64)(p1 >> 64) + (u64)(mid >> 64) == 0 && (((u128)(u64)mid << 64) | (u128)(u64)p0) <= bound) return;
+  }
   // |total| from the three limbs
   bool neg = (sum192[2] >> 63) != 0;
   u64 l0 = sum192[0], l1 = sum192[1], l2 = sum192[2];
@@ -1736,7 +1754,9 @@ struct Slot {
 };
 
 // find-or-insert in the global table.  No lane ever waits for another lane while holding a claim, so lanes of one
-// wave probing the same slot cannot deadlock.
+// wave probing the same slot cannot deadlock.  A lane that finds the slot BUSY goes round the probe loop (`continue`) — it must not spin in
+// place: an inner `while (state == BUSY) reload` can be scheduled before the publishing branch of the winner IN THE SAME WAVE and then
+// never ends (tried with a claim-first variant in round 4: the aggregate tests hung on the GPU).
 //
 // Memory ordering without agent-scope fences: an acquire/release pair at agent scope costs an L2 invalidate
 // (buffer_inv sc1) and an L2 write-back (buffer_wbl2 sc1) PER ROW on CDNA3/4 — the per-XCD L2s are not coherent for
@@ -1746,7 +1766,7 @@ struct Slot {
 // (s_waitcnt vmcnt(0)) in between.  A reader only looks at the key after it has seen READY (control dependency).
 template <int NK, int NW, class InitFn>
 CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* key, InitFn init, u64 max_probes,
-                                        u32* insert_counter = nullptr) {
+                                        u32* insert_counter = nullptr, bool* fresh = nullptr) {
   u64 h = hash_key<NK>(key) & (cap - 1);
   for (u64 probes = 0; probes < max_probes;) {
     Slot<NK, NW>* s = &tbl[h];
@@ -1764,6 +1784,7 @@ CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* k
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&s->state, kSlotReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (insert_counter) (*insert_counter)++;   // per-lane count, added to the table's group counter once per wave
+        if (fresh) *fresh = true;
         return s;
       }
       continue;  // lost the race: re-read this slot
@@ -1840,6 +1861,44 @@ CDEV void slot_apply(WordPtr acc, const u64* val) {
     }
   }
 }
+
+// the same contribution applied to accumulators nobody else can see yet (registers): what slot_apply does, without atomics
+template <class P>
+CDEV void slot_apply_private(u64* acc, const u64* val) {
+#pragma unroll
+  for (int k = 0; k < P::NW; k++) {
+    switch (P::op(k)) {
+      case G_ADD64: acc[k] += val[k]; break;
+      case G_ADD128: case G_ADD192: {
+        const int limbs = P::op(k) == G_ADD128 ? 2 : 3;
+        u64 carry = 0;
+        for (int j = 0; j < limbs; j++) {
+          const u64 a = acc[k + j], b = val[k + j];
+          const u64 t = a + b, r = t + carry;
+          carry = (t < a || r < t) ? 1 : 0;
+          acc[k + j] = r;
+        }
+        break;
+      }
+      case G_UMAX64: if (val[k] > acc[k]) acc[k] = val[k]; break;
+      case G_OR64: acc[k] |= val[k]; break;
+      case G_IMIN64: if ((i64)val[k] < (i64)acc[k]) acc[k] = val[k]; break;
+      case G_IMAX64: if ((i64)val[k] > (i64)acc[k]) acc[k] = val[k]; break;
+      case G_FADD64: acc[k] = (u64)__double_as_longlong(fp_add(__longlong_as_double((i64)acc[k]), __longlong_as_double((i64)val[k]))); break;
+      case G_FMIN64: acc_fmin64(acc + k, val + k); break;
+      case G_FMAX64: acc_fmax64(acc + k, val + k); break;
+      default: break;  // G_CONT
+    }
+  }
+}
+// A slot's first contribution travels with its key: the lane that wins an empty slot stores identity ⊕ its own value before it publishes the
+// slot, instead of the identity followed by NW device-scope read-modify-writes (each of them a round trip to the coherence point, the limbs
+// of a wide sum one after the other).  With as many groups as rows — SF100 Q3's 1.13 M — that is every row.
+template <class P>
+struct SlotInitWith {
+  const u64* val;
+  CDEV void operator()(u64* acc) const { P::init(acc); slot_apply_private<P>(acc, val); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Block-level accumulation in LDS, "carry-save" form.
@@ -2019,11 +2078,12 @@ CDEV void group_update(const GroupCtx<P>& g, bool active, const u64* key, const 
     return;
   }
   if (g.table_full()) return;   // this pass is void: the host grows the table and re-runs the chunk
-  Slot<P::NK, P::NW>* s = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
-  if (!s) { g.set_full(); return; }
   u64 val[P::NW];
   P::fold(pv, val);
-  slot_apply<P, __HIP_MEMORY_SCOPE_AGENT>(&s->acc[0], val);
+  bool fresh = false;
+  Slot<P::NK, P::NW>* s = table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInitWith<P>{val}, kMaxGlobalProbes, g.counter(), &fresh);
+  if (!s) { g.set_full(); return; }
+  if (!fresh) slot_apply<P, __HIP_MEMORY_SCOPE_AGENT>(&s->acc[0], val);
 }
 
 // Kernel template C body.  prm.out[0] = global table, prm.iarg[0] = its capacity, prm.out[2] = err/aux words.
@@ -2093,9 +2153,10 @@ CDEV void agg_grouped_body(const CometKParams& prm) {
 #pragma unroll
       for (int k = 0; k < P::NPW; k++) pw[k] = ls->acc[k];
       P::fold(pw, val);
-      S* gs = g.table_full() ? nullptr : table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInit<P>(), kMaxGlobalProbes, g.counter());
-      if (gs) slot_apply<P, __HIP_MEMORY_SCOPE_AGENT>(&gs->acc[0], val);
-      else g.set_full();
+      bool fresh = false;
+      S* gs = g.table_full() ? nullptr : table_find_or_insert<P::NK, P::NW>(g.glb, g.glb_cap, key, SlotInitWith<P>{val}, kMaxGlobalProbes, g.counter(), &fresh);
+      if (!gs) g.set_full();
+      else if (!fresh) slot_apply<P, __HIP_MEMORY_SCOPE_AGENT>(&gs->acc[0], val);
     }
   }
   flush_inserted(g.err, g.inserted);

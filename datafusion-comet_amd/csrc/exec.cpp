@@ -1226,11 +1226,19 @@ DevTable ExecutionContext::nested_aggregate(const Operator& agg) {
   }
   // the sub-plan shares the Operator nodes: wrap the node in a non-owning shared_ptr
   OperatorP sub_plan(const_cast<Operator*>(&agg), [](Operator*) {});
-  ExecutionContext sub(sub_plan, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&agg] + 1)), config_, sub_inputs, 0, device_id_);
+  static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
+  Timer tm;
+  auto mark = [&](const char* what) { if (trace) fprintf(stderr, "[comet] nested aggregate: %s at %.3f ms\n", what, tm.ns() / 1e6); };
+  auto subp = std::make_unique<ExecutionContext>(sub_plan, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&agg] + 1)), config_, sub_inputs, 0, device_id_);
+  ExecutionContext& sub = *subp;
+  struct Gone { std::unique_ptr<ExecutionContext>& p; decltype(mark)& m; ~Gone() { p.reset(); m("context released"); } } gone{subp, mark};
+  mark("context built");
   if (sub.sink_ != SinkKind::AggGrouped && sub.sink_ != SinkKind::AggNoGroup) throw CometError("internal: nested aggregate without an aggregate sink");
   sub.device_result_ = true;
   sub.start();
+  mark("started");
   sub.run_to_completion();
+  mark("input consumed");
   DevTable t;
   if (sub.sink_ == SinkKind::AggNoGroup) {
     // an ungrouped aggregate yields exactly one row (TPC-H Q14 / Q17 / Q19 compute on it): finish it the usual way, then put that row
@@ -1242,6 +1250,7 @@ DevTable ExecutionContext::nested_aggregate(const Operator& agg) {
   } else {
     t = sub.grouped_to_device();
   }
+  mark("groups emitted");
   input_rows += sub.input_rows;
   sub.collect_timings();
   last_kernel_ms += sub.last_kernel_ms;

@@ -296,6 +296,7 @@ class ExecutionContext {
   PinnedBuf export_host_;  // a small result's buffers land here side by side (one copy kernel instead of a hipMemcpy per buffer)
   DevBuf group_table_, group_backup_;
   int64_t group_cap_ = 0;
+  bool group_table_clear_ = false;    // grouped: the global table holds nothing but zeroes (no chunk has gone into it): its checkpoint is a memset
   DevBuf scratch_mask_, scratch_counts_;
   std::vector<std::unique_ptr<DevBuf>> out_vals_, out_valid_;
   DevBuf emit_arena_;   // finish_grouped: values + validity bytes of every output column of one emit

@@ -9,10 +9,10 @@ mkdir -p $OUT
 PQ=/tmp/q6pq; mkdir -p $PQ
 
 tests() {          # the whole GPU suite
-  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log | cut -c1-200
+  timeout ${TESTS_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q --timeout ${TEST_TIMEOUT:-300} --timeout-method=thread > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log | cut -c1-200
 }
 tests_sel() {      # tests matched by $SEL (a -k expression) or the files in $FILES
-  timeout 900 python -m pytest ${FILES:-tests} -m gpu -x -q ${SEL:+-k "$SEL"} > $OUT/pytest_sel.log 2>&1; tail -15 $OUT/pytest_sel.log | cut -c1-220
+  timeout ${TSEL_TIMEOUT:-900} python -m pytest ${FILES:-tests} -m gpu -x -q --timeout ${TEST_TIMEOUT:-120} --timeout-method=thread ${SEL:+-k "$SEL"} > $OUT/pytest_sel.log 2>&1; tail -15 $OUT/pytest_sel.log | cut -c1-220
 }
 smoke() {
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
@@ -92,6 +92,10 @@ q3_timeline() {    # device timeline of one SF100 Q3 run (kernels + copies in st
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/q3_tl -o t -- python $GRAFT_REPO_ROOT/tools/q3_dist.py --orders 150000000 --steps 2 --warmup 1 --no-verify > $OUT/q3_tl.log 2>&1)
   python tools/timeline.py $(find $OUT/q3_tl -name "*kernel_trace.csv") $(find $OUT/q3_tl -name "*memory_copy_trace.csv") > $OUT/q3_tl.txt 2>&1
   head -${TL_LINES:-200} $OUT/q3_tl.txt | cut -c1-160
+}
+q3_host() {        # host calls and device work of the last SF100 Q3 run side by side: what fills the gaps between the kernels
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $OUT/q3_host -o h -- python $GRAFT_REPO_ROOT/tools/q3_dist.py --orders 150000000 --steps 2 --warmup 1 --no-verify > $OUT/q3_host.log 2>&1)
+  python tools/hip_timeline.py $OUT/q3_host k_filter 4 > $OUT/q3_host.txt 2>&1; rm -rf $OUT/q3_host; head -${TL_LINES:-400} $OUT/q3_host.txt | cut -c1-140
 }
 q3() {
   timeout 300 python tools/q3_dist.py --orders 150000000 --steps 5 --warmup 2 --out $OUT/q3.json > $OUT/q3.log 2>&1; cut -c1-700 $OUT/q3.json; echo

@@ -10,7 +10,7 @@ from collections import OrderedDict, defaultdict
 
 root = sys.argv[1]
 PFX = sys.argv[2] if len(sys.argv) > 2 else "q95"
-KERNELS = ("k_jbuild", "k_jprobe", "k_jlds", "k_filter", "k_jbemit", "k_jbcount")
+KERNELS = ("k_jbuild", "k_jprobe", "k_jdprobe", "k_jlds", "k_filter", "k_jbmap", "k_jbcnt", "k_jdrows", "k_gagg", "k_gemit", "k_jbemit", "k_jbcount")
 
 
 def short(n):
