@@ -2323,6 +2323,10 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   for (auto& n : d.op_names) src << n << " <- ";
   src << "input\n";
   if (const char* e = getenv("COMET_EXPERIMENT")) src << "#define COMET_EXPERIMENT " << atoi(e) << "\n";
+  // An aggregate sink reads every column byte once and keeps nothing but its accumulators: its column loads are non-temporal (streaming)
+  // loads — SF100 Q1's k_gagg 7.24-7.58 -> 7.01-7.13 ms in three alternating pairs on one box.  Join probes keep ordinary loads (their
+  // bitmap and build rows want the L2; both of SF100 Q3's got ~3 % slower with streaming loads).
+  if (agg) src << "#ifndef COMET_LD_NT\n#define COMET_LD_NT 1\n#endif\n";
   src << "#include \"comet_device.hpp\"\nusing namespace comet;\n";
 
   std::ostringstream ex;

@@ -48,7 +48,9 @@ CDEV u128 uabs128(i128 v) { return v < 0 ? (u128)0 - (u128)v : (u128)v; }
 // kernel-argument struct makes the compiler emit FLAT loads, which bump lgkmcnt as well as vmcnt and thereby
 // couple every LDS wait to the outstanding HBM loads.
 #define COMET_GLOBAL __attribute__((address_space(1)))
-#ifdef COMET_LD_NT
+// COMET_LD_NT (set by the generator for aggregate sinks; COMET_LD_NT=0/1 in the environment overrides it for experiments): column loads as
+// non-temporal loads — the lines are marked for early eviction in the L2 instead of displacing what a kernel re-reads
+#if defined(COMET_LD_NT) && COMET_LD_NT
 template <class T>
 CDEV T ld_stream(const COMET_GLOBAL T* p) { return __builtin_nontemporal_load(p); }
 template <>

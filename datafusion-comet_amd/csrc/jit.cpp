@@ -72,9 +72,9 @@ bool looks_like_code_object(const std::vector<char>& b) { return b.size() > 64 &
 }  // namespace
 
 std::shared_ptr<CodeObject> jit_compile(const std::string& source_in) {
-  // COMET_LD_NT (an experiment switch): column loads of the generated kernels as non-temporal (streaming) loads
+  // COMET_LD_NT=0/1 (an experiment switch): column loads of EVERY generated kernel as ordinary / non-temporal loads, whatever the generator chose
   static const char* nt = getenv("COMET_LD_NT");
-  const std::string source = nt ? std::string("#define COMET_LD_NT ") + nt + "\n" + source_in : source_in;
+  const std::string source = nt ? std::string("#define COMET_LD_NT ") + (atoi(nt) ? "1" : "0") + "\n" + source_in : source_in;
   // the key covers the generated source AND the hand-written headers it instantiates
   static const uint64_t h2 = fnv1a(toolchain_tag(), fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader, fnv1a(kEmbeddedRyuHeader, fnv1a(kEmbeddedStrtodHeader, fnv1a(kEmbeddedStrtsHeader))))));
   uint64_t h1 = fnv1a(source);

@@ -43,7 +43,7 @@ for d in sorted(glob.glob(root + f"/{PFX}_*")):
 for k in KERNELS:
     if k not in per:
         continue
-    print(f"== {k}: {len(per[k])} dispatches per profiled program (reps+1 runs of Q95 stage A)")
+    print(f"== {k}: {len(per[k])} dispatches in the profiled program (warm-up + timed runs)")
     cols = sorted({c for o in per[k].values() for c in o if not c.startswith("_")})
     print("  ord " + " ".join(f"{c[:14]:>14s}" for c in ["us", "grid"] + cols) + "   HBM_rd_MB  hit%")
     for o in sorted(per[k]):
