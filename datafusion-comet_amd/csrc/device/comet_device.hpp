@@ -1780,9 +1780,12 @@ CDEV Slot<NK, NW>* table_find_or_insert(Slot<NK, NW>* tbl, u64 cap, const u64* k
         u64 acc0[NW];
         init(acc0);
 #pragma unroll
-        for (int k = 0; k < NK; k++) __hip_atomic_store(&s->key[k], key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (an empty slot is all zeroes — the host clears tables with a memset — so a word that is zero is not stored: every access to a slot is
+        // an operation at the device's coherence point, and their NUMBER bounds a table with as many groups as rows; the null-flag key word
+        // and the upper limbs of a sum are zero nearly always)
+        for (int k = 0; k < NK; k++) if (key[k]) __hip_atomic_store(&s->key[k], key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int k = 0; k < NW; k++) __hip_atomic_store(&s->acc[k], acc0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < NW; k++) if (acc0[k]) __hip_atomic_store(&s->acc[k], acc0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&s->state, kSlotReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (insert_counter) (*insert_counter)++;   // per-lane count, added to the table's group counter once per wave
