@@ -426,6 +426,22 @@ int64_t comet_parquet_host_plain_values(const uint8_t* plan, size_t plan_len, in
   });
 }
 
+int64_t comet_error_json(const char* error_type, const char* error_class, const char* from_type, const char* to_type, int32_t precision, int32_t scale,
+                         int32_t value_kind, const char* suffix, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail, char* out, int64_t cap) {
+  comet::ErrSite s;
+  s.error_type = error_type ? error_type : "";
+  s.error_class = error_class ? error_class : "";
+  s.from_type = from_type ? from_type : "";
+  s.to_type = to_type ? to_type : "";
+  s.precision = precision;
+  s.scale = scale;
+  s.value = value_kind;
+  s.suffix = suffix ? suffix : "";
+  const std::string j = comet::err_site_json(s, lo, hi, str, str_avail < 0 ? 0 : (size_t)str_avail);
+  if (out && cap > (int64_t)j.size()) memcpy(out, j.c_str(), j.size() + 1);
+  return (int64_t)j.size();
+}
+
 int64_t comet_zone_table(const char* zone, int64_t* out, int64_t cap) {
   return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
     const std::vector<int64_t> f = load_zone(zone ? zone : "")->flat();

@@ -15,6 +15,9 @@
 #include "regex.hpp"
 #include "tz.hpp"
 #include "kparams.h"
+static_assert(comet::kErrBytes == COMET_ERR_BYTES && comet::kErrAuxWords == COMET_ERR_AUX_WORDS && comet::kErrDetailWord == COMET_ERR_DETAIL_WORD &&
+              comet::kErrDetailStrBytes == COMET_ERR_DETAIL_STR_BYTES && 16 + 8 * COMET_ERR_AUX_WORDS <= 8 * COMET_ERR_DETAIL_WORD &&
+              8 * COMET_ERR_DETAIL_WORD + 32 + COMET_ERR_DETAIL_STR_BYTES <= COMET_ERR_BYTES - 64, "the error block's layout (kparams.h) and codegen.hpp disagree");
 
 #include <cstdio>
 #include <cstdlib>
@@ -501,8 +504,51 @@ struct Gen {
     stmt("if (" + cond + ") atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], " + std::to_string(1u << code) + "u);");
   }
 
-  // CheckOverflow / bound check shared tail: value `v` (rep), ok expr, bound 10^p-1
-  Val bound_check(Val x, int p, bool fail_on_error, int err_code) {
+  // … and leave the offending value for the error's JSON (err_sites.cpp): a number's bits, or a string's bytes
+  void raise_value(const std::string& cond, int code, const ErrSite& site, const std::string& lo, const std::string& hi = "0") {
+    uses_err = true;
+    const std::string eb = "prm.out[" + std::to_string(kOutErr) + "]";
+    stmt("if (" + cond + ") { atomicOr((unsigned int*)" + eb + ", " + std::to_string(1u << code) + "u); comet::err_detail(" + eb + ", " +
+         std::to_string(register_err_site(site)) + "u, (u64)(" + lo + "), (u64)(" + hi + ")); }");
+  }
+  void raise_value128(const std::string& cond, int code, const ErrSite& site, const Val& x) {
+    if (x.rep == Rep::I128) raise_value(cond, code, site, "(u128)(" + x.v + ")", "((u128)(" + x.v + ") >> 64)");
+    else raise_value(cond, code, site, "(i64)(" + x.v + ")", "((i64)(" + x.v + ") >> 63)");
+  }
+  void raise_str(const std::string& cond, int code, const ErrSite& site, const std::string& ptr, const std::string& len) {
+    uses_err = true;
+    const std::string eb = "prm.out[" + std::to_string(kOutErr) + "]";
+    stmt("if (" + cond + ") { atomicOr((unsigned int*)" + eb + ", " + std::to_string(1u << code) + "u); comet::err_detail_str(" + eb + ", " +
+         std::to_string(register_err_site(site)) + "u, (const u8*)(" + ptr + "), (i32)(" + len + ")); }");
+  }
+  static ErrSite out_of_range_site(const DType& to) {      // decimal_overflow_error (common/src/error.rs:769-775): the unscaled value, the target's (p, s)
+    ErrSite s;
+    s.error_type = "NumericValueOutOfRange";
+    s.error_class = "NUMERIC_VALUE_OUT_OF_RANGE.WITH_SUGGESTION";
+    s.precision = to.precision;
+    s.scale = to.scale;
+    return s;
+  }
+  static std::string spark_type_name(const DType& t) {
+    switch (t.id) {
+      case TypeId::Bool: return "BOOLEAN";
+      case TypeId::Int8: return "TINYINT";
+      case TypeId::Int16: return "SMALLINT";
+      case TypeId::Int32: return "INT";
+      case TypeId::Int64: return "BIGINT";
+      case TypeId::Float: return "FLOAT";
+      case TypeId::Double: return "DOUBLE";
+      case TypeId::Date: return "DATE";
+      case TypeId::Timestamp: return "TIMESTAMP";
+      case TypeId::TimestampNtz: return "TIMESTAMP_NTZ";
+      case TypeId::String: return "STRING";
+      case TypeId::Decimal: return "DECIMAL(" + std::to_string(t.precision) + "," + std::to_string(t.scale) + ")";
+      default: return t.str();
+    }
+  }
+
+  // CheckOverflow / bound check shared tail: value `v` (rep), ok expr, bound 10^p-1.  `site`: what the error names (the value defaults to x's)
+  Val bound_check(Val x, int p, bool fail_on_error, int err_code, const ErrSite* site = nullptr, const std::string* value_lo = nullptr) {
     u128 bound = pow10_u128(p) - 1;
     if (x.maxabs <= bound) return x;  // statically in range: nothing to emit
     x = named(x);
@@ -510,7 +556,9 @@ struct Gen {
                                           : "comet::dec_fits64(" + x.v + ", " + hex64((uint64_t)bound) + ")";
     if (x.rep != Rep::I128 && bound >= ((u128)1 << 63)) return x;  // i64 value cannot exceed a ≥2^63 bound
     if (fail_on_error) {
-      raise_if(and_ok(x.ok, "!" + fits), err_code);
+      if (site && value_lo) raise_value(and_ok(x.ok, "!" + fits), err_code, *site, *value_lo);
+      else if (site) raise_value128(and_ok(x.ok, "!" + fits), err_code, *site, x);
+      else raise_if(and_ok(x.ok, "!" + fits), err_code);
     } else {
       std::string o = newvar("bool");
       stmt(o + " = " + and_ok(x.ok, fits) + ";");
@@ -561,7 +609,7 @@ struct Gen {
       r.ok = and_ok(a.ok, b.ok);
       std::string val = newvar("i128"), dz = newvar("bool");
       stmt(val + " = comet::dec_rem(" + as128(a) + ", " + as128(b) + ", " + lit_u128(pow10_u128(smax - s1)) + ", " + lit_u128(pow10_u128(smax - s2)) + ", " + dz + ");");
-      if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, dz), 8);
+      if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, dz), 15);      // RemainderByZero
       else {
         std::string o = newvar("bool");
         stmt(o + " = " + and_ok(r.ok, "!" + dz) + ";");
@@ -685,7 +733,7 @@ struct Gen {
         a = named(a);
         b = named(b);
         const std::string bz = "((" + std::string(ct) + ")" + b.v + " == 0)";
-        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, bz), 8);
+        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, bz), 15);      // RemainderByZero
         else {
           std::string o = newvar("bool");
           stmt(o + " = " + and_ok(r.ok, "!" + bz) + ";");
@@ -738,7 +786,7 @@ struct Gen {
         a = named(a);
         b = named(b);
         const std::string bz = "((" + std::string(ct) + ")" + b.v + " == 0)";
-        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, bz), 8);
+        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(r.ok, bz), 15);      // RemainderByZero
         else {
           std::string o = newvar("bool");
           stmt(o + " = " + and_ok(r.ok, "!" + bz) + ";");
@@ -783,7 +831,16 @@ struct Gen {
       const char* nt = to.id == TypeId::Int8 ? "i8" : to.id == TypeId::Int16 ? "i16" : "i32";
       c = named(c);
       r.v = std::string("(") + rep_ctype(r.rep) + ")(" + nt + ")" + c.v;
-      if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(c.ok, std::string("(i64)(") + nt + ")" + c.v + " != (i64)" + c.v), 2);
+      if (e.eval_mode == EvalMode::Ansi) {
+        ErrSite site;      // cast_int_to_int_macro (numeric.rs:282-305, 828-845): value.to_string() + Spark's literal suffix of the source type
+        site.error_type = "CastOverFlow";
+        site.error_class = "CAST_OVERFLOW";
+        site.from_type = spark_type_name(from);
+        site.to_type = spark_type_name(to);
+        site.value = ErrSite::Int64;
+        site.suffix = from.id == TypeId::Int64 ? "L" : from.id == TypeId::Int16 ? "S" : "";
+        raise_value(and_ok(c.ok, std::string("(i64)(") + nt + ")" + c.v + " != (i64)" + c.v), 2, site, "(i64)" + c.v);
+      }
       r.maxabs = type_maxabs(to);
       return r;
     }
@@ -804,7 +861,10 @@ struct Gen {
       m.maxabs = sat_mul(c.maxabs, f);
       m.rep = rep_for_bound(m.maxabs);
       m.v = m.rep == Rep::I64 ? "((i64)" + c.v + " * " + lit_i64((int64_t)f) + ")" : "((i128)" + c.v + " * " + lit_i128((i128)f) + ")";
-      return bound_check(m, to.precision, e.eval_mode == EvalMode::Ansi, 3);
+      ErrSite site = out_of_range_site(to);      // cast_int_to_decimal128 (numeric.rs:755-765): the INPUT integer, v.to_string()
+      site.value = ErrSite::Int64Plain;
+      const std::string in_value = "(i64)" + c.v;
+      return bound_check(m, to.precision, e.eval_mode == EvalMode::Ansi, 3, &site, &in_value);
     }
     if (from.id == TypeId::Decimal && to.id == TypeId::Decimal) {
       // Deferred: CheckOverflow(Cast(dec→dec)) fuses into DecimalRescaleCheckOverflow (planner.rs:615-633).
@@ -874,9 +934,16 @@ struct Gen {
       // ANSI: NaN or |value| as dest == dest::MAX (i32::MAX for the narrow types, then try_from) → CAST_OVERFLOW
       c = named(c);
       const std::string d = "(double)" + c.v;
+      ErrSite site;      // cast_float_to_int*: format!("{:e}D" / "{:e}", value) with e → E (numeric.rs:335-349, 1028-1118)
+      site.error_type = "CastOverFlow";
+      site.error_class = "CAST_OVERFLOW";
+      site.from_type = spark_type_name(from);
+      site.to_type = spark_type_name(to);
+      site.value = from.id == TypeId::Double ? ErrSite::F64 : ErrSite::F32;
+      const std::string bits = from.id == TypeId::Double ? "(u64)__double_as_longlong(" + d + ")" : "(u64)(u32)__float_as_int((float)" + c.v + ")";
       if (to.id == TypeId::Int64) {
         r.v = "comet::f64_to_i64_sat(" + d + ")";
-        if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(c.ok, "(" + d + " != " + d + " || comet::f64_to_i64_sat(fabs(" + d + ")) == (i64)0x7fffffffffffffffll)"), 2);
+        if (e.eval_mode == EvalMode::Ansi) raise_value(and_ok(c.ok, "(" + d + " != " + d + " || comet::f64_to_i64_sat(fabs(" + d + ")) == (i64)0x7fffffffffffffffll)"), 2, site, bits);
       } else {
         const std::string i32v = "comet::f64_to_i32_sat(" + d + ")";
         if (to.id == TypeId::Int32) r.v = i32v;
@@ -884,7 +951,7 @@ struct Gen {
         if (e.eval_mode == EvalMode::Ansi) {
           std::string ovf = "(" + d + " != " + d + " || comet::f64_to_i32_sat(fabs(" + d + ")) == (i32)0x7fffffff";
           if (to.id != TypeId::Int32) ovf += " || (i32)(" + std::string(to.id == TypeId::Int8 ? "i8" : "i16") + ")" + i32v + " != " + i32v;
-          raise_if(and_ok(c.ok, ovf + ")"), 2);
+          raise_value(and_ok(c.ok, ovf + ")"), 2, site, bits);
         }
       }
       r.maxabs = type_maxabs(to);
@@ -904,7 +971,16 @@ struct Gen {
         const std::string mx = to.id == TypeId::Int64 ? "(u128)0x7fffffffffffffffull" : "(u128)0x7fffffffu";
         std::string ovf = "(comet::uabs128(" + t + ") > " + mx;
         if (to.id == TypeId::Int8 || to.id == TypeId::Int16) ovf += " || " + v + " != (i32)" + t;
-        raise_if(and_ok(c.ok, ovf + ")"), 2);
+        ErrSite site;      // cast_decimal_to_int*: "{}BD" of format_decimal_str(value, p, s), from "DECIMAL(p,s)" (numeric.rs:440-560)
+        site.error_type = "CastOverFlow";
+        site.error_class = "CAST_OVERFLOW";
+        site.from_type = spark_type_name(from);
+        site.to_type = spark_type_name(to);
+        site.value = ErrSite::DecimalBD;
+        site.precision = from.precision;
+        site.scale = from.scale;
+        Val cv = c;
+        raise_value128(and_ok(c.ok, ovf + ")"), 2, site, cv);
       }
       r.maxabs = type_maxabs(to);
       return r;
@@ -916,7 +992,11 @@ struct Gen {
       c = named(c);
       std::string out = newvar("i128"), rc = newvar("int");
       stmt(out + " = 0; " + rc + " = comet::f64_bits_to_decimal((u64)__double_as_longlong((double)" + c.v + "), " + std::to_string(to.precision) + ", " + std::to_string(to.scale) + ", " + out + ");");
-      if (e.eval_mode == EvalMode::Ansi) raise_if(and_ok(c.ok, "(" + rc + " == 3)"), 3);
+      if (e.eval_mode == EvalMode::Ansi) {
+        ErrSite site = out_of_range_site(to);      // numeric.rs:938-948: input_value.to_string() — Rust's Display of the f64
+        site.value = ErrSite::F64Display;
+        raise_value(and_ok(c.ok, "(" + rc + " == 3)"), 3, site, "(u64)__double_as_longlong((double)" + c.v + ")");
+      }
       std::string o = newvar("bool");
       stmt(o + " = " + and_ok(c.ok, "(" + rc + " == 0)") + ";");
       r.ok = o;
@@ -1006,8 +1086,27 @@ struct Gen {
     stmt(out + " = 0; " + rc + " = 2; " + (valid.ok.empty() ? "" : "if (" + valid.ok + ") ") + "{ i32 sn; comet::strp sp = comet::utf8_bytes(prm.in[" + std::to_string(loc.first) + "], " +
          loc.second + ", sn); " + rc + " = " + call + "; }");
     if (e.eval_mode == EvalMode::Ansi) {
-      raise_if("(" + rc + " == 1)", err_bit);
-      if (to.id == TypeId::Decimal) raise_if("(" + rc + " == 3)", 3);
+      // invalid_value(raw value, "STRING", type name) (string.rs:219, 359, 995-1117) / InvalidInputInCastToDatetime with the raw value (:39-70): the
+      // string's bytes go into the error block
+      auto raise_with_string = [&](const std::string& cond, int code, const ErrSite& site) {
+        uses_err = true;
+        const std::string eb = "prm.out[" + std::to_string(kOutErr) + "]";
+        stmt("if (" + cond + ") { atomicOr((unsigned int*)" + eb + ", " + std::to_string(1u << code) + "u); i32 en_; comet::strp ep_ = comet::utf8_bytes(prm.in[" +
+             std::to_string(loc.first) + "], " + loc.second + ", en_); comet::err_detail_str(" + eb + ", " + std::to_string(register_err_site(site)) + "u, (const u8*)ep_, en_); }");
+      };
+      ErrSite site;
+      const bool datetime = err_bit == 10 || err_bit == 13 || err_bit == 14;
+      site.error_type = datetime ? "InvalidInputInCastToDatetime" : "CastInvalidValue";
+      site.error_class = "CAST_INVALID_INPUT";
+      site.from_type = "STRING";
+      site.to_type = spark_type_name(to);
+      site.value = ErrSite::Str;
+      raise_with_string("(" + rc + " == 1)", err_bit, site);
+      if (to.id == TypeId::Decimal) {
+        ErrSite o = out_of_range_site(to);      // string.rs:645-652: the (trimmed) string that parsed to a decimal beyond the precision
+        o.value = ErrSite::Str;
+        raise_with_string("(" + rc + " == 3)", 3, o);
+      }
     }
     if (to.id == TypeId::Timestamp || to.id == TypeId::TimestampNtz) {
       raise_if("(" + rc + " == 4 || " + rc + " == 6)", 12);
@@ -1035,11 +1134,14 @@ struct Gen {
     r.ok = c.ok;
     const int delta = s_out - s_in;
     const u128 bound = pow10_u128(p_out) - 1;
+    // (the reference fails a rescale with a plain compute error, decimal_rescale_check.rs:124,145; here it is the CheckOverflow it fuses — the
+    // unscaled value that does not fit and the target's (p, s))
+    const ErrSite site = out_of_range_site(r.t);
     if (delta == 0) {
       r.v = c.v;
       r.rep = c.rep;
       r.maxabs = c.maxabs;
-      return bound_check(r, p_out, fail_on_error, 3);
+      return bound_check(r, p_out, fail_on_error, 3, &site);
     }
     if (std::abs(delta) > 38) throw CometError("DecimalRescaleCheckOverflow: scale delta " + std::to_string(delta) + " exceeds maximum supported range");
     u128 f = pow10_u128(std::abs(delta));
@@ -1048,7 +1150,7 @@ struct Gen {
       if (r.maxabs != kUnbounded && r.maxabs < ((u128)1 << 126)) {
         r.rep = rep_for_bound(r.maxabs);
         r.v = r.rep == Rep::I64 ? "(" + as64(c) + " * " + lit_i64((int64_t)f) + ")" : "(" + as128(c) + " * " + lit_i128((i128)f) + ")";
-        return bound_check(r, p_out, fail_on_error, 3);
+        return bound_check(r, p_out, fail_on_error, 3, &site);
       }
       c = named(c);
       std::string out = newvar("i128"), fit = newvar("bool");
@@ -1056,7 +1158,7 @@ struct Gen {
       r.rep = Rep::I128;
       r.v = out;
       r.maxabs = bound;
-      if (fail_on_error) raise_if(and_ok(c.ok, "!" + fit), 3);
+      if (fail_on_error) raise_value128(and_ok(c.ok, "!" + fit), 3, site, c);      // (the value before the multiplication that left 128 bits or the precision)
       else {
         std::string o = newvar("bool");
         stmt(o + " = " + and_ok(c.ok, fit) + ";");
@@ -1074,7 +1176,7 @@ struct Gen {
     r.maxabs = m;
     if (m <= bound) return r;  // cannot overflow: `fit` is always true
     r.maxabs = bound;
-    if (fail_on_error) raise_if(and_ok(c.ok, "!" + fit), 3);
+    if (fail_on_error) { Val ov = r; ov.v = out; ov.rep = Rep::I128; raise_value128(and_ok(c.ok, "!" + fit), 3, site, ov); }
     else {
       std::string o = newvar("bool");
       stmt(o + " = " + and_ok(c.ok, fit) + ";");
@@ -1784,7 +1886,8 @@ struct Gen {
         x.t = e.dtype;
         x.wide_decimal = false;
         x.is_cast_dec = false;
-        return bound_check(x, e.dtype.precision, e.fail_on_error, 3);
+        const ErrSite site = out_of_range_site(e.dtype);      // checkoverflow.rs:141-147: the first value that does not fit, unscaled
+        return bound_check(x, e.dtype.precision, e.fail_on_error, 3, &site);
       }
       case ExprKind::Hour: case ExprKind::Minute: case ExprKind::Second: {
         // SparkHour / SparkMinute / SparkSecond (datetime_funcs/extract_date_part.rs:83-110): of the session zone's wall clock; a TIMESTAMP_NTZ is one already
@@ -3003,7 +3106,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     int cap = 1024;
     while (cap > 16 && cap * slot_bytes > 10 * 1024) cap >>= 1;
     d.lds_cap = cap;
-    if (al.nkw > (kErrBytes - 16 - 64) / 8) throw   // the last 64 bytes of the block are scratch words of the executor
+    if (al.nkw > kErrAuxWords) throw   // the last 64 bytes of the block are scratch words of the executor
        CometError("too many overflow-tracked sums in one aggregate");
     src << "  static constexpr int NK = " << d.NK << ";\n  static constexpr int NPW = " << al.npw << ";\n  static constexpr int NKW = " << al.nkw
         << ";\n  static constexpr int LDS_CAP = " << cap << ";\n  static constexpr int GC = " << gc << ";\n  static constexpr int COPIES = " << copies << ";\n";

@@ -111,7 +111,27 @@ void fold_chain(const Operator& top, const Operator& source, const std::vector<D
 constexpr int kOutPartials = 0;      // AggNoGroup: partials;  Output: mask words
 constexpr int kOutCounts = 1;        // Output: tile counts / offsets
 constexpr int kOutErr = 2;           // u32[4] error flags (ANSI overflow etc.)
-constexpr int kErrBytes = 256;       // error/aux block: u32 flags[4] (u64 group counter at +8), then u64 aux words from +16
+constexpr int kErrBytes = 512;       // error/aux block (kparams.h COMET_ERR_BYTES): flags, group counter, aux words, error detail, scratch
+constexpr int kErrAuxWords = 22;     // (COMET_ERR_AUX_WORDS)
+constexpr int kErrDetailWord = 24;   // (COMET_ERR_DETAIL_WORD)
+constexpr int kErrDetailStrBytes = 224;
+
+// A raise site whose Spark error names the offending value (common/src/error.rs:318-380 params_as_json): what is static about it.  Sites are
+// registered process-wide under an id derived from their content, so the generated text — and with it the code-object cache key — does not
+// depend on the order plans arrive in.
+struct ErrSite {
+  enum Value : int { Unscaled128 = 0, Int64 = 1, F64 = 2, F32 = 3, Str = 4, DecimalBD = 5, F64Display = 6, Int64Plain = 7 };
+  std::string error_type;    // "NumericValueOutOfRange", "CastOverFlow", "CastInvalidValue", "InvalidInputInCastToDatetime"
+  std::string error_class;
+  std::string from_type, to_type;      // Spark SQL type names ("BIGINT", "DECIMAL(10,2)", "STRING" …)
+  int precision = 0, scale = 0;        // NumericValueOutOfRange; DecimalBD: the SOURCE decimal's
+  int value = Unscaled128;
+  std::string suffix;                  // Int64: Spark's literal suffix ("L", "S", "")
+};
+uint32_t register_err_site(const ErrSite& s);
+bool lookup_err_site(uint32_t id, ErrSite& out);
+// the error JSON of a site and the detail the device left (lo / hi: the value's bits or a string's length; str: its first bytes)
+std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint8_t* str, size_t str_avail);
 constexpr int kOutFirstCol = 4;      // out[4+2j] = values of col j, out[5+2j] = validity bytes of col j
 
 }  // namespace comet

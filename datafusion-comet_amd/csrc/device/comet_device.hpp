@@ -41,6 +41,24 @@ CDEV u64 hi64(i128 v) { return (u64)((u128)v >> 64); }
 CDEV u128 uabs128(i128 v) { return v < 0 ? (u128)0 - (u128)v : (u128)v; }
 
 // ---------------------------------------------------------------------------------------------
+// Error detail (kparams.h: the block behind out[2]).  The Spark error a raised flag becomes names the offending value
+// (common/src/error.rs params_as_json; the JVM side reads params("value") …): the FIRST lane to report leaves the raise site's id and the
+// value — its bits, or a string's bytes — for the host to format.  Cold code: reached on the row that fails the task.
+// ---------------------------------------------------------------------------------------------
+CDEV void err_detail(void* errbuf, u32 site, u64 lo, u64 hi) {
+  unsigned long long* d = (unsigned long long*)errbuf + COMET_ERR_DETAIL_WORD;
+  if (atomicCAS(d, 0ull, (unsigned long long)site + 1ull) == 0ull) { d[1] = lo; d[2] = hi; }
+}
+CDEV void err_detail_str(void* errbuf, u32 site, const u8* p, i32 n) {
+  unsigned long long* d = (unsigned long long*)errbuf + COMET_ERR_DETAIL_WORD;
+  if (atomicCAS(d, 0ull, (unsigned long long)site + 1ull) == 0ull) {
+    d[1] = (unsigned long long)(n < 0 ? 0 : n);
+    u8* o = (u8*)(d + 4);
+    for (i32 k = 0; k < n && k < COMET_ERR_DETAIL_STR_BYTES; k++) o[k] = p[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column access.  Lane l of a wave reads row base+l: every load instruction is one contiguous
 // 64×sizeof(T) segment (1 KiB for Decimal128).
 // ---------------------------------------------------------------------------------------------

@@ -293,11 +293,24 @@ void ExecutionContext::check_device_errors() {
 
 void ExecutionContext::raise_device_errors(uint32_t f) {
   if (!f) return;
-  // Spark error JSON as thrown through CometQueryExecutionException (native/common/src/error.rs:806-831)
+  // Spark error JSON as thrown through CometQueryExecutionException (native/common/src/error.rs:806-831).  An error that names the offending
+  // value left its raise site and the value in the detail words of the error block (kparams.h; err_sites.cpp formats them): the JVM side reads
+  // params("value"), params("precision") … back (ShimSparkErrorConverter.scala), a missing key would be a NoSuchElementException there.
+  if (f & (4u | 8u | 512u | 1024u | 8192u | 16384u)) {
+    uint64_t detail[4 + kErrDetailStrBytes / 8];
+    memset(detail, 0, sizeof detail);
+    read_small(detail, (const char*)err_flags_.p + 8 * kErrDetailWord, sizeof detail);
+    ErrSite site;
+    if (detail[0] != 0 && lookup_err_site((uint32_t)(detail[0] - 1), site)) {
+      // (the flag that is raised and the site that won the detail words can differ when two kinds of error meet in one launch: the site's own
+      // error is reported — it did occur)
+      throw CometError(err_site_json(site, detail[1], detail[2], (const uint8_t*)(detail + 4), (size_t)kErrDetailStrBytes), 1);
+    }
+  }
   if (f & 1u) throw CometError("{\"errorType\":\"ArithmeticOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"fromType\":\"decimal\"}}", 1);
   if (f & 2u) throw CometError("{\"errorType\":\"ArithmeticOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"fromType\":\"integer\"}}", 1);
   if (f & 4u) throw CometError("{\"errorType\":\"CastOverFlow\",\"errorClass\":\"CAST_OVERFLOW\",\"params\":{}}", 1);
-  if (f & 8u) throw CometError("{\"errorType\":\"NumericValueOutOfRange\",\"errorClass\":\"NUMERIC_VALUE_OUT_OF_RANGE\",\"params\":{}}", 1);
+  if (f & 8u) throw CometError("{\"errorType\":\"NumericValueOutOfRange\",\"errorClass\":\"NUMERIC_VALUE_OUT_OF_RANGE.WITH_SUGGESTION\",\"params\":{}}", 1);
   if (f & 512u) throw CometError("{\"errorType\":\"CastInvalidValue\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\"}}", 1);
   if (f & 1024u) throw CometError("{\"errorType\":\"InvalidInputInCastToDatetime\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\",\"toType\":\"DATE\"}}", 1);
   if (f & 8192u) throw CometError("{\"errorType\":\"InvalidInputInCastToDatetime\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\",\"toType\":\"TIMESTAMP\"}}", 1);
@@ -305,6 +318,7 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
   if (f & 4096u) throw CometError("a string cast to a timestamp names a time zone inside the value, or holds a time of day without a date (which takes the current date): not supported by the MI355X native engine");
   if (f & 2048u) throw CometError("a timestamp lies behind the end of its time zone's table (the year 2400): not supported by the MI355X native engine");
   if (f & 256u) throw CometError("{\"errorType\":\"DivideByZero\",\"errorClass\":\"DIVIDE_BY_ZERO\",\"params\":{}}", 1);
+  if (f & 32768u) throw CometError("{\"errorType\":\"RemainderByZero\",\"errorClass\":\"REMAINDER_BY_ZERO\",\"params\":{}}", 1);      // (common/src/error.rs:81-82, 684)
   if (f & 64u) throw CometError("Utf8 group keys longer than 15 bytes are not supported by the GPU hash aggregate yet");
   if (f & 16u)
     throw CometError("decimal sum overflow cannot be decided order-independently for this input (mixed signs beyond the precision bound); "

@@ -130,6 +130,9 @@ def _load() -> ctypes.CDLL:
     lib.comet_plan_set_memory_manager.argtypes = [c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64]
     lib.comet_parquet_prune_report.restype = c.c_int64
     lib.comet_parquet_prune_report.argtypes = [c.c_char_p, c.c_size_t, c.c_int32, c.c_char_p, c.c_size_t]
+    lib.comet_error_json.restype = c.c_int64
+    lib.comet_error_json.argtypes = [c.c_char_p, c.c_char_p, c.c_char_p, c.c_char_p, c.c_int32, c.c_int32, c.c_int32, c.c_char_p, c.c_uint64, c.c_uint64, c.c_char_p,
+                                     c.c_int64, c.c_char_p, c.c_int64]
     lib.comet_zone_table.restype = c.c_int64
     lib.comet_zone_table.argtypes = [c.c_char_p, c.c_void_p, c.c_int64]
     lib.comet_rlike_match.restype = c.c_int32
@@ -1060,6 +1063,17 @@ def page_decompress(codec: int, data: bytes, uncompressed_size: int) -> bytes:
     if lib().comet_page_decompress(codec, data, len(data), out.ctypes.data, uncompressed_size) != 0:
         _raise_last(0)
     return out[:uncompressed_size].tobytes()
+
+
+def error_json(error_type: str, error_class: str, value_kind: int, lo: int = 0, hi: int = 0, from_type: str = "", to_type: str = "", precision: int = 0, scale: int = 0,
+               suffix: str = "", string: bytes = b"") -> dict:
+    """the Spark error JSON of one raise site and the value a kernel left (comet_error_json; csrc/err_sites.cpp), parsed"""
+    import json
+    buf = ctypes.create_string_buffer(4096)
+    n = lib().comet_error_json(error_type.encode(), error_class.encode(), from_type.encode(), to_type.encode(), precision, scale, value_kind, suffix.encode(),
+                               lo & (2**64 - 1), hi & (2**64 - 1), string, len(string), buf, len(buf))
+    assert 0 < n < len(buf)
+    return json.loads(buf.value.decode())
 
 
 def zone_table(zone: str):

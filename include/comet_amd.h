@@ -190,6 +190,17 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
  * offsets ("UTC", "+05:30") without it.  Returns the number of words (written when cap suffices), or -2 and comet_last_error(0).  Needs no GPU. */
 int64_t comet_zone_table(const char* zone, int64_t* out, int64_t cap);
 
+/* ---- Spark error JSON (csrc/err_sites.cpp) ---------------------------------------------------------------------------------------------
+ * What a failing task throws through CometQueryExecutionException when the error names the offending value: {"errorType", "errorClass",
+ * "params": {"value", "precision", "scale"} | {"value", "fromType", "toType"}} exactly as native/common/src/error.rs:318-380 serialises it and
+ * spark/…/ShimSparkErrorConverter.scala reads it back.  This entry formats ONE such error from a raise site's static part and the value the
+ * kernel left in its error block (value_kind: 0 unscaled decimal in (hi, lo), 1 integer + literal suffix, 2 double as "{:e}D", 3 float as
+ * "{:e}", 4 the first str_avail bytes of a string of lo bytes, 5 decimal(precision, scale) + "BD", 6 double as Rust prints it, 7 integer) —
+ * the executor calls the same routine; exported so that the formats are testable without a GPU.  Returns the JSON's length (written when cap
+ * suffices). */
+int64_t comet_error_json(const char* error_type, const char* error_class, const char* from_type, const char* to_type, int32_t precision, int32_t scale,
+                         int32_t value_kind, const char* suffix, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail, char* out, int64_t cap);
+
 /* ---- the host page codecs (csrc/parquet_meta.cpp) ---------------------------------------------------------------------------------------
  * What the scan's host threads run on the pages the device does not decompress itself: Parquet CompressionCodec 0 UNCOMPRESSED, 1 SNAPPY,
  * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and

@@ -643,7 +643,7 @@ class Evaluator:
                     L, R = dec_to_int(a.values, i) * 10 ** (sm - s1), dec_to_int(b.values, i) * 10 ** (sm - s2)
                     if R == 0:
                         if e.eval_mode == S.ANSI and live[i]:
-                            raise OracleError("REMAINDER_BY_ZERO / DIVIDE_BY_ZERO")
+                            raise OracleError("REMAINDER_BY_ZERO")
                         nz[i] = False
                         res.append(0)
                         continue
@@ -679,7 +679,7 @@ class Evaluator:
             zero = y == 0
             live = np.ones(n, bool) if valid is None else valid
             if e.eval_mode == S.ANSI and (zero & live).any():
-                raise OracleError("REMAINDER_BY_ZERO / DIVIDE_BY_ZERO")
+                raise OracleError("REMAINDER_BY_ZERO")
             with np.errstate(all="ignore"):
                 if rt.type_id in (S.FLOAT, S.DOUBLE):
                     r = np.fmod(x, np.where(zero, 1, y)).astype(nt)

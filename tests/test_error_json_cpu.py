@@ -1,0 +1,67 @@
+"""The Spark error JSON of errors that name the offending value (csrc/err_sites.cpp through comet_error_json): the keys the JVM side reads back
+(spark/src/main/spark-3.5/…/ShimSparkErrorConverter.scala: params("value"), params("precision"), params("scale"), params("fromType"),
+params("toType") — a missing one is a NoSuchElementException there) and the value formats of the reference's raise sites
+(common/src/error.rs:318-380, 769-775; conversion_funcs/numeric.rs:282-305, 335-349, 440-585, 755-765, 938-948; string.rs:39-70, 219, 359, 1117)."""
+import struct
+
+from datafusion_comet_amd import native
+
+NVOOR = ("NumericValueOutOfRange", "NUMERIC_VALUE_OUT_OF_RANGE.WITH_SUGGESTION")
+OVF = ("CastOverFlow", "CAST_OVERFLOW")
+
+
+def _f64(x):
+    return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+
+def _f32(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def test_numeric_value_out_of_range():
+    # decimal_overflow_error (error.rs:769-775): the UNSCALED i128, to_string(); error.rs:941-953's own test expects the keys value / precision / scale
+    j = native.error_json(*NVOOR, 0, lo=99999, precision=5, scale=2)
+    assert j == {"errorType": "NumericValueOutOfRange", "errorClass": "NUMERIC_VALUE_OUT_OF_RANGE.WITH_SUGGESTION", "params": {"value": "99999", "precision": 5, "scale": 2}}
+    big = -(10**30 + 7)
+    j = native.error_json(*NVOOR, 0, lo=big & (2**64 - 1), hi=(big >> 64) & (2**64 - 1), precision=28, scale=10)
+    assert j["params"] == {"value": str(big), "precision": 28, "scale": 10}
+    # cast_int_to_decimal128 (numeric.rs:760): the input integer; numeric.rs:1396-1400's test: 1000 → decimal(3,2)
+    assert native.error_json(*NVOOR, 7, lo=1000, precision=3, scale=2)["params"] == {"value": "1000", "precision": 3, "scale": 2}
+    assert native.error_json(*NVOOR, 7, lo=-5 & (2**64 - 1), precision=3, scale=2)["params"]["value"] == "-5"
+    # cast_float_to_decimal128 (numeric.rs:943): Rust's Display of the f64; numeric.rs:1566-1571 and :1739-1744 expect "4242.42" and "99.995"
+    for x, want in [(4242.42, "4242.42"), (99.995, "99.995"), (1e21, "1000000000000000000000"), (-0.5, "-0.5"), (1e-7, "0.0000001"), (123456789.0, "123456789")]:
+        assert native.error_json(*NVOOR, 6, lo=_f64(x), precision=5, scale=2)["params"]["value"] == want, x
+
+
+def test_cast_overflow():
+    # cast_int_to_int_macro: value.to_string() + the source type's literal suffix (numeric.rs:296-300, 828-845)
+    j = native.error_json(*OVF, 1, lo=2147483648, from_type="BIGINT", to_type="INT", suffix="L")
+    assert j == {"errorType": "CastOverFlow", "errorClass": "CAST_OVERFLOW", "params": {"value": "2147483648L", "fromType": "BIGINT", "toType": "INT"}}
+    assert native.error_json(*OVF, 1, lo=-129 & (2**64 - 1), from_type="SMALLINT", to_type="TINYINT", suffix="S")["params"]["value"] == "-129S"
+    assert native.error_json(*OVF, 1, lo=40000, from_type="INT", to_type="SMALLINT")["params"]["value"] == "40000"
+    # cast_float_to_int*: format!("{:e}D", v).replace("e", "E") for doubles, "{:e}" for floats (numeric.rs:335-349, 1028-1118)
+    for x, want in [(1e10, "1E10D"), (3.0e9, "3E9D"), (-2.5e19, "-2.5E19D"), (1.5e-7, "1.5E-7D"), (float("nan"), "NaND"), (float("inf"), "infD"), (123456789012.5, "1.234567890125E11D")]:
+        assert native.error_json(*OVF, 2, lo=_f64(x), from_type="DOUBLE", to_type="INT")["params"]["value"] == want, x
+    for x, want in [(3.0e9, "3E9"), (1.5e10, "1.5E10"), (float("nan"), "NaN")]:
+        assert native.error_json(*OVF, 3, lo=_f32(x), from_type="FLOAT", to_type="INT")["params"]["value"] == want, x
+    # cast_decimal_to_int*: format_decimal_str(value, p, s) + "BD", from "DECIMAL(p,s)" (numeric.rs:440-585)
+    for unscaled, p, s, want in [(1234567890123, 15, 2, "12345678901.23BD"), (-1234567890123, 15, 2, "-12345678901.23BD"), (5, 10, 3, "0.005BD"), (-5, 10, 3, "-0.005BD"),
+                                 (123456, 6, 0, "123456BD"), (10**20, 38, 0, "1" + "0" * 20 + "BD")]:
+        j = native.error_json(*OVF, 5, lo=unscaled & (2**64 - 1), hi=(unscaled >> 64) & (2**64 - 1), from_type=f"DECIMAL({p},{s})", to_type="INT", precision=p, scale=s)
+        assert j["params"] == {"value": want, "fromType": f"DECIMAL({p},{s})", "toType": "INT"}, (unscaled, p, s)
+
+
+def test_strings_that_do_not_parse():
+    # invalid_value(raw value, "STRING", type name) (string.rs:1117; error.rs:961-970's test expects value "abc", fromType STRING, toType INT)
+    j = native.error_json("CastInvalidValue", "CAST_INVALID_INPUT", 4, lo=3, from_type="STRING", to_type="INT", string=b"abc")
+    assert j == {"errorType": "CastInvalidValue", "errorClass": "CAST_INVALID_INPUT", "params": {"value": "abc", "fromType": "STRING", "toType": "INT"}}
+    # the raw value with its whitespace, quotes and backslashes survives JSON (InvalidInputInCastToDatetime, string.rs:53-63)
+    raw = ' 2020-13-01 "x"\\\t'.encode()
+    j = native.error_json("InvalidInputInCastToDatetime", "CAST_INVALID_INPUT", 4, lo=len(raw), from_type="STRING", to_type="TIMESTAMP_NTZ", string=raw)
+    assert j["params"] == {"value": raw.decode(), "fromType": "STRING", "toType": "TIMESTAMP_NTZ"}
+    # a value longer than the error block keeps its first bytes
+    long = ("x" * 300).encode()
+    j = native.error_json("CastInvalidValue", "CAST_INVALID_INPUT", 4, lo=300, from_type="STRING", to_type="DECIMAL(10,2)", string=long[:224])
+    assert j["params"]["value"] == "x" * 224 + "..." and j["params"]["toType"] == "DECIMAL(10,2)"
+    assert native.error_json("CastInvalidValue", "CAST_INVALID_INPUT", 4, lo=0, from_type="STRING", to_type="BOOLEAN", string=b"")["params"]["value"] == ""
+    assert native.error_json("CastInvalidValue", "CAST_INVALID_INPUT", 4, lo=2, from_type="STRING", to_type="INT", string="é".encode())["params"]["value"] == "é"

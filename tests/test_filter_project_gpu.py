@@ -257,7 +257,7 @@ def test_remainder_int_and_float(built):
         assert g_.fill_null(0).to_numpy().tobytes() == w_.fill_null(0).to_numpy().tobytes(), f"column {i}"
     assert got.column(0)[0].as_py() == 0 and got.column(0)[1].as_py() is None and got.column(0)[2].as_py() == -1
     ansi = S.project(S.scan(fields), [S.math("remainder", A, B, S.T_INT32, S.ANSI)])
-    with pytest.raises(native.CometQueryExecutionException, match="DIVIDE_BY_ZERO"):
+    with pytest.raises(native.CometQueryExecutionException, match="REMAINDER_BY_ZERO"):
         _run(ansi, table=t, ncols=1)
 
 
@@ -295,7 +295,7 @@ def test_remainder_decimal(built):
         assert got.column(i).to_pylist() == want.column(i).to_pylist(), f"case {cases[i]}"
     assert got.column(0).null_count > t.column(0).null_count        # zero divisors became NULL
     ansi = S.project(S.scan(fields), [S.math("remainder", S.col(0, fields[0]), S.col(1, fields[1]), S.decimal(12, 2), S.ANSI)])
-    with pytest.raises(native.CometQueryExecutionException, match="DIVIDE_BY_ZERO"):
+    with pytest.raises(native.CometQueryExecutionException, match="REMAINDER_BY_ZERO"):
         _run(ansi, table=t, ncols=1)
 
 
@@ -517,3 +517,21 @@ def test_coalesce(built):
     for i in range(len(exprs)):
         assert got.column(i).to_pylist() == want.column(i).to_pylist(), f"expression {i}"
     assert got.column(1).null_count == 0
+
+
+def test_the_references_modulo_vectors(built):
+    """modulo_expr.rs:360-985 — the cases tests/test_modulo_kats_cpu.py transcribes — through the C ABI: -0.0 is a zero divisor, NULL operands
+    never raise, NaN / ±Infinity dividends, literal operands; ANSI raises REMAINDER_BY_ZERO (common/src/error.rs:81-82, 684)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("modulo_kats", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_modulo_kats_cpu.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for args, kw, want in m.CASES:
+        plan, table = m.build(*args, **kw)
+        if want == "raise":
+            with pytest.raises(native.CometQueryExecutionException, match='"errorClass":"REMAINDER_BY_ZERO"'):
+                _run(plan, table, 1)
+        else:
+            got = pa.Table.from_batches(_run(plan, table, 1)).column(0).to_pylist()
+            assert m.same(got, want), (args, kw, got)

@@ -253,3 +253,40 @@ def test_unknown_time_zones_are_refused_by_name(built):
     plan = S.project(S.scan([S.T_TIMESTAMP]), [S.cast(S.col(0, S.T_TIMESTAMP), STR, S.LEGACY, "Mars/Olympus")])
     with pytest.raises(native.CometNativeException, match="Mars/Olympus"):
         _run(plan, t.select(["ts"]), 1)
+
+
+def test_errors_name_the_offending_value(built):
+    """ANSI errors carry what the JVM side reads back (ShimSparkErrorConverter.scala: params("value"), "precision", "scale", "fromType", "toType"):
+    the kernel leaves the raise site and the value's bits — or the string's bytes — in its error block (kparams.h), csrc/err_sites.cpp formats
+    them like the reference's raise sites do (tests/test_error_json_cpu.py holds the formats)"""
+    import json
+    from decimal import Decimal
+    from datafusion_comet_amd.tpch import _dec128_array
+    D = S.decimal(12, 2)
+    fields = [S.T_INT64, S.T_DOUBLE, D, STR]
+    i64, f64, d, s = (S.col(i, t) for i, t in enumerate(fields))
+
+    def table(a=1, b=1.0, c=100, text="1"):
+        # (three rows; the middle one is the offender, its neighbours are harmless)
+        return pa.table({"a": pa.array([1, a, None], pa.int64()), "b": pa.array([1.0, b, None], pa.float64()), "c": _dec128_array(np.array([100, c, 100], np.int64), 12, 2),
+                         "s": pa.array(["1", text, None], pa.utf8())})
+
+    cases = [
+        (S.cast(s, I32, S.ANSI), table(text="12x"), "CastInvalidValue", {"value": "12x", "fromType": "STRING", "toType": "INT"}),
+        (S.cast(s, S.T_DATE, S.ANSI), table(text=" 2020-13-01 "), "InvalidInputInCastToDatetime", {"value": " 2020-13-01 ", "fromType": "STRING", "toType": "DATE"}),
+        (S.cast(s, S.T_TIMESTAMP, S.ANSI, "Asia/Kolkata"), table(text='yester"day"'), "InvalidInputInCastToDatetime", {"value": 'yester"day"', "fromType": "STRING", "toType": "TIMESTAMP"}),
+        (S.cast(s, S.decimal(5, 0), S.ANSI), table(text="123456789"), "NumericValueOutOfRange", {"value": "123456789", "precision": 5, "scale": 0}),
+        (S.cast(s, S.decimal(10, 2), S.ANSI), table(text="1e"), "CastInvalidValue", {"value": "1e", "fromType": "STRING", "toType": "DECIMAL(10,2)"}),
+        (S.cast(i64, I32, S.ANSI), table(a=2147483648), "CastOverFlow", {"value": "2147483648L", "fromType": "BIGINT", "toType": "INT"}),
+        (S.cast(f64, I32, S.ANSI), table(b=3e9), "CastOverFlow", {"value": "3E9D", "fromType": "DOUBLE", "toType": "INT"}),
+        (S.cast(d, I32, S.ANSI), table(c=999999999999), "CastOverFlow", {"value": "9999999999.99BD", "fromType": "DECIMAL(12,2)", "toType": "INT"}),
+        (S.cast(i64, S.decimal(3, 2), S.ANSI), table(a=1000), "NumericValueOutOfRange", {"value": "1000", "precision": 3, "scale": 2}),
+        (S.cast(f64, S.decimal(5, 2), S.ANSI), table(b=4242.42), "NumericValueOutOfRange", {"value": "4242.42", "precision": 5, "scale": 2}),
+        (S.check_overflow(S.math("multiply", d, d, S.decimal(25, 4)), S.decimal(20, 4), True), table(c=999999999999), "NumericValueOutOfRange",
+         {"value": str(999999999999 ** 2), "precision": 20, "scale": 4}),
+    ]
+    for expr, t, etype, params in cases:
+        with pytest.raises(native.CometQueryExecutionException) as ei:
+            _run(S.project(S.scan(fields), [expr]), t, 1)
+        j = json.loads(str(ei.value))
+        assert j["errorType"] == etype and j["params"] == params, (etype, j)
