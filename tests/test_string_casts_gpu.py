@@ -266,10 +266,10 @@ def test_errors_name_the_offending_value(built):
     fields = [S.T_INT64, S.T_DOUBLE, D, STR]
     i64, f64, d, s = (S.col(i, t) for i, t in enumerate(fields))
 
-    def table(a=1, b=1.0, c=100, text="1"):
+    def table(a=1, b=1.0, c=100, text="2020"):
         # (three rows; the middle one is the offender, its neighbours are harmless)
         return pa.table({"a": pa.array([1, a, None], pa.int64()), "b": pa.array([1.0, b, None], pa.float64()), "c": _dec128_array(np.array([100, c, 100], np.int64), 12, 2),
-                         "s": pa.array(["1", text, None], pa.utf8())})
+                         "s": pa.array(["2020", text, None], pa.utf8())})      # ("2020" is an integer, a decimal, a date and a timestamp)
 
     cases = [
         (S.cast(s, I32, S.ANSI), table(text="12x"), "CastInvalidValue", {"value": "12x", "fromType": "STRING", "toType": "INT"}),
