@@ -1453,7 +1453,14 @@ struct Gen {
           const std::string ct = a.t.id == TypeId::Int64 ? "i64" : a.t.id == TypeId::Int32 ? "i32" : a.t.id == TypeId::Int16 ? "i16" : "i8";
           const std::string ut = a.t.id == TypeId::Int64 ? "u64" : a.t.id == TypeId::Int32 ? "u32" : a.t.id == TypeId::Int16 ? "unsigned short" : "u8";
           const std::string mn = a.t.id == TypeId::Int64 ? "(i64)0x8000000000000000ull" : a.t.id == TypeId::Int32 ? "(i32)0x80000000" : a.t.id == TypeId::Int16 ? "-32768" : "-128";
-          if (fail) raise_if(and_ok(a.ok, "(" + a.v + " == " + mn + ")"), 1);
+          if (fail) {
+            ErrSite site;      // abs.rs:205-255: arithmetic_overflow_error("Int8" / "Int16" / "Int32" / "Int64")
+            site.error_type = "ArithmeticOverflow";
+            site.error_class = "ARITHMETIC_OVERFLOW";
+            site.from_type = a.t.id == TypeId::Int64 ? "Int64" : a.t.id == TypeId::Int32 ? "Int32" : a.t.id == TypeId::Int16 ? "Int16" : "Int8";
+            site.value = ErrSite::NoValue;
+            raise_value(and_ok(a.ok, "(" + a.v + " == " + mn + ")"), 1, site, "0");
+          }
           r.v = std::string("(") + rep_ctype(a.rep) + ")(" + ct + ")(" + a.v + " < 0 ? (" + ut + ")0 - (" + ut + ")(" + ct + ")" + a.v + " : (" + ut + ")(" + ct + ")" + a.v + ")";
           return r;
         }
@@ -1921,7 +1928,12 @@ struct Gen {
         if (e.fail_on_error && a.t.is_integer()) {
           a = named(a);
           std::string mn = a.t.id == TypeId::Int64 ? "(i64)0x8000000000000000ull" : a.t.id == TypeId::Int32 ? "(i32)0x80000000" : a.t.id == TypeId::Int16 ? "-32768" : "-128";
-          raise_if(and_ok(a.ok, a.v + " == " + mn), 1);
+          ErrSite site;      // negative.rs:136-150: arithmetic_overflow_error("byte" / "short" / "integer" / "long")
+          site.error_type = "ArithmeticOverflow";
+          site.error_class = "ARITHMETIC_OVERFLOW";
+          site.from_type = a.t.id == TypeId::Int64 ? "long" : a.t.id == TypeId::Int32 ? "integer" : a.t.id == TypeId::Int16 ? "short" : "byte";
+          site.value = ErrSite::NoValue;
+          raise_value(and_ok(a.ok, a.v + " == " + mn), 1, site, "0");
         }
         return r;
       }

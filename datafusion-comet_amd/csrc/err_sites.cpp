@@ -108,6 +108,8 @@ bool lookup_err_site(uint32_t id, ErrSite& out) {
 }
 
 std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint8_t* str, size_t str_avail) {
+  if (s.value == ErrSite::NoValue)      // ArithmeticOverflow { from_type } (error.rs:369-373): which type overflowed, no value
+    return "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{\"fromType\":\"" + s.from_type + "\"}}";
   std::string value;
   const __int128 v128 = (__int128)(((unsigned __int128)hi << 64) | lo);
   switch (s.value) {
@@ -118,6 +120,7 @@ std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint
     case ErrSite::F32: { float f; uint32_t b = (uint32_t)lo; memcpy(&f, &b, 4); value = rust_lower_exp(f); break; }
     case ErrSite::F64Display: { double d; memcpy(&d, &lo, 8); value = rust_display(d); break; }      // cast_float_to_decimal128: input_value.to_string()
     case ErrSite::DecimalBD: value = decimal_str(v128, s.precision, s.scale) + "BD"; break;   // cast_decimal_to_int*: "{}BD"
+    case ErrSite::NoValue: break;
     case ErrSite::Str: {
       const size_t n = (size_t)lo, have = std::min(n, str_avail);
       value.assign((const char*)str, have);

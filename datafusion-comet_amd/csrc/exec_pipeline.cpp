@@ -296,7 +296,7 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
   // Spark error JSON as thrown through CometQueryExecutionException (native/common/src/error.rs:806-831).  An error that names the offending
   // value left its raise site and the value in the detail words of the error block (kparams.h; err_sites.cpp formats them): the JVM side reads
   // params("value"), params("precision") … back (ShimSparkErrorConverter.scala), a missing key would be a NoSuchElementException there.
-  if (f & (4u | 8u | 512u | 1024u | 8192u | 16384u)) {
+  if (f & (2u | 4u | 8u | 512u | 1024u | 8192u | 16384u)) {
     uint64_t detail[4 + kErrDetailStrBytes / 8];
     memset(detail, 0, sizeof detail);
     read_small(detail, (const char*)err_flags_.p + 8 * kErrDetailWord, sizeof detail);

@@ -65,3 +65,9 @@ def test_strings_that_do_not_parse():
     assert j["params"]["value"] == "x" * 224 + "..." and j["params"]["toType"] == "DECIMAL(10,2)"
     assert native.error_json("CastInvalidValue", "CAST_INVALID_INPUT", 4, lo=0, from_type="STRING", to_type="BOOLEAN", string=b"")["params"]["value"] == ""
     assert native.error_json("CastInvalidValue", "CAST_INVALID_INPUT", 4, lo=2, from_type="STRING", to_type="INT", string="é".encode())["params"]["value"] == "é"
+
+
+def test_arithmetic_overflow_names_the_type():
+    # ArithmeticOverflow { from_type } (error.rs:369-373): negative.rs:136-150 says "byte" / "short" / "integer" / "long", abs.rs:205-255 "Int8" … "Int64"
+    j = native.error_json("ArithmeticOverflow", "ARITHMETIC_OVERFLOW", 8, from_type="long")
+    assert j == {"errorType": "ArithmeticOverflow", "errorClass": "ARITHMETIC_OVERFLOW", "params": {"fromType": "long"}}

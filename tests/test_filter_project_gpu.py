@@ -224,7 +224,7 @@ def test_scalar_functions_exact_subset(built):
     rows = lambda tb: sorted(zip(*[tb.column(i).to_pylist() for i in range(tb.num_columns)]), key=lambda r: (r[0] is None, r[0] or 0))
     assert rows(pa.Table.from_batches(_run(agg, table=t, ncols=4, batch_size=0))) == rows(_oracle(agg, t))
     ansi = S.project(S.scan([S.T_DOUBLE, D, S.T_INT32, S.T_DATE]), [sf("abs", [I, S.lit(True, S.T_BOOL)], S.T_INT32)])
-    with pytest.raises(native.CometQueryExecutionException, match="ARITHMETIC_OVERFLOW"):
+    with pytest.raises(native.CometQueryExecutionException, match='ARITHMETIC_OVERFLOW.*"fromType":"Int32"'):      # abs.rs:238
         _run(ansi, table=t, ncols=1)
     with pytest.raises(native.CometNativeException, match="levenshtein"):
         native.compile_plan(S.project(S.scan([S.T_DOUBLE]), [sf("levenshtein", [S.col(0, S.T_DOUBLE)], S.T_INT32)]).encode())
