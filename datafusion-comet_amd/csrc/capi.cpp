@@ -442,6 +442,24 @@ int64_t comet_error_json(const char* error_type, const char* error_class, const 
   return (int64_t)j.size();
 }
 
+int64_t comet_plan_error_json(const uint8_t* plan, size_t plan_len, int32_t site_index, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail,
+                              char* out, int64_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    OperatorP op = decode_operator(plan, plan_len);
+    const Operator* leaf = op.get();
+    while (!leaf->children.empty()) leaf = leaf->children[0].get();
+    std::vector<bool> none(leaf->scan_fields.size(), false);
+    const PipelineDesc d = generate_pipeline(*op, none);
+    if (site_index < 0 || (size_t)site_index >= d.site_contexts.size())
+      throw CometError("the plan's pipeline has " + std::to_string(d.site_contexts.size()) + " raise sites with a QueryContext");
+    ErrSite site;
+    if (!lookup_err_site(d.site_contexts[(size_t)site_index].first, site)) throw CometError("internal: a raise site is not registered");
+    const std::string j = err_site_json(site, lo, hi, str, str_avail < 0 ? 0 : (size_t)str_avail, d.site_contexts[(size_t)site_index].second.get());
+    if (out && cap > (int64_t)j.size()) memcpy(out, j.c_str(), j.size() + 1);
+    return (int64_t)j.size();
+  });
+}
+
 int64_t comet_zone_table(const char* zone, int64_t* out, int64_t cap) {
   return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
     const std::vector<int64_t> f = load_zone(zone ? zone : "")->flat();

@@ -53,6 +53,14 @@ u128 sat_add(u128 a, u128 b) {
 thread_local bool g_uses_ryu = false;      // the source being generated calls into comet_ryu.hpp (Float → Decimal)
 thread_local bool g_uses_strtod = false;   // … into comet_strtod.hpp (String → Float / Double)
 thread_local bool g_uses_strts = false;    // … into comet_strts.hpp (String → Timestamp)
+// the pipeline being generated: where raise sites with a QueryContext are noted, and how many sites of each content it has seen (err_sites.cpp)
+thread_local std::vector<std::pair<uint32_t, std::shared_ptr<QueryContext>>>* g_site_sink = nullptr;
+thread_local std::map<std::string, int>* g_site_ordinals = nullptr;
+struct SiteScope {
+  std::map<std::string, int> ordinals;
+  explicit SiteScope(PipelineDesc& d) { g_site_sink = &d.site_contexts; g_site_ordinals = &ordinals; }
+  ~SiteScope() { g_site_sink = nullptr; g_site_ordinals = nullptr; }
+};
 std::string with_optional_headers(std::string src) {
   if (g_uses_ryu) {
     const std::string inc = "using namespace comet;\n";
@@ -501,15 +509,44 @@ struct Gen {
   // raise a Spark error for the rows where `cond` holds (ANSI mode)
   void raise_if(const std::string& cond, int code) {
     uses_err = true;
+    if (current_context() && (code == 0 || code == 1 || code == 8 || code == 15)) {
+      // an error without a value — but with the SQL fragment of its expression: a site, so that the executor finds the context
+      ErrSite site;
+      site.value = ErrSite::NoValue;
+      switch (code) {
+        case 0: site.error_type = "ArithmeticOverflow"; site.error_class = "ARITHMETIC_OVERFLOW"; site.from_type = "decimal"; break;
+        case 1: site.error_type = "ArithmeticOverflow"; site.error_class = "ARITHMETIC_OVERFLOW"; site.from_type = "integer"; break;
+        case 8: site.error_type = "DivideByZero"; site.error_class = "DIVIDE_BY_ZERO"; break;
+        default: site.error_type = "RemainderByZero"; site.error_class = "REMAINDER_BY_ZERO"; break;
+      }
+      raise_value(cond, code, site, "0");
+      return;
+    }
     stmt("if (" + cond + ") atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], " + std::to_string(1u << code) + "u);");
   }
 
+  // the expression whose code is being emitted (innermost last): its QueryContext goes with the errors it raises (planner.rs:302-316, 582-597 —
+  // the reference looks the context up under the expression's expr_id: both must be there)
+  std::vector<std::shared_ptr<QueryContext>> ctx_stack;
+  std::shared_ptr<QueryContext> current_context() const { return ctx_stack.empty() ? nullptr : ctx_stack.back(); }
+  // a site's id: its content and its ordinal among the pipeline's sites of that content — not the SQL text, which is noted beside the pipeline
+  uint32_t site_id(const ErrSite& site) {
+    int ord = 0;
+    if (g_site_ordinals) {
+      const std::string c = site.error_type + "|" + site.from_type + "|" + site.to_type + "|" + std::to_string(site.precision) + "|" + std::to_string(site.scale) + "|" +
+                            std::to_string(site.value) + "|" + site.suffix;
+      ord = (*g_site_ordinals)[c]++;
+    }
+    const uint32_t id = register_err_site(site, ord);
+    if (auto c = current_context()) if (g_site_sink) g_site_sink->emplace_back(id, c);
+    return id;
+  }
   // … and leave the offending value for the error's JSON (err_sites.cpp): a number's bits, or a string's bytes
   void raise_value(const std::string& cond, int code, const ErrSite& site, const std::string& lo, const std::string& hi = "0") {
     uses_err = true;
     const std::string eb = "prm.out[" + std::to_string(kOutErr) + "]";
     stmt("if (" + cond + ") { atomicOr((unsigned int*)" + eb + ", " + std::to_string(1u << code) + "u); comet::err_detail(" + eb + ", " +
-         std::to_string(register_err_site(site)) + "u, (u64)(" + lo + "), (u64)(" + hi + ")); }");
+         std::to_string(site_id(site)) + "u, (u64)(" + lo + "), (u64)(" + hi + ")); }");
   }
   void raise_value128(const std::string& cond, int code, const ErrSite& site, const Val& x) {
     if (x.rep == Rep::I128) raise_value(cond, code, site, "(u128)(" + x.v + ")", "((u128)(" + x.v + ") >> 64)");
@@ -519,7 +556,7 @@ struct Gen {
     uses_err = true;
     const std::string eb = "prm.out[" + std::to_string(kOutErr) + "]";
     stmt("if (" + cond + ") { atomicOr((unsigned int*)" + eb + ", " + std::to_string(1u << code) + "u); comet::err_detail_str(" + eb + ", " +
-         std::to_string(register_err_site(site)) + "u, (const u8*)(" + ptr + "), (i32)(" + len + ")); }");
+         std::to_string(site_id(site)) + "u, (const u8*)(" + ptr + "), (i32)(" + len + ")); }");
   }
   static ErrSite out_of_range_site(const DType& to) {      // decimal_overflow_error (common/src/error.rs:769-775): the unscaled value, the target's (p, s)
     ErrSite s;
@@ -1092,7 +1129,7 @@ struct Gen {
         uses_err = true;
         const std::string eb = "prm.out[" + std::to_string(kOutErr) + "]";
         stmt("if (" + cond + ") { atomicOr((unsigned int*)" + eb + ", " + std::to_string(1u << code) + "u); i32 en_; comet::strp ep_ = comet::utf8_bytes(prm.in[" +
-             std::to_string(loc.first) + "], " + loc.second + ", en_); comet::err_detail_str(" + eb + ", " + std::to_string(register_err_site(site)) + "u, (const u8*)ep_, en_); }");
+             std::to_string(loc.first) + "], " + loc.second + ", en_); comet::err_detail_str(" + eb + ", " + std::to_string(site_id(site)) + "u, (const u8*)ep_, en_); }");
       };
       ErrSite site;
       const bool datetime = err_bit == 10 || err_bit == 13 || err_bit == 14;
@@ -1802,6 +1839,15 @@ struct Gen {
   }
 
   Val gen_uncached(const Expr& e) {
+    struct Scope {
+      std::vector<std::shared_ptr<QueryContext>>& st;
+      ~Scope() { st.pop_back(); }
+    } scope{ctx_stack};
+    ctx_stack.push_back(e.qctx && e.has_expr_id ? e.qctx : nullptr);
+    return gen_node(e);
+  }
+
+  Val gen_node(const Expr& e) {
     switch (e.kind) {
       case ExprKind::Bound: return column(e.bound_index);
       case ExprKind::Literal: return literal(e);
@@ -2354,6 +2400,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
   const Operator& scan = *chain.back();
   PipelineDesc d;
+  SiteScope site_scope(d);
   d.in_types = source_types ? *source_types : scan.scan_fields;
   for (auto* op : chain) d.op_names.push_back(op_name(op->proto_tag));
   if (in_has_validity.size() != d.in_types.size()) throw CometError("internal: validity mask arity mismatch");
@@ -3274,6 +3321,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   }
 
   PipelineDesc d;
+  SiteScope site_scope(d);
   d.sink = SinkKind::Output;
   d.R = 1;
   d.op_names.push_back("HashJoin");
@@ -3529,6 +3577,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
 PipelineDesc generate_sort_keys(const Operator& sort, const std::vector<DType>& types, const std::vector<bool>& valid) {
   if (sort.kind != OpKind::Sort || sort.sort_orders.empty()) throw CometError("Sort needs at least one sort expression");
   PipelineDesc d;
+  SiteScope site_scope(d);
   d.sink = SinkKind::Output;
   d.R = 1;
   d.op_names.push_back("Sort");

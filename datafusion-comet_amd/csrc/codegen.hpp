@@ -3,6 +3,7 @@
 // templates of device/comet_device.hpp.
 #pragma once
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,9 @@ struct PipelineDesc {
   std::vector<DType> in_types;     // Scan fields
   std::vector<bool> in_used;       // columns the kernels actually read
   std::vector<OutCol> out_cols;    // output schema in order
+  // raise sites of this pipeline's kernels whose expression carries a QueryContext: the executor attaches it to the error (the site ids in the
+  // generated text do not depend on the SQL text, so plans that differ only in it share their code objects)
+  std::vector<std::pair<uint32_t, std::shared_ptr<QueryContext>>> site_contexts;
   std::string source;              // full HIP translation unit
   std::vector<std::string> kernels;  // extern "C" kernel names present in `source`
   // static row bound under which decimal sums cannot overflow (Appendix C.1 rule); 0 = no limit
@@ -128,10 +132,10 @@ struct ErrSite {
   int value = Unscaled128;
   std::string suffix;                  // Int64: Spark's literal suffix ("L", "S", "")
 };
-uint32_t register_err_site(const ErrSite& s);
+uint32_t register_err_site(const ErrSite& s, int ordinal = 0);      // ordinal: the n-th site of this very content in one pipeline
 bool lookup_err_site(uint32_t id, ErrSite& out);
 // the error JSON of a site and the detail the device left (lo / hi: the value's bits or a string's length; str: its first bytes)
-std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint8_t* str, size_t str_avail);
+std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint8_t* str, size_t str_avail, const QueryContext* ctx = nullptr);
 constexpr int kOutFirstCol = 4;      // out[4+2j] = values of col j, out[5+2j] = validity bytes of col j
 
 }  // namespace comet

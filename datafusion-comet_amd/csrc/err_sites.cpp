@@ -8,6 +8,8 @@
 #include <map>
 #include <mutex>
 
+#include <algorithm>
+
 #include "codegen.hpp"
 
 namespace comet {
@@ -89,8 +91,8 @@ std::string rust_display(double x) {
 
 }  // namespace
 
-uint32_t register_err_site(const ErrSite& s) {
-  const std::string c = canon(s);
+uint32_t register_err_site(const ErrSite& s, int ordinal) {
+  const std::string c = canon(s) + "#" + std::to_string(ordinal);
   uint32_t h = 2166136261u;
   for (unsigned char ch : c) { h ^= ch; h *= 16777619u; }
   h &= 0x7fffffffu;
@@ -107,9 +109,40 @@ bool lookup_err_site(uint32_t id, ErrSite& out) {
   return true;
 }
 
-std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint8_t* str, size_t str_avail) {
+// SparkErrorWithContext::to_json (error.rs:806-831): "context" with the QueryContext's fields and "summary" = QueryContext::format_summary
+// (query_context.rs:104-158: "== SQL [of TYPE [NAME]] (line L, position P+1) ==", the SQL text, and carets under the fragment)
+static std::string context_json(const QueryContext& c) {
+  auto chars = [](const std::string& t) { size_t n = 0; for (unsigned char ch : t) n += (ch & 0xC0) != 0x80; return n; };
+  auto byte_of_char = [](const std::string& t, size_t k, size_t& out) {      // char_index_to_byte_offset: None behind the last character
+    size_t n = 0;
+    for (size_t i = 0; i < t.size(); i++)
+      if (((unsigned char)t[i] & 0xC0) != 0x80) { if (n == k) { out = i; return true; } n++; }
+    return false;
+  };
+  const size_t start_char = (size_t)std::max(c.start_index, 0), stop_char = (size_t)std::max(c.stop_index + 1, 0);
+  size_t b0 = 0, b1 = 0;
+  bool ok0 = byte_of_char(c.sql_text, start_char, b0), ok1 = byte_of_char(c.sql_text, stop_char, b1);
+  if (!ok1 && stop_char == chars(c.sql_text)) { b1 = c.sql_text.size(); ok1 = true; }
+  const std::string fragment = (ok0 && ok1 && b1 >= b0) ? c.sql_text.substr(b0, b1 - b0) : "";
+  std::string summary = "== SQL";
+  if (c.has_object_type && !c.object_type.empty()) {
+    summary += " of " + c.object_type;
+    if (c.has_object_name && !c.object_name.empty()) summary += " " + c.object_name;
+  }
+  summary += " (line " + std::to_string(c.line) + ", position " + std::to_string(c.start_position + 1) + ") ==\n" + c.sql_text + "\n" +
+             std::string((size_t)std::max(c.start_position, 0), ' ') + std::string(std::max<size_t>(chars(fragment), 1), '^');
+  std::string j = ",\"context\":{\"sqlText\":\"" + json_escape(c.sql_text) + "\",\"startIndex\":" + std::to_string(c.start_index) + ",\"stopIndex\":" +
+                  std::to_string(c.stop_index) + ",\"objectType\":" + (c.has_object_type ? "\"" + json_escape(c.object_type) + "\"" : std::string("null")) +
+                  ",\"objectName\":" + (c.has_object_name ? "\"" + json_escape(c.object_name) + "\"" : std::string("null")) + ",\"line\":" + std::to_string(c.line) +
+                  ",\"startPosition\":" + std::to_string(c.start_position) + "},\"summary\":\"" + json_escape(summary) + "\"";
+  return j;
+}
+
+std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint8_t* str, size_t str_avail, const QueryContext* ctx) {
+  const std::string tail = (ctx ? context_json(*ctx) : std::string()) + "}";
   if (s.value == ErrSite::NoValue)      // ArithmeticOverflow { from_type } (error.rs:369-373): which type overflowed, no value
-    return "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{\"fromType\":\"" + s.from_type + "\"}}";
+    return "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{" +
+           (s.from_type.empty() ? std::string() : "\"fromType\":\"" + s.from_type + "\"") + "}" + tail;
   std::string value;
   const __int128 v128 = (__int128)(((unsigned __int128)hi << 64) | lo);
   switch (s.value) {
@@ -133,7 +166,7 @@ std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint
   std::string j = "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{\"value\":\"" + json_escape(value) + "\"";
   if (s.error_type == "NumericValueOutOfRange") j += ",\"precision\":" + std::to_string(s.precision) + ",\"scale\":" + std::to_string(s.scale);
   else j += ",\"fromType\":\"" + s.from_type + "\",\"toType\":\"" + s.to_type + "\"";
-  return j + "}}";
+  return j + "}" + tail;
 }
 
 }  // namespace comet

@@ -777,6 +777,7 @@ Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid, const
                             dict_id_col_.empty() ? nullptr : &dict_id_col_);
   Variant v;
   v.desc = pv->desc;
+  note_sites(v.desc);
   v.mod = jit_load(pv->code);
   auto res = variants_.emplace(key, std::move(v));
   return res.first->second;
@@ -1065,6 +1066,7 @@ DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTab
   if (pv->desc.sink != SinkKind::Output) throw CometError("internal: run_chain_to_device on an aggregate chain");
   Variant v;
   v.desc = pv->desc;
+  note_sites(v.desc);
   v.mod = jit_load(pv->code);
   const PipelineDesc& d = v.desc;
   const int64_t n = in.rows;

@@ -211,6 +211,9 @@ class ExecutionContext {
   void export_batch(HostBatch& b, ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out);
   void check_device_errors();
   void raise_device_errors(uint32_t flags);
+  // the QueryContexts of a pipeline's raise sites (PipelineDesc::site_contexts), kept for the errors this context's kernels may raise
+  void note_sites(const PipelineDesc& d) { for (auto& kv : d.site_contexts) site_ctx_[kv.first] = kv.second; }
+  std::map<uint32_t, std::shared_ptr<QueryContext>> site_ctx_;
   void read_small(void* dst, const void* dev_src, size_t n);
   void write_small(void* dev_dst, const void* src, size_t n);
   void timed_begin();

@@ -125,6 +125,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   }
   Variant v;
   v.desc = pv->desc;
+  note_sites(v.desc);
   v.mod = jit_load(pv->code);
   const PipelineDesc& d = v.desc;
   const bool build_left = j.build_side == BuildSide::Left;

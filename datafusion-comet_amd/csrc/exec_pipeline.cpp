@@ -296,7 +296,7 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
   // Spark error JSON as thrown through CometQueryExecutionException (native/common/src/error.rs:806-831).  An error that names the offending
   // value left its raise site and the value in the detail words of the error block (kparams.h; err_sites.cpp formats them): the JVM side reads
   // params("value"), params("precision") … back (ShimSparkErrorConverter.scala), a missing key would be a NoSuchElementException there.
-  if (f & (2u | 4u | 8u | 512u | 1024u | 8192u | 16384u)) {
+  {
     uint64_t detail[4 + kErrDetailStrBytes / 8];
     memset(detail, 0, sizeof detail);
     read_small(detail, (const char*)err_flags_.p + 8 * kErrDetailWord, sizeof detail);
@@ -304,7 +304,8 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
     if (detail[0] != 0 && lookup_err_site((uint32_t)(detail[0] - 1), site)) {
       // (the flag that is raised and the site that won the detail words can differ when two kinds of error meet in one launch: the site's own
       // error is reported — it did occur)
-      throw CometError(err_site_json(site, detail[1], detail[2], (const uint8_t*)(detail + 4), (size_t)kErrDetailStrBytes), 1);
+      auto cx = site_ctx_.find((uint32_t)(detail[0] - 1));      // the SQL fragment of the expression, when the plan carried one
+      throw CometError(err_site_json(site, detail[1], detail[2], (const uint8_t*)(detail + 4), (size_t)kErrDetailStrBytes, cx == site_ctx_.end() ? nullptr : cx->second.get()), 1);
     }
   }
   if (f & 1u) throw CometError("{\"errorType\":\"ArithmeticOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"fromType\":\"decimal\"}}", 1);

@@ -72,6 +72,7 @@ std::shared_ptr<DevBuf> ExecutionContext::sort_key_planes(const Operator& sop, c
   }
   Variant v;
   v.desc = pv->desc;
+  note_sites(v.desc);
   v.mod = jit_load(pv->code);
   W = v.desc.sort_key_bytes;
   CometKParams prm;

@@ -349,6 +349,7 @@ DevTable ExecutionContext::expand(const Operator& ex, const DevTable& in) {
       auto pv = planned_variant(*part.proj, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[part.proj.get()] + 1)), in.has_valid, true, &in.types);
       Variant v;
       v.desc = pv->desc;
+      note_sites(v.desc);
       v.mod = jit_load(pv->code);
       if (!u.mod) u.mod = v.mod;
       CometKParams prm;

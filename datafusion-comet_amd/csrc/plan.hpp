@@ -55,6 +55,15 @@ enum class ExprKind : int {
 struct Expr;
 typedef std::shared_ptr<Expr> ExprP;
 
+// QueryContext (expr.proto:109-141; Spark's SQLQueryContext): where in the SQL text an expression stands — attached to the errors it raises
+struct QueryContext {
+  std::string sql_text;
+  int32_t start_index = 0, stop_index = 0, line = 0, start_position = 0;
+  bool has_object_type = false, has_object_name = false;
+  std::string object_type, object_name;
+  int32_t sql_text_idx = -1;      // index into the root Operator.sql_text_pool (resolved into sql_text by decode_operator)
+};
+
 struct Expr {
   ExprKind kind = ExprKind::Unsupported;
   int proto_tag = 0;              // raw oneof tag (for error messages)
@@ -79,6 +88,8 @@ struct Expr {
   std::string lit_bytes;          // string/bytes
   int lit_case = 0;               // which Literal.value arm was present (1..11), 0 = none
   uint64_t expr_id = 0;
+  bool has_expr_id = false;
+  std::shared_ptr<QueryContext> qctx;      // Expr.query_context = 90 (the reference registers it under expr_id, planner.rs:302-316: both must be there)
 };
 
 // AggExpr.expr_struct oneof tags (expr.proto:143-176)
@@ -126,6 +137,7 @@ struct Operator {
   OpKind kind = OpKind::Unsupported;
   int proto_tag = 0;
   uint32_t plan_id = 0;
+  std::vector<std::string> sql_text_pool;      // (root only) the SQL texts QueryContext.sql_text_idx points into
   std::vector<OperatorP> children;
   // Scan
   std::vector<DType> scan_fields;

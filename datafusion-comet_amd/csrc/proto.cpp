@@ -227,12 +227,34 @@ void decode_expr_body(Reader r, Expr& e) {
   }
 }
 
+// the contexts of the plan being decoded: their sql_text_idx is resolved against the ROOT operator's pool once the root is complete
+thread_local std::vector<std::shared_ptr<QueryContext>>* g_decoded_contexts = nullptr;
+
+std::shared_ptr<QueryContext> decode_query_context(Reader r) {
+  auto c = std::make_shared<QueryContext>();
+  while (!r.done()) {
+    int wt, f = r.tag(wt);
+    if (f == 1 && wt == 2) c->sql_text = r.bytes();
+    else if (f == 2 && wt == 0) c->start_index = (int32_t)r.varint();
+    else if (f == 3 && wt == 0) c->stop_index = (int32_t)r.varint();
+    else if (f == 4 && wt == 2) { c->object_type = r.bytes(); c->has_object_type = true; }
+    else if (f == 5 && wt == 2) { c->object_name = r.bytes(); c->has_object_name = true; }
+    else if (f == 6 && wt == 0) c->line = (int32_t)r.varint();
+    else if (f == 7 && wt == 0) c->start_position = (int32_t)r.varint();
+    else if (f == 8 && wt == 0) c->sql_text_idx = (int32_t)r.varint();
+    else r.skip(wt);
+  }
+  if (g_decoded_contexts) g_decoded_contexts->push_back(c);
+  return c;
+}
+
 ExprP decode_expr(Reader r) {
   auto e = std::make_shared<Expr>();
   while (!r.done()) {
     int wt, f = r.tag(wt);
-    if (f == 91 && wt == 0) { e->expr_id = r.varint(); continue; }
-    if (f == 90) { r.skip(wt); continue; }  // QueryContext: error decoration only
+    if (f == 91 && wt == 0) { e->expr_id = r.varint(); e->has_expr_id = true; continue; }
+    if (f == 90 && wt == 2) { e->qctx = decode_query_context(r.sub()); continue; }
+    if (f == 90) { r.skip(wt); continue; }
     if (wt != 2) { r.skip(wt); continue; }
     e->proto_tag = f;
     switch (f) {
@@ -385,6 +407,7 @@ OperatorP decode_operator_r(Reader r) {
     int wt, f = r.tag(wt);
     if (f == 1 && wt == 2) { op->children.push_back(decode_operator_r(r.sub())); continue; }
     if (f == 2 && wt == 0) { op->plan_id = (uint32_t)r.varint(); continue; }
+    if (f == 3 && wt == 2) { op->sql_text_pool.push_back(r.bytes()); continue; }      // operator.proto:39-47
     if (f < 100 || wt != 2) { r.skip(wt); continue; }
     op->proto_tag = f;
     Reader b = r.sub();
@@ -688,7 +711,20 @@ void put_varint(std::string& s, uint64_t v) {
 
 }  // namespace
 
-OperatorP decode_operator(const uint8_t* data, size_t len) { return decode_operator_r(Reader(data, len)); }
+OperatorP decode_operator(const uint8_t* data, size_t len) {
+  std::vector<std::shared_ptr<QueryContext>> contexts;
+  struct Scope {
+    std::vector<std::shared_ptr<QueryContext>>*& slot;
+    std::vector<std::shared_ptr<QueryContext>>* prev;
+    ~Scope() { slot = prev; }
+  } scope{g_decoded_contexts, g_decoded_contexts};
+  g_decoded_contexts = &contexts;
+  OperatorP root = decode_operator_r(Reader(data, len));
+  // QueryContext.sql_text_idx → the root's pool (a query text shared by many expressions travels once per plan, expr.proto:137-141)
+  for (auto& c : contexts)
+    if (c->sql_text_idx >= 0 && (size_t)c->sql_text_idx < root->sql_text_pool.size()) c->sql_text = root->sql_text_pool[(size_t)c->sql_text_idx];
+  return root;
+}
 ExprP decode_expr_bytes(const uint8_t* data, size_t len) { return decode_expr(Reader(data, len)); }
 DType decode_datatype_bytes(const uint8_t* data, size_t len) { return decode_datatype(Reader(data, len)); }
 

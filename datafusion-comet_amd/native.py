@@ -133,6 +133,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_error_json.restype = c.c_int64
     lib.comet_error_json.argtypes = [c.c_char_p, c.c_char_p, c.c_char_p, c.c_char_p, c.c_int32, c.c_int32, c.c_int32, c.c_char_p, c.c_uint64, c.c_uint64, c.c_char_p,
                                      c.c_int64, c.c_char_p, c.c_int64]
+    lib.comet_plan_error_json.restype = c.c_int64
+    lib.comet_plan_error_json.argtypes = [c.c_char_p, c.c_size_t, c.c_int32, c.c_uint64, c.c_uint64, c.c_char_p, c.c_int64, c.c_char_p, c.c_int64]
     lib.comet_zone_table.restype = c.c_int64
     lib.comet_zone_table.argtypes = [c.c_char_p, c.c_void_p, c.c_int64]
     lib.comet_rlike_match.restype = c.c_int32
@@ -1073,6 +1075,16 @@ def error_json(error_type: str, error_class: str, value_kind: int, lo: int = 0, 
     n = lib().comet_error_json(error_type.encode(), error_class.encode(), from_type.encode(), to_type.encode(), precision, scale, value_kind, suffix.encode(),
                                lo & (2**64 - 1), hi & (2**64 - 1), string, len(string), buf, len(buf))
     assert 0 < n < len(buf)
+    return json.loads(buf.value.decode())
+
+
+def plan_error_json(plan: bytes, site_index: int, lo: int = 0, hi: int = 0, string: bytes = b"") -> dict:
+    """the error JSON of the site_index-th raise site with a QueryContext of a plan's pipeline (comet_plan_error_json), parsed"""
+    import json
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = lib().comet_plan_error_json(plan, len(plan), site_index, lo & (2**64 - 1), hi & (2**64 - 1), string, len(string), buf, len(buf))
+    if n < 0:
+        _raise_last(0)
     return json.loads(buf.value.decode())
 
 

@@ -177,7 +177,21 @@ class Expr:
                 body += _f_msg(4, self.children[2 * n].encode())
         else:  # BinaryExpr / UnaryExpr
             body = b"".join(_f_msg(i + 1, c.encode()) for i, c in enumerate(self.children))
-        return _f_msg(tag, body)
+        out = _f_msg(tag, body)
+        qc = getattr(self, "query_context", None)
+        if qc is not None:      # Expr.query_context = 90 (QueryContext, expr.proto:109-141), Expr.expr_id = 91
+            c = (_f_bytes(1, qc["sql_text"].encode()) if qc.get("sql_text") else b"") + _f_varint(2, qc.get("start_index", 0)) + _f_varint(3, qc.get("stop_index", 0))
+            if qc.get("object_type") is not None:
+                c += _f_bytes(4, qc["object_type"].encode())
+            if qc.get("object_name") is not None:
+                c += _f_bytes(5, qc["object_name"].encode())
+            c += _f_varint(6, qc.get("line", 0)) + _f_varint(7, qc.get("start_position", 0))
+            if qc.get("sql_text_idx") is not None:
+                c += _f_varint(8, qc["sql_text_idx"])
+            out += _f_msg(90, c)
+        if getattr(self, "expr_id", None) is not None:
+            out += _f_varint(91, self.expr_id)
+        return out
 
     def _encode_literal(self) -> bytes:
         t = self.dtype
@@ -281,6 +295,14 @@ def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY, timezone: str = 
     e = Expr("cast", [child], dtype=dtype, eval_mode=eval_mode)
     e.timezone = timezone
     e.is_spark4_plus = is_spark4_plus
+    return e
+
+
+def with_context(e: Expr, expr_id: int, **qc) -> Expr:
+    """attach Spark's SQLQueryContext to an expression (sql_text | sql_text_idx, start_index, stop_index, line, start_position, object_type,
+    object_name) under its expr_id: the errors it raises carry it"""
+    e.query_context = qc
+    e.expr_id = expr_id
     return e
 
 
@@ -444,6 +466,8 @@ class Operator:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
         if self.plan_id:
             out += _f_varint(2, self.plan_id)
+        for text in getattr(self, "sql_text_pool", None) or []:      # Operator.sql_text_pool = 3 (root only, operator.proto:39-47)
+            out += _f_bytes(3, text.encode())
         if self.kind == "scan":
             body = b"".join(_f_msg(1, f.encode()) for f in self.fields) + _f_bytes(2, b"test_scan")
         elif self.kind == "window":

@@ -201,6 +201,12 @@ int64_t comet_zone_table(const char* zone, int64_t* out, int64_t cap);
 int64_t comet_error_json(const char* error_type, const char* error_class, const char* from_type, const char* to_type, int32_t precision, int32_t scale,
                          int32_t value_kind, const char* suffix, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail, char* out, int64_t cap);
 
+/* The same for the site_index-th raise site — in the order they are generated — of a Projection / Filter plan whose expressions carry a
+ * QueryContext (expr.proto:103-141, planner.rs:302-316): the JSON then holds "context" and "summary" like SparkErrorWithContext::to_json
+ * (error.rs:806-831).  Generates the plan's kernel text, compiles and runs nothing.  Returns the length, or -2 and comet_last_error(0). */
+int64_t comet_plan_error_json(const uint8_t* plan, size_t plan_len, int32_t site_index, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail,
+                              char* out, int64_t cap);
+
 /* ---- the host page codecs (csrc/parquet_meta.cpp) ---------------------------------------------------------------------------------------
  * What the scan's host threads run on the pages the device does not decompress itself: Parquet CompressionCodec 0 UNCOMPRESSED, 1 SNAPPY,
  * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and

@@ -71,3 +71,51 @@ def test_arithmetic_overflow_names_the_type():
     # ArithmeticOverflow { from_type } (error.rs:369-373): negative.rs:136-150 says "byte" / "short" / "integer" / "long", abs.rs:205-255 "Int8" … "Int64"
     j = native.error_json("ArithmeticOverflow", "ARITHMETIC_OVERFLOW", 8, from_type="long")
     assert j == {"errorType": "ArithmeticOverflow", "errorClass": "ARITHMETIC_OVERFLOW", "params": {"fromType": "long"}}
+
+
+def _ctx_plan(ctx, pool=None):
+    from datafusion_comet_amd import serde as S
+    fields = [S.T_STRING, S.T_INT32]
+    e = S.with_context(S.cast(S.col(0, S.T_STRING), S.T_INT32, S.ANSI), 17, **ctx)
+    plan = S.project(S.scan(fields), [e, S.math("remainder", S.col(1, S.T_INT32), S.col(1, S.T_INT32), S.T_INT32, S.ANSI)])
+    if pool is not None:
+        plan.sql_text_pool = pool
+    return plan.encode()
+
+
+def test_errors_carry_the_query_context():
+    """SparkErrorWithContext::to_json (error.rs:806-831) and QueryContext::format_summary (query_context.rs:104-158; its tests :303-330 expect
+    "== SQL of VIEW v1 (line 1, position 8) ==", the text and three carets for "a/b"): the expression's context, registered under its expr_id
+    (planner.rs:302-316), travels with the error its raise site raises"""
+    sql = "SELECT a/b FROM t"
+    j = native.plan_error_json(_ctx_plan(dict(sql_text=sql, start_index=7, stop_index=9, object_type="VIEW", object_name="v1", line=1, start_position=7)), 0, lo=3, string=b"abc")
+    assert j["errorType"] == "CastInvalidValue" and j["params"] == {"value": "abc", "fromType": "STRING", "toType": "INT"}
+    assert j["context"] == {"sqlText": sql, "startIndex": 7, "stopIndex": 9, "objectType": "VIEW", "objectName": "v1", "line": 1, "startPosition": 7}
+    assert j["summary"] == "== SQL of VIEW v1 (line 1, position 8) ==\nSELECT a/b FROM t\n       ^^^"
+    # without an object; the text from the root operator's pool (expr.proto:137-141, operator.proto:39-47); a fragment with a two-byte character
+    # (query_context.rs:396-404: "café" is characters 7..10)
+    sql2 = "SELECT café FROM t"
+    j = native.plan_error_json(_ctx_plan(dict(sql_text_idx=1, start_index=7, stop_index=10, line=1, start_position=7), pool=["SELECT 1", sql2]), 0, lo=1, string=b"x")
+    assert j["context"] == {"sqlText": sql2, "startIndex": 7, "stopIndex": 10, "objectType": None, "objectName": None, "line": 1, "startPosition": 7}
+    assert j["summary"] == "== SQL (line 1, position 8) ==\nSELECT café FROM t\n       ^^^^"
+    # only expressions that carry a context have one: the remainder beside the cast does not
+    import pytest
+    with pytest.raises(native.CometNativeException, match="1 raise sites with a QueryContext"):
+        native.plan_error_json(_ctx_plan(dict(sql_text=sql, start_index=7, stop_index=9, line=1, start_position=7)), 1)
+
+
+def test_the_kernel_text_does_not_depend_on_the_sql_text(tmp_path, monkeypatch):
+    """the code-object cache is keyed by the generated text: two queries that differ only in their SQL text (every query, under Spark 4's ANSI
+    default) must share their kernels — site ids come from the raise site's content and ordinal, the context is kept beside the pipeline"""
+    import os
+    from datafusion_comet_amd import serde as S
+
+    def plan(sql):
+        e = S.with_context(S.cast(S.col(0, S.T_STRING), S.decimal(17, 3), S.ANSI), 5, sql_text=sql, start_index=7, stop_index=20, line=1, start_position=7)
+        return S.project(S.scan([S.T_STRING]), [e]).encode()
+    monkeypatch.setenv("COMET_JIT_DUMP_DIR", str(tmp_path))
+    native.compile_plan(plan("SELECT CAST(s AS DECIMAL(17,3)) FROM t"))
+    first = sorted(os.listdir(tmp_path))
+    assert first and any("err_detail_str" in open(tmp_path / f).read() for f in first)
+    native.compile_plan(plan("select cast(s as decimal(17,3)) from another_table -- v2"))
+    assert sorted(os.listdir(tmp_path)) == first          # nothing new was generated: the second plan found its kernels compiled

@@ -289,4 +289,20 @@ def test_errors_name_the_offending_value(built):
         with pytest.raises(native.CometQueryExecutionException) as ei:
             _run(S.project(S.scan(fields), [expr]), t, 1)
         j = json.loads(str(ei.value))
-        assert j["errorType"] == etype and j["params"] == params, (etype, j)
+        assert j["errorType"] == etype and j["params"] == params and "context" not in j, (etype, j)
+    # an expression that carries Spark's SQLQueryContext (expr.proto:103-141) raises with it (SparkErrorWithContext::to_json, error.rs:806-831) —
+    # an error that names a value and one that does not
+    sql = "SELECT CAST(s AS INT), a % b FROM t"
+    cast = S.with_context(S.cast(s, I32, S.ANSI), 7, sql_text=sql, start_index=7, stop_index=20, line=1, start_position=7, object_type="VIEW", object_name="v1")
+    with pytest.raises(native.CometQueryExecutionException) as ei:
+        _run(S.project(S.scan(fields), [cast]), table(text="12x"), 1)
+    j = json.loads(str(ei.value))
+    assert j["params"]["value"] == "12x" and j["context"]["sqlText"] == sql and j["context"]["objectName"] == "v1"
+    assert j["summary"] == "== SQL of VIEW v1 (line 1, position 8) ==\n" + sql + "\n" + " " * 7 + "^" * 14
+    rem = S.with_context(S.math("remainder", i64, S.math("subtract", i64, i64, S.T_INT64), S.T_INT64, S.ANSI), 8, sql_text_idx=0, start_index=23, stop_index=27, line=1, start_position=23)
+    plan = S.project(S.scan(fields), [rem])
+    plan.sql_text_pool = [sql]
+    with pytest.raises(native.CometQueryExecutionException) as ei:
+        _run(plan, table(a=5), 1)
+    j = json.loads(str(ei.value))
+    assert j["errorType"] == "RemainderByZero" and j["params"] == {} and j["context"]["sqlText"] == sql and j["summary"].endswith(" " * 23 + "^" * 5)
