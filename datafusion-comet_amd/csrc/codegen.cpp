@@ -2796,6 +2796,10 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
               fin += "      comet::sum_overflow_decide(acc + " + W + ", " + kw(amax) + ", " + kw(sflags) + ", acc[" + std::to_string(cnt.word) + "], " +
                      lit_u128(bound) + ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
               g.uses_err = true;
+              // ANSI: merging into an overflow fails the query (sum_decimal.rs:352-358, 594-600)
+              if (a.eval_mode == EvalMode::Ansi)
+                fin += "      if (acc[" + std::to_string(any_ovf.word) + "] != 0 || ovf || (acc[" + std::to_string(cnt.word) + "] != 0 && !comet::dec_fits(total, " + lit_u128(bound) +
+                       "))) atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], 65536u);\n";
               if (emit_state) {
                 // merged state (sum_decimal.rs:281-295 after :309-368): sum is NULL once any side overflowed, is_empty only
                 // if every merged state was empty
@@ -2846,6 +2850,9 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
               // arrow's sum() skips NULL partial sums and only the batch total is checked against the precision.
               if (grouped) fin += "      bool sum_ok = acc[" + std::to_string(bad.word) + "] == 0 && !ovf;\n";
               else fin += "      bool sum_ok = acc[" + std::to_string(nsum.word) + "] != 0 && comet::dec_fits(total, " + lit_u128(bound) + ");\n";
+              // ANSI: an overflowed sum under a count fails the query (avg_decimal.rs:366-380, 576-580, 610-616)
+              if (a.eval_mode == EvalMode::Ansi)
+                fin += "      if (!sum_ok && count > 0) atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], 131072u);\n";
               if (emit_state) {
                 // state: grouped sums and counts share the is_not_null mask (:638-653); ungrouped (sum Option, count) (:301-306)
                 fin += "      ((i128*)" + out_val(out_j) + ")" + ROW + " = sum_ok ? total : (i128)0;\n";
@@ -3013,6 +3020,10 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             fin += "      comet::sum_overflow_decide(acc + " + W + ", " + kw(amax) + ", " + kw(sflags) + ", acc[" + C + "], " + lit_u128(bound) +
                    ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
             g.uses_err = true;
+            // ANSI: an overflowing decimal SUM fails the query instead of turning NULL (sum_decimal.rs:211-215, 427-431).  An average only notes the
+            // overflow in its state here (avg_decimal.rs:268-300, 483-503) and raises when the states are merged or evaluated (:366-380, 576-580, 610-616)
+            if (a.eval_mode == EvalMode::Ansi && !is_avg)
+              fin += "      if (ovf) atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], 65536u);\n";
           }
           if (!is_avg) {
             // SumDecimal state (sum_decimal.rs:281-295, :526-538): (sum | NULL if overflowed, is_empty)

@@ -1622,6 +1622,9 @@ def _agg_final(S, a, child, state_col, n, gid, ng, grouped, emit_state=False):
             return [Col(a.sum_dtype, ints_to_dec(vals), v), Col(S.T_INT64, cnts, v)], 2
         vals, ok = [], []
         for s in states:
+            # evaluate (avg_decimal.rs:597-636): under ANSI an overflowed sum below a count is an error (:610-616), not NULL
+            if a.eval_mode == S.ANSI and not s.is_not_null and s.count > 0:
+                raise OracleError("ARITHMETIC_OVERFLOW avg")
             out = (ctypes.c_uint64 * 2)()
             has = C.o_avgdec_evaluate(ctypes.byref(s), a.dtype.precision, a.dtype.scale, a.sum_dtype.scale, out)
             vals.append(_limbs_to_int(out) if has else 0)

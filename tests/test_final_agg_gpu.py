@@ -213,3 +213,52 @@ def test_count_distinct_rewrite_with_mixed_mode_aggregate(built, grouped):
         want_cnt = len(set(a[sel & ~am].tolist()))
         s_, a_, c_ = got_rows[gv]
         assert s_ == want_sum and c_ == want_cnt and abs(a_ - want_avg) <= 1e-9 * max(1.0, abs(want_avg)), (gv, s_, want_sum, c_, want_cnt)
+
+
+def test_ansi_decimal_sums_raise_where_legacy_ones_turn_null(built):
+    """sum / avg of decimals under ANSI: an overflow fails the query with DecimalSumOverflow (sum_decimal.rs:211-215, 352-358, 427-431, 594-600;
+    avg_decimal.rs:366-380, 610-616; error.rs:75-76, 374-377) where the LEGACY aggregate gives NULL — Partial, Final and grouped"""
+    import json
+    from decimal import Decimal
+    from oracle import oracle as O
+    D10 = S.decimal(10, 2)
+    big = pa.table({"k": pa.array([1, 1, 2], pa.int32()), "v": pa.array([Decimal("99999999.99"), Decimal("0.01"), Decimal("5.00")], pa.decimal128(10, 2))})
+    k, v = S.col(0, S.T_INT32), S.col(1, D10)
+    for grouping in ([], [k]):
+        for agg, fn in ((lambda m: S.sum_(v, D10, m), "sum"), (lambda m: S.avg(v, S.decimal(14, 6), D10, m), "avg")):
+            legacy = S.hash_agg(S.scan([S.T_INT32, D10]), grouping, [agg(S.LEGACY)], S.PARTIAL)
+            got = _run(legacy, big, len(grouping) + 2)
+            assert got.column(len(grouping)).null_count == 1, (fn, grouping)          # the overflowed state: sum NULL
+            ansi = S.hash_agg(S.scan([S.T_INT32, D10]), grouping, [agg(S.ANSI)], S.PARTIAL)
+            if fn == "avg":      # an average notes the overflow in its Partial state and raises when the states are merged / evaluated
+                assert _run(ansi, big, len(grouping) + 2).column(len(grouping)).null_count == 1
+                continue
+            with pytest.raises(native.CometQueryExecutionException) as ei:
+                _run(ansi, big, len(grouping) + 2)
+            assert json.loads(str(ei.value)) == {"errorType": "DecimalSumOverflow", "errorClass": "ARITHMETIC_OVERFLOW", "params": {"functionName": fn}}
+            with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW"):
+                O.run_plan_to_arrow(S, ansi, big)
+    # Final: two partial sums that do not fit together
+    states = pa.table({"s": pa.array([Decimal("99999999.99"), Decimal("0.01")], pa.decimal128(10, 2)), "e": pa.array([False, False])})
+    fin = lambda m: S.hash_agg(S.scan([D10, S.T_BOOL]), [], [S.sum_(S.col(0, D10), D10, m)], S.FINAL)
+    assert _run(fin(S.LEGACY), states, 1).column(0).to_pylist() == [None]
+    with pytest.raises(native.CometQueryExecutionException, match='DecimalSumOverflow.*"functionName":"sum"'):
+        _run(fin(S.ANSI), states, 1)
+    # a GROUPED average whose partial state overflowed (sum NULL under a count): NULL, or the error under ANSI (avg_decimal.rs:542-636); the
+    # ungrouped accumulator skips NULL partial sums instead (:331-356) and gives 1.00 / 3 in both modes
+    avg_states = pa.table({"k": pa.array([7, 7], pa.int32()), "s": pa.array([None, Decimal("1.00")], pa.decimal128(10, 2)), "c": pa.array([2, 1], pa.int64())})
+    favg = lambda m, g: (S.hash_agg(S.scan([S.T_INT32, D10, S.T_INT64]), [S.col(0, S.T_INT32)], [S.avg(S.col(1, D10), S.decimal(14, 6), D10, m)], S.FINAL) if g else
+                         S.hash_agg(S.scan([D10, S.T_INT64]), [], [S.avg(S.col(0, D10), S.decimal(14, 6), D10, m)], S.FINAL))
+    assert _run(favg(S.LEGACY, True), avg_states, 2).column(1).to_pylist() == [None] == O.run_plan_to_arrow(S, favg(S.LEGACY, True), avg_states).column(1).to_pylist()
+    with pytest.raises(native.CometQueryExecutionException, match='DecimalSumOverflow.*"functionName":"avg"'):
+        _run(favg(S.ANSI, True), avg_states, 2)
+    with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW avg"):
+        O.run_plan_to_arrow(S, favg(S.ANSI, True), avg_states)
+    flat = avg_states.select(["s", "c"])
+    for m in (S.LEGACY, S.ANSI):
+        assert _run(favg(m, False), flat, 1).column(0).to_pylist() == [Decimal("0.333333")] == O.run_plan_to_arrow(S, favg(m, False), flat).column(0).to_pylist()
+    # … and ANSI sums that fit are the LEGACY sums
+    ok = pa.table({"k": pa.array([1, 1, 2], pa.int32()), "v": pa.array([Decimal("1.50"), Decimal("2.25"), None], pa.decimal128(10, 2))})
+    a = _run(S.hash_agg(S.scan([S.T_INT32, D10]), [k], [S.sum_(v, D10, S.ANSI)], S.PARTIAL), ok, 3)
+    b = _run(S.hash_agg(S.scan([S.T_INT32, D10]), [k], [S.sum_(v, D10, S.LEGACY)], S.PARTIAL), ok, 3)
+    assert sorted(zip(*[c.to_pylist() for c in a.columns]), key=str) == sorted(zip(*[c.to_pylist() for c in b.columns]), key=str)
