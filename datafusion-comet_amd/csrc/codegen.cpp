@@ -877,6 +877,12 @@ struct Gen {
         site.value = ErrSite::Int64;
         site.suffix = from.id == TypeId::Int64 ? "L" : from.id == TypeId::Int16 ? "S" : "";
         raise_value(and_ok(c.ok, std::string("(i64)(") + nt + ")" + c.v + " != (i64)" + c.v), 2, site, "(i64)" + c.v);
+      } else if (e.eval_mode == EvalMode::Try) {
+        // try_cast does not reach Comet's narrowing (cast.rs:284-293 `if eval_mode != Try`) but arrow's cast with safe = true (:236-241, 401-407):
+        // NULL when the value does not fit the target type
+        std::string o = newvar("bool");
+        stmt(o + " = " + and_ok(c.ok, std::string("((i64)(") + nt + ")" + c.v + " == (i64)" + c.v + ")") + ";");
+        r.ok = o;
       }
       r.maxabs = type_maxabs(to);
       return r;
@@ -991,6 +997,19 @@ struct Gen {
           raise_value(and_ok(c.ok, ovf + ")"), 2, site, bits);
         }
       }
+      if (e.eval_mode == EvalMode::Try) {
+        // arrow's safe cast (cast.rs:311-326 `if eval_mode != Try` → :401-407): the value truncated toward zero, NULL when that does not fit the
+        // target type — MIN − 1 < d < MAX + 1, both bounds exact doubles; a NaN fails both comparisons
+        const double lo = to.id == TypeId::Int64 ? -9223372036854775808.0 : to.id == TypeId::Int32 ? -2147483649.0 : to.id == TypeId::Int16 ? -32769.0 : -129.0;
+        const double hi = to.id == TypeId::Int64 ? 9223372036854775808.0 : to.id == TypeId::Int32 ? 2147483648.0 : to.id == TypeId::Int16 ? 32768.0 : 128.0;
+        char lob[40], hib[40];
+        snprintf(lob, sizeof lob, "%.1f", lo);
+        snprintf(hib, sizeof hib, "%.1f", hi);
+        std::string o = newvar("bool");
+        stmt(o + " = " + and_ok(c.ok, "(" + d + (to.id == TypeId::Int64 ? " >= " : " > ") + lob + " && " + d + " < " + hib + ")") + ";");
+        r.ok = o;
+        r.v = to.id == TypeId::Int64 ? "comet::f64_to_i64_sat(" + d + ")" : "comet::f64_to_i32_sat(" + d + ")";      // (in range: plain truncation)
+      }
       r.maxabs = type_maxabs(to);
       return r;
     }
@@ -1018,6 +1037,14 @@ struct Gen {
         site.scale = from.scale;
         Val cv = c;
         raise_value128(and_ok(c.ok, ovf + ")"), 2, site, cv);
+      } else if (e.eval_mode == EvalMode::Try) {
+        // arrow's safe cast (cast.rs:319-326 `if eval_mode != Try` → :401-407): the truncated quotient, NULL when it does not fit the target type
+        const char* lo = to.id == TypeId::Int64 ? "-(i128)0x7fffffffffffffffll - 1" : to.id == TypeId::Int32 ? "-(i128)2147483648ll" : to.id == TypeId::Int16 ? "-(i128)32768" : "-(i128)128";
+        const char* hi = to.id == TypeId::Int64 ? "(i128)0x7fffffffffffffffll" : to.id == TypeId::Int32 ? "(i128)2147483647" : to.id == TypeId::Int16 ? "(i128)32767" : "(i128)127";
+        std::string o = newvar("bool");
+        stmt(o + " = " + and_ok(c.ok, "(" + t + " >= " + lo + " && " + t + " <= " + hi + ")") + ";");
+        r.ok = o;
+        r.v = std::string("(") + nt + ")" + t;
       }
       r.maxabs = type_maxabs(to);
       return r;

@@ -760,10 +760,18 @@ class Evaluator:
         if to == frm:
             return c
         ints = (S.INT8, S.INT16, S.INT32, S.INT64)
+        def try_result(vals, fits):
+            # TRY (try_cast) of a number to an integer type does not reach Comet's own kernels (cast.rs:284-293, 311-326: `if eval_mode != Try`) but
+            # arrow's cast with `safe: true` (:236-241, 401-407; arrow-cast 58.4, third party — its published rule restated, parity unpinned): the
+            # value truncated toward zero, NULL when that does not fit the target type (a NaN never does)
+            v2 = fits if c.valid is None else (c.valid & fits)
+            return Col(to, np.where(fits, vals, 0).astype(_np_dtype(S, to)), None if v2.all() else v2)
         if frm.type_id in ints and to.type_id in ints:
             r = c.values.astype(np.int64).astype(_np_dtype(S, to))   # LEGACY wraps
             if e.eval_mode == S.ANSI and ((r.astype(np.int64) != c.values.astype(np.int64)) & c.ok()).any():
                 raise OracleError("CAST_OVERFLOW")
+            if e.eval_mode == S.TRY:
+                return try_result(r, r.astype(np.int64) == c.values.astype(np.int64))
             return Col(to, r, c.valid)
         if frm.type_id in ints + (S.FLOAT,) and to.type_id == S.DOUBLE:
             return Col(to, c.values.astype(np.float64), c.valid)
@@ -806,6 +814,12 @@ class Evaluator:
                 out.append(v)
             if e.eval_mode == S.ANSI and (ovf & c.ok()).any():
                 raise OracleError("CAST_OVERFLOW")
+            if e.eval_mode == S.TRY:
+                bits = wrap[to.type_id]
+                lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+                xs = c.values.astype(np.float64)
+                fits = np.array([x == x and abs(x) != float("inf") and lo <= int(x) <= hi for x in xs], bool)
+                return try_result(np.array([int(x) if f else 0 for x, f in zip(xs, fits)], np.int64), fits)
             return Col(to, np.array(out, dtype=_np_dtype(S, to)), c.valid)
         if frm.type_id == S.DECIMAL and to.type_id in ints:
             # numeric.rs:426-560: truncate toward zero by 10^scale, then `as`
@@ -825,6 +839,12 @@ class Evaluator:
                     out.append(nv)
             if e.eval_mode == S.ANSI and (ovf & c.ok()).any():
                 raise OracleError("CAST_OVERFLOW")
+            if e.eval_mode == S.TRY:
+                bits = wrap[to.type_id]
+                lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+                ts = [abs(dec_to_int(c.values, i)) // d * (-1 if dec_to_int(c.values, i) < 0 else 1) for i in range(n)]
+                fits = np.array([lo <= t <= hi for t in ts], bool)
+                return try_result(np.array([t if f else 0 for t, f in zip(ts, fits)], np.int64), fits)
             return Col(to, np.array(out, dtype=_np_dtype(S, to)), c.valid)
         if frm.type_id == S.DECIMAL and to.type_id in (S.FLOAT, S.DOUBLE):
             div = float(10.0 ** frm.scale)
