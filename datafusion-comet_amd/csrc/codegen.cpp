@@ -958,6 +958,48 @@ struct Gen {
         r.maxabs = 1;
         return r;
       }
+      if (from.is_float() && (to_ts || to_ntz)) {
+        // cast_float_to_timestamp (numeric.rs:87-135, 1210-1233): seconds → µs in double arithmetic; NaN / ±Infinity and a product beyond a bigint are
+        // NULL (ANSI: CAST_INVALID_INPUT to TIMESTAMP, CAST_OVERFLOW to BIGINT); `micros as i64` otherwise
+        c = named(c);
+        const std::string d = "(double)" + c.v;
+        std::string m = newvar("double"), finite = newvar("bool"), fits = newvar("bool");
+        stmt(m + " = comet::fp_mul(" + d + ", 1000000.0);");
+        stmt(finite + " = " + d + " == " + d + " && fabs(" + d + ") <= 1.7976931348623157e308;");
+        stmt(fits + " = floor(" + m + ") <= 9223372036854775808.0 && ceil(" + m + ") >= -9223372036854775808.0;");
+        if (e.eval_mode == EvalMode::Ansi) {
+          ErrSite bad;      // value: val.to_string() (Rust's Display: NaN, inf, -inf), from DOUBLE whatever the source width
+          bad.error_type = "CastInvalidValue";
+          bad.error_class = "CAST_INVALID_INPUT";
+          bad.from_type = "DOUBLE";
+          bad.to_type = "TIMESTAMP";
+          bad.value = ErrSite::F64Display;
+          raise_value(and_ok(c.ok, "!" + finite), 9, bad, "(u64)__double_as_longlong(" + d + ")");
+          ErrSite big;      // value: "{:e}" of the MICROSECONDS, upper-cased, + "D" — "Infinity" / "-Infinity" when the product left the doubles
+          big.error_type = "CastOverFlow";
+          big.error_class = "CAST_OVERFLOW";
+          big.from_type = "DOUBLE";
+          big.to_type = "BIGINT";
+          big.value = ErrSite::F64Micros;
+          raise_value(and_ok(c.ok, "(" + finite + " && !" + fits + ")"), 2, big, "(u64)__double_as_longlong(" + m + ")");
+        }
+        std::string o = newvar("bool");
+        stmt(o + " = " + and_ok(c.ok, "(" + finite + " && " + fits + ")") + ";");
+        r.ok = o;
+        r.v = "comet::f64_to_i64_sat(" + m + ")";
+        r.maxabs = type_maxabs(to);
+        return r;
+      }
+      if (from.id == TypeId::Decimal && (to_ts || to_ntz)) {
+        // cast_decimal_to_timestamp (numeric.rs:1184-1208): value · 10^6 / 10^scale in 256 bits, truncated toward zero, then `as_i128() as i64` — the low
+        // 64 bits in every mode.  For scale ≥ 6 that is one division; below, the wrapping 128-bit product has the same low bits as the 256-bit one
+        c = named(c);
+        if (from.scale >= 6) r.v = "(i64)(" + as128(c) + " / " + lit_i128((i128)pow10_u128(from.scale - 6)) + ")";
+        else r.v = "(i64)(u64)((u128)" + as128(c) + " * " + lit_u128(pow10_u128(6 - from.scale)) + ")";
+        r.ok = c.ok;
+        r.maxabs = type_maxabs(to);
+        return r;
+      }
       if (from_ts && to_ntz) {
         c = named(c);
         r.ok = c.ok;

@@ -154,6 +154,14 @@ std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint
     case ErrSite::F64Display: { double d; memcpy(&d, &lo, 8); value = rust_display(d); break; }      // cast_float_to_decimal128: input_value.to_string()
     case ErrSite::DecimalBD: value = decimal_str(v128, s.precision, s.scale) + "BD"; break;   // cast_decimal_to_int*: "{}BD"
     case ErrSite::NoValue: break;
+    case ErrSite::F64Micros: {      // cast_float_to_timestamp (numeric.rs:111-127): format!("{:e}", micros).to_uppercase() + "D", infinities by their Java names
+      double d;
+      memcpy(&d, &lo, 8);
+      if (std::isinf(d)) value = d < 0 ? "-Infinity" : "Infinity";
+      else if (std::isnan(d)) value = "NaN";
+      else { value = rust_lower_exp(d) + "D"; for (char& ch : value) if (ch == 'e') ch = 'E'; }
+      break;
+    }
     case ErrSite::Str: {
       const size_t n = (size_t)lo, have = std::min(n, str_avail);
       value.assign((const char*)str, have);

@@ -846,6 +846,36 @@ class Evaluator:
                 fits = np.array([lo <= t <= hi for t in ts], bool)
                 return try_result(np.array([t if f else 0 for t, f in zip(ts, fits)], np.int64), fits)
             return Col(to, np.array(out, dtype=_np_dtype(S, to)), c.valid)
+        if frm.type_id in (S.FLOAT, S.DOUBLE) and to.type_id in (S.TIMESTAMP, S.TIMESTAMP_NTZ):
+            # cast_float_to_timestamp (numeric.rs:87-135): NaN / ±Infinity → NULL (ANSI: CAST_INVALID_INPUT); micros = val · 10^6 in double arithmetic,
+            # kept when floor(micros) ≤ i64::MAX as f64 and ceil(micros) ≥ i64::MIN as f64 (`micros as i64`, saturating), else NULL (ANSI: CAST_OVERFLOW)
+            import math
+            out, ok = [], np.zeros(n, bool)
+            for i, x in enumerate(c.values.astype(np.float64)):
+                x = float(x)
+                if x != x or math.isinf(x):
+                    if e.eval_mode == S.ANSI and c.ok()[i]:
+                        raise OracleError("CAST_INVALID_INPUT")
+                    out.append(0)
+                    continue
+                m = x * 1000000.0
+                if not math.isinf(m) and math.floor(m) <= 9223372036854775808.0 and math.ceil(m) >= -9223372036854775808.0:
+                    ok[i] = True
+                    out.append(max(-2**63, min(2**63 - 1, int(m))))
+                else:
+                    if e.eval_mode == S.ANSI and c.ok()[i]:
+                        raise OracleError("CAST_OVERFLOW")
+                    out.append(0)
+            v2 = ok if c.valid is None else (c.valid & ok)
+            return Col(to, np.array(out, np.int64), None if v2.all() else v2)
+        if frm.type_id == S.DECIMAL and to.type_id in (S.TIMESTAMP, S.TIMESTAMP_NTZ):
+            # cast_decimal_to_timestamp (numeric.rs:1184-1208): value · 10^6 / 10^scale in 256 bits, truncated toward zero, `as_i128() as i64`
+            out = []
+            for i in range(n):
+                v = dec_to_int(c.values, i) * 1_000_000
+                q = abs(v) // 10 ** frm.scale * (-1 if v < 0 else 1)
+                out.append(as_int(q, 64))
+            return Col(to, np.array(out, np.int64), c.valid)
         if frm.type_id == S.DECIMAL and to.type_id in (S.FLOAT, S.DOUBLE):
             div = float(10.0 ** frm.scale)
             vals = np.array([float(dec_to_int(c.values, i)) / div for i in range(n)], np.float64)     # int → f64 rounds to nearest even, like `as f64`

@@ -35,14 +35,16 @@ def test_functions_the_sheet_disables_are_refused_by_name(built, cls, func, args
 
 
 def test_refusals_below_the_class_level_and_unsupported_operators(built):
-    # Cast is ONE class: most casts run, double → timestamp is refused at createPlan — what comet_check_plan exists for
+    # Cast is ONE class: most casts run, timestamp → double is refused at createPlan — what comet_check_plan exists for
     ok, _ = native.check_plan(C.probe_plan(S.cast(S.col(0, S.T_INT32), S.T_DOUBLE)).encode())
     assert ok
     ok, _ = native.check_plan(C.probe_plan(S.cast(S.col(0, S.T_INT32), S.T_STRING)).encode())
     assert ok
     ok, _ = native.check_plan(C.probe_plan(S.cast(S.col(4, S.T_STRING), S.T_TIMESTAMP)).encode())
     assert ok
-    ok, msg = native.check_plan(C.probe_plan(S.cast(S.col(2, S.T_DOUBLE), S.T_TIMESTAMP)).encode())
+    ok, _ = native.check_plan(C.probe_plan(S.cast(S.col(2, S.T_DOUBLE), S.T_TIMESTAMP)).encode())
+    assert ok
+    ok, msg = native.check_plan(C.probe_plan(S.cast(S.cast(S.col(2, S.T_DOUBLE), S.T_TIMESTAMP), S.T_DOUBLE)).encode())
     assert not ok and "Cast" in msg
     # an operator the engine does not run (Explode = 114) is refused by name
     explode = S.Operator.__new__(S.Operator)

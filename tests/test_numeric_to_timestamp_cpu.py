@@ -1,0 +1,48 @@
+"""float / double / decimal → timestamp on the oracle against the reference's own vectors (conversion_funcs/numeric.rs:1753-1860
+test_cast_decimal_to_timestamp, test_cast_float_to_timestamp) and the rules of :87-135, 1184-1208; tests/test_temporal_casts_gpu.py runs the
+same casts on the GPU against this oracle."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import serde as S
+from datafusion_comet_amd.tpch import _dec128_array
+from oracle import oracle as O
+
+TS, NTZ = S.T_TIMESTAMP, S.DataType(S.TIMESTAMP_NTZ)
+
+
+def _cast(arr, frm, to, mode=S.LEGACY, tz="UTC"):
+    plan = S.project(S.scan([frm]), [S.cast(S.col(0, frm), to, mode, tz)])
+    return O.run_plan_to_arrow(S, plan, pa.table({"v": arr})).column(0).cast(pa.int64()).to_pylist()
+
+
+def test_the_references_decimal_vectors():
+    for to in (TS, NTZ):
+        for tz in ("UTC", "America/Los_Angeles"):      # (the zone only labels the result: the value is epoch microseconds)
+            # numeric.rs:1765-1782: Decimal128(18,6) unscaled 0, 1e6, -1e6, 1.5e6, 123456789 → the same microseconds
+            got = _cast(_dec128_array(np.array([0, 1_000_000, -1_000_000, 1_500_000, 123_456_789], np.int64), 18, 6), S.decimal(18, 6), to, tz=tz)
+            assert got == [0, 1_000_000, -1_000_000, 1_500_000, 123_456_789]
+            # :1786-1800: Decimal128(10,2) unscaled 100, 150, -250 → 1.0 s, 1.5 s, -2.5 s
+            assert _cast(_dec128_array(np.array([100, 150, -250], np.int64), 10, 2), S.decimal(10, 2), to, tz=tz) == [1_000_000, 1_500_000, -2_500_000]
+    # truncation toward zero below a microsecond (scale 8), wrapping to 64 bits like `as_i128() as i64` (scale 0, 10^13 s)
+    assert _cast(_dec128_array(np.array([199, -199, 100], np.int64), 10, 8), S.decimal(10, 8), TS) == [1, -1, 1]
+    assert _cast(_dec128_array(np.array([10**13], np.int64), 20, 0), S.decimal(20, 0), TS) == [(10**19 + 2**63) % 2**64 - 2**63]
+
+
+def test_the_references_float_vectors():
+    for mode in (S.LEGACY, S.ANSI, S.TRY):
+        for to in (TS, NTZ):
+            # numeric.rs:1815-1832 / :1836-1848
+            assert _cast(pa.array([0.0, 1.0, -1.0, 1.5, 0.000001, None], pa.float64()), S.T_DOUBLE, to, mode) == [0, 1_000_000, -1_000_000, 1_500_000, 1, None]
+            assert _cast(pa.array([0.0, 1.0, -1.0, None], pa.float32()), S.T_FLOAT, to, mode) == [0, 1_000_000, -1_000_000, None]
+    # :1852-1858: NaN and infinity raise under ANSI, are NULL otherwise; so is a product beyond a bigint
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        assert _cast(pa.array([bad]), S.T_DOUBLE, TS) == [None]
+        with pytest.raises(O.OracleError, match="CAST_INVALID_INPUT"):
+            _cast(pa.array([bad]), S.T_DOUBLE, TS, S.ANSI)
+    assert _cast(pa.array([1e13, -1e13, 9.3e12, 1e303]), S.T_DOUBLE, TS) == [None, None, None, None]
+    with pytest.raises(O.OracleError, match="CAST_OVERFLOW"):
+        _cast(pa.array([1e13]), S.T_DOUBLE, TS, S.ANSI)
+    # the edge: 9223372036854.775 s · 10^6 rounds to 2^63 as a double — floor(micros) ≤ i64::MAX as f64 holds, `as i64` saturates
+    assert _cast(pa.array([9223372036854.775, -9223372036854.775]), S.T_DOUBLE, TS) == [2**63 - 1, -2**63]

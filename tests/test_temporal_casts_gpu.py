@@ -80,3 +80,46 @@ def test_unknown_zones_and_instants_behind_the_tables_end(built):
     for tz in ("Europe/Berlin", "America/Los_Angeles", "Australia/Sydney", "Asia/Tokyo"):
         c = lambda x, to: S.cast(x, to, S.LEGACY, tz)
         _check([c(ts, D), c(ts, NTZ), c(ntz, TS), c(ts, STR), S.time_part("hour", ts, tz)], far)
+
+
+def test_floats_and_decimals_to_timestamps(built):
+    """cast_float_to_timestamp / cast_decimal_to_timestamp (numeric.rs:87-135, 1184-1233; tests/test_numeric_to_timestamp_cpu.py pins the oracle on
+    the reference's vectors): seconds → microseconds, NaN / ±Infinity / beyond a bigint → NULL (ANSI: the reference's two errors), decimals
+    truncated toward zero and wrapped to 64 bits"""
+    import json
+    from datafusion_comet_amd.tpch import _dec128_array
+    from oracle import oracle as O
+    rng = np.random.default_rng(12)
+    n = 4000
+    f = np.concatenate([[0.0, 1.0, -1.0, 1.5, 0.000001, float("nan"), float("inf"), float("-inf"), 1e13, -1e13, 9.3e12, 1e303, 9223372036854.775, -9223372036854.775, -0.0],
+                        rng.normal(0, 1e9, n), rng.normal(0, 1e13, n // 4), rng.random(n // 4) * 1e-5])
+    m = len(f)
+    lo = np.concatenate([[0, 1_000_000, -1_000_000, 1_500_000, 123_456_789, 199, -199], rng.integers(-10**17, 10**17, m - 7)]).astype(np.int64)
+    with np.errstate(over="ignore", invalid="ignore"):
+        f32 = f.astype(np.float32)
+    mask = rng.random(m) < 0.05
+    big = [int(x) * 10**15 + 7 for x in lo]
+    wide = pa.Array.from_buffers(pa.decimal128(38, 0), m, [None, pa.py_buffer(np.array([[v & (2**64 - 1), (v >> 64) & (2**64 - 1)] for v in big], np.uint64).tobytes())])
+    t = pa.table({"f": pa.array(f, mask=mask), "g": pa.array(f32, mask=mask), "d6": _dec128_array(lo, 18, 6), "d2": _dec128_array(lo, 18, 2), "d8": _dec128_array(lo, 18, 8), "w": wide})
+    fields = [S.T_DOUBLE, S.T_FLOAT, S.decimal(18, 6), S.decimal(18, 2), S.decimal(18, 8), S.decimal(38, 0)]
+    cols = [S.col(k, ty) for k, ty in enumerate(fields)]
+    for mode in (S.LEGACY, S.TRY):
+        outs = [S.cast(c, to, mode, "America/Los_Angeles") for c in cols for to in (TS, NTZ)]
+        plan = S.project(S.scan(fields), outs)
+        got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], len(outs), plan.encode(), batch_size=0))
+        want = O.run_plan_to_arrow(S, plan, t)
+        for k in range(len(outs)):
+            g, w = got.column(k).cast(pa.int64()).to_pylist(), want.column(k).cast(pa.int64()).to_pylist()
+            if g != w:
+                j = next(x for x in range(m) if g[x] != w[x])
+                raise AssertionError(f"output {k}, row {j}: got {g[j]!r}, want {w[j]!r}, input {[c[j].as_py() for c in t.columns]!r}")
+        assert got.column(0).cast(pa.int64()).to_pylist()[:5] == [0, 1_000_000, -1_000_000, 1_500_000, 1]          # numeric.rs:1815-1832
+    for bad, etype, params in [(float("nan"), "CastInvalidValue", {"value": "NaN", "fromType": "DOUBLE", "toType": "TIMESTAMP"}),
+                               (float("-inf"), "CastInvalidValue", {"value": "-inf", "fromType": "DOUBLE", "toType": "TIMESTAMP"}),
+                               (1e13, "CastOverFlow", {"value": "1E19D", "fromType": "DOUBLE", "toType": "BIGINT"}),
+                               (1e303, "CastOverFlow", {"value": "Infinity", "fromType": "DOUBLE", "toType": "BIGINT"})]:
+        tb = pa.table({"f": pa.array([1.0, bad, None])})
+        with pytest.raises(native.CometQueryExecutionException) as ei:
+            native.execute_to_table([native.HostInput.from_table(tb)], 1, S.project(S.scan([S.T_DOUBLE]), [S.cast(S.col(0, S.T_DOUBLE), TS, S.ANSI)]).encode(), batch_size=0)
+        j = json.loads(str(ei.value))
+        assert j["errorType"] == etype and j["params"] == params, j

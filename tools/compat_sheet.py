@@ -86,7 +86,7 @@ def probes():
         "Remainder": (S.math("remainder", i64, L(7, S.T_INT64), S.T_INT64), "integers, floats and decimals"),
         "IntegralDivide": (S.integral_divide(i64, S.T_INT64, L(3, S.T_INT64), S.T_INT64), "integers and decimals"),
         "UnaryMinus": (S.Expr("unary_minus", [i64]), ""),
-        "Cast": (S.cast(i32, S.T_INT64), "the numeric matrix; string -> boolean / integers / floats / decimal / date; integers, booleans, floats, decimals, dates and timestamps -> string (output columns); float -> decimal; date <-> timestamp <-> bigint in any time zone; string -> timestamp / timestamp_ntz (a zone NAME inside a value or a time of day without a date fails the task); float / decimal <-> timestamp is REFUSED"),
+        "Cast": (S.cast(i32, S.T_INT64), "the numeric matrix; string -> boolean / integers / floats / decimal / date; integers, booleans, floats, decimals, dates and timestamps -> string (output columns); float -> decimal; date <-> timestamp <-> bigint in any time zone; string -> timestamp / timestamp_ntz (a zone NAME inside a value or a time of day without a date fails the task); float / decimal -> timestamp; timestamp -> float / decimal is REFUSED"),
         "CheckOverflow": (S.check_overflow(S.math("add", dec, dec, S.decimal(13, 2)), S.decimal(13, 2)), ""),
         "EqualTo": (S.eq(i32, L(1, S.T_INT32)), "all flat types incl. Utf8 of any length"), "EqualNullSafe": (S.eq_null_safe(i32, L(1, S.T_INT32)), ""),
         "GreaterThan": (S.gt(d, L(9000, S.T_DATE)), ""), "GreaterThanOrEqual": (S.gt_eq(f64, L(0.5, S.T_DOUBLE)), ""), "LessThan": (S.lt(dec, dec), ""),
@@ -194,7 +194,7 @@ def render() -> str:
     w("")
     w("## 4. Refusals below the class level (what `comet_check_plan` is for)")
     w("")
-    w("* `Cast`: float / decimal / boolean <-> timestamp, binary, casts of a COMPUTED string; a cast to string is an output column (not an operand); on a")
+    w("* `Cast`: timestamp -> float / decimal / boolean, binary, casts of a COMPUTED string; a cast to string is an output column (not an operand); on a")
     w("  device-resident input ANY type mismatch with the declared Scan fields.  Time zones come from the system's database ($TZDIR, /usr/share/zoneinfo).")
     w("* `Min` / `Max` of decimal(> 18) in grouped aggregates; more than four Float64 sums / averages in one aggregate.")
     w("* `RLike`: patterns outside the byte-exact subset (`\\\\p{..}`, scoped flags, look-around, `\\\\b` under `(?m)`) are refused by name.")
