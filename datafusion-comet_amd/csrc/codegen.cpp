@@ -1125,7 +1125,7 @@ struct Gen {
       r.maxabs = 1;
       return r;
     }
-    if ((is_intlike(from) || from.is_float()) && to.id == TypeId::Bool) {
+    if ((is_intlike(from) || from.is_float() || from.id == TypeId::Decimal) && to.id == TypeId::Bool) {      // decimals: spark_cast_decimal_to_boolean (numeric.rs:853-864)
       r.v = "(" + c.v + " != 0)";
       return r;
     }

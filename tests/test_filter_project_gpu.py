@@ -316,7 +316,7 @@ def test_more_casts(built):
     outs = [S.cast(F, S.T_INT8), S.cast(F, S.T_INT16), S.cast(F, S.T_INT32), S.cast(F, S.T_INT64), S.cast(F, S.T_FLOAT),
             S.cast(Dc, S.T_INT8), S.cast(Dc, S.T_INT32), S.cast(Dc, S.T_INT64), S.cast(Wc, S.T_INT16), S.cast(Wc, S.T_INT64),
             S.cast(Dc, S.T_DOUBLE), S.cast(Wc, S.T_DOUBLE), S.cast(Dc, S.T_FLOAT),
-            S.cast(B, S.T_INT32), S.cast(B, S.T_DOUBLE), S.cast(I, S.T_BOOL), S.cast(F, S.T_BOOL)]
+            S.cast(B, S.T_INT32), S.cast(B, S.T_DOUBLE), S.cast(I, S.T_BOOL), S.cast(F, S.T_BOOL), S.cast(Dc, S.T_BOOL), S.cast(Wc, S.T_BOOL)]
     plan = S.project(S.scan(fields), outs)
     got = pa.Table.from_batches(_run(plan, table=t, ncols=len(outs), batch_size=0))
     want = _oracle(plan, t)

@@ -46,3 +46,12 @@ def test_the_references_float_vectors():
         _cast(pa.array([1e13]), S.T_DOUBLE, TS, S.ANSI)
     # the edge: 9223372036854.775 s · 10^6 rounds to 2^63 as a double — floor(micros) ≤ i64::MAX as f64 holds, `as i64` saturates
     assert _cast(pa.array([9223372036854.775, -9223372036854.775]), S.T_DOUBLE, TS) == [2**63 - 1, -2**63]
+
+
+def test_the_references_decimal_to_boolean_vector():
+    # numeric.rs:1286-1298: Decimal128(10,2) 0, 100, -100, NULL → false, true, true, NULL
+    arr = pa.array([0, 100, -100, None], pa.int64())
+    from decimal import Decimal
+    d = pa.array([None if v is None else Decimal(v).scaleb(-2) for v in arr.to_pylist()], pa.decimal128(10, 2))
+    plan = S.project(S.scan([S.decimal(10, 2)]), [S.cast(S.col(0, S.decimal(10, 2)), S.T_BOOL)])
+    assert O.run_plan_to_arrow(S, plan, pa.table({"v": d})).column(0).to_pylist() == [False, True, True, None]
