@@ -921,6 +921,11 @@ struct Gen {
       return x;
     }
     if (from.id == TypeId::Date && to.id == TypeId::Date) return c;
+    if (from.id == TypeId::Date && to.id == TypeId::Int32) {      // cast.rs:273-276: a Date32 is its days since the epoch — the same 32 bits
+      r.v = "(i32)" + c.v;      // (Spark's own date → int is NULL and the JVM side plans it as a literal, CometCast.scala:126-140: this is the native cast of the reference's internals)
+      r.maxabs = type_maxabs(to);
+      return r;
+    }
     {
       // Temporal casts (conversion_funcs/temporal.rs:37-78, cast.rs:395-415, utils.rs:62-87,269-297): the time zone is the Cast's (Expr::func)
       const bool from_ts = from.id == TypeId::Timestamp, from_ntz = from.id == TypeId::TimestampNtz;

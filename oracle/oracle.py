@@ -887,6 +887,8 @@ class Evaluator:
             return Col(to, c.values.astype(_np_dtype(S, to)), c.valid)
         if frm.type_id in ints + (S.FLOAT, S.DOUBLE) and to.type_id == S.BOOL:
             return Col(to, c.values != 0, c.valid)
+        if frm.type_id == S.DATE and to.type_id == S.INT32:      # cast.rs:273-276: the days since the epoch, reinterpreted
+            return Col(to, c.values.astype(np.int32), c.valid)
         if frm.type_id == S.DECIMAL and to.type_id == S.BOOL:      # spark_cast_decimal_to_boolean (numeric.rs:853-864): value != 0
             return Col(to, np.array([dec_to_int(c.values, i) != 0 for i in range(n)], bool), c.valid)
         if frm.type_id in (S.FLOAT, S.DOUBLE) and to.type_id == S.DECIMAL:

@@ -55,3 +55,12 @@ def test_the_references_decimal_to_boolean_vector():
     d = pa.array([None if v is None else Decimal(v).scaleb(-2) for v in arr.to_pylist()], pa.decimal128(10, 2))
     plan = S.project(S.scan([S.decimal(10, 2)]), [S.cast(S.col(0, S.decimal(10, 2)), S.T_BOOL)])
     assert O.run_plan_to_arrow(S, plan, pa.table({"v": d})).column(0).to_pylist() == [False, True, True, None]
+
+
+def test_date_to_int_is_the_day_number():
+    # cast.rs:273-276 (Date32 → Int32 reinterprets); the plan compiles for gfx950 and the oracle gives the days
+    from datafusion_comet_amd import native
+    plan = S.project(S.scan([S.T_DATE]), [S.cast(S.col(0, S.T_DATE), S.T_INT32)])
+    native.compile_plan(plan.encode())
+    t = pa.table({"d": pa.array([0, 19723, None, -5], pa.int32()).cast(pa.date32())})
+    assert O.run_plan_to_arrow(S, plan, t).column(0).to_pylist() == [0, 19723, None, -5]
