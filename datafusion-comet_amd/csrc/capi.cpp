@@ -450,6 +450,11 @@ int64_t comet_plan_error_json(const uint8_t* plan, size_t plan_len, int32_t site
     while (!leaf->children.empty()) leaf = leaf->children[0].get();
     std::vector<bool> none(leaf->scan_fields.size(), false);
     const PipelineDesc d = generate_pipeline(*op, none);
+    if (site_index == -1 || site_index == -2) {      // the pipeline's ANSI decimal sum (-1) / average (-2) overflow
+      const std::string j = decimal_sum_overflow_json(-1 - site_index, d.agg_ctx[-1 - site_index].get());
+      if (out && cap > (int64_t)j.size()) memcpy(out, j.c_str(), j.size() + 1);
+      return (int64_t)j.size();
+    }
     if (site_index < 0 || (size_t)site_index >= d.site_contexts.size())
       throw CometError("the plan's pipeline has " + std::to_string(d.site_contexts.size()) + " raise sites with a QueryContext");
     ErrSite site;

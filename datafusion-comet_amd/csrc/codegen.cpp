@@ -2719,6 +2719,16 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   // Final and PartialMerge both MERGE Partial states (merge_batch); Final then evaluates, PartialMerge re-emits the state
   const bool grouped = !group_exprs.empty();
   d.sink = grouped ? SinkKind::AggGrouped : SinkKind::AggNoGroup;
+  // the context an ANSI decimal sum (0) / average (1) raises its DecimalSumOverflow with (PipelineDesc::agg_ctx)
+  auto note_agg_ctx = [&](int kind, const AggExpr& a) {
+    std::shared_ptr<QueryContext> c = (a.qctx && a.has_expr_id) ? a.qctx : nullptr;
+    static const std::shared_ptr<QueryContext> none;
+    if (d.agg_ctx_mixed[kind]) return;
+    if (!d.agg_ctx[kind] && !d.agg_ctx_seen[kind]) { d.agg_ctx[kind] = c; d.agg_ctx_seen[kind] = true; return; }
+    const QueryContext* x = d.agg_ctx[kind].get();
+    const bool same = (!x && !c) || (x && c && x->sql_text == c->sql_text && x->start_index == c->start_index && x->stop_index == c->stop_index);
+    if (!same) { d.agg_ctx_mixed[kind] = true; d.agg_ctx[kind] = nullptr; }
+  };
   AggLowering al(g, grouped);
   std::string fin;  // finalize body; ROW is "[0]" (ungrouped) or "[pos]" (grouped emit)
   const std::string ROW = grouped ? "[pos]" : "[0]";
@@ -2871,6 +2881,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
                      lit_u128(bound) + ", ovf, (unsigned int*)prm.out[" + std::to_string(kOutErr) + "]);\n";
               g.uses_err = true;
               // ANSI: merging into an overflow fails the query (sum_decimal.rs:352-358, 594-600)
+              if (a.eval_mode == EvalMode::Ansi) note_agg_ctx(0, a);
               if (a.eval_mode == EvalMode::Ansi)
                 fin += "      if (acc[" + std::to_string(any_ovf.word) + "] != 0 || ovf || (acc[" + std::to_string(cnt.word) + "] != 0 && !comet::dec_fits(total, " + lit_u128(bound) +
                        "))) atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], 65536u);\n";
@@ -2925,6 +2936,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
               if (grouped) fin += "      bool sum_ok = acc[" + std::to_string(bad.word) + "] == 0 && !ovf;\n";
               else fin += "      bool sum_ok = acc[" + std::to_string(nsum.word) + "] != 0 && comet::dec_fits(total, " + lit_u128(bound) + ");\n";
               // ANSI: an overflowed sum under a count fails the query (avg_decimal.rs:366-380, 576-580, 610-616)
+              if (a.eval_mode == EvalMode::Ansi) note_agg_ctx(1, a);
               if (a.eval_mode == EvalMode::Ansi)
                 fin += "      if (!sum_ok && count > 0) atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], 131072u);\n";
               if (emit_state) {
@@ -3096,6 +3108,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
             g.uses_err = true;
             // ANSI: an overflowing decimal SUM fails the query instead of turning NULL (sum_decimal.rs:211-215, 427-431).  An average only notes the
             // overflow in its state here (avg_decimal.rs:268-300, 483-503) and raises when the states are merged or evaluated (:366-380, 576-580, 610-616)
+            if (a.eval_mode == EvalMode::Ansi && !is_avg) note_agg_ctx(0, a);
             if (a.eval_mode == EvalMode::Ansi && !is_avg)
               fin += "      if (ovf) atomicOr((unsigned int*)prm.out[" + std::to_string(kOutErr) + "], 65536u);\n";
           }

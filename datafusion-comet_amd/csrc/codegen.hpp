@@ -54,6 +54,10 @@ struct PipelineDesc {
   // raise sites of this pipeline's kernels whose expression carries a QueryContext: the executor attaches it to the error (the site ids in the
   // generated text do not depend on the SQL text, so plans that differ only in it share their code objects)
   std::vector<std::pair<uint32_t, std::shared_ptr<QueryContext>>> site_contexts;
+  // the QueryContext of the pipeline's ANSI decimal sum ([0]) / average ([1]) — the DecimalSumOverflow flags do not say WHICH aggregate
+  // overflowed, so a context is attached only when all of a kind that carry one carry the same; agg_ctx_mixed[k]: they differ
+  std::shared_ptr<QueryContext> agg_ctx[2];
+  bool agg_ctx_mixed[2] = {false, false}, agg_ctx_seen[2] = {false, false};
   std::string source;              // full HIP translation unit
   std::vector<std::string> kernels;  // extern "C" kernel names present in `source`
   // static row bound under which decimal sums cannot overflow (Appendix C.1 rule); 0 = no limit
@@ -124,7 +128,7 @@ constexpr int kErrDetailStrBytes = 224;
 // registered process-wide under an id derived from their content, so the generated text — and with it the code-object cache key — does not
 // depend on the order plans arrive in.
 struct ErrSite {
-  enum Value : int { Unscaled128 = 0, Int64 = 1, F64 = 2, F32 = 3, Str = 4, DecimalBD = 5, F64Display = 6, Int64Plain = 7, NoValue = 8, F64Micros = 9 };
+  enum Value : int { Unscaled128 = 0, Int64 = 1, F64 = 2, F32 = 3, Str = 4, DecimalBD = 5, F64Display = 6, Int64Plain = 7, NoValue = 8, F64Micros = 9, FunctionName = 10 };
   std::string error_type;    // "NumericValueOutOfRange", "CastOverFlow", "CastInvalidValue", "InvalidInputInCastToDatetime"
   std::string error_class;
   std::string from_type, to_type;      // Spark SQL type names ("BIGINT", "DECIMAL(10,2)", "STRING" …)
@@ -136,6 +140,8 @@ uint32_t register_err_site(const ErrSite& s, int ordinal = 0);      // ordinal: 
 bool lookup_err_site(uint32_t id, ErrSite& out);
 // the error JSON of a site and the detail the device left (lo / hi: the value's bits or a string's length; str: its first bytes)
 std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint8_t* str, size_t str_avail, const QueryContext* ctx = nullptr);
+// DecimalSumOverflow of an ANSI decimal sum (kind 0) / average (1), with the aggregate's context when the plan carried one
+std::string decimal_sum_overflow_json(int kind, const QueryContext* ctx);
 constexpr int kOutFirstCol = 4;      // out[4+2j] = values of col j, out[5+2j] = validity bytes of col j
 
 }  // namespace comet

@@ -140,6 +140,8 @@ static std::string context_json(const QueryContext& c) {
 
 std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint8_t* str, size_t str_avail, const QueryContext* ctx) {
   const std::string tail = (ctx ? context_json(*ctx) : std::string()) + "}";
+  if (s.value == ErrSite::FunctionName)      // DecimalSumOverflow { function_name } (error.rs:75-76, 374-377); the name travels in from_type
+    return "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{\"functionName\":\"" + s.from_type + "\"}" + tail;
   if (s.value == ErrSite::NoValue)      // ArithmeticOverflow { from_type } (error.rs:369-373): which type overflowed, no value
     return "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{" +
            (s.from_type.empty() ? std::string() : "\"fromType\":\"" + s.from_type + "\"") + "}" + tail;
@@ -153,7 +155,7 @@ std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint
     case ErrSite::F32: { float f; uint32_t b = (uint32_t)lo; memcpy(&f, &b, 4); value = rust_lower_exp(f); break; }
     case ErrSite::F64Display: { double d; memcpy(&d, &lo, 8); value = rust_display(d); break; }      // cast_float_to_decimal128: input_value.to_string()
     case ErrSite::DecimalBD: value = decimal_str(v128, s.precision, s.scale) + "BD"; break;   // cast_decimal_to_int*: "{}BD"
-    case ErrSite::NoValue: break;
+    case ErrSite::NoValue: case ErrSite::FunctionName: break;
     case ErrSite::F64Micros: {      // cast_float_to_timestamp (numeric.rs:111-127): format!("{:e}", micros).to_uppercase() + "D", infinities by their Java names
       double d;
       memcpy(&d, &lo, 8);
@@ -175,6 +177,15 @@ std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint
   if (s.error_type == "NumericValueOutOfRange") j += ",\"precision\":" + std::to_string(s.precision) + ",\"scale\":" + std::to_string(s.scale);
   else j += ",\"fromType\":\"" + s.from_type + "\",\"toType\":\"" + s.to_type + "\"";
   return j + "}" + tail;
+}
+
+std::string decimal_sum_overflow_json(int kind, const QueryContext* ctx) {
+  ErrSite s;      // decimal_sum_overflow_error("sum" / "avg") (spark-expr/src/lib.rs:131-135)
+  s.error_type = "DecimalSumOverflow";
+  s.error_class = "ARITHMETIC_OVERFLOW";
+  s.from_type = kind == 0 ? "sum" : "avg";
+  s.value = ErrSite::FunctionName;
+  return err_site_json(s, 0, 0, nullptr, 0, ctx);
 }
 
 }  // namespace comet

@@ -212,7 +212,11 @@ class ExecutionContext {
   void check_device_errors();
   void raise_device_errors(uint32_t flags);
   // the QueryContexts of a pipeline's raise sites (PipelineDesc::site_contexts), kept for the errors this context's kernels may raise
-  void note_sites(const PipelineDesc& d) { for (auto& kv : d.site_contexts) site_ctx_[kv.first] = kv.second; }
+  void note_sites(const PipelineDesc& d) {
+    for (auto& kv : d.site_contexts) site_ctx_[kv.first] = kv.second;
+    for (int k = 0; k < 2; k++) if (d.agg_ctx[k]) agg_ctx_[k] = d.agg_ctx[k];
+  }
+  std::shared_ptr<QueryContext> agg_ctx_[2];      // … and of its ANSI decimal sum / average (PipelineDesc::agg_ctx)
   std::map<uint32_t, std::shared_ptr<QueryContext>> site_ctx_;
   void read_small(void* dst, const void* dev_src, size_t n);
   void write_small(void* dev_dst, const void* src, size_t n);

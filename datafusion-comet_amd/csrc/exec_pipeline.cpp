@@ -320,8 +320,10 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
   if (f & 2048u) throw CometError("a timestamp lies behind the end of its time zone's table (the year 2400): not supported by the MI355X native engine");
   if (f & 256u) throw CometError("{\"errorType\":\"DivideByZero\",\"errorClass\":\"DIVIDE_BY_ZERO\",\"params\":{}}", 1);
   // decimal_sum_overflow_error (spark-expr/src/lib.rs:131-135; error.rs:75-76, 374-377): ANSI sum / avg of decimals
-  if (f & 65536u) throw CometError("{\"errorType\":\"DecimalSumOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"functionName\":\"sum\"}}", 1);
-  if (f & 131072u) throw CometError("{\"errorType\":\"DecimalSumOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"functionName\":\"avg\"}}", 1);
+  if (f & (65536u | 131072u)) {
+    const int kind = (f & 65536u) ? 0 : 1;
+    throw CometError(decimal_sum_overflow_json(kind, agg_ctx_[kind].get()), 1);
+  }
   if (f & 32768u) throw CometError("{\"errorType\":\"RemainderByZero\",\"errorClass\":\"REMAINDER_BY_ZERO\",\"params\":{}}", 1);      // (common/src/error.rs:81-82, 684)
   if (f & 64u) throw CometError("Utf8 group keys longer than 15 bytes are not supported by the GPU hash aggregate yet");
   if (f & 16u)

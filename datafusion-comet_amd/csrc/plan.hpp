@@ -105,6 +105,8 @@ struct AggExpr {
   ExprP filter;                   // AggExpr.filter = 89
   bool ignore_nulls = false;      // First / Last
   uint64_t expr_id = 0;
+  bool has_expr_id = false;
+  std::shared_ptr<QueryContext> qctx;      // AggExpr.query_context = 90: goes with the aggregate's DecimalSumOverflow (sum_decimal.rs wrap_error_with_context)
 };
 
 // Operator.op_struct oneof tags (operator.proto:32-79)

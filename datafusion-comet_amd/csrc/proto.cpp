@@ -279,7 +279,8 @@ AggExpr decode_agg_expr(Reader r) {
   while (!r.done()) {
     int wt, f = r.tag(wt);
     if (f == 89 && wt == 2) { a.filter = decode_expr(r.sub()); continue; }
-    if (f == 91 && wt == 0) { a.expr_id = r.varint(); continue; }
+    if (f == 91 && wt == 0) { a.expr_id = r.varint(); a.has_expr_id = true; continue; }
+    if (f == 90 && wt == 2) { a.qctx = decode_query_context(r.sub()); continue; }      // AggExpr.query_context (expr.proto:171-175)
     if (f == 90 || wt != 2) { r.skip(wt); continue; }
     a.proto_tag = f;
     Reader b = r.sub();

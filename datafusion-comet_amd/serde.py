@@ -34,6 +34,25 @@ def _tag(field_no: int, wt: int) -> bytes:
     return _varint((field_no << 3) | wt)
 
 
+def _context_fields(e) -> bytes:
+    """query_context = 90 (QueryContext, expr.proto:109-141) and expr_id = 91 of an Expr or an AggExpr (set by with_context)"""
+    out = b""
+    qc = getattr(e, "query_context", None)
+    if qc is not None:
+        c = (_f_bytes(1, qc["sql_text"].encode()) if qc.get("sql_text") else b"") + _f_varint(2, qc.get("start_index", 0)) + _f_varint(3, qc.get("stop_index", 0))
+        if qc.get("object_type") is not None:
+            c += _f_bytes(4, qc["object_type"].encode())
+        if qc.get("object_name") is not None:
+            c += _f_bytes(5, qc["object_name"].encode())
+        c += _f_varint(6, qc.get("line", 0)) + _f_varint(7, qc.get("start_position", 0))
+        if qc.get("sql_text_idx") is not None:
+            c += _f_varint(8, qc["sql_text_idx"])
+        out += _f_msg(90, c)
+    if getattr(e, "expr_id", None) is not None:
+        out += _f_varint(91, e.expr_id)
+    return out
+
+
 def _f_varint(field_no: int, v: int) -> bytes:
     return _tag(field_no, 0) + _varint(v)
 
@@ -177,21 +196,7 @@ class Expr:
                 body += _f_msg(4, self.children[2 * n].encode())
         else:  # BinaryExpr / UnaryExpr
             body = b"".join(_f_msg(i + 1, c.encode()) for i, c in enumerate(self.children))
-        out = _f_msg(tag, body)
-        qc = getattr(self, "query_context", None)
-        if qc is not None:      # Expr.query_context = 90 (QueryContext, expr.proto:109-141), Expr.expr_id = 91
-            c = (_f_bytes(1, qc["sql_text"].encode()) if qc.get("sql_text") else b"") + _f_varint(2, qc.get("start_index", 0)) + _f_varint(3, qc.get("stop_index", 0))
-            if qc.get("object_type") is not None:
-                c += _f_bytes(4, qc["object_type"].encode())
-            if qc.get("object_name") is not None:
-                c += _f_bytes(5, qc["object_name"].encode())
-            c += _f_varint(6, qc.get("line", 0)) + _f_varint(7, qc.get("start_position", 0))
-            if qc.get("sql_text_idx") is not None:
-                c += _f_varint(8, qc["sql_text_idx"])
-            out += _f_msg(90, c)
-        if getattr(self, "expr_id", None) is not None:
-            out += _f_varint(91, self.expr_id)
-        return out
+        return _f_msg(tag, body) + _context_fields(self)
 
     def _encode_literal(self) -> bytes:
         t = self.dtype
@@ -298,8 +303,8 @@ def cast(child: Expr, dtype: DataType, eval_mode: int = LEGACY, timezone: str = 
     return e
 
 
-def with_context(e: Expr, expr_id: int, **qc) -> Expr:
-    """attach Spark's SQLQueryContext to an expression (sql_text | sql_text_idx, start_index, stop_index, line, start_position, object_type,
+def with_context(e, expr_id: int, **qc):
+    """attach Spark's SQLQueryContext to an expression or an aggregate (sql_text | sql_text_idx, start_index, stop_index, line, start_position, object_type,
     object_name) under its expr_id: the errors it raises carry it"""
     e.query_context = qc
     e.expr_id = expr_id
@@ -373,7 +378,7 @@ class AggExpr:
         out = _f_msg(self.TAGS[self.kind], body)
         if self.filter is not None:
             out += _f_msg(89, self.filter.encode())
-        return out
+        return out + _context_fields(self)
 
 
 def count(*children: Expr) -> AggExpr:

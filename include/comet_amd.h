@@ -203,7 +203,8 @@ int64_t comet_error_json(const char* error_type, const char* error_class, const 
 
 /* The same for the site_index-th raise site — in the order they are generated — of a Projection / Filter plan whose expressions carry a
  * QueryContext (expr.proto:103-141, planner.rs:302-316): the JSON then holds "context" and "summary" like SparkErrorWithContext::to_json
- * (error.rs:806-831).  Generates the plan's kernel text, compiles and runs nothing.  Returns the length, or -2 and comet_last_error(0). */
+ * (error.rs:806-831).  site_index -1 / -2: the DecimalSumOverflow of the pipeline's ANSI decimal sum / average, with the aggregate's context.
+ * Generates the plan's kernel text, compiles and runs nothing.  Returns the length, or -2 and comet_last_error(0). */
 int64_t comet_plan_error_json(const uint8_t* plan, size_t plan_len, int32_t site_index, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail,
                               char* out, int64_t cap);
 

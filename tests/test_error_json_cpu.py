@@ -119,3 +119,22 @@ def test_the_kernel_text_does_not_depend_on_the_sql_text(tmp_path, monkeypatch):
     assert first and any("err_detail_str" in open(tmp_path / f).read() for f in first)
     native.compile_plan(plan("select cast(s as decimal(17,3)) from another_table -- v2"))
     assert sorted(os.listdir(tmp_path)) == first          # nothing new was generated: the second plan found its kernels compiled
+
+
+def test_decimal_sum_overflow_carries_the_aggregates_context():
+    """sum_decimal.rs / avg_decimal.rs wrap_error_with_context: the aggregate's own QueryContext (AggExpr.query_context = 90 under expr_id = 91); the
+    flag a kernel raises does not say WHICH sum overflowed, so the context is attached only when the pipeline's ANSI sums agree on it"""
+    from datafusion_comet_amd import serde as S
+    D = S.decimal(10, 2)
+    sql = "SELECT sum(v), sum(w) FROM t"
+    ctx = dict(sql_text=sql, start_index=7, stop_index=12, line=1, start_position=7)
+    one = S.hash_agg(S.scan([D, D]), [], [S.with_context(S.sum_(S.col(0, D), D, S.ANSI), 3, **ctx)], S.PARTIAL)
+    j = native.plan_error_json(one.encode(), -1)
+    assert j["errorType"] == "DecimalSumOverflow" and j["errorClass"] == "ARITHMETIC_OVERFLOW" and j["params"] == {"functionName": "sum"}
+    assert j["context"]["sqlText"] == sql and j["summary"] == "== SQL (line 1, position 8) ==\n" + sql + "\n" + " " * 7 + "^" * 6
+    two = S.hash_agg(S.scan([D, D]), [], [S.with_context(S.sum_(S.col(0, D), D, S.ANSI), 3, **ctx),
+                                           S.with_context(S.sum_(S.col(1, D), D, S.ANSI), 4, sql_text=sql, start_index=15, stop_index=20, line=1, start_position=15)], S.PARTIAL)
+    j = native.plan_error_json(two.encode(), -1)
+    assert j["params"] == {"functionName": "sum"} and "context" not in j
+    assert native.plan_error_json(S.hash_agg(S.scan([D, S.T_INT64]), [], [S.avg(S.col(0, D), S.decimal(14, 6), D, S.ANSI)], S.FINAL).encode(), -2) == \
+        {"errorType": "DecimalSumOverflow", "errorClass": "ARITHMETIC_OVERFLOW", "params": {"functionName": "avg"}}
