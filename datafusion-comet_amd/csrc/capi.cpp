@@ -191,6 +191,7 @@ int64_t comet_parquet_reader_init(const char* file_path, int64_t file_size, cons
     if (!file_path || !required_schema_ipc) throw CometError("initRecordBatchReader: file path and required schema are mandatory");
     auto op = std::make_shared<Operator>();
     op->kind = OpKind::NativeScan;
+    op->reader_api = true;      // (format errors stay "parquet: …" → ParquetRuntimeException, parquet/mod.rs; a plan's NativeScan classifies them for Spark)
     op->proto_tag = 111;
     op->required_schema = decode_ipc_schema(required_schema_ipc, required_len);
     op->data_schema = data_schema_ipc && data_len ? decode_ipc_schema(data_schema_ipc, data_len) : op->required_schema;

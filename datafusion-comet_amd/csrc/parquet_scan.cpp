@@ -154,13 +154,20 @@ namespace {
 
 // A Parquet file opened for positional reads.  Column chunks are pread() by the scan threads into their own scratch
 // (no mmap: tearing down a mapping of several hundred MB costs milliseconds of page-table work after every scan).
+// the file is not there (errno ENOENT): Spark tells that apart from a file it cannot read (jni-bridge/src/errors.rs:633-655)
+struct FileMissing : CometError {
+  explicit FileMissing(const std::string& m) : CometError(m) {}
+};
 struct OpenFile {
   int fd = -1;
   size_t size = 0;
   std::vector<uint8_t> footer;   // "PAR1" + FileMetaData + length + "PAR1": what parse_footer needs
   explicit OpenFile(const std::string& path) {
     fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) throw CometError("cannot open Parquet file " + path);
+    if (fd < 0) {
+      if (errno == ENOENT) throw FileMissing("Object at location " + path + " not found");      // (object_store's NotFound, word for word: the JVM side cuts the path out of it)
+      throw CometError("cannot open Parquet file " + path + ": " + strerror(errno));
+    }
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); fd = -1; throw CometError("cannot stat " + path); }
     size = (size_t)st.st_size;
@@ -169,6 +176,8 @@ struct OpenFile {
       if (size < 12) throw CometError("not a Parquet file (too short): " + path);
       read_at(head, 4, 0);
       read_at(tail, 8, (int64_t)size - 8);
+      if (memcmp(tail + 4, "PAR1", 4) != 0 || memcmp(head, "PAR1", 4) != 0)      // (the magic before the length, as parquet-rs reads a footer)
+        throw CometError("not a Parquet file (missing PAR1 magic; encrypted footers are not supported): " + path);
       uint32_t mlen;
       memcpy(&mlen, tail, 4);
       if ((size_t)mlen + 12 > size) throw CometError("parquet: bad footer length");
@@ -1499,8 +1508,23 @@ struct Sel {
 // nor uploaded and the scan emits only the kept rows; the Filter above re-checks every row it gets, as it does after row-group pruning.
 void select_row_groups(const Operator& op, bool page_index, std::vector<Sel>& sels, int64_t& total_rows, int64_t& row_groups_pruned, int64_t& rows_pruned_page_index) {
   for (auto& pf : op.files) {
-    auto mf = std::make_shared<OpenFile>(path_from_uri(pf.file_path));
-    auto fm = std::make_shared<pq::FileMeta>(pq::parse_footer(mf->footer.data(), mf->footer.size()));
+    // A file that is missing, or whose footer cannot be read, fails the task the way the reference classifies it
+    // (jni-bridge/src/errors.rs:600-735 try_classify_file_read_error): FileNotFound { message } — Spark's readCurrentFileNotFoundError — or
+    // CannotReadFile { filePath, message } — its FAILED_READ_FILE; a bad magic carries Spark's own "is not a Parquet file" (:720-735)
+    std::shared_ptr<OpenFile> mf;
+    std::shared_ptr<pq::FileMeta> fm;
+    try {
+      mf = std::make_shared<OpenFile>(path_from_uri(pf.file_path));
+      fm = std::make_shared<pq::FileMeta>(pq::parse_footer(mf->footer.data(), mf->footer.size()));
+    } catch (const FileMissing& e) {
+      if (op.reader_api) throw;
+      throw spark_error("FileNotFound", "\"message\":\"" + json_escape(e.what()) + "\"");
+    } catch (const CometError& e) {
+      if (e.kind != 0 || op.reader_api) throw;
+      std::string msg = e.what();
+      if (msg.find("not a Parquet file") != std::string::npos) msg = "Invalid Parquet file. Corrupt footer (file is not a Parquet file): " + msg;
+      throw spark_error("CannotReadFile", "\"filePath\":\"" + json_escape(pf.file_path) + "\",\"message\":\"" + json_escape(msg) + "\"");
+    }
     for (size_t g = 0; g < fm->row_groups.size(); g++) {
       const pq::RowGroup& rg = fm->row_groups[g];
       if (rg.columns.empty()) continue;

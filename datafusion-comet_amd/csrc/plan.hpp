@@ -140,6 +140,7 @@ struct Operator {
   int proto_tag = 0;
   uint32_t plan_id = 0;
   std::vector<std::string> sql_text_pool;      // (root only) the SQL texts QueryContext.sql_text_idx points into
+  bool reader_api = false;                      // NativeScan built by the parquet.Native record-batch reader, not decoded from a plan
   std::vector<OperatorP> children;
   // Scan
   std::vector<DType> scan_fields;

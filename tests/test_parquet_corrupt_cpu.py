@@ -54,6 +54,42 @@ def test_random_corruption_never_crashes(built, tmp_path, codec, region):
         try:
             _touch_everything(bad_path)
             outcomes["ok"] += 1
-        except native.CometNativeException:
+        except (native.CometNativeException, native.CometQueryExecutionException):      # (a footer that cannot be read is Spark's FAILED_READ_FILE: below)
             outcomes["error"] += 1
     assert outcomes["error"] > 0, outcomes
+
+
+def test_missing_and_unreadable_files_are_classified_like_the_reference(built, tmp_path):
+    """jni-bridge/src/errors.rs:600-735 (try_classify_file_read_error, cannot_read_file_message): a file that is not there is FileNotFound { message }
+    with object_store's "Object at location <path> not found" (ShimSparkErrorConverter cuts the path out of it for Spark's
+    readCurrentFileNotFoundError); a footer that cannot be read is CannotReadFile { filePath, message } — Spark's FAILED_READ_FILE — and a
+    bad magic says "is not a Parquet file" as Spark's own reader does"""
+    import json
+    scan = lambda p: S.native_scan([p], ["k"], [S.T_INT64]).encode()
+    import os
+    missing = str(tmp_path / "nope.parquet")
+    open(missing, "wb").write(b"x")          # (the plan records the file's size: it is there when the plan is made and gone when the task runs)
+    plan = scan(missing)
+    os.unlink(missing)
+    with pytest.raises(native.CometQueryExecutionException) as ei:
+        native.parquet_prune_report(plan, False)
+    j = json.loads(str(ei.value))
+    assert j["errorType"] == "FileNotFound" and j["params"] == {"message": f"Object at location {missing} not found"}
+    garbage = str(tmp_path / "garbage.parquet")
+    open(garbage, "wb").write(b"this is not a parquet file at all, just text" * 3)
+    with pytest.raises(native.CometQueryExecutionException) as ei:
+        native.parquet_prune_report(scan(garbage), False)
+    j = json.loads(str(ei.value))
+    assert j["errorType"] == "CannotReadFile" and j["params"]["filePath"].endswith("garbage.parquet") and "is not a Parquet file" in j["params"]["message"]
+    good = _file(tmp_path, "SNAPPY")
+    raw = open(good, "rb").read()
+    cut = str(tmp_path / "cut.parquet")
+    open(cut, "wb").write(raw[: len(raw) - 100])          # the tail with the footer's length and magic is gone
+    with pytest.raises(native.CometQueryExecutionException) as ei:
+        native.parquet_prune_report(scan(cut), False)
+    assert json.loads(str(ei.value))["errorType"] == "CannotReadFile"
+    tiny = str(tmp_path / "tiny.parquet")
+    open(tiny, "wb").write(b"PAR1")
+    with pytest.raises(native.CometQueryExecutionException) as ei:
+        native.parquet_prune_report(scan(tiny), False)
+    assert "is not a Parquet file" in json.loads(str(ei.value))["params"]["message"]
