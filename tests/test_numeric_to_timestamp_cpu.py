@@ -64,3 +64,18 @@ def test_date_to_int_is_the_day_number():
     native.compile_plan(plan.encode())
     t = pa.table({"d": pa.array([0, 19723, None, -5], pa.int32()).cast(pa.date32())})
     assert O.run_plan_to_arrow(S, plan, t).column(0).to_pylist() == [0, 19723, None, -5]
+
+
+def test_the_references_hour_minute_second_vectors():
+    """datetime_funcs/extract_date_part.rs:128-189: 2024-01-15 18:30:45 UTC — a TIMESTAMP shows hour 10 in a Los Angeles session, a TIMESTAMP_NTZ is a
+    wall clock already: hour 18 / minute 30 / second 45 whatever the session zone (issue #3180 of the reference)"""
+    MICROS = 1_705_343_445_000_000
+
+    def part(kind, dtype, arrow_type, tz):
+        plan = S.project(S.scan([dtype]), [S.time_part(kind, S.col(0, dtype), tz)])
+        return O.run_plan_to_arrow(S, plan, pa.table({"t": pa.array([MICROS], arrow_type)})).column(0).to_pylist()[0]
+    assert part("hour", TS, pa.timestamp("us", tz="UTC"), "America/Los_Angeles") == 10
+    for tz in ("UTC", "America/Los_Angeles", "Asia/Tokyo"):
+        assert part("hour", NTZ, pa.timestamp("us"), tz) == 18
+    assert part("minute", NTZ, pa.timestamp("us"), "Asia/Tokyo") == 30 and part("second", NTZ, pa.timestamp("us"), "Asia/Tokyo") == 45
+    assert part("hour", TS, pa.timestamp("us", tz="UTC"), "Asia/Tokyo") == 3          # (18:30 UTC is 03:30 the next day in Tokyo)
