@@ -1,4 +1,4 @@
-"""float / double / decimal → timestamp on the oracle against the reference's own vectors (conversion_funcs/numeric.rs:1753-1860
+"""Casts on the oracle against the reference's own vectors: float / double / decimal → timestamp (conversion_funcs/numeric.rs:1753-1860
 test_cast_decimal_to_timestamp, test_cast_float_to_timestamp) and the rules of :87-135, 1184-1208; tests/test_temporal_casts_gpu.py runs the
 same casts on the GPU against this oracle."""
 import numpy as np
@@ -79,3 +79,27 @@ def test_the_references_hour_minute_second_vectors():
         assert part("hour", NTZ, pa.timestamp("us"), tz) == 18
     assert part("minute", NTZ, pa.timestamp("us"), "Asia/Tokyo") == 30 and part("second", NTZ, pa.timestamp("us"), "Asia/Tokyo") == 45
     assert part("hour", TS, pa.timestamp("us", tz="UTC"), "Asia/Tokyo") == 3          # (18:30 UTC is 03:30 the next day in Tokyo)
+
+
+def test_more_of_the_references_cast_vectors():
+    from decimal import Decimal
+
+    def cast(arr, frm, to, mode=S.LEGACY):
+        plan = S.project(S.scan([frm]), [S.cast(S.col(0, frm), to, mode)])
+        return O.run_plan_to_arrow(S, plan, pa.table({"v": arr})).column(0)
+    # numeric.rs:1243-1263 test_spark_cast_int_to_int_overflow: LEGACY keeps the low bits, ANSI raises
+    assert cast(pa.array([2**63 - 1, -2**63, 100], pa.int64()), S.T_INT64, S.T_INT32).to_pylist() == [-1, 0, 100]
+    with pytest.raises(O.OracleError, match="CAST_OVERFLOW"):
+        cast(pa.array([2**63 - 1], pa.int64()), S.T_INT64, S.T_INT32, S.ANSI)
+    # :1301-1317 int → decimal(10,2); :1319-1360 overflow is NULL in LEGACY and TRY; :1380-1404 an error under ANSI
+    assert cast(pa.array([100, -100, None], pa.int32()), S.T_INT32, S.decimal(10, 2)).to_pylist() == [Decimal("100.00"), Decimal("-100.00"), None]
+    for mode in (S.LEGACY, S.TRY):
+        assert cast(pa.array([9, 1000, None, -9], pa.int32()), S.T_INT32, S.decimal(3, 2), mode).to_pylist() == [Decimal("9.00"), None, None, Decimal("-9.00")]
+    with pytest.raises(O.OracleError, match="NUMERIC_VALUE_OUT_OF_RANGE"):
+        cast(pa.array([9, 1000], pa.int32()), S.T_INT32, S.decimal(3, 2), S.ANSI)
+    # boolean.rs:205-230: true is one microsecond, false the epoch
+    for to in (TS, NTZ):
+        assert cast(pa.array([True, False, None]), S.T_BOOL, to).cast(pa.int64()).to_pylist() == [1, 0, None]
+    # boolean.rs:90-172: true / false as 1 / 0 in every numeric type
+    for to, one in ((S.T_INT8, 1), (S.T_INT16, 1), (S.T_INT32, 1), (S.T_INT64, 1), (S.T_FLOAT, 1.0), (S.T_DOUBLE, 1.0)):
+        assert cast(pa.array([True, False, None]), S.T_BOOL, to).to_pylist() == [one, 0, None]
