@@ -103,3 +103,19 @@ def test_more_of_the_references_cast_vectors():
     # boolean.rs:90-172: true / false as 1 / 0 in every numeric type
     for to, one in ((S.T_INT8, 1), (S.T_INT16, 1), (S.T_INT32, 1), (S.T_INT64, 1), (S.T_FLOAT, 1.0), (S.T_DOUBLE, 1.0)):
         assert cast(pa.array([True, False, None]), S.T_BOOL, to).to_pylist() == [one, 0, None]
+
+
+def test_the_references_integer_round_vectors():
+    """math_funcs/round.rs:381-460 — bigint rounded at positions beyond its nineteen digits: at -19 the halves ±5·10^18 round to ±10^19, which wraps
+    to its low 64 bits in LEGACY (WRAPPED_1E19 = 10^19 as i64) and is an overflow under ANSI; at -20 and below everything is 0 in both modes.
+    (The kernels refuse positions below -18 by name; these pin the oracle.)"""
+    def rnd(vals, scale, **kw):
+        plan = S.project(S.scan([S.T_INT64]), [S.scalar_func("round", [S.col(0, S.T_INT64), S.lit(scale, S.T_INT64)], S.T_INT64, **kw)])
+        return O.run_plan_to_arrow(S, plan, pa.table({"v": pa.array(vals, pa.int64())})).column(0).to_pylist()
+    wrapped = 10**19 - 2**64
+    assert rnd([5 * 10**18, -5 * 10**18, 5 * 10**18 - 1, 0, 2**63 - 1, -2**63], -19) == [wrapped, -wrapped, 0, 0, wrapped, -wrapped]
+    with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW"):
+        rnd([5 * 10**18], -19, fail_on_error=True)
+    for fail in (False, True):
+        assert rnd([2**63 - 1, -2**63, 0, 10**18], -20, fail_on_error=fail) == [0, 0, 0, 0]
+        assert rnd([2**63 - 1, -2**63, 0, 5 * 10**18], -40, fail_on_error=fail) == [0, 0, 0, 0]
