@@ -119,3 +119,21 @@ def test_the_references_integer_round_vectors():
     for fail in (False, True):
         assert rnd([2**63 - 1, -2**63, 0, 10**18], -20, fail_on_error=fail) == [0, 0, 0, 0]
         assert rnd([2**63 - 1, -2**63, 0, 5 * 10**18], -40, fail_on_error=fail) == [0, 0, 0, 0]
+
+
+def test_the_references_ceil_and_floor_vectors():
+    """math_funcs/ceil.rs and floor.rs (their array tests): floats and doubles to bigint, bigints unchanged, decimal(5,2) to decimal(4,0)"""
+    from decimal import Decimal
+
+    def f(name, arr, ty, rt):
+        plan = S.project(S.scan([ty]), [S.scalar_func(name, [S.col(0, ty)], rt)])
+        return O.run_plan_to_arrow(S, plan, pa.table({"v": arr})).column(0).to_pylist()
+    up, down = [125.2345, 15.0001, 0.1, -0.9, -1.1, 123.0], [125.9345, 15.9999, 0.9, -0.1, -1.999, 123.0]
+    for ty, arr in ((S.T_DOUBLE, lambda v: pa.array(v, pa.float64())), (S.T_FLOAT, lambda v: pa.array(np.array(v, np.float32)))):
+        assert f("ceil", arr(up), ty, S.T_INT64) == [126, 16, 1, 0, -1, 123]
+        assert f("floor", arr(down), ty, S.T_INT64) == [125, 15, 0, -1, -2, 123]
+    for name in ("ceil", "floor"):
+        assert f(name, pa.array([-1, 0, 1, None], pa.int64()), S.T_INT64, S.T_INT64) == [-1, 0, 1, None]
+    d = pa.array([Decimal("123.45"), Decimal("125.00"), Decimal("-129.99")], pa.decimal128(5, 2))
+    assert f("ceil", d, S.decimal(5, 2), S.decimal(4, 0)) == [Decimal("124"), Decimal("125"), Decimal("-129")]
+    assert f("floor", d, S.decimal(5, 2), S.decimal(4, 0)) == [Decimal("123"), Decimal("125"), Decimal("-130")]
