@@ -137,3 +137,24 @@ def test_the_references_ceil_and_floor_vectors():
     d = pa.array([Decimal("123.45"), Decimal("125.00"), Decimal("-129.99")], pa.decimal128(5, 2))
     assert f("ceil", d, S.decimal(5, 2), S.decimal(4, 0)) == [Decimal("124"), Decimal("125"), Decimal("-129")]
     assert f("floor", d, S.decimal(5, 2), S.decimal(4, 0)) == [Decimal("123"), Decimal("125"), Decimal("-130")]
+
+
+def test_the_references_checked_arithmetic_vectors():
+    """math_funcs/checked_arithmetic.rs (its six tests): NULLs propagate, an overflow is NULL in TRY mode and an error under ANSI, and a NULL row
+    whose value slot holds garbage does not raise"""
+    I32 = S.T_INT32
+
+    def op(name, l, r, mode):
+        plan = S.project(S.scan([I32, I32]), [S.math(name, S.col(0, I32), S.col(1, I32), I32, mode)])
+        return O.run_plan_to_arrow(S, plan, pa.table({"l": l, "r": r})).column(0).to_pylist()
+    a32 = lambda v: pa.array(v, pa.int32())
+    mx, mn = 2**31 - 1, -2**31
+    assert op("add", a32([1, None, 3, None]), a32([10, 20, None, None]), S.TRY) == [11, None, None, None]
+    assert op("add", a32([mx, 1]), a32([1, 1]), S.TRY) == [None, 2]
+    with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW"):
+        op("add", a32([mx]), a32([1]), S.ANSI)
+    assert op("subtract", a32([mn, 5]), a32([1, 3]), S.TRY) == [None, 2]
+    assert op("multiply", a32([mx, 5]), a32([2, 3]), S.TRY) == [None, 15]
+    # a NULL row with i32::MAX in its value slot: no error under ANSI
+    garbage = pa.Array.from_buffers(pa.int32(), 2, [pa.py_buffer(bytes([0b10])), pa.py_buffer(np.array([mx, 1], np.int32).tobytes())])
+    assert op("add", garbage, a32([1, 1]), S.ANSI) == [None, 2]
