@@ -1,4 +1,4 @@
-"""Casts on the oracle against the reference's own vectors: float / double / decimal → timestamp (conversion_funcs/numeric.rs:1753-1860
+"""The oracle against more of the reference's own unit-test vectors (casts, date parts, round / ceil / floor / abs, checked arithmetic): float / double / decimal → timestamp (conversion_funcs/numeric.rs:1753-1860
 test_cast_decimal_to_timestamp, test_cast_float_to_timestamp) and the rules of :87-135, 1184-1208; tests/test_temporal_casts_gpu.py runs the
 same casts on the GPU against this oracle."""
 import numpy as np
@@ -158,3 +158,17 @@ def test_the_references_checked_arithmetic_vectors():
     # a NULL row with i32::MAX in its value slot: no error under ANSI
     garbage = pa.Array.from_buffers(pa.int32(), 2, [pa.py_buffer(bytes([0b10])), pa.py_buffer(np.array([mx, 1], np.int32).tobytes())])
     assert op("add", garbage, a32([1, 1]), S.ANSI) == [None, 2]
+
+
+def test_the_references_abs_vectors():
+    """math_funcs/abs.rs (its array tests): [-1, MIN, MAX, NULL] → [1, MIN, MAX, NULL] in LEGACY — the minimum wraps onto itself — and an
+    ARITHMETIC_OVERFLOW with fail_on_error"""
+    for ty, arrow, bits in ((S.T_INT8, pa.int8(), 8), (S.T_INT16, pa.int16(), 16), (S.T_INT32, pa.int32(), 32), (S.T_INT64, pa.int64(), 64)):
+        mn, mx = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+        t = pa.table({"v": pa.array([-1, mn, mx, None], arrow)})
+        legacy = S.project(S.scan([ty]), [S.scalar_func("abs", [S.col(0, ty), S.lit(False, S.T_BOOL)], ty)])
+        assert O.run_plan_to_arrow(S, legacy, t).column(0).to_pylist() == [1, mn, mx, None]
+        ansi = S.project(S.scan([ty]), [S.scalar_func("abs", [S.col(0, ty), S.lit(True, S.T_BOOL)], ty)])
+        with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW"):
+            O.run_plan_to_arrow(S, ansi, t)
+        assert O.run_plan_to_arrow(S, ansi, pa.table({"v": pa.array([-1, mx, None], arrow)})).column(0).to_pylist() == [1, mx, None]

@@ -83,7 +83,7 @@ def test_unknown_zones_and_instants_behind_the_tables_end(built):
 
 
 def test_floats_and_decimals_to_timestamps(built):
-    """cast_float_to_timestamp / cast_decimal_to_timestamp (numeric.rs:87-135, 1184-1233; tests/test_reference_cast_vectors_cpu.py pins the oracle on
+    """cast_float_to_timestamp / cast_decimal_to_timestamp (numeric.rs:87-135, 1184-1233; tests/test_reference_vectors_cpu.py pins the oracle on
     the reference's vectors): seconds → microseconds, NaN / ±Infinity / beyond a bigint → NULL (ANSI: the reference's two errors), decimals
     truncated toward zero and wrapped to 64 bits"""
     import json
