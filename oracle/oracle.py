@@ -331,6 +331,25 @@ class Evaluator:
                 anynull |= ~li.ok()
             ok = v.ok() & (hit | ~anynull)
             return Col(S.T_BOOL, ~hit if e.negated else hit, None if ok.all() else ok)
+        if k == "unary_minus":
+            # NegativeExpr (math_funcs/negative.rs:100-160): integers wrap in LEGACY (the minimum negates onto itself) and raise ARITHMETIC_OVERFLOW
+            # with fail_on_error — only for VALID rows —, floats and decimals change sign
+            a = self.eval(e.children[0], cols, n)
+            tid = a.dtype.type_id
+            if tid in (S.INT8, S.INT16, S.INT32, S.INT64):
+                bits = {S.INT8: 8, S.INT16: 16, S.INT32: 32, S.INT64: 64}[tid]
+                lo = -(1 << (bits - 1))
+                x = a.values.astype(np.int64)
+                if e.fail_on_error and ((x == lo) & a.ok()).any():
+                    raise OracleError("ARITHMETIC_OVERFLOW")
+                with np.errstate(over="ignore"):
+                    r = np.where(x == lo, lo, -x)
+                return Col(a.dtype, r.astype(_np_dtype(S, a.dtype)), a.valid)
+            if tid in (S.FLOAT, S.DOUBLE):
+                return Col(a.dtype, -a.values, a.valid)
+            if tid == S.DECIMAL:
+                return Col(a.dtype, ints_to_dec([-dec_to_int(a.values, i) for i in range(n)]), a.valid)
+            raise NotImplementedError(f"oracle: unary minus over {a.dtype}")
         raise NotImplementedError(f"oracle: expression {k}")
 
     def _scalar_func(self, e, cols, n) -> Col:

@@ -172,3 +172,25 @@ def test_the_references_abs_vectors():
         with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW"):
             O.run_plan_to_arrow(S, ansi, t)
         assert O.run_plan_to_arrow(S, ansi, pa.table({"v": pa.array([-1, mx, None], arrow)})).column(0).to_pylist() == [1, mx, None]
+
+
+def test_the_references_date_diff_and_negative_vectors():
+    """datetime_funcs/date_diff.rs (basic, and the i32 wrap of extreme inputs); math_funcs/negative.rs: LEGACY wraps the minimum onto itself, ANSI
+    raises, and a minimum sitting in a NULL slot does not"""
+    D = S.T_DATE
+
+    def diff(end, start):
+        plan = S.project(S.scan([D, D]), [S.scalar_func("date_diff", [S.col(0, D), S.col(1, D)], S.T_INT32)])
+        t = pa.table({"e": pa.array([end], pa.int32()).cast(pa.date32()), "s": pa.array([start], pa.int32()).cast(pa.date32())})
+        return O.run_plan_to_arrow(S, plan, t).column(0).to_pylist()[0]
+    mx, mn = 2**31 - 1, -2**31
+    assert diff(18263, 18262) == 1 and diff(18262, 18263) == -1
+    assert diff(mx, mn) == -1 and diff(mn, mx) == 1          # i32::MAX.wrapping_sub(i32::MIN), i32::MIN.wrapping_sub(i32::MAX)
+    for ty, arrow, bits in ((S.T_INT8, pa.int8(), 8), (S.T_INT16, pa.int16(), 16), (S.T_INT32, pa.int32(), 32), (S.T_INT64, pa.int64(), 64)):
+        lo = -(1 << (bits - 1))
+        neg = lambda fail: S.project(S.scan([ty]), [S.Expr("unary_minus", [S.col(0, ty)], fail_on_error=fail)])
+        assert O.run_plan_to_arrow(S, neg(False), pa.table({"v": pa.array([lo, 7, None], arrow)})).column(0).to_pylist() == [lo, -7, None]
+        with pytest.raises(O.OracleError, match="ARITHMETIC_OVERFLOW"):
+            O.run_plan_to_arrow(S, neg(True), pa.table({"v": pa.array([lo], arrow)}))
+        hidden = pa.Array.from_buffers(arrow, 2, [pa.py_buffer(bytes([0b10])), pa.py_buffer(np.array([lo, 7]).astype(arrow.to_pandas_dtype()).tobytes())])
+        assert O.run_plan_to_arrow(S, neg(True), pa.table({"v": hidden})).column(0).to_pylist() == [None, -7]
