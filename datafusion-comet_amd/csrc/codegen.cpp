@@ -2039,7 +2039,9 @@ struct Gen {
         Val a = gen(e.children.at(0));
         Val r = a;
         switch (a.rep) {
-          case Rep::I32: r.v = "(i32)(0u - (u32)" + a.v + ")"; break;
+          case Rep::I32:      // (a tinyint / smallint lives in 32 bits: its minimum negates onto itself like Rust's wrapping_neg of the narrow type)
+            r.v = a.t.id == TypeId::Int8 ? "(i32)(i8)(0u - (u32)" + a.v + ")" : a.t.id == TypeId::Int16 ? "(i32)(i16)(0u - (u32)" + a.v + ")" : "(i32)(0u - (u32)" + a.v + ")";
+            break;
           case Rep::I64: r.v = "(i64)(0ull - (u64)" + a.v + ")"; break;
           case Rep::I128: r.v = "(i128)((u128)0 - (u128)" + a.v + ")"; break;
           case Rep::F32: case Rep::F64: r.v = "(-" + a.v + ")"; break;
