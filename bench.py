@@ -8,8 +8,10 @@ every rank owns SF100 rows (weak scaling), rank 0 prints ONE JSON line.
 
   value                  whole-job rows/s at task level (createPlan..releasePlan, every launch of the task included) over the table as any
                          Arrow producer hands it over — no comet:utf8_fixed_len declaration; the declared variant is a sub-object of roofline
-  roofline               the dominant kernel k_gagg: SURVEY §8(d)'s algorithmic 78 B/row × the rows one launch processes ÷ the kernel's
-                         average duration, measured with HIP events on the plan's stream inside libcomet (comet_plan_kernel_stats);
+  roofline               SURVEY §8(d)'s algorithmic 78 B/row × the rows one task processes ÷ the time of EVERY kernel that reads those bytes:
+                         the dominant kernel k_gagg (70 B/row) + the task's utf8_uniform_kernel launches (the 2 × 4 B/row of Utf8 offsets),
+                         measured with HIP events on the plan's stream inside libcomet (comet_plan_kernel_stats / _aux_kernel_stats);
+                         `kernels` lists each with its own ms, algorithmic bytes and PMC traffic;
                          `traffic` = HBM bytes per launch measured IN THIS RUN by two rocprofv3 passes (--pmc FETCH_SIZE / WRITE_SIZE)
                          over tools/resident.py at the same row count (null when rocprofv3 is unavailable or --no-pmc)
   cpu_baseline           the oracle's operator-at-a-time C restatement of the reference's Q1 pipeline (oracle/comet_oracle.c
@@ -114,7 +116,7 @@ def main():
             if b is None:
                 break
             out.append(b)
-        stats = it.kernel_stats()
+        stats = it.kernel_stats() + it.aux_kernel_stats()      # (k_gagg ms, launches, rows, utf8_uniform_kernel ms, launches)
         it.close()
         return out, stats
 
@@ -128,11 +130,13 @@ def main():
         result, _ = step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, launches = 0.0, 0
+    kernel_ms, launches, aux_ms, aux_launches = 0.0, 0, 0.0, 0
     for _ in range(args.steps):
         result, st = step()
         kernel_ms += st[0]
         launches += st[1]
+        aux_ms += st[3]
+        aux_launches += st[4]
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -234,13 +238,32 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         rows_per_s = n * world * args.steps / elapsed
         avg_kernel_ms = kernel_ms / max(launches, 1)
-        algo_bytes = n * tpch.Q1_BYTES_PER_ROW            # per launch: one k_gagg launch processes the rank's n rows
-        achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        # Every byte is charged to the kernel that reads it.  SURVEY §8(d)'s 78 B/row = 4 (l_shipdate) + 4·16 (decimals) + 2·(4 + 1) (two
+        # Utf8 keys: offsets + the byte): k_gagg reads 70 of them — with both keys verified one byte long it addresses the bytes directly and
+        # never loads an offset — and the task's utf8_uniform_kernel launches (one per key column) read the other 2·4.  `frac` is the 78 B/row
+        # over ALL of those launches (the HIP-event time of k_gagg + of the verification launches, per task).
+        aux_ms_per_task = aux_ms / max(args.steps, 1)
+        aux_per_task = aux_launches / max(args.steps, 1)
+        gagg_bytes = n * (tpch.Q1_BYTES_PER_ROW - 8)
+        aux_bytes = n * 8
+        algo_bytes = n * tpch.Q1_BYTES_PER_ROW            # per task: one k_gagg launch + one utf8_uniform_kernel launch per key column over the rank's n rows
+        kernels_ms = avg_kernel_ms + aux_ms_per_task
+        achieved = algo_bytes / (kernels_ms * 1e-3) / 1e9
         pmc = legs.get("pmc") or {}
-        traffic = (pmc.get("k_gagg") or {}).get("traffic_bytes_per_launch")
+        traffic_gagg = (pmc.get("k_gagg") or {}).get("traffic_bytes_per_launch")
+        traffic_aux = (pmc.get("utf8_uniform_kernel") or {}).get("traffic_bytes_per_launch")
+        traffic = (traffic_gagg + traffic_aux * aux_per_task) if (traffic_gagg and traffic_aux is not None) else traffic_gagg
+        kernels = [{"name": "k_gagg", "ms": avg_kernel_ms, "launches_per_task": launches / max(args.steps, 1), "algorithmic_bytes": gagg_bytes,
+                    "algorithmic_GBps": gagg_bytes / (avg_kernel_ms * 1e-3) / 1e9, "frac": gagg_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": traffic_gagg},
+                   {"name": "utf8_uniform_kernel", "ms": aux_ms_per_task, "launches_per_task": aux_per_task, "algorithmic_bytes": aux_bytes,
+                    "algorithmic_GBps": (aux_bytes / (aux_ms_per_task * 1e-3) / 1e9) if aux_ms_per_task else None,
+                    "frac": (aux_bytes / (aux_ms_per_task * 1e-3) / 1e9 / HBM_PEAK_GBS) if aux_ms_per_task else None,
+                    "traffic": (traffic_aux * aux_per_task) if traffic_aux is not None else None,
+                    "note": "ms = one HIP-event pair around the task's verification launches (they run back to back on the plan's stream)"}]
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "k_gagg", "kernel_ms": avg_kernel_ms, "launches_timed": launches,
-                "algorithmic_bytes": algo_bytes,
+                "traffic": traffic, "kernel": "k_gagg + utf8_uniform_kernel (every kernel that reads the 78 B/row)", "kernel_ms": kernels_ms,
+                "launches_timed": launches, "algorithmic_bytes": algo_bytes, "kernels": kernels,
                 "task_level": {"ms": ms_per_step, "algorithmic_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9,
                                "frac": algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "utf8_fixed_len_metadata": False,
@@ -253,7 +276,7 @@ def main():
                 "note": "same tasks over the same shard whose owner declares comet:utf8_fixed_len=1 on the two key columns (Arrow field metadata; "
                         "verified by utf8_uniform_kernel once per buffer, verdict cached): not `value`, no reference producer emits the key"}
         if traffic:
-            roof["physical"] = {"GBps": traffic / (avg_kernel_ms * 1e-3) / 1e9, "frac": traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            roof["physical"] = {"GBps": traffic / (kernels_ms * 1e-3) / 1e9, "frac": traffic / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "bytes_per_row": traffic / n, "note": pmc.get("note")}
         line = {
             "metric": "rows/sec, TPC-H SF100 Q1 scan->filter->agg (HBM-resident Arrow columns)",
@@ -433,13 +456,13 @@ def measure_traffic(args, local_rank, rows, queries):
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
                     name = r["Kernel_Name"].split("(")[0]
-                    if name in ("k_gagg", "k_agg") and r["Counter_Name"] == counter:
+                    if name in ("k_gagg", "k_agg", "utf8_uniform_kernel") and r["Counter_Name"] == counter:
                         raw.setdefault((name, counter), []).append(float(r["Counter_Value"]))
         except subprocess.TimeoutExpired:
             return {"error": f"rocprofv3 {counter} pass timed out"}
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    for name in ("k_gagg", "k_agg"):
+    for name in ("k_gagg", "k_agg", "utf8_uniform_kernel"):
         f, w = raw.get((name, "FETCH_SIZE")), raw.get((name, "WRITE_SIZE"))
         if not f or not w:
             continue

@@ -365,6 +365,13 @@ void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launche
   if (input_rows) *input_rows = ctx->input_rows;
 }
 
+void comet_plan_aux_kernel_stats(int64_t handle, double* aux_ms, int64_t* aux_launches) {
+  auto ctx = lookup(handle);
+  if (!ctx) return;
+  if (aux_ms) *aux_ms = ctx->last_aux_ms;
+  if (aux_launches) *aux_launches = ctx->last_aux_launches;
+}
+
 int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     OperatorP op = decode_operator(plan, plan_len);

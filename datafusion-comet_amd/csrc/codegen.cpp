@@ -58,7 +58,8 @@ thread_local std::vector<std::pair<uint32_t, std::shared_ptr<QueryContext>>>* g_
 thread_local std::map<std::string, int>* g_site_ordinals = nullptr;
 struct SiteScope {
   std::map<std::string, int> ordinals;
-  explicit SiteScope(PipelineDesc& d) { g_site_sink = &d.site_contexts; g_site_ordinals = &ordinals; }
+  // (the optional-header flags start clean: a generation that threw after setting one must not make the next, unrelated kernel include the tables)
+  explicit SiteScope(PipelineDesc& d) { g_site_sink = &d.site_contexts; g_site_ordinals = &ordinals; g_uses_ryu = g_uses_strtod = g_uses_strts = false; }
   ~SiteScope() { g_site_sink = nullptr; g_site_ordinals = nullptr; }
 };
 std::string with_optional_headers(std::string src) {
@@ -538,7 +539,7 @@ struct Gen {
       ord = (*g_site_ordinals)[c]++;
     }
     const uint32_t id = register_err_site(site, ord);
-    if (auto c = current_context()) if (g_site_sink) g_site_sink->emplace_back(id, c);
+    if (g_site_sink) g_site_sink->emplace_back(id, current_context());      // (a site without a context is listed too: it must not inherit another pipeline's)
     return id;
   }
   // … and leave the offending value for the error's JSON (err_sites.cpp): a number's bits, or a string's bytes
@@ -940,7 +941,9 @@ struct Gen {
       }
       if (from.id == TypeId::Date && (to_ts || to_ntz)) {
         c = named(c);
-        const std::string local = "((i64)" + c.v + " * 86400000000ll)";
+        // (unsigned product: defined for every Date32 — beyond ±106 751 991 days the reference's `d as i64 * 86_400 * 1_000_000` wraps in a release
+        // build, temporal.rs:50, and its zoned arm panics inside chrono; no kernel may hold signed-overflow UB either way)
+        const std::string local = "((i64)((u64)(i64)" + c.v + " * 86400000000ull))";
         r.v = to_ts ? utc_of(e.func, local, c.ok) : local;
         r.maxabs = type_maxabs(to);
         return r;

@@ -18,6 +18,7 @@ namespace {
 
 std::mutex g_mu;
 std::map<uint32_t, ErrSite> g_sites;
+std::map<uint32_t, std::string> g_site_canon;      // id → canonical text + ordinal of the site that owns it
 
 std::string canon(const ErrSite& s) {
   return s.error_type + "|" + s.error_class + "|" + s.from_type + "|" + s.to_type + "|" + std::to_string(s.precision) + "|" + std::to_string(s.scale) + "|" +
@@ -97,8 +98,14 @@ uint32_t register_err_site(const ErrSite& s, int ordinal) {
   for (unsigned char ch : c) { h ^= ch; h *= 16777619u; }
   h &= 0x7fffffffu;
   std::lock_guard<std::mutex> lk(g_mu);
-  g_sites.emplace(h, s);
-  return h;
+  // two different sites that hash alike must not share an id (the second would be reported with the first one's class, types and value
+  // kind): the later one probes to the next free id.  The id goes into the kernel text, so the text — and with it the code-object cache
+  // key — follows whatever id was handed out; nothing else depends on it.
+  for (;; h = (h + 1) & 0x7fffffffu) {
+    auto it = g_sites.find(h);
+    if (it == g_sites.end()) { g_sites.emplace(h, s); g_site_canon.emplace(h, c); return h; }
+    if (g_site_canon[h] == c) return h;
+  }
 }
 
 bool lookup_err_site(uint32_t id, ErrSite& out) {

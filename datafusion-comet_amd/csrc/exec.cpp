@@ -722,6 +722,7 @@ ExecutionContext::~ExecutionContext() {
   if (stream_) {
     (void)hipStreamSynchronize(stream_);  // pooled buffers go back only once the stream is idle
     for (auto& pr : timed_) { pool_put_event(device_id_, pr.first); pool_put_event(device_id_, pr.second); }
+    for (hipEvent_t& e : aux_ev_) if (e) { pool_put_event(device_id_, e); e = nullptr; }
     pool_put_stream(device_id_, stream_);
   }
 }

@@ -162,6 +162,10 @@ class ExecutionContext {
   // timing of the last run (for bench.py): device time of the main kernels measured with HIP events
   double last_kernel_ms = 0;
   int64_t last_kernel_launches = 0;
+  // input-verification launches ahead of the main kernels (utf8_uniform_kernel over a device input's Utf8 offsets): timed apart, so a
+  // roofline can charge a column's bytes to the kernel that reads them
+  double last_aux_ms = 0;
+  int64_t last_aux_launches = 0;
   int64_t input_rows = 0;
 
  private:
@@ -212,10 +216,31 @@ class ExecutionContext {
   void check_device_errors();
   void raise_device_errors(uint32_t flags);
   // the QueryContexts of a pipeline's raise sites (PipelineDesc::site_contexts), kept for the errors this context's kernels may raise
+  // A site's id is its content + its ordinal INSIDE its pipeline (the kernel text stays independent of the plan around it), so two pipelines of
+  // one plan can hold sites with the same id and different SQL fragments.  Errors are checked after each pipeline's launches: the
+  // pipeline noted last answers first; an id that two pipelines disagree on and that the last one does not hold reports no fragment at all
+  // rather than the wrong one.
   void note_sites(const PipelineDesc& d) {
-    for (auto& kv : d.site_contexts) site_ctx_[kv.first] = kv.second;
+    site_ctx_last_.clear();
+    for (auto& kv : d.site_contexts) {
+      site_ctx_last_[kv.first] = kv.second;
+      auto it = site_ctx_.find(kv.first);
+      if (it == site_ctx_.end()) site_ctx_[kv.first] = kv.second;
+      else if (it->second != kv.second && !(it->second && kv.second && it->second->sql_text == kv.second->sql_text && it->second->start_index == kv.second->start_index &&
+                                            it->second->stop_index == kv.second->stop_index))
+        site_ctx_ambiguous_.insert(kv.first);
+    }
     for (int k = 0; k < 2; k++) if (d.agg_ctx[k]) agg_ctx_[k] = d.agg_ctx[k];
   }
+  const QueryContext* site_context(uint32_t id) const {
+    auto a = site_ctx_last_.find(id);
+    if (a != site_ctx_last_.end()) return a->second.get();
+    if (site_ctx_ambiguous_.count(id)) return nullptr;
+    auto b = site_ctx_.find(id);
+    return b == site_ctx_.end() ? nullptr : b->second.get();
+  }
+  std::map<uint32_t, std::shared_ptr<QueryContext>> site_ctx_last_;
+  std::set<uint32_t> site_ctx_ambiguous_;
   std::shared_ptr<QueryContext> agg_ctx_[2];      // … and of its ANSI decimal sum / average (PipelineDesc::agg_ctx)
   std::map<uint32_t, std::shared_ptr<QueryContext>> site_ctx_;
   void read_small(void* dst, const void* dev_src, size_t n);
@@ -235,6 +260,8 @@ class ExecutionContext {
   hipStream_t stream_ = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_;   // (start, stop) around each main-kernel launch
   size_t timed_done_ = 0;
+  hipEvent_t aux_ev_[2] = {nullptr, nullptr};              // (start, stop) around pull_device_table's verification launches; aux_n_ of them
+  int aux_n_ = 0;
   bool started_ = false, finished_ = false;
   std::vector<DType> in_types_;
   std::map<std::string, Variant> variants_;

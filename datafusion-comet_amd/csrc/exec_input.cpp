@@ -559,6 +559,9 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
     uint32_t* flags = (uint32_t*)err_flags_.p + (kErrBytes / 4 - 16);   // last 16 words of the error/aux block: scratch
     HIP_CHECK(hipMemsetAsync(flags, 0, 64, stream_));
     bool any = false;
+    if (!aux_ev_[0]) { aux_ev_[0] = pool_get_event(device_id_); aux_ev_[1] = pool_get_event(device_id_); }
+    HIP_CHECK(hipEventRecord(aux_ev_[0], stream_));
+    int aux_launched = 0;
     for (size_t k = 0; k < scols.size(); k++) {
       first[k] = ends[2 * k];
       const int64_t total = (int64_t)ends[2 * k + 1] - ends[2 * k];
@@ -578,6 +581,7 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
           continue;
         }
         if (comet_launch_utf8_uniform(off, rows, hint, flags + k, stream_) != 0) continue;
+        aux_launched++;
         len[k] = hint;
         declared[k] = true;
         any = true;
@@ -585,12 +589,16 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
       }
       if (total % rows != 0 || total / rows > 15 || total < 0) continue;
       if (comet_launch_utf8_uniform(off, rows, (int32_t)(total / rows), flags + k, stream_) != 0) continue;
+      aux_launched++;
       len[k] = (int32_t)(total / rows);
       any = true;
     }
     if (any) {
+      HIP_CHECK(hipEventRecord(aux_ev_[1], stream_));
       uint32_t f[16];
-      read_small(f, flags, 64);
+      read_small(f, flags, 64);      // (synchronises the stream: the event pair is complete)
+      float aux = 0;
+      if (hipEventElapsedTime(&aux, aux_ev_[0], aux_ev_[1]) == hipSuccess) { last_aux_ms += aux; last_aux_launches += aux_launched; }
       HIP_CHECK(hipMemsetAsync(flags, 0, 64, stream_));
       for (size_t k = 0; k < scols.size(); k++) {
         if (len[k] < 0) continue;

@@ -304,8 +304,8 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
     if (detail[0] != 0 && lookup_err_site((uint32_t)(detail[0] - 1), site)) {
       // (the flag that is raised and the site that won the detail words can differ when two kinds of error meet in one launch: the site's own
       // error is reported — it did occur)
-      auto cx = site_ctx_.find((uint32_t)(detail[0] - 1));      // the SQL fragment of the expression, when the plan carried one
-      throw CometError(err_site_json(site, detail[1], detail[2], (const uint8_t*)(detail + 4), (size_t)kErrDetailStrBytes, cx == site_ctx_.end() ? nullptr : cx->second.get()), 1);
+      // the SQL fragment of the expression, when the plan carried one
+      throw CometError(err_site_json(site, detail[1], detail[2], (const uint8_t*)(detail + 4), (size_t)kErrDetailStrBytes, site_context((uint32_t)(detail[0] - 1))), 1);
     }
   }
   if (f & 1u) throw CometError("{\"errorType\":\"ArithmeticOverflow\",\"errorClass\":\"ARITHMETIC_OVERFLOW\",\"params\":{\"fromType\":\"decimal\"}}", 1);

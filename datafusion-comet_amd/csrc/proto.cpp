@@ -721,7 +721,9 @@ OperatorP decode_operator(const uint8_t* data, size_t len) {
   } scope{g_decoded_contexts, g_decoded_contexts};
   g_decoded_contexts = &contexts;
   OperatorP root = decode_operator_r(Reader(data, len));
-  // QueryContext.sql_text_idx → the root's pool (a query text shared by many expressions travels once per plan, expr.proto:137-141)
+  // QueryContext.sql_text_idx → the root's pool (a query text shared by many expressions travels once per plan, expr.proto:137-141).  An index
+  // outside the pool keeps the context's own sql_text, as the reference does ("warn rather than fail: a degraded error message is better
+  // than a failed query", planner.rs:329-343).
   for (auto& c : contexts)
     if (c->sql_text_idx >= 0 && (size_t)c->sql_text_idx < root->sql_text_pool.size()) c->sql_text = root->sql_text_pool[(size_t)c->sql_text_idx];
   return root;

@@ -59,6 +59,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_explain.argtypes = [c.c_int64]
     lib.comet_plan_kernel_stats.restype = None
     lib.comet_plan_kernel_stats.argtypes = [c.c_int64, c.POINTER(c.c_double), c.POINTER(c.c_int64), c.POINTER(c.c_int64)]
+    lib.comet_plan_aux_kernel_stats.restype = None
+    lib.comet_plan_aux_kernel_stats.argtypes = [c.c_int64, c.POINTER(c.c_double), c.POINTER(c.c_int64)]
     lib.comet_compile_plan.restype = c.c_int32
     lib.comet_compile_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_char_p, c.c_size_t]
     lib.comet_check_plan.restype = c.c_int32
@@ -733,6 +735,12 @@ class CometExecIterator:
         ms, launches, rows = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
         lib().comet_plan_kernel_stats(self.handle, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows))
         return ms.value, launches.value, rows.value
+
+    def aux_kernel_stats(self):
+        """(ms, launches) of the input-verification kernels (utf8_uniform_kernel) this plan ran ahead of its main kernels"""
+        ms, launches = ctypes.c_double(), ctypes.c_int64()
+        lib().comet_plan_aux_kernel_stats(self.handle, ctypes.byref(ms), ctypes.byref(launches))
+        return ms.value, launches.value
 
     def metrics(self) -> bytes:
         n = lib().comet_plan_metrics(self.handle, None, 0)

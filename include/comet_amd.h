@@ -95,6 +95,11 @@ const char* comet_explain(int64_t handle);
  * stream: total milliseconds, number of timed launches, input rows.  Used by bench.py's roofline. */
 void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launches, int64_t* input_rows);
 
+/* … and of the input-verification launches that run ahead of them (utf8_uniform_kernel over the Utf8 offsets of an HBM-resident input,
+ * the check behind addressing fixed-length strings directly): total milliseconds and launches, timed apart from the main kernels so that
+ * bench.py's roofline charges every column's bytes to the kernel that reads them. */
+void comet_plan_aux_kernel_stats(int64_t handle, double* aux_ms, int64_t* aux_launches);
+
 /* Decode + plan + generate + compile (hiprtc, gfx950) without touching a GPU.  Returns 0 on success and
  * writes a description into out (NUL terminated, truncated to cap), -2 on error (comet_last_error(0)). */
 int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size_t cap);

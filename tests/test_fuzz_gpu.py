@@ -43,7 +43,9 @@ class Gen:
     def int32(self, d):
         if d == 0 or self.rng.random() < 0.3:
             return self.pick([S.col(0, I32), S.col(8, I32), S.lit(int(self.rng.integers(-1000, 1000)), I32)])
-        k = self.pick(["add", "subtract", "multiply", "if", "case"])
+        k = self.pick(["add", "subtract", "multiply", "if", "case", "neg"])
+        if k == "neg":      # NegativeExpr, LEGACY wrap (math_funcs/negative.rs:100-160)
+            return S.Expr("unary_minus", [self.int32(d - 1)])
         if k == "if":
             return S.if_(self.boolean(d - 1), self.int32(d - 1), self.int32(d - 1))
         if k == "case":
@@ -54,7 +56,9 @@ class Gen:
     def int64(self, d):
         if d == 0 or self.rng.random() < 0.3:
             return self.pick([S.col(1, I64), S.lit(int(self.rng.integers(-10**12, 10**12)), I64), S.cast(S.col(0, I32), I64)])
-        k = self.pick(["add", "subtract", "multiply", "if"])
+        k = self.pick(["add", "subtract", "multiply", "if", "neg"])
+        if k == "neg":
+            return S.Expr("unary_minus", [self.int64(d - 1)])
         if k == "if":
             return S.if_(self.boolean(d - 1), self.int64(d - 1), self.int64(d - 1))
         return S.math(k, self.int64(d - 1), self.int64(d - 1), I64)
@@ -62,7 +66,9 @@ class Gen:
     def f64(self, d):
         if d == 0 or self.rng.random() < 0.3:
             return self.pick([S.col(4, F64), S.col(5, F64), S.lit(float(self.rng.integers(-50, 50)) / 4, F64)])
-        k = self.pick(["add", "subtract", "multiply", "divide", "if"])
+        k = self.pick(["add", "subtract", "multiply", "divide", "if", "neg"])
+        if k == "neg":
+            return S.Expr("unary_minus", [self.f64(d - 1)])
         if k == "if":
             return S.if_(self.boolean(d - 1), self.f64(d - 1), self.f64(d - 1))
         return S.math(k, self.f64(d - 1), self.f64(d - 1), F64)
@@ -72,6 +78,9 @@ class Gen:
         if d == 0 or self.rng.random() < 0.35:
             c = self.pick([(S.col(2, D), 12, 2), (S.col(3, D), 12, 2), (S.lit(int(self.rng.integers(-99999, 99999)), D), 12, 2)])
             return c
+        if self.rng.random() < 0.15:
+            a, p1, s1 = self.dec(d - 1)
+            return S.Expr("unary_minus", [a]), p1, s1
         (a, p1, s1), (b, p2, s2) = self.dec(d - 1), self.dec(d - 1)
         k = self.pick(["add", "subtract", "multiply"])
         if k == "multiply":

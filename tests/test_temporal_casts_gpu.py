@@ -123,3 +123,29 @@ def test_floats_and_decimals_to_timestamps(built):
             native.execute_to_table([native.HostInput.from_table(tb)], 1, S.project(S.scan([S.T_DOUBLE]), [S.cast(S.col(0, S.T_DOUBLE), TS, S.ANSI)]).encode(), batch_size=0)
         j = json.loads(str(ei.value))
         assert j["errorType"] == etype and j["params"] == params, j
+
+
+def test_cast_date_as_int(built):
+    """cast.rs:273-277 `(Date32, Int32)`: the days since the epoch, reinterpreted — every mode, NULLs kept, extremes of the type included; and as an
+    operand of later arithmetic and of a filter (the value must be the day number there too)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    n = 50_001
+    days = rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64, endpoint=True).astype(np.int32)
+    days[:7] = [0, -1, 1, 19723, -719162, 2**31 - 1, -2**31]
+    mask = rng.random(n) < 0.1
+    mask[:7] = False
+    t = pa.table({"d": pa.array(days, pa.int32(), mask=mask).cast(pa.date32())})
+    d = S.col(0, D)
+    outs = [S.cast(d, S.T_INT32, mode) for mode in (S.LEGACY, S.TRY, S.ANSI)]
+    outs.append(S.math("add", S.cast(S.cast(d, S.T_INT32), I64), S.lit(1, I64), I64))
+    plan = S.project(S.scan([D]), outs)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], len(outs), plan.encode(), batch_size=0))
+    want = O.run_plan_to_arrow(S, plan, t)
+    for k in range(len(outs)):
+        assert got.column(k).combine_chunks().equals(want.column(k).combine_chunks()), k
+    assert got.column(0).to_pylist()[:7] == [0, -1, 1, 19723, -719162, 2**31 - 1, -2**31]
+    fplan = S.project(S.filter_(S.scan([D]), S.gt(S.cast(d, S.T_INT32), S.lit(19000, S.T_INT32))), [S.cast(d, S.T_INT32)])
+    g2 = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t)], 1, fplan.encode(), batch_size=0))
+    w2 = O.run_plan_to_arrow(S, fplan, t)
+    assert g2.num_rows == w2.num_rows > 0 and g2.column(0).combine_chunks().equals(w2.column(0).combine_chunks())
