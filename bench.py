@@ -228,11 +228,20 @@ def main():
             legs["exchange_probe"] = probe
         fb = ["--allow-fallback"] if exchange != "native" else []      # (the child still reports its transport; THIS process turns it into the exit code)
         if args.q3_orders > 0:
-            legs["q3"] = run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1", "--exchange", exchange] + fb,
+            legs["q3"] = run_child_leg([os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "3", "--warmup", "1", "--kernel-times", "--exchange", exchange] + fb,
                                        rank, local_rank, world, args.leg_timeout, 1017)
         if args.q95_orders > 0:
-            legs["q95"] = run_child_leg([os.path.join(ROOT, "tools", "q95_dist.py"), "--orders", str(args.q95_orders), "--steps", "2", "--warmup", "1", "--verify", "torch", "--exchange", exchange] + fb,
+            legs["q95"] = run_child_leg([os.path.join(ROOT, "tools", "q95_dist.py"), "--orders", str(args.q95_orders), "--steps", "2", "--warmup", "1", "--kernel-times", "--verify", "torch", "--exchange", exchange] + fb,
                                         rank, local_rank, world, args.leg_timeout, 1517)
+
+        # HBM traffic of the two join legs on one GPU (PMC passes over the same tools, one counted run each)
+        if world == 1 and rank == 0 and not args.no_pmc:
+            if legs.get("q3") is not None and "roofline" in legs["q3"]:
+                attach_leg_traffic(legs["q3"], measure_leg_traffic(args, local_rank, [os.path.join(ROOT, "tools", "q3_dist.py"), "--orders", str(args.q3_orders), "--steps", "1",
+                                                                                      "--warmup", "1", "--no-verify"], 2))
+            if legs.get("q95") is not None and "roofline" in legs["q95"]:
+                attach_leg_traffic(legs["q95"], measure_leg_traffic(args, local_rank, [os.path.join(ROOT, "tools", "q95_dist.py"), "--orders", str(args.q95_orders), "--steps", "1",
+                                                                                       "--warmup", "1", "--no-verify"], 2))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -424,6 +433,66 @@ def cpu_baseline(args, dtab, plan_bytes, local_rank):
                             "sample": f"first {m} rows, one contiguous {per}-row slice per thread x {reps} passes ({len(slices)} threads = the cgroup CPU quota), {dtn:.2f} s",
                             "groups": sorted("".join(k) for k in set().union(*[set(p) for p in parts]))},
             "gpu_states_equal_cpu_states_on_the_one_thread_sample": bool(same)}
+
+
+def measure_leg_traffic(args, local_rank, tool_cmd, runs):
+    """HBM bytes per RUN of every generated kernel (k_*) of a leg's tool: the same two rocprofv3 passes as measure_traffic over `tool_cmd`, which
+    executes the query `runs` times; per kernel name the launches of all runs are summed and divided by `runs` (a probe kernel is launched
+    once per join, with different sizes).  FETCH_SIZE doubled as for the headline."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return {"error": "rocprofv3 not found"}
+    raw = {}
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    env["LOCAL_RANK"] = str(local_rank)
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="comet_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable] + tool_cmd
+        try:
+            p = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.leg_timeout)
+            if p.returncode != 0:
+                return {"error": f"rocprofv3 {counter} pass exit code {p.returncode}", "log_tail": p.stdout[-400:]}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"].split("(")[0]
+                    if name.startswith("k_") and r["Counter_Name"] == counter:
+                        e = raw.setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
+                        e[counter] += float(r["Counter_Value"])
+                        if counter == "FETCH_SIZE":
+                            e["launches"] += 1
+        except subprocess.TimeoutExpired:
+            return {"error": f"rocprofv3 {counter} pass timed out"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    res = {}
+    for name, e in raw.items():
+        fetch, write = 2.0 * 1024.0 * e["FETCH_SIZE"] / runs, 1024.0 * e["WRITE_SIZE"] / runs
+        res[name] = {"traffic_bytes_per_run": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "launches_per_run": e["launches"] / runs}
+    return res
+
+
+def attach_leg_traffic(leg, pmc):
+    """per-kernel PMC traffic into a leg's roofline.kernels, their sum over ALL of the query's generated kernels into roofline.traffic"""
+    if not leg or "roofline" not in leg or not pmc or "error" in pmc:
+        if leg and "roofline" in leg and pmc and "error" in pmc:
+            leg["roofline"]["traffic_error"] = pmc
+        return
+    for k in leg["roofline"]["kernels"]:
+        t = pmc.get(k["name"])
+        if t:
+            k["traffic"] = t["traffic_bytes_per_run"]
+            k["physical_GBps"] = (t["traffic_bytes_per_run"] / (k["ms"] * 1e-3) / 1e9) if k["ms"] else None
+    leg["roofline"]["traffic"] = sum(t["traffic_bytes_per_run"] for t in pmc.values())
+    leg["roofline"]["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the same tool with one timed run, summed over every generated kernel of the "
+                                      "query, per run; FETCH_SIZE x2 (gfx950); traffic / algorithmic_bytes > 1 = re-reads and random-access line waste")
 
 
 def measure_traffic(args, local_rank, rows, queries):

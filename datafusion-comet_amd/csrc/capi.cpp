@@ -365,6 +365,22 @@ void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launche
   if (input_rows) *input_rows = ctx->input_rows;
 }
 
+void comet_set_kernel_times(int32_t on) { g_kernel_times.store(on ? 1 : 0); }
+
+int64_t comet_plan_kernel_times(int64_t handle, char* buf, size_t cap) {
+  auto ctx = lookup(handle);
+  if (!ctx) return -1;
+  return guarded(ctx.get(), (int64_t)-2, [&]() -> int64_t {
+    std::string s = ctx->kernel_times_json();
+    if (buf && cap) {
+      size_t n = std::min(cap - 1, s.size());
+      memcpy(buf, s.data(), n);
+      buf[n] = 0;
+    }
+    return (int64_t)s.size();
+  });
+}
+
 void comet_plan_aux_kernel_stats(int64_t handle, double* aux_ms, int64_t* aux_launches) {
   auto ctx = lookup(handle);
   if (!ctx) return;

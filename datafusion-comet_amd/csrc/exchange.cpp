@@ -14,7 +14,6 @@
 // Fixed-width columns (ints, floats, dates, timestamps, decimals), Boolean (bit-packed values travel one byte per row like validity)
 // and Utf8 / Binary: the lengths travel one int32 per row, the bytes — gathered into partition order — with per-partition BYTE counts
 // (a second count exchange), and the receiver rebuilds its int32 offsets with one prefix sum over the received lengths.
-#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <condition_variable>
@@ -29,6 +28,7 @@
 
 #include "../../include/comet_amd.h"
 #include "exchange_core.hpp"
+#include "exchange_rccl.hpp"
 #include "exchange_tcp.hpp"
 #include "exec.hpp"
 #include "plan.hpp"
@@ -56,54 +56,18 @@ namespace {
     if (e_ != hipSuccess) throw CometError(std::string("exchange: ") + #call + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-// ---- RCCL through dlopen (no link-time dependency: a single-GPU deployment never loads it) ----
-typedef struct ncclComm* ncclComm_t;
-struct NcclUniqueId { char internal[128]; };
-struct Rccl {
-  void* lib = nullptr;
-  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
-  int (*CommInitRank)(ncclComm_t*, int, NcclUniqueId, int) = nullptr;
-  int (*CommDestroy)(ncclComm_t) = nullptr;
-  int (*CommCount)(const ncclComm_t, int*) = nullptr;          // (optional: what the communicator itself says about its size / this rank)
-  int (*CommUserRank)(const ncclComm_t, int*) = nullptr;
-  int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-  static Rccl& get() {
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [&]() {
-      const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
-      for (const char* n : names)       // a copy the process already holds (torch ships one) is reused: two RCCL instances do not share state
-        if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-      for (const char* n : names)
-        if (!r.lib && (r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-      if (!r.lib) return;
-      auto sym = [&](const char* s) { return dlsym(r.lib, s); };
-      r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
-      r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
-      r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
-      r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
-      r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
-      r.Send = (decltype(r.Send))sym("ncclSend");
-      r.Recv = (decltype(r.Recv))sym("ncclRecv");
-      r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
-      r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
-      r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
-      r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-    });
-    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.Send || !r.Recv || !r.AllGather || !r.GroupStart || !r.GroupEnd)
-      throw CometError("exchange: librccl.so could not be loaded (needed for the multi-process RCCL transport)");
-    return r;
-  }
-  void check(int rc, const char* what) {
-    if (rc != 0) throw CometError(std::string("exchange: ") + what + ": " + (GetErrorString ? GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
-  }
+// ---- RCCL through dlopen (exchange_rccl.hpp: no link-time dependency, a single-GPU deployment never loads it) over HBM ----
+using xchg::NcclUniqueId;
+using xchg::Rccl;
+using xchg::ncclComm_t;
+struct HipMem {
+  using Buf = DevBuf;
+  using HostBuf = PinnedBuf;
+  static void h2d(void* dst, const void* src, size_t n, void* st) { XHIP(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (hipStream_t)st)); }
+  static void d2h(void* dst, const void* src, size_t n, void* st) { XHIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, (hipStream_t)st)); }
+  static void sync(void* st) { XHIP(hipStreamSynchronize((hipStream_t)st)); }
 };
-constexpr int kNcclInt64 = 4, kNcclUint8 = 1;   // ncclDataType_t (nccl.h): ncclUint8 = 1, ncclInt64 = 4
+using RcclTransport = xchg::RcclTransportT<HipMem>;      // one process per GPU; everything is enqueued on the communicator's stream
 
 // ---- in-process rendezvous of the local transport ----
 struct LocalGroup {
@@ -131,50 +95,7 @@ struct LocalGroup {
 std::mutex g_groups_mu;
 std::map<int64_t, std::shared_ptr<LocalGroup>> g_groups;
 
-// ---- transports (exchange_core.hpp Transport) ----
-// RCCL: one process per GPU; everything is enqueued on the communicator's stream, the counts cross through device memory
-class RcclTransport : public xchg::Transport {
- public:
-  RcclTransport(ncclComm_t comm, int world, int rank, hipStream_t st, std::atomic<int64_t>* sent = nullptr, std::atomic<int64_t>* received = nullptr)
-      : comm_(comm), world_(world), rank_(rank), st_(st), sent_(sent), received_(received) {}
-  int world() const override { return world_; }
-  int rank() const override { return rank_; }
-  bool host_memory() const override { return false; }
-  void allgather_i64(const int64_t* mine, int n, int64_t* all) override {
-    Rccl& r = Rccl::get();
-    DevBuf dsend, dall;
-    PinnedBuf hsend, hall;
-    dsend.ensure((size_t)n * 8 + 16);
-    dall.ensure((size_t)n * world_ * 8 + 16);
-    hsend.ensure((size_t)n * 8 + 16);
-    hall.ensure((size_t)n * world_ * 8 + 16);
-    memcpy(hsend.p, mine, (size_t)n * 8);
-    XHIP(hipMemcpyAsync(dsend.p, hsend.p, (size_t)n * 8, hipMemcpyHostToDevice, st_));
-    r.check(r.AllGather(dsend.p, dall.p, (size_t)n, kNcclInt64, comm_, st_), "ncclAllGather");
-    XHIP(hipMemcpyAsync(hall.p, dall.p, (size_t)n * world_ * 8, hipMemcpyDeviceToHost, st_));
-    XHIP(hipStreamSynchronize(st_));
-    memcpy(all, hall.p, (size_t)n * world_ * 8);
-  }
-  void alltoallv(const void* send_buf, void* recv_buf, int w, const xchg::Split& sp) override {
-    // ONE group of send / recv pairs per buffer: xGMI is point to point, the all-to-all maps one to one onto the links
-    Rccl& r = Rccl::get();
-    r.check(r.GroupStart(), "ncclGroupStart");
-    for (int p = 0; p < world_; p++) {
-      if (sent_ && p != rank_) sent_->fetch_add((int64_t)sp.send[(size_t)p] * w);           // bytes that leave this GPU (the rank's own partition stays)
-      if (received_ && p != rank_) received_->fetch_add((int64_t)sp.recv[(size_t)p] * w);
-      if (sp.send[(size_t)p]) r.check(r.Send((const char*)send_buf + (size_t)sp.starts[(size_t)p] * (size_t)w, (size_t)sp.send[(size_t)p] * (size_t)w, kNcclUint8, p, comm_, st_), "ncclSend");
-      if (sp.recv[(size_t)p]) r.check(r.Recv((char*)recv_buf + (size_t)sp.roff[(size_t)p] * (size_t)w, (size_t)sp.recv[(size_t)p] * (size_t)w, kNcclUint8, p, comm_, st_), "ncclRecv");
-    }
-    r.check(r.GroupEnd(), "ncclGroupEnd");
-  }
-
- private:
-  ncclComm_t comm_;
-  int world_, rank_;
-  hipStream_t st_;
-  std::atomic<int64_t>*sent_, *received_;
-};
-
+// ---- transports (exchange_core.hpp Transport); the RCCL one is exchange_rccl.hpp's ----
 // N task threads of one process: publish through the group's slots, pull the slices with peer copies
 class LocalTransport : public xchg::Transport {
  public:

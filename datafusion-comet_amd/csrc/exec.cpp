@@ -723,6 +723,8 @@ ExecutionContext::~ExecutionContext() {
     (void)hipStreamSynchronize(stream_);  // pooled buffers go back only once the stream is idle
     for (auto& pr : timed_) { pool_put_event(device_id_, pr.first); pool_put_event(device_id_, pr.second); }
     for (hipEvent_t& e : aux_ev_) if (e) { pool_put_event(device_id_, e); e = nullptr; }
+    for (auto& p : kt_pending_) { pool_put_event(device_id_, p.a); pool_put_event(device_id_, p.b); }
+    kt_pending_.clear();
     pool_put_stream(device_id_, stream_);
   }
 }
@@ -787,7 +789,40 @@ Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid, const
 void ExecutionContext::launch(Variant& v, const char* kernel, int grid, CometKParams& prm) {
   hipFunction_t fn = v.mod->fn(kernel);
   void* args[] = {&prm};
+  // COMET_KERNEL_TIMES=1 / comet_set_kernel_times(1) (a measurement switch, off by default): an event pair around EVERY generated-kernel launch, summed per kernel
+  // name (comet_plan_kernel_times) — what bench.py's Q3 / Q95 rooflines name their dominant kernel from
+  if (!g_kernel_times.load(std::memory_order_relaxed)) {
+    HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream_, args, nullptr));
+    return;
+  }
+  hipEvent_t a = pool_get_event(device_id_), b = pool_get_event(device_id_);
+  HIP_CHECK(hipEventRecord(a, stream_));
   HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream_, args, nullptr));
+  HIP_CHECK(hipEventRecord(b, stream_));
+  kt_pending_.push_back({kernel, a, b});
+}
+
+std::atomic<int> g_kernel_times{getenv("COMET_KERNEL_TIMES") != nullptr && atoi(getenv("COMET_KERNEL_TIMES")) != 0 ? 1 : 0};
+
+// per-kernel-name totals of the launches timed so far, as JSON: {"k_jprobe": {"ms": 1.2, "calls": 3}, …}
+std::string ExecutionContext::kernel_times_json() {
+  if (!kt_pending_.empty()) {
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    for (auto& p : kt_pending_) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { kernel_times_[p.name].first += ms; kernel_times_[p.name].second++; }
+      pool_put_event(device_id_, p.a);
+      pool_put_event(device_id_, p.b);
+    }
+    kt_pending_.clear();
+  }
+  std::string s = "{";
+  for (auto& kv : kernel_times_) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s\"%s\": {\"ms\": %.6f, \"calls\": %lld}", s.size() > 1 ? ", " : "", kv.first.c_str(), kv.second.first, (long long)kv.second.second);
+    s += buf;
+  }
+  return s + "}";
 }
 
 // Utf8 group keys longer than the 15 bytes that fit the packed key words: replace them by representative row indices
@@ -1258,6 +1293,10 @@ DevTable ExecutionContext::nested_aggregate(const Operator& agg) {
   sub.collect_timings();
   last_kernel_ms += sub.last_kernel_ms;
   last_kernel_launches += sub.last_kernel_launches;
+  if (!sub.kt_pending_.empty() || !sub.kernel_times_.empty()) {
+    sub.kernel_times_json();
+    for (auto& kv : sub.kernel_times_) { kernel_times_[kv.first].first += kv.second.first; kernel_times_[kv.first].second += kv.second.second; }
+  }
   return t;
 }
 

@@ -136,6 +136,8 @@ std::vector<uint8_t> parquet_host_plain_values(const Operator& native_scan, size
 // queue one task on the same threads (FIFO) without waiting
 void scan_pool_submit(std::function<void()> fn);
 
+extern std::atomic<int> g_kernel_times;      // COMET_KERNEL_TIMES / comet_set_kernel_times: per-kernel event pairs in ExecutionContext::launch
+
 class ExecutionContext {
  public:
   ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vector<std::pair<std::string, std::string>> config,
@@ -164,6 +166,7 @@ class ExecutionContext {
   int64_t last_kernel_launches = 0;
   // input-verification launches ahead of the main kernels (utf8_uniform_kernel over a device input's Utf8 offsets): timed apart, so a
   // roofline can charge a column's bytes to the kernel that reads them
+  std::string kernel_times_json();
   double last_aux_ms = 0;
   int64_t last_aux_launches = 0;
   int64_t input_rows = 0;
@@ -260,6 +263,9 @@ class ExecutionContext {
   hipStream_t stream_ = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_;   // (start, stop) around each main-kernel launch
   size_t timed_done_ = 0;
+  struct KtPending { std::string name; hipEvent_t a, b; };
+  std::vector<KtPending> kt_pending_;                        // COMET_KERNEL_TIMES=1: one event pair per generated-kernel launch
+  std::map<std::string, std::pair<double, int64_t>> kernel_times_;
   hipEvent_t aux_ev_[2] = {nullptr, nullptr};              // (start, stop) around pull_device_table's verification launches; aux_n_ of them
   int aux_n_ = 0;
   bool started_ = false, finished_ = false;

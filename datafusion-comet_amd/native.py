@@ -59,6 +59,10 @@ def _load() -> ctypes.CDLL:
     lib.comet_explain.argtypes = [c.c_int64]
     lib.comet_plan_kernel_stats.restype = None
     lib.comet_plan_kernel_stats.argtypes = [c.c_int64, c.POINTER(c.c_double), c.POINTER(c.c_int64), c.POINTER(c.c_int64)]
+    lib.comet_set_kernel_times.restype = None
+    lib.comet_set_kernel_times.argtypes = [c.c_int32]
+    lib.comet_plan_kernel_times.restype = c.c_int64
+    lib.comet_plan_kernel_times.argtypes = [c.c_int64, c.c_char_p, c.c_size_t]
     lib.comet_plan_aux_kernel_stats.restype = None
     lib.comet_plan_aux_kernel_stats.argtypes = [c.c_int64, c.POINTER(c.c_double), c.POINTER(c.c_int64)]
     lib.comet_compile_plan.restype = c.c_int32
@@ -706,7 +710,37 @@ class Native:
 
     @staticmethod
     def releasePlan(handle: int) -> None:
+        if _kernel_times_sink is not None:      # measurement only (collect_kernel_times): the plan's per-kernel totals before it goes
+            buf = ctypes.create_string_buffer(1 << 16)
+            if lib().comet_plan_kernel_times(handle, buf, len(buf)) > 2:
+                import json
+                for k, v in json.loads(buf.value.decode()).items():
+                    e = _kernel_times_sink.setdefault(k, {"ms": 0.0, "calls": 0})
+                    e["ms"] += v["ms"]
+                    e["calls"] += v["calls"]
         lib().comet_release_plan(handle)
+
+
+_kernel_times_sink = None
+
+
+class collect_kernel_times:
+    """with collect_kernel_times() as kt: …  — every plan created and released inside the block times each of its generated-kernel launches
+    with its own HIP event pair (comet_set_kernel_times); kt.times = {kernel name: {"ms", "calls"}} summed over those plans.  A measurement
+    switch for the bench legs' rooflines: the event pairs cost a few microseconds per launch, so timed loops run with it off."""
+
+    def __enter__(self):
+        global _kernel_times_sink
+        self.times = {}
+        _kernel_times_sink = self.times
+        lib().comet_set_kernel_times(1)
+        return self
+
+    def __exit__(self, *exc):
+        global _kernel_times_sink
+        lib().comet_set_kernel_times(0)
+        _kernel_times_sink = None
+        return False
 
 
 class CometExecIterator:
@@ -735,6 +769,13 @@ class CometExecIterator:
         ms, launches, rows = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
         lib().comet_plan_kernel_stats(self.handle, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows))
         return ms.value, launches.value, rows.value
+
+    def kernel_times(self) -> dict:
+        """{kernel name: {"ms", "calls"}} of this plan's generated-kernel launches; empty unless COMET_KERNEL_TIMES=1 was set before the library loaded"""
+        import json
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = lib().comet_plan_kernel_times(self.handle, buf, len(buf))
+        return json.loads(buf.value.decode()) if n > 0 else {}
 
     def aux_kernel_stats(self):
         """(ms, launches) of the input-verification kernels (utf8_uniform_kernel) this plan ran ahead of its main kernels"""

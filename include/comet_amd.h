@@ -95,6 +95,13 @@ const char* comet_explain(int64_t handle);
  * stream: total milliseconds, number of timed launches, input rows.  Used by bench.py's roofline. */
 void comet_plan_kernel_stats(int64_t handle, double* kernel_ms, int64_t* launches, int64_t* input_rows);
 
+/* With COMET_KERNEL_TIMES=1 in the environment or after comet_set_kernel_times(1) (a measurement switch; off by default) every generated-kernel launch of the plan is bracketed
+ * by its own HIP event pair; this returns the totals per kernel name as JSON ({"k_jprobe": {"ms": 1.2, "calls": 3}, …}; "{}" when the switch
+ * is off): the byte length, at most cap - 1 bytes + NUL copied into buf.  bench.py's Q3 / Q95 rooflines name their dominant kernel from it. */
+int64_t comet_plan_kernel_times(int64_t handle, char* buf, size_t cap);
+/* … the same switch at run time (process-wide; plans created afterwards time their launches). */
+void comet_set_kernel_times(int32_t on);
+
 /* … and of the input-verification launches that run ahead of them (utf8_uniform_kernel over the Utf8 offsets of an HBM-resident input,
  * the check behind addressing fixed-length strings directly): total milliseconds and launches, timed apart from the main kernels so that
  * bench.py's roofline charges every column's bytes to the kernel that reads them. */

@@ -7,6 +7,7 @@
 // oracle computed (oracle.hash_partition_ids — the pinned restatement of the reference's murmur3 + pmod), so the only murmur3 on the CPU
 // stays the oracle's.  What the tests pin with it: the count exchange, the splits, the order of the collectives, validity-on-any-rank,
 // the Utf8 byte split, the offset rebuild, and the transport's behaviour when a peer dies or goes silent.
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +18,7 @@
 #include <vector>
 
 #include "../../datafusion-comet_amd/csrc/exchange_core.hpp"
+#include "../../datafusion-comet_amd/csrc/exchange_rccl.hpp"
 #include "../../datafusion-comet_amd/csrc/exchange_tcp.hpp"
 
 using namespace comet::xchg;
@@ -101,7 +103,24 @@ struct HostOps {
   void sync() {}
 };
 
+// the product's RCCL transport (csrc/exchange_rccl.hpp — the text libcomet.so compiles) over host memory: "device" buffers are malloc'ed, the
+// stream is nothing.  Whatever librccl COMET_RCCL_LIBRARY names answers it; the tests name tests/fake_rccl/.
+struct HostMem {
+  using Buf = HostBufT;
+  using HostBuf = HostBufT;
+  static void h2d(void* dst, const void* src, size_t n, void*) { memcpy(dst, src, n); }
+  static void d2h(void* dst, const void* src, size_t n, void*) { memcpy(dst, src, n); }
+  static void sync(void*) {}
+};
+struct RcclComm {
+  ncclComm_t nccl = nullptr;
+  int world = 1, rank = 0;
+  std::atomic<int64_t> sent{0}, received{0};
+  std::unique_ptr<RcclTransportT<HostMem>> t;
+};
+
 std::mutex g_mu;
+std::map<int64_t, std::unique_ptr<RcclComm>> g_rccl;
 std::map<int64_t, std::unique_ptr<TcpTransport>> g_comms;
 std::map<int64_t, std::unique_ptr<Result<HostOps>>> g_results;
 int64_t g_next = 1;
@@ -126,19 +145,86 @@ int64_t xh_comm_init_tcp(const char* peers, int32_t world, int32_t rank, int32_t
   }
 }
 
+// ---- the RCCL wire: the same three steps as comet_comm_unique_id / comet_comm_init_rank / comet_comm_stats (csrc/exchange.cpp) ----
+int32_t xh_comm_unique_id(uint8_t* out128) {
+  try {
+    NcclUniqueId id;
+    Rccl& r = Rccl::get();
+    r.check(r.GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(out128, id.internal, 128);
+    return 0;
+  } catch (const std::exception& e) {
+    t_error = e.what();
+    return -2;
+  }
+}
+
+int64_t xh_comm_init_rccl(const uint8_t* id128, int32_t world, int32_t rank) {
+  try {
+    Rccl& r = Rccl::get();
+    std::unique_ptr<RcclComm> c(new RcclComm());
+    c->world = world;
+    c->rank = rank;
+    NcclUniqueId id;
+    memcpy(id.internal, id128, 128);
+    r.check(r.CommInitRank(&c->nccl, world, id, rank), "ncclCommInitRank");
+    c->t.reset(new RcclTransportT<HostMem>(c->nccl, world, rank, nullptr, &c->sent, &c->received));
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int64_t h = g_next++;
+    g_rccl[h] = std::move(c);
+    return h;
+  } catch (const std::exception& e) {
+    t_error = e.what();
+    return 0;
+  }
+}
+
+// out[0] = ncclCommCount, out[1] = ncclCommUserRank, out[2] / out[3] = bytes sent to / received from other ranks (comet_comm_stats's four)
+int32_t xh_comm_stats(int64_t comm, int64_t* out4) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_rccl.find(comm);
+  if (it == g_rccl.end()) return -1;
+  Rccl& r = Rccl::get();
+  int v = -1;
+  out4[0] = (r.CommCount && r.CommCount(it->second->nccl, &v) == 0) ? v : -1;
+  v = -1;
+  out4[1] = (r.CommUserRank && r.CommUserRank(it->second->nccl, &v) == 0) ? v : -1;
+  out4[2] = it->second->sent.load();
+  out4[3] = it->second->received.load();
+  return 0;
+}
+
+// the stand-in library's own log of the calls it saw on this communicator (fake_rccl_counters; 7 values) — 0 when the loaded library has none
+int32_t xh_comm_wire_counters(int64_t comm, int64_t* out7) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_rccl.find(comm);
+  if (it == g_rccl.end()) return -1;
+  auto fn = (void (*)(ncclComm_t, int64_t*))dlsym(Rccl::get().lib, "fake_rccl_counters");
+  if (!fn) return 0;
+  fn(it->second->nccl, out7);
+  return 7;
+}
+
 void xh_comm_destroy(int64_t comm) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_comms.erase(comm);
+  auto it = g_rccl.find(comm);
+  if (it != g_rccl.end()) {
+    if (it->second->nccl) Rccl::get().CommDestroy(it->second->nccl);
+    g_rccl.erase(it);
+  }
 }
 
 int64_t xh_exchange(int64_t comm, int32_t n_cols, const CometExchangeColumn* cols, int64_t rows, const int32_t* oracle_pids) {
   try {
-    TcpTransport* t;
+    Transport* t;
     {
       std::lock_guard<std::mutex> lk(g_mu);
       auto it = g_comms.find(comm);
-      if (it == g_comms.end()) throw Error("invalid communicator handle");
-      t = it->second.get();
+      auto ir = g_rccl.find(comm);
+      if (it != g_comms.end()) t = it->second.get();
+      else if (ir != g_rccl.end()) t = ir->second->t.get();
+      else throw Error("invalid communicator handle");
     }
     HostOps ops;
     ops.oracle_pids = oracle_pids;

@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--mode", default="normal", choices=["normal", "die_before_exchange", "silent", "wrong_collective"])
     ap.add_argument("--timeout-ms", type=int, default=20000)
     ap.add_argument("--rounds", type=int, default=1)
+    ap.add_argument("--wire", default="tcp", choices=["tcp", "rccl"], help="rccl: the product's RcclTransportT over whatever COMET_RCCL_LIBRARY names (tests/fake_rccl/)")
+    ap.add_argument("--id-file", default="", help="rccl: where rank 0 leaves the 128-byte unique id for the other ranks (the out-of-band control plane)")
     a = ap.parse_args()
     from datafusion_comet_amd import serde as S
     from oracle import oracle as O
@@ -92,8 +94,30 @@ def main():
             f.write(msg)
         sys.exit(3)
 
-    peers = ",".join("127.0.0.1:" + p for p in a.ports.split(","))
-    comm = lib.xh_comm_init_tcp(peers.encode(), a.world, a.rank, a.timeout_ms)
+    if a.wire == "rccl":
+        lib.xh_comm_init_rccl.restype = ctypes.c_int64
+        lib.xh_comm_init_rccl.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]
+        lib.xh_comm_unique_id.argtypes = [ctypes.c_char_p]
+        lib.xh_comm_stats.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+        lib.xh_comm_wire_counters.argtypes = [ctypes.c_int64, ctypes.c_void_p]
+        idbuf = ctypes.create_string_buffer(128)
+        if a.rank == 0:
+            if lib.xh_comm_unique_id(idbuf) != 0:
+                fail("unique id: " + lib.xh_last_error().decode())
+            with open(a.id_file + ".tmp", "wb") as f:
+                f.write(idbuf.raw)
+            os.replace(a.id_file + ".tmp", a.id_file)
+        else:
+            t0 = time.time()
+            while not os.path.exists(a.id_file):
+                if time.time() - t0 > a.timeout_ms / 1000.0:
+                    fail("init: no unique id from rank 0")
+                time.sleep(0.02)
+            idbuf.raw = open(a.id_file, "rb").read()
+        comm = lib.xh_comm_init_rccl(idbuf.raw, a.world, a.rank)
+    else:
+        peers = ",".join("127.0.0.1:" + p for p in a.ports.split(","))
+        comm = lib.xh_comm_init_tcp(peers.encode(), a.world, a.rank, a.timeout_ms)
     if not comm:
         fail("init: " + lib.xh_last_error().decode())
     if a.mode == "die_before_exchange":
@@ -141,6 +165,14 @@ def main():
                 arrays.append(pa.Array.from_buffers(f.type, rows, [valid, grab(pv, rows * w)]))
         lib.xh_result_release(h)
         outs.append(pa.Table.from_arrays(arrays, schema=pa.schema([shard.schema.field(i) for i in range(ncols)])))
+    if a.wire == "rccl":
+        import json
+        st, wc = (ctypes.c_int64 * 4)(), (ctypes.c_int64 * 7)()
+        lib.xh_comm_stats(comm, st)
+        nw = lib.xh_comm_wire_counters(comm, wc)
+        with open(a.out + ".stats", "w") as f:
+            json.dump({"comm_count": st[0], "comm_rank": st[1], "bytes_sent": st[2], "bytes_received": st[3],
+                       "wire": dict(zip(["allgathers", "groups", "sends", "recvs", "self_pairs", "bytes_out", "bytes_in"], list(wc))) if nw == 7 else None}, f)
     lib.xh_comm_destroy(comm)
     with pa.OSFile(a.out, "wb") as f, pa.ipc.new_file(f, outs[0].schema) as w:
         for o in outs:

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--exchange", default="native", choices=["native", "torch", "torch-fallback"],
                     help="native: the exchange runs inside libcomet.so (partition kernels + RCCL send/recv groups); torch: torch.distributed all_to_all")
     ap.add_argument("--allow-fallback", action="store_true", help="N > 1 ranks: exit 0 even when the exchange did NOT run over the in-library RCCL transport")
+    ap.add_argument("--kernel-times", action="store_true", help="after the timed runs, one more with per-kernel HIP events: adds a roofline object naming the dominant kernel")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import torch
@@ -79,6 +80,16 @@ def main():
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     sec = float(dt.item()) / a.steps
+    # one more, untimed run with an event pair around every generated-kernel launch: which kernel the query's time sits in (roofline below)
+    ktimes = None
+    if a.kernel_times:
+        from datafusion_comet_amd import native
+        with native.collect_kernel_times() as kt:
+            if single_plan:
+                parallel.run_q3_single(eng, customer, orders, lineitem)
+            else:
+                parallel.run_q3_distributed(eng, part, customer, orders, lineitem)
+        ktimes = kt.times
     # what the wire itself says: RCCL's rank count, and the bytes every rank sent / received over it (gathered: rank 0 prints them all)
     wire = None
     if world > 1:
@@ -102,6 +113,16 @@ def main():
                 "stage_ms_rank0": {k: round(v / a.steps * 1e3, 3) for k, v in timings.items() if not k.startswith("exchange_")},
                 "exchange_rows_rank0": timings.get("exchange_rows", 0) // a.steps, "exchange_bytes_rank0": timings.get("exchange_bytes", 0) // a.steps,
                 "plan": "one native plan (fused probe chains)" if single_plan else "5 stage plans cut at the exchanges", "exchange": exchange_kind, "exchange_transport": transport, "exchange_wire": wire, "groups_rank0": groups, "top1": [str(x) for x in top[0]] if top else None, "verified_vs_torch": ok, "scaling": "strong"}
+        if ktimes is not None:
+            # the algorithmic bytes of the query are its input tables, each read once (30.3 GB at SF100) — joins and aggregates
+            # are HBM-bound gathers and streams.  `achieved` = those bytes ÷ the whole query's time (all ranks); `kernels` = where one run's
+            # device time goes on rank 0 (ms summed over the launches of that name), largest first; `traffic` is filled in by bench.py's PMC pass
+            ks = sorted(({"name": k, "ms": v["ms"], "calls": v["calls"]} for k, v in ktimes.items()), key=lambda e: -e["ms"])
+            ach = int(tot[1].item()) / sec / 1e9
+            line["roofline"] = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "algorithmic_bytes": int(tot[1].item()), "achieved": ach, "frac": ach / 8000.0 / world,
+                                "dominant_kernel": ks[0]["name"] if ks else None, "kernel_ms_total_rank0": sum(e["ms"] for e in ks), "kernels": ks[:8], "traffic": None,
+                                "note": "achieved = input bytes of the three tables / sec_per_run (whole query, frac against the HBM peak of all ranks); "
+                                        "kernels = one extra untimed run on rank 0 with an event pair around every generated-kernel launch"}
         s = json.dumps(line)
         print(s, flush=True)
         if a.out:
