@@ -3651,6 +3651,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbemit(const CometKParams prm) { comet::join_build_unmatched_emit_body<P>(prm); }\n";
   // single-pass probes (comet_device.hpp template D'): the chained global table, or an LDS table for small build sides
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe(const CometKParams prm) { comet::join_probe_fused_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe_km(const CometKParams prm) { comet::join_probe_fused_body<P, true>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jlds(const CometKParams prm) { comet::join_probe_lds_body<P>(prm); }\n";
   // the key bitmap's two helpers: a sample of the probe side through the finished table (does it pay?), and the bitmap's own build pass
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jsample(const CometKParams prm) { comet::join_sample_body<P>(prm); }\n";
@@ -3658,7 +3659,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jdrows(const CometKParams prm) { comet::join_direct_rows_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jdprobe(const CometKParams prm) { comet::join_probe_direct_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbmap(const CometKParams prm) { comet::join_keymap_build_body<P>(prm); }\n";
-  d.kernels = {"k_jbuild", "k_jbcnt", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jlds", "k_jsample", "k_jbmap", "k_jdrows", "k_jdprobe"};
+  d.kernels = {"k_jbuild", "k_jbcnt", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jprobe_km", "k_jlds", "k_jsample", "k_jbmap", "k_jdrows", "k_jdprobe"};
   d.join_outer_build = outer_build;
   d.join_build_only = build_only;
   const char* jt_name = build_only ? (keep_matched ? "LeftSemi" : "LeftAnti") : keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";

@@ -2648,7 +2648,11 @@ struct JoinDirectTable {
 //   2. output positions in (wave, slice, lane) order — a wave's consecutive list entries are consecutive input rows, so a clustered
 //      probe side gives a (locally) clustered join output, which the next join's build exploits (runs); one atomic per tile reserves
 //      the range.
-template <class P, class T>
+// KM (compile time): a key bitmap may be present (k_jprobe_km, k_jdprobe).  The bitmap's sweeps hold sixteen keys and sixteen bitmap words per
+// thread; a kernel that CAN take them is allocated the registers for them whether the bitmap exists at run time or not, and a probe that lives
+// on random accesses (TPC-DS Q95's self-joins: 72 M rows, duplicate-heavy keys, no bitmap) lost a fifth of its speed to the lower occupancy
+// (round-5 bisect: 22.7 → 26.7 ms, profiles/r5_q95_bisect.txt).  So the table probe without a bitmap is its own kernel with the plain filter loop.
+template <class P, class T, bool KM>
 CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
   const i64 n = prm.n;
   const i64 cap_out = prm.iarg[6];
@@ -2668,12 +2672,21 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
     // together: one loop that filtered, looked up and compacted row after row spent its time in sixteen dependent load latencies)
     u32 m = 0;
     u32 alive_bits = 0, can_bits = 0;
+    if (!(KM && P::KEYMAP)) {
+#pragma unroll
+      for (int r = 0; r < kJoinR0; r++) {
+        const i64 j = base + (i64)r * kBlock + threadIdx.x;
+        const bool alive = j < n && P::pkeep(prm, j);
+        if (alive) alive_bits |= 1u << r;
+        if (alive && P::pvalid(prm, j)) can_bits |= 1u << r;
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < kJoinR0; r++) {
       const i64 j = base + (i64)r * kBlock + threadIdx.x;
       if (j < n && P::pkeep(prm, j)) alive_bits |= 1u << r;
     }
-    if (P::KEYMAP && keymap) {
+    if (keymap) {
       u64 keys[kJoinR0];
 #pragma unroll
       for (int r = 0; r < kJoinR0; r++) {
@@ -2697,6 +2710,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
         const i64 j = base + (i64)r * kBlock + threadIdx.x;
         if (((alive_bits >> r) & 1u) && P::pvalid(prm, j)) can_bits |= 1u << r;
       }
+    }
     }
 #pragma unroll
     for (int r = 0; r < kJoinR0; r++) {
@@ -2867,7 +2881,14 @@ CDEV void join_keymap_build_body(const CometKParams& prm) {
       u32* w = (u32*)(km + 2) + (idx >> 5);
       const u32 bit = 1u << (idx & 31u);
       // (runs of equal keys: the bit is usually there already) — a bit that was there means the key is NOT unique: out[47][4] says so
-      if ((*w & bit) || (atomicOr(w, bit) & bit)) ((volatile unsigned long long*)prm.out[47])[4] = 1ull;
+      // (one store per WAVE that saw one, and only while the flag is still clear: with duplicate-heavy keys — Q95's 7 M returned order lines — every
+      // lane storing into the one word made this pass 1.13 ms instead of 0.1)
+      const bool dup = (*w & bit) || (atomicOr(w, bit) & bit);
+      if (dup) {
+        volatile unsigned long long* flag = (volatile unsigned long long*)prm.out[47] + 4;
+        const u64 who = __ballot(true);
+        if (lane_id() == (int)__builtin_ctzll(who) && *flag == 0ull) *flag = 1ull;
+      }
     }
   }
 }
@@ -2889,13 +2910,13 @@ CDEV void join_direct_rows_body(const CometKParams& prm) {
 template <class P>
 CDEV void join_probe_direct_body(const CometKParams& prm) {
   const JoinDirectTable<P> t{(const u64*)prm.out[kJoinKeyMap], (const u32*)prm.out[0], (const u32*)prm.out[1]};
-  join_probe_tiles<P>(prm, t);
+  join_probe_tiles<P, JoinDirectTable<P>, true>(prm, t);
 }
 
-template <class P>
+template <class P, bool KM = false>
 CDEV void join_probe_fused_body(const CometKParams& prm) {
   JoinGlobalTable<P> t{(const u32*)prm.out[0], (const i32*)prm.out[1], (u64)prm.iarg[0] - 1, (int)prm.iarg[2], prm.iarg[1]};
-  join_probe_tiles<P>(prm, t);
+  join_probe_tiles<P, JoinGlobalTable<P>, KM>(prm, t);
 }
 
 template <class P>
@@ -2917,7 +2938,7 @@ CDEV void join_probe_lds_body(const CometKParams& prm) {
   }
   __syncthreads();
   JoinLdsTable<P> t{(const COMET_LDS u32*)s_rows, (const COMET_LDS unsigned short*)s_tags};
-  join_probe_tiles<P>(prm, t);
+  join_probe_tiles<P, JoinLdsTable<P>, false>(prm, t);
 }
 
 }  // namespace comet

@@ -298,7 +298,8 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     prm.iarg[6] = out_cap;
     HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 8, stream_));
     const int64_t ptiles = (n + 4095) / 4096;      // kJoinR0 × 256 probe rows per tile (comet_device.hpp)
-    launch(v, use_lds ? "k_jlds" : direct ? "k_jdprobe" : "k_jprobe", (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
+    // (k_jprobe_km: the table probe that asks the key bitmap first; without a bitmap the leaner k_jprobe — comet_device.hpp join_probe_tiles)
+    launch(v, use_lds ? "k_jlds" : direct ? "k_jdprobe" : keymap_built ? "k_jprobe_km" : "k_jprobe", (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
     uint64_t emitted = 0;
     read_small(&emitted, emitted_buf.p, 8);
     out_rows = d.join_build_only ? 0 : (int64_t)emitted;

@@ -3,6 +3,13 @@
 
 namespace comet {
 
+// An executor runs 8-16 task threads against one GPU, each with a handful of streams (its plan's, a copy stream, two decompression-group
+// streams).  ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues — four by default — and a stream that waits for an event
+// holds up whatever shares its queue: sixteen concurrent zstd scans took 80 ms with four queues and 62 ms with sixteen (profiles/r5_executor_*).
+// The runtime reads the variable when it initialises (the first HIP call), so loading the library is early enough in a JVM; a value the
+// operator has set stays.
+__attribute__((constructor)) static void comet_hip_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 // ---------------------------------------------------------------------------------------------
 // buffers
 // ---------------------------------------------------------------------------------------------
@@ -42,6 +49,20 @@ int current_device() {
 }
 }  // namespace
 
+// what the pools could NOT serve (process-wide): calls and nanoseconds spent in hipMalloc / hipHostMalloc — a miss is a driver call that takes
+// a lock every other HIP call of the process waits for (COMET_TRACE_STAGES prints the deltas per scan)
+std::atomic<int64_t> g_dev_alloc_calls{0}, g_dev_alloc_ns{0}, g_pinned_alloc_calls{0}, g_pinned_alloc_ns{0};
+void pool_miss_counters(int64_t out[4]) {
+  out[0] = g_dev_alloc_calls.load(); out[1] = g_dev_alloc_ns.load(); out[2] = g_pinned_alloc_calls.load(); out[3] = g_pinned_alloc_ns.load();
+}
+namespace {
+struct AllocTimer {
+  std::atomic<int64_t>&calls, &ns;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  AllocTimer(std::atomic<int64_t>& c, std::atomic<int64_t>& n) : calls(c), ns(n) {}
+  ~AllocTimer() { calls.fetch_add(1); ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()); }
+};
+}  // namespace
 namespace {
 thread_local std::shared_ptr<MemAccount> t_account;
 void raise_peak(std::atomic<int64_t>& peak, int64_t v) {
@@ -129,6 +150,7 @@ void DevBuf::ensure(size_t n) {
         return;
       }
     }
+    AllocTimer alloc_timer(g_dev_alloc_calls, g_dev_alloc_ns);
     if (hipMalloc(&p, cls) != hipSuccess) {
       // out of memory: hand every idle block of this device back to the driver and try once more
       (void)hipGetLastError();
@@ -192,6 +214,7 @@ void PinnedBuf::ensure(size_t n) {
         return;
       }
     }
+    AllocTimer alloc_timer(g_pinned_alloc_calls, g_pinned_alloc_ns);
     HIP_CHECK(hipHostMalloc(&p, cls, hipHostMallocDefault));
     cap = cls;
   } catch (...) {

@@ -38,6 +38,14 @@ typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section 
   int32_t pad;
 } PqRun;
 
+typedef struct PqPendingRuns { /* a dictionary-encoded page whose index section the DEVICE walks (device/pq_runs.hpp): its run headers are not known to the host */
+  int64_t begin, end;          /* the section, byte offsets in the column's byte buffer (the device-decompressed region) */
+  int32_t bit_width;
+  int32_t max_values;          /* stop behind this many values; -1: walk to the section's end */
+  int32_t page;                /* column-global index of the page (pq_write_runs_kernel fills its idx_run_first / idx_run_count) */
+  int32_t pad;
+} PqPendingRuns;
+
 typedef struct PqInflate {     /* one compressed page body the device decompresses (snappy_kernels.hip); offsets relative to the column's byte buffer */
   int64_t src_off;             /* compressed bytes, 16-byte aligned, readable up to the next multiple of 16 */
   int64_t dst_off;             /* where the decompressed page goes, 16-byte aligned */

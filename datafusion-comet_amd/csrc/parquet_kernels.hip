@@ -9,6 +9,7 @@
 
 #include "device/comet_device.hpp"
 #include "parquet_dev.h"
+#include "device/pq_runs.hpp"
 
 using namespace comet;
 
@@ -55,6 +56,60 @@ __global__ __launch_bounds__(256) void pq_validity_kernel(PqDecodeArgs a) {
     }
     a.valid_out[row] = valid;
   }
+}
+
+// 1b. run headers of index sections the device inflated (device/pq_runs.hpp): one lane per page.  Pass 1 counts a page's runs, a prefix sum
+// places them, pass 2 walks again and writes the PqRun entries behind the column's host-parsed runs and the page's (first, count).
+// A malformed section leaves (page job << 8 | 0xE0 + status) in *err, like the decompression kernels.
+__global__ __launch_bounds__(256) void pq_count_runs_kernel(const PqPendingRuns* __restrict__ pend, int n, const u8* __restrict__ bytes, u32* __restrict__ counts, u32* err) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= n) return;
+  const PqPendingRuns p = pend[i];
+  i32 runs = 0;
+  const int st = pq_walk_runs(bytes, p.begin, p.end, p.bit_width, p.max_values, &runs, [](i64, i32, i32, int, u32) {});
+  if (st != PQ_RUNS_OK) { atomicCAS(err, 0u, ((u32)i << 8) | (0xE0u + (u32)st)); runs = 0; }
+  counts[i] = runs > 0 ? (u32)runs : 1u;      // (a page of NULLs only has no run: one RLE run of zeros stands for it, as on the host)
+}
+// one word from device memory to wherever `dst` points — pinned host memory: the scan reads a count without queueing a copy command
+__global__ void pq_store_u32_kernel(const u32* __restrict__ src, u32* dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __hip_atomic_store(dst, *src, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(256) void pq_write_runs_kernel(const PqPendingRuns* __restrict__ pend, int n, const u8* __restrict__ bytes, const i32* __restrict__ offsets, i32 run_base,
+                                                            PqRun* __restrict__ runs, PqPage* __restrict__ pages) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= n) return;
+  const PqPendingRuns p = pend[i];
+  const i32 first = run_base + offsets[i];
+  PqRun* out = runs + first;
+  i32 k = 0;
+  i32 nruns = 0;
+  const int st = pq_walk_runs(bytes, p.begin, p.end, p.bit_width, p.max_values, &nruns, [&](i64 byte_off, i32 value_start, i32 count, int is_rle, u32 rle_value) {
+    PqRun r;
+    r.byte_off = byte_off;
+    r.value_start = value_start;
+    r.count = count;
+    r.is_rle = is_rle;
+    r.rle_value = rle_value;
+    r.page = p.page;
+    r.pad = 0;
+    out[k++] = r;
+  });
+  if (st != PQ_RUNS_OK || k == 0) {      // (a malformed section was reported by pass 1; its page decodes as zeros and the scan fails on the error word)
+    PqRun r;
+    r.byte_off = 0;
+    r.value_start = 0;
+    r.count = pages[p.page].num_values;
+    r.is_rle = 1;
+    r.rle_value = 0;
+    r.page = p.page;
+    r.pad = 0;
+    out[0] = r;
+    k = 1;
+  }
+  pages[p.page].idx_run_first = first;
+  pages[p.page].idx_run_count = k;
 }
 
 // 2. exclusive prefix count of valid rows (per 1024-row tile: count, then scan of tile counts, then apply)
@@ -718,6 +773,13 @@ void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* 
   hipLaunchKernelGGL(pq_tile_count_kernel, grid_tiles(n), 256, 0, s, valid, (i64)n, (u64*)tiles);
   hipLaunchKernelGGL(pq_tile_scan_kernel, 1, 256, 0, s, (u64*)tiles, (i64)((n + 1023) / 1024));
   hipLaunchKernelGGL(pq_vidx_kernel, grid_tiles(n), 256, 0, s, valid, (i64)n, (const u64*)tiles, (u32*)vidx);
+}
+void pq_launch_store_u32(const uint32_t* src, uint32_t* dst, void* st) { hipLaunchKernelGGL(pq_store_u32_kernel, 1, 64, 0, (hipStream_t)st, (const u32*)src, (u32*)dst); }
+void pq_launch_count_runs(const PqPendingRuns* pend, int n, const uint8_t* bytes, uint32_t* counts, uint32_t* err, void* st) {
+  if (n > 0) hipLaunchKernelGGL(pq_count_runs_kernel, (n + 255) / 256, 256, 0, (hipStream_t)st, pend, n, (const u8*)bytes, (u32*)counts, (u32*)err);
+}
+void pq_launch_write_runs(const PqPendingRuns* pend, int n, const uint8_t* bytes, const int32_t* offsets, int32_t run_base, PqRun* runs, PqPage* pages, void* st) {
+  if (n > 0) hipLaunchKernelGGL(pq_write_runs_kernel, (n + 255) / 256, 256, 0, (hipStream_t)st, pend, n, (const u8*)bytes, (const i32*)offsets, (i32)run_base, runs, pages);
 }
 void pq_launch_decode_runs(const PqDecodeArgs* a, void* st) {
   if (a->n_idx_runs <= 0) return;

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cerrno>
 #include <atomic>
+#include <cstdarg>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -24,6 +25,7 @@
 
 #include "exec.hpp"
 #include "parquet_dev.h"
+namespace comet { void pool_miss_counters(int64_t out[4]); }
 namespace comet { namespace detail {      // per-process stream / event pools (exec_memory.cpp)
 hipStream_t pool_get_stream(int dev);
 void pool_put_stream(int dev, hipStream_t s);
@@ -43,6 +45,9 @@ void pq_launch_validity(const PqDecodeArgs* a, void* st);
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st);
 void pq_launch_decode_fixed(const PqDecodeArgs* a, void* st);
 void pq_launch_decode_runs(const PqDecodeArgs* a, void* st);
+void pq_launch_store_u32(const uint32_t* src, uint32_t* dst, void* st);
+void pq_launch_count_runs(const PqPendingRuns* pend, int n, const uint8_t* bytes, uint32_t* counts, uint32_t* err, void* st);
+void pq_launch_write_runs(const PqPendingRuns* pend, int n, const uint8_t* bytes, const int32_t* offsets, int32_t run_base, PqRun* runs, PqPage* pages, void* st);
 void pq_launch_expand_nulls(const PqDecodeArgs* a, void* st);
 void pq_launch_string_lengths(const PqDecodeArgs* a, void* st);
 void pq_launch_string_copy(const PqDecodeArgs* a, void* st);
@@ -339,6 +344,8 @@ struct ScanOptions {
   bool device_zstd_dict = false;       // COMET_DEVICE_ZSTD_DICT=1: dictionary-encoded zstd pages are inflated by the device too, their index sections come back and the host reads the run
                                        // headers there.  Off: measured on SF10 Q6 (profiles/r3_parquet_q6_zstd_dict.txt) the device inflates these Huffman-only pages at 4–7 GB/s
                                        // (one serial LDS-lookup chain per literal stream) where a host core does 6 GB/s — 87 vs 38 ms with 16 scan threads, 111 vs 97 ms with one
+  bool device_runs = true;             // … and the run headers of those index sections are walked ON THE DEVICE (device/pq_runs.hpp: count, prefix sum, write — four bytes come back instead of
+                                       // the sections); COMET_DEVICE_RUNS=0: the round-3 path, sections read back and parsed by the scan threads
   bool device_zstd = true;             // zstd PLAIN pages of fixed-width columns take the device pipeline too (COMET_DEVICE_ZSTD=0: host threads inflate them)
   bool read_in_place = true;           // chunks whose pages the device inflates are pread() straight into their pinned slot; page bodies are uploaded from where they land (COMET_PARQUET_READ_IN_PLACE=0: read into scratch, copy bodies)
   bool device_dict_pages = true;       // dictionary-encoded snappy pages cross PCIe compressed too (COMET_DEVICE_DICT_PAGES=0: host-inflated as before)
@@ -1621,8 +1628,22 @@ std::vector<uint8_t> parquet_host_plain_values(const Operator& op, size_t col) {
   return out;
 }
 
+// COMET_TRACE_STAGES lines carry the scan's number: eight concurrent tasks write into one stderr
+static std::atomic<int> g_scan_seq{0};
+static void trace_line(int scan, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "[comet] parquet#%d: %s", scan, buf);
+}
+
 DevTable ExecutionContext::scan_parquet(const Operator& op) {
   static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
+  const int scan_id = g_scan_seq.fetch_add(1);
+  int64_t miss0[4] = {0, 0, 0, 0};
+  if (trace) pool_miss_counters(miss0);
   const auto t_begin = std::chrono::steady_clock::now();
   auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   const size_t ncol = op.required_schema.size();
@@ -1640,6 +1661,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (const char* e = getenv("COMET_PARQUET_READ_IN_PLACE")) so.read_in_place = atoi(e) != 0;
   if (const char* e = getenv("COMET_DEVICE_ZSTD")) so.device_zstd = atoi(e) != 0;
   if (const char* e = getenv("COMET_DEVICE_ZSTD_DICT")) so.device_zstd_dict = atoi(e) != 0;
+  if (const char* e = getenv("COMET_DEVICE_RUNS")) so.device_runs = atoi(e) != 0;
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy_mode = kv.second == "auto" ? -1 : (kv.second != "false" && kv.second != "0");
   if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
@@ -1664,7 +1686,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (total_rows == 0) return out;
   if (total_rows >= ((int64_t)1 << 31)) throw CometError("GPU Parquet scan: more than 2^31 rows in one partition");
 
-  if (trace) fprintf(stderr, "[comet] parquet: footers + row-group selection done at %.2f ms\n", ms_since());
+  if (trace) trace_line(scan_id, "footers + row-group selection done at %.2f ms\n", ms_since());
   // Host threads prepare the column chunks (decompression dominates: ~1 GB/s per core for zstd) straight into one pinned
   // block per column; this thread concatenates a finished column's tables, uploads and decodes the whole column at once.
   // spark.comet.gpu.scanThreads / COMET_SCAN_THREADS bound the pool.
@@ -1768,7 +1790,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     so.device_snappy = snappy_on_device || zstd_on_device;
     if (!zstd_on_device && getenv("COMET_DEVICE_ZSTD") == nullptr) so.device_zstd = false;
   }
-  if (trace) fprintf(stderr, "[comet] parquet: %.1f MB of snappy / %.1f MB of zstd pages of fixed-width columns, decompressed on the %s%s\n", (double)plain_snappy_bytes / 1e6,
+  if (trace) trace_line(scan_id, "%.1f MB of snappy / %.1f MB of zstd pages of fixed-width columns, decompressed on the %s%s\n", (double)plain_snappy_bytes / 1e6,
                      (double)plain_zstd_bytes / 1e6, so.device_snappy ? "device" : "host", so.device_snappy && plain_zstd_bytes && !so.device_zstd ? " (zstd: host)" : "");
   auto run_task = [&](size_t t, bool raw_read) {
     const size_t c = t / nsel, si = t % nsel;
@@ -1995,7 +2017,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   // everything behind a column's uploads: its tables (pages, runs, dictionaries) assembled and sent, the decode kernels queued.  A column
   // with dictionary-encoded pages the DEVICE inflates comes here late — their run headers are read back first (below).
   static const bool one_wave_snappy = getenv("COMET_SNAPPY_ONE_WAVE") != nullptr && atoi(getenv("COMET_SNAPPY_ONE_WAVE")) != 0;
-  auto finish_column = [&](const size_t c, const std::shared_ptr<ColumnDevice>& cd, const size_t S, const bool may_inflate) {
+  // (`dr`: the column has pages whose run headers the device walks — their descriptors, the prefix sum of their run counts and the total are there)
+  struct DeviceRuns { std::shared_ptr<DevBuf> pend, offsets; int npend = 0; int64_t total = 0; };
+  auto finish_column = [&](const size_t c, const std::shared_ptr<ColumnDevice>& cd, const size_t S, const bool may_inflate, const DeviceRuns* dr) {
     const ColumnPlan& cp = plans[c];
     const bool is_string = cp.is_string;
     auto values = std::make_shared<DevBuf>();
@@ -2016,13 +2040,14 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       n_zjobs += hc.zinflate.size();
     }
     if ((n_jobs || n_zjobs) && !may_inflate) throw CometError("internal: device pages in a column without a decompression region");
-    if (trace) fprintf(stderr, "[comet] parquet: column %zu host chunks ready at %.2f ms\n", c, ms_since());
+    if (trace) trace_line(scan_id, "column %zu host chunks ready at %.2f ms\n", c, ms_since());
     // concatenate the chunks' tables: offsets become column-global
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t o = 0;
     const size_t off_pages = o; o = al(o + n_pages * sizeof(PqPage));
     const size_t off_def = o; o = al(o + n_def * sizeof(PqRun) + 16);
-    const size_t off_idx = o; o = al(o + n_idx * sizeof(PqRun) + 16);
+    const size_t n_idx_dev = dr ? (size_t)dr->total : 0;      // runs the device writes behind the host's
+    const size_t off_idx = o; o = al(o + (n_idx + n_idx_dev) * sizeof(PqRun) + 16);
     const size_t off_dict = o; o = al(o + n_dict + 16);
     const size_t off_doffs = o; o = al(o + n_doffs * 4 + 16);
     const size_t off_soffs = o; o = al(o + n_soffs * 8 + 16);
@@ -2080,12 +2105,15 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         ido += hc.dict_offs.size();
         for (int64_t v : hc.str_offs) SO[iso++] = v ? v + base : 0;
       }
-      if (n_pages >= ((size_t)1 << 31) || n_idx >= ((size_t)1 << 31)) throw CometError("parquet: too many pages / runs in one column");
+      if (n_pages >= ((size_t)1 << 31) || n_idx + n_idx_dev >= ((size_t)1 << 31)) throw CometError("parquet: too many pages / runs in one column");
     }
     cd->tables.ensure(o + 16);
     upload(cd->tables.p, cd->h_tables.p, (o + 15) & ~(size_t)15);
     upload_fence(stream_);
     const char* tb = (const char*)cd->tables.p;
+    if (dr && dr->npend)      // the device-walked pages' runs go behind the host's; each such page's (first, count) is filled in on the device
+      pq_launch_write_runs((const PqPendingRuns*)dr->pend->p, dr->npend, (const uint8_t*)cd->bytes.p, (const int32_t*)dr->offsets->p, (int32_t)n_idx,
+                           (PqRun*)((char*)cd->tables.p + off_idx), (PqPage*)((char*)cd->tables.p + off_pages), stream_);
     if (n_jobs) {
       if (n_jobs >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
       // (the multi-kernel pipeline was launched group by group while the slices crossed PCIe, above)
@@ -2108,7 +2136,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     a.plain_str_offs = (const int64_t*)(tb + off_soffs);
     a.n_rows = total_rows;
     a.out_width = cp.out_width;
-    a.n_idx_runs = (int32_t)n_idx;
+    a.n_idx_runs = (int32_t)(n_idx + n_idx_dev);
     if (any_optional) {
       valid_bytes->ensure((size_t)total_rows + 16);
       if (!vidx->p) vidx->ensure((size_t)total_rows * 4 + 16);
@@ -2184,7 +2212,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     out.owners.push_back(valid_bytes);
     out.cols[c] = cv;
   };
-  struct Deferred { size_t c; std::shared_ptr<ColumnDevice> cd; size_t S; bool may_inflate; std::shared_ptr<PinnedBuf> readback; hipEvent_t done; std::vector<const uint8_t*> at; };
+  struct Deferred { size_t c; std::shared_ptr<ColumnDevice> cd; size_t S; bool may_inflate; std::shared_ptr<PinnedBuf> readback; hipEvent_t done; std::vector<const uint8_t*> at;
+                    DeviceRuns dr; std::shared_ptr<DevBuf> counts; };
   std::vector<Deferred> deferred;
   // (an error thrown while read-backs are in flight: they land in pinned staging memory that goes back to its pool — wait for them first)
   struct ReadbackGuard {
@@ -2259,7 +2288,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       }
       const double t_wait = trace ? ms_since() : 0;
       wait_for(c * nsel + si);
-      if (trace && ms_since() - t_wait > 0.3) fprintf(stderr, "[comet] parquet: column %zu waited %.2f ms for chunk %zu (until %.2f ms)\n", c, ms_since() - t_wait, si, ms_since());
+      if (trace && ms_since() - t_wait > 0.3) trace_line(scan_id, "column %zu waited %.2f ms for chunk %zu (until %.2f ms)\n", c, ms_since() - t_wait, si, ms_since());
       HostChunk& hc = chunks[c * nsel + si];
       // is the chunk behind this one ready too?  Then its slices join this batch (one launch for all of them)
       bool next_ready = false;
@@ -2316,19 +2345,34 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       if (group_full) {
         if (group_jobs.size() >= ((size_t)1 << 23) || zgroup_jobs.size() >= ((size_t)1 << 23)) throw CometError("parquet: too many pages in one column");
         const double t_launch = trace ? ms_since() : 0;
-        hipStream_t gs = next_group_stream();
-        upload_fence(gs);
+        // The pipelines' tables cross on the COPY stream, behind the page bytes; the group's stream is then fenced behind both and gets kernels
+        // only.  (A host → device copy queued on a stream that waits for another stream's event holds the calling thread until that event has
+        // happened: with the tables sent on the group's stream every launch here cost its task 7–10 ms — the time its page bytes needed to
+        // cross — and eight concurrent tasks issued nothing else meanwhile: profiles/r5_executor_trace.txt.)
+        Snappy2Scratch* sn = nullptr;
+        Zstd2Scratch* zs = nullptr;
         if (!group_jobs.empty()) {
           cd->snappy2.emplace_back(new Snappy2Scratch());
-          cd->snappy2.back()->run(group_jobs.data(), (int)group_jobs.size(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, gs);
+          sn = cd->snappy2.back().get();
+          sn->stage(group_jobs.data(), (int)group_jobs.size(), copy_stream);
         }
         if (!zgroup_jobs.empty()) {
           cd->zstd2.emplace_back(new Zstd2Scratch());
-          cd->zstd2.back()->run(zgroup_jobs.data(), (int)zgroup_jobs.size(), zgroup_blocks.data(), (uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, gs);
+          zs = cd->zstd2.back().get();
+          zs->stage(zgroup_jobs.data(), (int)zgroup_jobs.size(), zgroup_blocks.data(), copy_stream);
         }
-        if (trace) fprintf(stderr, "[comet] parquet: column %zu group of %zu snappy / %zu zstd pages (%zu blocks, %.1f MB) up to chunk %zu launched at %.2f ms\n", c, group_jobs.size(),
+        stream_dirty[0] = 1;
+        hipStream_t gs = next_group_stream();
+        const double t_stream = trace ? ms_since() : 0;
+        upload_fence(gs);
+        const double t_fence = trace ? ms_since() : 0;
+        if (sn) sn->launch((uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, gs);
+        if (zs) zs->launch((uint8_t*)cd->bytes.p, (uint32_t*)inflate_err->p + c, gs);
+        if (trace) trace_line(scan_id, "column %zu group of %zu snappy / %zu zstd pages (%zu blocks, %.1f MB) up to chunk %zu launched at %.2f ms\n", c, group_jobs.size(),
                            zgroup_jobs.size(), zgroup_blocks.size(), (double)group_bytes / 1e6, si, ms_since());
-        if (trace && ms_since() - t_launch > 0.3) fprintf(stderr, "[comet] parquet: … that launch took %.2f ms of this thread\n", ms_since() - t_launch);
+        if (trace && ms_since() - t_launch > 0.3)
+          trace_line(scan_id, "… that launch took %.2f ms of this thread (tables + stream %.2f, fence %.2f, kernels %.2f)\n", ms_since() - t_launch, t_stream - t_launch, t_fence - t_stream,
+                     ms_since() - t_fence);
         pages_inflated_on_device_ += (int64_t)(group_jobs.size() + zgroup_jobs.size());
         group_jobs.clear();
         zgroup_jobs.clear();
@@ -2345,10 +2389,56 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     size_t pending_bytes = 0;
     for (size_t si = 0; si < nsel; si++)
       for (const HostChunk::Pending& pe : chunks[c * nsel + si].pending) pending_bytes += ((pe.end - pe.begin) + 15) & ~(size_t)15;
+    if (pending_bytes && so.device_runs) {
+      // The device walks the run headers where the sections lie (device/pq_runs.hpp): one descriptor per page in the coordinates of the column's
+      // byte buffer, a count pass, a prefix sum — and FOUR BYTES come back (the total, which sizes the run table) instead of the sections.
+      Deferred d{c, cd, S, may_inflate, std::make_shared<PinnedBuf>(), get_event(), {}, {}, nullptr};
+      size_t npend = 0, page_base = 0;
+      for (size_t si = 0; si < nsel; si++) npend += chunks[c * nsel + si].pending.size();
+      if (npend >= ((size_t)1 << 30)) throw CometError("parquet: too many pages in one column");
+      d.readback->ensure(npend * sizeof(PqPendingRuns) + 128);
+      PqPendingRuns* pd = (PqPendingRuns*)d.readback->p;
+      size_t k = 0;
+      for (size_t si = 0; si < nsel; si++) {
+        const HostChunk& hc = chunks[c * nsel + si];
+        for (const HostChunk::Pending& pe : hc.pending) {
+          PqPendingRuns& x = pd[k++];
+          x.begin = (int64_t)(slot_off[c][si] + S + pe.begin);
+          x.end = (int64_t)(slot_off[c][si] + S + pe.end);
+          x.bit_width = hc.pages[pe.page].bit_width;
+          x.max_values = pe.values;
+          x.page = (int32_t)(page_base + pe.page);      // column-global: the chunks' pages are concatenated in row-group order (finish_column)
+          x.pad = 0;
+        }
+        page_base += hc.pages.size();
+      }
+      d.dr.pend = std::make_shared<DevBuf>();
+      d.dr.offsets = std::make_shared<DevBuf>();
+      d.counts = std::make_shared<DevBuf>();
+      d.dr.pend->ensure(npend * sizeof(PqPendingRuns) + 16);
+      d.counts->ensure(npend * 4 + 16);
+      d.dr.offsets->ensure((npend + 1) * 4 + 16);
+      d.dr.npend = (int)npend;
+      // (descriptors on the copy stream, stream_ fenced behind it: no host → device copy on a stream that waits — see the group launch above)
+      upload(d.dr.pend->p, pd, (npend * sizeof(PqPendingRuns) + 15) & ~(size_t)15);
+      upload_fence(stream_);
+      pq_launch_count_runs((const PqPendingRuns*)d.dr.pend->p, (int)npend, (const uint8_t*)cd->bytes.p, (uint32_t*)d.counts->p, (uint32_t*)inflate_err->p + c, stream_);
+      auto rtiles = std::make_shared<DevBuf>();
+      rtiles->ensure((size_t)((npend + 1023) / 1024 + 2) * 8);
+      pq_launch_u32_scan((const uint32_t*)d.counts->p, (int64_t)npend, (uint64_t*)rtiles->p, (int32_t*)d.dr.offsets->p, stream_);
+      out.owners.push_back(rtiles);
+      // the total lands behind the descriptors in the same pinned block, STORED there by a one-lane kernel (pinned host memory is device
+      // addressable): a device → host copy command on this stream would hold the calling thread until the decompression before it is done
+      pq_launch_store_u32((const uint32_t*)((char*)d.dr.offsets->p + npend * 4), (uint32_t*)((char*)d.readback->p + ((npend * sizeof(PqPendingRuns) + 15) & ~(size_t)15) + 16), stream_);
+      HIP_CHECK(hipEventRecord(d.done, stream_));
+      deferred.push_back(std::move(d));
+      if (trace) trace_line(scan_id, "column %zu: the device walks the run headers of %zu pages (%.1f MB of index sections stay where they are)\n", c, npend, (double)pending_bytes / 1e6);
+      continue;
+    }
     if (pending_bytes) {
       // where they land: the chunk's own pinned slot, between its staged bytes and the page bodies read in place — a device-inflated chunk
       // leaves that part (sized for host-inflated pages) unused; a chunk without the room gets a buffer of its own
-      Deferred d{c, cd, S, may_inflate, std::make_shared<PinnedBuf>(), get_event(), {}};
+      Deferred d{c, cd, S, may_inflate, std::make_shared<PinnedBuf>(), get_event(), {}, {}, nullptr};
       size_t spill = 0;
       for (size_t si = 0; si < nsel; si++) {
         const HostChunk& hc = chunks[c * nsel + si];
@@ -2375,15 +2465,27 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       }
       HIP_CHECK(hipEventRecord(d.done, stream_));
       deferred.push_back(std::move(d));
-      if (trace) fprintf(stderr, "[comet] parquet: column %zu waits for %.1f MB of index sections from the device\n", c, (double)pending_bytes / 1e6);
+      if (trace) trace_line(scan_id, "column %zu waits for %.1f MB of index sections from the device\n", c, (double)pending_bytes / 1e6);
       continue;
     }
-    finish_column(c, cd, S, may_inflate);
+    finish_column(c, cd, S, may_inflate, nullptr);
   }
-  if (trace && !deferred.empty()) fprintf(stderr, "[comet] parquet: uploads of all columns issued at %.2f ms\n", ms_since());
+  if (trace && !deferred.empty()) trace_line(scan_id, "uploads of all columns issued at %.2f ms\n", ms_since());
   for (Deferred& d : deferred) {
     HIP_CHECK(hipEventSynchronize(d.done));
-    if (trace) fprintf(stderr, "[comet] parquet: column %zu index sections back at %.2f ms\n", d.c, ms_since());
+    if (d.dr.npend) {
+      int32_t total = 0;
+      memcpy(&total, (char*)d.readback->p + (((size_t)d.dr.npend * sizeof(PqPendingRuns) + 15) & ~(size_t)15) + 16, 4);
+      if (total < 0) throw CometError("parquet: too many runs in one column");
+      d.dr.total = total;
+      if (trace) trace_line(scan_id, "column %zu: %d runs counted on the device at %.2f ms\n", d.c, total, ms_since());
+      finish_column(d.c, d.cd, d.S, d.may_inflate, &d.dr);
+      out.owners.push_back(d.dr.pend);
+      out.owners.push_back(d.dr.offsets);
+      out.owners.push_back(d.counts);
+      continue;
+    }
+    if (trace) trace_line(scan_id, "column %zu index sections back at %.2f ms\n", d.c, ms_since());
     // the run headers of every pending page, parsed on the scan threads (a chunk per task), positions in the coordinates of the
     // device-decompressed region — where the decode kernels will read the indices
     std::vector<std::exception_ptr> errs(nsel);
@@ -2433,8 +2535,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     }
     for (auto& e : errs)
       if (e) std::rethrow_exception(e);
-    if (trace) fprintf(stderr, "[comet] parquet: column %zu run headers parsed at %.2f ms\n", d.c, ms_since());
-    finish_column(d.c, d.cd, d.S, d.may_inflate);
+    if (trace) trace_line(scan_id, "column %zu run headers parsed at %.2f ms\n", d.c, ms_since());
+    finish_column(d.c, d.cd, d.S, d.may_inflate, nullptr);
   }
   readback_guard.done = true;
   // Hive partition columns: one constant per file (SparkPartitionedFile.partition_values, operator.proto:103-109), appended after
@@ -2524,11 +2626,17 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     out.owners.push_back(vbytes);
     out.cols[ncol + p] = cv;
   }
-  if (trace) fprintf(stderr, "[comet] parquet: all launches issued at %.2f ms\n", ms_since());
-  if (trace) fprintf(stderr, "[comet] parquet: scan threads spent %.2f ms on chunks: %.2f reading, %.2f walking zstd frames, %.2f inflating pages\n", (double)g_ns_chunk.exchange(0) / 1e6,
+  if (trace) trace_line(scan_id, "all launches issued at %.2f ms\n", ms_since());
+  if (trace) trace_line(scan_id, "scan threads spent %.2f ms on chunks: %.2f reading, %.2f walking zstd frames, %.2f inflating pages\n", (double)g_ns_chunk.exchange(0) / 1e6,
                      (double)g_ns_read.exchange(0) / 1e6, (double)g_ns_walk.exchange(0) / 1e6, (double)g_ns_inflate.exchange(0) / 1e6);
   HIP_CHECK(hipStreamSynchronize(stream_));
-  if (trace) fprintf(stderr, "[comet] parquet: device idle at %.2f ms\n", ms_since());
+  if (trace) trace_line(scan_id, "device idle at %.2f ms\n", ms_since());
+  if (trace) {
+    int64_t miss1[4];
+    pool_miss_counters(miss1);
+    trace_line(scan_id, "pool misses while this scan ran (process-wide): %lld hipMalloc (%.2f ms), %lld hipHostMalloc (%.2f ms)\n", (long long)(miss1[0] - miss0[0]),
+               (double)(miss1[1] - miss0[1]) / 1e6, (long long)(miss1[2] - miss0[2]), (double)(miss1[3] - miss0[3]) / 1e6);
+  }
   {
     std::vector<uint32_t> ierr(ncol, 0);
     for (size_t c0 = 0; c0 < ncol; c0 += 512) {   // read_small carries up to 4 KiB
@@ -2543,18 +2651,18 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   out.owners.push_back(vidx);
   // staging buffers can go back to the pools now that the stream is idle
   keep.clear();
-  if (trace) fprintf(stderr, "[comet] parquet: device buffers released at %.2f ms\n", ms_since());
+  if (trace) trace_line(scan_id, "device buffers released at %.2f ms\n", ms_since());
   // the run tables are many large vectors (one munmap each when freed): give them to a throw-away thread instead of paying
   // ~5 ms of page-table teardown on the query's critical path
   {
     auto* garbage = new std::vector<HostChunk>(std::move(chunks));
     std::thread([garbage]() { delete garbage; }).detach();
   }
-  if (trace) fprintf(stderr, "[comet] parquet: host tables handed off at %.2f ms\n", ms_since());
+  if (trace) trace_line(scan_id, "host tables handed off at %.2f ms\n", ms_since());
   col_staged.clear();
-  if (trace) fprintf(stderr, "[comet] parquet: staging released at %.2f ms\n", ms_since());
+  if (trace) trace_line(scan_id, "staging released at %.2f ms\n", ms_since());
   sels.clear();
-  if (trace) fprintf(stderr, "[comet] parquet: files closed at %.2f ms\n", ms_since());
+  if (trace) trace_line(scan_id, "files closed at %.2f ms\n", ms_since());
   return out;
 }
 

@@ -23,6 +23,12 @@ namespace comet {
 using namespace comet_snappy2;
 
 void Snappy2Scratch::run(const PqInflate* jobs_host, int njobs, uint8_t* bytes_dev, uint32_t* err_dev, hipStream_t st) {
+  stage(jobs_host, njobs, st);
+  launch(bytes_dev, err_dev, st);
+}
+
+void Snappy2Scratch::stage(const PqInflate* jobs_host, int njobs, hipStream_t copy_st) {
+  njobs_ = njobs;
   if (njobs <= 0) return;
   std::vector<i64> so((size_t)njobs), dof((size_t)njobs);
   std::vector<i32> sl((size_t)njobs), dl((size_t)njobs), body((size_t)njobs);
@@ -54,22 +60,28 @@ void Snappy2Scratch::run(const PqInflate* jobs_host, int njobs, uint8_t* bytes_d
   if (pl.nchunks) memcpy((char*)h_tables.p + o_cp, pl.chunk_page.data(), 4 * (size_t)pl.nchunks);
   if (pl.nfrags) memcpy((char*)h_tables.p + o_fp, pl.frag_page.data(), 4 * (size_t)pl.nfrags);
   tables.ensure(total + 16);
-  HIP_CHECK(hipMemcpyAsync(tables.p, h_tables.p, total, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(tables.p, h_tables.p, total, hipMemcpyHostToDevice, copy_st));
   fns.ensure(sizeof(ChunkFn) * (size_t)pl.nchunks * kWin + 16);
   ins.ensure(sizeof(ChunkIn) * (size_t)pl.nchunks + 16);
   elems.ensure(sizeof(Elem) * (size_t)nelems + 16);
-  status.ensure(4 * (size_t)njobs + 16);
   frag_chunk.ensure(4 * (size_t)pl.nfrags + 16);
+  status = (uint32_t*)((char*)tables.p + o_st);      // the per-page status words live where their initial values were uploaded
+  nchunks_ = pl.nchunks;
+  nfrags_ = pl.nfrags;
+  o_pages_ = o_pages; o_cp_ = o_cp; o_fp_ = o_fp; o_st_ = o_st; o_jobs_ = o_jobs;
+}
+
+void Snappy2Scratch::launch(uint8_t* bytes_dev, uint32_t* err_dev, hipStream_t st) {
+  if (njobs_ <= 0) return;
   char* tb = (char*)tables.p;
-  HIP_CHECK(hipMemcpyAsync(status.p, tb + o_st, 4 * (size_t)njobs, hipMemcpyDeviceToDevice, st));
-  sn2_launch_window(tb + o_pages, (const int32_t*)(tb + o_cp), bytes_dev, fns.p, (const uint32_t*)status.p, pl.nchunks, st);
-  sn2_launch_chain(tb + o_pages, njobs, bytes_dev, fns.p, ins.p, (int32_t*)frag_chunk.p, (uint32_t*)status.p, st);
-  sn2_launch_emit(tb + o_pages, (const int32_t*)(tb + o_cp), bytes_dev, ins.p, elems.p, (const uint32_t*)status.p, pl.nchunks, st);
-  sn2_launch_exec(tb + o_pages, (const int32_t*)(tb + o_fp), bytes_dev, elems.p, ins.p, (const int32_t*)frag_chunk.p, (uint32_t*)status.p, pl.nfrags, st);
+  sn2_launch_window(tb + o_pages_, (const int32_t*)(tb + o_cp_), bytes_dev, fns.p, (const uint32_t*)status, nchunks_, st);
+  sn2_launch_chain(tb + o_pages_, njobs_, bytes_dev, fns.p, ins.p, (int32_t*)frag_chunk.p, status, st);
+  sn2_launch_emit(tb + o_pages_, (const int32_t*)(tb + o_cp_), bytes_dev, ins.p, elems.p, (const uint32_t*)status, nchunks_, st);
+  sn2_launch_exec(tb + o_pages_, (const int32_t*)(tb + o_fp_), bytes_dev, elems.p, ins.p, (const int32_t*)frag_chunk.p, status, nfrags_, st);
   // what the pipeline would not decode — legal streams that are not fragment-shaped — goes to the one-wave kernel; errors to `err`
-  pq_launch_snappy_fallback((const PqInflate*)(tb + o_jobs), njobs, bytes_dev, (const uint32_t*)status.p, err_dev, st);
-  chunks_ += pl.nchunks;
-  frags_ += pl.nfrags;
+  pq_launch_snappy_fallback((const PqInflate*)(tb + o_jobs_), njobs_, bytes_dev, (const uint32_t*)status, err_dev, st);
+  chunks_ += nchunks_;
+  frags_ += nfrags_;
 }
 
 }  // namespace comet
@@ -127,7 +139,7 @@ extern "C" int64_t comet_snappy2_inflate_pages(const uint8_t* streams, const int
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (kernel_ms) *kernel_ms = (double)ms;
-    if (status_out) HIP_CHECK(hipMemcpy(status_out, sc.status.p, 4 * (size_t)npages, hipMemcpyDeviceToHost));
+    if (status_out) HIP_CHECK(hipMemcpy(status_out, sc.status, 4 * (size_t)npages, hipMemcpyDeviceToHost));
     uint32_t h_err = 0;
     HIP_CHECK(hipMemcpy(&h_err, derr.p, 4, hipMemcpyDeviceToHost));
     if (h_err) return (int64_t)h_err;

@@ -22,12 +22,18 @@ namespace comet {
 using namespace comet_zstd2;
 
 void Zstd2Scratch::run(const PqInflate* jobs_host, int njobs, const ZBlock* blocks_host, uint8_t* bytes_dev, uint32_t* err_dev, hipStream_t st) {
+  stage(jobs_host, njobs, blocks_host, st);
+  launch(bytes_dev, err_dev, st);
+}
+
+void Zstd2Scratch::stage(const PqInflate* jobs_host, int njobs, const ZBlock* blocks_host, hipStream_t copy_st) {
+  njobs_ = njobs;
   if (njobs <= 0) return;
   int64_t nblocks = 0, nrecs = 0, nlits = 0;
   for (int i = 0; i < njobs; i++) nblocks += jobs_host[i].pad;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t b_pages = sizeof(ZPage) * (size_t)njobs, b_blocks = sizeof(ZBlock) * (size_t)nblocks + 16, b_bp = 4 * (size_t)nblocks + 16;
-  const size_t o_pages = 0, o_blocks = al(b_pages), o_bp = o_blocks + al(b_blocks), o_ord = o_bp + al(b_bp), total = o_ord + al(b_bp);
+  const size_t o_pages = 0, o_blocks = al(b_pages), o_bp = o_blocks + al(b_blocks), o_ord = o_bp + al(b_bp), o_st = o_ord + al(b_bp), total = o_st + al(4 * (size_t)njobs + 16);
   h_tables.ensure(total + 16);
   ZPage* P = (ZPage*)((char*)h_tables.p + o_pages);
   ZBlock* B = (ZBlock*)((char*)h_tables.p + o_blocks);
@@ -67,20 +73,27 @@ void Zstd2Scratch::run(const PqInflate* jobs_host, int njobs, const ZBlock* bloc
     for (size_t k = 1; k < count.size(); k++) count[k] += count[k - 1];
     for (int64_t k = 0; k < nblocks; k++) ORD[count[(size_t)bucket(B[k])]++] = (int32_t)k;
   }
+  memset((char*)h_tables.p + o_st, 0, 4 * (size_t)njobs + 16);      // the per-page status words start clear
   tables.ensure(total + 16);
-  HIP_CHECK(hipMemcpyAsync(tables.p, h_tables.p, total, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(tables.p, h_tables.p, total, hipMemcpyHostToDevice, copy_st));
   recs.ensure(sizeof(ZRec) * (size_t)nrecs + 64);
   lits.ensure((size_t)nlits + 64);
-  status.ensure(4 * (size_t)njobs + 16);
-  HIP_CHECK(hipMemsetAsync(status.p, 0, 4 * (size_t)njobs, st));
+  status = (uint32_t*)((char*)tables.p + o_st);
+  nblocks_ = nblocks;
+  nrecs_ = nrecs;
+  o_pages_ = o_pages; o_blocks_ = o_blocks; o_bp_ = o_bp; o_ord_ = o_ord;
+}
+
+void Zstd2Scratch::launch(uint8_t* bytes_dev, uint32_t* err_dev, hipStream_t st) {
+  if (njobs_ <= 0) return;
   char* tb = (char*)tables.p;
-  zs2_launch_entropy(tb + o_pages, tb + o_blocks, (const int32_t*)(tb + o_bp), (const int32_t*)(tb + o_ord), bytes_dev, (uint8_t*)lits.p, recs.p, (uint32_t*)status.p, nblocks, st);
-  zs2_launch_blocks(tb + o_pages, njobs, tb + o_blocks, (uint32_t*)status.p, st);
-  zs2_launch_scan(tb + o_pages, tb + o_blocks, (const int32_t*)(tb + o_bp), recs.p, (uint32_t*)status.p, nblocks, st);
-  zs2_launch_exec(tb + o_pages, njobs, bytes_dev, (const uint8_t*)lits.p, recs.p, (uint32_t*)status.p, st);
-  zs2_launch_report((const uint32_t*)status.p, njobs, err_dev, st);
-  blocks_ += nblocks;
-  records_ += nrecs;
+  zs2_launch_entropy(tb + o_pages_, tb + o_blocks_, (const int32_t*)(tb + o_bp_), (const int32_t*)(tb + o_ord_), bytes_dev, (uint8_t*)lits.p, recs.p, status, nblocks_, st);
+  zs2_launch_blocks(tb + o_pages_, njobs_, tb + o_blocks_, status, st);
+  zs2_launch_scan(tb + o_pages_, tb + o_blocks_, (const int32_t*)(tb + o_bp_), recs.p, status, nblocks_, st);
+  zs2_launch_exec(tb + o_pages_, njobs_, bytes_dev, (const uint8_t*)lits.p, recs.p, status, st);
+  zs2_launch_report((const uint32_t*)status, njobs_, err_dev, st);
+  blocks_ += nblocks_;
+  records_ += nrecs_;
 }
 
 }  // namespace comet
@@ -145,7 +158,7 @@ extern "C" int64_t comet_zstd2_inflate_pages(const uint8_t* streams, const int64
     (void)hipEventDestroy(e1);
     if (kernel_ms) *kernel_ms = (double)ms;
     std::vector<uint32_t> st_host(jobs.size());
-    HIP_CHECK(hipMemcpy(st_host.data(), sc.status.p, 4 * jobs.size(), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(st_host.data(), sc.status, 4 * jobs.size(), hipMemcpyDeviceToHost));
     int64_t rc = 0;
     for (size_t k = 0; k < jobs.size(); k++) {
       const int i = job_page[k];

@@ -44,6 +44,11 @@ zstd_bench() {     # the 480-page zstd pipeline (levels 1 and 3) + per-kernel st
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/zstd_stats -o z -- python $GRAFT_REPO_ROOT/tools/snappy_bench.py --codec zstd --level 1 --pages 480 --kinds decimal_int64 --no-check > /dev/null 2>&1)
   grep -E '^"(zs2|sn2|pq_)' $OUT/zstd_stats/z_kernel_stats.csv | cut -c1-120
 }
+dict_idx_bench() { # the decompression pipelines on the index sections of dictionary-encoded pages (bit-packed random indices: raw or Huffman-only blocks under zstd)
+  for C in zstd snappy; do
+    timeout 120 python tools/snappy_bench.py --codec $C --level 1 --pages 240 --skip-one-wave --kinds dict_idx_bw4,dict_idx_bw6,dict_idx_bw12 --out $OUT/dict_idx_$C.json > /dev/null 2> $OUT/dict_idx_$C.err; cut -c1-700 $OUT/dict_idx_$C.json; echo
+  done
+}
 snappy_bench() {
   timeout 200 python tools/snappy_bench.py --pages 480 --out $OUT/snappy_bench.json > /dev/null 2> $OUT/snappy_bench.err; cut -c1-900 $OUT/snappy_bench.json; echo
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/snappy_stats -o s -- python $GRAFT_REPO_ROOT/tools/snappy_bench.py --pages 480 --kinds decimal_int64 --no-check --skip-one-wave > /dev/null 2>&1)
@@ -110,6 +115,22 @@ for k,v in d['legs'].items():
   for t,e in v.items():
     if t.startswith('tasks_'): print(k,t,{a:(round(b,3) if isinstance(b,float) else b) for a,b in e.items()})" 2>&1 | tail -12; tail -3 $OUT/executor.log | cut -c1-300
 }
+executor_envs() {  # the executor leg under environment switches: "$EXEC_ENVS" = ;-separated "VAR=a,VAR2=b" entries ("-" = none); legs in $EXEC_LEGS
+  IFS=';' read -ra ENTRIES <<< "${EXEC_ENVS:--}"
+  for E in "${ENTRIES[@]}"; do
+    N=exec_$(echo "$E" | tr -c 'A-Za-z0-9_\n' '_')
+    env $([ "$E" = "-" ] || echo $E | tr ',' ' ') timeout 300 python tools/executor_bench.py --dir $PQ --steps ${EXEC_STEPS:-3} --no-link --legs ${EXEC_LEGS:-parquet_snappy,parquet_zstd} --out $OUT/$N.json > $OUT/$N.log 2>&1
+    echo "== $E: $(python -c "
+import json;d=json.load(open('$OUT/$N.json'))
+print('  '.join(f'{k}/{t}: {e[\"wall_ms\"]:.1f} ms' for k,v in d['legs'].items() for t,e in v.items() if t.startswith('tasks_')))" 2>&1 | tail -1)"
+  done
+}
+executor_trace() { # one traced wave of 8 one-core tasks per codec: every task's stage lines (times relative to its own scan's start)
+  for L in ${EXEC_LEGS:-parquet_snappy parquet_zstd}; do
+    COMET_TRACE_STAGES=1 timeout 300 python tools/executor_bench.py --dir $PQ --steps 2 --no-link --tasks 8 --legs $L > /dev/null 2> $OUT/exec_trace_$L.log
+    echo "== $L: $(grep -c 'device idle' $OUT/exec_trace_$L.log) scans traced"; grep "device idle\|all launches\|scan threads spent" $OUT/exec_trace_$L.log | tail -24 | cut -c1-200
+  done
+}
 q95_stats() {      # kernel statistics of TPC-DS Q95 stage A on one GPU
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q95_stats -o q95 -- python $GRAFT_REPO_ROOT/tools/q95_bench.py --orders 16000000 --reps 2 --verify none > $OUT/q95_stats.log 2>&1)
   python - <<PYEOF
@@ -118,6 +139,22 @@ rows=list(csv.DictReader(open("$OUT/q95_stats/q95_kernel_stats.csv")))
 for r in rows[:14]:
     m=re.search(r"(k_\w+|[a-z_0-9]+_kernel|__amd\w+)", r["Name"]); print(f'{(m.group(1) if m else r["Name"][:30]):28s} calls {r["Calls"]:>4s} total_ms {float(r["TotalDurationNs"])/1e6:9.3f} avg_ms {float(r["AverageNs"])/1e6:8.3f}')
 PYEOF
+}
+q95_bisect() {     # TPC-DS Q95 stage A with the libraries of earlier commits (bisect/<tag>/, built from git worktrees) and with HEAD's join switches, on ONE box
+  for v in $(ls bisect 2>/dev/null); do timeout 200 python tools/q95_variant.py --root bisect/$v --tag $v 2> $OUT/q95_$v.err | tee -a $OUT/q95_bisect.jsonl | cut -c1-300; done
+  timeout 200 python tools/q95_variant.py --root . --tag head 2> $OUT/q95_head.err | tee -a $OUT/q95_bisect.jsonl | cut -c1-300
+  for E in ${Q95_ENVS:-COMET_JOIN_KEYMAP=0 COMET_JOIN_DIRECT=0 COMET_JOIN_COUNT_RUNS=0}; do
+    env $E timeout 200 python tools/q95_variant.py --root . --tag "head $E" 2> $OUT/q95_env.err | tee -a $OUT/q95_bisect.jsonl | cut -c1-300
+  done
+  for v in ${Q95_STATS:-r3 head}; do
+    R=bisect/$v; [ $v = head ] && R=.
+    (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q95_stats_$v -o q -- python $GRAFT_REPO_ROOT/tools/q95_variant.py --root $GRAFT_REPO_ROOT/$R --reps 2 > /dev/null 2>&1)
+    echo "== kernel stats $v (3 runs)"; python tools/kernel_stats_csv.py $OUT/q95_stats_$v/q_kernel_stats.csv 14 2>&1 | cut -c1-150 | tee $OUT/q95_kernel_stats_$v.txt
+  done
+}
+small_legs() {     # the bench legs' tools at toy sizes: a typo must not cost a full-size run
+  timeout 200 python tools/q3_dist.py --orders 1500000 --steps 1 --warmup 1 --kernel-times 2>&1 | tail -1 | cut -c1-1500
+  timeout 200 python tools/q95_dist.py --orders 200000 --steps 1 --warmup 1 --kernel-times 2>&1 | tail -1 | cut -c1-1500
 }
 read_probe() {     # page cache -> pinned memory -> device, nothing else: what bounds a scan before the GPU sees a byte
   ls $PQ/*.parquet > /dev/null 2>&1 || timeout 200 python tools/parquet_q6.py --codec snappy --dir $PQ --steps 1 > /dev/null 2>&1

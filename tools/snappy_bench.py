@@ -31,6 +31,21 @@ def main():
         "double": lambda: rng.standard_normal(n8).tobytes(),
         "int32_lowcard": lambda: rng.integers(0, 50, a.page_bytes // 4).astype(np.int32).tobytes(),
     }
+    def dict_indices(card, bw):
+        """the index section of a dictionary-encoded page as parquet-cpp writes it: bit-packed runs of 63 groups of eight random indices"""
+        def gen():
+            out = bytearray()
+            while len(out) < a.page_bytes:
+                v = rng.integers(0, card, 504).astype(np.uint64)
+                bits = np.zeros(504 * bw, np.uint8)
+                for b in range(bw):
+                    bits[b::bw] = (v >> np.uint64(b)) & np.uint64(1)
+                out += bytes([(63 << 1) | 1]) + np.packbits(bits, bitorder="little").tobytes()
+            return bytes(out[:a.page_bytes])
+        return gen
+    kinds["dict_idx_bw4"] = dict_indices(11, 4)        # l_discount / l_tax: 11 / 9 distinct values
+    kinds["dict_idx_bw6"] = dict_indices(50, 6)        # l_quantity
+    kinds["dict_idx_bw12"] = dict_indices(2526, 12)    # l_shipdate
     res = {"pages": a.pages, "page_bytes": a.page_bytes, "codec": a.codec}
     if a.codec == "zstd":
         res["level"] = a.level
