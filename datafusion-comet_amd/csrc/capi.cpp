@@ -77,12 +77,26 @@ auto guarded(ExecutionContext* ctx, decltype(std::declval<F>()()) err_value, F f
 
 }  // namespace
 
+
+// COMET_TRACE_STAGES: every plan call with its begin on the process clock (the same clock the scan traces use), so that the calls of
+// concurrent tasks can be laid side by side
+struct ApiTrace {
+  const char* what; int64_t handle; double t0; bool on;
+  ApiTrace(const char* w, int64_t h) : what(w), handle(h), t0(0), on(false) {
+    static const bool trace = getenv("COMET_TRACE_STAGES") != nullptr;
+    on = trace;
+    if (on) t0 = comet::process_clock_ms();
+  }
+  ~ApiTrace() { if (on) fprintf(stderr, "[comet] api: %s of plan %lld began at %.2f ms of the process clock, took %.2f ms\n", what, (long long)handle, t0, comet::process_clock_ms() - t0); }
+};
+
 extern "C" {
 
 int64_t comet_create_plan(const uint8_t* plan, size_t plan_len, const uint8_t* config, size_t config_len, void** inputs,
                           const int32_t* input_kinds, int32_t n_inputs, int32_t partition_count, int32_t batch_size,
                           int32_t device_id) {
   (void)partition_count;
+  ApiTrace api_trace("createPlan", 0);
   return guarded(nullptr, (int64_t)0, [&]() -> int64_t {
     // Ownership of every input stream passes to the library with this call (the reference takes the C structs over as soon as it has
     // their addresses): whatever fails below — plan decoding, an unknown input kind, planning itself — each stream is released once.
@@ -282,6 +296,7 @@ int64_t comet_execute_plan(int64_t handle, struct ArrowArray** out_arrays, struc
     t_last_error = "invalid plan handle";
     return -2;
   }
+  ApiTrace api_trace("executePlan", handle);
   return guarded(ctx.get(), (int64_t)-2, [&]() -> int64_t { return ctx->execute(out_arrays, out_schemas, n_out); });
 }
 
@@ -303,6 +318,7 @@ void comet_release_plan(int64_t handle) {
     ctx = it->second;
     g_ctx.erase(it);
   }
+  ApiTrace api_trace("releasePlan", handle);
   guarded(nullptr, 0, [&]() -> int {
     std::shared_ptr<MemAccount> mem = ctx->memory_account();
     ctx.reset();          // (another thread still inside a call keeps the context alive until it returns)

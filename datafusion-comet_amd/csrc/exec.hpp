@@ -21,6 +21,7 @@
 #include "plan.hpp"
 
 namespace comet {
+double process_clock_ms();      // exec_util.cpp
 
 // Native memory one plan (one Spark task) holds, the way the reference's CometUnifiedMemoryPool reports it
 // (native/core/src/execution/memory_pools/unified_pool.rs:64-150): every growth of PINNED HOST staging asks the host's memory manager

@@ -1,7 +1,14 @@
+#include <chrono>
 // Small host helpers shared by the execution engine: type widths, bit copies, Arrow format checks, ScanExec's casts.
 #include "exec_internal.hpp"
 
 namespace comet {
+
+// milliseconds since the first call in this process (COMET_TRACE_STAGES lines of concurrent tasks share this clock)
+double process_clock_ms() {
+  static const auto epoch = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - epoch).count();
+}
 namespace detail {
 
 

@@ -346,6 +346,9 @@ struct ScanOptions {
                                        // (one serial LDS-lookup chain per literal stream) where a host core does 6 GB/s — 87 vs 38 ms with 16 scan threads, 111 vs 97 ms with one
   bool device_runs = true;             // … and the run headers of those index sections are walked ON THE DEVICE (device/pq_runs.hpp: count, prefix sum, write — four bytes come back instead of
                                        // the sections); COMET_DEVICE_RUNS=0: the round-3 path, sections read back and parsed by the scan threads
+  bool device_runs_snappy = false;     // snappy: a dictionary-encoded page's run headers are walked on the device too instead of being read THROUGH the compressed stream by the scan thread
+                                       // (SnappyView: ≈ 6 µs of a scan thread per page — 9.6 of the 17 ms a one-core task spent preparing its 1500 pages, profiles/r5_executor_wave.txt); decided per scan from
+                                       // its scan threads (scan_parquet), COMET_DEVICE_RUNS_SNAPPY=0/1 forces it.  Pruned scans keep the host walk (their pages' runs are clipped on the host)
   bool device_zstd = true;             // zstd PLAIN pages of fixed-width columns take the device pipeline too (COMET_DEVICE_ZSTD=0: host threads inflate them)
   bool read_in_place = true;           // chunks whose pages the device inflates are pread() straight into their pinned slot; page bodies are uploaded from where they land (COMET_PARQUET_READ_IN_PLACE=0: read into scratch, copy bodies)
   bool device_dict_pages = true;       // dictionary-encoded snappy pages cross PCIe compressed too (COMET_DEVICE_DICT_PAGES=0: host-inflated as before)
@@ -1170,9 +1173,12 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     // hundred header bytes — decompressing these pages on host threads was what the scan waited for once the PLAIN pages had moved to
     // the device (SF10 Q6: 8 of 14 ms).  A page that compresses into many elements is inflated on the host as before (it is small).
     pq::SnappyView view;
-    const bool dev_dict = dev_shape && !dev_page && (h.encoding == pq::RLE_DICTIONARY || h.encoding == pq::PLAIN_DICTIONARY) && so.device_dict_pages &&
-                          view.build(body + (h.type == pq::DATA_PAGE ? 0 : h.def_bytes), (size_t)h.compressed_size - (h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes), 2048) &&
-                          view.out_len == (size_t)h.uncompressed_size - (h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes);
+    const bool dict_enc = dev_shape && !dev_page && (h.encoding == pq::RLE_DICTIONARY || h.encoding == pq::PLAIN_DICTIONARY) && so.device_dict_pages;
+    // (the device walks the run headers once it has inflated the page — nothing of the stream is looked at here but its first bytes)
+    const bool walk_on_device = dict_enc && so.device_runs && so.device_runs_snappy && src.keep == nullptr;
+    const bool dev_dict = walk_on_device ||
+                          (dict_enc && view.build(body + (h.type == pq::DATA_PAGE ? 0 : h.def_bytes), (size_t)h.compressed_size - (h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes), 2048) &&
+                           view.out_len == (size_t)h.uncompressed_size - (h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes));
     dev_page = dev_page || dev_dict;
     if (dev_page) {
       const size_t ipage = (hc.ipos + 15) & ~(size_t)15;
@@ -1186,8 +1192,9 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
           memcpy(&dl, pre, 4);
           lvl = 4 + (size_t)dl;
           if (lvl > un_len) throw CometError("parquet: definition levels longer than their page");
-          tmp.resize(lvl + 8);
-          if (pq::snappy_prefix(body, comp_len, tmp.data(), lvl) != lvl) throw CometError("parquet: data page shorter than its definition levels");
+          const size_t want = lvl + (walk_on_device && lvl < un_len ? 1 : 0);      // … and the index section's first byte, the bit width
+          tmp.resize(want + 8);
+          if (pq::snappy_prefix(body, comp_len, tmp.data(), want) != want) throw CometError("parquet: data page shorter than its definition levels");
           const size_t first = def_runs.size();
           pg.def_run_first = (int32_t)first;
           // positions in the coordinates of the decompressed region, where the device will put these same bytes
@@ -1236,12 +1243,24 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
         if (lvl + 1 > un_len) throw CometError("parquet: dictionary-encoded page without a bit width");
         auto get = [&](size_t p) { return view.at(p - ipage); };
         pg.encoding = 1;
-        pg.bit_width = get(ipage + lvl);
+        if (!walk_on_device) {
+          pg.bit_width = get(ipage + lvl);
+        } else if (h.type == pq::DATA_PAGE && max_def > 0) {
+          pg.bit_width = tmp[lvl];
+        } else {
+          uint8_t b0 = 0;
+          if (pq::snappy_prefix(body + comp_off, comp_len, &b0, 1) != 1) throw CometError("parquet: dictionary-encoded page without a bit width");
+          pg.bit_width = b0;
+        }
         if (pg.bit_width > 32) throw CometError("parquet: dictionary index bit width > 32");
         pg.values_off = (int64_t)(ipage + lvl + 1) | kInflatedBit;
         const size_t first = idx_runs.size();
         pg.idx_run_first = (int32_t)first;
-        if (pg.bit_width == 0) {
+        const bool is_pending = walk_on_device && pg.bit_width != 0 && lvl + 1 < un_len;
+        if (is_pending) {
+          // PENDING, like a zstd page of this kind: the column's deferred step counts, places and writes the runs on the device (read_columns)
+          hc.pending.push_back({pages.size(), ipage + lvl + 1, ipage + un_len, -1});
+        } else if (pg.bit_width == 0 || walk_on_device) {      // every index is 0 / a page of NULLs only: one run, nothing to walk
           PqRun r;
           memset(&r, 0, sizeof r);
           r.is_rle = 1;
@@ -1252,7 +1271,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
           for (size_t r = first; r < idx_runs.size(); r++) idx_runs[r].byte_off |= kInflatedBit;
         }
         pg.idx_run_count = (int32_t)(idx_runs.size() - first);
-        if (pg.idx_run_count == 0) {   // page of NULLs only
+        if (pg.idx_run_count == 0 && !is_pending) {   // page of NULLs only
           PqRun r;
           memset(&r, 0, sizeof r);
           r.is_rle = 1;
@@ -1686,7 +1705,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (total_rows == 0) return out;
   if (total_rows >= ((int64_t)1 << 31)) throw CometError("GPU Parquet scan: more than 2^31 rows in one partition");
 
-  if (trace) trace_line(scan_id, "footers + row-group selection done at %.2f ms\n", ms_since());
+  if (trace) trace_line(scan_id, "scan began at %.2f ms of the process clock; footers + row-group selection done at %.2f ms\n", process_clock_ms() - ms_since(), ms_since());
   // Host threads prepare the column chunks (decompression dominates: ~1 GB/s per core for zstd) straight into one pinned
   // block per column; this thread concatenates a finished column's tables, uploads and decodes the whole column at once.
   // spark.comet.gpu.scanThreads / COMET_SCAN_THREADS bound the pool.
@@ -1744,6 +1763,16 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   int max_inflight = ScanPool::get().size();
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scanThreads") max_inflight = std::max(1, atoi(kv.second.c_str()));
+  const int host_threads = std::max(1, std::min(max_inflight, ScanPool::get().size()));
+  // A task with a few scan threads (a Spark task owns ONE core) leaves to the device whatever the device can do: the index sections of
+  // dictionary-encoded pages are inflated there whatever the codec (zstd: 31 of the 84 ms a one-thread scan of SF10 Q6 spent, now 61 ms) and their
+  // run headers are walked there (snappy: the look through the compressed stream was 9.6 of a task's 17 ms).  A scan with a dozen threads keeps
+  // both on the host: its threads are idle anyway, and a column whose run table the device sizes is decoded one host round trip later
+  // (SF10 Q6 with 32 threads: zstd 16.9 against 15.0 ms).
+  static const int kFewThreads = getenv("COMET_PQ_FEW_THREADS") ? atoi(getenv("COMET_PQ_FEW_THREADS")) : 4;
+  if (getenv("COMET_DEVICE_ZSTD_DICT") == nullptr) so.device_zstd_dict = host_threads <= kFewThreads;
+  so.device_runs_snappy = host_threads <= kFewThreads;
+  if (const char* e = getenv("COMET_DEVICE_RUNS_SNAPPY")) so.device_runs_snappy = atoi(e) != 0;
   // Columns are taken largest first: the big PLAIN columns are the ones whose pages the device decompresses, and that kernel then runs
   // while the host threads are still preparing the small (dictionary-encoded) columns.
   std::vector<size_t> order(ncol);
@@ -1779,7 +1808,6 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   // zstd (profiles/r3_zstd_pipeline.json): the sequence decoder is one scalar lane per 128 KiB block — what bounds it is that lane's
   // instruction count, not the number of blocks — so the device inflates at a rate that a host with a dozen idle cores matches; a Spark
   // task, which owns one core, is better off on the device by a wide margin.
-  const int host_threads = std::max(1, std::min(max_inflight, ScanPool::get().size()));
   if (so.device_snappy_mode >= 0) {
     so.device_snappy = so.device_snappy_mode != 0;
   } else {
@@ -1852,35 +1880,38 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   // Spark task that owns one core), each from the shared cursor until none is left
   const size_t nworkers = std::min<size_t>(npieces, (size_t)std::max(1, std::min(max_inflight, ScanPool::get().size())));
   std::mutex piece_err_mu;
+  auto process_piece = [&, prog](size_t pi) {
+    const Piece& pc = pieces[pi];
+    const size_t t = pc.t;
+    if (!pc.whole && !prog->cancelled.load()) {
+      try {
+        read_piece(pc);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(piece_err_mu);
+        if (!chunks[t].err) chunks[t].err = std::current_exception();
+      }
+    }
+    if (pieces_left[t].fetch_sub(1) != 1) return;      // another thread lands the chunk's last piece
+    if (!prog->cancelled.load() && !chunks[t].err) {
+      try {
+        run_task(t, !pc.whole);
+      } catch (...) {
+        chunks[t].err = std::current_exception();
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lk(prog->mu);
+      prog->done[t] = 1;
+      prog->finished++;
+    }
+    prog->cv.notify_all();
+  };
   for (size_t wk = 0; wk < nworkers; wk++) {
-    ScanPool::get().submit([prog, npieces, &pieces, &pieces_left, &read_piece, &run_task, &chunks, &piece_err_mu]() {
+    ScanPool::get().submit([prog, npieces, &process_piece]() {
       for (;;) {
         const size_t pi = prog->next.fetch_add(1);
         if (pi >= npieces) break;
-        const Piece& pc = pieces[pi];
-        const size_t t = pc.t;
-        if (!pc.whole && !prog->cancelled.load()) {
-          try {
-            read_piece(pc);
-          } catch (...) {
-            std::lock_guard<std::mutex> lk(piece_err_mu);
-            if (!chunks[t].err) chunks[t].err = std::current_exception();
-          }
-        }
-        if (pieces_left[t].fetch_sub(1) != 1) continue;      // another thread lands the chunk's last piece
-        if (!prog->cancelled.load() && !chunks[t].err) {
-          try {
-            run_task(t, !pc.whole);
-          } catch (...) {
-            chunks[t].err = std::current_exception();
-          }
-        }
-        {
-          std::lock_guard<std::mutex> lk(prog->mu);
-          prog->done[t] = 1;
-          prog->finished++;
-        }
-        prog->cv.notify_all();
+        process_piece(pi);
       }
     });
   }
@@ -1893,9 +1924,27 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       p->cv.wait(lk, [&] { return p->finished == n; });
     }
   } drain{prog, ntasks};
+  // While the chunk it needs is not ready, the task's own thread READS pieces too instead of sleeping (a task with one scan thread got its
+  // 62 MB of SF10 Q6 at the 8 GB/s one pread() loop reaches next to seven others: 7.5 of its 17 ms).  Only pieces of chunks that are read in
+  // place — 2 MiB of pread(), at most the page-header walk of the chunk whose last piece this is; a chunk that is decompressed on the host
+  // would keep this thread from the copies and launches that are waiting for it.
+  static const bool help_reading = getenv("COMET_PQ_TASK_READS") == nullptr || atoi(getenv("COMET_PQ_TASK_READS")) != 0;
   auto wait_for = [&](size_t t) {
-    std::unique_lock<std::mutex> lk(prog->mu);
-    prog->cv.wait(lk, [&] { return prog->done[t] != 0; });
+    for (;;) {
+      {
+        std::lock_guard<std::mutex> lk(prog->mu);
+        if (prog->done[t]) break;
+      }
+      size_t pi = prog->next.load();
+      bool took = false;
+      while (help_reading && pi < npieces && !pieces[pi].whole) {
+        if (prog->next.compare_exchange_weak(pi, pi + 1)) { took = true; break; }
+      }
+      if (took) { process_piece(pi); continue; }
+      std::unique_lock<std::mutex> lk(prog->mu);
+      prog->cv.wait(lk, [&] { return prog->done[t] != 0; });
+      break;
+    }
     if (chunks[t].err) std::rethrow_exception(chunks[t].err);
   };
 

@@ -144,3 +144,60 @@ def test_mixed_chunks_dictionary_then_plain(built, tmp_path):
     got, m = _scan_with_metrics(path, t, True)
     _assert_same(got, papq.read_table(path))
     assert m["pages_decompressed_on_device"] >= 8
+
+
+def _scan_conf(path, table, conf):
+    plan = S.native_scan([path], table.schema.names, _types(table.schema))
+    it = native.CometExecIterator([], table.num_columns, plan.encode(), batch_size=0, config=S.config_map(conf))
+    batches = []
+    while True:
+        b = native.Native.executePlan(it.handle, table.num_columns)
+        if b is None:
+            break
+        batches.append(b)
+    m = S.decode_metric_node(it.metrics())
+    it.close()
+    while m[1]:
+        m = m[1][0]
+    return pa.Table.from_batches(batches), m[0]
+
+
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+def test_dictionary_encoded_snappy_pages_walked_on_the_device(built, tmp_path, version, monkeypatch):
+    """round 5: a task with few scan threads does not look through the compressed stream for a dictionary-encoded page's run headers — the
+    page is registered as pending, the device inflates it and walks the headers where they land (device/pq_runs.hpp).  Forced on and off here,
+    both against pyarrow: bit widths 0 / 4 / 6 / 12, NULLs in front of the indices (v1) or outside the stream (v2), pages of NULLs only, long RLE runs"""
+    from tests.test_device_zstd_gpu import _dict_table
+    t = _dict_table(1_200_000, 37)
+    path = str(tmp_path / f"dict_snappy_v{version[0]}.parquet")
+    papq.write_table(t, path, compression="snappy", use_dictionary=True, data_page_version=version, row_group_size=500_000, data_page_size=64 << 10)
+    want = papq.read_table(path)
+    monkeypatch.setenv("COMET_DEVICE_RUNS_SNAPPY", "1")
+    got, m = _scan_conf(path, t, {"spark.comet.gpu.scan.deviceDecompress": "true"})
+    _assert_same(got, want)
+    monkeypatch.setenv("COMET_DEVICE_RUNS_SNAPPY", "0")
+    host, mh = _scan_conf(path, t, {"spark.comet.gpu.scan.deviceDecompress": "true"})
+    _assert_same(host, want)
+    # (a page that compresses into more than 2048 elements is inflated on the host when the host looks through it, on the device otherwise)
+    assert m["pages_decompressed_on_device"] >= mh["pages_decompressed_on_device"] > 20
+
+
+@pytest.mark.parametrize("codec", ["snappy", "zstd"])
+def test_one_scan_thread_task(built, tmp_path, codec):
+    """the executor's shape: spark.comet.gpu.scanThreads=1 — the device takes the dictionary-encoded pages of either codec (auto), the task's own
+    thread reads pieces while it waits for its scan thread; several row groups, dictionary → PLAIN fallback inside a chunk, NULLs"""
+    from tests.test_device_zstd_gpu import _dict_table
+    t = _dict_table(900_000, 38)
+    path = str(tmp_path / f"one_thread_{codec}.parquet")
+    papq.write_table(t, path, compression=codec, use_dictionary=True, row_group_size=200_000, data_page_size=128 << 10)
+    want = papq.read_table(path)
+    got, m = _scan_conf(path, t, {"spark.comet.gpu.scanThreads": "1"})
+    _assert_same(got, want)
+    assert m["pages_decompressed_on_device"] > 20
+    many, mm = _scan_conf(path, t, {"spark.comet.gpu.scanThreads": "16"})
+    _assert_same(many, want)
+    big = _mixed_table(400_000, 39)
+    path2 = str(tmp_path / f"one_thread_plain_{codec}.parquet")
+    papq.write_table(big, path2, compression=codec, use_dictionary=False, row_group_size=50_000, data_page_size=64 << 10)
+    got2, _ = _scan_conf(path2, big, {"spark.comet.gpu.scanThreads": "1"})
+    _assert_same(got2, papq.read_table(path2))

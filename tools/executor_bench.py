@@ -178,15 +178,17 @@ def main():
                 return [native.HostInput.from_table(table.slice(lo, hi - lo), 8192)], plan, conf
         res["legs"][leg] = {"rows": nrows, "bytes_over_pcie": moved}
         for T in (int(x) for x in a.tasks.split(",")):
-            best, ok = None, True
+            best, ok, walls = None, True, []
             for it in range(a.steps + 1):
+                time.sleep(0.06)      # (outside the timed wave: a profile of this run tells the waves apart by the silence between them)
                 wall, results = run_wave(lambda t: make_task(t, T), T, native, ncols)
                 ok = ok and q6_total(results) == want
                 if it:
                     best = wall if best is None else min(best, wall)
+                    walls.append(wall)
             if best is None:
                 best = wall
-            entry = {"wall_ms": best * 1e3, "rows_per_s": nrows / best, "pcie_GBps": moved / best / 1e9, "answers_match_one_plan": ok}
+            entry = {"wall_ms": best * 1e3, "wall_ms_median": sorted(walls)[len(walls) // 2] * 1e3 if walls else best * 1e3, "wall_ms_all": [round(w * 1e3, 2) for w in walls], "rows_per_s": nrows / best, "pcie_GBps": moved / best / 1e9, "answers_match_one_plan": ok}
             if link:
                 entry["frac_of_measured_link"] = moved / best / 1e9 / link
             if a.busy:

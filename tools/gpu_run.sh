@@ -14,6 +14,9 @@ tests() {          # the whole GPU suite
 tests_sel() {      # tests matched by $SEL (a -k expression) or the files in $FILES
   timeout ${TSEL_TIMEOUT:-900} python -m pytest ${FILES:-tests} -m gpu -x -q --timeout ${TEST_TIMEOUT:-120} --timeout-method=thread ${SEL:+-k "$SEL"} > $OUT/pytest_sel.log 2>&1; tail -15 $OUT/pytest_sel.log | cut -c1-220
 }
+tests_forced() {   # the Parquet files of the GPU suite with every scan treated as a few-thread task (device-inflated dictionary pages, device-walked run headers, reading task thread)
+  COMET_PQ_FEW_THREADS=100000 timeout ${TSEL_TIMEOUT:-900} python -m pytest tests/test_parquet_gpu.py tests/test_parquet_fixtures_gpu.py tests/test_parquet_fuzz_gpu.py tests/test_parquet_page_index_gpu.py tests/test_device_zstd_gpu.py tests/test_device_snappy_gpu.py -m gpu -x -q --timeout ${TEST_TIMEOUT:-120} --timeout-method=thread > $OUT/pytest_forced.log 2>&1; tail -15 $OUT/pytest_forced.log | cut -c1-220
+}
 smoke() {
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 }
@@ -129,6 +132,13 @@ executor_trace() { # one traced wave of 8 one-core tasks per codec: every task's
   for L in ${EXEC_LEGS:-parquet_snappy parquet_zstd}; do
     COMET_TRACE_STAGES=1 timeout 300 python tools/executor_bench.py --dir $PQ --steps 2 --no-link --tasks 8 --legs $L > /dev/null 2> $OUT/exec_trace_$L.log
     echo "== $L: $(grep -c 'device idle' $OUT/exec_trace_$L.log) scans traced"; grep "device idle\|all launches\|scan threads spent" $OUT/exec_trace_$L.log | tail -24 | cut -c1-200
+  done
+}
+executor_wave() {  # one wave of $WAVE_TASKS one-core tasks per leg under rocprofv3 (kernels, copies, HIP API): tools/wave_timeline.py says who waits for whom
+  for L in ${EXEC_LEGS:-parquet_snappy parquet_zstd}; do
+    (cd /tmp && COMET_TRACE_STAGES=1 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT/wave_$L -o w -- python $GRAFT_REPO_ROOT/tools/executor_bench.py --dir $PQ --steps 1 --no-link --tasks ${WAVE_TASKS:-8} --legs $L > /dev/null 2> $OUT/wave_$L.log)
+    python tools/wave_timeline.py $OUT/wave_$L ${WAVE_MIN_US:-300} > $OUT/wave_$L.txt 2>&1; rm -rf $OUT/wave_$L
+    echo "== $L"; head -${WAVE_LINES:-60} $OUT/wave_$L.txt | cut -c1-160
   done
 }
 q95_stats() {      # kernel statistics of TPC-DS Q95 stage A on one GPU
