@@ -78,6 +78,7 @@ auto guarded(ExecutionContext* ctx, decltype(std::declval<F>()()) err_value, F f
 }  // namespace
 
 
+namespace comet { namespace detail { void plan_execution_begins(); void plan_execution_ends(); int plans_executing(); } }
 // COMET_TRACE_STAGES: every plan call with its begin on the process clock (the same clock the scan traces use), so that the calls of
 // concurrent tasks can be laid side by side
 struct ApiTrace {
@@ -297,6 +298,7 @@ int64_t comet_execute_plan(int64_t handle, struct ArrowArray** out_arrays, struc
     return -2;
   }
   ApiTrace api_trace("executePlan", handle);
+  struct Executing { Executing() { comet::detail::plan_execution_begins(); } ~Executing() { comet::detail::plan_execution_ends(); } } executing;
   return guarded(ctx.get(), (int64_t)-2, [&]() -> int64_t { return ctx->execute(out_arrays, out_schemas, n_out); });
 }
 
@@ -306,6 +308,7 @@ int64_t comet_execute_plan_device(int64_t handle, struct ArrowDeviceArray** out_
     t_last_error = "invalid plan handle";
     return -2;
   }
+  struct Executing { Executing() { comet::detail::plan_execution_begins(); } ~Executing() { comet::detail::plan_execution_ends(); } } executing;
   return guarded(ctx.get(), (int64_t)-2, [&]() -> int64_t { return ctx->execute_device(out_arrays, out_schemas, n_out); });
 }
 

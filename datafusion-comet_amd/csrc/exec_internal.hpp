@@ -100,9 +100,13 @@ extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int3
 
 namespace comet {
 namespace detail {
+void plan_execution_begins();      // exec_memory.cpp: how many plans execute right now decides how threads wait for the device
+void plan_execution_ends();
+int plans_executing();
 
 // per-process stream / event pools (exec_memory.cpp)
 hipStream_t pool_get_stream(int dev);
+hipStream_t shared_copy_stream(int dev);      // one per device for all scans: never returned to the pool, never synchronised as a whole
 void pool_put_stream(int dev, hipStream_t s);
 hipEvent_t pool_get_event(int dev);
 void pool_put_event(int dev, hipEvent_t e);

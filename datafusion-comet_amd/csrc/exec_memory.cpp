@@ -5,7 +5,7 @@ namespace comet {
 
 // An executor runs 8-16 task threads against one GPU, each with a handful of streams (its plan's, a copy stream, two decompression-group
 // streams).  ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues — four by default — and a stream that waits for an event
-// holds up whatever shares its queue: sixteen concurrent zstd scans took 80 ms with four queues and 62 ms with sixteen (profiles/r5_executor_*).
+// holds up whatever shares its queue: sixteen concurrent zstd scans took 80 ms with four queues and 62 ms with sixteen (profiles/r5_executor_shape.md).
 // The runtime reads the variable when it initialises (the first HIP call), so loading the library is early enough in a JVM; a value the
 // operator has set stays.
 __attribute__((constructor)) static void comet_hip_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
@@ -257,6 +257,29 @@ void detail::pool_put_stream(int dev, hipStream_t s) {
   std::lock_guard<std::mutex> lk(pools().mu);
   pools().streams[dev].push_back(s);
 }
+// Plans executing at this moment (executePlan calls in flight): a scan decides by it what it leaves to the device — with many tasks at once
+// the device's decompression kernels are the bound and host threads take what they can (parquet_scan.cpp).
+namespace {
+std::atomic<int> g_plans_executing{0};
+}  // namespace
+void detail::plan_execution_begins() { g_plans_executing.fetch_add(1); }
+void detail::plan_execution_ends() { g_plans_executing.fetch_sub(1); }
+int detail::plans_executing() { return g_plans_executing.load(); }
+
+// COMET_PQ_SHARED_COPY_STREAM=1: one host → device copy stream per device for every Parquet scan of the process (the link is one FIFO whoever
+// queues the copies, and every stream with pending work wants a hardware queue: GPU_MAX_HW_QUEUES of them, and 32 queues time-slice the
+// runlist — 74 ms for a wave that takes 20).  Measured and not the default: one submission that stalls then holds every task's copies.
+hipStream_t detail::shared_copy_stream(int dev) {
+  std::lock_guard<std::mutex> lk(pools().mu);
+  static std::map<int, hipStream_t> shared;
+  auto it = shared.find(dev);
+  if (it != shared.end()) return it->second;
+  hipStream_t s;
+  HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  shared[dev] = s;
+  return s;
+}
+
 hipEvent_t detail::pool_get_event(int dev) {
   {
     std::lock_guard<std::mutex> lk(pools().mu);

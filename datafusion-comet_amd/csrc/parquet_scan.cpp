@@ -31,6 +31,8 @@ hipStream_t pool_get_stream(int dev);
 void pool_put_stream(int dev, hipStream_t s);
 hipEvent_t pool_get_event(int dev);
 void pool_put_event(int dev, hipEvent_t e);
+int plans_executing();
+hipStream_t shared_copy_stream(int dev);
 } }
 #include "device/snappy2.hpp"
 #include "snappy2.hpp"
@@ -347,7 +349,7 @@ struct ScanOptions {
   bool device_runs = true;             // … and the run headers of those index sections are walked ON THE DEVICE (device/pq_runs.hpp: count, prefix sum, write — four bytes come back instead of
                                        // the sections); COMET_DEVICE_RUNS=0: the round-3 path, sections read back and parsed by the scan threads
   bool device_runs_snappy = false;     // snappy: a dictionary-encoded page's run headers are walked on the device too instead of being read THROUGH the compressed stream by the scan thread
-                                       // (SnappyView: ≈ 6 µs of a scan thread per page — 9.6 of the 17 ms a one-core task spent preparing its 1500 pages, profiles/r5_executor_wave.txt); decided per scan from
+                                       // (SnappyView: ≈ 6 µs of a scan thread per page — 9.6 of the 17 ms a one-core task spent preparing its 1500 pages, profiles/r5_executor_shape.md); decided per scan from
                                        // its scan threads (scan_parquet), COMET_DEVICE_RUNS_SNAPPY=0/1 forces it.  Pruned scans keep the host walk (their pages' runs are clipped on the host)
   bool device_zstd = true;             // zstd PLAIN pages of fixed-width columns take the device pipeline too (COMET_DEVICE_ZSTD=0: host threads inflate them)
   bool read_in_place = true;           // chunks whose pages the device inflates are pread() straight into their pinned slot; page bodies are uploaded from where they land (COMET_PARQUET_READ_IN_PLACE=0: read into scratch, copy bodies)
@@ -1764,14 +1766,19 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scanThreads") max_inflight = std::max(1, atoi(kv.second.c_str()));
   const int host_threads = std::max(1, std::min(max_inflight, ScanPool::get().size()));
-  // A task with a few scan threads (a Spark task owns ONE core) leaves to the device whatever the device can do: the index sections of
-  // dictionary-encoded pages are inflated there whatever the codec (zstd: 31 of the 84 ms a one-thread scan of SF10 Q6 spent, now 61 ms) and their
-  // run headers are walked there (snappy: the look through the compressed stream was 9.6 of a task's 17 ms).  A scan with a dozen threads keeps
-  // both on the host: its threads are idle anyway, and a column whose run table the device sizes is decoded one host round trip later
-  // (SF10 Q6 with 32 threads: zstd 16.9 against 15.0 ms).
+  // A LONE task with a few scan threads (a Spark task owns one core; nothing else executes in the process) leaves to the device whatever the
+  // device can do: the index sections of dictionary-encoded pages are inflated there whatever the codec, and their run headers are walked there
+  // (SF10 Q6 with one scan thread: zstd 84 → 39 ms, the host no longer inflates 165 MB of index sections; snappy 25 ms, the host no longer
+  // looks through every compressed page for its run headers — ≈ 6 µs a page).  Not so a scan with a dozen threads — they are idle anyway, and a
+  // column whose run table the device sizes is decoded one host round trip later (zstd 16.9 against 15.0 ms) — and not so a task that is one
+  // of many: eight tasks at once have sixteen cores between them and ONE device, whose decompression kernels are then the bound (zstd: a kernel
+  // running 0.81 of the wave); measured over the SF10 Q6 file, eight / sixteen tasks: 19.1 / 25.5 ms (snappy) and 25.5 / 28.7 ms (zstd) with the
+  // host doing its part, 22.7 / 32.4 and 31.2 / 32.5 ms with the device taking everything (profiles/r5_executor_shape.md).
   static const int kFewThreads = getenv("COMET_PQ_FEW_THREADS") ? atoi(getenv("COMET_PQ_FEW_THREADS")) : 4;
-  if (getenv("COMET_DEVICE_ZSTD_DICT") == nullptr) so.device_zstd_dict = host_threads <= kFewThreads;
-  so.device_runs_snappy = host_threads <= kFewThreads;
+  static const int kLonePlans = getenv("COMET_PQ_LONE_PLANS") ? atoi(getenv("COMET_PQ_LONE_PLANS")) : 2;
+  const bool few_threads = host_threads <= kFewThreads && detail::plans_executing() <= kLonePlans;
+  if (getenv("COMET_DEVICE_ZSTD_DICT") == nullptr) so.device_zstd_dict = few_threads;
+  so.device_runs_snappy = few_threads;
   if (const char* e = getenv("COMET_DEVICE_RUNS_SNAPPY")) so.device_runs_snappy = atoi(e) != 0;
   // Columns are taken largest first: the big PLAIN columns are the ones whose pages the device decompresses, and that kernel then runs
   // while the host threads are still preparing the small (dictionary-encoded) columns.
@@ -1800,7 +1807,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return col_bytes[a] > col_bytes[b]; });
   // COMET_PQ_ORDER=small_first: the small columns' chunks are prepared and sent first (their slices cross in latency-bound copies that then
   // overlap the big column's host work), the big column last; =big_first (default) starts the device pipeline of the big column as early as possible
-  static const bool small_first = getenv("COMET_PQ_ORDER") != nullptr && !strcmp(getenv("COMET_PQ_ORDER"), "small_first");
+  // A lone few-thread task takes its small columns first: a column whose run table the device sizes is finished one host round trip after its
+  // pages are inflated, and with the big column last those round trips happen WHILE the big column is read and crosses.
+  static const char* order_env = getenv("COMET_PQ_ORDER");
+  const bool small_first = order_env ? !strcmp(order_env, "small_first") : few_threads;
   if (small_first) std::reverse(order.begin(), order.end());
   // Measured on MI355X (profiles/r3_snappy_pipeline.json): the multi-kernel pipeline inflates PLAIN pages at 70–80 GB/s of output whatever
   // their number (it parallelises inside the pages), plus about half a millisecond of launches; a host core decompresses the same bytes at
@@ -1929,12 +1939,16 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   // place — 2 MiB of pread(), at most the page-header walk of the chunk whose last piece this is; a chunk that is decompressed on the host
   // would keep this thread from the copies and launches that are waiting for it.
   static const bool help_reading = getenv("COMET_PQ_TASK_READS") == nullptr || atoi(getenv("COMET_PQ_TASK_READS")) != 0;
+  // (while_waiting: what else this thread has to do between pieces — columns whose run counts have come back from the device are finished
+  // there; → true while it wants to be called again soon)
+  std::function<bool()> while_waiting;
   auto wait_for = [&](size_t t) {
     for (;;) {
       {
         std::lock_guard<std::mutex> lk(prog->mu);
         if (prog->done[t]) break;
       }
+      const bool again = while_waiting ? while_waiting() : false;
       size_t pi = prog->next.load();
       bool took = false;
       while (help_reading && pi < npieces && !pieces[pi].whole) {
@@ -1942,6 +1956,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       }
       if (took) { process_piece(pi); continue; }
       std::unique_lock<std::mutex> lk(prog->mu);
+      if (again) { prog->cv.wait_for(lk, std::chrono::microseconds(150), [&] { return prog->done[t] != 0; }); continue; }
       prog->cv.wait(lk, [&] { return prog->done[t] != 0; });
       break;
     }
@@ -1957,18 +1972,27 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   // COMET_PQ_COPY_STREAMS=n spreads the copies over n streams (17–18 ms, noisier).
   // (streams and events come from the process-wide pools: creating a stream costs 10 ms and destroying one 2 ms when eight tasks do it at
   // once — hipStreamCreateWithFlags was a quarter of the wall time of eight concurrent scans, profiles/r4_executor_hip_api.txt)
-  hipStream_t copy_stream = detail::pool_get_stream(device_id_);
+  // (COMET_PQ_SHARED_COPY_STREAM=1: ONE copy stream for all scans of the process, detail::shared_copy_stream — measured and lost: a submission
+  // that stalls holds every task's copies behind it, 22.7 / 32.5 ms against 19.0 / 23.2 for eight / sixteen snappy tasks)
+  static const bool shared_copies = getenv("COMET_PQ_SHARED_COPY_STREAM") != nullptr && atoi(getenv("COMET_PQ_SHARED_COPY_STREAM")) != 0;
+  hipStream_t copy_stream = shared_copies ? detail::shared_copy_stream(device_id_) : detail::pool_get_stream(device_id_);
   std::vector<hipStream_t> extra_streams;
   std::vector<hipEvent_t> events;
   PinnedBuf upload_descs;
   struct StreamGuard {
-    int dev; hipStream_t& s; std::vector<hipStream_t>& extra; std::vector<hipEvent_t>& ev;
+    int dev; hipStream_t& s; std::vector<hipStream_t>& extra; std::vector<hipEvent_t>& ev; bool shared;
     ~StreamGuard() {
       for (hipStream_t x : extra) { (void)hipStreamSynchronize(x); detail::pool_put_stream(dev, x); }
-      if (s) { (void)hipStreamSynchronize(s); detail::pool_put_stream(dev, s); }
+      if (s && shared) {
+        // this scan's copies (read from pinned staging that is about to go back to its pool) are behind an event of its own; other scans' later
+        // copies are none of its business
+        hipEvent_t e = detail::pool_get_event(dev);
+        if (hipEventRecord(e, s) == hipSuccess) (void)hipEventSynchronize(e);
+        detail::pool_put_event(dev, e);
+      } else if (s) { (void)hipStreamSynchronize(s); detail::pool_put_stream(dev, s); }
       for (hipEvent_t e : ev) detail::pool_put_event(dev, e);
     }
-  } stream_guard{device_id_, copy_stream, extra_streams, events};
+  } stream_guard{device_id_, copy_stream, extra_streams, events, shared_copies};
   auto get_event = [&]() {
     hipEvent_t e = detail::pool_get_event(device_id_);
     events.push_back(e);
@@ -1993,7 +2017,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       d.len = (uint64_t)len;
     } else {
       const size_t k = rr++ % (extra_streams.size() + 1);
+      const double t_copy = trace ? ms_since() : 0;
       HIP_CHECK(hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, k ? extra_streams[k - 1] : copy_stream));
+      if (trace && ms_since() - t_copy > 0.3) trace_line(scan_id, "hipMemcpyAsync of %.2f MB held this thread %.2f ms (from %.2f ms)\n", (double)len / 1e6, ms_since() - t_copy, t_copy);
       stream_dirty[k] = 1;
     }
   };
@@ -2022,7 +2048,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   // (zstd: the sequence kernel lasts as long as ONE block's serial chain whatever the number of blocks — two groups side by side take no
   // longer than one; snappy: the one-lane-per-page hop kernel and the tails of the others leave most of the GPU idle), so the next group's
   // first kernels run under the previous group's last ones.  The column's decode kernels wait for every group (join_groups).
-  static const int n_group_streams = getenv("COMET_PQ_GROUP_STREAMS") ? std::max(0, std::min(8, atoi(getenv("COMET_PQ_GROUP_STREAMS")))) : 2;
+  // (… while few plans execute.  With several at once the other tasks' kernels fill those gaps, and every extra stream is a hardware queue
+  // the tasks compete for — see detail::shared_copy_stream: the groups then run on the plan's own stream)
+  static const int group_streams_env = getenv("COMET_PQ_GROUP_STREAMS") ? std::max(0, std::min(8, atoi(getenv("COMET_PQ_GROUP_STREAMS")))) : -1;
+  const int n_group_streams = group_streams_env >= 0 ? group_streams_env : detail::plans_executing() >= 3 ? 0 : 2;
   std::vector<hipStream_t> group_streams;
   std::vector<hipEvent_t> group_events;
   std::vector<char> group_dirty;
@@ -2262,12 +2291,36 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     out.cols[c] = cv;
   };
   struct Deferred { size_t c; std::shared_ptr<ColumnDevice> cd; size_t S; bool may_inflate; std::shared_ptr<PinnedBuf> readback; hipEvent_t done; std::vector<const uint8_t*> at;
-                    DeviceRuns dr; std::shared_ptr<DevBuf> counts; };
-  std::vector<Deferred> deferred;
+                    DeviceRuns dr; std::shared_ptr<DevBuf> counts; bool finished = false; };
+  std::deque<Deferred> deferred;      // (a deque: entries are finished in place while later columns append)
+  // a column whose run counts the device has delivered is finished as soon as this thread notices — between the chunks of the columns behind it
+  static const bool eager_finish = getenv("COMET_PQ_EAGER_FINISH") == nullptr || atoi(getenv("COMET_PQ_EAGER_FINISH")) != 0;
+  auto finish_counted = [&](Deferred& d) {
+    int32_t total = 0;
+    memcpy(&total, (char*)d.readback->p + (((size_t)d.dr.npend * sizeof(PqPendingRuns) + 15) & ~(size_t)15) + 16, 4);
+    if (total < 0) throw CometError("parquet: too many runs in one column");
+    d.dr.total = total;
+    if (trace) trace_line(scan_id, "column %zu: %d runs counted on the device at %.2f ms\n", d.c, total, ms_since());
+    finish_column(d.c, d.cd, d.S, d.may_inflate, &d.dr);
+    out.owners.push_back(d.dr.pend);
+    out.owners.push_back(d.dr.offsets);
+    out.owners.push_back(d.counts);
+    d.finished = true;
+  };
+  while_waiting = [&]() -> bool {
+    if (!eager_finish) return false;
+    bool open = false;
+    for (Deferred& d : deferred) {
+      if (d.finished || !d.dr.npend) continue;
+      if (hipEventQuery(d.done) == hipSuccess) finish_counted(d);
+      else open = true;
+    }
+    return open;
+  };
   // (an error thrown while read-backs are in flight: they land in pinned staging memory that goes back to its pool — wait for them first)
   struct ReadbackGuard {
     hipStream_t s;
-    const std::vector<Deferred>& d;
+    const std::deque<Deferred>& d;
     bool done = false;
     ~ReadbackGuard() { if (!done && !d.empty()) (void)hipStreamSynchronize(s); }
   } readback_guard{stream_, deferred};
@@ -2336,6 +2389,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         if (!ready && pending_piece_bytes() >= ((size_t)2 << 20)) { flush_pieces(); upload_flush(); }
       }
       const double t_wait = trace ? ms_since() : 0;
+      if (while_waiting) (void)while_waiting();
       wait_for(c * nsel + si);
       if (trace && ms_since() - t_wait > 0.3) trace_line(scan_id, "column %zu waited %.2f ms for chunk %zu (until %.2f ms)\n", c, ms_since() - t_wait, si, ms_since());
       HostChunk& hc = chunks[c * nsel + si];
@@ -2388,7 +2442,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       const size_t zleft_est = zstd_chunks_in_group ? (nsel - 1 - si) * zgroup_blocks.size() / zstd_chunks_in_group : 0;
       static const size_t kZGroupBlocks = getenv("COMET_PQ_ZGROUP_BLOCKS") ? (size_t)std::max(64, atoi(getenv("COMET_PQ_ZGROUP_BLOCKS"))) : 2800;
       const bool zfull = zgroup_blocks.size() >= kZGroupBlocks && zgroup_blocks.size() + zleft_est > (kZGroupBlocks == 2800 ? (size_t)4096 : kZGroupBlocks * 3 / 2);
-      const bool group_full = (!group_jobs.empty() || !zgroup_jobs.empty()) && ((zgroup_jobs.empty() ? group_bytes >= ((size_t)48 << 20) : zfull) || si + 1 == nsel);
+      // (snappy: a lone few-thread task gets its big column at the rate one or two pread() loops reach — groups of 12 MB start inflating
+      // while the rest is still being read; a scan with many threads keeps groups of 48 MB, fewer launches)
+      static const size_t kSGroupEnv = getenv("COMET_PQ_SGROUP_MB") ? (size_t)std::max(1, atoi(getenv("COMET_PQ_SGROUP_MB"))) << 20 : 0;
+      const size_t sgroup_bytes = kSGroupEnv ? kSGroupEnv : few_threads ? ((size_t)12 << 20) : ((size_t)48 << 20);
+      const bool group_full = (!group_jobs.empty() || !zgroup_jobs.empty()) && ((zgroup_jobs.empty() ? group_bytes >= sgroup_bytes : zfull) || si + 1 == nsel);
       if (group_full || si + 1 == nsel) flush_pieces();
       if (!next_ready || group_full) upload_flush();
       if (group_full) {
@@ -2397,7 +2455,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         // The pipelines' tables cross on the COPY stream, behind the page bytes; the group's stream is then fenced behind both and gets kernels
         // only.  (A host → device copy queued on a stream that waits for another stream's event holds the calling thread until that event has
         // happened: with the tables sent on the group's stream every launch here cost its task 7–10 ms — the time its page bytes needed to
-        // cross — and eight concurrent tasks issued nothing else meanwhile: profiles/r5_executor_trace.txt.)
+        // cross — and eight concurrent tasks issued nothing else meanwhile: the first session of round 5, stage traces.)
         Snappy2Scratch* sn = nullptr;
         Zstd2Scratch* zs = nullptr;
         if (!group_jobs.empty()) {
@@ -2520,18 +2578,12 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     finish_column(c, cd, S, may_inflate, nullptr);
   }
   if (trace && !deferred.empty()) trace_line(scan_id, "uploads of all columns issued at %.2f ms\n", ms_since());
+  while_waiting = nullptr;
   for (Deferred& d : deferred) {
+    if (d.finished) continue;
     HIP_CHECK(hipEventSynchronize(d.done));
     if (d.dr.npend) {
-      int32_t total = 0;
-      memcpy(&total, (char*)d.readback->p + (((size_t)d.dr.npend * sizeof(PqPendingRuns) + 15) & ~(size_t)15) + 16, 4);
-      if (total < 0) throw CometError("parquet: too many runs in one column");
-      d.dr.total = total;
-      if (trace) trace_line(scan_id, "column %zu: %d runs counted on the device at %.2f ms\n", d.c, total, ms_since());
-      finish_column(d.c, d.cd, d.S, d.may_inflate, &d.dr);
-      out.owners.push_back(d.dr.pend);
-      out.owners.push_back(d.dr.offsets);
-      out.owners.push_back(d.counts);
+      finish_counted(d);
       continue;
     }
     if (trace) trace_line(scan_id, "column %zu index sections back at %.2f ms\n", d.c, ms_since());

@@ -42,6 +42,17 @@ def link_rate(torch, nbytes=1 << 30):
     return nbytes / best / 1e9
 
 
+def cfs_throttled_us():
+    """microseconds this cgroup has spent throttled by its CPU quota so far (cgroup v2 cpu.stat; None when there is no such file)"""
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("throttled_usec"):
+                return int(line.split()[1])
+    except OSError:
+        pass
+    return None
+
+
 def run_wave(make_task, T, native, ncols):
     """T tasks, one thread each; → (wall seconds, [result batches per task])."""
     results = [None] * T
@@ -178,10 +189,14 @@ def main():
                 return [native.HostInput.from_table(table.slice(lo, hi - lo), 8192)], plan, conf
         res["legs"][leg] = {"rows": nrows, "bytes_over_pcie": moved}
         for T in (int(x) for x in a.tasks.split(",")):
-            best, ok, walls = None, True, []
+            best, ok, walls, throttled = None, True, [], []
             for it in range(a.steps + 1):
                 time.sleep(0.06)      # (outside the timed wave: a profile of this run tells the waves apart by the silence between them)
+                thr0 = cfs_throttled_us()
                 wall, results = run_wave(lambda t: make_task(t, T), T, native, ncols)
+                thr1 = cfs_throttled_us()
+                if it and thr0 is not None and thr1 is not None:
+                    throttled.append(round((thr1 - thr0) / 1e3, 2))
                 ok = ok and q6_total(results) == want
                 if it:
                     best = wall if best is None else min(best, wall)
@@ -189,6 +204,8 @@ def main():
             if best is None:
                 best = wall
             entry = {"wall_ms": best * 1e3, "wall_ms_median": sorted(walls)[len(walls) // 2] * 1e3 if walls else best * 1e3, "wall_ms_all": [round(w * 1e3, 2) for w in walls], "rows_per_s": nrows / best, "pcie_GBps": moved / best / 1e9, "answers_match_one_plan": ok}
+            if throttled:
+                entry["cfs_throttled_ms_all"] = throttled      # time the cgroup's CPU quota held the process's threads during each timed wave
             if link:
                 entry["frac_of_measured_link"] = moved / best / 1e9 / link
             if a.busy:

@@ -122,22 +122,22 @@ executor_envs() {  # the executor leg under environment switches: "$EXEC_ENVS" =
   IFS=';' read -ra ENTRIES <<< "${EXEC_ENVS:--}"
   for E in "${ENTRIES[@]}"; do
     N=exec_$(echo "$E" | tr -c 'A-Za-z0-9_\n' '_')
-    env $([ "$E" = "-" ] || echo $E | tr ',' ' ') timeout 300 python tools/executor_bench.py --dir $PQ --steps ${EXEC_STEPS:-3} --no-link --legs ${EXEC_LEGS:-parquet_snappy,parquet_zstd} --out $OUT/$N.json > $OUT/$N.log 2>&1
+    env $([ "$E" = "-" ] || echo $E | tr ',' ' ') ${EXEC_TRACE:+COMET_TRACE_STAGES=1} timeout 300 python tools/executor_bench.py --dir $PQ --steps ${EXEC_STEPS:-3} --no-link --legs $(echo ${EXEC_LEGS:-parquet_snappy,parquet_zstd} | tr ' ' ',') --tasks ${EXEC_TASKS:-8,16} --out $OUT/$N.json > $OUT/$N.log 2>&1
     echo "== $E: $(python -c "
 import json;d=json.load(open('$OUT/$N.json'))
-print('  '.join(f'{k}/{t}: {e[\"wall_ms\"]:.1f} ms' for k,v in d['legs'].items() for t,e in v.items() if t.startswith('tasks_')))" 2>&1 | tail -1)"
+print('  '.join(f'{k}/{t}: {e[\"wall_ms\"]:.1f} ms (median {e[\"wall_ms_median\"]:.1f})' for k,v in d['legs'].items() for t,e in v.items() if t.startswith('tasks_')))" 2>&1 | tail -1)  slow copies: $(grep -c 'held this thread' $OUT/$N.log), longest $(grep 'held this thread' $OUT/$N.log | sed 's/.*held this thread \([0-9.]*\) ms.*/\1/' | sort -n | tail -1) ms"
   done
 }
 executor_trace() { # one traced wave of 8 one-core tasks per codec: every task's stage lines (times relative to its own scan's start)
   for L in ${EXEC_LEGS:-parquet_snappy parquet_zstd}; do
     COMET_TRACE_STAGES=1 timeout 300 python tools/executor_bench.py --dir $PQ --steps 2 --no-link --tasks 8 --legs $L > /dev/null 2> $OUT/exec_trace_$L.log
-    echo "== $L: $(grep -c 'device idle' $OUT/exec_trace_$L.log) scans traced"; grep "device idle\|all launches\|scan threads spent" $OUT/exec_trace_$L.log | tail -24 | cut -c1-200
+    echo "== $L: $(grep -c 'device idle' $OUT/exec_trace_$L.log) scans traced, $(grep -c 'held this thread' $OUT/exec_trace_$L.log) slow copies"; grep "device idle\|held this thread\|launch took" $OUT/exec_trace_$L.log | tail -${TRACE_LINES:-30} | cut -c1-200
   done
 }
 executor_wave() {  # one wave of $WAVE_TASKS one-core tasks per leg under rocprofv3 (kernels, copies, HIP API): tools/wave_timeline.py says who waits for whom
   for L in ${EXEC_LEGS:-parquet_snappy parquet_zstd}; do
-    (cd /tmp && COMET_TRACE_STAGES=1 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT/wave_$L -o w -- python $GRAFT_REPO_ROOT/tools/executor_bench.py --dir $PQ --steps 1 --no-link --tasks ${WAVE_TASKS:-8} --legs $L > /dev/null 2> $OUT/wave_$L.log)
-    python tools/wave_timeline.py $OUT/wave_$L ${WAVE_MIN_US:-300} > $OUT/wave_$L.txt 2>&1; rm -rf $OUT/wave_$L
+    (cd /tmp && COMET_TRACE_STAGES=1 timeout 120 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT/wave_$L -o w -- python $GRAFT_REPO_ROOT/tools/executor_bench.py --dir $PQ --steps 1 --no-link --tasks ${WAVE_TASKS:-8} --legs $L > /dev/null 2> $OUT/wave_$L.log)
+    python tools/wave_timeline.py $OUT/wave_$L ${WAVE_MIN_US:-300} $OUT/wave_${L}_device.txt > $OUT/wave_$L.txt 2>&1; rm -rf $OUT/wave_$L
     echo "== $L"; head -${WAVE_LINES:-60} $OUT/wave_$L.txt | cut -c1-160
   done
 }

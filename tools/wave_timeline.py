@@ -15,13 +15,16 @@ min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0
 kern, cop, api = [], [], []
 for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        kern.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("<")[0][-40:]))
+        nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        kern.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm.split("(")[0].split("<")[0][-40:], r.get("Queue_Id", "?")))
 for f in glob.glob(root + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         cop.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (r.get("Direction") or "")[:24]))
 for f in glob.glob(root + "/**/*hip_api_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         api.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"], r.get("Thread_Id", "?")))
+kern_q = {(a, b, n): q for a, b, n, q in kern}
+kern = [(a, b, n) for a, b, n, q in kern]
 dev = sorted([(a, b) for a, b, _ in kern] + [(a, b) for a, b, _ in cop])
 if not dev:
     sys.exit("no device activity")
@@ -107,3 +110,10 @@ for th, calls in sorted(per.items(), key=lambda kv: kv[1][0][0]):
     for a, b, fn in calls:
         if (b - a) / 1e3 >= min_us:
             print(f"    {(a - t0) / 1e6:8.2f} {(b - a) / 1e6:8.2f}  {fn}")
+
+# the device side in start order (kernels of 30 us and more, every copy): start ms, duration ms, what, hardware queue — written next to the summary when a third argument names a file
+if len(sys.argv) > 3:
+    with open(sys.argv[3], "w") as f:
+        rows = [(a, b, n, kern_q.get((a, b, n), "?")) for a, b, n in kern if a >= t0 and a < t1 and b - a >= 30_000] + [(a, b, "copy " + d, "-") for a, b, d in cop if a >= t0 and a < t1]
+        for a, b, n, q in sorted(rows):
+            f.write(f"{(a - t0) / 1e6:8.3f} {(b - a) / 1e6:7.3f}  {n:40s} q{q}\n")
