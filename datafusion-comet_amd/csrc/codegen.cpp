@@ -179,11 +179,27 @@ const char* store_ctype(const DType& t) {
 // ---------------------------------------------------------------------------------------------
 // Expression substitution (Projection folding) and conjunct splitting.
 // ---------------------------------------------------------------------------------------------
+// GetStructField(struct column, k) (expr.proto:528-531; the reference evaluates it on the struct array, planner.rs:776-779): the chain's source
+// table carries every field of its struct columns as a column of its own (DType::virt_parent / virt_kid), so the expression folds into a
+// plain column reference.  `g_source_cols`: the Bound expressions of the source's columns while a chain is being folded.
+thread_local const std::vector<ExprP>* g_source_cols = nullptr;
+ExprP lower_struct_field(const ExprP& e, const ExprP& child) {
+  if (child->kind != ExprKind::Bound || !child->has_dtype || child->dtype.id != TypeId::Struct)
+    throw CometError("GetStructField of anything but a struct COLUMN is not supported yet");
+  if (e->bound_index < 0 || (size_t)e->bound_index >= child->dtype.kids.size()) throw CometError("GetStructField: ordinal " + std::to_string(e->bound_index) + " is out of range");
+  if (g_source_cols)
+    for (auto& c : *g_source_cols)
+      if (c->dtype.virt_parent == child->bound_index && c->dtype.virt_kid == e->bound_index) return c;
+  throw CometError("GetStructField is supported in Projection / Filter chains over a materialised source (a Parquet scan, a join) only");
+}
+
 ExprP substitute(const ExprP& e, const std::vector<ExprP>& cols, std::map<const Expr*, ExprP>& memo) {
   auto it = memo.find(e.get());
   if (it != memo.end()) return it->second;
   ExprP out;
-  if (e->kind == ExprKind::Bound) {
+  if (e->kind == ExprKind::GetStructField && e->children.size() == 1) {
+    out = lower_struct_field(e, substitute(e->children[0], cols, memo));
+  } else if (e->kind == ExprKind::Bound) {
     if (e->bound_index < 0 || (size_t)e->bound_index >= cols.size())
       throw CometError("Column index " + std::to_string(e->bound_index) + " is out of bound. Schema has " +
                        std::to_string(cols.size()) + " fields");
@@ -2496,6 +2512,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     b->has_dtype = true;
     cols.push_back(b);
   }
+  const std::vector<ExprP> source_cols = cols;
+  struct SourceColsScope { SourceColsScope(const std::vector<ExprP>* c) { g_source_cols = c; } ~SourceColsScope() { g_source_cols = nullptr; } } source_cols_scope(&source_cols);
   std::vector<ExprP> preds;
   const Operator* agg = nullptr;
   std::vector<ExprP> group_exprs;
@@ -2581,8 +2599,10 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     Gen ge(d.in_types, in_has_validity);
     if (str_fixed_len) ge.str_fixed_len = *str_fixed_len;
     for (auto& c : cols) {
+      // (… and so is a nested column: its rows are gathered by the executor, children and all — exec.cpp take_nested)
       const bool is_str_type = c->kind == ExprKind::Bound && c->bound_index >= 0 && (size_t)c->bound_index < d.in_types.size() &&
-                               (d.in_types[(size_t)c->bound_index].id == TypeId::String || d.in_types[(size_t)c->bound_index].id == TypeId::Bytes);
+                               (d.in_types[(size_t)c->bound_index].id == TypeId::String || d.in_types[(size_t)c->bound_index].id == TypeId::Bytes ||
+                                d.in_types[(size_t)c->bound_index].is_nested());
       if (is_str_type) {
         // a Utf8 column passed through: emit the source row index, the executor gathers the string afterwards
         const int src = c->bound_index;
@@ -2596,6 +2616,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         outs.push_back(v);
         OutCol oc;
         oc.type = v.t;
+        oc.type.virt_parent = oc.type.virt_kid = -1;
         oc.nullable = !v.ok.empty();
         oc.gather_src = src;
         d.out_cols.push_back(oc);

@@ -281,6 +281,16 @@ __global__ __launch_bounds__(256) void take_utf8_lengths_kernel(const i32* offs,
     lengths[k] = utf8_row_valid(ok_bytes, src_valid_bits, k, r) ? (u32)(offs[r + 1] - offs[r]) : 0u;
   }
 }
+// rows of a List column taken by index: output row k's elements are source elements offs[idx[k]] …; the element indices, one per output element
+// (eight lanes per row, like the byte copy below) — the element column is then taken by them, whatever its type
+__global__ __launch_bounds__(256) void take_list_indices_kernel(const i32* offs, const u32* idx, i64 n, const i32* out_offs, u32* elem_idx) {
+  const int sub = threadIdx.x & 7;
+  for (i64 k = ((i64)blockIdx.x * 256 + threadIdx.x) >> 3; k < n; k += ((i64)gridDim.x * 256) >> 3) {
+    const i32 lo = out_offs[k], len = out_offs[k + 1] - lo;
+    const i32 src = offs[idx[k]];
+    for (i32 j = sub; j < len; j += 8) elem_idx[lo + j] = (u32)(src + j);
+  }
+}
 // eight lanes copy one value: they write consecutive bytes, so a wave stores 8 contiguous runs instead of 64 scattered bytes per step
 __global__ __launch_bounds__(256) void take_utf8_copy_kernel(const i32* offs, const u8* bytes, const u32* idx, const u8* ok_bytes, const u8* src_valid_bits,
                                                              i64 n, const i32* out_offs, u8* out_bytes) {
@@ -519,6 +529,10 @@ int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n
 int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t n,
                                    uint32_t* lengths, void* stream) {
   if (n > 0) hipLaunchKernelGGL(take_utf8_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offs, idx, ok_bytes, src_valid_bits, (i64)n, lengths);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_take_list_indices(const int32_t* offs, const uint32_t* idx, int64_t n, const int32_t* out_offs, uint32_t* elem_idx, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(take_list_indices_kernel, grid_for(n * 8), 256, 0, (hipStream_t)stream, offs, idx, (i64)n, out_offs, elem_idx);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits,

@@ -17,6 +17,43 @@
 #include "exec_internal.hpp"
 
 namespace comet {
+
+// `in` with every field of its struct columns as a column of its own behind the real ones (DType::virt_parent / virt_kid name them): what
+// GetStructField folds into (codegen.cpp lower_struct_field).  A field's validity already says NULL where its struct is NULL (the Parquet
+// scan derives both from one definition level), so the field column is the field's view as it is.
+DevTable extend_struct_fields(const DevTable& in) {
+  bool any = false;
+  for (auto& t : in.types) any |= t.id == TypeId::Struct;
+  if (!any) return in;
+  DevTable x = in;
+  for (size_t i = 0; i < in.types.size(); i++) {
+    if (in.types[i].id != TypeId::Struct) continue;
+    for (size_t k = 0; k < in.types[i].kids.size() && k < in.cols[i].kids.size(); k++) {
+      DType kt = in.types[i].kids[k];
+      kt.virt_parent = (int)i;
+      kt.virt_kid = (int)k;
+      x.types.push_back(kt);
+      x.cols.push_back(in.cols[i].kids[k]);
+      x.has_valid.push_back(k < in.cols[i].kid_has_valid.size() && in.cols[i].kid_has_valid[k]);
+    }
+  }
+  return x;
+}
+
+std::vector<DType> extend_struct_field_types(const std::vector<DType>& types) {
+  std::vector<DType> x = types;
+  for (size_t i = 0; i < types.size(); i++) {
+    if (types[i].id != TypeId::Struct) continue;
+    for (size_t k = 0; k < types[i].kids.size(); k++) {
+      DType kt = types[i].kids[k];
+      kt.virt_parent = (int)i;
+      kt.virt_kid = (int)k;
+      x.push_back(kt);
+    }
+  }
+  return x;
+}
+
 namespace detail {
 
 // Planned pipelines are shared by every task that runs the same plan bytes (a Spark stage = thousands of
@@ -271,7 +308,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     // than the packed 15 bytes be swapped for representative row indices (prepare_dict_keys)
     if (sink_ == SinkKind::AggGrouped && !pv->desc.str_key_cols.empty()) has_join_ = true;
   } else {
-    in_types_ = infer_schema(*root_source_);
+    in_types_ = extend_struct_field_types(infer_schema(*root_source_));      // (a struct's fields are columns of their own to the chain above: GetStructField)
     if (plan_.get() != root_source_) {
       std::vector<bool> none(in_types_.size(), false);
       auto pv = planned_variant(*plan_, plan_hash_, none, false, &in_types_);
@@ -553,7 +590,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       if (e->kind == ExprKind::Bound && (e->bound_index < 0 || (size_t)e->bound_index >= st.size()))
         throw CometError("ShuffleWriter: hash expression references column " + std::to_string(e->bound_index) + " of " + std::to_string(st.size()));
     for (auto& t : st)
-      if (expected_format(t) == "?") throw CometError("ShuffleWriter: column type " + t.str() + " is not supported");
+      if (expected_format(t) == "?" || t.is_nested()) throw CometError("ShuffleWriter: column type " + t.str() + " is not supported");
     auto sp = shuffle_projs_.find(&op);
     if (sp != shuffle_projs_.end()) {
       Operator& pr = *sp->second;
@@ -696,13 +733,13 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     if (src->children.size() != 1) throw CometError(std::string(op_name(src->proto_tag)) + " expects exactly one child");
     src = src->children[0].get();
   } while (!is_source(*src, &op));
-  std::vector<DType> st = infer_schema(*src);
+  std::vector<DType> st = extend_struct_field_types(infer_schema(*src));      // (as run_chain_to_device will see the source: struct fields as columns of their own)
   std::vector<bool> none(st.size(), false);
   PipelineDesc d = generate_pipeline(op, none, &st);
   if (compile_in_infer_) jit_compile(d.source);
   explain_ += d.explain;
   std::vector<DType> out;
-  for (auto& c : d.out_cols) out.push_back(c.type);
+  for (auto& c : d.out_cols) { out.push_back(c.type); out.back().virt_parent = out.back().virt_kid = -1; }
   return out;
 }
 
@@ -919,6 +956,77 @@ void ExecutionContext::take_utf8(const DeviceColumnView& src, const uint32_t* id
   owners.push_back(data);
 }
 
+DeviceColumnView ExecutionContext::take_column(const DeviceColumnView& src, const DType& t, bool has_valid, const uint32_t* idx, const uint8_t* ok_bytes, int64_t rows,
+                                               bool& out_has_valid, std::vector<std::shared_ptr<void>>& owners) {
+  DeviceColumnView out;
+  out_has_valid = false;
+  if (src.offset != 0 && t.id != TypeId::String && t.id != TypeId::Bytes) throw CometError("take: a column with a non-zero Arrow offset is not supported here");
+  auto take_validity = [&]() {
+    if (!has_valid || !src.valid) return;
+    auto bm = std::make_shared<DevBuf>();
+    bm->ensure((size_t)((rows + 7) / 8) + 16);
+    if (rows && comet_launch_take(0, src.valid, idx, rows, bm->p, stream_) != 0) throw CometError("take: validity");
+    out.valid = (const uint8_t*)bm->p;
+    out_has_valid = true;
+    owners.push_back(bm);
+  };
+  if (t.id == TypeId::Struct) {
+    for (size_t k = 0; k < t.kids.size(); k++) {
+      bool hv = false;
+      out.kids.push_back(take_column(src.kids.at(k), t.kids[k], k < src.kid_has_valid.size() && src.kid_has_valid[k], idx, ok_bytes, rows, hv, owners));
+      out.kid_has_valid.push_back(hv ? 1 : 0);
+    }
+    out.kid_rows = rows;
+    take_validity();
+    return out;
+  }
+  if (t.id == TypeId::List) {
+    // lengths of the taken rows → new offsets → the source element index of every output element → the element column taken by those
+    auto offsets = std::make_shared<DevBuf>();
+    offsets->ensure((size_t)(rows + 1) * 4 + 16);
+    int32_t total = 0;
+    if (rows == 0) {
+      HIP_CHECK(hipMemsetAsync(offsets->p, 0, 4, stream_));
+    } else {
+      DevBuf lengths, tiles;
+      lengths.ensure((size_t)rows * 4 + 16);
+      tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+      if (comet_launch_take_utf8_lengths((const int32_t*)src.data, idx, ok_bytes, has_valid ? src.valid : nullptr, rows, (uint32_t*)lengths.p, stream_) != 0)
+        throw CometError("take (list): launch failed");
+      pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)offsets->p, stream_);
+      read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
+      if (total < 0) throw CometError("List column exceeds 2^31 elements");
+      HIP_CHECK(hipStreamSynchronize(stream_));   // lengths / tiles go back to the pool
+    }
+    auto eidx = std::make_shared<DevBuf>();
+    eidx->ensure((size_t)std::max(total, 1) * 4 + 16);
+    if (rows && comet_launch_take_list_indices((const int32_t*)src.data, idx, rows, (const int32_t*)offsets->p, (uint32_t*)eidx->p, stream_) != 0)
+      throw CometError("take (list): launch failed");
+    bool hv = false;
+    out.kids.push_back(take_column(src.kids.at(0), t.kids.at(0), !src.kid_has_valid.empty() && src.kid_has_valid[0], (const uint32_t*)eidx->p, nullptr, total, hv, owners));
+    out.kid_has_valid.push_back(hv ? 1 : 0);
+    out.kid_rows = total;
+    out.data = offsets->p;
+    owners.push_back(offsets);
+    owners.push_back(eidx);
+    take_validity();
+    return out;
+  }
+  if (t.id == TypeId::String || t.id == TypeId::Bytes) {
+    take_utf8(src, idx, ok_bytes, has_valid ? src.valid : nullptr, rows, out, owners);
+    take_validity();
+    return out;
+  }
+  const int w = t.id == TypeId::Bool ? 0 : fixed_width(t);
+  auto vals = std::make_shared<DevBuf>();
+  vals->ensure((w ? (size_t)std::max<int64_t>(rows, 1) * (size_t)w : (size_t)((rows + 7) / 8)) + 16);
+  if (rows && comet_launch_take(w, src.data, idx, rows, vals->p, stream_) != 0) throw CometError("take: unsupported width");
+  out.data = vals->p;
+  owners.push_back(vals);
+  take_validity();
+  return out;
+}
+
 DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals,
                                             const std::vector<std::shared_ptr<DevBuf>>& valid_bytes, int64_t rows, const GatherSource& gather_source) {
   const PipelineDesc& d = v.desc;
@@ -1058,7 +1166,14 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
       if (!gather_source) throw CometError("internal: gathered Utf8 column without a source table");
       auto src = gather_source(oc.gather_src);
       const DeviceColumnView& sc = src.first->cols[(size_t)src.second];
-      take_utf8(sc, (const uint32_t*)vals[j]->p, (oc.nullable && rows) ? (const uint8_t*)valid_bytes[j]->p : nullptr, nullptr, rows, cv, t.owners);
+      if (oc.type.is_nested()) {
+        // a nested column passed through: its rows — children and all — by the source row indices the emit kernel wrote.  (The output's own
+        // validity is the kernel's ok byte, as for every column; the children keep theirs.)
+        bool hv_unused = false;
+        cv = take_column(sc, oc.type, false, (const uint32_t*)vals[j]->p, (oc.nullable && rows) ? (const uint8_t*)valid_bytes[j]->p : nullptr, rows, hv_unused, t.owners);
+      } else {
+        take_utf8(sc, (const uint32_t*)vals[j]->p, (oc.nullable && rows) ? (const uint8_t*)valid_bytes[j]->p : nullptr, nullptr, rows, cv, t.owners);
+      }
     }
     if (oc.type.id == TypeId::Bool) {
       // kernels store booleans as bytes; Arrow wants bits
@@ -1088,6 +1203,7 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
       hv = true;
     }
     t.types.push_back(oc.type);
+    t.types.back().virt_parent = t.types.back().virt_kid = -1;      // (a struct field's column was the SOURCE's: the result is a column like any other)
     t.cols.push_back(cv);
     t.has_valid.push_back(hv);
   }
@@ -1097,7 +1213,9 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
 // ---- exact Float64 sums: window bookkeeping (device side: comet_device.hpp "Exact Float64 sums") ----
 
 // Filter/Project chain `top` over the resident table `in` → resident table
-DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTable& in) {
+DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTable& in_plain) {
+  const DevTable in = extend_struct_fields(in_plain);
+  if (in.cols.size() > COMET_MAX_IN) throw CometError("too many columns (struct fields included) for one GPU pipeline");
   auto pv = planned_variant(top, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&top] + 1)), in.has_valid, true, &in.types);
   if (pv->desc.sink != SinkKind::Output) throw CometError("internal: run_chain_to_device on an aggregate chain");
   Variant v;
@@ -1326,9 +1444,90 @@ DevTable ExecutionContext::host_batch_to_table(const HostBatch& b) {
 }
 
 // resident table → host batches of ≤ batch_size rows (root of a plan that ends in a join)
+// ---- nested columns on their way out: the whole column comes back (one synchronous copy per buffer — nested results are not the hot path),
+// batches are slices of it ----
+namespace {
+HostColumn download_column(const DeviceColumnView& v, const DType& t, bool has_valid, int64_t rows, hipStream_t st) {
+  HostColumn c;
+  c.type = t;
+  c.length = rows;
+  auto fetch = [&](std::vector<uint8_t>& dst, const void* src, size_t bytes) {
+    dst.resize(bytes);
+    if (bytes) HIP_CHECK(hipMemcpyAsync(dst.data(), src, bytes, hipMemcpyDeviceToHost, st));
+  };
+  if (has_valid && v.valid && rows) fetch(c.validity, v.valid, (size_t)((rows + 7) / 8));
+  if (t.id == TypeId::Struct) {
+    for (size_t i = 0; i < t.kids.size(); i++)
+      c.children.push_back(download_column(v.kids.at(i), t.kids[i], i < v.kid_has_valid.size() && v.kid_has_valid[i], rows, st));
+  } else if (t.id == TypeId::List) {
+    fetch(c.values, v.data, (size_t)(rows + 1) * 4);
+    HIP_CHECK(hipStreamSynchronize(st));
+    const int64_t nel = rows ? ((const int32_t*)c.values.data())[rows] : 0;
+    if (nel < 0 || nel > v.kid_rows) throw CometError("internal: list offsets run past the element column");
+    c.children.push_back(download_column(v.kids.at(0), t.kids.at(0), !v.kid_has_valid.empty() && v.kid_has_valid[0], nel, st));
+  } else if (t.id == TypeId::String || t.id == TypeId::Bytes) {
+    fetch(c.values, (const int32_t*)v.data + v.offset, (size_t)(rows + 1) * 4);
+    HIP_CHECK(hipStreamSynchronize(st));
+    const int32_t* o = (const int32_t*)c.values.data();
+    const int64_t lo = rows ? o[0] : 0, hi = rows ? o[rows] : 0;
+    if (hi > lo) fetch(c.data, (const uint8_t*)v.aux + lo, (size_t)(hi - lo));
+    if (lo) { int32_t* w = (int32_t*)c.values.data(); for (int64_t i = 0; i <= rows; i++) w[i] -= (int32_t)lo; }
+  } else if (t.id == TypeId::Bool) {
+    fetch(c.values, v.data, (size_t)((rows + 7) / 8));
+  } else {
+    fetch(c.values, v.data, (size_t)rows * (size_t)fixed_width(t));
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (!c.validity.empty()) {
+    int64_t nulls = 0;
+    for (int64_t i = 0; i < rows; i++) nulls += !((c.validity[(size_t)(i >> 3)] >> (i & 7)) & 1);
+    c.null_count = nulls;
+    if (!nulls) c.validity.clear();
+  }
+  return c;
+}
+std::vector<uint8_t> slice_bits(const std::vector<uint8_t>& b, int64_t off, int64_t len) {
+  std::vector<uint8_t> o((size_t)((len + 7) / 8), 0);
+  for (int64_t i = 0; i < len; i++)
+    if ((b[(size_t)((off + i) >> 3)] >> ((off + i) & 7)) & 1) o[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+  return o;
+}
+HostColumn slice_column(const HostColumn& c, int64_t off, int64_t len) {
+  if (off == 0 && len == c.length) return c;
+  HostColumn o;
+  o.type = c.type;
+  o.length = len;
+  if (!c.validity.empty()) {
+    o.validity = slice_bits(c.validity, off, len);
+    for (int64_t i = 0; i < len; i++) o.null_count += !((o.validity[(size_t)(i >> 3)] >> (i & 7)) & 1);
+    if (!o.null_count) o.validity.clear();
+  }
+  const TypeId id = c.type.id;
+  if (id == TypeId::Struct) {
+    for (auto& k : c.children) o.children.push_back(slice_column(k, off, len));
+  } else if (id == TypeId::List || id == TypeId::String || id == TypeId::Bytes) {
+    const int32_t* src = (const int32_t*)c.values.data();
+    o.values.resize((size_t)(len + 1) * 4);
+    int32_t* w = (int32_t*)o.values.data();
+    for (int64_t i = 0; i <= len; i++) w[i] = src[off + i] - src[off];
+    if (id == TypeId::List) o.children.push_back(slice_column(c.children.at(0), src[off], src[off + len] - src[off]));
+    else o.data.assign(c.data.begin() + src[off], c.data.begin() + src[off + len]);
+  } else if (id == TypeId::Bool) {
+    o.values = slice_bits(c.values, off, len);
+  } else {
+    const size_t w = (size_t)fixed_width(c.type);
+    o.values.assign(c.values.begin() + (size_t)off * w, c.values.begin() + (size_t)(off + len) * w);
+  }
+  return o;
+}
+}  // namespace
+
 void ExecutionContext::table_to_host_batches(const DevTable& t) {
   if (t.rows == 0) return;
   const size_t ncol = t.cols.size();
+  std::vector<HostColumn> nested(ncol);      // nested columns, whole
+  for (size_t j = 0; j < ncol; j++)
+    if (t.types[j].is_nested()) nested[j] = download_column(t.cols[j], t.types[j], t.has_valid[j], t.rows, stream_);
   std::vector<std::vector<uint8_t>> hv(ncol), hb(ncol);
   std::vector<std::vector<uint8_t>> hd(ncol);
   // what has to come back: values (offsets for Utf8) and validity of every column; then the Utf8 bytes, whose size the offsets tell
@@ -1365,6 +1564,7 @@ void ExecutionContext::table_to_host_batches(const DevTable& t) {
   std::vector<Piece> pieces;
   for (size_t j = 0; j < ncol; j++) {
     const DType& ty = t.types[j];
+    if (ty.is_nested()) continue;
     const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;
     size_t bytes = is_str ? (size_t)(t.rows + 1) * 4 : ty.id == TypeId::Bool ? (size_t)((t.rows + 7) / 8) : (size_t)t.rows * fixed_width(ty);
     pieces.push_back({t.cols[j].data, &hv[j], bytes});
@@ -1387,6 +1587,7 @@ void ExecutionContext::table_to_host_batches(const DevTable& t) {
     HostBatch b;
     b.rows = len;
     for (size_t j = 0; j < ncol; j++) {
+      if (t.types[j].is_nested()) { b.cols.push_back(slice_column(nested[j], off, len)); continue; }
       HostColumn c;
       c.type = t.types[j];
       c.length = len;
@@ -1422,7 +1623,7 @@ void ExecutionContext::table_to_host_batches(const DevTable& t) {
 
 void ExecutionContext::run_to_completion() {
   if (has_join_) {
-    DevTable src = materialize(*root_source_);
+    DevTable src = extend_struct_fields(materialize(*root_source_));
     if (plan_.get() == root_source_) throw CometError("internal: bare join root");
     if (sink_ == SinkKind::AggGrouped) prepare_dict_keys(src);
     process_chunk(src.cols, src.has_valid, src.rows);
@@ -1502,6 +1703,8 @@ int64_t ExecutionContext::execute_device(ArrowDeviceArray** out_arrays, ArrowSch
   finished_ = true;
   if ((size_t)n_out != tab.cols.size())
     throw CometError("Output column count mismatch: expected " + std::to_string(n_out) + ", got " + std::to_string(tab.cols.size()));
+  for (size_t c = 0; c < tab.types.size(); c++)
+    if (tab.types[c].is_nested()) throw CometError("executePlan (device arrays): nested column of type " + tab.types[c].str() + " — nested results are exported through host batches");
   for (int j = 0; j < n_out; j++) {
     const DType& ty = tab.types[(size_t)j];
     const bool is_str = ty.id == TypeId::String || ty.id == TypeId::Bytes;

@@ -84,8 +84,9 @@ struct HostColumn {
   int64_t length = 0;
   int64_t null_count = 0;
   std::vector<uint8_t> validity;  // bitmap, empty if null_count == 0
-  std::vector<uint8_t> values;    // fixed width values / bit-packed booleans / int32 offsets (Utf8)
+  std::vector<uint8_t> values;    // fixed width values / bit-packed booleans / int32 offsets (Utf8, List)
   std::vector<uint8_t> data;      // Utf8 bytes
+  std::vector<HostColumn> children;   // Struct: one per field (each `length` rows); List: the one element column (offsets[length] elements)
 };
 struct HostBatch {
   int64_t rows = 0;
@@ -105,6 +106,11 @@ struct DeviceColumnView {
   const void* aux = nullptr;
   int64_t offset = 0;
   int fixed_len = -1;   // Utf8: every value has this byte length (aux then addresses the bytes directly); -1 = variable
+  // Nested columns (DType::kids): a Struct has no buffers of its own but `valid`; its fields are `kids`, each as long as the struct.  A List's
+  // `data` are its int32 offsets (rows + 1), kids[0] its elements — kid_rows of them.  kid_has_valid[i]: kids[i].valid is a bitmap.
+  std::vector<DeviceColumnView> kids;
+  std::vector<char> kid_has_valid;
+  int64_t kid_rows = 0;
 };
 
 // a table resident in HBM (Arrow layout); owners keep pooled buffers / producer arrays alive
@@ -205,6 +211,9 @@ class ExecutionContext {
   typedef std::function<std::pair<const DevTable*, int>(int)> GatherSource;   // OutCol::gather_src → (table, column)
   DevTable outputs_to_table(Variant& v, const std::vector<std::shared_ptr<DevBuf>>& vals, const std::vector<std::shared_ptr<DevBuf>>& valid_bytes,
                             int64_t rows, const GatherSource& gather_source = nullptr);
+  // rows idx[0 … rows) of a column of ANY type (nested ones with their children) → a new resident column; ok_bytes (optional): rows whose byte is 0 come out NULL / empty
+  DeviceColumnView take_column(const DeviceColumnView& src, const DType& t, bool has_valid, const uint32_t* idx, const uint8_t* ok_bytes, int64_t rows, bool& out_has_valid,
+                               std::vector<std::shared_ptr<void>>& owners);
   void take_utf8(const DeviceColumnView& src, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t rows,
                  DeviceColumnView& out, std::vector<std::shared_ptr<void>>& owners);
   void table_to_host_batches(const DevTable& t);

@@ -60,7 +60,7 @@ void bit_fill_ones(uint8_t* dst, int64_t dst_off, int64_t n) {
 }
 
 bool format_matches(const char* fmt, const DType& t) {
-  if (!fmt) return false;
+  if (!fmt || t.is_nested()) return false;      // (nested columns do not come in through Scan inputs: the Parquet scan produces them)
   std::string f = fmt;
   if (t.id == TypeId::Timestamp) return f.rfind("tsu:", 0) == 0 && f.size() > 4;
   if (t.id == TypeId::Decimal) {

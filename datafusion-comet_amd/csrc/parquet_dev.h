@@ -25,6 +25,7 @@ typedef struct PqPage {        /* one data page of a column (all selected row gr
   int32_t lvl_skip;
   int32_t val_skip;
   int32_t value_count;         /* non-NULL values of the page (= num_values for a page without NULLs): what its runs / PLAIN bytes hold */
+  int32_t rep_run_first, rep_run_count;   /* repetition-level runs of a list leaf (count 0: every level 0) */
 } PqPage;
 
 typedef struct PqRun {         /* one run of an RLE / bit-packed hybrid section */
@@ -90,6 +91,9 @@ typedef struct PqDecodeArgs {
   const int32_t* str_offsets;  /* strings (copy phase): output offsets at the chunk's row offset */
   uint8_t* str_bytes_out;      /* strings (copy phase): output data buffer */
   void* dense_out;             /* run-at-a-time kernel on a column with NULLs: values go here densely (value ordinal), expanded to rows afterwards */
+  const PqRun* rep_runs;       /* list leaves: repetition-level runs */
+  int32_t max_rep;
+  int32_t pad;
 } PqDecodeArgs;
 
 #endif

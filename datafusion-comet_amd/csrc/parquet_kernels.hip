@@ -58,6 +58,57 @@ __global__ __launch_bounds__(256) void pq_validity_kernel(PqDecodeArgs a) {
   }
 }
 
+// 1a. Nested leaves (a struct's field, a list's element): the LEVELS themselves, one byte per entry of the column — what the assembly kernels
+// below turn into struct validity, list offsets, list validity and element validity (Dremel's definition / repetition levels:
+// parquet-format LogicalTypes.md "Nested Types"; the reference reads them through the parquet crate's record reader).
+__global__ __launch_bounds__(256) void pq_levels_kernel(PqDecodeArgs a, int which, u8* __restrict__ out) {
+  const int maxl = which ? a.max_rep : a.max_def;
+  const int bw = maxl <= 1 ? 1 : (32 - __clz(maxl));
+  for (i64 row = (i64)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (i64)gridDim.x * 256) {
+    const PqPage pg = a.pages[pq_find_page(a.pages, a.npages, row)];
+    const i32 first = which ? pg.rep_run_first : pg.def_run_first, count = which ? pg.rep_run_count : pg.def_run_count;
+    u32 lvl = which ? 0u : (u32)maxl;      // no runs: every repetition level 0 / every value defined
+    if (maxl > 0 && count > 0) lvl = pq_hybrid_value(which ? a.rep_runs : a.def_runs, first, count, a.bytes, bw, (i32)(row - pg.row_start) + pg.lvl_skip);
+    out[row] = (u8)lvl;
+  }
+}
+// out[i] = level[i] >= thr
+__global__ __launch_bounds__(256) void pq_level_ge_kernel(const u8* __restrict__ lv, i64 n, int thr, u8* __restrict__ out) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = lv[i] >= (u8)thr;
+}
+// list leaf, pass 1: which entries start a row (repetition level 0) and which hold an element slot (definition level >= def_slot)
+__global__ __launch_bounds__(256) void pq_list_flags_kernel(const u8* __restrict__ def, const u8* __restrict__ rep, i64 n, int def_slot, u32* __restrict__ starts, u32* __restrict__ elems) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    starts[i] = rep[i] == 0;
+    elems[i] = def[i] >= (u8)def_slot;
+  }
+}
+// list leaf, pass 2 (behind the two prefix sums): offsets and validity of the rows, validity and values of the elements.
+// start_idx / elem_idx: exclusive prefix counts (n + 1 entries).  A file whose row starts do not add up to `rows` sets *err.
+__global__ __launch_bounds__(256) void pq_list_assemble_kernel(const u8* __restrict__ def, const u8* __restrict__ rep, i64 n, i64 rows, int def_list, int def_slot, int max_def,
+                                                               const i32* __restrict__ start_idx, const i32* __restrict__ elem_idx, const u8* __restrict__ values, int width,
+                                                               i32* __restrict__ offsets, u8* __restrict__ list_valid, u8* __restrict__ elem_valid, u8* __restrict__ elem_values, u32* err) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i <= n; i += (i64)gridDim.x * 256) {
+    if (i == n) {
+      if ((i64)start_idx[n] != rows) atomicCAS(err, 0u, 0xD1u);
+      else offsets[rows] = elem_idx[n];
+      continue;
+    }
+    const u8 d = def[i];
+    if (rep[i] == 0) {
+      const i64 r = start_idx[i];
+      if (r < rows) { offsets[r] = elem_idx[i]; list_valid[r] = d >= (u8)def_list; }
+    }
+    if (d >= (u8)def_slot) {
+      const i64 e = elem_idx[i];
+      elem_valid[e] = d == (u8)max_def;
+      const u8* src = values + i * (i64)width;
+      u8* dst = elem_values + e * (i64)width;
+      for (int k = 0; k < width; k++) dst[k] = d == (u8)max_def ? src[k] : (u8)0;
+    }
+  }
+}
+
 // 1b. run headers of index sections the device inflated (device/pq_runs.hpp): one lane per page.  Pass 1 counts a page's runs, a prefix sum
 // places them, pass 2 walks again and writes the PqRun entries behind the column's host-parsed runs and the page's (first, count).
 // A malformed section leaves (page job << 8 | 0xE0 + status) in *err, like the decompression kernels.
@@ -768,6 +819,18 @@ __global__ __launch_bounds__(256) void pq_upload_kernel(const PqCopyDesc* __rest
 
 extern "C" {
 void pq_launch_validity(const PqDecodeArgs* a, void* st) { hipLaunchKernelGGL(pq_validity_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a); }
+void pq_launch_levels(const PqDecodeArgs* a, int which, uint8_t* out, void* st) { hipLaunchKernelGGL(pq_levels_kernel, grid_rows(a->n_rows), 256, 0, (hipStream_t)st, *a, which, (u8*)out); }
+void pq_launch_level_ge(const uint8_t* lv, int64_t n, int thr, uint8_t* out, void* st) {
+  if (n > 0) hipLaunchKernelGGL(pq_level_ge_kernel, grid_rows(n), 256, 0, (hipStream_t)st, (const u8*)lv, (i64)n, thr, (u8*)out);
+}
+void pq_launch_list_flags(const uint8_t* def, const uint8_t* rep, int64_t n, int def_slot, uint32_t* starts, uint32_t* elems, void* st) {
+  if (n > 0) hipLaunchKernelGGL(pq_list_flags_kernel, grid_rows(n), 256, 0, (hipStream_t)st, (const u8*)def, (const u8*)rep, (i64)n, def_slot, (u32*)starts, (u32*)elems);
+}
+void pq_launch_list_assemble(const uint8_t* def, const uint8_t* rep, int64_t n, int64_t rows, int def_list, int def_slot, int max_def, const int32_t* start_idx, const int32_t* elem_idx,
+                             const uint8_t* values, int width, int32_t* offsets, uint8_t* list_valid, uint8_t* elem_valid, uint8_t* elem_values, uint32_t* err, void* st) {
+  hipLaunchKernelGGL(pq_list_assemble_kernel, grid_rows(n + 1), 256, 0, (hipStream_t)st, (const u8*)def, (const u8*)rep, (i64)n, (i64)rows, def_list, def_slot, max_def, (const i32*)start_idx,
+                     (const i32*)elem_idx, (const u8*)values, width, (i32*)offsets, (u8*)list_valid, (u8*)elem_valid, (u8*)elem_values, (u32*)err);
+}
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st) {
   hipStream_t s = (hipStream_t)st;
   hipLaunchKernelGGL(pq_tile_count_kernel, grid_tiles(n), 256, 0, s, valid, (i64)n, (u64*)tiles);

@@ -45,6 +45,11 @@ extern "C" int comet_launch_fill_utf8(int32_t* offsets, uint8_t* bytes, int64_t 
 extern "C" {
 void pq_launch_validity(const PqDecodeArgs* a, void* st);
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st);
+void pq_launch_levels(const PqDecodeArgs* a, int which, uint8_t* out, void* st);
+void pq_launch_level_ge(const uint8_t* lv, int64_t n, int thr, uint8_t* out, void* st);
+void pq_launch_list_flags(const uint8_t* def, const uint8_t* rep, int64_t n, int def_slot, uint32_t* starts, uint32_t* elems, void* st);
+void pq_launch_list_assemble(const uint8_t* def, const uint8_t* rep, int64_t n, int64_t rows, int def_list, int def_slot, int max_def, const int32_t* start_idx, const int32_t* elem_idx,
+                             const uint8_t* values, int width, int32_t* offsets, uint8_t* list_valid, uint8_t* elem_valid, uint8_t* elem_values, uint32_t* err, void* st);
 void pq_launch_decode_fixed(const PqDecodeArgs* a, void* st);
 void pq_launch_decode_runs(const PqDecodeArgs* a, void* st);
 void pq_launch_store_u32(const uint32_t* src, uint32_t* dst, void* st);
@@ -319,7 +324,36 @@ struct ColumnPlan {
   bool is_string = false;
   int dec_scale_up = 0;   // decimal scale widening: unscaled value × 10^dec_scale_up
   bool missing = false;   // the file has no such column: every value is NULL (schema evolution)
+  // Dremel levels of the leaf (parquet-format LogicalTypes.md "Nested Types"): a top-level column has max_def 0 / 1 and no repetition.  A
+  // struct's field: def_parent = the level from which the struct itself is defined (0: a required struct).  A list's element: def_parent = the
+  // level from which the list is defined (not NULL), def_slot = the level from which an entry holds an element slot (below: an empty or NULL list)
+  int max_def = 0, max_rep = 0, def_parent = 0, def_slot = 0;
+  bool nested_leaf() const { return max_def > 1 || max_rep > 0; }
 };
+
+// The file's schema as a tree (FileMeta.schema is its depth-first flattening): per element its parent, its levels and — for a primitive —
+// its ordinal among the leaves, which is the index of its chunk in every row group.
+struct SchemaNode { int parent = -1, def = 0, rep = 0, leaf = -1; std::vector<int> kids; };
+std::vector<SchemaNode> schema_tree(const pq::FileMeta& fm) {
+  std::vector<SchemaNode> t(fm.schema.size());
+  int leaf = 0;
+  size_t i = 1;
+  std::function<void(int)> walk = [&](int parent) {
+    const int n = fm.schema[(size_t)parent].num_children;
+    for (int k = 0; k < n && i < fm.schema.size(); k++) {
+      const int me = (int)i++;
+      const pq::SchemaElement& e = fm.schema[(size_t)me];
+      t[(size_t)me].parent = parent;
+      t[(size_t)me].def = t[(size_t)parent].def + (e.repetition != 0 ? 1 : 0);
+      t[(size_t)me].rep = t[(size_t)parent].rep + (e.repetition == 2 ? 1 : 0);
+      t[(size_t)parent].kids.push_back(me);
+      if (e.num_children > 0) walk(me);
+      else t[(size_t)me].leaf = leaf++;
+    }
+  };
+  if (!fm.schema.empty()) walk(0);
+  return t;
+}
 
 int out_width_of(const DType& t) {
   switch (t.id) {
@@ -406,27 +440,65 @@ CometError schema_convert_error(const std::string& column, int pt, const DType& 
 ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, const ScanOptions& so) {
   ColumnPlan cp;
   bool file_has_ids = false;
-  for (size_t i = 1; i < fm.schema.size(); i++) {
-    if (fm.schema[i].num_children > 0) throw CometError("nested Parquet schemas are not supported by the GPU scan yet");
-    file_has_ids |= fm.schema[i].field_id >= 0;
-  }
+  for (size_t i = 1; i < fm.schema.size(); i++) file_has_ids |= fm.schema[i].field_id >= 0;
   if (so.match_by_id && !so.ignore_missing_field_id && !file_has_ids) throw spark_error("ParquetMissingFieldIds", "");
-  const bool by_id = so.match_by_id && want.field_id >= 0;
-  std::vector<int> hits;
-  for (size_t i = 1; i < fm.schema.size(); i++) {
-    const pq::SchemaElement& e = fm.schema[i];
-    const bool hit = by_id ? e.field_id == want.field_id : (so.case_sensitive ? e.name == want.name : iequals(e.name, want.name));
-    if (hit) hits.push_back((int)i);
+  const std::vector<SchemaNode> tree = schema_tree(fm);
+  // the one child of group `g` that answers to (name, id): -1 none; more than one is the reference's duplicate-field error
+  auto child_of = [&](int g, const std::string& name, int id) -> int {
+    const bool by_id = so.match_by_id && id >= 0;
+    std::vector<int> hits;
+    for (int k : tree[(size_t)g].kids) {
+      const pq::SchemaElement& e = fm.schema[(size_t)k];
+      const bool hit = by_id ? e.field_id == id : (so.case_sensitive ? e.name == name : iequals(e.name, name));
+      if (hit) hits.push_back(k);
+    }
+    if (hits.size() > 1) {
+      std::string names;
+      for (int h : hits) names += (names.empty() ? "" : ", ") + fm.schema[(size_t)h].name;
+      if (by_id) throw spark_error("DuplicateFieldByFieldId", "\"requiredId\":" + std::to_string(id) + ",\"matchedFields\":\"" + json_escape(names) + "\"");
+      throw spark_error("DuplicateFieldCaseInsensitive", "\"requiredFieldName\":\"" + json_escape(name) + "\",\"matchedOrcFields\":\"[" + json_escape(names) + "]\"");
+    }
+    return hits.empty() ? -1 : hits[0];
+  };
+  int at = -1;
+  if (want.nest == 0) {
+    at = child_of(0, want.name, want.field_id);
+    if (at >= 0 && fm.schema[(size_t)at].num_children > 0)
+      throw CometError("Parquet column '" + want.name + "' is a group (struct / list / map) in the file but is read as " + want.dtype.str());
+  } else {
+    const int g = child_of(0, want.parent, want.parent_field_id);
+    if (g < 0) throw CometError("Parquet column '" + want.parent + "': a nested column the file does not have is not supported by the GPU scan yet");
+    const pq::SchemaElement& ge = fm.schema[(size_t)g];
+    if (ge.num_children == 0) throw CometError("Parquet column '" + want.parent + "' is a primitive in the file but is read as a nested column");
+    if (ge.repetition == 2) throw CometError("Parquet column '" + want.parent + "': repeated groups outside a LIST annotation are not supported by the GPU scan yet");
+    if (want.nest == 1) {
+      if (ge.converted_type == 3 || ge.converted_type == 1 || ge.converted_type == 2)      // LIST, MAP, MAP_KEY_VALUE
+        throw CometError("Parquet column '" + want.parent + "' is a list / map in the file but is read as a struct");
+      at = child_of(g, want.name, want.field_id);
+      if (at < 0) throw CometError("Parquet column '" + want.parent + "': struct field '" + want.name + "' the file does not have is not supported by the GPU scan yet");
+      if (fm.schema[(size_t)at].num_children > 0 || fm.schema[(size_t)at].repetition == 2)
+        throw CometError("Parquet column '" + want.parent + "." + want.name + "': nesting deeper than one level is not supported by the GPU scan yet");
+      cp.def_parent = tree[(size_t)g].def;
+    } else {
+      // the standard three-level list: <list-repetition> group <name> (LIST) { repeated group list { <element-repetition> <type> element; } }
+      // (parquet-format LogicalTypes.md "Lists"; the repeated group and the element may carry any name)
+      if (tree[(size_t)g].kids.size() != 1) throw CometError("Parquet column '" + want.parent + "': not a LIST group of one repeated field");
+      const int rp = tree[(size_t)g].kids[0];
+      const pq::SchemaElement& re = fm.schema[(size_t)rp];
+      if (re.repetition != 2) throw CometError("Parquet column '" + want.parent + "': not a LIST group of one repeated field");
+      if (re.num_children == 0) at = rp;                                     // legacy two-level list: the repeated field IS the element (required)
+      else if (tree[(size_t)rp].kids.size() == 1 && fm.schema[(size_t)tree[(size_t)rp].kids[0]].num_children == 0 && fm.schema[(size_t)tree[(size_t)rp].kids[0]].repetition != 2)
+        at = tree[(size_t)rp].kids[0];
+      else throw CometError("Parquet column '" + want.parent + "': lists of groups / of lists are not supported by the GPU scan yet");
+      cp.def_parent = tree[(size_t)g].def;
+      cp.def_slot = tree[(size_t)rp].def;
+    }
   }
-  if (hits.size() > 1) {
-    std::string names;
-    for (int h : hits) names += (names.empty() ? "" : ", ") + fm.schema[(size_t)h].name;
-    if (by_id) throw spark_error("DuplicateFieldByFieldId", "\"requiredId\":" + std::to_string(want.field_id) + ",\"matchedFields\":\"" + json_escape(names) + "\"");
-    throw spark_error("DuplicateFieldCaseInsensitive", "\"requiredFieldName\":\"" + json_escape(want.name) + "\",\"matchedOrcFields\":\"[" + json_escape(names) + "]\"");
-  }
-  if (hits.size() == 1) {
-    cp.leaf = hits[0] - 1;
-    cp.el = fm.schema[(size_t)hits[0]];
+  if (at >= 0) {
+    cp.leaf = tree[(size_t)at].leaf;
+    cp.el = fm.schema[(size_t)at];
+    cp.max_def = tree[(size_t)at].def;
+    cp.max_rep = tree[(size_t)at].rep;
   }
   if (cp.leaf < 0) {
     // a column the file does not have reads as NULL, or as its default value (schema evolution; schema_adapter.rs replace_missing_with_defaults)
@@ -436,7 +508,7 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, const Sc
     cp.kind = -2;
     return cp;
   }
-  if (cp.el.repetition == 2) throw CometError("repeated Parquet columns are not supported by the GPU scan yet");
+  if (cp.el.repetition == 2 && want.nest != 2) throw CometError("repeated Parquet columns are not supported by the GPU scan yet");
   const DType& t = want.dtype;
   const int pt = cp.el.type;
   auto bad = [&]() { return CometError("Parquet column '" + want.name + "': physical type " + std::to_string(pt) + " cannot be read as " + t.str() + " by the GPU scan yet"); };
@@ -735,7 +807,7 @@ struct HostChunk {
   std::vector<PqInflate> zinflate; // … zstd ones: `preamble` = the page's first block in zblocks, `pad` = its block count
   std::vector<comet_zstd2::ZBlock> zblocks;   // what the host walk over those pages' frames found (device/zstd2.hpp)
   std::vector<PqPage> pages;
-  std::vector<PqRun> def_runs, idx_runs;
+  std::vector<PqRun> def_runs, idx_runs, rep_runs;
   std::vector<uint8_t> dict_bytes;
   std::vector<int32_t> dict_offs;
   std::vector<int64_t> str_offs;
@@ -837,9 +909,15 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   if ((size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
   const pq::ColumnMeta& cm = rg.columns[(size_t)cp.leaf];
   hc.cp = cp;
-  const int max_def = cp.el.repetition == 1 ? 1 : 0;
+  const int max_def = cp.max_def;
+  // (a nested leaf: its levels take more than one bit, a list's element has repetition levels in front of them and more entries than the row
+  // group has rows; its pages are inflated on the host and its levels parsed there — the device paths below read one-bit levels)
+  const bool nested_leaf = cp.nested_leaf();
+  const int def_bw = max_def <= 1 ? 1 : 32 - __builtin_clz((unsigned)max_def);
+  const int rep_bw = cp.max_rep <= 1 ? 1 : 32 - __builtin_clz((unsigned)cp.max_rep);
+  if (nested_leaf && src.keep) throw CometError("internal: page-index pruning over a nested column");
   hc.max_def = max_def;
-  hc.n_rows = src.keep ? ranges_rows(*src.keep) : rg.num_rows;
+  hc.n_rows = src.keep ? ranges_rows(*src.keep) : cp.max_rep > 0 ? cm.num_values : rg.num_rows;
   hc.compressed = cm.total_compressed;
   size_t spos = 0;
   std::vector<PqPage>& pages = hc.pages;
@@ -855,7 +933,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
   // land), else into this thread's scratch; then parse from memory
   static thread_local std::vector<uint8_t> raw;
   const size_t staged_cap = slot_cap;
-  const bool in_place = so.device_snappy && in_place_shape(cm, cp.is_string, so) && raw_area != nullptr && raw_area > staged && raw_cap >= in_place_extra(cm);
+  const bool in_place = so.device_snappy && !nested_leaf && in_place_shape(cm, cp.is_string, so) && raw_area != nullptr && raw_area > staged && raw_cap >= in_place_extra(cm);
   uint8_t* rawp;
   if (in_place) {
     rawp = raw_area;
@@ -901,9 +979,16 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
         const int64_t m = std::min<int64_t>(r.count, upto - r.value_start);
         if (r.is_rle) {
           if (r.rle_value == (uint32_t)max_def) cnt += m;
-        } else {
+        } else if (def_bw == 1) {
           const uint8_t* b = levels + (r.byte_off & ~kInflatedBit);
           for (int64_t i = 0; i < m; i++) cnt += (b[i >> 3] >> (i & 7)) & 1;     // max_def == 1: one bit per level
+        } else {
+          const uint8_t* b = levels + (r.byte_off & ~kInflatedBit);
+          for (int64_t i = 0; i < m; i++) {
+            const int64_t bit = i * def_bw;
+            const uint32_t w = (uint32_t)b[bit >> 3] | ((uint32_t)b[(bit >> 3) + 1] << 8);      // (def_bw ≤ 8: a level spans at most two bytes; staged pages are followed by 16 zero bytes)
+            cnt += ((w >> (bit & 7)) & ((1u << def_bw) - 1)) == (uint32_t)max_def;
+          }
         }
       }
       return cnt;
@@ -1062,7 +1147,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     // so the page is registered as PENDING — the device inflates it, the index section comes back over PCIe and the host parses the headers
     // then (read_columns, "deferred").  The bit width — the index section's first byte — is read here with the levels.
     const bool z_dict = (h.encoding == pq::RLE_DICTIONARY || h.encoding == pq::PLAIN_DICTIONARY) && so.device_zstd_dict && src.keep == nullptr;
-    if (so.device_snappy && so.device_zstd && cm.codec == pq::ZSTD && !cp.is_string && (h.encoding == pq::PLAIN || z_dict) && h.uncompressed_size >= kMinDevicePage &&
+    if (so.device_snappy && so.device_zstd && !nested_leaf && cm.codec == pq::ZSTD && !cp.is_string && (h.encoding == pq::PLAIN || z_dict) && h.uncompressed_size >= kMinDevicePage &&
         (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.def_bytes >= 0 && h.compressed_size > h.def_bytes && h.uncompressed_size > h.def_bytes)) &&
         (in_place || h.compressed_size <= h.uncompressed_size)) {
       const size_t comp_off = h.type == pq::DATA_PAGE ? 0 : (size_t)h.def_bytes;
@@ -1167,7 +1252,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     // (a page that did not compress — bit-packed dictionary indices of random values, doubles — is a little LARGER than its content: read
     // in place it crosses as it is and the one-wave kernel copies it at HBM speed; staged by copy it must fit the slot's uncompressed size)
     const int64_t dev_max_compressed = in_place ? (int64_t)h.uncompressed_size + h.uncompressed_size / 6 + 64 : (int64_t)h.uncompressed_size;
-    const bool dev_shape = so.device_snappy && cm.codec == pq::SNAPPY && !cp.is_string && h.uncompressed_size >= kMinDevicePage &&
+    const bool dev_shape = so.device_snappy && !nested_leaf && cm.codec == pq::SNAPPY && !cp.is_string && h.uncompressed_size >= kMinDevicePage &&
                            h.compressed_size <= dev_max_compressed && (h.type == pq::DATA_PAGE || (h.v2_compressed && !h.rep_bytes && h.compressed_size > h.def_bytes));
     bool dev_page = dev_shape && h.encoding == pq::PLAIN;
     // … and so do dictionary-encoded pages: the run headers of the index section are read THROUGH the compressed stream (SnappyView:
@@ -1295,6 +1380,18 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
       { HostTimer tm(g_ns_inflate); pq::decompress(cm.codec, body, (size_t)h.compressed_size, staged + spos, (size_t)h.uncompressed_size); }
       page_end = spos + (size_t)h.uncompressed_size;
       size_t p = page_begin;
+      if (cp.max_rep > 0) {      // a list's element: [length][repetition levels] come first
+        if (h.rep_encoding != pq::RLE) throw CometError("parquet: only RLE repetition levels are supported");
+        uint32_t rl;
+        if (p + 4 > page_end) throw CometError("parquet: truncated data page");
+        memcpy(&rl, staged + p, 4);
+        p += 4;
+        if ((size_t)rl > page_end - p) throw CometError("parquet: repetition levels longer than their page");
+        pg.rep_run_first = (int32_t)hc.rep_runs.size();
+        parse_hybrid_runs(staged, p, p + rl, rep_bw, h.num_values, hc.rep_runs);
+        pg.rep_run_count = (int32_t)hc.rep_runs.size() - pg.rep_run_first;
+        p += rl;
+      }
       if (max_def > 0) {
         if (h.def_encoding != pq::RLE) throw CometError("parquet: only RLE definition levels are supported");
         uint32_t dl;
@@ -1303,24 +1400,31 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
         p += 4;
         if ((size_t)dl > page_end - p) throw CometError("parquet: definition levels longer than their page");
         pg.def_run_first = (int32_t)def_runs.size();
-        parse_hybrid_runs(staged, p, p + dl, 1, h.num_values, def_runs);
+        parse_hybrid_runs(staged, p, p + dl, def_bw, h.num_values, def_runs);
         pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
         p += dl;
       }
       vals_begin = p;
     } else {
       // v2: levels are never compressed and precede the (optionally compressed) values
-      if (h.rep_bytes) throw CometError("parquet: repetition levels are not supported");
-      if (h.def_bytes < 0 || h.def_bytes > h.compressed_size || h.def_bytes > h.uncompressed_size) throw CometError("parquet: v2 page levels longer than the page");
-      memcpy(staged + spos, body, (size_t)h.def_bytes);
+      if (h.rep_bytes && cp.max_rep == 0) throw CometError("parquet: repetition levels in a column that is not repeated");
+      if (h.rep_bytes < 0 || h.def_bytes < 0 || (int64_t)h.rep_bytes + h.def_bytes > h.compressed_size || (int64_t)h.rep_bytes + h.def_bytes > h.uncompressed_size)
+        throw CometError("parquet: v2 page levels longer than the page");
+      const size_t lv = (size_t)h.rep_bytes + (size_t)h.def_bytes;
+      memcpy(staged + spos, body, lv);
+      if (cp.max_rep > 0 && h.rep_bytes) {
+        pg.rep_run_first = (int32_t)hc.rep_runs.size();
+        parse_hybrid_runs(staged, spos, spos + (size_t)h.rep_bytes, rep_bw, h.num_values, hc.rep_runs);
+        pg.rep_run_count = (int32_t)hc.rep_runs.size() - pg.rep_run_first;
+      }
       if (max_def > 0 && h.def_bytes) {
         pg.def_run_first = (int32_t)def_runs.size();
-        parse_hybrid_runs(staged, spos, spos + (size_t)h.def_bytes, 1, h.num_values, def_runs);
+        parse_hybrid_runs(staged, spos + (size_t)h.rep_bytes, spos + lv, def_bw, h.num_values, def_runs);
         pg.def_run_count = (int32_t)def_runs.size() - pg.def_run_first;
       }
-      vals_begin = spos + (size_t)h.def_bytes;
-      const size_t vcomp = (size_t)h.compressed_size - (size_t)h.def_bytes, vun = (size_t)h.uncompressed_size - (size_t)h.def_bytes;
-      { HostTimer tm(g_ns_inflate); pq::decompress(h.v2_compressed ? cm.codec : pq::UNCOMPRESSED, body + h.def_bytes, vcomp, staged + vals_begin, vun); }
+      vals_begin = spos + lv;
+      const size_t vcomp = (size_t)h.compressed_size - lv, vun = (size_t)h.uncompressed_size - lv;
+      { HostTimer tm(g_ns_inflate); pq::decompress(h.v2_compressed ? cm.codec : pq::UNCOMPRESSED, body + lv, vcomp, staged + vals_begin, vun); }
       page_end = vals_begin + vun;
     }
     int value_encoding = h.encoding;
@@ -1420,7 +1524,7 @@ void decode_chunk_host(const ChunkSource& src, const StructField& want, const Sc
     emit(pg, values_seen, values_seen + h.num_values, staged);
     values_seen += h.num_values;
   }
-  if (values_seen != rg.num_rows || out_pos != hc.n_rows) throw CometError("parquet: column chunk values do not add up to the row group's rows (nested data?)");
+  if (values_seen != (cp.max_rep > 0 ? cm.num_values : rg.num_rows) || out_pos != hc.n_rows) throw CometError("parquet: column chunk values do not add up to the row group's rows");
   if (pages.empty()) throw CometError("parquet: column chunk without data pages");
   memset(staged + spos, 0, 16);
   hc.spos = spos;
@@ -1667,13 +1771,67 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   if (trace) pool_miss_counters(miss0);
   const auto t_begin = std::chrono::steady_clock::now();
   auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-  const size_t ncol = op.required_schema.size();
+  // The scan works on LEAVES: a top-level column of a flat type is its own leaf; a struct column is one leaf per field, a list column the one
+  // leaf of its elements (one level of nesting: parquet_support.rs:249-383 converts structs, lists and maps of any depth).  Every leaf runs
+  // through the same machinery — its entries (rows; a list leaf: its level entries) are decoded into values + validity — and a nested
+  // column is assembled from its leaves' values and LEVELS at the end (pq_levels_kernel and the assembly kernels in parquet_kernels.hip).
+  const size_t ntop = op.required_schema.size();
+  std::vector<StructField> fields;               // the leaves
+  struct TopCol { int kind = 0; size_t first = 0, count = 0; };      // kind 0 flat, 1 struct, 2 list
+  std::vector<TopCol> tops(ntop);
+  std::vector<int> top_of;                       // leaf → its top-level column
+  for (size_t t = 0; t < ntop; t++) {
+    const StructField& f = op.required_schema[t];
+    tops[t].first = fields.size();
+    if (f.dtype.id == TypeId::Struct) {
+      tops[t].kind = 1;
+      if (f.dtype.kids.empty()) throw CometError("Parquet column '" + f.name + "': a struct without fields");
+      for (size_t k = 0; k < f.dtype.kids.size(); k++) {
+        if (f.dtype.kids[k].is_nested()) throw CometError("Parquet column '" + f.name + "': nesting deeper than one level is not supported by the GPU scan yet");
+        StructField lf;
+        lf.name = k < f.dtype.kid_names.size() ? f.dtype.kid_names[k] : std::string();
+        lf.dtype = f.dtype.kids[k];
+        lf.nullable = k < f.dtype.kid_nullable.size() ? f.dtype.kid_nullable[k] != 0 : true;
+        lf.nest = 1;
+        lf.parent = f.name;
+        lf.parent_field_id = f.field_id;
+        fields.push_back(lf);
+        top_of.push_back((int)t);
+      }
+    } else if (f.dtype.id == TypeId::List) {
+      tops[t].kind = 2;
+      if (f.dtype.kids.size() != 1) throw CometError("Parquet column '" + f.name + "': a list without an element type");
+      const DType& el = f.dtype.kids[0];
+      if (el.is_nested() || el.id == TypeId::String || el.id == TypeId::Bytes || el.id == TypeId::Bool)
+        throw CometError("Parquet column '" + f.name + "': lists of " + el.str() + " are not supported by the GPU scan yet (fixed-width elements are)");
+      StructField lf;
+      lf.name = "element";
+      lf.dtype = el;
+      lf.nest = 2;
+      lf.parent = f.name;
+      lf.parent_field_id = f.field_id;
+      fields.push_back(lf);
+      top_of.push_back((int)t);
+    } else if (f.dtype.is_nested()) {
+      throw CometError("Parquet column '" + f.name + "': " + f.dtype.str() + " columns are not supported by the GPU scan yet");
+    } else {
+      fields.push_back(f);
+      top_of.push_back((int)t);
+    }
+    tops[t].count = fields.size() - tops[t].first;
+  }
+  bool any_nested = false;
+  for (auto& tc : tops) any_nested |= tc.kind != 0;
+  const size_t ncol = fields.size();
   const size_t npart = op.partition_schema.size();
-  DevTable out;
+  DevTable out, lf_out;                          // lf_out: the leaves' columns (types / cols / has_valid), out: what the scan returns
   for (auto& f : op.required_schema) out.types.push_back(f.dtype);
   for (auto& f : op.partition_schema) out.types.push_back(f.dtype);
-  out.cols.assign(ncol + npart, DeviceColumnView());
-  out.has_valid.assign(ncol + npart, false);
+  out.cols.assign(ntop + npart, DeviceColumnView());
+  out.has_valid.assign(ntop + npart, false);
+  for (auto& f : fields) lf_out.types.push_back(f.dtype);
+  lf_out.cols.assign(ncol, DeviceColumnView());
+  lf_out.has_valid.assign(ncol, false);
   if (op.files.empty()) return out;   // EmptyExec (planner.rs:1548-1556)
   if (op.encryption_enabled) throw CometError("Parquet modular encryption is not supported by the GPU scan");
   ScanOptions so = ScanOptions::of(op);
@@ -1686,7 +1844,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   for (auto& kv : config_)
     if (kv.first == "spark.comet.gpu.scan.deviceDecompress") so.device_snappy_mode = kv.second == "auto" ? -1 : (kv.second != "false" && kv.second != "0");
   if (op.default_values.size() != op.default_values_indexes.size()) throw CometError("NativeScan: default_values and default_values_indexes differ in length");
-  auto default_of = [&](size_t c) -> const Expr* {
+  auto default_of = [&](size_t leaf) -> const Expr* {
+    if (fields[leaf].nest != 0) return nullptr;      // (default values belong to top-level columns)
+    const size_t c = (size_t)top_of[leaf];
     for (size_t k = 0; k < op.default_values_indexes.size(); k++)
       if ((size_t)op.default_values_indexes[k] == c) return op.default_values[k].get();
     return nullptr;
@@ -1699,6 +1859,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   // pass 1: open files, pick row groups (midpoint rule), prune by statistics and page index, total rows
   std::vector<Sel> sels;
   int64_t total_rows = 0, rg_pruned = 0, rows_pruned = 0;
+  if (any_nested) page_index = false;            // (a kept row range does not say which ENTRIES of a list leaf it covers)
   select_row_groups(op, page_index, sels, total_rows, rg_pruned, rows_pruned);
   row_groups_pruned_ += rg_pruned;
   rows_pruned_page_index_ += rows_pruned;
@@ -1722,32 +1883,38 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   std::vector<std::vector<size_t>> raw_off(ncol, std::vector<size_t>(nsel + 1, 0));
   std::vector<size_t> raw_base(ncol, 0);
   std::vector<std::unique_ptr<PinnedBuf>> col_staged(ncol);
+  // a leaf's ENTRIES: its rows — or, the element leaf of a list, its level entries (ColumnMetaData.num_values); per row group where they start
+  std::vector<std::vector<int64_t>> ent_off(ncol, std::vector<int64_t>(nsel + 1, 0));
+  std::vector<int64_t> ent_total(ncol, 0);
   for (size_t c = 0; c < ncol; c++) {
     bool have = false;
     const Expr* dflt = default_of(c);
     for (size_t si = 0; si < nsel; si++) {
-      ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
+      ColumnPlan cp = plan_column(fields[c], *sels[si].meta, so);
       const pq::RowGroup& rg = sels[si].meta->row_groups[(size_t)sels[si].rg];
       if (!cp.missing && (size_t)cp.leaf >= rg.columns.size()) throw CometError("parquet: column index out of range");
+      ent_off[c][si + 1] = ent_off[c][si] + ((!cp.missing && cp.max_rep > 0) ? rg.columns[(size_t)cp.leaf].num_values : sels[si].rows);
       chunk_missing[c * nsel + si] = cp.missing;
       if (!cp.missing && !have) { plans[c] = cp; have = true; }
       size_t cap_bytes, raw_bytes = 0;
       if (cp.missing) {
-        cap_bytes = synth_capacity(op.required_schema[c].dtype, rg.num_rows);
+        cap_bytes = synth_capacity(fields[c].dtype, rg.num_rows);
       } else {
         ChunkSource csrc{sels[si].file.get(), sels[si].meta.get(), sels[si].rg, nullptr};
         cap_bytes = chunk_staging_capacity(csrc, rg.columns[(size_t)cp.leaf], cp.el.repetition == 1 ? 1 : 0, cp.is_string, so);   // reads the chunk only if it holds DELTA_BYTE_ARRAY pages
-        if (in_place_shape(rg.columns[(size_t)cp.leaf], cp.is_string, so)) raw_bytes = in_place_extra(rg.columns[(size_t)cp.leaf]);
+        if (in_place_shape(rg.columns[(size_t)cp.leaf], cp.is_string || cp.nested_leaf(), so)) raw_bytes = in_place_extra(rg.columns[(size_t)cp.leaf]);
       }
       slot_off[c][si + 1] = slot_off[c][si] + cap_bytes;
       raw_off[c][si + 1] = raw_off[c][si] + raw_bytes;
     }
     raw_base[c] = (slot_off[c][nsel] + 64 + 63) & ~(size_t)63;
     if (!have) {
-      plans[c] = plan_column(op.required_schema[c], *sels[0].meta, so);
+      plans[c] = plan_column(fields[c], *sels[0].meta, so);
       all_missing[c] = dflt == nullptr || dflt->lit_null;
     }
-    plans[c].out_width = out_width_of(op.required_schema[c].dtype);
+    plans[c].out_width = out_width_of(fields[c].dtype);
+    ent_total[c] = ent_off[c][nsel];
+    if (ent_total[c] >= ((int64_t)1 << 31)) throw CometError("GPU Parquet scan: more than 2^31 list elements in one partition");
     col_staged[c].reset(new PinnedBuf());
     col_staged[c]->ensure(raw_base[c] + raw_off[c][nsel] + 64);
   }
@@ -1790,16 +1957,16 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     order[c] = c;
     for (size_t si = 0; si < nsel; si++) {
       if (chunk_missing[c * nsel + si]) continue;
-      ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
+      ColumnPlan cp = plan_column(fields[c], *sels[si].meta, so);
       const pq::ColumnMeta& cm = sels[si].meta->row_groups[(size_t)sels[si].rg].columns[(size_t)cp.leaf];
       col_bytes[c] += cm.total_compressed;
       // snappy chunks of fixed-width columns are what the device inflates: PLAIN pages, and dictionary-encoded pages whose run headers the
       // host reads through the compressed stream
-      if (cm.codec == pq::SNAPPY && !cp.is_string && cp.src_width > 0 && cm.num_values > 0 &&
+      if (cm.codec == pq::SNAPPY && !cp.is_string && !cp.nested_leaf() && cp.src_width > 0 && cm.num_values > 0 &&
           (so.device_dict_pages || (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values))
         plain_snappy_bytes += cm.total_uncompressed;
       // … and zstd chunks: PLAIN pages, and — when the chunk is read whole — dictionary-encoded pages (index sections come back for their run headers)
-      if (cm.codec == pq::ZSTD && so.device_zstd && !cp.is_string && cp.src_width > 0 && cm.num_values > 0 &&
+      if (cm.codec == pq::ZSTD && so.device_zstd && !cp.is_string && !cp.nested_leaf() && cp.src_width > 0 && cm.num_values > 0 &&
           ((so.device_zstd_dict && sels[si].keep == nullptr) || (double)cm.total_uncompressed >= 0.75 * (double)cp.src_width * (double)cm.num_values))
         plain_zstd_bytes += cm.total_uncompressed;
     }
@@ -1838,8 +2005,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const size_t cap = slot_off[c][si + 1] - slot_off[c][si];
     const size_t rcap = raw_off[c][si + 1] - raw_off[c][si];
     uint8_t* rarea = rcap ? (uint8_t*)col_staged[c]->p + raw_base[c] + raw_off[c][si] : nullptr;
-    if (chunk_missing[t]) synth_chunk(op.required_schema[c], default_of(c), sels[si].rows, chunks[t], slot, cap);
-    else { HostTimer tm(g_ns_chunk); decode_chunk_host(src, op.required_schema[c], so, chunks[t], slot, cap, rarea, rcap, raw_read); }
+    if (chunk_missing[t]) synth_chunk(fields[c], default_of(c), sels[si].rows, chunks[t], slot, cap);
+    else { HostTimer tm(g_ns_chunk); decode_chunk_host(src, fields[c], so, chunks[t], slot, cap, rarea, rcap, raw_read); }
   };
   // The unit of host work is a PIECE, in the order the device consumes the bytes (columns largest first, their chunks in row order).  A chunk
   // that is read in place is read in pieces of a couple of MiB by whichever threads are free, and the thread that lands its last piece walks
@@ -1856,11 +2023,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       pieces_left[t].store(1);
       bool split = false;
       if (!all_missing[c] && !chunk_missing[t] && raw_off[c][si + 1] > raw_off[c][si] && so.device_snappy) {
-        ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
+        ColumnPlan cp = plan_column(fields[c], *sels[si].meta, so);
         const pq::ColumnMeta& cm = sels[si].meta->row_groups[(size_t)sels[si].rg].columns[(size_t)cp.leaf];
         const int64_t off = chunk_file_offset(cm);
         // (a chunk that lies outside its file stays whole: decode_chunk_host says so)
-        if (in_place_shape(cm, cp.is_string, so) && off >= 0 && cm.total_compressed > 0 && (size_t)(off + cm.total_compressed) <= sels[si].file->size &&
+        if (in_place_shape(cm, cp.is_string || cp.nested_leaf(), so) && off >= 0 && cm.total_compressed > 0 && (size_t)(off + cm.total_compressed) <= sels[si].file->size &&
             raw_off[c][si + 1] - raw_off[c][si] >= in_place_extra(cm)) {
           const size_t total = (size_t)cm.total_compressed;
           size_t np = 0;
@@ -1880,7 +2047,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   const size_t npieces = pieces.size();
   auto read_piece = [&](const Piece& pc) {
     const size_t c = pc.t / nsel, si = pc.t % nsel;
-    ColumnPlan cp = plan_column(op.required_schema[c], *sels[si].meta, so);
+    ColumnPlan cp = plan_column(fields[c], *sels[si].meta, so);
     const pq::ColumnMeta& cm = sels[si].meta->row_groups[(size_t)sels[si].rg].columns[(size_t)cp.leaf];
     HostTimer tc(g_ns_chunk);
     HostTimer tm(g_ns_read);
@@ -2083,7 +2250,9 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       }
   };
   auto tiles = std::make_shared<DevBuf>();
-  tiles->ensure((size_t)((total_rows + 1023) / 1024 + 2) * 8);
+  int64_t max_entries = total_rows;
+  for (size_t c = 0; c < ncol; c++) max_entries = std::max(max_entries, ent_total[c]);
+  tiles->ensure((size_t)((max_entries + 1023) / 1024 + 2) * 8);
   // one word per column: first failing page of the device decompression (job << 8 | code), 0 = fine
   auto inflate_err = std::make_shared<DevBuf>();
   inflate_err->ensure(ncol * 4 + 16);
@@ -2097,19 +2266,24 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   static const bool one_wave_snappy = getenv("COMET_SNAPPY_ONE_WAVE") != nullptr && atoi(getenv("COMET_SNAPPY_ONE_WAVE")) != 0;
   // (`dr`: the column has pages whose run headers the device walks — their descriptors, the prefix sum of their run counts and the total are there)
   struct DeviceRuns { std::shared_ptr<DevBuf> pend, offsets; int npend = 0; int64_t total = 0; };
+  // the LEVELS of nested leaves, one byte per entry (finish_column fills them; the assembly at the end reads them)
+  std::vector<std::shared_ptr<DevBuf>> leaf_def(ncol), leaf_rep(ncol);
+  std::vector<std::shared_ptr<DevBuf>> leaf_raw_values(ncol);      // a list leaf: its values over ENTRIES (the elements are compacted out of them)
   auto finish_column = [&](const size_t c, const std::shared_ptr<ColumnDevice>& cd, const size_t S, const bool may_inflate, const DeviceRuns* dr) {
     const ColumnPlan& cp = plans[c];
     const bool is_string = cp.is_string;
+    const int64_t nrows = ent_total[c];           // the leaf's entries (a list's element leaf: more than the scan has rows)
     auto values = std::make_shared<DevBuf>();
     auto valid_bytes = std::make_shared<DevBuf>();
     auto lengths = std::make_shared<DevBuf>();
     bool any_optional = false;
-    size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0, n_jobs = 0, n_zjobs = 0;
+    size_t n_pages = 0, n_def = 0, n_idx = 0, n_dict = 0, n_doffs = 0, n_soffs = 0, n_jobs = 0, n_zjobs = 0, n_rep = 0;
     for (size_t si = 0; si < nsel; si++) {
       HostChunk& hc = chunks[c * nsel + si];
-      any_optional |= hc.max_def > 0 && !hc.no_nulls;
+      any_optional |= hc.max_def > 0 && (!hc.no_nulls || cp.nested_leaf());      // (a nested leaf always keeps its levels: the assembly reads them)
       n_pages += hc.pages.size();
-      n_def += hc.no_nulls ? 0 : hc.def_runs.size();
+      n_def += (hc.no_nulls && !cp.nested_leaf()) ? 0 : hc.def_runs.size();
+      n_rep += hc.rep_runs.size();
       n_idx += hc.idx_runs.size();
       n_dict += (hc.dict_bytes.size() + 15) & ~(size_t)15;
       n_doffs += hc.dict_offs.size();
@@ -2130,6 +2304,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     const size_t off_doffs = o; o = al(o + n_doffs * 4 + 16);
     const size_t off_soffs = o; o = al(o + n_soffs * 8 + 16);
     const size_t off_jobs = o; o = al(o + n_jobs * sizeof(PqInflate) + 16);
+    const size_t off_rep = o; o = al(o + n_rep * sizeof(PqRun) + 16);
     cd->h_tables.ensure(o + 16);
     cd->tables.ensure(o + 16);
     char* tb_h = (char*)cd->h_tables.p;
@@ -2142,14 +2317,15 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       int32_t* DO = (int32_t*)(tb_h + off_doffs);
       int64_t* SO = (int64_t*)(tb_h + off_soffs);
       PqInflate* J = (PqInflate*)(tb_h + off_jobs);
-      size_t ip = 0, id = 0, ii = 0, idb = 0, ido = 0, iso = 0, ij = 0;
+      PqRun* RP = (PqRun*)(tb_h + off_rep);
+      size_t ip = 0, id = 0, ii = 0, idb = 0, ido = 0, iso = 0, ij = 0, irp = 0;
       runs_kernel_ok = true;
       for (size_t si = 0; si < nsel; si++) {
         HostChunk& hc = chunks[c * nsel + si];
         const int64_t base = (int64_t)slot_off[c][si];
         // an offset into the chunk's slot of the staged region, or (flagged) of the device-decompressed region behind it
         auto global_off = [&](int64_t v) { return (v & kInflatedBit) ? (v & ~kInflatedBit) + base + (int64_t)S : v + base; };
-        const bool nulls = hc.max_def > 0 && !hc.no_nulls;
+        const bool nulls = hc.max_def > 0 && (!hc.no_nulls || cp.nested_leaf());
         for (const PqInflate& src : hc.inflate) {
           PqInflate job = src;
           job.src_off += base;
@@ -2158,7 +2334,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         }
         for (const PqPage& src : hc.pages) {
           PqPage pg = src;
-          pg.row_start += sels[si].row_off;
+          pg.row_start += ent_off[c][si];
+          pg.rep_run_first += (int32_t)irp;
           pg.values_off = global_off(pg.values_off);
           pg.str_first += (int64_t)iso;
           if (nulls) pg.def_run_first += (int32_t)id;
@@ -2172,6 +2349,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         if (nulls)
           for (const PqRun& r : hc.def_runs) { D[id] = r; D[id].byte_off = global_off(r.byte_off); id++; }
         for (const PqRun& r : hc.idx_runs) { I[ii] = r; I[ii].byte_off = global_off(r.byte_off); ii++; }
+        for (const PqRun& r : hc.rep_runs) { RP[irp] = r; RP[irp].byte_off = global_off(r.byte_off); irp++; }
         // every index run (and PLAIN chunk) learns its page: the run-at-a-time kernel starts from the run
         for (size_t gp = ip - hc.pages.size(); gp < ip; gp++)
           for (int32_t r = P[gp].idx_run_first; r < P[gp].idx_run_first + P[gp].idx_run_count; r++) I[r].page = (int32_t)gp;
@@ -2205,26 +2383,43 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     memset(&a, 0, sizeof a);
     a.pages = (const PqPage*)(tb + off_pages);
     a.npages = (int32_t)n_pages;
-    a.max_def = any_optional ? 1 : 0;
+    a.max_def = any_optional ? std::max(cp.max_def, 1) : 0;      // (the validity kernel compares with it; every other kernel asks "> 0")
+    a.rep_runs = (const PqRun*)(tb + off_rep);
+    a.max_rep = cp.max_rep;
     a.def_runs = (const PqRun*)(tb + off_def);
     a.idx_runs = (const PqRun*)(tb + off_idx);
     a.bytes = (const uint8_t*)cd->bytes.p;
     a.dict = (const uint8_t*)(tb + off_dict);
     a.dict_offs = (const int32_t*)(tb + off_doffs);
     a.plain_str_offs = (const int64_t*)(tb + off_soffs);
-    a.n_rows = total_rows;
+    a.n_rows = nrows;
     a.out_width = cp.out_width;
     a.n_idx_runs = (int32_t)(n_idx + n_idx_dev);
     if (any_optional) {
-      valid_bytes->ensure((size_t)total_rows + 16);
-      if (!vidx->p) vidx->ensure((size_t)total_rows * 4 + 16);
+      valid_bytes->ensure((size_t)nrows + 16);
+      if (!vidx->p) vidx->ensure((size_t)nrows * 4 + 16);
       a.valid_out = (uint8_t*)valid_bytes->p;
       a.vidx = (uint32_t*)vidx->p;
       pq_launch_validity(&a, stream_);
-      pq_launch_vidx(a.valid_out, total_rows, (uint64_t*)tiles->p, a.vidx, stream_);
+      pq_launch_vidx(a.valid_out, nrows, (uint64_t*)tiles->p, a.vidx, stream_);
+    }
+    if (fields[c].nest != 0) {
+      leaf_def[c] = std::make_shared<DevBuf>();
+      leaf_def[c]->ensure((size_t)nrows + 16);
+      if (any_optional) pq_launch_levels(&a, 0, (uint8_t*)leaf_def[c]->p, stream_);
+      else HIP_CHECK(hipMemsetAsync(leaf_def[c]->p, cp.max_def, (size_t)nrows + 16, stream_));      // a chunk without level runs: everything defined
+      out.owners.push_back(leaf_def[c]);
+      if (fields[c].nest == 2) {
+        leaf_rep[c] = std::make_shared<DevBuf>();
+        leaf_rep[c]->ensure((size_t)nrows + 16);
+        PqDecodeArgs ar = a;
+        if (!any_optional) ar.max_def = std::max(cp.max_def, 1);
+        pq_launch_levels(&ar, 1, (uint8_t*)leaf_rep[c]->p, stream_);
+        out.owners.push_back(leaf_rep[c]);
+      }
     }
     if (!is_string) {
-      values->ensure((size_t)total_rows * cp.out_width + 16);
+      values->ensure((size_t)nrows * cp.out_width + 16);
       a.values_out = values->p;
       // a column without NULLs (and without pruned pages) is decoded a RUN at a time: a wave takes one bit-packed run / RLE run / chunk of
       // a PLAIN page and every lane decodes 8 of its values with all loads in flight at once; otherwise row by row
@@ -2234,7 +2429,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
           // with NULLs a page's runs hold fewer values than it has rows: the values are decoded densely by their ordinal among the
           // column's non-NULL values (vidx of the page's first row + index in the page), then spread to their rows
           auto dense = std::make_shared<DevBuf>();
-          dense->ensure((size_t)total_rows * cp.out_width + 16);
+          dense->ensure((size_t)nrows * cp.out_width + 16);
           a.dense_out = dense->p;
           pq_launch_decode_runs(&a, stream_);
           pq_launch_expand_nulls(&a, stream_);
@@ -2247,17 +2442,17 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         pq_launch_decode_fixed(&a, stream_);
       }
     } else {
-      lengths->ensure((size_t)total_rows * 4 + 16);
+      lengths->ensure((size_t)nrows * 4 + 16);
       a.lengths_out = (uint32_t*)lengths->p;
       pq_launch_string_lengths(&a, stream_);
     }
     DeviceColumnView cv;
     if (is_string) {
       auto offsets = std::make_shared<DevBuf>();
-      offsets->ensure((size_t)(total_rows + 1) * 4 + 16);
-      pq_launch_u32_scan((const uint32_t*)lengths->p, total_rows, (uint64_t*)tiles->p, (int32_t*)offsets->p, stream_);
+      offsets->ensure((size_t)(nrows + 1) * 4 + 16);
+      pq_launch_u32_scan((const uint32_t*)lengths->p, nrows, (uint64_t*)tiles->p, (int32_t*)offsets->p, stream_);
       int32_t total_bytes = 0;
-      read_small(&total_bytes, (char*)offsets->p + (size_t)total_rows * 4, 4);
+      read_small(&total_bytes, (char*)offsets->p + (size_t)nrows * 4, 4);
       auto data = std::make_shared<DevBuf>();
       data->ensure((size_t)std::max(total_bytes, 1) + 16);
       a.str_offsets = (const int32_t*)offsets->p;
@@ -2268,27 +2463,28 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       out.owners.push_back(offsets);
       out.owners.push_back(data);
       out.owners.push_back(lengths);
-    } else if (out.types[c].id == TypeId::Bool) {
+    } else if (lf_out.types[c].id == TypeId::Bool) {
       auto bits = std::make_shared<DevBuf>();
-      bits->ensure((size_t)((total_rows + 7) / 8) + 16);
-      pq_launch_pack((const uint8_t*)values->p, (uint8_t*)bits->p, total_rows, stream_);
+      bits->ensure((size_t)((nrows + 7) / 8) + 16);
+      pq_launch_pack((const uint8_t*)values->p, (uint8_t*)bits->p, nrows, stream_);
       cv.data = bits->p;
       out.owners.push_back(bits);
       out.owners.push_back(values);
     } else {
       cv.data = values->p;
       out.owners.push_back(values);
+      leaf_raw_values[c] = values;
     }
     if (any_optional) {
       auto bm = std::make_shared<DevBuf>();
-      bm->ensure((size_t)((total_rows + 7) / 8) + 16);
-      pq_launch_pack((const uint8_t*)valid_bytes->p, (uint8_t*)bm->p, total_rows, stream_);
+      bm->ensure((size_t)((nrows + 7) / 8) + 16);
+      pq_launch_pack((const uint8_t*)valid_bytes->p, (uint8_t*)bm->p, nrows, stream_);
       cv.valid = (const uint8_t*)bm->p;
-      out.has_valid[c] = true;
+      lf_out.has_valid[c] = true;
       out.owners.push_back(bm);
     }
     out.owners.push_back(valid_bytes);
-    out.cols[c] = cv;
+    lf_out.cols[c] = cv;
   };
   struct Deferred { size_t c; std::shared_ptr<ColumnDevice> cd; size_t S; bool may_inflate; std::shared_ptr<PinnedBuf> readback; hipEvent_t done; std::vector<const uint8_t*> at;
                     DeviceRuns dr; std::shared_ptr<DevBuf> counts; bool finished = false; };
@@ -2331,7 +2527,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       // all-NULL column: zeroed values, zeroed validity bitmap
       DeviceColumnView mv;
       auto zeros = std::make_shared<DevBuf>();
-      const size_t vb = cp.is_string ? (size_t)(total_rows + 1) * 4 : out.types[c].id == TypeId::Bool ? (size_t)((total_rows + 7) / 8) : (size_t)total_rows * cp.out_width;
+      const size_t vb = cp.is_string ? (size_t)(total_rows + 1) * 4 : lf_out.types[c].id == TypeId::Bool ? (size_t)((total_rows + 7) / 8) : (size_t)total_rows * cp.out_width;
       zeros->ensure(vb + 16);
       HIP_CHECK(hipMemsetAsync(zeros->p, 0, vb + 16, stream_));
       auto bm = std::make_shared<DevBuf>();
@@ -2340,8 +2536,8 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       mv.data = zeros->p;
       mv.valid = (const uint8_t*)bm->p;
       if (cp.is_string) mv.aux = zeros->p;   // no bytes are ever addressed (all offsets 0)
-      out.has_valid[c] = true;
-      out.cols[c] = mv;
+      lf_out.has_valid[c] = true;
+      lf_out.cols[c] = mv;
       out.owners.push_back(zeros);
       out.owners.push_back(bm);
       for (size_t si = 0; si < nsel; si++) wait_for(c * nsel + si);
@@ -2640,6 +2836,76 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     finish_column(d.c, d.cd, d.S, d.may_inflate, nullptr);
   }
   readback_guard.done = true;
+  // ---- the scan's columns from their leaves: a flat column is its leaf; a struct is its fields' columns under a validity of its own; a list
+  // is assembled from its element leaf's levels (rows start where the repetition level is 0, an entry holds an element slot from the
+  // repeated group's definition level on) ----
+  for (size_t t = 0; t < ntop; t++) {
+    const TopCol& tc = tops[t];
+    const size_t l0 = tc.first;
+    if (tc.kind == 0) {
+      out.cols[t] = lf_out.cols[l0];
+      out.has_valid[t] = lf_out.has_valid[l0];
+      continue;
+    }
+    DeviceColumnView nv;
+    if (tc.kind == 1) {
+      for (size_t l = l0; l < l0 + tc.count; l++) {
+        nv.kids.push_back(lf_out.cols[l]);
+        nv.kid_has_valid.push_back(lf_out.has_valid[l] ? 1 : 0);
+      }
+      nv.kid_rows = total_rows;
+      const int def_parent = plans[l0].def_parent;
+      if (def_parent > 0) {        // an optional struct: NULL where its fields' definition level stops short of it
+        auto vb = std::make_shared<DevBuf>(), bm = std::make_shared<DevBuf>();
+        vb->ensure((size_t)total_rows + 16);
+        bm->ensure((size_t)((total_rows + 7) / 8) + 16);
+        pq_launch_level_ge((const uint8_t*)leaf_def[l0]->p, total_rows, def_parent, (uint8_t*)vb->p, stream_);
+        pq_launch_pack((const uint8_t*)vb->p, (uint8_t*)bm->p, total_rows, stream_);
+        nv.valid = (const uint8_t*)bm->p;
+        out.has_valid[t] = true;
+        out.owners.push_back(vb);
+        out.owners.push_back(bm);
+      }
+    } else {
+      const ColumnPlan& cp = plans[l0];
+      const int64_t n = ent_total[l0];
+      const int w = cp.out_width;
+      if (!leaf_raw_values[l0] || !leaf_def[l0] || !leaf_rep[l0]) throw CometError("internal: list column without its leaf's levels");
+      auto starts = std::make_shared<DevBuf>(), elems = std::make_shared<DevBuf>(), start_idx = std::make_shared<DevBuf>(), elem_idx = std::make_shared<DevBuf>();
+      auto offsets = std::make_shared<DevBuf>(), lvb = std::make_shared<DevBuf>(), lbm = std::make_shared<DevBuf>(), evb = std::make_shared<DevBuf>(), ebm = std::make_shared<DevBuf>(),
+           evals = std::make_shared<DevBuf>();
+      starts->ensure((size_t)n * 4 + 16);
+      elems->ensure((size_t)n * 4 + 16);
+      start_idx->ensure((size_t)(n + 1) * 4 + 16);
+      elem_idx->ensure((size_t)(n + 1) * 4 + 16);
+      offsets->ensure((size_t)(total_rows + 1) * 4 + 16);
+      lvb->ensure((size_t)total_rows + 16);
+      lbm->ensure((size_t)((total_rows + 7) / 8) + 16);
+      evb->ensure((size_t)n + 16);
+      ebm->ensure((size_t)((n + 7) / 8) + 16);
+      evals->ensure((size_t)n * (size_t)w + 16);
+      HIP_CHECK(hipMemsetAsync(evb->p, 0, (size_t)n + 16, stream_));
+      const uint8_t* defp = (const uint8_t*)leaf_def[l0]->p;
+      const uint8_t* repp = (const uint8_t*)leaf_rep[l0]->p;
+      pq_launch_list_flags(defp, repp, n, cp.def_slot, (uint32_t*)starts->p, (uint32_t*)elems->p, stream_);
+      pq_launch_u32_scan((const uint32_t*)starts->p, n, (uint64_t*)tiles->p, (int32_t*)start_idx->p, stream_);
+      pq_launch_u32_scan((const uint32_t*)elems->p, n, (uint64_t*)tiles->p, (int32_t*)elem_idx->p, stream_);
+      pq_launch_list_assemble(defp, repp, n, total_rows, cp.def_parent, cp.def_slot, cp.max_def, (const int32_t*)start_idx->p, (const int32_t*)elem_idx->p,
+                              (const uint8_t*)leaf_raw_values[l0]->p, w, (int32_t*)offsets->p, (uint8_t*)lvb->p, (uint8_t*)evb->p, (uint8_t*)evals->p, (uint32_t*)inflate_err->p + l0, stream_);
+      pq_launch_pack((const uint8_t*)lvb->p, (uint8_t*)lbm->p, total_rows, stream_);
+      pq_launch_pack((const uint8_t*)evb->p, (uint8_t*)ebm->p, n, stream_);
+      DeviceColumnView ev;
+      ev.data = evals->p;
+      ev.valid = (const uint8_t*)ebm->p;
+      nv.data = offsets->p;
+      nv.kids.push_back(ev);
+      nv.kid_has_valid.push_back(cp.max_def > cp.def_slot ? 1 : 0);       // (elements can be NULL only if the element field is optional)
+      nv.kid_rows = n;                                                    // room for; offsets[rows] says how many there are
+      if (cp.def_parent > 0) { nv.valid = (const uint8_t*)lbm->p; out.has_valid[t] = true; }
+      for (auto& b : {starts, elems, start_idx, elem_idx, offsets, lvb, lbm, evb, ebm, evals}) out.owners.push_back(b);
+    }
+    out.cols[t] = nv;
+  }
   // Hive partition columns: one constant per file (SparkPartitionedFile.partition_values, operator.proto:103-109), appended after
   // the file columns (planner.rs:1558-1575); a NULL partition value clears the validity of its rows
   for (size_t p = 0; p < npart; p++) {
@@ -2721,11 +2987,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       bm->ensure((size_t)((total_rows + 7) / 8) + 16);
       pq_launch_pack((const uint8_t*)vbytes->p, (uint8_t*)bm->p, total_rows, stream_);
       cv.valid = (const uint8_t*)bm->p;
-      out.has_valid[ncol + p] = true;
+      out.has_valid[ntop + p] = true;
       out.owners.push_back(bm);
     }
     out.owners.push_back(vbytes);
-    out.cols[ncol + p] = cv;
+    out.cols[ntop + p] = cv;
   }
   if (trace) trace_line(scan_id, "all launches issued at %.2f ms\n", ms_since());
   if (trace) trace_line(scan_id, "scan threads spent %.2f ms on chunks: %.2f reading, %.2f walking zstd frames, %.2f inflating pages\n", (double)g_ns_chunk.exchange(0) / 1e6,
@@ -2744,9 +3010,11 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       const size_t n = std::min<size_t>(512, ncol - c0);
       read_small(ierr.data() + c0, (char*)inflate_err->p + c0 * 4, n * 4);
     }
-    for (size_t c = 0; c < ncol; c++)
-      if (ierr[c]) throw CometError("Parquet column '" + op.required_schema[c].name + "': corrupt compressed data page (device decompression, page job " +
+    for (size_t c = 0; c < ncol; c++) {
+      if (ierr[c] == 0xD1u) throw CometError("Parquet column '" + fields[c].parent + "': the list's repetition levels do not add up to the row group's rows");
+      if (ierr[c]) throw CometError("Parquet column '" + fields[c].name + "': corrupt compressed data page (device decompression, page job " +
                                     std::to_string(ierr[c] >> 8) + ", code " + std::to_string(ierr[c] & 0xff) + ")");
+    }
   }
   out.owners.push_back(tiles);
   out.owners.push_back(vidx);

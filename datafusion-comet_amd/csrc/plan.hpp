@@ -30,7 +30,22 @@ enum class TypeId : int {
 struct DType {
   TypeId id = TypeId::Unknown;
   int precision = 0, scale = 0;  // Decimal only
-  bool operator==(const DType& o) const { return id == o.id && precision == o.precision && scale == o.scale; }
+  // Nested types (types.proto StructInfo / ListInfo): a Struct's fields, a List's one element type ("element").  Nested columns are read by
+  // the Parquet scan, passed through Filter / Projection (gathered by row index like Utf8 columns), taken apart by GetStructField and exported;
+  // no expression computes on them.
+  std::vector<DType> kids;
+  std::vector<std::string> kid_names;
+  std::vector<char> kid_nullable;
+  // a struct's field made addressable as a column of its own (exec.cpp extend_struct_fields: the chain's input table gets one such column
+  // per field behind its real columns; GetStructField(Bound(parent), kid) is then a Bound reference to it).  Not part of the type's identity
+  int virt_parent = -1, virt_kid = -1;
+  bool is_nested() const { return id == TypeId::Struct || id == TypeId::List || id == TypeId::Map; }
+  bool operator==(const DType& o) const {
+    if (id != o.id || precision != o.precision || scale != o.scale || kids.size() != o.kids.size()) return false;
+    for (size_t i = 0; i < kids.size(); i++)
+      if (kids[i] != o.kids[i] || (id == TypeId::Struct && i < kid_names.size() && i < o.kid_names.size() && kid_names[i] != o.kid_names[i])) return false;
+    return true;
+  }
   bool operator!=(const DType& o) const { return !(*this == o); }
   bool is_decimal() const { return id == TypeId::Decimal; }
   bool is_integer() const { return id == TypeId::Int8 || id == TypeId::Int16 || id == TypeId::Int32 || id == TypeId::Int64; }
@@ -49,6 +64,7 @@ enum class ExprKind : int {
   Eq = 9, Neq = 10, Gt = 11, GtEq = 12, Lt = 13, LtEq = 14, IsNull = 15, IsNotNull = 16, And = 17, Or = 18,
   CheckOverflow = 25, Like = 26, RLike = 30, ScalarFunc = 31, EqNullSafe = 32, NeqNullSafe = 33, BitAnd = 34, BitOr = 35, BitXor = 36, Remainder = 37, CaseWhen = 38, In = 39, Not = 40,
   UnaryMinus = 41, ShiftRight = 42, ShiftLeft = 43, If = 44, IntegralDivide = 59, NormalizeNaNAndZero = 45, Unbound = 51,
+  GetStructField = 54,              // expr.proto:528-531: child = 1, ordinal = 2 (kept in Expr::bound_index)
   Unsupported = -1
 };
 
@@ -124,6 +140,11 @@ struct StructField {  // SparkStructField (operator.proto:117-124)
   DType dtype;
   bool nullable = true;
   int field_id = -1;   // metadata["PARQUET:field_id"] (CometParquetUtils.PARQUET_FIELD_ID_META_KEY), -1 = none
+  // the Parquet scan's own use: a LEAF of a nested column it reads — nest 1: field `name` of the struct column `parent`; 2: the element of
+  // the list column `parent` (0: a top-level column)
+  int nest = 0;
+  std::string parent;
+  int parent_field_id = -1;
 };
 
 struct PartitionedFile {  // SparkPartitionedFile (operator.proto:103-109)

@@ -103,6 +103,32 @@ DType decode_datatype(Reader r) {
             else if (f3 == 2 && wt3 == 0) d.scale = (int)(int32_t)dec.varint();
             else dec.skip(wt3);
           }
+        } else if (f2 == 3 && wt2 == 2) {  // ListInfo: element_type = 1, contains_null = 2
+          Reader li = info.sub();
+          DType el;
+          el.id = TypeId::Bool;
+          bool contains_null = false;
+          while (!li.done()) {
+            int wt3, f3 = li.tag(wt3);
+            if (f3 == 1 && wt3 == 2) el = decode_datatype(li.sub());
+            else if (f3 == 2 && wt3 == 0) contains_null = li.varint() != 0;
+            else li.skip(wt3);
+          }
+          d.kids.assign(1, el);
+          d.kid_names.assign(1, "element");
+          d.kid_nullable.assign(1, contains_null ? 1 : 0);
+        } else if (f2 == 5 && wt2 == 2) {  // StructInfo: field_names = 1, field_datatypes = 2, field_nullable = 3 (packed or not)
+          Reader si = info.sub();
+          while (!si.done()) {
+            int wt3, f3 = si.tag(wt3);
+            if (f3 == 1 && wt3 == 2) d.kid_names.push_back(si.bytes());
+            else if (f3 == 2 && wt3 == 2) d.kids.push_back(decode_datatype(si.sub()));
+            else if (f3 == 3 && wt3 == 0) d.kid_nullable.push_back(si.varint() != 0 ? 1 : 0);
+            else if (f3 == 3 && wt3 == 2) { Reader pk = si.sub(); while (!pk.done()) d.kid_nullable.push_back(pk.varint() != 0 ? 1 : 0); }
+            else si.skip(wt3);
+          }
+          while (d.kid_nullable.size() < d.kids.size()) d.kid_nullable.push_back(1);
+          while (d.kid_names.size() < d.kids.size()) d.kid_names.push_back("");
         } else {
           info.skip(wt2);
         }
@@ -204,6 +230,10 @@ void decode_expr_body(Reader r, Expr& e) {
       case ExprKind::If:
         if (f >= 1 && f <= 3 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
         break;
+      case ExprKind::GetStructField:
+        if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 2 && wt == 0) { e.bound_index = (int)(int32_t)r.varint(); handled = true; }
+        break;
       case ExprKind::ScalarFunc:
         // ScalarFunc{func=1, args=2, return_type=3, fail_on_error=4} (expr.proto:466-471)
         if (f == 1 && wt == 2) { e.func = r.bytes(); handled = true; }
@@ -261,9 +291,9 @@ ExprP decode_expr(Reader r) {
       case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
       case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
       case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 25: case 26: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
-      case 44: case 45: case 51:
+      case 44: case 45: case 51: case 54:
         e->kind = (ExprKind)f;
-        if (e->kind == ExprKind::Bound) e->bound_index = 0;  // proto3 omits zero-valued scalars
+        if (e->kind == ExprKind::Bound || e->kind == ExprKind::GetStructField) e->bound_index = 0;  // proto3 omits zero-valued scalars
         decode_expr_body(r.sub(), *e);
         break;
       default:
@@ -791,6 +821,12 @@ std::string DType::str() const {
     case TypeId::Date: return "Date32";
     case TypeId::Null: return "Null";
     case TypeId::Decimal: return "Decimal128(" + std::to_string(precision) + ", " + std::to_string(scale) + ")";
+    case TypeId::Struct: {
+      std::string o = "Struct(";
+      for (size_t i = 0; i < kids.size(); i++) o += (i ? ", " : "") + (i < kid_names.size() ? kid_names[i] : std::string("?")) + ": " + kids[i].str();
+      return o + ")";
+    }
+    case TypeId::List: return "List(" + (kids.empty() ? std::string("?") : kids[0].str()) + ")";
     default: return "Unsupported(" + std::to_string((int)id) + ")";
   }
 }
@@ -815,7 +851,7 @@ const char* expr_name(int t) {
     case 15: return "IsNull"; case 16: return "IsNotNull"; case 17: return "And"; case 18: return "Or";
     case 19: return "SortOrder"; case 25: return "CheckOverflow"; case 26: return "Like"; case 30: return "RLike"; case 31: return "ScalarFunc";
     case 32: return "EqNullSafe"; case 33: return "NeqNullSafe"; case 37: return "Remainder"; case 38: return "CaseWhen";
-    case 39: return "In"; case 40: return "Not"; case 41: return "UnaryMinus"; case 44: return "If";
+    case 39: return "In"; case 40: return "Not"; case 41: return "UnaryMinus"; case 44: return "If"; case 54: return "GetStructField";
     case 45: return "NormalizeNaNAndZero"; default: return "Expr";
   }
 }

@@ -1128,13 +1128,26 @@ namespace {
 struct ExportedColumn {
   HostColumn col;
   const void* buffers[3];
+  std::vector<ArrowArray> children;        // nested columns: the children's arrays live here, released with their parent
+  std::vector<ArrowArray*> child_ptrs;
 };
 void release_array(ArrowArray* a) {
-  delete (ExportedColumn*)a->private_data;
+  auto* ec = (ExportedColumn*)a->private_data;
+  for (auto& c : ec->children)
+    if (c.release) c.release(&c);
+  delete ec;
   a->release = nullptr;
 }
+struct ExportedSchema {
+  std::string format, name;
+  std::vector<ArrowSchema> children;
+  std::vector<ArrowSchema*> child_ptrs;
+};
 void release_schema(ArrowSchema* s) {
-  delete (std::string*)s->private_data;
+  auto* es = (ExportedSchema*)s->private_data;
+  for (auto& c : es->children)
+    if (c.release) c.release(&c);
+  delete es;
   s->release = nullptr;
 }
 void export_column(HostColumn&& col, ArrowArray* a) {
@@ -1143,25 +1156,53 @@ void export_column(HostColumn&& col, ArrowArray* a) {
   memset(a, 0, sizeof *a);
   a->length = ec->col.length;
   a->null_count = ec->col.null_count;
-  const bool is_str = ec->col.type.id == TypeId::String || ec->col.type.id == TypeId::Bytes;
-  a->n_buffers = is_str ? 3 : 2;
+  const TypeId id = ec->col.type.id;
+  const bool is_str = id == TypeId::String || id == TypeId::Bytes;
   static const uint8_t kEmpty[8] = {0};
   ec->buffers[0] = ec->col.null_count ? ec->col.validity.data() : nullptr;
-  ec->buffers[1] = ec->col.values.empty() ? (const void*)kEmpty : (const void*)ec->col.values.data();
-  ec->buffers[2] = is_str ? (ec->col.data.empty() ? (const void*)kEmpty : (const void*)ec->col.data.data()) : nullptr;
+  if (id == TypeId::Struct) {
+    a->n_buffers = 1;                       // Arrow struct layout: validity only
+  } else {
+    a->n_buffers = is_str ? 3 : 2;          // (a List: validity + int32 offsets)
+    ec->buffers[1] = ec->col.values.empty() ? (const void*)kEmpty : (const void*)ec->col.values.data();
+    ec->buffers[2] = is_str ? (ec->col.data.empty() ? (const void*)kEmpty : (const void*)ec->col.data.data()) : nullptr;
+  }
+  if (id == TypeId::Struct || id == TypeId::List) {
+    ec->children.resize(ec->col.children.size());
+    for (size_t i = 0; i < ec->col.children.size(); i++) {
+      export_column(std::move(ec->col.children[i]), &ec->children[i]);
+      ec->child_ptrs.push_back(&ec->children[i]);
+    }
+    ec->col.children.clear();
+    a->n_children = (int64_t)ec->children.size();
+    a->children = ec->child_ptrs.data();
+  }
   a->buffers = ec->buffers;
   a->private_data = ec;
   a->release = release_array;
 }
-void export_schema(const DType& t, ArrowSchema* s) {
+void export_schema_named(const DType& t, const std::string& name, bool nullable, ArrowSchema* s) {
   memset(s, 0, sizeof *s);
-  auto* fmt = new std::string(expected_format(t));
-  s->format = fmt->c_str();
-  s->name = "";
-  s->flags = ARROW_FLAG_NULLABLE;
-  s->private_data = fmt;
+  auto* es = new ExportedSchema();
+  es->format = expected_format(t);
+  es->name = name;
+  s->format = es->format.c_str();
+  s->name = es->name.c_str();
+  s->flags = nullable ? ARROW_FLAG_NULLABLE : 0;
+  if (t.id == TypeId::Struct || t.id == TypeId::List) {
+    es->children.resize(t.kids.size());
+    for (size_t i = 0; i < t.kids.size(); i++) {
+      const std::string kn = t.id == TypeId::List ? "element" : (i < t.kid_names.size() ? t.kid_names[i] : std::string());
+      export_schema_named(t.kids[i], kn, i < t.kid_nullable.size() ? t.kid_nullable[i] != 0 : true, &es->children[i]);
+      es->child_ptrs.push_back(&es->children[i]);
+    }
+    s->n_children = (int64_t)es->children.size();
+    s->children = es->child_ptrs.data();
+  }
+  s->private_data = es;
   s->release = release_schema;
 }
+void export_schema(const DType& t, ArrowSchema* s) { export_schema_named(t, "", true, s); }
 }  // namespace
 
 std::string expected_format(const DType& t) {
@@ -1179,6 +1220,8 @@ std::string expected_format(const DType& t) {
     case TypeId::String: return "u";
     case TypeId::Bytes: return "z";
     case TypeId::Decimal: return "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale);
+    case TypeId::Struct: return "+s";
+    case TypeId::List: return "+l";
     default: return "?";
   }
 }

@@ -70,11 +70,17 @@ def _f_msg(field_no: int, b: bytes) -> bytes:
 BOOL, INT8, INT16, INT32, INT64, FLOAT, DOUBLE, STRING, BYTES, TIMESTAMP, DECIMAL, TIMESTAMP_NTZ, DATE, NULL = range(14)
 
 
+LIST, MAP, STRUCT = 14, 15, 16
+
+
 @dataclass(frozen=True)
 class DataType:
     type_id: int
     precision: int = 0
     scale: int = 0
+    fields: tuple = ()              # STRUCT: ((name, DataType, nullable), …) — types.proto StructInfo
+    element: Optional["DataType"] = None   # LIST: ListInfo.element_type
+    contains_null: bool = True      # LIST: ListInfo.contains_null
 
     def encode(self) -> bytes:
         out = b""
@@ -83,6 +89,14 @@ class DataType:
         if self.type_id == DECIMAL:
             dec = _f_varint(1, self.precision) + (_f_varint(2, self.scale) if self.scale else b"")
             out += _f_msg(2, _f_msg(2, dec))
+        elif self.type_id == LIST:
+            li = _f_msg(1, self.element.encode()) + (_f_varint(2, 1) if self.contains_null else b"")
+            out += _f_msg(2, _f_msg(3, li))
+        elif self.type_id == STRUCT:
+            si = b"".join(_f_bytes(1, n.encode()) for n, _, _ in self.fields)
+            si += b"".join(_f_msg(2, t.encode()) for _, t, _ in self.fields)
+            si += _f_bytes(3, bytes(1 if nl else 0 for _, _, nl in self.fields))      # repeated bool: packed, as protobuf-java writes it
+            out += _f_msg(2, _f_msg(5, si))
         return out
 
     def __repr__(self):
@@ -90,7 +104,20 @@ class DataType:
                  "decimal", "timestamp_ntz", "date", "null"]
         if self.type_id == DECIMAL:
             return f"decimal({self.precision},{self.scale})"
+        if self.type_id == LIST:
+            return f"list<{self.element!r}>"
+        if self.type_id == STRUCT:
+            return "struct<" + ", ".join(f"{n}: {t!r}" for n, t, _ in self.fields) + ">"
         return names[self.type_id]
+
+
+def struct_type(fields) -> DataType:
+    """fields: [(name, DataType, nullable)]"""
+    return DataType(STRUCT, fields=tuple((n, t, bool(nl)) for n, t, nl in fields))
+
+
+def list_type(element: DataType, contains_null: bool = True) -> DataType:
+    return DataType(LIST, element=element, contains_null=contains_null)
 
 
 def decimal(p: int, s: int) -> DataType:
@@ -108,6 +135,10 @@ def from_arrow_type(t) -> DataType:
     import pyarrow as pa
     if pa.types.is_decimal(t):
         return decimal(t.precision, t.scale)
+    if pa.types.is_struct(t):
+        return struct_type([(t.field(i).name, from_arrow_type(t.field(i).type), t.field(i).nullable) for i in range(t.num_fields)])
+    if pa.types.is_list(t):
+        return list_type(from_arrow_type(t.value_type), t.value_field.nullable)
     if pa.types.is_timestamp(t):
         return T_TIMESTAMP if t.tz else DataType(TIMESTAMP_NTZ)
     m = {pa.bool_(): T_BOOL, pa.int8(): T_INT8, pa.int16(): T_INT16, pa.int32(): T_INT32, pa.int64(): T_INT64, pa.float32(): T_FLOAT,
@@ -141,7 +172,7 @@ class Expr:
     TAGS = dict(hour=22, minute=23, second=24, literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
                 lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, like=26, rlike=30, scalar_func=31, eq_null_safe=32,
                 neq_null_safe=33, bit_and=34, bit_or=35, bit_xor=36, shift_right=42, shift_left=43, integral_divide=59, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
-                unbound=51)
+                unbound=51, get_struct_field=54)
 
     def encode(self) -> bytes:
         k = self.kind
@@ -183,6 +214,8 @@ class Expr:
                 body += _f_varint(3, 1)
         elif k == "if_":
             body = b"".join(_f_msg(i + 1, c.encode()) for i, c in enumerate(self.children))
+        elif k == "get_struct_field":      # expr.proto:528-531: child = 1, ordinal = 2
+            body = _f_msg(1, self.children[0].encode()) + (_f_varint(2, self.index) if self.index else b"")
         elif k == "scalar_func":   # ScalarFunc{func=1, args=2, return_type=3, fail_on_error=4}; value = function name
             body = _f_bytes(1, self.value.encode()) + b"".join(_f_msg(2, c.encode()) for c in self.children)
             if self.dtype is not None:
@@ -245,6 +278,10 @@ def lit(value, dtype: DataType) -> Expr:
 
 def col(index: int, dtype: DataType) -> Expr:
     return Expr("bound", dtype=dtype, index=index)
+
+
+def get_struct_field(child: Expr, ordinal: int) -> Expr:
+    return Expr("get_struct_field", [child], index=ordinal)
 
 
 def _bin(kind):

@@ -1,0 +1,175 @@
+"""Nested columns through the Parquet scan and the plan above it (the reference: parquet/parquet_support.rs:166-383
+parquet_convert_array / parquet_convert_struct_to_struct, GetStructField planner.rs:776-779): struct-of-flat and list-of-flat columns decoded
+on the device from their leaves' definition / repetition levels, exported as Arrow struct / list arrays, passed through Filter / Projection
+(gathered by row index, children and all), taken apart by GetStructField — every result against pyarrow's own reading of the same file."""
+import datetime
+from decimal import Decimal
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pyarrow.parquet as papq
+import pytest
+
+from datafusion_comet_amd import native, serde as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _nested_table(n, seed, nullable=True):
+    rng = np.random.default_rng(seed)
+
+    def mask(p):
+        return rng.random(n) < p if nullable else np.zeros(n, dtype=bool)
+
+    a = rng.integers(-1000, 1000, n).astype(np.int32)
+    b = ["s%d" % (v % 37) if v % 5 else "a much longer string value %d" % v for v in rng.integers(0, 10**6, n)]
+    c = rng.standard_normal(n)
+    d = [Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**9, 10**9, n)]
+    e = [datetime.date(1995, 1, 1) + datetime.timedelta(days=int(v)) for v in rng.integers(0, 3000, n)]
+    ma, mb, mc, md, me, ms = mask(0.1), mask(0.15), mask(0.05), mask(0.2), mask(0.1), mask(0.12)
+    st_type = pa.struct([pa.field("a", pa.int32(), nullable), pa.field("b", pa.string(), nullable), pa.field("c", pa.float64(), nullable),
+                         pa.field("d", pa.decimal128(12, 2), nullable), pa.field("e", pa.date32(), nullable)])
+    structs = []
+    for i in range(n):
+        if ms[i]:
+            structs.append(None)
+        else:
+            structs.append({"a": None if ma[i] else int(a[i]), "b": None if mb[i] else b[i], "c": None if mc[i] else float(c[i]), "d": None if md[i] else d[i],
+                            "e": None if me[i] else e[i]})
+    lens = rng.integers(0, 9, n)
+    lens[rng.random(n) < 0.1] = 0                                      # empty lists
+    lens[rng.random(n) < 0.02] = 300                                   # a few long ones (they cross pages)
+    lnull = mask(0.1)
+    li, lf, ld = [], [], []
+    for i in range(n):
+        k = int(lens[i])
+        if lnull[i]:
+            li.append(None); lf.append(None); ld.append(None)
+            continue
+        vi = rng.integers(-10**12, 10**12, k)
+        en = rng.random(k) < (0.15 if nullable else 0.0)
+        li.append([None if en[j] else int(vi[j]) for j in range(k)])
+        lf.append([None if en[j] else float(vi[j]) * 0.5 for j in range(k)])
+        ld.append([None if en[j] else datetime.date(2000, 1, 1) + datetime.timedelta(days=int(vi[j] % 5000)) for j in range(k)])
+    return pa.table({
+        "k": pa.array(np.arange(n, dtype=np.int64)),
+        "s": pa.array(structs, st_type),
+        "li": pa.array(li, pa.list_(pa.field("element", pa.int64(), nullable))),
+        "f": pa.array(rng.integers(0, 100, n).astype(np.int32), pa.int32(), mask=mask(0.1)),
+        "lf": pa.array(lf, pa.list_(pa.field("element", pa.float64(), nullable))),
+        "ld": pa.array(ld, pa.list_(pa.field("element", pa.date32(), nullable))),
+        "t": pa.array(["row %d" % i for i in range(n)]),
+    }, schema=pa.schema([pa.field("k", pa.int64(), False), pa.field("s", st_type, nullable), pa.field("li", pa.list_(pa.field("element", pa.int64(), nullable)), nullable),
+                         pa.field("f", pa.int32(), nullable), pa.field("lf", pa.list_(pa.field("element", pa.float64(), nullable)), nullable),
+                         pa.field("ld", pa.list_(pa.field("element", pa.date32(), nullable)), nullable), pa.field("t", pa.string(), False)]))
+
+
+def _types(schema):
+    return [S.from_arrow_type(f.type) for f in schema]
+
+
+def _run(plan, ncols, conf=None):
+    batches = native.execute_to_table([], ncols, plan.encode(), **({"config": S.config_map(conf)} if conf else {}))
+    return pa.Table.from_batches(batches) if batches else None
+
+
+def _same(got_col, want_col, what):
+    g, w = got_col.combine_chunks().to_pylist(), want_col.combine_chunks().to_pylist()
+    assert len(g) == len(w), what
+    for i, (x, y) in enumerate(zip(g, w)):
+        assert x == y, f"{what}: row {i}: {x!r} != {y!r}"
+
+
+def _scan_and_compare(path, t):
+    want = papq.read_table(path)
+    got = _run(S.native_scan([path], t.schema.names, _types(t.schema)), t.num_columns)
+    assert got.num_rows == want.num_rows
+    for i, name in enumerate(t.schema.names):
+        assert got.column(i).type == want.column(name).type or pa.types.is_nested(want.column(name).type), name
+        _same(got.column(i), want.column(name), name)
+    return got
+
+
+@pytest.mark.parametrize("codec,version,dictionary", [("none", "1.0", True), ("snappy", "1.0", False), ("zstd", "2.0", True), ("snappy", "2.0", True), ("gzip", "1.0", True)])
+def test_scan_of_struct_and_list_columns(built, tmp_path, codec, version, dictionary):
+    """several row groups, small pages (lists cross them), NULL structs / fields / lists / elements, empty lists, next to flat columns"""
+    t = _nested_table(20_000, 41)
+    path = str(tmp_path / f"nested_{codec}_{version}.parquet")
+    papq.write_table(t, path, compression=codec, data_page_version=version, use_dictionary=dictionary, row_group_size=6_000, data_page_size=8 << 10)
+    got = _scan_and_compare(path, t)
+    assert pa.types.is_struct(got.column(1).type) and pa.types.is_list(got.column(2).type)
+
+
+def test_required_structs_fields_lists_and_elements(built, tmp_path):
+    """nothing optional: no definition levels for the struct's fields, one level for the lists (an element slot or an empty list)"""
+    t = _nested_table(5_000, 42, nullable=False)
+    path = str(tmp_path / "nested_required.parquet")
+    papq.write_table(t, path, compression="snappy", row_group_size=2_000, data_page_size=16 << 10)
+    _scan_and_compare(path, t)
+
+
+def test_a_subset_of_the_struct_fields_in_another_order(built, tmp_path):
+    """the requested struct names fields c, a of the file's (a, b, c, d, e): Spark's clipped schema — matched by name"""
+    t = _nested_table(3_000, 43)
+    path = str(tmp_path / "nested_subset.parquet")
+    papq.write_table(t, path, compression="zstd", row_group_size=1_000)
+    st = S.struct_type([("c", S.T_DOUBLE, True), ("a", S.T_INT32, True)])
+    got = _run(S.native_scan([path], ["s", "k"], [st, S.T_INT64]), 2)
+    want = papq.read_table(path)
+    ws = want.column("s").combine_chunks()
+    exp = [None if v is None else {"c": v["c"], "a": v["a"]} for v in ws.to_pylist()]
+    assert got.column(0).combine_chunks().to_pylist() == exp
+    _same(got.column(1), want.column("k"), "k")
+
+
+def test_get_struct_field_and_passthrough_in_a_projection(built, tmp_path):
+    t = _nested_table(8_000, 44)
+    path = str(tmp_path / "nested_proj.parquet")
+    papq.write_table(t, path, compression="snappy", row_group_size=3_000, data_page_size=32 << 10)
+    ty = _types(t.schema)
+    scan = S.native_scan([path], t.schema.names, ty)
+    s = S.col(1, ty[1])
+    plan = S.project(scan, [S.col(0, ty[0]), S.get_struct_field(s, 0), S.get_struct_field(s, 1), S.get_struct_field(s, 3), S.col(2, ty[2]), s, S.get_struct_field(s, 4)])
+    got = _run(plan, 7)
+    want = papq.read_table(path)
+    ws = want.column("s").combine_chunks()
+    _same(got.column(0), want.column("k"), "k")
+    for out, fld in ((1, "a"), (2, "b"), (3, "d"), (6, "e")):
+        exp = [None if v is None else v[fld] for v in ws.to_pylist()]
+        assert got.column(out).combine_chunks().to_pylist() == exp, fld
+    _same(got.column(4), want.column("li"), "li")
+    _same(got.column(5), want.column("s"), "s")
+
+
+def test_filter_passes_nested_columns_through(built, tmp_path):
+    """Filter on a flat column and on a struct's field; the struct and the lists of the surviving rows are gathered, children and all"""
+    t = _nested_table(12_000, 45)
+    path = str(tmp_path / "nested_filter.parquet")
+    papq.write_table(t, path, compression="zstd", row_group_size=5_000, data_page_size=16 << 10)
+    ty = _types(t.schema)
+    scan = S.native_scan([path], t.schema.names, ty)
+    s = S.col(1, ty[1])
+    pred = S.and_(S.lt(S.col(3, ty[3]), S.lit(40, S.T_INT32)), S.gt(S.get_struct_field(s, 0), S.lit(-500, S.T_INT32)))
+    plan = S.project(S.filter_(scan, pred), [S.col(0, ty[0]), s, S.col(2, ty[2]), S.col(5, ty[5]), S.col(6, ty[6])])
+    got = _run(plan, 5)
+    want = papq.read_table(path)
+    keep = [i for i, (f, sv) in enumerate(zip(want.column("f").to_pylist(), want.column("s").to_pylist()))
+            if f is not None and f < 40 and sv is not None and sv["a"] is not None and sv["a"] > -500]
+    assert got.num_rows == len(keep) and len(keep) > 100
+    wt = want.take(pa.array(keep, pa.int64()))
+    for out, name in enumerate(["k", "s", "li", "ld", "t"]):
+        _same(got.column(out), wt.column(name), name)
+
+
+def test_what_the_nested_scan_refuses(built, tmp_path):
+    t = pa.table({"m": pa.array([[("a", 1)], None], pa.map_(pa.string(), pa.int32())),
+                  "ss": pa.array([{"x": {"y": 1}}, None], pa.struct([("x", pa.struct([("y", pa.int32())]))])),
+                  "ls": pa.array([["a"], None], pa.list_(pa.string()))})
+    path = str(tmp_path / "nested_refused.parquet")
+    papq.write_table(t, path)
+    deep = S.struct_type([("x", S.struct_type([("y", S.T_INT32, True)]), True)])
+    for names, types, msg in ((["ss"], [deep], "deeper than one level"), (["ls"], [S.list_type(S.T_STRING)], "lists of Utf8"),
+                              (["ss"], [S.T_INT32], "is a group")):
+        with pytest.raises((native.CometNativeException, native.CometQueryExecutionException), match=msg):
+            _run(S.native_scan([path], names, types), len(names))
