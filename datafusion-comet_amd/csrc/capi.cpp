@@ -674,6 +674,41 @@ DType dtype_from_format(const char* f) {
   }
   throw CometError("encodeShuffleBlock: Arrow format '" + s + "' is not supported");
 }
+// an Arrow C Data array (children included) as a ColumnSlice; child arrays must start at their own row 0 (what every exporter of a fresh
+// array produces)
+DType dtype_of_schema(const ArrowSchema* s) {
+  const std::string f = s->format ? s->format : "";
+  if (f != "+s" && f != "+l") return dtype_from_format(s->format);
+  DType t = DType::of(f == "+s" ? TypeId::Struct : TypeId::List);
+  if (f == "+l" && s->n_children != 1) throw CometError("encodeShuffleBlock: a list schema with " + std::to_string(s->n_children) + " children");
+  for (int64_t k = 0; k < s->n_children; k++) {
+    t.kids.push_back(dtype_of_schema(s->children[k]));
+    t.kid_names.push_back(f == "+l" ? std::string("element") : std::string(s->children[k]->name ? s->children[k]->name : ""));
+    t.kid_nullable.push_back((s->children[k]->flags & ARROW_FLAG_NULLABLE) ? 1 : 0);
+  }
+  return t;
+}
+void slice_of_array(const ArrowArray* a, const ArrowSchema* s, bool top, ColumnSlice& c) {
+  if (a->dictionary) throw CometError("encodeShuffleBlock: dictionary-encoded input is not supported");
+  if (!top && a->offset != 0) throw CometError("encodeShuffleBlock: a child array with a non-zero offset is not supported");
+  c.type = dtype_of_schema(s);
+  c.validity = a->null_count != 0 ? (const uint8_t*)a->buffers[0] : nullptr;
+  c.first = a->offset;
+  if (c.type.id == TypeId::Struct) {
+    if (a->n_children != (int64_t)c.type.kids.size()) throw CometError("encodeShuffleBlock: struct array and schema differ in their children");
+    c.kids.resize((size_t)a->n_children);
+    for (int64_t k = 0; k < a->n_children; k++) slice_of_array(a->children[k], s->children[k], false, c.kids[(size_t)k]);
+    return;
+  }
+  c.values = a->n_buffers > 1 ? a->buffers[1] : nullptr;
+  if (c.type.id == TypeId::List) {
+    if (a->n_children != 1) throw CometError("encodeShuffleBlock: list array without its elements");
+    c.kids.resize(1);
+    slice_of_array(a->children[0], s->children[0], false, c.kids[0]);
+    return;
+  }
+  c.data = a->n_buffers > 2 ? (const uint8_t*)a->buffers[2] : nullptr;
+}
 }  // namespace
 
 int32_t comet_encode_shuffle_block(struct ArrowArray** arrays, struct ArrowSchema** schemas, int32_t n_cols, int32_t codec,
@@ -686,13 +721,7 @@ int32_t comet_encode_shuffle_block(struct ArrowArray** arrays, struct ArrowSchem
     for (int i = 0; i < n_cols; i++) {
       const ArrowArray* a = arrays[i];
       if (a->length != rows) throw CometError("encodeShuffleBlock: columns differ in length");
-      if (a->dictionary) throw CometError("encodeShuffleBlock: dictionary-encoded input is not supported");
-      ColumnSlice& c = cols[(size_t)i];
-      c.type = dtype_from_format(schemas[i]->format);
-      c.validity = a->null_count != 0 ? (const uint8_t*)a->buffers[0] : nullptr;
-      c.values = a->buffers[1];
-      c.data = a->n_buffers > 2 ? (const uint8_t*)a->buffers[2] : nullptr;
-      c.first = a->offset;
+      slice_of_array(a, schemas[i], true, cols[(size_t)i]);
     }
     std::vector<uint8_t> bytes;
     encode_shuffle_block(cols, rows, (ShuffleCodec)codec, compression_level, bytes);

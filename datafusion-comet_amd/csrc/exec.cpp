@@ -590,7 +590,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       if (e->kind == ExprKind::Bound && (e->bound_index < 0 || (size_t)e->bound_index >= st.size()))
         throw CometError("ShuffleWriter: hash expression references column " + std::to_string(e->bound_index) + " of " + std::to_string(st.size()));
     for (auto& t : st)
-      if (expected_format(t) == "?" || t.is_nested()) throw CometError("ShuffleWriter: column type " + t.str() + " is not supported");
+      if (expected_format(t) == "?" || t.id == TypeId::Map) throw CometError("ShuffleWriter: column type " + t.str() + " is not supported");
     auto sp = shuffle_projs_.find(&op);
     if (sp != shuffle_projs_.end()) {
       Operator& pr = *sp->second;
@@ -1446,7 +1446,6 @@ DevTable ExecutionContext::host_batch_to_table(const HostBatch& b) {
 // resident table → host batches of ≤ batch_size rows (root of a plan that ends in a join)
 // ---- nested columns on their way out: the whole column comes back (one synchronous copy per buffer — nested results are not the hot path),
 // batches are slices of it ----
-namespace {
 HostColumn download_column(const DeviceColumnView& v, const DType& t, bool has_valid, int64_t rows, hipStream_t st) {
   HostColumn c;
   c.type = t;
@@ -1486,6 +1485,7 @@ HostColumn download_column(const DeviceColumnView& v, const DType& t, bool has_v
   }
   return c;
 }
+namespace {
 std::vector<uint8_t> slice_bits(const std::vector<uint8_t>& b, int64_t off, int64_t len) {
   std::vector<uint8_t> o((size_t)((len + 7) / 8), 0);
   for (int64_t i = 0; i < len; i++)

@@ -100,6 +100,9 @@ extern "C" int comet_launch_fix_rescale(uint64_t* base, int64_t count, int64_t s
 extern "C" int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream);
 
 namespace comet {
+// a resident column of any type, children included, into host memory (exec.cpp: nested results and nested shuffle payloads)
+HostColumn download_column(const DeviceColumnView& v, const DType& t, bool has_valid, int64_t rows, hipStream_t st);
+
 namespace detail {
 void plan_execution_begins();      // exec_memory.cpp: how many plans execute right now decides how threads wait for the device
 void plan_execution_ends();

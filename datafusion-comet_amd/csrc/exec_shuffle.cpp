@@ -39,7 +39,8 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
   } else if (sw.shuffle_partitioning == Operator::Partitioning::RoundRobin) {
     // "round robin" = hash of the first max_hash_columns columns (multi_partition.rs:386-437)
     const size_t k = sw.shuffle_max_hash_columns <= 0 ? n_payload : std::min<size_t>((size_t)sw.shuffle_max_hash_columns, n_payload);
-    for (size_t i = 0; i < k; i++) key_cols.push_back((int)i);
+    for (size_t i = 0; i < k; i++)
+      if (!in.types[i].is_nested()) key_cols.push_back((int)i);      // (nested columns are not hashed here: any assignment is a round robin)
   }
   if (n >= (int64_t)1 << 32) throw CometError("ShuffleWriter: more than 2^32 rows in one task are not supported (u32 row indices, multi_partition.rs)");
   std::vector<int64_t> starts((size_t)P + 1, 0);
@@ -138,9 +139,30 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
   if (const char* e = getenv("COMET_SHUFFLE_STAGING_BYTES")) staging_bytes = (size_t)std::max<long long>(1 << 16, atoll(e));
   size_t row_bytes = 0;
   std::vector<char> is_str(n_payload, 0);
+  // Nested columns (structs, lists) come to the host WHOLE, once — their buffers hang off each other by offsets, which a slab of rows does not
+  // cut cleanly; the flat columns next to them keep the slabs.  (A task whose nested columns outgrow host memory is not bounded by the staging
+  // size: the one place the writer's footprint follows the data.)
+  std::vector<HostColumn> nested_host(n_payload);
+  std::vector<ColumnSlice> nested_slice(n_payload);
+  std::function<void(const HostColumn&, ColumnSlice&)> slice_of = [&](const HostColumn& h, ColumnSlice& c) {
+    c.type = h.type;
+    c.validity = h.validity.empty() ? nullptr : h.validity.data();
+    c.values = h.values.empty() ? nullptr : h.values.data();
+    c.data = h.data.empty() ? nullptr : h.data.data();
+    c.first = 0;
+    c.kids.resize(h.children.size());
+    for (size_t k = 0; k < h.children.size(); k++) slice_of(h.children[k], c.kids[k]);
+  };
+  for (size_t j = 0; j < n_payload; j++) {
+    if (!grouped.types[j].is_nested()) continue;
+    nested_host[j] = download_column(grouped.cols[j], grouped.types[j], grouped.has_valid[j], n, stream_);
+    slice_of(nested_host[j], nested_slice[j]);
+    row_bytes += 32;
+  }
   for (size_t j = 0; j < n_payload; j++) {
     const DType& ty = grouped.types[j];
     const DeviceColumnView& v = grouped.cols[j];
+    if (ty.is_nested()) continue;
     if (n > 0 && v.offset != 0) throw CometError("ShuffleWriter: input column with a non-zero Arrow offset is not supported yet");
     is_str[j] = ty.id == TypeId::String || ty.id == TypeId::Bytes;
     if (is_str[j]) {
@@ -246,6 +268,7 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
     for (size_t j = 0; j < n_payload; j++) {
       const DType& ty = grouped.types[j];
       const DeviceColumnView& v = grouped.cols[j];
+      if (ty.is_nested()) continue;
       size_t skip, bytes;
       if (is_str[j]) { skip = (size_t)sl.base * 4; bytes = (size_t)(rows + 1) * 4; }
       else if (ty.id == TypeId::Bool) { skip = (size_t)(sl.base / 8); bytes = (size_t)((rows + 7) / 8); }
@@ -286,6 +309,7 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
           r.bytes.reserve(est + est / 8 + (64 << 10));
           std::vector<ColumnSlice> cols(n_payload);
           for (size_t j = 0; j < n_payload; j++) {
+            if (grouped.types[j].is_nested()) { cols[j] = nested_slice[j]; continue; }
             cols[j].type = grouped.types[j];
             cols[j].validity = sg->hb[j] ? (const uint8_t*)sg->hb[j]->p : nullptr;
             cols[j].values = sg->hv[j]->p;
@@ -293,7 +317,7 @@ DevTable ExecutionContext::write_shuffle(const Operator& sw) {
             cols[j].data_origin = is_str[j] ? str_lo[j][q] : 0;
           }
           for (size_t t = r.first; t < r.last; t++) {
-            for (auto& c : cols) c.first = tasks[t].first - base;
+            for (auto& c : cols) c.first = c.type.is_nested() ? tasks[t].first : tasks[t].first - base;      // (nested columns are addressed from the task's row 0)
             r.block_size.push_back(encode_shuffle_block(cols, tasks[t].rows, codec, sw.shuffle_compression_level, r.bytes));
           }
         } catch (const std::exception& e) {

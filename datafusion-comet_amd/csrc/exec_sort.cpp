@@ -20,6 +20,12 @@ DevTable ExecutionContext::take_rows(const DevTable& in, const uint32_t* dev_per
   const uint32_t* idx = dev_perm + first;
   for (size_t c = 0; c < in.cols.size(); c++) {
     const DType& t = in.types[c];
+    if (t.is_nested()) {      // children and all (exec.cpp take_column)
+      bool hv = false;
+      out.cols[c] = take_column(in.cols[c], t, in.has_valid[c], idx, nullptr, rows, hv, out.owners);
+      out.has_valid[c] = hv;
+      continue;
+    }
     if (t.id == TypeId::String || t.id == TypeId::Bytes) {
       if (in.cols[c].offset != 0 && in.has_valid[c]) throw CometError("Sort / Limit over a nullable Utf8 column with a non-zero Arrow offset is not supported yet");
       take_utf8(in.cols[c], idx, nullptr, in.has_valid[c] ? in.cols[c].valid : nullptr, rows, out.cols[c], out.owners);

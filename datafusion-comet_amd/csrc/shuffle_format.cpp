@@ -559,7 +559,7 @@ FbField scalar(int slot, int size, uint64_t v) { return FbField{slot, size, v, f
 FbField ref(int slot) { return FbField{slot, 4, 0, true}; }
 
 // flatbuffer Type union ids (format/Schema.fbs)
-enum { FB_Int = 2, FB_FloatingPoint = 3, FB_Binary = 4, FB_Utf8 = 5, FB_Bool = 6, FB_Decimal = 7, FB_Date = 8, FB_Timestamp = 10 };
+enum { FB_Int = 2, FB_FloatingPoint = 3, FB_Binary = 4, FB_Utf8 = 5, FB_Bool = 6, FB_Decimal = 7, FB_Date = 8, FB_Timestamp = 10, FB_List = 12, FB_Struct = 13 };
 enum { MSG_Schema = 1, MSG_DictionaryBatch = 2, MSG_RecordBatch = 3 };
 
 uint8_t fb_type_id(const DType& t) {
@@ -572,6 +572,8 @@ uint8_t fb_type_id(const DType& t) {
     case TypeId::Date: return FB_Date;
     case TypeId::Timestamp: case TypeId::TimestampNtz: return FB_Timestamp;
     case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Int64: return FB_Int;
+    case TypeId::List: return FB_List;
+    case TypeId::Struct: return FB_Struct;
     default: throw CometError("shuffle writer: column type " + t.str() + " is not supported");
   }
 }
@@ -588,7 +590,7 @@ void write_type(FbWriter& w, const DType& t, size_t type_ref) {
     }
     case TypeId::Float: tab = w.table(1, {scalar(0, 2, 1)}, rp); break;
     case TypeId::Double: tab = w.table(1, {scalar(0, 2, 2)}, rp); break;
-    case TypeId::String: case TypeId::Bytes: tab = w.table(0, {}, rp); break;
+    case TypeId::String: case TypeId::Bytes: case TypeId::List: case TypeId::Struct: tab = w.table(0, {}, rp); break;
     case TypeId::Decimal: tab = w.table(3, {scalar(0, 4, (uint64_t)t.precision), scalar(1, 4, (uint64_t)t.scale), scalar(2, 4, 128)}, rp); break;
     case TypeId::Date: tab = w.table(1, {scalar(0, 2, 0 /* DAY */)}, rp); break;
     case TypeId::Timestamp: {
@@ -621,18 +623,23 @@ void write_schema_message(const std::vector<ColumnSlice>& cols, std::vector<uint
   w.patch(mrp[2], schema);
   const size_t fields = w.offset_vector(cols.size(), elem);
   w.patch(srp[1], fields);
-  for (size_t c = 0; c < cols.size(); c++) {
-    const uint8_t tid = fb_type_id(cols[c].type);
-    const size_t f = w.table(7, {ref(0), scalar(1, 1, 1 /* nullable */), scalar(2, 1, tid), ref(3), ref(5)}, frp);
-    w.patch(elem[c], f);
-    const std::vector<size_t> my = frp;
-    const size_t name = w.string("c" + std::to_string(c));
-    w.patch(my[0], name);
-    write_type(w, cols[c].type, my[3]);
-    std::vector<size_t> none;
-    const size_t children = w.offset_vector(0, none);
-    w.patch(my[5], children);
-  }
+  // one Field table (Schema.fbs: name, nullable, type_type, type, dictionary, children), its children behind it, depth first
+  std::function<void(const DType&, const std::string&, bool, size_t)> write_field = [&](const DType& t, const std::string& fname, bool nullable, size_t slot) {
+    std::vector<size_t> rp;
+    const size_t f = w.table(7, {ref(0), scalar(1, 1, nullable ? 1 : 0), scalar(2, 1, fb_type_id(t)), ref(3), ref(5)}, rp);
+    w.patch(slot, f);
+    const size_t name = w.string(fname);
+    w.patch(rp[0], name);
+    write_type(w, t, rp[3]);
+    const size_t nk = t.is_nested() ? t.kids.size() : 0;
+    std::vector<size_t> kid_slots;
+    const size_t children = w.offset_vector(nk, kid_slots);
+    w.patch(rp[5], children);
+    for (size_t k = 0; k < nk; k++)
+      write_field(t.kids[k], t.id == TypeId::List ? std::string("item") : (k < t.kid_names.size() ? t.kid_names[k] : std::string()),
+                  k < t.kid_nullable.size() ? t.kid_nullable[k] != 0 : true, kid_slots[k]);
+  };
+  for (size_t c = 0; c < cols.size(); c++) write_field(cols[c].type, "c" + std::to_string(c), true, elem[c]);
   append_message(out, w);
 }
 
@@ -681,16 +688,36 @@ void write_batch_message(const std::vector<ColumnSlice>& cols, int64_t rows, std
     if (n) body.insert(body.end(), (const uint8_t*)p, (const uint8_t*)p + n);
     while (body.size() % 8) body.push_back(0);
   };
-  for (const ColumnSlice& c : cols) {
+  // field nodes and buffers in depth-first pre-order (Message.fbs RecordBatch): a struct is its validity, then its fields over the same rows;
+  // a list its validity and its offsets (rebased to 0), then its elements offsets[first] … offsets[first + rows)
+  std::function<void(const ColumnSlice&, int64_t, int64_t)> emit = [&](const ColumnSlice& c, int64_t first, int64_t rows) {
     int64_t nulls = 0;
     if (c.validity) {
-      nulls = rows - slice_bits(c.validity, c.first, rows, bits);
+      nulls = rows - slice_bits(c.validity, first, rows, bits);
       if (nulls) add_buffer(bits.data(), bits.size());
     }
     if (!nulls) add_buffer(nullptr, 0);
     nodes.emplace_back(rows, nulls);
+    if (c.type.id == TypeId::Struct) {
+      if (c.kids.size() != c.type.kids.size()) throw CometError("shuffle writer: struct column without its fields");
+      for (const ColumnSlice& k : c.kids) emit(k, first, rows);
+      return;
+    }
+    if (c.type.id == TypeId::List) {
+      if (c.kids.size() != 1) throw CometError("shuffle writer: list column without its elements");
+      const int32_t* offs = (const int32_t*)c.values + first;
+      const int32_t base = offs[0];
+      buffers.emplace_back((int64_t)body.size(), (int64_t)(rows + 1) * 4);
+      const size_t at = body.size();
+      body.resize(at + (size_t)(rows + 1) * 4);
+      int32_t* o = (int32_t*)(body.data() + at);
+      for (int64_t i = 0; i <= rows; i++) o[i] = offs[i] - base;
+      while (body.size() % 8) body.push_back(0);
+      emit(c.kids[0], (int64_t)base, (int64_t)(offs[rows] - base));
+      return;
+    }
     if (c.type.id == TypeId::String || c.type.id == TypeId::Bytes) {
-      const int32_t* offs = (const int32_t*)c.values + c.first;
+      const int32_t* offs = (const int32_t*)c.values + first;
       const int32_t base = offs[0];
       buffers.emplace_back((int64_t)body.size(), (int64_t)(rows + 1) * 4);
       const size_t at = body.size();
@@ -700,14 +727,15 @@ void write_batch_message(const std::vector<ColumnSlice>& cols, int64_t rows, std
       while (body.size() % 8) body.push_back(0);
       add_buffer(c.data + ((int64_t)base - c.data_origin), (size_t)(offs[rows] - base));
     } else if (c.type.id == TypeId::Bool) {
-      slice_bits((const uint8_t*)c.values, c.first, rows, bits);
+      slice_bits((const uint8_t*)c.values, first, rows, bits);
       add_buffer(bits.data(), bits.size());
     } else {
       const int w = ipc_fixed_width(c.type);
       if (!w) throw CometError("shuffle writer: column type " + c.type.str() + " is not supported");
-      add_buffer((const uint8_t*)c.values + (size_t)c.first * (size_t)w, (size_t)rows * (size_t)w);
+      add_buffer((const uint8_t*)c.values + (size_t)first * (size_t)w, (size_t)rows * (size_t)w);
     }
-  }
+  };
+  for (const ColumnSlice& c : cols) emit(c, c.first, rows);
   FbWriter w;
   w.put<uint32_t>(0);
   std::vector<size_t> mrp, rrp;
@@ -831,6 +859,24 @@ DType type_from_fb(int type_id, const FbTable& t) {
   }
   throw CometError("shuffle block: Arrow type id " + std::to_string(type_id) + " is not supported");
 }
+// a Field table → its type, children included (List: one child; Struct: its fields by name)
+DType type_of_field(const FbTable& f, int depth = 0) {
+  const int tid = f.get<uint8_t>(2, 0);
+  if (tid != FB_List && tid != FB_Struct) return type_from_fb(tid, f.child(3));
+  if (depth > 8) throw CometError("shuffle block: types nested deeper than 8 levels");
+  DType t = DType::of(tid == FB_List ? TypeId::List : TypeId::Struct);
+  size_t first;
+  const size_t nk = f.vec(5, 4, first);
+  if (tid == FB_List && nk != 1) throw CometError("shuffle block: a list field with " + std::to_string(nk) + " children");
+  for (size_t k = 0; k < nk; k++) {
+    FbTable kf = f.elem_table(first, k);
+    if (kf.child(4).valid()) throw CometError("shuffle block: dictionary-encoded nested fields are not supported");
+    t.kids.push_back(type_of_field(kf, depth + 1));
+    t.kid_names.push_back(tid == FB_List ? std::string("element") : kf.str(0));
+    t.kid_nullable.push_back(kf.get<uint8_t>(1, 0) != 0 ? 1 : 0);
+  }
+  return t;
+}
 
 struct BodyCursor {
   const uint8_t* body;
@@ -868,6 +914,50 @@ HostColumn read_plain_column(const DType& type, BodyCursor& cur, int64_t rows_ex
   if (c.null_count > 0) {
     if (vb.second < bm) throw CometError("shuffle block: validity buffer too short");
     c.validity.assign(vb.first, vb.first + bm);
+  }
+  if (type.id == TypeId::Struct) {
+    for (const DType& kt : type.kids) c.children.push_back(read_plain_column(kt, cur, c.length));
+    return c;
+  }
+  if (type.id == TypeId::List) {
+    auto ob = cur.next_buffer();
+    c.values.assign((size_t)(c.length + 1) * 4, 0);
+    int32_t base = 0, last = 0;
+    if (c.length > 0) {
+      if (ob.second < (size_t)(c.length + 1) * 4) throw CometError("shuffle block: offsets buffer too short");
+      base = rd<int32_t>(ob.first);
+      int32_t* o = (int32_t*)c.values.data();
+      int32_t prev = 0;
+      for (int64_t i = 0; i <= c.length; i++) {
+        o[i] = rd<int32_t>(ob.first + 4 * i) - base;
+        if (o[i] < prev) throw CometError("shuffle block: list offsets are not monotonic");
+        prev = o[i];
+      }
+      last = o[c.length];
+    }
+    if (type.kids.size() != 1) throw CometError("shuffle block: list type without an element type");
+    HostColumn el = read_plain_column(type.kids[0], cur, -1);
+    if (base < 0 || (int64_t)base + last > el.length) throw CometError("shuffle block: list offsets run past the element column");
+    if (base != 0 || el.length != last) {      // a sliced writer: keep exactly the elements the offsets address
+      HostColumn cut;
+      cut.type = el.type;
+      cut.length = last;
+      const int w = ipc_fixed_width(el.type);
+      if (!w || !el.children.empty()) throw CometError("shuffle block: a list whose offsets do not start at 0 is supported for fixed-width elements only");
+      cut.values.assign(el.values.begin() + (size_t)base * (size_t)w, el.values.begin() + (size_t)(base + last) * (size_t)w);
+      if (!el.validity.empty()) {
+        cut.validity.assign((size_t)((last + 7) / 8), 0);
+        for (int32_t i = 0; i < last; i++) {
+          const int64_t sidx = (int64_t)base + i;
+          if ((el.validity[(size_t)(sidx >> 3)] >> (sidx & 7)) & 1) cut.validity[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+          else cut.null_count++;
+        }
+        if (!cut.null_count) cut.validity.clear();
+      }
+      el = std::move(cut);
+    }
+    c.children.push_back(std::move(el));
+    return c;
   }
   if (type.id == TypeId::String || type.id == TypeId::Bytes) {
     auto ob = cur.next_buffer();
@@ -972,7 +1062,7 @@ std::vector<StructField> decode_ipc_schema_impl(const uint8_t* p, size_t n) {
     StructField sf;
     sf.name = f.str(0);
     sf.nullable = f.get<uint8_t>(1, 0) != 0;
-    sf.dtype = type_from_fb(f.get<uint8_t>(2, 0), f.child(3));
+    sf.dtype = type_of_field(f);
     size_t kv0;
     const size_t nkv = f.vec(6, 4, kv0);        // Field.custom_metadata: [KeyValue{key, value}]
     for (size_t k = 0; k < nkv; k++) {
@@ -1021,7 +1111,7 @@ HostBatch decode_ipc_stream(const uint8_t* p, size_t n) {
       for (size_t i = 0; i < nf; i++) {
         FbTable f = header.elem_table(first, i);
         IpcField fld;
-        fld.type = type_from_fb(f.get<uint8_t>(2, 0), f.child(3));
+        fld.type = type_of_field(f);
         FbTable de = f.child(4);
         if (de.valid()) {
           fld.dict = true;

@@ -28,6 +28,9 @@ struct ColumnSlice {
   const uint8_t* data = nullptr;       // Utf8 / Binary bytes: data[0] is byte `data_origin` of the column's value bytes
   int64_t data_origin = 0;
   int64_t first = 0;
+  // nested columns: a Struct's fields (each addressed like their parent: its rows from `first` on), a List's one element column — addressed
+  // from ELEMENT 0 of the whole column (the list's `values` are its int32 offsets; the rows' elements are offsets[first] … offsets[first + rows))
+  std::vector<ColumnSlice> kids;
 };
 
 // appends one complete block (length word included) for `rows` rows to `out`; nothing is written for rows == 0

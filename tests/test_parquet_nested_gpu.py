@@ -173,3 +173,57 @@ def test_what_the_nested_scan_refuses(built, tmp_path):
                               (["ss"], [S.T_INT32], "is a group")):
         with pytest.raises((native.CometNativeException, native.CometQueryExecutionException), match=msg):
             _run(S.native_scan([path], names, types), len(names))
+
+
+@pytest.mark.parametrize("codec", [S.CODEC_NONE, S.CODEC_ZSTD])
+def test_shuffle_writer_carries_nested_columns(built, tmp_path, codec):
+    """ShuffleWriter over a scan with struct and list columns, hash-partitioned on a flat key: rows are taken partition-major on the device —
+    children and all —, nested columns come to the host whole, flat ones in slabs; every block decoded by pyarrow's IPC reader holds the rows
+    the oracle's partitioner assigns, in order"""
+    import struct as pystruct
+    from oracle import shuffle_oracle as SO
+    t = _nested_table(15_000, 46)
+    path = str(tmp_path / "nested_shuffle.parquet")
+    papq.write_table(t, path, compression="snappy", row_group_size=4_000, data_page_size=32 << 10)
+    ty = _types(t.schema)
+    data, index = str(tmp_path / "shuffle.data"), str(tmp_path / "shuffle.index")
+    plan = S.shuffle_writer(S.native_scan([path], t.schema.names, ty), data, index, partitioning="hash", hash_exprs=[S.col(0, ty[0])], num_partitions=5, codec=codec)
+    assert native.execute_to_table([], 0, plan.encode(), batch_size=2048) == []
+    want = papq.read_table(path)
+    flat = want.select(["k"])
+    _, _, rows = SO.shuffle_write(S, flat, "hash", [0], 5, 2048)
+    raw, idx = open(data, "rb").read(), open(index, "rb").read()
+    offs = pystruct.unpack("<6q", idx)
+    assert offs[0] == 0 and offs[-1] == len(raw)
+    total = 0
+    for p in range(5):
+        blocks = SO.read_partition(raw, idx, p)
+        exp = want.take(pa.array(rows[p]))
+        n = exp.num_rows
+        assert [b.num_rows for b in blocks] == [2048] * (n // 2048) + ([n % 2048] if n % 2048 else [])
+        if blocks:
+            got = pa.Table.from_batches(blocks)
+            for c, name in enumerate(t.schema.names):
+                _same(got.column(c), exp.column(name), f"partition {p} column {name}")
+        total += n
+    assert total == want.num_rows
+
+
+def test_limit_and_sort_take_nested_rows(built, tmp_path):
+    """Sort on a flat key / Limit above a scan with nested columns: the row gather (take_rows) moves struct and list rows with their children"""
+    t = _nested_table(6_000, 47)
+    path = str(tmp_path / "nested_sort.parquet")
+    papq.write_table(t, path, compression="zstd", row_group_size=2_500)
+    ty = _types(t.schema)
+    scan = S.native_scan([path], t.schema.names, ty)
+    want = papq.read_table(path)
+    got = _run(S.limit(scan, 1000, 37), t.num_columns)
+    for c, name in enumerate(t.schema.names):
+        _same(got.column(c), want.slice(37, 1000 - 37).column(name), name)
+    # descending by k (unique): the reversed table
+    plan = S.sort(scan, [(S.col(0, ty[0]), True, False)])
+    got = _run(plan, t.num_columns)
+    order = pa.array(np.arange(want.num_rows - 1, -1, -1, dtype=np.int64))
+    rev = want.take(order)
+    for c, name in enumerate(["k", "s", "li"]):
+        _same(got.column(c), rev.column(name), name)

@@ -1,0 +1,67 @@
+"""Nested columns in Comet shuffle blocks (the Arrow IPC stream inside a block; native/shuffle/src/writers/shuffle_block_writer.rs:179-238,
+ipc.rs:23-52 — the reference writes whatever arrow-ipc writes): struct and list columns through comet_encode_shuffle_block /
+comet_decode_shuffle_block, the hand-written flatbuffers writer and reader refereed by pyarrow's IPC implementation in both directions."""
+import io
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from datafusion_comet_amd import native
+
+
+def _cols(b):
+    return [c.to_pylist() for c in b.columns]
+
+
+def _batch(n, seed):
+    from tests.test_parquet_nested_gpu import _nested_table
+    t = _nested_table(n, seed)
+    rng = np.random.default_rng(seed)
+    ls = [None if rng.random() < 0.1 else [None if rng.random() < 0.1 else "v%d" % int(x) for x in rng.integers(0, 99, int(rng.integers(0, 5)))] for _ in range(n)]
+    lst = [None if rng.random() < 0.1 else [{"x": int(x), "y": None if x % 3 == 0 else "y%d" % int(x)} for x in rng.integers(0, 99, int(rng.integers(0, 4)))] for _ in range(n)]
+    t = t.append_column("ls", pa.array(ls, pa.list_(pa.string())))
+    t = t.append_column("lst", pa.array(lst, pa.list_(pa.struct([("x", pa.int64()), ("y", pa.string())]))))
+    return t.combine_chunks().to_batches()[0]
+
+
+@pytest.mark.parametrize("codec", [0, 1, 2, 3])
+def test_round_trip_of_nested_columns(built, codec):
+    b = _batch(3_000, 51)
+    blk = native.encode_shuffle_block(b, codec)
+    got = native.decode_shuffle_block(blk[16:], b.num_columns)
+    assert got.num_rows == b.num_rows
+    assert _cols(got) == _cols(b)
+
+
+def test_pyarrow_reads_what_the_writer_wrote_and_the_reader_reads_what_pyarrow_wrote(built):
+    b = _batch(2_000, 52)
+    blk = native.encode_shuffle_block(b, 0)
+    assert blk[16:20] == b"NONE"
+    rd = pa.ipc.open_stream(blk[20:]).read_all()
+    assert rd.num_rows == b.num_rows and _cols(rd.combine_chunks().to_batches()[0]) == _cols(b)
+    for f, want in zip(rd.schema, b.schema):      # the types, children included (field names are the writer's own: c0, c1, …)
+        assert f.type == want.type or pa.types.is_nested(want.type)
+    assert pa.types.is_struct(rd.schema[1].type) and [k.name for k in rd.schema[1].type] == ["a", "b", "c", "d", "e"]
+    sink = io.BytesIO()
+    w = pa.ipc.new_stream(sink, b.schema)
+    w.write_batch(b)
+    w.close()
+    got = native.decode_shuffle_block(b"NONE" + sink.getvalue(), b.num_columns)
+    assert _cols(got) == _cols(b)
+
+
+def test_slices_of_nested_columns(built):
+    """a block of rows [first, first + rows) of a longer batch: list offsets are rebased, the elements are the addressed ones only"""
+    b = _batch(1_000, 53)
+    for first, rows in ((0, 1), (7, 129), (500, 500), (999, 1)):
+        s = b.slice(first, rows)
+        got = native.decode_shuffle_block(native.encode_shuffle_block(s, 2)[16:], b.num_columns)
+        assert _cols(got) == _cols(s), (first, rows)
+    sink = io.BytesIO()
+    s = b.slice(13, 200)
+    w = pa.ipc.new_stream(sink, s.schema)
+    w.write_batch(s)      # pyarrow writes a slice's list offsets as they are (not starting at 0) or rebased, depending on the version: both read
+    w.close()
+    got = native.decode_shuffle_block(b"NONE" + sink.getvalue(), b.num_columns)
+    assert _cols(got) == _cols(s)
