@@ -202,7 +202,10 @@ def render() -> str:
     w("* Computed Utf8 values used as operands of further expressions must fit 15 bytes (literals, substring, CASE over those).")
     w("* Window: RANGE frames with value offsets over non-integer keys, floating-point aggregates over frames, MIN / MAX over sliding frames wider")
     w("  than 4096 rows, lag / lead defaults of Utf8 / Boolean type.")
-    w("* Nested types (struct, list, map) in scans, plans and shuffle files; Parquet: nested schemas, TIMESTAMP(NANOS) / TIME, encrypted files.")
+    w("* Nested types: struct-of-flat and list-of-flat (fixed-width elements) columns are read from Parquet, passed through Filter / Projection / Sort /")
+    w("  Limit / ShuffleWriter, taken apart by `GetStructField` and exported; maps, deeper trees, lists of strings / booleans, nested columns arriving")
+    w("  through Scan / ShuffleScan inputs and every expression that computes on a list or builds a struct are refused.  Parquet: TIMESTAMP(NANOS) /")
+    w("  TIME, encrypted files.")
     w("* ShuffleWriter with more than 4096 partitions.")
     w("")
     return "\n".join(out) + "\n"
