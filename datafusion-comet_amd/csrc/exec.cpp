@@ -294,6 +294,10 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     root_source_ = root_source_->children[0].get();
   }
   if (root_source_->kind == OpKind::HashAgg) has_join_ = true;   // operators above an aggregate: the aggregate is materialised
+  // a Scan with struct / list fields is a materialised source too: its chunk is resident as a whole (children and all) and the chain above
+  // it runs over that table, where a struct's fields are columns of their own and nested rows are gathered by index
+  if (root_source_->kind == OpKind::Scan)
+    for (auto& t : root_source_->scan_fields) has_join_ = has_join_ || t.is_nested();
   // Validate the plan shape eagerly (generated, not compiled) so that unsupported operators fail at createPlan
   // like the reference's planner would on first execute.
   if (!has_join_) {

@@ -126,6 +126,7 @@ struct Staging {  // host→device staging of one input stream (one chunk at a t
   std::vector<std::unique_ptr<PinnedBuf>> stage_vals, stage_valid, stage_aux;
   std::vector<std::unique_ptr<DevBuf>> dev_vals, dev_valid, dev_aux;
   std::vector<int> dict_index_width;   // per column: byte width of dictionary indices (0 = not dictionary-encoded)
+  std::vector<std::shared_ptr<void>> nested_keep;   // device buffers of this chunk's nested columns (children, offsets, bitmaps): live as long as the set
   hipEvent_t busy = nullptr;           // recorded behind the last GPU work that reads this set
 };
 

@@ -78,6 +78,13 @@ void ExecutionContext::validate_input_schema(size_t input, const std::vector<DTy
     for (size_t c = 0; c < types.size() && err.empty(); c++) {
       const ArrowSchema* f = sch.children[c];
       const char* fmt = f->dictionary ? f->dictionary->format : f->format;
+      if (types[c].is_nested()) {
+        // a struct / list column of a host stream (a JVM-side scan's batches, a shuffle block): matched field by field, uploaded with its children
+        if (in.kind == 0 && nested_schema_matches(f, types[c])) continue;
+        err = "Scan input column " + std::to_string(c) + " (Arrow format '" + (fmt ? fmt : "?") + "') does not match the declared " + types[c].str() +
+              (in.kind == 0 ? " field by field (nested input columns are not cast)" : ": nested columns of device-resident inputs are not supported");
+        break;
+      }
       if (format_matches(fmt, types[c])) continue;
       if (in.kind == 0 && !f->dictionary && scan_cast_supported(parse_src_format(fmt), types[c])) {
         if (scan_cast_from_.size() <= input) scan_cast_from_.resize(input + 1);
@@ -287,6 +294,74 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
   }
   if (!dict_keep.empty()) HIP_CHECK(hipStreamSynchronize(stream_));   // uploaded indices/dictionaries are released below
   dict_keep.clear();
+  // Nested columns: the chunk's batches are concatenated on the host (offsets rebased, children appended) and go up buffer by buffer; the
+  // device buffers live with this staging set.  Not the streaming-store path of the flat columns: nested inputs are not the hot path.
+  stg.nested_keep.clear();
+  std::vector<DeviceColumnView> nested_views(nc);
+  std::function<DeviceColumnView(const HostColumn&, bool&)> upload_nested = [&](const HostColumn& h, bool& hv) -> DeviceColumnView {
+    DeviceColumnView v;
+    auto up = [&](const void* src, size_t n) -> const void* {
+      auto d = std::make_shared<DevBuf>();
+      d->ensure(n + 16);
+      if (n) HIP_CHECK(hipMemcpyAsync(d->p, src, n, hipMemcpyHostToDevice, stream_));
+      stg.nested_keep.push_back(d);
+      return d->p;
+    };
+    // (NULLs are counted here: a struct's fields were masked by their struct's validity after their own counts were taken)
+    int64_t nulls = 0;
+    for (int64_t i = 0; i < h.length && !h.validity.empty(); i++) nulls += !((h.validity[(size_t)(i >> 3)] >> (i & 7)) & 1);
+    hv = nulls > 0;
+    if (hv) v.valid = (const uint8_t*)up(h.validity.data(), (size_t)((h.length + 7) / 8));
+    if (h.type.id == TypeId::Struct) {
+      for (const HostColumn& k : h.children) {
+        bool khv = false;
+        v.kids.push_back(upload_nested(k, khv));
+        v.kid_has_valid.push_back(khv ? 1 : 0);
+      }
+      v.kid_rows = h.length;
+    } else if (h.type.id == TypeId::List) {
+      static const int32_t zero = 0;
+      v.data = h.values.empty() ? up(&zero, 4) : up(h.values.data(), (size_t)(h.length + 1) * 4);
+      bool khv = false;
+      v.kids.push_back(upload_nested(h.children.at(0), khv));
+      v.kid_has_valid.push_back(khv ? 1 : 0);
+      v.kid_rows = h.children[0].length;
+    } else if (h.type.id == TypeId::String || h.type.id == TypeId::Bytes) {
+      static const int32_t zero = 0;
+      v.data = h.values.empty() ? up(&zero, 4) : up(h.values.data(), (size_t)(h.length + 1) * 4);
+      v.aux = up(h.data.data(), h.data.size());
+    } else if (h.type.id == TypeId::Bool) {
+      v.data = up(h.values.data(), (size_t)((h.length + 7) / 8));
+    } else {
+      v.data = up(h.values.data(), (size_t)h.length * (size_t)fixed_width(h.type));
+    }
+    return v;
+  };
+  std::vector<HostColumn> nested_host;      // (alive until the copies queued above have run: synchronised below)
+  nested_host.reserve(nc);
+  for (size_t c = 0; c < nc; c++) {
+    if (!in_types_[c].is_nested()) continue;
+    nested_host.emplace_back();
+    HostColumn& h = nested_host.back();
+    h.type = in_types_[c];
+    // (an empty struct / list still needs its children's shape)
+    std::function<void(HostColumn&, const DType&)> shape = [&](HostColumn& x, const DType& t) {
+      x.type = t;
+      if (t.id == TypeId::Struct) { x.children.resize(t.kids.size()); for (size_t k = 0; k < t.kids.size(); k++) shape(x.children[k], t.kids[k]); }
+      else if (t.id == TypeId::List) { x.children.resize(1); shape(x.children[0], t.kids.at(0)); }
+    };
+    shape(h, in_types_[c]);
+    for (auto& a : held) {
+      if (a.children[c]->length != a.length) throw CometError("ragged input batch");
+      append_nested_rows(h, a.children[c], in_types_[c], 0, a.children[c]->length);
+    }
+    bool hv = false;
+    nested_views[c] = upload_nested(h, hv);
+    has_valid[c] = hv;
+    dict_done[c] = true;
+  }
+  if (!nested_host.empty()) HIP_CHECK(hipStreamSynchronize(stream_));
+  nested_host.clear();
   for (size_t c = 0; c < nc; c++) {
     if (dict_done[c]) continue;
     const DType& t = in_types_[c];
@@ -441,6 +516,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
   for (auto& a : held) if (a.release) a.release(&a);
   views.assign(nc, DeviceColumnView());
   for (size_t c = 0; c < nc; c++) {
+    if (in_types_[c].is_nested()) { views[c] = nested_views[c]; continue; }
     views[c].data = dev_vals_[c]->p;
     views[c].valid = has_valid[c] ? (const uint8_t*)dev_valid_[c]->p : nullptr;
     views[c].aux = dev_aux_[c]->p;

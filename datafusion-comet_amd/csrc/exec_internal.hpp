@@ -119,6 +119,8 @@ void pool_put_event(int dev, hipEvent_t e);
 int fixed_width(const DType& t);
 inline int out_width(const OutCol& oc) { return (oc.view_src >= 0 || oc.fmt_kind) ? 16 : (oc.gather_src >= 0 || !oc.concat_cols.empty()) ? 4 : oc.packed_string ? 16 : (oc.type.id == TypeId::Bool ? 1 : fixed_width(oc.type)); }
 void bit_append(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t src_off, int64_t n);
+bool nested_schema_matches(const ArrowSchema* f, const DType& t);
+void append_nested_rows(HostColumn& dst, const ArrowArray* a, const DType& t, int64_t off, int64_t len);
 void bit_fill_ones(uint8_t* dst, int64_t dst_off, int64_t n);
 bool format_matches(const char* fmt, const DType& t);
 struct SrcFmt {

@@ -59,8 +59,91 @@ void bit_fill_ones(uint8_t* dst, int64_t dst_off, int64_t n) {
   }
 }
 
+// a nested input column: the stream's field (children and all) against the declared type.  Dictionary-encoded children are not unpacked.
+bool nested_schema_matches(const ArrowSchema* f, const DType& t) {
+  if (!f || !f->format || f->dictionary) return false;
+  const std::string fmt = f->format;
+  if (t.id == TypeId::Struct) {
+    if (fmt != "+s" || (size_t)f->n_children != t.kids.size()) return false;
+    for (size_t k = 0; k < t.kids.size(); k++)
+      if (!nested_schema_matches(f->children[k], t.kids[k])) return false;
+    return true;
+  }
+  if (t.id == TypeId::List) return fmt == "+l" && f->n_children == 1 && t.kids.size() == 1 && nested_schema_matches(f->children[0], t.kids[0]);
+  if (t.is_nested()) return false;
+  return format_matches(f->format, t);
+}
+
+// Arrow C arrays of one nested column (the batches of a chunk) → ONE host column: rows [off, off + len) of `a` appended to `dst`, children
+// and all (struct: the same rows of every field; list: offsets rebased onto what `dst` holds, the addressed elements appended).  Validity
+// bitmaps are always built (all ones where a batch has none) and dropped by the caller when nothing is NULL.
+void append_nested_rows(HostColumn& dst, const ArrowArray* a, const DType& t, int64_t off, int64_t len) {
+  if (a->dictionary) throw CometError("dictionary-encoded fields inside a nested input column are not supported");
+  const int64_t src0 = a->offset + off;
+  const int64_t at = dst.length;
+  dst.type = t;
+  dst.validity.resize((size_t)((at + len + 7) / 8) + 8, 0);
+  if (a->null_count != 0 && a->n_buffers > 0 && a->buffers[0]) {
+    bit_append(dst.validity.data(), at, (const uint8_t*)a->buffers[0], src0, len);
+    const uint8_t* vb = (const uint8_t*)a->buffers[0];
+    for (int64_t i = 0; i < len; i++) dst.null_count += !((vb[(size_t)((src0 + i) >> 3)] >> ((src0 + i) & 7)) & 1);
+  } else {
+    bit_fill_ones(dst.validity.data(), at, len);
+  }
+  dst.length = at + len;
+  if (t.id == TypeId::Struct) {
+    if ((size_t)a->n_children != t.kids.size()) throw CometError("nested input column: struct array and declared type differ in their fields");
+    if (dst.children.size() != t.kids.size()) dst.children.resize(t.kids.size());
+    for (size_t k = 0; k < t.kids.size(); k++) append_nested_rows(dst.children[k], a->children[k], t.kids[k], src0, len);
+    // Arrow leaves a field's slot under a NULL struct undefined (pyarrow writes a VALID zero there); in HBM a field's validity says NULL
+    // wherever its struct is NULL — what the Parquet scan's levels give, and what GetStructField reads as the field's own validity
+    std::function<void(HostColumn&, const HostColumn&)> mask = [&](HostColumn& kid, const HostColumn& parent) {
+      for (int64_t i = at; i < at + len; i++)
+        if (!((parent.validity[(size_t)(i >> 3)] >> (i & 7)) & 1)) kid.validity[(size_t)(i >> 3)] &= (uint8_t)~(1u << (i & 7));
+      if (kid.type.id == TypeId::Struct)
+        for (HostColumn& g : kid.children) mask(g, kid);
+    };
+    if (dst.null_count > 0)
+      for (HostColumn& k : dst.children) mask(k, dst);
+    return;
+  }
+  if (t.id == TypeId::List) {
+    if (a->n_children != 1 || t.kids.size() != 1) throw CometError("nested input column: list array without its elements");
+    if (dst.children.empty()) dst.children.resize(1);
+    const int32_t* o = (const int32_t*)a->buffers[1] + src0;
+    if (dst.values.empty()) dst.values.assign(4, 0);                     // offsets[0] = 0
+    const int32_t base = (int32_t)dst.children[0].length;
+    const size_t was = dst.values.size();
+    dst.values.resize(was + (size_t)len * 4);
+    int32_t* w = (int32_t*)(dst.values.data() + was);
+    for (int64_t i = 0; i < len; i++) w[i] = base + (o[i + 1] - o[0]);
+    if ((int64_t)base + (o[len] - o[0]) > 0x7fffffffll) throw CometError("nested input column: more than 2^31 list elements in one chunk");
+    append_nested_rows(dst.children[0], a->children[0], t.kids[0], o[0], o[len] - o[0]);
+    return;
+  }
+  if (t.id == TypeId::String || t.id == TypeId::Bytes) {
+    const int32_t* o = (const int32_t*)a->buffers[1] + src0;
+    if (dst.values.empty()) dst.values.assign(4, 0);
+    const int32_t base = (int32_t)dst.data.size();
+    const size_t was = dst.values.size();
+    dst.values.resize(was + (size_t)len * 4);
+    int32_t* w = (int32_t*)(dst.values.data() + was);
+    for (int64_t i = 0; i < len; i++) w[i] = base + (o[i + 1] - o[0]);
+    if (o[len] > o[0]) dst.data.insert(dst.data.end(), (const uint8_t*)a->buffers[2] + o[0], (const uint8_t*)a->buffers[2] + o[len]);
+    return;
+  }
+  if (t.id == TypeId::Bool) {
+    dst.values.resize((size_t)((at + len + 7) / 8) + 8, 0);
+    bit_append(dst.values.data(), at, (const uint8_t*)a->buffers[1], src0, len);
+    return;
+  }
+  const size_t w = (size_t)fixed_width(t);
+  const uint8_t* src = (const uint8_t*)a->buffers[1] + (size_t)src0 * w;
+  dst.values.insert(dst.values.end(), src, src + (size_t)len * w);
+}
+
 bool format_matches(const char* fmt, const DType& t) {
-  if (!fmt || t.is_nested()) return false;      // (nested columns do not come in through Scan inputs: the Parquet scan produces them)
+  if (!fmt || t.is_nested()) return false;      // (nested columns are matched field by field: nested_schema_matches)
   std::string f = fmt;
   if (t.id == TypeId::Timestamp) return f.rfind("tsu:", 0) == 0 && f.size() > 4;
   if (t.id == TypeId::Decimal) {

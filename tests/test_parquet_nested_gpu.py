@@ -227,3 +227,56 @@ def test_limit_and_sort_take_nested_rows(built, tmp_path):
     rev = want.take(order)
     for c, name in enumerate(["k", "s", "li"]):
         _same(got.column(c), rev.column(name), name)
+
+
+def test_nested_columns_of_a_host_stream_input(built):
+    """Scan (what the JVM hands over as ArrowArrayStream batches) with struct and list fields — lists of strings and of structs, a struct
+    inside a struct too: the batches of a chunk are concatenated on the host and uploaded with their children; Filter on a flat column and on a
+    struct's field, GetStructField, passthrough"""
+    from tests.test_shuffle_nested_cpu import _batch
+    b = _batch(9_000, 61)
+    t = pa.Table.from_batches([b])
+    inner = pa.array([None if i % 7 == 0 else {"p": i, "q": {"r": "r%d" % i, "z": None if i % 3 == 0 else i * 0.5}} for i in range(t.num_rows)],
+                     pa.struct([("p", pa.int64()), ("q", pa.struct([("r", pa.string()), ("z", pa.float64())]))]))
+    t = t.append_column("deep", inner)
+    ty = _types(t.schema)
+    names = t.schema.names
+    s = S.col(names.index("s"), ty[names.index("s")])
+    scan = S.scan(ty)
+    pred = S.and_(S.gt_eq(S.col(0, ty[0]), S.lit(100, S.T_INT64)), S.lt(S.get_struct_field(s, 0), S.lit(600, S.T_INT32)))
+    outs = [S.col(i, ty[i]) for i in range(len(ty))] + [S.get_struct_field(s, 1), S.get_struct_field(S.col(names.index("deep"), ty[names.index("deep")]), 0)]
+    plan = S.project(S.filter_(scan, pred), outs)
+    got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t, 1000)], len(outs), plan.encode()))
+    keep = [i for i, (k, sv) in enumerate(zip(t.column("k").to_pylist(), t.column("s").to_pylist())) if k >= 100 and sv is not None and sv["a"] is not None and sv["a"] < 600]
+    assert got.num_rows == len(keep) and len(keep) > 500
+    want = t.take(pa.array(keep, pa.int64()))
+    for c, name in enumerate(names):
+        _same(got.column(c), want.column(name), name)
+    assert got.column(len(names)).to_pylist() == [v["b"] for v in want.column("s").to_pylist()]
+    assert got.column(len(names) + 1).to_pylist() == [None if v is None else v["p"] for v in want.column("deep").to_pylist()]
+
+
+def test_nested_columns_round_trip_through_shuffle_files(built, tmp_path):
+    """stage 1 writes shuffle files with struct / list columns (GPU writer), stage 2 reads every partition back through a ShuffleScan leaf and
+    passes the rows on: the union of the partitions is the table"""
+    t = _nested_table(10_000, 48)
+    path = str(tmp_path / "nested_rt.parquet")
+    papq.write_table(t, path, compression="zstd", row_group_size=3_000)
+    ty = _types(t.schema)
+    data, index = str(tmp_path / "shuffle.data"), str(tmp_path / "shuffle.index")
+    P = 4
+    plan = S.shuffle_writer(S.native_scan([path], t.schema.names, ty), data, index, partitioning="hash", hash_exprs=[S.col(0, ty[0])], num_partitions=P, codec=S.CODEC_LZ4)
+    assert native.execute_to_table([], 0, plan.encode(), batch_size=1500) == []
+    back = S.project(S.shuffle_scan(ty), [S.col(i, ty[i]) for i in range(len(ty))])
+    rows = {}
+    for p in range(P):
+        out = native.execute_to_table([native.ShuffleBlockInput.from_files(data, index, p)], len(ty), back.encode(), batch_size=0)
+        for b in out:
+            cols = [c.to_pylist() for c in b.columns]
+            for i in range(b.num_rows):
+                rows[cols[0][i]] = tuple(cols[j][i] for j in range(1, len(cols)))
+    want = papq.read_table(path)
+    wcols = [want.column(n).to_pylist() for n in t.schema.names]
+    assert len(rows) == want.num_rows
+    for i in range(want.num_rows):
+        assert rows[wcols[0][i]] == tuple(wcols[j][i] for j in range(1, len(wcols))), i

@@ -203,9 +203,9 @@ def render() -> str:
     w("* Window: RANGE frames with value offsets over non-integer keys, floating-point aggregates over frames, MIN / MAX over sliding frames wider")
     w("  than 4096 rows, lag / lead defaults of Utf8 / Boolean type.")
     w("* Nested types: struct-of-flat and list-of-flat (fixed-width elements) columns are read from Parquet, passed through Filter / Projection / Sort /")
-    w("  Limit / ShuffleWriter, taken apart by `GetStructField` and exported; maps, deeper trees, lists of strings / booleans, nested columns arriving")
-    w("  through Scan / ShuffleScan inputs and every expression that computes on a list or builds a struct are refused.  Parquet: TIMESTAMP(NANOS) /")
-    w("  TIME, encrypted files.")
+    w("  Limit / ShuffleWriter, taken apart by `GetStructField` and exported; struct / list columns of any depth arrive through Scan / ShuffleScan inputs;")
+    w("  maps, deeper trees and lists of strings / booleans in the Parquet scan, and every expression that computes on a list or builds a struct are refused.")
+    w("  Parquet: TIMESTAMP(NANOS) / TIME, encrypted files.")
     w("* ShuffleWriter with more than 4096 partitions.")
     w("")
     return "\n".join(out) + "\n"
