@@ -2481,7 +2481,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     if (cur->kind == OpKind::Scan) break;
     // materialised sources: joins, Parquet scans, sorts, limits — and an aggregate BELOW other operators (nothing fuses
     // across a pipeline breaker: its result is materialised in HBM and read like a scan)
-    if (cur->kind == OpKind::HashJoin || cur->kind == OpKind::NativeScan || cur->kind == OpKind::Sort || cur->kind == OpKind::Limit || cur->kind == OpKind::Expand || cur->kind == OpKind::Window ||
+    if (cur->kind == OpKind::Explode || cur->kind == OpKind::HashJoin || cur->kind == OpKind::NativeScan || cur->kind == OpKind::Sort || cur->kind == OpKind::Limit || cur->kind == OpKind::Expand || cur->kind == OpKind::Window ||
         (cur->kind == OpKind::HashAgg && cur != &root)) {
       if (!source_types) throw CometError("internal: materialised source without a schema");
       break;

@@ -291,6 +291,35 @@ __global__ __launch_bounds__(256) void take_list_indices_kernel(const i32* offs,
     for (i32 j = sub; j < len; j += 8) elem_idx[lo + j] = (u32)(src + j);
   }
 }
+// Explode (operators: UnnestExec in the reference, planner.rs:1949-2110): rows of a List column → one output row per element.  counts[r] = the
+// row's elements — a NULL list has none — or ONE for an empty / NULL list under explode_outer (its element is NULL).
+__global__ __launch_bounds__(256) void explode_counts_kernel(const i32* offs, const u8* valid_bits, i64 n, int outer, u32* counts) {
+  for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < n; r += (i64)gridDim.x * 256) {
+    const bool ok = !valid_bits || ((valid_bits[r >> 3] >> (r & 7)) & 1);
+    const u32 len = ok ? (u32)(offs[r + 1] - offs[r]) : 0u;
+    counts[r] = (len == 0 && outer) ? 1u : len;
+  }
+}
+// per output row: its input row, its element (source index in the element column), whether there is one (0: the NULL row of explode_outer),
+// its position in the list, and the element's validity byte (there is one AND its own validity bit says so)
+__global__ __launch_bounds__(256) void explode_indices_kernel(const i32* offs, const u8* valid_bits, const u8* elem_valid_bits, i64 n, const i32* out_offs, u32* row_idx, u32* elem_idx,
+                                                              u8* has_elem, i32* pos, u8* elem_ok) {
+  const int sub = threadIdx.x & 7;
+  for (i64 r = ((i64)blockIdx.x * 256 + threadIdx.x) >> 3; r < n; r += ((i64)gridDim.x * 256) >> 3) {
+    const i32 lo = out_offs[r], cnt = out_offs[r + 1] - lo;
+    const bool ok = !valid_bits || ((valid_bits[r >> 3] >> (r & 7)) & 1);
+    const i32 src = offs[r], len = ok ? offs[r + 1] - src : 0;
+    for (i32 j = sub; j < cnt; j += 8) {
+      const bool real = j < len;
+      const u32 e = real ? (u32)(src + j) : 0u;
+      row_idx[lo + j] = (u32)r;
+      elem_idx[lo + j] = e;
+      has_elem[lo + j] = real;
+      pos[lo + j] = real ? j : 0;
+      elem_ok[lo + j] = real && (!elem_valid_bits || ((elem_valid_bits[e >> 3] >> (e & 7)) & 1));
+    }
+  }
+}
 // eight lanes copy one value: they write consecutive bytes, so a wave stores 8 contiguous runs instead of 64 scattered bytes per step
 __global__ __launch_bounds__(256) void take_utf8_copy_kernel(const i32* offs, const u8* bytes, const u32* idx, const u8* ok_bytes, const u8* src_valid_bits,
                                                              i64 n, const i32* out_offs, u8* out_bytes) {
@@ -529,6 +558,16 @@ int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n
 int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t n,
                                    uint32_t* lengths, void* stream) {
   if (n > 0) hipLaunchKernelGGL(take_utf8_lengths_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offs, idx, ok_bytes, src_valid_bits, (i64)n, lengths);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_explode_counts(const int32_t* offs, const uint8_t* valid_bits, int64_t n, int outer, uint32_t* counts, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(explode_counts_kernel, grid_for(n), 256, 0, (hipStream_t)stream, offs, valid_bits, (i64)n, outer, counts);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int comet_launch_explode_indices(const int32_t* offs, const uint8_t* valid_bits, const uint8_t* elem_valid_bits, int64_t n, const int32_t* out_offs, uint32_t* row_idx,
+                                 uint32_t* elem_idx, uint8_t* has_elem, int32_t* pos, uint8_t* elem_ok, void* stream) {
+  if (n > 0)
+    hipLaunchKernelGGL(explode_indices_kernel, grid_for(n * 8), 256, 0, (hipStream_t)stream, offs, valid_bits, elem_valid_bits, (i64)n, out_offs, row_idx, elem_idx, has_elem, pos, elem_ok);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int comet_launch_take_list_indices(const int32_t* offs, const uint32_t* idx, int64_t n, const int32_t* out_offs, uint32_t* elem_idx, void* stream) {

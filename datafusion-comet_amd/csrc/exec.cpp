@@ -209,7 +209,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     node_id_[&op] = (int)node_id_.size();
     if (op.kind == OpKind::Scan && !scan_input_.count(&op)) scan_input_.emplace(&op, scan_input_.size());   // (bound above, before the semi-join reduction)
     if (op.kind == OpKind::HashJoin || op.kind == OpKind::NativeScan || op.kind == OpKind::Sort || op.kind == OpKind::Limit || op.kind == OpKind::ShuffleWriter ||
-        op.kind == OpKind::Expand || op.kind == OpKind::Window)
+        op.kind == OpKind::Expand || op.kind == OpKind::Window || op.kind == OpKind::Explode)
       has_join_ = true;
     if (op.kind == OpKind::Window) {
       for (int t = 0; t < 2; t++) {
@@ -329,7 +329,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
 // limits, and an aggregate that is not the top of the chain being fused.
 bool ExecutionContext::is_source(const Operator& op, const Operator* chain_top) {
   switch (op.kind) {
-    case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: case OpKind::ShuffleWriter: case OpKind::Expand: case OpKind::Window: return true;
+    case OpKind::Explode: case OpKind::Scan: case OpKind::HashJoin: case OpKind::NativeScan: case OpKind::Sort: case OpKind::Limit: case OpKind::ShuffleWriter: case OpKind::Expand: case OpKind::Window: return true;
     case OpKind::HashAgg: return &op != chain_top;
     default: return false;
   }
@@ -488,6 +488,43 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     }
     explain_ += "  window: " + std::to_string(op.window_fns.size()) + " function(s), " + std::to_string(op.window_partition.size()) + " partition key(s), " +
                 std::to_string(op.window_order.size()) + " order key(s)\n";
+    return out;
+  }
+  if (op.kind == OpKind::Explode) {
+    // Explode / posexplode [_outer] (planner.rs:1949-2110: a Projection of the carried columns ++ [pos] ++ the list, then UnnestExec): output =
+    // project_list ++ [pos Int32] ++ [element].  The carried columns are a fused Projection over the resident child (evaluated once per INPUT
+    // row, then gathered by the output rows' input row); the list must be a column of the child
+    if (op.children.size() != 1) throw CometError("Explode expects exactly one child");
+    std::vector<DType> st = infer_schema(*op.children[0]);
+    const ExprP& lc = op.explode_child;
+    if (!lc) throw CometError("Explode operator requires a child expression");
+    if (lc->kind != ExprKind::Bound || lc->bound_index < 0 || (size_t)lc->bound_index >= st.size())
+      throw CometError("Explode: the exploded expression must be a column of the child (computed arrays are not supported)");
+    const DType& lt = st[(size_t)lc->bound_index];
+    if (lt.id != TypeId::List || lt.kids.size() != 1) throw CometError("Explode: column " + std::to_string(lc->bound_index) + " is " + lt.str() + ", not a list (maps are not supported)");
+    std::vector<DType> out;
+    if (!op.project_list.empty()) {
+      auto sc = std::make_shared<Operator>();
+      sc->kind = OpKind::Scan;
+      sc->proto_tag = 100;
+      sc->scan_fields = st;
+      auto pr = std::make_shared<Operator>();
+      pr->kind = OpKind::Projection;
+      pr->proto_tag = 101;
+      pr->children.push_back(sc);
+      pr->project_list = op.project_list;
+      node_id_[pr.get()] = (int)node_id_.size();
+      std::vector<DType> ext = extend_struct_field_types(st);
+      std::vector<bool> none(ext.size(), false);
+      PipelineDesc d = generate_pipeline(*pr, none, &ext);
+      if (compile_in_infer_) jit_compile(d.source);
+      explain_ += d.explain;
+      for (auto& c : d.out_cols) { out.push_back(c.type); out.back().virt_parent = out.back().virt_kid = -1; }
+      explode_proj_[&op] = pr;
+    }
+    if (op.explode_position) out.push_back(DType::of(TypeId::Int32));
+    out.push_back(lt.kids[0]);
+    explain_ += std::string("  explode") + (op.explode_outer ? "_outer" : "") + (op.explode_position ? " with positions" : "") + " of column " + std::to_string(lc->bound_index) + "\n";
     return out;
   }
   if (op.kind == OpKind::Expand) {
@@ -1350,6 +1387,10 @@ DevTable ExecutionContext::materialize(const Operator& op) {
   if (op.kind == OpKind::Expand) {
     DevTable in = materialize(*op.children[0]);
     return expand(op, in);
+  }
+  if (op.kind == OpKind::Explode) {
+    DevTable in = materialize(*op.children[0]);
+    return explode(op, in);
   }
   if (op.kind == OpKind::Window) {
     DevTable in = materialize(*op.children[0]);

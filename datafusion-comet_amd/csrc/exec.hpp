@@ -206,6 +206,7 @@ class ExecutionContext {
   DevTable nested_aggregate(const Operator& agg);
   DevTable write_shuffle(const Operator& sw);
   DevTable expand(const Operator& ex, const DevTable& in);
+  DevTable explode(const Operator& ex, const DevTable& in);
   DevTable window(const Operator& w, const DevTable& in);
   void prepare_dict_keys(DevTable& src);
   static bool is_source(const Operator& op, const Operator* chain_top);
@@ -299,6 +300,7 @@ class ExecutionContext {
     std::vector<OutCol> out_cols;   // unified output schema
   };
   std::map<const Operator*, ExpandInfo> expand_info_;
+  std::map<const Operator*, OperatorP> explode_proj_;   // Explode → the synthetic Projection of the columns it carries alongside
   std::map<const Operator*, OperatorP> window_psort_, window_osort_;   // Window → synthetic Sorts describing its partition / order keys
   std::map<const Operator*, OperatorP> range_sort_, range_bsort_;   // ShuffleWriter(range) → synthetic Sort over its rows / its boundary rows
   std::shared_ptr<void> planes_owner_;

@@ -84,6 +84,9 @@ extern "C" int comet_launch_partition_indices(const int32_t* pids, int64_t n, in
 extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream);
 extern "C" int comet_launch_take_utf8_lengths(const int32_t* offs, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits, int64_t n,
                                               uint32_t* lengths, void* stream);
+extern "C" int comet_launch_explode_counts(const int32_t* offs, const uint8_t* valid_bits, int64_t n, int outer, uint32_t* counts, void* stream);
+extern "C" int comet_launch_explode_indices(const int32_t* offs, const uint8_t* valid_bits, const uint8_t* elem_valid_bits, int64_t n, const int32_t* out_offs, uint32_t* row_idx,
+                                            uint32_t* elem_idx, uint8_t* has_elem, int32_t* pos, uint8_t* elem_ok, void* stream);
 extern "C" int comet_launch_take_list_indices(const int32_t* offs, const uint32_t* idx, int64_t n, const int32_t* out_offs, uint32_t* elem_idx, void* stream);
 extern "C" int comet_launch_take_utf8_copy(const int32_t* offs, const uint8_t* bytes, const uint32_t* idx, const uint8_t* ok_bytes, const uint8_t* src_valid_bits,
                                            int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);

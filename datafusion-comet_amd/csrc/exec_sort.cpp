@@ -57,6 +57,85 @@ DevTable ExecutionContext::take_rows(const DevTable& in, const uint32_t* dev_per
   return out;
 }
 
+// Explode: one output row per element of a List column (see infer_schema for the plan shape).  counts → prefix sum → per output row its
+// input row / element / position (exchange_kernels.hip explode_*), then the carried columns taken by input row and the element column taken
+// by element index — any element type, children and all.
+DevTable ExecutionContext::explode(const Operator& ex, const DevTable& in) {
+  const int lc = ex.explode_child->bound_index;
+  const DeviceColumnView& lv = in.cols.at((size_t)lc);
+  const DType& lt = in.types.at((size_t)lc);
+  if (lt.id != TypeId::List || lv.kids.size() != 1) throw CometError("Explode: the exploded column is not a resident list");
+  const int64_t n = in.rows;
+  const uint8_t* lvalid = in.has_valid[(size_t)lc] ? lv.valid : nullptr;
+  const bool ehv = !lv.kid_has_valid.empty() && lv.kid_has_valid[0] && lv.kids[0].valid;
+  // the carried columns, once per input row
+  DevTable carried;
+  auto pit = explode_proj_.find(&ex);
+  if (pit != explode_proj_.end()) carried = run_chain_to_device(*pit->second, in);
+  DevBuf counts, tiles;
+  auto out_offs = std::make_shared<DevBuf>();
+  counts.ensure((size_t)std::max<int64_t>(n, 1) * 4 + 16);
+  tiles.ensure((size_t)((n + 1023) / 1024 + 2) * 8);
+  out_offs->ensure((size_t)(n + 1) * 4 + 16);
+  int32_t total = 0;
+  if (n > 0) {
+    if (comet_launch_explode_counts((const int32_t*)lv.data, lvalid, n, ex.explode_outer ? 1 : 0, (uint32_t*)counts.p, stream_) != 0) throw CometError("explode: launch failed");
+    pq_launch_u32_scan((const uint32_t*)counts.p, n, (uint64_t*)tiles.p, (int32_t*)out_offs->p, stream_);
+    read_small(&total, (char*)out_offs->p + (size_t)n * 4, 4);
+    if (total < 0) throw CometError("Explode: more than 2^31 output rows in one partition");
+  }
+  auto row_idx = std::make_shared<DevBuf>(), elem_idx = std::make_shared<DevBuf>(), has_elem = std::make_shared<DevBuf>(), pos = std::make_shared<DevBuf>(),
+       elem_ok = std::make_shared<DevBuf>();
+  const size_t cap = (size_t)std::max(total, 1);
+  row_idx->ensure(cap * 4 + 16);
+  elem_idx->ensure(cap * 4 + 16);
+  has_elem->ensure(cap + 16);
+  pos->ensure(cap * 4 + 16);
+  elem_ok->ensure(cap + 16);
+  if (total > 0 &&
+      comet_launch_explode_indices((const int32_t*)lv.data, lvalid, ehv ? lv.kids[0].valid : nullptr, n, (const int32_t*)out_offs->p, (uint32_t*)row_idx->p, (uint32_t*)elem_idx->p,
+                                   (uint8_t*)has_elem->p, (int32_t*)pos->p, (uint8_t*)elem_ok->p, stream_) != 0)
+    throw CometError("explode: launch failed");
+  DevTable out;
+  out.rows = total;
+  for (size_t c = 0; c < carried.cols.size(); c++) {
+    bool hv = false;
+    out.cols.push_back(take_column(carried.cols[c], carried.types[c], carried.has_valid[c], (const uint32_t*)row_idx->p, nullptr, total, hv, out.owners));
+    out.types.push_back(carried.types[c]);
+    out.has_valid.push_back(hv);
+  }
+  auto pack = [&](const std::shared_ptr<DevBuf>& bytes) -> const uint8_t* {
+    auto bm = std::make_shared<DevBuf>();
+    bm->ensure((size_t)((total + 7) / 8) + 16);
+    if (total > 0) pq_launch_pack((const uint8_t*)bytes->p, (uint8_t*)bm->p, total, stream_);
+    out.owners.push_back(bm);
+    return (const uint8_t*)bm->p;
+  };
+  if (ex.explode_position) {
+    DeviceColumnView pv;
+    pv.data = pos->p;
+    if (ex.explode_outer) pv.valid = pack(has_elem);      // the NULL row of an empty / NULL list has no position
+    out.cols.push_back(pv);
+    out.types.push_back(DType::of(TypeId::Int32));
+    out.has_valid.push_back(ex.explode_outer);
+    out.owners.push_back(pos);
+  }
+  {
+    // the element: taken by its index; its validity is "there is one, and its own bit says valid" (elem_ok), whatever its type
+    bool hv_unused = false;
+    DeviceColumnView ev = take_column(lv.kids[0], lt.kids[0], false, (const uint32_t*)elem_idx->p, (const uint8_t*)has_elem->p, total, hv_unused, out.owners);
+    const bool nullable = ex.explode_outer || ehv;
+    if (nullable) ev.valid = pack(elem_ok);
+    out.cols.push_back(ev);
+    out.types.push_back(lt.kids[0]);
+    out.has_valid.push_back(nullable);
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));      // counts / tiles / index buffers may go back to their pools; `in` may be released by the caller
+  out.owners.push_back(out_offs);
+  for (auto& o : carried.owners) out.owners.push_back(o);
+  return out;
+}
+
 // Sort (planner.rs:1488-1522 → SortExec with fetch / skip): order-preserving key bytes per row (generated kernel), LSD radix
 // sort of a row permutation over the byte planes that actually vary, then one take per column of rows [skip, skip+fetch).
 // order-preserving key bytes of every row of `in` under sop.sort_orders, as W byte planes of n rows (plane p of row i at p·n + i)

@@ -109,6 +109,13 @@ __global__ __launch_bounds__(256) void pq_list_assemble_kernel(const u8* __restr
   }
 }
 
+// list leaf whose elements are not fixed-width (strings, booleans): the entry of every element slot, so that the element column can be TAKEN
+// out of the leaf's column over entries (exec.cpp take_column) instead of copied value by value
+__global__ __launch_bounds__(256) void pq_list_elem_entries_kernel(const u8* __restrict__ def, i64 n, int def_slot, const i32* __restrict__ elem_idx, u32* __restrict__ entries) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256)
+    if (def[i] >= (u8)def_slot) entries[elem_idx[i]] = (u32)i;
+}
+
 // 1b. run headers of index sections the device inflated (device/pq_runs.hpp): one lane per page.  Pass 1 counts a page's runs, a prefix sum
 // places them, pass 2 walks again and writes the PqRun entries behind the column's host-parsed runs and the page's (first, count).
 // A malformed section leaves (page job << 8 | 0xE0 + status) in *err, like the decompression kernels.
@@ -830,6 +837,9 @@ void pq_launch_list_assemble(const uint8_t* def, const uint8_t* rep, int64_t n, 
                              const uint8_t* values, int width, int32_t* offsets, uint8_t* list_valid, uint8_t* elem_valid, uint8_t* elem_values, uint32_t* err, void* st) {
   hipLaunchKernelGGL(pq_list_assemble_kernel, grid_rows(n + 1), 256, 0, (hipStream_t)st, (const u8*)def, (const u8*)rep, (i64)n, (i64)rows, def_list, def_slot, max_def, (const i32*)start_idx,
                      (const i32*)elem_idx, (const u8*)values, width, (i32*)offsets, (u8*)list_valid, (u8*)elem_valid, (u8*)elem_values, (u32*)err);
+}
+void pq_launch_list_elem_entries(const uint8_t* def, int64_t n, int def_slot, const int32_t* elem_idx, uint32_t* entries, void* st) {
+  if (n > 0) hipLaunchKernelGGL(pq_list_elem_entries_kernel, grid_rows(n), 256, 0, (hipStream_t)st, (const u8*)def, (i64)n, def_slot, (const i32*)elem_idx, (u32*)entries);
 }
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st) {
   hipStream_t s = (hipStream_t)st;

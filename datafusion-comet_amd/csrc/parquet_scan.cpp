@@ -47,6 +47,7 @@ void pq_launch_validity(const PqDecodeArgs* a, void* st);
 void pq_launch_vidx(const uint8_t* valid, int64_t n, uint64_t* tiles, uint32_t* vidx, void* st);
 void pq_launch_levels(const PqDecodeArgs* a, int which, uint8_t* out, void* st);
 void pq_launch_level_ge(const uint8_t* lv, int64_t n, int thr, uint8_t* out, void* st);
+void pq_launch_list_elem_entries(const uint8_t* def, int64_t n, int def_slot, const int32_t* elem_idx, uint32_t* entries, void* st);
 void pq_launch_list_flags(const uint8_t* def, const uint8_t* rep, int64_t n, int def_slot, uint32_t* starts, uint32_t* elems, void* st);
 void pq_launch_list_assemble(const uint8_t* def, const uint8_t* rep, int64_t n, int64_t rows, int def_list, int def_slot, int max_def, const int32_t* start_idx, const int32_t* elem_idx,
                              const uint8_t* values, int width, int32_t* offsets, uint8_t* list_valid, uint8_t* elem_valid, uint8_t* elem_values, uint32_t* err, void* st);
@@ -1802,8 +1803,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       tops[t].kind = 2;
       if (f.dtype.kids.size() != 1) throw CometError("Parquet column '" + f.name + "': a list without an element type");
       const DType& el = f.dtype.kids[0];
-      if (el.is_nested() || el.id == TypeId::String || el.id == TypeId::Bytes || el.id == TypeId::Bool)
-        throw CometError("Parquet column '" + f.name + "': lists of " + el.str() + " are not supported by the GPU scan yet (fixed-width elements are)");
+      if (el.is_nested()) throw CometError("Parquet column '" + f.name + "': lists of " + el.str() + " are not supported by the GPU scan yet (lists of flat types are)");
       StructField lf;
       lf.name = "element";
       lf.dtype = el;
@@ -2869,8 +2869,10 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
     } else {
       const ColumnPlan& cp = plans[l0];
       const int64_t n = ent_total[l0];
-      const int w = cp.out_width;
-      if (!leaf_raw_values[l0] || !leaf_def[l0] || !leaf_rep[l0]) throw CometError("internal: list column without its leaf's levels");
+      const TypeId eid = lf_out.types[l0].id;
+      const bool by_take = eid == TypeId::String || eid == TypeId::Bytes || eid == TypeId::Bool;      // elements that are not one fixed-width value each
+      const int w = by_take ? 0 : cp.out_width;
+      if ((!by_take && !leaf_raw_values[l0]) || !leaf_def[l0] || !leaf_rep[l0]) throw CometError("internal: list column without its leaf's levels");
       auto starts = std::make_shared<DevBuf>(), elems = std::make_shared<DevBuf>(), start_idx = std::make_shared<DevBuf>(), elem_idx = std::make_shared<DevBuf>();
       auto offsets = std::make_shared<DevBuf>(), lvb = std::make_shared<DevBuf>(), lbm = std::make_shared<DevBuf>(), evb = std::make_shared<DevBuf>(), ebm = std::make_shared<DevBuf>(),
            evals = std::make_shared<DevBuf>();
@@ -2891,16 +2893,34 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       pq_launch_u32_scan((const uint32_t*)starts->p, n, (uint64_t*)tiles->p, (int32_t*)start_idx->p, stream_);
       pq_launch_u32_scan((const uint32_t*)elems->p, n, (uint64_t*)tiles->p, (int32_t*)elem_idx->p, stream_);
       pq_launch_list_assemble(defp, repp, n, total_rows, cp.def_parent, cp.def_slot, cp.max_def, (const int32_t*)start_idx->p, (const int32_t*)elem_idx->p,
-                              (const uint8_t*)leaf_raw_values[l0]->p, w, (int32_t*)offsets->p, (uint8_t*)lvb->p, (uint8_t*)evb->p, (uint8_t*)evals->p, (uint32_t*)inflate_err->p + l0, stream_);
+                              by_take ? nullptr : (const uint8_t*)leaf_raw_values[l0]->p, w, (int32_t*)offsets->p, (uint8_t*)lvb->p, (uint8_t*)evb->p, (uint8_t*)evals->p,
+                              (uint32_t*)inflate_err->p + l0, stream_);
       pq_launch_pack((const uint8_t*)lvb->p, (uint8_t*)lbm->p, total_rows, stream_);
-      pq_launch_pack((const uint8_t*)evb->p, (uint8_t*)ebm->p, n, stream_);
       DeviceColumnView ev;
-      ev.data = evals->p;
-      ev.valid = (const uint8_t*)ebm->p;
       nv.data = offsets->p;
-      nv.kids.push_back(ev);
-      nv.kid_has_valid.push_back(cp.max_def > cp.def_slot ? 1 : 0);       // (elements can be NULL only if the element field is optional)
-      nv.kid_rows = n;                                                    // room for; offsets[rows] says how many there are
+      if (by_take) {
+        // strings / booleans: the leaf's column over ENTRIES is a column like any other (offsets + bytes, or bits, + validity); the elements
+        // are its entries that hold a slot, taken in order (one small read tells how many there are)
+        auto entries = std::make_shared<DevBuf>();
+        entries->ensure((size_t)n * 4 + 16);
+        pq_launch_list_elem_entries(defp, n, cp.def_slot, (const int32_t*)elem_idx->p, (uint32_t*)entries->p, stream_);
+        int32_t nel = 0;
+        read_small(&nel, (char*)elem_idx->p + (size_t)n * 4, 4);
+        if (nel < 0 || nel > n) throw CometError("internal: list element count out of range");
+        bool ehv = false;
+        ev = take_column(lf_out.cols[l0], lf_out.types[l0], lf_out.has_valid[l0], (const uint32_t*)entries->p, nullptr, nel, ehv, out.owners);
+        HIP_CHECK(hipStreamSynchronize(stream_));      // (`entries` may go back to its pool)
+        nv.kids.push_back(ev);
+        nv.kid_has_valid.push_back(ehv ? 1 : 0);
+        nv.kid_rows = nel;
+      } else {
+        pq_launch_pack((const uint8_t*)evb->p, (uint8_t*)ebm->p, n, stream_);
+        ev.data = evals->p;
+        ev.valid = (const uint8_t*)ebm->p;
+        nv.kids.push_back(ev);
+        nv.kid_has_valid.push_back(cp.max_def > cp.def_slot ? 1 : 0);     // (elements can be NULL only if the element field is optional)
+        nv.kid_rows = n;                                                  // room for; offsets[rows] says how many there are
+      }
       if (cp.def_parent > 0) { nv.valid = (const uint8_t*)lbm->p; out.has_valid[t] = true; }
       for (auto& b : {starts, elems, start_idx, elem_idx, offsets, lvb, lbm, evb, ebm, evals}) out.owners.push_back(b);
     }

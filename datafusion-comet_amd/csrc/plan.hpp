@@ -128,7 +128,7 @@ struct AggExpr {
 // Operator.op_struct oneof tags (operator.proto:32-79)
 enum class OpKind : int {
   Scan = 100, Projection = 101, Filter = 102, Sort = 103, HashAgg = 104, Limit = 105, ShuffleWriter = 106, Expand = 107, HashJoin = 109, Window = 110,   // SortMergeJoin (108) decodes to HashJoin + smj
-  NativeScan = 111, Unsupported = -1
+  NativeScan = 111, Explode = 114, Unsupported = -1
 };
 
 enum class AggMode : int { Partial = 0, Final = 1, PartialMerge = 2 };
@@ -226,6 +226,9 @@ struct Operator {
   std::vector<ExprP> window_partition;
   // Expand (operator.proto:738-741): project_list holds num_expr_per_project expressions per projection, back to back
   std::vector<std::vector<ExprP>> expand_projections;
+  // Explode (operator.proto:743-752): the list to explode, explode_outer, posexplode; project_list = the columns carried alongside
+  ExprP explode_child;
+  bool explode_outer = false, explode_position = false;
   // ShuffleScan (operator.proto:134-138) decodes to Scan with this flag: its input is a stream of shuffle blocks
   bool shuffle_scan = false;
   // ShuffleWriter (operator.proto:688-707; Partitioning partitioning.proto:29-66)

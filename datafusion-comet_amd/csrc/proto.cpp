@@ -556,6 +556,17 @@ OperatorP decode_operator_r(Reader r) {
         if (own_child) op->window_child = own_child;
         break;
       }
+      case 114:
+        op->kind = OpKind::Explode;
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 2) op->explode_child = decode_expr(b.sub());
+          else if (f2 == 2 && wt2 == 0) op->explode_outer = b.varint() != 0;
+          else if (f2 == 3 && wt2 == 2) op->project_list.push_back(decode_expr(b.sub()));
+          else if (f2 == 4 && wt2 == 0) op->explode_position = b.varint() != 0;
+          else b.skip(wt2);
+        }
+        break;
       case 107: {
         op->kind = OpKind::Expand;
         std::vector<ExprP> all;

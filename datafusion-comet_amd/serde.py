@@ -498,11 +498,13 @@ class Operator:
     codec: int = 0                              # CompressionCodec: 0 None, 1 Zstd, 2 Lz4, 3 Snappy
     compression_level: int = 1
     bounds: List[list] = field(default_factory=list)          # range partitioning: boundary rows (lists of literal Exprs), ascending
+    outer: bool = False                         # explode: explode_outer
+    position: bool = False                      # explode: posexplode
     projections: List[list] = field(default_factory=list)     # expand: one list of Exprs per projection
     window_fns: List[tuple] = field(default_factory=list)     # window: (function name, argument Exprs, result DataType)
     partition_by: List[Expr] = field(default_factory=list)    # window
 
-    TAGS = dict(shuffle_writer=106, shuffle_scan=116, expand=107, window=110, bnlj=117, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
+    TAGS = dict(shuffle_writer=106, shuffle_scan=116, expand=107, explode=114, window=110, bnlj=117, scan=100, projection=101, filter=102, sort=103, hash_agg=104, limit=105, sort_merge_join=108, hash_join=109, native_scan=111)
 
     def encode(self) -> bytes:
         out = b"".join(_f_msg(1, c.encode()) for c in self.children)
@@ -564,6 +566,10 @@ class Operator:
         elif self.kind == "expand":
             # Expand{project_list=1 (all projections back to back), num_expr_per_project=3} (operator.proto:738-741)
             body = b"".join(_f_msg(1, e.encode()) for proj in self.projections for e in proj) + _f_varint(3, len(self.projections[0]))
+        elif self.kind == "explode":
+            # Explode{child=1, outer=2, project_list=3, position=4} (operator.proto:743-752)
+            body = _f_msg(1, self.exprs[0].encode()) + (_f_varint(2, 1) if self.outer else b"") + b"".join(_f_msg(3, e.encode()) for e in self.exprs[1:])
+            body += _f_varint(4, 1) if self.position else b""
         elif self.kind == "shuffle_scan":
             # ShuffleScan{fields=1, source=2} (operator.proto:134-138)
             body = b"".join(_f_msg(1, f.encode()) for f in self.fields) + _f_bytes(2, b"CometShuffleExchangeExec [id=test]")
@@ -683,6 +689,11 @@ def scan(fields: Sequence[DataType]) -> Operator:
 def expand(child: Operator, projections: Sequence[Sequence[Expr]]) -> Operator:
     """One output row per input row and projection (grouping sets / rollup / cube)."""
     return Operator("expand", [child], projections=[list(p) for p in projections])
+
+
+def explode(child: Operator, array: Expr, project_list: Sequence[Expr] = (), outer: bool = False, position: bool = False) -> Operator:
+    """explode / posexplode [_outer]: output = project_list ++ [pos] ++ [element], one row per element of `array`."""
+    return Operator("explode", [child], exprs=[array] + list(project_list), outer=outer, position=position)
 
 
 def window(child: Operator, partition_by: Sequence[Expr], order_by: Sequence, fns: Sequence[tuple]) -> Operator:

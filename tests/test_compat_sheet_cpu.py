@@ -46,14 +46,19 @@ def test_refusals_below_the_class_level_and_unsupported_operators(built):
     assert ok
     ok, msg = native.check_plan(C.probe_plan(S.cast(S.cast(S.col(2, S.T_DOUBLE), S.T_TIMESTAMP), S.T_DOUBLE)).encode())
     assert not ok and "Cast" in msg
-    # an operator the engine does not run (Explode = 114) is refused by name
-    explode = S.Operator.__new__(S.Operator)
+    # an operator the engine does not run (ParquetWriter = 113) is refused by name; Explode (114) runs since round 5 — over a list COLUMN:
+    # without its child expression, and over a column that is not a list, it is refused with the reason
     plan = S.project(S.scan([S.T_INT32]), [S.col(0, S.T_INT32)]).encode()
-    bogus = S._f_msg(1, plan) + S._f_msg(114, b"")
-    ok, msg = native.check_plan(bogus)
+    ok, msg = native.check_plan(S._f_msg(1, plan) + S._f_msg(113, b""))
+    assert not ok and "ParquetWriter" in msg
+    ok, msg = native.check_plan(S._f_msg(1, plan) + S._f_msg(114, b""))
     assert not ok and "Explode" in msg
+    ok, msg = native.check_plan(S.explode(S.scan([S.T_INT32]), S.col(0, S.T_INT32)).encode())
+    assert not ok and "not a list" in msg
+    ok, _ = native.check_plan(S.explode(S.scan([S.T_INT32, S.list_type(S.T_STRING)]), S.col(1, S.list_type(S.T_STRING)), [S.col(0, S.T_INT32)], outer=True, position=True).encode())
+    assert ok
     text = C.render()
-    assert "--conf spark.comet.exec.explode.enabled=false" in text and "--conf spark.comet.exec.sample.enabled=false" in text
+    assert "--conf spark.comet.exec.explode.enabled=false" not in text and "--conf spark.comet.exec.sample.enabled=false" in text
 
 
 def test_the_committed_sheet_is_the_generators_output(built):

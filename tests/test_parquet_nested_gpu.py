@@ -165,11 +165,11 @@ def test_filter_passes_nested_columns_through(built, tmp_path):
 def test_what_the_nested_scan_refuses(built, tmp_path):
     t = pa.table({"m": pa.array([[("a", 1)], None], pa.map_(pa.string(), pa.int32())),
                   "ss": pa.array([{"x": {"y": 1}}, None], pa.struct([("x", pa.struct([("y", pa.int32())]))])),
-                  "ls": pa.array([["a"], None], pa.list_(pa.string()))})
+                  "ls": pa.array([[{"y": 1}], None], pa.list_(pa.struct([("y", pa.int32())])))})
     path = str(tmp_path / "nested_refused.parquet")
     papq.write_table(t, path)
     deep = S.struct_type([("x", S.struct_type([("y", S.T_INT32, True)]), True)])
-    for names, types, msg in ((["ss"], [deep], "deeper than one level"), (["ls"], [S.list_type(S.T_STRING)], "lists of Utf8"),
+    for names, types, msg in ((["ss"], [deep], "deeper than one level"), (["ls"], [S.list_type(S.struct_type([("y", S.T_INT32, True)]))], "lists of Struct"),
                               (["ss"], [S.T_INT32], "is a group")):
         with pytest.raises((native.CometNativeException, native.CometQueryExecutionException), match=msg):
             _run(S.native_scan([path], names, types), len(names))
@@ -280,3 +280,100 @@ def test_nested_columns_round_trip_through_shuffle_files(built, tmp_path):
     assert len(rows) == want.num_rows
     for i in range(want.num_rows):
         assert rows[wcols[0][i]] == tuple(wcols[j][i] for j in range(1, len(wcols))), i
+
+
+@pytest.mark.parametrize("codec,version", [("snappy", "1.0"), ("zstd", "2.0")])
+def test_lists_of_strings_and_booleans(built, tmp_path, codec, version):
+    """elements that are not one fixed-width value each: the element column is TAKEN out of the leaf's column over entries (offsets + bytes, or
+    bits) by the entries that hold a slot — dictionary-encoded and PLAIN strings, long and empty ones, NULL elements, empty and NULL lists"""
+    rng = np.random.default_rng(49)
+    n = 12_000
+    words = ["", "a", "bb", "a considerably longer string that does not fit any packed form", "日本語", "x" * 300]
+
+    def lst(make, pnull=0.1, pel=0.15):
+        out = []
+        for _ in range(n):
+            if rng.random() < pnull:
+                out.append(None)
+                continue
+            k = int(rng.integers(0, 7)) if rng.random() > 0.03 else 200
+            out.append([None if rng.random() < pel else make() for _ in range(k)])
+        return out
+
+    t = pa.table({
+        "k": pa.array(np.arange(n, dtype=np.int64)),
+        "ls": pa.array(lst(lambda: words[int(rng.integers(0, len(words)))]), pa.list_(pa.string())),                 # few distinct values: dictionary pages
+        "lu": pa.array(lst(lambda: "u%d" % int(rng.integers(0, 10**9))), pa.list_(pa.string())),                      # unique values: falls back to PLAIN
+        "lb": pa.array(lst(lambda: bool(rng.integers(0, 2))), pa.list_(pa.bool_())),
+        "lr": pa.array(lst(lambda: "r%d" % int(rng.integers(0, 50)), pnull=0.0, pel=0.0), pa.list_(pa.field("element", pa.string(), False)), ),
+    })
+    path = str(tmp_path / f"lists_{codec}.parquet")
+    papq.write_table(t, path, compression=codec, data_page_version=version, row_group_size=5_000, data_page_size=16 << 10)
+    _scan_and_compare(path, t)
+    ty = _types(t.schema)
+    plan = S.project(S.filter_(S.native_scan([path], t.schema.names, ty), S.lt(S.col(0, ty[0]), S.lit(3_000, S.T_INT64))), [S.col(1, ty[1]), S.col(3, ty[3])])
+    got = _run(plan, 2)
+    want = papq.read_table(path).slice(0, 3_000)
+    _same(got.column(0), want.column("ls"), "ls")
+    _same(got.column(1), want.column("lb"), "lb")
+
+
+def _explode_ref(rows_k, lists, outer, position):
+    """Spark's explode / posexplode [_outer] restated on Python lists: (carried value, [pos,] element) per element; a NULL or empty list yields
+    nothing — or one row with NULL position and element under *_outer (GenerateExec; the reference: planner.rs:1949-2110 over UnnestExec)"""
+    out = []
+    for k, l in zip(rows_k, lists):
+        if not l:
+            if outer:
+                out.append((k, None, None) if position else (k, None))
+            continue
+        for j, e in enumerate(l):
+            out.append((k, j, e) if position else (k, e))
+    return out
+
+
+@pytest.mark.parametrize("outer", [False, True])
+@pytest.mark.parametrize("position", [False, True])
+def test_explode_of_list_columns(built, tmp_path, outer, position):
+    t = _nested_table(7_000, 50)
+    path = str(tmp_path / "explode.parquet")
+    papq.write_table(t, path, compression="snappy", row_group_size=2_500)
+    ty = _types(t.schema)
+    scan = S.native_scan([path], t.schema.names, ty)
+    want = papq.read_table(path)
+    ks = want.column("k").to_pylist()
+    for col, name in ((2, "li"), (5, "ld")):
+        plan = S.explode(scan, S.col(col, ty[col]), [S.col(0, ty[0])], outer=outer, position=position)
+        got = _run(plan, 3 if position else 2)
+        exp = _explode_ref(ks, want.column(name).to_pylist(), outer, position)
+        rows = list(zip(*[got.column(c).to_pylist() for c in range(got.num_columns)]))
+        assert rows == exp, name
+    # carried: a struct (gathered with its children), one of its fields, a string; Filter + Projection above the Explode
+    s = S.col(1, ty[1])
+    ex = S.explode(scan, S.col(4, ty[4]), [S.col(0, ty[0]), s, S.get_struct_field(s, 1), S.col(6, ty[6])], outer=outer, position=False)
+    plan = S.project(S.filter_(ex, S.lt(S.col(0, S.T_INT64), S.lit(2_000, S.T_INT64))), [S.col(0, S.T_INT64), S.col(1, ty[1]), S.col(2, S.T_STRING), S.col(3, S.T_STRING), S.col(4, S.T_DOUBLE)])
+    got = _run(plan, 5)
+    exp = []
+    for k, sv, tv, l in zip(ks, want.column("s").to_pylist(), want.column("t").to_pylist(), want.column("lf").to_pylist()):
+        if k >= 2_000:
+            continue
+        for e in (l if l else ([None] if outer else [])):
+            exp.append((k, sv, None if sv is None else sv["b"], tv, e))
+    rows = list(zip(*[got.column(c).to_pylist() for c in range(5)]))
+    assert rows == exp
+
+
+def test_explode_of_lists_of_strings_and_structs(built):
+    """element types that are gathered, not copied: strings (Parquet scan) and structs (a host-stream input)"""
+    from tests.test_shuffle_nested_cpu import _batch
+    b = _batch(4_000, 62)
+    t = pa.Table.from_batches([b])
+    ty = _types(t.schema)
+    names = t.schema.names
+    for name in ("ls", "lst"):
+        c = names.index(name)
+        plan = S.explode(S.scan(ty), S.col(c, ty[c]), [S.col(0, ty[0])], outer=True, position=True)
+        got = pa.Table.from_batches(native.execute_to_table([native.HostInput.from_table(t, 700)], 3, plan.encode()))
+        exp = _explode_ref(t.column("k").to_pylist(), t.column(name).to_pylist(), True, True)
+        rows = list(zip(*[got.column(i).to_pylist() for i in range(3)]))
+        assert rows == exp, name

@@ -60,7 +60,7 @@ OPERATORS = [
     ("takeOrderedAndProject", True, "Sort with fetch + Projection"), ("collectLimit", True, "Limit"),
     ("broadcastExchange", True, "JVM-side operator (no native plan node)"), ("coalesce", True, "JVM-side operator (no native plan node)"),
     ("union", True, "JVM-side operator: its children are separate native plans"),
-    ("explode", False, "Explode (nested arrays)"), ("sample", False, "Sample (Spark's XORShift sequence)"), ("localTableScan", False, "off by default in the reference too"),
+    ("explode", True, "Explode: explode / posexplode [_outer] of a list COLUMN (any element type); computed arrays and maps are refused at createPlan"), ("sample", False, "Sample (Spark's XORShift sequence)"), ("localTableScan", False, "off by default in the reference too"),
 ]
 OTHER_KEYS = [
     ("spark.comet.scan.icebergNative.enabled", "false", "IcebergScan is not implemented"),
