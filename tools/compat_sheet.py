@@ -204,7 +204,7 @@ def render() -> str:
     w("  than 4096 rows, lag / lead defaults of Utf8 / Boolean type.")
     w("* Nested types: struct-of-flat and list-of-flat (fixed-width elements) columns are read from Parquet, passed through Filter / Projection / Sort /")
     w("  Limit / ShuffleWriter, taken apart by `GetStructField` and exported; struct / list columns of any depth arrive through Scan / ShuffleScan inputs;")
-    w("  maps, deeper trees and lists of strings / booleans in the Parquet scan, and every expression that computes on a list or builds a struct are refused.")
+    w("  `Explode` of a list column runs; maps, deeper trees in the Parquet scan, and every expression that computes on a list or builds a struct / an array are refused.")
     w("  Parquet: TIMESTAMP(NANOS) / TIME, encrypted files.")
     w("* ShuffleWriter with more than 4096 partitions.")
     w("")
