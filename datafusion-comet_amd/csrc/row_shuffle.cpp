@@ -109,6 +109,12 @@ struct ColumnBuild {
   size_t width = 0;                // bytes per value, 0 for Bool / variable-length
 };
 
+inline bool row_is_null(const uint8_t* row, size_t idx) {
+  uint64_t w;
+  memcpy(&w, row + (idx >> 6) * 8, 8);
+  return (w >> (idx & 63)) & 1;
+}
+
 size_t value_width(const DType& t) {
   switch (t.id) {
     case TypeId::Int8: return 1;
@@ -117,14 +123,160 @@ size_t value_width(const DType& t) {
     case TypeId::Int64: case TypeId::Double: case TypeId::Timestamp: case TypeId::TimestampNtz: return 8;
     case TypeId::Decimal: return 16;
     case TypeId::Bool: case TypeId::String: case TypeId::Bytes: return 0;
-    default: throw CometError("writeSortedFileNative: unsupported column type " + t.str() + " (flat types only)");
+    case TypeId::Struct: case TypeId::List: return 0;      // (nested columns: NestedBuild below)
+    default: throw CometError("writeSortedFileNative: unsupported column type " + t.str());
   }
 }
 
-inline bool row_is_null(const uint8_t* row, size_t idx) {
-  uint64_t w;
-  memcpy(&w, row + (idx >> 6) * 8, 8);
-  return (w >> (idx & 63)) & 1;
+// ---- nested columns: a struct is a nested UnsafeRow (null bitset | 8-byte slots | variable part, offsets from the struct's first byte), a list
+// an UnsafeArrayData (element count | null bitset | elements at their natural width, the region rounded up to 8 | variable part, offsets from
+// the array's first byte) — spark_unsafe/row.rs:140-330 + list.rs / map.rs read these; columnar_to_row.rs:570-830 writes them.  One
+// NestedBuild per column and child column; values are appended row by row.
+struct NestedBuild {
+  DType type;
+  std::vector<uint8_t> validity, values, data;
+  std::vector<NestedBuild> kids;
+  int64_t length = 0, nulls = 0;
+  size_t width = 0;
+};
+void nested_init(NestedBuild& b, const DType& t) {
+  b = NestedBuild();
+  b.type = t;
+  if (t.id == TypeId::Map) throw CometError("writeSortedFileNative: map columns are not supported");
+  b.width = value_width(t);
+  if (t.id == TypeId::String || t.id == TypeId::Bytes || t.id == TypeId::List) b.values.assign(4, 0);      // offsets[0] = 0
+  if (t.id == TypeId::Struct || t.id == TypeId::List) {
+    b.kids.resize(t.kids.size());
+    for (size_t k = 0; k < t.kids.size(); k++) nested_init(b.kids[k], t.kids[k]);
+  }
+}
+void nested_push_validity(NestedBuild& b, bool valid) {
+  const int64_t i = b.length;
+  if ((size_t)((i + 8) / 8) > b.validity.size()) b.validity.resize((size_t)((i + 8) / 8) + 64, 0);
+  if (valid) b.validity[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+  else b.nulls++;
+}
+int32_t nested_last_offset(const NestedBuild& b) {
+  int32_t v;
+  memcpy(&v, b.values.data() + b.values.size() - 4, 4);
+  return v;
+}
+void nested_append_null(NestedBuild& b) {
+  nested_push_validity(b, false);
+  switch (b.type.id) {
+    case TypeId::Struct: for (auto& k : b.kids) nested_append_null(k); break;
+    case TypeId::List: case TypeId::String: case TypeId::Bytes: { const int32_t e = nested_last_offset(b); b.values.insert(b.values.end(), (const uint8_t*)&e, (const uint8_t*)&e + 4); break; }
+    case TypeId::Bool: if ((size_t)((b.length + 8) / 8) > b.values.size()) b.values.resize((size_t)((b.length + 8) / 8) + 64, 0); break;
+    default: b.values.insert(b.values.end(), b.width, 0);
+  }
+  b.length++;
+}
+size_t array_element_size(const DType& t) {      // UnsafeArrayData: primitive elements at their natural width, everything else an 8-byte slot
+  switch (t.id) {
+    case TypeId::Bool: case TypeId::Int8: return 1;
+    case TypeId::Int16: return 2;
+    case TypeId::Int32: case TypeId::Float: case TypeId::Date: return 4;
+    default: return 8;
+  }
+}
+// one non-NULL value: `slot` holds the value itself (a primitive: its low `width` bytes) or (offset << 32) | size of its bytes, the offset counted
+// from `base` (the enclosing row / struct / array), which is `size` bytes long
+void nested_append_value(NestedBuild& b, const uint8_t* base, size_t size, const uint8_t* slot, size_t slot_width, int depth = 0) {
+  if (depth > 16) throw CometError("writeSortedFileNative: types nested deeper than 16 levels");
+  auto var_part = [&](size_t& off, size_t& len) {
+    if (slot_width < 8) throw CometError("writeSortedFileNative: a variable-length value in a slot of fewer than 8 bytes");
+    uint64_t os;
+    memcpy(&os, slot, 8);
+    off = (size_t)(os >> 32);
+    len = (size_t)(os & 0xFFFFFFFFu);
+    if (off + len > size) throw CometError("writeSortedFileNative: variable-length field points outside its row");
+  };
+  nested_push_validity(b, true);
+  switch (b.type.id) {
+    case TypeId::Bool:
+      if ((size_t)((b.length + 8) / 8) > b.values.size()) b.values.resize((size_t)((b.length + 8) / 8) + 64, 0);
+      if (slot[0]) b.values[(size_t)(b.length >> 3)] |= (uint8_t)(1u << (b.length & 7));
+      break;
+    case TypeId::String: case TypeId::Bytes: {
+      size_t off, len;
+      var_part(off, len);
+      const int64_t e = (int64_t)nested_last_offset(b) + (int64_t)len;
+      if (e > INT32_MAX) throw CometError("writeSortedFileNative: more than 2 GiB of string data in one batch");
+      b.data.insert(b.data.end(), base + off, base + off + len);
+      const int32_t e32 = (int32_t)e;
+      b.values.insert(b.values.end(), (const uint8_t*)&e32, (const uint8_t*)&e32 + 4);
+      break;
+    }
+    case TypeId::Decimal: {
+      i128 v;
+      if (b.type.precision <= 18) {
+        if (slot_width < 8) throw CometError("writeSortedFileNative: a decimal in a slot of fewer than 8 bytes");
+        int64_t x;
+        memcpy(&x, slot, 8);
+        v = x;
+      } else {
+        size_t off, len;
+        var_part(off, len);
+        if (len > 16) throw CometError("writeSortedFileNative: bad wide-decimal field");
+        const uint8_t* p = base + off;
+        u128 u = (len && (p[0] & 0x80)) ? ~(u128)0 : 0;
+        for (size_t k = 0; k < len; k++) u = (u << 8) | p[k];
+        v = (i128)u;
+      }
+      b.values.insert(b.values.end(), (const uint8_t*)&v, (const uint8_t*)&v + 16);
+      break;
+    }
+    case TypeId::Struct: {
+      size_t off, len;
+      var_part(off, len);
+      const uint8_t* row = base + off;
+      const size_t nf = b.kids.size(), bitset = ((nf + 63) / 64) * 8;
+      if (bitset + nf * 8 > len) throw CometError("writeSortedFileNative: a nested struct is shorter than its fixed-width region");
+      for (size_t k = 0; k < nf; k++) {
+        if (row_is_null(row, k)) nested_append_null(b.kids[k]);
+        else nested_append_value(b.kids[k], row, len, row + bitset + k * 8, 8, depth + 1);
+      }
+      break;
+    }
+    case TypeId::List: {
+      size_t off, len;
+      var_part(off, len);
+      NestedBuild& el = b.kids.at(0);
+      if (len) {      // (a zero slot: no bytes at all — read as an empty array)
+        const uint8_t* arr = base + off;
+        if (len < 8) throw CometError("writeSortedFileNative: an array shorter than its element count");
+        int64_t n;
+        memcpy(&n, arr, 8);
+        const size_t esize = array_element_size(el.type);
+        if (n < 0 || (uint64_t)n > (uint64_t)len) throw CometError("writeSortedFileNative: bad array element count");
+        const size_t bitset = (((size_t)n + 63) / 64) * 8;
+        if (8 + bitset + (size_t)n * esize > len) throw CometError("writeSortedFileNative: an array is shorter than its elements");
+        const uint8_t* elems = arr + 8 + bitset;
+        for (int64_t j = 0; j < n; j++) {
+          if (row_is_null(arr + 8, (size_t)j)) nested_append_null(el);
+          else nested_append_value(el, arr, len, elems + (size_t)j * esize, esize, depth + 1);
+        }
+      }
+      if (el.length > INT32_MAX) throw CometError("writeSortedFileNative: more than 2^31 list elements in one batch");
+      const int32_t e = (int32_t)el.length;
+      b.values.insert(b.values.end(), (const uint8_t*)&e, (const uint8_t*)&e + 4);
+      break;
+    }
+    default:
+      if (slot_width < b.width) throw CometError("writeSortedFileNative: a value wider than its slot");
+      b.values.insert(b.values.end(), slot, slot + b.width);      // little-endian: the low bytes are the value
+  }
+  b.length++;
+}
+void nested_slice(const NestedBuild& b, ColumnSlice& s) {
+  s = ColumnSlice();
+  s.type = b.type;
+  s.validity = b.nulls ? b.validity.data() : nullptr;
+  s.values = b.values.empty() ? nullptr : b.values.data();
+  s.data = b.data.data();
+  s.first = 0;
+  s.kids.resize(b.kids.size());
+  for (size_t k = 0; k < b.kids.size(); k++) nested_slice(b.kids[k], s.kids[k]);
 }
 
 void append_column(ColumnBuild& c, size_t idx, size_t nfields, const int64_t* addrs, const int32_t* sizes, size_t first, size_t n) {
@@ -210,6 +362,7 @@ SortedFileResult write_sorted_rows(const int64_t* row_addresses, const int32_t* 
   // fresh state: CRC32 / CRC32C start at 0, Adler32 at 1 (checksum.rs:41-68)
   uint32_t sum = has_initial ? initial_checksum : (checksum_algo == 1 ? 1u : 0u);
   std::vector<ColumnBuild> cols(schema.size());
+  std::vector<NestedBuild> nested(schema.size());
   for (size_t i = 0; i < schema.size(); i++) {
     cols[i].type = schema[i];
     cols[i].width = value_width(schema[i]);
@@ -223,6 +376,20 @@ SortedFileResult write_sorted_rows(const int64_t* row_addresses, const int32_t* 
       const size_t n = std::min(batch_size, row_num - at);
       const auto t0 = std::chrono::steady_clock::now();
       for (size_t i = 0; i < cols.size(); i++) {
+        if (schema[i].is_nested()) {
+          // a struct / list column: its slot addresses a nested row / array inside the row; appended value by value
+          nested_init(nested[i], schema[i]);
+          const size_t bitset = ((cols.size() + 63) / 64) * 8, slot_at = bitset + i * 8;
+          for (size_t r = 0; r < n; r++) {
+            const uint8_t* row = (const uint8_t*)(uintptr_t)row_addresses[at + r];
+            const size_t row_size = (size_t)row_sizes[at + r];
+            if (slot_at + 8 > row_size) throw CometError("writeSortedFileNative: row " + std::to_string(at + r) + " is shorter than its fixed-width region");
+            if (row_is_null(row, i)) nested_append_null(nested[i]);
+            else nested_append_value(nested[i], row, row_size, row + slot_at, 8);
+          }
+          nested_slice(nested[i], slices[i]);
+          continue;
+        }
         append_column(cols[i], i, cols.size(), row_addresses, row_sizes, at, n);
         ColumnSlice& s = slices[i];
         s.type = cols[i].type;
