@@ -65,3 +65,31 @@ def test_slices_of_nested_columns(built):
     w.close()
     got = native.decode_shuffle_block(b"NONE" + sink.getvalue(), b.num_columns)
     assert _cols(got) == _cols(s)
+
+
+@pytest.mark.parametrize("codec", [0, 2])
+def test_corrupted_nested_blocks_fail_cleanly(built, codec):
+    """blocks with struct / list columns, overwritten, truncated or extended: an exception or a structurally sound batch — never a crash or a read
+    outside the block (child counts, list offsets against the element column, nesting depth are all checked)"""
+    import random
+    b = _batch(200, 54)
+    blk = native.encode_shuffle_block(b, codec)[16:]
+    rng = random.Random(2000 + codec)
+    outcomes = {"ok": 0, "error": 0}
+    for trial in range(600):
+        bad = bytearray(blk)
+        k = trial % 4
+        if k == 0:
+            bad = bad[: rng.randrange(0, len(bad))]
+        elif k == 1:
+            bad += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 9)))
+        else:
+            lim = len(bad) if k == 2 else min(len(bad), 2500)          # everywhere / concentrated on the frame header and the flatbuffers (schema with children, nodes, buffers)
+            for _ in range(rng.randrange(1, 4)):
+                bad[rng.randrange(0, lim)] = rng.choice([0, 0xFF, 0x80, rng.randrange(256)])
+        try:
+            native.decode_shuffle_block(bytes(bad), b.num_columns).validate(full=True)
+            outcomes["ok"] += 1
+        except (native.CometNativeException, pa.ArrowInvalid):
+            outcomes["error"] += 1
+    assert outcomes["error"] > 0, outcomes
