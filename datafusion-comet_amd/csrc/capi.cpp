@@ -78,7 +78,11 @@ auto guarded(ExecutionContext* ctx, decltype(std::declval<F>()()) err_value, F f
 }  // namespace
 
 
-namespace comet { namespace detail { void plan_execution_begins(); void plan_execution_ends(); int plans_executing(); } }
+namespace comet { namespace detail {
+void plan_execution_begins(); void plan_execution_ends(); int plans_executing();
+bool nested_schema_matches(const ArrowSchema* f, const DType& t);
+void append_nested_rows(HostColumn& dst, const ArrowArray* a, const DType& t, int64_t off, int64_t len);
+} }
 // COMET_TRACE_STAGES: every plan call with its begin on the process clock (the same clock the scan traces use), so that the calls of
 // concurrent tasks can be laid side by side
 struct ApiTrace {
@@ -733,6 +737,42 @@ int32_t comet_encode_shuffle_block(struct ArrowArray** arrays, struct ArrowSchem
       memcpy(*out, bytes.data(), bytes.size());
     }
     return 0;
+  });
+}
+
+int64_t comet_concat_nested_column(struct ArrowArray** arrays, struct ArrowSchema* schema, int32_t n, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    if (!arrays || !schema || !out || !out_schema || n < 0) throw CometError("concatNestedColumn: bad arguments");
+    const DType t = dtype_of_schema(schema);
+    if (!t.is_nested()) throw CometError("concatNestedColumn: " + t.str() + " is not a nested type");
+    if (!comet::detail::nested_schema_matches(schema, t)) throw CometError("concatNestedColumn: the schema does not describe " + t.str());
+    HostColumn h;
+    h.type = t;
+    std::function<void(HostColumn&, const DType&)> shape = [&](HostColumn& x, const DType& tt) {
+      x.type = tt;
+      if (tt.id == TypeId::Struct) { x.children.resize(tt.kids.size()); for (size_t k = 0; k < tt.kids.size(); k++) shape(x.children[k], tt.kids[k]); }
+      else if (tt.id == TypeId::List) { x.children.resize(1); shape(x.children[0], tt.kids.at(0)); }
+    };
+    shape(h, t);
+    for (int32_t i = 0; i < n; i++) comet::detail::append_nested_rows(h, arrays[i], t, 0, arrays[i]->length);
+    // what the upload does: NULLs are counted from the bitmaps (fields were masked after their own counts), all-valid bitmaps are dropped
+    std::function<void(HostColumn&)> finish = [&](HostColumn& x) {
+      int64_t nulls = 0;
+      for (int64_t r = 0; r < x.length && !x.validity.empty(); r++) nulls += !((x.validity[(size_t)(r >> 3)] >> (r & 7)) & 1);
+      x.null_count = nulls;
+      if (!nulls) x.validity.clear();
+      if ((x.type.id == TypeId::List || x.type.id == TypeId::String || x.type.id == TypeId::Bytes) && x.values.empty()) x.values.assign(4, 0);
+      for (auto& k : x.children) finish(k);
+    };
+    finish(h);
+    const int64_t rows = h.length;
+    HostBatch b;
+    b.rows = rows;
+    b.cols.push_back(std::move(h));
+    ArrowArray* oa[1] = {out};
+    ArrowSchema* os[1] = {out_schema};
+    export_host_batch(b, oa, os, 1);
+    return rows;
   });
 }
 

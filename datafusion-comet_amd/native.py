@@ -89,6 +89,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_encode_shuffle_block.restype = c.c_int32
     lib.comet_encode_shuffle_block.argtypes = [c.POINTER(c.c_void_p), c.POINTER(c.c_void_p), c.c_int32, c.c_int32, c.c_int32,
                                                c.POINTER(c.c_void_p), c.POINTER(c.c_int64)]
+    lib.comet_concat_nested_column.restype = c.c_int64
+    lib.comet_concat_nested_column.argtypes = [c.POINTER(c.c_void_p), c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p]
     lib.comet_sort_row_partitions.restype = None
     lib.comet_sort_row_partitions.argtypes = [c.c_void_p, c.c_int64]
     lib.comet_write_sorted_rows.restype = c.c_int32
@@ -536,6 +538,24 @@ def decode_shuffle_block(block: bytes, num_cols: int) -> pa.RecordBatch:
         _raise_last(0)
     cols = [pa.Array._import_from_c(ctypes.addressof(a), ctypes.addressof(s)) for a, s in zip(arrays, schemas)]
     return pa.RecordBatch.from_arrays(cols, names=[f"c{i}" for i in range(len(cols))])
+
+
+def concat_nested_column(chunks: Sequence[pa.Array]) -> pa.Array:
+    """comet_concat_nested_column: what a Scan leaf makes of the batches of one chunk of a struct / list column before uploading it."""
+    l = lib()
+    n = len(chunks)
+    arrays = [ArrowArrayC() for _ in range(n)]
+    schemas = [ArrowSchemaC() for _ in range(n)]
+    for i, ch in enumerate(chunks):
+        ch._export_to_c(ctypes.addressof(arrays[i]), ctypes.addressof(schemas[i]))
+    aaddr = (ctypes.c_void_p * max(n, 1))(*[ctypes.addressof(a) for a in arrays])
+    out_a, out_s = ArrowArrayC(), ArrowSchemaC()
+    rows = l.comet_concat_nested_column(aaddr, ctypes.addressof(schemas[0]), n, ctypes.addressof(out_a), ctypes.addressof(out_s))
+    for a, s in zip(arrays, schemas):
+        pa.Array._import_from_c(ctypes.addressof(a), ctypes.addressof(s))
+    if rows < 0:
+        _raise_last(0)
+    return pa.Array._import_from_c(ctypes.addressof(out_a), ctypes.addressof(out_s))
 
 
 def encode_shuffle_block(batch: pa.RecordBatch, codec: int = 0, level: int = 1) -> bytes:

@@ -303,6 +303,13 @@ const char* comet_exchange_last_error(void);
 int64_t comet_decode_shuffle_block(const uint8_t* block, int64_t len, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas,
                                    int32_t n_out);
 
+/* What a Scan / ShuffleScan leaf does with the batches of one chunk of a NESTED input column before it uploads them (csrc/exec_util.cpp
+ * append_nested_rows; the reference's ScanExec takes the batches as they come, operators/scan.rs:134-164, and DataFusion's kernels honour
+ * a struct's validity themselves): `n` Arrow arrays of one struct / list column (any depth; offsets and slices as the producer left them) are
+ * concatenated into ONE host column — list offsets rebased, children appended, every field's validity masked by its struct's — which is moved
+ * into *out / *out_schema.  Host-side only; the test entry of that step.  Returns the rows, or -2 on error. */
+int64_t comet_concat_nested_column(struct ArrowArray** arrays, struct ArrowSchema* schema, int32_t n, struct ArrowArray* out, struct ArrowSchema* out_schema);
+
 /* The framing step of the shuffle writer on its own (ShuffleBlockWriter::write_batch, native/shuffle/src/writers/
  * shuffle_block_writer.rs:179-238): encodes the host-resident columns (Arrow C Data, one array + schema per column, any offset) as ONE
  * complete block — u64le length, u64le field count, codec tag, Arrow IPC stream under `codec` (0 none, 1 zstd, 2 lz4 frame,

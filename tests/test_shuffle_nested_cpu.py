@@ -93,3 +93,26 @@ def test_corrupted_nested_blocks_fail_cleanly(built, codec):
         except (native.CometNativeException, pa.ArrowInvalid):
             outcomes["error"] += 1
     assert outcomes["error"] > 0, outcomes
+
+
+def test_nested_input_batches_are_concatenated_like_pyarrow_does(built):
+    """the host step of a Scan / ShuffleScan leaf over nested columns (comet_concat_nested_column = exec_util.cpp append_nested_rows): batches and
+    SLICES of batches of struct / list columns become one column equal to pyarrow's own concatenation; a field under a NULL struct comes out
+    NULL whatever the producer left in its slot (pyarrow leaves a valid zero)"""
+    b = _batch(2_500, 55)
+    for name in ("s", "li", "ld", "ls", "lst"):
+        col = b.column(b.schema.get_field_index(name))
+        parts = [col.slice(0, 700), col.slice(700, 1), col.slice(701, 0), col.slice(701, 1299), col.slice(2000, 500)]
+        got = native.concat_nested_column(parts)
+        got.validate(full=True)
+        assert got.to_pylist() == col.to_pylist(), name
+    s = b.column(b.schema.get_field_index("s"))
+    got = native.concat_nested_column([s.slice(3, 1000), s.slice(1003, 500)])
+    want = s.slice(3, 1500)
+    nulls = [i for i, v in enumerate(want.to_pylist()) if v is None]
+    assert len(nulls) > 50
+    for f in range(got.type.num_fields):
+        kid = got.field(f)
+        assert all(not kid[i].is_valid for i in nulls), got.type.field(f).name      # masked by the struct's validity
+    with pytest.raises(native.CometNativeException, match="not a nested type"):
+        native.concat_nested_column([pa.array([1, 2, 3])])
