@@ -41,6 +41,7 @@ hipStream_t shared_copy_stream(int dev);
 #include "parquet_meta.hpp"
 
 extern "C" int comet_launch_fill(int width, void* dst, int64_t n, const void* value, void* stream);
+extern "C" int comet_launch_take(int width, const void* src, const uint32_t* idx, int64_t n, void* dst, void* stream);
 extern "C" int comet_launch_fill_utf8(int32_t* offsets, uint8_t* bytes, int64_t n, int32_t base, int32_t len, const uint8_t* dev_value, void* stream);
 extern "C" {
 void pq_launch_validity(const PqDecodeArgs* a, void* st);
@@ -329,6 +330,7 @@ struct ColumnPlan {
   // struct's field: def_parent = the level from which the struct itself is defined (0: a required struct).  A list's element: def_parent = the
   // level from which the list is defined (not NULL), def_slot = the level from which an entry holds an element slot (below: an empty or NULL list)
   int max_def = 0, max_rep = 0, def_parent = 0, def_slot = 0;
+  int def_elem = 0;       // a list of structs: the level from which the element STRUCT is defined (= def_slot when it cannot be NULL)
   bool nested_leaf() const { return max_def > 1 || max_rep > 0; }
 };
 
@@ -472,7 +474,27 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, const Sc
     const pq::SchemaElement& ge = fm.schema[(size_t)g];
     if (ge.num_children == 0) throw CometError("Parquet column '" + want.parent + "' is a primitive in the file but is read as a nested column");
     if (ge.repetition == 2) throw CometError("Parquet column '" + want.parent + "': repeated groups outside a LIST annotation are not supported by the GPU scan yet");
-    if (want.nest == 1) {
+    if (want.nest == 3) {
+      // a list of structs: <rep> group <name> (LIST) { repeated group list { <rep> group element { fields } } } — or the legacy shape whose
+      // repeated group IS the struct (several fields, or one field that is not named like an element wrapper)
+      if (tree[(size_t)g].kids.size() != 1) throw CometError("Parquet column '" + want.parent + "': not a LIST group of one repeated field");
+      const int rp = tree[(size_t)g].kids[0];
+      const pq::SchemaElement& re = fm.schema[(size_t)rp];
+      if (re.repetition != 2 || re.num_children == 0) throw CometError("Parquet column '" + want.parent + "': not a list of structs in this file");
+      int es = rp;
+      if (tree[(size_t)rp].kids.size() == 1) {
+        const int only = tree[(size_t)rp].kids[0];
+        const pq::SchemaElement& oe = fm.schema[(size_t)only];
+        if (oe.num_children > 0 && oe.repetition != 2 && oe.converted_type != 3 && oe.converted_type != 1) es = only;      // the element wrapper
+      }
+      at = child_of(es, want.name, want.field_id);
+      if (at < 0) throw CometError("Parquet column '" + want.parent + "': field '" + want.name + "' of its struct elements is not in the file (not supported by the GPU scan yet)");
+      if (fm.schema[(size_t)at].num_children > 0 || fm.schema[(size_t)at].repetition == 2)
+        throw CometError("Parquet column '" + want.parent + "." + want.name + "': nesting deeper than a list of flat structs is not supported by the GPU scan yet");
+      cp.def_parent = tree[(size_t)g].def;
+      cp.def_slot = tree[(size_t)rp].def;
+      cp.def_elem = tree[(size_t)es].def;
+    } else if (want.nest == 1) {
       if (ge.converted_type == 3 || ge.converted_type == 1 || ge.converted_type == 2)      // LIST, MAP, MAP_KEY_VALUE
         throw CometError("Parquet column '" + want.parent + "' is a list / map in the file but is read as a struct");
       at = child_of(g, want.name, want.field_id);
@@ -495,6 +517,7 @@ ColumnPlan plan_column(const StructField& want, const pq::FileMeta& fm, const Sc
       cp.def_slot = tree[(size_t)rp].def;
     }
   }
+
   if (at >= 0) {
     cp.leaf = tree[(size_t)at].leaf;
     cp.el = fm.schema[(size_t)at];
@@ -1803,7 +1826,24 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       tops[t].kind = 2;
       if (f.dtype.kids.size() != 1) throw CometError("Parquet column '" + f.name + "': a list without an element type");
       const DType& el = f.dtype.kids[0];
-      if (el.is_nested()) throw CometError("Parquet column '" + f.name + "': lists of " + el.str() + " are not supported by the GPU scan yet (lists of flat types are)");
+      if (el.id == TypeId::Struct && !el.kids.empty()) {
+        // a list of structs: one leaf per field of the element struct, all under the same repeated group (the same repetition levels)
+        tops[t].kind = 3;
+        for (size_t k = 0; k < el.kids.size(); k++) {
+          if (el.kids[k].is_nested()) throw CometError("Parquet column '" + f.name + "': nesting deeper than a list of flat structs is not supported by the GPU scan yet");
+          StructField lf;
+          lf.name = k < el.kid_names.size() ? el.kid_names[k] : std::string();
+          lf.dtype = el.kids[k];
+          lf.nest = 3;
+          lf.parent = f.name;
+          lf.parent_field_id = f.field_id;
+          fields.push_back(lf);
+          top_of.push_back((int)t);
+        }
+        tops[t].count = fields.size() - tops[t].first;
+        continue;
+      }
+      if (el.is_nested()) throw CometError("Parquet column '" + f.name + "': lists of " + el.str() + " are not supported by the GPU scan yet (lists of flat types and of flat structs are)");
       StructField lf;
       lf.name = "element";
       lf.dtype = el;
@@ -2409,7 +2449,7 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       if (any_optional) pq_launch_levels(&a, 0, (uint8_t*)leaf_def[c]->p, stream_);
       else HIP_CHECK(hipMemsetAsync(leaf_def[c]->p, cp.max_def, (size_t)nrows + 16, stream_));      // a chunk without level runs: everything defined
       out.owners.push_back(leaf_def[c]);
-      if (fields[c].nest == 2) {
+      if (fields[c].nest >= 2) {
         leaf_rep[c] = std::make_shared<DevBuf>();
         leaf_rep[c]->ensure((size_t)nrows + 16);
         PqDecodeArgs ar = a;
@@ -2848,6 +2888,66 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
       continue;
     }
     DeviceColumnView nv;
+    if (tc.kind == 3) {
+      // A list of structs: its fields' leaves sit under ONE repeated group — the same repetition levels, the same element slots.  The first
+      // leaf's levels give the rows' offsets and validity and the entry of every slot; every field is then TAKEN out of its leaf's column over
+      // entries by those (exec.cpp take_column: any flat type), the element struct's validity is one more level comparison taken the same way.
+      const ColumnPlan& cp = plans[l0];
+      const int64_t n = ent_total[l0];
+      for (size_t l = l0; l < l0 + tc.count; l++)
+        if (ent_total[l] != n || !leaf_def[l] || !leaf_rep[l]) throw CometError("Parquet column '" + fields[l0].parent + "': the fields of its struct elements differ in their level entries");
+      auto starts = std::make_shared<DevBuf>(), elems = std::make_shared<DevBuf>(), start_idx = std::make_shared<DevBuf>(), elem_idx = std::make_shared<DevBuf>();
+      auto offsets = std::make_shared<DevBuf>(), lvb = std::make_shared<DevBuf>(), lbm = std::make_shared<DevBuf>(), evb = std::make_shared<DevBuf>(), entries = std::make_shared<DevBuf>();
+      starts->ensure((size_t)n * 4 + 16);
+      elems->ensure((size_t)n * 4 + 16);
+      start_idx->ensure((size_t)(n + 1) * 4 + 16);
+      elem_idx->ensure((size_t)(n + 1) * 4 + 16);
+      offsets->ensure((size_t)(total_rows + 1) * 4 + 16);
+      lvb->ensure((size_t)total_rows + 16);
+      lbm->ensure((size_t)((total_rows + 7) / 8) + 16);
+      evb->ensure((size_t)n + 16);
+      entries->ensure((size_t)n * 4 + 16);
+      const uint8_t* defp = (const uint8_t*)leaf_def[l0]->p;
+      const uint8_t* repp = (const uint8_t*)leaf_rep[l0]->p;
+      pq_launch_list_flags(defp, repp, n, cp.def_slot, (uint32_t*)starts->p, (uint32_t*)elems->p, stream_);
+      pq_launch_u32_scan((const uint32_t*)starts->p, n, (uint64_t*)tiles->p, (int32_t*)start_idx->p, stream_);
+      pq_launch_u32_scan((const uint32_t*)elems->p, n, (uint64_t*)tiles->p, (int32_t*)elem_idx->p, stream_);
+      pq_launch_list_assemble(defp, repp, n, total_rows, cp.def_parent, cp.def_slot, cp.max_def, (const int32_t*)start_idx->p, (const int32_t*)elem_idx->p, nullptr, 0,
+                              (int32_t*)offsets->p, (uint8_t*)lvb->p, (uint8_t*)evb->p, nullptr, (uint32_t*)inflate_err->p + l0, stream_);
+      pq_launch_pack((const uint8_t*)lvb->p, (uint8_t*)lbm->p, total_rows, stream_);
+      pq_launch_list_elem_entries(defp, n, cp.def_slot, (const int32_t*)elem_idx->p, (uint32_t*)entries->p, stream_);
+      int32_t nel = 0;
+      read_small(&nel, (char*)elem_idx->p + (size_t)n * 4, 4);
+      if (nel < 0 || nel > n) throw CometError("internal: list element count out of range");
+      DeviceColumnView sv;      // the element struct
+      for (size_t l = l0; l < l0 + tc.count; l++) {
+        bool khv = false;
+        sv.kids.push_back(take_column(lf_out.cols[l], lf_out.types[l], lf_out.has_valid[l], (const uint32_t*)entries->p, nullptr, nel, khv, out.owners));
+        sv.kid_has_valid.push_back(khv ? 1 : 0);
+      }
+      sv.kid_rows = nel;
+      const bool elem_nullable = cp.def_elem > cp.def_slot;
+      if (elem_nullable) {      // an optional element struct: NULL where the definition level stops short of it
+        auto sb = std::make_shared<DevBuf>(), st = std::make_shared<DevBuf>(), sbm = std::make_shared<DevBuf>();
+        sb->ensure((size_t)n + 16);
+        st->ensure((size_t)std::max(nel, 1) + 16);
+        sbm->ensure((size_t)((nel + 7) / 8) + 16);
+        pq_launch_level_ge(defp, n, cp.def_elem, (uint8_t*)sb->p, stream_);
+        if (nel > 0 && comet_launch_take(1, sb->p, (const uint32_t*)entries->p, nel, st->p, stream_) != 0) throw CometError("parquet: launch failed");
+        if (nel > 0) pq_launch_pack((const uint8_t*)st->p, (uint8_t*)sbm->p, nel, stream_);
+        sv.valid = (const uint8_t*)sbm->p;
+        for (auto& b : {sb, st, sbm}) out.owners.push_back(b);
+      }
+      HIP_CHECK(hipStreamSynchronize(stream_));      // (`entries` and the scratch arrays may go back to their pools)
+      nv.data = offsets->p;
+      nv.kids.push_back(sv);
+      nv.kid_has_valid.push_back(elem_nullable ? 1 : 0);
+      nv.kid_rows = nel;
+      if (cp.def_parent > 0) { nv.valid = (const uint8_t*)lbm->p; out.has_valid[t] = true; }
+      for (auto& b : {offsets, lbm}) out.owners.push_back(b);
+      out.cols[t] = nv;
+      continue;
+    }
     if (tc.kind == 1) {
       for (size_t l = l0; l < l0 + tc.count; l++) {
         nv.kids.push_back(lf_out.cols[l]);

@@ -141,7 +141,7 @@ struct StructField {  // SparkStructField (operator.proto:117-124)
   bool nullable = true;
   int field_id = -1;   // metadata["PARQUET:field_id"] (CometParquetUtils.PARQUET_FIELD_ID_META_KEY), -1 = none
   // the Parquet scan's own use: a LEAF of a nested column it reads — nest 1: field `name` of the struct column `parent`; 2: the element of
-  // the list column `parent` (0: a top-level column)
+  // the list column `parent`; 3: field `name` of the struct elements of the list column `parent` (0: a top-level column)
   int nest = 0;
   std::string parent;
   int parent_field_id = -1;

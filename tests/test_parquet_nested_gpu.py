@@ -165,11 +165,11 @@ def test_filter_passes_nested_columns_through(built, tmp_path):
 def test_what_the_nested_scan_refuses(built, tmp_path):
     t = pa.table({"m": pa.array([[("a", 1)], None], pa.map_(pa.string(), pa.int32())),
                   "ss": pa.array([{"x": {"y": 1}}, None], pa.struct([("x", pa.struct([("y", pa.int32())]))])),
-                  "ls": pa.array([[{"y": 1}], None], pa.list_(pa.struct([("y", pa.int32())])))})
+                  "ls": pa.array([[[1]], None], pa.list_(pa.list_(pa.int32())))})
     path = str(tmp_path / "nested_refused.parquet")
     papq.write_table(t, path)
     deep = S.struct_type([("x", S.struct_type([("y", S.T_INT32, True)]), True)])
-    for names, types, msg in ((["ss"], [deep], "deeper than one level"), (["ls"], [S.list_type(S.struct_type([("y", S.T_INT32, True)]))], "lists of Struct"),
+    for names, types, msg in ((["ss"], [deep], "deeper than one level"), (["ls"], [S.list_type(S.list_type(S.T_INT32))], "lists of List"),
                               (["ss"], [S.T_INT32], "is a group")):
         with pytest.raises((native.CometNativeException, native.CometQueryExecutionException), match=msg):
             _run(S.native_scan([path], names, types), len(names))
@@ -377,3 +377,40 @@ def test_explode_of_lists_of_strings_and_structs(built):
         exp = _explode_ref(t.column("k").to_pylist(), t.column(name).to_pylist(), True, True)
         rows = list(zip(*[got.column(i).to_pylist() for i in range(3)]))
         assert rows == exp, name
+
+
+@pytest.mark.parametrize("codec,version,nullable", [("snappy", "1.0", True), ("zstd", "2.0", True), ("none", "1.0", False)])
+def test_lists_of_structs_out_of_parquet(built, tmp_path, codec, version, nullable):
+    """array<struct<…>>: the fields' leaves share one repeated group; offsets / list validity / the element struct's validity come from the first
+    leaf's levels, every field is taken out of its leaf by the slots' entries.  NULL lists, empty lists, NULL element structs, NULL fields,
+    strings and decimals among the fields, lists that cross pages; then Explode and a Filter above it"""
+    rng = np.random.default_rng(63)
+    n = 9_000
+    ft = pa.struct([pa.field("x", pa.int64(), nullable), pa.field("y", pa.string(), nullable), pa.field("z", pa.decimal128(10, 2), nullable), pa.field("w", pa.bool_(), nullable)])
+    lt = pa.list_(pa.field("element", ft, nullable))
+
+    def maybe(p, f):
+        return f() if (not nullable or rng.random() >= p) else None
+
+    def elem():
+        return {"x": maybe(0.1, lambda: int(rng.integers(-10**9, 10**9))), "y": maybe(0.15, lambda: "y%d" % int(rng.integers(0, 40)) if rng.random() < 0.8 else "a longer value of y %d" % int(rng.integers(0, 10**6))),
+                "z": maybe(0.1, lambda: Decimal(int(rng.integers(-10**7, 10**7))).scaleb(-2)), "w": maybe(0.1, lambda: bool(rng.integers(0, 2)))}
+
+    lists = []
+    for _ in range(n):
+        k = int(rng.integers(0, 6)) if rng.random() > 0.02 else 150
+        lists.append(maybe(0.1, lambda: [maybe(0.12, elem) for _ in range(k)]))
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64)), "ls": pa.array(lists, lt), "v": pa.array(rng.integers(0, 100, n).astype(np.int32))},
+                 schema=pa.schema([pa.field("k", pa.int64(), False), pa.field("ls", lt, nullable), pa.field("v", pa.int32(), False)]))
+    path = str(tmp_path / f"list_struct_{codec}.parquet")
+    papq.write_table(t, path, compression=codec, data_page_version=version, row_group_size=4_000, data_page_size=16 << 10)
+    _scan_and_compare(path, t)
+    ty = _types(t.schema)
+    scan = S.native_scan([path], t.schema.names, ty)
+    want = papq.read_table(path)
+    ex = S.explode(S.filter_(scan, S.lt(S.col(2, ty[2]), S.lit(50, S.T_INT32))), S.col(1, ty[1]), [S.col(0, ty[0])], outer=True, position=True)
+    got = _run(ex, 3)
+    keep = [i for i, v in enumerate(want.column("v").to_pylist()) if v < 50]
+    exp = _explode_ref([want.column("k")[i].as_py() for i in keep], [want.column("ls")[i].as_py() for i in keep], True, True)
+    rows = list(zip(*[got.column(c).to_pylist() for c in range(3)]))
+    assert rows == exp
