@@ -682,13 +682,17 @@ DType dtype_from_format(const char* f) {
 // array produces)
 DType dtype_of_schema(const ArrowSchema* s) {
   const std::string f = s->format ? s->format : "";
-  if (f != "+s" && f != "+l") return dtype_from_format(s->format);
-  DType t = DType::of(f == "+s" ? TypeId::Struct : TypeId::List);
-  if (f == "+l" && s->n_children != 1) throw CometError("encodeShuffleBlock: a list schema with " + std::to_string(s->n_children) + " children");
+  if (f != "+s" && f != "+l" && f != "+m") return dtype_from_format(s->format);
+  DType t = DType::of(f == "+s" ? TypeId::Struct : f == "+l" ? TypeId::List : TypeId::Map);
+  if (f != "+s" && s->n_children != 1) throw CometError("encodeShuffleBlock: a list / map schema with " + std::to_string(s->n_children) + " children");
   for (int64_t k = 0; k < s->n_children; k++) {
     t.kids.push_back(dtype_of_schema(s->children[k]));
-    t.kid_names.push_back(f == "+l" ? std::string("element") : std::string(s->children[k]->name ? s->children[k]->name : ""));
+    t.kid_names.push_back(f == "+l" ? std::string("element") : f == "+m" ? std::string("entries") : std::string(s->children[k]->name ? s->children[k]->name : ""));
     t.kid_nullable.push_back((s->children[k]->flags & ARROW_FLAG_NULLABLE) ? 1 : 0);
+  }
+  if (f == "+m") {      // (whatever the producer called them: the entries' two fields are the key and the value)
+    if (t.kids[0].id != TypeId::Struct || t.kids[0].kids.size() != 2) throw CometError("encodeShuffleBlock: a map whose entries are not (key, value) structs");
+    t.kids[0].kid_names = {"key", "value"};
   }
   return t;
 }
@@ -705,7 +709,7 @@ void slice_of_array(const ArrowArray* a, const ArrowSchema* s, bool top, ColumnS
     return;
   }
   c.values = a->n_buffers > 1 ? a->buffers[1] : nullptr;
-  if (c.type.id == TypeId::List) {
+  if (c.type.is_listlike()) {
     if (a->n_children != 1) throw CometError("encodeShuffleBlock: list array without its elements");
     c.kids.resize(1);
     slice_of_array(a->children[0], s->children[0], false, c.kids[0]);
@@ -751,7 +755,7 @@ int64_t comet_concat_nested_column(struct ArrowArray** arrays, struct ArrowSchem
     std::function<void(HostColumn&, const DType&)> shape = [&](HostColumn& x, const DType& tt) {
       x.type = tt;
       if (tt.id == TypeId::Struct) { x.children.resize(tt.kids.size()); for (size_t k = 0; k < tt.kids.size(); k++) shape(x.children[k], tt.kids[k]); }
-      else if (tt.id == TypeId::List) { x.children.resize(1); shape(x.children[0], tt.kids.at(0)); }
+      else if (tt.is_listlike()) { x.children.resize(1); shape(x.children[0], tt.kids.at(0)); }
     };
     shape(h, t);
     for (int32_t i = 0; i < n; i++) comet::detail::append_nested_rows(h, arrays[i], t, 0, arrays[i]->length);
@@ -761,7 +765,7 @@ int64_t comet_concat_nested_column(struct ArrowArray** arrays, struct ArrowSchem
       for (int64_t r = 0; r < x.length && !x.validity.empty(); r++) nulls += !((x.validity[(size_t)(r >> 3)] >> (r & 7)) & 1);
       x.null_count = nulls;
       if (!nulls) x.validity.clear();
-      if ((x.type.id == TypeId::List || x.type.id == TypeId::String || x.type.id == TypeId::Bytes) && x.values.empty()) x.values.assign(4, 0);
+      if ((x.type.is_listlike() || x.type.id == TypeId::String || x.type.id == TypeId::Bytes) && x.values.empty()) x.values.assign(4, 0);
       for (auto& k : x.children) finish(k);
     };
     finish(h);

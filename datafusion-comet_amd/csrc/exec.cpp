@@ -631,7 +631,7 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
       if (e->kind == ExprKind::Bound && (e->bound_index < 0 || (size_t)e->bound_index >= st.size()))
         throw CometError("ShuffleWriter: hash expression references column " + std::to_string(e->bound_index) + " of " + std::to_string(st.size()));
     for (auto& t : st)
-      if (expected_format(t) == "?" || t.id == TypeId::Map) throw CometError("ShuffleWriter: column type " + t.str() + " is not supported");
+      if (expected_format(t) == "?") throw CometError("ShuffleWriter: column type " + t.str() + " is not supported");
     auto sp = shuffle_projs_.find(&op);
     if (sp != shuffle_projs_.end()) {
       Operator& pr = *sp->second;
@@ -1021,7 +1021,7 @@ DeviceColumnView ExecutionContext::take_column(const DeviceColumnView& src, cons
     take_validity();
     return out;
   }
-  if (t.id == TypeId::List) {
+  if (t.is_listlike()) {
     // lengths of the taken rows → new offsets → the source element index of every output element → the element column taken by those
     auto offsets = std::make_shared<DevBuf>();
     offsets->ensure((size_t)(rows + 1) * 4 + 16);
@@ -1503,7 +1503,7 @@ HostColumn download_column(const DeviceColumnView& v, const DType& t, bool has_v
   if (t.id == TypeId::Struct) {
     for (size_t i = 0; i < t.kids.size(); i++)
       c.children.push_back(download_column(v.kids.at(i), t.kids[i], i < v.kid_has_valid.size() && v.kid_has_valid[i], rows, st));
-  } else if (t.id == TypeId::List) {
+  } else if (t.is_listlike()) {
     fetch(c.values, v.data, (size_t)(rows + 1) * 4);
     HIP_CHECK(hipStreamSynchronize(st));
     const int64_t nel = rows ? ((const int32_t*)c.values.data())[rows] : 0;
@@ -1550,12 +1550,12 @@ HostColumn slice_column(const HostColumn& c, int64_t off, int64_t len) {
   const TypeId id = c.type.id;
   if (id == TypeId::Struct) {
     for (auto& k : c.children) o.children.push_back(slice_column(k, off, len));
-  } else if (id == TypeId::List || id == TypeId::String || id == TypeId::Bytes) {
+  } else if (id == TypeId::List || id == TypeId::Map || id == TypeId::String || id == TypeId::Bytes) {
     const int32_t* src = (const int32_t*)c.values.data();
     o.values.resize((size_t)(len + 1) * 4);
     int32_t* w = (int32_t*)o.values.data();
     for (int64_t i = 0; i <= len; i++) w[i] = src[off + i] - src[off];
-    if (id == TypeId::List) o.children.push_back(slice_column(c.children.at(0), src[off], src[off + len] - src[off]));
+    if (id == TypeId::List || id == TypeId::Map) o.children.push_back(slice_column(c.children.at(0), src[off], src[off + len] - src[off]));
     else o.data.assign(c.data.begin() + src[off], c.data.begin() + src[off + len]);
   } else if (id == TypeId::Bool) {
     o.values = slice_bits(c.values, off, len);

@@ -319,7 +319,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
         v.kid_has_valid.push_back(khv ? 1 : 0);
       }
       v.kid_rows = h.length;
-    } else if (h.type.id == TypeId::List) {
+    } else if (h.type.is_listlike()) {
       static const int32_t zero = 0;
       v.data = h.values.empty() ? up(&zero, 4) : up(h.values.data(), (size_t)(h.length + 1) * 4);
       bool khv = false;
@@ -348,7 +348,7 @@ bool ExecutionContext::pull_host_table(size_t input, const std::vector<DType>& i
     std::function<void(HostColumn&, const DType&)> shape = [&](HostColumn& x, const DType& t) {
       x.type = t;
       if (t.id == TypeId::Struct) { x.children.resize(t.kids.size()); for (size_t k = 0; k < t.kids.size(); k++) shape(x.children[k], t.kids[k]); }
-      else if (t.id == TypeId::List) { x.children.resize(1); shape(x.children[0], t.kids.at(0)); }
+      else if (t.is_listlike()) { x.children.resize(1); shape(x.children[0], t.kids.at(0)); }
     };
     shape(h, in_types_[c]);
     for (auto& a : held) {

@@ -70,6 +70,7 @@ bool nested_schema_matches(const ArrowSchema* f, const DType& t) {
     return true;
   }
   if (t.id == TypeId::List) return fmt == "+l" && f->n_children == 1 && t.kids.size() == 1 && nested_schema_matches(f->children[0], t.kids[0]);
+  if (t.id == TypeId::Map) return fmt == "+m" && f->n_children == 1 && t.kids.size() == 1 && nested_schema_matches(f->children[0], t.kids[0]);
   if (t.is_nested()) return false;
   return format_matches(f->format, t);
 }
@@ -107,7 +108,7 @@ void append_nested_rows(HostColumn& dst, const ArrowArray* a, const DType& t, in
       for (HostColumn& k : dst.children) mask(k, dst);
     return;
   }
-  if (t.id == TypeId::List) {
+  if (t.is_listlike()) {
     if (a->n_children != 1 || t.kids.size() != 1) throw CometError("nested input column: list array without its elements");
     if (dst.children.empty()) dst.children.resize(1);
     const int32_t* o = (const int32_t*)a->buffers[1] + src0;

@@ -1822,10 +1822,13 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
         fields.push_back(lf);
         top_of.push_back((int)t);
       }
-    } else if (f.dtype.id == TypeId::List) {
+    } else if (f.dtype.id == TypeId::List || f.dtype.id == TypeId::Map) {
+      // (a map is a list of (key, value) entry structs — in the file: <rep> group m (MAP) { repeated group key_value { required key; <rep> value } } —
+      // and in HBM: the same offsets + entries layout, Arrow's)
       tops[t].kind = 2;
       if (f.dtype.kids.size() != 1) throw CometError("Parquet column '" + f.name + "': a list without an element type");
       const DType& el = f.dtype.kids[0];
+      if (f.dtype.id == TypeId::Map && (el.id != TypeId::Struct || el.kids.size() != 2)) throw CometError("Parquet column '" + f.name + "': a map type without (key, value) entries");
       if (el.id == TypeId::Struct && !el.kids.empty()) {
         // a list of structs: one leaf per field of the element struct, all under the same repeated group (the same repetition levels)
         tops[t].kind = 3;

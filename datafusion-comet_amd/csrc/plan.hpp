@@ -40,6 +40,8 @@ struct DType {
   // per field behind its real columns; GetStructField(Bound(parent), kid) is then a Bound reference to it).  Not part of the type's identity
   int virt_parent = -1, virt_kid = -1;
   bool is_nested() const { return id == TypeId::Struct || id == TypeId::List || id == TypeId::Map; }
+  // a List, or a Map — which is laid out as a list of (key, value) entry structs (Arrow's Map layout): kids[0] = Struct(key, value)
+  bool is_listlike() const { return id == TypeId::List || id == TypeId::Map; }
   bool operator==(const DType& o) const {
     if (id != o.id || precision != o.precision || scale != o.scale || kids.size() != o.kids.size()) return false;
     for (size_t i = 0; i < kids.size(); i++)

@@ -117,6 +117,25 @@ DType decode_datatype(Reader r) {
           d.kids.assign(1, el);
           d.kid_names.assign(1, "element");
           d.kid_nullable.assign(1, contains_null ? 1 : 0);
+        } else if (f2 == 4 && wt2 == 2) {  // MapInfo: key_type = 1, value_type = 2, value_contains_null = 3
+          Reader mi = info.sub();
+          DType kt, vt;
+          kt.id = vt.id = TypeId::Bool;
+          bool vnull = false;
+          while (!mi.done()) {
+            int wt3, f3 = mi.tag(wt3);
+            if (f3 == 1 && wt3 == 2) kt = decode_datatype(mi.sub());
+            else if (f3 == 2 && wt3 == 2) vt = decode_datatype(mi.sub());
+            else if (f3 == 3 && wt3 == 0) vnull = mi.varint() != 0;
+            else mi.skip(wt3);
+          }
+          DType entries = DType::of(TypeId::Struct);
+          entries.kids = {kt, vt};
+          entries.kid_names = {"key", "value"};
+          entries.kid_nullable = {0, (char)(vnull ? 1 : 0)};
+          d.kids.assign(1, entries);
+          d.kid_names.assign(1, "entries");
+          d.kid_nullable.assign(1, 0);
         } else if (f2 == 5 && wt2 == 2) {  // StructInfo: field_names = 1, field_datatypes = 2, field_nullable = 3 (packed or not)
           Reader si = info.sub();
           while (!si.done()) {
@@ -838,6 +857,7 @@ std::string DType::str() const {
       return o + ")";
     }
     case TypeId::List: return "List(" + (kids.empty() ? std::string("?") : kids[0].str()) + ")";
+    case TypeId::Map: return "Map(" + (kids.empty() || kids[0].kids.size() != 2 ? std::string("?") : kids[0].kids[0].str() + ", " + kids[0].kids[1].str()) + ")";
     default: return "Unsupported(" + std::to_string((int)id) + ")";
   }
 }

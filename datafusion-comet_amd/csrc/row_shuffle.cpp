@@ -123,7 +123,7 @@ size_t value_width(const DType& t) {
     case TypeId::Int64: case TypeId::Double: case TypeId::Timestamp: case TypeId::TimestampNtz: return 8;
     case TypeId::Decimal: return 16;
     case TypeId::Bool: case TypeId::String: case TypeId::Bytes: return 0;
-    case TypeId::Struct: case TypeId::List: return 0;      // (nested columns: NestedBuild below)
+    case TypeId::Struct: case TypeId::List: case TypeId::Map: return 0;      // (nested columns: NestedBuild below)
     default: throw CometError("writeSortedFileNative: unsupported column type " + t.str());
   }
 }
@@ -142,10 +142,9 @@ struct NestedBuild {
 void nested_init(NestedBuild& b, const DType& t) {
   b = NestedBuild();
   b.type = t;
-  if (t.id == TypeId::Map) throw CometError("writeSortedFileNative: map columns are not supported");
   b.width = value_width(t);
-  if (t.id == TypeId::String || t.id == TypeId::Bytes || t.id == TypeId::List) b.values.assign(4, 0);      // offsets[0] = 0
-  if (t.id == TypeId::Struct || t.id == TypeId::List) {
+  if (t.id == TypeId::String || t.id == TypeId::Bytes || t.is_listlike()) b.values.assign(4, 0);      // offsets[0] = 0
+  if (t.id == TypeId::Struct || t.is_listlike()) {
     b.kids.resize(t.kids.size());
     for (size_t k = 0; k < t.kids.size(); k++) nested_init(b.kids[k], t.kids[k]);
   }
@@ -165,7 +164,7 @@ void nested_append_null(NestedBuild& b) {
   nested_push_validity(b, false);
   switch (b.type.id) {
     case TypeId::Struct: for (auto& k : b.kids) nested_append_null(k); break;
-    case TypeId::List: case TypeId::String: case TypeId::Bytes: { const int32_t e = nested_last_offset(b); b.values.insert(b.values.end(), (const uint8_t*)&e, (const uint8_t*)&e + 4); break; }
+    case TypeId::List: case TypeId::Map: case TypeId::String: case TypeId::Bytes: { const int32_t e = nested_last_offset(b); b.values.insert(b.values.end(), (const uint8_t*)&e, (const uint8_t*)&e + 4); break; }
     case TypeId::Bool: if ((size_t)((b.length + 8) / 8) > b.values.size()) b.values.resize((size_t)((b.length + 8) / 8) + 64, 0); break;
     default: b.values.insert(b.values.end(), b.width, 0);
   }
@@ -236,6 +235,43 @@ void nested_append_value(NestedBuild& b, const uint8_t* base, size_t size, const
         if (row_is_null(row, k)) nested_append_null(b.kids[k]);
         else nested_append_value(b.kids[k], row, len, row + bitset + k * 8, 8, depth + 1);
       }
+      break;
+    }
+    case TypeId::Map: {
+      // UnsafeMapData (map.rs; written by columnar_to_row.rs:1788-1836): 8-byte size of the key array | key array | value array, both
+      // UnsafeArrayData of the same element count — appended entry by entry into the entries struct's (key, value) children
+      size_t off, len;
+      var_part(off, len);
+      NestedBuild& en = b.kids.at(0);
+      if (en.kids.size() != 2) throw CometError("writeSortedFileNative: a map type without (key, value) entries");
+      if (len) {
+        const uint8_t* m = base + off;
+        if (len < 8) throw CometError("writeSortedFileNative: a map shorter than its key-array size");
+        int64_t ksz;
+        memcpy(&ksz, m, 8);
+        if (ksz < 8 || (uint64_t)ksz + 8 > (uint64_t)len) throw CometError("writeSortedFileNative: bad map key-array size");
+        const uint8_t* ka = m + 8;
+        const uint8_t* va = ka + ksz;
+        const size_t vsz = len - 8 - (size_t)ksz;
+        if (vsz < 8) throw CometError("writeSortedFileNative: a map without its value array");
+        int64_t nk, nv;
+        memcpy(&nk, ka, 8);
+        memcpy(&nv, va, 8);
+        if (nk < 0 || nk != nv || (uint64_t)nk > (uint64_t)len) throw CometError("writeSortedFileNative: a map whose key and value arrays differ in length");
+        const size_t kes = array_element_size(en.kids[0].type), ves = array_element_size(en.kids[1].type), bitset = (((size_t)nk + 63) / 64) * 8;
+        if (8 + bitset + (size_t)nk * kes > (size_t)ksz || 8 + bitset + (size_t)nk * ves > vsz) throw CometError("writeSortedFileNative: a map array is shorter than its elements");
+        for (int64_t j = 0; j < nk; j++) {
+          nested_push_validity(en, true);      // an entry is never NULL
+          en.length++;
+          if (row_is_null(ka + 8, (size_t)j)) throw CometError("writeSortedFileNative: a NULL map key");
+          nested_append_value(en.kids[0], ka, (size_t)ksz, ka + 8 + bitset + (size_t)j * kes, kes, depth + 1);
+          if (row_is_null(va + 8, (size_t)j)) nested_append_null(en.kids[1]);
+          else nested_append_value(en.kids[1], va, vsz, va + 8 + bitset + (size_t)j * ves, ves, depth + 1);
+        }
+      }
+      if (en.length > INT32_MAX) throw CometError("writeSortedFileNative: more than 2^31 map entries in one batch");
+      const int32_t e = (int32_t)en.length;
+      b.values.insert(b.values.end(), (const uint8_t*)&e, (const uint8_t*)&e + 4);
       break;
     }
     case TypeId::List: {

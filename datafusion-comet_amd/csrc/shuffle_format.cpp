@@ -559,7 +559,7 @@ FbField scalar(int slot, int size, uint64_t v) { return FbField{slot, size, v, f
 FbField ref(int slot) { return FbField{slot, 4, 0, true}; }
 
 // flatbuffer Type union ids (format/Schema.fbs)
-enum { FB_Int = 2, FB_FloatingPoint = 3, FB_Binary = 4, FB_Utf8 = 5, FB_Bool = 6, FB_Decimal = 7, FB_Date = 8, FB_Timestamp = 10, FB_List = 12, FB_Struct = 13 };
+enum { FB_Int = 2, FB_FloatingPoint = 3, FB_Binary = 4, FB_Utf8 = 5, FB_Bool = 6, FB_Decimal = 7, FB_Date = 8, FB_Timestamp = 10, FB_List = 12, FB_Struct = 13, FB_Map = 17 };
 enum { MSG_Schema = 1, MSG_DictionaryBatch = 2, MSG_RecordBatch = 3 };
 
 uint8_t fb_type_id(const DType& t) {
@@ -574,6 +574,7 @@ uint8_t fb_type_id(const DType& t) {
     case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Int64: return FB_Int;
     case TypeId::List: return FB_List;
     case TypeId::Struct: return FB_Struct;
+    case TypeId::Map: return FB_Map;
     default: throw CometError("shuffle writer: column type " + t.str() + " is not supported");
   }
 }
@@ -591,6 +592,7 @@ void write_type(FbWriter& w, const DType& t, size_t type_ref) {
     case TypeId::Float: tab = w.table(1, {scalar(0, 2, 1)}, rp); break;
     case TypeId::Double: tab = w.table(1, {scalar(0, 2, 2)}, rp); break;
     case TypeId::String: case TypeId::Bytes: case TypeId::List: case TypeId::Struct: tab = w.table(0, {}, rp); break;
+    case TypeId::Map: tab = w.table(1, {scalar(0, 1, 0 /* keysSorted = false */)}, rp); break;
     case TypeId::Decimal: tab = w.table(3, {scalar(0, 4, (uint64_t)t.precision), scalar(1, 4, (uint64_t)t.scale), scalar(2, 4, 128)}, rp); break;
     case TypeId::Date: tab = w.table(1, {scalar(0, 2, 0 /* DAY */)}, rp); break;
     case TypeId::Timestamp: {
@@ -636,8 +638,8 @@ void write_schema_message(const std::vector<ColumnSlice>& cols, std::vector<uint
     const size_t children = w.offset_vector(nk, kid_slots);
     w.patch(rp[5], children);
     for (size_t k = 0; k < nk; k++)
-      write_field(t.kids[k], t.id == TypeId::List ? std::string("item") : (k < t.kid_names.size() ? t.kid_names[k] : std::string()),
-                  k < t.kid_nullable.size() ? t.kid_nullable[k] != 0 : true, kid_slots[k]);
+      write_field(t.kids[k], t.id == TypeId::List ? std::string("item") : t.id == TypeId::Map ? std::string("entries") : (k < t.kid_names.size() ? t.kid_names[k] : std::string()),
+                  t.id == TypeId::Map ? false : (k < t.kid_nullable.size() ? t.kid_nullable[k] != 0 : true), kid_slots[k]);
   };
   for (size_t c = 0; c < cols.size(); c++) write_field(cols[c].type, "c" + std::to_string(c), true, elem[c]);
   append_message(out, w);
@@ -703,7 +705,7 @@ void write_batch_message(const std::vector<ColumnSlice>& cols, int64_t rows, std
       for (const ColumnSlice& k : c.kids) emit(k, first, rows);
       return;
     }
-    if (c.type.id == TypeId::List) {
+    if (c.type.is_listlike()) {
       if (c.kids.size() != 1) throw CometError("shuffle writer: list column without its elements");
       const int32_t* offs = (const int32_t*)c.values + first;
       const int32_t base = offs[0];
@@ -862,18 +864,22 @@ DType type_from_fb(int type_id, const FbTable& t) {
 // a Field table → its type, children included (List: one child; Struct: its fields by name)
 DType type_of_field(const FbTable& f, int depth = 0) {
   const int tid = f.get<uint8_t>(2, 0);
-  if (tid != FB_List && tid != FB_Struct) return type_from_fb(tid, f.child(3));
+  if (tid != FB_List && tid != FB_Struct && tid != FB_Map) return type_from_fb(tid, f.child(3));
   if (depth > 8) throw CometError("shuffle block: types nested deeper than 8 levels");
-  DType t = DType::of(tid == FB_List ? TypeId::List : TypeId::Struct);
+  DType t = DType::of(tid == FB_List ? TypeId::List : tid == FB_Map ? TypeId::Map : TypeId::Struct);
   size_t first;
   const size_t nk = f.vec(5, 4, first);
-  if (tid == FB_List && nk != 1) throw CometError("shuffle block: a list field with " + std::to_string(nk) + " children");
+  if (tid != FB_Struct && nk != 1) throw CometError("shuffle block: a list / map field with " + std::to_string(nk) + " children");
   for (size_t k = 0; k < nk; k++) {
     FbTable kf = f.elem_table(first, k);
     if (kf.child(4).valid()) throw CometError("shuffle block: dictionary-encoded nested fields are not supported");
     t.kids.push_back(type_of_field(kf, depth + 1));
-    t.kid_names.push_back(tid == FB_List ? std::string("element") : kf.str(0));
+    t.kid_names.push_back(tid == FB_List ? std::string("element") : tid == FB_Map ? std::string("entries") : kf.str(0));
     t.kid_nullable.push_back(kf.get<uint8_t>(1, 0) != 0 ? 1 : 0);
+  }
+  if (tid == FB_Map) {
+    if (t.kids[0].id != TypeId::Struct || t.kids[0].kids.size() != 2) throw CometError("shuffle block: a map whose entries are not (key, value) structs");
+    t.kids[0].kid_names = {"key", "value"};
   }
   return t;
 }
@@ -919,7 +925,7 @@ HostColumn read_plain_column(const DType& type, BodyCursor& cur, int64_t rows_ex
     for (const DType& kt : type.kids) c.children.push_back(read_plain_column(kt, cur, c.length));
     return c;
   }
-  if (type.id == TypeId::List) {
+  if (type.is_listlike()) {
     auto ob = cur.next_buffer();
     c.values.assign((size_t)(c.length + 1) * 4, 0);
     int32_t base = 0, last = 0;
@@ -1257,7 +1263,7 @@ void export_column(HostColumn&& col, ArrowArray* a) {
     ec->buffers[1] = ec->col.values.empty() ? (const void*)kEmpty : (const void*)ec->col.values.data();
     ec->buffers[2] = is_str ? (ec->col.data.empty() ? (const void*)kEmpty : (const void*)ec->col.data.data()) : nullptr;
   }
-  if (id == TypeId::Struct || id == TypeId::List) {
+  if (id == TypeId::Struct || id == TypeId::List || id == TypeId::Map) {
     ec->children.resize(ec->col.children.size());
     for (size_t i = 0; i < ec->col.children.size(); i++) {
       export_column(std::move(ec->col.children[i]), &ec->children[i]);
@@ -1279,11 +1285,11 @@ void export_schema_named(const DType& t, const std::string& name, bool nullable,
   s->format = es->format.c_str();
   s->name = es->name.c_str();
   s->flags = nullable ? ARROW_FLAG_NULLABLE : 0;
-  if (t.id == TypeId::Struct || t.id == TypeId::List) {
+  if (t.id == TypeId::Struct || t.id == TypeId::List || t.id == TypeId::Map) {
     es->children.resize(t.kids.size());
     for (size_t i = 0; i < t.kids.size(); i++) {
-      const std::string kn = t.id == TypeId::List ? "element" : (i < t.kid_names.size() ? t.kid_names[i] : std::string());
-      export_schema_named(t.kids[i], kn, i < t.kid_nullable.size() ? t.kid_nullable[i] != 0 : true, &es->children[i]);
+      const std::string kn = t.id == TypeId::List ? "element" : t.id == TypeId::Map ? "entries" : (i < t.kid_names.size() ? t.kid_names[i] : std::string());
+      export_schema_named(t.kids[i], kn, t.id == TypeId::Map ? false : (i < t.kid_nullable.size() ? t.kid_nullable[i] != 0 : true), &es->children[i]);
       es->child_ptrs.push_back(&es->children[i]);
     }
     s->n_children = (int64_t)es->children.size();
@@ -1312,6 +1318,7 @@ std::string expected_format(const DType& t) {
     case TypeId::Decimal: return "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale);
     case TypeId::Struct: return "+s";
     case TypeId::List: return "+l";
+    case TypeId::Map: return "+m";
     default: return "?";
   }
 }

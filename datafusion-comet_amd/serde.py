@@ -92,6 +92,9 @@ class DataType:
         elif self.type_id == LIST:
             li = _f_msg(1, self.element.encode()) + (_f_varint(2, 1) if self.contains_null else b"")
             out += _f_msg(2, _f_msg(3, li))
+        elif self.type_id == MAP:      # MapInfo{key_type = 1, value_type = 2, value_contains_null = 3}; fields = (("key", K, False), ("value", V, nullable))
+            mi = _f_msg(1, self.fields[0][1].encode()) + _f_msg(2, self.fields[1][1].encode()) + (_f_varint(3, 1) if self.fields[1][2] else b"")
+            out += _f_msg(2, _f_msg(4, mi))
         elif self.type_id == STRUCT:
             si = b"".join(_f_bytes(1, n.encode()) for n, _, _ in self.fields)
             si += b"".join(_f_msg(2, t.encode()) for _, t, _ in self.fields)
@@ -106,6 +109,8 @@ class DataType:
             return f"decimal({self.precision},{self.scale})"
         if self.type_id == LIST:
             return f"list<{self.element!r}>"
+        if self.type_id == MAP:
+            return f"map<{self.fields[0][1]!r}, {self.fields[1][1]!r}>"
         if self.type_id == STRUCT:
             return "struct<" + ", ".join(f"{n}: {t!r}" for n, t, _ in self.fields) + ">"
         return names[self.type_id]
@@ -114,6 +119,10 @@ class DataType:
 def struct_type(fields) -> DataType:
     """fields: [(name, DataType, nullable)]"""
     return DataType(STRUCT, fields=tuple((n, t, bool(nl)) for n, t, nl in fields))
+
+
+def map_type(key: DataType, value: DataType, value_contains_null: bool = True) -> DataType:
+    return DataType(MAP, fields=(("key", key, False), ("value", value, bool(value_contains_null))))
 
 
 def list_type(element: DataType, contains_null: bool = True) -> DataType:
@@ -139,6 +148,8 @@ def from_arrow_type(t) -> DataType:
         return struct_type([(t.field(i).name, from_arrow_type(t.field(i).type), t.field(i).nullable) for i in range(t.num_fields)])
     if pa.types.is_list(t):
         return list_type(from_arrow_type(t.value_type), t.value_field.nullable)
+    if pa.types.is_map(t):
+        return map_type(from_arrow_type(t.key_type), from_arrow_type(t.item_type), t.item_field.nullable)
     if pa.types.is_timestamp(t):
         return T_TIMESTAMP if t.tz else DataType(TIMESTAMP_NTZ)
     m = {pa.bool_(): T_BOOL, pa.int8(): T_INT8, pa.int16(): T_INT16, pa.int32(): T_INT32, pa.int64(): T_INT64, pa.float32(): T_FLOAT,

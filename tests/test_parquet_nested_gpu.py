@@ -414,3 +414,51 @@ def test_lists_of_structs_out_of_parquet(built, tmp_path, codec, version, nullab
     exp = _explode_ref([want.column("k")[i].as_py() for i in keep], [want.column("ls")[i].as_py() for i in keep], True, True)
     rows = list(zip(*[got.column(c).to_pylist() for c in range(3)]))
     assert rows == exp
+
+
+@pytest.mark.parametrize("codec,version", [("snappy", "1.0"), ("zstd", "2.0")])
+def test_map_columns_out_of_parquet_and_through_a_shuffle(built, tmp_path, codec, version):
+    """map<K, V>: in the file a MAP group of one repeated key_value group (required key, optional value) — read like a list of (key, value)
+    structs, laid out in HBM like Arrow's Map (offsets + entries); exported as `+m`, passed through a Filter, written to and read back from
+    shuffle files"""
+    rng = np.random.default_rng(64)
+    n = 8_000
+
+    def mk(make_v, pnull=0.1):
+        out = []
+        for _ in range(n):
+            if rng.random() < pnull:
+                out.append(None)
+                continue
+            k = int(rng.integers(0, 6)) if rng.random() > 0.02 else 120
+            out.append([("key-%d" % j, None if rng.random() < 0.15 else make_v()) for j in range(k)])
+        return out
+
+    t = pa.table({"k": pa.array(np.arange(n, dtype=np.int64)),
+                  "m": pa.array(mk(lambda: int(rng.integers(-10**9, 10**9))), pa.map_(pa.string(), pa.int64())),
+                  "ms": pa.array(mk(lambda: "v%d" % int(rng.integers(0, 30))), pa.map_(pa.string(), pa.string())),
+                  "mi": pa.array([None if rng.random() < 0.1 else [(int(j), float(j) * 0.5) for j in range(int(rng.integers(0, 4)))] for _ in range(n)], pa.map_(pa.int32(), pa.float64()))})
+    path = str(tmp_path / f"maps_{codec}.parquet")
+    papq.write_table(t, path, compression=codec, data_page_version=version, row_group_size=3_000, data_page_size=16 << 10)
+    got = _scan_and_compare(path, t)
+    assert pa.types.is_map(got.column(1).type)
+    ty = _types(t.schema)
+    scan = S.native_scan([path], t.schema.names, ty)
+    want = papq.read_table(path)
+    plan = S.project(S.filter_(scan, S.gt_eq(S.col(0, ty[0]), S.lit(5_000, S.T_INT64))), [S.col(1, ty[1]), S.col(3, ty[3]), S.col(0, ty[0])])
+    got = _run(plan, 3)
+    _same(got.column(0), want.slice(5_000).column("m"), "m")
+    _same(got.column(1), want.slice(5_000).column("mi"), "mi")
+    data, index = str(tmp_path / "shuffle.data"), str(tmp_path / "shuffle.index")
+    assert native.execute_to_table([], 0, S.shuffle_writer(scan, data, index, partitioning="hash", hash_exprs=[S.col(0, ty[0])], num_partitions=3, codec=S.CODEC_ZSTD).encode(), batch_size=2000) == []
+    back = S.project(S.shuffle_scan(ty), [S.col(i, ty[i]) for i in range(len(ty))])
+    rows = {}
+    for p in range(3):
+        for b in native.execute_to_table([native.ShuffleBlockInput.from_files(data, index, p)], len(ty), back.encode(), batch_size=0):
+            cols = [c.to_pylist() for c in b.columns]
+            for i in range(b.num_rows):
+                rows[cols[0][i]] = tuple(cols[j][i] for j in range(1, len(cols)))
+    wcols = [want.column(nm).to_pylist() for nm in t.schema.names]
+    assert len(rows) == n
+    for i in range(n):
+        assert rows[wcols[0][i]] == tuple(wcols[j][i] for j in range(1, len(wcols))), i

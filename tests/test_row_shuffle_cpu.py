@@ -241,6 +241,11 @@ def test_write_sorted_rows_with_nested_columns(built, tmp_path, codec):
         "lst": pa.array(lst(lambda: {"p": maybe(0.1, lambda: int(rng.integers(0, 99))), "q": maybe(0.2, words)}), pa.list_(inner)),
         "ll": pa.array(lst(lambda: [int(x) for x in rng.integers(0, 9, int(rng.integers(0, 4)))]), pa.list_(pa.list_(pa.int32()))),
         "s": pa.array([words() for _ in range(n)], pa.string()),
+        # maps: UnsafeMapData = key-array size | key array | value array (map.rs; columnar_to_row.rs:1788-1836)
+        "m": pa.array([maybe(0.1, lambda: [("k%d" % j, maybe(0.2, lambda: int(rng.integers(-99, 99)))) for j in range(int(rng.integers(0, 5)))]) for _ in range(n)], pa.map_(pa.string(), pa.int64())),
+        "mi": pa.array([maybe(0.1, lambda: [(int(j), maybe(0.2, words)) for j in range(int(rng.integers(0, 4)))]) for _ in range(n)], pa.map_(pa.int32(), pa.string())),
+        "ml": pa.array([maybe(0.1, lambda: [(int(j), [float(x) for x in rng.integers(0, 9, int(rng.integers(0, 3)))]) for j in range(int(rng.integers(0, 3)))]) for _ in range(n)],
+                       pa.map_(pa.int16(), pa.list_(pa.float64()))),
     }
     t = pa.table(cols)
     types = [S.from_arrow_type(f.type) for f in t.schema]

@@ -22,6 +22,10 @@ def _batch(n, seed):
     lst = [None if rng.random() < 0.1 else [{"x": int(x), "y": None if x % 3 == 0 else "y%d" % int(x)} for x in rng.integers(0, 99, int(rng.integers(0, 4)))] for _ in range(n)]
     t = t.append_column("ls", pa.array(ls, pa.list_(pa.string())))
     t = t.append_column("lst", pa.array(lst, pa.list_(pa.struct([("x", pa.int64()), ("y", pa.string())]))))
+    mp = [None if rng.random() < 0.1 else [("k%d" % j, None if rng.random() < 0.2 else float(rng.integers(0, 999)) / 4) for j in range(int(rng.integers(0, 5)))] for _ in range(n)]
+    mnest = [None if rng.random() < 0.1 else [(int(j) * 3, [int(x) for x in rng.integers(0, 9, int(rng.integers(0, 3)))]) for j in range(int(rng.integers(0, 4)))] for _ in range(n)]
+    t = t.append_column("mp", pa.array(mp, pa.map_(pa.string(), pa.float64())))
+    t = t.append_column("mnest", pa.array(mnest, pa.map_(pa.int32(), pa.list_(pa.int64()))))
     return t.combine_chunks().to_batches()[0]
 
 
@@ -100,7 +104,7 @@ def test_nested_input_batches_are_concatenated_like_pyarrow_does(built):
     SLICES of batches of struct / list columns become one column equal to pyarrow's own concatenation; a field under a NULL struct comes out
     NULL whatever the producer left in its slot (pyarrow leaves a valid zero)"""
     b = _batch(2_500, 55)
-    for name in ("s", "li", "ld", "ls", "lst"):
+    for name in ("s", "li", "ld", "ls", "lst", "mp", "mnest"):
         col = b.column(b.schema.get_field_index(name))
         parts = [col.slice(0, 700), col.slice(700, 1), col.slice(701, 0), col.slice(701, 1299), col.slice(2000, 500)]
         got = native.concat_nested_column(parts)

@@ -202,9 +202,9 @@ def render() -> str:
     w("* Computed Utf8 values used as operands of further expressions must fit 15 bytes (literals, substring, CASE over those).")
     w("* Window: RANGE frames with value offsets over non-integer keys, floating-point aggregates over frames, MIN / MAX over sliding frames wider")
     w("  than 4096 rows, lag / lead defaults of Utf8 / Boolean type.")
-    w("* Nested types: struct-of-flat and list-of-flat (fixed-width elements) columns are read from Parquet, passed through Filter / Projection / Sort /")
+    w("* Nested types: struct-of-flat, list-of-flat, list-of-flat-struct and map columns are read from Parquet, passed through Filter / Projection / Sort /")
     w("  Limit / ShuffleWriter, taken apart by `GetStructField` and exported; struct / list columns of any depth arrive through Scan / ShuffleScan inputs;")
-    w("  `Explode` of a list column runs; maps, deeper trees in the Parquet scan, and every expression that computes on a list or builds a struct / an array are refused.")
+    w("  `Explode` of a list column runs; deeper trees in the Parquet scan, `Explode` of a map, and every expression that computes on a list / map or builds a struct / an array are refused.")
     w("  Parquet: TIMESTAMP(NANOS) / TIME, encrypted files.")
     w("* ShuffleWriter with more than 4096 partitions.")
     w("")
