@@ -542,6 +542,27 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
   });
 }
 
+int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* start, int32_t* len) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    static std::mutex mu;
+    static std::map<std::pair<std::string, int>, std::shared_ptr<const RegexProg>> cache;
+    const std::pair<std::string, int> key(pattern ? pattern : "", (int)group);
+    std::shared_ptr<const RegexProg> p;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = cache.find(key);
+      if (it != cache.end()) p = it->second;
+    }
+    if (!p) {
+      p = std::make_shared<const RegexProg>(compile_regex_captures(key.first, group, "regexp_extract"));
+      std::lock_guard<std::mutex> lk(mu);
+      if (cache.size() >= 64) cache.clear();
+      cache[key] = p;
+    }
+    return regex_prog_extract(*p, value, value_len, start, len) ? 1 : 0;
+  });
+}
+
 int64_t comet_snappy_view_read(const uint8_t* src, size_t src_len, int32_t max_elems, const int64_t* offsets, int32_t n, uint8_t* out) {
   return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
     pq::SnappyView v;

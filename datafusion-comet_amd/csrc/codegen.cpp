@@ -53,13 +53,14 @@ u128 sat_add(u128 a, u128 b) {
 thread_local bool g_uses_ryu = false;      // the source being generated calls into comet_ryu.hpp (Float → Decimal)
 thread_local bool g_uses_strtod = false;   // … into comet_strtod.hpp (String → Float / Double)
 thread_local bool g_uses_strts = false;    // … into comet_strts.hpp (String → Timestamp)
+thread_local bool g_uses_regex_vm = false; // … into comet_regex_vm.hpp (regexp_extract)
 // the pipeline being generated: where raise sites with a QueryContext are noted, and how many sites of each content it has seen (err_sites.cpp)
 thread_local std::vector<std::pair<uint32_t, std::shared_ptr<QueryContext>>>* g_site_sink = nullptr;
 thread_local std::map<std::string, int>* g_site_ordinals = nullptr;
 struct SiteScope {
   std::map<std::string, int> ordinals;
   // (the optional-header flags start clean: a generation that threw after setting one must not make the next, unrelated kernel include the tables)
-  explicit SiteScope(PipelineDesc& d) { g_site_sink = &d.site_contexts; g_site_ordinals = &ordinals; g_uses_ryu = g_uses_strtod = g_uses_strts = false; }
+  explicit SiteScope(PipelineDesc& d) { g_site_sink = &d.site_contexts; g_site_ordinals = &ordinals; g_uses_ryu = g_uses_strtod = g_uses_strts = g_uses_regex_vm = false; }
   ~SiteScope() { g_site_sink = nullptr; g_site_ordinals = nullptr; }
 };
 std::string with_optional_headers(std::string src) {
@@ -78,7 +79,12 @@ std::string with_optional_headers(std::string src) {
     const size_t at = src.find(inc);
     if (at != std::string::npos) src.insert(at + inc.size(), "namespace comet {\n#include \"comet_strts.hpp\"\n}\n");
   }
-  g_uses_ryu = g_uses_strtod = g_uses_strts = false;
+  if (g_uses_regex_vm) {
+    const std::string inc = "using namespace comet;\n";
+    const size_t at = src.find(inc);
+    if (at != std::string::npos) src.insert(at + inc.size(), "#include \"comet_regex_vm.hpp\"\n");
+  }
+  g_uses_ryu = g_uses_strtod = g_uses_strts = g_uses_regex_vm = false;
   return src;
 }
 
@@ -1357,6 +1363,40 @@ struct Gen {
       oc.pad_pattern = pat;
       oc.pad_left = f == "lpad";
       call = "utf8_view_pad(@, " + std::to_string(clamp32(n)) + ", " + (f == "read_side_padding" ? "false" : "true") + ")";
+    } else if (f == "regexp_extract") {
+      // spark_regexp_extract (string_funcs/regexp_extract.rs:38-108): the bytes group `idx` of the pattern's leftmost match spans, the empty
+      // string without a match or with the group unset; pattern and idx are literals (strings.scala:472-473), a NULL one makes every row NULL
+      // (regexp_extract_common.rs:58-81).  The pattern becomes a program of comet_regex_vm.hpp's matcher (regex.cpp), a constant of the kernel.
+      if (e.children.size() < 2 || e.children.size() > 3) throw CometError("regexp_extract expects 2 or 3 arguments (subject, pattern, [idx]), got " + std::to_string(e.children.size()));
+      const ExprP& pat = e.children[1];
+      if (pat->kind != ExprKind::Literal || (pat->dtype.id != TypeId::String && !pat->lit_null)) throw CometError("regexp_extract pattern must be a scalar string");
+      long long group = 1;
+      bool all_null = pat->lit_null;
+      if (e.children.size() == 3) {
+        const ExprP& gi = e.children[2];
+        if (gi->kind != ExprKind::Literal || (gi->dtype.id != TypeId::Int32 && !gi->lit_null)) throw CometError("regexp_extract idx must be an Int32 scalar");
+        if (gi->lit_null) all_null = true;
+        else group = gi->lit_i64;
+      }
+      if (all_null) {
+        Val valid = str_col_validity(idx);
+        (void)valid;
+        out.t = DType::of(TypeId::String);
+        out.rep = Rep::I64;
+        std::string v = newvar("comet::strview");
+        stmt(v + " = comet::strview{(u32)" + locate(idx).second + ", 0u, 0u, 0u};");
+        out.v = v;
+        out.ok = "false";
+        oc.view_src = idx;
+        return true;
+      }
+      const RegexProg prog = compile_regex_captures(pat->lit_bytes, (int)std::max<long long>(std::min<long long>(group, 1 << 20), -(1 << 20)), "regexp_extract");
+      const std::string name = "rxp" + std::to_string(regex_progs++);
+      std::string d = "    static const u32 " + name + "[] = {";
+      for (size_t k = 0; k < prog.words.size(); k++) d += (k ? "," : "") + std::to_string(prog.words[k]) + "u";
+      decls += d + "};\n";
+      g_uses_regex_vm = true;
+      call = "utf8_view_regex(@, " + name + ")";
     } else {
       return false;
     }
@@ -1375,6 +1415,7 @@ struct Gen {
   }
 
   // ---- time zones (csrc/tz.cpp): a region zone's table is a constant array of the kernel; fixed offsets are constants of the expression ----
+  int regex_progs = 0;      // regexp_extract programs declared so far (constants of the kernel, like the zone tables)
   std::map<std::string, std::string> zone_vars;
   std::string zone_table(const std::string& tz) {
     auto it = zone_vars.find(tz);

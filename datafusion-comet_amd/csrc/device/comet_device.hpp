@@ -17,6 +17,10 @@
 #endif
 #include "kparams.h"
 
+// regexp_extract's matcher (comet_regex_vm.hpp, included by the generated sources that call utf8_view_regex)
+template <class P>
+__device__ bool rx_extract(const unsigned int* w, P text, int n, int& m0, int& m1);
+
 namespace comet {
 
 typedef long long i64;
@@ -195,6 +199,19 @@ CDEV strview utf8_view_trim(const CometCol& c, i64 i, int mode) {
   if (mode & 1) while (a < b && p[a] == 0x20) a++;
   if (mode & 2) while (b > a && p[b - 1] == 0x20) b--;
   strview r = {(u32)i, (u32)a, (u32)(b - a), 0u};
+  return r;
+}
+// regexp_extract: the span of one group in the leftmost match (comet_regex_vm.hpp's matcher over the program the host compiled); no match
+// or an unset group = the empty string.  The generated source includes the matcher's header before it calls this (a template: instantiated there).
+template <class W>
+CDEV strview utf8_view_regex(const CometCol& c, i64 i, const W* prog) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j], nbytes = off[j + 1] - lo;
+  const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
+  i32 m0 = -1, m1 = -1;
+  rx_extract(prog, p, nbytes, m0, m1);
+  strview r = {(u32)i, m0 < 0 ? 0u : (u32)m0, m0 < 0 ? 0u : (u32)(m1 - m0), 0u};
   return r;
 }
 // pad (or, with `truncate`, cut) the value to `target` characters: rpad / lpad truncate, read-side padding of CHAR(n) columns does not

@@ -24,6 +24,7 @@ extern const char* const kEmbeddedKParamsHeader;
 extern const char* const kEmbeddedRyuHeader;
 extern const char* const kEmbeddedStrtodHeader;
 extern const char* const kEmbeddedStrtsHeader;
+extern const char* const kEmbeddedRegexVmHeader;
 
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) {
@@ -76,7 +77,7 @@ std::shared_ptr<CodeObject> jit_compile(const std::string& source_in) {
   static const char* nt = getenv("COMET_LD_NT");
   const std::string source = nt ? std::string("#define COMET_LD_NT ") + (atoi(nt) ? "1" : "0") + "\n" + source_in : source_in;
   // the key covers the generated source AND the hand-written headers it instantiates
-  static const uint64_t h2 = fnv1a(toolchain_tag(), fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader, fnv1a(kEmbeddedRyuHeader, fnv1a(kEmbeddedStrtodHeader, fnv1a(kEmbeddedStrtsHeader))))));
+  static const uint64_t h2 = fnv1a(toolchain_tag(), fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader, fnv1a(kEmbeddedRyuHeader, fnv1a(kEmbeddedStrtodHeader, fnv1a(kEmbeddedStrtsHeader, fnv1a(kEmbeddedRegexVmHeader)))))));
   uint64_t h1 = fnv1a(source);
   char keybuf[64];
   snprintf(keybuf, sizeof keybuf, "%016llx_%016llx", (unsigned long long)h1, (unsigned long long)h2);
@@ -118,9 +119,9 @@ std::shared_ptr<CodeObject> jit_compile(const std::string& source_in) {
     }
   }
   hiprtcProgram prog;
-  const char* headers[] = {kEmbeddedDeviceHeader, kEmbeddedKParamsHeader, kEmbeddedRyuHeader, kEmbeddedStrtodHeader, kEmbeddedStrtsHeader};
-  const char* names[] = {"comet_device.hpp", "kparams.h", "comet_ryu.hpp", "comet_strtod.hpp", "comet_strts.hpp"};
-  if (hiprtcCreateProgram(&prog, source.c_str(), "comet_pipeline.hip", 5, headers, names) != HIPRTC_SUCCESS)
+  const char* headers[] = {kEmbeddedDeviceHeader, kEmbeddedKParamsHeader, kEmbeddedRyuHeader, kEmbeddedStrtodHeader, kEmbeddedStrtsHeader, kEmbeddedRegexVmHeader};
+  const char* names[] = {"comet_device.hpp", "kparams.h", "comet_ryu.hpp", "comet_strtod.hpp", "comet_strts.hpp", "comet_regex_vm.hpp"};
+  if (hiprtcCreateProgram(&prog, source.c_str(), "comet_pipeline.hip", 6, headers, names) != HIPRTC_SUCCESS)
     throw CometError("hiprtcCreateProgram failed");
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"};
   hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);

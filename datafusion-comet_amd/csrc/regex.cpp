@@ -32,6 +32,7 @@
 
 #include "plan.hpp"
 #include "regex_unicode_tables.hpp"
+#include "device/regex_vm.hpp"
 
 namespace comet {
 namespace {
@@ -51,11 +52,15 @@ typedef std::shared_ptr<Node> NodeP;
 // node 0 is the entry; an edge leads to another node or (−1) to the class's end
 struct TrieNode { std::vector<std::pair<ByteSet, int>> edges; };
 struct Node {
-  enum Kind { Bytes, Cat, Alt, Repeat, Bol, Eol, Empty, Trie, WordB, NotWordB } kind = Empty;
+  // OneChar: ONE scalar value — kids[0] is its byte-level automaton (what the search DFA is built from), `set` / `wide` its members as scalar
+  // values (what the capture program tests); Group: a capturing group, `min` = its number
+  enum Kind { Bytes, Cat, Alt, Repeat, Bol, Eol, Empty, Trie, WordB, NotWordB, OneChar, Group } kind = Empty;
   ByteSet set{};
   std::vector<NodeP> kids;
   int min = 0, max = -1;   // Repeat: max −1 = unbounded
+  bool lazy = false;       // Repeat: x*? prefers to stop (the same language; another capture)
   std::vector<TrieNode> trie;
+  std::vector<std::pair<int, int>> wide;   // OneChar: members beyond ASCII, sorted ranges
 };
 NodeP mk(Node::Kind k) {
   auto n = std::make_shared<Node>();
@@ -65,6 +70,13 @@ NodeP mk(Node::Kind k) {
 NodeP mk_bytes(const ByteSet& s) {
   auto n = mk(Node::Bytes);
   n->set = s;
+  return n;
+}
+NodeP mk_char(NodeP bytes, const ByteSet& ascii, std::vector<std::pair<int, int>> wide) {
+  auto n = mk(Node::OneChar);
+  n->kids.push_back(std::move(bytes));
+  n->set = ascii;
+  n->wide = std::move(wide);
   return n;
 }
 NodeP mk_cat(std::vector<NodeP> kids) {
@@ -170,6 +182,8 @@ struct Parser {
   bool dotall = false;    // a leading (?s): `.` matches \n too
   bool multiline = false; // a leading (?m): ^ also matches after a \n, $ also before one
   bool has_wordb = false; // the pattern holds \b / \B
+  int ngroups = 0;        // capturing groups seen so far
+  bool bytes_too = true;  // build the byte-level automaton of every class (the search DFA's input; the capture program tests scalar values instead)
   explicit Parser(const std::string& s) : p(s) {
     // leading flags (?i) (?s) (?m), alone or combined: they hold for the whole pattern
     if (p.compare(0, 2, "(?") == 0) {
@@ -237,7 +251,8 @@ struct Parser {
         if (mn > 64 || mx > 64 || (mx >= 0 && mx < mn)) fail("a repetition count above 64 (or max below min)");
         i = j + 1;
       } else break;
-      if (more() && (p[i] == '?')) i++;                    // lazy: same language
+      bool lazy = false;
+      if (more() && (p[i] == '?')) { i++; lazy = true; }   // lazy: the same language, another preference (captures only)
       else if (more() && p[i] == '+') fail("possessive quantifiers");
       if (a->kind == Node::Bol || a->kind == Node::Eol) fail("a quantifier on an anchor");
       if (++stacked + depth > 100) fail("quantifiers stacked more than 100 deep");
@@ -245,6 +260,7 @@ struct Parser {
       r->kids.push_back(a);
       r->min = mn;
       r->max = mx;
+      r->lazy = lazy;
       a = r;
     }
     return a;
@@ -292,20 +308,27 @@ struct Parser {
   // one literal scalar value as an item: its UTF-8 bytes in sequence (under (?i): an ASCII letter in both cases plus its fold partner)
   NodeP literal_item(int cp) {
     if (icase && cp >= 0x80) fail("case-insensitive matching of a non-ASCII literal");
-    if (icase && is_letter(cp)) {
-      ByteSet s{};
-      bs_add(s, cp | 0x20);
-      bs_add(s, cp & ~0x20);
-      NodeP extra = fold_partner(cp);
-      return extra ? mk_alt({mk_bytes(s), extra}) : mk_bytes(s);
-    }
+    if (icase && is_letter(cp)) return folded_letter(cp);
     std::vector<NodeP> seq;
     for (unsigned char b : utf8_of(cp)) {
       ByteSet s{};
       bs_add(s, b);
       seq.push_back(mk_bytes(s));
     }
-    return mk_cat(seq);
+    ByteSet as{};
+    if (cp < 128) bs_add(as, cp);
+    return mk_char(mk_cat(seq), as, cp < 128 ? std::vector<std::pair<int, int>>{} : std::vector<std::pair<int, int>>{{cp, cp}});
+  }
+  // an ASCII letter under (?i): both cases, and the scalar value beyond ASCII that folds to it (k, s)
+  static NodeP folded_letter(int b) {
+    ByteSet s{};
+    bs_add(s, b | 0x20);
+    bs_add(s, b & ~0x20);
+    NodeP extra = fold_partner(b);
+    std::vector<std::pair<int, int>> wide;
+    if ((b | 0x20) == 'k') wide.emplace_back(0x212A, 0x212A);
+    if ((b | 0x20) == 's') wide.emplace_back(0x17F, 0x17F);
+    return mk_char(extra ? mk_alt({mk_bytes(s), extra}) : mk_bytes(s), s, wide);
   }
   // the byte of an escaped punctuation / control character, or -1
   int simple_escape(char c) const {
@@ -328,21 +351,26 @@ struct Parser {
       if (++depth > 100) fail("groups nested more than 100 deep");
       struct Leave { int& d; ~Leave() { d--; } } leave{depth};
       i++;
+      int number = 0;
       if (more() && p[i] == '?') {
         if (i + 1 < p.size() && p[i + 1] == ':') i += 2;
         else fail("group flags, named groups and look-around ((?…) other than (?:…) and a leading (?i))");
-      }
+      } else number = ++ngroups;
       NodeP inner = parse_alt();
       if (!more() || p[i] != ')') fail("an unclosed group");
       i++;
-      return inner;
+      if (!number) return inner;
+      auto g = mk(Node::Group);
+      g->kids.push_back(inner);
+      g->min = number;
+      return g;
     }
     if (ch == '[') return parse_class();
     if (ch == '.') {
       i++;
       ByteSet s = bs_range(0, 127);
       if (!dotall) s[0] &= ~((uint64_t)1 << '\n');
-      return one_char(s, true);
+      return mk_char(one_char(s, true), s, {{128, 0x10FFFF}});
     }
     if (ch == '^') { i++; return mk(Node::Bol); }
     if (ch == '$') { i++; return mk(Node::Eol); }
@@ -387,18 +415,15 @@ struct Parser {
       i += 2;
       ByteSet s{};
       bs_add(s, b);
-      return mk_bytes(s);
+      return mk_char(mk_bytes(s), s, {});
     }
     if (icase && ch >= 0x80) fail("case-insensitive matching of a non-ASCII literal");
     if (icase && is_letter(ch)) {
       i++;
-      ByteSet s{};
-      bs_add(s, ch | 0x20);
-      bs_add(s, ch & ~0x20);
-      NodeP extra = fold_partner(ch);
-      return extra ? mk_alt({mk_bytes(s), extra}) : mk_bytes(s);
+      return folded_letter(ch);
     }
     // a literal character: its UTF-8 bytes in sequence form ONE item (a quantifier after "é" repeats both bytes)
+    const size_t first = i;
     std::vector<NodeP> seq;
     do {
       ByteSet s{};
@@ -406,7 +431,11 @@ struct Parser {
       seq.push_back(mk_bytes(s));
       i++;
     } while (ch >= 0x80 && more() && ((unsigned char)p[i] & 0xC0) == 0x80);
-    return mk_cat(seq);
+    size_t at = first;
+    const int cp = ch < 0x80 ? ch : decode_utf8_at(at);
+    ByteSet as{};
+    if (cp < 128) bs_add(as, cp);
+    return mk_char(mk_cat(seq), as, cp < 128 ? std::vector<std::pair<int, int>>{} : std::vector<std::pair<int, int>>{{cp, cp}});
   }
   // one scalar value of the pattern at p[i] (UTF-8 decoded; the pattern is valid UTF-8 — it arrived as a Java String)
   int decode_utf8_at(size_t& at) const {
@@ -542,6 +571,7 @@ struct Parser {
       if (next <= 0x10FFFF) rest.emplace_back(next, 0x10FFFF);
       wide = rest;
     }
+    if (!bytes_too) return mk_char(mk(Node::Empty), s, wide);
     std::vector<NodeP> alts;
     bool any = false;
     for (int b = 0; b < 128; b++) any |= bs_has(s, b);
@@ -549,8 +579,8 @@ struct Parser {
     if (wide.size() == 1 && wide[0].first == 128 && wide[0].second == 0x10FFFF) alts.push_back(multibyte());
     else if (wide.size() > 24) alts.push_back(class_trie(wide));      // \w, \W, \D, [^…] of those: one shared automaton instead of a thousand sequences
     else for (auto& r : wide) utf8_range_items(r.first, r.second, alts);
-    if (alts.empty()) return mk_bytes(ByteSet{});     // a class nothing can match
-    return mk_alt(alts);
+    if (alts.empty()) return mk_char(mk_bytes(ByteSet{}), s, wide);     // a class nothing can match
+    return mk_char(mk_alt(alts), s, wide);
   }
   // scalar values [lo, hi] (beyond ASCII) as alternatives of byte-range sequences: split at the surrogate gap and at the encoded-length
   // boundaries, then until the continuation bytes of every piece span full ranges (the construction of the crate's utf8-ranges)
@@ -610,6 +640,7 @@ struct Nfa {
 int build(Nfa& nfa, const NodeP& n, int next) {
   switch (n->kind) {
     case Node::Empty: return next;
+    case Node::OneChar: case Node::Group: return build(nfa, n->kids[0], next);
     case Node::Bytes: {
       const int s = nfa.add(NState::Byte);
       nfa.st[(size_t)s].set = n->set;
@@ -987,6 +1018,174 @@ RegexDfa compile_rlike(const std::string& pattern) {
   dfa.nstates = (int)sets.size();
   dfa.trans.resize((size_t)dfa.nstates * NC * 2, 0);
   return dfa;
+}
+
+// ---- regexp_extract: the capture program of device/regex_vm.hpp ----
+namespace {
+bool nullable(const NodeP& n) {
+  switch (n->kind) {
+    case Node::Empty: case Node::Bol: case Node::Eol: case Node::WordB: case Node::NotWordB: return true;
+    case Node::Bytes: case Node::Trie: case Node::OneChar: return false;
+    case Node::Cat: for (auto& k : n->kids) if (!nullable(k)) return false; return true;
+    case Node::Alt: for (auto& k : n->kids) if (nullable(k)) return true; return false;
+    case Node::Repeat: return n->min == 0 || nullable(n->kids[0]);
+    case Node::Group: return nullable(n->kids[0]);
+  }
+  return false;
+}
+struct ProgBuilder {
+  const std::string& pattern;
+  const char* fn;
+  int wanted;
+  std::vector<std::array<uint32_t, 2>> ins;
+  struct Cls { ByteSet ascii; std::vector<std::pair<int, int>> wide; };
+  std::vector<Cls> classes;
+  [[noreturn]] void fail(const std::string& why) const {
+    throw CometError(std::string(fn) + " pattern '" + pattern + "' is not supported by the MI355X native engine: " + why);
+  }
+  int add(uint32_t kind, int out, uint32_t arg) {
+    if ((int)ins.size() >= kRxMaxInstr) fail("it needs more than " + std::to_string(kRxMaxInstr) + " matcher instructions (long counted repetitions)");
+    ins.push_back({kind | ((uint32_t)out << 8), arg});
+    return (int)ins.size() - 1;
+  }
+  int add_class(const ByteSet& ascii, std::vector<std::pair<int, int>> wide) {
+    // sorted, merged ranges (the matcher's binary search wants them disjoint)
+    std::sort(wide.begin(), wide.end());
+    std::vector<std::pair<int, int>> m;
+    for (auto& r : wide) {
+      if (!m.empty() && r.first <= m.back().second + 1) m.back().second = std::max(m.back().second, r.second);
+      else m.push_back(r);
+    }
+    for (size_t c = 0; c < classes.size(); c++)
+      if (classes[c].ascii == ascii && classes[c].wide == m) return (int)c;
+    classes.push_back({ascii, m});
+    return (int)classes.size() - 1;
+  }
+  // the fragment for `n` that continues at instruction `next`; → its entry
+  int build(const NodeP& n, int next) {
+    switch (n->kind) {
+      case Node::Empty: return next;
+      case Node::Bytes: case Node::Trie: fail("internal: a byte-level item outside a character");
+      case Node::OneChar: {
+        int members = 0, only = -1;
+        for (int b = 0; b < 128; b++) if (bs_has(n->set, b)) { members++; only = b; }
+        if (n->wide.empty() && members == 1) return add(1, next, (uint32_t)only);
+        if (members == 0 && n->wide.size() == 1 && n->wide[0].first == n->wide[0].second) return add(1, next, (uint32_t)n->wide[0].first);
+        return add(2, next, (uint32_t)add_class(n->set, n->wide));
+      }
+      case Node::Bol: return add(5, next, 0);
+      case Node::Eol: return add(6, next, 0);
+      case Node::WordB: return add(7, next, 0);
+      case Node::NotWordB: return add(8, next, 0);
+      case Node::Group: {
+        if (n->min != wanted) return build(n->kids[0], next);
+        const int close = add(4, next, 1);
+        const int body = build(n->kids[0], close);
+        return add(4, body, 0);
+      }
+      case Node::Cat: {
+        int cur = next;
+        for (size_t k = n->kids.size(); k-- > 0;) cur = build(n->kids[k], cur);
+        return cur;
+      }
+      case Node::Alt: {
+        int cur = build(n->kids.back(), next);
+        for (size_t k = n->kids.size() - 1; k-- > 0;) {
+          const int a = build(n->kids[k], next);
+          cur = add(3, a, (uint32_t)cur);
+        }
+        return cur;
+      }
+      case Node::Repeat: {
+        const NodeP& kid = n->kids[0];
+        // (the crate compiles x* over an x that can match nothing as (x+)? to keep its preference order; such patterns are refused instead)
+        if (n->max < 0 && nullable(kid)) fail("an unbounded repetition of something that can match the empty string");
+        auto split = [&](int body, int exit) { return n->lazy ? add(3, exit, (uint32_t)body) : add(3, body, (uint32_t)exit); };
+        int cur = next;
+        if (n->max < 0) {
+          const int loop = add(3, 0, 0);
+          const int body = build(kid, loop);
+          ins[(size_t)loop] = n->lazy ? std::array<uint32_t, 2>{3u | ((uint32_t)next << 8), (uint32_t)body} : std::array<uint32_t, 2>{3u | ((uint32_t)body << 8), (uint32_t)next};
+          cur = loop;
+        } else {
+          for (int k = 0; k < n->max - n->min; k++) {
+            const int body = build(kid, cur);
+            cur = split(body, next);
+          }
+        }
+        for (int k = 0; k < n->min; k++) cur = build(kid, cur);
+        return cur;
+      }
+    }
+    return next;
+  }
+};
+}  // namespace
+
+RegexProg compile_regex_captures(const std::string& pattern, int group, const char* fn) {
+  Parser ps(pattern);
+  ps.bytes_too = false;
+  NodeP ast;
+  try {
+    ast = ps.parse_alt();
+    if (ps.more()) ps.fail("an unmatched ')'");
+  } catch (const CometError& e) {
+    // (the parser names RLIKE: the same syntax, another function)
+    std::string m = e.what();
+    const size_t at = m.find("RLIKE pattern");
+    if (at != std::string::npos) m.replace(at, 5, fn);
+    throw CometError(m);
+  }
+  // regexp_extract_common.rs:85-92
+  if (group < 0 || group > ps.ngroups)
+    throw CometError("The value of parameter `idx` in `" + std::string(fn) + "` is invalid: Expects group index between 0 and " + std::to_string(ps.ngroups) + ", but got " + std::to_string(group) + ".");
+  if (ps.has_wordb && ps.multiline) throw CometError(std::string(fn) + " pattern '" + pattern + "': \\b under (?m) is not supported by the MI355X native engine");
+  ProgBuilder b{pattern, fn, group, {}, {}};
+  const int match = b.add(0, 0, 0);
+  int entry;
+  if (group == 0) {
+    const int close = b.add(4, match, 1);
+    const int body = b.build(ast, close);
+    entry = b.add(4, body, 0);
+  } else entry = b.build(ast, match);
+  uint32_t word_class = 0;
+  if (ps.has_wordb) {
+    ByteSet as{};
+    std::vector<std::pair<int, int>> wide;
+    Parser::add_perl_class('w', as, wide);
+    word_class = (uint32_t)b.add_class(as, wide);
+  }
+  RegexProg prog;
+  prog.ngroups = ps.ngroups;
+  std::vector<uint32_t>& w = prog.words;
+  w.assign(6, 0);
+  w[0] = (uint32_t)b.ins.size();
+  w[1] = (uint32_t)entry;
+  w[2] = (ps.multiline ? 1u : 0u) | (ps.has_wordb ? 2u : 0u);
+  w[4] = word_class;
+  for (auto& i : b.ins) { w.push_back(i[0]); w.push_back(i[1]); }
+  w[3] = (uint32_t)w.size();
+  const size_t table = w.size();
+  w.resize(table + 6 * b.classes.size(), 0);
+  for (size_t c = 0; c < b.classes.size(); c++) {
+    for (int k = 0; k < 2; k++) {
+      w[table + 6 * c + 2 * (size_t)k] = (uint32_t)b.classes[c].ascii[(size_t)k];
+      w[table + 6 * c + 2 * (size_t)k + 1] = (uint32_t)(b.classes[c].ascii[(size_t)k] >> 32);
+    }
+    w[table + 6 * c + 4] = (uint32_t)w.size();
+    w[table + 6 * c + 5] = (uint32_t)b.classes[c].wide.size();
+    for (auto& r : b.classes[c].wide) { w.push_back((uint32_t)r.first); w.push_back((uint32_t)r.second); }
+  }
+  if (w.size() > 16384) throw CometError(std::string(fn) + " pattern '" + pattern + "' is too large for the MI355X native engine");
+  return prog;
+}
+
+bool regex_prog_extract(const RegexProg& prog, const uint8_t* s, size_t n, int32_t* start, int32_t* len) {
+  int32_t m0 = -1, m1 = -1;
+  const bool hit = rx_extract(prog.words.data(), s, (int32_t)n, m0, m1);
+  *start = m0 < 0 ? 0 : m0;
+  *len = m0 < 0 ? 0 : m1 - m0;
+  return hit;
 }
 
 bool regex_dfa_match(const RegexDfa& d, const uint8_t* s, size_t n) {

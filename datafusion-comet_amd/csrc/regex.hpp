@@ -22,4 +22,14 @@ RegexDfa compile_rlike(const std::string& pattern);
 // host-side walk of the same tables the device walks (tests)
 bool regex_dfa_match(const RegexDfa& d, const uint8_t* s, size_t n);
 
+// regexp_extract (string_funcs/regexp_extract.rs): the pattern as a program of device/regex_vm.hpp's matcher that reports group `group`;
+// `fn` names the function in refusals.  Throws the reference's message for a group index out of range (regexp_extract_common.rs:85-92).
+struct RegexProg {
+  std::vector<uint32_t> words;
+  int ngroups = 0;
+};
+RegexProg compile_regex_captures(const std::string& pattern, int group, const char* fn);
+// the device's matcher run on the host (tests): → matched?; [*start, *start + *len) = the group's bytes (empty when unset / no match)
+bool regex_prog_extract(const RegexProg& prog, const uint8_t* s, size_t n, int32_t* start, int32_t* len);
+
 }  // namespace comet

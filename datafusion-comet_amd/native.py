@@ -147,6 +147,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_zone_table.argtypes = [c.c_char_p, c.c_void_p, c.c_int64]
     lib.comet_rlike_match.restype = c.c_int32
     lib.comet_rlike_match.argtypes = [c.c_char_p, c.c_char_p, c.c_size_t]
+    lib.comet_regexp_extract_host.restype = c.c_int32
+    lib.comet_regexp_extract_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32)]
     lib.comet_page_decompress.restype = c.c_int32
     lib.comet_page_decompress.argtypes = [c.c_int32, c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]
     lib.comet_snappy_inflate_pages.restype = c.c_int64
@@ -1176,6 +1178,16 @@ def rlike_match(pattern: str, value: str) -> bool:
     if rc < 0:
         _raise_last(0)
     return rc == 1
+
+
+def regexp_extract_host(pattern: str, group: int, value: str):
+    """the device's capture matcher on the host (comet_regexp_extract_host): → (matched, the group's text)"""
+    v = value.encode()
+    a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+    rc = lib().comet_regexp_extract_host(pattern.encode(), group, v, len(v), ctypes.byref(a), ctypes.byref(b))
+    if rc < 0:
+        _raise_last(0)
+    return rc == 1, v[a.value:a.value + b.value].decode()
 
 
 def parquet_host_plain_values(plan: bytes, column: int) -> bytes:

@@ -195,6 +195,13 @@ int64_t comet_parquet_host_plain_values(const uint8_t* plan, size_t plan_len, in
  * -2 and comet_last_error(0) for a pattern outside the subset.  Needs no GPU; the device walks the same tables. */
 int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t value_len);
 
+/* ---- regexp_extract's matcher (csrc/regex.cpp compile_regex_captures + csrc/device/regex_vm.hpp) — diagnostic entry -----------------------
+ * Compiles `pattern` for capture group `group` the way the planner does for ScalarFunc regexp_extract (string_funcs/regexp_extract.rs:
+ * the crate's leftmost match, one group's span) and runs the device's matcher over `value` on the host: 1 a match, 0 none (the result is
+ * the empty string either way when the group is unset), [*start, *start + *len) = the group's bytes inside `value`; -2 and
+ * comet_last_error(0) for a pattern outside the subset or a group index out of range (the reference's message).  Needs no GPU. */
+int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* start, int32_t* len);
+
 /* ---- time zones (csrc/tz.cpp) -------------------------------------------------------------------------------------------------------------
  * The table a Cast / date-part expression with `zone` as its time zone is planned with: { n, offset before the first transition, first instant
  * the table does not answer, n transition instants (UTC seconds), n offsets (seconds east of UTC) } — read from the system's time-zone

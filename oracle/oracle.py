@@ -502,6 +502,34 @@ class Evaluator:
             for i in range(n):
                 out[i] = (a.values[i].upper() if f == "upper" else a.values[i].lower()) if a.ok()[i] else None
             return Col(S.T_STRING, out, a.valid)
+        if f == "regexp_extract":
+            # spark_regexp_extract (string_funcs/regexp_extract.rs:38-108; arguments regexp_extract_common.rs:36-107): group `idx` (default 1) of the
+            # FIRST match of the pattern (the crate's Regex::captures_read: leftmost, alternatives / repetitions preferred in pattern order); the empty
+            # string without a match or when the group took no part in it; NULL for a NULL subject, pattern or idx; idx outside 0..groups is an error.
+            # The crate is not here: Python's `re` — a backtracking engine, i.e. the same leftmost, preference-ordered match — stands in for it on the
+            # syntax both read alike ($ is "at the very end" in the crate: \Z here; \z likewise; \d \w \s Unicode-aware in both).
+            import re
+            a = self.eval(e.children[0], cols, n)
+            pat = e.children[1].value
+            idx = e.children[2].value if len(e.children) > 2 else 1
+            if pat is None or idx is None:
+                return Col(S.T_STRING, np.array([None] * n, dtype=object), np.zeros(n, bool))
+            multiline = re.match(r"\(\?[is]*m[ism]*\)", pat) is not None
+            py = (pat if multiline else re.sub(r"(?<!\\)\$", r"\\Z", pat)).replace("\\z", "\\Z")
+            try:
+                rx = re.compile(py)
+            except re.error as err:
+                raise OracleError("The value of parameter `regexp` in `regexp_extract` is invalid: '%s' (%s)" % (pat, err))
+            if idx < 0 or idx > rx.groups:
+                raise OracleError("The value of parameter `idx` in `regexp_extract` is invalid: Expects group index between 0 and %d, but got %d." % (rx.groups, idx))
+            out = np.empty(n, dtype=object)
+            for i in range(n):
+                if a.ok()[i]:
+                    m = rx.search(a.values[i])
+                    out[i] = (m.group(int(idx)) or "") if m else ""
+                else:
+                    out[i] = None
+            return Col(S.T_STRING, out, a.valid)
         if f == "concat":
             # Spark's Concat (datafusion-spark's SparkConcat, jni_api.rs:70): the arguments' bytes one after the other; NULL as soon as one is NULL
             args = [self.eval(c, cols, n) for c in e.children]

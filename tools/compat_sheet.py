@@ -101,6 +101,8 @@ def probes():
         "Hour": (S.time_part("hour", S.cast(d, S.T_TIMESTAMP)), "any time zone of the database"), "Minute": (S.time_part("minute", S.cast(d, S.T_TIMESTAMP)), ""),
         "Second": (S.time_part("second", S.cast(d, S.T_TIMESTAMP)), ""),
         "Like": (S.like(s, L("a%_b", S.T_STRING)), "% and _, backslash escapes"), "RLike": (S.rlike(s, L("^ab+c$", S.T_STRING)), "the byte-exact subset incl. \\d \\w \\b (Unicode 16 tables of the crate); \\p{..} refused by name"),
+        "RegExpExtract": (f("regexp_extract", [s, L(r"(\d+)-(\w+)", S.T_STRING), L(2, S.T_INT32)], S.T_STRING),
+                          "what the JVM sends under spark.comet.expression.RegExpExtract.allowIncompatible (literal pattern and idx): an output column; the crate's leftmost, preference-ordered match by a matcher of ≤ 64 instructions; \\p{..}, named groups, scoped flags refused by name"),
         "StartsWith": (f("starts_with", [s, L("ab", S.T_STRING)], S.T_BOOL), ""), "EndsWith": (f("ends_with", [s, L("ab", S.T_STRING)], S.T_BOOL), ""),
         "Contains": (f("contains", [s, L("ab", S.T_STRING)], S.T_BOOL), ""),
         "Substring": (f("substring", [s, L(2, S.T_INT32), L(3, S.T_INT32)], S.T_STRING), "literal bounds"), "Left": (f("substring", [s, L(1, S.T_INT32), L(3, S.T_INT32)], S.T_STRING), "serialized as Substring"),
