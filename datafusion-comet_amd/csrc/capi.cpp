@@ -563,6 +563,15 @@ int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint
   });
 }
 
+int32_t comet_split_host(const char* pattern, int32_t limit, const uint8_t* value, size_t value_len, int32_t* starts, int32_t* lens, int32_t cap) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    const RegexProg prog = compile_regex_captures(pattern ? pattern : "", 0, "split");
+    const auto pieces = regex_prog_split(prog, value, value_len, limit);
+    for (size_t k = 0; k < pieces.size() && (int32_t)k < cap; k++) { starts[k] = pieces[k].first; lens[k] = pieces[k].second; }
+    return (int32_t)pieces.size();
+  });
+}
+
 int64_t comet_snappy_view_read(const uint8_t* src, size_t src_len, int32_t max_elems, const int64_t* offsets, int32_t n, uint8_t* out) {
   return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
     pq::SnappyView v;

@@ -189,6 +189,62 @@ const char* store_ctype(const DType& t) {
 // table carries every field of its struct columns as a column of its own (DType::virt_parent / virt_kid), so the expression folds into a
 // plain column reference.  `g_source_cols`: the Bound expressions of the source's columns while a chain is being folded.
 thread_local const std::vector<ExprP>* g_source_cols = nullptr;
+// split(<Utf8 source column>, <pattern>, <limit>) (string_funcs/split.rs; strings.scala:598-631 sends it under
+// spark.comet.expression.StringSplit.allowIncompatible): a list<string> column DERIVED from the source table — the executor computes it before the
+// fused kernel runs (exec.cpp extend_derived), the chain addresses it as column (source columns + k).  `g_derived`: where a fold notes them.
+thread_local std::vector<DerivedCol>* g_derived = nullptr;
+ExprP lower_split(const ExprP& e) {
+  if (e->children.size() < 2 || e->children.size() > 3) throw CometError("split expects 2 or 3 arguments (string, pattern, [limit]), got " + std::to_string(e->children.size()));
+  const ExprP &subject = e->children[0], &pat = e->children[1];
+  if (!g_derived || !g_source_cols) throw CometError("split is supported in Projection / Filter chains only");
+  const int nsrc = (int)g_source_cols->size();
+  if (subject->kind != ExprKind::Bound || subject->bound_index < 0 || subject->bound_index >= nsrc || !subject->has_dtype || subject->dtype.id != TypeId::String)
+    throw CometError("split is supported over a Utf8 COLUMN of the source (not over a computed string) by the MI355X native engine");
+  if (pat->kind != ExprKind::Literal || (pat->dtype.id != TypeId::String && !pat->lit_null)) throw CometError("split pattern must be a string literal");
+  int limit = -1;
+  if (e->children.size() == 3) {
+    const ExprP& l = e->children[2];
+    if (l->kind != ExprKind::Literal || l->lit_null || l->dtype.id != TypeId::Int32) throw CometError("split limit argument must be an Int32 scalar");
+    limit = (int)std::max<long long>(std::min<long long>(l->lit_i64, 0x7fffffffLL), -1);
+  }
+  if (pat->lit_null) throw CometError("split with a NULL pattern is not supported by the MI355X native engine");
+  DerivedCol dc;
+  dc.kind = 1;
+  dc.src = subject->bound_index;
+  dc.limit = limit;
+  try {
+    dc.prog = compile_regex_captures(pat->lit_bytes, 0, "split").words;
+  } catch (const CometError& err) {
+    const std::string m = err.what();
+    if (m.find("not supported") != std::string::npos) throw;
+    throw CometError("Invalid regex pattern '" + pat->lit_bytes + "': " + m);      // split.rs:201-203
+  }
+  dc.type.id = TypeId::List;
+  DType elem = DType::of(TypeId::String);
+  dc.type.kids.push_back(elem);
+  dc.type.kid_names.push_back("item");
+  dc.type.kid_nullable.push_back(false);
+  for (size_t k = 0; k < g_derived->size(); k++) {
+    const DerivedCol& o = (*g_derived)[k];
+    if (o.kind == dc.kind && o.src == dc.src && o.limit == dc.limit && o.prog == dc.prog) {
+      auto b = std::make_shared<Expr>();
+      b->kind = ExprKind::Bound;
+      b->proto_tag = 3;
+      b->bound_index = nsrc + (int)k;
+      b->dtype = o.type;
+      b->has_dtype = true;
+      return b;
+    }
+  }
+  g_derived->push_back(dc);
+  auto b = std::make_shared<Expr>();
+  b->kind = ExprKind::Bound;
+  b->proto_tag = 3;
+  b->bound_index = nsrc + (int)g_derived->size() - 1;
+  b->dtype = dc.type;
+  b->has_dtype = true;
+  return b;
+}
 ExprP lower_struct_field(const ExprP& e, const ExprP& child) {
   if (child->kind != ExprKind::Bound || !child->has_dtype || child->dtype.id != TypeId::Struct)
     throw CometError("GetStructField of anything but a struct COLUMN is not supported yet");
@@ -205,6 +261,10 @@ ExprP substitute(const ExprP& e, const std::vector<ExprP>& cols, std::map<const 
   ExprP out;
   if (e->kind == ExprKind::GetStructField && e->children.size() == 1) {
     out = lower_struct_field(e, substitute(e->children[0], cols, memo));
+  } else if (e->kind == ExprKind::ScalarFunc && e->func == "split") {
+    auto n = std::make_shared<Expr>(*e);
+    for (auto& c : n->children) c = substitute(c, cols, memo);
+    out = lower_split(n);
   } else if (e->kind == ExprKind::Bound) {
     if (e->bound_index < 0 || (size_t)e->bound_index >= cols.size())
       throw CometError("Column index " + std::to_string(e->bound_index) + " is out of bound. Schema has " +
@@ -2555,6 +2615,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   }
   const std::vector<ExprP> source_cols = cols;
   struct SourceColsScope { SourceColsScope(const std::vector<ExprP>* c) { g_source_cols = c; } ~SourceColsScope() { g_source_cols = nullptr; } } source_cols_scope(&source_cols);
+  struct DerivedScope { DerivedScope(std::vector<DerivedCol>* c) { g_derived = c; } ~DerivedScope() { g_derived = nullptr; } } derived_scope(&d.derived);
   std::vector<ExprP> preds;
   const Operator* agg = nullptr;
   std::vector<ExprP> group_exprs;
@@ -2611,7 +2672,16 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     }
   }
 
-  Gen g(d.in_types, in_has_validity);
+  // the derived columns follow the source's: a split is NULL where its subject is
+  std::vector<bool> valid_all = in_has_validity;
+  for (auto& dc : d.derived) {
+    d.in_types.push_back(dc.type);
+    valid_all.push_back(in_has_validity[(size_t)dc.src]);
+  }
+  if (!d.derived.empty() && agg) throw CometError("split inside an aggregate's chain is not supported by the MI355X native engine yet");
+  if (d.in_types.size() > COMET_MAX_IN) throw CometError("too many scan columns for one GPU pipeline");
+  const std::vector<bool>& in_has_validity_all = valid_all;
+  Gen g(d.in_types, in_has_validity_all);
   if (str_fixed_len) g.str_fixed_len = *str_fixed_len;
   if (const char* e = getenv("COMET_GEN_EAGER")) g.eager_loads = atoi(e) != 0;
   g.pipelined = agg != nullptr;   // aggregate sinks prefetch tile t+1's first-stage columns while computing tile t
@@ -2637,7 +2707,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     d.sink = SinkKind::Output;
     std::vector<Val> outs;
     // outputs are evaluated in the emit kernel (per surviving row); predicates in the mask kernel.
-    Gen ge(d.in_types, in_has_validity);
+    Gen ge(d.in_types, in_has_validity_all);
     if (str_fixed_len) ge.str_fixed_len = *str_fixed_len;
     for (auto& c : cols) {
       // (… and so is a nested column: its rows are gathered by the executor, children and all — exec.cpp take_nested)
@@ -2652,7 +2722,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
         v.t = d.in_types[(size_t)src];
         v.rep = Rep::I64;
         v.v = "idx[r]";
-        if (in_has_validity[(size_t)src]) v.ok = "comet::ld_valid(prm.in[" + std::to_string(ge.locate(src).first) + "], idx[r])";
+        if (in_has_validity_all[(size_t)src]) v.ok = "comet::ld_valid(prm.in[" + std::to_string(ge.locate(src).first) + "], idx[r])";
         v = ge.named(v);
         outs.push_back(v);
         OutCol oc;

@@ -39,6 +39,17 @@ struct OutCol {
   bool pad_left = false;
 };
 
+// A column the executor computes over the chain's SOURCE table before the fused kernel runs, addressed by the chain like a source column
+// (in_types holds it behind the source's own columns): today split(<Utf8 column>, <pattern literal>, <limit literal>) → list<string>,
+// which the chain passes through by row index like any nested column.
+struct DerivedCol {
+  int kind = 0;                     // 1: split
+  int src = -1;                     // the source column
+  std::vector<uint32_t> prog;       // split: the pattern as a group-0 program of device/regex_vm.hpp
+  int limit = -1;
+  DType type;
+};
+
 // How the host must treat each group-key word / accumulator word of a grouped aggregate.
 struct PipelineDesc {
   SinkKind sink = SinkKind::Output;
@@ -48,7 +59,8 @@ struct PipelineDesc {
   int NK = 0;                      // key words (grouped)
   int NPW = 0;                     // private limb-form words per group (grouped)
   int lds_cap = 0;
-  std::vector<DType> in_types;     // Scan fields
+  std::vector<DType> in_types;     // Scan fields (behind them: the derived columns, in order)
+  std::vector<DerivedCol> derived; // columns the executor computes over the source before the launch (split)
   std::vector<bool> in_used;       // columns the kernels actually read
   std::vector<OutCol> out_cols;    // output schema in order
   // raise sites of this pipeline's kernels whose expression carries a QueryContext: the executor attaches it to the error (the site ids in the

@@ -19,7 +19,7 @@
 
 // regexp_extract's matcher (comet_regex_vm.hpp, included by the generated sources that call utf8_view_regex)
 template <class P>
-__device__ bool rx_extract(const unsigned int* w, P text, int n, int& m0, int& m1);
+__device__ bool rx_search(const unsigned int* w, P text, int n, int from, int& m0, int& m1);
 
 namespace comet {
 
@@ -210,7 +210,7 @@ CDEV strview utf8_view_regex(const CometCol& c, i64 i, const W* prog) {
   const i32 lo = off[j], nbytes = off[j + 1] - lo;
   const COMET_GLOBAL u8* p = (const COMET_GLOBAL u8*)c.aux + lo;
   i32 m0 = -1, m1 = -1;
-  rx_extract(prog, p, nbytes, m0, m1);
+  rx_search(prog, p, nbytes, 0, m0, m1);
   strview r = {(u32)i, m0 < 0 ? 0u : (u32)m0, m0 < 0 ? 0u : (u32)(m1 - m0), 0u};
   return r;
 }

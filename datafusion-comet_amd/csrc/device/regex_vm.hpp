@@ -112,9 +112,10 @@ RXVM_FN void rx_add(const rx_u32* w, RxList& l, RxStack& st, rx_u32 pc, rx_i32 p
   }
 }
 
+// The leftmost match that starts at or behind byte `from` (a character boundary; what lies before it is still seen by ^, \b and (?m)).
 // → matched?; [m0, m1) = the wanted group's bytes, m0 < 0 when the group took no part in the match
 template <class P>
-RXVM_ENTRY bool rx_extract(const rx_u32* w, P text, rx_i32 n, rx_i32& m0, rx_i32& m1) {
+RXVM_ENTRY bool rx_search(const rx_u32* w, P text, rx_i32 n, rx_i32 from, rx_i32& m0, rx_i32& m1) {
   RxList la, lb;
   RxStack st;
   RxList* cl = &la;
@@ -123,19 +124,26 @@ RXVM_ENTRY bool rx_extract(const rx_u32* w, P text, rx_i32 n, rx_i32& m0, rx_i32
   const rx_u32 wcls = w[4], entry = w[1];
   bool matched = false;
   m0 = m1 = -1;
-  rx_i32 pos = 0, len0 = 0, len1 = 0;
+  if (from > n) return false;
+  rx_i32 pos = from, len0 = 0, len1 = 0;
   rx_u32 cp0 = 0, cp1 = 0;
-  if (n > 0) cp0 = rx_decode(text, 0, n, len0);
+  if (pos < n) cp0 = rx_decode(text, pos, n, len0);
   RxAt at;
-  at.start = true;
-  at.end = n == 0;
-  at.after_nl = false;
-  at.before_nl = n > 0 && cp0 == (rx_u32)'\n';
+  at.start = pos == 0;
+  at.end = pos >= n;
+  at.after_nl = pos > 0 && text[pos - 1] == (rx_u8)'\n';
+  at.before_nl = pos < n && cp0 == (rx_u32)'\n';
   at.prev_word = false;
-  at.next_word = wordb && n > 0 && cp0 < 0x110000u && rx_class_has(w, wcls, cp0);
+  if (wordb && pos > 0) {
+    rx_i32 k = pos - 1, lk = 0;
+    while (k > 0 && (text[k] & 0xC0u) == 0x80u) k--;
+    const rx_u32 pc = rx_decode(text, k, n, lk);
+    at.prev_word = pc < 0x110000u && rx_class_has(w, wcls, pc);
+  }
+  at.next_word = wordb && pos < n && cp0 < 0x110000u && rx_class_has(w, wcls, cp0);
   cl->n = 0;
   cl->seen = 0;
-  rx_add(w, *cl, st, entry, 0, at, -1, -1);
+  rx_add(w, *cl, st, entry, pos, at, -1, -1);
   while (true) {
     const bool at_end = pos >= n;
     const rx_i32 q = at_end ? pos : pos + len0;
@@ -180,4 +188,41 @@ RXVM_ENTRY bool rx_extract(const rx_u32* w, P text, rx_i32 n, rx_i32& m0, rx_i32
   }
   if (matched && (m0 < 0 || m1 < m0)) m0 = m1 = -1;
   return matched;
+}
+
+template <class P>
+RXVM_FN bool rx_extract(const rx_u32* w, P text, rx_i32 n, rx_i32& m0, rx_i32& m1) {
+  return rx_search(w, text, n, 0, m0, m1);
+}
+
+// split(str, pattern, limit) (string_funcs/split.rs:434-472 over the crate's Regex::split / find_iter): the pieces between successive
+// matches of a group-0 program.  find_iter's rule for empty matches: one that ends where the previous match ended is dropped and the
+// search resumes one character on.  limit > 0: at most limit − 1 cuts; limit = 0: trailing empty pieces are dropped (nothing left = one
+// empty piece); limit < 0: every piece.  `emit(k, start, len)` sees piece k; → the number of pieces the list holds.  With `max_emit` the
+// caller bounds what is emitted (the writing pass passes the count the counting pass returned).
+template <class P, class F>
+RXVM_FN rx_i32 rx_split(const rx_u32* w, P text, rx_i32 n, rx_i32 limit, rx_i32 max_emit, F emit) {
+  rx_i32 last = 0, at = 0, last_end = -1, k = 0, kept = 0;
+  while (true) {
+    if (limit > 0 && k >= limit - 1) break;
+    rx_i32 m0 = -1, m1 = -1;
+    if (!rx_search(w, text, n, at, m0, m1) || m0 < 0) break;
+    if (m0 == m1 && m1 == last_end) {
+      // an empty match right behind the previous match: the search resumes behind the next character
+      at = at + 1;
+      while (at < n && (text[at] & 0xC0u) == 0x80u) at++;
+      if (!rx_search(w, text, n, at, m0, m1) || m0 < 0) break;
+    }
+    if (k < max_emit) emit(k, last, m0 - last);
+    if (m0 > last) kept = k + 1;
+    k++;
+    last = m1;
+    at = m1;
+    last_end = m1;
+  }
+  if (k < max_emit) emit(k, last, n - last);
+  if (n > last) kept = k + 1;
+  k++;
+  if (limit == 0) return kept == 0 ? 1 : kept;
+  return k;
 }

@@ -308,6 +308,7 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     sink_ = pv->desc.sink;
     if (sink_ == SinkKind::Output)
       for (auto& oc : pv->desc.out_cols) materialize_root_ |= oc.gather_src >= 0 || oc.packed_string || oc.view_src >= 0 || oc.fmt_kind || !oc.concat_cols.empty();   // Utf8 outputs are finished on the device (gather / unpack)
+      materialize_root_ |= !pv->desc.derived.empty();      // (split: computed over the resident source)
     // a grouped aggregate keyed by Utf8 columns sees its whole input at once (like a join input): only then can strings longer
     // than the packed 15 bytes be swapped for representative row indices (prepare_dict_keys)
     if (sink_ == SinkKind::AggGrouped && !pv->desc.str_key_cols.empty()) has_join_ = true;
@@ -1251,14 +1252,82 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
   return t;
 }
 
+// The chain's derived columns (codegen.hpp DerivedCol) computed over its source table and appended to it.  split: two passes of the matcher per
+// row (regex_kernels.hip) — the pieces counted, a prefix sum, every piece described as a view of its source value — and the element column
+// assembled from the views like every string view's result.
+void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol>& derived) {
+  for (const DerivedCol& dc : derived) {
+    if (dc.kind != 1 || dc.src < 0 || (size_t)dc.src >= in.cols.size()) throw CometError("internal: unknown derived column");
+    const DeviceColumnView sc = in.cols[(size_t)dc.src];
+    const bool hv = in.has_valid[(size_t)dc.src];
+    const int64_t rows = in.rows;
+    if (!sc.data && rows) throw CometError("split over a Utf8 column without offsets is not supported");
+    DevBuf prog, counts, tiles;
+    auto list_offs = std::make_shared<DevBuf>();
+    prog.ensure(dc.prog.size() * 4 + 16);
+    // (a program with \\b carries the \\w table: several KB — not a write_small)
+    HIP_CHECK(hipMemcpyAsync(prog.p, dc.prog.data(), dc.prog.size() * 4, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    counts.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
+    tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+    list_offs->ensure((size_t)(rows + 2) * 4);
+    HIP_CHECK(hipMemsetAsync(list_offs->p, 0, 8, stream_));
+    const int32_t* offs = (const int32_t*)sc.data + sc.offset;
+    const uint8_t* vbits = hv ? sc.valid : nullptr;
+    if (comet_launch_split_count(offs, (const uint8_t*)sc.aux, vbits, sc.offset, rows, (const uint32_t*)prog.p, dc.limit, (uint32_t*)counts.p, stream_) != 0) throw CometError("split: launch failed");
+    if (rows) pq_launch_u32_scan((const uint32_t*)counts.p, rows, (uint64_t*)tiles.p, (int32_t*)list_offs->p, stream_);
+    int32_t total = 0;
+    if (rows) read_small(&total, (char*)list_offs->p + (size_t)rows * 4, 4);
+    if (total < 0) throw CometError("split: more than 2^31 pieces in one table");
+    DevBuf views, lengths, etiles;
+    auto eoffs = std::make_shared<DevBuf>(), ebytes = std::make_shared<DevBuf>();
+    views.ensure((size_t)std::max<int32_t>(total, 1) * 16 + 16);
+    lengths.ensure((size_t)std::max<int32_t>(total, 1) * 4 + 16);
+    etiles.ensure((size_t)((total + 1023) / 1024 + 2) * 8);
+    eoffs->ensure((size_t)(total + 2) * 4);
+    HIP_CHECK(hipMemsetAsync(eoffs->p, 0, 8, stream_));
+    if (comet_launch_split_write(offs, (const uint8_t*)sc.aux, vbits, sc.offset, rows, (const uint32_t*)prog.p, dc.limit, (const int32_t*)list_offs->p, views.p, stream_) != 0)
+      throw CometError("split: launch failed");
+    if (comet_launch_strview_lengths(views.p, nullptr, total, nullptr, 0, (uint32_t*)lengths.p, stream_) != 0) throw CometError("split: launch failed");
+    if (total) pq_launch_u32_scan((const uint32_t*)lengths.p, total, (uint64_t*)etiles.p, (int32_t*)eoffs->p, stream_);
+    int32_t nbytes = 0;
+    if (total) read_small(&nbytes, (char*)eoffs->p + (size_t)total * 4, 4);
+    if (nbytes < 0) throw CometError("Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+    ebytes->ensure((size_t)nbytes + 16);
+    if (comet_launch_strview_copy(views.p, nullptr, offs, (const uint8_t*)sc.aux, total, nullptr, 0, 0, (const int32_t*)eoffs->p, (uint8_t*)ebytes->p, stream_) != 0)
+      throw CometError("split: launch failed");
+    HIP_CHECK(hipStreamSynchronize(stream_));      // the program, counts, views and lengths go back to the pool
+    DeviceColumnView elem;
+    elem.data = eoffs->p;
+    elem.aux = ebytes->p;
+    DeviceColumnView lv;
+    lv.data = list_offs->p;
+    lv.valid = sc.valid;
+    lv.offset = 0;
+    lv.kids.push_back(elem);
+    lv.kid_has_valid.push_back(false);
+    lv.kid_rows = total;
+    if (hv && sc.offset != 0) throw CometError("split over a sliced Utf8 column with NULLs is not supported yet");
+    in.types.push_back(dc.type);
+    in.cols.push_back(lv);
+    in.has_valid.push_back(hv);
+    in.owners.push_back(list_offs);
+    in.owners.push_back(eoffs);
+    in.owners.push_back(ebytes);
+    split_rows_ += rows;
+  }
+}
+
 // ---- exact Float64 sums: window bookkeeping (device side: comet_device.hpp "Exact Float64 sums") ----
 
 // Filter/Project chain `top` over the resident table `in` → resident table
 DevTable ExecutionContext::run_chain_to_device(const Operator& top, const DevTable& in_plain) {
-  const DevTable in = extend_struct_fields(in_plain);
+  DevTable in = extend_struct_fields(in_plain);
   if (in.cols.size() > COMET_MAX_IN) throw CometError("too many columns (struct fields included) for one GPU pipeline");
   auto pv = planned_variant(top, plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&top] + 1)), in.has_valid, true, &in.types);
   if (pv->desc.sink != SinkKind::Output) throw CometError("internal: run_chain_to_device on an aggregate chain");
+  extend_derived(in, pv->desc.derived);      // (split: list columns computed over the source, passed through by row index)
+  if (in.cols.size() > COMET_MAX_IN) throw CometError("too many columns (derived columns included) for one GPU pipeline");
   Variant v;
   v.desc = pv->desc;
   note_sites(v.desc);

@@ -193,6 +193,7 @@ class ExecutionContext {
   DevTable scan_parquet(const Operator& native_scan);
   int64_t launch_fused_filter(Variant& v, CometKParams& prm, int64_t n);
   DevTable run_chain_to_device(const Operator& top, const DevTable& in);
+  void extend_derived(DevTable& in, const std::vector<DerivedCol>& derived);
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
   DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix,
                           const JoinFusion* fused_probe = nullptr);
@@ -287,6 +288,7 @@ class ExecutionContext {
   std::string explain_;
   SinkKind sink_ = SinkKind::Output;
   bool has_join_ = false;
+  int64_t split_rows_ = 0;          // rows that went through split's kernels (tests: the device path ran)
   bool materialize_root_ = false;   // plain Scan chain whose outputs need the materialising path (Utf8 pass-through)
   bool compile_in_infer_ = false;
   std::vector<const Operator*> nested_aggs_;

@@ -254,12 +254,14 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
 // Small host↔device transfers go through a pinned scratch block: a copy to/from PAGEABLE memory makes the runtime set up
 // staging for the stream, which was measured at 9–24 ms on the first such copy of each plan (profiles/r1_q3_*).
 void ExecutionContext::read_small(void* dst, const void* dev_src, size_t n) {
+  if (n > 4096) throw CometError("internal: read_small of " + std::to_string(n) + " bytes (its staging holds 4096)");
   small_host_.ensure(4096);
   HIP_CHECK(hipMemcpyAsync(small_host_.p, dev_src, n, hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipStreamSynchronize(stream_));
   memcpy(dst, small_host_.p, n);
 }
 void ExecutionContext::write_small(void* dev_dst, const void* src, size_t n) {
+  if (n > 2048) throw CometError("internal: write_small of " + std::to_string(n) + " bytes (its staging holds 2048)");
   small_host_.ensure(4096);
   HIP_CHECK(hipStreamSynchronize(stream_));   // the scratch may still be the source of an earlier async copy
   memcpy((char*)small_host_.p + 2048, src, n);

@@ -1188,6 +1188,14 @@ bool regex_prog_extract(const RegexProg& prog, const uint8_t* s, size_t n, int32
   return hit;
 }
 
+std::vector<std::pair<int32_t, int32_t>> regex_prog_split(const RegexProg& prog, const uint8_t* s, size_t n, int32_t limit) {
+  // the device's two passes: count, then write that many pieces
+  const int32_t count = rx_split(prog.words.data(), s, (int32_t)n, limit, 0, [](int32_t, int32_t, int32_t) {});
+  std::vector<std::pair<int32_t, int32_t>> out((size_t)count, {-1, -1});
+  rx_split(prog.words.data(), s, (int32_t)n, limit, count, [&](int32_t k, int32_t a, int32_t len) { out[(size_t)k] = {a, len}; });
+  return out;
+}
+
 bool regex_dfa_match(const RegexDfa& d, const uint8_t* s, size_t n) {
   int st = 0;
   if (d.flags[0] & 1) return true;

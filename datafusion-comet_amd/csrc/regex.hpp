@@ -32,4 +32,7 @@ RegexProg compile_regex_captures(const std::string& pattern, int group, const ch
 // the device's matcher run on the host (tests): → matched?; [*start, *start + *len) = the group's bytes (empty when unset / no match)
 bool regex_prog_extract(const RegexProg& prog, const uint8_t* s, size_t n, int32_t* start, int32_t* len);
 
+// split(str, pattern, limit) (string_funcs/split.rs) with a group-0 program: the pieces as (start, length) inside `s`, by the device's own two passes
+std::vector<std::pair<int32_t, int32_t>> regex_prog_split(const RegexProg& prog, const uint8_t* s, size_t n, int32_t limit);
+
 }  // namespace comet

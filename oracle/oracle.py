@@ -141,6 +141,8 @@ def col_to_arrow(S, c: Col) -> pa.Array:
     n = len(c)
     t = c.dtype
     mask = None if c.valid is None or c.valid.all() else ~c.valid
+    if t.type_id == getattr(S, "LIST", -1):      # (split's result: lists of strings as Python lists)
+        return pa.array([None if (mask is not None and mask[i]) else list(c.values[i]) for i in range(n)], type=pa.list_(pa.field("item", pa.utf8(), nullable=t.contains_null)))
     if t.type_id == S.DECIMAL:
         vals = c.values.copy()
         if mask is not None:
@@ -161,6 +163,50 @@ def col_to_arrow(S, c: Col) -> pa.Array:
     if t.type_id == S.STRING:
         return pa.array([None if (mask is not None and mask[i]) else c.values[i] for i in range(n)], type=pa.utf8())
     return pa.array(c.values, type=pt, mask=mask)
+
+
+def crate_pattern_to_python(pat: str):
+    """the crate's pattern in Python's `re` syntax, for the part both read alike: $ / \\z are "at the very end" there (\\Z here) unless (?m)"""
+    import re
+    multiline = re.match(r"\(\?[is]*m[ism]*\)", pat) is not None
+    return re.compile((pat if multiline else re.sub(r"(?<!\\)\$", r"\\Z", pat)).replace("\\z", "\\Z"))
+
+
+def find_iter_like_the_crate(rx, text: str):
+    """regex::Regex::find_iter (regex-automata util::iter::Searcher::advance): successive leftmost matches, each search starting where the last
+    match ended; an EMPTY match that ends where the previous match ended is dropped and the search repeated one character on."""
+    at, last_end = 0, None
+    while at <= len(text):
+        m = rx.search(text, at)
+        if m is None:
+            return
+        if m.start() == m.end() and m.end() == last_end:
+            at += 1
+            if at > len(text):
+                return
+            m = rx.search(text, at)
+            if m is None:
+                return
+        yield m
+        at = last_end = m.end()
+
+
+def split_like_the_crate(pat: str, text: str, limit: int):
+    """push_split_parts (string_funcs/split.rs:434-472) over Regex::split / find_iter as above"""
+    rx = crate_pattern_to_python(pat)
+    parts, last = [], 0
+    for count, m in enumerate(find_iter_like_the_crate(rx, text)):
+        if limit > 0 and count >= limit - 1:
+            break
+        parts.append(text[last:m.start()])
+        last = m.end()
+    parts.append(text[last:])
+    if limit == 0:
+        while parts and parts[-1] == "":
+            parts.pop()
+        if not parts:
+            parts = [""]
+    return parts
 
 
 # --------------------------------------------------------------------------- expression evaluation
@@ -502,6 +548,16 @@ class Evaluator:
             for i in range(n):
                 out[i] = (a.values[i].upper() if f == "upper" else a.values[i].lower()) if a.ok()[i] else None
             return Col(S.T_STRING, out, a.valid)
+        if f == "split":
+            # spark_split (string_funcs/split.rs:32-97, 434-472): the pieces between the pattern's matches — limit > 0: at most limit - 1 cuts;
+            # limit = 0: trailing empty pieces dropped (nothing left: one empty piece); limit < 0 (the default): every piece.  NULL subject → NULL list.
+            a = self.eval(e.children[0], cols, n)
+            pat = e.children[1].value
+            limit = int(e.children[2].value) if len(e.children) > 2 else -1
+            out = np.empty(n, dtype=object)
+            for i in range(n):
+                out[i] = split_like_the_crate(pat, a.values[i], limit) if a.ok()[i] else None
+            return Col(S.list_type(S.T_STRING, False), out, a.valid)
         if f == "regexp_extract":
             # spark_regexp_extract (string_funcs/regexp_extract.rs:38-108; arguments regexp_extract_common.rs:36-107): group `idx` (default 1) of the
             # FIRST match of the pattern (the crate's Regex::captures_read: leftmost, alternatives / repetitions preferred in pattern order); the empty
@@ -514,10 +570,8 @@ class Evaluator:
             idx = e.children[2].value if len(e.children) > 2 else 1
             if pat is None or idx is None:
                 return Col(S.T_STRING, np.array([None] * n, dtype=object), np.zeros(n, bool))
-            multiline = re.match(r"\(\?[is]*m[ism]*\)", pat) is not None
-            py = (pat if multiline else re.sub(r"(?<!\\)\$", r"\\Z", pat)).replace("\\z", "\\Z")
             try:
-                rx = re.compile(py)
+                rx = crate_pattern_to_python(pat)
             except re.error as err:
                 raise OracleError("The value of parameter `regexp` in `regexp_extract` is invalid: '%s' (%s)" % (pat, err))
             if idx < 0 or idx > rx.groups:

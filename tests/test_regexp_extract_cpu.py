@@ -133,3 +133,48 @@ def test_the_gpu_tests_patterns_on_the_host():
         want = O.run_plan_to_arrow(S, S.project(S.scan([S.T_STRING, S.T_INT32]), [G._rx(pat, idx)]), t).column(0).to_pylist()
         got = [None if v is None else ext(pat, idx, v) for v in vals]
         assert got == want, (pat, idx)
+
+
+# ---- split: the device's two passes (rx_split) on the host ----
+
+def test_split_reference_vectors():
+    # string_funcs/split.rs tests: test_split_regex, _limit_positive, _limit_zero, _limit_negative, _empty_string
+    assert native.split_host(r"\d+", -1, "foo123bar456baz") == ["foo", "bar", "baz"]
+    assert native.split_host(",", 3, "a,b,c,d,e") == ["a", "b", "c,d,e"]
+    assert native.split_host(",", 0, "a,b,c,,") == ["a", "b", "c"]
+    assert native.split_host(",", -1, "a,b,c,,") == ["a", "b", "c", "", ""]
+    assert native.split_host(",", -1, "") == [""]
+
+
+def test_split_empty_matches_follow_find_iter():
+    assert native.split_host("", -1, "abc") == ["", "a", "b", "c", ""]
+    assert native.split_host("", 0, "abc") == ["", "a", "b", "c"]
+    assert native.split_host("x*", -1, "axxbéc") == ["", "a", "b", "é", "c", ""]
+    assert native.split_host("", -1, "") == ["", ""]
+    assert native.split_host(",", 0, ",,,") == [""]
+    assert native.split_host(r"\b", -1, "ab cd") == ["", "ab", " ", "cd", ""]
+    assert native.split_host(r"(?m)^", -1, "a\nb\n") == ["", "a\n", "b\n", ""]
+
+
+def test_split_against_the_oracles_restatement():
+    from oracle import oracle as O
+    rng = random.Random(77)
+    checked = 0
+    for _ in range(500):
+        groups = [0]
+        pat = gen(rng, 2, groups)
+        try:
+            O.crate_pattern_to_python(pat)
+        except re.error:
+            continue
+        for _ in range(5):
+            text = "".join(rng.choice(ALPHA) for _ in range(rng.randint(0, 10)))
+            limit = rng.choice([-1, -1, 0, 1, 2, 3])
+            try:
+                got = native.split_host(pat, limit, text)
+            except Exception as e:  # noqa: BLE001
+                assert "not supported" in str(e), (pat, str(e))
+                break
+            assert got == O.split_like_the_crate(pat, text, limit), (pat, limit, text)
+            checked += 1
+    assert checked > 1500

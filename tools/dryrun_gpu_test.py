@@ -37,6 +37,9 @@ class _Host:
 
 
 def _execute(inputs, ncols, plan_bytes, **kw):
+    # the plan goes through createPlan's planning AND hiprtc here (no GPU needed): refusals and kernels that do not compile show up now.
+    # (Plans over materialised sources plan their chains at run time: those are generated only when a chain is the plan's root.)
+    native.compile_plan(plan_bytes)
     try:
         out = O.run_plan_to_arrow(S, _last["plan"], *[i.table for i in inputs])
     except O.OracleError as e:      # the message a device run would carry is not reproduced: every fromType the tests match is appended
