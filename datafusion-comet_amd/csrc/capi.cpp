@@ -572,6 +572,26 @@ int32_t comet_split_host(const char* pattern, int32_t limit, const uint8_t* valu
   });
 }
 
+namespace comet_dates_host {
+#include "device/dates.hpp"
+}
+int32_t comet_date_fn_host(int32_t fn, int64_t a, int64_t b, int64_t c, int64_t* out) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    using namespace comet_dates_host;
+    switch (fn) {
+      case 0: *out = date_part((i32)a, (int)b); return 1;
+      case 1: *out = date_weekday_mon0((i32)a) + 1; return 1;
+      case 2: *out = date_iso_week((i32)a); return 1;
+      case 3: if (!date_in_chrono_range((i32)a)) return 0; *out = date_trunc_days((i32)a, (int)b); return 1;
+      case 4: if (!date_in_chrono_range((i32)a)) return 0; *out = date_last_day((i32)a); return 1;
+      case 5: if (!date_in_chrono_range((i32)a)) return 0; *out = date_next_day((i32)a, (int)b); return 1;
+      case 6: { i32 o = 0; if (!date_make((i32)a, (i32)b, (i32)c, o)) return 0; *out = o; return 1; }
+      case 7: *out = ts_trunc_local_us(a, (int)b); return 1;
+      default: throw CometError("comet_date_fn_host: unknown function");
+    }
+  });
+}
+
 int64_t comet_snappy_view_read(const uint8_t* src, size_t src_len, int32_t max_elems, const int64_t* offsets, int32_t n, uint8_t* out) {
   return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
     pq::SnappyView v;

@@ -1842,15 +1842,243 @@ struct Gen {
       if (e.children.size() != 2 || e.children[0]->kind != ExprKind::Literal) throw CometError("datepart expects (field literal, date)");
       std::string part = e.children[0]->lit_bytes;
       for (auto& ch : part) ch = (char)tolower((unsigned char)ch);
-      int code = part == "year" ? 0 : part == "month" ? 1 : part == "day" ? 2 : part == "quarter" ? 3 : part == "dow" ? 4 : part == "doy" ? 5 : -1;
+      // (isodow: 1 = Monday … 7 = Sunday — CometWeekDay subtracts one for Spark's weekday(); week: the ISO-8601 week, Spark's weekofyear)
+      int code = part == "year" ? 0 : part == "month" ? 1 : part == "day" ? 2 : part == "quarter" ? 3 : part == "dow" ? 4 : part == "doy" ? 5 : part == "isodow" ? 6 : part == "week" ? 7 : -1;
       if (code < 0) throw CometError("datepart field '" + part + "' is not supported by the MI355X native engine yet");
       Val a = arg(1);
       if (a.t.id != TypeId::Date) throw CometError("datepart over " + a.t.str() + " is not supported by the MI355X native engine yet");
       r.t = DType::of(TypeId::Int32);
       r.rep = Rep::I32;
       r.ok = a.ok;
-      r.v = "comet::date_part(" + a.v + ", " + std::to_string(code) + ")";
+      r.v = code == 6 ? "(comet::date_weekday_mon0(" + a.v + ") + 1)" : code == 7 ? "comet::date_iso_week(" + a.v + ")" : "comet::date_part(" + a.v + ", " + std::to_string(code) + ")";
       r.maxabs = 6000000;
+      return r;
+    }
+    // ---- Float64 functions the reference hands to DataFusion / datafusion-spark (QueryPlanSerde.scala:117-174 CometScalarFunction(name); Spark casts the
+    // argument to double): the device's libm (ocml) stands where Rust's std — the platform's libm — stands in the reference; both are within an
+    // ulp or two of the exact value, the GPU tests state the tolerance.  cot = 1 / tan, csc = 1 / sin, sec = 1 / cos (datafusion-spark), degrees /
+    // radians = one multiplication by the constant f64::to_degrees / to_radians use, rint = Java's Math.rint (ties to even).
+    {
+      static const std::map<std::string, std::string> unary = {
+          {"acos", "acos(@)"}, {"acosh", "acosh(@)"}, {"asin", "asin(@)"}, {"asinh", "asinh(@)"}, {"atan", "atan(@)"}, {"atanh", "atanh(@)"}, {"cbrt", "cbrt(@)"},
+          {"cos", "cos(@)"}, {"cosh", "cosh(@)"}, {"exp", "exp(@)"}, {"expm1", "expm1(@)"}, {"ln", "log(@)"}, {"log2", "log2(@)"}, {"log10", "log10(@)"},
+          {"sin", "sin(@)"}, {"sinh", "sinh(@)"}, {"tan", "tan(@)"}, {"tanh", "tanh(@)"}, {"cot", "(1.0 / tan(@))"}, {"csc", "(1.0 / sin(@))"}, {"sec", "(1.0 / cos(@))"},
+          {"degrees", "(@ * (180.0 / 3.14159265358979323846))"}, {"radians", "(@ * (3.14159265358979323846 / 180.0))"}, {"rint", "comet::f64_rint(@)"}};
+      auto it = unary.find(f);
+      if (it != unary.end()) {
+        if (e.children.size() != 1) throw CometError(f + " expects one argument");
+        Val a = arg(0);
+        if (a.rep != Rep::F64) throw CometError(f + " expects a Float64 argument (got " + a.t.str() + ")");
+        r = a;
+        std::string x = it->second;
+        for (size_t p0 = x.find('@'); p0 != std::string::npos; p0 = x.find('@')) x.replace(p0, 1, a.v);
+        r.v = x;
+        return r;
+      }
+    }
+    if (f == "pi") {
+      r.t = DType::of(TypeId::Double);
+      r.rep = Rep::F64;
+      r.v = "3.14159265358979323846";
+      return r;
+    }
+    if (f == "atan2" || f == "pow" || f == "power" || f == "spark_log") {
+      if (e.children.size() != 2) throw CometError(f + " expects two arguments");
+      Val a = arg(0), b = arg(1);
+      if (a.rep != Rep::F64 || b.rep != Rep::F64) throw CometError(f + " expects Float64 arguments");
+      r.t = DType::of(TypeId::Double);
+      r.rep = Rep::F64;
+      r.ok = and_ok(a.ok, b.ok);
+      if (f == "atan2") r.v = "atan2(" + a.v + ", " + b.v + ")";
+      else if (f == "spark_log") {
+        // spark_log (math_funcs/log.rs:30-38): log(base, value) = ln(value) / ln(base), NULL when base <= 0 or value <= 0
+        r.ok = and_ok(r.ok, "(" + a.v + " > 0.0 && " + b.v + " > 0.0)");
+        r.v = "(log(" + b.v + ") / log(" + a.v + "))";
+      } else {
+        // spark_powf (math_funcs/pow.rs:24-29): Java's Math.pow — |base| = 1 with an infinite or NaN exponent is NaN (C's pow says 1)
+        r.v = "((fabs(" + a.v + ") == 1.0 && !isfinite(" + b.v + ")) ? __longlong_as_double(0x7ff8000000000000ll) : pow(" + a.v + ", " + b.v + "))";
+      }
+      return r;
+    }
+    if (f == "factorial") {
+      // datafusion-spark SparkFactorial (Spark's Factorial): Int32 in 0..20 → its factorial as Int64, NULL outside
+      Val a = arg(0);
+      if (a.t.id != TypeId::Int32) throw CometError("factorial expects an Int32 argument");
+      decls += "    static const i64 fact_tab[21] = {1ll,1ll,2ll,6ll,24ll,120ll,720ll,5040ll,40320ll,362880ll,3628800ll,39916800ll,479001600ll,6227020800ll,87178291200ll,1307674368000ll,"
+               "20922789888000ll,355687428096000ll,6402373705728000ll,121645100408832000ll,2432902008176640000ll};\n";
+      r.t = DType::of(TypeId::Int64);
+      r.rep = Rep::I64;
+      r.ok = and_ok(a.ok, "(" + a.v + " >= 0 && " + a.v + " <= 20)");
+      r.v = "fact_tab[(" + a.v + " >= 0 && " + a.v + " <= 20) ? " + a.v + " : 0]";
+      return r;
+    }
+    if (f == "bitwise_not" || f == "bit_count" || f == "bit_get" || f == "getbit" || f == "shiftrightunsigned") {
+      // datafusion-spark's bitwise functions (jni_api.rs:639-668): Java's ~x, Integer / Long.bitCount (a narrower value sign-extended first), (x >> pos) & 1
+      // as a byte, x >>> (n mod width)
+      Val a = arg(0);
+      if (!a.t.is_integer() && !(f == "bit_count" && a.t.id == TypeId::Bool)) throw CometError(f + " expects an integral argument (got " + a.t.str() + ")");
+      const bool is64 = a.t.id == TypeId::Int64;
+      if (f == "bitwise_not") {
+        r = a;
+        r.v = "(" + std::string(rep_ctype(a.rep)) + ")(~(" + a.v + "))";
+        return r;
+      }
+      if (f == "bit_count") {
+        r.t = DType::of(TypeId::Int32);
+        r.rep = Rep::I32;
+        r.ok = a.ok;
+        r.v = a.t.id == TypeId::Bool ? "(i32)(" + a.v + " ? 1 : 0)" : is64 ? "(i32)__popcll((u64)" + a.v + ")" : "(i32)__popcll((u64)(i64)" + a.v + ")";      // (Spark counts the bits of the value widened to a long)
+        r.maxabs = 64;
+        return r;
+      }
+      Val b = arg(1);
+      if (!(b.t.id == TypeId::Int32 || b.t.id == TypeId::Int8 || b.t.id == TypeId::Int16)) throw CometError(f + " expects an Int32 second argument");
+      r.ok = and_ok(a.ok, b.ok);
+      if (f == "shiftrightunsigned") {
+        if (a.t.id != TypeId::Int32 && a.t.id != TypeId::Int64) throw CometError("shiftrightunsigned expects an Int32 or Int64 value");
+        r.t = a.t;
+        r.rep = a.rep;
+        r.v = is64 ? "(i64)((u64)" + a.v + " >> ((int)" + b.v + " & 63))" : "(i32)((u32)" + a.v + " >> ((int)" + b.v + " & 31))";
+        r.maxabs = type_maxabs(a.t);
+        return r;
+      }
+      // bit_get: a position outside the value's bits is an error in Spark (and in datafusion-spark): refused rows raise nothing here — the position must be a literal in range
+      const int width = a.t.id == TypeId::Int8 ? 8 : a.t.id == TypeId::Int16 ? 16 : a.t.id == TypeId::Int32 ? 32 : 64;
+      if (e.children[1]->kind != ExprKind::Literal || e.children[1]->lit_null || e.children[1]->lit_i64 < 0 || e.children[1]->lit_i64 >= width)
+        throw CometError("bit_get is supported with a literal position inside the value's " + std::to_string(width) + " bits");
+      r.t = DType::of(TypeId::Int8);
+      r.rep = Rep::I32;
+      r.v = "(i32)(((u64)(i64)" + a.v + " >> " + std::to_string(e.children[1]->lit_i64) + ") & 1ull)";
+      r.maxabs = 1;
+      return r;
+    }
+    if (f == "greatest" || f == "least") {
+      // DataFusion's greatest / least (Spark's): NULL arguments are skipped, the result is NULL only when every argument is; NaN is the greatest double
+      if (e.children.size() < 2) throw CometError(f + " expects at least two arguments");
+      Val acc = arg(0);
+      for (size_t k = 1; k < e.children.size(); k++) {
+        Val b = arg(k);
+        if (!(b.t == acc.t)) throw CometError(f + " expects arguments of one type (got " + acc.t.str() + " and " + b.t.str() + ")");
+        if (acc.rep == Rep::STR || acc.rep == Rep::B) throw CometError(f + " of " + acc.t.str() + " is not supported by the MI355X native engine yet");
+        std::string better;      // b beats acc
+        if (acc.rep == Rep::F64 || acc.rep == Rep::F32) {
+          const std::string an = "(" + acc.v + " != " + acc.v + ")", bn = "(" + b.v + " != " + b.v + ")";
+          better = f == "greatest" ? "(" + bn + " || (!" + an + " && " + b.v + " > " + acc.v + "))" : "(" + an + " || (!" + bn + " && " + b.v + " < " + acc.v + "))";
+        } else {
+          better = "(" + b.v + (f == "greatest" ? " > " : " < ") + acc.v + ")";
+        }
+        const std::string aok = acc.ok.empty() ? "true" : acc.ok, bok = b.ok.empty() ? "true" : b.ok;
+        std::string take = newvar("bool");
+        stmt(take + " = " + bok + " && (!" + aok + " || " + better + ");");
+        Val n = acc;
+        std::string v = newvar(rep_ctype(acc.rep));
+        stmt(v + " = " + take + " ? " + b.v + " : " + acc.v + ";");
+        n.v = v;
+        if (acc.ok.empty() || b.ok.empty()) n.ok = "";
+        else {
+          std::string o = newvar("bool");
+          stmt(o + " = " + acc.ok + " || " + b.ok + ";");
+          n.ok = o;
+        }
+        n.maxabs = std::max(acc.maxabs, b.maxabs);
+        acc = n;
+      }
+      return acc;
+    }
+    // ---- dates ----
+    if (f == "last_day" || f == "date_from_unix_date") {
+      Val a = arg(0);
+      r.t = DType::of(TypeId::Date);
+      r.rep = Rep::I32;
+      r.maxabs = (u128)1 << 31;
+      if (f == "date_from_unix_date") {
+        // SparkDateFromUnixDate (datetime_funcs/date_from_unix_date.rs:52-60): the Int32 IS the date
+        if (a.t.id != TypeId::Int32) throw CometError("date_from_unix_date expects Int32Array input");
+        r.ok = a.ok;
+        r.v = a.v;
+        return r;
+      }
+      if (a.t.id != TypeId::Date) throw CometError("last_day expects a Date32 argument");
+      r.ok = and_ok(a.ok, "comet::date_in_chrono_range(" + a.v + ")");
+      r.v = "comet::date_last_day(" + a.v + ")";
+      return r;
+    }
+    if (f == "date_trunc" || f == "trunc") {
+      // SparkDateTrunc (datetime_funcs/date_trunc.rs → kernels/temporal.rs:63-100, 326-352): a Date32 to the first day of its year / quarter / month /
+      // (Monday) week; the format is a literal here (datetime.scala: anything else is sent only under allowIncompatible)
+      if (e.children.size() != 2 || e.children[1]->kind != ExprKind::Literal || e.children[1]->lit_null) throw CometError("date_trunc is supported with a literal format");
+      std::string fmt = e.children[1]->lit_bytes;
+      for (auto& ch : fmt) ch = (char)toupper((unsigned char)ch);
+      const int unit = (fmt == "YEAR" || fmt == "YYYY" || fmt == "YY") ? 0 : fmt == "QUARTER" ? 1 : (fmt == "MONTH" || fmt == "MON" || fmt == "MM") ? 2 : fmt == "WEEK" ? 3 : -1;
+      if (unit < 0) throw CometError("Unsupported format: \"" + e.children[1]->lit_bytes + "\" for function 'date_trunc'");
+      Val a = arg(0);
+      if (a.t.id != TypeId::Date) throw CometError("Invalid input to function DateTrunc. Expected (Date32, Utf8)");
+      r.t = DType::of(TypeId::Date);
+      r.rep = Rep::I32;
+      r.ok = and_ok(a.ok, "comet::date_in_chrono_range(" + a.v + ")");
+      r.v = "comet::date_trunc_days(" + a.v + ", " + std::to_string(unit) + ")";
+      r.maxabs = (u128)1 << 31;
+      return r;
+    }
+    if (f == "next_day") {
+      // SparkNextDay (datetime_funcs/next_day.rs:49-68): the first date later than the start that falls on the named day; a name that is none is NULL
+      // (IllegalDayOfWeek under ANSI).  The day's name is a literal here.
+      if (e.children.size() != 2 || e.children[1]->kind != ExprKind::Literal) throw CometError("next_day is supported with a literal day of the week");
+      Val a = arg(0);
+      if (a.t.id != TypeId::Date) throw CometError("next_day expects a Date32 start date");
+      r.t = DType::of(TypeId::Date);
+      r.rep = Rep::I32;
+      r.maxabs = (u128)1 << 31;
+      std::string name = e.children[1]->lit_bytes;
+      for (auto& ch : name) ch = (char)toupper((unsigned char)ch);
+      static const char* names[7][3] = {{"MO", "MON", "MONDAY"}, {"TU", "TUE", "TUESDAY"}, {"WE", "WED", "WEDNESDAY"}, {"TH", "THU", "THURSDAY"}, {"FR", "FRI", "FRIDAY"}, {"SA", "SAT", "SATURDAY"}, {"SU", "SUN", "SUNDAY"}};
+      int day = -1;
+      for (int d = 0; d < 7 && !e.children[1]->lit_null; d++)
+        for (int k = 0; k < 3; k++)
+          if (name == names[d][k]) day = d;
+      if (day < 0) {
+        if (e.fail_on_error && !e.children[1]->lit_null) throw CometError("{\"errorType\":\"IllegalDayOfWeek\",\"errorClass\":\"ILLEGAL_DAY_OF_WEEK\",\"params\":{\"string\":\"" + e.children[1]->lit_bytes + "\"}}", 1);
+        r.ok = "false";
+        r.v = "0";
+        return r;
+      }
+      r.ok = and_ok(a.ok, "comet::date_in_chrono_range(" + a.v + ")");
+      r.v = "comet::date_next_day(" + a.v + ", " + std::to_string(day) + ")";
+      return r;
+    }
+    if (f == "make_date") {
+      // SparkMakeDate (datetime_funcs/make_date.rs:87-96, 150-166): chrono's from_ymd_opt — anything it refuses is NULL; under ANSI the task fails
+      // (DatetimeFieldOutOfBounds), which is refused here at planning time
+      if (e.children.size() != 3) throw CometError("make_date expects three arguments");
+      if (e.fail_on_error) throw CometError("make_date in ANSI mode (DATETIME_FIELD_OUT_OF_BOUNDS) is not supported by the MI355X native engine yet");
+      Val y = arg(0), m = arg(1), d = arg(2);
+      for (const Val* x : {&y, &m, &d})
+        if (!(x->t.id == TypeId::Int32 || x->t.id == TypeId::Int16 || x->t.id == TypeId::Int8)) throw CometError("make_date expects Int32 arguments");
+      std::string out = newvar("i32"), ok = newvar("bool");
+      stmt(out + " = 0; " + ok + " = comet::date_make(" + y.v + ", " + m.v + ", " + d.v + ", " + out + ");");
+      r.t = DType::of(TypeId::Date);
+      r.rep = Rep::I32;
+      r.ok = and_ok(and_ok(and_ok(y.ok, m.ok), d.ok), ok);
+      r.v = out;
+      r.maxabs = (u128)1 << 31;
+      return r;
+    }
+    if (f == "seconds_to_timestamp" || f == "timestamp_seconds") {
+      // SparkSecondsToTimestamp (datetime_funcs/seconds_to_timestamp.rs:63-105): Int32 · 10^6; Int64 · 10^6 checked ("long overflow" fails the task:
+      // refused rows cannot be told from here, so Int64 is taken when the product cannot overflow only … it can: the check runs on the device);
+      // Float32 / Float64: (s · 10^6) as i64 — Rust's saturating conversion —, NaN / ±∞ are NULL
+      Val a = arg(0);
+      r.t = DType::of(TypeId::Timestamp);
+      r.rep = Rep::I64;
+      r.ok = a.ok;
+      if (a.t.id == TypeId::Int32) r.v = "((i64)" + a.v + " * 1000000ll)";
+      else if (a.t.id == TypeId::Int64) {
+        raise_if(and_ok(a.ok, "(" + a.v + " > 9223372036854ll || " + a.v + " < -9223372036854ll)"), 18);
+        r.v = "(i64)((u64)" + a.v + " * 1000000ull)";
+      } else if (a.rep == Rep::F64 || a.rep == Rep::F32) {
+        r.ok = and_ok(a.ok, "isfinite((double)" + a.v + ")");
+        r.v = "comet::f64_to_i64_sat((double)" + a.v + " * 1000000.0)";
+      } else throw CometError("seconds_to_timestamp expects Int32, Int64, Float32 or Float64 input, got " + a.t.str());
       return r;
     }
     throw CometError("Scalar function '" + f + "' is not supported by the MI355X native engine");
@@ -2148,6 +2376,43 @@ struct Gen {
         const std::string sec = "(" + local + " - comet::tz_floor_div(" + local + ", 86400000000ll) * 86400000000ll) / 1000000ll";
         r.v = e.kind == ExprKind::Hour ? "(i32)((" + sec + ") / 3600)" : e.kind == ExprKind::Minute ? "(i32)((" + sec + ") / 60 % 60)" : "(i32)((" + sec + ") % 60)";
         r.maxabs = 64;
+        return r;
+      }
+      case ExprKind::TruncTimestamp: {
+        // timestamp_trunc (datetime_funcs/timestamp_trunc.rs → kernels/temporal.rs:179-270, 587-625): the instant's wall clock in the zone cut to the
+        // unit, read back as an instant.  The reference sends it for UTC only unless allowIncompatible (datetime.scala CometTruncTimestamp): zones
+        // with transitions are refused here.
+        if (e.children.size() != 2) throw CometError("TruncTimestamp expects a format and a child");
+        const Expr& fe = *e.children[0];
+        if (fe.kind != ExprKind::Literal || fe.lit_null) throw CometError("TruncTimestamp is supported with a literal format");
+        std::string fmt = fe.lit_bytes;
+        for (auto& ch : fmt) ch = (char)toupper((unsigned char)ch);
+        static const std::map<std::string, int> units = {{"YEAR", 0}, {"YYYY", 0}, {"YY", 0}, {"QUARTER", 1}, {"MONTH", 2}, {"MON", 2}, {"MM", 2}, {"WEEK", 3}, {"DAY", 4}, {"DD", 4},
+                                                         {"HOUR", 5}, {"MINUTE", 6}, {"SECOND", 7}, {"MILLISECOND", 8}, {"MICROSECOND", 9}};
+        auto it = units.find(fmt);
+        if (it == units.end()) throw CometError("Unsupported format: \"" + fe.lit_bytes + "\" for function 'timestamp_trunc'");
+        Val c = named(gen(e.children[1]));
+        if (c.t.id != TypeId::Timestamp && c.t.id != TypeId::TimestampNtz) throw CometError("timestamp_trunc does not support " + c.t.str());
+        long long secs = 0;
+        if (c.t.id == TypeId::Timestamp && !fixed_zone_offset(e.func, secs)) throw CometError("TruncTimestamp in a time zone with transitions ('" + e.func + "') is not supported by the MI355X native engine");
+        Val r = c;
+        const std::string off = lit_i64(secs * 1000000);
+        r.v = "(comet::ts_trunc_local_us(" + c.v + " + " + off + ", " + std::to_string(it->second) + ") - " + off + ")";
+        return r;
+      }
+      case ExprKind::UnixTimestamp: {
+        // SparkUnixTimestamp (datetime_funcs/unix_timestamp.rs:70-150): an instant's whole seconds (floor); a TIMESTAMP_NTZ's likewise; a date's midnight
+        // in the session zone, as an instant
+        Val c = named(gen(e.children.at(0)));
+        Val r;
+        r.t = DType::of(TypeId::Int64);
+        r.rep = Rep::I64;
+        r.ok = c.ok;
+        if (c.t.id == TypeId::Timestamp || c.t.id == TypeId::TimestampNtz) r.v = "comet::floor_div_i64(" + c.v + ", 1000000ll)";
+        else if (c.t.id == TypeId::Date) {
+          const std::string local = "((i64)" + c.v + " * 86400000000ll)";
+          r.v = "comet::floor_div_i64(" + utc_of(e.func, local, c.ok) + ", 1000000ll)";
+        } else throw CometError("unix_timestamp does not support input type: " + c.t.str());
         return r;
       }
       case ExprKind::Cast: {

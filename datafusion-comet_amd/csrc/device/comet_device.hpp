@@ -418,15 +418,8 @@ CDEV int str_to_decimal(strp p, i32 n, int precision, int scale, i128& out) {
   out = neg ? -(i128)mag : (i128)mag;
   return 0;
 }
-// days_from_civil (string.rs:1221-1228)
-CDEV i64 str_days_from_civil(i64 y, i64 m, i64 d) {
-  if (m <= 2) { y -= 1; m += 9; } else m -= 3;
-  const i64 era = (y >= 0 ? y : y - 399) / 400;
-  const i64 yoe = y - era * 400;
-  const i64 doy = (153 * m + 2) / 5 + d - 1;
-  const i64 doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
-  return era * 146097 + doe - 719468;
-}
+#include "dates.hpp"
+
 // resolve_epoch_day (string.rs:1929-1955)
 CDEV int str_resolve_date(i64 y, i64 m, i64 d, i32& out) {
   if (m < 1 || m > 12) return 1;
@@ -661,6 +654,8 @@ CDEV i64 tz_local_to_utc_us(tzp zt, i64 local_us, bool& beyond) {
 // Scalar functions (ScalarFunc, expr.proto:466-471): the exact, integer/IEEE-defined subset.
 // ---------------------------------------------------------------------------------------------
 // Rust `x as i64`: saturating, NaN → 0 (spark_ceil / spark_floor: math_funcs/ceil.rs:31-40, floor.rs)
+// Java's Math.rint (datafusion-spark SparkRint): the closest integral double, ties to even — the current rounding mode's rint
+CDEV double f64_rint(double x) { return rint(x); }
 CDEV i64 f64_to_i64_sat(double x) {
   if (x != x) return 0;
   if (x >= 9223372036854775808.0) return (i64)0x7fffffffffffffffll;
@@ -677,35 +672,6 @@ CDEV i32 f64_to_i32_sat(double x) {
 // div_ceil / div_floor of the unscaled value by 10^scale (decimal_ceil_f / decimal_floor_f)
 CDEV i128 dec_div_ceil(i128 x, i128 d) { i128 q = x / d, r = x % d; return (r > 0) ? q + 1 : q; }
 CDEV i128 dec_div_floor(i128 x, i128 d) { i128 q = x / d, r = x % d; return (r < 0) ? q - 1 : q; }
-// proleptic Gregorian civil date from days since 1970-01-01 (Howard Hinnant's algorithm; what chrono / arrow's date_part use)
-CDEV void civil_from_days(i32 z0, i32& y, i32& m, i32& d) {
-  i64 z = (i64)z0 + 719468;
-  const i64 era = (z >= 0 ? z : z - 146096) / 146097;
-  const i64 doe = z - era * 146097;
-  const i64 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
-  const i64 doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
-  const i64 mp = (5 * doy + 2) / 153;
-  d = (i32)(doy - (153 * mp + 2) / 5 + 1);
-  m = (i32)(mp < 10 ? mp + 3 : mp - 9);
-  y = (i32)(yoe + era * 400 + (m <= 2 ? 1 : 0));
-}
-CDEV i32 date_part(i32 days, int part) {   // 0 year, 1 month, 2 day, 3 quarter, 4 dow (Sunday = 0), 5 doy (1-based)
-  i32 y, m, d;
-  civil_from_days(days, y, m, d);
-  switch (part) {
-    case 0: return y;
-    case 1: return m;
-    case 2: return d;
-    case 3: return (m - 1) / 3 + 1;
-    case 4: { i64 w = ((i64)days + 4) % 7; return (i32)(w < 0 ? w + 7 : w); }   // 1970-01-01 was a Thursday
-    default: {
-      const bool leap = (y % 4 == 0 && y % 100 != 0) || y % 400 == 0;
-      const int cum[12] = {0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334};
-      return cum[m - 1] + d + ((leap && m > 2) ? 1 : 0);
-    }
-  }
-}
-
 // Direct Utf8 comparisons for predicates: byte-wise unsigned lexicographic order (Spark's UTF8String binary compare, arrow-ord's
 // string kernels), any length, no packing.  Returns <0, 0, >0.
 CDEV int utf8_cmp_lit(const CometCol& c, i64 i, const char* lit, i32 n) {

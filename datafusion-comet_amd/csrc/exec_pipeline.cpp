@@ -320,6 +320,7 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
   if (f & 16384u) throw CometError("{\"errorType\":\"InvalidInputInCastToDatetime\",\"errorClass\":\"CAST_INVALID_INPUT\",\"params\":{\"fromType\":\"STRING\",\"toType\":\"TIMESTAMP_NTZ\"}}", 1);
   if (f & 4096u) throw CometError("a string cast to a timestamp names a time zone inside the value, or holds a time of day without a date (which takes the current date): not supported by the MI355X native engine");
   if (f & 2048u) throw CometError("a timestamp lies behind the end of its time zone's table (the year 2400): not supported by the MI355X native engine");
+  if (f & 262144u) throw CometError("Arrow error: Compute error: long overflow");      // (seconds_to_timestamp of an Int64 beyond i64 / 10^6: seconds_to_timestamp.rs:70-75)
   if (f & 256u) throw CometError("{\"errorType\":\"DivideByZero\",\"errorClass\":\"DIVIDE_BY_ZERO\",\"params\":{}}", 1);
   // decimal_sum_overflow_error (spark-expr/src/lib.rs:131-135; error.rs:75-76, 374-377): ANSI sum / avg of decimals
   if (f & (65536u | 131072u)) {

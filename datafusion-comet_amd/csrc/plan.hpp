@@ -63,6 +63,7 @@ enum class EvalMode : int { Legacy = 0, Try = 1, Ansi = 2 };
 enum class ExprKind : int {
   Literal = 2, Bound = 3, Add = 4, Subtract = 5, Multiply = 6, Divide = 7, Cast = 8,
   Hour = 22, Minute = 23, Second = 24,      // expr.proto:436-453: child = 1, timezone = 2 (kept in Expr::func)
+  TruncTimestamp = 47, UnixTimestamp = 65,  // expr.proto:507-511 (children = [format, child]), 455-458; the zone in Expr::func
   Eq = 9, Neq = 10, Gt = 11, GtEq = 12, Lt = 13, LtEq = 14, IsNull = 15, IsNotNull = 16, And = 17, Or = 18,
   CheckOverflow = 25, Like = 26, RLike = 30, ScalarFunc = 31, EqNullSafe = 32, NeqNullSafe = 33, BitAnd = 34, BitOr = 35, BitXor = 36, Remainder = 37, CaseWhen = 38, In = 39, Not = 40,
   UnaryMinus = 41, ShiftRight = 42, ShiftLeft = 43, If = 44, IntegralDivide = 59, NormalizeNaNAndZero = 45, Unbound = 51,

@@ -151,6 +151,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_regexp_extract_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32)]
     lib.comet_split_host.restype = c.c_int32
     lib.comet_split_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.c_int32]
+    lib.comet_date_fn_host.restype = c.c_int32
+    lib.comet_date_fn_host.argtypes = [c.c_int32, c.c_int64, c.c_int64, c.c_int64, c.POINTER(c.c_int64)]
     lib.comet_page_decompress.restype = c.c_int32
     lib.comet_page_decompress.argtypes = [c.c_int32, c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]
     lib.comet_snappy_inflate_pages.restype = c.c_int64
@@ -1201,6 +1203,15 @@ def split_host(pattern: str, limit: int, value: str):
     if k < 0:
         _raise_last(0)
     return [v[a[i]:a[i] + b[i]].decode() for i in range(k)]
+
+
+def date_fn_host(fn: int, a: int, b: int = 0, c: int = 0):
+    """the generated kernels' calendar functions on the host (comet_date_fn_host): → the value, or None for NULL"""
+    out = ctypes.c_int64(0)
+    rc = lib().comet_date_fn_host(fn, a, b, c, ctypes.byref(out))
+    if rc < 0:
+        _raise_last(0)
+    return out.value if rc == 1 else None
 
 
 def parquet_host_plain_values(plan: bytes, column: int) -> bytes:

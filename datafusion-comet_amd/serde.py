@@ -180,7 +180,7 @@ class Expr:
     check_divide_overflow: bool = False   # MathExpr field 6 (integral_divide only)
 
     # field numbers of Expr.expr_struct (expr.proto:30-107)
-    TAGS = dict(hour=22, minute=23, second=24, literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
+    TAGS = dict(trunc_timestamp=47, unix_timestamp=65, hour=22, minute=23, second=24, literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
                 lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, like=26, rlike=30, scalar_func=31, eq_null_safe=32,
                 neq_null_safe=33, bit_and=34, bit_or=35, bit_xor=36, shift_right=42, shift_left=43, integral_divide=59, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
                 unbound=51, get_struct_field=54)
@@ -201,8 +201,10 @@ class Expr:
                 body += _f_varint(5, self.eval_mode)
             if getattr(self, "check_divide_overflow", False):
                 body += _f_varint(6, 1)
-        elif k in ("hour", "minute", "second"):      # expr.proto:436-453: child = 1, timezone = 2
+        elif k in ("hour", "minute", "second", "unix_timestamp"):      # expr.proto:436-458: child = 1, timezone = 2
             body = _f_msg(1, self.children[0].encode()) + _f_bytes(2, (getattr(self, "timezone", None) or "UTC").encode())
+        elif k == "trunc_timestamp":                                   # expr.proto:507-511: format = 1, child = 2, timezone = 3
+            body = _f_msg(1, self.children[1].encode()) + _f_msg(2, self.children[0].encode()) + _f_bytes(3, (getattr(self, "timezone", None) or "UTC").encode())
         elif k == "cast":
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.dtype.encode()) + _f_bytes(3, (getattr(self, "timezone", None) or "UTC").encode())
             if self.eval_mode:
@@ -363,6 +365,20 @@ def time_part(kind: str, child: Expr, timezone: str = "UTC") -> Expr:
     """Hour / Minute / Second of a timestamp in the session time zone (expr.proto:436-453)."""
     assert kind in ("hour", "minute", "second")
     e = Expr(kind, [child])
+    e.timezone = timezone
+    return e
+
+
+def trunc_timestamp(child: Expr, fmt: str, timezone: str = "UTC") -> Expr:
+    """TruncTimestamp (date_trunc(fmt, ts); expr.proto:507-511): children = [timestamp, format literal]"""
+    e = Expr("trunc_timestamp", [child, lit(fmt, T_STRING)])
+    e.timezone = timezone
+    return e
+
+
+def unix_timestamp(child: Expr, timezone: str = "UTC") -> Expr:
+    """UnixTimestamp of a timestamp / timestamp_ntz / date (expr.proto:455-458) → bigint seconds"""
+    e = Expr("unix_timestamp", [child])
     e.timezone = timezone
     return e
 

@@ -207,6 +207,11 @@ int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint
  * subset.  Needs no GPU. */
 int32_t comet_split_host(const char* pattern, int32_t limit, const uint8_t* value, size_t value_len, int32_t* starts, int32_t* lens, int32_t cap);
 
+/* The calendar functions of the generated kernels (csrc/device/dates.hpp) on the host — diagnostic entry: fn 0 date_part(days, part), 1 isodow, 2 ISO week,
+ * 3 date_trunc(days, unit), 4 last_day, 5 next_day(days, weekday Monday = 0), 6 make_date(y, m, d), 7 timestamp_trunc(wall-clock µs, unit).  → 1 and *out,
+ * 0 = NULL, -2 and comet_last_error(0).  Needs no GPU. */
+int32_t comet_date_fn_host(int32_t fn, int64_t a, int64_t b, int64_t c, int64_t* out);
+
 /* ---- time zones (csrc/tz.cpp) -------------------------------------------------------------------------------------------------------------
  * The table a Cast / date-part expression with `zone` as its time zone is planned with: { n, offset before the first transition, first instant
  * the table does not answer, n transition instants (UTC seconds), n offsets (seconds east of UTC) } — read from the system's time-zone

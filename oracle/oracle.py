@@ -165,6 +165,21 @@ def col_to_arrow(S, c: Col) -> pa.Array:
     return pa.array(c.values, type=pt, mask=mask)
 
 
+_LIBM_LIB = None
+
+
+def _libm_fn(name: str, nargs: int = 1):
+    """a function of the platform's libm (glibc here as on the reference's hosts): C semantics for NaN, infinities and domain errors, no Python exceptions"""
+    global _LIBM_LIB
+    import ctypes.util
+    if _LIBM_LIB is None:
+        _LIBM_LIB = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    fn = getattr(_LIBM_LIB, name)
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_double] * nargs
+    return fn
+
+
 def crate_pattern_to_python(pat: str):
     """the crate's pattern in Python's `re` syntax, for the part both read alike: $ / \\z are "at the very end" there (\\Z here) unless (?m)"""
     import re
@@ -267,6 +282,44 @@ class Evaluator:
                     sec = (C.utc_to_local_us(tz, us) if a.dtype.type_id == S.TIMESTAMP else us) % 86_400_000_000 // 1_000_000
                     out[i] = {"hour": sec // 3600, "minute": sec // 60 % 60, "second": sec % 60}[k]
             return Col(S.T_INT32, out, a.valid)
+        if k == "unix_timestamp":
+            # SparkUnixTimestamp (datetime_funcs/unix_timestamp.rs:70-150): floor(µs / 10^6) of an instant or a TIMESTAMP_NTZ; a date's midnight in the zone as an instant
+            from . import strcast as C
+            a = self.eval(e.children[0], cols, n)
+            tz = getattr(e, "timezone", None) or "UTC"
+            out = np.zeros(n, np.int64)
+            for i in range(n):
+                if a.ok()[i]:
+                    out[i] = (C.local_to_utc_us(tz, int(a.values[i]) * 86_400_000_000) if a.dtype.type_id == S.DATE else int(a.values[i])) // 1_000_000
+            return Col(S.T_INT64, out, a.valid)
+        if k == "trunc_timestamp":
+            # timestamp_trunc (kernels/temporal.rs:179-270, 587-625): the zone's wall clock cut to the unit (fixed-offset zones and UTC here)
+            import datetime
+            from . import strcast as C
+            a = self.eval(e.children[0], cols, n)
+            tz = getattr(e, "timezone", None) or "UTC"
+            u = e.children[1].value.upper()
+            U = datetime.datetime(1970, 1, 1)
+            out = np.zeros(n, np.int64)
+            for i in range(n):
+                if not a.ok()[i]:
+                    continue
+                us = int(a.values[i])
+                loc = C.utc_to_local_us(tz, us) if a.dtype.type_id == S.TIMESTAMP else us
+                t = U + datetime.timedelta(microseconds=loc)
+                z = dict(hour=0, minute=0, second=0, microsecond=0)
+                if u in ("YEAR", "YYYY", "YY"): t = t.replace(month=1, day=1, **z)
+                elif u == "QUARTER": t = t.replace(month=(t.month - 1) // 3 * 3 + 1, day=1, **z)
+                elif u in ("MONTH", "MON", "MM"): t = t.replace(day=1, **z)
+                elif u == "WEEK": t = (t - datetime.timedelta(days=t.weekday())).replace(**z)
+                elif u in ("DAY", "DD"): t = t.replace(**z)
+                elif u == "HOUR": t = t.replace(minute=0, second=0, microsecond=0)
+                elif u == "MINUTE": t = t.replace(second=0, microsecond=0)
+                elif u == "SECOND": t = t.replace(microsecond=0)
+                elif u == "MILLISECOND": t = t.replace(microsecond=t.microsecond // 1000 * 1000)
+                elif u != "MICROSECOND": raise OracleError("Unsupported format: %r for function 'timestamp_trunc'" % u)
+                out[i] = (t - U) // datetime.timedelta(microseconds=1) - (loc - us)
+            return Col(a.dtype, out, a.valid)
         if k == "not_":
             a = self.eval(e.children[0], cols, n)
             return Col(S.T_BOOL, ~a.values.astype(bool), a.valid)
@@ -412,7 +465,7 @@ class Evaluator:
                 if a.ok()[i]:
                     d = datetime.date(1970, 1, 1) + datetime.timedelta(days=int(a.values[i]))
                     out[i] = {"year": d.year, "month": d.month, "day": d.day, "quarter": (d.month - 1) // 3 + 1, "dow": (d.weekday() + 1) % 7,
-                              "doy": d.timetuple().tm_yday}[part]
+                              "doy": d.timetuple().tm_yday, "isodow": d.isoweekday(), "week": d.isocalendar()[1]}[part]
             return Col(S.T_INT32, out, a.valid)
         if f == "xxhash64":
             # spark_xxhash64 (hash_funcs/xxhash64.rs:31-82): XXH64 (the `xxhash` package here, twox-hash there) of each non-NULL value's
@@ -548,6 +601,145 @@ class Evaluator:
             for i in range(n):
                 out[i] = (a.values[i].upper() if f == "upper" else a.values[i].lower()) if a.ok()[i] else None
             return Col(S.T_STRING, out, a.valid)
+        # ---- the Float64 functions the reference hands to DataFusion / datafusion-spark (QueryPlanSerde.scala:117-174): numpy's libm where Rust's std stands
+        # there — both within an ulp or two of the exact value, the tests compare with a stated tolerance
+        _LIBM = {"acos": "acos", "acosh": "acosh", "asin": "asin", "asinh": "asinh", "atan": "atan", "atanh": "atanh", "cbrt": "cbrt", "cos": "cos", "cosh": "cosh", "exp": "exp",
+                 "expm1": "expm1", "ln": "log", "log2": "log2", "log10": "log10", "sin": "sin", "sinh": "sinh", "tan": "tan", "tanh": "tanh", "cot": "tan", "csc": "sin", "sec": "cos",
+                 "rint": "rint"}
+        if f in _LIBM or f in ("degrees", "radians"):
+            a = self.eval(e.children[0], cols, n)
+            x = a.values.astype(np.float64)
+            if f == "degrees":      # f64::to_degrees: x · (180 / π as the constant 57.29577951308232…)
+                v = x * (180.0 / np.pi)
+            elif f == "radians":    # f64::to_radians: x · (π / 180)
+                v = x * (np.pi / 180.0)
+            else:
+                fn = _libm_fn(_LIBM[f])       # the platform's libm: what Rust's f64 methods call in the reference
+                v = np.array([fn(float(t)) for t in x], dtype=np.float64)
+                if f in ("cot", "csc", "sec"):      # datafusion-spark: 1 / tan, 1 / sin, 1 / cos
+                    with np.errstate(all="ignore"):
+                        v = 1.0 / v
+            return Col(S.T_DOUBLE, v, a.valid)
+        if f == "pi":
+            return Col(S.T_DOUBLE, np.full(n, np.pi), None)
+        if f in ("atan2", "pow", "power", "spark_log"):
+            a, b = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            x, y = a.values.astype(np.float64), b.values.astype(np.float64)
+            ok = a.ok() & b.ok()
+            with np.errstate(all="ignore"):
+                if f == "atan2":
+                    fn = _libm_fn("atan2", 2)
+                    v = np.array([fn(float(p), float(q)) for p, q in zip(x, y)], dtype=np.float64)
+                elif f == "spark_log":      # math_funcs/log.rs:30-38: ln(value) / ln(base), NULL when base <= 0 or value <= 0
+                    ok = ok & (x > 0) & (y > 0)
+                    ln = _libm_fn("log")
+                    v = np.array([ln(float(q)) if q > 0 else 0.0 for q in y], dtype=np.float64) / np.array([ln(float(p)) if p > 0 else 1.0 for p in x], dtype=np.float64)
+                else:                       # math_funcs/pow.rs:24-29: Java's Math.pow — |base| = 1 with an infinite / NaN exponent is NaN
+                    fn = _libm_fn("pow", 2)
+                    v = np.where((np.abs(x) == 1.0) & ~np.isfinite(y), np.nan, np.array([fn(float(p), float(q)) for p, q in zip(x, y)], dtype=np.float64))
+            return Col(S.T_DOUBLE, v, None if ok.all() else ok)
+        if f == "factorial":                # Spark's Factorial: 0..20, NULL outside
+            import math
+            a = self.eval(e.children[0], cols, n)
+            inside = (a.values >= 0) & (a.values <= 20)
+            ok = a.ok() & inside
+            return Col(S.T_INT64, np.array([math.factorial(int(v)) if i else 0 for v, i in zip(a.values, inside)], dtype=np.int64), None if ok.all() else ok)
+        if f in ("bitwise_not", "bit_count", "bit_get", "getbit", "shiftrightunsigned"):
+            a = self.eval(e.children[0], cols, n)
+            if f == "bitwise_not":
+                return Col(a.dtype, ~a.values, a.valid)
+            if f == "bit_count":            # Java's Long.bitCount of the value widened to a long
+                v = a.values.astype(np.int64).view(np.uint64)
+                return Col(S.T_INT32, np.array([bin(int(x)).count("1") for x in v], dtype=np.int32), a.valid)
+            b = self.eval(e.children[1], cols, n)
+            ok = a.ok() & b.ok()
+            if f == "shiftrightunsigned":   # Java's >>>: the count modulo the width
+                if a.values.dtype == np.int64:
+                    v = (a.values.view(np.uint64) >> (b.values.astype(np.int64) & 63).astype(np.uint64)).view(np.int64)
+                else:
+                    v = (a.values.astype(np.int32).view(np.uint32) >> (b.values.astype(np.int64) & 31).astype(np.uint32)).view(np.int32)
+                return Col(a.dtype, v, None if ok.all() else ok)
+            return Col(S.T_INT8, ((a.values.astype(np.int64) >> b.values.astype(np.int64)) & 1).astype(np.int8), None if ok.all() else ok)
+        if f in ("greatest", "least"):
+            # NULL arguments are skipped, NULL only when every argument is; NaN is the greatest double (Spark's ordering, DataFusion's total order)
+            args = [self.eval(c, cols, n) for c in e.children]
+            vals = args[0].values.copy()
+            ok = args[0].ok().copy()
+            for b in args[1:]:
+                bv, bok = b.values, b.ok()
+                if vals.dtype.kind == "f":
+                    an, bn = np.isnan(vals), np.isnan(bv)
+                    with np.errstate(all="ignore"):
+                        better = (bn | (~an & (bv > vals))) if f == "greatest" else (an | (~bn & (bv < vals)))
+                else:
+                    better = (bv > vals) if f == "greatest" else (bv < vals)
+                take = bok & (~ok | better)
+                vals = np.where(take, bv, vals)
+                ok = ok | bok
+            return Col(args[0].dtype, vals, None if ok.all() else ok)
+        if f in ("last_day", "date_from_unix_date", "date_trunc", "trunc", "next_day", "make_date"):
+            import datetime
+            E = datetime.date(1970, 1, 1)
+            to_date = lambda v: E + datetime.timedelta(days=int(v))
+            a = self.eval(e.children[0], cols, n)
+            if f == "date_from_unix_date":  # date_from_unix_date.rs:52-60: the Int32 is the date
+                return Col(S.T_DATE, a.values.astype(np.int32), a.valid)
+            out = np.zeros(n, np.int32)
+            ok = a.ok().copy()
+            if f == "make_date":            # make_date.rs:87-96: chrono's from_ymd_opt — what it refuses is NULL
+                m, d = self.eval(e.children[1], cols, n), self.eval(e.children[2], cols, n)
+                ok &= m.ok() & d.ok()
+                for i in range(n):
+                    if ok[i]:
+                        try:
+                            out[i] = (datetime.date(int(a.values[i]), int(m.values[i]), int(d.values[i])) - E).days
+                        except ValueError:
+                            ok[i] = False       # (years beyond 1..9999 are not generated by the tests: Python's calendar ends there)
+                return Col(S.T_DATE, out, None if ok.all() else ok)
+            arg = e.children[1].value if len(e.children) > 1 else None
+            if f == "next_day":             # next_day.rs:49-68
+                names = {"MO": 0, "MON": 0, "MONDAY": 0, "TU": 1, "TUE": 1, "TUESDAY": 1, "WE": 2, "WED": 2, "WEDNESDAY": 2, "TH": 3, "THU": 3, "THURSDAY": 3, "FR": 4, "FRI": 4,
+                         "FRIDAY": 4, "SA": 5, "SAT": 5, "SATURDAY": 5, "SU": 6, "SUN": 6, "SUNDAY": 6}
+                target = names.get(arg.upper()) if arg is not None else None
+                if target is None:
+                    return Col(S.T_DATE, out, np.zeros(n, bool))
+            for i in range(n):
+                if not ok[i]:
+                    continue
+                dd = to_date(a.values[i])
+                if f == "last_day":
+                    import calendar
+                    r = dd.replace(day=calendar.monthrange(dd.year, dd.month)[1])
+                elif f == "next_day":
+                    r = dd + datetime.timedelta(days=7 - (dd.weekday() - target) % 7)
+                else:                       # kernels/temporal.rs:63-100, 326-337
+                    u = arg.upper()
+                    if u in ("YEAR", "YYYY", "YY"):
+                        r = datetime.date(dd.year, 1, 1)
+                    elif u == "QUARTER":
+                        r = datetime.date(dd.year, (dd.month - 1) // 3 * 3 + 1, 1)
+                    elif u in ("MONTH", "MON", "MM"):
+                        r = datetime.date(dd.year, dd.month, 1)
+                    elif u == "WEEK":
+                        r = dd - datetime.timedelta(days=dd.weekday())
+                    else:
+                        raise OracleError("Unsupported format: %r for function 'date_trunc'" % arg)
+                out[i] = (r - E).days
+            return Col(S.T_DATE, out, None if ok.all() else ok)
+        if f in ("seconds_to_timestamp", "timestamp_seconds"):
+            # seconds_to_timestamp.rs:63-105: integers · 10^6 (an Int64 product beyond i64: "long overflow"), floats (s · 10^6) as i64 saturating, NaN / ±inf NULL
+            a = self.eval(e.children[0], cols, n)
+            if a.values.dtype.kind == "f":
+                x = a.values.astype(np.float64)
+                ok = a.ok() & np.isfinite(x)
+                with np.errstate(all="ignore"):
+                    p = np.where(np.isfinite(x), x, 0.0) * 1e6
+                v = np.where(p >= 9.223372036854775807e18, np.iinfo(np.int64).max, np.where(p <= -9.223372036854775808e18, np.iinfo(np.int64).min, np.trunc(np.clip(p, -9.2e18, 9.2e18)).astype(np.int64)))
+                return Col(S.T_TIMESTAMP, v.astype(np.int64), None if ok.all() else ok)
+            big = a.ok() & (np.abs(a.values.astype(np.float64)) > 9223372036854.0)
+            if big.any():
+                raise OracleError("long overflow")
+            return Col(S.T_TIMESTAMP, a.values.astype(np.int64) * 1000000, a.valid)
         if f == "split":
             # spark_split (string_funcs/split.rs:32-97, 434-472): the pieces between the pattern's matches — limit > 0: at most limit - 1 cuts;
             # limit = 0: trailing empty pieces dropped (nothing left: one empty piece); limit < 0 (the default): every piece.  NULL subject → NULL list.

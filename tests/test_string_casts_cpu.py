@@ -87,7 +87,7 @@ i32 f_ts(i64 us, i64 off, u8* o) { return fmt_timestamp(us, off, o); }
     c = d / "dev_strcast.cpp"
     c.write_text(shim)
     so = d / "libdevstrcast.so"
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-o", str(so), str(c)])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-I", os.path.dirname(_HDR), "-o", str(so), str(c)])      # (-I: the section includes dates.hpp)
     return ctypes.CDLL(str(so))
 
 

@@ -58,7 +58,7 @@ int t_ntz(const u8* p, i32 n, i64* out) { return str_to_timestamp_ntz(p, n, *out
 """
     d = tmp_path_factory.mktemp("strts")
     (d / "t.cpp").write_text(shim)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-I", _CSRC, "-o", str(d / "libts.so"), str(d / "t.cpp")])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-I", _CSRC, "-I", os.path.join(_CSRC, "device"), "-o", str(d / "libts.so"), str(d / "t.cpp")])
     return ctypes.CDLL(str(d / "libts.so"))
 
 

@@ -121,6 +121,46 @@ def probes():
         "Murmur3Hash": (f("murmur3_hash", [i64, d, L(42, S.T_INT32)], S.T_INT32), "fixed-width types (Spark's hash(...)); Utf8 arguments are refused"), "XxHash64": (f("xxhash64", [i64, L(42, S.T_INT64)], S.T_INT64), "fixed-width types"),
         "KnownFloatingPointNormalized": (S.Expr("normalize_nan_and_zero", [f64], dtype=S.T_DOUBLE), "NormalizeNaNAndZero"),
         "SortOrder": (i32, "inside Sort / Window / SortMergeJoin / range partitioning"),
+        "StringSplit": (f("split", [s, L(",", S.T_STRING), L(-1, S.T_INT32)], S.list_type(S.T_STRING, False)),
+                        "under spark.comet.expression.StringSplit.allowIncompatible: of a Utf8 COLUMN with a literal pattern and limit, computed over the chain's source and passed through / exploded; the matcher's pattern subset"),
+        "UnixDate": (S.cast(d, S.T_INT32), "serialized as Cast(date AS int)"), "Days": (S.cast(d, S.T_INT32), "serialized as Cast(date AS int)"),
+        "WeekDay": (S.date_part("isodow", d), "datepart('isodow') − 1"), "WeekOfYear": (S.date_part("week", d), "the ISO-8601 week"),
+        "LastDay": (f("last_day", [d], S.T_DATE), ""), "DateFromUnixDate": (f("date_from_unix_date", [i32], S.T_DATE), ""),
+        "TruncDate": (f("date_trunc", [d, L("quarter", S.T_STRING)], S.T_DATE), "literal format: year / yyyy / yy / quarter / month / mon / mm / week"),
+        "NextDay": (f("next_day", [d, L("TU", S.T_STRING)], S.T_DATE), "literal day name (an unknown name under ANSI fails at createPlan)"),
+        "MakeDate": (f("make_date", [i32, i32, i32], S.T_DATE), "LEGACY / TRY (NULL for an invalid date); ANSI mode is refused"),
+        "SecondsToTimestamp": (f("seconds_to_timestamp", [i32], S.T_TIMESTAMP), "Int32 / Int64 / Float32 / Float64"),
+        "TruncTimestamp": (S.trunc_timestamp(S.cast(d, S.T_TIMESTAMP), "hour"), "literal format; UTC and fixed-offset zones (what the JVM sends without allowIncompatible), TIMESTAMP_NTZ"),
+        "UnixTimestamp": (S.unix_timestamp(d, "America/Los_Angeles"), "timestamp / timestamp_ntz / date in any zone of the database"),
+        "BitwiseNot": (f("bitwise_not", [i64], S.T_INT64), ""), "BitwiseCount": (f("bit_count", [i64], S.T_INT32), ""),
+        "BitwiseGet": (f("bit_get", [i64, L(3, S.T_INT32)], S.T_INT8), "literal position inside the value's bits"),
+        "ShiftRightUnsigned": (f("shiftrightunsigned", [i64, i32], S.T_INT64), ""),
+        "Factorial": (f("factorial", [i32], S.T_INT64), ""), "Greatest": (f("greatest", [i64, L(1, S.T_INT64), i64], S.T_INT64), "numbers, decimals, dates, timestamps"),
+        "Least": (f("least", [f64, f64], S.T_DOUBLE), ""), "Pi": (f("pi", [], S.T_DOUBLE), ""), "Atan2": (f("atan2", [f64, f64], S.T_DOUBLE), ""), "Pow": (f("pow", [f64, f64], S.T_DOUBLE), "Java's Math.pow corner cases (math_funcs/pow.rs)"),
+        "Logarithm": (f("spark_log", [f64, f64], S.T_DOUBLE), ""), "Log": (f("ln", [f64], S.T_DOUBLE), "the JVM wraps the argument in If(x <= 0, NULL, x)"),
+        "Log2": (f("log2", [f64], S.T_DOUBLE), ""), "Log10": (f("log10", [f64], S.T_DOUBLE), ""),
+        "Acos": (f("acos", [f64], S.T_DOUBLE), "Float64; the device's libm (within a few ulp of the reference's)"),
+        "Acosh": (f("acosh", [f64], S.T_DOUBLE), ""),
+        "Asin": (f("asin", [f64], S.T_DOUBLE), ""),
+        "Asinh": (f("asinh", [f64], S.T_DOUBLE), ""),
+        "Atan": (f("atan", [f64], S.T_DOUBLE), ""),
+        "Atanh": (f("atanh", [f64], S.T_DOUBLE), ""),
+        "Cbrt": (f("cbrt", [f64], S.T_DOUBLE), ""),
+        "Cos": (f("cos", [f64], S.T_DOUBLE), ""),
+        "Cosh": (f("cosh", [f64], S.T_DOUBLE), ""),
+        "Csc": (f("csc", [f64], S.T_DOUBLE), ""),
+        "Exp": (f("exp", [f64], S.T_DOUBLE), ""),
+        "Expm1": (f("expm1", [f64], S.T_DOUBLE), ""),
+        "Rint": (f("rint", [f64], S.T_DOUBLE), ""),
+        "Sec": (f("sec", [f64], S.T_DOUBLE), ""),
+        "Sin": (f("sin", [f64], S.T_DOUBLE), ""),
+        "Sinh": (f("sinh", [f64], S.T_DOUBLE), ""),
+        "Tan": (f("tan", [f64], S.T_DOUBLE), ""),
+        "Tanh": (f("tanh", [f64], S.T_DOUBLE), ""),
+        "ToDegrees": (f("degrees", [f64], S.T_DOUBLE), ""),
+        "ToRadians": (f("radians", [f64], S.T_DOUBLE), ""),
+        "Cot": (f("cot", [f64], S.T_DOUBLE), ""),
+
     }
     return P
 
