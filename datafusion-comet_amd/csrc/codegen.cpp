@@ -362,7 +362,11 @@ struct Gen {
     k << (int)e->kind << ":" << (int)e->dtype.id << "," << e->dtype.precision << "," << e->dtype.scale << ":"
       << (int)e->eval_mode << e->fail_on_error << e->negated;
     if (e->kind == ExprKind::Bound) k << "#" << e->bound_index;
-    if (e->kind == ExprKind::ScalarFunc) k << "F" << e->func;
+    // (`func` is a ScalarFunc's name — and the time zone of a Cast / Hour / Minute / Second / TruncTimestamp / UnixTimestamp: the same child in two zones
+    // is two values)
+    if (!e->func.empty()) k << "F" << e->func.size() << ":" << e->func;
+    if (e->is_spark4_plus) k << "S4";
+    if (e->check_divide_overflow) k << "DO";
     if (e->kind == ExprKind::CaseWhen) k << "W" << e->n_when;
     if (e->kind == ExprKind::Literal) {
       k << "L" << e->lit_case << e->lit_null << e->lit_bool << ":" << e->lit_i64 << ":";

@@ -104,6 +104,8 @@ def test_timestamps(built):
     _check([S.trunc_timestamp(ts, u, "+05:30") for u in ("week", "DD", "hour")] + [S.trunc_timestamp(ntz, u) for u in ("yyyy", "mm", "week", "minute")], types, t)
     _check([S.unix_timestamp(ts), S.unix_timestamp(ntz), S.unix_timestamp(d), S.unix_timestamp(d, "America/Los_Angeles"), S.unix_timestamp(d, "+05:30"), f("seconds_to_timestamp", [s], TS),
             f("seconds_to_timestamp", [x], TS), f("seconds_to_timestamp", [S.cast(s, I64)], TS)], types, t)
+    # one child in several zones inside ONE kernel: the zone belongs to the expression's identity (the generator once merged these)
+    _check([S.time_part("hour", ts, "UTC"), S.time_part("hour", ts, "+05:30"), S.time_part("hour", ts, "America/Los_Angeles"), S.cast(ts, D, timezone="UTC"), S.cast(ts, D, timezone="Asia/Tokyo")], types, t)
 
 
 def test_refusals_and_errors(built):
