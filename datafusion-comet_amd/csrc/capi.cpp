@@ -563,6 +563,16 @@ int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint
   });
 }
 
+int32_t comet_extract_all_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* starts, int32_t* lens, int32_t cap) {
+  return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
+    const RegexProg whole = compile_regex_captures(pattern ? pattern : "", 0, "regexp_extract_all");
+    const RegexProg grp = group == 0 ? RegexProg() : compile_regex_captures(pattern ? pattern : "", group, "regexp_extract_all");
+    const auto spans = regex_prog_find_all(whole, group == 0 ? whole : grp, value, value_len);
+    for (size_t k = 0; k < spans.size() && (int32_t)k < cap; k++) { starts[k] = spans[k].first; lens[k] = spans[k].second; }
+    return (int32_t)spans.size();
+  });
+}
+
 int32_t comet_split_host(const char* pattern, int32_t limit, const uint8_t* value, size_t value_len, int32_t* starts, int32_t* lens, int32_t cap) {
   return guarded(nullptr, (int32_t)-2, [&]() -> int32_t {
     const RegexProg prog = compile_regex_captures(pattern ? pattern : "", 0, "split");

@@ -194,25 +194,32 @@ thread_local const std::vector<ExprP>* g_source_cols = nullptr;
 // fused kernel runs (exec.cpp extend_derived), the chain addresses it as column (source columns + k).  `g_derived`: where a fold notes them.
 thread_local std::vector<DerivedCol>* g_derived = nullptr;
 ExprP lower_split(const ExprP& e) {
-  if (e->children.size() < 2 || e->children.size() > 3) throw CometError("split expects 2 or 3 arguments (string, pattern, [limit]), got " + std::to_string(e->children.size()));
+  const bool all = e->func == "regexp_extract_all";      // (string_funcs/regexp_extract_all.rs: (subject, pattern, [idx = 1]) → group idx of every match)
+  const std::string fname = all ? "regexp_extract_all" : "split";
+  if (e->children.size() < 2 || e->children.size() > 3)
+    throw CometError(all ? "regexp_extract_all expects 2 or 3 arguments (subject, pattern, [idx]), got " + std::to_string(e->children.size())
+                         : "split expects 2 or 3 arguments (string, pattern, [limit]), got " + std::to_string(e->children.size()));
   const ExprP &subject = e->children[0], &pat = e->children[1];
-  if (!g_derived || !g_source_cols) throw CometError("split is supported in Projection / Filter chains only");
+  if (!g_derived || !g_source_cols) throw CometError(fname + " is supported in Projection / Filter chains only");
   const int nsrc = (int)g_source_cols->size();
   if (subject->kind != ExprKind::Bound || subject->bound_index < 0 || subject->bound_index >= nsrc || !subject->has_dtype || subject->dtype.id != TypeId::String)
-    throw CometError("split is supported over a Utf8 COLUMN of the source (not over a computed string) by the MI355X native engine");
-  if (pat->kind != ExprKind::Literal || (pat->dtype.id != TypeId::String && !pat->lit_null)) throw CometError("split pattern must be a string literal");
-  int limit = -1;
+    throw CometError(fname + " is supported over a Utf8 COLUMN of the source (not over a computed string) by the MI355X native engine");
+  if (pat->kind != ExprKind::Literal || (pat->dtype.id != TypeId::String && !pat->lit_null)) throw CometError(fname + " pattern must be a string literal");
+  int limit = all ? 1 : -1;      // (regexp_extract_all: the group index travels here)
   if (e->children.size() == 3) {
     const ExprP& l = e->children[2];
-    if (l->kind != ExprKind::Literal || l->lit_null || l->dtype.id != TypeId::Int32) throw CometError("split limit argument must be an Int32 scalar");
-    limit = (int)std::max<long long>(std::min<long long>(l->lit_i64, 0x7fffffffLL), -1);
+    if (l->kind != ExprKind::Literal || l->lit_null || l->dtype.id != TypeId::Int32) throw CometError(all ? "regexp_extract_all idx must be an Int32 scalar" : "split limit argument must be an Int32 scalar");
+    limit = (int)std::max<long long>(std::min<long long>(l->lit_i64, 0x7fffffffLL), all ? -0x7fffffffLL : -1);
   }
-  if (pat->lit_null) throw CometError("split with a NULL pattern is not supported by the MI355X native engine");
+  if (pat->lit_null) throw CometError(fname + " with a NULL pattern is not supported by the MI355X native engine");
   DerivedCol dc;
-  dc.kind = 1;
+  dc.kind = all ? 2 : 1;
   dc.src = subject->bound_index;
   dc.limit = limit;
-  try {
+  if (all) {
+    dc.prog = compile_regex_captures(pat->lit_bytes, 0, "regexp_extract_all").words;
+    if (limit != 0) dc.prog2 = compile_regex_captures(pat->lit_bytes, limit, "regexp_extract_all").words;      // (the reference's message for an index out of range)
+  } else try {
     dc.prog = compile_regex_captures(pat->lit_bytes, 0, "split").words;
   } catch (const CometError& err) {
     const std::string m = err.what();
@@ -223,7 +230,7 @@ ExprP lower_split(const ExprP& e) {
   DType elem = DType::of(TypeId::String);
   dc.type.kids.push_back(elem);
   dc.type.kid_names.push_back("item");
-  dc.type.kid_nullable.push_back(false);
+  dc.type.kid_nullable.push_back(all);      // (regexp_extract_all's item field is nullable, split's is not: regexp_extract_all.rs:101, split.rs:318)
   for (size_t k = 0; k < g_derived->size(); k++) {
     const DerivedCol& o = (*g_derived)[k];
     if (o.kind == dc.kind && o.src == dc.src && o.limit == dc.limit && o.prog == dc.prog) {
@@ -261,7 +268,7 @@ ExprP substitute(const ExprP& e, const std::vector<ExprP>& cols, std::map<const 
   ExprP out;
   if (e->kind == ExprKind::GetStructField && e->children.size() == 1) {
     out = lower_struct_field(e, substitute(e->children[0], cols, memo));
-  } else if (e->kind == ExprKind::ScalarFunc && e->func == "split") {
+  } else if (e->kind == ExprKind::ScalarFunc && (e->func == "split" || e->func == "regexp_extract_all")) {
     auto n = std::make_shared<Expr>(*e);
     for (auto& c : n->children) c = substitute(c, cols, memo);
     out = lower_split(n);

@@ -43,9 +43,10 @@ struct OutCol {
 // (in_types holds it behind the source's own columns): today split(<Utf8 column>, <pattern literal>, <limit literal>) → list<string>,
 // which the chain passes through by row index like any nested column.
 struct DerivedCol {
-  int kind = 0;                     // 1: split
+  int kind = 0;                     // 1: split, 2: regexp_extract_all
   int src = -1;                     // the source column
-  std::vector<uint32_t> prog;       // split: the pattern as a group-0 program of device/regex_vm.hpp
+  std::vector<uint32_t> prog;       // the pattern as a group-0 program of device/regex_vm.hpp
+  std::vector<uint32_t> prog2;      // regexp_extract_all: the wanted group's program (empty: group 0)
   int limit = -1;
   DType type;
 };

@@ -226,3 +226,29 @@ RXVM_FN rx_i32 rx_split(const rx_u32* w, P text, rx_i32 n, rx_i32 limit, rx_i32 
   if (limit == 0) return kept == 0 ? 1 : kept;
   return k;
 }
+
+// regexp_extract_all(str, pattern, idx) (string_funcs/regexp_extract_all.rs:79-108 over the crate's captures_iter = find_iter's matches): group idx of
+// EVERY match.  `w0` is the pattern's group-0 program (it drives the iteration), `wg` the wanted group's (the same program when idx = 0): searched
+// from the same position both find the same match.  `emit(k, start, len)` sees match k's group (empty when it took no part); → the number of matches.
+template <class P, class F>
+RXVM_FN rx_i32 rx_find_all(const rx_u32* w0, const rx_u32* wg, P text, rx_i32 n, rx_i32 max_emit, F emit) {
+  rx_i32 at = 0, last_end = -1, k = 0;
+  while (true) {
+    rx_i32 m0 = -1, m1 = -1;
+    if (!rx_search(w0, text, n, at, m0, m1) || m0 < 0) break;
+    if (m0 == m1 && m1 == last_end) {
+      at = at + 1;
+      while (at < n && (text[at] & 0xC0u) == 0x80u) at++;
+      if (!rx_search(w0, text, n, at, m0, m1) || m0 < 0) break;
+    }
+    if (k < max_emit) {
+      rx_i32 g0 = m0, g1 = m1;
+      if (wg != w0 && !rx_search(wg, text, n, at, g0, g1)) g0 = g1 = -1;
+      emit(k, g0 < 0 ? 0 : g0, g0 < 0 ? 0 : g1 - g0);
+    }
+    k++;
+    at = m1;
+    last_end = m1;
+  }
+  return k;
+}

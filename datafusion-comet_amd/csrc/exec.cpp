@@ -1257,7 +1257,7 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
 // assembled from the views like every string view's result.
 void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol>& derived) {
   for (const DerivedCol& dc : derived) {
-    if (dc.kind != 1 || dc.src < 0 || (size_t)dc.src >= in.cols.size()) throw CometError("internal: unknown derived column");
+    if ((dc.kind != 1 && dc.kind != 2) || dc.src < 0 || (size_t)dc.src >= in.cols.size()) throw CometError("internal: unknown derived column");
     const DeviceColumnView sc = in.cols[(size_t)dc.src];
     const bool hv = in.has_valid[(size_t)dc.src];
     const int64_t rows = in.rows;
@@ -1267,6 +1267,16 @@ void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol
     prog.ensure(dc.prog.size() * 4 + 16);
     // (a program with \\b carries the \\w table: several KB — not a write_small)
     HIP_CHECK(hipMemcpyAsync(prog.p, dc.prog.data(), dc.prog.size() * 4, hipMemcpyHostToDevice, stream_));
+    DevBuf prog_group;      // regexp_extract_all: the wanted group's program (group 0: the pattern's own)
+    const uint32_t* prog2 = nullptr;
+    if (dc.kind == 2) {
+      if (dc.prog2.empty()) prog2 = (const uint32_t*)prog.p;
+      else {
+        prog_group.ensure(dc.prog2.size() * 4 + 16);
+        HIP_CHECK(hipMemcpyAsync(prog_group.p, dc.prog2.data(), dc.prog2.size() * 4, hipMemcpyHostToDevice, stream_));
+        prog2 = (const uint32_t*)prog_group.p;
+      }
+    }
     HIP_CHECK(hipStreamSynchronize(stream_));
     counts.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
     tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
@@ -1274,7 +1284,7 @@ void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol
     HIP_CHECK(hipMemsetAsync(list_offs->p, 0, 8, stream_));
     const int32_t* offs = (const int32_t*)sc.data + sc.offset;
     const uint8_t* vbits = hv ? sc.valid : nullptr;
-    if (comet_launch_split_count(offs, (const uint8_t*)sc.aux, vbits, sc.offset, rows, (const uint32_t*)prog.p, dc.limit, (uint32_t*)counts.p, stream_) != 0) throw CometError("split: launch failed");
+    if (comet_launch_split_count(offs, (const uint8_t*)sc.aux, vbits, sc.offset, rows, (const uint32_t*)prog.p, prog2, dc.limit, (uint32_t*)counts.p, stream_) != 0) throw CometError("split: launch failed");
     if (rows) pq_launch_u32_scan((const uint32_t*)counts.p, rows, (uint64_t*)tiles.p, (int32_t*)list_offs->p, stream_);
     int32_t total = 0;
     if (rows) read_small(&total, (char*)list_offs->p + (size_t)rows * 4, 4);
@@ -1286,7 +1296,7 @@ void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol
     etiles.ensure((size_t)((total + 1023) / 1024 + 2) * 8);
     eoffs->ensure((size_t)(total + 2) * 4);
     HIP_CHECK(hipMemsetAsync(eoffs->p, 0, 8, stream_));
-    if (comet_launch_split_write(offs, (const uint8_t*)sc.aux, vbits, sc.offset, rows, (const uint32_t*)prog.p, dc.limit, (const int32_t*)list_offs->p, views.p, stream_) != 0)
+    if (comet_launch_split_write(offs, (const uint8_t*)sc.aux, vbits, sc.offset, rows, (const uint32_t*)prog.p, prog2, dc.limit, (const int32_t*)list_offs->p, views.p, stream_) != 0)
       throw CometError("split: launch failed");
     if (comet_launch_strview_lengths(views.p, nullptr, total, nullptr, 0, (uint32_t*)lengths.p, stream_) != 0) throw CometError("split: launch failed");
     if (total) pq_launch_u32_scan((const uint32_t*)lengths.p, total, (uint64_t*)etiles.p, (int32_t*)eoffs->p, stream_);

@@ -63,9 +63,9 @@ extern "C" int comet_launch_strcase_write(const void* views, const uint8_t* ok_b
 extern "C" int comet_launch_popcount128(const void* blocks, int64_t n, uint32_t* counts, void* stream);
 extern "C" int comet_launch_strfmt_lengths(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream);
 extern "C" int comet_launch_strfmt_write(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
-extern "C" int comet_launch_split_count(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, int32_t limit, uint32_t* counts,
-                                        void* stream);
-extern "C" int comet_launch_split_write(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, int32_t limit,
+extern "C" int comet_launch_split_count(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, const uint32_t* prog2, int32_t limit,
+                                        uint32_t* counts, void* stream);
+extern "C" int comet_launch_split_write(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, const uint32_t* prog2, int32_t limit,
                                         const int32_t* list_offs, void* views, void* stream);
 extern "C" int comet_launch_strview_lengths(const void* views, const uint8_t* ok_bytes, int64_t n, const uint8_t* pattern, int32_t pattern_bytes, uint32_t* lengths, void* stream);
 extern "C" int comet_launch_strview_copy(const void* views, const uint8_t* ok_bytes, const int32_t* src_offs, const uint8_t* src_bytes, int64_t n, const uint8_t* pattern,

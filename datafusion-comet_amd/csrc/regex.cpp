@@ -1196,6 +1196,15 @@ std::vector<std::pair<int32_t, int32_t>> regex_prog_split(const RegexProg& prog,
   return out;
 }
 
+std::vector<std::pair<int32_t, int32_t>> regex_prog_find_all(const RegexProg& whole, const RegexProg& group, const uint8_t* s, size_t n) {
+  const uint32_t* w0 = whole.words.data();
+  const uint32_t* wg = &group == &whole ? w0 : group.words.data();
+  const int32_t count = rx_find_all(w0, wg, s, (int32_t)n, 0, [](int32_t, int32_t, int32_t) {});
+  std::vector<std::pair<int32_t, int32_t>> out((size_t)count, {-1, -1});
+  rx_find_all(w0, wg, s, (int32_t)n, count, [&](int32_t k, int32_t a, int32_t len) { out[(size_t)k] = {a, len}; });
+  return out;
+}
+
 bool regex_dfa_match(const RegexDfa& d, const uint8_t* s, size_t n) {
   int st = 0;
   if (d.flags[0] & 1) return true;

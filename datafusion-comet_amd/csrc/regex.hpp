@@ -35,4 +35,7 @@ bool regex_prog_extract(const RegexProg& prog, const uint8_t* s, size_t n, int32
 // split(str, pattern, limit) (string_funcs/split.rs) with a group-0 program: the pieces as (start, length) inside `s`, by the device's own two passes
 std::vector<std::pair<int32_t, int32_t>> regex_prog_split(const RegexProg& prog, const uint8_t* s, size_t n, int32_t limit);
 
+// regexp_extract_all: group spans of every match, by the device's two passes (`whole` = the group-0 program, `group` = the wanted group's or `whole` itself)
+std::vector<std::pair<int32_t, int32_t>> regex_prog_find_all(const RegexProg& whole, const RegexProg& group, const uint8_t* s, size_t n);
+
 }  // namespace comet

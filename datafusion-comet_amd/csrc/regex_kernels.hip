@@ -13,26 +13,30 @@ using namespace comet;
 
 namespace {
 
-__global__ __launch_bounds__(256) void split_count_kernel(const i32* offs, const u8* bytes, const u8* valid_bits, i64 vfirst, i64 n, const u32* prog, i32 limit, u32* counts) {
+// (prog2 set: regexp_extract_all — prog drives the iteration over the matches, prog2 reports the wanted group; string_funcs/regexp_extract_all.rs:79-108)
+__global__ __launch_bounds__(256) void split_count_kernel(const i32* offs, const u8* bytes, const u8* valid_bits, i64 vfirst, i64 n, const u32* prog, const u32* prog2, i32 limit, u32* counts) {
   for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < n; r += (i64)gridDim.x * 256) {
     const bool ok = !valid_bits || ((valid_bits[(vfirst + r) >> 3] >> ((vfirst + r) & 7)) & 1);
     u32 c = 0;
     if (ok) {
       const i32 lo = offs[r], len = offs[r + 1] - lo;
-      c = (u32)rx_split(prog, bytes + lo, len, limit, 0, [](i32, i32, i32) {});
+      c = prog2 ? (u32)rx_find_all(prog, prog2, bytes + lo, len, 0, [](i32, i32, i32) {}) : (u32)rx_split(prog, bytes + lo, len, limit, 0, [](i32, i32, i32) {});
     }
     counts[r] = c;
   }
 }
 
-__global__ __launch_bounds__(256) void split_write_kernel(const i32* offs, const u8* bytes, const u8* valid_bits, i64 vfirst, i64 n, const u32* prog, i32 limit, const i32* list_offs, strview* views) {
+__global__ __launch_bounds__(256) void split_write_kernel(const i32* offs, const u8* bytes, const u8* valid_bits, i64 vfirst, i64 n, const u32* prog, const u32* prog2, i32 limit, const i32* list_offs,
+                                                          strview* views) {
   for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < n; r += (i64)gridDim.x * 256) {
     const bool ok = !valid_bits || ((valid_bits[(vfirst + r) >> 3] >> ((vfirst + r) & 7)) & 1);
     if (!ok) continue;
     const i32 first = list_offs[r], cnt = list_offs[r + 1] - first;
     const i32 lo = offs[r], len = offs[r + 1] - lo;
     strview* out = views + first;
-    rx_split(prog, bytes + lo, len, limit, cnt, [&](i32 k, i32 a, i32 m) { out[k] = strview{(u32)r, (u32)a, (u32)m, 0u}; });
+    auto put = [&](i32 k, i32 a, i32 m) { out[k] = strview{(u32)r, (u32)a, (u32)m, 0u}; };
+    if (prog2) rx_find_all(prog, prog2, bytes + lo, len, cnt, put);
+    else rx_split(prog, bytes + lo, len, limit, cnt, put);
   }
 }
 
@@ -41,12 +45,13 @@ inline dim3 grid_rows(i64 n) { return dim3((unsigned)((n + 255) / 256 < 256 * 16
 }  // namespace
 
 // offs: the column's offsets at its first row (the view's offset applied by the caller); row r's validity is bit valid_first + r of valid_bits (null: every row is valid)
-extern "C" int comet_launch_split_count(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, int32_t limit, uint32_t* counts, void* stream) {
-  if (n > 0) hipLaunchKernelGGL(split_count_kernel, grid_rows(n), 256, 0, (hipStream_t)stream, offs, bytes, valid_bits, (i64)valid_first, (i64)n, prog, limit, counts);
+extern "C" int comet_launch_split_count(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, const uint32_t* prog2, int32_t limit, uint32_t* counts,
+                                        void* stream) {
+  if (n > 0) hipLaunchKernelGGL(split_count_kernel, grid_rows(n), 256, 0, (hipStream_t)stream, offs, bytes, valid_bits, (i64)valid_first, (i64)n, prog, prog2, limit, counts);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-extern "C" int comet_launch_split_write(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, int32_t limit, const int32_t* list_offs,
-                                        void* views, void* stream) {
-  if (n > 0) hipLaunchKernelGGL(split_write_kernel, grid_rows(n), 256, 0, (hipStream_t)stream, offs, bytes, valid_bits, (i64)valid_first, (i64)n, prog, limit, list_offs, (strview*)views);
+extern "C" int comet_launch_split_write(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, const uint32_t* prog2, int32_t limit,
+                                        const int32_t* list_offs, void* views, void* stream) {
+  if (n > 0) hipLaunchKernelGGL(split_write_kernel, grid_rows(n), 256, 0, (hipStream_t)stream, offs, bytes, valid_bits, (i64)valid_first, (i64)n, prog, prog2, limit, list_offs, (strview*)views);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -149,6 +149,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_rlike_match.argtypes = [c.c_char_p, c.c_char_p, c.c_size_t]
     lib.comet_regexp_extract_host.restype = c.c_int32
     lib.comet_regexp_extract_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32)]
+    lib.comet_extract_all_host.restype = c.c_int32
+    lib.comet_extract_all_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.c_int32]
     lib.comet_split_host.restype = c.c_int32
     lib.comet_split_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.c_int32]
     lib.comet_date_fn_host.restype = c.c_int32
@@ -1192,6 +1194,17 @@ def regexp_extract_host(pattern: str, group: int, value: str):
     if rc < 0:
         _raise_last(0)
     return rc == 1, v[a.value:a.value + b.value].decode()
+
+
+def extract_all_host(pattern: str, group: int, value: str):
+    """regexp_extract_all(value, pattern, group) by the device's two passes on the host (comet_extract_all_host)"""
+    v = value.encode()
+    cap = len(v) + 2
+    a, b = (ctypes.c_int32 * cap)(), (ctypes.c_int32 * cap)()
+    k = lib().comet_extract_all_host(pattern.encode(), group, v, len(v), a, b, cap)
+    if k < 0:
+        _raise_last(0)
+    return [v[a[i]:a[i] + b[i]].decode() for i in range(k)]
 
 
 def split_host(pattern: str, limit: int, value: str):

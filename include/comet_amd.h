@@ -202,6 +202,10 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
  * comet_last_error(0) for a pattern outside the subset or a group index out of range (the reference's message).  Needs no GPU. */
 int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* start, int32_t* len);
 
+/* regexp_extract_all(value, pattern, group) (string_funcs/regexp_extract_all.rs) by the device's two passes (rx_find_all) on the host: the number of matches,
+ * the group's (start, length) per match written while they fit `cap`; -2 and comet_last_error(0).  Needs no GPU. */
+int32_t comet_extract_all_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* starts, int32_t* lens, int32_t cap);
+
 /* split(value, pattern, limit) (string_funcs/split.rs:434-472) by the device's two passes (csrc/device/regex_vm.hpp rx_split) on the host: the
  * number of pieces, their (start, length) inside `value` written while they fit `cap`; -2 and comet_last_error(0) for a pattern outside the
  * subset.  Needs no GPU. */

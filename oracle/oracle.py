@@ -740,6 +740,19 @@ class Evaluator:
             if big.any():
                 raise OracleError("long overflow")
             return Col(S.T_TIMESTAMP, a.values.astype(np.int64) * 1000000, a.valid)
+        if f == "regexp_extract_all":
+            # spark_regexp_extract_all (string_funcs/regexp_extract_all.rs:32-108): group idx (default 1) of EVERY match — the crate's captures_iter, i.e. find_iter's
+            # matches —, the empty string where the group took no part; no match: an empty list; NULL subject: NULL
+            a = self.eval(e.children[0], cols, n)
+            pat = e.children[1].value
+            idx = int(e.children[2].value) if len(e.children) > 2 else 1
+            rx = crate_pattern_to_python(pat)
+            if idx < 0 or idx > rx.groups:
+                raise OracleError("The value of parameter `idx` in `regexp_extract_all` is invalid: Expects group index between 0 and %d, but got %d." % (rx.groups, idx))
+            out = np.empty(n, dtype=object)
+            for i in range(n):
+                out[i] = [m.group(idx) or "" for m in find_iter_like_the_crate(rx, a.values[i])] if a.ok()[i] else None
+            return Col(S.list_type(S.T_STRING, True), out, a.valid)
         if f == "split":
             # spark_split (string_funcs/split.rs:32-97, 434-472): the pieces between the pattern's matches — limit > 0: at most limit - 1 cuts;
             # limit = 0: trailing empty pieces dropped (nothing left: one empty piece); limit < 0 (the default): every piece.  NULL subject → NULL list.

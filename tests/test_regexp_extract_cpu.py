@@ -178,3 +178,43 @@ def test_split_against_the_oracles_restatement():
             assert got == O.split_like_the_crate(pat, text, limit), (pat, limit, text)
             checked += 1
     assert checked > 1500
+
+
+# ---- regexp_extract_all: the device's two passes (rx_find_all) on the host ----
+
+def test_extract_all_reference_vectors():
+    # string_funcs/regexp_extract_all.rs tests: basic_group_extraction, second_group, idx_zero_returns_whole_matches, no_match_returns_empty_array,
+    # null_subject_returns_null's valid rows, unmatched_optional_group_returns_empty_string
+    ea = native.extract_all_host
+    assert [ea(r"(\d+)-(\d+)", 1, v) for v in ("100-200, 300-400", "foo-bar", "nodelim")] == [["100", "300"], [], []]
+    assert ea(r"(\d+)-(\d+)", 2, "100-200, 300-400") == ["200", "400"]
+    assert ea(r"\d+", 0, "abc123def456") == ["123", "456"]
+    assert ea(r"(\d+)", 1, "abc") == []
+    assert [ea(r"(\d)", 1, v) for v in ("1 2 3", "4 5")] == [["1", "2", "3"], ["4", "5"]]
+    assert ea(r"(foo)(bar)?", 2, "foo foo") == ["", ""]
+    with pytest.raises(Exception, match=r"in `regexp_extract_all` is invalid: Expects group index between 0 and 2, but got 3"):
+        ea(r"(a)(b)", 3, "abc")
+
+
+def test_extract_all_against_the_oracles_restatement():
+    from oracle import oracle as O
+    rng = random.Random(78)
+    checked = 0
+    for _ in range(500):
+        groups = [0]
+        pat = gen(rng, 2, groups)
+        try:
+            rx = O.crate_pattern_to_python(pat)
+        except re.error:
+            continue
+        for _ in range(4):
+            text = "".join(rng.choice(ALPHA) for _ in range(rng.randint(0, 10)))
+            idx = rng.randint(0, groups[0])
+            try:
+                got = native.extract_all_host(pat, idx, text)
+            except Exception as e:  # noqa: BLE001
+                assert "not supported" in str(e), (pat, str(e))
+                break
+            assert got == [m.group(idx) or "" for m in O.find_iter_like_the_crate(rx, text)], (pat, idx, text)
+            checked += 1
+    assert checked > 1200

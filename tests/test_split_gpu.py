@@ -83,3 +83,19 @@ def test_what_split_refuses(built):
                       (S.project(S.scan([STR, I32]), [_sp("(a*)*")]), "empty string")):
         with pytest.raises(native.CometNativeException, match=why):
             _run(plan, t, 1)
+
+
+def _all(pattern, *idx):
+    return S.scalar_func("regexp_extract_all", [S.col(0, STR), S.lit(pattern, STR)] + [S.lit(i, I32) for i in idx], S.list_type(STR, True))
+
+
+def test_regexp_extract_all(built):
+    """string_funcs/regexp_extract_all.rs: group idx of every match, through the same derived-column path (the group-0 program drives the iteration, the
+    group's program reports)"""
+    ref = pa.table({"s": pa.array(["100-200, 300-400", "foo-bar", "nodelim", None, "abc123def456", "foo foo", "1 2 3"]), "k": pa.array(np.arange(7, dtype=np.int32))})
+    got = _check([_all(r"(\d+)-(\d+)", 1), _all(r"(\d+)-(\d+)", 2), _all(r"\d+", 0), _all(r"(foo)(bar)?", 2), _all(r"(\d)")], ref)
+    assert got.column(0).to_pylist()[:4] == [["100", "300"], [], [], None] and got.column(3).to_pylist()[5] == ["", ""]
+    t = _table(20_000, 24)
+    _check([_all(r"(\w+)=(\w*)", 2), _all(r"[^,;\s]+", 0), _all(r"(\d+)", 1), _all(r"x*", 0), S.col(1, I32)], t, S.filter_(S.scan([STR, I32]), S.lt(S.col(1, I32), S.lit(60, I32))))
+    with pytest.raises(native.CometNativeException, match="Expects group index between 0 and 1, but got 2"):
+        _run(S.project(S.scan([STR, I32]), [_all(r"(a)", 2)]), ref, 1)

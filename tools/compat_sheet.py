@@ -103,6 +103,7 @@ def probes():
         "Like": (S.like(s, L("a%_b", S.T_STRING)), "% and _, backslash escapes"), "RLike": (S.rlike(s, L("^ab+c$", S.T_STRING)), "the byte-exact subset incl. \\d \\w \\b (Unicode 16 tables of the crate); \\p{..} refused by name"),
         "RegExpExtract": (f("regexp_extract", [s, L(r"(\d+)-(\w+)", S.T_STRING), L(2, S.T_INT32)], S.T_STRING),
                           "what the JVM sends under spark.comet.expression.RegExpExtract.allowIncompatible (literal pattern and idx): an output column; the crate's leftmost, preference-ordered match by a matcher of ≤ 64 instructions; \\p{..}, named groups, scoped flags refused by name"),
+        "RegExpExtractAll": (f("regexp_extract_all", [s, L(r"(\d+)", S.T_STRING), L(1, S.T_INT32)], S.list_type(S.T_STRING, True)), "under allowIncompatible, like StringSplit: a list<string> column derived from the chain's source"),
         "StartsWith": (f("starts_with", [s, L("ab", S.T_STRING)], S.T_BOOL), ""), "EndsWith": (f("ends_with", [s, L("ab", S.T_STRING)], S.T_BOOL), ""),
         "Contains": (f("contains", [s, L("ab", S.T_STRING)], S.T_BOOL), ""),
         "Substring": (f("substring", [s, L(2, S.T_INT32), L(3, S.T_INT32)], S.T_STRING), "literal bounds"), "Left": (f("substring", [s, L(1, S.T_INT32), L(3, S.T_INT32)], S.T_STRING), "serialized as Substring"),
