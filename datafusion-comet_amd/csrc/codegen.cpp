@@ -237,7 +237,7 @@ ExprP lower_split(const ExprP& e) {
       auto b = std::make_shared<Expr>();
       b->kind = ExprKind::Bound;
       b->proto_tag = 3;
-      b->bound_index = nsrc + (int)k;
+      b->bound_index = nsrc + 2 * (int)k;
       b->dtype = o.type;
       b->has_dtype = true;
       return b;
@@ -247,7 +247,7 @@ ExprP lower_split(const ExprP& e) {
   auto b = std::make_shared<Expr>();
   b->kind = ExprKind::Bound;
   b->proto_tag = 3;
-  b->bound_index = nsrc + (int)g_derived->size() - 1;
+  b->bound_index = nsrc + 2 * ((int)g_derived->size() - 1);      // (two columns per derived list: the list, then its elements)
   b->dtype = dc.type;
   b->has_dtype = true;
   return b;
@@ -373,6 +373,7 @@ struct Gen {
     // is two values)
     if (!e->func.empty()) k << "F" << e->func.size() << ":" << e->func;
     if (e->is_spark4_plus) k << "S4";
+    if (e->one_based) k << "OB";
     if (e->check_divide_overflow) k << "DO";
     if (e->kind == ExprKind::CaseWhen) k << "W" << e->n_when;
     if (e->kind == ExprKind::Literal) {
@@ -1589,6 +1590,100 @@ struct Gen {
 
   // ScalarFunc (expr.proto:466-471 → create_comet_physical_fun, comet_scalar_funcs.rs): the subset whose results are defined
   // exactly (integer / IEEE operations): ceil, floor, abs, sqrt, signum, isnan, datepart.  Everything else is rejected by name.
+  // ---- lists (array_funcs/{list_extract,size}.rs, datafusion-spark's array_contains): the chain's source table carries the element column of every list of
+  // flat elements as a column of its own (exec.cpp extend_struct_fields; a derived split / regexp_extract_all list likewise), so a row's elements are
+  // element-column rows offs[i] … offs[i + 1] ----
+  static std::string load_of(const DType& t, const std::string& c, const std::string& row) {
+    switch (t.id) {
+      case TypeId::Bool: return "comet::ld_bool(" + c + ", " + row + ")";
+      case TypeId::Int8: return "(i32)comet::ld<i8>(" + c + ", " + row + ")";
+      case TypeId::Int16: return "(i32)comet::ld<i16>(" + c + ", " + row + ")";
+      case TypeId::Int32: case TypeId::Date: return "comet::ld<i32>(" + c + ", " + row + ")";
+      case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz: return "comet::ld<i64>(" + c + ", " + row + ")";
+      case TypeId::Float: return "comet::ld<float>(" + c + ", " + row + ")";
+      case TypeId::Double: return "comet::ld<double>(" + c + ", " + row + ")";
+      case TypeId::Decimal: return t.precision <= 18 ? "comet::ld_dec_lo(" + c + ", " + row + ")" : "comet::ld<i128>(" + c + ", " + row + ")";
+      default: throw CometError("list elements of type " + t.str() + " are not supported in an expression by the MI355X native engine");
+    }
+  }
+  struct ListRef { int idx = -1, elem = -1; std::string off, len, ok, ecol; DType etype; };
+  // a list COLUMN's row: first element, count, validity; `need_elements`: the element column must be addressable too
+  ListRef list_ref(const ExprP& x, const char* who, bool need_elements) {
+    if (x->kind != ExprKind::Bound || x->bound_index < 0 || (size_t)x->bound_index >= in_types.size() || !in_types[(size_t)x->bound_index].is_listlike())
+      throw CometError(std::string(who) + " is supported over a list / map COLUMN (not over a computed array) by the MI355X native engine");
+    ListRef l;
+    l.idx = x->bound_index;
+    in_used[(size_t)l.idx] = true;
+    auto loc = locate(l.idx);
+    const std::string c = "prm.in[" + std::to_string(loc.first) + "]";
+    l.off = newvar("i32");
+    l.len = newvar("i32");
+    stmt(l.off + " = comet::ld<i32>(" + c + ", " + loc.second + "); " + l.len + " = comet::ld<i32>(" + c + ", (" + loc.second + ") + 1) - " + l.off + ";");
+    if (in_valid[(size_t)l.idx]) {
+      l.ok = newvar("bool");
+      stmt(l.ok + " = comet::ld_valid(" + c + ", " + loc.second + ");");
+    }
+    if (need_elements) {
+      for (size_t j = 0; j < in_types.size(); j++)
+        if (in_types[j].virt_parent == l.idx && in_types[j].virt_kid == 0 && in_types[(size_t)l.idx].id == TypeId::List) l.elem = (int)j;
+      if (l.elem < 0) throw CometError(std::string(who) + ": the elements of " + in_types[(size_t)l.idx].str() + " are not addressable by an expression (lists of flat elements are)");
+      in_used[(size_t)l.elem] = true;
+      l.etype = in_types[(size_t)l.elem];
+      l.ecol = "prm.in[" + std::to_string(locate(l.elem).first) + "]";
+    }
+    return l;
+  }
+  // ListExtract's element position (array_funcs/list_extract.rs:229-320): → the element-column row (i64, -1: none) and whether there is one
+  void list_extract_pos(const Expr& e, ListRef& l, std::string& row, std::string& hit) {
+    if (e.children.size() < 2) throw CometError("ListExtract expects a child and an ordinal");
+    if (e.children.size() > 2 && !(e.children[2]->kind == ExprKind::Literal && e.children[2]->lit_null)) throw CometError("ListExtract with a default value is not supported by the MI355X native engine yet");
+    l = list_ref(e.children[0], e.one_based ? "element_at" : "GetArrayItem", true);
+    Val ord = named(gen(e.children[1]));
+    if (ord.t.id != TypeId::Int32) throw CometError("ListExtract expects an Int32 ordinal, got " + ord.t.str());
+    const std::string both = and_ok(l.ok, ord.ok).empty() ? "true" : and_ok(l.ok, ord.ok);
+    const std::string o = "(i64)" + ord.v, n = "(i64)" + l.len;
+    std::string pos = newvar("i64");
+    if (e.one_based) {
+      ErrSite z;      // element_at(arr, 0): INVALID_INDEX_OF_ZERO in every mode (list_extract.rs:234-236)
+      z.error_type = "InvalidIndexOfZero";
+      z.error_class = "INVALID_INDEX_OF_ZERO";
+      z.value = ErrSite::NoValue;
+      raise_value("(" + both + " && " + ord.v + " == 0)", 19, z, "0");
+      stmt(pos + " = " + o + " > 0 ? (" + o + " <= " + n + " ? " + o + " - 1 : -1) : (-(" + o + ") <= " + n + " ? " + n + " + " + o + " : -1);");
+    } else {
+      stmt(pos + " = (" + o + " >= 0 && " + o + " < " + n + ") ? " + o + " : -1;");
+    }
+    if (e.fail_on_error) {
+      ErrSite s;      // InvalidElementAtIndex / InvalidArrayIndex { index_value, array_size } (list_extract.rs:294-311; error.rs:397-414)
+      s.error_type = e.one_based ? "InvalidElementAtIndex" : "InvalidArrayIndex";
+      s.error_class = e.one_based ? "INVALID_ARRAY_INDEX_IN_ELEMENT_AT" : "INVALID_ARRAY_INDEX";
+      s.value = ErrSite::IndexAndSize;
+      raise_value("(" + both + " && " + pos + " < 0" + (e.one_based ? " && " + ord.v + " != 0" : "") + ")", 19, s, "(i64)" + ord.v, "(i64)" + l.len);
+    }
+    hit = newvar("bool");
+    stmt(hit + " = " + both + " && " + pos + " >= 0;");
+    row = newvar("i64");
+    stmt(row + " = " + hit + " ? (i64)" + l.off + " + " + pos + " : (i64)0;");
+  }
+  Val list_extract(const Expr& e) {
+    ListRef l;
+    std::string row, hit;
+    list_extract_pos(e, l, row, hit);
+    if (l.etype.id == TypeId::String || l.etype.id == TypeId::Bytes) throw CometError("an element of a list of strings is supported as an OUTPUT column only (not as an operand) by the MI355X native engine");
+    Val r;
+    r.t = l.etype;
+    r.t.virt_parent = r.t.virt_kid = -1;
+    r.rep = rep_for_type(r.t);
+    r.maxabs = type_maxabs(r.t);
+    std::string ok = newvar("bool");
+    stmt(ok + " = " + hit + (in_valid[(size_t)l.elem] ? " && comet::ld_valid(" + l.ecol + ", " + row + ")" : "") + ";");
+    std::string v = newvar(rep_ctype(r.rep));
+    stmt(v + " = " + ok + " ? " + load_of(l.etype, l.ecol, row) + " : (" + rep_ctype(r.rep) + ")0;");
+    r.v = v;
+    r.ok = ok;
+    return r;
+  }
+
   Val scalar_func(const Expr& e) {
     const std::string& f = e.func;
     auto arg = [&](size_t i) { return named(gen(e.children.at(i))); };
@@ -1863,6 +1958,52 @@ struct Gen {
       r.ok = a.ok;
       r.v = code == 6 ? "(comet::date_weekday_mon0(" + a.v + ") + 1)" : code == 7 ? "comet::date_iso_week(" + a.v + ")" : "comet::date_part(" + a.v + ", " + std::to_string(code) + ")";
       r.maxabs = 6000000;
+      return r;
+    }
+    if (f == "size" || f == "cardinality") {
+      // SparkSizeFunc (array_funcs/size.rs:79-125): the row's element (entry) count, -1 for a NULL list / map — never NULL (CometSize wraps it in a
+      // CASE WHEN for spark.sql.legacy.sizeOfNull = false)
+      if (e.children.size() != 1) throw CometError("size expects one argument");
+      ListRef l = list_ref(e.children[0], "size", false);
+      r.t = DType::of(TypeId::Int32);
+      r.rep = Rep::I32;
+      r.v = l.ok.empty() ? l.len : "(" + l.ok + " ? " + l.len + " : -1)";
+      r.maxabs = (u128)1 << 31;
+      return r;
+    }
+    if (f == "array_contains") {
+      // datafusion-spark SparkArrayContains (Spark's ArrayContains): NULL for a NULL array or key; true when an element equals the key; otherwise NULL when
+      // the array holds a NULL element, else false.  Keys: a literal or a column of the element type (integers, dates, decimals up to 18 digits, booleans;
+      // strings against a literal)
+      if (e.children.size() != 2) throw CometError("array_contains expects two arguments");
+      ListRef l = list_ref(e.children[0], "array_contains", true);
+      const bool str = l.etype.id == TypeId::String;
+      std::string keyok, cmp;
+      const std::string j = newvar("i32");
+      if (str) {
+        if (!is_str_lit(e.children[1]) && !(e.children[1]->kind == ExprKind::Literal && e.children[1]->lit_null)) throw CometError("array_contains over a list of strings is supported with a literal key");
+        if (e.children[1]->lit_null) keyok = "false";
+        cmp = "comet::utf8_eq_lit(" + l.ecol + ", (i64)" + l.off + " + " + j + ", " + c_bytes(e.children[1]->lit_bytes) + ", " + std::to_string(e.children[1]->lit_bytes.size()) + ")";
+      } else {
+        Val key = named(gen(e.children[1]));
+        DType kt = key.t, et = l.etype;
+        kt.virt_parent = kt.virt_kid = et.virt_parent = et.virt_kid = -1;
+        if (!(kt == et)) throw CometError("array_contains: the key's type " + key.t.str() + " is not the elements' " + l.etype.str());
+        if (key.rep == Rep::F64 || key.rep == Rep::F32 || key.rep == Rep::STR) throw CometError("array_contains over " + l.etype.str() + " elements is not supported by the MI355X native engine yet");
+        keyok = key.ok;
+        cmp = "(" + load_of(l.etype, l.ecol, "(i64)" + l.off + " + " + j) + " == " + key.v + ")";
+      }
+      const std::string found = newvar("bool"), sawnull = newvar("bool");
+      const std::string ev = in_valid[(size_t)l.elem] ? "comet::ld_valid(" + l.ecol + ", (i64)" + l.off + " + " + j + ")" : "true";
+      const std::string both = and_ok(l.ok, keyok).empty() ? "true" : and_ok(l.ok, keyok);
+      stmt(found + " = false; " + sawnull + " = false; if (" + both + ") for (" + j + " = 0; " + j + " < " + l.len + " && !" + found + "; " + j + "++) { if (!" + ev + ") " + sawnull + " = true; else if (" + cmp +
+           ") " + found + " = true; }");
+      r.t = DType::of(TypeId::Bool);
+      r.rep = Rep::B;
+      r.v = found;
+      const std::string ok = newvar("bool");
+      stmt(ok + " = " + both + " && (" + found + " || !" + sawnull + ");");
+      r.ok = ok;
       return r;
     }
     // ---- Float64 functions the reference hands to DataFusion / datafusion-spark (QueryPlanSerde.scala:117-174 CometScalarFunction(name); Spark casts the
@@ -2343,7 +2484,9 @@ struct Gen {
       }
       case ExprKind::IsNull: case ExprKind::IsNotNull: {
         // a Utf8 column's NULL-ness needs its validity bit only, never the (packed, ≤15-byte) value
-        Val a = is_str_col(e.children.at(0)) ? str_col_validity(e.children[0]->bound_index) : gen(e.children.at(0));
+        const ExprP& c0 = e.children.at(0);
+        const bool nested_col = c0->kind == ExprKind::Bound && c0->bound_index >= 0 && (size_t)c0->bound_index < in_types.size() && in_types[(size_t)c0->bound_index].is_nested();
+        Val a = (is_str_col(c0) || nested_col) ? str_col_validity(c0->bound_index) : gen(c0);      // (a nested column: its validity bit, like a Utf8 column's)
         Val r;
         r.t = DType::of(TypeId::Bool);
         r.rep = Rep::B;
@@ -2389,6 +2532,7 @@ struct Gen {
         r.maxabs = 64;
         return r;
       }
+      case ExprKind::ListExtract: return list_extract(e);
       case ExprKind::TruncTimestamp: {
         // timestamp_trunc (datetime_funcs/timestamp_trunc.rs → kernels/temporal.rs:179-270, 587-625): the instant's wall clock in the zone cut to the
         // unit, read back as an instant.  The reference sends it for UTC only unless allowIncompatible (datetime.scala CometTruncTimestamp): zones
@@ -2953,6 +3097,11 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   for (auto& dc : d.derived) {
     d.in_types.push_back(dc.type);
     valid_all.push_back(in_has_validity[(size_t)dc.src]);
+    DType et = dc.type.kids[0];      // … and its element column behind it, addressable like the element column of a source list (list_ref)
+    et.virt_parent = (int)d.in_types.size() - 1;
+    et.virt_kid = 0;
+    d.in_types.push_back(et);
+    valid_all.push_back(false);
   }
   if (!d.derived.empty() && agg) throw CometError("split inside an aggregate's chain is not supported by the MI355X native engine yet");
   if (d.in_types.size() > COMET_MAX_IN) throw CometError("too many scan columns for one GPU pipeline");
@@ -2990,6 +3139,28 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
       const bool is_str_type = c->kind == ExprKind::Bound && c->bound_index >= 0 && (size_t)c->bound_index < d.in_types.size() &&
                                (d.in_types[(size_t)c->bound_index].id == TypeId::String || d.in_types[(size_t)c->bound_index].id == TypeId::Bytes ||
                                 d.in_types[(size_t)c->bound_index].is_nested());
+      if (c->kind == ExprKind::ListExtract && !c->children.empty() && c->children[0]->kind == ExprKind::Bound && c->children[0]->bound_index >= 0 &&
+          (size_t)c->children[0]->bound_index < d.in_types.size() && d.in_types[(size_t)c->children[0]->bound_index].id == TypeId::List &&
+          !d.in_types[(size_t)c->children[0]->bound_index].kids.empty() && d.in_types[(size_t)c->children[0]->bound_index].kids[0].id == TypeId::String) {
+        // an element of a list of strings (split(s, ',')[0], element_at(arr, -1)): the ELEMENT column's row travels, the executor gathers the string
+        Gen::ListRef l;
+        std::string row, hit;
+        ge.list_extract_pos(*c, l, row, hit);
+        Val v;
+        v.t = DType::of(TypeId::String);
+        v.rep = Rep::I64;
+        v.v = row;
+        v.ok = in_has_validity_all[(size_t)l.elem] ? "(" + hit + " && comet::ld_valid(" + l.ecol + ", " + row + "))" : hit;
+        v = ge.named(v);
+        outs.push_back(v);
+        OutCol oc;
+        oc.type = v.t;
+        oc.nullable = true;
+        oc.gather_src = l.elem;
+        d.out_cols.push_back(oc);
+        ex << "  output: " << explain_expr(c) << " : Utf8 (an element gathered from column " << l.elem << ")\n";
+        continue;
+      }
       if (is_str_type) {
         // a Utf8 column passed through: emit the source row index, the executor gathers the string afterwards
         const int src = c->bound_index;

@@ -141,7 +141,7 @@ constexpr int kErrDetailStrBytes = 224;
 // registered process-wide under an id derived from their content, so the generated text — and with it the code-object cache key — does not
 // depend on the order plans arrive in.
 struct ErrSite {
-  enum Value : int { Unscaled128 = 0, Int64 = 1, F64 = 2, F32 = 3, Str = 4, DecimalBD = 5, F64Display = 6, Int64Plain = 7, NoValue = 8, F64Micros = 9, FunctionName = 10 };
+  enum Value : int { Unscaled128 = 0, Int64 = 1, F64 = 2, F32 = 3, Str = 4, DecimalBD = 5, F64Display = 6, Int64Plain = 7, NoValue = 8, F64Micros = 9, FunctionName = 10, IndexAndSize = 11 };
   std::string error_type;    // "NumericValueOutOfRange", "CastOverFlow", "CastInvalidValue", "InvalidInputInCastToDatetime"
   std::string error_class;
   std::string from_type, to_type;      // Spark SQL type names ("BIGINT", "DECIMAL(10,2)", "STRING" …)

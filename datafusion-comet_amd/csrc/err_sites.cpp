@@ -149,6 +149,9 @@ std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint
   const std::string tail = (ctx ? context_json(*ctx) : std::string()) + "}";
   if (s.value == ErrSite::FunctionName)      // DecimalSumOverflow { function_name } (error.rs:75-76, 374-377); the name travels in from_type
     return "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{\"functionName\":\"" + s.from_type + "\"}" + tail;
+  if (s.value == ErrSite::IndexAndSize)      // InvalidArrayIndex / InvalidElementAtIndex { index_value, array_size } (error.rs:397-414)
+    return "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{\"indexValue\":" + std::to_string((long long)(int64_t)lo) + ",\"arraySize\":" +
+           std::to_string((long long)(int64_t)hi) + "}" + tail;
   if (s.value == ErrSite::NoValue)      // ArithmeticOverflow { from_type } (error.rs:369-373): which type overflowed, no value
     return "{\"errorType\":\"" + s.error_type + "\",\"errorClass\":\"" + s.error_class + "\",\"params\":{" +
            (s.from_type.empty() ? std::string() : "\"fromType\":\"" + s.from_type + "\"") + "}" + tail;
@@ -162,7 +165,7 @@ std::string err_site_json(const ErrSite& s, uint64_t lo, uint64_t hi, const uint
     case ErrSite::F32: { float f; uint32_t b = (uint32_t)lo; memcpy(&f, &b, 4); value = rust_lower_exp(f); break; }
     case ErrSite::F64Display: { double d; memcpy(&d, &lo, 8); value = rust_display(d); break; }      // cast_float_to_decimal128: input_value.to_string()
     case ErrSite::DecimalBD: value = decimal_str(v128, s.precision, s.scale) + "BD"; break;   // cast_decimal_to_int*: "{}BD"
-    case ErrSite::NoValue: case ErrSite::FunctionName: break;
+    case ErrSite::NoValue: case ErrSite::FunctionName: case ErrSite::IndexAndSize: break;
     case ErrSite::F64Micros: {      // cast_float_to_timestamp (numeric.rs:111-127): format!("{:e}", micros).to_uppercase() + "D", infinities by their Java names
       double d;
       memcpy(&d, &lo, 8);

@@ -21,12 +21,23 @@ namespace comet {
 // `in` with every field of its struct columns as a column of its own behind the real ones (DType::virt_parent / virt_kid name them): what
 // GetStructField folds into (codegen.cpp lower_struct_field).  A field's validity already says NULL where its struct is NULL (the Parquet
 // scan derives both from one definition level), so the field column is the field's view as it is.
+// … and the element column of every List of flat elements (virt_kid 0 of a List: what ListExtract / array_contains address, codegen.cpp list_ref).
+static bool list_of_flat(const DType& t) { return t.id == TypeId::List && t.kids.size() == 1 && !t.kids[0].is_nested(); }
 DevTable extend_struct_fields(const DevTable& in) {
   bool any = false;
-  for (auto& t : in.types) any |= t.id == TypeId::Struct;
+  for (auto& t : in.types) any |= t.id == TypeId::Struct || list_of_flat(t);
   if (!any) return in;
   DevTable x = in;
   for (size_t i = 0; i < in.types.size(); i++) {
+    if (list_of_flat(in.types[i]) && in.cols[i].kids.size() == 1) {
+      DType kt = in.types[i].kids[0];
+      kt.virt_parent = (int)i;
+      kt.virt_kid = 0;
+      x.types.push_back(kt);
+      x.cols.push_back(in.cols[i].kids[0]);
+      x.has_valid.push_back(!in.cols[i].kid_has_valid.empty() && in.cols[i].kid_has_valid[0]);
+      continue;
+    }
     if (in.types[i].id != TypeId::Struct) continue;
     for (size_t k = 0; k < in.types[i].kids.size() && k < in.cols[i].kids.size(); k++) {
       DType kt = in.types[i].kids[k];
@@ -43,6 +54,13 @@ DevTable extend_struct_fields(const DevTable& in) {
 std::vector<DType> extend_struct_field_types(const std::vector<DType>& types) {
   std::vector<DType> x = types;
   for (size_t i = 0; i < types.size(); i++) {
+    if (list_of_flat(types[i])) {
+      DType kt = types[i].kids[0];
+      kt.virt_parent = (int)i;
+      kt.virt_kid = 0;
+      x.push_back(kt);
+      continue;
+    }
     if (types[i].id != TypeId::Struct) continue;
     for (size_t k = 0; k < types[i].kids.size(); k++) {
       DType kt = types[i].kids[k];
@@ -1321,6 +1339,12 @@ void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol
     in.types.push_back(dc.type);
     in.cols.push_back(lv);
     in.has_valid.push_back(hv);
+    DType et = dc.type.kids[0];      // the elements as a column of their own (codegen.cpp list_ref: ListExtract / array_contains over the derived list)
+    et.virt_parent = (int)in.types.size() - 1;
+    et.virt_kid = 0;
+    in.types.push_back(et);
+    in.cols.push_back(elem);
+    in.has_valid.push_back(false);
     in.owners.push_back(list_offs);
     in.owners.push_back(eoffs);
     in.owners.push_back(ebytes);

@@ -68,6 +68,7 @@ enum class ExprKind : int {
   CheckOverflow = 25, Like = 26, RLike = 30, ScalarFunc = 31, EqNullSafe = 32, NeqNullSafe = 33, BitAnd = 34, BitOr = 35, BitXor = 36, Remainder = 37, CaseWhen = 38, In = 39, Not = 40,
   UnaryMinus = 41, ShiftRight = 42, ShiftLeft = 43, If = 44, IntegralDivide = 59, NormalizeNaNAndZero = 45, Unbound = 51,
   GetStructField = 54,              // expr.proto:528-531: child = 1, ordinal = 2 (kept in Expr::bound_index)
+  ListExtract = 56,                 // expr.proto:533-539: children = [child, ordinal, (default value)], one_based, fail_on_error
   Unsupported = -1
 };
 
@@ -93,6 +94,7 @@ struct Expr {
   EvalMode eval_mode = EvalMode::Legacy;
   bool fail_on_error = false;     // CheckOverflow / UnaryMinus
   bool check_divide_overflow = false;   // IntegralDivide (MathExpr field 6)
+  bool one_based = false;         // ListExtract: element_at counts from 1 (negative: from the end), GetArrayItem from 0
   bool is_spark4_plus = false;    // Cast (expr.proto:349-351): Spark 4's reading of leading whitespace before T-prefixed time-only strings
   bool negated = false;           // In
   std::string func;               // ScalarFunc.func

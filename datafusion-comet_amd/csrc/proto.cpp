@@ -257,6 +257,11 @@ void decode_expr_body(Reader r, Expr& e) {
         if (f == 1 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
         else if (f == 2 && wt == 0) { e.bound_index = (int)(int32_t)r.varint(); handled = true; }
         break;
+      case ExprKind::ListExtract:
+        if (f >= 1 && f <= 3 && wt == 2) { e.children.push_back(decode_expr(r.sub())); handled = true; }
+        else if (f == 4 && wt == 0) { e.one_based = r.varint() != 0; handled = true; }
+        else if (f == 5 && wt == 0) { e.fail_on_error = r.varint() != 0; handled = true; }
+        break;
       case ExprKind::ScalarFunc:
         // ScalarFunc{func=1, args=2, return_type=3, fail_on_error=4} (expr.proto:466-471)
         if (f == 1 && wt == 2) { e.func = r.bytes(); handled = true; }
@@ -313,7 +318,7 @@ ExprP decode_expr(Reader r) {
     switch (f) {
       case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
       case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
-      case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 47: case 65: case 25: case 26: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
+      case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 47: case 65: case 56: case 25: case 26: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
       case 44: case 45: case 51: case 54:
         e->kind = (ExprKind)f;
         if (e->kind == ExprKind::Bound || e->kind == ExprKind::GetStructField) e->bound_index = 0;  // proto3 omits zero-valued scalars
@@ -886,7 +891,7 @@ const char* expr_name(int t) {
     case 15: return "IsNull"; case 16: return "IsNotNull"; case 17: return "And"; case 18: return "Or";
     case 19: return "SortOrder"; case 25: return "CheckOverflow"; case 26: return "Like"; case 30: return "RLike"; case 31: return "ScalarFunc";
     case 32: return "EqNullSafe"; case 33: return "NeqNullSafe"; case 37: return "Remainder"; case 38: return "CaseWhen";
-    case 39: return "In"; case 40: return "Not"; case 41: return "UnaryMinus"; case 44: return "If"; case 54: return "GetStructField";
+    case 39: return "In"; case 40: return "Not"; case 41: return "UnaryMinus"; case 44: return "If"; case 54: return "GetStructField"; case 56: return "ListExtract";
     case 45: return "NormalizeNaNAndZero"; case 47: return "TruncTimestamp"; case 65: return "UnixTimestamp"; default: return "Expr";
   }
 }

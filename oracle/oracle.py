@@ -121,6 +121,11 @@ def col_from_arrow(S, arr: pa.Array, t) -> Col:
     valid = None
     if arr.null_count:
         valid = np.array(arr.is_valid().to_numpy(zero_copy_only=False), dtype=bool)
+    if t.type_id == getattr(S, "LIST", -1):      # lists of flat elements as Python lists (size / element_at / array_contains; split's results)
+        vals = np.empty(n, dtype=object)
+        for i, v in enumerate(arr.to_pylist()):
+            vals[i] = v
+        return Col(t, vals, valid)
     if t.type_id == S.DECIMAL:
         buf = arr.buffers()[1]
         vals = np.frombuffer(buf, dtype=DEC128)[arr.offset:arr.offset + n].copy()
@@ -142,7 +147,8 @@ def col_to_arrow(S, c: Col) -> pa.Array:
     t = c.dtype
     mask = None if c.valid is None or c.valid.all() else ~c.valid
     if t.type_id == getattr(S, "LIST", -1):      # (split's result: lists of strings as Python lists)
-        return pa.array([None if (mask is not None and mask[i]) else list(c.values[i]) for i in range(n)], type=pa.list_(pa.field("item", pa.utf8(), nullable=t.contains_null)))
+        et = {S.STRING: pa.utf8(), S.INT32: pa.int32(), S.INT64: pa.int64(), S.DOUBLE: pa.float64(), S.DATE: pa.date32()}[t.element.type_id]
+        return pa.array([None if (mask is not None and mask[i]) else list(c.values[i]) for i in range(n)], type=pa.list_(pa.field("item", et, nullable=t.contains_null)))
     if t.type_id == S.DECIMAL:
         vals = c.values.copy()
         if mask is not None:
@@ -282,6 +288,35 @@ class Evaluator:
                     sec = (C.utc_to_local_us(tz, us) if a.dtype.type_id == S.TIMESTAMP else us) % 86_400_000_000 // 1_000_000
                     out[i] = {"hour": sec // 3600, "minute": sec // 60 % 60, "second": sec % 60}[k]
             return Col(S.T_INT32, out, a.valid)
+        if k == "list_extract":
+            # ListExtract (array_funcs/list_extract.rs:229-320): GetArrayItem counts from 0, element_at from 1 (negative: from the end; 0: INVALID_INDEX_OF_ZERO);
+            # outside the list: NULL, or the error under ANSI; a NULL list / ordinal / element: NULL
+            a, o = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            one = bool(getattr(e, "one_based", False))
+            out, ok = [None] * n, np.zeros(n, bool)
+            for i in range(n):
+                if not (a.ok()[i] and o.ok()[i]):
+                    continue
+                lst, idx = a.values[i], int(o.values[i])
+                if one:
+                    if idx == 0:
+                        raise OracleError("INVALID_INDEX_OF_ZERO")
+                    pos = idx - 1 if 0 < idx <= len(lst) else (len(lst) + idx if idx < 0 and -idx <= len(lst) else None)
+                else:
+                    pos = idx if 0 <= idx < len(lst) else None
+                if pos is None:
+                    if e.fail_on_error:
+                        raise OracleError(("INVALID_ARRAY_INDEX_IN_ELEMENT_AT" if one else "INVALID_ARRAY_INDEX") + ' "indexValue":%d,"arraySize":%d' % (idx, len(lst)))
+                    continue
+                if lst[pos] is not None:
+                    out[i], ok[i] = lst[pos], True
+            et = a.dtype.element
+            if et.type_id == S.STRING:
+                return Col(et, np.array(out, dtype=object), ok)
+            if et.type_id == S.DATE:
+                import datetime
+                out = [(v - datetime.date(1970, 1, 1)).days if v is not None else 0 for v in out]
+            return Col(et, np.array([0 if v is None else v for v in out], dtype=_np_dtype(S, et)), ok)
         if k == "unix_timestamp":
             # SparkUnixTimestamp (datetime_funcs/unix_timestamp.rs:70-150): floor(µs / 10^6) of an instant or a TIMESTAMP_NTZ; a date's midnight in the zone as an instant
             from . import strcast as C
@@ -740,6 +775,25 @@ class Evaluator:
             if big.any():
                 raise OracleError("long overflow")
             return Col(S.T_TIMESTAMP, a.values.astype(np.int64) * 1000000, a.valid)
+        if f in ("size", "cardinality"):
+            # SparkSizeFunc (array_funcs/size.rs:79-125): the element count, -1 for a NULL list; never NULL
+            a = self.eval(e.children[0], cols, n)
+            return Col(S.T_INT32, np.array([len(v) if okv else -1 for v, okv in zip(a.values, a.ok())], dtype=np.int32), None)
+        if f == "array_contains":
+            # Spark's ArrayContains (datafusion-spark SparkArrayContains): NULL array / key: NULL; found: true; else NULL if the array holds a NULL, else false
+            a, key = self.eval(e.children[0], cols, n), self.eval(e.children[1], cols, n)
+            import datetime
+            out, ok = np.zeros(n, bool), np.zeros(n, bool)
+            for i in range(n):
+                if not (a.ok()[i] and key.ok()[i]):
+                    continue
+                kv = key.values[i]
+                if a.dtype.element.type_id == S.DATE:
+                    kv = datetime.date(1970, 1, 1) + datetime.timedelta(days=int(kv))
+                found = any(v is not None and v == kv for v in a.values[i])
+                out[i] = found
+                ok[i] = found or all(v is not None for v in a.values[i])
+            return Col(S.T_BOOL, out, None if ok.all() else ok)
         if f == "regexp_extract_all":
             # spark_regexp_extract_all (string_funcs/regexp_extract_all.rs:32-108): group idx (default 1) of EVERY match — the crate's captures_iter, i.e. find_iter's
             # matches —, the empty string where the group took no part; no match: an empty list; NULL subject: NULL
