@@ -71,7 +71,7 @@ OTHER_KEYS = [
 
 
 def probes():
-    """Spark class → (probe expression over Scan[int32, int64, double, decimal(12,2), string, date, bool], note).  A class is ACCEPTED iff it
+    """Spark class → (probe expression over Scan[int32, int64, double, decimal(12,2), string, date, bool, array<bigint>], note).  A class is ACCEPTED iff it
     is listed here; tests/test_compat_sheet_cpu.py runs every probe through comet_check_plan."""
     from datafusion_comet_amd import serde as S
     D = S.decimal(12, 2)
@@ -122,6 +122,10 @@ def probes():
         "Murmur3Hash": (f("murmur3_hash", [i64, d, L(42, S.T_INT32)], S.T_INT32), "fixed-width types (Spark's hash(...)); Utf8 arguments are refused"), "XxHash64": (f("xxhash64", [i64, L(42, S.T_INT64)], S.T_INT64), "fixed-width types"),
         "KnownFloatingPointNormalized": (S.Expr("normalize_nan_and_zero", [f64], dtype=S.T_DOUBLE), "NormalizeNaNAndZero"),
         "SortOrder": (i32, "inside Sort / Window / SortMergeJoin / range partitioning"),
+        "Size": (f("size", [S.col(7, S.list_type(S.T_INT64))], S.T_INT32), "of a list / map COLUMN (-1 for NULL; the JVM's CASE WHEN around it for sizeOfNull = false runs too)"),
+        "GetArrayItem": (S.list_extract(S.col(7, S.list_type(S.T_INT64)), L(0, S.T_INT32)), "ListExtract over a list COLUMN of flat elements (a split's result too); string elements as output columns; ANSI errors as the reference's"),
+        "ElementAt": (S.list_extract(S.col(7, S.list_type(S.T_INT64)), L(-1, S.T_INT32), one_based=True), "arrays (ListExtract, one-based, negative from the end); maps are refused"),
+        "ArrayContains": (f("array_contains", [S.col(7, S.list_type(S.T_INT64)), L(3, S.T_INT64)], S.T_BOOL), "list COLUMN of integers / dates / decimals(<= 18) / booleans with a key of that type; lists of strings with a literal key"),
         "StringSplit": (f("split", [s, L(",", S.T_STRING), L(-1, S.T_INT32)], S.list_type(S.T_STRING, False)),
                         "under spark.comet.expression.StringSplit.allowIncompatible: of a Utf8 COLUMN with a literal pattern and limit, computed over the chain's source and passed through / exploded; the matcher's pattern subset"),
         "UnixDate": (S.cast(d, S.T_INT32), "serialized as Cast(date AS int)"), "Days": (S.cast(d, S.T_INT32), "serialized as Cast(date AS int)"),
@@ -172,7 +176,7 @@ ACCEPTED_AGGREGATES = {"Sum": "integers, decimals, Float64 (exact, order indepen
 
 def probe_plan(expr):
     from datafusion_comet_amd import serde as S
-    fields = [S.T_INT32, S.T_INT64, S.T_DOUBLE, S.decimal(12, 2), S.T_STRING, S.T_DATE, S.T_BOOL]
+    fields = [S.T_INT32, S.T_INT64, S.T_DOUBLE, S.decimal(12, 2), S.T_STRING, S.T_DATE, S.T_BOOL, S.list_type(S.T_INT64)]
     return S.project(S.scan(fields), [expr])
 
 
@@ -247,7 +251,8 @@ def render() -> str:
     w("  than 4096 rows, lag / lead defaults of Utf8 / Boolean type.")
     w("* Nested types: struct-of-flat, list-of-flat, list-of-flat-struct and map columns are read from Parquet, passed through Filter / Projection / Sort /")
     w("  Limit / ShuffleWriter, taken apart by `GetStructField` and exported; struct / list columns of any depth arrive through Scan / ShuffleScan inputs;")
-    w("  `Explode` of a list column runs; deeper trees in the Parquet scan, `Explode` of a map, and every expression that computes on a list / map or builds a struct / an array are refused.")
+    w("  `Explode` of a list column runs; `size`, `arr[i]` / `element_at`, `array_contains` over a list COLUMN of flat elements run; deeper trees in the Parquet scan, `Explode` of a map,")
+    w("  the other array / map functions and everything that builds a struct / an array / a map are refused.")
     w("  Parquet: TIMESTAMP(NANOS) / TIME, encrypted files.")
     w("* ShuffleWriter with more than 4096 partitions.")
     w("")
