@@ -12,6 +12,10 @@
 #include "shuffle_format.hpp"
 #include "parquet_meta.hpp"
 #include "regex.hpp"
+// (device/strfn.hpp, as the host sees it: comet_strfn_host below)
+namespace comet_strfn_host_ns {
+#include "device/strfn.hpp"
+}
 #include "row_shuffle.hpp"
 #include "tz.hpp"
 
@@ -560,6 +564,18 @@ int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint
       cache[key] = p;
     }
     return regex_prog_extract(*p, value, value_len, start, len) ? 1 : 0;
+  });
+}
+
+int64_t comet_strfn_host(int32_t op, const uint8_t* value, int32_t n, const uint8_t* a, int32_t na, const uint8_t* b, int32_t nb, int64_t k, uint8_t* out, int64_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    using namespace comet_strfn_host_ns;
+    if (op == 20) return (int64_t)sf_crc32(value, (sf_i64)n);
+    if (op == 21) return (int64_t)sf_instr(value, n, a, na);
+    if (op == 22) return (int64_t)sf_ascii(value, n);
+    const int64_t len = sf_len(op, value, n, a, na, b, nb, k);
+    if (len <= cap && out) sf_write(op, value, n, a, na, b, nb, k, out);
+    return len;
   });
 }
 

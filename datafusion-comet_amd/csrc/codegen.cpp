@@ -193,6 +193,79 @@ thread_local const std::vector<ExprP>* g_source_cols = nullptr;
 // spark.comet.expression.StringSplit.allowIncompatible): a list<string> column DERIVED from the source table — the executor computes it before the
 // fused kernel runs (exec.cpp extend_derived), the chain addresses it as column (source columns + k).  `g_derived`: where a fold notes them.
 thread_local std::vector<DerivedCol>* g_derived = nullptr;
+// the chain's column index of derived column k: behind the source's columns and the columns of the derived columns before it
+static int derived_index(int nsrc, size_t k) {
+  int at = nsrc;
+  for (size_t j = 0; j < k; j++) at += (*g_derived)[j].columns();
+  return at;
+}
+// A string function of a source Utf8 column whose result is new bytes — reverse, repeat, replace, substring_index, md5 / sha1 / sha2 (device/strfn.hpp) — becomes
+// a DERIVED Utf8 column too (kind 3): computed over the source before the fused kernel runs, then a column like any other to the chain — an output, a
+// comparison's operand, a LIKE's subject, whatever its length.  The subject may be wrapped in Cast(… AS BINARY) (Spark's Md5 / Sha1 / Sha2 take binary).
+static const ExprP& unwrap_binary_cast(const ExprP& x) {
+  if (x->kind == ExprKind::Cast && x->children.size() == 1 && (x->dtype.id == TypeId::Bytes || x->dtype.id == TypeId::String)) return x->children[0];
+  return x;
+}
+bool is_strfn(const std::string& f) {
+  return f == "reverse" || f == "repeat" || f == "replace" || f == "substring_index" || f == "substr_index" || f == "md5" || f == "sha1" || f == "sha2";
+}
+ExprP lower_strfn(const ExprP& e) {
+  const std::string& f = e->func;
+  if (!g_derived || !g_source_cols) throw CometError(f + " is supported in Projection / Filter chains only");
+  if (e->children.empty()) throw CometError(f + " expects arguments");
+  const ExprP& subject = unwrap_binary_cast(e->children[0]);
+  const int nsrc = (int)g_source_cols->size();
+  if (subject->kind != ExprKind::Bound || subject->bound_index < 0 || subject->bound_index >= nsrc || !subject->has_dtype ||
+      (subject->dtype.id != TypeId::String && subject->dtype.id != TypeId::Bytes))
+    throw CometError(f + " is supported over a Utf8 COLUMN of the source (not over a computed string) by the MI355X native engine");
+  auto str_lit = [&](size_t i, const char* what) -> std::string {
+    if (i >= e->children.size() || e->children[i]->kind != ExprKind::Literal || e->children[i]->lit_null || e->children[i]->dtype.id != TypeId::String)
+      throw CometError(f + ": " + what + " must be a string literal");
+    return e->children[i]->lit_bytes;
+  };
+  auto int_lit = [&](size_t i, const char* what) -> long long {
+    if (i >= e->children.size() || e->children[i]->kind != ExprKind::Literal || e->children[i]->lit_null || !e->children[i]->dtype.is_integer())
+      throw CometError(f + ": " + what + " must be an integer literal");
+    return e->children[i]->lit_i64;
+  };
+  DerivedCol dc;
+  dc.kind = 3;
+  dc.src = subject->bound_index;
+  if (f == "reverse") dc.op = 1;
+  else if (f == "repeat") {
+    dc.op = 2;
+    dc.arg_k = int_lit(1, "the count");
+    if (dc.arg_k < 0) throw CometError("repeat with a negative count is not supported (the reference fails the task)");
+  } else if (f == "replace") {
+    dc.op = 3;
+    dc.arg_a = str_lit(1, "the search string");
+    dc.arg_b = e->children.size() > 2 ? str_lit(2, "the replacement") : std::string();
+  } else if (f == "substring_index" || f == "substr_index") {
+    dc.op = 4;
+    dc.arg_a = str_lit(1, "the delimiter");
+    dc.arg_k = int_lit(2, "the count");
+  } else if (f == "md5") dc.op = 10;
+  else if (f == "sha1") dc.op = 11;
+  else {
+    const long long bits = int_lit(1, "the bit length");
+    dc.op = bits == 224 ? 12 : (bits == 256 || bits == 0) ? 13 : bits == 384 ? 14 : bits == 512 ? 15 : -1;
+    if (dc.op < 0) throw CometError("sha2 with a bit length of " + std::to_string(bits) + " (NULL in Spark) is not supported by the MI355X native engine");
+  }
+  dc.type = DType::of(TypeId::String);
+  size_t k = 0;
+  for (; k < g_derived->size(); k++) {
+    const DerivedCol& o = (*g_derived)[k];
+    if (o.kind == 3 && o.src == dc.src && o.op == dc.op && o.arg_a == dc.arg_a && o.arg_b == dc.arg_b && o.arg_k == dc.arg_k) break;
+  }
+  if (k == g_derived->size()) g_derived->push_back(dc);
+  auto b = std::make_shared<Expr>();
+  b->kind = ExprKind::Bound;
+  b->proto_tag = 3;
+  b->bound_index = derived_index(nsrc, k);
+  b->dtype = dc.type;
+  b->has_dtype = true;
+  return b;
+}
 ExprP lower_split(const ExprP& e) {
   const bool all = e->func == "regexp_extract_all";      // (string_funcs/regexp_extract_all.rs: (subject, pattern, [idx = 1]) → group idx of every match)
   const std::string fname = all ? "regexp_extract_all" : "split";
@@ -237,7 +310,7 @@ ExprP lower_split(const ExprP& e) {
       auto b = std::make_shared<Expr>();
       b->kind = ExprKind::Bound;
       b->proto_tag = 3;
-      b->bound_index = nsrc + 2 * (int)k;
+      b->bound_index = derived_index(nsrc, k);
       b->dtype = o.type;
       b->has_dtype = true;
       return b;
@@ -247,7 +320,7 @@ ExprP lower_split(const ExprP& e) {
   auto b = std::make_shared<Expr>();
   b->kind = ExprKind::Bound;
   b->proto_tag = 3;
-  b->bound_index = nsrc + 2 * ((int)g_derived->size() - 1);      // (two columns per derived list: the list, then its elements)
+  b->bound_index = derived_index(nsrc, g_derived->size() - 1);      // (two columns per derived list: the list, then its elements)
   b->dtype = dc.type;
   b->has_dtype = true;
   return b;
@@ -268,6 +341,10 @@ ExprP substitute(const ExprP& e, const std::vector<ExprP>& cols, std::map<const 
   ExprP out;
   if (e->kind == ExprKind::GetStructField && e->children.size() == 1) {
     out = lower_struct_field(e, substitute(e->children[0], cols, memo));
+  } else if (e->kind == ExprKind::ScalarFunc && is_strfn(e->func)) {
+    auto n = std::make_shared<Expr>(*e);
+    for (auto& c : n->children) c = substitute(c, cols, memo);
+    out = lower_strfn(n);
   } else if (e->kind == ExprKind::ScalarFunc && (e->func == "split" || e->func == "regexp_extract_all")) {
     auto n = std::make_shared<Expr>(*e);
     for (auto& c : n->children) c = substitute(c, cols, memo);
@@ -1960,6 +2037,30 @@ struct Gen {
       r.maxabs = 6000000;
       return r;
     }
+    if (f == "instr" || f == "strpos" || f == "ascii" || f == "crc32") {
+      // DataFusion's strpos (Spark's instr: the 1-based CHARACTER position of a literal's first occurrence, 0 when there is none), ascii (the first scalar value,
+      // 0 for the empty string), datafusion-spark's crc32 (zlib's, as a bigint) — of a Utf8 column (crc32: possibly under Cast(… AS BINARY))
+      const ExprP& s0 = f == "crc32" && !e.children.empty() && e.children[0]->kind == ExprKind::Cast && e.children[0]->children.size() == 1 ? e.children[0]->children[0] : e.children.at(0);
+      if (!is_str_col(s0)) throw CometError(f + " is supported for a Utf8 column");
+      const int idx = s0->bound_index;
+      Val valid = str_col_validity(idx);
+      auto loc = locate(idx);
+      const std::string c = "prm.in[" + std::to_string(loc.first) + "], " + loc.second;
+      r.ok = valid.ok;
+      if (f == "crc32") {
+        r.t = DType::of(TypeId::Int64);
+        r.rep = Rep::I64;
+        r.v = "comet::utf8_crc32(" + c + ")";
+        return r;
+      }
+      r.t = DType::of(TypeId::Int32);
+      r.rep = Rep::I32;
+      r.maxabs = (u128)1 << 31;
+      if (f == "ascii") { r.v = "comet::utf8_ascii(" + c + ")"; return r; }
+      if (e.children.size() != 2 || !is_str_lit(e.children[1])) throw CometError(f + " is supported for a Utf8 column and a literal");
+      r.v = "comet::utf8_instr_lit(" + c + ", " + c_bytes(e.children[1]->lit_bytes) + ", " + std::to_string(e.children[1]->lit_bytes.size()) + ")";
+      return r;
+    }
     if (f == "size" || f == "cardinality") {
       // SparkSizeFunc (array_funcs/size.rs:79-125): the row's element (entry) count, -1 for a NULL list / map — never NULL (CometSize wraps it in a
       // CASE WHEN for spark.sql.legacy.sizeOfNull = false)
@@ -3097,6 +3198,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
   for (auto& dc : d.derived) {
     d.in_types.push_back(dc.type);
     valid_all.push_back(in_has_validity[(size_t)dc.src]);
+    if (dc.kind == 3) continue;
     DType et = dc.type.kids[0];      // … and its element column behind it, addressable like the element column of a source list (list_ref)
     et.virt_parent = (int)d.in_types.size() - 1;
     et.virt_kid = 0;

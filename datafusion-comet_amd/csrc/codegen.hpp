@@ -43,7 +43,11 @@ struct OutCol {
 // (in_types holds it behind the source's own columns): today split(<Utf8 column>, <pattern literal>, <limit literal>) → list<string>,
 // which the chain passes through by row index like any nested column.
 struct DerivedCol {
-  int kind = 0;                     // 1: split, 2: regexp_extract_all
+  int kind = 0;                     // 1: split, 2: regexp_extract_all (two columns each: the list, then its elements), 3: a string function → Utf8 (one column)
+  int op = 0;                       // kind 3: device/strfn.hpp's operation (SF_REVERSE …)
+  std::string arg_a, arg_b;         // kind 3: the literal arguments' bytes
+  long long arg_k = 0;              // kind 3: the integer argument
+  int columns() const { return kind == 3 ? 1 : 2; }
   int src = -1;                     // the source column
   std::vector<uint32_t> prog;       // the pattern as a group-0 program of device/regex_vm.hpp
   std::vector<uint32_t> prog2;      // regexp_extract_all: the wanted group's program (empty: group 0)

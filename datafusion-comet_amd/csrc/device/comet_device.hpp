@@ -17,6 +17,12 @@
 #endif
 #include "kparams.h"
 
+// string functions with new bytes, digests, instr / ascii / crc32 (plain C++ the host runs too)
+#ifndef STRFN
+#define STRFN __device__ inline
+#endif
+#include "strfn.hpp"
+
 // regexp_extract's matcher (comet_regex_vm.hpp, included by the generated sources that call utf8_view_regex)
 template <class P>
 __device__ bool rx_search(const unsigned int* w, P text, int n, int from, int& m0, int& m1);
@@ -213,6 +219,25 @@ CDEV strview utf8_view_regex(const CometCol& c, i64 i, const W* prog) {
   rx_search(prog, p, nbytes, 0, m0, m1);
   strview r = {(u32)i, m0 < 0 ? 0u : (u32)m0, m0 < 0 ? 0u : (u32)(m1 - m0), 0u};
   return r;
+}
+// instr / ascii / crc32 of a Utf8 value (device/strfn.hpp, the source the host tests run)
+CDEV i32 utf8_instr_lit(const CometCol& c, i64 i, const char* lit, i32 m) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j];
+  return sf_instr((const COMET_GLOBAL u8*)c.aux + lo, off[j + 1] - lo, (const u8*)lit, m);
+}
+CDEV i32 utf8_ascii(const CometCol& c, i64 i) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j];
+  return sf_ascii((const COMET_GLOBAL u8*)c.aux + lo, off[j + 1] - lo);
+}
+CDEV i64 utf8_crc32(const CometCol& c, i64 i) {
+  const COMET_GLOBAL i32* off = (const COMET_GLOBAL i32*)c.data;
+  const i64 j = c.offset + i;
+  const i32 lo = off[j];
+  return (i64)sf_crc32((const COMET_GLOBAL u8*)c.aux + lo, (long long)(off[j + 1] - lo));
 }
 // pad (or, with `truncate`, cut) the value to `target` characters: rpad / lpad truncate, read-side padding of CHAR(n) columns does not
 // (static_invoke/char_varchar_utils/read_side_padding.rs:35-47)

@@ -1270,11 +1270,60 @@ DevTable ExecutionContext::outputs_to_table(Variant& v, const std::vector<std::s
   return t;
 }
 
+// A derived Utf8 column (DerivedCol kind 3): a string function of a source column with new bytes (device/strfn.hpp) — lengths, prefix sum, bytes.
+void ExecutionContext::extend_derived_strfn(DevTable& in, const DerivedCol& dc) {
+  if (dc.src < 0 || (size_t)dc.src >= in.cols.size()) throw CometError("internal: unknown derived column");
+  const DeviceColumnView sc = in.cols[(size_t)dc.src];
+  const bool hv = in.has_valid[(size_t)dc.src];
+  const int64_t rows = in.rows;
+  if (!sc.data && rows) throw CometError("a string function over a Utf8 column without offsets is not supported");
+  if (hv && sc.offset != 0) throw CometError("a string function over a sliced Utf8 column with NULLs is not supported yet");
+  DevBuf args, lengths, tiles, flag;
+  auto offsets = std::make_shared<DevBuf>(), bytes = std::make_shared<DevBuf>();
+  const size_t na = dc.arg_a.size(), nb = dc.arg_b.size();
+  args.ensure(na + nb + 16);
+  if (na) HIP_CHECK(hipMemcpyAsync(args.p, dc.arg_a.data(), na, hipMemcpyHostToDevice, stream_));
+  if (nb) HIP_CHECK(hipMemcpyAsync((char*)args.p + na, dc.arg_b.data(), nb, hipMemcpyHostToDevice, stream_));
+  flag.ensure(16);
+  HIP_CHECK(hipMemsetAsync(flag.p, 0, 4, stream_));
+  lengths.ensure((size_t)std::max<int64_t>(rows, 1) * 4 + 16);
+  tiles.ensure((size_t)((rows + 1023) / 1024 + 2) * 8);
+  offsets->ensure((size_t)(rows + 2) * 4);
+  HIP_CHECK(hipMemsetAsync(offsets->p, 0, 8, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));      // (the literals came from pageable memory)
+  const int32_t* offs = (const int32_t*)sc.data + sc.offset;
+  const uint8_t* vbits = hv ? sc.valid : nullptr;
+  const uint8_t *a = (const uint8_t*)args.p, *b = (const uint8_t*)args.p + na;
+  if (comet_launch_strfn_len(dc.op, offs, (const uint8_t*)sc.aux, vbits, sc.offset, rows, a, (int32_t)na, b, (int32_t)nb, dc.arg_k, (uint32_t*)lengths.p, (uint32_t*)flag.p, stream_) != 0)
+    throw CometError("string function: launch failed");
+  if (rows) pq_launch_u32_scan((const uint32_t*)lengths.p, rows, (uint64_t*)tiles.p, (int32_t*)offsets->p, stream_);
+  int32_t total = 0;
+  uint32_t too_long = 0;
+  if (rows) read_small(&total, (char*)offsets->p + (size_t)rows * 4, 4);
+  read_small(&too_long, flag.p, 4);
+  if (total < 0 || too_long) throw CometError("Utf8 column exceeds 2 GiB of string data (LargeUtf8 is not supported)");
+  bytes->ensure((size_t)total + 16);
+  if (comet_launch_strfn_write(dc.op, offs, (const uint8_t*)sc.aux, vbits, sc.offset, rows, a, (int32_t)na, b, (int32_t)nb, dc.arg_k, (const int32_t*)offsets->p, (uint8_t*)bytes->p, stream_) != 0)
+    throw CometError("string function: launch failed");
+  HIP_CHECK(hipStreamSynchronize(stream_));      // the literals, lengths and tiles go back to the pool
+  DeviceColumnView cv;
+  cv.data = offsets->p;
+  cv.aux = bytes->p;
+  cv.valid = sc.valid;
+  in.types.push_back(dc.type);
+  in.cols.push_back(cv);
+  in.has_valid.push_back(hv);
+  in.owners.push_back(offsets);
+  in.owners.push_back(bytes);
+  strfn_rows_ += rows;
+}
+
 // The chain's derived columns (codegen.hpp DerivedCol) computed over its source table and appended to it.  split: two passes of the matcher per
 // row (regex_kernels.hip) — the pieces counted, a prefix sum, every piece described as a view of its source value — and the element column
 // assembled from the views like every string view's result.
 void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol>& derived) {
   for (const DerivedCol& dc : derived) {
+    if (dc.kind == 3) { extend_derived_strfn(in, dc); continue; }
     if ((dc.kind != 1 && dc.kind != 2) || dc.src < 0 || (size_t)dc.src >= in.cols.size()) throw CometError("internal: unknown derived column");
     const DeviceColumnView sc = in.cols[(size_t)dc.src];
     const bool hv = in.has_valid[(size_t)dc.src];

@@ -194,6 +194,7 @@ class ExecutionContext {
   int64_t launch_fused_filter(Variant& v, CometKParams& prm, int64_t n);
   DevTable run_chain_to_device(const Operator& top, const DevTable& in);
   void extend_derived(DevTable& in, const std::vector<DerivedCol>& derived);
+  void extend_derived_strfn(DevTable& in, const DerivedCol& dc);
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
   DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix,
                           const JoinFusion* fused_probe = nullptr);
@@ -288,6 +289,7 @@ class ExecutionContext {
   std::string explain_;
   SinkKind sink_ = SinkKind::Output;
   bool has_join_ = false;
+  int64_t strfn_rows_ = 0;          // rows that went through the derived string functions' kernels
   int64_t split_rows_ = 0;          // rows that went through split's kernels (tests: the device path ran)
   bool materialize_root_ = false;   // plain Scan chain whose outputs need the materialising path (Utf8 pass-through)
   bool compile_in_infer_ = false;

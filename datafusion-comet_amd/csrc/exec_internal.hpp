@@ -63,6 +63,10 @@ extern "C" int comet_launch_strcase_write(const void* views, const uint8_t* ok_b
 extern "C" int comet_launch_popcount128(const void* blocks, int64_t n, uint32_t* counts, void* stream);
 extern "C" int comet_launch_strfmt_lengths(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream);
 extern "C" int comet_launch_strfmt_write(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);
+extern "C" int comet_launch_strfn_len(int op, const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint8_t* a, int32_t na, const uint8_t* b,
+                                      int32_t nb, int64_t k, uint32_t* lengths, uint32_t* too_long, void* stream);
+extern "C" int comet_launch_strfn_write(int op, const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint8_t* a, int32_t na, const uint8_t* b,
+                                        int32_t nb, int64_t k, const int32_t* out_offs, uint8_t* out, void* stream);
 extern "C" int comet_launch_split_count(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, const uint32_t* prog2, int32_t limit,
                                         uint32_t* counts, void* stream);
 extern "C" int comet_launch_split_write(const int32_t* offs, const uint8_t* bytes, const uint8_t* valid_bits, int64_t valid_first, int64_t n, const uint32_t* prog, const uint32_t* prog2, int32_t limit,

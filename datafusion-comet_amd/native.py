@@ -151,6 +151,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_regexp_extract_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32)]
     lib.comet_extract_all_host.restype = c.c_int32
     lib.comet_extract_all_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.c_int32]
+    lib.comet_strfn_host.restype = c.c_int64
+    lib.comet_strfn_host.argtypes = [c.c_int32, c.c_char_p, c.c_int32, c.c_char_p, c.c_int32, c.c_char_p, c.c_int32, c.c_int64, c.c_void_p, c.c_int64]
     lib.comet_split_host.restype = c.c_int32
     lib.comet_split_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.c_int32]
     lib.comet_date_fn_host.restype = c.c_int32
@@ -1205,6 +1207,18 @@ def extract_all_host(pattern: str, group: int, value: str):
     if k < 0:
         _raise_last(0)
     return [v[a[i]:a[i] + b[i]].decode() for i in range(k)]
+
+
+def strfn_host(op: int, value: bytes, a: bytes = b"", b: bytes = b"", k: int = 0):
+    """csrc/device/strfn.hpp on the host (comet_strfn_host): ops 1-15 → the result's bytes; 20 crc32 / 21 instr / 22 ascii → the value"""
+    if op >= 20:
+        return lib().comet_strfn_host(op, value, len(value), a, len(a), b, len(b), k, None, 0)
+    n = lib().comet_strfn_host(op, value, len(value), a, len(a), b, len(b), k, None, 0)
+    if n < 0:
+        _raise_last(0)
+    buf = ctypes.create_string_buffer(max(n, 1))
+    lib().comet_strfn_host(op, value, len(value), a, len(a), b, len(b), k, buf, n)
+    return buf.raw[:n]
 
 
 def split_host(pattern: str, limit: int, value: str):

@@ -202,6 +202,11 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
  * comet_last_error(0) for a pattern outside the subset or a group index out of range (the reference's message).  Needs no GPU. */
 int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* start, int32_t* len);
 
+/* The string functions and digests of csrc/device/strfn.hpp on the host — diagnostic entry: op 1 reverse, 2 repeat(k), 3 replace(a, b), 4 substring_index(a, k),
+ * 10 md5, 11 sha1, 12-15 sha224 / 256 / 384 / 512 (hexadecimal digits): the result's length, its bytes written when they fit `cap`; op 20 crc32, 21 instr(a),
+ * 22 ascii: the value.  Needs no GPU. */
+int64_t comet_strfn_host(int32_t op, const uint8_t* value, int32_t n, const uint8_t* a, int32_t na, const uint8_t* b, int32_t nb, int64_t k, uint8_t* out, int64_t cap);
+
 /* regexp_extract_all(value, pattern, group) (string_funcs/regexp_extract_all.rs) by the device's two passes (rx_find_all) on the host: the number of matches,
  * the group's (start, length) per match written while they fit `cap`; -2 and comet_last_error(0).  Needs no GPU. */
 int32_t comet_extract_all_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* starts, int32_t* lens, int32_t cap);

@@ -775,6 +775,42 @@ class Evaluator:
             if big.any():
                 raise OracleError("long overflow")
             return Col(S.T_TIMESTAMP, a.values.astype(np.int64) * 1000000, a.valid)
+        if f in ("reverse", "repeat", "replace", "substring_index", "substr_index", "md5", "sha1", "sha2", "instr", "strpos", "ascii", "crc32"):
+            # DataFusion / datafusion-spark string functions and digests (QueryPlanSerde.scala:208-249): reverse = the scalar values reversed; repeat; replace = Rust's
+            # str::replace (an empty search string matches before every character and at the end — what Python's does too); substring_index = DataFusion's substr_index
+            # (split / rsplit without overlap); md5 / sha1 / sha2 = lower-case hexadecimal digits of the UTF-8 bytes' digest; instr = 1-based character position of
+            # the first occurrence (0: none); ascii = the first scalar value (0: empty); crc32 = zlib's
+            import hashlib
+            import zlib
+            c0 = e.children[0]
+            if c0.kind == "cast" and c0.dtype.type_id in (S.BYTES, S.STRING):      # Spark's Md5 / Sha1 / Sha2 / Crc32 take binary: Cast(s AS BINARY) around the column
+                c0 = c0.children[0]
+            a = self.eval(c0, cols, n)
+            lit = lambda i: e.children[i].value
+
+            def sub_index(v, d, k):      # DataFusion's substr_index: split (k > 0) / rsplit (k < 0) pieces, Rust's non-overlapping scans from that side
+                if k == 0 or d == "":
+                    return ""
+                if k > 0:
+                    return d.join(v.split(d)[:k])
+                pieces, rest = [], v      # from the right
+                for _ in range(-k):
+                    at = rest.rfind(d)
+                    if at < 0:
+                        return v
+                    pieces.append(rest[at + len(d):])
+                    rest = rest[:at]
+                return d.join(reversed(pieces))
+            fn = {"reverse": lambda v: v[::-1], "repeat": lambda v: v * max(int(lit(1)), 0), "replace": lambda v: v.replace(lit(1), lit(2) if len(e.children) > 2 else ""),
+                  "substring_index": lambda v: sub_index(v, lit(1), int(lit(2))), "substr_index": lambda v: sub_index(v, lit(1), int(lit(2))),
+                  "md5": lambda v: hashlib.md5(v.encode()).hexdigest(), "sha1": lambda v: hashlib.sha1(v.encode()).hexdigest(),
+                  "sha2": lambda v: hashlib.new({224: "sha224", 256: "sha256", 0: "sha256", 384: "sha384", 512: "sha512"}[int(lit(1))], v.encode()).hexdigest() if f == "sha2" else None,
+                  "instr": lambda v: v.find(lit(1)) + 1, "strpos": lambda v: v.find(lit(1)) + 1, "ascii": lambda v: ord(v[0]) if v else 0, "crc32": lambda v: zlib.crc32(v.encode())}[f]
+            if f in ("instr", "strpos", "ascii"):
+                return Col(S.T_INT32, np.array([fn(v) if okv else 0 for v, okv in zip(a.values, a.ok())], dtype=np.int32), a.valid)
+            if f == "crc32":
+                return Col(S.T_INT64, np.array([fn(v) if okv else 0 for v, okv in zip(a.values, a.ok())], dtype=np.int64), a.valid)
+            return Col(S.T_STRING, np.array([fn(v) if okv else None for v, okv in zip(a.values, a.ok())], dtype=object), a.valid)
         if f in ("size", "cardinality"):
             # SparkSizeFunc (array_funcs/size.rs:79-125): the element count, -1 for a NULL list; never NULL
             a = self.eval(e.children[0], cols, n)
