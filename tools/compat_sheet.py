@@ -126,6 +126,12 @@ def probes():
         "GetArrayItem": (S.list_extract(S.col(7, S.list_type(S.T_INT64)), L(0, S.T_INT32)), "ListExtract over a list COLUMN of flat elements (a split's result too); string elements as output columns; ANSI errors as the reference's"),
         "ElementAt": (S.list_extract(S.col(7, S.list_type(S.T_INT64)), L(-1, S.T_INT32), one_based=True), "arrays (ListExtract, one-based, negative from the end); maps are refused"),
         "ArrayContains": (f("array_contains", [S.col(7, S.list_type(S.T_INT64)), L(3, S.T_INT64)], S.T_BOOL), "list COLUMN of integers / dates / decimals(<= 18) / booleans with a key of that type; lists of strings with a literal key"),
+        "Reverse": (f("reverse", [s], S.T_STRING), "of a Utf8 COLUMN: a derived column of the chain's source (usable as an operand, any length); arrays are refused"),
+        "StringRepeat": (f("repeat", [s, L(2, S.T_INT64)], S.T_STRING), "literal count >= 0; derived column"), "StringReplace": (f("replace", [s, L("a", S.T_STRING), L("b", S.T_STRING)], S.T_STRING), "under allowIncompatible (Rust's str::replace for an empty search string); literal arguments; derived column"),
+        "SubstringIndex": (f("substring_index", [s, L(".", S.T_STRING), L(2, S.T_INT64)], S.T_STRING), "literal delimiter and count; derived column"),
+        "Md5": (f("md5", [S.cast(s, S.DataType(S.BYTES))], S.T_STRING), "of a Utf8 column (under Cast AS BINARY too); derived column"), "Sha1": (f("sha1", [S.cast(s, S.DataType(S.BYTES))], S.T_STRING), ""),
+        "Sha2": (f("sha2", [S.cast(s, S.DataType(S.BYTES)), L(256, S.T_INT32)], S.T_STRING), "224 / 256 / 0 / 384 / 512"), "Crc32": (f("crc32", [S.cast(s, S.DataType(S.BYTES))], S.T_INT64), ""),
+        "StringInstr": (f("instr", [s, L("b", S.T_STRING)], S.T_INT32), "literal substring"), "Ascii": (f("ascii", [s], S.T_INT32), ""),
         "StringSplit": (f("split", [s, L(",", S.T_STRING), L(-1, S.T_INT32)], S.list_type(S.T_STRING, False)),
                         "under spark.comet.expression.StringSplit.allowIncompatible: of a Utf8 COLUMN with a literal pattern and limit, computed over the chain's source and passed through / exploded; the matcher's pattern subset"),
         "UnixDate": (S.cast(d, S.T_INT32), "serialized as Cast(date AS int)"), "Days": (S.cast(d, S.T_INT32), "serialized as Cast(date AS int)"),
