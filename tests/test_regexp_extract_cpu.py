@@ -218,3 +218,24 @@ def test_extract_all_against_the_oracles_restatement():
             assert got == [m.group(idx) or "" for m in O.find_iter_like_the_crate(rx, text)], (pat, idx, text)
             checked += 1
     assert checked > 1200
+
+
+def test_random_patterns_neither_crash_nor_hang():
+    """patterns are user text inside plan bytes: whatever they are, planning answers (a program or a refusal by name) and the matcher terminates"""
+    import time
+    rng = random.Random(99)
+    atoms = list("ab01.*+?|()[]{}^$\\-,:") + ["\\d", "\\w", "\\s", "\\b", "\\B", "[^", "(?:", "(?i)", "(?m)", "{2,}", "{0,3}", "é", "\\x41", "\\u00e9", "\\p{L}", "[[:alpha:]]", "*?", "+?", "\\z", "\\A"]
+    texts = ["", "a", "ab01 ab", "aaaaaaaaaaaaaaaaaaaaaaaaaaaaaa", "é中 a-b,c:d\n", "((((", "0" * 64]
+    t0 = time.time()
+    ran = refused = 0
+    for _ in range(6000):
+        pat = "".join(rng.choice(atoms) for _ in range(rng.randint(0, 10)))
+        for fn in (lambda v: native.regexp_extract_host(pat, rng.randint(0, 2), v), lambda v: native.split_host(pat, rng.choice([-1, 0, 2]), v), lambda v: native.extract_all_host(pat, 0, v)):
+            try:
+                for v in texts:
+                    fn(v)
+                ran += 1
+            except Exception as e:  # noqa: BLE001
+                assert isinstance(e, native.CometNativeException), (pat, type(e))
+                refused += 1
+    assert ran > 1000 and refused > 1000 and time.time() - t0 < 120
