@@ -299,6 +299,45 @@ void comet_parquet_reader_close(int64_t handle) {
   r.reset();
 }
 
+int32_t comet_plan_set_subquery(int64_t handle, int64_t id, int32_t is_null, const uint8_t* value, size_t value_len) {
+  auto ctx = lookup(handle);
+  if (!ctx) {
+    t_last_error = "invalid plan handle";
+    return -2;
+  }
+  return guarded(ctx.get(), (int32_t)-2, [&]() -> int32_t {
+    ctx->set_subquery_value(id, is_null != 0, std::string((const char*)value, value ? value_len : 0));
+    return 0;
+  });
+}
+
+int32_t comet_plan_set_subquery_provider(int64_t handle, comet_subquery_provider provider, void* provider_ctx) {
+  auto ctx = lookup(handle);
+  if (!ctx) {
+    t_last_error = "invalid plan handle";
+    return -2;
+  }
+  return guarded(ctx.get(), (int32_t)-2, [&]() -> int32_t {
+    ctx->set_subquery_provider([provider, provider_ctx](int64_t id, const DType& type, bool& is_null, std::string& value) -> bool {
+      if (!provider) return false;
+      int32_t nul = 1;
+      int64_t len = 0;
+      value.assign(64, '\0');
+      int32_t rc = provider(provider_ctx, id, (int32_t)type.id, &nul, (uint8_t*)&value[0], (int64_t)value.size(), &len);
+      if (rc == 1 && len > (int64_t)value.size()) {      // a longer string / binary: once more with room
+        value.assign((size_t)len, '\0');
+        rc = provider(provider_ctx, id, (int32_t)type.id, &nul, (uint8_t*)&value[0], (int64_t)value.size(), &len);
+      }
+      if (rc < 0) throw CometError("the scalar subquery provider failed for subquery " + std::to_string(id));
+      if (rc == 0) return false;
+      is_null = nul != 0;
+      value.resize((size_t)std::max<int64_t>(0, std::min<int64_t>(len, (int64_t)value.size())));
+      return true;
+    });
+    return 0;
+  });
+}
+
 int64_t comet_execute_plan(int64_t handle, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas, int32_t n_out) {
   auto ctx = lookup(handle);
   if (!ctx) {

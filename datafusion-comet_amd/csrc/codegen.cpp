@@ -451,6 +451,7 @@ struct Gen {
     if (!e->func.empty()) k << "F" << e->func.size() << ":" << e->func;
     if (e->is_spark4_plus) k << "S4";
     if (e->one_based) k << "OB";
+    if (e->kind == ExprKind::Subquery) k << "Q" << e->lit_i64;
     if (e->check_divide_overflow) k << "DO";
     if (e->kind == ExprKind::CaseWhen) k << "W" << e->n_when;
     if (e->kind == ExprKind::Literal) {
@@ -2632,6 +2633,16 @@ struct Gen {
         r.v = e.kind == ExprKind::Hour ? "(i32)((" + sec + ") / 3600)" : e.kind == ExprKind::Minute ? "(i32)((" + sec + ") / 60 % 60)" : "(i32)((" + sec + ") % 60)";
         r.maxabs = 64;
         return r;
+      }
+      case ExprKind::Subquery: {
+        // a scalar subquery the executor has not asked for yet (createPlan's dry generation): a NULL of its type — at the first executePlan the node becomes
+        // a Literal and the plan is generated anew under a hash that carries the value (exec.cpp resolve_subqueries)
+        Expr nul;
+        nul.kind = ExprKind::Literal;
+        nul.dtype = e.dtype;
+        nul.has_dtype = true;
+        nul.lit_null = true;
+        return literal(nul);
       }
       case ExprKind::ListExtract: return list_extract(e);
       case ExprKind::TruncTimestamp: {

@@ -1936,8 +1936,57 @@ int64_t ExecutionContext::execute_device(ArrowDeviceArray** out_arrays, ArrowSch
   return tab.rows;
 }
 
+void ExecutionContext::resolve_subqueries() {
+  if (subqueries_resolved_) return;
+  subqueries_resolved_ = true;
+  uint64_t sig = 0xcbf29ce484222325ull;
+  auto mix = [&](const void* p, size_t n) { for (size_t k = 0; k < n; k++) sig = (sig ^ ((const uint8_t*)p)[k]) * 0x100000001b3ull; };
+  for (auto& e : plan_->subqueries) {
+    if (e->kind != ExprKind::Subquery) continue;      // (one node, listed once)
+    const int64_t id = e->lit_i64;
+    bool is_null = true;
+    std::string v;
+    bool found = false;
+    auto it = subquery_values_.find(id);
+    if (it != subquery_values_.end()) { is_null = it->second.first; v = it->second.second; found = true; }
+    else if (subquery_provider_) found = subquery_provider_(id, e->dtype, is_null, v);
+    if (!found) throw CometError("Subquery " + std::to_string(id) + " is not registered with this plan (CometScalarSubquery.setSubquery / comet_plan_set_subquery)");
+    auto need = [&](size_t n) { if (!is_null && v.size() < n) throw CometError("Subquery " + std::to_string(id) + ": the value has " + std::to_string(v.size()) + " bytes, its type needs " + std::to_string(n)); };
+    e->kind = ExprKind::Literal;
+    e->proto_tag = 2;
+    e->lit_null = is_null;
+    e->lit_i64 = 0;
+    int64_t i = 0;
+    double d = 0;
+    switch (e->dtype.id) {
+      case TypeId::Bool: need(1); e->lit_bool = !is_null && v[0] != 0; e->lit_case = 1; break;
+      case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Date: case TypeId::Int64: case TypeId::Timestamp: case TypeId::TimestampNtz:
+        need(8);
+        if (!is_null) memcpy(&i, v.data(), 8);
+        e->lit_i64 = i;
+        e->lit_case = e->dtype.id == TypeId::Int8 ? 2 : e->dtype.id == TypeId::Int16 ? 3 : (e->dtype.id == TypeId::Int32 || e->dtype.id == TypeId::Date) ? 4 : 5;
+        break;
+      case TypeId::Float: case TypeId::Double:
+        need(8);
+        if (!is_null) memcpy(&d, v.data(), 8);
+        e->lit_f64 = e->dtype.id == TypeId::Float ? (double)(float)d : d;
+        e->lit_case = e->dtype.id == TypeId::Float ? 6 : 7;
+        break;
+      case TypeId::Decimal: e->lit_dec = is_null ? 0 : decode_decimal_be(v); e->lit_case = 10; break;
+      case TypeId::String: case TypeId::Bytes: e->lit_bytes = is_null ? std::string() : v; e->lit_case = e->dtype.id == TypeId::String ? 8 : 9; break;
+      default: throw CometError("Unsupported scalar subquery data type " + e->dtype.str());
+    }
+    mix(&id, 8);
+    mix(&is_null, 1);
+    mix(v.data(), v.size());
+  }
+  // the plan's kernels carry the values: planned anew, under a hash that names them
+  if (!plan_->subqueries.empty()) plan_hash_ ^= sig * 0x9E3779B97F4A7C15ull;
+}
+
 int64_t ExecutionContext::execute(ArrowArray** out_arrays, ArrowSchema** out_schemas, int n_out) {
   mem_->owner = std::this_thread::get_id();
+  if (!subqueries_resolved_) resolve_subqueries();
   AccountScope account(mem_);
   mem_->flush();
   Timer t;

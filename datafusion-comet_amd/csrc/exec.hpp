@@ -159,6 +159,14 @@ class ExecutionContext {
   std::string metrics_proto();
   // the host's memory manager for this plan's pinned staging (see MemAccount); stats: host used / peak, device used / peak
   void set_memory_manager(int64_t (*acquire)(void*, int64_t), void (*release)(void*, int64_t), void* ctx, long long task_id);
+  // Scalar subqueries (expr.proto:513-516; expressions/subquery.rs:72-180): the reference asks the JVM for a subquery's value when the expression is first
+  // evaluated (CometScalarSubquery.isNull / getInt / … (planId, id)) — here every Subquery node of the plan becomes a Literal at the first executePlan.  The value
+  // comes from the provider (JNI: those static methods; C ABI: comet_plan_set_subquery's table).  → false: no such subquery.  Value bytes: integers / dates /
+  // timestamps 8-byte little-endian, booleans 1 byte, floats and doubles an 8-byte double, decimals BigInteger.toByteArray, strings / binary as they are.
+  typedef std::function<bool(int64_t id, const DType& type, bool& is_null, std::string& value)> SubqueryProvider;
+  void set_subquery_provider(SubqueryProvider p) { subquery_provider_ = std::move(p); }
+  void set_subquery_value(int64_t id, bool is_null, std::string value) { subquery_values_[id] = {is_null, std::move(value)}; }
+  void resolve_subqueries();
   void memory_stats(int64_t out[4]);
   std::shared_ptr<MemAccount> memory_account() const { return mem_; }
   const std::string& explain();
@@ -289,6 +297,9 @@ class ExecutionContext {
   std::string explain_;
   SinkKind sink_ = SinkKind::Output;
   bool has_join_ = false;
+  SubqueryProvider subquery_provider_;
+  std::map<int64_t, std::pair<bool, std::string>> subquery_values_;
+  bool subqueries_resolved_ = false;
   int64_t strfn_rows_ = 0;          // rows that went through the derived string functions' kernels
   int64_t split_rows_ = 0;          // rows that went through split's kernels (tests: the device path ran)
   bool materialize_root_ = false;   // plain Scan chain whose outputs need the materialising path (Utf8 pass-through)

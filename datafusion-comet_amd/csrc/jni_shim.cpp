@@ -19,11 +19,13 @@ namespace {
 JavaVM* g_vm = nullptr;
 
 struct BlockIterator;
+struct JvmSubqueries { jlong plan_id; };      // createPlan's plan id: what CometScalarSubquery's static methods are asked with
 struct JavaSide {                 // global refs held for the lifetime of a plan (jni_api.rs:423-436,517-527)
   std::vector<jobject> iterators;
   jobject metrics_node = nullptr;
   long long metrics_interval_ms = 0;                           // createPlan's metricsUpdateInterval (jni_api.rs:906-909)
   struct MemoryManager* memory = nullptr;                      // createPlan's taskMemoryManager (owned; freed by releasePlan)
+  JvmSubqueries* subqueries = nullptr;                    // createPlan's plan id, for CometScalarSubquery's static methods (owned)
   std::chrono::steady_clock::time_point last_metrics_push;
 };
 
@@ -151,8 +153,84 @@ JNIEXPORT jboolean JNICALL Java_org_apache_comet_NativeBase_isObjectStoreSchemeS
 }
 
 // Native.createPlan (jni_api.rs:371-562)
+// Scalar subqueries: org.apache.spark.sql.comet.CometScalarSubquery's static methods (jni-bridge/src/comet_exec.rs:54-126), asked with the plan id createPlan was
+// given and the subquery's id — on the task thread, with the env of the executePlan call in progress (expressions/subquery.rs:72-180).
+// modified UTF-8 (what GetStringUTFChars hands out) → UTF-8: C0 80 is NUL, a supplementary character comes as two three-byte surrogates
+static std::string from_modified_utf8(const char* s) {
+  std::string o;
+  const unsigned char* p = (const unsigned char*)s;
+  while (*p) {
+    if (p[0] == 0xC0 && p[1] == 0x80) { o.push_back('\0'); p += 2; continue; }
+    if (p[0] == 0xED && (p[1] & 0xF0) == 0xA0 && p[2] && p[3] == 0xED && (p[4] & 0xF0) == 0xB0 && p[5]) {
+      const unsigned hi = 0xD000u | ((p[1] & 0x3Fu) << 6) | (p[2] & 0x3Fu), lo = 0xD000u | ((p[4] & 0x3Fu) << 6) | (p[5] & 0x3Fu);
+      const unsigned cp = 0x10000u + ((hi - 0xD800u) << 10) + (lo - 0xDC00u);
+      o.push_back((char)(0xF0 | (cp >> 18)));
+      o.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+      o.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+      o.push_back((char)(0x80 | (cp & 0x3F)));
+      p += 6;
+      continue;
+    }
+    o.push_back((char)*p++);
+  }
+  return o;
+}
+static int32_t subquery_from_jvm(void* vctx, int64_t id, int32_t type_id, int32_t* is_null, uint8_t* out, int64_t cap, int64_t* len) {
+  JNIEnv* env = t_env;
+  JvmSubqueries* c = (JvmSubqueries*)vctx;
+  if (!env || !c) return -1;
+  jclass cls = jni_FindClass(env, "org/apache/spark/sql/comet/CometScalarSubquery");
+  if (!cls || jni_ExceptionCheck(env)) return -1;
+  auto method = [&](const char* name, const char* sig) { return jni_GetStaticMethodID(env, cls, name, sig); };
+  jmethodID m_null = method("isNull", "(JJ)Z");
+  if (!m_null || jni_ExceptionCheck(env)) return -1;
+  const bool nul = jni_CallStaticBooleanMethodJJ(env, cls, m_null, c->plan_id, (jlong)id) != 0;
+  if (jni_ExceptionCheck(env)) return -1;
+  *is_null = nul ? 1 : 0;
+  *len = 0;
+  if (nul) return 1;
+  auto put64 = [&](int64_t v) { if (cap >= 8) memcpy(out, &v, 8); *len = 8; };
+  auto putf = [&](double v) { if (cap >= 8) memcpy(out, &v, 8); *len = 8; };
+  auto put_bytes = [&](const void* p, size_t n) { if ((int64_t)n <= cap) memcpy(out, p, n); *len = (int64_t)n; };
+  jmethodID m = nullptr;
+  switch (type_id) {      // types.proto:43-66
+    case 0: m = method("getBoolean", "(JJ)Z"); if (m) { const uint8_t b = jni_CallStaticBooleanMethodJJ(env, cls, m, c->plan_id, (jlong)id) ? 1 : 0; put_bytes(&b, 1); } break;
+    case 1: m = method("getByte", "(JJ)B"); if (m) put64((int64_t)jni_CallStaticByteMethodJJ(env, cls, m, c->plan_id, (jlong)id)); break;
+    case 2: m = method("getShort", "(JJ)S"); if (m) put64((int64_t)jni_CallStaticShortMethodJJ(env, cls, m, c->plan_id, (jlong)id)); break;
+    case 3: case 12: m = method("getInt", "(JJ)I"); if (m) put64((int64_t)jni_CallStaticIntMethodJJ(env, cls, m, c->plan_id, (jlong)id)); break;            // int, date
+    case 4: case 9: case 11: m = method("getLong", "(JJ)J"); if (m) put64((int64_t)jni_CallStaticLongMethodJJ(env, cls, m, c->plan_id, (jlong)id)); break;   // long, timestamp, timestamp_ntz
+    case 5: m = method("getFloat", "(JJ)F"); if (m) putf((double)jni_CallStaticFloatMethodJJ(env, cls, m, c->plan_id, (jlong)id)); break;
+    case 6: m = method("getDouble", "(JJ)D"); if (m) putf(jni_CallStaticDoubleMethodJJ(env, cls, m, c->plan_id, (jlong)id)); break;
+    case 10: case 8: {      // decimal: BigInteger.toByteArray; binary: the bytes
+      m = method(type_id == 10 ? "getDecimal" : "getBinary", "(JJ)[B");
+      if (!m) break;
+      jbyteArray a = (jbyteArray)jni_CallStaticObjectMethodJJ(env, cls, m, c->plan_id, (jlong)id);
+      if (!a || jni_ExceptionCheck(env)) return -1;
+      const jsize n = jni_GetArrayLength(env, a);
+      std::vector<uint8_t> tmp((size_t)n + 1);
+      jni_GetByteArrayRegion(env, a, 0, n, (jbyte*)tmp.data());
+      put_bytes(tmp.data(), (size_t)n);
+      break;
+    }
+    case 7: {      // string
+      m = method("getString", "(JJ)Ljava/lang/String;");
+      if (!m) break;
+      jstring js = (jstring)jni_CallStaticObjectMethodJJ(env, cls, m, c->plan_id, (jlong)id);
+      if (!js || jni_ExceptionCheck(env)) return -1;
+      const char* chars = jni_GetStringUTFChars(env, js);
+      const std::string u = from_modified_utf8(chars ? chars : "");
+      if (chars) jni_ReleaseStringUTFChars(env, js, chars);
+      put_bytes(u.data(), u.size());
+      break;
+    }
+    default: return -1;
+  }
+  if (!m || jni_ExceptionCheck(env)) return -1;
+  return 1;
+}
+
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
-    JNIEnv* env, jclass, jlong /*id*/, jobjectArray iterators, jbyteArray plan, jbyteArray configMap, jint partitionCount,
+    JNIEnv* env, jclass, jlong plan_id, jobjectArray iterators, jbyteArray plan, jbyteArray configMap, jint partitionCount,
     jobject metricsNode, jlong metricsUpdateInterval, jobject taskMemoryManager, jobjectArray /*localDirs*/, jint batchSize,
     jboolean /*offHeapMode*/, jstring /*memoryPoolType*/, jlong /*memoryLimit*/, jlong /*memoryLimitPerTask*/, jlong taskAttemptId,
     jlong /*taskCPUs*/, jobject /*keyUnwrapper*/, jobject /*taskContext*/, jobject /*classLoader*/) {
@@ -230,6 +308,8 @@ JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
       jni_ExceptionClear(env);      // not a CometTaskMemoryManager: run unaccounted rather than fail the task
     }
   }
+  js.subqueries = new JvmSubqueries{plan_id};
+  comet_plan_set_subquery_provider(h, subquery_from_jvm, js.subqueries);
   if (metricsNode) js.metrics_node = jni_NewGlobalRef(env, metricsNode);
   js.metrics_interval_ms = (long long)metricsUpdateInterval;
   js.last_metrics_push = std::chrono::steady_clock::now();
@@ -301,6 +381,7 @@ JNIEXPORT void JNICALL Java_org_apache_comet_Native_releasePlan(JNIEnv* env, jcl
     jni_DeleteGlobalRef(env, js.memory->obj);
     delete js.memory;
   }
+  delete js.subqueries;
   for (jobject g : js.iterators) jni_DeleteGlobalRef(env, g);
   if (js.metrics_node) jni_DeleteGlobalRef(env, js.metrics_node);
 }

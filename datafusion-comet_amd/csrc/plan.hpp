@@ -68,6 +68,7 @@ enum class ExprKind : int {
   CheckOverflow = 25, Like = 26, RLike = 30, ScalarFunc = 31, EqNullSafe = 32, NeqNullSafe = 33, BitAnd = 34, BitOr = 35, BitXor = 36, Remainder = 37, CaseWhen = 38, In = 39, Not = 40,
   UnaryMinus = 41, ShiftRight = 42, ShiftLeft = 43, If = 44, IntegralDivide = 59, NormalizeNaNAndZero = 45, Unbound = 51,
   GetStructField = 54,              // expr.proto:528-531: child = 1, ordinal = 2 (kept in Expr::bound_index)
+  Subquery = 50,                    // expr.proto:513-516: a scalar subquery's result — id = 1 (kept in Expr::lit_i64), datatype = 2; a Literal once the executor has asked for it
   ListExtract = 56,                 // expr.proto:533-539: children = [child, ordinal, (default value)], one_based, fail_on_error
   Unsupported = -1
 };
@@ -166,6 +167,7 @@ struct Operator {
   int proto_tag = 0;
   uint32_t plan_id = 0;
   std::vector<std::string> sql_text_pool;      // (root only) the SQL texts QueryContext.sql_text_idx points into
+  std::vector<ExprP> subqueries;               // (root only) every Subquery expression of the plan (resolved into literals at the first executePlan)
   bool reader_api = false;                      // NativeScan built by the parquet.Native record-batch reader, not decoded from a plan
   std::vector<OperatorP> children;
   // Scan
@@ -252,7 +254,8 @@ struct Operator {
 // proto.cpp
 OperatorP decode_operator(const uint8_t* data, size_t len);
 ExprP decode_expr_bytes(const uint8_t* data, size_t len);   // one serialized spark_expression.Expr
-DType decode_datatype_bytes(const uint8_t* data, size_t len);   // one serialized spark_expression.DataType (types.proto:27-41)
+DType decode_datatype_bytes(const uint8_t* data, size_t len);
+i128 decode_decimal_be(const std::string& bytes);   // BigInteger.toByteArray → the unscaled value (decimal literals, scalar subqueries)   // one serialized spark_expression.DataType (types.proto:27-41)
 std::vector<std::pair<std::string, std::string>> decode_config_map(const uint8_t* data, size_t len);
 // NativeMetricNode encoder (metric.proto:26-29)
 struct MetricNode {

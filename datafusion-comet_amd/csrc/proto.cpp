@@ -287,6 +287,7 @@ void decode_expr_body(Reader r, Expr& e) {
 
 // the contexts of the plan being decoded: their sql_text_idx is resolved against the ROOT operator's pool once the root is complete
 thread_local std::vector<std::shared_ptr<QueryContext>>* g_decoded_contexts = nullptr;
+thread_local std::vector<ExprP>* g_decoded_subqueries = nullptr;
 
 std::shared_ptr<QueryContext> decode_query_context(Reader r) {
   auto c = std::make_shared<QueryContext>();
@@ -317,6 +318,18 @@ ExprP decode_expr(Reader r) {
     e->proto_tag = f;
     switch (f) {
       case 2: e->kind = ExprKind::Literal; decode_literal(r.sub(), *e); break;
+      case 50: {      // Subquery{id = 1, datatype = 2} (expr.proto:513-516)
+        e->kind = ExprKind::Subquery;
+        Reader b = r.sub();
+        while (!b.done()) {
+          int wt2, f2 = b.tag(wt2);
+          if (f2 == 1 && wt2 == 0) e->lit_i64 = (int64_t)b.varint();
+          else if (f2 == 2 && wt2 == 2) { e->dtype = decode_datatype(b.sub()); e->has_dtype = true; }
+          else b.skip(wt2);
+        }
+        if (g_decoded_subqueries) g_decoded_subqueries->push_back(e);
+        break;
+      }
       case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14:
       case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 47: case 65: case 56: case 25: case 26: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 42: case 43: case 59: case 38: case 39: case 40: case 41:
       case 44: case 45: case 51: case 54:
@@ -789,7 +802,11 @@ OperatorP decode_operator(const uint8_t* data, size_t len) {
     ~Scope() { slot = prev; }
   } scope{g_decoded_contexts, g_decoded_contexts};
   g_decoded_contexts = &contexts;
+  std::vector<ExprP> subqueries;
+  struct SubScope { std::vector<ExprP>* prev; ~SubScope() { g_decoded_subqueries = prev; } } sub_scope{g_decoded_subqueries};
+  g_decoded_subqueries = &subqueries;
   OperatorP root = decode_operator_r(Reader(data, len));
+  root->subqueries = std::move(subqueries);
   // QueryContext.sql_text_idx → the root's pool (a query text shared by many expressions travels once per plan, expr.proto:137-141).  An index
   // outside the pool keeps the context's own sql_text, as the reference does ("warn rather than fail: a degraded error message is better
   // than a failed query", planner.rs:329-343).
@@ -799,6 +816,7 @@ OperatorP decode_operator(const uint8_t* data, size_t len) {
 }
 ExprP decode_expr_bytes(const uint8_t* data, size_t len) { return decode_expr(Reader(data, len)); }
 DType decode_datatype_bytes(const uint8_t* data, size_t len) { return decode_datatype(Reader(data, len)); }
+i128 decode_decimal_be(const std::string& bytes) { return decode_be_twos_complement(bytes); }
 
 std::vector<std::pair<std::string, std::string>> decode_config_map(const uint8_t* data, size_t len) {
   std::vector<std::pair<std::string, std::string>> out;
@@ -892,7 +910,7 @@ const char* expr_name(int t) {
     case 19: return "SortOrder"; case 25: return "CheckOverflow"; case 26: return "Like"; case 30: return "RLike"; case 31: return "ScalarFunc";
     case 32: return "EqNullSafe"; case 33: return "NeqNullSafe"; case 37: return "Remainder"; case 38: return "CaseWhen";
     case 39: return "In"; case 40: return "Not"; case 41: return "UnaryMinus"; case 44: return "If"; case 54: return "GetStructField"; case 56: return "ListExtract";
-    case 45: return "NormalizeNaNAndZero"; case 47: return "TruncTimestamp"; case 65: return "UnixTimestamp"; default: return "Expr";
+    case 45: return "NormalizeNaNAndZero"; case 47: return "TruncTimestamp"; case 50: return "Subquery"; case 65: return "UnixTimestamp"; default: return "Expr";
   }
 }
 

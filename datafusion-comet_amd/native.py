@@ -153,6 +153,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_extract_all_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.c_int32]
     lib.comet_strfn_host.restype = c.c_int64
     lib.comet_strfn_host.argtypes = [c.c_int32, c.c_char_p, c.c_int32, c.c_char_p, c.c_int32, c.c_char_p, c.c_int32, c.c_int64, c.c_void_p, c.c_int64]
+    lib.comet_plan_set_subquery.restype = c.c_int32
+    lib.comet_plan_set_subquery.argtypes = [c.c_int64, c.c_int64, c.c_int32, c.c_char_p, c.c_size_t]
     lib.comet_split_host.restype = c.c_int32
     lib.comet_split_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.c_int32]
     lib.comet_date_fn_host.restype = c.c_int32
@@ -777,11 +779,15 @@ class CometExecIterator:
     """Per-task driver: createPlan → executePlan* → releasePlan (CometExecIterator.scala:109,158,236)."""
 
     def __init__(self, inputs: Sequence, num_output_cols: int, plan: bytes, config: bytes = b"", batch_size: int = 8192,
-                 device_id: int = 0):
+                 device_id: int = 0, subqueries=None):
         self._inputs = list(inputs)  # keep the exported streams alive
         self.num_output_cols = num_output_cols
         self.handle = Native.createPlan(self._inputs, plan, config, 1, batch_size, device_id)
         self._closed = False
+        # scalar subqueries: {id: value bytes or None for NULL} (comet_plan_set_subquery; what CometScalarSubquery.setSubquery registers on the JVM side)
+        for sid, val in (subqueries or {}).items():
+            if lib().comet_plan_set_subquery(self.handle, sid, 1 if val is None else 0, val or b"", len(val or b"")) != 0:
+                _raise_last(self.handle)
 
     def __iter__(self) -> Iterator[pa.RecordBatch]:
         return self
@@ -1219,6 +1225,25 @@ def strfn_host(op: int, value: bytes, a: bytes = b"", b: bytes = b"", k: int = 0
     buf = ctypes.create_string_buffer(max(n, 1))
     lib().comet_strfn_host(op, value, len(value), a, len(a), b, len(b), k, buf, n)
     return buf.raw[:n]
+
+
+def subquery_value(v, dtype) -> Optional[bytes]:
+    """a scalar subquery's value in comet_plan_set_subquery's encoding (include/comet_amd.h)"""
+    import struct
+    from . import serde as S
+    if v is None:
+        return None
+    t = dtype.type_id
+    if t == S.BOOL:
+        return b"\x01" if v else b"\x00"
+    if t in (S.FLOAT, S.DOUBLE):
+        return struct.pack("<d", float(v))
+    if t == S.DECIMAL:
+        u = int(v)
+        return u.to_bytes(max(1, (u.bit_length() + 8) // 8), "big", signed=True)
+    if t in (S.STRING, S.BYTES):
+        return v.encode() if isinstance(v, str) else bytes(v)
+    return struct.pack("<q", int(v))
 
 
 def split_host(pattern: str, limit: int, value: str):

@@ -180,7 +180,7 @@ class Expr:
     check_divide_overflow: bool = False   # MathExpr field 6 (integral_divide only)
 
     # field numbers of Expr.expr_struct (expr.proto:30-107)
-    TAGS = dict(list_extract=56, trunc_timestamp=47, unix_timestamp=65, hour=22, minute=23, second=24, literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
+    TAGS = dict(subquery=50, list_extract=56, trunc_timestamp=47, unix_timestamp=65, hour=22, minute=23, second=24, literal=2, bound=3, add=4, subtract=5, multiply=6, divide=7, cast=8, eq=9, neq=10, gt=11, gt_eq=12,
                 lt=13, lt_eq=14, is_null=15, is_not_null=16, and_=17, or_=18, check_overflow=25, like=26, rlike=30, scalar_func=31, eq_null_safe=32,
                 neq_null_safe=33, bit_and=34, bit_or=35, bit_xor=36, shift_right=42, shift_left=43, integral_divide=59, remainder=37, case_when=38, in_=39, not_=40, unary_minus=41, if_=44, normalize_nan_and_zero=45,
                 unbound=51, get_struct_field=54)
@@ -203,6 +203,8 @@ class Expr:
                 body += _f_varint(6, 1)
         elif k in ("hour", "minute", "second", "unix_timestamp"):      # expr.proto:436-458: child = 1, timezone = 2
             body = _f_msg(1, self.children[0].encode()) + _f_bytes(2, (getattr(self, "timezone", None) or "UTC").encode())
+        elif k == "subquery":                                          # expr.proto:513-516: id = 1, datatype = 2
+            body = _f_varint(1, int(self.value)) + _f_msg(2, self.dtype.encode())
         elif k == "list_extract":                                      # expr.proto:533-539
             body = _f_msg(1, self.children[0].encode()) + _f_msg(2, self.children[1].encode())
             if len(self.children) > 2:
@@ -375,6 +377,11 @@ def time_part(kind: str, child: Expr, timezone: str = "UTC") -> Expr:
     e = Expr(kind, [child])
     e.timezone = timezone
     return e
+
+
+def subquery(sub_id: int, dtype: DataType) -> Expr:
+    """a scalar subquery's result (ScalarSubquery → Subquery{id, datatype}, expr.proto:513-516): the native side asks for the value at the first executePlan"""
+    return Expr("subquery", [], dtype=dtype, value=sub_id)
 
 
 def list_extract(child: Expr, ordinal: Expr, one_based: bool = False, fail_on_error: bool = False, default: Optional[Expr] = None) -> Expr:

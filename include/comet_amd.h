@@ -202,6 +202,17 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
  * comet_last_error(0) for a pattern outside the subset or a group index out of range (the reference's message).  Needs no GPU. */
 int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* start, int32_t* len);
 
+/* ---- scalar subqueries (expr.proto:513-516 Subquery{id, datatype}; native/core/src/execution/expressions/subquery.rs:72-180) ------------------------------
+ * The reference asks the JVM for a subquery's value when the expression is first evaluated: CometScalarSubquery.isNull / getBoolean / getByte / getShort / getInt /
+ * getLong / getFloat / getDouble / getDecimal / getString / getBinary (planId, id) (jni-bridge/src/comet_exec.rs:54-126).  Here every Subquery of a plan becomes a
+ * literal at the first comet_execute_plan.  The values come from a table filled with comet_plan_set_subquery (JVM-free callers) or from a provider callback (the
+ * JNI shim registers one that calls those static methods).  Value bytes: integers / dates / timestamps 8-byte little-endian, booleans 1 byte, floats and doubles an
+ * 8-byte double, decimals BigInteger.toByteArray (big-endian two's complement of the unscaled value), strings / binary as they are.
+ * provider: → 1 and *is_null / out[0, *len) (when *len > cap it is called once more with room), 0: no such subquery, < 0: failed.  type_id: types.proto's. */
+typedef int32_t (*comet_subquery_provider)(void* ctx, int64_t id, int32_t type_id, int32_t* is_null, uint8_t* out, int64_t cap, int64_t* len);
+int32_t comet_plan_set_subquery(int64_t handle, int64_t id, int32_t is_null, const uint8_t* value, size_t value_len);
+int32_t comet_plan_set_subquery_provider(int64_t handle, comet_subquery_provider provider, void* provider_ctx);
+
 /* The string functions and digests of csrc/device/strfn.hpp on the host — diagnostic entry: op 1 reverse, 2 repeat(k), 3 replace(a, b), 4 substring_index(a, k),
  * 10 md5, 11 sha1, 12-15 sha224 / 256 / 384 / 512 (hexadecimal digits): the result's length, its bytes written when they fit `cap`; op 20 crc32, 21 instr(a),
  * 22 ascii: the value.  Needs no GPU. */

@@ -231,6 +231,8 @@ def split_like_the_crate(pat: str, text: str, limit: int):
 
 
 # --------------------------------------------------------------------------- expression evaluation
+SUBQUERIES = {}      # scalar subquery id → Python value (None = NULL): what a test registered for the plan it runs (CometScalarSubquery.setSubquery's part)
+
 
 
 class OracleError(Exception):
@@ -288,6 +290,11 @@ class Evaluator:
                     sec = (C.utc_to_local_us(tz, us) if a.dtype.type_id == S.TIMESTAMP else us) % 86_400_000_000 // 1_000_000
                     out[i] = {"hour": sec // 3600, "minute": sec // 60 % 60, "second": sec % 60}[k]
             return Col(S.T_INT32, out, a.valid)
+        if k == "subquery":
+            # Subquery{id, datatype} (expressions/subquery.rs:72-180): the value the JVM holds for the id — here the evaluator's `subqueries` table — as a scalar
+            v = SUBQUERIES.get(int(e.value))
+            lit = S.lit(v, e.dtype)
+            return self.eval(lit, cols, n)
         if k == "list_extract":
             # ListExtract (array_funcs/list_extract.rs:229-320): GetArrayItem counts from 0, element_at from 1 (negative: from the end; 0: INVALID_INDEX_OF_ZERO);
             # outside the list: NULL, or the error under ANSI; a NULL list / ordinal / element: NULL

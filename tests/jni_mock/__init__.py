@@ -44,6 +44,9 @@ def load():
     m.mock_metrics_pushes.argtypes = [vp]
     m.mock_metrics_bytes.restype = vp
     m.mock_metrics_bytes.argtypes = [vp]
+    m.mock_set_subquery.restype = None
+    m.mock_set_subquery.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_char_p, ctypes.c_int64]
+    m.mock_static_calls.restype = ctypes.c_char_p
     m.mock_exception_class.restype = ctypes.c_char_p
     m.mock_exception_msg.restype = ctypes.c_char_p
     return m

@@ -2,6 +2,7 @@
  * Implements exactly the JNI functions jni_shim.cpp calls, at their specified function-table indices, over
  * tiny C "objects".  It proves the shim's marshalling, ownership and exception mapping without a JVM. */
 #include <stdarg.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -88,6 +89,47 @@ static jobject f_CallObjectMethod(JNIEnv* e, jobject o, jmethodID m, ...) {
   if (m != &g_mid_getbuffer || it->addr < 1) return NULL;
   return ((MObj**)it->data)[it->addr - 1];
 }
+/* ---- org.apache.spark.sql.comet.CometScalarSubquery: static isNull / get<Type>(planId, id) over a table the test fills ---- */
+typedef struct { int64_t plan_id, id; int is_null; int64_t i; double d; char* bytes; int64_t nbytes; } MSub;
+static MSub g_subs[32];
+static int g_nsubs;
+static char g_static_calls[4096];      /* "isNull(7,3);getInt(7,3);" … in call order */
+static int g_mids_static[12];
+static const char* k_static_names[12] = {"isNull", "getBoolean", "getByte", "getShort", "getInt", "getLong", "getFloat", "getDouble", "getDecimal", "getString", "getBinary", 0};
+static jmethodID f_GetStaticMethodID(JNIEnv* e, jclass c, const char* n, const char* sig) {
+  (void)e; (void)sig;
+  if (!c || ((MObj*)c)->kind != K_CLASS || strcmp(((MObj*)c)->cname, "org/apache/spark/sql/comet/CometScalarSubquery")) return NULL;
+  for (int k = 0; k_static_names[k]; k++)
+    if (!strcmp(n, k_static_names[k])) return &g_mids_static[k];
+  return NULL;
+}
+static MSub* sub_of(jmethodID m, va_list ap) {
+  const int64_t plan = va_arg(ap, int64_t), id = va_arg(ap, int64_t);
+  const int k = (int)((int*)m - g_mids_static);
+  char note[96];
+  snprintf(note, sizeof note, "%s(%lld,%lld);", k_static_names[k], (long long)plan, (long long)id);
+  strncat(g_static_calls, note, sizeof g_static_calls - strlen(g_static_calls) - 1);
+  for (int s = 0; s < g_nsubs; s++)
+    if (g_subs[s].plan_id == plan && g_subs[s].id == id) return &g_subs[s];
+  return NULL;
+}
+#define STATIC_CALL(NAME, T, EXPR) static T NAME(JNIEnv* e, jclass c, jmethodID m, ...) { (void)e; (void)c; va_list ap; va_start(ap, m); MSub* s = sub_of(m, ap); va_end(ap); return (T)(EXPR); }
+STATIC_CALL(f_CallStaticBooleanMethod, jboolean, (int*)m == &g_mids_static[0] ? (!s || s->is_null) : (s && s->i != 0))
+STATIC_CALL(f_CallStaticByteMethod, jbyte, s ? s->i : 0)
+STATIC_CALL(f_CallStaticShortMethod, jshort, s ? s->i : 0)
+STATIC_CALL(f_CallStaticIntMethod, jint, s ? s->i : 0)
+STATIC_CALL(f_CallStaticLongMethod, jlong, s ? s->i : 0)
+STATIC_CALL(f_CallStaticFloatMethod, jfloat, s ? s->d : 0)
+STATIC_CALL(f_CallStaticDoubleMethod, jdouble, s ? s->d : 0)
+static jobject f_CallStaticObjectMethod(JNIEnv* e, jclass c, jmethodID m, ...) {
+  (void)e; (void)c;
+  va_list ap; va_start(ap, m); MSub* s = sub_of(m, ap); va_end(ap);
+  if (!s) return NULL;
+  MObj* o = calloc(1, sizeof *o);
+  if ((int*)m == &g_mids_static[9]) { o->kind = K_STRING; o->data = strdup(s->bytes ? s->bytes : ""); return o; }
+  o->kind = K_BYTES; o->len = s->nbytes; o->data = malloc((size_t)s->nbytes + 1); memcpy(o->data, s->bytes, (size_t)s->nbytes);
+  return o;
+}
 static void* f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return b && ((MObj*)b)->kind == K_BYTES ? ((MObj*)b)->data : NULL; }
 static void f_ExceptionClear(JNIEnv* e) { (void)e; g_exc_pending = 0; }
 /* K_INTS: data = int32[len]; K_INFO (NativeColumnarToRowInfo): addr = memory address, data = MObj*[2] {offsets, lengths} */
@@ -136,6 +178,11 @@ static void f_GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, jlon
 static jint f_GetJavaVM(JNIEnv* e, JavaVM** vm) { (void)e; *vm = (JavaVM*)&g_vm; return 0; }
 
 JNIEnv* mock_env(void) {
+  g_tab.fn[JNI_GetStaticMethodID] = (void*)f_GetStaticMethodID; g_tab.fn[JNI_CallStaticObjectMethod] = (void*)f_CallStaticObjectMethod;
+  g_tab.fn[JNI_CallStaticBooleanMethod] = (void*)f_CallStaticBooleanMethod; g_tab.fn[JNI_CallStaticByteMethod] = (void*)f_CallStaticByteMethod;
+  g_tab.fn[JNI_CallStaticShortMethod] = (void*)f_CallStaticShortMethod; g_tab.fn[JNI_CallStaticIntMethod] = (void*)f_CallStaticIntMethod;
+  g_tab.fn[JNI_CallStaticLongMethod] = (void*)f_CallStaticLongMethod; g_tab.fn[JNI_CallStaticFloatMethod] = (void*)f_CallStaticFloatMethod;
+  g_tab.fn[JNI_CallStaticDoubleMethod] = (void*)f_CallStaticDoubleMethod;
   g_tab.fn[JNI_FindClass] = (void*)f_FindClass; g_tab.fn[JNI_ThrowNew] = (void*)f_ThrowNew; g_tab.fn[JNI_ExceptionCheck] = (void*)f_ExceptionCheck;
   g_tab.fn[JNI_NewGlobalRef] = (void*)f_NewGlobalRef; g_tab.fn[JNI_DeleteGlobalRef] = (void*)f_DeleteGlobalRef;
   g_tab.fn[JNI_DeleteLocalRef] = (void*)f_DeleteLocalRef; g_tab.fn[JNI_GetObjectClass] = (void*)f_GetObjectClass;
@@ -173,6 +220,16 @@ void* mock_string(const char* s) { MObj* o = calloc(1, sizeof *o); o->kind = K_S
 int64_t mock_metrics_len(void* n) { return ((MObj*)n)->len; }
 long long mock_metrics_pushes(void* node) { return ((MObj*)node)->addr; }
 const void* mock_metrics_bytes(void* n) { return ((MObj*)n)->data; }
+/* CometScalarSubquery.setSubquery(planId, …): is_null / integer / double / bytes (decimal: BigInteger.toByteArray, string: modified UTF-8) */
+void mock_set_subquery(int64_t plan_id, int64_t id, int is_null, int64_t i, double d, const void* bytes, int64_t nbytes) {
+  MSub* s = &g_subs[g_nsubs++ % 32];
+  s->plan_id = plan_id; s->id = id; s->is_null = is_null; s->i = i; s->d = d; s->nbytes = nbytes;
+  s->bytes = malloc((size_t)nbytes + 1);
+  if (nbytes) memcpy(s->bytes, bytes, (size_t)nbytes);
+  s->bytes[nbytes] = 0;
+}
+const char* mock_static_calls(void) { return g_static_calls; }
+void mock_static_calls_clear(void) { g_static_calls[0] = 0; g_nsubs = 0; }
 int mock_exception_pending(void) { return g_exc_pending; }
 const char* mock_exception_class(void) { return g_exc_class; }
 const char* mock_exception_msg(void) { return g_exc_msg; }

@@ -138,3 +138,40 @@ def test_task_memory_manager_is_bound_and_released(jvm):
     h2 = jvm.create_plan([inp2.address], tpch.q6_plan().encode(), memory_manager=jvm.m.mock_plain_object())
     assert h2 > 0 and jvm.exception() is None and jvm.m.mock_live_global_refs() == 1
     jvm.release_plan(h2)
+
+
+def test_scalar_subqueries_are_asked_of_the_jvm_at_the_first_execute(jvm):
+    """Subquery{id, datatype} (expr.proto:513-516): CometScalarSubquery.isNull / get<Type>(planId, id) with createPlan's plan id (jni-bridge/src/comet_exec.rs:54-126),
+    on the first executePlan — not at createPlan (operators.scala registers the subqueries behind the iterator's construction).  No GPU here: the call sequence is
+    what is checked; the values' way into the kernels is tests/test_scalar_batch_gpu.py's."""
+    import struct
+    jvm.m.mock_static_calls_clear()
+    t = pa.table({"a": pa.array([1, 2, 3], pa.int64()), "s": pa.array(["x", "y", "z"])})
+    inp = native.HostInput.from_table(t)
+    D = S.decimal(10, 2)
+    plan = S.project(S.filter_(S.scan([S.T_INT64, S.T_STRING]), S.gt(S.col(0, S.T_INT64), S.subquery(5, S.T_INT64))),
+                     [S.subquery(6, S.T_DOUBLE), S.subquery(7, D), S.subquery(8, S.T_STRING), S.subquery(9, S.T_INT32), S.subquery(10, S.T_BOOL), S.subquery(11, S.T_DATE)])
+    jvm.m.mock_set_subquery(1, 5, 0, 2, 0.0, b"", 0)
+    jvm.m.mock_set_subquery(1, 6, 0, 0, 2.5, b"", 0)
+    jvm.m.mock_set_subquery(1, 7, 0, 0, 0.0, (12345).to_bytes(2, "big", signed=True), 2)
+    jvm.m.mock_set_subquery(1, 8, 0, 0, 0.0, "h\xc3\xa9".encode("latin-1"), 3)
+    jvm.m.mock_set_subquery(1, 9, 1, 0, 0.0, b"", 0)
+    jvm.m.mock_set_subquery(1, 10, 0, 1, 0.0, b"", 0)
+    jvm.m.mock_set_subquery(1, 11, 0, 19000, 0.0, b"", 0)
+    h = jvm.create_plan([inp.address], plan.encode())
+    assert h > 0 and jvm.exception() is None
+    assert jvm.m.mock_static_calls() == b""                 # nothing is asked at createPlan
+    arrays = [native.new_arrow_array() for _ in range(7)] if hasattr(native, "new_arrow_array") else None
+    jvm.execute_plan(h, [], [])                               # (fails behind the subqueries without a GPU, or on the column count with one: either way they were asked)
+    calls = jvm.m.mock_static_calls().decode()
+    assert calls == ("isNull(1,5);getLong(1,5);isNull(1,6);getDouble(1,6);isNull(1,7);getDecimal(1,7);isNull(1,8);getString(1,8);isNull(1,9);isNull(1,10);getBoolean(1,10);"
+                     "isNull(1,11);getInt(1,11);"), calls
+    jvm.m.mock_exception_clear()
+    jvm.release_plan(h)
+    # a subquery nobody registered: the mock answers isNull = true (like a JVM whose map has no entry would throw: here NULL) — and a plan whose subquery id the
+    # C ABI's table does not hold fails by name
+    t2 = pa.table({"a": pa.array([1], pa.int64())})
+    it = native.CometExecIterator([native.HostInput.from_table(t2)], 1, S.project(S.scan([S.T_INT64]), [S.subquery(3, S.T_INT64)]).encode())
+    with pytest.raises(native.CometNativeException, match="Subquery 3 is not registered"):
+        next(it)
+    it.close()

@@ -119,3 +119,32 @@ def test_refusals_and_errors(built):
     big = pa.table({"a": pa.array([5, 9_223_372_036_855], pa.int64()), "ts": t.column(1), "d": t.column(2)})
     with pytest.raises(Exception, match="long overflow"):
         _run(S.project(S.scan(types), [f("seconds_to_timestamp", [S.col(0, I64)], TS)]), big, 1)
+
+
+def test_scalar_subqueries(built):
+    """Subquery{id, datatype} (expr.proto:513-516; expressions/subquery.rs): the values registered for the plan (comet_plan_set_subquery here, CometScalarSubquery's
+    static methods under the JVM — tests/test_jni_shim_cpu.py) become literals of the kernels at the first executePlan; a second plan with other values must not
+    run the first one's kernels (the values are part of the plan's hash)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(37)
+    n = 20_000
+    DEC = S.decimal(12, 2)
+    t = pa.table({"a": pa.array(rng.integers(-50, 50, n), pa.int64(), mask=rng.random(n) < 0.05), "x": _doubles(n, 38), "s": pa.array(np.array(["ab", "cd", "a much longer string than 15 bytes"], dtype=object)[rng.integers(0, 3, n)]),
+                  "d": pa.array(rng.integers(18_000, 20_000, n), pa.int32()).cast(pa.date32())})
+    types = [I64, F64, STR, D]
+    a, x, s, d = S.col(0, I64), S.col(1, F64), S.col(2, STR), S.col(3, D)
+    plan = S.project(S.filter_(S.scan(types), S.gt(a, S.subquery(1, I64))),
+                     [S.math("add", a, S.subquery(2, I64), I64), S.math("multiply", x, S.subquery(3, F64), F64), S.subquery(4, DEC), S.eq(s, S.subquery(5, STR)), S.subquery(6, I32), S.lt(d, S.subquery(7, D)),
+                      S.and_(S.subquery(8, S.T_BOOL), S.is_not_null(a))])
+    for vals in ({1: 10, 2: 1000, 3: 0.5, 4: 123456, 5: "a much longer string than 15 bytes", 6: None, 7: 19_000, 8: True},
+                 {1: -20, 2: -1, 3: -3.0, 4: -99, 5: "cd", 6: 7, 7: 18_500, 8: False}):
+        tys = {1: I64, 2: I64, 3: F64, 4: DEC, 5: STR, 6: I32, 7: D, 8: S.T_BOOL}
+        O.SUBQUERIES = dict(vals)
+        try:
+            got = _run(plan, t, 7, subqueries={k: native.subquery_value(v, tys[k]) for k, v in vals.items()})
+            want = O.run_plan_to_arrow(S, plan, t)
+        finally:
+            O.SUBQUERIES = {}
+        assert got.num_rows == want.num_rows > 0
+        for i in range(7):
+            assert all((p == q) or (p != p and q != q) for p, q in zip(got.column(i).to_pylist(), want.column(i).to_pylist())), f"output {i}"

@@ -132,6 +132,7 @@ def probes():
         "Md5": (f("md5", [S.cast(s, S.DataType(S.BYTES))], S.T_STRING), "of a Utf8 column (under Cast AS BINARY too); derived column"), "Sha1": (f("sha1", [S.cast(s, S.DataType(S.BYTES))], S.T_STRING), ""),
         "Sha2": (f("sha2", [S.cast(s, S.DataType(S.BYTES)), L(256, S.T_INT32)], S.T_STRING), "224 / 256 / 0 / 384 / 512"), "Crc32": (f("crc32", [S.cast(s, S.DataType(S.BYTES))], S.T_INT64), ""),
         "StringInstr": (f("instr", [s, L("b", S.T_STRING)], S.T_INT32), "literal substring"), "Ascii": (f("ascii", [s], S.T_INT32), ""),
+        "ScalarSubquery": (S.subquery(1, S.T_INT64), "Subquery{id, datatype}: the value is asked of CometScalarSubquery's static methods (or comet_plan_set_subquery) at the first executePlan and becomes a literal of the kernels"),
         "StringSplit": (f("split", [s, L(",", S.T_STRING), L(-1, S.T_INT32)], S.list_type(S.T_STRING, False)),
                         "under spark.comet.expression.StringSplit.allowIncompatible: of a Utf8 COLUMN with a literal pattern and limit, computed over the chain's source and passed through / exploded; the matcher's pattern subset"),
         "UnixDate": (S.cast(d, S.T_INT32), "serialized as Cast(date AS int)"), "Days": (S.cast(d, S.T_INT32), "serialized as Cast(date AS int)"),
