@@ -12,7 +12,7 @@ tests() {          # the whole GPU suite
   timeout ${TESTS_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q --timeout ${TEST_TIMEOUT:-300} --timeout-method=thread > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log | cut -c1-200
 }
 tests_sel() {      # tests matched by $SEL (a -k expression) or the files in $FILES
-  timeout ${TSEL_TIMEOUT:-900} python -m pytest ${FILES:-tests} -m gpu ${NOX:+--maxfail=5} ${NOX:--x} -q --timeout ${TEST_TIMEOUT:-120} --timeout-method=thread ${SEL:+-k "$SEL"} > $OUT/pytest_sel.log 2>&1; tail -15 $OUT/pytest_sel.log | cut -c1-220
+  timeout ${TSEL_TIMEOUT:-900} python -m pytest ${FILES:-tests} -m gpu $([ -n "$NOX" ] && echo --maxfail=5 || echo -x) -q --timeout ${TEST_TIMEOUT:-120} --timeout-method=thread ${SEL:+-k "$SEL"} > $OUT/pytest_sel.log 2>&1; tail -15 $OUT/pytest_sel.log | cut -c1-220
 }
 tests_forced() {   # the Parquet files of the GPU suite with every scan treated as a few-thread task (device-inflated dictionary pages, device-walked run headers, reading task thread)
   COMET_PQ_FEW_THREADS=100000 timeout ${TSEL_TIMEOUT:-900} python -m pytest tests/test_parquet_gpu.py tests/test_parquet_fixtures_gpu.py tests/test_parquet_fuzz_gpu.py tests/test_parquet_page_index_gpu.py tests/test_device_zstd_gpu.py tests/test_device_snappy_gpu.py -m gpu -x -q --timeout ${TEST_TIMEOUT:-120} --timeout-method=thread > $OUT/pytest_forced.log 2>&1; tail -15 $OUT/pytest_forced.log | cut -c1-220
