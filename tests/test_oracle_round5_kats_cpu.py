@@ -91,3 +91,16 @@ def test_pow_and_log():
         t = pa.table({"b": pa.array([c["base"]], pa.float64()), "v": pa.array([c["value"]], pa.float64())})
         got = _eval(S.scalar_func("spark_log", [S.col(0, F64), S.col(1, F64)], F64), [F64, F64], t)[0]
         assert got == c["expected"] or (got is not None and abs(got - c["expected"]) < 1e-12), c
+
+
+def test_size_and_list_extract():
+    k = K["lists"]
+    LI = S.list_type(I32, True)
+    for c in k["size"]:
+        t = pa.table({"l": pa.array(c["lists"], pa.list_(pa.int32()))})
+        assert _eval(S.scalar_func("size", [S.col(0, LI)], I32), [LI], t) == c["expected"], c
+    for c in k["list_extract"]:
+        t = pa.table({"l": pa.array(c["lists"], pa.list_(pa.int32()))})
+        assert _eval(S.list_extract(S.col(0, LI), S.lit(c["index"], I32), one_based=c["one_based"]), [LI], t) == c["expected"], c
+    with pytest.raises(O.OracleError, match="INVALID_INDEX_OF_ZERO"):
+        _eval(S.list_extract(S.col(0, LI), S.lit(0, I32), one_based=True), [LI], pa.table({"l": pa.array([[1]], pa.list_(pa.int32()))}))
