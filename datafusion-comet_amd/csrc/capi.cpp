@@ -12,6 +12,15 @@
 #include "shuffle_format.hpp"
 #include "parquet_meta.hpp"
 #include "regex.hpp"
+// (jit.cpp: the header texts hiprtc compiles against)
+namespace comet {
+extern const char* const kEmbeddedDeviceHeader;
+extern const char* const kEmbeddedKParamsHeader;
+extern const char* const kEmbeddedRyuHeader;
+extern const char* const kEmbeddedStrtodHeader;
+extern const char* const kEmbeddedStrtsHeader;
+extern const char* const kEmbeddedRegexVmHeader;
+}
 // (device/strfn.hpp, as the host sees it: comet_strfn_host below)
 namespace comet_strfn_host_ns {
 #include "device/strfn.hpp"
@@ -464,6 +473,64 @@ int32_t comet_compile_plan(const uint8_t* plan, size_t plan_len, char* out, size
       out[n] = 0;
     }
     return 0;
+  });
+}
+
+static std::string json_str(const std::string& s) {
+  std::string o = "\"";
+  for (unsigned char ch : s) {
+    if (ch == '"' || ch == '\\') { o += '\\'; o += (char)ch; }
+    else if (ch == '\n') o += "\\n";
+    else if (ch == '\t') o += "\\t";
+    else if (ch == '\r') o += "\\r";
+    else if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); o += b; }
+    else o += (char)ch;
+  }
+  return o + "\"";
+}
+int64_t comet_plan_codegen(const uint8_t* plan, size_t plan_len, const uint8_t* has_valid, int32_t n_valid, char* out, int64_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    OperatorP op = decode_operator(plan, plan_len);
+    const Operator* leaf = op.get();
+    while (!leaf->children.empty()) leaf = leaf->children[0].get();
+    if (leaf->kind != OpKind::Scan) throw CometError("comet_plan_codegen: a Filter / Projection / HashAggregate chain over ONE Scan leaf is expected");
+    std::vector<bool> hv(leaf->scan_fields.size(), false);
+    for (int32_t k = 0; k < n_valid && (size_t)k < hv.size(); k++) hv[(size_t)k] = has_valid && has_valid[k] != 0;
+    PipelineDesc d = generate_pipeline(*op, hv);
+    std::string j = "{\"sink\":" + std::to_string((int)d.sink) + ",\"has_filter\":" + (d.has_filter ? "true" : "false") + ",\"R\":" + std::to_string(d.R) + ",\"derived\":" + std::to_string(d.derived.size()) +
+                    ",\"kernels\":[";
+    for (size_t k = 0; k < d.kernels.size(); k++) j += (k ? "," : "") + json_str(d.kernels[k]);
+    j += "],\"out\":[";
+    for (size_t k = 0; k < d.out_cols.size(); k++) {
+      const OutCol& oc = d.out_cols[k];
+      j += std::string(k ? "," : "") + "{\"type\":" + std::to_string((int)oc.type.id) + ",\"precision\":" + std::to_string(oc.type.precision) + ",\"scale\":" + std::to_string(oc.type.scale) +
+           ",\"nullable\":" + (oc.nullable ? "true" : "false") + ",\"gather_src\":" + std::to_string(oc.gather_src) + ",\"view_src\":" + std::to_string(oc.view_src) + ",\"fmt_kind\":" +
+           std::to_string(oc.fmt_kind) + ",\"packed_string\":" + (oc.packed_string ? "true" : "false") + ",\"concat\":" + std::to_string(oc.concat_cols.size()) + ",\"case_mode\":" +
+           std::to_string(oc.case_mode) + ",\"pad\":" + json_str(oc.pad_pattern) + ",\"pad_left\":" + (oc.pad_left ? "true" : "false") + "}";
+    }
+    j += "],\"source\":" + json_str(d.source) + "}";
+    if (out && cap > (int64_t)j.size()) memcpy(out, j.c_str(), j.size() + 1);
+    return (int64_t)j.size();
+  });
+}
+int64_t comet_error_site_json(uint32_t site_id, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail, char* out, int64_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    ErrSite site;
+    if (!lookup_err_site(site_id, site)) throw CometError("no raise site with id " + std::to_string(site_id) + " is registered in this process");
+    const std::string j = err_site_json(site, lo, hi, str, str_avail < 0 ? 0 : (size_t)str_avail, nullptr);
+    if (out && cap > (int64_t)j.size()) memcpy(out, j.c_str(), j.size() + 1);
+    return (int64_t)j.size();
+  });
+}
+int64_t comet_embedded_header(const char* name, char* out, int64_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    const std::string n = name ? name : "";
+    const char* t = n == "comet_device.hpp" ? kEmbeddedDeviceHeader : n == "kparams.h" ? kEmbeddedKParamsHeader : n == "comet_ryu.hpp" ? kEmbeddedRyuHeader : n == "comet_strtod.hpp" ? kEmbeddedStrtodHeader
+                    : n == "comet_strts.hpp" ? kEmbeddedStrtsHeader : n == "comet_regex_vm.hpp" ? kEmbeddedRegexVmHeader : nullptr;
+    if (!t) throw CometError("no embedded header named '" + n + "'");
+    const int64_t len = (int64_t)strlen(t);
+    if (out && cap > len) memcpy(out, t, (size_t)len + 1);
+    return len;
   });
 }
 

@@ -153,6 +153,12 @@ def _load() -> ctypes.CDLL:
     lib.comet_extract_all_host.argtypes = [c.c_char_p, c.c_int32, c.c_char_p, c.c_size_t, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.c_int32]
     lib.comet_strfn_host.restype = c.c_int64
     lib.comet_strfn_host.argtypes = [c.c_int32, c.c_char_p, c.c_int32, c.c_char_p, c.c_int32, c.c_char_p, c.c_int32, c.c_int64, c.c_void_p, c.c_int64]
+    lib.comet_plan_codegen.restype = c.c_int64
+    lib.comet_plan_codegen.argtypes = [c.c_char_p, c.c_size_t, c.c_char_p, c.c_int32, c.c_void_p, c.c_int64]
+    lib.comet_error_site_json.restype = c.c_int64
+    lib.comet_error_site_json.argtypes = [c.c_uint32, c.c_uint64, c.c_uint64, c.c_char_p, c.c_int64, c.c_void_p, c.c_int64]
+    lib.comet_embedded_header.restype = c.c_int64
+    lib.comet_embedded_header.argtypes = [c.c_char_p, c.c_void_p, c.c_int64]
     lib.comet_plan_set_subquery.restype = c.c_int32
     lib.comet_plan_set_subquery.argtypes = [c.c_int64, c.c_int64, c.c_int32, c.c_char_p, c.c_size_t]
     lib.comet_split_host.restype = c.c_int32
@@ -1225,6 +1231,35 @@ def strfn_host(op: int, value: bytes, a: bytes = b"", b: bytes = b"", k: int = 0
     buf = ctypes.create_string_buffer(max(n, 1))
     lib().comet_strfn_host(op, value, len(value), a, len(a), b, len(b), k, buf, n)
     return buf.raw[:n]
+
+
+def plan_codegen(plan: bytes, has_valid: Sequence[bool]) -> dict:
+    """the generated HIP source of a chain over one Scan leaf and its output descriptors (comet_plan_codegen)"""
+    import json
+    hv = bytes(1 if v else 0 for v in has_valid)
+    n = lib().comet_plan_codegen(plan, len(plan), hv, len(hv), None, 0)
+    if n < 0:
+        _raise_last(0)
+    buf = ctypes.create_string_buffer(n + 1)
+    lib().comet_plan_codegen(plan, len(plan), hv, len(hv), buf, n + 1)
+    return json.loads(buf.value.decode())
+
+
+def error_site_json(site_id: int, lo: int, hi: int, text: bytes = b"") -> str:
+    buf = ctypes.create_string_buffer(1 << 14)
+    n = lib().comet_error_site_json(site_id, lo, hi, text, len(text), buf, len(buf))
+    if n < 0:
+        _raise_last(0)
+    return buf.value.decode()
+
+
+def embedded_header(name: str) -> str:
+    n = lib().comet_embedded_header(name.encode(), None, 0)
+    if n < 0:
+        _raise_last(0)
+    buf = ctypes.create_string_buffer(n + 1)
+    lib().comet_embedded_header(name.encode(), buf, n + 1)
+    return buf.value.decode()
 
 
 def subquery_value(v, dtype) -> Optional[bytes]:

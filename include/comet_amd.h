@@ -202,6 +202,18 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
  * comet_last_error(0) for a pattern outside the subset or a group index out of range (the reference's message).  Needs no GPU. */
 int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* start, int32_t* len);
 
+/* ---- what the generator writes — diagnostic entries (tests/emu: the generated per-row code compiled and run on the HOST against the oracle) --------------------
+ * comet_plan_codegen: the HIP source generated for a Filter / Projection / HashAggregate chain over one Scan leaf (has_valid[k]: column k arrives with a validity
+ * bitmap) and what the executor needs to read its outputs, as JSON {"sink", "has_filter", "R", "kernels": [...], "out": [{"type", "precision", "scale", "nullable",
+ * "gather_src", "view_src", "fmt_kind", "packed_string", "concat", "case_mode", "pad", "pad_left"}], "source"}: the length, the text written when it fits `cap`.
+ * comet_embedded_header: the text of a header hiprtc compiles that source against ("comet_device.hpp", "kparams.h", "comet_ryu.hpp", "comet_strtod.hpp",
+ * "comet_strts.hpp", "comet_regex_vm.hpp").  -2 and comet_last_error(0) on failure.  Neither needs a GPU. */
+int64_t comet_plan_codegen(const uint8_t* plan, size_t plan_len, const uint8_t* has_valid, int32_t n_valid, char* out, int64_t cap);
+int64_t comet_embedded_header(const char* name, char* out, int64_t cap);
+/* the Spark error JSON of a raise site of a pipeline generated in this process (the site id a kernel leaves in the error block's detail words, kparams.h) and the
+ * detail it left: what check_device_errors throws, without the SQL context */
+int64_t comet_error_site_json(uint32_t site_id, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail, char* out, int64_t cap);
+
 /* ---- scalar subqueries (expr.proto:513-516 Subquery{id, datatype}; native/core/src/execution/expressions/subquery.rs:72-180) ------------------------------
  * The reference asks the JVM for a subquery's value when the expression is first evaluated: CometScalarSubquery.isNull / getBoolean / getByte / getShort / getInt /
  * getLong / getFloat / getDouble / getDecimal / getString / getBinary (planId, id) (jni-bridge/src/comet_exec.rs:54-126).  Here every Subquery of a plan becomes a

@@ -1,0 +1,256 @@
+"""TEST INFRASTRUCTURE: run the per-row code the generator writes for a Filter / Projection chain — and every device helper it calls — on the HOST.
+
+comet_plan_codegen hands out the HIP source of a plan; it is compiled with g++ against the very header texts hiprtc uses (comet_embedded_header), made host-
+compilable by tests/emu/hip_host_shim.hpp (qualifiers and intrinsics as no-ops / one-lane stand-ins) and two textual patches (the address-space qualifiers).
+The kernel BODIES are not emulated — ballots, LDS tables and the ordered compaction only have to compile; the driver below walks the rows itself: keep_tile for
+every thread slot of a tile, positions in row order (what the device's single-pass compaction produces), emit_tile.  The executor's part behind the kernel
+(gathering Utf8 values by row index, assembling string views) is done here in Python for the output kinds that need it; kinds the emulator does not know
+raise Unsupported.  Nothing under datafusion-comet_amd/ imports this; it is the CPU suite's way to check generated code against the oracle without a GPU."""
+import ctypes
+import hashlib
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pyarrow as pa
+
+from datafusion_comet_amd import native, serde as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_DIR = None
+_CACHE = {}
+
+
+class Unsupported(Exception):
+    pass
+
+
+DRIVER = r"""
+template <class P>
+static long long emu_impl(const CometKParams* prm_in) {
+  CometKParams prm = *prm_in;
+  const i64 n = prm.n;
+  if constexpr (requires { P::keep_tile(prm, (i64)0, n, (bool*)nullptr); }) {
+    constexpr int R = P::R;
+    constexpr i64 kRows = (i64)R * comet::kBlock;
+    i64 total = 0;
+    static bool keep[R * 256];
+    static i64 posn[R * 256];
+    for (i64 base = 0; base < n; base += kRows) {
+      for (unsigned t = 0; t < 256; t++) {
+        threadIdx.x = t;
+        bool k[R];
+        P::keep_tile(prm, base, n, k);
+        for (int r = 0; r < R; r++) keep[r * 256 + t] = k[r];
+      }
+      for (int s = 0; s < R * 256; s++) { posn[s] = total; total += keep[s] ? 1 : 0; }      // slot order (r, t) IS row order
+      for (unsigned t = 0; t < 256; t++) {
+        threadIdx.x = t;
+        bool k[R];
+        i64 idx[R], pos[R];
+        for (int r = 0; r < R; r++) { k[r] = keep[r * 256 + t]; idx[r] = base + (i64)r * 256 + t; pos[r] = posn[r * 256 + t]; }
+        P::emit_tile(prm, k, idx, pos);
+      }
+    }
+    return total;
+  } else {
+    threadIdx.x = 0;
+    for (i64 i = 0; i < n; i++) P::emit(prm, i, i);
+    return n;
+  }
+}
+// (every plan's library defines a struct P, its statics and emu_run: hidden visibility, no unique symbols, symbolic binding keep each library to itself)
+extern "C" __attribute__((visibility("default"))) long long emu_run(const CometKParams* prm_in) { return emu_impl<P>(prm_in); }
+"""
+
+
+def _workdir():
+    global _DIR
+    if _DIR is None:
+        _DIR = tempfile.mkdtemp(prefix="comet_emu_")
+        dev = native.embedded_header("comet_device.hpp")
+        dev = re.sub(r"#define COMET_GLOBAL [^\n]*", "#define COMET_GLOBAL", dev)
+        dev = re.sub(r"#define COMET_LDS [^\n]*", "#define COMET_LDS", dev)
+        dev = dev.replace("template <> struct as_i64<COMET_LDS u64*> { typedef COMET_LDS i64* type; };", "")
+        open(os.path.join(_DIR, "comet_device.hpp"), "w").write(dev)
+        for name in ("kparams.h", "comet_ryu.hpp", "comet_strtod.hpp", "comet_strts.hpp", "comet_regex_vm.hpp"):
+            open(os.path.join(_DIR, name), "w").write(native.embedded_header(name))
+    return _DIR
+
+
+def _compiled(source: str):
+    key = hashlib.sha1(source.encode()).hexdigest()[:20]
+    if key not in _CACHE:
+        d = _workdir()
+        cpp = os.path.join(d, key + ".cpp")
+        open(cpp, "w").write('#include "hip_host_shim.hpp"\n' + source + DRIVER)
+        so = os.path.join(d, key + ".so")
+        r = subprocess.run(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-fvisibility=hidden", "-fno-gnu-unique", "-Wl,-Bsymbolic", "-I", HERE, "-I", d, "-x", "c++", cpp, "-o", so], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("the generated source does not compile for the host:\n" + "\n".join(l for l in r.stderr.splitlines() if "error" in l)[:3000])
+        lib = ctypes.CDLL(so)
+        lib.emu_run.restype = ctypes.c_longlong
+        lib.emu_run.argtypes = [ctypes.c_void_p]
+        _CACHE[key] = lib
+    return _CACHE[key]
+
+
+class _Col(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("valid", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("offset", ctypes.c_longlong)]
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_longlong), ("iarg", ctypes.c_longlong * 7), ("inp", _Col * 24), ("out", ctypes.c_void_p * 48)]
+
+
+_NP = {S.BOOL: np.uint8, S.INT8: np.int8, S.INT16: np.int16, S.INT32: np.int32, S.DATE: np.int32, S.INT64: np.int64, S.TIMESTAMP: np.int64, S.TIMESTAMP_NTZ: np.int64, S.FLOAT: np.float32,
+       S.DOUBLE: np.float64}
+_PA = {S.BOOL: pa.bool_(), S.INT8: pa.int8(), S.INT16: pa.int16(), S.INT32: pa.int32(), S.DATE: pa.date32(), S.INT64: pa.int64(), S.TIMESTAMP: pa.timestamp("us", tz="UTC"),
+       S.TIMESTAMP_NTZ: pa.timestamp("us"), S.FLOAT: pa.float32(), S.DOUBLE: pa.float64()}
+
+
+def _addr(buf):
+    return buf.address if buf is not None else None
+
+
+def run_chain(plan, table: pa.Table) -> pa.Table:
+    """Evaluate a Filter / Projection chain over ONE Scan leaf on the host, through the generated code.  Output kinds beyond fixed-width values, gathered Utf8
+    columns and plain string views raise Unsupported."""
+    cols = [table.column(i).combine_chunks() if isinstance(table.column(i), pa.ChunkedArray) else table.column(i) for i in range(table.num_columns)]
+    has_valid = [c.null_count > 0 for c in cols]
+    desc = native.plan_codegen(plan if isinstance(plan, (bytes, bytearray)) else plan.encode(), has_valid)
+    if desc["sink"] != 0:
+        raise Unsupported("aggregate sinks are not emulated")
+    if desc["derived"]:
+        raise Unsupported("derived columns are computed by the executor's own kernels")
+    lib = _compiled(desc["source"])
+    n = table.num_rows
+    prm = _Params()
+    prm.n = n
+    keep = []
+    for i, c in enumerate(cols):
+        bufs = c.buffers()
+        t = c.type
+        prm.inp[i].offset = c.offset
+        prm.inp[i].valid = _addr(bufs[0]) if has_valid[i] else None
+        if pa.types.is_string(t) or pa.types.is_binary(t):
+            prm.inp[i].data = _addr(bufs[1])
+            prm.inp[i].aux = _addr(bufs[2]) if bufs[2] is not None else ctypes.addressof(ctypes.create_string_buffer(1))
+        elif pa.types.is_nested(t) or pa.types.is_dictionary(t):
+            raise Unsupported("nested / dictionary inputs")
+        else:
+            prm.inp[i].data = _addr(bufs[1])
+        keep.append(bufs)
+    errbuf = np.zeros(512, np.uint8)
+    scratch0, scratch1 = np.zeros(8 * (n // 2048 + 4), np.uint8), np.zeros(64, np.uint8)
+    prm.out[0], prm.out[1], prm.out[2] = scratch0.ctypes.data, scratch1.ctypes.data, errbuf.ctypes.data
+    outs = []
+    for j, oc in enumerate(desc["out"]):
+        width = 16 if (oc["view_src"] >= 0 or oc["fmt_kind"] or oc["type"] == S.DECIMAL or oc["packed_string"]) else 4 if (oc["gather_src"] >= 0 or oc["concat"]) else np.dtype(_NP[oc["type"]]).itemsize
+        vals = np.zeros((n + 1) * width + 16, np.uint8)
+        ok = np.ones(n + 16, np.uint8)
+        prm.out[4 + 2 * j] = vals.ctypes.data
+        prm.out[5 + 2 * j] = ok.ctypes.data
+        outs.append((vals, ok, width))
+    rows = lib.emu_run(ctypes.byref(prm))
+    flags = int(errbuf[:4].view(np.uint32)[0])
+    if flags:
+        _raise_like_the_executor(flags, errbuf)
+    arrays = []
+    for (vals, ok, width), oc in zip(outs, desc["out"]):
+        mask = None if not oc["nullable"] else (ok[:rows] == 0)
+        if mask is not None and not mask.any():
+            mask = None
+        if oc["fmt_kind"] or oc["concat"] or oc["packed_string"] or oc["case_mode"] or oc["pad"]:
+            raise Unsupported("output columns the executor formats / concatenates / case-maps / pads")
+        if oc["gather_src"] >= 0:
+            src = cols[oc["gather_src"]].to_pylist()
+            idx = vals[:rows * 4].view(np.uint32)
+            arrays.append(pa.array([None if (mask is not None and mask[r]) else src[idx[r]] for r in range(rows)], cols[oc["gather_src"]].type))
+        elif oc["view_src"] >= 0:
+            src = [None if v is None else v.encode() for v in cols[oc["view_src"]].to_pylist()]
+            v = vals[:rows * 16].view(np.uint32).reshape(-1, 4)      # strview {row, start, len, pad}
+            arrays.append(pa.array([None if (mask is not None and mask[r]) else src[v[r, 0]][v[r, 1]:v[r, 1] + v[r, 2]].decode() for r in range(rows)], pa.utf8()))
+        elif oc["type"] == S.DECIMAL:
+            raw = vals[:rows * 16].tobytes()
+            vb = None if mask is None else pa.py_buffer(np.packbits(~mask, bitorder="little").tobytes())
+            arrays.append(pa.Array.from_buffers(pa.decimal128(oc["precision"], oc["scale"]), rows, [vb, pa.py_buffer(raw)], null_count=0 if mask is None else int(mask.sum())))
+        elif oc["type"] == S.BOOL:
+            arrays.append(pa.array(vals[:rows].astype(bool), pa.bool_(), mask=mask))
+        else:
+            x = vals[:rows * width].view(_NP[oc["type"]])
+            base = {S.DATE: pa.int32(), S.TIMESTAMP: pa.int64(), S.TIMESTAMP_NTZ: pa.int64()}.get(oc["type"])
+            a = pa.array(x, base or _PA[oc["type"]], mask=mask)
+            arrays.append(a.cast(_PA[oc["type"]]) if base else a)
+    return pa.table(arrays, names=[f"col_{i}" for i in range(len(arrays))])
+
+
+_FLAG_JSON = [(1, '{"errorType":"ArithmeticOverflow","errorClass":"ARITHMETIC_OVERFLOW","params":{"fromType":"decimal"}}'),
+              (2, '{"errorType":"ArithmeticOverflow","errorClass":"ARITHMETIC_OVERFLOW","params":{"fromType":"integer"}}'), (4, '{"errorType":"CastOverFlow","errorClass":"CAST_OVERFLOW","params":{}}'),
+              (8, '{"errorType":"NumericValueOutOfRange","errorClass":"NUMERIC_VALUE_OUT_OF_RANGE.WITH_SUGGESTION","params":{}}'),
+              (512, '{"errorType":"CastInvalidValue","errorClass":"CAST_INVALID_INPUT","params":{"fromType":"STRING"}}'),
+              (1024, '{"errorType":"InvalidInputInCastToDatetime","errorClass":"CAST_INVALID_INPUT","params":{"fromType":"STRING","toType":"DATE"}}'),
+              (8192, '{"errorType":"InvalidInputInCastToDatetime","errorClass":"CAST_INVALID_INPUT","params":{"fromType":"STRING","toType":"TIMESTAMP"}}'),
+              (16384, '{"errorType":"InvalidInputInCastToDatetime","errorClass":"CAST_INVALID_INPUT","params":{"fromType":"STRING","toType":"TIMESTAMP_NTZ"}}'),
+              (256, '{"errorType":"DivideByZero","errorClass":"DIVIDE_BY_ZERO","params":{}}'), (32768, '{"errorType":"RemainderByZero","errorClass":"REMAINDER_BY_ZERO","params":{}}')]
+
+
+def _raise_like_the_executor(flags, block):
+    """exec_pipeline.cpp check_device_errors, for the flags a Filter / Projection chain can raise: the site's JSON when a site left its detail, else the flag's"""
+    detail = block[192:].view(np.uint64)
+    if detail[0] != 0:
+        raise native.CometQueryExecutionException(native.error_site_json(int(detail[0]) - 1, int(detail[1]), int(detail[2]), bytes(block[192 + 32:192 + 32 + 224])))
+    for bit, js in _FLAG_JSON:
+        if flags & bit:
+            raise native.CometQueryExecutionException(js)
+    if flags & 262144:
+        raise native.CometNativeException("Arrow error: Compute error: long overflow")
+    if flags & 4096:
+        raise native.CometNativeException("a string cast to a timestamp names a time zone inside the value, or holds a time of day without a date (which takes the current date): not supported by the MI355X native engine")
+    if flags & 2048:
+        raise native.CometNativeException("a timestamp lies behind the end of its time zone's table (the year 2400): not supported by the MI355X native engine")
+    raise DeviceError(flags, block)
+
+
+class DeviceError(Exception):
+    """the generated code raised an error flag (what check_device_errors turns into a Spark error on the device path)"""
+
+    def __init__(self, flags, block):
+        super().__init__("device error flags %d" % flags)
+        self.flags = flags
+        self.block = block
+
+
+class _HostInput:
+    def __init__(self, table):
+        self.table = table
+
+    @staticmethod
+    def from_table(table, batch_rows=8192):
+        return _HostInput(table)
+
+
+def run_gpu_test_on_host(module: str, fn: str, **params):
+    """Run a GPU parity test's Python with the EMULATOR standing in for the device: the plan's generated code, compiled for the host, evaluates the rows; what the
+    test compares it with (the oracle) is untouched.  → "ok", or raises (Unsupported: the plan needs something the emulator does not do)."""
+    import importlib
+    mod = importlib.import_module(module)
+    saved = (native.HostInput, native.execute_to_table)
+
+    def execute(inputs, ncols, plan_bytes, **kw):
+        if kw.get("subqueries"):
+            raise Unsupported("scalar subqueries are resolved by the executor")
+        if len(inputs) != 1:
+            raise Unsupported("plans with several inputs")
+        out = run_chain(plan_bytes, inputs[0].table)
+        assert out.num_columns == ncols, (out.num_columns, ncols)
+        return out.to_batches() if out.num_rows else []
+
+    native.HostInput, native.execute_to_table = _HostInput, execute
+    try:
+        getattr(mod, fn)(None, **params)
+    finally:
+        native.HostInput, native.execute_to_table = saved
+    return "ok"

@@ -1,0 +1,53 @@
+"""The GENERATED code on the host: GPU parity tests of Filter / Projection plans run here with tests/emu/codegen_emu.py standing in for the device — the source
+the generator writes for the plan (comet_plan_codegen), compiled by g++ against the header texts hiprtc uses, evaluates every row; the test's own comparison
+with the oracle, its expected errors (the executor's JSON, rebuilt from the error block the code leaves) and its refusals are the test's.  What is NOT covered
+this way: the kernel bodies (ballots, LDS, ordered compaction), the executor behind the kernel (formatting casts to string, concat, case mapping, padding,
+derived columns, subquery resolution), aggregates and joins — those remain the GPU suite's.  What is: every expression's lowering, the common-subexpression
+logic (the time-zone bug of round 5 fails here), the device helpers (decimals, casts, dates, time zones, the regex matcher, string parsers) — without a GPU."""
+import pytest
+
+from tests.emu import codegen_emu as E
+
+PLAIN = {
+    "tests.test_filter_project_gpu": ["test_bitwise_and_shifts", "test_decimal_division", "test_decimal_projection_narrow_and_wide", "test_empty_input_gives_empty_output",
+                                      "test_filter_keeps_only_true_and_valid", "test_integral_divide", "test_more_casts", "test_murmur3_hash_expression",
+                                      "test_projection_only_int_wrapping_and_float", "test_reference_planner_case_col_eq_3", "test_remainder_decimal", "test_remainder_int_and_float",
+                                      "test_round_and_date_arithmetic", "test_the_references_modulo_vectors", "test_try_casts_to_integers", "test_unary_minus"],
+    "tests.test_string_casts_gpu": ["test_ansi_raises_where_the_reference_raises", "test_parsed_values_feed_filters_and_arithmetic", "test_strings_to_floats",
+                                    "test_timestamp_strings_under_ansi_and_the_refusals", "test_unknown_time_zones_are_refused_by_name"],
+    "tests.test_scalar_batch_gpu": ["test_dates", "test_float64_functions", "test_integers_and_bits", "test_refusals_and_errors", "test_timestamps"],
+    "tests.test_regexp_extract_gpu": ["test_below_a_filter_with_nulls_and_no_rows", "test_errors_of_the_reference_and_refusals", "test_groups_classes_and_preferences",
+                                      "test_null_pattern_or_index_is_null_everywhere", "test_the_references_vectors"],
+    "tests.test_temporal_casts_gpu": ["test_cast_date_as_int", "test_floats_and_decimals_to_timestamps", "test_the_references_date_to_timestamp_vectors"],
+    "tests.test_rlike_gpu": ["test_unsupported_patterns_fail_at_create_plan"],
+}
+PARAMS = [("tests.test_string_casts_gpu", "test_string_to_values", dict(mode=0)),
+          ("tests.test_string_casts_gpu", "test_string_to_values", dict(mode=1)), ("tests.test_string_casts_gpu", "test_strings_to_timestamps", dict(tz="America/New_York")),
+          ("tests.test_string_casts_gpu", "test_strings_to_timestamps", dict(tz="+05:30")),
+          ("tests.test_rlike_gpu", "test_projection_and_filter_match_the_oracle", dict(pattern="\\bRose\\b")), ("tests.test_rlike_gpu", "test_projection_and_filter_match_the_oracle", dict(pattern="^[\\w#]+\\d{9}$"))] + \
+         [("tests.test_fuzz_gpu", "test_random_filter_project", dict(seed=s)) for s in (0, 1, 2, 3, 4, 5, 6, 7)]
+
+
+@pytest.mark.parametrize("module,fn", [(m, f) for m, fs in PLAIN.items() for f in fs])
+def test_gpu_parity_test_on_the_host(built, module, fn):
+    assert E.run_gpu_test_on_host(module, fn) == "ok"
+
+
+@pytest.mark.parametrize("module,fn,params", PARAMS, ids=[f"{f}-{list(p.values())[0]}" for _, f, p in PARAMS])
+def test_parametrized_gpu_parity_test_on_the_host(built, module, fn, params):
+    assert E.run_gpu_test_on_host(module, fn, **params) == "ok"
+
+
+def test_one_child_in_several_zones_is_several_values(built):
+    """round 5's generator bug (found on the GPU, r2): the common-subexpression key left the time zone out — this is the plan that showed it"""
+    import numpy as np
+    import pyarrow as pa
+    from datafusion_comet_amd import serde as S
+    from oracle import oracle as O
+    t = pa.table({"d": pa.array(np.arange(-40_000, 40_000, 7, dtype=np.int32)).cast(pa.date32())})
+    d = S.col(0, S.T_DATE)
+    plan = S.project(S.scan([S.T_DATE]), [S.unix_timestamp(d), S.unix_timestamp(d, "America/Los_Angeles"), S.unix_timestamp(d, "+05:30")])
+    got, want = E.run_chain(plan, t), O.run_plan_to_arrow(S, plan, t)
+    for i in range(3):
+        assert got.column(i).to_pylist() == want.column(i).to_pylist(), i
+    assert got.column(0).to_pylist() != got.column(1).to_pylist()
