@@ -12,6 +12,9 @@
 #include "shuffle_format.hpp"
 #include "parquet_meta.hpp"
 #include "regex.hpp"
+namespace comet {
+std::vector<DType> extend_struct_field_types(const std::vector<DType>& types);      // exec.cpp
+}
 // (jit.cpp: the header texts hiprtc compiles against)
 namespace comet {
 extern const char* const kEmbeddedDeviceHeader;
@@ -494,9 +497,13 @@ int64_t comet_plan_codegen(const uint8_t* plan, size_t plan_len, const uint8_t* 
     const Operator* leaf = op.get();
     while (!leaf->children.empty()) leaf = leaf->children[0].get();
     if (leaf->kind != OpKind::Scan) throw CometError("comet_plan_codegen: a Filter / Projection / HashAggregate chain over ONE Scan leaf is expected");
-    std::vector<bool> hv(leaf->scan_fields.size(), false);
+    // (a source with struct / list columns: the chain sees their fields and elements as columns behind the real ones, like over a materialised source)
+    bool nested = false;
+    for (auto& t : leaf->scan_fields) nested = nested || t.is_nested();
+    const std::vector<DType> types = nested ? extend_struct_field_types(leaf->scan_fields) : leaf->scan_fields;
+    std::vector<bool> hv(types.size(), false);
     for (int32_t k = 0; k < n_valid && (size_t)k < hv.size(); k++) hv[(size_t)k] = has_valid && has_valid[k] != 0;
-    PipelineDesc d = generate_pipeline(*op, hv);
+    PipelineDesc d = nested ? generate_pipeline(*op, hv, &types) : generate_pipeline(*op, hv);
     std::string j = "{\"sink\":" + std::to_string((int)d.sink) + ",\"has_filter\":" + (d.has_filter ? "true" : "false") + ",\"R\":" + std::to_string(d.R) + ",\"derived\":" + std::to_string(d.derived.size()) +
                     ",\"kernels\":[";
     for (size_t k = 0; k < d.kernels.size(); k++) j += (k ? "," : "") + json_str(d.kernels[k]);

@@ -15,6 +15,7 @@ import tempfile
 
 import numpy as np
 import pyarrow as pa
+import pyarrow.compute
 
 from datafusion_comet_amd import native, serde as S
 
@@ -119,7 +120,20 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
     """Evaluate a Filter / Projection chain over ONE Scan leaf on the host, through the generated code.  Output kinds beyond fixed-width values, gathered Utf8
     columns and plain string views raise Unsupported."""
     cols = [table.column(i).combine_chunks() if isinstance(table.column(i), pa.ChunkedArray) else table.column(i) for i in range(table.num_columns)]
-    has_valid = [c.null_count > 0 for c in cols]
+    # struct fields and the elements of lists of flat values are columns of their own behind the real ones (exec.cpp extend_struct_fields); a field is NULL where
+    # its struct is (what the executor's import makes of pyarrow's layout)
+    virt = []
+    for c in cols:
+        if pa.types.is_list(c.type) and not pa.types.is_nested(c.type.value_type):
+            virt.append(c.values)
+        elif pa.types.is_struct(c.type):
+            for k in range(c.type.num_fields):
+                f = c.field(k)
+                if c.null_count:
+                    f = pa.compute.if_else(c.is_valid(), f, pa.scalar(None, f.type))
+                virt.append(f)
+    bound = cols + virt
+    has_valid = [c.null_count > 0 for c in bound]
     desc = native.plan_codegen(plan if isinstance(plan, (bytes, bytearray)) else plan.encode(), has_valid)
     if desc["sink"] != 0:
         raise Unsupported("aggregate sinks are not emulated")
@@ -130,7 +144,9 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
     prm = _Params()
     prm.n = n
     keep = []
-    for i, c in enumerate(cols):
+    if len(bound) > 24:
+        raise Unsupported("more than COMET_MAX_IN columns")
+    for i, c in enumerate(bound):
         bufs = c.buffers()
         t = c.type
         prm.inp[i].offset = c.offset
@@ -138,11 +154,16 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
         if pa.types.is_string(t) or pa.types.is_binary(t):
             prm.inp[i].data = _addr(bufs[1])
             prm.inp[i].aux = _addr(bufs[2]) if bufs[2] is not None else ctypes.addressof(ctypes.create_string_buffer(1))
+        elif pa.types.is_list(t):
+            prm.inp[i].data = _addr(bufs[1])      # the offsets; the elements are a column of their own
+        elif pa.types.is_struct(t):
+            prm.inp[i].data = None
         elif pa.types.is_nested(t) or pa.types.is_dictionary(t):
-            raise Unsupported("nested / dictionary inputs")
+            raise Unsupported("map / dictionary inputs")
         else:
             prm.inp[i].data = _addr(bufs[1])
-        keep.append(bufs)
+        keep.append((c, bufs))
+    cols = bound
     errbuf = np.zeros(512, np.uint8)
     scratch0, scratch1 = np.zeros(8 * (n // 2048 + 4), np.uint8), np.zeros(64, np.uint8)
     prm.out[0], prm.out[1], prm.out[2] = scratch0.ctypes.data, scratch1.ctypes.data, errbuf.ctypes.data
