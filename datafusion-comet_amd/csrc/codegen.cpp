@@ -292,12 +292,14 @@ ExprP lower_split(const ExprP& e) {
   if (all) {
     dc.prog = compile_regex_captures(pat->lit_bytes, 0, "regexp_extract_all").words;
     if (limit != 0) dc.prog2 = compile_regex_captures(pat->lit_bytes, limit, "regexp_extract_all").words;      // (the reference's message for an index out of range)
-  } else try {
-    dc.prog = compile_regex_captures(pat->lit_bytes, 0, "split").words;
-  } catch (const CometError& err) {
-    const std::string m = err.what();
-    if (m.find("not supported") != std::string::npos) throw;
-    throw CometError("Invalid regex pattern '" + pat->lit_bytes + "': " + m);      // split.rs:201-203
+  } else {
+    try {
+      dc.prog = compile_regex_captures(pat->lit_bytes, 0, "split").words;
+    } catch (const CometError& err) {
+      const std::string m = err.what();
+      if (m.find("not supported") != std::string::npos) throw;
+      throw CometError("Invalid regex pattern '" + pat->lit_bytes + "': " + m);      // split.rs:201-203
+    }
   }
   dc.type.id = TypeId::List;
   DType elem = DType::of(TypeId::String);

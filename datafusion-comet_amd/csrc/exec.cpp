@@ -1329,6 +1329,7 @@ void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol
     const bool hv = in.has_valid[(size_t)dc.src];
     const int64_t rows = in.rows;
     if (!sc.data && rows) throw CometError("split over a Utf8 column without offsets is not supported");
+    if (hv && sc.offset != 0) throw CometError("split over a sliced Utf8 column with NULLs is not supported yet");      // (the list shares the column's validity bitmap)
     DevBuf prog, counts, tiles;
     auto list_offs = std::make_shared<DevBuf>();
     prog.ensure(dc.prog.size() * 4 + 16);
@@ -1384,7 +1385,6 @@ void ExecutionContext::extend_derived(DevTable& in, const std::vector<DerivedCol
     lv.kids.push_back(elem);
     lv.kid_has_valid.push_back(false);
     lv.kid_rows = total;
-    if (hv && sc.offset != 0) throw CometError("split over a sliced Utf8 column with NULLs is not supported yet");
     in.types.push_back(dc.type);
     in.cols.push_back(lv);
     in.has_valid.push_back(hv);

@@ -210,6 +210,7 @@ static int32_t subquery_from_jvm(void* vctx, int64_t id, int32_t type_id, int32_
       std::vector<uint8_t> tmp((size_t)n + 1);
       jni_GetByteArrayRegion(env, a, 0, n, (jbyte*)tmp.data());
       put_bytes(tmp.data(), (size_t)n);
+      jni_DeleteLocalRef(env, a);
       break;
     }
     case 7: {      // string
@@ -221,12 +222,14 @@ static int32_t subquery_from_jvm(void* vctx, int64_t id, int32_t type_id, int32_
       const std::string u = from_modified_utf8(chars ? chars : "");
       if (chars) jni_ReleaseStringUTFChars(env, js, chars);
       put_bytes(u.data(), u.size());
+      jni_DeleteLocalRef(env, js);
       break;
     }
     default: return -1;
   }
-  if (!m || jni_ExceptionCheck(env)) return -1;
-  return 1;
+  const bool failed = !m || jni_ExceptionCheck(env);
+  jni_DeleteLocalRef(env, cls);      // (one class lookup per subquery and task: the values are asked for once)
+  return failed ? -1 : 1;
 }
 
 JNIEXPORT jlong JNICALL Java_org_apache_comet_Native_createPlan(
