@@ -629,6 +629,28 @@ int64_t comet_plan_error_json(const uint8_t* plan, size_t plan_len, int32_t site
   });
 }
 
+int64_t comet_plan_site_error_json(const uint8_t* plan, size_t plan_len, uint32_t site_id, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail,
+                                   char* out, int64_t cap) {
+  return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
+    OperatorP op = decode_operator(plan, plan_len);
+    const Operator* leaf = op.get();
+    while (!leaf->children.empty()) leaf = leaf->children[0].get();
+    bool nested = false;      // (as in comet_plan_codegen: fields and elements are columns behind the real ones)
+    for (auto& t : leaf->scan_fields) nested = nested || t.is_nested();
+    const std::vector<DType> types = nested ? extend_struct_field_types(leaf->scan_fields) : leaf->scan_fields;
+    std::vector<bool> none(types.size(), false);
+    const PipelineDesc d = nested ? generate_pipeline(*op, none, &types) : generate_pipeline(*op, none);
+    ErrSite site;
+    if (!lookup_err_site(site_id, site)) throw CometError("no raise site with id " + std::to_string(site_id) + " is registered in this process");
+    const QueryContext* ctx = nullptr;      // what ExecutionContext::site_context answers for the pipeline's kernels
+    for (auto& kv : d.site_contexts)
+      if (kv.first == site_id) { ctx = kv.second.get(); break; }
+    const std::string j = err_site_json(site, lo, hi, str, str_avail < 0 ? 0 : (size_t)str_avail, ctx);
+    if (out && cap > (int64_t)j.size()) memcpy(out, j.c_str(), j.size() + 1);
+    return (int64_t)j.size();
+  });
+}
+
 int64_t comet_zone_table(const char* zone, int64_t* out, int64_t cap) {
   return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {
     const std::vector<int64_t> f = load_zone(zone ? zone : "")->flat();

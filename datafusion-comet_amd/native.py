@@ -157,6 +157,8 @@ def _load() -> ctypes.CDLL:
     lib.comet_plan_codegen.argtypes = [c.c_char_p, c.c_size_t, c.c_char_p, c.c_int32, c.c_void_p, c.c_int64]
     lib.comet_error_site_json.restype = c.c_int64
     lib.comet_error_site_json.argtypes = [c.c_uint32, c.c_uint64, c.c_uint64, c.c_char_p, c.c_int64, c.c_void_p, c.c_int64]
+    lib.comet_plan_site_error_json.restype = c.c_int64
+    lib.comet_plan_site_error_json.argtypes = [c.c_char_p, c.c_size_t, c.c_uint32, c.c_uint64, c.c_uint64, c.c_char_p, c.c_int64, c.c_void_p, c.c_int64]
     lib.comet_embedded_header.restype = c.c_int64
     lib.comet_embedded_header.argtypes = [c.c_char_p, c.c_void_p, c.c_int64]
     lib.comet_plan_set_subquery.restype = c.c_int32
@@ -1248,6 +1250,15 @@ def plan_codegen(plan: bytes, has_valid: Sequence[bool]) -> dict:
 def error_site_json(site_id: int, lo: int, hi: int, text: bytes = b"") -> str:
     buf = ctypes.create_string_buffer(1 << 14)
     n = lib().comet_error_site_json(site_id, lo, hi, text, len(text), buf, len(buf))
+    if n < 0:
+        _raise_last(0)
+    return buf.value.decode()
+
+
+def plan_site_error_json(plan: bytes, site_id: int, lo: int, hi: int, text: bytes = b"") -> str:
+    """comet_plan_site_error_json: the raise site's JSON with the QueryContext the plan gives it — check_device_errors' text"""
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = lib().comet_plan_site_error_json(plan, len(plan), site_id, lo, hi, text, len(text), buf, len(buf))
     if n < 0:
         _raise_last(0)
     return buf.value.decode()

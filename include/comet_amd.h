@@ -269,6 +269,11 @@ int64_t comet_error_json(const char* error_type, const char* error_class, const 
 int64_t comet_plan_error_json(const uint8_t* plan, size_t plan_len, int32_t site_index, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail,
                               char* out, int64_t cap);
 
+/* The same by the site's ID — what a kernel leaves in the error block's detail words (kparams.h) — with the QueryContext the plan's pipeline gives that site, if
+ * any: exactly what check_device_errors throws for it (the host emulation of generated code in tests/emu rebuilds the executor's error with this). */
+int64_t comet_plan_site_error_json(const uint8_t* plan, size_t plan_len, uint32_t site_id, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail,
+                                   char* out, int64_t cap);
+
 /* ---- the host page codecs (csrc/parquet_meta.cpp) ---------------------------------------------------------------------------------------
  * What the scan's host threads run on the pages the device does not decompress itself: Parquet CompressionCodec 0 UNCOMPRESSED, 1 SNAPPY,
  * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and

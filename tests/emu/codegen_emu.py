@@ -178,7 +178,7 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
     rows = lib.emu_run(ctypes.byref(prm))
     flags = int(errbuf[:4].view(np.uint32)[0])
     if flags:
-        _raise_like_the_executor(flags, errbuf)
+        _raise_like_the_executor(flags, errbuf, plan)
     arrays = []
     for (vals, ok, width), oc in zip(outs, desc["out"]):
         mask = None if not oc["nullable"] else (ok[:rows] == 0)
@@ -218,11 +218,11 @@ _FLAG_JSON = [(1, '{"errorType":"ArithmeticOverflow","errorClass":"ARITHMETIC_OV
               (256, '{"errorType":"DivideByZero","errorClass":"DIVIDE_BY_ZERO","params":{}}'), (32768, '{"errorType":"RemainderByZero","errorClass":"REMAINDER_BY_ZERO","params":{}}')]
 
 
-def _raise_like_the_executor(flags, block):
+def _raise_like_the_executor(flags, block, plan):
     """exec_pipeline.cpp check_device_errors, for the flags a Filter / Projection chain can raise: the site's JSON when a site left its detail, else the flag's"""
     detail = block[192:].view(np.uint64)
     if detail[0] != 0:
-        raise native.CometQueryExecutionException(native.error_site_json(int(detail[0]) - 1, int(detail[1]), int(detail[2]), bytes(block[192 + 32:192 + 32 + 224])))
+        raise native.CometQueryExecutionException(native.plan_site_error_json(plan, int(detail[0]) - 1, int(detail[1]), int(detail[2]), bytes(block[192 + 32:192 + 32 + 224])))
     for bit, js in _FLAG_JSON:
         if flags & bit:
             raise native.CometQueryExecutionException(js)
@@ -267,7 +267,7 @@ def run_gpu_test_on_host(module: str, fn: str, **params):
             raise Unsupported("plans with several inputs")
         out = run_chain(plan_bytes, inputs[0].table)
         assert out.num_columns == ncols, (out.num_columns, ncols)
-        return out.to_batches() if out.num_rows else []
+        return out.to_batches(max_chunksize=kw.get("batch_size", 8192) or None) if out.num_rows else []      # spark.comet.batchSize bounds an output batch
 
     native.HostInput, native.execute_to_table = _HostInput, execute
     try:

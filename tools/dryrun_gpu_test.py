@@ -41,7 +41,7 @@ def _execute(inputs, ncols, plan_bytes, **kw):
     # (Plans over materialised sources plan their chains at run time: those are generated only when a chain is the plan's root.)
     native.compile_plan(plan_bytes)
     try:
-        out = O.run_plan_to_arrow(S, _last["plan"], *[i.table for i in inputs])
+        out = O.run_plan_to_arrow(S, _last["plan"], [i.table for i in inputs])
     except O.OracleError as e:      # the message a device run would carry is not reproduced: every fromType the tests match is appended
         raise native.CometQueryExecutionException(str(e) + ' "fromType":"byte" "fromType":"short" "fromType":"integer" "fromType":"long" "fromType":"Int32"')
     assert out.num_columns == ncols, (out.num_columns, ncols)
