@@ -567,7 +567,7 @@ int64_t comet_parquet_prune_report(const uint8_t* plan, size_t plan_len, int32_t
     const Operator* scan = op.get();
     while (scan && scan->kind != OpKind::NativeScan) scan = scan->children.empty() ? nullptr : scan->children[0].get();
     if (!scan) throw CometError("comet_parquet_prune_report: the plan holds no NativeScan");
-    const std::string j = parquet_prune_report(*scan, page_index != 0);
+    const std::string j = parquet_prune_report(*scan, (page_index & 1) != 0, (page_index & 2) == 0);
     if (out && cap) {
       const size_t n = std::min(cap - 1, j.size());
       memcpy(out, j.data(), n);
@@ -576,6 +576,9 @@ int64_t comet_parquet_prune_report(const uint8_t* plan, size_t plan_len, int32_t
     return (int64_t)j.size();
   });
 }
+
+uint64_t comet_xxh64(const uint8_t* data, size_t len, uint64_t seed) { return pq::xxh64(data, len, seed); }
+int32_t comet_sbbf_might_contain(const uint8_t* bitset, size_t nbytes, uint64_t hash) { return pq::sbbf_might_contain(bitset, nbytes, hash) ? 1 : 0; }
 
 int64_t comet_parquet_host_plain_values(const uint8_t* plan, size_t plan_len, int32_t column, uint8_t* out, size_t cap) {
   return guarded(nullptr, (int64_t)-2, [&]() -> int64_t {

@@ -2047,7 +2047,8 @@ std::string ExecutionContext::metrics_proto() {
     }
     if (op.kind == OpKind::NativeScan) {
       n.metrics.emplace_back("bytes_scanned", bytes_scanned_);
-      n.metrics.emplace_back("row_groups_pruned_statistics", row_groups_pruned_);
+      n.metrics.emplace_back("row_groups_pruned_statistics", row_groups_pruned_ - row_groups_pruned_bloom_);
+      n.metrics.emplace_back("row_groups_pruned_bloom_filter", row_groups_pruned_bloom_);      // (DataFusion's ParquetFileMetrics names)
       n.metrics.emplace_back("pages_decompressed_on_device", pages_inflated_on_device_);
       n.metrics.emplace_back("page_index_rows_pruned", rows_pruned_page_index_);
     }

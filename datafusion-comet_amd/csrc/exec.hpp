@@ -138,7 +138,7 @@ struct Variant {  // one JIT specialisation of the pipeline (per input-validity 
 // parquet_scan.cpp: run fn(0..n-1) on the process-wide scan threads and wait
 void scan_pool_parallel(size_t n, const std::function<void(size_t)>& fn);
 // row-group / page-index selection of a NativeScan as JSON (parquet_scan.cpp; host only)
-std::string parquet_prune_report(const Operator& native_scan, bool page_index);
+std::string parquet_prune_report(const Operator& native_scan, bool page_index, bool bloom_filters = true);
 // host-staged PLAIN value bytes of one column of a NativeScan (parquet_scan.cpp; host only, a test hook)
 std::vector<uint8_t> parquet_host_plain_values(const Operator& native_scan, size_t column);
 // queue one task on the same threads (FIFO) without waiting
@@ -336,6 +336,7 @@ class ExecutionContext {
   int64_t join_build_rows_ = 0, join_probe_rows_ = 0, join_keymap_bytes_ = 0, join_direct_maps_ = 0;
   int64_t bytes_scanned_ = 0;
   int64_t row_groups_pruned_ = 0;
+  int64_t row_groups_pruned_bloom_ = 0;    // … of them, by a column chunk's Bloom filter (the statistics had not ruled them out)
   std::shared_ptr<MemAccount> mem_ = std::make_shared<MemAccount>();
   int64_t rows_pruned_page_index_ = 0;     // rows the Parquet page index ruled out (never decoded)
   int64_t pages_inflated_on_device_ = 0;   // data pages decompressed by snappy_kernels.hip

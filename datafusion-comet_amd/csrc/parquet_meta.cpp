@@ -193,6 +193,8 @@ ColumnMeta read_column_meta(TReader& r) {
       case 7: m.total_compressed = r.zigzag(); break;
       case 9: m.data_page_offset = r.zigzag(); break;
       case 11: m.dictionary_page_offset = r.zigzag(); break;
+      case 14: m.bloom_filter_offset = r.zigzag(); break;
+      case 15: m.bloom_filter_length = (int32_t)r.zigzag(); break;
       case 12: {   // Statistics
         int16_t f2 = 0;
         std::string mn, mx, mn_old, mx_old;
@@ -568,6 +570,71 @@ uint8_t SnappyView::at(size_t o) const {
     o = (size_t)e.out_pos - e.src + ((o - e.out_pos) % e.src);     // a copy: the byte `offset` back — for a copy that overlaps itself (offset < length) taken modulo the offset, so that every step lands BEFORE the element: at most one step per element
   }
   throw CometError("snappy: copy chain too deep for a sparse read");
+}
+
+// ---- Bloom filters (parquet-format BloomFilter.md; parquet.thrift BloomFilterHeader { 1 numBytes, 2 algorithm, 3 hash, 4 compression }, each of the three a union
+// with ONE arm so far: BLOCK, XXHASH, UNCOMPRESSED) ------------------------------------------------------------------------------------------------------------
+size_t parse_bloom_header(const uint8_t* data, size_t len, int32_t& num_bytes) {
+  TReader r(data, len);
+  int16_t fid = 0;
+  num_bytes = -1;
+  bool seen[5] = {false, false, false, false, false};
+  while (int t = r.field(fid)) {
+    if (fid == 1 && t == 5) { num_bytes = (int32_t)r.zigzag(); seen[1] = true; }
+    else if (fid >= 2 && fid <= 4 && t == 12) {      // a union: exactly one field, whose id names the arm
+      int16_t f2 = 0;
+      int arms = 0;
+      while (int t2 = r.field(f2)) {
+        if (f2 != 1) throw CometError("parquet: a Bloom filter with an algorithm / hash / compression this reader does not know");
+        arms++;
+        r.skip(t2);
+      }
+      if (arms != 1) throw CometError("parquet: malformed Bloom filter header");
+      seen[fid] = true;
+    } else r.skip(t);
+  }
+  if (!seen[1] || !seen[2] || !seen[3] || !seen[4] || num_bytes < 32 || (num_bytes & 31)) throw CometError("parquet: malformed Bloom filter header");
+  return (size_t)(r.p - data);
+}
+
+uint64_t xxh64(const void* data, size_t len, uint64_t seed) {
+  constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull, P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+  auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+  auto rd64 = [](const uint8_t* q) { uint64_t v; memcpy(&v, q, 8); return v; };
+  auto rd32 = [](const uint8_t* q) { uint32_t v; memcpy(&v, q, 4); return (uint64_t)v; };
+  auto round = [&](uint64_t acc, uint64_t in) { return rotl(acc + in * P2, 31) * P1; };
+  auto merge = [&](uint64_t h, uint64_t v) { return (h ^ round(0, v)) * P1 + P4; };
+  const uint8_t* q = (const uint8_t*)data;
+  const uint8_t* const e = q + len;
+  uint64_t h;
+  if (len >= 32) {
+    uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+    for (; e - q >= 32; q += 32) { v1 = round(v1, rd64(q)); v2 = round(v2, rd64(q + 8)); v3 = round(v3, rd64(q + 16)); v4 = round(v4, rd64(q + 24)); }
+    h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+    h = merge(merge(merge(merge(h, v1), v2), v3), v4);
+  } else {
+    h = seed + P5;
+  }
+  h += (uint64_t)len;
+  for (; e - q >= 8; q += 8) h = rotl(h ^ round(0, rd64(q)), 27) * P1 + P4;
+  if (e - q >= 4) { h = rotl(h ^ (rd32(q) * P1), 23) * P2 + P3; q += 4; }
+  for (; q < e; q++) h = rotl(h ^ (*q * P5), 11) * P1;
+  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+  return h;
+}
+
+bool sbbf_might_contain(const uint8_t* bits, size_t nbytes, uint64_t hash) {
+  static const uint32_t kSalt[8] = {0x47b6137bu, 0x44974d91u, 0x8824ad5bu, 0xa2b7289du, 0x705495c7u, 0x2df1424bu, 0x9efc4947u, 0x5c6bfb31u};
+  const uint64_t nblocks = nbytes / 32;
+  if (nblocks == 0) return true;
+  const uint8_t* block = bits + (size_t)(((hash >> 32) * nblocks) >> 32) * 32;
+  const uint32_t key = (uint32_t)hash;
+  for (int i = 0; i < 8; i++) {
+    uint32_t w;
+    memcpy(&w, block + 4 * i, 4);
+    if (!(w & (1u << ((key * kSalt[i]) >> 27)))) return false;
+  }
+  return true;
 }
 
 PageIndex parse_page_index(const uint8_t* column_index, size_t ci_len, const uint8_t* offset_index, size_t oi_len) {

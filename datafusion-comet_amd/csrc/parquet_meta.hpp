@@ -49,7 +49,17 @@ struct ColumnMeta {
   // page index (ColumnChunk fields 4-7): where the OffsetIndex / ColumnIndex of this chunk sit in the file (0 = the writer wrote none)
   int64_t offset_index_offset = 0, column_index_offset = 0;
   int32_t offset_index_length = 0, column_index_length = 0;
+  // ColumnMetaData 14 / 15: where the chunk's Bloom filter (header + bitset) sits (0 = none; a length is optional in the format)
+  int64_t bloom_filter_offset = 0;
+  int32_t bloom_filter_length = 0;
 };
+
+// The split-block Bloom filter of a column chunk (parquet-format BloomFilter.md): blocks of 256 bits = eight 32-bit words; a value's XXH64 (seed 0, over its
+// PLAIN encoding — a BYTE_ARRAY without its length prefix) picks the block with its high 32 bits and one bit per word with its low 32 bits times eight salts.
+// Only BLOCK / XXHASH / UNCOMPRESSED exist in the format; anything else is "no usable filter".
+size_t parse_bloom_header(const uint8_t* data, size_t len, int32_t& num_bytes);     // → the header's length in bytes; throws CometError on what it cannot use
+bool sbbf_might_contain(const uint8_t* bits, size_t nbytes, uint64_t hash);
+uint64_t xxh64(const void* data, size_t len, uint64_t seed);
 
 // The page index of one column chunk (parquet.thrift ColumnIndex / OffsetIndex): one entry per DATA page, in file order.
 struct PageIndex {

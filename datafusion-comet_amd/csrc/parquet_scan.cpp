@@ -315,7 +315,9 @@ bool lit_i64(const Expr& e, int64_t& v) {
   }
 }
 // can `pred` be proven FALSE (or NULL) for every row of the row group?
-bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::FileMeta& fm, const pq::RowGroup& rg, bool case_sensitive);
+struct BloomCache;
+bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::FileMeta& fm, const pq::RowGroup& rg, bool case_sensitive, BloomCache* bloom = nullptr,
+            bool* by_bloom = nullptr);
 
 struct ColumnPlan {
   int leaf = -1;          // index into row_group.columns
@@ -688,25 +690,131 @@ StatView chunk_stats(const pq::ColumnMeta& cm) {
   return sv;
 }
 
-// Host half of one column chunk (one column of one row group): page walk, decompression straight into the column's pinned
-// staging block at the chunk's slot, hybrid-run tables.  Independent of every other chunk, so chunks are prepared by a
-// pool of host threads (scan_parquet); the calling thread then concatenates a column's tables and decodes the WHOLE column
-// (all row groups) with one upload and one launch per kernel.
-bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::FileMeta& fm, const pq::RowGroup& rg, bool case_sensitive) {
+// ---- row-group pruning from Bloom filters (DataFusion's ParquetSource probes a chunk's filter for `column = literal` and `column IN (literals)` when
+// datafusion.execution.parquet.bloom_filter_on_read is on — the default, carried through by parquet_exec.rs:251-252).  A filter answers "certainly absent" or
+// "maybe there"; like the statistics, only an optimisation.  The literal is hashed in the chunk's PLAIN encoding, so only pairs of file type and literal whose
+// encoding is beyond doubt are probed: signed INT32 / INT64 integers, dates, microsecond timestamps and decimals of the file's scale, BYTE_ARRAY strings,
+// FIXED_LEN_BYTE_ARRAY decimals of the file's scale.  Floats (NaN, -0.0), unsigned and INT96 columns, rebased dates (before 1582-10-15) are left alone.
+struct BloomCache {
+  const OpenFile* file;
+  const pq::RowGroup* rg;
+  std::map<int, std::shared_ptr<std::vector<uint8_t>>> by_leaf;      // nullptr = the chunk has no (usable) filter
+  const std::vector<uint8_t>* get(int leaf) {
+    auto it = by_leaf.find(leaf);
+    if (it != by_leaf.end()) return it->second.get();
+    std::shared_ptr<std::vector<uint8_t>> bits;
+    const pq::ColumnMeta& cm = rg->columns[(size_t)leaf];
+    if (cm.bloom_filter_offset > 0 && (size_t)cm.bloom_filter_offset + 40 <= file->size) {
+      try {
+        uint8_t head[64];
+        const size_t avail = std::min<size_t>(sizeof head, file->size - (size_t)cm.bloom_filter_offset);
+        file->read_at(head, avail, cm.bloom_filter_offset);
+        int32_t nbytes = 0;
+        const size_t hlen = pq::parse_bloom_header(head, avail, nbytes);
+        // (128 MB: the format's upper bound of a filter)
+        if (nbytes <= (128 << 20) && (size_t)cm.bloom_filter_offset + hlen + (size_t)nbytes <= file->size &&
+            (cm.bloom_filter_length <= 0 || (size_t)cm.bloom_filter_length == hlen + (size_t)nbytes)) {
+          bits = std::make_shared<std::vector<uint8_t>>((size_t)nbytes);
+          file->read_at(bits->data(), bits->size(), cm.bloom_filter_offset + (int64_t)hlen);
+        }
+      } catch (const CometError&) {
+        bits.reset();      // a filter this reader cannot make sense of prunes nothing
+      }
+    }
+    by_leaf.emplace(leaf, bits);
+    return bits.get();
+  }
+};
+// the PLAIN encoding of `lit` as a value of the file column (false: not a pair this reader hashes)
+bool plain_bytes_of(const Expr& lit, const LeafCol& c, std::string& out) {
+  if (lit.kind != ExprKind::Literal || lit.lit_null) return false;
+  const pq::SchemaElement& el = *c.el;
+  const DType& t = c.want;
+  if ((el.int_bits > 0 && !el.int_signed) || el.type == pq::INT96) return false;
+  if (el.type == pq::BYTE_ARRAY) {
+    if (!((t.id == TypeId::String && lit.dtype.id == TypeId::String) || (t.id == TypeId::Bytes && lit.dtype.id == TypeId::Bytes))) return false;
+    out = lit.lit_bytes;
+    return true;
+  }
+  const bool dec = t.id == TypeId::Decimal;
+  if (dec != (lit.dtype.id == TypeId::Decimal)) return false;
+  if (dec && (el.scale != t.scale || lit.dtype.scale != t.scale)) return false;
+  if (el.type == pq::FLBA) {
+    if (!dec || el.type_length < 1 || el.type_length > 16) return false;
+    const int bits = 8 * el.type_length;
+    if (bits < 128 && (lit.lit_dec >= ((i128)1 << (bits - 1)) || lit.lit_dec < -((i128)1 << (bits - 1)))) return false;
+    out.assign((size_t)el.type_length, '\0');
+    for (int b = 0; b < el.type_length; b++) out[(size_t)(el.type_length - 1 - b)] = (char)(uint8_t)((u128)lit.lit_dec >> (8 * b));
+    return true;
+  }
+  int64_t v;
+  if (!lit_i64(lit, v)) return false;
+  switch (t.id) {
+    case TypeId::Int8: case TypeId::Int16: case TypeId::Int32: case TypeId::Int64: case TypeId::Decimal: break;
+    case TypeId::Date: if (lit.dtype.id != TypeId::Date || v < -141427) return false; break;
+    case TypeId::Timestamp: case TypeId::TimestampNtz:
+      if ((lit.dtype.id != TypeId::Timestamp && lit.dtype.id != TypeId::TimestampNtz) || el.ts_unit != 2 || v < -141427ll * 86400000000ll) return false;
+      break;
+    default: return false;
+  }
+  if (t.id != TypeId::Timestamp && t.id != TypeId::TimestampNtz && el.ts_unit != 0) return false;
+  if ((t.id == TypeId::Date) != (lit.dtype.id == TypeId::Date)) return false;
+  if (el.type == pq::INT32) {
+    if (v < INT32_MIN || v > INT32_MAX) return false;
+    const int32_t x = (int32_t)v;
+    out.assign((const char*)&x, 4);
+    return true;
+  }
+  if (el.type == pq::INT64) { out.assign((const char*)&v, 8); return true; }
+  return false;
+}
+// does the chunk's Bloom filter prove that NONE of the literals is a value of the column?
+bool bloom_proves_absent(const LeafCol& c, const Expr* const* lits, size_t n, BloomCache& bc) {
+  if (n == 0) return false;
+  const std::vector<uint8_t>* bits = nullptr;
+  std::string enc;
+  for (size_t i = 0; i < n; i++) {
+    if (lits[i]->kind == ExprKind::Literal && lits[i]->lit_null) continue;      // a NULL in the list matches nothing
+    if (!plain_bytes_of(*lits[i], c, enc)) return false;
+    if (!bits && !(bits = bc.get(c.leaf))) return false;
+    if (pq::sbbf_might_contain(bits->data(), bits->size(), pq::xxh64(enc.data(), enc.size(), 0))) return false;
+  }
+  return bits != nullptr;
+}
+
+bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::FileMeta& fm, const pq::RowGroup& rg, bool case_sensitive, BloomCache* bloom, bool* by_bloom) {
   if (pred.kind == ExprKind::And) {
     for (auto& c : pred.children)
-      if (prunes(*c, schema, fm, rg, case_sensitive)) return true;
+      if (prunes(*c, schema, fm, rg, case_sensitive, bloom, by_bloom)) return true;
     return false;
   }
   if (pred.kind == ExprKind::Or) {
-    for (auto& c : pred.children)
-      if (!prunes(*c, schema, fm, rg, case_sensitive)) return false;
+    bool any_bloom = false;
+    for (auto& c : pred.children) {
+      bool b = false;
+      if (!prunes(*c, schema, fm, rg, case_sensitive, bloom, &b)) return false;
+      any_bloom = any_bloom || b;
+    }
+    if (by_bloom && any_bloom) *by_bloom = true;
     return !pred.children.empty();
   }
-  LeafPred lp;
   LeafCol col;
+  if (pred.kind == ExprKind::In && !pred.negated && pred.children.size() >= 2) {      // column IN (literals): a filter may rule every one of them out
+    if (!bloom || !leaf_column(*pred.children[0], schema, fm, rg.columns.size(), case_sensitive, col)) return false;
+    std::vector<const Expr*> lits;
+    for (size_t i = 1; i < pred.children.size(); i++) lits.push_back(pred.children[i].get());
+    if (!bloom_proves_absent(col, lits.data(), lits.size(), *bloom)) return false;
+    if (by_bloom) *by_bloom = true;
+    return true;
+  }
+  LeafPred lp;
   if (!leaf_pred(pred, lp) || !leaf_column(*lp.col, schema, fm, rg.columns.size(), case_sensitive, col)) return false;
-  return stats_prove_false(lp, col, chunk_stats(rg.columns[(size_t)col.leaf]));
+  if (stats_prove_false(lp, col, chunk_stats(rg.columns[(size_t)col.leaf]))) return true;
+  if (bloom && lp.kind == ExprKind::Eq && bloom_proves_absent(col, &lp.lit, 1, *bloom)) {
+    if (by_bloom) *by_bloom = true;
+    return true;
+  }
+  return false;
 }
 
 // ---- page-index pruning: which ROWS of a row group can a pushed-down filter still be true for? ---------------------------------------
@@ -922,6 +1030,10 @@ size_t chunk_staging_capacity(const ChunkSource& src, const pq::ColumnMeta& cm, 
   return staged_capacity(cm) + (cm.prefix_encoded ? ((prefix_encoded_plain_bytes(src, cm, max_def) + 15) & ~(size_t)15) : 0);
 }
 
+// Host half of one column chunk (one column of one row group): page walk, decompression straight into the column's pinned
+// staging block at the chunk's slot, hybrid-run tables.  Independent of every other chunk, so chunks are prepared by a
+// pool of host threads (scan_parquet); the calling thread then concatenates a column's tables and decodes the WHOLE column
+// (all row groups) with one upload and one launch per kernel.
 // `raw_area` (optional, above `staged` in the same pinned block, `raw_cap` bytes): where a chunk that is read in place keeps the file's bytes —
 // the raw areas of a column's chunks lie NEXT TO EACH OTHER behind the column's staging slots, so what crosses PCIe compressed is contiguous
 // and a column's ready chunks cross in a handful of copies.  `raw_read`: the scan threads have already read the chunk into it (in pieces).
@@ -1662,7 +1774,8 @@ struct Sel {
 // pushed-down filters' min / max statistics, and — with a page index (ColumnIndex / OffsetIndex; parquet_exec.rs turns on DataFusion's
 // page-index pruning) — which ROWS of the survivors can the filters still be true for.  Pages outside those rows are neither decompressed
 // nor uploaded and the scan emits only the kept rows; the Filter above re-checks every row it gets, as it does after row-group pruning.
-void select_row_groups(const Operator& op, bool page_index, std::vector<Sel>& sels, int64_t& total_rows, int64_t& row_groups_pruned, int64_t& rows_pruned_page_index) {
+void select_row_groups(const Operator& op, bool page_index, std::vector<Sel>& sels, int64_t& total_rows, int64_t& row_groups_pruned, int64_t& rows_pruned_page_index,
+                       bool bloom_filters = true, int64_t* row_groups_pruned_bloom = nullptr) {
   for (auto& pf : op.files) {
     // A file that is missing, or whose footer cannot be read, fails the task the way the reference classifies it
     // (jni-bridge/src/errors.rs:600-735 try_classify_file_read_error): FileNotFound { message } — Spark's readCurrentFileNotFoundError — or
@@ -1691,10 +1804,15 @@ void select_row_groups(const Operator& op, bool page_index, std::vector<Sel>& se
       int64_t mid = start + comp / 2;
       const bool whole = pf.length <= 0;
       if (!whole && !(mid >= pf.start && mid < pf.start + pf.length)) continue;
-      bool skip = false;
+      bool skip = false, by_bloom = false;
+      BloomCache blooms{mf.get(), &rg, {}};
       for (auto& df : op.data_filters)
-        if (prunes(*df, op.required_schema, *fm, rg, op.case_sensitive)) { skip = true; break; }
-      if (skip) { row_groups_pruned++; continue; }
+        if (prunes(*df, op.required_schema, *fm, rg, op.case_sensitive, bloom_filters ? &blooms : nullptr, &by_bloom)) { skip = true; break; }
+      if (skip) {
+        row_groups_pruned++;
+        if (by_bloom && row_groups_pruned_bloom) (*row_groups_pruned_bloom)++;      // (counted in row_groups_pruned too: the row groups the scan did not read)
+        continue;
+      }
       std::shared_ptr<Ranges> keep;
       int64_t rows = rg.num_rows;
       if (page_index && !op.data_filters.empty()) {
@@ -1719,11 +1837,12 @@ void select_row_groups(const Operator& op, bool page_index, std::vector<Sel>& se
 
 // What select_row_groups decides for a NativeScan, as JSON — host only (footers and page indexes are read, no page is): the CPU-side
 // check of row-group and page-index pruning (include/comet_amd.h comet_parquet_prune_report).
-std::string parquet_prune_report(const Operator& op, bool page_index) {
+std::string parquet_prune_report(const Operator& op, bool page_index, bool bloom_filters) {
   std::vector<Sel> sels;
-  int64_t total = 0, rg_pruned = 0, rows_pruned = 0;
-  select_row_groups(op, page_index, sels, total, rg_pruned, rows_pruned);
-  std::string j = "{\"rows\": " + std::to_string(total) + ", \"row_groups_pruned\": " + std::to_string(rg_pruned) + ", \"page_index_rows_pruned\": " + std::to_string(rows_pruned) +
+  int64_t total = 0, rg_pruned = 0, rows_pruned = 0, rg_bloom = 0;
+  select_row_groups(op, page_index, sels, total, rg_pruned, rows_pruned, bloom_filters, &rg_bloom);
+  std::string j = "{\"rows\": " + std::to_string(total) + ", \"row_groups_pruned\": " + std::to_string(rg_pruned) + ", \"row_groups_pruned_bloom_filter\": " + std::to_string(rg_bloom) +
+                  ", \"page_index_rows_pruned\": " + std::to_string(rows_pruned) +
                   ", \"row_groups\": [";
   for (size_t i = 0; i < sels.size(); i++) {
     const Sel& sl = sels[i];
@@ -1903,8 +2022,15 @@ DevTable ExecutionContext::scan_parquet(const Operator& op) {
   std::vector<Sel> sels;
   int64_t total_rows = 0, rg_pruned = 0, rows_pruned = 0;
   if (any_nested) page_index = false;            // (a kept row range does not say which ENTRIES of a list leaf it covers)
-  select_row_groups(op, page_index, sels, total_rows, rg_pruned, rows_pruned);
+  // datafusion.execution.parquet.bloom_filter_on_read (default true) reaches the reference's scan through spark.comet.datafusion.* (jni_api.rs:611-620, parquet_exec.rs:251-252)
+  bool bloom_filters = true;
+  int64_t rg_bloom = 0;
+  if (const char* e = getenv("COMET_PARQUET_BLOOM_FILTER")) bloom_filters = atoi(e) != 0;
+  for (auto& kv : config_)
+    if (kv.first == "spark.comet.datafusion.execution.parquet.bloom_filter_on_read") bloom_filters = kv.second != "false" && kv.second != "0";
+  select_row_groups(op, page_index, sels, total_rows, rg_pruned, rows_pruned, bloom_filters, &rg_bloom);
   row_groups_pruned_ += rg_pruned;
+  row_groups_pruned_bloom_ += rg_bloom;
   rows_pruned_page_index_ += rows_pruned;
   out.rows = total_rows;
   bytes_scanned_ = 0;

@@ -1323,11 +1323,25 @@ def parquet_host_plain_values(plan: bytes, column: int) -> bytes:
     return buf.raw[:n]
 
 
-def parquet_prune_report(plan: bytes, page_index: bool = True) -> dict:
-    """row-group / page-index selection of the plan's NativeScan (comet_parquet_prune_report; host only)"""
+def xxh64(data: bytes, seed: int = 0) -> int:
+    l = lib()
+    l.comet_xxh64.restype = ctypes.c_uint64
+    l.comet_xxh64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
+    return l.comet_xxh64(data, len(data), seed)
+
+
+def sbbf_might_contain(bitset: bytes, h: int) -> bool:
+    l = lib()
+    l.comet_sbbf_might_contain.restype = ctypes.c_int32
+    l.comet_sbbf_might_contain.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64]
+    return bool(l.comet_sbbf_might_contain(bitset, len(bitset), h))
+
+
+def parquet_prune_report(plan: bytes, page_index: bool = True, bloom_filters: bool = True) -> dict:
+    """row-group / Bloom-filter / page-index selection of the plan's NativeScan (comet_parquet_prune_report; host only)"""
     import json
     buf = ctypes.create_string_buffer(1 << 20)
-    n = lib().comet_parquet_prune_report(plan, len(plan), 1 if page_index else 0, buf, len(buf))
+    n = lib().comet_parquet_prune_report(plan, len(plan), (1 if page_index else 0) | (0 if bloom_filters else 2), buf, len(buf))
     if n < 0:
         _raise_last(0)
     return json.loads(buf.value.decode())

@@ -179,10 +179,15 @@ void comet_plan_memory_stats(int64_t plan, int64_t* out4);
 
 /* ---- Parquet scan planning — diagnostic entry ------------------------------------------------------------------------------------------
  * What the scan of a serialized plan's NativeScan would read: the row groups its byte ranges select, those the pushed-down data_filters
- * rule out by min / max statistics, and (page_index != 0) the row ranges of the survivors the page index leaves — as JSON
- * {"rows", "row_groups_pruned", "page_index_rows_pruned", "row_groups": [{"row_group", "num_rows", "keep": [[begin, end), …]}]}.
- * Reads footers and page indexes only; needs no GPU.  Returns the JSON's length (truncated to cap − 1 in `out`), or -2. */
+ * rule out by min / max statistics or — `column = literal`, `column IN (literals)` — by the column chunks' Bloom filters, and (page_index & 1) the row
+ * ranges of the survivors the page index leaves (page_index & 2: WITHOUT the Bloom filters, datafusion.execution.parquet.bloom_filter_on_read = false) — as JSON
+ * {"rows", "row_groups_pruned", "row_groups_pruned_bloom_filter", "page_index_rows_pruned", "row_groups": [{"row_group", "num_rows", "keep": [[begin, end), …]}]}
+ * (row_groups_pruned counts those the Bloom filters ruled out too).  Reads footers, Bloom filters and page indexes only; needs no GPU.  Returns the JSON's length (truncated to cap − 1 in `out`), or -2. */
 int64_t comet_parquet_prune_report(const uint8_t* plan, size_t plan_len, int32_t page_index, char* out, size_t cap);
+/* The two functions a Parquet Bloom filter is probed with (parquet-format BloomFilter.md): XXH64 of a value's PLAIN encoding, and the split-block test of a
+ * hash against a filter's bitset (a multiple of 32 bytes).  Host only; what tests/test_parquet_bloom_cpu.py pins against the xxhash package and pyarrow's filters. */
+uint64_t comet_xxh64(const uint8_t* data, size_t len, uint64_t seed);
+int32_t comet_sbbf_might_contain(const uint8_t* bitset, size_t nbytes, uint64_t hash);
 /* Diagnostic, host only: the PLAIN value bytes the scan stages for column `column` of the plan's NativeScan (selected row groups, page after
  * page, NULLs left out, BYTE_ARRAY values as 4-byte length + bytes) — DELTA_BINARY_PACKED / DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY / BYTE_STREAM_SPLIT pages are
  * rewritten as PLAIN on the host (the reference reads them through arrow-rs, parquet/parquet_exec.rs:60-211).  Returns the byte count (the first

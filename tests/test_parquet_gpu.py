@@ -223,6 +223,50 @@ def test_row_group_pruning_from_statistics(built, tmp_path):
     assert native.execute_to_table([], 3, nothing.encode()) == []
 
 
+def test_row_group_pruning_from_bloom_filters(built, tmp_path):
+    """`column = literal` / `column IN (...)` pushed into the scan rule row groups out by the chunks' Bloom filters where min / max cannot
+    (datafusion.execution.parquet.bloom_filter_on_read, parquet_exec.rs:251-252; the decision itself: tests/test_parquet_bloom_cpu.py): same answer as
+    without them, fewer bytes scanned, counted under DataFusion's metric name"""
+    import pyarrow.compute as pc
+    n = 80_000
+    rng = np.random.default_rng(15)
+    kv = rng.integers(0, 1_000_000, n)
+    t = pa.table({"k": pa.array(kv, pa.int64()), "s": pa.array(["name-%06d" % v for v in rng.integers(0, 500_000, n)]), "x": pa.array(rng.integers(0, 100, n), pa.int32())})
+    path = str(tmp_path / "bloom.parquet")
+    papq.write_table(t, path, row_group_size=10_000, bloom_filter_options={"k": {"ndv": 10_000, "fpp": 0.01}, "s": {"ndv": 10_000, "fpp": 0.01}})
+    types = [S.T_INT64, S.T_STRING, S.T_INT32]
+    k, s = S.col(0, S.T_INT64), S.col(1, S.T_STRING)
+    k_here, s_here = int(kv[12_345]), t.column("s")[54_321].as_py()
+    pred = S.or_(S.eq(k, S.lit(k_here, S.T_INT64)), S.eq(s, S.lit(s_here, S.T_STRING)))
+
+    def run(filters, predicate=pred):
+        plan = S.filter_(S.native_scan([path], t.schema.names, types, data_filters=filters), predicate)
+        it = native.CometExecIterator([], 3, plan.encode(), batch_size=0)
+        batches = []
+        while True:
+            b = native.Native.executePlan(it.handle, 3)
+            if b is None:
+                break
+            batches.append(b)
+        node = S.decode_metric_node(it.metrics())
+        it.close()
+        while node[1]:
+            node = node[1][0]
+        return (pa.Table.from_batches(batches) if batches else None), node[0]
+
+    full, m_full = run([])
+    pruned, m_pruned = run([pred])
+    want = t.filter(pc.or_(pc.equal(t.column("k"), k_here), pc.equal(t.column("s"), s_here)))
+    assert full.num_rows == want.num_rows >= 2 and pruned.equals(full)
+    assert sorted(pruned.column(0).to_pylist()) == sorted(want.column("k").to_pylist())
+    assert m_pruned["row_groups_pruned_bloom_filter"] >= 4 and m_full["row_groups_pruned_bloom_filter"] == 0 and m_pruned["row_groups_pruned_statistics"] == 0
+    assert m_pruned["bytes_scanned"] < m_full["bytes_scanned"]
+    # IN over the string column, one literal present
+    inp = S.in_(s, [S.lit("no such name", S.T_STRING), S.lit(s_here, S.T_STRING)])
+    got, m_in = run([inp], inp)
+    assert got.num_rows == pc.sum(pc.equal(t.column("s"), s_here)).as_py() and m_in["row_groups_pruned_bloom_filter"] >= 4
+
+
 def test_hive_partition_columns(built, tmp_path):
     """Partition columns are appended after the file columns as one constant per file (operator.proto:103-109, planner.rs:1558-1575),
     NULL partition values included; a filter / aggregate above sees them like any column."""
