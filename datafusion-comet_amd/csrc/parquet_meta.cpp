@@ -209,7 +209,7 @@ ColumnMeta read_column_meta(TReader& r) {
             default: r.skip(t2);
           }
         }
-        if (has_new) { m.min_value = mn; m.max_value = mx; m.has_min_max = true; }
+        if (has_new) { m.min_value = mn; m.max_value = mx; m.has_min_max = true; m.stats_typed_order = true; }
         else if (has_old) { m.min_value = mn_old; m.max_value = mx_old; m.has_min_max = true; }   // signed physical types only (checked by the user)
         break;
       }

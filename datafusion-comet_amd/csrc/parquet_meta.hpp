@@ -45,6 +45,7 @@ struct ColumnMeta {
   // Statistics (parquet.thrift Statistics: 3 null_count, 5 max_value, 6 min_value; 1/2 = deprecated max/min, signed order only)
   bool has_min_max = false;
   std::string min_value, max_value;   // PLAIN-encoded
+  bool stats_typed_order = false;     // they are Statistics.min_value / max_value (5 / 6: the column's own order, unsigned bytewise for BYTE_ARRAY), not the deprecated pair
   int64_t null_count = -1;            // -1 = not recorded
   // page index (ColumnChunk fields 4-7): where the OffsetIndex / ColumnIndex of this chunk sit in the file (0 = the writer wrote none)
   int64_t offset_index_offset = 0, column_index_offset = 0;

@@ -291,7 +291,7 @@ void parse_hybrid_runs(const uint8_t* staged, size_t pos, size_t end, int bw, in
 // ---- row-group pruning from column-chunk statistics (the reference pushes data_filters into DataFusion's ParquetSource, which
 // prunes row groups by min/max; parquet_exec.rs:60-211).  Only an optimisation: the plan's Filter still runs on what is read.
 // A row group is skipped when some conjunct `column <op> literal` cannot be TRUE for any row given [min, max] (and for
-// IS NOT NULL when every value is NULL).  Integers, dates, timestamps and INT32/INT64-backed decimals are handled.
+// IS NOT NULL when every value is NULL).  Integers, dates, timestamps, INT32/INT64-backed decimals and strings (unsigned bytewise) are handled.
 bool stat_i64(const pq::ColumnMeta& cm, const pq::SchemaElement& el, int64_t& mn, int64_t& mx) {
   if (!cm.has_min_max) return false;
   auto rd = [&](const std::string& b, int64_t& v) {
@@ -608,6 +608,7 @@ struct StatView {
   const std::string* mx = nullptr;
   int64_t null_count = -1, num_values = 0;
   bool all_null = false;
+  bool typed_order = true;      // min / max follow the column's order (a ColumnIndex always; a chunk's Statistics when they are the min_value / max_value pair)
 };
 bool stat_i64(const StatView& sv, const pq::SchemaElement& el, int64_t& mn, int64_t& mx) {
   if (!sv.has_min_max || !sv.mn || !sv.mx) return false;
@@ -666,6 +667,24 @@ bool stats_prove_false(const LeafPred& lp, const LeafCol& c, const StatView& sv)
   int64_t v, mn, mx;
   const pq::SchemaElement* el = c.el;
   const DType& t = c.want;
+  if (el->type == pq::BYTE_ARRAY) {
+    // strings: unsigned bytewise order — Spark's (UTF8String.compareTo) and the column order of BYTE_ARRAY statistics.  A writer may shorten them
+    // (a prefix for min, an incremented prefix for max): still a lower and an upper bound, which is all these tests use.
+    if (!sv.typed_order || !sv.has_min_max || !sv.mn || !sv.mx || t.id != TypeId::String || lp.lit->kind != ExprKind::Literal || lp.lit->lit_null ||
+        lp.lit->dtype.id != TypeId::String)
+      return false;
+    const std::string& s = lp.lit->lit_bytes;
+    const int lo = s.compare(*sv.mn) < 0 ? -1 : (s == *sv.mn ? 0 : 1);       // (std::string compares as unsigned char)
+    const int hi = s.compare(*sv.mx) < 0 ? -1 : (s == *sv.mx ? 0 : 1);
+    switch (lp.kind) {
+      case ExprKind::Eq: return lo < 0 || hi > 0;
+      case ExprKind::Lt: return lo <= 0;      // min >= literal
+      case ExprKind::LtEq: return lo < 0;
+      case ExprKind::Gt: return hi >= 0;      // max <= literal
+      case ExprKind::GtEq: return hi > 0;
+      default: return false;
+    }
+  }
   if (!lit_i64(*lp.lit, v) || !stat_i64(sv, *el, mn, mx)) return false;
   // statistics are in the file's unit / signedness: do not compare them with a microsecond or signed literal
   if ((el->ts_unit != 0 && el->ts_unit != 2) || (el->int_bits > 0 && !el->int_signed) || el->type == pq::INT96) return false;
@@ -687,6 +706,7 @@ StatView chunk_stats(const pq::ColumnMeta& cm) {
   sv.mx = &cm.max_value;
   sv.null_count = cm.null_count;
   sv.num_values = cm.num_values;
+  sv.typed_order = cm.stats_typed_order;
   return sv;
 }
 

@@ -89,3 +89,40 @@ def test_file_without_an_index_prunes_row_groups_only(built, tmp_path):
     rep = _report(path, t, [S.lt(k, S.lit(50_000, I64))])
     assert rep["page_index_rows_pruned"] == 0 and rep["row_groups_pruned"] >= 1
     assert all(rg["keep"] == [[0, rg["num_rows"]]] for rg in rep["row_groups"])
+
+
+def test_string_columns_prune_by_unsigned_byte_order(built, tmp_path):
+    """min / max of a BYTE_ARRAY column are in unsigned bytewise order — Spark's string order: names that start with bytes ≥ 0x80 ("é…", "日本…") sort
+    BEHIND the ASCII ones; a signed reading would put them first and rule out the wrong row groups.  Row groups and pages, every comparison, a shortened
+    statistic (pyarrow cuts the ColumnIndex's min / max of long values) still a bound."""
+    STR = S.T_STRING
+    rng = np.random.default_rng(4)
+    names = sorted({"name-%07d" % v for v in rng.integers(0, 2_000_000, 120_000)} | {"é-%06d" % v for v in rng.integers(0, 900_000, 40_000)} |
+                   {"日本-%06d-" % v + "x" * 80 for v in rng.integers(0, 900_000, 40_000)}, key=lambda x: x.encode())
+    n = len(names)
+    t = pa.table({"s": pa.array(names, pa.utf8(), mask=rng.random(n) < 0.02), "u": pa.array(rng.integers(0, 100, n), pa.int64())})
+    path = str(tmp_path / "strings.parquet")
+    papq.write_table(t, path, row_group_size=20_000, data_page_size=1 << 12, write_batch_size=500, write_page_index=True)
+    sv = np.array([x.encode() if x is not None else None for x in t.column("s").to_pylist()], dtype=object)
+    valid = np.array([x is not None for x in sv])
+    s = S.col(0, STR)
+
+    def kept(filters, page_index=True):
+        rep = native.parquet_prune_report(S.native_scan([path], ["s", "u"], [STR, I64], data_filters=filters).encode(), page_index)
+        return _kept_mask(rep, n, rg_rows=20_000), rep
+
+    import operator
+    for lit in ("name-1000000", "é-450000", "日本-450000-" + "x" * 80, "a", "zzzz", "\U0001F600"):
+        b = lit.encode()
+        for make, op in ((S.eq, operator.eq), (S.lt, operator.lt), (S.lt_eq, operator.le), (S.gt, operator.gt), (S.gt_eq, operator.ge)):
+            want = np.array([v is not None and op(v, b) for v in sv])
+            for pi in (True, False):
+                m, rep = kept([make(s, S.lit(lit, STR))], pi)
+                assert not (want & ~m).any(), (lit, make.__name__, pi)
+                if pi:
+                    assert m.sum() <= want.sum() + 2 * 20_000 or m.sum() < 0.6 * n, (lit, make.__name__, int(m.sum()), int(want.sum()))
+    # equality deep inside the non-ASCII range: one row group, a page or two
+    m, rep = kept([S.eq(s, S.lit("é-450000", STR))])
+    assert rep["row_groups_pruned"] >= n // 20_000 - 1 and m.sum() < 3000
+    # a literal of another type decides nothing
+    assert kept([S.eq(s, S.lit(5, I64))])[1]["rows"] == n
