@@ -716,6 +716,44 @@ void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, siz
       if (got != dst_len) throw CometError("parquet: lz4 page decompressed to " + std::to_string(got) + " bytes, expected " + std::to_string(dst_len));
       return;
     }
+    case LZ4: {
+      // The deprecated codec (parquet-format Compression.md "LZ4"): Hadoop's BlockCompressorStream framing — a big-endian u32 with the decompressed size
+      // of a chunk, then (big-endian u32 compressed size, raw LZ4 block) until the chunk is covered; chunks repeat.  parquet-mr and parquet-cpp (pyarrow's
+      // compression="lz4") write it; some older writers put one raw block there instead — like the Parquet readers, fall back to that when the framing does not add up.
+      auto be32 = [](const uint8_t* q) { return ((size_t)q[0] << 24) | ((size_t)q[1] << 16) | ((size_t)q[2] << 8) | (size_t)q[3]; };
+      bool framed = true;
+      size_t i = 0, o = 0;
+      try {
+        while (framed && i < src_len) {
+          if (src_len - i < 8) { framed = false; break; }
+          const size_t chunk = be32(src + i);
+          i += 4;
+          if (chunk > dst_len - o) { framed = false; break; }
+          const size_t chunk_end = o + chunk;
+          while (o < chunk_end) {
+            if (src_len - i < 4) { framed = false; break; }
+            const size_t clen = be32(src + i);
+            i += 4;
+            if (clen > src_len - i) { framed = false; break; }
+            const size_t got = lz4_decompress_block(src + i, clen, dst, chunk_end, o);
+            if (got <= o || got > chunk_end) { framed = false; break; }
+            o = got;
+            i += clen;
+          }
+        }
+      } catch (const CometError&) {
+        framed = false;
+      }
+      if (framed && o == dst_len) return;
+      size_t got = 0;
+      try {
+        got = lz4_decompress_block(src, src_len, dst, dst_len, 0);
+      } catch (const CometError&) {
+        got = (size_t)-1;
+      }
+      if (got != dst_len) throw CometError("parquet: an LZ4 page is neither Hadoop-framed nor one raw block of the expected size (" + std::to_string(dst_len) + " bytes)");
+      return;
+    }
     case GZIP: {
       // zlib through dlopen (no headers in the image: z_stream restated; the layout is part of zlib's stable ABI)
       struct ZStream {
@@ -751,7 +789,7 @@ void decompress(int codec, const uint8_t* src, size_t src_len, uint8_t* dst, siz
       if (rc != 1 /* Z_STREAM_END */ || produced != dst_len) throw CometError("parquet: gzip decompression failed");
       return;
     }
-    default: throw CometError("parquet: compression codec " + std::to_string(codec) + " is not supported yet (UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4_RAW are)");
+    default: throw CometError("parquet: compression codec " + std::to_string(codec) + " is not supported (UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4, LZ4_RAW are)");
   }
 }
 

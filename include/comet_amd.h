@@ -281,7 +281,7 @@ int64_t comet_plan_site_error_json(const uint8_t* plan, size_t plan_len, uint32_
 
 /* ---- the host page codecs (csrc/parquet_meta.cpp) ---------------------------------------------------------------------------------------
  * What the scan's host threads run on the pages the device does not decompress itself: Parquet CompressionCodec 0 UNCOMPRESSED, 1 SNAPPY,
- * 2 GZIP, 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and
+ * 2 GZIP, 5 LZ4 (Hadoop-framed, or one raw block), 6 ZSTD, 7 LZ4_RAW; dst_len is the page header's uncompressed_page_size and must match exactly.  Needs no GPU.  0, or -2 and
  * comet_last_error(0). */
 int32_t comet_page_decompress(int32_t codec, const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len);
 /* Diagnostic entry for the scan's sparse reads of snappy pages (parquet_meta.hpp SnappyView: the run headers of a dictionary-encoded page
