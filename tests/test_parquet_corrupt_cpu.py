@@ -59,6 +59,42 @@ def test_random_corruption_never_crashes(built, tmp_path, codec, region):
     assert outcomes["error"] > 0, outcomes
 
 
+def test_corrupted_bloom_filters_never_crash(built, tmp_path):
+    """the filters' headers and bitsets (read by the row-group selection for `column = literal` / IN), and the footer fields that say where they are"""
+    rng = np.random.default_rng(2)
+    n = 6000
+    t = pa.table({"k": pa.array(rng.integers(0, 10**6, n), pa.int64()), "s": pa.array(["str-%d" % int(i) for i in rng.integers(0, 5000, n)])})
+    path = str(tmp_path / "bloom.parquet")
+    papq.write_table(t, path, row_group_size=1500, bloom_filter_options={"k": {"ndv": 1500}, "s": {"ndv": 1500}})
+    raw = bytearray(open(path, "rb").read())
+    k, sc = S.col(0, S.T_INT64), S.col(1, S.T_STRING)
+    plan = S.native_scan([path], ["k", "s"], [S.T_INT64, S.T_STRING], data_filters=[S.or_(S.eq(k, S.lit(77, S.T_INT64)), S.in_(sc, [S.lit("str-1", S.T_STRING), S.lit("nope", S.T_STRING)]))])
+    assert native.parquet_prune_report(plan.encode(), False)["row_groups_pruned_bloom_filter"] >= 1
+    md = papq.ParquetFile(path).metadata
+    footer_len = int.from_bytes(raw[-8:-4], "little")
+    last_page_end = max(md.row_group(g).column(c).data_page_offset + md.row_group(g).column(c).total_compressed_size for g in range(md.num_row_groups) for c in range(2))
+    regions = [(last_page_end, len(raw) - 8 - footer_len), (len(raw) - 8 - footer_len, len(raw) - 4)]      # the filters; the footer
+    assert regions[0][1] - regions[0][0] > 8000
+    bad_path = str(tmp_path / "bad.parquet")
+    open(bad_path, "wb").write(raw)
+    bad_plan = S.native_scan([bad_path], ["k", "s"], [S.T_INT64, S.T_STRING], data_filters=plan.data_filters).encode()
+    outcomes = {"ok": 0, "error": 0}
+    for trial in range(400):
+        lo, hi = regions[trial % 2]
+        bad = bytearray(raw)
+        for pos in rng.integers(lo, hi, int(rng.integers(1, 6))):
+            bad[int(pos)] = int(rng.integers(0, 256))
+        if trial % 4 == 0:      # (a filter is mostly bitset: aim some hits at the first filter's header)
+            bad[regions[0][0] + int(rng.integers(0, 40))] = int(rng.integers(0, 256))
+        open(bad_path, "wb").write(bad)
+        try:
+            native.parquet_prune_report(bad_plan, False)
+            outcomes["ok"] += 1
+        except (native.CometNativeException, native.CometQueryExecutionException):
+            outcomes["error"] += 1
+    assert outcomes["ok"] > 0 and outcomes["error"] > 0, outcomes
+
+
 def test_missing_and_unreadable_files_are_classified_like_the_reference(built, tmp_path):
     """jni-bridge/src/errors.rs:600-735 (try_classify_file_read_error, cannot_read_file_message): a file that is not there is FileNotFound { message }
     with object_store's "Object at location <path> not found" (ShimSparkErrorConverter cuts the path out of it for Spark's
