@@ -11,6 +11,7 @@ import hashlib
 import os
 import re
 import subprocess
+import threading
 import tempfile
 
 import numpy as np
@@ -28,12 +29,96 @@ class Unsupported(Exception):
     pass
 
 
+_RUN_LOCK = threading.Lock()
+
+
 DRIVER = r"""
+// ---- aggregate sinks: the generated per-row code (keys, private words, fold, combine, emit / finalize) with a std::map where the device has its LDS and global hash
+// tables.  A tile's rows meet in a tile-local table of PRIVATE words (P::pop), which is folded (P::fold) into the contribution the global accumulators take
+// (P::op) — the two steps of the device's block; the kernels' own machinery (slots, tickets, rehash, float exponent windows) is not run.
+typedef std::map<std::vector<u64>, std::vector<u64>> EmuTable;
+static EmuTable* g_emu_local = nullptr;
+template <class P, class G, class K, class V>
+static void emu_group_update(const G&, bool active, const K* key, const V* pv) {
+  if (!active) return;
+  std::vector<u64> k(key, key + P::NK);
+  auto it = g_emu_local->find(k);
+  if (it == g_emu_local->end()) {
+    std::vector<u64> w(P::NPW);
+    for (int i = 0; i < P::NPW; i++) w[i] = P::pidentity(i);
+    it = g_emu_local->emplace(k, w).first;
+  }
+  for (int i = 0; i < P::NPW; i++) it->second[i] = comet::pword_combine<P>(i, it->second[i], (u64)pv[i]);
+}
+template <class P>
+static long long emu_grouped(CometKParams& prm) {
+  constexpr i64 kRows = (i64)P::R * comet::kBlock;
+  EmuTable global, local;
+  std::vector<std::vector<u64>> order;
+  comet::GroupCtx<P> grp{};
+  u64 kacc[P::NKW > 0 ? P::NKW : 1];
+  P::kinit(kacc);
+  g_emu_local = &local;
+  for (i64 base = 0; base < prm.n; base += kRows) {
+    local.clear();
+    for (unsigned t = 0; t < 256; t++) {
+      threadIdx.x = t;
+      typename P::L ld;
+      P::tile_load(prm, base, prm.n, ld);
+      P::tile_grouped(prm, base, prm.n, ld, grp, kacc);
+    }
+    for (auto& kv : local) {
+      auto it = global.find(kv.first);
+      if (it == global.end()) {
+        std::vector<u64> acc(P::NW);
+        P::init(acc.data());
+        it = global.emplace(kv.first, acc).first;
+        order.push_back(kv.first);
+      }
+      u64 val[P::NW];
+      P::fold(kv.second.data(), val);
+      comet::slot_apply_private<P>(it->second.data(), val);
+    }
+  }
+  threadIdx.x = 0;
+  // the kernel-level accumulators (value bounds for the overflow proof) land behind the error block's flags, as the kernel's last step leaves them
+  { unsigned long long* aux = (unsigned long long*)prm.out[2] + 2; for (int k = 0; k < P::NKW; k++) aux[k] = P::kop(k) == comet::G_UMAX64 ? (kacc[k] > aux[k] ? kacc[k] : aux[k]) : (aux[k] | kacc[k]); }
+  i64 pos = 0;
+  for (auto& k : order) P::emit_group(prm, k.data(), global[k].data(), pos++);
+  return pos;
+}
+template <class P>
+static long long emu_ungrouped(CometKParams& prm) {
+  constexpr i64 kRows = (i64)P::R * comet::kBlock;
+  u64 acc[P::NW];
+  P::init(acc);
+  for (i64 base = 0; base < prm.n; base += kRows)
+    for (unsigned t = 0; t < 256; t++) {
+      threadIdx.x = t;
+      u64 a[P::NW];
+      P::init(a);
+      typename P::L ld;
+      P::tile_load(prm, base, prm.n, ld);
+      P::tile(prm, base, prm.n, ld, a);
+      P::combine(acc, a);
+    }
+  threadIdx.x = 0;
+  P::kexport(prm, acc);
+  P::finalize(prm, acc);
+  return 1;
+}
+
 template <class P>
 static long long emu_impl(const CometKParams* prm_in) {
   CometKParams prm = *prm_in;
   const i64 n = prm.n;
-  if constexpr (requires { P::keep_tile(prm, (i64)0, n, (bool*)nullptr); }) {
+  if constexpr (requires { P::NPW; P::emit_group(prm, (const u64*)nullptr, (const u64*)nullptr, (i64)0); }) {
+    if constexpr (requires(typename P::L& ld, const comet::GroupCtx<P>& g) { P::tile_grouped(prm, (i64)0, n, ld, g, (u64*)nullptr); }) return emu_grouped<P>(prm);
+    else return -1;
+  } else if constexpr (requires { P::finalize(prm, (const u64*)nullptr); }) {
+    if constexpr (requires(typename P::L& ld) { P::tile(prm, (i64)0, n, ld, (u64*)nullptr); }) return emu_ungrouped<P>(prm);
+    else return -1;
+  } else if constexpr (requires { P::keep_tile(prm, (i64)0, n, (bool*)nullptr); }) {
     constexpr int R = P::R;
     constexpr i64 kRows = (i64)R * comet::kBlock;
     i64 total = 0;
@@ -75,6 +160,7 @@ def _workdir():
         dev = re.sub(r"#define COMET_GLOBAL [^\n]*", "#define COMET_GLOBAL", dev)
         dev = re.sub(r"#define COMET_LDS [^\n]*", "#define COMET_LDS", dev)
         dev = dev.replace("template <> struct as_i64<COMET_LDS u64*> { typedef COMET_LDS i64* type; };", "")
+        dev = dev.replace('__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");', "")      # (the aggregate kernels' bodies only have to COMPILE here)
         open(os.path.join(_DIR, "comet_device.hpp"), "w").write(dev)
         for name in ("kparams.h", "comet_ryu.hpp", "comet_strtod.hpp", "comet_strts.hpp", "comet_regex_vm.hpp"):
             open(os.path.join(_DIR, name), "w").write(native.embedded_header(name))
@@ -86,7 +172,10 @@ def _compiled(source: str):
     if key not in _CACHE:
         d = _workdir()
         cpp = os.path.join(d, key + ".cpp")
-        open(cpp, "w").write('#include "hip_host_shim.hpp"\n' + source + DRIVER)
+        # (the grouped sink's rows go to the driver's table instead of the device's: declared ahead of the generated struct, defined behind it)
+        prefix = ('#include "hip_host_shim.hpp"\n#include <map>\n#include <vector>\n'
+                  'template <class P, class G, class K, class V> static void emu_group_update(const G&, bool, const K*, const V*);\n')
+        open(cpp, "w").write(prefix + source.replace("comet::group_update<P>(", "emu_group_update<P>(") + DRIVER)
         so = os.path.join(d, key + ".so")
         r = subprocess.run(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-fvisibility=hidden", "-fno-gnu-unique", "-Wl,-Bsymbolic", "-I", HERE, "-I", d, "-x", "c++", cpp, "-o", so], capture_output=True, text=True)
         if r.returncode != 0:
@@ -135,10 +224,12 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
     bound = cols + virt
     has_valid = [c.null_count > 0 for c in bound]
     desc = native.plan_codegen(plan if isinstance(plan, (bytes, bytearray)) else plan.encode(), has_valid)
-    if desc["sink"] != 0:
-        raise Unsupported("aggregate sinks are not emulated")
+    if desc["sink"] not in (0, 1, 2):
+        raise Unsupported("sink %d is not emulated" % desc["sink"])
     if desc["derived"]:
         raise Unsupported("derived columns are computed by the executor's own kernels")
+    if "comet::fix_scale(" in desc["source"]:
+        raise Unsupported("Float64 sums / averages: the executor picks their fixed-point scale from a pass of its own")
     lib = _compiled(desc["source"])
     n = table.num_rows
     prm = _Params()
@@ -175,7 +266,10 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
         prm.out[4 + 2 * j] = vals.ctypes.data
         prm.out[5 + 2 * j] = ok.ctypes.data
         outs.append((vals, ok, width))
-    rows = lib.emu_run(ctypes.byref(prm))
+    with _RUN_LOCK:      # (threadIdx and the aggregate driver's table are globals of the shim: one emulated launch at a time)
+        rows = lib.emu_run(ctypes.byref(prm))
+    if rows < 0:
+        raise Unsupported("an aggregate sink of another shape than tile / tile_grouped")
     flags = int(errbuf[:4].view(np.uint32)[0])
     if flags:
         _raise_like_the_executor(flags, errbuf, plan)
@@ -184,8 +278,12 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
         mask = None if not oc["nullable"] else (ok[:rows] == 0)
         if mask is not None and not mask.any():
             mask = None
-        if oc["fmt_kind"] or oc["concat"] or oc["packed_string"] or oc["case_mode"] or oc["pad"]:
+        if oc["fmt_kind"] or oc["concat"] or oc["case_mode"] or oc["pad"]:
             raise Unsupported("output columns the executor formats / concatenates / case-maps / pads")
+        if oc["packed_string"]:      # str16: bytes 0-14 and the length in the last byte (what the executor expands into offsets + data, exec_pipeline.cpp)
+            raw = vals[:rows * 16].reshape(-1, 16)
+            arrays.append(pa.array([None if (mask is not None and mask[r]) else raw[r, :raw[r, 15]].tobytes().decode() for r in range(rows)], pa.utf8()))
+            continue
         if oc["gather_src"] >= 0:
             src = cols[oc["gather_src"]].to_pylist()
             idx = vals[:rows * 4].view(np.uint32)
@@ -226,6 +324,11 @@ def _raise_like_the_executor(flags, block, plan):
     for bit, js in _FLAG_JSON:
         if flags & bit:
             raise native.CometQueryExecutionException(js)
+    if flags & (65536 | 131072):      # the ANSI decimal sum / average of an aggregate sink overflowed (decimal_sum_overflow_json with the aggregate's SQL context)
+        import json
+        raise native.CometQueryExecutionException(json.dumps(native.plan_error_json(plan, -1 if flags & 65536 else -2), separators=(",", ":"), ensure_ascii=False))
+    if flags & 64:
+        raise Unsupported("Utf8 group keys longer than 15 bytes take another path of the executor")
     if flags & 262144:
         raise native.CometNativeException("Arrow error: Compute error: long overflow")
     if flags & 4096:

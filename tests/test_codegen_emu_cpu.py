@@ -1,8 +1,9 @@
 """The GENERATED code on the host: GPU parity tests of Filter / Projection plans run here with tests/emu/codegen_emu.py standing in for the device — the source
 the generator writes for the plan (comet_plan_codegen), compiled by g++ against the header texts hiprtc uses, evaluates every row; the test's own comparison
 with the oracle, its expected errors (the executor's JSON, rebuilt from the error block the code leaves) and its refusals are the test's.  What is NOT covered
-this way: the kernel bodies (ballots, LDS, ordered compaction), the executor behind the kernel (formatting casts to string, concat, case mapping, padding,
-derived columns, subquery resolution), aggregates and joins — those remain the GPU suite's.  What is: every expression's lowering, the common-subexpression
+this way: the kernel bodies (ballots, LDS and global hash tables, ordered compaction), the executor behind the kernel (formatting casts to string, concat, case mapping,
+padding, derived columns, subquery resolution, the fixed-point scale of Float64 sums) and joins — those remain the GPU suite's.  Aggregate sinks ARE covered since the
+round's last session: the generated key / private-word / fold / combine / emit code runs around a std::map in the driver.  What is: every expression's lowering, the common-subexpression
 logic (the time-zone bug of round 5 fails here), the device helpers (decimals, casts, dates, time zones, the regex matcher, string parsers) — without a GPU."""
 import pytest
 
@@ -12,7 +13,8 @@ PLAIN = {
     "tests.test_filter_project_gpu": ["test_bitwise_and_shifts", "test_decimal_division", "test_decimal_projection_narrow_and_wide", "test_empty_input_gives_empty_output",
                                       "test_filter_keeps_only_true_and_valid", "test_integral_divide", "test_more_casts", "test_murmur3_hash_expression",
                                       "test_projection_only_int_wrapping_and_float", "test_reference_planner_case_col_eq_3", "test_remainder_decimal", "test_remainder_int_and_float",
-                                      "test_round_and_date_arithmetic", "test_the_references_modulo_vectors", "test_try_casts_to_integers", "test_unary_minus"],
+                                      "test_round_and_date_arithmetic", "test_the_references_modulo_vectors", "test_try_casts_to_integers", "test_unary_minus",
+                                      "test_case_when_projection_and_conditional_sum", "test_coalesce", "test_scalar_functions_exact_subset"],
     "tests.test_string_casts_gpu": ["test_ansi_raises_where_the_reference_raises", "test_parsed_values_feed_filters_and_arithmetic", "test_strings_to_floats",
                                     "test_timestamp_strings_under_ansi_and_the_refusals", "test_unknown_time_zones_are_refused_by_name",
                                     # (the executor's error text — the site's JSON with the plan's SQL context — is rebuilt by comet_plan_site_error_json)
@@ -23,12 +25,20 @@ PLAIN = {
     "tests.test_temporal_casts_gpu": ["test_cast_date_as_int", "test_floats_and_decimals_to_timestamps", "test_the_references_date_to_timestamp_vectors"],
     "tests.test_rlike_gpu": ["test_unsupported_patterns_fail_at_create_plan"],
     "tests.test_aligned_import_gpu": ["test_reference_under_aligned_decimal128_kat", "test_under_aligned_decimal_10_2_in_domain_values"],
-    "tests.test_utf8_passthrough_gpu": ["test_like_and_string_predicates", "test_string_predicates_any_length"],
+    "tests.test_utf8_passthrough_gpu": ["test_like_and_string_predicates", "test_string_predicates_any_length", "test_substring_as_filter_and_group_key"],
+    # aggregate sinks (the generated keys / private words / fold / combine / emit around a std::map; Float64 sums excepted): Q6, Q1, Partial → Final, ANSI decimal sums
+    "tests.test_q6_gpu": ["test_q6_chunked_execution_equals_single_chunk", "test_q6_empty_input_emits_one_state_row", "test_q6_nothing_passes_filter", "test_q6_with_nulls_matches_oracle"],
+    "tests.test_q1_gpu": ["test_grouped_empty_input_emits_nothing", "test_high_cardinality_int_keys_grow_the_table", "test_null_group_keys_and_null_values", "test_q1_chunked_equals_unchunked"],
+    "tests.test_final_agg_gpu": ["test_ansi_decimal_sums_raise_where_legacy_ones_turn_null", "test_final_with_overflowed_partial_is_null", "test_q1_partial_then_final",
+                                 "test_q6_final_of_empty_partials_is_null", "test_q6_partial_then_final"],
     "tests.test_split_gpu": ["test_what_split_refuses"], "tests.test_strfn_gpu": ["test_refusals"], "tests.test_string_views_gpu": ["test_long_pad_strings_are_refused"],
     # (a Scan with list columns: the element columns are bound behind the real ones, as the executor does)
     "tests.test_list_exprs_gpu": ["test_array_contains", "test_elements_by_position", "test_errors_of_the_reference_and_refusals", "test_size_and_nullness"],
 }
-PARAMS = [("tests.test_filter_project_gpu", "test_config1_project_filter_1m_rows", dict(nulls=False)), ("tests.test_filter_project_gpu", "test_config1_project_filter_1m_rows", dict(nulls=True)),
+PARAMS = [("tests.test_q6_gpu", "test_q6_host_stream_matches_oracle", dict(n=n)) for n in (1, 64, 65, 100_003, 1 << 20)] + \
+         [("tests.test_q1_gpu", "test_q1_host_stream_matches_oracle", dict(n=n)) for n in (1, 8192, 200_003)] + \
+         [("tests.test_aligned_import_gpu", "test_under_aligned_decimal_column_through_filter_and_sum", dict(batch_rows=1000)),
+          ("tests.test_filter_project_gpu", "test_config1_project_filter_1m_rows", dict(nulls=False)), ("tests.test_filter_project_gpu", "test_config1_project_filter_1m_rows", dict(nulls=True)),
           ("tests.test_string_casts_gpu", "test_string_to_values", dict(mode=0)),
           ("tests.test_string_casts_gpu", "test_string_to_values", dict(mode=1)), ("tests.test_string_casts_gpu", "test_strings_to_timestamps", dict(tz="America/New_York")),
           ("tests.test_string_casts_gpu", "test_strings_to_timestamps", dict(tz="+05:30")),
@@ -68,3 +78,27 @@ def test_one_child_in_several_zones_is_several_values(built):
     for i in range(3):
         assert got.column(i).to_pylist() == want.column(i).to_pylist(), i
     assert got.column(0).to_pylist() != got.column(1).to_pylist()
+
+
+def test_a_wrong_addend_in_an_aggregate_sink_is_caught(built, monkeypatch):
+    """the emulation of aggregate sinks is not vacuous: with every addend of the first sum one too large in the generated source — the ungrouped sink's feed, the
+    grouped sink's first limb — the Q6 and Q1 parity tests fail"""
+    import re
+    from datafusion_comet_amd import native
+    orig = native.plan_codegen
+    changed = []
+
+    def mutated(plan, has_valid):
+        d = orig(plan, has_valid)
+        src = re.sub(r"comet::acc_feed_i128\(acc \+ (\d+), ", r"comet::acc_feed_i128(acc + \1, (i128)1 + ", d["source"], count=1)
+        if src == d["source"]:
+            src = re.sub(r"comet::limb_of\(", "comet::limb_of((i128)1 + ", src, count=1)
+        changed.append(src != d["source"])
+        d["source"] = src
+        return d
+
+    monkeypatch.setattr(native, "plan_codegen", mutated)
+    for module, fn, params in (("tests.test_q6_gpu", "test_q6_with_nulls_matches_oracle", {}), ("tests.test_q1_gpu", "test_q1_host_stream_matches_oracle", dict(n=8192))):
+        with pytest.raises(AssertionError):
+            E.run_gpu_test_on_host(module, fn, **params)
+    assert changed and all(changed)
