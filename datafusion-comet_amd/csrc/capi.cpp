@@ -515,6 +515,9 @@ int64_t comet_plan_codegen(const uint8_t* plan, size_t plan_len, const uint8_t* 
            std::to_string(oc.fmt_kind) + ",\"packed_string\":" + (oc.packed_string ? "true" : "false") + ",\"concat\":" + std::to_string(oc.concat_cols.size()) + ",\"case_mode\":" +
            std::to_string(oc.case_mode) + ",\"pad\":" + json_str(oc.pad_pattern) + ",\"pad_left\":" + (oc.pad_left ? "true" : "false") + "}";
     }
+    j += "],\"fix_sums\":[";      // exact Float64 sums: the accumulator word and the aux words (exponent range seen) of each, for the scale pass (exec_pipeline.cpp adjust_fix_scales)
+    for (size_t k = 0; k < d.fix_sums.size(); k++)
+      j += std::string(k ? "," : "") + "{\"word\":" + std::to_string(d.fix_sums[k].word) + ",\"aux_hi\":" + std::to_string(d.fix_sums[k].aux_hi) + ",\"aux_lo\":" + std::to_string(d.fix_sums[k].aux_lo) + "}";
     j += "],\"source\":" + json_str(d.source) + "}";
     if (out && cap > (int64_t)j.size()) memcpy(out, j.c_str(), j.size() + 1);
     return (int64_t)j.size();

@@ -228,8 +228,6 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
         raise Unsupported("sink %d is not emulated" % desc["sink"])
     if desc["derived"]:
         raise Unsupported("derived columns are computed by the executor's own kernels")
-    if "comet::fix_scale(" in desc["source"]:
-        raise Unsupported("Float64 sums / averages: the executor picks their fixed-point scale from a pass of its own")
     lib = _compiled(desc["source"])
     n = table.num_rows
     prm = _Params()
@@ -266,8 +264,28 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
         prm.out[4 + 2 * j] = vals.ctypes.data
         prm.out[5 + 2 * j] = ok.ctypes.data
         outs.append((vals, ok, width))
-    with _RUN_LOCK:      # (threadIdx and the aggregate driver's table are globals of the shim: one emulated launch at a time)
-        rows = lib.emu_run(ctypes.byref(prm))
+    # exact Float64 sums: the executor's scale pass (exec_pipeline.cpp: run, read the exponent range the kernel left in the aux words, move the fixed-point window,
+    # run again — three times at most; one chunk here, so nothing has been accumulated before and the window may move down as well as up)
+    FIX_W, scales = 158, [-94] * len(desc.get("fix_sums", []))
+    for attempt in range(4):
+        prm.iarg[6] = sum((sc & 0xffff) << (16 * f) for f, sc in enumerate(scales))
+        with _RUN_LOCK:      # (threadIdx and the aggregate driver's table are globals of the shim: one emulated launch at a time)
+            rows = lib.emu_run(ctypes.byref(prm))
+        if not scales or attempt >= 3:
+            break
+        aux = errbuf[16:].view(np.uint64)
+        moved = False
+        for f, fs in enumerate(desc["fix_sums"]):
+            hi, lo = int(aux[fs["aux_hi"]]), int(aux[fs["aux_lo"]])
+            if hi == 0:
+                continue
+            top, low, sc = hi - 1200, 1200 - lo, scales[f]
+            target = top + 10 - FIX_W if top > sc + FIX_W else ((low if top - low <= FIX_W - 10 else top + 2 - FIX_W) if low < sc else sc)
+            target = max(target, -1300)
+            if target != sc:
+                scales[f], moved = target, True
+        if not moved:
+            break
     if rows < 0:
         raise Unsupported("an aggregate sink of another shape than tile / tile_grouped")
     flags = int(errbuf[:4].view(np.uint32)[0])

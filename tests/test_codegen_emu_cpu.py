@@ -2,7 +2,7 @@
 the generator writes for the plan (comet_plan_codegen), compiled by g++ against the header texts hiprtc uses, evaluates every row; the test's own comparison
 with the oracle, its expected errors (the executor's JSON, rebuilt from the error block the code leaves) and its refusals are the test's.  What is NOT covered
 this way: the kernel bodies (ballots, LDS and global hash tables, ordered compaction), the executor behind the kernel (formatting casts to string, concat, case mapping,
-padding, derived columns, subquery resolution, the fixed-point scale of Float64 sums) and joins — those remain the GPU suite's.  Aggregate sinks ARE covered since the
+padding, derived columns, subquery resolution) and joins — those remain the GPU suite's.  Aggregate sinks ARE covered since the
 round's last session: the generated key / private-word / fold / combine / emit code runs around a std::map in the driver.  What is: every expression's lowering, the common-subexpression
 logic (the time-zone bug of round 5 fails here), the device helpers (decimals, casts, dates, time zones, the regex matcher, string parsers) — without a GPU."""
 import pytest
@@ -31,12 +31,18 @@ PLAIN = {
     "tests.test_q1_gpu": ["test_grouped_empty_input_emits_nothing", "test_high_cardinality_int_keys_grow_the_table", "test_null_group_keys_and_null_values", "test_q1_chunked_equals_unchunked"],
     "tests.test_final_agg_gpu": ["test_ansi_decimal_sums_raise_where_legacy_ones_turn_null", "test_final_with_overflowed_partial_is_null", "test_q1_partial_then_final",
                                  "test_q6_final_of_empty_partials_is_null", "test_q6_partial_then_final"],
+    # exact Float64 sums: the executor's scale pass (run, read the exponent range, move the fixed-point window, run again) is the emulator's
+    "tests.test_float_agg_gpu": ["test_exponent_window_moves_with_the_data", "test_non_finite_addends_follow_ieee", "test_ungrouped_sum_and_avg_are_the_correctly_rounded_exact_sum",
+                                 "test_within_one_ulp_of_the_sequential_reference_where_that_is_exact"],
     "tests.test_split_gpu": ["test_what_split_refuses"], "tests.test_strfn_gpu": ["test_refusals"], "tests.test_string_views_gpu": ["test_long_pad_strings_are_refused"],
     # (a Scan with list columns: the element columns are bound behind the real ones, as the executor does)
     "tests.test_list_exprs_gpu": ["test_array_contains", "test_elements_by_position", "test_errors_of_the_reference_and_refusals", "test_size_and_nullness"],
 }
 PARAMS = [("tests.test_q6_gpu", "test_q6_host_stream_matches_oracle", dict(n=n)) for n in (1, 64, 65, 100_003, 1 << 20)] + \
          [("tests.test_q1_gpu", "test_q1_host_stream_matches_oracle", dict(n=n)) for n in (1, 8192, 200_003)] + \
+         [("tests.test_float_agg_gpu", "test_grouped_sums_low_and_high_cardinality", dict(ngroups=g)) for g in (5, 40_000)] + \
+         [("tests.test_final_agg_gpu", fn, dict(grouped=g)) for fn in ("test_partial_merge_then_final", "test_count_distinct_rewrite_with_mixed_mode_aggregate") for g in (False, True)] + \
+         [("tests.test_fuzz_gpu", "test_random_grouped_aggregate", dict(seed=sd)) for sd in range(8)] + \
          [("tests.test_aligned_import_gpu", "test_under_aligned_decimal_column_through_filter_and_sum", dict(batch_rows=1000)),
           ("tests.test_filter_project_gpu", "test_config1_project_filter_1m_rows", dict(nulls=False)), ("tests.test_filter_project_gpu", "test_config1_project_filter_1m_rows", dict(nulls=True)),
           ("tests.test_string_casts_gpu", "test_string_to_values", dict(mode=0)),
@@ -54,6 +60,12 @@ def test_gpu_parity_test_on_the_host(built, module, fn):
 @pytest.mark.parametrize("module,fn,params", PARAMS, ids=[f"{f}-{list(p.values())[0]}" for _, f, p in PARAMS])
 def test_parametrized_gpu_parity_test_on_the_host(built, module, fn, params):
     assert E.run_gpu_test_on_host(module, fn, **params) == "ok"
+
+
+def test_aggregate_fuzz_beyond_the_gpu_suites_seeds(built):
+    """the grouped-aggregate generator with seeds the GPU suite does not run (it runs 0..23)"""
+    for seed in range(24, 48):
+        assert E.run_gpu_test_on_host("tests.test_fuzz_gpu", "test_random_grouped_aggregate", seed=seed) == "ok", seed
 
 
 @pytest.mark.parametrize("first", [64, 96, 128, 160])
