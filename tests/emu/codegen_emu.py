@@ -167,17 +167,36 @@ def _workdir():
     return _DIR
 
 
+_FLAGS = ["-std=c++20", "-O1", "-fPIC", "-w", "-ffp-contract=off", "-fvisibility=hidden", "-fno-gnu-unique"]
+_PCH = {}
+
+
+def _prefix_header(nt: bool) -> str:
+    """the shim, the containers the aggregate driver uses and the device header, precompiled once per process (a plan then compiles in 0.4 s instead of 0.65):
+    with COMET_LD_NT = 1 for the sources that define it (aggregate sinks), without for the others — what the source's own first lines would have done"""
+    name = "emu_prefix_nt.hpp" if nt else "emu_prefix.hpp"
+    if name not in _PCH:
+        d = _workdir()
+        hdr = os.path.join(d, name)
+        open(hdr, "w").write('#include "hip_host_shim.hpp"\n#include <map>\n#include <vector>\n' + ("#define COMET_LD_NT 1\n" if nt else "") + '#include "comet_device.hpp"\n')
+        r = subprocess.run(["g++"] + _FLAGS + ["-I", HERE, "-I", d, "-x", "c++-header", hdr, "-o", hdr + ".gch"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("the device header does not compile for the host:\n" + r.stderr[:3000])
+        _PCH[name] = True
+    return name
+
+
 def _compiled(source: str):
     key = hashlib.sha1(source.encode()).hexdigest()[:20]
     if key not in _CACHE:
         d = _workdir()
         cpp = os.path.join(d, key + ".cpp")
         # (the grouped sink's rows go to the driver's table instead of the device's: declared ahead of the generated struct, defined behind it)
-        prefix = ('#include "hip_host_shim.hpp"\n#include <map>\n#include <vector>\n'
+        prefix = ('#include "%s"\n' % _prefix_header("#define COMET_LD_NT 1" in source) +
                   'template <class P, class G, class K, class V> static void emu_group_update(const G&, bool, const K*, const V*);\n')
         open(cpp, "w").write(prefix + source.replace("comet::group_update<P>(", "emu_group_update<P>(") + DRIVER)
         so = os.path.join(d, key + ".so")
-        r = subprocess.run(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-fvisibility=hidden", "-fno-gnu-unique", "-Wl,-Bsymbolic", "-I", HERE, "-I", d, "-x", "c++", cpp, "-o", so], capture_output=True, text=True)
+        r = subprocess.run(["g++"] + _FLAGS + ["-shared", "-Wl,-Bsymbolic", "-I", HERE, "-I", d, "-x", "c++", cpp, "-o", so], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("the generated source does not compile for the host:\n" + "\n".join(l for l in r.stderr.splitlines() if "error" in l)[:3000])
         lib = ctypes.CDLL(so)

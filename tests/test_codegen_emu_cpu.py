@@ -64,11 +64,11 @@ def test_parametrized_gpu_parity_test_on_the_host(built, module, fn, params):
 
 def test_aggregate_fuzz_beyond_the_gpu_suites_seeds(built):
     """the grouped-aggregate generator with seeds the GPU suite does not run (it runs 0..23)"""
-    for seed in range(24, 48):
+    for seed in range(24, 40):
         assert E.run_gpu_test_on_host("tests.test_fuzz_gpu", "test_random_grouped_aggregate", seed=seed) == "ok", seed
 
 
-@pytest.mark.parametrize("first", [64, 96, 128, 160])
+@pytest.mark.parametrize("first", [64, 128])
 def test_expression_fuzz_beyond_the_gpu_suites_seeds(built, first):
     """tests/test_fuzz_gpu.py's random Filter / Projection plans under seeds the GPU suite does not run (it runs 0 … 63): 32 plans per case, generated code against the oracle.
     (Seeds 64 … 463 were walked once by hand: two differences, both the SIGN BIT of a NaN out of -(0.0 / 0.0) — x86's default NaN is negative, numpy's negation makes it
