@@ -819,11 +819,20 @@ bool prunes(const Expr& pred, const std::vector<StructField>& schema, const pq::
     return !pred.children.empty();
   }
   LeafCol col;
-  if (pred.kind == ExprKind::In && !pred.negated && pred.children.size() >= 2) {      // column IN (literals): a filter may rule every one of them out
-    if (!bloom || !leaf_column(*pred.children[0], schema, fm, rg.columns.size(), case_sensitive, col)) return false;
-    std::vector<const Expr*> lits;
-    for (size_t i = 1; i < pred.children.size(); i++) lits.push_back(pred.children[i].get());
-    if (!bloom_proves_absent(col, lits.data(), lits.size(), *bloom)) return false;
+  if (pred.kind == ExprKind::In && !pred.negated && pred.children.size() >= 2) {
+    // column IN (literals): every literal must be ruled out — by the chunk's min / max, and what they leave by its Bloom filter
+    if (!leaf_column(*pred.children[0], schema, fm, rg.columns.size(), case_sensitive, col)) return false;
+    const StatView sv = chunk_stats(rg.columns[(size_t)col.leaf]);
+    std::vector<const Expr*> left;
+    for (size_t i = 1; i < pred.children.size(); i++) {
+      const Expr* l = pred.children[i].get();
+      if (l->kind != ExprKind::Literal) return false;
+      if (l->lit_null) continue;      // a NULL in the list matches nothing
+      const LeafPred eq{ExprKind::Eq, pred.children[0].get(), l};
+      if (!stats_prove_false(eq, col, sv)) left.push_back(l);
+    }
+    if (left.empty()) return true;
+    if (!bloom || !bloom_proves_absent(col, left.data(), left.size(), *bloom)) return false;
     if (by_bloom) *by_bloom = true;
     return true;
   }

@@ -126,3 +126,21 @@ def test_string_columns_prune_by_unsigned_byte_order(built, tmp_path):
     assert rep["row_groups_pruned"] >= n // 20_000 - 1 and m.sum() < 3000
     # a literal of another type decides nothing
     assert kept([S.eq(s, S.lit(5, I64))])[1]["rows"] == n
+
+
+def test_in_lists_prune_by_statistics(built, tmp_path):
+    """column IN (literals): a row group is ruled out when min / max rule out EVERY literal (NULLs in the list match nothing); NOT IN decides nothing"""
+    path, t = _file(tmp_path, "inlist.parquet", index=False)
+    k = S.col(0, I64)
+    kv = np.asarray(t.column("k"))
+    L = lambda v: S.lit(v, I64)
+    for items in ([10, 20, 999_990], [500_000], [-5, 2_000_000], [10, None]):
+        rep = _report(path, t, [S.in_(k, [L(v) for v in items])], page_index=False)
+        kept = _kept_mask(rep, t.num_rows)
+        want = np.isin(kv, [v for v in items if v is not None])
+        assert not (want & ~kept).any(), items
+        assert rep["row_groups_pruned"] >= 1 and rep["row_groups_pruned_bloom_filter"] == 0, items
+    assert _report(path, t, [S.in_(k, [L(-5), L(2_000_000)])], page_index=False)["rows"] == 0
+    assert _report(path, t, [S.in_(k, [L(-5)], negated=True)], page_index=False)["rows"] == t.num_rows
+    # a list with something that is not a literal decides nothing
+    assert _report(path, t, [S.in_(k, [L(-5), S.col(2, I64)])], page_index=False)["rows"] == t.num_rows
