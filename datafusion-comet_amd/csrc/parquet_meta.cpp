@@ -193,8 +193,8 @@ ColumnMeta read_column_meta(TReader& r) {
       case 7: m.total_compressed = r.zigzag(); break;
       case 9: m.data_page_offset = r.zigzag(); break;
       case 11: m.dictionary_page_offset = r.zigzag(); break;
-      case 14: m.bloom_filter_offset = r.zigzag(); break;
-      case 15: m.bloom_filter_length = (int32_t)r.zigzag(); break;
+      case 14: if (t == 6) m.bloom_filter_offset = r.zigzag(); else r.skip(t); break;
+      case 15: if (t == 5) m.bloom_filter_length = (int32_t)r.zigzag(); else r.skip(t); break;
       case 12: {   // Statistics
         int16_t f2 = 0;
         std::string mn, mx, mn_old, mx_old;
