@@ -372,7 +372,19 @@ def main():
             line["exchange_probe"] = legs["exchange_probe"]
         if pmc:
             line["pmc"] = pmc
-        print(json.dumps(line))
+        # the complete record (per-kernel lists, notes, PMC tables) next to the run; the printed line is its short form (< 6 KB: what the driver's record keeps)
+        full_path = None
+        try:
+            out_dir = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out_dir, exist_ok=True)
+            full_path = os.path.join(out_dir, f"bench_full_n{world}.json")
+            with open(full_path, "w") as f:
+                json.dump(line, f)
+        except OSError:
+            full_path = None
+        short = compact_line(line)
+        short["full_record"] = os.path.relpath(full_path, ROOT) if full_path else None
+        print(json.dumps(short, separators=(",", ":")))
     if world > 1:
         dist.destroy_process_group()
         fell_back = not args.no_extra_legs and (args.q3_orders > 0 or args.q95_orders > 0) and exchange != "native"
@@ -380,6 +392,104 @@ def main():
             fell_back = fell_back or any((legs.get(k) or {}).get("exit_code") == 4 for k in ("q3", "q95"))
         if fell_back and not args.allow_fallback:
             sys.exit(4)      # the multi-GPU legs did not run over the in-library RCCL exchange: the line says so, and so does the exit code
+
+
+def _r(x, nd=3):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE line the driver keeps is the last ≈ 6 KB of stdout: the headline fields, a short `roofline` and `cpu_baseline`, and every extra leg's numbers FLAT under
+    `legs` — the per-kernel lists, notes and PMC tables go to the sidecar file `full_record` names."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _r(full[k], 4) for k in keep if k in full}
+    cfg = full.get("config", {})
+    line["config"] = {"workload": cfg.get("workload"), "rows_per_gpu": cfg.get("rows_per_gpu"), "bytes_per_row_algorithmic": cfg.get("bytes_per_row_algorithmic"),
+                      "parallelism": cfg.get("parallelism")}
+    ro = full.get("roofline", {})
+    line["roofline"] = {"bound": ro.get("bound"), "achieved": _r(ro.get("achieved"), 1), "peak": ro.get("peak"), "unit": ro.get("unit"), "frac": _r(ro.get("frac"), 4),
+                        "traffic": ro.get("traffic"), "algorithmic_bytes": ro.get("algorithmic_bytes"), "kernel_ms": _r(ro.get("kernel_ms"), 4),
+                        "kernels": [{"name": k.get("name"), "ms": _r(k.get("ms"), 4), "frac": _r(k.get("frac"), 4)} for k in ro.get("kernels", [])],
+                        "task_level_frac": _r((ro.get("task_level") or {}).get("frac"), 4)}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {"value": _r(cb.get("value"), 0), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": str(cb.get("sample"))[:120]}
+        ca = full.get("cpu_baseline_all_cores") or {}
+        line["cpu_baseline_all_cores"] = {"value": _r(ca.get("value"), 0), "cores": ca.get("cores")}
+    rc = full.get("result_check") or {}
+    line["verified"] = rc.get("all_8_aggregates_of_all_groups_match_torch_on_every_rank")
+    legs = {}
+
+    def put(k, v, nd=3):
+        if v is not None:
+            legs[k] = _r(v, nd)
+
+    def top_kernels(roof, n=6):
+        ks = sorted((roof or {}).get("kernels") or [], key=lambda k: -(k.get("ms") or 0))[:n]
+        return {k["name"]: _r(k.get("ms"), 3) for k in ks if k.get("name")}
+
+    for name in ("q3", "q95"):
+        q = full.get(name)
+        if not q:
+            continue
+        if "error" in q:
+            legs[name + "_error"] = str(q["error"])[:160]
+            continue
+        roof = q.get("roofline") or {}
+        put(name + "_ms", q.get("sec_per_run") and q["sec_per_run"] * 1e3)
+        put(name + "_frac", roof.get("frac"), 4)
+        put(name + "_traffic_over_algorithmic", (roof.get("traffic") / roof["algorithmic_bytes"]) if roof.get("traffic") and roof.get("algorithmic_bytes") else None)
+        put(name + "_kernel_ms_total", roof.get("kernel_ms_total_rank0"))
+        put(name + "_dominant_kernel", roof.get("dominant_kernel"))
+        legs[name + "_kernels_ms"] = top_kernels(roof)
+        for sk, sv in (q.get("stage_ms_rank0") or {}).items():
+            put(f"{name}_stage_{sk}_ms", sv)
+        put(name + "_verified", q.get("verified", q.get("verified_vs_torch")))
+        put(name + "_exchange_transport", q.get("exchange_transport"))
+        put(name + "_n_gpus", q.get("n_gpus"))
+    for key, tag in (("q6_sf100", "q6_sf100"), ("q6", "q6"), ("q6_sf10", "q6_sf10")):
+        q = full.get(key)
+        if q and "error" not in q:
+            put(tag + "_kernel_ms", q.get("kernel_ms"), 4)
+            put(tag + "_task_ms", q.get("ms_per_task"), 4)
+            put(tag + "_physical_frac", (q.get("roofline") or {}).get("frac"), 4)
+            put(tag + "_verified", q.get("verified_vs_torch"))
+    pq = full.get("q6_sf10_parquet") or {}
+    for c in ("snappy", "zstd"):
+        e = pq.get(c)
+        if e and "error" not in e:
+            put(f"pq6_{c}_ms", e.get("ms_best"))
+            put(f"pq6_{c}_ms_median", e.get("ms_median"))
+            put(f"pq6_{c}_frac_of_link", (e.get("roofline") or {}).get("frac"), 4)
+            put(f"pq6_{c}_floor_ms", (e.get("roofline") or {}).get("floor_ms_at_measured_link"))
+            put(f"pq6_{c}_matches_resident", e.get("matches_resident_plan"))
+        elif e:
+            legs[f"pq6_{c}_error"] = str(e.get("error"))[:120]
+    one = pq.get("zstd_one_scan_thread") or {}
+    put("pq6_zstd_one_thread_device_ms", (one.get("device") or {}).get("ms_best"))
+    put("pq6_zstd_one_thread_host_ms", (one.get("host") or {}).get("ms_best"))
+    ex = full.get("executor_shape") or {}
+    put("link_GBps", ex.get("pcie_link_GBps_measured"), 2)
+    for leg, tag in (("parquet_snappy", "snappy"), ("parquet_zstd", "zstd"), ("host_stream", "host")):
+        for t in ("tasks_8", "tasks_16"):
+            e = ((ex.get("legs") or {}).get(leg) or {}).get(t) or {}
+            put(f"exec_{tag}_{t[6:]}_frac", e.get("frac_of_measured_link"), 4)
+            put(f"exec_{tag}_{t[6:]}_ms", e.get("wall_ms"))
+            put(f"exec_{tag}_{t[6:]}_ms_median", e.get("wall_ms_median"))
+    for key, tag in (("snappy_pipeline", "snappy"), ("zstd_pipeline", "zstd")):
+        for kind, e in (full.get(key) or {}).items():
+            if isinstance(e, dict) and "pipeline" in e:
+                put(f"{tag}_{kind}_out_GBps", e["pipeline"].get("out_GBps"), 1)
+    pt = full.get("paths") or {}
+    put("host_stream_rows_per_s", (pt.get("host_arrow_stream") or {}).get("rows_per_s"), 0)
+    put("parquet_path_rows_per_s", (pt.get("parquet") or {}).get("rows_per_s"), 0)
+    put("cold_create_plan_ms", full.get("cold_create_plan_ms"), 1)
+    tl = (ro.get("task_level_with_declared_fixed_len") or {})
+    put("headline_ms_with_declared_fixed_len", tl.get("ms"))
+    if full.get("exchange_probe") is not None:
+        put("exchange_probe_ok", (full["exchange_probe"] or {}).get("ok"))
+    line["legs"] = legs
+    return line
 
 
 def cpu_baseline(args, dtab, plan_bytes, local_rank):

@@ -2160,7 +2160,8 @@ struct Gen {
       // datafusion-spark SparkFactorial (Spark's Factorial): Int32 in 0..20 → its factorial as Int64, NULL outside
       Val a = arg(0);
       if (a.t.id != TypeId::Int32) throw CometError("factorial expects an Int32 argument");
-      decls += "    static const i64 fact_tab[21] = {1ll,1ll,2ll,6ll,24ll,120ll,720ll,5040ll,40320ll,362880ll,3628800ll,39916800ll,479001600ll,6227020800ll,87178291200ll,1307674368000ll,"
+      if (decls.find("fact_tab[21]") == std::string::npos)      // once per kernel: two distinct factorial calls share the table
+        decls += "    static const i64 fact_tab[21] = {1ll,1ll,2ll,6ll,24ll,120ll,720ll,5040ll,40320ll,362880ll,3628800ll,39916800ll,479001600ll,6227020800ll,87178291200ll,1307674368000ll,"
                "20922789888000ll,355687428096000ll,6402373705728000ll,121645100408832000ll,2432902008176640000ll};\n";
       r.t = DType::of(TypeId::Int64);
       r.rep = Rep::I64;
@@ -4255,6 +4256,25 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
         << g.decls << g.body() << "    return " << e << ";\n  }\n";
   }
   {
+    // cond(i, j): the residual condition ALONE — what the bucket table still has to ask of a build row whose one-word key its entry settled
+    if (j.join_condition) {
+      Gen g(ct, cv);
+      g.locate = locate_combined;
+      std::map<const Expr*, ExprP> m2;
+      Val c = g.gen(substitute(j.join_condition, phys, m2));
+      Val r;
+      r.rep = Rep::B;
+      r.v = Gen::and_ok(c.ok, c.v);
+      r = g.named(r);
+      std::string e = r.v;
+      for (size_t p0 = e.find("[r]"); p0 != std::string::npos; p0 = e.find("[r]")) e.replace(p0, 3, "[0]");
+      src << "  static __device__ __forceinline__ bool cond(const CometKParams& prm, i64 i, i64 j) {\n    bool k[R] = {true};\n"
+          << g.decls << g.body() << "    return " << e << ";\n  }\n";
+    } else {
+      src << "  static __device__ __forceinline__ bool cond(const CometKParams&, i64, i64) { return true; }\n";
+    }
+  }
+  {
     // emit(i, j, pos): output = left columns then right columns (Inner / outer); left columns only (Semi/Anti).
     // Outer joins add emit_probe_only(j, pos) / emit_build_only(i, pos): the other side's columns are NULL.
     const int nout = (mode == 0 && !build_only) ? nl + nr : nl;
@@ -4353,7 +4373,18 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jdrows(const CometKParams prm) { comet::join_direct_rows_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jdprobe(const CometKParams prm) { comet::join_probe_direct_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbmap(const CometKParams prm) { comet::join_keymap_build_body<P>(prm); }\n";
-  d.kernels = {"k_jbuild", "k_jbcnt", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jprobe_km", "k_jlds", "k_jsample", "k_jbmap", "k_jdrows", "k_jdprobe"};
+  // the bucket table (comet_device.hpp template D''): partition passes, the LDS build, the probes; and the bitmap-only semi / anti join
+  src << "extern \"C\" __global__ __launch_bounds__(1024) void k_jphist(const CometKParams prm) { comet::join_part_hist_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(1024) void k_jpscat(const CometKParams prm) { comet::join_part_scatter_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jtbuild(const CometKParams prm) { comet::join_table_build_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe_b(const CometKParams prm) { comet::join_probe_bucket_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe_bkm(const CometKParams prm) { comet::join_probe_bucket_body<P, true>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jsample_b(const CometKParams prm) { comet::join_sample_bucket_body<P>(prm); }\n";
+  if (dedup_build) src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe_bm(const CometKParams prm) { comet::join_probe_bitmap_body<P>(prm); }\n";
+  d.kernels = {"k_jbuild", "k_jbcnt", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jprobe_km", "k_jlds", "k_jsample", "k_jbmap", "k_jdrows", "k_jdprobe",
+               "k_jphist", "k_jpscat", "k_jtbuild", "k_jprobe_b", "k_jprobe_bkm", "k_jsample_b"};
+  if (dedup_build) d.kernels.push_back("k_jprobe_bm");
+  d.join_dedup_build = dedup_build;
   d.join_outer_build = outer_build;
   d.join_build_only = build_only;
   const char* jt_name = build_only ? (keep_matched ? "LeftSemi" : "LeftAnti") : keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";

@@ -85,6 +85,7 @@ struct PipelineDesc {
   std::vector<int> sort_str_cols;
   bool join_build_only = false;     // LeftSemi/LeftAnti built on the left: only the tail pass produces rows
   bool join_outer_build = false;    // hash join that must also emit the build rows no probe row matched
+  bool join_dedup_build = false;    // semi / anti join that keeps probe rows and has no residual condition: only a key's existence matters
   std::string explain;             // human-readable fused plan
   std::vector<std::string> op_names;  // operator names root→leaf (metrics tree / tracing label)
   // grouped aggregates: source columns that serve DIRECTLY as Utf8 group keys (the executor measures their longest value: above 15

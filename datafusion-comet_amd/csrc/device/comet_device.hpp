@@ -2531,6 +2531,8 @@ constexpr int kJoinR0 = 16;                  // probe rows per thread and tile: 
 template <class P>
 struct JoinGlobalTable {
   static constexpr bool BY_KEY = false;      // peek() takes the key's hash
+  typedef u32 Entry;                         // what peek() hands out: the bucket's head
+  static CDEV Entry none() { return kJoinNoRow; }
   const u32* head;
   const i32* next;
   u64 mask;
@@ -2594,6 +2596,8 @@ struct JoinGlobalTable {
 template <class P>
 struct JoinLdsTable {
   static constexpr bool BY_KEY = false;
+  typedef u32 Entry;
+  static CDEV Entry none() { return kJoinEmpty; }
   const COMET_LDS u32* rows;             // address_space(3): ds_read, not FLAT (a FLAT access waits for every outstanding global load)
   const COMET_LDS unsigned short* tags;
   CDEV u32 peek(u64 h) const { return rows[((u32)(h >> 32)) & (kJoinLdsCap - 1)]; }
@@ -2618,6 +2622,8 @@ struct JoinLdsTable {
 template <class P>
 struct JoinDirectTable {
   static constexpr bool BY_KEY = true;       // peek() takes the key itself
+  typedef u32 Entry;
+  static CDEV Entry none() { return kJoinNoRow; }
   const u64* km;
   const u32* ranks;
   const u32* rows;
@@ -2743,7 +2749,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
     const u32 m = m_all > (u32)q0 * kWave ? m_all - (u32)q0 * kWave : 0u;
     // ---- 1. probe: key loads + hashes of every slice, then every bucket head, then row by row ----
     u64 hs[kJoinR];
-    u32 he[kJoinR];
+    typename T::Entry he[kJoinR];
     u32 keyed = 0;                                   // bit q: my entry of slice q exists and has a non-NULL key (it can match)
 #pragma unroll
     for (int q = 0; q < kJoinR; q++) {
@@ -2760,7 +2766,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < kJoinR; q++) he[q] = (q < nslice && ((keyed >> q) & 1u)) ? table.peek(hs[q]) : kJoinNoRow;
+    for (int q = 0; q < kJoinR; q++) he[q] = (q < nslice && ((keyed >> q) & 1u)) ? table.peek(hs[q]) : T::none();
     typename T::Pre pre[kJoinR];
 #pragma unroll
     for (int q = 0; q < kJoinR; q++) {
@@ -2835,7 +2841,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
           if (pos < cap_out) P::emit(prm, (i64)first[q], j, pos);
         } else {
           const u64 h = T::BY_KEY ? P::pkey0(prm, j) : P::phash(prm, j);            // several matches (rare outside many-to-many joins): walk the candidates again
-          const u32 e2 = table.peek(h);
+          const typename T::Entry e2 = table.peek(h);
           table.for_each(prm, j, h, e2, table.prefetch(prm, j, h, e2), [&](u32 row) {
             if (pos < cap_out) P::emit(prm, (i64)row, j, pos);
             pos++;
@@ -2853,9 +2859,8 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
 // is looked up in the finished table first — out[47] = { u64 rows alive, u64 rows with a match } — and the executor builds the bitmap
 // (join_keymap_build_body: one more pass over the build keys) only when fewer than half of them found a partner.  TPC-DS Q95's self-joins,
 // where nearly every probe row has one, skip it (measured with the bitmap always on: 22.6 → 25.4 ms).
-template <class P>
-CDEV void join_sample_body(const CometKParams& prm) {
-  JoinGlobalTable<P> t{(const u32*)prm.out[0], (const i32*)prm.out[1], (u64)prm.iarg[0] - 1, (int)prm.iarg[2], prm.iarg[1]};
+template <class P, class T>
+CDEV void join_sample_table(const CometKParams& prm, const T& t) {
   unsigned long long* cnt = (unsigned long long*)prm.out[47];
   const i64 ns = prm.iarg[5], n = prm.n;
   const i64 s = (i64)blockIdx.x * kBlock + threadIdx.x;
@@ -2865,7 +2870,7 @@ CDEV void join_sample_body(const CometKParams& prm) {
     alive = j < n && P::pkeep(prm, j) && P::pvalid(prm, j);
     if (alive) {
       const u64 h = P::phash(prm, j);
-      const u32 e = t.peek(h);
+      const typename T::Entry e = t.peek(h);
       t.for_each(prm, j, h, e, t.prefetch(prm, j, h, e), [&](u32) { hit = true; return false; });
     }
   }
@@ -2874,6 +2879,11 @@ CDEV void join_sample_body(const CometKParams& prm) {
     if (ba) atomicAdd(cnt, (unsigned long long)__popcll(ba));
     if (bh) atomicAdd(cnt + 1, (unsigned long long)__popcll(bh));
   }
+}
+template <class P>
+CDEV void join_sample_body(const CometKParams& prm) {
+  JoinGlobalTable<P> t{(const u32*)prm.out[0], (const i32*)prm.out[1], (u64)prm.iarg[0] - 1, (int)prm.iarg[2], prm.iarg[1]};
+  join_sample_table<P, JoinGlobalTable<P>>(prm, t);
 }
 template <class P>
 CDEV void join_keymap_build_body(const CometKParams& prm) {
@@ -2947,6 +2957,241 @@ CDEV void join_probe_lds_body(const CometKParams& prm) {
   __syncthreads();
   JoinLdsTable<P> t{(const COMET_LDS u32*)s_rows, (const COMET_LDS unsigned short*)s_tags};
   join_probe_tiles<P, JoinLdsTable<P>, false>(prm, t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel template D'' (round 6) — the BUCKET TABLE: the general hash join as streaming passes plus ONE random 16-byte access per probe key.
+// The chained table above pays, per build run, a device-scope atomicExch on a random word of a 128 MB array (executed at the memory side: a
+// 64-byte read-modify-write each — k_jbuild ran at 0.95 TB/s) and, per probe key, up to four dependent random lines (head, build key, next[],
+// the residual's column).  Here the build side is PARTITIONED on the bits of its hash that pick the slot, each partition's open-addressing
+// table is built in LDS by one workgroup ("hash-join probe staged through LDS open-addressing tables", north_star — the staging is the BUILD:
+// no global atomic anywhere) and written out with coalesced 16-byte stores:
+//   entry = { u64 sig = the key's 64-bit hash, u32 row = the run's leader, u32 cnt = rows of the run }      row = kJoinNoRow: empty
+//   slot(h) = umulhi(h, NP · S) — partition = slot / S, linear probing wraps inside the partition (S = kJoinPartSlots slots, ≈ half full)
+// hash_key<1> is a bijection of its one key word, so for single-word keys (every integer / date / float key, decimals ≤ 18 digits) sig == h IS
+// key equality: a probe row reads its entry and knows — no build-key gather, no next[] — and touches the build side only for a residual
+// condition (P::cond) or for the columns it emits.  Keys of several words verify the leader with P::match (one gather, on a 2^-64 collision or
+// a true match only).  A run of equal neighbouring keys (fact tables clustered on the key) is one entry; its followers sit right behind the
+// leader, `cnt` says how many: next[] does not exist on this path.
+//   k_jphist   G blocks × 1024 threads, block b owns rows [b·chunk, (b+1)·chunk): classify runs, LDS histogram over the NP partitions → cnt[b][p]
+//   (static)   comet_launch_join_part_scan: per partition the exclusive prefix over the blocks, in place; tot[p]
+//   k_jpscat   same blocks: exclusive scan of tot[] (every block, in LDS) + its own prefix = its cursors; records {sig,row,cnt} scattered to
+//              recs[] — partition-major, contiguous per partition; block 0 leaves pstart[0 .. NP]
+//   k_jtbuild  one 256-thread block per partition: LDS table (sig / row / cnt planes, 64 KB), LDS atomicCAS claims, coalesced write-out
+//   k_jprobe_b join_probe_tiles over JoinBucketTable (k_jprobe_bkm: behind the key bitmap)
+// A partition that would fill its table beyond 7/8 (many separate runs of ONE key: a many-to-many join on a scattered low-cardinality key) raises
+// out[47][6]; the executor then runs the join over the chained table instead.
+// out[0] = table (uint4[NP·S]), out[1] = recs (uint4[leaders]), out[3] = { u32 pstart[NP + 1 … padded to kJoinPartMax + 16], u32 tot[kJoinPartMax], u32 cnt[G][NP] };
+// iarg[0] = NP · S, iarg[1] = build rows, iarg[2] = NP, iarg[5] = chunk (rows per block, a multiple of 1024).
+// ---------------------------------------------------------------------------------------------
+constexpr int kJoinPartSlots = 4096;
+constexpr int kJoinPartMax = 16384;                 // partitions at most (the 64 KB LDS histogram / cursor array of the partition passes)
+constexpr int kJoinPartBlock = 1024;
+constexpr int kJoinPartTotOff = kJoinPartMax + 16;  // u32 index of tot[] in out[3]
+constexpr int kJoinPartCntOff = 2 * kJoinPartMax + 16;
+
+// the run a build row leads: like join_build_classify, but the run's LENGTH comes back instead of next[] markers
+template <class P>
+CDEV bool join_classify_run(const CometKParams& prm, i64 i, i64 nb, u64& h, u32& cnt) {
+  const int lane = (int)(threadIdx.x & (kWave - 1));
+  const bool valid = i < nb && P::bvalid(prm, i);
+  u64 kw[P::NKW];
+#pragma unroll
+  for (int w = 0; w < P::NKW; w++) kw[w] = 0;
+  if (valid) P::bkeys(prm, i, kw);
+  bool same = valid && lane > 0;
+#pragma unroll
+  for (int w = 0; w < P::NKW; w++) {
+    const u32 lo = __shfl_up((u32)kw[w], 1, kWave), hi = __shfl_up((u32)(kw[w] >> 32), 1, kWave);
+    same = same && (((u64)hi << 32) | lo) == kw[w];
+  }
+  same = same && __shfl_up(valid ? 1 : 0, 1, kWave) != 0;
+  const u64 followers = __ballot(same);
+  const u64 after = lane < kWave - 1 ? followers >> (lane + 1) : 0ull;        // the lanes behind me that continue a run: mine, while the bits are ones
+  cnt = P::DEDUP_BUILD ? 1u : 1u + (u32)__builtin_ctzll(~after);
+  h = hash_key<P::NKW>(kw);
+  return valid && !same;
+}
+
+template <class P>
+CDEV void join_part_hist_body(const CometKParams& prm) {
+  __shared__ u32 s_hist[kJoinPartMax];
+  const i64 nb = prm.iarg[1], chunk = prm.iarg[5];
+  const u64 slots = (u64)prm.iarg[0];
+  const int np = (int)prm.iarg[2];
+  u32* cnt = (u32*)prm.out[3] + kJoinPartCntOff;
+  for (int p = threadIdx.x; p < np; p += kJoinPartBlock) s_hist[p] = 0;
+  __syncthreads();
+  const i64 r0 = (i64)blockIdx.x * chunk, r1 = r0 + chunk < nb ? r0 + chunk : nb;
+  for (i64 wbase = r0 + (i64)(threadIdx.x & ~(kWave - 1)); wbase < r1; wbase += kJoinPartBlock) {      // wave-uniform: lane l holds row wbase + l
+    u64 h;
+    u32 c;
+    if (join_classify_run<P>(prm, wbase + (threadIdx.x & (kWave - 1)), nb, h, c)) atomicAdd(&s_hist[(u32)(__umul64hi(h, slots) / kJoinPartSlots)], 1u);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < np; p += kJoinPartBlock) cnt[(i64)blockIdx.x * np + p] = s_hist[p];
+}
+
+template <class P>
+CDEV void join_part_scatter_body(const CometKParams& prm) {
+  __shared__ u32 s_cur[kJoinPartMax];
+  __shared__ u32 s_wsum[kJoinPartBlock / kWave];
+  const i64 nb = prm.iarg[1], chunk = prm.iarg[5];
+  const u64 slots = (u64)prm.iarg[0];
+  const int np = (int)prm.iarg[2];
+  u32* pstart = (u32*)prm.out[3];
+  const u32* tot = pstart + kJoinPartTotOff;
+  const u32* cnt = pstart + kJoinPartCntOff + (i64)blockIdx.x * np;
+  uint4* recs = (uint4*)prm.out[1];
+  // exclusive scan of tot[0 .. np): sixteen consecutive partitions per thread
+  constexpr int kPer = kJoinPartMax / kJoinPartBlock;
+  const int lane = (int)(threadIdx.x & (kWave - 1)), wv = (int)(threadIdx.x >> 6);
+  u32 v[kPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int p = (int)threadIdx.x * kPer + k;
+    v[k] = p < np ? tot[p] : 0u;
+    sum += v[k];
+  }
+  u32 x = sum;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const u32 y = __shfl_up(x, d, kWave);
+    if (lane >= d) x += y;
+  }
+  if (lane == kWave - 1) s_wsum[wv] = x;
+  __syncthreads();
+  u32 run = x - sum;
+  for (int w = 0; w < wv; w++) run += s_wsum[w];
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int p = (int)threadIdx.x * kPer + k;
+    if (p < np) {
+      s_cur[p] = run + cnt[p];
+      if (blockIdx.x == 0) pstart[p] = run;
+    }
+    run += v[k];
+    if (blockIdx.x == 0 && p == np - 1) pstart[np] = run;
+  }
+  __syncthreads();
+  const i64 r0 = (i64)blockIdx.x * chunk, r1 = r0 + chunk < nb ? r0 + chunk : nb;
+  for (i64 wbase = r0 + (i64)(threadIdx.x & ~(kWave - 1)); wbase < r1; wbase += kJoinPartBlock) {
+    const i64 i = wbase + lane;
+    u64 h;
+    u32 c;
+    if (join_classify_run<P>(prm, i, nb, h, c)) {
+      const u32 pos = atomicAdd(&s_cur[(u32)(__umul64hi(h, slots) / kJoinPartSlots)], 1u);
+      recs[pos] = uint4{(u32)h, (u32)(h >> 32), (u32)i, c};
+    }
+  }
+}
+
+template <class P>
+CDEV void join_table_build_body(const CometKParams& prm) {
+  __shared__ u64 s_sig[kJoinPartSlots];
+  __shared__ u32 s_row[kJoinPartSlots];
+  __shared__ u32 s_cnt[kJoinPartSlots];
+  const u64 slots = (u64)prm.iarg[0];
+  const int np = (int)prm.iarg[2];
+  const u32* pstart = (const u32*)prm.out[3];
+  const uint4* recs = (const uint4*)prm.out[1];
+  uint4* tab = (uint4*)prm.out[0];
+  for (int p = blockIdx.x; p < np; p += gridDim.x) {
+    for (int s2 = threadIdx.x; s2 < kJoinPartSlots; s2 += kBlock) s_row[s2] = kJoinNoRow;
+    __syncthreads();
+    const u32 r0 = pstart[p], r1 = pstart[p + 1];
+    if (r1 - r0 > (u32)(kJoinPartSlots - kJoinPartSlots / 8)) {
+      if (threadIdx.x == 0) ((volatile unsigned long long*)prm.out[47])[6] = 1ull;       // too full to probe in a few steps: the executor takes the chained table
+    } else {
+      for (u32 r = r0 + threadIdx.x; r < r1; r += kBlock) {
+        const uint4 rec = recs[r];
+        const u64 h = ((u64)rec.y << 32) | rec.x;
+        u32 s2 = (u32)__umul64hi(h, slots) & (u32)(kJoinPartSlots - 1);
+        while (atomicCAS(&s_row[s2], kJoinNoRow, rec.z) != kJoinNoRow) s2 = (s2 + 1) & (u32)(kJoinPartSlots - 1);
+        s_sig[s2] = h;
+        s_cnt[s2] = rec.w;
+      }
+    }
+    __syncthreads();
+    for (int s2 = threadIdx.x; s2 < kJoinPartSlots; s2 += kBlock) {
+      const u32 row = s_row[s2];
+      const u64 sg = row != kJoinNoRow ? s_sig[s2] : 0ull;
+      tab[(i64)p * kJoinPartSlots + s2] = uint4{(u32)sg, (u32)(sg >> 32), row, row != kJoinNoRow ? s_cnt[s2] : 0u};
+    }
+    __syncthreads();
+  }
+}
+
+template <class P>
+struct JoinBucketTable {
+  static constexpr bool BY_KEY = false;
+  typedef uint4 Entry;
+  static CDEV Entry none() { return uint4{0u, 0u, kJoinNoRow, 0u}; }
+  const uint4* tab;
+  u64 slots;
+  CDEV Entry peek(u64 h) const { return tab[__umul64hi(h, slots)]; }
+  struct Pre {
+    uint4 e2;   // the slot behind the home slot (linear probing: about every second lookup needs it)
+    bool m;     // the home slot holds the key and its leader passes the residual condition
+  };
+  static CDEV bool holds(const uint4& e, u64 h) { return e.x == (u32)h && e.y == (u32)(h >> 32); }
+  // the leader of an entry whose signature matched: single-word keys are equal already
+  static CDEV bool leader_ok(const CometKParams& prm, u32 row, i64 j) { return P::NKW == 1 ? P::cond(prm, (i64)row, j) : P::match(prm, (i64)row, j); }
+  CDEV Pre prefetch(const CometKParams& prm, i64 j, u64 h, const Entry& e) const {
+    Pre p{none(), false};
+    if (e.z == kJoinNoRow) return p;
+    const u64 g = __umul64hi(h, slots);
+    p.e2 = tab[(g & ~(u64)(kJoinPartSlots - 1)) | ((g + 1) & (u64)(kJoinPartSlots - 1))];
+    if (holds(e, h)) p.m = leader_ok(prm, e.z, j);
+    return p;
+  }
+  template <class F>
+  CDEV void for_each(const CometKParams& prm, i64 j, u64 h, const Entry& e, const Pre& pre, F f) const {
+    if (e.z == kJoinNoRow) return;
+    const u64 g = __umul64hi(h, slots);
+    uint4 cur = e;
+    for (u32 t = 0; t < (u32)kJoinPartSlots; t++) {
+      if (holds(cur, h)) {
+        const bool mi = t == 0 ? pre.m : leader_ok(prm, cur.z, j);
+        if (mi && !f(cur.z)) return;
+        for (u32 k = 1; k < cur.w; k++) {               // the run's followers: the rows right behind the leader (same key; another residual, maybe)
+          const bool mk = P::NKW == 1 ? (!P::HAS_COND || P::cond(prm, (i64)(cur.z + k), j)) : P::match(prm, (i64)(cur.z + k), j);
+          if (mk && !f(cur.z + k)) return;
+        }
+      }
+      cur = t == 0 ? pre.e2 : tab[(g & ~(u64)(kJoinPartSlots - 1)) | ((g + t + 1) & (u64)(kJoinPartSlots - 1))];
+      if (cur.z == kJoinNoRow) return;
+    }
+  }
+};
+template <class P, bool KM = false>
+CDEV void join_probe_bucket_body(const CometKParams& prm) {
+  JoinBucketTable<P> t{(const uint4*)prm.out[0], (u64)prm.iarg[0]};
+  join_probe_tiles<P, JoinBucketTable<P>, KM>(prm, t);
+}
+template <class P>
+CDEV void join_sample_bucket_body(const CometKParams& prm) {
+  JoinBucketTable<P> t{(const uint4*)prm.out[0], (u64)prm.iarg[0]};
+  join_sample_table<P, JoinBucketTable<P>>(prm, t);
+}
+
+// The BITMAP-ONLY join (round 6): a LeftSemi / LeftAnti join that keeps probe rows, has no residual condition (P::DEDUP_BUILD) and joins on one
+// integer key whose build values span a foreign key's range asks nothing of its build side but "is the key there" — the key bitmap IS the
+// answer.  No table, no build rows: the tile's filter phase looks the bit up (k_jbmap built it), every row that is still "keyed" matches.
+template <class P>
+struct JoinBitmapTable {
+  static constexpr bool BY_KEY = true;
+  typedef u32 Entry;
+  static CDEV Entry none() { return kJoinNoRow; }
+  CDEV u32 peek(u64) const { return 0u; }
+  struct Pre {};
+  CDEV Pre prefetch(const CometKParams&, i64, u64, u32) const { return Pre{}; }
+  template <class F>
+  CDEV void for_each(const CometKParams&, i64, u64, u32, const Pre&, F f) const { f(0u); }
+};
+template <class P>
+CDEV void join_probe_bitmap_body(const CometKParams& prm) {
+  join_probe_tiles<P, JoinBitmapTable<P>, true>(prm, JoinBitmapTable<P>{});
 }
 
 }  // namespace comet

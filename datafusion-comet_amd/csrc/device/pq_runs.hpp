@@ -20,7 +20,7 @@
 #endif
 
 // status of a walk
-enum { PQ_RUNS_OK = 0, PQ_RUNS_TRUNCATED_HEADER = 1, PQ_RUNS_TRUNCATED_RLE = 2, PQ_RUNS_BAD_WIDTH = 3 };
+enum { PQ_RUNS_OK = 0, PQ_RUNS_TRUNCATED_HEADER = 1, PQ_RUNS_TRUNCATED_RLE = 2, PQ_RUNS_BAD_WIDTH = 3, PQ_RUNS_BAD_COUNT = 4, PQ_RUNS_TRUNCATED_PACKED = 5 };
 
 // Walks the section bytes[begin, end) and calls emit(byte_off, value_start, count, is_rle, rle_value) for every run that holds values, in
 // order; stops behind max_values values when max_values >= 0.  Mirrors parse_hybrid_runs_from (parquet_scan.cpp) decision for decision:
@@ -59,10 +59,18 @@ PQ_RUNS_FN int pq_walk_runs(const uint8_t* bytes, int64_t begin, int64_t end, in
     int32_t count;
     if (h & 1) {
       const int64_t groups = (int64_t)(h >> 1);
+      if (groups > (int64_t)(INT32_MAX - vstart) / 8) return PQ_RUNS_BAD_COUNT;      // (a header of up to 56 bits: the count must stay a value index)
       count = (int32_t)(groups * 8);
+      // the payload ends inside the section — or, when the page's value count is known, at least the values still wanted do (some writers cut
+      // the last group's padding)
+      if (pos + groups * bw > end) {
+        const int64_t wanted = max_values >= 0 ? (int64_t)(max_values - vstart) : (int64_t)count;
+        if (max_values < 0 || pos + (wanted * bw + 7) / 8 > end) return PQ_RUNS_TRUNCATED_PACKED;
+      }
       if (count != 0) { emit(pos, vstart, count, 0, 0u); n++; }
       pos += groups * bw;
     } else {
+      if ((h >> 1) > (uint64_t)(INT32_MAX - vstart)) return PQ_RUNS_BAD_COUNT;
       count = (int32_t)(h >> 1);
       if (pos + vbytes > end) return PQ_RUNS_TRUNCATED_RLE;
       uint32_t v = 0;

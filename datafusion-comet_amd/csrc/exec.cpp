@@ -883,18 +883,18 @@ Variant& ExecutionContext::variant_for(const std::vector<bool>& has_valid, const
   return res.first->second;
 }
 
-void ExecutionContext::launch(Variant& v, const char* kernel, int grid, CometKParams& prm) {
+void ExecutionContext::launch(Variant& v, const char* kernel, int grid, CometKParams& prm, int block) {
   hipFunction_t fn = v.mod->fn(kernel);
   void* args[] = {&prm};
   // COMET_KERNEL_TIMES=1 / comet_set_kernel_times(1) (a measurement switch, off by default): an event pair around EVERY generated-kernel launch, summed per kernel
   // name (comet_plan_kernel_times) — what bench.py's Q3 / Q95 rooflines name their dominant kernel from
   if (!g_kernel_times.load(std::memory_order_relaxed)) {
-    HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream_, args, nullptr));
+    HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, 0, stream_, args, nullptr));
     return;
   }
   hipEvent_t a = pool_get_event(device_id_), b = pool_get_event(device_id_);
   HIP_CHECK(hipEventRecord(a, stream_));
-  HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream_, args, nullptr));
+  HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, 0, stream_, args, nullptr));
   HIP_CHECK(hipEventRecord(b, stream_));
   kt_pending_.push_back({kernel, a, b});
 }
@@ -2056,6 +2056,8 @@ std::string ExecutionContext::metrics_proto() {
       n.metrics.emplace_back("join_build_rows", join_build_rows_);
       n.metrics.emplace_back("join_probe_rows", join_probe_rows_);
       n.metrics.emplace_back("join_direct_maps", join_direct_maps_);      // joins probed through the direct map of a unique integer key
+      n.metrics.emplace_back("join_bucket_tables", join_bucket_tables_);  // joins probed through the partitioned, LDS-built bucket table
+      n.metrics.emplace_back("join_bitmap_only", join_bitmap_only_);      // semi / anti joins answered by the build side's key bitmap alone
     }
     for (auto& c : op.children) n.children.push_back(build(*c, false));
     return n;

@@ -150,7 +150,8 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   const int64_t n = P.rows;
   const bool use_lds = B.rows > 0 && B.rows <= 6144 && getenv("COMET_JOIN_GLOBAL_TABLE") == nullptr;
   DevBuf head, next, matched, btiles, emitted_buf;
-  emitted_buf.ensure(64);
+  emitted_buf.ensure(64);      // u64 words: [0] emitted rows / leaders, [1] smallest key, [2] largest key, [3] keyed rows, [4] "a key came twice", [6] "a bucket-table partition overflowed"
+  HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 64, stream_));
   prm.n = n;
   prm.iarg[1] = B.rows;
   // The bucket array holds one entry per RUN of equal neighbouring keys (comet_device.hpp "Runs of equal keys"), not one per row: a large
@@ -160,9 +161,14 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   static const bool count_runs = getenv("COMET_JOIN_COUNT_RUNS") == nullptr || atoi(getenv("COMET_JOIN_COUNT_RUNS")) != 0;
   DevBuf keymap;
   uint64_t keymap_first = 0, keymap_range = 0;       // a candidate for the key bitmap: one integer key whose values span a foreign key's range
-  if (!use_lds && count_runs && B.rows >= (1 << 20)) {
-    const uint64_t init[4] = {0, ~0ull, 0, 0};       // leaders, smallest key, largest key (order-preserving u64), rows with a non-NULL key
-    write_small(emitted_buf.p, init, sizeof init);
+  // The general table (comet_device.hpp template D''): partitioned build into LDS, 16-byte entries, one random access per probe key.  Small build
+  // sides keep the chained table (it sits in L2, and one launch builds it); so does a build side with more runs than 16384 partitions hold.
+  static const int64_t bucket_min_rows = getenv("COMET_JOIN_BUCKET_MIN_ROWS") ? atoll(getenv("COMET_JOIN_BUCKET_MIN_ROWS")) : 65536;
+  static const int bitmap_only_mode = getenv("COMET_JOIN_BITMAP_ONLY") ? atoi(getenv("COMET_JOIN_BITMAP_ONLY")) : 1;
+  bool bucket = !use_lds && !join_no_bucket_ && bucket_min_rows >= 0 && B.rows >= bucket_min_rows;
+  if (!use_lds && count_runs && B.rows >= (bucket ? 65536 : (1 << 20))) {
+    // leaders, smallest key, largest key (order-preserving u64), rows with a non-NULL key
+    HIP_CHECK(hipMemsetAsync((char*)emitted_buf.p + 8, 0xff, 8, stream_));
     prm.out[0] = emitted_buf.p;
     prm.out[kOutErr] = err_flags_.p;
     launch(v, "k_jbcnt", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
@@ -200,7 +206,13 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     join_keymap_bytes_ += (int64_t)words * 4;
     keymap_built = true;
   };
-  if (keymap_range && direct_mode != 0 && entries == keyed_rows) {       // (no two neighbouring rows share a key: a clustered fact table is spared the pass)
+  // A semi / anti join that only asks whether the key exists (no residual, probe rows kept) over such a key: the bitmap is the whole build side.
+  const bool bitmap_only = keymap_range != 0 && d.join_dedup_build && bitmap_only_mode != 0 && n > 0;
+  if (bitmap_only) {
+    build_keymap();
+    bucket = false;
+    join_bitmap_only_++;
+  } else if (keymap_range && direct_mode != 0 && entries == keyed_rows) {       // (no two neighbouring rows share a key: a clustered fact table is spared the pass)
     build_keymap();
     uint64_t dup = 1;
     read_small(&dup, (char*)emitted_buf.p + 32, 8);
@@ -221,8 +233,38 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
       join_direct_maps_++;
     }
   }
+  // ---- the bucket table: partition passes, LDS build ----
+  DevBuf btab, brecs, bpart;
+  int64_t bslots = 0;
+  if (direct || bitmap_only || B.rows == 0) bucket = false;
+  if (bucket) {
+    constexpr int64_t kS = 4096, kMaxP = 16384;            // comet_device.hpp kJoinPartSlots, kJoinPartMax
+    const int64_t np = std::max<int64_t>(1, (std::max<int64_t>(entries, 1) + kS / 2 - 1) / (kS / 2));
+    if (np > kMaxP) bucket = false;
+    else {
+      const int64_t g = std::min<int64_t>(256, (B.rows + 4095) / 4096);
+      const int64_t chunk = ((B.rows + g - 1) / g + 1023) / 1024 * 1024;
+      bslots = np * kS;
+      btab.ensure((size_t)bslots * 16);
+      brecs.ensure((size_t)std::max<int64_t>(entries, 1) * 16 + 16);
+      bpart.ensure((size_t)(2 * kMaxP + 16 + g * np) * 4 + 16);
+      prm.iarg[0] = bslots;
+      prm.iarg[2] = np;
+      prm.iarg[5] = chunk;
+      prm.out[0] = btab.p;
+      prm.out[1] = brecs.p;
+      prm.out[3] = bpart.p;
+      prm.out[47] = emitted_buf.p;
+      prm.out[kOutErr] = err_flags_.p;
+      launch(v, "k_jphist", (int)g, prm, 1024);
+      if (comet_launch_join_part_scan((uint32_t*)bpart.p + (2 * kMaxP + 16), (int)g, (int)np, (uint32_t*)bpart.p + (kMaxP + 16), stream_) != 0) throw CometError("hash join: launch failed");
+      launch(v, "k_jpscat", (int)g, prm, 1024);
+      launch(v, "k_jtbuild", (int)np, prm);
+      join_bucket_tables_++;
+    }
+  }
   int64_t cap = 1024;
-  if (!direct) {
+  if (!direct && !bucket && !bitmap_only) {
     while (cap < 2 * entries) cap <<= 1;
     head.ensure((size_t)cap * 4);     // u32 per bucket: newest run leader | tag | "more than one row" flag (comet_device.hpp template D)
     next.ensure((size_t)std::max<int64_t>(B.rows, 1) * 4 + 16);
@@ -238,14 +280,14 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     prm.out[46] = btiles.p;
     prm.iarg[3] = nbtiles;
   }
-  prm.iarg[0] = cap;
-  {
+  if (!bucket) prm.iarg[0] = cap;
+  if (!bucket) {
     int ib = 1;                                   // bits of a build row index: rows ≤ 2^ib − 1, so an index is never all ones
     while (ib < 31 && ((int64_t)1 << ib) - 1 < std::max<int64_t>(B.rows, 1)) ib++;
     if (((int64_t)1 << ib) - 1 < B.rows) throw CometError("HashJoin: build sides of 2^31 rows or more are not supported");
     prm.iarg[2] = ib;
   }
-  if (!direct) {
+  if (!direct && !bucket && !bitmap_only) {
     prm.out[0] = head.p;
     prm.out[1] = next.p;
   }
@@ -268,23 +310,24 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   };
   // ---- single-pass probe (comet_device.hpp template D'): a small build side is hashed into LDS by every block, a large one into the
   // chained global table; either way the probe counts and emits in one launch, reserving output ranges with one atomic per tile ----
-  if (!use_lds && !direct && B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
+  if (!use_lds && !direct && !bucket && !bitmap_only && B.rows) launch(v, "k_jbuild", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
   prm.out[47] = emitted_buf.p;
   // The key bitmap (comet_device.hpp kJoinKeyMap) pays when probe rows miss: 8192 probe rows, evenly spaced, go through the finished table
   // first; fewer than half with a partner → one more pass over the build keys sets the bits, and the probe asks them before the table.
   static const int keymap_mode = getenv("COMET_JOIN_KEYMAP") ? atoi(getenv("COMET_JOIN_KEYMAP")) : -1;      // 0 never, 1 always, default: by the sample
   // (… and only where the probe side is several times the build side: the bitmap's build pass costs what the build side's atomics cost —
   // 2.2 ms for each of TPC-DS Q95's 70 M-row builds, whose equally large probe sides it did not speed up)
-  if (keymap_built && !direct) {
+  if (bitmap_only) {
+    // (the bitmap is the table)
+  } else if (keymap_built && !direct) {
     // (the bitmap exists already — the build side turned out not to be unique — and filters the probe rows as below)
   } else if (!direct && keymap_range && keymap_mode != 0 && n >= (1 << 20) && (keymap_mode == 1 || n >= 4 * B.rows)) {
     bool wanted = keymap_mode == 1;
     if (!wanted) {
-      const uint64_t zero[2] = {0, 0};
-      write_small(emitted_buf.p, zero, sizeof zero);
+      HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 16, stream_));
       const int64_t ns = 8192;
       prm.iarg[5] = ns;
-      launch(v, "k_jsample", (int)((ns + 255) / 256), prm);
+      launch(v, bucket ? "k_jsample_b" : "k_jsample", (int)((ns + 255) / 256), prm);
       uint64_t cnt[2] = {0, 0};
       read_small(cnt, emitted_buf.p, sizeof cnt);
       wanted = cnt[0] >= 64 && cnt[1] * 2 < cnt[0];
@@ -299,9 +342,26 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     HIP_CHECK(hipMemsetAsync(emitted_buf.p, 0, 8, stream_));
     const int64_t ptiles = (n + 4095) / 4096;      // kJoinR0 × 256 probe rows per tile (comet_device.hpp)
     // (k_jprobe_km: the table probe that asks the key bitmap first; without a bitmap the leaner k_jprobe — comet_device.hpp join_probe_tiles)
-    launch(v, use_lds ? "k_jlds" : direct ? "k_jdprobe" : keymap_built ? "k_jprobe_km" : "k_jprobe", (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
-    uint64_t emitted = 0;
-    read_small(&emitted, emitted_buf.p, 8);
+    launch(v, use_lds ? "k_jlds" : bitmap_only ? "k_jprobe_bm" : direct ? "k_jdprobe" : bucket ? (keymap_built ? "k_jprobe_bkm" : "k_jprobe_b") : keymap_built ? "k_jprobe_km" : "k_jprobe",
+           (int)std::min<int64_t>(ptiles, use_lds ? 256 * 3 : 256 * 8), prm);
+    uint64_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    read_small(words, emitted_buf.p, sizeof words);
+    const uint64_t emitted = words[0];
+    if (bucket && words[6]) {
+      // a partition of the bucket table overflowed (many separate runs of one key): this join runs over the chained table
+      timed_end();
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      join_bucket_tables_--;
+      join_no_bucket_ = true;
+      try {
+        DevTable r = hash_join_impl(node, j, L, R, key_suffix, fused_probe);
+        join_no_bucket_ = false;
+        return r;
+      } catch (...) {
+        join_no_bucket_ = false;
+        throw;
+      }
+    }
     out_rows = d.join_build_only ? 0 : (int64_t)emitted;
     if (out_rows <= out_cap) break;
     if (attempt == 1) throw CometError("internal: hash join output exceeded its exact size");

@@ -65,6 +65,8 @@ DevTable ExecutionContext::explode(const Operator& ex, const DevTable& in) {
   const DeviceColumnView& lv = in.cols.at((size_t)lc);
   const DType& lt = in.types.at((size_t)lc);
   if (lt.id != TypeId::List || lv.kids.size() != 1) throw CometError("Explode: the exploded column is not a resident list");
+  // (the explode kernels index offsets and validity from the buffers' first element: a sliced list column would read other rows')
+  if (lv.offset != 0 || lv.kids[0].offset != 0) throw CometError("Explode: a sliced (offset != 0) list column is not supported");
   const int64_t n = in.rows;
   const uint8_t* lvalid = in.has_valid[(size_t)lc] ? lv.valid : nullptr;
   const bool ehv = !lv.kid_has_valid.empty() && lv.kid_has_valid[0] && lv.kids[0].valid;

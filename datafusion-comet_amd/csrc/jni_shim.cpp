@@ -181,6 +181,11 @@ static int32_t subquery_from_jvm(void* vctx, int64_t id, int32_t type_id, int32_
   if (!env || !c) return -1;
   jclass cls = jni_FindClass(env, "org/apache/spark/sql/comet/CometScalarSubquery");
   if (!cls || jni_ExceptionCheck(env)) return -1;
+  struct LocalRef {      // the class reference goes on EVERY way out: the calls run inside one long-lived executePlan frame, where leaked locals pile up
+    JNIEnv* env;
+    jobject o;
+    ~LocalRef() { if (o) jni_DeleteLocalRef(env, o); }
+  } cls_guard{env, (jobject)cls};
   auto method = [&](const char* name, const char* sig) { return jni_GetStaticMethodID(env, cls, name, sig); };
   jmethodID m_null = method("isNull", "(JJ)Z");
   if (!m_null || jni_ExceptionCheck(env)) return -1;
@@ -205,30 +210,29 @@ static int32_t subquery_from_jvm(void* vctx, int64_t id, int32_t type_id, int32_
       m = method(type_id == 10 ? "getDecimal" : "getBinary", "(JJ)[B");
       if (!m) break;
       jbyteArray a = (jbyteArray)jni_CallStaticObjectMethodJJ(env, cls, m, c->plan_id, (jlong)id);
+      LocalRef a_guard{env, (jobject)a};
       if (!a || jni_ExceptionCheck(env)) return -1;
       const jsize n = jni_GetArrayLength(env, a);
       std::vector<uint8_t> tmp((size_t)n + 1);
       jni_GetByteArrayRegion(env, a, 0, n, (jbyte*)tmp.data());
       put_bytes(tmp.data(), (size_t)n);
-      jni_DeleteLocalRef(env, a);
       break;
     }
     case 7: {      // string
       m = method("getString", "(JJ)Ljava/lang/String;");
       if (!m) break;
       jstring js = (jstring)jni_CallStaticObjectMethodJJ(env, cls, m, c->plan_id, (jlong)id);
+      LocalRef js_guard{env, (jobject)js};
       if (!js || jni_ExceptionCheck(env)) return -1;
       const char* chars = jni_GetStringUTFChars(env, js);
       const std::string u = from_modified_utf8(chars ? chars : "");
       if (chars) jni_ReleaseStringUTFChars(env, js, chars);
       put_bytes(u.data(), u.size());
-      jni_DeleteLocalRef(env, js);
       break;
     }
     default: return -1;
   }
-  const bool failed = !m || jni_ExceptionCheck(env);
-  jni_DeleteLocalRef(env, cls);      // (one class lookup per subquery and task: the values are asked for once)
+  const bool failed = !m || jni_ExceptionCheck(env);      // (one class lookup per subquery and task: the values are asked for once)
   return failed ? -1 : 1;
 }
 

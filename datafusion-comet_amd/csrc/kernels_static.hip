@@ -331,3 +331,32 @@ extern "C" int comet_launch_popcount128(const void* blocks, int64_t n, uint32_t*
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ---- bucket-table joins (comet_device.hpp template D''): cnt[b][p] = leaders of partition p that block b of the partition passes saw → in place its
+// exclusive prefix over the blocks (where block b's records of partition p start inside the partition), tot[p] = the partition's size
+__global__ __launch_bounds__(256) void join_part_scan_kernel(unsigned int* cnt, int g, int np, unsigned int* tot) {
+  const int p = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (p >= np) return;
+  unsigned int run = 0;
+  int b = 0;
+  for (; b + 8 <= g; b += 8) {
+    unsigned int c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = cnt[(long long)(b + k) * np + p];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      cnt[(long long)(b + k) * np + p] = run;
+      run += c[k];
+    }
+  }
+  for (; b < g; b++) {
+    const unsigned int c = cnt[(long long)b * np + p];
+    cnt[(long long)b * np + p] = run;
+    run += c;
+  }
+  tot[p] = run;
+}
+extern "C" int comet_launch_join_part_scan(uint32_t* cnt, int g, int np, uint32_t* tot, void* stream) {
+  if (g > 0 && np > 0) hipLaunchKernelGGL(join_part_scan_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cnt, g, np, tot);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void pq_write_runs_kernel(const PqPendingRuns*
   if (i >= n) return;
   const PqPendingRuns p = pend[i];
   const i32 first = run_base + offsets[i];
-  PqRun* out = runs + first;
+  const i32 reserved = offsets[i + 1] - offsets[i];      // what pass 1 counted for this page (the scan writes n + 1 prefix sums): a walk that fails half way — pass 1 then
+  PqRun* out = runs + first;                             // reserved ONE slot — must not spill the runs before the error into the next page's slots
   i32 k = 0;
   i32 nruns = 0;
   const int st = pq_walk_runs(bytes, p.begin, p.end, p.bit_width, p.max_values, &nruns, [&](i64 byte_off, i32 value_start, i32 count, int is_rle, u32 rle_value) {
@@ -152,9 +153,10 @@ __global__ __launch_bounds__(256) void pq_write_runs_kernel(const PqPendingRuns*
     r.rle_value = rle_value;
     r.page = p.page;
     r.pad = 0;
-    out[k++] = r;
+    if (k < reserved) out[k] = r;
+    k++;
   });
-  if (st != PQ_RUNS_OK || k == 0) {      // (a malformed section was reported by pass 1; its page decodes as zeros and the scan fails on the error word)
+  if (st != PQ_RUNS_OK || k == 0 || k > reserved) {      // (a malformed section was reported by pass 1; its page decodes as zeros and the scan fails on the error word)
     PqRun r;
     r.byte_off = 0;
     r.value_start = 0;

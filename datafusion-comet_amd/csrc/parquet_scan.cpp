@@ -259,18 +259,25 @@ void parse_hybrid_runs_from(const Get& get, size_t pos, size_t end, int bw, int3
       h |= (uint64_t)(b & 0x7f) << sh;
       if (!(b & 0x80)) break;
       sh += 7;
+      if (sh > 56) throw CometError("parquet: hybrid run header longer than eight bytes");
     }
     PqRun r;
     memset(&r, 0, sizeof r);
     r.value_start = vstart;
     if (h & 1) {
       int64_t groups = (int64_t)(h >> 1);
+      if (groups > (int64_t)(INT32_MAX - vstart) / 8) throw CometError("parquet: hybrid run count out of range");
       r.is_rle = 0;
       r.count = (int32_t)(groups * 8);
       r.byte_off = (int64_t)pos;
+      if (pos + (size_t)(groups * bw) > end) {      // (device/pq_runs.hpp makes the same decision)
+        const int64_t wanted = max_values >= 0 ? (int64_t)(max_values - vstart) : (int64_t)r.count;
+        if (max_values < 0 || pos + (size_t)((wanted * bw + 7) / 8) > end) throw CometError("parquet: truncated bit-packed run");
+      }
       pos += (size_t)(groups * bw);
     } else {
       r.is_rle = 1;
+      if ((h >> 1) > (uint64_t)(INT32_MAX - vstart)) throw CometError("parquet: hybrid run count out of range");
       r.count = (int32_t)(h >> 1);
       uint32_t v = 0;
       for (int k = 0; k < vbytes; k++) {

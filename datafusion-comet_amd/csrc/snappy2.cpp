@@ -9,6 +9,7 @@
 #include "exec.hpp"
 #include "parquet_dev.h"
 #include "snappy2.hpp"
+#include "../../include/comet_amd.h"
 
 extern "C" {
 void sn2_launch_window(const void* pages, const int32_t* chunk_page, const uint8_t* bytes, void* fns, const uint32_t* status, int64_t nchunks, void* st);

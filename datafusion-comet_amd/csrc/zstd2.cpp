@@ -1,6 +1,7 @@
 // Host side of the zstd pipeline (device/zstd2.hpp, zstd2_kernels.hip): lays out the page / block tables the host walk produced, sizes the
 // record and literal scratch, queues kernels A–D on the caller's stream — nothing is read back, so the scan stays asynchronous.
 #include "zstd2.hpp"
+#include "../../include/comet_amd.h"
 #include <algorithm>
 
 #include <hip/hip_runtime.h>

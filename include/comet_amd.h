@@ -19,6 +19,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libcomet.so is built with -fvisibility=hidden and an export list generated from this header (csrc/gen_exports.py): what is declared between this push and
+ * the pop at the end, plus the Java_org_apache_comet_* names, is the library's whole dynamic symbol table (tests/test_boundary_cpu.py diffs `nm -D` against it). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 struct ArrowArray;
 struct ArrowSchema;
@@ -207,7 +212,9 @@ int32_t comet_rlike_match(const char* pattern, const uint8_t* value, size_t valu
  * comet_last_error(0) for a pattern outside the subset or a group index out of range (the reference's message).  Needs no GPU. */
 int32_t comet_regexp_extract_host(const char* pattern, int32_t group, const uint8_t* value, size_t value_len, int32_t* start, int32_t* len);
 
-/* ---- what the generator writes — diagnostic entries (tests/emu: the generated per-row code compiled and run on the HOST against the oracle) --------------------
+#ifdef COMET_TEST_ABI
+/* ==== TEST ABI: exported for the repo's own tests and tools, NOT part of the product boundary — an integrator does not bind these (define COMET_TEST_ABI to see them) ====
+ * ---- what the generator writes — diagnostic entries (tests/emu: the generated per-row code compiled and run on the HOST against the oracle) --------------------
  * comet_plan_codegen: the HIP source generated for a Filter / Projection / HashAggregate chain over one Scan leaf (has_valid[k]: column k arrives with a validity
  * bitmap) and what the executor needs to read its outputs, as JSON {"sink", "has_filter", "R", "kernels": [...], "out": [{"type", "precision", "scale", "nullable",
  * "gather_src", "view_src", "fmt_kind", "packed_string", "concat", "case_mode", "pad", "pad_left"}], "source"}: the length, the text written when it fits `cap`.
@@ -218,6 +225,11 @@ int64_t comet_embedded_header(const char* name, char* out, int64_t cap);
 /* the Spark error JSON of a raise site of a pipeline generated in this process (the site id a kernel leaves in the error block's detail words, kparams.h) and the
  * detail it left: what check_device_errors throws, without the SQL context */
 int64_t comet_error_site_json(uint32_t site_id, uint64_t lo, uint64_t hi, const uint8_t* str, int64_t str_avail, char* out, int64_t cap);
+/* a streaming read of `bytes` bytes with `width`-byte loads (4 / 8 / 16) into a sink word: the known byte count tools/pmc_calibrate.py calibrates FETCH_SIZE on */
+int comet_calib_read(const void* buf, int64_t bytes, int32_t width, uint64_t* sink, void* stream);
+/* the headline's Utf8 pass on its own (kernels_static.hip utf8_uniform_kernel): *flag becomes non-zero unless every value of the n offsets has length L */
+int comet_launch_utf8_uniform(const int32_t* offsets, int64_t n, int32_t L, uint32_t* flag, void* stream);
+#endif /* COMET_TEST_ABI */
 
 /* ---- scalar subqueries (expr.proto:513-516 Subquery{id, datatype}; native/core/src/execution/expressions/subquery.rs:72-180) ------------------------------
  * The reference asks the JVM for a subquery's value when the expression is first evaluated: CometScalarSubquery.isNull / getBoolean / getByte / getShort / getInt /
@@ -362,12 +374,14 @@ const char* comet_exchange_last_error(void);
 int64_t comet_decode_shuffle_block(const uint8_t* block, int64_t len, struct ArrowArray** out_arrays, struct ArrowSchema** out_schemas,
                                    int32_t n_out);
 
-/* What a Scan / ShuffleScan leaf does with the batches of one chunk of a NESTED input column before it uploads them (csrc/exec_util.cpp
+#ifdef COMET_TEST_ABI
+/* (TEST ABI) What a Scan / ShuffleScan leaf does with the batches of one chunk of a NESTED input column before it uploads them (csrc/exec_util.cpp
  * append_nested_rows; the reference's ScanExec takes the batches as they come, operators/scan.rs:134-164, and DataFusion's kernels honour
  * a struct's validity themselves): `n` Arrow arrays of one struct / list column (any depth; offsets and slices as the producer left them) are
  * concatenated into ONE host column — list offsets rebased, children appended, every field's validity masked by its struct's — which is moved
  * into *out / *out_schema.  Host-side only; the test entry of that step.  Returns the rows, or -2 on error. */
 int64_t comet_concat_nested_column(struct ArrowArray** arrays, struct ArrowSchema* schema, int32_t n, struct ArrowArray* out, struct ArrowSchema* out_schema);
+#endif /* COMET_TEST_ABI */
 
 /* The framing step of the shuffle writer on its own (ShuffleBlockWriter::write_batch, native/shuffle/src/writers/
  * shuffle_block_writer.rs:179-238): encodes the host-resident columns (Arrow C Data, one array + schema per column, any offset) as ONE
@@ -416,6 +430,9 @@ int32_t comet_parquet_describe(const char* path, char* out, size_t cap);
 /* Library identity (NativeBase.java:82-106 loads "comet"). */
 const char* comet_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,24 @@ def test_library_exports_every_declared_symbol(built):
     assert b"gfx950" in native.lib().comet_version()
 
 
+def test_dynamic_symbol_table_is_the_header_plus_the_jni_names(built):
+    """The reference's cdylib exposes its JNI names and nothing else (native/core/Cargo.toml:110-113); here: those names plus the comet_* of
+    include/comet_amd.h.  `nm -D` of libcomet.so is diffed against the header — no kernel launcher, host stub or C++ symbol leaks out (the
+    library is built with -fvisibility=hidden and the export list csrc/gen_exports.py derives from the header)."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "comet_amd.h")).read()
+    declared = set(re.findall(r"\b(comet_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)))
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    jni = {n for n in exported if n.startswith("Java_org_apache_comet_")}
+    assert len(jni) == 21, sorted(jni)                      # jni_api.rs, lib.rs, parquet/mod.rs: the 21 names INTEGRATION.md lists
+    assert exported - jni - {"JNI_OnLoad", "JNI_OnUnload"} == declared, (sorted(exported - jni - declared), sorted(declared - exported))
+    # the diagnostic entries are fenced: an integrator who includes the header without COMET_TEST_ABI does not see them
+    plain = re.sub(r"#ifdef COMET_TEST_ABI.*?#endif /\* COMET_TEST_ABI \*/", "", hdr, flags=re.S)
+    for n in ("comet_plan_codegen", "comet_embedded_header", "comet_error_site_json", "comet_concat_nested_column", "comet_calib_read", "comet_launch_utf8_uniform"):
+        assert n in declared and not re.search(r"\b" + n + r"\s*\(", re.sub(r"/\*.*?\*/", "", plain, flags=re.S)), n
+
+
 def test_q6_plan_compiles_for_gfx950(built):
     text = native.compile_plan(tpch.q6_plan().encode())
     assert "sum_decimal -> (Decimal128(35, 4), is_empty)" in text

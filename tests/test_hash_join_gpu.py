@@ -351,3 +351,108 @@ def test_a_key_that_comes_twice_falls_back_to_the_hash_table(built):
     want = _oracle(j, [probe_t, build_t])
     assert m["join_direct_maps"] == 0
     assert got.num_rows == want.num_rows and _sorted(got).equals(_sorted(want))
+
+
+# ---- the bucket table (comet_device.hpp template D'': partitioned build into LDS tables, one random access per probe key) and the bitmap-only join ----
+ALL_TYPES = [S.INNER, S.LEFT_SEMI, S.LEFT_ANTI, S.LEFT_OUTER, S.RIGHT_OUTER, S.FULL_OUTER]
+KFIELDS = [S.T_INT64, S.T_INT32, S.T_INT32, S.T_INT64]      # k, k2, v, id
+
+
+def _sparse_dup_sides(nb, npr, seed, key_space=None):
+    """build side: sparse 64-bit keys (no range a bitmap could cover), about a third of them twice or more — SCATTERED duplicates (separate runs) and CLUSTERED ones
+    (neighbouring rows: one entry with a run length), a second key column with few values, NULLs in both; probe side: half its keys from the build side"""
+    rng = np.random.default_rng(seed)
+    key_space = key_space or nb
+    base = rng.integers(-(1 << 62), 1 << 62, key_space).astype(np.int64)
+    bk = base[rng.integers(0, key_space, nb)]
+    runs = rng.random(nb) < 0.25                                     # a quarter of the rows repeat their predecessor's keys: runs, also across wave boundaries
+    idx = np.arange(nb)
+    idx[runs] = 0
+    idx = np.maximum.accumulate(idx)
+    bk = bk[idx]
+    bk2 = rng.integers(0, 3, nb).astype(np.int32)[idx]
+    build_t = pa.table({"k": pa.array(bk, mask=rng.random(nb) < 0.02), "k2": pa.array(bk2, mask=rng.random(nb) < 0.02),
+                        "v": pa.array(rng.integers(-1000, 1000, nb), pa.int32()), "id": pa.array(np.arange(nb, dtype=np.int64))})
+    pk = np.where(rng.random(npr) < 0.5, base[rng.integers(0, key_space, npr)], rng.integers(-(1 << 62), 1 << 62, npr)).astype(np.int64)
+    probe_t = pa.table({"k": pa.array(pk, mask=rng.random(npr) < 0.02), "k2": pa.array(rng.integers(0, 3, npr).astype(np.int32), mask=rng.random(npr) < 0.02),
+                        "v": pa.array(rng.integers(-1000, 1000, npr), pa.int32()), "id": pa.array(np.arange(npr, dtype=np.int64))})
+    return probe_t, build_t
+
+
+@pytest.mark.parametrize("jt", ALL_TYPES)
+@pytest.mark.parametrize("two_cols", [False, True])
+def test_bucket_table_join_on_sparse_duplicate_keys(built, jt, two_cols):
+    """Every join type over the bucket table: sparse keys with scattered and clustered duplicates, one key column (the entry's signature IS the key) and
+    two (the leader is verified by P::match), NULL keys on both sides, with and without a residual condition, built on either side."""
+    probe_t, build_t = _sparse_dup_sides(150_000, 120_000, 71)
+    lk = [S.col(0, S.T_INT64)] + ([S.col(1, S.T_INT32)] if two_cols else [])
+    ncols = 4 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 8
+    for cond in (None, S.lt(S.col(2, S.T_INT32), S.col(6, S.T_INT32))):
+        for build in (S.BUILD_RIGHT, S.BUILD_LEFT):
+            tables = [probe_t, build_t] if build == S.BUILD_RIGHT else [build_t, probe_t]
+            j = S.hash_join(S.scan(KFIELDS), S.scan(KFIELDS), lk, lk, jt, build, cond)
+            got, m = _join_metrics(j, tables, ncols)
+            want = _oracle(j, tables)
+            assert m["join_bucket_tables"] == 1 and m["join_direct_maps"] == 0, m
+            assert got.num_rows == want.num_rows > 1000, (jt, two_cols, build)
+            assert _sorted(got).equals(_sorted(want)), (jt, two_cols, build, cond is not None)
+
+
+@pytest.mark.parametrize("jt", ALL_TYPES)
+def test_bucket_table_at_ten_million_build_rows(built, jt):
+    """≥ 10 M build rows, two key columns, sparse keys, duplicates both scattered and in runs (about 2,400 partitions of the table): all six join types
+    against the oracle, bit-exact as multisets."""
+    probe_t, build_t = _sparse_dup_sides(10_500_000, 1_500_000, 72, key_space=6_000_000)
+    lk = [S.col(0, S.T_INT64), S.col(1, S.T_INT32)]
+    ncols = 4 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 8
+    cond = S.lt(S.col(2, S.T_INT32), S.col(6, S.T_INT32)) if jt in (S.INNER, S.LEFT_SEMI, S.FULL_OUTER) else None
+    j = S.hash_join(S.scan(KFIELDS), S.scan(KFIELDS), lk, lk, jt, S.BUILD_RIGHT, cond)
+    got, m = _join_metrics(j, [probe_t, build_t], ncols)
+    want = _oracle(j, [probe_t, build_t])
+    assert m["join_bucket_tables"] == 1, m
+    assert got.num_rows == want.num_rows > 100_000
+    assert _sorted(got).equals(_sorted(want))
+
+
+@pytest.mark.parametrize("jt", [S.LEFT_SEMI, S.LEFT_ANTI])
+def test_semi_and_anti_join_answered_by_the_key_bitmap_alone(built, jt):
+    """A semi / anti join without a residual condition on one integer key of a foreign key's shape: the build side is its key bitmap — no table
+    (metric join_bitmap_only).  Duplicate and NULL build keys, probe keys below / above / in the holes of the range, a probe chain fused in."""
+    rng = np.random.default_rng(73)
+    nb, npr = 300_000, 500_000
+    bk = (rng.integers(0, nb, nb) * 3 + 1000).astype(np.int64)
+    build_t = pa.table({"k": pa.array(bk, mask=rng.random(nb) < 0.01), "v": pa.array(rng.integers(-1000, 1000, nb), pa.int32()), "id": pa.array(np.arange(nb, dtype=np.int64))})
+    pk = rng.integers(0, 1000 + 3 * nb + 2000, npr).astype(np.int64)
+    pk[:4] = [-5, 0, 999, 1000 + 3 * nb + 1999]
+    probe_t = pa.table({"k": pa.array(pk, mask=rng.random(npr) < 0.02), "v": pa.array(rng.integers(-1000, 1000, npr), pa.int32()), "id": pa.array(np.arange(npr, dtype=np.int64))})
+    chain = S.project(S.filter_(S.scan(CFIELDS), S.gt(S.col(1, S.T_INT32), S.lit(-900, S.T_INT32))), [S.col(0, S.T_INT64), S.col(1, S.T_INT32), S.col(2, S.T_INT64)])
+    for left in (S.scan(CFIELDS), chain):
+        j = S.hash_join(left, S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_RIGHT)
+        got, m = _join_metrics(j, [probe_t, build_t], 3)
+        want = _oracle(j, [probe_t, build_t])
+        assert m["join_bitmap_only"] == 1 and m["join_bucket_tables"] == 0, m
+        assert got.num_rows == want.num_rows > 10_000
+        assert _sorted(got).equals(_sorted(want))
+    # with a residual condition the rows of the build side matter: the bucket table
+    j = S.hash_join(S.scan(CFIELDS), S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_RIGHT, S.lt(S.col(1, S.T_INT32), S.col(4, S.T_INT32)))
+    got, m = _join_metrics(j, [probe_t, build_t], 3)
+    want = _oracle(j, [probe_t, build_t])
+    assert m["join_bitmap_only"] == 0 and m["join_bucket_tables"] == 1, m
+    assert _sorted(got).equals(_sorted(want))
+
+
+def test_bucket_table_partition_overflow_takes_the_chained_table(built):
+    """Three keys, each in tens of thousands of SEPARATE runs: every entry of a key lands in one partition, which cannot hold them — the build says so
+    and the join runs over the chained table (metric join_bucket_tables stays 0); the answer is the oracle's."""
+    rng = np.random.default_rng(74)
+    nb = 150_000
+    build_t = pa.table({"k": pa.array(rng.integers(0, 3, nb).astype(np.int64) * (1 << 40)), "k2": pa.array(np.zeros(nb, np.int32)),
+                        "v": pa.array(rng.integers(-1000, 1000, nb), pa.int32()), "id": pa.array(np.arange(nb, dtype=np.int64))})
+    probe_t = pa.table({"k": pa.array(np.array([0, 1 << 40, 5, 2 << 40, 1 << 40], dtype=np.int64)), "k2": pa.array(np.zeros(5, np.int32)),
+                        "v": pa.array(np.arange(5, dtype=np.int32)), "id": pa.array(np.arange(5, dtype=np.int64))})
+    j = S.hash_join(S.scan(KFIELDS), S.scan(KFIELDS), [S.col(0, S.T_INT64), S.col(1, S.T_INT32)], [S.col(0, S.T_INT64), S.col(1, S.T_INT32)], S.INNER, S.BUILD_RIGHT)
+    got, m = _join_metrics(j, [probe_t, build_t], 8)
+    want = _oracle(j, [probe_t, build_t])
+    assert m["join_bucket_tables"] == 0, m
+    assert got.num_rows == want.num_rows > 100_000
+    assert _sorted(got).equals(_sorted(want))
