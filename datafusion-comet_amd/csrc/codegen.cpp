@@ -2785,6 +2785,15 @@ struct Gen {
     if (v.rep != Rep::B) throw CometError("Filter predicate must be boolean, got " + v.t.str());
     stmt("k[r] = " + and_ok(v.ok, v.v) + ";");
     next_stage();
+    // isnotnull(<column>) as a conjunct of its own: every row that is still alive behind it holds a value — later references to the column read no validity
+    // bit, and a projection that passes it through yields a column WITHOUT a validity buffer (no byte per row written, no pack launch; TPC-DS Q95's
+    // scans are all of this shape: Filter(isnotnull(a) AND isnotnull(b)) → Project)
+    if (p->kind == ExprKind::IsNotNull && p->children.size() == 1 && p->children[0]->kind == ExprKind::Bound) {
+      auto it = col_cache.find(p->children[0]->bound_index);
+      if (it != col_cache.end()) it->second.ok.clear();
+      auto ck = cse.find(key_of(p->children[0]));
+      if (ck != cse.end()) ck->second.ok.clear();
+    }
   }
 
   // assemble the staged body: every stage is a load loop followed by a compute loop over the R rows
@@ -4069,8 +4078,16 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   // The probe side: the materialised child — or, with a fused probe chain (JoinFusion), the chain's SOURCE table; the child's columns
   // are then expressions over the source columns (fu->cols), its Filters conjuncts over them (fu->preds, P::pkeep).
   const std::vector<DType>& pt = fu ? fu->src_types : (build_left ? rt_in : lt_in);      // PHYSICAL probe columns
-  const std::vector<bool>& pv = fu ? fu->src_valid : (build_left ? rvalid_in : lvalid_in);
-  if (fu && pt.size() != pv.size()) throw CometError("internal: fused probe source validity arity mismatch");
+  const std::vector<bool>& pv_src = fu ? fu->src_valid : (build_left ? rvalid_in : lvalid_in);
+  if (fu && pt.size() != pv_src.size()) throw CometError("internal: fused probe source validity arity mismatch");
+  // a fused chain's isnotnull(<source column>) conjuncts: every probe row that passes P::pkeep holds a value there — keys, condition and output read
+  // no validity bit of such a column (P::pkeep itself still does)
+  std::vector<bool> pv(pv_src);
+  if (fu)
+    for (auto& p : fu->preds)
+      if (p->kind == ExprKind::IsNotNull && p->children.size() == 1 && p->children[0]->kind == ExprKind::Bound && p->children[0]->bound_index >= 0 &&
+          (size_t)p->children[0]->bound_index < pv.size())
+        pv[(size_t)p->children[0]->bound_index] = false;
   const int nb = (int)bt.size(), np = (int)pt.size();
   const int nprobe_logical = fu ? (int)fu->cols.size() : np;
   const int nl = build_left ? nb : nprobe_logical, nr = build_left ? nprobe_logical : nb;
@@ -4204,7 +4221,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   // P::pkeep(j): the Filters of a fused probe chain, conjunct by conjunct (columns load only for rows still alive); a row that fails is
   // not part of the probe side at all (outer / anti joins do not emit it either)
   if (fu && !fu->preds.empty()) {
-    Gen g(pt, pv);
+    Gen g(pt, pv_src);
     g.locate = [nb](int idx) { return std::make_pair(nb + idx, std::string("j")); };
     for (auto& p : fu->preds) {
       g.add_predicate(p);

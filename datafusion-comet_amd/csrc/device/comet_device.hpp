@@ -2533,6 +2533,7 @@ struct JoinGlobalTable {
   static constexpr bool BY_KEY = false;      // peek() takes the key's hash
   typedef u32 Entry;                         // what peek() hands out: the bucket's head
   static CDEV Entry none() { return kJoinNoRow; }
+  CDEV u64 key_of(const CometKParams& prm, i64 j) const { return P::phash(prm, j); }      // what peek() takes
   const u32* head;
   const i32* next;
   u64 mask;
@@ -2598,6 +2599,7 @@ struct JoinLdsTable {
   static constexpr bool BY_KEY = false;
   typedef u32 Entry;
   static CDEV Entry none() { return kJoinEmpty; }
+  CDEV u64 key_of(const CometKParams& prm, i64 j) const { return P::phash(prm, j); }
   const COMET_LDS u32* rows;             // address_space(3): ds_read, not FLAT (a FLAT access waits for every outstanding global load)
   const COMET_LDS unsigned short* tags;
   CDEV u32 peek(u64 h) const { return rows[((u32)(h >> 32)) & (kJoinLdsCap - 1)]; }
@@ -2624,6 +2626,7 @@ struct JoinDirectTable {
   static constexpr bool BY_KEY = true;       // peek() takes the key itself
   typedef u32 Entry;
   static CDEV Entry none() { return kJoinNoRow; }
+  CDEV u64 key_of(const CometKParams& prm, i64 j) const { return P::pkey0(prm, j); }
   const u64* km;
   const u32* ranks;
   const u32* rows;
@@ -2759,7 +2762,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
         if (k < m) {
           const u32 ent = list[k];
           if (!(ent & 0x8000u)) {
-            hs[q] = T::BY_KEY ? P::pkey0(prm, base + (i64)(ent & 0x7fffu)) : P::phash(prm, base + (i64)(ent & 0x7fffu));
+            hs[q] = table.key_of(prm, base + (i64)(ent & 0x7fffu));
             keyed |= 1u << q;
           }
         }
@@ -2840,7 +2843,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
         } else if (kind == 2) {
           if (pos < cap_out) P::emit(prm, (i64)first[q], j, pos);
         } else {
-          const u64 h = T::BY_KEY ? P::pkey0(prm, j) : P::phash(prm, j);            // several matches (rare outside many-to-many joins): walk the candidates again
+          const u64 h = table.key_of(prm, j);            // several matches (rare outside many-to-many joins): walk the candidates again
           const typename T::Entry e2 = table.peek(h);
           table.for_each(prm, j, h, e2, table.prefetch(prm, j, h, e2), [&](u32 row) {
             if (pos < cap_out) P::emit(prm, (i64)row, j, pos);
@@ -2869,7 +2872,7 @@ CDEV void join_sample_table(const CometKParams& prm, const T& t) {
     const i64 j = (i64)((unsigned __int128)s * (unsigned __int128)n / (unsigned __int128)ns);
     alive = j < n && P::pkeep(prm, j) && P::pvalid(prm, j);
     if (alive) {
-      const u64 h = P::phash(prm, j);
+      const u64 h = t.key_of(prm, j);
       const typename T::Entry e = t.peek(h);
       t.for_each(prm, j, h, e, t.prefetch(prm, j, h, e), [&](u32) { hit = true; return false; });
     }
@@ -2890,6 +2893,34 @@ CDEV void join_keymap_build_body(const CometKParams& prm) {
   if (!P::KEYMAP) return;
   u64* km = (u64*)prm.out[kJoinKeyMap];
   const i64 nb = prm.iarg[1];
+  if (prm.iarg[5] == 0) {
+    // nobody asks whether a key came twice (the bitmap filters probe rows, or IS the build side of a semi / anti join): the lanes of a wave whose keys
+    // fall into the same word (neighbouring rows of a clustered build side: every one of them) OR their bits together first — one atomic per
+    // wave and word instead of one per key (5.6 M device-scope atomics at the memory side cost Q95's three bitmaps 2.9 ms)
+    const int lane = lane_id();
+    for (i64 wbase = (i64)blockIdx.x * kBlock + (i64)wave_id() * kWave; wbase < nb; wbase += (i64)gridDim.x * kBlock) {
+      const i64 i = wbase + lane;
+      u64 kw[P::NKW];
+      u64 idx = ~0ull;
+      if (i < nb && P::bvalid(prm, i)) {
+        P::bkeys(prm, i, kw);
+        idx = kw[0] - km[0];
+      }
+      const bool in = idx < km[1];
+      u32 word = in ? (u32)(idx >> 5) : 0xffffffffu, bits = in ? 1u << (idx & 31u) : 0u;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {               // lanes further on with MY word (wherever they sit: one OR more into the same word is harmless)
+        const u32 ow = __shfl_down(word, d, kWave), ob = __shfl_down(bits, d, kWave);
+        if (lane + d < kWave && ow == word) bits |= ob;
+      }
+      const u32 pw = __shfl_up(word, 1, kWave);
+      if (in && (lane == 0 || pw != word)) {
+        u32* w = (u32*)(km + 2) + word;
+        if ((*w & bits) != bits) atomicOr(w, bits);
+      }
+    }
+    return;
+  }
   for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < nb; i += (i64)gridDim.x * kBlock) {
     if (!P::bvalid(prm, i)) continue;
     u64 kw[P::NKW];
@@ -2990,6 +3021,24 @@ constexpr int kJoinPartBlock = 1024;
 constexpr int kJoinPartTotOff = kJoinPartMax + 16;  // u32 index of tot[] in out[3]
 constexpr int kJoinPartCntOff = 2 * kJoinPartMax + 16;
 
+// The MONOTONE hash.  One integer key whose build values span [kmin, kmin + range): h = (key − kmin) · ⌊2^64 / range⌋ keeps the keys' ORDER — slot(h) = umulhi(h,
+// slots) grows with the key — and stays injective (so sig == h is still key equality).  Fact tables arrive clustered AND sorted on their keys (the lines of an
+// order follow the order numbers): with this hash the partition pass writes its records nearly in sequence, neighbouring waves of the probe read neighbouring lines
+// of the table, and both sides of TPC-DS Q95's 72 M × 72 M self-joins stream where a scrambling hash sent every run to a random line.  Keys in any other order
+// lose nothing.  A key distribution that is not spread evenly over its range overflows a partition; the build says so before the table is built and the executor
+// takes the scrambling hash.  out[3] u32 words kJoinPartMono…: u64 { mult (0: scrambling hash), kmin, range }.
+constexpr int kJoinPartMono = kJoinPartMax + 4;
+CDEV u64 join_mono_hash(const u64* mono, u64 key) {
+  const u64 idx = key - mono[1];
+  return idx < mono[2] ? idx * mono[0] : ~0ull;      // (idx · mult ≤ 2^64 − 1 − mult: all ones is no key's hash — a probe key outside the build side's range finds nothing)
+}
+template <class P>
+CDEV u64 join_bucket_hash(const CometKParams& prm, const u64* kw) {
+  const u64* mono = (const u64*)((const u32*)prm.out[3] + kJoinPartMono);
+  if (P::KEYMAP && mono[0]) return join_mono_hash(mono, kw[0]);
+  return hash_key<P::NKW>(kw);
+}
+
 // the run a build row leads: like join_build_classify, but the run's LENGTH comes back instead of next[] markers
 template <class P>
 CDEV bool join_classify_run(const CometKParams& prm, i64 i, i64 nb, u64& h, u32& cnt) {
@@ -3009,7 +3058,7 @@ CDEV bool join_classify_run(const CometKParams& prm, i64 i, i64 nb, u64& h, u32&
   const u64 followers = __ballot(same);
   const u64 after = lane < kWave - 1 ? followers >> (lane + 1) : 0ull;        // the lanes behind me that continue a run: mine, while the bits are ones
   cnt = P::DEDUP_BUILD ? 1u : 1u + (u32)__builtin_ctzll(~after);
-  h = hash_key<P::NKW>(kw);
+  h = join_bucket_hash<P>(prm, kw);
   return valid && !same;
 }
 
@@ -3129,11 +3178,20 @@ struct JoinBucketTable {
   static CDEV Entry none() { return uint4{0u, 0u, kJoinNoRow, 0u}; }
   const uint4* tab;
   u64 slots;
+  const u64* mono;
+  CDEV u64 key_of(const CometKParams& prm, i64 j) const {
+    if (P::KEYMAP && mono[0]) return join_mono_hash(mono, P::pkey0(prm, j));
+    return P::phash(prm, j);
+  }
   CDEV Entry peek(u64 h) const { return tab[__umul64hi(h, slots)]; }
   struct Pre {
     uint4 e2;   // the slot behind the home slot (linear probing: about every second lookup needs it)
-    bool m;     // the home slot holds the key and its leader passes the residual condition
+    u32 m;      // bit k: row k of the home slot's run holds the key and passes the residual condition (k < kPreRun; bit 0 = the leader)
   };
+  // rows of a run whose key / condition checks travel with the prefetch sweep: independent loads, ONE latency for the whole run — walked one after
+  // the other (a semi join whose condition fails for every row of the run walks all of it: TPC-DS Q95's single-warehouse orders) they were 5.7
+  // dependent latencies per probe row
+  static constexpr u32 kPreRun = 8;
   static CDEV bool holds(const uint4& e, u64 h) { return e.x == (u32)h && e.y == (u32)(h >> 32); }
   // the leader of an entry whose signature matched: single-word keys are equal already
   static CDEV bool leader_ok(const CometKParams& prm, u32 row, i64 j) { return P::NKW == 1 ? P::cond(prm, (i64)row, j) : P::match(prm, (i64)row, j); }
@@ -3142,9 +3200,17 @@ struct JoinBucketTable {
     if (e.z == kJoinNoRow) return p;
     const u64 g = __umul64hi(h, slots);
     p.e2 = tab[(g & ~(u64)(kJoinPartSlots - 1)) | ((g + 1) & (u64)(kJoinPartSlots - 1))];
-    if (holds(e, h)) p.m = leader_ok(prm, e.z, j);
+    if (holds(e, h)) {
+      p.m = leader_ok(prm, e.z, j) ? 1u : 0u;
+      if (P::HAS_COND || P::NKW != 1) {
+#pragma unroll
+        for (u32 k = 1; k < kPreRun; k++)
+          if (k < e.w && follower_ok(prm, e.z + k, j)) p.m |= 1u << k;
+      }
+    }
     return p;
   }
+  static CDEV bool follower_ok(const CometKParams& prm, u32 row, i64 j) { return P::NKW == 1 ? (!P::HAS_COND || P::cond(prm, (i64)row, j)) : P::match(prm, (i64)row, j); }
   template <class F>
   CDEV void for_each(const CometKParams& prm, i64 j, u64 h, const Entry& e, const Pre& pre, F f) const {
     if (e.z == kJoinNoRow) return;
@@ -3152,10 +3218,10 @@ struct JoinBucketTable {
     uint4 cur = e;
     for (u32 t = 0; t < (u32)kJoinPartSlots; t++) {
       if (holds(cur, h)) {
-        const bool mi = t == 0 ? pre.m : leader_ok(prm, cur.z, j);
+        const bool mi = t == 0 ? (pre.m & 1u) != 0 : leader_ok(prm, cur.z, j);
         if (mi && !f(cur.z)) return;
         for (u32 k = 1; k < cur.w; k++) {               // the run's followers: the rows right behind the leader (same key; another residual, maybe)
-          const bool mk = P::NKW == 1 ? (!P::HAS_COND || P::cond(prm, (i64)(cur.z + k), j)) : P::match(prm, (i64)(cur.z + k), j);
+          const bool mk = (!P::HAS_COND && P::NKW == 1) ? true : (t == 0 && k < kPreRun) ? ((pre.m >> k) & 1u) != 0 : follower_ok(prm, cur.z + k, j);
           if (mk && !f(cur.z + k)) return;
         }
       }
@@ -3166,12 +3232,12 @@ struct JoinBucketTable {
 };
 template <class P, bool KM = false>
 CDEV void join_probe_bucket_body(const CometKParams& prm) {
-  JoinBucketTable<P> t{(const uint4*)prm.out[0], (u64)prm.iarg[0]};
+  JoinBucketTable<P> t{(const uint4*)prm.out[0], (u64)prm.iarg[0], (const u64*)((const u32*)prm.out[3] + kJoinPartMono)};
   join_probe_tiles<P, JoinBucketTable<P>, KM>(prm, t);
 }
 template <class P>
 CDEV void join_sample_bucket_body(const CometKParams& prm) {
-  JoinBucketTable<P> t{(const uint4*)prm.out[0], (u64)prm.iarg[0]};
+  JoinBucketTable<P> t{(const uint4*)prm.out[0], (u64)prm.iarg[0], (const u64*)((const u32*)prm.out[3] + kJoinPartMono)};
   join_sample_table<P, JoinBucketTable<P>>(prm, t);
 }
 
@@ -3183,6 +3249,7 @@ struct JoinBitmapTable {
   static constexpr bool BY_KEY = true;
   typedef u32 Entry;
   static CDEV Entry none() { return kJoinNoRow; }
+  CDEV u64 key_of(const CometKParams&, i64) const { return 0ull; }
   CDEV u32 peek(u64) const { return 0u; }
   struct Pre {};
   CDEV Pre prefetch(const CometKParams&, i64, u64, u32) const { return Pre{}; }

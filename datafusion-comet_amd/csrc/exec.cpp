@@ -2057,6 +2057,7 @@ std::string ExecutionContext::metrics_proto() {
       n.metrics.emplace_back("join_probe_rows", join_probe_rows_);
       n.metrics.emplace_back("join_direct_maps", join_direct_maps_);      // joins probed through the direct map of a unique integer key
       n.metrics.emplace_back("join_bucket_tables", join_bucket_tables_);  // joins probed through the partitioned, LDS-built bucket table
+      n.metrics.emplace_back("join_mono_tables", join_mono_tables_);      // … of them, with the order-preserving hash
       n.metrics.emplace_back("join_bitmap_only", join_bitmap_only_);      // semi / anti joins answered by the build side's key bitmap alone
     }
     for (auto& c : op.children) n.children.push_back(build(*c, false));

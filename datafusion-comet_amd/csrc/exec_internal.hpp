@@ -60,7 +60,7 @@ extern "C" int comet_launch_concat_copy(const CometConcatArgs* a, const uint32_t
 extern "C" int comet_launch_strcase_lengths(const void* views, const uint8_t* ok_bytes, const int32_t* src_offs, const uint8_t* src_bytes, int64_t n, int mode, uint32_t* lengths, void* stream);
 extern "C" int comet_launch_strcase_write(const void* views, const uint8_t* ok_bytes, const int32_t* src_offs, const uint8_t* src_bytes, int64_t n, int mode, const int32_t* out_offs,
                                           uint8_t* out_bytes, void* stream);
-extern "C" int comet_launch_join_part_scan(uint32_t* cnt, int g, int np, uint32_t* tot, void* stream);
+extern "C" int comet_launch_join_part_scan(uint32_t* cnt, int g, int np, uint32_t* tot, uint32_t limit, uint64_t* over, void* stream);
 extern "C" int comet_launch_popcount128(const void* blocks, int64_t n, uint32_t* counts, void* stream);
 extern "C" int comet_launch_strfmt_lengths(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, uint32_t* lengths, void* stream);
 extern "C" int comet_launch_strfmt_write(int kind, long long arg, const void* vals128, const uint8_t* ok_bytes, int64_t n, const int32_t* out_offs, uint8_t* out_bytes, void* stream);

@@ -161,6 +161,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   static const bool count_runs = getenv("COMET_JOIN_COUNT_RUNS") == nullptr || atoi(getenv("COMET_JOIN_COUNT_RUNS")) != 0;
   DevBuf keymap;
   uint64_t keymap_first = 0, keymap_range = 0;       // a candidate for the key bitmap: one integer key whose values span a foreign key's range
+  uint64_t key_first = 0, key_range = 0;             // that key's range whatever its density (the monotone hash of the bucket table; 0: none / unknown)
   // The general table (comet_device.hpp template D''): partitioned build into LDS, 16-byte entries, one random access per probe key.  Small build
   // sides keep the chained table (it sits in L2, and one launch builds it); so does a build side with more runs than 16384 partitions hold.
   static const int64_t bucket_min_rows = getenv("COMET_JOIN_BUCKET_MIN_ROWS") ? atoll(getenv("COMET_JOIN_BUCKET_MIN_ROWS")) : 65536;
@@ -180,6 +181,10 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     // foreign key's shape.  k_jbcnt leaves min / max untouched when the kernel has no such key (KEYMAP false).
     if (got[1] <= got[2]) {
       const uint64_t range = got[2] - got[1] + 1;      // (never 0: the keys are 64-bit values of ≤ 2^31 rows … guarded below anyway)
+      if (range != 0) {
+        key_first = got[1] ^ ((uint64_t)1 << 63);
+        key_range = range;
+      }
       if (range != 0 && range <= ((uint64_t)1 << 31) && range <= (uint64_t)B.rows * 64) {
         keymap_first = got[1] ^ ((uint64_t)1 << 63);
         keymap_range = range;
@@ -191,14 +196,14 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   static const int direct_mode = getenv("COMET_JOIN_DIRECT") ? atoi(getenv("COMET_JOIN_DIRECT")) : 1;      // 0: never
   bool direct = false, keymap_built = false;
   DevBuf dranks, drows, dtiles;
-  auto build_keymap = [&]() {
+  auto build_keymap = [&](bool want_dup_flag) {
     const size_t words = (size_t)((keymap_range + 127) / 128) * 4;       // whole 128-bit blocks
     keymap.ensure(16 + words * 4 + 16);
     HIP_CHECK(hipMemsetAsync((char*)keymap.p + 16, 0, words * 4 + 16, stream_));
     const uint64_t hdr[2] = {keymap_first, keymap_range};
     write_small(keymap.p, hdr, sizeof hdr);
-    const uint64_t zero = 0;
-    write_small((char*)emitted_buf.p + 32, &zero, 8);                     // "a key came twice"
+    HIP_CHECK(hipMemsetAsync((char*)emitted_buf.p + 32, 0, 8, stream_));     // "a key came twice"
+    prm.iarg[5] = want_dup_flag ? 1 : 0;                                  // (0: the wave-combined build, which cannot tell)
     prm.out[44] = keymap.p;
     prm.out[47] = emitted_buf.p;
     prm.out[kOutErr] = err_flags_.p;
@@ -209,11 +214,11 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   // A semi / anti join that only asks whether the key exists (no residual, probe rows kept) over such a key: the bitmap is the whole build side.
   const bool bitmap_only = keymap_range != 0 && d.join_dedup_build && bitmap_only_mode != 0 && n > 0;
   if (bitmap_only) {
-    build_keymap();
+    build_keymap(false);
     bucket = false;
     join_bitmap_only_++;
   } else if (keymap_range && direct_mode != 0 && entries == keyed_rows) {       // (no two neighbouring rows share a key: a clustered fact table is spared the pass)
-    build_keymap();
+    build_keymap(true);
     uint64_t dup = 1;
     read_small(&dup, (char*)emitted_buf.p + 32, 8);
     if (!dup) {
@@ -256,11 +261,29 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
       prm.out[3] = bpart.p;
       prm.out[47] = emitted_buf.p;
       prm.out[kOutErr] = err_flags_.p;
-      launch(v, "k_jphist", (int)g, prm, 1024);
-      if (comet_launch_join_part_scan((uint32_t*)bpart.p + (2 * kMaxP + 16), (int)g, (int)np, (uint32_t*)bpart.p + (kMaxP + 16), stream_) != 0) throw CometError("hash join: launch failed");
+      // The monotone hash (comet_device.hpp join_mono_hash) where the key is one integer with a known range: slots in key order.  Whether the keys are spread
+      // evenly enough is asked BEFORE the table is built (a partition above 7/8 of its slots: the scan kernel's flag, one word read back) — if not, the
+      // scrambling hash, whose own overflow (many separate runs of one key) is only read with the probe's result.
+      static const int mono_mode = getenv("COMET_JOIN_MONO") ? atoi(getenv("COMET_JOIN_MONO")) : 1;
+      bool mono = mono_mode != 0 && key_range != 0;
+      for (int attempt = 0;; attempt++) {
+        const uint64_t mp[3] = {mono ? (~(uint64_t)0) / key_range : 0, key_first, key_range};      // (⌊(2^64 − 1) / range⌋ ≤ ⌊2^64 / range⌋: still injective, still below all ones)
+        write_small((uint32_t*)bpart.p + (kMaxP + 4), mp, sizeof mp);
+        launch(v, "k_jphist", (int)g, prm, 1024);
+        if (comet_launch_join_part_scan((uint32_t*)bpart.p + (2 * kMaxP + 16), (int)g, (int)np, (uint32_t*)bpart.p + (kMaxP + 16), (uint32_t)(kS - kS / 8),
+                                        (uint64_t*)emitted_buf.p + 6, stream_) != 0)
+          throw CometError("hash join: launch failed");
+        if (!mono) break;
+        uint64_t over = 0;
+        read_small(&over, (char*)emitted_buf.p + 48, 8);
+        if (!over) break;
+        mono = false;
+        HIP_CHECK(hipMemsetAsync((char*)emitted_buf.p + 48, 0, 8, stream_));
+      }
       launch(v, "k_jpscat", (int)g, prm, 1024);
       launch(v, "k_jtbuild", (int)np, prm);
       join_bucket_tables_++;
+      if (mono) join_mono_tables_++;
     }
   }
   int64_t cap = 1024;
@@ -332,7 +355,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
       read_small(cnt, emitted_buf.p, sizeof cnt);
       wanted = cnt[0] >= 64 && cnt[1] * 2 < cnt[0];
     }
-    if (wanted) build_keymap();
+    if (wanted) build_keymap(false);
   }
   // FK-shaped joins emit at most one row per probe row; anything beyond the capacity is counted, not written, and the probe re-run
   int64_t out_cap = d.join_build_only ? 1 : n + 1024;

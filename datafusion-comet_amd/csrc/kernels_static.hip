@@ -334,7 +334,7 @@ extern "C" int comet_launch_popcount128(const void* blocks, int64_t n, uint32_t*
 
 // ---- bucket-table joins (comet_device.hpp template D''): cnt[b][p] = leaders of partition p that block b of the partition passes saw → in place its
 // exclusive prefix over the blocks (where block b's records of partition p start inside the partition), tot[p] = the partition's size
-__global__ __launch_bounds__(256) void join_part_scan_kernel(unsigned int* cnt, int g, int np, unsigned int* tot) {
+__global__ __launch_bounds__(256) void join_part_scan_kernel(unsigned int* cnt, int g, int np, unsigned int* tot, unsigned int limit, unsigned long long* over) {
   const int p = (int)(blockIdx.x * 256 + threadIdx.x);
   if (p >= np) return;
   unsigned int run = 0;
@@ -355,8 +355,10 @@ __global__ __launch_bounds__(256) void join_part_scan_kernel(unsigned int* cnt, 
     run += c;
   }
   tot[p] = run;
+  if (run > limit) *(volatile unsigned long long*)over = 1ull;      // the partition would not fit its table (the executor asks before it builds with the monotone hash)
 }
-extern "C" int comet_launch_join_part_scan(uint32_t* cnt, int g, int np, uint32_t* tot, void* stream) {
-  if (g > 0 && np > 0) hipLaunchKernelGGL(join_part_scan_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cnt, g, np, tot);
+extern "C" int comet_launch_join_part_scan(uint32_t* cnt, int g, int np, uint32_t* tot, uint32_t limit, uint64_t* over, void* stream) {
+  if (g > 0 && np > 0)
+    hipLaunchKernelGGL(join_part_scan_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cnt, g, np, tot, (unsigned int)limit, (unsigned long long*)over);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -26,6 +26,7 @@ template <class T> static inline T __shfl(T v, int, int = 64) { return v; }
 template <class T> static inline T __shfl_up(T v, unsigned, int = 64) { return v; }
 template <class T> static inline T __shfl_down(T v, unsigned, int = 64) { return v; }
 template <class T> static inline T __shfl_xor(T v, int, int = 64) { return v; }
+static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * (unsigned __int128)b) >> 64); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }

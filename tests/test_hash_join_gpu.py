@@ -333,7 +333,10 @@ def test_unique_integer_build_key_goes_through_the_direct_map(built, jt):
         ncols = 3 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 6
         got, m = _join_metrics(j, [probe_t, build_t], ncols)
         want = _oracle(j, [probe_t, build_t])
-        assert m["join_direct_maps"] == 1, m
+        if cond is None and jt in (S.LEFT_SEMI, S.LEFT_ANTI):      # (only the key's existence matters: the bitmap alone answers, no rows[] needed)
+            assert m["join_bitmap_only"] == 1 and m["join_direct_maps"] == 0, m
+        else:
+            assert m["join_direct_maps"] == 1, m
         assert got.num_rows == want.num_rows > 1000
         assert _sorted(got).equals(_sorted(want))
 
@@ -456,3 +459,35 @@ def test_bucket_table_partition_overflow_takes_the_chained_table(built):
     assert m["join_bucket_tables"] == 0, m
     assert got.num_rows == want.num_rows > 100_000
     assert _sorted(got).equals(_sorted(want))
+
+
+def test_monotone_hash_is_dropped_for_keys_that_do_not_spread_over_their_range(built):
+    """One integer key → the bucket table tries the order-preserving hash (slots in key order: clustered, sorted fact tables then stream).  Keys 0 .. 200 000 plus
+    ONE key at 2^40: under that hash all but one entry would land in the first partition — the partition sizes say so before the table is built, and the join runs
+    with the scrambling hash (metrics: a bucket table, not a monotone one).  Dense keys with NULLs and duplicates keep the monotone hash."""
+    rng = np.random.default_rng(75)
+    nb, npr = 200_000, 150_000
+    bk = rng.permutation(np.arange(nb, dtype=np.int64))
+    bk[5] = 1 << 40
+    bk[1000:1100] = bk[900:1000]                                   # duplicates, far apart: no direct map
+    build_t = pa.table({"k": pa.array(bk, mask=rng.random(nb) < 0.01), "v": pa.array(rng.integers(-1000, 1000, nb), pa.int32()), "id": pa.array(np.arange(nb, dtype=np.int64))})
+    pk = rng.integers(-10, nb + 10, npr).astype(np.int64)
+    pk[:3] = [1 << 40, (1 << 40) + 1, -(1 << 50)]
+    probe_t = pa.table({"k": pa.array(pk, mask=rng.random(npr) < 0.02), "v": pa.array(rng.integers(-1000, 1000, npr), pa.int32()), "id": pa.array(np.arange(npr, dtype=np.int64))})
+    cond = S.lt(S.col(1, S.T_INT32), S.col(4, S.T_INT32))
+    for jt in (S.INNER, S.LEFT_ANTI, S.FULL_OUTER):
+        j = S.hash_join(S.scan(CFIELDS), S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_RIGHT, cond)
+        got, m = _join_metrics(j, [probe_t, build_t], 3 if jt == S.LEFT_ANTI else 6)
+        want = _oracle(j, [probe_t, build_t])
+        assert m["join_bucket_tables"] == 1 and m["join_mono_tables"] == 0, m
+        assert got.num_rows == want.num_rows > 1000 and _sorted(got).equals(_sorted(want))
+    # the same sides without the outlier: dense keys → the monotone hash; probe keys below, above and inside the range
+    bk2 = bk.copy()
+    bk2[5] = 17
+    build2 = build_t.set_column(0, "k", pa.array(bk2, mask=rng.random(nb) < 0.01))
+    for jt in (S.INNER, S.LEFT_SEMI, S.RIGHT_OUTER):
+        j = S.hash_join(S.scan(CFIELDS), S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_RIGHT, cond)
+        got, m = _join_metrics(j, [probe_t, build2], 3 if jt == S.LEFT_SEMI else 6)
+        want = _oracle(j, [probe_t, build2])
+        assert m["join_bucket_tables"] == 1 and m["join_mono_tables"] == 1, m
+        assert got.num_rows == want.num_rows > 1000 and _sorted(got).equals(_sorted(want))

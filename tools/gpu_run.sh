@@ -150,6 +150,20 @@ for r in rows[:14]:
     m=re.search(r"(k_\w+|[a-z_0-9]+_kernel|__amd\w+)", r["Name"]); print(f'{(m.group(1) if m else r["Name"][:30]):28s} calls {r["Calls"]:>4s} total_ms {float(r["TotalDurationNs"])/1e6:9.3f} avg_ms {float(r["AverageNs"])/1e6:8.3f}')
 PYEOF
 }
+q95_host() {       # host calls and device work of the last Q95 run side by side: what fills the gaps between the kernels
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT/q95_host -o h -- python $GRAFT_REPO_ROOT/tools/q95_bench.py --orders 16000000 --reps 2 --verify none > $OUT/q95_host.log 2>&1)
+  python tools/hip_timeline.py $OUT/q95_host k_filter ${TL_MIN_US:-4} 5 > $OUT/q95_host.txt 2>&1; rm -rf $OUT/q95_host; tail -${TL_LINES:-60} $OUT/q95_host.txt | cut -c1-140
+}
+q95_pmc() {        # per-kernel HBM traffic and wait cycles of Q95 stage A (separate PMC passes, as the guide prescribes)
+  Q95="python $GRAFT_REPO_ROOT/tools/q95_bench.py --orders 16000000 --reps 1 --verify none"
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q95_stats -o q95 -- $Q95 > $OUT/q95_stats.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/q95_fetch -o q95 -- $Q95 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/q95_tcc -o q95 -- $Q95 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/q95_sq -o q95 -- $Q95 > /dev/null 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/pmc_join_summary.py $OUT q95 > $OUT/q95_join_pmc.txt 2>&1; head -60 $OUT/q95_join_pmc.txt | cut -c1-260
+}
 q95_bisect() {     # TPC-DS Q95 stage A with the libraries of earlier commits (bisect/<tag>/, built from git worktrees) and with HEAD's join switches, on ONE box
   for v in $(ls bisect 2>/dev/null); do timeout 200 python tools/q95_variant.py --root bisect/$v --tag $v 2> $OUT/q95_$v.err | tee -a $OUT/q95_bisect.jsonl | cut -c1-300; done
   timeout 200 python tools/q95_variant.py --root . --tag head 2> $OUT/q95_head.err | tee -a $OUT/q95_bisect.jsonl | cut -c1-300

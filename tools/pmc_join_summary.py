@@ -10,7 +10,8 @@ from collections import OrderedDict, defaultdict
 
 root = sys.argv[1]
 PFX = sys.argv[2] if len(sys.argv) > 2 else "q95"
-KERNELS = ("k_jbuild", "k_jprobe", "k_jdprobe", "k_jlds", "k_filter", "k_jbmap", "k_jbcnt", "k_jdrows", "k_gagg", "k_gemit", "k_jbemit", "k_jbcount")
+KERNELS = ("k_jbuild", "k_jprobe", "k_jprobe_km", "k_jprobe_b", "k_jprobe_bkm", "k_jprobe_bm", "k_jdprobe", "k_jlds", "k_jphist", "k_jpscat", "k_jtbuild", "k_filter", "k_jbmap", "k_jbcnt",
+           "k_jdrows", "k_gagg", "k_gemit", "k_jbemit", "k_jbcount", "k_pack", "k_emit")
 
 
 def short(n):
