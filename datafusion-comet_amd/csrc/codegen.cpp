@@ -4222,6 +4222,10 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   // not part of the probe side at all (outer / anti joins do not emit it either)
   if (fu && !fu->preds.empty()) {
     Gen g(pt, pv_src);
+    // every load of the chain's predicates up front, no "only for rows still alive" staging: a staged load sits in a lane-dependent branch and is waited for
+    // inside it, so the probe tile's sixteen rows per thread became sixteen CHAINS of dependent latencies; straight-line loads of sixteen rows are in flight together
+    static const bool eager_keep = getenv("COMET_JOIN_EAGER_KEEP") == nullptr || atoi(getenv("COMET_JOIN_EAGER_KEEP")) != 0;
+    g.eager_loads = eager_keep;
     g.locate = [nb](int idx) { return std::make_pair(nb + idx, std::string("j")); };
     for (auto& p : fu->preds) {
       g.add_predicate(p);

@@ -2523,8 +2523,29 @@ CDEV void join_build_unmatched_emit_body(const CometKParams& prm) {
 constexpr int kJoinLdsCap = 8192;
 constexpr int kJoinLdsMaxBuild = 6144;
 constexpr u32 kJoinEmpty = 0xffffffffu;
-constexpr int kJoinR = 8;                    // slices of a wave's survivors probed together (eight random accesses in flight per lane)
-constexpr int kJoinR0 = 16;                  // probe rows per thread and tile: the filter / key bitmap phase runs over twice as many rows as one probe batch holds —
+#ifndef COMET_JOIN_R
+#define COMET_JOIN_R 4
+#endif
+#ifndef COMET_JOIN_R0
+#define COMET_JOIN_R0 16
+#endif
+#ifndef COMET_JOIN_UNCOND
+#define COMET_JOIN_UNCOND 1
+#endif
+#ifndef COMET_JOIN_PRE_RUN
+#define COMET_JOIN_PRE_RUN 2
+#endif
+#ifndef COMET_JOIN_FILTER_UNCOND
+#define COMET_JOIN_FILTER_UNCOND 1
+#endif
+#ifndef COMET_JOIN_KM_UNCOND
+#define COMET_JOIN_KM_UNCOND 1
+#endif
+#ifndef COMET_JOIN_DIRECT_UNCOND
+#define COMET_JOIN_DIRECT_UNCOND 1
+#endif
+constexpr int kJoinR = COMET_JOIN_R;                    // slices of a wave's survivors probed together (eight random accesses in flight per lane)
+constexpr int kJoinR0 = COMET_JOIN_R0;                  // probe rows per thread and tile: the filter / key bitmap phase runs over twice as many rows as one probe batch holds —
                                              // most rows end there, and a wave's handful of survivors costs the same latency whatever the tile's size
 
 // candidates of probe row j in the global chained table
@@ -2533,6 +2554,7 @@ struct JoinGlobalTable {
   static constexpr bool BY_KEY = false;      // peek() takes the key's hash
   typedef u32 Entry;                         // what peek() hands out: the bucket's head
   static CDEV Entry none() { return kJoinNoRow; }
+  static constexpr bool UNCONDITIONAL = false;      // peek() / prefetch() only for lanes that hold a probe row with a key
   CDEV u64 key_of(const CometKParams& prm, i64 j) const { return P::phash(prm, j); }      // what peek() takes
   const u32* head;
   const i32* next;
@@ -2597,6 +2619,7 @@ struct JoinGlobalTable {
 template <class P>
 struct JoinLdsTable {
   static constexpr bool BY_KEY = false;
+  static constexpr bool UNCONDITIONAL = false;
   typedef u32 Entry;
   static CDEV Entry none() { return kJoinEmpty; }
   CDEV u64 key_of(const CometKParams& prm, i64 j) const { return P::phash(prm, j); }
@@ -2624,6 +2647,7 @@ struct JoinLdsTable {
 template <class P>
 struct JoinDirectTable {
   static constexpr bool BY_KEY = true;       // peek() takes the key itself
+  static constexpr bool UNCONDITIONAL = COMET_JOIN_DIRECT_UNCOND != 0;      // (peek clamps keys outside the bitmap, prefetch clamps the row it reads back)
   typedef u32 Entry;
   static CDEV Entry none() { return kJoinNoRow; }
   CDEV u64 key_of(const CometKParams& prm, i64 j) const { return P::pkey0(prm, j); }
@@ -2631,7 +2655,8 @@ struct JoinDirectTable {
   const u32* ranks;
   const u32* rows;
   CDEV u32 peek(u64 key) const {             // position of the key among the build side's keys (its bit is set: the tile's filter phase looked)
-    const u64 idx = key - km[0];
+    u64 idx = key - km[0];
+    if (UNCONDITIONAL) idx = idx < km[1] ? idx : 0ull;      // (a lane without a probe row asks with whatever key it has)
     const u64 blk = idx >> 7;
     const uint4 w = ((const uint4*)(km + 2))[blk];
     const u32 b = (u32)idx & 127u;
@@ -2645,6 +2670,7 @@ struct JoinDirectTable {
   struct Pre { u32 row; bool m; };
   CDEV Pre prefetch(const CometKParams& prm, i64 j, u64, u32 e) const {
     Pre p{rows[e], true};
+    if (UNCONDITIONAL && p.row >= (u32)prm.iarg[1]) p.row = 0;      // (a position behind the last key: rows[] holds nothing there; such a lane's answer is dropped)
     if (P::HAS_COND) p.m = P::match(prm, (i64)p.row, j);
     return p;
   }
@@ -2693,11 +2719,47 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
 #pragma unroll
       for (int r = 0; r < kJoinR0; r++) {
         const i64 j = base + (i64)r * kBlock + threadIdx.x;
+#if COMET_JOIN_FILTER_UNCOND
+        const i64 js = j < n ? j : n - 1;                      // (a row that exists: the loads below carry no lane-dependent branch of their own)
+        const bool keep = P::pkeep(prm, js), pv = P::pvalid(prm, js);
+        const bool alive = keep & (j < n);
+        if (alive) alive_bits |= 1u << r;
+        if (alive & pv) can_bits |= 1u << r;
+#else
         const bool alive = j < n && P::pkeep(prm, j);
         if (alive) alive_bits |= 1u << r;
         if (alive && P::pvalid(prm, j)) can_bits |= 1u << r;
+#endif
       }
     } else {
+#if COMET_JOIN_KM_UNCOND
+    // (no lane-dependent branch around a load — see JoinBucketTable::UNCONDITIONAL: rows past the end read the table's last row, rows the chain's filter
+    // dropped still load their key, keys outside the bitmap read its first word; the answers are masked afterwards)
+#pragma unroll
+    for (int r = 0; r < kJoinR0; r++) {
+      const i64 j = base + (i64)r * kBlock + threadIdx.x;
+      const bool keep = P::pkeep(prm, j < n ? j : n - 1);
+      if (keep & (j < n)) alive_bits |= 1u << r;
+    }
+    if (keymap) {
+      u64 keys[kJoinR0];
+#pragma unroll
+      for (int r = 0; r < kJoinR0; r++) {
+        const i64 j = base + (i64)r * kBlock + threadIdx.x;
+        const i64 js = j < n ? j : n - 1;
+        const bool pv = P::pvalid(prm, js);
+        keys[r] = P::pkey0(prm, js);
+        if (((alive_bits >> r) & 1u) & pv) can_bits |= 1u << r;
+      }
+      const u64 first = keymap[0], bits = keymap[1];
+      u32 words[kJoinR0];
+#pragma unroll
+      for (int r = 0; r < kJoinR0; r++) {
+        const u64 idx = keys[r] - first;
+        const u32 w = ((const u32*)(keymap + 2))[idx < bits ? idx >> 5 : 0ull];
+        words[r] = (((can_bits >> r) & 1u) && idx < bits) ? w : 0u;
+      }
+#else
 #pragma unroll
     for (int r = 0; r < kJoinR0; r++) {
       const i64 j = base + (i64)r * kBlock + threadIdx.x;
@@ -2718,6 +2780,7 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
         const u64 idx = keys[r] - first;
         words[r] = (((can_bits >> r) & 1u) && idx < bits) ? ((const u32*)(keymap + 2))[idx >> 5] : 0u;
       }
+#endif
 #pragma unroll
       for (int r = 0; r < kJoinR0; r++)
         if (!((words[r] >> ((u32)(keys[r] - first) & 31u)) & 1u)) can_bits &= ~(1u << r);      // the build side does not hold the key: settled
@@ -2754,6 +2817,28 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
     u64 hs[kJoinR];
     typename T::Entry he[kJoinR];
     u32 keyed = 0;                                   // bit q: my entry of slice q exists and has a non-NULL key (it can match)
+    typename T::Pre pre[kJoinR];
+    if (T::UNCONDITIONAL) {
+      // No branch around any load: a lane without an entry (or with a NULL key) computes on the tile's first row and drops the result.  Three straight-line
+      // sweeps — keys, buckets, the runs' checks — each with all its loads in flight (slices that do not exist cost their instructions, not their latency).
+      i64 js[kJoinR];
+#pragma unroll
+      for (int q = 0; q < kJoinR; q++) {
+        const u32 k = (u32)q * kWave + (u32)lane;
+        const u32 ent = list[k < m ? k : 0u];
+        js[q] = k < m ? base + (i64)(ent & 0x7fffu) : base;
+        if (k < m && !(ent & 0x8000u)) keyed |= 1u << q;
+      }
+#pragma unroll
+      for (int q = 0; q < kJoinR; q++) hs[q] = table.key_of(prm, js[q]);
+#pragma unroll
+      for (int q = 0; q < kJoinR; q++) he[q] = table.peek(hs[q]);
+#pragma unroll
+      for (int q = 0; q < kJoinR; q++) pre[q] = table.prefetch(prm, js[q], hs[q], he[q]);
+#pragma unroll
+      for (int q = 0; q < kJoinR; q++)
+        if (!((keyed >> q) & 1u)) he[q] = T::none();
+    } else {
 #pragma unroll
     for (int q = 0; q < kJoinR; q++) {
       hs[q] = 0;
@@ -2770,11 +2855,11 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
     }
 #pragma unroll
     for (int q = 0; q < kJoinR; q++) he[q] = (q < nslice && ((keyed >> q) & 1u)) ? table.peek(hs[q]) : T::none();
-    typename T::Pre pre[kJoinR];
 #pragma unroll
     for (int q = 0; q < kJoinR; q++) {
       pre[q] = typename T::Pre();
       if (q < nslice && ((keyed >> q) & 1u)) pre[q] = table.prefetch(prm, base + (i64)(list[(u32)q * kWave + (u32)lane] & 0x7fffu), hs[q], he[q]);
+    }
     }
     // settle the rows; positions as we go: slice after slice inside the wave (exclusive scan of the emit counts + the wave's running total)
     u32 first[kJoinR], excl[kJoinR];
@@ -3032,10 +3117,16 @@ CDEV u64 join_mono_hash(const u64* mono, u64 key) {
   const u64 idx = key - mono[1];
   return idx < mono[2] ? idx * mono[0] : ~0ull;      // (idx · mult ≤ 2^64 − 1 − mult: all ones is no key's hash — a probe key outside the build side's range finds nothing)
 }
+// either hash of a key, chosen WITHOUT a branch (the choice is uniform, but a branch would cut the probe tile's straight-line load sweeps into blocks — and the
+// compiler waits for a block's loads at its end): both are computed, a mask picks
+CDEV u64 join_pick_hash(const u64* mono, u64 key0, u64 scrambled) {
+  const u64 pick = mono[0] ? ~0ull : 0ull;
+  return (join_mono_hash(mono, key0) & pick) | (scrambled & ~pick);
+}
 template <class P>
 CDEV u64 join_bucket_hash(const CometKParams& prm, const u64* kw) {
   const u64* mono = (const u64*)((const u32*)prm.out[3] + kJoinPartMono);
-  if (P::KEYMAP && mono[0]) return join_mono_hash(mono, kw[0]);
+  if (P::KEYMAP) return join_pick_hash(mono, kw[0], hash_key<P::NKW>(kw));
   return hash_key<P::NKW>(kw);
 }
 
@@ -3174,13 +3265,18 @@ CDEV void join_table_build_body(const CometKParams& prm) {
 template <class P>
 struct JoinBucketTable {
   static constexpr bool BY_KEY = false;
+  // peek() and prefetch() are safe for ANY lane (any hash lands on a slot; rows are clamped into the run, or to row 0): the tile calls them without a per-lane
+  // branch.  A load inside a lane-dependent branch is waited for before the branch ends (s_waitcnt vmcnt(0) in its block) — the eight "independent" bucket loads
+  // of a lane then run one after the other: 442 full waits for 610 loads in the first build of this kernel, 84 % of all wave cycles waiting
+  // (profiles/r6_q95_join_pmc.txt).  Straight-line loads are issued together and waited for once.
+  static constexpr bool UNCONDITIONAL = COMET_JOIN_UNCOND != 0;
   typedef uint4 Entry;
   static CDEV Entry none() { return uint4{0u, 0u, kJoinNoRow, 0u}; }
   const uint4* tab;
   u64 slots;
   const u64* mono;
   CDEV u64 key_of(const CometKParams& prm, i64 j) const {
-    if (P::KEYMAP && mono[0]) return join_mono_hash(mono, P::pkey0(prm, j));
+    if (P::KEYMAP) return join_pick_hash(mono, P::pkey0(prm, j), P::phash(prm, j));
     return P::phash(prm, j);
   }
   CDEV Entry peek(u64 h) const { return tab[__umul64hi(h, slots)]; }
@@ -3191,23 +3287,44 @@ struct JoinBucketTable {
   // rows of a run whose key / condition checks travel with the prefetch sweep: independent loads, ONE latency for the whole run — walked one after
   // the other (a semi join whose condition fails for every row of the run walks all of it: TPC-DS Q95's single-warehouse orders) they were 5.7
   // dependent latencies per probe row
-  static constexpr u32 kPreRun = 8;
+  static constexpr u32 kPreRun = COMET_JOIN_PRE_RUN;
   static CDEV bool holds(const uint4& e, u64 h) { return e.x == (u32)h && e.y == (u32)(h >> 32); }
   // the leader of an entry whose signature matched: single-word keys are equal already
   static CDEV bool leader_ok(const CometKParams& prm, u32 row, i64 j) { return P::NKW == 1 ? P::cond(prm, (i64)row, j) : P::match(prm, (i64)row, j); }
-  CDEV Pre prefetch(const CometKParams& prm, i64 j, u64 h, const Entry& e) const {
-    Pre p{none(), false};
-    if (e.z == kJoinNoRow) return p;
+  CDEV Pre prefetch(const CometKParams& prm, i64 j, u64 h, const Entry& e) const {      // (j: any valid probe row; e: an entry or none())
+    Pre p;
     const u64 g = __umul64hi(h, slots);
-    p.e2 = tab[(g & ~(u64)(kJoinPartSlots - 1)) | ((g + 1) & (u64)(kJoinPartSlots - 1))];
-    if (holds(e, h)) {
-      p.m = leader_ok(prm, e.z, j) ? 1u : 0u;
-      if (P::HAS_COND || P::NKW != 1) {
+    if (!UNCONDITIONAL) {
+      p.e2 = none();
+      p.m = 0;
+      if (e.z == kJoinNoRow) return p;
+      p.e2 = tab[(g & ~(u64)(kJoinPartSlots - 1)) | ((g + 1) & (u64)(kJoinPartSlots - 1))];
+      if (holds(e, h)) {
+        p.m = leader_ok(prm, e.z, j) ? 1u : 0u;
+        if (P::HAS_COND || P::NKW != 1) {
 #pragma unroll
-        for (u32 k = 1; k < kPreRun; k++)
-          if (k < e.w && follower_ok(prm, e.z + k, j)) p.m |= 1u << k;
+          for (u32 k = 1; k < kPreRun; k++)
+            if (k < e.w && follower_ok(prm, e.z + k, j)) p.m |= 1u << k;
+        }
       }
+      return p;
     }
+    p.e2 = tab[(g & ~(u64)(kJoinPartSlots - 1)) | ((g + 1) & (u64)(kJoinPartSlots - 1))];
+    const bool hit = e.z != kJoinNoRow && holds(e, h);
+    u32 m = hit ? 1u : 0u;
+    if (P::HAS_COND || P::NKW != 1) {
+      // the run's rows (the first kPreRun of them), every lane: a lane without a hit, or with a shorter run, checks row 0 / the run's last row again and drops the answer
+      const u32 row0 = hit ? e.z : 0u, last = hit ? e.z + e.w - 1u : 0u;
+      m = 0;
+#pragma unroll
+      for (u32 k = 0; k < kPreRun; k++) {
+        const u32 r = row0 + k <= last ? row0 + k : last;
+        const bool ok = k == 0 ? leader_ok(prm, r, j) : follower_ok(prm, r, j);
+        m |= (ok ? 1u : 0u) << k;
+      }
+      m &= hit ? (e.w >= kPreRun ? (1u << kPreRun) - 1u : (1u << e.w) - 1u) : 0u;
+    }
+    p.m = m;
     return p;
   }
   static CDEV bool follower_ok(const CometKParams& prm, u32 row, i64 j) { return P::NKW == 1 ? (!P::HAS_COND || P::cond(prm, (i64)row, j)) : P::match(prm, (i64)row, j); }
@@ -3247,6 +3364,7 @@ CDEV void join_sample_bucket_body(const CometKParams& prm) {
 template <class P>
 struct JoinBitmapTable {
   static constexpr bool BY_KEY = true;
+  static constexpr bool UNCONDITIONAL = false;
   typedef u32 Entry;
   static CDEV Entry none() { return kJoinNoRow; }
   CDEV u64 key_of(const CometKParams&, i64) const { return 0ull; }

@@ -334,6 +334,7 @@ class ExecutionContext {
   std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)
   std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index
   int64_t join_build_rows_ = 0, join_probe_rows_ = 0, join_keymap_bytes_ = 0, join_direct_maps_ = 0, join_bucket_tables_ = 0, join_bitmap_only_ = 0, join_mono_tables_ = 0;
+  int small_write_slot_ = 0;         // write_small's ring of staging slots
   bool join_no_bucket_ = false;      // set while a join whose bucket table overflowed re-runs over the chained table
   int64_t bytes_scanned_ = 0;
   int64_t row_groups_pruned_ = 0;

@@ -263,9 +263,23 @@ void ExecutionContext::read_small(void* dst, const void* dev_src, size_t n) {
 void ExecutionContext::write_small(void* dev_dst, const void* src, size_t n) {
   if (n > 2048) throw CometError("internal: write_small of " + std::to_string(n) + " bytes (its staging holds 2048)");
   small_host_.ensure(4096);
+  // a few words (table headers, hash parameters): sixteen 128-byte slots of the staging take turns, the stream is waited for only when they wrap — a slot may still
+  // be the source of an earlier async copy, but not of one sixteen writes (and at least one synchronisation) back
+  if (n <= 128) {
+    if (small_write_slot_ == 16) {
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      small_write_slot_ = 0;
+    }
+    char* slot = (char*)small_host_.p + 2048 + 128 * (size_t)small_write_slot_++;
+    memcpy(slot, src, n);
+    HIP_CHECK(hipMemcpyAsync(dev_dst, slot, n, hipMemcpyHostToDevice, stream_));
+    return;
+  }
   HIP_CHECK(hipStreamSynchronize(stream_));   // the scratch may still be the source of an earlier async copy
+  small_write_slot_ = 0;
   memcpy((char*)small_host_.p + 2048, src, n);
   HIP_CHECK(hipMemcpyAsync(dev_dst, (char*)small_host_.p + 2048, n, hipMemcpyHostToDevice, stream_));
+  small_write_slot_ = 16;                     // (the large write owns the whole area until the stream has been waited for)
 }
 
 void ExecutionContext::timed_begin() {

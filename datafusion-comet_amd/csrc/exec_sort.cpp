@@ -273,6 +273,7 @@ DevTable ExecutionContext::sort_table(const Operator& sop, const DevTable& in) {
   HIP_CHECK(hipMemsetAsync(flags.p, 0, (size_t)W * 4, stream_));
   if (comet_launch_sort_plane_varies((const uint8_t*)planes->p, n, W, (uint32_t*)flags.p, stream_) != 0) throw CometError("sort: launch failed");
   std::vector<uint32_t> varies((size_t)W);
+  if ((size_t)W * 4 > small_host_.cap) HIP_CHECK(hipStreamSynchronize(stream_));      // (growing the staging frees the old block: no copy out of write_small's slots may be in flight)
   small_host_.ensure(std::max<size_t>(4096, (size_t)W * 4));
   HIP_CHECK(hipMemcpyAsync(small_host_.p, flags.p, (size_t)W * 4, hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipStreamSynchronize(stream_));

@@ -75,7 +75,25 @@ bool looks_like_code_object(const std::vector<char>& b) { return b.size() > 64 &
 std::shared_ptr<CodeObject> jit_compile(const std::string& source_in) {
   // COMET_LD_NT=0/1 (an experiment switch): column loads of EVERY generated kernel as ordinary / non-temporal loads, whatever the generator chose
   static const char* nt = getenv("COMET_LD_NT");
-  const std::string source = nt ? std::string("#define COMET_LD_NT ") + (atoi(nt) ? "1" : "0") + "\n" + source_in : source_in;
+  std::string source = nt ? std::string("#define COMET_LD_NT ") + (atoi(nt) ? "1" : "0") + "\n" + source_in : source_in;
+  // COMET_JIT_DEFINES="NAME=value;NAME2=value2" (an experiment switch): #define lines in front of every generated source — the tuning constants of
+  // comet_device.hpp that are written as #ifndef defaults (join tile shape, …) can be A/B-ed on one box without rebuilding the library; part of the cache key
+  static const char* defs = getenv("COMET_JIT_DEFINES");
+  if (defs && *defs) {
+    std::string head, d = defs;
+    size_t pos = 0;
+    while (pos <= d.size()) {
+      size_t e = d.find(';', pos);
+      std::string item = d.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+      if (!item.empty()) {
+        size_t eq = item.find('=');
+        head += "#define " + (eq == std::string::npos ? item + " 1" : item.substr(0, eq) + " " + item.substr(eq + 1)) + "\n";
+      }
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+    source = head + source;
+  }
   // the key covers the generated source AND the hand-written headers it instantiates
   static const uint64_t h2 = fnv1a(toolchain_tag(), fnv1a(kEmbeddedDeviceHeader, fnv1a(kEmbeddedKParamsHeader, fnv1a(kEmbeddedRyuHeader, fnv1a(kEmbeddedStrtodHeader, fnv1a(kEmbeddedStrtsHeader, fnv1a(kEmbeddedRegexVmHeader)))))));
   uint64_t h1 = fnv1a(source);

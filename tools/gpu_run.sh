@@ -164,6 +164,25 @@ q95_pmc() {        # per-kernel HBM traffic and wait cycles of Q95 stage A (sepa
   cd $GRAFT_REPO_ROOT
   python tools/pmc_join_summary.py $OUT q95 > $OUT/q95_join_pmc.txt 2>&1; head -60 $OUT/q95_join_pmc.txt | cut -c1-260
 }
+q95_cfgs() {       # Q95 stage A under environment configurations: "$Q95_CFGS" = |-separated entries, each a space-separated list of VAR=value ("-" = none)
+  IFS='|' read -ra ENTRIES <<< "${Q95_CFGS:--}"
+  for E in "${ENTRIES[@]}"; do
+    E=$(echo $E)
+    [ "$E" = "-" ] && E=""
+    env $E timeout 300 python tools/q95_variant.py --root . --reps ${Q95_REPS:-3} --tag "$E" 2> $OUT/q95_cfg.err | tee -a $OUT/q95_cfgs.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(f'{min(d[\"stage_a_ms\"]):7.2f} ms  {d[\"tag\"]}  {d[\"result\"]}')" || tail -3 $OUT/q95_cfg.err
+  done
+}
+q3_cfgs() {        # SF100 Q3 on one GPU under environment configurations ("$Q3_CFGS", as q95_cfgs)
+  IFS='|' read -ra ENTRIES <<< "${Q3_CFGS:--}"
+  for E in "${ENTRIES[@]}"; do
+    E=$(echo $E)
+    [ "$E" = "-" ] && E=""
+    env $E timeout 300 python tools/q3_dist.py --orders 150000000 --steps 4 --warmup 2 --kernel-times > $OUT/q3_cfg.json 2> $OUT/q3_cfg.err; python -c "
+import json; d=json.load(open('$OUT/q3_cfg.json')); k=(d.get('roofline') or {}).get('kernels') or []
+print(f'{d[\"sec_per_run\"]*1e3:7.3f} ms  $E  stages {d[\"stage_ms_rank0\"]}  ' + ' '.join(f'{x[\"name\"]}={x[\"ms\"]:.2f}' for x in k[:6]), 'verified', d.get('verified_vs_torch'))" 2>&1 | tail -1
+    echo "{\"cfg\": \"$E\", \"out\": $(cat $OUT/q3_cfg.json)}" >> $OUT/q3_cfgs.jsonl
+  done
+}
 q95_bisect() {     # TPC-DS Q95 stage A with the libraries of earlier commits (bisect/<tag>/, built from git worktrees) and with HEAD's join switches, on ONE box
   for v in $(ls bisect 2>/dev/null); do timeout 200 python tools/q95_variant.py --root bisect/$v --tag $v 2> $OUT/q95_$v.err | tee -a $OUT/q95_bisect.jsonl | cut -c1-300; done
   timeout 200 python tools/q95_variant.py --root . --tag head 2> $OUT/q95_head.err | tee -a $OUT/q95_bisect.jsonl | cut -c1-300
