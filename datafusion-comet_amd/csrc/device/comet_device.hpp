@@ -2542,10 +2542,15 @@ constexpr u32 kJoinEmpty = 0xffffffffu;
 #define COMET_JOIN_KM_UNCOND 1
 #endif
 #ifndef COMET_JOIN_DIRECT_UNCOND
-#define COMET_JOIN_DIRECT_UNCOND 1
+#define COMET_JOIN_DIRECT_UNCOND 0      // (measured on SF100 Q3: the direct map's few survivors per tile gain nothing from the unconditional sweeps' extra instructions)
 #endif
 constexpr int kJoinR = COMET_JOIN_R;                    // slices of a wave's survivors probed together (eight random accesses in flight per lane)
-constexpr int kJoinR0 = COMET_JOIN_R0;                  // probe rows per thread and tile: the filter / key bitmap phase runs over twice as many rows as one probe batch holds —
+// (kJoinR0 = COMET_JOIN_R0, a template parameter of join_probe_tiles since round 6: the direct map's probe — nearly all of its work is the filter / bitmap phase —
+// takes 24 rows per thread (SF100 Q3: 4.09 → 3.90 ms), the bucket table's 16 (24 cost TPC-DS Q95 2 ms: registers))
+#ifndef COMET_JOIN_R0_DIRECT
+#define COMET_JOIN_R0_DIRECT 24
+#endif
+// probe rows per thread and tile: the filter / key bitmap phase runs over twice as many rows as one probe batch holds —
                                              // most rows end there, and a wave's handful of survivors costs the same latency whatever the tile's size
 
 // candidates of probe row j in the global chained table
@@ -2695,7 +2700,7 @@ struct JoinDirectTable {
 // thread; a kernel that CAN take them is allocated the registers for them whether the bitmap exists at run time or not, and a probe that lives
 // on random accesses (TPC-DS Q95's self-joins: 72 M rows, duplicate-heavy keys, no bitmap) lost a fifth of its speed to the lower occupancy
 // (round-5 bisect: 22.7 → 26.7 ms, profiles/r5_q95_bisect.txt).  So the table probe without a bitmap is its own kernel with the plain filter loop.
-template <class P, class T, bool KM>
+template <class P, class T, bool KM, int kJoinR0 = COMET_JOIN_R0>
 CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
   const i64 n = prm.n;
   const i64 cap_out = prm.iarg[6];
@@ -2757,7 +2762,10 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
       for (int r = 0; r < kJoinR0; r++) {
         const u64 idx = keys[r] - first;
         const u32 w = ((const u32*)(keymap + 2))[idx < bits ? idx >> 5 : 0ull];
-        words[r] = (((can_bits >> r) & 1u) && idx < bits) ? w : 0u;
+        // (a MASK, not a select: the compiler sinks a load whose value is only wanted under a condition into that branch — and waits for it there, sixteen
+        // dependent bitmap reads per thread and tile)
+        const u32 use = 0u - (u32)(((can_bits >> r) & 1u) & (idx < bits ? 1u : 0u));
+        words[r] = w & use;
       }
 #else
 #pragma unroll
@@ -3034,6 +3042,12 @@ CDEV void join_direct_rows_body(const CometKParams& prm) {
   const JoinDirectTable<P> t{km, (const u32*)prm.out[0], (const u32*)prm.out[1]};
   u32* rows = (u32*)prm.out[1];
   const i64 nb = prm.iarg[1];
+  // "a key came twice" = fewer bits in the bitmap than rows with a key (iarg[6]): the scan behind the bitmap counted the bits — ranks[number of blocks] —, so
+  // the bitmap's own build pass need not watch for duplicates and can OR a wave's neighbouring keys together (join_keymap_build_body)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const u64 nblocks = (km[1] + 127) >> 7;
+    if ((i64)((const u32*)prm.out[0])[nblocks] != prm.iarg[6]) ((volatile unsigned long long*)prm.out[47])[4] = 1ull;
+  }
   for (i64 i = (i64)blockIdx.x * kBlock + threadIdx.x; i < nb; i += (i64)gridDim.x * kBlock) {
     if (!P::bvalid(prm, i)) continue;
     u64 kw[P::NKW];
@@ -3044,7 +3058,7 @@ CDEV void join_direct_rows_body(const CometKParams& prm) {
 template <class P>
 CDEV void join_probe_direct_body(const CometKParams& prm) {
   const JoinDirectTable<P> t{(const u64*)prm.out[kJoinKeyMap], (const u32*)prm.out[0], (const u32*)prm.out[1]};
-  join_probe_tiles<P, JoinDirectTable<P>, true>(prm, t);
+  join_probe_tiles<P, JoinDirectTable<P>, true, COMET_JOIN_R0_DIRECT>(prm, t);
 }
 
 template <class P, bool KM = false>

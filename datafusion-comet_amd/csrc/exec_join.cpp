@@ -195,7 +195,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   // pass sees no bit twice — the bitmap, the keys below each of its 128-bit blocks and the build rows in key order replace the hash table.
   static const int direct_mode = getenv("COMET_JOIN_DIRECT") ? atoi(getenv("COMET_JOIN_DIRECT")) : 1;      // 0: never
   bool direct = false, keymap_built = false;
-  DevBuf dranks, drows, dtiles;
+  DevBuf dranks, drows, dtiles, dcounts;
   auto build_keymap = [&](bool want_dup_flag) {
     const size_t words = (size_t)((keymap_range + 127) / 128) * 4;       // whole 128-bit blocks
     keymap.ensure(16 + words * 4 + 16);
@@ -218,22 +218,25 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     bucket = false;
     join_bitmap_only_++;
   } else if (keymap_range && direct_mode != 0 && entries == keyed_rows) {       // (no two neighbouring rows share a key: a clustered fact table is spared the pass)
-    build_keymap(true);
-    uint64_t dup = 1;
-    read_small(&dup, (char*)emitted_buf.p + 32, 8);
-    if (!dup) {
+    build_keymap(false);      // (the wave-combined build: duplicates show as missing bits, counted below)
+    // ranks and rows[] are built right behind the bitmap, BEFORE the host knows whether a key came twice (one wait instead of three; with a duplicate the
+    // two small passes were for nothing — their writes stay inside their buffers either way)
+    {
       const int64_t nblocks = (int64_t)((keymap_range + 127) / 128);
-      DevBuf counts;
-      counts.ensure((size_t)nblocks * 4 + 16);
+      dcounts.ensure((size_t)nblocks * 4 + 16);
       dranks.ensure((size_t)(nblocks + 2) * 4);
       dtiles.ensure((size_t)((nblocks + 1023) / 1024 + 2) * 8);
       drows.ensure((size_t)B.rows * 4 + 16);
-      if (comet_launch_popcount128((const char*)keymap.p + 16, nblocks, (uint32_t*)counts.p, stream_) != 0) throw CometError("hash join: launch failed");
-      pq_launch_u32_scan((const uint32_t*)counts.p, nblocks, (uint64_t*)dtiles.p, (int32_t*)dranks.p, stream_);
+      if (comet_launch_popcount128((const char*)keymap.p + 16, nblocks, (uint32_t*)dcounts.p, stream_) != 0) throw CometError("hash join: launch failed");
+      pq_launch_u32_scan((const uint32_t*)dcounts.p, nblocks, (uint64_t*)dtiles.p, (int32_t*)dranks.p, stream_);
       prm.out[0] = dranks.p;
       prm.out[1] = drows.p;
+      prm.iarg[6] = keyed_rows;       // k_jdrows compares the bitmap's bit count with it: fewer bits = a key came twice
       launch(v, "k_jdrows", (int)std::min<int64_t>((B.rows + 255) / 256, 256 * 8), prm);
-      HIP_CHECK(hipStreamSynchronize(stream_));       // `counts` goes back to the pool
+    }
+    uint64_t dup = 1;
+    read_small(&dup, (char*)emitted_buf.p + 32, 8);
+    if (!dup) {
       direct = true;
       join_direct_maps_++;
     }
@@ -419,7 +422,9 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   const int nbuild = (int)nb;
   DevTable out = outputs_to_table(v, vals, vbytes, out_rows, [&](int c) { return c < nbuild ? std::make_pair(&B, c) : std::make_pair(&P, c - nbuild); });
   if (fused_probe) check_device_errors();     // the chain's expressions may raise ANSI errors; an unfused chain checks after its own launch
-  HIP_CHECK(hipStreamSynchronize(stream_));  // head/next/counts go back to the pool when this frame ends
+  // the tables of this frame (heads, records, bitmap, ranks …) go back to the pool when it ends: nothing queued may still read them.  The probe's result was
+  // waited for (read_small) and only the output's own buffers are touched after it — except by the build-side tail of an outer join, and when no probe ran
+  if (tail_rows > 0 || n == 0) HIP_CHECK(hipStreamSynchronize(stream_));
   out.owners.push_back(v.mod);
   join_build_rows_ += B.rows;
   join_probe_rows_ += P.rows;

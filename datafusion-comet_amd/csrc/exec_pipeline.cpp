@@ -423,9 +423,15 @@ DevTable ExecutionContext::grouped_to_device() {
   }
   Variant& v = *agg_variant_;
   const PipelineDesc& d = v.desc;
+  // the error flags and the group counter share the head of the error block: one read-back, one wait
   uint64_t ngroups = 0;
-  read_small(&ngroups, (char*)err_flags_.p + 8, 8);
-  check_device_errors();
+  {
+    uint32_t hdr[4] = {0, 0, 0, 0};
+    read_small(hdr, err_flags_.p, 16);
+    collect_timings();
+    memcpy(&ngroups, hdr + 2, 8);
+    raise_device_errors(hdr[0]);
+  }
   if (getenv("COMET_TRACE_STAGES")) fprintf(stderr, "[comet] grouped result: %llu groups in a table of %lld slots x %zu bytes\n", (unsigned long long)ngroups, (long long)group_cap_, (size_t)(8 + 8 * (d.NK + d.NW)));
   const size_t ncol = d.out_cols.size();
   CometKParams prm;
@@ -452,8 +458,7 @@ DevTable ExecutionContext::grouped_to_device() {
   if (!dict_id_col_.empty()) gs = [this](int c) { return std::make_pair((const DevTable*)&dict_src_, c); };
   DevTable t = outputs_to_table(v, vals, vbytes, (int64_t)ngroups, gs);
   t.owners.push_back(v.mod);
-  HIP_CHECK(hipStreamSynchronize(stream_));
-  check_device_errors();
+  check_device_errors();      // (its read-back waits for the stream: the emit's scratch goes back to the pool behind it)
   return t;
 }
 
