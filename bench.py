@@ -87,12 +87,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # the rank's device is bound BEFORE anything allocates or a communicator is created (LOCAL_RANK's GPU; one process per GPU)
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+    dev = init_rank(torch, dist, local_rank, world)
 
     from datafusion_comet_amd import native, serde as S, tpch, parallel
 
@@ -186,6 +181,7 @@ def main():
     torch.cuda.empty_cache()
 
     legs = {}
+    exchange = "native"
     if not args.no_extra_legs:
         if world == 1:
             legs["q6"] = run_child_leg([os.path.join(ROOT, "tools", "resident.py"), "--query", "q6", "--rows", str(args.rows), "--steps", "5"],
@@ -388,11 +384,48 @@ def main():
         print(json.dumps(short, separators=(",", ":")))
     if world > 1:
         dist.destroy_process_group()
-        fell_back = not args.no_extra_legs and (args.q3_orders > 0 or args.q95_orders > 0) and exchange != "native"
-        if rank == 0 and not args.no_extra_legs:
-            fell_back = fell_back or any((legs.get(k) or {}).get("exit_code") == 4 for k in ("q3", "q95"))
-        if fell_back and not args.allow_fallback:
-            sys.exit(4)      # the multi-GPU legs did not run over the in-library RCCL exchange: the line says so, and so does the exit code
+        rc = multi_gpu_exit_code(world, not args.no_extra_legs, args.q3_orders > 0 or args.q95_orders > 0, exchange, legs if rank == 0 else None, args.allow_fallback)
+        if rc:
+            sys.exit(rc)      # the multi-GPU legs did not run over the in-library RCCL exchange: the line says so, and so does the exit code
+
+
+def init_rank(torch, dist, local_rank: int, world: int, backend: str = "nccl") -> str:
+    """One process per GPU: the rank's device (LOCAL_RANK's) is bound BEFORE anything allocates and before a communicator exists — a process group
+    created first would put its context (and every rank's first allocation) on device 0.  → the device string.  (tests/test_bench_world8_cpu.py drives this
+    with recording stand-ins: eight ranks, the order of the calls.)"""
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
+    return dev
+
+
+def leg_env(environ, rank: int, local_rank: int, world: int, port_offset: int) -> dict:
+    """The environment of a child leg: the parent's rank identity, its OWN rendezvous port (the parent's + the leg's offset: the ranks of one leg meet each other,
+    never the parent's group or another leg's), none of torchrun's elastic-agent variables."""
+    env = dict(environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(int(environ.get("MASTER_PORT", "29500")) + port_offset)
+    env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"] = str(rank), str(local_rank), str(world)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)
+    return env
+
+
+def multi_gpu_exit_code(world: int, ran_extra_legs: bool, wanted_exchange_legs: bool, exchange: str, legs_rank0, allow_fallback: bool) -> int:
+    """0, or 4 when the multi-GPU legs did not run over the in-library RCCL exchange (the probe failed and they fell back to torch's all_to_all, or a leg itself
+    reported the fallback with exit code 4): the line says so in `exchange_transport`, and so does the exit code unless --allow-fallback."""
+    if world <= 1:
+        return 0
+    fell_back = ran_extra_legs and wanted_exchange_legs and exchange != "native"
+    if legs_rank0 is not None and ran_extra_legs:
+        fell_back = fell_back or any((legs_rank0.get(k) or {}).get("exit_code") == 4 for k in ("q3", "q95"))
+    return 4 if (fell_back and not allow_fallback) else 0
 
 
 def _r(x, nd=3):
@@ -663,13 +696,7 @@ def run_child_leg(cmd_tail, rank, local_rank, world, timeout, port_offset):
     import subprocess
     import tempfile
     out = os.path.join(tempfile.gettempdir(), f"comet_leg_{os.getpid()}_{port_offset}.json")
-    env = dict(os.environ)
-    env["MASTER_ADDR"] = "127.0.0.1"
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)
-    env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"] = str(rank), str(local_rank), str(world)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK"):
-        env.pop(k, None)
+    env = leg_env(os.environ, rank, local_rank, world, port_offset)
     cmd = [sys.executable] + list(cmd_tail) + ["--out", out]
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

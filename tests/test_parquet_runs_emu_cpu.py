@@ -56,11 +56,20 @@ def reference(section: bytes, bw: int, max_values: int = -1, lead: int = 3):
                 break
         if h & 1:
             groups = h >> 1
+            if groups > (2**31 - 1 - vstart) // 8:
+                return -4                      # a count that would leave the range of a value index (round 6, advisor finding)
+            if pos + groups * bw > len(section):
+                # the bit-packed payload must end inside the section — or, when the page's value count is known, at least the values still wanted must
+                wanted = (max_values - vstart) if max_values >= 0 else groups * 8
+                if max_values < 0 or pos + (wanted * bw + 7) // 8 > len(section):
+                    return -5
             if groups:
                 runs.append((lead + pos, vstart, groups * 8, 0, 0))
             pos += groups * bw
             vstart += groups * 8
         else:
+            if (h >> 1) > 2**31 - 1 - vstart:
+                return -4
             if pos + vb > len(section):
                 return -2
             v = int.from_bytes(section[pos:pos + vb], "little")
