@@ -1991,6 +1991,11 @@ struct GroupCtx {
   Slot<P::NK, P::NW>* glb;
   u64 glb_cap;
   unsigned int* err;                    // err[0] flags; ((u64*)err)[1] = number of groups in the global table
+  // the partition passes of a merging aggregate (template C'', below): 0 = none, 1 = count my row's partition, 2 = write my row's record
+  int part_mode = 0;
+  COMET_LDS u32* part = nullptr;        // the block's per-partition counters (mode 1) / cursors (mode 2)
+  u64* recs = nullptr;                  // mode 2: records { key[NK], val[NW] }, partition-major
+  u32 np = 0;
   mutable u32 inserted = 0;             // groups this lane inserted into the global table (flushed by flush_inserted)
   CDEV u32* counter() const { return &inserted; }
   CDEV bool table_full() const { return (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 32u) != 0; }
@@ -2094,6 +2099,22 @@ CDEV void group_update(const GroupCtx<P>& g, bool active, const u64* key, const 
     return;
   }
 #endif
+  if (g.part_mode) {      // (uniform: a partition pass of template C'')
+    const u32 p = (u32)__umul64hi(hash_key<P::NK>(key), (u64)g.np);
+    if (g.part_mode == 1) {
+      __hip_atomic_fetch_add(g.part + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return;
+    }
+    u64 val[P::NW];
+    P::fold(pv, val);
+    const u32 pos = __hip_atomic_fetch_add(g.part + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    u64* rec = g.recs + (u64)pos * (u64)(P::NK + P::NW);
+#pragma unroll
+    for (int k = 0; k < P::NK; k++) rec[k] = key[k];
+#pragma unroll
+    for (int k = 0; k < P::NW; k++) rec[P::NK + k] = val[k];
+    return;
+  }
   u32 ord = kNoOrdinal;
   COMET_LDS LSlot<P::NK, P::NPW>* ls = nullptr;
   if (P::LDS_CAP > 0) ls = lds_find_or_insert<P>(g, key, ord);
@@ -2209,6 +2230,192 @@ CDEV void agg_grouped_body(const CometKParams& prm) {
         else atomicOr(aux + k, (unsigned long long)kacc[k]);
       }
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Kernel template C'' (round 6) — a MERGING aggregate (Final / PartialMerge: about one input row per group) without the global table.
+// Template C gives every row a find-or-insert in a table in HBM: device-scope compare-and-swap, key and accumulator stores, the publishing store — all
+// executed at the memory side, ≈ 0.55 ns per row whatever the kernel does (SF100 Q3's Final aggregate: 1.13 M rows = 1.13 M groups, 0.62 ms, plus a
+// 0.15 ms emit pass over a table of 4 M slots and the memset that clears it).  The bucket table's recipe (template D'') fits: the rows are PARTITIONED on
+// their key hash (counts per block → column scan → scatter of { key, folded contribution } records; the same per-row code as template C runs, its
+// group_update sees part_mode and counts / writes instead of probing), one workgroup per partition merges its records in an LDS table (the find-or-insert
+// of template C over workgroup memory) and EMITS its groups from there — P::emit_group, positions from one atomic per partition; the group counter of the
+// error block ends as the row count.  No table in HBM, no emit pass over empty slots.
+//   out[1] = records, out[3] = { u32 pstart[…kJoinPartMax + 16], u32 tot[kJoinPartMax], u32 cnt[G][NP] } (the join's layout and scan kernel), iarg[2] = NP,
+//   iarg[5] = rows per block (a multiple of the tile); the output columns as for k_gemit.  A partition with more groups than its table holds raises
+//   the "table full" flag (32): the executor resets the counter and takes template C.
+// ---------------------------------------------------------------------------------------------
+constexpr int kJoinPartMax = 16384;                 // partitions at most (the 64 KB LDS histogram / cursor array of the partition passes; template D'' shares the layout)
+constexpr int kJoinPartTotOff = kJoinPartMax + 16;  // u32 index of tot[] in out[3]
+constexpr int kJoinPartCntOff = 2 * kJoinPartMax + 16;
+template <class P>
+struct AggPart {
+  static constexpr int kSlotBytes = 8 + 8 * (P::NK + P::NW);
+  static constexpr int kCap = kSlotBytes <= 48 ? 1024 : kSlotBytes <= 96 ? 512 : kSlotBytes <= 192 ? 256 : 128;      // ≤ 48 KB of workgroup memory
+};
+
+template <class P>
+CDEV void agg_publish_kacc(const CometKParams& prm, u64* kacc) {
+  if (P::NKW > 0) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+      for (int k = 0; k < P::NKW; k++) {
+        u64 o = shfl_xor_u64(kacc[k], m);
+        kacc[k] = P::kop(k) == G_UMAX64 ? (o > kacc[k] ? o : kacc[k]) : (kacc[k] | o);
+      }
+    }
+    if (lane_id() == 0) {
+      unsigned long long* aux = (unsigned long long*)prm.out[2] + 2;
+#pragma unroll
+      for (int k = 0; k < P::NKW; k++) {
+        if (P::kop(k) == G_UMAX64) atomicMax(aux + k, (unsigned long long)kacc[k]);
+        else atomicOr(aux + k, (unsigned long long)kacc[k]);
+      }
+    }
+  }
+}
+
+template <class P, int MODE>
+CDEV void agg_part_pass_body(const CometKParams& prm) {
+  __shared__ u32 s_part[kJoinPartMax];
+  __shared__ u32 s_wsum[kBlock / kWave];
+  __shared__ u32 s_carry;
+  const i64 n = prm.n, chunk = prm.iarg[5];
+  const int np = (int)prm.iarg[2];
+  u32* pstart = (u32*)prm.out[3];
+  u32* cnt = pstart + kJoinPartCntOff + (i64)blockIdx.x * np;
+  if (MODE == 1) {
+    for (int p = threadIdx.x; p < np; p += kBlock) s_part[p] = 0;
+  } else {
+    // cursors: exclusive scan of tot[] (256 partitions at a time, a carry between them) + where this block's records start inside each partition
+    const u32* tot = pstart + kJoinPartTotOff;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < np; b0 += kBlock) {
+      const int p = b0 + (int)threadIdx.x;
+      const u32 v = p < np ? tot[p] : 0u;
+      u32 x = v;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const u32 y = __shfl_up(x, d, kWave);
+        if (lane_id() >= d) x += y;
+      }
+      if (lane_id() == kWave - 1) s_wsum[wave_id()] = x;
+      __syncthreads();
+      u32 excl = s_carry + x - v;
+      for (int w = 0; w < wave_id(); w++) excl += s_wsum[w];
+      if (p < np) {
+        s_part[p] = excl + cnt[p];
+        if (blockIdx.x == 0) pstart[p] = excl;
+      }
+      __syncthreads();
+      if (threadIdx.x == kBlock - 1) s_carry = excl + v;      // (thread 255 sits at or behind the round's last partition: the running total)
+      __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) pstart[np] = s_carry;
+  }
+  __syncthreads();
+  GroupCtx<P> g;
+  g.lds = nullptr;
+  g.lds_count = nullptr;
+  g.ord_slot = nullptr;
+  g.priv = nullptr;
+  g.glb = nullptr;
+  g.glb_cap = 0;
+  g.err = (unsigned int*)prm.out[2];
+  g.part_mode = MODE;
+  g.part = (COMET_LDS u32*)s_part;
+  g.recs = (u64*)prm.out[1];
+  g.np = (u32)np;
+  u64 kacc[P::NKW > 0 ? P::NKW : 1];
+  P::kinit(kacc);
+  const i64 tile = (i64)P::R * kBlock;
+  const i64 r0 = (i64)blockIdx.x * chunk, r1 = r0 + chunk < n ? r0 + chunk : n;
+  for (i64 base = r0; base < r1; base += tile) {
+    if constexpr (P::PIPELINED) {
+      typename P::L ld;
+      P::tile_load(prm, base, r1, ld);
+      P::tile_grouped(prm, base, r1, ld, g, kacc);
+    } else {
+      P::tile_grouped(prm, base, r1, g, kacc);
+    }
+  }
+  __syncthreads();
+  if (MODE == 1) {
+    for (int p = threadIdx.x; p < np; p += kBlock) cnt[p] = s_part[p];
+  } else {
+    agg_publish_kacc<P>(prm, kacc);      // (the value bounds of the overflow proof: once, in the pass that keeps the rows)
+  }
+}
+
+template <class P>
+CDEV void agg_part_merge_body(const CometKParams& prm) {
+  typedef Slot<P::NK, P::NW> S;
+  constexpr int kCap = AggPart<P>::kCap;
+  constexpr int kPer = kCap / kBlock;
+  __shared__ S s_tbl[kCap];
+  __shared__ u32 s_wave[kBlock / kWave];
+  __shared__ unsigned long long s_base;
+  const int np = (int)prm.iarg[2];
+  const u32* pstart = (const u32*)prm.out[3];
+  const u64* recs = (const u64*)prm.out[1];
+  unsigned int* err = (unsigned int*)prm.out[2];
+  const int lane = lane_id(), wv = wave_id();
+  for (int p = blockIdx.x; p < np; p += gridDim.x) {
+    for (int i = threadIdx.x; i < kCap * (int)(sizeof(S) / 8); i += kBlock) ((u64*)s_tbl)[i] = 0ull;
+    __syncthreads();
+    const u32 r0 = pstart[p], r1 = pstart[p + 1];
+    u32 dummy = 0;
+    for (u32 r = r0 + threadIdx.x; r < r1; r += kBlock) {
+      const u64* rec = recs + (u64)r * (u64)(P::NK + P::NW);
+      u64 key[P::NK], val[P::NW];
+#pragma unroll
+      for (int k = 0; k < P::NK; k++) key[k] = rec[k];
+#pragma unroll
+      for (int k = 0; k < P::NW; k++) val[k] = rec[P::NK + k];
+      bool fresh = false;
+      S* gs = table_find_or_insert<P::NK, P::NW>((S*)s_tbl, (u64)kCap, key, SlotInitWith<P>{val}, (u64)kCap, &dummy, &fresh);
+      if (!gs) atomicOr(err, 32u);      // more groups than the partition's table holds: the executor takes template C
+      else if (!fresh) slot_apply<P, __HIP_MEMORY_SCOPE_WORKGROUP>(&gs->acc[0], val);
+    }
+    __syncthreads();
+    // emit: this partition's groups in slot order, ONE atomic for their rows
+    u32 before[kPer], ready = 0, run = 0;
+#pragma unroll
+    for (int r = 0; r < kPer; r++) {
+      const bool rd = s_tbl[r * kBlock + (int)threadIdx.x].state == kSlotReady;
+      const u64 b = __ballot(rd);
+      before[r] = run + (u32)__popcll(b & ((1ull << lane) - 1ull));
+      run += (u32)__popcll(b);
+      if (rd) ready |= 1u << r;
+    }
+    if (lane == 0) s_wave[wv] = run;
+    __syncthreads();
+    u32 woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; w++) {
+      if (w < wv) woff += s_wave[w];
+      total += s_wave[w];
+    }
+    if (threadIdx.x == 0 && total) s_base = atomicAdd((unsigned long long*)err + 1, (unsigned long long)total);
+    __syncthreads();
+    if (ready) {
+#pragma unroll
+      for (int r = 0; r < kPer; r++)
+        if ((ready >> r) & 1u) {
+          const S* sl = &s_tbl[r * kBlock + (int)threadIdx.x];
+          u64 key[P::NK], acc[P::NW];
+#pragma unroll
+          for (int k = 0; k < P::NK; k++) key[k] = sl->key[k];
+#pragma unroll
+          for (int k = 0; k < P::NW; k++) acc[k] = sl->acc[k];
+          P::emit_group(prm, key, acc, (i64)s_base + woff + before[r]);
+        }
+    }
+    __syncthreads();
   }
 }
 
@@ -3115,10 +3322,7 @@ CDEV void join_probe_lds_body(const CometKParams& prm) {
 // iarg[0] = NP · S, iarg[1] = build rows, iarg[2] = NP, iarg[5] = chunk (rows per block, a multiple of 1024).
 // ---------------------------------------------------------------------------------------------
 constexpr int kJoinPartSlots = 4096;
-constexpr int kJoinPartMax = 16384;                 // partitions at most (the 64 KB LDS histogram / cursor array of the partition passes)
 constexpr int kJoinPartBlock = 1024;
-constexpr int kJoinPartTotOff = kJoinPartMax + 16;  // u32 index of tot[] in out[3]
-constexpr int kJoinPartCntOff = 2 * kJoinPartMax + 16;
 
 // The MONOTONE hash.  One integer key whose build values span [kmin, kmin + range): h = (key − kmin) · ⌊2^64 / range⌋ keeps the keys' ORDER — slot(h) = umulhi(h,
 // slots) grows with the key — and stays injective (so sig == h is still key equality).  Fact tables arrive clustered AND sorted on their keys (the lines of an

@@ -1605,6 +1605,7 @@ DevTable ExecutionContext::nested_aggregate(const Operator& agg) {
   }
   mark("groups emitted");
   input_rows += sub.input_rows;
+  part_merges_ += sub.part_merges_;
   sub.collect_timings();
   last_kernel_ms += sub.last_kernel_ms;
   last_kernel_launches += sub.last_kernel_launches;
@@ -1823,6 +1824,7 @@ void ExecutionContext::run_to_completion() {
     DevTable src = extend_struct_fields(materialize(*root_source_));
     if (plan_.get() == root_source_) throw CometError("internal: bare join root");
     if (sink_ == SinkKind::AggGrouped) prepare_dict_keys(src);
+    single_chunk_hint_ = true;      // (the join's output is the aggregate's whole input)
     process_chunk(src.cols, src.has_valid, src.rows);
     HIP_CHECK(hipStreamSynchronize(stream_));
     return;
@@ -2052,6 +2054,7 @@ std::string ExecutionContext::metrics_proto() {
       n.metrics.emplace_back("pages_decompressed_on_device", pages_inflated_on_device_);
       n.metrics.emplace_back("page_index_rows_pruned", rows_pruned_page_index_);
     }
+    if (op.kind == OpKind::HashAgg && root) n.metrics.emplace_back("agg_partitioned_merges", part_merges_);      // merging aggregates run as partition → LDS merge → emit
     if (op.kind == OpKind::HashJoin && root) {      // (the plan's joins together: the counters are the context's)
       n.metrics.emplace_back("join_build_rows", join_build_rows_);
       n.metrics.emplace_back("join_probe_rows", join_probe_rows_);

@@ -335,6 +335,21 @@ class ExecutionContext {
   std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index
   int64_t join_build_rows_ = 0, join_probe_rows_ = 0, join_keymap_bytes_ = 0, join_direct_maps_ = 0, join_bucket_tables_ = 0, join_bitmap_only_ = 0, join_mono_tables_ = 0;
   int small_write_slot_ = 0;         // write_small's ring of staging slots
+  // the partitioned merging aggregate (exec_pipeline.cpp try_partitioned_merge): its input is known to be ONE chunk; the emitted result
+  bool single_chunk_hint_ = false, part_result_ready_ = false;
+  DevTable part_result_;
+  int64_t part_merges_ = 0;
+  bool try_partitioned_merge(Variant& v, CometKParams& prm, int64_t n);
+  struct DevPending {      // a device batch pulled one ahead of its turn
+    std::vector<DeviceColumnView> views;
+    std::vector<bool> has_valid;
+    int64_t rows = 0;
+    std::shared_ptr<void> keep;
+    bool valid = false;
+  };
+  DevPending dev_pending_;
+  bool dev_stream_done_ = false;
+  int64_t dev_chunks_seen_ = 0;
   bool join_no_bucket_ = false;      // set while a join whose bucket table overflowed re-runs over the chained table
   int64_t bytes_scanned_ = 0;
   int64_t row_groups_pruned_ = 0;

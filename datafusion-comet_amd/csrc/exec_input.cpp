@@ -701,12 +701,24 @@ bool ExecutionContext::pull_device_table(size_t input, const std::vector<DType>&
 
 // HBM-resident input (Arrow C Device stream, ARROW_DEVICE_ROCM): zero copy.
 bool ExecutionContext::pull_device_batch() {
-  std::vector<DeviceColumnView> views;
-  std::vector<bool> has_valid;
-  int64_t rows = 0;
-  std::shared_ptr<void> keep;
-  if (!pull_device_table(0, in_types_, views, has_valid, rows, keep)) return false;
-  process_chunk(views, has_valid, rows);
+  DevPending cur;
+  if (dev_pending_.valid) {
+    cur = std::move(dev_pending_);
+    dev_pending_ = DevPending();
+  } else {
+    if (dev_stream_done_ || !pull_device_table(0, in_types_, cur.views, cur.has_valid, cur.rows, cur.keep)) return false;
+  }
+  // A grouped aggregate looks ONE batch ahead before its first chunk: a merging aggregate whose whole input is that chunk can run partitioned
+  // (exec_pipeline.cpp try_partitioned_merge) — the usual shape of a Final aggregate over a device-resident table of Partial states
+  if (sink_ == SinkKind::AggGrouped && dev_chunks_seen_ == 0 && !dev_stream_done_) {
+    dev_pending_.valid = pull_device_table(0, in_types_, dev_pending_.views, dev_pending_.has_valid, dev_pending_.rows, dev_pending_.keep);
+    if (!dev_pending_.valid) dev_stream_done_ = true;
+    single_chunk_hint_ = !dev_pending_.valid;
+  } else {
+    single_chunk_hint_ = false;
+  }
+  dev_chunks_seen_++;
+  process_chunk(cur.views, cur.has_valid, cur.rows);
   HIP_CHECK(hipStreamSynchronize(stream_));
   return true;
 }

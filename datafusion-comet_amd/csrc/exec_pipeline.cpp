@@ -64,6 +64,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     if (agg_variant_ && (agg_variant_->desc.NW != d.NW || agg_variant_->desc.NK != d.NK))
       throw CometError("internal: group slot layout differs between variants");
     agg_variant_ = &v;
+    if (try_partitioned_merge(v, prm, n)) return;
     const size_t slot_bytes = 8 + 8 * (size_t)(d.NK + d.NW);
     auto alloc_table = [&](DevBuf& buf, int64_t cap) {
       buf.ensure((size_t)cap * slot_bytes);
@@ -349,6 +350,72 @@ void ExecutionContext::raise_device_errors(uint32_t f) {
   throw CometError("device error flags " + std::to_string(f));
 }
 
+// A merging aggregate (Final / PartialMerge) whose whole input is this one chunk: partition → merge in LDS → emit (comet_device.hpp template C'').  → true when
+// the result table is ready (part_result_); false: the caller runs template C (not eligible, or a partition held more groups than its LDS table).
+bool ExecutionContext::try_partitioned_merge(Variant& v, CometKParams& prm, int64_t n) {
+  const PipelineDesc& d = v.desc;
+  static const int64_t min_rows = getenv("COMET_AGG_PARTITIONED_MIN_ROWS") ? atoll(getenv("COMET_AGG_PARTITIONED_MIN_ROWS")) : 32768;
+  if (!d.merges_states || !single_chunk_hint_ || group_cap_ != 0 || part_result_ready_ || !d.fix_sums.empty() || !dict_id_col_.empty() || min_rows < 0 || n < min_rows) return false;
+  const int slot_bytes = 8 + 8 * (d.NK + d.NW);
+  const int64_t cap = slot_bytes <= 48 ? 1024 : slot_bytes <= 96 ? 512 : slot_bytes <= 192 ? 256 : 128;      // comet_device.hpp AggPart::kCap
+  constexpr int64_t kMaxP = 16384;                                                                            // kJoinPartMax
+  const int64_t np = (n + cap / 2 - 1) / (cap / 2);
+  if (np > kMaxP) return false;
+  const int64_t tile = (int64_t)d.R * 256;
+  const int64_t g = std::max<int64_t>(1, std::min<int64_t>(1024, (n + 4 * tile - 1) / (4 * tile)));
+  const int64_t chunk = ((n + g - 1) / g + tile - 1) / tile * tile;
+  const int64_t rec_words = d.NK + d.NW;
+  DevBuf recs, part;
+  recs.ensure((size_t)n * (size_t)rec_words * 8 + 16);
+  part.ensure((size_t)(2 * kMaxP + 16 + g * np) * 4 + 16);
+  const size_t ncol = d.out_cols.size();
+  std::vector<std::shared_ptr<DevBuf>> vals(ncol), vbytes(ncol);
+  for (size_t j = 0; j < ncol; j++) {
+    vals[j] = std::make_shared<DevBuf>();
+    vbytes[j] = std::make_shared<DevBuf>();
+    vals[j]->ensure((size_t)n * out_width(d.out_cols[j]) + 16);
+    vbytes[j]->ensure((size_t)n + 16);
+    HIP_CHECK(hipMemsetAsync(vbytes[j]->p, 1, (size_t)n, stream_));
+    prm.out[kOutFirstCol + 2 * j] = vals[j]->p;
+    prm.out[kOutFirstCol + 2 * j + 1] = vbytes[j]->p;
+  }
+  HIP_CHECK(hipMemsetAsync((char*)err_flags_.p + 8, 0, 8, stream_));      // the group counter: the merge's row positions come from it
+  prm.out[1] = recs.p;
+  prm.out[3] = part.p;
+  prm.iarg[2] = np;
+  prm.iarg[5] = chunk;
+  prm.iarg[kFixScaleArg] = packed_fix_scales(d);
+  timed_begin();
+  launch(v, "k_gphist", (int)g, prm);
+  if (comet_launch_join_part_scan((uint32_t*)part.p + (2 * kMaxP + 16), (int)g, (int)np, (uint32_t*)part.p + (kMaxP + 16), 0xffffffffu, (uint64_t*)((char*)err_flags_.p + kErrBytes - 8),
+                                  stream_) != 0)
+    throw CometError("partitioned aggregate: launch failed");
+  launch(v, "k_gpscat", (int)g, prm);
+  launch(v, "k_gpmerge", (int)std::min<int64_t>(np, 256 * 16), prm);
+  timed_end();
+  uint32_t hdr[4] = {0, 0, 0, 0};
+  read_small(hdr, err_flags_.p, 16);
+  if (hdr[0] & 32u) {
+    // a partition with more groups than its LDS table: forget the attempt (flag and counter), template C takes the chunk
+    uint32_t reset[4] = {hdr[0] & ~32u, hdr[1], 0, 0};
+    write_small(err_flags_.p, reset, 16);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    return false;
+  }
+  collect_timings();
+  raise_device_errors(hdr[0]);
+  uint64_t ngroups = 0;
+  memcpy(&ngroups, hdr + 2, 8);
+  GatherSource gs = nullptr;
+  part_result_ = outputs_to_table(v, vals, vbytes, (int64_t)ngroups, gs);
+  part_result_.owners.push_back(v.mod);
+  part_result_ready_ = true;
+  part_merges_++;
+  groups_committed_ = ngroups;
+  HIP_CHECK(hipStreamSynchronize(stream_));      // the records and the partition counters go back to the pool
+  return true;
+}
+
 void ExecutionContext::finish_aggregate() {
   // AggregateExec emits one state row even for empty input
   std::vector<bool> none(in_types_.size(), false);
@@ -410,6 +477,11 @@ void ExecutionContext::finish_aggregate() {
 // Grouped aggregate result left in HBM (stage boundary of a multi-GPU plan: Partial states feed the next stage's exchange
 // or Final aggregate without touching the host).  Utf8 group keys are not supported on this path yet.
 DevTable ExecutionContext::grouped_to_device() {
+  if (part_result_ready_) {      // the partitioned merge emitted already
+    part_result_ready_ = false;
+    check_device_errors();
+    return std::move(part_result_);
+  }
   DevTable empty;
   if (!agg_variant_) {   // no input rows → no groups: an empty table with the plan's output types
     std::vector<bool> none(in_types_.size(), false);
@@ -464,6 +536,11 @@ DevTable ExecutionContext::grouped_to_device() {
 
 void ExecutionContext::finish_grouped() {
   if (!agg_variant_) return;  // no input rows → no groups → no output batch
+  if (part_result_ready_) {
+    DevTable t = grouped_to_device();
+    table_to_host_batches(t);
+    return;
+  }
   Variant& v = *agg_variant_;
   const PipelineDesc& d = v.desc;
   uint64_t ngroups = 0;

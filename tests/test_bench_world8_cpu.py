@@ -177,7 +177,7 @@ def test_eight_ranks_run_the_bench_legs_host_logic_end_to_end():
     world = 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 90)
+    port = 30100 + (os.getpid() % 90)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

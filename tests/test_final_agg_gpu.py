@@ -262,3 +262,68 @@ def test_ansi_decimal_sums_raise_where_legacy_ones_turn_null(built):
     a = _run(S.hash_agg(S.scan([S.T_INT32, D10]), [k], [S.sum_(v, D10, S.ANSI)], S.PARTIAL), ok, 3)
     b = _run(S.hash_agg(S.scan([S.T_INT32, D10]), [k], [S.sum_(v, D10, S.LEGACY)], S.PARTIAL), ok, 3)
     assert sorted(zip(*[c.to_pylist() for c in a.columns]), key=str) == sorted(zip(*[c.to_pylist() for c in b.columns]), key=str)
+
+
+def _metrics_run(plan, dev_or_host_inputs, ncols):
+    it = native.CometExecIterator(dev_or_host_inputs, ncols, plan.encode(), batch_size=0)
+    batches = []
+    while True:
+        b = native.Native.executePlan(it.handle, ncols)
+        if b is None:
+            break
+        batches.append(b)
+    m = S.decode_metric_node(it.metrics())[0]
+    it.close()
+    return (pa.Table.from_batches(batches) if batches else None), m
+
+
+_MERGE_CASE = []
+
+
+def _merge_case():
+    """states of 40 K groups (a fifth of them in two or three rows), the Final plan and the oracle's answers — computed once (the oracle's Final is a Python loop per group)"""
+    if not _MERGE_CASE:
+        from oracle import oracle as O
+        rng = np.random.default_rng(91)
+        n = 48_000
+        k0 = rng.integers(0, 40_000, n).astype(np.int64) * 7919
+        k1 = (k0 % 5).astype(np.int32)
+        table = pa.table({"k0": pa.array(k0, mask=rng.random(n) < 0.001), "k1": pa.array(k1),
+                          "m": tpch._dec128_array(rng.integers(-10**9, 10**9, n), 12, 2), "q": pa.array(rng.integers(-1000, 1000, n), pa.int64(), mask=rng.random(n) < 0.05)})
+        D = S.decimal(12, 2)
+        partial = S.hash_agg(S.scan([S.T_INT64, S.T_INT32, D, S.T_INT64]), [S.col(0, S.T_INT64), S.col(1, S.T_INT32)],
+                             [S.sum_(S.col(2, D), S.decimal(22, 2)), S.count(S.col(3, S.T_INT64)), S.min_(S.col(3, S.T_INT64), S.T_INT64), S.max_(S.col(3, S.T_INT64), S.T_INT64),
+                              S.avg(S.col(2, D), S.decimal(16, 6), S.decimal(22, 2))], S.PARTIAL)
+        states = pa.concat_tables([O.run_plan_to_arrow(S, partial, sh) for sh in _shards(table, 3)]).combine_chunks()
+        fplan = _final_plan(partial, states.schema)
+        top = S.sort(fplan, [(S.col(2, S.decimal(22, 2)), True, True), (S.col(0, S.T_INT64), False, False), (S.col(1, S.T_INT32), False, False)], fetch=10)
+        want = O.run_plan_to_arrow(S, fplan, states)
+        srt = want.rename_columns([f"c{i}" for i in range(want.num_columns)]).combine_chunks().sort_by([("c2", "descending"), ("c0", "ascending"), ("c1", "ascending")])
+        _MERGE_CASE.append((states, fplan, top, want, srt.slice(0, 10)))
+    return _MERGE_CASE[0]
+
+
+@pytest.mark.parametrize("shape", ["final_over_device_table", "top10_above_final", "host_batches"])
+def test_merging_aggregate_of_many_groups_runs_partitioned(built, shape):
+    """A Final aggregate whose input is about one state row per group (the Final stage of a high-cardinality GROUP BY: SF100 Q3 has 1.13 M): when the whole input is ONE
+    device-resident chunk it is partitioned by key hash, merged per partition in LDS and emitted from there (comet_device.hpp template C''; metric agg_partitioned_merges) —
+    no table in HBM.  40 K groups, a fifth of them in two or three state rows (shards of one Partial), NULL group keys, sum / count / min / max / avg states;
+    bit-exact against the oracle's Final, under a Sort + fetch too (the aggregate is then a nested one); host batches keep the table path."""
+    states, fplan, top, want, want10 = _merge_case()
+    assert states.num_rows > 36_000
+    nout = want.num_columns
+    srt = lambda t: t.rename_columns([f"c{i}" for i in range(t.num_columns)]).combine_chunks().sort_by([("c0", "ascending"), ("c1", "ascending")])
+    if shape == "final_over_device_table":
+        dev = native.DeviceTable.from_arrow(states, "cuda:0")
+        got, m = _metrics_run(fplan, [native.DeviceInput(dev)], nout)
+        assert m["agg_partitioned_merges"] == 1, m
+        assert got.num_rows == want.num_rows and srt(got).equals(srt(want))
+    elif shape == "top10_above_final":
+        dev = native.DeviceTable.from_arrow(states, "cuda:0")
+        got, m = _metrics_run(top, [native.DeviceInput(dev)], nout)
+        assert m["agg_partitioned_merges"] == 1, m
+        assert [got.column(i).to_pylist() for i in range(nout)] == [want10.column(i).to_pylist() for i in range(nout)]
+    else:
+        got, m = _metrics_run(fplan, [native.HostInput.from_table(states)], nout)
+        assert m["agg_partitioned_merges"] == 0, m
+        assert got.num_rows == want.num_rows and srt(got).equals(srt(want))
