@@ -2888,7 +2888,9 @@ struct AggLowering {
   std::map<std::string, FSum> fsums;
   std::vector<PipelineDesc::FixSum> fix_sums;
   std::string kexport_code;   // ungrouped: thread 0 of each block publishes the exponent words with atomic max
-  static std::string fscale(int fidx) { return "comet::fix_scale(prm.iarg[" + std::to_string(kFixScaleArg) + "], " + std::to_string(fidx) + ")"; }
+  static std::string fscale(int fidx) {
+    return "comet::fix_scale(prm.iarg[" + std::to_string(fidx < 4 ? kFixScaleArg : kFixScaleArg2) + "], " + std::to_string(fidx & 3) + ")";
+  }
   std::string fread(const FSum& f) const {
     return "comet::fix192_to_f64(acc + " + std::to_string(f.word) + ", " + fscale(f.fidx) + ", acc[" + std::to_string(f.cls) + "])";
   }

@@ -100,8 +100,9 @@ struct PipelineDesc {
   // executor sizes the group table from the row count instead of growing it from the small default
   bool merges_states = false;
 };
-constexpr int kFixScaleArg = 6;
-constexpr int kFixMaxSums = 4;
+constexpr int kFixScaleArg = 6;      // scales of sums 0-3, 16 bits each
+constexpr int kFixScaleArg2 = 4;     // … of sums 4-7 (round 6: eight exact Float64 sums / averages per aggregate)
+constexpr int kFixMaxSums = 8;
 constexpr int kFixW = 158;            // must equal comet::kFixW
 constexpr int kFixDefaultScale = -94; // window [2^-94, 2^64): doubles from 2^-42 to 2^64 with every mantissa bit, without a re-run
 

@@ -2054,7 +2054,7 @@ std::string ExecutionContext::metrics_proto() {
       n.metrics.emplace_back("pages_decompressed_on_device", pages_inflated_on_device_);
       n.metrics.emplace_back("page_index_rows_pruned", rows_pruned_page_index_);
     }
-    if (op.kind == OpKind::HashAgg && root) n.metrics.emplace_back("agg_partitioned_merges", part_merges_);      // merging aggregates run as partition → LDS merge → emit
+    if (root && (op.kind == OpKind::HashAgg || part_merges_ > 0)) n.metrics.emplace_back("agg_partitioned_merges", part_merges_);      // merging aggregates run as partition → LDS merge → emit
     if (op.kind == OpKind::HashJoin && root) {      // (the plan's joins together: the counters are the context's)
       n.metrics.emplace_back("join_build_rows", join_build_rows_);
       n.metrics.emplace_back("join_probe_rows", join_probe_rows_);

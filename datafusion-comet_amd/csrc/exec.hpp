@@ -374,7 +374,7 @@ class ExecutionContext {
   bool fix_has_state_ = false;        // an earlier chunk already contributed to the accumulators at these scales
   int fix_attempts_ = 0;
   uint64_t groups_committed_ = 0;     // grouped: groups in the global table after the last completed chunk
-  long long packed_fix_scales(const PipelineDesc& d);
+  long long packed_fix_scales(const PipelineDesc& d, int first = 0);
   bool adjust_fix_scales(const PipelineDesc& d, const uint64_t* aux, std::vector<int>& shift_right);
   DevBuf err_flags_;
   PinnedBuf result_host_;

@@ -40,7 +40,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
     }
     prm.out[kOutPartials] = (char*)partials_.p + (size_t)n_partials_ * d.NW * 8;
     for (int attempt = 0;; attempt++) {
-      prm.iarg[kFixScaleArg] = packed_fix_scales(d);
+      prm.iarg[kFixScaleArg] = packed_fix_scales(d), prm.iarg[kFixScaleArg2] = packed_fix_scales(d, 4);
       timed_begin();
       launch(v, "k_agg", grid, prm);
       timed_end();
@@ -104,7 +104,7 @@ void ExecutionContext::process_chunk(const std::vector<DeviceColumnView>& cols, 
       }
       prm.out[0] = group_table_.p;
       prm.iarg[0] = group_cap_;
-      prm.iarg[kFixScaleArg] = packed_fix_scales(d);
+      prm.iarg[kFixScaleArg] = packed_fix_scales(d), prm.iarg[kFixScaleArg2] = packed_fix_scales(d, 4);
       timed_begin();
       launch(v, "k_gagg", grid, prm);
       timed_end();
@@ -384,7 +384,7 @@ bool ExecutionContext::try_partitioned_merge(Variant& v, CometKParams& prm, int6
   prm.out[3] = part.p;
   prm.iarg[2] = np;
   prm.iarg[5] = chunk;
-  prm.iarg[kFixScaleArg] = packed_fix_scales(d);
+  prm.iarg[kFixScaleArg] = packed_fix_scales(d), prm.iarg[kFixScaleArg2] = packed_fix_scales(d, 4);
   timed_begin();
   launch(v, "k_gphist", (int)g, prm);
   if (comet_launch_join_part_scan((uint32_t*)part.p + (2 * kMaxP + 16), (int)g, (int)np, (uint32_t*)part.p + (kMaxP + 16), 0xffffffffu, (uint64_t*)((char*)err_flags_.p + kErrBytes - 8),
@@ -444,7 +444,7 @@ void ExecutionContext::finish_aggregate() {
     prm.out[kOutFirstCol + 2 * j] = base + j * 32;
     prm.out[kOutFirstCol + 2 * j + 1] = base + j * 32 + 16;
   }
-  prm.iarg[kFixScaleArg] = packed_fix_scales(d);
+  prm.iarg[kFixScaleArg] = packed_fix_scales(d), prm.iarg[kFixScaleArg2] = packed_fix_scales(d, 4);
   launch(v, "k_agg_final", 1, prm);
   result_host_.ensure(block_bytes);
   HIP_CHECK(hipMemcpyAsync(result_host_.p, err_flags_.p, block_bytes, hipMemcpyDeviceToHost, stream_));
@@ -524,7 +524,7 @@ DevTable ExecutionContext::grouped_to_device() {
     prm.out[kOutFirstCol + 2 * j] = vals[j]->p;
     prm.out[kOutFirstCol + 2 * j + 1] = vbytes[j]->p;
   }
-  prm.iarg[kFixScaleArg] = packed_fix_scales(d);
+  prm.iarg[kFixScaleArg] = packed_fix_scales(d), prm.iarg[kFixScaleArg2] = packed_fix_scales(d, 4);
   if (ngroups) launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
   GatherSource gs = nullptr;
   if (!dict_id_col_.empty()) gs = [this](int c) { return std::make_pair((const DevTable*)&dict_src_, c); };
@@ -588,7 +588,7 @@ void ExecutionContext::finish_grouped() {
     prm.out[kOutFirstCol + 2 * j] = (char*)emit_arena_.p + val_off[j];
     prm.out[kOutFirstCol + 2 * j + 1] = (char*)emit_arena_.p + valid_base + j * valid_stride;
   }
-  prm.iarg[kFixScaleArg] = packed_fix_scales(d);
+  prm.iarg[kFixScaleArg] = packed_fix_scales(d), prm.iarg[kFixScaleArg2] = packed_fix_scales(d, 4);
   launch(v, "k_gemit", (int)std::min<int64_t>((group_cap_ + 255) / 256, 256 * 8), prm);
   // results come back through a pooled pinned buffer (a pageable destination would be staged by the runtime at a fraction of the rate)
   struct HostSpan {
@@ -659,10 +659,10 @@ void ExecutionContext::finish_grouped() {
   }
 }
 
-long long ExecutionContext::packed_fix_scales(const PipelineDesc& d) {
+long long ExecutionContext::packed_fix_scales(const PipelineDesc& d, int first) {      // sums first … first + 3, 16 bits each
   if (fix_scales_.size() != d.fix_sums.size()) fix_scales_.assign(d.fix_sums.size(), kFixDefaultScale);
   uint64_t p = 0;
-  for (size_t f = 0; f < fix_scales_.size(); f++) p |= (uint64_t)(uint16_t)(int16_t)fix_scales_[f] << (16 * f);
+  for (size_t f = (size_t)first; f < fix_scales_.size() && f < (size_t)first + 4; f++) p |= (uint64_t)(uint16_t)(int16_t)fix_scales_[f] << (16 * (f - (size_t)first));
   return (long long)p;
 }
 

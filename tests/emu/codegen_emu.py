@@ -287,7 +287,8 @@ def run_chain(plan, table: pa.Table) -> pa.Table:
     # run again — three times at most; one chunk here, so nothing has been accumulated before and the window may move down as well as up)
     FIX_W, scales = 158, [-94] * len(desc.get("fix_sums", []))
     for attempt in range(4):
-        prm.iarg[6] = sum((sc & 0xffff) << (16 * f) for f, sc in enumerate(scales))
+        prm.iarg[6] = sum((sc & 0xffff) << (16 * f) for f, sc in enumerate(scales[:4]))
+        prm.iarg[4] = sum((sc & 0xffff) << (16 * f) for f, sc in enumerate(scales[4:8]))      # (sums 4-7: codegen.hpp kFixScaleArg2)
         with _RUN_LOCK:      # (threadIdx and the aggregate driver's table are globals of the shim: one emulated launch at a time)
             rows = lib.emu_run(ctypes.byref(prm))
         if not scales or attempt >= 3:

@@ -41,6 +41,7 @@ PLAIN = {
 PARAMS = [("tests.test_q6_gpu", "test_q6_host_stream_matches_oracle", dict(n=n)) for n in (1, 64, 65, 100_003, 1 << 20)] + \
          [("tests.test_q1_gpu", "test_q1_host_stream_matches_oracle", dict(n=n)) for n in (1, 8192, 200_003)] + \
          [("tests.test_float_agg_gpu", "test_grouped_sums_low_and_high_cardinality", dict(ngroups=g)) for g in (5, 40_000)] + \
+         [("tests.test_float_agg_gpu", "test_seven_float_sums_and_averages_in_one_aggregate", dict(grouped=g)) for g in (False, True)] + \
          [("tests.test_final_agg_gpu", fn, dict(grouped=g)) for fn in ("test_partial_merge_then_final", "test_count_distinct_rewrite_with_mixed_mode_aggregate") for g in (False, True)] + \
          [("tests.test_fuzz_gpu", "test_random_grouped_aggregate", dict(seed=sd)) for sd in range(8)] + \
          [("tests.test_aligned_import_gpu", "test_under_aligned_decimal_column_through_filter_and_sum", dict(batch_rows=1000)),

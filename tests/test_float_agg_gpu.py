@@ -153,3 +153,44 @@ def test_non_finite_addends_follow_ieee(built):
     assert res[0] == inf and res[1] == -inf and res[2] == 5.0 and math.isnan(res[3]) and math.isnan(res[4]) and res[5] == 4.0 and res[6] == 0.0
     ug = run(S.hash_agg(S.scan([F64]), [], [S.sum_(S.col(0, F64), F64)]), pa.table({"x": pa.array([1e308, 1e308, -1e308])}), 1)
     assert ug.column(0)[0].as_py() == 1e308          # the exact sum is finite even though a running double sum overflows
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_seven_float_sums_and_averages_in_one_aggregate(built, grouped):
+    """Up to EIGHT exact Float64 sums per aggregate (round 6; four before: the scales of sums 4-7 travel in a second kernel argument word): four sums and three
+    averages over seven columns of very different magnitude (2^-30 … 2^40, so their fixed-point windows differ), NULLs, Partial → Final, grouped and ungrouped —
+    every sum bit-equal to math.fsum, every average to the correctly rounded sum divided by the count (avg.rs:239-280)."""
+    rng = np.random.default_rng(97)
+    n = 120_000
+    mags = [2.0 ** -30, 1.0, 2.0 ** 10, 2.0 ** 20, 2.0 ** 40, 2.0 ** -5, 2.0 ** 15]
+    cols = {f"x{i}": pa.array(rng.standard_normal(n) * m, mask=rng.random(n) < 0.03) for i, m in enumerate(mags)}
+    g = rng.integers(0, 5, n).astype(np.int32)
+    table = pa.table({"g": pa.array(g), **cols})
+    fields = [I32] + [F64] * 7
+    aggs = [S.sum_(S.col(1 + i, F64), F64) for i in range(4)] + [S.avg(S.col(5 + i, F64), F64, F64) for i in range(3)]
+    groups = [S.col(0, I32)] if grouped else []
+    partial = S.hash_agg(S.scan(fields), groups, aggs, S.PARTIAL)
+    ng = len(groups)
+    nstate = ng + 4 + 3 * 2
+    states = run(partial, table, nstate, batch_rows=20_000)
+    sfields = [I32] * ng + [F64] * 4 + [F64, S.T_INT64] * 3
+    final = S.hash_agg(S.scan(sfields), [S.col(i, I32) for i in range(ng)], aggs, S.FINAL)
+    out = run(final, states, ng + 7)
+    keys = sorted(set(g.tolist())) if grouped else [None]
+    assert out.num_rows == len(keys)
+    by_key = {(out.column(0)[r].as_py() if grouped else None): r for r in range(out.num_rows)}
+    for k in keys:
+        sel = (g == k) if grouped else np.ones(n, bool)
+        r = by_key[k]
+        for i in range(7):
+            xs = [v for v, keep in zip(table.column(1 + i).to_pylist(), sel) if keep and v is not None]
+            got = out.column(ng + i)[r].as_py()
+            want = math.fsum(xs) if i < 4 else math.fsum(xs) / len(xs)
+            assert got == want, (k, i, got, want, ulp_distance(got, want))
+
+
+def test_nine_float_sums_are_refused_by_name(built):
+    fields = [F64] * 9
+    plan = S.hash_agg(S.scan(fields), [], [S.sum_(S.col(i, F64), F64) for i in range(9)], S.PARTIAL)
+    with pytest.raises(native.CometNativeException, match="more than 8 distinct Float64 sums"):
+        native.compile_plan(plan.encode())

@@ -250,7 +250,7 @@ def render() -> str:
     w("")
     w("* `Cast`: timestamp -> float / decimal / boolean, binary, casts of a COMPUTED string; a cast to string is an output column (not an operand); on a")
     w("  device-resident input ANY type mismatch with the declared Scan fields.  Time zones come from the system's database ($TZDIR, /usr/share/zoneinfo).")
-    w("* `Min` / `Max` of decimal(> 18) in grouped aggregates; more than four Float64 sums / averages in one aggregate.")
+    w("* `Min` / `Max` of decimal(> 18) in grouped aggregates; more than eight Float64 sums / averages in one aggregate.")
     w("* `RLike`: patterns outside the byte-exact subset (`\\\\p{..}`, scoped flags, look-around, `\\\\b` under `(?m)`) are refused by name.")
     w("* `Concat`: of Utf8 columns and literals (at most eight), as an output column.")
     w("* Computed Utf8 values used as operands of further expressions must fit 15 bytes (literals, substring, CASE over those).")
