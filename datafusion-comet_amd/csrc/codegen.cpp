@@ -4059,7 +4059,7 @@ void fold_chain(const Operator& top, const Operator& source, const std::vector<D
 }
 
 PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, const std::vector<DType>& rt_in, const std::vector<bool>& lvalid_in,
-                           const std::vector<bool>& rvalid_in, const JoinFusion* fu) {
+                           const std::vector<bool>& rvalid_in, const JoinFusion* fu, const JoinFusion* fub) {
   if (j.kind != OpKind::HashJoin) throw CometError("internal: generate_join on a non-join");
   if (j.left_keys.size() != j.right_keys.size() || j.left_keys.empty()) throw CometError("HashJoin needs matching, non-empty key lists");
   int mode = 0;
@@ -4082,8 +4082,17 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   if (build_only) mode = 0;
   const bool outer_probe = !build_only && (build_left ? keep_right : keep_left);    // the probe side is the preserved one
   const bool outer_build = build_only || (build_left ? keep_left : keep_right);
-  const std::vector<DType>& bt = build_left ? lt_in : rt_in;
-  const std::vector<bool>& bv = build_left ? lvalid_in : rvalid_in;
+  // The build side: the materialised child — or (round 6), with a fused BUILD chain (fub), the chain's SOURCE table: build rows are source rows, the chain's
+  // Filters are part of P::bvalid (a row that fails them is in no table, no bitmap and no outer join's tail: P::bkeep), its columns expressions over the source.
+  const std::vector<DType>& bt = fub ? fub->src_types : (build_left ? lt_in : rt_in);
+  const std::vector<bool>& bv_src = fub ? fub->src_valid : (build_left ? lvalid_in : rvalid_in);
+  if (fub && bt.size() != bv_src.size()) throw CometError("internal: fused build source validity arity mismatch");
+  std::vector<bool> bv(bv_src);
+  if (fub)
+    for (auto& p : fub->preds)
+      if (p->kind == ExprKind::IsNotNull && p->children.size() == 1 && p->children[0]->kind == ExprKind::Bound && p->children[0]->bound_index >= 0 &&
+          (size_t)p->children[0]->bound_index < bv.size())
+        bv[(size_t)p->children[0]->bound_index] = false;
   // The probe side: the materialised child — or, with a fused probe chain (JoinFusion), the chain's SOURCE table; the child's columns
   // are then expressions over the source columns (fu->cols), its Filters conjuncts over them (fu->preds, P::pkeep).
   const std::vector<DType>& pt = fu ? fu->src_types : (build_left ? rt_in : lt_in);      // PHYSICAL probe columns
@@ -4099,14 +4108,19 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
         pv[(size_t)p->children[0]->bound_index] = false;
   const int nb = (int)bt.size(), np = (int)pt.size();
   const int nprobe_logical = fu ? (int)fu->cols.size() : np;
-  const int nl = build_left ? nb : nprobe_logical, nr = build_left ? nprobe_logical : nb;
+  const int nbuild_logical = fub ? (int)fub->cols.size() : nb;
+  const int nl = build_left ? nbuild_logical : nprobe_logical, nr = build_left ? nprobe_logical : nbuild_logical;
   if (nb + np > COMET_MAX_IN) throw CometError("too many columns for one GPU hash join");
-  const std::vector<ExprP>& bkeys = build_left ? j.left_keys : j.right_keys;
+  const std::vector<ExprP>& bkeys_logical = build_left ? j.left_keys : j.right_keys;
   const std::vector<ExprP>& pkeys_logical = build_left ? j.right_keys : j.left_keys;
-  std::vector<ExprP> pkeys;
+  std::vector<ExprP> pkeys, bkeys;
   {
     std::map<const Expr*, ExprP> memo;
     for (auto& k : pkeys_logical) pkeys.push_back(fu ? substitute(k, fu->cols, memo) : k);
+  }
+  {
+    std::map<const Expr*, ExprP> memo;
+    for (auto& k : bkeys_logical) bkeys.push_back(fub ? substitute(k, fub->cols, memo) : k);
   }
   // physical combined schema = kernel argument order: build columns (row i), then probe columns (row j)
   std::vector<DType> ct(bt);
@@ -4139,7 +4153,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   for (int c = 0; c < nl + nr; c++) {
     const bool is_left = c < nl;
     const int local = is_left ? c : c - nl;
-    if (is_left == build_left) phys.push_back(mk_bound(local, bt[(size_t)local]));
+    if (is_left == build_left) phys.push_back(fub ? fub->cols[(size_t)local] : mk_bound(local, bt[(size_t)local]));
     else if (!fu) phys.push_back(mk_bound(nb + local, pt[(size_t)local]));
     else phys.push_back(shift_bound(fu->cols[(size_t)local], nb));
   }
@@ -4221,7 +4235,22 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
     }
     return (int)words.size();
   };
-  key_fn("bvalid", "i", bt, bv, 0, bkeys, false);
+  if (fub && !fub->preds.empty()) {
+    // P::bvalid = the fused chain's Filters (every predicate column loaded up front, as in P::pkeep) AND the keys' validity
+    Gen g(bt, bv_src);
+    g.eager_loads = true;
+    g.locate = [](int idx) { return std::make_pair(idx, std::string("i")); };
+    for (auto& p : fub->preds) {
+      g.add_predicate(p);
+      ex << "  build filter (fused into the build passes): " << explain_expr(p) << "\n";
+    }
+    src << "  static __device__ __forceinline__ bool bkeep(const CometKParams& prm, i64 i) {\n    bool k[R] = {true};\n" << g.decls << g.body() << "    return k[0];\n  }\n";
+    key_fn("bkeysvalid", "i", bt, bv, 0, bkeys, false);
+    src << "  static __device__ __forceinline__ bool bvalid(const CometKParams& prm, i64 i) { return bkeep(prm, i) && bkeysvalid(prm, i); }\n";
+  } else {
+    src << "  static __device__ __forceinline__ bool bkeep(const CometKParams&, i64) { return true; }\n";
+    key_fn("bvalid", "i", bt, bv, 0, bkeys, false);
+  }
   int nwb = key_fn("bhash", "i", bt, bv, 0, bkeys, true);
   key_fn("pvalid", "j", pt, pv, nb, pkeys, false);
   int nwp = key_fn("phash", "j", pt, pv, nb, pkeys, true);
@@ -4419,7 +4448,7 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   d.join_build_only = build_only;
   const char* jt_name = build_only ? (keep_matched ? "LeftSemi" : "LeftAnti") : keep_left && keep_right ? "FullOuter" : keep_left ? "LeftOuter" : keep_right ? "RightOuter" : mode == 0 ? "Inner" : mode == 1 ? "LeftSemi" : "LeftAnti";
   ex << "  hash join: " << jt_name << ", build " << (build_left ? "left" : "right") << ", "
-     << j.left_keys.size() << " key(s)" << (fu ? ", probe side fused with its Filter / Projection chain" : "") << "\n";
+     << j.left_keys.size() << " key(s)" << (fu ? ", probe side fused with its Filter / Projection chain" : "") << (fub ? ", build side fused with its chain" : "") << "\n";
   d.in_types = ct;
   d.source = with_optional_headers(src.str());
   d.explain = ex.str();

@@ -130,7 +130,7 @@ struct JoinFusion {
 // left / right types and validity describe the join's children; with `probe_fusion` the probe side's entries are ignored
 PipelineDesc generate_join(const Operator& join, const std::vector<DType>& left_types, const std::vector<DType>& right_types,
                            const std::vector<bool>& left_has_validity, const std::vector<bool>& right_has_validity,
-                           const JoinFusion* probe_fusion = nullptr);
+                           const JoinFusion* probe_fusion = nullptr, const JoinFusion* build_fusion = nullptr);
 // the (cols, preds) of a Filter / Projection chain `top … down to (excluding) source`, over the source columns
 void fold_chain(const Operator& top, const Operator& source, const std::vector<DType>& source_types, std::vector<ExprP>& cols, std::vector<ExprP>& preds);
 

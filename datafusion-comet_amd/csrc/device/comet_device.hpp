@@ -2672,7 +2672,7 @@ CDEV void join_build_unmatched_count_body(const CometKParams& prm) {
 #pragma unroll
     for (int r = 0; r < kMaskTileRows / kBlock; r++) {
       i64 i = t * kMaskTileRows + r * kBlock + threadIdx.x;
-      local += (u32)__popcll(__ballot(i < nb && (matched[i] != 0) == P::BUILD_KEEP_MATCHED)) * (lane_id() == 0 ? 1u : 0u);
+      local += (u32)__popcll(__ballot(i < nb && (matched[i] != 0) == P::BUILD_KEEP_MATCHED && P::bkeep(prm, i))) * (lane_id() == 0 ? 1u : 0u);      // (bkeep: a fused build chain's Filters — a source row they drop is no build row)
     }
     if (lane_id() == 0) atomicAdd(&s_cnt, local);
     __syncthreads();
@@ -2693,7 +2693,7 @@ CDEV void join_build_unmatched_emit_body(const CometKParams& prm) {
     __syncthreads();
     for (int r = 0; r < kMaskTileRows / kBlock; r++) {
       i64 i = t * kMaskTileRows + r * kBlock + threadIdx.x;
-      const bool keep = i < nb && (matched[i] != 0) == P::BUILD_KEEP_MATCHED;
+      const bool keep = i < nb && (matched[i] != 0) == P::BUILD_KEEP_MATCHED && P::bkeep(prm, i);
       const u64 b = __ballot(keep);
       const u32 below = (u32)__popcll(b & ((1ull << lane_id()) - 1));
       if (lane_id() == 0) s_wave[wave_id()] = (u32)__popcll(b);

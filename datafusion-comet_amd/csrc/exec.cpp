@@ -128,8 +128,10 @@ ExecutionContext::ExecutionContext(OperatorP plan, uint64_t plan_hash, std::vect
     if (kv.first == "spark.comet.gpu.chunkRows") chunk_rows_ = std::max<long long>(1024, atoll(kv.second.c_str()));
     if (kv.first == "spark.comet.gpu.memory.limit") mem_->dev_limit = std::max<long long>(0, atoll(kv.second.c_str()));
     if (kv.first == "spark.comet.gpu.join.fuseProbe") fuse_probe_ = kv.second != "false" && kv.second != "0";
+    if (kv.first == "spark.comet.gpu.join.fuseBuild") fuse_build_ = (kv.second == "false" || kv.second == "0") ? 0 : kv.second == "always" ? 2 : 1;
   }
   if (const char* e = getenv("COMET_JOIN_FUSE_PROBE")) fuse_probe_ = atoi(e) != 0;
+  if (const char* e = getenv("COMET_JOIN_FUSE_BUILD")) fuse_build_ = atoi(e);
   if (const char* e = getenv("COMET_GPU_CHUNK_ROWS")) chunk_rows_ = std::max<long long>(1024, atoll(e));
   // Semi-join reduction.  A LeftSemi / LeftAnti join only asks whether its build side HOLDS a key: how often is irrelevant.  An Inner join
   // below it whose output is projected onto columns of ONE of its sides therefore only has to say which rows of that side have a partner
@@ -357,8 +359,42 @@ bool ExecutionContext::is_source(const Operator& op, const Operator* chain_top) 
 // Can this join read its probe chain's source directly?  The probe child must be a chain of Filters / Projections over a source
 // (Scan, Parquet scan, another join, …), no join key pair may be two Utf8 columns (those may need the string dictionary of hash_join,
 // which works on materialised columns), and the fused functor must generate — a computed Utf8 column in the chain's output does not.
+// The BUILD child as a Filter / Projection chain over a plain Scan leaf (round 6): the build passes then read the Scan's table — no materialised copy of the
+// filtered build side (TPC-DS Q95's two 70 M-row self-join builds: 1.3 ms of k_filter per run).  Same exclusions as on the probe side.
+bool ExecutionContext::plan_fused_build(const Operator& join, FusedProbe& fb) {
+  if (!fuse_build_ || join.children.size() != 2) return false;
+  const bool build_left = join.build_side == BuildSide::Left;
+  const Operator& child = *join.children[build_left ? 0 : 1];
+  if (child.kind != OpKind::Filter && child.kind != OpKind::Projection) return false;
+  const Operator* src = &child;
+  while (src->kind != OpKind::Scan) {
+    if ((src->kind != OpKind::Filter && src->kind != OpKind::Projection) || src->children.size() != 1) return false;
+    src = src->children[0].get();
+  }
+  for (size_t k = 0; k < join.left_keys.size() && k < join.right_keys.size(); k++) {
+    auto strk = [](const ExprP& e) { return e->kind == ExprKind::Bound && (!e->has_dtype || e->dtype.id == TypeId::String || e->dtype.id == TypeId::Bytes); };
+    if (strk(join.left_keys[k]) && strk(join.right_keys[k])) return false;
+  }
+  try {
+    fb.source = src;
+    fb.fu.src_types = src->scan_fields;
+    fb.fu.src_valid.assign(fb.fu.src_types.size(), false);
+    fold_chain(child, *src, fb.fu.src_types, fb.fu.cols, fb.fu.preds);
+  } catch (const CometError&) {
+    return false;
+  }
+  // By default only chains whose Filters merely drop NULLs are fused: the build passes (run count, bitmap, histogram, scatter) each read the SOURCE, so a
+  // selective filter makes them read several times what one k_filter would have left behind (SF100 Q3's customers of one market segment, 20 % of 15 M rows:
+  // 6.96 → 7.08 ms fused), while isnotnull(…) keeps nearly every row and the materialised copy is pure overhead (TPC-DS Q95's two self-join builds: 13.9 → 13.35 ms)
+  if (fuse_build_ < 2)
+    for (auto& p : fb.fu.preds)
+      if (p->kind != ExprKind::IsNotNull) return false;
+  return true;
+}
+
 bool ExecutionContext::plan_fused_probe(const Operator& join, const std::vector<DType>& build_types, PipelineDesc& desc) {
   fused_probe_.erase(&join);
+  fused_build_.erase(&join);
   if (!fuse_probe_ || join.children.size() != 2) return false;
   const bool build_left = join.build_side == BuildSide::Left;
   const Operator& child = *join.children[build_left ? 1 : 0];
@@ -381,7 +417,17 @@ bool ExecutionContext::plan_fused_probe(const Operator& join, const std::vector<
     fold_chain(child, *src, fp.fu.src_types, fp.fu.cols, fp.fu.preds);
     std::vector<DType> none_t;
     std::vector<bool> bv(build_types.size(), false), none_v;
-    desc = generate_join(join, build_left ? build_types : none_t, build_left ? none_t : build_types, build_left ? bv : none_v, build_left ? none_v : bv, &fp.fu);
+    FusedProbe fb;
+    bool with_build = plan_fused_build(join, fb);
+    if (with_build) {
+      try {
+        desc = generate_join(join, build_left ? build_types : none_t, build_left ? none_t : build_types, build_left ? bv : none_v, build_left ? none_v : bv, &fp.fu, &fb.fu);
+      } catch (const CometError&) {
+        with_build = false;
+      }
+    }
+    if (!with_build) desc = generate_join(join, build_left ? build_types : none_t, build_left ? none_t : build_types, build_left ? bv : none_v, build_left ? none_v : bv, &fp.fu);
+    else fused_build_[&join] = fb;
   } catch (const CometError&) {
     explain_ = explain_before;    // the unfused path reports its own errors
     return false;
@@ -748,7 +794,17 @@ std::vector<DType> ExecutionContext::infer_schema(const Operator& op) {
     }
     if (!fused) {
       std::vector<bool> lv(l.size(), false), rv(r.size(), false);
-      d = generate_join(op, l, r, lv, rv);   // validates keys / join type
+      FusedProbe fb;
+      bool with_build = plan_fused_build(op, fb);
+      if (with_build) {
+        try {
+          d = generate_join(op, l, r, lv, rv, nullptr, &fb.fu);
+          fused_build_[&op] = fb;
+        } catch (const CometError&) {
+          with_build = false;
+        }
+      }
+      if (!with_build) d = generate_join(op, l, r, lv, rv);   // validates keys / join type
     }
     if (compile_in_infer_) jit_compile(d.source);
     explain_ += d.explain;
@@ -1506,15 +1562,19 @@ DevTable ExecutionContext::materialize(const Operator& op) {
   }
   if (op.kind == OpKind::HashJoin) {
     auto fit = fused_probe_.find(&op);
+    auto fbit = fused_build_.find(&op);
     DevTable j;
-    if (fit != fused_probe_.end()) {
-      // the probe child's Filters / Projections run inside the probe kernel over the chain's source table
+    if (fit != fused_probe_.end() || fbit != fused_build_.end()) {
+      // the probe child's Filters / Projections run inside the probe kernel over the chain's source table; a fused build child's inside the build passes
       const bool build_left = op.build_side == BuildSide::Left;
-      DevTable b = materialize(*op.children[build_left ? 0 : 1]);
-      DevTable s = materialize(*fit->second.source);
-      JoinFusion fu = fit->second.fu;
-      fu.src_valid = s.has_valid;
-      j = build_left ? hash_join_impl(op, op, b, s, ":F", &fu) : hash_join_impl(op, op, s, b, ":F", &fu);
+      const bool fb_on = fbit != fused_build_.end(), fp_on = fit != fused_probe_.end();
+      DevTable b = materialize(fb_on ? *fbit->second.source : *op.children[build_left ? 0 : 1]);
+      DevTable s = materialize(fp_on ? *fit->second.source : *op.children[build_left ? 1 : 0]);
+      JoinFusion fu, fub;
+      if (fp_on) { fu = fit->second.fu; fu.src_valid = s.has_valid; }
+      if (fb_on) { fub = fbit->second.fu; fub.src_valid = b.has_valid; join_fused_builds_++; }
+      const char* sfx = fp_on && fb_on ? ":FB" : fp_on ? ":F" : ":B";
+      j = build_left ? hash_join_impl(op, op, b, s, sfx, fp_on ? &fu : nullptr, fb_on ? &fub : nullptr) : hash_join_impl(op, op, s, b, sfx, fp_on ? &fu : nullptr, fb_on ? &fub : nullptr);
     } else {
       DevTable l = materialize(*op.children[0]);
       DevTable r = materialize(*op.children[1]);
@@ -2060,6 +2120,7 @@ std::string ExecutionContext::metrics_proto() {
       n.metrics.emplace_back("join_probe_rows", join_probe_rows_);
       n.metrics.emplace_back("join_direct_maps", join_direct_maps_);      // joins probed through the direct map of a unique integer key
       n.metrics.emplace_back("join_bucket_tables", join_bucket_tables_);  // joins probed through the partitioned, LDS-built bucket table
+      n.metrics.emplace_back("join_fused_builds", join_fused_builds_);    // joins whose build passes read their build chain's Scan table
       n.metrics.emplace_back("join_mono_tables", join_mono_tables_);      // … of them, with the order-preserving hash
       n.metrics.emplace_back("join_bitmap_only", join_bitmap_only_);      // semi / anti joins answered by the build side's key bitmap alone
     }

@@ -205,10 +205,11 @@ class ExecutionContext {
   void extend_derived_strfn(DevTable& in, const DerivedCol& dc);
   DevTable hash_join(const Operator& j, const DevTable& l, const DevTable& r);
   DevTable hash_join_impl(const Operator& node, const Operator& j, const DevTable& l, const DevTable& r, const std::string& key_suffix,
-                          const JoinFusion* fused_probe = nullptr);
+                          const JoinFusion* fused_probe = nullptr, const JoinFusion* fused_build = nullptr);
   // Probe-side fusion (codegen.hpp JoinFusion): decided per join at createPlan (infer_schema)
   struct FusedProbe { const Operator* source = nullptr; JoinFusion fu; };
   bool plan_fused_probe(const Operator& join, const std::vector<DType>& build_types, PipelineDesc& desc);
+  bool plan_fused_build(const Operator& join, FusedProbe& fb);
   DevTable sort_table(const Operator& s, const DevTable& in);
   std::shared_ptr<DevBuf> sort_key_planes(const Operator& s, const DevTable& in, int& W, std::vector<int64_t>* str_len = nullptr, bool measure_only = false);
   DevTable literal_table(const std::vector<std::vector<ExprP>>& rows, const std::vector<DType>& types);
@@ -326,14 +327,16 @@ class ExecutionContext {
   bool device_result_ = false;                     // the grouped result stays in HBM (nested aggregate / execute_device)
   DevTable dict_src_;                              // the aggregate's input while such keys are in flight
   std::map<const Operator*, FusedProbe> fused_probe_;   // joins that read their probe chain's source table directly
+  std::map<const Operator*, FusedProbe> fused_build_;   // … and their build chain's (a Scan leaf's table)
   int64_t ramp_rows_ = 0;                          // host streams: size of the next chunk while the pipeline fills (doubles up to chunk_rows_)
   bool fuse_probe_ = true;                         // spark.comet.gpu.join.fuseProbe
+  int fuse_build_ = 1;                             // spark.comet.gpu.join.fuseBuild: 0 false, 1 true (chains whose Filters only drop NULLs), 2 "always"
   std::set<const Operator*> smj_needs_sort_;       // sort-merge joins whose output order is observable (others skip the sort)
   std::map<const Operator*, OperatorP> smj_sorts_;  // SortMergeJoin node → synthetic Sort over its output       // aggregates that are not the plan root (materialised by sub-contexts)
   const Operator* root_source_ = nullptr;          // Scan or HashJoin the root chain reads from
   std::map<const Operator*, int> node_id_;          // preorder ordinal (plan-cache key of sub-pipelines)
   std::map<const Operator*, size_t> scan_input_;    // Scan leaf → input stream index
-  int64_t join_build_rows_ = 0, join_probe_rows_ = 0, join_keymap_bytes_ = 0, join_direct_maps_ = 0, join_bucket_tables_ = 0, join_bitmap_only_ = 0, join_mono_tables_ = 0;
+  int64_t join_build_rows_ = 0, join_probe_rows_ = 0, join_keymap_bytes_ = 0, join_direct_maps_ = 0, join_bucket_tables_ = 0, join_bitmap_only_ = 0, join_mono_tables_ = 0, join_fused_builds_ = 0;
   int small_write_slot_ = 0;         // write_small's ring of staging slots
   // the partitioned merging aggregate (exec_pipeline.cpp try_partitioned_merge): its input is known to be ONE chunk; the emitted result
   bool single_chunk_hint_ = false, part_result_ready_ = false;

@@ -105,7 +105,8 @@ DevTable ExecutionContext::hash_join(const Operator& j, const DevTable& L, const
 }
 
 DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& j, const DevTable& L, const DevTable& R, const std::string& key_suffix,
-                                          const JoinFusion* fused_probe) {
+                                          const JoinFusion* fused_probe, const JoinFusion* fused_build) {
+  // with `fused_build` the build-side table (L when the build side is left) is the SOURCE of the build chain
   // with `fused_probe` the probe-side table (R when the build side is left) is the SOURCE of the probe chain
   // planned once per (join node, validity patterns)
   std::string key = std::to_string(plan_hash_ ^ (0x9E3779B97F4A7C15ull * (uint64_t)(node_id_[&node] + 1))) + ":J:" + validity_key(L.has_valid) + "|" +
@@ -118,7 +119,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   }
   if (!pv) {
     pv = std::make_shared<PlannedVariant>();
-    pv->desc = generate_join(j, L.types, R.types, L.has_valid, R.has_valid, fused_probe);
+    pv->desc = generate_join(j, L.types, R.types, L.has_valid, R.has_valid, fused_probe, fused_build);
     pv->code = jit_compile(pv->desc.source);
     std::lock_guard<std::mutex> lk(g_plan_mu);
     g_plan_cache[key] = pv;
@@ -380,7 +381,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
       join_bucket_tables_--;
       join_no_bucket_ = true;
       try {
-        DevTable r = hash_join_impl(node, j, L, R, key_suffix, fused_probe);
+        DevTable r = hash_join_impl(node, j, L, R, key_suffix, fused_probe, fused_build);
         join_no_bucket_ = false;
         return r;
       } catch (...) {
@@ -421,7 +422,7 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
   // gathered Utf8 payload columns name their source by its kernel-argument index: build columns, then probe columns
   const int nbuild = (int)nb;
   DevTable out = outputs_to_table(v, vals, vbytes, out_rows, [&](int c) { return c < nbuild ? std::make_pair(&B, c) : std::make_pair(&P, c - nbuild); });
-  if (fused_probe) check_device_errors();     // the chain's expressions may raise ANSI errors; an unfused chain checks after its own launch
+  if (fused_probe || fused_build) check_device_errors();     // the chain's expressions may raise ANSI errors; an unfused chain checks after its own launch
   // the tables of this frame (heads, records, bitmap, ranks …) go back to the pool when it ends: nothing queued may still read them.  The probe's result was
   // waited for (read_small) and only the output's own buffers are touched after it — except by the build-side tail of an outer join, and when no probe ran
   if (tail_rows > 0 || n == 0) HIP_CHECK(hipStreamSynchronize(stream_));

@@ -303,8 +303,8 @@ def _sorted(t):
     return t.sort_by([(n, "ascending") for n in t.column_names])
 
 
-def _join_metrics(plan, tables, ncols):
-    it = native.CometExecIterator([native.HostInput.from_table(t) for t in tables], ncols, plan.encode(), batch_size=0)
+def _join_metrics(plan, tables, ncols, config=b""):
+    it = native.CometExecIterator([native.HostInput.from_table(t) for t in tables], ncols, plan.encode(), config=config, batch_size=0)
     batches = []
     while True:
         b = native.Native.executePlan(it.handle, ncols)
@@ -491,3 +491,64 @@ def test_monotone_hash_is_dropped_for_keys_that_do_not_spread_over_their_range(b
         want = _oracle(j, [probe_t, build2])
         assert m["join_bucket_tables"] == 1 and m["join_mono_tables"] == 1, m
         assert got.num_rows == want.num_rows > 1000 and _sorted(got).equals(_sorted(want))
+
+
+# ---- build-side chain fusion (round 6): the build passes read the chain's Scan table; rows its Filters drop are no build rows ----
+@pytest.mark.parametrize("jt", ALL_TYPES)
+@pytest.mark.parametrize("size", ["lds", "bucket"])
+def test_fused_build_chain_matches_oracle_and_the_unfused_join(built, jt, size):
+    """The BUILD child (right) is Filter → Project (reordered columns, a computed key, a computed payload) → Filter over a Scan: the table, the bitmap and an outer
+    join's tail of unmatched build rows see only the rows the chain keeps (P::bkeep), output columns are the chain's expressions over the source row.  Small build
+    side (the per-block LDS table) and large (bucket table); probe side fused too or a bare scan; residual condition over a computed build column.  Same multiset as
+    the oracle and as the engine with spark.comet.gpu.join.fuseBuild=false."""
+    rng = np.random.default_rng(81 if size == "lds" else 82)
+    nb, npr = (4000, 6000) if size == "lds" else (180_000, 90_000)
+    keys = max(50, nb // 3)
+    build_t = pa.table({"w": pa.array(rng.integers(-1000, 1000, nb), pa.int32(), mask=rng.random(nb) < 0.05), "k": pa.array(rng.integers(0, keys, nb), pa.int64(), mask=rng.random(nb) < 0.03),
+                        "id": pa.array(np.arange(nb, dtype=np.int64))})
+    probe_t = pa.table({"k": pa.array(rng.integers(0, keys + keys // 4, npr), pa.int64(), mask=rng.random(npr) < 0.03), "v": pa.array(rng.integers(-1000, 1000, npr), pa.int32()),
+                        "id": pa.array(np.arange(npr, dtype=np.int64))})
+    BF = [S.T_INT32, S.T_INT64, S.T_INT64]
+    f1 = S.filter_(S.scan(BF), S.and_(S.gt(S.col(0, S.T_INT32), S.lit(-700, S.T_INT32)), S.is_not_null(S.col(1, S.T_INT64))))       # NULL w fails too
+    pr = S.project(f1, [S.math("add", S.col(1, S.T_INT64), S.lit(0, S.T_INT64), S.T_INT64), S.col(2, S.T_INT64), S.math("multiply", S.col(0, S.T_INT32), S.lit(2, S.T_INT32), S.T_INT32)])
+    bchain = S.filter_(pr, S.lt(S.col(2, S.T_INT32), S.lit(1600, S.T_INT32)))                                                          # → (k + 0, id, 2 w)
+    pchain = S.project(S.filter_(S.scan(CFIELDS), S.gt(S.col(1, S.T_INT32), S.lit(-900, S.T_INT32))), [S.col(0, S.T_INT64), S.col(1, S.T_INT32), S.col(2, S.T_INT64)])
+    ncols = 3 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 6
+    for left in (S.scan(CFIELDS), pchain):
+        for cond in (None, S.lt(S.col(1, S.T_INT32), S.col(5, S.T_INT32))):      # probe.v < 2 · build.w
+            j = S.hash_join(left, bchain, [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_RIGHT, cond)
+            always = S.config_map({"spark.comet.gpu.join.fuseBuild": "always"})      # (by default only chains whose Filters merely drop NULLs are fused)
+            assert "build side fused with its chain" not in native.compile_plan(j.encode())
+            got, m = _join_metrics(j, [probe_t, build_t], ncols, config=always)
+            assert m["join_fused_builds"] == 1, m
+            unfused = _run(j, [probe_t, build_t], ncols, batch_size=0, config=S.config_map({"spark.comet.gpu.join.fuseBuild": "false"}))
+            want = _oracle(j, [probe_t, build_t])
+            assert got.num_rows == want.num_rows == unfused.num_rows > 100, (jt, size, cond is not None)
+            assert _sorted(got).equals(_sorted(want)) and _sorted(unfused).equals(_sorted(want)), (jt, size, cond is not None)
+
+
+def test_fused_build_on_the_left_and_a_filter_that_keeps_nothing(built):
+    rng = np.random.default_rng(83)
+    nb, npr = 3000, 2000
+    left = pa.table({"k": pa.array(rng.integers(0, 500, nb), pa.int64()), "v": pa.array(rng.integers(-1000, 1000, nb), pa.int32()), "id": pa.array(np.arange(nb, dtype=np.int64))})
+    right = pa.table({"k": pa.array(rng.integers(0, 600, npr), pa.int64()), "v": pa.array(rng.integers(-1000, 1000, npr), pa.int32()), "id": pa.array(np.arange(npr, dtype=np.int64))})
+    lchain = S.filter_(S.scan(CFIELDS), S.gt(S.col(1, S.T_INT32), S.lit(0, S.T_INT32)))
+    for jt in (S.INNER, S.LEFT_SEMI, S.LEFT_ANTI, S.LEFT_OUTER, S.FULL_OUTER):      # LeftSemi / LeftAnti built on the left: the output is a subset of the BUILD rows the chain keeps
+        j = S.hash_join(lchain, S.scan(CFIELDS), [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], jt, S.BUILD_LEFT)
+        always = S.config_map({"spark.comet.gpu.join.fuseBuild": "always"})
+        (got, m), want = _join_metrics(j, [left, right], 3 if jt in (S.LEFT_SEMI, S.LEFT_ANTI) else 6, config=always), _oracle(j, [left, right])
+        assert m["join_fused_builds"] == 1, m
+        assert got.num_rows == want.num_rows > 0 and _sorted(got).equals(_sorted(want)), jt
+    none = S.filter_(S.scan(CFIELDS), S.gt(S.col(1, S.T_INT32), S.lit(5000, S.T_INT32)))
+    always = S.config_map({"spark.comet.gpu.join.fuseBuild": "always"})
+    j = S.hash_join(S.scan(CFIELDS), none, [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.LEFT_OUTER, S.BUILD_RIGHT)
+    got = _run(j, [left, right], 6, batch_size=0, config=always)
+    assert got.num_rows == left.num_rows and got.column(3).null_count == left.num_rows
+    j = S.hash_join(S.scan(CFIELDS), none, [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.RIGHT_OUTER, S.BUILD_RIGHT)
+    assert _run(j, [left, right], 6, batch_size=0, config=always) is None
+    # isnotnull-only chains are fused by default
+    nn = S.project(S.filter_(S.scan(CFIELDS), S.is_not_null(S.col(0, S.T_INT64))), [S.col(0, S.T_INT64), S.col(2, S.T_INT64)])
+    j = S.hash_join(S.scan(CFIELDS), nn, [S.col(0, S.T_INT64)], [S.col(0, S.T_INT64)], S.INNER, S.BUILD_RIGHT)
+    assert "build side fused with its chain" in native.compile_plan(j.encode())
+    got, want = _run(j, [left, right], 5, batch_size=0), _oracle(j, [left, right])
+    assert got.num_rows == want.num_rows > 0 and _sorted(got).equals(_sorted(want))
