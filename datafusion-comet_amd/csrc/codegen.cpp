@@ -4009,14 +4009,16 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_gemit(const CometKParams prm) { comet::agg_grouped_emit_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_grehash(const CometKParams prm) { comet::agg_grouped_rehash_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
-    if (d.merges_states) {
-      // a merging aggregate may run partitioned (comet_device.hpp template C''): count / scatter passes over the rows, an LDS merge + emit per partition
+    if (true) {
+      // a grouped aggregate over one chunk may run partitioned (comet_device.hpp template C''): count / scatter passes over the rows, an LDS merge + emit per partition
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_gphist(const CometKParams prm) { comet::agg_part_pass_body<P, 1>(prm); }\n";
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_gpscat(const CometKParams prm) { comet::agg_part_pass_body<P, 2>(prm); }\n";
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_gpmerge(const CometKParams prm) { comet::agg_part_merge_body<P>(prm); }\n";
     }
     d.kernels = {"k_gagg", "k_gemit", "k_grehash", "k_pack"};
-    if (d.merges_states) { d.kernels.push_back("k_gphist"); d.kernels.push_back("k_gpscat"); d.kernels.push_back("k_gpmerge"); }
+    d.kernels.push_back("k_gphist");
+    d.kernels.push_back("k_gpscat");
+    d.kernels.push_back("k_gpmerge");
   }
   d.source = with_optional_headers(src.str());
   d.explain = ex.str();
