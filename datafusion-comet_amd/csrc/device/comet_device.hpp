@@ -2968,8 +2968,8 @@ CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
 #pragma unroll
       for (int r = 0; r < kJoinR0; r++) {
         const u64 idx = keys[r] - first;
-        // (a row the chain's filter dropped asks for word 0: the one line every CU holds in its L1, instead of a random L2 request for nothing)
-        const u32 w = ((const u32*)(keymap + 2))[(idx < bits) & ((can_bits >> r) & 1u) ? idx >> 5 : 0ull];
+        // (rows the chain's filter dropped read their word too — sending them to word 0 instead was measured and is no faster: SF100 Q3 3.99 against 3.87–3.92 ms)
+        const u32 w = ((const u32*)(keymap + 2))[idx < bits ? idx >> 5 : 0ull];
         // (a MASK, not a select: the compiler sinks a load whose value is only wanted under a condition into that branch — and waits for it there, sixteen
         // dependent bitmap reads per thread and tile)
         const u32 use = 0u - (u32)(((can_bits >> r) & 1u) & (idx < bits ? 1u : 0u));
