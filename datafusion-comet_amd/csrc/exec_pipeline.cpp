@@ -428,7 +428,8 @@ bool ExecutionContext::try_partitioned_merge(Variant& v, CometKParams& prm, int6
   part_result_ready_ = true;
   part_merges_++;
   groups_committed_ = ngroups;
-  HIP_CHECK(hipStreamSynchronize(stream_));      // the records and the partition counters go back to the pool
+  // (the records and the partition counters go back to the pool with this frame: the merge kernel that read them was waited for by the read-back above, and what
+  // outputs_to_table queued behind it touches the output's own buffers only)
   return true;
 }
 
@@ -493,9 +494,8 @@ void ExecutionContext::finish_aggregate() {
 // Grouped aggregate result left in HBM (stage boundary of a multi-GPU plan: Partial states feed the next stage's exchange
 // or Final aggregate without touching the host).  Utf8 group keys are not supported on this path yet.
 DevTable ExecutionContext::grouped_to_device() {
-  if (part_result_ready_) {      // the partitioned merge emitted already
+  if (part_result_ready_) {      // the partitioned merge emitted already (and its error flags were read with the group count)
     part_result_ready_ = false;
-    check_device_errors();
     return std::move(part_result_);
   }
   DevTable empty;

@@ -152,7 +152,7 @@ PYEOF
 }
 q95_host() {       # host calls and device work of the last Q95 run side by side: what fills the gaps between the kernels
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT/q95_host -o h -- python $GRAFT_REPO_ROOT/tools/q95_bench.py --orders 16000000 --reps 2 --verify none > $OUT/q95_host.log 2>&1)
-  python tools/hip_timeline.py $OUT/q95_host k_filter ${TL_MIN_US:-4} 5 > $OUT/q95_host.txt 2>&1; rm -rf $OUT/q95_host; tail -${TL_LINES:-60} $OUT/q95_host.txt | cut -c1-140
+  python tools/hip_timeline.py $OUT/q95_host k_filter ${TL_MIN_US:-4} ${Q95_TL_NTH:-3} > $OUT/q95_host.txt 2>&1; rm -rf $OUT/q95_host; tail -${TL_LINES:-60} $OUT/q95_host.txt | cut -c1-140
 }
 q95_pmc() {        # per-kernel HBM traffic and wait cycles of Q95 stage A (separate PMC passes, as the guide prescribes)
   Q95="python $GRAFT_REPO_ROOT/tools/q95_bench.py --orders 16000000 --reps 1 --verify none"
