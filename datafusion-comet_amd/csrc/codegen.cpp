@@ -4009,16 +4009,21 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_gemit(const CometKParams prm) { comet::agg_grouped_emit_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_grehash(const CometKParams prm) { comet::agg_grouped_rehash_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
-    if (true) {
+    // (only where the path can apply — a merging aggregate, or one over a materialised source such as a join's output: a Partial aggregate over a Scan sees chunks
+    // of a stream, and its three extra kernels would only lengthen the cold compile: SF100 Q1's plan 497 → 680 ms)
+    const bool part_kernels = d.merges_states || source_types != nullptr;
+    if (part_kernels) {
       // a grouped aggregate over one chunk may run partitioned (comet_device.hpp template C''): count / scatter passes over the rows, an LDS merge + emit per partition
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_gphist(const CometKParams prm) { comet::agg_part_pass_body<P, 1>(prm); }\n";
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_gpscat(const CometKParams prm) { comet::agg_part_pass_body<P, 2>(prm); }\n";
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_gpmerge(const CometKParams prm) { comet::agg_part_merge_body<P>(prm); }\n";
     }
     d.kernels = {"k_gagg", "k_gemit", "k_grehash", "k_pack"};
-    d.kernels.push_back("k_gphist");
-    d.kernels.push_back("k_gpscat");
-    d.kernels.push_back("k_gpmerge");
+    if (part_kernels) {
+      d.kernels.push_back("k_gphist");
+      d.kernels.push_back("k_gpscat");
+      d.kernels.push_back("k_gpmerge");
+    }
   }
   d.source = with_optional_headers(src.str());
   d.explain = ex.str();

@@ -330,21 +330,24 @@ def test_merging_aggregate_of_many_groups_runs_partitioned(built, shape):
 
 
 @pytest.mark.parametrize("groups", [60_000, 4])
-def test_partial_aggregate_over_one_device_chunk_partitions_when_its_groups_are_many(built, groups):
-    """Any grouped aggregate over ONE modest device-resident chunk (a join's output, a resident table) may take the partition → LDS merge → emit path; whether the groups are
-    many is read off the partition sizes after the counting pass: 60 K groups of ≈ 3 rows run partitioned (metric 1), 4 groups of 50 K rows fall back to the table
-    path (metric 0).  Partial states bit-equal to the oracle's either way."""
+def test_partial_aggregate_over_a_joins_output_partitions_when_its_groups_are_many(built, groups):
+    """A grouped aggregate whose whole input is ONE modest chunk — here a join's output — may take the partition → LDS merge → emit path; whether the groups are many is
+    read off the partition sizes after the counting pass: 60 K groups of ≈ 3 rows run partitioned (metric 1), 4 groups of 50 K rows fall back to the table path
+    (metric 0).  Partial states bit-equal to the oracle's either way."""
     from oracle import oracle as O
     rng = np.random.default_rng(93)
     n = 200_000
     k = rng.integers(0, groups, n).astype(np.int64) * 104_729
     table = pa.table({"k": pa.array(k, mask=rng.random(n) < 0.002), "m": tpch._dec128_array(rng.integers(-10**9, 10**9, n), 12, 2),
-                      "q": pa.array(rng.integers(-1000, 1000, n), pa.int64(), mask=rng.random(n) < 0.05)})
+                      "q": pa.array(rng.integers(-1000, 1000, n), pa.int64(), mask=rng.random(n) < 0.05), "j": pa.array(np.zeros(n, np.int32))})
+    dim = pa.table({"j": pa.array(np.zeros(1, np.int32)), "w": pa.array(np.ones(1, np.int64))})
     D = S.decimal(12, 2)
-    partial = S.hash_agg(S.scan([S.T_INT64, D, S.T_INT64]), [S.col(0, S.T_INT64)],
-                         [S.sum_(S.col(1, D), S.decimal(22, 2)), S.count(S.col(2, S.T_INT64)), S.min_(S.col(2, S.T_INT64), S.T_INT64), S.avg(S.col(1, D), S.decimal(16, 6), S.decimal(22, 2))], S.PARTIAL)
-    want = O.run_plan_to_arrow(S, partial, table)
-    got, m = _metrics_run(partial, [native.DeviceInput(native.DeviceTable.from_arrow(table, "cuda:0"))], want.num_columns)
+    join = S.hash_join(S.scan([S.T_INT64, D, S.T_INT64, S.T_INT32]), S.scan([S.T_INT32, S.T_INT64]), [S.col(3, S.T_INT32)], [S.col(0, S.T_INT32)], S.INNER, S.BUILD_RIGHT)
+    partial = S.hash_agg(join, [S.col(0, S.T_INT64)],
+                         [S.sum_(S.col(1, D), S.decimal(22, 2)), S.count(S.col(2, S.T_INT64)), S.min_(S.col(2, S.T_INT64), S.T_INT64), S.avg(S.col(1, D), S.decimal(16, 6), S.decimal(22, 2)),
+                          S.sum_(S.col(5, S.T_INT64), S.T_INT64)], S.PARTIAL)
+    want = O.run_plan_to_arrow(S, partial, [table, dim])
+    got, m = _metrics_run(partial, [native.HostInput.from_table(table), native.HostInput.from_table(dim)], want.num_columns)
     assert m["agg_partitioned_merges"] == (1 if groups > 100 else 0), m
     srt = lambda t: t.rename_columns([f"c{i}" for i in range(t.num_columns)]).combine_chunks().sort_by([("c0", "ascending")])
     assert got.num_rows == want.num_rows and srt(got).equals(srt(want))
