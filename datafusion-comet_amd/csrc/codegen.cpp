@@ -4011,7 +4011,8 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
     // (only where the path can apply — a merging aggregate, or one over a materialised source such as a join's output: a Partial aggregate over a Scan sees chunks
     // of a stream, and its three extra kernels would only lengthen the cold compile: SF100 Q1's plan 497 → 680 ms)
-    const bool part_kernels = d.merges_states || source_types != nullptr;
+    // (… a Partial aggregate keyed by Utf8 columns is "materialised" only so that long strings can be swapped for row indices — TPC-H Q1's shape: four groups)
+    const bool part_kernels = d.merges_states || (source_types != nullptr && d.str_key_cols.empty());
     if (part_kernels) {
       // a grouped aggregate over one chunk may run partitioned (comet_device.hpp template C''): count / scatter passes over the rows, an LDS merge + emit per partition
       src << "extern \"C\" __global__ __launch_bounds__(256) void k_gphist(const CometKParams prm) { comet::agg_part_pass_body<P, 1>(prm); }\n";

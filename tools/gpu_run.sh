@@ -150,6 +150,10 @@ for r in rows[:14]:
     m=re.search(r"(k_\w+|[a-z_0-9]+_kernel|__amd\w+)", r["Name"]); print(f'{(m.group(1) if m else r["Name"][:30]):28s} calls {r["Calls"]:>4s} total_ms {float(r["TotalDurationNs"])/1e6:9.3f} avg_ms {float(r["AverageNs"])/1e6:8.3f}')
 PYEOF
 }
+q6_host() {        # host calls and device work of the last SF10 Q6 task (HBM-resident): what the task costs besides its kernel
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT/q6_host -o h -- python $GRAFT_REPO_ROOT/tools/resident.py --query q6 --rows 59986052 --steps 6 --no-check > $OUT/q6_host.log 2>&1)
+  python tools/hip_timeline.py $OUT/q6_host k_agg ${TL_MIN_US:-2} 1 > $OUT/q6_host.txt 2>&1; rm -rf $OUT/q6_host; tail -${TL_LINES:-90} $OUT/q6_host.txt | cut -c1-140
+}
 q95_host() {       # host calls and device work of the last Q95 run side by side: what fills the gaps between the kernels
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $OUT/q95_host -o h -- python $GRAFT_REPO_ROOT/tools/q95_bench.py --orders 16000000 --reps 2 --verify none > $OUT/q95_host.log 2>&1)
   python tools/hip_timeline.py $OUT/q95_host k_filter ${TL_MIN_US:-4} ${Q95_TL_NTH:-3} > $OUT/q95_host.txt 2>&1; rm -rf $OUT/q95_host; tail -${TL_LINES:-60} $OUT/q95_host.txt | cut -c1-140
