@@ -263,6 +263,20 @@ def render() -> str:
     w("  Parquet: TIMESTAMP(NANOS) / TIME, encrypted files.")
     w("* ShuffleWriter with more than 4096 partitions.")
     w("")
+    w("## 5. Results that are not bit-equal to the reference's (and how far apart they may be)")
+    w("")
+    w("* Float64 functions that both sides hand to a math library — `acos` `acosh` `asin` `asinh` `atan` `atanh` `atan2` `cbrt` `cos` `cosh` `cot` `csc` `sec` `exp` `expm1`")
+    w("  `ln` `log2` `log10` `sin` `sinh` `tan` `tanh` `pow` and Spark's `log(base, x)` — are evaluated by the device's libm (ROCm's ocml), the reference's by the platform")
+    w("  libm behind Rust's `std`: correctly rounded in neither, tested within 8 ulp of each other (`tests/test_scalar_batch_gpu.py`); `degrees`, `radians`, `rint`, `pi`,")
+    w("  `greatest` / `least` and the arithmetic operators are IEEE-exact and bit-equal.")
+    w("* Float64 / Float32 `sum` and `avg`: the reference adds in row order (its result moves with batch and partition boundaries); here the sum is the EXACT real sum")
+    w("  rounded once — the same bits for every order, chunking and grid, at most half an ulp from the truth, within the reference's own a-priori error bound of its")
+    w("  sequential sum and bit-equal to it wherever that one is exact (`tests/test_float_agg_gpu.py`).  Up to eight such sums per aggregate.")
+    w("* Join and hash-aggregate OUTPUT ORDER is unspecified in the reference (hash-table order per batch); tests compare multisets.  A sort-merge join's output is")
+    w("  ordered by its keys only where that order is observable (plan output, Limit, shuffle file).")
+    w("* Everything else on the path — integers, decimals (HALF_UP, overflow → NULL / ANSI error), dates, timestamps, strings, hashes (murmur3 / xxhash64), partition")
+    w("  ids, Parquet decode — is bit-exact against the oracle and the reference's own vectors.")
+    w("")
     return "\n".join(out) + "\n"
 
 
