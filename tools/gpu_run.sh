@@ -168,6 +168,12 @@ q95_pmc() {        # per-kernel HBM traffic and wait cycles of Q95 stage A (sepa
   cd $GRAFT_REPO_ROOT
   python tools/pmc_join_summary.py $OUT q95 > $OUT/q95_join_pmc.txt 2>&1; head -60 $OUT/q95_join_pmc.txt | cut -c1-260
 }
+pmc_sizes() {      # HBM bytes from the size-classed TCC->EA request counters (tools/pmc_sizes.py): calibration on a known 4 GiB read, then Q95, Q3 and the headline's kernels
+  timeout 400 python tools/pmc_sizes.py $OUT/pmc_sizes_calib.txt --calib -- python $GRAFT_REPO_ROOT/tools/pmc_calibrate.py --run | cut -c1-200
+  timeout 500 python tools/pmc_sizes.py $OUT/pmc_sizes_q95.txt -- python $GRAFT_REPO_ROOT/tools/q95_bench.py --orders 16000000 --reps 1 --verify none | cut -c1-200
+  timeout 500 python tools/pmc_sizes.py $OUT/pmc_sizes_q3.txt -- python $GRAFT_REPO_ROOT/tools/q3_dist.py --orders 150000000 --steps 1 --warmup 1 --no-verify | head -24 | cut -c1-200
+  timeout 500 python tools/pmc_sizes.py $OUT/pmc_sizes_q1.txt -- python $GRAFT_REPO_ROOT/tools/resident.py --rows 600037902 --query q1,q6 --steps 3 --no-check | head -12 | cut -c1-200
+}
 q95_cfgs() {       # Q95 stage A under environment configurations: "$Q95_CFGS" = |-separated entries, each a space-separated list of VAR=value ("-" = none)
   IFS='|' read -ra ENTRIES <<< "${Q95_CFGS:--}"
   for E in "${ENTRIES[@]}"; do
