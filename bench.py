@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip every extra leg (Q6, Q3, paths, PMC): headline + cpu_baseline only")
     args = ap.parse_args()
 
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT compiles with the installed ROCm's compiler, as under Spark (see that module)
     import pyarrow as pa
     import torch
     import torch.distributed as dist

@@ -856,6 +856,11 @@ int32_t comet_take_utf8_bytes(const int32_t* offsets, const uint8_t* bytes, cons
 
 const char* comet_version(void) { return "comet-mi355x 0.1.0 (gfx950)"; }
 
+const char* comet_jit_toolchain(void) {
+  static const std::string s = comet::jit_toolchain();
+  return s.c_str();
+}
+
 }  // extern "C"
 
 // ---- Parquet footer description (host-only; used by tests to pin the Thrift/footer parser against pyarrow) ----

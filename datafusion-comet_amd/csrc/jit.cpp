@@ -2,6 +2,7 @@
 
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
+#include <link.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -61,16 +62,49 @@ std::map<std::string, std::shared_ptr<CodeObject>> g_mem_cache;
 std::condition_variable g_cv;
 std::set<std::string> g_in_flight;
 
-// the compiler that produced a cached code object is part of its identity: a ROCm upgrade must not load stale objects
+// The compiler that produced a cached code object is part of its identity: a ROCm upgrade must not load stale objects.  hiprtc is a thin layer; the
+// compiler itself (clang + LLVM) lives in the code object manager, libamd_comgr — and a process can hold a hiprtc of one ROCm release bound to the comgr
+// of another (a Python process that imported a torch wheel with its own bundled ROCm: its comgr, or — preloaded into the global scope — the installed
+// one, answers every hiprtc).  amd_comgr_get_version, resolved the way hiprtc's own calls are, names the one that will compile; the first loaded
+// libamd_comgr's path is added for the reader.
+struct ComgrSeen { std::string path; };
+int comgr_seen_cb(struct dl_phdr_info* info, size_t, void* data) {
+  const char* n = info->dlpi_name;
+  if (n && strstr(n, "libamd_comgr")) {
+    auto* s = (ComgrSeen*)data;
+    if (s->path.empty()) s->path = n;
+  }
+  return 0;
+}
+std::string compiler_identity() {
+  std::string s;
+  typedef void (*GetVersion)(size_t*, size_t*);
+  if (auto gv = (GetVersion)dlsym(RTLD_DEFAULT, "amd_comgr_get_version")) {
+    size_t a = 0, b = 0;
+    gv(&a, &b);
+    s = "comgr " + std::to_string(a) + "." + std::to_string(b);
+    Dl_info info;
+    if (dladdr((void*)gv, &info) && info.dli_fname) s += std::string(" ") + info.dli_fname;
+  } else if (dlopen("libamd_comgr.so.3", RTLD_LAZY | RTLD_GLOBAL) && dlsym(RTLD_DEFAULT, "amd_comgr_get_version")) {
+    return compiler_identity();      // (hiprtc loads it on demand by this very name: now it is the one it will find)
+  } else {
+    ComgrSeen seen;
+    dl_iterate_phdr(comgr_seen_cb, &seen);
+    s = "comgr " + (seen.path.empty() ? std::string("(loaded on demand by hiprtc)") : seen.path);
+  }
+  return s;
+}
 std::string toolchain_tag() {
   int major = 0, minor = 0;
   hiprtcVersion(&major, &minor);
-  return std::to_string(major) + "." + std::to_string(minor);
+  return "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "; " + compiler_identity();
 }
 // a code object is an ELF image; anything else in the cache (a truncated or foreign file) is ignored and recompiled
 bool looks_like_code_object(const std::vector<char>& b) { return b.size() > 64 && b[0] == 0x7f && b[1] == 'E' && b[2] == 'L' && b[3] == 'F'; }
 
 }  // namespace
+
+std::string jit_toolchain() { return toolchain_tag(); }
 
 std::shared_ptr<CodeObject> jit_compile(const std::string& source_in) {
   // COMET_LD_NT=0/1 (an experiment switch): column loads of EVERY generated kernel as ordinary / non-temporal loads, whatever the generator chose

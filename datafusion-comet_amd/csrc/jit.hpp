@@ -19,6 +19,8 @@ struct CodeObject {
 
 // compile (or fetch from cache); throws CometError with the compiler log on failure. No GPU needed.
 std::shared_ptr<CodeObject> jit_compile(const std::string& source);
+// "hiprtc <version>; comgr <version> <path of the library that compiles>" — part of the cache key, reported by comet_jit_toolchain
+std::string jit_toolchain();
 
 struct LoadedModule {
   hipModule_t mod = nullptr;

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from typing import Iterator, List, Optional, Sequence
 
 import pyarrow as pa
@@ -36,6 +37,10 @@ def _load() -> ctypes.CDLL:
     # Import it first so that libcomet.so (NEEDED libamdhip64.so.7) binds to the SAME runtime instance —
     # two HIP runtimes in one process do not share a device context.  (Under the JVM there is no torch and
     # the system ROCm runtime is used.)
+    import datafusion_comet_amd as _pkg
+    if _pkg.SYSTEM_COMGR is None and os.environ.get("COMET_SYSTEM_COMGR", "1") != "0" and "torch" in sys.modules and os.path.exists("/opt/rocm/lib/libamd_comgr.so.3"):
+        sys.stderr.write("datafusion_comet_amd: torch was imported first — the JIT compiles with the torch wheel's bundled ROCm compiler, not the installed one "
+                         "(import datafusion_comet_amd before torch; see datafusion_comet_amd/__init__.py)\n")
     try:
         import torch  # noqa: F401
     except ImportError:
@@ -960,6 +965,14 @@ def check_plan(plan: bytes):
     buf = ctypes.create_string_buffer(1 << 16)
     rc = lib().comet_check_plan(plan, len(plan), buf, len(buf))
     return rc == 0, buf.value.decode(errors="replace")
+
+
+def jit_toolchain() -> str:
+    """which compiler this process's createPlan uses (comet_jit_toolchain): "hiprtc X.Y; comgr X.Y /path/libamd_comgr…" """
+    f = lib().comet_jit_toolchain
+    f.restype = ctypes.c_char_p
+    f.argtypes = []
+    return (f() or b"").decode()
 
 
 def compile_plan(plan: bytes) -> str:

@@ -430,6 +430,13 @@ int32_t comet_parquet_describe(const char* path, char* out, size_t cap);
 /* Library identity (NativeBase.java:82-106 loads "comet"). */
 const char* comet_version(void);
 
+/* The compiler behind createPlan's JIT in THIS process: "hiprtc <major.minor>; comgr <major.minor> <path of the libamd_comgr that compiles>".  Part of
+ * the code-object cache key.  A JVM executor gets the installed ROCm's (libcomet.so's RUNPATH); a process that loaded another ROCm first (a Python wheel
+ * with a bundled one) gets that one's unless the installed libamd_comgr was loaded into the global scope before it — kernels compiled by ROCm 7.0's
+ * clang 20 ran 10-15 % slower than ROCm 7.2's clang 22 on the join kernels (profiles/r6_jit_compiler.md).  No reference counterpart (DataFusion is
+ * compiled ahead of time, native/core/Cargo.toml). */
+const char* comet_jit_toolchain(void);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

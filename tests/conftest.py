@@ -6,6 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import datafusion_comet_amd  # noqa: E402,F401 — BEFORE anything imports torch: the JIT compiles with the installed ROCm's compiler, as under Spark (see that module)
 
 
 # the time-zone database: the system's when it has one, else the tzdata wheel's (csrc/tz.cpp reads $TZDIR first; Python's zoneinfo, the tests'

@@ -18,6 +18,7 @@ def main():
     a = ap.parse_args()
     import numpy as np
     import pyarrow as pa
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     import torch.distributed as dist
     from datafusion_comet_amd import native, parallel

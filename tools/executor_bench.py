@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import pyarrow.parquet as papq
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     from datafusion_comet_amd import native, serde as S, tpch
     res = {"what": "concurrent tasks on one GPU, one host thread and one scan thread each (the executor's shape)", "legs": {}}

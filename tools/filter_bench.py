@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(native, plan_bytes, table, ncols, reps):
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     best_k, best_w, rows = None, None, 0
     for r in range(reps + 1):

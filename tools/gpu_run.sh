@@ -174,6 +174,19 @@ pmc_sizes() {      # HBM bytes from the size-classed TCC->EA request counters (t
   timeout 500 python tools/pmc_sizes.py $OUT/pmc_sizes_q3.txt -- python $GRAFT_REPO_ROOT/tools/q3_dist.py --orders 150000000 --steps 1 --warmup 1 --no-verify | head -24 | cut -c1-200
   timeout 500 python tools/pmc_sizes.py $OUT/pmc_sizes_q1.txt -- python $GRAFT_REPO_ROOT/tools/resident.py --rows 600037902 --query q1,q6 --steps 3 --no-check | head -12 | cut -c1-200
 }
+q95_metrics() {    # Q95 stage A run by run: which table each join took, per-kernel event times
+  timeout 300 python tools/q95_metrics.py 2> $OUT/q95_metrics.err | tee -a $OUT/q95_metrics.jsonl | cut -c1-700 || tail -5 $OUT/q95_metrics.err
+}
+q95_jit_ab() {     # does a code object compiled under rocprofv3 differ from one compiled without it?  (a20: k_jprobe_b 2.50 ms under the profiler on a fresh box, 2.94 elsewhere)
+  mkdir -p /tmp/cacheA /tmp/cacheB
+  (cd /tmp && COMET_JIT_CACHE_DIR=/tmp/cacheA timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/jitab -o a -- python $GRAFT_REPO_ROOT/tools/q95_metrics.py --runs 3 2> /dev/null | cut -c1-330)
+  echo "-- plain, own cache"; COMET_JIT_CACHE_DIR=/tmp/cacheB timeout 300 python tools/q95_metrics.py --runs 3 2> /dev/null | cut -c1-330
+  echo "-- plain, the profiler-compiled cache"; COMET_JIT_CACHE_DIR=/tmp/cacheA timeout 300 python tools/q95_metrics.py --runs 3 2> /dev/null | cut -c1-330
+  echo "-- under the profiler, the plain-compiled cache"; (cd /tmp && COMET_JIT_CACHE_DIR=/tmp/cacheB timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/jitab2 -o a -- python $GRAFT_REPO_ROOT/tools/q95_metrics.py --runs 3 2> /dev/null | cut -c1-330)
+  (cd /tmp/cacheA && md5sum *.hsaco | sort -k2) > $OUT/cacheA.md5; (cd /tmp/cacheB && md5sum *.hsaco | sort -k2) > $OUT/cacheB.md5
+  diff $OUT/cacheA.md5 $OUT/cacheB.md5 | head -20
+  mkdir -p $OUT/hsaco; for f in $(diff $OUT/cacheA.md5 $OUT/cacheB.md5 | grep '^<' | awk '{print $3}' | head -4); do cp /tmp/cacheA/$f $OUT/hsaco/A_$f; cp /tmp/cacheB/$f $OUT/hsaco/B_$f; done; ls -la $OUT/hsaco | head
+}
 q95_cfgs() {       # Q95 stage A under environment configurations: "$Q95_CFGS" = |-separated entries, each a space-separated list of VAR=value ("-" = none)
   IFS='|' read -ra ENTRIES <<< "${Q95_CFGS:--}"
   for E in "${ENTRIES[@]}"; do

@@ -23,6 +23,7 @@ NBYTES = 4 << 30
 
 
 def run():
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     from datafusion_comet_amd import native
     lib = native.lib()

@@ -10,11 +10,12 @@ counter_defs.yaml lists, for gfx950, counters that carry the request size:
   TCC_EA0_RDREQ_DRAM_32B                32-byte units of the read requests that went to DRAM (a 64-B request counts 2, a 128-B request 4)
   TCC_EA0_WRREQ_WRITE_DRAM_32B          the same for writes
 
-  python tools/pmc_sizes.py <out.txt> [--calib] -- <program …>      # three rocprofv3 passes (--pmc … --kernel-trace) over the program
+  python tools/pmc_sizes.py <out.txt> [--calib] -- <program …>      # six rocprofv3 passes (--pmc … --kernel-trace) over the program
 
 --calib: the program is tools/pmc_calibrate.py --run (streaming reads of a known 4 GiB): prints counter ÷ truth per load width.
 Per kernel name, averaged over its dispatches: requests by size, read bytes by the size classes, DRAM read / write bytes, and 2 × FETCH_SIZE's
-formula (= 128 B × all read requests) for comparison."""
+formula (= 128 B × all read requests) for comparison, and FETCH_SIZE itself (doubled) with TCC_BUBBLE, the term of its gfx950 formula that is not a
+plain request count: FETCH_SIZE = 128·BUBBLE + 64·(RDREQ − BUBBLE − RDREQ_32B) + 32·RDREQ_32B."""
 import csv
 import glob
 import os
@@ -26,7 +27,8 @@ from collections import defaultdict
 
 PASSES = (("TCC_EA0_RDREQ_DRAM_32B_sum", "TCC_EA0_RDREQ_sum"),
           ("TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_32B_sum"),
-          ("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
+          ("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"),
+          ("FETCH_SIZE",), ("TCC_BUBBLE_sum", "TCC_EA0_RDREQ_sum"), ("WRITE_SIZE",))
 
 
 def main():
@@ -64,17 +66,18 @@ def main():
             o.write("# ERROR " + e + "\n")
         o.write("# per kernel, AVERAGE PER DISPATCH.  rd_by_class = 128·n128 + 64·n64 + 32·n32; rd_dram = 32 · RDREQ_DRAM_32B; wr_dram = 32 · WRREQ_WRITE_DRAM_32B;\n"
                 "# fetch_x2 = 128 B · RDREQ (what doubling FETCH_SIZE assumes).  MB = 1e6 bytes.\n")
-        o.write(f"{'kernel':28s} {'n':>4s} {'RDREQ':>12s} {'n128':>12s} {'n64':>12s} {'n32':>12s} {'rd_by_class_MB':>15s} {'rd_dram_MB':>11s} {'fetch_x2_MB':>12s} {'x2/dram':>8s} {'wr_dram_MB':>11s} {'WRREQ':>12s} {'wr64':>12s}\n")
+        o.write(f"{'kernel':28s} {'n':>4s} {'RDREQ':>12s} {'n128':>12s} {'n64':>12s} {'n32':>12s} {'rd_by_class_MB':>15s} {'rd_dram_MB':>11s} {'fetch_x2_MB':>12s} {'x2/dram':>8s} {'wr_dram_MB':>11s} {'WRREQ':>12s} {'wr64':>12s} {'2xFETCH_MB':>11s} {'BUBBLE':>12s} {'WRITE_SZ_MB':>11s}\n")
         rows = []
         for k, c in per.items():
             n = max(launches.get(k, 0), 1)
             g = lambda x: c.get(x, 0.0) / n
             rd_class = 128 * g("TCC_EA0_RDREQ_128B_sum") + 64 * g("TCC_EA0_RDREQ_64B_sum") + 32 * g("TCC_EA0_RDREQ_32B_sum")
             rd_dram = 32 * g("TCC_EA0_RDREQ_DRAM_32B_sum")
-            x2 = 128 * g("TCC_EA0_RDREQ_sum")
+            rdreq = g("TCC_EA0_RDREQ_sum") / 2          # (collected in two of the passes)
+            x2 = 128 * rdreq
             wr = 32 * g("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum")
-            rows.append((-(rd_dram + wr) * n, f"{k[:28]:28s} {n:4d} {g('TCC_EA0_RDREQ_sum'):12.0f} {g('TCC_EA0_RDREQ_128B_sum'):12.0f} {g('TCC_EA0_RDREQ_64B_sum'):12.0f} {g('TCC_EA0_RDREQ_32B_sum'):12.0f} "
-                         f"{rd_class / 1e6:15.1f} {rd_dram / 1e6:11.1f} {x2 / 1e6:12.1f} {x2 / max(rd_dram, 1):8.3f} {wr / 1e6:11.1f} {g('TCC_EA0_WRREQ_sum'):12.0f} {g('TCC_EA0_WRREQ_64B_sum'):12.0f}\n"))
+            rows.append((-(rd_dram + wr) * n, f"{k[:28]:28s} {n:4d} {rdreq:12.0f} {g('TCC_EA0_RDREQ_128B_sum'):12.0f} {g('TCC_EA0_RDREQ_64B_sum'):12.0f} {g('TCC_EA0_RDREQ_32B_sum'):12.0f} "
+                         f"{rd_class / 1e6:15.1f} {rd_dram / 1e6:11.1f} {x2 / 1e6:12.1f} {x2 / max(rd_dram, 1):8.3f} {wr / 1e6:11.1f} {g('TCC_EA0_WRREQ_sum'):12.0f} {g('TCC_EA0_WRREQ_64B_sum'):12.0f} {2 * 1024 * g('FETCH_SIZE') / 1e6:11.1f} {g('TCC_BUBBLE_sum'):12.0f} {1024 * g('WRITE_SIZE') / 1e6:11.1f}\n"))
         for _, line in sorted(rows)[:40]:
             o.write(line)
         if calib:

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--q1-rows", type=int, default=50_000_000)
     ap.add_argument("--steps", type=int, default=10)
     args = ap.parse_args()
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     from datafusion_comet_amd import native, tpch
 

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--kernel-times", action="store_true", help="after the timed runs, one more with per-kernel HIP events: adds a roofline object naming the dominant kernel")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     import torch.distributed as dist
     from datafusion_comet_amd import parallel, tpch

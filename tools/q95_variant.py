@@ -14,6 +14,7 @@ ap.add_argument("--tag", default="")
 a = ap.parse_args()
 sys.path.insert(0, os.path.abspath(a.root))
 import pyarrow as pa
+import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
 import torch
 from datafusion_comet_amd import native, tpcds
 cache = f"/tmp/q95_tables_{a.orders}"

@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 def run_query(q, rows, steps, seed, local, check):
     import pyarrow as pa
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     from datafusion_comet_amd import native, tpch
     dev = f"cuda:{local}"

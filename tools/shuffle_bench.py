@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import pyarrow as pa
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     import __graft_entry__ as g
     g.build()

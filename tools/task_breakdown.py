@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--rows", type=int, default=600_037_902)
     ap.add_argument("--steps", type=int, default=10)
     a = ap.parse_args()
+    import datafusion_comet_amd  # noqa: F401 — before torch: the JIT then compiles with the installed ROCm's compiler (see that module)
     import torch
     from datafusion_comet_amd import native, tpch
     plan = tpch.q1_plan().encode()
