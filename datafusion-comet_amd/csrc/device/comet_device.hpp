@@ -2355,7 +2355,7 @@ template <class P>
 CDEV void agg_part_merge_body(const CometKParams& prm) {
   typedef Slot<P::NK, P::NW> S;
   constexpr int kCap = AggPart<P>::kCap;
-  constexpr int kPer = kCap / kBlock;
+  constexpr int kPer = kCap >= kBlock ? kCap / kBlock : 1;      // slots per thread in the emit sweep (a table of wide slots is smaller than the block: its tail threads have none)
   __shared__ S s_tbl[kCap];
   __shared__ u32 s_wave[kBlock / kWave];
   __shared__ unsigned long long s_base;
@@ -2386,7 +2386,8 @@ CDEV void agg_part_merge_body(const CometKParams& prm) {
     u32 before[kPer], ready = 0, run = 0;
 #pragma unroll
     for (int r = 0; r < kPer; r++) {
-      const bool rd = s_tbl[r * kBlock + (int)threadIdx.x].state == kSlotReady;
+      const int si = r * kBlock + (int)threadIdx.x;
+      const bool rd = si < kCap && s_tbl[si < kCap ? si : 0].state == kSlotReady;
       const u64 b = __ballot(rd);
       before[r] = run + (u32)__popcll(b & ((1ull << lane) - 1ull));
       run += (u32)__popcll(b);

@@ -29,3 +29,22 @@ def built():
     import __graft_entry__ as g
     g.build()
     return True
+
+
+# COMET_COMPILE_SWEEP=1 python -m pytest tests -m gpu   (on a box WITHOUT a GPU): every plan a GPU test would create is decoded, planned, generated and
+# hiprtc-compiled for gfx950 instead (comet_compile_plan needs no device), then the test is skipped — a compiler change (a ROCm upgrade) is checked
+# against the whole suite's plan shapes in minutes, before any GPU time is spent.  Compilation errors fail the test.
+if os.environ.get("COMET_COMPILE_SWEEP") == "1":
+    @pytest.fixture(autouse=True)
+    def _compile_instead_of_run(monkeypatch):
+        from datafusion_comet_amd import native
+
+        def create(inputs, plan, config=b"", *a, **k):
+            try:
+                native.compile_plan(bytes(plan))
+            except native.CometNativeException as e:
+                if "hiprtc" in str(e):
+                    raise
+            pytest.skip("compile sweep: plan compiled")
+        monkeypatch.setattr(native.Native, "createPlan", staticmethod(create))
+        yield
