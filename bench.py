@@ -292,7 +292,8 @@ def main():
             "dtype": "i128 (Decimal128; 256-bit products) / i32 (Date32) / u8 (Utf8 keys)", "data": "synthetic",
             "config": {"workload": f"TPC-H {'SF100' if n == SF100_ROWS else 'SF10' if n == SF10_ROWS else str(n) + ' rows of'} Q1 stage 1 "
                                    "(Filter -> Project, 3 decimal ops incl. one 256-bit multiply -> partial HashAggregate, 2 Utf8 keys, 8 aggregates) per GPU",
-                       "rows_per_gpu": n, "bytes_per_row_algorithmic": tpch.Q1_BYTES_PER_ROW, "parallelism": f"row-range shards x{world}"},
+                       "rows_per_gpu": n, "bytes_per_row_algorithmic": tpch.Q1_BYTES_PER_ROW, "parallelism": f"row-range shards x{world}",
+                       "jit_toolchain": native.jit_toolchain()},
             "roofline": roof,
             "result_check": {"all_8_aggregates_of_all_groups_match_torch_on_every_rank": verified, "mismatches_rank0": problems[:4],
                              "groups_rank0": out_tab.num_rows, "final_rows_all_ranks": final_rows},
@@ -440,7 +441,7 @@ def compact_line(full: dict) -> dict:
     line = {k: _r(full[k], 4) for k in keep if k in full}
     cfg = full.get("config", {})
     line["config"] = {"workload": cfg.get("workload"), "rows_per_gpu": cfg.get("rows_per_gpu"), "bytes_per_row_algorithmic": cfg.get("bytes_per_row_algorithmic"),
-                      "parallelism": cfg.get("parallelism")}
+                      "parallelism": cfg.get("parallelism"), "jit_toolchain": cfg.get("jit_toolchain")}
     ro = full.get("roofline", {})
     line["roofline"] = {"bound": ro.get("bound"), "achieved": _r(ro.get("achieved"), 1), "peak": ro.get("peak"), "unit": ro.get("unit"), "frac": _r(ro.get("frac"), 4),
                         "traffic": ro.get("traffic"), "algorithmic_bytes": ro.get("algorithmic_bytes"), "kernel_ms": _r(ro.get("kernel_ms"), 4),

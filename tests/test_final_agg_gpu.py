@@ -332,11 +332,11 @@ def test_merging_aggregate_of_many_groups_runs_partitioned(built, shape):
 def test_merging_aggregate_with_wide_states_runs_partitioned(built):
     """Eight decimal sums, a count and a min per group: a slot of the partition's LDS table is wider than 192 bytes, so the table holds 128 slots — fewer than the
     workgroup has threads (comet_device.hpp AggPart::kCap; the emit sweep's tail threads hold no slot).  ROCm 7.2's compiler refused the kernel as first written
-    (a zero-length array for that shape; ROCm 7.0's accepted it and would have emitted nothing).  30 K groups, a quarter of them in two or three state rows."""
+    (a zero-length array for that shape; ROCm 7.0's accepted it and would have emitted nothing).  40 K groups, a fifth of them in two or three state rows."""
     from oracle import oracle as O
     rng = np.random.default_rng(97)
-    n = 36_000
-    k0 = rng.integers(0, 30_000, n).astype(np.int64) * 6151
+    n = 48_000
+    k0 = rng.integers(0, 40_000, n).astype(np.int64) * 6151
     cols = {"k0": pa.array(k0, mask=rng.random(n) < 0.001), "q": pa.array(rng.integers(-1000, 1000, n), pa.int64(), mask=rng.random(n) < 0.05)}
     for i in range(8):
         cols[f"m{i}"] = tpch._dec128_array(rng.integers(-10**9, 10**9, n), 12, 2)
@@ -348,6 +348,7 @@ def test_merging_aggregate_with_wide_states_runs_partitioned(built):
     fplan = _final_plan(partial, states.schema)
     want = O.run_plan_to_arrow(S, fplan, states)
     srt = lambda t: t.rename_columns([f"c{i}" for i in range(t.num_columns)]).combine_chunks().sort_by([("c0", "ascending")])
+    assert states.num_rows > 36_000      # (the partitioned path starts at 32 768 rows)
     dev = native.DeviceTable.from_arrow(states, "cuda:0")
     got, m = _metrics_run(fplan, [native.DeviceInput(dev)], want.num_columns)
     assert m["agg_partitioned_merges"] == 1, m
