@@ -4005,7 +4005,7 @@ PipelineDesc generate_pipeline(const Operator& root, const std::vector<bool>& in
     }
     src << "  static __device__ __forceinline__ void emit_group(const CometKParams& prm, const u64* key, const u64* acc, i64 pos) {\n"
         << key_emit << fin << "  }\n};\n";
-    src << "extern \"C\" __global__ __launch_bounds__(256) void k_gagg(const CometKParams prm) { comet::agg_grouped_body<P>(prm); }\n";
+    src << "extern \"C\" __global__ __launch_bounds__(256, COMET_WAVES_GAGG) void k_gagg(const CometKParams prm) { comet::agg_grouped_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_gemit(const CometKParams prm) { comet::agg_grouped_emit_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_grehash(const CometKParams prm) { comet::agg_grouped_rehash_body<P>(prm); }\n";
     src << "extern \"C\" __global__ __launch_bounds__(256) void k_pack(const CometKParams prm) { comet::pack_validity_body((const u8*)prm.out[0], (u8*)prm.out[1], prm.n); }\n";
@@ -4433,19 +4433,19 @@ PipelineDesc generate_join(const Operator& j, const std::vector<DType>& lt_in, c
   // single-pass probes (comet_device.hpp template D'): the chained global table, or an LDS table for small build sides
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe(const CometKParams prm) { comet::join_probe_fused_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe_km(const CometKParams prm) { comet::join_probe_fused_body<P, true>(prm); }\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jlds(const CometKParams prm) { comet::join_probe_lds_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256, COMET_WAVES_JLDS) void k_jlds(const CometKParams prm) { comet::join_probe_lds_body<P>(prm); }\n";
   // the key bitmap's two helpers: a sample of the probe side through the finished table (does it pay?), and the bitmap's own build pass
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jsample(const CometKParams prm) { comet::join_sample_body<P>(prm); }\n";
   // the direct map of a unique integer key (no hash table): build rows in key order, and the probe over it
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jdrows(const CometKParams prm) { comet::join_direct_rows_body<P>(prm); }\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jdprobe(const CometKParams prm) { comet::join_probe_direct_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256, COMET_WAVES_JDPROBE) void k_jdprobe(const CometKParams prm) { comet::join_probe_direct_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jbmap(const CometKParams prm) { comet::join_keymap_build_body<P>(prm); }\n";
   // the bucket table (comet_device.hpp template D''): partition passes, the LDS build, the probes; and the bitmap-only semi / anti join
   src << "extern \"C\" __global__ __launch_bounds__(1024) void k_jphist(const CometKParams prm) { comet::join_part_hist_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(1024) void k_jpscat(const CometKParams prm) { comet::join_part_scatter_body<P>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jtbuild(const CometKParams prm) { comet::join_table_build_body<P>(prm); }\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe_b(const CometKParams prm) { comet::join_probe_bucket_body<P>(prm); }\n";
-  src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe_bkm(const CometKParams prm) { comet::join_probe_bucket_body<P, true>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256, COMET_WAVES_JPROBE_B) void k_jprobe_b(const CometKParams prm) { comet::join_probe_bucket_body<P>(prm); }\n";
+  src << "extern \"C\" __global__ __launch_bounds__(256, COMET_WAVES_JPROBE_BKM) void k_jprobe_bkm(const CometKParams prm) { comet::join_probe_bucket_body<P, true>(prm); }\n";
   src << "extern \"C\" __global__ __launch_bounds__(256) void k_jsample_b(const CometKParams prm) { comet::join_sample_bucket_body<P>(prm); }\n";
   if (dedup_build) src << "extern \"C\" __global__ __launch_bounds__(256) void k_jprobe_bm(const CometKParams prm) { comet::join_probe_bitmap_body<P>(prm); }\n";
   d.kernels = {"k_jbuild", "k_jbcnt", "k_pack", "k_jbcount", "k_jbscan", "k_jbemit", "k_jprobe", "k_jprobe_km", "k_jlds", "k_jsample", "k_jbmap", "k_jdrows", "k_jdprobe",

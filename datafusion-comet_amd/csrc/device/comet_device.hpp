@@ -2758,6 +2758,25 @@ constexpr int kJoinR = COMET_JOIN_R;                    // slices of a wave's su
 #ifndef COMET_JOIN_R0_DIRECT
 #define COMET_JOIN_R0_DIRECT 24
 #endif
+// Waves per SIMD the register allocator must leave room for (the second argument of __launch_bounds__ in the generated kernels' declarations; 1 = no
+// request).  The two compilers this header has met differ by a few registers on the same source, and a few registers decide an occupancy step (512 VGPRs
+// per SIMD in units of 8): ROCm 7.2's clang 22 gives k_jdprobe 174 where ROCm 7.0's clang 20 gave 139 (two waves instead of three), k_jprobe_b 97 for 91
+// (four for five), k_gagg 86 for 80 (five for six) — profiles/r6_jit_compiler.md has what each request is worth.
+#ifndef COMET_WAVES_JDPROBE
+#define COMET_WAVES_JDPROBE 1
+#endif
+#ifndef COMET_WAVES_JPROBE_B
+#define COMET_WAVES_JPROBE_B 1
+#endif
+#ifndef COMET_WAVES_JPROBE_BKM
+#define COMET_WAVES_JPROBE_BKM 1
+#endif
+#ifndef COMET_WAVES_JLDS
+#define COMET_WAVES_JLDS 1
+#endif
+#ifndef COMET_WAVES_GAGG
+#define COMET_WAVES_GAGG 1
+#endif
 // probe rows per thread and tile: the filter / key bitmap phase runs over twice as many rows as one probe batch holds —
                                              // most rows end there, and a wave's handful of survivors costs the same latency whatever the tile's size
 

@@ -187,10 +187,13 @@ q95_jit_ab() {     # does a code object compiled under rocprofv3 differ from one
   diff $OUT/cacheA.md5 $OUT/cacheB.md5 | head -20
   mkdir -p $OUT/hsaco; for f in $(diff $OUT/cacheA.md5 $OUT/cacheB.md5 | grep '^<' | awk '{print $3}' | head -4); do cp /tmp/cacheA/$f $OUT/hsaco/A_$f; cp /tmp/cacheB/$f $OUT/hsaco/B_$f; done; ls -la $OUT/hsaco | head
 }
-headline_ab() {    # the headline loop (SF100 Q1, HBM-resident) with the torch wheel's compiler and with the installed one, on ONE box
-  for C in 0 1 0 1; do
-    COMET_SYSTEM_COMGR=$C timeout 600 python bench.py --steps ${HL_STEPS:-20} --warmup 3 --no-extra-legs --no-cpu-baseline 2> /dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('COMET_SYSTEM_COMGR=$C', d['value']/1e9, 'G rows/s', d['ms_per_step'], 'ms', 'frac', d['roofline']['frac'], d['config'].get('jit_toolchain'))"
+headline_ab() {    # the headline loop (SF100 Q1, HBM-resident) under environment configurations ("$HL_CFGS", as q95_cfgs; default: the torch wheel's compiler against the installed one), on ONE box
+  IFS='|' read -ra ENTRIES <<< "${HL_CFGS:-COMET_SYSTEM_COMGR=0|-|COMET_SYSTEM_COMGR=0|-}"
+  for E in "${ENTRIES[@]}"; do
+    E=$(echo $E)
+    [ "$E" = "-" ] && E=""
+    env $E timeout 600 python bench.py --steps ${HL_STEPS:-20} --warmup 3 --no-extra-legs --no-cpu-baseline 2> /dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(f'{d[\"value\"]/1e9:7.2f} G rows/s {d[\"ms_per_step\"]:7.3f} ms  frac {d[\"roofline\"][\"frac\"]}  kernel_ms {d[\"roofline\"].get(\"kernel_ms\")}  $E  ', d['config'].get('jit_toolchain'))"
   done
 }
 q95_cfgs() {       # Q95 stage A under environment configurations: "$Q95_CFGS" = |-separated entries, each a space-separated list of VAR=value ("-" = none)
