@@ -2756,12 +2756,13 @@ constexpr int kJoinR = COMET_JOIN_R;                    // slices of a wave's su
 // (kJoinR0 = COMET_JOIN_R0, a template parameter of join_probe_tiles since round 6: the direct map's probe — nearly all of its work is the filter / bitmap phase —
 // takes 24 rows per thread (SF100 Q3: 4.09 → 3.90 ms), the bucket table's 16 (24 cost TPC-DS Q95 2 ms: registers))
 #ifndef COMET_JOIN_R0_DIRECT
-#define COMET_JOIN_R0_DIRECT 24
+#define COMET_JOIN_R0_DIRECT 32      // (24 under ROCm 7.0's compiler; under ROCm 7.2's, SF100 Q3's k_jdprobe: 16 → 4.00, 24 → 4.15–4.23, 32 → 3.98–4.01 ms)
 #endif
 // Waves per SIMD the register allocator must leave room for (the second argument of __launch_bounds__ in the generated kernels' declarations; 1 = no
 // request).  The two compilers this header has met differ by a few registers on the same source, and a few registers decide an occupancy step (512 VGPRs
 // per SIMD in units of 8): ROCm 7.2's clang 22 gives k_jdprobe 174 where ROCm 7.0's clang 20 gave 139 (two waves instead of three), k_jprobe_b 97 for 91
-// (four for five), k_gagg 86 for 80 (five for six) — profiles/r6_jit_compiler.md has what each request is worth.
+// (four for five), k_gagg 86 for 80 (five for six) — and none of the requests pays (profiles/r6_jit_compiler.md: k_gagg held to six waves 9.44 ms for 7.65,
+// k_jdprobe held to three 5.22 ms for 4.23, k_jprobe_b held to five or six: no change), so the defaults ask for nothing.
 #ifndef COMET_WAVES_JDPROBE
 #define COMET_WAVES_JDPROBE 1
 #endif
@@ -2929,6 +2930,7 @@ struct JoinDirectTable {
 // (round-5 bisect: 22.7 → 26.7 ms, profiles/r5_q95_bisect.txt).  So the table probe without a bitmap is its own kernel with the plain filter loop.
 template <class P, class T, bool KM, int kJoinR0 = COMET_JOIN_R0>
 CDEV void join_probe_tiles(const CometKParams& prm, const T& table) {
+  static_assert(kJoinR0 >= 1 && kJoinR0 <= 32, "a tile's rows per thread are tracked in 32-bit masks (alive_bits, can_bits)");
   const i64 n = prm.n;
   const i64 cap_out = prm.iarg[6];
   unsigned long long* emitted = (unsigned long long*)prm.out[47];
