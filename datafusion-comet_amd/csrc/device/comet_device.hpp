@@ -2561,7 +2561,8 @@ CDEV bool join_build_classify(const CometKParams& prm, i64 i, i64 nb, u64& h, bo
     const u32 lo = __shfl_up((u32)kw[w], 1, kWave), hi = __shfl_up((u32)(kw[w] >> 32), 1, kWave);
     same = same && (((u64)hi << 32) | lo) == kw[w];
   }
-  same = same && __shfl_up(valid ? 1 : 0, 1, kWave) != 0;
+  const int prev_valid = __shfl_up(valid ? 1 : 0, 1, kWave);      // (its own statement: as the right operand of && only the lanes whose `same` still held would
+  same = same && prev_valid != 0;                                 //  execute the shuffle, and a shuffle FROM a lane that sits the instruction out returns anything)
   const u64 followers = __ballot(same);
   has_follower = lane < kWave - 1 && ((followers >> (lane + 1)) & 1ull) != 0 && !P::DEDUP_BUILD;
   h = hash_key<P::NKW>(kw);
@@ -2620,7 +2621,8 @@ CDEV void join_build_count_body(const CometKParams& prm) {
       const u32 lo = __shfl_up((u32)kw[w], 1, kWave), hi = __shfl_up((u32)(kw[w] >> 32), 1, kWave);
       same = same && (((u64)hi << 32) | lo) == kw[w];
     }
-    same = same && __shfl_up(valid ? 1 : 0, 1, kWave) != 0;
+    const int prev_valid = __shfl_up(valid ? 1 : 0, 1, kWave);      // (its own statement: as the right operand of && only the lanes whose `same` still held would
+  same = same && prev_valid != 0;                                 //  execute the shuffle, and a shuffle FROM a lane that sits the instruction out returns anything)
     mine += (u32)__popcll(__ballot(valid && !same));
     keyed += (u32)__popcll(__ballot(valid));
   }
@@ -3386,7 +3388,8 @@ CDEV bool join_classify_run(const CometKParams& prm, i64 i, i64 nb, u64& h, u32&
     const u32 lo = __shfl_up((u32)kw[w], 1, kWave), hi = __shfl_up((u32)(kw[w] >> 32), 1, kWave);
     same = same && (((u64)hi << 32) | lo) == kw[w];
   }
-  same = same && __shfl_up(valid ? 1 : 0, 1, kWave) != 0;
+  const int prev_valid = __shfl_up(valid ? 1 : 0, 1, kWave);      // (its own statement: as the right operand of && only the lanes whose `same` still held would
+  same = same && prev_valid != 0;                                 //  execute the shuffle, and a shuffle FROM a lane that sits the instruction out returns anything)
   const u64 followers = __ballot(same);
   const u64 after = lane < kWave - 1 ? followers >> (lane + 1) : 0ull;        // the lanes behind me that continue a run: mine, while the bits are ones
   cnt = P::DEDUP_BUILD ? 1u : 1u + (u32)__builtin_ctzll(~after);

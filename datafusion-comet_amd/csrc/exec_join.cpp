@@ -178,6 +178,9 @@ DevTable ExecutionContext::hash_join_impl(const Operator& node, const Operator& 
     read_small(got, emitted_buf.p, sizeof got);
     entries = std::min<int64_t>(B.rows, (int64_t)got[0]);
     keyed_rows = (int64_t)got[3];
+    if (getenv("COMET_JOIN_DEBUG"))
+      fprintf(stderr, "[join %s] build rows %lld: leaders %llu, keyed rows %llu, key min %lld max %lld\n", key_suffix.c_str(), (long long)B.rows, (unsigned long long)got[0],
+              (unsigned long long)got[3], (long long)(got[1] ^ ((uint64_t)1 << 63)), (long long)(got[2] ^ ((uint64_t)1 << 63)));
     // The key bitmap (comet_device.hpp kJoinKeyMap): one integer key whose values span at most 64 bits per build row and 2^31 bits — a
     // foreign key's shape.  k_jbcnt leaves min / max untouched when the kernel has no such key (KEYMAP false).
     if (got[1] <= got[2]) {

@@ -196,6 +196,14 @@ headline_ab() {    # the headline loop (SF100 Q1, HBM-resident) under environmen
 import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(f'{d[\"value\"]/1e9:7.2f} G rows/s {d[\"ms_per_step\"]:7.3f} ms  frac {d[\"roofline\"][\"frac\"]}  kernel_ms {d[\"roofline\"].get(\"kernel_ms\")}  $E  ', d['config'].get('jit_toolchain'))"
   done
 }
+fused_check() {    # tools/fused_build_check.py under environment configurations ("$FC_CFGS", as q95_cfgs), arguments "$FC_ARGS" (fuseBuild modes)
+  IFS='|' read -ra ENTRIES <<< "${FC_CFGS:--}"
+  for E in "${ENTRIES[@]}"; do
+    E=$(echo $E)
+    [ "$E" = "-" ] && E=""
+    echo "== $E"; env $E timeout 300 python tools/fused_build_check.py ${FC_ARGS:-always false} 2>&1 | grep -v "amdgpu.ids" | tail -14 | cut -c1-260
+  done
+}
 q95_cfgs() {       # Q95 stage A under environment configurations: "$Q95_CFGS" = |-separated entries, each a space-separated list of VAR=value ("-" = none)
   IFS='|' read -ra ENTRIES <<< "${Q95_CFGS:--}"
   for E in "${ENTRIES[@]}"; do
