@@ -174,8 +174,13 @@ STRTOD_ENTRY int str_to_float_bits(const u8* p, i32 n, bool is32, u64& out) {
   dec.trunc = false;
   bool saw_digit = false, saw_dot = false;
   i32 nall = 0;                        // digits behind the leading zeroes, kept or not
+  // The mantissa's end first (digits and points), then a loop over it that nothing leaves early.  One loop that both `continue`d (leading zeroes) and `break`ed
+  // (the first other character) handed ROCm 7.2's device compiler a wrong exit index — every number with an exponent came back as "not a number", on the GPU only
+  // (the same compiler's host build, UBSan / ASan / MSan clean, and ROCm 7.0's device build were right; profiles/r6_jit_compiler.md).
+  i32 mend = a;
+  while (mend < b && (p[mend] == '.' || (p[mend] >= '0' && p[mend] <= '9'))) mend++;
   i32 i = a;
-  for (; i < b; i++) {
+  for (; i < mend; i++) {
     const u8 ch = p[i];
     if (ch == '.') {
       if (saw_dot) return 1;
@@ -190,8 +195,6 @@ STRTOD_ENTRY int str_to_float_bits(const u8* p, i32 n, bool is32, u64& out) {
       nall++;
       if (dec.nd < 800) dec.d[dec.nd++] = (u8)(ch - '0');
       else if (ch != '0') dec.trunc = true;
-    } else {
-      break;
     }
   }
   if (!saw_digit) return 1;

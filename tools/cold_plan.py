@@ -30,7 +30,8 @@ print(json.dumps({"ms": (time.perf_counter() - t0) * 1e3, "plans": len(bs)}))
 
 
 def measure(query: str, cache_dir: str) -> dict:
-    env = dict(os.environ, COMET_JIT_CACHE_DIR=cache_dir)
+    # (ROCm 7.2's code object manager keeps a cache of its own under ~/.cache: off, or a plan some earlier process compiled would not be cold — 16 ms instead of 550)
+    env = dict(os.environ, COMET_JIT_CACHE_DIR=cache_dir, AMD_COMGR_CACHE="0")
     p = subprocess.run([sys.executable, "-c", CHILD % (ROOT, query)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     if p.returncode != 0:
         raise RuntimeError(p.stderr[-600:])

@@ -204,6 +204,14 @@ fused_check() {    # tools/fused_build_check.py under environment configurations
     echo "== $E"; env $E timeout 300 python tools/fused_build_check.py ${FC_ARGS:-always false} 2>&1 | grep -v "amdgpu.ids" | tail -14 | cut -c1-260
   done
 }
+strtod_check() {   # tools/strtod_check.py under environment configurations ("$SD_CFGS", as q95_cfgs)
+  IFS='|' read -ra ENTRIES <<< "${SD_CFGS:--|COMET_SYSTEM_COMGR=0}"
+  for E in "${ENTRIES[@]}"; do
+    E=$(echo $E)
+    [ "$E" = "-" ] && E=""
+    echo "== $E"; env $E timeout 300 python tools/strtod_check.py 2>&1 | grep -v amdgpu.ids | sed -n ${SD_LINES:-1,2p} | cut -c1-300
+  done
+}
 q95_cfgs() {       # Q95 stage A under environment configurations: "$Q95_CFGS" = |-separated entries, each a space-separated list of VAR=value ("-" = none)
   IFS='|' read -ra ENTRIES <<< "${Q95_CFGS:--}"
   for E in "${ENTRIES[@]}"; do
